@@ -1,0 +1,582 @@
+/*
+ * chd_world_oracle.c — CPU oracle for the *tick pipeline* (TEST INFRASTRUCTURE
+ * ONLY, see chd_oracle.h).  It composes the literal restatements of
+ * chd_oracle.c into the engine's tick model:
+ *
+ *   1. ingest entity updates: Notify decision (spatial.go:612-626) on
+ *      (last merged position, new position); accepted handovers move the
+ *      entity between the cells' entity maps (spatial.go:703-736); a locked
+ *      entity aborts (entity.go:197-224 -> spatial.go:675-679); every update is
+ *      appended to the entity channel's update buffer (data.go:149-173).
+ *   2. interest updates: QueryChannelIds + damping + Difference
+ *      (message_spatial.go:59-128) and SubscribeToChannel /
+ *      UnsubscribeFromChannel (subscription.go:34-125) on the spatial channels.
+ *   3. fan-out at time t: tickData (data.go:175-291) on every spatial (cell)
+ *      channel and on every entity channel.  Model decision:
+ *      an entity channel's subscribers are the subscribers of the cell that
+ *      holds it, sharing the cell subscription's phase (lastFanOutTime,
+ *      hadFirstFanOut) — exact because that state's evolution in tickData
+ *      does not depend on the update buffer's contents.
+ *
+ * Two modes, cross-checked in tests/test_world_oracle.py:
+ *   literal = 1: every entity channel and cell channel is an orc_channel and
+ *                orc_tick_data (the literal list walk) produces the sends.
+ *   literal = 0: the window formulation (while t >= last+interval ...) with the
+ *                literal buffer walk per (channel, subscriber, window); this is
+ *                also the loop nest timed as bench.py's cpu_baseline ("port").
+ */
+#include "chd_oracle.h"
+
+#include <pthread.h>
+#include <stdlib.h>
+#include <string.h>
+
+#define W_INVALID 0xFFFFFFFFu
+#define REC_FULL 0x80000000u
+
+typedef struct {
+    orc_time arrival;
+    uint32_t sender;
+} wupd;
+
+typedef struct {
+    wupd *v;
+    uint32_t head, len, cap;
+} wbuf;
+
+typedef struct {
+    uint32_t conn; /* bit31 = full */
+    uint32_t chan;
+} wrec;
+
+typedef struct {
+    uint32_t cell; /* cell index */
+    uint32_t interval_ms;
+    orc_time last;
+    uint8_t had_first, skip_self, access, is_new;
+} wpair;
+
+typedef struct orc_world {
+    orc_grid g;
+    uint32_t C, N, S, capq;
+    uint32_t default_interval_ms;
+    int32_t default_delay_ms;
+    int literal;
+    /* entities */
+    uint8_t *alive;
+    uint32_t *chan_id, *cell, *member, *eflags, *sender;
+    wbuf *ebuf;     /* entity channel update buffers */
+    wbuf *cbuf;     /* cell channel update buffers */
+    uint32_t max_interval_ms; /* maxFanOutIntervalMs (only grows) */
+    /* subscribers */
+    uint8_t *sub_alive;
+    uint32_t *conn_id;
+    wpair *pairs; /* [S][capq] */
+    uint32_t *pair_cnt;
+    /* outputs of the last tick */
+    wrec *rec; uint64_t nrec, caprec;
+    uint32_t *ho_ent, *ho_src, *ho_dst, *ho_srv_src, *ho_srv_dst; uint32_t nho, capho;
+    uint32_t *unsub_sub, *unsub_cell; uint32_t nunsub, capunsub;
+    int32_t *q_status; uint32_t nq_status;
+    uint32_t n_locked_abort;
+    uint64_t literal_mismatch;
+    uint32_t *server_of_cell;
+    int threads;
+} orc_world;
+
+static void wbuf_push(wbuf *b, orc_time t, uint32_t sender, uint32_t max_interval_ms) {
+    /* data.go:159-172 */
+    if (b->head + b->len == b->cap) {
+        if (b->head > 0) {
+            memmove(b->v, b->v + b->head, b->len * sizeof(wupd));
+            b->head = 0;
+        } else {
+            b->cap = b->cap ? b->cap * 2 : 8;
+            b->v = (wupd *)realloc(b->v, b->cap * sizeof(wupd));
+        }
+    }
+    b->v[b->head + b->len].arrival = t;
+    b->v[b->head + b->len].sender = sender;
+    b->len++;
+    if (b->len > 512) {
+        if (b->v[b->head].arrival + (orc_time)max_interval_ms * 1000000 < t) {
+            b->head++;
+            b->len--;
+        }
+    }
+}
+
+orc_world *orc_world_new(const orc_grid *g, uint32_t n_entities, uint32_t n_subs,
+                         uint32_t capq, uint32_t default_interval_ms,
+                         int32_t default_delay_ms, int literal) {
+    orc_world *w = (orc_world *)calloc(1, sizeof(orc_world));
+    w->g = *g;
+    w->C = g->cols * g->rows;
+    w->N = n_entities;
+    w->S = n_subs;
+    w->capq = capq;
+    w->default_interval_ms = default_interval_ms;
+    w->default_delay_ms = default_delay_ms;
+    w->literal = literal;
+    w->threads = 1;
+    w->alive = (uint8_t *)calloc(n_entities + 1, 1);
+    w->chan_id = (uint32_t *)calloc(n_entities + 1, 4);
+    w->cell = (uint32_t *)calloc(n_entities + 1, 4);
+    w->member = (uint32_t *)calloc(n_entities + 1, 4);
+    w->eflags = (uint32_t *)calloc(n_entities + 1, 4);
+    w->sender = (uint32_t *)calloc(n_entities + 1, 4);
+    w->ebuf = (wbuf *)calloc(n_entities + 1, sizeof(wbuf));
+    w->cbuf = (wbuf *)calloc(w->C + 1, sizeof(wbuf));
+    w->sub_alive = (uint8_t *)calloc(n_subs + 1, 1);
+    w->conn_id = (uint32_t *)calloc(n_subs + 1, 4);
+    w->pairs = (wpair *)calloc((size_t)n_subs * capq + 1, sizeof(wpair));
+    w->pair_cnt = (uint32_t *)calloc(n_subs + 1, 4);
+    w->server_of_cell = (uint32_t *)calloc(w->C + 1, 4);
+    {
+        double *t = (double *)malloc(sizeof(double) * 4 * (w->C + 1));
+        uint32_t *ids = (uint32_t *)malloc(4 * (w->C + 1));
+        orc_regions(g, t, t + w->C, t + 2 * w->C, t + 3 * w->C, ids, w->server_of_cell);
+        free(t);
+        free(ids);
+    }
+    return w;
+}
+
+void orc_world_free(orc_world *w) {
+    if (!w) return;
+    for (uint32_t i = 0; i < w->N; i++) free(w->ebuf[i].v);
+    for (uint32_t i = 0; i < w->C; i++) free(w->cbuf[i].v);
+    free(w->alive); free(w->chan_id); free(w->cell); free(w->member);
+    free(w->eflags); free(w->sender); free(w->ebuf); free(w->cbuf);
+    free(w->sub_alive); free(w->conn_id); free(w->pairs); free(w->pair_cnt);
+    free(w->rec); free(w->ho_ent); free(w->ho_src); free(w->ho_dst);
+    free(w->ho_srv_src); free(w->ho_srv_dst); free(w->unsub_sub);
+    free(w->unsub_cell); free(w->q_status); free(w->server_of_cell);
+    free(w);
+}
+
+void orc_world_set_threads(orc_world *w, int threads) { w->threads = threads < 1 ? 1 : threads; }
+
+static uint32_t cell_index(const orc_world *w, double x, double z) {
+    uint32_t id = orc_channel_id(&w->g, x, z);
+    return id ? id - w->g.id_start : W_INVALID;
+}
+
+/* spawn: the entity's channel gets its initial data and the entity is added to
+ * the cell that contains it (pkg/unreal/message.go:55 -> SpatialChannelData). */
+void orc_world_spawn(orc_world *w, uint32_t i, uint32_t chan_id, double x,
+                     double z, uint32_t flags, uint32_t sender) {
+    w->alive[i] = 1;
+    w->chan_id[i] = chan_id;
+    w->cell[i] = cell_index(w, x, z);
+    w->member[i] = w->cell[i];
+    w->eflags[i] = flags;
+    w->sender[i] = sender;
+    w->ebuf[i].head = w->ebuf[i].len = 0;
+}
+
+void orc_world_despawn(orc_world *w, uint32_t i) { w->alive[i] = 0; w->member[i] = W_INVALID; }
+void orc_world_set_flags(orc_world *w, uint32_t i, uint32_t flags) { w->eflags[i] = flags; }
+
+void orc_world_add_sub(orc_world *w, uint32_t s, uint32_t conn_id) {
+    w->sub_alive[s] = 1;
+    w->conn_id[s] = conn_id;
+    w->pair_cnt[s] = 0;
+}
+void orc_world_remove_sub(orc_world *w, uint32_t s) { w->sub_alive[s] = 0; w->pair_cnt[s] = 0; }
+
+static void push_rec(orc_world *w, uint32_t conn, uint32_t chan) {
+    if (w->nrec == w->caprec) {
+        w->caprec = w->caprec ? w->caprec * 2 : 1024;
+        w->rec = (wrec *)realloc(w->rec, w->caprec * sizeof(wrec));
+    }
+    w->rec[w->nrec].conn = conn;
+    w->rec[w->nrec].chan = chan;
+    w->nrec++;
+}
+
+/* literal buffer walk of data.go:225-269 for one (subscriber, window) */
+static int window_has_update(const wbuf *b, orc_time last, orc_time next,
+                             uint32_t conn, int skip_self) {
+    if (b->len == 0) return 0; /* bufp == nil */
+    orc_time last_update_time = 0;
+    if (last >= last_update_time) last_update_time = last;
+    int merged = 0;
+    for (uint32_t i = 0; i < b->len; i++) {
+        const wupd *be = &b->v[b->head + i];
+        if (be->sender == conn && skip_self) continue;
+        if (be->arrival >= last_update_time && be->arrival <= next) {
+            merged = 1;
+            last_update_time = be->arrival;
+        }
+    }
+    return merged;
+}
+
+typedef struct {
+    uint8_t full;
+    orc_time last, next;
+} wwin;
+
+/* windows of one pair at time t (net effect of tickData's revisit loop) */
+static uint32_t pair_windows(wpair *p, orc_time t, wwin *out, uint32_t cap) {
+    uint32_t n = 0;
+    if (p->access == ORC_ACCESS_NO) return 0;
+    for (;;) {
+        orc_time next = p->last + (orc_time)p->interval_ms * 1000000;
+        if (!(t >= next)) break;
+        if (n >= cap) break;
+        if (!p->had_first) {
+            out[n].full = 1; out[n].last = p->last; out[n].next = next; n++;
+            p->had_first = 1;
+            p->last = t;
+        } else {
+            out[n].full = 0; out[n].last = p->last; out[n].next = next; n++;
+            p->last = next;
+        }
+        if (p->interval_ms == 0) break; /* the reference would spin */
+    }
+    return n;
+}
+
+/* ---- per-cell subscriber buckets ---- */
+typedef struct { uint32_t s, p; } spref;
+
+typedef struct {
+    orc_world *w;
+    orc_time t;
+    const uint32_t *cell_off_sub; const spref *cell_subs;
+    const uint32_t *cell_off_ent; const uint32_t *cell_ents;
+    uint32_t c0, c1;
+    wrec *rec; uint64_t nrec, caprec;
+} fan_job;
+
+static void job_push(fan_job *j, uint32_t conn, uint32_t chan) {
+    if (j->nrec == j->caprec) {
+        j->caprec = j->caprec ? j->caprec * 2 : 4096;
+        j->rec = (wrec *)realloc(j->rec, j->caprec * sizeof(wrec));
+    }
+    j->rec[j->nrec].conn = conn;
+    j->rec[j->nrec].chan = chan;
+    j->nrec++;
+}
+
+#define MAXWIN 4096
+
+/* shared-state fan-out for cells [c0,c1): channel-major like the reference
+ * (one tickData per channel, walking that channel's subscribers). */
+static void *fan_cells(void *arg) {
+    fan_job *j = (fan_job *)arg;
+    orc_world *w = j->w;
+    wwin *wins = (wwin *)malloc(sizeof(wwin) * MAXWIN);
+    for (uint32_t c = j->c0; c < j->c1; c++) {
+        uint32_t ns = j->cell_off_sub[c + 1] - j->cell_off_sub[c];
+        if (!ns) continue;
+        const spref *subs = j->cell_subs + j->cell_off_sub[c];
+        /* channel 0: the spatial channel itself; then each entity channel */
+        uint32_t ne = j->cell_off_ent[c + 1] - j->cell_off_ent[c];
+        for (uint32_t k = 0; k <= ne; k++) {
+            const wbuf *b;
+            uint32_t chan;
+            if (k == 0) { b = &w->cbuf[c]; chan = w->g.id_start + c; }
+            else {
+                uint32_t e = j->cell_ents[j->cell_off_ent[c] + k - 1];
+                b = &w->ebuf[e];
+                chan = w->chan_id[e];
+            }
+            for (uint32_t si = 0; si < ns; si++) {
+                wpair tmp = w->pairs[(size_t)subs[si].s * w->capq + subs[si].p];
+                uint32_t conn = w->conn_id[subs[si].s];
+                uint32_t nw = pair_windows(&tmp, j->t, wins, MAXWIN);
+                for (uint32_t wi = 0; wi < nw; wi++) {
+                    if (wins[wi].full) job_push(j, conn | REC_FULL, chan);
+                    else if (window_has_update(b, wins[wi].last, wins[wi].next, conn, tmp.skip_self))
+                        job_push(j, conn, chan);
+                }
+            }
+        }
+        /* commit the subscription state (identical for every channel above) */
+        for (uint32_t si = 0; si < ns; si++) {
+            wpair *p = &w->pairs[(size_t)subs[si].s * w->capq + subs[si].p];
+            pair_windows(p, j->t, wins, MAXWIN);
+        }
+    }
+    free(wins);
+    return NULL;
+}
+
+/* oracle-only: force a queue element's phase (model: inherit the cell phase) */
+extern void orc__force_state(orc_channel *ch, uint32_t conn_id, orc_time last, int had_first);
+extern int orc__get_state(const orc_channel *ch, uint32_t conn_id, orc_time *last, int *had_first);
+
+static void fan_literal(orc_world *w, orc_time t, const uint32_t *cell_off_sub,
+                        const spref *cell_subs, const uint32_t *cell_off_ent,
+                        const uint32_t *cell_ents) {
+    orc_send *sends = (orc_send *)malloc(sizeof(orc_send) * 65536);
+    for (uint32_t c = 0; c < w->C; c++) {
+        uint32_t ns = cell_off_sub[c + 1] - cell_off_sub[c];
+        if (!ns) continue;
+        const spref *subs = cell_subs + cell_off_sub[c];
+        uint32_t ne = cell_off_ent[c + 1] - cell_off_ent[c];
+        orc_channel *first_ch = NULL;
+        for (uint32_t k = 0; k <= ne; k++) {
+            const wbuf *b;
+            uint32_t chan;
+            if (k == 0) { b = &w->cbuf[c]; chan = w->g.id_start + c; }
+            else {
+                uint32_t e = cell_ents[cell_off_ent[c] + k - 1];
+                b = &w->ebuf[e];
+                chan = w->chan_id[e];
+            }
+            orc_channel *ch = orc_channel_new();
+            orc_init_data(ch);
+            for (uint32_t i = 0; i < b->len; i++)
+                orc_on_update(ch, b->v[b->head + i].arrival, b->v[b->head + i].sender, i);
+            for (uint32_t si = 0; si < ns; si++) {
+                const wpair *p = &w->pairs[(size_t)subs[si].s * w->capq + subs[si].p];
+                uint32_t conn = w->conn_id[subs[si].s];
+                orc_subscribe(ch, conn, 0, p->interval_ms, 0, p->skip_self, 0, p->access);
+                orc__force_state(ch, conn, p->last, p->had_first);
+            }
+            int n = orc_tick_data(ch, t, sends, 65536);
+            for (int i = 0; i < n; i++)
+                push_rec(w, sends[i].conn_id | (sends[i].full ? REC_FULL : 0), chan);
+            if (k == 0) first_ch = ch;
+            else {
+                /* every channel's subscription state must have evolved alike */
+                for (uint32_t si = 0; si < ns; si++) {
+                    orc_time l0, l1; int f0, f1;
+                    uint32_t conn = w->conn_id[subs[si].s];
+                    orc__get_state(first_ch, conn, &l0, &f0);
+                    orc__get_state(ch, conn, &l1, &f1);
+                    if (l0 != l1 || f0 != f1) w->literal_mismatch++;
+                }
+                orc_channel_free(ch);
+            }
+        }
+        for (uint32_t si = 0; si < ns; si++) {
+            wpair *p = &w->pairs[(size_t)subs[si].s * w->capq + subs[si].p];
+            orc_time l; int f;
+            orc__get_state(first_ch, w->conn_id[subs[si].s], &l, &f);
+            p->last = l;
+            p->had_first = (uint8_t)f;
+        }
+        orc_channel_free(first_ch);
+    }
+    free(sends);
+}
+
+/*
+ * One tick.  Updates: n_upd entries (idx NULL => entity i = u), positions,
+ * sender (NULL => keep).  Cell-channel updates: n_cu (cell index, sender).
+ * Interest updates: n_q entries (q_sub NULL => subscriber s = i).
+ * Returns 0.
+ */
+int orc_world_tick(orc_world *w, orc_time t, uint32_t n_upd, const uint32_t *idx,
+                   const double *x, const double *z, const uint32_t *sender,
+                   uint32_t n_cu, const uint32_t *cu_cell, const uint32_t *cu_sender,
+                   uint32_t n_q, const uint32_t *q_sub, const orc_query *queries) {
+    w->nrec = 0; w->nho = 0; w->nunsub = 0; w->n_locked_abort = 0;
+
+    /* ---- 1. entity updates ---- */
+    for (uint32_t u = 0; u < n_upd; u++) {
+        uint32_t i = idx ? idx[u] : u;
+        if (!w->alive[i]) continue;
+        uint32_t src = w->cell[i];
+        uint32_t dst = cell_index(w, x[u], z[u]);
+        w->cell[i] = dst; /* merged position is now the new one */
+        if (sender) w->sender[i] = sender[u];
+        wbuf_push(&w->ebuf[i], t, w->sender[i], w->max_interval_ms);
+        if (src == W_INVALID || dst == W_INVALID || src == dst) continue; /* spatial.go:613-626 */
+        if (w->eflags[i] & 1u) { w->n_locked_abort++; continue; }        /* :675-679 */
+        if (w->nho == w->capho) {
+            w->capho = w->capho ? w->capho * 2 : 256;
+            w->ho_ent = (uint32_t *)realloc(w->ho_ent, 4 * w->capho);
+            w->ho_src = (uint32_t *)realloc(w->ho_src, 4 * w->capho);
+            w->ho_dst = (uint32_t *)realloc(w->ho_dst, 4 * w->capho);
+            w->ho_srv_src = (uint32_t *)realloc(w->ho_srv_src, 4 * w->capho);
+            w->ho_srv_dst = (uint32_t *)realloc(w->ho_srv_dst, 4 * w->capho);
+        }
+        w->ho_ent[w->nho] = i;
+        w->ho_src[w->nho] = src + w->g.id_start;
+        w->ho_dst[w->nho] = dst + w->g.id_start;
+        w->ho_srv_src[w->nho] = w->server_of_cell[src];
+        w->ho_srv_dst[w->nho] = w->server_of_cell[dst];
+        w->nho++;
+        w->member[i] = dst; /* RemoveEntity(src) + AddEntity(dst), :703-736 */
+    }
+    for (uint32_t u = 0; u < n_cu; u++)
+        wbuf_push(&w->cbuf[cu_cell[u]], t, cu_sender[u], w->max_interval_ms);
+
+    /* ---- 2. interest updates (message_spatial.go:59-128) ---- */
+    if (w->nq_status < n_q) {
+        w->q_status = (int32_t *)realloc(w->q_status, 4 * (n_q + 1));
+        w->nq_status = n_q;
+    }
+    {
+        uint32_t *ids = (uint32_t *)malloc(4 * (w->C + 1));
+        uint32_t *dists = (uint32_t *)malloc(4 * (w->C + 1));
+        wpair *np = (wpair *)malloc(sizeof(wpair) * (w->capq + 1));
+        for (uint32_t qi = 0; qi < n_q; qi++) {
+            uint32_t s = q_sub ? q_sub[qi] : qi;
+            uint32_t n = 0;
+            int rc = orc_query_channel_ids(&w->g, &queries[qi], ids, dists, w->C, &n);
+            if (rc == ORC_OK && n > w->capq) rc = ORC_E_CAP;
+            w->q_status[qi] = rc;
+            if (rc != ORC_OK || !w->sub_alive[s]) continue; /* error: nothing changes (:60-63) */
+            wpair *old = &w->pairs[(size_t)s * w->capq];
+            uint32_t nold = w->pair_cnt[s];
+            /* Difference(existing, new) -> unsub */
+            for (uint32_t o = 0; o < nold; o++) {
+                int found = 0;
+                for (uint32_t k = 0; k < n; k++)
+                    if (ids[k] - w->g.id_start == old[o].cell) { found = 1; break; }
+                if (found) continue;
+                if (w->nunsub == w->capunsub) {
+                    w->capunsub = w->capunsub ? w->capunsub * 2 : 256;
+                    w->unsub_sub = (uint32_t *)realloc(w->unsub_sub, 4 * w->capunsub);
+                    w->unsub_cell = (uint32_t *)realloc(w->unsub_cell, 4 * w->capunsub);
+                }
+                w->unsub_sub[w->nunsub] = s;
+                w->unsub_cell[w->nunsub] = old[o].cell + w->g.id_start;
+                w->nunsub++;
+            }
+            /* every new id is (re)subscribed with the damped interval */
+            for (uint32_t k = 0; k < n; k++) {
+                uint32_t c = ids[k] - w->g.id_start;
+                uint32_t iv = orc_damping_interval(dists[k], w->default_interval_ms);
+                const wpair *ex = NULL;
+                for (uint32_t o = 0; o < nold; o++)
+                    if (old[o].cell == c) { ex = &old[o]; break; }
+                if (ex) { /* subscription.go:44-57: options merged, state kept */
+                    np[k] = *ex;
+                    np[k].interval_ms = iv;
+                    np[k].is_new = 0;
+                } else { /* subscription.go:59-91 */
+                    np[k].cell = c;
+                    np[k].interval_ms = iv;
+                    np[k].last = t + (orc_time)w->default_delay_ms * 1000000;
+                    np[k].had_first = 0;   /* SkipFirstFanOut default false */
+                    np[k].skip_self = 1;   /* SkipSelfUpdateFanOut default true */
+                    np[k].access = ORC_ACCESS_READ;
+                    np[k].is_new = 1;
+                }
+                if (w->max_interval_ms < iv) w->max_interval_ms = iv;
+            }
+            memcpy(old, np, sizeof(wpair) * n);
+            w->pair_cnt[s] = n;
+        }
+        free(ids); free(dists); free(np);
+    }
+
+    /* ---- 3. fan-out (data.go:175-291 on every channel) ---- */
+    uint32_t *cell_off_sub = (uint32_t *)calloc(w->C + 2, 4);
+    uint32_t *cell_off_ent = (uint32_t *)calloc(w->C + 2, 4);
+    for (uint32_t s = 0; s < w->S; s++) {
+        if (!w->sub_alive[s]) continue;
+        for (uint32_t p = 0; p < w->pair_cnt[s]; p++)
+            cell_off_sub[w->pairs[(size_t)s * w->capq + p].cell + 1]++;
+    }
+    for (uint32_t i = 0; i < w->N; i++)
+        if (w->alive[i] && w->member[i] != W_INVALID) cell_off_ent[w->member[i] + 1]++;
+    for (uint32_t c = 0; c < w->C; c++) {
+        cell_off_sub[c + 1] += cell_off_sub[c];
+        cell_off_ent[c + 1] += cell_off_ent[c];
+    }
+    spref *cell_subs = (spref *)malloc(sizeof(spref) * (cell_off_sub[w->C] + 1));
+    uint32_t *cell_ents = (uint32_t *)malloc(4 * (cell_off_ent[w->C] + 1));
+    {
+        uint32_t *cur = (uint32_t *)malloc(4 * (w->C + 1));
+        memcpy(cur, cell_off_sub, 4 * w->C);
+        for (uint32_t s = 0; s < w->S; s++) {
+            if (!w->sub_alive[s]) continue;
+            for (uint32_t p = 0; p < w->pair_cnt[s]; p++) {
+                uint32_t c = w->pairs[(size_t)s * w->capq + p].cell;
+                cell_subs[cur[c]].s = s;
+                cell_subs[cur[c]].p = p;
+                cur[c]++;
+            }
+        }
+        memcpy(cur, cell_off_ent, 4 * w->C);
+        for (uint32_t i = 0; i < w->N; i++)
+            if (w->alive[i] && w->member[i] != W_INVALID) cell_ents[cur[w->member[i]]++] = i;
+        free(cur);
+    }
+    if (w->literal) {
+        fan_literal(w, t, cell_off_sub, cell_subs, cell_off_ent, cell_ents);
+    } else {
+        int nt = w->threads;
+        if ((uint32_t)nt > w->C) nt = (int)w->C;
+        fan_job *jobs = (fan_job *)calloc((size_t)nt, sizeof(fan_job));
+        pthread_t *th = (pthread_t *)calloc((size_t)nt, sizeof(pthread_t));
+        /* static partition of the cells (channels) over the host threads,
+         * balanced by work = subs x (entities + 1) */
+        uint64_t total = 0;
+        for (uint32_t c = 0; c < w->C; c++)
+            total += (uint64_t)(cell_off_sub[c + 1] - cell_off_sub[c]) * (cell_off_ent[c + 1] - cell_off_ent[c] + 1);
+        uint32_t c = 0;
+        uint64_t acc = 0;
+        for (int k = 0; k < nt; k++) {
+            jobs[k].w = w; jobs[k].t = t;
+            jobs[k].cell_off_sub = cell_off_sub; jobs[k].cell_subs = cell_subs;
+            jobs[k].cell_off_ent = cell_off_ent; jobs[k].cell_ents = cell_ents;
+            jobs[k].c0 = c;
+            uint64_t target = total * (uint64_t)(k + 1) / (uint64_t)nt;
+            while (c < w->C && (acc < target || k == nt - 1)) {
+                acc += (uint64_t)(cell_off_sub[c + 1] - cell_off_sub[c]) * (cell_off_ent[c + 1] - cell_off_ent[c] + 1);
+                c++;
+            }
+            jobs[k].c1 = c;
+        }
+        if (nt == 1) fan_cells(&jobs[0]);
+        else {
+            for (int k = 0; k < nt; k++) pthread_create(&th[k], NULL, fan_cells, &jobs[k]);
+            for (int k = 0; k < nt; k++) pthread_join(th[k], NULL);
+        }
+        for (int k = 0; k < nt; k++) {
+            if (w->nrec + jobs[k].nrec > w->caprec) {
+                w->caprec = (w->nrec + jobs[k].nrec) * 2;
+                w->rec = (wrec *)realloc(w->rec, w->caprec * sizeof(wrec));
+            }
+            if (jobs[k].nrec) memcpy(w->rec + w->nrec, jobs[k].rec, jobs[k].nrec * sizeof(wrec));
+            w->nrec += jobs[k].nrec;
+            free(jobs[k].rec);
+        }
+        free(jobs); free(th);
+    }
+    free(cell_off_sub); free(cell_off_ent); free(cell_subs); free(cell_ents);
+    return 0;
+}
+
+/* ---- accessors ---- */
+uint64_t orc_world_nrec(const orc_world *w) { return w->nrec; }
+void orc_world_records(const orc_world *w, uint32_t *conn, uint32_t *chan) {
+    for (uint64_t i = 0; i < w->nrec; i++) { conn[i] = w->rec[i].conn; chan[i] = w->rec[i].chan; }
+}
+uint32_t orc_world_nhandover(const orc_world *w) { return w->nho; }
+void orc_world_handovers(const orc_world *w, uint32_t *ent, uint32_t *src, uint32_t *dst,
+                         uint32_t *srv_src, uint32_t *srv_dst) {
+    memcpy(ent, w->ho_ent, 4 * w->nho); memcpy(src, w->ho_src, 4 * w->nho);
+    memcpy(dst, w->ho_dst, 4 * w->nho); memcpy(srv_src, w->ho_srv_src, 4 * w->nho);
+    memcpy(srv_dst, w->ho_srv_dst, 4 * w->nho);
+}
+uint32_t orc_world_nunsub(const orc_world *w) { return w->nunsub; }
+void orc_world_unsubs(const orc_world *w, uint32_t *sub, uint32_t *cell) {
+    memcpy(sub, w->unsub_sub, 4 * w->nunsub); memcpy(cell, w->unsub_cell, 4 * w->nunsub);
+}
+void orc_world_query_status(const orc_world *w, int32_t *out, uint32_t n) { memcpy(out, w->q_status, 4 * n); }
+uint32_t orc_world_locked_aborts(const orc_world *w) { return w->n_locked_abort; }
+uint64_t orc_world_literal_mismatch(const orc_world *w) { return w->literal_mismatch; }
+void orc_world_entity_state(const orc_world *w, uint32_t *cell, uint32_t *member) {
+    memcpy(cell, w->cell, 4 * w->N); memcpy(member, w->member, 4 * w->N);
+}
+uint32_t orc_world_pairs(const orc_world *w, uint32_t s, uint32_t *cell, uint32_t *interval_ms,
+                         int64_t *last, uint8_t *had_first, uint8_t *is_new) {
+    uint32_t n = w->pair_cnt[s];
+    for (uint32_t p = 0; p < n; p++) {
+        const wpair *q = &w->pairs[(size_t)s * w->capq + p];
+        cell[p] = q->cell + w->g.id_start; interval_ms[p] = q->interval_ms; last[p] = q->last;
+        had_first[p] = q->had_first; is_new[p] = q->is_new;
+    }
+    return n;
+}

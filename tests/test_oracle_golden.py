@@ -1,0 +1,330 @@
+"""Pins the CPU oracle against the reference's own test vectors.
+
+Each test transcribes the assertions of one Go test (file:line cited) from
+pkg/channeld/spatial_test.go / data_test.go.  If these pass, the restatement in
+oracle/chd_oracle.c reproduces every known-answer the reference holds for the
+SpatialChannel hot path.
+"""
+import math
+
+import numpy as np
+import pytest
+
+from oracle import pyoracle as orc
+
+START = 0x10000
+
+
+def q_cone(cx, cz, dx, dz, r, angle):
+    return orc.QueryBuilder(cone=(cx, cz, dx, dz, r, angle))
+
+
+def keys(g, qb):
+    rc, res = orc.query_channel_ids(g, qb)
+    assert rc == orc.OK
+    return res
+
+
+# ---- spatial_test.go:762-848  TestGetChannelId1/2 ----
+def test_get_channel_id_2():
+    g = orc.grid(100, 50, 0, 0, 9, 8, 3, 4, 2)
+    assert orc.channel_id(g, 0, 0) == START + 0
+    assert orc.channel_id(g, 100, 0) == START + 1
+    assert orc.channel_id(g, 0, 50) == START + 9
+    assert orc.channel_id(g, 899.99, 399.99) == START + 9 * 8 - 1
+    for x, z in [(-1, 0), (1.7976931348623157e308, 0), (0, -1), (900, 400)]:
+        assert orc.channel_id(g, x, z) == 0  # error
+
+
+def test_get_channel_id_1():
+    g = orc.grid(100, 50, -450, -200, 9, 8, 3, 4, 2)
+    assert orc.channel_id(g, -450, -200) == START + 0
+    assert orc.channel_id(g, -350, -200) == START + 1
+    assert orc.channel_id(g, -450, -150) == START + 9
+    assert orc.channel_id(g, 0, 0) == START + 9 * 4 + 4
+    assert orc.channel_id(g, 449.99, 199.99) == START + 9 * 8 - 1
+    for x, z in [(-500, 0), (500, 0), (0, -300), (0, 300), (450, 200)]:
+        assert orc.channel_id(g, x, z) == 0
+
+
+def test_get_channel_id_nan_inf():
+    g = orc.grid(100, 50, 0, 0, 9, 8)
+    for v in (float("nan"), float("inf"), float("-inf")):
+        assert orc.channel_id(g, v, 0) == 0
+        assert orc.channel_id(g, 0, v) == 0
+
+
+# ---- spatial_test.go:21-242  TestConeAOI ----
+def test_cone_aoi():
+    g1 = orc.grid(10, 10, 0, 0, 1, 1)
+    assert START in keys(g1, q_cone(5, 5, 1, 0, 1, math.pi / 4))
+
+    g2 = orc.grid(10, 10, 0, 0, 4, 1)
+    assert START in keys(g2, q_cone(0, 5, 1, 0, 1, math.pi / 4))
+    assert len(keys(g2, q_cone(0, 5, 1, 0, 25, math.pi / 4))) == 3
+    assert len(keys(g2, q_cone(0, 5, 1, 0, 100, math.pi / 4))) == 4
+    assert len(keys(g2, q_cone(0, 5, 0, 1, 100, math.pi / 4))) == 1
+
+    g3 = orc.grid(10, 10, 0, 0, 3, 3)
+    r = keys(g3, q_cone(5, 5, 1, 0, 100, 0.1))
+    assert sorted(r) == [65536, 65537, 65538]
+    r = keys(g3, q_cone(5, 5, 1, 0, 100, math.pi / 4))
+    assert sorted(r) == [65536, 65537, 65538, 65540, 65541, 65544]
+    r = keys(g3, q_cone(15, 15, -1, 0, 100, math.pi / 4))
+    assert len(r) == 4
+    assert sorted(r) == [65536, 65539, 65540, 65542]
+    r = keys(g3, q_cone(5, 15, 0, -1, 100, math.pi / 4))
+    assert len(r) == 3
+    assert sorted(r) == [65536, 65537, 65539]
+
+    # production-like query, spatial_test.go:209-240 (Center.Z unset -> 0)
+    g4 = orc.grid(1000, 1000, -2000, -500, 4, 1, 2, 1, 1)
+    assert len(keys(g4, q_cone(1250, 0, -0.087, 0.996, 30000, 0.5236))) == 1
+
+
+# ---- spatial_test.go:244-360  TestSphereAOI ----
+def test_sphere_aoi():
+    g1 = orc.grid(10, 10, 0, 0, 1, 1)
+    assert START in keys(g1, orc.QueryBuilder(sphere=(5, 5, 1)))
+    assert START in keys(g1, orc.QueryBuilder(sphere=(5, 5, 100)))
+
+    g2 = orc.grid(5, 5, -5, -5, 2, 2)
+    assert len(keys(g2, orc.QueryBuilder(sphere=(0, 0, 1)))) == 4
+    r = keys(g2, orc.QueryBuilder(sphere=(4.9, 4.9, 1)))
+    assert list(r) == [65539]
+    assert len(keys(g2, orc.QueryBuilder(sphere=(4.9, 4.9, 4.9)))) == 1
+    assert len(keys(g2, orc.QueryBuilder(sphere=(4.9, 4.9, 10)))) == 4
+
+    g3 = orc.grid(100, 100, -150, -150, 3, 3)
+    assert len(keys(g3, orc.QueryBuilder(sphere=(0, 0, 150)))) == 9
+    r = keys(g3, orc.QueryBuilder(sphere=(0, 0, 99)))
+    assert len(r) == 5  # no corner channels
+    assert sorted(r) == [START + 1, START + 3, START + 4, START + 5, START + 7]
+
+
+# ---- spatial_test.go:362-491  TestBoxAOI ----
+def test_box_aoi():
+    g1 = orc.grid(10, 10, 0, 0, 1, 1)
+    assert START in keys(g1, orc.QueryBuilder(box=(5, 5, 1, 1)))
+    assert START in keys(g1, orc.QueryBuilder(box=(5, 5, 100, 100)))
+
+    g2 = orc.grid(5, 5, -5, -5, 2, 2)
+    assert len(keys(g2, orc.QueryBuilder(box=(0, 0, 1, 1)))) == 4
+    r = keys(g2, orc.QueryBuilder(box=(4.9, 4.9, 1, 1)))
+    assert list(r) == [65539]
+    assert len(keys(g2, orc.QueryBuilder(box=(4.9, 4.9, 4.9, 4.9)))) == 1
+    r = keys(g2, orc.QueryBuilder(box=(4.9, 4.9, 4.9, 10)))
+    assert sorted(r) == [65537, 65539]
+
+    g3 = orc.grid(100, 100, -150, -150, 3, 3)
+    assert len(keys(g3, orc.QueryBuilder(box=(0, 0, 150, 150)))) == 9
+    assert len(keys(g3, orc.QueryBuilder(box=(0, 0, 100, 100)))) == 9
+
+
+def test_query_errors():
+    g = orc.grid(10, 10, 0, 0, 3, 3)
+    assert orc.query_channel_ids(g, None)[0] == orc.E_NILQUERY  # spatial.go:183
+    assert orc.query_channel_ids(g, orc.QueryBuilder(sphere=(5, 5, 0)))[0] == orc.E_EXTENT
+    assert orc.query_channel_ids(g, orc.QueryBuilder(sphere=(5, 5, -1)))[0] == orc.E_EXTENT
+    assert orc.query_channel_ids(g, orc.QueryBuilder(box=(5, 5, 0, 1)))[0] == orc.E_EXTENT
+    assert orc.query_channel_ids(g, orc.QueryBuilder(sphere=(-5, 5, 3)))[0] == orc.E_CENTER
+    assert orc.query_channel_ids(g, orc.QueryBuilder(cone=(50, 5, 1, 0, 3, 0.5)))[0] == orc.E_CENTER
+    # a failing later shape voids the earlier shapes' results (returns nil, err)
+    rc, res = orc.query_channel_ids(g, orc.QueryBuilder(box=(5, 5, 1, 1), sphere=(-5, 5, 3)))
+    assert rc == orc.E_CENTER and res == {}
+
+
+def test_spots_and_centre_dist():
+    g = orc.grid(10, 10, 0, 0, 3, 3)
+    # spatial.go:189-202: dist from Dists[i] when present, else 0; out-of-world spots skipped
+    qb = orc.QueryBuilder(spots=[(5, 5), (15, 5), (-1, 0), (25, 25)], spot_dists=[3, 1])
+    rc, res = orc.query_channel_ids(g, qb)
+    assert rc == orc.OK and res == {START: 3, START + 1: 1, START + 8: 0}
+    # centre cell is forced to 0, others ceil(dist/GridSize)
+    rc, res = orc.query_channel_ids(g, orc.QueryBuilder(sphere=(15, 15, 14)))
+    assert res[START + 4] == 0
+    assert all(d >= 1 for c, d in res.items() if c != START + 4)
+
+
+# ---- spatial_test.go:493-526  TestGetAdjacentChannels ----
+def test_adjacent():
+    assert orc.adjacent(orc.grid(10, 10, 0, 0, 1, 1, 1, 1, 1), START) == []
+    assert len(orc.adjacent(orc.grid(5, 5, -5, -5, 2, 2), START)) == 3
+    g = orc.grid(10, 10, 0, 0, 3, 3)
+    assert orc.adjacent(g, START + 4) == [START + i for i in (0, 1, 2, 3, 5, 6, 7, 8)]
+
+
+# ---- spatial_test.go:528-683  TestCreateSpatialChannels1/2/3 ----
+def test_create_channels_cells_and_borders():
+    g = orc.grid(20, 40, -40, -60, 4, 3, 2, 3, 1)
+    assert orc.server_channels(g, 0) == [START + 0, START + 1]
+    for i in range(1, 6):
+        assert len(orc.server_channels(g, i)) == 2
+    b = {i: set(orc.border_channels(g, i)) for i in range(6)}
+    assert {START + 2, START + 4, START + 5} <= b[0]
+    assert {START + 1, START + 6, START + 7} <= b[1]
+    assert {START + 0, START + 1, START + 6, START + 8, START + 9} <= b[2]
+    assert {START + 2, START + 3, START + 5, START + 10, START + 11} <= b[3]
+    assert {START + 6, START + 7, START + 9} <= b[5]
+    # no diagonals: server 0 (cells 0,1) never subscribes to 6 or 7
+    assert not ({START + 6, START + 7} & b[0])
+
+    # TestCreateSpatialChannels3: 2x2 grid, 2x2 servers, border 0 -> one cell each, no border subs
+    g3 = orc.grid(33, 77, 0, 0, 2, 2, 2, 2, 0)
+    assert [orc.server_channels(g3, i) for i in range(4)] == [[START], [START + 1], [START + 2], [START + 3]]
+    assert all(orc.border_channels(g3, i) == [] for i in range(4))
+    # TestCreateSpatialChannels2: 1x1
+    g2 = orc.grid(10, 10, 0, 0, 1, 1, 1, 1, 1)
+    assert orc.server_channels(g2, 0) == [START] and orc.border_channels(g2, 0) == []
+
+
+def test_regions_server_index():
+    g = orc.grid(2000, 2000, -15000, -15000, 15, 15, 3, 3, 0)
+    minx, minz, maxx, maxz, cid, srv = orc.regions(g)
+    assert cid[0] == START and cid[-1] == START + 224
+    assert minx[0] == -15000 and maxx[14] == 15000 and minz[15] == -13000
+    assert srv[0] == 0 and srv[5] == 1 and srv[14] == 2 and srv[15 * 5] == 3 and srv[224] == 8
+    # every server owns 25 cells
+    assert np.bincount(srv).tolist() == [25] * 9
+
+
+def test_load_config_validation():
+    # spatial.go:141-159 (note: border 0 is rejected although shipped configs use it)
+    import ctypes
+
+    which = ctypes.c_int(0)
+    L = orc.lib()
+    assert L.orc_validate_config(ctypes.byref(orc.grid(10, 10, 0, 0, 1, 1, 1, 1, 1)), ctypes.byref(which)) == 0
+    assert L.orc_validate_config(ctypes.byref(orc.grid(0, 10, 0, 0, 1, 1, 1, 1, 1)), ctypes.byref(which)) == orc.E_CONFIG
+    assert which.value == 1
+    assert L.orc_validate_config(ctypes.byref(orc.grid(10, 10, 0, 0, 1, 1, 1, 1, 0)), ctypes.byref(which)) == orc.E_CONFIG
+    assert which.value == 4
+
+
+def test_damping():
+    # message_spatial.go:16-38,66-79
+    assert [orc.lib().orc_damping_interval(d, 20) for d in range(5)] == [20, 50, 100, 20, 20]
+    assert orc.lib().orc_damping_interval(7, 33) == 33
+
+
+def test_interest_diff():
+    un, isnew = orc.interest_diff([1, 2, 3, 9], [2, 3, 4])
+    assert un == [1, 9] and isnew == [False, False, True]
+
+
+def test_notify_decision():
+    g = orc.grid(10, 10, 0, 0, 3, 3)
+    assert orc.notify_decision(g, 5, 5, 6, 6) == (False, START, START)
+    assert orc.notify_decision(g, 5, 5, 15, 5) == (True, START, START + 1)
+    assert orc.notify_decision(g, 5, 5, 35, 5)[0] is False  # dst out of world
+    assert orc.notify_decision(g, -5, 5, 5, 5)[0] is False  # src out of world
+
+
+def test_go_cos_known_values():
+    # Cephes port: exact at 0, symmetric, NaN for inf; agrees with libm to 1 ulp
+    assert orc.lib().orc_go_cos(0.0) == 1.0
+    assert math.isnan(orc.lib().orc_go_cos(float("inf")))
+    rng = np.random.default_rng(1)
+    for a in rng.uniform(0, math.pi, 2000):
+        v = orc.lib().orc_go_cos(float(a))
+        assert abs(v - math.cos(a)) <= 2.3e-16
+        assert orc.lib().orc_go_cos(-float(a)) == v
+
+
+def test_go_min_max_special_cases():
+    L = orc.lib()
+    inf, nan = float("inf"), float("nan")
+    assert L.orc_go_min(1.0, -inf) == -inf and math.isnan(L.orc_go_min(nan, 1.0))
+    assert L.orc_go_max(1.0, inf) == inf and math.isnan(L.orc_go_max(1.0, nan))
+    assert math.copysign(1, L.orc_go_min(0.0, -0.0)) == -1 and math.copysign(1, L.orc_go_max(-0.0, 0.0)) == 1
+
+
+# ---- data_test.go:98-174  TestFanOutChannelData (see DESIGN.md for 176-197) ----
+def test_fanout_timeline():
+    MS = orc.MS
+    ch = orc.Channel()
+    ch.init_data()  # InitData(dataMsg)
+    c0, c1, c2 = 1, 2, 3
+    # TEST channel type falls back to GLOBAL settings: interval 20 ms, delay 0 (settings.go:96-103,237-243)
+    ch.subscribe(c0, 0, 20, 0)
+    ch.subscribe(c1, 0, 50, 0)
+    start = 100 * MS
+
+    def count(sends, conn):
+        return sum(1 for s in sends if s["conn"] == conn)
+
+    got = {c0: [], c1: [], c2: []}
+
+    def tick(t):
+        n, sends = ch.tick_data(t)
+        assert n >= 0
+        for s in sends:
+            got[s["conn"]].append(s)
+
+    tick(start)  # F0 = whole data
+    assert len(got[c1]) == 1 and len(got[c2]) == 0 and got[c1][-1]["full"]
+    ch.subscribe(c2, 0, 100, 0)
+    tick(start + 50 * MS)  # F1 = no data, F7 = whole data
+    assert len(got[c1]) == 1 and len(got[c2]) == 1 and got[c2][-1]["full"]
+    ch.on_update(start + 60 * MS, c0, 1)  # U1
+    tick(start + 100 * MS)  # F2 = U1
+    assert len(got[c1]) == 2 and len(got[c2]) == 1
+    assert (got[c1][-1]["first"], got[c1][-1]["last"], got[c1][-1]["n"]) == (1, 1, 1)
+    ch.on_update(start + 120 * MS, c0, 2)  # U2
+    tick(start + 150 * MS)  # F8 = U1+U2; F3 = U2
+    assert len(got[c1]) == 3 and len(got[c2]) == 2
+    assert (got[c1][-1]["first"], got[c1][-1]["n"]) == (2, 1)
+    assert (got[c2][-1]["first"], got[c2][-1]["last"], got[c2][-1]["n"]) == (1, 2, 2)
+    ch.on_update(start + 205 * MS, c2, 3)  # U3 sent by c2
+    tick(start + 210 * MS)
+    assert len(got[c1]) == 3 and len(got[c2]) == 2  # data_test.go:171-174
+    # ---- beyond line 174 the reference test disagrees with data.go as written ----
+    tick(start + 250 * MS)
+    assert len(got[c1]) == 4 and got[c1][-1]["first"] == 3  # :178 holds
+    # :179 expects c2 == 3, but c2 sent U3 itself and SkipSelfUpdateFanOut defaults to
+    # true (subscription.go:27, data.go:242-245): the code as written sends nothing.
+    assert len(got[c2]) == 2
+    # c0 never receives its own updates (U1, U2): the first full state, then U3 from c2
+    assert len(got[c0]) == 2 and got[c0][0]["full"] and got[c0][1]["first"] == 3
+
+
+def test_fanout_catch_up_and_boundary():
+    MS = orc.MS
+    ch = orc.Channel()
+    ch.init_data()
+    ch.subscribe(7, 0, 20, 0)
+    n, s = ch.tick_data(100 * MS)
+    assert n == 1 and s[0]["full"]  # first: full, last = t
+    ch.on_update(120 * MS, 1, 11)  # exactly on a window boundary
+    ch.on_update(130 * MS, 1, 12)
+    n, s = ch.tick_data(170 * MS)  # windows [100,120] [120,140] [140,160]
+    assert [(x["first"], x["last"]) for x in s] == [(11, 11), (11, 12)]  # boundary update delivered twice
+    assert ch.queue()[0][1] == 160 * MS  # last = next, not t
+
+
+def test_fanout_no_access_closing_and_buffer_cap():
+    MS = orc.MS
+    ch = orc.Channel()
+    ch.init_data()
+    ch.subscribe(1, 0, 20, 0, access=0)  # NO_ACCESS stays queued, never served
+    ch.subscribe(2, 0, 20, 0)
+    ch.subscribe(3, 0, 20, -10)  # negative FanOutDelayMs (channeld.proto:229-233)
+    n, s = ch.tick_data(50 * MS)
+    assert sorted(x["conn"] for x in s) == [2, 3]
+    ch.set_closing(2)
+    n, s = ch.tick_data(100 * MS)
+    assert [c for c, _, _ in ch.queue()] .count(2) == 0
+    # soft cap: oldest dropped only if arrival + maxInterval < t (data.go:166-172)
+    for i in range(600):
+        ch.on_update(100 * MS, 9, i)
+    assert ch.buffer_len() == 600
+    ch.on_update(200 * MS, 9, 1000)
+    assert ch.buffer_len() == 600  # one pushed, one dropped
+
+
+def test_fanout_interval_zero_is_a_hang():
+    ch = orc.Channel()
+    ch.init_data()
+    ch.subscribe(1, 0, 0, 0)
+    n, _ = ch.tick_data(orc.MS)
+    assert n == orc.E_HANG  # the reference spins forever; the C-ABI rejects interval 0
