@@ -1,0 +1,179 @@
+"""ctypes binding of libchd_spatial.so (include/chd_spatial.h).
+
+This is the same boundary a cgo shim would use.  The library is
+HIP-only: if it cannot be loaded, or no gfx950 device is usable, every entry point
+of the package raises — there is no CPU path behind it.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "libchd_spatial.so")
+
+OK = 0
+E_CONFIG, E_INVAL, E_EXTENT, E_CENTER, E_CAPACITY, E_HANG = -1, -2, -3, -4, -5, -6
+E_TOO_LARGE, E_NO_DEVICE, E_HIP, E_STATE = -8, -9, -10, -11
+SHAPE_SPOTS, SHAPE_BOX, SHAPE_SPHERE, SHAPE_CONE = 1, 2, 4, 8
+REC_FULL = 0x80000000
+ENTITY_LOCKED = 1
+MAX_DAMPING = 8
+N_STAGES = 5
+STAGE_NAMES = ("ingest", "index", "interest", "plan", "emit")
+
+# every symbol include/chd_spatial.h declares (checked by tests/test_abi.py)
+SYMBOLS = (
+    "chd_create", "chd_destroy", "chd_last_error", "chd_abi_version",
+    "chd_get_channel_ids", "chd_notify_decide", "chd_query_channel_ids",
+    "chd_get_regions", "chd_get_adjacent_channels", "chd_server_channels",
+    "chd_border_channels", "chd_world_create", "chd_world_spawn", "chd_world_despawn",
+    "chd_world_set_entity_flags", "chd_subs_add", "chd_subs_remove", "chd_tick",
+    "chd_tick_device", "chd_tick_fetch", "chd_sync", "chd_subs_get",
+    "chd_world_get_entities", "chd_dev_alloc", "chd_dev_free", "chd_dev_upload",
+    "chd_dev_download", "chd_set_profiling", "chd_get_tick_stats",
+)
+
+
+class ChdError(RuntimeError):
+    def __init__(self, code: int, msg: str):
+        super().__init__(f"chd error {code}: {msg}")
+        self.code = code
+
+
+class GridCfg(C.Structure):
+    _fields_ = [
+        ("grid_width", C.c_double), ("grid_height", C.c_double),
+        ("world_offset_x", C.c_double), ("world_offset_z", C.c_double),
+        ("grid_cols", C.c_uint32), ("grid_rows", C.c_uint32),
+        ("server_cols", C.c_uint32), ("server_rows", C.c_uint32),
+        ("server_interest_border_size", C.c_uint32),
+        ("spatial_channel_id_start", C.c_uint32), ("entity_channel_id_start", C.c_uint32),
+        ("default_fanout_interval_ms", C.c_uint32), ("default_fanout_delay_ms", C.c_int32),
+        ("n_damping", C.c_uint32),
+        ("damping_max_dist", C.c_uint32 * MAX_DAMPING), ("damping_interval_ms", C.c_uint32 * MAX_DAMPING),
+        ("strict_load_config", C.c_uint32),
+    ]
+
+
+class AoiQuery(C.Structure):
+    _fields_ = [
+        ("shapes", C.c_uint32), ("spot_off", C.c_uint32), ("n_spots", C.c_uint32), ("n_spot_dists", C.c_uint32),
+        ("box_cx", C.c_double), ("box_cz", C.c_double), ("box_ex", C.c_double), ("box_ez", C.c_double),
+        ("sph_cx", C.c_double), ("sph_cz", C.c_double), ("sph_r", C.c_double),
+        ("cone_cx", C.c_double), ("cone_cz", C.c_double), ("cone_dx", C.c_double), ("cone_dz", C.c_double),
+        ("cone_r", C.c_double), ("cone_cos", C.c_double),
+        ("_reserved", C.c_double),
+    ]
+
+
+assert C.sizeof(AoiQuery) == 128
+
+
+class WorldCfg(C.Structure):
+    _fields_ = [
+        ("max_entities", C.c_uint32), ("max_subscribers", C.c_uint32), ("max_interest_cells", C.c_uint32),
+        ("max_records", C.c_uint64), ("max_handovers", C.c_uint32),
+    ]
+
+
+class FanoutRec(C.Structure):
+    _fields_ = [("conn", C.c_uint32), ("channel", C.c_uint32)]
+
+
+class HandoverRec(C.Structure):
+    _fields_ = [("entity", C.c_uint32), ("channel", C.c_uint32), ("src", C.c_uint32), ("dst", C.c_uint32),
+                ("src_server", C.c_uint32), ("dst_server", C.c_uint32)]
+
+
+_vp, _u32p, _f64p, _i32p, _u64p, _i64p, _u8p = (C.c_void_p,) * 7
+
+
+class TickIn(C.Structure):
+    _fields_ = [
+        ("now_ns", C.c_int64),
+        ("n_updates", C.c_uint32), ("upd_idx", _u32p), ("upd_x", _f64p), ("upd_z", _f64p), ("upd_sender", _u32p),
+        ("n_cell_updates", C.c_uint32), ("cell_upd_channel", _u32p), ("cell_upd_sender", _u32p),
+        ("n_queries", C.c_uint32), ("query_sub", _u32p), ("queries", _vp),
+        ("spot_x", _f64p), ("spot_z", _f64p), ("spot_dist", _u32p), ("n_spots_total", C.c_uint32),
+    ]
+
+
+class TickOut(C.Structure):
+    _fields_ = [
+        ("handovers", _vp), ("handovers_cap", C.c_uint32), ("n_handovers", C.c_uint32),
+        ("n_locked_aborts", C.c_uint32),
+        ("query_status", _i32p),
+        ("unsub_sub", _u32p), ("unsub_channel", _u32p), ("unsub_cap", C.c_uint32), ("n_unsubs", C.c_uint32),
+        ("newsub_sub", _u32p), ("newsub_channel", _u32p), ("newsub_interval_ms", _u32p),
+        ("newsub_cap", C.c_uint32), ("n_newsubs", C.c_uint32),
+        ("records", _vp), ("records_cap", C.c_uint64), ("n_records", C.c_uint64),
+        ("conn_rec_off", _u64p), ("conn_rec_cnt", _u32p),
+        ("overflow", C.c_uint32), ("history_overflow", C.c_uint32),
+    ]
+
+
+class TickStats(C.Structure):
+    _fields_ = [
+        ("stage_us", C.c_float * N_STAGES), ("total_us", C.c_float),
+        ("n_records", C.c_uint64), ("n_record_upper_bound", C.c_uint64),
+        ("n_handovers", C.c_uint32), ("n_unsubs", C.c_uint32), ("n_pairs", C.c_uint32),
+        ("algorithmic_bytes", C.c_uint64),
+    ]
+
+
+_lib = None
+
+
+def load():
+    """Loads the HIP library; raises if it is missing (no fallback)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            f"{LIB_PATH} is missing: build it with `python -m channeld_amd.build` (hipcc, gfx950). "
+            "channeld_amd has no CPU implementation."
+        )
+    L = C.CDLL(LIB_PATH)
+    P = C.POINTER
+    L.chd_abi_version.restype = C.c_int
+    L.chd_last_error.restype = C.c_char_p
+    L.chd_last_error.argtypes = [C.c_void_p]
+    L.chd_create.argtypes = [P(GridCfg), C.c_int, P(C.c_void_p)]
+    L.chd_destroy.argtypes = [C.c_void_p]
+    L.chd_destroy.restype = None
+    L.chd_sync.argtypes = [C.c_void_p]
+    L.chd_get_channel_ids.argtypes = [C.c_void_p, _f64p, _f64p, C.c_uint32, _u32p]
+    L.chd_notify_decide.argtypes = [C.c_void_p, _f64p, _f64p, _f64p, _f64p, C.c_uint32, _u32p, _u32p, _u8p]
+    L.chd_query_channel_ids.argtypes = [C.c_void_p, _vp, C.c_uint32, _f64p, _f64p, _u32p, C.c_uint32,
+                                        _u32p, _u32p, _u32p, _u32p, C.c_uint32, _i32p]
+    L.chd_get_regions.argtypes = [C.c_void_p, _f64p, _f64p, _f64p, _f64p, _u32p, _u32p]
+    L.chd_get_adjacent_channels.argtypes = [C.c_void_p, _u32p, C.c_uint32, _u32p, _u32p]
+    L.chd_server_channels.argtypes = [C.c_void_p, C.c_uint32, _u32p, C.c_uint32, P(C.c_uint32)]
+    L.chd_border_channels.argtypes = [C.c_void_p, C.c_uint32, _u32p, C.c_uint32, P(C.c_uint32)]
+    L.chd_world_create.argtypes = [C.c_void_p, P(WorldCfg)]
+    L.chd_world_spawn.argtypes = [C.c_void_p, C.c_uint32, _u32p, _u32p, _f64p, _f64p, _u32p, _u32p]
+    L.chd_world_despawn.argtypes = [C.c_void_p, C.c_uint32, _u32p]
+    L.chd_world_set_entity_flags.argtypes = [C.c_void_p, C.c_uint32, _u32p, _u32p]
+    L.chd_subs_add.argtypes = [C.c_void_p, C.c_uint32, _u32p, _u32p]
+    L.chd_subs_remove.argtypes = [C.c_void_p, C.c_uint32, _u32p]
+    L.chd_tick.argtypes = [C.c_void_p, P(TickIn), P(TickOut)]
+    L.chd_tick_device.argtypes = [C.c_void_p, P(TickIn)]
+    L.chd_tick_fetch.argtypes = [C.c_void_p, P(TickOut)]
+    L.chd_subs_get.argtypes = [C.c_void_p, C.c_uint32, _u32p, _u32p, _i64p, _u8p, _u8p, P(C.c_uint32)]
+    L.chd_world_get_entities.argtypes = [C.c_void_p, C.c_uint32, _u32p, _u32p, _u32p]
+    L.chd_dev_alloc.argtypes = [C.c_void_p, C.c_uint64, P(C.c_void_p)]
+    L.chd_dev_free.argtypes = [C.c_void_p, C.c_void_p]
+    L.chd_dev_upload.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64]
+    L.chd_dev_download.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64]
+    L.chd_set_profiling.argtypes = [C.c_void_p, C.c_int]
+    L.chd_get_tick_stats.argtypes = [C.c_void_p, P(TickStats)]
+    _lib = L
+    return L
+
+
+def check(ctx, rc: int):
+    if rc != OK:
+        msg = load().chd_last_error(ctx)
+        raise ChdError(rc, msg.decode() if msg else "")

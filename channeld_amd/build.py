@@ -1,0 +1,69 @@
+"""Builds libchd_spatial.so (the gfx950 HIP library behind include/chd_spatial.h).
+
+hipcc cross-compiles for gfx950 without a GPU.  The .so is written in-tree
+(channeld_amd/libchd_spatial.so) so that it travels with the repo snapshot.
+-ffp-contract=off: float64 with every operation rounded separately, as amd64 Go.
+"""
+from __future__ import annotations
+
+import os
+import shutil
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+LIB = os.path.join(HERE, "libchd_spatial.so")
+SOURCES = ["chd_api.hip", "k_spatial.hip", "k_index.hip", "k_aoi.hip", "k_fanout.hip"]
+HEADERS = ["chd_device.h", "chd_kernels.h", os.path.join("..", "..", "include", "chd_spatial.h")]
+FLAGS = [
+    "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off",
+    "-fno-fast-math", "-Wall", "-Wno-unused-function", "-Wno-unused-result",
+]
+
+
+def hipcc() -> str:
+    for c in (os.environ.get("HIPCC"), shutil.which("hipcc"), "/opt/rocm/bin/hipcc"):
+        if c and os.path.exists(c):
+            return c
+    raise RuntimeError("hipcc not found: libchd_spatial.so cannot be built (there is no CPU fallback)")
+
+
+def stale() -> bool:
+    if not os.path.exists(LIB):
+        return True
+    t = os.path.getmtime(LIB)
+    deps = [os.path.join(CSRC, s) for s in SOURCES + HEADERS] + [os.path.abspath(__file__)]
+    return any(os.path.getmtime(d) > t for d in deps)
+
+
+def build(force: bool = False, verbose: bool = False) -> str:
+    if not force and not stale():
+        return LIB
+    cc = hipcc()
+    objs = []
+    bdir = os.path.join(HERE, "build")
+    os.makedirs(bdir, exist_ok=True)
+    procs = []
+    for s in SOURCES:
+        o = os.path.join(bdir, s.replace(".hip", ".o"))
+        objs.append(o)
+        cmd = [cc, *FLAGS, "-c", os.path.join(CSRC, s), "-o", o]
+        if verbose:
+            print(" ".join(cmd), file=sys.stderr)
+        procs.append((s, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)))
+    for s, p in procs:
+        out, _ = p.communicate()
+        if p.returncode != 0:
+            raise RuntimeError(f"hipcc failed on {s}:\n{out}")
+        if verbose and out.strip():
+            print(out, file=sys.stderr)
+    cmd = [cc, "--offload-arch=gfx950", "-shared", "-fPIC", *objs, "-o", LIB]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    if r.returncode != 0:
+        raise RuntimeError(f"link failed:\n{r.stdout}\n{r.stderr}")
+    return LIB
+
+
+if __name__ == "__main__":
+    print(build(force="--force" in sys.argv, verbose=True))

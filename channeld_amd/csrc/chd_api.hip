@@ -1,0 +1,896 @@
+// chd_api.hip — the C-ABI of libchd_spatial.so (include/chd_spatial.h).
+// Host plumbing only: argument validation, device buffers, stream ordering,
+// error reporting.  Every computation is a HIP kernel; there is no CPU path.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "chd_kernels.h"
+
+extern uint32_t index_num_blocks(uint32_t N);
+
+namespace {
+
+struct DevBuf {
+    void *p = nullptr;
+    size_t cap = 0;
+};
+
+struct World {
+    bool created = false;
+    chd_world_cfg cfg{};
+    WorldDev d{};
+    std::vector<void *> allocs;
+    chd_fanout_rec *recs_dense = nullptr;
+    uint64_t recs_dense_cap = 0;
+    uint64_t *rec_off_exact = nullptr;  // [S+1]
+    uint32_t *newsub_sub = nullptr, *newsub_cell = nullptr, *newsub_iv = nullptr;
+    int64_t last_now = INT64_MIN;
+    uint32_t last_nq = 0;
+    bool ticked = false;
+};
+
+}  // namespace
+
+struct chd_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    chd_grid_cfg cfg{};
+    DevGrid g{};
+    AoiLimits lim{};
+    std::mutex mu;
+    std::string err;
+    World w;
+    TickRing ring{};
+    // scratch for the stateless entry points and for chd_tick's staging
+    DevBuf scratch[16];
+    bool profiling = false;
+    hipEvent_t ev[CHD_N_STAGES + 1]{};
+    bool ev_valid = false;
+    chd_tick_stats stats{};
+};
+
+namespace {
+
+thread_local std::string tl_err;
+
+int fail(chd_ctx *ctx, int code, const char *fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    tl_err = buf;
+    if (ctx) ctx->err = buf;
+    return code;
+}
+
+#define HIPCHK(call)                                                                         \
+    do {                                                                                     \
+        hipError_t _e = (call);                                                              \
+        if (_e != hipSuccess)                                                                \
+            return fail(ctx, CHD_E_HIP, "%s failed: %s (%s:%d)", #call, hipGetErrorString(_e), \
+                        __FILE__, __LINE__);                                                 \
+    } while (0)
+
+int ensure(chd_ctx *ctx, int slot, size_t bytes) {
+    DevBuf &b = ctx->scratch[slot];
+    if (bytes <= b.cap) return CHD_OK;
+    if (b.p) {
+        HIPCHK(hipStreamSynchronize(ctx->stream));
+        HIPCHK(hipFree(b.p));
+        b.p = nullptr;
+        b.cap = 0;
+    }
+    size_t cap = std::max<size_t>(bytes + bytes / 4, 4096);
+    HIPCHK(hipMalloc(&b.p, cap));
+    b.cap = cap;
+    return CHD_OK;
+}
+
+template <typename T>
+T *sbuf(chd_ctx *ctx, int slot) { return (T *)ctx->scratch[slot].p; }
+
+int bind(chd_ctx *ctx) {
+    HIPCHK(hipSetDevice(ctx->device));
+    return CHD_OK;
+}
+
+int up(chd_ctx *ctx, void *dst, const void *src, size_t bytes) {
+    if (!bytes) return CHD_OK;
+    HIPCHK(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, ctx->stream));
+    return CHD_OK;
+}
+int down(chd_ctx *ctx, void *dst, const void *src, size_t bytes) {
+    if (!bytes) return CHD_OK;
+    HIPCHK(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, ctx->stream));
+    return CHD_OK;
+}
+
+int after_launch(chd_ctx *ctx) {
+    HIPCHK(hipGetLastError());
+    return CHD_OK;
+}
+
+#define TRY(x)                \
+    do {                      \
+        int _rc = (x);        \
+        if (_rc) return _rc;  \
+    } while (0)
+
+template <typename T>
+int walloc(chd_ctx *ctx, T **out, size_t count, bool zero = true) {
+    void *p = nullptr;
+    size_t bytes = std::max<size_t>(count * sizeof(T), 256);
+    HIPCHK(hipMalloc(&p, bytes));
+    ctx->w.allocs.push_back(p);
+    if (zero) HIPCHK(hipMemsetAsync(p, 0, bytes, ctx->stream));
+    *out = (T *)p;
+    return CHD_OK;
+}
+
+}  // namespace
+
+// dense per-connection packing of the emitted records (for the host-facing fetch)
+__global__ void __launch_bounds__(256) k_pack_records(WorldDev w, const uint64_t *exact_off, chd_fanout_rec *dense) {
+    uint32_t s = blockIdx.x * 4u + (threadIdx.x >> 6);
+    if (s >= w.S) return;
+    uint32_t n = w.rec_cnt[s];
+    const chd_fanout_rec *src = w.recs + w.rec_ub[s];
+    chd_fanout_rec *dst = dense + exact_off[s];
+    for (uint32_t k = threadIdx.x & 63u; k < n; k += 64) dst[k] = src[k];
+}
+
+__global__ void __launch_bounds__(256) k_widen(const uint32_t *in, uint64_t *out, uint32_t n) {
+    uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    if (i < n) out[i] = in[i];
+}
+
+extern "C" {
+
+int chd_abi_version(void) { return CHD_ABI_VERSION; }
+
+const char *chd_last_error(const chd_ctx *ctx) {
+    if (!tl_err.empty()) return tl_err.c_str();
+    return ctx ? ctx->err.c_str() : "";
+}
+
+int chd_create(const chd_grid_cfg *cfg, int device, chd_ctx **out) {
+    chd_ctx *ctx = nullptr;
+    if (!cfg || !out) return fail(nullptr, CHD_E_INVAL, "chd_create: NULL argument");
+    *out = nullptr;
+    // LoadConfig validation, spatial.go:146-157 (same order)
+    if (!(cfg->grid_width > 0) || !(cfg->grid_height > 0))
+        return fail(nullptr, CHD_E_CONFIG, "GridWidth and GridHeight should be positive");
+    if (cfg->grid_cols == 0 || cfg->grid_rows == 0)
+        return fail(nullptr, CHD_E_CONFIG, "GridCols and GridRows should be positive");
+    if (cfg->server_cols == 0 || cfg->server_rows == 0)
+        return fail(nullptr, CHD_E_CONFIG, "ServerCols and ServerRows should be positive");
+    if (cfg->strict_load_config && cfg->server_interest_border_size == 0)
+        return fail(nullptr, CHD_E_CONFIG, "ServerInterestBorderSize should be positive");
+    if ((uint64_t)cfg->grid_cols * cfg->grid_rows > 0x7FFFFFFFull)
+        return fail(nullptr, CHD_E_CONFIG, "grid has too many cells");
+    if (cfg->n_damping > CHD_MAX_DAMPING) return fail(nullptr, CHD_E_INVAL, "n_damping > %d", CHD_MAX_DAMPING);
+
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
+        return fail(nullptr, CHD_E_NO_DEVICE, "no HIP device visible: libchd_spatial has no CPU path");
+    if (device < 0 || device >= ndev) return fail(nullptr, CHD_E_NO_DEVICE, "device %d of %d", device, ndev);
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device) != hipSuccess)
+        return fail(nullptr, CHD_E_NO_DEVICE, "hipGetDeviceProperties failed");
+    if (strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+        return fail(nullptr, CHD_E_NO_DEVICE, "device %d is %s; this library carries gfx950 (MI355X) code only",
+                    device, prop.gcnArchName);
+
+    ctx = new chd_ctx();
+    ctx->device = device;
+    ctx->cfg = *cfg;
+    if (hipSetDevice(device) != hipSuccess || hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) {
+        delete ctx;
+        return fail(nullptr, CHD_E_HIP, "cannot create a stream on device %d", device);
+    }
+    DevGrid &g = ctx->g;
+    g.gw = cfg->grid_width;
+    g.gh = cfg->grid_height;
+    g.offx = cfg->world_offset_x;
+    g.offz = cfg->world_offset_z;
+    // GridSize(): sqrt is correctly rounded on the host and on amd64 Go alike; the
+    // two products and the sum are separate roundings (this file is built with
+    // -ffp-contract=off).
+    {
+        volatile double a = g.gw * g.gw, b = g.gh * g.gh;
+        volatile double s = a + b;
+        g.gsz = std::sqrt(s);
+    }
+    g.world_w = g.gw * (double)cfg->grid_cols;
+    g.world_h = g.gh * (double)cfg->grid_rows;
+    g.cols = cfg->grid_cols;
+    g.rows = cfg->grid_rows;
+    g.ncell = cfg->grid_cols * cfg->grid_rows;
+    g.id_start = cfg->spatial_channel_id_start ? cfg->spatial_channel_id_start : 0x10000u;
+    g.server_cols = cfg->server_cols;
+    g.server_rows = cfg->server_rows;
+    g.sgc = cfg->grid_cols / cfg->server_cols + (cfg->grid_cols % cfg->server_cols ? 1 : 0);
+    g.sgr = cfg->grid_rows / cfg->server_rows + (cfg->grid_rows % cfg->server_rows ? 1 : 0);
+    g.border = cfg->server_interest_border_size;
+    g.default_interval_ms = cfg->default_fanout_interval_ms ? cfg->default_fanout_interval_ms : 20;
+    g.default_delay_ms = cfg->default_fanout_delay_ms;
+    if (cfg->n_damping == 0) {  // message_spatial.go:16-29
+        g.n_damp = 3;
+        const uint32_t d[3] = {0, 1, 2}, iv[3] = {20, 50, 100};
+        for (int i = 0; i < 3; i++) { g.damp_dist[i] = d[i]; g.damp_iv[i] = iv[i]; }
+    } else {
+        g.n_damp = cfg->n_damping;
+        for (uint32_t i = 0; i < cfg->n_damping; i++) {
+            g.damp_dist[i] = cfg->damping_max_dist[i];
+            g.damp_iv[i] = cfg->damping_interval_ms[i];
+            if (g.damp_iv[i] == 0) {
+                (void)hipStreamDestroy(ctx->stream);
+                delete ctx;
+                return fail(nullptr, CHD_E_INVAL, "fan-out interval 0 makes the reference's tickData spin forever");
+            }
+        }
+    }
+    ctx->lim.maxax = 256;
+    ctx->lim.winmax = std::min<uint32_t>(std::max<uint32_t>(g.ncell, 64), 1024);
+    ctx->ring.n = 0;
+    ctx->ring.cur_tick = 0;
+    *out = ctx;
+    tl_err.clear();
+    return CHD_OK;
+}
+
+void chd_destroy(chd_ctx *ctx) {
+    if (!ctx) return;
+    (void)hipSetDevice(ctx->device);
+    (void)hipStreamSynchronize(ctx->stream);
+    for (void *p : ctx->w.allocs) (void)hipFree(p);
+    if (ctx->w.recs_dense) (void)hipFree(ctx->w.recs_dense);
+    for (auto &b : ctx->scratch)
+        if (b.p) (void)hipFree(b.p);
+    if (ctx->ev_valid)
+        for (auto &e : ctx->ev) (void)hipEventDestroy(e);
+    (void)hipStreamDestroy(ctx->stream);
+    delete ctx;
+}
+
+int chd_sync(chd_ctx *ctx) {
+    if (!ctx) return fail(nullptr, CHD_E_INVAL, "NULL ctx");
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    TRY(bind(ctx));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    return CHD_OK;
+}
+
+int chd_get_channel_ids(chd_ctx *ctx, const double *x, const double *z, uint32_t n, uint32_t *out_ids) {
+    if (!ctx) return fail(nullptr, CHD_E_INVAL, "NULL ctx");
+    if (n && (!x || !z || !out_ids)) return fail(ctx, CHD_E_INVAL, "chd_get_channel_ids: NULL buffer");
+    if (!n) return CHD_OK;
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    TRY(bind(ctx));
+    TRY(ensure(ctx, 0, sizeof(double) * n));
+    TRY(ensure(ctx, 1, sizeof(double) * n));
+    TRY(ensure(ctx, 2, sizeof(uint32_t) * n));
+    TRY(up(ctx, sbuf<double>(ctx, 0), x, sizeof(double) * n));
+    TRY(up(ctx, sbuf<double>(ctx, 1), z, sizeof(double) * n));
+    launch_get_channel_ids(ctx->stream, ctx->g, sbuf<double>(ctx, 0), sbuf<double>(ctx, 1), n, sbuf<uint32_t>(ctx, 2));
+    TRY(after_launch(ctx));
+    TRY(down(ctx, out_ids, sbuf<uint32_t>(ctx, 2), sizeof(uint32_t) * n));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    return CHD_OK;
+}
+
+int chd_notify_decide(chd_ctx *ctx, const double *old_x, const double *old_z, const double *new_x,
+                      const double *new_z, uint32_t n, uint32_t *src_ids, uint32_t *dst_ids, uint8_t *handover) {
+    if (!ctx) return fail(nullptr, CHD_E_INVAL, "NULL ctx");
+    if (n && (!old_x || !old_z || !new_x || !new_z || !src_ids || !dst_ids || !handover))
+        return fail(ctx, CHD_E_INVAL, "chd_notify_decide: NULL buffer");
+    if (!n) return CHD_OK;
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    TRY(bind(ctx));
+    for (int k = 0; k < 4; k++) TRY(ensure(ctx, k, sizeof(double) * n));
+    TRY(ensure(ctx, 4, sizeof(uint32_t) * n));
+    TRY(ensure(ctx, 5, sizeof(uint32_t) * n));
+    TRY(ensure(ctx, 6, n));
+    const double *src[4] = {old_x, old_z, new_x, new_z};
+    for (int k = 0; k < 4; k++) TRY(up(ctx, sbuf<double>(ctx, k), src[k], sizeof(double) * n));
+    launch_notify_decide(ctx->stream, ctx->g, sbuf<double>(ctx, 0), sbuf<double>(ctx, 1), sbuf<double>(ctx, 2),
+                         sbuf<double>(ctx, 3), n, sbuf<uint32_t>(ctx, 4), sbuf<uint32_t>(ctx, 5), sbuf<uint8_t>(ctx, 6));
+    TRY(after_launch(ctx));
+    TRY(down(ctx, src_ids, sbuf<uint32_t>(ctx, 4), sizeof(uint32_t) * n));
+    TRY(down(ctx, dst_ids, sbuf<uint32_t>(ctx, 5), sizeof(uint32_t) * n));
+    TRY(down(ctx, handover, sbuf<uint8_t>(ctx, 6), n));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    return CHD_OK;
+}
+
+int chd_query_channel_ids(chd_ctx *ctx, const chd_aoi_query *queries, uint32_t nq, const double *spot_x,
+                          const double *spot_z, const uint32_t *spot_dist, uint32_t n_spots_total,
+                          uint32_t *offsets, uint32_t *ids, uint32_t *dists, uint32_t *intervals_ms,
+                          uint32_t cap, int32_t *status) {
+    if (!ctx) return fail(nullptr, CHD_E_INVAL, "NULL ctx");
+    if (!offsets || !status || (nq && !queries)) return fail(ctx, CHD_E_INVAL, "chd_query_channel_ids: NULL buffer (a nil query is an error in the reference, spatial.go:183)");
+    if (cap && (!ids || !dists)) return fail(ctx, CHD_E_INVAL, "chd_query_channel_ids: NULL output");
+    if (n_spots_total && (!spot_x || !spot_z)) return fail(ctx, CHD_E_INVAL, "chd_query_channel_ids: NULL spots");
+    for (uint32_t i = 0; i < nq; i++) {
+        if ((queries[i].shapes & CHD_SHAPE_SPOTS) &&
+            ((uint64_t)queries[i].spot_off + queries[i].n_spots > n_spots_total || queries[i].n_spot_dists > queries[i].n_spots))
+            return fail(ctx, CHD_E_INVAL, "query %u: spot range out of bounds", i);
+    }
+    offsets[0] = 0;
+    if (!nq) return CHD_OK;
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    TRY(bind(ctx));
+    const uint32_t stride = std::min<uint32_t>(ctx->g.ncell, ctx->lim.winmax);
+    TRY(ensure(ctx, 0, sizeof(chd_aoi_query) * nq));
+    TRY(ensure(ctx, 1, sizeof(double) * std::max(n_spots_total, 1u)));
+    TRY(ensure(ctx, 2, sizeof(double) * std::max(n_spots_total, 1u)));
+    TRY(ensure(ctx, 3, sizeof(uint32_t) * std::max(n_spots_total, 1u)));
+    TRY(ensure(ctx, 4, sizeof(uint32_t) * (size_t)nq * stride));
+    TRY(ensure(ctx, 5, sizeof(uint32_t) * (size_t)nq * stride));
+    TRY(ensure(ctx, 6, sizeof(uint32_t) * (size_t)nq * stride));
+    TRY(ensure(ctx, 7, sizeof(uint32_t) * (nq + 1)));   // counts
+    TRY(ensure(ctx, 8, sizeof(uint32_t) * (nq + 1)));   // offsets
+    TRY(ensure(ctx, 9, sizeof(int32_t) * nq));
+    TRY(ensure(ctx, 10, sizeof(uint32_t) * std::max(cap, 1u)));
+    TRY(ensure(ctx, 11, sizeof(uint32_t) * std::max(cap, 1u)));
+    TRY(ensure(ctx, 12, sizeof(uint32_t) * std::max(cap, 1u)));
+    TRY(up(ctx, sbuf<void>(ctx, 0), queries, sizeof(chd_aoi_query) * nq));
+    TRY(up(ctx, sbuf<void>(ctx, 1), spot_x, sizeof(double) * n_spots_total));
+    TRY(up(ctx, sbuf<void>(ctx, 2), spot_z, sizeof(double) * n_spots_total));
+    if (spot_dist) TRY(up(ctx, sbuf<void>(ctx, 3), spot_dist, sizeof(uint32_t) * n_spots_total));
+    else HIPCHK(hipMemsetAsync(sbuf<void>(ctx, 3), 0, sizeof(uint32_t) * std::max(n_spots_total, 1u), ctx->stream));
+    launch_aoi_stateless(ctx->stream, ctx->g, ctx->lim, sbuf<chd_aoi_query>(ctx, 0), nq, sbuf<double>(ctx, 1),
+                         sbuf<double>(ctx, 2), sbuf<uint32_t>(ctx, 3), stride, sbuf<uint32_t>(ctx, 4),
+                         sbuf<uint32_t>(ctx, 5), sbuf<uint32_t>(ctx, 6), sbuf<uint32_t>(ctx, 7), sbuf<int32_t>(ctx, 9));
+    launch_scan_u32(ctx->stream, sbuf<uint32_t>(ctx, 7), sbuf<uint32_t>(ctx, 8), nq);
+    launch_csr_gather(ctx->stream, nq, stride, sbuf<uint32_t>(ctx, 7), sbuf<uint32_t>(ctx, 8), sbuf<uint32_t>(ctx, 4),
+                      sbuf<uint32_t>(ctx, 5), sbuf<uint32_t>(ctx, 6), sbuf<uint32_t>(ctx, 10), sbuf<uint32_t>(ctx, 11),
+                      sbuf<uint32_t>(ctx, 12), cap, ctx->g.id_start);
+    TRY(after_launch(ctx));
+    TRY(down(ctx, offsets, sbuf<void>(ctx, 8), sizeof(uint32_t) * (nq + 1)));
+    TRY(down(ctx, status, sbuf<void>(ctx, 9), sizeof(int32_t) * nq));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    uint32_t total = offsets[nq];
+    if (total > cap) return fail(ctx, CHD_E_CAPACITY, "chd_query_channel_ids: %u results, capacity %u", total, cap);
+    TRY(down(ctx, ids, sbuf<void>(ctx, 10), sizeof(uint32_t) * total));
+    TRY(down(ctx, dists, sbuf<void>(ctx, 11), sizeof(uint32_t) * total));
+    if (intervals_ms) TRY(down(ctx, intervals_ms, sbuf<void>(ctx, 12), sizeof(uint32_t) * total));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    return CHD_OK;
+}
+
+int chd_get_regions(chd_ctx *ctx, double *min_x, double *min_z, double *max_x, double *max_z,
+                    uint32_t *channel_id, uint32_t *server_index) {
+    if (!ctx) return fail(nullptr, CHD_E_INVAL, "NULL ctx");
+    if (!min_x || !min_z || !max_x || !max_z || !channel_id || !server_index)
+        return fail(ctx, CHD_E_INVAL, "chd_get_regions: NULL buffer");
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    TRY(bind(ctx));
+    const uint32_t n = ctx->g.ncell;
+    for (int k = 0; k < 4; k++) TRY(ensure(ctx, k, sizeof(double) * n));
+    TRY(ensure(ctx, 4, sizeof(uint32_t) * n));
+    TRY(ensure(ctx, 5, sizeof(uint32_t) * n));
+    launch_regions(ctx->stream, ctx->g, sbuf<double>(ctx, 0), sbuf<double>(ctx, 1), sbuf<double>(ctx, 2),
+                   sbuf<double>(ctx, 3), sbuf<uint32_t>(ctx, 4), sbuf<uint32_t>(ctx, 5));
+    TRY(after_launch(ctx));
+    double *dst[4] = {min_x, min_z, max_x, max_z};
+    for (int k = 0; k < 4; k++) TRY(down(ctx, dst[k], sbuf<void>(ctx, k), sizeof(double) * n));
+    TRY(down(ctx, channel_id, sbuf<void>(ctx, 4), sizeof(uint32_t) * n));
+    TRY(down(ctx, server_index, sbuf<void>(ctx, 5), sizeof(uint32_t) * n));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    return CHD_OK;
+}
+
+int chd_get_adjacent_channels(chd_ctx *ctx, const uint32_t *channel_ids, uint32_t n, uint32_t *out, uint32_t *counts) {
+    if (!ctx) return fail(nullptr, CHD_E_INVAL, "NULL ctx");
+    if (n && (!channel_ids || !out || !counts)) return fail(ctx, CHD_E_INVAL, "chd_get_adjacent_channels: NULL buffer");
+    for (uint32_t i = 0; i < n; i++)
+        if (channel_ids[i] < ctx->g.id_start || channel_ids[i] - ctx->g.id_start >= ctx->g.ncell)
+            return fail(ctx, CHD_E_INVAL, "channel id %u is not a spatial channel of this grid", channel_ids[i]);
+    if (!n) return CHD_OK;
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    TRY(bind(ctx));
+    TRY(ensure(ctx, 0, sizeof(uint32_t) * n));
+    TRY(ensure(ctx, 1, sizeof(uint32_t) * 8 * (size_t)n));
+    TRY(ensure(ctx, 2, sizeof(uint32_t) * n));
+    TRY(up(ctx, sbuf<void>(ctx, 0), channel_ids, sizeof(uint32_t) * n));
+    HIPCHK(hipMemsetAsync(sbuf<void>(ctx, 1), 0, sizeof(uint32_t) * 8 * (size_t)n, ctx->stream));
+    launch_adjacent(ctx->stream, ctx->g, sbuf<uint32_t>(ctx, 0), n, sbuf<uint32_t>(ctx, 1), sbuf<uint32_t>(ctx, 2));
+    TRY(after_launch(ctx));
+    TRY(down(ctx, out, sbuf<void>(ctx, 1), sizeof(uint32_t) * 8 * (size_t)n));
+    TRY(down(ctx, counts, sbuf<void>(ctx, 2), sizeof(uint32_t) * n));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    return CHD_OK;
+}
+
+static int server_cells_common(chd_ctx *ctx, uint32_t server_index, int mode, uint32_t *out, uint32_t cap, uint32_t *n_out) {
+    if (!ctx) return fail(nullptr, CHD_E_INVAL, "NULL ctx");
+    if (!n_out || (cap && !out)) return fail(ctx, CHD_E_INVAL, "NULL buffer");
+    if (server_index >= ctx->g.server_cols * ctx->g.server_rows)
+        return fail(ctx, CHD_E_INVAL, "all %u grids are allocated to %u servers", ctx->g.ncell,
+                    ctx->g.server_cols * ctx->g.server_rows);  // spatial.go:390-392
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    TRY(bind(ctx));
+    TRY(ensure(ctx, 0, sizeof(uint32_t) * std::max(cap, 1u)));
+    TRY(ensure(ctx, 1, 2 * sizeof(uint32_t)));
+    launch_server_cells(ctx->stream, ctx->g, server_index, mode, sbuf<uint32_t>(ctx, 0), cap, sbuf<uint32_t>(ctx, 1),
+                        sbuf<uint32_t>(ctx, 1) + 1);
+    TRY(after_launch(ctx));
+    uint32_t res[2] = {0, 0};
+    TRY(down(ctx, res, sbuf<void>(ctx, 1), sizeof res));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    *n_out = 0;
+    if (res[1] == 1) return fail(ctx, CHD_E_CONFIG, "server %u: a cell falls outside the grid (GetChannelIdNoOffset error)", server_index);
+    if (res[1] == 2) return fail(ctx, CHD_E_CAPACITY, "server %u: output capacity %u too small", server_index, cap);
+    TRY(down(ctx, out, sbuf<void>(ctx, 0), sizeof(uint32_t) * res[0]));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    *n_out = res[0];
+    return CHD_OK;
+}
+
+int chd_server_channels(chd_ctx *ctx, uint32_t server_index, uint32_t *out, uint32_t cap, uint32_t *n_out) {
+    return server_cells_common(ctx, server_index, 0, out, cap, n_out);
+}
+int chd_border_channels(chd_ctx *ctx, uint32_t server_index, uint32_t *out, uint32_t cap, uint32_t *n_out) {
+    return server_cells_common(ctx, server_index, 1, out, cap, n_out);
+}
+
+// ---------------------------------------------------------------------------
+// world
+// ---------------------------------------------------------------------------
+
+int chd_world_create(chd_ctx *ctx, const chd_world_cfg *cfg) {
+    if (!ctx || !cfg) return fail(ctx, CHD_E_INVAL, "chd_world_create: NULL argument");
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    TRY(bind(ctx));
+    World &W = ctx->w;
+    if (W.created) return fail(ctx, CHD_E_STATE, "world already created");
+    if (cfg->max_entities == 0 || cfg->max_subscribers == 0)
+        return fail(ctx, CHD_E_INVAL, "max_entities and max_subscribers must be positive");
+    W.cfg = *cfg;
+    WorldDev &d = W.d;
+    const DevGrid &g = ctx->g;
+    d.N = cfg->max_entities;
+    d.S = cfg->max_subscribers;
+    d.capq = cfg->max_interest_cells ? cfg->max_interest_cells : std::min<uint32_t>(g.ncell, 256);
+    if (d.capq > ctx->lim.winmax) d.capq = ctx->lim.winmax;
+    if (d.capq > 0xFFFE) return fail(ctx, CHD_E_INVAL, "max_interest_cells too large");
+    const size_t N = d.N, S = d.S, P = (size_t)d.S * d.capq, C = g.ncell;
+    TRY(walloc(ctx, &d.chan_id, N));
+    TRY(walloc(ctx, &d.cell, N));
+    TRY(walloc(ctx, &d.member, N));
+    TRY(walloc(ctx, &d.eflags, N));
+    TRY(walloc(ctx, &d.sender, N));
+    TRY(walloc(ctx, &d.hist, N));
+    TRY(walloc(ctx, &d.hist_tick, N));
+    TRY(walloc(ctx, &d.cell_hist, C));
+    TRY(walloc(ctx, &d.cell_hist_tick, C));
+    TRY(walloc(ctx, &d.cell_sender, C));
+    d.nblk = (C <= 4096) ? index_num_blocks(d.N) : 1;
+    TRY(walloc(ctx, &d.blk_cnt, std::max(C * d.nblk + 1, 2 * C + 2)));
+    TRY(walloc(ctx, &d.ce_ent, N));
+    TRY(walloc(ctx, &d.ce_chan, N));
+    TRY(walloc(ctx, &d.ce_hist, N));
+    TRY(walloc(ctx, &d.ce_sender, N));
+    TRY(walloc(ctx, &d.conn_id, S));
+    TRY(walloc(ctx, &d.sub_alive, S));
+    TRY(walloc(ctx, &d.sub_tick, S));
+    TRY(walloc(ctx, &d.pair_cnt, S));
+    TRY(walloc(ctx, &d.pair_cell, P));
+    TRY(walloc(ctx, &d.pair_iv, P));
+    TRY(walloc(ctx, &d.pair_last, P));
+    TRY(walloc(ctx, &d.pair_flags, P));
+    TRY(walloc(ctx, &d.rec_ub, S + 1));
+    TRY(walloc(ctx, &d.rec_cnt, S));
+    TRY(walloc(ctx, &W.rec_off_exact, S + 1));
+    d.handovers_cap = cfg->max_handovers ? cfg->max_handovers : d.N;
+    TRY(walloc(ctx, &d.handovers, d.handovers_cap, false));
+    d.unsub_cap = (uint32_t)std::min<size_t>(P, 0x7FFFFFFF);
+    TRY(walloc(ctx, &d.unsub_sub, d.unsub_cap, false));
+    TRY(walloc(ctx, &d.unsub_cell, d.unsub_cap, false));
+    d.newsub_cap = d.unsub_cap;
+    TRY(walloc(ctx, &d.newsub_sub, d.newsub_cap, false));
+    TRY(walloc(ctx, &d.newsub_cell, d.newsub_cap, false));
+    TRY(walloc(ctx, &d.newsub_iv, d.newsub_cap, false));
+    TRY(walloc(ctx, &d.q_status, S));
+    TRY(walloc(ctx, &d.counters, CTR_COUNT));
+    uint64_t nrec = cfg->max_records;
+    if (!nrec) {
+        size_t free_b = 0, total_b = 0;
+        HIPCHK(hipMemGetInfo(&free_b, &total_b));
+        nrec = std::min<uint64_t>((uint64_t)(free_b * 0.5) / sizeof(chd_fanout_rec), 4000000000ull);
+    }
+    d.recs_cap = nrec;
+    TRY(walloc(ctx, &d.recs, nrec, false));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    W.created = true;
+    return CHD_OK;
+}
+
+#define NEED_WORLD()                                                              \
+    if (!ctx) return fail(nullptr, CHD_E_INVAL, "NULL ctx");                       \
+    if (!ctx->w.created) return fail(ctx, CHD_E_STATE, "chd_world_create has not been called")
+
+int chd_world_spawn(chd_ctx *ctx, uint32_t n, const uint32_t *idx, const uint32_t *chan_id, const double *x,
+                    const double *z, const uint32_t *flags, const uint32_t *sender) {
+    NEED_WORLD();
+    if (!n) return CHD_OK;
+    if (!chan_id || !x || !z) return fail(ctx, CHD_E_INVAL, "chd_world_spawn: NULL buffer");
+    if (!idx && n > ctx->w.d.N) return fail(ctx, CHD_E_INVAL, "chd_world_spawn: n > max_entities");
+    if (idx)
+        for (uint32_t i = 0; i < n; i++)
+            if (idx[i] >= ctx->w.d.N) return fail(ctx, CHD_E_INVAL, "entity slot %u out of range", idx[i]);
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    TRY(bind(ctx));
+    TRY(ensure(ctx, 0, 4 * (size_t)n)); TRY(ensure(ctx, 1, 4 * (size_t)n));
+    TRY(ensure(ctx, 2, 8 * (size_t)n)); TRY(ensure(ctx, 3, 8 * (size_t)n));
+    TRY(ensure(ctx, 4, 4 * (size_t)n)); TRY(ensure(ctx, 5, 4 * (size_t)n));
+    if (idx) TRY(up(ctx, sbuf<void>(ctx, 0), idx, 4 * (size_t)n));
+    TRY(up(ctx, sbuf<void>(ctx, 1), chan_id, 4 * (size_t)n));
+    TRY(up(ctx, sbuf<void>(ctx, 2), x, 8 * (size_t)n));
+    TRY(up(ctx, sbuf<void>(ctx, 3), z, 8 * (size_t)n));
+    if (flags) TRY(up(ctx, sbuf<void>(ctx, 4), flags, 4 * (size_t)n));
+    if (sender) TRY(up(ctx, sbuf<void>(ctx, 5), sender, 4 * (size_t)n));
+    launch_spawn(ctx->stream, ctx->g, ctx->w.d, n, idx ? sbuf<uint32_t>(ctx, 0) : nullptr, sbuf<uint32_t>(ctx, 1),
+                 sbuf<double>(ctx, 2), sbuf<double>(ctx, 3), flags ? sbuf<uint32_t>(ctx, 4) : nullptr,
+                 sender ? sbuf<uint32_t>(ctx, 5) : nullptr, ctx->ring.cur_tick);
+    TRY(after_launch(ctx));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    return CHD_OK;
+}
+
+int chd_world_despawn(chd_ctx *ctx, uint32_t n, const uint32_t *idx) {
+    NEED_WORLD();
+    if (!n) return CHD_OK;
+    if (!idx) return fail(ctx, CHD_E_INVAL, "chd_world_despawn: NULL idx");
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    TRY(bind(ctx));
+    TRY(ensure(ctx, 0, 4 * (size_t)n));
+    TRY(up(ctx, sbuf<void>(ctx, 0), idx, 4 * (size_t)n));
+    launch_despawn(ctx->stream, ctx->w.d, n, sbuf<uint32_t>(ctx, 0));
+    TRY(after_launch(ctx));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    return CHD_OK;
+}
+
+int chd_world_set_entity_flags(chd_ctx *ctx, uint32_t n, const uint32_t *idx, const uint32_t *flags) {
+    NEED_WORLD();
+    if (!n) return CHD_OK;
+    if (!idx || !flags) return fail(ctx, CHD_E_INVAL, "chd_world_set_entity_flags: NULL buffer");
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    TRY(bind(ctx));
+    TRY(ensure(ctx, 0, 4 * (size_t)n)); TRY(ensure(ctx, 1, 4 * (size_t)n));
+    TRY(up(ctx, sbuf<void>(ctx, 0), idx, 4 * (size_t)n));
+    TRY(up(ctx, sbuf<void>(ctx, 1), flags, 4 * (size_t)n));
+    launch_set_flags(ctx->stream, ctx->w.d, n, sbuf<uint32_t>(ctx, 0), sbuf<uint32_t>(ctx, 1));
+    TRY(after_launch(ctx));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    return CHD_OK;
+}
+
+static int subs_common(chd_ctx *ctx, uint32_t n, const uint32_t *slot, const uint32_t *conn, int add) {
+    NEED_WORLD();
+    if (!n) return CHD_OK;
+    if (add && !conn) return fail(ctx, CHD_E_INVAL, "chd_subs_add: NULL conn_id");
+    if (!slot && n > ctx->w.d.S) return fail(ctx, CHD_E_INVAL, "n > max_subscribers");
+    if (slot)
+        for (uint32_t i = 0; i < n; i++)
+            if (slot[i] >= ctx->w.d.S) return fail(ctx, CHD_E_INVAL, "subscriber slot %u out of range", slot[i]);
+    if (add)
+        for (uint32_t i = 0; i < n; i++)
+            if (conn[i] & CHD_REC_FULL) return fail(ctx, CHD_E_INVAL, "connection id %u exceeds 31 bits (settings.go:90)", conn[i]);
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    TRY(bind(ctx));
+    TRY(ensure(ctx, 0, 4 * (size_t)n)); TRY(ensure(ctx, 1, 4 * (size_t)n));
+    if (slot) TRY(up(ctx, sbuf<void>(ctx, 0), slot, 4 * (size_t)n));
+    if (add) TRY(up(ctx, sbuf<void>(ctx, 1), conn, 4 * (size_t)n));
+    launch_subs_add(ctx->stream, ctx->w.d, n, slot ? sbuf<uint32_t>(ctx, 0) : nullptr, sbuf<uint32_t>(ctx, 1), add);
+    TRY(after_launch(ctx));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    return CHD_OK;
+}
+
+int chd_subs_add(chd_ctx *ctx, uint32_t n, const uint32_t *slot, const uint32_t *conn_id) {
+    return subs_common(ctx, n, slot, conn_id, 1);
+}
+int chd_subs_remove(chd_ctx *ctx, uint32_t n, const uint32_t *slot) { return subs_common(ctx, n, slot, nullptr, 0); }
+
+// the device-side tick; caller holds the mutex.  `in` carries DEVICE pointers.
+static int tick_locked(chd_ctx *ctx, const chd_tick_in *in) {
+    World &W = ctx->w;
+    WorldDev &d = W.d;
+    if (in->now_ns < W.last_now) return fail(ctx, CHD_E_INVAL, "now_ns went backwards (%lld < %lld)", (long long)in->now_ns, (long long)W.last_now);
+    if (in->n_updates && (!in->upd_x || !in->upd_z)) return fail(ctx, CHD_E_INVAL, "tick: NULL update positions");
+    if (!in->upd_idx && in->n_updates > d.N) return fail(ctx, CHD_E_INVAL, "tick: n_updates > max_entities");
+    if (in->n_queries && !in->queries) return fail(ctx, CHD_E_INVAL, "tick: NULL queries");
+    if (in->n_queries > d.S) return fail(ctx, CHD_E_INVAL, "tick: n_queries > max_subscribers (one interest update per connection per tick)");
+    if (in->n_cell_updates && (!in->cell_upd_channel || !in->cell_upd_sender)) return fail(ctx, CHD_E_INVAL, "tick: NULL cell updates");
+    W.last_now = in->now_ns;
+    // advance the tick ring
+    TickRing &r = ctx->ring;
+    for (int j = CHD_HIST_BITS - 1; j > 0; j--) r.t[j] = r.t[j - 1];
+    r.t[0] = in->now_ns;
+    if (r.n < CHD_HIST_BITS) r.n++;
+    r.cur_tick++;
+    hipStream_t st = ctx->stream;
+    const bool prof = ctx->profiling;
+    if (prof && !ctx->ev_valid) {
+        for (auto &e : ctx->ev) HIPCHK(hipEventCreate(&e));
+        ctx->ev_valid = true;
+    }
+    HIPCHK(hipMemsetAsync(d.counters, 0, sizeof(uint32_t) * CTR_COUNT, st));
+    if (prof) HIPCHK(hipEventRecord(ctx->ev[0], st));
+    launch_ingest(st, ctx->g, d, in->n_updates, in->upd_idx, in->upd_x, in->upd_z, in->upd_sender, r.cur_tick);
+    launch_cell_updates(st, ctx->g, d, in->n_cell_updates, in->cell_upd_channel, in->cell_upd_sender, r.cur_tick);
+    if (prof) HIPCHK(hipEventRecord(ctx->ev[1], st));
+    launch_index_build(st, ctx->g, d, r.cur_tick);
+    if (prof) HIPCHK(hipEventRecord(ctx->ev[2], st));
+    launch_aoi_interest(st, ctx->g, ctx->lim, d, in->queries, in->n_queries, in->query_sub, in->spot_x, in->spot_z,
+                        in->spot_dist, in->now_ns, r.cur_tick);
+    if (prof) HIPCHK(hipEventRecord(ctx->ev[3], st));
+    launch_fanout_plan(st, ctx->g, d, in->now_ns, r);
+    if (prof) HIPCHK(hipEventRecord(ctx->ev[4], st));
+    launch_fanout_emit(st, ctx->g, d, in->now_ns, r);
+    if (prof) HIPCHK(hipEventRecord(ctx->ev[5], st));
+    TRY(after_launch(ctx));
+    W.last_nq = in->n_queries;
+    W.ticked = true;
+    return CHD_OK;
+}
+
+int chd_tick_device(chd_ctx *ctx, const chd_tick_in *d_in) {
+    NEED_WORLD();
+    if (!d_in) return fail(ctx, CHD_E_INVAL, "chd_tick_device: NULL input");
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    TRY(bind(ctx));
+    return tick_locked(ctx, d_in);
+}
+
+static int fetch_locked(chd_ctx *ctx, chd_tick_out *out) {
+    World &W = ctx->w;
+    WorldDev &d = W.d;
+    if (!W.ticked) return fail(ctx, CHD_E_STATE, "no tick to fetch");
+    hipStream_t st = ctx->stream;
+    uint32_t ctr[CTR_COUNT];
+    // exact per-connection offsets
+    hipLaunchKernelGGL(k_widen, dim3((d.S + 255) / 256), dim3(256), 0, st, d.rec_cnt, W.rec_off_exact, d.S);
+    launch_scan_u64_inplace(st, W.rec_off_exact, d.S);
+    TRY(down(ctx, ctr, d.counters, sizeof ctr));
+    uint64_t total = 0;
+    TRY(down(ctx, &total, W.rec_off_exact + d.S, sizeof total));
+    HIPCHK(hipStreamSynchronize(st));
+    out->n_handovers = std::min(ctr[CTR_HANDOVERS], d.handovers_cap);
+    out->n_locked_aborts = ctr[CTR_LOCKED];
+    out->n_unsubs = std::min(ctr[CTR_UNSUBS], d.unsub_cap);
+    out->overflow = ctr[CTR_OVERFLOW];
+    out->history_overflow = ctr[CTR_HIST_OVERFLOW];
+    out->n_records = total;
+    int rc = CHD_OK;
+    if (out->handovers) {
+        uint32_t n = std::min(out->n_handovers, out->handovers_cap);
+        if (n < out->n_handovers) { out->overflow |= OVF_HANDOVER; rc = CHD_E_CAPACITY; }
+        TRY(down(ctx, out->handovers, d.handovers, sizeof(chd_handover_rec) * n));
+    }
+    if (out->query_status) TRY(down(ctx, out->query_status, d.q_status, sizeof(int32_t) * W.last_nq));
+    if (out->unsub_sub && out->unsub_channel) {
+        uint32_t n = std::min(out->n_unsubs, out->unsub_cap);
+        if (n < out->n_unsubs) { out->overflow |= OVF_UNSUB; rc = CHD_E_CAPACITY; }
+        TRY(down(ctx, out->unsub_sub, d.unsub_sub, 4 * (size_t)n));
+        TRY(down(ctx, out->unsub_channel, d.unsub_cell, 4 * (size_t)n));
+    }
+    out->n_newsubs = std::min(ctr[CTR_NEWSUBS], d.newsub_cap);
+    if (out->newsub_sub && out->newsub_channel) {
+        uint32_t n = std::min(out->n_newsubs, out->newsub_cap);
+        if (n < out->n_newsubs) { out->overflow |= OVF_NEWSUB; rc = CHD_E_CAPACITY; }
+        TRY(down(ctx, out->newsub_sub, d.newsub_sub, 4 * (size_t)n));
+        TRY(down(ctx, out->newsub_channel, d.newsub_cell, 4 * (size_t)n));
+        if (out->newsub_interval_ms) TRY(down(ctx, out->newsub_interval_ms, d.newsub_iv, 4 * (size_t)n));
+    }
+    if (out->conn_rec_off) TRY(down(ctx, out->conn_rec_off, W.rec_off_exact, sizeof(uint64_t) * (d.S + 1)));
+    if (out->conn_rec_cnt) TRY(down(ctx, out->conn_rec_cnt, d.rec_cnt, sizeof(uint32_t) * d.S));
+    if (out->records && total) {
+        if (total > out->records_cap) {
+            out->overflow |= OVF_RECORDS;
+            rc = CHD_E_CAPACITY;
+        } else {
+            if (W.recs_dense_cap < total) {
+                if (W.recs_dense) HIPCHK(hipFree(W.recs_dense));
+                W.recs_dense = nullptr;
+                W.recs_dense_cap = total + total / 4;
+                HIPCHK(hipMalloc((void **)&W.recs_dense, W.recs_dense_cap * sizeof(chd_fanout_rec)));
+            }
+            hipLaunchKernelGGL(k_pack_records, dim3((d.S + 3) / 4), dim3(256), 0, st, d, W.rec_off_exact, W.recs_dense);
+            TRY(after_launch(ctx));
+            TRY(down(ctx, out->records, W.recs_dense, sizeof(chd_fanout_rec) * total));
+        }
+    }
+    HIPCHK(hipStreamSynchronize(st));
+    if (out->overflow && rc == CHD_OK) rc = CHD_E_CAPACITY;
+    // stats
+    chd_tick_stats &s = ctx->stats;
+    s.n_records = total;
+    uint64_t ub = 0;
+    HIPCHK(hipMemcpy(&ub, d.rec_ub + d.S, sizeof ub, hipMemcpyDeviceToHost));
+    s.n_record_upper_bound = ub;
+    s.n_handovers = out->n_handovers;
+    s.n_unsubs = out->n_unsubs;
+    s.n_pairs = ctr[CTR_PAIRS];
+    if (ctx->profiling && ctx->ev_valid) {
+        float tot = 0;
+        for (int k = 0; k < CHD_N_STAGES; k++) {
+            float ms = 0;
+            (void)hipEventElapsedTime(&ms, ctx->ev[k], ctx->ev[k + 1]);
+            s.stage_us[k] = ms * 1000.f;
+            tot += ms * 1000.f;
+        }
+        s.total_us = tot;
+    }
+    if (rc == CHD_E_CAPACITY) return fail(ctx, rc, "tick output truncated (overflow mask 0x%x)", out->overflow);
+    return rc;
+}
+
+int chd_tick_fetch(chd_ctx *ctx, chd_tick_out *out) {
+    NEED_WORLD();
+    if (!out) return fail(ctx, CHD_E_INVAL, "chd_tick_fetch: NULL output");
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    TRY(bind(ctx));
+    return fetch_locked(ctx, out);
+}
+
+int chd_tick(chd_ctx *ctx, const chd_tick_in *in, chd_tick_out *out) {
+    NEED_WORLD();
+    if (!in || !out) return fail(ctx, CHD_E_INVAL, "chd_tick: NULL argument");
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    TRY(bind(ctx));
+    chd_tick_in din = *in;
+    const size_t nu = in->n_updates, nq = in->n_queries, nc = in->n_cell_updates, ns = in->n_spots_total;
+    if (nu && (!in->upd_x || !in->upd_z)) return fail(ctx, CHD_E_INVAL, "tick: NULL update positions");
+    if (nq && !in->queries) return fail(ctx, CHD_E_INVAL, "tick: NULL queries");
+    if (in->upd_idx)
+        for (size_t i = 0; i < nu; i++)
+            if (in->upd_idx[i] >= ctx->w.d.N) return fail(ctx, CHD_E_INVAL, "tick: entity slot %u out of range", in->upd_idx[i]);
+    if (in->query_sub)
+        for (size_t i = 0; i < nq; i++)
+            if (in->query_sub[i] >= ctx->w.d.S) return fail(ctx, CHD_E_INVAL, "tick: subscriber slot %u out of range", in->query_sub[i]);
+    for (size_t i = 0; i < nq; i++)
+        if ((in->queries[i].shapes & CHD_SHAPE_SPOTS) &&
+            ((uint64_t)in->queries[i].spot_off + in->queries[i].n_spots > ns || in->queries[i].n_spot_dists > in->queries[i].n_spots))
+            return fail(ctx, CHD_E_INVAL, "tick: query %zu spot range out of bounds", i);
+    for (size_t i = 0; i < nc; i++)
+        if (in->cell_upd_channel[i] < ctx->g.id_start || in->cell_upd_channel[i] - ctx->g.id_start >= ctx->g.ncell)
+            return fail(ctx, CHD_E_INVAL, "tick: cell update %zu is not a spatial channel", i);
+    auto stage = [&](int slot, const void *src, size_t bytes, const void **dst) -> int {
+        *dst = nullptr;
+        if (!src || !bytes) return CHD_OK;
+        TRY(ensure(ctx, slot, bytes));
+        TRY(up(ctx, ctx->scratch[slot].p, src, bytes));
+        *dst = ctx->scratch[slot].p;
+        return CHD_OK;
+    };
+    TRY(stage(0, in->upd_idx, 4 * nu, (const void **)&din.upd_idx));
+    TRY(stage(1, in->upd_x, 8 * nu, (const void **)&din.upd_x));
+    TRY(stage(2, in->upd_z, 8 * nu, (const void **)&din.upd_z));
+    TRY(stage(3, in->upd_sender, 4 * nu, (const void **)&din.upd_sender));
+    TRY(stage(4, in->cell_upd_channel, 4 * nc, (const void **)&din.cell_upd_channel));
+    TRY(stage(5, in->cell_upd_sender, 4 * nc, (const void **)&din.cell_upd_sender));
+    TRY(stage(6, in->query_sub, 4 * nq, (const void **)&din.query_sub));
+    TRY(stage(7, in->queries, sizeof(chd_aoi_query) * nq, (const void **)&din.queries));
+    TRY(stage(8, in->spot_x, 8 * ns, (const void **)&din.spot_x));
+    TRY(stage(9, in->spot_z, 8 * ns, (const void **)&din.spot_z));
+    TRY(stage(10, in->spot_dist, 4 * ns, (const void **)&din.spot_dist));
+    if (ns && !in->spot_dist) {
+        TRY(ensure(ctx, 10, 4 * ns));
+        HIPCHK(hipMemsetAsync(ctx->scratch[10].p, 0, 4 * ns, ctx->stream));
+        din.spot_dist = (const uint32_t *)ctx->scratch[10].p;
+    }
+    TRY(tick_locked(ctx, &din));
+    return fetch_locked(ctx, out);
+}
+
+int chd_subs_get(chd_ctx *ctx, uint32_t slot, uint32_t *channel, uint32_t *interval_ms, int64_t *last_fanout_ns,
+                 uint8_t *had_first, uint8_t *is_new, uint32_t *n_out) {
+    NEED_WORLD();
+    if (!n_out) return fail(ctx, CHD_E_INVAL, "chd_subs_get: NULL n_out");
+    WorldDev &d = ctx->w.d;
+    if (slot >= d.S) return fail(ctx, CHD_E_INVAL, "subscriber slot %u out of range", slot);
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    TRY(bind(ctx));
+    uint32_t cnt = 0, stick = 0;
+    TRY(down(ctx, &cnt, d.pair_cnt + slot, 4));
+    TRY(down(ctx, &stick, d.sub_tick + slot, 4));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    const bool fresh = (stick == ctx->ring.cur_tick);
+    std::vector<uint32_t> fl(cnt), cell(cnt);
+    const size_t pb = (size_t)slot * d.capq;
+    TRY(down(ctx, cell.data(), d.pair_cell + pb, 4 * (size_t)cnt));
+    TRY(down(ctx, fl.data(), d.pair_flags + pb, 4 * (size_t)cnt));
+    if (interval_ms) TRY(down(ctx, interval_ms, d.pair_iv + pb, 4 * (size_t)cnt));
+    if (last_fanout_ns) TRY(down(ctx, last_fanout_ns, d.pair_last + pb, 8 * (size_t)cnt));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    for (uint32_t i = 0; i < cnt; i++) {
+        if (channel) channel[i] = cell[i] + ctx->g.id_start;
+        if (had_first) had_first[i] = (fl[i] & PF_HAD_FIRST) ? 1 : 0;
+        if (is_new) is_new[i] = (fresh && (fl[i] & PF_NEW)) ? 1 : 0;
+    }
+    *n_out = cnt;
+    return CHD_OK;
+}
+
+int chd_world_get_entities(chd_ctx *ctx, uint32_t n, const uint32_t *idx, uint32_t *cell_channel, uint32_t *member_channel) {
+    NEED_WORLD();
+    WorldDev &d = ctx->w.d;
+    if (!idx && n > d.N) return fail(ctx, CHD_E_INVAL, "n > max_entities");
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    TRY(bind(ctx));
+    std::vector<uint32_t> cell(d.N), mem(d.N);
+    TRY(down(ctx, cell.data(), d.cell, 4 * (size_t)d.N));
+    TRY(down(ctx, mem.data(), d.member, 4 * (size_t)d.N));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    for (uint32_t u = 0; u < n; u++) {
+        uint32_t i = idx ? idx[u] : u;
+        if (i >= d.N) return fail(ctx, CHD_E_INVAL, "entity slot %u out of range", i);
+        if (cell_channel) cell_channel[u] = cell[i] == CHD_INVALID ? 0u : cell[i] + ctx->g.id_start;
+        if (member_channel) member_channel[u] = mem[i] == CHD_INVALID ? 0u : mem[i] + ctx->g.id_start;
+    }
+    return CHD_OK;
+}
+
+int chd_dev_alloc(chd_ctx *ctx, uint64_t bytes, void **d_out) {
+    if (!ctx || !d_out) return fail(ctx, CHD_E_INVAL, "chd_dev_alloc: NULL argument");
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    TRY(bind(ctx));
+    HIPCHK(hipMalloc(d_out, bytes ? bytes : 256));
+    return CHD_OK;
+}
+int chd_dev_free(chd_ctx *ctx, void *d_ptr) {
+    if (!ctx) return fail(nullptr, CHD_E_INVAL, "NULL ctx");
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    TRY(bind(ctx));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    HIPCHK(hipFree(d_ptr));
+    return CHD_OK;
+}
+int chd_dev_upload(chd_ctx *ctx, void *d_dst, const void *src, uint64_t bytes) {
+    if (!ctx) return fail(nullptr, CHD_E_INVAL, "NULL ctx");
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    TRY(bind(ctx));
+    TRY(up(ctx, d_dst, src, bytes));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    return CHD_OK;
+}
+int chd_dev_download(chd_ctx *ctx, void *dst, const void *d_src, uint64_t bytes) {
+    if (!ctx) return fail(nullptr, CHD_E_INVAL, "NULL ctx");
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    TRY(bind(ctx));
+    TRY(down(ctx, dst, d_src, bytes));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    return CHD_OK;
+}
+
+int chd_set_profiling(chd_ctx *ctx, int enabled) {
+    if (!ctx) return fail(nullptr, CHD_E_INVAL, "NULL ctx");
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    ctx->profiling = enabled != 0;
+    return CHD_OK;
+}
+
+int chd_get_tick_stats(chd_ctx *ctx, chd_tick_stats *out) {
+    if (!ctx || !out) return fail(ctx, CHD_E_INVAL, "chd_get_tick_stats: NULL argument");
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    // byte model of DESIGN.md §4: 12 B per emitted message dominate
+    chd_tick_stats s = ctx->stats;
+    s.algorithmic_bytes = 12ull * s.n_records + 32ull * s.n_handovers;
+    *out = s;
+    return CHD_OK;
+}
+
+}  // extern "C"

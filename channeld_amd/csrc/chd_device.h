@@ -1,0 +1,124 @@
+// chd_device.h — shared device-side definitions for the gfx950 kernels.
+//
+// Arithmetic contract: IEEE float64, every operation rounded
+// separately (the library is compiled with -ffp-contract=off), IEEE division
+// and correctly rounded sqrt — the same results as amd64 Go, which emits no
+// FMA.  wave = 64 lanes everywhere.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define CHD_INVALID 0xFFFFFFFFu
+#define CHD_ABSENT 0xFFFFFFFFu
+#define CHD_WAVE 64
+#define CHD_HIST_BITS 32
+
+// pair flags (per subscriber x spatial channel subscription state,
+// subscription.go:13-31 + data.go:39-44)
+#define PF_HAD_FIRST 1u  // fanOutConnection.hadFirstFanOut
+#define PF_SKIP_SELF 2u  // options.SkipSelfUpdateFanOut
+#define PF_NO_ACCESS 4u  // options.DataAccess == NO_ACCESS
+#define PF_NEW 8u        // subscribed during the current tick
+
+// entity flags
+#define EF_LOCKED 1u
+#define EF_ALIVE 0x80000000u
+
+// device counters (one uint32 each unless noted), zeroed every tick
+enum {
+    CTR_HANDOVERS = 0,
+    CTR_LOCKED = 1,
+    CTR_UNSUBS = 2,
+    CTR_OVERFLOW = 3,
+    CTR_HIST_OVERFLOW = 4,
+    CTR_PAIRS = 5,
+    CTR_NEWSUBS = 6,
+    CTR_COUNT = 16
+};
+
+#define OVF_HANDOVER 1u
+#define OVF_UNSUB 2u
+#define OVF_RECORDS 4u
+#define OVF_NEWSUB 8u
+
+struct DevGrid {
+    double gw, gh, offx, offz;
+    double gsz;               // GridSize() = sqrt(gw*gw + gh*gh), spatial.go:134-139
+    double world_w, world_h;  // WorldWidth()/WorldHeight(), spatial.go:126-132
+    uint32_t cols, rows, ncell, id_start;
+    uint32_t server_cols, server_rows, sgc, sgr;  // server grid dims, spatial.go:321-330
+    uint32_t border;
+    uint32_t default_interval_ms;
+    int32_t default_delay_ms;
+    uint32_t n_damp;
+    uint32_t damp_dist[8];
+    uint32_t damp_iv[8];
+};
+
+struct TickRing {
+    int64_t t[CHD_HIST_BITS];  // t[j] = arrival stamp of tick (cur - j); valid for j < n
+    uint32_t n;
+    uint32_t cur_tick;
+};
+
+// int(math.Floor(v)) then `< 0 || >= n`  (spatial.go:170-177).  NaN/±Inf/huge
+// convert to MinInt64 on amd64, i.e. "negative": same outcome as this predicate.
+__device__ __forceinline__ bool grid_coord(double v, uint32_t n, uint32_t &out) {
+    double f = floor(v);
+    if (!(f >= 0.0) || !(f < (double)n)) return false;
+    out = (uint32_t)f;
+    return true;
+}
+
+// GetChannelIdWithOffset (spatial.go:169-180) as a cell INDEX (id - id_start),
+// CHD_INVALID for the error return.
+__device__ __forceinline__ uint32_t cell_of(const DevGrid &g, double x, double z) {
+    uint32_t gx, gy;
+    if (!grid_coord((x - g.offx) / g.gw, g.cols, gx)) return CHD_INVALID;
+    if (!grid_coord((z - g.offz) / g.gh, g.rows, gy)) return CHD_INVALID;
+    return gx + gy * g.cols;
+}
+
+__device__ __forceinline__ uint32_t server_of(const DevGrid &g, uint32_t cell) {
+    // GetRegions (spatial.go:336-351)
+    uint32_t x = cell % g.cols, y = cell / g.cols;
+    return x / g.sgc + (y / g.sgr) * g.server_cols;
+}
+
+// math.Min / math.Max with Go's special cases (Go src/math/dim.go)
+__device__ __forceinline__ double go_min(double x, double y) {
+    if ((isinf(x) && x < 0) || (isinf(y) && y < 0)) return -INFINITY;
+    if (isnan(x) || isnan(y)) return NAN;
+    if (x == 0 && x == y) return signbit(x) ? x : y;
+    return x < y ? x : y;
+}
+__device__ __forceinline__ double go_max(double x, double y) {
+    if ((isinf(x) && x > 0) || (isinf(y) && y > 0)) return INFINITY;
+    if (isnan(x) || isnan(y)) return NAN;
+    if (x == 0 && x == y) return signbit(x) ? y : x;
+    return x > y ? x : y;
+}
+
+// uint(math.Ceil(d)) for the small non-negative values of the path
+__device__ __forceinline__ uint32_t go_uint_ceil(double d) {
+    double c = ceil(d);
+    if (!(c >= 0.0)) return 0;
+    if (c >= 4294967295.0) return 4294967295u;
+    return (uint32_t)c;
+}
+
+// getSpatialDampingSettings + nil branch (message_spatial.go:31-38,66-79)
+__device__ __forceinline__ uint32_t damping_interval(const DevGrid &g, uint32_t dist) {
+    for (uint32_t i = 0; i < g.n_damp; i++)
+        if (dist <= g.damp_dist[i]) return g.damp_iv[i];
+    return g.default_interval_ms;
+}
+
+__device__ __forceinline__ uint32_t lane_id() { return threadIdx.x & 63u; }
+
+// number of set bits below this lane
+__device__ __forceinline__ uint32_t mask_rank(uint64_t mask) {
+    return __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32),
+                                     __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
+}

@@ -1,0 +1,104 @@
+// chd_kernels.h — host-callable launchers of the gfx950 kernels.
+// Every launcher enqueues on `st` and returns immediately.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/chd_spatial.h"
+#include "chd_device.h"
+
+// ---- world state (all device pointers, SoA) ----
+struct WorldDev {
+    uint32_t N, S, capq;
+    // entities
+    uint32_t *chan_id;    // entity channel id
+    uint32_t *cell;       // cell index of the last merged position (Notify's "old")
+    uint32_t *member;     // cell whose entity map holds the entity
+    uint32_t *eflags;     // EF_*
+    uint32_t *sender;     // senderConnId of the entity's updates
+    uint32_t *hist;       // bit j: an update arrived at tick (hist_tick - j)
+    uint32_t *hist_tick;
+    // spatial (cell) channels' own update history
+    uint32_t *cell_hist, *cell_hist_tick, *cell_sender;
+    // cell index (rebuilt every tick)
+    uint32_t nblk;        // histogram blocks
+    uint32_t *blk_cnt;    // [ncell*nblk + 1] counts -> exclusive scan (cell-major)
+    uint32_t *ce_ent, *ce_chan, *ce_hist, *ce_sender;  // [N] sorted by cell
+    // subscribers
+    uint32_t *conn_id;    // [S]
+    uint32_t *sub_alive;  // [S]
+    uint32_t *sub_tick;   // [S] tick of the subscriber's last interest update
+    uint32_t *pair_cnt;   // [S]
+    uint32_t *pair_cell;  // [S*capq] cell index
+    uint32_t *pair_iv;    // [S*capq] FanOutIntervalMs
+    int64_t *pair_last;   // [S*capq] lastFanOutTime
+    uint32_t *pair_flags; // [S*capq] PF_*
+    // fan-out outputs
+    uint64_t *rec_ub;     // [S+1] upper bound per subscriber -> exclusive scan = rec offsets
+    uint32_t *rec_cnt;    // [S]
+    chd_fanout_rec *recs; uint64_t recs_cap;
+    chd_handover_rec *handovers; uint32_t handovers_cap;
+    uint32_t *unsub_sub, *unsub_cell; uint32_t unsub_cap;
+    uint32_t *newsub_sub, *newsub_cell, *newsub_iv; uint32_t newsub_cap;
+    int32_t *q_status;    // [S]
+    uint32_t *counters;   // CTR_COUNT
+};
+
+// ---- stateless ----
+void launch_get_channel_ids(hipStream_t st, DevGrid g, const double *x, const double *z,
+                            uint32_t n, uint32_t *out);
+void launch_notify_decide(hipStream_t st, DevGrid g, const double *ox, const double *oz,
+                          const double *nx, const double *nz, uint32_t n, uint32_t *src,
+                          uint32_t *dst, uint8_t *handover);
+void launch_regions(hipStream_t st, DevGrid g, double *min_x, double *min_z, double *max_x,
+                    double *max_z, uint32_t *channel_id, uint32_t *server_index);
+void launch_adjacent(hipStream_t st, DevGrid g, const uint32_t *ids, uint32_t n, uint32_t *out,
+                     uint32_t *counts);
+// mode 0: CreateChannels cells (spatial.go:399-424); mode 1: border subs (:481-590).
+// out[cap], *n_out (device), *err (device, set to 1 on GetChannelIdNoOffset error)
+void launch_server_cells(hipStream_t st, DevGrid g, uint32_t server_index, int mode,
+                         uint32_t *out, uint32_t cap, uint32_t *n_out, uint32_t *err);
+
+// ---- world ----
+void launch_spawn(hipStream_t st, DevGrid g, WorldDev w, uint32_t n, const uint32_t *idx,
+                  const uint32_t *chan_id, const double *x, const double *z,
+                  const uint32_t *flags, const uint32_t *sender, uint32_t cur_tick);
+void launch_despawn(hipStream_t st, WorldDev w, uint32_t n, const uint32_t *idx);
+void launch_set_flags(hipStream_t st, WorldDev w, uint32_t n, const uint32_t *idx,
+                      const uint32_t *flags);
+void launch_subs_add(hipStream_t st, WorldDev w, uint32_t n, const uint32_t *slot,
+                     const uint32_t *conn, int add);
+
+// K1: cell assign + handover detect (+ update history)
+void launch_ingest(hipStream_t st, DevGrid g, WorldDev w, uint32_t n, const uint32_t *idx,
+                   const double *x, const double *z, const uint32_t *sender, uint32_t cur_tick);
+void launch_cell_updates(hipStream_t st, DevGrid g, WorldDev w, uint32_t n,
+                         const uint32_t *chan, const uint32_t *sender, uint32_t cur_tick);
+// K2: cell index build
+void launch_index_build(hipStream_t st, DevGrid g, WorldDev w, uint32_t cur_tick);
+// K3/K4: AOI query (+ interest diff when stateful)
+struct AoiLimits {
+    uint32_t maxax;   // samples per lattice axis
+    uint32_t winmax;  // cells in the per-query table
+};
+void launch_aoi_stateless(hipStream_t st, DevGrid g, AoiLimits lim, const chd_aoi_query *q,
+                          uint32_t nq, const double *spot_x, const double *spot_z,
+                          const uint32_t *spot_dist, uint32_t stride, uint32_t *cells,
+                          uint32_t *dists, uint32_t *ivs, uint32_t *counts, int32_t *status);
+void launch_aoi_interest(hipStream_t st, DevGrid g, AoiLimits lim, WorldDev w,
+                         const chd_aoi_query *q, uint32_t nq, const uint32_t *q_sub,
+                         const double *spot_x, const double *spot_z, const uint32_t *spot_dist,
+                         int64_t now_ns, uint32_t cur_tick);
+size_t aoi_lds_bytes(AoiLimits lim, uint32_t capq);
+// compaction of the fixed-stride stateless output into CSR
+void launch_scan_u32(hipStream_t st, const uint32_t *in, uint32_t *out, uint32_t n);  // exclusive, out[n]=total
+void launch_scan_u32_inplace(hipStream_t st, uint32_t *data, uint32_t n);             // data[n] = total
+void launch_scan_u64_inplace(hipStream_t st, uint64_t *data, uint32_t n);
+void launch_csr_gather(hipStream_t st, uint32_t nq, uint32_t stride, const uint32_t *counts,
+                       const uint32_t *offsets, const uint32_t *cells, const uint32_t *dists,
+                       const uint32_t *ivs, uint32_t *out_ids, uint32_t *out_dists,
+                       uint32_t *out_ivs, uint32_t cap, uint32_t id_start);
+// K5: fan-out
+void launch_fanout_plan(hipStream_t st, DevGrid g, WorldDev w, int64_t now_ns, TickRing ring);
+void launch_fanout_emit(hipStream_t st, DevGrid g, WorldDev w, int64_t now_ns, TickRing ring);

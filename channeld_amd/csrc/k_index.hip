@@ -1,0 +1,207 @@
+// k_index.hip — K2: the cell -> entity index, i.e. the per-cell entity maps
+// the reference keeps in SpatialChannelData.Entities
+// (pkg/unrealpb/extension.go:32-86), rebuilt every tick as a stable counting
+// sort of the entity slots by member cell:
+//
+//   k_index_hist   : per-block histogram of member cells in LDS (one LDS
+//                    atomic per entity), written cell-major to blk_cnt[c*nblk+b]
+//   scan           : exclusive scan of blk_cnt (cell-major), so that
+//                    blk_cnt[c*nblk+b] = cell_off[c] + (entities of c in blocks < b)
+//                    and blk_cnt[c*nblk] = cell_off[c]
+//   k_index_scatter: stable scatter — ranks inside a block come from wave
+//                    ballots (peer masks by key bits), never from atomics, so the
+//                    per-cell order is by entity slot and the output is
+//                    deterministic.  Writes the SoA the emit kernel streams:
+//                    ce_chan (entity channel id), ce_hist (update history
+//                    aligned to this tick), ce_sender, ce_ent.
+//
+// Also here: the generic exclusive scans (single workgroup, 1024 lanes,
+// wave-shuffle scan + LDS carry).
+#include "chd_kernels.h"
+
+#define IDX_BLOCK 256
+#define IDX_ITEMS 4
+#define IDX_TILE (IDX_BLOCK * IDX_ITEMS)
+#define IDX_MAX_LDS_CELLS 4096  // 4 waves x 4096 x 4 B = 64 KiB of dynamic LDS
+
+uint32_t index_num_blocks(uint32_t N) { return (N + IDX_TILE - 1) / IDX_TILE; }
+
+__global__ void __launch_bounds__(IDX_BLOCK) k_index_hist(WorldDev w, uint32_t ncell) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    uint32_t *h = (uint32_t *)smem;
+    for (uint32_t c = threadIdx.x; c < ncell; c += IDX_BLOCK) h[c] = 0;
+    __syncthreads();
+    uint32_t base = blockIdx.x * IDX_TILE;
+#pragma unroll
+    for (int r = 0; r < IDX_ITEMS; r++) {
+        // wave w handles the contiguous chunk [base + w*256 + r*64, +64)
+        uint32_t i = base + (threadIdx.x >> 6) * (IDX_ITEMS * 64) + r * 64 + (threadIdx.x & 63);
+        if (i < w.N) {
+            uint32_t m = (w.eflags[i] & EF_ALIVE) ? w.member[i] : CHD_INVALID;
+            if (m < ncell) atomicAdd(&h[m], 1u);
+        }
+    }
+    __syncthreads();
+    for (uint32_t c = threadIdx.x; c < ncell; c += IDX_BLOCK) w.blk_cnt[(size_t)c * w.nblk + blockIdx.x] = h[c];
+}
+
+__global__ void __launch_bounds__(IDX_BLOCK) k_index_scatter(WorldDev w, uint32_t ncell, uint32_t key_bits,
+                                                             uint32_t cur_tick) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    uint32_t *wcnt = (uint32_t *)smem;  // [4][ncell] running per-wave counters
+    const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    for (uint32_t c = threadIdx.x; c < 4 * ncell; c += IDX_BLOCK) wcnt[c] = 0;
+    __syncthreads();
+    uint32_t *mycnt = wcnt + wave * ncell;
+    uint32_t base = blockIdx.x * IDX_TILE + wave * (IDX_ITEMS * 64);
+    uint32_t key[IDX_ITEMS], lrank[IDX_ITEMS];
+#pragma unroll
+    for (int r = 0; r < IDX_ITEMS; r++) {
+        uint32_t i = base + r * 64 + lane;
+        uint32_t m = CHD_INVALID;
+        if (i < w.N && (w.eflags[i] & EF_ALIVE)) m = w.member[i];
+        bool valid = m < ncell;
+        key[r] = valid ? m : CHD_INVALID;
+        // peers = lanes of this wave holding the same key
+        uint64_t peers = __ballot(valid);
+        for (uint32_t b = 0; b < key_bits; b++) {
+            uint64_t bm = __ballot(valid && ((m >> b) & 1u));
+            peers &= ((m >> b) & 1u) ? bm : ~bm;
+        }
+        uint32_t pre = 0;
+        if (valid) {
+            uint32_t rk = mask_rank(peers);
+            int leader = __ffsll((unsigned long long)peers) - 1;
+            if ((int)lane == leader) {
+                pre = mycnt[m];
+                mycnt[m] = pre + (uint32_t)__popcll(peers);
+            }
+            pre = __shfl(pre, leader);
+            lrank[r] = pre + rk;
+        } else {
+            lrank[r] = 0;
+        }
+    }
+    __syncthreads();
+    // exclusive prefix over the 4 waves, in place: wcnt[w][c] -> entities of c in waves < w
+    for (uint32_t c = threadIdx.x; c < ncell; c += IDX_BLOCK) {
+        uint32_t a0 = wcnt[c], a1 = wcnt[ncell + c], a2 = wcnt[2 * ncell + c];
+        uint32_t g0 = w.blk_cnt[(size_t)c * w.nblk + blockIdx.x];  // scanned: global base of this block for c
+        wcnt[c] = g0;
+        wcnt[ncell + c] = g0 + a0;
+        wcnt[2 * ncell + c] = g0 + a0 + a1;
+        wcnt[3 * ncell + c] = g0 + a0 + a1 + a2;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < IDX_ITEMS; r++) {
+        if (key[r] == CHD_INVALID) continue;
+        uint32_t i = base + r * 64 + lane;
+        uint32_t pos = mycnt[key[r]] + lrank[r];
+        uint32_t age = cur_tick - w.hist_tick[i];
+        uint32_t h = (age >= CHD_HIST_BITS) ? 0u : (w.hist[i] << age);
+        w.ce_ent[pos] = i;
+        w.ce_chan[pos] = w.chan_id[i];
+        w.ce_hist[pos] = h;
+        w.ce_sender[pos] = w.sender[i];
+    }
+}
+
+// fallback for grids too large for the LDS counters: global atomics, the order
+// inside a cell is then not deterministic (documented in DESIGN.md).
+__global__ void __launch_bounds__(256) k_index_hist_global(WorldDev w, uint32_t ncell) {
+    uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    if (i >= w.N) return;
+    if (!(w.eflags[i] & EF_ALIVE)) return;
+    uint32_t m = w.member[i];
+    if (m < ncell) atomicAdd(&w.blk_cnt[m], 1u);
+}
+
+__global__ void __launch_bounds__(256) k_index_scatter_global(WorldDev w, uint32_t ncell, uint32_t *cursor,
+                                                              uint32_t cur_tick) {
+    uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    if (i >= w.N) return;
+    if (!(w.eflags[i] & EF_ALIVE)) return;
+    uint32_t m = w.member[i];
+    if (m >= ncell) return;
+    uint32_t pos = w.blk_cnt[m] + atomicAdd(&cursor[m], 1u);
+    uint32_t age = cur_tick - w.hist_tick[i];
+    uint32_t h = (age >= CHD_HIST_BITS) ? 0u : (w.hist[i] << age);
+    w.ce_ent[pos] = i;
+    w.ce_chan[pos] = w.chan_id[i];
+    w.ce_hist[pos] = h;
+    w.ce_sender[pos] = w.sender[i];
+}
+
+// ------------------------------------------------------------------------
+// exclusive scans: one workgroup of 1024 lanes walks the array in 1024-element
+// tiles; in-wave inclusive scan by DPP-style shuffles, 16 wave totals combined
+// through LDS.  out[n] receives the grand total.
+// ------------------------------------------------------------------------
+template <typename T>
+__device__ __forceinline__ T wave_incl_scan(T v) {
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        T o = __shfl_up(v, d);
+        if ((int)(threadIdx.x & 63) >= d) v += o;
+    }
+    return v;
+}
+
+template <typename T>
+__global__ void __launch_bounds__(1024) k_scan_excl(const T *in, T *out, uint32_t n) {
+    __shared__ T wtot[16];
+    __shared__ T carry_s;
+    const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (threadIdx.x == 0) carry_s = 0;
+    __syncthreads();
+    for (uint32_t base = 0; base < n; base += 1024) {
+        uint32_t i = base + threadIdx.x;
+        T v = (i < n) ? in[i] : (T)0;
+        T inc = wave_incl_scan(v);
+        if (lane == 63) wtot[wave] = inc;
+        __syncthreads();
+        T carry = carry_s;
+        T woff = 0;
+        for (uint32_t k = 0; k < wave; k++) woff += wtot[k];
+        if (i < n) out[i] = carry + woff + inc - v;
+        __syncthreads();
+        if (threadIdx.x == 1023) carry_s = carry + woff + inc;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) out[n] = carry_s;
+}
+
+void launch_scan_u32(hipStream_t st, const uint32_t *in, uint32_t *out, uint32_t n) {
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_scan_excl<uint32_t>), dim3(1), dim3(1024), 0, st, in, out, n);
+}
+void launch_scan_u32_inplace(hipStream_t st, uint32_t *data, uint32_t n) {
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_scan_excl<uint32_t>), dim3(1), dim3(1024), 0, st, data, data, n);
+}
+void launch_scan_u64_inplace(hipStream_t st, uint64_t *data, uint32_t n) {
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_scan_excl<uint64_t>), dim3(1), dim3(1024), 0, st, data, data, n);
+}
+
+static uint32_t bits_for(uint32_t ncell) {
+    uint32_t b = 0;
+    while ((1u << b) < ncell) b++;
+    return b ? b : 1;
+}
+
+void launch_index_build(hipStream_t st, DevGrid g, WorldDev w, uint32_t cur_tick) {
+    if (!w.N) return;
+    if (g.ncell <= IDX_MAX_LDS_CELLS) {
+        hipLaunchKernelGGL(k_index_hist, dim3(w.nblk), dim3(IDX_BLOCK), g.ncell * 4, st, w, g.ncell);
+        launch_scan_u32_inplace(st, w.blk_cnt, g.ncell * w.nblk);
+        hipLaunchKernelGGL(k_index_scatter, dim3(w.nblk), dim3(IDX_BLOCK), 4 * g.ncell * 4, st, w, g.ncell,
+                           bits_for(g.ncell), cur_tick);
+    } else {
+        // nblk == 1 layout: blk_cnt[c] then scan -> cell_off; cursor lives behind it
+        uint32_t *cursor = w.blk_cnt + (size_t)g.ncell + 1;
+        (void)hipMemsetAsync(w.blk_cnt, 0, sizeof(uint32_t) * (2 * (size_t)g.ncell + 2), st);
+        hipLaunchKernelGGL(k_index_hist_global, dim3((w.N + 255) / 256), dim3(256), 0, st, w, g.ncell);
+        launch_scan_u32_inplace(st, w.blk_cnt, g.ncell);
+        hipLaunchKernelGGL(k_index_scatter_global, dim3((w.N + 255) / 256), dim3(256), 0, st, w, g.ncell, cursor,
+                           cur_tick);
+    }
+}

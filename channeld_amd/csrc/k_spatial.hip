@@ -1,0 +1,344 @@
+// k_spatial.hip — cell assignment, handover detection, regions, adjacency.
+//
+// Replaces (reference file:line): GetChannelIdWithOffset spatial.go:169-180,
+// the decision part of Notify spatial.go:612-626 + lock abort :675-679 +
+// entity-map move :703-736, GetRegions :319-356, GetAdjacentChannels :358-381,
+// CreateChannels cell ownership :399-424, subToAdjacentChannels :481-590.
+//
+// All kernels are HBM-streaming (one thread per point, SoA f64 loads, coalesced
+// 4-byte stores); handover records are compacted per wave with ballot +
+// mbcnt and one atomic per wave.
+#include "chd_kernels.h"
+
+static inline unsigned nblocks(uint64_t n, unsigned bs) { return (unsigned)((n + bs - 1) / bs); }
+
+__global__ void __launch_bounds__(256) k_get_channel_ids(DevGrid g, const double *__restrict__ x,
+                                                         const double *__restrict__ z, uint32_t n,
+                                                         uint32_t *__restrict__ out) {
+    uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    if (i >= n) return;
+    uint32_t c = cell_of(g, x[i], z[i]);
+    out[i] = (c == CHD_INVALID) ? 0u : c + g.id_start;
+}
+
+void launch_get_channel_ids(hipStream_t st, DevGrid g, const double *x, const double *z,
+                            uint32_t n, uint32_t *out) {
+    if (!n) return;
+    hipLaunchKernelGGL(k_get_channel_ids, dim3(nblocks(n, 256)), dim3(256), 0, st, g, x, z, n, out);
+}
+
+__global__ void __launch_bounds__(256) k_notify_decide(DevGrid g, const double *__restrict__ ox,
+                                                       const double *__restrict__ oz,
+                                                       const double *__restrict__ nx,
+                                                       const double *__restrict__ nz, uint32_t n,
+                                                       uint32_t *__restrict__ src,
+                                                       uint32_t *__restrict__ dst,
+                                                       uint8_t *__restrict__ handover) {
+    uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    if (i >= n) return;
+    // spatial.go:613-626: src error returns before dst is computed
+    uint32_t s = cell_of(g, ox[i], oz[i]);
+    uint32_t d = CHD_INVALID;
+    if (s != CHD_INVALID) d = cell_of(g, nx[i], nz[i]);
+    src[i] = (s == CHD_INVALID) ? 0u : s + g.id_start;
+    dst[i] = (d == CHD_INVALID) ? 0u : d + g.id_start;
+    handover[i] = (s != CHD_INVALID && d != CHD_INVALID && s != d) ? 1 : 0;
+}
+
+void launch_notify_decide(hipStream_t st, DevGrid g, const double *ox, const double *oz,
+                          const double *nx, const double *nz, uint32_t n, uint32_t *src,
+                          uint32_t *dst, uint8_t *handover) {
+    if (!n) return;
+    hipLaunchKernelGGL(k_notify_decide, dim3(nblocks(n, 256)), dim3(256), 0, st, g, ox, oz, nx, nz, n,
+                       src, dst, handover);
+}
+
+__global__ void __launch_bounds__(256) k_regions(DevGrid g, double *min_x, double *min_z,
+                                                 double *max_x, double *max_z,
+                                                 uint32_t *channel_id, uint32_t *server_index) {
+    uint32_t index = blockIdx.x * 256u + threadIdx.x;
+    if (index >= g.ncell) return;
+    uint32_t x = index % g.cols, y = index / g.cols;
+    // spatial.go:340-350
+    min_x[index] = g.offx + g.gw * (double)x;
+    min_z[index] = g.offz + g.gh * (double)y;
+    max_x[index] = g.offx + g.gw * (double)(x + 1);
+    max_z[index] = g.offz + g.gh * (double)(y + 1);
+    channel_id[index] = g.id_start + index;
+    server_index[index] = x / g.sgc + (y / g.sgr) * g.server_cols;
+}
+
+void launch_regions(hipStream_t st, DevGrid g, double *min_x, double *min_z, double *max_x,
+                    double *max_z, uint32_t *channel_id, uint32_t *server_index) {
+    hipLaunchKernelGGL(k_regions, dim3(nblocks(g.ncell, 256)), dim3(256), 0, st, g, min_x, min_z,
+                       max_x, max_z, channel_id, server_index);
+}
+
+__global__ void __launch_bounds__(256) k_adjacent(DevGrid g, const uint32_t *__restrict__ ids,
+                                                  uint32_t n, uint32_t *__restrict__ out,
+                                                  uint32_t *__restrict__ counts) {
+    uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    if (i >= n) return;
+    uint32_t index = ids[i] - g.id_start;
+    int32_t gx = (int32_t)(index % g.cols), gy = (int32_t)(index / g.cols);
+    uint32_t k = 0;
+    for (int32_t y = gy - 1; y <= gy + 1; y++) {
+        if (y < 0 || y > (int32_t)(g.rows - 1)) continue;
+        for (int32_t x = gx - 1; x <= gx + 1; x++) {
+            if (x < 0 || x > (int32_t)(g.cols - 1)) continue;
+            if (x == gx && y == gy) continue;
+            out[8u * i + k++] = (uint32_t)x + (uint32_t)y * g.cols + g.id_start;
+        }
+    }
+    counts[i] = k;
+}
+
+void launch_adjacent(hipStream_t st, DevGrid g, const uint32_t *ids, uint32_t n, uint32_t *out,
+                     uint32_t *counts) {
+    if (!n) return;
+    hipLaunchKernelGGL(k_adjacent, dim3(nblocks(n, 256)), dim3(256), 0, st, g, ids, n, out, counts);
+}
+
+// GetChannelIdNoOffset (spatial.go:165-167)
+__device__ __forceinline__ uint32_t cell_no_offset(const DevGrid &g, double x, double z) {
+    uint32_t gx, gy;
+    if (!grid_coord((x - 0.0) / g.gw, g.cols, gx)) return CHD_INVALID;
+    if (!grid_coord((z - 0.0) / g.gh, g.rows, gy)) return CHD_INVALID;
+    return gx + gy * g.cols;
+}
+
+// One thread: the reference's nested loops in their own order (control plane,
+// a few dozen cells; kept on the device so that no grid arithmetic lives on the host).
+__global__ void k_server_cells(DevGrid g, uint32_t server_index, int mode, uint32_t *out,
+                               uint32_t cap, uint32_t *n_out, uint32_t *err) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    uint32_t sx = server_index % g.server_cols, sy = server_index / g.server_cols;
+    uint32_t n = 0;
+    *err = 0;
+#define ADD(px, pz)                                   \
+    do {                                              \
+        uint32_t _c = cell_no_offset(g, (px), (pz));  \
+        if (_c == CHD_INVALID) { *err = 1; *n_out = 0; return; } \
+        if (n >= cap) { *err = 2; *n_out = 0; return; }          \
+        out[n++] = _c + g.id_start;                   \
+    } while (0)
+    if (mode == 0) {  // spatial.go:410-424
+        for (uint32_t y = 0; y < g.sgr; y++)
+            for (uint32_t x = 0; x < g.sgc; x++)
+                ADD((double)(sx * g.sgc + x) * g.gw, (double)(sy * g.sgr + y) * g.gh);
+    } else if (g.border != 0) {  // spatial.go:481-590
+        if (cell_no_offset(g, (double)(sx * g.sgc) * g.gw, (double)(sy * g.sgr) * g.gh) == CHD_INVALID) {
+            *err = 1; *n_out = 0; return;
+        }
+        if (sx > 0)
+            for (uint32_t y = 0; y < g.sgr; y++)
+                for (uint32_t x = 1; x <= g.border; x++)
+                    ADD((double)(sx * g.sgc - x) * g.gw, (double)(sy * g.sgr + y) * g.gh);
+        if (sx < g.server_cols - 1)
+            for (uint32_t y = 0; y < g.sgr; y++)
+                for (uint32_t x = 0; x < g.border; x++)
+                    ADD((double)((sx + 1) * g.sgc + x) * g.gw, (double)(sy * g.sgr + y) * g.gh);
+        if (sy > 0)
+            for (uint32_t y = 1; y <= g.border; y++)
+                for (uint32_t x = 0; x < g.sgc; x++)
+                    ADD((double)(sx * g.sgc + x) * g.gw, (double)(sy * g.sgr - y) * g.gh);
+        if (sy < g.server_rows - 1)
+            for (uint32_t y = 0; y < g.border; y++)
+                for (uint32_t x = 0; x < g.sgc; x++)
+                    ADD((double)(sx * g.sgc + x) * g.gw, (double)((sy + 1) * g.sgr + y) * g.gh);
+    }
+#undef ADD
+    *n_out = n;
+}
+
+void launch_server_cells(hipStream_t st, DevGrid g, uint32_t server_index, int mode,
+                         uint32_t *out, uint32_t cap, uint32_t *n_out, uint32_t *err) {
+    hipLaunchKernelGGL(k_server_cells, dim3(1), dim3(64), 0, st, g, server_index, mode, out, cap, n_out, err);
+}
+
+// ------------------------------------------------------------------------
+// world: spawn / despawn / subscribers
+// ------------------------------------------------------------------------
+
+__global__ void __launch_bounds__(256) k_spawn(DevGrid g, WorldDev w, uint32_t n,
+                                               const uint32_t *__restrict__ idx,
+                                               const uint32_t *__restrict__ chan_id,
+                                               const double *__restrict__ x,
+                                               const double *__restrict__ z,
+                                               const uint32_t *__restrict__ flags,
+                                               const uint32_t *__restrict__ sender,
+                                               uint32_t cur_tick) {
+    uint32_t u = blockIdx.x * 256u + threadIdx.x;
+    if (u >= n) return;
+    uint32_t i = idx ? idx[u] : u;
+    if (i >= w.N) return;
+    uint32_t c = cell_of(g, x[u], z[u]);
+    w.chan_id[i] = chan_id[u];
+    w.cell[i] = c;
+    w.member[i] = c;
+    w.eflags[i] = (flags ? (flags[u] & ~EF_ALIVE) : 0u) | EF_ALIVE;
+    w.sender[i] = sender ? sender[u] : 0u;
+    w.hist[i] = 0;
+    w.hist_tick[i] = cur_tick;
+}
+
+void launch_spawn(hipStream_t st, DevGrid g, WorldDev w, uint32_t n, const uint32_t *idx,
+                  const uint32_t *chan_id, const double *x, const double *z,
+                  const uint32_t *flags, const uint32_t *sender, uint32_t cur_tick) {
+    if (!n) return;
+    hipLaunchKernelGGL(k_spawn, dim3(nblocks(n, 256)), dim3(256), 0, st, g, w, n, idx, chan_id, x, z,
+                       flags, sender, cur_tick);
+}
+
+__global__ void __launch_bounds__(256) k_despawn(WorldDev w, uint32_t n, const uint32_t *idx) {
+    uint32_t u = blockIdx.x * 256u + threadIdx.x;
+    if (u >= n) return;
+    uint32_t i = idx ? idx[u] : u;
+    if (i >= w.N) return;
+    w.eflags[i] = 0;
+    w.member[i] = CHD_INVALID;
+    w.cell[i] = CHD_INVALID;
+}
+
+void launch_despawn(hipStream_t st, WorldDev w, uint32_t n, const uint32_t *idx) {
+    if (!n) return;
+    hipLaunchKernelGGL(k_despawn, dim3(nblocks(n, 256)), dim3(256), 0, st, w, n, idx);
+}
+
+__global__ void __launch_bounds__(256) k_set_flags(WorldDev w, uint32_t n, const uint32_t *idx,
+                                                   const uint32_t *flags) {
+    uint32_t u = blockIdx.x * 256u + threadIdx.x;
+    if (u >= n) return;
+    uint32_t i = idx ? idx[u] : u;
+    if (i >= w.N) return;
+    uint32_t alive = w.eflags[i] & EF_ALIVE;
+    w.eflags[i] = (flags[u] & ~EF_ALIVE) | alive;
+}
+
+void launch_set_flags(hipStream_t st, WorldDev w, uint32_t n, const uint32_t *idx,
+                      const uint32_t *flags) {
+    if (!n) return;
+    hipLaunchKernelGGL(k_set_flags, dim3(nblocks(n, 256)), dim3(256), 0, st, w, n, idx, flags);
+}
+
+__global__ void __launch_bounds__(256) k_subs_add(WorldDev w, uint32_t n, const uint32_t *slot,
+                                                  const uint32_t *conn, int add) {
+    uint32_t u = blockIdx.x * 256u + threadIdx.x;
+    if (u >= n) return;
+    uint32_t s = slot ? slot[u] : u;
+    if (s >= w.S) return;
+    w.sub_alive[s] = add ? 1u : 0u;
+    w.conn_id[s] = add ? conn[u] : 0u;
+    w.pair_cnt[s] = 0;
+}
+
+void launch_subs_add(hipStream_t st, WorldDev w, uint32_t n, const uint32_t *slot,
+                     const uint32_t *conn, int add) {
+    if (!n) return;
+    hipLaunchKernelGGL(k_subs_add, dim3(nblocks(n, 256)), dim3(256), 0, st, w, n, slot, conn, add);
+}
+
+// ------------------------------------------------------------------------
+// K1: ingest one batch of entity position updates.
+//   src = cell of the last merged position (== GetChannelId(oldInfo), kept as
+//         the 4-byte cell index instead of re-reading 16 bytes of old position)
+//   dst = GetChannelId(newInfo)
+//   either invalid -> no handover (spatial.go:613-622); equal -> nothing (:624);
+//   locked -> abort (entity.go:197-224, spatial.go:675-679);
+//   else record {entity, src, dst, servers} and move the entity to dst's
+//   entity map (spatial.go:703-736).
+// Every update also enters the entity channel's update history
+// (ChannelData.OnUpdate, data.go:159-164) as bit 0 of a 32-tick bitmask.
+// Traffic per update: 16 B (x,z) + 4 B cell R + 4 B cell W + 8 B history R/W
+// + 4 B flags; handover records are rare (1-2 %).
+// ------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_ingest(DevGrid g, WorldDev w, uint32_t n,
+                                                const uint32_t *__restrict__ idx,
+                                                const double *__restrict__ x,
+                                                const double *__restrict__ z,
+                                                const uint32_t *__restrict__ sender,
+                                                uint32_t cur_tick) {
+    uint32_t u = blockIdx.x * 256u + threadIdx.x;
+    bool ho = false, locked = false;
+    uint32_t i = 0, src = CHD_INVALID, dst = CHD_INVALID;
+    if (u < n) {
+        i = idx ? idx[u] : u;
+        uint32_t ef = (i < w.N) ? w.eflags[i] : 0u;
+        if (ef & EF_ALIVE) {
+            dst = cell_of(g, x[u], z[u]);
+            src = w.cell[i];
+            w.cell[i] = dst;
+            uint32_t age = cur_tick - w.hist_tick[i];
+            uint32_t h = (age >= CHD_HIST_BITS) ? 0u : (w.hist[i] << age);
+            w.hist[i] = h | 1u;
+            w.hist_tick[i] = cur_tick;
+            if (sender) w.sender[i] = sender[u];
+            if (src != CHD_INVALID && dst != CHD_INVALID && src != dst) {
+                if (ef & EF_LOCKED) locked = true;
+                else ho = true;
+            }
+        }
+    }
+    uint64_t lm = __ballot(locked);
+    uint64_t hm = __ballot(ho);
+    if (lm && lane_id() == 0) atomicAdd(&w.counters[CTR_LOCKED], (uint32_t)__popcll(lm));
+    if (hm) {
+        uint32_t base = 0;
+        if (lane_id() == 0) base = atomicAdd(&w.counters[CTR_HANDOVERS], (uint32_t)__popcll(hm));
+        base = __shfl(base, 0);
+        if (ho) {
+            w.member[i] = dst;
+            uint32_t pos = base + mask_rank(hm);
+            if (pos < w.handovers_cap) {
+                chd_handover_rec r;
+                r.entity = i;
+                r.channel = w.chan_id[i];
+                r.src = src + g.id_start;
+                r.dst = dst + g.id_start;
+                r.src_server = server_of(g, src);
+                r.dst_server = server_of(g, dst);
+                w.handovers[pos] = r;
+            } else {
+                atomicOr(&w.counters[CTR_OVERFLOW], OVF_HANDOVER);
+            }
+        }
+    }
+}
+
+void launch_ingest(hipStream_t st, DevGrid g, WorldDev w, uint32_t n, const uint32_t *idx,
+                   const double *x, const double *z, const uint32_t *sender, uint32_t cur_tick) {
+    if (!n) return;
+    hipLaunchKernelGGL(k_ingest, dim3(nblocks(n, 256)), dim3(256), 0, st, g, w, n, idx, x, z, sender,
+                       cur_tick);
+}
+
+// spatial-channel data updates (spawn/destroy merges through OnUpdate)
+__global__ void __launch_bounds__(256) k_cell_updates(DevGrid g, WorldDev w, uint32_t n,
+                                                      const uint32_t *__restrict__ chan,
+                                                      const uint32_t *__restrict__ sender,
+                                                      uint32_t cur_tick) {
+    uint32_t u = blockIdx.x * 256u + threadIdx.x;
+    if (u >= n) return;
+    uint32_t c = chan[u] - g.id_start;
+    if (c >= g.ncell) return;
+    // several updates of one cell in a batch: all carry the same stamp, so the
+    // history bit is idempotent; the last sender wins like the entity path.
+    uint32_t age = cur_tick - w.cell_hist_tick[c];
+    if (age != 0) {
+        uint32_t h = (age >= CHD_HIST_BITS) ? 0u : (w.cell_hist[c] << age);
+        w.cell_hist[c] = h | 1u;
+        w.cell_hist_tick[c] = cur_tick;
+    } else {
+        w.cell_hist[c] |= 1u;
+    }
+    w.cell_sender[c] = sender[u];
+}
+
+void launch_cell_updates(hipStream_t st, DevGrid g, WorldDev w, uint32_t n, const uint32_t *chan,
+                         const uint32_t *sender, uint32_t cur_tick) {
+    if (!n) return;
+    // one block, sequential per cell semantics are idempotent; duplicates of a cell
+    // in one batch race only on identical values except cell_sender (last wins).
+    hipLaunchKernelGGL(k_cell_updates, dim3(nblocks(n, 256)), dim3(256), 0, st, g, w, n, chan, sender,
+                       cur_tick);
+}

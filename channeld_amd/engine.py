@@ -1,0 +1,235 @@
+"""SpatialWorld — the batched tick of the SpatialChannel hot path on one MI355X.
+
+One `tick()` replaces, for the whole world: Notify on every updated entity
+(spatial.go:612-736), handleUpdateSpatialInterest for every connection that sent
+UPDATE_SPATIAL_INTEREST (message_spatial.go:41-129) and Channel.tickData on every
+spatial and entity channel (data.go:175-318).  See include/chd_spatial.h.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from dataclasses import dataclass
+from typing import Optional, Sequence
+
+import numpy as np
+
+from . import _lib
+from ._lib import AoiQuery, FanoutRec, HandoverRec, TickIn, TickOut, TickStats, WorldCfg
+from .controller import StaticGrid2DSpatialController, SpatialInterestQuery, pack_queries, _f64, _ptr, _u32
+
+REC_DTYPE = np.dtype([("conn", np.uint32), ("channel", np.uint32)])
+HANDOVER_DTYPE = np.dtype([("entity", np.uint32), ("channel", np.uint32), ("src", np.uint32), ("dst", np.uint32),
+                           ("src_server", np.uint32), ("dst_server", np.uint32)])
+assert REC_DTYPE.itemsize == C.sizeof(FanoutRec) and HANDOVER_DTYPE.itemsize == C.sizeof(HandoverRec)
+
+
+@dataclass
+class TickResult:
+    handovers: np.ndarray          # HANDOVER_DTYPE
+    n_locked_aborts: int
+    query_status: np.ndarray       # int32 per query
+    unsub_sub: np.ndarray          # subscriber slots
+    unsub_channel: np.ndarray      # spatial channel ids
+    newsub_sub: np.ndarray
+    newsub_channel: np.ndarray
+    newsub_interval_ms: np.ndarray
+    records: Optional[np.ndarray]  # REC_DTYPE, grouped per connection slot
+    conn_rec_off: np.ndarray       # uint64[S+1]
+    conn_rec_cnt: np.ndarray       # uint32[S]
+    n_records: int
+    overflow: int
+    history_overflow: int
+
+    def records_of(self, slot: int) -> np.ndarray:
+        a = int(self.conn_rec_off[slot])
+        return self.records[a: a + int(self.conn_rec_cnt[slot])]
+
+
+class DeviceArray:
+    """A device buffer owned by the library's context (inputs kept resident in HBM)."""
+
+    def __init__(self, world: "SpatialWorld", nbytes: int):
+        self.world = world
+        self.nbytes = nbytes
+        p = C.c_void_p(None)
+        _lib.check(world.ctx, world.lib.chd_dev_alloc(world.ctx, nbytes, C.byref(p)))
+        self.ptr = p
+
+    def upload(self, host: np.ndarray, offset: int = 0):
+        host = np.ascontiguousarray(host)
+        assert offset + host.nbytes <= self.nbytes
+        _lib.check(self.world.ctx, self.world.lib.chd_dev_upload(
+            self.world.ctx, C.c_void_p(self.ptr.value + offset), host.ctypes.data_as(C.c_void_p), host.nbytes))
+
+    def at(self, byte_offset: int) -> C.c_void_p:
+        return C.c_void_p(self.ptr.value + byte_offset)
+
+    def free(self):
+        if self.ptr:
+            self.world.lib.chd_dev_free(self.world.ctx, self.ptr)
+            self.ptr = C.c_void_p(None)
+
+
+class SpatialWorld:
+    def __init__(self, ctl: StaticGrid2DSpatialController, max_entities: int, max_subscribers: int,
+                 max_interest_cells: int = 0, max_records: int = 0, max_handovers: int = 0):
+        self.ctl = ctl
+        self.lib = _lib.load()
+        self.ctx = ctl.ctx
+        self.N, self.S = int(max_entities), int(max_subscribers)
+        ncell = ctl.GridCols * ctl.GridRows
+        self.capq = int(max_interest_cells) if max_interest_cells else min(ncell, 256)
+        cfg = WorldCfg(self.N, self.S, self.capq, int(max_records), int(max_handovers))
+        _lib.check(self.ctx, self.lib.chd_world_create(self.ctx, C.byref(cfg)))
+
+    # ---- population ----
+    def spawn(self, idx, chan_id, x, z, flags=None, sender=None):
+        idx_a = None if idx is None else _u32(idx)
+        ch, xa, za = _u32(chan_id), _f64(x), _f64(z)
+        fl = None if flags is None else _u32(flags)
+        sn = None if sender is None else _u32(sender)
+        _lib.check(self.ctx, self.lib.chd_world_spawn(self.ctx, len(ch), _ptr(idx_a), _ptr(ch), _ptr(xa), _ptr(za),
+                                                      _ptr(fl), _ptr(sn)))
+
+    def despawn(self, idx):
+        a = _u32(idx)
+        _lib.check(self.ctx, self.lib.chd_world_despawn(self.ctx, len(a), _ptr(a)))
+
+    def set_entity_flags(self, idx, flags):
+        a, f = _u32(idx), _u32(flags)
+        _lib.check(self.ctx, self.lib.chd_world_set_entity_flags(self.ctx, len(a), _ptr(a), _ptr(f)))
+
+    def add_subscribers(self, slots, conn_ids):
+        s = None if slots is None else _u32(slots)
+        c = _u32(conn_ids)
+        _lib.check(self.ctx, self.lib.chd_subs_add(self.ctx, len(c), _ptr(s), _ptr(c)))
+
+    def remove_subscribers(self, slots):
+        s = _u32(slots)
+        _lib.check(self.ctx, self.lib.chd_subs_remove(self.ctx, len(s), _ptr(s)))
+
+    # ---- tick ----
+    def _alloc_out(self, n_queries: int, want_records: bool, records_cap: int):
+        o = TickOut()
+        self._o_ho = np.zeros(max(self.N, 1), dtype=HANDOVER_DTYPE)
+        o.handovers = self._o_ho.ctypes.data_as(C.c_void_p)
+        o.handovers_cap = len(self._o_ho)
+        self._o_qs = np.zeros(max(n_queries, 1), dtype=np.int32)
+        o.query_status = _ptr(self._o_qs)
+        ucap = max(self.S * self.capq, 1)
+        self._o_us, self._o_uc = np.zeros(ucap, dtype=np.uint32), np.zeros(ucap, dtype=np.uint32)
+        o.unsub_sub, o.unsub_channel, o.unsub_cap = _ptr(self._o_us), _ptr(self._o_uc), ucap
+        self._o_ns, self._o_nc, self._o_ni = (np.zeros(ucap, dtype=np.uint32) for _ in range(3))
+        o.newsub_sub, o.newsub_channel, o.newsub_interval_ms, o.newsub_cap = _ptr(self._o_ns), _ptr(self._o_nc), _ptr(self._o_ni), ucap
+        self._o_off = np.zeros(self.S + 1, dtype=np.uint64)
+        self._o_cnt = np.zeros(self.S, dtype=np.uint32)
+        o.conn_rec_off, o.conn_rec_cnt = _ptr(self._o_off), _ptr(self._o_cnt)
+        if want_records:
+            self._o_rec = np.zeros(max(records_cap, 1), dtype=REC_DTYPE)
+            o.records = self._o_rec.ctypes.data_as(C.c_void_p)
+            o.records_cap = len(self._o_rec)
+        else:
+            self._o_rec = None
+        return o
+
+    def _result(self, o: TickOut, n_queries: int) -> TickResult:
+        return TickResult(
+            handovers=self._o_ho[: o.n_handovers].copy(), n_locked_aborts=int(o.n_locked_aborts),
+            query_status=self._o_qs[:n_queries].copy(),
+            unsub_sub=self._o_us[: o.n_unsubs].copy(), unsub_channel=self._o_uc[: o.n_unsubs].copy(),
+            newsub_sub=self._o_ns[: o.n_newsubs].copy(), newsub_channel=self._o_nc[: o.n_newsubs].copy(),
+            newsub_interval_ms=self._o_ni[: o.n_newsubs].copy(),
+            records=None if self._o_rec is None else self._o_rec[: int(o.n_records)],
+            conn_rec_off=self._o_off, conn_rec_cnt=self._o_cnt, n_records=int(o.n_records),
+            overflow=int(o.overflow), history_overflow=int(o.history_overflow))
+
+    def tick(self, now_ns: int, upd_idx=None, upd_x=None, upd_z=None, upd_sender=None,
+             cell_upd_channel=None, cell_upd_sender=None, query_sub=None,
+             queries: Optional[Sequence[SpatialInterestQuery]] = None, records_cap: int = 1 << 22,
+             want_records: bool = True) -> TickResult:
+        ti = TickIn()
+        ti.now_ns = int(now_ns)
+        keep = []
+        if upd_x is not None and len(upd_x):
+            ux, uz = _f64(upd_x), _f64(upd_z)
+            ui = None if upd_idx is None else _u32(upd_idx)
+            us = None if upd_sender is None else _u32(upd_sender)
+            keep += [ux, uz, ui, us]
+            ti.n_updates, ti.upd_idx, ti.upd_x, ti.upd_z, ti.upd_sender = len(ux), _ptr(ui), _ptr(ux), _ptr(uz), _ptr(us)
+        if cell_upd_channel is not None and len(cell_upd_channel):
+            cc, cs = _u32(cell_upd_channel), _u32(cell_upd_sender)
+            keep += [cc, cs]
+            ti.n_cell_updates, ti.cell_upd_channel, ti.cell_upd_sender = len(cc), _ptr(cc), _ptr(cs)
+        nq = 0
+        if queries is not None and len(queries):
+            qs = None if query_sub is None else _u32(query_sub)
+            nq = len(queries)
+            if isinstance(queries, np.ndarray):  # packed chd_aoi_query records (synth.AOI_DTYPE)
+                assert queries.dtype.itemsize == C.sizeof(AoiQuery)
+                qa = np.ascontiguousarray(queries)
+                keep += [qa, qs]
+                ti.n_queries, ti.query_sub, ti.queries = nq, _ptr(qs), qa.ctypes.data_as(C.c_void_p)
+            else:
+                arr, sx, sz, sd = pack_queries(queries)
+                keep += [arr, sx, sz, sd, qs]
+                ti.n_queries, ti.query_sub, ti.queries = nq, _ptr(qs), C.cast(arr, C.c_void_p)
+                ti.spot_x, ti.spot_z, ti.spot_dist, ti.n_spots_total = _ptr(sx), _ptr(sz), _ptr(sd), len(sx)
+        o = self._alloc_out(nq, want_records, records_cap)
+        rc = self.lib.chd_tick(self.ctx, C.byref(ti), C.byref(o))
+        if rc not in (_lib.OK,):
+            _lib.check(self.ctx, rc)
+        return self._result(o, nq)
+
+    # ---- device-resident path (bench): inputs already in HBM ----
+    def device_array(self, host: np.ndarray) -> DeviceArray:
+        host = np.ascontiguousarray(host)
+        d = DeviceArray(self, max(host.nbytes, 256))
+        d.upload(host)
+        return d
+
+    def tick_device(self, now_ns: int, n_updates: int = 0, d_upd_x=None, d_upd_z=None, d_upd_idx=None,
+                    d_upd_sender=None, n_queries: int = 0, d_queries=None, d_query_sub=None):
+        ti = TickIn()
+        ti.now_ns = int(now_ns)
+        ti.n_updates, ti.upd_idx, ti.upd_x, ti.upd_z, ti.upd_sender = n_updates, d_upd_idx, d_upd_x, d_upd_z, d_upd_sender
+        ti.n_queries, ti.query_sub, ti.queries = n_queries, d_query_sub, d_queries
+        _lib.check(self.ctx, self.lib.chd_tick_device(self.ctx, C.byref(ti)))
+        self._last_nq = n_queries
+
+    def fetch(self, want_records: bool = False, records_cap: int = 0) -> TickResult:
+        nq = getattr(self, "_last_nq", 0)
+        o = self._alloc_out(nq, want_records, records_cap)
+        _lib.check(self.ctx, self.lib.chd_tick_fetch(self.ctx, C.byref(o)))
+        return self._result(o, nq)
+
+    def sync(self):
+        _lib.check(self.ctx, self.lib.chd_sync(self.ctx))
+
+    def set_profiling(self, on: bool):
+        _lib.check(self.ctx, self.lib.chd_set_profiling(self.ctx, 1 if on else 0))
+
+    def stats(self) -> dict:
+        s = TickStats()
+        _lib.check(self.ctx, self.lib.chd_get_tick_stats(self.ctx, C.byref(s)))
+        return dict(stage_us={n: float(s.stage_us[i]) for i, n in enumerate(_lib.STAGE_NAMES)}, total_us=float(s.total_us),
+                    n_records=int(s.n_records), n_record_upper_bound=int(s.n_record_upper_bound),
+                    n_handovers=int(s.n_handovers), n_unsubs=int(s.n_unsubs), n_pairs=int(s.n_pairs),
+                    algorithmic_bytes=int(s.algorithmic_bytes))
+
+    # ---- introspection ----
+    def subscriptions(self, slot: int):
+        cap = self.capq
+        ch, iv = np.zeros(cap, dtype=np.uint32), np.zeros(cap, dtype=np.uint32)
+        last = np.zeros(cap, dtype=np.int64)
+        hf, nw = np.zeros(cap, dtype=np.uint8), np.zeros(cap, dtype=np.uint8)
+        n = C.c_uint32(0)
+        _lib.check(self.ctx, self.lib.chd_subs_get(self.ctx, int(slot), _ptr(ch), _ptr(iv), _ptr(last), _ptr(hf), _ptr(nw), C.byref(n)))
+        k = n.value
+        return ch[:k], iv[:k], last[:k], hf[:k], nw[:k]
+
+    def entity_state(self, idx=None):
+        n = self.N if idx is None else len(idx)
+        a = None if idx is None else _u32(idx)
+        cell, mem = np.zeros(n, dtype=np.uint32), np.zeros(n, dtype=np.uint32)
+        _lib.check(self.ctx, self.lib.chd_world_get_entities(self.ctx, n, _ptr(a), _ptr(cell), _ptr(mem)))
+        return cell, mem

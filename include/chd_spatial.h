@@ -1,0 +1,297 @@
+/*
+ * chd_spatial.h — C-ABI of libchd_spatial.so, the MI355X-native (HIP/gfx950)
+ * replacement for channeld's SpatialChannel hot path.
+ *
+ * The reference (channeldorg/channeld) is pure Go and has no FFI layer; its
+ * boundary for this path is the Go interface `SpatialController`
+ * (pkg/channeld/spatial.go:17-35) plus the per-channel fan-out tick
+ * (pkg/channeld/data.go:175-318).  Each entry point below names the reference
+ * symbol it replaces; INTEGRATION.md shows the cgo shim (a second Go type
+ * implementing SpatialController) a channeld maintainer would add on top.
+ *
+ * Conventions
+ *   - plain C, no exceptions cross the boundary, no torch / HIP types;
+ *   - every function returns 0 (CHD_OK) or a negative chd_status;
+ *     chd_last_error(ctx) gives a message for the calling thread's last failure;
+ *   - all pointers are HOST pointers unless the name starts with d_ (device);
+ *     inputs are borrowed for the duration of the call only (cgo pointer rules);
+ *     outputs are caller-allocated;
+ *   - channel ids are channeld ChannelIds (uint32): 0 = invalid / out of world
+ *     (GLOBAL is never a spatial id), spatial ids start at
+ *     spatial_channel_id_start (settings.go:94), entity ids are the engine's;
+ *   - every entry point is thread-safe: it binds the HIP device of the ctx to
+ *     the calling OS thread (goroutines migrate between threads) and serialises
+ *     on the ctx's stream with one mutex;
+ *   - ALL compute runs in HIP kernels on the ctx's device.  There is no CPU
+ *     fallback: without a usable gfx950 device chd_create fails with
+ *     CHD_E_NO_DEVICE.
+ *   - arithmetic is IEEE float64 with no FMA contraction, matching amd64 Go.
+ */
+#ifndef CHD_SPATIAL_H
+#define CHD_SPATIAL_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define CHD_ABI_VERSION 1
+
+typedef struct chd_ctx chd_ctx;
+
+typedef enum {
+    CHD_OK = 0,
+    CHD_E_CONFIG = -1,      /* LoadConfig validation failed (spatial.go:146-157) */
+    CHD_E_INVAL = -2,       /* NULL / out-of-range argument (Go would nil-deref) */
+    CHD_E_EXTENT = -3,      /* per-query: invalid box extent / radius (spatial.go:208-215 ...) */
+    CHD_E_CENTER = -4,      /* per-query: AOI centre out of the world (spatial.go:228-231 ...) */
+    CHD_E_CAPACITY = -5,    /* output / interest-set capacity exceeded */
+    CHD_E_HANG = -6,        /* the reference would loop forever on this input */
+    CHD_E_TOO_LARGE = -8,   /* per-query: sample lattice or cell window beyond engine limits */
+    CHD_E_NO_DEVICE = -9,   /* no usable HIP device / kernel image */
+    CHD_E_HIP = -10,        /* HIP runtime error (message in chd_last_error) */
+    CHD_E_STATE = -11       /* call sequence error (e.g. tick before world_create) */
+} chd_status;
+
+/* The 9 fields of StaticGrid2DSpatialController (spatial.go:89-124) + the id
+ * ranges of GlobalSettings (settings.go:94-95) + the SPATIAL channel settings
+ * used on the path (settings.go:64-74) + the damping table
+ * (message_spatial.go:16-29). */
+#define CHD_MAX_DAMPING 8
+typedef struct {
+    double grid_width, grid_height;
+    double world_offset_x, world_offset_z;
+    uint32_t grid_cols, grid_rows;
+    uint32_t server_cols, server_rows;
+    uint32_t server_interest_border_size;
+    uint32_t spatial_channel_id_start;   /* 0 => 0x10000 */
+    uint32_t entity_channel_id_start;    /* 0 => 0x80000 */
+    uint32_t default_fanout_interval_ms; /* SPATIAL DefaultFanOutIntervalMs; 0 => 20 */
+    int32_t default_fanout_delay_ms;     /* SPATIAL DefaultFanOutDelayMs */
+    uint32_t n_damping;                  /* 0 => the reference's table {0:20,1:50,2:100} */
+    uint32_t damping_max_dist[CHD_MAX_DAMPING];
+    uint32_t damping_interval_ms[CHD_MAX_DAMPING];
+    /* LoadConfig rejects ServerInterestBorderSize == 0 (spatial.go:155) but
+     * InitSpatialController drops that error (spatial.go:68) and the shipped
+     * configs use 0.  strict_load_config != 0 reproduces the rejection. */
+    uint32_t strict_load_config;
+} chd_grid_cfg;
+
+/* replaces: InitSpatialController + LoadConfig (spatial.go:40-74,141-159) */
+int chd_create(const chd_grid_cfg *cfg, int device, chd_ctx **out);
+void chd_destroy(chd_ctx *ctx);
+const char *chd_last_error(const chd_ctx *ctx);
+int chd_abi_version(void);
+
+/* replaces: GetChannelId (spatial.go:161-180), batched.  out_ids[i] == 0 means
+ * "(0, err)": the point is outside the world. */
+int chd_get_channel_ids(chd_ctx *ctx, const double *x, const double *z,
+                        uint32_t n, uint32_t *out_ids);
+
+/* replaces: the decision part of Notify (spatial.go:612-626), batched and
+ * stateless: src/dst ids (0 = error) and handover[i] = 1 iff both valid and
+ * different. */
+int chd_notify_decide(chd_ctx *ctx, const double *old_x, const double *old_z,
+                      const double *new_x, const double *new_z, uint32_t n,
+                      uint32_t *src_ids, uint32_t *dst_ids, uint8_t *handover);
+
+/* channeldpb.SpatialInterestQuery (channeld.proto:386-440), flattened.
+ * A shape is present iff its bit is set (a nil sub-message in Go).  Spots live
+ * in side arrays shared by the batch: spots [spot_off, spot_off+n_spots),
+ * of which the first n_spot_dists have an explicit dist.
+ * cone_cos = math.Cos(ConeAOI.Angle) evaluated by the caller (Go evaluates
+ * its own pure-Go cos; the device never evaluates cos — SURVEY §8c). */
+#define CHD_SHAPE_SPOTS 1u
+#define CHD_SHAPE_BOX 2u
+#define CHD_SHAPE_SPHERE 4u
+#define CHD_SHAPE_CONE 8u
+typedef struct {
+    uint32_t shapes;
+    uint32_t spot_off, n_spots, n_spot_dists;
+    double box_cx, box_cz, box_ex, box_ez;
+    double sph_cx, sph_cz, sph_r;
+    double cone_cx, cone_cz, cone_dx, cone_dz, cone_r, cone_cos;
+    double _reserved;
+} chd_aoi_query; /* 128 bytes */
+
+/* replaces: QueryChannelIds (spatial.go:182-317), batched.  CSR output:
+ * query i owns [offsets[i], offsets[i+1]) of ids/dists, sorted by channel id
+ * (the Go map is unordered).  status[i] is CHD_OK or the error the reference
+ * returns for that query (then its range is empty).  cap = capacity of
+ * ids/dists; CHD_E_CAPACITY if the total does not fit.  Also returns the
+ * damped fan-out interval per entry (message_spatial.go:31-38,66-79) when
+ * intervals_ms != NULL. */
+int chd_query_channel_ids(chd_ctx *ctx, const chd_aoi_query *queries, uint32_t nq,
+                          const double *spot_x, const double *spot_z,
+                          const uint32_t *spot_dist, uint32_t n_spots_total,
+                          uint32_t *offsets /* nq+1 */, uint32_t *ids,
+                          uint32_t *dists, uint32_t *intervals_ms, uint32_t cap,
+                          int32_t *status /* nq */);
+
+/* replaces: GetRegions (spatial.go:319-356).  SoA, grid_cols*grid_rows entries.
+ * Y range is the constant [MinY, MaxY] of spatial.go:80-83 and is not returned. */
+int chd_get_regions(chd_ctx *ctx, double *min_x, double *min_z, double *max_x,
+                    double *max_z, uint32_t *channel_id, uint32_t *server_index);
+
+/* replaces: GetAdjacentChannels (spatial.go:358-381), batched: out[8*i ..] holds
+ * counts[i] ids in the reference's row-major order. */
+int chd_get_adjacent_channels(chd_ctx *ctx, const uint32_t *channel_ids,
+                              uint32_t n, uint32_t *out /* 8*n */,
+                              uint32_t *counts /* n */);
+
+/* replaces: the cell-ownership arithmetic of CreateChannels (spatial.go:399-424):
+ * the channel ids created for spatial server `server_index`, in creation order.
+ * *n_out = count.  CHD_E_CONFIG if a cell falls outside the grid (:418-421). */
+int chd_server_channels(chd_ctx *ctx, uint32_t server_index, uint32_t *out,
+                        uint32_t cap, uint32_t *n_out);
+
+/* replaces: subToAdjacentChannels (spatial.go:481-590): the border channels
+ * server `server_index` is subscribed to, in the reference's call order. */
+int chd_border_channels(chd_ctx *ctx, uint32_t server_index, uint32_t *out,
+                        uint32_t cap, uint32_t *n_out);
+
+/* ------------------------------------------------------------------ */
+/* The batched tick: entity updates -> handover, interest updates ->    */
+/* sub/unsub diff, fan-out decisions -> per-connection records.         */
+/* ------------------------------------------------------------------ */
+
+typedef struct {
+    uint32_t max_entities;       /* entity slots [0, max_entities) */
+    uint32_t max_subscribers;    /* subscriber slots */
+    uint32_t max_interest_cells; /* per-subscriber interest-set capacity (0 => min(cells,256)) */
+    uint64_t max_records;        /* fan-out record capacity per tick (0 => auto) */
+    uint32_t max_handovers;      /* handover record capacity per tick (0 => max_entities) */
+} chd_world_cfg;
+
+#define CHD_ENTITY_LOCKED 1u /* member of a non-empty lock group (entity.go:197-224) */
+
+int chd_world_create(chd_ctx *ctx, const chd_world_cfg *cfg);
+
+/* Entity channel creation + spawn into the cell containing (x,z)
+ * (message_spatial.go:231-237, pkg/unreal/message.go:55).  idx = entity slots,
+ * chan_id = entity channel ids (NetGUIDs), sender = the connection that will
+ * send the entity's updates (channel owner).  flags: CHD_ENTITY_*. */
+int chd_world_spawn(chd_ctx *ctx, uint32_t n, const uint32_t *idx,
+                    const uint32_t *chan_id, const double *x, const double *z,
+                    const uint32_t *flags, const uint32_t *sender);
+int chd_world_despawn(chd_ctx *ctx, uint32_t n, const uint32_t *idx);
+int chd_world_set_entity_flags(chd_ctx *ctx, uint32_t n, const uint32_t *idx,
+                               const uint32_t *flags);
+
+/* A client connection with spatial interest (connection.go:106
+ * spatialSubscriptions).  Slot -> ConnectionId.  Removing a subscriber drops all
+ * its subscriptions (a closing connection, data.go:183-188). */
+int chd_subs_add(chd_ctx *ctx, uint32_t n, const uint32_t *slot,
+                 const uint32_t *conn_id);
+int chd_subs_remove(chd_ctx *ctx, uint32_t n, const uint32_t *slot);
+
+/* fan-out record: one fanOutDataUpdate decision (data.go:293-318). */
+#define CHD_REC_FULL 0x80000000u /* in .conn: first fan-out, whole channel data */
+typedef struct {
+    uint32_t conn;    /* ConnectionId (31 bits, settings.go:90) | CHD_REC_FULL */
+    uint32_t channel; /* ChannelId: a spatial channel or an entity channel */
+} chd_fanout_rec;
+
+typedef struct {
+    uint32_t entity;     /* entity slot */
+    uint32_t channel;    /* entity channel id */
+    uint32_t src, dst;   /* spatial channel ids */
+    uint32_t src_server, dst_server; /* ServerIndex of src/dst (spatial.go:336-351);
+                                        cross-server iff different (:683) */
+} chd_handover_rec;
+
+typedef struct {
+    int64_t now_ns; /* ChannelTime of this tick (channel.go:28-37); also the
+                       arrival time stamped on this batch's updates (data.go:161) */
+    /* entity ChannelDataUpdates merged this tick */
+    uint32_t n_updates;
+    const uint32_t *upd_idx;    /* entity slots, NULL => slot u = u */
+    const double *upd_x, *upd_z;/* new position (SpatialInfo X,Z; Y is ignored) */
+    const uint32_t *upd_sender; /* senderConnId, NULL => the entity's owner */
+    /* spatial-channel data updates (spawn/destroy merges), optional */
+    uint32_t n_cell_updates;
+    const uint32_t *cell_upd_channel; /* spatial channel ids */
+    const uint32_t *cell_upd_sender;
+    /* UPDATE_SPATIAL_INTEREST messages (message_spatial.go:41-129) */
+    uint32_t n_queries;
+    const uint32_t *query_sub;  /* subscriber slots, NULL => slot i = i */
+    const chd_aoi_query *queries;
+    const double *spot_x, *spot_z;
+    const uint32_t *spot_dist;
+    uint32_t n_spots_total;
+} chd_tick_in;
+
+typedef struct {
+    /* caller-allocated, any of them may be NULL (then that output stays on the
+     * device and only the counts are returned) */
+    chd_handover_rec *handovers; uint32_t handovers_cap; uint32_t n_handovers;
+    uint32_t n_locked_aborts;          /* handovers aborted by a lock (spatial.go:675-679) */
+    int32_t *query_status;             /* n_queries */
+    uint32_t *unsub_sub, *unsub_channel; uint32_t unsub_cap; uint32_t n_unsubs;
+    /* subscriptions created this tick (SubscribeToChannel's new branch,
+     * subscription.go:59-91): subscriber slot, spatial channel, damped interval.
+     * Re-subscriptions of already subscribed channels only merge the interval
+     * (subscription.go:44-57) and are visible through chd_subs_get. */
+    uint32_t *newsub_sub, *newsub_channel, *newsub_interval_ms; uint32_t newsub_cap; uint32_t n_newsubs;
+    chd_fanout_rec *records; uint64_t records_cap; uint64_t n_records;
+    uint64_t *conn_rec_off;            /* max_subscribers+1: slot s owns records
+                                          [conn_rec_off[s], conn_rec_off[s]+conn_rec_cnt[s]) */
+    uint32_t *conn_rec_cnt;            /* max_subscribers */
+    uint32_t overflow;                 /* !=0: some output was truncated (CHD_E_CAPACITY) */
+    uint32_t history_overflow;         /* windows reaching beyond the 32-tick update history */
+} chd_tick_out;
+
+/* replaces, for the whole world in one call: Notify (spatial.go:612-736,
+ * decision + entity-map update), handleUpdateSpatialInterest
+ * (message_spatial.go:41-129) and tickData on every spatial and entity channel
+ * (data.go:175-318).  Order inside a tick: entity updates, interest updates,
+ * fan-out at now_ns.  now_ns must not decrease between ticks. */
+int chd_tick(chd_ctx *ctx, const chd_tick_in *in, chd_tick_out *out);
+
+/* Same, with every input already resident in device memory (d_* pointers of the
+ * same layout) and outputs left on the device; asynchronous on the ctx stream.
+ * This is what bench.py times.  Use chd_tick_fetch to read the outputs back. */
+int chd_tick_device(chd_ctx *ctx, const chd_tick_in *d_in);
+int chd_tick_fetch(chd_ctx *ctx, chd_tick_out *out);
+int chd_sync(chd_ctx *ctx);
+
+/* Read back the interest set of a subscriber slot (the keys of
+ * Connection.spatialSubscriptions, with the per-subscription fan-out state of
+ * subscription.go:13-31 / data.go:39-44).  Arrays have max_interest_cells
+ * entries; *n_out = count. */
+int chd_subs_get(chd_ctx *ctx, uint32_t slot, uint32_t *channel,
+                 uint32_t *interval_ms, int64_t *last_fanout_ns,
+                 uint8_t *had_first, uint8_t *is_new, uint32_t *n_out);
+/* entity state: position-derived cell id and the cell whose entity map holds it */
+int chd_world_get_entities(chd_ctx *ctx, uint32_t n, const uint32_t *idx,
+                           uint32_t *cell_channel, uint32_t *member_channel);
+
+/* device memory, for callers that keep their batches on the GPU (bench, tests) */
+int chd_dev_alloc(chd_ctx *ctx, uint64_t bytes, void **d_out);
+int chd_dev_free(chd_ctx *ctx, void *d_ptr);
+int chd_dev_upload(chd_ctx *ctx, void *d_dst, const void *src, uint64_t bytes);
+int chd_dev_download(chd_ctx *ctx, void *dst, const void *d_src, uint64_t bytes);
+
+/* metrics (channel_tick_duration analogue, metrics.go): GPU time of the last
+ * tick per stage in microseconds, measured with HIP events on the ctx stream. */
+#define CHD_STAGE_INGEST 0   /* K1 cell assign + handover */
+#define CHD_STAGE_INDEX 1    /* K2 cell index build */
+#define CHD_STAGE_INTEREST 2 /* K3+K4 AOI query + diff */
+#define CHD_STAGE_PLAN 3     /* K5a due plan + scan */
+#define CHD_STAGE_EMIT 4     /* K5b fan-out emit */
+#define CHD_N_STAGES 5
+typedef struct {
+    float stage_us[CHD_N_STAGES];
+    float total_us;
+    uint64_t n_records, n_record_upper_bound;
+    uint32_t n_handovers, n_unsubs, n_pairs;
+    uint64_t algorithmic_bytes; /* DESIGN.md §4 byte model for the last tick */
+} chd_tick_stats;
+int chd_set_profiling(chd_ctx *ctx, int enabled); /* HIP events around stages */
+int chd_get_tick_stats(chd_ctx *ctx, chd_tick_stats *out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CHD_SPATIAL_H */

@@ -420,10 +420,14 @@ int orc_world_tick(orc_world *w, orc_time t, uint32_t n_upd, const uint32_t *idx
         for (uint32_t qi = 0; qi < n_q; qi++) {
             uint32_t s = q_sub ? q_sub[qi] : qi;
             uint32_t n = 0;
+            if (!w->sub_alive[s]) { /* GetConnection == nil, message_spatial.go:53-57 */
+                w->q_status[qi] = -2;
+                continue;
+            }
             int rc = orc_query_channel_ids(&w->g, &queries[qi], ids, dists, w->C, &n);
             if (rc == ORC_OK && n > w->capq) rc = ORC_E_CAP;
             w->q_status[qi] = rc;
-            if (rc != ORC_OK || !w->sub_alive[s]) continue; /* error: nothing changes (:60-63) */
+            if (rc != ORC_OK) continue; /* error: nothing changes (:60-63) */
             wpair *old = &w->pairs[(size_t)s * w->capq];
             uint32_t nold = w->pair_cnt[s];
             /* Difference(existing, new) -> unsub */

@@ -258,6 +258,28 @@ def interest_diff(existing, new):
 
 MS = 1_000_000  # ns per ms
 
+ORC_QUERY_DTYPE = np.dtype([
+    ("shapes", "<u4"), ("n_spots", "<u4"), ("n_spot_dists", "<u4"), ("_pad", "<u4"),
+    ("spot_x", "<u8"), ("spot_z", "<u8"), ("spot_dist", "<u8"),
+    ("box_cx", "<f8"), ("box_cz", "<f8"), ("box_ex", "<f8"), ("box_ez", "<f8"),
+    ("sph_cx", "<f8"), ("sph_cz", "<f8"), ("sph_r", "<f8"),
+    ("cone_cx", "<f8"), ("cone_cz", "<f8"), ("cone_dx", "<f8"), ("cone_dz", "<f8"),
+    ("cone_r", "<f8"), ("cone_angle", "<f8"), ("cone_cos", "<f8"),
+    ("use_cone_cos", "<u4"), ("_pad2", "<u4"),
+])
+assert ORC_QUERY_DTYPE.itemsize == C.sizeof(Query)
+
+
+def queries_from_aoi(aoi: np.ndarray) -> np.ndarray:
+    """chd_aoi_query records (channeld_amd.synth.AOI_DTYPE, no spots) -> orc_query records."""
+    q = np.zeros(len(aoi), dtype=ORC_QUERY_DTYPE)
+    assert not (aoi["shapes"] & SHAPE_SPOTS).any()
+    for f in ("shapes", "box_cx", "box_cz", "box_ex", "box_ez", "sph_cx", "sph_cz", "sph_r",
+              "cone_cx", "cone_cz", "cone_dx", "cone_dz", "cone_r", "cone_cos"):
+        q[f] = aoi[f]
+    q["use_cone_cos"] = 1
+    return q
+
 
 class Channel:
     """A channel's fan-out state (data.go / subscription.go restatement)."""
@@ -356,7 +378,12 @@ class World:
         n_q = 0 if queries is None else len(queries)
         qs = None if q_sub is None else np.ascontiguousarray(q_sub, dtype=np.uint32)
         qarr = None
-        if n_q:
+        if n_q and isinstance(queries, np.ndarray):
+            qnp = queries if queries.dtype == ORC_QUERY_DTYPE else queries_from_aoi(queries)
+            qnp = np.ascontiguousarray(qnp)
+            self._qnp = qnp
+            qarr = C.cast(qnp.ctypes.data_as(C.c_void_p), C.POINTER(Query))
+        elif n_q:
             qarr = (Query * n_q)()
             for i, qb in enumerate(queries):
                 qarr[i] = qb.q

@@ -1,0 +1,350 @@
+"""GPU parity tests (run with `-m gpu` on an MI355X): every result of the HIP path,
+called through the C-ABI of libchd_spatial.so, must equal the CPU oracle bit for bit
+(channel ids, handover assignment, interest sets incl. dist and damped interval,
+fan-out record multisets, subscription state)."""
+import math
+
+import numpy as np
+import pytest
+
+from oracle import pyoracle as orc
+
+pytestmark = pytest.mark.gpu
+
+START = 0x10000
+
+
+@pytest.fixture(scope="module")
+def amd():
+    import channeld_amd
+
+    channeld_amd.load()
+    return channeld_amd
+
+
+def make_ctl(amd, gw, gh, offx, offz, cols, rows, sc=1, sr=1, border=0):
+    import json
+
+    ctl = amd.StaticGrid2DSpatialController()
+    err = ctl.LoadConfig(json.dumps(dict(GridWidth=gw, GridHeight=gh, WorldOffsetX=offx, WorldOffsetZ=offz,
+                                         GridCols=cols, GridRows=rows, ServerCols=sc, ServerRows=sr,
+                                         ServerInterestBorderSize=border)).encode(), strict=False)
+    assert err is None
+    return ctl
+
+
+def SI(amd, x, z):
+    return amd.SpatialInfo(X=x, Z=z)
+
+
+# ---------------------------------------------------------------- GetChannelId
+def test_get_channel_id_golden(amd):
+    # spatial_test.go:762-848 through the mirror of the Go interface
+    ctl = make_ctl(amd, 100, 50, 0, 0, 9, 8, 3, 4, 2)
+    assert ctl.GetChannelId(SI(amd, 0, 0)) == (START, None)
+    assert ctl.GetChannelId(SI(amd, 100, 0))[0] == START + 1
+    assert ctl.GetChannelId(SI(amd, 0, 50))[0] == START + 9
+    assert ctl.GetChannelId(SI(amd, 899.99, 399.99))[0] == START + 71
+    for x, z in [(-1, 0), (1.7976931348623157e308, 0), (0, -1), (900, 400)]:
+        cid, err = ctl.GetChannelId(SI(amd, x, z))
+        assert cid == 0 and err is not None
+    ctl = make_ctl(amd, 100, 50, -450, -200, 9, 8, 3, 4, 2)
+    assert ctl.GetChannelId(SI(amd, 0, 0))[0] == START + 9 * 4 + 4
+    assert ctl.GetChannelId(SI(amd, 449.99, 199.99))[0] == START + 71
+    assert ctl.GetChannelId(SI(amd, 450, 200))[1] is not None
+
+
+@pytest.mark.parametrize("grid", [
+    (2000, 2000, -15000, -15000, 15, 15), (100, 50, -450, -200, 9, 8), (33, 77, 0, 0, 2, 2), (0.1, 0.3, -1.7, 2.9, 64, 48),
+])
+def test_get_channel_ids_random_million(amd, grid):
+    gw, gh, offx, offz, cols, rows = grid
+    ctl = make_ctl(amd, *grid)
+    g = orc.grid(*grid)
+    rng = np.random.default_rng(7)
+    n = 1_000_000
+    W, H = gw * cols, gh * rows
+    x = offx + rng.uniform(-0.1, 1.1, n) * W
+    z = offz + rng.uniform(-0.1, 1.1, n) * H
+    # exact cell edges, float32-representable coordinates (UE positions), specials
+    k = n // 8
+    x[:k] = offx + rng.integers(-1, cols + 2, k) * gw
+    z[k:2 * k] = offz + rng.integers(-1, rows + 2, k) * gh
+    x[2 * k:3 * k] = np.float64(np.float32(x[2 * k:3 * k]))
+    z[2 * k:3 * k] = np.float64(np.float32(z[2 * k:3 * k]))
+    x[3 * k:3 * k + 6] = [np.nan, np.inf, -np.inf, 1.7976931348623157e308, -1.7976931348623157e308, 5e-324]
+    z[3 * k + 6:3 * k + 9] = [np.nan, np.inf, -np.inf]
+    x[3 * k + 9] = np.nextafter(offx + W, -np.inf)
+    x[3 * k + 10] = np.nextafter(offx, -np.inf)
+    got = ctl.get_channel_ids(x, z)
+    want = orc.channel_ids(g, x, z)
+    assert np.array_equal(got, want)
+    assert (got == 0).sum() > 1000 and (got != 0).sum() > 100000
+
+
+def test_notify_batch(amd):
+    grid = (2000, 2000, -15000, -15000, 15, 15, 3, 3, 0)
+    ctl = make_ctl(amd, *grid)
+    g = orc.grid(*grid)
+    rng = np.random.default_rng(11)
+    n = 200_000
+    ox = rng.uniform(-16000, 16000, n)
+    oz = rng.uniform(-16000, 16000, n)
+    nx = ox + rng.normal(0, 600, n)
+    nz = oz + rng.normal(0, 600, n)
+    src, dst, ho = ctl.notify_batch(ox, oz, nx, nz)
+    for i in rng.integers(0, n, 3000):
+        h, s, d = orc.notify_decision(g, ox[i], oz[i], nx[i], nz[i])
+        assert (bool(ho[i]), int(src[i]), int(dst[i])) == (h, s, d)
+    want_src = orc.channel_ids(g, ox, oz)
+    assert np.array_equal(src, want_src)
+    assert ho.sum() > 1000
+    # the Go-shaped single call
+    calls = []
+    ctl.Notify(SI(amd, 100, 100), SI(amd, 2100, 100), lambda s, d, data: calls.append((s, d)))
+    ctl.Notify(SI(amd, 100, 100), SI(amd, 200, 100), lambda s, d, data: calls.append((s, d)))
+    ctl.Notify(SI(amd, 100, 100), SI(amd, 99999, 100), lambda s, d, data: calls.append((s, d)))
+    assert calls == [(START + 7 * 15 + 7, START + 7 * 15 + 8)]
+
+
+# ---------------------------------------------------------------- QueryChannelIds golden
+def Q(amd, **kw):
+    return amd.SpatialInterestQuery(**kw)
+
+
+def test_cone_aoi_golden(amd):
+    # spatial_test.go:21-242
+    cone = lambda cx, cz, dx, dz, r, a: Q(amd, ConeAOI=amd.ConeAOI(Center=SI(amd, cx, cz), Direction=SI(amd, dx, dz), Radius=r, Angle=a))
+    ctl1 = make_ctl(amd, 10, 10, 0, 0, 1, 1)
+    res, err = ctl1.QueryChannelIds(cone(5, 5, 1, 0, 1, math.pi / 4))
+    assert err is None and START in res
+    ctl2 = make_ctl(amd, 10, 10, 0, 0, 4, 1)
+    assert START in ctl2.QueryChannelIds(cone(0, 5, 1, 0, 1, math.pi / 4))[0]
+    assert len(ctl2.QueryChannelIds(cone(0, 5, 1, 0, 25, math.pi / 4))[0]) == 3
+    assert len(ctl2.QueryChannelIds(cone(0, 5, 1, 0, 100, math.pi / 4))[0]) == 4
+    assert len(ctl2.QueryChannelIds(cone(0, 5, 0, 1, 100, math.pi / 4))[0]) == 1
+    ctl3 = make_ctl(amd, 10, 10, 0, 0, 3, 3)
+    assert sorted(ctl3.QueryChannelIds(cone(5, 5, 1, 0, 100, 0.1))[0]) == [65536, 65537, 65538]
+    assert sorted(ctl3.QueryChannelIds(cone(5, 5, 1, 0, 100, math.pi / 4))[0]) == [65536, 65537, 65538, 65540, 65541, 65544]
+    assert sorted(ctl3.QueryChannelIds(cone(15, 15, -1, 0, 100, math.pi / 4))[0]) == [65536, 65539, 65540, 65542]
+    assert sorted(ctl3.QueryChannelIds(cone(5, 15, 0, -1, 100, math.pi / 4))[0]) == [65536, 65537, 65539]
+    ctl4 = make_ctl(amd, 1000, 1000, -2000, -500, 4, 1, 2, 1, 1)
+    assert len(ctl4.QueryChannelIds(cone(1250, 0, -0.087, 0.996, 30000, 0.5236))[0]) == 1
+
+
+def test_sphere_box_aoi_golden(amd):
+    # spatial_test.go:244-491
+    sph = lambda cx, cz, r: Q(amd, SphereAOI=amd.SphereAOI(Center=SI(amd, cx, cz), Radius=r))
+    box = lambda cx, cz, ex, ez: Q(amd, BoxAOI=amd.BoxAOI(Center=SI(amd, cx, cz), Extent=SI(amd, ex, ez)))
+    c1 = make_ctl(amd, 10, 10, 0, 0, 1, 1)
+    assert START in c1.QueryChannelIds(sph(5, 5, 1))[0] and START in c1.QueryChannelIds(sph(5, 5, 100))[0]
+    assert START in c1.QueryChannelIds(box(5, 5, 1, 1))[0] and START in c1.QueryChannelIds(box(5, 5, 100, 100))[0]
+    c2 = make_ctl(amd, 5, 5, -5, -5, 2, 2)
+    assert len(c2.QueryChannelIds(sph(0, 0, 1))[0]) == 4
+    assert list(c2.QueryChannelIds(sph(4.9, 4.9, 1))[0]) == [65539]
+    assert len(c2.QueryChannelIds(sph(4.9, 4.9, 4.9))[0]) == 1
+    assert len(c2.QueryChannelIds(sph(4.9, 4.9, 10))[0]) == 4
+    assert len(c2.QueryChannelIds(box(0, 0, 1, 1))[0]) == 4
+    assert list(c2.QueryChannelIds(box(4.9, 4.9, 1, 1))[0]) == [65539]
+    assert len(c2.QueryChannelIds(box(4.9, 4.9, 4.9, 4.9))[0]) == 1
+    assert sorted(c2.QueryChannelIds(box(4.9, 4.9, 4.9, 10))[0]) == [65537, 65539]
+    c3 = make_ctl(amd, 100, 100, -150, -150, 3, 3)
+    assert len(c3.QueryChannelIds(sph(0, 0, 150))[0]) == 9
+    assert sorted(c3.QueryChannelIds(sph(0, 0, 99))[0]) == [START + 1, START + 3, START + 4, START + 5, START + 7]
+    assert len(c3.QueryChannelIds(box(0, 0, 150, 150))[0]) == 9
+    assert len(c3.QueryChannelIds(box(0, 0, 100, 100))[0]) == 9
+
+
+def test_query_errors(amd):
+    ctl = make_ctl(amd, 10, 10, 0, 0, 3, 3)
+    assert ctl.QueryChannelIds(None)[1] is not None
+    sph = lambda cx, cz, r: Q(amd, SphereAOI=amd.SphereAOI(Center=SI(amd, cx, cz), Radius=r))
+    from channeld_amd import _lib
+
+    assert ctl.QueryChannelIds(sph(5, 5, 0))[1].code == _lib.E_EXTENT
+    assert ctl.QueryChannelIds(sph(-5, 5, 3))[1].code == _lib.E_CENTER
+    res, err = ctl.QueryChannelIds(Q(amd, BoxAOI=amd.BoxAOI(Center=SI(amd, 5, 5), Extent=SI(amd, 1, 1)),
+                                     SphereAOI=amd.SphereAOI(Center=SI(amd, -5, 5), Radius=3)))
+    assert res is None and err.code == _lib.E_CENTER
+    assert ctl.QueryChannelIds(Q(amd, BoxAOI=amd.BoxAOI(Center=None, Extent=SI(amd, 1, 1))))[1].code == _lib.E_INVAL
+
+
+# ---------------------------------------------------------------- QueryChannelIds random
+def random_queries(amd, rng, grid, n, multi=False):
+    gw, gh, offx, offz, cols, rows = grid[:6]
+    W, H = gw * cols, gh * rows
+    qs, obs = [], []
+    for i in range(n):
+        kind = rng.integers(0, 4 if not multi else 5)
+        cx = offx + rng.uniform(-0.05, 1.05) * W
+        cz = offz + rng.uniform(-0.05, 1.05) * H
+        if rng.random() < 0.3:  # float32 coordinates and cell-aligned centres
+            cx, cz = float(np.float32(cx)), float(np.float32(cz))
+        if rng.random() < 0.1:
+            cx = offx + rng.integers(0, cols) * gw
+        kw_a, kw_o = {}, {}
+        r = float(rng.choice([0.3, 0.5, 1.0, 1.5, 2.0, 3.0, 4.7]) * gw * rng.uniform(0.8, 1.2))
+        if rng.random() < 0.15:
+            r = float(rng.choice([1.0, 2.0, 3.0]) * gw)  # radii that are exact cell multiples
+        if kind == 0 or kind == 4:
+            kw_a["SphereAOI"] = amd.SphereAOI(Center=SI(amd, cx, cz), Radius=r)
+            kw_o["sphere"] = (cx, cz, r)
+        if kind == 1 or kind == 4:
+            ex, ez = r, float(r * rng.uniform(0.3, 1.5))
+            bx, bz = cx + (gw if kind == 4 else 0), cz
+            kw_a["BoxAOI"] = amd.BoxAOI(Center=SI(amd, bx, bz), Extent=SI(amd, ex, ez))
+            kw_o["box"] = (bx, bz, ex, ez)
+        if kind == 2 or kind == 4:
+            ang = float(rng.choice([0.1, 0.5236, math.pi / 4, 1.2, 2.5]))
+            th = rng.uniform(0, 2 * math.pi)
+            dx, dz = math.cos(th), math.sin(th)
+            if rng.random() < 0.3:
+                dx, dz = float(rng.choice([1, 0, -1])), float(rng.choice([1, -1]))
+            kw_a["ConeAOI"] = amd.ConeAOI(Center=SI(amd, cx, cz), Direction=SI(amd, dx, dz), Radius=r * 1.5, Angle=ang)
+            kw_o["cone"] = (cx, cz, dx, dz, r * 1.5, ang)
+        if kind == 3 or kind == 4:
+            m = int(rng.integers(1, 6))
+            spots = [(offx + rng.uniform(-0.1, 1.1) * W, offz + rng.uniform(-0.1, 1.1) * H) for _ in range(m)]
+            if m > 2:
+                spots[2] = spots[0]  # same cell twice: the later spot wins
+            dists = [int(v) for v in rng.integers(0, 5, int(rng.integers(0, m + 1)))]
+            kw_a["SpotsAOI"] = amd.SpotsAOI(Spots=[SI(amd, a, b) for a, b in spots], Dists=dists)
+            kw_o["spots"], kw_o["spot_dists"] = spots, dists
+        qs.append(Q(amd, **kw_a))
+        obs.append(orc.QueryBuilder(**kw_o))
+    return qs, obs
+
+
+@pytest.mark.parametrize("grid", [
+    (2000, 2000, -15000, -15000, 15, 15), (10, 10, 0, 0, 3, 3), (100, 50, -450, -200, 9, 8), (5, 5, -5, -5, 2, 2),
+    (50, 50, -1000, -1000, 40, 40),  # 1600 cells: per-query window path
+])
+def test_query_channel_ids_random(amd, grid):
+    ctl = make_ctl(amd, *grid)
+    g = orc.grid(*grid)
+    rng = np.random.default_rng(abs(hash(grid)) % (2 ** 31))
+    n = 1500
+    qs, obs = random_queries(amd, rng, grid, n, multi=True)
+    status, res, ivs = ctl.query_channel_ids_batch(qs, with_intervals=True)
+    n_ok = 0
+    for i in range(n):
+        rc, want = orc.query_channel_ids(g, obs[i])
+        assert int(status[i]) == rc, f"query {i}: status {status[i]} vs oracle {rc}"
+        assert res[i] == want, f"query {i}: {res[i]} vs {want}"
+        if rc == 0:
+            n_ok += 1
+            for c, d in want.items():
+                assert ivs[i][c] == orc.lib().orc_damping_interval(d, 20)
+    assert n_ok > n // 3
+
+
+def test_query_benchmark_shapes_many(amd):
+    # the bench's own query mix at the benchmark grid: 20k queries, dists included
+    from channeld_amd import synth
+
+    cfg = synth.load_config("spatial_static_benchmark.json")
+    g = orc.grid_from_config(cfg)
+    sw = synth.SynthWorld(synth.WorldSpec(cfg, 20000, 20000, 0xC0FFEE01))
+    sw.step()
+    aoi = sw.queries()
+    ctl = make_ctl(amd, 2000, 2000, -15000, -15000, 15, 15, 3, 3, 0)
+    import ctypes as C
+    from channeld_amd import _lib
+
+    nq = len(aoi)
+    cap = nq * 225
+    offsets = np.zeros(nq + 1, dtype=np.uint32)
+    ids, dists, ivs = (np.zeros(cap, dtype=np.uint32) for _ in range(3))
+    status = np.zeros(nq, dtype=np.int32)
+    _lib.check(ctl.ctx, _lib.load().chd_query_channel_ids(
+        ctl.ctx, aoi.ctypes.data_as(C.c_void_p), nq, None, None, None, 0,
+        offsets.ctypes.data_as(C.c_void_p), ids.ctypes.data_as(C.c_void_p), dists.ctypes.data_as(C.c_void_p),
+        ivs.ctypes.data_as(C.c_void_p), cap, status.ctypes.data_as(C.c_void_p)))
+    oq = orc.queries_from_aoi(aoi)
+    oid, odist = np.zeros(225, dtype=np.uint32), np.zeros(225, dtype=np.uint32)
+    n = C.c_uint32(0)
+    P = C.POINTER
+    total = 0
+    for i in range(nq):
+        rc = orc.lib().orc_query_channel_ids(C.byref(g), C.cast(oq[i:i + 1].ctypes.data_as(C.c_void_p), P(orc.Query)),
+                                             oid.ctypes.data_as(P(C.c_uint32)), odist.ctypes.data_as(P(C.c_uint32)), 225, C.byref(n))
+        assert rc == status[i]
+        a, b = int(offsets[i]), int(offsets[i + 1])
+        assert b - a == n.value
+        assert np.array_equal(ids[a:b], oid[: n.value]) and np.array_equal(dists[a:b], odist[: n.value])
+        total += n.value
+    assert total > 100000
+
+
+# ---------------------------------------------------------------- regions / adjacency / servers
+def test_regions_adjacent_servers(amd):
+    for grid in [(2000, 2000, -15000, -15000, 15, 15, 3, 3, 0), (20, 40, -40, -60, 4, 3, 2, 3, 1), (33, 77, 0, 0, 2, 2, 2, 2, 0),
+                 (10, 10, 0, 0, 1, 1, 1, 1, 1), (100, 50, 0, 0, 9, 8, 3, 4, 2)]:
+        ctl = make_ctl(amd, *grid)
+        g = orc.grid(*grid)
+        regs, err = ctl.GetRegions()
+        minx, minz, maxx, maxz, cid, srv = orc.regions(g)
+        assert err is None and len(regs) == g.cols * g.rows
+        for i, r in enumerate(regs):
+            assert (r.Min.X, r.Min.Z, r.Max.X, r.Max.Z, r.ChannelId, r.ServerIndex) == (minx[i], minz[i], maxx[i], maxz[i], cid[i], srv[i])
+        allc = [START + i for i in range(g.cols * g.rows)]
+        adj = ctl.get_adjacent_channels_batch(allc)
+        for c, a in zip(allc, adj):
+            assert a == orc.adjacent(g, c)
+        for s in range(g.server_cols * g.server_rows):
+            assert ctl.server_channels(s) == orc.server_channels(g, s)
+            assert ctl.border_channels(s) == orc.border_channels(g, s)
+
+
+def test_create_channels_like_reference_test(amd):
+    # spatial_test.go:612-683 TestCreateSpatialChannels1 with the reference's test double
+    class Conn:
+        def __init__(self):
+            self.subscribedChannels = {}
+            self.closing = False
+
+    ctl = make_ctl(amd, 20, 40, -40, -60, 4, 3, 2, 3, 1)
+    conns = [Conn() for _ in range(6)]
+    ch0, err = ctl.CreateChannels(conns[0])
+    assert err is None and ch0 == [START + 0, START + 1]
+    for i in range(1, 6):
+        ch, err = ctl.CreateChannels(conns[i])
+        assert err is None and len(ch) == 2
+    assert ctl.nextServerIndex() == 6
+    assert {START + 2, START + 4, START + 5} <= set(conns[0].subscribedChannels)
+    assert {START + 1, START + 6, START + 7} <= set(conns[1].subscribedChannels)
+    assert {START + 0, START + 1, START + 6, START + 8, START + 9} <= set(conns[2].subscribedChannels)
+    assert {START + 2, START + 3, START + 5, START + 10, START + 11} <= set(conns[3].subscribedChannels)
+    assert {START + 6, START + 7, START + 9} <= set(conns[5].subscribedChannels)
+    assert ctl.CreateChannels(Conn())[1] is not None
+    # TestCreateSpatialChannels3: slot reuse after Tick()
+    ctl = make_ctl(amd, 33, 77, 0, 0, 2, 2, 2, 2, 0)
+    c = Conn()
+    while True:
+        ch, err = ctl.CreateChannels(c)
+        if err is not None:
+            break
+        assert len(ch) == 1
+    assert c.subscribedChannels == {}
+    c.closing = True
+    ctl.Tick()
+    assert ctl.nextServerIndex() == 0
+    c.closing = False
+    ch, err = ctl.CreateChannels(c)
+    assert err is None and ch[0] == START and ctl.nextServerIndex() == 1
+
+
+def test_load_config_errors(amd):
+    import json
+
+    ctl = amd.StaticGrid2DSpatialController()
+    base = dict(GridWidth=10, GridHeight=10, WorldOffsetX=0, WorldOffsetZ=0, GridCols=1, GridRows=1, ServerCols=1, ServerRows=1,
+                ServerInterestBorderSize=1)
+    assert ctl.LoadConfig(json.dumps(base).encode()) is None
+    for k, v in [("GridWidth", 0), ("GridRows", 0), ("ServerCols", 0), ("ServerInterestBorderSize", 0)]:
+        bad = dict(base)
+        bad[k] = v
+        assert ctl.LoadConfig(json.dumps(bad).encode()) is not None  # spatial.go:146-157
+    bad = dict(base)
+    bad["ServerInterestBorderSize"] = 0
+    assert ctl.LoadConfig(json.dumps({"Config": bad}).encode(), strict=False) is None  # InitSpatialController ignores it

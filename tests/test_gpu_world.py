@@ -1,0 +1,231 @@
+"""GPU parity of the batched tick (chd_tick through the C-ABI) against the
+tick-pipeline oracle: handover records, entity maps, interest sets with their
+fan-out state, unsub/new-sub lists and the multiset of fan-out records per
+connection, tick after tick on the same seeded synthetic input."""
+import json
+
+import numpy as np
+import pytest
+
+from channeld_amd import synth
+from oracle import pyoracle as orc
+
+pytestmark = pytest.mark.gpu
+
+
+def make(amd, cfg, N, S, capq=0, max_records=0):
+    ctl = amd.StaticGrid2DSpatialController()
+    assert ctl.LoadConfig(json.dumps(cfg).encode(), strict=False) is None
+    w = amd.SpatialWorld(ctl, N, S, max_interest_cells=capq, max_records=max_records)
+    return ctl, w
+
+
+def canon(conn, chan):
+    return np.sort((conn.astype(np.uint64) << np.uint64(32)) | chan.astype(np.uint64))
+
+
+def compare_tick(k, res, ow, S, id_start=0x10000, check_pairs=None, gw=None):
+    # handovers (order is not defined in the reference: compare as sets keyed by entity)
+    ent, src, dst, ssrc, sdst = ow.handovers()
+    got = np.sort(res.handovers, order="entity")
+    o = np.argsort(ent)
+    assert len(got) == len(ent), f"tick {k}: {len(got)} handovers vs oracle {len(ent)}"
+    assert np.array_equal(got["entity"], ent[o]) and np.array_equal(got["src"], src[o]) and np.array_equal(got["dst"], dst[o])
+    assert np.array_equal(got["src_server"], ssrc[o]) and np.array_equal(got["dst_server"], sdst[o])
+    assert res.n_locked_aborts == ow.locked_aborts()
+    # interest updates
+    assert np.array_equal(res.query_status, ow.query_status()), f"tick {k}: query status"
+    us, uc = ow.unsubs()
+    assert np.array_equal(canon(res.unsub_sub, res.unsub_channel), canon(us, uc)), f"tick {k}: unsubs"
+    # fan-out records
+    oc, och = ow.records()
+    assert res.n_records == len(oc), f"tick {k}: {res.n_records} records vs oracle {len(oc)}"
+    assert np.array_equal(canon(res.records["conn"], res.records["channel"]), canon(oc, och)), f"tick {k}: records"
+    assert res.overflow == 0 and res.history_overflow == 0
+    # records are grouped per connection slot
+    assert int(res.conn_rec_off[S]) == res.n_records
+    if check_pairs is not None:
+        new_pairs = []
+        for s in check_pairs:
+            gch, giv, glast, ghf, gnew = gw.subscriptions(s)
+            wch, wiv, wlast, whf, wnew = ow.pairs(s)
+            assert np.array_equal(gch, wch) and np.array_equal(giv, wiv), f"tick {k} sub {s}: interest set"
+            assert np.array_equal(glast, wlast) and np.array_equal(ghf, whf), f"tick {k} sub {s}: fan-out state"
+            assert np.array_equal(gnew, wnew), f"tick {k} sub {s}: is_new"
+
+
+def run_world(amd, cfg_name, N, S, ticks, seed, tick_ms=50, capq=0, aoi_scale=1.0, sparse=False, check_subs=8):
+    cfg = synth.load_config(cfg_name)
+    g = orc.grid_from_config(cfg)
+    spec = synth.WorldSpec(cfg, N, S, seed, tick_ms=tick_ms, aoi_scale=aoi_scale, outside_frac=0.01, locked_frac=0.02)
+    sw = synth.SynthWorld(spec)
+    ctl, gw = make(amd, cfg, N, S, capq)
+    ow = orc.World(g, N, S, gw.capq, 20, 0, literal=False)
+    ow.set_threads(4)
+    ow.spawn(np.arange(N), sw.chan_id, sw.x, sw.z, sw.flags, sw.sender)
+    gw.spawn(None, sw.chan_id, sw.x, sw.z, sw.flags, sw.sender)
+    for s in range(S):
+        ow.add_sub(s, int(sw.sub_conn[s]))
+    gw.add_subscribers(None, sw.sub_conn)
+    rng = np.random.default_rng(seed & 0xFFFF)
+    total = 0
+    n_ho = 0
+    for k in range(ticks):
+        sw.step()
+        q = sw.queries()
+        if sparse and k % 3 == 1:
+            idx = np.sort(rng.choice(N, N // 2, replace=False)).astype(np.uint32)
+            qsub = np.sort(rng.choice(S, S // 2, replace=False)).astype(np.uint32)
+        else:
+            idx = np.arange(N, dtype=np.uint32)
+            qsub = np.arange(S, dtype=np.uint32)
+        ow.tick(sw.now_ns(), idx, sw.x[idx], sw.z[idx], None, None, None, qsub, q[qsub])
+        res = gw.tick(sw.now_ns(), upd_idx=idx, upd_x=sw.x[idx], upd_z=sw.z[idx], query_sub=qsub, queries=q[qsub],
+                      records_cap=max(1 << 20, 4 * len(ow.records()[0])))
+        subs = rng.choice(S, min(check_subs, S), replace=False)
+        compare_tick(k, res, ow, S, check_pairs=subs, gw=gw)
+        # new-sub list == the oracle's is_new pairs of the re-queried subscribers
+        want = []
+        for s in qsub:
+            ch, iv, _, _, nw = ow.pairs(int(s))
+            want += [(int(s), int(c), int(i)) for c, i, n in zip(ch, iv, nw) if n]
+        got = sorted(zip(res.newsub_sub.tolist(), res.newsub_channel.tolist(), res.newsub_interval_ms.tolist()))
+        assert got == sorted(want), f"tick {k}: new-sub list"
+        total += res.n_records
+        n_ho += len(res.handovers)
+    # entity maps at the end
+    cell, member = gw.entity_state()
+    ocell, omember = ow.entity_state()
+    to_id = lambda a: np.where(a == 0xFFFFFFFF, 0, a + 0x10000).astype(np.uint32)
+    assert np.array_equal(cell, to_id(ocell)) and np.array_equal(member, to_id(omember))
+    return total, n_ho
+
+
+@pytest.fixture(scope="module")
+def amd():
+    import channeld_amd
+
+    channeld_amd.load()
+    return channeld_amd
+
+
+def test_world_config_a_2x2(amd):
+    # BASELINE config A: spatial_static_2x2.json, 1K entities / 256 subscribers
+    total, n_ho = run_world(amd, "spatial_static_2x2.json", 1000, 256, 30, 0xC0FFEE00)
+    assert total > 100000 and n_ho > 0
+
+
+def test_world_benchmark_grid(amd):
+    total, n_ho = run_world(amd, "spatial_static_benchmark.json", 6000, 400, 24, 0xC0FFEE01)
+    assert total > 200000 and n_ho > 20
+
+
+def test_world_sparse_updates_and_requeries(amd):
+    total, n_ho = run_world(amd, "spatial_static_benchmark.json", 3000, 200, 24, 0xC0FFEE05, tick_ms=33, sparse=True)
+    assert total > 50000
+
+
+def test_world_irregular_ticks_4x4(amd):
+    # 7 ms ticks against 20/50/100 ms intervals; derived config D grid
+    total, n_ho = run_world(amd, "spatial_static_4x4.json", 2000, 150, 40, 0xC0FFEE03, tick_ms=7, aoi_scale=0.5)
+    assert total > 50000
+
+
+def test_world_8x8_small_aoi(amd):
+    total, n_ho = run_world(amd, "spatial_static_8x8.json", 4000, 300, 20, 0xC0FFEE04, tick_ms=20, aoi_scale=0.4)
+    assert total > 50000
+
+
+def test_world_slow_ticks_catch_up(amd):
+    # 170 ms ticks: several catch-up windows per tick for every interval class
+    total, n_ho = run_world(amd, "spatial_static_benchmark.json", 2000, 100, 16, 0xC0FFEE06, tick_ms=170)
+    assert total > 50000
+
+
+def test_world_despawn_lock_and_remove_subscriber(amd):
+    cfg = synth.load_config("spatial_static_2x2.json")
+    g = orc.grid_from_config(cfg)
+    N, S = 64, 8
+    ctl, gw = make(amd, cfg, N, S)
+    ow = orc.World(g, N, S, gw.capq, 20, 0)
+    x = np.linspace(-1900, 1900, N)
+    z = np.linspace(-1900, 1900, N)[::-1].copy()
+    chan = (0x80000 + np.arange(N)).astype(np.uint32)
+    flags = np.zeros(N, dtype=np.uint32)
+    sender = np.full(N, 5, dtype=np.uint32)
+    ow.spawn(np.arange(N), chan, x, z, flags, sender)
+    gw.spawn(None, chan, x, z, flags, sender)
+    conns = (1000 + np.arange(S)).astype(np.uint32)
+    for s in range(S):
+        ow.add_sub(s, int(conns[s]))
+    gw.add_subscribers(None, conns)
+    qs = [orc.QueryBuilder(sphere=(float(x[s * 8]), float(z[s * 8]), 900.0)) for s in range(S)]
+    import channeld_amd as A
+
+    gq = [A.SpatialInterestQuery(SphereAOI=A.SphereAOI(Center=A.SpatialInfo(X=float(x[s * 8]), Z=float(z[s * 8])), Radius=900.0)) for s in range(S)]
+    t = 0
+    for k in range(12):
+        t += 40_000_000
+        x = x + 130.0
+        if k == 3:  # lock a few entities right before they cross the x = 0 border
+            for i in (30, 31, 33):
+                ow.set_flags(i, 1)
+            gw.set_entity_flags([30, 31, 33], [1, 1, 1])
+        if k == 5:
+            ow.despawn(10)
+            gw.despawn([10])
+            ow.remove_sub(2)
+            gw.remove_subscribers([2])
+        if k == 7:
+            for i in (30, 31, 33):
+                ow.set_flags(i, 0)
+            gw.set_entity_flags([30, 31, 33], [0, 0, 0])
+        queries = qs if k % 4 == 0 else None
+        gqueries = gq if k % 4 == 0 else None
+        ow.tick(t, None, x, z, None, None, None, None, queries)
+        res = gw.tick(t, upd_x=x, upd_z=z, queries=gqueries)
+        compare_tick(k, res, ow, S, check_pairs=range(S), gw=gw)
+    cell, member = gw.entity_state()
+    ocell, omember = ow.entity_state()
+    to_id = lambda a: np.where(a == 0xFFFFFFFF, 0, a + 0x10000).astype(np.uint32)
+    live = np.ones(N, dtype=bool)
+    live[10] = False
+    assert np.array_equal(cell[live], to_id(ocell)[live]) and np.array_equal(member[live], to_id(omember)[live])
+
+
+def test_cell_channel_updates_and_self_skip(amd):
+    # spatial-channel data updates sent by a subscriber itself are not fanned back to it
+    cfg = synth.load_config("spatial_static_2x2.json")
+    g = orc.grid_from_config(cfg)
+    N, S = 16, 3
+    ctl, gw = make(amd, cfg, N, S)
+    ow = orc.World(g, N, S, gw.capq, 20, 0)
+    x = np.full(N, 500.0)
+    z = np.full(N, 500.0)
+    chan = (0x80000 + np.arange(N)).astype(np.uint32)
+    conns = np.array([7, 8, 9], dtype=np.uint32)
+    sender = np.full(N, 7, dtype=np.uint32)  # connection 7 sends every entity update
+    ow.spawn(np.arange(N), chan, x, z, np.zeros(N, dtype=np.uint32), sender)
+    gw.spawn(None, chan, x, z, None, sender)
+    for s in range(S):
+        ow.add_sub(s, int(conns[s]))
+    gw.add_subscribers(None, conns)
+    import channeld_amd as A
+
+    qs = [orc.QueryBuilder(sphere=(500.0, 500.0, 100.0)) for _ in range(S)]
+    gq = [A.SpatialInterestQuery(SphereAOI=A.SphereAOI(Center=A.SpatialInfo(X=500.0, Z=500.0), Radius=100.0)) for _ in range(S)]
+    t = 0
+    seen_delta = {7: 0, 8: 0, 9: 0}
+    for k in range(10):
+        t += 20_000_000
+        cu_cell = np.array([3], dtype=np.uint32)   # cell index 3 = channel 0x10003 holds (500,500)
+        cu_sender = np.array([8], dtype=np.uint32)
+        ow.tick(t, None, x, z, None, cu_cell, cu_sender, None, qs if k == 0 else None)
+        res = gw.tick(t, upd_x=x, upd_z=z, cell_upd_channel=cu_cell + 0x10000, cell_upd_sender=cu_sender,
+                      queries=gq if k == 0 else None)
+        compare_tick(k, res, ow, S)
+        for r in res.records:
+            if not (r["conn"] & 0x80000000):
+                seen_delta[int(r["conn"])] += 1
+    # 7 never receives entity deltas (its own), 8 never receives the cell channel's deltas
+    assert seen_delta[9] > seen_delta[7] > 0 and seen_delta[9] > seen_delta[8] > 0
