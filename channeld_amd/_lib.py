@@ -31,7 +31,7 @@ SYMBOLS = (
     "chd_world_set_entity_flags", "chd_subs_add", "chd_subs_remove", "chd_tick",
     "chd_tick_device", "chd_tick_fetch", "chd_sync", "chd_subs_get",
     "chd_world_get_entities", "chd_dev_alloc", "chd_dev_free", "chd_dev_upload",
-    "chd_dev_download", "chd_set_profiling", "chd_get_tick_stats",
+    "chd_dev_download", "chd_set_profiling", "chd_get_tick_stats", "chd_get_tick_history",
 )
 
 
@@ -169,6 +169,7 @@ def load():
     L.chd_dev_download.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64]
     L.chd_set_profiling.argtypes = [C.c_void_p, C.c_int]
     L.chd_get_tick_stats.argtypes = [C.c_void_p, P(TickStats)]
+    L.chd_get_tick_history.argtypes = [C.c_void_p, C.c_uint32, P(TickStats)]
     _lib = L
     return L
 

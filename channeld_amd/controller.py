@@ -263,7 +263,7 @@ class StaticGrid2DSpatialController:
         arr, sx, sz, sd = pack_queries(queries)
         nq = len(queries)
         ncell = self.GridCols * self.GridRows
-        cap = max(1, nq * min(ncell, 1024))
+        cap = max(1, nq * min(ncell, 4096))
         offsets = np.zeros(nq + 1, dtype=np.uint32)
         ids = np.zeros(cap, dtype=np.uint32)
         dists = np.zeros(cap, dtype=np.uint32)

@@ -51,9 +51,8 @@ struct chd_ctx {
     TickRing ring{};
     // scratch for the stateless entry points and for chd_tick's staging
     DevBuf scratch[16];
-    bool profiling = false;
-    hipEvent_t ev[CHD_N_STAGES + 1]{};
-    bool ev_valid = false;
+    int prof_depth = 0;                 // 0 = off
+    std::vector<hipEvent_t> ev;         // [prof_depth][CHD_N_STAGES + 1]
     chd_tick_stats stats{};
 };
 
@@ -240,7 +239,8 @@ int chd_create(const chd_grid_cfg *cfg, int device, chd_ctx **out) {
         }
     }
     ctx->lim.maxax = 256;
-    ctx->lim.winmax = std::min<uint32_t>(std::max<uint32_t>(g.ncell, 64), 1024);
+    ctx->lim.winmax = std::min<uint32_t>(std::max<uint32_t>(g.ncell, 64), 4096);
+    ctx->lim.maxdim = std::min<uint32_t>(ctx->lim.winmax, std::max(g.cols, g.rows));
     ctx->ring.n = 0;
     ctx->ring.cur_tick = 0;
     *out = ctx;
@@ -256,8 +256,7 @@ void chd_destroy(chd_ctx *ctx) {
     if (ctx->w.recs_dense) (void)hipFree(ctx->w.recs_dense);
     for (auto &b : ctx->scratch)
         if (b.p) (void)hipFree(b.p);
-    if (ctx->ev_valid)
-        for (auto &e : ctx->ev) (void)hipEventDestroy(e);
+    for (auto &e : ctx->ev) (void)hipEventDestroy(e);
     (void)hipStreamDestroy(ctx->stream);
     delete ctx;
 }
@@ -503,6 +502,7 @@ int chd_world_create(chd_ctx *ctx, const chd_world_cfg *cfg) {
     TRY(walloc(ctx, &d.newsub_iv, d.newsub_cap, false));
     TRY(walloc(ctx, &d.q_status, S));
     TRY(walloc(ctx, &d.counters, CTR_COUNT));
+    TRY(walloc(ctx, &d.tick_ring, (size_t)TICK_RING * 8));
     uint64_t nrec = cfg->max_records;
     if (!nrec) {
         size_t free_b = 0, total_b = 0;
@@ -622,25 +622,23 @@ static int tick_locked(chd_ctx *ctx, const chd_tick_in *in) {
     if (r.n < CHD_HIST_BITS) r.n++;
     r.cur_tick++;
     hipStream_t st = ctx->stream;
-    const bool prof = ctx->profiling;
-    if (prof && !ctx->ev_valid) {
-        for (auto &e : ctx->ev) HIPCHK(hipEventCreate(&e));
-        ctx->ev_valid = true;
-    }
+    const bool prof = ctx->prof_depth > 0;
+    hipEvent_t *ev = prof ? &ctx->ev[(size_t)(r.cur_tick % (uint32_t)ctx->prof_depth) * (CHD_N_STAGES + 1)] : nullptr;
     HIPCHK(hipMemsetAsync(d.counters, 0, sizeof(uint32_t) * CTR_COUNT, st));
-    if (prof) HIPCHK(hipEventRecord(ctx->ev[0], st));
+    if (prof) HIPCHK(hipEventRecord(ev[0], st));
     launch_ingest(st, ctx->g, d, in->n_updates, in->upd_idx, in->upd_x, in->upd_z, in->upd_sender, r.cur_tick);
     launch_cell_updates(st, ctx->g, d, in->n_cell_updates, in->cell_upd_channel, in->cell_upd_sender, r.cur_tick);
-    if (prof) HIPCHK(hipEventRecord(ctx->ev[1], st));
+    if (prof) HIPCHK(hipEventRecord(ev[1], st));
     launch_index_build(st, ctx->g, d, r.cur_tick);
-    if (prof) HIPCHK(hipEventRecord(ctx->ev[2], st));
+    if (prof) HIPCHK(hipEventRecord(ev[2], st));
     launch_aoi_interest(st, ctx->g, ctx->lim, d, in->queries, in->n_queries, in->query_sub, in->spot_x, in->spot_z,
                         in->spot_dist, in->now_ns, r.cur_tick);
-    if (prof) HIPCHK(hipEventRecord(ctx->ev[3], st));
+    if (prof) HIPCHK(hipEventRecord(ev[3], st));
     launch_fanout_plan(st, ctx->g, d, in->now_ns, r);
-    if (prof) HIPCHK(hipEventRecord(ctx->ev[4], st));
+    if (prof) HIPCHK(hipEventRecord(ev[4], st));
     launch_fanout_emit(st, ctx->g, d, in->now_ns, r);
-    if (prof) HIPCHK(hipEventRecord(ctx->ev[5], st));
+    if (prof) HIPCHK(hipEventRecord(ev[5], st));
+    launch_tick_epilogue(st, d, r.cur_tick % TICK_RING);
     TRY(after_launch(ctx));
     W.last_nq = in->n_queries;
     W.ticked = true;
@@ -724,11 +722,12 @@ static int fetch_locked(chd_ctx *ctx, chd_tick_out *out) {
     s.n_handovers = out->n_handovers;
     s.n_unsubs = out->n_unsubs;
     s.n_pairs = ctr[CTR_PAIRS];
-    if (ctx->profiling && ctx->ev_valid) {
+    if (ctx->prof_depth > 0) {
+        hipEvent_t *ev = &ctx->ev[(size_t)(ctx->ring.cur_tick % (uint32_t)ctx->prof_depth) * (CHD_N_STAGES + 1)];
         float tot = 0;
         for (int k = 0; k < CHD_N_STAGES; k++) {
             float ms = 0;
-            (void)hipEventElapsedTime(&ms, ctx->ev[k], ctx->ev[k + 1]);
+            (void)hipEventElapsedTime(&ms, ev[k], ev[k + 1]);
             s.stage_us[k] = ms * 1000.f;
             tot += ms * 1000.f;
         }
@@ -876,10 +875,59 @@ int chd_dev_download(chd_ctx *ctx, void *dst, const void *d_src, uint64_t bytes)
     return CHD_OK;
 }
 
-int chd_set_profiling(chd_ctx *ctx, int enabled) {
+int chd_set_profiling(chd_ctx *ctx, int depth) {
     if (!ctx) return fail(nullptr, CHD_E_INVAL, "NULL ctx");
+    if (depth < 0 || depth > TICK_RING) return fail(ctx, CHD_E_INVAL, "profiling depth must be in [0, %d]", TICK_RING);
     std::lock_guard<std::mutex> lk(ctx->mu);
-    ctx->profiling = enabled != 0;
+    TRY(bind(ctx));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    for (auto &e : ctx->ev) (void)hipEventDestroy(e);
+    ctx->ev.clear();
+    ctx->prof_depth = 0;
+    if (depth > 0) {
+        ctx->ev.resize((size_t)depth * (CHD_N_STAGES + 1));
+        for (auto &e : ctx->ev) HIPCHK(hipEventCreate(&e));
+        // record every event once so that elapsed-time queries on unused slots are defined
+        for (auto &e : ctx->ev) HIPCHK(hipEventRecord(e, ctx->stream));
+        HIPCHK(hipStreamSynchronize(ctx->stream));
+        ctx->prof_depth = depth;
+    }
+    return CHD_OK;
+}
+
+int chd_get_tick_history(chd_ctx *ctx, uint32_t n, chd_tick_stats *out) {
+    NEED_WORLD();
+    if (!out || n == 0 || n > TICK_RING) return fail(ctx, CHD_E_INVAL, "chd_get_tick_history: bad arguments");
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    TRY(bind(ctx));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    std::vector<uint64_t> ring((size_t)TICK_RING * 8);
+    HIPCHK(hipMemcpy(ring.data(), ctx->w.d.tick_ring, ring.size() * sizeof(uint64_t), hipMemcpyDeviceToHost));
+    const uint32_t cur = ctx->ring.cur_tick;
+    for (uint32_t k = 0; k < n; k++) {
+        chd_tick_stats &s = out[k];
+        memset(&s, 0, sizeof s);
+        if (k >= cur) continue;  // before the first tick
+        const uint32_t tick = cur - k;
+        const uint64_t *r = &ring[(size_t)(tick % TICK_RING) * 8];
+        s.n_records = r[0];
+        s.n_record_upper_bound = r[1];
+        s.n_handovers = (uint32_t)r[2];
+        s.n_unsubs = (uint32_t)r[4];
+        s.n_pairs = (uint32_t)r[6];
+        s.algorithmic_bytes = 12ull * s.n_records + 32ull * s.n_handovers;
+        if (ctx->prof_depth > 0 && k < (uint32_t)ctx->prof_depth) {
+            hipEvent_t *ev = &ctx->ev[(size_t)(tick % (uint32_t)ctx->prof_depth) * (CHD_N_STAGES + 1)];
+            float tot = 0;
+            for (int j = 0; j < CHD_N_STAGES; j++) {
+                float ms = 0;
+                (void)hipEventElapsedTime(&ms, ev[j], ev[j + 1]);
+                s.stage_us[j] = ms * 1000.f;
+                tot += ms * 1000.f;
+            }
+            s.total_us = tot;
+        }
+    }
     return CHD_OK;
 }
 

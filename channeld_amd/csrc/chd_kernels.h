@@ -43,6 +43,7 @@ struct WorldDev {
     uint32_t *newsub_sub, *newsub_cell, *newsub_iv; uint32_t newsub_cap;
     int32_t *q_status;    // [S]
     uint32_t *counters;   // CTR_COUNT
+    uint64_t *tick_ring;  // [TICK_RING][8] per-tick totals written by the epilogue
 };
 
 // ---- stateless ----
@@ -81,6 +82,7 @@ void launch_index_build(hipStream_t st, DevGrid g, WorldDev w, uint32_t cur_tick
 struct AoiLimits {
     uint32_t maxax;   // samples per lattice axis
     uint32_t winmax;  // cells in the per-query table
+    uint32_t maxdim;  // max(window width, window height) <= max(cols, rows)
 };
 void launch_aoi_stateless(hipStream_t st, DevGrid g, AoiLimits lim, const chd_aoi_query *q,
                           uint32_t nq, const double *spot_x, const double *spot_z,
@@ -102,3 +104,5 @@ void launch_csr_gather(hipStream_t st, uint32_t nq, uint32_t stride, const uint3
 // K5: fan-out
 void launch_fanout_plan(hipStream_t st, DevGrid g, WorldDev w, int64_t now_ns, TickRing ring);
 void launch_fanout_emit(hipStream_t st, DevGrid g, WorldDev w, int64_t now_ns, TickRing ring);
+#define TICK_RING 1024
+void launch_tick_epilogue(hipStream_t st, WorldDev w, uint32_t slot);

@@ -217,3 +217,30 @@ void launch_fanout_emit(hipStream_t st, DevGrid g, WorldDev w, int64_t now_ns, T
     hipLaunchKernelGGL(k_fanout_emit, dim3((w.S + FO_WAVES - 1) / FO_WAVES), dim3(64 * FO_WAVES), 0, st, g, w,
                        now_ns, ring);
 }
+
+// per-tick totals into the device-side history ring (read back by chd_get_tick_history)
+__global__ void __launch_bounds__(1024) k_tick_epilogue(WorldDev w, uint32_t slot) {
+    __shared__ unsigned long long part[16];
+    unsigned long long sum = 0;
+    for (uint32_t s = threadIdx.x; s < w.S; s += 1024) sum += w.rec_cnt[s];
+    for (int d = 32; d >= 1; d >>= 1) sum += __shfl_xor(sum, d);
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = sum;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        unsigned long long tot = 0;
+        for (int k = 0; k < 16; k++) tot += part[k];
+        uint64_t *r = w.tick_ring + (size_t)slot * 8;
+        r[0] = tot;
+        r[1] = w.rec_ub[w.S];
+        r[2] = w.counters[CTR_HANDOVERS];
+        r[3] = w.counters[CTR_LOCKED];
+        r[4] = w.counters[CTR_UNSUBS];
+        r[5] = w.counters[CTR_NEWSUBS];
+        r[6] = w.counters[CTR_PAIRS];
+        r[7] = (uint64_t)w.counters[CTR_OVERFLOW] | ((uint64_t)w.counters[CTR_HIST_OVERFLOW] << 32);
+    }
+}
+
+void launch_tick_epilogue(hipStream_t st, WorldDev w, uint32_t slot) {
+    hipLaunchKernelGGL(k_tick_epilogue, dim3(1), dim3(1024), 0, st, w, slot);
+}

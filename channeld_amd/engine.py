@@ -205,8 +205,20 @@ class SpatialWorld:
     def sync(self):
         _lib.check(self.ctx, self.lib.chd_sync(self.ctx))
 
-    def set_profiling(self, on: bool):
-        _lib.check(self.ctx, self.lib.chd_set_profiling(self.ctx, 1 if on else 0))
+    def set_profiling(self, depth: int):
+        """depth > 0: HIP events around the stages of each tick, last `depth` ticks kept."""
+        _lib.check(self.ctx, self.lib.chd_set_profiling(self.ctx, int(depth)))
+
+    def history(self, n: int):
+        """Per-tick statistics of the last n ticks, oldest first."""
+        arr = (TickStats * n)()
+        _lib.check(self.ctx, self.lib.chd_get_tick_history(self.ctx, n, arr))
+        out = []
+        for s in reversed(arr):
+            out.append(dict(stage_us=[float(s.stage_us[i]) for i in range(_lib.N_STAGES)], total_us=float(s.total_us),
+                            n_records=int(s.n_records), n_record_upper_bound=int(s.n_record_upper_bound),
+                            n_handovers=int(s.n_handovers), n_unsubs=int(s.n_unsubs), n_pairs=int(s.n_pairs)))
+        return out
 
     def stats(self) -> dict:
         s = TickStats()

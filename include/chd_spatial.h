@@ -288,8 +288,14 @@ typedef struct {
     uint32_t n_handovers, n_unsubs, n_pairs;
     uint64_t algorithmic_bytes; /* DESIGN.md §4 byte model for the last tick */
 } chd_tick_stats;
-int chd_set_profiling(chd_ctx *ctx, int enabled); /* HIP events around stages */
+/* depth > 0: record HIP events around the stages of the next ticks, keeping the
+ * last `depth` ticks (<= 1024); 0 turns it off. */
+int chd_set_profiling(chd_ctx *ctx, int depth);
 int chd_get_tick_stats(chd_ctx *ctx, chd_tick_stats *out);
+/* Statistics of the last n ticks (out[0] = most recent), n <= 1024.  Counts come
+ * from a device-side ring written by every tick; stage times need profiling.
+ * Synchronises the stream. */
+int chd_get_tick_history(chd_ctx *ctx, uint32_t n, chd_tick_stats *out);
 
 #ifdef __cplusplus
 }

@@ -82,6 +82,7 @@ typedef struct orc_world {
     uint64_t literal_mismatch;
     uint32_t *server_of_cell;
     int threads;
+    struct fan_job_s *jobs; int njobs; /* per-thread record buffers, kept across ticks */
 } orc_world;
 
 static void wbuf_push(wbuf *b, orc_time t, uint32_t sender, uint32_t max_interval_ms) {
@@ -142,6 +143,8 @@ orc_world *orc_world_new(const orc_grid *g, uint32_t n_entities, uint32_t n_subs
     return w;
 }
 
+static void orc__free_jobs(orc_world *w);
+
 void orc_world_free(orc_world *w) {
     if (!w) return;
     for (uint32_t i = 0; i < w->N; i++) free(w->ebuf[i].v);
@@ -152,6 +155,7 @@ void orc_world_free(orc_world *w) {
     free(w->rec); free(w->ho_ent); free(w->ho_src); free(w->ho_dst);
     free(w->ho_srv_src); free(w->ho_srv_dst); free(w->unsub_sub);
     free(w->unsub_cell); free(w->q_status); free(w->server_of_cell);
+    orc__free_jobs(w);
     free(w);
 }
 
@@ -242,7 +246,7 @@ static uint32_t pair_windows(wpair *p, orc_time t, wwin *out, uint32_t cap) {
 /* ---- per-cell subscriber buckets ---- */
 typedef struct { uint32_t s, p; } spref;
 
-typedef struct {
+typedef struct fan_job_s {
     orc_world *w;
     orc_time t;
     const uint32_t *cell_off_sub; const spref *cell_subs;
@@ -250,6 +254,13 @@ typedef struct {
     uint32_t c0, c1;
     wrec *rec; uint64_t nrec, caprec;
 } fan_job;
+
+static void orc__free_jobs(orc_world *w) {
+    for (int k = 0; k < w->njobs; k++) free(w->jobs[k].rec);
+    free(w->jobs);
+    w->jobs = NULL;
+    w->njobs = 0;
+}
 
 static void job_push(fan_job *j, uint32_t conn, uint32_t chan) {
     if (j->nrec == j->caprec) {
@@ -377,6 +388,9 @@ int orc_world_tick(orc_world *w, orc_time t, uint32_t n_upd, const uint32_t *idx
                    uint32_t n_cu, const uint32_t *cu_cell, const uint32_t *cu_sender,
                    uint32_t n_q, const uint32_t *q_sub, const orc_query *queries) {
     w->nrec = 0; w->nho = 0; w->nunsub = 0; w->n_locked_abort = 0;
+    /* is_new = "subscribed during the latest tick" */
+    for (uint32_t s = 0; s < w->S; s++)
+        for (uint32_t p = 0; p < w->pair_cnt[s]; p++) w->pairs[(size_t)s * w->capq + p].is_new = 0;
 
     /* ---- 1. entity updates ---- */
     for (uint32_t u = 0; u < n_upd; u++) {
@@ -511,7 +525,13 @@ int orc_world_tick(orc_world *w, orc_time t, uint32_t n_upd, const uint32_t *idx
     } else {
         int nt = w->threads;
         if ((uint32_t)nt > w->C) nt = (int)w->C;
-        fan_job *jobs = (fan_job *)calloc((size_t)nt, sizeof(fan_job));
+        if (w->njobs != nt) {
+            for (int k = 0; k < w->njobs; k++) free(w->jobs[k].rec);
+            free(w->jobs);
+            w->jobs = (fan_job *)calloc((size_t)nt, sizeof(fan_job));
+            w->njobs = nt;
+        }
+        fan_job *jobs = w->jobs;
         pthread_t *th = (pthread_t *)calloc((size_t)nt, sizeof(pthread_t));
         /* static partition of the cells (channels) over the host threads,
          * balanced by work = subs x (entities + 1) */
@@ -521,7 +541,7 @@ int orc_world_tick(orc_world *w, orc_time t, uint32_t n_upd, const uint32_t *idx
         uint32_t c = 0;
         uint64_t acc = 0;
         for (int k = 0; k < nt; k++) {
-            jobs[k].w = w; jobs[k].t = t;
+            jobs[k].w = w; jobs[k].t = t; jobs[k].nrec = 0;
             jobs[k].cell_off_sub = cell_off_sub; jobs[k].cell_subs = cell_subs;
             jobs[k].cell_off_ent = cell_off_ent; jobs[k].cell_ents = cell_ents;
             jobs[k].c0 = c;
@@ -537,16 +557,9 @@ int orc_world_tick(orc_world *w, orc_time t, uint32_t n_upd, const uint32_t *idx
             for (int k = 0; k < nt; k++) pthread_create(&th[k], NULL, fan_cells, &jobs[k]);
             for (int k = 0; k < nt; k++) pthread_join(th[k], NULL);
         }
-        for (int k = 0; k < nt; k++) {
-            if (w->nrec + jobs[k].nrec > w->caprec) {
-                w->caprec = (w->nrec + jobs[k].nrec) * 2;
-                w->rec = (wrec *)realloc(w->rec, w->caprec * sizeof(wrec));
-            }
-            if (jobs[k].nrec) memcpy(w->rec + w->nrec, jobs[k].rec, jobs[k].nrec * sizeof(wrec));
-            w->nrec += jobs[k].nrec;
-            free(jobs[k].rec);
-        }
-        free(jobs); free(th);
+        w->nrec = 0;
+        for (int k = 0; k < nt; k++) w->nrec += jobs[k].nrec;
+        free(th);
     }
     free(cell_off_sub); free(cell_off_ent); free(cell_subs); free(cell_ents);
     return 0;
@@ -555,7 +568,13 @@ int orc_world_tick(orc_world *w, orc_time t, uint32_t n_upd, const uint32_t *idx
 /* ---- accessors ---- */
 uint64_t orc_world_nrec(const orc_world *w) { return w->nrec; }
 void orc_world_records(const orc_world *w, uint32_t *conn, uint32_t *chan) {
-    for (uint64_t i = 0; i < w->nrec; i++) { conn[i] = w->rec[i].conn; chan[i] = w->rec[i].chan; }
+    if (w->literal) {
+        for (uint64_t i = 0; i < w->nrec; i++) { conn[i] = w->rec[i].conn; chan[i] = w->rec[i].chan; }
+        return;
+    }
+    uint64_t o = 0;
+    for (int k = 0; k < w->njobs; k++)
+        for (uint64_t i = 0; i < w->jobs[k].nrec; i++, o++) { conn[o] = w->jobs[k].rec[i].conn; chan[o] = w->jobs[k].rec[i].chan; }
 }
 uint32_t orc_world_nhandover(const orc_world *w) { return w->nho; }
 void orc_world_handovers(const orc_world *w, uint32_t *ent, uint32_t *src, uint32_t *dst,

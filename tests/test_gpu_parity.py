@@ -170,7 +170,7 @@ def test_query_errors(amd):
 
 
 # ---------------------------------------------------------------- QueryChannelIds random
-def random_queries(amd, rng, grid, n, multi=False):
+def random_queries(amd, rng, grid, n, multi=False, local_spots=False):
     gw, gh, offx, offz, cols, rows = grid[:6]
     W, H = gw * cols, gh * rows
     qs, obs = [], []
@@ -204,7 +204,10 @@ def random_queries(amd, rng, grid, n, multi=False):
             kw_o["cone"] = (cx, cz, dx, dz, r * 1.5, ang)
         if kind == 3 or kind == 4:
             m = int(rng.integers(1, 6))
-            spots = [(offx + rng.uniform(-0.1, 1.1) * W, offz + rng.uniform(-0.1, 1.1) * H) for _ in range(m)]
+            if local_spots:
+                spots = [(cx + rng.uniform(-10, 10) * gw, cz + rng.uniform(-10, 10) * gh) for _ in range(m)]
+            else:
+                spots = [(offx + rng.uniform(-0.1, 1.1) * W, offz + rng.uniform(-0.1, 1.1) * H) for _ in range(m)]
             if m > 2:
                 spots[2] = spots[0]  # same cell twice: the later spot wins
             dists = [int(v) for v in rng.integers(0, 5, int(rng.integers(0, m + 1)))]
@@ -274,6 +277,28 @@ def test_query_benchmark_shapes_many(amd):
         assert np.array_equal(ids[a:b], oid[: n.value]) and np.array_equal(dists[a:b], odist[: n.value])
         total += n.value
     assert total > 100000
+
+
+def test_query_large_grid_window_path(amd):
+    # 14400 cells > the 4096-cell table: the per-query cell window is used
+    grid = (50, 50, -3000, -3000, 120, 120)
+    ctl = make_ctl(amd, *grid)
+    g = orc.grid(*grid)
+    rng = np.random.default_rng(99)
+    n = 1200
+    qs, obs = random_queries(amd, rng, grid, n, multi=True, local_spots=True)
+    status, res = ctl.query_channel_ids_batch(qs)
+    n_ok = 0
+    for i in range(n):
+        rc, want = orc.query_channel_ids(g, obs[i])
+        assert int(status[i]) == rc and res[i] == want, f"query {i}"
+        n_ok += rc == 0
+    assert n_ok > n // 3
+    # a world-wide query exceeds the engine's window and says so instead of guessing
+    from channeld_amd import _lib
+
+    big = amd.SpatialInterestQuery(SphereAOI=amd.SphereAOI(Center=amd.SpatialInfo(X=0, Z=0), Radius=2900))
+    assert ctl.QueryChannelIds(big)[1].code == _lib.E_TOO_LARGE
 
 
 # ---------------------------------------------------------------- regions / adjacency / servers
