@@ -1,0 +1,122 @@
+"""C-ABI surface checks that need no GPU: libchd_spatial.so loads, exports every
+symbol include/chd_spatial.h declares (and nothing the header does not know), the
+ctypes mirrors have the header's struct sizes, and — on a box without a gfx950
+device — the library refuses to create a context instead of falling back to a
+CPU path."""
+import ctypes as C
+import os
+import re
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HEADER = os.path.join(ROOT, "include", "chd_spatial.h")
+
+
+def header_symbols():
+    src = open(HEADER).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(chd_[a-z0-9_]+)\s*\(", src)))
+
+
+@pytest.fixture(scope="module")
+def lib():
+    from channeld_amd import build
+
+    return C.CDLL(build.build())
+
+
+def test_header_and_binding_agree():
+    from channeld_amd import _lib
+
+    assert sorted(_lib.SYMBOLS) == header_symbols()
+
+
+def test_every_declared_symbol_is_exported(lib):
+    missing = [s for s in header_symbols() if not hasattr(lib, s)]
+    assert not missing, missing
+
+
+def test_no_undeclared_chd_exports():
+    from channeld_amd import build
+
+    out = subprocess.run(["nm", "-D", "--defined-only", build.build()], capture_output=True, text=True, check=True).stdout
+    exported = sorted({l.split()[-1] for l in out.splitlines() if " T " in l and l.split()[-1].startswith("chd_")})
+    assert exported == header_symbols()
+
+
+def test_abi_version(lib):
+    lib.chd_abi_version.restype = C.c_int
+    src = open(HEADER).read()
+    assert lib.chd_abi_version() == int(re.search(r"#define CHD_ABI_VERSION (\d+)", src).group(1))
+
+
+def test_struct_sizes_match_header(tmp_path):
+    """sizeof() as the C compiler sees the header vs the ctypes mirrors."""
+    from channeld_amd import _lib
+
+    names = {
+        "chd_grid_cfg": _lib.GridCfg, "chd_aoi_query": _lib.AoiQuery, "chd_world_cfg": _lib.WorldCfg,
+        "chd_fanout_rec": _lib.FanoutRec, "chd_handover_rec": _lib.HandoverRec, "chd_tick_in": _lib.TickIn,
+        "chd_tick_out": _lib.TickOut, "chd_tick_stats": _lib.TickStats,
+    }
+    prog = '#include <stdio.h>\n#include "chd_spatial.h"\nint main(void){\n'
+    for n in names:
+        prog += f'  printf("{n} %zu\\n", sizeof({n}));\n'
+    prog += "  return 0; }\n"
+    c = tmp_path / "sz.c"
+    c.write_text(prog)
+    exe = tmp_path / "sz"
+    subprocess.run(["gcc", "-std=c11", "-I", os.path.join(ROOT, "include"), str(c), "-o", str(exe)], check=True)
+    out = subprocess.run([str(exe)], capture_output=True, text=True, check=True).stdout
+    sizes = dict(l.split() for l in out.splitlines())
+    for n, t in names.items():
+        assert int(sizes[n]) == C.sizeof(t), n
+
+
+def test_header_compiles_as_c_and_cxx(tmp_path):
+    c = tmp_path / "h.c"
+    c.write_text('#include "chd_spatial.h"\nint main(void){return CHD_OK;}\n')
+    subprocess.run(["gcc", "-std=c99", "-Wall", "-Werror", "-I", os.path.join(ROOT, "include"), "-c", str(c), "-o", str(tmp_path / "h.o")], check=True)
+    subprocess.run(["g++", "-x", "c++", "-std=c++11", "-Wall", "-Werror", "-I", os.path.join(ROOT, "include"), "-c", str(c), "-o", str(tmp_path / "h2.o")], check=True)
+
+
+def _no_gpu():
+    try:
+        import torch
+
+        return not torch.cuda.is_available()
+    except Exception:
+        return True
+
+
+@pytest.mark.skipif(not _no_gpu(), reason="a GPU is visible")
+def test_no_device_means_no_context():
+    """No CPU fallback: without a gfx950 device chd_create fails loudly."""
+    import json
+
+    import channeld_amd as A
+    from channeld_amd import _lib, synth
+
+    cfg = synth.load_config("spatial_static_2x2.json")
+    ctl = A.StaticGrid2DSpatialController(device=0)
+    with pytest.raises(_lib.ChdError) as e:
+        ctl.LoadConfig(json.dumps(cfg).encode(), strict=False)
+    assert e.value.code == _lib.E_NO_DEVICE
+
+
+def test_product_never_touches_the_oracle():
+    """Nothing under channeld_amd/ (product) or include/ may import, link or load oracle/."""
+    bad = []
+    for base in ("channeld_amd", "include"):
+        for dp, _, fns in os.walk(os.path.join(ROOT, base)):
+            if "__pycache__" in dp or os.path.basename(dp) == "build":
+                continue
+            for fn in fns:
+                if not fn.endswith((".py", ".hip", ".h", ".cpp", ".c")):
+                    continue
+                txt = open(os.path.join(dp, fn), errors="ignore").read()
+                if re.search(r"liboracle|pyoracle|from oracle|import oracle|chd_oracle\.h|orc_", txt):
+                    bad.append(os.path.join(dp, fn))
+    assert not bad, bad
