@@ -137,14 +137,23 @@ int walloc(chd_ctx *ctx, T **out, size_t count, bool zero = true) {
 
 }  // namespace
 
-// dense per-connection packing of the emitted records (for the host-facing fetch)
+// dense per-connection packing of the emitted records (for the host-facing fetch):
+// a connection's records sit in one segment per subscription inside its range
 __global__ void __launch_bounds__(256) k_pack_records(WorldDev w, const uint64_t *exact_off, chd_fanout_rec *dense) {
     uint32_t s = blockIdx.x * 4u + (threadIdx.x >> 6);
     if (s >= w.S) return;
-    uint32_t n = w.rec_cnt[s];
-    const chd_fanout_rec *src = w.recs + w.rec_ub[s];
+    if (w.rec_cnt[s] == 0) return;
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t cnt = w.pair_cnt[s];
+    const size_t pbase = (size_t)s * w.capq;
+    const chd_fanout_rec *base = w.recs + w.rec_ub[s];
     chd_fanout_rec *dst = dense + exact_off[s];
-    for (uint32_t k = threadIdx.x & 63u; k < n; k += 64) dst[k] = src[k];
+    for (uint32_t p = 0; p < cnt; p++) {
+        const uint32_t n = w.pair_nrec[pbase + p];
+        const chd_fanout_rec *src = base + w.pair_rel[pbase + p];
+        for (uint32_t k = lane; k < n; k += 64) dst[k] = src[k];
+        dst += n;
+    }
 }
 
 __global__ void __launch_bounds__(256) k_widen(const uint32_t *in, uint64_t *out, uint32_t n) {
@@ -476,10 +485,8 @@ int chd_world_create(chd_ctx *ctx, const chd_world_cfg *cfg) {
     TRY(walloc(ctx, &d.cell_sender, C));
     d.nblk = (C <= 4096) ? index_num_blocks(d.N) : 1;
     TRY(walloc(ctx, &d.blk_cnt, std::max(C * d.nblk + 1, 2 * C + 2)));
-    TRY(walloc(ctx, &d.ce_ent, N));
-    TRY(walloc(ctx, &d.ce_chan, N));
-    TRY(walloc(ctx, &d.ce_hist, N));
-    TRY(walloc(ctx, &d.ce_sender, N));
+    TRY(walloc(ctx, &d.ce, N));
+    TRY(walloc(ctx, &d.cell_off, C + 1));
     TRY(walloc(ctx, &d.conn_id, S));
     TRY(walloc(ctx, &d.sub_alive, S));
     TRY(walloc(ctx, &d.sub_tick, S));
@@ -488,6 +495,8 @@ int chd_world_create(chd_ctx *ctx, const chd_world_cfg *cfg) {
     TRY(walloc(ctx, &d.pair_iv, P));
     TRY(walloc(ctx, &d.pair_last, P));
     TRY(walloc(ctx, &d.pair_flags, P));
+    TRY(walloc(ctx, &d.pair_rel, P));
+    TRY(walloc(ctx, &d.pair_nrec, P));
     TRY(walloc(ctx, &d.rec_ub, S + 1));
     TRY(walloc(ctx, &d.rec_cnt, S));
     TRY(walloc(ctx, &W.rec_off_exact, S + 1));
@@ -502,6 +511,7 @@ int chd_world_create(chd_ctx *ctx, const chd_world_cfg *cfg) {
     TRY(walloc(ctx, &d.newsub_iv, d.newsub_cap, false));
     TRY(walloc(ctx, &d.q_status, S));
     TRY(walloc(ctx, &d.counters, CTR_COUNT));
+    TRY(walloc(ctx, &d.tot64, 64 * 16));
     TRY(walloc(ctx, &d.tick_ring, (size_t)TICK_RING * 8));
     uint64_t nrec = cfg->max_records;
     if (!nrec) {
@@ -624,7 +634,6 @@ static int tick_locked(chd_ctx *ctx, const chd_tick_in *in) {
     hipStream_t st = ctx->stream;
     const bool prof = ctx->prof_depth > 0;
     hipEvent_t *ev = prof ? &ctx->ev[(size_t)(r.cur_tick % (uint32_t)ctx->prof_depth) * (CHD_N_STAGES + 1)] : nullptr;
-    HIPCHK(hipMemsetAsync(d.counters, 0, sizeof(uint32_t) * CTR_COUNT, st));
     if (prof) HIPCHK(hipEventRecord(ev[0], st));
     launch_ingest(st, ctx->g, d, in->n_updates, in->upd_idx, in->upd_x, in->upd_z, in->upd_sender, r.cur_tick);
     launch_cell_updates(st, ctx->g, d, in->n_cell_updates, in->cell_upd_channel, in->cell_upd_sender, r.cur_tick);
@@ -658,14 +667,23 @@ static int fetch_locked(chd_ctx *ctx, chd_tick_out *out) {
     WorldDev &d = W.d;
     if (!W.ticked) return fail(ctx, CHD_E_STATE, "no tick to fetch");
     hipStream_t st = ctx->stream;
-    uint32_t ctr[CTR_COUNT];
+    uint32_t ctr[CTR_COUNT] = {0};
+    uint64_t ringrow[8];
     // exact per-connection offsets
     hipLaunchKernelGGL(k_widen, dim3((d.S + 255) / 256), dim3(256), 0, st, d.rec_cnt, W.rec_off_exact, d.S);
     launch_scan_u64_inplace(st, W.rec_off_exact, d.S);
-    TRY(down(ctx, ctr, d.counters, sizeof ctr));
+    // the per-tick counters were folded into the history ring by the tick's epilogue
+    TRY(down(ctx, ringrow, d.tick_ring + (size_t)(ctx->ring.cur_tick % TICK_RING) * 8, sizeof ringrow));
     uint64_t total = 0;
     TRY(down(ctx, &total, W.rec_off_exact + d.S, sizeof total));
     HIPCHK(hipStreamSynchronize(st));
+    ctr[CTR_HANDOVERS] = (uint32_t)ringrow[2];
+    ctr[CTR_LOCKED] = (uint32_t)ringrow[3];
+    ctr[CTR_UNSUBS] = (uint32_t)ringrow[4];
+    ctr[CTR_NEWSUBS] = (uint32_t)ringrow[5];
+    ctr[CTR_PAIRS] = (uint32_t)ringrow[6];
+    ctr[CTR_OVERFLOW] = (uint32_t)(ringrow[7] & 0xFFFFFFFFu);
+    ctr[CTR_HIST_OVERFLOW] = (uint32_t)(ringrow[7] >> 32);
     out->n_handovers = std::min(ctr[CTR_HANDOVERS], d.handovers_cap);
     out->n_locked_aborts = ctr[CTR_LOCKED];
     out->n_unsubs = std::min(ctr[CTR_UNSUBS], d.unsub_cap);

@@ -24,7 +24,8 @@ struct WorldDev {
     // cell index (rebuilt every tick)
     uint32_t nblk;        // histogram blocks
     uint32_t *blk_cnt;    // [ncell*nblk + 1] counts -> exclusive scan (cell-major)
-    uint32_t *ce_ent, *ce_chan, *ce_hist, *ce_sender;  // [N] sorted by cell
+    uint4 *ce;            // [N] sorted by cell: {entity channel id, history aligned to this tick, sender, slot}
+    uint32_t *cell_off;   // [ncell+1] cell c owns ce[cell_off[c], cell_off[c+1])
     // subscribers
     uint32_t *conn_id;    // [S]
     uint32_t *sub_alive;  // [S]
@@ -34,15 +35,18 @@ struct WorldDev {
     uint32_t *pair_iv;    // [S*capq] FanOutIntervalMs
     int64_t *pair_last;   // [S*capq] lastFanOutTime
     uint32_t *pair_flags; // [S*capq] PF_*
+    uint32_t *pair_rel;   // [S*capq] this tick: segment offset inside the connection's record range
+    uint32_t *pair_nrec;  // [S*capq] this tick: records emitted for the subscription
     // fan-out outputs
-    uint64_t *rec_ub;     // [S+1] upper bound per subscriber -> exclusive scan = rec offsets
-    uint32_t *rec_cnt;    // [S]
+    uint64_t *rec_ub;     // [S+1] upper bound per subscriber -> exclusive scan = base of its record range
+    uint32_t *rec_cnt;    // [S] records emitted for the connection (sum of its pair_nrec)
     chd_fanout_rec *recs; uint64_t recs_cap;
     chd_handover_rec *handovers; uint32_t handovers_cap;
     uint32_t *unsub_sub, *unsub_cell; uint32_t unsub_cap;
     uint32_t *newsub_sub, *newsub_cell, *newsub_iv; uint32_t newsub_cap;
     int32_t *q_status;    // [S]
     uint32_t *counters;   // CTR_COUNT
+    uint64_t *tot64;      // [64][16] hashed per-tick totals, one 128-B line per bucket: {records, subscriptions}
     uint64_t *tick_ring;  // [TICK_RING][8] per-tick totals written by the epilogue
 };
 

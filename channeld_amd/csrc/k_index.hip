@@ -11,9 +11,9 @@
 //   k_index_scatter: stable scatter — ranks inside a block come from wave
 //                    ballots (peer masks by key bits), never from atomics, so the
 //                    per-cell order is by entity slot and the output is
-//                    deterministic.  Writes the SoA the emit kernel streams:
-//                    ce_chan (entity channel id), ce_hist (update history
-//                    aligned to this tick), ce_sender, ce_ent.
+//                    deterministic.  Writes what the emit kernel streams: one
+//                    16-byte entry per entity {entity channel id, update history
+//                    aligned to this tick, sender, entity slot}, and cell_off.
 //
 // Also here: the generic exclusive scans (single workgroup, 1024 lanes,
 // wave-shuffle scan + LDS carry).
@@ -100,10 +100,11 @@ __global__ void __launch_bounds__(IDX_BLOCK) k_index_scatter(WorldDev w, uint32_
         uint32_t pos = mycnt[key[r]] + lrank[r];
         uint32_t age = cur_tick - w.hist_tick[i];
         uint32_t h = (age >= CHD_HIST_BITS) ? 0u : (w.hist[i] << age);
-        w.ce_ent[pos] = i;
-        w.ce_chan[pos] = w.chan_id[i];
-        w.ce_hist[pos] = h;
-        w.ce_sender[pos] = w.sender[i];
+        w.ce[pos] = make_uint4(w.chan_id[i], h, w.sender[i], i);
+    }
+    // compact cell offsets for the fan-out kernels (blk_cnt is cell-major with stride nblk)
+    if (blockIdx.x == 0) {
+        for (uint32_t c = threadIdx.x; c <= ncell; c += IDX_BLOCK) w.cell_off[c] = w.blk_cnt[(size_t)c * w.nblk];
     }
 }
 
@@ -127,10 +128,7 @@ __global__ void __launch_bounds__(256) k_index_scatter_global(WorldDev w, uint32
     uint32_t pos = w.blk_cnt[m] + atomicAdd(&cursor[m], 1u);
     uint32_t age = cur_tick - w.hist_tick[i];
     uint32_t h = (age >= CHD_HIST_BITS) ? 0u : (w.hist[i] << age);
-    w.ce_ent[pos] = i;
-    w.ce_chan[pos] = w.chan_id[i];
-    w.ce_hist[pos] = h;
-    w.ce_sender[pos] = w.sender[i];
+    w.ce[pos] = make_uint4(w.chan_id[i], h, w.sender[i], i);
 }
 
 // ------------------------------------------------------------------------
@@ -148,6 +146,7 @@ __device__ __forceinline__ T wave_incl_scan(T v) {
     return v;
 }
 
+#define SCAN_ITEMS 4
 template <typename T>
 __global__ void __launch_bounds__(1024) k_scan_excl(const T *in, T *out, uint32_t n) {
     __shared__ T wtot[16];
@@ -155,18 +154,30 @@ __global__ void __launch_bounds__(1024) k_scan_excl(const T *in, T *out, uint32_
     const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     if (threadIdx.x == 0) carry_s = 0;
     __syncthreads();
-    for (uint32_t base = 0; base < n; base += 1024) {
-        uint32_t i = base + threadIdx.x;
-        T v = (i < n) ? in[i] : (T)0;
-        T inc = wave_incl_scan(v);
+    // each lane owns SCAN_ITEMS consecutive elements of a 4096-element tile
+    for (uint32_t base = 0; base < n; base += 1024 * SCAN_ITEMS) {
+        const uint32_t i0 = base + threadIdx.x * SCAN_ITEMS;
+        T v[SCAN_ITEMS];
+        T sum = 0;
+#pragma unroll
+        for (int k = 0; k < SCAN_ITEMS; k++) {
+            v[k] = (i0 + k < n) ? in[i0 + k] : (T)0;
+            sum += v[k];
+        }
+        T inc = wave_incl_scan(sum);
         if (lane == 63) wtot[wave] = inc;
         __syncthreads();
         T carry = carry_s;
         T woff = 0;
         for (uint32_t k = 0; k < wave; k++) woff += wtot[k];
-        if (i < n) out[i] = carry + woff + inc - v;
+        T run = carry + woff + inc - sum;
+#pragma unroll
+        for (int k = 0; k < SCAN_ITEMS; k++) {
+            if (i0 + k < n) out[i0 + k] = run;
+            run += v[k];
+        }
         __syncthreads();
-        if (threadIdx.x == 1023) carry_s = carry + woff + inc;
+        if (threadIdx.x == 1023) carry_s = run;
         __syncthreads();
     }
     if (threadIdx.x == 0) out[n] = carry_s;
@@ -201,6 +212,7 @@ void launch_index_build(hipStream_t st, DevGrid g, WorldDev w, uint32_t cur_tick
         (void)hipMemsetAsync(w.blk_cnt, 0, sizeof(uint32_t) * (2 * (size_t)g.ncell + 2), st);
         hipLaunchKernelGGL(k_index_hist_global, dim3((w.N + 255) / 256), dim3(256), 0, st, w, g.ncell);
         launch_scan_u32_inplace(st, w.blk_cnt, g.ncell);
+        (void)hipMemcpyAsync(w.cell_off, w.blk_cnt, sizeof(uint32_t) * ((size_t)g.ncell + 1), hipMemcpyDeviceToDevice, st);
         hipLaunchKernelGGL(k_index_scatter_global, dim3((w.N + 255) / 256), dim3(256), 0, st, w, g.ncell, cursor,
                            cur_tick);
     }

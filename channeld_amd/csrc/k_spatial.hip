@@ -252,55 +252,78 @@ void launch_subs_add(hipStream_t st, WorldDev w, uint32_t n, const uint32_t *slo
 // Traffic per update: 16 B (x,z) + 4 B cell R + 4 B cell W + 8 B history R/W
 // + 4 B flags; handover records are rare (1-2 %).
 // ------------------------------------------------------------------------
+#define ING_ITEMS 1
 __global__ void __launch_bounds__(256) k_ingest(DevGrid g, WorldDev w, uint32_t n,
                                                 const uint32_t *__restrict__ idx,
                                                 const double *__restrict__ x,
                                                 const double *__restrict__ z,
                                                 const uint32_t *__restrict__ sender,
                                                 uint32_t cur_tick) {
-    uint32_t u = blockIdx.x * 256u + threadIdx.x;
-    bool ho = false, locked = false;
-    uint32_t i = 0, src = CHD_INVALID, dst = CHD_INVALID;
-    if (u < n) {
-        i = idx ? idx[u] : u;
-        uint32_t ef = (i < w.N) ? w.eflags[i] : 0u;
-        if (ef & EF_ALIVE) {
-            dst = cell_of(g, x[u], z[u]);
-            src = w.cell[i];
-            w.cell[i] = dst;
-            uint32_t age = cur_tick - w.hist_tick[i];
-            uint32_t h = (age >= CHD_HIST_BITS) ? 0u : (w.hist[i] << age);
-            w.hist[i] = h | 1u;
-            w.hist_tick[i] = cur_tick;
-            if (sender) w.sender[i] = sender[u];
-            if (src != CHD_INVALID && dst != CHD_INVALID && src != dst) {
-                if (ef & EF_LOCKED) locked = true;
-                else ho = true;
+    // handover records are compacted per wave (ballot + mbcnt) and per workgroup
+    // (LDS), so the global counter sees ONE atomic per 1024 updates: same-address
+    // atomics serialise at ~12 ns each and would otherwise dominate this kernel.
+    __shared__ uint32_t s_cnt[4 * ING_ITEMS], s_lock[4 * ING_ITEMS];
+    const uint32_t wave = threadIdx.x >> 6, lane = lane_id();
+    bool ho[ING_ITEMS], locked[ING_ITEMS];
+    uint32_t ent[ING_ITEMS], src[ING_ITEMS], dst[ING_ITEMS];
+    uint64_t hm[ING_ITEMS];
+#pragma unroll
+    for (int j = 0; j < ING_ITEMS; j++) {
+        const uint32_t u = (blockIdx.x * ING_ITEMS + j) * 256u + threadIdx.x;
+        ho[j] = false; locked[j] = false;
+        ent[j] = 0; src[j] = CHD_INVALID; dst[j] = CHD_INVALID;
+        if (u < n) {
+            const uint32_t i = idx ? idx[u] : u;
+            ent[j] = i;
+            uint32_t ef = (i < w.N) ? w.eflags[i] : 0u;
+            if (ef & EF_ALIVE) {
+                dst[j] = cell_of(g, x[u], z[u]);
+                src[j] = w.cell[i];
+                w.cell[i] = dst[j];
+                uint32_t age = cur_tick - w.hist_tick[i];
+                uint32_t h = (age >= CHD_HIST_BITS) ? 0u : (w.hist[i] << age);
+                w.hist[i] = h | 1u;
+                w.hist_tick[i] = cur_tick;
+                if (sender) w.sender[i] = sender[u];
+                if (src[j] != CHD_INVALID && dst[j] != CHD_INVALID && src[j] != dst[j]) {
+                    if (ef & EF_LOCKED) locked[j] = true;
+                    else ho[j] = true;
+                }
             }
         }
+        hm[j] = __ballot(ho[j]);
+        uint64_t lm = __ballot(locked[j]);
+        if (lane == 0) {
+            s_cnt[wave * ING_ITEMS + j] = (uint32_t)__popcll(hm[j]);
+            s_lock[wave * ING_ITEMS + j] = (uint32_t)__popcll(lm);
+        }
     }
-    uint64_t lm = __ballot(locked);
-    uint64_t hm = __ballot(ho);
-    if (lm && lane_id() == 0) atomicAdd(&w.counters[CTR_LOCKED], (uint32_t)__popcll(lm));
-    if (hm) {
-        uint32_t base = 0;
-        if (lane_id() == 0) base = atomicAdd(&w.counters[CTR_HANDOVERS], (uint32_t)__popcll(hm));
-        base = __shfl(base, 0);
-        if (ho) {
-            w.member[i] = dst;
-            uint32_t pos = base + mask_rank(hm);
-            if (pos < w.handovers_cap) {
-                chd_handover_rec r;
-                r.entity = i;
-                r.channel = w.chan_id[i];
-                r.src = src + g.id_start;
-                r.dst = dst + g.id_start;
-                r.src_server = server_of(g, src);
-                r.dst_server = server_of(g, dst);
-                w.handovers[pos] = r;
-            } else {
-                atomicOr(&w.counters[CTR_OVERFLOW], OVF_HANDOVER);
-            }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint32_t tot = 0, ltot = 0;
+        for (int k = 0; k < 4 * ING_ITEMS; k++) { tot += s_cnt[k]; ltot += s_lock[k]; }
+        uint32_t base = tot ? atomicAdd(&w.counters[CTR_HANDOVERS], tot) : 0u;
+        if (ltot) atomicAdd(&w.counters[CTR_LOCKED], ltot);
+        for (int k = 0; k < 4 * ING_ITEMS; k++) { uint32_t c = s_cnt[k]; s_cnt[k] = base; base += c; }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < ING_ITEMS; j++) {
+        if (!ho[j]) continue;
+        const uint32_t i = ent[j];
+        w.member[i] = dst[j];
+        uint32_t pos = s_cnt[wave * ING_ITEMS + j] + mask_rank(hm[j]);
+        if (pos < w.handovers_cap) {
+            chd_handover_rec r;
+            r.entity = i;
+            r.channel = w.chan_id[i];
+            r.src = src[j] + g.id_start;
+            r.dst = dst[j] + g.id_start;
+            r.src_server = server_of(g, src[j]);
+            r.dst_server = server_of(g, dst[j]);
+            w.handovers[pos] = r;
+        } else {
+            atomicOr(&w.counters[CTR_OVERFLOW], OVF_HANDOVER);
         }
     }
 }
@@ -308,8 +331,8 @@ __global__ void __launch_bounds__(256) k_ingest(DevGrid g, WorldDev w, uint32_t 
 void launch_ingest(hipStream_t st, DevGrid g, WorldDev w, uint32_t n, const uint32_t *idx,
                    const double *x, const double *z, const uint32_t *sender, uint32_t cur_tick) {
     if (!n) return;
-    hipLaunchKernelGGL(k_ingest, dim3(nblocks(n, 256)), dim3(256), 0, st, g, w, n, idx, x, z, sender,
-                       cur_tick);
+    hipLaunchKernelGGL(k_ingest, dim3(nblocks(n, 256 * ING_ITEMS)), dim3(256), 0, st, g, w, n, idx, x, z,
+                       sender, cur_tick);
 }
 
 // spatial-channel data updates (spawn/destroy merges through OnUpdate)
