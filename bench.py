@@ -100,13 +100,19 @@ def main():
 
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the HIP path has no CPU fallback")
+    if os.environ.get("CHD_BENCH_SHARE_GPU"):  # test hook: several ranks on one GPU (gloo, host-staged exchange)
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dist_on = world_size > 1
     if dist_on:
         import torch.distributed as dist
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        backend = os.environ.get("CHD_DIST_BACKEND", "nccl")  # "nccl" is RCCL on ROCm
+        if backend == "nccl":
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend=backend)
 
     import channeld_amd as A
     from channeld_amd import synth

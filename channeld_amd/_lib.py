@@ -32,6 +32,8 @@ SYMBOLS = (
     "chd_tick_device", "chd_tick_fetch", "chd_sync", "chd_subs_get",
     "chd_world_get_entities", "chd_dev_alloc", "chd_dev_free", "chd_dev_upload",
     "chd_dev_download", "chd_set_profiling", "chd_get_tick_stats", "chd_get_tick_history",
+    "chd_set_stream", "chd_shard_spawn", "chd_shard_ingest", "chd_shard_import", "chd_shard_fanout",
+    "chd_shard_get_entities", "chd_shard_table_bytes",
 )
 
 
@@ -113,6 +115,14 @@ class TickOut(C.Structure):
     ]
 
 
+class EntityState(C.Structure):
+    _fields_ = [("chan_id", C.c_uint32), ("cell", C.c_uint32), ("member", C.c_uint32), ("eflags", C.c_uint32),
+                ("sender", C.c_uint32), ("hist", C.c_uint32), ("_pad", C.c_uint32 * 2)]
+
+
+assert C.sizeof(EntityState) == 32
+
+
 class TickStats(C.Structure):
     _fields_ = [
         ("stage_us", C.c_float * N_STAGES), ("total_us", C.c_float),
@@ -167,6 +177,14 @@ def load():
     L.chd_dev_free.argtypes = [C.c_void_p, C.c_void_p]
     L.chd_dev_upload.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64]
     L.chd_dev_download.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64]
+    L.chd_set_stream.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
+    L.chd_shard_spawn.argtypes = [C.c_void_p, C.c_uint32, _u32p, _f64p, _f64p, _u32p, _u32p]
+    L.chd_shard_ingest.argtypes = [C.c_void_p, C.c_int64, _f64p, _f64p, _u8p, C.c_uint32, C.c_uint32, C.c_uint32,
+                                   _vp, C.c_uint32]
+    L.chd_shard_table_bytes.argtypes = [C.c_void_p, P(C.c_uint64)]
+    L.chd_shard_import.argtypes = [C.c_void_p, _vp, C.c_uint32, C.c_uint32, _vp]
+    L.chd_shard_fanout.argtypes = [C.c_void_p, _vp, C.c_uint32, P(TickIn)]
+    L.chd_shard_get_entities.argtypes = [C.c_void_p, _u32p, _u32p, _u32p, P(C.c_uint32)]
     L.chd_set_profiling.argtypes = [C.c_void_p, C.c_int]
     L.chd_get_tick_stats.argtypes = [C.c_void_p, P(TickStats)]
     L.chd_get_tick_history.argtypes = [C.c_void_p, C.c_uint32, P(TickStats)]

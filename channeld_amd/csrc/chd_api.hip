@@ -35,13 +35,15 @@ struct World {
     int64_t last_now = INT64_MIN;
     uint32_t last_nq = 0;
     bool ticked = false;
+    int slot_mode = 0;  // 0 unset, 1 caller-chosen slots (chd_world_spawn), 2 library-managed (chd_shard_spawn)
 };
 
 }  // namespace
 
 struct chd_ctx {
     int device = 0;
-    hipStream_t stream = nullptr;
+    hipStream_t stream = nullptr;      // where work is enqueued (own_stream unless chd_set_stream)
+    hipStream_t own_stream = nullptr;
     chd_grid_cfg cfg{};
     DevGrid g{};
     AoiLimits lim{};
@@ -201,10 +203,11 @@ int chd_create(const chd_grid_cfg *cfg, int device, chd_ctx **out) {
     ctx = new chd_ctx();
     ctx->device = device;
     ctx->cfg = *cfg;
-    if (hipSetDevice(device) != hipSuccess || hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) {
+    if (hipSetDevice(device) != hipSuccess || hipStreamCreateWithFlags(&ctx->own_stream, hipStreamNonBlocking) != hipSuccess) {
         delete ctx;
         return fail(nullptr, CHD_E_HIP, "cannot create a stream on device %d", device);
     }
+    ctx->stream = ctx->own_stream;
     DevGrid &g = ctx->g;
     g.gw = cfg->grid_width;
     g.gh = cfg->grid_height;
@@ -241,7 +244,7 @@ int chd_create(const chd_grid_cfg *cfg, int device, chd_ctx **out) {
             g.damp_dist[i] = cfg->damping_max_dist[i];
             g.damp_iv[i] = cfg->damping_interval_ms[i];
             if (g.damp_iv[i] == 0) {
-                (void)hipStreamDestroy(ctx->stream);
+                (void)hipStreamDestroy(ctx->own_stream);
                 delete ctx;
                 return fail(nullptr, CHD_E_INVAL, "fan-out interval 0 makes the reference's tickData spin forever");
             }
@@ -266,7 +269,7 @@ void chd_destroy(chd_ctx *ctx) {
     for (auto &b : ctx->scratch)
         if (b.p) (void)hipFree(b.p);
     for (auto &e : ctx->ev) (void)hipEventDestroy(e);
-    (void)hipStreamDestroy(ctx->stream);
+    (void)hipStreamDestroy(ctx->own_stream);
     delete ctx;
 }
 
@@ -487,6 +490,12 @@ int chd_world_create(chd_ctx *ctx, const chd_world_cfg *cfg) {
     TRY(walloc(ctx, &d.blk_cnt, std::max(C * d.nblk + 1, 2 * C + 2)));
     TRY(walloc(ctx, &d.ce, N));
     TRY(walloc(ctx, &d.cell_off, C + 1));
+    TRY(walloc(ctx, &d.cell_tab, 2 * C));
+    TRY(walloc(ctx, &d.free_stack, N));
+    TRY(walloc(ctx, &d.free_top, 1));
+    d.ce_view = d.ce;
+    d.cell_start = d.cell_off;
+    d.cell_end = d.cell_off + 1;
     TRY(walloc(ctx, &d.conn_id, S));
     TRY(walloc(ctx, &d.sub_alive, S));
     TRY(walloc(ctx, &d.sub_tick, S));
@@ -521,6 +530,8 @@ int chd_world_create(chd_ctx *ctx, const chd_world_cfg *cfg) {
     }
     d.recs_cap = nrec;
     TRY(walloc(ctx, &d.recs, nrec, false));
+    launch_free_stack_init(ctx->stream, d);
+    TRY(after_launch(ctx));
     HIPCHK(hipStreamSynchronize(ctx->stream));
     W.created = true;
     return CHD_OK;
@@ -540,6 +551,8 @@ int chd_world_spawn(chd_ctx *ctx, uint32_t n, const uint32_t *idx, const uint32_
         for (uint32_t i = 0; i < n; i++)
             if (idx[i] >= ctx->w.d.N) return fail(ctx, CHD_E_INVAL, "entity slot %u out of range", idx[i]);
     std::lock_guard<std::mutex> lk(ctx->mu);
+    if (ctx->w.slot_mode == 2) return fail(ctx, CHD_E_STATE, "chd_world_spawn on a world whose slots are library-managed (chd_shard_spawn)");
+    ctx->w.slot_mode = 1;
     TRY(bind(ctx));
     TRY(ensure(ctx, 0, 4 * (size_t)n)); TRY(ensure(ctx, 1, 4 * (size_t)n));
     TRY(ensure(ctx, 2, 8 * (size_t)n)); TRY(ensure(ctx, 3, 8 * (size_t)n));
@@ -614,23 +627,39 @@ int chd_subs_add(chd_ctx *ctx, uint32_t n, const uint32_t *slot, const uint32_t 
 }
 int chd_subs_remove(chd_ctx *ctx, uint32_t n, const uint32_t *slot) { return subs_common(ctx, n, slot, nullptr, 0); }
 
-// the device-side tick; caller holds the mutex.  `in` carries DEVICE pointers.
+// ---- the device-side tick, in stages; caller holds the mutex ----
+static int tick_begin(chd_ctx *ctx, int64_t now_ns) {
+    World &W = ctx->w;
+    if (now_ns < W.last_now) return fail(ctx, CHD_E_INVAL, "now_ns went backwards (%lld < %lld)", (long long)now_ns, (long long)W.last_now);
+    W.last_now = now_ns;
+    TickRing &r = ctx->ring;
+    for (int j = CHD_HIST_BITS - 1; j > 0; j--) r.t[j] = r.t[j - 1];
+    r.t[0] = now_ns;
+    if (r.n < CHD_HIST_BITS) r.n++;
+    r.cur_tick++;
+    return CHD_OK;
+}
+
+static int check_queries(chd_ctx *ctx, const chd_tick_in *in) {
+    if (in->n_queries && !in->queries) return fail(ctx, CHD_E_INVAL, "tick: NULL queries");
+    if (in->n_queries > ctx->w.d.S) return fail(ctx, CHD_E_INVAL, "tick: n_queries > max_subscribers (one interest update per connection per tick)");
+    return CHD_OK;
+}
+
+// `in` carries DEVICE pointers.
 static int tick_locked(chd_ctx *ctx, const chd_tick_in *in) {
     World &W = ctx->w;
     WorldDev &d = W.d;
-    if (in->now_ns < W.last_now) return fail(ctx, CHD_E_INVAL, "now_ns went backwards (%lld < %lld)", (long long)in->now_ns, (long long)W.last_now);
     if (in->n_updates && (!in->upd_x || !in->upd_z)) return fail(ctx, CHD_E_INVAL, "tick: NULL update positions");
     if (!in->upd_idx && in->n_updates > d.N) return fail(ctx, CHD_E_INVAL, "tick: n_updates > max_entities");
-    if (in->n_queries && !in->queries) return fail(ctx, CHD_E_INVAL, "tick: NULL queries");
-    if (in->n_queries > d.S) return fail(ctx, CHD_E_INVAL, "tick: n_queries > max_subscribers (one interest update per connection per tick)");
+    TRY(check_queries(ctx, in));
     if (in->n_cell_updates && (!in->cell_upd_channel || !in->cell_upd_sender)) return fail(ctx, CHD_E_INVAL, "tick: NULL cell updates");
-    W.last_now = in->now_ns;
-    // advance the tick ring
+    if (W.slot_mode == 2) return fail(ctx, CHD_E_STATE, "chd_tick on a region-sharded world: use chd_shard_ingest/import/fanout");
+    TRY(tick_begin(ctx, in->now_ns));
     TickRing &r = ctx->ring;
-    for (int j = CHD_HIST_BITS - 1; j > 0; j--) r.t[j] = r.t[j - 1];
-    r.t[0] = in->now_ns;
-    if (r.n < CHD_HIST_BITS) r.n++;
-    r.cur_tick++;
+    d.ce_view = d.ce;
+    d.cell_start = d.cell_off;
+    d.cell_end = d.cell_off + 1;
     hipStream_t st = ctx->stream;
     const bool prof = ctx->prof_depth > 0;
     hipEvent_t *ev = prof ? &ctx->ev[(size_t)(r.cur_tick % (uint32_t)ctx->prof_depth) * (CHD_N_STAGES + 1)] : nullptr;
@@ -811,6 +840,161 @@ int chd_tick(chd_ctx *ctx, const chd_tick_in *in, chd_tick_out *out) {
     }
     TRY(tick_locked(ctx, &din));
     return fetch_locked(ctx, out);
+}
+
+// ---------------------------------------------------------------------------
+// region-sharded worlds
+// ---------------------------------------------------------------------------
+
+int chd_set_stream(chd_ctx *ctx, void *hip_stream, int external) {
+    if (!ctx) return fail(nullptr, CHD_E_INVAL, "NULL ctx");
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    TRY(bind(ctx));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    ctx->stream = external ? (hipStream_t)hip_stream : ctx->own_stream;
+    return CHD_OK;
+}
+
+int chd_shard_spawn(chd_ctx *ctx, uint32_t n, const uint32_t *chan_id, const double *x, const double *z,
+                    const uint32_t *flags, const uint32_t *sender) {
+    NEED_WORLD();
+    if (!n) return CHD_OK;
+    if (!chan_id || !x || !z) return fail(ctx, CHD_E_INVAL, "chd_shard_spawn: NULL buffer");
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    if (ctx->w.slot_mode == 1) return fail(ctx, CHD_E_STATE, "chd_shard_spawn on a world with caller-chosen slots (chd_world_spawn)");
+    ctx->w.slot_mode = 2;
+    TRY(bind(ctx));
+    TRY(ensure(ctx, 1, 4 * (size_t)n));
+    TRY(ensure(ctx, 2, 8 * (size_t)n)); TRY(ensure(ctx, 3, 8 * (size_t)n));
+    TRY(ensure(ctx, 4, 4 * (size_t)n)); TRY(ensure(ctx, 5, 4 * (size_t)n));
+    TRY(up(ctx, sbuf<void>(ctx, 1), chan_id, 4 * (size_t)n));
+    TRY(up(ctx, sbuf<void>(ctx, 2), x, 8 * (size_t)n));
+    TRY(up(ctx, sbuf<void>(ctx, 3), z, 8 * (size_t)n));
+    if (flags) TRY(up(ctx, sbuf<void>(ctx, 4), flags, 4 * (size_t)n));
+    if (sender) TRY(up(ctx, sbuf<void>(ctx, 5), sender, 4 * (size_t)n));
+    launch_spawn_auto(ctx->stream, ctx->g, ctx->w.d, n, sbuf<uint32_t>(ctx, 1), sbuf<double>(ctx, 2), sbuf<double>(ctx, 3),
+                      flags ? sbuf<uint32_t>(ctx, 4) : nullptr, sender ? sbuf<uint32_t>(ctx, 5) : nullptr,
+                      ctx->ring.cur_tick);
+    TRY(after_launch(ctx));
+    uint32_t ovf = 0;
+    TRY(down(ctx, &ovf, ctx->w.d.counters + CTR_OVERFLOW, 4));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    if (ovf & OVF_SLOTS) return fail(ctx, CHD_E_CAPACITY, "chd_shard_spawn: more entities than max_entities slots");
+    return CHD_OK;
+}
+
+static uint64_t shard_table_bytes(const chd_ctx *ctx) {
+    uint64_t b = sizeof(uint4) * (uint64_t)ctx->w.d.N + sizeof(uint32_t) * ((uint64_t)ctx->g.ncell + 1);
+    return (b + 15) & ~15ull;
+}
+
+int chd_shard_table_bytes(chd_ctx *ctx, uint64_t *bytes) {
+    NEED_WORLD();
+    if (!bytes) return fail(ctx, CHD_E_INVAL, "chd_shard_table_bytes: NULL output");
+    *bytes = shard_table_bytes(ctx);
+    return CHD_OK;
+}
+
+int chd_shard_ingest(chd_ctx *ctx, int64_t now_ns, const double *d_x_by_chan, const double *d_z_by_chan,
+                     const uint8_t *d_has_update, uint32_t n_chan, uint32_t rank, uint32_t world,
+                     chd_entity_state *d_send, uint32_t cap) {
+    NEED_WORLD();
+    if (n_chan && (!d_x_by_chan || !d_z_by_chan)) return fail(ctx, CHD_E_INVAL, "chd_shard_ingest: NULL positions");
+    if (!world || rank >= world) return fail(ctx, CHD_E_INVAL, "chd_shard_ingest: rank %u of %u", rank, world);
+    if (world != ctx->g.server_cols * ctx->g.server_rows)
+        return fail(ctx, CHD_E_INVAL, "chd_shard_ingest: %u ranks but the grid has %u server regions", world,
+                    ctx->g.server_cols * ctx->g.server_rows);
+    if (world > 1 && (!d_send || !cap)) return fail(ctx, CHD_E_INVAL, "chd_shard_ingest: NULL send buffer");
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    if (ctx->w.slot_mode == 1) return fail(ctx, CHD_E_STATE, "chd_shard_ingest on a world with caller-chosen slots");
+    ctx->w.slot_mode = 2;
+    TRY(bind(ctx));
+    TRY(tick_begin(ctx, now_ns));
+    const uint32_t eid0 = ctx->cfg.entity_channel_id_start ? ctx->cfg.entity_channel_id_start : 0x80000u;
+    launch_ingest_by_channel(ctx->stream, ctx->g, ctx->w.d, d_x_by_chan, d_z_by_chan, d_has_update, n_chan, eid0,
+                             ctx->ring.cur_tick);
+    if (world > 1) launch_export(ctx->stream, ctx->g, ctx->w.d, rank, world, d_send, cap, ctx->ring.cur_tick);
+    TRY(after_launch(ctx));
+    return CHD_OK;
+}
+
+int chd_shard_import(chd_ctx *ctx, const chd_entity_state *d_recv, uint32_t world, uint32_t cap, void *d_table_out) {
+    NEED_WORLD();
+    if (world > 1 && !d_recv) return fail(ctx, CHD_E_INVAL, "chd_shard_import: NULL receive buffer");
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    if (ctx->w.slot_mode != 2) return fail(ctx, CHD_E_STATE, "chd_shard_import before chd_shard_ingest");
+    TRY(bind(ctx));
+    WorldDev &d = ctx->w.d;
+    hipStream_t st = ctx->stream;
+    if (world > 1) launch_import(st, d, d_recv, world, cap, ctx->ring.cur_tick);
+    launch_index_build(st, ctx->g, d, ctx->ring.cur_tick);
+    TRY(after_launch(ctx));
+    if (d_table_out) {
+        unsigned char *t = (unsigned char *)d_table_out;
+        HIPCHK(hipMemcpyAsync(t, d.ce, sizeof(uint4) * (size_t)d.N, hipMemcpyDeviceToDevice, st));
+        HIPCHK(hipMemcpyAsync(t + sizeof(uint4) * (size_t)d.N, d.cell_off, sizeof(uint32_t) * ((size_t)ctx->g.ncell + 1),
+                              hipMemcpyDeviceToDevice, st));
+    }
+    return CHD_OK;
+}
+
+int chd_shard_fanout(chd_ctx *ctx, const void *d_tables, uint32_t world, const chd_tick_in *d_in) {
+    NEED_WORLD();
+    if (!d_in) return fail(ctx, CHD_E_INVAL, "chd_shard_fanout: NULL input");
+    if (!d_tables || !world) return fail(ctx, CHD_E_INVAL, "chd_shard_fanout: NULL gathered tables");
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    if (ctx->w.slot_mode != 2) return fail(ctx, CHD_E_STATE, "chd_shard_fanout before chd_shard_ingest");
+    TRY(bind(ctx));
+    TRY(check_queries(ctx, d_in));
+    World &W = ctx->w;
+    WorldDev &d = W.d;
+    hipStream_t st = ctx->stream;
+    const TickRing &r = ctx->ring;
+    const int64_t now = W.last_now;
+    // stage events: ingest/index ran in the earlier phases (their slots read 0 here)
+    const bool prof = ctx->prof_depth > 0;
+    hipEvent_t *ev = prof ? &ctx->ev[(size_t)(r.cur_tick % (uint32_t)ctx->prof_depth) * (CHD_N_STAGES + 1)] : nullptr;
+    if (prof) for (int k = 0; k <= 2; k++) HIPCHK(hipEventRecord(ev[k], st));
+    launch_cell_table(st, ctx->g, d, d_tables, world, shard_table_bytes(ctx));
+    d.ce_view = (const uint4 *)d_tables;
+    d.cell_start = d.cell_tab;
+    d.cell_end = d.cell_tab + ctx->g.ncell;
+    launch_aoi_interest(st, ctx->g, ctx->lim, d, d_in->queries, d_in->n_queries, d_in->query_sub, d_in->spot_x,
+                        d_in->spot_z, d_in->spot_dist, now, r.cur_tick);
+    if (prof) HIPCHK(hipEventRecord(ev[3], st));
+    launch_fanout_plan(st, ctx->g, d, now, r);
+    if (prof) HIPCHK(hipEventRecord(ev[4], st));
+    launch_fanout_emit(st, ctx->g, d, now, r);
+    if (prof) HIPCHK(hipEventRecord(ev[5], st));
+    launch_tick_epilogue(st, d, r.cur_tick % TICK_RING);
+    TRY(after_launch(ctx));
+    W.last_nq = d_in->n_queries;
+    W.ticked = true;
+    return CHD_OK;
+}
+
+int chd_shard_get_entities(chd_ctx *ctx, uint32_t *chan_id, uint32_t *cell_channel, uint32_t *member_channel, uint32_t *n_out) {
+    NEED_WORLD();
+    if (!chan_id || !n_out) return fail(ctx, CHD_E_INVAL, "chd_shard_get_entities: NULL buffer");
+    WorldDev &d = ctx->w.d;
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    TRY(bind(ctx));
+    std::vector<uint32_t> ch(d.N), cell(d.N), mem(d.N), fl(d.N);
+    TRY(down(ctx, ch.data(), d.chan_id, 4 * (size_t)d.N));
+    TRY(down(ctx, cell.data(), d.cell, 4 * (size_t)d.N));
+    TRY(down(ctx, mem.data(), d.member, 4 * (size_t)d.N));
+    TRY(down(ctx, fl.data(), d.eflags, 4 * (size_t)d.N));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    uint32_t n = 0;
+    for (uint32_t i = 0; i < d.N; i++) {
+        if (!(fl[i] & EF_ALIVE)) continue;
+        chan_id[n] = ch[i];
+        if (cell_channel) cell_channel[n] = cell[i] == CHD_INVALID ? 0u : cell[i] + ctx->g.id_start;
+        if (member_channel) member_channel[n] = mem[i] == CHD_INVALID ? 0u : mem[i] + ctx->g.id_start;
+        n++;
+    }
+    *n_out = n;
+    return CHD_OK;
 }
 
 int chd_subs_get(chd_ctx *ctx, uint32_t slot, uint32_t *channel, uint32_t *interval_ms, int64_t *last_fanout_ns,

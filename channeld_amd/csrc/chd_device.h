@@ -41,6 +41,8 @@ enum {
 #define OVF_UNSUB 2u
 #define OVF_RECORDS 4u
 #define OVF_NEWSUB 8u
+#define OVF_SLOTS 16u    // sharded world: no free entity slot for a spawn / an immigrant
+#define OVF_MIGRATE 32u  // sharded world: an emigrant did not fit its destination's send segment
 
 struct DevGrid {
     double gw, gh, offx, offz;

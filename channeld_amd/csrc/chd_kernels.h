@@ -26,6 +26,14 @@ struct WorldDev {
     uint32_t *blk_cnt;    // [ncell*nblk + 1] counts -> exclusive scan (cell-major)
     uint4 *ce;            // [N] sorted by cell: {entity channel id, history aligned to this tick, sender, slot}
     uint32_t *cell_off;   // [ncell+1] cell c owns ce[cell_off[c], cell_off[c+1])
+    // what the fan-out kernels read: cell c owns ce_view[cell_start[c], cell_end[c]).  Single GPU: ce_view = ce,
+    // cell_start = cell_off, cell_end = cell_off + 1.  Region-sharded: ce_view = the all-gathered tables.
+    const uint4 *ce_view;
+    const uint32_t *cell_start, *cell_end;
+    uint32_t *cell_tab;   // [2*ncell] storage of cell_start/cell_end in sharded mode
+    // slot allocator of region-sharded worlds (entities migrate between ranks)
+    uint32_t *free_stack; // [N]
+    int32_t *free_top;    // number of free slots
     // subscribers
     uint32_t *conn_id;    // [S]
     uint32_t *sub_alive;  // [S]
@@ -80,6 +88,22 @@ void launch_ingest(hipStream_t st, DevGrid g, WorldDev w, uint32_t n, const uint
                    const double *x, const double *z, const uint32_t *sender, uint32_t cur_tick);
 void launch_cell_updates(hipStream_t st, DevGrid g, WorldDev w, uint32_t n,
                          const uint32_t *chan, const uint32_t *sender, uint32_t cur_tick);
+// pull-mode ingest of region-sharded worlds: every live slot reads its position by entity channel id
+void launch_ingest_by_channel(hipStream_t st, DevGrid g, WorldDev w, const double *x_by_chan,
+                              const double *z_by_chan, const uint8_t *has_update, uint32_t n_chan,
+                              uint32_t entity_id_start, uint32_t cur_tick);
+// entities whose member cell belongs to another rank leave (state packed per destination, slot freed)
+void launch_export(hipStream_t st, DevGrid g, WorldDev w, uint32_t rank, uint32_t world,
+                   chd_entity_state *send, uint32_t cap, uint32_t cur_tick);
+void launch_import(hipStream_t st, WorldDev w, const chd_entity_state *recv, uint32_t world, uint32_t cap,
+                   uint32_t cur_tick);
+void launch_spawn_auto(hipStream_t st, DevGrid g, WorldDev w, uint32_t n, const uint32_t *chan_id,
+                       const double *x, const double *z, const uint32_t *flags, const uint32_t *sender,
+                       uint32_t cur_tick);
+void launch_free_stack_init(hipStream_t st, WorldDev w);
+// tables = world x table_bytes; each: N 16-byte entries, then ncell+1 offsets
+void launch_cell_table(hipStream_t st, DevGrid g, WorldDev w, const void *tables, uint32_t world,
+                       uint64_t table_bytes);
 // K2: cell index build
 void launch_index_build(hipStream_t st, DevGrid g, WorldDev w, uint32_t cur_tick);
 // K3/K4: AOI query (+ interest diff when stateful)

@@ -79,7 +79,7 @@ __global__ void __launch_bounds__(64 * FO_WAVES) k_fanout_plan(DevGrid g, WorldD
                 int64_t I = (int64_t)w.pair_iv[pbase + p] * 1000000;
                 if (!(fl & PF_NO_ACCESS) && I > 0 && now >= L + I) {
                     uint32_t c = w.pair_cell[pbase + p];
-                    uint64_t size = (uint64_t)(w.cell_off[c + 1] - w.cell_off[c]) + 1;
+                    uint64_t size = (uint64_t)(w.cell_end[c] - w.cell_start[c]) + 1;
                     if (!(fl & PF_HAD_FIRST)) {
                         ub = size;  // one full-state window, then last = now
                     } else {
@@ -197,7 +197,7 @@ __global__ void __launch_bounds__(64 * FO_WAVES) k_fanout_emit(DevGrid g, WorldD
     }
     const uint32_t conn = w.conn_id[s];
     const int64_t my_t = ring_stamp(ring);
-    const uint4 *__restrict__ ce = w.ce;
+    const uint4 *__restrict__ ce = w.ce_view;
     uint32_t total = 0;
     uint32_t hist_ovf = 0;
     for (uint32_t tile = 0; tile < cnt; tile += FO_TILE) {
@@ -216,8 +216,8 @@ __global__ void __launch_bounds__(64 * FO_WAVES) k_fanout_emit(DevGrid g, WorldD
                     const uint32_t k = atomicAdd(&n_due, 1u);
                     d_p[k] = p; d_fl[k] = fl; d_L[k] = L; d_iv[k] = iv; d_c[k] = c;
                     d_rel[k] = w.pair_rel[pbase + p];
-                    d_start[k] = w.cell_off[c];
-                    d_end[k] = w.cell_off[c + 1];
+                    d_start[k] = w.cell_start[c];
+                    d_end[k] = w.cell_end[c];
                     const uint32_t age = ring.cur_tick - w.cell_hist_tick[c];
                     d_chh[k] = age < CHD_HIST_BITS ? (w.cell_hist[c] << age) : 0u;
                     d_chs[k] = w.cell_sender[c];

@@ -36,7 +36,7 @@
 extern "C" {
 #endif
 
-#define CHD_ABI_VERSION 1
+#define CHD_ABI_VERSION 2
 
 typedef struct chd_ctx chd_ctx;
 
@@ -266,6 +266,80 @@ int chd_subs_get(chd_ctx *ctx, uint32_t slot, uint32_t *channel,
 /* entity state: position-derived cell id and the cell whose entity map holds it */
 int chd_world_get_entities(chd_ctx *ctx, uint32_t n, const uint32_t *idx,
                            uint32_t *cell_channel, uint32_t *member_channel);
+
+/* ------------------------------------------------------------------ */
+/* Region-sharded worlds: one ctx per GPU, rank r owns the cells whose  */
+/* ServerIndex (GetRegions, spatial.go:336-351) is r - the partition    */
+/* CreateChannels gives spatial server r (spatial.go:399-424).  Every   */
+/* rank is created with the SAME global grid config.  The three phases  */
+/* below bracket the two exchange steps of a tick:*/
+/*   chd_shard_ingest -> all-to-all(emigrants)                          */
+/*   chd_shard_import -> all-gather(cell tables)                        */
+/*   chd_shard_fanout                                                   */
+/* All pointers are DEVICE pointers (the exchange buffers are owned by  */
+/* the caller, e.g. torch tensors handed to RCCL); calls are            */
+/* asynchronous on the ctx stream.                                      */
+/* ------------------------------------------------------------------ */
+
+/* external != 0: enqueue all later work of this ctx on the caller's HIP stream
+ * (hipStream_t; NULL is the legacy default stream, which is what torch's default
+ * "current stream" is) so that it orders with the caller's collectives without host
+ * synchronisation.  external == 0 restores the ctx's own non-blocking stream. */
+int chd_set_stream(chd_ctx *ctx, void *hip_stream, int external);
+
+/* An entity crossing to another rank: the cross-server handover of
+ * spatial.go:683-700 carries the entity's whole engine-side state. */
+typedef struct {
+    uint32_t chan_id;  /* entity channel id */
+    uint32_t cell;     /* cell index of the last merged position (0xFFFFFFFF = out of world) */
+    uint32_t member;   /* cell index whose entity map holds it */
+    uint32_t eflags;
+    uint32_t sender;
+    uint32_t hist;     /* update history, aligned to the tick of the export */
+    uint32_t _pad[2];
+} chd_entity_state; /* 32 bytes */
+
+/* Sharded worlds address entities by channel id; slots are allocated by the library.
+ * Spawns the entities given (the caller passes only those whose cell belongs to this
+ * rank; out-of-world entities may live on any one rank).  Not mixable with
+ * chd_world_spawn on the same ctx. */
+int chd_shard_spawn(chd_ctx *ctx, uint32_t n, const uint32_t *chan_id, const double *x,
+                    const double *z, const uint32_t *flags, const uint32_t *sender);
+
+/* Phase 1.  Starts tick `now_ns`.  Every live entity e of this rank reads its new
+ * position from d_x_by_chan/d_z_by_chan[e.chan_id - entity_channel_id_start]
+ * (d_has_update, if not NULL, marks which channels carry an update this tick) and goes
+ * through the Notify decision like chd_tick's ingest; then every entity whose member cell
+ * now belongs to another rank is packed into the send buffer and leaves this rank.
+ * d_send = world segments of (cap + 1) records: record 0 of segment `dst` is a header whose
+ * chan_id field holds the number of emigrants k, followed by the k states.  Equal-sized
+ * segments: one all-to-all moves them.  If a destination's `cap` is exceeded the surplus
+ * stays and retries next tick (overflow flag). */
+int chd_shard_ingest(chd_ctx *ctx, int64_t now_ns, const double *d_x_by_chan,
+                     const double *d_z_by_chan, const uint8_t *d_has_update, uint32_t n_chan,
+                     uint32_t rank, uint32_t world, chd_entity_state *d_send, uint32_t cap);
+
+/* Size of one rank's published cell table: max_entities 16-byte entries {channel id,
+ * history, sender, slot} sorted by cell, then grid_cols*grid_rows+1 CSR offsets (u32),
+ * padded to 16 bytes. */
+int chd_shard_table_bytes(chd_ctx *ctx, uint64_t *bytes);
+
+/* Phase 2, after the all-to-all: the states in d_recv (same layout as d_send, segment
+ * `src` = what rank src sent here) join this rank; then the local cell index is rebuilt
+ * and published into d_table_out (chd_shard_table_bytes). */
+int chd_shard_import(chd_ctx *ctx, const chd_entity_state *d_recv, uint32_t world,
+                     uint32_t cap, void *d_table_out);
+
+/* Phase 3, after the all-gather: d_tables = world tables, rank-major.  Runs the interest
+ * updates of d_in (queries of this rank's connections; the update fields of d_in are
+ * ignored) and the fan-out of this rank's connections over the gathered tables.  Outputs
+ * as chd_tick_device. */
+int chd_shard_fanout(chd_ctx *ctx, const void *d_tables, uint32_t world, const chd_tick_in *d_in);
+
+/* Live entities of this rank: channel ids and cell / member channel ids (0 = none).
+ * Arrays have max_entities room; *n_out = count. */
+int chd_shard_get_entities(chd_ctx *ctx, uint32_t *chan_id, uint32_t *cell_channel,
+                           uint32_t *member_channel, uint32_t *n_out);
 
 /* device memory, for callers that keep their batches on the GPU (bench, tests) */
 int chd_dev_alloc(chd_ctx *ctx, uint64_t bytes, void **d_out);

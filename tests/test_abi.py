@@ -59,7 +59,7 @@ def test_struct_sizes_match_header(tmp_path):
     names = {
         "chd_grid_cfg": _lib.GridCfg, "chd_aoi_query": _lib.AoiQuery, "chd_world_cfg": _lib.WorldCfg,
         "chd_fanout_rec": _lib.FanoutRec, "chd_handover_rec": _lib.HandoverRec, "chd_tick_in": _lib.TickIn,
-        "chd_tick_out": _lib.TickOut, "chd_tick_stats": _lib.TickStats,
+        "chd_tick_out": _lib.TickOut, "chd_tick_stats": _lib.TickStats, "chd_entity_state": _lib.EntityState,
     }
     prog = '#include <stdio.h>\n#include "chd_spatial.h"\nint main(void){\n'
     for n in names:

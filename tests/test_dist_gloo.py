@@ -1,0 +1,160 @@
+"""world_size-2 (and 4) gloo runs of the region-sharded tick schedule on CPU.
+
+The orchestration under test is channeld_amd/dist.py (ShardedWorld + Comm: all-to-all
+of emigrants, all-gather of cell tables).  The engine is the numpy stand-in of
+tests/shard_sim.py; the reference point is the single-world CPU oracle: after every
+tick the union of the ranks' entity tables must equal the oracle's (cell, member) per
+entity, every entity must live on exactly the rank that owns its member cell, and
+every connection's visible set must equal {e : member(e) in interest(conn)} of the
+single world."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+from channeld_amd import synth  # noqa: E402
+from channeld_amd.dist import Comm, ShardedWorld, server_layout, server_of_cell, weak_scaled_config  # noqa: E402
+
+
+def free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def make_cfg(world):
+    base = {"WorldOffsetX": -4000, "WorldOffsetZ": -4000, "GridWidth": 2000, "GridHeight": 2000, "GridCols": 3,
+            "GridRows": 2, "ServerCols": 1, "ServerRows": 1, "ServerInterestBorderSize": 1}
+    return weak_scaled_config(base, world)
+
+
+def world_inputs(cfg, N, S, ticks, seed):
+    sw = synth.SynthWorld(synth.WorldSpec(cfg, N, S, seed, tick_ms=50, outside_frac=0.01, locked_frac=0.03))
+    frames = []
+    x0, z0 = sw.x.copy(), sw.z.copy()
+    rng = np.random.default_rng(seed & 0xFFFF)
+    for _ in range(ticks):
+        sw.step()
+        # amplify the motion so that region borders are crossed often
+        jump = rng.random(N) < 0.15
+        sw.x = np.where(jump & ~sw.outside, np.float64(np.float32(sw.offx + rng.random(N) * sw.W * 0.999)), sw.x)
+        frames.append((sw.x.copy(), sw.z.copy(), sw.queries().copy(), sw.now_ns()))
+    return sw, x0, z0, frames
+
+
+def worker(rank, world, port, N, S, ticks, seed, out):
+    from oracle import pyoracle as orc
+    from shard_sim import SimShardEngine
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        cfg = make_cfg(world)
+        sw, x0, z0, frames = world_inputs(cfg, N, S, ticks, seed)
+        g = orc.grid_from_config(cfg)
+        ids0 = orc.channel_ids(g, x0, z0)
+        owner = np.where(ids0 == 0, 0, server_of_cell(cfg, np.where(ids0 == 0, 0, ids0 - 0x10000)))
+        mine = np.nonzero(owner == rank)[0]
+        my_subs = np.nonzero(owner[:S] == rank)[0]
+        eng = SimShardEngine(cfg, rank, world, N)
+        eng.spawn(sw.chan_id[mine], x0[mine], z0[mine], sw.flags[mine])
+        eng.add_subscribers(sw.sub_conn[my_subs])
+        sworld = ShardedWorld(eng, Comm(rank, world))
+        # the single world, on rank 0 only
+        ow = None
+        if rank == 0:
+            ow = orc.World(g, N, S, min(g.cols * g.rows, 256), 20, 0, literal=False)
+            ow.spawn(np.arange(N), sw.chan_id, x0, z0, sw.flags, sw.sender)
+            for s in range(S):
+                ow.add_sub(s, int(sw.sub_conn[s]))
+        n_cross = 0
+        for k, (x, z, q, now) in enumerate(frames):
+            oq = orc.queries_from_aoi(q[my_subs])
+            qb = []
+            for i in range(len(my_subs)):
+                b = orc.QueryBuilder()
+                b.q = orc.Query.from_buffer_copy(oq[i].tobytes())
+                qb.append(b)
+            sworld.tick(now, torch.from_numpy(x), torch.from_numpy(z), qb, len(qb))
+            state = dict(chan=eng.chan.copy(), cell=eng.cell.copy(), member=eng.member.copy(), visible=eng.visible,
+                         handovers=eng.handovers)
+            gathered = [None] * world
+            dist.all_gather_object(gathered, state)
+            if rank != 0:
+                continue
+            ow.tick(now, None, x, z, None, None, None, None, q)
+            ocell, omember = ow.entity_state()
+            chans = np.concatenate([s["chan"] for s in gathered])
+            assert len(chans) == N and len(np.unique(chans)) == N, f"tick {k}: an entity was lost or duplicated"
+            for r, s in enumerate(gathered):
+                i = (s["chan"] - 0x80000).astype(np.int64)
+                assert np.array_equal(s["cell"], ocell[i]) and np.array_equal(s["member"], omember[i]), f"tick {k} rank {r}"
+                valid = s["member"] != 0xFFFFFFFF
+                assert (server_of_cell(cfg, s["member"][valid]) == r).all(), f"tick {k}: entity on the wrong rank"
+            ent, src, dst, ssrc, sdst = ow.handovers()
+            got = sorted(h for s in gathered for h in s["handovers"])
+            want = sorted((int(sw.chan_id[e]), int(a) - 0x10000, int(b) - 0x10000) for e, a, b in zip(ent, src, dst))
+            assert got == want, f"tick {k}: handovers"
+            n_cross += int((ssrc != sdst).sum())
+            # visible sets
+            member_of = omember
+            for s_idx in range(S):
+                cells, _, _, _, _ = ow.pairs(s_idx)
+                want_vis = set(int(c) for c in sw.chan_id[np.isin(member_of, cells.astype(np.int64) - 0x10000)])
+                conn = int(sw.sub_conn[s_idx])
+                got_vis = next(st["visible"][conn] for st in gathered if conn in st["visible"])
+                assert got_vis == want_vis, f"tick {k}: visible set of connection {conn}"
+        if rank == 0:
+            out.put(("ok", n_cross))
+    except Exception as e:  # surface the failure in the parent
+        import traceback
+
+        out.put(("fail", f"rank {rank}: {e}\n{traceback.format_exc()}"))
+        raise
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 4])
+def test_sharded_schedule_matches_single_world(world):
+    ctx = mp.get_context("spawn")
+    out = ctx.Queue()
+    port = free_port()
+    procs = [ctx.Process(target=worker, args=(r, world, port, 600, 48, 6, 0xC0FFEE07, out)) for r in range(world)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(timeout=240)
+    status, info = out.get(timeout=5)
+    assert status == "ok", info
+    assert all(p.exitcode == 0 for p in procs)
+    assert info > 0, "the test world never crossed a region border"
+
+
+def test_layout_helpers():
+    assert [server_layout(w) for w in (1, 2, 4, 8)] == [(1, 1), (2, 1), (2, 2), (4, 2)]
+    base = synth.load_config("spatial_static_benchmark.json")
+    cfg = weak_scaled_config(base, 8)
+    assert (cfg["GridCols"], cfg["GridRows"], cfg["ServerCols"], cfg["ServerRows"]) == (60, 30, 4, 2)
+    # the host-side routing arithmetic agrees with the oracle's GetRegions restatement
+    from oracle import pyoracle as orc
+
+    g = orc.grid_from_config(cfg)
+    srv = orc.regions(g)[5]
+    assert np.array_equal(server_of_cell(cfg, np.arange(60 * 30)), srv.astype(np.int64))
+    for w in (1, 2, 4, 8):
+        c = weak_scaled_config(base, w)
+        counts = np.bincount(server_of_cell(c, np.arange(c["GridCols"] * c["GridRows"])), minlength=w)
+        assert (counts == 225).all()
