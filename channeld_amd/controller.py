@@ -281,6 +281,23 @@ class StaticGrid2DSpatialController:
             return status[:nq], res, ivr
         return status[:nq], res
 
+    def query_channel_ids_packed(self, queries: np.ndarray):
+        """Batched QueryChannelIds on packed chd_aoi_query records (numpy, 128 B each, no spots):
+        returns the CSR (offsets, channel ids, dists, damped intervals, status)."""
+        q = np.ascontiguousarray(queries)
+        assert q.dtype.itemsize == C.sizeof(AoiQuery)
+        nq = len(q)
+        ncell = self.GridCols * self.GridRows
+        cap = max(1, nq * min(ncell, 4096))
+        offsets = np.zeros(nq + 1, dtype=np.uint32)
+        ids, dists, ivs = (np.zeros(cap, dtype=np.uint32) for _ in range(3))
+        status = np.zeros(max(nq, 1), dtype=np.int32)
+        self._check(self._lib.chd_query_channel_ids(
+            self.ctx, q.ctypes.data_as(C.c_void_p), nq, None, None, None, 0,
+            _ptr(offsets), _ptr(ids), _ptr(dists), _ptr(ivs), cap, _ptr(status)))
+        n = int(offsets[nq])
+        return offsets, ids[:n], dists[:n], ivs[:n], status[:nq]
+
     def QueryChannelIds(self, query: Optional[SpatialInterestQuery]) -> Tuple[Optional[Dict[int, int]], Optional[SpatialError]]:
         """spatial.go:182-317: (map[ChannelId]uint, nil) or (nil, err)."""
         if query is None:
