@@ -18,6 +18,8 @@ E_TOO_LARGE, E_NO_DEVICE, E_HIP, E_STATE = -8, -9, -10, -11
 SHAPE_SPOTS, SHAPE_BOX, SHAPE_SPHERE, SHAPE_CONE = 1, 2, 4, 8
 REC_FULL = 0x80000000
 ENTITY_LOCKED = 1
+WORLD_CONN_MAJOR_EMIT = 1
+WORLD_CELL_MAJOR_EMIT = 2
 MAX_DAMPING = 8
 N_STAGES = 5
 STAGE_NAMES = ("ingest", "index", "interest", "plan", "emit")
@@ -75,7 +77,7 @@ assert C.sizeof(AoiQuery) == 128
 class WorldCfg(C.Structure):
     _fields_ = [
         ("max_entities", C.c_uint32), ("max_subscribers", C.c_uint32), ("max_interest_cells", C.c_uint32),
-        ("max_records", C.c_uint64), ("max_handovers", C.c_uint32),
+        ("max_records", C.c_uint64), ("max_handovers", C.c_uint32), ("flags", C.c_uint32),
     ]
 
 
@@ -117,7 +119,7 @@ class TickOut(C.Structure):
 
 class EntityState(C.Structure):
     _fields_ = [("chan_id", C.c_uint32), ("cell", C.c_uint32), ("member", C.c_uint32), ("eflags", C.c_uint32),
-                ("sender", C.c_uint32), ("hist", C.c_uint32), ("_pad", C.c_uint32 * 2)]
+                ("sender", C.c_uint32), ("hist", C.c_uint32), ("sender_prev", C.c_uint32), ("hist_prev", C.c_uint32)]
 
 
 assert C.sizeof(EntityState) == 32

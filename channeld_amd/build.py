@@ -22,6 +22,9 @@ FLAGS = [
 ]
 
 
+EXTRA = os.environ.get("CHD_EXTRA_FLAGS", "").split()
+
+
 def hipcc() -> str:
     for c in (os.environ.get("HIPCC"), shutil.which("hipcc"), "/opt/rocm/bin/hipcc"):
         if c and os.path.exists(c):
@@ -48,7 +51,7 @@ def build(force: bool = False, verbose: bool = False) -> str:
     for s in SOURCES:
         o = os.path.join(bdir, s.replace(".hip", ".o"))
         objs.append(o)
-        cmd = [cc, *FLAGS, "-c", os.path.join(CSRC, s), "-o", o]
+        cmd = [cc, *FLAGS, *EXTRA, "-c", os.path.join(CSRC, s), "-o", o]
         if verbose:
             print(" ".join(cmd), file=sys.stderr)
         procs.append((s, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)))

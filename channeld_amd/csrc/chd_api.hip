@@ -158,6 +158,18 @@ __global__ void __launch_bounds__(256) k_pack_records(WorldDev w, const uint64_t
     }
 }
 
+__global__ void __launch_bounds__(256) k_rec_cnt(WorldDev w) {
+    uint32_t s = blockIdx.x * 4u + (threadIdx.x >> 6);
+    if (s >= w.S) return;
+    uint32_t sum = 0;
+    if (w.sub_alive[s]) {
+        const uint32_t cnt = w.pair_cnt[s];
+        for (uint32_t p = threadIdx.x & 63u; p < cnt; p += 64) sum += w.pair_nrec[(size_t)s * w.capq + p];
+    }
+    for (int d = 32; d >= 1; d >>= 1) sum += __shfl_xor(sum, d);
+    if ((threadIdx.x & 63u) == 0) w.rec_cnt[s] = sum;
+}
+
 __global__ void __launch_bounds__(256) k_widen(const uint32_t *in, uint64_t *out, uint32_t n) {
     uint32_t i = blockIdx.x * 256u + threadIdx.x;
     if (i < n) out[i] = in[i];
@@ -483,17 +495,47 @@ int chd_world_create(chd_ctx *ctx, const chd_world_cfg *cfg) {
     TRY(walloc(ctx, &d.sender, N));
     TRY(walloc(ctx, &d.hist, N));
     TRY(walloc(ctx, &d.hist_tick, N));
+    TRY(walloc(ctx, &d.sender_prev, N));
+    TRY(walloc(ctx, &d.hist_prev, N));
     TRY(walloc(ctx, &d.cell_hist, C));
     TRY(walloc(ctx, &d.cell_hist_tick, C));
     TRY(walloc(ctx, &d.cell_sender, C));
+    TRY(walloc(ctx, &d.cell_hist_prev, C));
+    TRY(walloc(ctx, &d.cell_sender_prev, C));
     d.nblk = (C <= 4096) ? index_num_blocks(d.N) : 1;
     TRY(walloc(ctx, &d.blk_cnt, std::max(C * d.nblk + 1, 2 * C + 2)));
     TRY(walloc(ctx, &d.ce, N));
+    TRY(walloc(ctx, &d.ce_sprev, N));
     TRY(walloc(ctx, &d.cell_off, C + 1));
+    TRY(walloc(ctx, &d.cell_ref, C));
+    TRY(walloc(ctx, &d.active_cells, C));
+    TRY(walloc(ctx, &d.n_active, 1));
+    // cell-major emit: grids up to 4096 cells (64 bitmap words per connection), unless the caller opts out
+    // (also bounded by the memory of the per-item due lists: ~40 B per cell x connection slot)
+    const size_t n_items_max = C * ((S + 255) / 256);
+    const bool cm_possible = C <= 4096 && n_items_max * sizeof(WsItemG) <= (2ull << 30);
+    const bool cm_wanted = (cfg->flags & CHD_WORLD_CELL_MAJOR_EMIT) ||
+                           (!(cfg->flags & CHD_WORLD_CONN_MAJOR_EMIT) && N / C >= 1024);
+    if ((cfg->flags & CHD_WORLD_CELL_MAJOR_EMIT) && !cm_possible)
+        return fail(ctx, CHD_E_INVAL, "cell-major emit needs a grid of at most 4096 cells (and cells x subscribers x 40 B <= 2 GiB)");
+    d.wb = (cm_possible && cm_wanted) ? (uint32_t)((C + 63) / 64) : 0u;
+    d.sub_bits = nullptr;
+    d.items = nullptr;
+    if (d.wb) {
+        TRY(walloc(ctx, &d.sub_bits, S * d.wb));
+        TRY(walloc(ctx, &d.items, n_items_max, false));
+    }
+    {
+        hipDeviceProp_t prop;
+        HIPCHK(hipGetDeviceProperties(&prop, ctx->device));
+        d.emit_grid = (uint32_t)std::max(prop.multiProcessorCount, 1) * 4u;  // 4 workgroups of ~37 KB LDS per CU
+    }
     TRY(walloc(ctx, &d.cell_tab, 2 * C));
     TRY(walloc(ctx, &d.free_stack, N));
     TRY(walloc(ctx, &d.free_top, 1));
     d.ce_view = d.ce;
+    d.ce_sprev_view = d.ce_sprev;
+    d.ce_sprev_stride = 0;
     d.cell_start = d.cell_off;
     d.cell_end = d.cell_off + 1;
     TRY(walloc(ctx, &d.conn_id, S));
@@ -658,6 +700,8 @@ static int tick_locked(chd_ctx *ctx, const chd_tick_in *in) {
     TRY(tick_begin(ctx, in->now_ns));
     TickRing &r = ctx->ring;
     d.ce_view = d.ce;
+    d.ce_sprev_view = d.ce_sprev;
+    d.ce_sprev_stride = 0;
     d.cell_start = d.cell_off;
     d.cell_end = d.cell_off + 1;
     hipStream_t st = ctx->stream;
@@ -698,7 +742,8 @@ static int fetch_locked(chd_ctx *ctx, chd_tick_out *out) {
     hipStream_t st = ctx->stream;
     uint32_t ctr[CTR_COUNT] = {0};
     uint64_t ringrow[8];
-    // exact per-connection offsets
+    // per-connection record counts (sum of its subscriptions' segments), then exact offsets
+    hipLaunchKernelGGL(k_rec_cnt, dim3((d.S + 3) / 4), dim3(256), 0, st, d);
     hipLaunchKernelGGL(k_widen, dim3((d.S + 255) / 256), dim3(256), 0, st, d.rec_cnt, W.rec_off_exact, d.S);
     launch_scan_u64_inplace(st, W.rec_off_exact, d.S);
     // the per-tick counters were folded into the history ring by the tick's epilogue
@@ -884,7 +929,7 @@ int chd_shard_spawn(chd_ctx *ctx, uint32_t n, const uint32_t *chan_id, const dou
 }
 
 static uint64_t shard_table_bytes(const chd_ctx *ctx) {
-    uint64_t b = sizeof(uint4) * (uint64_t)ctx->w.d.N + sizeof(uint32_t) * ((uint64_t)ctx->g.ncell + 1);
+    uint64_t b = (sizeof(uint4) + sizeof(uint32_t)) * (uint64_t)ctx->w.d.N + sizeof(uint32_t) * ((uint64_t)ctx->g.ncell + 1);
     return (b + 15) & ~15ull;
 }
 
@@ -932,8 +977,9 @@ int chd_shard_import(chd_ctx *ctx, const chd_entity_state *d_recv, uint32_t worl
     if (d_table_out) {
         unsigned char *t = (unsigned char *)d_table_out;
         HIPCHK(hipMemcpyAsync(t, d.ce, sizeof(uint4) * (size_t)d.N, hipMemcpyDeviceToDevice, st));
-        HIPCHK(hipMemcpyAsync(t + sizeof(uint4) * (size_t)d.N, d.cell_off, sizeof(uint32_t) * ((size_t)ctx->g.ncell + 1),
-                              hipMemcpyDeviceToDevice, st));
+        HIPCHK(hipMemcpyAsync(t + sizeof(uint4) * (size_t)d.N, d.ce_sprev, sizeof(uint32_t) * (size_t)d.N, hipMemcpyDeviceToDevice, st));
+        HIPCHK(hipMemcpyAsync(t + (sizeof(uint4) + sizeof(uint32_t)) * (size_t)d.N, d.cell_off,
+                              sizeof(uint32_t) * ((size_t)ctx->g.ncell + 1), hipMemcpyDeviceToDevice, st));
     }
     return CHD_OK;
 }
@@ -957,6 +1003,8 @@ int chd_shard_fanout(chd_ctx *ctx, const void *d_tables, uint32_t world, const c
     if (prof) for (int k = 0; k <= 2; k++) HIPCHK(hipEventRecord(ev[k], st));
     launch_cell_table(st, ctx->g, d, d_tables, world, shard_table_bytes(ctx));
     d.ce_view = (const uint4 *)d_tables;
+    d.ce_sprev_view = nullptr;
+    d.ce_sprev_stride = (uint32_t)(shard_table_bytes(ctx) / sizeof(uint4));
     d.cell_start = d.cell_tab;
     d.cell_end = d.cell_tab + ctx->g.ncell;
     launch_aoi_interest(st, ctx->g, ctx->lim, d, d_in->queries, d_in->n_queries, d_in->query_sub, d_in->spot_x,

@@ -34,6 +34,7 @@ enum {
     CTR_HIST_OVERFLOW = 4,
     CTR_PAIRS = 5,
     CTR_NEWSUBS = 6,
+    CTR_SENDER_OVERFLOW = 7,  // a third sender inside a channel's 32-tick update history
     CTR_COUNT = 16
 };
 

@@ -8,6 +8,24 @@
 #include "../../include/chd_spatial.h"
 #include "chd_device.h"
 
+// due subscriptions of one cell-major work item (active cell x 256 connection slots), written by
+// k_fanout_items and copied to LDS by the emit kernel's loader wave
+struct WsItemG {
+    uint32_t pi[256];     // connection slot * capq + subscription index
+    uint32_t conn[256];
+    uint32_t flags[256];  // WSF_*
+    uint32_t out16[256];  // segment start in the record buffer, in units of 16 records (128-byte lines)
+    uint32_t wm[4][256];  // the first four non-empty fan-out windows as masks over the tick ring
+    uint32_t iv[256];     // generic path only (more than four non-empty windows): interval and
+    int64_t L[256];       //   lastFanOutTime before this tick
+    uint32_t ndue, nsub, c, start, end, ch_hist, ch_hprev, ch_sender, ch_sprev, _pad[7];
+};
+#define WSF_FIRST 1u        // first fan-out of the subscription: full state
+#define WSF_SKIP_SELF 2u
+#define WSF_GENERIC 4u      // more than four non-empty windows: walk them from (L, iv)
+#define WSF_NWIN_SHIFT 8    // bits 8..10: number of stored windows
+#define WSF_OWN_SHIFT 16    // bit 16+j: the spatial channel's own update passes window j
+
 // ---- world state (all device pointers, SoA) ----
 struct WorldDev {
     uint32_t N, S, capq;
@@ -17,18 +35,23 @@ struct WorldDev {
     uint32_t *member;     // cell whose entity map holds the entity
     uint32_t *eflags;     // EF_*
     uint32_t *sender;     // senderConnId of the entity's updates
-    uint32_t *hist;       // bit j: an update arrived at tick (hist_tick - j)
+    uint32_t *hist;       // bit j: an update of `sender` arrived at tick (hist_tick - j)
     uint32_t *hist_tick;
+    uint32_t *sender_prev, *hist_prev;  // the previous sender's updates still inside the history
     // spatial (cell) channels' own update history
-    uint32_t *cell_hist, *cell_hist_tick, *cell_sender;
+    uint32_t *cell_hist, *cell_hist_tick, *cell_sender, *cell_hist_prev, *cell_sender_prev;
     // cell index (rebuilt every tick)
     uint32_t nblk;        // histogram blocks
     uint32_t *blk_cnt;    // [ncell*nblk + 1] counts -> exclusive scan (cell-major)
-    uint4 *ce;            // [N] sorted by cell: {entity channel id, history aligned to this tick, sender, slot}
+    uint4 *ce;            // [N] sorted by cell: {entity channel id, history of `sender` aligned to this tick,
+                          //  sender, history of the previous sender}
+    uint32_t *ce_sprev;   // [N] previous sender (read only where its history intersects a window)
     uint32_t *cell_off;   // [ncell+1] cell c owns ce[cell_off[c], cell_off[c+1])
     // what the fan-out kernels read: cell c owns ce_view[cell_start[c], cell_end[c]).  Single GPU: ce_view = ce,
     // cell_start = cell_off, cell_end = cell_off + 1.  Region-sharded: ce_view = the all-gathered tables.
     const uint4 *ce_view;
+    const uint32_t *ce_sprev_view;
+    uint32_t ce_sprev_stride;  // sharded: entries of rank o start at o*stride16 (16-B units), its sprev at +N entries
     const uint32_t *cell_start, *cell_end;
     uint32_t *cell_tab;   // [2*ncell] storage of cell_start/cell_end in sharded mode
     // slot allocator of region-sharded worlds (entities migrate between ranks)
@@ -43,6 +66,14 @@ struct WorldDev {
     uint32_t *pair_iv;    // [S*capq] FanOutIntervalMs
     int64_t *pair_last;   // [S*capq] lastFanOutTime
     uint32_t *pair_flags; // [S*capq] PF_*
+    // cell-major fan-out (grids up to 4096 cells): interest bitmap per connection and subscriber count per cell
+    uint32_t wb;                    // 64-bit words per bitmap row (0 = cell-major path off)
+    unsigned long long *sub_bits;   // [S*wb]
+    uint32_t *cell_ref;             // [ncell] live subscriptions of the cell
+    uint32_t *active_cells;         // [ncell] cells with cell_ref > 0 (compacted every tick)
+    uint32_t *n_active;             // [1]
+    uint32_t emit_grid;             // persistent grid of the cell-major emit kernel (workgroups)
+    WsItemG *items;                 // [ncell * ceil(S/256)]
     uint32_t *pair_rel;   // [S*capq] this tick: segment offset inside the connection's record range
     uint32_t *pair_nrec;  // [S*capq] this tick: records emitted for the subscription
     // fan-out outputs
@@ -57,6 +88,45 @@ struct WorldDev {
     uint64_t *tot64;      // [64][16] hashed per-tick totals, one 128-B line per bucket: {records, subscriptions}
     uint64_t *tick_ring;  // [TICK_RING][8] per-tick totals written by the epilogue
 };
+
+// ChannelData.OnUpdate (data.go:159-164) on the entity channel's bit-mask update
+// buffer.  Every buffered update keeps its senderConnId (tickData compares it with
+// the subscriber for SkipSelfUpdateFanOut, data.go:242-245): bits are kept per sender
+// for the current and the previous sender of the channel; a third sender inside the
+// 32-tick window folds the oldest bits into the previous one (counted, never silent).
+__device__ __forceinline__ void push_update(const WorldDev &w, uint32_t i, uint32_t snd, uint32_t cur_tick) {
+    const uint32_t age = cur_tick - w.hist_tick[i];
+    uint32_t h = (age >= CHD_HIST_BITS) ? 0u : (w.hist[i] << age);
+    uint32_t hp = (age >= CHD_HIST_BITS) ? 0u : (w.hist_prev[i] << age);
+    const uint32_t cur = w.sender[i];
+    if (snd != cur) {
+        const uint32_t prev = w.sender_prev[i];
+        if (snd == prev) {  // the previous sender is back: the two histories swap roles
+            const uint32_t t = h;
+            h = hp;
+            hp = t;
+            w.sender_prev[i] = cur;
+        } else {
+            if (h != 0) {
+                if (hp != 0 && prev != cur) atomicAdd(&w.counters[CTR_SENDER_OVERFLOW], 1u);
+                hp |= h;
+                w.sender_prev[i] = cur;
+            }
+            h = 0;
+        }
+        w.sender[i] = snd;
+    }
+    w.hist[i] = h | 1u;
+    w.hist_prev[i] = hp;
+    w.hist_tick[i] = cur_tick;
+}
+
+// previous sender of the entry at position gpos of the (possibly gathered) cell tables
+__device__ __forceinline__ uint32_t load_sprev(const WorldDev &w, uint32_t gpos) {
+    if (w.ce_sprev_stride == 0) return w.ce_sprev_view[gpos];
+    const uint32_t o = gpos / w.ce_sprev_stride, l = gpos % w.ce_sprev_stride;
+    return ((const uint32_t *)(w.ce_view + (size_t)o * w.ce_sprev_stride + w.N))[l];
+}
 
 // ---- stateless ----
 void launch_get_channel_ids(hipStream_t st, DevGrid g, const double *x, const double *z,

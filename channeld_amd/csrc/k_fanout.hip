@@ -39,7 +39,8 @@
 #include "chd_kernels.h"
 
 #define FO_WAVES 4
-#define FO_UNROLL 4
+#define CHD_SEG_ALIGN 16u  // records: 16 x 8 B = one 128-byte line
+#define FO_UNROLL 8
 
 // stamp of ring slot `lane` (INT64_MAX for unused slots): loaded once per wave
 __device__ __forceinline__ int64_t ring_stamp(const TickRing &ring) {
@@ -51,15 +52,24 @@ __device__ __forceinline__ uint32_t window_mask(int64_t my_t, int64_t lo, int64_
     return (uint32_t)__ballot(my_t >= lo && my_t <= hi);
 }
 
-// windows [.., hi] with hi < oldest stamp can never select an update: skip them
-__device__ __forceinline__ int64_t skippable(const TickRing &ring, int64_t L, int64_t I, int64_t nwin) {
-    if (ring.n == 0) return nwin;
-    int64_t oldest = ring.t[ring.n - 1];
-    if (oldest <= L) return 0;
-    int64_t d = oldest - L;
-    int64_t k = (d + I - 1) / I - 1;  // windows whose hi = L+(k+1)I stays < oldest
+// Windows that end before the oldest buffered stamp can never select an update: jump over
+// them (a subscription that was not served for longer than the 32-tick history).  This is
+// the only place the window walk divides (64-bit division is ~hundreds of instructions on
+// the GPU); the common case returns without one.  Returns true if the jump lost history.
+__device__ __forceinline__ bool fast_forward(const TickRing &ring, int64_t now, int64_t &L, int64_t I) {
+    if (ring.n == 0) {  // nothing buffered at all: every due window is empty
+        const int64_t nwin = (now - L) / I;
+        L += nwin * I;
+        return false;
+    }
+    const int64_t oldest = ring.t[ring.n - 1];
+    if (oldest <= L + I) return false;  // the next window already reaches the history
+    const int64_t nwin = (now - L) / I;
+    int64_t k = (oldest - L + I - 1) / I - 1;  // windows whose hi = L+(k+1)I stays < oldest
     if (k < 0) k = 0;
-    return k < nwin ? k : nwin;
+    if (k > nwin) k = nwin;
+    L += k * I;
+    return k > 0 && ring.n == CHD_HIST_BITS;
 }
 
 __global__ void __launch_bounds__(64 * FO_WAVES) k_fanout_plan(DevGrid g, WorldDev w, int64_t now, TickRing ring) {
@@ -90,6 +100,10 @@ __global__ void __launch_bounds__(64 * FO_WAVES) k_fanout_plan(DevGrid g, WorldD
                     }
                 }
             }
+            // every segment starts on a 128-byte line and is padded to whole lines: a line shared by
+            // two segments would be written in two partial pieces by different workgroups, and partial
+            // lines cost a read-modify-write at the (ECC) HBM — measured 3.7 vs 5.4 TB/s of stores
+            ub = (ub + (CHD_SEG_ALIGN - 1)) & ~(uint64_t)(CHD_SEG_ALIGN - 1);
             // exclusive prefix over the subscriptions, in list order
             uint64_t inc = ub;
 #pragma unroll
@@ -107,14 +121,62 @@ __global__ void __launch_bounds__(64 * FO_WAVES) k_fanout_plan(DevGrid g, WorldD
     if (lane == 0) w.rec_ub[s] = carry > 0xFFFFFFFFull ? (1ull << 40) : carry;
 }
 
+// cells with at least one live subscription, ascending (cell-major emit walks this list)
+__global__ void __launch_bounds__(1024) k_active_cells(WorldDev w, uint32_t ncell) {
+    __shared__ uint32_t wtot[16];
+    __shared__ uint32_t carry_s;
+    const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (threadIdx.x == 0) carry_s = 0;
+    __syncthreads();
+    for (uint32_t base = 0; base < ncell; base += 1024) {
+        const uint32_t c = base + threadIdx.x;
+        const bool act = c < ncell && w.cell_ref[c] != 0;
+        const uint64_t m = __ballot(act);
+        if (lane == 0) wtot[wave] = (uint32_t)__popcll(m);
+        __syncthreads();
+        uint32_t off = carry_s;
+        for (uint32_t k = 0; k < wave; k++) off += wtot[k];
+        if (act) w.active_cells[off + mask_rank(m)] = c;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            uint32_t t = carry_s;
+            for (int k = 0; k < 16; k++) t += wtot[k];
+            carry_s = t;
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) *w.n_active = carry_s;
+}
+
 void launch_fanout_plan(hipStream_t st, DevGrid g, WorldDev w, int64_t now_ns, TickRing ring) {
     if (!w.S) return;
     hipLaunchKernelGGL(k_fanout_plan, dim3((w.S + FO_WAVES - 1) / FO_WAVES), dim3(64 * FO_WAVES), 0, st, g, w,
                        now_ns, ring);
     launch_scan_u64_inplace(st, w.rec_ub, w.S);
+    if (w.wb) hipLaunchKernelGGL(k_active_cells, dim3(1), dim3(1024), 0, st, w, g.ncell);
 }
 
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+
+// fill the rest of the segment's last 128-byte line (never read: beyond the segment's record
+// count) so that the line leaves L2 as one full-line write
+__device__ __forceinline__ void pad_segment(chd_fanout_rec *__restrict__ out, uint32_t n_out) {
+    const uint32_t pad = (0u - n_out) & (CHD_SEG_ALIGN - 1);
+    if (lane_id() < pad) {
+        chd_fanout_rec r;
+        r.conn = 0xFFFFFFFFu;
+        r.channel = 0;
+        out[n_out + lane_id()] = r;
+    }
+}
+
+// the spatial channel's own buffered updates against one window (two-sender history)
+__device__ __forceinline__ bool cell_update_passes(uint32_t h, uint32_t snd, uint32_t hp, uint32_t sndp, uint32_t wm,
+                                                   bool skip_self, uint32_t conn) {
+    const uint32_t a = h & wm, b = hp & wm;
+    if (!skip_self) return (a | b) != 0;
+    return (a != 0 && snd != conn) || (b != 0 && sndp != conn);
+}
 
 // One window (or the full state) of one cell for one connection: stream the cell's
 // entries, 4 x 64 per step.  The four 16-byte loads are issued back to back from
@@ -122,10 +184,10 @@ typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 // behind the ballot branches and interleaves waits: 2-3 serialised L2 round trips
 // per step instead of one).
 template <bool FULL>
-__device__ __forceinline__ uint32_t emit_cell(const uint4 *__restrict__ ce, uint32_t start, uint32_t end,
+__device__ __forceinline__ uint32_t emit_cell(const WorldDev &w, const uint4 *__restrict__ ce, uint32_t start, uint32_t end,
                                               uint32_t wm, bool skip_self, uint32_t conn, uint32_t conn_tag,
                                               chd_fanout_rec *__restrict__ out, uint32_t n_out) {
-    static_assert(FO_UNROLL == 4, "the load block below names four entries");
+    static_assert(FO_UNROLL == 8, "the load block below names eight entries");
     const uint32_t lane = lane_id();
     for (uint32_t b = start; b < end; b += 64 * FO_UNROLL) {
         u32x4 e[FO_UNROLL];
@@ -135,29 +197,46 @@ __device__ __forceinline__ uint32_t emit_cell(const uint4 *__restrict__ ce, uint
             uint32_t pos = b + j * 64 + lane;
             p[j] = ce + (pos < end ? pos : end - 1);
         }
+        // On gfx950 the vm counter is in-order: waiting for these loads also drains the record stores
+        // of the previous step, so a step should be as large as registers allow (8 x 64 entries: a
+        // typical cell in one step).
         asm volatile(
-            "global_load_dwordx4 %0, %4, off\n\t"
-            "global_load_dwordx4 %1, %5, off\n\t"
-            "global_load_dwordx4 %2, %6, off\n\t"
-            "global_load_dwordx4 %3, %7, off\n\t"
+            "global_load_dwordx4 %0, %8, off\n\t"
+            "global_load_dwordx4 %1, %9, off\n\t"
+            "global_load_dwordx4 %2, %10, off\n\t"
+            "global_load_dwordx4 %3, %11, off\n\t"
+            "global_load_dwordx4 %4, %12, off\n\t"
+            "global_load_dwordx4 %5, %13, off\n\t"
+            "global_load_dwordx4 %6, %14, off\n\t"
+            "global_load_dwordx4 %7, %15, off\n\t"
             "s_waitcnt vmcnt(0)"
-            : "=&v"(e[0]), "=&v"(e[1]), "=&v"(e[2]), "=&v"(e[3])
-            : "v"(p[0]), "v"(p[1]), "v"(p[2]), "v"(p[3])
+            : "=&v"(e[0]), "=&v"(e[1]), "=&v"(e[2]), "=&v"(e[3]), "=&v"(e[4]), "=&v"(e[5]), "=&v"(e[6]), "=&v"(e[7])
+            : "v"(p[0]), "v"(p[1]), "v"(p[2]), "v"(p[3]), "v"(p[4]), "v"(p[5]), "v"(p[6]), "v"(p[7])
             : "memory");
 #pragma unroll
         for (int j = 0; j < FO_UNROLL; j++) {
-            uint32_t pos = b + j * 64 + lane;
+            if (end - b <= (uint32_t)(j * 64)) break;  // uniform
+            const uint32_t pos = b + j * 64 + lane;
             bool pass = pos < end;
             if (!FULL) {
-                pass = pass && (e[j].y & wm) != 0;
-                if (skip_self) pass = pass && e[j].z != conn;
+                const uint32_t a = e[j].y & wm, b2 = e[j].w & wm;  // current / previous sender's updates in the window
+                if (!skip_self) {
+                    pass = pass && (a | b2) != 0;
+                } else {
+                    bool pa = a != 0 && e[j].z != conn;
+                    if (__ballot(pass && b2 != 0)) {  // rare: a previous sender's update is still buffered
+                        if (pass && b2 != 0) pa = pa || load_sprev(w, pos) != conn;
+                    }
+                    pass = pass && pa;
+                }
             }
-            uint64_t m = __ballot(pass);
+            const uint64_t m = __ballot(pass);
+            const uint32_t at = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, n_out));
             if (pass) {
                 chd_fanout_rec r;
                 r.conn = conn_tag;
                 r.channel = e[j].x;
-                out[n_out + mask_rank(m)] = r;
+                out[at] = r;
             }
             n_out += (uint32_t)__popcll(m);
         }
@@ -171,7 +250,7 @@ __global__ void __launch_bounds__(64 * FO_WAVES) k_fanout_emit(DevGrid g, WorldD
     // due subscriptions of this connection, staged once per workgroup so that the
     // streaming waves never wait on per-subscription pointer chasing
     __shared__ uint32_t d_p[FO_TILE], d_fl[FO_TILE], d_c[FO_TILE], d_start[FO_TILE], d_end[FO_TILE], d_rel[FO_TILE],
-        d_chh[FO_TILE], d_chs[FO_TILE], d_iv[FO_TILE];
+        d_chh[FO_TILE], d_chs[FO_TILE], d_iv[FO_TILE], d_chhp[FO_TILE], d_chsp[FO_TILE];
     __shared__ int64_t d_L[FO_TILE];
     __shared__ uint32_t n_due, ticket;
     __shared__ uint32_t wave_total[FO_WAVES];
@@ -221,6 +300,8 @@ __global__ void __launch_bounds__(64 * FO_WAVES) k_fanout_emit(DevGrid g, WorldD
                     const uint32_t age = ring.cur_tick - w.cell_hist_tick[c];
                     d_chh[k] = age < CHD_HIST_BITS ? (w.cell_hist[c] << age) : 0u;
                     d_chs[k] = w.cell_sender[c];
+                    d_chhp[k] = age < CHD_HIST_BITS ? (w.cell_hist_prev[c] << age) : 0u;
+                    d_chsp[k] = w.cell_sender_prev[c];
                 } else {
                     w.pair_nrec[pbase + p] = 0;
                 }
@@ -251,26 +332,22 @@ __global__ void __launch_bounds__(64 * FO_WAVES) k_fanout_emit(DevGrid g, WorldD
                     r.channel = c + g.id_start;
                     out[0] = r;
                 }
-                n_out = emit_cell<true>(ce, start, end, 0u, false, conn, conn | CHD_REC_FULL, out, 1u);
+                n_out = emit_cell<true>(w, ce, start, end, 0u, false, conn, conn | CHD_REC_FULL, out, 1u);
                 fl |= PF_HAD_FIRST;
                 L = now;
             }
             // catch-up windows (data.go:224-271 + the revisit through :273-286)
             if (now >= L + I) {
-                int64_t nwin = (now - L) / I;
-                int64_t skip = skippable(ring, L, I, nwin);
-                if (skip > 0 && ring.n == CHD_HIST_BITS) hist_ovf = 1;
-                L += skip * I;
-                nwin -= skip;
+                if (fast_forward(ring, now, L, I)) hist_ovf = 1;
                 const uint32_t ch_hist = d_chh[k];
                 const uint32_t ch_sender = d_chs[k];
-                for (int64_t j = 0; j < nwin; j++) {
+                while (now >= L + I) {
                     const int64_t next = L + I;
                     const int64_t lo = L > 0 ? L : 0;  // lastUpdateTime starts at max(last, 0)
                     const uint32_t wm = window_mask(my_t, lo, next);
                     if (wm) {
                         // the spatial channel's own buffered updates
-                        if ((ch_hist & wm) && !(skip_self && ch_sender == conn)) {
+                        if (cell_update_passes(ch_hist, ch_sender, d_chhp[k], d_chsp[k], wm, skip_self, conn)) {
                             if (lane == 0) {
                                 chd_fanout_rec r;
                                 r.conn = conn;
@@ -279,11 +356,12 @@ __global__ void __launch_bounds__(64 * FO_WAVES) k_fanout_emit(DevGrid g, WorldD
                             }
                             n_out += 1;
                         }
-                        n_out = emit_cell<false>(ce, start, end, wm, skip_self, conn, conn, out, n_out);
+                        n_out = emit_cell<false>(w, ce, start, end, wm, skip_self, conn, conn, out, n_out);
                     }
                     L = next;
                 }
             }
+            pad_segment(out, n_out);
             if (lane == 0) {
                 w.pair_last[pbase + p] = L;
                 w.pair_flags[pbase + p] = fl;
@@ -308,9 +386,487 @@ __global__ void __launch_bounds__(64 * FO_WAVES) k_fanout_emit(DevGrid g, WorldD
     }
 }
 
+// ---------------------------------------------------------------------------
+// Cell-major emit (grids up to 4096 cells), wave-specialised and persistent.
+//
+// Work item = (active cell c, chunk of 256 connection slots); unit = (item, tile of
+// WS_TILE entity entries of c).  A persistent grid strides over the items.  In every
+// workgroup wave 0 is the LOADER and waves 1-3 are STREAMERS, double-buffered
+// through LDS:
+//   loader   new item: one lane per connection slot — interest-bitmap test, rank in
+//            the bitmap row (= index of the subscription in the connection's
+//            cell-sorted list), due test of tickData (data.go:175-291) -> list of due
+//            subscriptions in LDS (ballot-compacted, deterministic order);
+//            every unit: the tile's 16-byte entries -> LDS (SoA)
+//   streamer each due subscription x each non-empty fan-out window: stream the LDS
+//            tile, ballot/mbcnt compaction, 512-byte contiguous wave stores of
+//            {conn, channel} records; fan-out state write-back on the last tile
+// The streamers never issue a global load, so they never execute an s_waitcnt vmcnt:
+// on gfx950 the vm counter is in-order, and a wave that waits for a load also drains
+// every record store it issued before it (measured: that drain + the pointer chasing
+// of the due test kept the store stream at 55 % of what a plain store kernel reaches).
+// The workgroup barrier between units orders LDS only.  Each cell table is read from
+// L2 once per (cell, chunk) instead of once per subscription; the HBM traffic that
+// remains is the 8 B/record stream.
+// ---------------------------------------------------------------------------
+#define WS_TILE 512
+#define WS_SUBS 256
+#define WS_ROUNDS (WS_SUBS / 64)
+#define WS_WAVES 8
+#define WS_STREAMERS (WS_WAVES - 1)
+
+struct WsList {  // the due subscriptions of one item (LDS copy of WsItemG's first ndue entries)
+    uint32_t pi[WS_SUBS], conn[WS_SUBS], flags[WS_SUBS], out16[WS_SUBS], nout[WS_SUBS];
+    uint32_t wm[4][WS_SUBS];
+    uint32_t ndue, c, item;
+};
+
+struct WsTile {  // one tile of the item's cell
+    uint32_t chan[WS_TILE], hist[WS_TILE], snd[WS_TILE], hprev[WS_TILE], sprev[WS_TILE];
+    uint32_t valid, tn, gpos, first, last, list_buf, any_prev, ticket;
+};
+
+__device__ __forceinline__ void lds_barrier() {
+    // orders LDS only: __syncthreads() would add s_waitcnt vmcnt(0), i.e. drain the record stores
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+}
+
+// The streamers' inner loop.  Everything that is wave-uniform stays on the scalar unit: the
+// bounds mask comes from the tile length, the window / sender tests are ballots combined as
+// 64-bit scalars, the write position is mbcnt(mask) + n_out with n_out as mbcnt's addend.
+// Per 64 records that leaves ~6 vector ALU instructions, 3 LDS reads and one 512-byte store.
+// PREV = some entry of the tile still buffers updates of a previous sender (rare): only then
+// the two-sender test (and its side-table load) is compiled in.
+template <bool FULL, bool PREV>
+__device__ __forceinline__ uint32_t emit_tile(const WorldDev &w, const WsTile &T, uint32_t wm, bool skip_self,
+                                              uint32_t conn, uint32_t conn_tag, chd_fanout_rec *__restrict__ out,
+                                              uint32_t n_out) {
+    const uint32_t lane = lane_id();
+    const uint32_t tn = T.tn;
+    for (uint32_t b = 0; b < tn; b += 256) {
+        uint32_t chan[4], ha[4], hb[4], snd[4];
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            // reads beyond tn stay inside the tile arrays (WS_TILE is a multiple of 256) and are masked below
+            const uint32_t idx = b + j * 64 + lane;
+            chan[j] = T.chan[idx];
+            if (!FULL) {
+                ha[j] = T.hist[idx];
+                snd[j] = T.snd[idx];
+                if (PREV) hb[j] = T.hprev[idx];
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            if (tn - b <= (uint32_t)(j * 64)) break;  // uniform
+            bool pl = b + j * 64 + lane < tn;
+            if (!FULL) {
+                bool pa = (ha[j] & wm) != 0;
+                if (skip_self) pa = pa && snd[j] != conn;
+                if (PREV) {
+                    const bool pb = pl && (hb[j] & wm) != 0;
+                    if (__ballot(pb)) {
+                        bool other = pb;
+                        if (pb && skip_self) other = T.sprev[b + j * 64 + lane] != conn;
+                        pa = pa || other;
+                    }
+                }
+                pl = pl && pa;
+            }
+            const uint64_t m = __ballot(pl);
+            const uint32_t pos = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, n_out));
+            if (pl) {
+                chd_fanout_rec r;
+                r.conn = conn_tag;
+                r.channel = chan[j];
+#ifdef CHD_EXP_NOSTREAM
+                out[pos & 511u] = r;  // experiment: same instructions, L2-resident target
+#else
+                out[pos] = r;
+#endif
+            }
+            n_out += (uint32_t)__popcll(m);
+        }
+    }
+    return n_out;
+}
+
+// window [lo, hi] as a mask over the tick ring (bit j = the stamp of tick cur-j lies in it)
+__device__ __forceinline__ uint32_t window_mask_serial(const TickRing &ring, int64_t lo, int64_t hi) {
+    uint32_t m = 0;
+    for (uint32_t j = 0; j < ring.n; j++) m |= (ring.t[j] >= lo && ring.t[j] <= hi) ? (1u << j) : 0u;
+    return m;
+}
+
+// K5a': per work item (active cell, chunk of 256 connection slots) the list of due
+// subscriptions, in global memory.  One thread per connection slot: interest-bitmap test,
+// rank in the bitmap row (= index of the subscription in the connection's cell-sorted
+// list), due test of tickData (data.go:194-199) and the whole catch-up window walk
+// (data.go:224-271 + the revisit through :273-286): the non-empty windows become masks
+// over the tick ring, the subscription's lastFanOutTime / hadFirstFanOut are advanced here,
+// so that the emit kernel's streamers only replay masks.  Ballot + LDS compaction keeps the
+// list order deterministic.  Subscribed but not due -> its record count is 0.
+__global__ void __launch_bounds__(WS_SUBS) k_fanout_items(DevGrid g, WorldDev w, int64_t now, TickRing ring,
+                                                          uint32_t chunks) {
+    __shared__ uint32_t wcnt[WS_SUBS / 64], wsub[WS_SUBS / 64];
+    const uint32_t n_items = *w.n_active * chunks;
+    const uint32_t lane = lane_id(), wave = threadIdx.x >> 6;
+    for (uint32_t item = blockIdx.x; item < n_items; item += gridDim.x) {
+        const uint32_t c = w.active_cells[item / chunks];
+        const uint32_t s = (item % chunks) * WS_SUBS + threadIdx.x;
+        const uint32_t wi = c >> 6, bit = c & 63u;
+        uint32_t ch_hist = 0, ch_hprev = 0;
+        {
+            const uint32_t age = ring.cur_tick - w.cell_hist_tick[c];
+            if (age < CHD_HIST_BITS) { ch_hist = w.cell_hist[c] << age; ch_hprev = w.cell_hist_prev[c] << age; }
+        }
+        const uint32_t ch_sender = w.cell_sender[c], ch_sprev = w.cell_sender_prev[c];
+        bool sub = false, due = false;
+        uint32_t fl = 0, iv = 0, conn = 0, flags = 0, wms[4] = {0, 0, 0, 0};
+        int64_t L = 0;
+        uint64_t outpos = 0;
+        size_t pi = 0;
+        if (s < w.S) {
+            const unsigned long long *row = w.sub_bits + (size_t)s * w.wb;
+            const unsigned long long word = row[wi];
+            uint32_t pre = 0;
+            for (uint32_t k = 0; k < wi; k++) pre += (uint32_t)__popcll(row[k]);
+            const uint32_t alive = w.sub_alive[s];
+            const uint64_t ub0 = w.rec_ub[s], ub1 = w.rec_ub[s + 1];
+            conn = w.conn_id[s];
+            sub = alive && ((word >> bit) & 1ull);
+            if (sub) {
+                pi = (size_t)s * w.capq + pre + (uint32_t)__popcll(word & ((1ull << bit) - 1ull));
+                fl = w.pair_flags[pi];
+                L = w.pair_last[pi];
+                iv = w.pair_iv[pi];
+                const int64_t I = (int64_t)iv * 1000000;
+                due = !(fl & PF_NO_ACCESS) && I > 0 && now >= L + I;
+                if (due && ub1 > w.recs_cap) {
+                    // no room for this connection's worst case: state untouched, it catches up next tick
+                    atomicOr(&w.counters[CTR_OVERFLOW], OVF_RECORDS);
+                    due = false;
+                }
+                if (due) {
+                    outpos = ub0 + w.pair_rel[pi];
+                    const bool skip_self = (fl & PF_SKIP_SELF) != 0;
+                    int64_t Lw = L;
+                    if (!(fl & PF_HAD_FIRST)) {  // data.go:217-223: full state, last = t
+                        flags |= WSF_FIRST;
+                        Lw = now;
+                    }
+                    if (skip_self) flags |= WSF_SKIP_SELF;
+                    uint32_t nw = 0;
+                    if (now >= Lw + I) {
+                        if (fast_forward(ring, now, Lw, I)) atomicAdd(&w.counters[CTR_HIST_OVERFLOW], 1u);
+                        while (now >= Lw + I) {
+                            const int64_t next = Lw + I;
+                            const uint32_t wm = window_mask_serial(ring, Lw > 0 ? Lw : 0, next);
+                            if (wm) {
+                                if (nw < 4) {
+                                    wms[nw] = wm;
+                                    if (cell_update_passes(ch_hist, ch_sender, ch_hprev, ch_sprev, wm, skip_self, conn))
+                                        flags |= 1u << (WSF_OWN_SHIFT + nw);
+                                }
+                                nw++;
+                            }
+                            Lw = next;
+                        }
+                    }
+                    if (nw > 4) flags |= WSF_GENERIC;
+                    flags |= (nw > 4 ? 4u : nw) << WSF_NWIN_SHIFT;
+                    w.pair_last[pi] = Lw;
+                    w.pair_flags[pi] = fl | PF_HAD_FIRST;
+                } else {
+                    w.pair_nrec[pi] = 0;
+                }
+            }
+        }
+        const uint64_t m = __ballot(due), sm = __ballot(sub);
+        __syncthreads();
+        if (lane == 0) { wcnt[wave] = (uint32_t)__popcll(m); wsub[wave] = (uint32_t)__popcll(sm); }
+        __syncthreads();
+        uint32_t base = 0, total = 0, nsub = 0;
+        for (uint32_t k = 0; k < WS_SUBS / 64; k++) {
+            if (k < wave) base += wcnt[k];
+            total += wcnt[k];
+            nsub += wsub[k];
+        }
+        WsItemG &G = w.items[item];
+        if (due) {
+            const uint32_t k = base + mask_rank(m);
+            G.pi[k] = (uint32_t)pi; G.conn[k] = conn; G.flags[k] = flags; G.out16[k] = (uint32_t)(outpos / CHD_SEG_ALIGN);
+            G.wm[0][k] = wms[0]; G.wm[1][k] = wms[1]; G.wm[2][k] = wms[2]; G.wm[3][k] = wms[3];
+            G.iv[k] = iv; G.L[k] = L;
+        }
+        if (threadIdx.x == 0) {
+            G.ndue = total;
+            G.nsub = nsub;
+            G.c = c;
+            G.ch_hist = ch_hist; G.ch_hprev = ch_hprev; G.ch_sender = ch_sender; G.ch_sprev = ch_sprev;
+            G.start = w.cell_start[c];
+            G.end = w.cell_end[c];
+        }
+    }
+}
+
+// loader: the item's due list global -> LDS (the first ndue entries of each array)
+__device__ __forceinline__ uint32_t ws_load_item(const WsItemG &G, uint32_t item, WsList &Lst, uint32_t &start,
+                                                 uint32_t &end, uint32_t &n_subscribed) {
+    const uint32_t lane = lane_id();
+    const uint32_t nd = G.ndue;
+    n_subscribed += G.nsub;
+    if (nd == 0) return 0;
+    start = G.start;
+    end = G.end;
+    for (uint32_t k = lane; k < nd; k += 64) {
+        Lst.pi[k] = G.pi[k]; Lst.conn[k] = G.conn[k]; Lst.flags[k] = G.flags[k]; Lst.out16[k] = G.out16[k];
+        Lst.wm[0][k] = G.wm[0][k]; Lst.wm[1][k] = G.wm[1][k]; Lst.wm[2][k] = G.wm[2][k]; Lst.wm[3][k] = G.wm[3][k];
+        Lst.nout[k] = 0;
+    }
+    if (lane == 0) { Lst.ndue = nd; Lst.c = G.c; Lst.item = item; }
+    return nd;
+}
+
+__global__ void __launch_bounds__(64 * WS_WAVES) k_fanout_emit_ws(DevGrid g, WorldDev w, int64_t now, TickRing ring,
+                                                                 uint32_t chunks) {
+    __shared__ WsList lists[2];
+    __shared__ WsTile tiles[2];
+    const uint32_t lane = lane_id();
+    const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const uint32_t n_items = *w.n_active * chunks;
+    const int64_t my_t = ring_stamp(ring);
+    // Consume the stamp once, here: the compiler's waitcnt pass otherwise keeps its load "pending" at
+    // the window loop's header and puts an s_waitcnt vmcnt(0) INSIDE the loop, where it drains the
+    // streamer's record stores once per window.
+    const uint32_t hist_ovf = __ballot(my_t == INT64_MIN) ? 1u : 0u;  // (always 0)
+    // loader state (uniform)
+    uint32_t item = blockIdx.x, item_seq = 0, tile0 = 0, cell_end = 0;
+    bool have_item = false;
+    uint32_t n_subscribed = 0;
+    // streamer accumulators
+    unsigned long long wave_sum = 0;
+
+    // prepares the next unit into tiles[tb] (and, for a new item, its due list)
+    auto prepare = [&](uint32_t tb) {
+        WsTile &T = tiles[tb];
+        for (;;) {
+            if (!have_item) {
+                if (item >= n_items) {
+                    if (lane == 0) T.valid = 0;
+                    return;
+                }
+                const uint32_t nd = ws_load_item(w.items[item], item, lists[item_seq & 1u], tile0, cell_end, n_subscribed);
+                item += gridDim.x;
+                if (nd == 0) continue;  // nobody in this chunk is due for this cell: no unit at all
+                have_item = true;
+                item_seq++;
+                if (lane == 0) { T.first = 1; }
+            } else if (lane == 0) {
+                T.first = 0;
+            }
+            const uint32_t tn = min(cell_end - tile0, (uint32_t)WS_TILE);
+            uint32_t prev_or = 0;
+            {
+                static_assert(WS_TILE == 512, "eight 16-byte loads per lane");
+                u32x4 e[8];
+                const uint4 *q[8];
+                const uint32_t last_i = tn ? tn - 1u : 0u;
+#pragma unroll
+                for (int j = 0; j < 8; j++) q[j] = w.ce_view + tile0 + min((uint32_t)(j * 64) + lane, last_i);
+                // one round trip for the whole tile (the compiler would wait after every load)
+                asm volatile(
+                    "global_load_dwordx4 %0, %8, off\n\t"
+                    "global_load_dwordx4 %1, %9, off\n\t"
+                    "global_load_dwordx4 %2, %10, off\n\t"
+                    "global_load_dwordx4 %3, %11, off\n\t"
+                    "global_load_dwordx4 %4, %12, off\n\t"
+                    "global_load_dwordx4 %5, %13, off\n\t"
+                    "global_load_dwordx4 %6, %14, off\n\t"
+                    "global_load_dwordx4 %7, %15, off\n\t"
+                    "s_waitcnt vmcnt(0)"
+                    : "=&v"(e[0]), "=&v"(e[1]), "=&v"(e[2]), "=&v"(e[3]), "=&v"(e[4]), "=&v"(e[5]), "=&v"(e[6]), "=&v"(e[7])
+                    : "v"(q[0]), "v"(q[1]), "v"(q[2]), "v"(q[3]), "v"(q[4]), "v"(q[5]), "v"(q[6]), "v"(q[7])
+                    : "memory");
+#pragma unroll
+                for (int j = 0; j < 8; j++) {
+                    const uint32_t idx = j * 64 + lane;
+                    if (idx < tn) {
+                        T.chan[idx] = e[j].x; T.hist[idx] = e[j].y; T.snd[idx] = e[j].z; T.hprev[idx] = e[j].w;
+                        prev_or |= e[j].w;
+                    }
+                }
+                if (__ballot(prev_or != 0)) {  // rare: previous senders' ids for the two-sender test
+#pragma unroll
+                    for (int j = 0; j < 8; j++) {
+                        const uint32_t idx = j * 64 + lane;
+                        if (idx < tn) T.sprev[idx] = load_sprev(w, tile0 + idx);
+                    }
+                }
+            }
+            const uint64_t any_prev = __ballot(prev_or != 0);
+            if (lane == 0) {
+                T.any_prev = any_prev ? 1u : 0u;
+                T.ticket = 0;
+                T.valid = 1;
+                T.tn = tn;
+                T.gpos = tile0;
+                T.last = tile0 + tn >= cell_end ? 1u : 0u;
+                T.list_buf = (item_seq - 1u) & 1u;
+            }
+            tile0 += tn;
+            if (tile0 >= cell_end) have_item = false;
+            return;
+        }
+    };
+
+    // The two roles run in SEPARATE loops that meet only at the workgroup barrier (same number of
+    // barriers on both sides).  With one shared loop the compiler merges the loader's pending-load
+    // state into the streamers' code and protects their registers with s_waitcnt vmcnt(0) — which,
+    // on the in-order vm counter, drains the streamers' record stores once per subscription.
+#ifdef CHD_PROFILE_EMIT
+    long long t_work = 0, t_wait = 0, t_mark = clock64();
+    uint32_t n_units = 0;
+#define WS_MARK(acc) do { long long _t = clock64(); acc += _t - t_mark; t_mark = _t; } while (0)
+#else
+#define WS_MARK(acc) do { } while (0)
+#endif
+    if (wave == 0) {
+        prepare(0);
+        WS_MARK(t_work);
+        lds_barrier();
+        WS_MARK(t_wait);
+        for (uint32_t u = 0;; u++) {
+            if (!tiles[u & 1u].valid) break;
+            prepare((u + 1u) & 1u);
+            WS_MARK(t_work);
+            lds_barrier();
+            WS_MARK(t_wait);
+        }
+    } else {
+        lds_barrier();
+        WS_MARK(t_wait);
+        for (uint32_t u = 0;; u++) {
+            const WsTile &T = tiles[u & 1u];
+            if (!T.valid) break;
+#ifdef CHD_PROFILE_EMIT
+            n_units++;
+#endif
+            WsList &Lst = lists[T.list_buf];
+            const uint32_t ndue = Lst.ndue, c = Lst.c;
+            const bool first_tile = T.first != 0, last_tile = T.last != 0;
+            for (;;) {
+                uint32_t k = 0;
+                if (lane == 0) k = atomicAdd(&tiles[u & 1u].ticket, 1u);
+                k = __builtin_amdgcn_readfirstlane(k);
+                if (k >= ndue) break;
+                const uint32_t flags = Lst.flags[k];
+                const uint32_t conn = Lst.conn[k];
+                const bool skip_self = (flags & WSF_SKIP_SELF) != 0;
+#ifdef CHD_EXP_NOSTREAM
+                chd_fanout_rec *__restrict__ out = w.recs + (size_t)(blockIdx.x * WS_WAVES + wave) * 512u;
+#else
+                chd_fanout_rec *__restrict__ out = w.recs + (size_t)Lst.out16[k] * CHD_SEG_ALIGN;
+#endif
+                uint32_t n_out = Lst.nout[k];
+                if (flags & WSF_FIRST) {
+                    // first fan-out: whole data of the spatial channel and of every entity channel in it
+                    if (first_tile) {
+                        if (lane == 0) {
+                            chd_fanout_rec r;
+                            r.conn = conn | CHD_REC_FULL;
+                            r.channel = c + g.id_start;
+                            out[0] = r;
+                        }
+                        n_out = 1;
+                    }
+                    n_out = emit_tile<true, false>(w, T, 0u, false, conn, conn | CHD_REC_FULL, out, n_out);
+                }
+                if (!(flags & WSF_GENERIC)) {
+                    const uint32_t nw = (flags >> WSF_NWIN_SHIFT) & 7u;
+                    for (uint32_t j = 0; j < nw; j++) {
+                        const uint32_t wm = Lst.wm[j][k];
+                        if (first_tile && ((flags >> (WSF_OWN_SHIFT + j)) & 1u)) {  // the spatial channel's own update
+                            if (lane == 0) {
+                                chd_fanout_rec r;
+                                r.conn = conn;
+                                r.channel = c + g.id_start;
+                                out[n_out] = r;
+                            }
+                            n_out += 1;
+                        }
+                        n_out = T.any_prev ? emit_tile<false, true>(w, T, wm, skip_self, conn, conn, out, n_out)
+                                           : emit_tile<false, false>(w, T, wm, skip_self, conn, conn, out, n_out);
+                    }
+                } else {
+                    // more than four non-empty windows (a subscription that was not served for several ticks):
+                    // walk them from the state before this tick (the only global loads a streamer ever issues)
+                    const WsItemG &G = w.items[Lst.item];
+                    int64_t L = (flags & WSF_FIRST) ? now : G.L[k];
+                    const int64_t I = (int64_t)G.iv[k] * 1000000;
+                    if (now >= L + I) {
+                        (void)fast_forward(ring, now, L, I);
+                        while (now >= L + I) {
+                            const int64_t next = L + I;
+                            const uint32_t wm = window_mask(my_t, L > 0 ? L : 0, next);
+                            if (wm) {
+                                if (first_tile && cell_update_passes(G.ch_hist, G.ch_sender, G.ch_hprev, G.ch_sprev, wm, skip_self, conn)) {
+                                    if (lane == 0) {
+                                        chd_fanout_rec r;
+                                        r.conn = conn;
+                                        r.channel = c + g.id_start;
+                                        out[n_out] = r;
+                                    }
+                                    n_out += 1;
+                                }
+                                n_out = T.any_prev ? emit_tile<false, true>(w, T, wm, skip_self, conn, conn, out, n_out)
+                                                   : emit_tile<false, false>(w, T, wm, skip_self, conn, conn, out, n_out);
+                            }
+                            L = next;
+                        }
+                    }
+                }
+                if (last_tile) pad_segment(out, n_out);
+                if (lane == 0) {
+                    Lst.nout[k] = n_out;
+                    if (last_tile) {
+                        w.pair_nrec[Lst.pi[k]] = n_out;
+                        wave_sum += n_out;
+                    }
+                }
+            }
+            WS_MARK(t_work);
+            lds_barrier();
+            WS_MARK(t_wait);
+        }
+    }
+#ifdef CHD_PROFILE_EMIT
+    if (lane == 0 && (blockIdx.x == 0 || blockIdx.x == 517) && ring.cur_tick == 60)
+        printf("emit_ws block %u wave %u: units %u work %lld wait %lld (records %llu)\n", blockIdx.x, wave, n_units, t_work,
+               t_wait, wave_sum);
+#endif
+    if (lane == 0) {
+        unsigned long long *slot = (unsigned long long *)&w.tot64[(size_t)((blockIdx.x * WS_WAVES + wave) & 63u) * 16];
+        if (wave_sum) atomicAdd(slot, wave_sum);
+        if (n_subscribed) atomicAdd(slot + 1, (unsigned long long)n_subscribed);
+        if (hist_ovf) atomicAdd(&w.counters[CTR_HIST_OVERFLOW], 1u);
+    }
+}
+
 void launch_fanout_emit(hipStream_t st, DevGrid g, WorldDev w, int64_t now_ns, TickRing ring) {
     if (!w.S) return;
-    hipLaunchKernelGGL(k_fanout_emit, dim3(w.S), dim3(64 * FO_WAVES), 0, st, g, w, now_ns, ring);
+    if (w.wb) {
+        const uint32_t chunks = (w.S + WS_SUBS - 1) / WS_SUBS;
+        const uint64_t max_items = (uint64_t)g.ncell * chunks;
+        const uint32_t grid = (uint32_t)(max_items < w.emit_grid ? max_items : w.emit_grid);
+        const uint32_t pgrid = (uint32_t)(max_items < 8u * w.emit_grid ? max_items : 8u * w.emit_grid);
+        hipLaunchKernelGGL(k_fanout_items, dim3(pgrid), dim3(WS_SUBS), 0, st, g, w, now_ns, ring, chunks);
+        hipLaunchKernelGGL(k_fanout_emit_ws, dim3(grid), dim3(64 * WS_WAVES), 0, st, g, w, now_ns, ring, chunks);
+    } else {
+        hipLaunchKernelGGL(k_fanout_emit, dim3(w.S), dim3(64 * FO_WAVES), 0, st, g, w, now_ns, ring);
+    }
 }
 
 // Per-tick totals into the device-side history ring (read back by chd_tick_fetch /
@@ -331,7 +887,8 @@ __global__ void __launch_bounds__(64) k_tick_epilogue(WorldDev w, uint32_t slot)
         r[4] = w.counters[CTR_UNSUBS];
         r[5] = w.counters[CTR_NEWSUBS];
         r[6] = pairs;
-        r[7] = (uint64_t)w.counters[CTR_OVERFLOW] | ((uint64_t)w.counters[CTR_HIST_OVERFLOW] << 32);
+        r[7] = (uint64_t)w.counters[CTR_OVERFLOW] |
+               ((uint64_t)(w.counters[CTR_HIST_OVERFLOW] + w.counters[CTR_SENDER_OVERFLOW]) << 32);
     }
     __syncthreads();
     if (lane < CTR_COUNT) w.counters[lane] = 0;

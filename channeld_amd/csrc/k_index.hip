@@ -12,8 +12,9 @@
 //                    ballots (peer masks by key bits), never from atomics, so the
 //                    per-cell order is by entity slot and the output is
 //                    deterministic.  Writes what the emit kernel streams: one
-//                    16-byte entry per entity {entity channel id, update history
-//                    aligned to this tick, sender, entity slot}, and cell_off.
+//                    16-byte entry per entity {entity channel id, update history of
+//                    its sender aligned to this tick, sender, history of the previous
+//                    sender} (+ the previous sender in a side array), and cell_off.
 //
 // Also here: the generic exclusive scans (single workgroup, 1024 lanes,
 // wave-shuffle scan + LDS carry).
@@ -100,7 +101,9 @@ __global__ void __launch_bounds__(IDX_BLOCK) k_index_scatter(WorldDev w, uint32_
         uint32_t pos = mycnt[key[r]] + lrank[r];
         uint32_t age = cur_tick - w.hist_tick[i];
         uint32_t h = (age >= CHD_HIST_BITS) ? 0u : (w.hist[i] << age);
-        w.ce[pos] = make_uint4(w.chan_id[i], h, w.sender[i], i);
+        uint32_t hp = (age >= CHD_HIST_BITS) ? 0u : (w.hist_prev[i] << age);
+        w.ce[pos] = make_uint4(w.chan_id[i], h, w.sender[i], hp);
+        w.ce_sprev[pos] = w.sender_prev[i];
     }
     // compact cell offsets for the fan-out kernels (blk_cnt is cell-major with stride nblk)
     if (blockIdx.x == 0) {
@@ -128,7 +131,9 @@ __global__ void __launch_bounds__(256) k_index_scatter_global(WorldDev w, uint32
     uint32_t pos = w.blk_cnt[m] + atomicAdd(&cursor[m], 1u);
     uint32_t age = cur_tick - w.hist_tick[i];
     uint32_t h = (age >= CHD_HIST_BITS) ? 0u : (w.hist[i] << age);
-    w.ce[pos] = make_uint4(w.chan_id[i], h, w.sender[i], i);
+    uint32_t hp = (age >= CHD_HIST_BITS) ? 0u : (w.hist_prev[i] << age);
+    w.ce[pos] = make_uint4(w.chan_id[i], h, w.sender[i], hp);
+    w.ce_sprev[pos] = w.sender_prev[i];
 }
 
 // ------------------------------------------------------------------------

@@ -54,6 +54,8 @@ __global__ void __launch_bounds__(256) k_spawn_auto(DevGrid g, WorldDev w, uint3
     w.sender[i] = sender ? sender[u] : 0u;
     w.hist[i] = 0;
     w.hist_tick[i] = cur_tick;
+    w.sender_prev[i] = 0;
+    w.hist_prev[i] = 0;
 }
 
 void launch_spawn_auto(hipStream_t st, DevGrid g, WorldDev w, uint32_t n, const uint32_t *chan_id,
@@ -83,10 +85,7 @@ __global__ void __launch_bounds__(256) k_ingest_by_channel(DevGrid g, WorldDev w
             dst = cell_of(g, xs[k], zs[k]);
             src = w.cell[i];
             w.cell[i] = dst;
-            uint32_t age = cur_tick - w.hist_tick[i];
-            uint32_t h = (age >= CHD_HIST_BITS) ? 0u : (w.hist[i] << age);
-            w.hist[i] = h | 1u;
-            w.hist_tick[i] = cur_tick;
+            push_update(w, i, w.sender[i], cur_tick);
             if (src != CHD_INVALID && dst != CHD_INVALID && src != dst) {
                 if (ef & EF_LOCKED) locked = true;
                 else ho = true;
@@ -157,7 +156,8 @@ __global__ void __launch_bounds__(256) k_export(DevGrid g, WorldDev w, uint32_t 
     e.sender = w.sender[i];
     const uint32_t age = cur_tick - w.hist_tick[i];
     e.hist = age >= CHD_HIST_BITS ? 0u : (w.hist[i] << age);
-    e._pad[0] = e._pad[1] = 0;
+    e.hist_prev = age >= CHD_HIST_BITS ? 0u : (w.hist_prev[i] << age);
+    e.sender_prev = w.sender_prev[i];
     seg[1 + k] = e;
     w.eflags[i] = 0;
     w.member[i] = CHD_INVALID;
@@ -192,6 +192,8 @@ __global__ void __launch_bounds__(256) k_import(WorldDev w, const chd_entity_sta
     w.sender[i] = e.sender;
     w.hist[i] = e.hist;
     w.hist_tick[i] = cur_tick;
+    w.hist_prev[i] = e.hist_prev;
+    w.sender_prev[i] = e.sender_prev;
 }
 
 void launch_import(hipStream_t st, WorldDev w, const chd_entity_state *recv, uint32_t world, uint32_t cap,
@@ -207,7 +209,7 @@ __global__ void __launch_bounds__(256) k_cell_table(DevGrid g, WorldDev w, const
     uint32_t o = server_of(g, c);
     uint32_t a = 0, b = 0;
     if (o < world) {
-        const uint32_t *off = (const uint32_t *)(tables + (size_t)o * table_bytes + sizeof(uint4) * (size_t)w.N);
+        const uint32_t *off = (const uint32_t *)(tables + (size_t)o * table_bytes + (sizeof(uint4) + sizeof(uint32_t)) * (size_t)w.N);
         const uint32_t base = (uint32_t)((size_t)o * (table_bytes / sizeof(uint4)));  // in 16-byte entries
         a = base + off[c];
         b = base + off[c + 1];

@@ -180,6 +180,8 @@ __global__ void __launch_bounds__(256) k_spawn(DevGrid g, WorldDev w, uint32_t n
     w.sender[i] = sender ? sender[u] : 0u;
     w.hist[i] = 0;
     w.hist_tick[i] = cur_tick;
+    w.sender_prev[i] = 0;
+    w.hist_prev[i] = 0;
 }
 
 void launch_spawn(hipStream_t st, DevGrid g, WorldDev w, uint32_t n, const uint32_t *idx,
@@ -227,6 +229,14 @@ __global__ void __launch_bounds__(256) k_subs_add(WorldDev w, uint32_t n, const 
     if (u >= n) return;
     uint32_t s = slot ? slot[u] : u;
     if (s >= w.S) return;
+    // a connection that goes away (or is replaced) drops its subscriptions
+    // (data.go:183-188): per-cell subscriber counts and its interest bitmap row follow
+    if (w.sub_alive[s]) {
+        const uint32_t cnt = w.pair_cnt[s];
+        for (uint32_t p = 0; p < cnt; p++) atomicSub(&w.cell_ref[w.pair_cell[(size_t)s * w.capq + p]], 1u);
+    }
+    if (w.sub_bits)
+        for (uint32_t k = 0; k < w.wb; k++) w.sub_bits[(size_t)s * w.wb + k] = 0;
     w.sub_alive[s] = add ? 1u : 0u;
     w.conn_id[s] = add ? conn[u] : 0u;
     w.pair_cnt[s] = 0;
@@ -280,11 +290,7 @@ __global__ void __launch_bounds__(256) k_ingest(DevGrid g, WorldDev w, uint32_t 
                 dst[j] = cell_of(g, x[u], z[u]);
                 src[j] = w.cell[i];
                 w.cell[i] = dst[j];
-                uint32_t age = cur_tick - w.hist_tick[i];
-                uint32_t h = (age >= CHD_HIST_BITS) ? 0u : (w.hist[i] << age);
-                w.hist[i] = h | 1u;
-                w.hist_tick[i] = cur_tick;
-                if (sender) w.sender[i] = sender[u];
+                push_update(w, i, sender ? sender[u] : w.sender[i], cur_tick);
                 if (src[j] != CHD_INVALID && dst[j] != CHD_INVALID && src[j] != dst[j]) {
                     if (ef & EF_LOCKED) locked[j] = true;
                     else ho[j] = true;
@@ -335,33 +341,58 @@ void launch_ingest(hipStream_t st, DevGrid g, WorldDev w, uint32_t n, const uint
                        sender, cur_tick);
 }
 
-// spatial-channel data updates (spawn/destroy merges through OnUpdate)
+// spatial-channel data updates (spawn/destroy merges through OnUpdate).  One thread per
+// cell applies the batch's updates of its cell in batch order (same two-sender history
+// as the entity channels), so several updates of one cell in a tick are deterministic.
 __global__ void __launch_bounds__(256) k_cell_updates(DevGrid g, WorldDev w, uint32_t n,
                                                       const uint32_t *__restrict__ chan,
                                                       const uint32_t *__restrict__ sender,
                                                       uint32_t cur_tick) {
-    uint32_t u = blockIdx.x * 256u + threadIdx.x;
-    if (u >= n) return;
-    uint32_t c = chan[u] - g.id_start;
+    const uint32_t c = blockIdx.x * 256u + threadIdx.x;
     if (c >= g.ncell) return;
-    // several updates of one cell in a batch: all carry the same stamp, so the
-    // history bit is idempotent; the last sender wins like the entity path.
-    uint32_t age = cur_tick - w.cell_hist_tick[c];
-    if (age != 0) {
-        uint32_t h = (age >= CHD_HIST_BITS) ? 0u : (w.cell_hist[c] << age);
-        w.cell_hist[c] = h | 1u;
-        w.cell_hist_tick[c] = cur_tick;
-    } else {
-        w.cell_hist[c] |= 1u;
+    bool touched = false;
+    uint32_t h = 0, hp = 0, cur = 0, prev = 0;
+    for (uint32_t u = 0; u < n; u++) {
+        if (chan[u] - g.id_start != c) continue;
+        if (!touched) {
+            const uint32_t age = cur_tick - w.cell_hist_tick[c];
+            h = (age >= CHD_HIST_BITS) ? 0u : (w.cell_hist[c] << age);
+            hp = (age >= CHD_HIST_BITS) ? 0u : (w.cell_hist_prev[c] << age);
+            cur = w.cell_sender[c];
+            prev = w.cell_sender_prev[c];
+            touched = true;
+        }
+        const uint32_t snd = sender[u];
+        if (snd != cur) {
+            if (snd == prev) {
+                const uint32_t t = h;
+                h = hp;
+                hp = t;
+                prev = cur;
+            } else {
+                if (h != 0) {
+                    if (hp != 0 && prev != cur) atomicAdd(&w.counters[CTR_SENDER_OVERFLOW], 1u);
+                    hp |= h;
+                    prev = cur;
+                }
+                h = 0;
+            }
+            cur = snd;
+        }
+        h |= 1u;
     }
-    w.cell_sender[c] = sender[u];
+    if (touched) {
+        w.cell_hist[c] = h;
+        w.cell_hist_prev[c] = hp;
+        w.cell_sender[c] = cur;
+        w.cell_sender_prev[c] = prev;
+        w.cell_hist_tick[c] = cur_tick;
+    }
 }
 
 void launch_cell_updates(hipStream_t st, DevGrid g, WorldDev w, uint32_t n, const uint32_t *chan,
                          const uint32_t *sender, uint32_t cur_tick) {
     if (!n) return;
-    // one block, sequential per cell semantics are idempotent; duplicates of a cell
-    // in one batch race only on identical values except cell_sender (last wins).
-    hipLaunchKernelGGL(k_cell_updates, dim3(nblocks(n, 256)), dim3(256), 0, st, g, w, n, chan, sender,
+    hipLaunchKernelGGL(k_cell_updates, dim3(nblocks(g.ncell, 256)), dim3(256), 0, st, g, w, n, chan, sender,
                        cur_tick);
 }

@@ -72,14 +72,14 @@ class DeviceArray:
 
 class SpatialWorld:
     def __init__(self, ctl: StaticGrid2DSpatialController, max_entities: int, max_subscribers: int,
-                 max_interest_cells: int = 0, max_records: int = 0, max_handovers: int = 0):
+                 max_interest_cells: int = 0, max_records: int = 0, max_handovers: int = 0, flags: int = 0):
         self.ctl = ctl
         self.lib = _lib.load()
         self.ctx = ctl.ctx
         self.N, self.S = int(max_entities), int(max_subscribers)
         ncell = ctl.GridCols * ctl.GridRows
         self.capq = int(max_interest_cells) if max_interest_cells else min(ncell, 256)
-        cfg = WorldCfg(self.N, self.S, self.capq, int(max_records), int(max_handovers))
+        cfg = WorldCfg(self.N, self.S, self.capq, int(max_records), int(max_handovers), int(flags))
         _lib.check(self.ctx, self.lib.chd_world_create(self.ctx, C.byref(cfg)))
 
     # ---- population ----

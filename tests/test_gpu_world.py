@@ -13,10 +13,21 @@ from oracle import pyoracle as orc
 pytestmark = pytest.mark.gpu
 
 
+EMIT_FLAGS = 0
+
+
+@pytest.fixture(autouse=True, params=["cell-major", "conn-major"])
+def emit_mode(request):
+    """Every world test runs against both forms of the fan-out emit kernel."""
+    global EMIT_FLAGS
+    EMIT_FLAGS = 1 if request.param == "conn-major" else 2  # CHD_WORLD_CONN_MAJOR_EMIT / CHD_WORLD_CELL_MAJOR_EMIT
+    yield request.param
+
+
 def make(amd, cfg, N, S, capq=0, max_records=0):
     ctl = amd.StaticGrid2DSpatialController()
     assert ctl.LoadConfig(json.dumps(cfg).encode(), strict=False) is None
-    w = amd.SpatialWorld(ctl, N, S, max_interest_cells=capq, max_records=max_records)
+    w = amd.SpatialWorld(ctl, N, S, max_interest_cells=capq, max_records=max_records, flags=EMIT_FLAGS)
     return ctl, w
 
 
@@ -229,3 +240,59 @@ def test_cell_channel_updates_and_self_skip(amd):
                 seen_delta[int(r["conn"])] += 1
     # 7 never receives entity deltas (its own), 8 never receives the cell channel's deltas
     assert seen_delta[9] > seen_delta[7] > 0 and seen_delta[9] > seen_delta[8] > 0
+
+
+def test_changing_senders_keep_per_update_self_skip(amd):
+    """SkipSelfUpdateFanOut compares each BUFFERED update's senderConnId with the subscriber
+    (data.go:242-245).  Entities are updated by connection 7 on some ticks and 8 on others
+    (an ownership change); subscribers 7 and 8 must each miss exactly their own updates, also
+    while the other sender's older updates are still inside their slower fan-out windows."""
+    cfg = synth.load_config("spatial_static_2x2.json")
+    g = orc.grid_from_config(cfg)
+    N, S = 40, 3
+    ctl, gw = make(amd, cfg, N, S)
+    ow = orc.World(g, N, S, gw.capq, 20, 0)
+    rng = np.random.default_rng(5)
+    x = rng.uniform(-1900, 1900, N)
+    z = rng.uniform(-1900, 1900, N)
+    chan = (0x80000 + np.arange(N)).astype(np.uint32)
+    conns = np.array([7, 8, 9], dtype=np.uint32)
+    sender0 = np.full(N, 7, dtype=np.uint32)
+    ow.spawn(np.arange(N), chan, x, z, np.zeros(N, dtype=np.uint32), sender0)
+    gw.spawn(None, chan, x, z, None, sender0)
+    for s in range(S):
+        ow.add_sub(s, int(conns[s]))
+    gw.add_subscribers(None, conns)
+    import channeld_amd as A
+
+    # a sphere covering the whole 2x2 world: cells at distance 1-2 get 50/100 ms intervals, so windows span several ticks
+    qs = [orc.QueryBuilder(sphere=(-1000.0, -1000.0, 3000.0)) for _ in range(S)]
+    gq = [A.SpatialInterestQuery(SphereAOI=A.SphereAOI(Center=A.SpatialInfo(X=-1000.0, Z=-1000.0), Radius=3000.0)) for _ in range(S)]
+    t = 0
+    deltas = {7: 0, 8: 0, 9: 0}
+    for k in range(24):
+        t += 20_000_000
+        snd = np.where((np.arange(N) + k // 3) % 2 == 0, 7, 8).astype(np.uint32)  # ownership flips every 3 ticks
+        idx = np.arange(N, dtype=np.uint32)
+        ow.tick(t, idx, x, z, snd, None, None, None, qs if k == 0 else None)
+        res = gw.tick(t, upd_idx=idx, upd_x=x, upd_z=z, upd_sender=snd, queries=gq if k == 0 else None)
+        compare_tick(k, res, ow, S)
+        for r in res.records:
+            if not (r["conn"] & 0x80000000):
+                deltas[int(r["conn"])] += 1
+    assert deltas[9] > deltas[7] > 0 and deltas[9] > deltas[8] > 0
+
+
+def test_third_sender_inside_the_history_is_flagged(amd):
+    cfg = synth.load_config("spatial_static_2x2.json")
+    N, S = 4, 1
+    ctl, gw = make(amd, cfg, N, S)
+    x = np.full(N, 500.0)
+    z = np.full(N, 500.0)
+    gw.spawn(None, (0x80000 + np.arange(N)).astype(np.uint32), x, z, None, np.full(N, 5, dtype=np.uint32))
+    gw.add_subscribers(None, np.array([9], dtype=np.uint32))
+    flagged = 0
+    for k, snd in enumerate((5, 6, 7, 5)):
+        res = gw.tick((k + 1) * 20_000_000, upd_x=x, upd_z=z, upd_sender=np.full(N, snd, dtype=np.uint32))
+        flagged += res.history_overflow
+    assert flagged > 0
