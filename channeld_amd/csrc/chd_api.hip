@@ -507,6 +507,7 @@ int chd_world_create(chd_ctx *ctx, const chd_world_cfg *cfg) {
     TRY(walloc(ctx, &d.ce, N));
     TRY(walloc(ctx, &d.ce_sprev, N));
     TRY(walloc(ctx, &d.cell_off, C + 1));
+    TRY(walloc(ctx, &d.cell_tot, C));
     TRY(walloc(ctx, &d.cell_ref, C));
     TRY(walloc(ctx, &d.active_cells, C));
     TRY(walloc(ctx, &d.n_active, 1));

@@ -34,7 +34,8 @@ enum {
     CTR_HIST_OVERFLOW = 4,
     CTR_PAIRS = 5,
     CTR_NEWSUBS = 6,
-    CTR_SENDER_OVERFLOW = 7,  // a third sender inside a channel's 32-tick update history
+    CTR_SENDER_OVERFLOW = 7,
+    CTR_SCAN_DONE = 8,        // workgroups of k_index_scan that have finished (last-block pattern)  // a third sender inside a channel's 32-tick update history
     CTR_COUNT = 16
 };
 

@@ -47,6 +47,7 @@ struct WorldDev {
                           //  sender, history of the previous sender}
     uint32_t *ce_sprev;   // [N] previous sender (read only where its history intersects a window)
     uint32_t *cell_off;   // [ncell+1] cell c owns ce[cell_off[c], cell_off[c+1])
+    uint32_t *cell_tot;   // [ncell] entities per cell (intermediate of the index build)
     // what the fan-out kernels read: cell c owns ce_view[cell_start[c], cell_end[c]).  Single GPU: ce_view = ce,
     // cell_start = cell_off, cell_end = cell_off + 1.  Region-sharded: ce_view = the all-gathered tables.
     const uint4 *ce_view;

@@ -5,9 +5,8 @@
 //
 //   k_index_hist   : per-block histogram of member cells in LDS (one LDS
 //                    atomic per entity), written cell-major to blk_cnt[c*nblk+b]
-//   scan           : exclusive scan of blk_cnt (cell-major), so that
-//                    blk_cnt[c*nblk+b] = cell_off[c] + (entities of c in blocks < b)
-//                    and blk_cnt[c*nblk] = cell_off[c]
+//   k_index_scan   : one wave per cell: blk_cnt[c*nblk+b] -> entities of c in blocks < b;
+//                    the last workgroup scans the cell totals into cell_off
 //   k_index_scatter: stable scatter — ranks inside a block come from wave
 //                    ballots (peer masks by key bits), never from atomics, so the
 //                    per-cell order is by entity slot and the output is
@@ -46,8 +45,61 @@ __global__ void __launch_bounds__(IDX_BLOCK) k_index_hist(WorldDev w, uint32_t n
     for (uint32_t c = threadIdx.x; c < ncell; c += IDX_BLOCK) w.blk_cnt[(size_t)c * w.nblk + blockIdx.x] = h[c];
 }
 
+template <typename T>
+__device__ __forceinline__ T wave_incl_scan(T v);
+
+// Second step: one wave per cell turns the cell's per-block counts into prefixes (entities of the
+// cell in earlier blocks) and records the cell's total; the LAST workgroup to finish then scans the
+// totals into cell_off (a release/acquire pair at device scope makes the other workgroups' totals
+// visible across the XCDs' private L2s).  Replaces a single-workgroup scan over cells x blocks.
+__global__ void __launch_bounds__(256) k_index_scan(WorldDev w, uint32_t ncell, int finalize) {
+    __shared__ uint32_t is_last;
+    __shared__ uint32_t part[256];
+    const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
+    const uint32_t c = blockIdx.x * 4u + wave;
+    if (c < ncell) {
+        uint32_t *row = w.blk_cnt + (size_t)c * w.nblk;
+        uint32_t carry = 0;
+        for (uint32_t b0 = 0; b0 < w.nblk; b0 += 64) {
+            const uint32_t b = b0 + lane;
+            const uint32_t v = b < w.nblk ? row[b] : 0u;
+            const uint32_t inc = wave_incl_scan(v);
+            if (b < w.nblk) row[b] = carry + inc - v;
+            carry += __shfl(inc, 63);
+        }
+        if (lane == 0) (finalize ? w.cell_off : w.cell_tot)[c] = carry;  // the cell's total
+    }
+    // small grids: the scatter workgroups scan the few cell totals themselves (no cross-workgroup step)
+    if (!finalize) return;
+    __threadfence();
+    __syncthreads();
+    if (threadIdx.x == 0) is_last = atomicAdd(&w.counters[CTR_SCAN_DONE], 1u) == gridDim.x - 1u ? 1u : 0u;
+    __syncthreads();
+    if (!is_last) return;
+    __threadfence();
+    // exclusive scan of the ncell totals (<= 4096): contiguous chunk per thread, then a 256-wide scan
+    const uint32_t per = (ncell + 255u) / 256u;
+    const uint32_t lo = threadIdx.x * per, hi = min(lo + per, ncell);
+    uint32_t sum = 0;
+    for (uint32_t i = lo; i < hi; i++) sum += __atomic_load_n(&w.cell_off[i], __ATOMIC_RELAXED);
+    part[threadIdx.x] = sum;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint32_t run = 0;
+        for (uint32_t i = 0; i < 256; i++) { const uint32_t v = part[i]; part[i] = run; run += v; }
+        w.cell_off[ncell] = run;
+    }
+    __syncthreads();
+    uint32_t run = part[threadIdx.x];
+    for (uint32_t i = lo; i < hi; i++) {
+        const uint32_t v = w.cell_off[i];
+        w.cell_off[i] = run;
+        run += v;
+    }
+}
+
 __global__ void __launch_bounds__(IDX_BLOCK) k_index_scatter(WorldDev w, uint32_t ncell, uint32_t key_bits,
-                                                             uint32_t cur_tick) {
+                                                             uint32_t cur_tick, int local_base) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     uint32_t *wcnt = (uint32_t *)smem;  // [4][ncell] running per-wave counters
     const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -84,10 +136,41 @@ __global__ void __launch_bounds__(IDX_BLOCK) k_index_scatter(WorldDev w, uint32_
         }
     }
     __syncthreads();
+    // cell bases: either final in cell_off (k_index_scan's last workgroup) or scanned here from the
+    // cell totals (ncell <= 1024: four cells per lane, one wave scan, 256 partials)
+    uint32_t *cbase = wcnt + 4 * ncell;
+    if (local_base) {
+        __shared__ uint32_t part[IDX_BLOCK];
+        const uint32_t per = (ncell + IDX_BLOCK - 1) / IDX_BLOCK;
+        const uint32_t lo = threadIdx.x * per, hi = min(lo + per, ncell);
+        uint32_t sum = 0;
+        for (uint32_t i = lo; i < hi; i++) sum += w.cell_tot[i];
+        part[threadIdx.x] = sum;
+        __syncthreads();
+        if (threadIdx.x < 64) {  // scan of the 256 partials by one wave, 4 per lane
+            uint32_t v[4], t = 0;
+            for (int k = 0; k < 4; k++) { v[k] = part[threadIdx.x * 4 + k]; t += v[k]; }
+            uint32_t inc = wave_incl_scan(t);
+            uint32_t run = inc - t;
+            for (int k = 0; k < 4; k++) { part[threadIdx.x * 4 + k] = run; run += v[k]; }
+        }
+        __syncthreads();
+        uint32_t run = part[threadIdx.x];
+        for (uint32_t i = lo; i < hi; i++) {
+            cbase[i] = run;
+            run += w.cell_tot[i];
+        }
+        if (blockIdx.x == 0) {  // publish the CSR offsets for the fan-out kernels
+            uint32_t r2 = part[threadIdx.x];
+            for (uint32_t i = lo; i < hi; i++) { w.cell_off[i] = r2; r2 += w.cell_tot[i]; }
+            if (hi == ncell && lo < hi) w.cell_off[ncell] = r2;
+        }
+        __syncthreads();
+    }
     // exclusive prefix over the 4 waves, in place: wcnt[w][c] -> entities of c in waves < w
     for (uint32_t c = threadIdx.x; c < ncell; c += IDX_BLOCK) {
         uint32_t a0 = wcnt[c], a1 = wcnt[ncell + c], a2 = wcnt[2 * ncell + c];
-        uint32_t g0 = w.blk_cnt[(size_t)c * w.nblk + blockIdx.x];  // scanned: global base of this block for c
+        uint32_t g0 = (local_base ? cbase[c] : w.cell_off[c]) + w.blk_cnt[(size_t)c * w.nblk + blockIdx.x];  // cell base + entities of c in earlier blocks
         wcnt[c] = g0;
         wcnt[ncell + c] = g0 + a0;
         wcnt[2 * ncell + c] = g0 + a0 + a1;
@@ -104,10 +187,6 @@ __global__ void __launch_bounds__(IDX_BLOCK) k_index_scatter(WorldDev w, uint32_
         uint32_t hp = (age >= CHD_HIST_BITS) ? 0u : (w.hist_prev[i] << age);
         w.ce[pos] = make_uint4(w.chan_id[i], h, w.sender[i], hp);
         w.ce_sprev[pos] = w.sender_prev[i];
-    }
-    // compact cell offsets for the fan-out kernels (blk_cnt is cell-major with stride nblk)
-    if (blockIdx.x == 0) {
-        for (uint32_t c = threadIdx.x; c <= ncell; c += IDX_BLOCK) w.cell_off[c] = w.blk_cnt[(size_t)c * w.nblk];
     }
 }
 
@@ -208,9 +287,10 @@ void launch_index_build(hipStream_t st, DevGrid g, WorldDev w, uint32_t cur_tick
     if (!w.N) return;
     if (g.ncell <= IDX_MAX_LDS_CELLS) {
         hipLaunchKernelGGL(k_index_hist, dim3(w.nblk), dim3(IDX_BLOCK), g.ncell * 4, st, w, g.ncell);
-        launch_scan_u32_inplace(st, w.blk_cnt, g.ncell * w.nblk);
-        hipLaunchKernelGGL(k_index_scatter, dim3(w.nblk), dim3(IDX_BLOCK), 4 * g.ncell * 4, st, w, g.ncell,
-                           bits_for(g.ncell), cur_tick);
+        const int local_base = g.ncell <= 1024;
+        hipLaunchKernelGGL(k_index_scan, dim3((g.ncell + 3) / 4), dim3(256), 0, st, w, g.ncell, !local_base);
+        hipLaunchKernelGGL(k_index_scatter, dim3(w.nblk), dim3(IDX_BLOCK), (local_base ? 5 : 4) * g.ncell * 4, st, w,
+                           g.ncell, bits_for(g.ncell), cur_tick, local_base);
     } else {
         // nblk == 1 layout: blk_cnt[c] then scan -> cell_off; cursor lives behind it
         uint32_t *cursor = w.blk_cnt + (size_t)g.ncell + 1;

@@ -147,6 +147,12 @@ def test_world_8x8_small_aoi(amd):
     assert total > 50000
 
 
+def test_world_40x40_grid_1600_cells(amd):
+    # > 1024 cells: the index build's cross-workgroup total scan, 25 bitmap words per connection
+    total, n_ho = run_world(amd, "spatial_static_40x40.json", 5000, 300, 12, 0xC0FFEE08, tick_ms=40, aoi_scale=1.0)
+    assert total > 50000 and n_ho > 0
+
+
 def test_world_slow_ticks_catch_up(amd):
     # 170 ms ticks: several catch-up windows per tick for every interval class
     total, n_ho = run_world(amd, "spatial_static_benchmark.json", 2000, 100, 16, 0xC0FFEE06, tick_ms=170)
