@@ -35,7 +35,7 @@ SYMBOLS = (
     "chd_world_get_entities", "chd_dev_alloc", "chd_dev_free", "chd_dev_upload",
     "chd_dev_download", "chd_set_profiling", "chd_get_tick_stats", "chd_get_tick_history",
     "chd_set_stream", "chd_shard_spawn", "chd_shard_ingest", "chd_shard_import", "chd_shard_fanout",
-    "chd_shard_get_entities", "chd_shard_table_bytes",
+    "chd_shard_get_entities", "chd_shard_table_bytes", "chd_shard_interest",
 )
 
 
@@ -186,6 +186,7 @@ def load():
     L.chd_shard_table_bytes.argtypes = [C.c_void_p, P(C.c_uint64)]
     L.chd_shard_import.argtypes = [C.c_void_p, _vp, C.c_uint32, C.c_uint32, _vp]
     L.chd_shard_fanout.argtypes = [C.c_void_p, _vp, C.c_uint32, P(TickIn)]
+    L.chd_shard_interest.argtypes = [C.c_void_p, P(TickIn)]
     L.chd_shard_get_entities.argtypes = [C.c_void_p, _u32p, _u32p, _u32p, P(C.c_uint32)]
     L.chd_set_profiling.argtypes = [C.c_void_p, C.c_int]
     L.chd_get_tick_stats.argtypes = [C.c_void_p, P(TickStats)]

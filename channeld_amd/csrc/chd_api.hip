@@ -985,6 +985,20 @@ int chd_shard_import(chd_ctx *ctx, const chd_entity_state *d_recv, uint32_t worl
     return CHD_OK;
 }
 
+int chd_shard_interest(chd_ctx *ctx, const chd_tick_in *d_in) {
+    NEED_WORLD();
+    if (!d_in) return fail(ctx, CHD_E_INVAL, "chd_shard_interest: NULL input");
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    if (ctx->w.slot_mode != 2) return fail(ctx, CHD_E_STATE, "chd_shard_interest before chd_shard_ingest");
+    TRY(bind(ctx));
+    TRY(check_queries(ctx, d_in));
+    launch_aoi_interest(ctx->stream, ctx->g, ctx->lim, ctx->w.d, d_in->queries, d_in->n_queries, d_in->query_sub,
+                        d_in->spot_x, d_in->spot_z, d_in->spot_dist, ctx->w.last_now, ctx->ring.cur_tick);
+    TRY(after_launch(ctx));
+    ctx->w.last_nq = d_in->n_queries;
+    return CHD_OK;
+}
+
 int chd_shard_fanout(chd_ctx *ctx, const void *d_tables, uint32_t world, const chd_tick_in *d_in) {
     NEED_WORLD();
     if (!d_in) return fail(ctx, CHD_E_INVAL, "chd_shard_fanout: NULL input");
@@ -1017,7 +1031,7 @@ int chd_shard_fanout(chd_ctx *ctx, const void *d_tables, uint32_t world, const c
     if (prof) HIPCHK(hipEventRecord(ev[5], st));
     launch_tick_epilogue(st, d, r.cur_tick % TICK_RING);
     TRY(after_launch(ctx));
-    W.last_nq = d_in->n_queries;
+    if (d_in->n_queries) W.last_nq = d_in->n_queries;
     W.ticked = true;
     return CHD_OK;
 }

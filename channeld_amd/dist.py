@@ -10,10 +10,11 @@ Connections (subscribers) are pinned to ranks.  One tick:
     all-to-all         the reference's cross-server handover (spatial.go:683-700):
                        ~32 B per border crossing, a few hundred per tick
     engine.import_     immigrants take slots; local cell index rebuilt + published
-    all-gather         every rank's cell table (16 B per entity): an AOI that
+    all-gather         every rank's cell table (20 B per entity): an AOI that
                        straddles a region border reads remote cells
                        (generalises ServerInterestBorderSize, spatial.go:481-590)
-    engine.fanout      interest updates + fan-out of the local connections
+      engine.interest  ... while the interest updates of the local connections run
+    engine.fanout      fan-out of the local connections over the gathered tables
 
 With backend "nccl" (= RCCL over xGMI) the exchange buffers are device tensors and
 everything is ordered on torch's current stream without host synchronisation.  With
@@ -108,16 +109,25 @@ class Comm:
         recv = torch.stack([allbuf[src][self.rank] for src in range(self.world)])
         return recv.to(send.device)
 
-    def all_gather(self, t):
-        """every rank's `t`, rank-major, as one flat tensor."""
+    def all_gather(self, t, overlap=None):
+        """every rank's `t`, rank-major, as one flat tensor.  `overlap()` (optional) is work for the
+        compute stream that does not depend on the result: with RCCL it is enqueued while the
+        collective runs on the communication stream."""
         import torch
 
         if self.world == 1:
+            if overlap:
+                overlap()
             return t
         if not self.staged:
             out = torch.empty(self.world * t.numel(), dtype=t.dtype, device=t.device)
-            self.dist.all_gather_into_tensor(out, t.contiguous().view(-1))
+            work = self.dist.all_gather_into_tensor(out, t.contiguous().view(-1), async_op=True)
+            if overlap:
+                overlap()
+            work.wait()  # the compute stream waits for the collective (no host synchronisation)
             return out
+        if overlap:
+            overlap()
         host = t.detach().cpu().contiguous().view(-1)
         parts = [torch.empty_like(host) for _ in range(self.world)]
         self.dist.all_gather(parts, host)
@@ -203,14 +213,19 @@ class HipShardEngine:
         self._lib.check(self.ctx, self.lib.chd_shard_import(self.ctx, rp, self.world, self.cap, C.c_void_p(self.table.data_ptr())))
         return self.table
 
-    def fanout(self, tables, queries=None, n_queries: int = 0):
+    def interest(self, queries=None, n_queries: int = 0):
         """queries: uint8 device tensor of n_queries packed chd_aoi_query records for slots 0..n_queries-1."""
         ti = self._lib.TickIn()
         if queries is not None and n_queries:
             ti.n_queries, ti.queries = int(n_queries), C.c_void_p(queries.data_ptr())
+        self._queries = queries
+        self._lib.check(self.ctx, self.lib.chd_shard_interest(self.ctx, C.byref(ti)))
+        self.sw._last_nq = int(n_queries)
+
+    def fanout(self, tables):
+        ti = self._lib.TickIn()
         self._tables = tables
         self._lib.check(self.ctx, self.lib.chd_shard_fanout(self.ctx, C.c_void_p(tables.data_ptr()), self.world, C.byref(ti)))
-        self.sw._last_nq = int(n_queries)
 
     def fetch(self, want_records=False, records_cap=0):
         return self.sw.fetch(want_records=want_records, records_cap=records_cap)
@@ -239,8 +254,9 @@ class ShardedWorld:
         send = self.engine.ingest(now_ns, x_by_chan, z_by_chan, has_update)
         recv = self.comm.all_to_all(send) if self.comm.world > 1 else None
         table = self.engine.import_(recv)
-        tables = self.comm.all_gather(table)
-        self.engine.fanout(tables, queries, n_queries)
+        # the interest updates do not read the gathered tables: they run under the all-gather
+        tables = self.comm.all_gather(table, overlap=lambda: self.engine.interest(queries, n_queries))
+        self.engine.fanout(tables)
 
 
 # ---------------------------------------------------------------------------

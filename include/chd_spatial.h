@@ -341,6 +341,12 @@ int chd_shard_table_bytes(chd_ctx *ctx, uint64_t *bytes);
 int chd_shard_import(chd_ctx *ctx, const chd_entity_state *d_recv, uint32_t world,
                      uint32_t cap, void *d_table_out);
 
+/* Optional, any time between chd_shard_ingest and chd_shard_fanout: the interest updates
+ * of this rank's connections (the query fields of d_in).  They do not depend on the
+ * gathered tables, so a caller can run them while the all-gather is in flight and then
+ * pass no queries to chd_shard_fanout. */
+int chd_shard_interest(chd_ctx *ctx, const chd_tick_in *d_in);
+
 /* Phase 3, after the all-gather: d_tables = world tables, rank-major.  Runs the interest
  * updates of d_in (queries of this rank's connections; the update fields of d_in are
  * ignored) and the fan-out of this rank's connections over the gathered tables.  Outputs

@@ -29,7 +29,7 @@ class SimShardEngine:
         self.member = np.zeros(0, dtype=np.uint32)
         self.flags = np.zeros(0, dtype=np.uint32)
         self.subs = []          # (conn_id,)
-        self.interest = {}      # slot -> sorted cell indices
+        self.interest_sets = {} # slot -> sorted cell indices
         self.visible = {}       # conn -> set of entity channels (last tick)
         self.handovers = []     # (chan, src_cell, dst_cell) of the last tick
         self.table_words = 4 * max_entities + self.ncell + 1
@@ -101,18 +101,20 @@ class SimShardEngine:
         table[4 * self.N: 4 * self.N + self.ncell + 1] = np.concatenate([[0], np.cumsum(counts)])
         return torch.from_numpy(table.view(np.int32))
 
-    def fanout(self, tables, queries=None, n_queries=0):
-        t = tables.numpy().view(np.uint32).reshape(self.world, self.table_words)
+    def interest(self, queries=None, n_queries=0):
         if queries is not None:
             for slot in range(n_queries):
                 rc, m = orc.query_channel_ids(self.g, queries[slot])
                 if rc == 0:
-                    self.interest[slot] = sorted(c - ID0 for c in m)
+                    self.interest_sets[slot] = sorted(c - ID0 for c in m)
+
+    def fanout(self, tables):
+        t = tables.numpy().view(np.uint32).reshape(self.world, self.table_words)
         owner = server_of_cell(self.cfg, np.arange(self.ncell))
         self.visible = {}
         for slot, conn in enumerate(self.subs):
             vis = set()
-            for c in self.interest.get(slot, []):
+            for c in self.interest_sets.get(slot, []):
                 tab = t[owner[c]]
                 off = tab[4 * self.N: 4 * self.N + self.ncell + 1]
                 ent = tab[: 4 * self.N].reshape(self.N, 4)
