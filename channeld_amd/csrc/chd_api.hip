@@ -504,7 +504,7 @@ int chd_world_create(chd_ctx *ctx, const chd_world_cfg *cfg) {
     TRY(walloc(ctx, &d.cell_sender_prev, C));
     d.nblk = (C <= 4096) ? index_num_blocks(d.N) : 1;
     TRY(walloc(ctx, &d.blk_cnt, std::max(C * d.nblk + 1, 2 * C + 2)));
-    TRY(walloc(ctx, &d.ce, N));
+    TRY(walloc(ctx, &d.ce, N + 1));  // + 1: the emit kernel loads entries in adjacent pairs
     TRY(walloc(ctx, &d.ce_sprev, N));
     TRY(walloc(ctx, &d.cell_off, C + 1));
     TRY(walloc(ctx, &d.cell_tot, C));

@@ -183,6 +183,27 @@ __device__ __forceinline__ bool cell_update_passes(uint32_t h, uint32_t snd, uin
 // one asm block (left to itself the compiler splits them into dwords, sinks pieces
 // behind the ballot branches and interleaves waits: 2-3 serialised L2 round trips
 // per step instead of one).
+// the per-entry test of one window (two-sender history); `pos` only for the rare side-table load
+template <bool FULL>
+__device__ __forceinline__ bool entry_passes(const WorldDev &w, const u32x4 &e, uint32_t pos, bool in_range,
+                                             uint32_t wm, bool skip_self, uint32_t conn) {
+    if (FULL) return in_range;
+    const uint32_t a = e.y & wm, b2 = e.w & wm;  // current / previous sender's updates in the window
+    if (!skip_self) return in_range && (a | b2) != 0;
+    bool pa = a != 0 && e.z != conn;
+    if (__ballot(in_range && b2 != 0)) {  // rare: a previous sender's update is still buffered
+        if (in_range && b2 != 0) pa = pa || load_sprev(w, pos) != conn;
+    }
+    return in_range && pa;
+}
+
+// One window (or the full state) of one cell for one connection.  A step covers 512 entries:
+// every lane owns FOUR PAIRS of adjacent entries (eight 16-byte loads issued back to back from one
+// asm block — left to itself the compiler splits them into dwords, sinks pieces behind the ballot
+// branches and interleaves waits).  The kernel is instruction-issue bound (SQ counters: the SIMDs
+// are ~90 % busy), so the common case is made cheap: when all 128 entries of a pair-row pass, each
+// lane writes its two records with ONE 16-byte store at out[n_out + 2*lane] and no rank arithmetic;
+// otherwise ballot/mbcnt compaction keeps entry order.
 template <bool FULL>
 __device__ __forceinline__ uint32_t emit_cell(const WorldDev &w, const uint4 *__restrict__ ce, uint32_t start, uint32_t end,
                                               uint32_t wm, bool skip_self, uint32_t conn, uint32_t conn_tag,
@@ -191,54 +212,65 @@ __device__ __forceinline__ uint32_t emit_cell(const WorldDev &w, const uint4 *__
     const uint32_t lane = lane_id();
     for (uint32_t b = start; b < end; b += 64 * FO_UNROLL) {
         u32x4 e[FO_UNROLL];
-        const uint4 *p[FO_UNROLL];
+        const uint4 *p[FO_UNROLL / 2];
 #pragma unroll
-        for (int j = 0; j < FO_UNROLL; j++) {
-            uint32_t pos = b + j * 64 + lane;
-            p[j] = ce + (pos < end ? pos : end - 1);
+        for (int j = 0; j < FO_UNROLL / 2; j++) {
+            // row j of the step = entries [b + 128 j, b + 128 j + 128); this lane owns 2*lane and 2*lane + 1.
+            // `end - 2` keeps both loads inside the cell (cells of fewer than 2 entries: see below).
+            const uint32_t pos = b + j * 128 + 2 * lane;
+            p[j] = ce + (pos + 1 < end ? pos : (end >= start + 2 ? end - 2 : start));  // ce has one spare entry
         }
         // On gfx950 the vm counter is in-order: waiting for these loads also drains the record stores
-        // of the previous step, so a step should be as large as registers allow (8 x 64 entries: a
-        // typical cell in one step).
+        // of the previous step, so a step should be as large as registers allow.
         asm volatile(
             "global_load_dwordx4 %0, %8, off\n\t"
-            "global_load_dwordx4 %1, %9, off\n\t"
-            "global_load_dwordx4 %2, %10, off\n\t"
-            "global_load_dwordx4 %3, %11, off\n\t"
-            "global_load_dwordx4 %4, %12, off\n\t"
-            "global_load_dwordx4 %5, %13, off\n\t"
-            "global_load_dwordx4 %6, %14, off\n\t"
-            "global_load_dwordx4 %7, %15, off\n\t"
+            "global_load_dwordx4 %1, %8, off offset:16\n\t"
+            "global_load_dwordx4 %2, %9, off\n\t"
+            "global_load_dwordx4 %3, %9, off offset:16\n\t"
+            "global_load_dwordx4 %4, %10, off\n\t"
+            "global_load_dwordx4 %5, %10, off offset:16\n\t"
+            "global_load_dwordx4 %6, %11, off\n\t"
+            "global_load_dwordx4 %7, %11, off offset:16\n\t"
             "s_waitcnt vmcnt(0)"
             : "=&v"(e[0]), "=&v"(e[1]), "=&v"(e[2]), "=&v"(e[3]), "=&v"(e[4]), "=&v"(e[5]), "=&v"(e[6]), "=&v"(e[7])
-            : "v"(p[0]), "v"(p[1]), "v"(p[2]), "v"(p[3]), "v"(p[4]), "v"(p[5]), "v"(p[6]), "v"(p[7])
+            : "v"(p[0]), "v"(p[1]), "v"(p[2]), "v"(p[3])
             : "memory");
 #pragma unroll
-        for (int j = 0; j < FO_UNROLL; j++) {
-            if (end - b <= (uint32_t)(j * 64)) break;  // uniform
-            const uint32_t pos = b + j * 64 + lane;
-            bool pass = pos < end;
-            if (!FULL) {
-                const uint32_t a = e[j].y & wm, b2 = e[j].w & wm;  // current / previous sender's updates in the window
-                if (!skip_self) {
-                    pass = pass && (a | b2) != 0;
-                } else {
-                    bool pa = a != 0 && e[j].z != conn;
-                    if (__ballot(pass && b2 != 0)) {  // rare: a previous sender's update is still buffered
-                        if (pass && b2 != 0) pa = pa || load_sprev(w, pos) != conn;
-                    }
-                    pass = pass && pa;
+        for (int j = 0; j < FO_UNROLL / 2; j++) {
+            if (end - b <= (uint32_t)(j * 128)) break;  // uniform
+            const uint32_t pos = b + j * 128 + 2 * lane;
+            const bool in0 = pos < end, in1 = pos + 1 < end;
+            // a lane whose pair was clamped loaded entries q, q+1 with q = end-2 (or start): entry `pos`
+            // is then the pair's second entry unless pos == q
+            const uint32_t q = in1 ? pos : (end >= start + 2 ? end - 2 : start);
+            const u32x4 ea = pos == q ? e[2 * j] : e[2 * j + 1];
+            const bool pass0 = entry_passes<FULL>(w, ea, pos, in0, wm, skip_self, conn);
+            const bool pass1 = entry_passes<FULL>(w, e[2 * j + 1], pos + 1, in1, wm, skip_self, conn);
+            const uint64_t m0 = __ballot(pass0), m1 = __ballot(pass1);
+            if ((m0 & m1) == ~0ull) {
+                // all 128 entries pass: records of the row are contiguous, two per lane
+                u32x4 r;
+                r.x = conn_tag; r.y = ea.x; r.z = conn_tag; r.w = e[2 * j + 1].x;
+                *(u32x4 *)(void *)(out + n_out + 2 * lane) = r;
+                n_out += 128;
+            } else {
+                // entry order: records before this lane's pair = passing entries of lower lanes
+                const uint32_t at = __builtin_amdgcn_mbcnt_hi((uint32_t)(m1 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m1,
+                                    __builtin_amdgcn_mbcnt_hi((uint32_t)(m0 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m0, n_out))));
+                if (pass0) {
+                    chd_fanout_rec r;
+                    r.conn = conn_tag;
+                    r.channel = ea.x;
+                    out[at] = r;
                 }
+                if (pass1) {
+                    chd_fanout_rec r;
+                    r.conn = conn_tag;
+                    r.channel = e[2 * j + 1].x;
+                    out[at + (pass0 ? 1u : 0u)] = r;
+                }
+                n_out += (uint32_t)__popcll(m0) + (uint32_t)__popcll(m1);
             }
-            const uint64_t m = __ballot(pass);
-            const uint32_t at = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, n_out));
-            if (pass) {
-                chd_fanout_rec r;
-                r.conn = conn_tag;
-                r.channel = e[j].x;
-                out[at] = r;
-            }
-            n_out += (uint32_t)__popcll(m);
         }
     }
     return n_out;

@@ -16,7 +16,7 @@ __global__ void __launch_bounds__(256) k_seg(v2u *out, uint32_t nseg, uint32_t s
     }
 }
 int main() {
-    const size_t bytes = 1ull << 30;
+    const size_t bytes = 2ull << 30;
     void *buf; hipMalloc(&buf, bytes + 4096);
     hipEvent_t a, b; hipEventCreate(&a); hipEventCreate(&b);
     struct { const char *name; uint32_t seg, pitch, shift; int scatter; } cases[] = {
@@ -30,6 +30,8 @@ int main() {
         {"448-rec segments at 448 pitch, linear", 448, 448, 0, 0},
         {"64-rec segments (one store) at 64 pitch, scattered", 64, 64, 0, 1},
         {"4096-rec segments at 4096 pitch, scattered", 4096, 4096, 0, 1},
+        {"448-rec segments at 1120 pitch (holes, like worst-case slots), scattered", 448, 1120, 0, 1},
+        {"448-rec segments at 1120 pitch, linear", 448, 1120, 0, 0},
     };
     for (auto &c : cases) {
         uint32_t nseg = (uint32_t)(bytes / 8 / c.pitch);
