@@ -189,6 +189,14 @@ def main():
     lat = np.array(lat) if lat else np.array([0.0])
     gpu_lat = np.array([h["total_us"] for h in world.history(min(L, 1024))]) / 1e3 if L else np.array([0.0])
 
+    # HBM bytes per launch of the dominant kernel from the PMC passes (FETCH_SIZE / WRITE_SIZE in separate
+    # rocprofv3 runs, tools/pmc_summary.py); only quoted for the workload it was measured on
+    traffic = None
+    tpath = os.path.join(ROOT, "profiles", "hbm_traffic.json")
+    if os.path.exists(tpath) and (N, S) == (100_000, 10_000) and args.aoi_scale == 1.0 and args.tick_ms == 50:
+        with open(tpath) as f:
+            traffic = json.load(f)["kernels"].get("k_fanout_emit", {}).get("bytes_per_launch")
+
     out = {
         "metric": "AOI-filtered fanout msgs/sec + p99 tick latency, 100K entities / 10K subs",
         "value": msgs / elapsed, "unit": "msgs/s", "n_gpus": 1, "steps": K, "warmup": W,
@@ -201,7 +209,8 @@ def main():
         "p99_tick_gpu_ms": float(np.percentile(gpu_lat, 99)),
         "stage_us_avg": {n: float(v) for n, v in zip(("ingest", "index", "interest", "plan", "emit"), stage_avg)},
         "roofline": {"bound": "hbm", "kernel": "k_fanout_emit", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                     "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_unit": "bytes per launch (PMC, profiles/hbm_traffic.json)",
+                     "algorithmic_bytes_per_launch": float(BYTES_PER_MSG * emit_msgs.mean()),
                      "bytes_per_msg": BYTES_PER_MSG, "msgs_per_launch": float(emit_msgs.mean()), "avg_launch_us": float(emit_us.mean())},
     }
     if not args.no_cpu and args.cpu_seconds > 0:
