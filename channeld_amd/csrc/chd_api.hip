@@ -506,6 +506,10 @@ int chd_world_create(chd_ctx *ctx, const chd_world_cfg *cfg) {
     TRY(walloc(ctx, &d.blk_cnt, std::max(C * d.nblk + 1, 2 * C + 2)));
     TRY(walloc(ctx, &d.ce, N + 1));  // + 1: the emit kernel loads entries in adjacent pairs
     TRY(walloc(ctx, &d.ce_sprev, N));
+    TRY(walloc(ctx, &d.ce8, N + 2));
+    TRY(walloc(ctx, &d.cell_usender, C));
+    TRY(walloc(ctx, &d.blk_smin, C * d.nblk + 1));
+    TRY(walloc(ctx, &d.blk_smax, C * d.nblk + 1));
     TRY(walloc(ctx, &d.cell_off, C + 1));
     TRY(walloc(ctx, &d.cell_tot, C));
     TRY(walloc(ctx, &d.cell_ref, C));
@@ -535,6 +539,7 @@ int chd_world_create(chd_ctx *ctx, const chd_world_cfg *cfg) {
     TRY(walloc(ctx, &d.free_stack, N));
     TRY(walloc(ctx, &d.free_top, 1));
     d.ce_view = d.ce;
+    d.ce8_view = d.ce8;
     d.ce_sprev_view = d.ce_sprev;
     d.ce_sprev_stride = 0;
     d.cell_start = d.cell_off;
@@ -701,6 +706,7 @@ static int tick_locked(chd_ctx *ctx, const chd_tick_in *in) {
     TRY(tick_begin(ctx, in->now_ns));
     TickRing &r = ctx->ring;
     d.ce_view = d.ce;
+    d.ce8_view = d.ce8;
     d.ce_sprev_view = d.ce_sprev;
     d.ce_sprev_stride = 0;
     d.cell_start = d.cell_off;
@@ -1018,6 +1024,7 @@ int chd_shard_fanout(chd_ctx *ctx, const void *d_tables, uint32_t world, const c
     if (prof) for (int k = 0; k <= 2; k++) HIPCHK(hipEventRecord(ev[k], st));
     launch_cell_table(st, ctx->g, d, d_tables, world, shard_table_bytes(ctx));
     d.ce_view = (const uint4 *)d_tables;
+    d.ce8_view = nullptr;  // gathered tables carry the 16-byte entries only
     d.ce_sprev_view = nullptr;
     d.ce_sprev_stride = (uint32_t)(shard_table_bytes(ctx) / sizeof(uint4));
     d.cell_start = d.cell_tab;

@@ -46,6 +46,10 @@ struct WorldDev {
     uint4 *ce;            // [N] sorted by cell: {entity channel id, history of `sender` aligned to this tick,
                           //  sender, history of the previous sender}
     uint32_t *ce_sprev;   // [N] previous sender (read only where its history intersects a window)
+    uint2 *ce8;           // [N] compact entries {entity channel id, history of any sender} for single-sender cells
+    uint32_t *cell_usender;           // [ncell] the one sender of the cell's buffered updates, or CHD_NONUNIFORM
+    uint32_t *blk_smin, *blk_smax;    // [ncell*nblk] per-block sender range (index build intermediate)
+    const uint2 *ce8_view;            // nullptr where compact entries are not available (gathered tables)
     uint32_t *cell_off;   // [ncell+1] cell c owns ce[cell_off[c], cell_off[c+1])
     uint32_t *cell_tot;   // [ncell] entities per cell (intermediate of the index build)
     // what the fan-out kernels read: cell c owns ce_view[cell_start[c], cell_end[c]).  Single GPU: ce_view = ce,

@@ -276,13 +276,75 @@ __device__ __forceinline__ uint32_t emit_cell(const WorldDev &w, const uint4 *__
     return n_out;
 }
 
+// The same stream over COMPACT 8-byte entries {channel, history}: used when all buffered updates of
+// the cell come from one sender (the usual case: the spatial server that owns the cell), so the
+// SkipSelfUpdateFanOut test is one scalar compare per subscription and the L2 read volume halves.
+// A lane's adjacent entry pair is ONE 16-byte load; a step covers 512 entries with four loads.
+template <bool FULL>
+__device__ __forceinline__ uint32_t emit_cell8(const uint2 *__restrict__ ce8, uint32_t start, uint32_t end, uint32_t wm,
+                                               uint32_t conn_tag, chd_fanout_rec *__restrict__ out, uint32_t n_out) {
+    const uint32_t lane = lane_id();
+    for (uint32_t b = start; b < end; b += 512) {
+        u32x4 e[4];
+        const uint2 *p[4];
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const uint32_t pos = b + j * 128 + 2 * lane;
+            p[j] = ce8 + (pos + 1 < end ? pos : (end >= start + 2 ? end - 2 : start));  // ce8 has spare entries
+        }
+        asm volatile(
+            "global_load_dwordx4 %0, %4, off\n\t"
+            "global_load_dwordx4 %1, %5, off\n\t"
+            "global_load_dwordx4 %2, %6, off\n\t"
+            "global_load_dwordx4 %3, %7, off\n\t"
+            "s_waitcnt vmcnt(0)"
+            : "=&v"(e[0]), "=&v"(e[1]), "=&v"(e[2]), "=&v"(e[3])
+            : "v"(p[0]), "v"(p[1]), "v"(p[2]), "v"(p[3])
+            : "memory");
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            if (end - b <= (uint32_t)(j * 128)) break;  // uniform
+            const uint32_t pos = b + j * 128 + 2 * lane;
+            const bool in0 = pos < end, in1 = pos + 1 < end;
+            const uint32_t q = in1 ? pos : (end >= start + 2 ? end - 2 : start);
+            const uint32_t chan_a = pos == q ? e[j].x : e[j].z, hist_a = pos == q ? e[j].y : e[j].w;
+            const bool pass0 = in0 && (FULL || (hist_a & wm) != 0);
+            const bool pass1 = in1 && (FULL || (e[j].w & wm) != 0);
+            const uint64_t m0 = __ballot(pass0), m1 = __ballot(pass1);
+            if ((m0 & m1) == ~0ull) {
+                u32x4 r;
+                r.x = conn_tag; r.y = chan_a; r.z = conn_tag; r.w = e[j].z;
+                *(u32x4 *)(void *)(out + n_out + 2 * lane) = r;
+                n_out += 128;
+            } else {
+                const uint32_t at = __builtin_amdgcn_mbcnt_hi((uint32_t)(m1 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m1,
+                                    __builtin_amdgcn_mbcnt_hi((uint32_t)(m0 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m0, n_out))));
+                if (pass0) {
+                    chd_fanout_rec r;
+                    r.conn = conn_tag;
+                    r.channel = chan_a;
+                    out[at] = r;
+                }
+                if (pass1) {
+                    chd_fanout_rec r;
+                    r.conn = conn_tag;
+                    r.channel = e[j].z;
+                    out[at + (pass0 ? 1u : 0u)] = r;
+                }
+                n_out += (uint32_t)__popcll(m0) + (uint32_t)__popcll(m1);
+            }
+        }
+    }
+    return n_out;
+}
+
 #define FO_TILE 256  // subscriptions staged in LDS per round (= workgroup size)
 
 __global__ void __launch_bounds__(64 * FO_WAVES) k_fanout_emit(DevGrid g, WorldDev w, int64_t now, TickRing ring) {
     // due subscriptions of this connection, staged once per workgroup so that the
     // streaming waves never wait on per-subscription pointer chasing
     __shared__ uint32_t d_p[FO_TILE], d_fl[FO_TILE], d_c[FO_TILE], d_start[FO_TILE], d_end[FO_TILE], d_rel[FO_TILE],
-        d_chh[FO_TILE], d_chs[FO_TILE], d_iv[FO_TILE], d_chhp[FO_TILE], d_chsp[FO_TILE];
+        d_chh[FO_TILE], d_chs[FO_TILE], d_iv[FO_TILE], d_chhp[FO_TILE], d_chsp[FO_TILE], d_us[FO_TILE];
     __shared__ int64_t d_L[FO_TILE];
     __shared__ uint32_t n_due, ticket;
     __shared__ uint32_t wave_total[FO_WAVES];
@@ -334,6 +396,7 @@ __global__ void __launch_bounds__(64 * FO_WAVES) k_fanout_emit(DevGrid g, WorldD
                     d_chs[k] = w.cell_sender[c];
                     d_chhp[k] = age < CHD_HIST_BITS ? (w.cell_hist_prev[c] << age) : 0u;
                     d_chsp[k] = w.cell_sender_prev[c];
+                    d_us[k] = w.ce8_view ? w.cell_usender[c] : CHD_NONUNIFORM;
                 } else {
                     w.pair_nrec[pbase + p] = 0;
                 }
@@ -353,6 +416,7 @@ __global__ void __launch_bounds__(64 * FO_WAVES) k_fanout_emit(DevGrid g, WorldD
             const uint32_t c = d_c[k];
             const uint32_t start = d_start[k], end = d_end[k];
             const bool skip_self = (fl & PF_SKIP_SELF) != 0;
+            const uint32_t us = d_us[k];
             chd_fanout_rec *__restrict__ out = w.recs + base + d_rel[k];
             uint32_t n_out = 0;
             if (!(fl & PF_HAD_FIRST)) {
@@ -364,7 +428,8 @@ __global__ void __launch_bounds__(64 * FO_WAVES) k_fanout_emit(DevGrid g, WorldD
                     r.channel = c + g.id_start;
                     out[0] = r;
                 }
-                n_out = emit_cell<true>(w, ce, start, end, 0u, false, conn, conn | CHD_REC_FULL, out, 1u);
+                n_out = w.ce8_view ? emit_cell8<true>(w.ce8_view, start, end, 0u, conn | CHD_REC_FULL, out, 1u)
+                                   : emit_cell<true>(w, ce, start, end, 0u, false, conn, conn | CHD_REC_FULL, out, 1u);
                 fl |= PF_HAD_FIRST;
                 L = now;
             }
@@ -388,7 +453,8 @@ __global__ void __launch_bounds__(64 * FO_WAVES) k_fanout_emit(DevGrid g, WorldD
                             }
                             n_out += 1;
                         }
-                        n_out = emit_cell<false>(w, ce, start, end, wm, skip_self, conn, conn, out, n_out);
+                        if (us == CHD_NONUNIFORM) n_out = emit_cell<false>(w, ce, start, end, wm, skip_self, conn, conn, out, n_out);
+                        else if (!(skip_self && us == conn)) n_out = emit_cell8<false>(w.ce8_view, start, end, wm, conn, out, n_out);
                     }
                     L = next;
                 }
