@@ -45,6 +45,8 @@ def parse():
     ap.add_argument("--latency-steps", type=int, default=-1, help="extra synchronous ticks for p50/p99 (default min(steps,200))")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU baseline budget (0 = skip)")
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--recipients", action="store_true",
+                    help="also plan the handover-message recipients every tick (CHD_WORLD_HANDOVER_RECIPIENTS)")
     ap.add_argument("--emit", choices=["auto", "cell-major", "conn-major"], default="auto",
                     help="form of the fan-out emit kernel (include/chd_spatial.h: CHD_WORLD_*_EMIT)")
     return ap.parse_args()
@@ -137,7 +139,7 @@ def main():
     ctl = A.StaticGrid2DSpatialController(device=local_rank)
     err = ctl.LoadConfig(json.dumps(cfg).encode(), strict=False)
     assert err is None, err
-    world = A.SpatialWorld(ctl, N, S, flags={"auto": 0, "conn-major": 1, "cell-major": 2}[args.emit])
+    world = A.SpatialWorld(ctl, N, S, flags={"auto": 0, "conn-major": 1, "cell-major": 2}[args.emit] | (4 if args.recipients else 0))
     world.spawn(None, sw.chan_id, sw.x, sw.z, sw.flags, sw.sender)
     world.add_subscribers(None, sw.sub_conn)
 

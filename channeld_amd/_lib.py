@@ -20,6 +20,10 @@ REC_FULL = 0x80000000
 ENTITY_LOCKED = 1
 WORLD_CONN_MAJOR_EMIT = 1
 WORLD_CELL_MAJOR_EMIT = 2
+WORLD_HANDOVER_RECIPIENTS = 4
+HO_SRC_ONLY, HO_DST_NEW, HO_DST_KNOWN = 0, 1, 2
+BROADCAST_ALL_BUT_SENDER, BROADCAST_ALL_BUT_OWNER, BROADCAST_ALL_BUT_CLIENT, BROADCAST_ALL_BUT_SERVER = 4, 8, 16, 32
+BROADCAST_ADJACENT_CHANNELS = 64
 MAX_DAMPING = 8
 N_STAGES = 5
 STAGE_NAMES = ("ingest", "index", "interest", "plan", "emit")
@@ -36,6 +40,7 @@ SYMBOLS = (
     "chd_dev_download", "chd_set_profiling", "chd_get_tick_stats", "chd_get_tick_history",
     "chd_set_stream", "chd_shard_spawn", "chd_shard_ingest", "chd_shard_import", "chd_shard_fanout",
     "chd_shard_get_entities", "chd_shard_table_bytes", "chd_shard_interest",
+    "chd_handover_recipients", "chd_adjacent_recipients",
 )
 
 
@@ -188,6 +193,8 @@ def load():
     L.chd_shard_fanout.argtypes = [C.c_void_p, _vp, C.c_uint32, P(TickIn)]
     L.chd_shard_interest.argtypes = [C.c_void_p, P(TickIn)]
     L.chd_shard_get_entities.argtypes = [C.c_void_p, _u32p, _u32p, _u32p, P(C.c_uint32)]
+    L.chd_handover_recipients.argtypes = [C.c_void_p, _u32p, _u32p, _u8p, C.c_uint64, P(C.c_uint64)]
+    L.chd_adjacent_recipients.argtypes = [C.c_void_p, C.c_uint32, _u32p, _u32p, _u32p, _u32p, _u32p, _u32p, C.c_uint64]
     L.chd_set_profiling.argtypes = [C.c_void_p, C.c_int]
     L.chd_get_tick_stats.argtypes = [C.c_void_p, P(TickStats)]
     L.chd_get_tick_history.argtypes = [C.c_void_p, C.c_uint32, P(TickStats)]

@@ -36,6 +36,11 @@ struct World {
     uint32_t last_nq = 0;
     bool ticked = false;
     int slot_mode = 0;  // 0 unset, 1 caller-chosen slots (chd_world_spawn), 2 library-managed (chd_shard_spawn)
+    bool plan_recipients = false;      // CHD_WORLD_HANDOVER_RECIPIENTS
+    uint32_t *ho_rcp_off = nullptr;    // [handovers_cap + 1] recipients of handover h: [off[h], off[h+1])
+    uint32_t *ho_rcp_conn = nullptr;   // connection ids
+    uint8_t *ho_rcp_kind = nullptr;    // CHD_HO_*
+    uint64_t ho_rcp_cap = 0;
 };
 
 }  // namespace
@@ -523,13 +528,15 @@ int chd_world_create(chd_ctx *ctx, const chd_world_cfg *cfg) {
                            (!(cfg->flags & CHD_WORLD_CONN_MAJOR_EMIT) && N / C >= 1024);
     if ((cfg->flags & CHD_WORLD_CELL_MAJOR_EMIT) && !cm_possible)
         return fail(ctx, CHD_E_INVAL, "cell-major emit needs a grid of at most 4096 cells (and cells x subscribers x 40 B <= 2 GiB)");
-    d.wb = (cm_possible && cm_wanted) ? (uint32_t)((C + 63) / 64) : 0u;
+    // the interest bitmap (one bit per cell and connection) exists for every grid of up to 4096 cells:
+    // the recipient planners use it too; larger grids fall back to searching the sorted subscription lists
+    d.wb = C <= 4096 ? (uint32_t)((C + 63) / 64) : 0u;
+    d.cm_emit = (cm_possible && cm_wanted) ? 1u : 0u;
     d.sub_bits = nullptr;
     d.items = nullptr;
-    if (d.wb) {
-        TRY(walloc(ctx, &d.sub_bits, S * d.wb));
-        TRY(walloc(ctx, &d.items, n_items_max, false));
-    }
+    if (d.wb) TRY(walloc(ctx, &d.sub_bits, S * d.wb));
+    if (d.cm_emit) TRY(walloc(ctx, &d.items, n_items_max, false));
+    W.plan_recipients = (cfg->flags & CHD_WORLD_HANDOVER_RECIPIENTS) != 0;
     {
         hipDeviceProp_t prop;
         HIPCHK(hipGetDeviceProperties(&prop, ctx->device));
@@ -559,6 +566,12 @@ int chd_world_create(chd_ctx *ctx, const chd_world_cfg *cfg) {
     TRY(walloc(ctx, &W.rec_off_exact, S + 1));
     d.handovers_cap = cfg->max_handovers ? cfg->max_handovers : d.N;
     TRY(walloc(ctx, &d.handovers, d.handovers_cap, false));
+    if (cfg->flags & CHD_WORLD_HANDOVER_RECIPIENTS) {
+        W.ho_rcp_cap = std::min<uint64_t>((uint64_t)d.handovers_cap * S, 1ull << 25);
+        TRY(walloc(ctx, &W.ho_rcp_off, (size_t)d.handovers_cap + 1));
+        TRY(walloc(ctx, &W.ho_rcp_conn, W.ho_rcp_cap, false));
+        TRY(walloc(ctx, &W.ho_rcp_kind, W.ho_rcp_cap, false));
+    }
     d.unsub_cap = (uint32_t)std::min<size_t>(P, 0x7FFFFFFF);
     TRY(walloc(ctx, &d.unsub_sub, d.unsub_cap, false));
     TRY(walloc(ctx, &d.unsub_cell, d.unsub_cap, false));
@@ -717,6 +730,13 @@ static int tick_locked(chd_ctx *ctx, const chd_tick_in *in) {
     if (prof) HIPCHK(hipEventRecord(ev[0], st));
     launch_ingest(st, ctx->g, d, in->n_updates, in->upd_idx, in->upd_x, in->upd_z, in->upd_sender, r.cur_tick);
     launch_cell_updates(st, ctx->g, d, in->n_cell_updates, in->cell_upd_channel, in->cell_upd_sender, r.cur_tick);
+    if (W.plan_recipients) {
+        // who receives each handover's message: on the subscriptions as they are NOW, before this tick's
+        // interest updates (the reference sends from Notify, spatial.go:776-857)
+        launch_handover_recipients_count(st, ctx->g, d, W.ho_rcp_off);
+        launch_scan_u32_inplace_dev(st, W.ho_rcp_off, d.handovers_cap, d.counters + CTR_HANDOVERS);
+        launch_handover_recipients_fill(st, ctx->g, d, W.ho_rcp_off, W.ho_rcp_conn, W.ho_rcp_kind, W.ho_rcp_cap);
+    }
     if (prof) HIPCHK(hipEventRecord(ev[1], st));
     launch_index_build(st, ctx->g, d, r.cur_tick);
     if (prof) HIPCHK(hipEventRecord(ev[2], st));
@@ -1064,6 +1084,69 @@ int chd_shard_get_entities(chd_ctx *ctx, uint32_t *chan_id, uint32_t *cell_chann
         n++;
     }
     *n_out = n;
+    return CHD_OK;
+}
+
+int chd_handover_recipients(chd_ctx *ctx, uint32_t *offsets, uint32_t *conn, uint8_t *kind, uint64_t cap, uint64_t *n_out) {
+    NEED_WORLD();
+    if (!offsets || !n_out || (cap && (!conn || !kind))) return fail(ctx, CHD_E_INVAL, "chd_handover_recipients: NULL buffer");
+    World &W = ctx->w;
+    if (!W.plan_recipients) return fail(ctx, CHD_E_STATE, "the world was created without CHD_WORLD_HANDOVER_RECIPIENTS");
+    if (!W.ticked) return fail(ctx, CHD_E_STATE, "no tick yet");
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    TRY(bind(ctx));
+    uint64_t ringrow[8];
+    TRY(down(ctx, ringrow, W.d.tick_ring + (size_t)(ctx->ring.cur_tick % TICK_RING) * 8, sizeof ringrow));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    const uint32_t nh = std::min<uint32_t>((uint32_t)ringrow[2], W.d.handovers_cap);
+    TRY(down(ctx, offsets, W.ho_rcp_off, sizeof(uint32_t) * ((size_t)nh + 1)));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    const uint64_t total = offsets[nh];
+    *n_out = total;
+    if (total > W.ho_rcp_cap) return fail(ctx, CHD_E_CAPACITY, "handover recipients: %llu exceed the engine capacity %llu", (unsigned long long)total, (unsigned long long)W.ho_rcp_cap);
+    if (total > cap) return fail(ctx, CHD_E_CAPACITY, "handover recipients: %llu, capacity %llu", (unsigned long long)total, (unsigned long long)cap);
+    TRY(down(ctx, conn, W.ho_rcp_conn, sizeof(uint32_t) * total));
+    TRY(down(ctx, kind, W.ho_rcp_kind, total));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    return CHD_OK;
+}
+
+int chd_adjacent_recipients(chd_ctx *ctx, uint32_t n_req, const uint32_t *channel, const uint32_t *broadcast,
+                            const uint32_t *sender_conn, const uint32_t *client_conn, uint32_t *offsets, uint32_t *conns,
+                            uint64_t cap) {
+    NEED_WORLD();
+    if (!offsets) return fail(ctx, CHD_E_INVAL, "chd_adjacent_recipients: NULL offsets");
+    offsets[0] = 0;
+    if (!n_req) return CHD_OK;
+    if (!channel || !broadcast || !sender_conn || !client_conn || (cap && !conns))
+        return fail(ctx, CHD_E_INVAL, "chd_adjacent_recipients: NULL buffer");
+    for (uint32_t i = 0; i < n_req; i++) {
+        if (channel[i] < ctx->g.id_start || channel[i] - ctx->g.id_start >= ctx->g.ncell)
+            return fail(ctx, CHD_E_INVAL, "request %u: BroadcastType_ADJACENT_CHANNELS only works for a spatial channel (message.go:190-193)", i);
+    }
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    TRY(bind(ctx));
+    const size_t nb = sizeof(uint32_t) * (size_t)n_req;
+    for (int k = 0; k < 4; k++) TRY(ensure(ctx, k, nb));
+    TRY(ensure(ctx, 4, nb + sizeof(uint32_t)));
+    TRY(ensure(ctx, 5, sizeof(uint32_t) * std::max<uint64_t>(cap, 1)));
+    TRY(up(ctx, sbuf<void>(ctx, 0), channel, nb));
+    TRY(up(ctx, sbuf<void>(ctx, 1), broadcast, nb));
+    TRY(up(ctx, sbuf<void>(ctx, 2), sender_conn, nb));
+    TRY(up(ctx, sbuf<void>(ctx, 3), client_conn, nb));
+    WorldDev &d = ctx->w.d;
+    launch_adjacent_recipients(ctx->stream, ctx->g, d, n_req, sbuf<uint32_t>(ctx, 0), sbuf<uint32_t>(ctx, 1), sbuf<uint32_t>(ctx, 2),
+                               sbuf<uint32_t>(ctx, 3), sbuf<uint32_t>(ctx, 4), nullptr, 0, 0);
+    launch_scan_u32_inplace(ctx->stream, sbuf<uint32_t>(ctx, 4), n_req);
+    launch_adjacent_recipients(ctx->stream, ctx->g, d, n_req, sbuf<uint32_t>(ctx, 0), sbuf<uint32_t>(ctx, 1), sbuf<uint32_t>(ctx, 2),
+                               sbuf<uint32_t>(ctx, 3), sbuf<uint32_t>(ctx, 4), sbuf<uint32_t>(ctx, 5), cap, 1);
+    TRY(after_launch(ctx));
+    TRY(down(ctx, offsets, sbuf<void>(ctx, 4), nb + sizeof(uint32_t)));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    const uint64_t total = offsets[n_req];
+    if (total > cap) return fail(ctx, CHD_E_CAPACITY, "chd_adjacent_recipients: %llu recipients, capacity %llu", (unsigned long long)total, (unsigned long long)cap);
+    TRY(down(ctx, conns, sbuf<void>(ctx, 5), sizeof(uint32_t) * total));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
     return CHD_OK;
 }
 

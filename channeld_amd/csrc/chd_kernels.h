@@ -72,7 +72,8 @@ struct WorldDev {
     int64_t *pair_last;   // [S*capq] lastFanOutTime
     uint32_t *pair_flags; // [S*capq] PF_*
     // cell-major fan-out (grids up to 4096 cells): interest bitmap per connection and subscriber count per cell
-    uint32_t wb;                    // 64-bit words per bitmap row (0 = cell-major path off)
+    uint32_t wb;                    // 64-bit words per bitmap row (0: grid larger than 4096 cells, no bitmap)
+    uint32_t cm_emit;               // cell-major emit selected
     unsigned long long *sub_bits;   // [S*wb]
     uint32_t *cell_ref;             // [ncell] live subscriptions of the cell
     uint32_t *active_cells;         // [ncell] cells with cell_ref > 0 (compacted every tick)
@@ -124,6 +125,21 @@ __device__ __forceinline__ void push_update(const WorldDev &w, uint32_t i, uint3
     w.hist[i] = h | 1u;
     w.hist_prev[i] = hp;
     w.hist_tick[i] = cur_tick;
+}
+
+// Is connection slot s subscribed to cell c?  Interest bitmap where it exists, else a binary search of
+// the connection's cell-sorted subscription list.
+__device__ __forceinline__ bool is_subscribed(const WorldDev &w, uint32_t s, uint32_t c) {
+    if (w.wb) return (w.sub_bits[(size_t)s * w.wb + (c >> 6)] >> (c & 63u)) & 1ull;
+    const uint32_t *cells = w.pair_cell + (size_t)s * w.capq;
+    uint32_t lo = 0, hi = w.pair_cnt[s];
+    while (lo < hi) {
+        const uint32_t mid = (lo + hi) >> 1;
+        const uint32_t v = cells[mid];
+        if (v == c) return true;
+        if (v < c) lo = mid + 1; else hi = mid;
+    }
+    return false;
 }
 
 // previous sender of the entry at position gpos of the (possibly gathered) cell tables
@@ -200,10 +216,18 @@ size_t aoi_lds_bytes(AoiLimits lim, uint32_t capq);
 void launch_scan_u32(hipStream_t st, const uint32_t *in, uint32_t *out, uint32_t n);  // exclusive, out[n]=total
 void launch_scan_u32_inplace(hipStream_t st, uint32_t *data, uint32_t n);             // data[n] = total
 void launch_scan_u64_inplace(hipStream_t st, uint64_t *data, uint32_t n);
+void launch_scan_u32_inplace_dev(hipStream_t st, uint32_t *data, uint32_t n_max, const uint32_t *n_dev);  // n = min(n_max, *n_dev)
 void launch_csr_gather(hipStream_t st, uint32_t nq, uint32_t stride, const uint32_t *counts,
                        const uint32_t *offsets, const uint32_t *cells, const uint32_t *dists,
                        const uint32_t *ivs, uint32_t *out_ids, uint32_t *out_dists,
                        uint32_t *out_ivs, uint32_t cap, uint32_t id_start);
+// recipient planning (decision parts)
+void launch_handover_recipients_count(hipStream_t st, DevGrid g, WorldDev w, uint32_t *off);
+void launch_handover_recipients_fill(hipStream_t st, DevGrid g, WorldDev w, const uint32_t *off, uint32_t *conn,
+                                     uint8_t *kind, uint64_t cap);
+void launch_adjacent_recipients(hipStream_t st, DevGrid g, WorldDev w, uint32_t n_req, const uint32_t *channel,
+                                const uint32_t *broadcast, const uint32_t *sender_conn, const uint32_t *client_conn,
+                                uint32_t *off, uint32_t *conns, uint64_t cap, int fill);
 // K5: fan-out
 void launch_fanout_plan(hipStream_t st, DevGrid g, WorldDev w, int64_t now_ns, TickRing ring);
 void launch_fanout_emit(hipStream_t st, DevGrid g, WorldDev w, int64_t now_ns, TickRing ring);

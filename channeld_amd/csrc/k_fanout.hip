@@ -153,7 +153,7 @@ void launch_fanout_plan(hipStream_t st, DevGrid g, WorldDev w, int64_t now_ns, T
     hipLaunchKernelGGL(k_fanout_plan, dim3((w.S + FO_WAVES - 1) / FO_WAVES), dim3(64 * FO_WAVES), 0, st, g, w,
                        now_ns, ring);
     launch_scan_u64_inplace(st, w.rec_ub, w.S);
-    if (w.wb) hipLaunchKernelGGL(k_active_cells, dim3(1), dim3(1024), 0, st, w, g.ncell);
+    if (w.cm_emit) hipLaunchKernelGGL(k_active_cells, dim3(1), dim3(1024), 0, st, w, g.ncell);
 }
 
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
@@ -955,7 +955,7 @@ __global__ void __launch_bounds__(64 * WS_WAVES) k_fanout_emit_ws(DevGrid g, Wor
 
 void launch_fanout_emit(hipStream_t st, DevGrid g, WorldDev w, int64_t now_ns, TickRing ring) {
     if (!w.S) return;
-    if (w.wb) {
+    if (w.cm_emit) {
         const uint32_t chunks = (w.S + WS_SUBS - 1) / WS_SUBS;
         const uint64_t max_items = (uint64_t)g.ncell * chunks;
         const uint32_t grid = (uint32_t)(max_items < w.emit_grid ? max_items : w.emit_grid);

@@ -263,7 +263,8 @@ __device__ __forceinline__ T wave_incl_scan(T v) {
 
 #define SCAN_ITEMS 4
 template <typename T>
-__global__ void __launch_bounds__(1024) k_scan_excl(const T *in, T *out, uint32_t n) {
+__global__ void __launch_bounds__(1024) k_scan_excl(const T *in, T *out, uint32_t n, const uint32_t *n_dev) {
+    if (n_dev) n = min(n, *n_dev);  // length known only on the device
     __shared__ T wtot[16];
     __shared__ T carry_s;
     const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -299,13 +300,16 @@ __global__ void __launch_bounds__(1024) k_scan_excl(const T *in, T *out, uint32_
 }
 
 void launch_scan_u32(hipStream_t st, const uint32_t *in, uint32_t *out, uint32_t n) {
-    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_scan_excl<uint32_t>), dim3(1), dim3(1024), 0, st, in, out, n);
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_scan_excl<uint32_t>), dim3(1), dim3(1024), 0, st, in, out, n, (const uint32_t *)nullptr);
 }
 void launch_scan_u32_inplace(hipStream_t st, uint32_t *data, uint32_t n) {
-    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_scan_excl<uint32_t>), dim3(1), dim3(1024), 0, st, data, data, n);
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_scan_excl<uint32_t>), dim3(1), dim3(1024), 0, st, data, data, n, (const uint32_t *)nullptr);
+}
+void launch_scan_u32_inplace_dev(hipStream_t st, uint32_t *data, uint32_t n_max, const uint32_t *n_dev) {
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_scan_excl<uint32_t>), dim3(1), dim3(1024), 0, st, data, data, n_max, n_dev);
 }
 void launch_scan_u64_inplace(hipStream_t st, uint64_t *data, uint32_t n) {
-    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_scan_excl<uint64_t>), dim3(1), dim3(1024), 0, st, data, data, n);
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_scan_excl<uint64_t>), dim3(1), dim3(1024), 0, st, data, data, n, (const uint32_t *)nullptr);
 }
 
 static uint32_t bits_for(uint32_t ncell) {

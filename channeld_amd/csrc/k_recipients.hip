@@ -1,0 +1,137 @@
+// k_recipients.hip — recipient planning for the messages the reference assembles around
+// the hot path (decision parts; protobuf assembly stays on the host).
+//
+//   handover recipients  spatial.go:776-857: for handover (src cell, dst cell) every
+//                        connection subscribed to src only gets the message without
+//                        per-recipient entity data (:780-787); every connection subscribed
+//                        to dst gets it with entity data — full state, plus a subscription
+//                        to the entity channel, if it was not yet subscribed to that channel
+//                        (:797-857, `shouldSend`).  In the engine's model the
+//                        entity channel's subscribers are the subscribers of the cell that
+//                        held the entity, i.e. of src.
+//   adjacent broadcast   message.go:188-239: de-duplicated connections of a spatial channel
+//                        and its up-to-8 neighbours (spatial.go:358-381), with the reference's
+//                        flag filters.
+//
+// Both are "which connection slots have one of these cells in their interest set" sweeps:
+// one workgroup per request walks the connection slots 256 at a time, tests the interest
+// bitmap (64-bit words, one per 64 cells) and compacts with ballot + a 4-wave LDS prefix, so the
+// lists come out in ascending slot order without atomics.  Two passes (count, scan, fill) keep
+// the output dense.  Traffic: ~16 B of bitmap per (request, slot) from L2.
+#include "chd_kernels.h"
+
+static inline unsigned nblocks(uint64_t n, unsigned bs) { return (unsigned)((n + bs - 1) / bs); }
+
+#define RCP_NONE 0xFFu
+
+// block-wide exclusive position of a flag in thread order; returns the block total through `total`
+__device__ __forceinline__ uint32_t block_rank(bool flag, uint32_t *wcnt, uint32_t &total) {
+    const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
+    const uint64_t m = __ballot(flag);
+    __syncthreads();
+    if (lane == 0) wcnt[wave] = (uint32_t)__popcll(m);
+    __syncthreads();
+    uint32_t base = 0;
+    total = 0;
+    for (uint32_t k = 0; k < 4; k++) {
+        if (k < wave) base += wcnt[k];
+        total += wcnt[k];
+    }
+    return base + mask_rank(m);
+}
+
+__device__ __forceinline__ uint8_t handover_kind(const WorldDev &w, uint32_t s, uint32_t src, uint32_t dst) {
+    if (s >= w.S || !w.sub_alive[s]) return RCP_NONE;
+    const bool in_src = is_subscribed(w, s, src), in_dst = is_subscribed(w, s, dst);
+    if (in_dst) return in_src ? CHD_HO_DST_KNOWN : CHD_HO_DST_NEW;
+    return in_src ? CHD_HO_SRC_ONLY : RCP_NONE;
+}
+
+// fill == 0: off[h] = number of recipients of handover h;  fill != 0: write them at off[h]
+__global__ void __launch_bounds__(256) k_handover_recipients(DevGrid g, WorldDev w, uint32_t *off, uint32_t *conn,
+                                                             uint8_t *kind, uint64_t cap, int fill) {
+    __shared__ uint32_t wcnt[4];
+    const uint32_t n = min(w.counters[CTR_HANDOVERS], w.handovers_cap);
+    for (uint32_t h = blockIdx.x; h < n; h += gridDim.x) {
+        const chd_handover_rec r = w.handovers[h];
+        const uint32_t src = r.src - g.id_start, dst = r.dst - g.id_start;
+        uint32_t run = fill ? off[h] : 0u;
+        for (uint32_t s0 = 0; s0 < w.S; s0 += 256) {
+            const uint32_t s = s0 + threadIdx.x;
+            const uint8_t k = handover_kind(w, s, src, dst);
+            uint32_t total;
+            const uint32_t pos = run + block_rank(k != RCP_NONE, wcnt, total);
+            if (fill && k != RCP_NONE && pos < cap) {
+                conn[pos] = w.conn_id[s];
+                kind[pos] = k;
+            }
+            run += total;
+        }
+        if (!fill && threadIdx.x == 0) off[h] = run;
+    }
+}
+
+void launch_handover_recipients_count(hipStream_t st, DevGrid g, WorldDev w, uint32_t *off) {
+    const unsigned grid = (unsigned)std::min<uint32_t>(w.handovers_cap ? w.handovers_cap : 1u, 2048u);
+    hipLaunchKernelGGL(k_handover_recipients, dim3(grid), dim3(256), 0, st, g, w, off, nullptr, nullptr, 0, 0);
+}
+
+void launch_handover_recipients_fill(hipStream_t st, DevGrid g, WorldDev w, const uint32_t *off, uint32_t *conn,
+                                     uint8_t *kind, uint64_t cap) {
+    const unsigned grid = (unsigned)std::min<uint32_t>(w.handovers_cap ? w.handovers_cap : 1u, 2048u);
+    hipLaunchKernelGGL(k_handover_recipients, dim3(grid), dim3(256), 0, st, g, w, (uint32_t *)off, conn, kind, cap, 1);
+}
+
+__global__ void __launch_bounds__(256) k_adjacent_recipients(DevGrid g, WorldDev w, uint32_t n_req,
+                                                             const uint32_t *__restrict__ channel,
+                                                             const uint32_t *__restrict__ broadcast,
+                                                             const uint32_t *__restrict__ sender_conn,
+                                                             const uint32_t *__restrict__ client_conn, uint32_t *off,
+                                                             uint32_t *conns, uint64_t cap, int fill) {
+    __shared__ uint32_t wcnt[4];
+    const uint32_t r = blockIdx.x;
+    if (r >= n_req) return;
+    const uint32_t bc = broadcast[r];
+    const uint32_t index = channel[r] - g.id_start;
+    // GetAdjacentChannels (spatial.go:358-381) + the centre unless ALL_BUT_OWNER (message.go:201-204)
+    uint32_t cells[9], nc = 0;
+    if (index < g.ncell) {
+        const int32_t gx = (int32_t)(index % g.cols), gy = (int32_t)(index / g.cols);
+        for (int32_t y = gy - 1; y <= gy + 1; y++) {
+            if (y < 0 || y > (int32_t)(g.rows - 1)) continue;
+            for (int32_t x = gx - 1; x <= gx + 1; x++) {
+                if (x < 0 || x > (int32_t)(g.cols - 1)) continue;
+                if (x == gx && y == gy) continue;
+                cells[nc++] = (uint32_t)x + (uint32_t)y * g.cols;
+            }
+        }
+        if (!(bc & CHD_BROADCAST_ALL_BUT_OWNER)) cells[nc++] = index;
+    }
+    uint32_t run = fill ? off[r] : 0u;
+    for (uint32_t s0 = 0; s0 < w.S; s0 += 256) {
+        const uint32_t s = s0 + threadIdx.x;
+        bool hit = false;
+        uint32_t cid = 0;
+        if (s < w.S && w.sub_alive[s]) {
+            for (uint32_t k = 0; k < nc && !hit; k++) hit = is_subscribed(w, s, cells[k]);
+            cid = w.conn_id[s];
+            // every connection registered here is a CLIENT connection (message.go:227-233)
+            if (bc & CHD_BROADCAST_ALL_BUT_CLIENT) hit = false;
+            if ((bc & CHD_BROADCAST_ALL_BUT_SENDER) && cid == sender_conn[r]) hit = false;  // :223-225
+            if (cid == client_conn[r]) hit = false;                                        // :235-237
+        }
+        uint32_t total;
+        const uint32_t pos = run + block_rank(hit, wcnt, total);
+        if (fill && hit && pos < cap) conns[pos] = cid;
+        run += total;
+    }
+    if (!fill && threadIdx.x == 0) off[r] = run;
+}
+
+void launch_adjacent_recipients(hipStream_t st, DevGrid g, WorldDev w, uint32_t n_req, const uint32_t *channel,
+                                const uint32_t *broadcast, const uint32_t *sender_conn, const uint32_t *client_conn,
+                                uint32_t *off, uint32_t *conns, uint64_t cap, int fill) {
+    if (!n_req) return;
+    hipLaunchKernelGGL(k_adjacent_recipients, dim3(n_req), dim3(256), 0, st, g, w, n_req, channel, broadcast, sender_conn,
+                       client_conn, off, conns, cap, fill);
+}

@@ -228,6 +228,27 @@ class SpatialWorld:
                     n_handovers=int(s.n_handovers), n_unsubs=int(s.n_unsubs), n_pairs=int(s.n_pairs),
                     algorithmic_bytes=int(s.algorithmic_bytes))
 
+    # ---- recipient planning (decision parts) ----
+    def handover_recipients(self, n_handovers: int):
+        """Recipients of the last tick's handover messages: (offsets[n+1], conn ids, kinds)."""
+        off = np.zeros(n_handovers + 1, dtype=np.uint32)
+        cap = max(n_handovers * self.S, 1)
+        conn = np.zeros(cap, dtype=np.uint32)
+        kind = np.zeros(cap, dtype=np.uint8)
+        n = C.c_uint64(0)
+        _lib.check(self.ctx, self.lib.chd_handover_recipients(self.ctx, _ptr(off), _ptr(conn), _ptr(kind), cap, C.byref(n)))
+        return off, conn[: n.value], kind[: n.value]
+
+    def adjacent_recipients(self, channel, broadcast, sender_conn, client_conn):
+        """BroadcastType_ADJACENT_CHANNELS (message.go:188-239): CSR of de-duplicated connection ids per request."""
+        ch, bc, sn, cl = _u32(channel), _u32(broadcast), _u32(sender_conn), _u32(client_conn)
+        off = np.zeros(len(ch) + 1, dtype=np.uint32)
+        cap = max(len(ch) * self.S, 1)
+        conns = np.zeros(cap, dtype=np.uint32)
+        _lib.check(self.ctx, self.lib.chd_adjacent_recipients(self.ctx, len(ch), _ptr(ch), _ptr(bc), _ptr(sn), _ptr(cl),
+                                                              _ptr(off), _ptr(conns), cap))
+        return off, conns[: int(off[-1])]
+
     # ---- introspection ----
     def subscriptions(self, slot: int):
         cap = self.capq

@@ -173,6 +173,8 @@ typedef struct {
  * Default: cell-major when max_entities / cells >= 1024.  The flags force one form. */
 #define CHD_WORLD_CONN_MAJOR_EMIT 1u
 #define CHD_WORLD_CELL_MAJOR_EMIT 2u
+/* also plan, every tick, who receives each handover's ChannelDataHandoverMessage (chd_handover_recipients) */
+#define CHD_WORLD_HANDOVER_RECIPIENTS 4u
 
 #define CHD_ENTITY_LOCKED 1u /* member of a non-empty lock group (entity.go:197-224) */
 
@@ -357,6 +359,43 @@ int chd_shard_fanout(chd_ctx *ctx, const void *d_tables, uint32_t world, const c
  * Arrays have max_entities room; *n_out = count. */
 int chd_shard_get_entities(chd_ctx *ctx, uint32_t *chan_id, uint32_t *cell_channel,
                            uint32_t *member_channel, uint32_t *n_out);
+
+/* ------------------------------------------------------------------ */
+/* Recipient planning: WHO gets the messages the reference assembles    */
+/* around the path (the protobuf assembly itself     */
+/* stays on the host).  Connections = the client connections registered */
+/* with chd_subs_add; the spatial servers' own subscriptions are static */
+/* (chd_server_channels / chd_border_channels) and handled by the host. */
+/* ------------------------------------------------------------------ */
+
+/* Recipients of the ChannelDataHandoverMessage of every handover of the LAST tick
+ * (spatial.go:776-857), evaluated on the subscriptions as they were when the handover
+ * happened (before that tick's interest updates).  Needs CHD_WORLD_HANDOVER_RECIPIENTS.
+ * Handover h (index into chd_tick_out.handovers of the same tick) owns
+ * [offsets[h], offsets[h+1]) of conn/kind, ascending connection slot. */
+#define CHD_HO_SRC_ONLY 0  /* in src only: the message without per-recipient entity data (:780-787) */
+#define CHD_HO_DST_NEW 1   /* in dst, not yet subscribed to the entity channel (= not in src): full entity
+                              data, SubscribeToChannel(entity channel) (:797-857, shouldSend) */
+#define CHD_HO_DST_KNOWN 2 /* in dst and in src: already subscribed to the entity channel */
+int chd_handover_recipients(chd_ctx *ctx, uint32_t *offsets /* n_handovers+1 */, uint32_t *conn,
+                            uint8_t *kind, uint64_t cap, uint64_t *n_out);
+
+/* replaces: the connection merge of BroadcastType_ADJACENT_CHANNELS (message.go:188-239):
+ * for request r the de-duplicated connections subscribed to spatial channel channel[r] or
+ * one of its (up to 8) adjacent channels, filtered by the broadcast flags exactly as the
+ * reference does (the centre channel is included unless ALL_BUT_OWNER is set, :201-204;
+ * ALL_BUT_SENDER drops sender_conn[r], :223-225; ALL_BUT_CLIENT drops every client
+ * connection, :227-229; the connection client_conn[r] of the ServerForwardMessage is
+ * always dropped, :235-237).  CSR output, ascending connection slot. */
+#define CHD_BROADCAST_ALL_BUT_SENDER 4u
+#define CHD_BROADCAST_ALL_BUT_OWNER 8u
+#define CHD_BROADCAST_ALL_BUT_CLIENT 16u
+#define CHD_BROADCAST_ALL_BUT_SERVER 32u
+#define CHD_BROADCAST_ADJACENT_CHANNELS 64u
+int chd_adjacent_recipients(chd_ctx *ctx, uint32_t n_req, const uint32_t *channel,
+                            const uint32_t *broadcast, const uint32_t *sender_conn,
+                            const uint32_t *client_conn, uint32_t *offsets /* n_req+1 */,
+                            uint32_t *conns, uint64_t cap);
 
 /* device memory, for callers that keep their batches on the GPU (bench, tests) */
 int chd_dev_alloc(chd_ctx *ctx, uint64_t bytes, void **d_out);

@@ -77,6 +77,8 @@ typedef struct orc_world {
     wrec *rec; uint64_t nrec, caprec;
     uint32_t *ho_ent, *ho_src, *ho_dst, *ho_srv_src, *ho_srv_dst; uint32_t nho, capho;
     uint32_t *unsub_sub, *unsub_cell; uint32_t nunsub, capunsub;
+    /* handover message recipients of the last tick (spatial.go:776-857) */
+    uint32_t *rcp_ho, *rcp_conn; uint8_t *rcp_kind; uint64_t nrcp, caprcp;
     int32_t *q_status; uint32_t nq_status;
     uint32_t n_locked_abort;
     uint64_t literal_mismatch;
@@ -146,6 +148,7 @@ orc_world *orc_world_new(const orc_grid *g, uint32_t n_entities, uint32_t n_subs
 static void orc__free_jobs(orc_world *w);
 
 void orc_world_free(orc_world *w) {
+    if (w) { free(w->rcp_ho); free(w->rcp_conn); free(w->rcp_kind); }
     if (!w) return;
     for (uint32_t i = 0; i < w->N; i++) free(w->ebuf[i].v);
     for (uint32_t i = 0; i < w->C; i++) free(w->cbuf[i].v);
@@ -387,7 +390,7 @@ int orc_world_tick(orc_world *w, orc_time t, uint32_t n_upd, const uint32_t *idx
                    const double *x, const double *z, const uint32_t *sender,
                    uint32_t n_cu, const uint32_t *cu_cell, const uint32_t *cu_sender,
                    uint32_t n_q, const uint32_t *q_sub, const orc_query *queries) {
-    w->nrec = 0; w->nho = 0; w->nunsub = 0; w->n_locked_abort = 0;
+    w->nrec = 0; w->nho = 0; w->nunsub = 0; w->n_locked_abort = 0; w->nrcp = 0;
     /* is_new = "subscribed during the latest tick" */
     for (uint32_t s = 0; s < w->S; s++)
         for (uint32_t p = 0; p < w->pair_cnt[s]; p++) w->pairs[(size_t)s * w->capq + p].is_new = 0;
@@ -421,6 +424,39 @@ int orc_world_tick(orc_world *w, orc_time t, uint32_t n_upd, const uint32_t *idx
     }
     for (uint32_t u = 0; u < n_cu; u++)
         wbuf_push(&w->cbuf[cu_cell[u]], t, cu_sender[u], w->max_interval_ms);
+
+    /* ---- 1b. who receives each handover's ChannelDataHandoverMessage (spatial.go:776-857) ----
+     * srcChannelSubConns / dstChannelSubConns as they are now (Notify runs before this tick's
+     * interest updates).  Step 4-1: connections of src that are not in dst get the message without
+     * per-recipient entity data (kind 0).  Step 4-2: connections of dst are subscribed to the entity
+     * channel; `shouldSend` (newly subscribed) -> full entity data (kind 1), else kind 2.  In the tick
+     * model the entity channel's subscribers are the subscribers of the cell that held it (src). */
+    for (uint32_t h = 0; h < w->nho; h++) {
+        uint32_t src = w->ho_src[h] - w->g.id_start, dst = w->ho_dst[h] - w->g.id_start;
+        for (uint32_t s = 0; s < w->S; s++) {
+            if (!w->sub_alive[s]) continue;
+            int in_src = 0, in_dst = 0;
+            const wpair *pp = &w->pairs[(size_t)s * w->capq];
+            for (uint32_t p = 0; p < w->pair_cnt[s]; p++) {
+                if (pp[p].cell == src) in_src = 1;
+                if (pp[p].cell == dst) in_dst = 1;
+            }
+            int kind = -1;
+            if (in_dst) kind = in_src ? 2 : 1;
+            else if (in_src) kind = 0;
+            if (kind < 0) continue;
+            if (w->nrcp == w->caprcp) {
+                w->caprcp = w->caprcp ? w->caprcp * 2 : 1024;
+                w->rcp_ho = (uint32_t *)realloc(w->rcp_ho, 4 * w->caprcp);
+                w->rcp_conn = (uint32_t *)realloc(w->rcp_conn, 4 * w->caprcp);
+                w->rcp_kind = (uint8_t *)realloc(w->rcp_kind, w->caprcp);
+            }
+            w->rcp_ho[w->nrcp] = h;
+            w->rcp_conn[w->nrcp] = w->conn_id[s];
+            w->rcp_kind[w->nrcp] = (uint8_t)kind;
+            w->nrcp++;
+        }
+    }
 
     /* ---- 2. interest updates (message_spatial.go:59-128) ---- */
     if (w->nq_status < n_q) {
@@ -583,6 +619,38 @@ void orc_world_handovers(const orc_world *w, uint32_t *ent, uint32_t *src, uint3
     memcpy(dst, w->ho_dst, 4 * w->nho); memcpy(srv_src, w->ho_srv_src, 4 * w->nho);
     memcpy(srv_dst, w->ho_srv_dst, 4 * w->nho);
 }
+uint64_t orc_world_nrcp(const orc_world *w) { return w->nrcp; }
+void orc_world_recipients(const orc_world *w, uint32_t *ho, uint32_t *conn, uint8_t *kind) {
+    memcpy(ho, w->rcp_ho, 4 * w->nrcp); memcpy(conn, w->rcp_conn, 4 * w->nrcp); memcpy(kind, w->rcp_kind, w->nrcp);
+}
+
+/* BroadcastType_ADJACENT_CHANNELS, message.go:188-239, for the client connections of the world:
+ * GetAdjacentChannels (+ the centre unless ALL_BUT_OWNER), merge of the channels' connections into
+ * one set, then the flag filters in the reference's order.  Returns the number of connection ids
+ * written (ascending connection slot). */
+uint32_t orc_world_adjacent_recipients(const orc_world *w, uint32_t channel, uint32_t broadcast, uint32_t sender_conn,
+                                       uint32_t client_conn, uint32_t *out) {
+    uint32_t ids[9];
+    uint32_t n = orc_adjacent(&w->g, channel, ids);
+    if (!(broadcast & 8u)) ids[n++] = channel; /* !ALL_BUT_OWNER.Check -> append the centre (:201-204) */
+    uint32_t k = 0;
+    for (uint32_t s = 0; s < w->S; s++) {
+        if (!w->sub_alive[s]) continue;
+        int hit = 0;
+        const wpair *pp = &w->pairs[(size_t)s * w->capq];
+        for (uint32_t p = 0; p < w->pair_cnt[s] && !hit; p++)
+            for (uint32_t j = 0; j < n; j++)
+                if (pp[p].cell + w->g.id_start == ids[j]) { hit = 1; break; }
+        if (!hit) continue;
+        uint32_t cid = w->conn_id[s];
+        if ((broadcast & 4u) && cid == sender_conn) continue; /* ALL_BUT_SENDER (:223-225) */
+        if (broadcast & 16u) continue;                         /* ALL_BUT_CLIENT: these are client connections (:227-229) */
+        if (cid == client_conn) continue;                       /* the client named in the ServerForwardMessage (:235-237) */
+        out[k++] = cid;
+    }
+    return k;
+}
+
 uint32_t orc_world_nunsub(const orc_world *w) { return w->nunsub; }
 void orc_world_unsubs(const orc_world *w, uint32_t *sub, uint32_t *cell) {
     memcpy(sub, w->unsub_sub, 4 * w->nunsub); memcpy(cell, w->unsub_cell, 4 * w->nunsub);

@@ -127,6 +127,11 @@ def lib():
     L.orc_world_nhandover.restype = C.c_uint32
     L.orc_world_nhandover.argtypes = [C.c_void_p]
     L.orc_world_handovers.argtypes = [C.c_void_p, up, up, up, up, up]
+    L.orc_world_nrcp.restype = C.c_uint64
+    L.orc_world_nrcp.argtypes = [C.c_void_p]
+    L.orc_world_recipients.argtypes = [C.c_void_p, up, up, u8p]
+    L.orc_world_adjacent_recipients.restype = C.c_uint32
+    L.orc_world_adjacent_recipients.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, up]
     L.orc_world_nunsub.restype = C.c_uint32
     L.orc_world_nunsub.argtypes = [C.c_void_p]
     L.orc_world_unsubs.argtypes = [C.c_void_p, up, up]
@@ -412,6 +417,20 @@ class World:
         a = [np.zeros(max(n, 1), dtype=np.uint32) for _ in range(2)]
         lib().orc_world_unsubs(self.h, *[_p(v, C.c_uint32) for v in a])
         return a[0][:n], a[1][:n]
+
+    def recipients(self):
+        """(handover index, connection id, kind) of the last tick's handover messages."""
+        n = int(lib().orc_world_nrcp(self.h))
+        ho, conn = np.zeros(max(n, 1), dtype=np.uint32), np.zeros(max(n, 1), dtype=np.uint32)
+        kind = np.zeros(max(n, 1), dtype=np.uint8)
+        lib().orc_world_recipients(self.h, _p(ho, C.c_uint32), _p(conn, C.c_uint32), _p(kind, C.c_uint8))
+        return ho[:n], conn[:n], kind[:n]
+
+    def adjacent_recipients(self, channel, broadcast, sender_conn, client_conn):
+        out = np.zeros(self.S + 1, dtype=np.uint32)
+        n = lib().orc_world_adjacent_recipients(self.h, int(channel), int(broadcast), int(sender_conn), int(client_conn),
+                                                _p(out, C.c_uint32))
+        return out[:n]
 
     def query_status(self):
         out = np.zeros(max(self._nq, 1), dtype=np.int32)

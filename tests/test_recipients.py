@@ -1,0 +1,145 @@
+"""Recipient planning (decision parts).
+
+CPU: the oracle's restatement of the recipient sets of spatial.go:776-857 (handover
+message) and message.go:188-239 (ADJACENT_CHANNELS broadcast) on hand-built
+subscription states.  GPU: chd_handover_recipients / chd_adjacent_recipients through the
+C-ABI against the oracle, tick after tick on seeded worlds (bitmap path and, on a grid of
+more than 4096 cells, the sorted-list search path)."""
+import json
+
+import numpy as np
+import pytest
+
+from channeld_amd import synth
+from oracle import pyoracle as orc
+
+
+def small_world(conns_and_spheres):
+    cfg = synth.load_config("spatial_static_benchmark.json")  # 15x15 cells of 2000, offset -15000
+    g = orc.grid_from_config(cfg)
+    S = len(conns_and_spheres)
+    ow = orc.World(g, 4, S, 225, 20, 0)
+    for s, (conn, _) in enumerate(conns_and_spheres):
+        ow.add_sub(s, conn)
+    qs = [orc.QueryBuilder(sphere=sp) for _, sp in conns_and_spheres]
+    return cfg, g, ow, qs
+
+
+def test_oracle_handover_recipient_kinds():
+    # entity 0 walks from cell (7,7) to cell (8,7); A sees only src, B only dst, C both, D neither
+    cell = lambda gx, gz: (-15000 + 2000 * gx + 1000.0, -15000 + 2000 * gz + 1000.0)
+    subs = [(11, (*cell(6, 7), 900.0)), (12, (*cell(9, 7), 900.0)), (13, (-15000 + 2000 * 8 - 1.0, cell(7, 7)[1], 900.0)),
+            (14, (*cell(1, 1), 900.0))]
+    cfg, g, ow, qs = small_world(subs)
+    x0, z0 = cell(7, 7)
+    ow.spawn([0], [0x80000], [x0], [z0], [0], [5])
+    ow.tick(20_000_000, [0], [x0], [z0], None, None, None, None, qs)
+    # A's sphere (radius 900 around the centre of (6,7)) does not reach (7,7): widen it by hand-picked spots instead
+    qs2 = [orc.QueryBuilder(spots=[cell(7, 7)]), orc.QueryBuilder(spots=[cell(8, 7)]),
+           orc.QueryBuilder(spots=[cell(7, 7), cell(8, 7)]), orc.QueryBuilder(spots=[cell(1, 1)])]
+    ow.tick(40_000_000, [0], [x0], [z0], None, None, None, None, qs2)
+    x1, z1 = cell(8, 7)
+    ow.tick(60_000_000, [0], [x1], [z1], None, None, None, None, None)
+    ent, src, dst, _, _ = ow.handovers()
+    assert len(ent) == 1 and src[0] == 0x10000 + 7 + 7 * 15 and dst[0] == 0x10000 + 8 + 7 * 15
+    ho, conn, kind = ow.recipients()
+    assert sorted(zip(conn.tolist(), kind.tolist())) == [(11, 0), (12, 1), (13, 2)]
+
+
+def test_oracle_adjacent_broadcast_flags():
+    cell = lambda gx, gz: (-15000 + 2000 * gx + 1000.0, -15000 + 2000 * gz + 1000.0)
+    # conn 21 in the centre cell (5,5), 22 in the neighbour (6,6), 23 two cells away (7,5), 24 in both centre and neighbour
+    subs = [(21, None), (22, None), (23, None), (24, None)]
+    cfg, g, ow, _ = small_world([(c, (0, 0, 1)) for c, _ in subs])
+    qs = [orc.QueryBuilder(spots=[cell(5, 5)]), orc.QueryBuilder(spots=[cell(6, 6)]), orc.QueryBuilder(spots=[cell(7, 5)]),
+          orc.QueryBuilder(spots=[cell(5, 5), cell(4, 5)])]
+    ow.tick(20_000_000, None, None, None, None, None, None, None, qs)
+    ch = 0x10000 + 5 + 5 * 15
+    ADJ, BUT_SENDER, BUT_OWNER, BUT_CLIENT = 64, 4, 8, 16
+    assert ow.adjacent_recipients(ch, ADJ, 0, 0).tolist() == [21, 22, 24]
+    assert ow.adjacent_recipients(ch, ADJ | BUT_OWNER, 0, 0).tolist() == [22, 24]      # centre channel left out, 24 stays via (4,5)
+    assert ow.adjacent_recipients(ch, ADJ | BUT_SENDER, 22, 0).tolist() == [21, 24]
+    assert ow.adjacent_recipients(ch, ADJ, 22, 0).tolist() == [21, 22, 24]              # sender only dropped with the flag
+    assert ow.adjacent_recipients(ch, ADJ, 0, 24).tolist() == [21, 22]                  # ServerForwardMessage.ClientConnId
+    assert ow.adjacent_recipients(ch, ADJ | BUT_CLIENT, 0, 0).tolist() == []
+
+
+@pytest.fixture(scope="module")
+def amd():
+    import channeld_amd
+
+    channeld_amd.load()
+    return channeld_amd
+
+
+def run_recipients(amd, cfg, N, S, ticks, seed, flags=4, aoi_scale=1.0, capq=0):
+    g = orc.grid_from_config(cfg)
+    sw = synth.SynthWorld(synth.WorldSpec(cfg, N, S, seed, tick_ms=50, aoi_scale=aoi_scale, outside_frac=0.01, locked_frac=0.02))
+    ctl = amd.StaticGrid2DSpatialController()
+    assert ctl.LoadConfig(json.dumps(cfg).encode(), strict=False) is None
+    gw = amd.SpatialWorld(ctl, N, S, max_interest_cells=capq, flags=flags)
+    ow = orc.World(g, N, S, gw.capq, 20, 0)
+    ow.spawn(np.arange(N), sw.chan_id, sw.x, sw.z, sw.flags, sw.sender)
+    gw.spawn(None, sw.chan_id, sw.x, sw.z, sw.flags, sw.sender)
+    for s in range(S):
+        ow.add_sub(s, int(sw.sub_conn[s]))
+    gw.add_subscribers(None, sw.sub_conn)
+    rng = np.random.default_rng(seed & 0xFFFF)
+    n_rcp = n_adj = 0
+    kinds = set()
+    for k in range(ticks):
+        sw.step()
+        jump = rng.random(N) < 0.05  # extra cell crossings
+        sw.x = np.where(jump & ~sw.outside, np.float64(np.float32(sw.offx + rng.random(N) * sw.W * 0.999)), sw.x)
+        q = sw.queries()
+        ow.tick(sw.now_ns(), None, sw.x, sw.z, None, None, None, None, q)
+        res = gw.tick(sw.now_ns(), upd_x=sw.x, upd_z=sw.z, queries=q, want_records=False)
+        # ---- handover message recipients ----
+        ent, src, dst, _, _ = ow.handovers()
+        oh, oconn, okind = ow.recipients()
+        off, conn, kind = gw.handover_recipients(len(res.handovers))
+        assert len(conn) == len(oconn), f"tick {k}: {len(conn)} recipients vs oracle {len(oconn)}"
+        want = {}
+        for h, c, kd in zip(oh.tolist(), oconn.tolist(), okind.tolist()):
+            want.setdefault(int(ent[h]), []).append((c, kd))
+        for h in range(len(res.handovers)):
+            e = int(res.handovers["entity"][h])
+            got = list(zip(conn[off[h]:off[h + 1]].tolist(), kind[off[h]:off[h + 1]].tolist()))
+            assert got == want.get(e, []), f"tick {k}: recipients of the handover of entity {e}"
+        n_rcp += len(conn)
+        kinds.update(kind.tolist())
+        # ---- adjacent broadcast ----
+        ncell = g.cols * g.rows
+        chans = (0x10000 + rng.integers(0, ncell, 12)).astype(np.uint32)
+        bcs = rng.choice([64, 64 | 4, 64 | 8, 64 | 16, 64 | 4 | 8], 12).astype(np.uint32)
+        senders = sw.sub_conn[rng.integers(0, S, 12)].astype(np.uint32)
+        clients = np.where(rng.random(12) < 0.5, sw.sub_conn[rng.integers(0, S, 12)], 0).astype(np.uint32)
+        aoff, aconn = gw.adjacent_recipients(chans, bcs, senders, clients)
+        for r in range(12):
+            want_r = ow.adjacent_recipients(int(chans[r]), int(bcs[r]), int(senders[r]), int(clients[r]))
+            assert np.array_equal(aconn[aoff[r]:aoff[r + 1]], want_r), f"tick {k}: adjacent request {r}"
+            n_adj += len(want_r)
+    return n_rcp, n_adj, kinds
+
+
+@pytest.mark.gpu
+def test_gpu_recipients_benchmark_grid(amd):
+    cfg = synth.load_config("spatial_static_benchmark.json")
+    n_rcp, n_adj, kinds = run_recipients(amd, cfg, 3000, 300, 8, 0xC0FFEE31)
+    assert n_rcp > 1000 and n_adj > 100 and kinds == {0, 1, 2}
+
+
+@pytest.mark.gpu
+def test_gpu_recipients_cell_major_world(amd):
+    cfg = synth.load_config("spatial_static_8x8.json")
+    n_rcp, n_adj, kinds = run_recipients(amd, cfg, 2000, 200, 6, 0xC0FFEE32, flags=4 | 2, aoi_scale=0.5)
+    assert n_rcp > 500 and kinds == {0, 1, 2}
+
+
+@pytest.mark.gpu
+def test_gpu_recipients_large_grid_list_search(amd):
+    # 80 x 80 = 6400 cells: no interest bitmap, membership by binary search of the subscription lists
+    cfg = {"WorldOffsetX": -40000, "WorldOffsetZ": -40000, "GridWidth": 1000, "GridHeight": 1000, "GridCols": 80,
+           "GridRows": 80, "ServerCols": 2, "ServerRows": 2, "ServerInterestBorderSize": 1}
+    n_rcp, n_adj, kinds = run_recipients(amd, cfg, 3000, 200, 5, 0xC0FFEE33, aoi_scale=1.0, capq=256)
+    assert n_rcp > 300 and kinds == {0, 1, 2}
