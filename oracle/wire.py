@@ -1,0 +1,90 @@
+"""CPU restatement of the server -> client wire format of the fan-out path
+(TEST INFRASTRUCTURE ONLY, see chd_oracle.h).
+
+What the reference does for one fan-out message (paths relative to the channeld tree):
+  data.go:293-318        fanOutDataUpdate: ChannelDataUpdateMessage{Data: anypb.New(update)},
+                         MessageContext{MsgType: CHANNEL_DATA_UPDATE (8), ChannelId: ch.id,
+                         Broadcast: 0, StubId: 0}
+  connection.go:57-83    queuedMessagePackSender.Send: MessagePack{ChannelId, Broadcast, StubId,
+                         MsgType, MsgBody: proto.Marshal(msg)}; dropped if proto.Size(mp) >=
+                         MaxPacketSize - PacketHeaderSize (65535 - 5)
+  connection.go:626-714  flush: MessagePacks are appended to one Packet until proto.Size(packet)
+                         would exceed MaxPacketSize; the offending pack opens the next packet;
+                         tag = {'C','H', size_hi, size_lo, compressionType} + proto.Marshal(packet)
+
+Third-party dependency restated: google.golang.org/protobuf v1.28.1 (go.mod:14) — the standard
+proto3 wire format (varint field keys, length-delimited submessages, zero-valued scalar fields
+omitted, fields in field-number order).  Pinned against python-protobuf driven by the reference's
+OWN embedded descriptor (tests/golden/make_wire_golden.py -> tests/golden/wire_packets.npz).
+"""
+from typing import Iterable, List, Tuple
+
+MAX_PACKET_SIZE = 0xFFFF      # connection.go:27
+PACKET_HEADER_SIZE = 5        # connection.go:28
+MSG_CHANNEL_DATA_UPDATE = 8   # channeld.proto:121
+
+
+def varint(v: int) -> bytes:
+    out = bytearray()
+    while True:
+        b = v & 0x7F
+        v >>= 7
+        if v:
+            out.append(b | 0x80)
+        else:
+            out.append(b)
+            return bytes(out)
+
+
+def field_bytes(num: int, payload: bytes) -> bytes:
+    return varint((num << 3) | 2) + varint(len(payload)) + payload
+
+
+def field_varint(num: int, v: int) -> bytes:
+    return b"" if v == 0 else varint(num << 3) + varint(v)  # proto3: zero scalars are not emitted
+
+
+def channel_data_update(any_bytes: bytes, context_conn_id: int = 0) -> bytes:
+    """ChannelDataUpdateMessage (channeld.proto:333-340): data = 1 (Any), contextConnId = 2.
+    `any_bytes` is the serialized google.protobuf.Any; a set-but-empty Any still emits the field."""
+    return field_bytes(1, any_bytes) + field_varint(2, context_conn_id)
+
+
+def message_pack(channel_id: int, msg_type: int, body: bytes, broadcast: int = 0, stub_id: int = 0) -> bytes:
+    """MessagePack (channeld.proto:15-34)."""
+    return (field_varint(1, channel_id) + field_varint(2, broadcast) + field_varint(3, stub_id)
+            + field_varint(4, msg_type) + (field_bytes(5, body) if body else b""))
+
+
+def fanout_message_pack(channel_id: int, any_bytes: bytes) -> bytes:
+    return message_pack(channel_id, MSG_CHANNEL_DATA_UPDATE, channel_data_update(any_bytes))
+
+
+def frame(packet_bytes: bytes, compression: int = 0) -> bytes:
+    n = len(packet_bytes)
+    assert n <= MAX_PACKET_SIZE
+    return bytes([67, 72, (n >> 8) & 0xFF, n & 0xFF, compression]) + packet_bytes  # connection.go:683-687
+
+
+def flush_stream(packs: Iterable[bytes]) -> Tuple[bytes, List[int]]:
+    """The byte stream successive flush() calls write for one connection's queue of MessagePacks,
+    and the number of packs per packet.  Packs of size >= 65530 are dropped by Send (:72-77)."""
+    out = bytearray()
+    counts: List[int] = []
+    cur = bytearray()
+    n_in = 0
+    for mp in packs:
+        if len(mp) >= MAX_PACKET_SIZE - PACKET_HEADER_SIZE:
+            continue
+        entry = field_bytes(1, mp)  # Packet.messages = 1
+        if n_in and len(cur) + len(entry) > MAX_PACKET_SIZE:
+            out += frame(bytes(cur))
+            counts.append(n_in)
+            cur = bytearray()
+            n_in = 0
+        cur += entry
+        n_in += 1
+    if n_in:
+        out += frame(bytes(cur))
+        counts.append(n_in)
+    return bytes(out), counts
