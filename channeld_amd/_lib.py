@@ -21,6 +21,8 @@ ENTITY_LOCKED = 1
 WORLD_CONN_MAJOR_EMIT = 1
 WORLD_CELL_MAJOR_EMIT = 2
 WORLD_HANDOVER_RECIPIENTS = 4
+WORLD_WIRE = 8
+WIRE_ENTITY_UPDATE, WIRE_ENTITY_FULL, WIRE_CELL_UPDATE, WIRE_CELL_FULL = 0, 1, 2, 3
 HO_SRC_ONLY, HO_DST_NEW, HO_DST_KNOWN = 0, 1, 2
 BROADCAST_ALL_BUT_SENDER, BROADCAST_ALL_BUT_OWNER, BROADCAST_ALL_BUT_CLIENT, BROADCAST_ALL_BUT_SERVER = 4, 8, 16, 32
 BROADCAST_ADJACENT_CHANNELS = 64
@@ -40,7 +42,7 @@ SYMBOLS = (
     "chd_dev_download", "chd_set_profiling", "chd_get_tick_stats", "chd_get_tick_history",
     "chd_set_stream", "chd_shard_spawn", "chd_shard_ingest", "chd_shard_import", "chd_shard_fanout",
     "chd_shard_get_entities", "chd_shard_table_bytes", "chd_shard_interest",
-    "chd_handover_recipients", "chd_adjacent_recipients",
+    "chd_handover_recipients", "chd_adjacent_recipients", "chd_wire_set_payloads", "chd_wire_build", "chd_wire_fetch",
 )
 
 
@@ -83,6 +85,7 @@ class WorldCfg(C.Structure):
     _fields_ = [
         ("max_entities", C.c_uint32), ("max_subscribers", C.c_uint32), ("max_interest_cells", C.c_uint32),
         ("max_records", C.c_uint64), ("max_handovers", C.c_uint32), ("flags", C.c_uint32),
+        ("wire_max_update_len", C.c_uint32), ("wire_max_full_len", C.c_uint32),
     ]
 
 
@@ -193,6 +196,9 @@ def load():
     L.chd_shard_fanout.argtypes = [C.c_void_p, _vp, C.c_uint32, P(TickIn)]
     L.chd_shard_interest.argtypes = [C.c_void_p, P(TickIn)]
     L.chd_shard_get_entities.argtypes = [C.c_void_p, _u32p, _u32p, _u32p, P(C.c_uint32)]
+    L.chd_wire_set_payloads.argtypes = [C.c_void_p, C.c_int, C.c_uint32, _u32p, _u32p, _u8p]
+    L.chd_wire_build.argtypes = [C.c_void_p, P(C.c_uint64), P(C.c_uint64), P(C.c_uint32)]
+    L.chd_wire_fetch.argtypes = [C.c_void_p, _u64p, _u32p, _u8p, C.c_uint64]
     L.chd_handover_recipients.argtypes = [C.c_void_p, _u32p, _u32p, _u8p, C.c_uint64, P(C.c_uint64)]
     L.chd_adjacent_recipients.argtypes = [C.c_void_p, C.c_uint32, _u32p, _u32p, _u32p, _u32p, _u32p, _u32p, C.c_uint64]
     L.chd_set_profiling.argtypes = [C.c_void_p, C.c_int]

@@ -36,6 +36,10 @@ struct World {
     uint32_t last_nq = 0;
     bool ticked = false;
     int slot_mode = 0;  // 0 unset, 1 caller-chosen slots (chd_world_spawn), 2 library-managed (chd_shard_spawn)
+    bool wire = false;                 // CHD_WORLD_WIRE
+    WireDev x{};
+    uint64_t wire_cap = 0;             // bytes allocated for x.bytes
+    bool wire_built = false;
     bool plan_recipients = false;      // CHD_WORLD_HANDOVER_RECIPIENTS
     uint32_t *ho_rcp_off = nullptr;    // [handovers_cap + 1] recipients of handover h: [off[h], off[h+1])
     uint32_t *ho_rcp_conn = nullptr;   // connection ids
@@ -283,6 +287,7 @@ void chd_destroy(chd_ctx *ctx) {
     (void)hipStreamSynchronize(ctx->stream);
     for (void *p : ctx->w.allocs) (void)hipFree(p);
     if (ctx->w.recs_dense) (void)hipFree(ctx->w.recs_dense);
+    if (ctx->w.x.bytes) (void)hipFree(ctx->w.x.bytes);
     for (auto &b : ctx->scratch)
         if (b.p) (void)hipFree(b.p);
     for (auto &e : ctx->ev) (void)hipEventDestroy(e);
@@ -589,8 +594,31 @@ int chd_world_create(chd_ctx *ctx, const chd_world_cfg *cfg) {
         HIPCHK(hipMemGetInfo(&free_b, &total_b));
         nrec = std::min<uint64_t>((uint64_t)(free_b * 0.5) / sizeof(chd_fanout_rec), 4000000000ull);
     }
+    W.wire = (cfg->flags & CHD_WORLD_WIRE) != 0;
+    if (W.wire && !cfg->max_records) nrec = std::min<uint64_t>(nrec / 3, 1000000000ull);  // three more 4-byte arrays per record
     d.recs_cap = nrec;
     TRY(walloc(ctx, &d.recs, nrec, false));
+    d.rec_pos = nullptr;
+    d.ce_slot = nullptr;
+    if (W.wire) {
+        WireDev &x = W.x;
+        TRY(walloc(ctx, &d.rec_pos, nrec, false));
+        TRY(walloc(ctx, &d.ce_slot, N + 2));
+        TRY(walloc(ctx, &x.rec_woff, nrec, false));
+        TRY(walloc(ctx, &x.rec_wtag, nrec, false));
+        x.stride[0] = ((cfg->wire_max_update_len ? cfg->wire_max_update_len : 128u) + 15u) & ~15u;
+        x.stride[1] = ((cfg->wire_max_full_len ? cfg->wire_max_full_len : 1024u) + 15u) & ~15u;
+        for (int k = 0; k < 2; k++) {
+            TRY(walloc(ctx, &x.pay_ent[k], N * x.stride[k]));
+            TRY(walloc(ctx, &x.pay_cell[k], C * x.stride[k]));
+            TRY(walloc(ctx, &x.len_ent[k], N));
+            TRY(walloc(ctx, &x.len_cell[k], C));
+        }
+        TRY(walloc(ctx, &x.conn_wlen, S + 1));
+        x.conn_woff = x.conn_wlen;
+        TRY(walloc(ctx, &x.conn_npk, S));
+        TRY(walloc(ctx, &x.n_dropped, 1));
+    }
     launch_free_stack_init(ctx->stream, d);
     TRY(after_launch(ctx));
     HIPCHK(hipStreamSynchronize(ctx->stream));
@@ -751,6 +779,7 @@ static int tick_locked(chd_ctx *ctx, const chd_tick_in *in) {
     TRY(after_launch(ctx));
     W.last_nq = in->n_queries;
     W.ticked = true;
+    W.wire_built = false;
     return CHD_OK;
 }
 
@@ -1084,6 +1113,111 @@ int chd_shard_get_entities(chd_ctx *ctx, uint32_t *chan_id, uint32_t *cell_chann
         n++;
     }
     *n_out = n;
+    return CHD_OK;
+}
+
+// ---------------------------------------------------------------------------
+// wire-format fan-out buffers
+// ---------------------------------------------------------------------------
+
+int chd_wire_set_payloads(chd_ctx *ctx, int kind, uint32_t n, const uint32_t *idx, const uint32_t *lens, const uint8_t *bytes) {
+    NEED_WORLD();
+    World &W = ctx->w;
+    if (!W.wire) return fail(ctx, CHD_E_STATE, "the world was created without CHD_WORLD_WIRE");
+    if (kind < 0 || kind > 3) return fail(ctx, CHD_E_INVAL, "chd_wire_set_payloads: kind %d", kind);
+    if (!n) return CHD_OK;
+    if (!idx || !lens) return fail(ctx, CHD_E_INVAL, "chd_wire_set_payloads: NULL buffer");
+    const int full = kind & 1, cell = kind >> 1;
+    std::vector<uint64_t> off(n);
+    std::vector<uint32_t> ix(n);
+    uint64_t total = 0;
+    for (uint32_t i = 0; i < n; i++) {
+        if (lens[i] > W.x.stride[full])
+            return fail(ctx, CHD_E_CAPACITY, "payload %u: %u bytes exceed wire_max_%s_len (%u)", i, lens[i], full ? "full" : "update", W.x.stride[full]);
+        uint32_t v = idx[i];
+        if (cell) {
+            if (v < ctx->g.id_start || v - ctx->g.id_start >= ctx->g.ncell) return fail(ctx, CHD_E_INVAL, "payload %u: %u is not a spatial channel", i, v);
+            v -= ctx->g.id_start;
+        } else if (v >= W.d.N) {
+            return fail(ctx, CHD_E_INVAL, "payload %u: entity slot %u out of range", i, v);
+        }
+        ix[i] = v;
+        off[i] = total;
+        total += lens[i];
+    }
+    if (total && !bytes) return fail(ctx, CHD_E_INVAL, "chd_wire_set_payloads: NULL bytes");
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    TRY(bind(ctx));
+    TRY(ensure(ctx, 0, 4 * (size_t)n)); TRY(ensure(ctx, 1, 4 * (size_t)n)); TRY(ensure(ctx, 2, 8 * (size_t)n));
+    TRY(ensure(ctx, 3, std::max<uint64_t>(total, 16)));
+    TRY(up(ctx, sbuf<void>(ctx, 0), ix.data(), 4 * (size_t)n));
+    TRY(up(ctx, sbuf<void>(ctx, 1), lens, 4 * (size_t)n));
+    TRY(up(ctx, sbuf<void>(ctx, 2), off.data(), 8 * (size_t)n));
+    TRY(up(ctx, sbuf<void>(ctx, 3), bytes, total));
+    launch_wire_set_payloads(ctx->stream, W.x, full, cell, n, cell ? ctx->g.ncell : W.d.N, sbuf<uint32_t>(ctx, 0),
+                             sbuf<uint32_t>(ctx, 1), sbuf<uint64_t>(ctx, 2), sbuf<uint8_t>(ctx, 3));
+    TRY(after_launch(ctx));
+    HIPCHK(hipStreamSynchronize(ctx->stream));  // the staging vectors go out of scope
+    return CHD_OK;
+}
+
+int chd_wire_build(chd_ctx *ctx, uint64_t *total_bytes, uint64_t *total_packets, uint32_t *dropped) {
+    NEED_WORLD();
+    World &W = ctx->w;
+    if (!W.wire) return fail(ctx, CHD_E_STATE, "the world was created without CHD_WORLD_WIRE");
+    if (!W.ticked) return fail(ctx, CHD_E_STATE, "no tick to build the wire buffers of");
+    if (W.slot_mode == 2) return fail(ctx, CHD_E_STATE, "wire buffers are not available on region-sharded worlds yet");
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    TRY(bind(ctx));
+    WorldDev &d = W.d;
+    hipStream_t st = ctx->stream;
+    HIPCHK(hipMemsetAsync(W.x.n_dropped, 0, sizeof(uint32_t), st));
+    launch_wire_layout(st, d, W.x);
+    launch_scan_u64_inplace(st, W.x.conn_wlen, d.S);
+    TRY(after_launch(ctx));
+    uint64_t total = 0;
+    uint32_t ndrop = 0;
+    TRY(down(ctx, &total, W.x.conn_wlen + d.S, sizeof total));
+    TRY(down(ctx, &ndrop, W.x.n_dropped, sizeof ndrop));
+    HIPCHK(hipStreamSynchronize(st));
+    if (total > W.wire_cap) {
+        if (W.x.bytes) HIPCHK(hipFree(W.x.bytes));
+        W.x.bytes = nullptr;
+        W.wire_cap = total + total / 8 + 4096;
+        HIPCHK(hipMalloc((void **)&W.x.bytes, W.wire_cap));
+    }
+    launch_wire_copy(st, d, W.x);
+    TRY(after_launch(ctx));
+    W.wire_built = true;
+    if (total_bytes) *total_bytes = total;
+    if (dropped) *dropped = ndrop;
+    if (total_packets) {
+        std::vector<uint32_t> npk(d.S);
+        TRY(down(ctx, npk.data(), W.x.conn_npk, sizeof(uint32_t) * d.S));
+        HIPCHK(hipStreamSynchronize(st));
+        uint64_t t = 0;
+        for (uint32_t v : npk) t += v;
+        *total_packets = t;
+    }
+    return CHD_OK;
+}
+
+int chd_wire_fetch(chd_ctx *ctx, uint64_t *conn_off, uint32_t *conn_packets, uint8_t *bytes, uint64_t cap) {
+    NEED_WORLD();
+    World &W = ctx->w;
+    if (!W.wire_built) return fail(ctx, CHD_E_STATE, "chd_wire_build has not run for the last tick");
+    if (!conn_off) return fail(ctx, CHD_E_INVAL, "chd_wire_fetch: NULL conn_off");
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    TRY(bind(ctx));
+    TRY(down(ctx, conn_off, W.x.conn_woff, sizeof(uint64_t) * ((size_t)W.d.S + 1)));
+    if (conn_packets) TRY(down(ctx, conn_packets, W.x.conn_npk, sizeof(uint32_t) * W.d.S));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    const uint64_t total = conn_off[W.d.S];
+    if (bytes) {
+        if (total > cap) return fail(ctx, CHD_E_CAPACITY, "chd_wire_fetch: %llu bytes, capacity %llu", (unsigned long long)total, (unsigned long long)cap);
+        TRY(down(ctx, bytes, W.x.bytes, total));
+        HIPCHK(hipStreamSynchronize(ctx->stream));
+    }
     return CHD_OK;
 }
 

@@ -86,6 +86,8 @@ struct WorldDev {
     uint64_t *rec_ub;     // [S+1] upper bound per subscriber -> exclusive scan = base of its record range
     uint32_t *rec_cnt;    // [S] records emitted for the connection (sum of its pair_nrec)
     chd_fanout_rec *recs; uint64_t recs_cap;
+    uint32_t *rec_pos;    // wire mode only (else nullptr): cell-table position of each record's entity, or CHD_POS_CELL | cell
+    uint32_t *ce_slot;    // [N] entity slot of each cell-table entry (wire mode: payload lookup)
     chd_handover_rec *handovers; uint32_t handovers_cap;
     uint32_t *unsub_sub, *unsub_cell; uint32_t unsub_cap;
     uint32_t *newsub_sub, *newsub_cell, *newsub_iv; uint32_t newsub_cap;
@@ -221,6 +223,23 @@ void launch_csr_gather(hipStream_t st, uint32_t nq, uint32_t stride, const uint3
                        const uint32_t *offsets, const uint32_t *cells, const uint32_t *dists,
                        const uint32_t *ivs, uint32_t *out_ids, uint32_t *out_dists,
                        uint32_t *out_ivs, uint32_t cap, uint32_t id_start);
+// wire-format fan-out buffers
+struct WireDev {
+    uint32_t stride[2];                 // payload slot size in bytes: [0] update (delta), [1] full state
+    uint8_t *pay_ent[2], *pay_cell[2];  // [N * stride], [ncell * stride]: serialized google.protobuf.Any per channel
+    uint32_t *len_ent[2], *len_cell[2]; // [N], [ncell]
+    uint32_t *rec_woff;                 // per record: byte offset of its Packet entry in the connection's stream (~0 = dropped)
+    uint32_t *rec_wtag;                 // per record: 0, or 0x80000000 | packet length if it opens a packet
+    uint64_t *conn_wlen;                // [S+1] stream length per connection -> exclusive scan = conn_woff
+    uint64_t *conn_woff;                // alias of conn_wlen after the scan
+    uint32_t *conn_npk;                 // [S] packets per connection
+    uint32_t *n_dropped;                // [1]
+    uint8_t *bytes;                     // the wire arena
+};
+void launch_wire_layout(hipStream_t st, WorldDev w, WireDev x);
+void launch_wire_copy(hipStream_t st, WorldDev w, WireDev x);
+void launch_wire_set_payloads(hipStream_t st, WireDev x, int full, int cell, uint32_t n, uint32_t limit, const uint32_t *idx,
+                              const uint32_t *lens, const uint64_t *off, const uint8_t *bytes);
 // recipient planning (decision parts)
 void launch_handover_recipients_count(hipStream_t st, DevGrid g, WorldDev w, uint32_t *off);
 void launch_handover_recipients_fill(hipStream_t st, DevGrid g, WorldDev w, const uint32_t *off, uint32_t *conn,

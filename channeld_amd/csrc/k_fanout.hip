@@ -207,7 +207,7 @@ __device__ __forceinline__ bool entry_passes(const WorldDev &w, const u32x4 &e, 
 template <bool FULL>
 __device__ __forceinline__ uint32_t emit_cell(const WorldDev &w, const uint4 *__restrict__ ce, uint32_t start, uint32_t end,
                                               uint32_t wm, bool skip_self, uint32_t conn, uint32_t conn_tag,
-                                              chd_fanout_rec *__restrict__ out, uint32_t n_out) {
+                                              chd_fanout_rec *__restrict__ out, uint32_t *__restrict__ opos, uint32_t n_out) {
     static_assert(FO_UNROLL == 8, "the load block below names eight entries");
     const uint32_t lane = lane_id();
     for (uint32_t b = start; b < end; b += 64 * FO_UNROLL) {
@@ -252,6 +252,7 @@ __device__ __forceinline__ uint32_t emit_cell(const WorldDev &w, const uint4 *__
                 u32x4 r;
                 r.x = conn_tag; r.y = ea.x; r.z = conn_tag; r.w = e[2 * j + 1].x;
                 *(u32x4 *)(void *)(out + n_out + 2 * lane) = r;
+                if (opos) { opos[n_out + 2 * lane] = pos; opos[n_out + 2 * lane + 1] = pos + 1; }
                 n_out += 128;
             } else {
                 // entry order: records before this lane's pair = passing entries of lower lanes
@@ -262,12 +263,14 @@ __device__ __forceinline__ uint32_t emit_cell(const WorldDev &w, const uint4 *__
                     r.conn = conn_tag;
                     r.channel = ea.x;
                     out[at] = r;
+                    if (opos) opos[at] = pos;
                 }
                 if (pass1) {
                     chd_fanout_rec r;
                     r.conn = conn_tag;
                     r.channel = e[2 * j + 1].x;
                     out[at + (pass0 ? 1u : 0u)] = r;
+                    if (opos) opos[at + (pass0 ? 1u : 0u)] = pos + 1;
                 }
                 n_out += (uint32_t)__popcll(m0) + (uint32_t)__popcll(m1);
             }
@@ -282,7 +285,8 @@ __device__ __forceinline__ uint32_t emit_cell(const WorldDev &w, const uint4 *__
 // A lane's adjacent entry pair is ONE 16-byte load; a step covers 512 entries with four loads.
 template <bool FULL>
 __device__ __forceinline__ uint32_t emit_cell8(const uint2 *__restrict__ ce8, uint32_t start, uint32_t end, uint32_t wm,
-                                               uint32_t conn_tag, chd_fanout_rec *__restrict__ out, uint32_t n_out) {
+                                               uint32_t conn_tag, chd_fanout_rec *__restrict__ out,
+                                               uint32_t *__restrict__ opos, uint32_t n_out) {
     const uint32_t lane = lane_id();
     for (uint32_t b = start; b < end; b += 512) {
         u32x4 e[4];
@@ -315,6 +319,7 @@ __device__ __forceinline__ uint32_t emit_cell8(const uint2 *__restrict__ ce8, ui
                 u32x4 r;
                 r.x = conn_tag; r.y = chan_a; r.z = conn_tag; r.w = e[j].z;
                 *(u32x4 *)(void *)(out + n_out + 2 * lane) = r;
+                if (opos) { opos[n_out + 2 * lane] = pos; opos[n_out + 2 * lane + 1] = pos + 1; }
                 n_out += 128;
             } else {
                 const uint32_t at = __builtin_amdgcn_mbcnt_hi((uint32_t)(m1 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m1,
@@ -324,12 +329,14 @@ __device__ __forceinline__ uint32_t emit_cell8(const uint2 *__restrict__ ce8, ui
                     r.conn = conn_tag;
                     r.channel = chan_a;
                     out[at] = r;
+                    if (opos) opos[at] = pos;
                 }
                 if (pass1) {
                     chd_fanout_rec r;
                     r.conn = conn_tag;
                     r.channel = e[j].z;
                     out[at + (pass0 ? 1u : 0u)] = r;
+                    if (opos) opos[at + (pass0 ? 1u : 0u)] = pos + 1;
                 }
                 n_out += (uint32_t)__popcll(m0) + (uint32_t)__popcll(m1);
             }
@@ -418,6 +425,8 @@ __global__ void __launch_bounds__(64 * FO_WAVES) k_fanout_emit(DevGrid g, WorldD
             const bool skip_self = (fl & PF_SKIP_SELF) != 0;
             const uint32_t us = d_us[k];
             chd_fanout_rec *__restrict__ out = w.recs + base + d_rel[k];
+            // wire mode: which cell-table entry (or, with bit 31, which spatial channel) each record came from
+            uint32_t *__restrict__ opos = w.rec_pos ? w.rec_pos + base + d_rel[k] : nullptr;
             uint32_t n_out = 0;
             if (!(fl & PF_HAD_FIRST)) {
                 // first fan-out: the whole data of the spatial channel and of every
@@ -427,9 +436,10 @@ __global__ void __launch_bounds__(64 * FO_WAVES) k_fanout_emit(DevGrid g, WorldD
                     r.conn = conn | CHD_REC_FULL;
                     r.channel = c + g.id_start;
                     out[0] = r;
+                    if (opos) opos[0] = CHD_POS_CELL | c;
                 }
-                n_out = w.ce8_view ? emit_cell8<true>(w.ce8_view, start, end, 0u, conn | CHD_REC_FULL, out, 1u)
-                                   : emit_cell<true>(w, ce, start, end, 0u, false, conn, conn | CHD_REC_FULL, out, 1u);
+                n_out = w.ce8_view ? emit_cell8<true>(w.ce8_view, start, end, 0u, conn | CHD_REC_FULL, out, opos, 1u)
+                                   : emit_cell<true>(w, ce, start, end, 0u, false, conn, conn | CHD_REC_FULL, out, opos, 1u);
                 fl |= PF_HAD_FIRST;
                 L = now;
             }
@@ -450,11 +460,12 @@ __global__ void __launch_bounds__(64 * FO_WAVES) k_fanout_emit(DevGrid g, WorldD
                                 r.conn = conn;
                                 r.channel = c + g.id_start;
                                 out[n_out] = r;
+                                if (opos) opos[n_out] = CHD_POS_CELL | c;
                             }
                             n_out += 1;
                         }
-                        if (us == CHD_NONUNIFORM) n_out = emit_cell<false>(w, ce, start, end, wm, skip_self, conn, conn, out, n_out);
-                        else if (!(skip_self && us == conn)) n_out = emit_cell8<false>(w.ce8_view, start, end, wm, conn, out, n_out);
+                        if (us == CHD_NONUNIFORM) n_out = emit_cell<false>(w, ce, start, end, wm, skip_self, conn, conn, out, opos, n_out);
+                        else if (!(skip_self && us == conn)) n_out = emit_cell8<false>(w.ce8_view, start, end, wm, conn, out, opos, n_out);
                     }
                     L = next;
                 }
@@ -540,7 +551,7 @@ __device__ __forceinline__ void lds_barrier() {
 template <bool FULL, bool PREV>
 __device__ __forceinline__ uint32_t emit_tile(const WorldDev &w, const WsTile &T, uint32_t wm, bool skip_self,
                                               uint32_t conn, uint32_t conn_tag, chd_fanout_rec *__restrict__ out,
-                                              uint32_t n_out) {
+                                              uint32_t *__restrict__ opos, uint32_t n_out) {
     const uint32_t lane = lane_id();
     const uint32_t tn = T.tn;
     for (uint32_t b = 0; b < tn; b += 256) {
@@ -579,11 +590,8 @@ __device__ __forceinline__ uint32_t emit_tile(const WorldDev &w, const WsTile &T
                 chd_fanout_rec r;
                 r.conn = conn_tag;
                 r.channel = chan[j];
-#ifdef CHD_EXP_NOSTREAM
-                out[pos & 511u] = r;  // experiment: same instructions, L2-resident target
-#else
                 out[pos] = r;
-#endif
+                if (opos) opos[pos] = T.gpos + b + j * 64 + lane;
             }
             n_out += (uint32_t)__popcll(m);
         }
@@ -863,11 +871,8 @@ __global__ void __launch_bounds__(64 * WS_WAVES) k_fanout_emit_ws(DevGrid g, Wor
                 const uint32_t flags = Lst.flags[k];
                 const uint32_t conn = Lst.conn[k];
                 const bool skip_self = (flags & WSF_SKIP_SELF) != 0;
-#ifdef CHD_EXP_NOSTREAM
-                chd_fanout_rec *__restrict__ out = w.recs + (size_t)(blockIdx.x * WS_WAVES + wave) * 512u;
-#else
                 chd_fanout_rec *__restrict__ out = w.recs + (size_t)Lst.out16[k] * CHD_SEG_ALIGN;
-#endif
+                uint32_t *__restrict__ opos = w.rec_pos ? w.rec_pos + (size_t)Lst.out16[k] * CHD_SEG_ALIGN : nullptr;
                 uint32_t n_out = Lst.nout[k];
                 if (flags & WSF_FIRST) {
                     // first fan-out: whole data of the spatial channel and of every entity channel in it
@@ -877,10 +882,11 @@ __global__ void __launch_bounds__(64 * WS_WAVES) k_fanout_emit_ws(DevGrid g, Wor
                             r.conn = conn | CHD_REC_FULL;
                             r.channel = c + g.id_start;
                             out[0] = r;
+                            if (opos) opos[0] = CHD_POS_CELL | c;
                         }
                         n_out = 1;
                     }
-                    n_out = emit_tile<true, false>(w, T, 0u, false, conn, conn | CHD_REC_FULL, out, n_out);
+                    n_out = emit_tile<true, false>(w, T, 0u, false, conn, conn | CHD_REC_FULL, out, opos, n_out);
                 }
                 if (!(flags & WSF_GENERIC)) {
                     const uint32_t nw = (flags >> WSF_NWIN_SHIFT) & 7u;
@@ -892,11 +898,12 @@ __global__ void __launch_bounds__(64 * WS_WAVES) k_fanout_emit_ws(DevGrid g, Wor
                                 r.conn = conn;
                                 r.channel = c + g.id_start;
                                 out[n_out] = r;
+                                if (opos) opos[n_out] = CHD_POS_CELL | c;
                             }
                             n_out += 1;
                         }
-                        n_out = T.any_prev ? emit_tile<false, true>(w, T, wm, skip_self, conn, conn, out, n_out)
-                                           : emit_tile<false, false>(w, T, wm, skip_self, conn, conn, out, n_out);
+                        n_out = T.any_prev ? emit_tile<false, true>(w, T, wm, skip_self, conn, conn, out, opos, n_out)
+                                           : emit_tile<false, false>(w, T, wm, skip_self, conn, conn, out, opos, n_out);
                     }
                 } else {
                     // more than four non-empty windows (a subscription that was not served for several ticks):
@@ -916,11 +923,12 @@ __global__ void __launch_bounds__(64 * WS_WAVES) k_fanout_emit_ws(DevGrid g, Wor
                                         r.conn = conn;
                                         r.channel = c + g.id_start;
                                         out[n_out] = r;
+                                        if (opos) opos[n_out] = CHD_POS_CELL | c;
                                     }
                                     n_out += 1;
                                 }
-                                n_out = T.any_prev ? emit_tile<false, true>(w, T, wm, skip_self, conn, conn, out, n_out)
-                                                   : emit_tile<false, false>(w, T, wm, skip_self, conn, conn, out, n_out);
+                                n_out = T.any_prev ? emit_tile<false, true>(w, T, wm, skip_self, conn, conn, out, opos, n_out)
+                                                   : emit_tile<false, false>(w, T, wm, skip_self, conn, conn, out, opos, n_out);
                             }
                             L = next;
                         }

@@ -218,6 +218,7 @@ __global__ void __launch_bounds__(IDX_BLOCK) k_index_scatter(WorldDev w, uint32_
         w.ce[pos] = make_uint4(w.chan_id[i], h, w.sender[i], hp);
         w.ce8[pos] = make_uint2(w.chan_id[i], h | hp);
         w.ce_sprev[pos] = w.sender_prev[i];
+        if (w.ce_slot) w.ce_slot[pos] = i;
     }
 }
 
@@ -244,6 +245,7 @@ __global__ void __launch_bounds__(256) k_index_scatter_global(WorldDev w, uint32
     uint32_t hp = (age >= CHD_HIST_BITS) ? 0u : (w.hist_prev[i] << age);
     w.ce[pos] = make_uint4(w.chan_id[i], h, w.sender[i], hp);
     w.ce_sprev[pos] = w.sender_prev[i];
+    if (w.ce_slot) w.ce_slot[pos] = i;
 }
 
 // ------------------------------------------------------------------------

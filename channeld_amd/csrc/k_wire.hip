@@ -1,0 +1,227 @@
+// k_wire.hip — wire-format fan-out buffers on the device.
+//
+// What the reference does per fan-out message, three marshals deep:
+//   data.go:293-318        ChannelDataUpdateMessage{Data: anypb.New(update)} for (conn, channel)
+//   connection.go:57-83    MessagePack{ChannelId, MsgType = CHANNEL_DATA_UPDATE, MsgBody}; a pack whose
+//                          size is >= MaxPacketSize - PacketHeaderSize is dropped
+//   connection.go:626-714  flush: packs are appended to a Packet while proto.Size(packet) <= 65535,
+//                          the pack that would overflow opens the next packet; every packet goes out
+//                          behind the 5-byte tag {'C','H', size_hi, size_lo, compression}
+// Here the host supplies, per channel, the serialized google.protobuf.Any of its (merged) update
+// and of its full state; everything else — the three nested length-delimited headers, the greedy
+// packet split and the tags — is produced per connection from the tick's fan-out records:
+//
+//   k_wire_layout  one wave per connection walks its records in stream order (subscription
+//                  segments, records inside them): entry size of every record from the channel id's
+//                  varint length and the payload length (wave prefix sum), greedy packet cuts with
+//                  wave-uniform bookkeeping; per record its byte offset in the connection's stream
+//                  and, for the first record of a packet, that packet's length (for the tag)
+//   scan           connection stream lengths -> bases in the wire arena
+//   k_wire_copy    one lane per record: tag (if first of its packet) + headers are composed in
+//                  registers and streamed with the payload through a byte FIFO into the arena
+//                  (dword stores once the destination is aligned)
+// Bytes written per message = 5/packet + ~12 header + payload: this is the P*M term of SURVEY §8d.
+#include "chd_kernels.h"
+
+#define WIRE_MAX_PACKET 65535u
+#define WIRE_DROP_SIZE 65530u  // MaxPacketSize - PacketHeaderSize (connection.go:72)
+
+__device__ __forceinline__ uint32_t vlen(uint32_t v) { return v < (1u << 7) ? 1u : v < (1u << 14) ? 2u : v < (1u << 21) ? 3u : v < (1u << 28) ? 4u : 5u; }
+
+struct WireMsg {
+    uint32_t chan, any_len, body_len, mp_len, entry;  // entry = bytes inside the Packet (0: dropped by Send)
+    const uint8_t *pay;
+};
+
+__device__ __forceinline__ WireMsg wire_msg(const WorldDev &w, const WireDev &x, chd_fanout_rec rec, uint32_t pos) {
+    WireMsg m;
+    const uint32_t full = rec.conn >> 31;
+    m.chan = rec.channel;
+    if (pos & CHD_POS_CELL) {
+        const uint32_t c = pos & ~CHD_POS_CELL;
+        m.any_len = x.len_cell[full][c];
+        m.pay = x.pay_cell[full] + (size_t)c * x.stride[full];
+    } else {
+        const uint32_t slot = w.ce_slot[pos];
+        m.any_len = x.len_ent[full][slot];
+        m.pay = x.pay_ent[full] + (size_t)slot * x.stride[full];
+    }
+    m.body_len = 1u + vlen(m.any_len) + m.any_len;                       // ChannelDataUpdateMessage.data = 1
+    m.mp_len = (m.chan ? 1u + vlen(m.chan) : 0u) + 2u                    // channelId = 1 (omitted if 0), msgType = 4 -> 0x20 0x08
+               + 1u + vlen(m.body_len) + m.body_len;                     // msgBody = 5
+    m.entry = m.mp_len >= WIRE_DROP_SIZE ? 0u : 1u + vlen(m.mp_len) + m.mp_len;  // Packet.messages = 1
+    return m;
+}
+
+// One wave per connection slot.
+__global__ void __launch_bounds__(256) k_wire_layout(WorldDev w, WireDev x) {
+    const uint32_t s = blockIdx.x * 4u + (threadIdx.x >> 6);
+    if (s >= w.S) return;
+    const uint32_t lane = threadIdx.x & 63u;
+    uint64_t pkt_base = 0;   // stream offset of the current packet's tag
+    uint32_t pkt_used = 0;   // bytes of entries in the current packet
+    uint64_t pkt_first = ~0ull;  // record index of the current packet's first entry
+    uint32_t npk = 0, ndropped = 0;
+    if (w.sub_alive[s]) {
+        const uint32_t cnt = w.pair_cnt[s];
+        const size_t pbase = (size_t)s * w.capq;
+        const uint64_t rbase = w.rec_ub[s];
+        for (uint32_t p = 0; p < cnt; p++) {
+            const uint32_t n = w.pair_nrec[pbase + p];
+            const uint64_t seg = rbase + w.pair_rel[pbase + p];
+            for (uint32_t i0 = 0; i0 < n; i0 += 64) {
+                const uint32_t i = i0 + lane;
+                const bool valid = i < n;
+                uint32_t entry = 0;
+                if (valid) entry = wire_msg(w, x, w.recs[seg + i], w.rec_pos[seg + i]).entry;
+                if (valid && entry == 0) x.rec_woff[seg + i] = 0xFFFFFFFFu;  // dropped
+                ndropped += (uint32_t)__popcll(__ballot(valid && entry == 0));
+                // inclusive prefix of the entry sizes over the chunk
+                uint32_t cum = entry;
+#pragma unroll
+                for (int d = 1; d < 64; d <<= 1) {
+                    const uint32_t o = __shfl_up(cum, d);
+                    if ((int)lane >= d) cum += o;
+                }
+                uint32_t start_lane = 0, cum_before_start = 0;
+                for (;;) {
+                    // bytes the current packet would hold after this lane's entry
+                    const uint32_t rel = pkt_used + (cum - cum_before_start);
+                    const bool mine = valid && lane >= start_lane;
+                    const uint64_t over = __ballot(mine && entry != 0 && rel > WIRE_MAX_PACKET);
+                    const uint32_t f = over ? (uint32_t)__ffsll((unsigned long long)over) - 1u : 64u;
+                    // lanes [start_lane, f) stay in the current packet
+                    if (mine && lane < f && entry != 0) {
+                        x.rec_woff[seg + i] = (uint32_t)(pkt_base + 5u + rel - entry);
+                        x.rec_wtag[seg + i] = 0;
+                    }
+                    // the first entry of the current packet, if it is in this range
+                    const uint64_t firsts = __ballot(mine && lane < f && entry != 0);
+                    if (pkt_first == ~0ull && firsts) pkt_first = seg + i0 + (uint32_t)__ffsll((unsigned long long)firsts) - 1u;
+                    const uint32_t cum_f = f < 64 ? __shfl(cum - entry, (int)f) : __shfl(cum, 63);  // prefix before lane f
+                    pkt_used += cum_f - cum_before_start;
+                    if (f == 64) break;
+                    // close the packet (flush, connection.go:646-661): lane f's entry opens the next one
+                    if (lane == 0 && pkt_first != ~0ull) x.rec_wtag[pkt_first] = 0x80000000u | pkt_used;
+                    pkt_base += 5u + pkt_used;
+                    npk += 1;
+                    pkt_used = 0;
+                    pkt_first = ~0ull;
+                    start_lane = f;
+                    cum_before_start = cum_f;
+                }
+            }
+        }
+        if (pkt_used) {  // the last, partly filled packet
+            if (lane == 0 && pkt_first != ~0ull) x.rec_wtag[pkt_first] = 0x80000000u | pkt_used;
+            pkt_base += 5u + pkt_used;
+            npk += 1;
+        }
+    }
+    if (lane == 0) {
+        x.conn_wlen[s] = pkt_base;
+        x.conn_npk[s] = npk;
+        if (ndropped) atomicAdd(x.n_dropped, ndropped);
+    }
+}
+
+void launch_wire_layout(hipStream_t st, WorldDev w, WireDev x) {
+    if (!w.S) return;
+    hipLaunchKernelGGL(k_wire_layout, dim3((w.S + 3) / 4), dim3(256), 0, st, w, x);
+}
+
+// byte FIFO into global memory: single bytes until the destination is dword-aligned, dwords after
+struct ByteOut {
+    uint8_t *d;
+    uint64_t acc;
+    uint32_t nacc;
+    __device__ __forceinline__ void drain() {
+        while (nacc && ((uintptr_t)d & 3u)) { *d++ = (uint8_t)acc; acc >>= 8; nacc--; }
+        while (nacc >= 4) { *(uint32_t *)(void *)d = (uint32_t)acc; d += 4; acc >>= 32; nacc -= 4; }
+    }
+    __device__ __forceinline__ void push(uint32_t v, uint32_t nbytes) {  // nbytes in 1..4, upper bytes of v zero
+        acc |= (uint64_t)v << (8 * nacc);
+        nacc += nbytes;
+        drain();
+    }
+    __device__ __forceinline__ void varint(uint32_t v) {
+        while (v >= 0x80u) { push((v & 0x7Fu) | 0x80u, 1); v >>= 7; }
+        push(v, 1);
+    }
+    __device__ __forceinline__ void finish() {
+        while (nacc) { *d++ = (uint8_t)acc; acc >>= 8; nacc--; }
+    }
+};
+
+__global__ void __launch_bounds__(256) k_wire_copy(WorldDev w, WireDev x) {
+    __shared__ uint32_t ticket;
+    const uint32_t s = blockIdx.x;
+    if (!w.sub_alive[s] || x.conn_woff[s + 1] == x.conn_woff[s]) return;  // (conn_wlen was scanned in place)
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t cnt = w.pair_cnt[s];
+    const size_t pbase = (size_t)s * w.capq;
+    const uint64_t rbase = w.rec_ub[s];
+    uint8_t *stream = x.bytes + x.conn_woff[s];
+    if (threadIdx.x == 0) ticket = 0;
+    __syncthreads();
+    for (;;) {
+        uint32_t p = 0;
+        if (lane == 0) p = atomicAdd(&ticket, 1u);
+        p = __builtin_amdgcn_readfirstlane(p);
+        if (p >= cnt) break;
+        const uint32_t n = w.pair_nrec[pbase + p];
+        const uint64_t seg = rbase + w.pair_rel[pbase + p];
+        for (uint32_t i = lane; i < n; i += 64) {
+            const uint32_t woff = x.rec_woff[seg + i];
+            if (woff == 0xFFFFFFFFu) continue;  // dropped by the size check of Send
+            const WireMsg m = wire_msg(w, x, w.recs[seg + i], w.rec_pos[seg + i]);
+            const uint32_t tag = x.rec_wtag[seg + i];
+            ByteOut o;
+            o.acc = 0; o.nacc = 0;
+            o.d = stream + woff;
+            if (tag) {  // first entry of a packet: the 5-byte tag sits right before it (connection.go:683-687)
+                const uint32_t plen = tag & 0xFFFFu;
+                o.d -= 5;
+                o.push(67u | (72u << 8) | (((plen >> 8) & 0xFFu) << 16) | ((plen & 0xFFu) << 24), 4);
+                o.push(0u, 1);  // CompressionType_NO_COMPRESSION
+            }
+            o.push(0x0Au, 1); o.varint(m.mp_len);                          // Packet.messages
+            if (m.chan) { o.push(0x08u, 1); o.varint(m.chan); }            // MessagePack.channelId
+            o.push(0x20u | (0x08u << 8), 2);                               // MessagePack.msgType = CHANNEL_DATA_UPDATE
+            o.push(0x2Au, 1); o.varint(m.body_len);                        // MessagePack.msgBody
+            o.push(0x0Au, 1); o.varint(m.any_len);                         // ChannelDataUpdateMessage.data
+            const uint32_t *src = (const uint32_t *)(const void *)m.pay;   // payload slots are 16-byte aligned
+            uint32_t k = 0;
+            for (; k + 4 <= m.any_len; k += 4) o.push(src[k >> 2], 4);
+            if (k < m.any_len) o.push(src[k >> 2] & (0xFFFFFFFFu >> (8 * (4 - (m.any_len - k)))), m.any_len - k);
+            o.finish();
+        }
+    }
+}
+
+void launch_wire_copy(hipStream_t st, WorldDev w, WireDev x) {
+    if (!w.S) return;
+    hipLaunchKernelGGL(k_wire_copy, dim3(w.S), dim3(256), 0, st, w, x);
+}
+
+// payload upload: kind k, entry idx[i] <- lens[i] bytes at bytes + off[i]
+__global__ void __launch_bounds__(256) k_wire_set_payloads(WireDev x, int full, int cell, uint32_t n, uint32_t limit,
+                                                           const uint32_t *__restrict__ idx, const uint32_t *__restrict__ lens,
+                                                           const uint64_t *__restrict__ off, const uint8_t *__restrict__ bytes) {
+    const uint32_t u = blockIdx.x * 4u + (threadIdx.x >> 6);
+    if (u >= n) return;
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t i = idx[u];
+    if (i >= limit) return;
+    const uint32_t len = lens[u];
+    uint8_t *dst = (cell ? x.pay_cell[full] : x.pay_ent[full]) + (size_t)i * x.stride[full];
+    const uint8_t *src = bytes + off[u];
+    for (uint32_t k = lane; k < len; k += 64) dst[k] = src[k];
+    if (lane == 0) (cell ? x.len_cell[full] : x.len_ent[full])[i] = len;
+}
+
+void launch_wire_set_payloads(hipStream_t st, WireDev x, int full, int cell, uint32_t n, uint32_t limit, const uint32_t *idx,
+                              const uint32_t *lens, const uint64_t *off, const uint8_t *bytes) {
+    if (!n) return;
+    hipLaunchKernelGGL(k_wire_set_payloads, dim3((n + 3) / 4), dim3(256), 0, st, x, full, cell, n, limit, idx, lens, off, bytes);
+}

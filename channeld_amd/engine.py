@@ -72,14 +72,16 @@ class DeviceArray:
 
 class SpatialWorld:
     def __init__(self, ctl: StaticGrid2DSpatialController, max_entities: int, max_subscribers: int,
-                 max_interest_cells: int = 0, max_records: int = 0, max_handovers: int = 0, flags: int = 0):
+                 max_interest_cells: int = 0, max_records: int = 0, max_handovers: int = 0, flags: int = 0,
+                 wire_max_update_len: int = 0, wire_max_full_len: int = 0):
         self.ctl = ctl
         self.lib = _lib.load()
         self.ctx = ctl.ctx
         self.N, self.S = int(max_entities), int(max_subscribers)
         ncell = ctl.GridCols * ctl.GridRows
         self.capq = int(max_interest_cells) if max_interest_cells else min(ncell, 256)
-        cfg = WorldCfg(self.N, self.S, self.capq, int(max_records), int(max_handovers), int(flags))
+        cfg = WorldCfg(self.N, self.S, self.capq, int(max_records), int(max_handovers), int(flags),
+                       int(wire_max_update_len), int(wire_max_full_len))
         _lib.check(self.ctx, self.lib.chd_world_create(self.ctx, C.byref(cfg)))
 
     # ---- population ----
@@ -227,6 +229,31 @@ class SpatialWorld:
                     n_records=int(s.n_records), n_record_upper_bound=int(s.n_record_upper_bound),
                     n_handovers=int(s.n_handovers), n_unsubs=int(s.n_unsubs), n_pairs=int(s.n_pairs),
                     algorithmic_bytes=int(s.algorithmic_bytes))
+
+    # ---- wire-format fan-out buffers ----
+    def wire_set_payloads(self, kind: int, idx, payloads):
+        """payloads: list of bytes (serialized google.protobuf.Any), one per idx."""
+        ix = _u32(idx)
+        lens = _u32([len(b) for b in payloads])
+        blob = np.frombuffer(b"".join(payloads), dtype=np.uint8) if lens.sum() else np.zeros(1, dtype=np.uint8)
+        _lib.check(self.ctx, self.lib.chd_wire_set_payloads(self.ctx, int(kind), len(ix), _ptr(ix), _ptr(lens),
+                                                            blob.ctypes.data_as(C.c_void_p)))
+
+    def wire_build(self):
+        """Builds the per-connection packet streams of the last tick on the device: (bytes, packets, dropped)."""
+        tb, tp, dr = C.c_uint64(0), C.c_uint64(0), C.c_uint32(0)
+        _lib.check(self.ctx, self.lib.chd_wire_build(self.ctx, C.byref(tb), C.byref(tp), C.byref(dr)))
+        return tb.value, tp.value, dr.value
+
+    def wire_fetch(self, want_bytes: bool = True):
+        off = np.zeros(self.S + 1, dtype=np.uint64)
+        npk = np.zeros(self.S, dtype=np.uint32)
+        _lib.check(self.ctx, self.lib.chd_wire_fetch(self.ctx, _ptr(off), _ptr(npk), None, 0))
+        total = int(off[self.S])
+        data = np.zeros(max(total, 1), dtype=np.uint8)
+        if want_bytes and total:
+            _lib.check(self.ctx, self.lib.chd_wire_fetch(self.ctx, _ptr(off), _ptr(npk), data.ctypes.data_as(C.c_void_p), total))
+        return off, npk, data[:total]
 
     # ---- recipient planning (SURVEY 8f-2 / 8f-4, decision parts) ----
     def handover_recipients(self, n_handovers: int):

@@ -36,7 +36,7 @@
 extern "C" {
 #endif
 
-#define CHD_ABI_VERSION 2
+#define CHD_ABI_VERSION 3
 
 typedef struct chd_ctx chd_ctx;
 
@@ -163,6 +163,8 @@ typedef struct {
     uint64_t max_records;        /* fan-out record capacity per tick (0 => auto) */
     uint32_t max_handovers;      /* handover record capacity per tick (0 => max_entities) */
     uint32_t flags;              /* CHD_WORLD_* */
+    uint32_t wire_max_update_len; /* CHD_WORLD_WIRE: largest serialized Any of a channel update (0 => 128) */
+    uint32_t wire_max_full_len;   /* CHD_WORLD_WIRE: largest serialized Any of a channel's full state (0 => 1024) */
 } chd_world_cfg;
 
 /* The fan-out emit kernel has two forms.  Connection-major: one workgroup per connection
@@ -175,6 +177,8 @@ typedef struct {
 #define CHD_WORLD_CELL_MAJOR_EMIT 2u
 /* also plan, every tick, who receives each handover's ChannelDataHandoverMessage (chd_handover_recipients) */
 #define CHD_WORLD_HANDOVER_RECIPIENTS 4u
+/* keep what chd_wire_build needs: which channel table entry every fan-out record came from (+4 B per record) */
+#define CHD_WORLD_WIRE 8u
 
 #define CHD_ENTITY_LOCKED 1u /* member of a non-empty lock group (entity.go:197-224) */
 
@@ -396,6 +400,40 @@ int chd_adjacent_recipients(chd_ctx *ctx, uint32_t n_req, const uint32_t *channe
                             const uint32_t *broadcast, const uint32_t *sender_conn,
                             const uint32_t *client_conn, uint32_t *offsets /* n_req+1 */,
                             uint32_t *conns, uint64_t cap);
+
+/* ------------------------------------------------------------------ */
+/* Wire-format fan-out buffers: the bytes the gateway's   */
+/* flush goroutine would write per connection for the tick's fan-out    */
+/* messages, built on the device so that the host does one conn.Write   */
+/* per connection instead of three marshals per message.                */
+/* ------------------------------------------------------------------ */
+
+/* replaces: anypb.New(updateMsg) results handed to fanOutDataUpdate (data.go:293-302).
+ * The host keeps merging channel data (ChannelData.OnUpdate, data.go:149-173) and gives the
+ * engine, per channel, the serialized google.protobuf.Any to fan out:
+ *   kind CHD_WIRE_ENTITY_UPDATE / CHD_WIRE_ENTITY_FULL : idx = entity slots
+ *   kind CHD_WIRE_CELL_UPDATE / CHD_WIRE_CELL_FULL     : idx = spatial channel ids
+ * bytes = the payloads back to back, lens[i] bytes each.  A payload stays until replaced.
+ * (A window that holds several buffered updates of one channel fans out that channel's
+ * CURRENT payload once per window, as the reference sends one merged message per window.) */
+#define CHD_WIRE_ENTITY_UPDATE 0
+#define CHD_WIRE_ENTITY_FULL 1
+#define CHD_WIRE_CELL_UPDATE 2
+#define CHD_WIRE_CELL_FULL 3
+int chd_wire_set_payloads(chd_ctx *ctx, int kind, uint32_t n, const uint32_t *idx,
+                          const uint32_t *lens, const uint8_t *bytes);
+
+/* replaces, for every connection at once: queuedMessagePackSender.Send (connection.go:57-83:
+ * MessagePack{ChannelId, MsgType: CHANNEL_DATA_UPDATE, MsgBody: ChannelDataUpdateMessage{Data}},
+ * packs of 65530 bytes or more are dropped) and flush (connection.go:626-714: greedy Packets of
+ * at most 65535 bytes, each behind the tag 'C','H',size_hi,size_lo,compression=0) for the fan-out
+ * records of the LAST tick, in the order chd_tick_fetch reports them.  The streams stay on the
+ * device (chd_wire_fetch copies them out); *total_bytes, *total_packets, *dropped are optional. */
+int chd_wire_build(chd_ctx *ctx, uint64_t *total_bytes, uint64_t *total_packets, uint32_t *dropped);
+
+/* conn_off[s] .. conn_off[s+1] = connection slot s's stream inside bytes (max_subscribers+1
+ * offsets); conn_packets[s] = its number of packets.  bytes may be NULL (offsets only). */
+int chd_wire_fetch(chd_ctx *ctx, uint64_t *conn_off, uint32_t *conn_packets, uint8_t *bytes, uint64_t cap);
 
 /* device memory, for callers that keep their batches on the GPU (bench, tests) */
 int chd_dev_alloc(chd_ctx *ctx, uint64_t bytes, void **d_out);

@@ -1,0 +1,119 @@
+"""GPU: wire-format fan-out buffers (chd_wire_* through the C-ABI).
+
+The per-connection byte streams built on the device must equal what the reference's send path
+produces for the same messages in the same order: MessagePack{channelId, msgType=8,
+msgBody=ChannelDataUpdateMessage{data}} (data.go:293-318, connection.go:57-83), greedy Packets of
+at most 65535 bytes behind the 5-byte tag (connection.go:626-714).  Expected bytes come from
+oracle/wire.py, which tests/test_wire_oracle.py pins against packets serialized with the
+reference's own protobuf descriptor.  WHICH messages go to whom is the records' parity
+(tests/test_gpu_world.py); here the records of each tick are the message list."""
+import json
+
+import numpy as np
+import pytest
+
+from channeld_amd import synth
+from oracle import wire
+
+pytestmark = pytest.mark.gpu
+
+WIRE, CELL_MAJOR, CONN_MAJOR = 8, 2, 1
+ENT_UPD, ENT_FULL, CELL_UPD, CELL_FULL = 0, 1, 2, 3
+
+
+@pytest.fixture(scope="module")
+def amd():
+    import channeld_amd
+
+    channeld_amd.load()
+    return channeld_amd
+
+
+def any_bytes(rng, n):
+    return bytes(rng.integers(0, 256, int(n), dtype=np.uint8))
+
+
+def run_wire(amd, cfg_name, N, S, ticks, seed, flags, upd_len, full_len, max_upd=0, max_full=0, tick_ms=50, aoi_scale=1.0):
+    cfg = synth.load_config(cfg_name)
+    sw = synth.SynthWorld(synth.WorldSpec(cfg, N, S, seed, tick_ms=tick_ms, aoi_scale=aoi_scale))
+    ctl = amd.StaticGrid2DSpatialController()
+    assert ctl.LoadConfig(json.dumps(cfg).encode(), strict=False) is None
+    w = amd.SpatialWorld(ctl, N, S, flags=flags | WIRE, max_records=1 << 22, wire_max_update_len=max_upd, wire_max_full_len=max_full)
+    w.spawn(None, sw.chan_id, sw.x, sw.z, sw.flags, sw.sender)
+    w.add_subscribers(None, sw.sub_conn)
+    rng = np.random.default_rng(seed & 0xFFFF)
+    ncell = ctl.GridCols * ctl.GridRows
+    ent = {0: {}, 1: {}}     # full? -> slot -> Any bytes
+    cell = {0: {}, 1: {}}    # full? -> channel id -> Any bytes
+    for i in range(N):
+        ent[1][i] = any_bytes(rng, full_len())
+    for c in range(ncell):
+        cell[0][0x10000 + c] = any_bytes(rng, upd_len())
+        cell[1][0x10000 + c] = any_bytes(rng, full_len())
+    w.wire_set_payloads(ENT_FULL, list(ent[1]), list(ent[1].values()))
+    w.wire_set_payloads(CELL_UPD, list(cell[0]), list(cell[0].values()))
+    w.wire_set_payloads(CELL_FULL, list(cell[1]), list(cell[1].values()))
+    total_bytes = total_packets = total_dropped = 0
+    for k in range(ticks):
+        sw.step()
+        # this tick's merged update of every entity, as the host would marshal it
+        upd = {i: any_bytes(rng, upd_len()) for i in range(N)}
+        ent[0].update(upd)
+        w.wire_set_payloads(ENT_UPD, list(upd), list(upd.values()))
+        cu = 0x10000 + rng.integers(0, ncell, 3).astype(np.uint32)
+        res = w.tick(sw.now_ns(), upd_x=sw.x, upd_z=sw.z, queries=sw.queries(), cell_upd_channel=cu,
+                     cell_upd_sender=np.full(3, 5, dtype=np.uint32), records_cap=1 << 22)
+        nbytes, npackets, ndropped = w.wire_build()
+        off, npk, data = w.wire_fetch()
+        assert int(off[S]) == nbytes == len(data) and int(npk.sum()) == npackets
+        dropped = 0
+        for s in range(S):
+            recs = res.records_of(s)
+            packs = []
+            for r in recs:
+                full = int(r["conn"]) >> 31
+                ch = int(r["channel"])
+                a = cell[full][ch] if ch < 0x80000 else ent[full][ch - 0x80000]
+                packs.append(wire.fanout_message_pack(ch, a))
+            dropped += sum(1 for p in packs if len(p) >= 65530)
+            want, counts = wire.flush_stream(packs)
+            got = data[int(off[s]):int(off[s + 1])].tobytes()
+            assert len(got) == len(want), f"tick {k} slot {s}: {len(got)} bytes vs {len(want)}"
+            assert got == want, f"tick {k} slot {s}: stream bytes"
+            assert int(npk[s]) == len(counts)
+        assert ndropped == dropped
+        total_bytes += nbytes
+        total_packets += npackets
+        total_dropped += ndropped
+    return total_bytes, total_packets, total_dropped
+
+
+@pytest.mark.parametrize("mode", [CONN_MAJOR, CELL_MAJOR])
+def test_wire_streams_small_world(amd, mode):
+    rng = np.random.default_rng(1)
+    tb, tp, td = run_wire(amd, "spatial_static_2x2.json", 300, 24, 6, 0xC0FFEE41, mode,
+                          upd_len=lambda: rng.integers(0, 100), full_len=lambda: rng.integers(40, 300))
+    assert tb > 100_000 and tp >= 24 and td == 0
+
+
+def test_wire_many_packets_per_connection(amd):
+    # ~30 KB full states: a first fan-out of a few dozen channels spans many packets
+    rng = np.random.default_rng(2)
+    tb, tp, td = run_wire(amd, "spatial_static_2x2.json", 120, 6, 4, 0xC0FFEE42, CONN_MAJOR, max_full=30000,
+                          upd_len=lambda: rng.integers(10, 90), full_len=lambda: rng.integers(15000, 30000))
+    assert tp > 60 and td == 0
+
+
+def test_wire_oversized_messages_are_dropped_like_send_does(amd):
+    rng = np.random.default_rng(3)
+    tb, tp, td = run_wire(amd, "spatial_static_2x2.json", 40, 4, 3, 0xC0FFEE43, CONN_MAJOR, max_full=66000,
+                          upd_len=lambda: rng.integers(10, 60), full_len=lambda: rng.choice([200, 65600]))
+    assert td > 0
+
+
+def test_wire_benchmark_grid_position_updates(amd):
+    # the minimal position update of SURVEY a14: a 21-byte value inside a 66-byte Any
+    rng = np.random.default_rng(4)
+    tb, tp, td = run_wire(amd, "spatial_static_benchmark.json", 3000, 60, 5, 0xC0FFEE44, CONN_MAJOR,
+                          upd_len=lambda: 66, full_len=lambda: rng.integers(100, 400))
+    assert tb > 1_000_000 and td == 0
