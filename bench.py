@@ -45,6 +45,9 @@ def parse():
     ap.add_argument("--latency-steps", type=int, default=-1, help="extra synchronous ticks for p50/p99 (default min(steps,200))")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU baseline budget (0 = skip)")
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--wire", type=int, default=0, metavar="TICKS",
+                    help="after the timed region, also materialise the wire-format packet streams (SURVEY 8f-1) for TICKS ticks "
+                         "and report their rate (66-byte Any per update: the minimal position update of SURVEY a14)")
     ap.add_argument("--recipients", action="store_true",
                     help="also plan the handover-message recipients every tick (CHD_WORLD_HANDOVER_RECIPIENTS)")
     ap.add_argument("--emit", choices=["auto", "cell-major", "conn-major"], default="auto",
@@ -139,7 +142,7 @@ def main():
     ctl = A.StaticGrid2DSpatialController(device=local_rank)
     err = ctl.LoadConfig(json.dumps(cfg).encode(), strict=False)
     assert err is None, err
-    world = A.SpatialWorld(ctl, N, S, flags={"auto": 0, "conn-major": 1, "cell-major": 2}[args.emit] | (4 if args.recipients else 0))
+    world = A.SpatialWorld(ctl, N, S, flags={"auto": 0, "conn-major": 1, "cell-major": 2}[args.emit] | (4 if args.recipients else 0) | (8 if args.wire else 0))
     world.spawn(None, sw.chan_id, sw.x, sw.z, sw.flags, sw.sender)
     world.add_subscribers(None, sw.sub_conn)
 
@@ -181,6 +184,32 @@ def main():
     # dominant kernel: k_fanout_emit.  achieved = algorithmic bytes per launch / avg launch time
     achieved = float((BYTES_PER_MSG * emit_msgs.mean()) / (emit_us.mean() * 1e-6) / 1e9)
 
+    # ---- optional: wire-format packet streams of a few more ticks (payload materialisation) ----
+    wire_info = None
+    if args.wire:
+        rng = np.random.default_rng(7)
+        upd = [bytes(rng.integers(0, 256, 66, dtype=np.uint8))] * N
+        world.wire_set_payloads(0, np.arange(N), upd)
+        world.wire_set_payloads(1, np.arange(N), [bytes(300)] * N)
+        ncell = ctl.GridCols * ctl.GridRows
+        world.wire_set_payloads(2, 0x10000 + np.arange(ncell), [bytes(40)] * ncell)
+        world.wire_set_payloads(3, 0x10000 + np.arange(ncell), [bytes(200)] * ncell)
+        wb, wt, wp = [], [], []
+        for t in range(W + K - args.wire, W + K):  # replay the last ticks' inputs at later channel times
+            world.tick_device(int(now[W + K - 1]) + (t + 1) * args.tick_ms * 1_000_000, n_updates=N, d_upd_x=d_x.at(t * N * 8),
+                              d_upd_z=d_z.at(t * N * 8), n_queries=S, d_queries=d_q.at(t * S * 128))
+            world.sync()
+            a = time.perf_counter()
+            nbytes, npackets, ndropped = world.wire_build()
+            world.sync()
+            wt.append(time.perf_counter() - a)
+            wb.append(nbytes)
+            wp.append(npackets)
+        wire_info = {"ticks": args.wire, "bytes_per_tick": float(np.mean(wb)), "packets_per_tick": float(np.mean(wp)),
+                     "ms_per_build": 1e3 * float(np.min(wt)), "ms_per_build_all": [round(1e3 * v, 2) for v in wt], "written_GBps": float(wb[int(np.argmin(wt))] / np.min(wt) / 1e9),
+                     "frac_of_hbm_peak": float(wb[int(np.argmin(wt))] / np.min(wt) / 1e9 / HBM_PEAK_GBS),
+                     "payload": "66-byte Any per entity update, 40-byte per spatial channel update"}
+
     # ---- latency phase: one synchronous tick at a time (p50/p99 of the tick) ----
     lat = []
     for t in range(W + K, W + K + L):
@@ -215,6 +244,8 @@ def main():
                      "algorithmic_bytes_per_launch": float(BYTES_PER_MSG * emit_msgs.mean()),
                      "bytes_per_msg": BYTES_PER_MSG, "msgs_per_launch": float(emit_msgs.mean()), "avg_launch_us": float(emit_us.mean())},
     }
+    if wire_info:
+        out["wire"] = wire_info
     if not args.no_cpu and args.cpu_seconds > 0:
         out["cpu_baseline"] = cpu_baseline(cfg, N, S, seed, args.tick_ms, args.aoi_scale, args.cpu_seconds)
     print(json.dumps(out))

@@ -1183,7 +1183,7 @@ int chd_wire_build(chd_ctx *ctx, uint64_t *total_bytes, uint64_t *total_packets,
     if (total > W.wire_cap) {
         if (W.x.bytes) HIPCHK(hipFree(W.x.bytes));
         W.x.bytes = nullptr;
-        W.wire_cap = total + total / 8 + 4096;
+        W.wire_cap = total + total / 2 + 4096;  // head-room: the arena is only re-allocated when a tick outgrows it
         HIPCHK(hipMalloc((void **)&W.x.bytes, W.wire_cap));
     }
     launch_wire_copy(st, d, W.x);

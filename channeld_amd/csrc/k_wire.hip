@@ -130,34 +130,56 @@ void launch_wire_layout(hipStream_t st, WorldDev w, WireDev x) {
     hipLaunchKernelGGL(k_wire_layout, dim3((w.S + 3) / 4), dim3(256), 0, st, w, x);
 }
 
-// byte FIFO into global memory: single bytes until the destination is dword-aligned, dwords after
-struct ByteOut {
-    uint8_t *d;
-    uint64_t acc;
-    uint32_t nacc;
-    __device__ __forceinline__ void drain() {
-        while (nacc && ((uintptr_t)d & 3u)) { *d++ = (uint8_t)acc; acc >>= 8; nacc--; }
-        while (nacc >= 4) { *(uint32_t *)(void *)d = (uint32_t)acc; d += 4; acc >>= 32; nacc -= 4; }
-    }
-    __device__ __forceinline__ void push(uint32_t v, uint32_t nbytes) {  // nbytes in 1..4, upper bytes of v zero
-        acc |= (uint64_t)v << (8 * nacc);
-        nacc += nbytes;
-        drain();
-    }
-    __device__ __forceinline__ void varint(uint32_t v) {
-        while (v >= 0x80u) { push((v & 0x7Fu) | 0x80u, 1); v >>= 7; }
-        push(v, 1);
-    }
-    __device__ __forceinline__ void finish() {
-        while (nacc) { *d++ = (uint8_t)acc; acc >>= 8; nacc--; }
-    }
+// Copy kernel.  A chunk of 64 consecutive records of one subscription segment is a CONTIGUOUS byte
+// range of the connection's stream (~5-6 KB).  Each lane first describes its own message in LDS
+// (start, header bytes incl. a packet tag if it opens a packet, payload pointer/length); then the wave
+// writes the range cooperatively: lane l produces output dwords l, l+64, ... — message found by binary
+// search of the 64 starts — so stores are fully coalesced and payload reads are 4-byte gathers from
+// the L2-resident payload table.  Only the dwords that straddle a message / header boundary (and the
+// unaligned ends of the range) are assembled byte by byte.
+#define WIRE_HDR_MAX 32  // 5 tag + 1+3 + 1+5 + 2 + 1+3 + 1+3 = 25 bytes at most
+
+struct WireChunk {
+    uint32_t start[64];   // message start, relative to the chunk's first byte
+    uint32_t hlen[64];    // header bytes (tag included)
+    uint32_t plen[64];    // payload bytes
+    const uint8_t *pay[64];
+    uint8_t hdr[64][WIRE_HDR_MAX];
 };
+
+__device__ __forceinline__ uint32_t put_varint(uint8_t *h, uint32_t n, uint32_t v) {
+    while (v >= 0x80u) { h[n++] = (uint8_t)((v & 0x7Fu) | 0x80u); v >>= 7; }
+    h[n++] = (uint8_t)v;
+    return n;
+}
+
+// message index owning relative byte position r (messages are sorted, zero-length ones never own a byte)
+__device__ __forceinline__ uint32_t owner_of(const WireChunk &c, uint32_t r) {
+    uint32_t lo = 0, hi = 63;  // last j with start[j] <= r and (hlen+plen) > 0 reaching r
+    while (lo < hi) {
+        const uint32_t mid = (lo + hi + 1) >> 1;
+        if (c.start[mid] <= r) lo = mid; else hi = mid - 1;
+    }
+    // zero-length (dropped / beyond the chunk) entries share the start of their successor: step back over them
+    while (lo > 0 && c.hlen[lo] + c.plen[lo] == 0) lo--;
+    return lo;
+}
+
+__device__ __forceinline__ uint32_t byte_at(const WireChunk &c, uint32_t r) {
+    const uint32_t j = owner_of(c, r);
+    const uint32_t k = r - c.start[j];
+    return k < c.hlen[j] ? c.hdr[j][k] : c.pay[j][k - c.hlen[j]];
+}
+
+typedef uint32_t u32_unaligned __attribute__((aligned(1)));
 
 __global__ void __launch_bounds__(256) k_wire_copy(WorldDev w, WireDev x) {
     __shared__ uint32_t ticket;
+    __shared__ WireChunk chunks[4];
     const uint32_t s = blockIdx.x;
     if (!w.sub_alive[s] || x.conn_woff[s + 1] == x.conn_woff[s]) return;  // (conn_wlen was scanned in place)
     const uint32_t lane = threadIdx.x & 63u;
+    WireChunk &c = chunks[threadIdx.x >> 6];
     const uint32_t cnt = w.pair_cnt[s];
     const size_t pbase = (size_t)s * w.capq;
     const uint64_t rbase = w.rec_ub[s];
@@ -171,30 +193,84 @@ __global__ void __launch_bounds__(256) k_wire_copy(WorldDev w, WireDev x) {
         if (p >= cnt) break;
         const uint32_t n = w.pair_nrec[pbase + p];
         const uint64_t seg = rbase + w.pair_rel[pbase + p];
-        for (uint32_t i = lane; i < n; i += 64) {
-            const uint32_t woff = x.rec_woff[seg + i];
-            if (woff == 0xFFFFFFFFu) continue;  // dropped by the size check of Send
-            const WireMsg m = wire_msg(w, x, w.recs[seg + i], w.rec_pos[seg + i]);
-            const uint32_t tag = x.rec_wtag[seg + i];
-            ByteOut o;
-            o.acc = 0; o.nacc = 0;
-            o.d = stream + woff;
-            if (tag) {  // first entry of a packet: the 5-byte tag sits right before it (connection.go:683-687)
-                const uint32_t plen = tag & 0xFFFFu;
-                o.d -= 5;
-                o.push(67u | (72u << 8) | (((plen >> 8) & 0xFFu) << 16) | ((plen & 0xFFu) << 24), 4);
-                o.push(0u, 1);  // CompressionType_NO_COMPRESSION
+        for (uint32_t i0 = 0; i0 < n; i0 += 64) {
+            const uint32_t i = i0 + lane;
+            // ---- describe this lane's message ----
+            uint32_t begin = 0xFFFFFFFFu, hl = 0, pl = 0;
+            const uint8_t *pay = nullptr;
+            if (i < n) {
+                const uint32_t woff = x.rec_woff[seg + i];
+                if (woff != 0xFFFFFFFFu) {  // not dropped by the size check of Send
+                    const WireMsg m = wire_msg(w, x, w.recs[seg + i], w.rec_pos[seg + i]);
+                    const uint32_t tag = x.rec_wtag[seg + i];
+                    uint8_t *h = c.hdr[lane];
+                    begin = woff;
+                    if (tag) {  // opens a packet: the 5-byte tag sits right before it (connection.go:683-687)
+                        const uint32_t plen = tag & 0xFFFFu;
+                        h[0] = 67; h[1] = 72; h[2] = (uint8_t)(plen >> 8); h[3] = (uint8_t)plen; h[4] = 0;
+                        hl = 5;
+                        begin -= 5;
+                    }
+                    h[hl++] = 0x0A; hl = put_varint(h, hl, m.mp_len);                     // Packet.messages
+                    if (m.chan) { h[hl++] = 0x08; hl = put_varint(h, hl, m.chan); }       // MessagePack.channelId
+                    h[hl++] = 0x20; h[hl++] = 0x08;                                       // MessagePack.msgType = CHANNEL_DATA_UPDATE
+                    h[hl++] = 0x2A; hl = put_varint(h, hl, m.body_len);                   // MessagePack.msgBody
+                    h[hl++] = 0x0A; hl = put_varint(h, hl, m.any_len);                    // ChannelDataUpdateMessage.data
+                    pl = m.any_len;
+                    pay = m.pay;
+                }
             }
-            o.push(0x0Au, 1); o.varint(m.mp_len);                          // Packet.messages
-            if (m.chan) { o.push(0x08u, 1); o.varint(m.chan); }            // MessagePack.channelId
-            o.push(0x20u | (0x08u << 8), 2);                               // MessagePack.msgType = CHANNEL_DATA_UPDATE
-            o.push(0x2Au, 1); o.varint(m.body_len);                        // MessagePack.msgBody
-            o.push(0x0Au, 1); o.varint(m.any_len);                         // ChannelDataUpdateMessage.data
-            const uint32_t *src = (const uint32_t *)(const void *)m.pay;   // payload slots are 16-byte aligned
-            uint32_t k = 0;
-            for (; k + 4 <= m.any_len; k += 4) o.push(src[k >> 2], 4);
-            if (k < m.any_len) o.push(src[k >> 2] & (0xFFFFFFFFu >> (8 * (4 - (m.any_len - k)))), m.any_len - k);
-            o.finish();
+            // chunk range: first byte of the first live message .. end of the last
+            uint32_t lo = begin, hi = begin == 0xFFFFFFFFu ? 0u : begin + hl + pl;
+            for (int d = 32; d >= 1; d >>= 1) {
+                lo = min(lo, (uint32_t)__shfl_xor((int)lo, d));
+                hi = max(hi, (uint32_t)__shfl_xor((int)hi, d));
+            }
+            if (lo == 0xFFFFFFFFu) continue;  // nothing live in this chunk
+            // dead entries take the start of the next live one (so that `start` stays sorted): suffix-min scan
+            uint32_t st = begin;
+            for (int d = 1; d < 64; d <<= 1) {
+                const uint32_t o = __shfl_down(st, d);
+                if (lane + d < 64) st = min(st, o);
+            }
+            if (st == 0xFFFFFFFFu) st = hi;
+            c.start[lane] = st - lo;
+            c.hlen[lane] = hl;
+            c.plen[lane] = pl;
+            c.pay[lane] = pay;
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            // ---- write the range: dword t of the 4-byte-aligned cover goes to lane t % 64 ----
+            uint8_t *dst0 = stream + lo;
+            const uint32_t len = hi - lo;
+            const uint32_t mis = (uint32_t)((uintptr_t)dst0 & 3u);  // bytes of the first dword that precede the range
+            const uint32_t ndw = (mis + len + 3u) >> 2;
+            for (uint32_t t = lane; t < ndw; t += 64) {
+                const int32_t r0 = (int32_t)(t * 4u) - (int32_t)mis;  // relative position of the dword's first byte
+                uint8_t *d = dst0 + r0;
+                if (r0 >= 0 && (uint32_t)r0 + 4u <= len) {
+                    const uint32_t j = owner_of(c, (uint32_t)r0);
+                    const uint32_t k = (uint32_t)r0 - c.start[j];
+                    uint32_t v;
+                    if (k >= c.hlen[j] && k + 4u <= c.hlen[j] + c.plen[j]) {
+                        v = *(const u32_unaligned *)(c.pay[j] + (k - c.hlen[j]));  // payload interior: one 4-byte gather
+                    } else {
+                        v = byte_at(c, (uint32_t)r0) | (byte_at(c, (uint32_t)r0 + 1u) << 8) | (byte_at(c, (uint32_t)r0 + 2u) << 16) |
+                            (byte_at(c, (uint32_t)r0 + 3u) << 24);
+                    }
+                    *(uint32_t *)(void *)d = v;
+                } else {
+                    // an end of the range: only the bytes inside it (neighbouring chunks own the others)
+                    for (int q = 0; q < 4; q++) {
+                        const int32_t r = r0 + q;
+                        if (r >= 0 && (uint32_t)r < len) d[q] = (uint8_t)byte_at(c, (uint32_t)r);
+                    }
+                }
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         }
     }
 }
