@@ -144,7 +144,7 @@ struct WireChunk {
     uint32_t hlen[64];    // header bytes (tag included)
     uint32_t plen[64];    // payload bytes
     const uint8_t *pay[64];
-    uint8_t hdr[64][WIRE_HDR_MAX];
+    __attribute__((aligned(16))) uint8_t hdr[64][WIRE_HDR_MAX];
 };
 
 __device__ __forceinline__ uint32_t put_varint(uint8_t *h, uint32_t n, uint32_t v) {
@@ -165,13 +165,25 @@ __device__ __forceinline__ uint32_t owner_of(const WireChunk &c, uint32_t r) {
     return lo;
 }
 
-__device__ __forceinline__ uint32_t byte_at(const WireChunk &c, uint32_t r) {
-    const uint32_t j = owner_of(c, r);
-    const uint32_t k = r - c.start[j];
+// which message owns relative byte r, and r's offset inside it.  When all 64 messages of the chunk have
+// the same size T (the usual case: same payload type, same channel-id width, no packet tag in the chunk)
+// that is a multiply-high by M = ceil(2^32 / T) — exact for r < 2^32 / T — instead of the search.
+__device__ __forceinline__ void locate(const WireChunk &c, uint32_t r, uint32_t T, uint32_t M, uint32_t &j, uint32_t &k) {
+    if (T) {
+        j = __umulhi(r, M);
+        k = r - j * T;
+    } else {
+        j = owner_of(c, r);
+        k = r - c.start[j];
+    }
+}
+
+__device__ __forceinline__ uint32_t byte_at(const WireChunk &c, uint32_t r, uint32_t T, uint32_t M) {
+    uint32_t j, k;
+    locate(c, r, T, M, j, k);
     return k < c.hlen[j] ? c.hdr[j][k] : c.pay[j][k - c.hlen[j]];
 }
 
-typedef uint32_t u32_unaligned __attribute__((aligned(1)));
 
 __global__ void __launch_bounds__(256) k_wire_copy(WorldDev w, WireDev x) {
     __shared__ uint32_t ticket;
@@ -241,6 +253,12 @@ __global__ void __launch_bounds__(256) k_wire_copy(WorldDev w, WireDev x) {
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            // uniform chunk?  all 64 lanes live, equal sizes
+            const uint32_t mysz = hl + pl;
+            const uint32_t T0 = __shfl(mysz, 0);
+            const bool uniform = __ballot(begin == 0xFFFFFFFFu || mysz != T0) == 0 && T0 != 0;
+            const uint32_t T = uniform ? T0 : 0u;
+            const uint32_t M = uniform ? (uint32_t)((0x100000000ull + T0 - 1u) / T0) : 0u;
             // ---- write the range: dword t of the 4-byte-aligned cover goes to lane t % 64 ----
             uint8_t *dst0 = stream + lo;
             const uint32_t len = hi - lo;
@@ -250,21 +268,34 @@ __global__ void __launch_bounds__(256) k_wire_copy(WorldDev w, WireDev x) {
                 const int32_t r0 = (int32_t)(t * 4u) - (int32_t)mis;  // relative position of the dword's first byte
                 uint8_t *d = dst0 + r0;
                 if (r0 >= 0 && (uint32_t)r0 + 4u <= len) {
-                    const uint32_t j = owner_of(c, (uint32_t)r0);
-                    const uint32_t k = (uint32_t)r0 - c.start[j];
+                    uint32_t j, k;
+                    locate(c, (uint32_t)r0, T, M, j, k);
+                    const uint32_t h = c.hlen[j];
                     uint32_t v;
-                    if (k >= c.hlen[j] && k + 4u <= c.hlen[j] + c.plen[j]) {
-                        v = *(const u32_unaligned *)(c.pay[j] + (k - c.hlen[j]));  // payload interior: one 4-byte gather
+                    if (k >= h && k + 4u <= h + c.plen[j]) {
+                        // payload interior: two aligned dwords of the (16-byte aligned) payload slot, funnel-shifted
+                        const uint32_t o = k - h;
+                        const uint32_t *src = (const uint32_t *)(const void *)(c.pay[j] + (o & ~3u));
+                        const uint32_t a = src[0];
+                        const uint32_t sh = o & 3u;
+                        v = sh ? __builtin_amdgcn_alignbyte(src[1], a, sh) : a;
+                    } else if (k + 4u <= h) {
+                        // header interior: two aligned dwords of the lane's 32-byte header row in LDS, funnel-shifted
+                        const uint32_t *hs = (const uint32_t *)(const void *)(c.hdr[j] + (k & ~3u));
+                        const uint32_t sh = k & 3u;
+                        v = sh ? __builtin_amdgcn_alignbyte(hs[1], hs[0], sh) : hs[0];
                     } else {
-                        v = byte_at(c, (uint32_t)r0) | (byte_at(c, (uint32_t)r0 + 1u) << 8) | (byte_at(c, (uint32_t)r0 + 2u) << 16) |
-                            (byte_at(c, (uint32_t)r0 + 3u) << 24);
+                        // straddles header/payload or two messages: byte by byte (two such dwords per message)
+                        const uint32_t r = (uint32_t)r0;
+                        v = byte_at(c, r, T, M) | (byte_at(c, r + 1u, T, M) << 8) | (byte_at(c, r + 2u, T, M) << 16) |
+                            (byte_at(c, r + 3u, T, M) << 24);
                     }
                     *(uint32_t *)(void *)d = v;
                 } else {
                     // an end of the range: only the bytes inside it (neighbouring chunks own the others)
                     for (int q = 0; q < 4; q++) {
                         const int32_t r = r0 + q;
-                        if (r >= 0 && (uint32_t)r < len) d[q] = (uint8_t)byte_at(c, (uint32_t)r);
+                        if (r >= 0 && (uint32_t)r < len) d[q] = (uint8_t)byte_at(c, (uint32_t)r, T, M);
                     }
                 }
             }
