@@ -520,6 +520,9 @@ int chd_world_create(chd_ctx *ctx, const chd_world_cfg *cfg) {
     TRY(walloc(ctx, &d.cell_usender, C));
     TRY(walloc(ctx, &d.blk_smin, C * d.nblk + 1));
     TRY(walloc(ctx, &d.blk_smax, C * d.nblk + 1));
+    TRY(walloc(ctx, &d.blk_hand, C * d.nblk + 1));
+    TRY(walloc(ctx, &d.cell_hand, C));
+    TRY(walloc(ctx, &d.ce_chan, N + 8));
     TRY(walloc(ctx, &d.cell_off, C + 1));
     TRY(walloc(ctx, &d.cell_tot, C));
     TRY(walloc(ctx, &d.cell_ref, C));
@@ -552,6 +555,7 @@ int chd_world_create(chd_ctx *ctx, const chd_world_cfg *cfg) {
     TRY(walloc(ctx, &d.free_top, 1));
     d.ce_view = d.ce;
     d.ce8_view = d.ce8;
+    d.ce_chan_view = d.ce_chan;
     d.ce_sprev_view = d.ce_sprev;
     d.ce_sprev_stride = 0;
     d.cell_start = d.cell_off;
@@ -748,6 +752,7 @@ static int tick_locked(chd_ctx *ctx, const chd_tick_in *in) {
     TickRing &r = ctx->ring;
     d.ce_view = d.ce;
     d.ce8_view = d.ce8;
+    d.ce_chan_view = d.ce_chan;
     d.ce_sprev_view = d.ce_sprev;
     d.ce_sprev_stride = 0;
     d.cell_start = d.cell_off;
@@ -1074,6 +1079,7 @@ int chd_shard_fanout(chd_ctx *ctx, const void *d_tables, uint32_t world, const c
     launch_cell_table(st, ctx->g, d, d_tables, world, shard_table_bytes(ctx));
     d.ce_view = (const uint4 *)d_tables;
     d.ce8_view = nullptr;  // gathered tables carry the 16-byte entries only
+    d.ce_chan_view = nullptr;
     d.ce_sprev_view = nullptr;
     d.ce_sprev_stride = (uint32_t)(shard_table_bytes(ctx) / sizeof(uint4));
     d.cell_start = d.cell_tab;

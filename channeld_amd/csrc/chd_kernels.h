@@ -48,7 +48,10 @@ struct WorldDev {
     uint32_t *ce_sprev;   // [N] previous sender (read only where its history intersects a window)
     uint2 *ce8;           // [N] compact entries {entity channel id, history of any sender} for single-sender cells
     uint32_t *cell_usender;           // [ncell] the one sender of the cell's buffered updates, or CHD_NONUNIFORM
-    uint32_t *blk_smin, *blk_smax;    // [ncell*nblk] per-block sender range (index build intermediate)
+    uint32_t *blk_smin, *blk_smax, *blk_hand;  // [ncell*nblk] per-block sender range / AND of histories (index build intermediates)
+    uint32_t *cell_hand;              // [ncell] AND of the histories of the cell's entities (aligned to this tick)
+    uint32_t *ce_chan;                // [N + 4] the entity channel ids alone, cell-sorted: what an all-pass window copies
+    const uint32_t *ce_chan_view;     // nullptr where not available (gathered tables)
     const uint2 *ce8_view;            // nullptr where compact entries are not available (gathered tables)
     uint32_t *cell_off;   // [ncell+1] cell c owns ce[cell_off[c], cell_off[c+1])
     uint32_t *cell_tot;   // [ncell] entities per cell (intermediate of the index build)

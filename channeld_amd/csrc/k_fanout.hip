@@ -345,13 +345,52 @@ __device__ __forceinline__ uint32_t emit_cell8(const uint2 *__restrict__ ce8, ui
     return n_out;
 }
 
+// Every entity of the cell passes the window (the AND of their histories intersects it and the cell has
+// one sender that is not this connection — or this is the full state): no per-entry test, no ballot.
+// A lane copies FOUR adjacent channel ids per step (one 16-byte load) into four records (two 16-byte
+// stores): ~15 instructions per 256 records instead of ~250, and exactly the algorithmic 12 bytes per
+// message of traffic.
+__device__ __forceinline__ uint32_t emit_cell_all(const uint32_t *__restrict__ chans, uint32_t start, uint32_t end,
+                                                  uint32_t conn_tag, chd_fanout_rec *__restrict__ out,
+                                                  uint32_t *__restrict__ opos, uint32_t n_out) {
+    const uint32_t lane = lane_id();
+    const uint32_t n = end - start;
+    // (batching several steps' loads before the first store measured slower on MI355X: 219 vs 198 us per launch)
+    for (uint32_t b = 0; b < n; b += 256) {
+        const uint32_t k = b + 4 * lane;      // this lane's first entry of the step, relative to start
+        if (k + 4 <= n) {
+            const u32x4 c4 = *(const u32x4 *)(const void *)(chans + start + k);
+            u32x4 r0, r1;
+            r0.x = conn_tag; r0.y = c4.x; r0.z = conn_tag; r0.w = c4.y;
+            r1.x = conn_tag; r1.y = c4.z; r1.z = conn_tag; r1.w = c4.w;
+            u32x4 *o = (u32x4 *)(void *)(out + n_out + k);
+            o[0] = r0;
+            o[1] = r1;
+            if (opos) {
+                u32x4 p4;
+                p4.x = start + k; p4.y = start + k + 1; p4.z = start + k + 2; p4.w = start + k + 3;
+                *(u32x4 *)(void *)(opos + n_out + k) = p4;
+            }
+        } else {
+            for (uint32_t q = k; q < n && q < k + 4; q++) {
+                chd_fanout_rec r;
+                r.conn = conn_tag;
+                r.channel = chans[start + q];
+                out[n_out + q] = r;
+                if (opos) opos[n_out + q] = start + q;
+            }
+        }
+    }
+    return n_out + n;
+}
+
 #define FO_TILE 256  // subscriptions staged in LDS per round (= workgroup size)
 
 __global__ void __launch_bounds__(64 * FO_WAVES) k_fanout_emit(DevGrid g, WorldDev w, int64_t now, TickRing ring) {
     // due subscriptions of this connection, staged once per workgroup so that the
     // streaming waves never wait on per-subscription pointer chasing
     __shared__ uint32_t d_p[FO_TILE], d_fl[FO_TILE], d_c[FO_TILE], d_start[FO_TILE], d_end[FO_TILE], d_rel[FO_TILE],
-        d_chh[FO_TILE], d_chs[FO_TILE], d_iv[FO_TILE], d_chhp[FO_TILE], d_chsp[FO_TILE], d_us[FO_TILE];
+        d_chh[FO_TILE], d_chs[FO_TILE], d_iv[FO_TILE], d_chhp[FO_TILE], d_chsp[FO_TILE], d_us[FO_TILE], d_hand[FO_TILE];
     __shared__ int64_t d_L[FO_TILE];
     __shared__ uint32_t n_due, ticket;
     __shared__ uint32_t wave_total[FO_WAVES];
@@ -404,6 +443,7 @@ __global__ void __launch_bounds__(64 * FO_WAVES) k_fanout_emit(DevGrid g, WorldD
                     d_chhp[k] = age < CHD_HIST_BITS ? (w.cell_hist_prev[c] << age) : 0u;
                     d_chsp[k] = w.cell_sender_prev[c];
                     d_us[k] = w.ce8_view ? w.cell_usender[c] : CHD_NONUNIFORM;
+                    d_hand[k] = w.ce_chan_view ? w.cell_hand[c] : 0u;
                 } else {
                     w.pair_nrec[pbase + p] = 0;
                 }
@@ -438,8 +478,8 @@ __global__ void __launch_bounds__(64 * FO_WAVES) k_fanout_emit(DevGrid g, WorldD
                     out[0] = r;
                     if (opos) opos[0] = CHD_POS_CELL | c;
                 }
-                n_out = w.ce8_view ? emit_cell8<true>(w.ce8_view, start, end, 0u, conn | CHD_REC_FULL, out, opos, 1u)
-                                   : emit_cell<true>(w, ce, start, end, 0u, false, conn, conn | CHD_REC_FULL, out, opos, 1u);
+                n_out = w.ce_chan_view ? emit_cell_all(w.ce_chan_view, start, end, conn | CHD_REC_FULL, out, opos, 1u)
+                                       : emit_cell<true>(w, ce, start, end, 0u, false, conn, conn | CHD_REC_FULL, out, opos, 1u);
                 fl |= PF_HAD_FIRST;
                 L = now;
             }
@@ -465,7 +505,9 @@ __global__ void __launch_bounds__(64 * FO_WAVES) k_fanout_emit(DevGrid g, WorldD
                             n_out += 1;
                         }
                         if (us == CHD_NONUNIFORM) n_out = emit_cell<false>(w, ce, start, end, wm, skip_self, conn, conn, out, opos, n_out);
-                        else if (!(skip_self && us == conn)) n_out = emit_cell8<false>(w.ce8_view, start, end, wm, conn, out, opos, n_out);
+                        else if (!(skip_self && us == conn))
+                            n_out = (d_hand[k] & wm) ? emit_cell_all(w.ce_chan_view, start, end, conn, out, opos, n_out)
+                                                     : emit_cell8<false>(w.ce8_view, start, end, wm, conn, out, opos, n_out);
                     }
                     L = next;
                 }

@@ -31,8 +31,9 @@ __global__ void __launch_bounds__(IDX_BLOCK) k_index_hist(WorldDev w, uint32_t n
     uint32_t *h = (uint32_t *)smem;
     // per cell also the range of sender ids whose updates are still buffered: a cell whose entities all
     // have ONE sender lets the emit kernel stream 8-byte entries and test the sender once per subscription
-    uint32_t *smin = h + ncell, *smax = h + 2 * ncell;
-    for (uint32_t c = threadIdx.x; c < ncell; c += IDX_BLOCK) { h[c] = 0; smin[c] = 0xFFFFFFFFu; smax[c] = 0; }
+    // ... and the AND of the entities' update histories: a window that intersects it is hit by EVERY entity of the cell
+    uint32_t *smin = h + ncell, *smax = h + 2 * ncell, *hand = h + 3 * ncell;
+    for (uint32_t c = threadIdx.x; c < ncell; c += IDX_BLOCK) { h[c] = 0; smin[c] = 0xFFFFFFFFu; smax[c] = 0; hand[c] = 0xFFFFFFFFu; }
     __syncthreads();
     uint32_t base = blockIdx.x * IDX_TILE;
 #pragma unroll
@@ -47,7 +48,10 @@ __global__ void __launch_bounds__(IDX_BLOCK) k_index_hist(WorldDev w, uint32_t n
                 atomicMin(&smin[m], snd);
                 atomicMax(&smax[m], snd);
                 const uint32_t age = cur_tick - w.hist_tick[i];
-                if (age < CHD_HIST_BITS && (w.hist_prev[i] << age) != 0) {
+                const uint32_t hp = age < CHD_HIST_BITS ? (w.hist_prev[i] << age) : 0u;
+                const uint32_t hc = age < CHD_HIST_BITS ? (w.hist[i] << age) : 0u;
+                atomicAnd(&hand[m], hc | hp);
+                if (hp != 0) {
                     const uint32_t sp = w.sender_prev[i];
                     atomicMin(&smin[m], sp);
                     atomicMax(&smax[m], sp);
@@ -61,6 +65,7 @@ __global__ void __launch_bounds__(IDX_BLOCK) k_index_hist(WorldDev w, uint32_t n
         w.blk_cnt[k] = h[c];
         w.blk_smin[k] = smin[c];
         w.blk_smax[k] = smax[c];
+        w.blk_hand[k] = hand[c];
     }
 }
 
@@ -78,7 +83,7 @@ __global__ void __launch_bounds__(256) k_index_scan(WorldDev w, uint32_t ncell, 
     const uint32_t c = blockIdx.x * 4u + wave;
     if (c < ncell) {
         uint32_t *row = w.blk_cnt + (size_t)c * w.nblk;
-        uint32_t carry = 0, lo = 0xFFFFFFFFu, hi = 0;
+        uint32_t carry = 0, lo = 0xFFFFFFFFu, hi = 0, ha = 0xFFFFFFFFu;
         for (uint32_t b0 = 0; b0 < w.nblk; b0 += 64) {
             const uint32_t b = b0 + lane;
             const uint32_t v = b < w.nblk ? row[b] : 0u;
@@ -87,16 +92,19 @@ __global__ void __launch_bounds__(256) k_index_scan(WorldDev w, uint32_t ncell, 
                 row[b] = carry + inc - v;
                 lo = min(lo, w.blk_smin[(size_t)c * w.nblk + b]);
                 hi = max(hi, w.blk_smax[(size_t)c * w.nblk + b]);
+                ha &= w.blk_hand[(size_t)c * w.nblk + b];
             }
             carry += __shfl(inc, 63);
         }
         for (int d = 32; d >= 1; d >>= 1) {
             lo = min(lo, (uint32_t)__shfl_xor((int)lo, d));
             hi = max(hi, (uint32_t)__shfl_xor((int)hi, d));
+            ha &= (uint32_t)__shfl_xor((int)ha, d);
         }
         if (lane == 0) {
             (finalize ? w.cell_off : w.cell_tot)[c] = carry;  // the cell's total
             w.cell_usender[c] = carry == 0 ? 0u : (lo == hi ? lo : CHD_NONUNIFORM);
+            w.cell_hand[c] = carry == 0 ? 0u : ha;
         }
     }
     // small grids: the scatter workgroups scan the few cell totals themselves (no cross-workgroup step)
@@ -217,6 +225,7 @@ __global__ void __launch_bounds__(IDX_BLOCK) k_index_scatter(WorldDev w, uint32_
         uint32_t hp = (age >= CHD_HIST_BITS) ? 0u : (w.hist_prev[i] << age);
         w.ce[pos] = make_uint4(w.chan_id[i], h, w.sender[i], hp);
         w.ce8[pos] = make_uint2(w.chan_id[i], h | hp);
+        w.ce_chan[pos] = w.chan_id[i];
         w.ce_sprev[pos] = w.sender_prev[i];
         if (w.ce_slot) w.ce_slot[pos] = i;
     }
@@ -323,7 +332,7 @@ static uint32_t bits_for(uint32_t ncell) {
 void launch_index_build(hipStream_t st, DevGrid g, WorldDev w, uint32_t cur_tick) {
     if (!w.N) return;
     if (g.ncell <= IDX_MAX_LDS_CELLS) {
-        hipLaunchKernelGGL(k_index_hist, dim3(w.nblk), dim3(IDX_BLOCK), 3 * g.ncell * 4, st, w, g.ncell, cur_tick);
+        hipLaunchKernelGGL(k_index_hist, dim3(w.nblk), dim3(IDX_BLOCK), 4 * g.ncell * 4, st, w, g.ncell, cur_tick);
         const int local_base = g.ncell <= 1024;
         hipLaunchKernelGGL(k_index_scan, dim3((g.ncell + 3) / 4), dim3(256), 0, st, w, g.ncell, !local_base);
         hipLaunchKernelGGL(k_index_scatter, dim3(w.nblk), dim3(IDX_BLOCK), (local_base ? 5 : 4) * g.ncell * 4, st, w,
@@ -333,6 +342,7 @@ void launch_index_build(hipStream_t st, DevGrid g, WorldDev w, uint32_t cur_tick
         uint32_t *cursor = w.blk_cnt + (size_t)g.ncell + 1;
         (void)hipMemsetAsync(w.blk_cnt, 0, sizeof(uint32_t) * (2 * (size_t)g.ncell + 2), st);
         (void)hipMemsetAsync(w.cell_usender, 0xFF, sizeof(uint32_t) * (size_t)g.ncell, st);  // CHD_NONUNIFORM
+        (void)hipMemsetAsync(w.cell_hand, 0, sizeof(uint32_t) * (size_t)g.ncell, st);
         hipLaunchKernelGGL(k_index_hist_global, dim3((w.N + 255) / 256), dim3(256), 0, st, w, g.ncell);
         launch_scan_u32_inplace(st, w.blk_cnt, g.ncell);
         (void)hipMemcpyAsync(w.cell_off, w.blk_cnt, sizeof(uint32_t) * ((size_t)g.ncell + 1), hipMemcpyDeviceToDevice, st);
