@@ -30,6 +30,8 @@ struct World {
     std::vector<void *> allocs;
     chd_fanout_rec *recs_dense = nullptr;
     uint64_t recs_dense_cap = 0;
+    uint32_t *list_dense = nullptr;  // fetch-time staging of the packed unsub / new-sub lists
+    size_t list_dense_cap = 0;
     uint64_t *rec_off_exact = nullptr;  // [S+1]
     uint32_t *newsub_sub = nullptr, *newsub_cell = nullptr, *newsub_iv = nullptr;
     int64_t last_now = INT64_MIN;
@@ -287,6 +289,7 @@ void chd_destroy(chd_ctx *ctx) {
     (void)hipStreamSynchronize(ctx->stream);
     for (void *p : ctx->w.allocs) (void)hipFree(p);
     if (ctx->w.recs_dense) (void)hipFree(ctx->w.recs_dense);
+    if (ctx->w.list_dense) (void)hipFree(ctx->w.list_dense);
     if (ctx->w.x.bytes) (void)hipFree(ctx->w.x.bytes);
     for (auto &b : ctx->scratch)
         if (b.p) (void)hipFree(b.p);
@@ -581,7 +584,11 @@ int chd_world_create(chd_ctx *ctx, const chd_world_cfg *cfg) {
         TRY(walloc(ctx, &W.ho_rcp_conn, W.ho_rcp_cap, false));
         TRY(walloc(ctx, &W.ho_rcp_kind, W.ho_rcp_cap, false));
     }
-    d.unsub_cap = (uint32_t)std::min<size_t>(P, 0x7FFFFFFF);
+    // banked lists: a bank holds the worst case of the subscriber slots that map to it
+    d.list_bank_cap = (uint32_t)std::min<size_t>((size_t)((S + CHD_LIST_BANKS - 1) / CHD_LIST_BANKS) * d.capq, 0x7FFFFFFFu / CHD_LIST_BANKS);
+    d.unsub_cap = d.list_bank_cap * CHD_LIST_BANKS;
+    TRY(walloc(ctx, &d.list_ctr, 2 * CHD_LIST_BANKS * 32));
+    TRY(walloc(ctx, &d.list_bank_n, 2 * CHD_LIST_BANKS));
     TRY(walloc(ctx, &d.unsub_sub, d.unsub_cap, false));
     TRY(walloc(ctx, &d.unsub_cell, d.unsub_cap, false));
     d.newsub_cap = d.unsub_cap;
@@ -796,6 +803,22 @@ int chd_tick_device(chd_ctx *ctx, const chd_tick_in *d_in) {
     return tick_locked(ctx, d_in);
 }
 
+// Banked list (bank b = entries [b*bank_cap, b*bank_cap + bank_n[b])) -> dense, banks in order.  One block per bank.
+__global__ void __launch_bounds__(256) k_list_pack(const uint32_t *bank_n, uint32_t bank_cap, const uint32_t *a,
+                                                   const uint32_t *b, const uint32_t *c, uint32_t *da, uint32_t *db,
+                                                   uint32_t *dc) {
+    const uint32_t bank = blockIdx.x;
+    size_t off = 0;
+    for (uint32_t i = 0; i < bank; i++) off += bank_n[i];
+    const uint32_t n = bank_n[bank];
+    const size_t src = (size_t)bank * bank_cap;
+    for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) {
+        da[off + i] = a[src + i];
+        db[off + i] = b[src + i];
+        if (c) dc[off + i] = c[src + i];
+    }
+}
+
 static int fetch_locked(chd_ctx *ctx, chd_tick_out *out) {
     World &W = ctx->w;
     WorldDev &d = W.d;
@@ -832,19 +855,40 @@ static int fetch_locked(chd_ctx *ctx, chd_tick_out *out) {
         TRY(down(ctx, out->handovers, d.handovers, sizeof(chd_handover_rec) * n));
     }
     if (out->query_status) TRY(down(ctx, out->query_status, d.q_status, sizeof(int32_t) * W.last_nq));
-    if (out->unsub_sub && out->unsub_channel) {
-        uint32_t n = std::min(out->n_unsubs, out->unsub_cap);
-        if (n < out->n_unsubs) { out->overflow |= OVF_UNSUB; rc = CHD_E_CAPACITY; }
-        TRY(down(ctx, out->unsub_sub, d.unsub_sub, 4 * (size_t)n));
-        TRY(down(ctx, out->unsub_channel, d.unsub_cell, 4 * (size_t)n));
-    }
     out->n_newsubs = std::min(ctr[CTR_NEWSUBS], d.newsub_cap);
-    if (out->newsub_sub && out->newsub_channel) {
-        uint32_t n = std::min(out->n_newsubs, out->newsub_cap);
-        if (n < out->n_newsubs) { out->overflow |= OVF_NEWSUB; rc = CHD_E_CAPACITY; }
-        TRY(down(ctx, out->newsub_sub, d.newsub_sub, 4 * (size_t)n));
-        TRY(down(ctx, out->newsub_channel, d.newsub_cell, 4 * (size_t)n));
-        if (out->newsub_interval_ms) TRY(down(ctx, out->newsub_interval_ms, d.newsub_iv, 4 * (size_t)n));
+    const bool want_un = out->unsub_sub && out->unsub_channel && out->n_unsubs;
+    const bool want_new = out->newsub_sub && out->newsub_channel && out->n_newsubs;
+    if (want_un || want_new) {
+        // the device keeps both lists in banks (WorldDev::list_ctr): pack them into dense staging first
+        const size_t nu = want_un ? out->n_unsubs : 0, nn = want_new ? out->n_newsubs : 0, need = 2 * nu + 3 * nn;
+        if (W.list_dense_cap < need) {
+            if (W.list_dense) HIPCHK(hipFree(W.list_dense));
+            W.list_dense = nullptr;
+            W.list_dense_cap = need + need / 4 + 1024;
+            HIPCHK(hipMalloc((void **)&W.list_dense, W.list_dense_cap * sizeof(uint32_t)));
+        }
+        uint32_t *du = W.list_dense, *dn = W.list_dense + 2 * nu;
+        if (want_un)
+            hipLaunchKernelGGL(k_list_pack, dim3(CHD_LIST_BANKS), dim3(256), 0, st, d.list_bank_n, d.list_bank_cap,
+                               (const uint32_t *)d.unsub_sub, (const uint32_t *)d.unsub_cell, (const uint32_t *)nullptr,
+                               du, du + nu, (uint32_t *)nullptr);
+        if (want_new)
+            hipLaunchKernelGGL(k_list_pack, dim3(CHD_LIST_BANKS), dim3(256), 0, st, d.list_bank_n + CHD_LIST_BANKS,
+                               d.list_bank_cap, (const uint32_t *)d.newsub_sub, (const uint32_t *)d.newsub_cell,
+                               (const uint32_t *)d.newsub_iv, dn, dn + nn, dn + 2 * nn);
+        if (want_un) {
+            uint32_t n = std::min(out->n_unsubs, out->unsub_cap);
+            if (n < out->n_unsubs) { out->overflow |= OVF_UNSUB; rc = CHD_E_CAPACITY; }
+            TRY(down(ctx, out->unsub_sub, du, 4 * (size_t)n));
+            TRY(down(ctx, out->unsub_channel, du + nu, 4 * (size_t)n));
+        }
+        if (want_new) {
+            uint32_t n = std::min(out->n_newsubs, out->newsub_cap);
+            if (n < out->n_newsubs) { out->overflow |= OVF_NEWSUB; rc = CHD_E_CAPACITY; }
+            TRY(down(ctx, out->newsub_sub, dn, 4 * (size_t)n));
+            TRY(down(ctx, out->newsub_channel, dn + nn, 4 * (size_t)n));
+            if (out->newsub_interval_ms) TRY(down(ctx, out->newsub_interval_ms, dn + 2 * nn, 4 * (size_t)n));
+        }
     }
     if (out->conn_rec_off) TRY(down(ctx, out->conn_rec_off, W.rec_off_exact, sizeof(uint64_t) * (d.S + 1)));
     if (out->conn_rec_cnt) TRY(down(ctx, out->conn_rec_cnt, d.rec_cnt, sizeof(uint32_t) * d.S));

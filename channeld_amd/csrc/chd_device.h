@@ -28,10 +28,12 @@
 #define EF_ALIVE 0x80000000u
 
 // device counters (one uint32 each unless noted), zeroed every tick
+#define CHD_LIST_BANKS 64u
+
 enum {
     CTR_HANDOVERS = 0,
     CTR_LOCKED = 1,
-    CTR_UNSUBS = 2,
+    CTR_UNSUBS = 2,   // (fetch-side index only: the device keeps per-bank tails, WorldDev::list_ctr)
     CTR_OVERFLOW = 3,
     CTR_HIST_OVERFLOW = 4,
     CTR_PAIRS = 5,
@@ -116,9 +118,13 @@ __device__ __forceinline__ uint32_t go_uint_ceil(double d) {
 
 // getSpatialDampingSettings + nil branch (message_spatial.go:31-38,66-79)
 __device__ __forceinline__ uint32_t damping_interval(const DevGrid &g, uint32_t dist) {
-    for (uint32_t i = 0; i < g.n_damp; i++)
-        if (dist <= g.damp_dist[i]) return g.damp_iv[i];
-    return g.default_interval_ms;
+    // first matching entry wins; written as a fully unrolled reverse select so that every table read has a
+    // constant index (scalar kernarg loads, once per kernel) instead of a per-lane load from the kernarg segment
+    uint32_t iv = g.default_interval_ms;
+#pragma unroll
+    for (int i = CHD_MAX_DAMPING - 1; i >= 0; i--)
+        iv = ((uint32_t)i < g.n_damp && dist <= g.damp_dist[i]) ? g.damp_iv[i] : iv;
+    return iv;
 }
 
 __device__ __forceinline__ uint32_t lane_id() { return threadIdx.x & 63u; }

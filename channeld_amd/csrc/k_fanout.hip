@@ -1019,6 +1019,7 @@ void launch_fanout_emit(hipStream_t st, DevGrid g, WorldDev w, int64_t now_ns, T
 
 // Per-tick totals into the device-side history ring (read back by chd_tick_fetch /
 // chd_get_tick_history), then the per-tick counters are cleared for the next tick.
+static_assert(CHD_LIST_BANKS == 64, "one epilogue lane per list bank");
 __global__ void __launch_bounds__(64) k_tick_epilogue(WorldDev w, uint32_t slot) {
     const uint32_t lane = threadIdx.x;
     unsigned long long sum = w.tot64[(size_t)lane * 16], pairs = w.tot64[(size_t)lane * 16 + 1];
@@ -1026,14 +1027,26 @@ __global__ void __launch_bounds__(64) k_tick_epilogue(WorldDev w, uint32_t slot)
         sum += __shfl_xor(sum, d);
         pairs += __shfl_xor(pairs, d);
     }
+    // unsub / new-sub bank tails: totals for the ring, per-bank counts kept for chd_tick_fetch
+    uint32_t un = w.list_ctr[lane * 32u], nn = w.list_ctr[(CHD_LIST_BANKS + lane) * 32u];
+    un = un < w.list_bank_cap ? un : w.list_bank_cap;
+    nn = nn < w.list_bank_cap ? nn : w.list_bank_cap;
+    w.list_bank_n[lane] = un;
+    w.list_bank_n[CHD_LIST_BANKS + lane] = nn;
+    w.list_ctr[lane * 32u] = 0;
+    w.list_ctr[(CHD_LIST_BANKS + lane) * 32u] = 0;
+    for (int d = 32; d >= 1; d >>= 1) {
+        un += __shfl_xor(un, d);
+        nn += __shfl_xor(nn, d);
+    }
     if (lane == 0) {
         uint64_t *r = w.tick_ring + (size_t)slot * 8;
         r[0] = sum;
         r[1] = w.rec_ub[w.S];
         r[2] = w.counters[CTR_HANDOVERS];
         r[3] = w.counters[CTR_LOCKED];
-        r[4] = w.counters[CTR_UNSUBS];
-        r[5] = w.counters[CTR_NEWSUBS];
+        r[4] = un;
+        r[5] = nn;
         r[6] = pairs;
         r[7] = (uint64_t)w.counters[CTR_OVERFLOW] |
                ((uint64_t)(w.counters[CTR_HIST_OVERFLOW] + w.counters[CTR_SENDER_OVERFLOW]) << 32);
