@@ -48,6 +48,8 @@ def parse():
     ap.add_argument("--wire", type=int, default=0, metavar="TICKS",
                     help="after the timed region, also materialise the wire-format packet streams (SURVEY 8f-1) for TICKS ticks "
                          "and report their rate (66-byte Any per update: the minimal position update of SURVEY a14)")
+    ap.add_argument("--overlap-interest", action="store_true",
+                    help="run the interest updates on a second stream beside ingest + index (CHD_WORLD_OVERLAP_INTEREST)")
     ap.add_argument("--recipients", action="store_true",
                     help="also plan the handover-message recipients every tick (CHD_WORLD_HANDOVER_RECIPIENTS)")
     ap.add_argument("--emit", choices=["auto", "cell-major", "conn-major"], default="auto",
@@ -142,7 +144,7 @@ def main():
     ctl = A.StaticGrid2DSpatialController(device=local_rank)
     err = ctl.LoadConfig(json.dumps(cfg).encode(), strict=False)
     assert err is None, err
-    world = A.SpatialWorld(ctl, N, S, flags={"auto": 0, "conn-major": 1, "cell-major": 2}[args.emit] | (4 if args.recipients else 0) | (8 if args.wire else 0))
+    world = A.SpatialWorld(ctl, N, S, flags={"auto": 0, "conn-major": 1, "cell-major": 2}[args.emit] | (4 if args.recipients else 0) | (8 if args.wire else 0) | (16 if args.overlap_interest else 0))
     world.spawn(None, sw.chan_id, sw.x, sw.z, sw.flags, sw.sender)
     world.add_subscribers(None, sw.sub_conn)
 

@@ -22,6 +22,7 @@ WORLD_CONN_MAJOR_EMIT = 1
 WORLD_CELL_MAJOR_EMIT = 2
 WORLD_HANDOVER_RECIPIENTS = 4
 WORLD_WIRE = 8
+WORLD_OVERLAP_INTEREST = 16
 WIRE_ENTITY_UPDATE, WIRE_ENTITY_FULL, WIRE_CELL_UPDATE, WIRE_CELL_FULL = 0, 1, 2, 3
 HO_SRC_ONLY, HO_DST_NEW, HO_DST_KNOWN = 0, 1, 2
 BROADCAST_ALL_BUT_SENDER, BROADCAST_ALL_BUT_OWNER, BROADCAST_ALL_BUT_CLIENT, BROADCAST_ALL_BUT_SERVER = 4, 8, 16, 32

@@ -43,6 +43,7 @@ struct World {
     uint64_t wire_cap = 0;             // bytes allocated for x.bytes
     bool wire_built = false;
     bool plan_recipients = false;      // CHD_WORLD_HANDOVER_RECIPIENTS
+    bool overlap_interest = false;     // CHD_WORLD_OVERLAP_INTEREST
     uint32_t *ho_rcp_off = nullptr;    // [handovers_cap + 1] recipients of handover h: [off[h], off[h+1])
     uint32_t *ho_rcp_conn = nullptr;   // connection ids
     uint8_t *ho_rcp_kind = nullptr;    // CHD_HO_*
@@ -51,10 +52,14 @@ struct World {
 
 }  // namespace
 
+#define EV_PER_TICK (CHD_N_STAGES + 3)
+
 struct chd_ctx {
     int device = 0;
     hipStream_t stream = nullptr;      // where work is enqueued (own_stream unless chd_set_stream)
     hipStream_t own_stream = nullptr;
+    hipStream_t aux_stream = nullptr;   // interest updates run here, beside ingest + index build on `stream`
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     chd_grid_cfg cfg{};
     DevGrid g{};
     AoiLimits lim{};
@@ -65,7 +70,8 @@ struct chd_ctx {
     // scratch for the stateless entry points and for chd_tick's staging
     DevBuf scratch[16];
     int prof_depth = 0;                 // 0 = off
-    std::vector<hipEvent_t> ev;         // [prof_depth][CHD_N_STAGES + 1]
+    std::vector<hipEvent_t> ev;         // [prof_depth][EV_PER_TICK]: stage boundaries on `stream`, then interest begin/end
+    std::vector<uint8_t> ev_overlap;    // [prof_depth] the slot's tick ran the interest stage on aux_stream
     chd_tick_stats stats{};
 };
 
@@ -231,6 +237,13 @@ int chd_create(const chd_grid_cfg *cfg, int device, chd_ctx **out) {
         return fail(nullptr, CHD_E_HIP, "cannot create a stream on device %d", device);
     }
     ctx->stream = ctx->own_stream;
+    if (hipStreamCreateWithFlags(&ctx->aux_stream, hipStreamNonBlocking) != hipSuccess ||
+        hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&ctx->ev_join, hipEventDisableTiming) != hipSuccess) {
+        (void)hipStreamDestroy(ctx->own_stream);
+        delete ctx;
+        return fail(nullptr, CHD_E_HIP, "cannot create the second stream on device %d", device);
+    }
     DevGrid &g = ctx->g;
     g.gw = cfg->grid_width;
     g.gh = cfg->grid_height;
@@ -294,6 +307,9 @@ void chd_destroy(chd_ctx *ctx) {
     for (auto &b : ctx->scratch)
         if (b.p) (void)hipFree(b.p);
     for (auto &e : ctx->ev) (void)hipEventDestroy(e);
+    (void)hipEventDestroy(ctx->ev_fork);
+    (void)hipEventDestroy(ctx->ev_join);
+    (void)hipStreamDestroy(ctx->aux_stream);
     (void)hipStreamDestroy(ctx->own_stream);
     delete ctx;
 }
@@ -548,6 +564,7 @@ int chd_world_create(chd_ctx *ctx, const chd_world_cfg *cfg) {
     if (d.wb) TRY(walloc(ctx, &d.sub_bits, S * d.wb));
     if (d.cm_emit) TRY(walloc(ctx, &d.items, n_items_max, false));
     W.plan_recipients = (cfg->flags & CHD_WORLD_HANDOVER_RECIPIENTS) != 0;
+    W.overlap_interest = (cfg->flags & CHD_WORLD_OVERLAP_INTEREST) != 0;
     {
         hipDeviceProp_t prop;
         HIPCHK(hipGetDeviceProperties(&prop, ctx->device));
@@ -766,8 +783,25 @@ static int tick_locked(chd_ctx *ctx, const chd_tick_in *in) {
     d.cell_end = d.cell_off + 1;
     hipStream_t st = ctx->stream;
     const bool prof = ctx->prof_depth > 0;
-    hipEvent_t *ev = prof ? &ctx->ev[(size_t)(r.cur_tick % (uint32_t)ctx->prof_depth) * (CHD_N_STAGES + 1)] : nullptr;
-    if (prof) HIPCHK(hipEventRecord(ev[0], st));
+    hipEvent_t *ev = prof ? &ctx->ev[(size_t)(r.cur_tick % (uint32_t)ctx->prof_depth) * EV_PER_TICK] : nullptr;
+    // CHD_WORLD_OVERLAP_INTEREST: the interest updates touch subscriptions only, ingest + index build entities
+    // only, so the two can run side by side on two streams and join before the fan-out plan.  (Not with handover
+    // recipients: those are planned on the subscriptions as they were BEFORE this tick's interest updates.)
+    const bool overlap = W.overlap_interest && !W.plan_recipients && in->n_queries > 0;
+    if (prof) {
+        ctx->ev_overlap[r.cur_tick % (uint32_t)ctx->prof_depth] = overlap;
+        HIPCHK(hipEventRecord(ev[0], st));
+    }
+    if (overlap) {
+        hipStream_t ax = ctx->aux_stream;
+        HIPCHK(hipEventRecord(ctx->ev_fork, st));
+        HIPCHK(hipStreamWaitEvent(ax, ctx->ev_fork, 0));
+        if (prof) HIPCHK(hipEventRecord(ev[CHD_N_STAGES + 1], ax));
+        launch_aoi_interest(ax, ctx->g, ctx->lim, d, in->queries, in->n_queries, in->query_sub, in->spot_x, in->spot_z,
+                            in->spot_dist, in->now_ns, r.cur_tick);
+        if (prof) HIPCHK(hipEventRecord(ev[CHD_N_STAGES + 2], ax));
+        HIPCHK(hipEventRecord(ctx->ev_join, ax));
+    }
     launch_ingest(st, ctx->g, d, in->n_updates, in->upd_idx, in->upd_x, in->upd_z, in->upd_sender, r.cur_tick);
     launch_cell_updates(st, ctx->g, d, in->n_cell_updates, in->cell_upd_channel, in->cell_upd_sender, r.cur_tick);
     if (W.plan_recipients) {
@@ -780,8 +814,10 @@ static int tick_locked(chd_ctx *ctx, const chd_tick_in *in) {
     if (prof) HIPCHK(hipEventRecord(ev[1], st));
     launch_index_build(st, ctx->g, d, r.cur_tick);
     if (prof) HIPCHK(hipEventRecord(ev[2], st));
-    launch_aoi_interest(st, ctx->g, ctx->lim, d, in->queries, in->n_queries, in->query_sub, in->spot_x, in->spot_z,
-                        in->spot_dist, in->now_ns, r.cur_tick);
+    if (overlap) HIPCHK(hipStreamWaitEvent(st, ctx->ev_join, 0));
+    else
+        launch_aoi_interest(st, ctx->g, ctx->lim, d, in->queries, in->n_queries, in->query_sub, in->spot_x, in->spot_z,
+                            in->spot_dist, in->now_ns, r.cur_tick);
     if (prof) HIPCHK(hipEventRecord(ev[3], st));
     launch_fanout_plan(st, ctx->g, d, in->now_ns, r);
     if (prof) HIPCHK(hipEventRecord(ev[4], st));
@@ -817,6 +853,26 @@ __global__ void __launch_bounds__(256) k_list_pack(const uint32_t *bank_n, uint3
         db[off + i] = b[src + i];
         if (c) dc[off + i] = c[src + i];
     }
+}
+
+// Stage times of one profiled tick.  With the interest stage on the second stream its time is its own
+// begin/end pair; the tick total is always first-to-last event on the main stream.
+static void stage_times(chd_ctx *ctx, uint32_t tick, chd_tick_stats &s) {
+    const uint32_t slot = tick % (uint32_t)ctx->prof_depth;
+    hipEvent_t *ev = &ctx->ev[(size_t)slot * EV_PER_TICK];
+    for (int k = 0; k < CHD_N_STAGES; k++) {
+        float ms = 0;
+        (void)hipEventElapsedTime(&ms, ev[k], ev[k + 1]);
+        s.stage_us[k] = ms * 1000.f;
+    }
+    if (ctx->ev_overlap[slot]) {
+        float ms = 0;
+        (void)hipEventElapsedTime(&ms, ev[CHD_N_STAGES + 1], ev[CHD_N_STAGES + 2]);
+        s.stage_us[2] = ms * 1000.f;
+    }
+    float ms = 0;
+    (void)hipEventElapsedTime(&ms, ev[0], ev[CHD_N_STAGES]);
+    s.total_us = ms * 1000.f;
 }
 
 static int fetch_locked(chd_ctx *ctx, chd_tick_out *out) {
@@ -919,17 +975,7 @@ static int fetch_locked(chd_ctx *ctx, chd_tick_out *out) {
     s.n_handovers = out->n_handovers;
     s.n_unsubs = out->n_unsubs;
     s.n_pairs = ctr[CTR_PAIRS];
-    if (ctx->prof_depth > 0) {
-        hipEvent_t *ev = &ctx->ev[(size_t)(ctx->ring.cur_tick % (uint32_t)ctx->prof_depth) * (CHD_N_STAGES + 1)];
-        float tot = 0;
-        for (int k = 0; k < CHD_N_STAGES; k++) {
-            float ms = 0;
-            (void)hipEventElapsedTime(&ms, ev[k], ev[k + 1]);
-            s.stage_us[k] = ms * 1000.f;
-            tot += ms * 1000.f;
-        }
-        s.total_us = tot;
-    }
+    if (ctx->prof_depth > 0) stage_times(ctx, ctx->ring.cur_tick, s);
     if (rc == CHD_E_CAPACITY) return fail(ctx, rc, "tick output truncated (overflow mask 0x%x)", out->overflow);
     return rc;
 }
@@ -1118,8 +1164,11 @@ int chd_shard_fanout(chd_ctx *ctx, const void *d_tables, uint32_t world, const c
     const int64_t now = W.last_now;
     // stage events: ingest/index ran in the earlier phases (their slots read 0 here)
     const bool prof = ctx->prof_depth > 0;
-    hipEvent_t *ev = prof ? &ctx->ev[(size_t)(r.cur_tick % (uint32_t)ctx->prof_depth) * (CHD_N_STAGES + 1)] : nullptr;
-    if (prof) for (int k = 0; k <= 2; k++) HIPCHK(hipEventRecord(ev[k], st));
+    hipEvent_t *ev = prof ? &ctx->ev[(size_t)(r.cur_tick % (uint32_t)ctx->prof_depth) * EV_PER_TICK] : nullptr;
+    if (prof) {
+        ctx->ev_overlap[r.cur_tick % (uint32_t)ctx->prof_depth] = 0;
+        for (int k = 0; k <= 2; k++) HIPCHK(hipEventRecord(ev[k], st));
+    }
     launch_cell_table(st, ctx->g, d, d_tables, world, shard_table_bytes(ctx));
     d.ce_view = (const uint4 *)d_tables;
     d.ce8_view = nullptr;  // gathered tables carry the 16-byte entries only
@@ -1424,7 +1473,8 @@ int chd_set_profiling(chd_ctx *ctx, int depth) {
     ctx->ev.clear();
     ctx->prof_depth = 0;
     if (depth > 0) {
-        ctx->ev.resize((size_t)depth * (CHD_N_STAGES + 1));
+        ctx->ev.resize((size_t)depth * EV_PER_TICK);
+        ctx->ev_overlap.assign((size_t)depth, 0);
         for (auto &e : ctx->ev) HIPCHK(hipEventCreate(&e));
         // record every event once so that elapsed-time queries on unused slots are defined
         for (auto &e : ctx->ev) HIPCHK(hipEventRecord(e, ctx->stream));
@@ -1455,17 +1505,7 @@ int chd_get_tick_history(chd_ctx *ctx, uint32_t n, chd_tick_stats *out) {
         s.n_unsubs = (uint32_t)r[4];
         s.n_pairs = (uint32_t)r[6];
         s.algorithmic_bytes = 12ull * s.n_records + 32ull * s.n_handovers;
-        if (ctx->prof_depth > 0 && k < (uint32_t)ctx->prof_depth) {
-            hipEvent_t *ev = &ctx->ev[(size_t)(tick % (uint32_t)ctx->prof_depth) * (CHD_N_STAGES + 1)];
-            float tot = 0;
-            for (int j = 0; j < CHD_N_STAGES; j++) {
-                float ms = 0;
-                (void)hipEventElapsedTime(&ms, ev[j], ev[j + 1]);
-                s.stage_us[j] = ms * 1000.f;
-                tot += ms * 1000.f;
-            }
-            s.total_us = tot;
-        }
+        if (ctx->prof_depth > 0 && k < (uint32_t)ctx->prof_depth) stage_times(ctx, tick, s);
     }
     return CHD_OK;
 }

@@ -47,6 +47,7 @@ enum {
 #define OVF_UNSUB 2u
 #define OVF_RECORDS 4u
 #define OVF_NEWSUB 8u
+#define OVF_INTERNAL 0x8000u  // a kernel's defensive loop bound tripped (a bug, never a capacity)
 #define OVF_SLOTS 16u    // sharded world: no free entity slot for a spawn / an immigrant
 #define OVF_MIGRATE 32u  // sharded world: an emigrant did not fit its destination's send segment
 

@@ -40,7 +40,12 @@
 
 #define FO_WAVES 4
 #define CHD_SEG_ALIGN 16u  // records: 16 x 8 B = one 128-byte line
-#define FO_UNROLL 8
+#ifndef FO_UNROLL
+#define FO_UNROLL 4
+#endif
+#ifndef FO_UNROLL8
+#define FO_UNROLL8 2
+#endif
 
 // stamp of ring slot `lane` (INT64_MAX for unused slots): loaded once per wave
 __device__ __forceinline__ int64_t ring_stamp(const TickRing &ring) {
@@ -52,24 +57,47 @@ __device__ __forceinline__ uint32_t window_mask(int64_t my_t, int64_t lo, int64_
     return (uint32_t)__ballot(my_t >= lo && my_t <= hi);
 }
 
-// Windows that end before the oldest buffered stamp can never select an update: jump over
-// them (a subscription that was not served for longer than the 32-tick history).  This is
-// the only place the window walk divides (64-bit division is ~hundreds of instructions on
-// the GPU); the common case returns without one.  Returns true if the jump lost history.
-__device__ __forceinline__ bool fast_forward(const TickRing &ring, int64_t now, int64_t &L, int64_t I) {
-    if (ring.n == 0) {  // nothing buffered at all: every due window is empty
-        const int64_t nwin = (now - L) / I;
-        L += nwin * I;
-        return false;
+// floor(d / (iv ms)) for d >= 0 ns, without a 64-bit division (hundreds of instructions on the GPU, and enough live
+// scalars to spill the emit kernel's): ns -> ms is a division by a constant (multiply-high), the rest is 32-bit.
+// Clamped to 2^32 - 1 ms (49 days): an UNDERESTIMATE there, which every caller tolerates (it jumps fewer windows
+// and comes back).
+__device__ __forceinline__ int64_t div_interval(int64_t d, uint32_t iv) {
+    const uint64_t ms = (uint64_t)d / 1000000u;
+    const uint32_t m32 = ms > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)ms;
+    return (int64_t)(m32 / iv);
+}
+
+// The window [max(L,0), L + I] holds no buffered stamp: how many windows to move `last` on in one go.  Empty
+// windows emit nothing, so this is the walk of tickData with its empty iterations folded: straight to the window
+// that holds the oldest stamp newer than L + I, or past every due window when there is none.  (A connection
+// served after a long pause would otherwise walk every empty interval: 10^6 iterations for 1 ms intervals after
+// 1000 s.)  `ts_newer` = that stamp, valid when n_newer != 0.
+__device__ __forceinline__ int64_t empty_windows_to(int64_t ts_newer, uint32_t n_newer, int64_t now, int64_t L, uint32_t iv) {
+    const int64_t I = (int64_t)iv * 1000000;
+    const int64_t left = div_interval(now - L, iv);    // windows still due (>= 1; an underestimate only when clamped)
+    int64_t j = left;
+    if (n_newer) {
+        const int64_t k = div_interval(ts_newer - L, iv);  // window k = [L + kI, L + (k+1)I] holds ts ...
+        j = (ts_newer - L) - k * I == 0 ? k - 1 : k;       // ... and so does window k-1 when ts is its upper edge
+        if (j > left) j = left;
     }
-    const int64_t oldest = ring.t[ring.n - 1];
-    if (oldest <= L + I) return false;  // the next window already reaches the history
-    const int64_t nwin = (now - L) / I;
-    int64_t k = (oldest - L + I - 1) / I - 1;  // windows whose hi = L+(k+1)I stays < oldest
-    if (k < 0) k = 0;
-    if (k > nwin) k = nwin;
-    L += k * I;
-    return k > 0 && ring.n == CHD_HIST_BITS;
+    return j < 1 ? 1 : j;
+}
+
+// wave form: lane j holds the stamp of ring slot j (ring_stamp); stamps do not increase with the slot index, so
+// the stamps newer than the window are slots [0, newer)
+__device__ __forceinline__ int64_t empty_windows(const TickRing &ring, int64_t my_t, int64_t now, int64_t L, uint32_t iv) {
+    const uint32_t newer = (uint32_t)__popcll(__ballot(lane_id() < ring.n && my_t > L + (int64_t)iv * 1000000));
+    const uint32_t src = newer ? newer - 1 : 0;
+    const int64_t ts = ((int64_t)__shfl((int)(my_t >> 32), (int)src) << 32) | (uint32_t)__shfl((int)my_t, (int)src);
+    return empty_windows_to(ts, newer, now, L, iv);
+}
+
+// Updates older than the 32-tick history can no longer be selected: a subscription whose next window ends before
+// the oldest stamp of a FULL ring may have lost some (reported as history_overflow; the windows themselves are
+// empty and folded by empty_windows).
+__device__ __forceinline__ bool history_lost(const TickRing &ring, int64_t oldest, int64_t L, int64_t I) {
+    return ring.n == CHD_HIST_BITS && oldest > L + I;
 }
 
 __global__ void __launch_bounds__(64 * FO_WAVES) k_fanout_plan(DevGrid g, WorldDev w, int64_t now, TickRing ring) {
@@ -208,7 +236,7 @@ template <bool FULL>
 __device__ __forceinline__ uint32_t emit_cell(const WorldDev &w, const uint4 *__restrict__ ce, uint32_t start, uint32_t end,
                                               uint32_t wm, bool skip_self, uint32_t conn, uint32_t conn_tag,
                                               chd_fanout_rec *__restrict__ out, uint32_t *__restrict__ opos, uint32_t n_out) {
-    static_assert(FO_UNROLL == 8, "the load block below names eight entries");
+    static_assert(FO_UNROLL == 8 || FO_UNROLL == 4, "the load blocks below name eight / four entries");
     const uint32_t lane = lane_id();
     for (uint32_t b = start; b < end; b += 64 * FO_UNROLL) {
         u32x4 e[FO_UNROLL];
@@ -222,6 +250,7 @@ __device__ __forceinline__ uint32_t emit_cell(const WorldDev &w, const uint4 *__
         }
         // On gfx950 the vm counter is in-order: waiting for these loads also drains the record stores
         // of the previous step, so a step should be as large as registers allow.
+#if FO_UNROLL == 8
         asm volatile(
             "global_load_dwordx4 %0, %8, off\n\t"
             "global_load_dwordx4 %1, %8, off offset:16\n\t"
@@ -235,6 +264,17 @@ __device__ __forceinline__ uint32_t emit_cell(const WorldDev &w, const uint4 *__
             : "=&v"(e[0]), "=&v"(e[1]), "=&v"(e[2]), "=&v"(e[3]), "=&v"(e[4]), "=&v"(e[5]), "=&v"(e[6]), "=&v"(e[7])
             : "v"(p[0]), "v"(p[1]), "v"(p[2]), "v"(p[3])
             : "memory");
+#else
+        asm volatile(
+            "global_load_dwordx4 %0, %4, off\n\t"
+            "global_load_dwordx4 %1, %4, off offset:16\n\t"
+            "global_load_dwordx4 %2, %5, off\n\t"
+            "global_load_dwordx4 %3, %5, off offset:16\n\t"
+            "s_waitcnt vmcnt(0)"
+            : "=&v"(e[0]), "=&v"(e[1]), "=&v"(e[2]), "=&v"(e[3])
+            : "v"(p[0]), "v"(p[1])
+            : "memory");
+#endif
 #pragma unroll
         for (int j = 0; j < FO_UNROLL / 2; j++) {
             if (end - b <= (uint32_t)(j * 128)) break;  // uniform
@@ -288,14 +328,15 @@ __device__ __forceinline__ uint32_t emit_cell8(const uint2 *__restrict__ ce8, ui
                                                uint32_t conn_tag, chd_fanout_rec *__restrict__ out,
                                                uint32_t *__restrict__ opos, uint32_t n_out) {
     const uint32_t lane = lane_id();
-    for (uint32_t b = start; b < end; b += 512) {
-        u32x4 e[4];
-        const uint2 *p[4];
+    for (uint32_t b = start; b < end; b += 128 * FO_UNROLL8) {
+        u32x4 e[FO_UNROLL8];
+        const uint2 *p[FO_UNROLL8];
 #pragma unroll
-        for (int j = 0; j < 4; j++) {
+        for (int j = 0; j < FO_UNROLL8; j++) {
             const uint32_t pos = b + j * 128 + 2 * lane;
             p[j] = ce8 + (pos + 1 < end ? pos : (end >= start + 2 ? end - 2 : start));  // ce8 has spare entries
         }
+#if FO_UNROLL8 == 4
         asm volatile(
             "global_load_dwordx4 %0, %4, off\n\t"
             "global_load_dwordx4 %1, %5, off\n\t"
@@ -305,8 +346,17 @@ __device__ __forceinline__ uint32_t emit_cell8(const uint2 *__restrict__ ce8, ui
             : "=&v"(e[0]), "=&v"(e[1]), "=&v"(e[2]), "=&v"(e[3])
             : "v"(p[0]), "v"(p[1]), "v"(p[2]), "v"(p[3])
             : "memory");
+#else
+        asm volatile(
+            "global_load_dwordx4 %0, %2, off\n\t"
+            "global_load_dwordx4 %1, %3, off\n\t"
+            "s_waitcnt vmcnt(0)"
+            : "=&v"(e[0]), "=&v"(e[1])
+            : "v"(p[0]), "v"(p[1])
+            : "memory");
+#endif
 #pragma unroll
-        for (int j = 0; j < 4; j++) {
+        for (int j = 0; j < FO_UNROLL8; j++) {
             if (end - b <= (uint32_t)(j * 128)) break;  // uniform
             const uint32_t pos = b + j * 128 + 2 * lane;
             const bool in0 = pos < end, in1 = pos + 1 < end;
@@ -355,7 +405,9 @@ __device__ __forceinline__ uint32_t emit_cell_all(const uint32_t *__restrict__ c
                                                   uint32_t *__restrict__ opos, uint32_t n_out) {
     const uint32_t lane = lane_id();
     const uint32_t n = end - start;
-    // (batching several steps' loads before the first store measured slower on MI355X: 219 vs 198 us per launch)
+    // Measured on MI355X, config B: batching several steps' loads before the first store was slower (219 vs 198 us
+    // per launch), and so was giving every lane two adjacent records per row so that each store instruction writes
+    // one contiguous 1 KiB run (217 vs 200 us: twice the load instructions for the same stores).
     for (uint32_t b = 0; b < n; b += 256) {
         const uint32_t k = b + 4 * lane;      // this lane's first entry of the step, relative to start
         if (k + 4 <= n) {
@@ -416,6 +468,7 @@ __global__ void __launch_bounds__(64 * FO_WAVES) k_fanout_emit(DevGrid g, WorldD
     }
     const uint32_t conn = w.conn_id[s];
     const int64_t my_t = ring_stamp(ring);
+    const int64_t oldest = ring.n ? ring.t[ring.n - 1] : INT64_MAX;
     const uint4 *__restrict__ ce = w.ce_view;
     uint32_t total = 0;
     uint32_t hist_ovf = 0;
@@ -485,14 +538,18 @@ __global__ void __launch_bounds__(64 * FO_WAVES) k_fanout_emit(DevGrid g, WorldD
             }
             // catch-up windows (data.go:224-271 + the revisit through :273-286)
             if (now >= L + I) {
-                if (fast_forward(ring, now, L, I)) hist_ovf = 1;
+                if (history_lost(ring, oldest, L, I)) hist_ovf = 1;
                 const uint32_t ch_hist = d_chh[k];
                 const uint32_t ch_sender = d_chs[k];
                 while (now >= L + I) {
                     const int64_t next = L + I;
                     const int64_t lo = L > 0 ? L : 0;  // lastUpdateTime starts at max(last, 0)
                     const uint32_t wm = window_mask(my_t, lo, next);
-                    if (wm) {
+                    if (!wm) {
+                        L += empty_windows(ring, my_t, now, L, d_iv[k]) * I;
+                        continue;
+                    }
+                    {
                         // the spatial channel's own buffered updates
                         if (cell_update_passes(ch_hist, ch_sender, d_chhp[k], d_chsp[k], wm, skip_self, conn)) {
                             if (lane == 0) {
@@ -648,6 +705,13 @@ __device__ __forceinline__ uint32_t window_mask_serial(const TickRing &ring, int
     return m;
 }
 
+// empty_windows for a single thread (the stamps come from the kernel argument)
+__device__ __forceinline__ int64_t empty_windows_serial(const TickRing &ring, int64_t now, int64_t L, uint32_t iv) {
+    uint32_t newer = 0;
+    for (uint32_t j = 0; j < ring.n; j++) newer += ring.t[j] > L + (int64_t)iv * 1000000 ? 1u : 0u;
+    return empty_windows_to(newer ? ring.t[newer - 1] : 0, newer, now, L, iv);
+}
+
 // K5a': per work item (active cell, chunk of 256 connection slots) the list of due
 // subscriptions, in global memory.  One thread per connection slot: interest-bitmap test,
 // rank in the bitmap row (= index of the subscription in the connection's cell-sorted
@@ -708,7 +772,7 @@ __global__ void __launch_bounds__(WS_SUBS) k_fanout_items(DevGrid g, WorldDev w,
                     if (skip_self) flags |= WSF_SKIP_SELF;
                     uint32_t nw = 0;
                     if (now >= Lw + I) {
-                        if (fast_forward(ring, now, Lw, I)) atomicAdd(&w.counters[CTR_HIST_OVERFLOW], 1u);
+                        if (history_lost(ring, ring.n ? ring.t[ring.n - 1] : INT64_MAX, Lw, I)) atomicAdd(&w.counters[CTR_HIST_OVERFLOW], 1u);
                         while (now >= Lw + I) {
                             const int64_t next = Lw + I;
                             const uint32_t wm = window_mask_serial(ring, Lw > 0 ? Lw : 0, next);
@@ -719,6 +783,9 @@ __global__ void __launch_bounds__(WS_SUBS) k_fanout_items(DevGrid g, WorldDev w,
                                         flags |= 1u << (WSF_OWN_SHIFT + nw);
                                 }
                                 nw++;
+                            } else {
+                                Lw += empty_windows_serial(ring, now, Lw, iv) * I;
+                                continue;
                             }
                             Lw = next;
                         }
@@ -954,7 +1021,6 @@ __global__ void __launch_bounds__(64 * WS_WAVES) k_fanout_emit_ws(DevGrid g, Wor
                     int64_t L = (flags & WSF_FIRST) ? now : G.L[k];
                     const int64_t I = (int64_t)G.iv[k] * 1000000;
                     if (now >= L + I) {
-                        (void)fast_forward(ring, now, L, I);
                         while (now >= L + I) {
                             const int64_t next = L + I;
                             const uint32_t wm = window_mask(my_t, L > 0 ? L : 0, next);
@@ -971,6 +1037,9 @@ __global__ void __launch_bounds__(64 * WS_WAVES) k_fanout_emit_ws(DevGrid g, Wor
                                 }
                                 n_out = T.any_prev ? emit_tile<false, true>(w, T, wm, skip_self, conn, conn, out, opos, n_out)
                                                    : emit_tile<false, false>(w, T, wm, skip_self, conn, conn, out, opos, n_out);
+                            } else {
+                                L += empty_windows(ring, my_t, now, L, G.iv[k]) * I;
+                                continue;
                             }
                             L = next;
                         }

@@ -226,13 +226,17 @@ typedef struct {
 } wwin;
 
 /* windows of one pair at time t (net effect of tickData's revisit loop) */
-static uint32_t pair_windows(wpair *p, orc_time t, wwin *out, uint32_t cap) {
+static uint32_t pair_windows(wpair *p, orc_time t, wwin **pout, uint32_t *cap) {
     uint32_t n = 0;
     if (p->access == ORC_ACCESS_NO) return 0;
     for (;;) {
         orc_time next = p->last + (orc_time)p->interval_ms * 1000000;
         if (!(t >= next)) break;
-        if (n >= cap) break;
+        if (n >= *cap) { /* the reference's loop has no bound: neither has this */
+            *cap *= 2;
+            *pout = (wwin *)realloc(*pout, sizeof(wwin) * *cap);
+        }
+        wwin *out = *pout;
         if (!p->had_first) {
             out[n].full = 1; out[n].last = p->last; out[n].next = next; n++;
             p->had_first = 1;
@@ -275,14 +279,15 @@ static void job_push(fan_job *j, uint32_t conn, uint32_t chan) {
     j->nrec++;
 }
 
-#define MAXWIN 4096
+#define MAXWIN 4096 /* initial capacity of the window list (grows) */
 
 /* shared-state fan-out for cells [c0,c1): channel-major like the reference
  * (one tickData per channel, walking that channel's subscribers). */
 static void *fan_cells(void *arg) {
     fan_job *j = (fan_job *)arg;
     orc_world *w = j->w;
-    wwin *wins = (wwin *)malloc(sizeof(wwin) * MAXWIN);
+    uint32_t wcap = MAXWIN;
+    wwin *wins = (wwin *)malloc(sizeof(wwin) * wcap);
     for (uint32_t c = j->c0; c < j->c1; c++) {
         uint32_t ns = j->cell_off_sub[c + 1] - j->cell_off_sub[c];
         if (!ns) continue;
@@ -301,7 +306,7 @@ static void *fan_cells(void *arg) {
             for (uint32_t si = 0; si < ns; si++) {
                 wpair tmp = w->pairs[(size_t)subs[si].s * w->capq + subs[si].p];
                 uint32_t conn = w->conn_id[subs[si].s];
-                uint32_t nw = pair_windows(&tmp, j->t, wins, MAXWIN);
+                uint32_t nw = pair_windows(&tmp, j->t, &wins, &wcap);
                 for (uint32_t wi = 0; wi < nw; wi++) {
                     if (wins[wi].full) job_push(j, conn | REC_FULL, chan);
                     else if (window_has_update(b, wins[wi].last, wins[wi].next, conn, tmp.skip_self))
@@ -312,7 +317,7 @@ static void *fan_cells(void *arg) {
         /* commit the subscription state (identical for every channel above) */
         for (uint32_t si = 0; si < ns; si++) {
             wpair *p = &w->pairs[(size_t)subs[si].s * w->capq + subs[si].p];
-            pair_windows(p, j->t, wins, MAXWIN);
+            pair_windows(p, j->t, &wins, &wcap);
         }
     }
     free(wins);

@@ -24,10 +24,10 @@ def emit_mode(request):
     yield request.param
 
 
-def make(amd, cfg, N, S, capq=0, max_records=0):
+def make(amd, cfg, N, S, capq=0, max_records=0, extra_flags=0):
     ctl = amd.StaticGrid2DSpatialController()
     assert ctl.LoadConfig(json.dumps(cfg).encode(), strict=False) is None
-    w = amd.SpatialWorld(ctl, N, S, max_interest_cells=capq, max_records=max_records, flags=EMIT_FLAGS)
+    w = amd.SpatialWorld(ctl, N, S, max_interest_cells=capq, max_records=max_records, flags=EMIT_FLAGS | extra_flags)
     return ctl, w
 
 
@@ -65,12 +65,12 @@ def compare_tick(k, res, ow, S, id_start=0x10000, check_pairs=None, gw=None):
             assert np.array_equal(gnew, wnew), f"tick {k} sub {s}: is_new"
 
 
-def run_world(amd, cfg_name, N, S, ticks, seed, tick_ms=50, capq=0, aoi_scale=1.0, sparse=False, check_subs=8):
+def run_world(amd, cfg_name, N, S, ticks, seed, tick_ms=50, capq=0, aoi_scale=1.0, sparse=False, check_subs=8, pauses=None, extra_flags=0):
     cfg = synth.load_config(cfg_name)
     g = orc.grid_from_config(cfg)
     spec = synth.WorldSpec(cfg, N, S, seed, tick_ms=tick_ms, aoi_scale=aoi_scale, outside_frac=0.01, locked_frac=0.02)
     sw = synth.SynthWorld(spec)
-    ctl, gw = make(amd, cfg, N, S, capq)
+    ctl, gw = make(amd, cfg, N, S, capq, extra_flags=extra_flags)
     ow = orc.World(g, N, S, gw.capq, 20, 0, literal=False)
     ow.set_threads(4)
     ow.spawn(np.arange(N), sw.chan_id, sw.x, sw.z, sw.flags, sw.sender)
@@ -81,8 +81,11 @@ def run_world(amd, cfg_name, N, S, ticks, seed, tick_ms=50, capq=0, aoi_scale=1.
     rng = np.random.default_rng(seed & 0xFFFF)
     total = 0
     n_ho = 0
+    late_ns = 0  # accumulated lateness of the tick clock (pauses: {tick: extra ms})
     for k in range(ticks):
         sw.step()
+        late_ns += (pauses or {}).get(k, 0) * 1_000_000
+        now = sw.now_ns() + late_ns
         q = sw.queries()
         if sparse and k % 3 == 1:
             idx = np.sort(rng.choice(N, N // 2, replace=False)).astype(np.uint32)
@@ -90,8 +93,8 @@ def run_world(amd, cfg_name, N, S, ticks, seed, tick_ms=50, capq=0, aoi_scale=1.
         else:
             idx = np.arange(N, dtype=np.uint32)
             qsub = np.arange(S, dtype=np.uint32)
-        ow.tick(sw.now_ns(), idx, sw.x[idx], sw.z[idx], None, None, None, qsub, q[qsub])
-        res = gw.tick(sw.now_ns(), upd_idx=idx, upd_x=sw.x[idx], upd_z=sw.z[idx], query_sub=qsub, queries=q[qsub],
+        ow.tick(now, idx, sw.x[idx], sw.z[idx], None, None, None, qsub, q[qsub])
+        res = gw.tick(now, upd_idx=idx, upd_x=sw.x[idx], upd_z=sw.z[idx], query_sub=qsub, queries=q[qsub],
                       records_cap=max(1 << 20, 4 * len(ow.records()[0])))
         subs = rng.choice(S, min(check_subs, S), replace=False)
         compare_tick(k, res, ow, S, check_pairs=subs, gw=gw)
@@ -157,6 +160,22 @@ def test_world_slow_ticks_catch_up(amd):
     # 170 ms ticks: several catch-up windows per tick for every interval class
     total, n_ho = run_world(amd, "spatial_static_benchmark.json", 2000, 100, 16, 0xC0FFEE06, tick_ms=170)
     assert total > 50000
+
+
+def test_world_interest_on_second_stream(amd):
+    # CHD_WORLD_OVERLAP_INTEREST: interest updates beside ingest + index build, joined before the fan-out plan
+    from channeld_amd import _lib
+
+    total, n_ho = run_world(amd, "spatial_static_benchmark.json", 3000, 200, 14, 0xC0FFEE0A, sparse=True,
+                            extra_flags=_lib.WORLD_OVERLAP_INTEREST)
+    assert total > 50000 and n_ho > 0
+
+
+def test_world_long_pauses_fold_empty_windows(amd):
+    # ticks 5, 11 and 12 arrive 90 s, 7.3 s and 61 ms late: thousands of empty fan-out windows lie between the
+    # buffered stamps; the kernels fold them (empty_windows), the oracle walks every one of them
+    total, n_ho = run_world(amd, "spatial_static_2x2.json", 300, 32, 18, 0xC0FFEE09, pauses={5: 90_000, 11: 7_300, 12: 61})
+    assert total > 5000
 
 
 def test_world_despawn_lock_and_remove_subscriber(amd):

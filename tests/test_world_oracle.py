@@ -13,7 +13,7 @@ def canon(conn, chan):
     return np.sort(a)
 
 
-def run_pair(cfg_name, N, S, ticks, tick_ms, seed, capq=64, aoi_scale=1.0, drop_every=0):
+def run_pair(cfg_name, N, S, ticks, tick_ms, seed, capq=64, aoi_scale=1.0, drop_every=0, pauses=None):
     cfg = synth.load_config(cfg_name)
     g = orc.grid_from_config(cfg)
     spec = synth.WorldSpec(cfg, N, S, seed, tick_ms=tick_ms, aoi_scale=aoi_scale, outside_frac=0.01, locked_frac=0.02)
@@ -24,8 +24,11 @@ def run_pair(cfg_name, N, S, ticks, tick_ms, seed, capq=64, aoi_scale=1.0, drop_
         for s in range(S):
             w.add_sub(s, int(sw.sub_conn[s]))
     total = 0
+    late_ns = 0
     for k in range(ticks):
         sw.step()
+        late_ns += (pauses or {}).get(k, 0) * 1_000_000
+        now = sw.now_ns() + late_ns
         q = sw.queries()
         # only part of the entities update on some ticks (sparse idx path)
         if drop_every and k % drop_every == 1:
@@ -34,7 +37,7 @@ def run_pair(cfg_name, N, S, ticks, tick_ms, seed, capq=64, aoi_scale=1.0, drop_
             idx = np.arange(N, dtype=np.uint32)
         outs = []
         for w in worlds:
-            w.tick(sw.now_ns(), idx, sw.x[idx], sw.z[idx], None, None, None, None, q)
+            w.tick(now, idx, sw.x[idx], sw.z[idx], None, None, None, None, q)
             outs.append((canon(*w.records()), [a.copy() for a in w.handovers()], [a.copy() for a in w.unsubs()],
                          w.query_status().copy()))
         (r0, h0, u0, s0), (r1, h1, u1, s1) = outs
@@ -63,3 +66,10 @@ def test_literal_equals_window_irregular_tick():
     # 7 ms ticks: several windows per tick for none, one tick per several windows for others
     total = run_pair("spatial_static_4x4.json", 200, 24, 20, 7, 0xC0FFEE03, capq=16, aoi_scale=0.5)
     assert total > 500
+
+
+def test_literal_equals_window_after_long_pauses():
+    # ticks that arrive 90 s / 7.3 s late: more than 4096 catch-up windows for the 20 ms interval class
+    # (the window formulation once capped its list there and spread the catch-up over two ticks)
+    total = run_pair("spatial_static_2x2.json", 300, 32, 18, 50, 0xC0FFEE09, capq=4, pauses={5: 90_000, 11: 7_300, 12: 61})
+    assert total > 5000
