@@ -48,6 +48,9 @@ def parse():
     ap.add_argument("--wire", type=int, default=0, metavar="TICKS",
                     help="after the timed region, also materialise the wire-format packet streams (SURVEY 8f-1) for TICKS ticks "
                          "and report their rate (66-byte Any per update: the minimal position update of SURVEY a14)")
+    ap.add_argument("--update-frac", type=float, default=1.0,
+                    help="diagnostic: only this fraction of the entities (random, per tick) send an update; BASELINE "
+                         "config B is 1.0 (every entity moves every tick) - lower values exercise the filtering emit paths")
     ap.add_argument("--overlap-interest", action="store_true",
                     help="run the interest updates on a second stream beside ingest + index (CHD_WORLD_OVERLAP_INTEREST)")
     ap.add_argument("--recipients", action="store_true",
@@ -157,11 +160,20 @@ def main():
     for t in range(T):
         sw.step()
         xs[t], zs[t], qs[t], now[t] = sw.x, sw.z, sw.queries(), sw.now_ns()
+    M, d_idx = N, None  # updates per tick
+    if args.update_frac < 1.0:
+        M = max(1, int(round(args.update_frac * N)))
+        rng = np.random.default_rng(seed)
+        idx = np.stack([np.sort(rng.choice(N, M, replace=False)).astype(np.uint32) for _ in range(T)])
+        xs = np.ascontiguousarray(np.take_along_axis(xs, idx.astype(np.int64), axis=1))
+        zs = np.ascontiguousarray(np.take_along_axis(zs, idx.astype(np.int64), axis=1))
+        d_idx = world.device_array(idx)
     d_x, d_z, d_q = world.device_array(xs), world.device_array(zs), world.device_array(qs)
     del xs, zs
 
     def tick(t):
-        world.tick_device(int(now[t]), n_updates=N, d_upd_x=d_x.at(t * N * 8), d_upd_z=d_z.at(t * N * 8),
+        world.tick_device(int(now[t]), n_updates=M, d_upd_x=d_x.at(t * M * 8), d_upd_z=d_z.at(t * M * 8),
+                          d_upd_idx=d_idx.at(t * M * 4) if d_idx is not None else None,
                           n_queries=S, d_queries=d_q.at(t * S * 128))
 
     world.set_profiling(min(1024, max(K, L, 1)))
@@ -198,8 +210,9 @@ def main():
         world.wire_set_payloads(3, 0x10000 + np.arange(ncell), [bytes(200)] * ncell)
         wb, wt, wp = [], [], []
         for t in range(W + K - args.wire, W + K):  # replay the last ticks' inputs at later channel times
-            world.tick_device(int(now[W + K - 1]) + (t + 1) * args.tick_ms * 1_000_000, n_updates=N, d_upd_x=d_x.at(t * N * 8),
-                              d_upd_z=d_z.at(t * N * 8), n_queries=S, d_queries=d_q.at(t * S * 128))
+            world.tick_device(int(now[W + K - 1]) + (t + 1) * args.tick_ms * 1_000_000, n_updates=M, d_upd_x=d_x.at(t * M * 8),
+                              d_upd_z=d_z.at(t * M * 8), d_upd_idx=d_idx.at(t * M * 4) if d_idx is not None else None,
+                              n_queries=S, d_queries=d_q.at(t * S * 128))
             world.sync()
             a = time.perf_counter()
             nbytes, npackets, ndropped = world.wire_build()
@@ -226,7 +239,7 @@ def main():
     # rocprofv3 runs, tools/pmc_summary.py); only quoted for the workload it was measured on
     traffic = None
     tpath = os.path.join(ROOT, "profiles", "hbm_traffic.json")
-    if os.path.exists(tpath) and (N, S) == (100_000, 10_000) and args.aoi_scale == 1.0 and args.tick_ms == 50:
+    if os.path.exists(tpath) and (N, S) == (100_000, 10_000) and args.aoi_scale == 1.0 and args.tick_ms == 50 and args.update_frac >= 1.0:
         with open(tpath) as f:
             traffic = json.load(f)["kernels"].get("k_fanout_emit", {}).get("bytes_per_launch")
 
@@ -235,7 +248,9 @@ def main():
         "value": msgs / elapsed, "unit": "msgs/s", "n_gpus": 1, "steps": K, "warmup": W,
         "ms_per_step": 1e3 * elapsed / K, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "f64", "data": "synthetic",
-        "config": {"workload": f"spatial_static_benchmark.json, {N} entities / {S} subs, 1xMI355X", "grid": "15x15 cells of 2000",
+        "config": {"workload": f"spatial_static_benchmark.json, {N} entities / {S} subs, 1xMI355X"
+                               + ("" if args.update_frac >= 1.0 else f", DIAGNOSTIC: {args.update_frac:g} of the entities update per tick"),
+                   "grid": "15x15 cells of 2000",
                    "tick_ms": args.tick_ms, "aoi": "70% sphere R=3 cells, 20% cone R=5 cells, 10% box extent 2 cells",
                    "msgs_per_tick": msgs / K, "message": "one fanOutDataUpdate decision (conn, channel); payload bytes excluded"},
         "p50_tick_ms": float(np.percentile(lat, 50)), "p99_tick_ms": float(np.percentile(lat, 99)),

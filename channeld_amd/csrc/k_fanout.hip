@@ -38,7 +38,9 @@
 // tables read; no MFMA — this is gather/compaction, not a contraction.
 #include "chd_kernels.h"
 
+#ifndef FO_WAVES
 #define FO_WAVES 4
+#endif
 #define CHD_SEG_ALIGN 16u  // records: 16 x 8 B = one 128-byte line
 #ifndef FO_UNROLL
 #define FO_UNROLL 4
@@ -436,16 +438,20 @@ __device__ __forceinline__ uint32_t emit_cell_all(const uint32_t *__restrict__ c
     return n_out + n;
 }
 
-#define FO_TILE 256  // subscriptions staged in LDS per round (= workgroup size)
 
-__global__ void __launch_bounds__(64 * FO_WAVES) k_fanout_emit(DevGrid g, WorldDev w, int64_t now, TickRing ring) {
+// WAVES waves per connection (= subscriptions staged in LDS per round / 64).  Measured at config B (10 K connections,
+// ~18 due subscriptions each): 192.8 / 194.4 / 196.8 / 227 us per launch with 1 / 2 / 4 / 8 waves; the launcher takes
+// one wave per connection when there are enough connections to fill the chip that way, four otherwise.
+template <int WAVES>
+__global__ void __launch_bounds__(64 * WAVES) k_fanout_emit(DevGrid g, WorldDev w, int64_t now, TickRing ring) {
+    constexpr uint32_t FO_TILE = 64 * WAVES;
     // due subscriptions of this connection, staged once per workgroup so that the
     // streaming waves never wait on per-subscription pointer chasing
     __shared__ uint32_t d_p[FO_TILE], d_fl[FO_TILE], d_c[FO_TILE], d_start[FO_TILE], d_end[FO_TILE], d_rel[FO_TILE],
         d_chh[FO_TILE], d_chs[FO_TILE], d_iv[FO_TILE], d_chhp[FO_TILE], d_chsp[FO_TILE], d_us[FO_TILE], d_hand[FO_TILE];
     __shared__ int64_t d_L[FO_TILE];
     __shared__ uint32_t n_due, ticket;
-    __shared__ uint32_t wave_total[FO_WAVES];
+    __shared__ uint32_t wave_total[WAVES];
     const uint32_t s = blockIdx.x;
     const uint32_t lane = lane_id();
     const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -459,7 +465,7 @@ __global__ void __launch_bounds__(64 * FO_WAVES) k_fanout_emit(DevGrid g, WorldD
     if (w.rec_ub[s + 1] > w.recs_cap) {
         // no room for this connection's worst case: leave its state untouched, it
         // catches up next tick (the reference's catch-up loop), and say so.
-        for (uint32_t p = threadIdx.x; p < cnt; p += 64 * FO_WAVES) w.pair_nrec[pbase + p] = 0;
+        for (uint32_t p = threadIdx.x; p < cnt; p += 64 * WAVES) w.pair_nrec[pbase + p] = 0;
         if (threadIdx.x == 0) {
             w.rec_cnt[s] = 0;
             if (w.rec_ub[s + 1] > base) atomicOr(&w.counters[CTR_OVERFLOW], OVF_RECORDS);
@@ -468,7 +474,10 @@ __global__ void __launch_bounds__(64 * FO_WAVES) k_fanout_emit(DevGrid g, WorldD
     }
     const uint32_t conn = w.conn_id[s];
     const int64_t my_t = ring_stamp(ring);
-    const int64_t oldest = ring.n ? ring.t[ring.n - 1] : INT64_MAX;
+    // (wave-uniform, but read through a dynamic index: keep it on the scalar side)
+    const int64_t oldest_v = ring.n ? ring.t[ring.n - 1] : INT64_MAX;
+    const int64_t oldest = ((int64_t)__builtin_amdgcn_readfirstlane((int)(oldest_v >> 32)) << 32) |
+                           (uint32_t)__builtin_amdgcn_readfirstlane((int)oldest_v);
     const uint4 *__restrict__ ce = w.ce_view;
     uint32_t total = 0;
     uint32_t hist_ovf = 0;
@@ -584,7 +593,7 @@ __global__ void __launch_bounds__(64 * FO_WAVES) k_fanout_emit(DevGrid g, WorldD
     __syncthreads();
     if (threadIdx.x == 0) {
         uint32_t t = 0;
-        for (int k = 0; k < FO_WAVES; k++) t += wave_total[k];
+        for (int k = 0; k < WAVES; k++) t += wave_total[k];
         w.rec_cnt[s] = t;
         // per-tick totals go through 64 hashed counters, one 128-byte line each: a
         // single word (or words sharing a line) would serialise S atomics at ~12 ns
@@ -1082,7 +1091,8 @@ void launch_fanout_emit(hipStream_t st, DevGrid g, WorldDev w, int64_t now_ns, T
         hipLaunchKernelGGL(k_fanout_items, dim3(pgrid), dim3(WS_SUBS), 0, st, g, w, now_ns, ring, chunks);
         hipLaunchKernelGGL(k_fanout_emit_ws, dim3(grid), dim3(64 * WS_WAVES), 0, st, g, w, now_ns, ring, chunks);
     } else {
-        hipLaunchKernelGGL(k_fanout_emit, dim3(w.S), dim3(64 * FO_WAVES), 0, st, g, w, now_ns, ring);
+        if (w.S >= 4096) hipLaunchKernelGGL(k_fanout_emit<1>, dim3(w.S), dim3(64), 0, st, g, w, now_ns, ring);
+        else hipLaunchKernelGGL(k_fanout_emit<4>, dim3(w.S), dim3(256), 0, st, g, w, now_ns, ring);
     }
 }
 

@@ -6,10 +6,10 @@ R=${GRAFT_REPO_ROOT:-$(pwd)}
 O=$R/gpurun_out/$TAG
 mkdir -p $O
 cd $R
-timeout 600 python -m pytest tests -m gpu -x -q > $O/pytest_gpu.log 2>&1; echo "pytest rc=$?" >> $O/pytest_gpu.log
-timeout 400 python bench.py "$@" > $O/bench.json 2> $O/bench.err
+timeout -s KILL 400 python -m pytest tests -m gpu -x -q > $O/pytest_gpu.log 2>&1; echo "pytest rc=$?" >> $O/pytest_gpu.log
+timeout -s KILL 400 python bench.py "$@" > $O/bench.json 2> $O/bench.err
 cd /tmp && export TMPDIR=/tmp
-timeout 300 rocprofv3 --kernel-trace --stats -d $O/prof -o kt -- python $R/bench.py --steps 50 --warmup 10 --no-cpu --latency-steps 0 > $O/prof_bench.json 2> $O/prof.err
+timeout -s KILL 300 rocprofv3 --kernel-trace --stats -d $O/prof -o kt -- python $R/bench.py --steps 50 --warmup 10 --no-cpu --latency-steps 0 > $O/prof_bench.json 2> $O/prof.err
 cd $R
 python tools/rocpd_summary.py $O/prof/kt_results.db > $O/kernel_stats.csv 2>> $O/prof.err
 rm -rf $O/prof

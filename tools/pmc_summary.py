@@ -10,8 +10,14 @@ reported as is, beside the kernel's own known output bytes where available.
 """
 import csv
 import json
+import re
 import sys
 from collections import defaultdict
+
+
+def kname(full):
+    """'void k_fanout_emit<1>(DevGrid, ...)' -> 'k_fanout_emit' (template instances of one kernel are one row)"""
+    return re.sub(r"<.*", "", full.split("(")[0].replace("void ", ""))
 
 
 def load(path, counter):
@@ -20,7 +26,7 @@ def load(path, counter):
         for r in csv.DictReader(f):
             if r["Counter_Name"] != counter:
                 continue
-            per[r["Kernel_Name"].split("(")[0]].append(float(r["Counter_Value"]))
+            per[kname(r["Kernel_Name"])].append(float(r["Counter_Value"]))
     return per
 
 

@@ -22,7 +22,7 @@ O = sys.argv[1]
 acc = defaultdict(lambda: defaultdict(list))
 for f in glob.glob(O + "/g*/**/*counter_collection.csv", recursive=True):
     for r in csv.DictReader(open(f)):
-        acc[r["Kernel_Name"].split("(")[0]][r["Counter_Name"]].append(float(r["Counter_Value"]))
+        acc[r["Kernel_Name"].split("(")[0].replace("void ", "").split("<")[0]][r["Counter_Name"]].append(float(r["Counter_Value"]))
 out = {k: {c: sum(v[5:]) / max(1, len(v[5:])) for c, v in d.items()} for k, d in acc.items() if k.startswith("k_")}
 json.dump(out, open(O + "/sq_summary.json", "w"), indent=1)
 for k in ("k_fanout_emit", "k_aoi_interest", "k_index_scatter", "k_ingest"):
