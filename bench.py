@@ -115,11 +115,15 @@ def main():
     if os.environ.get("CHD_BENCH_SHARE_GPU"):  # test hook: several ranks on one GPU (gloo, host-staged exchange)
         local_rank = 0
     torch.cuda.set_device(local_rank)
-    dist_on = world_size > 1
+    # CHD_BENCH_FORCE_DIST: take the sharded (RCCL) path with a single rank as well (test hook for one-GPU boxes)
+    dist_on = world_size > 1 or bool(os.environ.get("CHD_BENCH_FORCE_DIST"))
     if dist_on:
         import torch.distributed as dist
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29531")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
         backend = os.environ.get("CHD_DIST_BACKEND", "nccl")  # "nccl" is RCCL on ROCm
         if backend == "nccl":
             dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))

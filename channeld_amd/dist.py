@@ -89,7 +89,10 @@ class Comm:
 
         self.rank, self.world = rank, world
         self.dist = dist
-        self.backend = dist.get_backend() if world > 1 else "none"
+        # test hook: run the real collectives on a single-rank group too (RCCL dtype / stream / device_id coverage on
+        # a one-GPU box; tests/test_gpu_shard.py)
+        self.force = bool(os.environ.get("CHD_BENCH_FORCE_DIST")) and dist.is_initialized()
+        self.backend = dist.get_backend() if (world > 1 or self.force) else "none"
         # gloo has no all_to_all and wants host memory: stage through the CPU
         self.staged = (self.backend != "nccl") if staged is None else staged
 
@@ -97,7 +100,7 @@ class Comm:
         """send[dst] -> recv[src]; equal-sized segments."""
         import torch
 
-        if self.world == 1:
+        if self.world == 1 and not self.force:
             return send
         if not self.staged:
             recv = torch.empty_like(send)
@@ -115,7 +118,7 @@ class Comm:
         collective runs on the communication stream."""
         import torch
 
-        if self.world == 1:
+        if self.world == 1 and not self.force:
             if overlap:
                 overlap()
             return t
@@ -136,7 +139,7 @@ class Comm:
     def sum_int(self, v: int) -> int:
         import torch
 
-        if self.world == 1:
+        if self.world == 1 and not self.force:
             return int(v)
         dev = "cuda" if self.backend == "nccl" else "cpu"
         t = torch.tensor([int(v)], dtype=torch.int64, device=dev)
@@ -146,7 +149,7 @@ class Comm:
     def max_float(self, v: float) -> float:
         import torch
 
-        if self.world == 1:
+        if self.world == 1 and not self.force:
             return float(v)
         dev = "cuda" if self.backend == "nccl" else "cpu"
         t = torch.tensor([float(v)], dtype=torch.float64, device=dev)
@@ -154,7 +157,7 @@ class Comm:
         return float(t.item())
 
     def barrier(self):
-        if self.world > 1:
+        if self.world > 1 or self.force:
             self.dist.barrier()
 
 
@@ -252,7 +255,7 @@ class ShardedWorld:
 
     def tick(self, now_ns: int, x_by_chan, z_by_chan, queries=None, n_queries: int = 0, has_update=None):
         send = self.engine.ingest(now_ns, x_by_chan, z_by_chan, has_update)
-        recv = self.comm.all_to_all(send) if self.comm.world > 1 else None
+        recv = self.comm.all_to_all(send) if (self.comm.world > 1 or self.comm.force) else None
         table = self.engine.import_(recv)
         # the interest updates do not read the gathered tables: they run under the all-gather
         tables = self.comm.all_gather(table, overlap=lambda: self.engine.interest(queries, n_queries))

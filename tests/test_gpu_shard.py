@@ -164,3 +164,26 @@ def test_two_ranks_on_one_gpu_match_single_world():
 def test_four_ranks_on_one_gpu_match_single_world():
     total, cross = launch(4, 4000, 96, 6, 0xC0FFEE13)
     assert total > 0 and cross > 0
+
+
+def test_rccl_single_rank_bench_path():
+    """bench.py's sharded path exactly as the driver launches it (torch.distributed.run, backend "nccl" = RCCL,
+    device buffers, everything on torch's stream) — with the one rank a one-GPU box has.  CHD_BENCH_FORCE_DIST makes
+    the single rank issue the real collectives (all_to_all_single on int32, async all_gather_into_tensor on uint8,
+    all_reduce, barrier), so dtype support, device_id initialisation and the stream hand-over are exercised; the
+    message count must equal the unsharded path's on the same synthetic world."""
+    import json
+    import subprocess
+
+    env = dict(os.environ, CHD_BENCH_FORCE_DIST="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    common = ["--gpus", "1", "--steps", "6", "--warmup", "3", "--entities", "20000", "--subs", "2000", "--no-cpu", "--latency-steps", "0"]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
+           "--master-port", str(free_port()), os.path.join(ROOT, "bench.py")] + common
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=280, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-2000:]
+    sharded = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert sharded["n_gpus"] == 1 and "tiled 1x1" in sharded["config"]["workload"]
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + common, capture_output=True, text=True, timeout=280, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-2000:]
+    single = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert sharded["config"]["msgs_per_tick"] == pytest.approx(single["config"]["msgs_per_tick"], rel=0, abs=0.5)
