@@ -51,6 +51,8 @@ def parse():
     ap.add_argument("--update-frac", type=float, default=1.0,
                     help="diagnostic: only this fraction of the entities (random, per tick) send an update; BASELINE "
                          "config B is 1.0 (every entity moves every tick) - lower values exercise the filtering emit paths")
+    ap.add_argument("--update-masks", action="store_true",
+                    help="also write, per record, which buffered updates the message merges (CHD_WORLD_UPDATE_MASKS, +4 B/record)")
     ap.add_argument("--overlap-interest", action="store_true",
                     help="run the interest updates on a second stream beside ingest + index (CHD_WORLD_OVERLAP_INTEREST)")
     ap.add_argument("--recipients", action="store_true",
@@ -151,7 +153,7 @@ def main():
     ctl = A.StaticGrid2DSpatialController(device=local_rank)
     err = ctl.LoadConfig(json.dumps(cfg).encode(), strict=False)
     assert err is None, err
-    world = A.SpatialWorld(ctl, N, S, flags={"auto": 0, "conn-major": 1, "cell-major": 2}[args.emit] | (4 if args.recipients else 0) | (8 if args.wire else 0) | (16 if args.overlap_interest else 0))
+    world = A.SpatialWorld(ctl, N, S, flags={"auto": 0, "conn-major": 1, "cell-major": 2}[args.emit] | (4 if args.recipients else 0) | (8 if args.wire else 0) | (16 if args.overlap_interest else 0) | (32 if args.update_masks else 0))
     world.spawn(None, sw.chan_id, sw.x, sw.z, sw.flags, sw.sender)
     world.add_subscribers(None, sw.sub_conn)
 

@@ -23,6 +23,7 @@ WORLD_CELL_MAJOR_EMIT = 2
 WORLD_HANDOVER_RECIPIENTS = 4
 WORLD_WIRE = 8
 WORLD_OVERLAP_INTEREST = 16
+WORLD_UPDATE_MASKS = 32
 WIRE_ENTITY_UPDATE, WIRE_ENTITY_FULL, WIRE_CELL_UPDATE, WIRE_CELL_FULL = 0, 1, 2, 3
 HO_SRC_ONLY, HO_DST_NEW, HO_DST_KNOWN = 0, 1, 2
 BROADCAST_ALL_BUT_SENDER, BROADCAST_ALL_BUT_OWNER, BROADCAST_ALL_BUT_CLIENT, BROADCAST_ALL_BUT_SERVER = 4, 8, 16, 32
@@ -123,6 +124,7 @@ class TickOut(C.Structure):
         ("records", _vp), ("records_cap", C.c_uint64), ("n_records", C.c_uint64),
         ("conn_rec_off", _u64p), ("conn_rec_cnt", _u32p),
         ("overflow", C.c_uint32), ("history_overflow", C.c_uint32),
+        ("record_masks", _u32p),
     ]
 
 

@@ -158,7 +158,8 @@ int walloc(chd_ctx *ctx, T **out, size_t count, bool zero = true) {
 
 // dense per-connection packing of the emitted records (for the host-facing fetch):
 // a connection's records sit in one segment per subscription inside its range
-__global__ void __launch_bounds__(256) k_pack_records(WorldDev w, const uint64_t *exact_off, chd_fanout_rec *dense) {
+__global__ void __launch_bounds__(256) k_pack_records(WorldDev w, const uint64_t *exact_off, chd_fanout_rec *dense,
+                                                      uint32_t *dense_mask) {
     uint32_t s = blockIdx.x * 4u + (threadIdx.x >> 6);
     if (s >= w.S) return;
     if (w.rec_cnt[s] == 0) return;
@@ -167,11 +168,18 @@ __global__ void __launch_bounds__(256) k_pack_records(WorldDev w, const uint64_t
     const size_t pbase = (size_t)s * w.capq;
     const chd_fanout_rec *base = w.recs + w.rec_ub[s];
     chd_fanout_rec *dst = dense + exact_off[s];
+    const uint32_t *mbase = dense_mask ? w.rec_mask + w.rec_ub[s] : nullptr;
+    uint32_t *mdst = dense_mask ? dense_mask + exact_off[s] : nullptr;
     for (uint32_t p = 0; p < cnt; p++) {
         const uint32_t n = w.pair_nrec[pbase + p];
         const chd_fanout_rec *src = base + w.pair_rel[pbase + p];
         for (uint32_t k = lane; k < n; k += 64) dst[k] = src[k];
         dst += n;
+        if (mdst) {
+            const uint32_t *msrc = mbase + w.pair_rel[pbase + p];
+            for (uint32_t k = lane; k < n; k += 64) mdst[k] = msrc[k];
+            mdst += n;
+        }
     }
 }
 
@@ -555,10 +563,15 @@ int chd_world_create(chd_ctx *ctx, const chd_world_cfg *cfg) {
                            (!(cfg->flags & CHD_WORLD_CONN_MAJOR_EMIT) && N / C >= 1024);
     if ((cfg->flags & CHD_WORLD_CELL_MAJOR_EMIT) && !cm_possible)
         return fail(ctx, CHD_E_INVAL, "cell-major emit needs a grid of at most 4096 cells (and cells x subscribers x 40 B <= 2 GiB)");
+    // update masks: written by the connection-major form only (the cell-major streamers replay precomputed window
+    // masks from LDS and would need the cell's own histories per window)
+    const bool want_masks = (cfg->flags & CHD_WORLD_UPDATE_MASKS) != 0;
+    if (want_masks && (cfg->flags & CHD_WORLD_CELL_MAJOR_EMIT))
+        return fail(ctx, CHD_E_INVAL, "CHD_WORLD_UPDATE_MASKS is implemented by the connection-major emit only");
     // the interest bitmap (one bit per cell and connection) exists for every grid of up to 4096 cells:
     // the recipient planners use it too; larger grids fall back to searching the sorted subscription lists
     d.wb = C <= 4096 ? (uint32_t)((C + 63) / 64) : 0u;
-    d.cm_emit = (cm_possible && cm_wanted) ? 1u : 0u;
+    d.cm_emit = (cm_possible && cm_wanted && !want_masks) ? 1u : 0u;
     d.sub_bits = nullptr;
     d.items = nullptr;
     if (d.wb) TRY(walloc(ctx, &d.sub_bits, S * d.wb));
@@ -624,8 +637,12 @@ int chd_world_create(chd_ctx *ctx, const chd_world_cfg *cfg) {
     }
     W.wire = (cfg->flags & CHD_WORLD_WIRE) != 0;
     if (W.wire && !cfg->max_records) nrec = std::min<uint64_t>(nrec / 3, 1000000000ull);  // three more 4-byte arrays per record
+    const bool masks = (cfg->flags & CHD_WORLD_UPDATE_MASKS) != 0;
+    if (masks && !cfg->max_records) nrec = nrec * 2 / 3;  // one more 4-byte array per record
     d.recs_cap = nrec;
     TRY(walloc(ctx, &d.recs, nrec, false));
+    d.rec_mask = nullptr;
+    if (masks) TRY(walloc(ctx, &d.rec_mask, nrec, false));
     d.rec_pos = nullptr;
     d.ce_slot = nullptr;
     if (W.wire) {
@@ -957,11 +974,14 @@ static int fetch_locked(chd_ctx *ctx, chd_tick_out *out) {
                 if (W.recs_dense) HIPCHK(hipFree(W.recs_dense));
                 W.recs_dense = nullptr;
                 W.recs_dense_cap = total + total / 4;
-                HIPCHK(hipMalloc((void **)&W.recs_dense, W.recs_dense_cap * sizeof(chd_fanout_rec)));
+                // (+ half as much again for the masks of a CHD_WORLD_UPDATE_MASKS world)
+                HIPCHK(hipMalloc((void **)&W.recs_dense, W.recs_dense_cap * (sizeof(chd_fanout_rec) + (d.rec_mask ? 4 : 0))));
             }
-            hipLaunchKernelGGL(k_pack_records, dim3((d.S + 3) / 4), dim3(256), 0, st, d, W.rec_off_exact, W.recs_dense);
+            uint32_t *dmask = (d.rec_mask && out->record_masks) ? (uint32_t *)(W.recs_dense + W.recs_dense_cap) : nullptr;
+            hipLaunchKernelGGL(k_pack_records, dim3((d.S + 3) / 4), dim3(256), 0, st, d, W.rec_off_exact, W.recs_dense, dmask);
             TRY(after_launch(ctx));
             TRY(down(ctx, out->records, W.recs_dense, sizeof(chd_fanout_rec) * total));
+            if (dmask) TRY(down(ctx, out->record_masks, dmask, sizeof(uint32_t) * total));
         }
     }
     HIPCHK(hipStreamSynchronize(st));

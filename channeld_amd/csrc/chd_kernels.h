@@ -89,6 +89,7 @@ struct WorldDev {
     uint64_t *rec_ub;     // [S+1] upper bound per subscriber -> exclusive scan = base of its record range
     uint32_t *rec_cnt;    // [S] records emitted for the connection (sum of its pair_nrec)
     chd_fanout_rec *recs; uint64_t recs_cap;
+    uint32_t *rec_mask;   // CHD_WORLD_UPDATE_MASKS only (else nullptr): per record, the buffered updates (ring slots) the message merges
     uint32_t *rec_pos;    // wire mode only (else nullptr): cell-table position of each record's entity, or CHD_POS_CELL | cell
     uint32_t *ce_slot;    // [N] entity slot of each cell-table entry (wire mode: payload lookup)
     chd_handover_rec *handovers; uint32_t handovers_cap;

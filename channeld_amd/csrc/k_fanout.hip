@@ -208,6 +208,30 @@ __device__ __forceinline__ bool cell_update_passes(uint32_t h, uint32_t snd, uin
     return (a != 0 && snd != conn) || (b != 0 && sndp != conn);
 }
 
+// ... and WHICH of them the message merges (CHD_WORLD_UPDATE_MASKS): non-zero exactly when cell_update_passes
+__device__ __forceinline__ uint32_t cell_update_mask(uint32_t h, uint32_t snd, uint32_t hp, uint32_t sndp, uint32_t wm,
+                                                     bool skip_self, uint32_t conn) {
+    const uint32_t a = h & wm, b = hp & wm;
+    if (!skip_self) return a | b;
+    return (snd != conn ? a : 0u) | (sndp != conn ? b : 0u);
+}
+
+// the buffered updates of one 16-byte entry that a window's message merges (data.go:242-256 per element:
+// arrival inside the window and, with SkipSelfUpdateFanOut, sender != connection); non-zero exactly when
+// entry_passes<false>
+__device__ __forceinline__ uint32_t entry_mask(const WorldDev &w, const u32x4 &e, uint32_t pos, bool in_range, uint32_t wm,
+                                               bool skip_self, uint32_t conn) {
+    const uint32_t a = e.y & wm, b2 = e.w & wm;
+    uint32_t m = a | b2;
+    if (skip_self) {
+        m = e.z != conn ? a : 0u;
+        if (__ballot(in_range && b2 != 0)) {
+            if (in_range && b2 != 0 && load_sprev(w, pos) != conn) m |= b2;
+        }
+    }
+    return in_range ? m : 0u;
+}
+
 // One window (or the full state) of one cell for one connection: stream the cell's
 // entries, 4 x 64 per step.  The four 16-byte loads are issued back to back from
 // one asm block (left to itself the compiler splits them into dwords, sinks pieces
@@ -234,10 +258,11 @@ __device__ __forceinline__ bool entry_passes(const WorldDev &w, const u32x4 &e, 
 // are ~90 % busy), so the common case is made cheap: when all 128 entries of a pair-row pass, each
 // lane writes its two records with ONE 16-byte store at out[n_out + 2*lane] and no rank arithmetic;
 // otherwise ballot/mbcnt compaction keeps entry order.
-template <bool FULL>
+template <bool FULL, bool MASKS = false>
 __device__ __forceinline__ uint32_t emit_cell(const WorldDev &w, const uint4 *__restrict__ ce, uint32_t start, uint32_t end,
                                               uint32_t wm, bool skip_self, uint32_t conn, uint32_t conn_tag,
-                                              chd_fanout_rec *__restrict__ out, uint32_t *__restrict__ opos, uint32_t n_out) {
+                                              chd_fanout_rec *__restrict__ out, uint32_t *__restrict__ opos, uint32_t n_out,
+                                              uint32_t *__restrict__ omask = nullptr) {
     static_assert(FO_UNROLL == 8 || FO_UNROLL == 4, "the load blocks below name eight / four entries");
     const uint32_t lane = lane_id();
     for (uint32_t b = start; b < end; b += 64 * FO_UNROLL) {
@@ -286,8 +311,17 @@ __device__ __forceinline__ uint32_t emit_cell(const WorldDev &w, const uint4 *__
             // is then the pair's second entry unless pos == q
             const uint32_t q = in1 ? pos : (end >= start + 2 ? end - 2 : start);
             const u32x4 ea = pos == q ? e[2 * j] : e[2 * j + 1];
-            const bool pass0 = entry_passes<FULL>(w, ea, pos, in0, wm, skip_self, conn);
-            const bool pass1 = entry_passes<FULL>(w, e[2 * j + 1], pos + 1, in1, wm, skip_self, conn);
+            bool pass0, pass1;
+            uint32_t mk0 = 0, mk1 = 0;  // MASKS: the buffered updates each message merges
+            if (MASKS && !FULL) {
+                mk0 = entry_mask(w, ea, pos, in0, wm, skip_self, conn);
+                mk1 = entry_mask(w, e[2 * j + 1], pos + 1, in1, wm, skip_self, conn);
+                pass0 = mk0 != 0;
+                pass1 = mk1 != 0;
+            } else {
+                pass0 = entry_passes<FULL>(w, ea, pos, in0, wm, skip_self, conn);
+                pass1 = entry_passes<FULL>(w, e[2 * j + 1], pos + 1, in1, wm, skip_self, conn);
+            }
             const uint64_t m0 = __ballot(pass0), m1 = __ballot(pass1);
             if ((m0 & m1) == ~0ull) {
                 // all 128 entries pass: records of the row are contiguous, two per lane
@@ -295,6 +329,7 @@ __device__ __forceinline__ uint32_t emit_cell(const WorldDev &w, const uint4 *__
                 r.x = conn_tag; r.y = ea.x; r.z = conn_tag; r.w = e[2 * j + 1].x;
                 *(u32x4 *)(void *)(out + n_out + 2 * lane) = r;
                 if (opos) { opos[n_out + 2 * lane] = pos; opos[n_out + 2 * lane + 1] = pos + 1; }
+                if (MASKS) { omask[n_out + 2 * lane] = mk0; omask[n_out + 2 * lane + 1] = mk1; }
                 n_out += 128;
             } else {
                 // entry order: records before this lane's pair = passing entries of lower lanes
@@ -306,6 +341,7 @@ __device__ __forceinline__ uint32_t emit_cell(const WorldDev &w, const uint4 *__
                     r.channel = ea.x;
                     out[at] = r;
                     if (opos) opos[at] = pos;
+                    if (MASKS) omask[at] = mk0;
                 }
                 if (pass1) {
                     chd_fanout_rec r;
@@ -313,6 +349,7 @@ __device__ __forceinline__ uint32_t emit_cell(const WorldDev &w, const uint4 *__
                     r.channel = e[2 * j + 1].x;
                     out[at + (pass0 ? 1u : 0u)] = r;
                     if (opos) opos[at + (pass0 ? 1u : 0u)] = pos + 1;
+                    if (MASKS) omask[at + (pass0 ? 1u : 0u)] = mk1;
                 }
                 n_out += (uint32_t)__popcll(m0) + (uint32_t)__popcll(m1);
             }
@@ -325,10 +362,11 @@ __device__ __forceinline__ uint32_t emit_cell(const WorldDev &w, const uint4 *__
 // the cell come from one sender (the usual case: the spatial server that owns the cell), so the
 // SkipSelfUpdateFanOut test is one scalar compare per subscription and the L2 read volume halves.
 // A lane's adjacent entry pair is ONE 16-byte load; a step covers 512 entries with four loads.
-template <bool FULL>
+template <bool FULL, bool MASKS = false>
 __device__ __forceinline__ uint32_t emit_cell8(const uint2 *__restrict__ ce8, uint32_t start, uint32_t end, uint32_t wm,
                                                uint32_t conn_tag, chd_fanout_rec *__restrict__ out,
-                                               uint32_t *__restrict__ opos, uint32_t n_out) {
+                                               uint32_t *__restrict__ opos, uint32_t n_out,
+                                               uint32_t *__restrict__ omask = nullptr) {
     const uint32_t lane = lane_id();
     for (uint32_t b = start; b < end; b += 128 * FO_UNROLL8) {
         u32x4 e[FO_UNROLL8];
@@ -372,6 +410,7 @@ __device__ __forceinline__ uint32_t emit_cell8(const uint2 *__restrict__ ce8, ui
                 r.x = conn_tag; r.y = chan_a; r.z = conn_tag; r.w = e[j].z;
                 *(u32x4 *)(void *)(out + n_out + 2 * lane) = r;
                 if (opos) { opos[n_out + 2 * lane] = pos; opos[n_out + 2 * lane + 1] = pos + 1; }
+                if (MASKS) { omask[n_out + 2 * lane] = FULL ? 0u : (hist_a & wm); omask[n_out + 2 * lane + 1] = FULL ? 0u : (e[j].w & wm); }
                 n_out += 128;
             } else {
                 const uint32_t at = __builtin_amdgcn_mbcnt_hi((uint32_t)(m1 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m1,
@@ -382,6 +421,7 @@ __device__ __forceinline__ uint32_t emit_cell8(const uint2 *__restrict__ ce8, ui
                     r.channel = chan_a;
                     out[at] = r;
                     if (opos) opos[at] = pos;
+                    if (MASKS) omask[at] = FULL ? 0u : (hist_a & wm);
                 }
                 if (pass1) {
                     chd_fanout_rec r;
@@ -389,6 +429,7 @@ __device__ __forceinline__ uint32_t emit_cell8(const uint2 *__restrict__ ce8, ui
                     r.channel = e[j].z;
                     out[at + (pass0 ? 1u : 0u)] = r;
                     if (opos) opos[at + (pass0 ? 1u : 0u)] = pos + 1;
+                    if (MASKS) omask[at + (pass0 ? 1u : 0u)] = FULL ? 0u : (e[j].w & wm);
                 }
                 n_out += (uint32_t)__popcll(m0) + (uint32_t)__popcll(m1);
             }
@@ -404,7 +445,8 @@ __device__ __forceinline__ uint32_t emit_cell8(const uint2 *__restrict__ ce8, ui
 // message of traffic.
 __device__ __forceinline__ uint32_t emit_cell_all(const uint32_t *__restrict__ chans, uint32_t start, uint32_t end,
                                                   uint32_t conn_tag, chd_fanout_rec *__restrict__ out,
-                                                  uint32_t *__restrict__ opos, uint32_t n_out) {
+                                                  uint32_t *__restrict__ opos, uint32_t n_out,
+                                                  uint32_t *__restrict__ omask = nullptr) {
     const uint32_t lane = lane_id();
     const uint32_t n = end - start;
     // Measured on MI355X, config B: batching several steps' loads before the first store was slower (219 vs 198 us
@@ -425,6 +467,11 @@ __device__ __forceinline__ uint32_t emit_cell_all(const uint32_t *__restrict__ c
                 p4.x = start + k; p4.y = start + k + 1; p4.z = start + k + 2; p4.w = start + k + 3;
                 *(u32x4 *)(void *)(opos + n_out + k) = p4;
             }
+            if (omask) {  // (full-state records merge nothing: the only caller that passes masks)
+                u32x4 z4;
+                z4.x = 0; z4.y = 0; z4.z = 0; z4.w = 0;
+                *(u32x4 *)(void *)(omask + n_out + k) = z4;
+            }
         } else {
             for (uint32_t q = k; q < n && q < k + 4; q++) {
                 chd_fanout_rec r;
@@ -432,6 +479,7 @@ __device__ __forceinline__ uint32_t emit_cell_all(const uint32_t *__restrict__ c
                 r.channel = chans[start + q];
                 out[n_out + q] = r;
                 if (opos) opos[n_out + q] = start + q;
+                if (omask) omask[n_out + q] = 0;
             }
         }
     }
@@ -442,7 +490,7 @@ __device__ __forceinline__ uint32_t emit_cell_all(const uint32_t *__restrict__ c
 // WAVES waves per connection (= subscriptions staged in LDS per round / 64).  Measured at config B (10 K connections,
 // ~18 due subscriptions each): 192.8 / 194.4 / 196.8 / 227 us per launch with 1 / 2 / 4 / 8 waves; the launcher takes
 // one wave per connection when there are enough connections to fill the chip that way, four otherwise.
-template <int WAVES>
+template <int WAVES, bool MASKS>
 __global__ void __launch_bounds__(64 * WAVES) k_fanout_emit(DevGrid g, WorldDev w, int64_t now, TickRing ring) {
     constexpr uint32_t FO_TILE = 64 * WAVES;
     // due subscriptions of this connection, staged once per workgroup so that the
@@ -529,6 +577,8 @@ __global__ void __launch_bounds__(64 * WAVES) k_fanout_emit(DevGrid g, WorldDev 
             chd_fanout_rec *__restrict__ out = w.recs + base + d_rel[k];
             // wire mode: which cell-table entry (or, with bit 31, which spatial channel) each record came from
             uint32_t *__restrict__ opos = w.rec_pos ? w.rec_pos + base + d_rel[k] : nullptr;
+            // CHD_WORLD_UPDATE_MASKS: which buffered updates each record's message merges
+            uint32_t *__restrict__ omask = MASKS ? w.rec_mask + base + d_rel[k] : nullptr;
             uint32_t n_out = 0;
             if (!(fl & PF_HAD_FIRST)) {
                 // first fan-out: the whole data of the spatial channel and of every
@@ -539,9 +589,10 @@ __global__ void __launch_bounds__(64 * WAVES) k_fanout_emit(DevGrid g, WorldDev 
                     r.channel = c + g.id_start;
                     out[0] = r;
                     if (opos) opos[0] = CHD_POS_CELL | c;
+                    if (MASKS) omask[0] = 0;
                 }
-                n_out = w.ce_chan_view ? emit_cell_all(w.ce_chan_view, start, end, conn | CHD_REC_FULL, out, opos, 1u)
-                                       : emit_cell<true>(w, ce, start, end, 0u, false, conn, conn | CHD_REC_FULL, out, opos, 1u);
+                n_out = w.ce_chan_view ? emit_cell_all(w.ce_chan_view, start, end, conn | CHD_REC_FULL, out, opos, 1u, omask)
+                                       : emit_cell<true, MASKS>(w, ce, start, end, 0u, false, conn, conn | CHD_REC_FULL, out, opos, 1u, omask);
                 fl |= PF_HAD_FIRST;
                 L = now;
             }
@@ -567,13 +618,14 @@ __global__ void __launch_bounds__(64 * WAVES) k_fanout_emit(DevGrid g, WorldDev 
                                 r.channel = c + g.id_start;
                                 out[n_out] = r;
                                 if (opos) opos[n_out] = CHD_POS_CELL | c;
+                                if (MASKS) omask[n_out] = cell_update_mask(ch_hist, ch_sender, d_chhp[k], d_chsp[k], wm, skip_self, conn);
                             }
                             n_out += 1;
                         }
-                        if (us == CHD_NONUNIFORM) n_out = emit_cell<false>(w, ce, start, end, wm, skip_self, conn, conn, out, opos, n_out);
+                        if (us == CHD_NONUNIFORM) n_out = emit_cell<false, MASKS>(w, ce, start, end, wm, skip_self, conn, conn, out, opos, n_out, omask);
                         else if (!(skip_self && us == conn))
-                            n_out = (d_hand[k] & wm) ? emit_cell_all(w.ce_chan_view, start, end, conn, out, opos, n_out)
-                                                     : emit_cell8<false>(w.ce8_view, start, end, wm, conn, out, opos, n_out);
+                            n_out = (!MASKS && (d_hand[k] & wm)) ? emit_cell_all(w.ce_chan_view, start, end, conn, out, opos, n_out)
+                                                                 : emit_cell8<false, MASKS>(w.ce8_view, start, end, wm, conn, out, opos, n_out, omask);
                     }
                     L = next;
                 }
@@ -1091,8 +1143,11 @@ void launch_fanout_emit(hipStream_t st, DevGrid g, WorldDev w, int64_t now_ns, T
         hipLaunchKernelGGL(k_fanout_items, dim3(pgrid), dim3(WS_SUBS), 0, st, g, w, now_ns, ring, chunks);
         hipLaunchKernelGGL(k_fanout_emit_ws, dim3(grid), dim3(64 * WS_WAVES), 0, st, g, w, now_ns, ring, chunks);
     } else {
-        if (w.S >= 4096) hipLaunchKernelGGL(k_fanout_emit<1>, dim3(w.S), dim3(64), 0, st, g, w, now_ns, ring);
-        else hipLaunchKernelGGL(k_fanout_emit<4>, dim3(w.S), dim3(256), 0, st, g, w, now_ns, ring);
+        if (w.rec_mask) {
+            if (w.S >= 4096) hipLaunchKernelGGL((k_fanout_emit<1, true>), dim3(w.S), dim3(64), 0, st, g, w, now_ns, ring);
+            else hipLaunchKernelGGL((k_fanout_emit<4, true>), dim3(w.S), dim3(256), 0, st, g, w, now_ns, ring);
+        } else if (w.S >= 4096) hipLaunchKernelGGL((k_fanout_emit<1, false>), dim3(w.S), dim3(64), 0, st, g, w, now_ns, ring);
+        else hipLaunchKernelGGL((k_fanout_emit<4, false>), dim3(w.S), dim3(256), 0, st, g, w, now_ns, ring);
     }
 }
 

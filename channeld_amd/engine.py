@@ -39,6 +39,7 @@ class TickResult:
     n_records: int
     overflow: int
     history_overflow: int
+    record_masks: Optional[np.ndarray] = None  # CHD_WORLD_UPDATE_MASKS worlds: uint32 per record (bit j = update of tick cur-j)
 
     def records_of(self, slot: int) -> np.ndarray:
         a = int(self.conn_rec_off[slot])
@@ -78,6 +79,7 @@ class SpatialWorld:
         self.lib = _lib.load()
         self.ctx = ctl.ctx
         self.N, self.S = int(max_entities), int(max_subscribers)
+        self.flags = int(flags)
         ncell = ctl.GridCols * ctl.GridRows
         self.capq = int(max_interest_cells) if max_interest_cells else min(ncell, 256)
         cfg = WorldCfg(self.N, self.S, self.capq, int(max_records), int(max_handovers), int(flags),
@@ -132,6 +134,10 @@ class SpatialWorld:
             o.records_cap = len(self._o_rec)
         else:
             self._o_rec = None
+        self._o_mask = None
+        if want_records and (self.flags & _lib.WORLD_UPDATE_MASKS):
+            self._o_mask = np.zeros(max(records_cap, 1), dtype=np.uint32)
+            o.record_masks = _ptr(self._o_mask)
         return o
 
     def _result(self, o: TickOut, n_queries: int) -> TickResult:
@@ -143,7 +149,8 @@ class SpatialWorld:
             newsub_interval_ms=self._o_ni[: o.n_newsubs].copy(),
             records=None if self._o_rec is None else self._o_rec[: int(o.n_records)],
             conn_rec_off=self._o_off, conn_rec_cnt=self._o_cnt, n_records=int(o.n_records),
-            overflow=int(o.overflow), history_overflow=int(o.history_overflow))
+            overflow=int(o.overflow), history_overflow=int(o.history_overflow),
+            record_masks=None if self._o_mask is None else self._o_mask[: int(o.n_records)])
 
     def tick(self, now_ns: int, upd_idx=None, upd_x=None, upd_z=None, upd_sender=None,
              cell_upd_channel=None, cell_upd_sender=None, query_sub=None,

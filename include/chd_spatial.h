@@ -36,7 +36,7 @@
 extern "C" {
 #endif
 
-#define CHD_ABI_VERSION 3
+#define CHD_ABI_VERSION 4
 
 typedef struct chd_ctx chd_ctx;
 
@@ -184,6 +184,12 @@ typedef struct {
  * BASELINE config B the two cross-stream dependencies cost what the overlap saves (0.3145 vs 0.3123 ms per tick);
  * it pays when the interest stage is long (many / large AOI queries).  Ignored with CHD_WORLD_HANDOVER_RECIPIENTS. */
 #define CHD_WORLD_OVERLAP_INTEREST 16u
+/* also say, per fan-out record, WHICH buffered updates the message merges (chd_tick_out.record_masks): the selection
+ * of data.go:225-269 — arrival inside the subscription's window and, with SkipSelfUpdateFanOut, sender != connection —
+ * as a mask over the tick ring, bit j = the update that arrived with tick (current - j).  The host (or the wire builder)
+ * merges exactly those into the accumulated update, so slow subscribers get correct merged deltas.
+ * +4 B per record; windows every entity passes are then streamed with their histories instead of as a plain copy. */
+#define CHD_WORLD_UPDATE_MASKS 32u
 
 #define CHD_ENTITY_LOCKED 1u /* member of a non-empty lock group (entity.go:197-224) */
 
@@ -262,6 +268,8 @@ typedef struct {
     uint32_t overflow;                 /* !=0: some output was truncated (CHD_E_CAPACITY) */
     uint32_t history_overflow;         /* windows reaching beyond the 32-tick update history, or channels
                                           updated by more than two senders inside it (results then inexact) */
+    uint32_t *record_masks;            /* optional, records_cap entries, parallel to `records`: CHD_WORLD_UPDATE_MASKS
+                                          worlds only (else ignored); 0 for CHD_REC_FULL records */
 } chd_tick_out;
 
 /* replaces, for the whole world in one call: Notify (spatial.go:612-736,

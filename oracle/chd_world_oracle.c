@@ -47,6 +47,8 @@ typedef struct {
 typedef struct {
     uint32_t conn; /* bit31 = full */
     uint32_t chan;
+    uint32_t mask; /* window mode: which buffered updates the message merges, bit j = the one that arrived with
+                      tick (current - j); 0 for the full state */
 } wrec;
 
 typedef struct {
@@ -85,6 +87,7 @@ typedef struct orc_world {
     uint32_t *server_of_cell;
     int threads;
     struct fan_job_s *jobs; int njobs; /* per-thread record buffers, kept across ticks */
+    orc_time stamps[32]; uint32_t nstamps; /* channel times of the last 32 ticks, newest first */
 } orc_world;
 
 static void wbuf_push(wbuf *b, orc_time t, uint32_t sender, uint32_t max_interval_ms) {
@@ -203,8 +206,9 @@ static void push_rec(orc_world *w, uint32_t conn, uint32_t chan) {
 }
 
 /* literal buffer walk of data.go:225-269 for one (subscriber, window) */
-static int window_has_update(const wbuf *b, orc_time last, orc_time next,
-                             uint32_t conn, int skip_self) {
+static int window_has_update(const orc_world *w, const wbuf *b, orc_time last, orc_time next,
+                             uint32_t conn, int skip_self, uint32_t *mask) {
+    *mask = 0;
     if (b->len == 0) return 0; /* bufp == nil */
     orc_time last_update_time = 0;
     if (last >= last_update_time) last_update_time = last;
@@ -213,8 +217,10 @@ static int window_has_update(const wbuf *b, orc_time last, orc_time next,
         const wupd *be = &b->v[b->head + i];
         if (be->sender == conn && skip_self) continue;
         if (be->arrival >= last_update_time && be->arrival <= next) {
-            merged = 1;
+            merged = 1; /* data.go:249-256: this element is merged into the accumulated update */
             last_update_time = be->arrival;
+            for (uint32_t j = 0; j < w->nstamps; j++)
+                if (w->stamps[j] == be->arrival) *mask |= 1u << j;
         }
     }
     return merged;
@@ -269,13 +275,14 @@ static void orc__free_jobs(orc_world *w) {
     w->njobs = 0;
 }
 
-static void job_push(fan_job *j, uint32_t conn, uint32_t chan) {
+static void job_push(fan_job *j, uint32_t conn, uint32_t chan, uint32_t mask) {
     if (j->nrec == j->caprec) {
         j->caprec = j->caprec ? j->caprec * 2 : 4096;
         j->rec = (wrec *)realloc(j->rec, j->caprec * sizeof(wrec));
     }
     j->rec[j->nrec].conn = conn;
     j->rec[j->nrec].chan = chan;
+    j->rec[j->nrec].mask = mask;
     j->nrec++;
 }
 
@@ -308,9 +315,10 @@ static void *fan_cells(void *arg) {
                 uint32_t conn = w->conn_id[subs[si].s];
                 uint32_t nw = pair_windows(&tmp, j->t, &wins, &wcap);
                 for (uint32_t wi = 0; wi < nw; wi++) {
-                    if (wins[wi].full) job_push(j, conn | REC_FULL, chan);
-                    else if (window_has_update(b, wins[wi].last, wins[wi].next, conn, tmp.skip_self))
-                        job_push(j, conn, chan);
+                    uint32_t mask = 0;
+                    if (wins[wi].full) job_push(j, conn | REC_FULL, chan, 0);
+                    else if (window_has_update(w, b, wins[wi].last, wins[wi].next, conn, tmp.skip_self, &mask))
+                        job_push(j, conn, chan, mask);
                 }
             }
         }
@@ -396,6 +404,9 @@ int orc_world_tick(orc_world *w, orc_time t, uint32_t n_upd, const uint32_t *idx
                    uint32_t n_cu, const uint32_t *cu_cell, const uint32_t *cu_sender,
                    uint32_t n_q, const uint32_t *q_sub, const orc_query *queries) {
     w->nrec = 0; w->nho = 0; w->nunsub = 0; w->n_locked_abort = 0; w->nrcp = 0;
+    memmove(w->stamps + 1, w->stamps, sizeof(orc_time) * 31);
+    w->stamps[0] = t;
+    if (w->nstamps < 32) w->nstamps++;
     /* is_new = "subscribed during the latest tick" */
     for (uint32_t s = 0; s < w->S; s++)
         for (uint32_t p = 0; p < w->pair_cnt[s]; p++) w->pairs[(size_t)s * w->capq + p].is_new = 0;
@@ -616,6 +627,16 @@ void orc_world_records(const orc_world *w, uint32_t *conn, uint32_t *chan) {
     uint64_t o = 0;
     for (int k = 0; k < w->njobs; k++)
         for (uint64_t i = 0; i < w->jobs[k].nrec; i++, o++) { conn[o] = w->jobs[k].rec[i].conn; chan[o] = w->jobs[k].rec[i].chan; }
+}
+/* window mode only: per record (same order as orc_world_records) the merged-updates mask */
+void orc_world_record_masks(const orc_world *w, uint32_t *mask) {
+    if (w->literal) {
+        memset(mask, 0, 4 * w->nrec);
+        return;
+    }
+    uint64_t o = 0;
+    for (int k = 0; k < w->njobs; k++)
+        for (uint64_t i = 0; i < w->jobs[k].nrec; i++, o++) mask[o] = w->jobs[k].rec[i].mask;
 }
 uint32_t orc_world_nhandover(const orc_world *w) { return w->nho; }
 void orc_world_handovers(const orc_world *w, uint32_t *ent, uint32_t *src, uint32_t *dst,

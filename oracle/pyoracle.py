@@ -124,6 +124,7 @@ def lib():
     L.orc_world_nrec.restype = C.c_uint64
     L.orc_world_nrec.argtypes = [C.c_void_p]
     L.orc_world_records.argtypes = [C.c_void_p, up, up]
+    L.orc_world_record_masks.argtypes = [C.c_void_p, up]
     L.orc_world_nhandover.restype = C.c_uint32
     L.orc_world_nhandover.argtypes = [C.c_void_p]
     L.orc_world_handovers.argtypes = [C.c_void_p, up, up, up, up, up]
@@ -405,6 +406,13 @@ class World:
         chan = np.zeros(max(n, 1), dtype=np.uint32)
         lib().orc_world_records(self.h, _p(conn, C.c_uint32), _p(chan, C.c_uint32))
         return conn[:n], chan[:n]
+
+    def record_masks(self):
+        """window mode: per record of records() the merged-updates mask (bit j = the update of tick current - j)"""
+        n = lib().orc_world_nrec(self.h)
+        m = np.zeros(max(n, 1), dtype=np.uint32)
+        lib().orc_world_record_masks(self.h, _p(m, C.c_uint32))
+        return m[:n]
 
     def handovers(self):
         n = lib().orc_world_nhandover(self.h)

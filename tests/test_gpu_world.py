@@ -53,6 +53,12 @@ def compare_tick(k, res, ow, S, id_start=0x10000, check_pairs=None, gw=None):
     assert res.n_records == len(oc), f"tick {k}: {res.n_records} records vs oracle {len(oc)}"
     assert np.array_equal(canon(res.records["conn"], res.records["channel"]), canon(oc, och)), f"tick {k}: records"
     assert res.overflow == 0 and res.history_overflow == 0
+    if res.record_masks is not None:
+        # CHD_WORLD_UPDATE_MASKS: (connection, channel, merged-updates mask) triples as multisets
+        om = ow.record_masks()
+        key = lambda c, ch, m: np.sort(np.rec.fromarrays([c, ch, m], names="c,ch,m"), order=["c", "ch", "m"])
+        got, want = key(res.records["conn"], res.records["channel"], res.record_masks), key(oc, och, om)
+        assert np.array_equal(got, want), f"tick {k}: merged-update masks"
     # records are grouped per connection slot
     assert int(res.conn_rec_off[S]) == res.n_records
     if check_pairs is not None:
@@ -171,6 +177,20 @@ def test_world_interest_on_second_stream(amd):
     assert total > 50000 and n_ho > 0
 
 
+def test_world_update_masks(amd, emit_mode):
+    # per message, the buffered updates it merges (window x SkipSelfUpdateFanOut selection of
+    # data.go:225-269) - slow ticks so that 20 / 50 / 100 ms subscriptions merge different sets; sparse updates so
+    # that histories differ per entity; connection-major emit only
+    if emit_mode == "cell-major":
+        pytest.skip("update masks are written by the connection-major emit")
+    from channeld_amd import _lib
+
+    for cfg_name, tick_ms, seed in (("spatial_static_benchmark.json", 70, 0xC0FFEE0B), ("spatial_static_4x4.json", 33, 0xC0FFEE0C)):
+        total, n_ho = run_world(amd, cfg_name, 2500, 150, 14, seed, tick_ms=tick_ms, sparse=True,
+                                extra_flags=_lib.WORLD_UPDATE_MASKS)
+        assert total > 20000
+
+
 def test_world_long_pauses_fold_empty_windows(amd):
     # ticks 5, 11 and 12 arrive 90 s, 7.3 s and 61 ms late: thousands of empty fan-out windows lie between the
     # buffered stamps; the kernels fold them (empty_windows), the oracle walks every one of them
@@ -229,12 +249,24 @@ def test_world_despawn_lock_and_remove_subscriber(amd):
     assert np.array_equal(cell[live], to_id(ocell)[live]) and np.array_equal(member[live], to_id(omember)[live])
 
 
-def test_cell_channel_updates_and_self_skip(amd):
+def mask_variants(emit_mode):
+    """world flags to run a scenario with: plain, and with update masks where the emit form writes them"""
+    from channeld_amd import _lib
+
+    return (0, _lib.WORLD_UPDATE_MASKS) if emit_mode == "conn-major" else (0,)
+
+
+def test_cell_channel_updates_and_self_skip(amd, emit_mode):
+    for extra in mask_variants(emit_mode):
+        cell_channel_updates_and_self_skip(amd, extra)
+
+
+def cell_channel_updates_and_self_skip(amd, extra_flags):
     # spatial-channel data updates sent by a subscriber itself are not fanned back to it
     cfg = synth.load_config("spatial_static_2x2.json")
     g = orc.grid_from_config(cfg)
     N, S = 16, 3
-    ctl, gw = make(amd, cfg, N, S)
+    ctl, gw = make(amd, cfg, N, S, extra_flags=extra_flags)
     ow = orc.World(g, N, S, gw.capq, 20, 0)
     x = np.full(N, 500.0)
     z = np.full(N, 500.0)
@@ -267,7 +299,12 @@ def test_cell_channel_updates_and_self_skip(amd):
     assert seen_delta[9] > seen_delta[7] > 0 and seen_delta[9] > seen_delta[8] > 0
 
 
-def test_changing_senders_keep_per_update_self_skip(amd):
+def test_changing_senders_keep_per_update_self_skip(amd, emit_mode):
+    for extra in mask_variants(emit_mode):
+        changing_senders_keep_per_update_self_skip(amd, extra)
+
+
+def changing_senders_keep_per_update_self_skip(amd, extra_flags):
     """SkipSelfUpdateFanOut compares each BUFFERED update's senderConnId with the subscriber
     (data.go:242-245).  Entities are updated by connection 7 on some ticks and 8 on others
     (an ownership change); subscribers 7 and 8 must each miss exactly their own updates, also
@@ -275,7 +312,7 @@ def test_changing_senders_keep_per_update_self_skip(amd):
     cfg = synth.load_config("spatial_static_2x2.json")
     g = orc.grid_from_config(cfg)
     N, S = 40, 3
-    ctl, gw = make(amd, cfg, N, S)
+    ctl, gw = make(amd, cfg, N, S, extra_flags=extra_flags)
     ow = orc.World(g, N, S, gw.capq, 20, 0)
     rng = np.random.default_rng(5)
     x = rng.uniform(-1900, 1900, N)
