@@ -276,6 +276,8 @@ __device__ __forceinline__ T wave_incl_scan(T v) {
     return v;
 }
 
+// elements per lane and pass.  (16 - one pass for the 10 K per-connection totals instead of three - measured slower:
+// 11.5 vs 6.9 us, a lane's 16 consecutive u64 are a 128-byte stride between lanes.)
 #define SCAN_ITEMS 4
 template <typename T>
 __global__ void __launch_bounds__(1024) k_scan_excl(const T *in, T *out, uint32_t n, const uint32_t *n_dev) {
@@ -285,7 +287,7 @@ __global__ void __launch_bounds__(1024) k_scan_excl(const T *in, T *out, uint32_
     const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     if (threadIdx.x == 0) carry_s = 0;
     __syncthreads();
-    // each lane owns SCAN_ITEMS consecutive elements of a 4096-element tile
+    // each lane owns SCAN_ITEMS consecutive elements of a (1024 x SCAN_ITEMS)-element tile
     for (uint32_t base = 0; base < n; base += 1024 * SCAN_ITEMS) {
         const uint32_t i0 = base + threadIdx.x * SCAN_ITEMS;
         T v[SCAN_ITEMS];
