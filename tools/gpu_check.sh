@@ -11,6 +11,6 @@ timeout -s KILL 400 python bench.py "$@" > $O/bench.json 2> $O/bench.err
 cd /tmp && export TMPDIR=/tmp
 timeout -s KILL 300 rocprofv3 --kernel-trace --stats -d $O/prof -o kt -- python $R/bench.py --steps 50 --warmup 10 --no-cpu --latency-steps 0 > $O/prof_bench.json 2> $O/prof.err
 cd $R
-python tools/rocpd_summary.py $O/prof/kt_results.db > $O/kernel_stats.csv 2>> $O/prof.err
+python tools/rocpd_summary.py $O/prof/kt_results.db 10 > $O/kernel_stats.csv 2>> $O/prof.err
 rm -rf $O/prof
 tail -3 $O/pytest_gpu.log; cat $O/bench.json; head -8 $O/kernel_stats.csv
