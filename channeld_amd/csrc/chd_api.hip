@@ -545,6 +545,9 @@ int chd_world_create(chd_ctx *ctx, const chd_world_cfg *cfg) {
     TRY(walloc(ctx, &d.ce_sprev, N));
     TRY(walloc(ctx, &d.ce8, N + 2));
     TRY(walloc(ctx, &d.cell_usender, C));
+    TRY(walloc(ctx, &d.cell_smin, C));
+    TRY(walloc(ctx, &d.cell_smax, C));
+    HIPCHK(hipMemset(d.cell_smax, 0xFF, sizeof(uint32_t) * C));  // until the first index build: every id may be a sender
     TRY(walloc(ctx, &d.blk_smin, C * d.nblk + 1));
     TRY(walloc(ctx, &d.blk_smax, C * d.nblk + 1));
     TRY(walloc(ctx, &d.blk_hand, C * d.nblk + 1));

@@ -13,6 +13,7 @@
 #define CHD_ABSENT 0xFFFFFFFFu
 #define CHD_POS_CELL 0x80000000u     // rec_pos: the record is the spatial channel's own message, low bits = cell
 #define CHD_NONUNIFORM 0xFFFFFFFFu  // cell_usender: the cell's buffered updates come from more than one sender
+#define CHD_NOT_A_SENDER 0xFFFFFFFEu  // (emit, per connection) ... but this connection is none of them: no per-sender test needed
 #define CHD_WAVE 64
 #define CHD_HIST_BITS 32
 

@@ -48,6 +48,7 @@ struct WorldDev {
     uint32_t *ce_sprev;   // [N] previous sender (read only where its history intersects a window)
     uint2 *ce8;           // [N] compact entries {entity channel id, history of any sender} for single-sender cells
     uint32_t *cell_usender;           // [ncell] the one sender of the cell's buffered updates, or CHD_NONUNIFORM
+    uint32_t *cell_smin, *cell_smax;  // [ncell] range of the sender ids behind the cell's buffered updates (a connection outside it sent none of them)
     uint32_t *blk_smin, *blk_smax, *blk_hand;  // [ncell*nblk] per-block sender range / AND of histories (index build intermediates)
     uint32_t *cell_hand;              // [ncell] AND of the histories of the cell's entities (aligned to this tick)
     uint32_t *ce_chan;                // [N + 4] the entity channel ids alone, cell-sorted: what an all-pass window copies

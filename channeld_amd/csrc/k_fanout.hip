@@ -38,6 +38,18 @@
 // tables read; no MFMA — this is gather/compaction, not a contraction.
 #include "chd_kernels.h"
 
+// -DCHD_PROFILE_CONN_EMIT: per-phase cycle counts of a few sampled workgroups of the connection-major emit kernel,
+// printed at tick 60 (where do the waves wait?  PC sampling / thread trace are not available on this pool)
+#ifdef CHD_PROFILE_CONN_EMIT
+#define CE_MARK(acc) do { long long _t = clock64(); (acc) += _t - ce_mark; ce_mark = _t; } while (0)
+#define CE_WAIT_VM() asm volatile("s_waitcnt vmcnt(0)" ::: "memory")
+#define CE_WAIT_LGKM() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
+#else
+#define CE_MARK(acc) do { } while (0)
+#define CE_WAIT_VM() do { } while (0)
+#define CE_WAIT_LGKM() do { } while (0)
+#endif
+
 #ifndef FO_WAVES
 #define FO_WAVES 4
 #endif
@@ -47,6 +59,9 @@
 #endif
 #ifndef FO_UNROLL8
 #define FO_UNROLL8 2
+#endif
+#ifndef FO_COPY_AHEAD
+#define FO_COPY_AHEAD 0
 #endif
 
 // stamp of ring slot `lane` (INT64_MAX for unused slots): loaded once per wave
@@ -446,46 +461,113 @@ __device__ __forceinline__ uint32_t emit_cell8(const uint2 *__restrict__ ce8, ui
 __device__ __forceinline__ uint32_t emit_cell_all(const uint32_t *__restrict__ chans, uint32_t start, uint32_t end,
                                                   uint32_t conn_tag, chd_fanout_rec *__restrict__ out,
                                                   uint32_t *__restrict__ opos, uint32_t n_out,
-                                                  uint32_t *__restrict__ omask = nullptr) {
+                                                  uint32_t *__restrict__ omask = nullptr, long long *ce_prof = nullptr) {
     const uint32_t lane = lane_id();
     const uint32_t n = end - start;
-    // Measured on MI355X, config B: batching several steps' loads before the first store was slower (219 vs 198 us
-    // per launch), and so was giving every lane two adjacent records per row so that each store instruction writes
-    // one contiguous 1 KiB run (217 vs 200 us: twice the load instructions for the same stores).
+#ifdef CHD_PROFILE_CONN_EMIT
+    if (ce_prof) ce_prof[2] = clock64();  // [0] load wait, [1] store issue, [2] running mark
+#endif
+    // Measured on MI355X, config B: giving every lane two adjacent records per row so that each store instruction
+    // writes one contiguous 1 KiB run was slower (217 vs 200 us: twice the load instructions for the same stores).
+    // The lane that holds the cell's last 1-3 entries takes the SAME 16-byte load as everyone else (the column has
+    // spare entries behind it) and only narrows its stores: a separate load for it came after the step's record
+    // stores and, the vm counter being in-order, waited for all of them to drain (~6.6 K of ~13 K cycles per segment
+    // in the per-phase profile, -DCHD_PROFILE_CONN_EMIT).
+#if FO_COPY_AHEAD
+    // both steps of a cell of up to 512 entries are loaded before the first store, for the same reason
+    if (n <= 512) {
+        const uint32_t k0 = 4 * lane, k1 = 256 + 4 * lane;
+        u32x4 c[2];
+        c[0] = *(const u32x4 *)(const void *)(chans + start + (k0 < n ? k0 : 0));
+        c[1] = *(const u32x4 *)(const void *)(chans + start + (k1 < n ? k1 : 0));
+#pragma unroll
+        for (int h = 0; h < 2; h++) {
+            const uint32_t k = h ? k1 : k0;
+            if (k >= n) continue;
+            const u32x4 c4 = c[h];
+            const uint32_t m = n - k;
+            if (m >= 4) {
+                u32x4 r0, r1;
+                r0.x = conn_tag; r0.y = c4.x; r0.z = conn_tag; r0.w = c4.y;
+                r1.x = conn_tag; r1.y = c4.z; r1.z = conn_tag; r1.w = c4.w;
+                u32x4 *o = (u32x4 *)(void *)(out + n_out + k);
+                o[0] = r0;
+                o[1] = r1;
+                if (opos) {
+                    u32x4 p4;
+                    p4.x = start + k; p4.y = start + k + 1; p4.z = start + k + 2; p4.w = start + k + 3;
+                    *(u32x4 *)(void *)(opos + n_out + k) = p4;
+                }
+                if (omask) {
+                    u32x4 z4;
+                    z4.x = 0; z4.y = 0; z4.z = 0; z4.w = 0;
+                    *(u32x4 *)(void *)(omask + n_out + k) = z4;
+                }
+            } else {
+                const uint32_t cc[3] = {c4.x, c4.y, c4.z};
+#pragma unroll
+                for (uint32_t q = 0; q < 3; q++) {
+                    if (q < m) {
+                        chd_fanout_rec r;
+                        r.conn = conn_tag;
+                        r.channel = cc[q];
+                        out[n_out + k + q] = r;
+                        if (opos) opos[n_out + k + q] = start + k + q;
+                        if (omask) omask[n_out + k + q] = 0;
+                    }
+                }
+            }
+        }
+        return n_out + n;
+    }
+#endif
     for (uint32_t b = 0; b < n; b += 256) {
         const uint32_t k = b + 4 * lane;      // this lane's first entry of the step, relative to start
-        if (k + 4 <= n) {
-            const u32x4 c4 = *(const u32x4 *)(const void *)(chans + start + k);
-            u32x4 r0, r1;
-            r0.x = conn_tag; r0.y = c4.x; r0.z = conn_tag; r0.w = c4.y;
-            r1.x = conn_tag; r1.y = c4.z; r1.z = conn_tag; r1.w = c4.w;
-            u32x4 *o = (u32x4 *)(void *)(out + n_out + k);
-            o[0] = r0;
-            o[1] = r1;
-            if (opos) {
-                u32x4 p4;
-                p4.x = start + k; p4.y = start + k + 1; p4.z = start + k + 2; p4.w = start + k + 3;
-                *(u32x4 *)(void *)(opos + n_out + k) = p4;
+        if (k < n) {
+            const u32x4 c4 = *(const u32x4 *)(const void *)(chans + start + k);  // (up to 3 entries past the cell)
+#ifdef CHD_PROFILE_CONN_EMIT
+            asm volatile("s_waitcnt vmcnt(0)" : : "v"(c4) : "memory");
+            if (ce_prof) { long long _t = clock64(); ce_prof[0] += _t - ce_prof[2]; ce_prof[2] = _t; }
+#endif
+            const uint32_t m = n - k;             // entries of the cell this lane holds (>= 1)
+            if (m >= 4) {
+                u32x4 r0, r1;
+                r0.x = conn_tag; r0.y = c4.x; r0.z = conn_tag; r0.w = c4.y;
+                r1.x = conn_tag; r1.y = c4.z; r1.z = conn_tag; r1.w = c4.w;
+                u32x4 *o = (u32x4 *)(void *)(out + n_out + k);
+                o[0] = r0;
+                o[1] = r1;
+                if (opos) {
+                    u32x4 p4;
+                    p4.x = start + k; p4.y = start + k + 1; p4.z = start + k + 2; p4.w = start + k + 3;
+                    *(u32x4 *)(void *)(opos + n_out + k) = p4;
+                }
+                if (omask) {  // (full-state records merge nothing: the only caller that passes masks)
+                    u32x4 z4;
+                    z4.x = 0; z4.y = 0; z4.z = 0; z4.w = 0;
+                    *(u32x4 *)(void *)(omask + n_out + k) = z4;
+                }
+            } else {
+                const uint32_t cc[3] = {c4.x, c4.y, c4.z};
+#pragma unroll
+                for (uint32_t q = 0; q < 3; q++) {
+                    if (q < m) {
+                        chd_fanout_rec r;
+                        r.conn = conn_tag;
+                        r.channel = cc[q];
+                        out[n_out + k + q] = r;
+                        if (opos) opos[n_out + k + q] = start + k + q;
+                        if (omask) omask[n_out + k + q] = 0;
+                    }
+                }
             }
-            if (omask) {  // (full-state records merge nothing: the only caller that passes masks)
-                u32x4 z4;
-                z4.x = 0; z4.y = 0; z4.z = 0; z4.w = 0;
-                *(u32x4 *)(void *)(omask + n_out + k) = z4;
-            }
-        } else {
-            for (uint32_t q = k; q < n && q < k + 4; q++) {
-                chd_fanout_rec r;
-                r.conn = conn_tag;
-                r.channel = chans[start + q];
-                out[n_out + q] = r;
-                if (opos) opos[n_out + q] = start + q;
-                if (omask) omask[n_out + q] = 0;
-            }
+#ifdef CHD_PROFILE_CONN_EMIT
+            if (ce_prof) { long long _t = clock64(); ce_prof[1] += _t - ce_prof[2]; ce_prof[2] = _t; }
+#endif
         }
     }
     return n_out + n;
 }
-
 
 // WAVES waves per connection (= subscriptions staged in LDS per round / 64).  Measured at config B (10 K connections,
 // ~18 due subscriptions each): 192.8 / 194.4 / 196.8 / 227 us per launch with 1 / 2 / 4 / 8 waves; the launcher takes
@@ -520,6 +602,10 @@ __global__ void __launch_bounds__(64 * WAVES) k_fanout_emit(DevGrid g, WorldDev 
         }
         return;
     }
+#ifdef CHD_PROFILE_CONN_EMIT
+    long long ce_mark = clock64(), ce_pro = 0, ce_stage = 0, ce_ticket = 0, ce_decide = 0, ce_stream = 0, ce_tail = 0, ce_ls[3] = {0, 0, 0};
+    uint32_t ce_nseg = 0;
+#endif
     const uint32_t conn = w.conn_id[s];
     const int64_t my_t = ring_stamp(ring);
     // (wave-uniform, but read through a dynamic index: keep it on the scalar side)
@@ -529,6 +615,8 @@ __global__ void __launch_bounds__(64 * WAVES) k_fanout_emit(DevGrid g, WorldDev 
     const uint4 *__restrict__ ce = w.ce_view;
     uint32_t total = 0;
     uint32_t hist_ovf = 0;
+    CE_WAIT_VM();
+    CE_MARK(ce_pro);
     for (uint32_t tile = 0; tile < cnt; tile += FO_TILE) {
         if (threadIdx.x == 0) { n_due = 0; ticket = 0; }
         __syncthreads();
@@ -552,7 +640,16 @@ __global__ void __launch_bounds__(64 * WAVES) k_fanout_emit(DevGrid g, WorldDev 
                     d_chs[k] = w.cell_sender[c];
                     d_chhp[k] = age < CHD_HIST_BITS ? (w.cell_hist_prev[c] << age) : 0u;
                     d_chsp[k] = w.cell_sender_prev[c];
-                    d_us[k] = w.ce8_view ? w.cell_usender[c] : CHD_NONUNIFORM;
+                    uint32_t us = w.ce8_view ? w.cell_usender[c] : CHD_NONUNIFORM;
+                    // Several senders behind the cell's buffered updates, but this connection is none of them (outside
+                    // their id range) or does not skip its own: SkipSelfUpdateFanOut cannot drop anything, so the
+                    // sender-agnostic copy / compact streams apply.  (Entities keep the sender of the server that
+                    // spawned them: after some handovers about half of config B's cells hold two servers' entities,
+                    // and the subscribers are clients.)
+                    if (w.ce8_view && us == CHD_NONUNIFORM &&
+                        (!(fl & PF_SKIP_SELF) || conn < w.cell_smin[c] || conn > w.cell_smax[c]))
+                        us = CHD_NOT_A_SENDER;
+                    d_us[k] = us;
                     d_hand[k] = w.ce_chan_view ? w.cell_hand[c] : 0u;
                 } else {
                     w.pair_nrec[pbase + p] = 0;
@@ -560,12 +657,16 @@ __global__ void __launch_bounds__(64 * WAVES) k_fanout_emit(DevGrid g, WorldDev 
             }
         }
         __syncthreads();
+        CE_MARK(ce_stage);
         const uint32_t ndue = n_due;
         for (;;) {
             uint32_t k = 0;
             if (lane == 0) k = atomicAdd(&ticket, 1u);
             k = __builtin_amdgcn_readfirstlane(k);
             if (k >= ndue) break;
+#ifdef CHD_PROFILE_CONN_EMIT
+            ce_nseg++;
+#endif
             const uint32_t p = d_p[k];
             uint32_t fl = d_fl[k];
             int64_t L = d_L[k];
@@ -580,6 +681,8 @@ __global__ void __launch_bounds__(64 * WAVES) k_fanout_emit(DevGrid g, WorldDev 
             // CHD_WORLD_UPDATE_MASKS: which buffered updates each record's message merges
             uint32_t *__restrict__ omask = MASKS ? w.rec_mask + base + d_rel[k] : nullptr;
             uint32_t n_out = 0;
+            CE_WAIT_LGKM();
+            CE_MARK(ce_ticket);
             if (!(fl & PF_HAD_FIRST)) {
                 // first fan-out: the whole data of the spatial channel and of every
                 // entity channel in it (data.go:217-223); last = t
@@ -622,14 +725,21 @@ __global__ void __launch_bounds__(64 * WAVES) k_fanout_emit(DevGrid g, WorldDev 
                             }
                             n_out += 1;
                         }
+                        CE_MARK(ce_decide);
                         if (us == CHD_NONUNIFORM) n_out = emit_cell<false, MASKS>(w, ce, start, end, wm, skip_self, conn, conn, out, opos, n_out, omask);
                         else if (!(skip_self && us == conn))
+#ifdef CHD_PROFILE_CONN_EMIT
+                            n_out = (!MASKS && (d_hand[k] & wm)) ? emit_cell_all(w.ce_chan_view, start, end, conn, out, opos, n_out, nullptr, ce_ls)
+#else
                             n_out = (!MASKS && (d_hand[k] & wm)) ? emit_cell_all(w.ce_chan_view, start, end, conn, out, opos, n_out)
+#endif
                                                                  : emit_cell8<false, MASKS>(w.ce8_view, start, end, wm, conn, out, opos, n_out, omask);
+                        CE_MARK(ce_stream);
                     }
                     L = next;
                 }
             }
+            CE_MARK(ce_decide);
             pad_segment(out, n_out);
             if (lane == 0) {
                 w.pair_last[pbase + p] = L;
@@ -637,9 +747,16 @@ __global__ void __launch_bounds__(64 * WAVES) k_fanout_emit(DevGrid g, WorldDev 
                 w.pair_nrec[pbase + p] = n_out;
             }
             total += n_out;
+            CE_MARK(ce_tail);
         }
         __syncthreads();
     }
+#ifdef CHD_PROFILE_CONN_EMIT
+    if (lane == 0 && ring.cur_tick == 60 && s % 997u == 0)
+        printf("conn_emit s %u wave %u: segs %u records %u | cycles: prologue %lld stage %lld ticket+desc %lld decide %lld stream %lld "
+               "(load wait %lld, stores %lld) tail %lld\n", s, wave, ce_nseg, total, ce_pro, ce_stage, ce_ticket, ce_decide, ce_stream,
+               ce_ls[0], ce_ls[1], ce_tail);
+#endif
     if (lane == 0) wave_total[wave] = total;
     if (hist_ovf && lane == 0) atomicAdd(&w.counters[CTR_HIST_OVERFLOW], 1u);
     __syncthreads();

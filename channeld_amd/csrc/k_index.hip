@@ -108,6 +108,8 @@ __global__ void __launch_bounds__(256) k_index_scan(WorldDev w, uint32_t ncell, 
         if (lane == 0) {
             (finalize ? w.cell_off : w.cell_tot)[c] = carry;  // the cell's total
             w.cell_usender[c] = carry == 0 ? 0u : (lo == hi ? lo : CHD_NONUNIFORM);
+            w.cell_smin[c] = lo;  // (empty cell: [0xFFFFFFFF, 0], no connection is inside)
+            w.cell_smax[c] = hi;
             w.cell_hand[c] = carry == 0 ? 0u : ha;
         }
     }
@@ -348,6 +350,8 @@ void launch_index_build(hipStream_t st, DevGrid g, WorldDev w, uint32_t cur_tick
         uint32_t *cursor = w.blk_cnt + (size_t)g.ncell + 1;
         (void)hipMemsetAsync(w.blk_cnt, 0, sizeof(uint32_t) * (2 * (size_t)g.ncell + 2), st);
         (void)hipMemsetAsync(w.cell_usender, 0xFF, sizeof(uint32_t) * (size_t)g.ncell, st);  // CHD_NONUNIFORM
+        (void)hipMemsetAsync(w.cell_smin, 0, sizeof(uint32_t) * (size_t)g.ncell, st);      // sender range unknown: everything
+        (void)hipMemsetAsync(w.cell_smax, 0xFF, sizeof(uint32_t) * (size_t)g.ncell, st);
         (void)hipMemsetAsync(w.cell_hand, 0, sizeof(uint32_t) * (size_t)g.ncell, st);
         hipLaunchKernelGGL(k_index_hist_global, dim3((w.N + 255) / 256), dim3(256), 0, st, w, g.ncell);
         launch_scan_u32_inplace(st, w.blk_cnt, g.ncell);
