@@ -15,7 +15,9 @@ What the reference does for one fan-out message (paths relative to the channeld 
 Third-party dependency restated: google.golang.org/protobuf v1.28.1 (go.mod:14) — the standard
 proto3 wire format (varint field keys, length-delimited submessages, zero-valued scalar fields
 omitted, fields in field-number order).  Pinned against python-protobuf driven by the reference's
-OWN embedded descriptor (tests/golden/make_wire_golden.py -> tests/golden/wire_packets.npz).
+OWN embedded descriptor (tests/golden/make_wire_golden.py -> tests/golden/wire_packets.npz) and against the
+MessagePacks the Go server itself marshalled into the recordings under examples/replay/ (make_cpr_golden.py ->
+cpr_packs.npz).
 """
 from typing import Iterable, List, Tuple
 
