@@ -545,12 +545,15 @@ int orc_subscribe(orc_channel *ch, uint32_t conn_id, orc_time now,
         /* subscription.go:44-57: proto.Merge(&cs.options, options).
          * The caller passes the merged-in values; "absent" is encoded as
          * UINT32_MAX / INT32_MIN / -1 and keeps the old value. */
+        const int old_access = cs->access;
         if (interval_ms != UINT32_MAX) cs->interval_ms = interval_ms;
         if (delay_ms != INT32_MIN) cs->delay_ms = delay_ms;
         if (skip_self >= 0) cs->skip_self = skip_self;
         if (skip_first >= 0) cs->skip_first = skip_first;
         if (access >= 0) cs->access = access;
-        return 0;
+        /* subscription.go:47-57: "shouldSend" of a repeated subscription = dataAccessChanged
+         * (subscription_test.go:35-44) */
+        return cs->access != old_access;
     }
     if (ch->nsubs == ch->capsubs) {
         /* keep elem pointers valid: nodes are heap objects, subs may move */

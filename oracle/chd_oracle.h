@@ -155,8 +155,9 @@ orc_channel *orc_channel_new(void);
 void orc_channel_free(orc_channel *ch);
 
 /* SubscribeToChannel, subscription.go:34-102 (new-subscription branch and
- * the already-subscribed merge branch).  now = ch.GetTime().  Returns 1 if
- * newly subscribed, 0 if merged into an existing subscription. */
+ * the already-subscribed merge branch).  now = ch.GetTime().  Returns the
+ * reference's second result ("shouldSend"): 1 for a new subscription; for an
+ * existing one 1 iff the merged options changed DataAccess (:47-57). */
 int orc_subscribe(orc_channel *ch, uint32_t conn_id, orc_time now,
                   uint32_t interval_ms, int32_t delay_ms, int skip_self,
                   int skip_first, int access);

@@ -328,3 +328,16 @@ def test_fanout_interval_zero_is_a_hang():
     ch.subscribe(1, 0, 0, 0)
     n, _ = ch.tick_data(orc.MS)
     assert n == orc.E_HANG  # the reference spins forever; the C-ABI rejects interval 0
+
+
+def test_subscribe_to_channel_should_send():
+    """subscription_test.go:19-45 (TestSubscribeToChannel): the second result of SubscribeToChannel is true for a
+    new subscription, false when subscribing again with nil options, true again when the merged options change
+    DataAccess (subscription.go:44-57)."""
+    ch = orc.Channel()
+    c1 = 1
+    A_U32, A_I32 = orc.Channel.ABSENT_U32, orc.Channel.ABSENT_I32
+    assert ch.subscribe(c1, 0, 20, 0) == 1                       # :31-33
+    assert ch.subscribe(c1, 0, A_U32, A_I32) == 0                # :36-38  (nil options: nothing merged)
+    assert ch.subscribe(c1, 0, A_U32, A_I32, access=2) == 1      # :41-44  WRITE_ACCESS differs from the default READ
+    assert ch.subscribe(c1, 0, A_U32, A_I32, access=2) == 0      # same DataAccess again: nothing to send
