@@ -68,6 +68,13 @@ def frame(packet_bytes: bytes, compression: int = 0) -> bytes:
     return bytes([67, 72, (n >> 8) & 0xFF, n & 0xFF, compression]) + packet_bytes  # connection.go:683-687
 
 
+def read_size(tag: bytes) -> int:
+    """readSize (connection.go:445-453), the receiver's rule for the tag flush() writes: 0 unless 'C','H'."""
+    if tag[0] != 67 or tag[1] != 72:
+        return 0
+    return tag[3] | (tag[2] << 8)
+
+
 def flush_stream(packs: Iterable[bytes]) -> Tuple[bytes, List[int]]:
     """The byte stream successive flush() calls write for one connection's queue of MessagePacks,
     and the number of packs per packet.  Packs of size >= 65530 are dropped by Send (:72-77)."""

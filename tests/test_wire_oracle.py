@@ -97,3 +97,39 @@ def test_encoders_reproduce_the_references_recorded_packets():
         assert b"".join(wire.field_bytes(1, p) for p in packs[k:k + n_msgs]) == raw
         k += n_msgs
     assert k == len(packs)
+
+
+def test_read_size_golden():
+    """connection_test.go:71-93 (TestReadSize), transcribed."""
+    tag = bytearray([0, 0, 0, 0])
+    assert wire.read_size(tag) == 0
+    tag[3] = 1
+    assert wire.read_size(tag) == 0
+    tag = bytearray([67, 0, 0, 0])
+    assert wire.read_size(tag) == 0
+    tag[3] = 1
+    assert wire.read_size(tag) == 0
+    tag = bytearray([67, 72, 78, 0])
+    assert wire.read_size(tag) == 78 << 8
+    tag[3] = 1
+    assert wire.read_size(tag) == (78 << 8) + 1
+    tag = bytearray([67, 72, 0, 0])
+    assert wire.read_size(tag) == 0
+    tag[3] = 1
+    assert wire.read_size(tag) == 1
+
+
+@pytest.mark.parametrize("name", CASES)
+def test_streams_walk_with_the_receivers_rule(name):
+    """what flush() writes, read back the way readPacket does (connection.go:455-541): tag -> size -> next tag"""
+    stream = G[f"{name}_stream"].tobytes()
+    counts = G[f"{name}_counts"].tolist() if f"{name}_counts" in G.files else None
+    i, n_packets = 0, 0
+    while i < len(stream):
+        size = wire.read_size(stream[i:i + 4])
+        assert size > 0 and stream[i + 4] == 0      # compression type NONE
+        i += wire.PACKET_HEADER_SIZE + size
+        n_packets += 1
+    assert i == len(stream)
+    if counts is not None:
+        assert n_packets == len(counts)
