@@ -579,6 +579,19 @@ int orc_subscribe(orc_channel *ch, uint32_t conn_id, orc_time now,
     return 1;
 }
 
+/* the subscription's merged options (test accessor); -1 if not subscribed */
+int orc_sub_options(const orc_channel *ch, uint32_t conn_id, uint32_t *interval_ms, int32_t *delay_ms,
+                    int *skip_self, int *skip_first, int *access) {
+    for (uint32_t i = 0; i < ch->nsubs; i++) {
+        const sub_t *cs = &ch->subs[i];
+        if (cs->conn_id != conn_id) continue;
+        *interval_ms = cs->interval_ms; *delay_ms = cs->delay_ms;
+        *skip_self = cs->skip_self; *skip_first = cs->skip_first; *access = cs->access;
+        return 0;
+    }
+    return -1;
+}
+
 int orc_unsubscribe(orc_channel *ch, uint32_t conn_id) {
     sub_t *cs = find_sub(ch, conn_id);
     if (!cs) return -1;

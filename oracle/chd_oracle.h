@@ -162,6 +162,8 @@ int orc_subscribe(orc_channel *ch, uint32_t conn_id, orc_time now,
                   uint32_t interval_ms, int32_t delay_ms, int skip_self,
                   int skip_first, int access);
 /* UnsubscribeFromChannel, subscription.go:104-125. Returns 0, -1 if absent. */
+int orc_sub_options(const orc_channel *ch, uint32_t conn_id, uint32_t *interval_ms, int32_t *delay_ms,
+                    int *skip_self, int *skip_first, int *access);
 int orc_unsubscribe(orc_channel *ch, uint32_t conn_id);
 /* conn.IsClosing() becomes true: tickData drops it (data.go:183-188). */
 void orc_set_closing(orc_channel *ch, uint32_t conn_id);

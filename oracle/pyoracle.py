@@ -308,6 +308,15 @@ class Channel:
     def subscribe(self, conn, now, interval_ms, delay_ms=0, skip_self=-1, skip_first=-1, access=-1):
         return lib().orc_subscribe(self.h, conn, now, interval_ms, delay_ms, skip_self, skip_first, access)
 
+    def options(self, conn):
+        """(interval_ms, delay_ms, skip_self, skip_first, access) of the connection's subscription"""
+        iv, dl = C.c_uint32(), C.c_int32()
+        ss, sf, ac = C.c_int(), C.c_int(), C.c_int()
+        f = lib().orc_sub_options
+        f.argtypes = [C.c_void_p, C.c_uint32, C.POINTER(C.c_uint32), C.POINTER(C.c_int32), C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]
+        assert f(self.h, conn, C.byref(iv), C.byref(dl), C.byref(ss), C.byref(sf), C.byref(ac)) == 0
+        return iv.value, dl.value, ss.value, sf.value, ac.value
+
     def unsubscribe(self, conn):
         return lib().orc_unsubscribe(self.h, conn)
 

@@ -341,3 +341,15 @@ def test_subscribe_to_channel_should_send():
     assert ch.subscribe(c1, 0, A_U32, A_I32) == 0                # :36-38  (nil options: nothing merged)
     assert ch.subscribe(c1, 0, A_U32, A_I32, access=2) == 1      # :41-44  WRITE_ACCESS differs from the default READ
     assert ch.subscribe(c1, 0, A_U32, A_I32, access=2) == 0      # same DataAccess again: nothing to send
+
+
+def test_merge_sub_options():
+    """data_test.go:233-250 (TestMergeSubOptions): proto.Merge of subscription options overrides what the update
+    carries (interval 100 -> 50, WRITE -> READ access) and keeps what it does not (delay 200)."""
+    ch = orc.Channel()
+    c = 5
+    assert ch.subscribe(c, 0, 100, 200, access=2) == 1
+    assert ch.subscribe(c, 0, 50, orc.Channel.ABSENT_I32, access=1) == 1  # DataAccess changed -> shouldSend
+    iv, dl, skip_self, skip_first, access = ch.options(c)
+    assert (iv, dl, access) == (50, 200, 1)
+    assert (skip_self, skip_first) == (1, 0)                             # defaultSubOptions, subscription.go:20-29
