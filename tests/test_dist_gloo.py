@@ -1,4 +1,4 @@
-"""world_size-2 (and 4) gloo runs of the region-sharded tick schedule on CPU.
+"""world_size-2 (and 4, 8) gloo runs of the region-sharded tick schedule on CPU.
 
 The orchestration under test is channeld_amd/dist.py (ShardedWorld + Comm: all-to-all
 of emigrants, all-gather of cell tables).  The engine is the numpy stand-in of
@@ -127,7 +127,7 @@ def worker(rank, world, port, N, S, ticks, seed, out):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world", [2, 4])
+@pytest.mark.parametrize("world", [2, 4, 8])
 def test_sharded_schedule_matches_single_world(world):
     ctx = mp.get_context("spawn")
     out = ctx.Queue()
