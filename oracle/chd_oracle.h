@@ -14,7 +14,14 @@
  * The reference is Go; no Go toolchain exists in the build image and the
  * module's dependencies are not vendored, so the reference cannot be
  * compiled here.  Parity is pinned by the reference's own test vectors
- * (spatial_test.go, data_test.go) transcribed in tests/test_oracle_golden.py.
+ * (spatial_test.go, data_test.go, subscription_test.go, connection_test.go)
+ * transcribed in tests/test_oracle_golden.py / tests/test_wire_oracle.py, and
+ * for the wire format by the packets the Go server recorded in
+ * examples/replay (tests/golden/cpr_packs.npz).
+ * PARITY UNPINNED (no reference test or fixture exists; literal restatement
+ * only): Notify's handover outputs, the interest diff, AOI dist values, Spots
+ * AOIs, the cone boundary beyond result-set sizes, handover / broadcast
+ * recipient lists, the per-record merged-update masks.
  *
  * Third-party arithmetic restated here: Go's math.Cos (Go standard library,
  * src/math/sin.go — the Cephes port; go.mod pins `go 1.25`), math.Min/Max
