@@ -33,7 +33,11 @@ def free_port():
     return p
 
 
-def make_cfg(world):
+def make_cfg(world, name=None):
+    if name:  # one of the repo's StaticGrid2D configs whose server layout already has `world` regions
+        cfg = synth.load_config(name)
+        assert int(cfg["ServerCols"]) * int(cfg["ServerRows"]) == world
+        return cfg
     base = {"WorldOffsetX": -4000, "WorldOffsetZ": -4000, "GridWidth": 2000, "GridHeight": 2000, "GridCols": 3,
             "GridRows": 2, "ServerCols": 1, "ServerRows": 1, "ServerInterestBorderSize": 1}
     return weak_scaled_config(base, world)
@@ -53,7 +57,7 @@ def world_inputs(cfg, N, S, ticks, seed):
     return sw, x0, z0, frames
 
 
-def worker(rank, world, port, N, S, ticks, seed, out):
+def worker(rank, world, port, N, S, ticks, seed, out, cfg_name=None):
     from oracle import pyoracle as orc
     from shard_sim import SimShardEngine
 
@@ -61,7 +65,7 @@ def worker(rank, world, port, N, S, ticks, seed, out):
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
-        cfg = make_cfg(world)
+        cfg = make_cfg(world, cfg_name)
         sw, x0, z0, frames = world_inputs(cfg, N, S, ticks, seed)
         g = orc.grid_from_config(cfg)
         ids0 = orc.channel_ids(g, x0, z0)
@@ -133,6 +137,24 @@ def test_sharded_schedule_matches_single_world(world):
     out = ctx.Queue()
     port = free_port()
     procs = [ctx.Process(target=worker, args=(r, world, port, 600, 48, 6, 0xC0FFEE07, out)) for r in range(world)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(timeout=240)
+    status, info = out.get(timeout=5)
+    assert status == "ok", info
+    assert all(p.exitcode == 0 for p in procs)
+    assert info > 0, "the test world never crossed a region border"
+
+
+@pytest.mark.parametrize("cfg_name,world", [("spatial_static_4x4.json", 4), ("spatial_static_8x8.json", 8)])
+def test_named_configs_sharded_by_their_own_server_layout(cfg_name, world):
+    """BASELINE configs 4 and 5 (scaled down): the 4x4 world over its 2x2 servers = 4 ranks, the seamless 8x8 world over
+    its 4x2 servers = 8 ranks, handover all-to-all and table all-gather every tick, against the single world."""
+    ctx = mp.get_context("spawn")
+    out = ctx.Queue()
+    port = free_port()
+    procs = [ctx.Process(target=worker, args=(r, world, port, 500, 40, 5, 0xC0FFEE0D, out, cfg_name)) for r in range(world)]
     for p in procs:
         p.start()
     for p in procs:
