@@ -30,7 +30,7 @@ def canon(conn, chan):
     return np.sort((conn.astype(np.uint64) << np.uint64(32)) | chan.astype(np.uint64))
 
 
-def run_rank(rank, world, port, N, S, ticks, seed, out):
+def run_rank(rank, world, port, N, S, ticks, seed, out, cfg_name=None):
     import torch
     import torch.distributed as dist
 
@@ -46,7 +46,7 @@ def run_rank(rank, world, port, N, S, ticks, seed, out):
     try:
         torch.cuda.set_device(0)
         dev = torch.device("cuda", 0)
-        cfg = make_cfg(world)
+        cfg = make_cfg(world, cfg_name)
         sw, x0, z0, frames = world_inputs(cfg, N, S, ticks, seed)
         g = orc.grid_from_config(cfg)
         ids0 = orc.channel_ids(g, x0, z0)
@@ -134,13 +134,13 @@ def run_rank(rank, world, port, N, S, ticks, seed, out):
             dist.destroy_process_group()
 
 
-def launch(world, N, S, ticks, seed):
+def launch(world, N, S, ticks, seed, cfg_name=None):
     import torch.multiprocessing as mp
 
     ctx = mp.get_context("spawn")
     out = ctx.Queue()
     port = free_port()
-    procs = [ctx.Process(target=run_rank, args=(r, world, port, N, S, ticks, seed, out)) for r in range(world)]
+    procs = [ctx.Process(target=run_rank, args=(r, world, port, N, S, ticks, seed, out, cfg_name)) for r in range(world)]
     for p in procs:
         p.start()
     for p in procs:
@@ -163,6 +163,12 @@ def test_two_ranks_on_one_gpu_match_single_world():
 
 def test_four_ranks_on_one_gpu_match_single_world():
     total, cross = launch(4, 4000, 96, 6, 0xC0FFEE13)
+    assert total > 0 and cross > 0
+
+
+def test_4x4_world_on_its_four_servers_matches_single_world():
+    # BASELINE config 4 (scaled down): spatial_static_4x4.json, ServerCols x ServerRows = 2 x 2 -> four ranks
+    total, cross = launch(4, 3000, 80, 6, 0xC0FFEE14, cfg_name="spatial_static_4x4.json")
     assert total > 0 and cross > 0
 
 
