@@ -11,9 +11,11 @@ for the GPU and for the CPU baseline alike.
 
     python bench.py [--gpus N] [--steps K] [--warmup W]
 
-N > 1 is launched by torch.distributed.run (one rank per GPU, RCCL); see
-channeld_amd/dist.py for the sharding (weak scaling: 100K entities / 10K
-subscribers per GPU, world tiled by server region).
+N > 1: one rank per GPU over RCCL.  The driver launches the ranks itself with
+torch.distributed.run; run plainly (`python bench.py --gpus 8`, WORLD_SIZE unset) the script
+re-executes itself under torch.distributed.run on 127.0.0.1.  Either way it fails loudly
+when fewer than N devices are visible.  See channeld_amd/dist.py for the sharding (weak
+scaling: 100K entities / 10K subscribers per GPU, world tiled by server region).
 """
 from __future__ import annotations
 
@@ -42,7 +44,11 @@ def parse():
     ap.add_argument("--subs", type=int, default=10_000, help="per GPU")
     ap.add_argument("--tick-ms", type=int, default=50)
     ap.add_argument("--aoi-scale", type=float, default=1.0)
-    ap.add_argument("--latency-steps", type=int, default=-1, help="extra synchronous ticks for p50/p99 (default min(steps,200))")
+    ap.add_argument("--latency-steps", type=int, default=200, help="extra synchronous ticks for p50/p99 (SURVEY 8d: >= 200), independent of --steps")
+    ap.add_argument("--e2e-ticks", type=int, default=3,
+                    help="after the timed region, also time this many ticks END TO END as a Go host would see them: (i) chd_tick with "
+                         "host buffers (H2D of the inputs, dense per-connection pack, D2H of every record), (ii) chd_tick_device + "
+                         "chd_wire_build (the per-connection packet streams, SURVEY 8f-1) on a second world; 0 = skip")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU baseline budget (0 = skip)")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--wire", type=int, default=0, metavar="TICKS",
@@ -62,9 +68,11 @@ def parse():
     return ap.parse_args()
 
 
-def cpu_baseline(cfg, n_entities, n_subs, seed, tick_ms, aoi_scale, budget_s):
-    """The restated reference algorithm (oracle, window formulation = 'port'), one
-    thread per host core over the channels, same synthetic inputs, bounded sample."""
+def cpu_baseline(cfg, n_entities, n_subs, seed, tick_ms, aoi_scale, budget_s, single_thread_ticks=1):
+    """The restated reference algorithm (oracle, window formulation = 'port') on the same synthetic
+    inputs, on a bounded sample: `cores` host threads over the channels (one goroutine per channel
+    in the reference), then — on the same world, so the update buffers are equally deep — one more
+    tick on ONE thread (cpu_baseline_1t)."""
     from channeld_amd import synth
     from oracle import pyoracle as orc
 
@@ -80,35 +88,89 @@ def cpu_baseline(cfg, n_entities, n_subs, seed, tick_ms, aoi_scale, budget_s):
     warm, msgs, secs, ticks = 3, 0, 0.0, 0
     t_all = time.perf_counter()
     k = 0
-    while True:
+
+    def one_tick():
         sw.step()
         q = sw.queries()
         t0 = time.perf_counter()
         ow.tick(sw.now_ns(), None, sw.x, sw.z, None, None, None, None, q)
-        dt = time.perf_counter() - t0
+        return time.perf_counter() - t0, int(orc.lib().orc_world_nrec(ow.h))
+
+    while True:
+        dt, n = one_tick()
         k += 1
         if k > warm:  # the first ticks are subscription set-up + first (full-state) fan-outs
-            msgs += int(orc.lib().orc_world_nrec(ow.h))
+            msgs += n
             secs += dt
             ticks += 1
         if (time.perf_counter() - t_all > budget_s and ticks >= 2) or ticks >= 12:
             break
-    return {
+    out = {
         "value": msgs / secs if secs > 0 else 0.0, "unit": "msgs/s", "cores": cores, "kind": "port",
         "sample": f"{ticks} ticks of the same world after {warm} set-up ticks ({msgs} msgs in {secs:.2f} s; update buffers "
                   f"{k} deep, the reference's steady state is 512 deep and slower)",
         "ms_per_tick": 1e3 * secs / max(ticks, 1),
     }
+    one = None
+    if single_thread_ticks > 0:
+        ow.set_threads(1)
+        m1, s1 = 0, 0.0
+        for _ in range(single_thread_ticks):
+            dt, n = one_tick()
+            m1 += n
+            s1 += dt
+            k += 1
+        one = {"value": m1 / s1 if s1 > 0 else 0.0, "unit": "msgs/s", "cores": 1, "kind": "port",
+               "sample": f"{single_thread_ticks} more tick(s) of the same world on one thread ({m1} msgs in {s1:.2f} s; update buffers {k} deep)",
+               "ms_per_tick": 1e3 * s1 / single_thread_ticks}
+    return out, one
+
+
+def self_launch(args):
+    """`python bench.py --gpus N` run plainly (no WORLD_SIZE): become N ranks under torch.distributed.run."""
+    import socket
+
+    import torch
+
+    n = args.gpus
+    have = torch.cuda.device_count() if torch.cuda.is_available() else 0
+    if have < n and not os.environ.get("CHD_BENCH_SHARE_GPU"):
+        raise SystemExit(f"bench.py --gpus {n}: only {have} HIP device(s) visible; refusing to run fewer ranks than asked "
+                         f"(CHD_BENCH_SHARE_GPU=1 CHD_DIST_BACKEND=gloo shares one device for testing)")
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    sys.stdout.flush()
+    os.execve(sys.executable, cmd, env)
+
+
+def e2e_host_ticks(world, sw_frames, n):
+    """(i) of --e2e-ticks: chd_tick with HOST buffers — upload of the positions and queries, the tick, the dense
+    per-connection pack of the records and their download (8 B per message over PCIe)."""
+    out = []
+    for (now, x, z, q) in sw_frames[:n]:
+        a = time.perf_counter()
+        # output buffers are page-locked host memory (chd_host_alloc) reused from tick to tick, as a gateway would
+        res = world.tick(now, upd_x=x, upd_z=z, queries=q, records_cap=160_000_000, pinned=True)
+        out.append((time.perf_counter() - a, res.n_records))
+        assert res.overflow == 0, res.overflow
+    return out
 
 
 def main():
     args = parse()
+    world_size = int(os.environ.get("WORLD_SIZE", "0") or 0)
+    if args.gpus > 1 and world_size == 0:
+        self_launch(args)  # does not return
     rank = int(os.environ.get("RANK", "0"))
-    world_size = int(os.environ.get("WORLD_SIZE", "1"))
+    world_size = max(world_size, 1)
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    n_gpus = args.gpus
-    if world_size != n_gpus and world_size > 1:
-        n_gpus = world_size
+    if world_size != args.gpus and not os.environ.get("CHD_BENCH_FORCE_DIST"):
+        raise SystemExit(f"bench.py --gpus {args.gpus} launched with WORLD_SIZE={world_size}: the two must agree")
 
     import torch
 
@@ -116,6 +178,8 @@ def main():
         raise SystemExit("bench.py needs an MI355X: the HIP path has no CPU fallback")
     if os.environ.get("CHD_BENCH_SHARE_GPU"):  # test hook: several ranks on one GPU (gloo, host-staged exchange)
         local_rank = 0
+    elif torch.cuda.device_count() < world_size:
+        raise SystemExit(f"bench.py: {world_size} ranks but only {torch.cuda.device_count()} HIP device(s) visible")
     torch.cuda.set_device(local_rank)
     # CHD_BENCH_FORCE_DIST: take the sharded (RCCL) path with a single rank as well (test hook for one-GPU boxes)
     dist_on = world_size > 1 or bool(os.environ.get("CHD_BENCH_FORCE_DIST"))
@@ -136,13 +200,19 @@ def main():
     from channeld_amd import synth
 
     K, W = args.steps, args.warmup
-    L = min(K, 200) if args.latency_steps < 0 else args.latency_steps
+    L = max(args.latency_steps, 0)
     if dist_on:
         from channeld_amd import dist as cdist
 
         result = cdist.run_bench(args, rank, world_size, local_rank)
         if rank == 0:
+            if not args.no_cpu and args.cpu_seconds > 0:  # after the timed region, rank 0's host cores (the others wait in destroy)
+                base = synth.load_config("spatial_static_benchmark.json")
+                result["cpu_baseline"], one = cpu_baseline(base, args.entities, args.subs, 0xC0FFEE01, args.tick_ms, args.aoi_scale,
+                                                           args.cpu_seconds, single_thread_ticks=0)
+                result["cpu_baseline"]["sample"] = "ONE rank's share (config B): " + result["cpu_baseline"]["sample"]
             print(json.dumps(result))
+        dist.barrier()
         dist.destroy_process_group()
         return
 
@@ -153,19 +223,23 @@ def main():
     ctl = A.StaticGrid2DSpatialController(device=local_rank)
     err = ctl.LoadConfig(json.dumps(cfg).encode(), strict=False)
     assert err is None, err
-    world = A.SpatialWorld(ctl, N, S, flags={"auto": 0, "conn-major": 1, "cell-major": 2}[args.emit] | (4 if args.recipients else 0) | (8 if args.wire else 0) | (16 if args.overlap_interest else 0) | (32 if args.update_masks else 0))
+    world_flags = {"auto": 0, "conn-major": 1, "cell-major": 2}[args.emit] | (4 if args.recipients else 0) | (8 if args.wire else 0) | (16 if args.overlap_interest else 0) | (32 if args.update_masks else 0)
+    world = A.SpatialWorld(ctl, N, S, flags=world_flags)
     world.spawn(None, sw.chan_id, sw.x, sw.z, sw.flags, sw.sender)
     world.add_subscribers(None, sw.sub_conn)
 
     # ---- all tick inputs generated on the host once, then resident in HBM ----
+    E = max(args.e2e_ticks, 0)
     T = W + K + L
-    xs = np.empty((T, N), dtype=np.float64)
-    zs = np.empty((T, N), dtype=np.float64)
-    qs = np.empty((T, S), dtype=synth.AOI_DTYPE)
-    now = np.empty(T, dtype=np.int64)
-    for t in range(T):
+    xs = np.empty((T + E, N), dtype=np.float64)
+    zs = np.empty((T + E, N), dtype=np.float64)
+    qs = np.empty((T + E, S), dtype=synth.AOI_DTYPE)
+    now = np.empty(T + E, dtype=np.int64)
+    for t in range(T + E):
         sw.step()
         xs[t], zs[t], qs[t], now[t] = sw.x, sw.z, sw.queries(), sw.now_ns()
+    e2e_frames = [(int(now[t]), xs[t].copy(), zs[t].copy(), qs[t].copy()) for t in range(T, T + E)]
+    xs, zs, qs_dev = xs[:T], zs[:T], qs[:T]
     M, d_idx = N, None  # updates per tick
     if args.update_frac < 1.0:
         M = max(1, int(round(args.update_frac * N)))
@@ -174,7 +248,7 @@ def main():
         xs = np.ascontiguousarray(np.take_along_axis(xs, idx.astype(np.int64), axis=1))
         zs = np.ascontiguousarray(np.take_along_axis(zs, idx.astype(np.int64), axis=1))
         d_idx = world.device_array(idx)
-    d_x, d_z, d_q = world.device_array(xs), world.device_array(zs), world.device_array(qs)
+    d_x, d_z, d_q = world.device_array(xs), world.device_array(zs), world.device_array(qs_dev)
     del xs, zs
 
     def tick(t):
@@ -207,29 +281,9 @@ def main():
     # ---- optional: wire-format packet streams of a few more ticks (payload materialisation) ----
     wire_info = None
     if args.wire:
-        rng = np.random.default_rng(7)
-        upd = [bytes(rng.integers(0, 256, 66, dtype=np.uint8))] * N
-        world.wire_set_payloads(0, np.arange(N), upd)
-        world.wire_set_payloads(1, np.arange(N), [bytes(300)] * N)
-        ncell = ctl.GridCols * ctl.GridRows
-        world.wire_set_payloads(2, 0x10000 + np.arange(ncell), [bytes(40)] * ncell)
-        world.wire_set_payloads(3, 0x10000 + np.arange(ncell), [bytes(200)] * ncell)
-        wb, wt, wp = [], [], []
-        for t in range(W + K - args.wire, W + K):  # replay the last ticks' inputs at later channel times
-            world.tick_device(int(now[W + K - 1]) + (t + 1) * args.tick_ms * 1_000_000, n_updates=M, d_upd_x=d_x.at(t * M * 8),
-                              d_upd_z=d_z.at(t * M * 8), d_upd_idx=d_idx.at(t * M * 4) if d_idx is not None else None,
-                              n_queries=S, d_queries=d_q.at(t * S * 128))
-            world.sync()
-            a = time.perf_counter()
-            nbytes, npackets, ndropped = world.wire_build()
-            world.sync()
-            wt.append(time.perf_counter() - a)
-            wb.append(nbytes)
-            wp.append(npackets)
-        wire_info = {"ticks": args.wire, "bytes_per_tick": float(np.mean(wb)), "packets_per_tick": float(np.mean(wp)),
-                     "ms_per_build": 1e3 * float(np.min(wt)), "ms_per_build_all": [round(1e3 * v, 2) for v in wt], "written_GBps": float(wb[int(np.argmin(wt))] / np.min(wt) / 1e9),
-                     "frac_of_hbm_peak": float(wb[int(np.argmin(wt))] / np.min(wt) / 1e9 / HBM_PEAK_GBS),
-                     "payload": "66-byte Any per entity update, 40-byte per spatial channel update"}
+        wire_info = wire_phase(args, world, ctl, N, lambda t, at: world.tick_device(
+            at, n_updates=M, d_upd_x=d_x.at(t * M * 8), d_upd_z=d_z.at(t * M * 8), d_upd_idx=d_idx.at(t * M * 4) if d_idx is not None else None,
+            n_queries=S, d_queries=d_q.at(t * S * 128)), range(W + K - args.wire, W + K), int(now[W + K - 1]))
 
     # ---- latency phase: one synchronous tick at a time (p50/p99 of the tick) ----
     lat = []
@@ -241,8 +295,21 @@ def main():
     lat = np.array(lat) if lat else np.array([0.0])
     gpu_lat = np.array([h["total_us"] for h in world.history(min(L, 1024))]) / 1e3 if L else np.array([0.0])
 
+    # ---- end to end, as a Go host would observe it ("kernel-only AND end-to-end through the C-ABI") ----
+    e2e = None
+    if E and args.update_frac >= 1.0 and not args.wire:
+        e2e = {}
+        r = e2e_host_ticks(world, e2e_frames, E)
+        best = min(r, key=lambda v: v[0])
+        e2e["host_buffers"] = {
+            "what": "chd_tick(host pointers): H2D of positions + queries, the tick, dense per-connection pack, D2H of every 8-byte record",
+            "ticks": E, "ms_per_tick": 1e3 * best[0], "ms_all": [round(1e3 * v[0], 2) for v in r], "msgs_per_tick": best[1],
+            "value": best[1] / best[0], "unit": "msgs/s", "d2h_GBps": 8.0 * best[1] / best[0] / 1e9,
+            "note": "PCIe-bound: 8 B per message leave the device; never the headline value"}
+
     # HBM bytes per launch of the dominant kernel from the PMC passes (FETCH_SIZE / WRITE_SIZE in separate
-    # rocprofv3 runs, tools/pmc_summary.py); only quoted for the workload it was measured on
+    # rocprofv3 runs, tools/pmc_summary.py): not measurable from inside this process, so QUOTED from the committed
+    # summary of the same command, and only for the workload it was measured on
     traffic = None
     tpath = os.path.join(ROOT, "profiles", "hbm_traffic.json")
     if os.path.exists(tpath) and (N, S) == (100_000, 10_000) and args.aoi_scale == 1.0 and args.tick_ms == 50 and args.update_frac >= 1.0:
@@ -258,20 +325,84 @@ def main():
                                + ("" if args.update_frac >= 1.0 else f", DIAGNOSTIC: {args.update_frac:g} of the entities update per tick"),
                    "grid": "15x15 cells of 2000",
                    "tick_ms": args.tick_ms, "aoi": "70% sphere R=3 cells, 20% cone R=5 cells, 10% box extent 2 cells",
-                   "msgs_per_tick": msgs / K, "message": "one fanOutDataUpdate decision (conn, channel); payload bytes excluded"},
+                   "msgs_per_tick": msgs / K, "message": "one fanOutDataUpdate decision (conn, channel); payload bytes excluded",
+                   "value_is": "chd_tick_device: inputs resident in HBM, records left in HBM (see e2e for what a host observes)"},
         "p50_tick_ms": float(np.percentile(lat, 50)), "p99_tick_ms": float(np.percentile(lat, 99)),
-        "p99_tick_gpu_ms": float(np.percentile(gpu_lat, 99)),
+        "p99_tick_gpu_ms": float(np.percentile(gpu_lat, 99)), "latency_ticks": int(L),
         "stage_us_avg": {n: float(v) for n, v in zip(("ingest", "index", "interest", "plan", "emit"), stage_avg)},
         "roofline": {"bound": "hbm", "kernel": "k_fanout_emit", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_unit": "bytes per launch (PMC, profiles/hbm_traffic.json)",
+                     "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_quoted": traffic is not None,
+                     "traffic_source": "QUOTED, not measured in this run: bytes per launch from the rocprofv3 --pmc passes of this command (profiles/hbm_traffic.json)",
                      "algorithmic_bytes_per_launch": float(BYTES_PER_MSG * emit_msgs.mean()),
                      "bytes_per_msg": BYTES_PER_MSG, "msgs_per_launch": float(emit_msgs.mean()), "avg_launch_us": float(emit_us.mean())},
     }
     if wire_info:
         out["wire"] = wire_info
+    # (ii) of --e2e-ticks: the packet streams a gateway would hand to conn.Write, on a second world (the wire mode
+    # keeps one more 4-byte array per record, so it is never the headline world)
+    if e2e is not None:
+        world = None
+        ctl.close()
+        ctl2 = A.StaticGrid2DSpatialController(device=local_rank)
+        assert ctl2.LoadConfig(json.dumps(cfg).encode(), strict=False) is None
+        sw2 = synth.SynthWorld(synth.WorldSpec(cfg, N, S, seed, tick_ms=args.tick_ms, aoi_scale=args.aoi_scale))
+        w2 = A.SpatialWorld(ctl2, N, S, flags=8, max_records=400_000_000)
+        w2.spawn(None, sw2.chan_id, sw2.x, sw2.z, sw2.flags, sw2.sender)
+        w2.add_subscribers(None, sw2.sub_conn)
+        nw = 6 + E  # a few ticks to get past the first (full-state) fan-out
+        xs2 = np.empty((nw, N)); zs2 = np.empty((nw, N)); qs2 = np.empty((nw, S), dtype=synth.AOI_DTYPE); now2 = np.empty(nw, dtype=np.int64)
+        for t in range(nw):
+            sw2.step()
+            xs2[t], zs2[t], qs2[t], now2[t] = sw2.x, sw2.z, sw2.queries(), sw2.now_ns()
+        dx2, dz2, dq2 = w2.device_array(xs2), w2.device_array(zs2), w2.device_array(qs2)
+        e2e["wire"] = wire_phase(args, w2, ctl2, N, lambda t, at: w2.tick_device(
+            int(now2[t]), n_updates=N, d_upd_x=dx2.at(t * N * 8), d_upd_z=dz2.at(t * N * 8), n_queries=S, d_queries=dq2.at(t * S * 128)),
+            range(nw), 0, measure_last=E)
+        out["e2e"] = e2e
     if not args.no_cpu and args.cpu_seconds > 0:
-        out["cpu_baseline"] = cpu_baseline(cfg, N, S, seed, args.tick_ms, args.aoi_scale, args.cpu_seconds)
+        out["cpu_baseline"], one = cpu_baseline(cfg, N, S, seed, args.tick_ms, args.aoi_scale, args.cpu_seconds)
+        if one:
+            out["cpu_baseline_1t"] = one
     print(json.dumps(out))
+
+
+def wire_phase(args, world, ctl, N, tick_at, ticks, base_now, measure_last=None):
+    """chd_tick_device + chd_wire_build for `ticks`; reports the tick + build of the last `measure_last` (default all)."""
+    rng = np.random.default_rng(7)
+    upd = [bytes(rng.integers(0, 256, 66, dtype=np.uint8))] * N
+    world.wire_set_payloads(0, np.arange(N), upd)
+    world.wire_set_payloads(1, np.arange(N), [bytes(300)] * N)
+    ncell = ctl.GridCols * ctl.GridRows
+    world.wire_set_payloads(2, 0x10000 + np.arange(ncell), [bytes(40)] * ncell)
+    world.wire_set_payloads(3, 0x10000 + np.arange(ncell), [bytes(200)] * ncell)
+    ticks = list(ticks)
+    first = 0 if measure_last is None else max(len(ticks) - measure_last, 0)
+    wb, wt, wp, tt, nrec = [], [], [], [], []
+    for i, t in enumerate(ticks):  # (--wire: replays the last ticks' inputs at later channel times)
+        world.sync()
+        a0 = time.perf_counter()
+        tick_at(t, base_now + (t + 1) * args.tick_ms * 1_000_000)
+        world.sync()
+        if i < first:
+            continue  # (set-up ticks: the first, full-state fan-out would be tens of GB of packets)
+        a = time.perf_counter()
+        nbytes, npackets, ndropped = world.wire_build()
+        world.sync()
+        b = time.perf_counter()
+        if i >= first:
+            wt.append(b - a)
+            tt.append(b - a0)
+            wb.append(nbytes)
+            wp.append(npackets)
+            nrec.append(world.fetch().n_records)
+    k = int(np.argmin(tt))
+    return {"what": "chd_tick_device + chd_wire_build: per-connection Packet streams (tag + MessagePacks) ready for conn.Write, left in HBM",
+            "ticks": len(wt), "bytes_per_tick": float(np.mean(wb)), "packets_per_tick": float(np.mean(wp)), "msgs_per_tick": float(np.mean(nrec)),
+            "ms_per_build": 1e3 * float(np.min(wt)), "ms_per_build_all": [round(1e3 * v, 2) for v in wt],
+            "ms_tick_plus_build": 1e3 * tt[k], "value": nrec[k] / tt[k], "unit": "msgs/s", "packets_per_s": wp[k] / tt[k],
+            "written_GBps": float(wb[int(np.argmin(wt))] / np.min(wt) / 1e9),
+            "frac_of_hbm_peak": float(wb[int(np.argmin(wt))] / np.min(wt) / 1e9 / HBM_PEAK_GBS),
+            "payload": "66-byte Any per entity update, 40-byte per spatial channel update"}
 
 
 if __name__ == "__main__":

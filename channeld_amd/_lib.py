@@ -45,6 +45,7 @@ SYMBOLS = (
     "chd_set_stream", "chd_shard_spawn", "chd_shard_ingest", "chd_shard_import", "chd_shard_fanout",
     "chd_shard_get_entities", "chd_shard_table_bytes", "chd_shard_interest",
     "chd_handover_recipients", "chd_adjacent_recipients", "chd_wire_set_payloads", "chd_wire_build", "chd_wire_fetch",
+    "chd_tick_digest", "chd_host_alloc", "chd_host_free",
 )
 
 
@@ -145,6 +146,10 @@ class TickStats(C.Structure):
     ]
 
 
+class RecordsDigest(C.Structure):
+    _fields_ = [("count", C.c_uint64), ("sum", C.c_uint64), ("xor_", C.c_uint64), ("sum_masked", C.c_uint64)]
+
+
 _lib = None
 
 
@@ -204,6 +209,9 @@ def load():
     L.chd_wire_fetch.argtypes = [C.c_void_p, _u64p, _u32p, _u8p, C.c_uint64]
     L.chd_handover_recipients.argtypes = [C.c_void_p, _u32p, _u32p, _u8p, C.c_uint64, P(C.c_uint64)]
     L.chd_adjacent_recipients.argtypes = [C.c_void_p, C.c_uint32, _u32p, _u32p, _u32p, _u32p, _u32p, _u32p, C.c_uint64]
+    L.chd_tick_digest.argtypes = [C.c_void_p, P(RecordsDigest), _u64p]
+    L.chd_host_alloc.argtypes = [C.c_void_p, C.c_uint64, P(C.c_void_p)]
+    L.chd_host_free.argtypes = [C.c_void_p, C.c_void_p]
     L.chd_set_profiling.argtypes = [C.c_void_p, C.c_int]
     L.chd_get_tick_stats.argtypes = [C.c_void_p, P(TickStats)]
     L.chd_get_tick_history.argtypes = [C.c_void_p, C.c_uint32, P(TickStats)]

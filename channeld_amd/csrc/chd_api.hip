@@ -183,6 +183,62 @@ __global__ void __launch_bounds__(256) k_pack_records(WorldDev w, const uint64_t
     }
 }
 
+// Order-independent digest of the tick's fan-out records, where they lie (one padded segment per subscription):
+// h = mix64(conn << 32 | channel) per record (SplitMix64's finaliser); per connection the sum of its hashes, and
+// through 64 hashed buckets {count, sum, xor, sum of mix64(h + merged-updates mask)}.  One wave per connection, two
+// records per lane and load (segments start on 128-byte lines).  HBM-bound: reads the 8 B/record stream once.
+__device__ __forceinline__ unsigned long long mix64(unsigned long long k) {
+    k = (k ^ (k >> 30)) * 0xBF58476D1CE4E5B9ull;
+    k = (k ^ (k >> 27)) * 0x94D049BB133111EBull;
+    return k ^ (k >> 31);
+}
+
+__global__ void __launch_bounds__(256) k_records_digest(WorldDev w, unsigned long long *conn_sum, unsigned long long *buckets) {
+    const uint32_t s = blockIdx.x * 4u + (threadIdx.x >> 6);
+    if (s >= w.S) return;
+    const uint32_t lane = threadIdx.x & 63u;
+    unsigned long long sum = 0, x = 0, summ = 0, cnt = 0;
+    if (w.sub_alive[s] && w.rec_cnt[s]) {
+        const uint32_t np = w.pair_cnt[s];
+        const size_t pbase = (size_t)s * w.capq;
+        const uint64_t base = w.rec_ub[s];
+        for (uint32_t p = 0; p < np; p++) {
+            const uint32_t n = w.pair_nrec[pbase + p];
+            if (!n) continue;
+            const uint64_t at = base + w.pair_rel[pbase + p];
+            const chd_fanout_rec *src = w.recs + at;
+            const uint32_t *msrc = w.rec_mask ? w.rec_mask + at : nullptr;
+            for (uint32_t k = 2 * lane; k < n; k += 128) {
+                const uint4 v = *(const uint4 *)(const void *)(src + k);  // (the pad of the last line is readable)
+                const unsigned long long h0 = mix64(((unsigned long long)v.x << 32) | v.y);
+                sum += h0; x ^= h0; cnt++;
+                summ += mix64(h0 + (msrc ? msrc[k] : 0u));
+                if (k + 1 < n) {
+                    const unsigned long long h1 = mix64(((unsigned long long)v.z << 32) | v.w);
+                    sum += h1; x ^= h1; cnt++;
+                    summ += mix64(h1 + (msrc ? msrc[k + 1] : 0u));
+                }
+            }
+        }
+    }
+    for (int d = 32; d >= 1; d >>= 1) {
+        sum += __shfl_xor(sum, d);
+        x ^= __shfl_xor(x, d);
+        summ += __shfl_xor(summ, d);
+        cnt += __shfl_xor(cnt, d);
+    }
+    if (lane == 0) {
+        if (conn_sum) conn_sum[s] = sum;
+        if (cnt) {
+            unsigned long long *b = buckets + (size_t)(s & 63u) * 16;  // one 128-byte line per bucket
+            atomicAdd(b, cnt);
+            atomicAdd(b + 1, sum);
+            atomicXor(b + 2, x);
+            atomicAdd(b + 3, summ);
+        }
+    }
+}
+
 __global__ void __launch_bounds__(256) k_rec_cnt(WorldDev w) {
     uint32_t s = blockIdx.x * 4u + (threadIdx.x >> 6);
     if (s >= w.S) return;
@@ -297,6 +353,12 @@ int chd_create(const chd_grid_cfg *cfg, int device, chd_ctx **out) {
     ctx->lim.maxax = 256;
     ctx->lim.winmax = std::min<uint32_t>(std::max<uint32_t>(g.ncell, 64), 4096);
     ctx->lim.maxdim = std::min<uint32_t>(ctx->lim.winmax, std::max(g.cols, g.rows));
+    if (aoi_lds_bytes(ctx->lim, 1) > aoi_lds_limit()) {
+        (void)hipStreamDestroy(ctx->own_stream);
+        (void)hipStreamDestroy(ctx->aux_stream);
+        delete ctx;
+        return fail(nullptr, CHD_E_CONFIG, "grid of %u x %u cells: the per-query work area exceeds the LDS of a CU", g.cols, g.rows);
+    }
     ctx->ring.n = 0;
     ctx->ring.cur_tick = 0;
     *out = ctx;
@@ -524,6 +586,9 @@ int chd_world_create(chd_ctx *ctx, const chd_world_cfg *cfg) {
     d.capq = cfg->max_interest_cells ? cfg->max_interest_cells : std::min<uint32_t>(g.ncell, 256);
     if (d.capq > ctx->lim.winmax) d.capq = ctx->lim.winmax;
     if (d.capq > 0xFFFE) return fail(ctx, CHD_E_INVAL, "max_interest_cells too large");
+    if (aoi_lds_bytes(ctx->lim, d.capq) > aoi_lds_limit())
+        return fail(ctx, CHD_E_CONFIG, "max_interest_cells %u on this grid needs %zu bytes of LDS per query (limit %zu)", d.capq,
+                    aoi_lds_bytes(ctx->lim, d.capq), aoi_lds_limit());
     const size_t N = d.N, S = d.S, P = (size_t)d.S * d.capq, C = g.ncell;
     TRY(walloc(ctx, &d.chan_id, N));
     TRY(walloc(ctx, &d.cell, N));
@@ -1011,6 +1076,36 @@ int chd_tick_fetch(chd_ctx *ctx, chd_tick_out *out) {
     return fetch_locked(ctx, out);
 }
 
+int chd_tick_digest(chd_ctx *ctx, chd_records_digest *total, uint64_t *conn_sum) {
+    NEED_WORLD();
+    if (!total) return fail(ctx, CHD_E_INVAL, "chd_tick_digest: NULL output");
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    TRY(bind(ctx));
+    World &W = ctx->w;
+    WorldDev &d = W.d;
+    if (!W.ticked) return fail(ctx, CHD_E_STATE, "no tick to digest");
+    hipStream_t st = ctx->stream;
+    TRY(ensure(ctx, 14, sizeof(uint64_t) * 64 * 16));
+    TRY(ensure(ctx, 15, sizeof(uint64_t) * std::max<size_t>(d.S, 1)));
+    HIPCHK(hipMemsetAsync(sbuf<void>(ctx, 14), 0, sizeof(uint64_t) * 64 * 16, st));
+    hipLaunchKernelGGL(k_rec_cnt, dim3((d.S + 3) / 4), dim3(256), 0, st, d);
+    hipLaunchKernelGGL(k_records_digest, dim3((d.S + 3) / 4), dim3(256), 0, st, d, sbuf<unsigned long long>(ctx, 15),
+                       sbuf<unsigned long long>(ctx, 14));
+    TRY(after_launch(ctx));
+    uint64_t b[64 * 16];
+    TRY(down(ctx, b, sbuf<void>(ctx, 14), sizeof b));
+    if (conn_sum) TRY(down(ctx, conn_sum, sbuf<void>(ctx, 15), sizeof(uint64_t) * d.S));
+    HIPCHK(hipStreamSynchronize(st));
+    memset(total, 0, sizeof *total);
+    for (int k = 0; k < 64; k++) {
+        total->count += b[k * 16];
+        total->sum += b[k * 16 + 1];
+        total->xor_ ^= b[k * 16 + 2];
+        total->sum_masked += b[k * 16 + 3];
+    }
+    return CHD_OK;
+}
+
 int chd_tick(chd_ctx *ctx, const chd_tick_in *in, chd_tick_out *out) {
     NEED_WORLD();
     if (!in || !out) return fail(ctx, CHD_E_INVAL, "chd_tick: NULL argument");
@@ -1026,6 +1121,25 @@ int chd_tick(chd_ctx *ctx, const chd_tick_in *in, chd_tick_out *out) {
     if (in->query_sub)
         for (size_t i = 0; i < nq; i++)
             if (in->query_sub[i] >= ctx->w.d.S) return fail(ctx, CHD_E_INVAL, "tick: subscriber slot %u out of range", in->query_sub[i]);
+    // One update per entity and one interest update per connection per tick: the kernels rewrite an entity's /
+    // a connection's state in place, one thread / wave per input record, so a repeated slot would race (and the
+    // reference applies them one after the other: the host coalesces, keeping the last).  O(n) bitmaps.
+    if (in->upd_idx && nu > 1) {
+        std::vector<uint64_t> seen(((size_t)ctx->w.d.N + 63) / 64, 0);
+        for (size_t i = 0; i < nu; i++) {
+            const uint32_t v = in->upd_idx[i];
+            if (seen[v >> 6] & (1ull << (v & 63))) return fail(ctx, CHD_E_INVAL, "tick: entity slot %u is updated twice (coalesce the updates of a tick on the host)", v);
+            seen[v >> 6] |= 1ull << (v & 63);
+        }
+    }
+    if (in->query_sub && nq > 1) {
+        std::vector<uint64_t> seen(((size_t)ctx->w.d.S + 63) / 64, 0);
+        for (size_t i = 0; i < nq; i++) {
+            const uint32_t v = in->query_sub[i];
+            if (seen[v >> 6] & (1ull << (v & 63))) return fail(ctx, CHD_E_INVAL, "tick: subscriber slot %u sends two interest updates (keep the last one)", v);
+            seen[v >> 6] |= 1ull << (v & 63);
+        }
+    }
     for (size_t i = 0; i < nq; i++)
         if ((in->queries[i].shapes & CHD_SHAPE_SPOTS) &&
             ((uint64_t)in->queries[i].spot_off + in->queries[i].n_spots > ns || in->queries[i].n_spot_dists > in->queries[i].n_spots))
@@ -1483,6 +1597,22 @@ int chd_dev_download(chd_ctx *ctx, void *dst, const void *d_src, uint64_t bytes)
     TRY(bind(ctx));
     TRY(down(ctx, dst, d_src, bytes));
     HIPCHK(hipStreamSynchronize(ctx->stream));
+    return CHD_OK;
+}
+
+int chd_host_alloc(chd_ctx *ctx, uint64_t bytes, void **out) {
+    if (!ctx || !out) return fail(ctx, CHD_E_INVAL, "chd_host_alloc: NULL argument");
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    TRY(bind(ctx));
+    HIPCHK(hipHostMalloc(out, bytes ? bytes : 256, hipHostMallocDefault));
+    return CHD_OK;
+}
+int chd_host_free(chd_ctx *ctx, void *ptr) {
+    if (!ctx) return fail(nullptr, CHD_E_INVAL, "NULL ctx");
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    TRY(bind(ctx));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    HIPCHK(hipHostFree(ptr));
     return CHD_OK;
 }
 

@@ -226,6 +226,7 @@ void launch_aoi_interest(hipStream_t st, DevGrid g, AoiLimits lim, WorldDev w,
                          const double *spot_x, const double *spot_z, const uint32_t *spot_dist,
                          int64_t now_ns, uint32_t cur_tick);
 size_t aoi_lds_bytes(AoiLimits lim, uint32_t capq);
+size_t aoi_lds_limit();  // the most dynamic LDS an AOI launch may ask for (gfx950: 160 KiB per CU)
 // compaction of the fixed-stride stateless output into CSR
 void launch_scan_u32(hipStream_t st, const uint32_t *in, uint32_t *out, uint32_t n);  // exclusive, out[n]=total
 void launch_scan_u32_inplace(hipStream_t st, uint32_t *data, uint32_t n);             // data[n] = total

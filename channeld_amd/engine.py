@@ -113,7 +113,41 @@ class SpatialWorld:
         _lib.check(self.ctx, self.lib.chd_subs_remove(self.ctx, len(s), _ptr(s)))
 
     # ---- tick ----
-    def _alloc_out(self, n_queries: int, want_records: bool, records_cap: int):
+    def host_array(self, count: int, dtype) -> np.ndarray:
+        """A numpy array over page-locked host memory (chd_host_alloc); lives as long as the world's context."""
+        dtype = np.dtype(dtype)
+        p = C.c_void_p(None)
+        nbytes = max(int(count) * dtype.itemsize, 256)
+        _lib.check(self.ctx, self.lib.chd_host_alloc(self.ctx, nbytes, C.byref(p)))
+        buf = (C.c_uint8 * nbytes).from_address(p.value)
+        return np.frombuffer(buf, dtype=dtype, count=int(count))
+
+    def _alloc_out(self, n_queries: int, want_records: bool, records_cap: int, pinned: bool = False):
+        if pinned:
+            # page-locked output buffers, allocated once and reused from tick to tick (what a gateway would do)
+            key = (n_queries, want_records, records_cap)
+            if getattr(self, "_pinned_key", None) != key:
+                self._pinned_key = key
+                alloc = self.host_array
+                ucap = max(self.S * self.capq, 1)
+                self._p = dict(ho=alloc(max(self.N, 1), HANDOVER_DTYPE), qs=alloc(max(n_queries, 1), np.int32),
+                               us=alloc(ucap, np.uint32), uc=alloc(ucap, np.uint32), ns=alloc(ucap, np.uint32),
+                               nc=alloc(ucap, np.uint32), ni=alloc(ucap, np.uint32), off=alloc(self.S + 1, np.uint64),
+                               cnt=alloc(self.S, np.uint32), rec=alloc(max(records_cap, 1), REC_DTYPE) if want_records else None)
+            P = self._p
+            o = TickOut()
+            self._o_ho, self._o_qs, self._o_us, self._o_uc = P["ho"], P["qs"], P["us"], P["uc"]
+            self._o_ns, self._o_nc, self._o_ni, self._o_off, self._o_cnt, self._o_rec = P["ns"], P["nc"], P["ni"], P["off"], P["cnt"], P["rec"]
+            ucap = len(self._o_us)
+            o.handovers, o.handovers_cap = self._o_ho.ctypes.data_as(C.c_void_p), len(self._o_ho)
+            o.query_status = _ptr(self._o_qs)
+            o.unsub_sub, o.unsub_channel, o.unsub_cap = _ptr(self._o_us), _ptr(self._o_uc), ucap
+            o.newsub_sub, o.newsub_channel, o.newsub_interval_ms, o.newsub_cap = _ptr(self._o_ns), _ptr(self._o_nc), _ptr(self._o_ni), ucap
+            o.conn_rec_off, o.conn_rec_cnt = _ptr(self._o_off), _ptr(self._o_cnt)
+            if want_records:
+                o.records, o.records_cap = self._o_rec.ctypes.data_as(C.c_void_p), len(self._o_rec)
+            self._o_mask = None
+            return o
         o = TickOut()
         self._o_ho = np.zeros(max(self.N, 1), dtype=HANDOVER_DTYPE)
         o.handovers = self._o_ho.ctypes.data_as(C.c_void_p)
@@ -155,7 +189,7 @@ class SpatialWorld:
     def tick(self, now_ns: int, upd_idx=None, upd_x=None, upd_z=None, upd_sender=None,
              cell_upd_channel=None, cell_upd_sender=None, query_sub=None,
              queries: Optional[Sequence[SpatialInterestQuery]] = None, records_cap: int = 1 << 22,
-             want_records: bool = True) -> TickResult:
+             want_records: bool = True, pinned: bool = False) -> TickResult:
         ti = TickIn()
         ti.now_ns = int(now_ns)
         keep = []
@@ -183,7 +217,7 @@ class SpatialWorld:
                 keep += [arr, sx, sz, sd, qs]
                 ti.n_queries, ti.query_sub, ti.queries = nq, _ptr(qs), C.cast(arr, C.c_void_p)
                 ti.spot_x, ti.spot_z, ti.spot_dist, ti.n_spots_total = _ptr(sx), _ptr(sz), _ptr(sd), len(sx)
-        o = self._alloc_out(nq, want_records, records_cap)
+        o = self._alloc_out(nq, want_records, records_cap, pinned)
         rc = self.lib.chd_tick(self.ctx, C.byref(ti), C.byref(o))
         if rc not in (_lib.OK,):
             _lib.check(self.ctx, rc)
@@ -210,6 +244,14 @@ class SpatialWorld:
         o = self._alloc_out(nq, want_records, records_cap)
         _lib.check(self.ctx, self.lib.chd_tick_fetch(self.ctx, C.byref(o)))
         return self._result(o, nq)
+
+    def digest(self, per_connection: bool = True):
+        """Order-independent digest of the last tick's fan-out records, computed on the device:
+        ((count, sum, xor, sum_masked), per-slot sums or None).  See chd_tick_digest."""
+        d = _lib.RecordsDigest()
+        conn = np.zeros(max(self.S, 1), dtype=np.uint64) if per_connection else None
+        _lib.check(self.ctx, self.lib.chd_tick_digest(self.ctx, C.byref(d), _ptr(conn)))
+        return (int(d.count), int(d.sum), int(d.xor_), int(d.sum_masked)), (conn[: self.S] if per_connection else None)
 
     def sync(self):
         _lib.check(self.ctx, self.lib.chd_sync(self.ctx))

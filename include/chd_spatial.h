@@ -36,7 +36,7 @@
 extern "C" {
 #endif
 
-#define CHD_ABI_VERSION 4
+#define CHD_ABI_VERSION 5
 
 typedef struct chd_ctx chd_ctx;
 
@@ -281,10 +281,27 @@ int chd_tick(chd_ctx *ctx, const chd_tick_in *in, chd_tick_out *out);
 
 /* Same, with every input already resident in device memory (d_* pointers of the
  * same layout) and outputs left on the device; asynchronous on the ctx stream.
- * This is what bench.py times.  Use chd_tick_fetch to read the outputs back. */
+ * This is what bench.py times.  Use chd_tick_fetch to read the outputs back.
+ * PRECONDITION (checked by chd_tick, which sees the host arrays and returns CHD_E_INVAL;
+ * not checkable here without a device pass): upd_idx holds no entity slot twice and
+ * query_sub no subscriber slot twice — one update per entity and one interest update per
+ * connection per tick; the host coalesces (keeping the last), as the reference's
+ * sequential handlers would leave it. */
 int chd_tick_device(chd_ctx *ctx, const chd_tick_in *d_in);
 int chd_tick_fetch(chd_ctx *ctx, chd_tick_out *out);
 int chd_sync(chd_ctx *ctx);
+
+/* Order-independent digest of the LAST tick's fan-out records, computed on the device over the records
+ * where they lie (nothing crosses PCIe but the result): with h(r) = mix64(r.conn << 32 | r.channel), mix64 =
+ * SplitMix64's finaliser ((k ^ k>>30) * 0xBF58476D1CE4E5B9, (k ^ k>>27) * 0x94D049BB133111EB, k ^ k>>31),
+ * count = number of records, sum = sum of h (mod 2^64), xor_ = xor of h, sum_masked = sum of
+ * mix64(h + merged-updates mask) (mask = 0 unless the world has CHD_WORLD_UPDATE_MASKS); conn_sum[s]
+ * (optional, max_subscribers entries) = sum of h over connection slot s's records.  A receiver (or a test)
+ * that folds the messages it got the same way can check a whole tick without sorting 10^8 records. */
+typedef struct {
+    uint64_t count, sum, xor_, sum_masked;
+} chd_records_digest;
+int chd_tick_digest(chd_ctx *ctx, chd_records_digest *total, uint64_t *conn_sum);
 
 /* Read back the interest set of a subscriber slot (the keys of
  * Connection.spatialSubscriptions, with the per-subscription fan-out state of
@@ -453,6 +470,12 @@ int chd_dev_alloc(chd_ctx *ctx, uint64_t bytes, void **d_out);
 int chd_dev_free(chd_ctx *ctx, void *d_ptr);
 int chd_dev_upload(chd_ctx *ctx, void *d_dst, const void *src, uint64_t bytes);
 int chd_dev_download(chd_ctx *ctx, void *dst, const void *d_src, uint64_t bytes);
+
+/* Page-locked host memory for the buffers chd_tick / chd_tick_fetch / chd_wire_fetch fill: the device writes it by
+ * DMA at PCIe rate (pageable memory is staged through a bounce buffer at a fraction of it).  A cgo shim allocates
+ * its per-tick output buffers here once and reuses them (C memory, not Go memory: no cgo pointer rules apply). */
+int chd_host_alloc(chd_ctx *ctx, uint64_t bytes, void **out);
+int chd_host_free(chd_ctx *ctx, void *ptr);
 
 /* metrics (channel_tick_duration analogue, metrics.go): GPU time of the last
  * tick per stage in microseconds, measured with HIP events on the ctx stream. */

@@ -88,7 +88,19 @@ typedef struct orc_world {
     int threads;
     struct fan_job_s *jobs; int njobs; /* per-thread record buffers, kept across ticks */
     orc_time stamps[32]; uint32_t nstamps; /* channel times of the last 32 ticks, newest first */
+    /* digest mode (window formulation only): records are not stored, only folded into an order-independent
+     * digest (full-size parity runs: 10^8..10^9 records per tick) */
+    int digest_only;
+    uint64_t d_cnt, d_sum, d_xor, d_sum_masked;
+    uint64_t *d_conn; /* [S] per subscriber slot: sum of the record hashes */
 } orc_world;
+
+/* SplitMix64 finaliser: the record hash of the digests (same function in the device kernel and in tests/) */
+static inline uint64_t mix64(uint64_t k) {
+    k = (k ^ (k >> 30)) * 0xBF58476D1CE4E5B9ull;
+    k = (k ^ (k >> 27)) * 0x94D049BB133111EBull;
+    return k ^ (k >> 31);
+}
 
 static void wbuf_push(wbuf *b, orc_time t, uint32_t sender, uint32_t max_interval_ms) {
     /* data.go:159-172 */
@@ -160,7 +172,7 @@ void orc_world_free(orc_world *w) {
     free(w->sub_alive); free(w->conn_id); free(w->pairs); free(w->pair_cnt);
     free(w->rec); free(w->ho_ent); free(w->ho_src); free(w->ho_dst);
     free(w->ho_srv_src); free(w->ho_srv_dst); free(w->unsub_sub);
-    free(w->unsub_cell); free(w->q_status); free(w->server_of_cell);
+    free(w->unsub_cell); free(w->q_status); free(w->server_of_cell); free(w->d_conn);
     orc__free_jobs(w);
     free(w);
 }
@@ -266,16 +278,26 @@ typedef struct fan_job_s {
     const uint32_t *cell_off_ent; const uint32_t *cell_ents;
     uint32_t c0, c1;
     wrec *rec; uint64_t nrec, caprec;
+    uint64_t d_sum, d_xor, d_sum_masked; uint64_t *d_conn; /* digest mode */
 } fan_job;
 
 static void orc__free_jobs(orc_world *w) {
-    for (int k = 0; k < w->njobs; k++) free(w->jobs[k].rec);
+    for (int k = 0; k < w->njobs; k++) { free(w->jobs[k].rec); free(w->jobs[k].d_conn); }
     free(w->jobs);
     w->jobs = NULL;
     w->njobs = 0;
 }
 
-static void job_push(fan_job *j, uint32_t conn, uint32_t chan, uint32_t mask) {
+static void job_push(fan_job *j, uint32_t slot, uint32_t conn, uint32_t chan, uint32_t mask) {
+    if (j->w->digest_only) {
+        const uint64_t h = mix64(((uint64_t)conn << 32) | chan);
+        j->d_sum += h;
+        j->d_xor ^= h;
+        j->d_sum_masked += mix64(h + mask);
+        j->d_conn[slot] += h;
+        j->nrec++;
+        return;
+    }
     if (j->nrec == j->caprec) {
         j->caprec = j->caprec ? j->caprec * 2 : 4096;
         j->rec = (wrec *)realloc(j->rec, j->caprec * sizeof(wrec));
@@ -316,9 +338,9 @@ static void *fan_cells(void *arg) {
                 uint32_t nw = pair_windows(&tmp, j->t, &wins, &wcap);
                 for (uint32_t wi = 0; wi < nw; wi++) {
                     uint32_t mask = 0;
-                    if (wins[wi].full) job_push(j, conn | REC_FULL, chan, 0);
+                    if (wins[wi].full) job_push(j, subs[si].s, conn | REC_FULL, chan, 0);
                     else if (window_has_update(w, b, wins[wi].last, wins[wi].next, conn, tmp.skip_self, &mask))
-                        job_push(j, conn, chan, mask);
+                        job_push(j, subs[si].s, conn, chan, mask);
                 }
             }
         }
@@ -578,7 +600,7 @@ int orc_world_tick(orc_world *w, orc_time t, uint32_t n_upd, const uint32_t *idx
         int nt = w->threads;
         if ((uint32_t)nt > w->C) nt = (int)w->C;
         if (w->njobs != nt) {
-            for (int k = 0; k < w->njobs; k++) free(w->jobs[k].rec);
+            for (int k = 0; k < w->njobs; k++) { free(w->jobs[k].rec); free(w->jobs[k].d_conn); }
             free(w->jobs);
             w->jobs = (fan_job *)calloc((size_t)nt, sizeof(fan_job));
             w->njobs = nt;
@@ -594,6 +616,11 @@ int orc_world_tick(orc_world *w, orc_time t, uint32_t n_upd, const uint32_t *idx
         uint64_t acc = 0;
         for (int k = 0; k < nt; k++) {
             jobs[k].w = w; jobs[k].t = t; jobs[k].nrec = 0;
+            jobs[k].d_sum = jobs[k].d_xor = jobs[k].d_sum_masked = 0;
+            if (w->digest_only) {
+                if (!jobs[k].d_conn) jobs[k].d_conn = (uint64_t *)malloc(8 * ((size_t)w->S + 1));
+                memset(jobs[k].d_conn, 0, 8 * ((size_t)w->S + 1));
+            }
             jobs[k].cell_off_sub = cell_off_sub; jobs[k].cell_subs = cell_subs;
             jobs[k].cell_off_ent = cell_off_ent; jobs[k].cell_ents = cell_ents;
             jobs[k].c0 = c;
@@ -611,6 +638,15 @@ int orc_world_tick(orc_world *w, orc_time t, uint32_t n_upd, const uint32_t *idx
         }
         w->nrec = 0;
         for (int k = 0; k < nt; k++) w->nrec += jobs[k].nrec;
+        if (w->digest_only) {
+            if (!w->d_conn) w->d_conn = (uint64_t *)malloc(8 * ((size_t)w->S + 1));
+            memset(w->d_conn, 0, 8 * ((size_t)w->S + 1));
+            w->d_cnt = w->nrec; w->d_sum = w->d_xor = w->d_sum_masked = 0;
+            for (int k = 0; k < nt; k++) {
+                w->d_sum += jobs[k].d_sum; w->d_xor ^= jobs[k].d_xor; w->d_sum_masked += jobs[k].d_sum_masked;
+                for (uint32_t q = 0; q < w->S; q++) w->d_conn[q] += jobs[k].d_conn[q];
+            }
+        }
         free(th);
     }
     free(cell_off_sub); free(cell_off_ent); free(cell_subs); free(cell_ents);
@@ -619,6 +655,13 @@ int orc_world_tick(orc_world *w, orc_time t, uint32_t n_upd, const uint32_t *idx
 
 /* ---- accessors ---- */
 uint64_t orc_world_nrec(const orc_world *w) { return w->nrec; }
+/* digest mode: the window formulation folds every record into {count, sum, xor of mix64(conn << 32 | channel), sum of
+ * mix64(that hash + merged-updates mask)} and per subscriber slot the sum of the hashes, instead of storing it */
+void orc_world_set_digest_only(orc_world *w, int on) { w->digest_only = on && !w->literal; }
+void orc_world_digest(const orc_world *w, uint64_t out[4], uint64_t *conn_sum) {
+    out[0] = w->d_cnt; out[1] = w->d_sum; out[2] = w->d_xor; out[3] = w->d_sum_masked;
+    if (conn_sum && w->d_conn) memcpy(conn_sum, w->d_conn, 8 * (size_t)w->S);
+}
 void orc_world_records(const orc_world *w, uint32_t *conn, uint32_t *chan) {
     if (w->literal) {
         for (uint64_t i = 0; i < w->nrec; i++) { conn[i] = w->rec[i].conn; chan[i] = w->rec[i].chan; }

@@ -125,6 +125,8 @@ def lib():
     L.orc_world_nrec.argtypes = [C.c_void_p]
     L.orc_world_records.argtypes = [C.c_void_p, up, up]
     L.orc_world_record_masks.argtypes = [C.c_void_p, up]
+    L.orc_world_set_digest_only.argtypes = [C.c_void_p, C.c_int]
+    L.orc_world_digest.argtypes = [C.c_void_p, P(C.c_uint64), P(C.c_uint64)]
     L.orc_world_nhandover.restype = C.c_uint32
     L.orc_world_nhandover.argtypes = [C.c_void_p]
     L.orc_world_handovers.argtypes = [C.c_void_p, up, up, up, up, up]
@@ -415,6 +417,17 @@ class World:
         chan = np.zeros(max(n, 1), dtype=np.uint32)
         lib().orc_world_records(self.h, _p(conn, C.c_uint32), _p(chan, C.c_uint32))
         return conn[:n], chan[:n]
+
+    def set_digest_only(self, on=True):
+        """window mode: fold the records into an order-independent digest instead of storing them"""
+        lib().orc_world_set_digest_only(self.h, 1 if on else 0)
+
+    def digest(self):
+        """(count, sum, xor, sum_masked), per-slot sums — of the last tick, digest mode"""
+        out = np.zeros(4, dtype=np.uint64)
+        conn = np.zeros(max(self.S, 1), dtype=np.uint64)
+        lib().orc_world_digest(self.h, _p(out, C.c_uint64), _p(conn, C.c_uint64))
+        return tuple(int(v) for v in out), conn[: self.S]
 
     def record_masks(self):
         """window mode: per record of records() the merged-updates mask (bit j = the update of tick current - j)"""

@@ -169,6 +169,43 @@ def test_query_errors(amd):
     assert ctl.QueryChannelIds(Q(amd, BoxAOI=amd.BoxAOI(Center=None, Extent=SI(amd, 1, 1))))[1].code == _lib.E_INVAL
 
 
+def test_query_nan_extents_match_oracle(amd):
+    """A NaN radius / extent with a valid centre: the reference's lattice loops run zero times (`v <= hi` is false with
+    NaN) and the result is {centre cell: 0} (spatial.go:228-232); alone, beside a normal shape whose window does not
+    hold that centre, and with the centre outside the world (the centre error)."""
+    nan = float("nan")
+    grid = (2000, 2000, -15000, -15000, 15, 15)
+    ctl = make_ctl(amd, *grid)
+    g = orc.grid(*grid)
+    qs, obs = [], []
+
+    def add(kw_a, kw_o):
+        qs.append(Q(amd, **kw_a))
+        obs.append(orc.QueryBuilder(**kw_o))
+
+    for cx, cz in ((100.0, 100.0), (-14999.0, 14999.0), (9000.0, -3000.0), (-20000.0, 0.0)):
+        add(dict(SphereAOI=amd.SphereAOI(Center=SI(amd, cx, cz), Radius=nan)), dict(sphere=(cx, cz, nan)))
+        add(dict(BoxAOI=amd.BoxAOI(Center=SI(amd, cx, cz), Extent=SI(amd, nan, 500.0))), dict(box=(cx, cz, nan, 500.0)))
+        add(dict(BoxAOI=amd.BoxAOI(Center=SI(amd, cx, cz), Extent=SI(amd, 500.0, nan))), dict(box=(cx, cz, 500.0, nan)))
+        add(dict(ConeAOI=amd.ConeAOI(Center=SI(amd, cx, cz), Direction=SI(amd, 1, 0), Radius=nan, Angle=0.5)),
+            dict(cone=(cx, cz, 1.0, 0.0, nan, 0.5)))
+        # beside a normal shape far away from this centre
+        add(dict(SphereAOI=amd.SphereAOI(Center=SI(amd, cx, cz), Radius=nan),
+                 BoxAOI=amd.BoxAOI(Center=SI(amd, -9000.0, -9000.0), Extent=SI(amd, 2500.0, 2500.0))),
+            dict(sphere=(cx, cz, nan), box=(-9000.0, -9000.0, 2500.0, 2500.0)))
+        add(dict(ConeAOI=amd.ConeAOI(Center=SI(amd, cx, cz), Direction=SI(amd, 0, 1), Radius=nan, Angle=0.5),
+                 SpotsAOI=amd.SpotsAOI(Spots=[SI(amd, 12000.0, 12000.0)], Dists=[3])),
+            dict(cone=(cx, cz, 0.0, 1.0, nan, 0.5), spots=[(12000.0, 12000.0)], spot_dists=[3]))
+    status, res = ctl.query_channel_ids_batch(qs)
+    n_ok = 0
+    for i in range(len(qs)):
+        rc, want = orc.query_channel_ids(g, obs[i])
+        assert int(status[i]) == rc, f"query {i}: status {status[i]} vs oracle {rc}"
+        assert res[i] == want, f"query {i}: {res[i]} vs {want}"
+        n_ok += rc == 0
+    assert n_ok >= 18
+
+
 # ---------------------------------------------------------------- QueryChannelIds random
 def random_queries(amd, rng, grid, n, multi=False, local_spots=False):
     gw, gh, offx, offz, cols, rows = grid[:6]

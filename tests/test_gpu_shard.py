@@ -172,6 +172,14 @@ def test_4x4_world_on_its_four_servers_matches_single_world():
     assert total > 0 and cross > 0
 
 
+def test_8x8_world_on_its_eight_servers_matches_single_world():
+    """BASELINE config 5's layout (spatial_static_8x8.json: 8x8 cells, ServerCols x ServerRows = 4 x 2) on the HIP
+    engine: eight ranks (sharing the one GPU of the test box, exchange staged through gloo) against the single-world
+    oracle, record for record."""
+    total, cross = launch(8, 6000, 160, 6, 0xC0FFEE15, cfg_name="spatial_static_8x8.json")
+    assert total > 0 and cross > 0
+
+
 def test_rccl_single_rank_bench_path():
     """bench.py's sharded path exactly as the driver launches it (torch.distributed.run, backend "nccl" = RCCL,
     device buffers, everything on torch's stream) — with the one rank a one-GPU box has.  CHD_BENCH_FORCE_DIST makes

@@ -71,13 +71,13 @@ def compare_tick(k, res, ow, S, id_start=0x10000, check_pairs=None, gw=None):
             assert np.array_equal(gnew, wnew), f"tick {k} sub {s}: is_new"
 
 
-def run_world(amd, cfg_name, N, S, ticks, seed, tick_ms=50, capq=0, aoi_scale=1.0, sparse=False, check_subs=8, pauses=None, extra_flags=0):
+def run_world(amd, cfg_name, N, S, ticks, seed, tick_ms=50, capq=0, aoi_scale=1.0, sparse=False, check_subs=8, pauses=None, extra_flags=0, literal=False):
     cfg = synth.load_config(cfg_name)
     g = orc.grid_from_config(cfg)
     spec = synth.WorldSpec(cfg, N, S, seed, tick_ms=tick_ms, aoi_scale=aoi_scale, outside_frac=0.01, locked_frac=0.02)
     sw = synth.SynthWorld(spec)
     ctl, gw = make(amd, cfg, N, S, capq, extra_flags=extra_flags)
-    ow = orc.World(g, N, S, gw.capq, 20, 0, literal=False)
+    ow = orc.World(g, N, S, gw.capq, 20, 0, literal=literal)
     ow.set_threads(4)
     ow.spawn(np.arange(N), sw.chan_id, sw.x, sw.z, sw.flags, sw.sender)
     gw.spawn(None, sw.chan_id, sw.x, sw.z, sw.flags, sw.sender)
@@ -118,6 +118,8 @@ def run_world(amd, cfg_name, N, S, ticks, seed, tick_ms=50, capq=0, aoi_scale=1.
     ocell, omember = ow.entity_state()
     to_id = lambda a: np.where(a == 0xFFFFFFFF, 0, a + 0x10000).astype(np.uint32)
     assert np.array_equal(cell, to_id(ocell)) and np.array_equal(member, to_id(omember))
+    if literal:
+        assert ow.literal_mismatch() == 0  # every channel of a cell evolved its subscribers' state alike
     return total, n_ho
 
 
@@ -127,6 +129,16 @@ def amd():
 
     channeld_amd.load()
     return channeld_amd
+
+
+def test_world_against_the_literal_list_walk(amd):
+    """The GPU against the oracle's LITERAL mode: every spatial and entity channel is a real fanOutQueue walked by the
+    restated tickData (move-to-back + revisit, data.go:175-291) — not the window formulation the other world tests
+    (and the CPU baseline) use.  Irregular and slow ticks so that catch-up windows and 100 ms subscribers occur."""
+    total, n_ho = run_world(amd, "spatial_static_2x2.json", 600, 96, 24, 0xC0FFEE2A, literal=True, pauses={5: 35, 9: 130, 10: 7, 15: 260})
+    assert total > 50000 and n_ho > 0
+    total, n_ho = run_world(amd, "spatial_static_benchmark.json", 1500, 64, 10, 0xC0FFEE2B, literal=True, sparse=True)
+    assert total > 5000
 
 
 def test_world_config_a_2x2(amd):

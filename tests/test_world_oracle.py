@@ -73,3 +73,48 @@ def test_literal_equals_window_after_long_pauses():
     # (the window formulation once capped its list there and spread the catch-up over two ticks)
     total = run_pair("spatial_static_2x2.json", 300, 32, 18, 50, 0xC0FFEE09, capq=4, pauses={5: 90_000, 11: 7_300, 12: 61})
     assert total > 5000
+
+
+def test_digest_mode_equals_the_digest_of_the_stored_records():
+    """Full-size GPU parity folds records into digests instead of storing them (tests/test_gpu_fullsize.py):
+    the oracle's digest mode must be the digest of exactly the records its storing mode returns."""
+    cfg = synth.load_config("spatial_static_2x2.json")
+    g = orc.grid_from_config(cfg)
+    N, S = 800, 128
+    capq = 4
+    worlds = [orc.World(g, N, S, capq, 20, 0, literal=False) for _ in range(2)]
+    worlds[1].set_digest_only(True)
+    worlds[0].set_threads(1)
+    worlds[1].set_threads(3)
+    sw = synth.SynthWorld(synth.WorldSpec(cfg, N, S, 0xD16E57))
+    for w in worlds:
+        w.spawn(np.arange(N), sw.chan_id, sw.x, sw.z, sw.flags, sw.sender)
+        for s in range(S):
+            w.add_sub(s, int(sw.sub_conn[s]))
+
+    def mix64(k):
+        with np.errstate(over="ignore"):
+            k = (k ^ (k >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)
+            k = (k ^ (k >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)
+            return k ^ (k >> np.uint64(31))
+
+    total = 0
+    for k in range(9):
+        sw.step()
+        q = sw.queries()
+        for w in worlds:
+            w.tick(sw.now_ns() + (40_000_000 if k == 5 else 0), None, sw.x, sw.z, None, None, None, None, q)
+        conn, chan = worlds[0].records()
+        masks = worlds[0].record_masks()
+        h = mix64((conn.astype(np.uint64) << np.uint64(32)) | chan.astype(np.uint64))
+        (cnt, dsum, dxor, dmask), per_conn = worlds[1].digest()
+        assert cnt == len(conn)
+        assert dsum == int(np.add.reduce(h, dtype=np.uint64)) and dxor == int(np.bitwise_xor.reduce(h)) if len(h) else dsum == 0
+        with np.errstate(over="ignore"):
+            assert dmask == int(np.add.reduce(mix64(h + masks.astype(np.uint64)), dtype=np.uint64))
+        want = np.zeros(S, dtype=np.uint64)
+        with np.errstate(over="ignore"):
+            np.add.at(want, (conn & 0x7FFFFFFF).astype(np.int64) - 1000, h)
+        assert np.array_equal(per_conn, want)
+        total += cnt
+    assert total > 10000
