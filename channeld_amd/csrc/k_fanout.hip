@@ -36,6 +36,8 @@
 //                   [rec_ub[s] + pair_rel[s][p], + pair_nrec[s][p]).
 // HBM-bound: 8 B written per record (the stream) + the L2/MALL-resident cell
 // tables read; no MFMA — this is gather/compaction, not a contraction.
+#include <cstdlib>
+
 #include "chd_kernels.h"
 
 // -DCHD_PROFILE_CONN_EMIT: per-phase cycle counts of a few sampled workgroups of the connection-major emit kernel,
@@ -116,6 +118,9 @@ __device__ __forceinline__ int64_t empty_windows(const TickRing &ring, int64_t m
 __device__ __forceinline__ bool history_lost(const TickRing &ring, int64_t oldest, int64_t L, int64_t I) {
     return ring.n == CHD_HIST_BITS && oldest > L + I;
 }
+
+__device__ __forceinline__ uint32_t window_mask_serial(const TickRing &ring, int64_t lo, int64_t hi);
+__device__ __forceinline__ int64_t empty_windows_serial(const TickRing &ring, int64_t now, int64_t L, uint32_t iv);
 
 __global__ void __launch_bounds__(64 * FO_WAVES) k_fanout_plan(DevGrid g, WorldDev w, int64_t now, TickRing ring) {
     const uint32_t s = blockIdx.x * FO_WAVES + (threadIdx.x >> 6);
@@ -773,6 +778,306 @@ __global__ void __launch_bounds__(64 * WAVES) k_fanout_emit(DevGrid g, WorldDev 
 }
 
 // ---------------------------------------------------------------------------
+// Connection-major emit, pipelined form (one wave per connection; the launcher takes it when there are enough
+// connections to fill the chip with single waves and no per-record masks are wanted).  Two changes against
+// k_fanout_emit, both aimed at the per-segment latency that bounds it (SQ counters: 74 % of the wave cycles in
+// s_waitcnt, ~12 K cycles per 445-record segment of which ~2.4 K deciding and ~3.6 K waiting for two loads):
+//   * the catch-up window walk of tickData runs ONCE per subscription, lane-parallel in the staging phase (one
+//     lane per subscription, serial over the tick ring), and leaves up to four window masks + the advanced
+//     lastFanOutTime in LDS; the streaming loop only replays masks.  More than four non-empty windows (a
+//     subscription that was not served for several ticks) takes the in-wave walk of k_fanout_emit.
+//   * the channel-id column of the NEXT due subscription's cell (what an all-pass window or a first fan-out
+//     copies; up to 512 entries = two 16-byte loads per lane) is requested before the current segment's records
+//     are stored, and awaited with a COUNTED s_waitcnt: the vm counter is in-order, so `vmcnt(K)` with K <= the
+//     number of stores issued after the loads completes the loads and leaves those stores in flight.  A plain
+//     wait (what the compiler emits for any load) drains every record store issued before it.
+// Same outputs as k_fanout_emit (same segment layout, same state write-back): the parity tests cover both.
+// ---------------------------------------------------------------------------
+#define PI_NWIN_MASK 7u
+#define PI_FIRST 8u
+#define PI_GENERIC 16u
+#define PI_HLOST 32u
+
+// stores of a cell column held in registers (entries [0, n) of the cell, this lane: 4*lane.. and 256 + 4*lane..);
+// returns the records written (n).  `since` counts the wide stores certainly issued (lower bound, wave-uniform).
+__device__ __forceinline__ uint32_t store_column(const u32x4 &ca, const u32x4 &cb, uint32_t n, uint32_t start, uint32_t conn_tag,
+                                                 chd_fanout_rec *__restrict__ out, uint32_t *__restrict__ opos, uint32_t n_out,
+                                                 uint32_t &since) {
+    const uint32_t lane = lane_id();
+    // (opaque copy: left to itself the compiler builds the {tag, channel} register pairs of every store of every
+    // caller up front, from the moment the column registers exist — ~25 VGPRs held across the whole segment loop)
+    asm volatile("" : "+v"(conn_tag));
+#pragma unroll
+    for (int h = 0; h < 2; h++) {
+        const uint32_t k = (h ? 256u : 0u) + 4 * lane;
+        if (h && n <= 256) break;  // uniform
+        if (k < n) {
+            const u32x4 c4 = h ? cb : ca;
+            const uint32_t m = n - k;
+            if (m >= 4) {
+                u32x4 r0, r1;
+                r0.x = conn_tag; r0.y = c4.x; r0.z = conn_tag; r0.w = c4.y;
+                r1.x = conn_tag; r1.y = c4.z; r1.z = conn_tag; r1.w = c4.w;
+                u32x4 *o = (u32x4 *)(void *)(out + n_out + k);
+                o[0] = r0;
+                o[1] = r1;
+                if (opos) {
+                    u32x4 p4;
+                    p4.x = start + k; p4.y = start + k + 1; p4.z = start + k + 2; p4.w = start + k + 3;
+                    *(u32x4 *)(void *)(opos + n_out + k) = p4;
+                }
+            } else {
+                const uint32_t cc[3] = {c4.x, c4.y, c4.z};
+#pragma unroll
+                for (uint32_t q = 0; q < 3; q++) {
+                    if (q < m) {
+                        chd_fanout_rec r;
+                        r.conn = conn_tag;
+                        r.channel = cc[q];
+                        out[n_out + k + q] = r;
+                        if (opos) opos[n_out + k + q] = start + k + q;
+                    }
+                }
+            }
+        }
+        if (n >= (h ? 260u : 4u)) since += 2;  // lane 0 of this half holds four entries: both wide stores were issued
+    }
+    return n_out + n;
+}
+
+__global__ void __launch_bounds__(64) k_fanout_emit_pf(DevGrid g, WorldDev w, int64_t now, TickRing ring) {
+    constexpr uint32_t FO_TILE = 64;
+    __shared__ uint32_t d_p[FO_TILE], d_fl[FO_TILE], d_c[FO_TILE], d_start[FO_TILE], d_end[FO_TILE], d_rel[FO_TILE],
+        d_chh[FO_TILE], d_chs[FO_TILE], d_iv[FO_TILE], d_chhp[FO_TILE], d_chsp[FO_TILE], d_us[FO_TILE], d_hand[FO_TILE],
+        d_info[FO_TILE], d_wm[4][FO_TILE];
+    __shared__ int64_t d_L[FO_TILE], d_Ln[FO_TILE];
+    __shared__ uint32_t n_due;
+    const uint32_t s = blockIdx.x;
+    const uint32_t lane = lane_id();
+    if (!w.sub_alive[s]) {
+        if (lane == 0) w.rec_cnt[s] = 0;
+        return;
+    }
+    const uint32_t cnt = w.pair_cnt[s];
+    const size_t pbase = (size_t)s * w.capq;
+    const uint64_t base = w.rec_ub[s];
+    if (w.rec_ub[s + 1] > w.recs_cap) {
+        // no room for this connection's worst case: state untouched, it catches up next tick
+        for (uint32_t p = lane; p < cnt; p += 64) w.pair_nrec[pbase + p] = 0;
+        if (lane == 0) {
+            w.rec_cnt[s] = 0;
+            if (w.rec_ub[s + 1] > base) atomicOr(&w.counters[CTR_OVERFLOW], OVF_RECORDS);
+        }
+        return;
+    }
+    const uint32_t conn = w.conn_id[s];
+    const int64_t my_t = ring_stamp(ring);  // (generic path only)
+    const int64_t oldest_v = ring.n ? ring.t[ring.n - 1] : INT64_MAX;
+    const int64_t oldest = ((int64_t)__builtin_amdgcn_readfirstlane((int)(oldest_v >> 32)) << 32) |
+                           (uint32_t)__builtin_amdgcn_readfirstlane((int)oldest_v);
+    const uint4 *__restrict__ ce = w.ce_view;
+    const uint32_t *__restrict__ chans = w.ce_chan_view;
+    uint32_t total = 0, hist_ovf = 0;
+    for (uint32_t tile = 0; tile < cnt; tile += FO_TILE) {
+        if (lane == 0) n_due = 0;
+        __syncthreads();
+        {   // stage + decide: one lane per subscription
+            const uint32_t p = tile + lane;
+            bool due = false;
+            uint32_t fl = 0, iv = 0, c = 0, info = 0, wms[4] = {0, 0, 0, 0};
+            int64_t L = 0, Lw = 0;
+            if (p < cnt) {
+                fl = w.pair_flags[pbase + p];
+                L = w.pair_last[pbase + p];
+                iv = w.pair_iv[pbase + p];
+                const int64_t I = (int64_t)iv * 1000000;
+                // data.go:194-197: NO_ACCESS is skipped but stays queued
+                due = !(fl & PF_NO_ACCESS) && I > 0 && now >= L + I;
+                if (due) {
+                    c = w.pair_cell[pbase + p];
+                    Lw = L;
+                    if (!(fl & PF_HAD_FIRST)) {  // data.go:217-223: full state, last = t
+                        info |= PI_FIRST;
+                        Lw = now;
+                    }
+                    uint32_t nw = 0;
+                    if (now >= Lw + I) {
+                        if (history_lost(ring, oldest, Lw, I)) info |= PI_HLOST;
+                        while (now >= Lw + I) {  // data.go:224-271 + the revisit through :273-286
+                            const int64_t next = Lw + I;
+                            const uint32_t wm = window_mask_serial(ring, Lw > 0 ? Lw : 0, next);
+                            if (!wm) {
+                                Lw += empty_windows_serial(ring, now, Lw, iv) * I;
+                                continue;
+                            }
+                            if (nw < 4) wms[nw] = wm;
+                            nw++;
+                            Lw = next;
+                        }
+                    }
+                    if (nw > 4) info |= PI_GENERIC;
+                    info |= nw > 4 ? 4u : nw;
+                } else {
+                    w.pair_nrec[pbase + p] = 0;
+                }
+            }
+            // due subscriptions in list order (ballot compaction: no LDS atomics)
+            const uint64_t dm = __ballot(due);
+            if (due) {
+                const uint32_t k = mask_rank(dm);
+                d_p[k] = p; d_fl[k] = fl; d_L[k] = L; d_Ln[k] = Lw; d_iv[k] = iv; d_c[k] = c; d_info[k] = info;
+                d_wm[0][k] = wms[0]; d_wm[1][k] = wms[1]; d_wm[2][k] = wms[2]; d_wm[3][k] = wms[3];
+                d_rel[k] = w.pair_rel[pbase + p];
+                d_start[k] = w.cell_start[c];
+                d_end[k] = w.cell_end[c];
+                const uint32_t age = ring.cur_tick - w.cell_hist_tick[c];
+                d_chh[k] = age < CHD_HIST_BITS ? (w.cell_hist[c] << age) : 0u;
+                d_chs[k] = w.cell_sender[c];
+                d_chhp[k] = age < CHD_HIST_BITS ? (w.cell_hist_prev[c] << age) : 0u;
+                d_chsp[k] = w.cell_sender_prev[c];
+                uint32_t us = w.ce8_view ? w.cell_usender[c] : CHD_NONUNIFORM;
+                if (w.ce8_view && us == CHD_NONUNIFORM &&
+                    (!(fl & PF_SKIP_SELF) || conn < w.cell_smin[c] || conn > w.cell_smax[c]))
+                    us = CHD_NOT_A_SENDER;
+                d_us[k] = us;
+                d_hand[k] = chans ? w.cell_hand[c] : 0u;
+            }
+            if (lane == 0) n_due = (uint32_t)__popcll(dm);
+        }
+        __syncthreads();
+        const uint32_t ndue = n_due;
+        // the column of the first due subscription, then one segment ahead
+        u32x4 cur_a = {0, 0, 0, 0}, cur_b = {0, 0, 0, 0};
+        auto column_ptrs = [&](uint32_t k, const uint32_t *&pa, const uint32_t *&pb) {
+            const uint32_t st = d_start[k], n = d_end[k] - st;
+            const uint32_t ka = 4 * lane, kb = 256 + 4 * lane;
+            pa = chans + st + (ka < n ? ka : 0u);  // (the column has spare entries behind it)
+            pb = chans + st + (kb < n ? kb : 0u);
+        };
+        if (chans && ndue) {
+            const uint32_t *pa, *pb;
+            column_ptrs(0, pa, pb);
+            asm volatile(
+                "global_load_dwordx4 %0, %2, off\n\t"
+                "global_load_dwordx4 %1, %3, off\n\t"
+                "s_waitcnt vmcnt(0)"
+                : "=&v"(cur_a), "=&v"(cur_b)
+                : "v"(pa), "v"(pb)
+                : "memory");
+        }
+        for (uint32_t k = 0; k < ndue; k++) {
+            u32x4 nxt_a = {0, 0, 0, 0}, nxt_b = {0, 0, 0, 0};
+            const bool prefetch = chans && k + 1 < ndue;
+            if (prefetch) {
+                const uint32_t *pa, *pb;
+                column_ptrs(k + 1, pa, pb);
+                asm volatile(
+                    "global_load_dwordx4 %0, %2, off\n\t"
+                    "global_load_dwordx4 %1, %3, off"
+                    : "=&v"(nxt_a), "=&v"(nxt_b)
+                    : "v"(pa), "v"(pb)
+                    : "memory");
+            }
+            uint32_t since = 0;    // wide stores certainly issued after the prefetch (lower bound)
+            bool drained = false;  // a filtering stream waited for its own loads: everything older has completed
+            const uint32_t p = d_p[k];
+            const uint32_t fl = d_fl[k], info = d_info[k];
+            const uint32_t c = d_c[k];
+            const uint32_t start = d_start[k], end = d_end[k], n = end - start;
+            const bool skip_self = (fl & PF_SKIP_SELF) != 0;
+            const uint32_t us = d_us[k];
+            const bool in_regs = chans && n <= 512;  // the column is in cur_a / cur_b
+            chd_fanout_rec *__restrict__ out = w.recs + base + d_rel[k];
+            uint32_t *__restrict__ opos = w.rec_pos ? w.rec_pos + base + d_rel[k] : nullptr;
+            uint32_t n_out = 0;
+            if (info & PI_HLOST) hist_ovf = 1;
+            if (info & PI_FIRST) {
+                // first fan-out: the whole data of the spatial channel and of every entity channel in it
+                if (lane == 0) {
+                    chd_fanout_rec r;
+                    r.conn = conn | CHD_REC_FULL;
+                    r.channel = c + g.id_start;
+                    out[0] = r;
+                    if (opos) opos[0] = CHD_POS_CELL | c;
+                }
+                if (in_regs) n_out = store_column(cur_a, cur_b, n, start, conn | CHD_REC_FULL, out, opos, 1u, since);
+                else if (chans) n_out = emit_cell_all(chans, start, end, conn | CHD_REC_FULL, out, opos, 1u);
+                else { n_out = emit_cell<true, false>(w, ce, start, end, 0u, false, conn, conn | CHD_REC_FULL, out, opos, 1u); drained = true; }
+            }
+            const uint32_t ch_hist = d_chh[k], ch_sender = d_chs[k];
+            auto one_window = [&](uint32_t wm) {
+                // the spatial channel's own buffered updates
+                if (cell_update_passes(ch_hist, ch_sender, d_chhp[k], d_chsp[k], wm, skip_self, conn)) {
+                    if (lane == 0) {
+                        chd_fanout_rec r;
+                        r.conn = conn;
+                        r.channel = c + g.id_start;
+                        out[n_out] = r;
+                        if (opos) opos[n_out] = CHD_POS_CELL | c;
+                    }
+                    n_out += 1;
+                }
+                if (us == CHD_NONUNIFORM) {
+                    n_out = emit_cell<false, false>(w, ce, start, end, wm, skip_self, conn, conn, out, opos, n_out);
+                    drained = true;
+                } else if (!(skip_self && us == conn)) {
+                    if (d_hand[k] & wm) {
+                        if (in_regs) n_out = store_column(cur_a, cur_b, n, start, conn, out, opos, n_out, since);
+                        else n_out = emit_cell_all(chans, start, end, conn, out, opos, n_out);
+                    } else {
+                        n_out = emit_cell8<false, false>(w.ce8_view, start, end, wm, conn, out, opos, n_out);
+                        drained = true;
+                    }
+                }
+            };
+            if (!(info & PI_GENERIC)) {
+                const uint32_t nw = info & PI_NWIN_MASK;
+                for (uint32_t j = 0; j < nw; j++) one_window(d_wm[j][k]);
+            } else {
+                // more than four non-empty windows: walk them in the wave from the state before this tick
+                int64_t L = (info & PI_FIRST) ? now : d_L[k];
+                const int64_t I = (int64_t)d_iv[k] * 1000000;
+                while (now >= L + I) {
+                    const int64_t next = L + I;
+                    const uint32_t wm = window_mask(my_t, L > 0 ? L : 0, next);
+                    if (!wm) {
+                        L += empty_windows(ring, my_t, now, L, d_iv[k]) * I;
+                        continue;
+                    }
+                    one_window(wm);
+                    L = next;
+                }
+            }
+            pad_segment(out, n_out);
+            if (lane == 0) {
+                w.pair_last[pbase + p] = d_Ln[k];
+                w.pair_flags[pbase + p] = fl | PF_HAD_FIRST;
+                w.pair_nrec[pbase + p] = n_out;
+            }
+            total += n_out;
+            if (prefetch) {
+                // the two loads are older than every store of this segment: a counted wait completes them and
+                // leaves the youngest K stores in flight (K <= the stores certainly issued since)
+                if (drained || since < 2) asm volatile("s_waitcnt vmcnt(0)" : "+v"(nxt_a), "+v"(nxt_b) : : "memory");
+                else if (since < 4) asm volatile("s_waitcnt vmcnt(2)" : "+v"(nxt_a), "+v"(nxt_b) : : "memory");
+                else if (since < 8) asm volatile("s_waitcnt vmcnt(4)" : "+v"(nxt_a), "+v"(nxt_b) : : "memory");
+                else asm volatile("s_waitcnt vmcnt(8)" : "+v"(nxt_a), "+v"(nxt_b) : : "memory");
+                cur_a = nxt_a;
+                cur_b = nxt_b;
+            }
+        }
+        __syncthreads();
+    }
+    if (lane == 0) {
+        if (hist_ovf) atomicAdd(&w.counters[CTR_HIST_OVERFLOW], 1u);
+        w.rec_cnt[s] = total;
+        unsigned long long *slot = (unsigned long long *)&w.tot64[(size_t)(s & 63u) * 16];
+        if (total) atomicAdd(slot, (unsigned long long)total);
+        if (cnt) atomicAdd(slot + 1, (unsigned long long)cnt);
+    }
+}
+
+// ---------------------------------------------------------------------------
 // Cell-major emit (grids up to 4096 cells), wave-specialised and persistent.
 //
 // Work item = (active cell c, chunk of 256 connection slots); unit = (item, tile of
@@ -1263,7 +1568,12 @@ void launch_fanout_emit(hipStream_t st, DevGrid g, WorldDev w, int64_t now_ns, T
         if (w.rec_mask) {
             if (w.S >= 4096) hipLaunchKernelGGL((k_fanout_emit<1, true>), dim3(w.S), dim3(64), 0, st, g, w, now_ns, ring);
             else hipLaunchKernelGGL((k_fanout_emit<4, true>), dim3(w.S), dim3(256), 0, st, g, w, now_ns, ring);
-        } else if (w.S >= 4096) hipLaunchKernelGGL((k_fanout_emit<1, false>), dim3(w.S), dim3(64), 0, st, g, w, now_ns, ring);
+        } else if (w.S >= 4096) {
+            // CHD_EMIT_PIPELINED=0 keeps the first form (A/B runs)
+            static const bool pipelined = [] { const char *e = getenv("CHD_EMIT_PIPELINED"); return !(e && e[0] == '0'); }();
+            if (pipelined) hipLaunchKernelGGL(k_fanout_emit_pf, dim3(w.S), dim3(64), 0, st, g, w, now_ns, ring);
+            else hipLaunchKernelGGL((k_fanout_emit<1, false>), dim3(w.S), dim3(64), 0, st, g, w, now_ns, ring);
+        }
         else hipLaunchKernelGGL((k_fanout_emit<4, false>), dim3(w.S), dim3(256), 0, st, g, w, now_ns, ring);
     }
 }
