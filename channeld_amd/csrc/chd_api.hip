@@ -669,6 +669,7 @@ int chd_world_create(chd_ctx *ctx, const chd_world_cfg *cfg) {
     TRY(walloc(ctx, &d.pair_iv, P));
     TRY(walloc(ctx, &d.pair_last, P));
     TRY(walloc(ctx, &d.pair_flags, P));
+    TRY(walloc(ctx, &d.conn_defer, S));
     TRY(walloc(ctx, &d.pair_rel, P));
     TRY(walloc(ctx, &d.pair_nrec, P));
     TRY(walloc(ctx, &d.rec_ub, S + 1));

@@ -23,6 +23,8 @@
 #define PF_SKIP_SELF 2u  // options.SkipSelfUpdateFanOut
 #define PF_NO_ACCESS 4u  // options.DataAccess == NO_ACCESS
 #define PF_NEW 8u        // subscribed during the current tick
+#define PF_WRITE 16u     // options.DataAccess == WRITE_ACCESS (READ_ACCESS when neither this nor PF_NO_ACCESS is set)
+#define PF_DEFER 32u     // (inside one tick) due, left by the pipelined emit kernel to the deferred launch
 
 // entity flags
 #define EF_LOCKED 1u

@@ -84,6 +84,7 @@ struct WorldDev {
     uint32_t *n_active;             // [1]
     uint32_t emit_grid;             // persistent grid of the cell-major emit kernel (workgroups)
     WsItemG *items;                 // [ncell * ceil(S/256)]
+    uint32_t *conn_defer; // [S] this tick: the connection has subscriptions left to the deferred emit launch
     uint32_t *pair_rel;   // [S*capq] this tick: segment offset inside the connection's record range
     uint32_t *pair_nrec;  // [S*capq] this tick: records emitted for the subscription
     // fan-out outputs

@@ -577,7 +577,9 @@ __device__ __forceinline__ uint32_t emit_cell_all(const uint32_t *__restrict__ c
 // WAVES waves per connection (= subscriptions staged in LDS per round / 64).  Measured at config B (10 K connections,
 // ~18 due subscriptions each): 192.8 / 194.4 / 196.8 / 227 us per launch with 1 / 2 / 4 / 8 waves; the launcher takes
 // one wave per connection when there are enough connections to fill the chip that way, four otherwise.
-template <int WAVES, bool MASKS>
+// DEFERRED: second launch behind k_fanout_emit_pf — only the subscriptions that kernel marked PF_DEFER (their
+// connections are flagged in conn_defer; every other workgroup exits at once), record counts ADDED to the first launch's.
+template <int WAVES, bool MASKS, bool DEFERRED = false>
 __global__ void __launch_bounds__(64 * WAVES) k_fanout_emit(DevGrid g, WorldDev w, int64_t now, TickRing ring) {
     constexpr uint32_t FO_TILE = 64 * WAVES;
     // due subscriptions of this connection, staged once per workgroup so that the
@@ -590,7 +592,9 @@ __global__ void __launch_bounds__(64 * WAVES) k_fanout_emit(DevGrid g, WorldDev 
     const uint32_t s = blockIdx.x;
     const uint32_t lane = lane_id();
     const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    if (!w.sub_alive[s]) {
+    if (DEFERRED) {
+        if (!w.conn_defer[s]) return;
+    } else if (!w.sub_alive[s]) {
         if (threadIdx.x == 0) w.rec_cnt[s] = 0;
         return;
     }
@@ -633,10 +637,10 @@ __global__ void __launch_bounds__(64 * WAVES) k_fanout_emit(DevGrid g, WorldDev 
                 const uint32_t iv = w.pair_iv[pbase + p];
                 const int64_t I = (int64_t)iv * 1000000;
                 // data.go:194-197: NO_ACCESS is skipped but stays queued
-                if (!(fl & PF_NO_ACCESS) && I > 0 && now >= L + I) {
+                if (DEFERRED ? (fl & PF_DEFER) != 0 : (!(fl & PF_NO_ACCESS) && I > 0 && now >= L + I)) {
                     const uint32_t c = w.pair_cell[pbase + p];
                     const uint32_t k = atomicAdd(&n_due, 1u);
-                    d_p[k] = p; d_fl[k] = fl; d_L[k] = L; d_iv[k] = iv; d_c[k] = c;
+                    d_p[k] = p; d_fl[k] = fl & ~PF_DEFER; d_L[k] = L; d_iv[k] = iv; d_c[k] = c;
                     d_rel[k] = w.pair_rel[pbase + p];
                     d_start[k] = w.cell_start[c];
                     d_end[k] = w.cell_end[c];
@@ -656,7 +660,7 @@ __global__ void __launch_bounds__(64 * WAVES) k_fanout_emit(DevGrid g, WorldDev 
                         us = CHD_NOT_A_SENDER;
                     d_us[k] = us;
                     d_hand[k] = w.ce_chan_view ? w.cell_hand[c] : 0u;
-                } else {
+                } else if (!DEFERRED) {
                     w.pair_nrec[pbase + p] = 0;
                 }
             }
@@ -768,12 +772,12 @@ __global__ void __launch_bounds__(64 * WAVES) k_fanout_emit(DevGrid g, WorldDev 
     if (threadIdx.x == 0) {
         uint32_t t = 0;
         for (int k = 0; k < WAVES; k++) t += wave_total[k];
-        w.rec_cnt[s] = t;
+        w.rec_cnt[s] = DEFERRED ? w.rec_cnt[s] + t : t;
         // per-tick totals go through 64 hashed counters, one 128-byte line each: a
         // single word (or words sharing a line) would serialise S atomics at ~12 ns
         unsigned long long *slot = (unsigned long long *)&w.tot64[(size_t)(s & 63u) * 16];
         if (t) atomicAdd(slot, (unsigned long long)t);
-        if (cnt) atomicAdd(slot + 1, (unsigned long long)cnt);
+        if (cnt && !DEFERRED) atomicAdd(slot + 1, (unsigned long long)cnt);
     }
 }
 
@@ -797,6 +801,7 @@ __global__ void __launch_bounds__(64 * WAVES) k_fanout_emit(DevGrid g, WorldDev 
 #define PI_FIRST 8u
 #define PI_GENERIC 16u
 #define PI_HLOST 32u
+#define PI_NONE 64u  // SkipSelfUpdateFanOut and the cell's only sender is this connection: no entity record passes
 
 // stores of a cell column held in registers (entries [0, n) of the cell, this lane: 4*lane.. and 256 + 4*lane..);
 // returns the records written (n).  `since` counts the wide stores certainly issued (lower bound, wave-uniform).
@@ -848,14 +853,13 @@ __device__ __forceinline__ uint32_t store_column(const u32x4 &ca, const u32x4 &c
 __global__ void __launch_bounds__(64) k_fanout_emit_pf(DevGrid g, WorldDev w, int64_t now, TickRing ring) {
     constexpr uint32_t FO_TILE = 64;
     __shared__ uint32_t d_p[FO_TILE], d_fl[FO_TILE], d_c[FO_TILE], d_start[FO_TILE], d_end[FO_TILE], d_rel[FO_TILE],
-        d_chh[FO_TILE], d_chs[FO_TILE], d_iv[FO_TILE], d_chhp[FO_TILE], d_chsp[FO_TILE], d_us[FO_TILE], d_hand[FO_TILE],
-        d_info[FO_TILE], d_wm[4][FO_TILE];
-    __shared__ int64_t d_L[FO_TILE], d_Ln[FO_TILE];
+        d_chh[FO_TILE], d_chs[FO_TILE], d_chhp[FO_TILE], d_chsp[FO_TILE], d_info[FO_TILE], d_wm[4][FO_TILE];
+    __shared__ int64_t d_Ln[FO_TILE];
     __shared__ uint32_t n_due;
     const uint32_t s = blockIdx.x;
     const uint32_t lane = lane_id();
     if (!w.sub_alive[s]) {
-        if (lane == 0) w.rec_cnt[s] = 0;
+        if (lane == 0) { w.rec_cnt[s] = 0; w.conn_defer[s] = 0; }
         return;
     }
     const uint32_t cnt = w.pair_cnt[s];
@@ -866,16 +870,16 @@ __global__ void __launch_bounds__(64) k_fanout_emit_pf(DevGrid g, WorldDev w, in
         for (uint32_t p = lane; p < cnt; p += 64) w.pair_nrec[pbase + p] = 0;
         if (lane == 0) {
             w.rec_cnt[s] = 0;
+            w.conn_defer[s] = 0;
             if (w.rec_ub[s + 1] > base) atomicOr(&w.counters[CTR_OVERFLOW], OVF_RECORDS);
         }
         return;
     }
     const uint32_t conn = w.conn_id[s];
-    const int64_t my_t = ring_stamp(ring);  // (generic path only)
+    uint32_t any_deferred = 0;
     const int64_t oldest_v = ring.n ? ring.t[ring.n - 1] : INT64_MAX;
     const int64_t oldest = ((int64_t)__builtin_amdgcn_readfirstlane((int)(oldest_v >> 32)) << 32) |
                            (uint32_t)__builtin_amdgcn_readfirstlane((int)oldest_v);
-    const uint4 *__restrict__ ce = w.ce_view;
     const uint32_t *__restrict__ chans = w.ce_chan_view;
     uint32_t total = 0, hist_ovf = 0;
     for (uint32_t tile = 0; tile < cnt; tile += FO_TILE) {
@@ -921,11 +925,32 @@ __global__ void __launch_bounds__(64) k_fanout_emit_pf(DevGrid g, WorldDev w, in
                     w.pair_nrec[pbase + p] = 0;
                 }
             }
-            // due subscriptions in list order (ballot compaction: no LDS atomics)
-            const uint64_t dm = __ballot(due);
+            // Segments every window of which is a plain copy of the cell's channel column (or nothing at all) are
+            // streamed here; the others — a window some entity has no update in, a cell whose senders include this
+            // connection, more than four non-empty windows — are left to the second launch (k_fanout_emit<.., DEFERRED>):
+            // their filtering streams, inlined here, cost the common path 50 VGPRs and two waves per SIMD.
+            uint32_t us = CHD_NONUNIFORM, hand = 0;
+            bool simple = false;
             if (due) {
+                us = w.ce8_view ? w.cell_usender[c] : CHD_NONUNIFORM;
+                if (w.ce8_view && us == CHD_NONUNIFORM &&
+                    (!(fl & PF_SKIP_SELF) || conn < w.cell_smin[c] || conn > w.cell_smax[c]))
+                    us = CHD_NOT_A_SENDER;
+                hand = chans ? w.cell_hand[c] : 0u;
+                simple = chans != nullptr && !(info & PI_GENERIC);
+                const bool none = (fl & PF_SKIP_SELF) && us == conn;  // every buffered entity update is this connection's own
+                const uint32_t nw = info & PI_NWIN_MASK;
+#pragma unroll
+                for (uint32_t j = 0; j < 4; j++)
+                    if (j < nw && !none && (us == CHD_NONUNIFORM || !(hand & wms[j]))) simple = false;
+                if (!simple) w.pair_flags[pbase + p] = fl | PF_DEFER;
+            }
+            if (__ballot(due && !simple)) any_deferred = 1;
+            // due subscriptions in list order (ballot compaction: no LDS atomics)
+            const uint64_t dm = __ballot(due && simple);
+            if (due && simple) {
                 const uint32_t k = mask_rank(dm);
-                d_p[k] = p; d_fl[k] = fl; d_L[k] = L; d_Ln[k] = Lw; d_iv[k] = iv; d_c[k] = c; d_info[k] = info;
+                d_p[k] = p; d_fl[k] = fl; d_Ln[k] = Lw; d_c[k] = c; d_info[k] = info | (((fl & PF_SKIP_SELF) && us == conn) ? PI_NONE : 0u);
                 d_wm[0][k] = wms[0]; d_wm[1][k] = wms[1]; d_wm[2][k] = wms[2]; d_wm[3][k] = wms[3];
                 d_rel[k] = w.pair_rel[pbase + p];
                 d_start[k] = w.cell_start[c];
@@ -935,12 +960,6 @@ __global__ void __launch_bounds__(64) k_fanout_emit_pf(DevGrid g, WorldDev w, in
                 d_chs[k] = w.cell_sender[c];
                 d_chhp[k] = age < CHD_HIST_BITS ? (w.cell_hist_prev[c] << age) : 0u;
                 d_chsp[k] = w.cell_sender_prev[c];
-                uint32_t us = w.ce8_view ? w.cell_usender[c] : CHD_NONUNIFORM;
-                if (w.ce8_view && us == CHD_NONUNIFORM &&
-                    (!(fl & PF_SKIP_SELF) || conn < w.cell_smin[c] || conn > w.cell_smax[c]))
-                    us = CHD_NOT_A_SENDER;
-                d_us[k] = us;
-                d_hand[k] = chans ? w.cell_hand[c] : 0u;
             }
             if (lane == 0) n_due = (uint32_t)__popcll(dm);
         }
@@ -979,14 +998,12 @@ __global__ void __launch_bounds__(64) k_fanout_emit_pf(DevGrid g, WorldDev w, in
                     : "memory");
             }
             uint32_t since = 0;    // wide stores certainly issued after the prefetch (lower bound)
-            bool drained = false;  // a filtering stream waited for its own loads: everything older has completed
             const uint32_t p = d_p[k];
             const uint32_t fl = d_fl[k], info = d_info[k];
             const uint32_t c = d_c[k];
             const uint32_t start = d_start[k], end = d_end[k], n = end - start;
             const bool skip_self = (fl & PF_SKIP_SELF) != 0;
-            const uint32_t us = d_us[k];
-            const bool in_regs = chans && n <= 512;  // the column is in cur_a / cur_b
+            const bool in_regs = n <= 512;  // the column is in cur_a / cur_b
             chd_fanout_rec *__restrict__ out = w.recs + base + d_rel[k];
             uint32_t *__restrict__ opos = w.rec_pos ? w.rec_pos + base + d_rel[k] : nullptr;
             uint32_t n_out = 0;
@@ -1001,11 +1018,12 @@ __global__ void __launch_bounds__(64) k_fanout_emit_pf(DevGrid g, WorldDev w, in
                     if (opos) opos[0] = CHD_POS_CELL | c;
                 }
                 if (in_regs) n_out = store_column(cur_a, cur_b, n, start, conn | CHD_REC_FULL, out, opos, 1u, since);
-                else if (chans) n_out = emit_cell_all(chans, start, end, conn | CHD_REC_FULL, out, opos, 1u);
-                else { n_out = emit_cell<true, false>(w, ce, start, end, 0u, false, conn, conn | CHD_REC_FULL, out, opos, 1u); drained = true; }
+                else n_out = emit_cell_all(chans, start, end, conn | CHD_REC_FULL, out, opos, 1u);
             }
             const uint32_t ch_hist = d_chh[k], ch_sender = d_chs[k];
-            auto one_window = [&](uint32_t wm) {
+            const uint32_t nw = info & PI_NWIN_MASK;
+            for (uint32_t j = 0; j < nw; j++) {
+                const uint32_t wm = d_wm[j][k];
                 // the spatial channel's own buffered updates
                 if (cell_update_passes(ch_hist, ch_sender, d_chhp[k], d_chsp[k], wm, skip_self, conn)) {
                     if (lane == 0) {
@@ -1017,35 +1035,9 @@ __global__ void __launch_bounds__(64) k_fanout_emit_pf(DevGrid g, WorldDev w, in
                     }
                     n_out += 1;
                 }
-                if (us == CHD_NONUNIFORM) {
-                    n_out = emit_cell<false, false>(w, ce, start, end, wm, skip_self, conn, conn, out, opos, n_out);
-                    drained = true;
-                } else if (!(skip_self && us == conn)) {
-                    if (d_hand[k] & wm) {
-                        if (in_regs) n_out = store_column(cur_a, cur_b, n, start, conn, out, opos, n_out, since);
-                        else n_out = emit_cell_all(chans, start, end, conn, out, opos, n_out);
-                    } else {
-                        n_out = emit_cell8<false, false>(w.ce8_view, start, end, wm, conn, out, opos, n_out);
-                        drained = true;
-                    }
-                }
-            };
-            if (!(info & PI_GENERIC)) {
-                const uint32_t nw = info & PI_NWIN_MASK;
-                for (uint32_t j = 0; j < nw; j++) one_window(d_wm[j][k]);
-            } else {
-                // more than four non-empty windows: walk them in the wave from the state before this tick
-                int64_t L = (info & PI_FIRST) ? now : d_L[k];
-                const int64_t I = (int64_t)d_iv[k] * 1000000;
-                while (now >= L + I) {
-                    const int64_t next = L + I;
-                    const uint32_t wm = window_mask(my_t, L > 0 ? L : 0, next);
-                    if (!wm) {
-                        L += empty_windows(ring, my_t, now, L, d_iv[k]) * I;
-                        continue;
-                    }
-                    one_window(wm);
-                    L = next;
+                if (!(info & PI_NONE)) {  // every entity passes this window (checked when the segment was classified)
+                    if (in_regs) n_out = store_column(cur_a, cur_b, n, start, conn, out, opos, n_out, since);
+                    else n_out = emit_cell_all(chans, start, end, conn, out, opos, n_out);
                 }
             }
             pad_segment(out, n_out);
@@ -1058,7 +1050,7 @@ __global__ void __launch_bounds__(64) k_fanout_emit_pf(DevGrid g, WorldDev w, in
             if (prefetch) {
                 // the two loads are older than every store of this segment: a counted wait completes them and
                 // leaves the youngest K stores in flight (K <= the stores certainly issued since)
-                if (drained || since < 2) asm volatile("s_waitcnt vmcnt(0)" : "+v"(nxt_a), "+v"(nxt_b) : : "memory");
+                if (since < 2) asm volatile("s_waitcnt vmcnt(0)" : "+v"(nxt_a), "+v"(nxt_b) : : "memory");
                 else if (since < 4) asm volatile("s_waitcnt vmcnt(2)" : "+v"(nxt_a), "+v"(nxt_b) : : "memory");
                 else if (since < 8) asm volatile("s_waitcnt vmcnt(4)" : "+v"(nxt_a), "+v"(nxt_b) : : "memory");
                 else asm volatile("s_waitcnt vmcnt(8)" : "+v"(nxt_a), "+v"(nxt_b) : : "memory");
@@ -1071,6 +1063,7 @@ __global__ void __launch_bounds__(64) k_fanout_emit_pf(DevGrid g, WorldDev w, in
     if (lane == 0) {
         if (hist_ovf) atomicAdd(&w.counters[CTR_HIST_OVERFLOW], 1u);
         w.rec_cnt[s] = total;
+        w.conn_defer[s] = any_deferred;
         unsigned long long *slot = (unsigned long long *)&w.tot64[(size_t)(s & 63u) * 16];
         if (total) atomicAdd(slot, (unsigned long long)total);
         if (cnt) atomicAdd(slot + 1, (unsigned long long)cnt);
@@ -1571,7 +1564,10 @@ void launch_fanout_emit(hipStream_t st, DevGrid g, WorldDev w, int64_t now_ns, T
         } else if (w.S >= 4096) {
             // CHD_EMIT_PIPELINED=0 keeps the first form (A/B runs)
             static const bool pipelined = [] { const char *e = getenv("CHD_EMIT_PIPELINED"); return !(e && e[0] == '0'); }();
-            if (pipelined) hipLaunchKernelGGL(k_fanout_emit_pf, dim3(w.S), dim3(64), 0, st, g, w, now_ns, ring);
+            if (pipelined) {
+                hipLaunchKernelGGL(k_fanout_emit_pf, dim3(w.S), dim3(64), 0, st, g, w, now_ns, ring);
+                hipLaunchKernelGGL((k_fanout_emit<1, false, true>), dim3(w.S), dim3(64), 0, st, g, w, now_ns, ring);
+            }
             else hipLaunchKernelGGL((k_fanout_emit<1, false>), dim3(w.S), dim3(64), 0, st, g, w, now_ns, ring);
         }
         else hipLaunchKernelGGL((k_fanout_emit<4, false>), dim3(w.S), dim3(256), 0, st, g, w, now_ns, ring);
