@@ -10,7 +10,8 @@ import ctypes as C
 import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "libchd_spatial.so")
+# CHD_SPATIAL_LIB: another build of the same library (A/B runs of kernel variants; channeld_amd/build.py --variant)
+LIB_PATH = os.environ.get("CHD_SPATIAL_LIB") or os.path.join(HERE, "libchd_spatial.so")
 
 OK = 0
 E_CONFIG, E_INVAL, E_EXTENT, E_CENTER, E_CAPACITY, E_HANG = -1, -2, -3, -4, -5, -6
@@ -24,6 +25,7 @@ WORLD_HANDOVER_RECIPIENTS = 4
 WORLD_WIRE = 8
 WORLD_OVERLAP_INTEREST = 16
 WORLD_UPDATE_MASKS = 32
+WORLD_ONE_WAVE_EMIT = 64
 WIRE_ENTITY_UPDATE, WIRE_ENTITY_FULL, WIRE_CELL_UPDATE, WIRE_CELL_FULL = 0, 1, 2, 3
 HO_SRC_ONLY, HO_DST_NEW, HO_DST_KNOWN = 0, 1, 2
 BROADCAST_ALL_BUT_SENDER, BROADCAST_ALL_BUT_OWNER, BROADCAST_ALL_BUT_CLIENT, BROADCAST_ALL_BUT_SERVER = 4, 8, 16, 32

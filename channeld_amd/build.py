@@ -68,5 +68,34 @@ def build(force: bool = False, verbose: bool = False) -> str:
     return LIB
 
 
+def build_variant(name: str, extra_flags) -> str:
+    """A second build with extra compiler flags (e.g. -DFO_PF_WAVES=7) as channeld_amd/variants/libchd_<name>.so;
+    select it with CHD_SPATIAL_LIB=<path>.  For A/B measurements of kernel variants in one GPU session."""
+    cc = hipcc()
+    vdir = os.path.join(HERE, "variants")
+    bdir = os.path.join(HERE, "build", "variant_" + name)
+    os.makedirs(vdir, exist_ok=True)
+    os.makedirs(bdir, exist_ok=True)
+    procs, objs = [], []
+    for s in SOURCES:
+        o = os.path.join(bdir, s.replace(".hip", ".o"))
+        objs.append(o)
+        procs.append((s, subprocess.Popen([cc, *FLAGS, *extra_flags, "-c", os.path.join(CSRC, s), "-o", o],
+                                          stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)))
+    for s, p in procs:
+        out, _ = p.communicate()
+        if p.returncode != 0:
+            raise RuntimeError(f"hipcc failed on {s}:\n{out}")
+    lib = os.path.join(vdir, f"libchd_{name}.so")
+    r = subprocess.run([cc, "--offload-arch=gfx950", "-shared", "-fPIC", *objs, "-o", lib], capture_output=True, text=True)
+    if r.returncode != 0:
+        raise RuntimeError(f"link failed:\n{r.stdout}\n{r.stderr}")
+    return lib
+
+
 if __name__ == "__main__":
-    print(build(force="--force" in sys.argv, verbose=True))
+    if "--variant" in sys.argv:
+        i = sys.argv.index("--variant")
+        print(build_variant(sys.argv[i + 1], sys.argv[i + 2:]))
+    else:
+        print(build(force="--force" in sys.argv, verbose=True))

@@ -640,6 +640,7 @@ int chd_world_create(chd_ctx *ctx, const chd_world_cfg *cfg) {
     // the recipient planners use it too; larger grids fall back to searching the sorted subscription lists
     d.wb = C <= 4096 ? (uint32_t)((C + 63) / 64) : 0u;
     d.cm_emit = (cm_possible && cm_wanted && !want_masks) ? 1u : 0u;
+    d.one_wave_emit = (cfg->flags & CHD_WORLD_ONE_WAVE_EMIT) ? 1u : 0u;
     d.sub_bits = nullptr;
     d.items = nullptr;
     if (d.wb) TRY(walloc(ctx, &d.sub_bits, S * d.wb));

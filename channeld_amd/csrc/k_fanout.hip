@@ -850,7 +850,10 @@ __device__ __forceinline__ uint32_t store_column(const u32x4 &ca, const u32x4 &c
     return n_out + n;
 }
 
-__global__ void __launch_bounds__(64) k_fanout_emit_pf(DevGrid g, WorldDev w, int64_t now, TickRing ring) {
+#ifndef FO_PF_WAVES
+#define FO_PF_WAVES 6
+#endif
+__global__ void __launch_bounds__(64, FO_PF_WAVES) k_fanout_emit_pf(DevGrid g, WorldDev w, int64_t now, TickRing ring) {
     constexpr uint32_t FO_TILE = 64;
     __shared__ uint32_t d_p[FO_TILE], d_fl[FO_TILE], d_c[FO_TILE], d_start[FO_TILE], d_end[FO_TILE], d_rel[FO_TILE],
         d_chh[FO_TILE], d_chs[FO_TILE], d_chhp[FO_TILE], d_chsp[FO_TILE], d_info[FO_TILE], d_wm[4][FO_TILE];
@@ -1558,19 +1561,20 @@ void launch_fanout_emit(hipStream_t st, DevGrid g, WorldDev w, int64_t now_ns, T
         hipLaunchKernelGGL(k_fanout_items, dim3(pgrid), dim3(WS_SUBS), 0, st, g, w, now_ns, ring, chunks);
         hipLaunchKernelGGL(k_fanout_emit_ws, dim3(grid), dim3(64 * WS_WAVES), 0, st, g, w, now_ns, ring, chunks);
     } else {
+        // one wave per connection when the connections alone fill the chip (or when asked to: CHD_WORLD_ONE_WAVE_EMIT),
+        // four waves per connection otherwise
+        const bool one_wave = w.S >= 4096 || w.one_wave_emit;
         if (w.rec_mask) {
-            if (w.S >= 4096) hipLaunchKernelGGL((k_fanout_emit<1, true>), dim3(w.S), dim3(64), 0, st, g, w, now_ns, ring);
+            if (one_wave) hipLaunchKernelGGL((k_fanout_emit<1, true>), dim3(w.S), dim3(64), 0, st, g, w, now_ns, ring);
             else hipLaunchKernelGGL((k_fanout_emit<4, true>), dim3(w.S), dim3(256), 0, st, g, w, now_ns, ring);
-        } else if (w.S >= 4096) {
+        } else if (one_wave) {
             // CHD_EMIT_PIPELINED=0 keeps the first form (A/B runs)
             static const bool pipelined = [] { const char *e = getenv("CHD_EMIT_PIPELINED"); return !(e && e[0] == '0'); }();
             if (pipelined) {
                 hipLaunchKernelGGL(k_fanout_emit_pf, dim3(w.S), dim3(64), 0, st, g, w, now_ns, ring);
                 hipLaunchKernelGGL((k_fanout_emit<1, false, true>), dim3(w.S), dim3(64), 0, st, g, w, now_ns, ring);
-            }
-            else hipLaunchKernelGGL((k_fanout_emit<1, false>), dim3(w.S), dim3(64), 0, st, g, w, now_ns, ring);
-        }
-        else hipLaunchKernelGGL((k_fanout_emit<4, false>), dim3(w.S), dim3(256), 0, st, g, w, now_ns, ring);
+            } else hipLaunchKernelGGL((k_fanout_emit<1, false>), dim3(w.S), dim3(64), 0, st, g, w, now_ns, ring);
+        } else hipLaunchKernelGGL((k_fanout_emit<4, false>), dim3(w.S), dim3(256), 0, st, g, w, now_ns, ring);
     }
 }
 

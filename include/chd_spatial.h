@@ -191,6 +191,10 @@ typedef struct {
  * +4 B per record; windows every entity passes are then streamed with their histories instead of as a plain copy. */
 #define CHD_WORLD_UPDATE_MASKS 32u
 
+/* connection-major emit: one wave per connection (the pipelined form) also for worlds of fewer than 4096 connections,
+ * where four waves per connection is the default.  For tests and for small worlds with few subscriptions per connection. */
+#define CHD_WORLD_ONE_WAVE_EMIT 64u
+
 #define CHD_ENTITY_LOCKED 1u /* member of a non-empty lock group (entity.go:197-224) */
 
 int chd_world_create(chd_ctx *ctx, const chd_world_cfg *cfg);

@@ -16,11 +16,14 @@ pytestmark = pytest.mark.gpu
 EMIT_FLAGS = 0
 
 
-@pytest.fixture(autouse=True, params=["cell-major", "conn-major"])
+@pytest.fixture(autouse=True, params=["cell-major", "conn-major", "conn-major-1w"])
 def emit_mode(request):
-    """Every world test runs against both forms of the fan-out emit kernel."""
+    """Every world test runs against every form of the fan-out emit kernel: cell-major, connection-major with four
+    waves per connection, and connection-major with one wave per connection (the pipelined kernel + its deferred
+    launch: what config B's 10K connections take)."""
     global EMIT_FLAGS
-    EMIT_FLAGS = 1 if request.param == "conn-major" else 2  # CHD_WORLD_CONN_MAJOR_EMIT / CHD_WORLD_CELL_MAJOR_EMIT
+    # CHD_WORLD_CONN_MAJOR_EMIT / CHD_WORLD_CELL_MAJOR_EMIT / | CHD_WORLD_ONE_WAVE_EMIT
+    EMIT_FLAGS = {"conn-major": 1, "cell-major": 2, "conn-major-1w": 1 | 64}[request.param]
     yield request.param
 
 
@@ -265,7 +268,7 @@ def mask_variants(emit_mode):
     """world flags to run a scenario with: plain, and with update masks where the emit form writes them"""
     from channeld_amd import _lib
 
-    return (0, _lib.WORLD_UPDATE_MASKS) if emit_mode == "conn-major" else (0,)
+    return (0, _lib.WORLD_UPDATE_MASKS) if emit_mode.startswith("conn-major") else (0,)
 
 
 def test_cell_channel_updates_and_self_skip(amd, emit_mode):
