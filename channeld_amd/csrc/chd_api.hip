@@ -617,7 +617,7 @@ int chd_world_create(chd_ctx *ctx, const chd_world_cfg *cfg) {
     TRY(walloc(ctx, &d.blk_smax, C * d.nblk + 1));
     TRY(walloc(ctx, &d.blk_hand, C * d.nblk + 1));
     TRY(walloc(ctx, &d.cell_hand, C));
-    TRY(walloc(ctx, &d.ce_chan, N + 8));
+    TRY(walloc(ctx, &d.ce_chan, N + 520));  // + 512: the pipelined emit loads a whole 512-entry column image at any cell start
     TRY(walloc(ctx, &d.cell_off, C + 1));
     TRY(walloc(ctx, &d.cell_tot, C));
     TRY(walloc(ctx, &d.cell_ref, C));

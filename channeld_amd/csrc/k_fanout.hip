@@ -850,6 +850,40 @@ __device__ __forceinline__ uint32_t store_column(const u32x4 &ca, const u32x4 &c
     return n_out + n;
 }
 
+// The same column held as FOUR adjacent PAIRS per lane (q[h] = entries 128 h + 2 lane, + 1; four 8-byte loads, each one
+// 512 contiguous bytes per wave): every store instruction then writes ONE contiguous 1 KiB run of records (8 whole
+// 128-byte lines) instead of 16-byte pieces at a 32-byte stride — half of every line, the other halves coming with the
+// next instruction, i.e. two byte-masked write requests per line (tools/ubench/store_pair.hip measures the two layouts).
+typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ uint32_t store_column2(const u32x2 (&q)[4], uint32_t n, uint32_t start, uint32_t conn_tag,
+                                                  chd_fanout_rec *__restrict__ out, uint32_t *__restrict__ opos, uint32_t n_out,
+                                                  uint32_t &since) {
+    const uint32_t lane = lane_id();
+    asm volatile("" : "+v"(conn_tag));  // (see store_column)
+#pragma unroll
+    for (int h = 0; h < 4; h++) {
+        if (n <= (uint32_t)(128 * h)) break;  // uniform
+        const uint32_t k = 128u * h + 2 * lane;
+        if (k + 1 < n) {
+            u32x4 r;
+            r.x = conn_tag; r.y = q[h].x; r.z = conn_tag; r.w = q[h].y;
+            *(u32x4 *)(void *)(out + n_out + k) = r;
+            if (opos) { opos[n_out + k] = start + k; opos[n_out + k + 1] = start + k + 1; }
+        } else if (k < n) {
+            chd_fanout_rec r;
+            r.conn = conn_tag;
+            r.channel = q[h].x;
+            out[n_out + k] = r;
+            if (opos) opos[n_out + k] = start + k;
+        }
+        if (n >= (uint32_t)(128 * h + 2)) since += 1;  // lane 0 holds a whole pair: the wide store was issued
+    }
+    return n_out + n;
+}
+
+#ifndef FO_PF_LAYOUT
+#define FO_PF_LAYOUT 1  // 1: pairs per lane, contiguous stores (store_column2); 0: four entries per lane (store_column)
+#endif
 #ifndef FO_PF_WAVES
 #define FO_PF_WAVES 6
 #endif
@@ -969,6 +1003,40 @@ __global__ void __launch_bounds__(64, FO_PF_WAVES) k_fanout_emit_pf(DevGrid g, W
         __syncthreads();
         const uint32_t ndue = n_due;
         // the column of the first due subscription, then one segment ahead
+#if FO_PF_LAYOUT == 1
+        u32x2 cur[4] = {{0, 0}, {0, 0}, {0, 0}, {0, 0}};
+        auto column_ptr = [&](uint32_t k) {
+            // q[h] = entries 128 h + 2 lane, + 1 of the cell: ONE address register, the four quarters are immediate offsets
+            // (lanes beyond the cell read the spare entries behind the column or the next cells': never used)
+            return chans + d_start[k] + 2 * lane;
+        };
+        if (chans && ndue) {
+            const uint32_t *pa = column_ptr(0);
+            asm volatile(
+                "global_load_dwordx2 %0, %4, off\n\t"
+                "global_load_dwordx2 %1, %4, off offset:512\n\t"
+                "global_load_dwordx2 %2, %4, off offset:1024\n\t"
+                "global_load_dwordx2 %3, %4, off offset:1536\n\t"
+                "s_waitcnt vmcnt(0)"
+                : "=&v"(cur[0]), "=&v"(cur[1]), "=&v"(cur[2]), "=&v"(cur[3])
+                : "v"(pa)
+                : "memory");
+        }
+        for (uint32_t k = 0; k < ndue; k++) {
+            u32x2 nxt[4] = {{0, 0}, {0, 0}, {0, 0}, {0, 0}};
+            const bool prefetch = chans && k + 1 < ndue;
+            if (prefetch) {
+                const uint32_t *pa = column_ptr(k + 1);
+                asm volatile(
+                    "global_load_dwordx2 %0, %4, off\n\t"
+                    "global_load_dwordx2 %1, %4, off offset:512\n\t"
+                    "global_load_dwordx2 %2, %4, off offset:1024\n\t"
+                    "global_load_dwordx2 %3, %4, off offset:1536"
+                    : "=&v"(nxt[0]), "=&v"(nxt[1]), "=&v"(nxt[2]), "=&v"(nxt[3])
+                    : "v"(pa)
+                    : "memory");
+            }
+#else
         u32x4 cur_a = {0, 0, 0, 0}, cur_b = {0, 0, 0, 0};
         auto column_ptrs = [&](uint32_t k, const uint32_t *&pa, const uint32_t *&pb) {
             const uint32_t st = d_start[k], n = d_end[k] - st;
@@ -1000,6 +1068,7 @@ __global__ void __launch_bounds__(64, FO_PF_WAVES) k_fanout_emit_pf(DevGrid g, W
                     : "v"(pa), "v"(pb)
                     : "memory");
             }
+#endif
             uint32_t since = 0;    // wide stores certainly issued after the prefetch (lower bound)
             const uint32_t p = d_p[k];
             const uint32_t fl = d_fl[k], info = d_info[k];
@@ -1020,7 +1089,11 @@ __global__ void __launch_bounds__(64, FO_PF_WAVES) k_fanout_emit_pf(DevGrid g, W
                     out[0] = r;
                     if (opos) opos[0] = CHD_POS_CELL | c;
                 }
+#if FO_PF_LAYOUT == 1
+                if (in_regs) n_out = store_column2(cur, n, start, conn | CHD_REC_FULL, out, opos, 1u, since);
+#else
                 if (in_regs) n_out = store_column(cur_a, cur_b, n, start, conn | CHD_REC_FULL, out, opos, 1u, since);
+#endif
                 else n_out = emit_cell_all(chans, start, end, conn | CHD_REC_FULL, out, opos, 1u);
             }
             const uint32_t ch_hist = d_chh[k], ch_sender = d_chs[k];
@@ -1039,7 +1112,11 @@ __global__ void __launch_bounds__(64, FO_PF_WAVES) k_fanout_emit_pf(DevGrid g, W
                     n_out += 1;
                 }
                 if (!(info & PI_NONE)) {  // every entity passes this window (checked when the segment was classified)
+#if FO_PF_LAYOUT == 1
+                    if (in_regs) n_out = store_column2(cur, n, start, conn, out, opos, n_out, since);
+#else
                     if (in_regs) n_out = store_column(cur_a, cur_b, n, start, conn, out, opos, n_out, since);
+#endif
                     else n_out = emit_cell_all(chans, start, end, conn, out, opos, n_out);
                 }
             }
@@ -1053,12 +1130,21 @@ __global__ void __launch_bounds__(64, FO_PF_WAVES) k_fanout_emit_pf(DevGrid g, W
             if (prefetch) {
                 // the two loads are older than every store of this segment: a counted wait completes them and
                 // leaves the youngest K stores in flight (K <= the stores certainly issued since)
+#if FO_PF_LAYOUT == 1
+                if (since < 2) asm volatile("s_waitcnt vmcnt(0)" : "+v"(nxt[0]), "+v"(nxt[1]), "+v"(nxt[2]), "+v"(nxt[3]) : : "memory");
+                else if (since < 4) asm volatile("s_waitcnt vmcnt(2)" : "+v"(nxt[0]), "+v"(nxt[1]), "+v"(nxt[2]), "+v"(nxt[3]) : : "memory");
+                else if (since < 8) asm volatile("s_waitcnt vmcnt(4)" : "+v"(nxt[0]), "+v"(nxt[1]), "+v"(nxt[2]), "+v"(nxt[3]) : : "memory");
+                else asm volatile("s_waitcnt vmcnt(8)" : "+v"(nxt[0]), "+v"(nxt[1]), "+v"(nxt[2]), "+v"(nxt[3]) : : "memory");
+#pragma unroll
+                for (int h = 0; h < 4; h++) cur[h] = nxt[h];
+#else
                 if (since < 2) asm volatile("s_waitcnt vmcnt(0)" : "+v"(nxt_a), "+v"(nxt_b) : : "memory");
                 else if (since < 4) asm volatile("s_waitcnt vmcnt(2)" : "+v"(nxt_a), "+v"(nxt_b) : : "memory");
                 else if (since < 8) asm volatile("s_waitcnt vmcnt(4)" : "+v"(nxt_a), "+v"(nxt_b) : : "memory");
                 else asm volatile("s_waitcnt vmcnt(8)" : "+v"(nxt_a), "+v"(nxt_b) : : "memory");
                 cur_a = nxt_a;
                 cur_b = nxt_b;
+#endif
             }
         }
         __syncthreads();

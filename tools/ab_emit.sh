@@ -13,11 +13,6 @@ except Exception as e:
 PY
 }
 EXTRA=""
-run pipelined_pf6 A=1
+run pipelined A=1
 run old CHD_EMIT_PIPELINED=0
-run pf7 CHD_SPATIAL_LIB=$R/channeld_amd/variants/libchd_pf7.so
-run pf8 CHD_SPATIAL_LIB=$R/channeld_amd/variants/libchd_pf8.so
-run pf4 CHD_SPATIAL_LIB=$R/channeld_amd/variants/libchd_pf4.so
-EXTRA="--emit cell-major"; run cellmajor A=1
-EXTRA="--update-frac 0.5"; run half_pipelined A=1; run half_old CHD_EMIT_PIPELINED=0
-EXTRA="--update-masks"; run masks A=1
+for v in $R/channeld_amd/variants/libchd_*.so; do n=$(basename $v .so); run ${n#libchd_} CHD_SPATIAL_LIB=$v; done
