@@ -890,7 +890,7 @@ __device__ __forceinline__ uint32_t store_column2(const u32x2 (&q)[4], uint32_t 
 __global__ void __launch_bounds__(64, FO_PF_WAVES) k_fanout_emit_pf(DevGrid g, WorldDev w, int64_t now, TickRing ring) {
     constexpr uint32_t FO_TILE = 64;
     __shared__ uint32_t d_p[FO_TILE], d_fl[FO_TILE], d_c[FO_TILE], d_start[FO_TILE], d_end[FO_TILE], d_rel[FO_TILE],
-        d_chh[FO_TILE], d_chs[FO_TILE], d_chhp[FO_TILE], d_chsp[FO_TILE], d_info[FO_TILE], d_wm[4][FO_TILE];
+        d_chh[FO_TILE], d_chs[FO_TILE], d_chhp[FO_TILE], d_chsp[FO_TILE], d_info[FO_TILE], d_wm[4][FO_TILE], d_nout[FO_TILE];
     __shared__ int64_t d_Ln[FO_TILE];
     __shared__ uint32_t n_due;
     const uint32_t s = blockIdx.x;
@@ -1070,7 +1070,6 @@ __global__ void __launch_bounds__(64, FO_PF_WAVES) k_fanout_emit_pf(DevGrid g, W
             }
 #endif
             uint32_t since = 0;    // wide stores certainly issued after the prefetch (lower bound)
-            const uint32_t p = d_p[k];
             const uint32_t fl = d_fl[k], info = d_info[k];
             const uint32_t c = d_c[k];
             const uint32_t start = d_start[k], end = d_end[k], n = end - start;
@@ -1121,11 +1120,10 @@ __global__ void __launch_bounds__(64, FO_PF_WAVES) k_fanout_emit_pf(DevGrid g, W
                 }
             }
             pad_segment(out, n_out);
-            if (lane == 0) {
-                w.pair_last[pbase + p] = d_Ln[k];
-                w.pair_flags[pbase + p] = fl | PF_HAD_FIRST;
-                w.pair_nrec[pbase + p] = n_out;
-            }
+            // (the subscription's new state is written back once per tile, below: a 4- or 8-byte store per segment is a
+            // partially written line by the time the record stream has pushed it out of L2, and partial lines cost the
+            // ECC HBM a read-modify-write each — three per segment ate a quarter of the record stream's bandwidth)
+            if (lane == 0) d_nout[k] = n_out;
             total += n_out;
             if (prefetch) {
                 // the two loads are older than every store of this segment: a counted wait completes them and
@@ -1146,6 +1144,13 @@ __global__ void __launch_bounds__(64, FO_PF_WAVES) k_fanout_emit_pf(DevGrid g, W
                 cur_b = nxt_b;
 #endif
             }
+        }
+        __syncthreads();
+        if (lane < ndue) {  // fan-out state of the tile's streamed subscriptions: one store instruction per array
+            const uint32_t p = d_p[lane];
+            w.pair_last[pbase + p] = d_Ln[lane];
+            w.pair_flags[pbase + p] = d_fl[lane] | PF_HAD_FIRST;
+            w.pair_nrec[pbase + p] = d_nout[lane];
         }
         __syncthreads();
     }
