@@ -864,6 +864,9 @@ __device__ __forceinline__ uint32_t store_column2(const u32x2 (&q)[4], uint32_t 
     for (int h = 0; h < 4; h++) {
         if (n <= (uint32_t)(128 * h)) break;  // uniform
         const uint32_t k = 128u * h + 2 * lane;
+#ifdef FO_PF_NOSTORE  // experiment: everything but the record stores
+        if (n == 0xFFFFFFFFu)
+#endif
         if (k + 1 < n) {
             u32x4 r;
             r.x = conn_tag; r.y = q[h].x; r.z = conn_tag; r.w = q[h].y;

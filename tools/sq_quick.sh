@@ -1,0 +1,29 @@
+#!/bin/bash
+# Two SQ counter passes (cycles / instruction mix) over a short bench run; prints per-wave figures for the emit kernels.
+# usage: bash tools/sq_quick.sh <tag> [env assignments...]
+TAG=${1:-sq}; shift
+R=${GRAFT_REPO_ROOT:-$(pwd)}; O=$R/gpurun_out/$TAG; mkdir -p $O
+cd /tmp && export TMPDIR=/tmp
+i=0
+for grp in "SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAIT_ANY" \
+           "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_LDS SQ_INSTS_SMEM"; do
+  i=$((i+1))
+  env "$@" timeout 240 rocprofv3 --pmc $grp --output-format csv -d $O/g$i -o p -- python $R/bench.py --steps 12 --warmup 4 --no-cpu --latency-steps 0 --e2e-ticks 0 > $O/g$i.out 2> $O/g$i.err
+done
+cd $R
+python - "$O" <<'PY'
+import csv, glob, json, sys
+from collections import defaultdict
+O = sys.argv[1]
+acc = defaultdict(lambda: defaultdict(list))
+for f in glob.glob(O + "/g*/**/*counter_collection.csv", recursive=True):
+    for r in csv.DictReader(open(f)):
+        acc[r["Kernel_Name"].split("(")[0].replace("void ", "")][r["Counter_Name"]].append(float(r["Counter_Value"]))
+out = {k: {c: sum(v[4:]) / max(1, len(v[4:])) for c, v in d.items()} for k, d in acc.items() if k.startswith("k_")}
+json.dump(out, open(O + "/sq_summary.json", "w"), indent=1)
+for k, d in out.items():
+    if "emit" in k or "plan" in k or "interest" in k:
+        w = max(d.get("SQ_WAVES", 1), 1)
+        print(f"{k[:60]:60s} waves {w:7.0f} | per wave: cycles {4*d.get('SQ_WAVE_CYCLES',0)/w:9.0f} wait {4*d.get('SQ_WAIT_ANY',0)/w:9.0f} issue-stall {4*d.get('SQ_WAIT_INST_ANY',0)/w:8.0f} active {4*d.get('SQ_ACTIVE_INST_ANY',0)/w:8.0f} | VALU {d.get('SQ_INSTS_VALU',0)/w:7.0f} SALU {d.get('SQ_INSTS_SALU',0)/w:7.0f} LDS {d.get('SQ_INSTS_LDS',0)/w:6.0f} VMEM_RD {d.get('SQ_INSTS_VMEM_RD',0)/w:5.0f} VMEM_WR {d.get('SQ_INSTS_VMEM_WR',0)/w:5.0f} SMEM {d.get('SQ_INSTS_SMEM',0)/w:5.0f}")
+PY
+rm -rf $O/g*/
