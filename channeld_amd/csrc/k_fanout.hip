@@ -890,6 +890,15 @@ __device__ __forceinline__ uint32_t store_column2(const u32x2 (&q)[4], uint32_t 
 #ifndef FO_PF_WAVES
 #define FO_PF_WAVES 6
 #endif
+#ifdef FO_PF_TRACE  // diagnosis builds only: per-connection wall-clock marks of the last launch (100 MHz ticks)
+__device__ unsigned long long fo_trace[4 * 16384];
+extern "C" int chd_debug_trace(unsigned long long *out, unsigned n) {
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(fo_trace), sizeof(unsigned long long) * 4 * (n < 16384 ? n : 16384));
+}
+#define PF_TRACE(slot) do { if (lane == 0 && s < 16384) fo_trace[4 * s + (slot)] = wall_clock64(); } while (0)
+#else
+#define PF_TRACE(slot) do { } while (0)
+#endif
 __global__ void __launch_bounds__(64, FO_PF_WAVES) k_fanout_emit_pf(DevGrid g, WorldDev w, int64_t now, TickRing ring) {
     constexpr uint32_t FO_TILE = 64;
     __shared__ uint32_t d_p[FO_TILE], d_fl[FO_TILE], d_c[FO_TILE], d_start[FO_TILE], d_end[FO_TILE], d_rel[FO_TILE],
@@ -898,6 +907,7 @@ __global__ void __launch_bounds__(64, FO_PF_WAVES) k_fanout_emit_pf(DevGrid g, W
     __shared__ uint32_t n_due;
     const uint32_t s = blockIdx.x;
     const uint32_t lane = lane_id();
+    PF_TRACE(0);
     if (!w.sub_alive[s]) {
         if (lane == 0) { w.rec_cnt[s] = 0; w.conn_defer[s] = 0; }
         return;
@@ -1005,6 +1015,7 @@ __global__ void __launch_bounds__(64, FO_PF_WAVES) k_fanout_emit_pf(DevGrid g, W
         }
         __syncthreads();
         const uint32_t ndue = n_due;
+        PF_TRACE(1);
         // the column of the first due subscription, then one segment ahead
 #if FO_PF_LAYOUT == 1
         u32x2 cur[4] = {{0, 0}, {0, 0}, {0, 0}, {0, 0}};
@@ -1157,7 +1168,11 @@ __global__ void __launch_bounds__(64, FO_PF_WAVES) k_fanout_emit_pf(DevGrid g, W
         }
         __syncthreads();
     }
+    PF_TRACE(2);
     if (lane == 0) {
+#ifdef FO_PF_TRACE
+        if (s < 16384) fo_trace[4 * s + 3] = total;
+#endif
         if (hist_ovf) atomicAdd(&w.counters[CTR_HIST_OVERFLOW], 1u);
         w.rec_cnt[s] = total;
         w.conn_defer[s] = any_deferred;
