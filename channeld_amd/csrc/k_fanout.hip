@@ -895,21 +895,30 @@ __device__ unsigned long long fo_trace[4 * 16384];
 extern "C" int chd_debug_trace(unsigned long long *out, unsigned n) {
     return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(fo_trace), sizeof(unsigned long long) * 4 * (n < 16384 ? n : 16384));
 }
-#define PF_TRACE(slot) do { if (lane == 0 && s < 16384) fo_trace[4 * s + (slot)] = wall_clock64(); } while (0)
+#define PF_TRACE(slot) do { if (threadIdx.x == 0 && s < 16384) fo_trace[4 * s + (slot)] = wall_clock64(); } while (0)
 #else
 #define PF_TRACE(slot) do { } while (0)
 #endif
-__global__ void __launch_bounds__(64, FO_PF_WAVES) k_fanout_emit_pf(DevGrid g, WorldDev w, int64_t now, TickRing ring) {
+// WAVES waves per connection: wave 0 stages and decides (a connection rarely has more than 64 subscriptions), then the
+// waves take the due subscriptions round-robin.  Finer work items shorten the kernel's tail: with one wave per
+// connection a wave lives ~90 us on a ~170 us launch, and for the last ~80 us the chip drains at falling occupancy,
+// each remaining wave latency-bound (timeline in DESIGN.md, tools/emit_trace.py).
+#ifndef FO_PF_CONN_WAVES
+#define FO_PF_CONN_WAVES 4
+#endif
+template <int WAVES>
+__global__ void __launch_bounds__(64 * WAVES, FO_PF_WAVES) k_fanout_emit_pf(DevGrid g, WorldDev w, int64_t now, TickRing ring) {
     constexpr uint32_t FO_TILE = 64;
     __shared__ uint32_t d_p[FO_TILE], d_fl[FO_TILE], d_c[FO_TILE], d_start[FO_TILE], d_end[FO_TILE], d_rel[FO_TILE],
         d_chh[FO_TILE], d_chs[FO_TILE], d_chhp[FO_TILE], d_chsp[FO_TILE], d_info[FO_TILE], d_wm[4][FO_TILE], d_nout[FO_TILE];
     __shared__ int64_t d_Ln[FO_TILE];
-    __shared__ uint32_t n_due;
+    __shared__ uint32_t n_due, wave_total[WAVES];
     const uint32_t s = blockIdx.x;
     const uint32_t lane = lane_id();
+    const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     PF_TRACE(0);
     if (!w.sub_alive[s]) {
-        if (lane == 0) { w.rec_cnt[s] = 0; w.conn_defer[s] = 0; }
+        if (threadIdx.x == 0) { w.rec_cnt[s] = 0; w.conn_defer[s] = 0; }
         return;
     }
     const uint32_t cnt = w.pair_cnt[s];
@@ -917,8 +926,8 @@ __global__ void __launch_bounds__(64, FO_PF_WAVES) k_fanout_emit_pf(DevGrid g, W
     const uint64_t base = w.rec_ub[s];
     if (w.rec_ub[s + 1] > w.recs_cap) {
         // no room for this connection's worst case: state untouched, it catches up next tick
-        for (uint32_t p = lane; p < cnt; p += 64) w.pair_nrec[pbase + p] = 0;
-        if (lane == 0) {
+        for (uint32_t p = threadIdx.x; p < cnt; p += 64 * WAVES) w.pair_nrec[pbase + p] = 0;
+        if (threadIdx.x == 0) {
             w.rec_cnt[s] = 0;
             w.conn_defer[s] = 0;
             if (w.rec_ub[s + 1] > base) atomicOr(&w.counters[CTR_OVERFLOW], OVF_RECORDS);
@@ -933,9 +942,9 @@ __global__ void __launch_bounds__(64, FO_PF_WAVES) k_fanout_emit_pf(DevGrid g, W
     const uint32_t *__restrict__ chans = w.ce_chan_view;
     uint32_t total = 0, hist_ovf = 0;
     for (uint32_t tile = 0; tile < cnt; tile += FO_TILE) {
-        if (lane == 0) n_due = 0;
+        if (threadIdx.x == 0) n_due = 0;
         __syncthreads();
-        {   // stage + decide: one lane per subscription
+        if (wave == 0) {  // stage + decide: one lane per subscription
             const uint32_t p = tile + lane;
             bool due = false;
             uint32_t fl = 0, iv = 0, c = 0, info = 0, wms[4] = {0, 0, 0, 0};
@@ -1024,8 +1033,8 @@ __global__ void __launch_bounds__(64, FO_PF_WAVES) k_fanout_emit_pf(DevGrid g, W
             // (lanes beyond the cell read the spare entries behind the column or the next cells': never used)
             return chans + d_start[k] + 2 * lane;
         };
-        if (chans && ndue) {
-            const uint32_t *pa = column_ptr(0);
+        if (chans && wave < ndue) {
+            const uint32_t *pa = column_ptr(wave);
             asm volatile(
                 "global_load_dwordx2 %0, %4, off\n\t"
                 "global_load_dwordx2 %1, %4, off offset:512\n\t"
@@ -1036,11 +1045,11 @@ __global__ void __launch_bounds__(64, FO_PF_WAVES) k_fanout_emit_pf(DevGrid g, W
                 : "v"(pa)
                 : "memory");
         }
-        for (uint32_t k = 0; k < ndue; k++) {
+        for (uint32_t k = wave; k < ndue; k += WAVES) {
             u32x2 nxt[4] = {{0, 0}, {0, 0}, {0, 0}, {0, 0}};
-            const bool prefetch = chans && k + 1 < ndue;
+            const bool prefetch = chans && k + WAVES < ndue;
             if (prefetch) {
-                const uint32_t *pa = column_ptr(k + 1);
+                const uint32_t *pa = column_ptr(k + WAVES);
                 asm volatile(
                     "global_load_dwordx2 %0, %4, off\n\t"
                     "global_load_dwordx2 %1, %4, off offset:512\n\t"
@@ -1058,9 +1067,9 @@ __global__ void __launch_bounds__(64, FO_PF_WAVES) k_fanout_emit_pf(DevGrid g, W
             pa = chans + st + (ka < n ? ka : 0u);  // (the column has spare entries behind it)
             pb = chans + st + (kb < n ? kb : 0u);
         };
-        if (chans && ndue) {
+        if (chans && wave < ndue) {
             const uint32_t *pa, *pb;
-            column_ptrs(0, pa, pb);
+            column_ptrs(wave, pa, pb);
             asm volatile(
                 "global_load_dwordx4 %0, %2, off\n\t"
                 "global_load_dwordx4 %1, %3, off\n\t"
@@ -1069,12 +1078,12 @@ __global__ void __launch_bounds__(64, FO_PF_WAVES) k_fanout_emit_pf(DevGrid g, W
                 : "v"(pa), "v"(pb)
                 : "memory");
         }
-        for (uint32_t k = 0; k < ndue; k++) {
+        for (uint32_t k = wave; k < ndue; k += WAVES) {
             u32x4 nxt_a = {0, 0, 0, 0}, nxt_b = {0, 0, 0, 0};
-            const bool prefetch = chans && k + 1 < ndue;
+            const bool prefetch = chans && k + WAVES < ndue;
             if (prefetch) {
                 const uint32_t *pa, *pb;
-                column_ptrs(k + 1, pa, pb);
+                column_ptrs(k + WAVES, pa, pb);
                 asm volatile(
                     "global_load_dwordx4 %0, %2, off\n\t"
                     "global_load_dwordx4 %1, %3, off"
@@ -1160,7 +1169,7 @@ __global__ void __launch_bounds__(64, FO_PF_WAVES) k_fanout_emit_pf(DevGrid g, W
             }
         }
         __syncthreads();
-        if (lane < ndue) {  // fan-out state of the tile's streamed subscriptions: one store instruction per array
+        if (wave == 0 && lane < ndue) {  // fan-out state of the tile's streamed subscriptions: one store instruction per array
             const uint32_t p = d_p[lane];
             w.pair_last[pbase + p] = d_Ln[lane];
             w.pair_flags[pbase + p] = d_fl[lane] | PF_HAD_FIRST;
@@ -1168,12 +1177,17 @@ __global__ void __launch_bounds__(64, FO_PF_WAVES) k_fanout_emit_pf(DevGrid g, W
         }
         __syncthreads();
     }
+    if (lane == 0) wave_total[wave] = total;
+    if (hist_ovf && lane == 0) atomicAdd(&w.counters[CTR_HIST_OVERFLOW], 1u);
+    __syncthreads();
+    total = 0;
+#pragma unroll
+    for (int k = 0; k < WAVES; k++) total += wave_total[k];
     PF_TRACE(2);
-    if (lane == 0) {
+    if (threadIdx.x == 0) {
 #ifdef FO_PF_TRACE
         if (s < 16384) fo_trace[4 * s + 3] = total;
 #endif
-        if (hist_ovf) atomicAdd(&w.counters[CTR_HIST_OVERFLOW], 1u);
         w.rec_cnt[s] = total;
         w.conn_defer[s] = any_deferred;
         unsigned long long *slot = (unsigned long long *)&w.tot64[(size_t)(s & 63u) * 16];
@@ -1680,7 +1694,7 @@ void launch_fanout_emit(hipStream_t st, DevGrid g, WorldDev w, int64_t now_ns, T
             // CHD_EMIT_PIPELINED=0 keeps the first form (A/B runs)
             static const bool pipelined = [] { const char *e = getenv("CHD_EMIT_PIPELINED"); return !(e && e[0] == '0'); }();
             if (pipelined) {
-                hipLaunchKernelGGL(k_fanout_emit_pf, dim3(w.S), dim3(64), 0, st, g, w, now_ns, ring);
+                hipLaunchKernelGGL(k_fanout_emit_pf<FO_PF_CONN_WAVES>, dim3(w.S), dim3(64 * FO_PF_CONN_WAVES), 0, st, g, w, now_ns, ring);
                 hipLaunchKernelGGL((k_fanout_emit<1, false, true>), dim3(w.S), dim3(64), 0, st, g, w, now_ns, ring);
             } else hipLaunchKernelGGL((k_fanout_emit<1, false>), dim3(w.S), dim3(64), 0, st, g, w, now_ns, ring);
         } else hipLaunchKernelGGL((k_fanout_emit<4, false>), dim3(w.S), dim3(256), 0, st, g, w, now_ns, ring);
