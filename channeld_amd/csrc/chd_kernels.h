@@ -86,6 +86,14 @@ struct WorldDev {
     uint32_t emit_grid;             // persistent grid of the cell-major emit kernel (workgroups)
     WsItemG *items;                 // [ncell * ceil(S/256)]
     uint32_t *conn_defer; // [S] this tick: the connection has subscriptions left to the deferred emit launch
+    // descriptor-driven emit (k_fanout_plan_seg -> k_fanout_emit_seg): per connection the first n_simple[s] entries of its
+    // row [s*capq, ...) describe the due subscriptions whose every window is a plain copy of the cell's channel column
+    uint32_t *n_simple;   // [S]
+    uint4 *seg_desc;      // [S*capq] {segment offset in the connection's range, column start, entries, SD_* | windows}
+    uint32_t *seg_c;      // [S*capq] cell index
+    uint32_t *seg_p;      // [S*capq] index of the subscription in the connection's list
+    uint32_t *seg_fl;     // [S*capq] pair_flags after this tick
+    int64_t *seg_ln;      // [S*capq] lastFanOutTime after this tick
     uint32_t *pair_rel;   // [S*capq] this tick: segment offset inside the connection's record range
     uint32_t *pair_nrec;  // [S*capq] this tick: records emitted for the subscription
     // fan-out outputs

@@ -198,10 +198,23 @@ __global__ void __launch_bounds__(1024) k_active_cells(WorldDev w, uint32_t ncel
     if (threadIdx.x == 0) *w.n_active = carry_s;
 }
 
+// CHD_EMIT_PIPELINED=0 keeps the first connection-major form everywhere (A/B runs)
+static bool seg_path_enabled() {
+    static const bool on = [] { const char *e = getenv("CHD_EMIT_PIPELINED"); return !(e && e[0] == '0'); }();
+    return on;
+}
+// the descriptor-driven path: connection-major, one-wave geometry (>= 4096 connections or asked for), no per-record masks
+static bool seg_path(const WorldDev &w) { return !w.cm_emit && !w.rec_mask && (w.S >= 4096 || w.one_wave_emit) && seg_path_enabled(); }
+
+__global__ void __launch_bounds__(64 * FO_WAVES) k_fanout_plan_seg(DevGrid g, WorldDev w, int64_t now, TickRing ring);
+
 void launch_fanout_plan(hipStream_t st, DevGrid g, WorldDev w, int64_t now_ns, TickRing ring) {
     if (!w.S) return;
-    hipLaunchKernelGGL(k_fanout_plan, dim3((w.S + FO_WAVES - 1) / FO_WAVES), dim3(64 * FO_WAVES), 0, st, g, w,
-                       now_ns, ring);
+    if (seg_path(w))
+        hipLaunchKernelGGL(k_fanout_plan_seg, dim3((w.S + FO_WAVES - 1) / FO_WAVES), dim3(64 * FO_WAVES), 0, st, g, w, now_ns, ring);
+    else
+        hipLaunchKernelGGL(k_fanout_plan, dim3((w.S + FO_WAVES - 1) / FO_WAVES), dim3(64 * FO_WAVES), 0, st, g, w,
+                           now_ns, ring);
     launch_scan_u64_inplace(st, w.rec_ub, w.S);
     if (w.cm_emit) hipLaunchKernelGGL(k_active_cells, dim3(1), dim3(1024), 0, st, w, g.ncell);
 }
@@ -577,7 +590,7 @@ __device__ __forceinline__ uint32_t emit_cell_all(const uint32_t *__restrict__ c
 // WAVES waves per connection (= subscriptions staged in LDS per round / 64).  Measured at config B (10 K connections,
 // ~18 due subscriptions each): 192.8 / 194.4 / 196.8 / 227 us per launch with 1 / 2 / 4 / 8 waves; the launcher takes
 // one wave per connection when there are enough connections to fill the chip that way, four otherwise.
-// DEFERRED: second launch behind k_fanout_emit_pf — only the subscriptions that kernel marked PF_DEFER (their
+// DEFERRED: second launch behind k_fanout_emit_seg — only the subscriptions k_fanout_plan_seg marked PF_DEFER (their
 // connections are flagged in conn_defer; every other workgroup exits at once), record counts ADDED to the first launch's.
 template <int WAVES, bool MASKS, bool DEFERRED = false>
 __global__ void __launch_bounds__(64 * WAVES) k_fanout_emit(DevGrid g, WorldDev w, int64_t now, TickRing ring) {
@@ -782,84 +795,191 @@ __global__ void __launch_bounds__(64 * WAVES) k_fanout_emit(DevGrid g, WorldDev 
 }
 
 // ---------------------------------------------------------------------------
-// Connection-major emit, pipelined form (one wave per connection; the launcher takes it when there are enough
-// connections to fill the chip with single waves and no per-record masks are wanted).  Two changes against
-// k_fanout_emit, both aimed at the per-segment latency that bounds it (SQ counters: 74 % of the wave cycles in
-// s_waitcnt, ~12 K cycles per 445-record segment of which ~2.4 K deciding and ~3.6 K waiting for two loads):
-//   * the catch-up window walk of tickData runs ONCE per subscription, lane-parallel in the staging phase (one
-//     lane per subscription, serial over the tick ring), and leaves up to four window masks + the advanced
-//     lastFanOutTime in LDS; the streaming loop only replays masks.  More than four non-empty windows (a
-//     subscription that was not served for several ticks) takes the in-wave walk of k_fanout_emit.
-//   * the channel-id column of the NEXT due subscription's cell (what an all-pass window or a first fan-out
-//     copies; up to 512 entries = two 16-byte loads per lane) is requested before the current segment's records
-//     are stored, and awaited with a COUNTED s_waitcnt: the vm counter is in-order, so `vmcnt(K)` with K <= the
-//     number of stores issued after the loads completes the loads and leaves those stores in flight.  A plain
-//     wait (what the compiler emits for any load) drains every record store issued before it.
-// Same outputs as k_fanout_emit (same segment layout, same state write-back): the parity tests cover both.
+// Connection-major emit, descriptor-driven form (the launcher takes it when one wave per connection would fill the
+// chip — or CHD_WORLD_ONE_WAVE_EMIT asks for it — and no per-record masks are wanted).
+//
+// What bounded k_fanout_emit at config B (measured): not the record stores (a store-only kernel with
+// the same 10 K x 18 segment pattern takes ~125 us) and not occupancy, but (i) per-segment latency — window walk
+// and two dependent L2 round trips per segment, every load wait draining the wave's own record stores because the
+// vm counter is in-order — (ii) ~12 us of dependent gathers per connection before its first store, taken while the
+// store stream saturates the memory pipeline, and (iii) a tail: one wave per connection lives ~90 us of a ~170 us
+// launch, so the last ~80 us drain at falling occupancy with every remaining wave latency-bound.
+//
+//   k_fanout_plan_seg : one wave per connection, one lane per subscription, BEFORE the emit (no store stream to
+//                   contend with): due test, the whole catch-up window walk of tickData (serial over the tick ring,
+//                   up to four window masks), classification.  A subscription is SIMPLE when every non-empty window
+//                   is a plain copy of the cell's channel-id column (the AND of the entities' histories intersects
+//                   it and SkipSelfUpdateFanOut cannot drop anything) or nothing at all: then its record count is
+//                   known exactly (tight segment, no worst-case slot) and it becomes a 16-byte descriptor
+//                   {segment offset, column start, entries, windows / own-update bits}.  Everything else (a window
+//                   some entity has no update in, a cell whose senders include this connection, more than four
+//                   non-empty windows, gathered tables) is marked PF_DEFER with a worst-case slot and left to the
+//                   second launch, k_fanout_emit<.., DEFERRED>, whose filtering streams would cost this path 50 VGPRs.
+//   k_fanout_emit_seg : WAVES waves per connection take its descriptors round-robin: scalar descriptor load,
+//                   the column of the NEXT descriptor requested (four 8-byte loads per lane: pairs of adjacent
+//                   entries, so every store instruction writes one contiguous 1 KiB run of records) before the
+//                   current segment's records are stored, awaited with a COUNTED s_waitcnt — `vmcnt(K)` with K <= the
+//                   stores issued since completes the older loads and leaves those stores in flight.  No LDS, no
+//                   barrier, no decision; wave 0 commits the subscriptions' new fan-out state in one coalesced pass.
+// Same records, same segment order inside a connection's range, same state as k_fanout_emit: the parity tests run
+// both (tests/test_gpu_world.py "conn-major-1w", tests/test_gpu_fullsize.py).
 // ---------------------------------------------------------------------------
-#define PI_NWIN_MASK 7u
-#define PI_FIRST 8u
-#define PI_GENERIC 16u
-#define PI_HLOST 32u
-#define PI_NONE 64u  // SkipSelfUpdateFanOut and the cell's only sender is this connection: no entity record passes
+#define SD_NWIN_MASK 7u
+#define SD_FIRST 8u      // first fan-out: the cell's FULL record + every entity's
+#define SD_NONE 16u      // SkipSelfUpdateFanOut and the cell's only sender is this connection: no entity record passes
+#define SD_OWN_SHIFT 8   // bit 8 + j: the spatial channel's own buffered update passes window j
 
-// stores of a cell column held in registers (entries [0, n) of the cell, this lane: 4*lane.. and 256 + 4*lane..);
-// returns the records written (n).  `since` counts the wide stores certainly issued (lower bound, wave-uniform).
-__device__ __forceinline__ uint32_t store_column(const u32x4 &ca, const u32x4 &cb, uint32_t n, uint32_t start, uint32_t conn_tag,
-                                                 chd_fanout_rec *__restrict__ out, uint32_t *__restrict__ opos, uint32_t n_out,
-                                                 uint32_t &since) {
+typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+
+#ifndef FO_SEG_WAVES
+#define FO_SEG_WAVES 4   // waves per connection in k_fanout_emit_seg
+#endif
+#ifndef FO_SEG_OCC
+#define FO_SEG_OCC 5     // waves per SIMD the register allocator is asked for (84 VGPRs without a bound; occupancy is not what limits this kernel)
+#endif
+
+__global__ void __launch_bounds__(64 * FO_WAVES) k_fanout_plan_seg(DevGrid g, WorldDev w, int64_t now, TickRing ring) {
+    const uint32_t s = blockIdx.x * FO_WAVES + (threadIdx.x >> 6);
+    if (s >= w.S) return;
     const uint32_t lane = lane_id();
-    // (opaque copy: left to itself the compiler builds the {tag, channel} register pairs of every store of every
-    // caller up front, from the moment the column registers exist — ~25 VGPRs held across the whole segment loop)
-    asm volatile("" : "+v"(conn_tag));
-#pragma unroll
-    for (int h = 0; h < 2; h++) {
-        const uint32_t k = (h ? 256u : 0u) + 4 * lane;
-        if (h && n <= 256) break;  // uniform
-        if (k < n) {
-            const u32x4 c4 = h ? cb : ca;
-            const uint32_t m = n - k;
-            if (m >= 4) {
-                u32x4 r0, r1;
-                r0.x = conn_tag; r0.y = c4.x; r0.z = conn_tag; r0.w = c4.y;
-                r1.x = conn_tag; r1.y = c4.z; r1.z = conn_tag; r1.w = c4.w;
-                u32x4 *o = (u32x4 *)(void *)(out + n_out + k);
-                o[0] = r0;
-                o[1] = r1;
-                if (opos) {
-                    u32x4 p4;
-                    p4.x = start + k; p4.y = start + k + 1; p4.z = start + k + 2; p4.w = start + k + 3;
-                    *(u32x4 *)(void *)(opos + n_out + k) = p4;
+    uint64_t carry = 0;
+    uint32_t n_simple = 0, any_deferred = 0, hist_ovf = 0;
+    unsigned long long rec_simple = 0;
+    const uint32_t cnt = w.sub_alive[s] ? w.pair_cnt[s] : 0u;
+    const size_t pbase = (size_t)s * w.capq;
+    const uint32_t conn = w.conn_id[s];
+    const uint32_t *__restrict__ chans = w.ce_chan_view;
+    const int64_t oldest = ring.n ? ring.t[ring.n - 1] : INT64_MAX;
+    for (uint32_t p0 = 0; p0 < cnt; p0 += 64) {
+        const uint32_t p = p0 + lane;
+        uint64_t ub = 0;
+        bool due = false, simple = false;
+        uint32_t fl = 0, c = 0, size = 0, start = 0, info = 0, count = 0;
+        int64_t Lw = 0;
+        if (p < cnt) {
+            fl = w.pair_flags[pbase + p] & ~PF_DEFER;
+            const int64_t L = w.pair_last[pbase + p];
+            const uint32_t iv = w.pair_iv[pbase + p];
+            const int64_t I = (int64_t)iv * 1000000;
+            // data.go:194-197: NO_ACCESS is skipped but stays queued
+            due = !(fl & PF_NO_ACCESS) && I > 0 && now >= L + I;
+            if (due) {
+                c = w.pair_cell[pbase + p];
+                start = w.cell_start[c];
+                size = w.cell_end[c] - start;
+                uint32_t wms[4] = {0, 0, 0, 0}, nw = 0;
+                Lw = L;
+                if (!(fl & PF_HAD_FIRST)) {  // data.go:217-223: full state, last = t
+                    info |= SD_FIRST;
+                    Lw = now;
+                    ub = (uint64_t)size + 1;  // (the worst case of a deferred first fan-out, as k_fanout_plan)
+                } else {
+                    int64_t nwin = (now - L) / I;
+                    const int64_t lim = 2 * (int64_t)ring.n;  // a stamp lies in at most two windows
+                    if (nwin > lim) nwin = lim;
+                    ub = (uint64_t)nwin * ((uint64_t)size + 1);
                 }
-            } else {
-                const uint32_t cc[3] = {c4.x, c4.y, c4.z};
-#pragma unroll
-                for (uint32_t q = 0; q < 3; q++) {
-                    if (q < m) {
-                        chd_fanout_rec r;
-                        r.conn = conn_tag;
-                        r.channel = cc[q];
-                        out[n_out + k + q] = r;
-                        if (opos) opos[n_out + k + q] = start + k + q;
+                bool hlost = false;
+                if (now >= Lw + I) {
+                    hlost = history_lost(ring, oldest, Lw, I);
+                    while (now >= Lw + I) {  // data.go:224-271 + the revisit through :273-286
+                        const int64_t next = Lw + I;
+                        const uint32_t wm = window_mask_serial(ring, Lw > 0 ? Lw : 0, next);
+                        if (!wm) {
+                            Lw += empty_windows_serial(ring, now, Lw, iv) * I;
+                            continue;
+                        }
+                        if (nw < 4) wms[nw] = wm;
+                        nw++;
+                        Lw = next;
                     }
+                }
+                uint32_t us = w.ce8_view ? w.cell_usender[c] : CHD_NONUNIFORM;
+                const bool skip_self = (fl & PF_SKIP_SELF) != 0;
+                if (w.ce8_view && us == CHD_NONUNIFORM && (!skip_self || conn < w.cell_smin[c] || conn > w.cell_smax[c]))
+                    us = CHD_NOT_A_SENDER;
+                const uint32_t hand = chans ? w.cell_hand[c] : 0u;
+                const bool none = skip_self && us == conn;  // every buffered entity update is this connection's own
+                simple = chans != nullptr && nw <= 4;
+#pragma unroll
+                for (uint32_t j = 0; j < 4; j++)
+                    if (j < nw && !none && (us == CHD_NONUNIFORM || !(hand & wms[j]))) simple = false;
+                if (simple) {
+                    // exact record count: the segment is as long as what will be written
+                    const uint32_t age = ring.cur_tick - w.cell_hist_tick[c];
+                    const uint32_t chh = age < CHD_HIST_BITS ? (w.cell_hist[c] << age) : 0u;
+                    const uint32_t chhp = age < CHD_HIST_BITS ? (w.cell_hist_prev[c] << age) : 0u;
+                    const uint32_t chs = w.cell_sender[c], chsp = w.cell_sender_prev[c];
+                    count = (info & SD_FIRST) ? size + 1 : 0u;
+#pragma unroll
+                    for (uint32_t j = 0; j < 4; j++) {
+                        if (j >= nw) continue;
+                        if (cell_update_passes(chh, chs, chhp, chsp, wms[j], skip_self, conn)) {
+                            info |= 1u << (SD_OWN_SHIFT + j);
+                            count += 1;
+                        }
+                        if (!none) count += size;
+                    }
+                    info |= nw | (none ? SD_NONE : 0u);
+                    ub = count;
+                    if (hlost) hist_ovf = 1;  // (a deferred subscription is counted by the deferred launch)
+                } else {
+                    w.pair_flags[pbase + p] = fl | PF_DEFER;
                 }
             }
         }
-        if (n >= (h ? 260u : 4u)) since += 2;  // lane 0 of this half holds four entries: both wide stores were issued
+        // every segment starts on a 128-byte line and is padded to whole lines (k_fanout_plan)
+        ub = (ub + (CHD_SEG_ALIGN - 1)) & ~(uint64_t)(CHD_SEG_ALIGN - 1);
+        uint64_t inc = ub;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            uint64_t o = __shfl_up((unsigned long long)inc, d);
+            if ((int)lane >= d) inc += o;
+        }
+        const uint64_t rel = carry + inc - ub;
+        const uint32_t rel32 = rel > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)rel;
+        if (p < cnt) {
+            w.pair_rel[pbase + p] = rel32;
+            w.pair_nrec[pbase + p] = simple ? count : 0u;  // (a deferred subscription's count comes from the deferred launch)
+        }
+        carry += __shfl((unsigned long long)inc, 63);
+        const uint64_t sm = __ballot(due && simple);
+        if (__ballot(due && !simple)) any_deferred = 1;
+        if (due && simple) {
+            const size_t k = pbase + n_simple + mask_rank(sm);
+            w.seg_desc[k] = make_uint4(rel32, start, size, info);
+            w.seg_c[k] = c;
+            w.seg_p[k] = p;
+            w.seg_fl[k] = fl | PF_HAD_FIRST;
+            w.seg_ln[k] = Lw;
+            rec_simple += count;
+        }
+        n_simple += (uint32_t)__popcll(sm);
     }
-    return n_out + n;
+    for (int d = 32; d >= 1; d >>= 1) rec_simple += __shfl_xor(rec_simple, d);
+    if (__ballot(hist_ovf) && lane == 0) atomicAdd(&w.counters[CTR_HIST_OVERFLOW], 1u);
+    if (lane == 0) {
+        w.rec_ub[s] = carry > 0xFFFFFFFFull ? (1ull << 40) : carry;
+        w.n_simple[s] = n_simple;
+        w.conn_defer[s] = any_deferred;
+        w.rec_cnt[s] = (uint32_t)rec_simple;
+        unsigned long long *slot = (unsigned long long *)&w.tot64[(size_t)(s & 63u) * 16];
+        if (rec_simple) atomicAdd(slot, rec_simple);
+        if (cnt) atomicAdd(slot + 1, (unsigned long long)cnt);
+    }
 }
 
-// The same column held as FOUR adjacent PAIRS per lane (q[h] = entries 128 h + 2 lane, + 1; four 8-byte loads, each one
-// 512 contiguous bytes per wave): every store instruction then writes ONE contiguous 1 KiB run of records (8 whole
-// 128-byte lines) instead of 16-byte pieces at a 32-byte stride — half of every line, the other halves coming with the
-// next instruction, i.e. two byte-masked write requests per line (tools/ubench/store_pair.hip measures the two layouts).
-typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+// the records of one copy of a cell column held as four adjacent PAIRS per lane (q[h] = entries 128 h + 2 lane, + 1):
+// every store instruction writes ONE contiguous 1 KiB run (8 whole 128-byte lines).  tools/ubench/store_pair.hip: the
+// older layout — four entries per lane, two stores of 16-byte pieces at a 32-byte stride, i.e. two byte-masked write
+// requests per line — reaches 5.0 TB/s, this one 5.4.  `since` counts the wide stores certainly issued (wave-uniform).
 __device__ __forceinline__ uint32_t store_column2(const u32x2 (&q)[4], uint32_t n, uint32_t start, uint32_t conn_tag,
                                                   chd_fanout_rec *__restrict__ out, uint32_t *__restrict__ opos, uint32_t n_out,
                                                   uint32_t &since) {
     const uint32_t lane = lane_id();
-    asm volatile("" : "+v"(conn_tag));  // (see store_column)
+    // (opaque copy: left to itself the compiler builds the {tag, channel} register pairs of every store of every
+    // caller up front, from the moment the column registers exist — ~25 VGPRs held across the whole segment loop)
+    asm volatile("" : "+v"(conn_tag));
 #pragma unroll
     for (int h = 0; h < 4; h++) {
         if (n <= (uint32_t)(128 * h)) break;  // uniform
@@ -884,12 +1004,6 @@ __device__ __forceinline__ uint32_t store_column2(const u32x2 (&q)[4], uint32_t 
     return n_out + n;
 }
 
-#ifndef FO_PF_LAYOUT
-#define FO_PF_LAYOUT 1  // 1: pairs per lane, contiguous stores (store_column2); 0: four entries per lane (store_column)
-#endif
-#ifndef FO_PF_WAVES
-#define FO_PF_WAVES 6
-#endif
 #ifdef FO_PF_TRACE  // diagnosis builds only: per-connection wall-clock marks of the last launch (100 MHz ticks)
 __device__ unsigned long long fo_trace[4 * 16384];
 extern "C" int chd_debug_trace(unsigned long long *out, unsigned n) {
@@ -899,301 +1013,126 @@ extern "C" int chd_debug_trace(unsigned long long *out, unsigned n) {
 #else
 #define PF_TRACE(slot) do { } while (0)
 #endif
-// WAVES waves per connection: wave 0 stages and decides (a connection rarely has more than 64 subscriptions), then the
-// waves take the due subscriptions round-robin.  Finer work items shorten the kernel's tail: with one wave per
-// connection a wave lives ~90 us on a ~170 us launch, and for the last ~80 us the chip drains at falling occupancy,
-// each remaining wave latency-bound (timeline in DESIGN.md, tools/emit_trace.py).
-#ifndef FO_PF_CONN_WAVES
-#define FO_PF_CONN_WAVES 4
-#endif
+
 template <int WAVES>
-__global__ void __launch_bounds__(64 * WAVES, FO_PF_WAVES) k_fanout_emit_pf(DevGrid g, WorldDev w, int64_t now, TickRing ring) {
-    constexpr uint32_t FO_TILE = 64;
-    __shared__ uint32_t d_p[FO_TILE], d_fl[FO_TILE], d_c[FO_TILE], d_start[FO_TILE], d_end[FO_TILE], d_rel[FO_TILE],
-        d_chh[FO_TILE], d_chs[FO_TILE], d_chhp[FO_TILE], d_chsp[FO_TILE], d_info[FO_TILE], d_wm[4][FO_TILE], d_nout[FO_TILE];
-    __shared__ int64_t d_Ln[FO_TILE];
-    __shared__ uint32_t n_due, wave_total[WAVES];
+__global__ void __launch_bounds__(64 * WAVES, FO_SEG_OCC) k_fanout_emit_seg(DevGrid g, WorldDev w) {
     const uint32_t s = blockIdx.x;
     const uint32_t lane = lane_id();
     const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     PF_TRACE(0);
-    if (!w.sub_alive[s]) {
-        if (threadIdx.x == 0) { w.rec_cnt[s] = 0; w.conn_defer[s] = 0; }
-        return;
-    }
-    const uint32_t cnt = w.pair_cnt[s];
+    const uint32_t ns = w.n_simple[s];
     const size_t pbase = (size_t)s * w.capq;
     const uint64_t base = w.rec_ub[s];
     if (w.rec_ub[s + 1] > w.recs_cap) {
-        // no room for this connection's worst case: state untouched, it catches up next tick
-        for (uint32_t p = threadIdx.x; p < cnt; p += 64 * WAVES) w.pair_nrec[pbase + p] = 0;
-        if (threadIdx.x == 0) {
-            w.rec_cnt[s] = 0;
-            w.conn_defer[s] = 0;
-            if (w.rec_ub[s + 1] > base) atomicOr(&w.counters[CTR_OVERFLOW], OVF_RECORDS);
+        // no room for this connection's worst case: state untouched, it catches up next tick (also the deferred part)
+        if (w.rec_ub[s + 1] > base) {
+            const uint32_t cnt = w.pair_cnt[s];
+            for (uint32_t p = threadIdx.x; p < cnt; p += 64 * WAVES) w.pair_nrec[pbase + p] = 0;
+            if (threadIdx.x == 0) {
+                w.rec_cnt[s] = 0;
+                w.conn_defer[s] = 0;
+                atomicOr(&w.counters[CTR_OVERFLOW], OVF_RECORDS);
+            }
         }
         return;
     }
-    const uint32_t conn = w.conn_id[s];
-    uint32_t any_deferred = 0;
-    const int64_t oldest_v = ring.n ? ring.t[ring.n - 1] : INT64_MAX;
-    const int64_t oldest = ((int64_t)__builtin_amdgcn_readfirstlane((int)(oldest_v >> 32)) << 32) |
-                           (uint32_t)__builtin_amdgcn_readfirstlane((int)oldest_v);
-    const uint32_t *__restrict__ chans = w.ce_chan_view;
-    uint32_t total = 0, hist_ovf = 0;
-    for (uint32_t tile = 0; tile < cnt; tile += FO_TILE) {
-        if (threadIdx.x == 0) n_due = 0;
-        __syncthreads();
-        if (wave == 0) {  // stage + decide: one lane per subscription
-            const uint32_t p = tile + lane;
-            bool due = false;
-            uint32_t fl = 0, iv = 0, c = 0, info = 0, wms[4] = {0, 0, 0, 0};
-            int64_t L = 0, Lw = 0;
-            if (p < cnt) {
-                fl = w.pair_flags[pbase + p];
-                L = w.pair_last[pbase + p];
-                iv = w.pair_iv[pbase + p];
-                const int64_t I = (int64_t)iv * 1000000;
-                // data.go:194-197: NO_ACCESS is skipped but stays queued
-                due = !(fl & PF_NO_ACCESS) && I > 0 && now >= L + I;
-                if (due) {
-                    c = w.pair_cell[pbase + p];
-                    Lw = L;
-                    if (!(fl & PF_HAD_FIRST)) {  // data.go:217-223: full state, last = t
-                        info |= PI_FIRST;
-                        Lw = now;
-                    }
-                    uint32_t nw = 0;
-                    if (now >= Lw + I) {
-                        if (history_lost(ring, oldest, Lw, I)) info |= PI_HLOST;
-                        while (now >= Lw + I) {  // data.go:224-271 + the revisit through :273-286
-                            const int64_t next = Lw + I;
-                            const uint32_t wm = window_mask_serial(ring, Lw > 0 ? Lw : 0, next);
-                            if (!wm) {
-                                Lw += empty_windows_serial(ring, now, Lw, iv) * I;
-                                continue;
-                            }
-                            if (nw < 4) wms[nw] = wm;
-                            nw++;
-                            Lw = next;
-                        }
-                    }
-                    if (nw > 4) info |= PI_GENERIC;
-                    info |= nw > 4 ? 4u : nw;
-                } else {
-                    w.pair_nrec[pbase + p] = 0;
-                }
-            }
-            // Segments every window of which is a plain copy of the cell's channel column (or nothing at all) are
-            // streamed here; the others — a window some entity has no update in, a cell whose senders include this
-            // connection, more than four non-empty windows — are left to the second launch (k_fanout_emit<.., DEFERRED>):
-            // their filtering streams, inlined here, cost the common path 50 VGPRs and two waves per SIMD.
-            uint32_t us = CHD_NONUNIFORM, hand = 0;
-            bool simple = false;
-            if (due) {
-                us = w.ce8_view ? w.cell_usender[c] : CHD_NONUNIFORM;
-                if (w.ce8_view && us == CHD_NONUNIFORM &&
-                    (!(fl & PF_SKIP_SELF) || conn < w.cell_smin[c] || conn > w.cell_smax[c]))
-                    us = CHD_NOT_A_SENDER;
-                hand = chans ? w.cell_hand[c] : 0u;
-                simple = chans != nullptr && !(info & PI_GENERIC);
-                const bool none = (fl & PF_SKIP_SELF) && us == conn;  // every buffered entity update is this connection's own
-                const uint32_t nw = info & PI_NWIN_MASK;
-#pragma unroll
-                for (uint32_t j = 0; j < 4; j++)
-                    if (j < nw && !none && (us == CHD_NONUNIFORM || !(hand & wms[j]))) simple = false;
-                if (!simple) w.pair_flags[pbase + p] = fl | PF_DEFER;
-            }
-            if (__ballot(due && !simple)) any_deferred = 1;
-            // due subscriptions in list order (ballot compaction: no LDS atomics)
-            const uint64_t dm = __ballot(due && simple);
-            if (due && simple) {
-                const uint32_t k = mask_rank(dm);
-                d_p[k] = p; d_fl[k] = fl; d_Ln[k] = Lw; d_c[k] = c; d_info[k] = info | (((fl & PF_SKIP_SELF) && us == conn) ? PI_NONE : 0u);
-                d_wm[0][k] = wms[0]; d_wm[1][k] = wms[1]; d_wm[2][k] = wms[2]; d_wm[3][k] = wms[3];
-                d_rel[k] = w.pair_rel[pbase + p];
-                d_start[k] = w.cell_start[c];
-                d_end[k] = w.cell_end[c];
-                const uint32_t age = ring.cur_tick - w.cell_hist_tick[c];
-                d_chh[k] = age < CHD_HIST_BITS ? (w.cell_hist[c] << age) : 0u;
-                d_chs[k] = w.cell_sender[c];
-                d_chhp[k] = age < CHD_HIST_BITS ? (w.cell_hist_prev[c] << age) : 0u;
-                d_chsp[k] = w.cell_sender_prev[c];
-            }
-            if (lane == 0) n_due = (uint32_t)__popcll(dm);
+    if (!ns) return;
+    if (wave == WAVES - 1)  // the subscriptions' new fan-out state: one coalesced pass (lastFanOutTime, hadFirstFanOut)
+        for (uint32_t k = lane; k < ns; k += 64) {
+            const uint32_t p = w.seg_p[pbase + k];
+            w.pair_last[pbase + p] = w.seg_ln[pbase + k];
+            w.pair_flags[pbase + p] = w.seg_fl[pbase + k];
         }
-        __syncthreads();
-        const uint32_t ndue = n_due;
-        PF_TRACE(1);
-        // the column of the first due subscription, then one segment ahead
-#if FO_PF_LAYOUT == 1
-        u32x2 cur[4] = {{0, 0}, {0, 0}, {0, 0}, {0, 0}};
-        auto column_ptr = [&](uint32_t k) {
-            // q[h] = entries 128 h + 2 lane, + 1 of the cell: ONE address register, the four quarters are immediate offsets
-            // (lanes beyond the cell read the spare entries behind the column or the next cells': never used)
-            return chans + d_start[k] + 2 * lane;
-        };
-        if (chans && wave < ndue) {
-            const uint32_t *pa = column_ptr(wave);
+    const uint32_t conn = w.conn_id[s];
+    const uint32_t *__restrict__ chans = w.ce_chan_view;
+    const u32x4 *__restrict__ desc = (const u32x4 *)(const void *)(w.seg_desc + pbase);
+    PF_TRACE(1);
+    if (wave >= ns) return;
+    // q[h] = entries 128 h + 2 lane, + 1 of the cell: ONE address register, the four quarters are immediate offsets
+    // (lanes beyond the cell read the spare entries behind the column or the next cells': never used)
+    u32x2 cur[4];
+    u32x4 d = desc[wave];
+    {
+        const uint32_t *pa = chans + d.y + 2 * lane;
+        asm volatile(
+            "global_load_dwordx2 %0, %4, off\n\t"
+            "global_load_dwordx2 %1, %4, off offset:512\n\t"
+            "global_load_dwordx2 %2, %4, off offset:1024\n\t"
+            "global_load_dwordx2 %3, %4, off offset:1536\n\t"
+            "s_waitcnt vmcnt(0)"
+            : "=&v"(cur[0]), "=&v"(cur[1]), "=&v"(cur[2]), "=&v"(cur[3])
+            : "v"(pa)
+            : "memory");
+    }
+    for (uint32_t k = wave; k < ns; k += WAVES) {
+        u32x2 nxt[4] = {{0, 0}, {0, 0}, {0, 0}, {0, 0}};
+        u32x4 dn = d;
+        const bool prefetch = k + WAVES < ns;
+        if (prefetch) {
+            dn = desc[k + WAVES];
+            const uint32_t *pa = chans + dn.y + 2 * lane;
             asm volatile(
                 "global_load_dwordx2 %0, %4, off\n\t"
                 "global_load_dwordx2 %1, %4, off offset:512\n\t"
                 "global_load_dwordx2 %2, %4, off offset:1024\n\t"
-                "global_load_dwordx2 %3, %4, off offset:1536\n\t"
-                "s_waitcnt vmcnt(0)"
-                : "=&v"(cur[0]), "=&v"(cur[1]), "=&v"(cur[2]), "=&v"(cur[3])
+                "global_load_dwordx2 %3, %4, off offset:1536"
+                : "=&v"(nxt[0]), "=&v"(nxt[1]), "=&v"(nxt[2]), "=&v"(nxt[3])
                 : "v"(pa)
                 : "memory");
         }
-        for (uint32_t k = wave; k < ndue; k += WAVES) {
-            u32x2 nxt[4] = {{0, 0}, {0, 0}, {0, 0}, {0, 0}};
-            const bool prefetch = chans && k + WAVES < ndue;
-            if (prefetch) {
-                const uint32_t *pa = column_ptr(k + WAVES);
-                asm volatile(
-                    "global_load_dwordx2 %0, %4, off\n\t"
-                    "global_load_dwordx2 %1, %4, off offset:512\n\t"
-                    "global_load_dwordx2 %2, %4, off offset:1024\n\t"
-                    "global_load_dwordx2 %3, %4, off offset:1536"
-                    : "=&v"(nxt[0]), "=&v"(nxt[1]), "=&v"(nxt[2]), "=&v"(nxt[3])
-                    : "v"(pa)
-                    : "memory");
+        uint32_t since = 0;  // wide stores certainly issued after the prefetch (lower bound)
+        const uint32_t start = d.y, n = d.z, info = d.w;
+        const uint32_t cch = w.seg_c[pbase + k] + g.id_start;
+        chd_fanout_rec *__restrict__ out = w.recs + base + d.x;
+        uint32_t *__restrict__ opos = w.rec_pos ? w.rec_pos + base + d.x : nullptr;
+        const bool in_regs = n <= 512;  // the column is in cur[]
+        uint32_t n_out = 0;
+        if (info & SD_FIRST) {
+            // first fan-out: the whole data of the spatial channel and of every entity channel in it
+            if (lane == 0) {
+                chd_fanout_rec r;
+                r.conn = conn | CHD_REC_FULL;
+                r.channel = cch;
+                out[0] = r;
+                if (opos) opos[0] = CHD_POS_CELL | (cch - g.id_start);
             }
-#else
-        u32x4 cur_a = {0, 0, 0, 0}, cur_b = {0, 0, 0, 0};
-        auto column_ptrs = [&](uint32_t k, const uint32_t *&pa, const uint32_t *&pb) {
-            const uint32_t st = d_start[k], n = d_end[k] - st;
-            const uint32_t ka = 4 * lane, kb = 256 + 4 * lane;
-            pa = chans + st + (ka < n ? ka : 0u);  // (the column has spare entries behind it)
-            pb = chans + st + (kb < n ? kb : 0u);
-        };
-        if (chans && wave < ndue) {
-            const uint32_t *pa, *pb;
-            column_ptrs(wave, pa, pb);
-            asm volatile(
-                "global_load_dwordx4 %0, %2, off\n\t"
-                "global_load_dwordx4 %1, %3, off\n\t"
-                "s_waitcnt vmcnt(0)"
-                : "=&v"(cur_a), "=&v"(cur_b)
-                : "v"(pa), "v"(pb)
-                : "memory");
+            if (in_regs) n_out = store_column2(cur, n, start, conn | CHD_REC_FULL, out, opos, 1u, since);
+            else n_out = emit_cell_all(chans, start, start + n, conn | CHD_REC_FULL, out, opos, 1u);
         }
-        for (uint32_t k = wave; k < ndue; k += WAVES) {
-            u32x4 nxt_a = {0, 0, 0, 0}, nxt_b = {0, 0, 0, 0};
-            const bool prefetch = chans && k + WAVES < ndue;
-            if (prefetch) {
-                const uint32_t *pa, *pb;
-                column_ptrs(k + WAVES, pa, pb);
-                asm volatile(
-                    "global_load_dwordx4 %0, %2, off\n\t"
-                    "global_load_dwordx4 %1, %3, off"
-                    : "=&v"(nxt_a), "=&v"(nxt_b)
-                    : "v"(pa), "v"(pb)
-                    : "memory");
-            }
-#endif
-            uint32_t since = 0;    // wide stores certainly issued after the prefetch (lower bound)
-            const uint32_t fl = d_fl[k], info = d_info[k];
-            const uint32_t c = d_c[k];
-            const uint32_t start = d_start[k], end = d_end[k], n = end - start;
-            const bool skip_self = (fl & PF_SKIP_SELF) != 0;
-            const bool in_regs = n <= 512;  // the column is in cur_a / cur_b
-            chd_fanout_rec *__restrict__ out = w.recs + base + d_rel[k];
-            uint32_t *__restrict__ opos = w.rec_pos ? w.rec_pos + base + d_rel[k] : nullptr;
-            uint32_t n_out = 0;
-            if (info & PI_HLOST) hist_ovf = 1;
-            if (info & PI_FIRST) {
-                // first fan-out: the whole data of the spatial channel and of every entity channel in it
+        const uint32_t nw = info & SD_NWIN_MASK;
+        for (uint32_t j = 0; j < nw; j++) {
+            if ((info >> (SD_OWN_SHIFT + j)) & 1u) {  // the spatial channel's own buffered updates
                 if (lane == 0) {
                     chd_fanout_rec r;
-                    r.conn = conn | CHD_REC_FULL;
-                    r.channel = c + g.id_start;
-                    out[0] = r;
-                    if (opos) opos[0] = CHD_POS_CELL | c;
+                    r.conn = conn;
+                    r.channel = cch;
+                    out[n_out] = r;
+                    if (opos) opos[n_out] = CHD_POS_CELL | (cch - g.id_start);
                 }
-#if FO_PF_LAYOUT == 1
-                if (in_regs) n_out = store_column2(cur, n, start, conn | CHD_REC_FULL, out, opos, 1u, since);
-#else
-                if (in_regs) n_out = store_column(cur_a, cur_b, n, start, conn | CHD_REC_FULL, out, opos, 1u, since);
-#endif
-                else n_out = emit_cell_all(chans, start, end, conn | CHD_REC_FULL, out, opos, 1u);
+                n_out += 1;
             }
-            const uint32_t ch_hist = d_chh[k], ch_sender = d_chs[k];
-            const uint32_t nw = info & PI_NWIN_MASK;
-            for (uint32_t j = 0; j < nw; j++) {
-                const uint32_t wm = d_wm[j][k];
-                // the spatial channel's own buffered updates
-                if (cell_update_passes(ch_hist, ch_sender, d_chhp[k], d_chsp[k], wm, skip_self, conn)) {
-                    if (lane == 0) {
-                        chd_fanout_rec r;
-                        r.conn = conn;
-                        r.channel = c + g.id_start;
-                        out[n_out] = r;
-                        if (opos) opos[n_out] = CHD_POS_CELL | c;
-                    }
-                    n_out += 1;
-                }
-                if (!(info & PI_NONE)) {  // every entity passes this window (checked when the segment was classified)
-#if FO_PF_LAYOUT == 1
-                    if (in_regs) n_out = store_column2(cur, n, start, conn, out, opos, n_out, since);
-#else
-                    if (in_regs) n_out = store_column(cur_a, cur_b, n, start, conn, out, opos, n_out, since);
-#endif
-                    else n_out = emit_cell_all(chans, start, end, conn, out, opos, n_out);
-                }
+            if (!(info & SD_NONE)) {  // every entity passes this window (that is what made the subscription simple)
+                if (in_regs) n_out = store_column2(cur, n, start, conn, out, opos, n_out, since);
+                else n_out = emit_cell_all(chans, start, start + n, conn, out, opos, n_out);
             }
-            pad_segment(out, n_out);
-            // (the subscription's new state is written back once per tile, below: a 4- or 8-byte store per segment is a
-            // partially written line by the time the record stream has pushed it out of L2, and partial lines cost the
-            // ECC HBM a read-modify-write each — three per segment ate a quarter of the record stream's bandwidth)
-            if (lane == 0) d_nout[k] = n_out;
-            total += n_out;
-            if (prefetch) {
-                // the two loads are older than every store of this segment: a counted wait completes them and
-                // leaves the youngest K stores in flight (K <= the stores certainly issued since)
-#if FO_PF_LAYOUT == 1
-                if (since < 2) asm volatile("s_waitcnt vmcnt(0)" : "+v"(nxt[0]), "+v"(nxt[1]), "+v"(nxt[2]), "+v"(nxt[3]) : : "memory");
-                else if (since < 4) asm volatile("s_waitcnt vmcnt(2)" : "+v"(nxt[0]), "+v"(nxt[1]), "+v"(nxt[2]), "+v"(nxt[3]) : : "memory");
-                else if (since < 8) asm volatile("s_waitcnt vmcnt(4)" : "+v"(nxt[0]), "+v"(nxt[1]), "+v"(nxt[2]), "+v"(nxt[3]) : : "memory");
-                else asm volatile("s_waitcnt vmcnt(8)" : "+v"(nxt[0]), "+v"(nxt[1]), "+v"(nxt[2]), "+v"(nxt[3]) : : "memory");
+        }
+        pad_segment(out, n_out);
+        if (prefetch) {
+            // the four loads are older than every store of this segment: a counted wait completes them and leaves
+            // the youngest K stores in flight (K <= the stores certainly issued since)
+            if (since < 2) asm volatile("s_waitcnt vmcnt(0)" : "+v"(nxt[0]), "+v"(nxt[1]), "+v"(nxt[2]), "+v"(nxt[3]) : : "memory");
+            else if (since < 4) asm volatile("s_waitcnt vmcnt(2)" : "+v"(nxt[0]), "+v"(nxt[1]), "+v"(nxt[2]), "+v"(nxt[3]) : : "memory");
+            else if (since < 8) asm volatile("s_waitcnt vmcnt(4)" : "+v"(nxt[0]), "+v"(nxt[1]), "+v"(nxt[2]), "+v"(nxt[3]) : : "memory");
+            else asm volatile("s_waitcnt vmcnt(8)" : "+v"(nxt[0]), "+v"(nxt[1]), "+v"(nxt[2]), "+v"(nxt[3]) : : "memory");
 #pragma unroll
-                for (int h = 0; h < 4; h++) cur[h] = nxt[h];
-#else
-                if (since < 2) asm volatile("s_waitcnt vmcnt(0)" : "+v"(nxt_a), "+v"(nxt_b) : : "memory");
-                else if (since < 4) asm volatile("s_waitcnt vmcnt(2)" : "+v"(nxt_a), "+v"(nxt_b) : : "memory");
-                else if (since < 8) asm volatile("s_waitcnt vmcnt(4)" : "+v"(nxt_a), "+v"(nxt_b) : : "memory");
-                else asm volatile("s_waitcnt vmcnt(8)" : "+v"(nxt_a), "+v"(nxt_b) : : "memory");
-                cur_a = nxt_a;
-                cur_b = nxt_b;
-#endif
-            }
+            for (int h = 0; h < 4; h++) cur[h] = nxt[h];
+            d = dn;
         }
-        __syncthreads();
-        if (wave == 0 && lane < ndue) {  // fan-out state of the tile's streamed subscriptions: one store instruction per array
-            const uint32_t p = d_p[lane];
-            w.pair_last[pbase + p] = d_Ln[lane];
-            w.pair_flags[pbase + p] = d_fl[lane] | PF_HAD_FIRST;
-            w.pair_nrec[pbase + p] = d_nout[lane];
-        }
-        __syncthreads();
     }
-    if (lane == 0) wave_total[wave] = total;
-    if (hist_ovf && lane == 0) atomicAdd(&w.counters[CTR_HIST_OVERFLOW], 1u);
-    __syncthreads();
-    total = 0;
-#pragma unroll
-    for (int k = 0; k < WAVES; k++) total += wave_total[k];
     PF_TRACE(2);
-    if (threadIdx.x == 0) {
 #ifdef FO_PF_TRACE
-        if (s < 16384) fo_trace[4 * s + 3] = total;
+    if (threadIdx.x == 0 && s < 16384) fo_trace[4 * s + 3] = w.rec_cnt[s];
 #endif
-        w.rec_cnt[s] = total;
-        w.conn_defer[s] = any_deferred;
-        unsigned long long *slot = (unsigned long long *)&w.tot64[(size_t)(s & 63u) * 16];
-        if (total) atomicAdd(slot, (unsigned long long)total);
-        if (cnt) atomicAdd(slot + 1, (unsigned long long)cnt);
-    }
 }
 
 // ---------------------------------------------------------------------------
@@ -1691,10 +1630,9 @@ void launch_fanout_emit(hipStream_t st, DevGrid g, WorldDev w, int64_t now_ns, T
             if (one_wave) hipLaunchKernelGGL((k_fanout_emit<1, true>), dim3(w.S), dim3(64), 0, st, g, w, now_ns, ring);
             else hipLaunchKernelGGL((k_fanout_emit<4, true>), dim3(w.S), dim3(256), 0, st, g, w, now_ns, ring);
         } else if (one_wave) {
-            // CHD_EMIT_PIPELINED=0 keeps the first form (A/B runs)
-            static const bool pipelined = [] { const char *e = getenv("CHD_EMIT_PIPELINED"); return !(e && e[0] == '0'); }();
-            if (pipelined) {
-                hipLaunchKernelGGL(k_fanout_emit_pf<FO_PF_CONN_WAVES>, dim3(w.S), dim3(64 * FO_PF_CONN_WAVES), 0, st, g, w, now_ns, ring);
+            if (seg_path(w)) {
+                // (k_fanout_plan_seg has decided everything; see launch_fanout_plan)
+                hipLaunchKernelGGL(k_fanout_emit_seg<FO_SEG_WAVES>, dim3(w.S), dim3(64 * FO_SEG_WAVES), 0, st, g, w);
                 hipLaunchKernelGGL((k_fanout_emit<1, false, true>), dim3(w.S), dim3(64), 0, st, g, w, now_ns, ring);
             } else hipLaunchKernelGGL((k_fanout_emit<1, false>), dim3(w.S), dim3(64), 0, st, g, w, now_ns, ring);
         } else hipLaunchKernelGGL((k_fanout_emit<4, false>), dim3(w.S), dim3(256), 0, st, g, w, now_ns, ring);

@@ -15,4 +15,5 @@ PY
 EXTRA=""
 run pipelined A=1
 run old CHD_EMIT_PIPELINED=0
+EXTRA="--update-frac 0.5"; run half A=1; run half_old CHD_EMIT_PIPELINED=0; EXTRA=""
 for v in $R/channeld_amd/variants/libchd_*.so; do n=$(basename $v .so); run ${n#libchd_} CHD_SPATIAL_LIB=$v; done
