@@ -832,10 +832,10 @@ __global__ void __launch_bounds__(64 * WAVES) k_fanout_emit(DevGrid g, WorldDev 
 typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
 
 #ifndef FO_SEG_WAVES
-#define FO_SEG_WAVES 4   // waves per connection in k_fanout_emit_seg
+#define FO_SEG_WAVES 2   // waves per connection in k_fanout_emit_seg
 #endif
 #ifndef FO_SEG_OCC
-#define FO_SEG_OCC 5     // waves per SIMD the register allocator is asked for (84 VGPRs without a bound; occupancy is not what limits this kernel)
+#define FO_SEG_OCC 4     // waves per SIMD the register allocator is asked for (what limits this kernel is bytes in flight per wave, not waves)
 #endif
 
 __global__ void __launch_bounds__(64 * FO_WAVES) k_fanout_plan_seg(DevGrid g, WorldDev w, int64_t now, TickRing ring) {
@@ -1014,8 +1014,13 @@ extern "C" int chd_debug_trace(unsigned long long *out, unsigned n) {
 #define PF_TRACE(slot) do { } while (0)
 #endif
 
+#ifndef FO_SEG_BATCH
+#define FO_SEG_BATCH 4   // segments whose columns a wave loads together, between two waits
+#endif
+
 template <int WAVES>
 __global__ void __launch_bounds__(64 * WAVES, FO_SEG_OCC) k_fanout_emit_seg(DevGrid g, WorldDev w) {
+    constexpr int B = FO_SEG_BATCH;
     const uint32_t s = blockIdx.x;
     const uint32_t lane = lane_id();
     const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -1047,86 +1052,76 @@ __global__ void __launch_bounds__(64 * WAVES, FO_SEG_OCC) k_fanout_emit_seg(DevG
     const uint32_t *__restrict__ chans = w.ce_chan_view;
     const u32x4 *__restrict__ desc = (const u32x4 *)(const void *)(w.seg_desc + pbase);
     PF_TRACE(1);
-    if (wave >= ns) return;
-    // q[h] = entries 128 h + 2 lane, + 1 of the cell: ONE address register, the four quarters are immediate offsets
-    // (lanes beyond the cell read the spare entries behind the column or the next cells': never used)
-    u32x2 cur[4];
-    u32x4 d = desc[wave];
-    {
-        const uint32_t *pa = chans + d.y + 2 * lane;
-        asm volatile(
-            "global_load_dwordx2 %0, %4, off\n\t"
-            "global_load_dwordx2 %1, %4, off offset:512\n\t"
-            "global_load_dwordx2 %2, %4, off offset:1024\n\t"
-            "global_load_dwordx2 %3, %4, off offset:1536\n\t"
-            "s_waitcnt vmcnt(0)"
-            : "=&v"(cur[0]), "=&v"(cur[1]), "=&v"(cur[2]), "=&v"(cur[3])
-            : "v"(pa)
-            : "memory");
-    }
-    for (uint32_t k = wave; k < ns; k += WAVES) {
-        u32x2 nxt[4] = {{0, 0}, {0, 0}, {0, 0}, {0, 0}};
-        u32x4 dn = d;
-        const bool prefetch = k + WAVES < ns;
-        if (prefetch) {
-            dn = desc[k + WAVES];
-            const uint32_t *pa = chans + dn.y + 2 * lane;
+    // The vm counter is in-order: waiting for a load also waits for every record store issued before it, and a store
+    // takes ~3.5 us to complete while the chip streams (per-wave rate with one segment per wait: 446 records / 3.5 us,
+    // measured).  So the columns of B segments are loaded TOGETHER, one wait, then B segments' records are stored back
+    // to back: B times the bytes in flight per wave for the same number of waits.
+    for (uint32_t k0 = wave; k0 < ns; k0 += WAVES * B) {
+        u32x4 d[B];
+        u32x2 col[B][4];
+#pragma unroll
+        for (int b = 0; b < B; b++) {
+            const uint32_t k = k0 + b * WAVES;
+            d[b] = desc[k < ns ? k : k0];
+        }
+#pragma unroll
+        for (int b = 0; b < B; b++) {
+            // q[h] = entries 128 h + 2 lane, + 1 of the cell: ONE address register, the four quarters are immediate
+            // offsets (lanes beyond the cell read the spare entries behind the column or the next cells': never used)
+            const uint32_t *pa = chans + d[b].y + 2 * lane;
             asm volatile(
                 "global_load_dwordx2 %0, %4, off\n\t"
                 "global_load_dwordx2 %1, %4, off offset:512\n\t"
                 "global_load_dwordx2 %2, %4, off offset:1024\n\t"
                 "global_load_dwordx2 %3, %4, off offset:1536"
-                : "=&v"(nxt[0]), "=&v"(nxt[1]), "=&v"(nxt[2]), "=&v"(nxt[3])
+                : "=&v"(col[b][0]), "=&v"(col[b][1]), "=&v"(col[b][2]), "=&v"(col[b][3])
                 : "v"(pa)
                 : "memory");
         }
-        uint32_t since = 0;  // wide stores certainly issued after the prefetch (lower bound)
-        const uint32_t start = d.y, n = d.z, info = d.w;
-        const uint32_t cch = w.seg_c[pbase + k] + g.id_start;
-        chd_fanout_rec *__restrict__ out = w.recs + base + d.x;
-        uint32_t *__restrict__ opos = w.rec_pos ? w.rec_pos + base + d.x : nullptr;
-        const bool in_regs = n <= 512;  // the column is in cur[]
-        uint32_t n_out = 0;
-        if (info & SD_FIRST) {
-            // first fan-out: the whole data of the spatial channel and of every entity channel in it
-            if (lane == 0) {
-                chd_fanout_rec r;
-                r.conn = conn | CHD_REC_FULL;
-                r.channel = cch;
-                out[0] = r;
-                if (opos) opos[0] = CHD_POS_CELL | (cch - g.id_start);
-            }
-            if (in_regs) n_out = store_column2(cur, n, start, conn | CHD_REC_FULL, out, opos, 1u, since);
-            else n_out = emit_cell_all(chans, start, start + n, conn | CHD_REC_FULL, out, opos, 1u);
-        }
-        const uint32_t nw = info & SD_NWIN_MASK;
-        for (uint32_t j = 0; j < nw; j++) {
-            if ((info >> (SD_OWN_SHIFT + j)) & 1u) {  // the spatial channel's own buffered updates
+#pragma unroll
+        for (int b = 0; b < B; b++)
+            asm volatile("s_waitcnt vmcnt(0)" : "+v"(col[b][0]), "+v"(col[b][1]), "+v"(col[b][2]), "+v"(col[b][3]) : : "memory");
+#pragma unroll
+        for (int b = 0; b < B; b++) {
+            const uint32_t k = k0 + b * WAVES;
+            if (k >= ns) break;  // uniform
+            uint32_t since = 0;
+            const uint32_t start = d[b].y, n = d[b].z, info = d[b].w;
+            const uint32_t cch = w.seg_c[pbase + k] + g.id_start;
+            chd_fanout_rec *__restrict__ out = w.recs + base + d[b].x;
+            uint32_t *__restrict__ opos = w.rec_pos ? w.rec_pos + base + d[b].x : nullptr;
+            const bool in_regs = n <= 512;  // the column is in col[b]
+            uint32_t n_out = 0;
+            if (info & SD_FIRST) {
+                // first fan-out: the whole data of the spatial channel and of every entity channel in it
                 if (lane == 0) {
                     chd_fanout_rec r;
-                    r.conn = conn;
+                    r.conn = conn | CHD_REC_FULL;
                     r.channel = cch;
-                    out[n_out] = r;
-                    if (opos) opos[n_out] = CHD_POS_CELL | (cch - g.id_start);
+                    out[0] = r;
+                    if (opos) opos[0] = CHD_POS_CELL | (cch - g.id_start);
                 }
-                n_out += 1;
+                if (in_regs) n_out = store_column2(col[b], n, start, conn | CHD_REC_FULL, out, opos, 1u, since);
+                else n_out = emit_cell_all(chans, start, start + n, conn | CHD_REC_FULL, out, opos, 1u);
             }
-            if (!(info & SD_NONE)) {  // every entity passes this window (that is what made the subscription simple)
-                if (in_regs) n_out = store_column2(cur, n, start, conn, out, opos, n_out, since);
-                else n_out = emit_cell_all(chans, start, start + n, conn, out, opos, n_out);
+            const uint32_t nw = info & SD_NWIN_MASK;
+            for (uint32_t j = 0; j < nw; j++) {
+                if ((info >> (SD_OWN_SHIFT + j)) & 1u) {  // the spatial channel's own buffered updates
+                    if (lane == 0) {
+                        chd_fanout_rec r;
+                        r.conn = conn;
+                        r.channel = cch;
+                        out[n_out] = r;
+                        if (opos) opos[n_out] = CHD_POS_CELL | (cch - g.id_start);
+                    }
+                    n_out += 1;
+                }
+                if (!(info & SD_NONE)) {  // every entity passes this window (that is what made the subscription simple)
+                    if (in_regs) n_out = store_column2(col[b], n, start, conn, out, opos, n_out, since);
+                    else n_out = emit_cell_all(chans, start, start + n, conn, out, opos, n_out);
+                }
             }
-        }
-        pad_segment(out, n_out);
-        if (prefetch) {
-            // the four loads are older than every store of this segment: a counted wait completes them and leaves
-            // the youngest K stores in flight (K <= the stores certainly issued since)
-            if (since < 2) asm volatile("s_waitcnt vmcnt(0)" : "+v"(nxt[0]), "+v"(nxt[1]), "+v"(nxt[2]), "+v"(nxt[3]) : : "memory");
-            else if (since < 4) asm volatile("s_waitcnt vmcnt(2)" : "+v"(nxt[0]), "+v"(nxt[1]), "+v"(nxt[2]), "+v"(nxt[3]) : : "memory");
-            else if (since < 8) asm volatile("s_waitcnt vmcnt(4)" : "+v"(nxt[0]), "+v"(nxt[1]), "+v"(nxt[2]), "+v"(nxt[3]) : : "memory");
-            else asm volatile("s_waitcnt vmcnt(8)" : "+v"(nxt[0]), "+v"(nxt[1]), "+v"(nxt[2]), "+v"(nxt[3]) : : "memory");
-#pragma unroll
-            for (int h = 0; h < 4; h++) cur[h] = nxt[h];
-            d = dn;
+            pad_segment(out, n_out);
         }
     }
     PF_TRACE(2);

@@ -24,10 +24,12 @@ tr = np.zeros((S, 4), dtype=np.uint64)
 for t in range(T):
     w.tick_device(int(now[t]), n_updates=N, d_upd_x=dx.at(t * N * 8), d_upd_z=dz.at(t * N * 8), n_queries=S, d_queries=dq.at(t * S * 128))
     w.sync()
+    tr[:] = 0
     if t >= T - 3:
         assert lib.chd_debug_trace(tr.ctypes.data_as(C.c_void_p), S) == 0
-        t0 = tr[:, 0].min()
-        st, sg, en, rec = [(tr[:, k] - (t0 if k < 3 else 0)).astype(np.float64) * (0.01 if k < 3 else 1) for k in range(4)]  # us
+        ok = (tr[:, 2] > 0) & (tr[:, 1] > 0) & (tr[:, 2] >= tr[:, 0])  # connections that streamed something
+        t0 = tr[ok, 0].min()
+        st, sg, en, rec = [(tr[ok, k] - (t0 if k < 3 else 0)).astype(np.float64) * (0.01 if k < 3 else 1) for k in range(4)]  # us
         print(f"tick {t}: kernel span {en.max():.1f} us; wave lifetime mean {np.mean(en-st):.1f} p50 {np.median(en-st):.1f} p99 {np.percentile(en-st,99):.1f}; "
               f"stage phase mean {np.mean(sg-st):.1f} p99 {np.percentile(sg-st,99):.1f}; start times p50 {np.median(st):.1f} p90 {np.percentile(st,90):.1f} max {st.max():.1f}")
         edges = np.arange(0, en.max() + 10, 10)
