@@ -673,9 +673,7 @@ int chd_world_create(chd_ctx *ctx, const chd_world_cfg *cfg) {
     TRY(walloc(ctx, &d.conn_defer, S));
     TRY(walloc(ctx, &d.n_simple, S));
     TRY(walloc(ctx, &d.seg_desc, P, false));
-    TRY(walloc(ctx, &d.seg_c, P, false));
-    TRY(walloc(ctx, &d.seg_p, P, false));
-    TRY(walloc(ctx, &d.seg_fl, P, false));
+    TRY(walloc(ctx, &d.seg_desc2, P, false));
     TRY(walloc(ctx, &d.seg_ln, P, false));
     TRY(walloc(ctx, &d.pair_rel, P));
     TRY(walloc(ctx, &d.pair_nrec, P));

@@ -90,9 +90,7 @@ struct WorldDev {
     // row [s*capq, ...) describe the due subscriptions whose every window is a plain copy of the cell's channel column
     uint32_t *n_simple;   // [S]
     uint4 *seg_desc;      // [S*capq] {segment offset in the connection's range, column start, entries, SD_* | windows}
-    uint32_t *seg_c;      // [S*capq] cell index
-    uint32_t *seg_p;      // [S*capq] index of the subscription in the connection's list
-    uint32_t *seg_fl;     // [S*capq] pair_flags after this tick
+    uint4 *seg_desc2;     // [S*capq] {cell index, index of the subscription in the connection's list, pair_flags after this tick, -}
     int64_t *seg_ln;      // [S*capq] lastFanOutTime after this tick
     uint32_t *pair_rel;   // [S*capq] this tick: segment offset inside the connection's record range
     uint32_t *pair_nrec;  // [S*capq] this tick: records emitted for the subscription

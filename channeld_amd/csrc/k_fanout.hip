@@ -900,7 +900,9 @@ __global__ void __launch_bounds__(64 * FO_WAVES) k_fanout_plan_seg(DevGrid g, Wo
                     us = CHD_NOT_A_SENDER;
                 const uint32_t hand = chans ? w.cell_hand[c] : 0u;
                 const bool none = skip_self && us == conn;  // every buffered entity update is this connection's own
-                simple = chans != nullptr && nw <= 4;
+                // (a column of up to 512 entries is four 8-byte loads per lane; larger cells take the deferred launch — and at
+                // >= 1024 entities per cell the cell-major form is the default anyway)
+                simple = chans != nullptr && nw <= 4 && size <= 512;
 #pragma unroll
                 for (uint32_t j = 0; j < 4; j++)
                     if (j < nw && !none && (us == CHD_NONUNIFORM || !(hand & wms[j]))) simple = false;
@@ -948,9 +950,7 @@ __global__ void __launch_bounds__(64 * FO_WAVES) k_fanout_plan_seg(DevGrid g, Wo
         if (due && simple) {
             const size_t k = pbase + n_simple + mask_rank(sm);
             w.seg_desc[k] = make_uint4(rel32, start, size, info);
-            w.seg_c[k] = c;
-            w.seg_p[k] = p;
-            w.seg_fl[k] = fl | PF_HAD_FIRST;
+            w.seg_desc2[k] = make_uint4(c, p, fl | PF_HAD_FIRST, 0u);
             w.seg_ln[k] = Lw;
             rec_simple += count;
         }
@@ -1044,84 +1044,91 @@ __global__ void __launch_bounds__(64 * WAVES, FO_SEG_OCC) k_fanout_emit_seg(DevG
     if (!ns) return;
     if (wave == WAVES - 1)  // the subscriptions' new fan-out state: one coalesced pass (lastFanOutTime, hadFirstFanOut)
         for (uint32_t k = lane; k < ns; k += 64) {
-            const uint32_t p = w.seg_p[pbase + k];
-            w.pair_last[pbase + p] = w.seg_ln[pbase + k];
-            w.pair_flags[pbase + p] = w.seg_fl[pbase + k];
+            const uint4 d2 = w.seg_desc2[pbase + k];
+            w.pair_last[pbase + d2.y] = w.seg_ln[pbase + k];
+            w.pair_flags[pbase + d2.y] = d2.z;
         }
     const uint32_t conn = w.conn_id[s];
     const uint32_t *__restrict__ chans = w.ce_chan_view;
-    const u32x4 *__restrict__ desc = (const u32x4 *)(const void *)(w.seg_desc + pbase);
     PF_TRACE(1);
-    // The vm counter is in-order: waiting for a load also waits for every record store issued before it, and a store
-    // takes ~3.5 us to complete while the chip streams (per-wave rate with one segment per wait: 446 records / 3.5 us,
-    // measured).  So the columns of B segments are loaded TOGETHER, one wait, then B segments' records are stored back
-    // to back: B times the bytes in flight per wave for the same number of waits.
-    for (uint32_t k0 = wave; k0 < ns; k0 += WAVES * B) {
-        u32x4 d[B];
-        u32x2 col[B][4];
-#pragma unroll
-        for (int b = 0; b < B; b++) {
-            const uint32_t k = k0 + b * WAVES;
-            d[b] = desc[k < ns ? k : k0];
+    if (wave >= ns) return;
+    // Every descriptor of this wave in ONE vector load: lane j holds the wave's j-th segment (k = wave + j WAVES); the
+    // streaming loop reads them with v_readlane (scalar operands from there on).  No descriptor load ever sits between
+    // record stores: the vm counter is in-order, so ANY load wait also waits for every record store issued before it,
+    // and a store takes ~3.5 us to complete while the chip streams.
+    const uint32_t mine = (ns - wave + WAVES - 1) / WAVES;  // segments of this wave (a connection has at most 64 WAVES due ones per pass)
+    for (uint32_t j0 = 0; j0 < mine; j0 += 64) {
+        const uint32_t kl = wave + (j0 + lane) * WAVES;
+        u32x4 dv = {0, 0, 0, 0};
+        uint32_t cv = 0;
+        if (kl < ns) {
+            dv = *(const u32x4 *)(const void *)(w.seg_desc + pbase + kl);
+            cv = w.seg_desc2[pbase + kl].x;
         }
+        const uint32_t here = min(mine - j0, 64u);
+        // ... and the columns of B segments are loaded TOGETHER, one wait, then B segments' records are stored back to
+        // back: B times the bytes in flight per wave for the same number of waits (tools/ubench/store_conn2.hip).
+        for (uint32_t jb = 0; jb < here; jb += B) {
+            u32x2 col[B][4];
 #pragma unroll
-        for (int b = 0; b < B; b++) {
-            // q[h] = entries 128 h + 2 lane, + 1 of the cell: ONE address register, the four quarters are immediate
-            // offsets (lanes beyond the cell read the spare entries behind the column or the next cells': never used)
-            const uint32_t *pa = chans + d[b].y + 2 * lane;
-            asm volatile(
-                "global_load_dwordx2 %0, %4, off\n\t"
-                "global_load_dwordx2 %1, %4, off offset:512\n\t"
-                "global_load_dwordx2 %2, %4, off offset:1024\n\t"
-                "global_load_dwordx2 %3, %4, off offset:1536"
-                : "=&v"(col[b][0]), "=&v"(col[b][1]), "=&v"(col[b][2]), "=&v"(col[b][3])
-                : "v"(pa)
-                : "memory");
-        }
-#pragma unroll
-        for (int b = 0; b < B; b++)
-            asm volatile("s_waitcnt vmcnt(0)" : "+v"(col[b][0]), "+v"(col[b][1]), "+v"(col[b][2]), "+v"(col[b][3]) : : "memory");
-#pragma unroll
-        for (int b = 0; b < B; b++) {
-            const uint32_t k = k0 + b * WAVES;
-            if (k >= ns) break;  // uniform
-            uint32_t since = 0;
-            const uint32_t start = d[b].y, n = d[b].z, info = d[b].w;
-            const uint32_t cch = w.seg_c[pbase + k] + g.id_start;
-            chd_fanout_rec *__restrict__ out = w.recs + base + d[b].x;
-            uint32_t *__restrict__ opos = w.rec_pos ? w.rec_pos + base + d[b].x : nullptr;
-            const bool in_regs = n <= 512;  // the column is in col[b]
-            uint32_t n_out = 0;
-            if (info & SD_FIRST) {
-                // first fan-out: the whole data of the spatial channel and of every entity channel in it
-                if (lane == 0) {
-                    chd_fanout_rec r;
-                    r.conn = conn | CHD_REC_FULL;
-                    r.channel = cch;
-                    out[0] = r;
-                    if (opos) opos[0] = CHD_POS_CELL | (cch - g.id_start);
-                }
-                if (in_regs) n_out = store_column2(col[b], n, start, conn | CHD_REC_FULL, out, opos, 1u, since);
-                else n_out = emit_cell_all(chans, start, start + n, conn | CHD_REC_FULL, out, opos, 1u);
+            for (int b = 0; b < B; b++) {
+                // q[h] = entries 128 h + 2 lane, + 1 of the cell: ONE address register, the four quarters are immediate
+                // offsets (lanes beyond the cell read the spare entries behind the column or the next cells': never used)
+                const uint32_t jj = jb + b < here ? jb + b : jb;
+                const uint32_t start = (uint32_t)__builtin_amdgcn_readlane((int)dv.y, (int)jj);
+                const uint32_t *pa = chans + start + 2 * lane;
+                asm volatile(
+                    "global_load_dwordx2 %0, %4, off\n\t"
+                    "global_load_dwordx2 %1, %4, off offset:512\n\t"
+                    "global_load_dwordx2 %2, %4, off offset:1024\n\t"
+                    "global_load_dwordx2 %3, %4, off offset:1536"
+                    : "=&v"(col[b][0]), "=&v"(col[b][1]), "=&v"(col[b][2]), "=&v"(col[b][3])
+                    : "v"(pa)
+                    : "memory");
             }
-            const uint32_t nw = info & SD_NWIN_MASK;
-            for (uint32_t j = 0; j < nw; j++) {
-                if ((info >> (SD_OWN_SHIFT + j)) & 1u) {  // the spatial channel's own buffered updates
+#pragma unroll
+            for (int b = 0; b < B; b++)
+                asm volatile("s_waitcnt vmcnt(0)" : "+v"(col[b][0]), "+v"(col[b][1]), "+v"(col[b][2]), "+v"(col[b][3]) : : "memory");
+#pragma unroll
+            for (int b = 0; b < B; b++) {
+                if (jb + b >= here) break;  // uniform
+                uint32_t since = 0;
+                const int jj = (int)(jb + b);
+                const uint32_t rel = (uint32_t)__builtin_amdgcn_readlane((int)dv.x, jj), start = (uint32_t)__builtin_amdgcn_readlane((int)dv.y, jj);
+                const uint32_t n = (uint32_t)__builtin_amdgcn_readlane((int)dv.z, jj), info = (uint32_t)__builtin_amdgcn_readlane((int)dv.w, jj);
+                const uint32_t cch = (uint32_t)__builtin_amdgcn_readlane((int)cv, jj) + g.id_start;
+                chd_fanout_rec *__restrict__ out = w.recs + base + rel;
+                uint32_t *__restrict__ opos = w.rec_pos ? w.rec_pos + base + rel : nullptr;
+                uint32_t n_out = 0;
+                if (info & SD_FIRST) {
+                    // first fan-out: the whole data of the spatial channel and of every entity channel in it
                     if (lane == 0) {
                         chd_fanout_rec r;
-                        r.conn = conn;
+                        r.conn = conn | CHD_REC_FULL;
                         r.channel = cch;
-                        out[n_out] = r;
-                        if (opos) opos[n_out] = CHD_POS_CELL | (cch - g.id_start);
+                        out[0] = r;
+                        if (opos) opos[0] = CHD_POS_CELL | (cch - g.id_start);
                     }
-                    n_out += 1;
+                    n_out = store_column2(col[b], n, start, conn | CHD_REC_FULL, out, opos, 1u, since);
                 }
-                if (!(info & SD_NONE)) {  // every entity passes this window (that is what made the subscription simple)
-                    if (in_regs) n_out = store_column2(col[b], n, start, conn, out, opos, n_out, since);
-                    else n_out = emit_cell_all(chans, start, start + n, conn, out, opos, n_out);
+                const uint32_t nw = info & SD_NWIN_MASK;
+                for (uint32_t j = 0; j < nw; j++) {
+                    if ((info >> (SD_OWN_SHIFT + j)) & 1u) {  // the spatial channel's own buffered updates
+                        if (lane == 0) {
+                            chd_fanout_rec r;
+                            r.conn = conn;
+                            r.channel = cch;
+                            out[n_out] = r;
+                            if (opos) opos[n_out] = CHD_POS_CELL | (cch - g.id_start);
+                        }
+                        n_out += 1;
+                    }
+                    if (!(info & SD_NONE)) {  // every entity passes this window (that is what made the subscription simple)
+                        n_out = store_column2(col[b], n, start, conn, out, opos, n_out, since);
+                    }
                 }
+                pad_segment(out, n_out);
             }
-            pad_segment(out, n_out);
         }
     }
     PF_TRACE(2);
