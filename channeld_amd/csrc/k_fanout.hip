@@ -883,10 +883,20 @@ __global__ void __launch_bounds__(64 * FO_WAVES) k_fanout_plan_seg(DevGrid g, Wo
                 if (now >= Lw + I) {
                     hlost = history_lost(ring, oldest, Lw, I);
                     while (now >= Lw + I) {  // data.go:224-271 + the revisit through :273-286
-                        const int64_t next = Lw + I;
-                        const uint32_t wm = window_mask_serial(ring, Lw > 0 ? Lw : 0, next);
+                        const int64_t next = Lw + I, lo = Lw > 0 ? Lw : 0;
+                        // Window [lo, next] over the ring.  The stamps do not increase with the slot index, so the scan
+                        // stops at the first stamp older than the window — one or two slots for a subscription that is
+                        // served every tick (a full 32-slot scan per window and lane made this kernel VALU-bound: 44 us).
+                        uint32_t wm = 0, newer = 0;
+                        int64_t ts_newer = 0;
+                        for (uint32_t j = 0; j < ring.n; j++) {
+                            const int64_t tj = ring.t[j];
+                            if (tj < lo) break;
+                            if (tj <= next) wm |= 1u << j;
+                            else { newer++; ts_newer = tj; }  // (the last one kept = the oldest stamp newer than the window)
+                        }
                         if (!wm) {
-                            Lw += empty_windows_serial(ring, now, Lw, iv) * I;
+                            Lw += empty_windows_to(ts_newer, newer, now, Lw, iv) * I;
                             continue;
                         }
                         if (nw < 4) wms[nw] = wm;
