@@ -904,11 +904,15 @@ __global__ void __launch_bounds__(64 * FO_WAVES) k_fanout_plan_seg(DevGrid g, Wo
                         Lw = next;
                     }
                 }
-                uint32_t us = w.ce8_view ? w.cell_usender[c] : CHD_NONUNIFORM;
+                // (every per-cell word this lane may need is requested here, in one round trip with the cell bounds above)
+                const uint32_t c_us = w.cell_usender[c], c_smin = w.cell_smin[c], c_smax = w.cell_smax[c], c_hand = w.cell_hand[c];
+                const uint32_t c_htick = w.cell_hist_tick[c], c_hist = w.cell_hist[c], c_hprev = w.cell_hist_prev[c];
+                const uint32_t chs = w.cell_sender[c], chsp = w.cell_sender_prev[c];
+                uint32_t us = w.ce8_view ? c_us : CHD_NONUNIFORM;
                 const bool skip_self = (fl & PF_SKIP_SELF) != 0;
-                if (w.ce8_view && us == CHD_NONUNIFORM && (!skip_self || conn < w.cell_smin[c] || conn > w.cell_smax[c]))
+                if (w.ce8_view && us == CHD_NONUNIFORM && (!skip_self || conn < c_smin || conn > c_smax))
                     us = CHD_NOT_A_SENDER;
-                const uint32_t hand = chans ? w.cell_hand[c] : 0u;
+                const uint32_t hand = chans ? c_hand : 0u;
                 const bool none = skip_self && us == conn;  // every buffered entity update is this connection's own
                 // (a column of up to 512 entries is four 8-byte loads per lane; larger cells take the deferred launch — and at
                 // >= 1024 entities per cell the cell-major form is the default anyway)
@@ -918,10 +922,9 @@ __global__ void __launch_bounds__(64 * FO_WAVES) k_fanout_plan_seg(DevGrid g, Wo
                     if (j < nw && !none && (us == CHD_NONUNIFORM || !(hand & wms[j]))) simple = false;
                 if (simple) {
                     // exact record count: the segment is as long as what will be written
-                    const uint32_t age = ring.cur_tick - w.cell_hist_tick[c];
-                    const uint32_t chh = age < CHD_HIST_BITS ? (w.cell_hist[c] << age) : 0u;
-                    const uint32_t chhp = age < CHD_HIST_BITS ? (w.cell_hist_prev[c] << age) : 0u;
-                    const uint32_t chs = w.cell_sender[c], chsp = w.cell_sender_prev[c];
+                    const uint32_t age = ring.cur_tick - c_htick;
+                    const uint32_t chh = age < CHD_HIST_BITS ? (c_hist << age) : 0u;
+                    const uint32_t chhp = age < CHD_HIST_BITS ? (c_hprev << age) : 0u;
                     count = (info & SD_FIRST) ? size + 1 : 0u;
 #pragma unroll
                     for (uint32_t j = 0; j < 4; j++) {
@@ -1025,7 +1028,7 @@ extern "C" int chd_debug_trace(unsigned long long *out, unsigned n) {
 #endif
 
 #ifndef FO_SEG_BATCH
-#define FO_SEG_BATCH 4   // segments whose columns a wave loads together, between two waits
+#define FO_SEG_BATCH 2   // segments whose columns a wave loads together, between two waits
 #endif
 
 template <int WAVES>
