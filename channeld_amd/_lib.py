@@ -47,7 +47,7 @@ SYMBOLS = (
     "chd_set_stream", "chd_shard_spawn", "chd_shard_ingest", "chd_shard_import", "chd_shard_fanout",
     "chd_shard_get_entities", "chd_shard_table_bytes", "chd_shard_interest",
     "chd_handover_recipients", "chd_adjacent_recipients", "chd_wire_set_payloads", "chd_wire_build", "chd_wire_fetch",
-    "chd_tick_digest", "chd_host_alloc", "chd_host_free",
+    "chd_tick_digest", "chd_host_alloc", "chd_host_free", "chd_subs_set_options", "chd_subs_get_options",
 )
 
 
@@ -148,6 +148,16 @@ class TickStats(C.Structure):
     ]
 
 
+SUBOPT_ACCESS, SUBOPT_INTERVAL, SUBOPT_DELAY, SUBOPT_SKIP_SELF, SUBOPT_SKIP_FIRST = 1, 2, 4, 8, 16
+ACCESS_NONE, ACCESS_READ, ACCESS_WRITE = 0, 1, 2
+
+
+class SubOptions(C.Structure):
+    _fields_ = [("slot", C.c_uint32), ("channel", C.c_uint32), ("set", C.c_uint32), ("data_access", C.c_uint32),
+                ("fanout_interval_ms", C.c_uint32), ("fanout_delay_ms", C.c_int32),
+                ("skip_self_update_fanout", C.c_uint32), ("skip_first_fanout", C.c_uint32)]
+
+
 class RecordsDigest(C.Structure):
     _fields_ = [("count", C.c_uint64), ("sum", C.c_uint64), ("xor_", C.c_uint64), ("sum_masked", C.c_uint64)]
 
@@ -212,6 +222,8 @@ def load():
     L.chd_handover_recipients.argtypes = [C.c_void_p, _u32p, _u32p, _u8p, C.c_uint64, P(C.c_uint64)]
     L.chd_adjacent_recipients.argtypes = [C.c_void_p, C.c_uint32, _u32p, _u32p, _u32p, _u32p, _u32p, _u32p, C.c_uint64]
     L.chd_tick_digest.argtypes = [C.c_void_p, P(RecordsDigest), _u64p]
+    L.chd_subs_set_options.argtypes = [C.c_void_p, C.c_int64, C.c_uint32, P(SubOptions), _u8p, _i32p]
+    L.chd_subs_get_options.argtypes = [C.c_void_p, C.c_uint32, _u8p, _u8p, P(C.c_uint32)]
     L.chd_host_alloc.argtypes = [C.c_void_p, C.c_uint64, P(C.c_void_p)]
     L.chd_host_free.argtypes = [C.c_void_p, C.c_void_p]
     L.chd_set_profiling.argtypes = [C.c_void_p, C.c_int]

@@ -835,6 +835,77 @@ int chd_subs_add(chd_ctx *ctx, uint32_t n, const uint32_t *slot, const uint32_t 
 }
 int chd_subs_remove(chd_ctx *ctx, uint32_t n, const uint32_t *slot) { return subs_common(ctx, n, slot, nullptr, 0); }
 
+int chd_subs_set_options(chd_ctx *ctx, int64_t now_ns, uint32_t n, const chd_sub_options *opts, uint8_t *should_send, int32_t *status) {
+    NEED_WORLD();
+    if (!n) return CHD_OK;
+    if (!opts) return fail(ctx, CHD_E_INVAL, "chd_subs_set_options: NULL options");
+    WorldDev &d = ctx->w.d;
+    for (uint32_t i = 0; i < n; i++) {
+        const chd_sub_options &o = opts[i];
+        if (o.slot >= d.S) return fail(ctx, CHD_E_INVAL, "option %u: subscriber slot %u out of range", i, o.slot);
+        if (o.channel < ctx->g.id_start || o.channel - ctx->g.id_start >= ctx->g.ncell)
+            return fail(ctx, CHD_E_INVAL, "option %u: %u is not a spatial channel of this grid", i, o.channel);
+        if ((o.set & CHD_SUBOPT_ACCESS) && o.data_access > CHD_ACCESS_WRITE) return fail(ctx, CHD_E_INVAL, "option %u: DataAccess %u", i, o.data_access);
+        if ((o.set & CHD_SUBOPT_INTERVAL) && o.fanout_interval_ms == 0)
+            return fail(ctx, CHD_E_INVAL, "option %u: fan-out interval 0 makes the reference's tickData spin forever", i);
+    }
+    // one wave per connection, its records in call order: stable grouping by slot
+    std::vector<uint32_t> order(n), grp;
+    for (uint32_t i = 0; i < n; i++) order[i] = i;
+    std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return opts[a].slot < opts[b].slot; });
+    for (uint32_t r = 0; r < n; r++)
+        if (r == 0 || opts[order[r]].slot != opts[order[r - 1]].slot) grp.push_back(r);
+    const uint32_t ngrp = (uint32_t)grp.size();
+    grp.push_back(n);
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    TRY(bind(ctx));
+    TRY(ensure(ctx, 0, sizeof(chd_sub_options) * (size_t)n));
+    TRY(ensure(ctx, 1, 4 * (size_t)n));
+    TRY(ensure(ctx, 2, 4 * (size_t)(ngrp + 1)));
+    TRY(ensure(ctx, 3, (size_t)n));
+    TRY(ensure(ctx, 4, 4 * (size_t)n));
+    TRY(up(ctx, sbuf<void>(ctx, 0), opts, sizeof(chd_sub_options) * (size_t)n));
+    TRY(up(ctx, sbuf<void>(ctx, 1), order.data(), 4 * (size_t)n));
+    TRY(up(ctx, sbuf<void>(ctx, 2), grp.data(), 4 * (size_t)(ngrp + 1)));
+    launch_subs_set_options(ctx->stream, ctx->g, d, sbuf<chd_sub_options>(ctx, 0), sbuf<uint32_t>(ctx, 1), sbuf<uint32_t>(ctx, 2), ngrp,
+                            now_ns, sbuf<uint8_t>(ctx, 3), sbuf<int32_t>(ctx, 4));
+    TRY(after_launch(ctx));
+    std::vector<int32_t> st(n);
+    std::vector<uint8_t> ss(n);
+    TRY(down(ctx, ss.data(), sbuf<void>(ctx, 3), n));
+    TRY(down(ctx, st.data(), sbuf<void>(ctx, 4), 4 * (size_t)n));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    int rc = CHD_OK;
+    for (uint32_t i = 0; i < n; i++) {
+        if (should_send) should_send[i] = ss[i];
+        if (status) status[i] = st[i];
+        if (st[i] == CHD_E_CAPACITY) rc = CHD_E_CAPACITY;
+    }
+    if (rc) return fail(ctx, rc, "chd_subs_set_options: a connection's subscription list is full (max_interest_cells)");
+    return CHD_OK;
+}
+
+int chd_subs_get_options(chd_ctx *ctx, uint32_t slot, uint8_t *data_access, uint8_t *skip_self, uint32_t *n_out) {
+    NEED_WORLD();
+    if (!data_access || !skip_self || !n_out) return fail(ctx, CHD_E_INVAL, "chd_subs_get_options: NULL buffer");
+    WorldDev &d = ctx->w.d;
+    if (slot >= d.S) return fail(ctx, CHD_E_INVAL, "subscriber slot %u out of range", slot);
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    TRY(bind(ctx));
+    TRY(ensure(ctx, 0, d.capq));
+    TRY(ensure(ctx, 1, d.capq));
+    uint32_t cnt = 0;
+    TRY(down(ctx, &cnt, d.pair_cnt + slot, 4));
+    launch_subs_get_options(ctx->stream, d, slot, sbuf<uint8_t>(ctx, 0), sbuf<uint8_t>(ctx, 1));
+    TRY(after_launch(ctx));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    TRY(down(ctx, data_access, sbuf<void>(ctx, 0), cnt));
+    TRY(down(ctx, skip_self, sbuf<void>(ctx, 1), cnt));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    *n_out = cnt;
+    return CHD_OK;
+}
+
 // ---- the device-side tick, in stages; caller holds the mutex ----
 static int tick_begin(chd_ctx *ctx, int64_t now_ns) {
     World &W = ctx->w;

@@ -196,6 +196,10 @@ void launch_set_flags(hipStream_t st, WorldDev w, uint32_t n, const uint32_t *id
 void launch_subs_add(hipStream_t st, WorldDev w, uint32_t n, const uint32_t *slot,
                      const uint32_t *conn, int add);
 
+void launch_subs_set_options(hipStream_t st, DevGrid g, WorldDev w, const chd_sub_options *opts, const uint32_t *order,
+                             const uint32_t *grp_off, uint32_t n_groups, int64_t now_ns, uint8_t *should_send, int32_t *status);
+void launch_subs_get_options(hipStream_t st, WorldDev w, uint32_t s, uint8_t *access, uint8_t *skip_self);
+
 // K1: cell assign + handover detect (+ update history)
 void launch_ingest(hipStream_t st, DevGrid g, WorldDev w, uint32_t n, const uint32_t *idx,
                    const double *x, const double *z, const uint32_t *sender, uint32_t cur_tick);

@@ -248,6 +248,118 @@ void launch_subs_add(hipStream_t st, WorldDev w, uint32_t n, const uint32_t *slo
     hipLaunchKernelGGL(k_subs_add, dim3(nblocks(n, 256)), dim3(256), 0, st, w, n, slot, conn, add);
 }
 
+// SubscribeToChannel(conn, spatial channel, options) for explicit SUB_TO_CHANNEL messages (subscription.go:34-102;
+// handleSubToChannel, message.go) — the subscriptions an interest update creates carry only the damped interval
+// (message_spatial.go:66-79), every other option comes through here: the spatial servers' own subscriptions
+// (WRITE access, spatial.go:481-590) and clients that change DataAccess / SkipSelfUpdateFanOut / the interval.
+// One wave per connection, its records applied in call order (the reference handles a connection's messages one
+// after the other).  Already subscribed: the present fields overwrite the stored options (proto.Merge, :44-57), the
+// fan-out state stays, result = dataAccessChanged.  Else a new subscription: defaults (:21-31) merged with the
+// options, hadFirstFanOut = SkipFirstFanOut, lastFanOutTime = now + FanOutDelayMs (:59-75), result = true;
+// inserted into the connection's list (ascending cell), interest bitmap and per-cell count updated.
+__global__ void __launch_bounds__(64) k_subs_set_options(DevGrid g, WorldDev w, const chd_sub_options *__restrict__ opts,
+                                                         const uint32_t *__restrict__ order, const uint32_t *__restrict__ grp_off,
+                                                         int64_t now_ns, uint8_t *__restrict__ should_send, int32_t *__restrict__ status) {
+    const uint32_t lane = lane_id();
+    const uint32_t r0 = grp_off[blockIdx.x], r1 = grp_off[blockIdx.x + 1];
+    const uint32_t s = opts[order[r0]].slot;
+    const size_t pbase = (size_t)s * w.capq;
+    const bool alive = w.sub_alive[s] != 0;
+    for (uint32_t r = r0; r < r1; r++) {
+        const uint32_t i = order[r];
+        const chd_sub_options o = opts[i];
+        if (!alive) {  // IsClosing / no such connection: (nil, false)
+            if (lane == 0) { should_send[i] = 0; status[i] = CHD_E_INVAL; }
+            continue;
+        }
+        const uint32_t c = o.channel - g.id_start;
+        uint32_t cnt = w.pair_cnt[s];
+        // position of the first subscription with cell >= c (the list is ascending)
+        uint32_t pos = cnt;
+        bool found = false;
+        for (uint32_t b = 0; b < cnt; b += 64) {
+            const uint32_t v = b + lane < cnt ? w.pair_cell[pbase + b + lane] : 0xFFFFFFFFu;
+            const uint64_t m = __ballot(v >= c);
+            if (m) {
+                pos = b + (uint32_t)__ffsll((unsigned long long)m) - 1u;
+                found = (uint32_t)__shfl((int)v, (int)(pos - b)) == c;
+                break;
+            }
+        }
+        if (found) {
+            if (lane == 0) {
+                uint32_t fl = w.pair_flags[pbase + pos];
+                const uint32_t acc_old = (fl & PF_NO_ACCESS) ? 0u : (fl & PF_WRITE) ? 2u : 1u;
+                uint32_t acc = acc_old;
+                if (o.set & CHD_SUBOPT_ACCESS) acc = o.data_access;
+                fl &= ~(PF_NO_ACCESS | PF_WRITE);
+                fl |= acc == 0 ? PF_NO_ACCESS : acc == 2 ? PF_WRITE : 0u;
+                if (o.set & CHD_SUBOPT_SKIP_SELF) fl = o.skip_self_update_fanout ? (fl | PF_SKIP_SELF) : (fl & ~PF_SKIP_SELF);
+                w.pair_flags[pbase + pos] = fl;
+                if (o.set & CHD_SUBOPT_INTERVAL) w.pair_iv[pbase + pos] = o.fanout_interval_ms;
+                should_send[i] = acc != acc_old ? 1 : 0;  // dataAccessChanged
+                status[i] = CHD_OK;
+            }
+            continue;
+        }
+        if (cnt >= w.capq) {
+            if (lane == 0) { should_send[i] = 0; status[i] = CHD_E_CAPACITY; }
+            continue;
+        }
+        // open a slot at pos: move [pos, cnt) up by one, from the top, 64 entries at a time (read, then write)
+        for (uint32_t hi = cnt; hi > pos;) {
+            const uint32_t lo = hi - pos > 64 ? hi - 64 : pos;
+            const uint32_t k = lo + lane;
+            uint32_t vc = 0, vi = 0, vf = 0;
+            int64_t vl = 0;
+            if (k < hi) { vc = w.pair_cell[pbase + k]; vi = w.pair_iv[pbase + k]; vf = w.pair_flags[pbase + k]; vl = w.pair_last[pbase + k]; }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            if (k < hi) { w.pair_cell[pbase + k + 1] = vc; w.pair_iv[pbase + k + 1] = vi; w.pair_flags[pbase + k + 1] = vf; w.pair_last[pbase + k + 1] = vl; }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            hi = lo;
+        }
+        if (lane == 0) {
+            const uint32_t acc = (o.set & CHD_SUBOPT_ACCESS) ? o.data_access : 1u;  // default READ_ACCESS
+            const bool skip_self = (o.set & CHD_SUBOPT_SKIP_SELF) ? o.skip_self_update_fanout != 0 : true;
+            const bool skip_first = (o.set & CHD_SUBOPT_SKIP_FIRST) ? o.skip_first_fanout != 0 : false;
+            const int32_t delay = (o.set & CHD_SUBOPT_DELAY) ? o.fanout_delay_ms : g.default_delay_ms;
+            w.pair_cell[pbase + pos] = c;
+            w.pair_iv[pbase + pos] = (o.set & CHD_SUBOPT_INTERVAL) ? o.fanout_interval_ms : g.default_interval_ms;
+            w.pair_last[pbase + pos] = now_ns + (int64_t)delay * 1000000;
+            w.pair_flags[pbase + pos] = (acc == 0 ? PF_NO_ACCESS : acc == 2 ? PF_WRITE : 0u) | (skip_self ? PF_SKIP_SELF : 0u) |
+                                        (skip_first ? PF_HAD_FIRST : 0u);
+            w.pair_cnt[s] = cnt + 1;
+            atomicAdd(&w.cell_ref[c], 1u);
+            if (w.wb) w.sub_bits[(size_t)s * w.wb + (c >> 6)] |= 1ull << (c & 63u);
+            should_send[i] = 1;
+            status[i] = CHD_OK;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
+void launch_subs_set_options(hipStream_t st, DevGrid g, WorldDev w, const chd_sub_options *opts, const uint32_t *order,
+                             const uint32_t *grp_off, uint32_t n_groups, int64_t now_ns, uint8_t *should_send, int32_t *status) {
+    if (!n_groups) return;
+    hipLaunchKernelGGL(k_subs_set_options, dim3(n_groups), dim3(64), 0, st, g, w, opts, order, grp_off, now_ns, should_send, status);
+}
+
+// the options of a connection's subscriptions (chd_subs_get_options): 0 NO_ACCESS / 1 READ / 2 WRITE, SkipSelfUpdateFanOut
+__global__ void __launch_bounds__(64) k_subs_get_options(WorldDev w, uint32_t s, uint8_t *access, uint8_t *skip_self) {
+    const uint32_t cnt = w.pair_cnt[s];
+    for (uint32_t k = threadIdx.x; k < cnt; k += 64) {
+        const uint32_t fl = w.pair_flags[(size_t)s * w.capq + k];
+        access[k] = (fl & PF_NO_ACCESS) ? 0 : (fl & PF_WRITE) ? 2 : 1;
+        skip_self[k] = (fl & PF_SKIP_SELF) ? 1 : 0;
+    }
+}
+void launch_subs_get_options(hipStream_t st, WorldDev w, uint32_t s, uint8_t *access, uint8_t *skip_self) {
+    hipLaunchKernelGGL(k_subs_get_options, dim3(1), dim3(64), 0, st, w, s, access, skip_self);
+}
+
 // ------------------------------------------------------------------------
 // K1: ingest one batch of entity position updates.
 //   src = cell of the last merged position (== GetChannelId(oldInfo), kept as

@@ -112,6 +112,35 @@ class SpatialWorld:
         s = _u32(slots)
         _lib.check(self.ctx, self.lib.chd_subs_remove(self.ctx, len(s), _ptr(s)))
 
+    def set_sub_options(self, now_ns: int, options):
+        """SubscribeToChannel with explicit ChannelSubscriptionOptions (chd_subs_set_options).  options: iterable of dicts
+        with slot, channel and any of data_access, fanout_interval_ms, fanout_delay_ms, skip_self_update_fanout,
+        skip_first_fanout (absent = not set).  Returns (should_send[], status[])."""
+        options = list(options)
+        n = len(options)
+        arr = (_lib.SubOptions * max(n, 1))()
+        for i, o in enumerate(options):
+            a = arr[i]
+            a.slot, a.channel = int(o["slot"]), int(o["channel"])
+            for key, bit in (("data_access", _lib.SUBOPT_ACCESS), ("fanout_interval_ms", _lib.SUBOPT_INTERVAL),
+                             ("fanout_delay_ms", _lib.SUBOPT_DELAY), ("skip_self_update_fanout", _lib.SUBOPT_SKIP_SELF),
+                             ("skip_first_fanout", _lib.SUBOPT_SKIP_FIRST)):
+                if o.get(key) is not None:
+                    a.set |= bit
+                    setattr(a, key, int(o[key]))
+        ss, st = np.zeros(max(n, 1), dtype=np.uint8), np.zeros(max(n, 1), dtype=np.int32)
+        rc = self.lib.chd_subs_set_options(self.ctx, int(now_ns), n, arr, _ptr(ss), _ptr(st))
+        if rc not in (_lib.OK, _lib.E_CAPACITY):
+            _lib.check(self.ctx, rc)
+        return ss[:n], st[:n]
+
+    def sub_options(self, slot: int):
+        """(DataAccess, SkipSelfUpdateFanOut) of the slot's subscriptions, in the order of subscriptions()."""
+        acc, sk = np.zeros(self.capq, dtype=np.uint8), np.zeros(self.capq, dtype=np.uint8)
+        n = C.c_uint32(0)
+        _lib.check(self.ctx, self.lib.chd_subs_get_options(self.ctx, int(slot), _ptr(acc), _ptr(sk), C.byref(n)))
+        return acc[: n.value], sk[: n.value]
+
     # ---- tick ----
     def host_array(self, count: int, dtype) -> np.ndarray:
         """A numpy array over page-locked host memory (chd_host_alloc); lives as long as the world's context."""

@@ -217,6 +217,43 @@ int chd_subs_add(chd_ctx *ctx, uint32_t n, const uint32_t *slot,
                  const uint32_t *conn_id);
 int chd_subs_remove(chd_ctx *ctx, uint32_t n, const uint32_t *slot);
 
+/* channeldpb.ChannelSubscriptionOptions (channeld.proto:216-240) for ONE (connection, spatial channel) pair.  `set` says
+ * which fields are present (they are optional in the protobuf: an absent field keeps the stored / default value). */
+#define CHD_SUBOPT_ACCESS 1u
+#define CHD_SUBOPT_INTERVAL 2u
+#define CHD_SUBOPT_DELAY 4u
+#define CHD_SUBOPT_SKIP_SELF 8u
+#define CHD_SUBOPT_SKIP_FIRST 16u
+#define CHD_ACCESS_NONE 0u  /* ChannelDataAccess_NO_ACCESS: skipped by the fan-out but stays queued (data.go:194-197) */
+#define CHD_ACCESS_READ 1u
+#define CHD_ACCESS_WRITE 2u
+typedef struct {
+    uint32_t slot;                    /* connection slot (chd_subs_add) */
+    uint32_t channel;                 /* spatial channel id */
+    uint32_t set;                     /* CHD_SUBOPT_* */
+    uint32_t data_access;             /* CHD_ACCESS_* */
+    uint32_t fanout_interval_ms;      /* must not be 0 (the reference's tickData would spin) */
+    int32_t fanout_delay_ms;          /* may be negative (channeld.proto:229-233) */
+    uint32_t skip_self_update_fanout; /* 0 / 1 */
+    uint32_t skip_first_fanout;       /* 0 / 1 */
+} chd_sub_options;
+
+/* replaces: Connection.SubscribeToChannel(spatial channel, options) (subscription.go:34-102) as reached from an explicit
+ * SUB_TO_CHANNEL message (handleSubToChannel) — the spatial servers' own subscriptions (WRITE access, spatial.go:481-590:
+ * chd_server_channels / chd_border_channels give the channels) and clients that set DataAccess, SkipSelfUpdateFanOut,
+ * SkipFirstFanOut or their own interval / delay.  Records are applied in array order.  Already subscribed: the present
+ * fields are merged into the stored options, the fan-out state stays (:44-57) and should_send[i] = dataAccessChanged;
+ * else a new subscription with the defaults of :21-31 merged with the options, hadFirstFanOut = SkipFirstFanOut,
+ * lastFanOutTime = now_ns + FanOutDelayMs (:59-75) and should_send[i] = 1.  status[i] (optional) = CHD_OK, CHD_E_INVAL (no
+ * such connection: the reference returns (nil, false)) or CHD_E_CAPACITY (max_interest_cells).  An interest update
+ * (chd_tick) afterwards treats such a subscription like any other: kept with its options and state if the new query
+ * still holds the channel (only the interval is overwritten by the damped one, message_spatial.go:66-79), unsubscribed
+ * otherwise (Difference over spatialSubscriptions, :82). */
+int chd_subs_set_options(chd_ctx *ctx, int64_t now_ns, uint32_t n, const chd_sub_options *opts,
+                         uint8_t *should_send /* n, optional */, int32_t *status /* n, optional */);
+/* DataAccess (CHD_ACCESS_*) and SkipSelfUpdateFanOut of slot's subscriptions, in the order of chd_subs_get. */
+int chd_subs_get_options(chd_ctx *ctx, uint32_t slot, uint8_t *data_access, uint8_t *skip_self, uint32_t *n_out);
+
 /* fan-out record: one fanOutDataUpdate decision (data.go:293-318). */
 #define CHD_REC_FULL 0x80000000u /* in .conn: first fan-out, whole channel data */
 typedef struct {

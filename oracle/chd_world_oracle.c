@@ -207,6 +207,52 @@ void orc_world_add_sub(orc_world *w, uint32_t s, uint32_t conn_id) {
 }
 void orc_world_remove_sub(orc_world *w, uint32_t s) { w->sub_alive[s] = 0; w->pair_cnt[s] = 0; }
 
+/* SubscribeToChannel(conn, spatial channel, options) for an explicit SUB_TO_CHANNEL (subscription.go:34-102).  `set`
+ * bit 0 DataAccess, 1 FanOutIntervalMs, 2 FanOutDelayMs, 3 SkipSelfUpdateFanOut, 4 SkipFirstFanOut = the fields present.
+ * Returns the second result of SubscribeToChannel (should the subscription message be sent), or -1 when the
+ * connection does not exist / is closing ((nil, false)), -5 when the list is full. */
+int orc_world_set_sub_options(orc_world *w, uint32_t s, uint32_t channel, uint32_t set, uint32_t access, uint32_t interval_ms,
+                              int32_t delay_ms, uint32_t skip_self, uint32_t skip_first, orc_time now) {
+    if (s >= w->S || !w->sub_alive[s]) return -1;
+    const uint32_t c = channel - w->g.id_start;
+    wpair *pp = &w->pairs[(size_t)s * w->capq];
+    uint32_t n = w->pair_cnt[s], pos = 0;
+    while (pos < n && pp[pos].cell < c) pos++;
+    if (pos < n && pp[pos].cell == c) { /* :44-57: proto.Merge(&cs.options, options); dataAccessChanged */
+        wpair *p = &pp[pos];
+        const uint8_t old_access = p->access;
+        if (set & 1u) p->access = (uint8_t)access;
+        if (set & 2u) p->interval_ms = interval_ms;
+        if (set & 8u) p->skip_self = (uint8_t)(skip_self != 0);
+        /* FanOutDelayMs / SkipFirstFanOut only live in the stored options: the queue element is untouched */
+        if (w->max_interval_ms < p->interval_ms) w->max_interval_ms = p->interval_ms; /* (only grows; :83-86 is on the new branch) */
+        return old_access != p->access;
+    }
+    if (n >= w->capq) return -5;
+    memmove(&pp[pos + 1], &pp[pos], sizeof(wpair) * (n - pos));
+    wpair *p = &pp[pos];
+    p->cell = c;                                                         /* :59-64 defaults (:21-31) merged with the options */
+    p->access = (set & 1u) ? (uint8_t)access : ORC_ACCESS_READ;
+    p->interval_ms = (set & 2u) ? interval_ms : w->default_interval_ms;
+    p->skip_self = (set & 8u) ? (uint8_t)(skip_self != 0) : 1;
+    p->had_first = (set & 16u) ? (uint8_t)(skip_first != 0) : 0;          /* hadFirstFanOut: *cs.options.SkipFirstFanOut (:68) */
+    p->last = now + (orc_time)((set & 4u) ? delay_ms : w->default_delay_ms) * 1000000; /* :70 */
+    p->is_new = 0;
+    if (w->max_interval_ms < p->interval_ms) w->max_interval_ms = p->interval_ms; /* :83-86 */
+    w->pair_cnt[s] = n + 1;
+    return 1;
+}
+
+/* DataAccess and SkipSelfUpdateFanOut of a subscriber's pairs, list order */
+uint32_t orc_world_pair_options(const orc_world *w, uint32_t s, uint8_t *access, uint8_t *skip_self) {
+    uint32_t n = w->pair_cnt[s];
+    for (uint32_t p = 0; p < n; p++) {
+        access[p] = w->pairs[(size_t)s * w->capq + p].access;
+        skip_self[p] = w->pairs[(size_t)s * w->capq + p].skip_self;
+    }
+    return n;
+}
+
 static void push_rec(orc_world *w, uint32_t conn, uint32_t chan) {
     if (w->nrec == w->caprec) {
         w->caprec = w->caprec ? w->caprec * 2 : 1024;

@@ -125,6 +125,9 @@ def lib():
     L.orc_world_nrec.argtypes = [C.c_void_p]
     L.orc_world_records.argtypes = [C.c_void_p, up, up]
     L.orc_world_record_masks.argtypes = [C.c_void_p, up]
+    L.orc_world_set_sub_options.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_int32, C.c_uint32, C.c_uint32, C.c_int64]
+    L.orc_world_pair_options.restype = C.c_uint32
+    L.orc_world_pair_options.argtypes = [C.c_void_p, C.c_uint32, u8p, u8p]
     L.orc_world_set_digest_only.argtypes = [C.c_void_p, C.c_int]
     L.orc_world_digest.argtypes = [C.c_void_p, P(C.c_uint64), P(C.c_uint64)]
     L.orc_world_nhandover.restype = C.c_uint32
@@ -417,6 +420,20 @@ class World:
         chan = np.zeros(max(n, 1), dtype=np.uint32)
         lib().orc_world_records(self.h, _p(conn, C.c_uint32), _p(chan, C.c_uint32))
         return conn[:n], chan[:n]
+
+    def set_sub_options(self, now, slot, channel, data_access=None, fanout_interval_ms=None, fanout_delay_ms=None,
+                        skip_self_update_fanout=None, skip_first_fanout=None):
+        """SubscribeToChannel with explicit options (subscription.go:34-102); None = field absent.  Returns should-send
+        (1/0), -1 for a missing connection, -5 for a full list."""
+        vals = (data_access, fanout_interval_ms, fanout_delay_ms, skip_self_update_fanout, skip_first_fanout)
+        mask = sum(1 << i for i, v in enumerate(vals) if v is not None)
+        a, iv, dl, sk, sf = (0 if v is None else int(v) for v in vals)
+        return lib().orc_world_set_sub_options(self.h, int(slot), int(channel), mask, a, iv, dl, sk, sf, int(now))
+
+    def pair_options(self, s):
+        acc, sk = np.zeros(self.capq, dtype=np.uint8), np.zeros(self.capq, dtype=np.uint8)
+        n = lib().orc_world_pair_options(self.h, int(s), _p(acc, C.c_uint8), _p(sk, C.c_uint8))
+        return acc[:n], sk[:n]
 
     def set_digest_only(self, on=True):
         """window mode: fold the records into an order-independent digest instead of storing them"""

@@ -373,3 +373,89 @@ def test_third_sender_inside_the_history_is_flagged(amd):
         res = gw.tick((k + 1) * 20_000_000, upd_x=x, upd_z=z, upd_sender=np.full(N, snd, dtype=np.uint32))
         flagged += res.history_overflow
     assert flagged > 0
+
+
+def test_subscription_options_drive_every_fan_out_branch(amd, emit_mode):
+    """chd_subs_set_options = SubscribeToChannel with explicit ChannelSubscriptionOptions (subscription.go:34-102), against
+    the oracle's restatement, on a moving world: connections that are themselves senders of entity updates with
+    SkipSelfUpdateFanOut = false (they get their own updates back) and true (they do not); subscriptions put to
+    NO_ACCESS for some ticks (skipped but still queued, data.go:194-197) and back to READ (their catch-up windows come
+    out at once); server-like connections that subscribe explicitly with WRITE access, SkipFirstFanOut, positive and
+    negative FanOutDelayMs and their own interval; interest updates in between that keep, re-damp and drop such
+    subscriptions.  Results of SubscribeToChannel (should-send) and the stored options are compared as well."""
+    from channeld_amd import _lib
+
+    cfg = synth.load_config("spatial_static_4x4.json")
+    g = orc.grid_from_config(cfg)
+    N, S = 1200, 48
+    sw = synth.SynthWorld(synth.WorldSpec(cfg, N, S, 0x5AB0, tick_ms=33, outside_frac=0.01, locked_frac=0.01))
+    ctl, gw = make(amd, cfg, N, S)
+    ow = orc.World(g, N, S, gw.capq, 20, 0, literal=False)
+    conn = sw.sub_conn.copy()
+    # connections 0..7 send the updates of a third of the entities (entity i -> connection i % 8 for i % 3 == 0)
+    sender = sw.sender.copy()
+    mine = np.arange(N) % 3 == 0
+    sender[mine] = conn[np.arange(N)[mine] % 8]
+    ow.spawn(np.arange(N), sw.chan_id, sw.x, sw.z, sw.flags, sender)
+    gw.spawn(None, sw.chan_id, sw.x, sw.z, sw.flags, sender)
+    for s in range(S):
+        ow.add_sub(s, int(conn[s]))
+    gw.add_subscribers(None, conn)
+    rng = np.random.default_rng(77)
+    clients = np.arange(0, 40, dtype=np.uint32)   # follow entities, send interest updates
+    servers = np.arange(40, 48)                   # subscribe explicitly, never query
+    ncell = g.cols * g.rows
+
+    def apply(now, opts):
+        ss, st = gw.set_sub_options(now, opts)
+        for o, a, b in zip(opts, ss, st):
+            r = ow.set_sub_options(now, o["slot"], o["channel"], o.get("data_access"), o.get("fanout_interval_ms"), o.get("fanout_delay_ms"),
+                                   o.get("skip_self_update_fanout"), o.get("skip_first_fanout"))
+            assert (int(b), int(a)) == ((0, r) if r >= 0 else ((_lib.E_INVAL, 0) if r == -1 else (_lib.E_CAPACITY, 0))), (o, a, b, r)
+
+    total = n_full_self = 0
+    for k in range(30):
+        sw.step()
+        now = sw.now_ns() + (45_000_000 if k >= 17 else 0)  # one long pause
+        q = sw.queries()
+        # ---- explicit SUB_TO_CHANNEL messages before this tick's updates
+        opts = []
+        if k == 0:
+            for s in servers:  # a server subscribes to "its" cells: WRITE, own interval, delays of both signs, skip-first for some
+                for c in range(int(s) % 4, ncell, 4):
+                    opts.append(dict(slot=int(s), channel=0x10000 + c, data_access=2, fanout_interval_ms=int(rng.choice([20, 33, 70])),
+                                     fanout_delay_ms=int(rng.choice([-40, 0, 30])), skip_first_fanout=int(s) % 2,
+                                     skip_self_update_fanout=int(rng.integers(0, 2))))
+        if k == 2:
+            for s in range(0, 8, 2):  # sender connections that want their own updates back, on every channel they hold
+                ch, *_ = ow.pairs(s)
+                opts += [dict(slot=s, channel=int(c), skip_self_update_fanout=0) for c in ch]
+        if k in (5, 6):
+            for s in (9, 10, 11, 41):  # lose access ...
+                ch, *_ = ow.pairs(s)
+                opts += [dict(slot=s, channel=int(c), data_access=0) for c in ch[::2]]
+        if k == 12:
+            for s in (9, 10, 11, 41):  # ... and get it back: the skipped windows are caught up in one tick
+                ch, *_ = ow.pairs(s)
+                opts += [dict(slot=s, channel=int(c), data_access=1) for c in ch]
+        if k == 8:
+            opts += [dict(slot=3, channel=0x10000 + c, fanout_interval_ms=50, skip_first_fanout=1, fanout_delay_ms=-100) for c in (0, 5, 10, 15)]
+            opts += [dict(slot=20, channel=0x10000 + 7, data_access=2), dict(slot=20, channel=0x10000 + 7, data_access=2), dict(slot=20, channel=0x10000 + 7, data_access=1)]
+        if opts:
+            apply(now, [o for o in opts if o])
+        qsub = clients if k % 4 != 3 else clients[::2]
+        idx = np.arange(N, dtype=np.uint32)
+        ow.tick(now, idx, sw.x, sw.z, sender, None, None, qsub, q[qsub])
+        res = gw.tick(now, upd_idx=idx, upd_x=sw.x, upd_z=sw.z, upd_sender=sender, query_sub=qsub, queries=q[qsub],
+                      records_cap=max(1 << 20, 4 * len(ow.records()[0])))
+        compare_tick(k, res, ow, S, check_pairs=list(range(0, S, 5)) + [3, 9, 20, 41], gw=gw)
+        for s in (0, 2, 3, 9, 20, 41, 44):
+            ga, gs = gw.sub_options(s)
+            wa, ws = ow.pair_options(s)
+            assert np.array_equal(ga, wa) and np.array_equal(gs, ws), f"tick {k} slot {s}: stored options"
+        total += res.n_records
+        # a connection with SkipSelfUpdateFanOut = false receives updates of entities it sends
+        own = np.isin(res.records["channel"], sw.chan_id[mine]) & ((res.records["conn"] & 0x7FFFFFFF) == conn[0]) & ((res.records["conn"] >> 31) == 0)
+        n_full_self += int((own & np.isin(res.records["channel"], sw.chan_id[(np.arange(N) % 3 == 0) & (np.arange(N) % 8 == 0)])).sum())
+    assert total > 100000
+    assert n_full_self > 0  # the !SkipSelfUpdateFanOut branch produced records
