@@ -63,6 +63,9 @@ def parse():
                     help="run the interest updates on a second stream beside ingest + index (CHD_WORLD_OVERLAP_INTEREST)")
     ap.add_argument("--recipients", action="store_true",
                     help="also plan the handover-message recipients every tick (CHD_WORLD_HANDOVER_RECIPIENTS)")
+    ap.add_argument("--flat-interval-ms", type=int, default=0,
+                    help="strict-reference mode (SURVEY 9.6): one flat fan-out interval for every subscription (ENTITY channels: 50 ms in "
+                         "config/channel_settings_ue.json) instead of the distance-damped 20/50/100 ms; the default run reports it as a second line")
     ap.add_argument("--emit", choices=["auto", "cell-major", "conn-major"], default="auto",
                     help="form of the fan-out emit kernel (include/chd_spatial.h: CHD_WORLD_*_EMIT)")
     return ap.parse_args()
@@ -221,7 +224,7 @@ def main():
     seed = 0xC0FFEE01
     sw = synth.SynthWorld(synth.WorldSpec(cfg, N, S, seed, tick_ms=args.tick_ms, aoi_scale=args.aoi_scale))
     ctl = A.StaticGrid2DSpatialController(device=local_rank)
-    err = ctl.LoadConfig(json.dumps(cfg).encode(), strict=False)
+    err = ctl.LoadConfig(json.dumps(cfg).encode(), strict=False, **({"Damping": [(0xFFFFFFFF, args.flat_interval_ms)]} if args.flat_interval_ms else {}))
     assert err is None, err
     world_flags = {"auto": 0, "conn-major": 1, "cell-major": 2}[args.emit] | (4 if args.recipients else 0) | (8 if args.wire else 0) | (16 if args.overlap_interest else 0) | (32 if args.update_masks else 0)
     world = A.SpatialWorld(ctl, N, S, flags=world_flags)
@@ -359,11 +362,54 @@ def main():
             int(now2[t]), n_updates=N, d_upd_x=dx2.at(t * N * 8), d_upd_z=dz2.at(t * N * 8), n_queries=S, d_queries=dq2.at(t * S * 128)),
             range(nw), 0, measure_last=E)
         out["e2e"] = e2e
+    if e2e is not None and not args.flat_interval_ms:
+        # strict-reference mode beside the damped-interval model of `value`: a flat 50 ms interval for every
+        # subscription (the reference's ENTITY channel default), same world, same inputs, device-resident ticks
+        out["strict_reference_flat_50ms"] = flat_interval_line(A, synth, cfg, N, S, seed, args, local_rank, 50)
     if not args.no_cpu and args.cpu_seconds > 0:
         out["cpu_baseline"], one = cpu_baseline(cfg, N, S, seed, args.tick_ms, args.aoi_scale, args.cpu_seconds)
         if one:
             out["cpu_baseline_1t"] = one
     print(json.dumps(out))
+
+
+def flat_interval_line(A, synth, cfg, N, S, seed, args, local_rank, interval_ms, warm=10, steps=40):
+    import torch
+
+    ctl = A.StaticGrid2DSpatialController(device=local_rank)
+    assert ctl.LoadConfig(json.dumps(cfg).encode(), strict=False, Damping=[(0xFFFFFFFF, interval_ms)]) is None
+    sw = synth.SynthWorld(synth.WorldSpec(cfg, N, S, seed, tick_ms=args.tick_ms, aoi_scale=args.aoi_scale))
+    w = A.SpatialWorld(ctl, N, S, max_records=400_000_000)
+    w.spawn(None, sw.chan_id, sw.x, sw.z, sw.flags, sw.sender)
+    w.add_subscribers(None, sw.sub_conn)
+    T = warm + steps
+    xs = np.empty((T, N)); zs = np.empty((T, N)); qs = np.empty((T, S), dtype=synth.AOI_DTYPE); now = np.empty(T, dtype=np.int64)
+    for t in range(T):
+        sw.step()
+        xs[t], zs[t], qs[t], now[t] = sw.x, sw.z, sw.queries(), sw.now_ns()
+    dx, dz, dq = w.device_array(xs), w.device_array(zs), w.device_array(qs)
+    w.set_profiling(steps)
+
+    def tick(t):
+        w.tick_device(int(now[t]), n_updates=N, d_upd_x=dx.at(t * N * 8), d_upd_z=dz.at(t * N * 8), n_queries=S, d_queries=dq.at(t * S * 128))
+
+    for t in range(warm):
+        tick(t)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for t in range(warm, T):
+        tick(t)
+    torch.cuda.synchronize()
+    el = time.perf_counter() - t0
+    hist = w.history(steps)
+    msgs = sum(h["n_records"] for h in hist)
+    emit_us = float(np.mean([h["stage_us"][4] for h in hist]))
+    res = w.fetch()
+    assert res.overflow == 0 and res.history_overflow == 0
+    ctl.close()
+    return {"what": f"every subscription fans out every {interval_ms} ms (one-entry damping table), otherwise the headline workload",
+            "value": msgs / el, "unit": "msgs/s", "steps": steps, "ms_per_step": 1e3 * el / steps, "msgs_per_tick": msgs / steps,
+            "emit_us": emit_us, "emit_frac_of_hbm_peak": BYTES_PER_MSG * (msgs / steps) / (emit_us * 1e-6) / 1e9 / HBM_PEAK_GBS}
 
 
 def wire_phase(args, world, ctl, N, tick_at, ticks, base_now, measure_last=None):

@@ -7,6 +7,7 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <mutex>
 #include <string>
@@ -69,6 +70,7 @@ struct chd_ctx {
     TickRing ring{};
     // scratch for the stateless entry points and for chd_tick's staging
     DevBuf scratch[16];
+    bool force_device = false;          // CHD_NO_HOST_FAST_PATH=1: small stateless calls go to the device too (tests, measurements)
     int prof_depth = 0;                 // 0 = off
     std::vector<hipEvent_t> ev;         // [prof_depth][EV_PER_TICK]: stage boundaries on `stream`, then interest begin/end
     std::vector<uint8_t> ev_overlap;    // [prof_depth] the slot's tick ran the interest stage on aux_stream
@@ -350,6 +352,7 @@ int chd_create(const chd_grid_cfg *cfg, int device, chd_ctx **out) {
             }
         }
     }
+    { const char *e = getenv("CHD_NO_HOST_FAST_PATH"); ctx->force_device = e && e[0] == '1'; }
     ctx->lim.maxax = 256;
     ctx->lim.winmax = std::min<uint32_t>(std::max<uint32_t>(g.ncell, 64), 4096);
     ctx->lim.maxdim = std::min<uint32_t>(ctx->lim.winmax, std::max(g.cols, g.rows));
@@ -392,10 +395,38 @@ int chd_sync(chd_ctx *ctx) {
     return CHD_OK;
 }
 
+// Single-point callers (GetChannelId from handleCreateEntityChannel, handleQuerySpatialChannel, handleUnrealSpawnObject:
+// one call per message) must not pay a device round trip (mutex + H2D + launch + sync, ~20 us) for two
+// divisions: up to CHD_HOST_FAST_PATH points are answered on the host, lock-free, with the SAME arithmetic —
+// IEEE double subtract / divide / floor, this file is built with -ffp-contract=off like the kernels — so the
+// result is bit-identical to the kernel's (tests/test_gpu_parity.py compares the two paths point by point).
+// This is not a fallback: the context still requires a gfx950 device, and every batched call runs on it.
+#define CHD_HOST_FAST_PATH 16u
+namespace {
+inline bool host_coord(double v, uint32_t n, uint32_t &out) {  // grid_coord (chd_device.h)
+    const double f = std::floor(v);
+    if (!(f >= 0.0) || !(f < (double)n)) return false;
+    out = (uint32_t)f;
+    return true;
+}
+inline uint32_t host_channel_id(const DevGrid &g, double x, double z) {  // GetChannelIdWithOffset, spatial.go:169-180
+    uint32_t gx, gy;
+    volatile double dx = x - g.offx, dz = z - g.offz;  // (volatile: each operation rounded on its own, no re-association)
+    volatile double qx = dx / g.gw, qz = dz / g.gh;
+    if (!host_coord(qx, g.cols, gx)) return 0u;
+    if (!host_coord(qz, g.rows, gy)) return 0u;
+    return gx + gy * g.cols + g.id_start;
+}
+}  // namespace
+
 int chd_get_channel_ids(chd_ctx *ctx, const double *x, const double *z, uint32_t n, uint32_t *out_ids) {
     if (!ctx) return fail(nullptr, CHD_E_INVAL, "NULL ctx");
     if (n && (!x || !z || !out_ids)) return fail(ctx, CHD_E_INVAL, "chd_get_channel_ids: NULL buffer");
     if (!n) return CHD_OK;
+    if (n <= CHD_HOST_FAST_PATH && !ctx->force_device) {
+        for (uint32_t i = 0; i < n; i++) out_ids[i] = host_channel_id(ctx->g, x[i], z[i]);
+        return CHD_OK;
+    }
     std::lock_guard<std::mutex> lk(ctx->mu);
     TRY(bind(ctx));
     TRY(ensure(ctx, 0, sizeof(double) * n));
@@ -416,6 +447,14 @@ int chd_notify_decide(chd_ctx *ctx, const double *old_x, const double *old_z, co
     if (n && (!old_x || !old_z || !new_x || !new_z || !src_ids || !dst_ids || !handover))
         return fail(ctx, CHD_E_INVAL, "chd_notify_decide: NULL buffer");
     if (!n) return CHD_OK;
+    if (n <= CHD_HOST_FAST_PATH && !ctx->force_device) {  // (see chd_get_channel_ids)
+        for (uint32_t i = 0; i < n; i++) {
+            src_ids[i] = host_channel_id(ctx->g, old_x[i], old_z[i]);
+            dst_ids[i] = src_ids[i] ? host_channel_id(ctx->g, new_x[i], new_z[i]) : 0u;  // (:613-617: the src error returns first)
+            handover[i] = (src_ids[i] && dst_ids[i] && src_ids[i] != dst_ids[i]) ? 1 : 0;  // spatial.go:613-626
+        }
+        return CHD_OK;
+    }
     std::lock_guard<std::mutex> lk(ctx->mu);
     TRY(bind(ctx));
     for (int k = 0; k < 4; k++) TRY(ensure(ctx, k, sizeof(double) * n));

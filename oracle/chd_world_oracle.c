@@ -90,6 +90,8 @@ typedef struct orc_world {
     orc_time stamps[32]; uint32_t nstamps; /* channel times of the last 32 ticks, newest first */
     /* digest mode (window formulation only): records are not stored, only folded into an order-independent
      * digest (full-size parity runs: 10^8..10^9 records per tick) */
+    /* spatialDampingSettings (message_spatial.go:16-29) replaced by the host (the table is a package variable there) */
+    uint32_t n_damp, damp_dist[8], damp_iv[8];
     int digest_only;
     uint64_t d_cnt, d_sum, d_xor, d_sum_masked;
     uint64_t *d_conn; /* [S] per subscriber slot: sum of the record hashes */
@@ -177,6 +179,10 @@ void orc_world_free(orc_world *w) {
     free(w);
 }
 
+void orc_world_set_damping(orc_world *w, uint32_t n, const uint32_t *max_dist, const uint32_t *interval_ms) {
+    w->n_damp = n > 8 ? 8 : n;
+    for (uint32_t i = 0; i < w->n_damp; i++) { w->damp_dist[i] = max_dist[i]; w->damp_iv[i] = interval_ms[i]; }
+}
 void orc_world_set_threads(orc_world *w, int threads) { w->threads = threads < 1 ? 1 : threads; }
 
 static uint32_t cell_index(const orc_world *w, double x, double z) {
@@ -582,7 +588,11 @@ int orc_world_tick(orc_world *w, orc_time t, uint32_t n_upd, const uint32_t *idx
             /* every new id is (re)subscribed with the damped interval */
             for (uint32_t k = 0; k < n; k++) {
                 uint32_t c = ids[k] - w->g.id_start;
-                uint32_t iv = orc_damping_interval(dists[k], w->default_interval_ms);
+                uint32_t iv = w->default_interval_ms; /* getSpatialDampingSettings: first entry with dist <= MaxDistance, else the default */
+                if (w->n_damp == 0) iv = orc_damping_interval(dists[k], w->default_interval_ms);
+                else
+                    for (uint32_t di = 0; di < w->n_damp; di++)
+                        if (dists[k] <= w->damp_dist[di]) { iv = w->damp_iv[di]; break; }
                 const wpair *ex = NULL;
                 for (uint32_t o = 0; o < nold; o++)
                     if (old[o].cell == c) { ex = &old[o]; break; }

@@ -128,6 +128,7 @@ def lib():
     L.orc_world_set_sub_options.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_int32, C.c_uint32, C.c_uint32, C.c_int64]
     L.orc_world_pair_options.restype = C.c_uint32
     L.orc_world_pair_options.argtypes = [C.c_void_p, C.c_uint32, u8p, u8p]
+    L.orc_world_set_damping.argtypes = [C.c_void_p, C.c_uint32, up, up]
     L.orc_world_set_digest_only.argtypes = [C.c_void_p, C.c_int]
     L.orc_world_digest.argtypes = [C.c_void_p, P(C.c_uint64), P(C.c_uint64)]
     L.orc_world_nhandover.restype = C.c_uint32
@@ -434,6 +435,12 @@ class World:
         acc, sk = np.zeros(self.capq, dtype=np.uint8), np.zeros(self.capq, dtype=np.uint8)
         n = lib().orc_world_pair_options(self.h, int(s), _p(acc, C.c_uint8), _p(sk, C.c_uint8))
         return acc[:n], sk[:n]
+
+    def set_damping(self, table):
+        """table: [(max_dist, interval_ms), ...] replacing spatialDampingSettings (message_spatial.go:16-29)"""
+        d = np.array([t[0] for t in table], dtype=np.uint32)
+        iv = np.array([t[1] for t in table], dtype=np.uint32)
+        lib().orc_world_set_damping(self.h, len(table), _p(d, C.c_uint32), _p(iv, C.c_uint32))
 
     def set_digest_only(self, on=True):
         """window mode: fold the records into an order-independent digest instead of storing them"""

@@ -82,6 +82,60 @@ def test_get_channel_ids_random_million(amd, grid):
     assert (got == 0).sum() > 1000 and (got != 0).sum() > 100000
 
 
+def test_single_point_host_fast_path_is_bit_identical_to_the_kernel(amd):
+    """chd_get_channel_ids / chd_notify_decide answer up to 16 points on the host (no device round trip for the
+    one-call-per-message users of GetChannelId).  Same IEEE arithmetic: every point through the host path
+    (n = 1 calls), through the kernel (one batch), and through the kernel with n = 1 (CHD_NO_HOST_FAST_PATH) must agree
+    bit for bit, edges and non-finite inputs included; the oracle agrees with all three."""
+    import ctypes as C
+    import os
+    import time
+
+    from channeld_amd import _lib
+
+    grid = (2000, 2000, -15000, -15000, 15, 15, 3, 3, 0)
+    ctl = make_ctl(amd, *grid)
+    g = orc.grid(*grid)
+    rng = np.random.default_rng(123)
+    n = 4000
+    x = rng.uniform(-15500, 15500, n)
+    z = rng.uniform(-15500, 15500, n)
+    x[:40] = -15000 + 2000.0 * rng.integers(0, 16, 40)            # exactly on cell edges
+    z[40:80] = np.nextafter(-15000 + 2000.0 * rng.integers(0, 16, 40), -np.inf)
+    x[80:86] = [np.nan, np.inf, -np.inf, 1.7976931348623157e308, -0.0, 5e-324]
+    x32 = np.float64(np.float32(x[100:200]))                        # float32-representable, as the engines send
+    x[100:200] = x32
+    want = orc.channel_ids(g, x, z)
+    batch = ctl.get_channel_ids(x, z)
+    assert np.array_equal(batch, want)
+    lib = _lib.load()
+    one = np.zeros(1, dtype=np.uint32)
+    t0 = time.perf_counter()
+    host = np.array([(lib.chd_get_channel_ids(ctl.ctx, x[i:i + 1].ctypes.data_as(C.c_void_p), z[i:i + 1].ctypes.data_as(C.c_void_p), 1,
+                                              one.ctypes.data_as(C.c_void_p)), int(one[0]))[1] for i in range(n)], dtype=np.uint32)
+    t_host = (time.perf_counter() - t0) / n
+    assert np.array_equal(host, want)
+    os.environ["CHD_NO_HOST_FAST_PATH"] = "1"
+    try:
+        ctl2 = make_ctl(amd, *grid)
+    finally:
+        del os.environ["CHD_NO_HOST_FAST_PATH"]
+    m = 400
+    t0 = time.perf_counter()
+    dev = np.array([(lib.chd_get_channel_ids(ctl2.ctx, x[i:i + 1].ctypes.data_as(C.c_void_p), z[i:i + 1].ctypes.data_as(C.c_void_p), 1,
+                                             one.ctypes.data_as(C.c_void_p)), int(one[0]))[1] for i in range(m)], dtype=np.uint32)
+    t_dev = (time.perf_counter() - t0) / m
+    assert np.array_equal(dev, want[:m])
+    print(f"chd_get_channel_ids(n=1): host path {t_host * 1e6:.2f} us per call (incl. ctypes), device path {t_dev * 1e6:.1f} us")
+    assert t_host < t_dev
+    # Notify decision: host path (n = 1) against the batched kernel
+    nx, nz = x + rng.normal(0, 700, n), z + rng.normal(0, 700, n)
+    bs, bd, bh = ctl.notify_batch(x, z, nx, nz)
+    for i in range(0, n, 7):
+        s1, d1, h1 = ctl.notify_batch(x[i:i + 1], z[i:i + 1], nx[i:i + 1], nz[i:i + 1])
+        assert (int(s1[0]), int(d1[0]), int(h1[0])) == (int(bs[i]), int(bd[i]), int(bh[i])), i
+
+
 def test_notify_batch(amd):
     grid = (2000, 2000, -15000, -15000, 15, 15, 3, 3, 0)
     ctl = make_ctl(amd, *grid)

@@ -27,9 +27,9 @@ def emit_mode(request):
     yield request.param
 
 
-def make(amd, cfg, N, S, capq=0, max_records=0, extra_flags=0):
+def make(amd, cfg, N, S, capq=0, max_records=0, extra_flags=0, damping=None):
     ctl = amd.StaticGrid2DSpatialController()
-    assert ctl.LoadConfig(json.dumps(cfg).encode(), strict=False) is None
+    assert ctl.LoadConfig(json.dumps(cfg).encode(), strict=False, **({"Damping": damping} if damping else {})) is None
     w = amd.SpatialWorld(ctl, N, S, max_interest_cells=capq, max_records=max_records, flags=EMIT_FLAGS | extra_flags)
     return ctl, w
 
@@ -74,13 +74,15 @@ def compare_tick(k, res, ow, S, id_start=0x10000, check_pairs=None, gw=None):
             assert np.array_equal(gnew, wnew), f"tick {k} sub {s}: is_new"
 
 
-def run_world(amd, cfg_name, N, S, ticks, seed, tick_ms=50, capq=0, aoi_scale=1.0, sparse=False, check_subs=8, pauses=None, extra_flags=0, literal=False):
+def run_world(amd, cfg_name, N, S, ticks, seed, tick_ms=50, capq=0, aoi_scale=1.0, sparse=False, check_subs=8, pauses=None, extra_flags=0, literal=False, damping=None):
     cfg = synth.load_config(cfg_name)
     g = orc.grid_from_config(cfg)
     spec = synth.WorldSpec(cfg, N, S, seed, tick_ms=tick_ms, aoi_scale=aoi_scale, outside_frac=0.01, locked_frac=0.02)
     sw = synth.SynthWorld(spec)
-    ctl, gw = make(amd, cfg, N, S, capq, extra_flags=extra_flags)
+    ctl, gw = make(amd, cfg, N, S, capq, extra_flags=extra_flags, damping=damping)
     ow = orc.World(g, N, S, gw.capq, 20, 0, literal=literal)
+    if damping:
+        ow.set_damping(damping)
     ow.set_threads(4)
     ow.spawn(np.arange(N), sw.chan_id, sw.x, sw.z, sw.flags, sw.sender)
     gw.spawn(None, sw.chan_id, sw.x, sw.z, sw.flags, sw.sender)
@@ -142,6 +144,16 @@ def test_world_against_the_literal_list_walk(amd):
     assert total > 50000 and n_ho > 0
     total, n_ho = run_world(amd, "spatial_static_benchmark.json", 1500, 64, 10, 0xC0FFEE2B, literal=True, sparse=True)
     assert total > 5000
+
+
+def test_world_strict_reference_flat_interval(amd):
+    """SURVEY 9.6's strict-reference mode: one flat fan-out interval for every subscription (the ENTITY channels' 50 ms of
+    config/channel_settings_ue.json) instead of the distance-damped one — a one-entry damping table — and a custom
+    three-step table; both against the oracle with the same table."""
+    total, n_ho = run_world(amd, "spatial_static_benchmark.json", 3000, 160, 12, 0xC0FFEE3A, damping=[(0xFFFFFFFF, 50)])
+    assert total > 50000 and n_ho > 0
+    total, n_ho = run_world(amd, "spatial_static_4x4.json", 1500, 96, 12, 0xC0FFEE3B, tick_ms=33, damping=[(0, 33), (2, 66), (5, 200)])
+    assert total > 20000
 
 
 def test_world_config_a_2x2(amd):
