@@ -17,9 +17,9 @@
 //                  wave-uniform bookkeeping; per record its byte offset in the connection's stream
 //                  and, for the first record of a packet, that packet's length (for the tag)
 //   scan           connection stream lengths -> bases in the wire arena
-//   k_wire_copy    one lane per record: tag (if first of its packet) + headers are composed in
-//                  registers and streamed with the payload through a byte FIFO into the arena
-//                  (dword stores once the destination is aligned)
+//   k_wire_copy    per chunk of 64 records (a contiguous byte range of the stream) the wave builds the bytes as an
+//                  image in LDS — one lane per message: tag if it opens a packet, headers, payload — and streams
+//                  the image out with 16-byte stores
 // Bytes written per message = 5/packet + ~12 header + payload: this is the P*M term of SURVEY §8d.
 #include "chd_kernels.h"
 
@@ -130,22 +130,18 @@ void launch_wire_layout(hipStream_t st, WorldDev w, WireDev x) {
     hipLaunchKernelGGL(k_wire_layout, dim3((w.S + 3) / 4), dim3(256), 0, st, w, x);
 }
 
-// Copy kernel.  A chunk of 64 consecutive records of one subscription segment is a CONTIGUOUS byte
-// range of the connection's stream (~5-6 KB).  Each lane first describes its own message in LDS
-// (start, header bytes incl. a packet tag if it opens a packet, payload pointer/length); then the wave
-// writes the range cooperatively: lane l produces output dwords l, l+64, ... — message found by binary
-// search of the 64 starts — so stores are fully coalesced and payload reads are 4-byte gathers from
-// the L2-resident payload table.  Only the dwords that straddle a message / header boundary (and the
-// unaligned ends of the range) are assembled byte by byte.
+// Copy kernel.  A chunk of 64 consecutive records of one subscription segment is a CONTIGUOUS byte range of the
+// connection's stream (~5 KB for position updates).  The wave builds that range as an IMAGE in LDS — every lane
+// writes its own message there, header bytes then payload (16-byte loads from its channel's payload slot, unaligned
+// LDS dword stores) — at the same misalignment modulo 16 as the destination, and then streams the image out with
+// 16-byte LDS reads and 16-byte global stores, fully coalesced; only the two ends of the range are written byte by
+// byte (the neighbouring chunks, other waves, own the adjacent bytes).  ~100 wave instructions per 64 messages.
+// (The first version assigned output DWORDS to lanes and looked every one of them up — owner message, header or
+// payload, two payload loads and a funnel shift per dword: ~2500 instructions per 64 messages, 0.5 TB/s.)
+// A range longer than the image is cut into groups of consecutive messages; a single message longer than the image
+// (a full state of tens of KB) is copied cooperatively straight from its payload slot.
 #define WIRE_HDR_MAX 32  // 5 tag + 1+3 + 1+5 + 2 + 1+3 + 1+3 = 25 bytes at most
-
-struct WireChunk {
-    uint32_t start[64];   // message start, relative to the chunk's first byte
-    uint32_t hlen[64];    // header bytes (tag included)
-    uint32_t plen[64];    // payload bytes
-    const uint8_t *pay[64];
-    __attribute__((aligned(16))) uint8_t hdr[64][WIRE_HDR_MAX];
-};
+#define WIRE_IMG 8192u   // bytes of LDS image per wave
 
 __device__ __forceinline__ uint32_t put_varint(uint8_t *h, uint32_t n, uint32_t v) {
     while (v >= 0x80u) { h[n++] = (uint8_t)((v & 0x7Fu) | 0x80u); v >>= 7; }
@@ -153,45 +149,62 @@ __device__ __forceinline__ uint32_t put_varint(uint8_t *h, uint32_t n, uint32_t 
     return n;
 }
 
-// message index owning relative byte position r (messages are sorted, zero-length ones never own a byte)
-__device__ __forceinline__ uint32_t owner_of(const WireChunk &c, uint32_t r) {
-    uint32_t lo = 0, hi = 63;  // last j with start[j] <= r and (hlen+plen) > 0 reaching r
-    while (lo < hi) {
-        const uint32_t mid = (lo + hi + 1) >> 1;
-        if (c.start[mid] <= r) lo = mid; else hi = mid - 1;
+__device__ __forceinline__ uint32_t wire_hdr_len(const WireMsg &m, uint32_t tag) {
+    return (tag ? 5u : 0u) + 1u + vlen(m.mp_len) + (m.chan ? 1u + vlen(m.chan) : 0u) + 2u + 1u + vlen(m.body_len) + 1u + vlen(m.any_len);
+}
+
+// tag (if the message opens a packet) + the three nested length-delimited headers, byte by byte at h
+__device__ __forceinline__ uint32_t put_header(uint8_t *h, const WireMsg &m, uint32_t tag) {
+    uint32_t hl = 0;
+    if (tag) {  // opens a packet: the 5-byte tag sits right before it (connection.go:683-687)
+        const uint32_t plen = tag & 0xFFFFu;
+        h[0] = 67; h[1] = 72; h[2] = (uint8_t)(plen >> 8); h[3] = (uint8_t)plen; h[4] = 0;
+        hl = 5;
     }
-    // zero-length (dropped / beyond the chunk) entries share the start of their successor: step back over them
-    while (lo > 0 && c.hlen[lo] + c.plen[lo] == 0) lo--;
-    return lo;
+    h[hl++] = 0x0A; hl = put_varint(h, hl, m.mp_len);                     // Packet.messages
+    if (m.chan) { h[hl++] = 0x08; hl = put_varint(h, hl, m.chan); }       // MessagePack.channelId
+    h[hl++] = 0x20; h[hl++] = 0x08;                                       // MessagePack.msgType = CHANNEL_DATA_UPDATE
+    h[hl++] = 0x2A; hl = put_varint(h, hl, m.body_len);                   // MessagePack.msgBody
+    h[hl++] = 0x0A; hl = put_varint(h, hl, m.any_len);                    // ChannelDataUpdateMessage.data
+    return hl;
 }
 
-// which message owns relative byte r, and r's offset inside it.  When all 64 messages of the chunk have
-// the same size T (the usual case: same payload type, same channel-id width, no packet tag in the chunk)
-// that is a multiply-high by M = ceil(2^32 / T) — exact for r < 2^32 / T — instead of the search.
-__device__ __forceinline__ void locate(const WireChunk &c, uint32_t r, uint32_t T, uint32_t M, uint32_t &j, uint32_t &k) {
-    if (T) {
-        j = __umulhi(r, M);
-        k = r - j * T;
-    } else {
-        j = owner_of(c, r);
-        k = r - c.start[j];
+__device__ __forceinline__ void wire_wave_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// n bytes from src (any address space, any alignment) to global dst, by the whole wave: dwords where dst is aligned,
+// bytes at the two ends
+__device__ __forceinline__ void wave_copy_out(uint8_t *__restrict__ dst, const uint8_t *__restrict__ src, uint32_t n, bool src_is_image) {
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t head = min((16u - (uint32_t)((uintptr_t)dst & 15u)) & 15u, n);
+    if (lane < head) dst[lane] = src[lane];
+    const uint32_t nvec = (n - head) >> 4;
+    if (src_is_image) {  // same misalignment modulo 16 on both sides: 16-byte LDS reads, 16-byte stores
+        for (uint32_t v = lane; v < nvec; v += 64)
+            *(uint4 *)(void *)(dst + head + 16u * v) = *(const uint4 *)(const void *)(src + head + 16u * v);
+    } else {             // global payload slot (16-byte aligned) to an arbitrary destination: funnel-shifted dwords
+        const uint32_t ndw = nvec * 4u;
+        const uint32_t sh = (uint32_t)((uintptr_t)(src + head) & 3u);
+        const uint32_t *s32 = (const uint32_t *)(const void *)(src + head - sh);
+        for (uint32_t t = lane; t < ndw; t += 64) {
+            const uint32_t a = s32[t];
+            *(uint32_t *)(void *)(dst + head + 4u * t) = sh ? __builtin_amdgcn_alignbyte(s32[t + 1], a, sh) : a;
+        }
     }
+    const uint32_t done = head + 16u * nvec;
+    if (lane < n - done) dst[done + lane] = src[done + lane];
 }
-
-__device__ __forceinline__ uint32_t byte_at(const WireChunk &c, uint32_t r, uint32_t T, uint32_t M) {
-    uint32_t j, k;
-    locate(c, r, T, M, j, k);
-    return k < c.hlen[j] ? c.hdr[j][k] : c.pay[j][k - c.hlen[j]];
-}
-
 
 __global__ void __launch_bounds__(256) k_wire_copy(WorldDev w, WireDev x) {
     __shared__ uint32_t ticket;
-    __shared__ WireChunk chunks[4];
+    __shared__ __attribute__((aligned(16))) uint8_t images[4][WIRE_IMG + 48];
     const uint32_t s = blockIdx.x;
     if (!w.sub_alive[s] || x.conn_woff[s + 1] == x.conn_woff[s]) return;  // (conn_wlen was scanned in place)
     const uint32_t lane = threadIdx.x & 63u;
-    WireChunk &c = chunks[threadIdx.x >> 6];
+    uint8_t *img = images[threadIdx.x >> 6];
     const uint32_t cnt = w.pair_cnt[s];
     const size_t pbase = (size_t)s * w.capq;
     const uint64_t rbase = w.rec_ub[s];
@@ -208,100 +221,80 @@ __global__ void __launch_bounds__(256) k_wire_copy(WorldDev w, WireDev x) {
         for (uint32_t i0 = 0; i0 < n; i0 += 64) {
             const uint32_t i = i0 + lane;
             // ---- describe this lane's message ----
-            uint32_t begin = 0xFFFFFFFFu, hl = 0, pl = 0;
-            const uint8_t *pay = nullptr;
+            bool live = false;
+            uint32_t begin = 0, hl = 0, pl = 0, tag = 0;
+            WireMsg m;
+            m.chan = 0; m.any_len = 0; m.body_len = 0; m.mp_len = 0; m.entry = 0; m.pay = nullptr;
             if (i < n) {
                 const uint32_t woff = x.rec_woff[seg + i];
                 if (woff != 0xFFFFFFFFu) {  // not dropped by the size check of Send
-                    const WireMsg m = wire_msg(w, x, w.recs[seg + i], w.rec_pos[seg + i]);
-                    const uint32_t tag = x.rec_wtag[seg + i];
-                    uint8_t *h = c.hdr[lane];
-                    begin = woff;
-                    if (tag) {  // opens a packet: the 5-byte tag sits right before it (connection.go:683-687)
-                        const uint32_t plen = tag & 0xFFFFu;
-                        h[0] = 67; h[1] = 72; h[2] = (uint8_t)(plen >> 8); h[3] = (uint8_t)plen; h[4] = 0;
-                        hl = 5;
-                        begin -= 5;
-                    }
-                    h[hl++] = 0x0A; hl = put_varint(h, hl, m.mp_len);                     // Packet.messages
-                    if (m.chan) { h[hl++] = 0x08; hl = put_varint(h, hl, m.chan); }       // MessagePack.channelId
-                    h[hl++] = 0x20; h[hl++] = 0x08;                                       // MessagePack.msgType = CHANNEL_DATA_UPDATE
-                    h[hl++] = 0x2A; hl = put_varint(h, hl, m.body_len);                   // MessagePack.msgBody
-                    h[hl++] = 0x0A; hl = put_varint(h, hl, m.any_len);                    // ChannelDataUpdateMessage.data
+                    m = wire_msg(w, x, w.recs[seg + i], w.rec_pos[seg + i]);
+                    tag = x.rec_wtag[seg + i];
+                    hl = wire_hdr_len(m, tag);
                     pl = m.any_len;
-                    pay = m.pay;
+                    begin = woff - (tag ? 5u : 0u);
+                    live = true;
                 }
             }
-            // chunk range: first byte of the first live message .. end of the last
-            uint32_t lo = begin, hi = begin == 0xFFFFFFFFu ? 0u : begin + hl + pl;
-            for (int d = 32; d >= 1; d >>= 1) {
-                lo = min(lo, (uint32_t)__shfl_xor((int)lo, d));
-                hi = max(hi, (uint32_t)__shfl_xor((int)hi, d));
-            }
-            if (lo == 0xFFFFFFFFu) continue;  // nothing live in this chunk
-            // dead entries take the start of the next live one (so that `start` stays sorted): suffix-min scan
-            uint32_t st = begin;
-            for (int d = 1; d < 64; d <<= 1) {
-                const uint32_t o = __shfl_down(st, d);
-                if (lane + d < 64) st = min(st, o);
-            }
-            if (st == 0xFFFFFFFFu) st = hi;
-            c.start[lane] = st - lo;
-            c.hlen[lane] = hl;
-            c.plen[lane] = pl;
-            c.pay[lane] = pay;
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-            // uniform chunk?  all 64 lanes live, equal sizes
-            const uint32_t mysz = hl + pl;
-            const uint32_t T0 = __shfl(mysz, 0);
-            const bool uniform = __ballot(begin == 0xFFFFFFFFu || mysz != T0) == 0 && T0 != 0;
-            const uint32_t T = uniform ? T0 : 0u;
-            const uint32_t M = uniform ? (uint32_t)((0x100000000ull + T0 - 1u) / T0) : 0u;
-            // ---- write the range: dword t of the 4-byte-aligned cover goes to lane t % 64 ----
-            uint8_t *dst0 = stream + lo;
-            const uint32_t len = hi - lo;
-            const uint32_t mis = (uint32_t)((uintptr_t)dst0 & 3u);  // bytes of the first dword that precede the range
-            const uint32_t ndw = (mis + len + 3u) >> 2;
-            for (uint32_t t = lane; t < ndw; t += 64) {
-                const int32_t r0 = (int32_t)(t * 4u) - (int32_t)mis;  // relative position of the dword's first byte
-                uint8_t *d = dst0 + r0;
-                if (r0 >= 0 && (uint32_t)r0 + 4u <= len) {
-                    uint32_t j, k;
-                    locate(c, (uint32_t)r0, T, M, j, k);
-                    const uint32_t h = c.hlen[j];
-                    uint32_t v;
-                    if (k >= h && k + 4u <= h + c.plen[j]) {
-                        // payload interior: two aligned dwords of the (16-byte aligned) payload slot, funnel-shifted
-                        const uint32_t o = k - h;
-                        const uint32_t *src = (const uint32_t *)(const void *)(c.pay[j] + (o & ~3u));
-                        const uint32_t a = src[0];
-                        const uint32_t sh = o & 3u;
-                        v = sh ? __builtin_amdgcn_alignbyte(src[1], a, sh) : a;
-                    } else if (k + 4u <= h) {
-                        // header interior: two aligned dwords of the lane's 32-byte header row in LDS, funnel-shifted
-                        const uint32_t *hs = (const uint32_t *)(const void *)(c.hdr[j] + (k & ~3u));
-                        const uint32_t sh = k & 3u;
-                        v = sh ? __builtin_amdgcn_alignbyte(hs[1], hs[0], sh) : hs[0];
-                    } else {
-                        // straddles header/payload or two messages: byte by byte (two such dwords per message)
-                        const uint32_t r = (uint32_t)r0;
-                        v = byte_at(c, r, T, M) | (byte_at(c, r + 1u, T, M) << 8) | (byte_at(c, r + 2u, T, M) << 16) |
-                            (byte_at(c, r + 3u, T, M) << 24);
-                    }
-                    *(uint32_t *)(void *)d = v;
-                } else {
-                    // an end of the range: only the bytes inside it (neighbouring chunks own the others)
-                    for (int q = 0; q < 4; q++) {
-                        const int32_t r = r0 + q;
-                        if (r >= 0 && (uint32_t)r < len) d[q] = (uint8_t)byte_at(c, (uint32_t)r, T, M);
+            const uint32_t endb = begin + hl + pl;
+            // ---- groups of consecutive live messages that fit the image ----
+            uint32_t a = 0;
+            for (;;) {
+                const uint64_t lm = __ballot(live && lane >= a);
+                if (!lm) break;
+                const uint32_t fa = (uint32_t)__ffsll((unsigned long long)lm) - 1u;
+                const uint32_t lo = (uint32_t)__shfl((int)begin, (int)fa);
+                const uint64_t nf = __ballot(live && lane >= fa && endb - lo > WIRE_IMG);
+                const uint32_t b = nf ? (uint32_t)__ffsll((unsigned long long)nf) - 1u : 64u;
+                if (b == fa) {
+                    // one message longer than the image: header through the image, payload straight from its slot
+                    const uint32_t hl1 = (uint32_t)__shfl((int)hl, (int)fa), pl1 = (uint32_t)__shfl((int)pl, (int)fa);
+                    const uint64_t pay1 = ((uint64_t)(uint32_t)__shfl((int)((uintptr_t)m.pay >> 32), (int)fa) << 32) |
+                                          (uint32_t)__shfl((int)(uint32_t)(uintptr_t)m.pay, (int)fa);
+                    if (lane == fa) put_header(img, m, tag);
+                    wire_wave_sync();
+                    wave_copy_out(stream + lo, img, hl1, false);
+                    wave_copy_out(stream + lo + hl1, (const uint8_t *)(uintptr_t)pay1, pl1, false);
+                    wire_wave_sync();
+                    a = fa + 1;
+                    continue;
+                }
+                const bool mine = live && lane >= fa && lane < b;
+                uint32_t hi = mine ? endb : 0u;
+                uint32_t pieces = mine ? (pl + 15u) >> 4 : 0u;
+                for (int d = 32; d >= 1; d >>= 1) {
+                    hi = max(hi, (uint32_t)__shfl_xor((int)hi, d));
+                    pieces = max(pieces, (uint32_t)__shfl_xor((int)pieces, d));
+                }
+                const uint32_t off0 = (uint32_t)((uintptr_t)(stream + lo) & 15u);
+                uint8_t *d = img + off0 + (begin - lo);
+                if (mine) d += put_header(d, m, tag);
+                for (uint32_t q = 0; q < pieces; q++) {
+                    if (mine && 16u * q < pl) {
+                        const uint4 v = *(const uint4 *)(const void *)(m.pay + 16u * q);  // payload slots are 16-byte aligned and padded
+                        const uint32_t rem = pl - 16u * q;
+                        uint8_t *o = d + 16u * q;
+                        if (rem >= 16u) {
+                            __builtin_memcpy(o, &v.x, 4); __builtin_memcpy(o + 4, &v.y, 4);
+                            __builtin_memcpy(o + 8, &v.z, 4); __builtin_memcpy(o + 12, &v.w, 4);
+                        } else {
+                            const uint32_t vv[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+                            for (uint32_t k = 0; k < 4; k++) {
+                                if (4u * k + 4u <= rem) __builtin_memcpy(o + 4u * k, &vv[k], 4);
+                                else
+#pragma unroll
+                                    for (uint32_t bb = 0; bb < 3; bb++)
+                                        if (4u * k + bb < rem) o[4u * k + bb] = (uint8_t)(vv[k] >> (8u * bb));
+                            }
+                        }
                     }
                 }
+                wire_wave_sync();
+                wave_copy_out(stream + lo, img + off0, hi - lo, true);
+                wire_wave_sync();
+                a = b;
             }
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         }
     }
 }
