@@ -47,7 +47,7 @@ SYMBOLS = (
     "chd_set_stream", "chd_shard_spawn", "chd_shard_ingest", "chd_shard_import", "chd_shard_fanout",
     "chd_shard_get_entities", "chd_shard_table_bytes", "chd_shard_interest",
     "chd_handover_recipients", "chd_adjacent_recipients", "chd_wire_set_payloads", "chd_wire_build", "chd_wire_fetch",
-    "chd_tick_digest", "chd_host_alloc", "chd_host_free", "chd_subs_set_options", "chd_subs_get_options",
+    "chd_tick_digest", "chd_host_alloc", "chd_host_free", "chd_subs_set_options", "chd_subs_get_options", "chd_world_set_entity_groups",
 )
 
 
@@ -196,6 +196,7 @@ def load():
     L.chd_world_spawn.argtypes = [C.c_void_p, C.c_uint32, _u32p, _u32p, _f64p, _f64p, _u32p, _u32p]
     L.chd_world_despawn.argtypes = [C.c_void_p, C.c_uint32, _u32p]
     L.chd_world_set_entity_flags.argtypes = [C.c_void_p, C.c_uint32, _u32p, _u32p]
+    L.chd_world_set_entity_groups.argtypes = [C.c_void_p, C.c_uint32, _u32p, _u32p]
     L.chd_subs_add.argtypes = [C.c_void_p, C.c_uint32, _u32p, _u32p]
     L.chd_subs_remove.argtypes = [C.c_void_p, C.c_uint32, _u32p]
     L.chd_tick.argtypes = [C.c_void_p, P(TickIn), P(TickOut)]

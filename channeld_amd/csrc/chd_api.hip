@@ -43,6 +43,8 @@ struct World {
     WireDev x{};
     uint64_t wire_cap = 0;             // bytes allocated for x.bytes
     bool wire_built = false;
+    std::vector<uint32_t> group_id;    // host copy: handover group id per entity slot (0 = none), chd_world_set_entity_groups
+    void *grp_buf[4] = {nullptr, nullptr, nullptr, nullptr};  // device arrays behind WorldDev::grp_*
     bool plan_recipients = false;      // CHD_WORLD_HANDOVER_RECIPIENTS
     bool overlap_interest = false;     // CHD_WORLD_OVERLAP_INTEREST
     uint32_t *ho_rcp_off = nullptr;    // [handovers_cap + 1] recipients of handover h: [off[h], off[h+1])
@@ -374,6 +376,7 @@ void chd_destroy(chd_ctx *ctx) {
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
     for (void *p : ctx->w.allocs) (void)hipFree(p);
+    for (void *b : ctx->w.grp_buf) if (b) (void)hipFree(b);
     if (ctx->w.recs_dense) (void)hipFree(ctx->w.recs_dense);
     if (ctx->w.list_dense) (void)hipFree(ctx->w.list_dense);
     if (ctx->w.x.bytes) (void)hipFree(ctx->w.x.bytes);
@@ -813,6 +816,7 @@ int chd_world_spawn(chd_ctx *ctx, uint32_t n, const uint32_t *idx, const uint32_
     launch_spawn(ctx->stream, ctx->g, ctx->w.d, n, idx ? sbuf<uint32_t>(ctx, 0) : nullptr, sbuf<uint32_t>(ctx, 1),
                  sbuf<double>(ctx, 2), sbuf<double>(ctx, 3), flags ? sbuf<uint32_t>(ctx, 4) : nullptr,
                  sender ? sbuf<uint32_t>(ctx, 5) : nullptr, ctx->ring.cur_tick);
+    launch_group_locks(ctx->stream, ctx->w.d);
     TRY(after_launch(ctx));
     HIPCHK(hipStreamSynchronize(ctx->stream));
     return CHD_OK;
@@ -827,6 +831,7 @@ int chd_world_despawn(chd_ctx *ctx, uint32_t n, const uint32_t *idx) {
     TRY(ensure(ctx, 0, 4 * (size_t)n));
     TRY(up(ctx, sbuf<void>(ctx, 0), idx, 4 * (size_t)n));
     launch_despawn(ctx->stream, ctx->w.d, n, sbuf<uint32_t>(ctx, 0));
+    launch_group_locks(ctx->stream, ctx->w.d);
     TRY(after_launch(ctx));
     HIPCHK(hipStreamSynchronize(ctx->stream));
     return CHD_OK;
@@ -842,8 +847,55 @@ int chd_world_set_entity_flags(chd_ctx *ctx, uint32_t n, const uint32_t *idx, co
     TRY(up(ctx, sbuf<void>(ctx, 0), idx, 4 * (size_t)n));
     TRY(up(ctx, sbuf<void>(ctx, 1), flags, 4 * (size_t)n));
     launch_set_flags(ctx->stream, ctx->w.d, n, sbuf<uint32_t>(ctx, 0), sbuf<uint32_t>(ctx, 1));
+    launch_group_locks(ctx->stream, ctx->w.d);
     TRY(after_launch(ctx));
     HIPCHK(hipStreamSynchronize(ctx->stream));
+    return CHD_OK;
+}
+
+int chd_world_set_entity_groups(chd_ctx *ctx, uint32_t n, const uint32_t *idx, const uint32_t *group) {
+    NEED_WORLD();
+    if (!n) return CHD_OK;
+    if (!idx || !group) return fail(ctx, CHD_E_INVAL, "chd_world_set_entity_groups: NULL buffer");
+    World &W = ctx->w;
+    WorldDev &d = W.d;
+    for (uint32_t i = 0; i < n; i++)
+        if (idx[i] >= d.N) return fail(ctx, CHD_E_INVAL, "entity slot %u out of range", idx[i]);
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    if (W.slot_mode == 2) return fail(ctx, CHD_E_STATE, "handover groups are not available on region-sharded worlds (a group may span ranks)");
+    TRY(bind(ctx));
+    if (W.group_id.empty()) W.group_id.assign(d.N, 0u);
+    for (uint32_t i = 0; i < n; i++) W.group_id[idx[i]] = group[i];
+    // CSR of the groups (rare control-plane call: rebuilt on the host, O(N log N))
+    std::vector<uint32_t> order;
+    for (uint32_t i = 0; i < d.N; i++)
+        if (W.group_id[i]) order.push_back(i);
+    std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return W.group_id[a] < W.group_id[b]; });
+    std::vector<uint32_t> of(d.N, CHD_INVALID), off;
+    for (size_t k = 0; k < order.size(); k++) {
+        if (k == 0 || W.group_id[order[k]] != W.group_id[order[k - 1]]) off.push_back((uint32_t)k);
+        of[order[k]] = (uint32_t)off.size() - 1u;
+    }
+    const uint32_t G = (uint32_t)off.size();
+    off.push_back((uint32_t)order.size());
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    for (void *&b : W.grp_buf) { if (b) HIPCHK(hipFree(b)); b = nullptr; }
+    d.n_groups = 0;
+    d.grp_of = d.grp_off = d.grp_mem = d.grp_locked = nullptr;
+    if (G) {
+        const size_t sz[4] = {4 * (size_t)d.N, 4 * (size_t)(G + 1), 4 * std::max<size_t>(order.size(), 1), 4 * (size_t)G};
+        const void *src[4] = {of.data(), off.data(), order.data(), nullptr};
+        for (int k = 0; k < 4; k++) {
+            HIPCHK(hipMalloc(&W.grp_buf[k], sz[k]));
+            if (src[k]) HIPCHK(hipMemcpy(W.grp_buf[k], src[k], sz[k], hipMemcpyHostToDevice));
+        }
+        d.grp_of = (uint32_t *)W.grp_buf[0]; d.grp_off = (uint32_t *)W.grp_buf[1];
+        d.grp_mem = (uint32_t *)W.grp_buf[2]; d.grp_locked = (uint32_t *)W.grp_buf[3];
+        d.n_groups = G;
+        launch_group_locks(ctx->stream, d);
+        TRY(after_launch(ctx));
+        HIPCHK(hipStreamSynchronize(ctx->stream));
+    }
     return CHD_OK;
 }
 

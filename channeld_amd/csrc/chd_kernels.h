@@ -38,6 +38,11 @@ struct WorldDev {
     uint32_t *hist;       // bit j: an update of `sender` arrived at tick (hist_tick - j)
     uint32_t *hist_tick;
     uint32_t *sender_prev, *hist_prev;  // the previous sender's updates still inside the history
+    // handover groups (entity.go:58-244, FlatEntityGroupController): entities that cross cells together.  grp_of[i] =
+    // index of entity i's group (CHD_INVALID: a group of one); group k's members are grp_mem[grp_off[k] .. grp_off[k+1]);
+    // grp_locked[k] = members that are alive and locked (a locked member aborts the whole handover, entity.go:197-224)
+    uint32_t *grp_of, *grp_off, *grp_mem, *grp_locked;
+    uint32_t n_groups;
     // spatial (cell) channels' own update history
     uint32_t *cell_hist, *cell_hist_tick, *cell_sender, *cell_hist_prev, *cell_sender_prev;
     // cell index (rebuilt every tick)
@@ -200,6 +205,7 @@ void launch_subs_set_options(hipStream_t st, DevGrid g, WorldDev w, const chd_su
                              const uint32_t *grp_off, uint32_t n_groups, int64_t now_ns, uint8_t *should_send, int32_t *status);
 void launch_subs_get_options(hipStream_t st, WorldDev w, uint32_t s, uint8_t *access, uint8_t *skip_self);
 
+void launch_group_locks(hipStream_t st, WorldDev w);
 // K1: cell assign + handover detect (+ update history)
 void launch_ingest(hipStream_t st, DevGrid g, WorldDev w, uint32_t n, const uint32_t *idx,
                    const double *x, const double *z, const uint32_t *sender, uint32_t cur_tick);

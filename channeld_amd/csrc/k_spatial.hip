@@ -360,6 +360,21 @@ void launch_subs_get_options(hipStream_t st, WorldDev w, uint32_t s, uint8_t *ac
     hipLaunchKernelGGL(k_subs_get_options, dim3(1), dim3(64), 0, st, w, s, access, skip_self);
 }
 
+__global__ void __launch_bounds__(256) k_group_locks(WorldDev w) {
+    const uint32_t k = blockIdx.x * 256u + threadIdx.x;
+    if (k >= w.n_groups) return;
+    uint32_t n = 0;
+    for (uint32_t q = w.grp_off[k]; q < w.grp_off[k + 1]; q++) {
+        const uint32_t f = w.eflags[w.grp_mem[q]];
+        n += ((f & EF_ALIVE) && (f & EF_LOCKED)) ? 1u : 0u;
+    }
+    w.grp_locked[k] = n;
+}
+void launch_group_locks(hipStream_t st, WorldDev w) {
+    if (!w.n_groups) return;
+    hipLaunchKernelGGL(k_group_locks, dim3(nblocks(w.n_groups, 256)), dim3(256), 0, st, w);
+}
+
 // ------------------------------------------------------------------------
 // K1: ingest one batch of entity position updates.
 //   src = cell of the last merged position (== GetChannelId(oldInfo), kept as
@@ -404,7 +419,14 @@ __global__ void __launch_bounds__(256) k_ingest(DevGrid g, WorldDev w, uint32_t 
                 w.cell[i] = dst[j];
                 push_update(w, i, sender ? sender[u] : w.sender[i], cur_tick);
                 if (src[j] != CHD_INVALID && dst[j] != CHD_INVALID && src[j] != dst[j]) {
-                    if (ef & EF_LOCKED) locked[j] = true;
+                    // GetHandoverEntities (entity.go:197-224): a locked member of the notifier's handover group
+                    // empties the list and the handover does not happen (spatial.go:675-679)
+                    bool lk = (ef & EF_LOCKED) != 0;
+                    if (w.n_groups) {
+                        const uint32_t gi = w.grp_of[i];
+                        if (gi != CHD_INVALID && w.grp_locked[gi] != 0) lk = true;
+                    }
+                    if (lk) locked[j] = true;
                     else ho[j] = true;
                 }
             }
@@ -430,6 +452,18 @@ __global__ void __launch_bounds__(256) k_ingest(DevGrid g, WorldDev w, uint32_t 
         if (!ho[j]) continue;
         const uint32_t i = ent[j];
         w.member[i] = dst[j];
+        if (w.n_groups) {
+            // the whole handover group leaves src's entity map for dst's (spatial.go:703-736 run over handoverEntities):
+            // members that are in src's map move; one that is elsewhere stays where it is (RemoveEntity(src) fails for
+            // it; the reference would ALSO add it to dst's map, an entity in two maps — not modelled).  A member that
+            // hands over by its own update in this tick ends in its own dst either way (its store wins or this CAS fails).
+            const uint32_t gi = w.grp_of[i];
+            if (gi != CHD_INVALID)
+                for (uint32_t q = w.grp_off[gi]; q < w.grp_off[gi + 1]; q++) {
+                    const uint32_t m = w.grp_mem[q];
+                    if (m != i && (w.eflags[m] & EF_ALIVE)) atomicCAS(&w.member[m], src[j], dst[j]);
+                }
+        }
         uint32_t pos = s_cnt[wave * ING_ITEMS + j] + mask_rank(hm[j]);
         if (pos < w.handovers_cap) {
             chd_handover_rec r;

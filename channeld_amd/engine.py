@@ -103,6 +103,11 @@ class SpatialWorld:
         a, f = _u32(idx), _u32(flags)
         _lib.check(self.ctx, self.lib.chd_world_set_entity_flags(self.ctx, len(a), _ptr(a), _ptr(f)))
 
+    def set_entity_groups(self, idx, groups):
+        """handover groups (entity.go): entities with the same non-zero id cross cells together"""
+        a, g = _u32(idx), _u32(groups)
+        _lib.check(self.ctx, self.lib.chd_world_set_entity_groups(self.ctx, len(a), _ptr(a), _ptr(g)))
+
     def add_subscribers(self, slots, conn_ids):
         s = None if slots is None else _u32(slots)
         c = _u32(conn_ids)

@@ -210,6 +210,17 @@ int chd_world_despawn(chd_ctx *ctx, uint32_t n, const uint32_t *idx);
 int chd_world_set_entity_flags(chd_ctx *ctx, uint32_t n, const uint32_t *idx,
                                const uint32_t *flags);
 
+/* Handover groups (entity.go:58-244, FlatEntityGroupController; AddEntityGroupMessage / RemoveEntityGroupMessage stay
+ * with the Go host, the engine receives the result): entities with the same non-zero group id cross cells TOGETHER
+ * — when one of them hands over (its own old / new position, spatial.go:612-626) every member that is in the src
+ * cell's entity map moves to the dst cell's (:703-736 over handoverEntities) — and a locked member (CHD_ENTITY_LOCKED)
+ * aborts the handover of the whole group (GetHandoverEntities, entity.go:197-224; counted in n_locked_aborts).  One
+ * handover record per notifying entity, as the reference sends one ChannelDataHandoverMessage per Notify.  group 0 =
+ * no group (a group of one).  Deviations: a member that is in a THIRD cell's map stays there (the reference would
+ * also add it to dst's map, leaving it in two maps); "locked" is the entity's flag, not the notifier's lock-group
+ * membership test.  Not available on region-sharded worlds. */
+int chd_world_set_entity_groups(chd_ctx *ctx, uint32_t n, const uint32_t *idx, const uint32_t *group);
+
 /* A client connection with spatial interest (connection.go:106
  * spatialSubscriptions).  Slot -> ConnectionId.  Removing a subscriber drops all
  * its subscriptions (a closing connection, data.go:183-188). */

@@ -67,6 +67,7 @@ typedef struct orc_world {
     /* entities */
     uint8_t *alive;
     uint32_t *chan_id, *cell, *member, *eflags, *sender;
+    uint32_t *group; /* handover group id per entity (0 = never added to a group: GetHandoverEntities returns the entity itself) */
     wbuf *ebuf;     /* entity channel update buffers */
     wbuf *cbuf;     /* cell channel update buffers */
     uint32_t max_interval_ms; /* maxFanOutIntervalMs (only grows) */
@@ -145,6 +146,7 @@ orc_world *orc_world_new(const orc_grid *g, uint32_t n_entities, uint32_t n_subs
     w->member = (uint32_t *)calloc(n_entities + 1, 4);
     w->eflags = (uint32_t *)calloc(n_entities + 1, 4);
     w->sender = (uint32_t *)calloc(n_entities + 1, 4);
+    w->group = (uint32_t *)calloc(n_entities + 1, 4);
     w->ebuf = (wbuf *)calloc(n_entities + 1, sizeof(wbuf));
     w->cbuf = (wbuf *)calloc(w->C + 1, sizeof(wbuf));
     w->sub_alive = (uint8_t *)calloc(n_subs + 1, 1);
@@ -170,7 +172,7 @@ void orc_world_free(orc_world *w) {
     for (uint32_t i = 0; i < w->N; i++) free(w->ebuf[i].v);
     for (uint32_t i = 0; i < w->C; i++) free(w->cbuf[i].v);
     free(w->alive); free(w->chan_id); free(w->cell); free(w->member);
-    free(w->eflags); free(w->sender); free(w->ebuf); free(w->cbuf);
+    free(w->eflags); free(w->sender); free(w->group); free(w->ebuf); free(w->cbuf);
     free(w->sub_alive); free(w->conn_id); free(w->pairs); free(w->pair_cnt);
     free(w->rec); free(w->ho_ent); free(w->ho_src); free(w->ho_dst);
     free(w->ho_srv_src); free(w->ho_srv_dst); free(w->unsub_sub);
@@ -205,6 +207,7 @@ void orc_world_spawn(orc_world *w, uint32_t i, uint32_t chan_id, double x,
 
 void orc_world_despawn(orc_world *w, uint32_t i) { w->alive[i] = 0; w->member[i] = W_INVALID; }
 void orc_world_set_flags(orc_world *w, uint32_t i, uint32_t flags) { w->eflags[i] = flags; }
+void orc_world_set_group(orc_world *w, uint32_t i, uint32_t group) { w->group[i] = group; }
 
 void orc_world_add_sub(orc_world *w, uint32_t s, uint32_t conn_id) {
     w->sub_alive[s] = 1;
@@ -495,7 +498,12 @@ int orc_world_tick(orc_world *w, orc_time t, uint32_t n_upd, const uint32_t *idx
         if (sender) w->sender[i] = sender[u];
         wbuf_push(&w->ebuf[i], t, w->sender[i], w->max_interval_ms);
         if (src == W_INVALID || dst == W_INVALID || src == dst) continue; /* spatial.go:613-626 */
-        if (w->eflags[i] & 1u) { w->n_locked_abort++; continue; }        /* :675-679 */
+        /* GetHandoverEntities (entity.go:197-224): the notifier's handover group; a locked member empties it (:675-679) */
+        int any_locked = (w->eflags[i] & 1u) != 0;
+        if (w->group[i])
+            for (uint32_t m = 0; m < w->N && !any_locked; m++)
+                if (w->alive[m] && w->group[m] == w->group[i] && (w->eflags[m] & 1u)) any_locked = 1;
+        if (any_locked) { w->n_locked_abort++; continue; }
         if (w->nho == w->capho) {
             w->capho = w->capho ? w->capho * 2 : 256;
             w->ho_ent = (uint32_t *)realloc(w->ho_ent, 4 * w->capho);
@@ -511,6 +519,9 @@ int orc_world_tick(orc_world *w, orc_time t, uint32_t n_upd, const uint32_t *idx
         w->ho_srv_dst[w->nho] = w->server_of_cell[dst];
         w->nho++;
         w->member[i] = dst; /* RemoveEntity(src) + AddEntity(dst), :703-736 */
+        if (w->group[i]) /* ... for every entity of the handover group that is in src's map */
+            for (uint32_t m = 0; m < w->N; m++)
+                if (m != i && w->alive[m] && w->group[m] == w->group[i] && w->member[m] == src) w->member[m] = dst;
     }
     for (uint32_t u = 0; u < n_cu; u++)
         wbuf_push(&w->cbuf[cu_cell[u]], t, cu_sender[u], w->max_interval_ms);

@@ -117,6 +117,7 @@ def lib():
     L.orc_world_spawn.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_double, C.c_double, C.c_uint32, C.c_uint32]
     L.orc_world_despawn.argtypes = [C.c_void_p, C.c_uint32]
     L.orc_world_set_flags.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32]
+    L.orc_world_set_group.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32]
     L.orc_world_add_sub.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32]
     L.orc_world_remove_sub.argtypes = [C.c_void_p, C.c_uint32]
     L.orc_world_tick.argtypes = [C.c_void_p, C.c_int64, C.c_uint32, up, dp, dp, up,
@@ -376,6 +377,9 @@ class World:
 
     def set_flags(self, i, flags):
         lib().orc_world_set_flags(self.h, int(i), int(flags))
+
+    def set_group(self, i, group):
+        lib().orc_world_set_group(self.h, int(i), int(group))
 
     def despawn(self, i):
         lib().orc_world_despawn(self.h, int(i))

@@ -471,3 +471,70 @@ def test_subscription_options_drive_every_fan_out_branch(amd, emit_mode):
         n_full_self += int((own & np.isin(res.records["channel"], sw.chan_id[(np.arange(N) % 3 == 0) & (np.arange(N) % 8 == 0)])).sum())
     assert total > 100000
     assert n_full_self > 0  # the !SkipSelfUpdateFanOut branch produced records
+
+
+def test_handover_groups_move_together_and_locks_abort(amd, emit_mode):
+    """chd_world_set_entity_groups (entity.go handover groups): members that ride with a leader — same positions, some
+    of them without updates of their own — change cell with it; a locked member aborts the whole group's handover
+    until it is unlocked; lone entities are untouched.  Handover records, locked aborts, entity maps (every tick) and
+    fan-out records against the oracle's sequential restatement."""
+    cfg = synth.load_config("spatial_static_4x4.json")
+    g = orc.grid_from_config(cfg)
+    N, S = 900, 40
+    sw = synth.SynthWorld(synth.WorldSpec(cfg, N, S, 0x6A0B, tick_ms=50, outside_frac=0.0, locked_frac=0.0))
+    ctl, gw = make(amd, cfg, N, S)
+    ow = orc.World(g, N, S, gw.capq, 20, 0, literal=False)
+    # groups of three: leader 3k, riders 3k+1 (updated with the leader's position) and 3k+2 (never updated) for k < 120
+    K = 120
+    leader = np.arange(K) * 3
+    group = np.zeros(N, dtype=np.uint32)
+    for k in range(K):
+        group[3 * k: 3 * k + 3] = 1000 + k
+    x0, z0 = sw.x.copy(), sw.z.copy()
+    for k in range(K):
+        x0[3 * k + 1: 3 * k + 3] = x0[3 * k]
+        z0[3 * k + 1: 3 * k + 3] = z0[3 * k]
+    flags = np.zeros(N, dtype=np.uint32)
+    flags[3 * np.arange(0, K, 10) + 2] = 1  # every tenth group has a locked (and never updated) rider
+    ow.spawn(np.arange(N), sw.chan_id, x0, z0, flags, sw.sender)
+    gw.spawn(None, sw.chan_id, x0, z0, flags, sw.sender)
+    gidx = np.nonzero(group)[0].astype(np.uint32)
+    gw.set_entity_groups(gidx, group[gidx])
+    for i in gidx:
+        ow.set_group(int(i), int(group[i]))
+    for s in range(S):
+        ow.add_sub(s, int(sw.sub_conn[s]))
+    gw.add_subscribers(None, sw.sub_conn)
+    upd = np.array([i for i in range(N) if not (i < 3 * K and i % 3 == 2)], dtype=np.uint32)  # riders 3k+2 never update
+    rng = np.random.default_rng(9)
+    total_ho = total_lock = moved_riders = 0
+    for k in range(22):
+        sw.step()
+        # bigger steps for the leaders so that groups cross often; riders 3k+1 copy the leader
+        jump = rng.random(K) < 0.25
+        sw.x[leader] = np.where(jump, np.float64(np.float32(sw.offx + rng.random(K) * sw.W * 0.999)), sw.x[leader])
+        sw.x[leader + 1], sw.z[leader + 1] = sw.x[leader], sw.z[leader]
+        if k == 10:  # unlock: those groups move again from now on
+            idx = (3 * np.arange(0, K, 10) + 2).astype(np.uint32)
+            gw.set_entity_flags(idx, np.zeros(len(idx), dtype=np.uint32))
+            for i in idx:
+                ow.set_flags(int(i), 0)
+        if k == 14:  # lock some leaders instead
+            idx = (3 * np.arange(5, K, 10)).astype(np.uint32)
+            gw.set_entity_flags(idx, np.ones(len(idx), dtype=np.uint32))
+            for i in idx:
+                ow.set_flags(int(i), 1)
+        q = sw.queries()
+        ow.tick(sw.now_ns(), upd, sw.x[upd], sw.z[upd], None, None, None, None, q)
+        res = gw.tick(sw.now_ns(), upd_idx=upd, upd_x=sw.x[upd], upd_z=sw.z[upd], queries=q, records_cap=1 << 21)
+        compare_tick(k, res, ow, S)
+        cell, member = gw.entity_state()
+        ocell, omember = ow.entity_state()
+        to_id = lambda a: np.where(a == 0xFFFFFFFF, 0, a + 0x10000).astype(np.uint32)
+        assert np.array_equal(cell, to_id(ocell)), f"tick {k}: position cells"
+        assert np.array_equal(member, to_id(omember)), f"tick {k}: entity maps (group members move with the notifier)"
+        total_ho += len(res.handovers)
+        total_lock += res.n_locked_aborts
+        riders = 3 * np.arange(K) + 2
+        moved_riders += int((member[riders] != cell[riders]).sum())  # in another cell's map than their own position's
+    assert total_ho > 100 and total_lock > 5 and moved_riders > 50
