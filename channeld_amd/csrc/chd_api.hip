@@ -775,6 +775,16 @@ int chd_world_create(chd_ctx *ctx, const chd_world_cfg *cfg) {
             TRY(walloc(ctx, &x.len_ent[k], N));
             TRY(walloc(ctx, &x.len_cell[k], C));
         }
+        x.merge = masks ? 1u : 0u;
+        if (x.merge) {
+            // merged updates: the UPDATE payloads of the last CHD_HIST_BITS ticks per channel, and the Any type_urls
+            TRY(walloc(ctx, &x.ring_ent, N * CHD_HIST_BITS * x.stride[0], false));
+            TRY(walloc(ctx, &x.ring_cell, C * CHD_HIST_BITS * x.stride[0], false));
+            TRY(walloc(ctx, &x.rlen_ent, N * CHD_HIST_BITS));
+            TRY(walloc(ctx, &x.rlen_cell, C * CHD_HIST_BITS));
+            TRY(walloc(ctx, &x.url[0], 256));
+            TRY(walloc(ctx, &x.url[1], 256));
+        }
         TRY(walloc(ctx, &x.conn_wlen, S + 1));
         x.conn_woff = x.conn_wlen;
         TRY(walloc(ctx, &x.conn_npk, S));
@@ -1558,10 +1568,25 @@ int chd_wire_set_payloads(chd_ctx *ctx, int kind, uint32_t n, const uint32_t *id
     TRY(up(ctx, sbuf<void>(ctx, 1), lens, 4 * (size_t)n));
     TRY(up(ctx, sbuf<void>(ctx, 2), off.data(), 8 * (size_t)n));
     TRY(up(ctx, sbuf<void>(ctx, 3), bytes, total));
+    // (merge mode: an UPDATE payload set now belongs to the update that arrives with the NEXT tick)
     launch_wire_set_payloads(ctx->stream, W.x, full, cell, n, cell ? ctx->g.ncell : W.d.N, sbuf<uint32_t>(ctx, 0),
-                             sbuf<uint32_t>(ctx, 1), sbuf<uint64_t>(ctx, 2), sbuf<uint8_t>(ctx, 3));
+                             sbuf<uint32_t>(ctx, 1), sbuf<uint64_t>(ctx, 2), sbuf<uint8_t>(ctx, 3),
+                             (ctx->ring.cur_tick + 1u) & (CHD_HIST_BITS - 1u));
     TRY(after_launch(ctx));
     HIPCHK(hipStreamSynchronize(ctx->stream));  // the staging vectors go out of scope
+    return CHD_OK;
+}
+
+int chd_wire_set_type_url(chd_ctx *ctx, int cell, const uint8_t *url, uint32_t len) {
+    NEED_WORLD();
+    World &W = ctx->w;
+    if (!W.wire || !W.x.merge) return fail(ctx, CHD_E_STATE, "type urls belong to worlds with CHD_WORLD_WIRE | CHD_WORLD_UPDATE_MASKS");
+    if (len > 255 || (len && !url)) return fail(ctx, CHD_E_INVAL, "chd_wire_set_type_url: at most 255 bytes");
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    TRY(bind(ctx));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    if (len) HIPCHK(hipMemcpy(W.x.url[cell ? 1 : 0], url, len, hipMemcpyHostToDevice));
+    W.x.url_len[cell ? 1 : 0] = len;
     return CHD_OK;
 }
 
@@ -1576,6 +1601,7 @@ int chd_wire_build(chd_ctx *ctx, uint64_t *total_bytes, uint64_t *total_packets,
     WorldDev &d = W.d;
     hipStream_t st = ctx->stream;
     HIPCHK(hipMemsetAsync(W.x.n_dropped, 0, sizeof(uint32_t), st));
+    W.x.cur_tick = ctx->ring.cur_tick;
     launch_wire_layout(st, d, W.x);
     launch_scan_u64_inplace(st, W.x.conn_wlen, d.S);
     TRY(after_launch(ctx));

@@ -259,6 +259,15 @@ struct WireDev {
     uint32_t stride[2];                 // payload slot size in bytes: [0] update (delta), [1] full state
     uint8_t *pay_ent[2], *pay_cell[2];  // [N * stride], [ncell * stride]: serialized google.protobuf.Any per channel
     uint32_t *len_ent[2], *len_cell[2]; // [N], [ncell]
+    // merged updates (CHD_WORLD_WIRE | CHD_WORLD_UPDATE_MASKS): the UPDATE payloads are the serialized channel
+    // data update MESSAGES (not Any), kept per tick in a ring of CHD_HIST_BITS slots (slot = tick & 31); a record's message is
+    // Any{type_url, value = the updates its mask selects, oldest first, concatenated} — what a protobuf parser reads as their merge
+    uint32_t merge;                     // 0: one current payload per channel (pay_ent[0] / pay_cell[0] hold Any bytes)
+    uint32_t cur_tick;                  // tick of the records being built (ring slot of mask bit j = (cur_tick - j) & 31)
+    uint8_t *ring_ent, *ring_cell;      // [N * 32 * stride[0]], [ncell * 32 * stride[0]]
+    uint32_t *rlen_ent, *rlen_cell;     // [N * 32], [ncell * 32]
+    uint8_t *url[2];                    // type_url of the entity / spatial channel data message (padded to 4 bytes)
+    uint32_t url_len[2];
     uint32_t *rec_woff;                 // per record: byte offset of its Packet entry in the connection's stream (~0 = dropped)
     uint32_t *rec_wtag;                 // per record: 0, or 0x80000000 | packet length if it opens a packet
     uint64_t *conn_wlen;                // [S+1] stream length per connection -> exclusive scan = conn_woff
@@ -270,7 +279,7 @@ struct WireDev {
 void launch_wire_layout(hipStream_t st, WorldDev w, WireDev x);
 void launch_wire_copy(hipStream_t st, WorldDev w, WireDev x);
 void launch_wire_set_payloads(hipStream_t st, WireDev x, int full, int cell, uint32_t n, uint32_t limit, const uint32_t *idx,
-                              const uint32_t *lens, const uint64_t *off, const uint8_t *bytes);
+                              const uint32_t *lens, const uint64_t *off, const uint8_t *bytes, uint32_t ring_slot);
 // recipient planning (decision parts)
 void launch_handover_recipients_count(hipStream_t st, DevGrid g, WorldDev w, uint32_t *off);
 void launch_handover_recipients_fill(hipStream_t st, DevGrid g, WorldDev w, const uint32_t *off, uint32_t *conn,

@@ -30,21 +30,36 @@ __device__ __forceinline__ uint32_t vlen(uint32_t v) { return v < (1u << 7) ? 1u
 
 struct WireMsg {
     uint32_t chan, any_len, body_len, mp_len, entry;  // entry = bytes inside the Packet (0: dropped by Send)
-    const uint8_t *pay;
+    const uint8_t *pay;                                // the one payload (Any bytes), or the channel's ring row in merge mode
+    uint32_t mask;                                     // merge mode, update records: the ring slots to concatenate (bit j = tick cur - j)
+    uint32_t value_len;                                // merge mode: bytes of Any.value (sum of the selected updates)
+    uint32_t kind;                                     // merge mode: 1 + (0 entity, 1 cell) for an update record, else 0
 };
 
-__device__ __forceinline__ WireMsg wire_msg(const WorldDev &w, const WireDev &x, chd_fanout_rec rec, uint32_t pos) {
+__device__ __forceinline__ WireMsg wire_msg(const WorldDev &w, const WireDev &x, chd_fanout_rec rec, uint32_t pos, uint32_t mask) {
     WireMsg m;
     const uint32_t full = rec.conn >> 31;
     m.chan = rec.channel;
-    if (pos & CHD_POS_CELL) {
-        const uint32_t c = pos & ~CHD_POS_CELL;
-        m.any_len = x.len_cell[full][c];
-        m.pay = x.pay_cell[full] + (size_t)c * x.stride[full];
+    m.mask = 0; m.value_len = 0; m.kind = 0;
+    const bool cell = (pos & CHD_POS_CELL) != 0;
+    const uint32_t id = cell ? (pos & ~CHD_POS_CELL) : w.ce_slot[pos];
+    if (x.merge && !full) {
+        // Any{type_url, value}: value = the buffered updates the window selected (data.go:225-269), oldest first
+        const uint32_t *rl = (cell ? x.rlen_cell : x.rlen_ent) + (size_t)id * CHD_HIST_BITS;
+        uint32_t total = 0;
+        for (uint32_t mm = mask; mm; mm &= mm - 1u) total += rl[(x.cur_tick - (uint32_t)(__ffs((int)mm) - 1)) & (CHD_HIST_BITS - 1u)];
+        const uint32_t ul = x.url_len[cell ? 1 : 0];
+        m.mask = mask;
+        m.value_len = total;
+        m.kind = cell ? 2u : 1u;
+        m.pay = (cell ? x.ring_cell : x.ring_ent) + (size_t)id * CHD_HIST_BITS * x.stride[0];
+        m.any_len = (ul ? 1u + vlen(ul) + ul : 0u) + (total ? 1u + vlen(total) + total : 0u);  // empty fields are not emitted
+    } else if (cell) {
+        m.any_len = x.len_cell[full][id];
+        m.pay = x.pay_cell[full] + (size_t)id * x.stride[full];
     } else {
-        const uint32_t slot = w.ce_slot[pos];
-        m.any_len = x.len_ent[full][slot];
-        m.pay = x.pay_ent[full] + (size_t)slot * x.stride[full];
+        m.any_len = x.len_ent[full][id];
+        m.pay = x.pay_ent[full] + (size_t)id * x.stride[full];
     }
     m.body_len = 1u + vlen(m.any_len) + m.any_len;                       // ChannelDataUpdateMessage.data = 1
     m.mp_len = (m.chan ? 1u + vlen(m.chan) : 0u) + 2u                    // channelId = 1 (omitted if 0), msgType = 4 -> 0x20 0x08
@@ -73,7 +88,7 @@ __global__ void __launch_bounds__(256) k_wire_layout(WorldDev w, WireDev x) {
                 const uint32_t i = i0 + lane;
                 const bool valid = i < n;
                 uint32_t entry = 0;
-                if (valid) entry = wire_msg(w, x, w.recs[seg + i], w.rec_pos[seg + i]).entry;
+                if (valid) entry = wire_msg(w, x, w.recs[seg + i], w.rec_pos[seg + i], w.rec_mask ? w.rec_mask[seg + i] : 0u).entry;
                 if (valid && entry == 0) x.rec_woff[seg + i] = 0xFFFFFFFFu;  // dropped
                 ndropped += (uint32_t)__popcll(__ballot(valid && entry == 0));
                 // inclusive prefix of the entry sizes over the chunk
@@ -149,12 +164,20 @@ __device__ __forceinline__ uint32_t put_varint(uint8_t *h, uint32_t n, uint32_t 
     return n;
 }
 
-__device__ __forceinline__ uint32_t wire_hdr_len(const WireMsg &m, uint32_t tag) {
-    return (tag ? 5u : 0u) + 1u + vlen(m.mp_len) + (m.chan ? 1u + vlen(m.chan) : 0u) + 2u + 1u + vlen(m.body_len) + 1u + vlen(m.any_len);
+// bytes in front of the payload bytes proper: tag, the three nested headers and, in merge mode, the Any's own fields
+__device__ __forceinline__ uint32_t wire_any_prefix(const WireDev &x, const WireMsg &m) {
+    if (!m.kind) return 0u;
+    const uint32_t ul = x.url_len[m.kind - 1u];
+    return (ul ? 1u + vlen(ul) + ul : 0u) + (m.value_len ? 1u + vlen(m.value_len) : 0u);
+}
+__device__ __forceinline__ uint32_t wire_hdr_len(const WireDev &x, const WireMsg &m, uint32_t tag) {
+    return (tag ? 5u : 0u) + 1u + vlen(m.mp_len) + (m.chan ? 1u + vlen(m.chan) : 0u) + 2u + 1u + vlen(m.body_len) + 1u + vlen(m.any_len) +
+           wire_any_prefix(x, m);
 }
 
-// tag (if the message opens a packet) + the three nested length-delimited headers, byte by byte at h
-__device__ __forceinline__ uint32_t put_header(uint8_t *h, const WireMsg &m, uint32_t tag) {
+// tag (if the message opens a packet) + the three nested length-delimited headers (+ Any.type_url and the key of Any.value
+// in merge mode), byte by byte at h
+__device__ __forceinline__ uint32_t put_header(uint8_t *h, const WireDev &x, const WireMsg &m, uint32_t tag) {
     uint32_t hl = 0;
     if (tag) {  // opens a packet: the 5-byte tag sits right before it (connection.go:683-687)
         const uint32_t plen = tag & 0xFFFFu;
@@ -166,7 +189,39 @@ __device__ __forceinline__ uint32_t put_header(uint8_t *h, const WireMsg &m, uin
     h[hl++] = 0x20; h[hl++] = 0x08;                                       // MessagePack.msgType = CHANNEL_DATA_UPDATE
     h[hl++] = 0x2A; hl = put_varint(h, hl, m.body_len);                   // MessagePack.msgBody
     h[hl++] = 0x0A; hl = put_varint(h, hl, m.any_len);                    // ChannelDataUpdateMessage.data
+    if (m.kind) {
+        const uint32_t ul = x.url_len[m.kind - 1u];
+        if (ul) {                                                         // google.protobuf.Any.type_url = 1
+            h[hl++] = 0x0A; hl = put_varint(h, hl, ul);
+            const uint8_t *u = x.url[m.kind - 1u];
+            for (uint32_t k = 0; k < ul; k++) h[hl++] = u[k];
+        }
+        if (m.value_len) { h[hl++] = 0x12; hl = put_varint(h, hl, m.value_len); }  // Any.value = 2
+    }
     return hl;
+}
+
+// len bytes from a 16-byte aligned, padded global slot to d (LDS image, any alignment): 16-byte loads, unaligned dword stores
+__device__ __forceinline__ void lane_put_payload(uint8_t *d, const uint8_t *__restrict__ pay, uint32_t len) {
+    for (uint32_t q = 0; 16u * q < len; q++) {
+        const uint4 v = *(const uint4 *)(const void *)(pay + 16u * q);
+        const uint32_t rem = len - 16u * q;
+        uint8_t *o = d + 16u * q;
+        if (rem >= 16u) {
+            __builtin_memcpy(o, &v.x, 4); __builtin_memcpy(o + 4, &v.y, 4);
+            __builtin_memcpy(o + 8, &v.z, 4); __builtin_memcpy(o + 12, &v.w, 4);
+        } else {
+            const uint32_t vv[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+            for (uint32_t k = 0; k < 4; k++) {
+                if (4u * k + 4u <= rem) __builtin_memcpy(o + 4u * k, &vv[k], 4);
+                else
+#pragma unroll
+                    for (uint32_t bb = 0; bb < 3; bb++)
+                        if (4u * k + bb < rem) o[4u * k + bb] = (uint8_t)(vv[k] >> (8u * bb));
+            }
+        }
+    }
 }
 
 __device__ __forceinline__ void wire_wave_sync() {
@@ -224,14 +279,14 @@ __global__ void __launch_bounds__(256) k_wire_copy(WorldDev w, WireDev x) {
             bool live = false;
             uint32_t begin = 0, hl = 0, pl = 0, tag = 0;
             WireMsg m;
-            m.chan = 0; m.any_len = 0; m.body_len = 0; m.mp_len = 0; m.entry = 0; m.pay = nullptr;
+            m.chan = 0; m.any_len = 0; m.body_len = 0; m.mp_len = 0; m.entry = 0; m.pay = nullptr; m.mask = 0; m.value_len = 0; m.kind = 0;
             if (i < n) {
                 const uint32_t woff = x.rec_woff[seg + i];
                 if (woff != 0xFFFFFFFFu) {  // not dropped by the size check of Send
-                    m = wire_msg(w, x, w.recs[seg + i], w.rec_pos[seg + i]);
+                    m = wire_msg(w, x, w.recs[seg + i], w.rec_pos[seg + i], w.rec_mask ? w.rec_mask[seg + i] : 0u);
                     tag = x.rec_wtag[seg + i];
-                    hl = wire_hdr_len(m, tag);
-                    pl = m.any_len;
+                    hl = wire_hdr_len(x, m, tag);
+                    pl = m.kind ? m.value_len : m.any_len;
                     begin = woff - (tag ? 5u : 0u);
                     live = true;
                 }
@@ -247,46 +302,50 @@ __global__ void __launch_bounds__(256) k_wire_copy(WorldDev w, WireDev x) {
                 const uint64_t nf = __ballot(live && lane >= fa && endb - lo > WIRE_IMG);
                 const uint32_t b = nf ? (uint32_t)__ffsll((unsigned long long)nf) - 1u : 64u;
                 if (b == fa) {
-                    // one message longer than the image: header through the image, payload straight from its slot
-                    const uint32_t hl1 = (uint32_t)__shfl((int)hl, (int)fa), pl1 = (uint32_t)__shfl((int)pl, (int)fa);
-                    const uint64_t pay1 = ((uint64_t)(uint32_t)__shfl((int)((uintptr_t)m.pay >> 32), (int)fa) << 32) |
-                                          (uint32_t)__shfl((int)(uint32_t)(uintptr_t)m.pay, (int)fa);
-                    if (lane == fa) put_header(img, m, tag);
+                    // one message longer than the image: header through the image, payload straight from its slot(s)
+                    const uint32_t hl1 = (uint32_t)__shfl((int)hl, (int)fa);
+                    if (lane == fa) put_header(img, x, m, tag);
                     wire_wave_sync();
                     wave_copy_out(stream + lo, img, hl1, false);
-                    wave_copy_out(stream + lo + hl1, (const uint8_t *)(uintptr_t)pay1, pl1, false);
+                    const uint32_t kind1 = (uint32_t)__shfl((int)m.kind, (int)fa), mask1 = (uint32_t)__shfl((int)m.mask, (int)fa);
+                    const uint64_t pay1 = ((uint64_t)(uint32_t)__shfl((int)((uintptr_t)m.pay >> 32), (int)fa) << 32) |
+                                          (uint32_t)__shfl((int)(uint32_t)(uintptr_t)m.pay, (int)fa);
+                    if (!kind1) {
+                        wave_copy_out(stream + lo + hl1, (const uint8_t *)(uintptr_t)pay1, (uint32_t)__shfl((int)pl, (int)fa), false);
+                    } else {
+                        uint32_t at = lo + hl1;
+                        const uint32_t id1 = (uint32_t)__shfl((int)(((uintptr_t)m.pay - (uintptr_t)(kind1 == 2 ? x.ring_cell : x.ring_ent)) / ((size_t)CHD_HIST_BITS * x.stride[0])), (int)fa);
+                        const uint32_t *rl = (kind1 == 2 ? x.rlen_cell : x.rlen_ent) + (size_t)id1 * CHD_HIST_BITS;
+                        for (int jj = CHD_HIST_BITS - 1; jj >= 0; jj--) {
+                            if (!((mask1 >> jj) & 1u)) continue;
+                            const uint32_t sl = (x.cur_tick - (uint32_t)jj) & (CHD_HIST_BITS - 1u);
+                            wave_copy_out(stream + at, (const uint8_t *)(uintptr_t)pay1 + (size_t)sl * x.stride[0], rl[sl], false);
+                            at += rl[sl];
+                        }
+                    }
                     wire_wave_sync();
                     a = fa + 1;
                     continue;
                 }
                 const bool mine = live && lane >= fa && lane < b;
                 uint32_t hi = mine ? endb : 0u;
-                uint32_t pieces = mine ? (pl + 15u) >> 4 : 0u;
-                for (int d = 32; d >= 1; d >>= 1) {
-                    hi = max(hi, (uint32_t)__shfl_xor((int)hi, d));
-                    pieces = max(pieces, (uint32_t)__shfl_xor((int)pieces, d));
-                }
+                for (int d = 32; d >= 1; d >>= 1) hi = max(hi, (uint32_t)__shfl_xor((int)hi, d));
                 const uint32_t off0 = (uint32_t)((uintptr_t)(stream + lo) & 15u);
-                uint8_t *d = img + off0 + (begin - lo);
-                if (mine) d += put_header(d, m, tag);
-                for (uint32_t q = 0; q < pieces; q++) {
-                    if (mine && 16u * q < pl) {
-                        const uint4 v = *(const uint4 *)(const void *)(m.pay + 16u * q);  // payload slots are 16-byte aligned and padded
-                        const uint32_t rem = pl - 16u * q;
-                        uint8_t *o = d + 16u * q;
-                        if (rem >= 16u) {
-                            __builtin_memcpy(o, &v.x, 4); __builtin_memcpy(o + 4, &v.y, 4);
-                            __builtin_memcpy(o + 8, &v.z, 4); __builtin_memcpy(o + 12, &v.w, 4);
-                        } else {
-                            const uint32_t vv[4] = {v.x, v.y, v.z, v.w};
-#pragma unroll
-                            for (uint32_t k = 0; k < 4; k++) {
-                                if (4u * k + 4u <= rem) __builtin_memcpy(o + 4u * k, &vv[k], 4);
-                                else
-#pragma unroll
-                                    for (uint32_t bb = 0; bb < 3; bb++)
-                                        if (4u * k + bb < rem) o[4u * k + bb] = (uint8_t)(vv[k] >> (8u * bb));
-                            }
+                if (mine) {
+                    uint8_t *d = img + off0 + (begin - lo);
+                    d += put_header(d, x, m, tag);
+                    if (!m.kind) {
+                        lane_put_payload(d, m.pay, pl);  // payload slots are 16-byte aligned and padded
+                    } else {
+                        // the selected updates, oldest (highest bit) first
+                        const uint32_t *rl = (m.kind == 2 ? x.rlen_cell : x.rlen_ent) +
+                                             ((uintptr_t)m.pay - (uintptr_t)(m.kind == 2 ? x.ring_cell : x.ring_ent)) / x.stride[0];
+                        for (int jj = CHD_HIST_BITS - 1; jj >= 0; jj--) {
+                            if (!((m.mask >> jj) & 1u)) continue;
+                            const uint32_t sl = (x.cur_tick - (uint32_t)jj) & (CHD_HIST_BITS - 1u);
+                            const uint32_t ln = rl[sl];
+                            lane_put_payload(d, m.pay + (size_t)sl * x.stride[0], ln);
+                            d += ln;
                         }
                     }
                 }
@@ -307,21 +366,31 @@ void launch_wire_copy(hipStream_t st, WorldDev w, WireDev x) {
 // payload upload: kind k, entry idx[i] <- lens[i] bytes at bytes + off[i]
 __global__ void __launch_bounds__(256) k_wire_set_payloads(WireDev x, int full, int cell, uint32_t n, uint32_t limit,
                                                            const uint32_t *__restrict__ idx, const uint32_t *__restrict__ lens,
-                                                           const uint64_t *__restrict__ off, const uint8_t *__restrict__ bytes) {
+                                                           const uint64_t *__restrict__ off, const uint8_t *__restrict__ bytes,
+                                                           uint32_t ring_slot) {
     const uint32_t u = blockIdx.x * 4u + (threadIdx.x >> 6);
     if (u >= n) return;
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t i = idx[u];
     if (i >= limit) return;
     const uint32_t len = lens[u];
-    uint8_t *dst = (cell ? x.pay_cell[full] : x.pay_ent[full]) + (size_t)i * x.stride[full];
+    uint8_t *dst;
+    uint32_t *ldst;
+    if (x.merge && !full) {  // this update's slot of the channel's ring
+        const size_t e = (size_t)i * CHD_HIST_BITS + ring_slot;
+        dst = (cell ? x.ring_cell : x.ring_ent) + e * x.stride[0];
+        ldst = (cell ? x.rlen_cell : x.rlen_ent) + e;
+    } else {
+        dst = (cell ? x.pay_cell[full] : x.pay_ent[full]) + (size_t)i * x.stride[full];
+        ldst = (cell ? x.len_cell[full] : x.len_ent[full]) + i;
+    }
     const uint8_t *src = bytes + off[u];
     for (uint32_t k = lane; k < len; k += 64) dst[k] = src[k];
-    if (lane == 0) (cell ? x.len_cell[full] : x.len_ent[full])[i] = len;
+    if (lane == 0) *ldst = len;
 }
 
 void launch_wire_set_payloads(hipStream_t st, WireDev x, int full, int cell, uint32_t n, uint32_t limit, const uint32_t *idx,
-                              const uint32_t *lens, const uint64_t *off, const uint8_t *bytes) {
+                              const uint32_t *lens, const uint64_t *off, const uint8_t *bytes, uint32_t ring_slot) {
     if (!n) return;
-    hipLaunchKernelGGL(k_wire_set_payloads, dim3((n + 3) / 4), dim3(256), 0, st, x, full, cell, n, limit, idx, lens, off, bytes);
+    hipLaunchKernelGGL(k_wire_set_payloads, dim3((n + 3) / 4), dim3(256), 0, st, x, full, cell, n, limit, idx, lens, off, bytes, ring_slot);
 }

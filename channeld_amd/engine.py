@@ -322,6 +322,11 @@ class SpatialWorld:
         _lib.check(self.ctx, self.lib.chd_wire_set_payloads(self.ctx, int(kind), len(ix), _ptr(ix), _ptr(lens),
                                                             blob.ctypes.data_as(C.c_void_p)))
 
+    def wire_set_type_url(self, cell: bool, url: bytes):
+        """merge mode (WIRE | UPDATE_MASKS worlds): Any.type_url of the entity / spatial channel data message"""
+        a = np.frombuffer(url, dtype=np.uint8) if url else np.zeros(1, dtype=np.uint8)
+        _lib.check(self.ctx, self.lib.chd_wire_set_type_url(self.ctx, 1 if cell else 0, a.ctypes.data_as(C.c_void_p), len(url)))
+
     def wire_build(self):
         """Builds the per-connection packet streams of the last tick on the device: (bytes, packets, dropped)."""
         tb, tp, dr = C.c_uint64(0), C.c_uint64(0), C.c_uint32(0)

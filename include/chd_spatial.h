@@ -505,6 +505,22 @@ int chd_adjacent_recipients(chd_ctx *ctx, uint32_t n_req, const uint32_t *channe
 int chd_wire_set_payloads(chd_ctx *ctx, int kind, uint32_t n, const uint32_t *idx,
                           const uint32_t *lens, const uint8_t *bytes);
 
+/* Worlds with CHD_WORLD_WIRE | CHD_WORLD_UPDATE_MASKS build the MERGED update of every fan-out message on the device
+ * (data.go:225-269: tickData merges the buffered updates a subscriber's window selects — a 100 ms
+ * subscriber of a 50 ms world gets two ticks' deltas in one message).  In such a world
+ *   - the UPDATE payload kinds (CHD_WIRE_ENTITY_UPDATE, CHD_WIRE_CELL_UPDATE) are the serialized channel-data update
+ *     MESSAGES themselves (not wrapped in Any); a payload set between two ticks belongs to the update that arrives
+ *     with the NEXT chd_tick; the engine keeps the last 32 ticks' payloads per channel;
+ *   - chd_wire_set_type_url gives the Any.type_url of the entity (cell = 0) / spatial (cell = 1) channel data message
+ *     ("type.googleapis.com/..." as anypb.New writes it);
+ *   - a message's data field is Any{type_url, value = the selected updates, oldest first, concatenated}.  A protobuf
+ *     parser reads concatenated messages as their merge (proto.Merge semantics: last scalar wins, repeated fields
+ *     append, sub-messages merge), so the receiver decodes what the reference's accumulated message decodes to whenever
+ *     the channel data type uses the default merge; the BYTES differ from Go's re-marshalled merge (fields repeat), and
+ *     custom Merge implementations / ChannelDataMergeOptions (list limits, removable map entries) stay with the host.
+ *   The FULL payload kinds stay whole Any messages. */
+int chd_wire_set_type_url(chd_ctx *ctx, int cell, const uint8_t *url, uint32_t len);
+
 /* replaces, for every connection at once: queuedMessagePackSender.Send (connection.go:57-83:
  * MessagePack{ChannelId, MsgType: CHANNEL_DATA_UPDATE, MsgBody: ChannelDataUpdateMessage{Data}},
  * packs of 65530 bytes or more are dropped) and flush (connection.go:626-714: greedy Packets of

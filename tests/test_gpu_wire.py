@@ -117,3 +117,70 @@ def test_wire_benchmark_grid_position_updates(amd):
     tb, tp, td = run_wire(amd, "spatial_static_benchmark.json", 3000, 60, 5, 0xC0FFEE44, CONN_MAJOR,
                           upd_len=lambda: 66, full_len=lambda: rng.integers(100, 400))
     assert tb > 1_000_000 and td == 0
+
+
+def test_wire_merged_updates_for_slow_subscribers(amd):
+    """SURVEY 8f-3 on the device: a WIRE | UPDATE_MASKS world builds every message from the buffered updates the
+    subscriber's window selected (data.go:225-269) — Any{type_url, value = those updates' bytes, oldest first}.  Sparse
+    updates and 70 ms ticks so that 20 / 50 / 100 ms subscriptions merge different sets (one, two, three ticks' updates,
+    per sender); the expected streams are composed from the per-record masks (whose parity with the reference's buffer
+    walk tests/test_gpu_world.py establishes) and the host's own history of payloads, through the pinned wire oracle."""
+    MASKS = 32
+    cfg = synth.load_config("spatial_static_4x4.json")
+    N, S = 500, 24
+    sw = synth.SynthWorld(synth.WorldSpec(cfg, N, S, 0xC0FFEE45, tick_ms=70))
+    ctl = amd.StaticGrid2DSpatialController()
+    assert ctl.LoadConfig(json.dumps(cfg).encode(), strict=False) is None
+    w = amd.SpatialWorld(ctl, N, S, flags=CONN_MAJOR | WIRE | MASKS, max_records=1 << 21, wire_max_update_len=64, wire_max_full_len=256)
+    w.spawn(None, sw.chan_id, sw.x, sw.z, sw.flags, sw.sender)
+    w.add_subscribers(None, sw.sub_conn)
+    rng = np.random.default_rng(45)
+    ncell = ctl.GridCols * ctl.GridRows
+    url_e, url_c = b"type.googleapis.com/tpspb.EntityChannelData", b"type.googleapis.com/unrealpb.SpatialChannelData"
+    w.wire_set_type_url(False, url_e)
+    w.wire_set_type_url(True, url_c)
+    full_e = {i: any_bytes(rng, rng.integers(20, 200)) for i in range(N)}
+    full_c = {0x10000 + c: any_bytes(rng, rng.integers(20, 200)) for c in range(ncell)}
+    w.wire_set_payloads(ENT_FULL, list(full_e), list(full_e.values()))
+    w.wire_set_payloads(CELL_FULL, list(full_c), list(full_c.values()))
+    upd_e, upd_c = {}, {}   # (entity slot | channel id, tick index) -> the update message's bytes
+    merged2 = merged3 = 0
+    for k in range(14):
+        sw.step()
+        idx = np.sort(rng.choice(N, N // 2, replace=False)).astype(np.uint32) if k % 3 else np.arange(N, dtype=np.uint32)
+        pay = [any_bytes(rng, rng.integers(0, 60)) for _ in idx]
+        for i, b in zip(idx, pay):
+            upd_e[(int(i), k)] = b
+        w.wire_set_payloads(ENT_UPD, idx, pay)
+        cu = np.unique(0x10000 + rng.integers(0, ncell, 4)).astype(np.uint32)
+        cpay = [any_bytes(rng, rng.integers(1, 40)) for _ in cu]
+        for c, b in zip(cu, cpay):
+            upd_c[(int(c), k)] = b
+        w.wire_set_payloads(CELL_UPD, cu, cpay)
+        res = w.tick(sw.now_ns(), upd_idx=idx, upd_x=sw.x[idx], upd_z=sw.z[idx], queries=sw.queries(), cell_upd_channel=cu,
+                     cell_upd_sender=np.full(len(cu), 5, dtype=np.uint32), records_cap=1 << 21)
+        assert res.overflow == 0 and res.history_overflow == 0
+        nbytes, npackets, ndropped = w.wire_build()
+        off, npk, data = w.wire_fetch()
+        assert int(off[S]) == nbytes == len(data) and ndropped == 0
+        for s in range(S):
+            a, n = int(res.conn_rec_off[s]), int(res.conn_rec_cnt[s])
+            packs = []
+            for r, mask in zip(res.records[a:a + n], res.record_masks[a:a + n]):
+                ch, full = int(r["channel"]), int(r["conn"]) >> 31
+                if full:
+                    body = full_c[ch] if ch < 0x80000 else full_e[ch - 0x80000]
+                else:
+                    bits = [j for j in range(31, -1, -1) if (int(mask) >> j) & 1]  # oldest update first
+                    assert bits, "a delta record merges at least one buffered update"
+                    src, key, url = (upd_c, ch, url_c) if ch < 0x80000 else (upd_e, ch - 0x80000, url_e)
+                    value = b"".join(src[(key, k - j)] for j in bits)
+                    body = wire.field_bytes(1, url) + (wire.field_bytes(2, value) if value else b"")
+                    merged2 += len(bits) == 2
+                    merged3 += len(bits) >= 3
+                packs.append(wire.fanout_message_pack(ch, body))
+            want, counts = wire.flush_stream(packs)
+            got = data[int(off[s]):int(off[s + 1])].tobytes()
+            assert got == want, f"tick {k} slot {s}: merged stream bytes ({len(got)} vs {len(want)})"
+            assert int(npk[s]) == len(counts)
+    assert merged2 > 1000 and merged3 > 10  # windows that merged two / three and more ticks' updates were exercised

@@ -133,3 +133,53 @@ def test_streams_walk_with_the_receivers_rule(name):
     assert i == len(stream)
     if counts is not None:
         assert n_packets == len(counts)
+
+
+def test_concatenated_updates_decode_as_their_merge():
+    """What the device's merged-update messages rely on (include/chd_spatial.h): parsing the concatenation of
+    serialized messages gives proto.Merge of them in order — last scalar wins, repeated fields append, sub-messages and
+    map entries merge — which is how tickData accumulates the buffered updates (data.go:249-253, proto.Merge / the default
+    ReflectMerge).  Checked with python-protobuf on a message type built here (scalars, a nested message, a repeated
+    field, a map), over random update sequences."""
+    from google.protobuf import descriptor_pb2, descriptor_pool, message_factory
+
+    fd = descriptor_pb2.FileDescriptorProto(name="chd_merge_test.proto", package="chdtest", syntax="proto3")
+    vec = fd.message_type.add(name="Vec")
+    for i, n in enumerate(("x", "y", "z")):
+        vec.field.add(name=n, number=i + 1, type=descriptor_pb2.FieldDescriptorProto.TYPE_FLOAT, label=1)
+    st = fd.message_type.add(name="State")
+    st.field.add(name="pos", number=1, type=11, type_name=".chdtest.Vec", label=1)
+    st.field.add(name="health", number=2, type=descriptor_pb2.FieldDescriptorProto.TYPE_UINT32, label=1)
+    st.field.add(name="name", number=3, type=descriptor_pb2.FieldDescriptorProto.TYPE_STRING, label=1)
+    st.field.add(name="tags", number=4, type=descriptor_pb2.FieldDescriptorProto.TYPE_UINT32, label=3)
+    ent = st.nested_type.add(name="AttrEntry")
+    ent.options.map_entry = True
+    ent.field.add(name="key", number=1, type=descriptor_pb2.FieldDescriptorProto.TYPE_UINT32, label=1)
+    ent.field.add(name="value", number=2, type=11, type_name=".chdtest.Vec", label=1)
+    st.field.add(name="attr", number=5, type=11, type_name=".chdtest.State.AttrEntry", label=3)
+    pool = descriptor_pool.DescriptorPool()
+    pool.Add(fd)
+    State = message_factory.GetMessageClass(pool.FindMessageTypeByName("chdtest.State"))
+    rng = np.random.default_rng(3)
+    for trial in range(200):
+        updates = []
+        for _ in range(int(rng.integers(1, 5))):
+            u = State()
+            if rng.random() < 0.7:
+                u.pos.x = float(rng.random())
+                if rng.random() < 0.5:
+                    u.pos.z = float(rng.random())
+            if rng.random() < 0.4:
+                u.health = int(rng.integers(0, 100))
+            if rng.random() < 0.3:
+                u.name = "n%d" % rng.integers(0, 9)
+            u.tags.extend(int(v) for v in rng.integers(0, 9, int(rng.integers(0, 3))))
+            for key in rng.integers(0, 4, int(rng.integers(0, 3))):
+                u.attr[int(key)].y = float(rng.random())
+            updates.append(u)
+        acc = State()
+        for u in updates:
+            acc.MergeFrom(u)  # proto.Merge
+        got = State()
+        got.ParseFromString(b"".join(u.SerializeToString() for u in updates))
+        assert got == acc, trial
