@@ -122,13 +122,13 @@ def test_wire_benchmark_grid_position_updates(amd):
 def test_wire_merged_updates_for_slow_subscribers(amd):
     """SURVEY 8f-3 on the device: a WIRE | UPDATE_MASKS world builds every message from the buffered updates the
     subscriber's window selected (data.go:225-269) — Any{type_url, value = those updates' bytes, oldest first}.  Sparse
-    updates and 70 ms ticks so that 20 / 50 / 100 ms subscriptions merge different sets (one, two, three ticks' updates,
-    per sender); the expected streams are composed from the per-record masks (whose parity with the reference's buffer
+    updates and 33 ms ticks so that 20 / 50 / 100 ms subscriptions merge different sets (one, two, three or four ticks'
+    updates); the expected streams are composed from the per-record masks (whose parity with the reference's buffer
     walk tests/test_gpu_world.py establishes) and the host's own history of payloads, through the pinned wire oracle."""
     MASKS = 32
     cfg = synth.load_config("spatial_static_4x4.json")
     N, S = 500, 24
-    sw = synth.SynthWorld(synth.WorldSpec(cfg, N, S, 0xC0FFEE45, tick_ms=70))
+    sw = synth.SynthWorld(synth.WorldSpec(cfg, N, S, 0xC0FFEE45, tick_ms=33))
     ctl = amd.StaticGrid2DSpatialController()
     assert ctl.LoadConfig(json.dumps(cfg).encode(), strict=False) is None
     w = amd.SpatialWorld(ctl, N, S, flags=CONN_MAJOR | WIRE | MASKS, max_records=1 << 21, wire_max_update_len=64, wire_max_full_len=256)
