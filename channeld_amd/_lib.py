@@ -26,7 +26,7 @@ WORLD_WIRE = 8
 WORLD_OVERLAP_INTEREST = 16
 WORLD_UPDATE_MASKS = 32
 WORLD_ONE_WAVE_EMIT = 64
-WIRE_ENTITY_UPDATE, WIRE_ENTITY_FULL, WIRE_CELL_UPDATE, WIRE_CELL_FULL = 0, 1, 2, 3
+WIRE_ENTITY_UPDATE, WIRE_ENTITY_FULL, WIRE_CELL_UPDATE, WIRE_CELL_FULL, WIRE_ENTITY_OBJREF = 0, 1, 2, 3, 4
 HO_SRC_ONLY, HO_DST_NEW, HO_DST_KNOWN = 0, 1, 2
 BROADCAST_ALL_BUT_SENDER, BROADCAST_ALL_BUT_OWNER, BROADCAST_ALL_BUT_CLIENT, BROADCAST_ALL_BUT_SERVER = 4, 8, 16, 32
 BROADCAST_ADJACENT_CHANNELS = 64
@@ -47,7 +47,7 @@ SYMBOLS = (
     "chd_set_stream", "chd_shard_spawn", "chd_shard_ingest", "chd_shard_import", "chd_shard_fanout",
     "chd_shard_get_entities", "chd_shard_table_bytes", "chd_shard_interest",
     "chd_handover_recipients", "chd_adjacent_recipients", "chd_wire_set_payloads", "chd_wire_build", "chd_wire_fetch",
-    "chd_tick_digest", "chd_host_alloc", "chd_host_free", "chd_subs_set_options", "chd_subs_get_options", "chd_world_set_entity_groups", "chd_wire_set_type_url",
+    "chd_tick_digest", "chd_host_alloc", "chd_host_free", "chd_subs_set_options", "chd_subs_get_options", "chd_world_set_entity_groups", "chd_wire_set_type_url", "chd_handover_messages",
 )
 
 
@@ -219,6 +219,7 @@ def load():
     L.chd_shard_get_entities.argtypes = [C.c_void_p, _u32p, _u32p, _u32p, P(C.c_uint32)]
     L.chd_wire_set_payloads.argtypes = [C.c_void_p, C.c_int, C.c_uint32, _u32p, _u32p, _u8p]
     L.chd_wire_set_type_url.argtypes = [C.c_void_p, C.c_int, _u8p, C.c_uint32]
+    L.chd_handover_messages.argtypes = [C.c_void_p, _u32p, _u8p, C.c_uint64, P(C.c_uint64)]
     L.chd_wire_build.argtypes = [C.c_void_p, P(C.c_uint64), P(C.c_uint64), P(C.c_uint32)]
     L.chd_wire_fetch.argtypes = [C.c_void_p, _u64p, _u32p, _u8p, C.c_uint64]
     L.chd_handover_recipients.argtypes = [C.c_void_p, _u32p, _u32p, _u8p, C.c_uint64, P(C.c_uint64)]

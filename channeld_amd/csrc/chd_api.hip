@@ -785,6 +785,9 @@ int chd_world_create(chd_ctx *ctx, const chd_world_cfg *cfg) {
             TRY(walloc(ctx, &x.url[0], 256));
             TRY(walloc(ctx, &x.url[1], 256));
         }
+        TRY(walloc(ctx, &x.url[2], 256));
+        TRY(walloc(ctx, &x.pay_objref, N * x.stride[0]));
+        TRY(walloc(ctx, &x.len_objref, N));
         TRY(walloc(ctx, &x.conn_wlen, S + 1));
         x.conn_woff = x.conn_wlen;
         TRY(walloc(ctx, &x.conn_npk, S));
@@ -1538,10 +1541,11 @@ int chd_wire_set_payloads(chd_ctx *ctx, int kind, uint32_t n, const uint32_t *id
     NEED_WORLD();
     World &W = ctx->w;
     if (!W.wire) return fail(ctx, CHD_E_STATE, "the world was created without CHD_WORLD_WIRE");
-    if (kind < 0 || kind > 3) return fail(ctx, CHD_E_INVAL, "chd_wire_set_payloads: kind %d", kind);
+    if (kind < 0 || kind > CHD_WIRE_ENTITY_OBJREF) return fail(ctx, CHD_E_INVAL, "chd_wire_set_payloads: kind %d", kind);
     if (!n) return CHD_OK;
     if (!idx || !lens) return fail(ctx, CHD_E_INVAL, "chd_wire_set_payloads: NULL buffer");
-    const int full = kind & 1, cell = kind >> 1;
+    const bool objref = kind == CHD_WIRE_ENTITY_OBJREF;
+    const int full = objref ? 0 : (kind & 1), cell = objref ? 0 : (kind >> 1);
     std::vector<uint64_t> off(n);
     std::vector<uint32_t> ix(n);
     uint64_t total = 0;
@@ -1569,7 +1573,7 @@ int chd_wire_set_payloads(chd_ctx *ctx, int kind, uint32_t n, const uint32_t *id
     TRY(up(ctx, sbuf<void>(ctx, 2), off.data(), 8 * (size_t)n));
     TRY(up(ctx, sbuf<void>(ctx, 3), bytes, total));
     // (merge mode: an UPDATE payload set now belongs to the update that arrives with the NEXT tick)
-    launch_wire_set_payloads(ctx->stream, W.x, full, cell, n, cell ? ctx->g.ncell : W.d.N, sbuf<uint32_t>(ctx, 0),
+    launch_wire_set_payloads(ctx->stream, W.x, objref ? 2 : full, cell, n, cell ? ctx->g.ncell : W.d.N, sbuf<uint32_t>(ctx, 0),
                              sbuf<uint32_t>(ctx, 1), sbuf<uint64_t>(ctx, 2), sbuf<uint8_t>(ctx, 3),
                              (ctx->ring.cur_tick + 1u) & (CHD_HIST_BITS - 1u));
     TRY(after_launch(ctx));
@@ -1577,16 +1581,50 @@ int chd_wire_set_payloads(chd_ctx *ctx, int kind, uint32_t n, const uint32_t *id
     return CHD_OK;
 }
 
-int chd_wire_set_type_url(chd_ctx *ctx, int cell, const uint8_t *url, uint32_t len) {
+int chd_wire_set_type_url(chd_ctx *ctx, int which, const uint8_t *url, uint32_t len) {
     NEED_WORLD();
     World &W = ctx->w;
-    if (!W.wire || !W.x.merge) return fail(ctx, CHD_E_STATE, "type urls belong to worlds with CHD_WORLD_WIRE | CHD_WORLD_UPDATE_MASKS");
+    if (!W.wire) return fail(ctx, CHD_E_STATE, "the world was created without CHD_WORLD_WIRE");
+    if (which < 0 || which > 2) return fail(ctx, CHD_E_INVAL, "chd_wire_set_type_url: which = %d", which);
+    if (which < 2 && !W.x.merge) return fail(ctx, CHD_E_STATE, "update type urls belong to worlds with CHD_WORLD_WIRE | CHD_WORLD_UPDATE_MASKS");
     if (len > 255 || (len && !url)) return fail(ctx, CHD_E_INVAL, "chd_wire_set_type_url: at most 255 bytes");
     std::lock_guard<std::mutex> lk(ctx->mu);
     TRY(bind(ctx));
     HIPCHK(hipStreamSynchronize(ctx->stream));
-    if (len) HIPCHK(hipMemcpy(W.x.url[cell ? 1 : 0], url, len, hipMemcpyHostToDevice));
-    W.x.url_len[cell ? 1 : 0] = len;
+    if (len) HIPCHK(hipMemcpy(W.x.url[which], url, len, hipMemcpyHostToDevice));
+    W.x.url_len[which] = len;
+    return CHD_OK;
+}
+
+int chd_handover_messages(chd_ctx *ctx, uint32_t *offsets, uint8_t *bytes, uint64_t cap, uint64_t *n_out) {
+    NEED_WORLD();
+    if (!offsets || !n_out || (cap && !bytes)) return fail(ctx, CHD_E_INVAL, "chd_handover_messages: NULL buffer");
+    World &W = ctx->w;
+    if (!W.wire) return fail(ctx, CHD_E_STATE, "the world was created without CHD_WORLD_WIRE");
+    if (!W.ticked) return fail(ctx, CHD_E_STATE, "no tick yet");
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    TRY(bind(ctx));
+    uint64_t ringrow[8];
+    TRY(down(ctx, ringrow, W.d.tick_ring + (size_t)(ctx->ring.cur_tick % TICK_RING) * 8, sizeof ringrow));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    const uint32_t nh = std::min<uint32_t>((uint32_t)ringrow[2], W.d.handovers_cap);
+    offsets[0] = 0;
+    *n_out = 0;
+    if (!nh) return CHD_OK;
+    TRY(ensure(ctx, 0, sizeof(uint32_t) * (2 * (size_t)nh + 1)));
+    launch_handover_msg_sizes(ctx->stream, ctx->g, W.d, W.x, nh, sbuf<uint32_t>(ctx, 0));
+    launch_scan_u32_inplace(ctx->stream, sbuf<uint32_t>(ctx, 0), 2 * nh);
+    TRY(after_launch(ctx));
+    TRY(down(ctx, offsets, sbuf<void>(ctx, 0), sizeof(uint32_t) * (2 * (size_t)nh + 1)));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    const uint64_t total = offsets[2 * nh];
+    *n_out = total;
+    if (total > cap) return fail(ctx, CHD_E_CAPACITY, "chd_handover_messages: %llu bytes, capacity %llu", (unsigned long long)total, (unsigned long long)cap);
+    TRY(ensure(ctx, 1, std::max<uint64_t>(total, 16)));
+    launch_handover_msg_write(ctx->stream, ctx->g, W.d, W.x, nh, sbuf<uint32_t>(ctx, 0), sbuf<uint8_t>(ctx, 1), total);
+    TRY(after_launch(ctx));
+    TRY(down(ctx, bytes, sbuf<void>(ctx, 1), total));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
     return CHD_OK;
 }
 

@@ -266,8 +266,10 @@ struct WireDev {
     uint32_t cur_tick;                  // tick of the records being built (ring slot of mask bit j = (cur_tick - j) & 31)
     uint8_t *ring_ent, *ring_cell;      // [N * 32 * stride[0]], [ncell * 32 * stride[0]]
     uint32_t *rlen_ent, *rlen_cell;     // [N * 32], [ncell * 32]
-    uint8_t *url[2];                    // type_url of the entity / spatial channel data message (padded to 4 bytes)
-    uint32_t url_len[2];
+    uint8_t *url[3];                    // type_url of the entity / spatial channel data update message, and of the handover data
+    uint32_t url_len[3];
+    uint8_t *pay_objref;                // [N * stride[0]] serialized UnrealObjectRef per entity (CHD_WIRE_ENTITY_OBJREF)
+    uint32_t *len_objref;               // [N]
     uint32_t *rec_woff;                 // per record: byte offset of its Packet entry in the connection's stream (~0 = dropped)
     uint32_t *rec_wtag;                 // per record: 0, or 0x80000000 | packet length if it opens a packet
     uint64_t *conn_wlen;                // [S+1] stream length per connection -> exclusive scan = conn_woff
@@ -277,6 +279,9 @@ struct WireDev {
     uint8_t *bytes;                     // the wire arena
 };
 void launch_wire_layout(hipStream_t st, WorldDev w, WireDev x);
+// handover message assembly: sizes[2*nh] then, with off = exclusive scan of the sizes, the bytes
+void launch_handover_msg_sizes(hipStream_t st, DevGrid g, WorldDev w, WireDev x, uint32_t nh, uint32_t *sizes);
+void launch_handover_msg_write(hipStream_t st, DevGrid g, WorldDev w, WireDev x, uint32_t nh, const uint32_t *off, uint8_t *out, uint64_t cap);
 void launch_wire_copy(hipStream_t st, WorldDev w, WireDev x);
 void launch_wire_set_payloads(hipStream_t st, WireDev x, int full, int cell, uint32_t n, uint32_t limit, const uint32_t *idx,
                               const uint32_t *lens, const uint64_t *off, const uint8_t *bytes, uint32_t ring_slot);

@@ -363,6 +363,121 @@ void launch_wire_copy(hipStream_t st, WorldDev w, WireDev x) {
     hipLaunchKernelGGL(k_wire_copy, dim3(w.S), dim3(256), 0, st, w, x);
 }
 
+// ---------------------------------------------------------------------------
+// Handover message assembly: what Notify builds for every handover (spatial.go:738-773,797-857).
+// Two blobs per handover (entities with / without their full data, see include/chd_spatial.h); all nested lengths are
+// computed bottom-up by ho_layout, the same routine sizes (k_handover_msg_sizes) and writes (k_handover_msg_write:
+// one wave per blob, header bytes by lane 0, payloads copied by the wave).
+// ---------------------------------------------------------------------------
+#define WIRE_MSG_HANDOVER 12u  // MessageType_CHANNEL_DATA_HANDOVER (channeld.proto:133)
+
+struct HoEnt {  // one entity of the handover: map entry {key = 1: netId, value = 2: SpatialEntityState{objRef = 1, entityData = 3}}
+    uint32_t slot, net_id, ol, fl, state_len, entry_len;
+};
+
+__device__ __forceinline__ HoEnt ho_entity(const WorldDev &w, const WireDev &x, uint32_t slot, bool full) {
+    HoEnt e;
+    e.slot = slot;
+    e.net_id = w.chan_id[slot];
+    e.ol = x.len_objref[slot];
+    e.fl = full ? x.len_ent[1][slot] : 0u;
+    e.state_len = 1u + vlen(e.ol) + e.ol + (full ? 1u + vlen(e.fl) + e.fl : 0u);
+    e.entry_len = (e.net_id ? 1u + vlen(e.net_id) : 0u) + 1u + vlen(e.state_len) + e.state_len;
+    return e;
+}
+
+// members of handover h's entity list: the notifier alone, or the live members of its group
+template <typename F>
+__device__ __forceinline__ void ho_for_each_entity(const WorldDev &w, uint32_t notifier, F f) {
+    const uint32_t gi = w.n_groups ? w.grp_of[notifier] : CHD_INVALID;
+    if (gi == CHD_INVALID) { f(notifier); return; }
+    for (uint32_t q = w.grp_off[gi]; q < w.grp_off[gi + 1]; q++) {
+        const uint32_t m = w.grp_mem[q];
+        if (w.eflags[m] & EF_ALIVE) f(m);
+    }
+}
+
+struct HoLayout { uint32_t sd_len, any_len, hom_len, mp_len, ctx; };
+
+__device__ __forceinline__ HoLayout ho_layout(const DevGrid &g, const WorldDev &w, const WireDev &x, const chd_handover_rec &r, bool full) {
+    HoLayout L;
+    L.sd_len = 0;
+    ho_for_each_entity(w, r.entity, [&](uint32_t m) {
+        const HoEnt e = ho_entity(w, x, m, full);
+        L.sd_len += 1u + vlen(e.entry_len) + e.entry_len;  // SpatialChannelData.entities = 1
+    });
+    const uint32_t ul = x.url_len[2];
+    L.any_len = (ul ? 1u + vlen(ul) + ul : 0u) + (L.sd_len ? 1u + vlen(L.sd_len) + L.sd_len : 0u);
+    L.ctx = w.cell_sender[r.src - g.id_start];  // srcChannel.latestDataUpdateConnId (0 until the channel got an update)
+    L.hom_len = 1u + vlen(r.src) + 1u + vlen(r.dst) + (L.ctx ? 1u + vlen(L.ctx) : 0u) + 1u + vlen(L.any_len) + L.any_len;
+    L.mp_len = 1u + vlen(r.dst) + 2u + 1u + vlen(L.hom_len) + L.hom_len;  // channelId = dst, msgType = 12, msgBody
+    return L;
+}
+
+__global__ void __launch_bounds__(256) k_handover_msg_sizes(DevGrid g, WorldDev w, WireDev x, uint32_t nh, uint32_t *sizes) {
+    const uint32_t b = blockIdx.x * 256u + threadIdx.x;
+    if (b >= 2u * nh) return;
+    sizes[b] = ho_layout(g, w, x, w.handovers[b >> 1], (b & 1u) != 0).mp_len;
+}
+
+__global__ void __launch_bounds__(64) k_handover_msg_write(DevGrid g, WorldDev w, WireDev x, uint32_t nh, const uint32_t *__restrict__ off,
+                                                           uint8_t *__restrict__ out, uint64_t cap) {
+    const uint32_t b = blockIdx.x;
+    if (b >= 2u * nh || off[b + 1] > cap) return;
+    const uint32_t lane = threadIdx.x;
+    const bool full = (b & 1u) != 0;
+    const chd_handover_rec r = w.handovers[b >> 1];
+    const HoLayout L = ho_layout(g, w, x, r, full);
+    uint8_t *o = out + off[b];
+    uint32_t n = 0;
+    if (lane == 0) {
+        o[n++] = 0x08; n = put_varint(o, n, r.dst);                       // MessagePack.channelId = dstChannelId (spatial.go:771)
+        o[n++] = 0x20; o[n++] = (uint8_t)WIRE_MSG_HANDOVER;               // MessagePack.msgType
+        o[n++] = 0x2A; n = put_varint(o, n, L.hom_len);                   // MessagePack.msgBody
+        o[n++] = 0x08; n = put_varint(o, n, r.src);                       // ChannelDataHandoverMessage.srcChannelId
+        o[n++] = 0x10; n = put_varint(o, n, r.dst);                       // .dstChannelId
+        if (L.ctx) { o[n++] = 0x18; n = put_varint(o, n, L.ctx); }        // .contextConnId
+        o[n++] = 0x22; n = put_varint(o, n, L.any_len);                   // .data (Any)
+        const uint32_t ul = x.url_len[2];
+        if (ul) {
+            o[n++] = 0x0A; n = put_varint(o, n, ul);                      // Any.type_url
+            for (uint32_t k = 0; k < ul; k++) o[n++] = x.url[2][k];
+        }
+        if (L.sd_len) { o[n++] = 0x12; n = put_varint(o, n, L.sd_len); }  // Any.value = SpatialChannelData
+    }
+    n = (uint32_t)__shfl((int)n, 0);
+    ho_for_each_entity(w, r.entity, [&](uint32_t m) {
+        const HoEnt e = ho_entity(w, x, m, full);
+        uint32_t k = n;
+        if (lane == 0) {
+            o[k++] = 0x0A; k = put_varint(o, k, e.entry_len);             // SpatialChannelData.entities (map entry)
+            if (e.net_id) { o[k++] = 0x08; k = put_varint(o, k, e.net_id); }  // key
+            o[k++] = 0x12; k = put_varint(o, k, e.state_len);             // value = SpatialEntityState
+            o[k++] = 0x0A; k = put_varint(o, k, e.ol);                    // .objRef
+        }
+        k = (uint32_t)__shfl((int)k, 0);
+        wave_copy_out(o + k, x.pay_objref + (size_t)m * x.stride[0], e.ol, false);
+        k += e.ol;
+        if (full) {
+            uint32_t k2 = k;
+            if (lane == 0) { o[k2++] = 0x1A; k2 = put_varint(o, k2, e.fl); }  // .entityData = Any of the full entity data
+            k = (uint32_t)__shfl((int)k2, 0);
+            wave_copy_out(o + k, x.pay_ent[1] + (size_t)m * x.stride[1], e.fl, false);
+            k += e.fl;
+        }
+        n = k;
+    });
+}
+
+void launch_handover_msg_sizes(hipStream_t st, DevGrid g, WorldDev w, WireDev x, uint32_t nh, uint32_t *sizes) {
+    if (!nh) return;
+    hipLaunchKernelGGL(k_handover_msg_sizes, dim3((2 * nh + 255) / 256), dim3(256), 0, st, g, w, x, nh, sizes);
+}
+void launch_handover_msg_write(hipStream_t st, DevGrid g, WorldDev w, WireDev x, uint32_t nh, const uint32_t *off, uint8_t *out, uint64_t cap) {
+    if (!nh) return;
+    hipLaunchKernelGGL(k_handover_msg_write, dim3(2 * nh), dim3(64), 0, st, g, w, x, nh, off, out, cap);
+}
+
 // payload upload: kind k, entry idx[i] <- lens[i] bytes at bytes + off[i]
 __global__ void __launch_bounds__(256) k_wire_set_payloads(WireDev x, int full, int cell, uint32_t n, uint32_t limit,
                                                            const uint32_t *__restrict__ idx, const uint32_t *__restrict__ lens,
@@ -376,10 +491,13 @@ __global__ void __launch_bounds__(256) k_wire_set_payloads(WireDev x, int full, 
     const uint32_t len = lens[u];
     uint8_t *dst;
     uint32_t *ldst;
-    if (x.merge && !full) {  // this update's slot of the channel's ring
+    if (x.merge && full == 0) {  // this update's slot of the channel's ring
         const size_t e = (size_t)i * CHD_HIST_BITS + ring_slot;
         dst = (cell ? x.ring_cell : x.ring_ent) + e * x.stride[0];
         ldst = (cell ? x.rlen_cell : x.rlen_ent) + e;
+    } else if (full == 2) {  // CHD_WIRE_ENTITY_OBJREF
+        dst = x.pay_objref + (size_t)i * x.stride[0];
+        ldst = x.len_objref + i;
     } else {
         dst = (cell ? x.pay_cell[full] : x.pay_ent[full]) + (size_t)i * x.stride[full];
         ldst = (cell ? x.len_cell[full] : x.len_ent[full]) + i;

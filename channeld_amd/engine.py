@@ -322,10 +322,20 @@ class SpatialWorld:
         _lib.check(self.ctx, self.lib.chd_wire_set_payloads(self.ctx, int(kind), len(ix), _ptr(ix), _ptr(lens),
                                                             blob.ctypes.data_as(C.c_void_p)))
 
-    def wire_set_type_url(self, cell: bool, url: bytes):
-        """merge mode (WIRE | UPDATE_MASKS worlds): Any.type_url of the entity / spatial channel data message"""
+    def wire_set_type_url(self, which, url: bytes):
+        """Any.type_url: which = 0 / False entity update message, 1 / True spatial channel update message (merge mode:
+        WIRE | UPDATE_MASKS worlds), 2 handover data (chd_handover_messages)"""
         a = np.frombuffer(url, dtype=np.uint8) if url else np.zeros(1, dtype=np.uint8)
-        _lib.check(self.ctx, self.lib.chd_wire_set_type_url(self.ctx, 1 if cell else 0, a.ctypes.data_as(C.c_void_p), len(url)))
+        _lib.check(self.ctx, self.lib.chd_wire_set_type_url(self.ctx, int(which), a.ctypes.data_as(C.c_void_p), len(url)))
+
+    def handover_messages(self, n_handovers: int, cap: int = 1 << 24):
+        """The two MessagePacks of every handover of the last tick: [(without entity data, with entity data), ...]"""
+        off = np.zeros(2 * n_handovers + 1, dtype=np.uint32)
+        data = np.zeros(max(cap, 1), dtype=np.uint8)
+        n = C.c_uint64(0)
+        _lib.check(self.ctx, self.lib.chd_handover_messages(self.ctx, _ptr(off), _ptr(data), cap, C.byref(n)))
+        b = data[: n.value].tobytes()
+        return [(b[int(off[2 * h]):int(off[2 * h + 1])], b[int(off[2 * h + 1]):int(off[2 * h + 2])]) for h in range(n_handovers)]
 
     def wire_build(self):
         """Builds the per-connection packet streams of the last tick on the device: (bytes, packets, dropped)."""

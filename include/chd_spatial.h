@@ -502,6 +502,8 @@ int chd_adjacent_recipients(chd_ctx *ctx, uint32_t n_req, const uint32_t *channe
 #define CHD_WIRE_ENTITY_FULL 1
 #define CHD_WIRE_CELL_UPDATE 2
 #define CHD_WIRE_CELL_FULL 3
+#define CHD_WIRE_ENTITY_OBJREF 4 /* serialized unrealpb.UnrealObjectRef of the entity (idx = entity slots; at most wire_max_update_len
+                                   bytes): what MergeTo puts into SpatialEntityState.objRef (chd_handover_messages) */
 int chd_wire_set_payloads(chd_ctx *ctx, int kind, uint32_t n, const uint32_t *idx,
                           const uint32_t *lens, const uint8_t *bytes);
 
@@ -519,7 +521,23 @@ int chd_wire_set_payloads(chd_ctx *ctx, int kind, uint32_t n, const uint32_t *id
  *     the channel data type uses the default merge; the BYTES differ from Go's re-marshalled merge (fields repeat), and
  *     custom Merge implementations / ChannelDataMergeOptions (list limits, removable map entries) stay with the host.
  *   The FULL payload kinds stay whole Any messages. */
-int chd_wire_set_type_url(chd_ctx *ctx, int cell, const uint8_t *url, uint32_t len);
+int chd_wire_set_type_url(chd_ctx *ctx, int which /* 0 entity data, 1 spatial channel data updates, 2 handover data */,
+                          const uint8_t *url, uint32_t len);
+
+/* replaces: the message assembly of Notify (spatial.go:738-773,797-857; HandoverDataMerger.MergeTo,
+ * examples/channeld-ue-tps/tpspb/data.go:323-347): for every handover of the LAST tick the two MessagePacks the
+ * reference sends — ChannelDataHandoverMessage{srcChannelId, dstChannelId, contextConnId = the src channel's
+ * latestDataUpdateConnId, data = Any{type_url (which = 2), SpatialChannelData{entities}}} behind MessageContext{MsgType
+ * CHANNEL_DATA_HANDOVER, ChannelId = dstChannelId}:
+ *   blob 2h     entities carry their objRef only — for the recipients of kind CHD_HO_SRC_ONLY and CHD_HO_DST_KNOWN;
+ *   blob 2h + 1 entities also carry entityData = the entity's full state Any (CHD_WIRE_ENTITY_FULL) — for CHD_HO_DST_NEW
+ *               (`shouldSend`: the connection was just subscribed to the entity channel).
+ * The message does not depend on the recipient otherwise, so chd_handover_recipients says who gets which blob and the
+ * host queues the same bytes for each of them.  The entities of a handover = the notifying entity, or all live
+ * members of its handover group (chd_world_set_entity_groups), each as one map entry {netId = its entity channel id}.
+ * Needs CHD_WORLD_WIRE | CHD_WORLD_HANDOVER_RECIPIENTS, the CHD_WIRE_ENTITY_OBJREF / CHD_WIRE_ENTITY_FULL payloads
+ * and the type url.  offsets has 2 * n_handovers + 1 entries. */
+int chd_handover_messages(chd_ctx *ctx, uint32_t *offsets, uint8_t *bytes, uint64_t cap, uint64_t *n_out);
 
 /* replaces, for every connection at once: queuedMessagePackSender.Send (connection.go:57-83:
  * MessagePack{ChannelId, MsgType: CHANNEL_DATA_UPDATE, MsgBody: ChannelDataUpdateMessage{Data}},

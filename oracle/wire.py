@@ -62,6 +62,32 @@ def fanout_message_pack(channel_id: int, any_bytes: bytes) -> bytes:
     return message_pack(channel_id, MSG_CHANNEL_DATA_UPDATE, channel_data_update(any_bytes))
 
 
+MSG_CHANNEL_DATA_HANDOVER = 12  # channeld.proto:133
+
+
+def spatial_entity_state(obj_ref: bytes, entity_data_any: bytes = None) -> bytes:
+    """unrealpb.SpatialEntityState (unreal_common.proto:138-143): objRef = 1 (always set by MergeTo, tpspb/data.go:329-331),
+    removed = 2 (false: not emitted), entityData = 3 (the Any of the full entity channel data, only when fullData)."""
+    return field_bytes(1, obj_ref) + (field_bytes(3, entity_data_any) if entity_data_any is not None else b"")
+
+
+def spatial_channel_data(entries) -> bytes:
+    """unrealpb.SpatialChannelData{entities: map<uint32, SpatialEntityState>} (:145-147): one map-entry sub-message
+    {key = 1, value = 2} per (net id, SpatialEntityState bytes), in the order given (Go's map order is random; any order
+    decodes to the same message)."""
+    return b"".join(field_bytes(1, field_varint(1, net_id) + field_bytes(2, state)) for net_id, state in entries)
+
+
+def handover_message_pack(src: int, dst: int, context_conn_id: int, type_url: bytes, entries) -> bytes:
+    """The MessagePack Notify sends for one handover (spatial.go:738-773,797-857): ChannelDataHandoverMessage{srcChannelId = 1,
+    dstChannelId = 2, contextConnId = 3, data = 4: Any(SpatialChannelData)} (channeld.proto:416-425) inside
+    MessageContext{MsgType: CHANNEL_DATA_HANDOVER, ChannelId: dstChannelId} (:763-773)."""
+    sd = spatial_channel_data(entries)
+    any_bytes = (field_bytes(1, type_url) if type_url else b"") + (field_bytes(2, sd) if sd else b"")
+    hom = field_varint(1, src) + field_varint(2, dst) + field_varint(3, context_conn_id) + field_bytes(4, any_bytes)
+    return message_pack(dst, MSG_CHANNEL_DATA_HANDOVER, hom)
+
+
 def frame(packet_bytes: bytes, compression: int = 0) -> bytes:
     n = len(packet_bytes)
     assert n <= MAX_PACKET_SIZE

@@ -184,3 +184,63 @@ def test_wire_merged_updates_for_slow_subscribers(amd):
             assert got == want, f"tick {k} slot {s}: merged stream bytes ({len(got)} vs {len(want)})"
             assert int(npk[s]) == len(counts)
     assert merged2 > 1000 and merged3 > 10  # windows that merged two / three and more ticks' updates were exercised
+
+
+def test_handover_messages_on_the_device(amd):
+    """chd_handover_messages builds, per handover of the tick, the two MessagePacks Notify sends
+    (spatial.go:738-857) — ChannelDataHandoverMessage{src, dst, contextConnId, Any{SpatialChannelData{entities}}} with and
+    without the entities' full data — from the host's per-entity UnrealObjectRef / full-state payloads.  Compared byte
+    for byte with oracle/wire.py's composition (pinned to the reference's descriptors by tests/test_wire_oracle.py), for
+    lone entities and for handover groups; chd_handover_recipients says who gets which of the two."""
+    RECIPIENTS = 4
+    cfg = synth.load_config("spatial_static_4x4.json")
+    N, S = 600, 32
+    sw = synth.SynthWorld(synth.WorldSpec(cfg, N, S, 0xC0FFEE46, outside_frac=0.0, locked_frac=0.0))
+    ctl = amd.StaticGrid2DSpatialController()
+    assert ctl.LoadConfig(json.dumps(cfg).encode(), strict=False) is None
+    w = amd.SpatialWorld(ctl, N, S, flags=CONN_MAJOR | WIRE | RECIPIENTS, max_records=1 << 21, wire_max_update_len=96, wire_max_full_len=512)
+    # groups of two among the first 100 entities: the rider copies the leader's position
+    x0, z0 = sw.x.copy(), sw.z.copy()
+    x0[1:100:2], z0[1:100:2] = x0[0:100:2], z0[0:100:2]
+    w.spawn(None, sw.chan_id, x0, z0, sw.flags, sw.sender)
+    w.add_subscribers(None, sw.sub_conn)
+    gidx = np.arange(100, dtype=np.uint32)
+    w.set_entity_groups(gidx, 500 + gidx // 2)
+    rng = np.random.default_rng(46)
+    url = b"type.googleapis.com/unrealpb.SpatialChannelData"
+    w.wire_set_type_url(2, url)
+    objref = {i: any_bytes(rng, rng.integers(0, 90)) for i in range(N)}
+    full = {i: any_bytes(rng, rng.integers(10, 500)) for i in range(N)}
+    w.wire_set_payloads(4, list(objref), list(objref.values()))
+    w.wire_set_payloads(ENT_FULL, list(full), list(full.values()))
+    ncell = ctl.GridCols * ctl.GridRows
+    last_sender = {}
+    n_total = n_group = n_ctx = 0
+    for k in range(10):
+        sw.step()
+        jump = rng.random(N) < 0.1
+        sw.x = np.where(jump, np.float64(np.float32(sw.offx + rng.random(N) * sw.W * 0.999)), sw.x)
+        sw.x[1:100:2], sw.z[1:100:2] = sw.x[0:100:2], sw.z[0:100:2]
+        cu = np.unique(0x10000 + rng.integers(0, ncell, 5)).astype(np.uint32)
+        cs = rng.integers(1, 400, len(cu)).astype(np.uint32)
+        res = w.tick(sw.now_ns(), upd_x=sw.x, upd_z=sw.z, queries=sw.queries(), cell_upd_channel=cu, cell_upd_sender=cs, records_cap=1 << 21)
+        for c, s_ in zip(cu, cs):
+            last_sender[int(c)] = int(s_)  # srcChannel.latestDataUpdateConnId
+        nh = len(res.handovers)
+        msgs = w.handover_messages(nh)
+        assert len(msgs) == nh
+        for h, (ref_only, with_data) in zip(res.handovers, msgs):
+            e = int(h["entity"])
+            members = [e] if e >= 100 else [e & ~1, (e & ~1) + 1]  # group members in slot order (both alive)
+            ctx = last_sender.get(int(h["src"]), 0)
+            for blob, fulls in ((ref_only, False), (with_data, True)):
+                entries = [(int(sw.chan_id[m]), wire.spatial_entity_state(objref[m], full[m] if fulls else None)) for m in members]
+                want = wire.handover_message_pack(int(h["src"]), int(h["dst"]), ctx, url, entries)
+                assert blob == want, f"tick {k} entity {e} full={fulls}: {len(blob)} vs {len(want)} bytes"
+            n_total += 1
+            n_group += len(members) == 2
+            n_ctx += ctx != 0
+        # and the recipients still line up with the handover list
+        off, conn, kind = w.handover_recipients(nh)
+        assert len(off) == nh + 1 and int(off[-1]) == len(conn) == len(kind)
+    assert n_total > 100 and n_group > 5 and n_ctx > 5

@@ -183,3 +183,28 @@ def test_concatenated_updates_decode_as_their_merge():
         got = State()
         got.ParseFromString(b"".join(u.SerializeToString() for u in updates))
         assert got == acc, trial
+
+
+def test_handover_message_oracle_matches_the_reference_schema():
+    """oracle/wire.py's handover_message_pack (the restatement the GPU handover-message tests compare with) against
+    MessagePack{ChannelDataHandoverMessage{Any{unrealpb.SpatialChannelData}}} serialized with the reference's own
+    descriptors (tests/golden/make_handover_golden.py): 24 single-entity handovers with / without entityData, zero and
+    multi-byte contextConnId and net ids, an empty objRef; and a two-entity (handover group) message."""
+    import os
+
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "handover_msgs.npz"))
+    url = g["type_url"].tobytes()
+
+    def split(prefix):
+        lens, blob = g[prefix + "_len"], g[prefix + "_bytes"].tobytes()
+        off = np.concatenate([[0], np.cumsum(lens)]).astype(int)
+        return [blob[off[i]:off[i + 1]] for i in range(len(lens))]
+
+    objrefs, anys, packs = split("objref"), split("any"), split("pack")
+    for i in range(len(packs)):
+        state = wire.spatial_entity_state(objrefs[i], anys[i] if g["full"][i] else None)
+        got = wire.handover_message_pack(int(g["src"][i]), int(g["dst"][i]), int(g["ctx"][i]), url, [(int(g["net"][i]), state)])
+        assert got == packs[i], i
+    grefs = split("group_objref")
+    got = wire.handover_message_pack(0x10001, 0x10002, 0, url, [(0x80010, wire.spatial_entity_state(grefs[0])), (0x80020, wire.spatial_entity_state(grefs[1]))])
+    assert got == g["group_pack"].tobytes()
