@@ -77,7 +77,7 @@ def main():
     for nid in (0x80010, 0x80020):
         sd.entities[nid].objRef.netGUID = nid
     data = AnyCls()
-    data.Pack(sd, type_url_prefix="type.googleapis.com/")
+    data.Pack(sd, type_url_prefix="type.googleapis.com/", deterministic=True)  # (map entries in key order; Go's order is random)
     hom = Handover(srcChannelId=0x10001, dstChannelId=0x10002, data=data)
     out["group_pack"] = np.frombuffer(MessagePack(channelId=0x10002, msgType=12, msgBody=hom.SerializeToString(deterministic=True)).SerializeToString(), dtype=np.uint8)
     out["group_objrefs"] = np.array([ObjRef(netGUID=nid).SerializeToString() for nid in (0x80010, 0x80020)], dtype=object)
