@@ -45,7 +45,7 @@ SYMBOLS = (
     "chd_world_get_entities", "chd_dev_alloc", "chd_dev_free", "chd_dev_upload",
     "chd_dev_download", "chd_set_profiling", "chd_get_tick_stats", "chd_get_tick_history",
     "chd_set_stream", "chd_shard_spawn", "chd_shard_ingest", "chd_shard_import", "chd_shard_fanout",
-    "chd_shard_get_entities", "chd_shard_table_bytes", "chd_shard_interest",
+    "chd_shard_get_entities", "chd_shard_halo_layout", "chd_shard_interest",
     "chd_handover_recipients", "chd_adjacent_recipients", "chd_wire_set_payloads", "chd_wire_build", "chd_wire_fetch",
     "chd_tick_digest", "chd_host_alloc", "chd_host_free", "chd_subs_set_options", "chd_subs_get_options", "chd_world_set_entity_groups", "chd_wire_set_type_url", "chd_handover_messages",
 )
@@ -158,6 +158,10 @@ class SubOptions(C.Structure):
                 ("skip_self_update_fanout", C.c_uint32), ("skip_first_fanout", C.c_uint32)]
 
 
+class HaloSeg(C.Structure):
+    _fields_ = [("send_off", C.c_uint64), ("send_bytes", C.c_uint64), ("recv_off", C.c_uint64), ("recv_bytes", C.c_uint64)]
+
+
 class RecordsDigest(C.Structure):
     _fields_ = [("count", C.c_uint64), ("sum", C.c_uint64), ("xor_", C.c_uint64), ("sum_masked", C.c_uint64)]
 
@@ -212,7 +216,7 @@ def load():
     L.chd_shard_spawn.argtypes = [C.c_void_p, C.c_uint32, _u32p, _f64p, _f64p, _u32p, _u32p]
     L.chd_shard_ingest.argtypes = [C.c_void_p, C.c_int64, _f64p, _f64p, _u8p, C.c_uint32, C.c_uint32, C.c_uint32,
                                    _vp, C.c_uint32]
-    L.chd_shard_table_bytes.argtypes = [C.c_void_p, P(C.c_uint64)]
+    L.chd_shard_halo_layout.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, P(HaloSeg), P(C.c_uint64), P(C.c_uint64)]
     L.chd_shard_import.argtypes = [C.c_void_p, _vp, C.c_uint32, C.c_uint32, _vp]
     L.chd_shard_fanout.argtypes = [C.c_void_p, _vp, C.c_uint32, P(TickIn)]
     L.chd_shard_interest.argtypes = [C.c_void_p, P(TickIn)]

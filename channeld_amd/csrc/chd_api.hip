@@ -43,6 +43,10 @@ struct World {
     WireDev x{};
     uint64_t wire_cap = 0;             // bytes allocated for x.bytes
     bool wire_built = false;
+    // region-sharded worlds: halo exchange layout (chd_shard_halo_layout)
+    uint32_t halo_rank = 0, halo_world = 0;
+    uint64_t *d_halo_send_off = nullptr, *d_halo_recv_off = nullptr;  // [world] segment offsets on the device
+    uint32_t *d_ghost_off = nullptr;                                   // [world] first ghost entry of each source rank
     std::vector<uint32_t> group_id;    // host copy: handover group id per entity slot (0 = none), chd_world_set_entity_groups
     void *grp_buf[4] = {nullptr, nullptr, nullptr, nullptr};  // device arrays behind WorldDev::grp_*
     bool plan_recipients = false;      // CHD_WORLD_HANDOVER_RECIPIENTS
@@ -695,6 +699,8 @@ int chd_world_create(chd_ctx *ctx, const chd_world_cfg *cfg) {
         d.emit_grid = (uint32_t)std::max(prop.multiProcessorCount, 1) * 4u;  // 4 workgroups of ~37 KB LDS per CU
     }
     TRY(walloc(ctx, &d.cell_tab, 2 * C));
+    d.cell_cov = nullptr;  // (region-sharded worlds allocate it with the ghost room, chd_shard_halo_layout)
+    d.ghost_cap = 0;
     TRY(walloc(ctx, &d.free_stack, N));
     TRY(walloc(ctx, &d.free_top, 1));
     d.ce_view = d.ce;
@@ -1397,15 +1403,67 @@ int chd_shard_spawn(chd_ctx *ctx, uint32_t n, const uint32_t *chan_id, const dou
     return CHD_OK;
 }
 
-static uint64_t shard_table_bytes(const chd_ctx *ctx) {
-    uint64_t b = (sizeof(uint4) + sizeof(uint32_t)) * (uint64_t)ctx->w.d.N + sizeof(uint32_t) * ((uint64_t)ctx->g.ncell + 1);
-    return (b + 15) & ~15ull;
+// ghost room behind the own entries: reallocates the cell-sorted tables (rebuilt every tick, nothing to preserve)
+static int shard_reserve_ghosts(chd_ctx *ctx, uint32_t ghosts) {
+    World &W = ctx->w;
+    WorldDev &d = W.d;
+    if (ghosts <= d.ghost_cap && d.cell_cov) return CHD_OK;
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    const size_t n = (size_t)d.N + ghosts;
+    TRY(walloc(ctx, &d.ce, n + 1));
+    TRY(walloc(ctx, &d.ce_sprev, n));
+    TRY(walloc(ctx, &d.ce8, n + 2));
+    TRY(walloc(ctx, &d.ce_chan, n + 520));
+    if (!d.cell_cov) TRY(walloc(ctx, &d.cell_cov, ctx->g.ncell));
+    d.ghost_cap = ghosts;
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    return CHD_OK;
 }
 
-int chd_shard_table_bytes(chd_ctx *ctx, uint64_t *bytes) {
+int chd_shard_halo_layout(chd_ctx *ctx, uint32_t rank, uint32_t world, chd_halo_seg *segs, uint64_t *send_total, uint64_t *recv_total) {
     NEED_WORLD();
-    if (!bytes) return fail(ctx, CHD_E_INVAL, "chd_shard_table_bytes: NULL output");
-    *bytes = shard_table_bytes(ctx);
+    if (!segs || !send_total || !recv_total) return fail(ctx, CHD_E_INVAL, "chd_shard_halo_layout: NULL output");
+    const DevGrid &g = ctx->g;
+    if (!world || rank >= world) return fail(ctx, CHD_E_INVAL, "chd_shard_halo_layout: rank %u of %u", rank, world);
+    if (world != g.server_cols * g.server_rows)
+        return fail(ctx, CHD_E_INVAL, "chd_shard_halo_layout: %u ranks but the grid has %u server regions", world, g.server_cols * g.server_rows);
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    TRY(bind(ctx));
+    World &W = ctx->w;
+    const uint32_t halo = g.border, region = g.sgc * g.sgr, N = W.d.N;
+    uint64_t so = 0, ro = 0;
+    uint32_t ghosts = 0;
+    std::vector<uint64_t> soff(world), roff(world);
+    std::vector<uint32_t> goff(world);
+    for (uint32_t p = 0; p < world; p++) {
+        const HaloRect out = halo_rect(g.cols, g.rows, g.server_cols, g.sgc, g.sgr, halo, rank, p);
+        const HaloRect in = halo_rect(g.cols, g.rows, g.server_cols, g.sgc, g.sgr, halo, p, rank);
+        const uint32_t ocap = halo_cap_entries(N, out.w * out.h, region), icap = halo_cap_entries(N, in.w * in.h, region);
+        segs[p].send_off = soff[p] = so;
+        segs[p].send_bytes = halo_seg_bytes(ocap, out.w * out.h);
+        segs[p].recv_off = roff[p] = ro;
+        segs[p].recv_bytes = halo_seg_bytes(icap, in.w * in.h);
+        so += segs[p].send_bytes;
+        ro += segs[p].recv_bytes;
+        goff[p] = ghosts;
+        ghosts += icap;
+    }
+    *send_total = so;
+    *recv_total = ro;
+    if (rank == W.halo_rank && world == W.halo_world && W.d_ghost_off) return CHD_OK;  // (asked again)
+    // first call for this (rank, world) — or a query about ANOTHER rank's layout (host-staged exchanges need the
+    // senders' offsets): only this rank's own layout is installed, by the call that names its rank first
+    if (W.halo_world == 0) {
+        TRY(shard_reserve_ghosts(ctx, ghosts));
+        TRY(walloc(ctx, &W.d_halo_send_off, world));
+        TRY(walloc(ctx, &W.d_halo_recv_off, world));
+        TRY(walloc(ctx, &W.d_ghost_off, world));
+        HIPCHK(hipMemcpy(W.d_halo_send_off, soff.data(), 8 * (size_t)world, hipMemcpyHostToDevice));
+        HIPCHK(hipMemcpy(W.d_halo_recv_off, roff.data(), 8 * (size_t)world, hipMemcpyHostToDevice));
+        HIPCHK(hipMemcpy(W.d_ghost_off, goff.data(), 4 * (size_t)world, hipMemcpyHostToDevice));
+        W.halo_rank = rank;
+        W.halo_world = world;
+    }
     return CHD_OK;
 }
 
@@ -1432,24 +1490,24 @@ int chd_shard_ingest(chd_ctx *ctx, int64_t now_ns, const double *d_x_by_chan, co
     return CHD_OK;
 }
 
-int chd_shard_import(chd_ctx *ctx, const chd_entity_state *d_recv, uint32_t world, uint32_t cap, void *d_table_out) {
+int chd_shard_import(chd_ctx *ctx, const chd_entity_state *d_recv, uint32_t world, uint32_t cap, void *d_halo_send) {
     NEED_WORLD();
     if (world > 1 && !d_recv) return fail(ctx, CHD_E_INVAL, "chd_shard_import: NULL receive buffer");
     std::lock_guard<std::mutex> lk(ctx->mu);
     if (ctx->w.slot_mode != 2) return fail(ctx, CHD_E_STATE, "chd_shard_import before chd_shard_ingest");
+    World &W = ctx->w;
+    if (world > 1 && (W.halo_world != world || !d_halo_send)) return fail(ctx, CHD_E_STATE, "chd_shard_import: call chd_shard_halo_layout(rank, world) first and pass the halo send buffer");
     TRY(bind(ctx));
-    WorldDev &d = ctx->w.d;
+    WorldDev &d = W.d;
     hipStream_t st = ctx->stream;
+    // (the fan-out of the previous tick read the combined views; the index build works on the own tables)
+    d.ce_view = d.ce; d.ce8_view = d.ce8; d.ce_chan_view = d.ce_chan; d.ce_sprev_view = d.ce_sprev; d.ce_sprev_stride = 0;
+    d.cell_start = d.cell_off;
+    d.cell_end = d.cell_off + 1;
     if (world > 1) launch_import(st, d, d_recv, world, cap, ctx->ring.cur_tick);
     launch_index_build(st, ctx->g, d, ctx->ring.cur_tick);
+    if (world > 1) launch_halo_pack(st, ctx->g, d, W.halo_rank, world, ctx->g.border, (unsigned char *)d_halo_send, W.d_halo_send_off);
     TRY(after_launch(ctx));
-    if (d_table_out) {
-        unsigned char *t = (unsigned char *)d_table_out;
-        HIPCHK(hipMemcpyAsync(t, d.ce, sizeof(uint4) * (size_t)d.N, hipMemcpyDeviceToDevice, st));
-        HIPCHK(hipMemcpyAsync(t + sizeof(uint4) * (size_t)d.N, d.ce_sprev, sizeof(uint32_t) * (size_t)d.N, hipMemcpyDeviceToDevice, st));
-        HIPCHK(hipMemcpyAsync(t + (sizeof(uint4) + sizeof(uint32_t)) * (size_t)d.N, d.cell_off,
-                              sizeof(uint32_t) * ((size_t)ctx->g.ncell + 1), hipMemcpyDeviceToDevice, st));
-    }
     return CHD_OK;
 }
 
@@ -1467,16 +1525,19 @@ int chd_shard_interest(chd_ctx *ctx, const chd_tick_in *d_in) {
     return CHD_OK;
 }
 
-int chd_shard_fanout(chd_ctx *ctx, const void *d_tables, uint32_t world, const chd_tick_in *d_in) {
+int chd_shard_fanout(chd_ctx *ctx, const void *d_halo_recv, uint32_t world, const chd_tick_in *d_in) {
     NEED_WORLD();
     if (!d_in) return fail(ctx, CHD_E_INVAL, "chd_shard_fanout: NULL input");
-    if (!d_tables || !world) return fail(ctx, CHD_E_INVAL, "chd_shard_fanout: NULL gathered tables");
+    if (!world) return fail(ctx, CHD_E_INVAL, "chd_shard_fanout: world = 0");
+    if (world > 1 && !d_halo_recv) return fail(ctx, CHD_E_INVAL, "chd_shard_fanout: NULL halo receive buffer");
     std::lock_guard<std::mutex> lk(ctx->mu);
     if (ctx->w.slot_mode != 2) return fail(ctx, CHD_E_STATE, "chd_shard_fanout before chd_shard_ingest");
     TRY(bind(ctx));
     TRY(check_queries(ctx, d_in));
     World &W = ctx->w;
     WorldDev &d = W.d;
+    if (world > 1 && W.halo_world != world) return fail(ctx, CHD_E_STATE, "chd_shard_fanout: call chd_shard_halo_layout(rank, world) first");
+    if (!d.cell_cov) TRY(shard_reserve_ghosts(ctx, 0));
     hipStream_t st = ctx->stream;
     const TickRing &r = ctx->ring;
     const int64_t now = W.last_now;
@@ -1487,12 +1548,11 @@ int chd_shard_fanout(chd_ctx *ctx, const void *d_tables, uint32_t world, const c
         ctx->ev_overlap[r.cur_tick % (uint32_t)ctx->prof_depth] = 0;
         for (int k = 0; k <= 2; k++) HIPCHK(hipEventRecord(ev[k], st));
     }
-    launch_cell_table(st, ctx->g, d, d_tables, world, shard_table_bytes(ctx));
-    d.ce_view = (const uint4 *)d_tables;
-    d.ce8_view = nullptr;  // gathered tables carry the 16-byte entries only
-    d.ce_chan_view = nullptr;
-    d.ce_sprev_view = nullptr;
-    d.ce_sprev_stride = (uint32_t)(shard_table_bytes(ctx) / sizeof(uint4));
+    // the neighbours' border bands join the own tables as ghost entries: ONE local table over region + halo, so the
+    // fan-out takes the same kernels (and fast paths) as on a single GPU
+    launch_halo_unpack(st, ctx->g, d, world > 1 ? W.halo_rank : 0u, world, ctx->g.border, (const unsigned char *)d_halo_recv,
+                       W.d_halo_recv_off, W.d_ghost_off);
+    d.ce_view = d.ce; d.ce8_view = d.ce8; d.ce_chan_view = d.ce_chan; d.ce_sprev_view = d.ce_sprev; d.ce_sprev_stride = 0;
     d.cell_start = d.cell_tab;
     d.cell_end = d.cell_tab + ctx->g.ncell;
     launch_aoi_interest(st, ctx->g, ctx->lim, d, d_in->queries, d_in->n_queries, d_in->query_sub, d_in->spot_x,

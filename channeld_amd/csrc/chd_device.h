@@ -53,6 +53,7 @@ enum {
 #define OVF_INTERNAL 0x8000u  // a kernel's defensive loop bound tripped (a bug, never a capacity)
 #define OVF_SLOTS 16u    // sharded world: no free entity slot for a spawn / an immigrant
 #define OVF_MIGRATE 32u  // sharded world: an emigrant did not fit its destination's send segment
+#define OVF_HALO 64u     // sharded world: a border band did not fit its halo segment, or a subscription reaches a cell beyond the halo
 
 struct DevGrid {
     double gw, gh, offx, offz;
@@ -67,6 +68,45 @@ struct DevGrid {
     uint32_t damp_dist[8];
     uint32_t damp_iv[8];
 };
+
+// ---- halo exchange of region-sharded worlds (k_shard.hip) ----
+// What rank s sends rank d every tick: the cell tables of the cells of s's region that lie within `halo` cells of d's
+// region (the generalisation of ServerInterestBorderSize, spatial.go:114-118,481-590: the border band a spatial server
+// sees of its neighbours) — a rectangle of cells, empty for ranks further apart than the halo.
+struct HaloRect {
+    uint32_t x0, y0, w, h;  // cells [x0, x0+w) x [y0, y0+h) of the global grid; w*h == 0: nothing to exchange
+};
+__host__ __device__ inline HaloRect halo_rect(uint32_t cols, uint32_t rows, uint32_t server_cols, uint32_t sgc, uint32_t sgr,
+                                              uint32_t halo, uint32_t s, uint32_t d) {
+    HaloRect r = {0, 0, 0, 0};
+    if (s == d) return r;
+    const uint32_t sx0 = (s % server_cols) * sgc, sy0 = (s / server_cols) * sgr;
+    const uint32_t dx0 = (d % server_cols) * sgc, dy0 = (d / server_cols) * sgr;
+    const uint32_t sx1 = sx0 + sgc < cols ? sx0 + sgc : cols, sy1 = sy0 + sgr < rows ? sy0 + sgr : rows;
+    const uint32_t dx1 = dx0 + sgc < cols ? dx0 + sgc : cols, dy1 = dy0 + sgr < rows ? dy0 + sgr : rows;
+    const uint32_t ex0 = dx0 > halo ? dx0 - halo : 0u, ey0 = dy0 > halo ? dy0 - halo : 0u;
+    const uint32_t ex1 = dx1 + halo < cols ? dx1 + halo : cols, ey1 = dy1 + halo < rows ? dy1 + halo : rows;
+    const uint32_t x0 = sx0 > ex0 ? sx0 : ex0, x1 = sx1 < ex1 ? sx1 : ex1;
+    const uint32_t y0 = sy0 > ey0 ? sy0 : ey0, y1 = sy1 < ey1 ? sy1 : ey1;
+    if (x0 >= x1 || y0 >= y1) return r;
+    r.x0 = x0; r.y0 = y0; r.w = x1 - x0; r.h = y1 - y0;
+    return r;
+}
+// entries a halo segment can carry: the band's share of the sender's entity slots, with headroom for clustering
+__host__ __device__ inline uint32_t halo_cap_entries(uint32_t n_slots, uint32_t rect_cells, uint32_t region_cells) {
+    if (!rect_cells) return 0u;
+    const uint64_t c = (uint64_t)n_slots * rect_cells / (region_cells ? region_cells : 1u);
+    const uint64_t cap = c + c / 4 + 256u;
+    return (uint32_t)(cap < n_slots ? cap : n_slots);
+}
+// Segment layout (all parts 16-byte aligned): header {n_entries, n_cells, overflow, -} | per rect cell {usender, smin, smax,
+// hand} | entries (16 B x cap) | per rect cell count (u32) | previous senders (u32 x cap)
+__host__ __device__ inline uint64_t halo_seg_bytes(uint32_t cap, uint32_t rect_cells) {
+    if (!rect_cells) return 0ull;
+    const uint64_t a = 16ull + 16ull * rect_cells + 16ull * cap;
+    const uint64_t b = ((4ull * rect_cells + 15ull) & ~15ull) + ((4ull * cap + 15ull) & ~15ull);
+    return a + b;
+}
 
 struct TickRing {
     int64_t t[CHD_HIST_BITS];  // t[j] = arrival stamp of tick (cur - j); valid for j < n

@@ -57,17 +57,20 @@ struct WorldDev {
     uint32_t *blk_smin, *blk_smax, *blk_hand;  // [ncell*nblk] per-block sender range / AND of histories (index build intermediates)
     uint32_t *cell_hand;              // [ncell] AND of the histories of the cell's entities (aligned to this tick)
     uint32_t *ce_chan;                // [N + 4] the entity channel ids alone, cell-sorted: what an all-pass window copies
-    const uint32_t *ce_chan_view;     // nullptr where not available (gathered tables)
-    const uint2 *ce8_view;            // nullptr where compact entries are not available (gathered tables)
+    const uint32_t *ce_chan_view;     // (views: always the arrays above since the halo exchange appends the neighbours' entries to them)
+    const uint2 *ce8_view;
     uint32_t *cell_off;   // [ncell+1] cell c owns ce[cell_off[c], cell_off[c+1])
     uint32_t *cell_tot;   // [ncell] entities per cell (intermediate of the index build)
     // what the fan-out kernels read: cell c owns ce_view[cell_start[c], cell_end[c]).  Single GPU: ce_view = ce,
-    // cell_start = cell_off, cell_end = cell_off + 1.  Region-sharded: ce_view = the all-gathered tables.
+    // cell_start = cell_off, cell_end = cell_off + 1.  Region-sharded: the same arrays with the neighbours' border entities
+    // appended from index N on (ghosts), cell_start / cell_end = cell_tab.
     const uint4 *ce_view;
     const uint32_t *ce_sprev_view;
     uint32_t ce_sprev_stride;  // sharded: entries of rank o start at o*stride16 (16-B units), its sprev at +N entries
     const uint32_t *cell_start, *cell_end;
     uint32_t *cell_tab;   // [2*ncell] storage of cell_start/cell_end in sharded mode
+    uint32_t *cell_cov;   // sharded mode (else nullptr): [ncell] 1 = the cell's table is on this rank (own region or a received halo)
+    uint32_t ghost_cap;   // sharded mode: room behind the N own entries of ce / ce_sprev / ce8 / ce_chan for the neighbours' border entities
     // slot allocator of region-sharded worlds (entities migrate between ranks)
     uint32_t *free_stack; // [N]
     int32_t *free_top;    // number of free slots
@@ -224,9 +227,12 @@ void launch_spawn_auto(hipStream_t st, DevGrid g, WorldDev w, uint32_t n, const 
                        const double *x, const double *z, const uint32_t *flags, const uint32_t *sender,
                        uint32_t cur_tick);
 void launch_free_stack_init(hipStream_t st, WorldDev w);
-// tables = world x table_bytes; each: N 16-byte entries, then ncell+1 offsets
-void launch_cell_table(hipStream_t st, DevGrid g, WorldDev w, const void *tables, uint32_t world,
-                       uint64_t table_bytes);
+// halo exchange: pack this rank's border bands per destination (segments at seg_off[d]), and append the received ones behind
+// the own cell tables (ghost entries from index N on) + the cell views
+void launch_halo_pack(hipStream_t st, DevGrid g, WorldDev w, uint32_t rank, uint32_t world, uint32_t halo, unsigned char *send,
+                      const uint64_t *seg_off);
+void launch_halo_unpack(hipStream_t st, DevGrid g, WorldDev w, uint32_t rank, uint32_t world, uint32_t halo, const unsigned char *recv,
+                        const uint64_t *seg_off, const uint32_t *ghost_off);
 // K2: cell index build
 void launch_index_build(hipStream_t st, DevGrid g, WorldDev w, uint32_t cur_tick);
 // K3/K4: AOI query (+ interest diff when stateful)

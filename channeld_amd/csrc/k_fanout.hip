@@ -139,6 +139,8 @@ __global__ void __launch_bounds__(64 * FO_WAVES) k_fanout_plan(DevGrid g, WorldD
                 int64_t I = (int64_t)w.pair_iv[pbase + p] * 1000000;
                 if (!(fl & PF_NO_ACCESS) && I > 0 && now >= L + I) {
                     uint32_t c = w.pair_cell[pbase + p];
+                    // region-sharded world: the cell's table must be on this rank (own region or a received halo band)
+                    if (w.cell_cov && !w.cell_cov[c]) atomicOr(&w.counters[CTR_OVERFLOW], OVF_HALO);
                     uint64_t size = (uint64_t)(w.cell_end[c] - w.cell_start[c]) + 1;
                     if (!(fl & PF_HAD_FIRST)) {
                         ub = size;  // one full-state window, then last = now
@@ -813,7 +815,7 @@ __global__ void __launch_bounds__(64 * WAVES) k_fanout_emit(DevGrid g, WorldDev 
 //                   known exactly (tight segment, no worst-case slot) and it becomes a 16-byte descriptor
 //                   {segment offset, column start, entries, windows / own-update bits}.  Everything else (a window
 //                   some entity has no update in, a cell whose senders include this connection, more than four
-//                   non-empty windows, gathered tables) is marked PF_DEFER with a worst-case slot and left to the
+//                   non-empty windows, a cell of more than 512 entities) is marked PF_DEFER with a worst-case slot and left to the
 //                   second launch, k_fanout_emit<.., DEFERRED>, whose filtering streams would cost this path 50 VGPRs.
 //   k_fanout_emit_seg : WAVES waves per connection take its descriptors round-robin: scalar descriptor load,
 //                   the column of the NEXT descriptor requested (four 8-byte loads per lane: pairs of adjacent
@@ -865,6 +867,7 @@ __global__ void __launch_bounds__(64 * FO_WAVES) k_fanout_plan_seg(DevGrid g, Wo
             due = !(fl & PF_NO_ACCESS) && I > 0 && now >= L + I;
             if (due) {
                 c = w.pair_cell[pbase + p];
+                if (w.cell_cov && !w.cell_cov[c]) atomicOr(&w.counters[CTR_OVERFLOW], OVF_HALO);  // (see k_fanout_plan)
                 start = w.cell_start[c];
                 size = w.cell_end[c] - start;
                 uint32_t wms[4] = {0, 0, 0, 0}, nw = 0;
@@ -1312,6 +1315,7 @@ __global__ void __launch_bounds__(WS_SUBS) k_fanout_items(DevGrid g, WorldDev w,
                 iv = w.pair_iv[pi];
                 const int64_t I = (int64_t)iv * 1000000;
                 due = !(fl & PF_NO_ACCESS) && I > 0 && now >= L + I;
+                if (due && w.cell_cov && !w.cell_cov[c]) atomicOr(&w.counters[CTR_OVERFLOW], OVF_HALO);  // (see k_fanout_plan)
                 if (due && ub1 > w.recs_cap) {
                     // no room for this connection's worst case: state untouched, it catches up next tick
                     atomicOr(&w.counters[CTR_OVERFLOW], OVF_RECORDS);

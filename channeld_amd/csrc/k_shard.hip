@@ -9,8 +9,7 @@
 //                         state into the per-destination send segment (header record
 //                         = count), free the slot
 //   k_import            : received states take free slots
-//   k_cell_table        : after the all-gather, cell c's entries are the owner
-//                         rank's [cell_off_o[c], cell_off_o[c+1]) inside its segment
+//   k_halo_pack/_unpack : the border bands of the cell tables, per neighbour (see below)
 // A few hundred entities migrate per tick (border crossings only), so these kernels
 // are latency-trivial; the wire volume is what matters (32 B per emigrant).
 #include "chd_kernels.h"
@@ -202,24 +201,134 @@ void launch_import(hipStream_t st, WorldDev w, const chd_entity_state *recv, uin
     hipLaunchKernelGGL(k_import, dim3(nblocks(cap, 256), world), dim3(256), 0, st, w, recv, world, cap, cur_tick);
 }
 
-__global__ void __launch_bounds__(256) k_cell_table(DevGrid g, WorldDev w, const unsigned char *__restrict__ tables,
-                                                    uint32_t world, uint64_t table_bytes) {
-    const uint32_t c = blockIdx.x * 256u + threadIdx.x;
-    if (c >= g.ncell) return;
-    uint32_t o = server_of(g, c);
-    uint32_t a = 0, b = 0;
-    if (o < world) {
-        const uint32_t *off = (const uint32_t *)(tables + (size_t)o * table_bytes + (sizeof(uint4) + sizeof(uint32_t)) * (size_t)w.N);
-        const uint32_t base = (uint32_t)((size_t)o * (table_bytes / sizeof(uint4)));  // in 16-byte entries
-        a = base + off[c];
-        b = base + off[c + 1];
+// ---------------------------------------------------------------------------
+// Halo exchange (SURVEY 8e, C2 "border halo"): instead of every rank's whole cell table, rank s sends rank d only the
+// cells of its region within `halo` cells of d's region (chd_device.h: halo_rect) — one fixed-capacity segment per
+// (s, d) pair, exchanged with ONE all-to-all(v) whose split sizes are static (ranks further apart than the halo
+// exchange nothing).  The receiver appends the entries as GHOSTS behind its own cell-sorted tables, so the fan-out
+// kernels see one local table covering region + halo — the same arrays, the same fast paths as a single-GPU world.
+// ---------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_halo_pack(DevGrid g, WorldDev w, uint32_t rank, uint32_t world, uint32_t halo,
+                                                   unsigned char *__restrict__ send, const uint64_t *__restrict__ seg_off) {
+    const uint32_t d = blockIdx.x;
+    const HaloRect r = halo_rect(g.cols, g.rows, g.server_cols, g.sgc, g.sgr, halo, rank, d);
+    const uint32_t nc = r.w * r.h;
+    if (!nc) return;
+    const uint32_t cap = halo_cap_entries(w.N, nc, g.sgc * g.sgr);
+    unsigned char *seg = send + seg_off[d];
+    uint32_t *hdr = (uint32_t *)seg;
+    uint4 *agg = (uint4 *)(seg + 16);
+    uint4 *ent = (uint4 *)(seg + 16 + 16ull * nc);
+    uint32_t *cnt = (uint32_t *)(seg + 16 + 16ull * nc + 16ull * cap);
+    uint32_t *sprev = (uint32_t *)((unsigned char *)cnt + ((4ull * nc + 15ull) & ~15ull));
+    __shared__ uint32_t row_base[1024];  // entries in front of each rect row (rows <= 1024: grids are far smaller per axis band)
+    __shared__ uint32_t total_s;
+    // per cell: count + aggregates; per row: its entries are one contiguous run of the cell-sorted table
+    for (uint32_t k = threadIdx.x; k < nc; k += 256) {
+        const uint32_t c = (r.x0 + k % r.w) + (r.y0 + k / r.w) * g.cols;
+        cnt[k] = w.cell_off[c + 1] - w.cell_off[c];
+        agg[k] = make_uint4(w.cell_usender[c], w.cell_smin[c], w.cell_smax[c], w.cell_hand[c]);
     }
-    w.cell_tab[c] = a;
-    w.cell_tab[g.ncell + c] = b;
+    if (threadIdx.x == 0) {
+        uint32_t acc = 0;
+        for (uint32_t y = 0; y < r.h; y++) {
+            const uint32_t c0 = r.x0 + (r.y0 + y) * g.cols;
+            if (y < 1024) row_base[y] = acc;
+            acc += w.cell_off[c0 + r.w] - w.cell_off[c0];
+        }
+        total_s = acc;
+    }
+    __syncthreads();
+    const uint32_t total = total_s;
+    const bool ovf = total > cap || r.h > 1024;
+    if (threadIdx.x == 0) {
+        hdr[0] = ovf ? 0u : total; hdr[1] = nc; hdr[2] = ovf ? 1u : 0u; hdr[3] = 0u;
+        if (ovf) atomicOr(&w.counters[CTR_OVERFLOW], OVF_HALO);
+    }
+    if (ovf) return;
+    for (uint32_t y = 0; y < r.h; y++) {
+        const uint32_t c0 = r.x0 + (r.y0 + y) * g.cols;
+        const uint32_t a = w.cell_off[c0], n = w.cell_off[c0 + r.w] - a, base = row_base[y];
+        for (uint32_t k = threadIdx.x; k < n; k += 256) {
+            ent[base + k] = w.ce[a + k];
+            sprev[base + k] = w.ce_sprev[a + k];
+        }
+    }
 }
 
-void launch_cell_table(hipStream_t st, DevGrid g, WorldDev w, const void *tables, uint32_t world,
-                       uint64_t table_bytes) {
-    hipLaunchKernelGGL(k_cell_table, dim3(nblocks(g.ncell, 256)), dim3(256), 0, st, g, w,
-                       (const unsigned char *)tables, world, table_bytes);
+void launch_halo_pack(hipStream_t st, DevGrid g, WorldDev w, uint32_t rank, uint32_t world, uint32_t halo, unsigned char *send,
+                      const uint64_t *seg_off) {
+    if (world < 2) return;
+    hipLaunchKernelGGL(k_halo_pack, dim3(world), dim3(256), 0, st, g, w, rank, world, halo, send, seg_off);
+}
+
+// block s < world: the segment rank s sent; block `world`: this rank's own cells and the cells nobody covers
+__global__ void __launch_bounds__(256) k_halo_unpack(DevGrid g, WorldDev w, uint32_t rank, uint32_t world, uint32_t halo,
+                                                     const unsigned char *__restrict__ recv, const uint64_t *__restrict__ seg_off,
+                                                     const uint32_t *__restrict__ ghost_off) {
+    const uint32_t s = blockIdx.x;
+    if (s == world) {
+        // own region: the local index; cells of no received band: empty and NOT covered (a subscription to one of them is
+        // an error the plan kernels report: the halo is narrower than that connection's AOI reach)
+        for (uint32_t c = threadIdx.x; c < g.ncell; c += 256) {
+            const uint32_t o = server_of(g, c);
+            if (o == rank) {
+                w.cell_tab[c] = w.cell_off[c];
+                w.cell_tab[g.ncell + c] = w.cell_off[c + 1];
+                w.cell_cov[c] = 1;
+            } else {
+                const HaloRect r = halo_rect(g.cols, g.rows, g.server_cols, g.sgc, g.sgr, halo, o, rank);
+                const uint32_t x = c % g.cols, y = c / g.cols;
+                const bool in = o < world && r.w && x >= r.x0 && x < r.x0 + r.w && y >= r.y0 && y < r.y0 + r.h;
+                if (!in) { w.cell_tab[c] = 0; w.cell_tab[g.ncell + c] = 0; w.cell_cov[c] = 0; }
+            }
+        }
+        return;
+    }
+    const HaloRect r = halo_rect(g.cols, g.rows, g.server_cols, g.sgc, g.sgr, halo, s, rank);
+    const uint32_t nc = r.w * r.h;
+    if (!nc) return;
+    const uint32_t cap = halo_cap_entries(w.N, nc, g.sgc * g.sgr);
+    const unsigned char *seg = recv + seg_off[s];
+    const uint32_t *hdr = (const uint32_t *)seg;
+    const uint4 *agg = (const uint4 *)(seg + 16);
+    const uint4 *ent = (const uint4 *)(seg + 16 + 16ull * nc);
+    const uint32_t *cnt = (const uint32_t *)(seg + 16 + 16ull * nc + 16ull * cap);
+    const uint32_t *sprev = (const uint32_t *)((const unsigned char *)cnt + ((4ull * nc + 15ull) & ~15ull));
+    const uint32_t base = w.N + ghost_off[s];  // ghosts of rank s: ce[base, base + cap)
+    const bool bad = hdr[2] != 0 || hdr[1] != nc || hdr[0] > cap;
+    if (bad && threadIdx.x == 0) atomicOr(&w.counters[CTR_OVERFLOW], OVF_HALO);
+    // cell views: exclusive prefix of the counts (serial: a band has a few hundred cells)
+    __shared__ uint32_t total_s;
+    if (threadIdx.x == 0) {
+        uint32_t acc = 0;
+        for (uint32_t k = 0; k < nc; k++) {
+            const uint32_t c = (r.x0 + k % r.w) + (r.y0 + k / r.w) * g.cols;
+            const uint32_t n = bad ? 0u : cnt[k];
+            w.cell_tab[c] = base + acc;
+            w.cell_tab[g.ncell + c] = base + acc + n;
+            w.cell_cov[c] = bad ? 0u : 1u;
+            acc += n;
+        }
+        total_s = acc;
+    }
+    for (uint32_t k = threadIdx.x; k < nc; k += 256) {
+        const uint32_t c = (r.x0 + k % r.w) + (r.y0 + k / r.w) * g.cols;
+        const uint4 a = agg[k];
+        w.cell_usender[c] = a.x; w.cell_smin[c] = a.y; w.cell_smax[c] = a.z; w.cell_hand[c] = a.w;
+    }
+    __syncthreads();
+    const uint32_t total = total_s;
+    for (uint32_t k = threadIdx.x; k < total; k += 256) {
+        const uint4 e = ent[k];
+        w.ce[base + k] = e;
+        w.ce_sprev[base + k] = sprev[k];
+        w.ce8[base + k] = make_uint2(e.x, e.y | e.w);  // compact entry {channel, history of any sender}
+        w.ce_chan[base + k] = e.x;
+    }
+}
+
+void launch_halo_unpack(hipStream_t st, DevGrid g, WorldDev w, uint32_t rank, uint32_t world, uint32_t halo, const unsigned char *recv,
+                        const uint64_t *seg_off, const uint32_t *ghost_off) {
+    hipLaunchKernelGGL(k_halo_unpack, dim3(world + 1), dim3(256), 0, st, g, w, rank, world, halo, recv, seg_off, ghost_off);
 }

@@ -9,12 +9,16 @@ Connections (subscribers) are pinned to ranks.  One tick:
                        belongs to another rank are packed per destination
     all-to-all         the reference's cross-server handover (spatial.go:683-700):
                        ~32 B per border crossing, a few hundred per tick
-    engine.import_     immigrants take slots; local cell index rebuilt + published
-    all-gather         every rank's cell table (20 B per entity): an AOI that
-                       straddles a region border reads remote cells
-                       (generalises ServerInterestBorderSize, spatial.go:481-590)
+    engine.import_     immigrants take slots; local cell index rebuilt; the border
+                       bands of the cell tables packed per neighbour
+    all-to-all(v)      the halo: rank s sends rank d the cells of its region within
+                       ServerInterestBorderSize cells of d's region (20 B per entity
+                       + 20 B per cell), nothing to ranks further apart — an AOI
+                       that straddles a region border reads the neighbour's cells
+                       (spatial.go:114-118,481-590, generalised to a band incl. corners)
       engine.interest  ... while the interest updates of the local connections run
-    engine.fanout      fan-out of the local connections over the gathered tables
+    engine.fanout      the received bands join the local tables as ghost entries;
+                       fan-out of the local connections over region + halo
 
 With backend "nccl" (= RCCL over xGMI) the exchange buffers are device tensors and
 everything is ordered on torch's current stream without host synchronisation.  With
@@ -64,7 +68,8 @@ def weak_scaled_config(base: dict, world: int) -> dict:
     cfg["ServerCols"], cfg["ServerRows"] = sc, sr
     cfg["WorldOffsetX"] = -0.5 * cfg["GridCols"] * float(base["GridWidth"])
     cfg["WorldOffsetZ"] = -0.5 * cfg["GridRows"] * float(base["GridHeight"])
-    cfg["ServerInterestBorderSize"] = max(int(base.get("ServerInterestBorderSize", 1)), 1)
+    # the halo must cover the longest AOI reach of the workload: the bench's cones reach 5 cells
+    cfg["ServerInterestBorderSize"] = max(int(base.get("ServerInterestBorderSize", 1)), 5)
     return cfg
 
 
@@ -112,29 +117,47 @@ class Comm:
         recv = torch.stack([allbuf[src][self.rank] for src in range(self.world)])
         return recv.to(send.device)
 
-    def all_gather(self, t, overlap=None):
-        """every rank's `t`, rank-major, as one flat tensor.  `overlap()` (optional) is work for the
-        compute stream that does not depend on the result: with RCCL it is enqueued while the
-        collective runs on the communication stream."""
+    def halo_exchange(self, send, send_splits, recv_splits, send_offs_of_peers=None, overlap=None):
+        """send: flat uint8 tensor = the segments for every destination back to back (send_splits bytes each); returns the
+        flat receive buffer (recv_splits).  The split sizes are static (a function of the grid config), zero for ranks
+        further apart than the halo.  `overlap()` (optional) is work for the compute stream that does not depend on the
+        result.  Host-staged backends need `send_offs_of_peers[src]` = offset of the segment for THIS rank in rank src's
+        send buffer."""
         import torch
 
-        if self.world == 1 and not self.force:
+        n_send, n_recv = int(sum(send_splits)), int(sum(recv_splits))
+        if (self.world == 1 and not self.force) or (n_send == 0 and n_recv == 0):  # (nothing to exchange)
             if overlap:
                 overlap()
-            return t
+            return send
+        send = send.view(-1)[:n_send]
         if not self.staged:
-            out = torch.empty(self.world * t.numel(), dtype=t.dtype, device=t.device)
-            work = self.dist.all_gather_into_tensor(out, t.contiguous().view(-1), async_op=True)
+            recv = torch.empty(n_recv, dtype=send.dtype, device=send.device)
+            work = self.dist.all_to_all_single(recv, send, output_split_sizes=[int(v) for v in recv_splits],
+                                               input_split_sizes=[int(v) for v in send_splits], async_op=True)
             if overlap:
                 overlap()
             work.wait()  # the compute stream waits for the collective (no host synchronisation)
-            return out
+            return recv
         if overlap:
             overlap()
-        host = t.detach().cpu().contiguous().view(-1)
-        parts = [torch.empty_like(host) for _ in range(self.world)]
-        self.dist.all_gather(parts, host)
-        return torch.cat(parts).to(t.device)
+        host = send.detach().cpu().contiguous().view(-1)
+        sizes = [None] * self.world
+        self.dist.all_gather_object(sizes, int(host.numel()))
+        pad = max(max(sizes), 1)
+        buf = torch.zeros(pad, dtype=host.dtype)
+        buf[: host.numel()] = host
+        parts = [torch.empty_like(buf) for _ in range(self.world)]
+        self.dist.all_gather(parts, buf)
+        recv = torch.zeros(int(sum(recv_splits)), dtype=host.dtype)
+        at = 0
+        for src in range(self.world):
+            n = int(recv_splits[src])
+            if n:
+                o = int(send_offs_of_peers[src])
+                recv[at: at + n] = parts[src][o: o + n]
+            at += n
+        return recv.to(send.device)
 
     def sum_int(self, v: int) -> int:
         import torch
@@ -186,12 +209,24 @@ class HipShardEngine:
         self.lib, self.ctx = self.sw.lib, self.sw.ctx
         if use_torch_stream:
             _lib.check(self.ctx, self.lib.chd_set_stream(self.ctx, C.c_void_p(torch.cuda.current_stream(self.dev).cuda_stream), 1))
-        nb = C.c_uint64(0)
-        _lib.check(self.ctx, self.lib.chd_shard_table_bytes(self.ctx, C.byref(nb)))
-        self.table_bytes = int(nb.value)
         self.send = torch.zeros((world, (self.cap + 1) * ENTITY_STATE_WORDS), dtype=torch.int32, device=self.dev)
-        self.table = torch.zeros(self.table_bytes, dtype=torch.uint8, device=self.dev)
+        # the halo layout of this rank (installs it in the library) and, for host-staged exchanges, where every other
+        # rank keeps its segment for this one
+        segs, st, rt = self._layout(rank)
+        self.send_splits = [int(g.send_bytes) for g in segs]
+        self.recv_splits = [int(g.recv_bytes) for g in segs]
+        self.peer_send_off = [int(self._layout(p)[0][rank].send_off) if p != rank else 0 for p in range(world)] if world > 1 else [0]
+        self.halo_send = torch.zeros(max(st, 16), dtype=torch.uint8, device=self.dev)
         self._keep = None
+
+    def _layout(self, rank):
+        segs = (self._lib.HaloSeg * self.world)()
+        st, rt = C.c_uint64(0), C.c_uint64(0)
+        self._lib.check(self.ctx, self.lib.chd_shard_halo_layout(self.ctx, int(rank), self.world, segs, C.byref(st), C.byref(rt)))
+        return segs, int(st.value), int(rt.value)
+
+    def halo_splits(self):
+        return self.send_splits, self.recv_splits, self.peer_send_off
 
     def spawn(self, chan_id, x, z, flags, sender):
         from .controller import _f64, _ptr, _u32
@@ -213,8 +248,8 @@ class HipShardEngine:
     def import_(self, recv):
         rp = C.c_void_p(recv.data_ptr()) if recv is not None else None
         self._keep = recv
-        self._lib.check(self.ctx, self.lib.chd_shard_import(self.ctx, rp, self.world, self.cap, C.c_void_p(self.table.data_ptr())))
-        return self.table
+        self._lib.check(self.ctx, self.lib.chd_shard_import(self.ctx, rp, self.world, self.cap, C.c_void_p(self.halo_send.data_ptr())))
+        return self.halo_send
 
     def interest(self, queries=None, n_queries: int = 0):
         """queries: uint8 device tensor of n_queries packed chd_aoi_query records for slots 0..n_queries-1."""
@@ -225,10 +260,10 @@ class HipShardEngine:
         self._lib.check(self.ctx, self.lib.chd_shard_interest(self.ctx, C.byref(ti)))
         self.sw._last_nq = int(n_queries)
 
-    def fanout(self, tables):
+    def fanout(self, halo_recv):
         ti = self._lib.TickIn()
-        self._tables = tables
-        self._lib.check(self.ctx, self.lib.chd_shard_fanout(self.ctx, C.c_void_p(tables.data_ptr()), self.world, C.byref(ti)))
+        self._halo_recv = halo_recv
+        self._lib.check(self.ctx, self.lib.chd_shard_fanout(self.ctx, C.c_void_p(halo_recv.data_ptr()), self.world, C.byref(ti)))
 
     def fetch(self, want_records=False, records_cap=0):
         return self.sw.fetch(want_records=want_records, records_cap=records_cap)
@@ -256,10 +291,12 @@ class ShardedWorld:
     def tick(self, now_ns: int, x_by_chan, z_by_chan, queries=None, n_queries: int = 0, has_update=None):
         send = self.engine.ingest(now_ns, x_by_chan, z_by_chan, has_update)
         recv = self.comm.all_to_all(send) if (self.comm.world > 1 or self.comm.force) else None
-        table = self.engine.import_(recv)
-        # the interest updates do not read the gathered tables: they run under the all-gather
-        tables = self.comm.all_gather(table, overlap=lambda: self.engine.interest(queries, n_queries))
-        self.engine.fanout(tables)
+        halo_send = self.engine.import_(recv)
+        send_splits, recv_splits, peer_off = self.engine.halo_splits()
+        # the interest updates do not read the neighbours' tables: they run under the halo exchange
+        halo_recv = self.comm.halo_exchange(halo_send, send_splits, recv_splits, peer_off,
+                                            overlap=lambda: self.engine.interest(queries, n_queries))
+        self.engine.fanout(halo_recv)
 
 
 # ---------------------------------------------------------------------------
@@ -345,7 +382,8 @@ def run_bench(args, rank: int, world: int, local_rank: int) -> dict:
                                f"({args.entities} / {args.subs} per GPU)",
                    "grid": f"{cfg['GridCols']}x{cfg['GridRows']} cells of {int(cfg['GridWidth'])}, {sc}x{sr} server regions",
                    "tick_ms": args.tick_ms, "msgs_per_tick": msgs / K, "cross_rank_and_local_handovers_per_tick": handovers / K,
-                   "exchange": "all-to-all of emigrant states (32 B each) + all-gather of cell tables (16 B per entity) per tick",
+                   "exchange": "all-to-all of emigrant states (32 B each) + all-to-all(v) of the border bands of the cell tables "
+                               f"({cfg['ServerInterestBorderSize']} cells wide: {sum(eng.send_splits)} bytes sent per rank and tick) per tick",
                    "message": "one fanOutDataUpdate decision (conn, channel); payload bytes excluded"},
         "roofline": {"bound": "hbm", "kernel": "k_fanout_emit", "achieved": achieved, "peak": 8000.0, "unit": "GB/s",
                      "frac": achieved / 8000.0, "traffic": None, "bytes_per_msg": 12, "rank": 0,

@@ -370,10 +370,12 @@ int chd_world_get_entities(chd_ctx *ctx, uint32_t n, const uint32_t *idx,
 /* Region-sharded worlds: one ctx per GPU, rank r owns the cells whose  */
 /* ServerIndex (GetRegions, spatial.go:336-351) is r - the partition    */
 /* CreateChannels gives spatial server r (spatial.go:399-424).  Every   */
-/* rank is created with the SAME global grid config.  The three phases  */
-/* below bracket the two exchange steps of a tick:*/
-/*   chd_shard_ingest -> all-to-all(emigrants)                          */
-/*   chd_shard_import -> all-gather(cell tables)                        */
+/* rank is created with the SAME global grid config.  Two exchange      */
+/* steps per tick, both all-to-all, both for border traffic only        */
+/* (DESIGN.md section 7):                                               */
+/*   chd_shard_ingest -> all-to-all(emigrants: cross-server handovers)  */
+/*   chd_shard_import -> all-to-all(halo: the border bands of the cell  */
+/*                       tables, ServerInterestBorderSize cells wide)   */
 /*   chd_shard_fanout                                                   */
 /* All pointers are DEVICE pointers (the exchange buffers are owned by  */
 /* the caller, e.g. torch tensors handed to RCCL); calls are            */
@@ -418,28 +420,38 @@ int chd_shard_ingest(chd_ctx *ctx, int64_t now_ns, const double *d_x_by_chan,
                      const double *d_z_by_chan, const uint8_t *d_has_update, uint32_t n_chan,
                      uint32_t rank, uint32_t world, chd_entity_state *d_send, uint32_t cap);
 
-/* Size of one rank's published cell table: max_entities 16-byte entries {channel id,
- * history, sender, previous sender's history} sorted by cell, max_entities previous
- * senders (u32), then grid_cols*grid_rows+1 CSR offsets (u32), padded to 16 bytes. */
-int chd_shard_table_bytes(chd_ctx *ctx, uint64_t *bytes);
+/* The halo exchange.  Rank s sends rank d the cell tables of the cells of ITS region that lie within
+ * ServerInterestBorderSize cells of d's region (the grid config's own parameter for "how much of a neighbour a spatial
+ * server sees", spatial.go:114-118,481-590, generalised from the 4-neighbour border rows to a band around the whole
+ * region incl. the corners): one fixed-capacity segment per ordered pair of ranks, none for ranks further apart.  The
+ * layout is a pure function of (grid config, max_entities, rank): segs[p] = where the segment TO rank p sits in this
+ * rank's send buffer and where the segment FROM rank p lands in its receive buffer — the split sizes of one
+ * all-to-all(v).  Must be called once with the ctx's own rank before the first tick (it reserves room for the
+ * neighbours' border entities); it may be called for other ranks too (a host-staged exchange needs their offsets).
+ * A subscription that reaches a cell beyond the halo, or a band that outgrows its segment, sets overflow bit 64
+ * (CHD_E_CAPACITY from chd_tick_fetch): widen ServerInterestBorderSize / max_entities. */
+typedef struct {
+    uint64_t send_off, send_bytes, recv_off, recv_bytes;
+} chd_halo_seg;
+int chd_shard_halo_layout(chd_ctx *ctx, uint32_t rank, uint32_t world, chd_halo_seg *segs /* world */,
+                          uint64_t *send_total, uint64_t *recv_total);
 
-/* Phase 2, after the all-to-all: the states in d_recv (same layout as d_send, segment
- * `src` = what rank src sent here) join this rank; then the local cell index is rebuilt
- * and published into d_table_out (chd_shard_table_bytes). */
+/* Phase 2, after the all-to-all of emigrants: the states in d_recv (same layout as d_send, segment `src` = what rank src
+ * sent here) join this rank; the local cell index is rebuilt and the border bands are packed into d_halo_send
+ * (chd_shard_halo_layout; may be NULL when world == 1). */
 int chd_shard_import(chd_ctx *ctx, const chd_entity_state *d_recv, uint32_t world,
-                     uint32_t cap, void *d_table_out);
+                     uint32_t cap, void *d_halo_send);
 
 /* Optional, any time between chd_shard_ingest and chd_shard_fanout: the interest updates
  * of this rank's connections (the query fields of d_in).  They do not depend on the
  * gathered tables, so a caller can run them while the all-gather is in flight and then
- * pass no queries to chd_shard_fanout. */
+ * pass no queries to chd_shard_fanout (e.g. while the halo exchange is in flight). */
 int chd_shard_interest(chd_ctx *ctx, const chd_tick_in *d_in);
 
-/* Phase 3, after the all-gather: d_tables = world tables, rank-major.  Runs the interest
- * updates of d_in (queries of this rank's connections; the update fields of d_in are
- * ignored) and the fan-out of this rank's connections over the gathered tables.  Outputs
- * as chd_tick_device. */
-int chd_shard_fanout(chd_ctx *ctx, const void *d_tables, uint32_t world, const chd_tick_in *d_in);
+/* Phase 3, after the halo all-to-all: the received bands (d_halo_recv, chd_shard_halo_layout) join the own cell tables
+ * as ghost entries; then the interest updates of d_in (queries of this rank's connections; the update fields of d_in
+ * are ignored) and the fan-out of this rank's connections over region + halo.  Outputs as chd_tick_device. */
+int chd_shard_fanout(chd_ctx *ctx, const void *d_halo_recv, uint32_t world, const chd_tick_in *d_in);
 
 /* Live entities of this rank: channel ids and cell / member channel ids (0 = none).
  * Arrays have max_entities room; *n_out = count. */

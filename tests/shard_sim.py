@@ -34,6 +34,14 @@ class SimShardEngine:
         self.handovers = []     # (chan, src_cell, dst_cell) of the last tick
         self.table_words = 4 * max_entities + self.ncell + 1
         self.table_words += (-self.table_words) % 4
+        self.table_bytes = 4 * self.table_words
+
+    def halo_splits(self):
+        """This stand-in ships its whole cell table to every rank (the schedule and the split-size plumbing of dist.py are
+        under test, not the band geometry, which tests/test_gpu_shard.py covers on the HIP engine): equal segments, the one
+        for rank p at offset p * table_bytes of the send buffer."""
+        T = self.table_bytes
+        return [T] * self.world, [T] * self.world, [self.rank * T] * self.world
 
     def _cells(self, x, z):
         ids = orc.channel_ids(self.g, x, z)
@@ -99,7 +107,7 @@ class SimShardEngine:
         ent[: len(order), 3] = order
         counts = np.bincount(self.member[order].astype(np.int64), minlength=self.ncell)
         table[4 * self.N: 4 * self.N + self.ncell + 1] = np.concatenate([[0], np.cumsum(counts)])
-        return torch.from_numpy(table.view(np.int32))
+        return torch.from_numpy(np.tile(table.view(np.uint8), self.world))
 
     def interest(self, queries=None, n_queries=0):
         if queries is not None:
@@ -108,8 +116,8 @@ class SimShardEngine:
                 if rc == 0:
                     self.interest_sets[slot] = sorted(c - ID0 for c in m)
 
-    def fanout(self, tables):
-        t = tables.numpy().view(np.uint32).reshape(self.world, self.table_words)
+    def fanout(self, halo_recv):
+        t = halo_recv.numpy().view(np.uint32).reshape(self.world, self.table_words)
         owner = server_of_cell(self.cfg, np.arange(self.ncell))
         self.visible = {}
         for slot, conn in enumerate(self.subs):

@@ -35,8 +35,10 @@ def free_port():
 
 def make_cfg(world, name=None):
     if name:  # one of the repo's StaticGrid2D configs whose server layout already has `world` regions
-        cfg = synth.load_config(name)
+        cfg = dict(synth.load_config(name))
         assert int(cfg["ServerCols"]) * int(cfg["ServerRows"]) == world
+        # the halo (= ServerInterestBorderSize cells of every neighbour's border) must cover the test's AOI reach: cones of 5 cells
+        cfg["ServerInterestBorderSize"] = max(int(cfg.get("ServerInterestBorderSize", 1)), 5)
         return cfg
     base = {"WorldOffsetX": -4000, "WorldOffsetZ": -4000, "GridWidth": 2000, "GridHeight": 2000, "GridCols": 3,
             "GridRows": 2, "ServerCols": 1, "ServerRows": 1, "ServerInterestBorderSize": 1}
