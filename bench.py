@@ -33,6 +33,7 @@ if ROOT not in sys.path:
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8 TB/s spec
 BYTES_PER_MSG = 12     # 4 B entity id read + 8 B {conn, channel} record written
+DOMINANT = "k_fanout_emit_seg"  # the kernel the roofline object is about (rocprofv3 --kernel-trace name, template arguments dropped)
 
 
 def parse():
@@ -68,7 +69,13 @@ def parse():
                          "config/channel_settings_ue.json) instead of the distance-damped 20/50/100 ms; the default run reports it as a second line")
     ap.add_argument("--emit", choices=["auto", "cell-major", "conn-major"], default="auto",
                     help="form of the fan-out emit kernel (include/chd_spatial.h: CHD_WORLD_*_EMIT)")
-    return ap.parse_args()
+    ap.add_argument("--only-timed", action="store_true",
+                    help="profiling runs (rocprofv3 --kernel-trace / --pmc): warm-up + the timed region and nothing else (= --no-cpu "
+                         "--latency-steps 0 --e2e-ticks 0), so that per-kernel averages after skipping --warmup launches are the timed launches")
+    args = ap.parse_args()
+    if args.only_timed:
+        args.no_cpu, args.latency_steps, args.e2e_ticks = True, 0, 0
+    return args
 
 
 def cpu_baseline(cfg, n_entities, n_subs, seed, tick_ms, aoi_scale, budget_s, single_thread_ticks=1):
@@ -271,14 +278,16 @@ def main():
 
     hist = world.history(min(K, 1024))
     msgs = sum(h["n_records"] for h in hist)
-    emit_us = np.array([h["stage_us"][4] for h in hist])
-    emit_msgs = np.array([h["n_records"] for h in hist], dtype=np.float64)
+    # the dominant kernel alone (k_fanout_emit_seg; its own HIP event pair on the tick's stream) and the records IT wrote
+    # (the few connections it defers are written by a second, small launch inside the same emit stage)
+    emit_us = np.array([h["emit_main_us"] for h in hist])
+    emit_msgs = np.array([h["n_records"] - h["n_deferred_records"] for h in hist], dtype=np.float64)
     stage_avg = np.mean(np.array([h["stage_us"] for h in hist]), axis=0)
     res = world.fetch()
     assert res.overflow == 0 and res.history_overflow == 0, (res.overflow, res.history_overflow)
     if len(hist) < K:  # history ring shorter than the timed region: scale by the mean
         msgs = int(round(msgs * K / len(hist)))
-    # dominant kernel: k_fanout_emit.  achieved = algorithmic bytes per launch / avg launch time
+    # dominant kernel: k_fanout_emit_seg.  achieved = algorithmic bytes per launch / avg launch time
     achieved = float((BYTES_PER_MSG * emit_msgs.mean()) / (emit_us.mean() * 1e-6) / 1e9)
 
     # ---- optional: wire-format packet streams of a few more ticks (payload materialisation) ----
@@ -317,7 +326,7 @@ def main():
     tpath = os.path.join(ROOT, "profiles", "hbm_traffic.json")
     if os.path.exists(tpath) and (N, S) == (100_000, 10_000) and args.aoi_scale == 1.0 and args.tick_ms == 50 and args.update_frac >= 1.0:
         with open(tpath) as f:
-            traffic = json.load(f)["kernels"].get("k_fanout_emit", {}).get("bytes_per_launch")
+            traffic = json.load(f)["kernels"].get(DOMINANT, {}).get("bytes_per_launch")
 
     out = {
         "metric": "AOI-filtered fanout msgs/sec + p99 tick latency, 100K entities / 10K subs",
@@ -333,11 +342,12 @@ def main():
         "p50_tick_ms": float(np.percentile(lat, 50)), "p99_tick_ms": float(np.percentile(lat, 99)),
         "p99_tick_gpu_ms": float(np.percentile(gpu_lat, 99)), "latency_ticks": int(L),
         "stage_us_avg": {n: float(v) for n, v in zip(("ingest", "index", "interest", "plan", "emit"), stage_avg)},
-        "roofline": {"bound": "hbm", "kernel": "k_fanout_emit", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+        "roofline": {"bound": "hbm", "kernel": DOMINANT, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_quoted": traffic is not None,
                      "traffic_source": "QUOTED, not measured in this run: bytes per launch from the rocprofv3 --pmc passes of this command (profiles/hbm_traffic.json)",
                      "algorithmic_bytes_per_launch": float(BYTES_PER_MSG * emit_msgs.mean()),
-                     "bytes_per_msg": BYTES_PER_MSG, "msgs_per_launch": float(emit_msgs.mean()), "avg_launch_us": float(emit_us.mean())},
+                     "bytes_per_msg": BYTES_PER_MSG, "msgs_per_launch": float(emit_msgs.mean()), "avg_launch_us": float(emit_us.mean()),
+                     "emit_stage_us": float(stage_avg[4]), "deferred_msgs_per_tick": float(np.mean([h["n_deferred_records"] for h in hist]))},
     }
     if wire_info:
         out["wire"] = wire_info

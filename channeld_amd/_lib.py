@@ -141,9 +141,9 @@ assert C.sizeof(EntityState) == 32
 
 class TickStats(C.Structure):
     _fields_ = [
-        ("stage_us", C.c_float * N_STAGES), ("total_us", C.c_float),
+        ("stage_us", C.c_float * N_STAGES), ("total_us", C.c_float), ("emit_main_us", C.c_float),
         ("n_records", C.c_uint64), ("n_record_upper_bound", C.c_uint64),
-        ("n_handovers", C.c_uint32), ("n_unsubs", C.c_uint32), ("n_pairs", C.c_uint32),
+        ("n_handovers", C.c_uint32), ("n_unsubs", C.c_uint32), ("n_pairs", C.c_uint32), ("n_deferred_records", C.c_uint32),
         ("algorithmic_bytes", C.c_uint64),
     ]
 

@@ -59,7 +59,7 @@ struct World {
 
 }  // namespace
 
-#define EV_PER_TICK (CHD_N_STAGES + 3)
+#define EV_PER_TICK (CHD_N_STAGES + 4)
 
 struct chd_ctx {
     int device = 0;
@@ -1093,7 +1093,7 @@ static int tick_locked(chd_ctx *ctx, const chd_tick_in *in) {
     if (prof) HIPCHK(hipEventRecord(ev[3], st));
     launch_fanout_plan(st, ctx->g, d, in->now_ns, r);
     if (prof) HIPCHK(hipEventRecord(ev[4], st));
-    launch_fanout_emit(st, ctx->g, d, in->now_ns, r);
+    launch_fanout_emit(st, ctx->g, d, in->now_ns, r, prof ? ev[CHD_N_STAGES + 3] : nullptr);
     if (prof) HIPCHK(hipEventRecord(ev[5], st));
     launch_tick_epilogue(st, d, r.cur_tick % TICK_RING);
     TRY(after_launch(ctx));
@@ -1145,6 +1145,9 @@ static void stage_times(chd_ctx *ctx, uint32_t tick, chd_tick_stats &s) {
     float ms = 0;
     (void)hipEventElapsedTime(&ms, ev[0], ev[CHD_N_STAGES]);
     s.total_us = ms * 1000.f;
+    ms = 0;
+    (void)hipEventElapsedTime(&ms, ev[CHD_N_STAGES - 1], ev[CHD_N_STAGES + 3]);
+    s.emit_main_us = ms * 1000.f;
 }
 
 static int fetch_locked(chd_ctx *ctx, chd_tick_out *out) {
@@ -1560,7 +1563,7 @@ int chd_shard_fanout(chd_ctx *ctx, const void *d_halo_recv, uint32_t world, cons
     if (prof) HIPCHK(hipEventRecord(ev[3], st));
     launch_fanout_plan(st, ctx->g, d, now, r);
     if (prof) HIPCHK(hipEventRecord(ev[4], st));
-    launch_fanout_emit(st, ctx->g, d, now, r);
+    launch_fanout_emit(st, ctx->g, d, now, r, prof ? ev[CHD_N_STAGES + 3] : nullptr);
     if (prof) HIPCHK(hipEventRecord(ev[5], st));
     launch_tick_epilogue(st, d, r.cur_tick % TICK_RING);
     TRY(after_launch(ctx));
@@ -1949,6 +1952,7 @@ int chd_get_tick_history(chd_ctx *ctx, uint32_t n, chd_tick_stats *out) {
         s.n_handovers = (uint32_t)r[2];
         s.n_unsubs = (uint32_t)r[4];
         s.n_pairs = (uint32_t)r[6];
+        s.n_deferred_records = (uint32_t)(r[6] >> 32);
         s.algorithmic_bytes = 12ull * s.n_records + 32ull * s.n_handovers;
         if (ctx->prof_depth > 0 && k < (uint32_t)ctx->prof_depth) stage_times(ctx, tick, s);
     }

@@ -300,6 +300,6 @@ void launch_adjacent_recipients(hipStream_t st, DevGrid g, WorldDev w, uint32_t 
                                 uint32_t *off, uint32_t *conns, uint64_t cap, int fill);
 // K5: fan-out
 void launch_fanout_plan(hipStream_t st, DevGrid g, WorldDev w, int64_t now_ns, TickRing ring);
-void launch_fanout_emit(hipStream_t st, DevGrid g, WorldDev w, int64_t now_ns, TickRing ring);
+void launch_fanout_emit(hipStream_t st, DevGrid g, WorldDev w, int64_t now_ns, TickRing ring, hipEvent_t after_main = nullptr);
 #define TICK_RING 1024
 void launch_tick_epilogue(hipStream_t st, WorldDev w, uint32_t slot);

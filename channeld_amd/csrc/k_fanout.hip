@@ -792,6 +792,7 @@ __global__ void __launch_bounds__(64 * WAVES) k_fanout_emit(DevGrid g, WorldDev 
         // single word (or words sharing a line) would serialise S atomics at ~12 ns
         unsigned long long *slot = (unsigned long long *)&w.tot64[(size_t)(s & 63u) * 16];
         if (t) atomicAdd(slot, (unsigned long long)t);
+        if (t && DEFERRED) atomicAdd(slot + 2, (unsigned long long)t);  // (bench.py: what the descriptor kernel did NOT write)
         if (cnt && !DEFERRED) atomicAdd(slot + 1, (unsigned long long)cnt);
     }
 }
@@ -1632,8 +1633,12 @@ __global__ void __launch_bounds__(64 * WS_WAVES) k_fanout_emit_ws(DevGrid g, Wor
     }
 }
 
-void launch_fanout_emit(hipStream_t st, DevGrid g, WorldDev w, int64_t now_ns, TickRing ring) {
-    if (!w.S) return;
+void launch_fanout_emit(hipStream_t st, DevGrid g, WorldDev w, int64_t now_ns, TickRing ring, hipEvent_t after_main) {
+    if (!w.S) {
+        if (after_main) (void)hipEventRecord(after_main, st);
+        return;
+    }
+    bool marked = false;
     if (w.cm_emit) {
         const uint32_t chunks = (w.S + WS_SUBS - 1) / WS_SUBS;
         const uint64_t max_items = (uint64_t)g.ncell * chunks;
@@ -1652,10 +1657,13 @@ void launch_fanout_emit(hipStream_t st, DevGrid g, WorldDev w, int64_t now_ns, T
             if (seg_path(w)) {
                 // (k_fanout_plan_seg has decided everything; see launch_fanout_plan)
                 hipLaunchKernelGGL(k_fanout_emit_seg<FO_SEG_WAVES>, dim3(w.S), dim3(64 * FO_SEG_WAVES), 0, st, g, w);
+                if (after_main) (void)hipEventRecord(after_main, st);
+                marked = true;
                 hipLaunchKernelGGL((k_fanout_emit<1, false, true>), dim3(w.S), dim3(64), 0, st, g, w, now_ns, ring);
             } else hipLaunchKernelGGL((k_fanout_emit<1, false>), dim3(w.S), dim3(64), 0, st, g, w, now_ns, ring);
         } else hipLaunchKernelGGL((k_fanout_emit<4, false>), dim3(w.S), dim3(256), 0, st, g, w, now_ns, ring);
     }
+    if (after_main && !marked) (void)hipEventRecord(after_main, st);
 }
 
 // Per-tick totals into the device-side history ring (read back by chd_tick_fetch /
@@ -1663,10 +1671,11 @@ void launch_fanout_emit(hipStream_t st, DevGrid g, WorldDev w, int64_t now_ns, T
 static_assert(CHD_LIST_BANKS == 64, "one epilogue lane per list bank");
 __global__ void __launch_bounds__(64) k_tick_epilogue(WorldDev w, uint32_t slot) {
     const uint32_t lane = threadIdx.x;
-    unsigned long long sum = w.tot64[(size_t)lane * 16], pairs = w.tot64[(size_t)lane * 16 + 1];
+    unsigned long long sum = w.tot64[(size_t)lane * 16], pairs = w.tot64[(size_t)lane * 16 + 1], deferred = w.tot64[(size_t)lane * 16 + 2];
     for (int d = 32; d >= 1; d >>= 1) {
         sum += __shfl_xor(sum, d);
         pairs += __shfl_xor(pairs, d);
+        deferred += __shfl_xor(deferred, d);
     }
     // unsub / new-sub bank tails: totals for the ring, per-bank counts kept for chd_tick_fetch
     uint32_t un = w.list_ctr[lane * 32u], nn = w.list_ctr[(CHD_LIST_BANKS + lane) * 32u];
@@ -1688,7 +1697,7 @@ __global__ void __launch_bounds__(64) k_tick_epilogue(WorldDev w, uint32_t slot)
         r[3] = w.counters[CTR_LOCKED];
         r[4] = un;
         r[5] = nn;
-        r[6] = pairs;
+        r[6] = (pairs & 0xFFFFFFFFull) | ((deferred > 0xFFFFFFFFull ? 0xFFFFFFFFull : deferred) << 32);
         r[7] = (uint64_t)w.counters[CTR_OVERFLOW] |
                ((uint64_t)(w.counters[CTR_HIST_OVERFLOW] + w.counters[CTR_SENDER_OVERFLOW]) << 32);
     }
@@ -1696,6 +1705,7 @@ __global__ void __launch_bounds__(64) k_tick_epilogue(WorldDev w, uint32_t slot)
     if (lane < CTR_COUNT) w.counters[lane] = 0;
     w.tot64[(size_t)lane * 16] = 0;
     w.tot64[(size_t)lane * 16 + 1] = 0;
+    w.tot64[(size_t)lane * 16 + 2] = 0;
 }
 
 void launch_tick_epilogue(hipStream_t st, WorldDev w, uint32_t slot) {

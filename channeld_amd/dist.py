@@ -179,6 +179,18 @@ class Comm:
         self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
         return float(t.item())
 
+    def gather_floats(self, v) -> list:
+        """every rank's vector of floats, on every rank: [world][len(v)]"""
+        import torch
+
+        if self.world == 1 and not self.force:
+            return [list(map(float, v))]
+        dev = "cuda" if self.backend == "nccl" else "cpu"
+        t = torch.tensor(list(map(float, v)), dtype=torch.float64, device=dev)
+        parts = [torch.empty_like(t) for _ in range(self.world)]
+        self.dist.all_gather(parts, t)
+        return [p.cpu().tolist() for p in parts]
+
     def barrier(self):
         if self.world > 1 or self.force:
             self.dist.barrier()
@@ -331,7 +343,8 @@ def run_bench(args, rank: int, world: int, local_rank: int) -> dict:
     eng.add_subscribers(sw.sub_conn[my_subs])
     world_obj = ShardedWorld(eng, comm)
 
-    T = W + K
+    L = min(max(getattr(args, "latency_steps", 0), 0), 100)
+    T = W + K + L
     xs = np.empty((T, N), dtype=np.float64)
     zs = np.empty((T, N), dtype=np.float64)
     qs = np.empty((T, len(my_subs)), dtype=synth.AOI_DTYPE)
@@ -369,9 +382,20 @@ def run_bench(args, rank: int, world: int, local_rank: int) -> dict:
     assert res.overflow == 0 and res.history_overflow == 0, (res.overflow, res.history_overflow)
     msgs = comm.sum_int(msgs_local)
     handovers = comm.sum_int(sum(h["n_handovers"] for h in hist))
-    emit_us = np.array([h["stage_us"][4] for h in hist])
-    emit_msgs = np.array([h["n_records"] for h in hist], dtype=np.float64)
+    emit_us = np.array([h["emit_main_us"] for h in hist])
+    emit_msgs = np.array([h["n_records"] - h["n_deferred_records"] for h in hist], dtype=np.float64)
     achieved = float(12.0 * emit_msgs.mean() / (emit_us.mean() * 1e-6) / 1e9) if emit_us.mean() > 0 else 0.0
+    stage_avg = np.mean(np.array([h["stage_us"] for h in hist]), axis=0)
+    # latency phase: one synchronous tick at a time (every rank in lock step: the tick has two exchanges)
+    lat = []
+    for t in range(W + K, W + K + L):
+        a = time.perf_counter()
+        tick(t)
+        torch.cuda.synchronize()
+        lat.append((time.perf_counter() - a) * 1e3)
+    lat = np.array(lat) if lat else np.array([0.0])
+    per_rank = comm.gather_floats([achieved / 8000.0, float(emit_us.mean()), float(emit_msgs.mean()), float(np.percentile(lat, 50)),
+                                   float(np.percentile(lat, 99)), float(stage_avg.sum()), float(len(mine)), float(len(my_subs))])
     sc, sr = server_layout(world)
     return {
         "metric": "AOI-filtered fanout msgs/sec + p99 tick latency, 100K entities / 10K subs",
@@ -385,7 +409,11 @@ def run_bench(args, rank: int, world: int, local_rank: int) -> dict:
                    "exchange": "all-to-all of emigrant states (32 B each) + all-to-all(v) of the border bands of the cell tables "
                                f"({cfg['ServerInterestBorderSize']} cells wide: {sum(eng.send_splits)} bytes sent per rank and tick) per tick",
                    "message": "one fanOutDataUpdate decision (conn, channel); payload bytes excluded"},
-        "roofline": {"bound": "hbm", "kernel": "k_fanout_emit", "achieved": achieved, "peak": 8000.0, "unit": "GB/s",
-                     "frac": achieved / 8000.0, "traffic": None, "bytes_per_msg": 12, "rank": 0,
+        "p50_tick_ms": max(r[3] for r in per_rank), "p99_tick_ms": max(r[4] for r in per_rank), "latency_ticks": int(L),
+        "stage_us_avg": {n: float(v) for n, v in zip(("ingest", "index", "interest", "plan", "emit"), stage_avg)},
+        "per_rank": [{"rank": i, "roofline_frac": r[0], "emit_kernel_us": r[1], "msgs_per_launch": r[2], "p50_tick_ms": r[3],
+                      "p99_tick_ms": r[4], "gpu_stage_sum_us": r[5], "entities": int(r[6]), "subs": int(r[7])} for i, r in enumerate(per_rank)],
+        "roofline": {"bound": "hbm", "kernel": "k_fanout_emit_seg", "achieved": achieved, "peak": 8000.0, "unit": "GB/s",
+                     "frac": achieved / 8000.0, "traffic": None, "traffic_quoted": False, "bytes_per_msg": 12, "rank": 0,
                      "msgs_per_launch": float(emit_msgs.mean()), "avg_launch_us": float(emit_us.mean())},
     }

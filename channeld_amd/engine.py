@@ -300,15 +300,15 @@ class SpatialWorld:
         _lib.check(self.ctx, self.lib.chd_get_tick_history(self.ctx, n, arr))
         out = []
         for s in reversed(arr):
-            out.append(dict(stage_us=[float(s.stage_us[i]) for i in range(_lib.N_STAGES)], total_us=float(s.total_us),
+            out.append(dict(stage_us=[float(s.stage_us[i]) for i in range(_lib.N_STAGES)], total_us=float(s.total_us), emit_main_us=float(s.emit_main_us),
                             n_records=int(s.n_records), n_record_upper_bound=int(s.n_record_upper_bound),
-                            n_handovers=int(s.n_handovers), n_unsubs=int(s.n_unsubs), n_pairs=int(s.n_pairs)))
+                            n_handovers=int(s.n_handovers), n_unsubs=int(s.n_unsubs), n_pairs=int(s.n_pairs), n_deferred_records=int(s.n_deferred_records)))
         return out
 
     def stats(self) -> dict:
         s = TickStats()
         _lib.check(self.ctx, self.lib.chd_get_tick_stats(self.ctx, C.byref(s)))
-        return dict(stage_us={n: float(s.stage_us[i]) for i, n in enumerate(_lib.STAGE_NAMES)}, total_us=float(s.total_us),
+        return dict(stage_us={n: float(s.stage_us[i]) for i, n in enumerate(_lib.STAGE_NAMES)}, total_us=float(s.total_us), emit_main_us=float(s.emit_main_us),
                     n_records=int(s.n_records), n_record_upper_bound=int(s.n_record_upper_bound),
                     n_handovers=int(s.n_handovers), n_unsubs=int(s.n_unsubs), n_pairs=int(s.n_pairs),
                     algorithmic_bytes=int(s.algorithmic_bytes))

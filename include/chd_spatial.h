@@ -586,8 +586,10 @@ int chd_host_free(chd_ctx *ctx, void *ptr);
 typedef struct {
     float stage_us[CHD_N_STAGES];
     float total_us;
+    float emit_main_us; /* the emit stage's dominant kernel alone (k_fanout_emit_seg when the descriptor path runs; else = stage_us[4]) */
     uint64_t n_records, n_record_upper_bound;
     uint32_t n_handovers, n_unsubs, n_pairs;
+    uint32_t n_deferred_records; /* of n_records: written by the deferred-connection launch, not by the dominant emit kernel */
     uint64_t algorithmic_bytes; /* DESIGN.md §4 byte model for the last tick */
 } chd_tick_stats;
 /* depth > 0: record HIP events around the stages of the next ticks, keeping the

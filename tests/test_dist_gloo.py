@@ -33,33 +33,35 @@ def free_port():
     return p
 
 
-def make_cfg(world, name=None):
+def make_cfg(world, name=None, halo=64):
+    """halo = ServerInterestBorderSize: how many cells of every neighbour's border a rank receives.  Connections are pinned
+    to ranks while the entities they follow roam (world_inputs teleports 15 % of them per tick), so the default here is the
+    whole world; tests of the band geometry pass a small halo with slowly drifting entities."""
     if name:  # one of the repo's StaticGrid2D configs whose server layout already has `world` regions
         cfg = dict(synth.load_config(name))
         assert int(cfg["ServerCols"]) * int(cfg["ServerRows"]) == world
-        # the halo (= ServerInterestBorderSize cells of every neighbour's border) must cover the test's AOI reach: cones of 5 cells
-        cfg["ServerInterestBorderSize"] = max(int(cfg.get("ServerInterestBorderSize", 1)), 5)
+        cfg["ServerInterestBorderSize"] = halo
         return cfg
     base = {"WorldOffsetX": -4000, "WorldOffsetZ": -4000, "GridWidth": 2000, "GridHeight": 2000, "GridCols": 3,
-            "GridRows": 2, "ServerCols": 1, "ServerRows": 1, "ServerInterestBorderSize": 1}
+            "GridRows": 2, "ServerCols": 1, "ServerRows": 1, "ServerInterestBorderSize": halo}
     return weak_scaled_config(base, world)
 
 
-def world_inputs(cfg, N, S, ticks, seed):
-    sw = synth.SynthWorld(synth.WorldSpec(cfg, N, S, seed, tick_ms=50, outside_frac=0.01, locked_frac=0.03))
+def world_inputs(cfg, N, S, ticks, seed, jump_frac=0.15, aoi_scale=1.0):
+    sw = synth.SynthWorld(synth.WorldSpec(cfg, N, S, seed, tick_ms=50, outside_frac=0.01, locked_frac=0.03, aoi_scale=aoi_scale))
     frames = []
     x0, z0 = sw.x.copy(), sw.z.copy()
     rng = np.random.default_rng(seed & 0xFFFF)
     for _ in range(ticks):
         sw.step()
         # amplify the motion so that region borders are crossed often
-        jump = rng.random(N) < 0.15
+        jump = rng.random(N) < jump_frac
         sw.x = np.where(jump & ~sw.outside, np.float64(np.float32(sw.offx + rng.random(N) * sw.W * 0.999)), sw.x)
         frames.append((sw.x.copy(), sw.z.copy(), sw.queries().copy(), sw.now_ns()))
     return sw, x0, z0, frames
 
 
-def worker(rank, world, port, N, S, ticks, seed, out, cfg_name=None):
+def worker(rank, world, port, N, S, ticks, seed, out, cfg_name=None, halo=64, jump_frac=0.15, aoi_scale=1.0):
     from oracle import pyoracle as orc
     from shard_sim import SimShardEngine
 
@@ -67,8 +69,8 @@ def worker(rank, world, port, N, S, ticks, seed, out, cfg_name=None):
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
-        cfg = make_cfg(world, cfg_name)
-        sw, x0, z0, frames = world_inputs(cfg, N, S, ticks, seed)
+        cfg = make_cfg(world, cfg_name, halo)
+        sw, x0, z0, frames = world_inputs(cfg, N, S, ticks, seed, jump_frac, aoi_scale)
         g = orc.grid_from_config(cfg)
         ids0 = orc.channel_ids(g, x0, z0)
         owner = np.where(ids0 == 0, 0, server_of_cell(cfg, np.where(ids0 == 0, 0, ids0 - 0x10000)))
@@ -165,6 +167,24 @@ def test_named_configs_sharded_by_their_own_server_layout(cfg_name, world):
     assert status == "ok", info
     assert all(p.exitcode == 0 for p in procs)
     assert info > 0, "the test world never crossed a region border"
+
+
+def test_narrow_halo_on_the_40x40_grid():
+    """spatial_static_40x40.json over its 4 x 2 servers (regions of 10 x 20 cells) with a halo of 4 cells: each rank receives
+    only bands of its neighbours (the bench's geometry).  AOIs reach 3 cells and entities only drift, so every connection's
+    interest stays inside region + halo and the sharded world still equals the single one record for record."""
+    ctx = mp.get_context("spawn")
+    out = ctx.Queue()
+    port = free_port()
+    procs = [ctx.Process(target=worker, args=(r, 8, port, 3000, 120, 5, 0xC0FFEE1A, out, "spatial_static_40x40.json", 4, 0.0, 0.6))
+             for r in range(8)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(timeout=240)
+    status, info = out.get(timeout=5)
+    assert status == "ok", info
+    assert all(p.exitcode == 0 for p in procs)
 
 
 def test_layout_helpers():

@@ -30,7 +30,7 @@ def canon(conn, chan):
     return np.sort((conn.astype(np.uint64) << np.uint64(32)) | chan.astype(np.uint64))
 
 
-def run_rank(rank, world, port, N, S, ticks, seed, out, cfg_name=None):
+def run_rank(rank, world, port, N, S, ticks, seed, out, cfg_name=None, halo=64, jump_frac=0.15, aoi_scale=1.0):
     import torch
     import torch.distributed as dist
 
@@ -46,8 +46,8 @@ def run_rank(rank, world, port, N, S, ticks, seed, out, cfg_name=None):
     try:
         torch.cuda.set_device(0)
         dev = torch.device("cuda", 0)
-        cfg = make_cfg(world, cfg_name)
-        sw, x0, z0, frames = world_inputs(cfg, N, S, ticks, seed)
+        cfg = make_cfg(world, cfg_name, halo)
+        sw, x0, z0, frames = world_inputs(cfg, N, S, ticks, seed, jump_frac, aoi_scale)
         g = orc.grid_from_config(cfg)
         ids0 = orc.channel_ids(g, x0, z0)
         owner = np.where(ids0 == 0, 0, server_of_cell(cfg, np.where(ids0 == 0, 0, ids0 - 0x10000)))
@@ -134,13 +134,13 @@ def run_rank(rank, world, port, N, S, ticks, seed, out, cfg_name=None):
             dist.destroy_process_group()
 
 
-def launch(world, N, S, ticks, seed, cfg_name=None):
+def launch(world, N, S, ticks, seed, cfg_name=None, halo=64, jump_frac=0.15, aoi_scale=1.0):
     import torch.multiprocessing as mp
 
     ctx = mp.get_context("spawn")
     out = ctx.Queue()
     port = free_port()
-    procs = [ctx.Process(target=run_rank, args=(r, world, port, N, S, ticks, seed, out, cfg_name)) for r in range(world)]
+    procs = [ctx.Process(target=run_rank, args=(r, world, port, N, S, ticks, seed, out, cfg_name, halo, jump_frac, aoi_scale)) for r in range(world)]
     for p in procs:
         p.start()
     for p in procs:
@@ -178,6 +178,15 @@ def test_8x8_world_on_its_eight_servers_matches_single_world():
     oracle, record for record."""
     total, cross = launch(8, 6000, 160, 6, 0xC0FFEE15, cfg_name="spatial_static_8x8.json")
     assert total > 0 and cross > 0
+
+
+def test_narrow_halo_band_geometry_on_the_40x40_grid():
+    """The halo as the bench uses it: ranks receive only a band of their neighbours' cells.  spatial_static_40x40.json (40 x
+    40 cells) over its 4 x 2 servers (regions of 10 x 20 cells), halo = 4 cells (bands of the neighbours, corners included),
+    AOIs scaled to reach at most 3 cells, entities drifting slowly (no teleports), so no connection's AOI leaves region +
+    halo — the overflow flags stay 0 — and every record, handover and unsub still equals the single world's."""
+    total, cross = launch(8, 6000, 200, 6, 0xC0FFEE16, cfg_name="spatial_static_40x40.json", halo=4, jump_frac=0.0, aoi_scale=0.6)
+    assert total > 0
 
 
 def test_rccl_single_rank_bench_path():

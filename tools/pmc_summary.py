@@ -30,7 +30,7 @@ def load(path, counter):
     return per
 
 
-def main(d, skip=0):
+def main(d, skip=0, traffic_src=None):
     fetch = load(f"{d}/pmc_FETCH_SIZE/p_counter_collection.csv", "FETCH_SIZE")
     write = load(f"{d}/pmc_WRITE_SIZE/p_counter_collection.csv", "WRITE_SIZE")
     out = {}
@@ -41,8 +41,14 @@ def main(d, skip=0):
         wm = sum(w) / len(w) if w else 0.0
         out[k] = {"launches": max(len(f), len(w)), "fetch_KiB_avg": fm, "fetch_x2_MB_avg": 2 * fm * 1024 / 1e6,
                   "write_KiB_avg": wm, "write_MB_avg": wm * 1024 / 1e6}
-    print(json.dumps(out, indent=1))
+    if traffic_src:
+        # the form bench.py quotes from (profiles/hbm_traffic.json): bytes per launch = 2 x FETCH_SIZE + WRITE_SIZE
+        k = {n: {"fetch_bytes_per_launch": v["fetch_x2_MB_avg"] * 1e6, "write_bytes_per_launch": v["write_MB_avg"] * 1e6,
+                 "bytes_per_launch": v["fetch_x2_MB_avg"] * 1e6 + v["write_MB_avg"] * 1e6} for n, v in out.items()}
+        print(json.dumps({"source": traffic_src, "workload": "spatial_static_benchmark.json, 100000 entities / 10000 subs", "kernels": k}, indent=1))
+    else:
+        print(json.dumps(out, indent=1))
 
 
 if __name__ == "__main__":
-    main(sys.argv[1], int(sys.argv[2]) if len(sys.argv) > 2 else 0)
+    main(sys.argv[1], int(sys.argv[2]) if len(sys.argv) > 2 else 0, sys.argv[3] if len(sys.argv) > 3 else None)
