@@ -69,6 +69,9 @@ def parse():
                          "config/channel_settings_ue.json) instead of the distance-damped 20/50/100 ms; the default run reports it as a second line")
     ap.add_argument("--emit", choices=["auto", "cell-major", "conn-major"], default="auto",
                     help="form of the fan-out emit kernel (include/chd_spatial.h: CHD_WORLD_*_EMIT)")
+    ap.add_argument("--serial-ticks", action="store_true",
+                    help="do not pipeline successive ticks (CHD_WORLD_PIPELINE_TICKS off): every tick's kernels one after the other "
+                         "on one stream.  The default run times both schedules and reports the serial one as `serial_schedule`")
     ap.add_argument("--only-timed", action="store_true",
                     help="profiling runs (rocprofv3 --kernel-trace / --pmc): warm-up + the timed region and nothing else (= --no-cpu "
                          "--latency-steps 0 --e2e-ticks 0), so that per-kernel averages after skipping --warmup launches are the timed launches")
@@ -234,13 +237,18 @@ def main():
     err = ctl.LoadConfig(json.dumps(cfg).encode(), strict=False, **({"Damping": [(0xFFFFFFFF, args.flat_interval_ms)]} if args.flat_interval_ms else {}))
     assert err is None, err
     world_flags = {"auto": 0, "conn-major": 1, "cell-major": 2}[args.emit] | (4 if args.recipients else 0) | (8 if args.wire else 0) | (16 if args.overlap_interest else 0) | (32 if args.update_masks else 0)
+    # successive ticks pipelined over two streams (include/chd_spatial.h: CHD_WORLD_PIPELINE_TICKS) where the descriptor emit runs
+    pipe = not args.serial_ticks and args.emit != "cell-major" and not args.wire and not args.update_masks and S >= 4096
+    if pipe:
+        world_flags |= 128
     world = A.SpatialWorld(ctl, N, S, flags=world_flags)
     world.spawn(None, sw.chan_id, sw.x, sw.z, sw.flags, sw.sender)
     world.add_subscribers(None, sw.sub_conn)
 
     # ---- all tick inputs generated on the host once, then resident in HBM ----
     E = max(args.e2e_ticks, 0)
-    T = W + K + L
+    K2 = K if (pipe and not args.only_timed) else 0  # the same number of ticks again on the serial schedule
+    T = W + K + K2 + L
     xs = np.empty((T + E, N), dtype=np.float64)
     zs = np.empty((T + E, N), dtype=np.float64)
     qs = np.empty((T + E, S), dtype=synth.AOI_DTYPE)
@@ -287,6 +295,26 @@ def main():
     assert res.overflow == 0 and res.history_overflow == 0, (res.overflow, res.history_overflow)
     if len(hist) < K:  # history ring shorter than the timed region: scale by the mean
         msgs = int(round(msgs * K / len(hist)))
+    serial = None
+    if K2:
+        # the same world continues on the serial schedule (one stream, kernel after kernel): its rate, and the stage times
+        # free of cross-tick overlap
+        world.set_pipelining(False)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for t in range(W + K, W + K + K2):
+            tick(t)
+        torch.cuda.synchronize()
+        el2 = time.perf_counter() - t1
+        hist2 = world.history(min(K2, 1024))
+        m2 = sum(h["n_records"] for h in hist2) * (K2 / len(hist2))
+        stage_avg = np.mean(np.array([h["stage_us"] for h in hist2]), axis=0)
+        serial = {"what": "the same world, next %d ticks, CHD_WORLD_PIPELINE_TICKS switched off: every tick's kernels in sequence on one stream" % K2,
+                  "value": m2 / el2, "unit": "msgs/s", "ms_per_step": 1e3 * el2 / K2, "msgs_per_tick": m2 / K2,
+                  "emit_kernel_us": float(np.mean([h["emit_main_us"] for h in hist2])),
+                  "emit_kernel_frac_of_hbm_peak": float(BYTES_PER_MSG * np.mean([h["n_records"] - h["n_deferred_records"] for h in hist2])
+                                                        / (np.mean([h["emit_main_us"] for h in hist2]) * 1e-6) / 1e9 / HBM_PEAK_GBS)}
+        world.set_pipelining(True)
     # dominant kernel: k_fanout_emit_seg.  achieved = algorithmic bytes per launch / avg launch time
     achieved = float((BYTES_PER_MSG * emit_msgs.mean()) / (emit_us.mean() * 1e-6) / 1e9)
 
@@ -295,11 +323,11 @@ def main():
     if args.wire:
         wire_info = wire_phase(args, world, ctl, N, lambda t, at: world.tick_device(
             at, n_updates=M, d_upd_x=d_x.at(t * M * 8), d_upd_z=d_z.at(t * M * 8), d_upd_idx=d_idx.at(t * M * 4) if d_idx is not None else None,
-            n_queries=S, d_queries=d_q.at(t * S * 128)), range(W + K - args.wire, W + K), int(now[W + K - 1]))
+            n_queries=S, d_queries=d_q.at(t * S * 128)), range(W + K - args.wire, W + K), int(now[W + K - 1]))  # (--wire worlds are never pipelined: K2 = 0)
 
     # ---- latency phase: one synchronous tick at a time (p50/p99 of the tick) ----
     lat = []
-    for t in range(W + K, W + K + L):
+    for t in range(W + K + K2, W + K + K2 + L):
         a = time.perf_counter()
         tick(t)
         world.sync()
@@ -338,10 +366,14 @@ def main():
                    "grid": "15x15 cells of 2000",
                    "tick_ms": args.tick_ms, "aoi": "70% sphere R=3 cells, 20% cone R=5 cells, 10% box extent 2 cells",
                    "msgs_per_tick": msgs / K, "message": "one fanOutDataUpdate decision (conn, channel); payload bytes excluded",
-                   "value_is": "chd_tick_device: inputs resident in HBM, records left in HBM (see e2e for what a host observes)"},
+                   "value_is": "chd_tick_device: inputs resident in HBM, records left in HBM (see e2e for what a host observes)",
+                   "schedule": ("successive ticks pipelined over two HIP streams (CHD_WORLD_PIPELINE_TICKS): tick t's record kernel beside tick t+1's stages; "
+                                "every tick does all of its work inside the timed region, results equal the serial schedule's (tests/test_gpu_fullsize.py)")
+                               if pipe else "serial: every tick's kernels in sequence on one stream"},
         "p50_tick_ms": float(np.percentile(lat, 50)), "p99_tick_ms": float(np.percentile(lat, 99)),
         "p99_tick_gpu_ms": float(np.percentile(gpu_lat, 99)), "latency_ticks": int(L),
         "stage_us_avg": {n: float(v) for n, v in zip(("ingest", "index", "interest", "plan", "emit"), stage_avg)},
+        "stage_us_avg_is": "serial schedule (no overlap across ticks)" if (serial or not pipe) else "pipelined schedule: stages of successive ticks overlap, emit includes queueing",
         "roofline": {"bound": "hbm", "kernel": DOMINANT, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_quoted": traffic is not None,
                      "traffic_source": "QUOTED, not measured in this run: bytes per launch from the rocprofv3 --pmc passes of this command (profiles/hbm_traffic.json)",
@@ -349,6 +381,8 @@ def main():
                      "bytes_per_msg": BYTES_PER_MSG, "msgs_per_launch": float(emit_msgs.mean()), "avg_launch_us": float(emit_us.mean()),
                      "emit_stage_us": float(stage_avg[4]), "deferred_msgs_per_tick": float(np.mean([h["n_deferred_records"] for h in hist]))},
     }
+    if serial:
+        out["serial_schedule"] = serial
     if wire_info:
         out["wire"] = wire_info
     # (ii) of --e2e-ticks: the packet streams a gateway would hand to conn.Write, on a second world (the wire mode
@@ -389,7 +423,8 @@ def flat_interval_line(A, synth, cfg, N, S, seed, args, local_rank, interval_ms,
     ctl = A.StaticGrid2DSpatialController(device=local_rank)
     assert ctl.LoadConfig(json.dumps(cfg).encode(), strict=False, Damping=[(0xFFFFFFFF, interval_ms)]) is None
     sw = synth.SynthWorld(synth.WorldSpec(cfg, N, S, seed, tick_ms=args.tick_ms, aoi_scale=args.aoi_scale))
-    w = A.SpatialWorld(ctl, N, S, max_records=400_000_000)
+    pipe = not args.serial_ticks and S >= 4096
+    w = A.SpatialWorld(ctl, N, S, max_records=400_000_000, flags=128 if pipe else 0)
     w.spawn(None, sw.chan_id, sw.x, sw.z, sw.flags, sw.sender)
     w.add_subscribers(None, sw.sub_conn)
     T = warm + steps
@@ -413,11 +448,12 @@ def flat_interval_line(A, synth, cfg, N, S, seed, args, local_rank, interval_ms,
     el = time.perf_counter() - t0
     hist = w.history(steps)
     msgs = sum(h["n_records"] for h in hist)
-    emit_us = float(np.mean([h["stage_us"][4] for h in hist]))
+    emit_us = float(np.mean([h["emit_main_us"] for h in hist]))
     res = w.fetch()
     assert res.overflow == 0 and res.history_overflow == 0
     ctl.close()
-    return {"what": f"every subscription fans out every {interval_ms} ms (one-entry damping table), otherwise the headline workload",
+    return {"what": f"every subscription fans out every {interval_ms} ms (one-entry damping table), otherwise the headline workload"
+                    + (" (ticks pipelined, as the headline)" if pipe else " (serial schedule)"),
             "value": msgs / el, "unit": "msgs/s", "steps": steps, "ms_per_step": 1e3 * el / steps, "msgs_per_tick": msgs / steps,
             "emit_us": emit_us, "emit_frac_of_hbm_peak": BYTES_PER_MSG * (msgs / steps) / (emit_us * 1e-6) / 1e9 / HBM_PEAK_GBS}
 

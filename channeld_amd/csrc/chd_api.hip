@@ -51,6 +51,13 @@ struct World {
     void *grp_buf[4] = {nullptr, nullptr, nullptr, nullptr};  // device arrays behind WorldDev::grp_*
     bool plan_recipients = false;      // CHD_WORLD_HANDOVER_RECIPIENTS
     bool overlap_interest = false;     // CHD_WORLD_OVERLAP_INTEREST
+    // CHD_WORLD_PIPELINE_TICKS: everything the record-writing kernel reads (and the record buffer) exists twice, by tick parity
+    bool pipe_alloc = false, pipe_on = false;
+    uint32_t *pb_n_simple[2] = {nullptr, nullptr}, *pb_ce_chan[2] = {nullptr, nullptr}, *pb_ticket[2] = {nullptr, nullptr};
+    uint64_t *pb_rec_ub[2] = {nullptr, nullptr};
+    uint4 *pb_seg_desc[2] = {nullptr, nullptr}, *pb_seg_desc2[2] = {nullptr, nullptr};
+    chd_fanout_rec *pb_recs[2] = {nullptr, nullptr};
+    hipEvent_t ev_stages_done = nullptr, ev_stages_all = nullptr, ev_rec_sync = nullptr, ev_emit_done[2] = {nullptr, nullptr};
     uint32_t *ho_rcp_off = nullptr;    // [handovers_cap + 1] recipients of handover h: [off[h], off[h+1])
     uint32_t *ho_rcp_conn = nullptr;   // connection ids
     uint8_t *ho_rcp_kind = nullptr;    // CHD_HO_*
@@ -59,13 +66,14 @@ struct World {
 
 }  // namespace
 
-#define EV_PER_TICK (CHD_N_STAGES + 4)
+#define EV_PER_TICK (CHD_N_STAGES + 5)  // stage boundaries, interest begin/end (second stream), dominant emit kernel end / begin
 
 struct chd_ctx {
     int device = 0;
     hipStream_t stream = nullptr;      // where work is enqueued (own_stream unless chd_set_stream)
     hipStream_t own_stream = nullptr;
-    hipStream_t aux_stream = nullptr;   // interest updates run here, beside ingest + index build on `stream`
+    hipStream_t aux_stream = nullptr;   // interest updates run here, beside ingest + index build on `stream`; pipelined ticks: all stages
+    hipStream_t aux2_stream = nullptr;  // pipelined ticks: the interest updates, beside ingest + index build on aux_stream
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     chd_grid_cfg cfg{};
     DevGrid g{};
@@ -77,6 +85,7 @@ struct chd_ctx {
     // scratch for the stateless entry points and for chd_tick's staging
     DevBuf scratch[16];
     bool force_device = false;          // CHD_NO_HOST_FAST_PATH=1: small stateless calls go to the device too (tests, measurements)
+    bool chain = false, chain_prev = false;  // the previous call on this ctx was a pipelined tick (bind() shifts them)
     int prof_depth = 0;                 // 0 = off
     std::vector<hipEvent_t> ev;         // [prof_depth][EV_PER_TICK]: stage boundaries on `stream`, then interest begin/end
     std::vector<uint8_t> ev_overlap;    // [prof_depth] the slot's tick ran the interest stage on aux_stream
@@ -126,6 +135,10 @@ T *sbuf(chd_ctx *ctx, int slot) { return (T *)ctx->scratch[slot].p; }
 
 int bind(chd_ctx *ctx) {
     HIPCHK(hipSetDevice(ctx->device));
+    // every entry point passes here once: a pipelined tick that directly follows a pipelined tick (nothing else was asked
+    // of this ctx in between) may start its stages while the previous tick's records are still being written
+    ctx->chain_prev = ctx->chain;
+    ctx->chain = false;
     return CHD_OK;
 }
 
@@ -309,7 +322,14 @@ int chd_create(const chd_grid_cfg *cfg, int device, chd_ctx **out) {
         return fail(nullptr, CHD_E_HIP, "cannot create a stream on device %d", device);
     }
     ctx->stream = ctx->own_stream;
-    if (hipStreamCreateWithFlags(&ctx->aux_stream, hipStreamNonBlocking) != hipSuccess ||
+    // the second stream outranks the first: with CHD_WORLD_PIPELINE_TICKS its small, latency-bound kernels run beside a
+    // record kernel whose 10^4 workgroups would otherwise take every wave slot that frees up until its last one is placed
+    // (measured: k_ingest 176 us instead of 10 when it starts beside k_fanout_emit_seg at equal priority)
+    int prio_lo = 0, prio_hi = 0;
+    (void)hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);
+    if (const char *e = getenv("CHD_AUX_PRIORITY")) prio_hi = atoi(e);  // (experiments)
+    if (hipStreamCreateWithPriority(&ctx->aux_stream, hipStreamNonBlocking, prio_hi) != hipSuccess ||
+        hipStreamCreateWithPriority(&ctx->aux2_stream, hipStreamNonBlocking, prio_hi) != hipSuccess ||
         hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&ctx->ev_join, hipEventDisableTiming) != hipSuccess) {
         (void)hipStreamDestroy(ctx->own_stream);
@@ -365,6 +385,7 @@ int chd_create(const chd_grid_cfg *cfg, int device, chd_ctx **out) {
     if (aoi_lds_bytes(ctx->lim, 1) > aoi_lds_limit()) {
         (void)hipStreamDestroy(ctx->own_stream);
         (void)hipStreamDestroy(ctx->aux_stream);
+        (void)hipStreamDestroy(ctx->aux2_stream);
         delete ctx;
         return fail(nullptr, CHD_E_CONFIG, "grid of %u x %u cells: the per-query work area exceeds the LDS of a CU", g.cols, g.rows);
     }
@@ -379,6 +400,13 @@ void chd_destroy(chd_ctx *ctx) {
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
+    (void)hipStreamSynchronize(ctx->aux_stream);
+    if (ctx->w.ev_stages_done) {
+        (void)hipEventDestroy(ctx->w.ev_stages_done);
+        (void)hipEventDestroy(ctx->w.ev_rec_sync);
+        (void)hipEventDestroy(ctx->w.ev_stages_all);
+        for (auto &e : ctx->w.ev_emit_done) (void)hipEventDestroy(e);
+    }
     for (void *p : ctx->w.allocs) (void)hipFree(p);
     for (void *b : ctx->w.grp_buf) if (b) (void)hipFree(b);
     if (ctx->w.recs_dense) (void)hipFree(ctx->w.recs_dense);
@@ -390,6 +418,7 @@ void chd_destroy(chd_ctx *ctx) {
     (void)hipEventDestroy(ctx->ev_fork);
     (void)hipEventDestroy(ctx->ev_join);
     (void)hipStreamDestroy(ctx->aux_stream);
+    (void)hipStreamDestroy(ctx->aux2_stream);
     (void)hipStreamDestroy(ctx->own_stream);
     delete ctx;
 }
@@ -697,6 +726,10 @@ int chd_world_create(chd_ctx *ctx, const chd_world_cfg *cfg) {
         hipDeviceProp_t prop;
         HIPCHK(hipGetDeviceProperties(&prop, ctx->device));
         d.emit_grid = (uint32_t)std::max(prop.multiProcessorCount, 1) * 4u;  // 4 workgroups of ~37 KB LDS per CU
+        // k_fanout_emit_seg: persistent waves per CU (of the 32 wave slots; the rest stays free for the next tick's stages)
+        uint32_t per_cu = 8;   // (measured on config B: 8 -> 141 us, 16 -> 154 us, 32 -> 159 us; 6 -> 160 us)
+        if (const char *e = getenv("CHD_EMIT_WAVES_PER_CU")) per_cu = (uint32_t)std::min(std::max(atoi(e), 1), 64);
+        d.seg_waves = (uint32_t)std::max(prop.multiProcessorCount, 1) * per_cu;
     }
     TRY(walloc(ctx, &d.cell_tab, 2 * C));
     d.cell_cov = nullptr;  // (region-sharded worlds allocate it with the ghost room, chd_shard_halo_layout)
@@ -720,6 +753,7 @@ int chd_world_create(chd_ctx *ctx, const chd_world_cfg *cfg) {
     TRY(walloc(ctx, &d.pair_flags, P));
     TRY(walloc(ctx, &d.conn_defer, S));
     TRY(walloc(ctx, &d.n_simple, S));
+    TRY(walloc(ctx, &d.emit_ticket, 8 * 32));
     TRY(walloc(ctx, &d.seg_desc, P, false));
     TRY(walloc(ctx, &d.seg_desc2, P, false));
     TRY(walloc(ctx, &d.seg_ln, P, false));
@@ -761,8 +795,28 @@ int chd_world_create(chd_ctx *ctx, const chd_world_cfg *cfg) {
     if (W.wire && !cfg->max_records) nrec = std::min<uint64_t>(nrec / 3, 1000000000ull);  // three more 4-byte arrays per record
     const bool masks = (cfg->flags & CHD_WORLD_UPDATE_MASKS) != 0;
     if (masks && !cfg->max_records) nrec = nrec * 2 / 3;  // one more 4-byte array per record
+    // tick pipelining: only with the descriptor-driven connection-major emit (its record kernel reads descriptors, offsets
+    // and one column array: all of them, and the record buffer, then exist once per tick parity)
+    W.pipe_alloc = (cfg->flags & CHD_WORLD_PIPELINE_TICKS) && !d.cm_emit && !masks && !W.wire && (S >= 4096 || d.one_wave_emit);
+    W.pipe_on = W.pipe_alloc;
+    if (W.pipe_alloc && !cfg->max_records) nrec /= 2;
     d.recs_cap = nrec;
     TRY(walloc(ctx, &d.recs, nrec, false));
+    if (W.pipe_alloc) {
+        W.pb_n_simple[0] = d.n_simple; W.pb_rec_ub[0] = d.rec_ub; W.pb_seg_desc[0] = d.seg_desc; W.pb_seg_desc2[0] = d.seg_desc2;
+        W.pb_ce_chan[0] = d.ce_chan; W.pb_recs[0] = d.recs; W.pb_ticket[0] = d.emit_ticket;
+        TRY(walloc(ctx, &W.pb_ticket[1], 8 * 32));
+        TRY(walloc(ctx, &W.pb_n_simple[1], S));
+        TRY(walloc(ctx, &W.pb_rec_ub[1], S + 1));
+        TRY(walloc(ctx, &W.pb_seg_desc[1], P, false));
+        TRY(walloc(ctx, &W.pb_seg_desc2[1], P, false));
+        TRY(walloc(ctx, &W.pb_ce_chan[1], N + 520));
+        TRY(walloc(ctx, &W.pb_recs[1], nrec, false));
+        HIPCHK(hipEventCreateWithFlags(&W.ev_stages_done, hipEventDisableTiming));
+        HIPCHK(hipEventCreateWithFlags(&W.ev_rec_sync, hipEventDisableTiming));
+        HIPCHK(hipEventCreateWithFlags(&W.ev_stages_all, hipEventDisableTiming));
+        for (int k = 0; k < 2; k++) HIPCHK(hipEventCreateWithFlags(&W.ev_emit_done[k], hipEventDisableTiming));
+    }
     d.rec_mask = nullptr;
     if (masks) TRY(walloc(ctx, &d.rec_mask, nrec, false));
     d.rec_pos = nullptr;
@@ -1044,8 +1098,26 @@ static int tick_locked(chd_ctx *ctx, const chd_tick_in *in) {
     TRY(check_queries(ctx, in));
     if (in->n_cell_updates && (!in->cell_upd_channel || !in->cell_upd_sender)) return fail(ctx, CHD_E_INVAL, "tick: NULL cell updates");
     if (W.slot_mode == 2) return fail(ctx, CHD_E_STATE, "chd_tick on a region-sharded world: use chd_shard_ingest/import/fanout");
+    const bool chained = ctx->chain_prev;
     TRY(tick_begin(ctx, in->now_ns));
     TickRing &r = ctx->ring;
+    // CHD_WORLD_PIPELINE_TICKS: the record-writing kernel of this tick runs on `stream` while the NEXT tick's stages
+    // (ingest ... plan, commit, the deferred subscriptions, epilogue) run on the second stream: they write the other parity's
+    // copies of what that kernel reads.  Stream order: stages(t) -> records(t) on `stream`; stages(t+1) after stages(t)
+    // and after records(t-1), whose buffers they reuse.
+    const bool pipe = W.pipe_on && fanout_seg_path(d);
+    hipStream_t st = ctx->stream;
+    hipStream_t bs = pipe ? ctx->aux_stream : st;
+    const uint32_t par = r.cur_tick & 1u;
+    if (pipe) {
+        d.n_simple = W.pb_n_simple[par]; d.rec_ub = W.pb_rec_ub[par]; d.seg_desc = W.pb_seg_desc[par];
+        d.seg_desc2 = W.pb_seg_desc2[par]; d.ce_chan = W.pb_ce_chan[par]; d.recs = W.pb_recs[par]; d.emit_ticket = W.pb_ticket[par];
+        if (chained) HIPCHK(hipStreamWaitEvent(bs, W.ev_emit_done[par], 0));
+        else {  // something else was enqueued on `stream` since the last tick (or this is the first one): after all of it
+            HIPCHK(hipEventRecord(W.ev_rec_sync, st));
+            HIPCHK(hipStreamWaitEvent(bs, W.ev_rec_sync, 0));
+        }
+    }
     d.ce_view = d.ce;
     d.ce8_view = d.ce8;
     d.ce_chan_view = d.ce_chan;
@@ -1053,50 +1125,77 @@ static int tick_locked(chd_ctx *ctx, const chd_tick_in *in) {
     d.ce_sprev_stride = 0;
     d.cell_start = d.cell_off;
     d.cell_end = d.cell_off + 1;
-    hipStream_t st = ctx->stream;
     const bool prof = ctx->prof_depth > 0;
     hipEvent_t *ev = prof ? &ctx->ev[(size_t)(r.cur_tick % (uint32_t)ctx->prof_depth) * EV_PER_TICK] : nullptr;
     // CHD_WORLD_OVERLAP_INTEREST: the interest updates touch subscriptions only, ingest + index build entities
     // only, so the two can run side by side on two streams and join before the fan-out plan.  (Not with handover
     // recipients: those are planned on the subscriptions as they were BEFORE this tick's interest updates.)
-    const bool overlap = W.overlap_interest && !W.plan_recipients && in->n_queries > 0;
+    // Pipelined ticks always do, on a third stream (their stages are latency-bound and run beside an HBM-saturating kernel).
+    const bool overlap = (W.overlap_interest || pipe) && !W.plan_recipients && in->n_queries > 0;
+    // stage events: the serial schedule marks every stage boundary; the pipelined one only the begin and end of the stage
+    // stream's work (a timed event between two small kernels costs ~5 us of idle stream) — stage_times() reports that
+    // span as stage 0
+    const bool prof_stages = prof && !pipe;
     if (prof) {
-        ctx->ev_overlap[r.cur_tick % (uint32_t)ctx->prof_depth] = overlap;
-        HIPCHK(hipEventRecord(ev[0], st));
+        ctx->ev_overlap[r.cur_tick % (uint32_t)ctx->prof_depth] = (overlap ? 1 : 0) | (pipe ? 2 : 0);
+        HIPCHK(hipEventRecord(ev[0], bs));
     }
     if (overlap) {
-        hipStream_t ax = ctx->aux_stream;
-        HIPCHK(hipEventRecord(ctx->ev_fork, st));
+        hipStream_t ax = pipe ? ctx->aux2_stream : ctx->aux_stream;
+        HIPCHK(hipEventRecord(ctx->ev_fork, bs));
         HIPCHK(hipStreamWaitEvent(ax, ctx->ev_fork, 0));
-        if (prof) HIPCHK(hipEventRecord(ev[CHD_N_STAGES + 1], ax));
+        if (prof_stages) HIPCHK(hipEventRecord(ev[CHD_N_STAGES + 1], ax));
         launch_aoi_interest(ax, ctx->g, ctx->lim, d, in->queries, in->n_queries, in->query_sub, in->spot_x, in->spot_z,
                             in->spot_dist, in->now_ns, r.cur_tick);
-        if (prof) HIPCHK(hipEventRecord(ev[CHD_N_STAGES + 2], ax));
+        if (prof_stages) HIPCHK(hipEventRecord(ev[CHD_N_STAGES + 2], ax));
         HIPCHK(hipEventRecord(ctx->ev_join, ax));
     }
-    launch_ingest(st, ctx->g, d, in->n_updates, in->upd_idx, in->upd_x, in->upd_z, in->upd_sender, r.cur_tick);
-    launch_cell_updates(st, ctx->g, d, in->n_cell_updates, in->cell_upd_channel, in->cell_upd_sender, r.cur_tick);
+    launch_ingest(bs, ctx->g, d, in->n_updates, in->upd_idx, in->upd_x, in->upd_z, in->upd_sender, r.cur_tick);
+    launch_cell_updates(bs, ctx->g, d, in->n_cell_updates, in->cell_upd_channel, in->cell_upd_sender, r.cur_tick);
     if (W.plan_recipients) {
         // who receives each handover's message: on the subscriptions as they are NOW, before this tick's
         // interest updates (the reference sends from Notify, spatial.go:776-857)
-        launch_handover_recipients_count(st, ctx->g, d, W.ho_rcp_off);
-        launch_scan_u32_inplace_dev(st, W.ho_rcp_off, d.handovers_cap, d.counters + CTR_HANDOVERS);
-        launch_handover_recipients_fill(st, ctx->g, d, W.ho_rcp_off, W.ho_rcp_conn, W.ho_rcp_kind, W.ho_rcp_cap);
+        launch_handover_recipients_count(bs, ctx->g, d, W.ho_rcp_off);
+        launch_scan_u32_inplace_dev(bs, W.ho_rcp_off, d.handovers_cap, d.counters + CTR_HANDOVERS);
+        launch_handover_recipients_fill(bs, ctx->g, d, W.ho_rcp_off, W.ho_rcp_conn, W.ho_rcp_kind, W.ho_rcp_cap);
     }
-    if (prof) HIPCHK(hipEventRecord(ev[1], st));
-    launch_index_build(st, ctx->g, d, r.cur_tick);
-    if (prof) HIPCHK(hipEventRecord(ev[2], st));
-    if (overlap) HIPCHK(hipStreamWaitEvent(st, ctx->ev_join, 0));
+    if (prof_stages) HIPCHK(hipEventRecord(ev[1], bs));
+    launch_index_build(bs, ctx->g, d, r.cur_tick);
+    if (prof_stages) HIPCHK(hipEventRecord(ev[2], bs));
+    if (overlap) HIPCHK(hipStreamWaitEvent(bs, ctx->ev_join, 0));
     else
-        launch_aoi_interest(st, ctx->g, ctx->lim, d, in->queries, in->n_queries, in->query_sub, in->spot_x, in->spot_z,
+        launch_aoi_interest(bs, ctx->g, ctx->lim, d, in->queries, in->n_queries, in->query_sub, in->spot_x, in->spot_z,
                             in->spot_dist, in->now_ns, r.cur_tick);
-    if (prof) HIPCHK(hipEventRecord(ev[3], st));
-    launch_fanout_plan(st, ctx->g, d, in->now_ns, r);
-    if (prof) HIPCHK(hipEventRecord(ev[4], st));
-    launch_fanout_emit(st, ctx->g, d, in->now_ns, r, prof ? ev[CHD_N_STAGES + 3] : nullptr);
-    if (prof) HIPCHK(hipEventRecord(ev[5], st));
-    launch_tick_epilogue(st, d, r.cur_tick % TICK_RING);
+    if (prof_stages) HIPCHK(hipEventRecord(ev[3], bs));
+    launch_fanout_plan(bs, ctx->g, d, in->now_ns, r);
+    if (prof_stages) HIPCHK(hipEventRecord(ev[4], bs));
+    if (pipe) {
+        // the record kernel needs the plan and the scan; the deferred subscriptions (+ the state commit) and the epilogue finish beside it
+        HIPCHK(hipEventRecord(W.ev_stages_done, bs));
+        HIPCHK(hipStreamWaitEvent(st, W.ev_stages_done, 0));
+        if (prof) HIPCHK(hipEventRecord(ev[CHD_N_STAGES + 4], st));
+        launch_fanout_emit_main(st, ctx->g, d, in->now_ns, r);
+        if (prof) {
+            HIPCHK(hipEventRecord(ev[CHD_N_STAGES + 3], st));
+            HIPCHK(hipEventRecord(ev[5], st));
+        }
+        HIPCHK(hipEventRecord(W.ev_emit_done[par], st));
+        launch_fanout_emit_deferred(bs, ctx->g, d, in->now_ns, r);
+        launch_tick_epilogue(bs, d, r.cur_tick % TICK_RING);
+        if (prof) HIPCHK(hipEventRecord(ev[4], bs));
+        // ... and whatever is enqueued on `stream` after this tick comes after ALL of it
+        HIPCHK(hipEventRecord(W.ev_stages_all, bs));
+        HIPCHK(hipStreamWaitEvent(st, W.ev_stages_all, 0));
+    } else {
+        if (prof) HIPCHK(hipEventRecord(ev[CHD_N_STAGES + 4], st));
+        launch_fanout_emit_main(st, ctx->g, d, in->now_ns, r);
+        if (prof) HIPCHK(hipEventRecord(ev[CHD_N_STAGES + 3], st));
+        launch_fanout_emit_deferred(st, ctx->g, d, in->now_ns, r);
+        if (prof) HIPCHK(hipEventRecord(ev[5], st));
+        launch_tick_epilogue(st, d, r.cur_tick % TICK_RING);
+    }
     TRY(after_launch(ctx));
+    ctx->chain = pipe;
     W.last_nq = in->n_queries;
     W.ticked = true;
     W.wire_built = false;
@@ -1132,21 +1231,33 @@ __global__ void __launch_bounds__(256) k_list_pack(const uint32_t *bank_n, uint3
 static void stage_times(chd_ctx *ctx, uint32_t tick, chd_tick_stats &s) {
     const uint32_t slot = tick % (uint32_t)ctx->prof_depth;
     hipEvent_t *ev = &ctx->ev[(size_t)slot * EV_PER_TICK];
-    for (int k = 0; k < CHD_N_STAGES; k++) {
-        float ms = 0;
-        (void)hipEventElapsedTime(&ms, ev[k], ev[k + 1]);
-        s.stage_us[k] = ms * 1000.f;
-    }
-    if (ctx->ev_overlap[slot]) {
-        float ms = 0;
-        (void)hipEventElapsedTime(&ms, ev[CHD_N_STAGES + 1], ev[CHD_N_STAGES + 2]);
-        s.stage_us[2] = ms * 1000.f;
-    }
     float ms = 0;
+    if (ctx->ev_overlap[slot] & 2) {
+        // pipelined tick: stage 0 = everything on the stage stream (ingest ... plan, commit, deferred subscriptions, epilogue),
+        // stage 4 = from there to the end of the record kernel (includes waiting for the previous tick's record kernel)
+        for (int k = 0; k < CHD_N_STAGES; k++) s.stage_us[k] = 0.f;
+        (void)hipEventElapsedTime(&ms, ev[0], ev[4]);
+        s.stage_us[0] = ms * 1000.f;
+        ms = 0;
+        (void)hipEventElapsedTime(&ms, ev[4], ev[5]);
+        s.stage_us[4] = ms * 1000.f;
+    } else {
+        for (int k = 0; k < CHD_N_STAGES; k++) {
+            ms = 0;
+            (void)hipEventElapsedTime(&ms, ev[k], ev[k + 1]);
+            s.stage_us[k] = ms * 1000.f;
+        }
+        if (ctx->ev_overlap[slot] & 1) {
+            ms = 0;
+            (void)hipEventElapsedTime(&ms, ev[CHD_N_STAGES + 1], ev[CHD_N_STAGES + 2]);
+            s.stage_us[2] = ms * 1000.f;
+        }
+    }
+    ms = 0;
     (void)hipEventElapsedTime(&ms, ev[0], ev[CHD_N_STAGES]);
     s.total_us = ms * 1000.f;
     ms = 0;
-    (void)hipEventElapsedTime(&ms, ev[CHD_N_STAGES - 1], ev[CHD_N_STAGES + 3]);
+    (void)hipEventElapsedTime(&ms, ev[CHD_N_STAGES + 4], ev[CHD_N_STAGES + 3]);
     s.emit_main_us = ms * 1000.f;
 }
 
@@ -1563,7 +1674,10 @@ int chd_shard_fanout(chd_ctx *ctx, const void *d_halo_recv, uint32_t world, cons
     if (prof) HIPCHK(hipEventRecord(ev[3], st));
     launch_fanout_plan(st, ctx->g, d, now, r);
     if (prof) HIPCHK(hipEventRecord(ev[4], st));
-    launch_fanout_emit(st, ctx->g, d, now, r, prof ? ev[CHD_N_STAGES + 3] : nullptr);
+    if (prof) HIPCHK(hipEventRecord(ev[CHD_N_STAGES + 4], st));
+    launch_fanout_emit_main(st, ctx->g, d, now, r);
+    if (prof) HIPCHK(hipEventRecord(ev[CHD_N_STAGES + 3], st));
+    launch_fanout_emit_deferred(st, ctx->g, d, now, r);
     if (prof) HIPCHK(hipEventRecord(ev[5], st));
     launch_tick_epilogue(st, d, r.cur_tick % TICK_RING);
     TRY(after_launch(ctx));
@@ -1929,6 +2043,17 @@ int chd_set_profiling(chd_ctx *ctx, int depth) {
         HIPCHK(hipStreamSynchronize(ctx->stream));
         ctx->prof_depth = depth;
     }
+    return CHD_OK;
+}
+
+int chd_world_set_pipelining(chd_ctx *ctx, int on) {
+    NEED_WORLD();
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    TRY(bind(ctx));
+    if (!ctx->w.pipe_alloc) return fail(ctx, CHD_E_STATE, "chd_world_set_pipelining: the world was not created with CHD_WORLD_PIPELINE_TICKS (or the flag did not take effect)");
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->aux_stream));
+    ctx->w.pipe_on = on != 0;
     return CHD_OK;
 }
 

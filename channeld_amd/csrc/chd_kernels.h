@@ -92,6 +92,8 @@ struct WorldDev {
     uint32_t *active_cells;         // [ncell] cells with cell_ref > 0 (compacted every tick)
     uint32_t *n_active;             // [1]
     uint32_t emit_grid;             // persistent grid of the cell-major emit kernel (workgroups)
+    uint32_t seg_waves;             // persistent waves of k_fanout_emit_seg (connection-major descriptor emit)
+    uint32_t *emit_ticket;          // [8 x 32] k_fanout_emit_seg's ticket counters, one 128-byte line each (zeroed by k_fanout_plan_seg)
     WsItemG *items;                 // [ncell * ceil(S/256)]
     uint32_t *conn_defer; // [S] this tick: the connection has subscriptions left to the deferred emit launch
     // descriptor-driven emit (k_fanout_plan_seg -> k_fanout_emit_seg): per connection the first n_simple[s] entries of its
@@ -300,6 +302,8 @@ void launch_adjacent_recipients(hipStream_t st, DevGrid g, WorldDev w, uint32_t 
                                 uint32_t *off, uint32_t *conns, uint64_t cap, int fill);
 // K5: fan-out
 void launch_fanout_plan(hipStream_t st, DevGrid g, WorldDev w, int64_t now_ns, TickRing ring);
-void launch_fanout_emit(hipStream_t st, DevGrid g, WorldDev w, int64_t now_ns, TickRing ring, hipEvent_t after_main = nullptr);
+bool fanout_seg_path(const WorldDev &w);
+void launch_fanout_emit_main(hipStream_t st, DevGrid g, WorldDev w, int64_t now_ns, TickRing ring);
+void launch_fanout_emit_deferred(hipStream_t st, DevGrid g, WorldDev w, int64_t now_ns, TickRing ring);
 #define TICK_RING 1024
 void launch_tick_epilogue(hipStream_t st, WorldDev w, uint32_t slot);

@@ -607,9 +607,7 @@ __global__ void __launch_bounds__(64 * WAVES) k_fanout_emit(DevGrid g, WorldDev 
     const uint32_t s = blockIdx.x;
     const uint32_t lane = lane_id();
     const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    if (DEFERRED) {
-        if (!w.conn_defer[s]) return;
-    } else if (!w.sub_alive[s]) {
+    if (!DEFERRED && !w.sub_alive[s]) {
         if (threadIdx.x == 0) w.rec_cnt[s] = 0;
         return;
     }
@@ -618,13 +616,33 @@ __global__ void __launch_bounds__(64 * WAVES) k_fanout_emit(DevGrid g, WorldDev 
     const uint64_t base = w.rec_ub[s];
     if (w.rec_ub[s + 1] > w.recs_cap) {
         // no room for this connection's worst case: leave its state untouched, it
-        // catches up next tick (the reference's catch-up loop), and say so.
-        for (uint32_t p = threadIdx.x; p < cnt; p += 64 * WAVES) w.pair_nrec[pbase + p] = 0;
-        if (threadIdx.x == 0) {
-            w.rec_cnt[s] = 0;
-            if (w.rec_ub[s + 1] > base) atomicOr(&w.counters[CTR_OVERFLOW], OVF_RECORDS);
+        // catches up next tick (the reference's catch-up loop), and say so.  (DEFERRED: also for the part
+        // k_fanout_emit_seg would have written — it skips such a connection without a word.)
+        if (!DEFERRED || w.rec_ub[s + 1] > base) {
+            for (uint32_t p = threadIdx.x; p < cnt; p += 64 * WAVES) w.pair_nrec[pbase + p] = 0;
+            if (threadIdx.x == 0) {
+                // (k_fanout_plan_seg has already counted the records it planned for this connection into the tick's total)
+                if (DEFERRED && w.rec_cnt[s])
+                    atomicAdd((unsigned long long *)&w.tot64[(size_t)(s & 63u) * 16], 0ull - (unsigned long long)w.rec_cnt[s]);
+                w.rec_cnt[s] = 0;
+                if (w.rec_ub[s + 1] > base) atomicOr(&w.counters[CTR_OVERFLOW], OVF_RECORDS);
+            }
         }
         return;
+    }
+    if (DEFERRED) {
+        // The subscriptions' new fan-out state (lastFanOutTime, hadFirstFanOut: data.go:217-223,271) for everything
+        // k_fanout_plan_seg decided: one coalesced pass over the connection's descriptors.  Here and not in
+        // k_fanout_emit_seg, which therefore reads nothing that a later tick's stages write and writes nothing but
+        // records: with CHD_WORLD_PIPELINE_TICKS it runs on the record stream while this launch, the epilogue and the
+        // next tick's stages run beside it.
+        const uint32_t ns = w.n_simple[s];
+        for (uint32_t k = lane; k < ns; k += 64) {
+            const uint4 d2 = w.seg_desc2[pbase + k];
+            w.pair_last[pbase + d2.y] = w.seg_ln[pbase + k];
+            w.pair_flags[pbase + d2.y] = d2.z;
+        }
+        if (!w.conn_defer[s]) return;
     }
 #ifdef CHD_PROFILE_CONN_EMIT
     long long ce_mark = clock64(), ce_pro = 0, ce_stage = 0, ce_ticket = 0, ce_decide = 0, ce_stream = 0, ce_tail = 0, ce_ls[3] = {0, 0, 0};
@@ -842,6 +860,7 @@ typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
 #endif
 
 __global__ void __launch_bounds__(64 * FO_WAVES) k_fanout_plan_seg(DevGrid g, WorldDev w, int64_t now, TickRing ring) {
+    if (blockIdx.x == 0 && threadIdx.x < 8) w.emit_ticket[32u * threadIdx.x] = 0;  // (this tick's k_fanout_emit_seg starts after this kernel)
     const uint32_t s = blockIdx.x * FO_WAVES + (threadIdx.x >> 6);
     if (s >= w.S) return;
     const uint32_t lane = lane_id();
@@ -1035,40 +1054,41 @@ extern "C" int chd_debug_trace(unsigned long long *out, unsigned n) {
 #define FO_SEG_BATCH 2   // segments whose columns a wave loads together, between two waits
 #endif
 
+// A PERSISTENT grid of single-wave workgroups, far fewer than the chip has wave slots (WorldDev::seg_waves): the record
+// stream saturates HBM with ~4 waves per SIMD, and the slots left free are what lets the next tick's stages run beside
+// this kernel (CHD_WORLD_PIPELINE_TICKS) — a launch of one workgroup per connection takes every slot that frees up until
+// its last workgroup is placed, and a kernel on another stream, whatever its priority, starts only then (measured:
+// k_index_hist 154 us instead of 8).  Work is handed out by tickets: ticket T = (connection T / WAVES, role T % WAVES),
+// the role's segments are k = role, role + WAVES, ...; eight counters on eight lines, a wave takes from the one of its
+// XCD (blockIdx & 7), and requests its NEXT ticket before it starts storing, so the atomic's return is awaited together
+// with the first column loads and never drains record stores.
 template <int WAVES>
-__global__ void __launch_bounds__(64 * WAVES, FO_SEG_OCC) k_fanout_emit_seg(DevGrid g, WorldDev w) {
+__global__ void __launch_bounds__(64, FO_SEG_OCC) k_fanout_emit_seg(DevGrid g, WorldDev w, uint32_t n_tickets) {
     constexpr int B = FO_SEG_BATCH;
-    const uint32_t s = blockIdx.x;
     const uint32_t lane = lane_id();
-    const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const uint32_t bank = blockIdx.x & 7u;
+    uint32_t *__restrict__ ctr = w.emit_ticket + 32u * bank;
+    uint32_t tk = 0;
+    if (lane == 0) tk = atomicAdd(ctr, 1u);
+    tk = (uint32_t)__builtin_amdgcn_readfirstlane((int)tk);
+    for (;;) {
+    const uint32_t T = 8u * tk + bank;
+    if (T >= n_tickets) break;
+    // the next ticket: requested now, read at the bottom of the loop
+    uint32_t tk_next = 0;
+    if (lane == 0) tk_next = atomicAdd(ctr, 1u);
+    const uint32_t s = T / WAVES;
+    const uint32_t wave = T % WAVES;
     PF_TRACE(0);
     const uint32_t ns = w.n_simple[s];
     const size_t pbase = (size_t)s * w.capq;
-    const uint64_t base = w.rec_ub[s];
-    if (w.rec_ub[s + 1] > w.recs_cap) {
-        // no room for this connection's worst case: state untouched, it catches up next tick (also the deferred part)
-        if (w.rec_ub[s + 1] > base) {
-            const uint32_t cnt = w.pair_cnt[s];
-            for (uint32_t p = threadIdx.x; p < cnt; p += 64 * WAVES) w.pair_nrec[pbase + p] = 0;
-            if (threadIdx.x == 0) {
-                w.rec_cnt[s] = 0;
-                w.conn_defer[s] = 0;
-                atomicOr(&w.counters[CTR_OVERFLOW], OVF_RECORDS);
-            }
-        }
-        return;
-    }
-    if (!ns) return;
-    if (wave == WAVES - 1)  // the subscriptions' new fan-out state: one coalesced pass (lastFanOutTime, hadFirstFanOut)
-        for (uint32_t k = lane; k < ns; k += 64) {
-            const uint4 d2 = w.seg_desc2[pbase + k];
-            w.pair_last[pbase + d2.y] = w.seg_ln[pbase + k];
-            w.pair_flags[pbase + d2.y] = d2.z;
-        }
+    const uint64_t base = w.rec_ub[s], end = w.rec_ub[s + 1];
+    tk = (uint32_t)__builtin_amdgcn_readfirstlane((int)tk_next);
+    // (end > recs_cap: no room for this connection's worst case — the deferred launch leaves its state as it was and flags the tick)
+    if (wave >= ns || end > w.recs_cap) continue;
     const uint32_t conn = w.conn_id[s];
     const uint32_t *__restrict__ chans = w.ce_chan_view;
     PF_TRACE(1);
-    if (wave >= ns) return;
     // Every descriptor of this wave in ONE vector load: lane j holds the wave's j-th segment (k = wave + j WAVES); the
     // streaming loop reads them with v_readlane (scalar operands from there on).  No descriptor load ever sits between
     // record stores: the vm counter is in-order, so ANY load wait also waits for every record store issued before it,
@@ -1152,6 +1172,7 @@ __global__ void __launch_bounds__(64 * WAVES, FO_SEG_OCC) k_fanout_emit_seg(DevG
 #ifdef FO_PF_TRACE
     if (threadIdx.x == 0 && s < 16384) fo_trace[4 * s + 3] = w.rec_cnt[s];
 #endif
+    }
 }
 
 // ---------------------------------------------------------------------------
@@ -1633,12 +1654,11 @@ __global__ void __launch_bounds__(64 * WS_WAVES) k_fanout_emit_ws(DevGrid g, Wor
     }
 }
 
-void launch_fanout_emit(hipStream_t st, DevGrid g, WorldDev w, int64_t now_ns, TickRing ring, hipEvent_t after_main) {
-    if (!w.S) {
-        if (after_main) (void)hipEventRecord(after_main, st);
-        return;
-    }
-    bool marked = false;
+bool fanout_seg_path(const WorldDev &w) { return seg_path(w); }
+
+// the kernel that writes (nearly) all records of the tick
+void launch_fanout_emit_main(hipStream_t st, DevGrid g, WorldDev w, int64_t now_ns, TickRing ring) {
+    if (!w.S) return;
     if (w.cm_emit) {
         const uint32_t chunks = (w.S + WS_SUBS - 1) / WS_SUBS;
         const uint64_t max_items = (uint64_t)g.ncell * chunks;
@@ -1646,24 +1666,26 @@ void launch_fanout_emit(hipStream_t st, DevGrid g, WorldDev w, int64_t now_ns, T
         const uint32_t pgrid = (uint32_t)(max_items < 8u * w.emit_grid ? max_items : 8u * w.emit_grid);
         hipLaunchKernelGGL(k_fanout_items, dim3(pgrid), dim3(WS_SUBS), 0, st, g, w, now_ns, ring, chunks);
         hipLaunchKernelGGL(k_fanout_emit_ws, dim3(grid), dim3(64 * WS_WAVES), 0, st, g, w, now_ns, ring, chunks);
-    } else {
-        // one wave per connection when the connections alone fill the chip (or when asked to: CHD_WORLD_ONE_WAVE_EMIT),
-        // four waves per connection otherwise
-        const bool one_wave = w.S >= 4096 || w.one_wave_emit;
-        if (w.rec_mask) {
-            if (one_wave) hipLaunchKernelGGL((k_fanout_emit<1, true>), dim3(w.S), dim3(64), 0, st, g, w, now_ns, ring);
-            else hipLaunchKernelGGL((k_fanout_emit<4, true>), dim3(w.S), dim3(256), 0, st, g, w, now_ns, ring);
-        } else if (one_wave) {
-            if (seg_path(w)) {
-                // (k_fanout_plan_seg has decided everything; see launch_fanout_plan)
-                hipLaunchKernelGGL(k_fanout_emit_seg<FO_SEG_WAVES>, dim3(w.S), dim3(64 * FO_SEG_WAVES), 0, st, g, w);
-                if (after_main) (void)hipEventRecord(after_main, st);
-                marked = true;
-                hipLaunchKernelGGL((k_fanout_emit<1, false, true>), dim3(w.S), dim3(64), 0, st, g, w, now_ns, ring);
-            } else hipLaunchKernelGGL((k_fanout_emit<1, false>), dim3(w.S), dim3(64), 0, st, g, w, now_ns, ring);
-        } else hipLaunchKernelGGL((k_fanout_emit<4, false>), dim3(w.S), dim3(256), 0, st, g, w, now_ns, ring);
+        return;
     }
-    if (after_main && !marked) (void)hipEventRecord(after_main, st);
+    // one wave per connection when the connections alone fill the chip (or when asked to: CHD_WORLD_ONE_WAVE_EMIT),
+    // four waves per connection otherwise
+    const bool one_wave = w.S >= 4096 || w.one_wave_emit;
+    if (w.rec_mask) {
+        if (one_wave) hipLaunchKernelGGL((k_fanout_emit<1, true>), dim3(w.S), dim3(64), 0, st, g, w, now_ns, ring);
+        else hipLaunchKernelGGL((k_fanout_emit<4, true>), dim3(w.S), dim3(256), 0, st, g, w, now_ns, ring);
+    } else if (seg_path(w)) {
+        // (k_fanout_plan_seg has decided everything; see launch_fanout_plan)
+        const uint32_t n_tickets = w.S * FO_SEG_WAVES;
+        hipLaunchKernelGGL(k_fanout_emit_seg<FO_SEG_WAVES>, dim3(n_tickets < w.seg_waves ? n_tickets : w.seg_waves), dim3(64), 0, st, g, w, n_tickets);
+    } else if (one_wave) hipLaunchKernelGGL((k_fanout_emit<1, false>), dim3(w.S), dim3(64), 0, st, g, w, now_ns, ring);
+    else hipLaunchKernelGGL((k_fanout_emit<4, false>), dim3(w.S), dim3(256), 0, st, g, w, now_ns, ring);
+}
+
+// the subscriptions k_fanout_plan_seg left to the filtering kernel (descriptor path only)
+void launch_fanout_emit_deferred(hipStream_t st, DevGrid g, WorldDev w, int64_t now_ns, TickRing ring) {
+    if (!w.S || !seg_path(w)) return;
+    hipLaunchKernelGGL((k_fanout_emit<1, false, true>), dim3(w.S), dim3(64), 0, st, g, w, now_ns, ring);
 }
 
 // Per-tick totals into the device-side history ring (read back by chd_tick_fetch /

@@ -294,6 +294,10 @@ class SpatialWorld:
         """depth > 0: HIP events around the stages of each tick, last `depth` ticks kept."""
         _lib.check(self.ctx, self.lib.chd_set_profiling(self.ctx, int(depth)))
 
+    def set_pipelining(self, on: bool):
+        """CHD_WORLD_PIPELINE_TICKS (flags & 128) worlds: serial schedule (False) or pipelined ticks (True)."""
+        _lib.check(self.ctx, self.lib.chd_world_set_pipelining(self.ctx, 1 if on else 0))
+
     def history(self, n: int):
         """Per-tick statistics of the last n ticks, oldest first."""
         arr = (TickStats * n)()

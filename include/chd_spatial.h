@@ -195,6 +195,18 @@ typedef struct {
  * where four waves per connection is the default.  For tests and for small worlds with few subscriptions per connection. */
 #define CHD_WORLD_ONE_WAVE_EMIT 64u
 
+/* Pipeline successive ticks over two HIP streams: the kernel that writes tick t's records (HBM-write bound, ~55 % of a
+ * tick of config B) runs on the ctx stream while tick t+1's stages — ingest, index build, interest updates, fan-out plan,
+ * the subscriptions' new fan-out state — run beside it on a second stream; what that kernel reads (segment descriptors,
+ * record offsets, the cells' entity columns) and the record buffer itself then exist twice, by tick parity (max_records
+ * = 0 halves the automatic buffer size accordingly).  Results are those of the serial schedule, tick for tick; the
+ * latency of ONE tick does not change, the rate of back-to-back chd_tick_device calls does.
+ * Takes effect where the descriptor-driven connection-major emit runs (no cell-major emit, no CHD_WORLD_UPDATE_MASKS,
+ * no CHD_WORLD_WIRE, no region sharding) and is ignored elsewhere.  Contract: the device inputs of chd_tick_device
+ * must be COMPLETE when the call is made — the stages do not wait for work the caller merely enqueued on the ctx
+ * stream.  Everything else (chd_tick, fetch, digest, sync, any other entry point) orders itself after both streams. */
+#define CHD_WORLD_PIPELINE_TICKS 128u
+
 #define CHD_ENTITY_LOCKED 1u /* member of a non-empty lock group (entity.go:197-224) */
 
 int chd_world_create(chd_ctx *ctx, const chd_world_cfg *cfg);
@@ -595,6 +607,9 @@ typedef struct {
 /* depth > 0: record HIP events around the stages of the next ticks, keeping the
  * last `depth` ticks (<= 1024); 0 turns it off. */
 int chd_set_profiling(chd_ctx *ctx, int depth);
+/* Turn the tick pipelining of a CHD_WORLD_PIPELINE_TICKS world off (on = 0: serial schedule on the ctx stream, as without
+ * the flag) and on again; CHD_E_STATE for a world created without the flag (or where it did not take effect). */
+int chd_world_set_pipelining(chd_ctx *ctx, int on);
 int chd_get_tick_stats(chd_ctx *ctx, chd_tick_stats *out);
 /* Statistics of the last n ticks (out[0] = most recent), n <= 1024.  Counts come
  * from a device-side ring written by every tick; stage times need profiling.

@@ -134,6 +134,116 @@ def test_config_b_cell_major_emit_record_digests(amd):
     assert total > 400_000_000
 
 
+def run_pipelined_groups(amd, N, S, seed, groups, per_group, flags, max_records, cfg_name="spatial_static_benchmark.json"):
+    """CHD_WORLD_PIPELINE_TICKS: `per_group` ticks issued back to back through chd_tick_device (inputs resident, nothing
+    fetched in between, so tick t+1's stages overlap tick t's record kernel), then the group's LAST tick compared with
+    the oracle in full (records by digest, handovers, unsubs, state) and the ticks before it by their counts from the
+    device-side history ring.  The serial schedule must be reproduced tick for tick."""
+    cfg, sw, ctl, w = build(amd, N, S, seed, max_records=max_records, flags=flags, cfg_name=cfg_name)
+    ow = oracle_world(cfg, sw, N, S, w.capq)
+    k = 0
+    total = 0
+    for g in range(groups):
+        xs = np.empty((per_group, N)); zs = np.empty((per_group, N)); qs = np.empty((per_group, S), dtype=synth.AOI_DTYPE)
+        now, want = [], []
+        for t in range(per_group):
+            sw.step()
+            xs[t], zs[t], qs[t] = sw.x, sw.z, sw.queries()
+            now.append(sw.now_ns())
+            ow.tick(now[-1], None, sw.x, sw.z, None, None, None, None, qs[t])
+            want.append((ow.digest()[0][0], len(ow.handovers()[0]), len(ow.unsubs()[0])))
+        dx, dz, dq = w.device_array(xs), w.device_array(zs), w.device_array(qs)
+        w.sync()
+        for t in range(per_group):  # back to back: every call after the first is chained to a pipelined tick
+            w.tick_device(now[t], n_updates=N, d_upd_x=dx.at(t * N * 8), d_upd_z=dz.at(t * N * 8), n_queries=S, d_queries=dq.at(t * S * 128))
+        res = w.fetch(want_records=False)
+        compare_tick(k + per_group - 1, w, ow, res, sw)
+        hist = w.history(per_group)
+        got = [(h["n_records"], h["n_handovers"], h["n_unsubs"]) for h in hist]
+        assert got == want, f"group {g}: per-tick counts {got} != oracle {want}"
+        total += sum(c for c, _, _ in want)
+        k += per_group
+        for a in (dx, dz, dq):
+            a.free()
+    return total, (cfg, sw, ctl, w, ow)
+
+
+def test_config_b_pipelined_ticks_match_the_serial_oracle(amd):
+    """BASELINE config B with CHD_WORLD_PIPELINE_TICKS (what bench.py's `value` runs): 6 groups of 4 back-to-back ticks."""
+    total, (cfg, sw, ctl, w, ow) = run_pipelined_groups(amd, 100_000, 10_000, 0xC0FFEE21, 6, 4, flags=128, max_records=120_000_000)
+    assert total > 1_200_000_000
+    # ... and switched off on the same world: the serial schedule continues from the same state
+    w.set_pipelining(False)
+    for k in range(3):
+        sw.step()
+        q = sw.queries()
+        ow.tick(sw.now_ns(), None, sw.x, sw.z, None, None, None, None, q)
+        res = w.tick(sw.now_ns(), upd_x=sw.x, upd_z=sw.z, queries=q, want_records=False, records_cap=1)
+        compare_tick(100 + k, w, ow, res, sw)
+    w.set_pipelining(True)
+    for k in range(3):  # single pipelined ticks with a fetch after each (never chained)
+        sw.step()
+        q = sw.queries()
+        ow.tick(sw.now_ns(), None, sw.x, sw.z, None, None, None, None, q)
+        res = w.tick(sw.now_ns(), upd_x=sw.x, upd_z=sw.z, queries=q, want_records=False, records_cap=1)
+        compare_tick(200 + k, w, ow, res, sw)
+
+
+def test_pipelined_ticks_with_deferred_subscriptions_and_full_buffer(amd):
+    """The same on a world whose subscriptions partly take the deferred (filtering) launch — only 30 % of the entities
+    update per tick, so cells hold entities with and without buffered updates — and with a record buffer that does not hold
+    a whole tick: connections that do not fit keep their state and catch up (overflow flag), identically in both schedules."""
+    N, S = 20_000, 4_096
+    for max_records, expect_overflow in ((40_000_000, False), (1_500_000, True)):
+        seed = 0xC0FFEE22
+        worlds = []
+        for flags in (1 | 64, 1 | 64 | 128):
+            cfg, sw, ctl, w = build(amd, N, S, seed, max_records=max_records, flags=flags)
+            worlds.append((sw, w))
+        rng = np.random.default_rng(5)
+        ovf = 0
+        for g in range(4):
+            frames = []
+            for t in range(3):
+                for sw, _ in worlds:
+                    sw.step()
+                sw0 = worlds[0][0]
+                idx = np.sort(rng.choice(N, int(0.3 * N), replace=False)).astype(np.uint32)
+                frames.append((sw0.now_ns(), idx, sw0.x[idx].copy(), sw0.z[idx].copy(), sw0.queries().copy()))
+            outs = []
+            for (sw, w), chained in zip(worlds, (False, True)):
+                dev = [(now, len(idx), w.device_array(idx), w.device_array(x), w.device_array(z), w.device_array(q)) for now, idx, x, z, q in frames]
+                w.sync()
+                per = []
+                for now, n, di, dx, dz, dq in dev:
+                    w.tick_device(now, n_updates=n, d_upd_x=dx.at(0), d_upd_z=dz.at(0), d_upd_idx=di.at(0), n_queries=S, d_queries=dq.at(0))
+                    if not chained:
+                        w.sync()
+                try:
+                    res = w.fetch(want_records=False)
+                    overflow, ho = res.overflow, np.sort(res.handovers, order="entity").copy()
+                except amd.ChdError as e:  # "tick output truncated (overflow mask 0x4)": what the small buffer is there for
+                    assert expect_overflow and "0x4" in str(e), e
+                    overflow, ho = 4, None
+                (cnt, dsum, dxor, _), conn_sum = w.digest()
+                hist = [(h["n_records"], h["n_handovers"], h["n_unsubs"], h["n_deferred_records"]) for h in w.history(3)]
+                outs.append((cnt, dsum, dxor, conn_sum.copy(), hist, overflow, ho))
+                for _, _, di, dx, dz, dq in dev:
+                    for a in (di, dx, dz, dq):
+                        a.free()
+            a, b = outs
+            assert a[:3] == b[:3] and np.array_equal(a[3], b[3]), f"group {g}: record digests differ between the schedules"
+            assert a[4] == b[4] and a[5] == b[5] and (a[6] is None or np.array_equal(a[6], b[6])), f"group {g}: {a[4]} vs {b[4]}, overflow {a[5]} vs {b[5]}"
+            ovf |= a[5]
+            if g == 3 and not expect_overflow:
+                assert sum(h[3] for h in a[4]) > 0, "the world never took the deferred launch"
+        assert bool(ovf & 4) == expect_overflow, f"overflow mask {ovf:#x}"  # OVF_RECORDS
+        for (sw, w) in worlds:
+            c0, m0 = worlds[0][1].entity_state()
+            c1, m1 = w.entity_state()
+            assert np.array_equal(c0, c1) and np.array_equal(m0, m1)
+
+
 def test_config_c_one_million_entities_12_ticks_record_digests(amd):
     """BASELINE config C: 1M entities / 10K subscribers (cell-major emit auto-selected), every tick compared."""
     N, S = 1_000_000, 10_000

@@ -16,14 +16,15 @@ pytestmark = pytest.mark.gpu
 EMIT_FLAGS = 0
 
 
-@pytest.fixture(autouse=True, params=["cell-major", "conn-major", "conn-major-1w"])
+@pytest.fixture(autouse=True, params=["cell-major", "conn-major", "conn-major-1w", "conn-major-1w-pipe"])
 def emit_mode(request):
     """Every world test runs against every form of the fan-out emit kernel: cell-major, connection-major with four
     waves per connection, and connection-major with one wave per connection (the pipelined kernel + its deferred
-    launch: what config B's 10K connections take)."""
+    launch: what config B's 10K connections take), and the latter with CHD_WORLD_PIPELINE_TICKS (stages on the second stream;
+    these tests fetch after every tick, so ticks never overlap here — tests/test_gpu_fullsize.py issues them back to back)."""
     global EMIT_FLAGS
     # CHD_WORLD_CONN_MAJOR_EMIT / CHD_WORLD_CELL_MAJOR_EMIT / | CHD_WORLD_ONE_WAVE_EMIT
-    EMIT_FLAGS = {"conn-major": 1, "cell-major": 2, "conn-major-1w": 1 | 64}[request.param]
+    EMIT_FLAGS = {"conn-major": 1, "cell-major": 2, "conn-major-1w": 1 | 64, "conn-major-1w-pipe": 1 | 64 | 128}[request.param]
     yield request.param
 
 
