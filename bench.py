@@ -339,7 +339,9 @@ def main():
     e2e = None
     if E and args.update_frac >= 1.0 and not args.wire:
         e2e = {}
-        r = e2e_host_ticks(world, e2e_frames, E)
+        trace("e2e host ticks")
+        r = e2e_host_ticks(world, e2e_frames, E) if not os.environ.get("CHD_BENCH_SKIP_E2E_HOST") else [(1.0, 1)]
+        trace("e2e host ticks done")
         best = min(r, key=lambda v: v[0])
         e2e["host_buffers"] = {
             "what": "chd_tick(host pointers): H2D of positions + queries, the tick, dense per-connection pack, D2H of every 8-byte record",
@@ -387,9 +389,11 @@ def main():
         out["wire"] = wire_info
     # (ii) of --e2e-ticks: the packet streams a gateway would hand to conn.Write, on a second world (the wire mode
     # keeps one more 4-byte array per record, so it is never the headline world)
-    if e2e is not None:
+    if e2e is not None and not os.environ.get("CHD_BENCH_SKIP_E2E_WIRE"):
         world = None
+        trace("closing the first world")
         ctl.close()
+        trace("closed")
         ctl2 = A.StaticGrid2DSpatialController(device=local_rank)
         assert ctl2.LoadConfig(json.dumps(cfg).encode(), strict=False) is None
         sw2 = synth.SynthWorld(synth.WorldSpec(cfg, N, S, seed, tick_ms=args.tick_ms, aoi_scale=args.aoi_scale))
@@ -458,6 +462,11 @@ def flat_interval_line(A, synth, cfg, N, S, seed, args, local_rank, interval_ms,
             "emit_us": emit_us, "emit_frac_of_hbm_peak": BYTES_PER_MSG * (msgs / steps) / (emit_us * 1e-6) / 1e9 / HBM_PEAK_GBS}
 
 
+def trace(msg):
+    if os.environ.get("CHD_BENCH_TRACE"):
+        print(f"[bench {time.perf_counter():.3f}] {msg}", file=sys.stderr, flush=True)
+
+
 def wire_phase(args, world, ctl, N, tick_at, ticks, base_now, measure_last=None):
     """chd_tick_device + chd_wire_build for `ticks`; reports the tick + build of the last `measure_last` (default all)."""
     rng = np.random.default_rng(7)
@@ -473,13 +482,16 @@ def wire_phase(args, world, ctl, N, tick_at, ticks, base_now, measure_last=None)
     for i, t in enumerate(ticks):  # (--wire: replays the last ticks' inputs at later channel times)
         world.sync()
         a0 = time.perf_counter()
+        trace(f"wire tick {i}")
         tick_at(t, base_now + (t + 1) * args.tick_ms * 1_000_000)
         world.sync()
+        trace(f"wire tick {i} done")
         if i < first:
             continue  # (set-up ticks: the first, full-state fan-out would be tens of GB of packets)
         a = time.perf_counter()
         nbytes, npackets, ndropped = world.wire_build()
         world.sync()
+        trace(f"wire build {i} done: {nbytes} bytes")
         b = time.perf_counter()
         if i >= first:
             wt.append(b - a)

@@ -827,11 +827,17 @@ int chd_world_create(chd_ctx *ctx, const chd_world_cfg *cfg) {
         TRY(walloc(ctx, &d.ce_slot, N + 2));
         TRY(walloc(ctx, &x.rec_woff, nrec, false));
         TRY(walloc(ctx, &x.rec_wtag, nrec, false));
+        TRY(walloc(ctx, &x.seg_fast, P));
+        TRY(walloc(ctx, &x.conn_slow, S));
+        TRY(walloc(ctx, &x.trash, S * 4 * 16));
+        x.fast_ok = d.capq <= 512 ? 1u : 0u;
+        if (const char *e = getenv("CHD_WIRE_FAST")) x.fast_ok = (e[0] != '0' && x.fast_ok) ? 1u : 0u;  // (A/B runs)
         x.stride[0] = ((cfg->wire_max_update_len ? cfg->wire_max_update_len : 128u) + 15u) & ~15u;
         x.stride[1] = ((cfg->wire_max_full_len ? cfg->wire_max_full_len : 1024u) + 15u) & ~15u;
         for (int k = 0; k < 2; k++) {
-            TRY(walloc(ctx, &x.pay_ent[k], N * x.stride[k]));
-            TRY(walloc(ctx, &x.pay_cell[k], C * x.stride[k]));
+            // (+ 128: k_wire_copy_fast reads 80 bytes of a slot whatever its stride)
+            TRY(walloc(ctx, &x.pay_ent[k], N * x.stride[k] + 128));
+            TRY(walloc(ctx, &x.pay_cell[k], C * x.stride[k] + 128));
             TRY(walloc(ctx, &x.len_ent[k], N));
             TRY(walloc(ctx, &x.len_cell[k], C));
         }
@@ -851,7 +857,14 @@ int chd_world_create(chd_ctx *ctx, const chd_world_cfg *cfg) {
         TRY(walloc(ctx, &x.conn_wlen, S + 1));
         x.conn_woff = x.conn_wlen;
         TRY(walloc(ctx, &x.conn_npk, S));
-        TRY(walloc(ctx, &x.n_dropped, 1));
+        TRY(walloc(ctx, &x.n_dropped, 8 + 64));
+        x.ncell = (uint32_t)C;
+        x.npos = (uint32_t)N + 2u;
+        if (const char *e = getenv("CHD_DEBUG_POISON")) if (e[0] == '1') {  // (debugging: unwritten per-record words are recognisable)
+            HIPCHK(hipMemsetAsync(d.rec_pos, 0x7F, sizeof(uint32_t) * nrec, ctx->stream));
+            HIPCHK(hipMemsetAsync(x.rec_woff, 0x7F, sizeof(uint32_t) * nrec, ctx->stream));
+            HIPCHK(hipMemsetAsync(x.rec_wtag, 0x7F, sizeof(uint32_t) * nrec, ctx->stream));
+        }
     }
     launch_free_stack_init(ctx->stream, d);
     TRY(after_launch(ctx));
@@ -1815,25 +1828,44 @@ int chd_wire_build(chd_ctx *ctx, uint64_t *total_bytes, uint64_t *total_packets,
     TRY(bind(ctx));
     WorldDev &d = W.d;
     hipStream_t st = ctx->stream;
-    HIPCHK(hipMemsetAsync(W.x.n_dropped, 0, sizeof(uint32_t), st));
-    W.x.cur_tick = ctx->ring.cur_tick;
-    launch_wire_layout(st, d, W.x);
-    launch_scan_u64_inplace(st, W.x.conn_wlen, d.S);
-    TRY(after_launch(ctx));
-    uint64_t total = 0;
-    uint32_t ndrop = 0;
-    TRY(down(ctx, &total, W.x.conn_wlen + d.S, sizeof total));
-    TRY(down(ctx, &ndrop, W.x.n_dropped, sizeof ndrop));
-    HIPCHK(hipStreamSynchronize(st));
-    if (total > W.wire_cap) {
-        if (W.x.bytes) HIPCHK(hipFree(W.x.bytes));
-        W.x.bytes = nullptr;
-        W.wire_cap = total + total / 2 + 4096;  // head-room: the arena is only re-allocated when a tick outgrows it
-        HIPCHK(hipMalloc((void **)&W.x.bytes, W.wire_cap));
+    // (a second call for the same tick returns the streams already built: the layout pass rewrote the records' position words)
+    const bool again = W.wire_built;
+    if (!again) {
+        HIPCHK(hipMemsetAsync(W.x.n_dropped, 0, 4 * sizeof(uint32_t), st));
+        W.x.cur_tick = ctx->ring.cur_tick;
+        launch_wire_layout(st, d, W.x);
+        launch_scan_u64_inplace(st, W.x.conn_wlen, d.S);
+        TRY(after_launch(ctx));
     }
-    launch_wire_copy(st, d, W.x);
-    TRY(after_launch(ctx));
-    W.wire_built = true;
+    uint64_t total = 0;
+    uint32_t ndrop2[4] = {0, 0, 0, 0};
+    TRY(down(ctx, &total, W.x.conn_wlen + d.S, sizeof total));
+    TRY(down(ctx, ndrop2, W.x.n_dropped, sizeof ndrop2));
+    HIPCHK(hipStreamSynchronize(st));
+    const uint32_t ndrop = ndrop2[0];
+    if (ndrop2[1] || ndrop2[2]) return fail(ctx, CHD_E_STATE, "chd_wire_build: %u records of this tick carry no valid position word, %u name no entity slot", ndrop2[1], ndrop2[2]);
+    if (!again) {
+        if (total > W.wire_cap) {
+            if (W.x.bytes) HIPCHK(hipFree(W.x.bytes));
+            W.x.bytes = nullptr;
+            W.wire_cap = total + total / 2 + 4096;  // head-room: the arena is only re-allocated when a tick outgrows it
+            HIPCHK(hipMalloc((void **)&W.x.bytes, W.wire_cap));
+        }
+        launch_wire_copy(st, d, W.x);
+        TRY(after_launch(ctx));
+        uint32_t bad = 0;
+        TRY(down(ctx, &bad, W.x.n_dropped + 3, sizeof bad));
+        HIPCHK(hipStreamSynchronize(st));
+        if (bad) {
+            uint32_t g[16] = {0};
+            TRY(down(ctx, g, W.x.n_dropped + 8, sizeof g));
+            HIPCHK(hipStreamSynchronize(st));
+            return fail(ctx, CHD_E_STATE, "chd_wire_build: %u chunks of records lie outside their connection's stream; first: conn %u lo %u hi %u len %u count %u "
+                        "live %08x%08x woff0 %u | conn %u lo %u hi %u len %u count %u live %08x%08x woff0 %u", bad, g[0], g[1], g[2], g[3], g[4], g[6], g[5], g[7],
+                        g[8], g[9], g[10], g[11], g[12], g[14], g[13], g[15]);
+        }
+        W.wire_built = true;
+    }
     if (total_bytes) *total_bytes = total;
     if (dropped) *dropped = ndrop;
     if (total_packets) {

@@ -279,11 +279,16 @@ struct WireDev {
     uint8_t *pay_objref;                // [N * stride[0]] serialized UnrealObjectRef per entity (CHD_WIRE_ENTITY_OBJREF)
     uint32_t *len_objref;               // [N]
     uint32_t *rec_woff;                 // per record: byte offset of its Packet entry in the connection's stream (~0 = dropped)
-    uint32_t *rec_wtag;                 // per record: 0, or 0x80000000 | packet length if it opens a packet
+    uint32_t *rec_wtag;                 // per record: any_len | (packet length << 16, if it opens a packet)
+    uint8_t *seg_fast;                  // [S * capq] per subscription segment: every message carries <= 80 payload bytes (k_wire_copy_fast)
+    uint8_t *conn_slow;                 // [S] the connection has segments k_wire_copy_fast does not take
+    uint8_t *trash;                     // [S * 4 * 16] where k_wire_copy_fast's idle lanes store (unconditional stores)
+    uint32_t fast_ok;                   // capq <= 512: the fast kernel's LDS segment list holds a connection's segments
     uint64_t *conn_wlen;                // [S+1] stream length per connection -> exclusive scan = conn_woff
     uint64_t *conn_woff;                // alias of conn_wlen after the scan
     uint32_t *conn_npk;                 // [S] packets per connection
-    uint32_t *n_dropped;                // [1]
+    uint32_t *n_dropped;                // [2] messages dropped by the size check of Send; records without a valid position word
+    uint32_t ncell, npos;               // bounds of the position words: cells of the grid, entries of the cell table
     uint8_t *bytes;                     // the wire arena
 };
 void launch_wire_layout(hipStream_t st, WorldDev w, WireDev x);

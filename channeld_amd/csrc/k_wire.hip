@@ -36,13 +36,15 @@ struct WireMsg {
     uint32_t kind;                                     // merge mode: 1 + (0 entity, 1 cell) for an update record, else 0
 };
 
-__device__ __forceinline__ WireMsg wire_msg(const WorldDev &w, const WireDev &x, chd_fanout_rec rec, uint32_t pos, uint32_t mask) {
+// idc = CHD_POS_CELL | cell for a spatial channel's own message, else the entity's slot (k_wire_layout resolves the records'
+// cell-table positions once and leaves idc in rec_pos for the copy kernels)
+__device__ __forceinline__ WireMsg wire_msg(const WorldDev &w, const WireDev &x, chd_fanout_rec rec, uint32_t idc, uint32_t mask) {
     WireMsg m;
     const uint32_t full = rec.conn >> 31;
     m.chan = rec.channel;
     m.mask = 0; m.value_len = 0; m.kind = 0;
-    const bool cell = (pos & CHD_POS_CELL) != 0;
-    const uint32_t id = cell ? (pos & ~CHD_POS_CELL) : w.ce_slot[pos];
+    const bool cell = (idc & CHD_POS_CELL) != 0;
+    const uint32_t id = idc & ~CHD_POS_CELL;
     if (x.merge && !full) {
         // Any{type_url, value}: value = the buffered updates the window selected (data.go:225-269), oldest first
         const uint32_t *rl = (cell ? x.rlen_cell : x.rlen_ent) + (size_t)id * CHD_HIST_BITS;
@@ -68,7 +70,12 @@ __device__ __forceinline__ WireMsg wire_msg(const WorldDev &w, const WireDev &x,
     return m;
 }
 
+#define WIRE_FAST_PAY 80u  // k_wire_copy_fast keeps a message's payload in five 16-byte registers
+
 // One wave per connection slot.
+// Per record it leaves: rec_pos = idc (see wire_msg), rec_woff = offset of its Packet entry in the connection's stream
+// (~0: dropped by Send), rec_wtag = any_len | packet length << 16 (packet length != 0 only for the record that opens a packet);
+// per subscription segment seg_fast = 1 if every message of it carries at most WIRE_FAST_PAY payload bytes (no merging).
 __global__ void __launch_bounds__(256) k_wire_layout(WorldDev w, WireDev x) {
     const uint32_t s = blockIdx.x * 4u + (threadIdx.x >> 6);
     if (s >= w.S) return;
@@ -76,7 +83,8 @@ __global__ void __launch_bounds__(256) k_wire_layout(WorldDev w, WireDev x) {
     uint64_t pkt_base = 0;   // stream offset of the current packet's tag
     uint32_t pkt_used = 0;   // bytes of entries in the current packet
     uint64_t pkt_first = ~0ull;  // record index of the current packet's first entry
-    uint32_t npk = 0, ndropped = 0;
+    uint32_t pkt_first_len = 0;  // ... and its any_len
+    uint32_t npk = 0, ndropped = 0, any_slow = 0;
     if (w.sub_alive[s]) {
         const uint32_t cnt = w.pair_cnt[s];
         const size_t pbase = (size_t)s * w.capq;
@@ -84,11 +92,30 @@ __global__ void __launch_bounds__(256) k_wire_layout(WorldDev w, WireDev x) {
         for (uint32_t p = 0; p < cnt; p++) {
             const uint32_t n = w.pair_nrec[pbase + p];
             const uint64_t seg = rbase + w.pair_rel[pbase + p];
+            bool fast = !x.merge && x.fast_ok;
             for (uint32_t i0 = 0; i0 < n; i0 += 64) {
                 const uint32_t i = i0 + lane;
                 const bool valid = i < n;
-                uint32_t entry = 0;
-                if (valid) entry = wire_msg(w, x, w.recs[seg + i], w.rec_pos[seg + i], w.rec_mask ? w.rec_mask[seg + i] : 0u).entry;
+                uint32_t entry = 0, alen = 0;
+                if (valid) {
+                    uint32_t pos = w.rec_pos[seg + i];
+                    // (a record whose position word was never written would send the payload lookups anywhere: counted, and
+                    // chd_wire_build fails, rather than a memory fault)
+                    if ((pos & CHD_POS_CELL) ? (pos & ~CHD_POS_CELL) >= x.ncell : pos >= x.npos) {
+                        atomicAdd(x.n_dropped + 1, 1u);
+                        pos = CHD_POS_CELL;
+                    }
+                    uint32_t idc = (pos & CHD_POS_CELL) ? pos : w.ce_slot[pos];
+                    if (!(idc & CHD_POS_CELL) && idc >= w.N) {  // (same for a cell-table entry that names no entity slot)
+                        atomicAdd(x.n_dropped + 2, 1u);
+                        idc = CHD_POS_CELL;
+                    }
+                    const WireMsg m = wire_msg(w, x, w.recs[seg + i], idc, w.rec_mask ? w.rec_mask[seg + i] : 0u);
+                    w.rec_pos[seg + i] = idc;
+                    entry = m.entry;
+                    alen = m.any_len;
+                }
+                if (__ballot(valid && alen > WIRE_FAST_PAY)) fast = false;
                 if (valid && entry == 0) x.rec_woff[seg + i] = 0xFFFFFFFFu;  // dropped
                 ndropped += (uint32_t)__popcll(__ballot(valid && entry == 0));
                 // inclusive prefix of the entry sizes over the chunk
@@ -108,16 +135,20 @@ __global__ void __launch_bounds__(256) k_wire_layout(WorldDev w, WireDev x) {
                     // lanes [start_lane, f) stay in the current packet
                     if (mine && lane < f && entry != 0) {
                         x.rec_woff[seg + i] = (uint32_t)(pkt_base + 5u + rel - entry);
-                        x.rec_wtag[seg + i] = 0;
+                        x.rec_wtag[seg + i] = alen;
                     }
                     // the first entry of the current packet, if it is in this range
                     const uint64_t firsts = __ballot(mine && lane < f && entry != 0);
-                    if (pkt_first == ~0ull && firsts) pkt_first = seg + i0 + (uint32_t)__ffsll((unsigned long long)firsts) - 1u;
+                    if (pkt_first == ~0ull && firsts) {
+                        const uint32_t fl = (uint32_t)__ffsll((unsigned long long)firsts) - 1u;
+                        pkt_first = seg + i0 + fl;
+                        pkt_first_len = (uint32_t)__shfl((int)alen, (int)fl);
+                    }
                     const uint32_t cum_f = f < 64 ? __shfl(cum - entry, (int)f) : __shfl(cum, 63);  // prefix before lane f
                     pkt_used += cum_f - cum_before_start;
                     if (f == 64) break;
                     // close the packet (flush, connection.go:646-661): lane f's entry opens the next one
-                    if (lane == 0 && pkt_first != ~0ull) x.rec_wtag[pkt_first] = 0x80000000u | pkt_used;
+                    if (lane == 0 && pkt_first != ~0ull) x.rec_wtag[pkt_first] = (pkt_used << 16) | pkt_first_len;
                     pkt_base += 5u + pkt_used;
                     npk += 1;
                     pkt_used = 0;
@@ -126,9 +157,11 @@ __global__ void __launch_bounds__(256) k_wire_layout(WorldDev w, WireDev x) {
                     cum_before_start = cum_f;
                 }
             }
+            if (lane == 0) x.seg_fast[pbase + p] = (fast && n) ? 1 : 0;
+            if (n && !fast) any_slow = 1;
         }
         if (pkt_used) {  // the last, partly filled packet
-            if (lane == 0 && pkt_first != ~0ull) x.rec_wtag[pkt_first] = 0x80000000u | pkt_used;
+            if (lane == 0 && pkt_first != ~0ull) x.rec_wtag[pkt_first] = (pkt_used << 16) | pkt_first_len;
             pkt_base += 5u + pkt_used;
             npk += 1;
         }
@@ -136,6 +169,7 @@ __global__ void __launch_bounds__(256) k_wire_layout(WorldDev w, WireDev x) {
     if (lane == 0) {
         x.conn_wlen[s] = pkt_base;
         x.conn_npk[s] = npk;
+        x.conn_slow[s] = (uint8_t)any_slow;  // k_wire_copy has segments of this connection to write
         if (ndropped) atomicAdd(x.n_dropped, ndropped);
     }
 }
@@ -257,7 +291,7 @@ __global__ void __launch_bounds__(256) k_wire_copy(WorldDev w, WireDev x) {
     __shared__ uint32_t ticket;
     __shared__ __attribute__((aligned(16))) uint8_t images[4][WIRE_IMG + 48];
     const uint32_t s = blockIdx.x;
-    if (!w.sub_alive[s] || x.conn_woff[s + 1] == x.conn_woff[s]) return;  // (conn_wlen was scanned in place)
+    if (!w.sub_alive[s] || !x.conn_slow[s] || x.conn_woff[s + 1] == x.conn_woff[s]) return;  // (conn_wlen was scanned in place)
     const uint32_t lane = threadIdx.x & 63u;
     uint8_t *img = images[threadIdx.x >> 6];
     const uint32_t cnt = w.pair_cnt[s];
@@ -271,6 +305,7 @@ __global__ void __launch_bounds__(256) k_wire_copy(WorldDev w, WireDev x) {
         if (lane == 0) p = atomicAdd(&ticket, 1u);
         p = __builtin_amdgcn_readfirstlane(p);
         if (p >= cnt) break;
+        if (x.seg_fast[pbase + p]) continue;  // (k_wire_copy_fast writes those)
         const uint32_t n = w.pair_nrec[pbase + p];
         const uint64_t seg = rbase + w.pair_rel[pbase + p];
         for (uint32_t i0 = 0; i0 < n; i0 += 64) {
@@ -284,7 +319,8 @@ __global__ void __launch_bounds__(256) k_wire_copy(WorldDev w, WireDev x) {
                 const uint32_t woff = x.rec_woff[seg + i];
                 if (woff != 0xFFFFFFFFu) {  // not dropped by the size check of Send
                     m = wire_msg(w, x, w.recs[seg + i], w.rec_pos[seg + i], w.rec_mask ? w.rec_mask[seg + i] : 0u);
-                    tag = x.rec_wtag[seg + i];
+                    tag = x.rec_wtag[seg + i] >> 16;  // packet length if the message opens a packet
+                    if (tag) tag |= 0x80000000u;
                     hl = wire_hdr_len(x, m, tag);
                     pl = m.kind ? m.value_len : m.any_len;
                     begin = woff - (tag ? 5u : 0u);
@@ -358,8 +394,244 @@ __global__ void __launch_bounds__(256) k_wire_copy(WorldDev w, WireDev x) {
     }
 }
 
+// ---------------------------------------------------------------------------
+// The fast copy kernel: segments whose messages all carry <= WIRE_FAST_PAY payload bytes (k_wire_layout: seg_fast) — on a
+// steady-state tick, all of them.  Same image technique as k_wire_copy, software-pipelined so that a wave never waits for
+// its own record stores: on gfx950 the vm counter is in-order, and a wave that waits for ANY load also waits for every
+// store it issued before it (~3.5 us while the chip streams).  Per chunk of 64 records the wave
+//   - awaits the payload registers of THIS chunk and the per-record words of the NEXT one — loads issued one iteration
+//     ago, BEFORE the previous chunk's stores: the wait is counted (vmcnt = the stores issued since), so those stores
+//     stay in flight;
+//   - builds the image in LDS (headers byte by byte, payload from registers);
+//   - issues the payload loads of the next chunk and the per-record loads of the one after it;
+//   - streams the image out.
+// For the waits to be counted every global load and store of the loop is UNCONDITIONAL (straight-line code, a fixed
+// number of instructions per iteration): lanes without a message load from a valid dummy address and store to a
+// 16-byte trash slot of their wave.  Segment descriptors come from an LDS list built once per connection.
+// ---------------------------------------------------------------------------
+#define WIRE_FAST_IMG 7168u                     // 64 x (80 payload + 25 header + 5 tag) = 7040 bytes at most
+#define WIRE_FAST_VECS (WIRE_FAST_IMG / 1024u)  // 16-byte vector stores per lane and chunk
+
+typedef uint32_t wu32x4 __attribute__((ext_vector_type(4)));
+typedef uint32_t wu32x2 __attribute__((ext_vector_type(2)));
+
+struct WireFastMeta {
+    wu32x2 rec;
+    uint32_t idc, woff, wtag;
+};
+
+// Every global access of the loop is an ordinary load or store: the compiler tracks them and places the counted waits itself
+// (and waits before it ever COPIES a register whose load is still in flight — a hand-placed s_waitcnt around inline-asm loads
+// cannot: the register allocator is free to move an asm output to another register before the wait, and the hardware does not
+// interlock a v_mov on an outstanding load; that version delivered garbage in ~0.04 % of the chunks).  What keeps its waits
+// exact is the loop's shape: ONE entry with nothing in flight, a fixed number of unconditional loads and stores per step.
+__device__ __forceinline__ void wire_fast_load_meta(const WorldDev &w, const WireDev &x, uint64_t base, uint32_t count, WireFastMeta &m) {
+    // (lanes beyond the chunk re-read its last record: unconditional loads)
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint64_t r = base + (lane < count ? lane : (count ? count - 1u : 0u));
+    m.rec = *(const wu32x2 *)(const void *)(w.recs + r);
+    m.idc = w.rec_pos[r];
+    m.woff = x.rec_woff[r];
+    m.wtag = x.rec_wtag[r];
+}
+
+// The payload of this lane's message: five 16-byte loads from its slot.  (Tried: the five pieces of a message fetched by
+// ADJACENT lanes of one instruction — one cache-line request per message instead of five — with the pieces routed to the image
+// by cross-lane reads: 34 more VGPRs, one wave per SIMD fewer, 8 % slower.  The kernel is bound by the image build — VALU and
+// LDS instruction issue — not by L2 requests or HBM: with every store redirected to one trash line it takes the same time.)
+__device__ __forceinline__ void wire_fast_load_pay(const uint8_t *pay, wu32x4 (&P)[WIRE_FAST_PAY / 16]) {
+#pragma unroll
+    for (uint32_t q = 0; q < WIRE_FAST_PAY / 16; q++) P[q] = *(const wu32x4 *)(const void *)(pay + 16u * q);
+}
+
+// (bases and strides come in as values: indexing the kernel argument's arrays with a per-lane `full` makes the compiler load
+// them from memory inside the loop, and wait for that load with vmcnt(0))
+__device__ __forceinline__ const uint8_t *wire_fast_pay(const WireFastMeta &m, const uint8_t *pe0, const uint8_t *pe1,
+                                                        const uint8_t *pc0, const uint8_t *pc1, uint32_t st0, uint32_t st1) {
+    const bool full = (m.rec.x >> 31) != 0;
+    const uint32_t id = m.idc & ~CHD_POS_CELL;
+    const uint8_t *base = (m.idc & CHD_POS_CELL) ? (full ? pc1 : pc0) : (full ? pe1 : pe0);
+    return base + (size_t)id * (full ? st1 : st0);
+}
+
+#define WIRE_FAST_STORES (WIRE_FAST_VECS + 2u)  // VM stores per iteration: the vector stores + head bytes + tail bytes
+
+__global__ void __launch_bounds__(256) k_wire_copy_fast(WorldDev w, WireDev x) {
+    __shared__ uint32_t ticket, nseg;
+    __shared__ uint32_t seg_n[512], seg_rel[512];
+    __shared__ __attribute__((aligned(16))) uint8_t images[4][WIRE_FAST_IMG + 48];
+    const uint32_t s = blockIdx.x;
+    if (!w.sub_alive[s] || x.conn_woff[s + 1] == x.conn_woff[s]) return;  // (conn_wlen was scanned in place)
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    uint8_t *img = images[wave];
+    const uint32_t cnt = w.pair_cnt[s];
+    const size_t pbase = (size_t)s * w.capq;
+    const uint64_t rbase = w.rec_ub[s];
+    uint8_t *stream = x.bytes + x.conn_woff[s];
+    uint8_t *trash = x.trash + ((size_t)blockIdx.x * 4u + wave) * 16u;
+    const uint64_t stream_len = x.conn_woff[s + 1] - x.conn_woff[s];
+    // the connection's fast segments, compacted (order is irrelevant: every record knows its own offset)
+    if (threadIdx.x == 0) { ticket = 0; nseg = 0; }
+    __syncthreads();
+    for (uint32_t p0 = 0; p0 < cnt; p0 += 256) {
+        const uint32_t p = p0 + threadIdx.x;
+        const bool f = p < cnt && x.seg_fast[pbase + p] != 0;
+        if (f) {
+            const uint32_t k = atomicAdd(&nseg, 1u);
+            if (k < 512) { seg_n[k] = w.pair_nrec[pbase + p]; seg_rel[k] = w.pair_rel[pbase + p]; }
+        }
+    }
+    __syncthreads();
+    const uint32_t ns = min(nseg, 512u);  // (WireDev::fast_ok: capq <= 512)
+    if (!ns) return;
+    // ---- chunk cursor: (segment, offset) ----
+    uint64_t cur_base = 0;
+    uint32_t cur_n = 0, cur_i0 = 0;
+    auto next_chunk = [&](uint64_t &base, uint32_t &count) {
+        if (cur_i0 >= cur_n) {
+            uint32_t k = 0;
+            if (lane == 0) k = atomicAdd(&ticket, 1u);
+            k = (uint32_t)__builtin_amdgcn_readfirstlane((int)k);
+            if (k >= ns) { base = 0; count = 0; cur_n = 0; cur_i0 = 0; return; }
+            cur_base = rbase + seg_rel[k];
+            cur_n = seg_n[k];
+            cur_i0 = 0;
+        }
+        base = cur_base + cur_i0;
+        count = min(64u, cur_n - cur_i0);
+        cur_i0 += 64;
+    };
+    const uint8_t *pe0 = x.pay_ent[0], *pe1 = x.pay_ent[1], *pc0 = x.pay_cell[0], *pc1 = x.pay_cell[1];
+    const uint32_t st0 = x.stride[0], st1 = x.stride[1];
+    uint64_t b0, b1;
+    uint32_t c0, c1;
+    next_chunk(b0, c0);
+    if (!c0) return;
+    // Two sets of per-record registers (X, Y) and of payload registers take turns, so that no value is copied while its
+    // load is in flight (a copy would make the compiler wait right there).  The loop starts with a virtual EMPTY chunk
+    // (nothing to build, every store to the trash slot) whose step issues the first real loads: one loop entry, nothing in
+    // flight at it, and every step issues the same 9 loads and WIRE_FAST_STORES stores.
+    WireFastMeta mA, mB;
+    wu32x4 P0[WIRE_FAST_PAY / 16], P1[WIRE_FAST_PAY / 16];
+    b1 = b0; c1 = c0;  // the first real chunk is the virtual one's "next"
+    b0 = 0; c0 = 0;
+    wire_fast_load_meta(w, x, b1, c1, mB);
+    mA = mB;
+#pragma unroll
+    for (uint32_t q = 0; q < WIRE_FAST_PAY / 16; q++) { P0[q] = (wu32x4){0, 0, 0, 0}; P1[q] = (wu32x4){0, 0, 0, 0}; }
+    asm volatile("" : "+v"(mA.rec), "+v"(mA.idc), "+v"(mA.woff), "+v"(mA.wtag), "+v"(mB.rec), "+v"(mB.idc), "+v"(mB.woff), "+v"(mB.wtag));  // (arrived)
+    // one chunk: X = this chunk's per-record words, Y = the next chunk's, Pc = this chunk's payload registers, Pn = where the
+    // next chunk's go; X is reloaded with the chunk after the next
+    auto step = [&](WireFastMeta &X, WireFastMeta &Y, wu32x4 (&Pc)[WIRE_FAST_PAY / 16], wu32x4 (&Pn)[WIRE_FAST_PAY / 16]) {
+        const uint32_t x_chan = X.rec.y, x_wtag = X.wtag, x_woff = X.woff;
+        // ---- the loads of the following chunks go out NOW, under the image build below ----
+        wire_fast_load_pay(lane < c1 && Y.woff != 0xFFFFFFFFu ? wire_fast_pay(Y, pe0, pe1, pc0, pc1, st0, st1) : pe0, Pn);
+        uint64_t b2;
+        uint32_t c2;
+        next_chunk(b2, c2);
+        wire_fast_load_meta(w, x, b2, c2, X);  // (x_chan, x_wtag, x_woff: X's arrived words, other registers from here on)
+        // ---- this lane's message.  any_len <= 80, so every nested length is below 128 (one-byte varints) and the header is
+        // [tag: 5] 0x0A mp_len | [0x08 varint(channel id): c = 2..6 bytes, absent for channel 0] | 0x20 0x08 0x2A body_len 0x0A any_len
+        // = 8 + c bytes (put_header's layout; connection.go:57-83, data.go:293-318), composed in two 64-bit registers ----
+        const bool live = lane < c0 && x_woff != 0xFFFFFFFFu;
+        const uint32_t chan = x_chan, alen = x_wtag & 0xFFFFu, pk = x_wtag >> 16;
+        const uint32_t nv = vlen(chan), c = chan ? 1u + nv : 0u;
+        const uint32_t body = 2u + alen, mp = c + 4u + body;
+        const uint32_t L = 8u + c, tagb = pk ? 5u : 0u;
+        const uint32_t begin = live ? x_woff - tagb : 0xFFFFFFFFu;
+        const uint32_t endb = live ? x_woff + L + alen : 0u;
+        // (the layout pass numbers a chunk's messages in stream order: first live lane = lowest offset, last = highest end)
+        const uint64_t lm = __ballot(live);
+        const bool any = lm != 0;  // (uniform; a chunk of dropped messages only has nothing to write)
+        const uint32_t lo = any ? (uint32_t)__builtin_amdgcn_readlane((int)begin, (int)__builtin_ctzll(lm | (1ull << 63))) : 0u;
+        const uint32_t hi = any ? (uint32_t)__builtin_amdgcn_readlane((int)endb, 63 - (int)__builtin_clzll(lm | 1ull)) : 0u;
+        uint32_t nbytes = hi - lo;
+        if (hi < lo || nbytes > WIRE_FAST_IMG || (uint64_t)hi > stream_len) {  // (never, if the layout pass and this kernel agree)
+            if (lane == 0) {
+                const uint32_t k = atomicAdd(x.n_dropped + 3, 1u);
+                if (k < 8) {  // (what the first few looked like: chd_wire_build's error message)
+                    uint32_t *g = x.n_dropped + 8 + 8 * k;
+                    g[0] = s; g[1] = lo; g[2] = hi; g[3] = (uint32_t)stream_len; g[4] = c0; g[5] = (uint32_t)lm; g[6] = (uint32_t)(lm >> 32); g[7] = x_woff;
+                }
+            }
+            nbytes = 0;
+        }
+        const uint32_t off0 = any ? (uint32_t)((uintptr_t)(stream + lo) & 15u) : 0u;
+        if (live) {
+            // the payload first, in dwords (up to 3 bytes too many: the next message's header, written below by a LATER
+            // instruction, covers them), then the headers, exactly
+            uint8_t *pd = img + off0 + (begin - lo) + tagb + L;
+#pragma unroll
+            for (uint32_t q = 0; q < WIRE_FAST_PAY / 16; q++) {
+                const uint32_t vv[4] = {Pc[q].x, Pc[q].y, Pc[q].z, Pc[q].w};
+#pragma unroll
+                for (uint32_t k = 0; k < 4; k++)
+                    if (16u * q + 4u * k < alen) __builtin_memcpy(pd + 16u * q + 4u * k, &vv[k], 4);
+            }
+        }
+        if (live) {
+            uint8_t *d = img + off0 + (begin - lo);
+            if (pk) {  // opens a packet: the 5-byte tag sits right before it (connection.go:683-687)
+                d[0] = 67; d[1] = 72; d[2] = (uint8_t)(pk >> 8); d[3] = (uint8_t)pk; d[4] = 0;
+                d += 5;
+            }
+            uint64_t e = (uint64_t)((chan & 0x7Fu) | (((chan >> 7) & 0x7Fu) << 8) | (((chan >> 14) & 0x7Fu) << 16) | (((chan >> 21) & 0x7Fu) << 24)) |
+                         ((uint64_t)(chan >> 28) << 32);
+            e |= 0x8080808080ull & ((1ull << (8u * (nv - 1u))) - 1ull);  // continuation bits of all bytes but the last
+            const uint64_t f3 = c ? (0x08ull | (e << 8)) : 0ull;
+            const uint64_t f45 = 0x20ull | (0x08ull << 8) | (0x2Aull << 16) | ((uint64_t)body << 24) | (0x0Aull << 32) | ((uint64_t)alen << 40);
+            const uint32_t sh = 16u + 8u * c;  // 16 .. 64
+            const uint64_t lo64 = (0x0Aull | ((uint64_t)mp << 8)) | (f3 << 16) | (sh < 64u ? f45 << sh : 0ull);
+            const uint64_t hi64 = sh > 16u ? f45 >> (64u - sh) : 0ull;
+            const uint32_t w0 = (uint32_t)lo64, w1 = (uint32_t)(lo64 >> 32), w2 = (uint32_t)hi64, w3 = (uint32_t)(hi64 >> 32);
+            __builtin_memcpy(d, &w0, 4);
+            __builtin_memcpy(d + 4, &w1, 4);
+            if (c >= 4u) __builtin_memcpy(d + 8, &w2, 4);
+            const uint32_t tv = c >= 4u ? w3 : w2, tn = c & 3u;
+            uint8_t *t = d + (c >= 4u ? 12 : 8);
+            if (tn >= 1u) t[0] = (uint8_t)tv;
+            if (tn >= 2u) t[1] = (uint8_t)(tv >> 8);
+            if (tn >= 3u) t[2] = (uint8_t)(tv >> 16);
+        }
+        // ---- stream the image out: WIRE_FAST_VECS vector stores + head and tail bytes, all unconditional ----
+        wire_wave_sync();
+        {
+            uint8_t *dst = stream + lo;
+            const uint8_t *src = img + off0;
+            const uint32_t head = min((16u - off0) & 15u, nbytes);
+            const uint32_t nvec = (nbytes - head) >> 4;
+            const uint32_t done = head + 16u * nvec;
+            {
+                const bool ok = lane < head;
+                *(ok ? dst + lane : trash) = src[ok ? lane : 0u];
+            }
+#pragma unroll
+            for (uint32_t j = 0; j < WIRE_FAST_VECS; j++) {
+                const uint32_t v = lane + 64u * j;
+                const bool ok = v < nvec;
+                const wu32x4 val = *(const wu32x4 *)(const void *)(src + head + 16u * (ok ? v : 0u));
+                *(wu32x4 *)(void *)(ok ? dst + head + 16u * v : trash) = val;
+            }
+            {
+                const bool ok = lane < nbytes - done;
+                *(ok ? dst + done + lane : trash) = src[ok ? done + lane : 0u];
+            }
+        }
+        wire_wave_sync();
+        b0 = b1; c0 = c1; b1 = b2; c1 = c2;
+    };
+    for (;;) {
+        step(mA, mB, P0, P1);
+        if (!c0) break;
+        step(mB, mA, P1, P0);
+        if (!c0) break;
+    }
+}
+
 void launch_wire_copy(hipStream_t st, WorldDev w, WireDev x) {
     if (!w.S) return;
+    // segments of small messages (every steady-state update), then whatever is left (full states, merged updates)
+    if (!x.merge && x.fast_ok) hipLaunchKernelGGL(k_wire_copy_fast, dim3(w.S), dim3(256), 0, st, w, x);
     hipLaunchKernelGGL(k_wire_copy, dim3(w.S), dim3(256), 0, st, w, x);
 }
 
