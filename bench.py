@@ -69,9 +69,15 @@ def parse():
                          "config/channel_settings_ue.json) instead of the distance-damped 20/50/100 ms; the default run reports it as a second line")
     ap.add_argument("--emit", choices=["auto", "cell-major", "conn-major"], default="auto",
                     help="form of the fan-out emit kernel (include/chd_spatial.h: CHD_WORLD_*_EMIT)")
+    ap.add_argument("--headline", choices=["serial", "pipelined"], default="serial",
+                    help="schedule of the timed region that `value` and `roofline` are about.  serial (default): every tick's kernels one "
+                         "after the other on one stream, so the dominant kernel is measured with the chip to itself; pipelined "
+                         "(CHD_WORLD_PIPELINE_TICKS): tick t's record kernel beside tick t+1's stages on a second stream - higher "
+                         "whole-job throughput, but the record kernel then shares the chip.  The default run times both, the other "
+                         "one over the same number of ticks right after the timed region (`pipelined_schedule` / `serial_schedule`)")
     ap.add_argument("--serial-ticks", action="store_true",
-                    help="do not pipeline successive ticks (CHD_WORLD_PIPELINE_TICKS off): every tick's kernels one after the other "
-                         "on one stream.  The default run times both schedules and reports the serial one as `serial_schedule`")
+                    help="never pipeline successive ticks: the world is created without CHD_WORLD_PIPELINE_TICKS and only the serial "
+                         "schedule is timed")
     ap.add_argument("--only-timed", action="store_true",
                     help="profiling runs (rocprofv3 --kernel-trace / --pmc): warm-up + the timed region and nothing else (= --no-cpu "
                          "--latency-steps 0 --e2e-ticks 0), so that per-kernel averages after skipping --warmup launches are the timed launches")
@@ -247,7 +253,8 @@ def main():
 
     # ---- all tick inputs generated on the host once, then resident in HBM ----
     E = max(args.e2e_ticks, 0)
-    K2 = K if (pipe and not args.only_timed) else 0  # the same number of ticks again on the serial schedule
+    K2 = K if (pipe and not args.only_timed) else 0  # the same number of ticks again on the other schedule
+    head_pipe = pipe and args.headline == "pipelined"
     T = W + K + K2 + L
     xs = np.empty((T + E, N), dtype=np.float64)
     zs = np.empty((T + E, N), dtype=np.float64)
@@ -275,6 +282,8 @@ def main():
                           n_queries=S, d_queries=d_q.at(t * S * 128))
 
     world.set_profiling(min(1024, max(K, L, 1)))
+    if pipe and not head_pipe:
+        world.set_pipelining(False)
     for t in range(W):
         tick(t)
     torch.cuda.synchronize()
@@ -295,11 +304,10 @@ def main():
     assert res.overflow == 0 and res.history_overflow == 0, (res.overflow, res.history_overflow)
     if len(hist) < K:  # history ring shorter than the timed region: scale by the mean
         msgs = int(round(msgs * K / len(hist)))
-    serial = None
+    other = None
     if K2:
-        # the same world continues on the serial schedule (one stream, kernel after kernel): its rate, and the stage times
-        # free of cross-tick overlap
-        world.set_pipelining(False)
+        # the same world continues on the OTHER schedule for the same number of ticks: its rate and its record kernel's time
+        world.set_pipelining(not head_pipe)
         torch.cuda.synchronize()
         t1 = time.perf_counter()
         for t in range(W + K, W + K + K2):
@@ -308,13 +316,22 @@ def main():
         el2 = time.perf_counter() - t1
         hist2 = world.history(min(K2, 1024))
         m2 = sum(h["n_records"] for h in hist2) * (K2 / len(hist2))
-        stage_avg = np.mean(np.array([h["stage_us"] for h in hist2]), axis=0)
-        serial = {"what": "the same world, next %d ticks, CHD_WORLD_PIPELINE_TICKS switched off: every tick's kernels in sequence on one stream" % K2,
-                  "value": m2 / el2, "unit": "msgs/s", "ms_per_step": 1e3 * el2 / K2, "msgs_per_tick": m2 / K2,
-                  "emit_kernel_us": float(np.mean([h["emit_main_us"] for h in hist2])),
-                  "emit_kernel_frac_of_hbm_peak": float(BYTES_PER_MSG * np.mean([h["n_records"] - h["n_deferred_records"] for h in hist2])
-                                                        / (np.mean([h["emit_main_us"] for h in hist2]) * 1e-6) / 1e9 / HBM_PEAK_GBS)}
-        world.set_pipelining(True)
+        if head_pipe:  # stage times free of cross-tick overlap come from the serial leg
+            stage_avg = np.mean(np.array([h["stage_us"] for h in hist2]), axis=0)
+        k_us = float(np.mean([h["emit_main_us"] for h in hist2]))
+        other = {"what": ("the same world, next %d ticks, CHD_WORLD_PIPELINE_TICKS switched %s: " % (K2, "off" if head_pipe else "on"))
+                         + ("every tick's kernels in sequence on one stream" if head_pipe else
+                            "tick t's record kernel on the ctx stream beside tick t+1's stages on a second (interest updates: third) stream; "
+                            "every tick still does all of its work, results equal the serial schedule's (tests/test_gpu_fullsize.py)"),
+                 "value": m2 / el2, "unit": "msgs/s", "ms_per_step": 1e3 * el2 / K2, "msgs_per_tick": m2 / K2,
+                 "emit_kernel_us": k_us,
+                 "emit_kernel_frac_of_hbm_peak": float(BYTES_PER_MSG * np.mean([h["n_records"] - h["n_deferred_records"] for h in hist2])
+                                                       / (k_us * 1e-6) / 1e9 / HBM_PEAK_GBS),
+                 "whole_tick_frac_of_hbm_peak": float(BYTES_PER_MSG * (m2 / K2) / (el2 / K2) / 1e9 / HBM_PEAK_GBS)}
+        if not head_pipe:
+            other["note"] = ("the record kernel shares the chip with the next tick's latency-bound stages here, so ITS launch time is longer than "
+                             "in the serial schedule (roofline object) while the tick as a whole is shorter")
+        world.set_pipelining(head_pipe)
     # dominant kernel: k_fanout_emit_seg.  achieved = algorithmic bytes per launch / avg launch time
     achieved = float((BYTES_PER_MSG * emit_msgs.mean()) / (emit_us.mean() * 1e-6) / 1e9)
 
@@ -371,11 +388,11 @@ def main():
                    "value_is": "chd_tick_device: inputs resident in HBM, records left in HBM (see e2e for what a host observes)",
                    "schedule": ("successive ticks pipelined over two HIP streams (CHD_WORLD_PIPELINE_TICKS): tick t's record kernel beside tick t+1's stages; "
                                 "every tick does all of its work inside the timed region, results equal the serial schedule's (tests/test_gpu_fullsize.py)")
-                               if pipe else "serial: every tick's kernels in sequence on one stream"},
+                               if head_pipe else "serial: every tick's kernels in sequence on one stream (see pipelined_schedule for CHD_WORLD_PIPELINE_TICKS)"},
         "p50_tick_ms": float(np.percentile(lat, 50)), "p99_tick_ms": float(np.percentile(lat, 99)),
         "p99_tick_gpu_ms": float(np.percentile(gpu_lat, 99)), "latency_ticks": int(L),
         "stage_us_avg": {n: float(v) for n, v in zip(("ingest", "index", "interest", "plan", "emit"), stage_avg)},
-        "stage_us_avg_is": "serial schedule (no overlap across ticks)" if (serial or not pipe) else "pipelined schedule: stages of successive ticks overlap, emit includes queueing",
+        "stage_us_avg_is": "serial schedule (no overlap across ticks)" if (other or not head_pipe) else "pipelined schedule: stages of successive ticks overlap, emit includes queueing",
         "roofline": {"bound": "hbm", "kernel": DOMINANT, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_quoted": traffic is not None,
                      "traffic_source": "QUOTED, not measured in this run: bytes per launch from the rocprofv3 --pmc passes of this command (profiles/hbm_traffic.json)",
@@ -383,8 +400,9 @@ def main():
                      "bytes_per_msg": BYTES_PER_MSG, "msgs_per_launch": float(emit_msgs.mean()), "avg_launch_us": float(emit_us.mean()),
                      "emit_stage_us": float(stage_avg[4]), "deferred_msgs_per_tick": float(np.mean([h["n_deferred_records"] for h in hist]))},
     }
-    if serial:
-        out["serial_schedule"] = serial
+    out["roofline"]["whole_tick_frac"] = float(BYTES_PER_MSG * (msgs / K) / (elapsed / K) / 1e9 / HBM_PEAK_GBS)
+    if other:
+        out["serial_schedule" if head_pipe else "pipelined_schedule"] = other
     if wire_info:
         out["wire"] = wire_info
     # (ii) of --e2e-ticks: the packet streams a gateway would hand to conn.Write, on a second world (the wire mode
@@ -427,7 +445,7 @@ def flat_interval_line(A, synth, cfg, N, S, seed, args, local_rank, interval_ms,
     ctl = A.StaticGrid2DSpatialController(device=local_rank)
     assert ctl.LoadConfig(json.dumps(cfg).encode(), strict=False, Damping=[(0xFFFFFFFF, interval_ms)]) is None
     sw = synth.SynthWorld(synth.WorldSpec(cfg, N, S, seed, tick_ms=args.tick_ms, aoi_scale=args.aoi_scale))
-    pipe = not args.serial_ticks and S >= 4096
+    pipe = not args.serial_ticks and args.headline == "pipelined" and S >= 4096
     w = A.SpatialWorld(ctl, N, S, max_records=400_000_000, flags=128 if pipe else 0)
     w.spawn(None, sw.chan_id, sw.x, sw.z, sw.flags, sw.sender)
     w.add_subscribers(None, sw.sub_conn)
@@ -457,7 +475,7 @@ def flat_interval_line(A, synth, cfg, N, S, seed, args, local_rank, interval_ms,
     assert res.overflow == 0 and res.history_overflow == 0
     ctl.close()
     return {"what": f"every subscription fans out every {interval_ms} ms (one-entry damping table), otherwise the headline workload"
-                    + (" (ticks pipelined, as the headline)" if pipe else " (serial schedule)"),
+                    + (" (ticks pipelined, as the headline)" if pipe else " (serial schedule, as the headline)"),
             "value": msgs / el, "unit": "msgs/s", "steps": steps, "ms_per_step": 1e3 * el / steps, "msgs_per_tick": msgs / steps,
             "emit_us": emit_us, "emit_frac_of_hbm_peak": BYTES_PER_MSG * (msgs / steps) / (emit_us * 1e-6) / 1e9 / HBM_PEAK_GBS}
 
