@@ -282,6 +282,9 @@ def main():
                           n_queries=S, d_queries=d_q.at(t * S * 128))
 
     world.set_profiling(min(1024, max(K, L, 1)))
+    # throughput regions: only the event pair around the dominant kernel (a timed event at every stage boundary idles the
+    # stream for a few microseconds each); the stage breakdown comes from the latency phase below
+    world.set_profiling_scope(True)
     if pipe and not head_pipe:
         world.set_pipelining(False)
     for t in range(W):
@@ -299,7 +302,7 @@ def main():
     # (the few connections it defers are written by a second, small launch inside the same emit stage)
     emit_us = np.array([h["emit_main_us"] for h in hist])
     emit_msgs = np.array([h["n_records"] - h["n_deferred_records"] for h in hist], dtype=np.float64)
-    stage_avg = np.mean(np.array([h["stage_us"] for h in hist]), axis=0)
+    stage_avg = np.zeros(5)
     res = world.fetch()
     assert res.overflow == 0 and res.history_overflow == 0, (res.overflow, res.history_overflow)
     if len(hist) < K:  # history ring shorter than the timed region: scale by the mean
@@ -316,8 +319,6 @@ def main():
         el2 = time.perf_counter() - t1
         hist2 = world.history(min(K2, 1024))
         m2 = sum(h["n_records"] for h in hist2) * (K2 / len(hist2))
-        if head_pipe:  # stage times free of cross-tick overlap come from the serial leg
-            stage_avg = np.mean(np.array([h["stage_us"] for h in hist2]), axis=0)
         k_us = float(np.mean([h["emit_main_us"] for h in hist2]))
         other = {"what": ("the same world, next %d ticks, CHD_WORLD_PIPELINE_TICKS switched %s: " % (K2, "off" if head_pipe else "on"))
                          + ("every tick's kernels in sequence on one stream" if head_pipe else
@@ -343,6 +344,9 @@ def main():
             n_queries=S, d_queries=d_q.at(t * S * 128)), range(W + K - args.wire, W + K), int(now[W + K - 1]))  # (--wire worlds are never pipelined: K2 = 0)
 
     # ---- latency phase: one synchronous tick at a time (p50/p99 of the tick) ----
+    world.set_profiling_scope(False)
+    if pipe:
+        world.set_pipelining(False)  # (one synchronous tick at a time: nothing to pipeline; the stage events need the serial schedule)
     lat = []
     for t in range(W + K + K2, W + K + K2 + L):
         a = time.perf_counter()
@@ -350,7 +354,12 @@ def main():
         world.sync()
         lat.append((time.perf_counter() - a) * 1e3)
     lat = np.array(lat) if lat else np.array([0.0])
-    gpu_lat = np.array([h["total_us"] for h in world.history(min(L, 1024))]) / 1e3 if L else np.array([0.0])
+    lat_hist = world.history(min(L, 1024)) if L else []
+    gpu_lat = np.array([h["total_us"] for h in lat_hist]) / 1e3 if L else np.array([0.0])
+    if L:
+        stage_avg = np.mean(np.array([h["stage_us"] for h in lat_hist]), axis=0)
+    if pipe:
+        world.set_pipelining(head_pipe)
 
     # ---- end to end, as a Go host would observe it ("kernel-only AND end-to-end through the C-ABI") ----
     e2e = None
@@ -392,7 +401,8 @@ def main():
         "p50_tick_ms": float(np.percentile(lat, 50)), "p99_tick_ms": float(np.percentile(lat, 99)),
         "p99_tick_gpu_ms": float(np.percentile(gpu_lat, 99)), "latency_ticks": int(L),
         "stage_us_avg": {n: float(v) for n, v in zip(("ingest", "index", "interest", "plan", "emit"), stage_avg)},
-        "stage_us_avg_is": "serial schedule (no overlap across ticks)" if (other or not head_pipe) else "pipelined schedule: stages of successive ticks overlap, emit includes queueing",
+        "stage_us_avg_is": "HIP events at every stage boundary of the latency-phase ticks (serial schedule, one synchronous tick at a time); the timed "
+                           "region records only the pair around the dominant kernel (chd_set_profiling_scope)",
         "roofline": {"bound": "hbm", "kernel": DOMINANT, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_quoted": traffic is not None,
                      "traffic_source": "QUOTED, not measured in this run: bytes per launch from the rocprofv3 --pmc passes of this command (profiles/hbm_traffic.json)",
@@ -456,6 +466,7 @@ def flat_interval_line(A, synth, cfg, N, S, seed, args, local_rank, interval_ms,
         xs[t], zs[t], qs[t], now[t] = sw.x, sw.z, sw.queries(), sw.now_ns()
     dx, dz, dq = w.device_array(xs), w.device_array(zs), w.device_array(qs)
     w.set_profiling(steps)
+    w.set_profiling_scope(True)
 
     def tick(t):
         w.tick_device(int(now[t]), n_updates=N, d_upd_x=dx.at(t * N * 8), d_upd_z=dz.at(t * N * 8), n_queries=S, d_queries=dq.at(t * S * 128))

@@ -32,6 +32,7 @@ BROADCAST_ALL_BUT_SENDER, BROADCAST_ALL_BUT_OWNER, BROADCAST_ALL_BUT_CLIENT, BRO
 BROADCAST_ADJACENT_CHANNELS = 64
 MAX_DAMPING = 8
 N_STAGES = 5
+PROF_STAGES, PROF_RECORD_KERNEL = 0, 1
 STAGE_NAMES = ("ingest", "index", "interest", "plan", "emit")
 
 # every symbol include/chd_spatial.h declares (checked by tests/test_abi.py)
@@ -43,7 +44,7 @@ SYMBOLS = (
     "chd_world_set_entity_flags", "chd_subs_add", "chd_subs_remove", "chd_tick",
     "chd_tick_device", "chd_tick_fetch", "chd_sync", "chd_subs_get",
     "chd_world_get_entities", "chd_dev_alloc", "chd_dev_free", "chd_dev_upload",
-    "chd_dev_download", "chd_set_profiling", "chd_world_set_pipelining", "chd_get_tick_stats", "chd_get_tick_history",
+    "chd_dev_download", "chd_set_profiling", "chd_set_profiling_scope", "chd_world_set_pipelining", "chd_get_tick_stats", "chd_get_tick_history",
     "chd_set_stream", "chd_shard_spawn", "chd_shard_ingest", "chd_shard_import", "chd_shard_fanout",
     "chd_shard_get_entities", "chd_shard_halo_layout", "chd_shard_interest",
     "chd_handover_recipients", "chd_adjacent_recipients", "chd_wire_set_payloads", "chd_wire_build", "chd_wire_fetch",
@@ -234,6 +235,7 @@ def load():
     L.chd_host_alloc.argtypes = [C.c_void_p, C.c_uint64, P(C.c_void_p)]
     L.chd_host_free.argtypes = [C.c_void_p, C.c_void_p]
     L.chd_set_profiling.argtypes = [C.c_void_p, C.c_int]
+    L.chd_set_profiling_scope.argtypes = [C.c_void_p, C.c_int]
     L.chd_world_set_pipelining.argtypes = [C.c_void_p, C.c_int]
     L.chd_get_tick_stats.argtypes = [C.c_void_p, P(TickStats)]
     L.chd_get_tick_history.argtypes = [C.c_void_p, C.c_uint32, P(TickStats)]

@@ -87,6 +87,7 @@ struct chd_ctx {
     bool force_device = false;          // CHD_NO_HOST_FAST_PATH=1: small stateless calls go to the device too (tests, measurements)
     bool chain = false, chain_prev = false;  // the previous call on this ctx was a pipelined tick (bind() shifts them)
     int prof_depth = 0;                 // 0 = off
+    bool prof_kernel_only = false;      // chd_set_profiling_scope(CHD_PROF_RECORD_KERNEL): only the event pair around the dominant emit kernel
     std::vector<hipEvent_t> ev;         // [prof_depth][EV_PER_TICK]: stage boundaries on `stream`, then interest begin/end
     std::vector<uint8_t> ev_overlap;    // [prof_depth] the slot's tick ran the interest stage on aux_stream
     chd_tick_stats stats{};
@@ -1148,10 +1149,12 @@ static int tick_locked(chd_ctx *ctx, const chd_tick_in *in) {
     // stage events: the serial schedule marks every stage boundary; the pipelined one only the begin and end of the stage
     // stream's work (a timed event between two small kernels costs ~5 us of idle stream) — stage_times() reports that
     // span as stage 0
-    const bool prof_stages = prof && !pipe;
+    // chd_set_profiling_scope(CHD_PROF_RECORD_KERNEL): nothing but the pair around the record kernel (throughput runs)
+    const bool prof_ends = prof && !ctx->prof_kernel_only;
+    const bool prof_stages = prof_ends && !pipe;
     if (prof) {
-        ctx->ev_overlap[r.cur_tick % (uint32_t)ctx->prof_depth] = (overlap ? 1 : 0) | (pipe ? 2 : 0);
-        HIPCHK(hipEventRecord(ev[0], bs));
+        ctx->ev_overlap[r.cur_tick % (uint32_t)ctx->prof_depth] = (overlap ? 1 : 0) | (pipe ? 2 : 0) | (prof_ends ? 0 : 4);
+        if (prof_ends) HIPCHK(hipEventRecord(ev[0], bs));
     }
     if (overlap) {
         hipStream_t ax = pipe ? ctx->aux2_stream : ctx->aux_stream;
@@ -1188,14 +1191,12 @@ static int tick_locked(chd_ctx *ctx, const chd_tick_in *in) {
         HIPCHK(hipStreamWaitEvent(st, W.ev_stages_done, 0));
         if (prof) HIPCHK(hipEventRecord(ev[CHD_N_STAGES + 4], st));
         launch_fanout_emit_main(st, ctx->g, d, in->now_ns, r);
-        if (prof) {
-            HIPCHK(hipEventRecord(ev[CHD_N_STAGES + 3], st));
-            HIPCHK(hipEventRecord(ev[5], st));
-        }
+        if (prof) HIPCHK(hipEventRecord(ev[CHD_N_STAGES + 3], st));
+        if (prof_ends) HIPCHK(hipEventRecord(ev[5], st));
         HIPCHK(hipEventRecord(W.ev_emit_done[par], st));
         launch_fanout_emit_deferred(bs, ctx->g, d, in->now_ns, r);
         launch_tick_epilogue(bs, d, r.cur_tick % TICK_RING);
-        if (prof) HIPCHK(hipEventRecord(ev[4], bs));
+        if (prof_ends) HIPCHK(hipEventRecord(ev[4], bs));
         // ... and whatever is enqueued on `stream` after this tick comes after ALL of it
         HIPCHK(hipEventRecord(W.ev_stages_all, bs));
         HIPCHK(hipStreamWaitEvent(st, W.ev_stages_all, 0));
@@ -1204,7 +1205,7 @@ static int tick_locked(chd_ctx *ctx, const chd_tick_in *in) {
         launch_fanout_emit_main(st, ctx->g, d, in->now_ns, r);
         if (prof) HIPCHK(hipEventRecord(ev[CHD_N_STAGES + 3], st));
         launch_fanout_emit_deferred(st, ctx->g, d, in->now_ns, r);
-        if (prof) HIPCHK(hipEventRecord(ev[5], st));
+        if (prof_ends) HIPCHK(hipEventRecord(ev[5], st));
         launch_tick_epilogue(st, d, r.cur_tick % TICK_RING);
     }
     TRY(after_launch(ctx));
@@ -1245,6 +1246,14 @@ static void stage_times(chd_ctx *ctx, uint32_t tick, chd_tick_stats &s) {
     const uint32_t slot = tick % (uint32_t)ctx->prof_depth;
     hipEvent_t *ev = &ctx->ev[(size_t)slot * EV_PER_TICK];
     float ms = 0;
+    if (ctx->ev_overlap[slot] & 4) {
+        // CHD_PROF_RECORD_KERNEL: only the record kernel's own pair was taken
+        for (int k = 0; k < CHD_N_STAGES; k++) s.stage_us[k] = 0.f;
+        s.total_us = 0.f;
+        (void)hipEventElapsedTime(&ms, ev[CHD_N_STAGES + 4], ev[CHD_N_STAGES + 3]);
+        s.emit_main_us = ms * 1000.f;
+        return;
+    }
     if (ctx->ev_overlap[slot] & 2) {
         // pipelined tick: stage 0 = everything on the stage stream (ingest ... plan, commit, deferred subscriptions, epilogue),
         // stage 4 = from there to the end of the record kernel (includes waiting for the previous tick's record kernel)
@@ -1671,9 +1680,10 @@ int chd_shard_fanout(chd_ctx *ctx, const void *d_halo_recv, uint32_t world, cons
     // stage events: ingest/index ran in the earlier phases (their slots read 0 here)
     const bool prof = ctx->prof_depth > 0;
     hipEvent_t *ev = prof ? &ctx->ev[(size_t)(r.cur_tick % (uint32_t)ctx->prof_depth) * EV_PER_TICK] : nullptr;
+    const bool prof_ends = prof && !ctx->prof_kernel_only;  // (chd_set_profiling_scope)
     if (prof) {
-        ctx->ev_overlap[r.cur_tick % (uint32_t)ctx->prof_depth] = 0;
-        for (int k = 0; k <= 2; k++) HIPCHK(hipEventRecord(ev[k], st));
+        ctx->ev_overlap[r.cur_tick % (uint32_t)ctx->prof_depth] = prof_ends ? 0 : 4;
+        if (prof_ends) for (int k = 0; k <= 2; k++) HIPCHK(hipEventRecord(ev[k], st));
     }
     // the neighbours' border bands join the own tables as ghost entries: ONE local table over region + halo, so the
     // fan-out takes the same kernels (and fast paths) as on a single GPU
@@ -1684,14 +1694,14 @@ int chd_shard_fanout(chd_ctx *ctx, const void *d_halo_recv, uint32_t world, cons
     d.cell_end = d.cell_tab + ctx->g.ncell;
     launch_aoi_interest(st, ctx->g, ctx->lim, d, d_in->queries, d_in->n_queries, d_in->query_sub, d_in->spot_x,
                         d_in->spot_z, d_in->spot_dist, now, r.cur_tick);
-    if (prof) HIPCHK(hipEventRecord(ev[3], st));
+    if (prof_ends) HIPCHK(hipEventRecord(ev[3], st));
     launch_fanout_plan(st, ctx->g, d, now, r);
-    if (prof) HIPCHK(hipEventRecord(ev[4], st));
+    if (prof_ends) HIPCHK(hipEventRecord(ev[4], st));
     if (prof) HIPCHK(hipEventRecord(ev[CHD_N_STAGES + 4], st));
     launch_fanout_emit_main(st, ctx->g, d, now, r);
     if (prof) HIPCHK(hipEventRecord(ev[CHD_N_STAGES + 3], st));
     launch_fanout_emit_deferred(st, ctx->g, d, now, r);
-    if (prof) HIPCHK(hipEventRecord(ev[5], st));
+    if (prof_ends) HIPCHK(hipEventRecord(ev[5], st));
     launch_tick_epilogue(st, d, r.cur_tick % TICK_RING);
     TRY(after_launch(ctx));
     if (d_in->n_queries) W.last_nq = d_in->n_queries;
@@ -2075,6 +2085,16 @@ int chd_set_profiling(chd_ctx *ctx, int depth) {
         HIPCHK(hipStreamSynchronize(ctx->stream));
         ctx->prof_depth = depth;
     }
+    return CHD_OK;
+}
+
+int chd_set_profiling_scope(chd_ctx *ctx, int scope) {
+    if (!ctx) return fail(nullptr, CHD_E_INVAL, "NULL ctx");
+    if (scope != CHD_PROF_STAGES && scope != CHD_PROF_RECORD_KERNEL) return fail(ctx, CHD_E_INVAL, "chd_set_profiling_scope: unknown scope %d", scope);
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    TRY(bind(ctx));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    ctx->prof_kernel_only = scope == CHD_PROF_RECORD_KERNEL;
     return CHD_OK;
 }
 

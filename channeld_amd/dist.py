@@ -362,7 +362,8 @@ def run_bench(args, rank: int, world: int, local_rank: int) -> dict:
     def tick(t):
         world_obj.tick(int(now[t]), d_x[t], d_z[t], d_q[t], nq)
 
-    eng.sw.set_profiling(min(1024, max(K, 1)))
+    eng.sw.set_profiling(min(1024, max(K, L, 1)))
+    eng.sw.set_profiling_scope(True)  # timed region: only the pair around the dominant kernel; stage breakdown from the latency phase
     for t in range(W):
         tick(t)
     comm.barrier()
@@ -385,7 +386,8 @@ def run_bench(args, rank: int, world: int, local_rank: int) -> dict:
     emit_us = np.array([h["emit_main_us"] for h in hist])
     emit_msgs = np.array([h["n_records"] - h["n_deferred_records"] for h in hist], dtype=np.float64)
     achieved = float(12.0 * emit_msgs.mean() / (emit_us.mean() * 1e-6) / 1e9) if emit_us.mean() > 0 else 0.0
-    stage_avg = np.mean(np.array([h["stage_us"] for h in hist]), axis=0)
+    stage_avg = np.zeros(5)
+    eng.sw.set_profiling_scope(False)
     # latency phase: one synchronous tick at a time (every rank in lock step: the tick has two exchanges)
     lat = []
     for t in range(W + K, W + K + L):
@@ -394,6 +396,8 @@ def run_bench(args, rank: int, world: int, local_rank: int) -> dict:
         torch.cuda.synchronize()
         lat.append((time.perf_counter() - a) * 1e3)
     lat = np.array(lat) if lat else np.array([0.0])
+    if L:
+        stage_avg = np.mean(np.array([h["stage_us"] for h in eng.sw.history(min(L, 1024))]), axis=0)
     per_rank = comm.gather_floats([achieved / 8000.0, float(emit_us.mean()), float(emit_msgs.mean()), float(np.percentile(lat, 50)),
                                    float(np.percentile(lat, 99)), float(stage_avg.sum()), float(len(mine)), float(len(my_subs))])
     sc, sr = server_layout(world)

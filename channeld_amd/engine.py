@@ -294,6 +294,10 @@ class SpatialWorld:
         """depth > 0: HIP events around the stages of each tick, last `depth` ticks kept."""
         _lib.check(self.ctx, self.lib.chd_set_profiling(self.ctx, int(depth)))
 
+    def set_profiling_scope(self, record_kernel_only: bool):
+        """True: a profiled tick records only the event pair around the dominant record kernel (throughput runs); False (default): every stage boundary."""
+        _lib.check(self.ctx, self.lib.chd_set_profiling_scope(self.ctx, _lib.PROF_RECORD_KERNEL if record_kernel_only else _lib.PROF_STAGES))
+
     def set_pipelining(self, on: bool):
         """CHD_WORLD_PIPELINE_TICKS (flags & 128) worlds: serial schedule (False) or pipelined ticks (True)."""
         _lib.check(self.ctx, self.lib.chd_world_set_pipelining(self.ctx, 1 if on else 0))

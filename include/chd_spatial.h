@@ -329,7 +329,14 @@ typedef struct {
     uint64_t *conn_rec_off;            /* max_subscribers+1: slot s owns records
                                           [conn_rec_off[s], conn_rec_off[s]+conn_rec_cnt[s]) */
     uint32_t *conn_rec_cnt;            /* max_subscribers */
-    uint32_t overflow;                 /* !=0: some output was truncated (CHD_E_CAPACITY) */
+    uint32_t overflow;                 /* !=0: chd_tick_fetch returns CHD_E_CAPACITY.  Bits: 1 handover list, 2 unsub list,
+                                          4 record buffer, 8 new-sub list truncated (grow the *_cap / max_records);
+                                          region-sharded worlds: 16 no free entity slot for a spawn or an immigrant (the
+                                          entity is LOST: the world is no longer consistent - size max_entities with
+                                          headroom for clustering), 32 an emigrant did not fit its destination's send
+                                          segment (it stays with the wrong owner and is retried next tick), 64 a border
+                                          band outgrew its halo segment or a subscription reaches beyond the halo;
+                                          0x8000 an internal loop bound tripped (a bug, never a capacity) */
     uint32_t history_overflow;         /* windows reaching beyond the 32-tick update history, or channels
                                           updated by more than two senders inside it (results then inexact) */
     uint32_t *record_masks;            /* optional, records_cap entries, parallel to `records`: CHD_WORLD_UPDATE_MASKS
@@ -607,6 +614,14 @@ typedef struct {
 /* depth > 0: record HIP events around the stages of the next ticks, keeping the
  * last `depth` ticks (<= 1024); 0 turns it off. */
 int chd_set_profiling(chd_ctx *ctx, int depth);
+/* What a profiled tick records.  CHD_PROF_STAGES (default): an event at every stage boundary (a timed event between two
+ * short kernels idles the stream for a few microseconds: use it for stage breakdowns and latency runs).
+ * CHD_PROF_RECORD_KERNEL: nothing but the pair around the dominant record-writing kernel (chd_tick_stats.emit_main_us;
+ * stage_us and total_us read 0): for throughput runs, whose tick time the caller takes from its own clock.  The analogue
+ * of switching the reference's per-channel `channel_tick_duration` histogram (metrics.go) off while load-testing. */
+#define CHD_PROF_STAGES 0
+#define CHD_PROF_RECORD_KERNEL 1
+int chd_set_profiling_scope(chd_ctx *ctx, int scope);
 /* Turn the tick pipelining of a CHD_WORLD_PIPELINE_TICKS world off (on = 0: serial schedule on the ctx stream, as without
  * the flag) and on again; CHD_E_STATE for a world created without the flag (or where it did not take effect). */
 int chd_world_set_pipelining(chd_ctx *ctx, int on);
