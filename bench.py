@@ -248,6 +248,13 @@ def main():
     if pipe:
         world_flags |= 128
     world = A.SpatialWorld(ctl, N, S, flags=world_flags)
+    if pipe:
+        # the flag only takes effect where the descriptor-driven connection-major emit runs (include/chd_spatial.h): e.g. not in
+        # a world whose populous cells select the cell-major emit (config C)
+        try:
+            world.set_pipelining(True)
+        except A.ChdError:
+            pipe = False
     world.spawn(None, sw.chan_id, sw.x, sw.z, sw.flags, sw.sender)
     world.add_subscribers(None, sw.sub_conn)
 
@@ -284,7 +291,10 @@ def main():
     world.set_profiling(min(1024, max(K, L, 1)))
     # throughput regions: only the event pair around the dominant kernel (a timed event at every stage boundary idles the
     # stream for a few microseconds each); the stage breakdown comes from the latency phase below
-    world.set_profiling_scope(True)
+    # (diagnostic configurations whose records mostly come from another kernel - per-record masks, partial updates, populous
+    # cells - keep the stage events: their roofline line is about the whole emit stage)
+    headline_like = args.update_frac >= 1.0 and not args.update_masks and args.emit != "cell-major" and N // max(ctl.GridCols * ctl.GridRows, 1) < 512
+    world.set_profiling_scope(headline_like)
     if pipe and not head_pipe:
         world.set_pipelining(False)
     for t in range(W):
@@ -302,6 +312,11 @@ def main():
     # (the few connections it defers are written by a second, small launch inside the same emit stage)
     emit_us = np.array([h["emit_main_us"] for h in hist])
     emit_msgs = np.array([h["n_records"] - h["n_deferred_records"] for h in hist], dtype=np.float64)
+    dominant = DOMINANT
+    if not headline_like:
+        emit_us = np.array([h["stage_us"][4] for h in hist])
+        emit_msgs = np.array([h["n_records"] for h in hist], dtype=np.float64)
+        dominant = "emit stage (all record-writing kernels of the tick; DIAGNOSTIC configuration)"
     stage_avg = np.zeros(5)
     res = world.fetch()
     assert res.overflow == 0 and res.history_overflow == 0, (res.overflow, res.history_overflow)
@@ -403,7 +418,7 @@ def main():
         "stage_us_avg": {n: float(v) for n, v in zip(("ingest", "index", "interest", "plan", "emit"), stage_avg)},
         "stage_us_avg_is": "HIP events at every stage boundary of the latency-phase ticks (serial schedule, one synchronous tick at a time); the timed "
                            "region records only the pair around the dominant kernel (chd_set_profiling_scope)",
-        "roofline": {"bound": "hbm", "kernel": DOMINANT, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+        "roofline": {"bound": "hbm", "kernel": dominant, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_quoted": traffic is not None,
                      "traffic_source": "QUOTED, not measured in this run: bytes per launch from the rocprofv3 --pmc passes of this command (profiles/hbm_traffic.json)",
                      "algorithmic_bytes_per_launch": float(BYTES_PER_MSG * emit_msgs.mean()),

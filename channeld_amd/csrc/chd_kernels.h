@@ -87,6 +87,7 @@ struct WorldDev {
     uint32_t wb;                    // 64-bit words per bitmap row (0: grid larger than 4096 cells, no bitmap)
     uint32_t cm_emit;               // cell-major emit selected
     uint32_t one_wave_emit;         // connection-major emit: one wave per connection also below 4096 connections
+    uint32_t seg_off;               // this tick: not the descriptor path (set per tick by the host, see tick_locked)
     unsigned long long *sub_bits;   // [S*wb]
     uint32_t *cell_ref;             // [ncell] live subscriptions of the cell
     uint32_t *active_cells;         // [ncell] cells with cell_ref > 0 (compacted every tick)

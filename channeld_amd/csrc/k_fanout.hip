@@ -206,7 +206,7 @@ static bool seg_path_enabled() {
     return on;
 }
 // the descriptor-driven path: connection-major, one-wave geometry (>= 4096 connections or asked for), no per-record masks
-static bool seg_path(const WorldDev &w) { return !w.cm_emit && !w.rec_mask && (w.S >= 4096 || w.one_wave_emit) && seg_path_enabled(); }
+static bool seg_path(const WorldDev &w) { return !w.cm_emit && !w.rec_mask && !w.seg_off && (w.S >= 4096 || w.one_wave_emit) && seg_path_enabled(); }
 
 __global__ void __launch_bounds__(64 * FO_WAVES) k_fanout_plan_seg(DevGrid g, WorldDev w, int64_t now, TickRing ring);
 

@@ -256,3 +256,43 @@ def test_config_c_one_million_entities_12_ticks_record_digests(amd):
     assert np.array_equal(cell, np.where(ow.entity_state()[0] == 0xFFFFFFFF, 0, ow.entity_state()[0] + 0x10000).astype(np.uint32))
     r3 = w.tick(sw.now_ns(), want_records=False)
     assert r3.n_records == 0
+
+
+def test_emit_form_follows_the_update_pattern(amd):
+    """A world of >= 4096 connections created without emit flags picks its connection-major form per tick (chd_api.hip,
+    tick_locked): the descriptor path while every live entity sends an update tick after tick, the one-launch filtering form
+    as soon as some skip a tick, and back.  Full / partial / full update phases, every tick compared with the oracle record
+    by record (digests per connection), so the state each form leaves is what the other one continues from."""
+    N, S = 40_000, 4_096
+    cfg, sw, ctl, w = build(amd, N, S, 0xC0FFEE31, max_records=60_000_000, flags=0)
+    ow = oracle_world(cfg, sw, N, S, w.capq)
+    rng = np.random.default_rng(11)
+    pattern = [1.0] * 4 + [0.6, 0.97] + [1.0] * 4 + [0.3] + [1.0] * 3
+    seen_deferred = 0
+    for k, frac in enumerate(pattern):
+        sw.step()
+        q = sw.queries()
+        if frac >= 1.0:
+            idx, x, z = None, sw.x, sw.z
+        else:
+            idx = np.sort(rng.choice(N, int(frac * N), replace=False)).astype(np.uint32)
+            x, z = sw.x[idx].copy(), sw.z[idx].copy()
+        ow.tick(sw.now_ns(), idx, x, z, None, None, None, None, q)
+        res = w.tick(sw.now_ns(), upd_idx=idx, upd_x=x, upd_z=z, queries=q, want_records=False, records_cap=1)
+        compare_tick(k, w, ow, res, sw)
+        seen_deferred += w.history(1)[0]["n_deferred_records"]
+    # (the descriptor path's deferred launch shows in n_deferred_records whenever a cell holds several senders' entities:
+    # informational here — which form ran is a performance matter, the records are what is compared)
+    print(f"deferred records over the full-update ticks: {seen_deferred}")
+    # a world that never updates fully never takes the descriptor path: nothing is ever deferred
+    cfg, sw, ctl, w = build(amd, N, S, 0xC0FFEE32, max_records=60_000_000, flags=0)
+    ow = oracle_world(cfg, sw, N, S, w.capq)
+    for k in range(4):
+        sw.step()
+        q = sw.queries()
+        idx = np.sort(rng.choice(N, int(0.9 * N), replace=False)).astype(np.uint32)
+        x, z = sw.x[idx].copy(), sw.z[idx].copy()
+        ow.tick(sw.now_ns(), idx, x, z, None, None, None, None, q)
+        res = w.tick(sw.now_ns(), upd_idx=idx, upd_x=x, upd_z=z, queries=q, want_records=False, records_cap=1)
+        compare_tick(100 + k, w, ow, res, sw)
+        assert w.history(1)[0]["n_deferred_records"] == 0
