@@ -594,7 +594,7 @@ int chd_dev_download(chd_ctx *ctx, void *dst, const void *d_src, uint64_t bytes)
 int chd_host_alloc(chd_ctx *ctx, uint64_t bytes, void **out);
 int chd_host_free(chd_ctx *ctx, void *ptr);
 
-/* metrics (channel_tick_duration analogue, metrics.go): GPU time of the last
+/* metrics (channel_tick_duration analogue, channel.go:382-383): GPU time of the last
  * tick per stage in microseconds, measured with HIP events on the ctx stream. */
 #define CHD_STAGE_INGEST 0   /* K1 cell assign + handover */
 #define CHD_STAGE_INDEX 1    /* K2 cell index build */
@@ -618,7 +618,7 @@ int chd_set_profiling(chd_ctx *ctx, int depth);
  * short kernels idles the stream for a few microseconds: use it for stage breakdowns and latency runs).
  * CHD_PROF_RECORD_KERNEL: nothing but the pair around the dominant record-writing kernel (chd_tick_stats.emit_main_us;
  * stage_us and total_us read 0): for throughput runs, whose tick time the caller takes from its own clock.  The analogue
- * of switching the reference's per-channel `channel_tick_duration` histogram (metrics.go) off while load-testing. */
+ * of not scraping the reference's per-channel `channel_tick_duration` gauge (channel.go:382-383) while load-testing. */
 #define CHD_PROF_STAGES 0
 #define CHD_PROF_RECORD_KERNEL 1
 int chd_set_profiling_scope(chd_ctx *ctx, int scope);
