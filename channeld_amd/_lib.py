@@ -48,7 +48,7 @@ SYMBOLS = (
     "chd_set_stream", "chd_shard_spawn", "chd_shard_ingest", "chd_shard_import", "chd_shard_fanout",
     "chd_shard_get_entities", "chd_shard_halo_layout", "chd_shard_interest",
     "chd_handover_recipients", "chd_adjacent_recipients", "chd_wire_set_payloads", "chd_wire_build", "chd_wire_fetch",
-    "chd_tick_digest", "chd_host_alloc", "chd_host_free", "chd_subs_set_options", "chd_subs_get_options", "chd_world_set_entity_groups", "chd_wire_set_type_url", "chd_handover_messages",
+    "chd_tick_digest", "chd_host_alloc", "chd_host_free", "chd_subs_set_options", "chd_subs_get_options", "chd_world_set_entity_groups", "chd_world_set_handover_lists", "chd_wire_set_type_url", "chd_handover_messages",
 )
 
 
@@ -234,6 +234,7 @@ def load():
     L.chd_subs_get_options.argtypes = [C.c_void_p, C.c_uint32, _u8p, _u8p, P(C.c_uint32)]
     L.chd_host_alloc.argtypes = [C.c_void_p, C.c_uint64, P(C.c_void_p)]
     L.chd_host_free.argtypes = [C.c_void_p, C.c_void_p]
+    L.chd_world_set_handover_lists.argtypes = [C.c_void_p, C.c_uint32, _u32p, _u32p, C.c_uint32, _u32p, _u32p]
     L.chd_set_profiling.argtypes = [C.c_void_p, C.c_int]
     L.chd_set_profiling_scope.argtypes = [C.c_void_p, C.c_int]
     L.chd_world_set_pipelining.argtypes = [C.c_void_p, C.c_int]

@@ -969,7 +969,8 @@ int chd_world_set_entity_groups(chd_ctx *ctx, uint32_t n, const uint32_t *idx, c
     std::lock_guard<std::mutex> lk(ctx->mu);
     if (W.slot_mode == 2) return fail(ctx, CHD_E_STATE, "handover groups are not available on region-sharded worlds (a group may span ranks)");
     TRY(bind(ctx));
-    if (W.group_id.empty()) W.group_id.assign(d.N, 0u);
+    if (W.group_id.empty() || d.grp_exact) W.group_id.assign(d.N, 0u);  // (after chd_world_set_handover_lists: start over)
+    d.grp_exact = 0;
     for (uint32_t i = 0; i < n; i++) W.group_id[idx[i]] = group[i];
     // CSR of the groups (rare control-plane call: rebuilt on the host, O(N log N))
     std::vector<uint32_t> order;
@@ -1000,6 +1001,52 @@ int chd_world_set_entity_groups(chd_ctx *ctx, uint32_t n, const uint32_t *idx, c
         launch_group_locks(ctx->stream, d);
         TRY(after_launch(ctx));
         HIPCHK(hipStreamSynchronize(ctx->stream));
+    }
+    return CHD_OK;
+}
+
+int chd_world_set_handover_lists(chd_ctx *ctx, uint32_t n_lists, const uint32_t *list_off, const uint32_t *list_members,
+                                 uint32_t n, const uint32_t *idx, const uint32_t *list_of) {
+    NEED_WORLD();
+    if (n_lists && !list_off) return fail(ctx, CHD_E_INVAL, "chd_world_set_handover_lists: NULL list_off");
+    if (n && (!idx || !list_of)) return fail(ctx, CHD_E_INVAL, "chd_world_set_handover_lists: NULL idx / list_of");
+    World &W = ctx->w;
+    WorldDev &d = W.d;
+    const uint32_t total = n_lists ? list_off[n_lists] : 0u;
+    if (n_lists && list_off[0] != 0) return fail(ctx, CHD_E_INVAL, "chd_world_set_handover_lists: list_off[0] must be 0");
+    for (uint32_t k = 0; k < n_lists; k++)
+        if (list_off[k + 1] < list_off[k]) return fail(ctx, CHD_E_INVAL, "chd_world_set_handover_lists: list_off decreases at %u", k);
+    if (total && !list_members) return fail(ctx, CHD_E_INVAL, "chd_world_set_handover_lists: NULL list_members");
+    for (uint32_t q = 0; q < total; q++)
+        if (list_members[q] >= d.N) return fail(ctx, CHD_E_INVAL, "handover list member %u out of range", list_members[q]);
+    for (uint32_t i = 0; i < n; i++) {
+        if (idx[i] >= d.N) return fail(ctx, CHD_E_INVAL, "entity slot %u out of range", idx[i]);
+        if (list_of[i] != CHD_NO_HANDOVER_LIST && list_of[i] >= n_lists) return fail(ctx, CHD_E_INVAL, "entity slot %u: list %u of %u", idx[i], list_of[i], n_lists);
+    }
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    if (W.slot_mode == 2) return fail(ctx, CHD_E_STATE, "handover groups are not available on region-sharded worlds (a group may span ranks)");
+    TRY(bind(ctx));
+    std::vector<uint32_t> of(d.N, CHD_INVALID);
+    for (uint32_t i = 0; i < n; i++) of[idx[i]] = list_of[i] == CHD_NO_HANDOVER_LIST ? CHD_INVALID : list_of[i];
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->aux_stream));
+    for (void *&b : W.grp_buf) { if (b) HIPCHK(hipFree(b)); b = nullptr; }
+    W.group_id.clear();
+    d.n_groups = 0;
+    d.grp_exact = 0;
+    d.grp_of = d.grp_off = d.grp_mem = d.grp_locked = nullptr;
+    if (n_lists) {
+        const size_t sz[4] = {4 * (size_t)d.N, 4 * (size_t)(n_lists + 1), 4 * std::max<size_t>(total, 1), 4 * (size_t)n_lists};
+        const void *src[4] = {of.data(), list_off, total ? list_members : nullptr, nullptr};
+        for (int k = 0; k < 4; k++) {
+            HIPCHK(hipMalloc(&W.grp_buf[k], sz[k]));
+            if (src[k]) HIPCHK(hipMemcpy(W.grp_buf[k], src[k], k == 2 ? 4 * (size_t)total : sz[k], hipMemcpyHostToDevice));
+            else HIPCHK(hipMemset(W.grp_buf[k], 0, sz[k]));
+        }
+        d.grp_of = (uint32_t *)W.grp_buf[0]; d.grp_off = (uint32_t *)W.grp_buf[1];
+        d.grp_mem = (uint32_t *)W.grp_buf[2]; d.grp_locked = (uint32_t *)W.grp_buf[3];
+        d.n_groups = n_lists;
+        d.grp_exact = 1;
     }
     return CHD_OK;
 }

@@ -41,8 +41,12 @@ struct WorldDev {
     // handover groups (entity.go:58-244, FlatEntityGroupController): entities that cross cells together.  grp_of[i] =
     // index of entity i's group (CHD_INVALID: a group of one); group k's members are grp_mem[grp_off[k] .. grp_off[k+1]);
     // grp_locked[k] = members that are alive and locked (a locked member aborts the whole handover, entity.go:197-224)
+    // grp_exact (chd_world_set_handover_lists): the lists ARE GetHandoverEntities' results as the host's group controller
+    // evaluated them — an empty list = no handover (a locked member, or an emptied group), the notifier moves only if it is
+    // a member; grp_locked is then unused.
     uint32_t *grp_of, *grp_off, *grp_mem, *grp_locked;
     uint32_t n_groups;
+    uint32_t grp_exact;
     // spatial (cell) channels' own update history
     uint32_t *cell_hist, *cell_hist_tick, *cell_sender, *cell_hist_prev, *cell_sender_prev;
     // cell index (rebuilt every tick)

@@ -371,7 +371,7 @@ __global__ void __launch_bounds__(256) k_group_locks(WorldDev w) {
     w.grp_locked[k] = n;
 }
 void launch_group_locks(hipStream_t st, WorldDev w) {
-    if (!w.n_groups) return;
+    if (!w.n_groups || w.grp_exact) return;
     hipLaunchKernelGGL(k_group_locks, dim3(nblocks(w.n_groups, 256)), dim3(256), 0, st, w);
 }
 
@@ -424,7 +424,10 @@ __global__ void __launch_bounds__(256) k_ingest(DevGrid g, WorldDev w, uint32_t 
                     bool lk = (ef & EF_LOCKED) != 0;
                     if (w.n_groups) {
                         const uint32_t gi = w.grp_of[i];
-                        if (gi != CHD_INVALID && w.grp_locked[gi] != 0) lk = true;
+                        if (gi != CHD_INVALID) {
+                            // (exact lists: len(handoverEntities) == 0 -> "No handover happens", spatial.go:675-679)
+                            if (w.grp_exact ? w.grp_off[gi + 1] == w.grp_off[gi] : w.grp_locked[gi] != 0) lk = true;
+                        }
                     }
                     if (lk) locked[j] = true;
                     else ho[j] = true;
@@ -451,19 +454,24 @@ __global__ void __launch_bounds__(256) k_ingest(DevGrid g, WorldDev w, uint32_t 
     for (int j = 0; j < ING_ITEMS; j++) {
         if (!ho[j]) continue;
         const uint32_t i = ent[j];
-        w.member[i] = dst[j];
+        bool self_moves = true;
         if (w.n_groups) {
             // the whole handover group leaves src's entity map for dst's (spatial.go:703-736 run over handoverEntities):
             // members that are in src's map move; one that is elsewhere stays where it is (RemoveEntity(src) fails for
             // it; the reference would ALSO add it to dst's map, an entity in two maps — not modelled).  A member that
             // hands over by its own update in this tick ends in its own dst either way (its store wins or this CAS fails).
+            // Exact lists (chd_world_set_handover_lists): the notifier itself moves only if its list names it.
             const uint32_t gi = w.grp_of[i];
-            if (gi != CHD_INVALID)
+            if (gi != CHD_INVALID) {
+                if (w.grp_exact) self_moves = false;
                 for (uint32_t q = w.grp_off[gi]; q < w.grp_off[gi + 1]; q++) {
                     const uint32_t m = w.grp_mem[q];
-                    if (m != i && (w.eflags[m] & EF_ALIVE)) atomicCAS(&w.member[m], src[j], dst[j]);
+                    if (m == i) self_moves = true;
+                    else if (w.eflags[m] & EF_ALIVE) atomicCAS(&w.member[m], src[j], dst[j]);
                 }
+            }
         }
+        if (self_moves) w.member[i] = dst[j];
         uint32_t pos = s_cnt[wave * ING_ITEMS + j] + mask_rank(hm[j]);
         if (pos < w.handovers_cap) {
             chd_handover_rec r;

@@ -108,6 +108,15 @@ class SpatialWorld:
         a, g = _u32(idx), _u32(groups)
         _lib.check(self.ctx, self.lib.chd_world_set_entity_groups(self.ctx, len(a), _ptr(a), _ptr(g)))
 
+    def set_handover_lists(self, list_off, list_members, idx, list_of):
+        """The exact form (chd_world_set_handover_lists): list k = list_members[list_off[k]:list_off[k+1]] (entity slots) is what
+        GetHandoverEntities returns for every entity idx[i] with list_of[i] == k; 0xFFFFFFFF = the entity itself.  Replaces the
+        whole group state of the world; channeld_amd.groups.EntityGroupTable.engine_lists() produces the arrays."""
+        off, mem, a, lo = _u32(list_off), _u32(list_members), _u32(idx), _u32(list_of)
+        n_lists = max(len(off) - 1, 0)
+        _lib.check(self.ctx, self.lib.chd_world_set_handover_lists(self.ctx, n_lists, _ptr(off) if n_lists else None,
+                                                                   _ptr(mem) if len(mem) else None, len(a), _ptr(a), _ptr(lo)))
+
     def add_subscribers(self, slots, conn_ids):
         s = None if slots is None else _u32(slots)
         c = _u32(conn_ids)

@@ -36,7 +36,7 @@
 extern "C" {
 #endif
 
-#define CHD_ABI_VERSION 5
+#define CHD_ABI_VERSION 6
 
 typedef struct chd_ctx chd_ctx;
 
@@ -232,6 +232,22 @@ int chd_world_set_entity_flags(chd_ctx *ctx, uint32_t n, const uint32_t *idx,
  * also add it to dst's map, leaving it in two maps); "locked" is the entity's flag, not the notifier's lock-group
  * membership test.  Not available on region-sharded worlds. */
 int chd_world_set_entity_groups(chd_ctx *ctx, uint32_t n, const uint32_t *idx, const uint32_t *group);
+
+/* The exact form: the engine is given what FlatEntityGroupController.GetHandoverEntities (entity.go:197-224) returns for
+ * every entity channel, as the host's group controller evaluates it (the reference's per-channel handover / lock group
+ * pointers are not equivalence classes: a locked entity does not take over the group it is added to, a removed one keeps an
+ * EMPTY group and cannot hand over until it is re-added — entity_test.go:11-105; channeld_amd/groups.py mirrors the
+ * controller and produces these arrays).  List k = list_members[list_off[k] .. list_off[k+1]) (entity slots; ids without a
+ * live entity are left out by the host); entity idx[i] takes list list_of[i], CHD_NO_HANDOVER_LIST = "AddToGroup was never
+ * called: the entity itself".  When entity e crosses cells: an EMPTY list -> no handover (len(handoverEntities) == 0,
+ * spatial.go:675-679: a locked member or an emptied group; counted in n_locked_aborts); else one handover record and every
+ * list member that is in the src cell's entity map moves to dst's (:703-736) — the notifier itself only if the list names
+ * it.  CHD_ENTITY_LOCKED is still honoured (it empties the notifier's own result).  Replaces the WHOLE group state of the
+ * world (n_lists == 0 clears it); the later of this call and chd_world_set_entity_groups wins.  Same deviation as above for
+ * members in a third cell's map.  Not available on region-sharded worlds. */
+#define CHD_NO_HANDOVER_LIST 0xFFFFFFFFu
+int chd_world_set_handover_lists(chd_ctx *ctx, uint32_t n_lists, const uint32_t *list_off /* n_lists + 1 */,
+                                 const uint32_t *list_members, uint32_t n, const uint32_t *idx, const uint32_t *list_of);
 
 /* A client connection with spatial interest (connection.go:106
  * spatialSubscriptions).  Slot -> ConnectionId.  Removing a subscriber drops all

@@ -68,6 +68,11 @@ typedef struct orc_world {
     uint8_t *alive;
     uint32_t *chan_id, *cell, *member, *eflags, *sender;
     uint32_t *group; /* handover group id per entity (0 = never added to a group: GetHandoverEntities returns the entity itself) */
+    /* explicit GetHandoverEntities results (entity.go:197-224 as evaluated by a FlatEntityGroupController, oracle/groups.py):
+     * hl_has[i] != 0 -> entity i's handover list is hl_mem[i][0..hl_n[i]) (empty: locked or emptied group, no handover) */
+    uint8_t *hl_has;
+    uint32_t *hl_n;
+    uint32_t **hl_mem;
     wbuf *ebuf;     /* entity channel update buffers */
     wbuf *cbuf;     /* cell channel update buffers */
     uint32_t max_interval_ms; /* maxFanOutIntervalMs (only grows) */
@@ -147,6 +152,9 @@ orc_world *orc_world_new(const orc_grid *g, uint32_t n_entities, uint32_t n_subs
     w->eflags = (uint32_t *)calloc(n_entities + 1, 4);
     w->sender = (uint32_t *)calloc(n_entities + 1, 4);
     w->group = (uint32_t *)calloc(n_entities + 1, 4);
+    w->hl_has = (uint8_t *)calloc(n_entities + 1, 1);
+    w->hl_n = (uint32_t *)calloc(n_entities + 1, 4);
+    w->hl_mem = (uint32_t **)calloc(n_entities + 1, sizeof(uint32_t *));
     w->ebuf = (wbuf *)calloc(n_entities + 1, sizeof(wbuf));
     w->cbuf = (wbuf *)calloc(w->C + 1, sizeof(wbuf));
     w->sub_alive = (uint8_t *)calloc(n_subs + 1, 1);
@@ -172,6 +180,8 @@ void orc_world_free(orc_world *w) {
     for (uint32_t i = 0; i < w->N; i++) free(w->ebuf[i].v);
     for (uint32_t i = 0; i < w->C; i++) free(w->cbuf[i].v);
     free(w->alive); free(w->chan_id); free(w->cell); free(w->member);
+    for (uint32_t i = 0; i < w->N; i++) free(w->hl_mem[i]);
+    free(w->hl_has); free(w->hl_n); free(w->hl_mem);
     free(w->eflags); free(w->sender); free(w->group); free(w->ebuf); free(w->cbuf);
     free(w->sub_alive); free(w->conn_id); free(w->pairs); free(w->pair_cnt);
     free(w->rec); free(w->ho_ent); free(w->ho_src); free(w->ho_dst);
@@ -208,6 +218,17 @@ void orc_world_spawn(orc_world *w, uint32_t i, uint32_t chan_id, double x,
 void orc_world_despawn(orc_world *w, uint32_t i) { w->alive[i] = 0; w->member[i] = W_INVALID; }
 void orc_world_set_flags(orc_world *w, uint32_t i, uint32_t flags) { w->eflags[i] = flags; }
 void orc_world_set_group(orc_world *w, uint32_t i, uint32_t group) { w->group[i] = group; }
+/* has = 0: back to "AddToGroup was never called" (the entity itself) */
+void orc_world_set_handover_list(orc_world *w, uint32_t i, int has, uint32_t n, const uint32_t *members) {
+    free(w->hl_mem[i]);
+    w->hl_mem[i] = NULL;
+    w->hl_has[i] = has ? 1 : 0;
+    w->hl_n[i] = has ? n : 0;
+    if (has && n) {
+        w->hl_mem[i] = (uint32_t *)malloc(4 * (size_t)n);
+        memcpy(w->hl_mem[i], members, 4 * (size_t)n);
+    }
+}
 
 void orc_world_add_sub(orc_world *w, uint32_t s, uint32_t conn_id) {
     w->sub_alive[s] = 1;
@@ -500,7 +521,8 @@ int orc_world_tick(orc_world *w, orc_time t, uint32_t n_upd, const uint32_t *idx
         if (src == W_INVALID || dst == W_INVALID || src == dst) continue; /* spatial.go:613-626 */
         /* GetHandoverEntities (entity.go:197-224): the notifier's handover group; a locked member empties it (:675-679) */
         int any_locked = (w->eflags[i] & 1u) != 0;
-        if (w->group[i])
+        if (w->hl_has[i]) any_locked = any_locked || w->hl_n[i] == 0; /* len(handoverEntities) == 0: "No handover happens" (spatial.go:675-679) */
+        else if (w->group[i])
             for (uint32_t m = 0; m < w->N && !any_locked; m++)
                 if (w->alive[m] && w->group[m] == w->group[i] && (w->eflags[m] & 1u)) any_locked = 1;
         if (any_locked) { w->n_locked_abort++; continue; }
@@ -518,6 +540,14 @@ int orc_world_tick(orc_world *w, orc_time t, uint32_t n_upd, const uint32_t *idx
         w->ho_srv_src[w->nho] = w->server_of_cell[src];
         w->ho_srv_dst[w->nho] = w->server_of_cell[dst];
         w->nho++;
+        if (w->hl_has[i]) { /* RemoveEntity(src) + AddEntity(dst) over handoverEntities — the notifier only if it is one of them */
+            for (uint32_t q = 0; q < w->hl_n[i]; q++) {
+                uint32_t m = w->hl_mem[i][q];
+                if (m == i) w->member[m] = dst; /* (the notifier: RemoveEntity(src) may fail, AddEntity(dst) happens) */
+                else if (m < w->N && w->alive[m] && w->member[m] == src) w->member[m] = dst;
+            }
+            continue;
+        }
         w->member[i] = dst; /* RemoveEntity(src) + AddEntity(dst), :703-736 */
         if (w->group[i]) /* ... for every entity of the handover group that is in src's map */
             for (uint32_t m = 0; m < w->N; m++)

@@ -118,6 +118,7 @@ def lib():
     L.orc_world_despawn.argtypes = [C.c_void_p, C.c_uint32]
     L.orc_world_set_flags.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32]
     L.orc_world_set_group.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32]
+    L.orc_world_set_handover_list.argtypes = [C.c_void_p, C.c_uint32, C.c_int, C.c_uint32, C.POINTER(C.c_uint32)]
     L.orc_world_add_sub.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32]
     L.orc_world_remove_sub.argtypes = [C.c_void_p, C.c_uint32]
     L.orc_world_tick.argtypes = [C.c_void_p, C.c_int64, C.c_uint32, up, dp, dp, up,
@@ -380,6 +381,14 @@ class World:
 
     def set_group(self, i, group):
         lib().orc_world_set_group(self.h, int(i), int(group))
+
+    def set_handover_list(self, i, members):
+        """members = what GetHandoverEntities returns for entity i (entity.go:197-224); None = AddToGroup never called."""
+        if members is None:
+            lib().orc_world_set_handover_list(self.h, int(i), 0, 0, None)
+            return
+        m = np.ascontiguousarray(members, dtype=np.uint32)
+        lib().orc_world_set_handover_list(self.h, int(i), 1, len(m), _p(m, C.c_uint32) if len(m) else None)
 
     def despawn(self, i):
         lib().orc_world_despawn(self.h, int(i))

@@ -353,3 +353,49 @@ def test_merge_sub_options():
     iv, dl, skip_self, skip_first, access = ch.options(c)
     assert (iv, dl, access) == (50, 200, 1)
     assert (skip_self, skip_first) == (1, 0)                             # defaultSubOptions, subscription.go:20-29
+
+
+def test_entity_channel_group_controller():
+    """TestEntityChannelGroupController (pkg/channeld/entity_test.go:11-105), transcribed 1:1 against the restatement of
+    FlatEntityGroupController (oracle/groups.py, entity.go:58-224).  Channels exist for the characters and the vehicle only
+    (createChannelWithId); PlayerControllers / PlayerStates are plain group members."""
+    from oracle.groups import HANDOVER, LOCK, FlatEntityGroupController as Ctl
+
+    channels = {}
+    charA, pcA, psA, charB, pcB, psB, vehicle, charC, pcC, psC = range(1, 11)
+    # Case 1 (:14-26)
+    chA = Ctl(charA, channels)
+    chA.add_to_group(HANDOVER, [charA, pcA, psA])
+    h = chA.get_handover_entities()
+    assert len(h) == 3 and {charA, pcA, psA} <= set(h)
+    # Case 2 (:28-41): attacked by B -> locked from handover
+    chB = Ctl(charB, channels)
+    chB.add_to_group(HANDOVER, [charB, pcB, psB])
+    chB.add_to_group(LOCK, [charA, charB])
+    assert len(chA.get_handover_entities()) == 0
+    # Case 3 (:43-52)
+    chA.remove_from_group(LOCK, [charA])
+    assert len(chA.get_handover_entities()) == 3
+    assert len(chB.get_handover_entities()) == 0
+    # Case 4 (:54-88): vehicle and passengers
+    chV = Ctl(vehicle, channels)
+    chC = Ctl(charC, channels)
+    chC.add_to_group(HANDOVER, [charC, pcC, psC])
+    chV.add_to_group(HANDOVER, [vehicle, charC])
+    chC.add_to_group(LOCK, [charC])
+    chV.add_to_group(HANDOVER, [vehicle, charA])
+    chA.add_to_group(LOCK, [charA])
+    assert len(chC.get_handover_entities()) == 0
+    h = chV.get_handover_entities()
+    assert vehicle in h and charA in h and charC in h
+    chV.remove_from_group(HANDOVER, [charA])
+    chA.remove_from_group(LOCK, [charA])
+    chA.add_to_group(HANDOVER, [charA, pcA, psA])
+    assert len(chA.get_handover_entities()) == 3
+    # Case 5 (:90-104)
+    chV.add_to_group(HANDOVER, [vehicle, charA])
+    chB.add_to_group(LOCK, [charA, charB])
+    chV.remove_from_group(HANDOVER, [charA])
+    assert len(chA.get_handover_entities()) == 0
+    h = chV.get_handover_entities()
+    assert vehicle in h and charA not in h and charC in h
