@@ -68,8 +68,11 @@ def weak_scaled_config(base: dict, world: int) -> dict:
     cfg["ServerCols"], cfg["ServerRows"] = sc, sr
     cfg["WorldOffsetX"] = -0.5 * cfg["GridCols"] * float(base["GridWidth"])
     cfg["WorldOffsetZ"] = -0.5 * cfg["GridRows"] * float(base["GridHeight"])
-    # the halo must cover the longest AOI reach of the workload: the bench's cones reach 5 cells
-    cfg["ServerInterestBorderSize"] = max(int(base.get("ServerInterestBorderSize", 1)), 5)
+    # The halo must cover the longest AOI reach of the workload — the bench's cones reach 5 cells — PLUS how far a
+    # connection's AOI centre can stray from its rank's region: connections are pinned to ranks while the entity they
+    # follow random-walks (<= 0.02 cell per tick, SURVEY 8d: ~0.2 cell over a few hundred ticks, so it can end up in the
+    # neighbour's first column).  2 cells of margin; a subscription that still reaches beyond sets overflow bit 64.
+    cfg["ServerInterestBorderSize"] = max(int(base.get("ServerInterestBorderSize", 1)), 5 + 2)
     return cfg
 
 

@@ -202,3 +202,35 @@ def test_layout_helpers():
         c = weak_scaled_config(base, w)
         counts = np.bincount(server_of_cell(c, np.arange(c["GridCols"] * c["GridRows"])), minlength=w)
         assert (counts == 225).all()
+
+
+def test_bench_halo_covers_the_drift_of_pinned_connections():
+    """bench.py --gpus N pins connection j to the rank that owns entity j's cell at the start, while the entity random-walks:
+    its AOI (cones reach 5 cells) must stay inside region + halo for the whole run, or chd_tick_fetch fails with overflow
+    bit 64.  Conservative bound (every shape reaches its full radius in every direction) over the default run length."""
+    base = synth.load_config("spatial_static_benchmark.json")
+    world = 2
+    cfg = weak_scaled_config(base, world)
+    halo = cfg["ServerInterestBorderSize"]
+    N, S = 100_000 * world, 10_000 * world
+    sw = synth.SynthWorld(synth.WorldSpec(cfg, N, S, 0xC0FFEE01, tick_ms=50))
+    cols, rows = cfg["GridCols"], cfg["GridRows"]
+    sc, sr = server_layout(world)
+    sgc, sgr = cols // sc, rows // sr
+    gx, gy = np.floor((sw.x - sw.offx) / sw.gw), np.floor((sw.z - sw.offz) / sw.gh)
+    inside = (gx >= 0) & (gx < cols) & (gy >= 0) & (gy < rows)
+    owner = np.where(inside, server_of_cell(cfg, np.where(inside, gx + gy * cols, 0).astype(np.int64)), 0)[:S]
+    rx0, ry0 = (owner % sc) * sgc, (owner // sc) * sgr
+    R = np.where(sw.shape == synth.SHAPE_CONE, 5.0, np.where(sw.shape == synth.SHAPE_SPHERE, 3.0, 2.0)) * sw.gw
+    worst = 0
+    for t in range(20 + 200 + 100):  # bench defaults: warm-up + timed + latency ticks of the sharded run
+        sw.step()
+        x, z = sw.x[:S], sw.z[:S]
+        ok = (x >= sw.offx) & (x < sw.offx + cols * sw.gw) & (z >= sw.offz) & (z < sw.offz + rows * sw.gh)
+        lo_x = np.floor((np.maximum(x - R, sw.offx) - sw.offx) / sw.gw)
+        hi_x = np.floor((np.minimum(x + R, sw.offx + cols * sw.gw - 1e-9) - sw.offx) / sw.gw)
+        lo_z = np.floor((np.maximum(z - R, sw.offz) - sw.offz) / sw.gh)
+        hi_z = np.floor((np.minimum(z + R, sw.offz + rows * sw.gh - 1e-9) - sw.offz) / sw.gh)
+        need = np.maximum.reduce([rx0 - lo_x, hi_x - (rx0 + sgc - 1), ry0 - lo_z, hi_z - (ry0 + sgr - 1)])
+        worst = max(worst, int(np.where(ok, need, 0).max()))
+    assert 5 < worst <= halo, f"AOIs reach {worst} cells beyond the owner's region, halo = {halo}"
