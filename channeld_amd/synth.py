@@ -108,12 +108,12 @@ class SynthWorld:
         self.tick_index = 0
 
     def _place(self, off, extent, n):
-        v = np.float64(np.float32(off + self.rng.uniform(n) * extent))
+        v = (off + self.rng.uniform(n) * extent).astype(np.float32).astype(np.float64)
         hi = np.float64(off + extent)
         bad = v >= hi  # float32 rounding landed on the exclusive upper edge: nudge down one ulp
-        v[bad] = np.float64(np.nextafter(np.float32(v[bad]), np.float32(-np.inf)))
+        v[bad] = np.nextafter(v[bad].astype(np.float32), np.float32(-np.inf)).astype(np.float64)
         lo_bad = v < off
-        v[lo_bad] = np.float64(np.nextafter(np.float32(v[lo_bad]), np.float32(np.inf)))
+        v[lo_bad] = np.nextafter(v[lo_bad].astype(np.float32), np.float32(np.inf)).astype(np.float64)
         return v
 
     def step(self):
@@ -130,12 +130,12 @@ class SynthWorld:
         lo, hi = self.offz, self.offz + self.H
         nz = np.where(nz < lo, 2 * lo - nz, nz)
         nz = np.where(nz >= hi, 2 * hi - nz, nz)
-        nx = np.float64(np.float32(nx))
-        nz = np.float64(np.float32(nz))
+        nx = nx.astype(np.float32).astype(np.float64)
+        nz = nz.astype(np.float32).astype(np.float64)
         edge = nx >= self.offx + self.W
-        nx[edge] = np.float64(np.nextafter(np.float32(nx[edge]), np.float32(-np.inf)))
+        nx[edge] = np.nextafter(nx[edge].astype(np.float32), np.float32(-np.inf)).astype(np.float64)
         edge = nz >= self.offz + self.H
-        nz[edge] = np.float64(np.nextafter(np.float32(nz[edge]), np.float32(-np.inf)))
+        nz[edge] = np.nextafter(nz[edge].astype(np.float32), np.float32(-np.inf)).astype(np.float64)
         keep = self.outside
         self.x = np.where(keep, self.x, nx)
         self.z = np.where(keep, self.z, nz)
