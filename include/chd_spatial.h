@@ -581,7 +581,8 @@ int chd_wire_set_type_url(chd_ctx *ctx, int which /* 0 entity data, 1 spatial ch
  *               (`shouldSend`: the connection was just subscribed to the entity channel).
  * The message does not depend on the recipient otherwise, so chd_handover_recipients says who gets which blob and the
  * host queues the same bytes for each of them.  The entities of a handover = the notifying entity, or all live
- * members of its handover group (chd_world_set_entity_groups), each as one map entry {netId = its entity channel id}.
+ * members of its handover group / handover list (chd_world_set_entity_groups, chd_world_set_handover_lists), each as one map
+ * entry {netId = its entity channel id}.
  * Needs CHD_WORLD_WIRE | CHD_WORLD_HANDOVER_RECIPIENTS, the CHD_WIRE_ENTITY_OBJREF / CHD_WIRE_ENTITY_FULL payloads
  * and the type url.  offsets has 2 * n_handovers + 1 entries. */
 int chd_handover_messages(chd_ctx *ctx, uint32_t *offsets, uint8_t *bytes, uint64_t cap, uint64_t *n_out);
