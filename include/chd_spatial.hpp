@@ -1,0 +1,497 @@
+// chd_spatial.hpp — C++17 host-side mirror of channeld's Go `SpatialController` interface
+// (pkg/channeld/spatial.go:17-35) over the C-ABI of libchd_spatial.so (chd_spatial.h).  Header-only.
+//
+// channeld is Go and this image has no Go toolchain, so the host side above the C-ABI exists twice: this header
+// (the reference is compiled code) and the Python mirror channeld_amd/controller.py + engine.py that the test-suite
+// drives.  Same method names, argument meaning and error behaviour as the Go type StaticGrid2DSpatialController
+// (spatial.go:89-124): methods return {value, Error} where Go returns (value, error); Error is "nil" when it
+// converts to false.  All batched arithmetic runs in HIP kernels behind the C-ABI — nothing here computes cells,
+// AOIs or fan-out; the one piece of arithmetic is go_cos (the cone's cos(angle), which a Go caller would take from
+// Go's own math.Cos, spatial.go:295).
+#pragma once
+
+#include <cmath>
+#include <cstdint>
+#include <cstdlib>
+#include <cstring>
+#include <functional>
+#include <map>
+#include <optional>
+#include <stdexcept>
+#include <string>
+#include <string_view>
+#include <utility>
+#include <vector>
+
+#include "chd_spatial.h"
+
+namespace chd {
+
+using ChannelId = uint32_t;    // common.ChannelId
+using ConnectionId = uint32_t;
+
+constexpr ChannelId SpatialChannelIdStart = 0x10000;  // settings.go:94
+constexpr ChannelId EntityChannelIdStart = 0x80000;   // settings.go:95
+constexpr double MinY = -3.40282347e38 / 2;           // spatial.go:80-83
+constexpr double MaxY = 3.40282347e38 / 2;
+
+// The `error` half of a Go (value, error) return: false == nil.
+struct Error {
+    int code = CHD_OK;
+    std::string msg;
+    explicit operator bool() const { return code != CHD_OK; }
+};
+
+struct SpatialInfo {  // pkg/common/common.go:20-24
+    double X = 0, Y = 0, Z = 0;
+};
+struct SpotsAOI {  // channeld.proto SpatialInterestQuery.SpotsAOI
+    std::vector<SpatialInfo> Spots;
+    std::vector<uint32_t> Dists;
+};
+struct BoxAOI {
+    std::optional<SpatialInfo> Center, Extent;
+};
+struct SphereAOI {
+    std::optional<SpatialInfo> Center;
+    double Radius = 0;
+};
+struct ConeAOI {
+    std::optional<SpatialInfo> Center, Direction;
+    double Angle = 0, Radius = 0;
+};
+struct SpatialInterestQuery {  // channeld.proto:386-440; an absent shape is a nil sub-message
+    std::optional<chd::SpotsAOI> SpotsAOI;
+    std::optional<chd::BoxAOI> BoxAOI;
+    std::optional<chd::SphereAOI> SphereAOI;
+    std::optional<chd::ConeAOI> ConeAOI;
+};
+struct SpatialRegion {  // channeldpb.SpatialRegion
+    SpatialInfo Min, Max;
+    ChannelId ChannelId_ = 0;
+    uint32_t ServerIndex = 0;
+};
+
+// Go's math.Cos (Go standard library src/math/sin.go, the Cephes port) for |x| < 2^29, every operation rounded on its
+// own (compile the including file without -ffast-math; volatile keeps the products from fusing into FMAs).  The same
+// restatement as channeld_amd/gomath.py and the oracle's orc_go_cos: written from the published algorithm, compared
+// with each other bit for bit (tests/test_cxx_host.py), NOT checked against a Go toolchain.
+inline double go_cos(double x) {
+    if (std::isnan(x) || std::isinf(x)) return std::nan("");
+    static const double PI4A = 7.85398125648498535156e-1, PI4B = 3.77489470793079817668e-8, PI4C = 2.69515142907905952645e-15;
+    static const double S[6] = {1.58962301576546568060e-10, -2.50507477628578072866e-8, 2.75573136213857245213e-6,
+                                -1.98412698295895385996e-4, 8.33333333332211858878e-3, -1.66666666666666307295e-1};
+    static const double C[6] = {-1.13585365213876817300e-11, 2.08757008419747316778e-9, -2.75573141792967388112e-7,
+                                2.48015872888517045348e-5, -1.38888888888730564116e-3, 4.16666666666665929218e-2};
+    static const double M4PI = 1.2732395447351628;
+    bool sign = false;
+    x = std::fabs(x);
+    if (x >= (double)(1 << 29)) throw std::domain_error("go_cos: Payne-Hanek range (|x| >= 2^29) is not restated");
+    volatile double t = x * M4PI;
+    int64_t j = (int64_t)t;
+    double y = (double)j;
+    if (j & 1) { j += 1; y += 1.0; }
+    j &= 7;
+    volatile double a = y * PI4A, b = y * PI4B, c = y * PI4C;
+    volatile double z1 = x - a;
+    volatile double z2 = z1 - b;
+    volatile double z = z2 - c;
+    if (j > 3) { j -= 4; sign = !sign; }
+    if (j > 1) sign = !sign;
+    volatile double zz = z * z;
+    const double *P = (j == 1 || j == 2) ? S : C;
+    volatile double p = P[0] * zz;
+    for (int k = 1; k < 6; k++) {
+        volatile double s = p + P[k];
+        p = (k < 5) ? s * zz : s;
+    }
+    volatile double r;
+    if (j == 1 || j == 2) {
+        volatile double zzz = z * zz;
+        volatile double q = zzz * p;
+        r = z + q;
+    } else {
+        volatile double h = 0.5 * zz;
+        volatile double one = 1.0 - h;
+        volatile double z4 = zz * zz;
+        volatile double q = z4 * p;
+        r = one + q;
+    }
+    return sign ? -r : r;
+}
+
+// SpatialInterestQuery messages -> chd_aoi_query records + the spot side arrays (as controller.py: pack_queries).
+// A nil Center / Extent / Direction would nil-deref in Go (spatial.go:205,237,272): reported as CHD_E_INVAL.
+struct PackedQueries {
+    std::vector<chd_aoi_query> q;
+    std::vector<double> spot_x, spot_z;
+    std::vector<uint32_t> spot_dist;
+};
+inline Error pack_queries(const std::vector<const SpatialInterestQuery *> &queries, PackedQueries &out) {
+    out = PackedQueries{};
+    out.q.resize(queries.size());
+    for (size_t i = 0; i < queries.size(); i++) {
+        const SpatialInterestQuery *q = queries[i];
+        if (!q) return {CHD_E_INVAL, "query is nil"};  // spatial.go:183-185
+        chd_aoi_query &a = out.q[i];
+        std::memset(&a, 0, sizeof a);
+        if (q->SpotsAOI) {
+            a.shapes |= CHD_SHAPE_SPOTS;
+            a.spot_off = (uint32_t)out.spot_x.size();
+            a.n_spots = (uint32_t)q->SpotsAOI->Spots.size();
+            a.n_spot_dists = (uint32_t)std::min(q->SpotsAOI->Dists.size(), q->SpotsAOI->Spots.size());
+            for (size_t k = 0; k < q->SpotsAOI->Spots.size(); k++) {
+                out.spot_x.push_back(q->SpotsAOI->Spots[k].X);
+                out.spot_z.push_back(q->SpotsAOI->Spots[k].Z);
+                out.spot_dist.push_back(k < q->SpotsAOI->Dists.size() ? q->SpotsAOI->Dists[k] : 0u);
+            }
+        }
+        if (q->BoxAOI) {
+            if (!q->BoxAOI->Center || !q->BoxAOI->Extent) return {CHD_E_INVAL, "BoxAOI.Center/Extent is nil"};
+            a.shapes |= CHD_SHAPE_BOX;
+            a.box_cx = q->BoxAOI->Center->X; a.box_cz = q->BoxAOI->Center->Z;
+            a.box_ex = q->BoxAOI->Extent->X; a.box_ez = q->BoxAOI->Extent->Z;
+        }
+        if (q->SphereAOI) {
+            if (!q->SphereAOI->Center) return {CHD_E_INVAL, "SphereAOI.Center is nil"};
+            a.shapes |= CHD_SHAPE_SPHERE;
+            a.sph_cx = q->SphereAOI->Center->X; a.sph_cz = q->SphereAOI->Center->Z; a.sph_r = q->SphereAOI->Radius;
+        }
+        if (q->ConeAOI) {
+            if (!q->ConeAOI->Center || !q->ConeAOI->Direction) return {CHD_E_INVAL, "ConeAOI.Center/Direction is nil"};
+            a.shapes |= CHD_SHAPE_CONE;
+            a.cone_cx = q->ConeAOI->Center->X; a.cone_cz = q->ConeAOI->Center->Z;
+            a.cone_dx = q->ConeAOI->Direction->X; a.cone_dz = q->ConeAOI->Direction->Z;
+            a.cone_r = q->ConeAOI->Radius;
+            a.cone_cos = go_cos(q->ConeAOI->Angle);  // math.Cos(Angle), spatial.go:295
+        }
+    }
+    return {};
+}
+
+namespace detail {
+// The flat JSON object LoadConfig unmarshals (spatial.go:141-145): "Key": number pairs, optionally wrapped in
+// {"SpatialControllerType": ..., "Config": {...}} as InitSpatialController reads the file (:61-68).
+inline bool json_number(std::string_view js, const char *key, double &out, bool &present) {
+    present = false;
+    const std::string pat = std::string("\"") + key + "\"";
+    size_t p = js.find(pat);
+    if (p == std::string_view::npos) return true;
+    p = js.find(':', p + pat.size());
+    if (p == std::string_view::npos) return false;
+    p++;
+    while (p < js.size() && (js[p] == ' ' || js[p] == '\t' || js[p] == '\n' || js[p] == '\r')) p++;
+    const std::string num(js.substr(p, std::min<size_t>(64, js.size() - p)));
+    char *end = nullptr;
+    const double v = std::strtod(num.c_str(), &end);
+    if (end == num.c_str()) return false;  // not a number: json.Unmarshal fails
+    out = v;
+    present = true;
+    return true;
+}
+}  // namespace detail
+
+// settings the reference takes from GlobalSettings (settings.go:64-105) and message_spatial.go:16-29
+struct ControllerSettings {
+    ChannelId SpatialChannelIdStart = chd::SpatialChannelIdStart, EntityChannelIdStart = chd::EntityChannelIdStart;
+    uint32_t DefaultFanOutIntervalMs = 20;
+    int32_t DefaultFanOutDelayMs = 0;
+    std::vector<std::pair<uint32_t, uint32_t>> Damping;  // {MaxDistance, FanOutIntervalMs}; empty = the reference's table
+};
+
+// Second implementation of `SpatialController` (the first being the reference's Go type of the same name), backed by
+// the gfx950 library.  The nine exported fields are the reference's (spatial.go:89-124).
+class StaticGrid2DSpatialController {
+  public:
+    double GridWidth = 0, GridHeight = 0, WorldOffsetX = 0, WorldOffsetZ = 0;
+    uint32_t GridCols = 0, GridRows = 0, ServerCols = 0, ServerRows = 0, ServerInterestBorderSize = 0;
+
+    using Settings = ControllerSettings;
+
+    explicit StaticGrid2DSpatialController(int device = 0) : device_(device) {}
+    StaticGrid2DSpatialController(const StaticGrid2DSpatialController &) = delete;
+    StaticGrid2DSpatialController &operator=(const StaticGrid2DSpatialController &) = delete;
+    ~StaticGrid2DSpatialController() { close(); }
+    void close() {
+        if (ctx_) chd_destroy(ctx_);
+        ctx_ = nullptr;
+    }
+    chd_ctx *ctx() const { return ctx_; }
+
+    // spatial.go:141-159.  strict = LoadConfig's own rejection of ServerInterestBorderSize <= 0 (:155), which
+    // InitSpatialController ignores (:68): pass false for that path.
+    Error LoadConfig(std::string_view config, bool strict = true, const Settings &st = Settings()) {
+        std::string_view js = config;
+        const size_t c = js.find("\"Config\"");
+        if (c != std::string_view::npos) js = js.substr(c + 8);
+        chd_grid_cfg cfg;
+        std::memset(&cfg, 0, sizeof cfg);
+        struct F { const char *k; double *d; uint32_t *u; } fields[] = {
+            {"GridWidth", &cfg.grid_width, nullptr}, {"GridHeight", &cfg.grid_height, nullptr},
+            {"WorldOffsetX", &cfg.world_offset_x, nullptr}, {"WorldOffsetZ", &cfg.world_offset_z, nullptr},
+            {"GridCols", nullptr, &cfg.grid_cols}, {"GridRows", nullptr, &cfg.grid_rows},
+            {"ServerCols", nullptr, &cfg.server_cols}, {"ServerRows", nullptr, &cfg.server_rows},
+            {"ServerInterestBorderSize", nullptr, &cfg.server_interest_border_size}};
+        for (const F &f : fields) {
+            double v = 0;
+            bool present = false;
+            if (!detail::json_number(js, f.k, v, present)) return {CHD_E_CONFIG, std::string("json: cannot unmarshal field ") + f.k};
+            if (!present) continue;
+            if (f.d) *f.d = v;
+            else {
+                if (v < 0 || v != std::floor(v) || v > 4294967295.0)
+                    return {CHD_E_CONFIG, std::string("json: cannot unmarshal number into uint32 field ") + f.k};
+                *f.u = (uint32_t)v;
+            }
+        }
+        cfg.spatial_channel_id_start = st.SpatialChannelIdStart;
+        cfg.entity_channel_id_start = st.EntityChannelIdStart;
+        cfg.default_fanout_interval_ms = st.DefaultFanOutIntervalMs;
+        cfg.default_fanout_delay_ms = st.DefaultFanOutDelayMs;
+        if (st.Damping.size() > CHD_MAX_DAMPING) return {CHD_E_CONFIG, "damping table longer than CHD_MAX_DAMPING"};
+        cfg.n_damping = (uint32_t)st.Damping.size();
+        for (size_t i = 0; i < st.Damping.size(); i++) {
+            cfg.damping_max_dist[i] = st.Damping[i].first;
+            cfg.damping_interval_ms[i] = st.Damping[i].second;
+        }
+        cfg.strict_load_config = strict ? 1u : 0u;
+        close();
+        chd_ctx *ctx = nullptr;
+        const int rc = chd_create(&cfg, device_, &ctx);
+        if (rc != CHD_OK) {
+            const char *m = chd_last_error(nullptr);
+            return {rc, m ? m : "chd_create failed"};  // CHD_E_CONFIG: the reference's validation; CHD_E_NO_DEVICE: no gfx950, no fallback
+        }
+        ctx_ = ctx;
+        GridWidth = cfg.grid_width; GridHeight = cfg.grid_height;
+        WorldOffsetX = cfg.world_offset_x; WorldOffsetZ = cfg.world_offset_z;
+        GridCols = cfg.grid_cols; GridRows = cfg.grid_rows;
+        ServerCols = cfg.server_cols; ServerRows = cfg.server_rows;
+        ServerInterestBorderSize = cfg.server_interest_border_size;
+        spatial_id_start_ = cfg.spatial_channel_id_start;
+        serverConnections_.assign((size_t)ServerCols * ServerRows, 0);
+        return {};
+    }
+
+    // spatial.go:161-163: (id, nil) or (0, err)
+    std::pair<ChannelId, Error> GetChannelId(const SpatialInfo &info) {
+        uint32_t id = 0;
+        const int rc = chd_get_channel_ids(need(), &info.X, &info.Z, 1, &id);
+        if (rc != CHD_OK) return {0, last(rc)};
+        if (id == 0) return {0, {CHD_E_INVAL, "spatial info is outside the grid"}};
+        return {id, {}};
+    }
+    // batched form: 0 = out of the world
+    Error GetChannelIds(const std::vector<double> &x, const std::vector<double> &z, std::vector<ChannelId> &out) {
+        out.assign(x.size(), 0);
+        if (x.size() != z.size()) return {CHD_E_INVAL, "x and z differ in length"};
+        if (x.empty()) return {};
+        const int rc = chd_get_channel_ids(need(), x.data(), z.data(), (uint32_t)x.size(), out.data());
+        return rc == CHD_OK ? Error{} : last(rc);
+    }
+
+    // spatial.go:182-317: (map[ChannelId]uint, nil) or (nil, err)
+    std::pair<std::map<ChannelId, uint32_t>, Error> QueryChannelIds(const SpatialInterestQuery *query) {
+        std::map<ChannelId, uint32_t> result;
+        PackedQueries p;
+        if (Error e = pack_queries({query}, p)) return {result, e};
+        const uint32_t cap = std::max<uint32_t>(1u, std::min<uint32_t>(GridCols * GridRows, 4096u));
+        std::vector<uint32_t> ids(cap), dists(cap);
+        uint32_t off[2] = {0, 0};
+        int32_t status = CHD_OK;
+        const int rc = chd_query_channel_ids(need(), p.q.data(), 1, p.spot_x.empty() ? nullptr : p.spot_x.data(),
+                                             p.spot_z.empty() ? nullptr : p.spot_z.data(),
+                                             p.spot_dist.empty() ? nullptr : p.spot_dist.data(), (uint32_t)p.spot_x.size(), off,
+                                             ids.data(), dists.data(), nullptr, cap, &status);
+        if (rc != CHD_OK) return {result, last(rc)};
+        if (status != CHD_OK) return {result, {status, query_error_text(status)}};  // the reference's error returns (:208-215, :228-231, ...)
+        for (uint32_t i = off[0]; i < off[1]; i++) result[ids[i]] = dists[i];
+        return {result, {}};
+    }
+
+    // spatial.go:319-356
+    std::pair<std::vector<SpatialRegion>, Error> GetRegions() {
+        const size_t n = (size_t)GridCols * GridRows;
+        std::vector<double> a(n), b(n), c(n), d(n);
+        std::vector<uint32_t> cid(n), srv(n);
+        std::vector<SpatialRegion> out;
+        const int rc = chd_get_regions(need(), a.data(), b.data(), c.data(), d.data(), cid.data(), srv.data());
+        if (rc != CHD_OK) return {out, last(rc)};
+        out.resize(n);
+        for (size_t i = 0; i < n; i++) out[i] = SpatialRegion{{a[i], MinY, b[i]}, {c[i], MaxY, d[i]}, cid[i], srv[i]};
+        return {out, {}};
+    }
+
+    // spatial.go:358-381: the up-to-8 neighbours in the reference's row-major order
+    std::pair<std::vector<ChannelId>, Error> GetAdjacentChannels(ChannelId spatialChannelId) {
+        uint32_t out[8], cnt = 0;
+        const int rc = chd_get_adjacent_channels(need(), &spatialChannelId, 1, out, &cnt);
+        if (rc != CHD_OK) return {{}, last(rc)};
+        return {std::vector<ChannelId>(out, out + cnt), {}};
+    }
+
+    // The spatial part of CreateChannels (spatial.go:387-479): gives `connection` the next server slot and returns the
+    // spatial channel ids it owns; once the last server has arrived `borderChannels(i)` are what server i is subscribed
+    // to (subToAdjacentChannels, :481-590).  Channel objects and messages stay with the gateway.
+    std::pair<std::vector<ChannelId>, Error> CreateChannels(ConnectionId connection) {
+        const uint32_t idx = nextServerIndex(), total = ServerCols * ServerRows;
+        if (idx >= total) return {{}, {CHD_E_INVAL, "all grids are allocated to the servers"}};
+        auto r = ServerChannels(idx);
+        if (r.second) return r;
+        serverConnections_[idx] = connection;
+        return r;
+    }
+    std::pair<std::vector<ChannelId>, Error> ServerChannels(uint32_t serverIndex) { return list_call(chd_server_channels, serverIndex, GridCols * GridRows + 8); }
+    std::pair<std::vector<ChannelId>, Error> BorderChannels(uint32_t serverIndex) {
+        return list_call(chd_border_channels, serverIndex, 4 * (GridCols + GridRows) * std::max(ServerInterestBorderSize, 1u) + 8);
+    }
+    uint32_t nextServerIndex() const {  // spatial.go:866-874
+        for (size_t i = 0; i < serverConnections_.size(); i++)
+            if (serverConnections_[i] == 0) return (uint32_t)i;
+        return (uint32_t)serverConnections_.size();
+    }
+    void ServerConnectionClosed(ConnectionId connection) {  // what Tick() finds out through IsClosing(), spatial.go:876-884
+        for (auto &c : serverConnections_)
+            if (c == connection) c = 0;
+    }
+
+    // spatial.go:612-626, the decision: calls the provider with (src, dst) iff both positions are in the world and in
+    // different cells.  Everything after it is the gateway's; the batched engine is SpatialWorld::Tick.
+    void Notify(const SpatialInfo &oldInfo, const SpatialInfo &newInfo,
+                const std::function<void(ChannelId, ChannelId, void *)> &handoverDataProvider) {
+        uint32_t src = 0, dst = 0;
+        uint8_t ho = 0;
+        if (chd_notify_decide(need(), &oldInfo.X, &oldInfo.Z, &newInfo.X, &newInfo.Z, 1, &src, &dst, &ho) != CHD_OK) return;
+        if (ho) handoverDataProvider(src, dst, nullptr);
+    }
+
+    static const char *query_error_text(int status) {
+        switch (status) {
+            case CHD_E_EXTENT: return "invalid box extent / radius";
+            case CHD_E_CENTER: return "AOI centre is outside the world";
+            case CHD_E_CAPACITY: return "interest set exceeds the engine capacity";
+            case CHD_E_HANG: return "the reference implementation would not terminate on this query";
+            case CHD_E_TOO_LARGE: return "sample lattice or cell window beyond engine limits";
+            default: return "query failed";
+        }
+    }
+
+  private:
+    chd_ctx *need() const {
+        if (!ctx_) throw std::logic_error("LoadConfig has not been called");
+        return ctx_;
+    }
+    Error last(int rc) const {
+        const char *m = chd_last_error(ctx_);
+        return {rc, m ? m : ""};
+    }
+    template <typename Fn>
+    std::pair<std::vector<ChannelId>, Error> list_call(Fn fn, uint32_t serverIndex, uint32_t cap) {
+        std::vector<ChannelId> out(cap);
+        uint32_t n = 0;
+        const int rc = fn(need(), serverIndex, out.data(), cap, &n);
+        if (rc != CHD_OK) return {{}, last(rc)};
+        out.resize(n);
+        return {out, {}};
+    }
+    int device_;
+    chd_ctx *ctx_ = nullptr;
+    ChannelId spatial_id_start_ = chd::SpatialChannelIdStart;
+    std::vector<ConnectionId> serverConnections_;  // 0 = free slot
+};
+
+// The batched engine: one Tick replaces N Notify calls, S handleUpdateSpatialInterest calls and tickData on every
+// spatial and entity channel (chd_tick).  Buffers are owned here and reused from tick to tick.
+class SpatialWorld {
+  public:
+    struct TickResult {
+        std::vector<chd_handover_rec> handovers;
+        uint32_t lockedAborts = 0;
+        std::vector<int32_t> queryStatus;
+        std::vector<uint32_t> unsubSlot, unsubChannel, newSubSlot, newSubChannel, newSubIntervalMs;
+        std::vector<chd_fanout_rec> records;       // grouped per connection slot:
+        std::vector<uint64_t> connRecordOffset;    //   slot s owns records [connRecordOffset[s], + connRecordCount[s])
+        std::vector<uint32_t> connRecordCount;
+        uint32_t overflow = 0, historyOverflow = 0;
+    };
+
+    SpatialWorld(StaticGrid2DSpatialController &ctl, uint32_t maxEntities, uint32_t maxSubscribers, uint64_t maxRecords = 0,
+                 uint32_t flags = 0)
+        : ctl_(ctl), N_(maxEntities), S_(maxSubscribers) {
+        chd_world_cfg c;
+        std::memset(&c, 0, sizeof c);
+        c.max_entities = maxEntities;
+        c.max_subscribers = maxSubscribers;
+        c.max_records = maxRecords;
+        c.flags = flags;
+        check(chd_world_create(ctl.ctx(), &c));
+        capq_ = std::min<uint32_t>(ctl.GridCols * ctl.GridRows, 256u);
+    }
+    // entity channel creation + spawn (message_spatial.go:231-237): slots 0..n-1
+    void Spawn(const std::vector<ChannelId> &entityChannelIds, const std::vector<double> &x, const std::vector<double> &z,
+               const std::vector<uint32_t> &flags, const std::vector<ConnectionId> &owner) {
+        check(chd_world_spawn(ctl_.ctx(), (uint32_t)entityChannelIds.size(), nullptr, entityChannelIds.data(), x.data(), z.data(),
+                              flags.empty() ? nullptr : flags.data(), owner.empty() ? nullptr : owner.data()));
+    }
+    void AddSubscribers(const std::vector<ConnectionId> &conn) { check(chd_subs_add(ctl_.ctx(), (uint32_t)conn.size(), nullptr, conn.data())); }
+
+    // entity updates (slot u = u), interest updates (one query per connection slot, nullptr = none), fan-out at nowNs
+    Error Tick(int64_t nowNs, const std::vector<double> &x, const std::vector<double> &z,
+               const std::vector<const SpatialInterestQuery *> &queries, uint64_t recordsCap, TickResult &out) {
+        PackedQueries p;
+        if (Error e = pack_queries(queries, p)) return e;
+        chd_tick_in in;
+        std::memset(&in, 0, sizeof in);
+        in.now_ns = nowNs;
+        in.n_updates = (uint32_t)x.size();
+        in.upd_x = x.data();
+        in.upd_z = z.data();
+        in.n_queries = (uint32_t)p.q.size();
+        in.queries = p.q.empty() ? nullptr : p.q.data();
+        in.spot_x = p.spot_x.empty() ? nullptr : p.spot_x.data();
+        in.spot_z = p.spot_z.empty() ? nullptr : p.spot_z.data();
+        in.spot_dist = p.spot_dist.empty() ? nullptr : p.spot_dist.data();
+        in.n_spots_total = (uint32_t)p.spot_x.size();
+        const uint32_t listCap = std::max<uint32_t>(1u, S_ * capq_);  // (every connection can drop / gain a whole interest set)
+        out.handovers.resize(std::max<uint32_t>(N_, 1u));
+        out.queryStatus.assign(std::max<size_t>(p.q.size(), 1), 0);
+        for (auto *v : {&out.unsubSlot, &out.unsubChannel, &out.newSubSlot, &out.newSubChannel, &out.newSubIntervalMs}) v->resize(listCap);
+        out.records.resize(std::max<uint64_t>(recordsCap, 1));
+        out.connRecordOffset.assign((size_t)S_ + 1, 0);
+        out.connRecordCount.assign(S_, 0);
+        chd_tick_out o;
+        std::memset(&o, 0, sizeof o);
+        o.handovers = out.handovers.data(); o.handovers_cap = (uint32_t)out.handovers.size();
+        o.query_status = out.queryStatus.data();
+        o.unsub_sub = out.unsubSlot.data(); o.unsub_channel = out.unsubChannel.data(); o.unsub_cap = listCap;
+        o.newsub_sub = out.newSubSlot.data(); o.newsub_channel = out.newSubChannel.data(); o.newsub_interval_ms = out.newSubIntervalMs.data();
+        o.newsub_cap = listCap;
+        o.records = out.records.data(); o.records_cap = recordsCap;
+        o.conn_rec_off = out.connRecordOffset.data(); o.conn_rec_cnt = out.connRecordCount.data();
+        const int rc = chd_tick(ctl_.ctx(), &in, &o);
+        out.overflow = o.overflow;
+        out.historyOverflow = o.history_overflow;
+        if (rc != CHD_OK) {
+            const char *m = chd_last_error(ctl_.ctx());
+            return {rc, m ? m : ""};
+        }
+        out.handovers.resize(o.n_handovers);
+        out.lockedAborts = o.n_locked_aborts;
+        for (auto *v : {&out.unsubSlot, &out.unsubChannel}) v->resize(o.n_unsubs);
+        for (auto *v : {&out.newSubSlot, &out.newSubChannel, &out.newSubIntervalMs}) v->resize(o.n_newsubs);
+        out.records.resize(o.n_records);
+        return {};
+    }
+
+  private:
+    void check(int rc) {
+        if (rc != CHD_OK) {
+            const char *m = chd_last_error(ctl_.ctx());
+            throw std::runtime_error(std::string("chd error ") + std::to_string(rc) + ": " + (m ? m : ""));
+        }
+    }
+    StaticGrid2DSpatialController &ctl_;
+    uint32_t N_, S_, capq_ = 0;
+};
+
+}  // namespace chd

@@ -1,0 +1,169 @@
+"""include/chd_spatial.hpp — the C++17 host mirror of the Go SpatialController interface — against the Python mirror
+(channeld_amd/controller.py, engine.py): same C-ABI underneath, so every result must be identical.
+
+CPU: the header compiles and links against libchd_spatial.so, go_cos is bit-identical to channeld_amd.gomath.go_cos and the
+oracle's, query packing produces the same chd_aoi_query bytes, LoadConfig fails loudly without a device.
+GPU: the interface methods on golden inputs and a three-tick world, line by line."""
+import ctypes as C
+import os
+import struct
+import subprocess
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def exe(tmp_path_factory):
+    from channeld_amd import build
+
+    build.build()
+    out = str(tmp_path_factory.mktemp("cxx") / "host_mirror_check")
+    libdir = os.path.join(ROOT, "channeld_amd")
+    cmd = ["g++", "-std=c++17", "-O1", "-Wall", "-Wextra", "-Werror", "-I" + os.path.join(ROOT, "include"),
+           os.path.join(ROOT, "tests", "cxx", "host_mirror_check.cpp"), "-o", out, "-L" + libdir, "-lchd_spatial", "-Wl,-rpath," + libdir]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    return out
+
+
+def run(exe, *args):
+    r = subprocess.run([exe, *args], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, (r.stdout, r.stderr)
+    return r.stdout.splitlines()
+
+
+def fixed_queries():
+    from channeld_amd.controller import BoxAOI, ConeAOI, SpatialInfo, SpatialInterestQuery, SphereAOI, SpotsAOI
+
+    I = SpatialInfo
+    qs = [SpatialInterestQuery() for _ in range(5)]
+    qs[0].SphereAOI = SphereAOI(I(10.5, 0, -20.25), 150.0)
+    qs[1].BoxAOI = BoxAOI(I(4.9, 0, 4.9), I(4.9, 0, 10.0))
+    qs[2].ConeAOI = ConeAOI(I(-1500.0, 0, 250.0), I(0.6, 0, -0.8), 0.5236, 30000.0)
+    qs[3].SpotsAOI = SpotsAOI([I(1, 0, 2), I(-3, 0, 4.5), I(1e6, 0, 0)], [7, 0])
+    qs[4].SpotsAOI = SpotsAOI([I(100, 0, 100)], [])
+    qs[4].SphereAOI = SphereAOI(I(0, 0, 0), 3000.0)
+    qs[4].ConeAOI = ConeAOI(I(0, 0, 0), I(1, 0, 0), 0.1, 6000.0)
+    return qs
+
+
+def test_go_cos_is_bit_identical_in_all_three_restatements(exe):
+    from channeld_amd.gomath import go_cos
+    from oracle import pyoracle as orc
+
+    rng = np.random.default_rng(17)
+    xs = [0.0, 0.1, 0.5236, np.pi / 4, np.pi / 2, 1.0, 2.0, 3.0, np.pi, 4.0, 5.5, 6.283185307179586, 100.5, -0.3, 1e-9, 12345.678]
+    xs += list(rng.uniform(0, np.pi, 300)) + list(rng.uniform(-50, 50, 100))
+    got = run(exe, "cos", *[repr(float(x)) for x in xs])
+    L = orc.lib()
+    L.orc_go_cos.restype = C.c_double
+    L.orc_go_cos.argtypes = [C.c_double]
+    for x, line in zip(xs, got):
+        want = struct.unpack("<Q", struct.pack("<d", go_cos(float(x))))[0]
+        assert int(line, 16) == want, x
+        assert struct.unpack("<Q", struct.pack("<d", L.orc_go_cos(float(x))))[0] == want, x
+
+
+def test_query_packing_matches_the_python_mirror_byte_for_byte(exe):
+    from channeld_amd import _lib
+    from channeld_amd.controller import BoxAOI, SpatialError, SpatialInfo, SpatialInterestQuery, pack_queries
+
+    lines = run(exe, "pack")
+    arr, sx, sz, sd = pack_queries(fixed_queries())
+    assert lines[0] == bytes(arr).hex()
+    assert lines[1] == sx.tobytes().hex() and lines[2] == sz.tobytes().hex() and lines[3] == sd.tobytes().hex()
+    bad = SpatialInterestQuery()
+    bad.BoxAOI = BoxAOI(SpatialInfo(0, 0, 0), None)
+    with pytest.raises(SpatialError) as e:
+        pack_queries([bad])
+    assert lines[4] == f"nil-extent {e.value.code}" and lines[5] == f"nil-query {_lib.E_INVAL}"
+
+
+def test_load_config_fails_loudly_without_a_device(exe):
+    import torch
+
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present: LoadConfig succeeds")
+    from channeld_amd import _lib
+
+    lines = run(exe, "load", os.path.join(ROOT, "configs", "spatial_static_benchmark.json"))
+    assert lines == [f"load {_lib.E_NO_DEVICE}", f"badjson {_lib.E_CONFIG}", f"negcols {_lib.E_CONFIG}"]
+
+
+@pytest.mark.gpu
+@pytest.mark.xfail(strict=False, reason="written after the round's GPU budget was spent: its first run on hardware is the driver's; "
+                                        "non-gating until it has passed once (every value is ALSO checked through the Python mirror in the other GPU tests)")
+def test_gpu_cxx_mirror_equals_the_python_mirror(exe):
+    import json
+
+    import channeld_amd as A
+    from channeld_amd.controller import BoxAOI, ConeAOI, SpatialInfo, SpatialInterestQuery, SphereAOI
+
+    cfg_path = os.path.join(ROOT, "configs", "spatial_static_benchmark.json")
+    got = run(exe, "gpu", cfg_path)
+    A.load()
+    ctl = A.StaticGrid2DSpatialController()
+    assert ctl.LoadConfig(open(cfg_path, "rb").read(), strict=False) is None
+    want = []
+    want.append("grid %u %u %u %u %u %s %s %s %s" % (ctl.GridCols, ctl.GridRows, ctl.ServerCols, ctl.ServerRows, ctl.ServerInterestBorderSize,
+                                                    *[("%.17g" % v) for v in (ctl.GridWidth, ctl.GridHeight, ctl.WorldOffsetX, ctl.WorldOffsetZ)]))
+    W, H = ctl.GridWidth * ctl.GridCols, ctl.GridHeight * ctl.GridRows
+    for i in range(9):
+        p = SpatialInfo(ctl.WorldOffsetX + W * i / 8.0, 0, ctl.WorldOffsetZ + H * (8 - i) / 8.0 - (1e-9 * H if i == 0 else 0))
+        cid, err = ctl.GetChannelId(p)
+        want.append(f"id {cid} {0 if err is None else err.code}")
+    cx, cz = ctl.WorldOffsetX + W / 2, ctl.WorldOffsetZ + H / 2
+    qs = [SpatialInterestQuery() for _ in range(5)]
+    qs[0].SphereAOI = SphereAOI(SpatialInfo(cx, 0, cz), 1.5 * ctl.GridWidth)
+    qs[1].BoxAOI = BoxAOI(SpatialInfo(cx, 0, cz), SpatialInfo(ctl.GridWidth, 0, 2 * ctl.GridHeight))
+    qs[2].ConeAOI = ConeAOI(SpatialInfo(cx, 0, cz), SpatialInfo(0.6, 0, 0.8), 0.5236, 3 * ctl.GridWidth)
+    qs[3].SphereAOI = SphereAOI(SpatialInfo(cx, 0, cz), -1.0)
+    qs[4].SphereAOI = SphereAOI(SpatialInfo(ctl.WorldOffsetX - 10, 0, cz), ctl.GridWidth)
+    for q in qs:
+        res, err = ctl.QueryChannelIds(q)
+        want.append("aoi %d%s" % (0 if err is None else err.code, "".join(f" {k}:{v}" for k, v in sorted((res or {}).items()))))
+    regions, _ = ctl.GetRegions()
+    step = max(1, len(regions) // 5)
+    want.append("regions %d%s" % (len(regions), "".join(" %u:%u:%.17g:%.17g" % (r.ChannelId, r.ServerIndex, r.Min.X, r.Max.Z) for r in regions[::step])))
+    n = ctl.GridCols * ctl.GridRows
+    for c in (0x10000, 0x10000 + n // 2, 0x10000 + n - 1):
+        adj, _ = ctl.GetAdjacentChannels(c)
+        want.append(f"adj {c}:" + "".join(f" {a}" for a in adj))
+    own, _ = ctl.CreateChannels(object())
+    want.append(f"server0 {len(own)} first {own[0]} last {own[-1]} next {ctl.nextServerIndex()}")
+    calls = []
+    ctl.Notify(SpatialInfo(cx - 1, 0, cz - 1), SpatialInfo(cx + ctl.GridWidth, 0, cz - 1), lambda s, d, _: calls.append((s, d)))
+    ctl.Notify(SpatialInfo(cx - 1, 0, cz - 1), SpatialInfo(cx - 2, 0, cz - 1), lambda s, d, _: calls.append((s, d)))
+    want += [f"notify {s} {d}" for s, d in calls] + [f"notify-calls {len(calls)}"]
+    N, S = 64, 4
+    world = A.SpatialWorld(ctl, N, S, max_records=1 << 16)
+    ids = (0x80000 + np.arange(N)).astype(np.uint32)
+    x = ctl.WorldOffsetX + W * (np.arange(N) + 0.5) / N
+    z = ctl.WorldOffsetZ + H * (np.arange(N) + 0.5) / N
+    world.spawn(None, ids, x, z, np.zeros(N, dtype=np.uint32), np.ones(N, dtype=np.uint32))
+    world.add_subscribers(None, np.array([1000, 1001, 1002, 1003], dtype=np.uint32))
+    M64 = (1 << 64) - 1
+    for t in range(1, 4):
+        x = x + 0.3 * ctl.GridWidth
+        x = np.where(x >= ctl.WorldOffsetX + W, x - W, x)
+        q = [SpatialInterestQuery() for _ in range(S)]
+        for s in range(S):
+            q[s].SphereAOI = SphereAOI(SpatialInfo(float(x[s * 16]), 0, float(z[s * 16])), 1.2 * ctl.GridWidth)
+        try:
+            r = world.tick(t * 50_000_000, upd_x=x, upd_z=z, queries=q, records_cap=1 << 16)
+            rc = 0
+        except A.ChdError as e:
+            rc, r = e.code, None
+        want.append("tick %d rc %d handovers %d aborts %d unsubs %d newsubs %d records %d overflow %d" % (
+            t, rc, len(r.handovers), r.n_locked_aborts, len(r.unsub_sub), len(r.newsub_sub), r.n_records, r.overflow))
+        hsum = 0
+        for h in r.handovers:
+            hsum = (hsum + int(h["entity"]) * 1315423911 + int(h["src"]) * 31 + int(h["dst"])) & M64
+        rsum = 0
+        for rec in r.records:
+            rsum = (rsum + ((int(rec["conn"]) << 32 | int(rec["channel"])) * 0x9E3779B97F4A7C15)) & M64
+        want.append(f"digest {hsum} {rsum}" + "".join(f" {int(c)}" for c in r.conn_rec_cnt[:S]))
+    assert got == want, "\n".join(f"{a!r} | {b!r}" for a, b in zip(got, want) if a != b)
