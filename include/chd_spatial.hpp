@@ -10,6 +10,7 @@
 // Go's own math.Cos, spatial.go:295).
 #pragma once
 
+#include <algorithm>
 #include <cmath>
 #include <cstdint>
 #include <cstdlib>
@@ -492,6 +493,126 @@ class SpatialWorld {
     }
     StaticGrid2DSpatialController &ctl_;
     uint32_t N_, S_, capq_ = 0;
+};
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Entity group controllers (pkg/channeld/entity.go:58-224): one FlatEntityGroupController per ENTITY channel, each with
+// a pointer to a handover group and to a lock group; group instances are SHARED between the channels a cascade has
+// reached.  Notify asks the notifier's controller for GetHandoverEntities() (entity.go:197-224, spatial.go:675-679).
+// These per-channel views are not equivalence classes (a locked entity does not take over the group it is added to; one
+// removed from a group keeps an EMPTY group and cannot hand over until it is added again, entity_test.go:82-88), so the
+// engine takes the evaluated lists: EngineLists() -> chd_world_set_handover_lists.  Same method names and argument
+// meaning as the Go interface EntityGroupController (entity.go:49-56); the Python twin is channeld_amd/groups.py.
+// ---------------------------------------------------------------------------------------------------------------------
+enum EntityGroupType { EntityGroupType_HANDOVER = 0, EntityGroupType_LOCK = 1 };  // channeld.proto
+using EntityId = uint32_t;
+
+class EntityGroupTable {
+  public:
+    // an ENTITY channel was created (its controller is Initialize()d, entity.go:66-68); slot = the engine's entity slot
+    void CreateChannel(EntityId id, uint32_t slot) { ctl_[id] = Ctl{-1, -1, slot}; }
+    // Uninitialize (entity.go:70-78): the entity leaves its current groups, which other channels may share
+    void RemoveChannel(EntityId id) {
+        auto it = ctl_.find(id);
+        if (it == ctl_.end()) return;
+        if (it->second.handover >= 0) RemoveFromGroup(id, EntityGroupType_HANDOVER, {id});
+        if (ctl_[id].lock >= 0) RemoveFromGroup(id, EntityGroupType_LOCK, {id});
+        ctl_.erase(id);
+    }
+    // entity.go:104-158, on the controller of channel `id`
+    Error AddToGroup(EntityId id, EntityGroupType t, const std::vector<EntityId> &entities) {
+        if (ptr(id, t) < 0) ptr(id, t) = new_set();
+        for (EntityId e : entities) {
+            const int k = ptr(id, t);  // (read anew for every entity, as the Go loop reads ctl.handoverGroup)
+            sets_[k].insert({e, true});
+            if (ctl_.count(e)) cascade(e, t, k);  // GetChannel(e) != nil: the member's controller joins the shared instance
+        }
+        return {};
+    }
+    // entity.go:160-195; the reference's error when the group pointer is nil
+    Error RemoveFromGroup(EntityId id, EntityGroupType t, const std::vector<EntityId> &entities) {
+        if (ptr(id, t) < 0)
+            return {CHD_E_STATE, std::string(t == EntityGroupType_HANDOVER ? "handover" : "lock") + " group is nil, entityId: " + std::to_string(id)};
+        for (EntityId e : entities) {
+            sets_[ptr(id, t)].erase(e);  // (once the channel removes ITSELF its pointer is a fresh empty group)
+            if (ctl_.count(e)) ptr(e, t) = new_set();  // the removed entity's channel starts over with an EMPTY group
+        }
+        return {};
+    }
+    // entity.go:197-224 (entity ids, ascending)
+    std::vector<EntityId> GetHandoverEntities(EntityId id) const {
+        const Ctl &c = ctl_.at(id);
+        if (c.handover < 0) return {id};  // "If AddToGroup is never called, return the entity itself"
+        const auto &members = sets_[c.handover];
+        if (c.lock >= 0)
+            for (const auto &kv : members)
+                if (sets_[c.lock].count(kv.first)) return {};  // a locked member: the handover should not happen
+        std::vector<EntityId> out;
+        for (const auto &kv : members) out.push_back(kv.first);
+        return out;
+    }
+    // what chd_world_set_handover_lists takes: every channel's evaluated list, members as entity slots (ids without an
+    // entity channel have no engine state and are left out), identical lists shared
+    struct Lists {
+        std::vector<uint32_t> list_off{0}, list_members, idx, list_of;
+    };
+    Lists EngineLists() const {
+        Lists L;
+        std::map<std::vector<uint32_t>, uint32_t> seen;
+        std::vector<std::vector<uint32_t>> order;
+        for (const auto &kv : ctl_) {  // ascending entity id
+            L.idx.push_back(kv.second.slot);
+            if (kv.second.handover < 0) { L.list_of.push_back(CHD_NO_HANDOVER_LIST); continue; }
+            std::vector<uint32_t> key;
+            for (EntityId m : GetHandoverEntities(kv.first)) {
+                auto it = ctl_.find(m);
+                if (it != ctl_.end()) key.push_back(it->second.slot);
+            }
+            std::sort(key.begin(), key.end());
+            auto ins = seen.insert({key, (uint32_t)order.size()});
+            if (ins.second) order.push_back(key);
+            L.list_of.push_back(ins.first->second);
+        }
+        for (const auto &key : order) {
+            L.list_members.insert(L.list_members.end(), key.begin(), key.end());
+            L.list_off.push_back((uint32_t)L.list_members.size());
+        }
+        return L;
+    }
+    Error Upload(chd_ctx *ctx) const {
+        const Lists L = EngineLists();
+        const uint32_t n_lists = (uint32_t)L.list_off.size() - 1;
+        const int rc = chd_world_set_handover_lists(ctx, n_lists, n_lists ? L.list_off.data() : nullptr,
+                                                    L.list_members.empty() ? nullptr : L.list_members.data(), (uint32_t)L.idx.size(),
+                                                    L.idx.empty() ? nullptr : L.idx.data(), L.list_of.empty() ? nullptr : L.list_of.data());
+        if (rc == CHD_OK) return {};
+        const char *m = chd_last_error(ctx);
+        return {rc, m ? m : ""};
+    }
+
+  private:
+    struct Ctl { int handover, lock; uint32_t slot; };
+    int &ptr(EntityId id, EntityGroupType t) { return t == EntityGroupType_HANDOVER ? ctl_.at(id).handover : ctl_.at(id).lock; }
+    int new_set() { sets_.emplace_back(); return (int)sets_.size() - 1; }
+    void add_all(int dst, int src) {
+        if (src < 0 || src == dst) return;
+        for (const auto &kv : sets_[src]) sets_[dst].insert(kv);
+    }
+    // cascadeGroup (entity.go:80-102) on channel e's controller with the shared instance k
+    void cascade(EntityId e, EntityGroupType t, int k) {
+        Ctl &c = ctl_.at(e);
+        if (c.lock >= 0 && !sets_[c.lock].empty()) return;  // "Current entity is already locked, won't cascade."
+        if (t == EntityGroupType_HANDOVER) {
+            add_all(k, c.handover);
+            c.handover = k;
+        } else {  // LOCK outranks HANDOVER: the cascade brings the handover group's entities into the lock group
+            add_all(k, c.handover);
+            add_all(k, c.lock);
+            c.lock = k;
+        }
+    }
+    std::map<EntityId, Ctl> ctl_;
+    std::vector<std::map<EntityId, bool>> sets_;  // arena of group instances: "two channels share one group" = same index
 };
 
 }  // namespace chd

@@ -2,6 +2,7 @@
 // tests/test_cxx_host.py, which compares every line with what the Python mirror gets through the same C-ABI.
 //   host_mirror_check cos <x>...            go_cos bit patterns
 //   host_mirror_check pack                  the packed chd_aoi_query records of a fixed query set
+//   host_mirror_check groups < script     EntityGroupTable driven by a script on stdin
 //   host_mirror_check load <config.json>    LoadConfig only: prints the error code (CHD_E_NO_DEVICE without a GPU)
 //   host_mirror_check gpu <config.json>     the interface methods on golden inputs + one world of three ticks
 #include <cinttypes>
@@ -64,6 +65,35 @@ int main(int argc, char **argv) {
         bad.BoxAOI = BoxAOI{SpatialInfo{0, 0, 0}, std::nullopt};
         std::printf("nil-extent %d\n", pack_queries({&bad}, p).code);
         std::printf("nil-query %d\n", pack_queries({nullptr}, p).code);
+        return 0;
+    }
+    if (mode == "groups") {
+        // script on stdin: "C id slot" create channel, "A id type n e..." AddToGroup, "R id type n e..." RemoveFromGroup,
+        // "D id" remove channel, "G id" print GetHandoverEntities, "L" print the engine lists
+        EntityGroupTable t;
+        char op;
+        while (std::scanf(" %c", &op) == 1) {
+            if (op == 'C') { unsigned id, slot; if (std::scanf("%u %u", &id, &slot) != 2) return 3; t.CreateChannel(id, slot); }
+            else if (op == 'D') { unsigned id; if (std::scanf("%u", &id) != 1) return 3; t.RemoveChannel(id); }
+            else if (op == 'A' || op == 'R') {
+                unsigned id, ty, n;
+                if (std::scanf("%u %u %u", &id, &ty, &n) != 3) return 3;
+                std::vector<EntityId> es(n);
+                for (auto &e : es) if (std::scanf("%u", &e) != 1) return 3;
+                Error err = op == 'A' ? t.AddToGroup(id, (EntityGroupType)ty, es) : t.RemoveFromGroup(id, (EntityGroupType)ty, es);
+                std::printf("%c %d\n", op, err.code);
+            } else if (op == 'G') {
+                unsigned id;
+                if (std::scanf("%u", &id) != 1) return 3;
+                std::printf("G %u:", id);
+                for (EntityId e : t.GetHandoverEntities(id)) std::printf(" %u", e);
+                std::printf("\n");
+            } else if (op == 'L') {
+                auto L = t.EngineLists();
+                auto dump = [](const char *n, const std::vector<uint32_t> &v) { std::printf("%s", n); for (uint32_t x : v) std::printf(" %u", x); std::printf("\n"); };
+                dump("off", L.list_off); dump("mem", L.list_members); dump("idx", L.idx); dump("of", L.list_of);
+            } else return 3;
+        }
         return 0;
     }
     if (argc < 3) return 2;

@@ -167,3 +167,66 @@ def test_gpu_cxx_mirror_equals_the_python_mirror(exe):
             rsum = (rsum + ((int(rec["conn"]) << 32 | int(rec["channel"])) * 0x9E3779B97F4A7C15)) & M64
         want.append(f"digest {hsum} {rsum}" + "".join(f" {int(c)}" for c in r.conn_rec_cnt[:S]))
     assert got == want, "\n".join(f"{a!r} | {b!r}" for a, b in zip(got, want) if a != b)
+
+
+def test_cxx_entity_group_table_equals_the_restatement_and_the_python_mirror(exe):
+    """chd::EntityGroupTable (include/chd_spatial.hpp) on the reference's TestEntityChannelGroupController script and on
+    random scripts: GetHandoverEntities of every channel after every step equals oracle/groups.py (the literal restatement of
+    entity.go) and the engine lists equal channeld_amd/groups.py's."""
+    from channeld_amd import groups as G
+    from oracle import groups as OG
+
+    def run_script(ids, ops):
+        t = G.EntityGroupTable()
+        chans, ctl = {}, {}
+        lines = []
+        for slot, e in enumerate(ids):
+            t.CreateChannel(e, slot)
+            ctl[e] = OG.FlatEntityGroupController(e, chans)
+            lines.append(f"C {e} {slot}")
+        want = []
+        for (e, kind, ty, members) in ops:
+            if kind == "A":
+                t.AddToGroup(e, ty, members)
+                ctl[e].add_to_group(ty, members)
+                rc = 0
+            else:
+                err = t.RemoveFromGroup(e, ty, members)
+                try:
+                    ctl[e].remove_from_group(ty, members)
+                    rc = 0
+                except ValueError:
+                    rc = -11  # CHD_E_STATE: "... group is nil"
+                assert (err is None) == (rc == 0)
+            lines.append(f"{kind} {e} {ty} {len(members)} " + " ".join(map(str, members)))
+            want.append(f"{kind} {rc}")
+            for c in ids:
+                lines.append(f"G {c}")
+                want.append(f"G {c}:" + "".join(f" {m}" for m in sorted(ctl[c].get_handover_entities())))
+        lines.append("L")
+        off, mem, idx, list_of = t.engine_lists()
+        for name, v in (("off", off), ("mem", mem), ("idx", idx), ("of", list_of)):
+            want.append(name + "".join(f" {int(x)}" for x in v))
+        r = subprocess.run([exe, "groups"], input="\n".join(lines) + "\n", capture_output=True, text=True, timeout=60)
+        assert r.returncode == 0, r.stderr
+        assert r.stdout.splitlines() == want
+
+    H, L = 0, 1
+    charA, pcA, psA, charB, pcB, psB, vehicle, charC, pcC, psC = range(1, 11)
+    run_script([charA, charB, vehicle, charC], [
+        (charA, "A", H, [charA, pcA, psA]), (charB, "A", H, [charB, pcB, psB]), (charB, "A", L, [charA, charB]),
+        (charA, "R", L, [charA]), (charC, "A", H, [charC, pcC, psC]), (vehicle, "A", H, [vehicle, charC]),
+        (charC, "A", L, [charC]), (vehicle, "A", H, [vehicle, charA]), (charA, "A", L, [charA]),
+        (vehicle, "R", H, [charA]), (charA, "R", L, [charA]), (charA, "A", H, [charA, pcA, psA]),
+        (vehicle, "A", H, [vehicle, charA]), (charB, "A", L, [charA, charB]), (vehicle, "R", H, [charA])])
+    rng = np.random.default_rng(23)
+    for trial in range(25):
+        n_ch = int(rng.integers(2, 8))
+        ids = list(range(1, n_ch + 1))
+        pool = ids + list(range(100, 100 + int(rng.integers(0, 4))))
+        ops = []
+        for _ in range(int(rng.integers(5, 30))):
+            k = min(int(rng.integers(1, 4)), len(pool))
+            ops.append((int(rng.choice(ids)), "A" if rng.random() < 0.65 else "R", int(rng.integers(0, 2)),
+                        [int(v) for v in rng.choice(pool, size=k, replace=False)]))
+        run_script(ids, ops)
