@@ -484,7 +484,70 @@ class SpatialWorld {
         return {};
     }
 
+    // ---- the rest of the world API, one thin method per entry point (chd_spatial.h has the reference citations) ----
+    void Despawn(const std::vector<uint32_t> &slots) { check(chd_world_despawn(ctl_.ctx(), (uint32_t)slots.size(), slots.data())); }
+    void SetEntityFlags(const std::vector<uint32_t> &slots, const std::vector<uint32_t> &flags) {
+        check(chd_world_set_entity_flags(ctl_.ctx(), (uint32_t)slots.size(), slots.data(), flags.data()));
+    }
+    void RemoveSubscribers(const std::vector<uint32_t> &slots) { check(chd_subs_remove(ctl_.ctx(), (uint32_t)slots.size(), slots.data())); }
+    // Connection.SubscribeToChannel with explicit ChannelSubscriptionOptions (subscription.go:34-102); shouldSend[i] as there
+    Error SetSubOptions(int64_t nowNs, const std::vector<chd_sub_options> &opts, std::vector<uint8_t> &shouldSend, std::vector<int32_t> &status) {
+        shouldSend.assign(opts.size(), 0);
+        status.assign(opts.size(), 0);
+        return err(chd_subs_set_options(ctl_.ctx(), nowNs, (uint32_t)opts.size(), opts.data(), shouldSend.data(), status.data()));
+    }
+    // who receives each handover's ChannelDataHandoverMessage (spatial.go:776-857): CSR over the last tick's handovers
+    Error HandoverRecipients(uint32_t nHandovers, std::vector<uint32_t> &offsets, std::vector<uint32_t> &conn, std::vector<uint8_t> &kind) {
+        offsets.assign((size_t)nHandovers + 1, 0);
+        uint64_t n = 0;
+        int rc = chd_handover_recipients(ctl_.ctx(), offsets.data(), nullptr, nullptr, 0, &n);  // count
+        if (rc != CHD_OK && rc != CHD_E_CAPACITY) return err(rc);
+        conn.assign(std::max<uint64_t>(n, 1), 0);
+        kind.assign(std::max<uint64_t>(n, 1), 0);
+        rc = chd_handover_recipients(ctl_.ctx(), offsets.data(), conn.data(), kind.data(), conn.size(), &n);
+        conn.resize(n);
+        kind.resize(n);
+        return err(rc);
+    }
+    // wire-format fan-out buffers (connection.go:57-83,626-714): payloads in, per-connection packet streams out
+    void WireSetPayloads(int kind, const std::vector<uint32_t> &idx, const std::vector<uint32_t> &lens, const std::vector<uint8_t> &bytes) {
+        check(chd_wire_set_payloads(ctl_.ctx(), kind, (uint32_t)idx.size(), idx.data(), lens.data(), bytes.data()));
+    }
+    void WireSetTypeUrl(int which, const std::string &url) { check(chd_wire_set_type_url(ctl_.ctx(), which, (const uint8_t *)url.data(), (uint32_t)url.size())); }
+    Error WireBuild(uint64_t &totalBytes, uint64_t &totalPackets, uint32_t &dropped) { return err(chd_wire_build(ctl_.ctx(), &totalBytes, &totalPackets, &dropped)); }
+    Error WireFetch(std::vector<uint64_t> &connOff, std::vector<uint32_t> &connPackets, std::vector<uint8_t> &bytes) {
+        connOff.assign((size_t)S_ + 1, 0);
+        connPackets.assign(S_, 0);
+        int rc = chd_wire_fetch(ctl_.ctx(), connOff.data(), connPackets.data(), nullptr, 0);  // offsets only
+        if (rc != CHD_OK) return err(rc);
+        bytes.assign(std::max<uint64_t>(connOff[S_], 1), 0);
+        return err(chd_wire_fetch(ctl_.ctx(), connOff.data(), connPackets.data(), bytes.data(), bytes.size()));
+    }
+    // the two MessagePacks of every handover of the last tick (spatial.go:738-773,797-857): blob 2h / 2h+1
+    Error HandoverMessages(uint32_t nHandovers, std::vector<uint32_t> &offsets, std::vector<uint8_t> &bytes, uint64_t cap) {
+        offsets.assign(2 * (size_t)nHandovers + 1, 0);
+        bytes.assign(std::max<uint64_t>(cap, 1), 0);
+        uint64_t n = 0;
+        const int rc = chd_handover_messages(ctl_.ctx(), offsets.data(), bytes.data(), cap, &n);
+        bytes.resize(rc == CHD_OK ? n : 0);
+        return err(rc);
+    }
+    chd_records_digest Digest(std::vector<uint64_t> *perConnection = nullptr) {
+        chd_records_digest d;
+        std::memset(&d, 0, sizeof d);
+        if (perConnection) perConnection->assign(S_, 0);
+        check(chd_tick_digest(ctl_.ctx(), &d, perConnection ? perConnection->data() : nullptr));
+        return d;
+    }
+    void SetPipelining(bool on) { check(chd_world_set_pipelining(ctl_.ctx(), on ? 1 : 0)); }
+    void Sync() { check(chd_sync(ctl_.ctx())); }
+
   private:
+    Error err(int rc) const {
+        if (rc == CHD_OK) return {};
+        const char *m = chd_last_error(ctl_.ctx());
+        return {rc, m ? m : ""};
+    }
     void check(int rc) {
         if (rc != CHD_OK) {
             const char *m = chd_last_error(ctl_.ctx());
