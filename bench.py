@@ -225,6 +225,8 @@ def main():
 
         result = cdist.run_bench(args, rank, world_size, local_rank)
         if rank == 0:
+            result["collectives"] = {"backend": str(dist.get_backend()) + (" (RCCL over xGMI)" if str(dist.get_backend()) == "nccl" else ""),
+                                     "ranks": int(dist.get_world_size()), "devices_visible": int(torch.cuda.device_count())}
             if not args.no_cpu and args.cpu_seconds > 0:  # after the timed region, rank 0's host cores (the others wait in destroy)
                 base = synth.load_config("spatial_static_benchmark.json")
                 result["cpu_baseline"], one = cpu_baseline(base, args.entities, args.subs, 0xC0FFEE01, args.tick_ms, args.aoi_scale,
