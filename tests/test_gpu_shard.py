@@ -200,12 +200,14 @@ def test_rccl_single_rank_bench_path():
 
     env = dict(os.environ, CHD_BENCH_FORCE_DIST="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
     common = ["--gpus", "1", "--steps", "6", "--warmup", "3", "--entities", "20000", "--subs", "2000", "--no-cpu", "--latency-steps", "0"]
+    # (the sharded run also takes its latency phase — two synchronous ticks with stage events — as the driver's N > 1 runs do)
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
-           "--master-port", str(free_port()), os.path.join(ROOT, "bench.py")] + common
+           "--master-port", str(free_port()), os.path.join(ROOT, "bench.py")] + common[:-1] + ["2"]
     r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=280, cwd=ROOT)
     assert r.returncode == 0, r.stderr[-2000:]
     sharded = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
     assert sharded["n_gpus"] == 1 and "tiled 1x1" in sharded["config"]["workload"]
+    assert sharded["latency_ticks"] == 2 and sharded["collectives"]["ranks"] == 1
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + common, capture_output=True, text=True, timeout=280, cwd=ROOT)
     assert r.returncode == 0, r.stderr[-2000:]
     single = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
