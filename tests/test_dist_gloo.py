@@ -234,3 +234,55 @@ def test_bench_halo_covers_the_drift_of_pinned_connections():
         need = np.maximum.reduce([rx0 - lo_x, hi_x - (rx0 + sgc - 1), ry0 - lo_z, hi_z - (ry0 + sgr - 1)])
         worst = max(worst, int(np.where(ok, need, 0).max()))
     assert 5 < worst <= halo, f"AOIs reach {worst} cells beyond the owner's region, halo = {halo}"
+
+
+def _comm_helpers_rank(rank, world, port, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group(backend="gloo", rank=rank, world_size=world)
+    try:
+        comm = Comm(rank, world)
+        assert comm.backend == "gloo" and comm.staged
+        assert comm.sum_int(10 + rank) == sum(10 + r for r in range(world))
+        assert comm.max_float(0.5 * (rank + 1)) == 0.5 * world
+        got = comm.gather_floats([float(rank), 2.0 * rank, -1.0])
+        assert got == [[float(r), 2.0 * r, -1.0] for r in range(world)]
+        comm.barrier()
+        # equal-sized all-to-all: segment d of rank s = [100 s + d] * 3
+        send = torch.tensor([[100 * rank + d] * 3 for d in range(world)], dtype=torch.int32)
+        recv = comm.all_to_all(send)
+        assert recv.tolist() == [[100 * s + rank] * 3 for s in range(world)]
+        # all-to-all(v) of byte segments with static, uneven splits (zero to self): rank s sends rank d (s + d + 1) bytes of value 16 s + d
+        send_splits = [0 if d == rank else rank + d + 1 for d in range(world)]
+        recv_splits = [0 if s == rank else s + rank + 1 for s in range(world)]
+        buf = torch.cat([torch.full((n,), 16 * rank + d, dtype=torch.uint8) for d, n in enumerate(send_splits)] + [torch.zeros(5, dtype=torch.uint8)])
+        offs_of_peers = [sum((0 if d == s else s + d + 1) for d in range(rank)) for s in range(world)]  # where rank s keeps the segment for THIS rank
+        ran = []
+        got = comm.halo_exchange(buf, send_splits, recv_splits, offs_of_peers, overlap=lambda: ran.append(1))
+        want = [16 * s + rank for s in range(world) for _ in range(recv_splits[s])]
+        assert got.tolist() == want and ran == [1]
+        if rank == 0:
+            out.put("ok")
+    except Exception as e:
+        import traceback
+
+        out.put(f"rank {rank}: {e}\n{traceback.format_exc()}")
+        raise
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 4])
+def test_comm_helpers_across_ranks(world):
+    """Comm's reductions, gathers and the two exchange forms with more than one rank (gloo: host-staged; the same calls with
+    device tensors are RCCL's on the GPU boxes, where only one rank is available to the tests)."""
+    ctx = mp.get_context("spawn")
+    out = ctx.Queue()
+    port = free_port()
+    procs = [ctx.Process(target=_comm_helpers_rank, args=(r, world, port, out)) for r in range(world)]
+    for p in procs:
+        p.start()
+    status = out.get(timeout=120)
+    for p in procs:
+        p.join(timeout=60)
+    assert status == "ok", status
+    assert all(p.exitcode == 0 for p in procs)
