@@ -57,6 +57,9 @@ def test_go_cos_is_bit_identical_in_all_three_restatements(exe):
     rng = np.random.default_rng(17)
     xs = [0.0, 0.1, 0.5236, np.pi / 4, np.pi / 2, 1.0, 2.0, 3.0, np.pi, 4.0, 5.5, 6.283185307179586, 100.5, -0.3, 1e-9, 12345.678]
     xs += list(rng.uniform(0, np.pi, 300)) + list(rng.uniform(-50, 50, 100))
+    from test_oracle_golden import GO_VF  # the inputs of Go's own TestCos (src/math/all_test.go)
+
+    xs += GO_VF
     got = run(exe, "cos", *[repr(float(x)) for x in xs])
     L = orc.lib()
     L.orc_go_cos.restype = C.c_double

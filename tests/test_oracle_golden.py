@@ -231,6 +231,32 @@ def test_go_cos_known_values():
         assert orc.lib().orc_go_cos(-float(a)) == v
 
 
+# Go's own test vectors for math.Cos: the `vf` inputs and the `cos` expectations of the Go standard library's
+# src/math/all_test.go (TestCos asserts veryclose(cos[i], Cos(vf[i])), i.e. within 4e-16 relative).  The Go toolchain is not
+# in this image and the standard library is not part of /root/reference: the two tables are the published ones.
+GO_VF = [4.9790119248836735e+00, 7.7388724745781045e+00, -2.7688005719200159e-01, -5.0106036182710749e+00, 9.6362937071984173e+00,
+         2.9263772392439646e+00, 5.2290834314593066e+00, 2.7279399104360102e+00, 1.8253080916808550e+00, -8.6859247685756013e+00]
+GO_COS = [2.634752140995199110787593e-01, 1.148551260848219865642039e-01, 9.6191297325640768154550453e-01,
+          2.938141150061714816890637e-01, -9.777138189897924126294461e-01, -9.7693041344303219127199518e-01,
+          4.940088096948647263961162e-01, -9.1565869021018925545016502e-01, -2.517729313893103197176091e-01,
+          -7.39241351595676573201918e-01]
+
+
+def test_go_cos_meets_the_go_standard_librarys_own_test_vectors():
+    """Both restatements of Go's math.Cos (the oracle's C and the host mirror's Python; the C++ one is compared with them bit
+    for bit in test_cxx_host.py) against the expectations Go's own TestCos checks, with Go's own tolerance (`veryclose`:
+    4e-16 relative) — they agree to the last bit of the published decimals."""
+    from channeld_amd.gomath import go_cos
+
+    for x, want in zip(GO_VF, GO_COS):
+        for got in (orc.lib().orc_go_cos(x), go_cos(x)):
+            assert abs(got - want) <= 4e-16 * abs(want), (x, got, want)
+            assert got == want  # (stronger than Go's own check)
+    # cos(±0) = 1, cos(±Inf) = NaN, cos(NaN) = NaN: the special cases of src/math/sin.go
+    assert go_cos(0.0) == 1.0 and go_cos(-0.0) == 1.0
+    assert math.isnan(go_cos(float("inf"))) and math.isnan(go_cos(float("-inf"))) and math.isnan(go_cos(float("nan")))
+
+
 def test_go_min_max_special_cases():
     L = orc.lib()
     inf, nan = float("inf"), float("nan")
