@@ -385,6 +385,10 @@ int chd_create(const chd_grid_cfg *cfg, int device, chd_ctx **out) {
     }
     { const char *e = getenv("CHD_NO_HOST_FAST_PATH"); ctx->force_device = e && e[0] == '1'; }
     ctx->lim.maxax = 256;
+    // (experiments: the long-lattice path's sample buffers are 6 of the 11.8 KB of LDS a query holds on config B and bound
+    // the resident queries per CU at 13; CHD_AOI_MAXAX=64 keeps queries of up to 64 samples per axis — every shape of the
+    // bench — and returns CHD_E_TOO_LARGE for longer lattices.  Not a product setting.)
+    if (const char *e = getenv("CHD_AOI_MAXAX")) ctx->lim.maxax = (uint32_t)std::min(std::max(atoi(e), 64), 256);
     ctx->lim.winmax = std::min<uint32_t>(std::max<uint32_t>(g.ncell, 64), 4096);
     ctx->lim.maxdim = std::min<uint32_t>(ctx->lim.winmax, std::max(g.cols, g.rows));
     if (aoi_lds_bytes(ctx->lim, 1) > aoi_lds_limit()) {
