@@ -41,10 +41,18 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--entities", type=int, default=100_000, help="per GPU")
-    ap.add_argument("--subs", type=int, default=10_000, help="per GPU")
+    ap.add_argument("--entities", type=int, default=None, help="per GPU (config B / B-weak: default 100000); the WORLD's for --config D / E")
+    ap.add_argument("--subs", type=int, default=None, help="per GPU (default 10000); the WORLD's for --config D / E")
     ap.add_argument("--tick-ms", type=int, default=50)
-    ap.add_argument("--aoi-scale", type=float, default=1.0)
+    ap.add_argument("--aoi-scale", type=float, default=None, help="scale of the AOI radii (default 1.0; --config E: 0.5)")
+    ap.add_argument("--config", choices=["B", "B-weak", "D", "E"], default=None,
+                    help="N > 1 only: B-weak (default) = BASELINE config B tiled, one 15x15 region per GPU (weak scaling); D = BASELINE's 4x4 "
+                         "world on its 2x2 servers (4 GPUs); E = BASELINE's 8x8 world, 1M entities / 100K subs, on its 4x2 servers (8 GPUs)")
+    ap.add_argument("--verify", type=int, default=None, metavar="K",
+                    help="N > 1: check the first K ticks (part of the warm-up) against the single-world CPU oracle on rank 0's host cores - "
+                         "sum over ranks of chd_tick_digest, per-connection digests, handover / unsub counts - and fail loudly on any "
+                         "difference; `verified_ticks` in the line.  Default 2 when N > 1")
+    ap.add_argument("--max-records", type=int, default=0, help="fan-out record capacity per rank (0 = half of the free HBM; ranks sharing a GPU need a number)")
     ap.add_argument("--latency-steps", type=int, default=200, help="extra synchronous ticks for p50/p99 (SURVEY 8d: >= 200), independent of --steps")
     ap.add_argument("--e2e-ticks", type=int, default=3,
                     help="after the timed region, also time this many ticks END TO END as a Go host would see them: (i) chd_tick with "
@@ -84,6 +92,11 @@ def parse():
     args = ap.parse_args()
     if args.only_timed:
         args.no_cpu, args.latency_steps, args.e2e_ticks = True, 0, 0
+    if args.gpus <= 1 and not os.environ.get("CHD_BENCH_FORCE_DIST"):
+        if args.config not in (None, "B"):
+            ap.error("--config D / E / B-weak are multi-GPU workloads (--gpus N)")
+        args.entities, args.subs = args.entities or 100_000, args.subs or 10_000
+        args.aoi_scale = 1.0 if args.aoi_scale is None else args.aoi_scale
     return args
 
 
@@ -143,6 +156,34 @@ def cpu_baseline(cfg, n_entities, n_subs, seed, tick_ms, aoi_scale, budget_s, si
                "sample": f"{single_thread_ticks} more tick(s) of the same world on one thread ({m1} msgs in {s1:.2f} s; update buffers {k} deep)",
                "ms_per_tick": 1e3 * s1 / single_thread_ticks}
     return out, one
+
+
+class SingleWorldChecker:
+    """bench.py --gpus N --verify K: the SINGLE world the ranks' union is compared with — the oracle (restated reference
+    algorithm, window formulation, digest mode) on rank 0's host cores.  The checker, never the thing measured."""
+
+    def setup(self, cfg, n_entities, n_subs, capq, synth_world):
+        from oracle import pyoracle as orc
+
+        self.orc = orc
+        g = orc.grid_from_config(cfg)
+        self.ow = orc.World(g, n_entities, n_subs, capq, 20, 0, literal=False)
+        self.ow.set_threads(os.cpu_count() or 1)
+        self.ow.set_digest_only(True)
+        sw = synth_world
+        self.ow.spawn(np.arange(n_entities), sw.chan_id, sw.x, sw.z, sw.flags, sw.sender)
+        for s in range(n_subs):
+            self.ow.add_sub(s, int(sw.sub_conn[s]))
+
+    def step(self, now_ns, x, z, queries):
+        ow = self.ow
+        if os.environ.get("CHD_BENCH_VERIFY_SABOTAGE"):  # (tests: prove that a difference ends the run) one entity at a wrong position
+            x = x.copy()
+            x[0] = x[0] + 9000.0 if x[0] < 0 else x[0] - 9000.0
+        ow.tick(now_ns, None, x, z, None, None, None, None, queries)
+        (cnt, sm, xr, _), conn = ow.digest()
+        return {"digest": (cnt, sm, xr), "conn": conn, "handovers": len(ow.handovers()[0]), "locked": int(ow.locked_aborts()),
+                "unsubs": len(ow.unsubs()[0])}
 
 
 def self_launch(args):
@@ -223,14 +264,15 @@ def main():
     if dist_on:
         from channeld_amd import dist as cdist
 
-        result = cdist.run_bench(args, rank, world_size, local_rank)
+        result = cdist.run_bench(args, rank, world_size, local_rank, verifier=SingleWorldChecker())
         if rank == 0:
             result["collectives"] = {"backend": str(dist.get_backend()) + (" (RCCL over xGMI)" if str(dist.get_backend()) == "nccl" else ""),
                                      "ranks": int(dist.get_world_size()), "devices_visible": int(torch.cuda.device_count())}
-            if not args.no_cpu and args.cpu_seconds > 0:  # after the timed region, rank 0's host cores (the others wait in destroy)
+            if not args.no_cpu and args.cpu_seconds > 0 and (args.config or "B-weak") in ("B", "B-weak"):
+                # after the timed region, rank 0's host cores (the others wait in destroy)
                 base = synth.load_config("spatial_static_benchmark.json")
-                result["cpu_baseline"], one = cpu_baseline(base, args.entities, args.subs, 0xC0FFEE01, args.tick_ms, args.aoi_scale,
-                                                           args.cpu_seconds, single_thread_ticks=0)
+                result["cpu_baseline"], one = cpu_baseline(base, args.entities or 100_000, args.subs or 10_000, 0xC0FFEE01, args.tick_ms,
+                                                           1.0 if args.aoi_scale is None else args.aoi_scale, args.cpu_seconds, single_thread_ticks=0)
                 result["cpu_baseline"]["sample"] = "ONE rank's share (config B): " + result["cpu_baseline"]["sample"]
             print(json.dumps(result))
         dist.barrier()

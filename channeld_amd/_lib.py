@@ -216,7 +216,7 @@ def load():
     L.chd_set_stream.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
     L.chd_shard_spawn.argtypes = [C.c_void_p, C.c_uint32, _u32p, _f64p, _f64p, _u32p, _u32p]
     L.chd_shard_ingest.argtypes = [C.c_void_p, C.c_int64, _f64p, _f64p, _u8p, C.c_uint32, C.c_uint32, C.c_uint32,
-                                   _vp, C.c_uint32]
+                                   _vp, C.c_uint32, P(C.c_uint32)]
     L.chd_shard_halo_layout.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, P(HaloSeg), P(C.c_uint64), P(C.c_uint64)]
     L.chd_shard_import.argtypes = [C.c_void_p, _vp, C.c_uint32, C.c_uint32, _vp]
     L.chd_shard_fanout.argtypes = [C.c_void_p, _vp, C.c_uint32, P(TickIn)]
@@ -224,7 +224,7 @@ def load():
     L.chd_shard_get_entities.argtypes = [C.c_void_p, _u32p, _u32p, _u32p, P(C.c_uint32)]
     L.chd_wire_set_payloads.argtypes = [C.c_void_p, C.c_int, C.c_uint32, _u32p, _u32p, _u8p]
     L.chd_wire_set_type_url.argtypes = [C.c_void_p, C.c_int, _u8p, C.c_uint32]
-    L.chd_handover_messages.argtypes = [C.c_void_p, _u32p, _u8p, C.c_uint64, P(C.c_uint64)]
+    L.chd_handover_messages.argtypes = [C.c_void_p, C.c_uint32, _u32p, _u8p, C.c_uint64, P(C.c_uint64)]
     L.chd_wire_build.argtypes = [C.c_void_p, P(C.c_uint64), P(C.c_uint64), P(C.c_uint32)]
     L.chd_wire_fetch.argtypes = [C.c_void_p, _u64p, _u32p, _u8p, C.c_uint64]
     L.chd_handover_recipients.argtypes = [C.c_void_p, _u32p, _u32p, _u8p, C.c_uint64, P(C.c_uint64)]

@@ -51,6 +51,12 @@ struct World {
     uint32_t halo_rank = 0, halo_world = 0;
     uint64_t *d_halo_send_off = nullptr, *d_halo_recv_off = nullptr;  // [world] segment offsets on the device
     uint32_t *d_ghost_off = nullptr;                                   // [world] first ghost entry of each source rank
+    // adaptive emigrant segments (chd_shard_ingest, cap_used): the global maximum segment count of tick t arrives in pinned
+    // host memory by an async copy enqueued by chd_shard_import; tick t + 2 reads it (its event completed long before)
+    uint32_t *h_mig_gmax = nullptr;    // [4] pinned, by tick & 3
+    hipEvent_t ev_mig[4] = {nullptr, nullptr, nullptr, nullptr};
+    uint32_t mig_tick[4] = {0, 0, 0, 0};  // tick whose maximum the slot holds (0 = none)
+    uint32_t mig_cap = 0;                 // capacity the last chd_shard_ingest used
     std::vector<uint32_t> group_id;    // host copy: handover group id per entity slot (0 = none), chd_world_set_entity_groups
     void *grp_buf[4] = {nullptr, nullptr, nullptr, nullptr};  // device arrays behind WorldDev::grp_*
     bool plan_recipients = false;      // CHD_WORLD_HANDOVER_RECIPIENTS
@@ -417,6 +423,8 @@ void chd_destroy(chd_ctx *ctx) {
         for (auto &e : ctx->w.ev_emit_done) (void)hipEventDestroy(e);
     }
     for (void *p : ctx->w.allocs) (void)hipFree(p);
+    if (ctx->w.h_mig_gmax) (void)hipHostFree(ctx->w.h_mig_gmax);
+    for (auto &e : ctx->w.ev_mig) if (e) (void)hipEventDestroy(e);
     for (void *b : ctx->w.grp_buf) if (b) (void)hipFree(b);
     if (ctx->w.recs_dense) (void)hipFree(ctx->w.recs_dense);
     if (ctx->w.list_dense) (void)hipFree(ctx->w.list_dense);
@@ -745,6 +753,9 @@ int chd_world_create(chd_ctx *ctx, const chd_world_cfg *cfg) {
     d.ghost_cap = 0;
     TRY(walloc(ctx, &d.free_stack, N));
     TRY(walloc(ctx, &d.free_top, 1));
+    d.limbo = nullptr;  // (chd_shard_halo_layout)
+    TRY(walloc(ctx, &d.limbo_n, 2));
+    TRY(walloc(ctx, &d.mig_gmax, 4));
     d.ce_view = d.ce;
     d.ce8_view = d.ce8;
     d.ce_chan_view = d.ce_chan;
@@ -989,6 +1000,8 @@ int chd_world_set_entity_groups(chd_ctx *ctx, uint32_t n, const uint32_t *idx, c
     const uint32_t G = (uint32_t)off.size();
     off.push_back((uint32_t)order.size());
     HIPCHK(hipStreamSynchronize(ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->aux_stream));  // (pipelined ticks: k_ingest reads the group arrays on the stage streams)
+    HIPCHK(hipStreamSynchronize(ctx->aux2_stream));
     for (void *&b : W.grp_buf) { if (b) HIPCHK(hipFree(b)); b = nullptr; }
     d.n_groups = 0;
     d.grp_of = d.grp_off = d.grp_mem = d.grp_locked = nullptr;
@@ -1034,6 +1047,7 @@ int chd_world_set_handover_lists(chd_ctx *ctx, uint32_t n_lists, const uint32_t 
     for (uint32_t i = 0; i < n; i++) of[idx[i]] = list_of[i] == CHD_NO_HANDOVER_LIST ? CHD_INVALID : list_of[i];
     HIPCHK(hipStreamSynchronize(ctx->stream));
     HIPCHK(hipStreamSynchronize(ctx->aux_stream));
+    HIPCHK(hipStreamSynchronize(ctx->aux2_stream));
     for (void *&b : W.grp_buf) { if (b) HIPCHK(hipFree(b)); b = nullptr; }
     W.group_id.clear();
     d.n_groups = 0;
@@ -1573,6 +1587,11 @@ int chd_tick(chd_ctx *ctx, const chd_tick_in *in, chd_tick_out *out) {
         HIPCHK(hipMemsetAsync(ctx->scratch[10].p, 0, 4 * ns, ctx->stream));
         din.spot_dist = (const uint32_t *)ctx->scratch[10].p;
     }
+    // The staging uploads above were enqueued on `stream`; a CHAINED pipelined tick starts its stages on the second stream
+    // after the previous tick's record kernel only — older than those uploads (with pinned host buffers they really are
+    // asynchronous).  Host-pointer ticks therefore always take the un-chained path: the stage stream waits for everything
+    // enqueued on `stream` so far.  (chd_tick_device keeps the chained fast path: its inputs must be complete at call time.)
+    ctx->chain_prev = false;
     TRY(tick_locked(ctx, &din));
     return fetch_locked(ctx, out);
 }
@@ -1673,6 +1692,11 @@ int chd_shard_halo_layout(chd_ctx *ctx, uint32_t rank, uint32_t world, chd_halo_
         TRY(walloc(ctx, &W.d_halo_send_off, world));
         TRY(walloc(ctx, &W.d_halo_recv_off, world));
         TRY(walloc(ctx, &W.d_ghost_off, world));
+        if (world > 1) {
+            TRY(walloc(ctx, &W.d.limbo, 2 * (size_t)N, false));
+            HIPCHK(hipHostMalloc((void **)&W.h_mig_gmax, 4 * sizeof(uint32_t), hipHostMallocDefault));
+            for (auto &e : W.ev_mig) HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        }
         HIPCHK(hipMemcpy(W.d_halo_send_off, soff.data(), 8 * (size_t)world, hipMemcpyHostToDevice));
         HIPCHK(hipMemcpy(W.d_halo_recv_off, roff.data(), 8 * (size_t)world, hipMemcpyHostToDevice));
         HIPCHK(hipMemcpy(W.d_ghost_off, goff.data(), 4 * (size_t)world, hipMemcpyHostToDevice));
@@ -1682,9 +1706,24 @@ int chd_shard_halo_layout(chd_ctx *ctx, uint32_t rank, uint32_t world, chd_halo_
     return CHD_OK;
 }
 
+// Segment capacity of this tick's emigrant exchange.  Every rank must use the same value (the all-to-all's sizes), so it is a
+// pure function of a quantity every rank holds identically: the global maximum segment count of tick t - 2 (carried in the
+// segment headers, k_export_finish / k_import).  Four times that maximum plus a floor, as a power of two; the caller's `cap`
+// until two exchanges have been seen.  A burst beyond it sets overflow bit 32 for the tick (the surplus stays and retries).
+static uint32_t migrate_cap_for(World &W, uint32_t cur_tick, uint32_t cap_max) {
+    if (cur_tick < 3) return cap_max;
+    const uint32_t slot = (cur_tick - 2u) & 3u;
+    if (!W.h_mig_gmax || W.mig_tick[slot] != cur_tick - 2u) return cap_max;
+    (void)hipEventSynchronize(W.ev_mig[slot]);  // (recorded two ticks ago)
+    const uint64_t want = 4ull * W.h_mig_gmax[slot] + 64ull;
+    uint64_t c = 256;
+    while (c < want) c <<= 1;
+    return (uint32_t)std::min<uint64_t>(c, cap_max);
+}
+
 int chd_shard_ingest(chd_ctx *ctx, int64_t now_ns, const double *d_x_by_chan, const double *d_z_by_chan,
                      const uint8_t *d_has_update, uint32_t n_chan, uint32_t rank, uint32_t world,
-                     chd_entity_state *d_send, uint32_t cap) {
+                     chd_entity_state *d_send, uint32_t cap, uint32_t *cap_used) {
     NEED_WORLD();
     if (n_chan && (!d_x_by_chan || !d_z_by_chan)) return fail(ctx, CHD_E_INVAL, "chd_shard_ingest: NULL positions");
     if (!world || rank >= world) return fail(ctx, CHD_E_INVAL, "chd_shard_ingest: rank %u of %u", rank, world);
@@ -1697,10 +1736,14 @@ int chd_shard_ingest(chd_ctx *ctx, int64_t now_ns, const double *d_x_by_chan, co
     ctx->w.slot_mode = 2;
     TRY(bind(ctx));
     TRY(tick_begin(ctx, now_ns));
+    World &W = ctx->w;
+    const uint32_t use = (cap_used && world > 1) ? migrate_cap_for(W, ctx->ring.cur_tick, cap) : cap;
+    if (cap_used) *cap_used = use;
+    W.mig_cap = use;
     const uint32_t eid0 = ctx->cfg.entity_channel_id_start ? ctx->cfg.entity_channel_id_start : 0x80000u;
     launch_ingest_by_channel(ctx->stream, ctx->g, ctx->w.d, d_x_by_chan, d_z_by_chan, d_has_update, n_chan, eid0,
                              ctx->ring.cur_tick);
-    if (world > 1) launch_export(ctx->stream, ctx->g, ctx->w.d, rank, world, d_send, cap, ctx->ring.cur_tick);
+    if (world > 1) launch_export(ctx->stream, ctx->g, ctx->w.d, rank, world, d_send, use, ctx->ring.cur_tick);
     TRY(after_launch(ctx));
     return CHD_OK;
 }
@@ -1719,7 +1762,15 @@ int chd_shard_import(chd_ctx *ctx, const chd_entity_state *d_recv, uint32_t worl
     d.ce_view = d.ce; d.ce8_view = d.ce8; d.ce_chan_view = d.ce_chan; d.ce_sprev_view = d.ce_sprev; d.ce_sprev_stride = 0;
     d.cell_start = d.cell_off;
     d.cell_end = d.cell_off + 1;
-    if (world > 1) launch_import(st, d, d_recv, world, cap, ctx->ring.cur_tick);
+    if (world > 1) {
+        if (cap != W.mig_cap) return fail(ctx, CHD_E_INVAL, "chd_shard_import: cap %u, but this tick's chd_shard_ingest used %u", cap, W.mig_cap);
+        if (!d.limbo) return fail(ctx, CHD_E_STATE, "chd_shard_import: chd_shard_halo_layout has not installed this rank's layout");
+        launch_import(st, d, d_recv, world, cap, ctx->ring.cur_tick);
+        const uint32_t slot = ctx->ring.cur_tick & 3u;
+        HIPCHK(hipMemcpyAsync(W.h_mig_gmax + slot, d.mig_gmax + slot, sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+        HIPCHK(hipEventRecord(W.ev_mig[slot], st));
+        W.mig_tick[slot] = ctx->ring.cur_tick;
+    }
     launch_index_build(st, ctx->g, d, ctx->ring.cur_tick);
     if (world > 1) launch_halo_pack(st, ctx->g, d, W.halo_rank, world, ctx->g.border, (unsigned char *)d_halo_send, W.d_halo_send_off);
     TRY(after_launch(ctx));
@@ -1875,13 +1926,13 @@ int chd_wire_set_type_url(chd_ctx *ctx, int which, const uint8_t *url, uint32_t 
     return CHD_OK;
 }
 
-int chd_handover_messages(chd_ctx *ctx, uint32_t *offsets, uint8_t *bytes, uint64_t cap, uint64_t *n_out) {
+int chd_handover_messages(chd_ctx *ctx, uint32_t n_handovers, uint32_t *offsets, uint8_t *bytes, uint64_t cap, uint64_t *n_out) {
     NEED_WORLD();
     if (!offsets || !n_out || (cap && !bytes)) return fail(ctx, CHD_E_INVAL, "chd_handover_messages: NULL buffer");
     World &W = ctx->w;
+    std::lock_guard<std::mutex> lk(ctx->mu);
     if (!W.wire) return fail(ctx, CHD_E_STATE, "the world was created without CHD_WORLD_WIRE");
     if (!W.ticked) return fail(ctx, CHD_E_STATE, "no tick yet");
-    std::lock_guard<std::mutex> lk(ctx->mu);
     TRY(bind(ctx));
     uint64_t ringrow[8];
     TRY(down(ctx, ringrow, W.d.tick_ring + (size_t)(ctx->ring.cur_tick % TICK_RING) * 8, sizeof ringrow));
@@ -1889,6 +1940,8 @@ int chd_handover_messages(chd_ctx *ctx, uint32_t *offsets, uint8_t *bytes, uint6
     const uint32_t nh = std::min<uint32_t>((uint32_t)ringrow[2], W.d.handovers_cap);
     offsets[0] = 0;
     *n_out = 0;
+    if (nh > n_handovers)
+        return fail(ctx, CHD_E_CAPACITY, "chd_handover_messages: the last tick had %u handovers, offsets has room for %u", nh, n_handovers);
     if (!nh) return CHD_OK;
     TRY(ensure(ctx, 0, sizeof(uint32_t) * (2 * (size_t)nh + 1)));
     launch_handover_msg_sizes(ctx->stream, ctx->g, W.d, W.x, nh, sbuf<uint32_t>(ctx, 0));

@@ -51,9 +51,10 @@ enum {
 #define OVF_RECORDS 4u
 #define OVF_NEWSUB 8u
 #define OVF_INTERNAL 0x8000u  // a kernel's defensive loop bound tripped (a bug, never a capacity)
-#define OVF_SLOTS 16u    // sharded world: no free entity slot for a spawn / an immigrant
+#define OVF_SLOTS 16u    // sharded world: no free entity slot for a spawn / an immigrant (the immigrant waits in limbo, k_shard.hip)
 #define OVF_MIGRATE 32u  // sharded world: an emigrant did not fit its destination's send segment
 #define OVF_HALO 64u     // sharded world: a border band did not fit its halo segment, or a subscription reaches a cell beyond the halo
+#define OVF_LOST 128u    // sharded world: more immigrants waiting for a slot than the limbo list holds (max_entities): an entity was dropped
 
 struct DevGrid {
     double gw, gh, offx, offz;

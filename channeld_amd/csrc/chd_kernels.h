@@ -78,6 +78,9 @@ struct WorldDev {
     // slot allocator of region-sharded worlds (entities migrate between ranks)
     uint32_t *free_stack; // [N]
     int32_t *free_top;    // number of free slots
+    chd_entity_state *limbo;  // [2][N] immigrants that found no free slot, by tick parity (allocated with the halo layout)
+    uint32_t *limbo_n;        // [2]
+    uint32_t *mig_gmax;       // [4] by tick & 3: the largest emigrant segment count of that tick's exchange, over ALL ranks
     // subscribers
     uint32_t *conn_id;    // [S]
     uint32_t *sub_alive;  // [S]

@@ -132,6 +132,8 @@ __global__ void __launch_bounds__(256) k_export(DevGrid g, WorldDev w, uint32_t 
                                                 chd_entity_state *__restrict__ send, uint32_t cap,
                                                 uint32_t cur_tick) {
     const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    // (the limbo list this tick's import appends to starts empty: see k_import)
+    if (i == 0) w.limbo_n[(cur_tick + 1u) & 1u] = 0;
     if (i >= w.N) return;
     const uint32_t ef = w.eflags[i];
     if (!(ef & EF_ALIVE)) return;
@@ -165,25 +167,26 @@ __global__ void __launch_bounds__(256) k_export(DevGrid g, WorldDev w, uint32_t 
     w.free_stack[f] = i;
 }
 
+// Every header also carries the LARGEST count this rank put into any of its segments (field `cell` of record 0): after the
+// all-to-all every rank holds every source's maximum, i.e. the same global maximum — what the adaptive segment capacity of
+// the following ticks is derived from (chd_shard_ingest, cap_used), identically on every rank and without a collective.
+__global__ void __launch_bounds__(64) k_export_finish(chd_entity_state *__restrict__ send, uint32_t world, uint32_t cap) {
+    uint32_t m = 0;
+    for (uint32_t d = threadIdx.x; d < world; d += 64) m = max(m, min(send[(size_t)d * (cap + 1)].chan_id, cap));
+    for (int d = 32; d >= 1; d >>= 1) m = max(m, (uint32_t)__shfl_xor((int)m, d));
+    for (uint32_t d = threadIdx.x; d < world; d += 64) send[(size_t)d * (cap + 1)].cell = m;
+}
+
 void launch_export(hipStream_t st, DevGrid g, WorldDev w, uint32_t rank, uint32_t world,
                    chd_entity_state *send, uint32_t cap, uint32_t cur_tick) {
     // zero the segment headers (32 bytes at a pitch of (cap+1) records)
     (void)hipMemset2DAsync(send, sizeof(chd_entity_state) * ((size_t)cap + 1), 0, sizeof(chd_entity_state), world, st);
     if (!w.N) return;
     hipLaunchKernelGGL(k_export, dim3(nblocks(w.N, 256)), dim3(256), 0, st, g, w, rank, world, send, cap, cur_tick);
+    hipLaunchKernelGGL(k_export_finish, dim3(1), dim3(64), 0, st, send, world, cap);
 }
 
-__global__ void __launch_bounds__(256) k_import(WorldDev w, const chd_entity_state *__restrict__ recv,
-                                                uint32_t world, uint32_t cap, uint32_t cur_tick) {
-    const uint32_t src = blockIdx.y;
-    const uint32_t k = blockIdx.x * 256u + threadIdx.x;
-    if (src >= world) return;
-    const chd_entity_state *seg = recv + (size_t)src * (cap + 1);
-    const uint32_t n = min(seg[0].chan_id, cap);
-    if (k >= n) return;
-    const chd_entity_state e = seg[1 + k];
-    const uint32_t i = pop_slot(w);
-    if (i == CHD_INVALID) return;
+__device__ __forceinline__ void install_entity(const WorldDev &w, uint32_t i, const chd_entity_state &e, uint32_t cur_tick) {
     w.chan_id[i] = e.chan_id;
     w.cell[i] = e.cell;
     w.member[i] = e.member;
@@ -195,10 +198,54 @@ __global__ void __launch_bounds__(256) k_import(WorldDev w, const chd_entity_sta
     w.sender_prev[i] = e.sender_prev;
 }
 
+// An immigrant that finds no free slot is not lost: it waits in LIMBO (a side list of states, two buffers by tick parity)
+// and is offered a slot again at every later import, before the tick's own immigrants.  While it waits it is in no cell
+// table (visible to nobody) and its history does not advance: pop_slot has set overflow bit 16 for this tick, and does so
+// again every tick the entity is still waiting — the host sees a capacity error, never a silently shrinking world.
+__device__ __forceinline__ void to_limbo(const WorldDev &w, const chd_entity_state &e, uint32_t cur_tick) {
+    const uint32_t nb = (cur_tick + 1u) & 1u;
+    const uint32_t k = atomicAdd(&w.limbo_n[nb], 1u);
+    if (k < w.N) w.limbo[(size_t)nb * w.N + k] = e;
+    else { atomicSub(&w.limbo_n[nb], 1u); atomicOr(&w.counters[CTR_OVERFLOW], OVF_LOST); }
+}
+
+// blockIdx.y < world: the segment rank y sent; blockIdx.y == world: the entities waiting in limbo since earlier ticks.
+// Also folds the global maximum segment count of this tick's exchange (k_export_finish) into mig_gmax[cur_tick & 3].
+__global__ void __launch_bounds__(256) k_import(WorldDev w, const chd_entity_state *__restrict__ recv,
+                                                uint32_t world, uint32_t cap, uint32_t cur_tick) {
+    const uint32_t src = blockIdx.y;
+    const uint32_t k = blockIdx.x * 256u + threadIdx.x;
+    if (src == world) {
+        const uint32_t cb = cur_tick & 1u;
+        const uint32_t n = min(w.limbo_n[cb], w.N);
+        for (uint32_t q = k; q < n; q += gridDim.x * 256u) {
+            chd_entity_state e = w.limbo[(size_t)cb * w.N + q];
+            // (the histories were aligned to the tick of the export and have aged one tick per tick in limbo)
+            e.hist <<= 1; e.hist_prev <<= 1;
+            const uint32_t i = pop_slot(w);
+            if (i == CHD_INVALID) to_limbo(w, e, cur_tick);
+            else install_entity(w, i, e, cur_tick);
+        }
+        if (k == 0) {
+            uint32_t m = 0;
+            for (uint32_t s = 0; s < world; s++) m = max(m, recv[(size_t)s * (cap + 1)].cell);
+            w.mig_gmax[cur_tick & 3u] = m;
+        }
+        return;
+    }
+    const chd_entity_state *seg = recv + (size_t)src * (cap + 1);
+    const uint32_t n = min(seg[0].chan_id, cap);
+    if (k >= n) return;
+    const chd_entity_state e = seg[1 + k];
+    const uint32_t i = pop_slot(w);
+    if (i == CHD_INVALID) { to_limbo(w, e, cur_tick); return; }
+    install_entity(w, i, e, cur_tick);
+}
+
 void launch_import(hipStream_t st, WorldDev w, const chd_entity_state *recv, uint32_t world, uint32_t cap,
                    uint32_t cur_tick) {
     if (!world || !cap) return;
-    hipLaunchKernelGGL(k_import, dim3(nblocks(cap, 256), world), dim3(256), 0, st, w, recv, world, cap, cur_tick);
+    hipLaunchKernelGGL(k_import, dim3(nblocks(cap, 256), world + 1), dim3(256), 0, st, w, recv, world, cap, cur_tick);
 }
 
 // ---------------------------------------------------------------------------
@@ -296,10 +343,22 @@ __global__ void __launch_bounds__(256) k_halo_unpack(DevGrid g, WorldDev w, uint
     const uint32_t *cnt = (const uint32_t *)(seg + 16 + 16ull * nc + 16ull * cap);
     const uint32_t *sprev = (const uint32_t *)((const unsigned char *)cnt + ((4ull * nc + 15ull) & ~15ull));
     const uint32_t base = w.N + ghost_off[s];  // ghosts of rank s: ce[base, base + cap)
-    const bool bad = hdr[2] != 0 || hdr[1] != nc || hdr[0] > cap;
-    if (bad && threadIdx.x == 0) atomicOr(&w.counters[CTR_OVERFLOW], OVF_HALO);
+    // a segment is only taken when it is consistent: the sender's flag, the cell count of the rectangle, and per-cell counts
+    // that add up to the entry count it announces, inside the capacity both sides derive from the SAME max_entities
+    __shared__ uint32_t total_s, bad_s;
+    if (threadIdx.x == 0) {
+        uint32_t b = (hdr[2] != 0 || hdr[1] != nc || hdr[0] > cap) ? 1u : 0u;
+        if (!b) {
+            uint64_t sum = 0;
+            for (uint32_t k = 0; k < nc; k++) sum += cnt[k];
+            if (sum != hdr[0]) b = 1u;
+        }
+        bad_s = b;
+        if (b) atomicOr(&w.counters[CTR_OVERFLOW], OVF_HALO);
+    }
+    __syncthreads();
+    const bool bad = bad_s != 0;
     // cell views: exclusive prefix of the counts (serial: a band has a few hundred cells)
-    __shared__ uint32_t total_s;
     if (threadIdx.x == 0) {
         uint32_t acc = 0;
         for (uint32_t k = 0; k < nc; k++) {

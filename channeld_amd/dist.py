@@ -103,17 +103,28 @@ class Comm:
         self.backend = dist.get_backend() if (world > 1 or self.force) else "none"
         # gloo has no all_to_all and wants host memory: stage through the CPU
         self.staged = (self.backend != "nccl") if staged is None else staged
+        self.active = world > 1 or self.force
+        self._recv = {}  # receive buffers by (kind, numel): allocated once, reused every tick (stream-ordered)
+
+    def _buf(self, kind, like, numel):
+        import torch
+
+        key = (kind, int(numel), like.dtype)
+        b = self._recv.get(key)
+        if b is None:
+            b = self._recv[key] = torch.empty(int(numel), dtype=like.dtype, device=like.device)
+        return b
 
     def all_to_all(self, send):
         """send[dst] -> recv[src]; equal-sized segments."""
         import torch
 
-        if self.world == 1 and not self.force:
+        if not self.active:
             return send
         if not self.staged:
-            recv = torch.empty_like(send)
-            self.dist.all_to_all_single(recv.view(-1), send.view(-1))
-            return recv
+            recv = self._buf("a2a", send, send.numel())
+            self.dist.all_to_all_single(recv, send.reshape(-1))
+            return recv.view(send.shape)
         host = send.detach().cpu().contiguous()
         allbuf = [torch.empty_like(host) for _ in range(self.world)]
         self.dist.all_gather(allbuf, host)
@@ -122,22 +133,21 @@ class Comm:
 
     def halo_exchange(self, send, send_splits, recv_splits, send_offs_of_peers=None, overlap=None):
         """send: flat uint8 tensor = the segments for every destination back to back (send_splits bytes each); returns the
-        flat receive buffer (recv_splits).  The split sizes are static (a function of the grid config), zero for ranks
-        further apart than the halo.  `overlap()` (optional) is work for the compute stream that does not depend on the
-        result.  Host-staged backends need `send_offs_of_peers[src]` = offset of the segment for THIS rank in rank src's
-        send buffer."""
+        flat receive buffer (recv_splits).  The split sizes are static (a function of the grid config; lists of python ints),
+        zero for ranks further apart than the halo.  `overlap()` (optional) is work for the compute stream that does not
+        depend on the result.  Host-staged backends need `send_offs_of_peers[src]` = offset of the segment for THIS rank in
+        rank src's send buffer."""
         import torch
 
-        n_send, n_recv = int(sum(send_splits)), int(sum(recv_splits))
-        if (self.world == 1 and not self.force) or (n_send == 0 and n_recv == 0):  # (nothing to exchange)
+        n_send, n_recv = sum(send_splits), sum(recv_splits)
+        if not self.active or (n_send == 0 and n_recv == 0):  # (nothing to exchange)
             if overlap:
                 overlap()
             return send
         send = send.view(-1)[:n_send]
         if not self.staged:
-            recv = torch.empty(n_recv, dtype=send.dtype, device=send.device)
-            work = self.dist.all_to_all_single(recv, send, output_split_sizes=[int(v) for v in recv_splits],
-                                               input_split_sizes=[int(v) for v in send_splits], async_op=True)
+            recv = self._buf("halo", send, n_recv)
+            work = self.dist.all_to_all_single(recv, send, output_split_sizes=recv_splits, input_split_sizes=send_splits, async_op=True)
             if overlap:
                 overlap()
             work.wait()  # the compute stream waits for the collective (no host synchronisation)
@@ -162,23 +172,24 @@ class Comm:
             at += n
         return recv.to(send.device)
 
+    def _dev(self):
+        return "cuda" if self.backend == "nccl" else "cpu"
+
     def sum_int(self, v: int) -> int:
         import torch
 
-        if self.world == 1 and not self.force:
+        if not self.active:
             return int(v)
-        dev = "cuda" if self.backend == "nccl" else "cpu"
-        t = torch.tensor([int(v)], dtype=torch.int64, device=dev)
+        t = torch.tensor([int(v)], dtype=torch.int64, device=self._dev())
         self.dist.all_reduce(t)
         return int(t.item())
 
     def max_float(self, v: float) -> float:
         import torch
 
-        if self.world == 1 and not self.force:
+        if not self.active:
             return float(v)
-        dev = "cuda" if self.backend == "nccl" else "cpu"
-        t = torch.tensor([float(v)], dtype=torch.float64, device=dev)
+        t = torch.tensor([float(v)], dtype=torch.float64, device=self._dev())
         self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
         return float(t.item())
 
@@ -186,16 +197,34 @@ class Comm:
         """every rank's vector of floats, on every rank: [world][len(v)]"""
         import torch
 
-        if self.world == 1 and not self.force:
+        if not self.active:
             return [list(map(float, v))]
-        dev = "cuda" if self.backend == "nccl" else "cpu"
-        t = torch.tensor(list(map(float, v)), dtype=torch.float64, device=dev)
+        t = torch.tensor(list(map(float, v)), dtype=torch.float64, device=self._dev())
         parts = [torch.empty_like(t) for _ in range(self.world)]
         self.dist.all_gather(parts, t)
         return [p.cpu().tolist() for p in parts]
 
+    def gather_u64(self, arr: np.ndarray, pad_to: int) -> list:
+        """every rank's uint64 vector (any length <= pad_to), on every rank"""
+        import torch
+
+        a = np.ascontiguousarray(arr, dtype=np.uint64)
+        if not self.active:
+            return [a]
+        buf = np.zeros(pad_to + 1, dtype=np.uint64)
+        buf[0] = len(a)
+        buf[1: 1 + len(a)] = a
+        t = torch.from_numpy(buf.view(np.int64)).to(self._dev())
+        parts = [torch.empty_like(t) for _ in range(self.world)]
+        self.dist.all_gather(parts, t)
+        out = []
+        for p in parts:
+            h = p.cpu().numpy().view(np.uint64)
+            out.append(h[1: 1 + int(h[0])].copy())
+        return out
+
     def barrier(self):
-        if self.world > 1 or self.force:
+        if self.active:
             self.dist.barrier()
 
 
@@ -205,7 +234,8 @@ class Comm:
 
 class HipShardEngine:
     def __init__(self, cfg: dict, rank: int, world: int, max_entities: int, max_subscribers: int,
-                 migrate_cap: int = 4096, device: int = 0, max_records: int = 0, use_torch_stream: bool = True):
+                 migrate_cap: int = 4096, device: int = 0, max_records: int = 0, use_torch_stream: bool = True,
+                 adaptive_migrate: bool = False, flags: int = 0):
         import torch
 
         from . import _lib
@@ -220,11 +250,12 @@ class HipShardEngine:
         err = self.ctl.LoadConfig(json.dumps(cfg).encode(), strict=False)
         if err is not None:
             raise err
-        self.sw = SpatialWorld(self.ctl, max_entities, max_subscribers, max_records=max_records)
+        self.sw = SpatialWorld(self.ctl, max_entities, max_subscribers, max_records=max_records, flags=flags)
         self.lib, self.ctx = self.sw.lib, self.sw.ctx
         if use_torch_stream:
             _lib.check(self.ctx, self.lib.chd_set_stream(self.ctx, C.c_void_p(torch.cuda.current_stream(self.dev).cuda_stream), 1))
-        self.send = torch.zeros((world, (self.cap + 1) * ENTITY_STATE_WORDS), dtype=torch.int32, device=self.dev)
+        self.seg_words = (self.cap + 1) * ENTITY_STATE_WORDS
+        self.send = torch.zeros(world * self.seg_words, dtype=torch.int32, device=self.dev)
         # the halo layout of this rank (installs it in the library) and, for host-staged exchanges, where every other
         # rank keeps its segment for this one
         segs, st, rt = self._layout(rank)
@@ -232,7 +263,17 @@ class HipShardEngine:
         self.recv_splits = [int(g.recv_bytes) for g in segs]
         self.peer_send_off = [int(self._layout(p)[0][rank].send_off) if p != rank else 0 for p in range(world)] if world > 1 else [0]
         self.halo_send = torch.zeros(max(st, 16), dtype=torch.uint8, device=self.dev)
+        self._splits = (self.send_splits, self.recv_splits, self.peer_send_off)
         self._keep = None
+        # per-tick call arguments, built once (the per-tick host work is four C calls and two collectives)
+        self._p_send = C.c_void_p(self.send.data_ptr())
+        self._p_halo_send = C.c_void_p(self.halo_send.data_ptr())
+        self._cap_used = C.c_uint32(self.cap)
+        self._p_cap_used = C.byref(self._cap_used) if adaptive_migrate else None
+        self._ti_interest, self._ti_fanout = _lib.TickIn(), _lib.TickIn()
+        self._r_interest, self._r_fanout = C.byref(self._ti_interest), C.byref(self._ti_fanout)
+        self.cap_now = self.cap  # capacity this tick's exchange uses
+        self.cap_seen = []       # (adaptive) every capacity used so far
 
     def _layout(self, rank):
         segs = (self._lib.HaloSeg * self.world)()
@@ -241,7 +282,7 @@ class HipShardEngine:
         return segs, int(st.value), int(rt.value)
 
     def halo_splits(self):
-        return self.send_splits, self.recv_splits, self.peer_send_off
+        return self._splits
 
     def spawn(self, chan_id, x, z, flags, sender):
         from .controller import _f64, _ptr, _u32
@@ -253,32 +294,45 @@ class HipShardEngine:
         self.sw.add_subscribers(None, conn_ids)
 
     def ingest(self, now_ns: int, x_by_chan, z_by_chan, has_update=None):
-        """x_by_chan / z_by_chan: float64 device tensors indexed by channel id - EntityChannelIdStart."""
+        """x_by_chan / z_by_chan: float64 device tensors indexed by channel id - EntityChannelIdStart.  Returns the send
+        buffer of the emigrant exchange, [world, (capacity of this tick + 1) * 8] int32."""
         hp = C.c_void_p(has_update.data_ptr()) if has_update is not None else None
-        self._lib.check(self.ctx, self.lib.chd_shard_ingest(
-            self.ctx, int(now_ns), C.c_void_p(x_by_chan.data_ptr()), C.c_void_p(z_by_chan.data_ptr()), hp,
-            int(x_by_chan.numel()), self.rank, self.world, C.c_void_p(self.send.data_ptr()), self.cap))
-        return self.send
+        rc = self.lib.chd_shard_ingest(self.ctx, int(now_ns), C.c_void_p(x_by_chan.data_ptr()), C.c_void_p(z_by_chan.data_ptr()), hp,
+                                       int(x_by_chan.numel()), self.rank, self.world, self._p_send, self.cap, self._p_cap_used)
+        if rc:
+            self._lib.check(self.ctx, rc)
+        cu = self._cap_used.value
+        if cu != self.cap_now:
+            self.cap_now = cu
+            self.cap_seen.append(cu)
+        return self.send[: self.world * (cu + 1) * ENTITY_STATE_WORDS].view(self.world, -1)
 
     def import_(self, recv):
         rp = C.c_void_p(recv.data_ptr()) if recv is not None else None
         self._keep = recv
-        self._lib.check(self.ctx, self.lib.chd_shard_import(self.ctx, rp, self.world, self.cap, C.c_void_p(self.halo_send.data_ptr())))
+        rc = self.lib.chd_shard_import(self.ctx, rp, self.world, self.cap_now, self._p_halo_send)
+        if rc:
+            self._lib.check(self.ctx, rc)
         return self.halo_send
 
     def interest(self, queries=None, n_queries: int = 0):
         """queries: uint8 device tensor of n_queries packed chd_aoi_query records for slots 0..n_queries-1."""
-        ti = self._lib.TickIn()
+        ti = self._ti_interest
         if queries is not None and n_queries:
-            ti.n_queries, ti.queries = int(n_queries), C.c_void_p(queries.data_ptr())
+            ti.n_queries, ti.queries = int(n_queries), queries.data_ptr()
+        else:
+            ti.n_queries, ti.queries = 0, None
         self._queries = queries
-        self._lib.check(self.ctx, self.lib.chd_shard_interest(self.ctx, C.byref(ti)))
+        rc = self.lib.chd_shard_interest(self.ctx, self._r_interest)
+        if rc:
+            self._lib.check(self.ctx, rc)
         self.sw._last_nq = int(n_queries)
 
     def fanout(self, halo_recv):
-        ti = self._lib.TickIn()
         self._halo_recv = halo_recv
-        self._lib.check(self.ctx, self.lib.chd_shard_fanout(self.ctx, C.c_void_p(halo_recv.data_ptr()), self.world, C.byref(ti)))
+        rc = self.lib.chd_shard_fanout(self.ctx, C.c_void_p(halo_recv.data_ptr()), self.world, self._r_fanout)
+        if rc:
+            self._lib.check(self.ctx, rc)
 
     def fetch(self, want_records=False, records_cap=0):
         return self.sw.fetch(want_records=want_records, records_cap=records_cap)
@@ -304,33 +358,130 @@ class ShardedWorld:
         self.engine, self.comm = engine, comm
 
     def tick(self, now_ns: int, x_by_chan, z_by_chan, queries=None, n_queries: int = 0, has_update=None):
-        send = self.engine.ingest(now_ns, x_by_chan, z_by_chan, has_update)
-        recv = self.comm.all_to_all(send) if (self.comm.world > 1 or self.comm.force) else None
-        halo_send = self.engine.import_(recv)
-        send_splits, recv_splits, peer_off = self.engine.halo_splits()
+        eng, comm = self.engine, self.comm
+        send = eng.ingest(now_ns, x_by_chan, z_by_chan, has_update)
+        recv = comm.all_to_all(send) if comm.active else None
+        halo_send = eng.import_(recv)
+        send_splits, recv_splits, peer_off = eng.halo_splits()
         # the interest updates do not read the neighbours' tables: they run under the halo exchange
-        halo_recv = self.comm.halo_exchange(halo_send, send_splits, recv_splits, peer_off,
-                                            overlap=lambda: self.engine.interest(queries, n_queries))
-        self.engine.fanout(halo_recv)
+        halo_recv = comm.halo_exchange(halo_send, send_splits, recv_splits, peer_off,
+                                       overlap=lambda: eng.interest(queries, n_queries))
+        eng.fanout(halo_recv)
 
 
 # ---------------------------------------------------------------------------
-# bench.py --gpus N  (N > 1): weak scaling, config B per GPU
+# bench.py --gpus N  (N > 1)
 # ---------------------------------------------------------------------------
 
-def run_bench(args, rank: int, world: int, local_rank: int) -> dict:
+BENCH_SEED = 0xC0FFEE01
+
+
+def bench_world(args, world: int):
+    """The multi-GPU workload `--config` names: (grid config, entities, subscribers, per-rank slot counts, AOI scale, label).
+
+    B-weak  weak scaling of BASELINE config B: one 15x15 region of spatial_static_benchmark.json per rank (100K entities /
+            10K subscribers PER GPU), halo 7 cells.
+    D       BASELINE config 4: spatial_static_4x4.json on its 2x2 servers = 4 GPUs; --entities / --subs are the WORLD's
+            (default 100K / 10K, the metric's population).
+    E       BASELINE config 5: spatial_static_8x8.json (8x8 cells, 4x2 servers) = 8 GPUs, 1M entities / 100K subscribers.
+            At the bench's AOI radii (sphere 3 cells) every connection would see ~45 % of the world — 45 G records for
+            the first (full-state) fan-out alone — so E runs at --aoi-scale 0.5 unless told otherwise (said in the line)."""
+    from . import synth
+
+    name = getattr(args, "config", None) or "B-weak"
+    aoi = args.aoi_scale
+    if name in ("B", "B-weak"):
+        base = synth.load_config("spatial_static_benchmark.json")
+        cfg = weak_scaled_config(base, world)
+        ent, subs = (args.entities or 100_000), (args.subs or 10_000)
+        sc, sr = server_layout(world)
+        N, S = ent * world, subs * world
+        aoi = 1.0 if aoi is None else aoi
+        label = (f"spatial_static_benchmark.json tiled {sc}x{sr}: {N} entities / {S} subs, {world}xMI355X ({ent} / {subs} per GPU)")
+        return cfg, N, S, int(1.3 * ent) + 1024, int(1.3 * subs) + 256, aoi, label, "weak"
+    files = {"D": ("spatial_static_4x4.json", 100_000, 10_000), "E": ("spatial_static_8x8.json", 1_000_000, 100_000)}
+    if name not in files:
+        raise SystemExit(f"bench.py --config {name}: expected B-weak, D or E")
+    fn, n_def, s_def = files[name]
+    cfg = dict(synth.load_config(fn))
+    need = int(cfg["ServerCols"]) * int(cfg["ServerRows"])
+    if need != world:
+        raise SystemExit(f"bench.py --config {name}: {fn} has {cfg['ServerCols']}x{cfg['ServerRows']} server regions = {need} GPUs, launched with {world}")
+    N, S = (args.entities or n_def), (args.subs or s_def)
+    note = ""
+    if aoi is None:
+        aoi = 0.5 if name == "E" else 1.0
+        if name == "E":
+            note = " (AOI radii x0.5: at x1.0 the first full-state fan-out alone is ~45 G records)"
+    # the halo must cover the longest AOI reach (cones: 5 cells x scale) plus the drift of pinned connections
+    cfg["ServerInterestBorderSize"] = max(int(cfg.get("ServerInterestBorderSize", 1)), int(np.ceil(5.0 * aoi)) + 2)
+    label = f"{fn}, {N} entities / {S} subs, {cfg['ServerCols']}x{cfg['ServerRows']} server regions on {world}xMI355X{note}"
+    # regions of a few cells: entities cluster per region far less evenly than on the 15x15 tiles
+    return cfg, N, S, int(1.5 * N / world) + 4096, int(1.5 * S / world) + 256, aoi, label, "strong"
+
+
+def verify_tick(comm: Comm, eng: "HipShardEngine", my_subs, s_cap: int, step, tick_index: int):
+    """One tick of bench.py --verify: the ranks' fan-out digests (chd_tick_digest is additive over disjoint record sets:
+    count and sum add, xor xors), handover / locked-abort / unsub counts and every connection's own digest against a
+    SINGLE-world reference that rank 0 advances on its host cores: `step()` (rank 0 only; bench.py supplies it) ticks that
+    world and returns {"digest": (count, sum, xor), "conn": per-global-slot sums, "handovers", "locked", "unsubs"}.
+    Every rank learns the verdict; a difference ends the run."""
+    (cnt, sm, xr, _), conn_sum = eng.sw.digest(per_connection=True)
+    res = eng.fetch()
+    local = np.array([cnt, sm, xr, len(res.handovers), res.n_locked_aborts, len(res.unsub_sub), len(res.newsub_sub),
+                      res.overflow, res.history_overflow], dtype=np.uint64)
+    tot = comm.gather_u64(local, 16)
+    sums = comm.gather_u64(conn_sum[: len(my_subs)], s_cap)
+    subs = comm.gather_u64(np.asarray(my_subs, dtype=np.uint64), s_cap)
+    msg = ""
+    if comm.rank == 0:
+        ref = step()
+        (ocnt, osum, oxor), oconn = ref["digest"], ref["conn"]
+        M = np.uint64(0xFFFFFFFFFFFFFFFF)
+        g = np.stack(tot)
+        with np.errstate(over="ignore"):
+            got = (int(g[:, 0].sum()), int(g[:, 1].sum() & M), int(np.bitwise_xor.reduce(g[:, 2])))
+        want = (ocnt, osum, oxor)
+        if any(int(v) for v in g[:, 7]) or any(int(v) for v in g[:, 8]):
+            msg = f"tick {tick_index}: overflow flags {[int(v) for v in g[:, 7]]}, history overflow {[int(v) for v in g[:, 8]]}"
+        elif got != want:
+            msg = f"tick {tick_index}: records digest (count, sum, xor) over all ranks {got} != the single world's {want}"
+        else:
+            for r in range(comm.world):
+                bad = np.nonzero(sums[r] != oconn[subs[r].astype(np.int64)])[0]
+                if len(bad):
+                    msg = f"tick {tick_index}: rank {r}: {len(bad)} connections' record digests differ from the single world's (first: global slot {int(subs[r][bad[0]])})"
+                    break
+        if not msg:
+            checks = (("handovers", int(g[:, 3].sum()), int(ref["handovers"])), ("locked aborts", int(g[:, 4].sum()), int(ref["locked"])),
+                      ("unsubs", int(g[:, 5].sum()), int(ref["unsubs"])))
+            for what, a, b in checks:
+                if a != b:
+                    msg = f"tick {tick_index}: {what}: {a} over all ranks != {b} in the single world"
+                    break
+    flag = comm.gather_u64(np.array([1 if msg else 0], dtype=np.uint64), 1)
+    if int(flag[0][0]):
+        raise SystemExit("bench.py --verify FAILED: " + (msg or "(see rank 0)"))
+    return int(np.stack(tot)[:, 0].sum()) if comm.rank == 0 else 0
+
+
+def run_bench(args, rank: int, world: int, local_rank: int, verifier=None) -> dict:
+    """verifier (bench.py --verify; rank 0 uses it, the others pass None or ignore it): setup(cfg, N, S, capq, synth_world)
+    builds the single-world reference, step(now_ns, x, z, queries) ticks it and returns what verify_tick compares."""
     import torch
 
     from . import synth
 
     comm = Comm(rank, world)
     dev = torch.device("cuda", local_rank)
-    base = synth.load_config("spatial_static_benchmark.json")
-    cfg = weak_scaled_config(base, world)
-    N, S = args.entities * world, args.subs * world
+    cfg, N, S, n_max, s_max, aoi_scale, label, scaling = bench_world(args, world)
     K, W = args.steps, args.warmup
-    seed = 0xC0FFEE01
-    sw = synth.SynthWorld(synth.WorldSpec(cfg, N, S, seed, tick_ms=args.tick_ms, aoi_scale=args.aoi_scale))
+    V = max(int(args.verify), 0) if args.verify is not None else (2 if comm.active else 0)
+    if V and verifier is None:
+        raise SystemExit("run_bench: --verify needs a verifier (bench.py supplies the single-world checker)")
+    W = max(W, V)  # the verified ticks are the world's first ticks: part of the (untimed) warm-up
+    seed = BENCH_SEED
+    sw = synth.SynthWorld(synth.WorldSpec(cfg, N, S, seed, tick_ms=args.tick_ms, aoi_scale=aoi_scale))
     cols = int(cfg["GridCols"])
     gx = np.floor((sw.x - sw.offx) / sw.gw)
     gy = np.floor((sw.z - sw.offz) / sw.gh)
@@ -339,12 +490,19 @@ def run_bench(args, rank: int, world: int, local_rank: int) -> dict:
     owner = np.where(inside, server_of_cell(cfg, cell0), 0)      # out-of-world entities live on rank 0
     mine = np.nonzero(owner == rank)[0]
     my_subs = np.nonzero(owner[:S] == rank)[0]                    # connection j follows entity j
-    n_max = int(1.3 * args.entities) + 1024
-    s_max = int(1.3 * args.subs) + 256
-    eng = HipShardEngine(cfg, rank, world, n_max, s_max, migrate_cap=max(4096, args.entities // 8), device=local_rank)
+    if len(mine) > n_max or len(my_subs) > s_max:
+        raise SystemExit(f"rank {rank}: {len(mine)} entities / {len(my_subs)} connections exceed the per-rank slots {n_max} / {s_max}")
+    eng = HipShardEngine(cfg, rank, world, n_max, s_max, migrate_cap=max(4096, n_max // 8), device=local_rank,
+                         max_records=int(getattr(args, "max_records", 0) or 0), adaptive_migrate=True)
     eng.spawn(sw.chan_id[mine], sw.x[mine], sw.z[mine], sw.flags[mine], sw.sender[mine])
     eng.add_subscribers(sw.sub_conn[my_subs])
     world_obj = ShardedWorld(eng, comm)
+
+    # the single world the first V ticks are checked against lives on rank 0's host cores (the checker, never the thing
+    # measured); it is fed the same synthetic frames
+    checking = bool(V) and rank == 0
+    if checking:
+        verifier.setup(cfg, N, S, eng.sw.capq, sw)
 
     L = min(max(getattr(args, "latency_steps", 0), 0), 100)
     T = W + K + L
@@ -352,22 +510,37 @@ def run_bench(args, rank: int, world: int, local_rank: int) -> dict:
     zs = np.empty((T, N), dtype=np.float64)
     qs = np.empty((T, len(my_subs)), dtype=synth.AOI_DTYPE)
     now = np.empty(T, dtype=np.int64)
+    q_full = []
     for t in range(T):
         sw.step()
         xs[t], zs[t], now[t] = sw.x, sw.z, sw.now_ns()
-        qs[t] = sw.queries()[my_subs]
+        q = sw.queries()
+        qs[t] = q[my_subs]
+        if checking and t < V:
+            q_full.append(q.copy())
     d_x = torch.from_numpy(xs).to(dev)
     d_z = torch.from_numpy(zs).to(dev)
     d_q = torch.from_numpy(qs.view(np.uint8).reshape(T, -1)).to(dev)
-    del xs, zs
+    xv, zv, qv = list(d_x.unbind(0)), list(d_z.unbind(0)), list(d_q.unbind(0))  # (per-tick views made once, not per tick)
     nq = len(my_subs)
+    now_l = [int(v) for v in now]
 
     def tick(t):
-        world_obj.tick(int(now[t]), d_x[t], d_z[t], d_q[t], nq)
+        world_obj.tick(now_l[t], xv[t], zv[t], qv[t], nq)
+
+    # ---- the first V ticks, each checked against the single-world oracle ----
+    verified_msgs = []
+    t_verify = time.perf_counter()
+    for t in range(V):
+        tick(t)
+        verified_msgs.append(verify_tick(comm, eng, my_subs, s_max,
+                                         (lambda t=t: verifier.step(now_l[t], xs[t], zs[t], q_full[t])) if checking else None, t))
+    t_verify = time.perf_counter() - t_verify
+    del xs, zs, q_full
 
     eng.sw.set_profiling(min(1024, max(K, L, 1)))
     eng.sw.set_profiling_scope(True)  # timed region: only the pair around the dominant kernel; stage breakdown from the latency phase
-    for t in range(W):
+    for t in range(V, W):
         tick(t)
     comm.barrier()
     torch.cuda.synchronize()
@@ -383,7 +556,8 @@ def run_bench(args, rank: int, world: int, local_rank: int) -> dict:
     if len(hist) < K:
         msgs_local = int(round(msgs_local * K / len(hist)))
     res = eng.fetch()
-    assert res.overflow == 0 and res.history_overflow == 0, (res.overflow, res.history_overflow)
+    if res.overflow or res.history_overflow:
+        raise SystemExit(f"rank {rank}: overflow 0x{res.overflow:x}, history overflow {res.history_overflow} in the timed region")
     msgs = comm.sum_int(msgs_local)
     handovers = comm.sum_int(sum(h["n_handovers"] for h in hist))
     emit_us = np.array([h["emit_main_us"] for h in hist])
@@ -402,25 +576,33 @@ def run_bench(args, rank: int, world: int, local_rank: int) -> dict:
     if L:
         stage_avg = np.mean(np.array([h["stage_us"] for h in eng.sw.history(min(L, 1024))]), axis=0)
     per_rank = comm.gather_floats([achieved / 8000.0, float(emit_us.mean()), float(emit_msgs.mean()), float(np.percentile(lat, 50)),
-                                   float(np.percentile(lat, 99)), float(stage_avg.sum()), float(len(mine)), float(len(my_subs))])
-    sc, sr = server_layout(world)
+                                   float(np.percentile(lat, 99)), float(stage_avg.sum()), float(len(mine)), float(len(my_subs)),
+                                   float(eng.cap_now)])
+    sc, sr = int(cfg["ServerCols"]), int(cfg["ServerRows"])
+    dominant = "k_fanout_emit_ws (cell-major)" if n_max // (int(cfg["GridCols"]) * int(cfg["GridRows"])) >= 1024 else "k_fanout_emit_seg"
     return {
         "metric": "AOI-filtered fanout msgs/sec + p99 tick latency, 100K entities / 10K subs",
         "value": msgs / elapsed, "unit": "msgs/s", "n_gpus": world, "steps": K, "warmup": W,
-        "ms_per_step": 1e3 * elapsed / K, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "ms_per_step": 1e3 * elapsed / K, "higher_is_better": True, "scaling": scaling, "vs_baseline": None,
         "dtype": "f64", "data": "synthetic",
-        "config": {"workload": f"spatial_static_benchmark.json tiled {sc}x{sr}: {N} entities / {S} subs, {world}xMI355X "
-                               f"({args.entities} / {args.subs} per GPU)",
+        "verified_ticks": V,
+        "verified": ({"ticks": V, "against": "the single-world CPU restatement of the reference on rank 0's host cores, same synthetic frames",
+                      "compared": "sum over ranks of chd_tick_digest (count, sum, xor of mix64(conn, channel) over every fan-out record), every connection's own "
+                                  "digest, handover / locked-abort / unsub counts, overflow flags == 0",
+                      "msgs_per_verified_tick": verified_msgs, "seconds": round(t_verify, 2)} if V else None),
+        "config": {"workload": label, "config": getattr(args, "config", None) or "B-weak", "aoi_scale": aoi_scale,
                    "grid": f"{cfg['GridCols']}x{cfg['GridRows']} cells of {int(cfg['GridWidth'])}, {sc}x{sr} server regions",
                    "tick_ms": args.tick_ms, "msgs_per_tick": msgs / K, "cross_rank_and_local_handovers_per_tick": handovers / K,
-                   "exchange": "all-to-all of emigrant states (32 B each) + all-to-all(v) of the border bands of the cell tables "
+                   "exchange": "all-to-all of emigrant states (32 B each; segment capacity adapted to 4x the largest count of two ticks ago: "
+                               f"{eng.cap_now} records per peer now, {eng.cap} at start) + all-to-all(v) of the border bands of the cell tables "
                                f"({cfg['ServerInterestBorderSize']} cells wide: {sum(eng.send_splits)} bytes sent per rank and tick) per tick",
                    "message": "one fanOutDataUpdate decision (conn, channel); payload bytes excluded"},
         "p50_tick_ms": max(r[3] for r in per_rank), "p99_tick_ms": max(r[4] for r in per_rank), "latency_ticks": int(L),
         "stage_us_avg": {n: float(v) for n, v in zip(("ingest", "index", "interest", "plan", "emit"), stage_avg)},
         "per_rank": [{"rank": i, "roofline_frac": r[0], "emit_kernel_us": r[1], "msgs_per_launch": r[2], "p50_tick_ms": r[3],
-                      "p99_tick_ms": r[4], "gpu_stage_sum_us": r[5], "entities": int(r[6]), "subs": int(r[7])} for i, r in enumerate(per_rank)],
-        "roofline": {"bound": "hbm", "kernel": "k_fanout_emit_seg", "achieved": achieved, "peak": 8000.0, "unit": "GB/s",
+                      "p99_tick_ms": r[4], "gpu_stage_sum_us": r[5], "entities": int(r[6]), "subs": int(r[7]), "migrate_cap": int(r[8])}
+                     for i, r in enumerate(per_rank)],
+        "roofline": {"bound": "hbm", "kernel": dominant, "achieved": achieved, "peak": 8000.0, "unit": "GB/s",
                      "frac": achieved / 8000.0, "traffic": None, "traffic_quoted": False, "bytes_per_msg": 12, "rank": 0,
                      "msgs_per_launch": float(emit_msgs.mean()), "avg_launch_us": float(emit_us.mean())},
     }

@@ -350,7 +350,7 @@ class SpatialWorld:
         off = np.zeros(2 * n_handovers + 1, dtype=np.uint32)
         data = np.zeros(max(cap, 1), dtype=np.uint8)
         n = C.c_uint64(0)
-        _lib.check(self.ctx, self.lib.chd_handover_messages(self.ctx, _ptr(off), _ptr(data), cap, C.byref(n)))
+        _lib.check(self.ctx, self.lib.chd_handover_messages(self.ctx, int(n_handovers), _ptr(off), _ptr(data), cap, C.byref(n)))
         b = data[: n.value].tobytes()
         return [(b[int(off[2 * h]):int(off[2 * h + 1])], b[int(off[2 * h + 1]):int(off[2 * h + 2])]) for h in range(n_handovers)]
 

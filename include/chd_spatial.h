@@ -36,7 +36,7 @@
 extern "C" {
 #endif
 
-#define CHD_ABI_VERSION 6
+#define CHD_ABI_VERSION 7
 
 typedef struct chd_ctx chd_ctx;
 
@@ -347,9 +347,10 @@ typedef struct {
     uint32_t *conn_rec_cnt;            /* max_subscribers */
     uint32_t overflow;                 /* !=0: chd_tick_fetch returns CHD_E_CAPACITY.  Bits: 1 handover list, 2 unsub list,
                                           4 record buffer, 8 new-sub list truncated (grow the *_cap / max_records);
-                                          region-sharded worlds: 16 no free entity slot for a spawn or an immigrant (the
-                                          entity is LOST: the world is no longer consistent - size max_entities with
-                                          headroom for clustering), 32 an emigrant did not fit its destination's send
+                                          region-sharded worlds: 16 no free entity slot for an immigrant (it waits, in no
+                                          cell table, and takes the first slot that frees up: results are incomplete while
+                                          the bit is set - size max_entities with headroom for clustering; 128: more than
+                                          max_entities of them waiting, one was dropped), 32 an emigrant did not fit its destination's send
                                           segment (it stays with the wrong owner and is retried next tick), 64 a border
                                           band outgrew its halo segment or a subscription reaches beyond the halo;
                                           0x8000 an internal loop bound tripped (a bug, never a capacity) */
@@ -405,7 +406,9 @@ int chd_world_get_entities(chd_ctx *ctx, uint32_t n, const uint32_t *idx,
 /* Region-sharded worlds: one ctx per GPU, rank r owns the cells whose  */
 /* ServerIndex (GetRegions, spatial.go:336-351) is r - the partition    */
 /* CreateChannels gives spatial server r (spatial.go:399-424).  Every   */
-/* rank is created with the SAME global grid config.  Two exchange      */
+/* rank is created with the SAME global grid config and the SAME       */
+/* max_entities (the halo segment capacities are derived from it on     */
+/* both sides of every exchange).  Two exchange                         */
 /* steps per tick, both all-to-all, both for border traffic only        */
 /* (DESIGN.md section 7):                                               */
 /*   chd_shard_ingest -> all-to-all(emigrants: cross-server handovers)  */
@@ -450,10 +453,17 @@ int chd_shard_spawn(chd_ctx *ctx, uint32_t n, const uint32_t *chan_id, const dou
  * d_send = world segments of (cap + 1) records: record 0 of segment `dst` is a header whose
  * chan_id field holds the number of emigrants k, followed by the k states.  Equal-sized
  * segments: one all-to-all moves them.  If a destination's `cap` is exceeded the surplus
- * stays and retries next tick (overflow flag). */
+ * stays and retries next tick (overflow flag).
+ * cap_used (optional): a few hundred entities cross a region border per tick while `cap` is sized for the worst burst, and
+ * an all-to-all of full segments moves (cap + 1) x 32 B per peer whatever they hold.  With cap_used != NULL the library
+ * picks this tick's segment capacity itself — the caller's `cap` for the first ticks, then four times the largest segment
+ * count any rank saw two ticks ago (every header carries its sender's maximum, so every rank derives the SAME value and the
+ * all-to-all sizes agree without a collective), a power of two in [256, cap] — lays the segments out at a pitch of
+ * (*cap_used + 1) records and returns it: exchange world x (*cap_used + 1) records and pass *cap_used to chd_shard_import.
+ * Record 0's other fields are reserved (the library uses `cell`). */
 int chd_shard_ingest(chd_ctx *ctx, int64_t now_ns, const double *d_x_by_chan,
                      const double *d_z_by_chan, const uint8_t *d_has_update, uint32_t n_chan,
-                     uint32_t rank, uint32_t world, chd_entity_state *d_send, uint32_t cap);
+                     uint32_t rank, uint32_t world, chd_entity_state *d_send, uint32_t cap, uint32_t *cap_used);
 
 /* The halo exchange.  Rank s sends rank d the cell tables of the cells of ITS region that lie within
  * ServerInterestBorderSize cells of d's region (the grid config's own parameter for "how much of a neighbour a spatial
@@ -472,8 +482,10 @@ int chd_shard_halo_layout(chd_ctx *ctx, uint32_t rank, uint32_t world, chd_halo_
                           uint64_t *send_total, uint64_t *recv_total);
 
 /* Phase 2, after the all-to-all of emigrants: the states in d_recv (same layout as d_send, segment `src` = what rank src
- * sent here) join this rank; the local cell index is rebuilt and the border bands are packed into d_halo_send
- * (chd_shard_halo_layout; may be NULL when world == 1). */
+ * sent here; cap = the capacity chd_shard_ingest used this tick) join this rank; the local cell index is rebuilt and the
+ * border bands are packed into d_halo_send (chd_shard_halo_layout; may be NULL when world == 1).
+ * An immigrant that finds no free slot is NOT lost: it waits in a side list and takes the first slot that frees up at a
+ * later import; every tick it waits (in no cell table, visible to nobody) sets overflow bit 16. */
 int chd_shard_import(chd_ctx *ctx, const chd_entity_state *d_recv, uint32_t world,
                      uint32_t cap, void *d_halo_send);
 
@@ -583,9 +595,15 @@ int chd_wire_set_type_url(chd_ctx *ctx, int which /* 0 entity data, 1 spatial ch
  * host queues the same bytes for each of them.  The entities of a handover = the notifying entity, or all live
  * members of its handover group / handover list (chd_world_set_entity_groups, chd_world_set_handover_lists), each as one map
  * entry {netId = its entity channel id}.
- * Needs CHD_WORLD_WIRE | CHD_WORLD_HANDOVER_RECIPIENTS, the CHD_WIRE_ENTITY_OBJREF / CHD_WIRE_ENTITY_FULL payloads
- * and the type url.  offsets has 2 * n_handovers + 1 entries. */
-int chd_handover_messages(chd_ctx *ctx, uint32_t *offsets, uint8_t *bytes, uint64_t cap, uint64_t *n_out);
+ * Exactness: the reference decides `fullData` per (dst connection, ENTITY) (spatial.go:797-857: shouldSend of that entity
+ * channel's SubscribeToChannel); the two blobs are exact for single-entity handovers — every handover without groups —
+ * and for group handovers whose dst connections know all members or none.  A dst connection already subscribed to SOME
+ * members of a group gets a mixed message in the reference, which these two blobs cannot express: such a host assembles
+ * that message itself from the per-entity payloads it handed to chd_wire_set_payloads.
+ * Needs CHD_WORLD_WIRE, the CHD_WIRE_ENTITY_OBJREF / CHD_WIRE_ENTITY_FULL payloads and the type url (and
+ * CHD_WORLD_HANDOVER_RECIPIENTS for chd_handover_recipients, which says who gets which blob).  n_handovers = what the
+ * caller sized `offsets` for: 2 * n_handovers + 1 entries; CHD_E_CAPACITY when the last tick had more handovers. */
+int chd_handover_messages(chd_ctx *ctx, uint32_t n_handovers, uint32_t *offsets, uint8_t *bytes, uint64_t cap, uint64_t *n_out);
 
 /* replaces, for every connection at once: queuedMessagePackSender.Send (connection.go:57-83:
  * MessagePack{ChannelId, MsgType: CHANNEL_DATA_UPDATE, MsgBody: ChannelDataUpdateMessage{Data}},

@@ -528,7 +528,7 @@ class SpatialWorld {
         offsets.assign(2 * (size_t)nHandovers + 1, 0);
         bytes.assign(std::max<uint64_t>(cap, 1), 0);
         uint64_t n = 0;
-        const int rc = chd_handover_messages(ctl_.ctx(), offsets.data(), bytes.data(), cap, &n);
+        const int rc = chd_handover_messages(ctl_.ctx(), nHandovers, offsets.data(), bytes.data(), cap, &n);
         bytes.resize(rc == CHD_OK ? n : 0);
         return err(rc);
     }

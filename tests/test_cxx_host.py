@@ -97,8 +97,6 @@ def test_load_config_fails_loudly_without_a_device(exe):
 
 
 @pytest.mark.gpu
-@pytest.mark.xfail(strict=False, reason="written after the round's GPU budget was spent: its first run on hardware is the driver's; "
-                                        "non-gating until it has passed once (every value is ALSO checked through the Python mirror in the other GPU tests)")
 def test_gpu_cxx_mirror_equals_the_python_mirror(exe):
     import json
 
