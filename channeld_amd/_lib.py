@@ -91,7 +91,7 @@ class WorldCfg(C.Structure):
     _fields_ = [
         ("max_entities", C.c_uint32), ("max_subscribers", C.c_uint32), ("max_interest_cells", C.c_uint32),
         ("max_records", C.c_uint64), ("max_handovers", C.c_uint32), ("flags", C.c_uint32),
-        ("wire_max_update_len", C.c_uint32), ("wire_max_full_len", C.c_uint32),
+        ("wire_max_update_len", C.c_uint32), ("wire_max_full_len", C.c_uint32), ("history_depth", C.c_uint32),
     ]
 
 
@@ -114,6 +114,8 @@ class TickIn(C.Structure):
         ("n_cell_updates", C.c_uint32), ("cell_upd_channel", _u32p), ("cell_upd_sender", _u32p),
         ("n_queries", C.c_uint32), ("query_sub", _u32p), ("queries", _vp),
         ("spot_x", _f64p), ("spot_z", _f64p), ("spot_dist", _u32p), ("n_spots_total", C.c_uint32),
+        ("upd_arrival_ns", _i64p), ("cell_upd_arrival_ns", _i64p),
+        ("n_update_rounds", C.c_uint32), ("upd_round_off", _u32p),
     ]
 
 

@@ -16,6 +16,7 @@
 #define CHD_NOT_A_SENDER 0xFFFFFFFEu  // (emit, per connection) ... but this connection is none of them: no per-sender test needed
 #define CHD_WAVE 64
 #define CHD_HIST_BITS 32
+#define CHD_MAX_UPDATE_BUFFER 512u  // MaxUpdateMsgBufferSize, data.go:53-55
 
 // pair flags (per subscriber x spatial channel subscription state,
 // subscription.go:13-31 + data.go:39-44)
@@ -25,6 +26,8 @@
 #define PF_NEW 8u        // subscribed during the current tick
 #define PF_WRITE 16u     // options.DataAccess == WRITE_ACCESS (READ_ACCESS when neither this nor PF_NO_ACCESS is set)
 #define PF_DEFER 32u     // (inside one tick) due, left by the pipelined emit kernel to the deferred launch
+#define PF_DEEP 64u      // (inside one tick) due, but the tick-ring masks cannot answer its windows: served from the exact
+                         // update buffers by k_fanout_emit_deep (history_depth > 0), which clears the bit
 
 // entity flags
 #define EF_LOCKED 1u

@@ -49,6 +49,19 @@ struct WorldDev {
     uint32_t grp_exact;
     // spatial (cell) channels' own update history
     uint32_t *cell_hist, *cell_hist_tick, *cell_sender, *cell_hist_prev, *cell_sender_prev;
+    // Exact update buffers (chd_world_cfg.history_depth = deep_depth > 0): ChannelData.updateMsgBuffer element for element,
+    // a ring of {arrivalTime, senderConnId} per entity channel (deep_*) and per spatial channel (cdeep_*): n = updates ever
+    // pushed (write index n % D), len = elements held (the newest), drop = arrival of the newest element the ring had to
+    // overwrite although the reference would still hold it (INT64_MIN: none).  irr_tick = 1 + the last tick at which the
+    // channel took an update the tick-ring masks cannot represent (an arrival stamp off the tick's own, a third sender);
+    // cell_irr[c] = this tick some channel of cell c is like that inside the 32-tick mask horizon: its subscriptions go to
+    // k_fanout_emit_deep.  max_iv = maxFanOutIntervalMs (only grows; the eviction test of data.go:165-171).
+    uint32_t deep_depth;
+    int64_t *deep_a, *cdeep_a, *deep_drop, *cdeep_drop;
+    uint32_t *deep_s, *cdeep_s, *deep_n, *cdeep_n, *deep_len, *cdeep_len, *irr_tick, *cell_irr_tick;
+    uint32_t *cell_irr;
+    uint32_t *max_iv;
+    uint32_t *conn_deep;  // [S] this tick: the connection has PF_DEEP subscriptions
     // cell index (rebuilt every tick)
     uint32_t nblk;        // histogram blocks
     uint32_t *blk_cnt;    // [ncell*nblk + 1] counts -> exclusive scan (cell-major)
@@ -140,11 +153,30 @@ struct WorldDev {
 // the subscriber for SkipSelfUpdateFanOut, data.go:242-245): bits are kept per sender
 // for the current and the previous sender of the channel; a third sender inside the
 // 32-tick window folds the oldest bits into the previous one (counted, never silent).
-__device__ __forceinline__ void push_update(const WorldDev &w, uint32_t i, uint32_t snd, uint32_t cur_tick) {
+// One element into an exact update buffer (data.go:159-172): ring[(n % D)] = {arrival, sender}; beyond
+// MaxUpdateMsgBufferSize elements the oldest goes if it is older than maxFanOutIntervalMs, one per push, as the reference
+// does; a ring that is full of elements the reference would still hold overwrites its oldest and remembers that arrival
+// (a window that reaches it is reported as history_overflow, never silently short).
+__device__ __forceinline__ void deep_push(int64_t *__restrict__ A, uint32_t *__restrict__ S, uint32_t D, uint32_t &n, uint32_t &len,
+                                          int64_t &drop, int64_t arrival, uint32_t sender, uint32_t max_iv_ms) {
+    if (len == D) {  // no room: the oldest element leaves whatever its age
+        drop = A[(n - len) % D];
+        len--;
+    }
+    A[n % D] = arrival;
+    S[n % D] = sender;
+    n++;
+    len++;
+    if (len > CHD_MAX_UPDATE_BUFFER && A[(n - len) % D] + (int64_t)max_iv_ms * 1000000 < arrival) len--;
+}
+
+__device__ __forceinline__ void push_update(const WorldDev &w, uint32_t i, uint32_t snd, uint32_t cur_tick,
+                                            int64_t arrival = 0, int64_t now = 0) {
     const uint32_t age = cur_tick - w.hist_tick[i];
     uint32_t h = (age >= CHD_HIST_BITS) ? 0u : (w.hist[i] << age);
     uint32_t hp = (age >= CHD_HIST_BITS) ? 0u : (w.hist_prev[i] << age);
     const uint32_t cur = w.sender[i];
+    bool irregular = arrival != now;  // (the masks stand for "arrived with the tick's own stamp")
     if (snd != cur) {
         const uint32_t prev = w.sender_prev[i];
         if (snd == prev) {  // the previous sender is back: the two histories swap roles
@@ -154,7 +186,10 @@ __device__ __forceinline__ void push_update(const WorldDev &w, uint32_t i, uint3
             w.sender_prev[i] = cur;
         } else {
             if (h != 0) {
-                if (hp != 0 && prev != cur) atomicAdd(&w.counters[CTR_SENDER_OVERFLOW], 1u);
+                if (hp != 0 && prev != cur) {  // a third sender inside the mask horizon
+                    if (w.deep_depth) irregular = true;
+                    else atomicAdd(&w.counters[CTR_SENDER_OVERFLOW], 1u);
+                }
                 hp |= h;
                 w.sender_prev[i] = cur;
             }
@@ -165,6 +200,16 @@ __device__ __forceinline__ void push_update(const WorldDev &w, uint32_t i, uint3
     w.hist[i] = h | 1u;
     w.hist_prev[i] = hp;
     w.hist_tick[i] = cur_tick;
+    if (w.deep_depth) {
+        uint32_t n = w.deep_n[i], len = w.deep_len[i];
+        int64_t drop = w.deep_drop[i];
+        const size_t at = (size_t)i * w.deep_depth;
+        deep_push(w.deep_a + at, w.deep_s + at, w.deep_depth, n, len, drop, arrival, snd, *w.max_iv);
+        w.deep_n[i] = n;
+        w.deep_len[i] = len;
+        w.deep_drop[i] = drop;
+        if (irregular) w.irr_tick[i] = cur_tick + 1u;
+    }
 }
 
 // Is connection slot s subscribed to cell c?  Interest bitmap where it exists, else a binary search of
@@ -221,9 +266,11 @@ void launch_subs_get_options(hipStream_t st, WorldDev w, uint32_t s, uint8_t *ac
 void launch_group_locks(hipStream_t st, WorldDev w);
 // K1: cell assign + handover detect (+ update history)
 void launch_ingest(hipStream_t st, DevGrid g, WorldDev w, uint32_t n, const uint32_t *idx,
-                   const double *x, const double *z, const uint32_t *sender, uint32_t cur_tick);
+                   const double *x, const double *z, const uint32_t *sender, uint32_t cur_tick,
+                   const int64_t *arrival = nullptr, int64_t now_ns = 0);
 void launch_cell_updates(hipStream_t st, DevGrid g, WorldDev w, uint32_t n,
-                         const uint32_t *chan, const uint32_t *sender, uint32_t cur_tick);
+                         const uint32_t *chan, const uint32_t *sender, uint32_t cur_tick,
+                         const int64_t *arrival = nullptr, int64_t now_ns = 0);
 // pull-mode ingest of region-sharded worlds: every live slot reads its position by entity channel id
 void launch_ingest_by_channel(hipStream_t st, DevGrid g, WorldDev w, const double *x_by_chan,
                               const double *z_by_chan, const uint8_t *has_update, uint32_t n_chan,
@@ -318,5 +365,7 @@ void launch_fanout_plan(hipStream_t st, DevGrid g, WorldDev w, int64_t now_ns, T
 bool fanout_seg_path(const WorldDev &w);
 void launch_fanout_emit_main(hipStream_t st, DevGrid g, WorldDev w, int64_t now_ns, TickRing ring);
 void launch_fanout_emit_deferred(hipStream_t st, DevGrid g, WorldDev w, int64_t now_ns, TickRing ring);
+// subscriptions the tick-ring masks cannot answer (PF_DEEP), from the exact update buffers; no-op without history_depth
+void launch_fanout_emit_deep(hipStream_t st, DevGrid g, WorldDev w, int64_t now_ns, TickRing ring);
 #define TICK_RING 1024
 void launch_tick_epilogue(hipStream_t st, WorldDev w, uint32_t slot);

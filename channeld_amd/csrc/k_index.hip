@@ -17,6 +17,8 @@
 //
 // Also here: the generic exclusive scans (single workgroup, 1024 lanes,
 // wave-shuffle scan + LDS carry).
+#include <algorithm>
+
 #include "chd_kernels.h"
 
 #define IDX_BLOCK 256
@@ -55,6 +57,12 @@ __global__ void __launch_bounds__(IDX_BLOCK) k_index_hist(WorldDev w, uint32_t n
                 const uint32_t hp = age < CHD_HIST_BITS ? (w.hist_prev[i] << age) : 0u;
                 const uint32_t hc = age < CHD_HIST_BITS ? (w.hist[i] << age) : 0u;
                 atomicAnd(&hand[m], hc | hp);
+                // exact update buffers: an update the masks cannot represent, still inside their horizon (rare: a plain
+                // global atomic; cell_irr is cleared by the tick epilogue)
+                if (w.deep_depth) {
+                    const uint32_t it = w.irr_tick[i];
+                    if (it && cur_tick + 1u - it < CHD_HIST_BITS) atomicOr(&w.cell_irr[m], 1u);
+                }
                 if (hp != 0) {
                     const uint32_t sp = w.sender_prev[i];
                     atomicMin(&smin[m], sp);
@@ -64,6 +72,12 @@ __global__ void __launch_bounds__(IDX_BLOCK) k_index_hist(WorldDev w, uint32_t n
         }
     }
     __syncthreads();
+    if (w.deep_depth && blockIdx.x == 0) {  // ... and the spatial channels' own updates
+        for (uint32_t c = threadIdx.x; c < ncell; c += IDX_BLOCK) {
+            const uint32_t it = w.cell_irr_tick[c];
+            if (it && cur_tick + 1u - it < CHD_HIST_BITS) atomicOr(&w.cell_irr[c], 1u);
+        }
+    }
     for (uint32_t c = threadIdx.x; c < ncell; c += IDX_BLOCK) {
         const size_t k = (size_t)c * w.nblk + blockIdx.x;
         w.blk_cnt[k] = h[c];
@@ -239,12 +253,22 @@ __global__ void __launch_bounds__(IDX_BLOCK) k_index_scatter(WorldDev w, uint32_
 
 // fallback for grids too large for the LDS counters: global atomics, the order
 // inside a cell is then not deterministic (documented in DESIGN.md).
-__global__ void __launch_bounds__(256) k_index_hist_global(WorldDev w, uint32_t ncell) {
+__global__ void __launch_bounds__(256) k_index_hist_global(WorldDev w, uint32_t ncell, uint32_t cur_tick) {
     uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    if (w.deep_depth && i < ncell) {
+        const uint32_t it = w.cell_irr_tick[i];
+        if (it && cur_tick + 1u - it < CHD_HIST_BITS) atomicOr(&w.cell_irr[i], 1u);
+    }
     if (i >= w.N) return;
     if (!(w.eflags[i] & EF_ALIVE)) return;
     uint32_t m = w.member[i];
-    if (m < ncell) atomicAdd(&w.blk_cnt[m], 1u);
+    if (m < ncell) {
+        atomicAdd(&w.blk_cnt[m], 1u);
+        if (w.deep_depth) {
+            const uint32_t it = w.irr_tick[i];
+            if (it && cur_tick + 1u - it < CHD_HIST_BITS) atomicOr(&w.cell_irr[m], 1u);
+        }
+    }
 }
 
 __global__ void __launch_bounds__(256) k_index_scatter_global(WorldDev w, uint32_t ncell, uint32_t *cursor,
@@ -260,6 +284,7 @@ __global__ void __launch_bounds__(256) k_index_scatter_global(WorldDev w, uint32
     uint32_t hp = (age >= CHD_HIST_BITS) ? 0u : (w.hist_prev[i] << age);
     w.ce[pos] = make_uint4(w.chan_id[i], h, w.sender[i], hp);
     w.ce_sprev[pos] = w.sender_prev[i];
+    w.ce_chan[pos] = w.chan_id[i];
     if (w.ce_slot) w.ce_slot[pos] = i;
 }
 
@@ -353,7 +378,7 @@ void launch_index_build(hipStream_t st, DevGrid g, WorldDev w, uint32_t cur_tick
         (void)hipMemsetAsync(w.cell_smin, 0, sizeof(uint32_t) * (size_t)g.ncell, st);      // sender range unknown: everything
         (void)hipMemsetAsync(w.cell_smax, 0xFF, sizeof(uint32_t) * (size_t)g.ncell, st);
         (void)hipMemsetAsync(w.cell_hand, 0, sizeof(uint32_t) * (size_t)g.ncell, st);
-        hipLaunchKernelGGL(k_index_hist_global, dim3((w.N + 255) / 256), dim3(256), 0, st, w, g.ncell);
+        hipLaunchKernelGGL(k_index_hist_global, dim3((std::max(w.N, g.ncell) + 255) / 256), dim3(256), 0, st, w, g.ncell, cur_tick);
         launch_scan_u32_inplace(st, w.blk_cnt, g.ncell);
         (void)hipMemcpyAsync(w.cell_off, w.blk_cnt, sizeof(uint32_t) * ((size_t)g.ncell + 1), hipMemcpyDeviceToDevice, st);
         hipLaunchKernelGGL(k_index_scatter_global, dim3((w.N + 255) / 256), dim3(256), 0, st, w, g.ncell, cursor,

@@ -182,6 +182,12 @@ __global__ void __launch_bounds__(256) k_spawn(DevGrid g, WorldDev w, uint32_t n
     w.hist_tick[i] = cur_tick;
     w.sender_prev[i] = 0;
     w.hist_prev[i] = 0;
+    if (w.deep_depth) {  // a new channel's update buffer starts empty
+        w.deep_n[i] = 0;
+        w.deep_len[i] = 0;
+        w.deep_drop[i] = INT64_MIN;
+        w.irr_tick[i] = 0;
+    }
 }
 
 void launch_spawn(hipStream_t st, DevGrid g, WorldDev w, uint32_t n, const uint32_t *idx,
@@ -395,7 +401,7 @@ __global__ void __launch_bounds__(256) k_ingest(DevGrid g, WorldDev w, uint32_t 
                                                 const double *__restrict__ x,
                                                 const double *__restrict__ z,
                                                 const uint32_t *__restrict__ sender,
-                                                uint32_t cur_tick) {
+                                                uint32_t cur_tick, const int64_t *__restrict__ arrival, int64_t now) {
     // handover records are compacted per wave (ballot + mbcnt) and per workgroup
     // (LDS), so the global counter sees ONE atomic per 1024 updates: same-address
     // atomics serialise at ~12 ns each and would otherwise dominate this kernel.
@@ -417,7 +423,7 @@ __global__ void __launch_bounds__(256) k_ingest(DevGrid g, WorldDev w, uint32_t 
                 dst[j] = cell_of(g, x[u], z[u]);
                 src[j] = w.cell[i];
                 w.cell[i] = dst[j];
-                push_update(w, i, sender ? sender[u] : w.sender[i], cur_tick);
+                push_update(w, i, sender ? sender[u] : w.sender[i], cur_tick, arrival ? arrival[u] : now, now);
                 if (src[j] != CHD_INVALID && dst[j] != CHD_INVALID && src[j] != dst[j]) {
                     // GetHandoverEntities (entity.go:197-224): a locked member of the notifier's handover group
                     // empties the list and the handover does not happen (spatial.go:675-679)
@@ -489,10 +495,11 @@ __global__ void __launch_bounds__(256) k_ingest(DevGrid g, WorldDev w, uint32_t 
 }
 
 void launch_ingest(hipStream_t st, DevGrid g, WorldDev w, uint32_t n, const uint32_t *idx,
-                   const double *x, const double *z, const uint32_t *sender, uint32_t cur_tick) {
+                   const double *x, const double *z, const uint32_t *sender, uint32_t cur_tick,
+                   const int64_t *arrival, int64_t now_ns) {
     if (!n) return;
     hipLaunchKernelGGL(k_ingest, dim3(nblocks(n, 256 * ING_ITEMS)), dim3(256), 0, st, g, w, n, idx, x, z,
-                       sender, cur_tick);
+                       sender, cur_tick, arrival, now_ns);
 }
 
 // spatial-channel data updates (spawn/destroy merges through OnUpdate).  One thread per
@@ -501,11 +508,14 @@ void launch_ingest(hipStream_t st, DevGrid g, WorldDev w, uint32_t n, const uint
 __global__ void __launch_bounds__(256) k_cell_updates(DevGrid g, WorldDev w, uint32_t n,
                                                       const uint32_t *__restrict__ chan,
                                                       const uint32_t *__restrict__ sender,
-                                                      uint32_t cur_tick) {
+                                                      uint32_t cur_tick, const int64_t *__restrict__ arrival, int64_t now) {
     const uint32_t c = blockIdx.x * 256u + threadIdx.x;
     if (c >= g.ncell) return;
-    bool touched = false;
+    bool touched = false, irregular = false;
     uint32_t h = 0, hp = 0, cur = 0, prev = 0;
+    uint32_t dn = 0, dlen = 0;
+    int64_t ddrop = INT64_MIN;
+    const uint32_t max_iv = w.deep_depth ? *w.max_iv : 0u;
     for (uint32_t u = 0; u < n; u++) {
         if (chan[u] - g.id_start != c) continue;
         if (!touched) {
@@ -515,8 +525,15 @@ __global__ void __launch_bounds__(256) k_cell_updates(DevGrid g, WorldDev w, uin
             cur = w.cell_sender[c];
             prev = w.cell_sender_prev[c];
             touched = true;
+            if (w.deep_depth) { dn = w.cdeep_n[c]; dlen = w.cdeep_len[c]; ddrop = w.cdeep_drop[c]; }
         }
         const uint32_t snd = sender[u];
+        if (w.deep_depth) {
+            const int64_t a = arrival ? arrival[u] : now;
+            if (a != now) irregular = true;
+            const size_t at = (size_t)c * w.deep_depth;
+            deep_push(w.cdeep_a + at, w.cdeep_s + at, w.deep_depth, dn, dlen, ddrop, a, snd, max_iv);
+        }
         if (snd != cur) {
             if (snd == prev) {
                 const uint32_t t = h;
@@ -525,7 +542,10 @@ __global__ void __launch_bounds__(256) k_cell_updates(DevGrid g, WorldDev w, uin
                 prev = cur;
             } else {
                 if (h != 0) {
-                    if (hp != 0 && prev != cur) atomicAdd(&w.counters[CTR_SENDER_OVERFLOW], 1u);
+                    if (hp != 0 && prev != cur) {
+                        if (w.deep_depth) irregular = true;
+                        else atomicAdd(&w.counters[CTR_SENDER_OVERFLOW], 1u);
+                    }
                     hp |= h;
                     prev = cur;
                 }
@@ -534,6 +554,10 @@ __global__ void __launch_bounds__(256) k_cell_updates(DevGrid g, WorldDev w, uin
             cur = snd;
         }
         h |= 1u;
+    }
+    if (touched && w.deep_depth) {
+        w.cdeep_n[c] = dn; w.cdeep_len[c] = dlen; w.cdeep_drop[c] = ddrop;
+        if (irregular) w.cell_irr_tick[c] = cur_tick + 1u;
     }
     if (touched) {
         w.cell_hist[c] = h;
@@ -545,8 +569,8 @@ __global__ void __launch_bounds__(256) k_cell_updates(DevGrid g, WorldDev w, uin
 }
 
 void launch_cell_updates(hipStream_t st, DevGrid g, WorldDev w, uint32_t n, const uint32_t *chan,
-                         const uint32_t *sender, uint32_t cur_tick) {
+                         const uint32_t *sender, uint32_t cur_tick, const int64_t *arrival, int64_t now_ns) {
     if (!n) return;
     hipLaunchKernelGGL(k_cell_updates, dim3(nblocks(g.ncell, 256)), dim3(256), 0, st, g, w, n, chan, sender,
-                       cur_tick);
+                       cur_tick, arrival, now_ns);
 }

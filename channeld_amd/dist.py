@@ -334,8 +334,8 @@ class HipShardEngine:
         if rc:
             self._lib.check(self.ctx, rc)
 
-    def fetch(self, want_records=False, records_cap=0):
-        return self.sw.fetch(want_records=want_records, records_cap=records_cap)
+    def fetch(self, want_records=False, records_cap=0, check=True):
+        return self.sw.fetch(want_records=want_records, records_cap=records_cap, check=check)
 
     def entities(self):
         n = C.c_uint32(0)

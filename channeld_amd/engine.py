@@ -282,10 +282,14 @@ class SpatialWorld:
         _lib.check(self.ctx, self.lib.chd_tick_device(self.ctx, C.byref(ti)))
         self._last_nq = n_queries
 
-    def fetch(self, want_records: bool = False, records_cap: int = 0) -> TickResult:
+    def fetch(self, want_records: bool = False, records_cap: int = 0, check: bool = True) -> TickResult:
+        """check=False: a capacity error (chd_tick_fetch fills the outputs and the overflow mask, then returns
+        CHD_E_CAPACITY) is returned as a result with `overflow` set instead of raised."""
         nq = getattr(self, "_last_nq", 0)
         o = self._alloc_out(nq, want_records, records_cap)
-        _lib.check(self.ctx, self.lib.chd_tick_fetch(self.ctx, C.byref(o)))
+        rc = self.lib.chd_tick_fetch(self.ctx, C.byref(o))
+        if rc != _lib.OK and (check or rc != _lib.E_CAPACITY):
+            _lib.check(self.ctx, rc)
         return self._result(o, nq)
 
     def digest(self, per_connection: bool = True):

@@ -165,6 +165,17 @@ typedef struct {
     uint32_t flags;              /* CHD_WORLD_* */
     uint32_t wire_max_update_len; /* CHD_WORLD_WIRE: largest serialized Any of a channel update (0 => 128) */
     uint32_t wire_max_full_len;   /* CHD_WORLD_WIRE: largest serialized Any of a channel's full state (0 => 1024) */
+    /* ChannelData.updateMsgBuffer (data.go:53-55,149-173) per channel, element for element: {arrivalTime, senderConnId} of the
+     * last `history_depth` updates, with the reference's own eviction (beyond MaxUpdateMsgBufferSize = 512 elements the oldest
+     * goes once it is older than maxFanOutIntervalMs).  0: only the 32-tick bit ring (exact while every update is stamped
+     * with its tick's now_ns, a window reaches back at most 32 ticks and a channel has at most two senders inside it; anything
+     * else is COUNTED in history_overflow).  >= 32 (1024 covers the reference's 512 with room for the unexpired surplus):
+     * exact for any arrival stamps (chd_tick_in.upd_arrival_ns), any number of updates of a channel per tick
+     * (upd_round_off), any number of senders and windows as old as the buffer reaches — subscriptions the bit ring cannot
+     * answer are served from these buffers by a separate (slower) launch; history_overflow then only counts what the
+     * reference's buffer would still hold and this one had to drop.  12 B x history_depth per entity and cell.  Not on
+     * region-sharded worlds (the buffers do not migrate). */
+    uint32_t history_depth;
 } chd_world_cfg;
 
 /* The fan-out emit kernel has two forms.  Connection-major: one workgroup per connection
@@ -316,7 +327,7 @@ typedef struct {
     const uint32_t *upd_idx;    /* entity slots, NULL => slot u = u */
     const double *upd_x, *upd_z;/* new position (SpatialInfo X,Z; Y is ignored) */
     const uint32_t *upd_sender; /* senderConnId, NULL => the entity's owner */
-    /* spatial-channel data updates (spawn/destroy merges), optional */
+    /* spatial-channel data updates (spawn/destroy merges), optional; applied in array order */
     uint32_t n_cell_updates;
     const uint32_t *cell_upd_channel; /* spatial channel ids */
     const uint32_t *cell_upd_sender;
@@ -327,6 +338,22 @@ typedef struct {
     const double *spot_x, *spot_z;
     const uint32_t *spot_dist;
     uint32_t n_spots_total;
+    /* ---- exact update buffers (chd_world_cfg.history_depth > 0; ignored fields must be 0 / NULL otherwise) ----
+     * The reference stamps every update when it is ENQUEUED (Channel.PutMessage: arrivalTime = ch.GetTime(), channel.go:296-310
+     * -> handleChannelDataUpdate, message.go:651 -> OnUpdate, data.go:159-164), not when the tick handles it: an update
+     * enqueued at 249 ms and handled by the tick at 260 ms belongs to the fan-out window [200, 250].
+     * upd_arrival_ns[u] / cell_upd_arrival_ns[u]: that stamp, per update; <= now_ns, >= 0, not decreasing per channel
+     * (queue order).  NULL => now_ns (every update arrives with its tick). */
+    const int64_t *upd_arrival_ns;
+    const int64_t *cell_upd_arrival_ns;
+    /* Several updates of one entity channel between two ticks: the reference handles them one after the other (each its own
+     * Notify and its own buffer element).  The host hands them over in ROUNDS — round r holds every entity at most once, a
+     * channel's r-th update of the tick — as consecutive ranges of the update arrays: round r = [upd_round_off[r],
+     * upd_round_off[r+1]), upd_round_off[n_update_rounds] == n_updates; the rounds are applied in order (one ingest launch
+     * each).  n_update_rounds == 0 => one round (the precondition of chd_tick_device then covers all of upd_idx).
+     * upd_round_off is a HOST array in chd_tick AND chd_tick_device (the library reads it to launch). */
+    uint32_t n_update_rounds;
+    const uint32_t *upd_round_off;
 } chd_tick_in;
 
 typedef struct {
@@ -355,7 +382,8 @@ typedef struct {
                                           band outgrew its halo segment or a subscription reaches beyond the halo;
                                           0x8000 an internal loop bound tripped (a bug, never a capacity) */
     uint32_t history_overflow;         /* windows reaching beyond the 32-tick update history, or channels
-                                          updated by more than two senders inside it (results then inexact) */
+                                          updated by more than two senders inside it (results then inexact);
+                                          history_depth > 0: windows reaching an update the exact buffer had to drop */
     uint32_t *record_masks;            /* optional, records_cap entries, parallel to `records`: CHD_WORLD_UPDATE_MASKS
                                           worlds only (else ignored); 0 for CHD_REC_FULL records */
 } chd_tick_out;

@@ -208,7 +208,8 @@ def test_rccl_single_rank_bench_path():
     sharded = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
     assert sharded["n_gpus"] == 1 and "tiled 1x1" in sharded["config"]["workload"]
     # the sharded bench checks its own first ticks against the single-world oracle (default --verify 2 on the dist path)
-    assert sharded["verified_ticks"] == 2 and sharded["verified"]["msgs_per_verified_tick"][0] > 0
+    # (tick 0 creates the subscriptions and fans nothing out yet; tick 1 carries the first, full-state fan-out)
+    assert sharded["verified_ticks"] == 2 and sharded["verified"]["msgs_per_verified_tick"][1] > 0
     assert sharded["latency_ticks"] == 2 and sharded["collectives"]["ranks"] == 1
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + common, capture_output=True, text=True, timeout=280, cwd=ROOT)
     assert r.returncode == 0, r.stderr[-2000:]
@@ -235,7 +236,7 @@ def test_bench_verify_two_ranks():
     r, d = shared_gpu_bench(2, ["--steps", "4", "--warmup", "3", "--verify", "3", "--entities", "6000", "--subs", "400"])
     assert r.returncode == 0, r.stderr[-3000:]
     assert d["verified_ticks"] == 3 and d["n_gpus"] == 2 and d["warmup"] == 3
-    assert all(m > 0 for m in d["verified"]["msgs_per_verified_tick"])
+    assert all(m > 0 for m in d["verified"]["msgs_per_verified_tick"][1:])
     assert d["config"]["config"] == "B-weak" and d["scaling"] == "weak"
 
 
@@ -303,7 +304,7 @@ def test_immigrants_without_a_slot_wait_in_limbo_and_come_back():
             parts = [halos[p][peer_off[p]: peer_off[p] + recv_splits[p]] for p in range(2)]
             e.interest(None, 0)
             e.fanout(torch.cat(parts) if sum(recv_splits) else halos[r])
-        res = [e.fetch() for e in engs]
+        res = [e.fetch(check=False) for e in engs]
         present = np.concatenate([e.entities()[0] for e in engs])
         return [int(v.overflow) for v in res], present
 
