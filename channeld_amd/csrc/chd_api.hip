@@ -738,7 +738,7 @@ int chd_world_create(chd_ctx *ctx, const chd_world_cfg *cfg) {
     if (d.wb) TRY(walloc(ctx, &d.sub_bits, S * d.wb));
     if (d.cm_emit) TRY(walloc(ctx, &d.items, n_items_max, false));
     W.plan_recipients = (cfg->flags & CHD_WORLD_HANDOVER_RECIPIENTS) != 0;
-    W.overlap_interest = (cfg->flags & CHD_WORLD_OVERLAP_INTEREST) != 0;
+    W.overlap_interest = (cfg->flags & CHD_WORLD_OVERLAP_INTEREST) != 0 && !cfg->history_depth;
     {
         hipDeviceProp_t prop;
         HIPCHK(hipGetDeviceProperties(&prop, ctx->device));
@@ -817,7 +817,8 @@ int chd_world_create(chd_ctx *ctx, const chd_world_cfg *cfg) {
     if (masks && !cfg->max_records) nrec = nrec * 2 / 3;  // one more 4-byte array per record
     // tick pipelining: only with the descriptor-driven connection-major emit (its record kernel reads descriptors, offsets
     // and one column array: all of them, and the record buffer, then exist once per tick parity)
-    W.pipe_alloc = (cfg->flags & CHD_WORLD_PIPELINE_TICKS) && !d.cm_emit && !masks && !W.wire && (S >= 4096 || d.one_wave_emit);
+    // (not with exact update buffers: maxFanOutIntervalMs is written by the interest updates and read by the ingest)
+    W.pipe_alloc = (cfg->flags & CHD_WORLD_PIPELINE_TICKS) && !d.cm_emit && !masks && !W.wire && !cfg->history_depth && (S >= 4096 || d.one_wave_emit);
     W.pipe_on = W.pipe_alloc;
     if (W.pipe_alloc && !cfg->max_records) nrec /= 2;
     d.recs_cap = nrec;
@@ -841,10 +842,35 @@ int chd_world_create(chd_ctx *ctx, const chd_world_cfg *cfg) {
     if (masks) TRY(walloc(ctx, &d.rec_mask, nrec, false));
     d.rec_pos = nullptr;
     d.ce_slot = nullptr;
+    // exact update buffers (history_depth): ChannelData.updateMsgBuffer per entity and per spatial channel
+    d.deep_depth = cfg->history_depth;
+    if (d.deep_depth) {
+        if (d.deep_depth < CHD_HIST_BITS) return fail(ctx, CHD_E_INVAL, "history_depth must be 0 or at least %d (1024 covers the reference's 512-element buffers)", CHD_HIST_BITS);
+        const size_t D = d.deep_depth;
+        TRY(walloc(ctx, &d.deep_a, N * D, false));
+        TRY(walloc(ctx, &d.deep_s, N * D, false));
+        TRY(walloc(ctx, &d.deep_n, N));
+        TRY(walloc(ctx, &d.deep_len, N));
+        TRY(walloc(ctx, &d.deep_drop, N, false));
+        TRY(walloc(ctx, &d.irr_tick, N));
+        TRY(walloc(ctx, &d.cdeep_a, C * D, false));
+        TRY(walloc(ctx, &d.cdeep_s, C * D, false));
+        TRY(walloc(ctx, &d.cdeep_n, C));
+        TRY(walloc(ctx, &d.cdeep_len, C));
+        TRY(walloc(ctx, &d.cdeep_drop, C, false));
+        TRY(walloc(ctx, &d.cell_irr_tick, C));
+        TRY(walloc(ctx, &d.cell_irr, C));
+        TRY(walloc(ctx, &d.max_iv, 1));
+        TRY(walloc(ctx, &d.conn_deep, S));
+        TRY(walloc(ctx, &d.ce_slot, N + 2));
+        // drop = INT64_MIN ("nothing was ever dropped"): the byte pattern 0x80 repeated is a very negative int64 as well
+        HIPCHK(hipMemsetAsync(d.deep_drop, 0x80, sizeof(int64_t) * std::max<size_t>(N, 32), ctx->stream));
+        HIPCHK(hipMemsetAsync(d.cdeep_drop, 0x80, sizeof(int64_t) * std::max<size_t>(C, 32), ctx->stream));
+    }
     if (W.wire) {
         WireDev &x = W.x;
         TRY(walloc(ctx, &d.rec_pos, nrec, false));
-        TRY(walloc(ctx, &d.ce_slot, N + 2));
+        if (!d.ce_slot) TRY(walloc(ctx, &d.ce_slot, N + 2));
         TRY(walloc(ctx, &x.rec_woff, nrec, false));
         TRY(walloc(ctx, &x.rec_wtag, nrec, false));
         TRY(walloc(ctx, &x.seg_fast, P));
@@ -1192,9 +1218,19 @@ static int tick_locked(chd_ctx *ctx, const chd_tick_in *in) {
     WorldDev &d = W.d;
     if (in->n_updates && (!in->upd_x || !in->upd_z)) return fail(ctx, CHD_E_INVAL, "tick: NULL update positions");
     if (!in->upd_idx && in->n_updates > d.N) return fail(ctx, CHD_E_INVAL, "tick: n_updates > max_entities");
+    if (!in->upd_idx && in->n_update_rounds > 1) return fail(ctx, CHD_E_INVAL, "tick: update rounds need upd_idx");
     TRY(check_queries(ctx, in));
     if (in->n_cell_updates && (!in->cell_upd_channel || !in->cell_upd_sender)) return fail(ctx, CHD_E_INVAL, "tick: NULL cell updates");
     if (W.slot_mode == 2) return fail(ctx, CHD_E_STATE, "chd_tick on a region-sharded world: use chd_shard_ingest/import/fanout");
+    if (!d.deep_depth && (in->upd_arrival_ns || in->cell_upd_arrival_ns || in->n_update_rounds > 1))
+        return fail(ctx, CHD_E_STATE, "tick: arrival stamps / update rounds need a world with history_depth > 0 (the 32-tick bit ring stamps a batch with its tick)");
+    if (in->n_update_rounds) {
+        if (!in->upd_round_off) return fail(ctx, CHD_E_INVAL, "tick: NULL upd_round_off");
+        if (in->upd_round_off[0] != 0 || in->upd_round_off[in->n_update_rounds] != in->n_updates)
+            return fail(ctx, CHD_E_INVAL, "tick: upd_round_off must run from 0 to n_updates");
+        for (uint32_t r = 0; r < in->n_update_rounds; r++)
+            if (in->upd_round_off[r + 1] < in->upd_round_off[r]) return fail(ctx, CHD_E_INVAL, "tick: upd_round_off decreases at %u", r);
+    }
     const bool chained = ctx->chain_prev;
     TRY(tick_begin(ctx, in->now_ns));
     TickRing &r = ctx->ring;
@@ -1210,7 +1246,7 @@ static int tick_locked(chd_ctx *ctx, const chd_tick_in *in) {
     // every live entity has sent an update in this tick and in the one before.  Both forms write the same records, segment
     // order and state (the parity tests run both; the full-size tests cross from one to the other after the first tick);
     // worlds that ASK for the one-wave geometry (CHD_WORLD_ONE_WAVE_EMIT) always take the descriptor path.
-    W.full_streak = (W.n_live && in->n_updates >= W.n_live) ? std::min(W.full_streak + 1u, 1u << 20) : 0u;
+    W.full_streak = (W.n_live && in->n_updates >= W.n_live && in->n_update_rounds <= 1) ? std::min(W.full_streak + 1u, 1u << 20) : 0u;
     d.seg_off = (!d.one_wave_emit && W.full_streak < 2u) ? 1u : 0u;
     const bool pipe = W.pipe_on && fanout_seg_path(d);
     hipStream_t st = ctx->stream;
@@ -1259,8 +1295,20 @@ static int tick_locked(chd_ctx *ctx, const chd_tick_in *in) {
         if (prof_stages) HIPCHK(hipEventRecord(ev[CHD_N_STAGES + 2], ax));
         HIPCHK(hipEventRecord(ctx->ev_join, ax));
     }
-    launch_ingest(bs, ctx->g, d, in->n_updates, in->upd_idx, in->upd_x, in->upd_z, in->upd_sender, r.cur_tick);
-    launch_cell_updates(bs, ctx->g, d, in->n_cell_updates, in->cell_upd_channel, in->cell_upd_sender, r.cur_tick);
+    {
+        // one ingest launch per round of updates (a channel's r-th update of this tick: chd_tick_in.upd_round_off)
+        const uint32_t one[2] = {0u, in->n_updates};
+        const uint32_t nr = in->n_update_rounds ? in->n_update_rounds : 1u;
+        const uint32_t *off = in->n_update_rounds ? in->upd_round_off : one;
+        for (uint32_t k = 0; k < nr; k++) {
+            const uint32_t a = off[k], n = off[k + 1] - a;
+            launch_ingest(bs, ctx->g, d, n, in->upd_idx ? in->upd_idx + a : nullptr, in->upd_x + a, in->upd_z + a,
+                          in->upd_sender ? in->upd_sender + a : nullptr, r.cur_tick, in->upd_arrival_ns ? in->upd_arrival_ns + a : nullptr,
+                          in->now_ns);
+        }
+    }
+    launch_cell_updates(bs, ctx->g, d, in->n_cell_updates, in->cell_upd_channel, in->cell_upd_sender, r.cur_tick,
+                        in->cell_upd_arrival_ns, in->now_ns);
     if (W.plan_recipients) {
         // who receives each handover's message: on the subscriptions as they are NOW, before this tick's
         // interest updates (the reference sends from Notify, spatial.go:776-857)
@@ -1288,7 +1336,7 @@ static int tick_locked(chd_ctx *ctx, const chd_tick_in *in) {
         if (prof_ends) HIPCHK(hipEventRecord(ev[5], st));
         HIPCHK(hipEventRecord(W.ev_emit_done[par], st));
         launch_fanout_emit_deferred(bs, ctx->g, d, in->now_ns, r);
-        launch_tick_epilogue(bs, d, r.cur_tick % TICK_RING);
+        launch_tick_epilogue(bs, d, r.cur_tick % TICK_RING, ctx->g.ncell);
         if (prof_ends) HIPCHK(hipEventRecord(ev[4], bs));
         // ... and whatever is enqueued on `stream` after this tick comes after ALL of it
         HIPCHK(hipEventRecord(W.ev_stages_all, bs));
@@ -1298,8 +1346,9 @@ static int tick_locked(chd_ctx *ctx, const chd_tick_in *in) {
         launch_fanout_emit_main(st, ctx->g, d, in->now_ns, r);
         if (prof) HIPCHK(hipEventRecord(ev[CHD_N_STAGES + 3], st));
         launch_fanout_emit_deferred(st, ctx->g, d, in->now_ns, r);
+        launch_fanout_emit_deep(st, ctx->g, d, in->now_ns, r);
         if (prof_ends) HIPCHK(hipEventRecord(ev[5], st));
-        launch_tick_epilogue(st, d, r.cur_tick % TICK_RING);
+        launch_tick_epilogue(st, d, r.cur_tick % TICK_RING, ctx->g.ncell);
     }
     TRY(after_launch(ctx));
     ctx->chain = pipe;
@@ -1540,14 +1589,30 @@ int chd_tick(chd_ctx *ctx, const chd_tick_in *in, chd_tick_out *out) {
     // One update per entity and one interest update per connection per tick: the kernels rewrite an entity's /
     // a connection's state in place, one thread / wave per input record, so a repeated slot would race (and the
     // reference applies them one after the other: the host coalesces, keeping the last).  O(n) bitmaps.
+    if (in->n_update_rounds && (!in->upd_round_off || in->upd_round_off[in->n_update_rounds] != in->n_updates))
+        return fail(ctx, CHD_E_INVAL, "tick: upd_round_off must run from 0 to n_updates");
     if (in->upd_idx && nu > 1) {
+        // (inside one ROUND of updates: chd_tick_in.upd_round_off hands a channel's several updates of a tick over in rounds)
         std::vector<uint64_t> seen(((size_t)ctx->w.d.N + 63) / 64, 0);
-        for (size_t i = 0; i < nu; i++) {
-            const uint32_t v = in->upd_idx[i];
-            if (seen[v >> 6] & (1ull << (v & 63))) return fail(ctx, CHD_E_INVAL, "tick: entity slot %u is updated twice (coalesce the updates of a tick on the host)", v);
-            seen[v >> 6] |= 1ull << (v & 63);
+        const uint32_t one[2] = {0u, (uint32_t)nu};
+        const uint32_t nr = in->n_update_rounds ? in->n_update_rounds : 1u;
+        const uint32_t *off = in->n_update_rounds ? in->upd_round_off : one;
+        for (uint32_t r = 0; r < nr; r++) {
+            if (r) std::fill(seen.begin(), seen.end(), 0ull);
+            for (size_t i = off[r]; i < off[r + 1] && i < nu; i++) {
+                const uint32_t v = in->upd_idx[i];
+                if (seen[v >> 6] & (1ull << (v & 63)))
+                    return fail(ctx, CHD_E_INVAL, "tick: entity slot %u is updated twice in one round (coalesce the updates of a tick on the host, or hand them over in rounds: upd_round_off)", v);
+                seen[v >> 6] |= 1ull << (v & 63);
+            }
         }
     }
+    for (size_t i = 0; in->upd_arrival_ns && i < nu; i++)
+        if (in->upd_arrival_ns[i] < 0 || in->upd_arrival_ns[i] > in->now_ns)
+            return fail(ctx, CHD_E_INVAL, "tick: update %zu arrives at %lld, outside [0, now_ns]", i, (long long)in->upd_arrival_ns[i]);
+    for (size_t i = 0; in->cell_upd_arrival_ns && i < nc; i++)
+        if (in->cell_upd_arrival_ns[i] < 0 || in->cell_upd_arrival_ns[i] > in->now_ns)
+            return fail(ctx, CHD_E_INVAL, "tick: cell update %zu arrives at %lld, outside [0, now_ns]", i, (long long)in->cell_upd_arrival_ns[i]);
     if (in->query_sub && nq > 1) {
         std::vector<uint64_t> seen(((size_t)ctx->w.d.S + 63) / 64, 0);
         for (size_t i = 0; i < nq; i++) {
@@ -1582,6 +1647,8 @@ int chd_tick(chd_ctx *ctx, const chd_tick_in *in, chd_tick_out *out) {
     TRY(stage(8, in->spot_x, 8 * ns, (const void **)&din.spot_x));
     TRY(stage(9, in->spot_z, 8 * ns, (const void **)&din.spot_z));
     TRY(stage(10, in->spot_dist, 4 * ns, (const void **)&din.spot_dist));
+    TRY(stage(11, in->upd_arrival_ns, 8 * nu, (const void **)&din.upd_arrival_ns));
+    TRY(stage(12, in->cell_upd_arrival_ns, 8 * nc, (const void **)&din.cell_upd_arrival_ns));
     if (ns && !in->spot_dist) {
         TRY(ensure(ctx, 10, 4 * ns));
         HIPCHK(hipMemsetAsync(ctx->scratch[10].p, 0, 4 * ns, ctx->stream));
@@ -1616,6 +1683,7 @@ int chd_shard_spawn(chd_ctx *ctx, uint32_t n, const uint32_t *chan_id, const dou
     if (!chan_id || !x || !z) return fail(ctx, CHD_E_INVAL, "chd_shard_spawn: NULL buffer");
     std::lock_guard<std::mutex> lk(ctx->mu);
     if (ctx->w.slot_mode == 1) return fail(ctx, CHD_E_STATE, "chd_shard_spawn on a world with caller-chosen slots (chd_world_spawn)");
+    if (ctx->w.d.deep_depth) return fail(ctx, CHD_E_STATE, "history_depth is not available on region-sharded worlds (the update buffers do not migrate)");
     ctx->w.slot_mode = 2;
     TRY(bind(ctx));
     TRY(ensure(ctx, 1, 4 * (size_t)n));
@@ -1832,7 +1900,7 @@ int chd_shard_fanout(chd_ctx *ctx, const void *d_halo_recv, uint32_t world, cons
     if (prof) HIPCHK(hipEventRecord(ev[CHD_N_STAGES + 3], st));
     launch_fanout_emit_deferred(st, ctx->g, d, now, r);
     if (prof_ends) HIPCHK(hipEventRecord(ev[5], st));
-    launch_tick_epilogue(st, d, r.cur_tick % TICK_RING);
+    launch_tick_epilogue(st, d, r.cur_tick % TICK_RING, ctx->g.ncell);
     TRY(after_launch(ctx));
     if (d_in->n_queries) W.last_nq = d_in->n_queries;
     W.ticked = true;

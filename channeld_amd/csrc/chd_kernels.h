@@ -368,4 +368,4 @@ void launch_fanout_emit_deferred(hipStream_t st, DevGrid g, WorldDev w, int64_t 
 // subscriptions the tick-ring masks cannot answer (PF_DEEP), from the exact update buffers; no-op without history_depth
 void launch_fanout_emit_deep(hipStream_t st, DevGrid g, WorldDev w, int64_t now_ns, TickRing ring);
 #define TICK_RING 1024
-void launch_tick_epilogue(hipStream_t st, WorldDev w, uint32_t slot);
+void launch_tick_epilogue(hipStream_t st, WorldDev w, uint32_t slot, uint32_t ncell);

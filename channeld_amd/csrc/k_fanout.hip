@@ -119,6 +119,21 @@ __device__ __forceinline__ bool history_lost(const TickRing &ring, int64_t oldes
     return ring.n == CHD_HIST_BITS && oldest > L + I;
 }
 
+// Exact update buffers (history_depth > 0): a due subscription whose windows the tick-ring masks cannot answer — some
+// channel of its cell took an update the masks do not represent (an arrival stamp off the tick's own, a third sender), or
+// its next window ends before the oldest stamp of the full ring — is served from the buffers themselves by
+// k_fanout_emit_deep.  (A first fan-out sends full states and starts over at `now`: no window to evaluate.)
+__device__ __forceinline__ bool sub_is_deep(const WorldDev &w, const TickRing &ring, int64_t oldest, uint32_t fl, int64_t L, int64_t I,
+                                            uint32_t c) {
+    return w.deep_depth != 0 && (fl & PF_HAD_FIRST) && (w.cell_irr[c] != 0 || history_lost(ring, oldest, L, I));
+}
+// worst case of its segment: per channel of the cell one record per due window, and no more than the buffer holds elements
+__device__ __forceinline__ uint64_t deep_upper_bound(const WorldDev &w, int64_t now, int64_t L, int64_t I, uint64_t size) {
+    int64_t nwin = (now - L) / I;
+    if (nwin > (int64_t)w.deep_depth) nwin = (int64_t)w.deep_depth;
+    return (uint64_t)nwin * (size + 1);
+}
+
 __device__ __forceinline__ uint32_t window_mask_serial(const TickRing &ring, int64_t lo, int64_t hi);
 __device__ __forceinline__ int64_t empty_windows_serial(const TickRing &ring, int64_t now, int64_t L, uint32_t iv);
 
@@ -127,12 +142,15 @@ __global__ void __launch_bounds__(64 * FO_WAVES) k_fanout_plan(DevGrid g, WorldD
     if (s >= w.S) return;
     const uint32_t lane = lane_id();
     uint64_t carry = 0;
+    uint32_t any_deep = 0;
+    const int64_t oldest = ring.n ? ring.t[ring.n - 1] : INT64_MAX;
     if (w.sub_alive[s]) {
         const uint32_t cnt = w.pair_cnt[s];
         const size_t pbase = (size_t)s * w.capq;
         for (uint32_t p0 = 0; p0 < cnt; p0 += 64) {
             const uint32_t p = p0 + lane;
             uint64_t ub = 0;
+            bool deep = false;
             if (p < cnt) {
                 uint32_t fl = w.pair_flags[pbase + p];
                 int64_t L = w.pair_last[pbase + p];
@@ -142,7 +160,11 @@ __global__ void __launch_bounds__(64 * FO_WAVES) k_fanout_plan(DevGrid g, WorldD
                     // region-sharded world: the cell's table must be on this rank (own region or a received halo band)
                     if (w.cell_cov && !w.cell_cov[c]) atomicOr(&w.counters[CTR_OVERFLOW], OVF_HALO);
                     uint64_t size = (uint64_t)(w.cell_end[c] - w.cell_start[c]) + 1;
-                    if (!(fl & PF_HAD_FIRST)) {
+                    if (sub_is_deep(w, ring, oldest, fl, L, I, c)) {
+                        deep = true;
+                        ub = deep_upper_bound(w, now, L, I, size - 1);
+                        w.pair_flags[pbase + p] = fl | PF_DEEP;  // (the emit kernels skip it; k_fanout_emit_deep clears the bit)
+                    } else if (!(fl & PF_HAD_FIRST)) {
                         ub = size;  // one full-state window, then last = now
                     } else {
                         int64_t nwin = (now - L) / I;
@@ -166,11 +188,15 @@ __global__ void __launch_bounds__(64 * FO_WAVES) k_fanout_plan(DevGrid g, WorldD
             uint64_t rel = carry + inc - ub;
             if (p < cnt) w.pair_rel[pbase + p] = rel > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)rel;
             carry += __shfl((unsigned long long)inc, 63);
+            if (__ballot(deep)) any_deep = 1;
         }
     }
     // a connection whose worst case does not fit 32-bit segment offsets cannot be
     // served this tick: make its range exceed every capacity (flagged by emit)
-    if (lane == 0) w.rec_ub[s] = carry > 0xFFFFFFFFull ? (1ull << 40) : carry;
+    if (lane == 0) {
+        w.rec_ub[s] = carry > 0xFFFFFFFFull ? (1ull << 40) : carry;
+        if (w.deep_depth) w.conn_deep[s] = any_deep;
+    }
 }
 
 // cells with at least one live subscription, ascending (cell-major emit walks this list)
@@ -670,7 +696,7 @@ __global__ void __launch_bounds__(64 * WAVES) k_fanout_emit(DevGrid g, WorldDev 
                 const uint32_t iv = w.pair_iv[pbase + p];
                 const int64_t I = (int64_t)iv * 1000000;
                 // data.go:194-197: NO_ACCESS is skipped but stays queued
-                if (DEFERRED ? (fl & PF_DEFER) != 0 : (!(fl & PF_NO_ACCESS) && I > 0 && now >= L + I)) {
+                if (DEFERRED ? (fl & PF_DEFER) != 0 : (!(fl & (PF_NO_ACCESS | PF_DEEP)) && I > 0 && now >= L + I)) {
                     const uint32_t c = w.pair_cell[pbase + p];
                     const uint32_t k = atomicAdd(&n_due, 1u);
                     d_p[k] = p; d_fl[k] = fl & ~PF_DEFER; d_L[k] = L; d_iv[k] = iv; d_c[k] = c;
@@ -693,7 +719,7 @@ __global__ void __launch_bounds__(64 * WAVES) k_fanout_emit(DevGrid g, WorldDev 
                         us = CHD_NOT_A_SENDER;
                     d_us[k] = us;
                     d_hand[k] = w.ce_chan_view ? w.cell_hand[c] : 0u;
-                } else if (!DEFERRED) {
+                } else if (!DEFERRED && !(fl & PF_DEEP)) {
                     w.pair_nrec[pbase + p] = 0;
                 }
             }
@@ -865,7 +891,7 @@ __global__ void __launch_bounds__(64 * FO_WAVES) k_fanout_plan_seg(DevGrid g, Wo
     if (s >= w.S) return;
     const uint32_t lane = lane_id();
     uint64_t carry = 0;
-    uint32_t n_simple = 0, any_deferred = 0, hist_ovf = 0;
+    uint32_t n_simple = 0, any_deferred = 0, hist_ovf = 0, any_deep = 0;
     unsigned long long rec_simple = 0;
     const uint32_t cnt = w.sub_alive[s] ? w.pair_cnt[s] : 0u;
     const size_t pbase = (size_t)s * w.capq;
@@ -875,11 +901,11 @@ __global__ void __launch_bounds__(64 * FO_WAVES) k_fanout_plan_seg(DevGrid g, Wo
     for (uint32_t p0 = 0; p0 < cnt; p0 += 64) {
         const uint32_t p = p0 + lane;
         uint64_t ub = 0;
-        bool due = false, simple = false;
+        bool due = false, simple = false, deep = false;
         uint32_t fl = 0, c = 0, size = 0, start = 0, info = 0, count = 0;
         int64_t Lw = 0;
         if (p < cnt) {
-            fl = w.pair_flags[pbase + p] & ~PF_DEFER;
+            fl = w.pair_flags[pbase + p] & ~(PF_DEFER | PF_DEEP);
             const int64_t L = w.pair_last[pbase + p];
             const uint32_t iv = w.pair_iv[pbase + p];
             const int64_t I = (int64_t)iv * 1000000;
@@ -890,6 +916,14 @@ __global__ void __launch_bounds__(64 * FO_WAVES) k_fanout_plan_seg(DevGrid g, Wo
                 if (w.cell_cov && !w.cell_cov[c]) atomicOr(&w.counters[CTR_OVERFLOW], OVF_HALO);  // (see k_fanout_plan)
                 start = w.cell_start[c];
                 size = w.cell_end[c] - start;
+                if (sub_is_deep(w, ring, oldest, fl, L, I, c)) {  // exact update buffers: k_fanout_emit_deep's
+                    deep = true;
+                    due = false;
+                    ub = deep_upper_bound(w, now, L, I, size);
+                    w.pair_flags[pbase + p] = fl | PF_DEEP;
+                }
+            }
+            if (due) {
                 uint32_t wms[4] = {0, 0, 0, 0}, nw = 0;
                 Lw = L;
                 if (!(fl & PF_HAD_FIRST)) {  // data.go:217-223: full state, last = t
@@ -983,6 +1017,7 @@ __global__ void __launch_bounds__(64 * FO_WAVES) k_fanout_plan_seg(DevGrid g, Wo
         carry += __shfl((unsigned long long)inc, 63);
         const uint64_t sm = __ballot(due && simple);
         if (__ballot(due && !simple)) any_deferred = 1;
+        if (__ballot(deep)) any_deep = 1;
         if (due && simple) {
             const size_t k = pbase + n_simple + mask_rank(sm);
             w.seg_desc[k] = make_uint4(rel32, start, size, info);
@@ -998,6 +1033,7 @@ __global__ void __launch_bounds__(64 * FO_WAVES) k_fanout_plan_seg(DevGrid g, Wo
         w.rec_ub[s] = carry > 0xFFFFFFFFull ? (1ull << 40) : carry;
         w.n_simple[s] = n_simple;
         w.conn_defer[s] = any_deferred;
+        if (w.deep_depth) w.conn_deep[s] = any_deep;
         w.rec_cnt[s] = (uint32_t)rec_simple;
         unsigned long long *slot = (unsigned long long *)&w.tot64[(size_t)(s & 63u) * 16];
         if (rec_simple) atomicAdd(slot, rec_simple);
@@ -1336,7 +1372,7 @@ __global__ void __launch_bounds__(WS_SUBS) k_fanout_items(DevGrid g, WorldDev w,
                 L = w.pair_last[pi];
                 iv = w.pair_iv[pi];
                 const int64_t I = (int64_t)iv * 1000000;
-                due = !(fl & PF_NO_ACCESS) && I > 0 && now >= L + I;
+                due = !(fl & (PF_NO_ACCESS | PF_DEEP)) && I > 0 && now >= L + I;  // (PF_DEEP: k_fanout_plan gave it to k_fanout_emit_deep)
                 if (due && w.cell_cov && !w.cell_cov[c]) atomicOr(&w.counters[CTR_OVERFLOW], OVF_HALO);  // (see k_fanout_plan)
                 if (due && ub1 > w.recs_cap) {
                     // no room for this connection's worst case: state untouched, it catches up next tick
@@ -1376,7 +1412,7 @@ __global__ void __launch_bounds__(WS_SUBS) k_fanout_items(DevGrid g, WorldDev w,
                     flags |= (nw > 4 ? 4u : nw) << WSF_NWIN_SHIFT;
                     w.pair_last[pi] = Lw;
                     w.pair_flags[pi] = fl | PF_HAD_FIRST;
-                } else {
+                } else if (!(fl & PF_DEEP)) {
                     w.pair_nrec[pi] = 0;
                 }
             }
@@ -1688,11 +1724,154 @@ void launch_fanout_emit_deferred(hipStream_t st, DevGrid g, WorldDev w, int64_t 
     hipLaunchKernelGGL((k_fanout_emit<1, false, true>), dim3(w.S), dim3(64), 0, st, g, w, now_ns, ring);
 }
 
+
+// ---------------------------------------------------------------------------
+// Exact update buffers (chd_world_cfg.history_depth): tickData's buffer walk itself (data.go:225-269), for the subscriptions
+// the plan marked PF_DEEP.  One wave per connection.  Per subscription the due windows are k = 0 .. nwin-1, window k =
+// [max(L + k I, 0), L + (k+1) I] (both ends inclusive: `be.arrivalTime >= lastUpdateTime && be.arrivalTime <= nextFanOutTime`
+// with lastUpdateTime starting at max(lastFanOutTime, 0)); a channel gets one record per window that holds at least one
+// buffered update from a sender the subscription does not skip — an update at arrival a lies in window floor((a - L) / I)
+// and, when a sits exactly on that window's lower edge, in the one before as well.  One lane per channel of the cell walks
+// that channel's buffer from its newest element back to the first one older than the subscription's reach: O(updates inside
+// the reach), not O(buffer).  Two passes (count, wave prefix sum, write) keep a channel's records contiguous; the order of a
+// segment's records is not the hot path's (window-major there, channel-major here) — a connection's records are a multiset.
+// ---------------------------------------------------------------------------
+template <bool WRITE>
+__device__ __forceinline__ uint32_t deep_walk(const int64_t *__restrict__ A, const uint32_t *__restrict__ S, uint32_t D, uint32_t n,
+                                              uint32_t len, int64_t drop, int64_t L, int64_t I, int64_t nwin, bool skip_self,
+                                              uint32_t conn, uint32_t chan, uint32_t pos, chd_fanout_rec *__restrict__ out,
+                                              uint32_t *__restrict__ opos, uint32_t *__restrict__ omask, uint32_t at, uint32_t &lost) {
+    const int64_t lo0 = L > 0 ? L : 0, hi_all = L + nwin * I;
+    if (drop >= lo0) lost = 1;  // an update the reference would still hold, inside this subscription's reach, is gone
+    int64_t prevw = nwin;       // windows are met newest first: a window is new when its index is below the last one counted
+    uint32_t cnt = 0;
+    for (uint32_t q = 0; q < len; q++) {
+        const uint32_t idx = (n - 1u - q) % D;
+        const int64_t a = A[idx];
+        if (a < lo0) break;  // (arrival order: everything further back is older still)
+        if (a > hi_all) continue;
+        if (skip_self && S[idx] == conn) continue;
+        const int64_t k = (a - L) / I;
+        const bool edge = k >= 1 && (a - L) - k * I == 0;  // on the lower edge of window k = the upper edge of window k-1
+        if (k < nwin && k < prevw) {
+            if (WRITE) {
+                out[at + cnt].conn = conn; out[at + cnt].channel = chan;
+                if (opos) opos[at + cnt] = pos;
+                if (omask) omask[at + cnt] = 0;
+            }
+            cnt++;
+            prevw = k;
+        }
+        if (edge && k - 1 < prevw) {
+            if (WRITE) {
+                out[at + cnt].conn = conn; out[at + cnt].channel = chan;
+                if (opos) opos[at + cnt] = pos;
+                if (omask) omask[at + cnt] = 0;
+            }
+            cnt++;
+            prevw = k - 1;
+        }
+    }
+    return cnt;
+}
+
+__global__ void __launch_bounds__(64) k_fanout_emit_deep(DevGrid g, WorldDev w, int64_t now, TickRing ring) {
+    const uint32_t s = blockIdx.x;
+    if (!w.conn_deep[s]) return;
+    const uint32_t lane = lane_id();
+    const uint32_t cnt = w.pair_cnt[s];
+    const size_t pbase = (size_t)s * w.capq;
+    const uint64_t base = w.rec_ub[s];
+    const bool room = w.rec_ub[s + 1] <= w.recs_cap;
+    const uint32_t conn = w.conn_id[s];
+    const uint32_t D = w.deep_depth;
+    uint32_t total = 0, lost = 0;
+    for (uint32_t p = 0; p < cnt; p++) {
+        const uint32_t fl = w.pair_flags[pbase + p];
+        if (!(fl & PF_DEEP)) continue;  // (uniform)
+        if (!room) {
+            // no room for this connection's worst case: its state stays, it catches up next tick (flagged)
+            if (lane == 0) {
+                w.pair_flags[pbase + p] = fl & ~PF_DEEP;
+                w.pair_nrec[pbase + p] = 0;
+                atomicOr(&w.counters[CTR_OVERFLOW], OVF_RECORDS);
+            }
+            continue;
+        }
+        const int64_t L = w.pair_last[pbase + p];
+        const int64_t I = (int64_t)w.pair_iv[pbase + p] * 1000000;
+        const int64_t nwin = (now - L) / I;  // >= 1: the plan found it due
+        const uint32_t c = w.pair_cell[pbase + p];
+        const uint32_t start = w.cell_start[c], end = w.cell_end[c];
+        const bool skip_self = (fl & PF_SKIP_SELF) != 0;
+        const uint32_t rel = w.pair_rel[pbase + p];
+        chd_fanout_rec *__restrict__ out = w.recs + base + rel;
+        uint32_t *__restrict__ opos = w.rec_pos ? w.rec_pos + base + rel : nullptr;
+        uint32_t *__restrict__ omask = w.rec_mask ? w.rec_mask + base + rel : nullptr;
+        if (omask) lost = 1;  // (which updates a message merges is a mask over the tick ring: not expressible here)
+        uint32_t n_out = 0;
+        // the spatial channel's own buffer: lane 0
+        {
+            uint32_t k0 = 0;
+            const size_t at = (size_t)c * D;
+            if (lane == 0)
+                k0 = deep_walk<true>(w.cdeep_a + at, w.cdeep_s + at, D, w.cdeep_n[c], w.cdeep_len[c], w.cdeep_drop[c], L, I, nwin, skip_self,
+                                     conn, c + g.id_start, CHD_POS_CELL | c, out, opos, omask, 0u, lost);
+            n_out = (uint32_t)__shfl((int)k0, 0);
+        }
+        for (uint32_t b = start; b < end; b += 64) {
+            const uint32_t pos = b + lane;
+            const bool in = pos < end;
+            uint32_t e = 0, chan = 0, k = 0;
+            if (in) {
+                e = w.ce_slot[pos];
+                chan = w.ce_chan_view[pos];
+                const size_t at = (size_t)e * D;
+                k = deep_walk<false>(w.deep_a + at, w.deep_s + at, D, w.deep_n[e], w.deep_len[e], w.deep_drop[e], L, I, nwin, skip_self,
+                                     conn, chan, pos, out, opos, omask, 0u, lost);
+            }
+            uint32_t inc = k;
+#pragma unroll
+            for (int d = 1; d < 64; d <<= 1) {
+                const uint32_t o = (uint32_t)__shfl_up((int)inc, d);
+                if ((int)lane >= d) inc += o;
+            }
+            if (in && k) {
+                const size_t at = (size_t)e * D;
+                (void)deep_walk<true>(w.deep_a + at, w.deep_s + at, D, w.deep_n[e], w.deep_len[e], w.deep_drop[e], L, I, nwin, skip_self,
+                                      conn, chan, pos, out, opos, omask, n_out + inc - k, lost);
+            }
+            n_out += (uint32_t)__shfl((int)inc, 63);
+        }
+        pad_segment(out, n_out);
+        if (lane == 0) {
+            w.pair_last[pbase + p] = L + nwin * I;
+            w.pair_flags[pbase + p] = fl & ~PF_DEEP;
+            w.pair_nrec[pbase + p] = n_out;
+        }
+        total += n_out;
+    }
+    if (__ballot(lost != 0) && lane == 0) atomicAdd(&w.counters[CTR_HIST_OVERFLOW], 1u);
+    if (lane == 0 && total) {
+        w.rec_cnt[s] += total;
+        unsigned long long *slot = (unsigned long long *)&w.tot64[(size_t)(s & 63u) * 16];
+        atomicAdd(slot, (unsigned long long)total);
+        atomicAdd(slot + 2, (unsigned long long)total);  // (not written by the dominant emit kernel)
+    }
+}
+
+void launch_fanout_emit_deep(hipStream_t st, DevGrid g, WorldDev w, int64_t now_ns, TickRing ring) {
+    if (!w.S || !w.deep_depth) return;
+    hipLaunchKernelGGL(k_fanout_emit_deep, dim3(w.S), dim3(64), 0, st, g, w, now_ns, ring);
+}
+
 // Per-tick totals into the device-side history ring (read back by chd_tick_fetch /
 // chd_get_tick_history), then the per-tick counters are cleared for the next tick.
 static_assert(CHD_LIST_BANKS == 64, "one epilogue lane per list bank");
-__global__ void __launch_bounds__(64) k_tick_epilogue(WorldDev w, uint32_t slot) {
+__global__ void __launch_bounds__(64) k_tick_epilogue(WorldDev w, uint32_t slot, uint32_t ncell) {
     const uint32_t lane = threadIdx.x;
+    if (w.deep_depth)  // (set again by the next tick's index build)
+        for (uint32_t c = lane; c < ncell; c += 64) w.cell_irr[c] = 0;
     unsigned long long sum = w.tot64[(size_t)lane * 16], pairs = w.tot64[(size_t)lane * 16 + 1], deferred = w.tot64[(size_t)lane * 16 + 2];
     for (int d = 32; d >= 1; d >>= 1) {
         sum += __shfl_xor(sum, d);
@@ -1730,6 +1909,6 @@ __global__ void __launch_bounds__(64) k_tick_epilogue(WorldDev w, uint32_t slot)
     w.tot64[(size_t)lane * 16 + 2] = 0;
 }
 
-void launch_tick_epilogue(hipStream_t st, WorldDev w, uint32_t slot) {
-    hipLaunchKernelGGL(k_tick_epilogue, dim3(1), dim3(64), 0, st, w, slot);
+void launch_tick_epilogue(hipStream_t st, WorldDev w, uint32_t slot, uint32_t ncell) {
+    hipLaunchKernelGGL(k_tick_epilogue, dim3(1), dim3(64), 0, st, w, slot, ncell);
 }

@@ -74,7 +74,7 @@ class DeviceArray:
 class SpatialWorld:
     def __init__(self, ctl: StaticGrid2DSpatialController, max_entities: int, max_subscribers: int,
                  max_interest_cells: int = 0, max_records: int = 0, max_handovers: int = 0, flags: int = 0,
-                 wire_max_update_len: int = 0, wire_max_full_len: int = 0):
+                 wire_max_update_len: int = 0, wire_max_full_len: int = 0, history_depth: int = 0):
         self.ctl = ctl
         self.lib = _lib.load()
         self.ctx = ctl.ctx
@@ -83,7 +83,7 @@ class SpatialWorld:
         ncell = ctl.GridCols * ctl.GridRows
         self.capq = int(max_interest_cells) if max_interest_cells else min(ncell, 256)
         cfg = WorldCfg(self.N, self.S, self.capq, int(max_records), int(max_handovers), int(flags),
-                       int(wire_max_update_len), int(wire_max_full_len))
+                       int(wire_max_update_len), int(wire_max_full_len), int(history_depth))
         _lib.check(self.ctx, self.lib.chd_world_create(self.ctx, C.byref(cfg)))
 
     # ---- population ----
@@ -232,7 +232,10 @@ class SpatialWorld:
     def tick(self, now_ns: int, upd_idx=None, upd_x=None, upd_z=None, upd_sender=None,
              cell_upd_channel=None, cell_upd_sender=None, query_sub=None,
              queries: Optional[Sequence[SpatialInterestQuery]] = None, records_cap: int = 1 << 22,
-             want_records: bool = True, pinned: bool = False) -> TickResult:
+             want_records: bool = True, pinned: bool = False, upd_arrival_ns=None, cell_upd_arrival_ns=None,
+             upd_round_off=None) -> TickResult:
+        """upd_arrival_ns / cell_upd_arrival_ns: the arrivalTime of every update (history_depth worlds; None = now_ns);
+        upd_round_off: [0, ..., n_updates], the rounds of updates (a channel's r-th update of this tick lies in round r)."""
         ti = TickIn()
         ti.now_ns = int(now_ns)
         keep = []
@@ -242,10 +245,22 @@ class SpatialWorld:
             us = None if upd_sender is None else _u32(upd_sender)
             keep += [ux, uz, ui, us]
             ti.n_updates, ti.upd_idx, ti.upd_x, ti.upd_z, ti.upd_sender = len(ux), _ptr(ui), _ptr(ux), _ptr(uz), _ptr(us)
+            if upd_arrival_ns is not None:
+                ua = np.ascontiguousarray(upd_arrival_ns, dtype=np.int64)
+                keep.append(ua)
+                ti.upd_arrival_ns = _ptr(ua)
+            if upd_round_off is not None:
+                ro = _u32(upd_round_off)
+                keep.append(ro)
+                ti.n_update_rounds, ti.upd_round_off = len(ro) - 1, _ptr(ro)
         if cell_upd_channel is not None and len(cell_upd_channel):
             cc, cs = _u32(cell_upd_channel), _u32(cell_upd_sender)
             keep += [cc, cs]
             ti.n_cell_updates, ti.cell_upd_channel, ti.cell_upd_sender = len(cc), _ptr(cc), _ptr(cs)
+            if cell_upd_arrival_ns is not None:
+                ca = np.ascontiguousarray(cell_upd_arrival_ns, dtype=np.int64)
+                keep.append(ca)
+                ti.cell_upd_arrival_ns = _ptr(ca)
         nq = 0
         if queries is not None and len(queries):
             qs = None if query_sub is None else _u32(query_sub)

@@ -497,10 +497,14 @@ static void fan_literal(orc_world *w, orc_time t, const uint32_t *cell_off_sub,
  * Interest updates: n_q entries (q_sub NULL => subscriber s = i).
  * Returns 0.
  */
-int orc_world_tick(orc_world *w, orc_time t, uint32_t n_upd, const uint32_t *idx,
-                   const double *x, const double *z, const uint32_t *sender,
-                   uint32_t n_cu, const uint32_t *cu_cell, const uint32_t *cu_sender,
-                   uint32_t n_q, const uint32_t *q_sub, const orc_query *queries) {
+/* upd_arrival / cu_arrival: arrivalTime of every update (Channel.PutMessage stamps a message when it is ENQUEUED,
+ * channel.go:296-310; OnUpdate stores that stamp, data.go:159-164): NULL = the tick's own time.  Updates are applied in array
+ * order, so an entity may appear several times (each its own Notify and its own buffer element, as the reference's handler
+ * loop). */
+int orc_world_tick_arrivals(orc_world *w, orc_time t, uint32_t n_upd, const uint32_t *idx, const double *x, const double *z,
+                            const uint32_t *sender, const orc_time *upd_arrival, uint32_t n_cu, const uint32_t *cu_cell,
+                            const uint32_t *cu_sender, const orc_time *cu_arrival, uint32_t n_q, const uint32_t *q_sub,
+                            const orc_query *queries) {
     w->nrec = 0; w->nho = 0; w->nunsub = 0; w->n_locked_abort = 0; w->nrcp = 0;
     memmove(w->stamps + 1, w->stamps, sizeof(orc_time) * 31);
     w->stamps[0] = t;
@@ -517,7 +521,7 @@ int orc_world_tick(orc_world *w, orc_time t, uint32_t n_upd, const uint32_t *idx
         uint32_t dst = cell_index(w, x[u], z[u]);
         w->cell[i] = dst; /* merged position is now the new one */
         if (sender) w->sender[i] = sender[u];
-        wbuf_push(&w->ebuf[i], t, w->sender[i], w->max_interval_ms);
+        wbuf_push(&w->ebuf[i], upd_arrival ? upd_arrival[u] : t, w->sender[i], w->max_interval_ms);
         if (src == W_INVALID || dst == W_INVALID || src == dst) continue; /* spatial.go:613-626 */
         /* GetHandoverEntities (entity.go:197-224): the notifier's handover group; a locked member empties it (:675-679) */
         int any_locked = (w->eflags[i] & 1u) != 0;
@@ -554,7 +558,7 @@ int orc_world_tick(orc_world *w, orc_time t, uint32_t n_upd, const uint32_t *idx
                 if (m != i && w->alive[m] && w->group[m] == w->group[i] && w->member[m] == src) w->member[m] = dst;
     }
     for (uint32_t u = 0; u < n_cu; u++)
-        wbuf_push(&w->cbuf[cu_cell[u]], t, cu_sender[u], w->max_interval_ms);
+        wbuf_push(&w->cbuf[cu_cell[u]], cu_arrival ? cu_arrival[u] : t, cu_sender[u], w->max_interval_ms);
 
     /* ---- 1b. who receives each handover's ChannelDataHandoverMessage (spatial.go:776-857) ----
      * srcChannelSubConns / dstChannelSubConns as they are now (Notify runs before this tick's
@@ -748,6 +752,13 @@ int orc_world_tick(orc_world *w, orc_time t, uint32_t n_upd, const uint32_t *idx
     }
     free(cell_off_sub); free(cell_off_ent); free(cell_subs); free(cell_ents);
     return 0;
+}
+
+int orc_world_tick(orc_world *w, orc_time t, uint32_t n_upd, const uint32_t *idx,
+                   const double *x, const double *z, const uint32_t *sender,
+                   uint32_t n_cu, const uint32_t *cu_cell, const uint32_t *cu_sender,
+                   uint32_t n_q, const uint32_t *q_sub, const orc_query *queries) {
+    return orc_world_tick_arrivals(w, t, n_upd, idx, x, z, sender, NULL, n_cu, cu_cell, cu_sender, NULL, n_q, q_sub, queries);
 }
 
 /* ---- accessors ---- */

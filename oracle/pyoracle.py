@@ -123,6 +123,8 @@ def lib():
     L.orc_world_remove_sub.argtypes = [C.c_void_p, C.c_uint32]
     L.orc_world_tick.argtypes = [C.c_void_p, C.c_int64, C.c_uint32, up, dp, dp, up,
                                  C.c_uint32, up, up, C.c_uint32, up, P(Query)]
+    L.orc_world_tick_arrivals.argtypes = [C.c_void_p, C.c_int64, C.c_uint32, up, dp, dp, up, P(C.c_int64),
+                                          C.c_uint32, up, up, P(C.c_int64), C.c_uint32, up, P(Query)]
     L.orc_world_nrec.restype = C.c_uint64
     L.orc_world_nrec.argtypes = [C.c_void_p]
     L.orc_world_records.argtypes = [C.c_void_p, up, up]
@@ -400,7 +402,9 @@ class World:
         lib().orc_world_remove_sub(self.h, int(s))
 
     def tick(self, t, upd_idx=None, upd_x=None, upd_z=None, upd_sender=None,
-             cu_cell=None, cu_sender=None, q_sub=None, queries=None):
+             cu_cell=None, cu_sender=None, q_sub=None, queries=None, upd_arrival=None, cu_arrival=None):
+        """upd_arrival / cu_arrival: arrivalTime per update (ns; None = t).  Updates are applied in array order; an entity may
+        appear several times."""
         n_upd = 0 if upd_x is None else len(upd_x)
         ui = None if upd_idx is None else np.ascontiguousarray(upd_idx, dtype=np.uint32)
         ux = None if upd_x is None else np.ascontiguousarray(upd_x, dtype=np.float64)
@@ -421,10 +425,12 @@ class World:
             qarr = (Query * n_q)()
             for i, qb in enumerate(queries):
                 qarr[i] = qb.q
-        self._keep = (ui, ux, uz, us, cc, cs, qs, qarr, queries)
-        rc = lib().orc_world_tick(self.h, int(t), n_upd, _p(ui, C.c_uint32), _p(ux, C.c_double), _p(uz, C.c_double),
-                                  _p(us, C.c_uint32), n_cu, _p(cc, C.c_uint32), _p(cs, C.c_uint32),
-                                  n_q, _p(qs, C.c_uint32), qarr)
+        ua = None if upd_arrival is None else np.ascontiguousarray(upd_arrival, dtype=np.int64)
+        ca = None if cu_arrival is None else np.ascontiguousarray(cu_arrival, dtype=np.int64)
+        self._keep = (ui, ux, uz, us, cc, cs, qs, qarr, queries, ua, ca)
+        rc = lib().orc_world_tick_arrivals(self.h, int(t), n_upd, _p(ui, C.c_uint32), _p(ux, C.c_double), _p(uz, C.c_double),
+                                           _p(us, C.c_uint32), _p(ua, C.c_int64), n_cu, _p(cc, C.c_uint32), _p(cs, C.c_uint32),
+                                           _p(ca, C.c_int64), n_q, _p(qs, C.c_uint32), qarr)
         self._nq = n_q
         return rc
 

@@ -1,0 +1,232 @@
+"""GPU parity of the EXACT update buffers (chd_world_cfg.history_depth; SURVEY row a12: ChannelData.updateMsgBuffer,
+data.go:53-55,149-173,225-269) against the oracle's element-for-element buffers:
+
+* arrival stamps at ENQUEUE time (channel.go:296-310 -> message.go:651 -> data.go:159-164), anywhere inside a tick interval,
+* several updates of one channel between two ticks (update rounds), each its own Notify and its own buffer element,
+* more than two senders per channel,
+* windows far older than the 32-tick ring (a NO_ACCESS subscriber that regains access after 100+ ticks),
+* the reference's eviction beyond MaxUpdateMsgBufferSize = 512 elements,
+
+record multisets per connection, handovers, entity maps and subscription state every tick, history_overflow == 0 throughout;
+one world also against the LITERAL linked-list tickData."""
+import json
+
+import numpy as np
+import pytest
+
+from channeld_amd import synth
+from oracle import pyoracle as orc
+from test_gpu_world import canon, compare_tick
+
+pytestmark = pytest.mark.gpu
+
+MS = 1_000_000
+
+
+@pytest.fixture(scope="module")
+def amd():
+    import channeld_amd
+
+    channeld_amd.load()
+    return channeld_amd
+
+
+def make_pair(amd, cfg_name, N, S, depth, flags, literal=False, seed=1, tick_ms=50, aoi_scale=1.0):
+    cfg = synth.load_config(cfg_name)
+    g = orc.grid_from_config(cfg)
+    sw = synth.SynthWorld(synth.WorldSpec(cfg, N, S, seed, tick_ms=tick_ms, aoi_scale=aoi_scale, outside_frac=0.01, locked_frac=0.02))
+    ctl = amd.StaticGrid2DSpatialController()
+    assert ctl.LoadConfig(json.dumps(cfg).encode(), strict=False) is None
+    gw = amd.SpatialWorld(ctl, N, S, flags=flags, history_depth=depth)
+    ow = orc.World(g, N, S, gw.capq, 20, 0, literal=literal)
+    ow.set_threads(4)
+    ow.spawn(np.arange(N), sw.chan_id, sw.x, sw.z, sw.flags, sw.sender)
+    gw.spawn(None, sw.chan_id, sw.x, sw.z, sw.flags, sw.sender)
+    for s in range(S):
+        ow.add_sub(s, int(sw.sub_conn[s]))
+    gw.add_subscribers(None, sw.sub_conn)
+    return cfg, sw, ctl, gw, ow
+
+
+@pytest.mark.parametrize("flags", [1, 2, 1 | 64], ids=["conn-major", "cell-major", "conn-major-1w"])
+def test_arrival_stamps_rounds_and_senders_match_the_oracle(amd, flags):
+    """Every irregularity at once, on every emit form: per-update arrival stamps anywhere in (previous tick, this tick],
+    a quarter of the ticks fully on the grid (the fast mask paths and the exact path hand over to each other), some entities
+    updated twice per tick (rounds), three alternating senders, the spatial channels' own updates with stamps, irregular
+    tick lengths."""
+    N, S = 260, 24
+    cfg, sw, ctl, gw, ow = make_pair(amd, "spatial_static_4x4.json", N, S, 64, flags, seed=0xD11)
+    rng = np.random.default_rng(11)
+    now = 0
+    total = deep_ticks = 0
+    for k in range(40):
+        sw.step()
+        prev, now = now, now + int(rng.choice([20, 50, 50, 70])) * MS
+        q = sw.queries()
+        on_grid = k % 4 == 3
+        # round 0: every entity; round 1: a second update of a few of them (a step further along)
+        second = np.sort(rng.choice(N, 0 if on_grid else 30, replace=False)).astype(np.uint32)
+        x1, z1 = sw.x.copy(), sw.z.copy()
+        sw.step()
+        idx = np.concatenate([np.arange(N, dtype=np.uint32), second])
+        ux = np.concatenate([x1, sw.x[second]])
+        uz = np.concatenate([z1, sw.z[second]])
+        if len(second) == 0:
+            sw.x, sw.z = x1, z1
+        else:  # (entities without a second update stay where round 0 put them)
+            keep = np.ones(N, dtype=bool)
+            keep[second] = False
+            sw.x[keep], sw.z[keep] = x1[keep], z1[keep]
+        a0 = np.full(N, now, dtype=np.int64) if on_grid else rng.integers(prev + 1, now + 1, N).astype(np.int64)
+        a1 = np.minimum(a0[second] + rng.integers(1, 5 * MS, len(second)), now).astype(np.int64)
+        arr = np.concatenate([a0, a1])
+        snd = np.concatenate([sw.sender, sw.sender[second]]).astype(np.uint32)
+        if not on_grid:  # a third and fourth sender on some channels
+            flip = rng.random(len(snd)) < 0.2
+            snd = np.where(flip, rng.choice([901, 902, int(sw.sub_conn[0])], len(snd)), snd).astype(np.uint32)
+        ncu = int(rng.integers(0, 4))
+        cu = (0x10000 + rng.choice(16, ncu, replace=False)).astype(np.uint32)
+        cus = rng.choice([1, 2, 903], ncu).astype(np.uint32)
+        cua = np.sort(rng.integers(prev + 1, now + 1, ncu)).astype(np.int64)
+        ow.tick(now, idx, ux, uz, snd, cu - 0x10000, cus, None, q, upd_arrival=arr, cu_arrival=cua)
+        res = gw.tick(now, upd_idx=idx, upd_x=ux, upd_z=uz, upd_sender=snd, cell_upd_channel=cu, cell_upd_sender=cus,
+                      queries=q, upd_arrival_ns=arr, cell_upd_arrival_ns=cua, upd_round_off=[0, N, N + len(second)])
+        compare_tick(k, res, ow, S, check_pairs=range(0, S, 5), gw=gw)
+        total += res.n_records
+    cell, member = gw.entity_state()
+    ocell, omember = ow.entity_state()
+    to_id = lambda a: np.where(a == 0xFFFFFFFF, 0, a + 0x10000).astype(np.uint32)
+    assert np.array_equal(cell, to_id(ocell)) and np.array_equal(member, to_id(omember))
+    assert total > 10_000
+
+
+def test_exact_buffers_against_the_literal_list_walk(amd):
+    """... and the same kind of world against the oracle's LITERAL mode: every channel an orc_channel whose buffer holds the
+    given arrival stamps, orc_tick_data = the linked-list walk of data.go:175-291."""
+    N, S = 120, 10
+    cfg, sw, ctl, gw, ow = make_pair(amd, "spatial_static_2x2.json", N, S, 64, 1, literal=True, seed=0xD12)
+    rng = np.random.default_rng(12)
+    now = 0
+    for k in range(24):
+        sw.step()
+        prev, now = now, now + int(rng.choice([30, 50, 80])) * MS
+        arr = rng.integers(prev + 1, now + 1, N).astype(np.int64)
+        q = sw.queries()
+        ow.tick(now, None, sw.x, sw.z, None, None, None, None, q, upd_arrival=arr)
+        res = gw.tick(now, upd_x=sw.x, upd_z=sw.z, queries=q, upd_arrival_ns=arr)
+        compare_tick(k, res, ow, S, check_pairs=range(S), gw=gw)
+    assert ow.literal_mismatch() == 0
+
+
+def test_an_update_enqueued_before_a_window_edge_belongs_to_that_window(amd):
+    """an update enqueued at 249 ms and handled by the tick at 260 ms is delivered in window [200, 250] AT that
+    tick (data.go:247) — a batch stamped with its tick's time would deliver it one fan-out interval later."""
+    cfg, sw, ctl, gw, ow = make_pair(amd, "spatial_static_2x2.json", 4, 1, 32, 1, seed=3)
+    x = np.array([-100.0, -150.0, 120.0, 100.0])
+    z = np.array([-100.0, -120.0, 130.0, 100.0])
+    chan = int(orc.channel_ids(orc.grid_from_config(cfg), x[:1], z[:1])[0])
+    opts = dict(slot=0, channel=chan, fanout_interval_ms=50, fanout_delay_ms=0, skip_self_update_fanout=0)
+    gw.set_sub_options(100 * MS, [opts])
+    ow.set_sub_options(100 * MS, 0, chan, fanout_interval_ms=50, fanout_delay_ms=0, skip_self_update_fanout=0)
+    seen = {}
+    for now_ms, upd in ((100, None), (150, None), (160, None), (210, None), (260, 249), (310, None), (360, None)):
+        now = now_ms * MS
+        if upd is None:
+            ow.tick(now)
+            res = gw.tick(now)
+        else:
+            i, a = np.array([0], dtype=np.uint32), np.array([upd * MS], dtype=np.int64)
+            ow.tick(now, i, x[:1], z[:1], None, upd_arrival=a)
+            res = gw.tick(now, upd_idx=i, upd_x=x[:1], upd_z=z[:1], upd_arrival_ns=a)
+        oc, och = ow.records()
+        assert np.array_equal(canon(res.records["conn"], res.records["channel"]), canon(oc, och)), now_ms
+        assert res.history_overflow == 0
+        seen[now_ms] = [int(c) for c in res.records["channel"] if c >= 0x80000]
+    assert seen[260] == [0x80000]   # window [200, 250] holds the update that was enqueued at 249
+    assert seen[310] == [] and seen[360] == []
+
+
+def test_a_subscriber_that_regains_access_after_100_ticks_catches_up_exactly(amd):
+    """NO_ACCESS subscriptions are skipped but stay queued (data.go:194-197): when access comes back, tickData's catch-up
+    loop walks every fan-out interval since and the buffers decide window by window — far beyond the 32-tick ring."""
+    N, S = 150, 12
+    cfg, sw, ctl, gw, ow = make_pair(amd, "spatial_static_2x2.json", N, S, 256, 1 | 64, seed=0xD14)
+    rng = np.random.default_rng(14)
+    g = orc.grid_from_config(cfg)
+    now = 0
+    blocked = [1, 4, 7]
+    for k in range(140):
+        sw.step()
+        prev, now = now, now + 50 * MS
+        q = sw.queries()
+        upd = np.sort(rng.choice(N, N // 2, replace=False)).astype(np.uint32)  # sparse updates: windows differ per entity
+        arr = np.where(rng.random(len(upd)) < 0.5, now, rng.integers(prev + 1, now + 1, len(upd))).astype(np.int64)
+        ow.tick(now, upd, sw.x[upd], sw.z[upd], None, None, None, None, q, upd_arrival=arr)
+        res = gw.tick(now, upd_idx=upd, upd_x=sw.x[upd], upd_z=sw.z[upd], queries=q, upd_arrival_ns=arr, records_cap=1 << 22)
+        compare_tick(k, res, ow, S, check_pairs=blocked, gw=gw)
+        if k == 8 or k == 118:
+            access = 0 if k == 8 else 1
+            for s in blocked:
+                ch = gw.subscriptions(s)[0]
+                gw.set_sub_options(now, [dict(slot=s, channel=int(c), data_access=access) for c in ch])
+                for c in ch:
+                    ow.set_sub_options(now, s, int(c), data_access=access)
+        if k == 119:
+            assert res.n_records > 5_000  # the catch-up of three connections over 110 ticks
+
+
+def test_the_reference_eviction_beyond_512_buffered_updates(amd):
+    """MaxUpdateMsgBufferSize (data.go:53-55,165-171): beyond 512 elements the oldest goes once it is older than
+    maxFanOutIntervalMs, one per push.  A subscriber that was blocked for 620 ticks sees, in the reference, only what the
+    buffer still holds — and so here (history_depth 1024)."""
+    N, S = 12, 3
+    cfg, sw, ctl, gw, ow = make_pair(amd, "spatial_static_2x2.json", N, S, 1024, 1, seed=0xD15, tick_ms=10)
+    now = 0
+    rng = np.random.default_rng(15)
+    for k in range(660):
+        sw.step()
+        prev, now = now, now + 10 * MS
+        q = sw.queries()
+        arr = rng.integers(prev + 1, now + 1, N).astype(np.int64)
+        ow.tick(now, None, sw.x, sw.z, None, None, None, None, q, upd_arrival=arr)
+        res = gw.tick(now, upd_x=sw.x, upd_z=sw.z, queries=q, upd_arrival_ns=arr, records_cap=1 << 22)
+        if k < 6 or k > 625 or k % 50 == 0:
+            compare_tick(k, res, ow, S, check_pairs=range(S), gw=gw)
+        else:
+            assert res.history_overflow == 0 and res.overflow == 0 and res.n_records == len(ow.records()[0])
+        if k == 5 or k == 630:
+            access = 0 if k == 5 else 1
+            ch = gw.subscriptions(2)[0]
+            gw.set_sub_options(now, [dict(slot=2, channel=int(c), data_access=access) for c in ch])
+            for c in ch:
+                ow.set_sub_options(now, 2, int(c), data_access=access)
+
+
+def test_a_short_buffer_says_what_it_dropped(amd):
+    """history_depth smaller than what a window reaches back to: never silently short — history_overflow counts it."""
+    N, S = 12, 2
+    cfg, sw, ctl, gw, ow = make_pair(amd, "spatial_static_2x2.json", N, S, 32, 1, seed=0xD16, tick_ms=10)
+    now = 0
+    flagged = False
+    for k in range(80):
+        sw.step()
+        now += 10 * MS
+        q = sw.queries()
+        res = gw.tick(now, upd_x=sw.x, upd_z=sw.z, queries=q, upd_arrival_ns=np.full(N, now - 1, dtype=np.int64))
+        if k == 5 or k == 70:
+            ch = gw.subscriptions(1)[0]
+            gw.set_sub_options(now, [dict(slot=1, channel=int(c), data_access=0 if k == 5 else 1) for c in ch])
+        flagged = flagged or res.history_overflow != 0
+        if k < 70:
+            assert res.history_overflow == 0
+    assert flagged
+
+
+def test_arrival_stamps_need_history_depth(amd):
+    cfg, sw, ctl, gw, ow = make_pair(amd, "spatial_static_2x2.json", 8, 2, 0, 1, seed=4)
+    with pytest.raises(amd.ChdError):
+        gw.tick(50 * MS, upd_x=sw.x, upd_z=sw.z, upd_arrival_ns=np.full(8, 49 * MS, dtype=np.int64))
+    ctl2 = amd.StaticGrid2DSpatialController()
+    assert ctl2.LoadConfig(json.dumps(cfg).encode(), strict=False) is None
+    with pytest.raises(amd.ChdError):  # below the ring's own depth
+        amd.SpatialWorld(ctl2, 8, 2, history_depth=8)
