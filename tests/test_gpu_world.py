@@ -42,8 +42,8 @@ def canon(conn, chan):
 def compare_tick(k, res, ow, S, id_start=0x10000, check_pairs=None, gw=None):
     # handovers (order is not defined in the reference: compare as sets keyed by entity)
     ent, src, dst, ssrc, sdst = ow.handovers()
-    got = np.sort(res.handovers, order="entity")
-    o = np.argsort(ent)
+    got = np.sort(res.handovers, order=["entity", "src", "dst"])  # (an entity can hand over twice in a tick: update rounds)
+    o = np.lexsort((dst, src, ent))
     assert len(got) == len(ent), f"tick {k}: {len(got)} handovers vs oracle {len(ent)}"
     assert np.array_equal(got["entity"], ent[o]) and np.array_equal(got["src"], src[o]) and np.array_equal(got["dst"], dst[o])
     assert np.array_equal(got["src_server"], ssrc[o]) and np.array_equal(got["dst_server"], sdst[o])
