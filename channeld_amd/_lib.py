@@ -48,7 +48,7 @@ SYMBOLS = (
     "chd_set_stream", "chd_shard_spawn", "chd_shard_ingest", "chd_shard_import", "chd_shard_fanout",
     "chd_shard_get_entities", "chd_shard_halo_layout", "chd_shard_interest",
     "chd_handover_recipients", "chd_adjacent_recipients", "chd_wire_set_payloads", "chd_wire_build", "chd_wire_fetch",
-    "chd_tick_digest", "chd_host_alloc", "chd_host_free", "chd_subs_set_options", "chd_subs_get_options", "chd_world_set_entity_groups", "chd_world_set_handover_lists", "chd_wire_set_type_url", "chd_handover_messages",
+    "chd_tick_digest", "chd_tick_fetch_segments", "chd_host_alloc", "chd_host_free", "chd_subs_set_options", "chd_subs_get_options", "chd_world_set_entity_groups", "chd_world_set_handover_lists", "chd_wire_set_type_url", "chd_handover_messages",
 )
 
 
@@ -169,6 +169,20 @@ class RecordsDigest(C.Structure):
     _fields_ = [("count", C.c_uint64), ("sum", C.c_uint64), ("xor_", C.c_uint64), ("sum_masked", C.c_uint64)]
 
 
+class FanoutSegment(C.Structure):
+    _fields_ = [("channel", C.c_uint32), ("off", C.c_uint32), ("n_info", C.c_uint32), ("n_records", C.c_uint32)]
+
+
+class SegmentsOut(C.Structure):
+    _fields_ = [("segments", _vp), ("segments_cap", C.c_uint64), ("n_segments", C.c_uint64),
+                ("conn_seg_off", _u32p),
+                ("columns", _u32p), ("columns_cap", C.c_uint64), ("n_columns", C.c_uint64),
+                ("records", _vp), ("records_cap", C.c_uint64), ("n_explicit", C.c_uint64),
+                ("conn_rec_off", _u64p), ("n_records", C.c_uint64)]
+
+
+SEG_FIRST, SEG_NONE, SEG_EXPLICIT = 1 << 22, 1 << 23, 1 << 24
+
 _lib = None
 
 
@@ -232,6 +246,7 @@ def load():
     L.chd_handover_recipients.argtypes = [C.c_void_p, _u32p, _u32p, _u8p, C.c_uint64, P(C.c_uint64)]
     L.chd_adjacent_recipients.argtypes = [C.c_void_p, C.c_uint32, _u32p, _u32p, _u32p, _u32p, _u32p, _u32p, C.c_uint64]
     L.chd_tick_digest.argtypes = [C.c_void_p, P(RecordsDigest), _u64p]
+    L.chd_tick_fetch_segments.argtypes = [C.c_void_p, P(SegmentsOut)]
     L.chd_subs_set_options.argtypes = [C.c_void_p, C.c_int64, C.c_uint32, P(SubOptions), _u8p, _i32p]
     L.chd_subs_get_options.argtypes = [C.c_void_p, C.c_uint32, _u8p, _u8p, P(C.c_uint32)]
     L.chd_host_alloc.argtypes = [C.c_void_p, C.c_uint64, P(C.c_void_p)]

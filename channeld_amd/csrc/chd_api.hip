@@ -68,6 +68,11 @@ struct World {
     uint4 *pb_seg_desc[2] = {nullptr, nullptr}, *pb_seg_desc2[2] = {nullptr, nullptr};
     chd_fanout_rec *pb_recs[2] = {nullptr, nullptr};
     hipEvent_t ev_stages_done = nullptr, ev_stages_all = nullptr, ev_rec_sync = nullptr, ev_emit_done[2] = {nullptr, nullptr};
+    bool last_desc = false;            // the last tick took the descriptor path (k_fanout_plan_seg's descriptors are this tick's)
+    uint32_t *seg_cnt = nullptr;       // [S + 1] chd_tick_fetch_segments: segments per connection -> offsets
+    uint64_t *seg_exp = nullptr;       // [S + 1] explicit records per connection -> offsets
+    chd_fanout_segment *seg_stage = nullptr; size_t seg_stage_cap = 0;
+    chd_fanout_rec *seg_rec_stage = nullptr; size_t seg_rec_stage_cap = 0;
     uint32_t *ho_rcp_off = nullptr;    // [handovers_cap + 1] recipients of handover h: [off[h], off[h+1])
     uint32_t *ho_rcp_conn = nullptr;   // connection ids
     uint8_t *ho_rcp_kind = nullptr;    // CHD_HO_*
@@ -283,6 +288,82 @@ __global__ void __launch_bounds__(256) k_rec_cnt(WorldDev w) {
     if ((threadIdx.x & 63u) == 0) w.rec_cnt[s] = sum;
 }
 
+// ---- chd_tick_fetch_segments: the fan-out as segment descriptors (see include/chd_spatial.h) ----
+// pass 1 (fill == 0): per connection the number of segments and of explicit records; pass 2: write them.
+// One wave per connection.  Simple subscriptions = the descriptors of k_fanout_plan_seg (have_desc); explicit = every other
+// subscription that emitted records this tick.  LDS: one bit per subscription index (capq <= 65534).
+#define SEG_BITMAP_WORDS 2048
+__global__ void __launch_bounds__(64) k_segments(DevGrid g, WorldDev w, int have_desc, int fill, uint32_t *nseg, unsigned long long *nexp,
+                                                 chd_fanout_segment *seg_out, chd_fanout_rec *rec_out) {
+    __shared__ uint32_t simple_bits[SEG_BITMAP_WORDS];
+    const uint32_t s = blockIdx.x, lane = threadIdx.x;
+    const uint32_t cnt = w.sub_alive[s] ? w.pair_cnt[s] : 0u;
+    const size_t pbase = (size_t)s * w.capq;
+    const bool served = w.rec_ub[s + 1] <= w.recs_cap;  // (else the connection was skipped this tick and flagged)
+    const uint32_t ns = (have_desc && served && cnt) ? w.n_simple[s] : 0u;
+    for (uint32_t k = lane; k < (cnt + 31) / 32; k += 64) simple_bits[k] = 0;
+    __syncthreads();
+    const uint32_t seg0 = fill ? nseg[s] : 0u;
+    const unsigned long long exp0 = fill ? nexp[s] : 0ull;
+    for (uint32_t k = lane; k < ns; k += 64) {
+        const uint4 d = w.seg_desc[pbase + k], d2 = w.seg_desc2[pbase + k];
+        atomicOr(&simple_bits[d2.y >> 5], 1u << (d2.y & 31u));
+        if (fill) {
+            const uint32_t nw = d.w & 7u;
+            uint32_t info = d.z & 0x3FFFFFu, nrec = (d.w & 8u) ? d.z + 1u : 0u;
+            if (d.w & 8u) info |= CHD_SEG_FIRST;
+            if (d.w & 16u) info |= CHD_SEG_NONE;
+            info |= nw << 25;
+            for (uint32_t j = 0; j < nw; j++) {
+                if ((d.w >> (8 + j)) & 1u) { info |= CHD_SEG_OWN(j); nrec += 1u; }
+                if (!(d.w & 16u)) nrec += d.z;
+            }
+            chd_fanout_segment o;
+            o.channel = d2.x + g.id_start; o.off = d.y; o.n_info = info; o.n_records = nrec;
+            seg_out[seg0 + k] = o;
+        }
+    }
+    __syncthreads();
+    uint32_t n_explicit_seg = 0;
+    unsigned long long n_explicit_rec = 0;
+    for (uint32_t p0 = 0; p0 < cnt; p0 += 64) {
+        const uint32_t p = p0 + lane;
+        uint32_t n = 0;
+        if (p < cnt && served && !((simple_bits[p >> 5] >> (p & 31u)) & 1u)) n = w.pair_nrec[pbase + p];
+        const uint64_t m = __ballot(n != 0);
+        // exclusive prefix of the record counts over the wave
+        unsigned long long inc = n;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const unsigned long long o = __shfl_up(inc, d);
+            if ((int)lane >= d) inc += o;
+        }
+        if (fill && n) {
+            const unsigned long long at = n_explicit_rec + inc - n;
+            chd_fanout_segment o;
+            o.channel = w.pair_cell[pbase + p] + g.id_start;
+            o.off = (uint32_t)at; o.n_info = CHD_SEG_EXPLICIT; o.n_records = n;
+            seg_out[seg0 + ns + n_explicit_seg + mask_rank(m)] = o;
+        }
+        if (fill) {
+            // the wave copies the segments' records together, one segment after the other
+            for (uint64_t mm = m; mm; mm &= mm - 1) {
+                const int src = __ffsll((unsigned long long)mm) - 1;
+                const uint32_t pn = (uint32_t)__shfl((int)n, src);
+                const unsigned long long pat = n_explicit_rec + __shfl(inc, src) - pn;
+                const chd_fanout_rec *from = w.recs + w.rec_ub[s] + w.pair_rel[pbase + p0 + (uint32_t)src];
+                for (uint32_t k = lane; k < pn; k += 64) rec_out[exp0 + pat + k] = from[k];
+            }
+        }
+        n_explicit_seg += (uint32_t)__popcll(m);
+        n_explicit_rec += __shfl(inc, 63);
+    }
+    if (!fill && lane == 0) {
+        nseg[s] = ns + n_explicit_seg;
+        nexp[s] = n_explicit_rec;
+    }
+}
+
 __global__ void __launch_bounds__(256) k_widen(const uint32_t *in, uint64_t *out, uint32_t n) {
     uint32_t i = blockIdx.x * 256u + threadIdx.x;
     if (i < n) out[i] = in[i];
@@ -427,6 +508,8 @@ void chd_destroy(chd_ctx *ctx) {
     for (auto &e : ctx->w.ev_mig) if (e) (void)hipEventDestroy(e);
     for (void *b : ctx->w.grp_buf) if (b) (void)hipFree(b);
     if (ctx->w.recs_dense) (void)hipFree(ctx->w.recs_dense);
+    if (ctx->w.seg_stage) (void)hipFree(ctx->w.seg_stage);
+    if (ctx->w.seg_rec_stage) (void)hipFree(ctx->w.seg_rec_stage);
     if (ctx->w.list_dense) (void)hipFree(ctx->w.list_dense);
     if (ctx->w.x.bytes) (void)hipFree(ctx->w.x.bytes);
     for (auto &b : ctx->scratch)
@@ -1249,6 +1332,7 @@ static int tick_locked(chd_ctx *ctx, const chd_tick_in *in) {
     W.full_streak = (W.n_live && in->n_updates >= W.n_live && in->n_update_rounds <= 1) ? std::min(W.full_streak + 1u, 1u << 20) : 0u;
     d.seg_off = (!d.one_wave_emit && W.full_streak < 2u) ? 1u : 0u;
     const bool pipe = W.pipe_on && fanout_seg_path(d);
+    W.last_desc = fanout_seg_path(d);
     hipStream_t st = ctx->stream;
     hipStream_t bs = pipe ? ctx->aux_stream : st;
     const uint32_t par = r.cur_tick & 1u;
@@ -1539,6 +1623,67 @@ int chd_tick_fetch(chd_ctx *ctx, chd_tick_out *out) {
     std::lock_guard<std::mutex> lk(ctx->mu);
     TRY(bind(ctx));
     return fetch_locked(ctx, out);
+}
+
+int chd_tick_fetch_segments(chd_ctx *ctx, chd_segments_out *out) {
+    NEED_WORLD();
+    if (!out || !out->conn_seg_off || !out->conn_rec_off) return fail(ctx, CHD_E_INVAL, "chd_tick_fetch_segments: NULL output");
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    TRY(bind(ctx));
+    World &W = ctx->w;
+    WorldDev &d = W.d;
+    if (!W.ticked) return fail(ctx, CHD_E_STATE, "no tick to fetch");
+    if (d.capq > 32u * SEG_BITMAP_WORDS) return fail(ctx, CHD_E_TOO_LARGE, "chd_tick_fetch_segments: max_interest_cells %u > %u", d.capq, 32u * SEG_BITMAP_WORDS);
+    if ((uint64_t)d.S * d.capq > 0xFFFFFFFFull) return fail(ctx, CHD_E_TOO_LARGE, "chd_tick_fetch_segments: more than 2^32 subscriptions");
+    hipStream_t st = ctx->stream;
+    if (!W.seg_cnt) {
+        TRY(walloc(ctx, &W.seg_cnt, (size_t)d.S + 1));
+        TRY(walloc(ctx, &W.seg_exp, (size_t)d.S + 1));
+    }
+    hipLaunchKernelGGL(k_segments, dim3(d.S), dim3(64), 0, st, ctx->g, d, W.last_desc ? 1 : 0, 0, W.seg_cnt, (unsigned long long *)W.seg_exp,
+                       (chd_fanout_segment *)nullptr, (chd_fanout_rec *)nullptr);
+    launch_scan_u32_inplace(st, W.seg_cnt, d.S);
+    launch_scan_u64_inplace(st, W.seg_exp, d.S);
+    TRY(after_launch(ctx));
+    uint32_t nseg = 0;
+    uint64_t nexp = 0, ringrow[8];
+    TRY(down(ctx, &nseg, W.seg_cnt + d.S, sizeof nseg));
+    TRY(down(ctx, &nexp, W.seg_exp + d.S, sizeof nexp));
+    TRY(down(ctx, ringrow, d.tick_ring + (size_t)(ctx->ring.cur_tick % TICK_RING) * 8, sizeof ringrow));
+    HIPCHK(hipStreamSynchronize(st));
+    // the columns a descriptor may point into: the own cell tables (+ the neighbours' border entities on a sharded rank)
+    const uint64_t ncol = W.last_desc ? (uint64_t)d.N + d.ghost_cap : 0ull;
+    out->n_segments = nseg;
+    out->n_explicit = nexp;
+    out->n_columns = ncol;
+    out->n_records = ringrow[0];
+    if (nseg > out->segments_cap || nexp > out->records_cap || ncol > out->columns_cap || (nseg && !out->segments) || (nexp && !out->records) ||
+        (ncol && !out->columns))
+        return fail(ctx, CHD_E_CAPACITY, "chd_tick_fetch_segments: %u segments, %llu explicit records, %llu column entries needed", nseg,
+                    (unsigned long long)nexp, (unsigned long long)ncol);
+    if (W.seg_stage_cap < nseg) {
+        if (W.seg_stage) HIPCHK(hipFree(W.seg_stage));
+        W.seg_stage = nullptr;
+        W.seg_stage_cap = nseg + nseg / 4 + 1024;
+        HIPCHK(hipMalloc((void **)&W.seg_stage, W.seg_stage_cap * sizeof(chd_fanout_segment)));
+    }
+    if (W.seg_rec_stage_cap < nexp) {
+        if (W.seg_rec_stage) HIPCHK(hipFree(W.seg_rec_stage));
+        W.seg_rec_stage = nullptr;
+        W.seg_rec_stage_cap = nexp + nexp / 4 + 1024;
+        HIPCHK(hipMalloc((void **)&W.seg_rec_stage, W.seg_rec_stage_cap * sizeof(chd_fanout_rec)));
+    }
+    hipLaunchKernelGGL(k_segments, dim3(d.S), dim3(64), 0, st, ctx->g, d, W.last_desc ? 1 : 0, 1, W.seg_cnt, (unsigned long long *)W.seg_exp,
+                       W.seg_stage, W.seg_rec_stage);
+    TRY(after_launch(ctx));
+    TRY(down(ctx, out->conn_seg_off, W.seg_cnt, sizeof(uint32_t) * ((size_t)d.S + 1)));
+    TRY(down(ctx, out->conn_rec_off, W.seg_exp, sizeof(uint64_t) * ((size_t)d.S + 1)));
+    TRY(down(ctx, out->segments, W.seg_stage, sizeof(chd_fanout_segment) * (size_t)nseg));
+    TRY(down(ctx, out->records, W.seg_rec_stage, sizeof(chd_fanout_rec) * nexp));
+    if (ncol) TRY(down(ctx, out->columns, d.ce_chan_view, sizeof(uint32_t) * ncol));
+    HIPCHK(hipStreamSynchronize(st));
+    if (ringrow[7] & 0xFFFFFFFFull) return fail(ctx, CHD_E_CAPACITY, "tick output truncated (overflow mask 0x%x)", (uint32_t)ringrow[7]);
+    return CHD_OK;
 }
 
 int chd_tick_digest(chd_ctx *ctx, chd_records_digest *total, uint64_t *conn_sum) {
@@ -1885,6 +2030,8 @@ int chd_shard_fanout(chd_ctx *ctx, const void *d_halo_recv, uint32_t world, cons
     }
     // the neighbours' border bands join the own tables as ghost entries: ONE local table over region + halo, so the
     // fan-out takes the same kernels (and fast paths) as on a single GPU
+    d.seg_off = 0;
+    W.last_desc = fanout_seg_path(d);
     launch_halo_unpack(st, ctx->g, d, world > 1 ? W.halo_rank : 0u, world, ctx->g.border, (const unsigned char *)d_halo_recv,
                        W.d_halo_recv_off, W.d_ghost_off);
     d.ce_view = d.ce; d.ce8_view = d.ce8; d.ce_chan_view = d.ce_chan; d.ce_sprev_view = d.ce_sprev; d.ce_sprev_stride = 0;

@@ -18,6 +18,44 @@ from ._lib import AoiQuery, FanoutRec, HandoverRec, TickIn, TickOut, TickStats, 
 from .controller import StaticGrid2DSpatialController, SpatialInterestQuery, pack_queries, _f64, _ptr, _u32
 
 REC_DTYPE = np.dtype([("conn", np.uint32), ("channel", np.uint32)])
+
+
+def expand_segments(seg: dict, conn_ids) -> np.ndarray:
+    """What a host does with chd_tick_fetch_segments' output (include/chd_spatial.h: chd_fanout_segment): the fan-out records,
+    grouped per connection slot.  numpy, vectorised per segment kind — for tests and measurements; a gateway would write its
+    sockets while it walks the segments instead of materialising records."""
+    S = len(seg["conn_seg_off"]) - 1
+    segs, cols, recs = seg["segments"], seg["columns"], seg["records"]
+    out = np.empty(seg["n_records"], dtype=REC_DTYPE)
+    at = 0
+    slot_of = np.repeat(np.arange(S, dtype=np.int64), np.diff(seg["conn_seg_off"].astype(np.int64)))
+    conn_ids = np.asarray(conn_ids, dtype=np.uint32)
+    for k in range(len(segs)):
+        g = segs[k]
+        s = int(slot_of[k])
+        conn, info, n, ch = np.uint32(conn_ids[s]), int(g["n_info"]), int(g["n_info"]) & 0x3FFFFF, g["channel"]
+        if info & _lib.SEG_EXPLICIT:
+            a = int(seg["conn_rec_off"][s]) + int(g["off"])
+            m = int(g["n_records"])
+            out[at: at + m] = recs[a: a + m]
+            at += m
+            continue
+        col = cols[int(g["off"]): int(g["off"]) + n]
+        if info & _lib.SEG_FIRST:
+            out[at] = (conn | np.uint32(0x80000000), ch)
+            out["conn"][at + 1: at + 1 + n] = conn | np.uint32(0x80000000)
+            out["channel"][at + 1: at + 1 + n] = col
+            at += n + 1
+        for j in range((info >> 25) & 7):
+            if info & (1 << (28 + j)):
+                out[at] = (conn, ch)
+                at += 1
+            if not info & _lib.SEG_NONE:
+                out["conn"][at: at + n] = conn
+                out["channel"][at: at + n] = col
+                at += n
+    assert at == seg["n_records"], (at, seg["n_records"])
+    return out
 HANDOVER_DTYPE = np.dtype([("entity", np.uint32), ("channel", np.uint32), ("src", np.uint32), ("dst", np.uint32),
                            ("src_server", np.uint32), ("dst_server", np.uint32)])
 assert REC_DTYPE.itemsize == C.sizeof(FanoutRec) and HANDOVER_DTYPE.itemsize == C.sizeof(HandoverRec)
@@ -306,6 +344,39 @@ class SpatialWorld:
         if rc != _lib.OK and (check or rc != _lib.E_CAPACITY):
             _lib.check(self.ctx, rc)
         return self._result(o, nq)
+
+    SEG_DTYPE = np.dtype([("channel", np.uint32), ("off", np.uint32), ("n_info", np.uint32), ("n_records", np.uint32)])
+
+    def fetch_segments(self, pinned: bool = True):
+        """The last tick's fan-out in its compact form (chd_tick_fetch_segments): dict(segments SEG_DTYPE[], conn_seg_off
+        u32[S+1], columns u32[], records REC_DTYPE[] (the explicit segments'), conn_rec_off u64[S+1], n_records).  Buffers
+        (page-locked with pinned=True) are allocated once, grown on CHD_E_CAPACITY, and reused: the arrays returned are
+        views into them, valid until the next call."""
+        alloc = self.host_array if pinned else (lambda n, dt: np.zeros(n, dtype=dt))
+        b = getattr(self, "_seg_bufs", None)
+        if b is None:
+            b = self._seg_bufs = dict(seg=alloc(max(self.S * 8, 1024), self.SEG_DTYPE), off=alloc(self.S + 1, np.uint32),
+                                      col=alloc(self.N + 1024, np.uint32), rec=alloc(1 << 16, REC_DTYPE), roff=alloc(self.S + 1, np.uint64))
+        for _ in range(2):
+            so = _lib.SegmentsOut()
+            so.segments, so.segments_cap = b["seg"].ctypes.data_as(C.c_void_p), len(b["seg"])
+            so.conn_seg_off = _ptr(b["off"])
+            so.columns, so.columns_cap = _ptr(b["col"]), len(b["col"])
+            so.records, so.records_cap = b["rec"].ctypes.data_as(C.c_void_p), len(b["rec"])
+            so.conn_rec_off = _ptr(b["roff"])
+            rc = self.lib.chd_tick_fetch_segments(self.ctx, C.byref(so))
+            grow = rc == _lib.E_CAPACITY and (so.n_segments > so.segments_cap or so.n_columns > so.columns_cap or so.n_explicit > so.records_cap)
+            if not grow:
+                break
+            if so.n_segments > so.segments_cap:
+                b["seg"] = alloc(int(so.n_segments * 1.25) + 1024, self.SEG_DTYPE)
+            if so.n_columns > so.columns_cap:
+                b["col"] = alloc(int(so.n_columns) + 1024, np.uint32)
+            if so.n_explicit > so.records_cap:
+                b["rec"] = alloc(int(so.n_explicit * 1.25) + 1024, REC_DTYPE)
+        _lib.check(self.ctx, rc)
+        return dict(segments=b["seg"][: so.n_segments], conn_seg_off=b["off"], columns=b["col"][: so.n_columns],
+                    records=b["rec"][: so.n_explicit], conn_rec_off=b["roff"], n_records=int(so.n_records))
 
     def digest(self, per_connection: bool = True):
         """Order-independent digest of the last tick's fan-out records, computed on the device:

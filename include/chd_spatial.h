@@ -419,6 +419,47 @@ typedef struct {
 } chd_records_digest;
 int chd_tick_digest(chd_ctx *ctx, chd_records_digest *total, uint64_t *conn_sum);
 
+/* ------------------------------------------------------------------ */
+/* The COMPACT form of a tick's fan-out: what a gateway needs to write  */
+/* its sockets, without the expanded records crossing PCIe (8 B per     */
+/* message: 644 MB per tick at BASELINE config B, against ~4 MB here).  */
+/* ------------------------------------------------------------------ */
+
+/* One segment = one (connection, spatial channel) subscription that fanned out this tick.  Most segments are PLAIN COPIES
+ * of the cell's entity-channel column (every entity of the cell has an update inside every due window, or this is the first
+ * fan-out): they travel as a reference into `columns` and expand on the host to
+ *     CHD_SEG_FIRST : {conn | CHD_REC_FULL, channel}, then {conn | CHD_REC_FULL, columns[off + k]} for k < n
+ *     then, for window j < CHD_SEG_NWIN(n_info): {conn, channel} if bit CHD_SEG_OWN(j) is set (the spatial channel's own
+ *                     update passes window j), and, unless CHD_SEG_NONE, {conn, columns[off + k]} for k < n
+ * (conn = the ConnectionId of the slot, which the host registered itself).  Everything else — subscriptions that needed a
+ * per-entity decision — is CHD_SEG_EXPLICIT: records[conn_rec_off[slot] + off .. + n_records) hold its records as they are. */
+#define CHD_SEG_N(n_info) ((n_info) & 0x3FFFFFu)            /* entities of the cell (explicit: unused) */
+#define CHD_SEG_FIRST (1u << 22)
+#define CHD_SEG_NONE (1u << 23)
+#define CHD_SEG_EXPLICIT (1u << 24)
+#define CHD_SEG_NWIN(n_info) (((n_info) >> 25) & 7u)
+#define CHD_SEG_OWN(j) (1u << (28 + (j)))
+typedef struct {
+    uint32_t channel;   /* the spatial channel of the subscription */
+    uint32_t off;       /* first entry in `columns`; CHD_SEG_EXPLICIT: first record, relative to conn_rec_off[slot] */
+    uint32_t n_info;    /* CHD_SEG_* */
+    uint32_t n_records; /* records the segment expands to */
+} chd_fanout_segment;   /* 16 bytes */
+
+typedef struct {
+    chd_fanout_segment *segments; uint64_t segments_cap; uint64_t n_segments;
+    uint32_t *conn_seg_off;   /* max_subscribers + 1: slot s owns segments [conn_seg_off[s], conn_seg_off[s+1]) */
+    uint32_t *columns; uint64_t columns_cap; uint64_t n_columns;  /* the tick's cell-sorted entity channel ids */
+    chd_fanout_rec *records; uint64_t records_cap; uint64_t n_explicit;  /* the explicit segments' records, per slot */
+    uint64_t *conn_rec_off;   /* max_subscribers + 1: slot s's explicit records start at conn_rec_off[s] */
+    uint64_t n_records;       /* what all segments expand to (== chd_tick_out.n_records of the same tick) */
+} chd_segments_out;
+
+/* The last tick's fan-out in that form.  All buffers caller-allocated (chd_host_alloc memory makes the copies DMA);
+ * CHD_E_CAPACITY (n_* say what is needed) when one is too small.  replaces: the per-message loop of fanOutDataUpdate
+ * (data.go:293-318) on the host side of the boundary — the host walks segments instead of 8-byte records. */
+int chd_tick_fetch_segments(chd_ctx *ctx, chd_segments_out *out);
+
 /* Read back the interest set of a subscriber slot (the keys of
  * Connection.spatialSubscriptions, with the per-subscription fan-out state of
  * subscription.go:13-31 / data.go:39-44).  Arrays have max_interest_cells

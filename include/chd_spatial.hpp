@@ -413,6 +413,11 @@ class SpatialWorld {
         std::vector<chd_fanout_rec> records;       // grouped per connection slot:
         std::vector<uint64_t> connRecordOffset;    //   slot s owns records [connRecordOffset[s], + connRecordCount[s])
         std::vector<uint32_t> connRecordCount;
+        // what crossed PCIe (chd_tick_fetch_segments): `records` above is expanded from these on the host
+        std::vector<chd_fanout_segment> segments;  // slot s owns segments [connSegmentOffset[s], connSegmentOffset[s+1])
+        std::vector<uint32_t> connSegmentOffset, columns;
+        std::vector<chd_fanout_rec> explicitRecords;
+        std::vector<uint64_t> connExplicitOffset;
         uint32_t overflow = 0, historyOverflow = 0;
     };
 
@@ -434,7 +439,71 @@ class SpatialWorld {
         check(chd_world_spawn(ctl_.ctx(), (uint32_t)entityChannelIds.size(), nullptr, entityChannelIds.data(), x.data(), z.data(),
                               flags.empty() ? nullptr : flags.data(), owner.empty() ? nullptr : owner.data()));
     }
-    void AddSubscribers(const std::vector<ConnectionId> &conn) { check(chd_subs_add(ctl_.ctx(), (uint32_t)conn.size(), nullptr, conn.data())); }
+    void AddSubscribers(const std::vector<ConnectionId> &conn) {
+        check(chd_subs_add(ctl_.ctx(), (uint32_t)conn.size(), nullptr, conn.data()));
+        if (connIds_.size() < conn.size()) connIds_.resize(conn.size(), 0);
+        std::copy(conn.begin(), conn.end(), connIds_.begin());  // (slots 0 .. n-1)
+    }
+
+    // The fan-out of the last tick as the host consumes it: segment descriptors + the cells' entity-channel columns + the few
+    // explicit records (chd_tick_fetch_segments), expanded here into the per-connection records a flush loop would walk —
+    // what Go's fanOutDataUpdate loop (data.go:293-318) becomes on the host side of the boundary.
+    Error FetchSegments(TickResult &out) {
+        out.connSegmentOffset.assign((size_t)S_ + 1, 0);
+        out.connExplicitOffset.assign((size_t)S_ + 1, 0);
+        chd_segments_out so;
+        std::memset(&so, 0, sizeof so);
+        for (int attempt = 0; attempt < 2; attempt++) {
+            so.segments = out.segments.data(); so.segments_cap = out.segments.size();
+            so.conn_seg_off = out.connSegmentOffset.data();
+            so.columns = out.columns.data(); so.columns_cap = out.columns.size();
+            so.records = out.explicitRecords.data(); so.records_cap = out.explicitRecords.size();
+            so.conn_rec_off = out.connExplicitOffset.data();
+            const int rc = chd_tick_fetch_segments(ctl_.ctx(), &so);
+            if (rc == CHD_E_CAPACITY && attempt == 0 && (so.n_segments > so.segments_cap || so.n_columns > so.columns_cap || so.n_explicit > so.records_cap)) {
+                out.segments.resize(so.n_segments + so.n_segments / 4 + 16);
+                out.columns.resize(so.n_columns + 16);
+                out.explicitRecords.resize(so.n_explicit + so.n_explicit / 4 + 16);
+                continue;
+            }
+            if (rc != CHD_OK) return err(rc);
+            break;
+        }
+        out.segments.resize(so.n_segments);
+        out.explicitRecords.resize(so.n_explicit);
+        // expansion (include/chd_spatial.h: chd_fanout_segment)
+        out.records.clear();
+        out.records.reserve(so.n_records);
+        out.connRecordOffset.assign((size_t)S_ + 1, 0);
+        out.connRecordCount.assign(S_, 0);
+        for (uint32_t s = 0; s < S_; s++) {
+            out.connRecordOffset[s] = out.records.size();
+            const uint32_t conn = s < connIds_.size() ? connIds_[s] : 0u;
+            for (uint32_t k = out.connSegmentOffset[s]; k < out.connSegmentOffset[s + 1]; k++) {
+                const chd_fanout_segment &g = out.segments[k];
+                if (g.n_info & CHD_SEG_EXPLICIT) {
+                    const chd_fanout_rec *r = out.explicitRecords.data() + out.connExplicitOffset[s] + g.off;
+                    out.records.insert(out.records.end(), r, r + g.n_records);
+                    continue;
+                }
+                const uint32_t n = CHD_SEG_N(g.n_info);
+                const uint32_t *col = out.columns.data() + g.off;
+                if (g.n_info & CHD_SEG_FIRST) {
+                    out.records.push_back({conn | CHD_REC_FULL, g.channel});
+                    for (uint32_t e = 0; e < n; e++) out.records.push_back({conn | CHD_REC_FULL, col[e]});
+                }
+                for (uint32_t j = 0; j < CHD_SEG_NWIN(g.n_info); j++) {
+                    if (g.n_info & CHD_SEG_OWN(j)) out.records.push_back({conn, g.channel});
+                    if (!(g.n_info & CHD_SEG_NONE))
+                        for (uint32_t e = 0; e < n; e++) out.records.push_back({conn, col[e]});
+                }
+            }
+            out.connRecordCount[s] = (uint32_t)(out.records.size() - out.connRecordOffset[s]);
+        }
+        out.connRecordOffset[S_] = out.records.size();
+        if (out.records.size() != so.n_records) return {CHD_E_STATE, "segments expand to another number of records than the tick reported"};
+        return {};
+    }
 
     // entity updates (slot u = u), interest updates (one query per connection slot, nullptr = none), fan-out at nowNs
     Error Tick(int64_t nowNs, const std::vector<double> &x, const std::vector<double> &z,
@@ -457,9 +526,6 @@ class SpatialWorld {
         out.handovers.resize(std::max<uint32_t>(N_, 1u));
         out.queryStatus.assign(std::max<size_t>(p.q.size(), 1), 0);
         for (auto *v : {&out.unsubSlot, &out.unsubChannel, &out.newSubSlot, &out.newSubChannel, &out.newSubIntervalMs}) v->resize(listCap);
-        out.records.resize(std::max<uint64_t>(recordsCap, 1));
-        out.connRecordOffset.assign((size_t)S_ + 1, 0);
-        out.connRecordCount.assign(S_, 0);
         chd_tick_out o;
         std::memset(&o, 0, sizeof o);
         o.handovers = out.handovers.data(); o.handovers_cap = (uint32_t)out.handovers.size();
@@ -467,8 +533,7 @@ class SpatialWorld {
         o.unsub_sub = out.unsubSlot.data(); o.unsub_channel = out.unsubChannel.data(); o.unsub_cap = listCap;
         o.newsub_sub = out.newSubSlot.data(); o.newsub_channel = out.newSubChannel.data(); o.newsub_interval_ms = out.newSubIntervalMs.data();
         o.newsub_cap = listCap;
-        o.records = out.records.data(); o.records_cap = recordsCap;
-        o.conn_rec_off = out.connRecordOffset.data(); o.conn_rec_cnt = out.connRecordCount.data();
+        // (no dense records over PCIe: the fan-out comes back as segments, below)
         const int rc = chd_tick(ctl_.ctx(), &in, &o);
         out.overflow = o.overflow;
         out.historyOverflow = o.history_overflow;
@@ -480,7 +545,8 @@ class SpatialWorld {
         out.lockedAborts = o.n_locked_aborts;
         for (auto *v : {&out.unsubSlot, &out.unsubChannel}) v->resize(o.n_unsubs);
         for (auto *v : {&out.newSubSlot, &out.newSubChannel, &out.newSubIntervalMs}) v->resize(o.n_newsubs);
-        out.records.resize(o.n_records);
+        if (o.n_records > recordsCap) return {CHD_E_CAPACITY, "more fan-out records than recordsCap"};
+        if (Error e = FetchSegments(out)) return e;
         return {};
     }
 
@@ -556,6 +622,7 @@ class SpatialWorld {
     }
     StaticGrid2DSpatialController &ctl_;
     uint32_t N_, S_, capq_ = 0;
+    std::vector<ConnectionId> connIds_;  // ConnectionId per subscriber slot (the host registered them: AddSubscribers)
 };
 
 // ---------------------------------------------------------------------------------------------------------------------

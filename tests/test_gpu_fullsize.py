@@ -296,3 +296,36 @@ def test_emit_form_follows_the_update_pattern(amd):
         res = w.tick(sw.now_ns(), upd_idx=idx, upd_x=x, upd_z=z, queries=q, want_records=False, records_cap=1)
         compare_tick(100 + k, w, ow, res, sw)
         assert w.history(1)[0]["n_deferred_records"] == 0
+
+
+def test_config_b_segments_expand_to_the_device_digest(amd):
+    """VERDICT r2 #3 at full size: config B's fan-out leaves the device as segment descriptors + columns (a few MB instead of
+    644 MB of records); expanded on the host they digest to what the device computes over the records where they lie
+    (chd_tick_digest), in total and for every connection — first fan-out, the crossing to the descriptor path, steady state."""
+    from channeld_amd.engine import expand_segments
+
+    N, S = 100_000, 10_000
+    cfg, sw, ctl, w = build(amd, N, S, 0xC0FFEE31)
+    compact = []
+    for k in range(6):
+        sw.step()
+        w.tick(sw.now_ns(), upd_x=sw.x, upd_z=sw.z, queries=sw.queries(), want_records=False)
+        (cnt, sm, xr, _), conn_sum = w.digest(per_connection=True)
+        seg = w.fetch_segments()
+        assert seg["n_records"] == cnt
+        rec = expand_segments(seg, sw.sub_conn)
+        assert digest(rec["conn"], rec["channel"]) == (cnt, sm, xr), f"tick {k}"
+        # per connection: sums of the record hashes
+        h = mix64((rec["conn"].astype(np.uint64) << np.uint64(32)) | rec["channel"].astype(np.uint64))
+        per_seg = seg["segments"]["n_records"].astype(np.int64)
+        slot_of_seg = np.repeat(np.arange(S), np.diff(seg["conn_seg_off"].astype(np.int64)))
+        slot_of_rec = np.repeat(slot_of_seg, per_seg)
+        got = np.zeros(S, dtype=np.uint64)
+        with np.errstate(over="ignore"):
+            np.add.at(got, slot_of_rec, h)
+        assert np.array_equal(got, conn_sum), f"tick {k}: per-connection digests"
+        nbytes = seg["segments"].nbytes + seg["columns"].nbytes + seg["records"].nbytes + seg["conn_seg_off"].nbytes + seg["conn_rec_off"].nbytes
+        compact.append((cnt, nbytes))
+    # steady state: three orders of magnitude fewer bytes than the expanded records
+    cnt, nbytes = compact[-1]
+    assert cnt > 50_000_000 and nbytes < 8 * cnt / 50, compact

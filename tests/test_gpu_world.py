@@ -539,3 +539,43 @@ def test_handover_groups_move_together_and_locks_abort(amd, emit_mode):
         riders = 3 * np.arange(K) + 2
         moved_riders += int((member[riders] != cell[riders]).sum())  # in another cell's map than their own position's
     assert total_ho > 100 and total_lock > 5 and moved_riders > 50
+
+
+def test_segments_expand_to_the_dense_records(amd):
+    """chd_tick_fetch_segments — per connection the plan's descriptors + the cells' entity-channel columns + the
+    explicit records of the subscriptions that needed a per-entity decision — expands on the host to exactly the records
+    chd_tick returns densely, connection by connection, on every emit form (descriptor path: mostly column references;
+    the other forms: all explicit), through first fan-outs, sparse updates (filtered windows) and steady state."""
+    from channeld_amd.engine import expand_segments
+
+    cfg = synth.load_config("spatial_static_4x4.json")
+    N, S = 900, 48
+    sw = synth.SynthWorld(synth.WorldSpec(cfg, N, S, 0x5E6, tick_ms=50, outside_frac=0.01, locked_frac=0.02))
+    ctl, gw = make(amd, cfg, N, S)
+    gw.spawn(None, sw.chan_id, sw.x, sw.z, sw.flags, sw.sender)
+    gw.add_subscribers(None, sw.sub_conn)
+    rng = np.random.default_rng(6)
+    n_col = n_exp = 0
+    for k in range(14):
+        sw.step()
+        idx = np.arange(N, dtype=np.uint32) if k % 5 != 3 else np.sort(rng.choice(N, N // 2, replace=False)).astype(np.uint32)
+        res = gw.tick(sw.now_ns(), upd_idx=idx, upd_x=sw.x[idx], upd_z=sw.z[idx], queries=sw.queries())
+        seg = gw.fetch_segments(pinned=(k % 2 == 0))
+        assert seg["n_records"] == res.n_records
+        rec = expand_segments(seg, sw.sub_conn)
+        assert len(rec) == res.n_records
+        # per connection: the same multiset
+        off = np.zeros(S + 1, dtype=np.int64)
+        for s in range(S):
+            a, b = int(seg["conn_seg_off"][s]), int(seg["conn_seg_off"][s + 1])
+            off[s + 1] = off[s] + int(seg["segments"]["n_records"][a:b].sum())
+        for s in range(S):
+            want = res.records_of(s)
+            got = rec[off[s]: off[s + 1]]
+            assert np.array_equal(canon(got["conn"], got["channel"]), canon(want["conn"], want["channel"])), f"tick {k} slot {s}"
+        expl = (seg["segments"]["n_info"] & (1 << 24)) != 0
+        n_exp += int(expl.sum())
+        n_col += int((~expl).sum())
+    assert n_exp > 0
+    if EMIT_FLAGS & 64:
+        assert n_col > n_exp  # the descriptor path: segments are mostly references into the columns
