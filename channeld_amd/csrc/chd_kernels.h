@@ -74,6 +74,14 @@ struct WorldDev {
     uint32_t *blk_smin, *blk_smax, *blk_hand;  // [ncell*nblk] per-block sender range / AND of histories (index build intermediates)
     uint32_t *cell_hand;              // [ncell] AND of the histories of the cell's entities (aligned to this tick)
     uint32_t *ce_chan;                // [N + 4] the entity channel ids alone, cell-sorted: what an all-pass window copies
+    // WINDOW COLUMNS (descriptor path of partially updating worlds): behind the full column array, at j * wcol_stride for
+    // j = 1..4, the cell-sorted channel ids of the entities that have an update within the last j ticks (history & prefix
+    // mask of j bits) — a subsequence of the cell's column, stored from the cell's own start; cell_wcnt[(j-1) * ncell + c] =
+    // its length.  A fan-out window whose mask over the tick ring is exactly the last j ticks is then a plain copy of that
+    // column, as an all-pass window is of the full one.  Built by k_window_columns in the ticks where some entity skipped an
+    // update (wcol_on); wcol_stride == 0: not available (region-sharded worlds).
+    uint32_t wcol_stride, wcol_on;
+    uint32_t *cell_wcnt;
     const uint32_t *ce_chan_view;     // (views: always the arrays above since the halo exchange appends the neighbours' entries to them)
     const uint2 *ce8_view;
     uint32_t *cell_off;   // [ncell+1] cell c owns ce[cell_off[c], cell_off[c+1])
@@ -292,6 +300,9 @@ void launch_halo_unpack(hipStream_t st, DevGrid g, WorldDev w, uint32_t rank, ui
                         const uint64_t *seg_off, const uint32_t *ghost_off);
 // K2: cell index build
 void launch_index_build(hipStream_t st, DevGrid g, WorldDev w, uint32_t cur_tick);
+// the window columns of the cells that are not fully updated (WorldDev::wcol_*); after the index build
+void launch_window_columns(hipStream_t st, DevGrid g, WorldDev w);
+#define CHD_WCOLS 4
 // K3/K4: AOI query (+ interest diff when stateful)
 struct AoiLimits {
     uint32_t maxax;   // samples per lattice axis
