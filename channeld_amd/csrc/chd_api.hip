@@ -792,7 +792,12 @@ int chd_world_create(chd_ctx *ctx, const chd_world_cfg *cfg) {
     TRY(walloc(ctx, &d.blk_smax, C * d.nblk + 1));
     TRY(walloc(ctx, &d.blk_hand, C * d.nblk + 1));
     TRY(walloc(ctx, &d.cell_hand, C));
-    TRY(walloc(ctx, &d.ce_chan, N + 520));  // + 512: the pipelined emit loads a whole 512-entry column image at any cell start
+    // + 512: the pipelined emit loads a whole 512-entry column image at any cell start.  Behind the full column array: the four
+    // window columns (WorldDev::wcol_*), same stride.
+    d.wcol_stride = (uint32_t)((N + 520 + 63) & ~(size_t)63);
+    TRY(walloc(ctx, &d.ce_chan, (size_t)(CHD_WCOLS + 1) * d.wcol_stride + 520));
+    TRY(walloc(ctx, &d.cell_wcnt, (size_t)CHD_WCOLS * C));
+    d.wcol_on = 0;
     TRY(walloc(ctx, &d.cell_off, C + 1));
     TRY(walloc(ctx, &d.cell_tot, C));
     TRY(walloc(ctx, &d.cell_ref, C));
@@ -914,7 +919,7 @@ int chd_world_create(chd_ctx *ctx, const chd_world_cfg *cfg) {
         TRY(walloc(ctx, &W.pb_rec_ub[1], S + 1));
         TRY(walloc(ctx, &W.pb_seg_desc[1], P, false));
         TRY(walloc(ctx, &W.pb_seg_desc2[1], P, false));
-        TRY(walloc(ctx, &W.pb_ce_chan[1], N + 520));
+        TRY(walloc(ctx, &W.pb_ce_chan[1], (size_t)(CHD_WCOLS + 1) * d.wcol_stride + 520));
         TRY(walloc(ctx, &W.pb_recs[1], nrec, false));
         HIPCHK(hipEventCreateWithFlags(&W.ev_stages_done, hipEventDisableTiming));
         HIPCHK(hipEventCreateWithFlags(&W.ev_rec_sync, hipEventDisableTiming));
@@ -1330,7 +1335,15 @@ static int tick_locked(chd_ctx *ctx, const chd_tick_in *in) {
     // order and state (the parity tests run both; the full-size tests cross from one to the other after the first tick);
     // worlds that ASK for the one-wave geometry (CHD_WORLD_ONE_WAVE_EMIT) always take the descriptor path.
     W.full_streak = (W.n_live && in->n_updates >= W.n_live && in->n_update_rounds <= 1) ? std::min(W.full_streak + 1u, 1u << 20) : 0u;
-    d.seg_off = (!d.one_wave_emit && W.full_streak < 2u) ? 1u : 0u;
+    // Partially updating worlds keep the descriptor path where the WINDOW COLUMNS exist (WorldDev::wcol_*: per cell the entities
+    // updated within the last 1..4 ticks, compacted once per tick by k_window_columns): a window over exactly those ticks is
+    // then a plain copy again.  (Not in wire mode: its records carry cell-table positions.)
+    d.wcol_on = (W.full_streak < 2u && d.wcol_stride && !d.rec_pos && !d.cm_emit && !d.rec_mask) ? 1u : 0u;
+    d.seg_off = (!d.one_wave_emit && W.full_streak < 2u && !d.wcol_on) ? 1u : 0u;
+    if (const char *e = getenv("CHD_WINDOW_COLUMNS")) if (e[0] == '0') {  // (A/B runs: the per-tick choice of round 2)
+        d.wcol_on = 0;
+        d.seg_off = (!d.one_wave_emit && W.full_streak < 2u) ? 1u : 0u;
+    }
     const bool pipe = W.pipe_on && fanout_seg_path(d);
     W.last_desc = fanout_seg_path(d);
     hipStream_t st = ctx->stream;
@@ -1402,6 +1415,7 @@ static int tick_locked(chd_ctx *ctx, const chd_tick_in *in) {
     }
     if (prof_stages) HIPCHK(hipEventRecord(ev[1], bs));
     launch_index_build(bs, ctx->g, d, r.cur_tick);
+    if (d.wcol_on && fanout_seg_path(d)) launch_window_columns(bs, ctx->g, d);
     if (prof_stages) HIPCHK(hipEventRecord(ev[2], bs));
     if (overlap) HIPCHK(hipStreamWaitEvent(bs, ctx->ev_join, 0));
     else
@@ -1652,7 +1666,7 @@ int chd_tick_fetch_segments(chd_ctx *ctx, chd_segments_out *out) {
     TRY(down(ctx, ringrow, d.tick_ring + (size_t)(ctx->ring.cur_tick % TICK_RING) * 8, sizeof ringrow));
     HIPCHK(hipStreamSynchronize(st));
     // the columns a descriptor may point into: the own cell tables (+ the neighbours' border entities on a sharded rank)
-    const uint64_t ncol = W.last_desc ? (uint64_t)d.N + d.ghost_cap : 0ull;
+    const uint64_t ncol = !W.last_desc ? 0ull : d.wcol_on ? (uint64_t)(CHD_WCOLS + 1) * d.wcol_stride : (uint64_t)d.N + d.ghost_cap;
     out->n_segments = nseg;
     out->n_explicit = nexp;
     out->n_columns = ncol;
@@ -1861,6 +1875,7 @@ static int shard_reserve_ghosts(chd_ctx *ctx, uint32_t ghosts) {
     TRY(walloc(ctx, &d.ce_sprev, n));
     TRY(walloc(ctx, &d.ce8, n + 2));
     TRY(walloc(ctx, &d.ce_chan, n + 520));
+    d.wcol_stride = 0;  // (no window columns on region-sharded worlds: the tables are rebuilt with ghost room, one column array)
     if (!d.cell_cov) TRY(walloc(ctx, &d.cell_cov, ctx->g.ncell));
     d.ghost_cap = ghosts;
     HIPCHK(hipStreamSynchronize(ctx->stream));

@@ -974,9 +974,32 @@ __global__ void __launch_bounds__(64 * FO_WAVES) k_fanout_plan_seg(DevGrid g, Wo
                 // (a column of up to 512 entries is four 8-byte loads per lane; larger cells take the deferred launch — and at
                 // >= 1024 entities per cell the cell-major form is the default anyway)
                 simple = chans != nullptr && nw <= 4 && size <= 512;
+                // Which column every non-empty window copies: the cell's full column when every entity has an update inside
+                // the window (the AND of their histories intersects it), else — partially updating worlds — the WINDOW
+                // COLUMN of the last L ticks when the window is exactly those (mask = the low L bits, L <= 4: the steady state
+                // of a subscription served every interval).  One column per descriptor: all windows must agree.
+                uint32_t col = 0xFFFFFFFFu;  // 0 = full column, L = window column of the last L ticks
 #pragma unroll
-                for (uint32_t j = 0; j < 4; j++)
-                    if (j < nw && !none && (us == CHD_NONUNIFORM || !(hand & wms[j]))) simple = false;
+                for (uint32_t j = 0; j < 4; j++) {
+                    if (j >= nw || none) continue;
+                    uint32_t cj = 0xFFFFFFFEu;
+                    if (us != CHD_NONUNIFORM) {
+                        if (hand & wms[j]) cj = 0u;
+                        else if (w.wcol_on) {
+#pragma unroll
+                            for (uint32_t L = 1; L <= CHD_WCOLS; L++)
+                                if (wms[j] == (2u << (L - 1u)) - 1u) cj = L;
+                        }
+                    }
+                    if (cj == 0xFFFFFFFEu || (col != 0xFFFFFFFFu && col != cj)) simple = false;
+                    col = cj;
+                }
+                if (col == 0xFFFFFFFFu || (info & SD_FIRST)) col = 0u;  // (a first fan-out has no window: Lw = now)
+                uint32_t ncol = size;
+                if (simple && col) {
+                    ncol = w.cell_wcnt[(size_t)(col - 1u) * g.ncell + c];
+                    start += col * w.wcol_stride;
+                }
                 if (simple) {
                     // exact record count: the segment is as long as what will be written
                     const uint32_t age = ring.cur_tick - c_htick;
@@ -990,8 +1013,9 @@ __global__ void __launch_bounds__(64 * FO_WAVES) k_fanout_plan_seg(DevGrid g, Wo
                             info |= 1u << (SD_OWN_SHIFT + j);
                             count += 1;
                         }
-                        if (!none) count += size;
+                        if (!none) count += ncol;
                     }
+                    size = ncol;  // (what the descriptor carries: entries of the column the windows copy)
                     info |= nw | (none ? SD_NONE : 0u);
                     ub = count;
                     if (hlost) hist_ovf = 1;  // (a deferred subscription is counted by the deferred launch)

@@ -259,10 +259,11 @@ def test_config_c_one_million_entities_12_ticks_record_digests(amd):
 
 
 def test_emit_form_follows_the_update_pattern(amd):
-    """A world of >= 4096 connections created without emit flags picks its connection-major form per tick (chd_api.hip,
-    tick_locked): the descriptor path while every live entity sends an update tick after tick, the one-launch filtering form
-    as soon as some skip a tick, and back.  Full / partial / full update phases, every tick compared with the oracle record
-    by record (digests per connection), so the state each form leaves is what the other one continues from."""
+    """A world of >= 4096 connections created without emit flags takes the descriptor path every tick; what its windows copy
+    changes with the update pattern (chd_api.hip, tick_locked): the cells' full columns while every live entity sends an update
+    tick after tick, the WINDOW COLUMNS (per cell the entities updated within the last 1..4 ticks, k_window_columns) as soon as
+    some skip a tick, and back.  Full / partial / full update phases, every tick compared with the oracle record by record
+    (digests per connection), so the state each phase leaves is what the next one continues from."""
     N, S = 40_000, 4_096
     cfg, sw, ctl, w = build(amd, N, S, 0xC0FFEE31, max_records=60_000_000, flags=0)
     ow = oracle_world(cfg, sw, N, S, w.capq)
@@ -284,7 +285,7 @@ def test_emit_form_follows_the_update_pattern(amd):
     # (the descriptor path's deferred launch shows in n_deferred_records whenever a cell holds several senders' entities:
     # informational here — which form ran is a performance matter, the records are what is compared)
     print(f"deferred records over the full-update ticks: {seen_deferred}")
-    # a world that never updates fully never takes the descriptor path: nothing is ever deferred
+    # a world that never updates fully: window columns every tick — most records still come from the descriptor kernel
     cfg, sw, ctl, w = build(amd, N, S, 0xC0FFEE32, max_records=60_000_000, flags=0)
     ow = oracle_world(cfg, sw, N, S, w.capq)
     for k in range(4):
@@ -295,7 +296,9 @@ def test_emit_form_follows_the_update_pattern(amd):
         ow.tick(sw.now_ns(), idx, x, z, None, None, None, None, q)
         res = w.tick(sw.now_ns(), upd_idx=idx, upd_x=x, upd_z=z, queries=q, want_records=False, records_cap=1)
         compare_tick(100 + k, w, ow, res, sw)
-        assert w.history(1)[0]["n_deferred_records"] == 0
+        h = w.history(1)[0]
+        if k >= 2:  # (past the first, full-state fan-outs)
+            assert h["n_deferred_records"] < h["n_records"] // 4, h
 
 
 def test_config_b_segments_expand_to_the_device_digest(amd):
