@@ -74,12 +74,14 @@ struct WorldDev {
     uint32_t *blk_smin, *blk_smax, *blk_hand;  // [ncell*nblk] per-block sender range / AND of histories (index build intermediates)
     uint32_t *cell_hand;              // [ncell] AND of the histories of the cell's entities (aligned to this tick)
     uint32_t *ce_chan;                // [N + 4] the entity channel ids alone, cell-sorted: what an all-pass window copies
-    // WINDOW COLUMNS (descriptor path of partially updating worlds): behind the full column array, at j * wcol_stride for
-    // j = 1..4, the cell-sorted channel ids of the entities that have an update within the last j ticks (history & prefix
-    // mask of j bits) — a subsequence of the cell's column, stored from the cell's own start; cell_wcnt[(j-1) * ncell + c] =
-    // its length.  A fan-out window whose mask over the tick ring is exactly the last j ticks is then a plain copy of that
-    // column, as an all-pass window is of the full one.  Built by k_window_columns in the ticks where some entity skipped an
-    // update (wcol_on); wcol_stride == 0: not available (region-sharded worlds).
+    // WINDOW COLUMNS (descriptor path of partially updating worlds): behind the full column array, at (k + 1) * wcol_stride for
+    // k < CHD_WCOLS, the cell-sorted channel ids of the entities that have an update inside the ticks of wcol_mask(k) — runs
+    // of 1..3 ticks starting at the newest tick, the one before or the one before that: the masks a subscription served every
+    // interval produces (its windows are closed intervals: a stamp on an edge lies in two of them; an interest update that
+    // changes the damped interval leaves a window that starts at an older stamp) — a subsequence of the cell's column, stored
+    // from the cell's own start; cell_wcnt[k * ncell + c] = its length.  A fan-out window with exactly that mask is then a
+    // plain copy of that column, as an all-pass window is of the full one.  Built by k_window_columns in the ticks where some
+    // entity skipped an update (wcol_on); wcol_stride == 0: not available (region-sharded worlds).
     uint32_t wcol_stride, wcol_on;
     uint32_t *cell_wcnt;
     const uint32_t *ce_chan_view;     // (views: always the arrays above since the halo exchange appends the neighbours' entries to them)
@@ -302,7 +304,10 @@ void launch_halo_unpack(hipStream_t st, DevGrid g, WorldDev w, uint32_t rank, ui
 void launch_index_build(hipStream_t st, DevGrid g, WorldDev w, uint32_t cur_tick);
 // the window columns of the cells that are not fully updated (WorldDev::wcol_*); after the index build
 void launch_window_columns(hipStream_t st, DevGrid g, WorldDev w);
-#define CHD_WCOLS 4
+#define CHD_WCOLS 9
+__host__ __device__ inline uint32_t wcol_mask(uint32_t k) {  // runs of 1..3 ticks that start 0, 1 or 2 ticks back: 1 3 7, 2 6 14, 4 12 28
+    return ((2u << (k % 3u)) - 1u) << (k / 3u);
+}
 // K3/K4: AOI query (+ interest diff when stateful)
 struct AoiLimits {
     uint32_t maxax;   // samples per lattice axis

@@ -874,6 +874,7 @@ __global__ void __launch_bounds__(64 * WAVES) k_fanout_emit(DevGrid g, WorldDev 
 #define SD_NWIN_MASK 7u
 #define SD_FIRST 8u      // first fan-out: the cell's FULL record + every entity's
 #define SD_NONE 16u      // SkipSelfUpdateFanOut and the cell's only sender is this connection: no entity record passes
+#define SD_NOPAD 32u     // another part of the same subscription follows in the next records: do not pad the line
 #define SD_OWN_SHIFT 8   // bit 8 + j: the spatial channel's own buffered update passes window j
 
 typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
@@ -903,6 +904,8 @@ __global__ void __launch_bounds__(64 * FO_WAVES) k_fanout_plan_seg(DevGrid g, Wo
         uint64_t ub = 0;
         bool due = false, simple = false, deep = false;
         uint32_t fl = 0, c = 0, size = 0, start = 0, info = 0, count = 0;
+        uint32_t why = 0;  // (diagnosis builds)
+        uint32_t nd = 0, d_start[4] = {0, 0, 0, 0}, d_n[4] = {0, 0, 0, 0}, d_info[4] = {0, 0, 0, 0}, d_cnt[4] = {0, 0, 0, 0};
         int64_t Lw = 0;
         if (p < cnt) {
             fl = w.pair_flags[pbase + p] & ~(PF_DEFER | PF_DEEP);
@@ -974,11 +977,14 @@ __global__ void __launch_bounds__(64 * FO_WAVES) k_fanout_plan_seg(DevGrid g, Wo
                 // (a column of up to 512 entries is four 8-byte loads per lane; larger cells take the deferred launch — and at
                 // >= 1024 entities per cell the cell-major form is the default anyway)
                 simple = chans != nullptr && nw <= 4 && size <= 512;
+                if (!simple) why = 0x10000000u | (nw << 16) | size;
                 // Which column every non-empty window copies: the cell's full column when every entity has an update inside
-                // the window (the AND of their histories intersects it), else — partially updating worlds — the WINDOW
-                // COLUMN of the last L ticks when the window is exactly those (mask = the low L bits, L <= 4: the steady state
-                // of a subscription served every interval).  One column per descriptor: all windows must agree.
-                uint32_t col = 0xFFFFFFFFu;  // 0 = full column, L = window column of the last L ticks
+                // the window (the AND of their histories intersects it), else — partially updating worlds — the WINDOW COLUMN
+                // of exactly that mask (wcol_mask: runs of 1..3 ticks that start at the newest or the one before — what a
+                // subscription served every interval sees).  A descriptor carries one column: windows that agree share one
+                // descriptor, a subscription whose windows differ gets one descriptor per window (contiguous parts).
+                uint32_t wcol[4] = {0u, 0u, 0u, 0u};  // per window: 0 = full column, k + 1 = window column k
+                bool same = true;
 #pragma unroll
                 for (uint32_t j = 0; j < 4; j++) {
                     if (j >= nw || none) continue;
@@ -987,42 +993,69 @@ __global__ void __launch_bounds__(64 * FO_WAVES) k_fanout_plan_seg(DevGrid g, Wo
                         if (hand & wms[j]) cj = 0u;
                         else if (w.wcol_on) {
 #pragma unroll
-                            for (uint32_t L = 1; L <= CHD_WCOLS; L++)
-                                if (wms[j] == (2u << (L - 1u)) - 1u) cj = L;
+                            for (uint32_t k = 0; k < CHD_WCOLS; k++)
+                                if (wms[j] == wcol_mask(k)) cj = k + 1u;
                         }
                     }
-                    if (cj == 0xFFFFFFFEu || (col != 0xFFFFFFFFu && col != cj)) simple = false;
-                    col = cj;
-                }
-                if (col == 0xFFFFFFFFu || (info & SD_FIRST)) col = 0u;  // (a first fan-out has no window: Lw = now)
-                uint32_t ncol = size;
-                if (simple && col) {
-                    ncol = w.cell_wcnt[(size_t)(col - 1u) * g.ncell + c];
-                    start += col * w.wcol_stride;
+                    if (cj == 0xFFFFFFFEu) { simple = false; why = 0x20000000u | (us == CHD_NONUNIFORM ? 0x1000000u : 0u) | (j << 20) | (wms[j] & 0xFFFFFu); }
+                    wcol[j] = cj;
+                    if (j && cj != wcol[0]) same = false;
                 }
                 if (simple) {
-                    // exact record count: the segment is as long as what will be written
+                    // exact record counts: the segment is as long as what will be written
                     const uint32_t age = ring.cur_tick - c_htick;
                     const uint32_t chh = age < CHD_HIST_BITS ? (c_hist << age) : 0u;
                     const uint32_t chhp = age < CHD_HIST_BITS ? (c_hprev << age) : 0u;
-                    count = (info & SD_FIRST) ? size + 1 : 0u;
+                    uint32_t own = 0;
 #pragma unroll
-                    for (uint32_t j = 0; j < 4; j++) {
-                        if (j >= nw) continue;
-                        if (cell_update_passes(chh, chs, chhp, chsp, wms[j], skip_self, conn)) {
-                            info |= 1u << (SD_OWN_SHIFT + j);
-                            count += 1;
+                    for (uint32_t j = 0; j < 4; j++)
+                        if (j < nw && cell_update_passes(chh, chs, chhp, chsp, wms[j], skip_self, conn)) own |= 1u << j;
+                    if ((info & SD_FIRST) || nw == 0 || none || same) {
+                        // one descriptor: first fan-out (full column, no window), nothing to send, or windows that agree
+                        const uint32_t col = ((info & SD_FIRST) || nw == 0 || none) ? 0u : wcol[0];
+                        const uint32_t ncol = col ? w.cell_wcnt[(size_t)(col - 1u) * g.ncell + c] : size;
+                        nd = 1;
+                        d_start[0] = start + col * w.wcol_stride;
+                        d_n[0] = ncol;
+                        d_info[0] = info | nw | (none ? SD_NONE : 0u) | (own << SD_OWN_SHIFT);
+                        d_cnt[0] = ((info & SD_FIRST) ? size + 1u : 0u) + (uint32_t)__popc(own) + (none ? 0u : nw * ncol);
+                    } else {
+                        nd = nw;
+#pragma unroll
+                        for (uint32_t j = 0; j < 4; j++) {
+                            if (j >= nw) continue;
+                            const uint32_t col = wcol[j];
+                            const uint32_t ncol = col ? w.cell_wcnt[(size_t)(col - 1u) * g.ncell + c] : size;
+                            d_start[j] = start + col * w.wcol_stride;
+                            d_n[j] = ncol;
+                            d_info[j] = 1u | (((own >> j) & 1u) << SD_OWN_SHIFT) | (j + 1u < nw ? SD_NOPAD : 0u);
+                            d_cnt[j] = ((own >> j) & 1u) + ncol;
                         }
-                        if (!none) count += ncol;
                     }
-                    size = ncol;  // (what the descriptor carries: entries of the column the windows copy)
-                    info |= nw | (none ? SD_NONE : 0u);
-                    ub = count;
                     if (hlost) hist_ovf = 1;  // (a deferred subscription is counted by the deferred launch)
-                } else {
-                    w.pair_flags[pbase + p] = fl | PF_DEFER;
                 }
             }
+        }
+        // descriptor slots of this round: exclusive prefix over the lanes; a connection's row holds capq descriptors — a
+        // subscription that would not fit goes to the deferred launch instead (never seen: ~20 subscriptions per connection)
+        uint32_t dinc = simple ? nd : 0u;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const uint32_t o = (uint32_t)__shfl_up((int)dinc, d);
+            if ((int)lane >= d) dinc += o;
+        }
+        const uint32_t dbase = n_simple + dinc - (simple ? nd : 0u);
+        if (simple && dbase + nd > w.capq) simple = false;
+        if (due && !simple) w.pair_flags[pbase + p] = fl | PF_DEFER;
+#ifdef CHD_PLAN_DEBUG  // diagnosis builds: why was this subscription left to the filtering launch?
+        if (due && !simple && s < 40 && ring.cur_tick >= 8 && ring.cur_tick <= 9)
+            printf("tick %u s %u p %u iv %u why %x\n", ring.cur_tick, s, p, w.pair_iv[pbase + p], why);
+#endif
+        if (due && simple) {
+            count = 0;
+#pragma unroll
+            for (uint32_t j = 0; j < 4; j++) if (j < nd) count += d_cnt[j];
+            ub = count;
         }
         // every segment starts on a 128-byte line and is padded to whole lines (k_fanout_plan)
         ub = (ub + (CHD_SEG_ALIGN - 1)) & ~(uint64_t)(CHD_SEG_ALIGN - 1);
@@ -1039,17 +1072,26 @@ __global__ void __launch_bounds__(64 * FO_WAVES) k_fanout_plan_seg(DevGrid g, Wo
             w.pair_nrec[pbase + p] = simple ? count : 0u;  // (a deferred subscription's count comes from the deferred launch)
         }
         carry += __shfl((unsigned long long)inc, 63);
-        const uint64_t sm = __ballot(due && simple);
         if (__ballot(due && !simple)) any_deferred = 1;
         if (__ballot(deep)) any_deep = 1;
         if (due && simple) {
-            const size_t k = pbase + n_simple + mask_rank(sm);
-            w.seg_desc[k] = make_uint4(rel32, start, size, info);
-            w.seg_desc2[k] = make_uint4(c, p, fl | PF_HAD_FIRST, 0u);
-            w.seg_ln[k] = Lw;
+            uint32_t at = rel32;
+#pragma unroll
+            for (uint32_t j = 0; j < 4; j++) {
+                if (j >= nd) continue;
+                const size_t k = pbase + dbase + j;
+                w.seg_desc[k] = make_uint4(at, d_start[j], d_n[j], d_info[j]);
+                w.seg_desc2[k] = make_uint4(c, p, fl | PF_HAD_FIRST, 0u);
+                w.seg_ln[k] = Lw;
+                at += d_cnt[j];
+            }
             rec_simple += count;
         }
-        n_simple += (uint32_t)__popcll(sm);
+        {
+            uint32_t tot = (due && simple) ? nd : 0u;
+            for (int d = 32; d >= 1; d >>= 1) tot += (uint32_t)__shfl_xor((int)tot, d);
+            n_simple += tot;
+        }
     }
     for (int d = 32; d >= 1; d >>= 1) rec_simple += __shfl_xor(rec_simple, d);
     if (__ballot(hist_ovf) && lane == 0) atomicAdd(&w.counters[CTR_HIST_OVERFLOW], 1u);
@@ -1224,7 +1266,16 @@ __global__ void __launch_bounds__(64, FO_SEG_OCC) k_fanout_emit_seg(DevGrid g, W
                         n_out = store_column2(col[b], n, start, conn, out, opos, n_out, since);
                     }
                 }
-                pad_segment(out, n_out);
+                // (a later part of a split subscription starts anywhere inside a line: pad to the line of the segment's END)
+                if (!(info & SD_NOPAD)) {
+                    const uint32_t pad = (0u - (rel + n_out)) & (CHD_SEG_ALIGN - 1u);
+                    if (lane < pad) {
+                        chd_fanout_rec r;
+                        r.conn = 0xFFFFFFFFu;
+                        r.channel = 0;
+                        out[n_out + lane] = r;
+                    }
+                }
             }
         }
     }

@@ -356,9 +356,9 @@ void launch_scan_u64_inplace(hipStream_t st, uint64_t *data, uint32_t n) {
     hipLaunchKernelGGL(HIP_KERNEL_NAME(k_scan_excl<uint64_t>), dim3(1), dim3(1024), 0, st, data, data, n, (const uint32_t *)nullptr);
 }
 
-// Window columns (chd_kernels.h: WorldDev::wcol_*).  One workgroup per cell; for every prefix length j = 1..4 that the
+// Window columns (chd_kernels.h: WorldDev::wcol_*).  One workgroup per cell; for every window mask wcol_mask(j) that the
 // cell's entities do not ALL cover (cell_hand: then the full column serves), the channel ids of the entities with an update
-// inside the last j ticks, compacted in entry order (ballot ranks inside a wave, wave totals through LDS).
+// inside it, compacted in entry order (ballot ranks inside a wave, wave totals through LDS).
 __global__ void __launch_bounds__(256) k_window_columns(WorldDev w, uint32_t ncell) {
     __shared__ uint32_t wtot[CHD_WCOLS][4];
     const uint32_t c = blockIdx.x;
@@ -367,9 +367,10 @@ __global__ void __launch_bounds__(256) k_window_columns(WorldDev w, uint32_t nce
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
     uint32_t run[CHD_WCOLS];
     bool build[CHD_WCOLS];
+    bool any = false;
 #pragma unroll
-    for (int j = 0; j < CHD_WCOLS; j++) { run[j] = 0; build[j] = n != 0 && !(hand & ((2u << j) - 1u)); }
-    if (!(build[0] || build[1] || build[2] || build[3])) {
+    for (int j = 0; j < CHD_WCOLS; j++) { run[j] = 0; build[j] = n != 0 && !(hand & wcol_mask(j)); any = any || build[j]; }
+    if (!any) {
         if (threadIdx.x < CHD_WCOLS) w.cell_wcnt[threadIdx.x * ncell + c] = n;
         return;
     }
@@ -380,7 +381,7 @@ __global__ void __launch_bounds__(256) k_window_columns(WorldDev w, uint32_t nce
         uint64_t m[CHD_WCOLS];
 #pragma unroll
         for (int j = 0; j < CHD_WCOLS; j++) {
-            m[j] = __ballot(k < n && (e.y & ((2u << j) - 1u)) != 0);
+            m[j] = __ballot(k < n && (e.y & wcol_mask(j)) != 0);
             if (lane == 0) wtot[j][wave] = (uint32_t)__popcll(m[j]);
         }
         __syncthreads();
@@ -388,13 +389,15 @@ __global__ void __launch_bounds__(256) k_window_columns(WorldDev w, uint32_t nce
         for (int j = 0; j < CHD_WCOLS; j++) {
             uint32_t before = 0, all = 0;
             for (uint32_t q = 0; q < 4; q++) { const uint32_t t = wtot[j][q]; if (q < wave) before += t; all += t; }
-            if (build[j] && k < n && (e.y & ((2u << j) - 1u)) != 0)
+            if (build[j] && k < n && (e.y & wcol_mask(j)) != 0)
                 w.ce_chan[(size_t)(j + 1) * w.wcol_stride + start + run[j] + before + mask_rank(m[j])] = e.x;
             run[j] += all;
         }
         __syncthreads();
     }
-    if (threadIdx.x < CHD_WCOLS) w.cell_wcnt[threadIdx.x * ncell + c] = build[threadIdx.x] ? run[threadIdx.x] : n;
+#pragma unroll
+    for (int j = 0; j < CHD_WCOLS; j++)  // (constant indices: the counters stay in registers)
+        if (threadIdx.x == (uint32_t)j) w.cell_wcnt[(size_t)j * ncell + c] = build[j] ? run[j] : n;
 }
 
 void launch_window_columns(hipStream_t st, DevGrid g, WorldDev w) {

@@ -194,6 +194,16 @@ def test_pipelined_ticks_with_deferred_subscriptions_and_full_buffer(amd):
     update per tick, so cells hold entities with and without buffered updates — and with a record buffer that does not hold
     a whole tick: connections that do not fit keep their state and catch up (overflow flag), identically in both schedules."""
     N, S = 20_000, 4_096
+    # (with the window columns a partially updating world hardly defers anything: this test is about the deferred launch
+    # beside the record kernel, so it runs the per-entity filtering of round 2 — CHD_WINDOW_COLUMNS=0, read every tick)
+    os.environ["CHD_WINDOW_COLUMNS"] = "0"
+    try:
+        _pipelined_deferred_and_full_buffer(amd, N, S)
+    finally:
+        del os.environ["CHD_WINDOW_COLUMNS"]
+
+
+def _pipelined_deferred_and_full_buffer(amd, N, S):
     for max_records, expect_overflow in ((40_000_000, False), (1_500_000, True)):
         seed = 0xC0FFEE22
         worlds = []

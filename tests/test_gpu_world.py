@@ -576,6 +576,6 @@ def test_segments_expand_to_the_dense_records(amd):
         expl = (seg["segments"]["n_info"] & (1 << 24)) != 0
         n_exp += int(expl.sum())
         n_col += int((~expl).sum())
-    assert n_exp > 0
+    assert n_exp > 0 or (EMIT_FLAGS & 64)  # (window columns: the descriptor path may leave nothing explicit)
     if EMIT_FLAGS & 64:
         assert n_col > n_exp  # the descriptor path: segments are mostly references into the columns
