@@ -265,13 +265,18 @@ class StaticGrid2DSpatialController:
         ncell = self.GridCols * self.GridRows
         cap = max(1, nq * min(ncell, 4096))
         offsets = np.zeros(nq + 1, dtype=np.uint32)
-        ids = np.zeros(cap, dtype=np.uint32)
-        dists = np.zeros(cap, dtype=np.uint32)
-        ivs = np.zeros(cap, dtype=np.uint32)
         status = np.zeros(max(nq, 1), dtype=np.int32)
-        self._check(self._lib.chd_query_channel_ids(
-            self.ctx, C.cast(arr, C.c_void_p), nq, _ptr(sx), _ptr(sz), _ptr(sd), len(sx),
-            _ptr(offsets), _ptr(ids), _ptr(dists), _ptr(ivs), cap, _ptr(status)))
+        for _ in range(2):
+            ids = np.zeros(cap, dtype=np.uint32)
+            dists = np.zeros(cap, dtype=np.uint32)
+            ivs = np.zeros(cap, dtype=np.uint32)
+            rc = self._lib.chd_query_channel_ids(
+                self.ctx, C.cast(arr, C.c_void_p), nq, _ptr(sx), _ptr(sz), _ptr(sd), len(sx),
+                _ptr(offsets), _ptr(ids), _ptr(dists), _ptr(ivs), cap, _ptr(status))
+            if rc != _lib.E_CAPACITY or int(offsets[nq]) <= cap:
+                break
+            cap = int(offsets[nq])  # (queries without an engine limit can return whole worlds: offsets[nq] says how much)
+        self._check(rc)
         res, ivr = [], []
         for i in range(nq):
             a, b = int(offsets[i]), int(offsets[i + 1])

@@ -640,6 +640,7 @@ int chd_query_channel_ids(chd_ctx *ctx, const chd_aoi_query *queries, uint32_t n
     TRY(ensure(ctx, 10, sizeof(uint32_t) * std::max(cap, 1u)));
     TRY(ensure(ctx, 11, sizeof(uint32_t) * std::max(cap, 1u)));
     TRY(ensure(ctx, 12, sizeof(uint32_t) * std::max(cap, 1u)));
+    TRY(ensure(ctx, 13, aoi_scratch_bytes(ctx->lim) * (size_t)nq));
     TRY(up(ctx, sbuf<void>(ctx, 0), queries, sizeof(chd_aoi_query) * nq));
     TRY(up(ctx, sbuf<void>(ctx, 1), spot_x, sizeof(double) * n_spots_total));
     TRY(up(ctx, sbuf<void>(ctx, 2), spot_z, sizeof(double) * n_spots_total));
@@ -647,17 +648,46 @@ int chd_query_channel_ids(chd_ctx *ctx, const chd_aoi_query *queries, uint32_t n
     else HIPCHK(hipMemsetAsync(sbuf<void>(ctx, 3), 0, sizeof(uint32_t) * std::max(n_spots_total, 1u), ctx->stream));
     launch_aoi_stateless(ctx->stream, ctx->g, ctx->lim, sbuf<chd_aoi_query>(ctx, 0), nq, sbuf<double>(ctx, 1),
                          sbuf<double>(ctx, 2), sbuf<uint32_t>(ctx, 3), stride, sbuf<uint32_t>(ctx, 4),
-                         sbuf<uint32_t>(ctx, 5), sbuf<uint32_t>(ctx, 6), sbuf<uint32_t>(ctx, 7), sbuf<int32_t>(ctx, 9));
+                         sbuf<uint32_t>(ctx, 5), sbuf<uint32_t>(ctx, 6), sbuf<uint32_t>(ctx, 7), sbuf<int32_t>(ctx, 9),
+                         sbuf<unsigned char>(ctx, 13));
+    TRY(after_launch(ctx));
+    TRY(down(ctx, status, sbuf<void>(ctx, 9), sizeof(int32_t) * nq));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    // Queries beyond the in-kernel limits (a lattice of more than 256 lines per axis, a window of more than `winmax` cells:
+    // the reference has no such limit, spatial.go:217-226) take the whole GPU one at a time (launch_aoi_big_query); their
+    // counts join the offsets scan, their rows are copied behind the gather.
+    struct Big { uint32_t qi, n; uint32_t *ids, *dists, *ivs; };
+    std::vector<Big> big;
+    auto free_big = [&]() { for (auto &b : big) { (void)hipFree(b.ids); (void)hipFree(b.dists); (void)hipFree(b.ivs); } };
+    for (uint32_t i = 0; i < nq; i++) {
+        if (status[i] != CHD_E_TOO_LARGE) continue;
+        Big b{i, 0, nullptr, nullptr, nullptr};
+        status[i] = launch_aoi_big_query(ctx->stream, ctx->g, queries[i], sbuf<double>(ctx, 1), sbuf<double>(ctx, 2), sbuf<uint32_t>(ctx, 3),
+                                         &b.ids, &b.dists, &b.ivs, &b.n);
+        if (status[i] == CHD_E_HIP) { free_big(); return fail(ctx, CHD_E_HIP, "chd_query_channel_ids: query %u: out of device memory for its cell window", i); }
+        if (status[i] == CHD_OK) {
+            big.push_back(b);
+            HIPCHK(hipMemcpyAsync(sbuf<uint32_t>(ctx, 7) + i, &big.back().n, sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream));
+            HIPCHK(hipStreamSynchronize(ctx->stream));  // (the count lives in a vector element)
+        }
+    }
     launch_scan_u32(ctx->stream, sbuf<uint32_t>(ctx, 7), sbuf<uint32_t>(ctx, 8), nq);
     launch_csr_gather(ctx->stream, nq, stride, sbuf<uint32_t>(ctx, 7), sbuf<uint32_t>(ctx, 8), sbuf<uint32_t>(ctx, 4),
                       sbuf<uint32_t>(ctx, 5), sbuf<uint32_t>(ctx, 6), sbuf<uint32_t>(ctx, 10), sbuf<uint32_t>(ctx, 11),
-                      sbuf<uint32_t>(ctx, 12), cap, ctx->g.id_start);
-    TRY(after_launch(ctx));
-    TRY(down(ctx, offsets, sbuf<void>(ctx, 8), sizeof(uint32_t) * (nq + 1)));
-    TRY(down(ctx, status, sbuf<void>(ctx, 9), sizeof(int32_t) * nq));
-    HIPCHK(hipStreamSynchronize(ctx->stream));
+                      sbuf<uint32_t>(ctx, 12), cap, ctx->g.id_start, sbuf<int32_t>(ctx, 9));
+    if (hipGetLastError() != hipSuccess) { free_big(); return fail(ctx, CHD_E_HIP, "chd_query_channel_ids: launch failed"); }
+    if (hipMemcpyAsync(offsets, sbuf<void>(ctx, 8), sizeof(uint32_t) * (nq + 1), hipMemcpyDeviceToHost, ctx->stream) != hipSuccess ||
+        hipStreamSynchronize(ctx->stream) != hipSuccess) { free_big(); return fail(ctx, CHD_E_HIP, "chd_query_channel_ids: download failed"); }
     uint32_t total = offsets[nq];
-    if (total > cap) return fail(ctx, CHD_E_CAPACITY, "chd_query_channel_ids: %u results, capacity %u", total, cap);
+    if (total > cap) { free_big(); return fail(ctx, CHD_E_CAPACITY, "chd_query_channel_ids: %u results, capacity %u", total, cap); }
+    for (auto &b : big) {
+        const uint32_t at = offsets[b.qi];
+        (void)hipMemcpyAsync(sbuf<uint32_t>(ctx, 10) + at, b.ids, 4 * (size_t)b.n, hipMemcpyDeviceToDevice, ctx->stream);
+        (void)hipMemcpyAsync(sbuf<uint32_t>(ctx, 11) + at, b.dists, 4 * (size_t)b.n, hipMemcpyDeviceToDevice, ctx->stream);
+        (void)hipMemcpyAsync(sbuf<uint32_t>(ctx, 12) + at, b.ivs, 4 * (size_t)b.n, hipMemcpyDeviceToDevice, ctx->stream);
+    }
+    if (!big.empty()) (void)hipStreamSynchronize(ctx->stream);
+    free_big();
     TRY(down(ctx, ids, sbuf<void>(ctx, 10), sizeof(uint32_t) * total));
     TRY(down(ctx, dists, sbuf<void>(ctx, 11), sizeof(uint32_t) * total));
     if (intervals_ms) TRY(down(ctx, intervals_ms, sbuf<void>(ctx, 12), sizeof(uint32_t) * total));
@@ -851,6 +881,7 @@ int chd_world_create(chd_ctx *ctx, const chd_world_cfg *cfg) {
     d.ce_sprev_stride = 0;
     d.cell_start = d.cell_off;
     d.cell_end = d.cell_off + 1;
+    TRY(walloc(ctx, &d.aoi_scratch, aoi_scratch_bytes(ctx->lim) * S, false));
     TRY(walloc(ctx, &d.conn_id, S));
     TRY(walloc(ctx, &d.sub_alive, S));
     TRY(walloc(ctx, &d.sub_tick, S));

@@ -105,6 +105,7 @@ struct WorldDev {
     uint32_t *limbo_n;        // [2]
     uint32_t *mig_gmax;       // [4] by tick & 3: the largest emigrant segment count of that tick's exchange, over ALL ranks
     // subscribers
+    unsigned char *aoi_scratch;  // [S * aoi_scratch_bytes] the interest kernel's long-lattice work areas, per subscriber slot
     uint32_t *conn_id;    // [S]
     uint32_t *sub_alive;  // [S]
     uint32_t *sub_tick;   // [S] tick of the subscriber's last interest update
@@ -317,7 +318,8 @@ struct AoiLimits {
 void launch_aoi_stateless(hipStream_t st, DevGrid g, AoiLimits lim, const chd_aoi_query *q,
                           uint32_t nq, const double *spot_x, const double *spot_z,
                           const uint32_t *spot_dist, uint32_t stride, uint32_t *cells,
-                          uint32_t *dists, uint32_t *ivs, uint32_t *counts, int32_t *status);
+                          uint32_t *dists, uint32_t *ivs, uint32_t *counts, int32_t *status, unsigned char *scratch);
+size_t aoi_scratch_bytes(AoiLimits lim);  // global scratch per query (long-lattice path)
 void launch_aoi_interest(hipStream_t st, DevGrid g, AoiLimits lim, WorldDev w,
                          const chd_aoi_query *q, uint32_t nq, const uint32_t *q_sub,
                          const double *spot_x, const double *spot_z, const uint32_t *spot_dist,
@@ -332,7 +334,12 @@ void launch_scan_u32_inplace_dev(hipStream_t st, uint32_t *data, uint32_t n_max,
 void launch_csr_gather(hipStream_t st, uint32_t nq, uint32_t stride, const uint32_t *counts,
                        const uint32_t *offsets, const uint32_t *cells, const uint32_t *dists,
                        const uint32_t *ivs, uint32_t *out_ids, uint32_t *out_dists,
-                       uint32_t *out_ivs, uint32_t cap, uint32_t id_start);
+                       uint32_t *out_ivs, uint32_t cap, uint32_t id_start, const int32_t *status = nullptr);
+// One query beyond the in-kernel limits (lattice lines / cell window), on the whole GPU in passes over global memory; `q` is a
+// HOST copy, spots are device arrays.  On CHD_OK: *count results (ascending channel id) in freshly hipMalloc'ed device arrays
+// the caller frees; else the reference's error for the query (or CHD_E_TOO_LARGE beyond 65 535 lattice lines per axis).
+int launch_aoi_big_query(hipStream_t st, DevGrid g, const chd_aoi_query &q, const double *d_spot_x, const double *d_spot_z,
+                         const uint32_t *d_spot_dist, uint32_t **d_ids, uint32_t **d_dists, uint32_t **d_ivs, uint32_t *count);
 // wire-format fan-out buffers
 struct WireDev {
     uint32_t stride[2];                 // payload slot size in bytes: [0] update (delta), [1] full state

@@ -385,11 +385,46 @@ def test_query_large_grid_window_path(amd):
         assert int(status[i]) == rc and res[i] == want, f"query {i}"
         n_ok += rc == 0
     assert n_ok > n // 3
-    # a world-wide query exceeds the engine's window and says so instead of guessing
-    from channeld_amd import _lib
-
+    # a world-wide query exceeds the in-kernel window (4096 cells): it takes the whole-GPU passes and still equals the oracle
     big = amd.SpatialInterestQuery(SphereAOI=amd.SphereAOI(Center=amd.SpatialInfo(X=0, Z=0), Radius=2900))
-    assert ctl.QueryChannelIds(big)[1].code == _lib.E_TOO_LARGE
+    got, err = ctl.QueryChannelIds(big)
+    rc, want = orc.query_channel_ids(g, orc.QueryBuilder(sphere=(0, 0, 2900)))
+    assert err is None and rc == 0 and got == want and len(got) > 4096
+
+
+def test_query_without_engine_limits_on_the_reference_sizing_note(amd):
+    """VERDICT r2 #8 / spatial.go:85-88,217-226: the reference's own sizing note — a 100 x 100 km world of 50 m cells (2000 x
+    2000) — with the production-like radius of its tests (R = 30 000, spatial_test.go:223-236): 2 401 lattice lines per axis,
+    5.8 M samples, a window of 1 201 x 1 201 cells, ~1.1 M channel ids in the result.  No in-kernel path holds that; the
+    stateless API takes the whole GPU in passes over global memory (launch_aoi_big_query) and returns what the reference's loop
+    nest returns: key set and dists.  Also a box and a cone of that size, several shapes in one query, the error cases."""
+    grid = (50, 50, -50000, -50000, 2000, 2000)
+    ctl = make_ctl(amd, *grid)
+    g = orc.grid(*grid)
+    cases = [
+        (dict(SphereAOI=amd.SphereAOI(Center=amd.SpatialInfo(X=1234.5, Z=-987.25), Radius=30000)), dict(sphere=(1234.5, -987.25, 30000))),
+        (dict(BoxAOI=amd.BoxAOI(Center=amd.SpatialInfo(X=-20000, Z=30000), Extent=amd.SpatialInfo(X=25000, Z=9000))), dict(box=(-20000, 30000, 25000, 9000))),
+        (dict(ConeAOI=amd.ConeAOI(Center=amd.SpatialInfo(X=100, Z=200), Direction=amd.SpatialInfo(X=0.6, Z=0.8), Radius=28000, Angle=0.5236)),
+         dict(cone=(100, 200, 0.6, 0.8, 28000, 0.5236))),
+        (dict(BoxAOI=amd.BoxAOI(Center=amd.SpatialInfo(X=0, Z=0), Extent=amd.SpatialInfo(X=12000, Z=12000)),
+              SphereAOI=amd.SphereAOI(Center=amd.SpatialInfo(X=9000, Z=9000), Radius=15000)), dict(box=(0, 0, 12000, 12000), sphere=(9000, 9000, 15000))),
+    ]
+    for k, (kw, okw) in enumerate(cases):
+        got, err = ctl.QueryChannelIds(amd.SpatialInterestQuery(**kw))
+        rc, want = orc.query_channel_ids(g, orc.QueryBuilder(**okw), cap=2000 * 2000)
+        assert err is None and rc == 0, (k, err, rc)
+        assert got == want, f"case {k}: {len(got)} vs {len(want)} cells"
+        assert len(got) > 100_000
+    # errors stay the reference's: a centre outside the world (after the lattice), a zero extent
+    out = amd.SpatialInterestQuery(SphereAOI=amd.SphereAOI(Center=amd.SpatialInfo(X=60000, Z=0), Radius=30000))
+    assert ctl.QueryChannelIds(out)[1].code == orc.query_channel_ids(g, orc.QueryBuilder(sphere=(60000, 0, 30000)), cap=2000 * 2000)[0] != 0
+    # ... and a batch that mixes small and unlimited queries keeps its order
+    small = amd.SpatialInterestQuery(SphereAOI=amd.SphereAOI(Center=amd.SpatialInfo(X=10, Z=10), Radius=120))
+    bigq = amd.SpatialInterestQuery(SphereAOI=amd.SphereAOI(Center=amd.SpatialInfo(X=10, Z=10), Radius=9000))
+    status, res = ctl.query_channel_ids_batch([small, bigq, small])
+    assert list(status) == [0, 0, 0] and res[0] == res[2]
+    assert res[0] == orc.query_channel_ids(g, orc.QueryBuilder(sphere=(10, 10, 120)), cap=2000 * 2000)[1]
+    assert res[1] == orc.query_channel_ids(g, orc.QueryBuilder(sphere=(10, 10, 9000)), cap=2000 * 2000)[1]
 
 
 # ---------------------------------------------------------------- regions / adjacency / servers
