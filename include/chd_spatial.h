@@ -48,7 +48,10 @@ typedef enum {
     CHD_E_CENTER = -4,      /* per-query: AOI centre out of the world (spatial.go:228-231 ...) */
     CHD_E_CAPACITY = -5,    /* output / interest-set capacity exceeded */
     CHD_E_HANG = -6,        /* the reference would loop forever on this input */
-    CHD_E_TOO_LARGE = -8,   /* per-query: sample lattice or cell window beyond engine limits */
+    CHD_E_TOO_LARGE = -8,   /* per-query, interest updates of chd_tick only: sample lattice (> 256 lines per axis) or cell
+                               window (> 4096 cells) beyond the in-kernel limits — such an interest set would exceed
+                               max_interest_cells anyway.  chd_query_channel_ids has no such limit (beyond 65 535 lattice
+                               lines per axis): larger queries take whole-GPU passes over global memory */
     CHD_E_NO_DEVICE = -9,   /* no usable HIP device / kernel image */
     CHD_E_HIP = -10,        /* HIP runtime error (message in chd_last_error) */
     CHD_E_STATE = -11       /* call sequence error (e.g. tick before world_create) */
