@@ -14,7 +14,9 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libchd_spatial.so")
-SOURCES = ["chd_api.hip", "k_spatial.hip", "k_index.hip", "k_aoi.hip", "k_fanout.hip", "k_shard.hip", "k_recipients.hip", "k_wire.hip"]
+# k_front.hip is a unity build of k_spatial.hip + k_index.hip + k_aoi.hip (it fuses their kernel bodies into one launch)
+SOURCES = ["chd_api.hip", "k_front.hip", "k_fanout.hip", "k_shard.hip", "k_recipients.hip", "k_wire.hip"]
+UNITY_PARTS = ["k_spatial.hip", "k_index.hip", "k_aoi.hip"]
 HEADERS = ["chd_device.h", "chd_kernels.h", os.path.join("..", "..", "include", "chd_spatial.h")]
 FLAGS = [
     "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off",
@@ -36,7 +38,7 @@ def stale() -> bool:
     if not os.path.exists(LIB):
         return True
     t = os.path.getmtime(LIB)
-    deps = [os.path.join(CSRC, s) for s in SOURCES + HEADERS] + [os.path.abspath(__file__)]
+    deps = [os.path.join(CSRC, s) for s in SOURCES + UNITY_PARTS + HEADERS] + [os.path.abspath(__file__)]
     return any(os.path.getmtime(d) > t for d in deps)
 
 

@@ -68,6 +68,7 @@ struct World {
     uint4 *pb_seg_desc[2] = {nullptr, nullptr}, *pb_seg_desc2[2] = {nullptr, nullptr};
     chd_fanout_rec *pb_recs[2] = {nullptr, nullptr};
     hipEvent_t ev_stages_done = nullptr, ev_stages_all = nullptr, ev_rec_sync = nullptr, ev_emit_done[2] = {nullptr, nullptr};
+    unsigned long long front_seq = 0;  // fused front launches so far (k_front.hip: its grid-barrier counters only grow)
     bool last_desc = false;            // the last tick took the descriptor path (k_fanout_plan_seg's descriptors are this tick's)
     uint32_t *seg_cnt = nullptr;       // [S + 1] chd_tick_fetch_segments: segments per connection -> offsets
     uint64_t *seg_exp = nullptr;       // [S + 1] explicit records per connection -> offsets
@@ -871,6 +872,7 @@ int chd_world_create(chd_ctx *ctx, const chd_world_cfg *cfg) {
     d.ghost_cap = 0;
     TRY(walloc(ctx, &d.free_stack, N));
     TRY(walloc(ctx, &d.free_top, 1));
+    TRY(walloc(ctx, &d.front_bar, (8 + 8 + 1) * 16));  // (k_front.hip: struct FrontBar)
     d.limbo = nullptr;  // (chd_shard_halo_layout)
     TRY(walloc(ctx, &d.limbo_n, 2));
     TRY(walloc(ctx, &d.mig_gmax, 4));
@@ -1402,7 +1404,18 @@ static int tick_locked(chd_ctx *ctx, const chd_tick_in *in) {
     // only, so the two can run side by side on two streams and join before the fan-out plan.  (Not with handover
     // recipients: those are planned on the subscriptions as they were BEFORE this tick's interest updates.)
     // Pipelined ticks always do, on a third stream (their stages are latency-bound and run beside an HBM-saturating kernel).
-    const bool overlap = (W.overlap_interest || pipe) && !W.plan_recipients && in->n_queries > 0;
+    // The front of the tick — ingest -> cell index, and the interest updates — in ONE launch where it can be (k_front.hip):
+    // grids of up to 1024 cells, up to 512 index tiles (256 K entity slots), one round of updates, nothing between the ingest
+    // and the index (spatial-channel updates, handover recipients), no exact update buffers (their maxFanOutIntervalMs is
+    // written by the interest updates and read by the ingest).  OFF unless CHD_FRONT_FUSED=1: measured on config B it does not
+    // pay — the index chain with its three XCD-hierarchical grid barriers takes 44.6 us inside the launch (37 us as four
+    // kernels: a dependent kernel boundary costs ~1.5 us, a grid barrier 4-5), the interest half 44.3 us in 256-thread
+    // workgroups (40 in 64-thread ones), and together they take 68 us, not max(): both halves are issue-bound on the same CUs.
+    // Tick 0.2670 (fused) against 0.2695 ms.  Kept as an experiment (profiles/r03j_front_fusion.json).
+    const bool front_on = [] { const char *e = getenv("CHD_FRONT_FUSED"); return e && e[0] == '1'; }();
+    const bool fuse = front_on && front_fusable(ctx->g, d) && !W.plan_recipients && !in->n_cell_updates && in->n_update_rounds <= 1 &&
+                      !d.deep_depth && in->n_queries > 0 && in->n_updates > 0;
+    const bool overlap = !fuse && (W.overlap_interest || pipe) && !W.plan_recipients && in->n_queries > 0;
     // stage events: the serial schedule marks every stage boundary; the pipelined one only the begin and end of the stage
     // stream's work (a timed event between two small kernels costs ~5 us of idle stream) — stage_times() reports that
     // span as stage 0
@@ -1413,45 +1426,54 @@ static int tick_locked(chd_ctx *ctx, const chd_tick_in *in) {
         ctx->ev_overlap[r.cur_tick % (uint32_t)ctx->prof_depth] = (overlap ? 1 : 0) | (pipe ? 2 : 0) | (prof_ends ? 0 : 4);
         if (prof_ends) HIPCHK(hipEventRecord(ev[0], bs));
     }
-    if (overlap) {
-        hipStream_t ax = pipe ? ctx->aux2_stream : ctx->aux_stream;
-        HIPCHK(hipEventRecord(ctx->ev_fork, bs));
-        HIPCHK(hipStreamWaitEvent(ax, ctx->ev_fork, 0));
-        if (prof_stages) HIPCHK(hipEventRecord(ev[CHD_N_STAGES + 1], ax));
-        launch_aoi_interest(ax, ctx->g, ctx->lim, d, in->queries, in->n_queries, in->query_sub, in->spot_x, in->spot_z,
-                            in->spot_dist, in->now_ns, r.cur_tick);
-        if (prof_stages) HIPCHK(hipEventRecord(ev[CHD_N_STAGES + 2], ax));
-        HIPCHK(hipEventRecord(ctx->ev_join, ax));
-    }
-    {
-        // one ingest launch per round of updates (a channel's r-th update of this tick: chd_tick_in.upd_round_off)
-        const uint32_t one[2] = {0u, in->n_updates};
-        const uint32_t nr = in->n_update_rounds ? in->n_update_rounds : 1u;
-        const uint32_t *off = in->n_update_rounds ? in->upd_round_off : one;
-        for (uint32_t k = 0; k < nr; k++) {
-            const uint32_t a = off[k], n = off[k + 1] - a;
-            launch_ingest(bs, ctx->g, d, n, in->upd_idx ? in->upd_idx + a : nullptr, in->upd_x + a, in->upd_z + a,
-                          in->upd_sender ? in->upd_sender + a : nullptr, r.cur_tick, in->upd_arrival_ns ? in->upd_arrival_ns + a : nullptr,
-                          in->now_ns);
+    if (fuse) {
+        launch_front(bs, ctx->g, ctx->lim, d, ++W.front_seq, in->n_updates, in->upd_idx, in->upd_x, in->upd_z, in->upd_sender,
+                     in->upd_arrival_ns, in->queries, in->n_queries, in->query_sub, in->spot_x, in->spot_z, in->spot_dist, in->now_ns,
+                     r.cur_tick);
+        if (d.wcol_on && fanout_seg_path(d)) launch_window_columns(bs, ctx->g, d);
+        // (one launch: the ingest / index / interest stage times read as one, under CHD_STAGE_INGEST)
+        if (prof_stages) { HIPCHK(hipEventRecord(ev[1], bs)); HIPCHK(hipEventRecord(ev[2], bs)); }
+    } else {
+        if (overlap) {
+            hipStream_t ax = pipe ? ctx->aux2_stream : ctx->aux_stream;
+            HIPCHK(hipEventRecord(ctx->ev_fork, bs));
+            HIPCHK(hipStreamWaitEvent(ax, ctx->ev_fork, 0));
+            if (prof_stages) HIPCHK(hipEventRecord(ev[CHD_N_STAGES + 1], ax));
+            launch_aoi_interest(ax, ctx->g, ctx->lim, d, in->queries, in->n_queries, in->query_sub, in->spot_x, in->spot_z,
+                                in->spot_dist, in->now_ns, r.cur_tick);
+            if (prof_stages) HIPCHK(hipEventRecord(ev[CHD_N_STAGES + 2], ax));
+            HIPCHK(hipEventRecord(ctx->ev_join, ax));
         }
+        {
+            // one ingest launch per round of updates (a channel's r-th update of this tick: chd_tick_in.upd_round_off)
+            const uint32_t one[2] = {0u, in->n_updates};
+            const uint32_t nr = in->n_update_rounds ? in->n_update_rounds : 1u;
+            const uint32_t *off = in->n_update_rounds ? in->upd_round_off : one;
+            for (uint32_t k = 0; k < nr; k++) {
+                const uint32_t a = off[k], n = off[k + 1] - a;
+                launch_ingest(bs, ctx->g, d, n, in->upd_idx ? in->upd_idx + a : nullptr, in->upd_x + a, in->upd_z + a,
+                              in->upd_sender ? in->upd_sender + a : nullptr, r.cur_tick, in->upd_arrival_ns ? in->upd_arrival_ns + a : nullptr,
+                              in->now_ns);
+            }
+        }
+        launch_cell_updates(bs, ctx->g, d, in->n_cell_updates, in->cell_upd_channel, in->cell_upd_sender, r.cur_tick,
+                            in->cell_upd_arrival_ns, in->now_ns);
+        if (W.plan_recipients) {
+            // who receives each handover's message: on the subscriptions as they are NOW, before this tick's
+            // interest updates (the reference sends from Notify, spatial.go:776-857)
+            launch_handover_recipients_count(bs, ctx->g, d, W.ho_rcp_off);
+            launch_scan_u32_inplace_dev(bs, W.ho_rcp_off, d.handovers_cap, d.counters + CTR_HANDOVERS);
+            launch_handover_recipients_fill(bs, ctx->g, d, W.ho_rcp_off, W.ho_rcp_conn, W.ho_rcp_kind, W.ho_rcp_cap);
+        }
+        if (prof_stages) HIPCHK(hipEventRecord(ev[1], bs));
+        launch_index_build(bs, ctx->g, d, r.cur_tick);
+        if (d.wcol_on && fanout_seg_path(d)) launch_window_columns(bs, ctx->g, d);
+        if (prof_stages) HIPCHK(hipEventRecord(ev[2], bs));
+        if (overlap) HIPCHK(hipStreamWaitEvent(bs, ctx->ev_join, 0));
+        else
+            launch_aoi_interest(bs, ctx->g, ctx->lim, d, in->queries, in->n_queries, in->query_sub, in->spot_x, in->spot_z,
+                                in->spot_dist, in->now_ns, r.cur_tick);
     }
-    launch_cell_updates(bs, ctx->g, d, in->n_cell_updates, in->cell_upd_channel, in->cell_upd_sender, r.cur_tick,
-                        in->cell_upd_arrival_ns, in->now_ns);
-    if (W.plan_recipients) {
-        // who receives each handover's message: on the subscriptions as they are NOW, before this tick's
-        // interest updates (the reference sends from Notify, spatial.go:776-857)
-        launch_handover_recipients_count(bs, ctx->g, d, W.ho_rcp_off);
-        launch_scan_u32_inplace_dev(bs, W.ho_rcp_off, d.handovers_cap, d.counters + CTR_HANDOVERS);
-        launch_handover_recipients_fill(bs, ctx->g, d, W.ho_rcp_off, W.ho_rcp_conn, W.ho_rcp_kind, W.ho_rcp_cap);
-    }
-    if (prof_stages) HIPCHK(hipEventRecord(ev[1], bs));
-    launch_index_build(bs, ctx->g, d, r.cur_tick);
-    if (d.wcol_on && fanout_seg_path(d)) launch_window_columns(bs, ctx->g, d);
-    if (prof_stages) HIPCHK(hipEventRecord(ev[2], bs));
-    if (overlap) HIPCHK(hipStreamWaitEvent(bs, ctx->ev_join, 0));
-    else
-        launch_aoi_interest(bs, ctx->g, ctx->lim, d, in->queries, in->n_queries, in->query_sub, in->spot_x, in->spot_z,
-                            in->spot_dist, in->now_ns, r.cur_tick);
     if (prof_stages) HIPCHK(hipEventRecord(ev[3], bs));
     launch_fanout_plan(bs, ctx->g, d, in->now_ns, r);
     if (prof_stages) HIPCHK(hipEventRecord(ev[4], bs));

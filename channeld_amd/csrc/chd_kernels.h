@@ -105,6 +105,7 @@ struct WorldDev {
     uint32_t *limbo_n;        // [2]
     uint32_t *mig_gmax;       // [4] by tick & 3: the largest emigrant segment count of that tick's exchange, over ALL ranks
     // subscribers
+    unsigned long long *front_bar;  // [3 x 16] grid-barrier counters of the fused front kernel (k_front.hip), one 128-byte line each
     unsigned char *aoi_scratch;  // [S * aoi_scratch_bytes] the interest kernel's long-lattice work areas, per subscriber slot
     uint32_t *conn_id;    // [S]
     uint32_t *sub_alive;  // [S]
@@ -303,6 +304,10 @@ void launch_halo_unpack(hipStream_t st, DevGrid g, WorldDev w, uint32_t rank, ui
                         const uint64_t *seg_off, const uint32_t *ghost_off);
 // K2: cell index build
 void launch_index_build(hipStream_t st, DevGrid g, WorldDev w, uint32_t cur_tick);
+// K1 + K2 + K3/K4 in ONE launch (k_front.hip): the ingest -> index chain beside the interest updates.  launch_seq = 1, 2, ...
+// (how many times this world has taken the fused launch: the grid-barrier counters only grow).
+struct AoiLimits;
+bool front_fusable(const DevGrid &g, const WorldDev &w);
 // the window columns of the cells that are not fully updated (WorldDev::wcol_*); after the index build
 void launch_window_columns(hipStream_t st, DevGrid g, WorldDev w);
 #define CHD_WCOLS 9
@@ -315,6 +320,10 @@ struct AoiLimits {
     uint32_t winmax;  // cells in the per-query table
     uint32_t maxdim;  // max(window width, window height) <= max(cols, rows)
 };
+void launch_front(hipStream_t st, DevGrid g, AoiLimits lim, WorldDev w, unsigned long long launch_seq, uint32_t n_upd,
+                  const uint32_t *upd_idx, const double *upd_x, const double *upd_z, const uint32_t *upd_sender,
+                  const int64_t *upd_arrival, const chd_aoi_query *queries, uint32_t nq, const uint32_t *q_sub,
+                  const double *spot_x, const double *spot_z, const uint32_t *spot_dist, int64_t now_ns, uint32_t cur_tick);
 void launch_aoi_stateless(hipStream_t st, DevGrid g, AoiLimits lim, const chd_aoi_query *q,
                           uint32_t nq, const double *spot_x, const double *spot_z,
                           const uint32_t *spot_dist, uint32_t stride, uint32_t *cells,

@@ -904,8 +904,7 @@ __global__ void __launch_bounds__(64 * FO_WAVES) k_fanout_plan_seg(DevGrid g, Wo
         uint64_t ub = 0;
         bool due = false, simple = false, deep = false;
         uint32_t fl = 0, c = 0, size = 0, start = 0, info = 0, count = 0;
-        uint32_t why = 0;  // (diagnosis builds)
-        uint32_t nd = 0, d_start[4] = {0, 0, 0, 0}, d_n[4] = {0, 0, 0, 0}, d_info[4] = {0, 0, 0, 0}, d_cnt[4] = {0, 0, 0, 0};
+        uint32_t nd = 0, wcolp = 0, own = 0, ncol0 = 0;  // descriptors of this subscription; per window its column (4 bits each)
         int64_t Lw = 0;
         if (p < cnt) {
             fl = w.pair_flags[pbase + p] & ~(PF_DEFER | PF_DEEP);
@@ -977,13 +976,11 @@ __global__ void __launch_bounds__(64 * FO_WAVES) k_fanout_plan_seg(DevGrid g, Wo
                 // (a column of up to 512 entries is four 8-byte loads per lane; larger cells take the deferred launch — and at
                 // >= 1024 entities per cell the cell-major form is the default anyway)
                 simple = chans != nullptr && nw <= 4 && size <= 512;
-                if (!simple) why = 0x10000000u | (nw << 16) | size;
                 // Which column every non-empty window copies: the cell's full column when every entity has an update inside
                 // the window (the AND of their histories intersects it), else — partially updating worlds — the WINDOW COLUMN
                 // of exactly that mask (wcol_mask: runs of 1..3 ticks that start at the newest or the one before — what a
                 // subscription served every interval sees).  A descriptor carries one column: windows that agree share one
                 // descriptor, a subscription whose windows differ gets one descriptor per window (contiguous parts).
-                uint32_t wcol[4] = {0u, 0u, 0u, 0u};  // per window: 0 = full column, k + 1 = window column k
                 bool same = true;
 #pragma unroll
                 for (uint32_t j = 0; j < 4; j++) {
@@ -997,39 +994,35 @@ __global__ void __launch_bounds__(64 * FO_WAVES) k_fanout_plan_seg(DevGrid g, Wo
                                 if (wms[j] == wcol_mask(k)) cj = k + 1u;
                         }
                     }
-                    if (cj == 0xFFFFFFFEu) { simple = false; why = 0x20000000u | (us == CHD_NONUNIFORM ? 0x1000000u : 0u) | (j << 20) | (wms[j] & 0xFFFFFu); }
-                    wcol[j] = cj;
-                    if (j && cj != wcol[0]) same = false;
+                    if (cj == 0xFFFFFFFEu) simple = false;
+                    wcolp |= (cj & 15u) << (4u * j);
+                    if (j && cj != (wcolp & 15u)) same = false;
                 }
                 if (simple) {
                     // exact record counts: the segment is as long as what will be written
                     const uint32_t age = ring.cur_tick - c_htick;
                     const uint32_t chh = age < CHD_HIST_BITS ? (c_hist << age) : 0u;
                     const uint32_t chhp = age < CHD_HIST_BITS ? (c_hprev << age) : 0u;
-                    uint32_t own = 0;
 #pragma unroll
                     for (uint32_t j = 0; j < 4; j++)
                         if (j < nw && cell_update_passes(chh, chs, chhp, chsp, wms[j], skip_self, conn)) own |= 1u << j;
+                    info |= nw | (none ? SD_NONE : 0u);
                     if ((info & SD_FIRST) || nw == 0 || none || same) {
                         // one descriptor: first fan-out (full column, no window), nothing to send, or windows that agree
-                        const uint32_t col = ((info & SD_FIRST) || nw == 0 || none) ? 0u : wcol[0];
-                        const uint32_t ncol = col ? w.cell_wcnt[(size_t)(col - 1u) * g.ncell + c] : size;
+                        if ((info & SD_FIRST) || nw == 0 || none) wcolp = 0u;
+                        const uint32_t col = wcolp & 15u;
+                        ncol0 = col ? w.cell_wcnt[(size_t)(col - 1u) * g.ncell + c] : size;
                         nd = 1;
-                        d_start[0] = start + col * w.wcol_stride;
-                        d_n[0] = ncol;
-                        d_info[0] = info | nw | (none ? SD_NONE : 0u) | (own << SD_OWN_SHIFT);
-                        d_cnt[0] = ((info & SD_FIRST) ? size + 1u : 0u) + (uint32_t)__popc(own) + (none ? 0u : nw * ncol);
+                        count = ((info & SD_FIRST) ? size + 1u : 0u) + (uint32_t)__popc(own) + (none ? 0u : nw * ncol0);
                     } else {
+                        // the windows copy different columns: one descriptor per window, contiguous parts of the segment
                         nd = nw;
+                        count = (uint32_t)__popc(own);
 #pragma unroll
                         for (uint32_t j = 0; j < 4; j++) {
                             if (j >= nw) continue;
-                            const uint32_t col = wcol[j];
-                            const uint32_t ncol = col ? w.cell_wcnt[(size_t)(col - 1u) * g.ncell + c] : size;
-                            d_start[j] = start + col * w.wcol_stride;
-                            d_n[j] = ncol;
-                            d_info[j] = 1u | (((own >> j) & 1u) << SD_OWN_SHIFT) | (j + 1u < nw ? SD_NOPAD : 0u);
-                            d_cnt[j] = ((own >> j) & 1u) + ncol;
+                            const uint32_t col = (wcolp >> (4u * j)) & 15u;
+                            count += col ? w.cell_wcnt[(size_t)(col - 1u) * g.ncell + c] : size;
                         }
                     }
                     if (hlost) hist_ovf = 1;  // (a deferred subscription is counted by the deferred launch)
@@ -1047,16 +1040,7 @@ __global__ void __launch_bounds__(64 * FO_WAVES) k_fanout_plan_seg(DevGrid g, Wo
         const uint32_t dbase = n_simple + dinc - (simple ? nd : 0u);
         if (simple && dbase + nd > w.capq) simple = false;
         if (due && !simple) w.pair_flags[pbase + p] = fl | PF_DEFER;
-#ifdef CHD_PLAN_DEBUG  // diagnosis builds: why was this subscription left to the filtering launch?
-        if (due && !simple && s < 40 && ring.cur_tick >= 8 && ring.cur_tick <= 9)
-            printf("tick %u s %u p %u iv %u why %x\n", ring.cur_tick, s, p, w.pair_iv[pbase + p], why);
-#endif
-        if (due && simple) {
-            count = 0;
-#pragma unroll
-            for (uint32_t j = 0; j < 4; j++) if (j < nd) count += d_cnt[j];
-            ub = count;
-        }
+        if (due && simple) ub = count;
         // every segment starts on a 128-byte line and is padded to whole lines (k_fanout_plan)
         ub = (ub + (CHD_SEG_ALIGN - 1)) & ~(uint64_t)(CHD_SEG_ALIGN - 1);
         uint64_t inc = ub;
@@ -1075,15 +1059,24 @@ __global__ void __launch_bounds__(64 * FO_WAVES) k_fanout_plan_seg(DevGrid g, Wo
         if (__ballot(due && !simple)) any_deferred = 1;
         if (__ballot(deep)) any_deep = 1;
         if (due && simple) {
-            uint32_t at = rel32;
-#pragma unroll
-            for (uint32_t j = 0; j < 4; j++) {
-                if (j >= nd) continue;
-                const size_t k = pbase + dbase + j;
-                w.seg_desc[k] = make_uint4(at, d_start[j], d_n[j], d_info[j]);
+            if (nd == 1) {
+                const uint32_t col = wcolp & 15u;
+                const size_t k = pbase + dbase;
+                w.seg_desc[k] = make_uint4(rel32, start + col * w.wcol_stride, ncol0, info | (own << SD_OWN_SHIFT));
                 w.seg_desc2[k] = make_uint4(c, p, fl | PF_HAD_FIRST, 0u);
                 w.seg_ln[k] = Lw;
-                at += d_cnt[j];
+            } else {
+                uint32_t at = rel32;
+                for (uint32_t j = 0; j < nd; j++) {  // (rare: partially updating worlds, windows with different masks)
+                    const uint32_t col = (wcolp >> (4u * j)) & 15u;
+                    const uint32_t ncol = col ? w.cell_wcnt[(size_t)(col - 1u) * g.ncell + c] : size;
+                    const uint32_t o = (own >> j) & 1u;
+                    const size_t k = pbase + dbase + j;
+                    w.seg_desc[k] = make_uint4(at, start + col * w.wcol_stride, ncol, 1u | (o << SD_OWN_SHIFT) | (j + 1u < nd ? SD_NOPAD : 0u));
+                    w.seg_desc2[k] = make_uint4(c, p, fl | PF_HAD_FIRST, 0u);
+                    w.seg_ln[k] = Lw;
+                    at += o + ncol;
+                }
             }
             rec_simple += count;
         }

@@ -32,8 +32,7 @@
 
 uint32_t index_num_blocks(uint32_t N) { return (N + IDX_TILE - 1) / IDX_TILE; }
 
-__global__ void __launch_bounds__(IDX_BLOCK) k_index_hist(WorldDev w, uint32_t ncell, uint32_t cur_tick) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+__device__ __forceinline__ void index_hist_block(const WorldDev &w, uint32_t ncell, uint32_t cur_tick, uint32_t bid, unsigned char *smem) {
     uint32_t *h = (uint32_t *)smem;
     // per cell also the range of sender ids whose updates are still buffered: a cell whose entities all
     // have ONE sender lets the emit kernel stream 8-byte entries and test the sender once per subscription
@@ -41,7 +40,7 @@ __global__ void __launch_bounds__(IDX_BLOCK) k_index_hist(WorldDev w, uint32_t n
     uint32_t *smin = h + ncell, *smax = h + 2 * ncell, *hand = h + 3 * ncell;
     for (uint32_t c = threadIdx.x; c < ncell; c += IDX_BLOCK) { h[c] = 0; smin[c] = 0xFFFFFFFFu; smax[c] = 0; hand[c] = 0xFFFFFFFFu; }
     __syncthreads();
-    uint32_t base = blockIdx.x * IDX_TILE;
+    uint32_t base = bid * IDX_TILE;
 #pragma unroll
     for (int r = 0; r < IDX_ITEMS; r++) {
         // wave w handles the contiguous chunk [base + w*256 + r*64, +64)
@@ -72,19 +71,24 @@ __global__ void __launch_bounds__(IDX_BLOCK) k_index_hist(WorldDev w, uint32_t n
         }
     }
     __syncthreads();
-    if (w.deep_depth && blockIdx.x == 0) {  // ... and the spatial channels' own updates
+    if (w.deep_depth && bid == 0) {  // ... and the spatial channels' own updates
         for (uint32_t c = threadIdx.x; c < ncell; c += IDX_BLOCK) {
             const uint32_t it = w.cell_irr_tick[c];
             if (it && cur_tick + 1u - it < CHD_HIST_BITS) atomicOr(&w.cell_irr[c], 1u);
         }
     }
     for (uint32_t c = threadIdx.x; c < ncell; c += IDX_BLOCK) {
-        const size_t k = (size_t)c * w.nblk + blockIdx.x;
+        const size_t k = (size_t)c * w.nblk + bid;
         w.blk_cnt[k] = h[c];
         w.blk_smin[k] = smin[c];
         w.blk_smax[k] = smax[c];
         w.blk_hand[k] = hand[c];
     }
+}
+
+__global__ void __launch_bounds__(IDX_BLOCK) k_index_hist(WorldDev w, uint32_t ncell, uint32_t cur_tick) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    index_hist_block(w, ncell, cur_tick, blockIdx.x, smem);
 }
 
 template <typename T>
@@ -94,11 +98,9 @@ __device__ __forceinline__ T wave_incl_scan(T v);
 // cell in earlier blocks) and records the cell's total; the LAST workgroup to finish then scans the
 // totals into cell_off (a release/acquire pair at device scope makes the other workgroups' totals
 // visible across the XCDs' private L2s).  Replaces a single-workgroup scan over cells x blocks.
-__global__ void __launch_bounds__(256) k_index_scan(WorldDev w, uint32_t ncell, int finalize) {
-    __shared__ uint32_t is_last;
-    __shared__ uint32_t part[256];
-    const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
-    const uint32_t c = blockIdx.x * 4u + wave;
+// one wave: cell c's per-block counts -> prefixes, its total and aggregates
+__device__ __forceinline__ void index_scan_cell(const WorldDev &w, uint32_t ncell, int finalize, uint32_t c) {
+    const uint32_t lane = threadIdx.x & 63u;
     if (c < ncell) {
         uint32_t *row = w.blk_cnt + (size_t)c * w.nblk;
         uint32_t carry = 0, lo = 0xFFFFFFFFu, hi = 0, ha = 0xFFFFFFFFu;
@@ -127,6 +129,12 @@ __global__ void __launch_bounds__(256) k_index_scan(WorldDev w, uint32_t ncell, 
             w.cell_hand[c] = carry == 0 ? 0u : ha;
         }
     }
+}
+
+__global__ void __launch_bounds__(256) k_index_scan(WorldDev w, uint32_t ncell, int finalize) {
+    __shared__ uint32_t is_last;
+    __shared__ uint32_t part[256];
+    index_scan_cell(w, ncell, finalize, blockIdx.x * 4u + (threadIdx.x >> 6));
     // small grids: the scatter workgroups scan the few cell totals themselves (no cross-workgroup step)
     if (!finalize) return;
     __threadfence();
@@ -156,15 +164,14 @@ __global__ void __launch_bounds__(256) k_index_scan(WorldDev w, uint32_t ncell, 
     }
 }
 
-__global__ void __launch_bounds__(IDX_BLOCK) k_index_scatter(WorldDev w, uint32_t ncell, uint32_t key_bits,
-                                                             uint32_t cur_tick, int local_base) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+__device__ __forceinline__ void index_scatter_block(const WorldDev &w, uint32_t ncell, uint32_t key_bits, uint32_t cur_tick, int local_base,
+                                                    uint32_t bid, unsigned char *smem) {
     uint32_t *wcnt = (uint32_t *)smem;  // [4][ncell] running per-wave counters
     const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     for (uint32_t c = threadIdx.x; c < 4 * ncell; c += IDX_BLOCK) wcnt[c] = 0;
     __syncthreads();
     uint32_t *mycnt = wcnt + wave * ncell;
-    uint32_t base = blockIdx.x * IDX_TILE + wave * (IDX_ITEMS * 64);
+    uint32_t base = bid * IDX_TILE + wave * (IDX_ITEMS * 64);
     uint32_t key[IDX_ITEMS], lrank[IDX_ITEMS];
 #pragma unroll
     for (int r = 0; r < IDX_ITEMS; r++) {
@@ -218,7 +225,7 @@ __global__ void __launch_bounds__(IDX_BLOCK) k_index_scatter(WorldDev w, uint32_
             cbase[i] = run;
             run += w.cell_tot[i];
         }
-        if (blockIdx.x == 0) {  // publish the CSR offsets for the fan-out kernels
+        if (bid == 0) {  // publish the CSR offsets for the fan-out kernels
             uint32_t r2 = part[threadIdx.x];
             for (uint32_t i = lo; i < hi; i++) { w.cell_off[i] = r2; r2 += w.cell_tot[i]; }
             if (hi == ncell && lo < hi) w.cell_off[ncell] = r2;
@@ -228,7 +235,7 @@ __global__ void __launch_bounds__(IDX_BLOCK) k_index_scatter(WorldDev w, uint32_
     // exclusive prefix over the 4 waves, in place: wcnt[w][c] -> entities of c in waves < w
     for (uint32_t c = threadIdx.x; c < ncell; c += IDX_BLOCK) {
         uint32_t a0 = wcnt[c], a1 = wcnt[ncell + c], a2 = wcnt[2 * ncell + c];
-        uint32_t g0 = (local_base ? cbase[c] : w.cell_off[c]) + w.blk_cnt[(size_t)c * w.nblk + blockIdx.x];  // cell base + entities of c in earlier blocks
+        uint32_t g0 = (local_base ? cbase[c] : w.cell_off[c]) + w.blk_cnt[(size_t)c * w.nblk + bid];  // cell base + entities of c in earlier blocks
         wcnt[c] = g0;
         wcnt[ncell + c] = g0 + a0;
         wcnt[2 * ncell + c] = g0 + a0 + a1;
@@ -249,6 +256,12 @@ __global__ void __launch_bounds__(IDX_BLOCK) k_index_scatter(WorldDev w, uint32_
         w.ce_sprev[pos] = w.sender_prev[i];
         if (w.ce_slot) w.ce_slot[pos] = i;
     }
+}
+
+__global__ void __launch_bounds__(IDX_BLOCK) k_index_scatter(WorldDev w, uint32_t ncell, uint32_t key_bits,
+                                                             uint32_t cur_tick, int local_base) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    index_scatter_block(w, ncell, key_bits, cur_tick, local_base, blockIdx.x, smem);
 }
 
 // fallback for grids too large for the LDS counters: global atomics, the order

@@ -398,12 +398,13 @@ void launch_group_locks(hipStream_t st, WorldDev w) {
 // + 4 B flags; handover records are rare (1-2 %).
 // ------------------------------------------------------------------------
 #define ING_ITEMS 1
-__global__ void __launch_bounds__(256) k_ingest(DevGrid g, WorldDev w, uint32_t n,
-                                                const uint32_t *__restrict__ idx,
-                                                const double *__restrict__ x,
-                                                const double *__restrict__ z,
-                                                const uint32_t *__restrict__ sender,
-                                                uint32_t cur_tick, const int64_t *__restrict__ arrival, int64_t now) {
+// (`bid` = which 256-update block of the batch: blockIdx.x in k_ingest, a loop variable in the fused front kernel)
+__device__ __forceinline__ void ingest_block(const DevGrid &g, const WorldDev &w, uint32_t n,
+                                             const uint32_t *__restrict__ idx,
+                                             const double *__restrict__ x,
+                                             const double *__restrict__ z,
+                                             const uint32_t *__restrict__ sender,
+                                             uint32_t cur_tick, const int64_t *__restrict__ arrival, int64_t now, uint32_t bid) {
     // handover records are compacted per wave (ballot + mbcnt) and per workgroup
     // (LDS), so the global counter sees ONE atomic per 1024 updates: same-address
     // atomics serialise at ~12 ns each and would otherwise dominate this kernel.
@@ -414,7 +415,7 @@ __global__ void __launch_bounds__(256) k_ingest(DevGrid g, WorldDev w, uint32_t 
     uint64_t hm[ING_ITEMS];
 #pragma unroll
     for (int j = 0; j < ING_ITEMS; j++) {
-        const uint32_t u = (blockIdx.x * ING_ITEMS + j) * 256u + threadIdx.x;
+        const uint32_t u = (bid * ING_ITEMS + j) * 256u + threadIdx.x;
         ho[j] = false; locked[j] = false;
         ent[j] = 0; src[j] = CHD_INVALID; dst[j] = CHD_INVALID;
         if (u < n) {
@@ -494,6 +495,15 @@ __global__ void __launch_bounds__(256) k_ingest(DevGrid g, WorldDev w, uint32_t 
             atomicOr(&w.counters[CTR_OVERFLOW], OVF_HANDOVER);
         }
     }
+}
+
+__global__ void __launch_bounds__(256) k_ingest(DevGrid g, WorldDev w, uint32_t n,
+                                                const uint32_t *__restrict__ idx,
+                                                const double *__restrict__ x,
+                                                const double *__restrict__ z,
+                                                const uint32_t *__restrict__ sender,
+                                                uint32_t cur_tick, const int64_t *__restrict__ arrival, int64_t now) {
+    ingest_block(g, w, n, idx, x, z, sender, cur_tick, arrival, now, blockIdx.x);
 }
 
 void launch_ingest(hipStream_t st, DevGrid g, WorldDev w, uint32_t n, const uint32_t *idx,
