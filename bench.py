@@ -86,6 +86,8 @@ def parse():
     ap.add_argument("--serial-ticks", action="store_true",
                     help="never pipeline successive ticks: the world is created without CHD_WORLD_PIPELINE_TICKS and only the serial "
                          "schedule is timed")
+    ap.add_argument("--write-digests", action="store_true",
+                    help="record the latency-phase ticks' record digests into tests/golden/bench_digests_B.json instead of checking them")
     ap.add_argument("--only-timed", action="store_true",
                     help="profiling runs (rocprofv3 --kernel-trace / --pmc): warm-up + the timed region and nothing else (= --no-cpu "
                          "--latency-steps 0 --e2e-ticks 0), so that per-kernel averages after skipping --warmup launches are the timed launches")
@@ -423,11 +425,26 @@ def main():
     if pipe:
         world.set_pipelining(False)  # (one synchronous tick at a time: nothing to pipeline; the stage events need the serial schedule)
     lat = []
+    golden = load_bench_digests(args, N, S, M)
+    digests_checked, digests_out = 0, {}
     for t in range(W + K + K2, W + K + K2 + L):
         a = time.perf_counter()
         tick(t)
         world.sync()
         lat.append((time.perf_counter() - a) * 1e3)
+        # (outside the latency clock) the tick's records, digested where they lie, against the committed list: every tick of this
+        # world is a function of the seed alone, whatever the schedule; tick t + 1 is the (t + 1)-th tick since the world began
+        if golden is not None or args.write_digests:
+            (cnt, dsum, dxor, _), _ = world.digest(per_connection=False)
+            if args.write_digests:
+                digests_out[str(t + 1)] = [cnt, dsum, dxor]
+            elif str(t + 1) in golden:
+                if golden[str(t + 1)] != [cnt, dsum, dxor]:
+                    raise SystemExit(f"bench.py: tick {t + 1}: records digest {[cnt, dsum, dxor]} != committed {golden[str(t + 1)]} "
+                                     f"(tests/golden/bench_digests_B.json): the fan-out of this run is not the fan-out this world has")
+                digests_checked += 1
+    if args.write_digests:
+        write_bench_digests(digests_out)
     lat = np.array(lat) if lat else np.array([0.0])
     lat_hist = world.history(min(L, 1024)) if L else []
     gpu_lat = np.array([h["total_us"] for h in lat_hist]) / 1e3 if L else np.array([0.0])
@@ -470,11 +487,18 @@ def main():
     # HBM bytes per launch of the dominant kernel from the PMC passes (FETCH_SIZE / WRITE_SIZE in separate
     # rocprofv3 runs, tools/pmc_summary.py): not measurable from inside this process, so QUOTED from the committed
     # summary of the same command, and only for the workload it was measured on
-    traffic = None
+    traffic, traffic_note = None, None
     tpath = os.path.join(ROOT, "profiles", "hbm_traffic.json")
     if os.path.exists(tpath) and (N, S) == (100_000, 10_000) and args.aoi_scale == 1.0 and args.tick_ms == 50 and args.update_frac >= 1.0:
+        from channeld_amd.build import source_hash
+
         with open(tpath) as f:
-            traffic = json.load(f)["kernels"].get(DOMINANT, {}).get("bytes_per_launch")
+            tj = json.load(f)
+        # only a measurement of THESE kernel sources is quoted (the PMC passes stamp the summary with the hash of csrc/ + headers)
+        if tj.get("source_hash") == source_hash():
+            traffic = tj["kernels"].get(DOMINANT, {}).get("bytes_per_launch")
+        else:
+            traffic_note = f"profiles/hbm_traffic.json was measured on other kernel sources ({tj.get('source_hash')} != {source_hash()}): not quoted"
 
     out = {
         "metric": "AOI-filtered fanout msgs/sec + p99 tick latency, 100K entities / 10K subs",
@@ -492,12 +516,16 @@ def main():
                                if head_pipe else "serial: every tick's kernels in sequence on one stream (see pipelined_schedule for CHD_WORLD_PIPELINE_TICKS)"},
         "p50_tick_ms": float(np.percentile(lat, 50)), "p99_tick_ms": float(np.percentile(lat, 99)),
         "p99_tick_gpu_ms": float(np.percentile(gpu_lat, 99)), "latency_ticks": int(L),
+        "digest_checked_ticks": digests_checked,
+        "digest_check": "the latency-phase ticks' fan-out records (count, sum, xor of mix64(conn, channel), chd_tick_digest) against the committed per-tick "
+                        "list tests/golden/bench_digests_B.json; the same world's first 26 ticks are compared with the oracle in tests/test_gpu_fullsize.py",
         "stage_us_avg": {n: float(v) for n, v in zip(("ingest", "index", "interest", "plan", "emit"), stage_avg)},
         "stage_us_avg_is": "HIP events at every stage boundary of the latency-phase ticks (serial schedule, one synchronous tick at a time); the timed "
                            "region records only the pair around the dominant kernel (chd_set_profiling_scope)",
         "roofline": {"bound": "hbm", "kernel": dominant, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_quoted": traffic is not None,
-                     "traffic_source": "QUOTED, not measured in this run: bytes per launch from the rocprofv3 --pmc passes of this command (profiles/hbm_traffic.json)",
+                     "traffic_source": traffic_note or "QUOTED, not measured in this run: bytes per launch from the rocprofv3 --pmc passes of this command on the same "
+                                                       "kernel sources (profiles/hbm_traffic.json, source_hash checked)",
                      "algorithmic_bytes_per_launch": float(BYTES_PER_MSG * emit_msgs.mean()),
                      "bytes_per_msg": BYTES_PER_MSG, "msgs_per_launch": float(emit_msgs.mean()), "avg_launch_us": float(emit_us.mean()),
                      "emit_stage_us": float(stage_avg[4]), "deferred_msgs_per_tick": float(np.mean([h["n_deferred_records"] for h in hist]))},
@@ -596,6 +624,35 @@ def flat_interval_line(A, synth, cfg, N, S, seed, args, local_rank, interval_ms,
                     + (" (ticks pipelined, as the headline)" if pipe else " (serial schedule, as the headline)"),
             "value": msgs / el, "unit": "msgs/s", "steps": steps, "ms_per_step": 1e3 * el / steps, "msgs_per_tick": msgs / steps,
             "emit_us": emit_us, "emit_frac_of_hbm_peak": BYTES_PER_MSG * (msgs / steps) / (emit_us * 1e-6) / 1e9 / HBM_PEAK_GBS}
+
+
+DIGEST_FILE = os.path.join(ROOT, "tests", "golden", "bench_digests_B.json")
+
+
+def load_bench_digests(args, N, S, M):
+    """The committed per-tick record digests of the default world (config B, seed 0xC0FFEE01), or None when this run is another world."""
+    if (N, S, M) != (100_000, 10_000, 100_000) or args.aoi_scale != 1.0 or args.tick_ms != 50 or args.flat_interval_ms or not os.path.exists(DIGEST_FILE):
+        return None
+    with open(DIGEST_FILE) as f:
+        return json.load(f)["ticks"]
+
+
+def write_bench_digests(new):
+    """bench.py --write-digests (default world): merge this run's latency-phase ticks into the committed list."""
+    old = {}
+    if os.path.exists(DIGEST_FILE):
+        with open(DIGEST_FILE) as f:
+            old = json.load(f)["ticks"]
+    for k, v in new.items():
+        if k in old and old[k] != v:
+            raise SystemExit(f"--write-digests: tick {k} digests differently from the committed list: {v} vs {old[k]}")
+        old[k] = v
+    with open(DIGEST_FILE, "w") as f:
+        json.dump({"what": "per-tick digests {count, sum, xor of mix64(conn << 32 | channel)} of the fan-out records of bench.py's default world "
+                           "(spatial_static_benchmark.json, 100000 entities / 10000 subs, seed 0xC0FFEE01, 50 ms ticks), tick k = the k-th tick since the "
+                           "world began; computed on the device by chd_tick_digest (python bench.py --write-digests ...); the first 26 ticks of this "
+                           "world are compared with the CPU oracle in tests/test_gpu_fullsize.py, these pin the rest against drift and races",
+                   "ticks": dict(sorted(old.items(), key=lambda kv: int(kv[0])))}, f)
 
 
 def trace(msg):

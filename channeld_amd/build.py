@@ -27,6 +27,18 @@ FLAGS = [
 EXTRA = os.environ.get("CHD_EXTRA_FLAGS", "").split()
 
 
+def source_hash() -> str:
+    """sha256 (first 16 hex digits) over the kernel sources and headers of the library: what evidence under profiles/ is
+    stamped with (the GPU box has no .git), and what bench.py compares before it quotes a measured number from there."""
+    import hashlib
+
+    h = hashlib.sha256()
+    for f in sorted(SOURCES + UNITY_PARTS + HEADERS):
+        with open(os.path.join(CSRC, f), "rb") as fh:
+            h.update(f.encode() + b"\0" + fh.read())
+    return h.hexdigest()[:16]
+
+
 def hipcc() -> str:
     for c in (os.environ.get("HIPCC"), shutil.which("hipcc"), "/opt/rocm/bin/hipcc"):
         if c and os.path.exists(c):

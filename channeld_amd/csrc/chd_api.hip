@@ -805,6 +805,8 @@ int chd_world_create(chd_ctx *ctx, const chd_world_cfg *cfg) {
     TRY(walloc(ctx, &d.hist_tick, N));
     TRY(walloc(ctx, &d.sender_prev, N));
     TRY(walloc(ctx, &d.hist_prev, N));
+    TRY(walloc(ctx, &d.upd_mark, N));
+    TRY(walloc(ctx, &d.q_mark, S));
     TRY(walloc(ctx, &d.cell_hist, C));
     TRY(walloc(ctx, &d.cell_hist_tick, C));
     TRY(walloc(ctx, &d.cell_sender, C));
@@ -1453,7 +1455,7 @@ static int tick_locked(chd_ctx *ctx, const chd_tick_in *in) {
                 const uint32_t a = off[k], n = off[k + 1] - a;
                 launch_ingest(bs, ctx->g, d, n, in->upd_idx ? in->upd_idx + a : nullptr, in->upd_x + a, in->upd_z + a,
                               in->upd_sender ? in->upd_sender + a : nullptr, r.cur_tick, in->upd_arrival_ns ? in->upd_arrival_ns + a : nullptr,
-                              in->now_ns);
+                              in->now_ns, k);
             }
         }
         launch_cell_updates(bs, ctx->g, d, in->n_cell_updates, in->cell_upd_channel, in->cell_upd_sender, r.cur_tick,

@@ -57,6 +57,7 @@ enum {
 #define OVF_SLOTS 16u    // sharded world: no free entity slot for a spawn / an immigrant (the immigrant waits in limbo, k_shard.hip)
 #define OVF_MIGRATE 32u  // sharded world: an emigrant did not fit its destination's send segment
 #define OVF_HALO 64u     // sharded world: a border band did not fit its halo segment, or a subscription reaches a cell beyond the halo
+#define OVF_DUPLICATE 256u  // chd_tick_device's precondition broken: an entity slot twice in one round of updates / a subscriber slot twice
 #define OVF_LOST 128u    // sharded world: more immigrants waiting for a slot than the limbo list holds (max_entities): an entity was dropped
 
 struct DevGrid {

@@ -38,6 +38,8 @@ struct WorldDev {
     uint32_t *hist;       // bit j: an update of `sender` arrived at tick (hist_tick - j)
     uint32_t *hist_tick;
     uint32_t *sender_prev, *hist_prev;  // the previous sender's updates still inside the history
+    uint32_t *upd_mark;   // [N] (tick, round) of the slot's last update: a second one in the same round is a caller error (OVF_DUPLICATE)
+    uint32_t *q_mark;     // [S] tick of the slot's last interest update, likewise
     // handover groups (entity.go:58-244, FlatEntityGroupController): entities that cross cells together.  grp_of[i] =
     // index of entity i's group (CHD_INVALID: a group of one); group k's members are grp_mem[grp_off[k] .. grp_off[k+1]);
     // grp_locked[k] = members that are alive and locked (a locked member aborts the whole handover, entity.go:197-224)
@@ -279,7 +281,7 @@ void launch_group_locks(hipStream_t st, WorldDev w);
 // K1: cell assign + handover detect (+ update history)
 void launch_ingest(hipStream_t st, DevGrid g, WorldDev w, uint32_t n, const uint32_t *idx,
                    const double *x, const double *z, const uint32_t *sender, uint32_t cur_tick,
-                   const int64_t *arrival = nullptr, int64_t now_ns = 0);
+                   const int64_t *arrival = nullptr, int64_t now_ns = 0, uint32_t round = 0);
 void launch_cell_updates(hipStream_t st, DevGrid g, WorldDev w, uint32_t n,
                          const uint32_t *chan, const uint32_t *sender, uint32_t cur_tick,
                          const int64_t *arrival = nullptr, int64_t now_ns = 0);

@@ -86,7 +86,7 @@ __global__ void __launch_bounds__(256) k_front(DevGrid g, AoiLimits lim, WorldDe
     if (dbg & 2u) return;
     // K1: the batch of entity updates, 256 per step
     for (uint32_t b = bid; b * 256u < n_upd; b += nb) {
-        ingest_block(g, w, n_upd, upd_idx, upd_x, upd_z, upd_sender, cur_tick, upd_arrival, now_ns, b);
+        ingest_block(g, w, n_upd, upd_idx, upd_x, upd_z, upd_sender, cur_tick, upd_arrival, now_ns, b, (cur_tick << 8) | 0x80000000u);
         __syncthreads();  // (its LDS counters are reused by the next step)
     }
     front_barrier(w, (FrontBar *)w.front_bar, bar_seq + 1, nb);

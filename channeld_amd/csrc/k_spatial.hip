@@ -404,7 +404,8 @@ __device__ __forceinline__ void ingest_block(const DevGrid &g, const WorldDev &w
                                              const double *__restrict__ x,
                                              const double *__restrict__ z,
                                              const uint32_t *__restrict__ sender,
-                                             uint32_t cur_tick, const int64_t *__restrict__ arrival, int64_t now, uint32_t bid) {
+                                             uint32_t cur_tick, const int64_t *__restrict__ arrival, int64_t now, uint32_t bid,
+                                             uint32_t mark = 0) {
     // handover records are compacted per wave (ballot + mbcnt) and per workgroup
     // (LDS), so the global counter sees ONE atomic per 1024 updates: same-address
     // atomics serialise at ~12 ns each and would otherwise dominate this kernel.
@@ -421,6 +422,9 @@ __device__ __forceinline__ void ingest_block(const DevGrid &g, const WorldDev &w
         if (u < n) {
             const uint32_t i = idx ? idx[u] : u;
             ent[j] = i;
+            // chd_tick_device cannot see duplicates on the host: one returning atomic per EXPLICITLY indexed update (the identity
+            // mapping cannot repeat a slot) turns a broken precondition into an error instead of a race
+            if (idx && i < w.N && atomicExch(&w.upd_mark[i], mark) == mark) atomicOr(&w.counters[CTR_OVERFLOW], OVF_DUPLICATE);
             uint32_t ef = (i < w.N) ? w.eflags[i] : 0u;
             if (ef & EF_ALIVE) {
                 dst[j] = cell_of(g, x[u], z[u]);
@@ -502,16 +506,18 @@ __global__ void __launch_bounds__(256) k_ingest(DevGrid g, WorldDev w, uint32_t 
                                                 const double *__restrict__ x,
                                                 const double *__restrict__ z,
                                                 const uint32_t *__restrict__ sender,
-                                                uint32_t cur_tick, const int64_t *__restrict__ arrival, int64_t now) {
-    ingest_block(g, w, n, idx, x, z, sender, cur_tick, arrival, now, blockIdx.x);
+                                                uint32_t cur_tick, const int64_t *__restrict__ arrival, int64_t now, uint32_t mark) {
+    ingest_block(g, w, n, idx, x, z, sender, cur_tick, arrival, now, blockIdx.x, mark);
 }
 
 void launch_ingest(hipStream_t st, DevGrid g, WorldDev w, uint32_t n, const uint32_t *idx,
                    const double *x, const double *z, const uint32_t *sender, uint32_t cur_tick,
-                   const int64_t *arrival, int64_t now_ns) {
+                   const int64_t *arrival, int64_t now_ns, uint32_t round) {
     if (!n) return;
+    // (tick, round): distinct for every ingest launch of the last 2^24 ticks; never 0 = "no update yet"
+    const uint32_t mark = ((cur_tick << 8) | (round & 0xFFu)) | 0x80000000u;
     hipLaunchKernelGGL(k_ingest, dim3(nblocks(n, 256 * ING_ITEMS)), dim3(256), 0, st, g, w, n, idx, x, z,
-                       sender, cur_tick, arrival, now_ns);
+                       sender, cur_tick, arrival, now_ns, mark);
 }
 
 // spatial-channel data updates (spawn/destroy merges through OnUpdate).  One thread per

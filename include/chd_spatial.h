@@ -383,6 +383,8 @@ typedef struct {
                                           max_entities of them waiting, one was dropped), 32 an emigrant did not fit its destination's send
                                           segment (it stays with the wrong owner and is retried next tick), 64 a border
                                           band outgrew its halo segment or a subscription reaches beyond the halo;
+                                          256 chd_tick_device: an entity slot twice in one round of updates, or a subscriber
+                                          slot twice (the caller's precondition);
                                           0x8000 an internal loop bound tripped (a bug, never a capacity) */
     uint32_t history_overflow;         /* windows reaching beyond the 32-tick update history, or channels
                                           updated by more than two senders inside it (results then inexact);
@@ -401,11 +403,11 @@ int chd_tick(chd_ctx *ctx, const chd_tick_in *in, chd_tick_out *out);
 /* Same, with every input already resident in device memory (d_* pointers of the
  * same layout) and outputs left on the device; asynchronous on the ctx stream.
  * This is what bench.py times.  Use chd_tick_fetch to read the outputs back.
- * PRECONDITION (checked by chd_tick, which sees the host arrays and returns CHD_E_INVAL;
- * not checkable here without a device pass): upd_idx holds no entity slot twice and
- * query_sub no subscriber slot twice — one update per entity and one interest update per
- * connection per tick; the host coalesces (keeping the last), as the reference's
- * sequential handlers would leave it. */
+ * PRECONDITION (chd_tick sees the host arrays and returns CHD_E_INVAL up front): inside one round of updates upd_idx holds
+ * no entity slot twice, and query_sub no subscriber slot twice — the host coalesces (keeping the last, as the reference's
+ * sequential handlers would leave it) or hands several updates of a channel over in rounds (upd_round_off).  Here the
+ * device checks it while it ingests: a repeated slot sets overflow bit 256 (chd_tick_fetch then returns CHD_E_CAPACITY
+ * with the mask; that tick's state for the slot is one of the two updates, its results are not to be used). */
 int chd_tick_device(chd_ctx *ctx, const chd_tick_in *d_in);
 int chd_tick_fetch(chd_ctx *ctx, chd_tick_out *out);
 int chd_sync(chd_ctx *ctx);

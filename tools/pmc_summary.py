@@ -45,7 +45,11 @@ def main(d, skip=0, traffic_src=None):
         # the form bench.py quotes from (profiles/hbm_traffic.json): bytes per launch = 2 x FETCH_SIZE + WRITE_SIZE
         k = {n: {"fetch_bytes_per_launch": v["fetch_x2_MB_avg"] * 1e6, "write_bytes_per_launch": v["write_MB_avg"] * 1e6,
                  "bytes_per_launch": v["fetch_x2_MB_avg"] * 1e6 + v["write_MB_avg"] * 1e6} for n, v in out.items()}
-        print(json.dumps({"source": traffic_src, "workload": "spatial_static_benchmark.json, 100000 entities / 10000 subs", "kernels": k}, indent=1))
+        import os
+        sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+        from channeld_amd.build import source_hash
+        print(json.dumps({"source": traffic_src, "workload": "spatial_static_benchmark.json, 100000 entities / 10000 subs",
+                          "source_hash": source_hash(), "kernels": k}, indent=1))
     else:
         print(json.dumps(out, indent=1))
 
