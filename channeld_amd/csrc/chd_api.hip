@@ -2258,14 +2258,14 @@ int chd_wire_build(chd_ctx *ctx, uint64_t *total_bytes, uint64_t *total_packets,
     // (a second call for the same tick returns the streams already built: the layout pass rewrote the records' position words)
     const bool again = W.wire_built;
     if (!again) {
-        HIPCHK(hipMemsetAsync(W.x.n_dropped, 0, 4 * sizeof(uint32_t), st));
+        HIPCHK(hipMemsetAsync(W.x.n_dropped, 0, 8 * sizeof(uint32_t), st));
         W.x.cur_tick = ctx->ring.cur_tick;
         launch_wire_layout(st, d, W.x);
         launch_scan_u64_inplace(st, W.x.conn_wlen, d.S);
         TRY(after_launch(ctx));
     }
     uint64_t total = 0;
-    uint32_t ndrop2[4] = {0, 0, 0, 0};
+    uint32_t ndrop2[5] = {0, 0, 0, 0, 0};
     TRY(down(ctx, &total, W.x.conn_wlen + d.S, sizeof total));
     TRY(down(ctx, ndrop2, W.x.n_dropped, sizeof ndrop2));
     HIPCHK(hipStreamSynchronize(st));
@@ -2278,7 +2278,7 @@ int chd_wire_build(chd_ctx *ctx, uint64_t *total_bytes, uint64_t *total_packets,
             W.wire_cap = total + total / 2 + 4096;  // head-room: the arena is only re-allocated when a tick outgrows it
             HIPCHK(hipMalloc((void **)&W.x.bytes, W.wire_cap));
         }
-        launch_wire_copy(st, d, W.x);
+        launch_wire_copy(st, d, W.x, ndrop2[4]);
         TRY(after_launch(ctx));
         uint32_t bad = 0;
         TRY(down(ctx, &bad, W.x.n_dropped + 3, sizeof bad));

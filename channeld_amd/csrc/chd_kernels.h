@@ -384,7 +384,7 @@ void launch_wire_layout(hipStream_t st, WorldDev w, WireDev x);
 // handover message assembly: sizes[2*nh] then, with off = exclusive scan of the sizes, the bytes
 void launch_handover_msg_sizes(hipStream_t st, DevGrid g, WorldDev w, WireDev x, uint32_t nh, uint32_t *sizes);
 void launch_handover_msg_write(hipStream_t st, DevGrid g, WorldDev w, WireDev x, uint32_t nh, const uint32_t *off, uint8_t *out, uint64_t cap);
-void launch_wire_copy(hipStream_t st, WorldDev w, WireDev x);
+void launch_wire_copy(hipStream_t st, WorldDev w, WireDev x, uint32_t n_slow_conns);
 void launch_wire_set_payloads(hipStream_t st, WireDev x, int full, int cell, uint32_t n, uint32_t limit, const uint32_t *idx,
                               const uint32_t *lens, const uint64_t *off, const uint8_t *bytes, uint32_t ring_slot);
 // recipient planning (decision parts)
