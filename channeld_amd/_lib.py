@@ -48,7 +48,7 @@ SYMBOLS = (
     "chd_set_stream", "chd_shard_spawn", "chd_shard_ingest", "chd_shard_import", "chd_shard_fanout",
     "chd_shard_get_entities", "chd_shard_halo_layout", "chd_shard_interest",
     "chd_handover_recipients", "chd_adjacent_recipients", "chd_wire_set_payloads", "chd_wire_build", "chd_wire_fetch",
-    "chd_tick_digest", "chd_tick_fetch_segments", "chd_host_alloc", "chd_host_free", "chd_subs_set_options", "chd_subs_get_options", "chd_world_set_entity_groups", "chd_world_set_handover_lists", "chd_wire_set_type_url", "chd_handover_messages",
+    "chd_tick_digest", "chd_tick_fetch_segments", "chd_host_alloc", "chd_host_free", "chd_subs_set_options", "chd_subs_get_options", "chd_world_set_entity_groups", "chd_world_set_handover_lists", "chd_wire_set_type_url", "chd_wire_set_merge_schema", "chd_handover_messages",
 )
 
 
@@ -151,14 +151,15 @@ class TickStats(C.Structure):
     ]
 
 
-SUBOPT_ACCESS, SUBOPT_INTERVAL, SUBOPT_DELAY, SUBOPT_SKIP_SELF, SUBOPT_SKIP_FIRST = 1, 2, 4, 8, 16
+SUBOPT_ACCESS, SUBOPT_INTERVAL, SUBOPT_DELAY, SUBOPT_SKIP_SELF, SUBOPT_SKIP_FIRST, SUBOPT_FIELD_MASK = 1, 2, 4, 8, 16, 32
+MERGE_SCHEMA_NONE, MERGE_SCHEMA_TPS_ENTITY_MOVEMENT = 0, 1
 ACCESS_NONE, ACCESS_READ, ACCESS_WRITE = 0, 1, 2
 
 
 class SubOptions(C.Structure):
     _fields_ = [("slot", C.c_uint32), ("channel", C.c_uint32), ("set", C.c_uint32), ("data_access", C.c_uint32),
                 ("fanout_interval_ms", C.c_uint32), ("fanout_delay_ms", C.c_int32),
-                ("skip_self_update_fanout", C.c_uint32), ("skip_first_fanout", C.c_uint32)]
+                ("skip_self_update_fanout", C.c_uint32), ("skip_first_fanout", C.c_uint32), ("data_field_mask", C.c_uint32)]
 
 
 class HaloSeg(C.Structure):
@@ -240,6 +241,7 @@ def load():
     L.chd_shard_get_entities.argtypes = [C.c_void_p, _u32p, _u32p, _u32p, P(C.c_uint32)]
     L.chd_wire_set_payloads.argtypes = [C.c_void_p, C.c_int, C.c_uint32, _u32p, _u32p, _u8p]
     L.chd_wire_set_type_url.argtypes = [C.c_void_p, C.c_int, _u8p, C.c_uint32]
+    L.chd_wire_set_merge_schema.argtypes = [C.c_void_p, C.c_int]
     L.chd_handover_messages.argtypes = [C.c_void_p, C.c_uint32, _u32p, _u8p, C.c_uint64, P(C.c_uint64)]
     L.chd_wire_build.argtypes = [C.c_void_p, P(C.c_uint64), P(C.c_uint64), P(C.c_uint32)]
     L.chd_wire_fetch.argtypes = [C.c_void_p, _u64p, _u32p, _u8p, C.c_uint64]

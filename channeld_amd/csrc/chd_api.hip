@@ -1256,6 +1256,7 @@ int chd_subs_set_options(chd_ctx *ctx, int64_t now_ns, uint32_t n, const chd_sub
         if (o.channel < ctx->g.id_start || o.channel - ctx->g.id_start >= ctx->g.ncell)
             return fail(ctx, CHD_E_INVAL, "option %u: %u is not a spatial channel of this grid", i, o.channel);
         if ((o.set & CHD_SUBOPT_ACCESS) && o.data_access > CHD_ACCESS_WRITE) return fail(ctx, CHD_E_INVAL, "option %u: DataAccess %u", i, o.data_access);
+        if ((o.set & CHD_SUBOPT_FIELD_MASK) && o.data_field_mask > 0xFFu) return fail(ctx, CHD_E_INVAL, "option %u: data_field_mask has 8 bits", i);
         if ((o.set & CHD_SUBOPT_INTERVAL) && o.fanout_interval_ms == 0)
             return fail(ctx, CHD_E_INVAL, "option %u: fan-out interval 0 makes the reference's tickData spin forever", i);
     }
@@ -2208,6 +2209,19 @@ int chd_wire_set_type_url(chd_ctx *ctx, int which, const uint8_t *url, uint32_t 
     HIPCHK(hipStreamSynchronize(ctx->stream));
     if (len) HIPCHK(hipMemcpy(W.x.url[which], url, len, hipMemcpyHostToDevice));
     W.x.url_len[which] = len;
+    return CHD_OK;
+}
+
+int chd_wire_set_merge_schema(chd_ctx *ctx, int schema) {
+    NEED_WORLD();
+    World &W = ctx->w;
+    if (!W.wire || !W.x.merge) return fail(ctx, CHD_E_STATE, "merge schemas belong to worlds with CHD_WORLD_WIRE | CHD_WORLD_UPDATE_MASKS");
+    if (schema != CHD_MERGE_SCHEMA_NONE && schema != CHD_MERGE_SCHEMA_TPS_ENTITY_MOVEMENT) return fail(ctx, CHD_E_INVAL, "chd_wire_set_merge_schema: unknown schema %d", schema);
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    TRY(bind(ctx));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    W.x.schema = (uint32_t)schema;
+    W.wire_built = false;
     return CHD_OK;
 }
 

@@ -29,6 +29,8 @@
 #define PF_DEEP 64u      // (inside one tick) due, but the tick-ring masks cannot answer its windows: served from the exact
                          // update buffers by k_fanout_emit_deep (history_depth > 0), which clears the bit
 
+#define PF_FIELD_MASK_SHIFT 8u  // bits 8..15: the subscription's DataFieldMasks in bit form (chd_sub_options.data_field_mask)
+
 // entity flags
 #define EF_LOCKED 1u
 #define EF_ALIVE 0x80000000u

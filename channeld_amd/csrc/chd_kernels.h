@@ -360,6 +360,7 @@ struct WireDev {
     // data update MESSAGES (not Any), kept per tick in a ring of CHD_HIST_BITS slots (slot = tick & 31); a record's message is
     // Any{type_url, value = the updates its mask selects, oldest first, concatenated} — what a protobuf parser reads as their merge
     uint32_t merge;                     // 0: one current payload per channel (pay_ent[0] / pay_cell[0] hold Any bytes)
+    uint32_t schema;                    // merge mode: CHD_MERGE_SCHEMA_* of the entity update messages (0: concatenate the selected updates)
     uint32_t cur_tick;                  // tick of the records being built (ring slot of mask bit j = (cur_tick - j) & 31)
     uint8_t *ring_ent, *ring_cell;      // [N * 32 * stride[0]], [ncell * 32 * stride[0]]
     uint32_t *rlen_ent, *rlen_cell;     // [N * 32], [ncell * 32]

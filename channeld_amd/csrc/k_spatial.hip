@@ -301,6 +301,7 @@ __global__ void __launch_bounds__(64) k_subs_set_options(DevGrid g, WorldDev w, 
                 fl &= ~(PF_NO_ACCESS | PF_WRITE);
                 fl |= acc == 0 ? PF_NO_ACCESS : acc == 2 ? PF_WRITE : 0u;
                 if (o.set & CHD_SUBOPT_SKIP_SELF) fl = o.skip_self_update_fanout ? (fl | PF_SKIP_SELF) : (fl & ~PF_SKIP_SELF);
+                if (o.set & CHD_SUBOPT_FIELD_MASK) fl = (fl & ~(0xFFu << PF_FIELD_MASK_SHIFT)) | ((o.data_field_mask & 0xFFu) << PF_FIELD_MASK_SHIFT);
                 w.pair_flags[pbase + pos] = fl;
                 if (o.set & CHD_SUBOPT_INTERVAL) w.pair_iv[pbase + pos] = o.fanout_interval_ms;
                 if (w.deep_depth && w.pair_iv[pbase + pos] > *w.max_iv) atomicMax(w.max_iv, w.pair_iv[pbase + pos]);
@@ -337,7 +338,8 @@ __global__ void __launch_bounds__(64) k_subs_set_options(DevGrid g, WorldDev w, 
             if (w.deep_depth && w.pair_iv[pbase + pos] > *w.max_iv) atomicMax(w.max_iv, w.pair_iv[pbase + pos]);
             w.pair_last[pbase + pos] = now_ns + (int64_t)delay * 1000000;
             w.pair_flags[pbase + pos] = (acc == 0 ? PF_NO_ACCESS : acc == 2 ? PF_WRITE : 0u) | (skip_self ? PF_SKIP_SELF : 0u) |
-                                        (skip_first ? PF_HAD_FIRST : 0u);
+                                        (skip_first ? PF_HAD_FIRST : 0u) |
+                                        ((o.set & CHD_SUBOPT_FIELD_MASK) ? (o.data_field_mask & 0xFFu) << PF_FIELD_MASK_SHIFT : 0u);
             w.pair_cnt[s] = cnt + 1;
             atomicAdd(&w.cell_ref[c], 1u);
             if (w.wb) w.sub_bits[(size_t)s * w.wb + (c >> 6)] |= 1ull << (c & 63u);

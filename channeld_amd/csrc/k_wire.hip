@@ -28,17 +28,170 @@
 
 __device__ __forceinline__ uint32_t vlen(uint32_t v) { return v < (1u << 7) ? 1u : v < (1u << 14) ? 2u : v < (1u << 21) ? 3u : v < (1u << 28) ? 4u : 5u; }
 
+
+// ---------------------------------------------------------------------------
+// TYPED merge of the buffered updates a window selected (data.go:225-269 + tpspb/data.go:227-252 + data.go:294):
+// for the MOVEMENT subset of tpspb.EntityChannelData the accumulated update message is built field by field — proto.Merge
+// on this schema: sub-messages merge recursively, a leaf with explicit presence is overwritten when the source has it — then
+// filtered by the subscription's DataFieldMasks (fmutils.Filter) and written in field-number order, one-byte lengths (every
+// nested length is below 128): the bytes Go's proto.Marshal produces.  Schema (unreal_common.proto:161-184, tps.proto:22-35):
+//     EntityChannelData { 2: ActorState { 11: FRepMovement { 1 linearVelocity, 2 angularVelocity, 3 location, 4 rotation:
+//     FVector { 1 x, 2 y, 3 z: float }; 5 bSimulatedPhysicSleep, 6 bRepPhysics: bool } } }
+// An update that carries anything else (objRef, other states) is "not in the subset": the record then takes the generic
+// path (the selected updates concatenated, which a protobuf parser reads as their merge).  oracle/merge.py restates this,
+// pinned by python-protobuf on the reference's embedded descriptors (tests/golden/make_merge_golden.py).
+// ---------------------------------------------------------------------------
+#define CHD_SCHEMA_TPS_ENTITY_MOVEMENT 1u
+#define MV_ACTOR 1u
+#define MV_MOVE 2u
+#define MV_VEC(f) (4u << (f))           // f = 0..3
+#define MV_LEAF(f, a) (64u << ((f) * 3u + (a)))
+#define MV_BOOL(k) (1u << (18u + (k)))  // present
+#define MV_BVAL(k) (1u << (20u + (k)))  // value
+
+struct Movement {
+    uint32_t leaf[12];
+    uint32_t bits;
+};
+
+__device__ __forceinline__ bool mv_varint(const uint8_t *__restrict__ b, uint32_t &i, uint32_t end, uint64_t &v) {
+    v = 0;
+    for (uint32_t s = 0; s < 64; s += 7) {
+        if (i >= end) return false;
+        const uint32_t c = b[i++];
+        v |= (uint64_t)(c & 0x7Fu) << s;
+        if (!(c & 0x80u)) return true;
+    }
+    return false;
+}
+
+// proto.Merge(m, parse(b[0..n))); false: not in the subset (m is then unusable)
+__device__ bool mv_parse(const uint8_t *__restrict__ b, uint32_t n, Movement &m) {
+    uint32_t i = 0;
+    uint64_t v;
+    while (i < n) {
+        if (!mv_varint(b, i, n, v) || v != ((2u << 3) | 2u)) return false;           // actorState
+        if (!mv_varint(b, i, n, v) || v > n - i) return false;
+        const uint32_t e1 = i + (uint32_t)v;
+        m.bits |= MV_ACTOR;
+        while (i < e1) {
+            if (!mv_varint(b, i, e1, v) || v != ((11u << 3) | 2u)) return false;      // replicatedMovement
+            if (!mv_varint(b, i, e1, v) || v > e1 - i) return false;
+            const uint32_t e2 = i + (uint32_t)v;
+            m.bits |= MV_MOVE;
+            while (i < e2) {
+                if (!mv_varint(b, i, e2, v)) return false;
+                const uint32_t fn = (uint32_t)(v >> 3), wt = (uint32_t)v & 7u;
+                if (wt == 2u && fn >= 1u && fn <= 4u && v < 64u) {                  // an FVector
+                    if (!mv_varint(b, i, e2, v) || v > e2 - i) return false;
+                    const uint32_t e3 = i + (uint32_t)v, f = fn - 1u;
+                    m.bits |= MV_VEC(f);
+                    while (i < e3) {
+                        if (!mv_varint(b, i, e3, v)) return false;
+                        const uint32_t a = (uint32_t)(v >> 3) - 1u;
+                        if (((uint32_t)v & 7u) != 5u || a > 2u || v >= 32u || e3 - i < 4u) return false;
+                        const uint32_t val = (uint32_t)b[i] | ((uint32_t)b[i + 1] << 8) | ((uint32_t)b[i + 2] << 16) | ((uint32_t)b[i + 3] << 24);
+                        i += 4;
+                        // (constant indices: the leaves stay in registers)
+#pragma unroll
+                        for (uint32_t q = 0; q < 12; q++)
+                            if (q == f * 3u + a) m.leaf[q] = val;
+                        m.bits |= MV_LEAF(f, a);
+                    }
+                } else if (wt == 0u && (fn == 5u || fn == 6u) && v < 64u) {         // a bool
+                    if (!mv_varint(b, i, e2, v)) return false;
+                    const uint32_t k = fn - 5u;
+                    m.bits = (m.bits | MV_BOOL(k)) & ~MV_BVAL(k);
+                    if (v) m.bits |= MV_BVAL(k);
+                } else {
+                    return false;
+                }
+            }
+        }
+    }
+    return true;
+}
+
+// fmutils.Filter with the subscription's DataFieldMasks in bit form (chd_sub_options.data_field_mask)
+__device__ __forceinline__ void mv_filter(Movement &m, uint32_t fmask) {
+    if (!fmask) return;
+    if ((fmask & 64u) && !(fmask & 63u)) { m.bits = 0; return; }
+#pragma unroll
+    for (uint32_t f = 0; f < 4; f++)
+        if (!((fmask >> f) & 1u)) m.bits &= ~(MV_VEC(f) | MV_LEAF(f, 0) | MV_LEAF(f, 1) | MV_LEAF(f, 2));
+#pragma unroll
+    for (uint32_t k = 0; k < 2; k++)
+        if (!((fmask >> (4u + k)) & 1u)) m.bits &= ~(MV_BOOL(k) | MV_BVAL(k));
+}
+
+__device__ __forceinline__ uint32_t mv_move_len(const Movement &m) {
+    uint32_t n = 0;
+#pragma unroll
+    for (uint32_t f = 0; f < 4; f++)
+        if (m.bits & MV_VEC(f)) n += 2u + 5u * (uint32_t)__popc((m.bits >> (6u + 3u * f)) & 7u);
+    return n + 2u * (uint32_t)__popc((m.bits >> 18) & 3u);
+}
+__device__ __forceinline__ uint32_t mv_size(const Movement &m) {
+    if (!(m.bits & MV_ACTOR)) return 0u;
+    return 2u + ((m.bits & MV_MOVE) ? 2u + mv_move_len(m) : 0u);
+}
+
+__device__ uint32_t mv_write(const Movement &m, uint8_t *d) {
+    if (!(m.bits & MV_ACTOR)) return 0u;
+    uint32_t n = 0;
+    const uint32_t ml = mv_move_len(m);
+    d[n++] = 0x12; d[n++] = (uint8_t)((m.bits & MV_MOVE) ? 2u + ml : 0u);
+    if (m.bits & MV_MOVE) {
+        d[n++] = 0x5A; d[n++] = (uint8_t)ml;
+#pragma unroll
+        for (uint32_t f = 0; f < 4; f++) {
+            if (!(m.bits & MV_VEC(f))) continue;
+            d[n++] = (uint8_t)(0x0Au + 8u * f);
+            d[n++] = (uint8_t)(5u * (uint32_t)__popc((m.bits >> (6u + 3u * f)) & 7u));
+#pragma unroll
+            for (uint32_t a = 0; a < 3; a++) {
+                if (!(m.bits & MV_LEAF(f, a))) continue;
+                const uint32_t v = m.leaf[f * 3u + a];
+                d[n++] = (uint8_t)(0x0Du + 8u * a);
+                d[n++] = (uint8_t)v; d[n++] = (uint8_t)(v >> 8); d[n++] = (uint8_t)(v >> 16); d[n++] = (uint8_t)(v >> 24);
+            }
+        }
+#pragma unroll
+        for (uint32_t k = 0; k < 2; k++)
+            if (m.bits & MV_BOOL(k)) { d[n++] = (uint8_t)(0x28u + 8u * k); d[n++] = (m.bits & MV_BVAL(k)) ? 1 : 0; }
+    }
+    return n;
+}
+
+// the updates `mask` selects (bit j = tick cur - j, oldest first) of one entity channel, merged and filtered; false: one of
+// them is not in the subset
+__device__ bool mv_merge_selected(const WireDev &x, const uint8_t *__restrict__ ring_row, const uint32_t *__restrict__ rl, uint32_t mask,
+                                  uint32_t fmask, Movement &m) {
+    m.bits = 0;
+#pragma unroll
+    for (uint32_t q = 0; q < 12; q++) m.leaf[q] = 0;
+    for (int jj = CHD_HIST_BITS - 1; jj >= 0; jj--) {
+        if (!((mask >> jj) & 1u)) continue;
+        const uint32_t sl = (x.cur_tick - (uint32_t)jj) & (CHD_HIST_BITS - 1u);
+        if (!mv_parse(ring_row + (size_t)sl * x.stride[0], rl[sl], m)) return false;
+    }
+    mv_filter(m, fmask);
+    return true;
+}
+
 struct WireMsg {
     uint32_t chan, any_len, body_len, mp_len, entry;  // entry = bytes inside the Packet (0: dropped by Send)
     const uint8_t *pay;                                // the one payload (Any bytes), or the channel's ring row in merge mode
     uint32_t mask;                                     // merge mode, update records: the ring slots to concatenate (bit j = tick cur - j)
     uint32_t value_len;                                // merge mode: bytes of Any.value (sum of the selected updates)
-    uint32_t kind;                                     // merge mode: 1 + (0 entity, 1 cell) for an update record, else 0
+    uint32_t kind;                                     // merge mode: 1 + (0 entity, 1 cell) for an update record, 3 = entity update merged
+                                                       // field by field (typed schema), else 0
 };
 
 // idc = CHD_POS_CELL | cell for a spatial channel's own message, else the entity's slot (k_wire_layout resolves the records'
 // cell-table positions once and leaves idc in rec_pos for the copy kernels)
-__device__ __forceinline__ WireMsg wire_msg(const WorldDev &w, const WireDev &x, chd_fanout_rec rec, uint32_t idc, uint32_t mask) {
+__device__ __forceinline__ WireMsg wire_msg(const WorldDev &w, const WireDev &x, chd_fanout_rec rec, uint32_t idc, uint32_t mask,
+                                            uint32_t fmask = 0) {
     WireMsg m;
     const uint32_t full = rec.conn >> 31;
     m.chan = rec.channel;
@@ -55,6 +208,15 @@ __device__ __forceinline__ WireMsg wire_msg(const WorldDev &w, const WireDev &x,
         m.value_len = total;
         m.kind = cell ? 2u : 1u;
         m.pay = (cell ? x.ring_cell : x.ring_ent) + (size_t)id * CHD_HIST_BITS * x.stride[0];
+        if (!cell && x.schema == CHD_SCHEMA_TPS_ENTITY_MOVEMENT) {
+            // the accumulated update message itself, as the reference marshals it (else: the selected updates concatenated)
+            Movement mv;
+            if (mv_merge_selected(x, m.pay, rl, mask, fmask, mv)) {
+                total = mv_size(mv);
+                m.value_len = total;
+                m.kind = 3u;
+            }
+        }
         m.any_len = (ul ? 1u + vlen(ul) + ul : 0u) + (total ? 1u + vlen(total) + total : 0u);  // empty fields are not emitted
     } else if (cell) {
         m.any_len = x.len_cell[full][id];
@@ -92,6 +254,7 @@ __global__ void __launch_bounds__(256) k_wire_layout(WorldDev w, WireDev x) {
         for (uint32_t p = 0; p < cnt; p++) {
             const uint32_t n = w.pair_nrec[pbase + p];
             const uint64_t seg = rbase + w.pair_rel[pbase + p];
+            const uint32_t fmask = x.schema ? (w.pair_flags[pbase + p] >> PF_FIELD_MASK_SHIFT) & 0xFFu : 0u;  // DataFieldMasks, bit form
             bool fast = !x.merge && x.fast_ok;
             for (uint32_t i0 = 0; i0 < n; i0 += 64) {
                 const uint32_t i = i0 + lane;
@@ -110,7 +273,7 @@ __global__ void __launch_bounds__(256) k_wire_layout(WorldDev w, WireDev x) {
                         atomicAdd(x.n_dropped + 2, 1u);
                         idc = CHD_POS_CELL;
                     }
-                    const WireMsg m = wire_msg(w, x, w.recs[seg + i], idc, w.rec_mask ? w.rec_mask[seg + i] : 0u);
+                    const WireMsg m = wire_msg(w, x, w.recs[seg + i], idc, w.rec_mask ? w.rec_mask[seg + i] : 0u, fmask);
                     w.rec_pos[seg + i] = idc;
                     entry = m.entry;
                     alen = m.any_len;
@@ -200,9 +363,10 @@ __device__ __forceinline__ uint32_t put_varint(uint8_t *h, uint32_t n, uint32_t 
 }
 
 // bytes in front of the payload bytes proper: tag, the three nested headers and, in merge mode, the Any's own fields
+__device__ __forceinline__ uint32_t wire_url_index(uint32_t kind) { return kind == 2u ? 1u : 0u; }  // (kinds 1 and 3: the entity data type)
 __device__ __forceinline__ uint32_t wire_any_prefix(const WireDev &x, const WireMsg &m) {
     if (!m.kind) return 0u;
-    const uint32_t ul = x.url_len[m.kind - 1u];
+    const uint32_t ul = x.url_len[wire_url_index(m.kind)];
     return (ul ? 1u + vlen(ul) + ul : 0u) + (m.value_len ? 1u + vlen(m.value_len) : 0u);
 }
 __device__ __forceinline__ uint32_t wire_hdr_len(const WireDev &x, const WireMsg &m, uint32_t tag) {
@@ -225,10 +389,10 @@ __device__ __forceinline__ uint32_t put_header(uint8_t *h, const WireDev &x, con
     h[hl++] = 0x2A; hl = put_varint(h, hl, m.body_len);                   // MessagePack.msgBody
     h[hl++] = 0x0A; hl = put_varint(h, hl, m.any_len);                    // ChannelDataUpdateMessage.data
     if (m.kind) {
-        const uint32_t ul = x.url_len[m.kind - 1u];
+        const uint32_t ul = x.url_len[wire_url_index(m.kind)];
         if (ul) {                                                         // google.protobuf.Any.type_url = 1
             h[hl++] = 0x0A; hl = put_varint(h, hl, ul);
-            const uint8_t *u = x.url[m.kind - 1u];
+            const uint8_t *u = x.url[wire_url_index(m.kind)];
             for (uint32_t k = 0; k < ul; k++) h[hl++] = u[k];
         }
         if (m.value_len) { h[hl++] = 0x12; hl = put_varint(h, hl, m.value_len); }  // Any.value = 2
@@ -309,6 +473,7 @@ __global__ void __launch_bounds__(256) k_wire_copy(WorldDev w, WireDev x) {
         if (x.seg_fast[pbase + p]) continue;  // (k_wire_copy_fast writes those)
         const uint32_t n = w.pair_nrec[pbase + p];
         const uint64_t seg = rbase + w.pair_rel[pbase + p];
+        const uint32_t fmask = x.schema ? (w.pair_flags[pbase + p] >> PF_FIELD_MASK_SHIFT) & 0xFFu : 0u;
         for (uint32_t i0 = 0; i0 < n; i0 += 64) {
             const uint32_t i = i0 + lane;
             // ---- describe this lane's message ----
@@ -319,7 +484,7 @@ __global__ void __launch_bounds__(256) k_wire_copy(WorldDev w, WireDev x) {
             if (i < n) {
                 const uint32_t woff = x.rec_woff[seg + i];
                 if (woff != 0xFFFFFFFFu) {  // not dropped by the size check of Send
-                    m = wire_msg(w, x, w.recs[seg + i], w.rec_pos[seg + i], w.rec_mask ? w.rec_mask[seg + i] : 0u);
+                    m = wire_msg(w, x, w.recs[seg + i], w.rec_pos[seg + i], w.rec_mask ? w.rec_mask[seg + i] : 0u, fmask);
                     tag = x.rec_wtag[seg + i] >> 16;  // packet length if the message opens a packet
                     if (tag) tag |= 0x80000000u;
                     hl = wire_hdr_len(x, m, tag);
@@ -373,6 +538,11 @@ __global__ void __launch_bounds__(256) k_wire_copy(WorldDev w, WireDev x) {
                     d += put_header(d, x, m, tag);
                     if (!m.kind) {
                         lane_put_payload(d, m.pay, pl);  // payload slots are 16-byte aligned and padded
+                    } else if (m.kind == 3u) {
+                        // the accumulated update message, merged field by field (the layout pass sized it the same way)
+                        const uint32_t id = (uint32_t)(((uintptr_t)m.pay - (uintptr_t)x.ring_ent) / ((size_t)CHD_HIST_BITS * x.stride[0]));
+                        Movement mv;
+                        if (mv_merge_selected(x, m.pay, x.rlen_ent + (size_t)id * CHD_HIST_BITS, m.mask, fmask, mv)) (void)mv_write(mv, d);
                     } else {
                         // the selected updates, oldest (highest bit) first
                         const uint32_t *rl = (m.kind == 2 ? x.rlen_cell : x.rlen_ent) +

@@ -20,6 +20,29 @@ from .controller import StaticGrid2DSpatialController, SpatialInterestQuery, pac
 REC_DTYPE = np.dtype([("conn", np.uint32), ("channel", np.uint32)])
 
 
+MOVEMENT_FIELDS = ("linearVelocity", "angularVelocity", "location", "rotation", "bSimulatedPhysicSleep", "bRepPhysics")
+
+
+def movement_field_mask(paths) -> int:
+    """ChannelSubscriptionOptions.DataFieldMasks (path strings) -> chd_sub_options.data_field_mask for
+    CHD_MERGE_SCHEMA_TPS_ENTITY_MOVEMENT (include/chd_spatial.h): what a Go shim does when it forwards SUB_TO_CHANNEL."""
+    paths = list(paths)
+    if not paths:
+        return 0
+    m = 0
+    for p in paths:
+        parts = p.split(".")
+        if parts[0] != "actorState":
+            continue
+        if len(parts) == 1 or (len(parts) == 2 and parts[1] == "replicatedMovement"):
+            m |= 63  # the whole sub-message is listed
+        elif len(parts) >= 3 and parts[1] == "replicatedMovement" and parts[2] in MOVEMENT_FIELDS:
+            if len(parts) > 3:
+                raise ValueError("leaf-level DataFieldMasks (FVector components) are outside the engine's bit form: " + p)
+            m |= 1 << MOVEMENT_FIELDS.index(parts[2])
+    return m if m else 64
+
+
 def expand_segments(seg: dict, conn_ids) -> np.ndarray:
     """What a host does with chd_tick_fetch_segments' output (include/chd_spatial.h: chd_fanout_segment): the fan-out records,
     grouped per connection slot.  numpy, vectorised per segment kind — for tests and measurements; a gateway would write its
@@ -176,7 +199,7 @@ class SpatialWorld:
             a.slot, a.channel = int(o["slot"]), int(o["channel"])
             for key, bit in (("data_access", _lib.SUBOPT_ACCESS), ("fanout_interval_ms", _lib.SUBOPT_INTERVAL),
                              ("fanout_delay_ms", _lib.SUBOPT_DELAY), ("skip_self_update_fanout", _lib.SUBOPT_SKIP_SELF),
-                             ("skip_first_fanout", _lib.SUBOPT_SKIP_FIRST)):
+                             ("skip_first_fanout", _lib.SUBOPT_SKIP_FIRST), ("data_field_mask", _lib.SUBOPT_FIELD_MASK)):
                 if o.get(key) is not None:
                     a.set |= bit
                     setattr(a, key, int(o[key]))
@@ -434,6 +457,10 @@ class SpatialWorld:
         WIRE | UPDATE_MASKS worlds), 2 handover data (chd_handover_messages)"""
         a = np.frombuffer(url, dtype=np.uint8) if url else np.zeros(1, dtype=np.uint8)
         _lib.check(self.ctx, self.lib.chd_wire_set_type_url(self.ctx, int(which), a.ctypes.data_as(C.c_void_p), len(url)))
+
+    def wire_set_merge_schema(self, schema: int):
+        """CHD_MERGE_SCHEMA_*: entity update messages inside the schema are merged field by field, byte-identical to Go's re-marshal"""
+        _lib.check(self.ctx, self.lib.chd_wire_set_merge_schema(self.ctx, int(schema)))
 
     def handover_messages(self, n_handovers: int, cap: int = 1 << 24):
         """The two MessagePacks of every handover of the last tick: [(without entity data, with entity data), ...]"""

@@ -277,6 +277,7 @@ int chd_subs_remove(chd_ctx *ctx, uint32_t n, const uint32_t *slot);
 #define CHD_SUBOPT_DELAY 4u
 #define CHD_SUBOPT_SKIP_SELF 8u
 #define CHD_SUBOPT_SKIP_FIRST 16u
+#define CHD_SUBOPT_FIELD_MASK 32u
 #define CHD_ACCESS_NONE 0u  /* ChannelDataAccess_NO_ACCESS: skipped by the fan-out but stays queued (data.go:194-197) */
 #define CHD_ACCESS_READ 1u
 #define CHD_ACCESS_WRITE 2u
@@ -289,6 +290,14 @@ typedef struct {
     int32_t fanout_delay_ms;          /* may be negative (channeld.proto:229-233) */
     uint32_t skip_self_update_fanout; /* 0 / 1 */
     uint32_t skip_first_fanout;       /* 0 / 1 */
+    /* ChannelSubscriptionOptions.DataFieldMasks (channeld.proto:216-240; fmutils.Filter in fanOutDataUpdate, data.go:294) in
+     * the bit form of the world's merge schema (chd_wire_set_merge_schema; the host maps the path strings).  For
+     * CHD_MERGE_SCHEMA_TPS_ENTITY_MOVEMENT: bit f (0..5) = "actorState.replicatedMovement.<field f + 1>" (linearVelocity,
+     * angularVelocity, location, rotation, bSimulatedPhysicSleep, bRepPhysics) is listed; bit 6 = the masks list only fields
+     * outside actorState (every field of the subset is cleared); 0 = no masks (the message goes out whole).  Applied to the
+     * UPDATE messages the engine builds; the reference also filters the full state of a first fan-out — in place, on the
+     * channel's own data (data.go:219,294) — which stays with the host. */
+    uint32_t data_field_mask;
 } chd_sub_options;
 
 /* replaces: Connection.SubscribeToChannel(spatial channel, options) (subscription.go:34-102) as reached from an explicit
@@ -656,6 +665,21 @@ int chd_wire_set_payloads(chd_ctx *ctx, int kind, uint32_t n, const uint32_t *id
  *   The FULL payload kinds stay whole Any messages. */
 int chd_wire_set_type_url(chd_ctx *ctx, int which /* 0 entity data, 1 spatial channel data updates, 2 handover data */,
                           const uint8_t *url, uint32_t len);
+
+/* replaces, for one channel data type: the accumulation of tickData (data.go:249-253: proto.Merge of the first selected
+ * update into an empty message, the type's Merge for the rest) + fmutils.Filter (data.go:294) + proto.Marshal — BYTE FOR BYTE.
+ * CHD_WORLD_WIRE | CHD_WORLD_UPDATE_MASKS worlds.  With a schema set, an entity update record whose selected updates all lie
+ * inside the schema carries Any{type_url, value = the merged message as Go marshals it (fields in field-number order)};
+ * a record with an update outside it keeps the generic form (the selected updates concatenated: same decoded message,
+ * other bytes).
+ *   CHD_MERGE_SCHEMA_TPS_ENTITY_MOVEMENT: tpspb.EntityChannelData restricted to actorState.replicatedMovement
+ *   {linearVelocity, angularVelocity, location, rotation: FVector{x, y, z}; bSimulatedPhysicSleep, bRepPhysics}
+ *   (examples/channeld-ue-tps/tpspb/tps.proto:22-35, pkg/unrealpb/unreal_common.proto:55-59,161-184; EntityChannelData.Merge,
+ *   tpspb/data.go:227-252: objRef dropped from all but the first update — an update WITH an objRef is outside the subset).
+ * 0 = none (concatenate). */
+#define CHD_MERGE_SCHEMA_NONE 0
+#define CHD_MERGE_SCHEMA_TPS_ENTITY_MOVEMENT 1
+int chd_wire_set_merge_schema(chd_ctx *ctx, int schema);
 
 /* replaces: the message assembly of Notify (spatial.go:738-773,797-857; HandoverDataMerger.MergeTo,
  * examples/channeld-ue-tps/tpspb/data.go:323-347): for every handover of the LAST tick the two MessagePacks the

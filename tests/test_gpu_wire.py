@@ -244,3 +244,90 @@ def test_handover_messages_on_the_device(amd):
         off, conn, kind = w.handover_recipients(nh)
         assert len(off) == nh + 1 and int(off[-1]) == len(conn) == len(kind)
     assert n_total > 100 and n_group > 5 and n_ctx > 5
+
+
+def test_typed_merge_is_byte_identical_to_the_reference_marshal(amd):
+    """VERDICT r2 #9 / SURVEY 8f-3: with CHD_MERGE_SCHEMA_TPS_ENTITY_MOVEMENT the accumulated update of a slow subscriber is
+    merged FIELD BY FIELD on the device and marshalled as Go marshals it — proto.Merge of the first selected update, tpspb's
+    EntityChannelData.Merge for the rest (data.go:249-253, tpspb/data.go:227-252), fmutils.Filter with the subscription's
+    DataFieldMasks (data.go:294), fields in field-number order — not the concatenation of the selected updates.  Expected
+    bytes: oracle/merge.py, pinned by python-protobuf on the reference's embedded descriptors (tests/test_merge_oracle.py).
+    Updates outside the subset (here: one that carries an objRef) keep the generic, concatenated form."""
+    from channeld_amd.engine import movement_field_mask
+    from oracle import merge
+
+    MASKS = 32
+    cfg = synth.load_config("spatial_static_4x4.json")
+    N, S = 400, 20
+    sw = synth.SynthWorld(synth.WorldSpec(cfg, N, S, 0xC0FFEE46, tick_ms=33))
+    ctl = amd.StaticGrid2DSpatialController()
+    assert ctl.LoadConfig(json.dumps(cfg).encode(), strict=False) is None
+    w = amd.SpatialWorld(ctl, N, S, flags=CONN_MAJOR | WIRE | MASKS, max_records=1 << 21, wire_max_update_len=96, wire_max_full_len=256)
+    w.spawn(None, sw.chan_id, sw.x, sw.z, sw.flags, sw.sender)
+    w.add_subscribers(None, sw.sub_conn)
+    w.wire_set_merge_schema(1)
+    rng = np.random.default_rng(46)
+    ncell = ctl.GridCols * ctl.GridRows
+    url_e, url_c = b"type.googleapis.com/tpspb.EntityChannelData", b"type.googleapis.com/unrealpb.SpatialChannelData"
+    w.wire_set_type_url(False, url_e)
+    w.wire_set_type_url(True, url_c)
+    full_e = {i: any_bytes(rng, rng.integers(20, 200)) for i in range(N)}
+    full_c = {0x10000 + c: any_bytes(rng, rng.integers(20, 200)) for c in range(ncell)}
+    w.wire_set_payloads(ENT_FULL, list(full_e), list(full_e.values()))
+    w.wire_set_payloads(CELL_FULL, list(full_c), list(full_c.values()))
+    foreign = bytes([0x0A, 0x02, 0x08, 0x05])  # objRef { netGUID: 5 }: outside the movement subset
+    upd_e = {}
+    fmask = {}  # (slot, spatial channel) -> data_field_mask
+    typed2 = typed_masked = generic = 0
+    for k in range(14):
+        sw.step()
+        idx = np.sort(rng.choice(N, N // 2, replace=False)).astype(np.uint32) if k % 3 else np.arange(N, dtype=np.uint32)
+        pay = [foreign + merge.make_update(rng) if rng.random() < 0.03 else merge.make_update(rng) for _ in idx]
+        for i, b in zip(idx, pay):
+            upd_e[(int(i), k)] = b
+        w.wire_set_payloads(ENT_UPD, idx, pay)
+        res = w.tick(sw.now_ns(), upd_idx=idx, upd_x=sw.x[idx], upd_z=sw.z[idx], queries=sw.queries(), records_cap=1 << 21)
+        assert res.overflow == 0 and res.history_overflow == 0
+        nbytes, npackets, ndropped = w.wire_build()
+        off, npk, data = w.wire_fetch()
+        member = w.entity_state()[1]  # the spatial channel whose entity map holds each entity
+        for s in range(S):
+            a, n = int(res.conn_rec_off[s]), int(res.conn_rec_cnt[s])
+            packs = []
+            for r, mask in zip(res.records[a:a + n], res.record_masks[a:a + n]):
+                ch, full = int(r["channel"]), int(r["conn"]) >> 31
+                if full:
+                    body = full_c[ch] if ch < 0x80000 else full_e[ch - 0x80000]
+                else:
+                    bits = [j for j in range(31, -1, -1) if (int(mask) >> j) & 1]  # oldest update first
+                    if ch < 0x80000:
+                        value = b""  # (no spatial channel updates in this world)
+                        body = wire.field_bytes(1, url_c)
+                    else:
+                        e = ch - 0x80000
+                        ups = [upd_e[(e, k - j)] for j in bits]
+                        fm = fmask.get((s, int(member[e])), 0)
+                        try:
+                            value = merge.merged_update(ups, fm)
+                            typed2 += len(ups) >= 2
+                            typed_masked += fm != 0
+                        except merge.NotInSubset:
+                            value = b"".join(ups)
+                            generic += 1
+                        body = wire.field_bytes(1, url_e) + (wire.field_bytes(2, value) if value else b"")
+                packs.append(wire.fanout_message_pack(ch, body))
+            want, counts = wire.flush_stream(packs)
+            got = data[int(off[s]):int(off[s + 1])].tobytes()
+            assert got == want, f"tick {k} slot {s}: stream bytes ({len(got)} vs {len(want)})"
+        if k == 2:
+            # DataFieldMasks on every subscription of some connections (SUB_TO_CHANNEL with options; subscription.go:44-57 merges them)
+            opts = []
+            for s, paths in ((1, ["actorState.replicatedMovement.location"]), (4, ["actorState.replicatedMovement.location", "actorState.replicatedMovement.rotation",
+                                                                                     "actorState.replicatedMovement.bRepPhysics"]),
+                             (7, ["characterState"]), (9, ["actorState"])):
+                m = movement_field_mask(paths)
+                for c in w.subscriptions(s)[0]:
+                    opts.append(dict(slot=s, channel=int(c), data_field_mask=m))
+                    fmask[(s, int(c))] = m
+            w.set_sub_options(sw.now_ns(), opts)
+    assert typed2 > 1000 and typed_masked > 300 and generic > 20, (typed2, typed_masked, generic)

@@ -1,0 +1,36 @@
+"""The typed-merge oracle (oracle/merge.py: the movement subset of tpspb.EntityChannelData merged as tickData merges buffered
+updates, filtered by DataFieldMasks, marshalled) against the golden vectors python-protobuf produced from the reference's
+own embedded descriptors (tests/golden/make_merge_golden.py)."""
+import os
+
+import numpy as np
+
+from oracle import merge
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def test_merge_oracle_reproduces_protobuf_on_the_reference_descriptors():
+    g = np.load(os.path.join(HERE, "golden", "merge_vectors.npz"))
+    inputs, in_off, want, want_off = g["inputs"].tobytes(), g["in_off"], g["want"].tobytes(), g["want_off"]
+    u = 0
+    multi = masked = 0
+    for k, (cnt, mask) in enumerate(zip(g["in_cnt"], g["masks"])):
+        ups = [inputs[in_off[u + j]:in_off[u + j + 1]] for j in range(cnt)]
+        u += cnt
+        got = merge.merged_update(ups, int(mask))
+        assert got == want[want_off[k]:want_off[k + 1]], f"case {k}: {cnt} updates, mask {mask:#x}"
+        multi += cnt > 1
+        masked += mask != 0
+    assert multi > 100 and masked > 100
+
+
+def test_generated_updates_are_canonical_and_a_foreign_field_is_refused():
+    rng = np.random.default_rng(3)
+    for _ in range(200):
+        b = merge.make_update(rng)
+        assert merge.merged_update([b]) == b  # parse + serialize is the identity on canonical encodings
+    import pytest
+
+    with pytest.raises(merge.NotInSubset):
+        merge.merged_update([bytes([0x0A, 0x02, 0x08, 0x05])])  # objRef { netGUID: 5 }
