@@ -411,7 +411,9 @@ def main():
                              "in the serial schedule (roofline object) while the tick as a whole is shorter")
         world.set_pipelining(head_pipe)
     # dominant kernel: k_fanout_emit_seg.  achieved = algorithmic bytes per launch / avg launch time
-    achieved = float((BYTES_PER_MSG * emit_msgs.mean()) / (emit_us.mean() * 1e-6) / 1e9)
+    # (per-record masks: 4 more bytes written per message — DESIGN.md §4's 16 B/msg model of that diagnostic configuration)
+    bytes_per_msg = BYTES_PER_MSG + (4 if args.update_masks else 0)
+    achieved = float((bytes_per_msg * emit_msgs.mean()) / (emit_us.mean() * 1e-6) / 1e9)
 
     # ---- optional: wire-format packet streams of a few more ticks (payload materialisation) ----
     wire_info = None
@@ -526,8 +528,8 @@ def main():
                      "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_quoted": traffic is not None,
                      "traffic_source": traffic_note or "QUOTED, not measured in this run: bytes per launch from the rocprofv3 --pmc passes of this command on the same "
                                                        "kernel sources (profiles/hbm_traffic.json, source_hash checked)",
-                     "algorithmic_bytes_per_launch": float(BYTES_PER_MSG * emit_msgs.mean()),
-                     "bytes_per_msg": BYTES_PER_MSG, "msgs_per_launch": float(emit_msgs.mean()), "avg_launch_us": float(emit_us.mean()),
+                     "algorithmic_bytes_per_launch": float(bytes_per_msg * emit_msgs.mean()),
+                     "bytes_per_msg": bytes_per_msg, "msgs_per_launch": float(emit_msgs.mean()), "avg_launch_us": float(emit_us.mean()),
                      "emit_stage_us": float(stage_avg[4]), "deferred_msgs_per_tick": float(np.mean([h["n_deferred_records"] for h in hist]))},
     }
     out["roofline"]["whole_tick_frac"] = float(BYTES_PER_MSG * (msgs / K) / (elapsed / K) / 1e9 / HBM_PEAK_GBS)

@@ -962,7 +962,11 @@ int chd_world_create(chd_ctx *ctx, const chd_world_cfg *cfg) {
         for (int k = 0; k < 2; k++) HIPCHK(hipEventCreateWithFlags(&W.ev_emit_done[k], hipEventDisableTiming));
     }
     d.rec_mask = nullptr;
-    if (masks) TRY(walloc(ctx, &d.rec_mask, nrec, false));
+    d.seg_wm = nullptr;
+    if (masks) {
+        TRY(walloc(ctx, &d.rec_mask, nrec, false));
+        TRY(walloc(ctx, &d.seg_wm, P, false));
+    }
     d.rec_pos = nullptr;
     d.ce_slot = nullptr;
     // exact update buffers (history_depth): ChannelData.updateMsgBuffer per entity and per spatial channel

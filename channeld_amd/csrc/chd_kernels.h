@@ -136,6 +136,7 @@ struct WorldDev {
     uint32_t *n_simple;   // [S]
     uint4 *seg_desc;      // [S*capq] {segment offset in the connection's range, column start, entries, SD_* | windows}
     uint4 *seg_desc2;     // [S*capq] {cell index, index of the subscription in the connection's list, pair_flags after this tick, -}
+    uint4 *seg_wm;        // [S*capq] CHD_WORLD_UPDATE_MASKS only: the descriptor's (up to four) window masks = its records' merged-update masks
     int64_t *seg_ln;      // [S*capq] lastFanOutTime after this tick
     uint32_t *pair_rel;   // [S*capq] this tick: segment offset inside the connection's record range
     uint32_t *pair_nrec;  // [S*capq] this tick: records emitted for the subscription

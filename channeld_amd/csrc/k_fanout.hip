@@ -231,8 +231,9 @@ static bool seg_path_enabled() {
     static const bool on = [] { const char *e = getenv("CHD_EMIT_PIPELINED"); return !(e && e[0] == '0'); }();
     return on;
 }
-// the descriptor-driven path: connection-major, one-wave geometry (>= 4096 connections or asked for), no per-record masks
-static bool seg_path(const WorldDev &w) { return !w.cm_emit && !w.rec_mask && !w.seg_off && (w.S >= 4096 || w.one_wave_emit) && seg_path_enabled(); }
+// the descriptor-driven path: connection-major, one-wave geometry (>= 4096 connections or asked for); with per-record masks
+// (CHD_WORLD_UPDATE_MASKS) a window is a plain copy only where its mask is the same for every entity (k_fanout_plan_seg)
+static bool seg_path(const WorldDev &w) { return !w.cm_emit && !w.seg_off && (w.S >= 4096 || w.one_wave_emit) && seg_path_enabled(); }
 
 __global__ void __launch_bounds__(64 * FO_WAVES) k_fanout_plan_seg(DevGrid g, WorldDev w, int64_t now, TickRing ring);
 
@@ -905,6 +906,7 @@ __global__ void __launch_bounds__(64 * FO_WAVES) k_fanout_plan_seg(DevGrid g, Wo
         bool due = false, simple = false, deep = false;
         uint32_t fl = 0, c = 0, size = 0, start = 0, info = 0, count = 0;
         uint32_t nd = 0, wcolp = 0, own = 0, ncol0 = 0;  // descriptors of this subscription; per window its column (4 bits each)
+        uint4 wm4 = make_uint4(0u, 0u, 0u, 0u);          // (per-record masks) the windows' masks
         int64_t Lw = 0;
         if (p < cnt) {
             fl = w.pair_flags[pbase + p] & ~(PF_DEFER | PF_DEEP);
@@ -987,7 +989,9 @@ __global__ void __launch_bounds__(64 * FO_WAVES) k_fanout_plan_seg(DevGrid g, Wo
                     if (j >= nw || none) continue;
                     uint32_t cj = 0xFFFFFFFEu;
                     if (us != CHD_NONUNIFORM) {
-                        if (hand & wms[j]) cj = 0u;
+                        // (per-record masks: the record's mask is its entity's history inside the window — a constant, the
+                        // window's own mask, only where every entity has an update at EVERY stamp of the window)
+                        if (w.rec_mask ? (hand & wms[j]) == wms[j] : (hand & wms[j]) != 0u) cj = 0u;
                         else if (w.wcol_on) {
 #pragma unroll
                             for (uint32_t k = 0; k < CHD_WCOLS; k++)
@@ -998,7 +1002,7 @@ __global__ void __launch_bounds__(64 * FO_WAVES) k_fanout_plan_seg(DevGrid g, Wo
                     wcolp |= (cj & 15u) << (4u * j);
                     if (j && cj != (wcolp & 15u)) same = false;
                 }
-                if (simple) {
+                if (simple) {  // (may still turn false below)
                     // exact record counts: the segment is as long as what will be written
                     const uint32_t age = ring.cur_tick - c_htick;
                     const uint32_t chh = age < CHD_HIST_BITS ? (c_hist << age) : 0u;
@@ -1006,6 +1010,8 @@ __global__ void __launch_bounds__(64 * FO_WAVES) k_fanout_plan_seg(DevGrid g, Wo
 #pragma unroll
                     for (uint32_t j = 0; j < 4; j++)
                         if (j < nw && cell_update_passes(chh, chs, chhp, chsp, wms[j], skip_self, conn)) own |= 1u << j;
+                    if (own && w.rec_mask) simple = false;  // (the spatial channel's own record carries its own mask: the filtering launch)
+                    wm4 = make_uint4(wms[0], wms[1], wms[2], wms[3]);
                     info |= nw | (none ? SD_NONE : 0u);
                     if ((info & SD_FIRST) || nw == 0 || none || same) {
                         // one descriptor: first fan-out (full column, no window), nothing to send, or windows that agree
@@ -1065,6 +1071,7 @@ __global__ void __launch_bounds__(64 * FO_WAVES) k_fanout_plan_seg(DevGrid g, Wo
                 w.seg_desc[k] = make_uint4(rel32, start + col * w.wcol_stride, ncol0, info | (own << SD_OWN_SHIFT));
                 w.seg_desc2[k] = make_uint4(c, p, fl | PF_HAD_FIRST, 0u);
                 w.seg_ln[k] = Lw;
+                if (w.rec_mask) w.seg_wm[k] = wm4;
             } else {
                 uint32_t at = rel32;
                 for (uint32_t j = 0; j < nd; j++) {  // (rare: partially updating worlds, windows with different masks)
@@ -1106,7 +1113,7 @@ __global__ void __launch_bounds__(64 * FO_WAVES) k_fanout_plan_seg(DevGrid g, Wo
 // requests per line — reaches 5.0 TB/s, this one 5.4.  `since` counts the wide stores certainly issued (wave-uniform).
 __device__ __forceinline__ uint32_t store_column2(const u32x2 (&q)[4], uint32_t n, uint32_t start, uint32_t conn_tag,
                                                   chd_fanout_rec *__restrict__ out, uint32_t *__restrict__ opos, uint32_t n_out,
-                                                  uint32_t &since) {
+                                                  uint32_t &since, uint32_t *__restrict__ omask = nullptr, uint32_t wm = 0) {
     const uint32_t lane = lane_id();
     // (opaque copy: left to itself the compiler builds the {tag, channel} register pairs of every store of every
     // caller up front, from the moment the column registers exist — ~25 VGPRs held across the whole segment loop)
@@ -1123,12 +1130,14 @@ __device__ __forceinline__ uint32_t store_column2(const u32x2 (&q)[4], uint32_t 
             r.x = conn_tag; r.y = q[h].x; r.z = conn_tag; r.w = q[h].y;
             *(u32x4 *)(void *)(out + n_out + k) = r;
             if (opos) { opos[n_out + k] = start + k; opos[n_out + k + 1] = start + k + 1; }
+            if (omask) { u32x2 m2; m2.x = wm; m2.y = wm; *(u32x2 *)(void *)(omask + n_out + k) = m2; }  // (every entity merges the whole window)
         } else if (k < n) {
             chd_fanout_rec r;
             r.conn = conn_tag;
             r.channel = q[h].x;
             out[n_out + k] = r;
             if (opos) opos[n_out + k] = start + k;
+            if (omask) omask[n_out + k] = wm;
         }
         if (n >= (uint32_t)(128 * h + 2)) since += 1;  // lane 0 holds a whole pair: the wide store was issued
     }
@@ -1157,7 +1166,9 @@ extern "C" int chd_debug_trace(unsigned long long *out, unsigned n) {
 // the role's segments are k = role, role + WAVES, ...; eight counters on eight lines, a wave takes from the one of its
 // XCD (blockIdx & 7), and requests its NEXT ticket before it starts storing, so the atomic's return is awaited together
 // with the first column loads and never drains record stores.
-template <int WAVES>
+// MASKS (CHD_WORLD_UPDATE_MASKS): also the per-record merged-updates mask — on this path a constant per window, the window's
+// own mask (the plan took the subscription only if EVERY entity of the cell has an update at EVERY stamp of the window).
+template <int WAVES, bool MASKS = false>
 __global__ void __launch_bounds__(64, FO_SEG_OCC) k_fanout_emit_seg(DevGrid g, WorldDev w, uint32_t n_tickets) {
     constexpr int B = FO_SEG_BATCH;
     const uint32_t lane = lane_id();
@@ -1191,11 +1202,12 @@ __global__ void __launch_bounds__(64, FO_SEG_OCC) k_fanout_emit_seg(DevGrid g, W
     const uint32_t mine = (ns - wave + WAVES - 1) / WAVES;  // segments of this wave (a connection has at most 64 WAVES due ones per pass)
     for (uint32_t j0 = 0; j0 < mine; j0 += 64) {
         const uint32_t kl = wave + (j0 + lane) * WAVES;
-        u32x4 dv = {0, 0, 0, 0};
+        u32x4 dv = {0, 0, 0, 0}, wmv = {0, 0, 0, 0};
         uint32_t cv = 0;
         if (kl < ns) {
             dv = *(const u32x4 *)(const void *)(w.seg_desc + pbase + kl);
             cv = w.seg_desc2[pbase + kl].x;
+            if (MASKS) wmv = *(const u32x4 *)(const void *)(w.seg_wm + pbase + kl);
         }
         const uint32_t here = min(mine - j0, 64u);
         // ... and the columns of B segments are loaded TOGETHER, one wait, then B segments' records are stored back to
@@ -1231,6 +1243,12 @@ __global__ void __launch_bounds__(64, FO_SEG_OCC) k_fanout_emit_seg(DevGrid g, W
                 const uint32_t cch = (uint32_t)__builtin_amdgcn_readlane((int)cv, jj) + g.id_start;
                 chd_fanout_rec *__restrict__ out = w.recs + base + rel;
                 uint32_t *__restrict__ opos = w.rec_pos ? w.rec_pos + base + rel : nullptr;
+                uint32_t *__restrict__ omask = MASKS ? w.rec_mask + base + rel : nullptr;
+                uint32_t wms[4] = {0, 0, 0, 0};
+                if (MASKS) {
+                    wms[0] = (uint32_t)__builtin_amdgcn_readlane((int)wmv.x, jj); wms[1] = (uint32_t)__builtin_amdgcn_readlane((int)wmv.y, jj);
+                    wms[2] = (uint32_t)__builtin_amdgcn_readlane((int)wmv.z, jj); wms[3] = (uint32_t)__builtin_amdgcn_readlane((int)wmv.w, jj);
+                }
                 uint32_t n_out = 0;
                 if (info & SD_FIRST) {
                     // first fan-out: the whole data of the spatial channel and of every entity channel in it
@@ -1240,8 +1258,9 @@ __global__ void __launch_bounds__(64, FO_SEG_OCC) k_fanout_emit_seg(DevGrid g, W
                         r.channel = cch;
                         out[0] = r;
                         if (opos) opos[0] = CHD_POS_CELL | (cch - g.id_start);
+                        if (MASKS) omask[0] = 0;
                     }
-                    n_out = store_column2(col[b], n, start, conn | CHD_REC_FULL, out, opos, 1u, since);
+                    n_out = store_column2(col[b], n, start, conn | CHD_REC_FULL, out, opos, 1u, since, omask, 0u);
                 }
                 const uint32_t nw = info & SD_NWIN_MASK;
                 for (uint32_t j = 0; j < nw; j++) {
@@ -1256,7 +1275,7 @@ __global__ void __launch_bounds__(64, FO_SEG_OCC) k_fanout_emit_seg(DevGrid g, W
                         n_out += 1;
                     }
                     if (!(info & SD_NONE)) {  // every entity passes this window (that is what made the subscription simple)
-                        n_out = store_column2(col[b], n, start, conn, out, opos, n_out, since);
+                        n_out = store_column2(col[b], n, start, conn, out, opos, n_out, since, omask, j == 0 ? wms[0] : j == 1 ? wms[1] : j == 2 ? wms[2] : wms[3]);
                     }
                 }
                 // (a later part of a split subscription starts anywhere inside a line: pad to the line of the segment's END)
@@ -1775,13 +1794,15 @@ void launch_fanout_emit_main(hipStream_t st, DevGrid g, WorldDev w, int64_t now_
     // one wave per connection when the connections alone fill the chip (or when asked to: CHD_WORLD_ONE_WAVE_EMIT),
     // four waves per connection otherwise
     const bool one_wave = w.S >= 4096 || w.one_wave_emit;
-    if (w.rec_mask) {
-        if (one_wave) hipLaunchKernelGGL((k_fanout_emit<1, true>), dim3(w.S), dim3(64), 0, st, g, w, now_ns, ring);
-        else hipLaunchKernelGGL((k_fanout_emit<4, true>), dim3(w.S), dim3(256), 0, st, g, w, now_ns, ring);
-    } else if (seg_path(w)) {
+    if (seg_path(w)) {
         // (k_fanout_plan_seg has decided everything; see launch_fanout_plan)
         const uint32_t n_tickets = w.S * FO_SEG_WAVES;
-        hipLaunchKernelGGL(k_fanout_emit_seg<FO_SEG_WAVES>, dim3(n_tickets < w.seg_waves ? n_tickets : w.seg_waves), dim3(64), 0, st, g, w, n_tickets);
+        const dim3 grid(n_tickets < w.seg_waves ? n_tickets : w.seg_waves);
+        if (w.rec_mask) hipLaunchKernelGGL((k_fanout_emit_seg<FO_SEG_WAVES, true>), grid, dim3(64), 0, st, g, w, n_tickets);
+        else hipLaunchKernelGGL((k_fanout_emit_seg<FO_SEG_WAVES, false>), grid, dim3(64), 0, st, g, w, n_tickets);
+    } else if (w.rec_mask) {
+        if (one_wave) hipLaunchKernelGGL((k_fanout_emit<1, true>), dim3(w.S), dim3(64), 0, st, g, w, now_ns, ring);
+        else hipLaunchKernelGGL((k_fanout_emit<4, true>), dim3(w.S), dim3(256), 0, st, g, w, now_ns, ring);
     } else if (one_wave) hipLaunchKernelGGL((k_fanout_emit<1, false>), dim3(w.S), dim3(64), 0, st, g, w, now_ns, ring);
     else hipLaunchKernelGGL((k_fanout_emit<4, false>), dim3(w.S), dim3(256), 0, st, g, w, now_ns, ring);
 }
@@ -1789,7 +1810,8 @@ void launch_fanout_emit_main(hipStream_t st, DevGrid g, WorldDev w, int64_t now_
 // the subscriptions k_fanout_plan_seg left to the filtering kernel (descriptor path only)
 void launch_fanout_emit_deferred(hipStream_t st, DevGrid g, WorldDev w, int64_t now_ns, TickRing ring) {
     if (!w.S || !seg_path(w)) return;
-    hipLaunchKernelGGL((k_fanout_emit<1, false, true>), dim3(w.S), dim3(64), 0, st, g, w, now_ns, ring);
+    if (w.rec_mask) hipLaunchKernelGGL((k_fanout_emit<1, true, true>), dim3(w.S), dim3(64), 0, st, g, w, now_ns, ring);
+    else hipLaunchKernelGGL((k_fanout_emit<1, false, true>), dim3(w.S), dim3(64), 0, st, g, w, now_ns, ring);
 }
 
 
