@@ -501,6 +501,10 @@ def main():
             traffic = tj["kernels"].get(DOMINANT, {}).get("bytes_per_launch")
         else:
             traffic_note = f"profiles/hbm_traffic.json was measured on other kernel sources ({tj.get('source_hash')} != {source_hash()}): not quoted"
+    else:
+        traffic_note = "no PMC measurement of this configuration (profiles/hbm_traffic.json covers the headline workload only)"
+    if args.update_masks and traffic is not None:
+        traffic, traffic_note = None, "no PMC measurement of the masks configuration"
 
     out = {
         "metric": "AOI-filtered fanout msgs/sec + p99 tick latency, 100K entities / 10K subs",
