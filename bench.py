@@ -686,6 +686,9 @@ def wire_phase(args, world, ctl, N, tick_at, ticks, base_now, measure_last=None)
         world.sync()
         trace(f"wire tick {i} done")
         if i < first:
+            if i == first - 1:
+                world.wire_build()  # (untimed: allocates the stream arena the measured builds then reuse)
+                world.sync()
             continue  # (set-up ticks: the first, full-state fan-out would be tens of GB of packets)
         a = time.perf_counter()
         nbytes, npackets, ndropped = world.wire_build()
@@ -702,9 +705,12 @@ def wire_phase(args, world, ctl, N, tick_at, ticks, base_now, measure_last=None)
     return {"what": "chd_tick_device + chd_wire_build: per-connection Packet streams (tag + MessagePacks) ready for conn.Write, left in HBM",
             "ticks": len(wt), "bytes_per_tick": float(np.mean(wb)), "packets_per_tick": float(np.mean(wp)), "msgs_per_tick": float(np.mean(nrec)),
             "ms_per_build": 1e3 * float(np.min(wt)), "ms_per_build_all": [round(1e3 * v, 2) for v in wt],
+            "GB_per_build_all": [round(v / 1e9, 2) for v in wb],
+            "written_GBps_all": [round(b_ / t_ / 1e9) for b_, t_ in zip(wb, wt)],
             "ms_tick_plus_build": 1e3 * tt[k], "value": nrec[k] / tt[k], "unit": "msgs/s", "packets_per_s": wp[k] / tt[k],
-            "written_GBps": float(wb[int(np.argmin(wt))] / np.min(wt) / 1e9),
-            "frac_of_hbm_peak": float(wb[int(np.argmin(wt))] / np.min(wt) / 1e9 / HBM_PEAK_GBS),
+            "written_GBps": float(np.median([b_ / t_ / 1e9 for b_, t_ in zip(wb, wt)])),
+            "written_GBps_is": "median over the builds of bytes / time of that build (host clock around chd_wire_build + sync)",
+            "frac_of_hbm_peak": float(np.median([b_ / t_ / 1e9 for b_, t_ in zip(wb, wt)]) / HBM_PEAK_GBS),
             "payload": "66-byte Any per entity update, 40-byte per spatial channel update"}
 
 

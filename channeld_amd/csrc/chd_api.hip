@@ -46,6 +46,9 @@ struct World {
     bool wire = false;                 // CHD_WORLD_WIRE
     WireDev x{};
     uint64_t wire_cap = 0;             // bytes allocated for x.bytes
+    uint64_t cdesc_cap = 0;            // copy descriptors allocated for x.cdesc
+    uint64_t wire_ranges = 0;          // chd_wire_build_info: image ranges / record-path connections of the last build
+    uint32_t wire_slow_conns = 0;
     bool wire_built = false;
     // region-sharded worlds: halo exchange layout (chd_shard_halo_layout)
     uint32_t halo_rank = 0, halo_world = 0;
@@ -513,6 +516,7 @@ void chd_destroy(chd_ctx *ctx) {
     if (ctx->w.seg_rec_stage) (void)hipFree(ctx->w.seg_rec_stage);
     if (ctx->w.list_dense) (void)hipFree(ctx->w.list_dense);
     if (ctx->w.x.bytes) (void)hipFree(ctx->w.x.bytes);
+    if (ctx->w.x.cdesc) (void)hipFree(ctx->w.x.cdesc);
     for (auto &b : ctx->scratch)
         if (b.p) (void)hipFree(b.p);
     for (auto &e : ctx->ev) (void)hipEventDestroy(e);
@@ -1031,6 +1035,35 @@ int chd_world_create(chd_ctx *ctx, const chd_world_cfg *cfg) {
         x.conn_woff = x.conn_wlen;
         TRY(walloc(ctx, &x.conn_npk, S));
         TRY(walloc(ctx, &x.n_dropped, 8 + 64));
+        // the descriptor-driven stream builder (k_wire_layout_img): one image of every cell's messages per payload kind
+        x.img_on = x.merge ? 0u : 1u;
+        if (const char *e = getenv("CHD_WIRE_IMAGES")) if (e[0] == '0') x.img_on = 0;  // (A/B runs, tests of the record path)
+        if (x.img_on) {
+            size_t free_b = 0, total_b = 0;
+            (void)hipMemGetInfo(&free_b, &total_b);
+            for (int k = 0; k < 2; k++) {
+                // worst case: every channel's payload at its slot size + the three nested headers, images padded to 16 bytes
+                const uint64_t cap = (uint64_t)(N + C) * (x.stride[k] + 32u) + 16ull * C + 4096ull;
+                x.img_ok[k] = (cap < (1ull << 31) && cap < free_b / 8) ? 1u : 0u;  // (a descriptor's source offset has 31 bits)
+                if (!x.img_ok[k]) continue;
+                TRY(walloc(ctx, &x.img[k], cap, false));
+                x.img_cap[k] = cap;
+                TRY(walloc(ctx, &x.img_off[k], C + 1));
+                TRY(walloc(ctx, &x.img_len[k], C));
+                TRY(walloc(ctx, &x.img_own[k], C));
+                TRY(walloc(ctx, &x.img_bad[k], C));
+                TRY(walloc(ctx, &x.img_end[k], N + 2));
+            }
+            if (!x.img_ok[0] && !x.img_ok[1]) x.img_on = 0;
+            x.dpad = C <= 65536 ? 32u : 1u;
+            TRY(walloc(ctx, &x.cell_dcnt, C * x.dpad + 1));
+            TRY(walloc(ctx, &x.conn_ndesc, S));
+            TRY(walloc(ctx, &x.conn_key, S));
+            TRY(walloc(ctx, &x.conn_rank, S));
+            TRY(walloc(ctx, &x.rank_ndesc, S + 1));
+            TRY(walloc(ctx, &x.slow_list, S));
+            TRY(walloc(ctx, &x.cp_ticket, 32));
+        }
         x.ncell = (uint32_t)C;
         x.npos = (uint32_t)N + 2u;
         if (const char *e = getenv("CHD_DEBUG_POISON")) if (e[0] == '1') {  // (debugging: unwritten per-record words are recognisable)
@@ -2275,32 +2308,68 @@ int chd_wire_build(chd_ctx *ctx, uint64_t *total_bytes, uint64_t *total_packets,
     hipStream_t st = ctx->stream;
     // (a second call for the same tick returns the streams already built: the layout pass rewrote the records' position words)
     const bool again = W.wire_built;
+    // streams from the fan-out descriptors where the tick has them (k_wire_layout_img), else from the records (k_wire_layout)
+    const bool img = W.x.img_on && W.last_desc && !d.cm_emit && !d.wcol_on;
+    auto write_img = [&]() {  // (device-guarded: does nothing unless both arenas hold what the sizing pass found)
+        W.x.bytes_cap = W.wire_cap;
+        W.x.cdesc_cap = W.cdesc_cap;
+        launch_wire_layout_img(st, ctx->g, d, W.x, true);
+        launch_wire_copy_img(st, d, W.x, d.seg_waves ? d.seg_waves : 2048u);
+    };
     if (!again) {
         HIPCHK(hipMemsetAsync(W.x.n_dropped, 0, 8 * sizeof(uint32_t), st));
         W.x.cur_tick = ctx->ring.cur_tick;
-        launch_wire_layout(st, d, W.x);
+        if (img) {
+            HIPCHK(hipMemsetAsync(W.x.cp_ticket, 0, 32 * sizeof(uint32_t), st));
+            HIPCHK(hipMemsetAsync(W.x.cell_dcnt, 0, ((size_t)W.x.ncell * W.x.dpad + 1) * sizeof(uint32_t), st));
+            launch_wire_images(st, ctx->g, d, W.x);
+            launch_wire_layout_img(st, ctx->g, d, W.x, false);
+            launch_wire_conn_order(st, d, W.x);
+        } else {
+            launch_wire_layout(st, d, W.x);
+        }
         launch_scan_u64_inplace(st, W.x.conn_wlen, d.S);
+        // no host round trip between sizing and writing on the descriptor path: the writing kernels are enqueued for the
+        // arenas as they are and check on the device that they suffice
+        if (img) write_img();
         TRY(after_launch(ctx));
     }
     uint64_t total = 0;
-    uint32_t ndrop2[5] = {0, 0, 0, 0, 0};
+    uint32_t ndrop2[8] = {0, 0, 0, 0, 0, 0, 0, 0}, ndesc = 0;
     TRY(down(ctx, &total, W.x.conn_wlen + d.S, sizeof total));
     TRY(down(ctx, ndrop2, W.x.n_dropped, sizeof ndrop2));
+    if (img && !again) TRY(down(ctx, &ndesc, W.x.rank_ndesc + d.S, sizeof ndesc));
     HIPCHK(hipStreamSynchronize(st));
     const uint32_t ndrop = ndrop2[0];
     if (ndrop2[1] || ndrop2[2]) return fail(ctx, CHD_E_STATE, "chd_wire_build: %u records of this tick carry no valid position word, %u name no entity slot", ndrop2[1], ndrop2[2]);
+    if (ndrop2[6]) return fail(ctx, CHD_E_STATE, "chd_wire_build: the packet split of %u connections made no progress (a bug)", ndrop2[6]);
     if (!again) {
-        if (total > W.wire_cap) {
+        const bool grow_bytes = total > W.wire_cap, grow_desc = img && ndesc > W.cdesc_cap;
+        if (grow_bytes) {
             if (W.x.bytes) HIPCHK(hipFree(W.x.bytes));
             W.x.bytes = nullptr;
             W.wire_cap = total + total / 2 + 4096;  // head-room: the arena is only re-allocated when a tick outgrows it
             HIPCHK(hipMalloc((void **)&W.x.bytes, W.wire_cap));
         }
-        launch_wire_copy(st, d, W.x, ndrop2[4]);
+        if (grow_desc) {
+            if (W.x.cdesc) HIPCHK(hipFree(W.x.cdesc));
+            W.x.cdesc = nullptr;
+            W.cdesc_cap = (uint64_t)ndesc + ndesc / 2 + 4096;
+            HIPCHK(hipMalloc((void **)&W.x.cdesc, W.cdesc_cap * sizeof(uint4)));
+        }
+        if (img) {
+            if (grow_bytes || grow_desc) write_img();  // (the guarded launches above did nothing)
+        } else {
+            launch_wire_copy(st, d, W.x, ndrop2[4]);
+        }
+        W.wire_ranges = img ? ndesc : 0;
+        W.wire_slow_conns = ndrop2[4];
         TRY(after_launch(ctx));
-        uint32_t bad = 0;
-        TRY(down(ctx, &bad, W.x.n_dropped + 3, sizeof bad));
-        HIPCHK(hipStreamSynchronize(st));
+        uint32_t bad = ndrop2[3];
+        if (!img || grow_bytes || grow_desc) {  // (else everything ran before the synchronisation above)
+            TRY(down(ctx, &bad, W.x.n_dropped + 3, sizeof bad));
+            HIPCHK(hipStreamSynchronize(st));
+        }
         if (bad) {
             uint32_t g[16] = {0};
             TRY(down(ctx, g, W.x.n_dropped + 8, sizeof g));
@@ -2321,6 +2390,16 @@ int chd_wire_build(chd_ctx *ctx, uint64_t *total_bytes, uint64_t *total_packets,
         for (uint32_t v : npk) t += v;
         *total_packets = t;
     }
+    return CHD_OK;
+}
+
+int chd_wire_build_info(chd_ctx *ctx, uint64_t *n_image_ranges, uint32_t *n_record_path_connections) {
+    NEED_WORLD();
+    World &W = ctx->w;
+    if (!W.wire_built) return fail(ctx, CHD_E_STATE, "chd_wire_build has not run for the last tick");
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    if (n_image_ranges) *n_image_ranges = W.wire_ranges;
+    if (n_record_path_connections) *n_record_path_connections = W.wire_slow_conns;
     return CHD_OK;
 }
 

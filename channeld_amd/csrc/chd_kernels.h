@@ -381,7 +381,29 @@ struct WireDev {
     uint32_t *n_dropped;                // [2] messages dropped by the size check of Send; records without a valid position word
     uint32_t ncell, npos;               // bounds of the position words: cells of the grid, entries of the cell table
     uint8_t *bytes;                     // the wire arena
+    // streams from the fan-out descriptors (k_wire_layout_img): per cell and payload kind f (0 update, 1 full state) the IMAGE
+    // of the cell's messages — [own message][entity messages in column order] — built once per tick
+    uint32_t img_on;                    // the path exists for this world (no merged updates)
+    uint32_t img_ok[2];                 // ... and its arena of kind f
+    uint8_t *img[2];
+    uint64_t img_cap[2];
+    uint32_t *img_off[2];               // [ncell + 1] image offsets (16-byte aligned; the scan of the padded lengths)
+    uint32_t *img_len[2], *img_own[2];  // [ncell] image bytes; bytes of the own message in front
+    uint32_t *img_bad[2];               // [ncell] a message of the cell is dropped by Send / names no slot: its subscriptions take the record path
+    uint32_t *img_end[2];               // [npos] end of each entity message inside its cell's image (the packet cuts fall on these)
+    uint32_t *cell_dcnt;                // [ncell * dpad + 1] connections per cell of their first subscription -> exclusive scan
+    uint32_t dpad;                      // counter stride in words (32 = one per 128-byte line, grids up to 64K cells)
+    uint32_t *conn_ndesc, *conn_key, *conn_rank;  // [S] copy descriptors of the connection; its first cell; its place in the copy order
+    uint32_t *rank_ndesc;               // [S + 1] descriptor counts in copy order -> exclusive scan
+    uint4 *cdesc;                       // {dst lo, dst hi, src offset | kind << 31, bytes}: per connection in stream order, connections by rank
+    uint64_t bytes_cap, cdesc_cap;      // what the arenas hold (checked by the writing kernels: wire_img_fits)
+    uint32_t *slow_list;                // [S] connections with record-path segments (count: n_dropped[4])
+    uint32_t *cp_ticket;                // k_wire_copy_img's ticket counter
 };
+void launch_wire_images(hipStream_t st, DevGrid g, WorldDev w, WireDev x);
+void launch_wire_layout_img(hipStream_t st, DevGrid g, WorldDev w, WireDev x, bool emit);
+void launch_wire_conn_order(hipStream_t st, WorldDev w, WireDev x);
+void launch_wire_copy_img(hipStream_t st, WorldDev w, WireDev x, uint32_t waves);
 void launch_wire_layout(hipStream_t st, WorldDev w, WireDev x);
 // handover message assembly: sizes[2*nh] then, with off = exclusive scan of the sizes, the bytes
 void launch_handover_msg_sizes(hipStream_t st, DevGrid g, WorldDev w, WireDev x, uint32_t nh, uint32_t *sizes);

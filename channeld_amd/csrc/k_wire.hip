@@ -26,6 +26,12 @@
 #define WIRE_MAX_PACKET 65535u
 #define WIRE_DROP_SIZE 65530u  // MaxPacketSize - PacketHeaderSize (connection.go:72)
 
+// the descriptor-driven build runs without a host round trip between sizing and writing: the writing kernels check the
+// arenas themselves (the host re-runs them after growing an arena, chd_wire_build)
+__device__ __forceinline__ bool wire_img_fits(const WorldDev &w, const WireDev &x) {
+    return x.conn_woff[w.S] <= x.bytes_cap && x.rank_ndesc[w.S] <= x.cdesc_cap;
+}
+
 __device__ __forceinline__ uint32_t vlen(uint32_t v) { return v < (1u << 7) ? 1u : v < (1u << 14) ? 2u : v < (1u << 21) ? 3u : v < (1u << 28) ? 4u : 5u; }
 
 
@@ -452,11 +458,85 @@ __device__ __forceinline__ void wave_copy_out(uint8_t *__restrict__ dst, const u
     if (lane < n - done) dst[done + lane] = src[done + lane];
 }
 
-__global__ void __launch_bounds__(256) k_wire_copy(WorldDev w, WireDev x) {
-    __shared__ uint32_t ticket;
-    __shared__ __attribute__((aligned(16))) uint8_t images[4][WIRE_IMG + 48];
-    const uint32_t s = blockIdx.x;
-    if (!w.sub_alive[s] || !x.conn_slow[s] || x.conn_woff[s + 1] == x.conn_woff[s]) return;  // (conn_wlen was scanned in place)
+// One chunk of up to 64 messages, one per lane (live lanes: `begin` = byte offset of the message — of its tag, if it opens a
+// packet — in `stream`, ascending with the lane; hl / pl = header and payload bytes; m, tag, fmask as wire_msg / put_header
+// take them), written by the whole wave: groups of consecutive live messages whose byte range fits the LDS image are built
+// there and streamed out; a single message longer than the image is copied cooperatively straight from its payload slot(s).
+__device__ __forceinline__ void wire_put_messages(const WireDev &x, uint8_t *__restrict__ stream, uint8_t *img, bool live, uint32_t begin,
+                                                  uint32_t hl, uint32_t pl, const WireMsg &m, uint32_t tag, uint32_t fmask) {
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t endb = begin + hl + pl;
+    uint32_t a = 0;
+    for (;;) {
+        const uint64_t lm = __ballot(live && lane >= a);
+        if (!lm) break;
+        const uint32_t fa = (uint32_t)__ffsll((unsigned long long)lm) - 1u;
+        const uint32_t lo = (uint32_t)__shfl((int)begin, (int)fa);
+        const uint64_t nf = __ballot(live && lane >= fa && endb - lo > WIRE_IMG);
+        const uint32_t b = nf ? (uint32_t)__ffsll((unsigned long long)nf) - 1u : 64u;
+        if (b == fa) {
+            // one message longer than the image: header through the image, payload straight from its slot(s)
+            const uint32_t hl1 = (uint32_t)__shfl((int)hl, (int)fa);
+            if (lane == fa) put_header(img, x, m, tag);
+            wire_wave_sync();
+            wave_copy_out(stream + lo, img, hl1, false);
+            const uint32_t kind1 = (uint32_t)__shfl((int)m.kind, (int)fa), mask1 = (uint32_t)__shfl((int)m.mask, (int)fa);
+            const uint64_t pay1 = ((uint64_t)(uint32_t)__shfl((int)((uintptr_t)m.pay >> 32), (int)fa) << 32) |
+                                  (uint32_t)__shfl((int)(uint32_t)(uintptr_t)m.pay, (int)fa);
+            if (!kind1) {
+                wave_copy_out(stream + lo + hl1, (const uint8_t *)(uintptr_t)pay1, (uint32_t)__shfl((int)pl, (int)fa), false);
+            } else {
+                uint32_t at = lo + hl1;
+                const uint32_t id1 = (uint32_t)__shfl((int)(((uintptr_t)m.pay - (uintptr_t)(kind1 == 2 ? x.ring_cell : x.ring_ent)) / ((size_t)CHD_HIST_BITS * x.stride[0])), (int)fa);
+                const uint32_t *rl = (kind1 == 2 ? x.rlen_cell : x.rlen_ent) + (size_t)id1 * CHD_HIST_BITS;
+                for (int jj = CHD_HIST_BITS - 1; jj >= 0; jj--) {
+                    if (!((mask1 >> jj) & 1u)) continue;
+                    const uint32_t sl = (x.cur_tick - (uint32_t)jj) & (CHD_HIST_BITS - 1u);
+                    wave_copy_out(stream + at, (const uint8_t *)(uintptr_t)pay1 + (size_t)sl * x.stride[0], rl[sl], false);
+                    at += rl[sl];
+                }
+            }
+            wire_wave_sync();
+            a = fa + 1;
+            continue;
+        }
+        const bool mine = live && lane >= fa && lane < b;
+        uint32_t hi = mine ? endb : 0u;
+        for (int d = 32; d >= 1; d >>= 1) hi = max(hi, (uint32_t)__shfl_xor((int)hi, d));
+        const uint32_t off0 = (uint32_t)((uintptr_t)(stream + lo) & 15u);
+        if (mine) {
+            uint8_t *d = img + off0 + (begin - lo);
+            d += put_header(d, x, m, tag);
+            if (!m.kind) {
+                lane_put_payload(d, m.pay, pl);  // payload slots are 16-byte aligned and padded
+            } else if (m.kind == 3u) {
+                // the accumulated update message, merged field by field (the layout pass sized it the same way)
+                const uint32_t id = (uint32_t)(((uintptr_t)m.pay - (uintptr_t)x.ring_ent) / ((size_t)CHD_HIST_BITS * x.stride[0]));
+                Movement mv;
+                if (mv_merge_selected(x, m.pay, x.rlen_ent + (size_t)id * CHD_HIST_BITS, m.mask, fmask, mv)) (void)mv_write(mv, d);
+            } else {
+                // the selected updates, oldest (highest bit) first
+                const uint32_t *rl = (m.kind == 2 ? x.rlen_cell : x.rlen_ent) +
+                                     ((uintptr_t)m.pay - (uintptr_t)(m.kind == 2 ? x.ring_cell : x.ring_ent)) / x.stride[0];
+                for (int jj = CHD_HIST_BITS - 1; jj >= 0; jj--) {
+                    if (!((m.mask >> jj) & 1u)) continue;
+                    const uint32_t sl = (x.cur_tick - (uint32_t)jj) & (CHD_HIST_BITS - 1u);
+                    const uint32_t ln = rl[sl];
+                    lane_put_payload(d, m.pay + (size_t)sl * x.stride[0], ln);
+                    d += ln;
+                }
+            }
+        }
+        wire_wave_sync();
+        wave_copy_out(stream + lo, img + off0, hi - lo, true);
+        wire_wave_sync();
+        a = b;
+    }
+}
+
+// the record-path segments (seg_fast == 0) of connection s, by one workgroup of four waves taking segments in turn
+__device__ __forceinline__ void wire_copy_conn(const WorldDev &w, const WireDev &x, uint32_t s, uint8_t (*images)[WIRE_IMG + 48], uint32_t &ticket) {
+    if (!w.sub_alive[s] || !x.conn_slow[s] || x.conn_woff[s + 1] == x.conn_woff[s]) return;  // (conn_wlen was scanned in place; uniform)
     const uint32_t lane = threadIdx.x & 63u;
     uint8_t *img = images[threadIdx.x >> 6];
     const uint32_t cnt = w.pair_cnt[s];
@@ -493,75 +573,26 @@ __global__ void __launch_bounds__(256) k_wire_copy(WorldDev w, WireDev x) {
                     live = true;
                 }
             }
-            const uint32_t endb = begin + hl + pl;
-            // ---- groups of consecutive live messages that fit the image ----
-            uint32_t a = 0;
-            for (;;) {
-                const uint64_t lm = __ballot(live && lane >= a);
-                if (!lm) break;
-                const uint32_t fa = (uint32_t)__ffsll((unsigned long long)lm) - 1u;
-                const uint32_t lo = (uint32_t)__shfl((int)begin, (int)fa);
-                const uint64_t nf = __ballot(live && lane >= fa && endb - lo > WIRE_IMG);
-                const uint32_t b = nf ? (uint32_t)__ffsll((unsigned long long)nf) - 1u : 64u;
-                if (b == fa) {
-                    // one message longer than the image: header through the image, payload straight from its slot(s)
-                    const uint32_t hl1 = (uint32_t)__shfl((int)hl, (int)fa);
-                    if (lane == fa) put_header(img, x, m, tag);
-                    wire_wave_sync();
-                    wave_copy_out(stream + lo, img, hl1, false);
-                    const uint32_t kind1 = (uint32_t)__shfl((int)m.kind, (int)fa), mask1 = (uint32_t)__shfl((int)m.mask, (int)fa);
-                    const uint64_t pay1 = ((uint64_t)(uint32_t)__shfl((int)((uintptr_t)m.pay >> 32), (int)fa) << 32) |
-                                          (uint32_t)__shfl((int)(uint32_t)(uintptr_t)m.pay, (int)fa);
-                    if (!kind1) {
-                        wave_copy_out(stream + lo + hl1, (const uint8_t *)(uintptr_t)pay1, (uint32_t)__shfl((int)pl, (int)fa), false);
-                    } else {
-                        uint32_t at = lo + hl1;
-                        const uint32_t id1 = (uint32_t)__shfl((int)(((uintptr_t)m.pay - (uintptr_t)(kind1 == 2 ? x.ring_cell : x.ring_ent)) / ((size_t)CHD_HIST_BITS * x.stride[0])), (int)fa);
-                        const uint32_t *rl = (kind1 == 2 ? x.rlen_cell : x.rlen_ent) + (size_t)id1 * CHD_HIST_BITS;
-                        for (int jj = CHD_HIST_BITS - 1; jj >= 0; jj--) {
-                            if (!((mask1 >> jj) & 1u)) continue;
-                            const uint32_t sl = (x.cur_tick - (uint32_t)jj) & (CHD_HIST_BITS - 1u);
-                            wave_copy_out(stream + at, (const uint8_t *)(uintptr_t)pay1 + (size_t)sl * x.stride[0], rl[sl], false);
-                            at += rl[sl];
-                        }
-                    }
-                    wire_wave_sync();
-                    a = fa + 1;
-                    continue;
-                }
-                const bool mine = live && lane >= fa && lane < b;
-                uint32_t hi = mine ? endb : 0u;
-                for (int d = 32; d >= 1; d >>= 1) hi = max(hi, (uint32_t)__shfl_xor((int)hi, d));
-                const uint32_t off0 = (uint32_t)((uintptr_t)(stream + lo) & 15u);
-                if (mine) {
-                    uint8_t *d = img + off0 + (begin - lo);
-                    d += put_header(d, x, m, tag);
-                    if (!m.kind) {
-                        lane_put_payload(d, m.pay, pl);  // payload slots are 16-byte aligned and padded
-                    } else if (m.kind == 3u) {
-                        // the accumulated update message, merged field by field (the layout pass sized it the same way)
-                        const uint32_t id = (uint32_t)(((uintptr_t)m.pay - (uintptr_t)x.ring_ent) / ((size_t)CHD_HIST_BITS * x.stride[0]));
-                        Movement mv;
-                        if (mv_merge_selected(x, m.pay, x.rlen_ent + (size_t)id * CHD_HIST_BITS, m.mask, fmask, mv)) (void)mv_write(mv, d);
-                    } else {
-                        // the selected updates, oldest (highest bit) first
-                        const uint32_t *rl = (m.kind == 2 ? x.rlen_cell : x.rlen_ent) +
-                                             ((uintptr_t)m.pay - (uintptr_t)(m.kind == 2 ? x.ring_cell : x.ring_ent)) / x.stride[0];
-                        for (int jj = CHD_HIST_BITS - 1; jj >= 0; jj--) {
-                            if (!((m.mask >> jj) & 1u)) continue;
-                            const uint32_t sl = (x.cur_tick - (uint32_t)jj) & (CHD_HIST_BITS - 1u);
-                            const uint32_t ln = rl[sl];
-                            lane_put_payload(d, m.pay + (size_t)sl * x.stride[0], ln);
-                            d += ln;
-                        }
-                    }
-                }
-                wire_wave_sync();
-                wave_copy_out(stream + lo, img + off0, hi - lo, true);
-                wire_wave_sync();
-                a = b;
-            }
+            wire_put_messages(x, stream, img, live, begin, hl, pl, m, tag, fmask);
         }
+    }
+}
+
+__global__ void __launch_bounds__(256) k_wire_copy(WorldDev w, WireDev x) {
+    __shared__ uint32_t ticket;
+    __shared__ __attribute__((aligned(16))) uint8_t images[4][WIRE_IMG + 48];
+    wire_copy_conn(w, x, blockIdx.x, images, ticket);
+}
+
+// the same over the LIST of connections that have such segments (k_wire_layout_img collects it): a fixed, small grid
+__global__ void __launch_bounds__(256) k_wire_copy_list(WorldDev w, WireDev x) {
+    __shared__ uint32_t ticket;
+    __shared__ __attribute__((aligned(16))) uint8_t images[4][WIRE_IMG + 48];
+    if (!wire_img_fits(w, x)) return;
+    const uint32_t n = min(x.n_dropped[4], w.S);
+    for (uint32_t k = blockIdx.x; k < n; k += gridDim.x) {
+        wire_copy_conn(w, x, x.slow_list[k], images, ticket);
+        __syncthreads();
     }
 }
 
@@ -646,7 +677,7 @@ __global__ void __launch_bounds__(256) k_wire_copy_fast(WorldDev w, WireDev x) {
     __syncthreads();
     for (uint32_t p0 = 0; p0 < cnt; p0 += 256) {
         const uint32_t p = p0 + threadIdx.x;
-        const bool f = p < cnt && x.seg_fast[pbase + p] != 0;
+        const bool f = p < cnt && x.seg_fast[pbase + p] == 1;
         if (f) {
             const uint32_t k = atomicAdd(&nseg, 1u);
             if (k < 512) { seg_n[k] = w.pair_nrec[pbase + p]; seg_rel[k] = w.pair_rel[pbase + p]; }
@@ -956,4 +987,557 @@ void launch_wire_set_payloads(hipStream_t st, WireDev x, int full, int cell, uin
                               const uint32_t *lens, const uint64_t *off, const uint8_t *bytes, uint32_t ring_slot) {
     if (!n) return;
     hipLaunchKernelGGL(k_wire_set_payloads, dim3((n + 3) / 4), dim3(256), 0, st, x, full, cell, n, limit, idx, lens, off, bytes, ring_slot);
+}
+
+
+// ---------------------------------------------------------------------------
+// The wire streams from the fan-out DESCRIPTORS (k_fanout_plan_seg) instead of from the records.
+//
+// A simple subscription's messages are, per due window, "every entity channel of the cell, in column order" (+ the spatial
+// channel's own message in front): the same byte sequence for every subscriber of the cell, apart from where the packet
+// tags fall.  So the bytes are built ONCE per cell and tick — the cell's IMAGE: [own message][entity messages in column
+// order], one image of the update payloads and one of the full states (first fan-outs) — and a connection's stream is a
+// concatenation of image ranges with a 5-byte tag wherever the greedy packet rule (connection.go:626-714) cuts:
+//
+//   k_wire_img_sizes  one workgroup per cell and payload kind: entry size of every message (wire_msg), inclusive prefix
+//                     -> img_end (message boundaries, the packet cuts fall on them), image length
+//   scan              image lengths (16-byte aligned) -> image offsets in the arena
+//   k_wire_img_fill   the image bytes (wire_put_messages: the same routine the record path writes streams with)
+//   k_wire_layout_img one wave per connection walks its subscriptions in stream order — a handful of image ranges per
+//                     subscription instead of ~300 records: packet cuts by a 64-ary search over the cell's message
+//                     boundaries, one 16-byte copy descriptor {dst, src, len} per uncut range, the tags written directly.
+//                     Runs twice: sizes only (stream lengths and descriptor counts -> scans), then emitting.
+//                     Subscriptions without a usable descriptor (the deferred launch's, cells with an oversized message)
+//                     are walked record by record as k_wire_layout does and left to k_wire_copy_list.
+//   k_wire_conn_order the order the connections are copied in: by the cell of their first subscription
+//   k_wire_copy_ends / k_wire_copy_img   the copy: unaligned 16-byte loads from the images (L2 resident: ~8 MB per tick at
+//                     config B), destination-aligned 16-byte stores — the write stream is the only HBM traffic.
+// No host round trip between sizing and writing: the writing kernels check the arenas on the device (wire_img_fits) and
+// chd_wire_build re-runs them after growing one.
+// Worlds with merged updates (per-record payloads) and ticks without descriptors keep the record path above.
+// ---------------------------------------------------------------------------
+#define SDW_NWIN 7u
+#define SDW_FIRST 8u
+#define SDW_NONE 16u
+#define SDW_OWN_SHIFT 8u
+
+__global__ void __launch_bounds__(256) k_wire_img_sizes(DevGrid g, WorldDev w, WireDev x) {
+    __shared__ uint32_t wsum[4];
+    __shared__ uint32_t bad_any;
+    const uint32_t c = blockIdx.x, f = blockIdx.y, tid = threadIdx.x, lane = tid & 63u, wv = tid >> 6;
+    const uint32_t start = w.cell_start[c], n = w.cell_end[c] - start;
+    if (tid == 0) bad_any = 0;
+    // the spatial channel's own message
+    chd_fanout_rec r;
+    r.conn = f << 31;
+    r.channel = c + g.id_start;
+    const WireMsg own = wire_msg(w, x, r, CHD_POS_CELL | c, 0u);
+    uint32_t carry = own.entry;
+    uint32_t bad = own.entry == 0 ? 1u : 0u;  // (dropped by Send: the record path counts it)
+    __syncthreads();
+    for (uint32_t i0 = 0; i0 < n; i0 += 256) {
+        const uint32_t i = i0 + tid;
+        uint32_t entry = 0;
+        if (i < n) {
+            const uint32_t slot = w.ce_slot[start + i];
+            if (slot >= w.N) bad = 1;
+            else {
+                r.channel = w.ce_chan_view[start + i];
+                entry = wire_msg(w, x, r, slot, 0u).entry;
+                if (!entry) bad = 1;
+            }
+        }
+        uint32_t cum = entry;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const uint32_t o = __shfl_up(cum, d);
+            if ((int)lane >= d) cum += o;
+        }
+        if (lane == 63) wsum[wv] = cum;
+        __syncthreads();
+        uint32_t before = 0, total = 0;
+#pragma unroll
+        for (uint32_t k = 0; k < 4; k++) {
+            if (k < wv) before += wsum[k];
+            total += wsum[k];
+        }
+        if (i < n) x.img_end[f][start + i] = carry + before + cum;
+        carry += total;
+        __syncthreads();
+    }
+    if (bad) bad_any = 1;
+    __syncthreads();
+    if (tid == 0) {
+        x.img_own[f][c] = own.entry;
+        x.img_len[f][c] = carry;
+        x.img_bad[f][c] = bad_any;
+        x.img_off[f][c] = (carry + 15u) & ~15u;  // -> exclusive scan
+    }
+}
+
+#define WIRE_FILL_SPLIT 4u
+__global__ void __launch_bounds__(256) k_wire_img_fill(DevGrid g, WorldDev w, WireDev x) {
+    __shared__ __attribute__((aligned(16))) uint8_t images[4][WIRE_IMG + 48];
+    // grid (cell, kind * WIRE_FILL_SPLIT + part): the cell's chunks of 64 messages go round-robin over 4 * WIRE_FILL_SPLIT waves
+    const uint32_t c = blockIdx.x, f = blockIdx.y / WIRE_FILL_SPLIT, part = blockIdx.y % WIRE_FILL_SPLIT, lane = threadIdx.x & 63u;
+    const uint32_t wv = (threadIdx.x >> 6) + 4u * part;
+    if (x.img_bad[f][c]) return;
+    const uint32_t start = w.cell_start[c], n = w.cell_end[c] - start;
+    const uint64_t off = x.img_off[f][c];
+    if (off + x.img_len[f][c] > x.img_cap[f]) return;  // (never: the arena is sized for the worst case; the layout checks the same)
+    uint8_t *stream = x.img[f] + off;
+    uint8_t *img = images[threadIdx.x >> 6];
+    chd_fanout_rec r;
+    r.conn = f << 31;
+    // chunk -1 = the own message (wave 0 starts with it), then the entity messages in chunks of 64, round-robin over the waves
+    for (int32_t ch = (int32_t)wv - 1; ch * 64 < (int32_t)n; ch += 4 * (int32_t)WIRE_FILL_SPLIT) {
+        bool live = false;
+        uint32_t begin = 0, hl = 0, pl = 0;
+        WireMsg m;
+        m.chan = 0; m.any_len = 0; m.body_len = 0; m.mp_len = 0; m.entry = 0; m.pay = nullptr; m.mask = 0; m.value_len = 0; m.kind = 0;
+        if (ch < 0) {
+            if (lane == 0) {
+                r.channel = c + g.id_start;
+                m = wire_msg(w, x, r, CHD_POS_CELL | c, 0u);
+                begin = 0;
+                live = true;
+            }
+        } else {
+            const uint32_t i = (uint32_t)ch * 64u + lane;
+            if (i < n) {
+                r.channel = w.ce_chan_view[start + i];
+                m = wire_msg(w, x, r, w.ce_slot[start + i], 0u);
+                begin = x.img_end[f][start + i] - m.entry;
+                live = true;
+            }
+        }
+        if (live) {
+            hl = wire_hdr_len(x, m, 0u);
+            pl = m.any_len;
+        }
+        wire_put_messages(x, stream, img, live, begin, hl, pl, m, 0u, 0u);
+    }
+}
+
+// number of boundaries E[0..n) (ascending) that are <= T: 64-ary search by the whole wave (uniform arguments and result)
+__device__ __forceinline__ uint32_t wire_count_le(const uint32_t *__restrict__ E, uint32_t n, uint32_t T, uint32_t guess) {
+    const uint32_t lane = threadIdx.x & 63u;
+    uint32_t lo = 0, hi = n;  // E[k] <= T for k < lo, E[k] > T for k >= hi
+    {   // the messages of a cell are nearly equal in size: one probe of 64 consecutive boundaries around a linear guess
+        // usually brackets the answer
+        const uint32_t g0 = guess > 32u ? min(guess - 32u, n > 64u ? n - 64u : 0u) : 0u;
+        const uint32_t idx = g0 + lane;
+        const bool ok = idx < n && E[idx] <= T;
+        const uint32_t mcount = (uint32_t)__popcll(__ballot(ok));
+        const uint32_t span = min(64u, n - g0);
+        if (mcount == 0u) hi = g0;                 // E[g0] > T
+        else if (mcount == span) lo = g0 + span;   // all probed <= T
+        else return g0 + mcount;
+    }
+    while (lo < hi) {
+        const uint32_t step = (hi - lo + 63u) / 64u;
+        const uint32_t idx = lo + lane * step;
+        const bool ok = idx < hi && E[idx] <= T;
+        const uint32_t mcount = (uint32_t)__popcll(__ballot(ok));  // (monotone: the satisfied probes are a prefix)
+        if (!mcount) { hi = lo; break; }
+        const uint32_t nlo = lo + (mcount - 1u) * step + 1u;
+        const uint32_t nhi = min(hi, lo + mcount * step);
+        lo = nlo;
+        hi = nhi;
+    }
+    return lo;
+}
+
+template <bool EMIT>
+__global__ void __launch_bounds__(256) k_wire_layout_img(DevGrid g, WorldDev w, WireDev x) {
+    const uint32_t s = blockIdx.x * 4u + (threadIdx.x >> 6);
+    if (s >= w.S) return;
+    const uint32_t lane = threadIdx.x & 63u;
+    uint64_t pkt_base = 0;  // stream offset of the current packet's tag
+    uint32_t pkt_used = 0;  // bytes of entries in the current packet
+    uint32_t npk = 0, ndropped = 0, any_slow = 0, ndesc = 0, stuck = 0;
+    if (EMIT && !wire_img_fits(w, x)) return;
+    const uint64_t woff = EMIT ? x.conn_woff[s] : 0ull;
+    uint8_t *stream = EMIT ? x.bytes + woff : nullptr;
+    uint4 *dout = EMIT ? x.cdesc + x.rank_ndesc[x.conn_rank[s]] : nullptr;  // (rank_ndesc was scanned in place)
+
+    auto close_packet = [&]() {
+        if (EMIT && lane == 0) {  // the 5-byte tag in front of the packet (connection.go:683-687)
+            uint8_t *t = stream + pkt_base;
+            t[0] = 67; t[1] = 72; t[2] = (uint8_t)(pkt_used >> 8); t[3] = (uint8_t)pkt_used; t[4] = 0;
+        }
+        pkt_base += 5u + pkt_used;
+        npk += 1;
+        pkt_used = 0;
+    };
+    // The descriptors of a connection are contiguous, in stream order (consecutive ranges are adjacent in the stream: the
+    // copy kernel's neighbouring waves fill whole 128-byte lines between them); the CONNECTIONS are ordered by the cell of
+    // their first subscription (conn_rank), so the ~1000 connections being copied at any moment read a few cells' images.
+    auto emit = [&](uint32_t f, uint64_t src, uint32_t len) {
+        if (EMIT && lane == 0) {
+            const uint64_t dst = woff + pkt_base + 5u + pkt_used;
+            dout[ndesc] = make_uint4((uint32_t)dst, (uint32_t)(dst >> 32), (uint32_t)src | (f << 31), len);
+        }
+        ndesc += 1;
+        pkt_used += len;
+    };
+    // bytes [a, b) of cell c's image f (off / own = image offset / own-message bytes; E = the entity messages' ends)
+    auto piece = [&](uint32_t f, uint32_t off, uint32_t own, const uint32_t *__restrict__ E, uint32_t n, uint32_t a, uint32_t b, uint32_t ilen) {
+        while (a < b) {
+            const uint32_t room = WIRE_MAX_PACKET - pkt_used;
+            if (b - a <= room) {
+                emit(f, (uint64_t)off + a, b - a);
+                break;
+            }
+            const uint32_t T = a + room;
+            uint32_t e = a;
+            if (a < own && own <= T) e = own;
+            if (own <= T && n) {
+                // (E[k] ~ own + (k + 1) * average entry)
+                const uint32_t avg = max((ilen - own) / n, 1u);
+                const uint32_t cnt = wire_count_le(E, n, T, T > own ? (T - own) / avg : 0u);
+                if (cnt) {
+                    const uint32_t ec = E[cnt - 1u];
+                    if (ec > e && ec <= b) e = ec;
+                }
+            }
+            if (e > a) emit(f, (uint64_t)off + a, e - a);
+            if (!pkt_used) {  // (an entry is at most 65533 bytes: it fits an empty packet)
+                stuck = 1;
+                break;
+            }
+            close_packet();
+            a = e;
+        }
+    };
+
+    const bool served = w.sub_alive[s] && w.rec_ub[s + 1] <= w.recs_cap;
+    if (served) {
+        const uint32_t cnt = w.pair_cnt[s];
+        const size_t pbase = (size_t)s * w.capq;
+        const uint64_t rbase = w.rec_ub[s];
+        const uint32_t ns = w.n_simple[s];
+        uint32_t kd = 0;  // next descriptor of the connection (they ascend with the subscription index)
+        for (uint32_t p0 = 0; p0 < cnt; p0 += 64) {
+            const uint32_t p = p0 + lane;
+            const uint32_t nrec = p < cnt ? w.pair_nrec[pbase + p] : 0u;
+            const uint32_t rel = p < cnt ? w.pair_rel[pbase + p] : 0u;
+            // which subscriptions of this round have a descriptor
+            unsigned long long mbit = 0;
+            if (kd + lane < ns) {
+                const uint32_t pj = w.seg_desc2[pbase + kd + lane].y;
+                if (pj >= p0 && pj < p0 + 64u) mbit = 1ull << (pj - p0);
+            }
+#pragma unroll
+            for (int d = 32; d >= 1; d >>= 1) mbit |= __shfl_xor(mbit, d);
+            const bool simple = (mbit >> lane) & 1ull;
+            const uint32_t myk = kd + (uint32_t)__popcll(mbit & ((1ull << lane) - 1ull));
+            kd += (uint32_t)__popcll(mbit);
+            uint32_t info = 0, c = 0, csz = 0, cst = 0;
+            uint32_t off0 = 0, len0 = 0, own0 = 0, off1 = 0, len1 = 0, own1 = 0;
+            bool usable = false;
+            if (simple && nrec) {
+                const uint4 d = w.seg_desc[pbase + myk];
+                c = w.seg_desc2[pbase + myk].x;
+                info = d.w;
+                cst = w.cell_start[c];
+                csz = w.cell_end[c] - cst;
+                usable = d.y == cst && d.z == csz && d.x == rel;
+                const uint32_t f1 = (info & SDW_FIRST) ? 1u : 0u, f0 = (info & SDW_NWIN) ? 1u : 0u;
+                if (f0) {
+                    if (x.img_bad[0][c] || !x.img_ok[0]) usable = false;
+                    off0 = x.img_off[0][c]; len0 = x.img_len[0][c]; own0 = x.img_own[0][c];
+                    if ((uint64_t)off0 + len0 > x.img_cap[0]) usable = false;
+                }
+                if (f1) {
+                    if (x.img_bad[1][c] || !x.img_ok[1]) usable = false;
+                    off1 = x.img_off[1][c]; len1 = x.img_len[1][c]; own1 = x.img_own[1][c];
+                    if ((uint64_t)off1 + len1 > x.img_cap[1]) usable = false;
+                }
+            }
+            for (uint64_t act = __ballot(nrec != 0); act; act &= act - 1) {
+                const int L = __ffsll((unsigned long long)act) - 1;
+                if (__builtin_amdgcn_readlane((int)usable, L)) {
+                    const uint32_t infoL = (uint32_t)__builtin_amdgcn_readlane((int)info, L);
+                    const uint32_t cstL = (uint32_t)__builtin_amdgcn_readlane((int)cst, L), cszL = (uint32_t)__builtin_amdgcn_readlane((int)csz, L);
+                    if (infoL & SDW_FIRST)
+                        piece(1u, (uint32_t)__builtin_amdgcn_readlane((int)off1, L), (uint32_t)__builtin_amdgcn_readlane((int)own1, L), x.img_end[1] + cstL, cszL, 0u, (uint32_t)__builtin_amdgcn_readlane((int)len1, L), (uint32_t)__builtin_amdgcn_readlane((int)len1, L));
+                    const uint32_t nw = infoL & SDW_NWIN;
+                    if (nw) {
+                        const uint32_t o0 = (uint32_t)__builtin_amdgcn_readlane((int)off0, L), ow = (uint32_t)__builtin_amdgcn_readlane((int)own0, L), ln = (uint32_t)__builtin_amdgcn_readlane((int)len0, L);
+                        for (uint32_t j = 0; j < nw; j++) {
+                            const uint32_t a = ((infoL >> (SDW_OWN_SHIFT + j)) & 1u) ? 0u : ow;
+                            const uint32_t b = (infoL & SDW_NONE) ? ow : ln;
+                            piece(0u, o0, ow, x.img_end[0] + cstL, cszL, a, b, ln);
+                        }
+                    }
+                    if (EMIT && lane == 0) x.seg_fast[pbase + p0 + (uint32_t)L] = 2;  // (neither record-path copy kernel takes it)
+                    continue;
+                }
+                // ---- record by record (k_wire_layout's walk; the tags are written here, so rec_wtag carries no packet length) ----
+                const uint32_t n = (uint32_t)__builtin_amdgcn_readlane((int)nrec, L);
+                const uint64_t seg = rbase + (uint32_t)__builtin_amdgcn_readlane((int)rel, L);
+                const uint32_t fmask = x.schema ? (w.pair_flags[pbase + p0 + (uint32_t)L] >> PF_FIELD_MASK_SHIFT) & 0xFFu : 0u;
+                any_slow = 1;
+                if (EMIT && lane == 0) x.seg_fast[pbase + p0 + (uint32_t)L] = 0;
+                for (uint32_t i0 = 0; i0 < n; i0 += 64) {
+                    const uint32_t i = i0 + lane;
+                    const bool valid = i < n;
+                    uint32_t entry = 0, alen = 0;
+                    if (valid) {
+                        uint32_t pos = w.rec_pos[seg + i];
+                        if ((pos & CHD_POS_CELL) ? (pos & ~CHD_POS_CELL) >= x.ncell : pos >= x.npos) {
+                            if (EMIT) atomicAdd(x.n_dropped + 1, 1u);
+                            pos = CHD_POS_CELL;
+                        }
+                        uint32_t idc = (pos & CHD_POS_CELL) ? pos : w.ce_slot[pos];
+                        if (!(idc & CHD_POS_CELL) && idc >= w.N) {
+                            if (EMIT) atomicAdd(x.n_dropped + 2, 1u);
+                            idc = CHD_POS_CELL;
+                        }
+                        const WireMsg m = wire_msg(w, x, w.recs[seg + i], idc, w.rec_mask ? w.rec_mask[seg + i] : 0u, fmask);
+                        if (EMIT) w.rec_pos[seg + i] = idc;  // (k_wire_copy reads the resolved word; the sizing pass must leave it alone)
+                        entry = m.entry;
+                        alen = m.any_len;
+                    }
+                    if (EMIT && valid && entry == 0) x.rec_woff[seg + i] = 0xFFFFFFFFu;  // dropped
+                    ndropped += (uint32_t)__popcll(__ballot(valid && entry == 0));
+                    uint32_t cum = entry;
+#pragma unroll
+                    for (int d = 1; d < 64; d <<= 1) {
+                        const uint32_t o = __shfl_up(cum, d);
+                        if ((int)lane >= d) cum += o;
+                    }
+                    uint32_t start_lane = 0, cum_before_start = 0;
+                    for (;;) {
+                        const uint32_t relb = pkt_used + (cum - cum_before_start);
+                        const bool mine = valid && lane >= start_lane;
+                        const uint64_t over = __ballot(mine && entry != 0 && relb > WIRE_MAX_PACKET);
+                        const uint32_t fo = over ? (uint32_t)__ffsll((unsigned long long)over) - 1u : 64u;
+                        if (EMIT && mine && lane < fo && entry != 0) {
+                            x.rec_woff[seg + i] = (uint32_t)(pkt_base + 5u + relb - entry);
+                            x.rec_wtag[seg + i] = alen;
+                        }
+                        const uint32_t cum_f = fo < 64 ? __shfl(cum - entry, (int)fo) : __shfl(cum, 63);
+                        pkt_used += cum_f - cum_before_start;
+                        if (fo == 64) break;
+                        close_packet();
+                        start_lane = fo;
+                        cum_before_start = cum_f;
+                    }
+                }
+            }
+        }
+        if (pkt_used) close_packet();
+    }
+    if (lane == 0) {
+        if (!EMIT) {
+            x.conn_wlen[s] = pkt_base;
+            x.conn_ndesc[s] = ndesc;
+            // place among the connections: by the cell of the first subscription, arrival order inside a cell
+            const uint32_t key = (served && w.pair_cnt[s]) ? w.pair_cell[(size_t)s * w.capq] : 0u;
+            x.conn_key[s] = key;
+            x.conn_rank[s] = atomicAdd(&x.cell_dcnt[(size_t)key * x.dpad], 1u);  // (-> k_wire_conn_order adds the cell's base)
+            x.conn_npk[s] = npk;
+            x.conn_slow[s] = (uint8_t)any_slow;
+            if (any_slow) x.slow_list[atomicAdd(x.n_dropped + 4, 1u)] = s;
+            if (ndropped) atomicAdd(x.n_dropped, ndropped);
+            if (stuck) atomicAdd(x.n_dropped + 6, 1u);
+        }
+    }
+}
+
+typedef uint32_t wu32x4u __attribute__((ext_vector_type(4), aligned(1)));
+
+// The copy: persistent workgroups take tickets of WIRE_CP_BATCH consecutive descriptors (half a connection's stream: ranges
+// that are adjacent in the stream are written close in time, so the 128-byte lines they share leave L2 whole).  It reads
+// as many bytes as it writes, and the reads should stay in L2: what was measured at config B (5.03 GB per build, whole
+// build incl. layout): connections in slot order 1.87 ms — the 2048 waves read all ~8 MB of images at once; every read
+// confined to a 1 MB window (wrong bytes, a bound) 1.34 ms; cells split over the XCDs' L2s by HW_REG_XCC_ID 1.74 ms;
+// descriptors sorted by CELL (one or two images live at a time, but the stream written in 18 KB pieces scattered in time:
+// partial lines) 1.63 ms; connections ordered by the cell of their first subscription (conn_rank) 1.51 ms — what is built.
+// k_wire_copy_ends writes the up to 15 bytes in front of and behind the 16-byte aligned body of every range;
+// k_wire_copy_img moves the bodies.
+#define WIRE_CP_BATCH 16u
+
+struct CpRange { const uint8_t *sp; uint8_t *dp; uint32_t nvec; };
+
+__device__ __forceinline__ CpRange cp_range(const WireDev &x, uint4 d, uint32_t srcmask) {
+    uint8_t *dst = x.bytes + (((uint64_t)d.y << 32) | d.x);
+    const uint8_t *src = x.img[d.z >> 31] + (d.z & 0x7FFFFFFFu & srcmask);
+    const uint32_t head = min((16u - (uint32_t)((uintptr_t)dst & 15u)) & 15u, d.w);
+    CpRange r;
+    r.sp = src + head;
+    r.dp = dst + head;
+    r.nvec = (d.w - head) >> 4;
+    return r;
+}
+
+__global__ void __launch_bounds__(256) k_wire_copy_ends(WorldDev w, WireDev x, uint32_t srcmask) {
+    if (!wire_img_fits(w, x)) return;
+    const uint32_t ndesc = x.rank_ndesc[w.S];
+    for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < ndesc; i += gridDim.x * 256u) {
+    const uint4 d = x.cdesc[i];
+    uint8_t *dst = x.bytes + (((uint64_t)d.y << 32) | d.x);
+    const uint8_t *src = x.img[d.z >> 31] + (d.z & 0x7FFFFFFFu & srcmask);
+    const uint32_t len = d.w;
+    const uint32_t head = min((16u - (uint32_t)((uintptr_t)dst & 15u)) & 15u, len);
+    const uint32_t done = head + (((len - head) >> 4) << 4);
+    for (uint32_t k = 0; k < head; k++) dst[k] = src[k];
+    for (uint32_t k = done; k < len; k++) dst[k] = src[k];
+    }
+}
+
+// k_wire_copy_img: workgroups of two LOADER and two STORER waves around double-buffered LDS tiles.  gfx950's vm counter is
+// in-order — a wave that waits for a load also waits for every store it issued before (~3.5 us while the chip streams) — so
+// the waves that store never load: loader p reads piece after piece (CPW_K 16-byte vectors per lane, unaligned: the body is
+// aligned to the DESTINATION) from the images into its tile, storer p drains the tile of the phase before into the stream
+// with aligned 16-byte stores that nothing ever waits for.  One LDS-only barrier per phase (lds_barrier: __syncthreads()
+// would wait for the stores).  All four waves walk the same sequence of pieces — the bodies of the ticket's ranges, cut
+// into pieces of at most 64 * CPW_K vectors — from the descriptors each holds in its registers.
+// (A single-wave version with counted s_waitcnt around inline-asm loads was dropped: the register allocator copied
+// in-flight registers across the branches that chose the count.)
+#ifndef CPW_K
+#define CPW_K 4u
+#endif
+#define CPW_PIECE (64u * CPW_K)
+
+__device__ __forceinline__ void cpw_lds_barrier() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+}
+
+struct CpStream {  // the ticket's pieces in order: uniform per wave
+    uint4 dl;
+    uint64_t todo;
+    CpRange r;
+    uint32_t v;     // next vector of r
+    bool open;
+};
+
+__device__ __forceinline__ bool cpw_next(const WireDev &x, CpStream &st, uint32_t srcmask, const uint8_t *&sp, uint8_t *&dp, uint32_t &nv) {
+    if (!st.open || st.v >= st.r.nvec) {
+        if (!st.todo) { st.open = false; return false; }
+        const int L = __ffsll((unsigned long long)st.todo) - 1;
+        st.todo &= st.todo - 1;
+        uint4 d;
+        d.x = (uint32_t)__builtin_amdgcn_readlane((int)st.dl.x, L); d.y = (uint32_t)__builtin_amdgcn_readlane((int)st.dl.y, L);
+        d.z = (uint32_t)__builtin_amdgcn_readlane((int)st.dl.z, L); d.w = (uint32_t)__builtin_amdgcn_readlane((int)st.dl.w, L);
+        st.r = cp_range(x, d, srcmask);
+        st.v = 0;
+        st.open = true;
+    }
+    sp = st.r.sp + 16u * (size_t)st.v;
+    dp = st.r.dp + 16u * (size_t)st.v;
+    nv = min(st.r.nvec - st.v, CPW_PIECE);
+    st.v += CPW_PIECE;
+    return true;
+}
+
+template <bool NT>
+__global__ void __launch_bounds__(256) k_wire_copy_img(WorldDev w, WireDev x, uint32_t srcmask) {
+    __shared__ wu32x4 tile[2][2][CPW_PIECE];
+    __shared__ uint32_t ticket_s;
+    if (!wire_img_fits(w, x)) return;
+    const uint32_t ndesc = x.rank_ndesc[w.S];
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t wv = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), pair = wv & 1u;  // (scalar: the roles are separate code paths)
+    const bool storer = wv >= 2u;
+    for (;;) {
+        if (threadIdx.x == 0) ticket_s = atomicAdd(x.cp_ticket, 1u);
+        cpw_lds_barrier();
+        const uint32_t i0 = ticket_s * WIRE_CP_BATCH;
+        cpw_lds_barrier();  // (everyone has read the ticket before thread 0 takes the next one)
+        if (i0 >= ndesc) break;
+        CpStream st;
+        st.dl = make_uint4(0u, 0u, 0u, 0u);
+        const bool have = lane < WIRE_CP_BATCH && i0 + lane < ndesc;
+        if (have) st.dl = x.cdesc[i0 + lane];
+        const uint32_t my_nvec = have ? cp_range(x, st.dl, srcmask).nvec : 0u;
+        st.todo = __ballot(my_nvec != 0u);
+        st.open = false;
+        st.v = 0;
+        uint32_t np = (my_nvec + CPW_PIECE - 1u) / CPW_PIECE;  // pieces of the ticket
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) np += (uint32_t)__shfl_xor((int)np, d);
+        const uint32_t fills = (np + 1u) / 2u;
+        // phase ph < fills: the loaders fill tile[ph & 1] with pieces 2 ph (pair 0) and 2 ph + 1 (pair 1);
+        // phase ph >= 1:   the storers drain tile[(ph - 1) & 1].  One barrier per phase, fills + 1 phases.
+        for (uint32_t ph = 0; ph <= fills; ph++) {
+            const bool work = storer ? ph >= 1u : ph < fills;
+            if (work) {
+                const uint8_t *sp = nullptr, *sp2 = nullptr;
+                uint8_t *dp = nullptr, *dp2 = nullptr;
+                uint32_t nv = 0, nv2 = 0;
+                const bool a = cpw_next(x, st, srcmask, sp, dp, nv);
+                const bool b2 = a && cpw_next(x, st, srcmask, sp2, dp2, nv2);
+                if (pair) { sp = sp2; dp = dp2; nv = b2 ? nv2 : 0u; }
+                else if (!a) nv = 0u;
+                wu32x4 q[CPW_K];
+                if (nv) {  // (uniform)
+                    if (!storer) {
+                        // unconditional loads: a lane beyond the piece repeats its last vector (in bounds, into its own tile slot)
+#pragma unroll
+                        for (uint32_t k = 0; k < CPW_K; k++) q[k] = *(const wu32x4u *)(const void *)(sp + 16u * (size_t)min(lane + 64u * k, nv - 1u));
+#pragma unroll
+                        for (uint32_t k = 0; k < CPW_K; k++) tile[ph & 1u][pair][lane + 64u * k] = q[k];
+                    } else {
+#pragma unroll
+                        for (uint32_t k = 0; k < CPW_K; k++) q[k] = tile[(ph - 1u) & 1u][pair][lane + 64u * k];
+#pragma unroll
+                        for (uint32_t k = 0; k < CPW_K; k++)
+                            if (lane + 64u * k < nv) {
+                                if (NT) __builtin_nontemporal_store(q[k], (wu32x4 *)(void *)(dp + 16u * (size_t)(lane + 64u * k)));
+                                else *(wu32x4 *)(void *)(dp + 16u * (size_t)(lane + 64u * k)) = q[k];
+                            }
+                    }
+                }
+            }
+            cpw_lds_barrier();
+        }
+    }
+}
+
+// rank of every connection in the copy order (cell_dcnt: connections per first cell, scanned) and its descriptor count there
+__global__ void __launch_bounds__(256) k_wire_conn_order(WireDev x, uint32_t S) {
+    const uint32_t s = blockIdx.x * 256u + threadIdx.x;
+    if (s >= S) return;
+    const uint32_t r = x.cell_dcnt[(size_t)x.conn_key[s] * x.dpad] + x.conn_rank[s];
+    x.conn_rank[s] = r;
+    x.rank_ndesc[r] = x.conn_ndesc[s];
+}
+
+void launch_wire_conn_order(hipStream_t st, WorldDev w, WireDev x) {
+    if (!w.S) return;
+    launch_scan_u32_inplace(st, x.cell_dcnt, x.ncell * x.dpad);
+    hipLaunchKernelGGL(k_wire_conn_order, dim3((w.S + 255u) / 256u), dim3(256), 0, st, x, w.S);
+    launch_scan_u32_inplace(st, x.rank_ndesc, w.S);
+}
+
+void launch_wire_images(hipStream_t st, DevGrid g, WorldDev w, WireDev x) {
+    if (!g.ncell) return;
+    hipLaunchKernelGGL(k_wire_img_sizes, dim3(g.ncell, 2), dim3(256), 0, st, g, w, x);
+    launch_scan_u32_inplace(st, x.img_off[0], g.ncell);
+    launch_scan_u32_inplace(st, x.img_off[1], g.ncell);
+    hipLaunchKernelGGL(k_wire_img_fill, dim3(g.ncell, 2 * WIRE_FILL_SPLIT), dim3(256), 0, st, g, w, x);
+}
+
+void launch_wire_layout_img(hipStream_t st, DevGrid g, WorldDev w, WireDev x, bool emit) {
+    if (!w.S) return;
+    if (emit) hipLaunchKernelGGL(k_wire_layout_img<true>, dim3((w.S + 3) / 4), dim3(256), 0, st, g, w, x);
+    else hipLaunchKernelGGL(k_wire_layout_img<false>, dim3((w.S + 3) / 4), dim3(256), 0, st, g, w, x);
+}
+
+void launch_wire_copy_img(hipStream_t st, WorldDev w, WireDev x, uint32_t waves) {
+    static const uint32_t mult = [] { const char *e = getenv("CHD_WIRE_COPY_WAVES"); return e ? (uint32_t)atoi(e) : 2u; }();  // x 8 waves per CU
+    waves *= mult ? mult : 1u;
+    static const uint32_t srcmask = [] { const char *e = getenv("CHD_WIRE_COPY_SRCMASK"); return e ? (uint32_t)strtoul(e, nullptr, 0) : 0xFFFFFFFFu; }();  // (timing experiments only)
+    static const bool nt = [] { const char *e = getenv("CHD_WIRE_COPY_NT"); return e && e[0] == '1'; }();
+    // (everything sized on the device: the descriptor count and the list of record-path connections are not known to the host yet)
+    hipLaunchKernelGGL(k_wire_copy_ends, dim3(2048), dim3(256), 0, st, w, x, srcmask);
+    const uint32_t wgs = waves / 4u ? waves / 4u : 1u;  // (four waves each)
+    if (nt) hipLaunchKernelGGL(k_wire_copy_img<true>, dim3(wgs), dim3(256), 0, st, w, x, srcmask);
+    else hipLaunchKernelGGL(k_wire_copy_img<false>, dim3(wgs), dim3(256), 0, st, w, x, srcmask);
+    hipLaunchKernelGGL(k_wire_copy_list, dim3(512), dim3(256), 0, st, w, x);
 }

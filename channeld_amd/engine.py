@@ -477,6 +477,12 @@ class SpatialWorld:
         _lib.check(self.ctx, self.lib.chd_wire_build(self.ctx, C.byref(tb), C.byref(tp), C.byref(dr)))
         return tb.value, tp.value, dr.value
 
+    def wire_build_info(self):
+        """(image ranges copied, connections with a subscription walked record by record) of the last wire_build."""
+        nr, nc = C.c_uint64(0), C.c_uint32(0)
+        _lib.check(self.ctx, self.lib.chd_wire_build_info(self.ctx, C.byref(nr), C.byref(nc)))
+        return nr.value, nc.value
+
     def wire_fetch(self, want_bytes: bool = True):
         off = np.zeros(self.S + 1, dtype=np.uint64)
         npk = np.zeros(self.S, dtype=np.uint32)

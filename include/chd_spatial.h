@@ -711,6 +711,13 @@ int chd_handover_messages(chd_ctx *ctx, uint32_t n_handovers, uint32_t *offsets,
  * device (chd_wire_fetch copies them out); *total_bytes, *total_packets, *dropped are optional. */
 int chd_wire_build(chd_ctx *ctx, uint64_t *total_bytes, uint64_t *total_packets, uint32_t *dropped);
 
+/* How the last chd_wire_build produced its streams (diagnostics; no reference counterpart).  On ticks that took the
+ * descriptor path of the fan-out the streams are concatenations of per-cell message IMAGES (every subscriber of a cell gets
+ * the same bytes apart from where the packet tags fall): *n_image_ranges = ranges copied from the images (0: the streams
+ * were built record by record), *n_record_path_connections = connections with at least one subscription that was still
+ * walked record by record (per-entity decisions, merged updates, a message Send drops). */
+int chd_wire_build_info(chd_ctx *ctx, uint64_t *n_image_ranges, uint32_t *n_record_path_connections);
+
 /* conn_off[s] .. conn_off[s+1] = connection slot s's stream inside bytes (max_subscribers+1
  * offsets); conn_packets[s] = its number of packets.  bytes may be NULL (offsets only). */
 int chd_wire_fetch(chd_ctx *ctx, uint64_t *conn_off, uint32_t *conn_packets, uint8_t *bytes, uint64_t cap);

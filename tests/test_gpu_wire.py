@@ -17,7 +17,8 @@ from oracle import wire
 
 pytestmark = pytest.mark.gpu
 
-WIRE, CELL_MAJOR, CONN_MAJOR = 8, 2, 1
+WIRE, CELL_MAJOR, CONN_MAJOR, ONE_WAVE = 8, 2, 1, 64
+DESC = CONN_MAJOR | ONE_WAVE  # the fan-out's descriptor path: the streams are assembled from per-cell message images
 ENT_UPD, ENT_FULL, CELL_UPD, CELL_FULL = 0, 1, 2, 3
 
 
@@ -54,6 +55,7 @@ def run_wire(amd, cfg_name, N, S, ticks, seed, flags, upd_len, full_len, max_upd
     w.wire_set_payloads(CELL_UPD, list(cell[0]), list(cell[0].values()))
     w.wire_set_payloads(CELL_FULL, list(cell[1]), list(cell[1].values()))
     total_bytes = total_packets = total_dropped = 0
+    run_wire.image_ranges = run_wire.record_path_conns = 0
     for k in range(ticks):
         sw.step()
         # this tick's merged update of every entity, as the host would marshal it
@@ -64,6 +66,9 @@ def run_wire(amd, cfg_name, N, S, ticks, seed, flags, upd_len, full_len, max_upd
         res = w.tick(sw.now_ns(), upd_x=sw.x, upd_z=sw.z, queries=sw.queries(), cell_upd_channel=cu,
                      cell_upd_sender=np.full(3, 5, dtype=np.uint32), records_cap=1 << 22)
         nbytes, npackets, ndropped = w.wire_build()
+        nr, nc = w.wire_build_info()
+        run_wire.image_ranges += nr
+        run_wire.record_path_conns += nc
         off, npk, data = w.wire_fetch()
         assert int(off[S]) == nbytes == len(data) and int(npk.sum()) == npackets
         dropped = 0
@@ -88,33 +93,55 @@ def run_wire(amd, cfg_name, N, S, ticks, seed, flags, upd_len, full_len, max_upd
     return total_bytes, total_packets, total_dropped
 
 
-@pytest.mark.parametrize("mode", [CONN_MAJOR, CELL_MAJOR])
+@pytest.mark.parametrize("mode", [CONN_MAJOR, CELL_MAJOR, DESC])
 def test_wire_streams_small_world(amd, mode):
     rng = np.random.default_rng(1)
     tb, tp, td = run_wire(amd, "spatial_static_2x2.json", 300, 24, 6, 0xC0FFEE41, mode,
                           upd_len=lambda: rng.integers(0, 100), full_len=lambda: rng.integers(40, 300))
     assert tb > 100_000 and tp >= 24 and td == 0
+    assert (run_wire.image_ranges > 0) == (mode == DESC)
 
 
-def test_wire_many_packets_per_connection(amd):
+def test_wire_streams_from_cell_images_match_the_record_path(amd, monkeypatch):
+    """The descriptor-driven builder (per-cell message images + copy ranges, k_wire_layout_img) against the oracle on a
+    world with every kind of subscription: first fan-outs (full states), 20 / 50 / 100 ms windows (one to three windows per
+    fan-out, the spatial channels' own updates in front), cells of a few hundred entities so that a piece is cut by several
+    packets, and the subscriptions the fan-out defers (record path) in the same streams."""
+    rng = np.random.default_rng(7)
+    tb, tp, td = run_wire(amd, "spatial_static_4x4.json", 2400, 32, 6, 0xC0FFEE47, DESC, tick_ms=33,
+                          upd_len=lambda: rng.integers(20, 120), full_len=lambda: rng.integers(100, 600), max_full=600)
+    assert run_wire.image_ranges > 1000 and td == 0
+    ranges = run_wire.image_ranges
+    # the same world through the record path: same bytes (both equal the oracle), no image ranges
+    monkeypatch.setenv("CHD_WIRE_IMAGES", "0")
+    rng = np.random.default_rng(7)
+    tb2, tp2, td2 = run_wire(amd, "spatial_static_4x4.json", 2400, 32, 6, 0xC0FFEE47, DESC, tick_ms=33,
+                             upd_len=lambda: rng.integers(20, 120), full_len=lambda: rng.integers(100, 600), max_full=600)
+    assert (tb2, tp2, td2) == (tb, tp, td) and run_wire.image_ranges == 0 and ranges > 0
+
+
+@pytest.mark.parametrize("mode", [CONN_MAJOR, DESC])
+def test_wire_many_packets_per_connection(amd, mode):
     # ~30 KB full states: a first fan-out of a few dozen channels spans many packets
     rng = np.random.default_rng(2)
-    tb, tp, td = run_wire(amd, "spatial_static_2x2.json", 120, 6, 4, 0xC0FFEE42, CONN_MAJOR, max_full=30000,
+    tb, tp, td = run_wire(amd, "spatial_static_2x2.json", 120, 6, 4, 0xC0FFEE42, mode, max_full=30000,
                           upd_len=lambda: rng.integers(10, 90), full_len=lambda: rng.integers(15000, 30000))
     assert tp > 60 and td == 0
 
 
-def test_wire_oversized_messages_are_dropped_like_send_does(amd):
+@pytest.mark.parametrize("mode", [CONN_MAJOR, DESC])
+def test_wire_oversized_messages_are_dropped_like_send_does(amd, mode):
     rng = np.random.default_rng(3)
-    tb, tp, td = run_wire(amd, "spatial_static_2x2.json", 40, 4, 3, 0xC0FFEE43, CONN_MAJOR, max_full=66000,
+    tb, tp, td = run_wire(amd, "spatial_static_2x2.json", 40, 4, 3, 0xC0FFEE43, mode, max_full=66000,
                           upd_len=lambda: rng.integers(10, 60), full_len=lambda: rng.choice([200, 65600]))
     assert td > 0
 
 
-def test_wire_benchmark_grid_position_updates(amd):
+@pytest.mark.parametrize("mode", [CONN_MAJOR, DESC])
+def test_wire_benchmark_grid_position_updates(amd, mode):
     # the minimal position update of SURVEY a14: a 21-byte value inside a 66-byte Any
     rng = np.random.default_rng(4)
-    tb, tp, td = run_wire(amd, "spatial_static_benchmark.json", 3000, 60, 5, 0xC0FFEE44, CONN_MAJOR,
+    tb, tp, td = run_wire(amd, "spatial_static_benchmark.json", 3000, 60, 5, 0xC0FFEE44, mode,
                           upd_len=lambda: 66, full_len=lambda: rng.integers(100, 400))
     assert tb > 1_000_000 and td == 0
 
