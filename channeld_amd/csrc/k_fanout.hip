@@ -1037,13 +1037,18 @@ __global__ void __launch_bounds__(64 * FO_WAVES) k_fanout_plan_seg(DevGrid g, Wo
         }
         // descriptor slots of this round: exclusive prefix over the lanes; a connection's row holds capq descriptors — a
         // subscription that would not fit goes to the deferred launch instead (never seen: ~20 subscriptions per connection)
-        uint32_t dinc = simple ? nd : 0u;
+        uint32_t dbase;
+        if (w.wcol_on) {  // (uniform) a subscription may take several descriptors
+            uint32_t dinc = simple ? nd : 0u;
 #pragma unroll
-        for (int d = 1; d < 64; d <<= 1) {
-            const uint32_t o = (uint32_t)__shfl_up((int)dinc, d);
-            if ((int)lane >= d) dinc += o;
+            for (int d = 1; d < 64; d <<= 1) {
+                const uint32_t o = (uint32_t)__shfl_up((int)dinc, d);
+                if ((int)lane >= d) dinc += o;
+            }
+            dbase = n_simple + dinc - (simple ? nd : 0u);
+        } else {          // one each: the rank among the simple lanes
+            dbase = n_simple + mask_rank(__ballot(simple));
         }
-        const uint32_t dbase = n_simple + dinc - (simple ? nd : 0u);
         if (simple && dbase + nd > w.capq) simple = false;
         if (due && !simple) w.pair_flags[pbase + p] = fl | PF_DEFER;
         if (due && simple) ub = count;
@@ -1087,10 +1092,12 @@ __global__ void __launch_bounds__(64 * FO_WAVES) k_fanout_plan_seg(DevGrid g, Wo
             }
             rec_simple += count;
         }
-        {
+        if (w.wcol_on) {
             uint32_t tot = (due && simple) ? nd : 0u;
             for (int d = 32; d >= 1; d >>= 1) tot += (uint32_t)__shfl_xor((int)tot, d);
             n_simple += tot;
+        } else {
+            n_simple += (uint32_t)__popcll(__ballot(due && simple));
         }
     }
     for (int d = 32; d >= 1; d >>= 1) rec_simple += __shfl_xor(rec_simple, d);
