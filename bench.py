@@ -54,7 +54,7 @@ def parse():
                          "difference; `verified_ticks` in the line.  Default 2 when N > 1")
     ap.add_argument("--max-records", type=int, default=0, help="fan-out record capacity per rank (0 = half of the free HBM; ranks sharing a GPU need a number)")
     ap.add_argument("--latency-steps", type=int, default=200, help="extra synchronous ticks for p50/p99 (SURVEY 8d: >= 200), independent of --steps")
-    ap.add_argument("--e2e-ticks", type=int, default=3,
+    ap.add_argument("--e2e-ticks", type=int, default=5,
                     help="after the timed region, also time this many ticks END TO END as a Go host would see them: (i) chd_tick with "
                          "host buffers (H2D of the inputs, dense per-connection pack, D2H of every record), (ii) chd_tick_device + "
                          "chd_wire_build (the per-connection packet streams, SURVEY 8f-1) on a second world; 0 = skip")
