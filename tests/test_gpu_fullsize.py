@@ -342,3 +342,62 @@ def test_config_b_segments_expand_to_the_device_digest(amd):
     # steady state: three orders of magnitude fewer bytes than the expanded records
     cnt, nbytes = compact[-1]
     assert cnt > 50_000_000 and nbytes < 8 * cnt / 50, compact
+
+
+def test_config_b_wire_streams_from_images_equal_the_record_path(amd, monkeypatch):
+    """SURVEY 8f-1 at full size: the packet streams of config B's ticks (5 - 8 GB each) built from the fan-out descriptors
+    (per-cell message images + copy ranges, k_wire_layout_img) equal, byte for byte, the streams the record path builds for
+    the same ticks (k_wire_layout + copy kernels, CHD_WIRE_IMAGES=0) — and the record path is what tests/test_gpu_wire.py
+    pins to the wire oracle.  Payload lengths vary per channel (20 - 120 bytes, full states 100 - 400) so that message
+    boundaries, packet cuts and the 16-byte alignment of every copied range differ from connection to connection."""
+    N, S, WIRE = 100_000, 10_000, 8
+    cfg = synth.load_config("spatial_static_benchmark.json")
+    rng = np.random.default_rng(0xB17E5)
+    upd_len = rng.integers(20, 121, N)
+    full_len = rng.integers(100, 401, N)
+    blob = rng.integers(0, 256, 400, dtype=np.uint8).tobytes() * 2
+    ncell = int(cfg["GridCols"]) * int(cfg["GridRows"])
+
+    def make(images):
+        if images:
+            monkeypatch.delenv("CHD_WIRE_IMAGES", raising=False)
+        else:
+            monkeypatch.setenv("CHD_WIRE_IMAGES", "0")
+        sw = synth.SynthWorld(synth.WorldSpec(cfg, N, S, 0xC0FFEE51))
+        ctl = amd.StaticGrid2DSpatialController()
+        assert ctl.LoadConfig(json.dumps(cfg).encode(), strict=False) is None
+        w = amd.SpatialWorld(ctl, N, S, flags=WIRE, max_records=400_000_000, wire_max_update_len=128, wire_max_full_len=400)
+        w.spawn(None, sw.chan_id, sw.x, sw.z, sw.flags, sw.sender)
+        w.add_subscribers(None, sw.sub_conn)
+        w.wire_set_payloads(0, np.arange(N), [blob[i % 37: i % 37 + int(upd_len[i])] for i in range(N)])
+        w.wire_set_payloads(1, np.arange(N), [blob[i % 41: i % 41 + int(full_len[i])] for i in range(N)])
+        w.wire_set_payloads(2, 0x10000 + np.arange(ncell), [blob[c % 29: c % 29 + 40 + c % 50] for c in range(ncell)])
+        w.wire_set_payloads(3, 0x10000 + np.arange(ncell), [blob[c % 31: c % 31 + 200 + c % 90] for c in range(ncell)])
+        return sw, ctl, w
+
+    worlds = [make(True), make(False)]
+    checked = 0
+    for k in range(6):
+        outs = []
+        for sw, _ctl, w in worlds:
+            sw.step()
+            w.tick(sw.now_ns(), upd_x=sw.x, upd_z=sw.z, queries=sw.queries(), want_records=False)
+            if k < 3:
+                continue  # (the first fan-outs are full states of ~10^8 channels: tens of GB of packets)
+            nbytes, npackets, ndropped = w.wire_build()
+            outs.append((nbytes, npackets, ndropped, w.wire_build_info(), w.wire_fetch()))
+        if k < 3:
+            continue
+        (nb0, np0, nd0, info0, (off0, npk0, data0)), (nb1, np1, nd1, info1, (off1, npk1, data1)) = outs
+        assert info0[0] > 100_000 and info1[0] == 0, "one world takes the image path, the other the record path"
+        assert (nb0, np0, nd0) == (nb1, np1, nd1) and nb0 > 3_000_000_000
+        assert np.array_equal(off0, off1) and np.array_equal(npk0, npk1)
+        step = 1 << 28
+        for a in range(0, nb0, step):
+            if not np.array_equal(data0[a:a + step], data1[a:a + step]):
+                bad = a + int(np.flatnonzero(data0[a:a + step] != data1[a:a + step])[0])
+                s = int(np.searchsorted(off0, bad, side="right")) - 1
+                raise AssertionError(f"tick {k}: streams differ at byte {bad} (connection slot {s}, offset {bad - int(off0[s])} of {int(off0[s + 1] - off0[s])})")
+        checked += 1
+        del data0, data1, outs
+    assert checked == 3
