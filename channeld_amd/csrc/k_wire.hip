@@ -1362,9 +1362,9 @@ typedef uint32_t wu32x4u __attribute__((ext_vector_type(4), aligned(1)));
 
 struct CpRange { const uint8_t *sp; uint8_t *dp; uint32_t nvec; };
 
-__device__ __forceinline__ CpRange cp_range(const WireDev &x, uint4 d, uint32_t srcmask) {
+__device__ __forceinline__ CpRange cp_range(const WireDev &x, uint4 d) {
     uint8_t *dst = x.bytes + (((uint64_t)d.y << 32) | d.x);
-    const uint8_t *src = x.img[d.z >> 31] + (d.z & 0x7FFFFFFFu & srcmask);
+    const uint8_t *src = x.img[d.z >> 31] + (d.z & 0x7FFFFFFFu);
     const uint32_t head = min((16u - (uint32_t)((uintptr_t)dst & 15u)) & 15u, d.w);
     CpRange r;
     r.sp = src + head;
@@ -1373,13 +1373,13 @@ __device__ __forceinline__ CpRange cp_range(const WireDev &x, uint4 d, uint32_t 
     return r;
 }
 
-__global__ void __launch_bounds__(256) k_wire_copy_ends(WorldDev w, WireDev x, uint32_t srcmask) {
+__global__ void __launch_bounds__(256) k_wire_copy_ends(WorldDev w, WireDev x) {
     if (!wire_img_fits(w, x)) return;
     const uint32_t ndesc = x.rank_ndesc[w.S];
     for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < ndesc; i += gridDim.x * 256u) {
     const uint4 d = x.cdesc[i];
     uint8_t *dst = x.bytes + (((uint64_t)d.y << 32) | d.x);
-    const uint8_t *src = x.img[d.z >> 31] + (d.z & 0x7FFFFFFFu & srcmask);
+    const uint8_t *src = x.img[d.z >> 31] + (d.z & 0x7FFFFFFFu);
     const uint32_t len = d.w;
     const uint32_t head = min((16u - (uint32_t)((uintptr_t)dst & 15u)) & 15u, len);
     const uint32_t done = head + (((len - head) >> 4) << 4);
@@ -1416,7 +1416,7 @@ struct CpStream {  // the ticket's pieces in order: uniform per wave
     bool open;
 };
 
-__device__ __forceinline__ bool cpw_next(const WireDev &x, CpStream &st, uint32_t srcmask, const uint8_t *&sp, uint8_t *&dp, uint32_t &nv) {
+__device__ __forceinline__ bool cpw_next(const WireDev &x, CpStream &st, const uint8_t *&sp, uint8_t *&dp, uint32_t &nv) {
     if (!st.open || st.v >= st.r.nvec) {
         if (!st.todo) { st.open = false; return false; }
         const int L = __ffsll((unsigned long long)st.todo) - 1;
@@ -1424,7 +1424,7 @@ __device__ __forceinline__ bool cpw_next(const WireDev &x, CpStream &st, uint32_
         uint4 d;
         d.x = (uint32_t)__builtin_amdgcn_readlane((int)st.dl.x, L); d.y = (uint32_t)__builtin_amdgcn_readlane((int)st.dl.y, L);
         d.z = (uint32_t)__builtin_amdgcn_readlane((int)st.dl.z, L); d.w = (uint32_t)__builtin_amdgcn_readlane((int)st.dl.w, L);
-        st.r = cp_range(x, d, srcmask);
+        st.r = cp_range(x, d);
         st.v = 0;
         st.open = true;
     }
@@ -1436,7 +1436,7 @@ __device__ __forceinline__ bool cpw_next(const WireDev &x, CpStream &st, uint32_
 }
 
 template <bool NT>
-__global__ void __launch_bounds__(256) k_wire_copy_img(WorldDev w, WireDev x, uint32_t srcmask) {
+__global__ void __launch_bounds__(256) k_wire_copy_img(WorldDev w, WireDev x) {
     __shared__ wu32x4 tile[2][2][CPW_PIECE];
     __shared__ uint32_t ticket_s;
     if (!wire_img_fits(w, x)) return;
@@ -1454,7 +1454,7 @@ __global__ void __launch_bounds__(256) k_wire_copy_img(WorldDev w, WireDev x, ui
         st.dl = make_uint4(0u, 0u, 0u, 0u);
         const bool have = lane < WIRE_CP_BATCH && i0 + lane < ndesc;
         if (have) st.dl = x.cdesc[i0 + lane];
-        const uint32_t my_nvec = have ? cp_range(x, st.dl, srcmask).nvec : 0u;
+        const uint32_t my_nvec = have ? cp_range(x, st.dl).nvec : 0u;
         st.todo = __ballot(my_nvec != 0u);
         st.open = false;
         st.v = 0;
@@ -1470,8 +1470,8 @@ __global__ void __launch_bounds__(256) k_wire_copy_img(WorldDev w, WireDev x, ui
                 const uint8_t *sp = nullptr, *sp2 = nullptr;
                 uint8_t *dp = nullptr, *dp2 = nullptr;
                 uint32_t nv = 0, nv2 = 0;
-                const bool a = cpw_next(x, st, srcmask, sp, dp, nv);
-                const bool b2 = a && cpw_next(x, st, srcmask, sp2, dp2, nv2);
+                const bool a = cpw_next(x, st, sp, dp, nv);
+                const bool b2 = a && cpw_next(x, st, sp2, dp2, nv2);
                 if (pair) { sp = sp2; dp = dp2; nv = b2 ? nv2 : 0u; }
                 else if (!a) nv = 0u;
                 wu32x4 q[CPW_K];
@@ -1532,12 +1532,11 @@ void launch_wire_layout_img(hipStream_t st, DevGrid g, WorldDev w, WireDev x, bo
 void launch_wire_copy_img(hipStream_t st, WorldDev w, WireDev x, uint32_t waves) {
     static const uint32_t mult = [] { const char *e = getenv("CHD_WIRE_COPY_WAVES"); return e ? (uint32_t)atoi(e) : 2u; }();  // x 8 waves per CU
     waves *= mult ? mult : 1u;
-    static const uint32_t srcmask = [] { const char *e = getenv("CHD_WIRE_COPY_SRCMASK"); return e ? (uint32_t)strtoul(e, nullptr, 0) : 0xFFFFFFFFu; }();  // (timing experiments only)
     static const bool nt = [] { const char *e = getenv("CHD_WIRE_COPY_NT"); return e && e[0] == '1'; }();
     // (everything sized on the device: the descriptor count and the list of record-path connections are not known to the host yet)
-    hipLaunchKernelGGL(k_wire_copy_ends, dim3(2048), dim3(256), 0, st, w, x, srcmask);
+    hipLaunchKernelGGL(k_wire_copy_ends, dim3(2048), dim3(256), 0, st, w, x);
     const uint32_t wgs = waves / 4u ? waves / 4u : 1u;  // (four waves each)
-    if (nt) hipLaunchKernelGGL(k_wire_copy_img<true>, dim3(wgs), dim3(256), 0, st, w, x, srcmask);
-    else hipLaunchKernelGGL(k_wire_copy_img<false>, dim3(wgs), dim3(256), 0, st, w, x, srcmask);
+    if (nt) hipLaunchKernelGGL(k_wire_copy_img<true>, dim3(wgs), dim3(256), 0, st, w, x);
+    else hipLaunchKernelGGL(k_wire_copy_img<false>, dim3(wgs), dim3(256), 0, st, w, x);
     hipLaunchKernelGGL(k_wire_copy_list, dim3(512), dim3(256), 0, st, w, x);
 }
