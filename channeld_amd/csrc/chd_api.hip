@@ -973,6 +973,9 @@ int chd_world_create(chd_ctx *ctx, const chd_world_cfg *cfg) {
     }
     d.rec_pos = nullptr;
     d.ce_slot = nullptr;
+    d.seg_no_pos = 0;
+    d.wcol_slot = nullptr;
+    d.pair_desc = nullptr;
     // exact update buffers (history_depth): ChannelData.updateMsgBuffer per entity and per spatial channel
     d.deep_depth = cfg->history_depth;
     if (d.deep_depth) {
@@ -1041,20 +1044,31 @@ int chd_world_create(chd_ctx *ctx, const chd_world_cfg *cfg) {
         if (x.img_on) {
             size_t free_b = 0, total_b = 0;
             (void)hipMemGetInfo(&free_b, &total_b);
+            // window columns in wire worlds (partially updating ticks): nine more update images per cell, if they fit
+            x.img_ncol = 1u + CHD_WCOLS;
             for (int k = 0; k < 2; k++) {
                 // worst case: every channel's payload at its slot size + the three nested headers, images padded to 16 bytes
-                const uint64_t cap = (uint64_t)(N + C) * (x.stride[k] + 32u) + 16ull * C + 4096ull;
+                const uint64_t one = (uint64_t)(N + C) * (x.stride[k] + 32u) + 16ull * C + 4096ull;
+                uint64_t cap = one * (k == 0 ? x.img_ncol : 1u);
+                if (k == 0 && !(cap < (1ull << 31) && cap < free_b / 8)) { x.img_ncol = 1; cap = one; }
                 x.img_ok[k] = (cap < (1ull << 31) && cap < free_b / 8) ? 1u : 0u;  // (a descriptor's source offset has 31 bits)
                 if (!x.img_ok[k]) continue;
+                const size_t ni = (size_t)(k == 0 ? x.img_ncol : 1u) * C;
                 TRY(walloc(ctx, &x.img[k], cap, false));
                 x.img_cap[k] = cap;
-                TRY(walloc(ctx, &x.img_off[k], C + 1));
-                TRY(walloc(ctx, &x.img_len[k], C));
-                TRY(walloc(ctx, &x.img_own[k], C));
-                TRY(walloc(ctx, &x.img_bad[k], C));
-                TRY(walloc(ctx, &x.img_end[k], N + 2));
+                TRY(walloc(ctx, &x.img_off[k], ni + 1));
+                TRY(walloc(ctx, &x.img_len[k], ni));
+                TRY(walloc(ctx, &x.img_own[k], ni));
+                TRY(walloc(ctx, &x.img_bad[k], ni));
+                TRY(walloc(ctx, &x.img_end[k], k == 0 ? (size_t)x.img_ncol * d.wcol_stride + 520 : N + 2));
             }
             if (!x.img_ok[0] && !x.img_ok[1]) x.img_on = 0;
+            if (x.img_on) {
+                // (see WorldDev::seg_no_pos) — and with them the window columns of partially updating ticks stay available
+                d.seg_no_pos = 1;
+                TRY(walloc(ctx, &d.wcol_slot, (size_t)(CHD_WCOLS + 1) * d.wcol_stride + 520, false));
+                TRY(walloc(ctx, &d.pair_desc, P, false));
+            }
             x.dpad = C <= 65536 ? 32u : 1u;
             TRY(walloc(ctx, &x.cell_dcnt, C * x.dpad + 1));
             TRY(walloc(ctx, &x.conn_ndesc, S));
@@ -1411,7 +1425,7 @@ static int tick_locked(chd_ctx *ctx, const chd_tick_in *in) {
     // Partially updating worlds keep the descriptor path where the WINDOW COLUMNS exist (WorldDev::wcol_*: per cell the entities
     // updated within the last 1..4 ticks, compacted once per tick by k_window_columns): a window over exactly those ticks is
     // then a plain copy again.  (Not in wire mode: its records carry cell-table positions.)
-    d.wcol_on = (W.full_streak < 2u && d.wcol_stride && !d.rec_pos && !d.cm_emit && !d.rec_mask) ? 1u : 0u;
+    d.wcol_on = (W.full_streak < 2u && d.wcol_stride && (!d.rec_pos || (d.seg_no_pos && W.x.img_ncol > 1u && W.x.img_ok[0])) && !d.cm_emit && !d.rec_mask) ? 1u : 0u;
     d.seg_off = (!d.one_wave_emit && W.full_streak < 2u && !d.wcol_on) ? 1u : 0u;
     if (const char *e = getenv("CHD_WINDOW_COLUMNS")) if (e[0] == '0') {  // (A/B runs: the per-tick choice of round 2)
         d.wcol_on = 0;
@@ -2309,7 +2323,7 @@ int chd_wire_build(chd_ctx *ctx, uint64_t *total_bytes, uint64_t *total_packets,
     // (a second call for the same tick returns the streams already built: the layout pass rewrote the records' position words)
     const bool again = W.wire_built;
     // streams from the fan-out descriptors where the tick has them (k_wire_layout_img), else from the records (k_wire_layout)
-    const bool img = W.x.img_on && W.last_desc && !d.cm_emit && !d.wcol_on;
+    const bool img = W.x.img_on && W.last_desc && !d.cm_emit;
     auto write_img = [&]() {  // (device-guarded: does nothing unless both arenas hold what the sizing pass found)
         W.x.bytes_cap = W.wire_cap;
         W.x.cdesc_cap = W.cdesc_cap;

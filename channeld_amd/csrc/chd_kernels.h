@@ -86,6 +86,13 @@ struct WorldDev {
     // entity skipped an update (wcol_on); wcol_stride == 0: not available (region-sharded worlds).
     uint32_t wcol_stride, wcol_on;
     uint32_t *cell_wcnt;
+    // wire worlds whose streams are built from the descriptors (WireDev::img_on): the record kernel writes no position words
+    // (seg_no_pos; k_wire_layout_img derives them for the few subscriptions it still walks record by record), the window
+    // columns also carry the entities' SLOTS (wcol_slot: same indexing as ce_chan's columns 1..9), and the plan leaves every
+    // subscription's first descriptor index (pair_desc: index | count << 28, ~0 = no descriptor this tick)
+    uint32_t seg_no_pos;
+    uint32_t *wcol_slot;
+    uint32_t *pair_desc;
     const uint32_t *ce_chan_view;     // (views: always the arrays above since the halo exchange appends the neighbours' entries to them)
     const uint2 *ce8_view;
     uint32_t *cell_off;   // [ncell+1] cell c owns ce[cell_off[c], cell_off[c+1])
@@ -385,12 +392,14 @@ struct WireDev {
     // of the cell's messages — [own message][entity messages in column order] — built once per tick
     uint32_t img_on;                    // the path exists for this world (no merged updates)
     uint32_t img_ok[2];                 // ... and its arena of kind f
+    uint32_t img_ncol;                  // update images per cell: 1 (the full column) or 1 + CHD_WCOLS (+ the window columns)
     uint8_t *img[2];
     uint64_t img_cap[2];
-    uint32_t *img_off[2];               // [ncell + 1] image offsets (16-byte aligned; the scan of the padded lengths)
-    uint32_t *img_len[2], *img_own[2];  // [ncell] image bytes; bytes of the own message in front
-    uint32_t *img_bad[2];               // [ncell] a message of the cell is dropped by Send / names no slot: its subscriptions take the record path
-    uint32_t *img_end[2];               // [npos] end of each entity message inside its cell's image (the packet cuts fall on these)
+    // indexed by image = col * ncell + cell (family 0: col < img_ncol; family 1: col 0)
+    uint32_t *img_off[2];               // [images + 1] image offsets (16-byte aligned; the scan of the padded lengths)
+    uint32_t *img_len[2], *img_own[2];  // image bytes; bytes of the own message in front
+    uint32_t *img_bad[2];               // a message of the image is dropped by Send / names no slot: its subscriptions take the record path
+    uint32_t *img_end[2];               // [col * wcol_stride + table position] end of each entity message inside its image (the packet cuts fall on these)
     uint32_t *cell_dcnt;                // [ncell * dpad + 1] connections per cell of their first subscription -> exclusive scan
     uint32_t dpad;                      // counter stride in words (32 = one per 128-byte line, grids up to 64K cells)
     uint32_t *conn_ndesc, *conn_key, *conn_rank;  // [S] copy descriptors of the connection; its first cell; its place in the copy order

@@ -1065,6 +1065,7 @@ __global__ void __launch_bounds__(64 * FO_WAVES) k_fanout_plan_seg(DevGrid g, Wo
         if (p < cnt) {
             w.pair_rel[pbase + p] = rel32;
             w.pair_nrec[pbase + p] = simple ? count : 0u;  // (a deferred subscription's count comes from the deferred launch)
+            if (w.pair_desc) w.pair_desc[pbase + p] = (due && simple) ? (dbase | (nd << 28)) : 0xFFFFFFFFu;
         }
         carry += __shfl((unsigned long long)inc, 63);
         if (__ballot(due && !simple)) any_deferred = 1;
@@ -1249,7 +1250,7 @@ __global__ void __launch_bounds__(64, FO_SEG_OCC) k_fanout_emit_seg(DevGrid g, W
                 const uint32_t n = (uint32_t)__builtin_amdgcn_readlane((int)dv.z, jj), info = (uint32_t)__builtin_amdgcn_readlane((int)dv.w, jj);
                 const uint32_t cch = (uint32_t)__builtin_amdgcn_readlane((int)cv, jj) + g.id_start;
                 chd_fanout_rec *__restrict__ out = w.recs + base + rel;
-                uint32_t *__restrict__ opos = w.rec_pos ? w.rec_pos + base + rel : nullptr;
+                uint32_t *__restrict__ opos = (w.rec_pos && !w.seg_no_pos) ? w.rec_pos + base + rel : nullptr;
                 uint32_t *__restrict__ omask = MASKS ? w.rec_mask + base + rel : nullptr;
                 uint32_t wms[4] = {0, 0, 0, 0};
                 if (MASKS) {

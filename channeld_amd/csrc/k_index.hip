@@ -402,8 +402,11 @@ __global__ void __launch_bounds__(256) k_window_columns(WorldDev w, uint32_t nce
         for (int j = 0; j < CHD_WCOLS; j++) {
             uint32_t before = 0, all = 0;
             for (uint32_t q = 0; q < 4; q++) { const uint32_t t = wtot[j][q]; if (q < wave) before += t; all += t; }
-            if (build[j] && k < n && (e.y & wcol_mask(j)) != 0)
-                w.ce_chan[(size_t)(j + 1) * w.wcol_stride + start + run[j] + before + mask_rank(m[j])] = e.x;
+            if (build[j] && k < n && (e.y & wcol_mask(j)) != 0) {
+                const size_t at = (size_t)(j + 1) * w.wcol_stride + start + run[j] + before + mask_rank(m[j]);
+                w.ce_chan[at] = e.x;
+                if (w.wcol_slot) w.wcol_slot[at] = w.ce_slot[start + k];  // (wire worlds: whose payload the column entry stands for)
+            }
             run[j] += all;
         }
         __syncthreads();

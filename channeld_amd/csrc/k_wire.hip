@@ -1021,11 +1021,44 @@ void launch_wire_set_payloads(hipStream_t st, WireDev x, int full, int cell, uin
 #define SDW_NONE 16u
 #define SDW_OWN_SHIFT 8u
 
-__global__ void __launch_bounds__(256) k_wire_img_sizes(DevGrid g, WorldDev w, WireDev x) {
+// An image = (family f, column col, cell c): f = 0 the update payloads — col 0 every entity of the cell, col 1..9 the cell's
+// WINDOW COLUMN col - 1 (partially updating ticks: the entities with an update inside that window shape, k_window_columns) —,
+// f = 1 the full states (col 0 only).  Its k-th message is the entity at table position start + k (col 0) or the k-th entry of
+// the window column (channel id in ce_chan's column, slot in wcol_slot's).
+struct ImgSel { uint32_t f, col, c, start, n, ii; size_t e0; };  // ii: index into img_len / img_own / img_bad / img_off; e0: into img_end
+
+__device__ __forceinline__ ImgSel img_sel(const WorldDev &w, const WireDev &x, uint32_t c, uint32_t y, uint32_t ncol) {
+    ImgSel s;
+    s.f = y >= ncol ? 1u : 0u;
+    s.col = s.f ? 0u : y;
+    s.c = c;
+    s.start = w.cell_start[c];
+    s.n = w.cell_end[c] - s.start;
+    if (s.col) {
+        // a column the cell's common history covers is never built (k_window_columns) nor referenced (k_fanout_plan_seg)
+        s.n = (w.cell_hand[c] & wcol_mask(s.col - 1u)) ? 0u : w.cell_wcnt[(size_t)(s.col - 1u) * x.ncell + c];
+    }
+    s.ii = s.col * x.ncell + c;
+    s.e0 = (size_t)s.col * w.wcol_stride + s.start;
+    return s;
+}
+__device__ __forceinline__ void img_entry(const WorldDev &w, const ImgSel &s, uint32_t k, uint32_t &slot, uint32_t &chan) {
+    if (s.col) {
+        const size_t at = (size_t)s.col * w.wcol_stride + s.start + k;
+        chan = w.ce_chan[at];
+        slot = w.wcol_slot[at];
+    } else {
+        chan = w.ce_chan_view[s.start + k];
+        slot = w.ce_slot[s.start + k];
+    }
+}
+
+__global__ void __launch_bounds__(256) k_wire_img_sizes(DevGrid g, WorldDev w, WireDev x, uint32_t ncol) {
     __shared__ uint32_t wsum[4];
     __shared__ uint32_t bad_any;
-    const uint32_t c = blockIdx.x, f = blockIdx.y, tid = threadIdx.x, lane = tid & 63u, wv = tid >> 6;
-    const uint32_t start = w.cell_start[c], n = w.cell_end[c] - start;
+    const uint32_t c = blockIdx.x, tid = threadIdx.x, lane = tid & 63u, wv = tid >> 6;
+    const ImgSel sel = img_sel(w, x, c, blockIdx.y, ncol);
+    const uint32_t f = sel.f, n = sel.n;
     if (tid == 0) bad_any = 0;
     // the spatial channel's own message
     chd_fanout_rec r;
@@ -1039,10 +1072,11 @@ __global__ void __launch_bounds__(256) k_wire_img_sizes(DevGrid g, WorldDev w, W
         const uint32_t i = i0 + tid;
         uint32_t entry = 0;
         if (i < n) {
-            const uint32_t slot = w.ce_slot[start + i];
+            uint32_t slot, chan;
+            img_entry(w, sel, i, slot, chan);
             if (slot >= w.N) bad = 1;
             else {
-                r.channel = w.ce_chan_view[start + i];
+                r.channel = chan;
                 entry = wire_msg(w, x, r, slot, 0u).entry;
                 if (!entry) bad = 1;
             }
@@ -1061,30 +1095,32 @@ __global__ void __launch_bounds__(256) k_wire_img_sizes(DevGrid g, WorldDev w, W
             if (k < wv) before += wsum[k];
             total += wsum[k];
         }
-        if (i < n) x.img_end[f][start + i] = carry + before + cum;
+        if (i < n) x.img_end[f][sel.e0 + i] = carry + before + cum;
         carry += total;
         __syncthreads();
     }
     if (bad) bad_any = 1;
     __syncthreads();
     if (tid == 0) {
-        x.img_own[f][c] = own.entry;
-        x.img_len[f][c] = carry;
-        x.img_bad[f][c] = bad_any;
-        x.img_off[f][c] = (carry + 15u) & ~15u;  // -> exclusive scan
+        const bool unused = sel.col != 0u && n == 0u;  // (no image: nothing references it)
+        x.img_own[f][sel.ii] = own.entry;
+        x.img_len[f][sel.ii] = unused ? 0u : carry;
+        x.img_bad[f][sel.ii] = bad_any;
+        x.img_off[f][sel.ii] = unused ? 0u : (carry + 15u) & ~15u;  // -> exclusive scan
     }
 }
 
 #define WIRE_FILL_SPLIT 4u
-__global__ void __launch_bounds__(256) k_wire_img_fill(DevGrid g, WorldDev w, WireDev x) {
+__global__ void __launch_bounds__(256) k_wire_img_fill(DevGrid g, WorldDev w, WireDev x, uint32_t ncol) {
     __shared__ __attribute__((aligned(16))) uint8_t images[4][WIRE_IMG + 48];
-    // grid (cell, kind * WIRE_FILL_SPLIT + part): the cell's chunks of 64 messages go round-robin over 4 * WIRE_FILL_SPLIT waves
-    const uint32_t c = blockIdx.x, f = blockIdx.y / WIRE_FILL_SPLIT, part = blockIdx.y % WIRE_FILL_SPLIT, lane = threadIdx.x & 63u;
+    // grid (cell, image * WIRE_FILL_SPLIT + part): the cell's chunks of 64 messages go round-robin over 4 * WIRE_FILL_SPLIT waves
+    const uint32_t c = blockIdx.x, part = blockIdx.y % WIRE_FILL_SPLIT, lane = threadIdx.x & 63u;
+    const ImgSel sel = img_sel(w, x, c, blockIdx.y / WIRE_FILL_SPLIT, ncol);
+    const uint32_t f = sel.f, n = sel.n;
     const uint32_t wv = (threadIdx.x >> 6) + 4u * part;
-    if (x.img_bad[f][c]) return;
-    const uint32_t start = w.cell_start[c], n = w.cell_end[c] - start;
-    const uint64_t off = x.img_off[f][c];
-    if (off + x.img_len[f][c] > x.img_cap[f]) return;  // (never: the arena is sized for the worst case; the layout checks the same)
+    if (x.img_bad[f][sel.ii] || !x.img_len[f][sel.ii]) return;
+    const uint64_t off = x.img_off[f][sel.ii];
+    if (off + x.img_len[f][sel.ii] > x.img_cap[f]) return;  // (never: the arena is sized for the worst case; the layout checks the same)
     uint8_t *stream = x.img[f] + off;
     uint8_t *img = images[threadIdx.x >> 6];
     chd_fanout_rec r;
@@ -1105,9 +1141,10 @@ __global__ void __launch_bounds__(256) k_wire_img_fill(DevGrid g, WorldDev w, Wi
         } else {
             const uint32_t i = (uint32_t)ch * 64u + lane;
             if (i < n) {
-                r.channel = w.ce_chan_view[start + i];
-                m = wire_msg(w, x, r, w.ce_slot[start + i], 0u);
-                begin = x.img_end[f][start + i] - m.entry;
+                uint32_t slot;
+                img_entry(w, sel, i, slot, r.channel);
+                m = wire_msg(w, x, r, slot, 0u);
+                begin = x.img_end[f][sel.e0 + i] - m.entry;
                 live = true;
             }
         }
@@ -1146,6 +1183,32 @@ __device__ __forceinline__ uint32_t wire_count_le(const uint32_t *__restrict__ E
         hi = nhi;
     }
     return lo;
+}
+
+// what a descriptor copies from: its cell, column and the images of both families (lane-private or uniform)
+struct DescGeom { uint32_t info, c, cst, n, col, off0, len0, own0, off1, len1, own1; };
+
+__device__ __forceinline__ bool desc_geom(const WorldDev &w, const WireDev &x, uint4 d, uint32_t c, DescGeom &G) {
+    G.info = d.w; G.c = c; G.n = d.z;
+    G.cst = w.cell_start[c];
+    G.col = (w.wcol_on && w.wcol_stride) ? d.y / w.wcol_stride : 0u;
+    G.off0 = G.len0 = G.own0 = G.off1 = G.len1 = G.own1 = 0;
+    const uint32_t csz = w.cell_end[c] - G.cst;
+    bool usable = d.y == G.cst + G.col * w.wcol_stride && G.col < x.img_ncol &&
+                  d.z == (G.col ? w.cell_wcnt[(size_t)(G.col - 1u) * x.ncell + c] : csz);
+    if (d.w & SDW_NWIN) {
+        const uint32_t ii = G.col * x.ncell + c;
+        if (!x.img_ok[0] || x.img_bad[0][ii]) usable = false;
+        G.off0 = x.img_off[0][ii]; G.len0 = x.img_len[0][ii]; G.own0 = x.img_own[0][ii];
+        if ((uint64_t)G.off0 + G.len0 > x.img_cap[0]) usable = false;
+        if (G.col && (w.cell_hand[c] & wcol_mask(G.col - 1u))) usable = false;  // (a column that was not built)
+    }
+    if (d.w & SDW_FIRST) {
+        if (G.col || !x.img_ok[1] || x.img_bad[1][c]) usable = false;
+        G.off1 = x.img_off[1][c]; G.len1 = x.img_len[1][c]; G.own1 = x.img_own[1][c];
+        if ((uint64_t)G.off1 + G.len1 > x.img_cap[1]) usable = false;
+    }
+    return usable;
 }
 
 template <bool EMIT>
@@ -1216,59 +1279,51 @@ __global__ void __launch_bounds__(256) k_wire_layout_img(DevGrid g, WorldDev w, 
         const uint32_t cnt = w.pair_cnt[s];
         const size_t pbase = (size_t)s * w.capq;
         const uint64_t rbase = w.rec_ub[s];
-        const uint32_t ns = w.n_simple[s];
-        uint32_t kd = 0;  // next descriptor of the connection (they ascend with the subscription index)
         for (uint32_t p0 = 0; p0 < cnt; p0 += 64) {
             const uint32_t p = p0 + lane;
             const uint32_t nrec = p < cnt ? w.pair_nrec[pbase + p] : 0u;
             const uint32_t rel = p < cnt ? w.pair_rel[pbase + p] : 0u;
-            // which subscriptions of this round have a descriptor
-            unsigned long long mbit = 0;
-            if (kd + lane < ns) {
-                const uint32_t pj = w.seg_desc2[pbase + kd + lane].y;
-                if (pj >= p0 && pj < p0 + 64u) mbit = 1ull << (pj - p0);
-            }
-#pragma unroll
-            for (int d = 32; d >= 1; d >>= 1) mbit |= __shfl_xor(mbit, d);
-            const bool simple = (mbit >> lane) & 1ull;
-            const uint32_t myk = kd + (uint32_t)__popcll(mbit & ((1ull << lane) - 1ull));
-            kd += (uint32_t)__popcll(mbit);
-            uint32_t info = 0, c = 0, csz = 0, cst = 0;
-            uint32_t off0 = 0, len0 = 0, own0 = 0, off1 = 0, len1 = 0, own1 = 0;
+            // the subscription's descriptors (k_fanout_plan_seg: pair_desc), the first one's geometry lane-parallel
+            const uint32_t pd = (p < cnt && nrec) ? w.pair_desc[pbase + p] : 0xFFFFFFFFu;
+            const bool simple = pd != 0xFFFFFFFFu;
+            const uint32_t dfirst = pd & 0x0FFFFFFFu, ndp = simple ? pd >> 28 : 0u;
+            DescGeom G;
             bool usable = false;
-            if (simple && nrec) {
-                const uint4 d = w.seg_desc[pbase + myk];
-                c = w.seg_desc2[pbase + myk].x;
-                info = d.w;
-                cst = w.cell_start[c];
-                csz = w.cell_end[c] - cst;
-                usable = d.y == cst && d.z == csz && d.x == rel;
-                const uint32_t f1 = (info & SDW_FIRST) ? 1u : 0u, f0 = (info & SDW_NWIN) ? 1u : 0u;
-                if (f0) {
-                    if (x.img_bad[0][c] || !x.img_ok[0]) usable = false;
-                    off0 = x.img_off[0][c]; len0 = x.img_len[0][c]; own0 = x.img_own[0][c];
-                    if ((uint64_t)off0 + len0 > x.img_cap[0]) usable = false;
-                }
-                if (f1) {
-                    if (x.img_bad[1][c] || !x.img_ok[1]) usable = false;
-                    off1 = x.img_off[1][c]; len1 = x.img_len[1][c]; own1 = x.img_own[1][c];
-                    if ((uint64_t)off1 + len1 > x.img_cap[1]) usable = false;
-                }
+            if (simple) {
+                usable = desc_geom(w, x, w.seg_desc[pbase + dfirst], w.seg_desc2[pbase + dfirst].x, G);
+                if (w.seg_desc[pbase + dfirst].x != rel) usable = false;
             }
             for (uint64_t act = __ballot(nrec != 0); act; act &= act - 1) {
                 const int L = __ffsll((unsigned long long)act) - 1;
-                if (__builtin_amdgcn_readlane((int)usable, L)) {
-                    const uint32_t infoL = (uint32_t)__builtin_amdgcn_readlane((int)info, L);
-                    const uint32_t cstL = (uint32_t)__builtin_amdgcn_readlane((int)cst, L), cszL = (uint32_t)__builtin_amdgcn_readlane((int)csz, L);
-                    if (infoL & SDW_FIRST)
-                        piece(1u, (uint32_t)__builtin_amdgcn_readlane((int)off1, L), (uint32_t)__builtin_amdgcn_readlane((int)own1, L), x.img_end[1] + cstL, cszL, 0u, (uint32_t)__builtin_amdgcn_readlane((int)len1, L), (uint32_t)__builtin_amdgcn_readlane((int)len1, L));
-                    const uint32_t nw = infoL & SDW_NWIN;
-                    if (nw) {
-                        const uint32_t o0 = (uint32_t)__builtin_amdgcn_readlane((int)off0, L), ow = (uint32_t)__builtin_amdgcn_readlane((int)own0, L), ln = (uint32_t)__builtin_amdgcn_readlane((int)len0, L);
+                const uint32_t ndL = (uint32_t)__builtin_amdgcn_readlane((int)ndp, L);
+                const uint32_t dfL = (uint32_t)__builtin_amdgcn_readlane((int)dfirst, L);
+                bool ok = __builtin_amdgcn_readlane((int)usable, L) != 0;
+                // (a subscription split into one descriptor per window — partially updating ticks, windows that copy different
+                // columns — is usable only if every part is: checked before anything is emitted)
+                for (uint32_t t = 1; ok && t < ndL; t++) {
+                    DescGeom Gt;
+                    ok = desc_geom(w, x, w.seg_desc[pbase + dfL + t], w.seg_desc2[pbase + dfL + t].x, Gt);
+                }
+                if (ok) {
+                    for (uint32_t t = 0; t < ndL; t++) {
+                        DescGeom H;
+                        if (t == 0) {
+                            H.info = (uint32_t)__builtin_amdgcn_readlane((int)G.info, L); H.cst = (uint32_t)__builtin_amdgcn_readlane((int)G.cst, L);
+                            H.n = (uint32_t)__builtin_amdgcn_readlane((int)G.n, L); H.col = (uint32_t)__builtin_amdgcn_readlane((int)G.col, L);
+                            H.off0 = (uint32_t)__builtin_amdgcn_readlane((int)G.off0, L); H.len0 = (uint32_t)__builtin_amdgcn_readlane((int)G.len0, L);
+                            H.own0 = (uint32_t)__builtin_amdgcn_readlane((int)G.own0, L); H.off1 = (uint32_t)__builtin_amdgcn_readlane((int)G.off1, L);
+                            H.len1 = (uint32_t)__builtin_amdgcn_readlane((int)G.len1, L); H.own1 = (uint32_t)__builtin_amdgcn_readlane((int)G.own1, L);
+                            H.c = (uint32_t)__builtin_amdgcn_readlane((int)G.c, L);
+                        } else {
+                            (void)desc_geom(w, x, w.seg_desc[pbase + dfL + t], w.seg_desc2[pbase + dfL + t].x, H);
+                        }
+                        if (H.info & SDW_FIRST) piece(1u, H.off1, H.own1, x.img_end[1] + H.cst, H.n, 0u, H.len1, H.len1);
+                        const uint32_t nw = H.info & SDW_NWIN;
+                        const uint32_t *E0 = x.img_end[0] + (size_t)H.col * w.wcol_stride + H.cst;
                         for (uint32_t j = 0; j < nw; j++) {
-                            const uint32_t a = ((infoL >> (SDW_OWN_SHIFT + j)) & 1u) ? 0u : ow;
-                            const uint32_t b = (infoL & SDW_NONE) ? ow : ln;
-                            piece(0u, o0, ow, x.img_end[0] + cstL, cszL, a, b, ln);
+                            const uint32_t a = ((H.info >> (SDW_OWN_SHIFT + j)) & 1u) ? 0u : H.own0;
+                            const uint32_t b = (H.info & SDW_NONE) ? H.own0 : H.len0;
+                            piece(0u, H.off0, H.own0, E0, H.n, a, b, H.len0);
                         }
                     }
                     if (EMIT && lane == 0) x.seg_fast[pbase + p0 + (uint32_t)L] = 2;  // (neither record-path copy kernel takes it)
@@ -1280,17 +1335,49 @@ __global__ void __launch_bounds__(256) k_wire_layout_img(DevGrid g, WorldDev w, 
                 const uint32_t fmask = x.schema ? (w.pair_flags[pbase + p0 + (uint32_t)L] >> PF_FIELD_MASK_SHIFT) & 0xFFu : 0u;
                 any_slow = 1;
                 if (EMIT && lane == 0) x.seg_fast[pbase + p0 + (uint32_t)L] = 0;
+                // whose message record i of the segment is.  The deferred launch left a position word per record; for a
+                // subscription WITH descriptors (its images are not usable: a message Send drops, no arena) the record kernel
+                // wrote none (WorldDev::seg_no_pos): the descriptors say it — per part the own message, then the column's entries
+                auto derived = [&](uint32_t i) -> uint32_t {
+                    uint32_t acc = 0, out = 0xFFFFFFFFu;
+                    for (uint32_t t = 0; t < ndL; t++) {
+                        const uint4 d = w.seg_desc[pbase + dfL + t];
+                        const uint32_t c = w.seg_desc2[pbase + dfL + t].x, cst = w.cell_start[c], nn = d.z;
+                        const uint32_t col = (w.wcol_on && w.wcol_stride) ? d.y / w.wcol_stride : 0u;
+                        auto ent = [&](uint32_t k) { return col ? w.wcol_slot[(size_t)col * w.wcol_stride + cst + k] : w.ce_slot[cst + k]; };
+                        if (d.w & SDW_FIRST) {
+                            if (i == acc) out = CHD_POS_CELL | c;
+                            else if (i > acc && i <= acc + nn) out = ent(i - acc - 1u);
+                            acc += nn + 1u;
+                        }
+                        for (uint32_t j = 0; j < (d.w & SDW_NWIN); j++) {
+                            if ((d.w >> (SDW_OWN_SHIFT + j)) & 1u) {
+                                if (i == acc) out = CHD_POS_CELL | c;
+                                acc += 1u;
+                            }
+                            if (!(d.w & SDW_NONE)) {
+                                if (i >= acc && i < acc + nn) out = ent(i - acc);
+                                acc += nn;
+                            }
+                        }
+                    }
+                    return out;
+                };
                 for (uint32_t i0 = 0; i0 < n; i0 += 64) {
                     const uint32_t i = i0 + lane;
                     const bool valid = i < n;
                     uint32_t entry = 0, alen = 0;
                     if (valid) {
-                        uint32_t pos = w.rec_pos[seg + i];
+                        uint32_t pos = ndL ? 0u : w.rec_pos[seg + i];
                         if ((pos & CHD_POS_CELL) ? (pos & ~CHD_POS_CELL) >= x.ncell : pos >= x.npos) {
                             if (EMIT) atomicAdd(x.n_dropped + 1, 1u);
                             pos = CHD_POS_CELL;
                         }
-                        uint32_t idc = (pos & CHD_POS_CELL) ? pos : w.ce_slot[pos];
+                        uint32_t idc = ndL ? derived(i) : (pos & CHD_POS_CELL) ? pos : w.ce_slot[pos];
+                        if (ndL && (idc & CHD_POS_CELL) && (idc & ~CHD_POS_CELL) >= x.ncell) {  // (no part of the descriptors claims the record)
+                            if (EMIT) atomicAdd(x.n_dropped + 1, 1u);
+                            idc = CHD_POS_CELL;
+                        }
                         if (!(idc & CHD_POS_CELL) && idc >= w.N) {
                             if (EMIT) atomicAdd(x.n_dropped + 2, 1u);
                             idc = CHD_POS_CELL;
@@ -1517,10 +1604,11 @@ void launch_wire_conn_order(hipStream_t st, WorldDev w, WireDev x) {
 
 void launch_wire_images(hipStream_t st, DevGrid g, WorldDev w, WireDev x) {
     if (!g.ncell) return;
-    hipLaunchKernelGGL(k_wire_img_sizes, dim3(g.ncell, 2), dim3(256), 0, st, g, w, x);
-    launch_scan_u32_inplace(st, x.img_off[0], g.ncell);
+    const uint32_t ncol = w.wcol_on ? x.img_ncol : 1u;  // update images per cell: the full column (+ the window columns of this tick)
+    hipLaunchKernelGGL(k_wire_img_sizes, dim3(g.ncell, ncol + 1u), dim3(256), 0, st, g, w, x, ncol);
+    launch_scan_u32_inplace(st, x.img_off[0], ncol * g.ncell);
     launch_scan_u32_inplace(st, x.img_off[1], g.ncell);
-    hipLaunchKernelGGL(k_wire_img_fill, dim3(g.ncell, 2 * WIRE_FILL_SPLIT), dim3(256), 0, st, g, w, x);
+    hipLaunchKernelGGL(k_wire_img_fill, dim3(g.ncell, (ncol + 1u) * WIRE_FILL_SPLIT), dim3(256), 0, st, g, w, x, ncol);
 }
 
 void launch_wire_layout_img(hipStream_t st, DevGrid g, WorldDev w, WireDev x, bool emit) {

@@ -34,7 +34,7 @@ def any_bytes(rng, n):
     return bytes(rng.integers(0, 256, int(n), dtype=np.uint8))
 
 
-def run_wire(amd, cfg_name, N, S, ticks, seed, flags, upd_len, full_len, max_upd=0, max_full=0, tick_ms=50, aoi_scale=1.0):
+def run_wire(amd, cfg_name, N, S, ticks, seed, flags, upd_len, full_len, max_upd=0, max_full=0, tick_ms=50, aoi_scale=1.0, update_frac=1.0):
     cfg = synth.load_config(cfg_name)
     sw = synth.SynthWorld(synth.WorldSpec(cfg, N, S, seed, tick_ms=tick_ms, aoi_scale=aoi_scale))
     ctl = amd.StaticGrid2DSpatialController()
@@ -63,8 +63,12 @@ def run_wire(amd, cfg_name, N, S, ticks, seed, flags, upd_len, full_len, max_upd
         ent[0].update(upd)
         w.wire_set_payloads(ENT_UPD, list(upd), list(upd.values()))
         cu = 0x10000 + rng.integers(0, ncell, 3).astype(np.uint32)
-        res = w.tick(sw.now_ns(), upd_x=sw.x, upd_z=sw.z, queries=sw.queries(), cell_upd_channel=cu,
-                     cell_upd_sender=np.full(3, 5, dtype=np.uint32), records_cap=1 << 22)
+        if update_frac >= 1.0:
+            idx = None
+        else:  # a partially updating tick (ticks 0 and 1 complete, so that the world is on the descriptor path before)
+            idx = np.arange(N, dtype=np.uint32) if k < 2 else np.flatnonzero(rng.random(N) < update_frac).astype(np.uint32)
+        res = w.tick(sw.now_ns(), upd_idx=idx, upd_x=sw.x if idx is None else sw.x[idx], upd_z=sw.z if idx is None else sw.z[idx],
+                     queries=sw.queries(), cell_upd_channel=cu, cell_upd_sender=np.full(3, 5, dtype=np.uint32), records_cap=1 << 22)
         nbytes, npackets, ndropped = w.wire_build()
         nr, nc = w.wire_build_info()
         run_wire.image_ranges += nr
@@ -118,6 +122,17 @@ def test_wire_streams_from_cell_images_match_the_record_path(amd, monkeypatch):
     tb2, tp2, td2 = run_wire(amd, "spatial_static_4x4.json", 2400, 32, 6, 0xC0FFEE47, DESC, tick_ms=33,
                              upd_len=lambda: rng.integers(20, 120), full_len=lambda: rng.integers(100, 600), max_full=600)
     assert (tb2, tp2, td2) == (tb, tp, td) and run_wire.image_ranges == 0 and ranges > 0
+
+
+@pytest.mark.parametrize("frac", [0.9, 0.5])
+def test_wire_streams_of_partially_updating_ticks_from_window_column_images(amd, frac):
+    """Wire worlds keep the window columns on partially updating ticks (the record kernel writes no position words there;
+    WorldDev::seg_no_pos): a subscription's window copies the cell's WINDOW COLUMN, and its bytes come from that column's
+    image — one more image per (cell, window shape).  33 ms ticks: one- to three-tick windows, so several shapes are live."""
+    rng = np.random.default_rng(8)
+    tb, tp, td = run_wire(amd, "spatial_static_4x4.json", 2400, 32, 8, 0xC0FFEE48, DESC, tick_ms=33, update_frac=frac,
+                          upd_len=lambda: rng.integers(20, 120), full_len=lambda: rng.integers(100, 600), max_full=600)
+    assert run_wire.image_ranges > 1000 and td == 0
 
 
 @pytest.mark.parametrize("mode", [CONN_MAJOR, DESC])
