@@ -678,7 +678,16 @@ def wire_phase(args, world, ctl, N, tick_at, ticks, base_now, measure_last=None)
     ticks = list(ticks)
     first = 0 if measure_last is None else max(len(ticks) - measure_last, 0)
     wb, wt, wp, tt, nrec = [], [], [], [], []
+    merge = bool(getattr(args, "update_masks", False))
+    if merge:
+        # merged updates: the update payloads are the channel data update MESSAGES of each tick (here the 21-byte
+        # position update of SURVEY a14), a fan-out message carries Any{type_url, the updates its window selected}
+        world.wire_set_type_url(False, b"type.googleapis.com/tpspb.EntityChannelData")
+        world.wire_set_type_url(True, b"type.googleapis.com/unrealpb.SpatialChannelData")
+        upd = [bytes(rng.integers(0, 256, 21, dtype=np.uint8))] * N
     for i, t in enumerate(ticks):  # (--wire: replays the last ticks' inputs at later channel times)
+        if merge:
+            world.wire_set_payloads(0, np.arange(N), upd)  # (this tick's updates: they go into the tick's ring slot)
         world.sync()
         a0 = time.perf_counter()
         trace(f"wire tick {i}")
@@ -711,7 +720,8 @@ def wire_phase(args, world, ctl, N, tick_at, ticks, base_now, measure_last=None)
             "written_GBps": float(np.median([b_ / t_ / 1e9 for b_, t_ in zip(wb, wt)])),
             "written_GBps_is": "median over the builds of bytes / time of that build (host clock around chd_wire_build + sync)",
             "frac_of_hbm_peak": float(np.median([b_ / t_ / 1e9 for b_, t_ in zip(wb, wt)]) / HBM_PEAK_GBS),
-            "payload": "66-byte Any per entity update, 40-byte per spatial channel update"}
+            "payload": ("merged updates: 21-byte update message per entity and tick, Any{type_url, value = the window's updates}" if merge
+                        else "66-byte Any per entity update, 40-byte per spatial channel update")}
 
 
 if __name__ == "__main__":

@@ -1039,7 +1039,7 @@ int chd_world_create(chd_ctx *ctx, const chd_world_cfg *cfg) {
         TRY(walloc(ctx, &x.conn_npk, S));
         TRY(walloc(ctx, &x.n_dropped, 8 + 64));
         // the descriptor-driven stream builder (k_wire_layout_img): one image of every cell's messages per payload kind
-        x.img_on = x.merge ? 0u : 1u;
+        x.img_on = 1u;
         if (const char *e = getenv("CHD_WIRE_IMAGES")) if (e[0] == '0') x.img_on = 0;  // (A/B runs, tests of the record path)
         if (x.img_on) {
             size_t free_b = 0, total_b = 0;
@@ -1048,9 +1048,12 @@ int chd_world_create(chd_ctx *ctx, const chd_world_cfg *cfg) {
             x.img_ncol = 1u + CHD_WCOLS;
             for (int k = 0; k < 2; k++) {
                 // worst case: every channel's payload at its slot size + the three nested headers, images padded to 16 bytes
-                const uint64_t one = (uint64_t)(N + C) * (x.stride[k] + 32u) + 16ull * C + 4096ull;
-                uint64_t cap = one * (k == 0 ? x.img_ncol : 1u);
-                if (k == 0 && !(cap < (1ull << 31) && cap < free_b / 8)) { x.img_ncol = 1; cap = one; }
+                // (merge mode: an update message carries up to three ticks' updates behind the Any's type url; the images that are
+                // built are the ones the tick's descriptors ask for — room for four of the nine per cell, checked on the device)
+                const uint64_t per = (k == 0 && x.merge) ? 3ull * x.stride[0] + 256u + 48u : x.stride[k] + 32u;
+                const uint64_t one = (uint64_t)(N + C) * per + 16ull * C + 4096ull;
+                uint64_t cap = one * (k == 0 ? (x.merge ? 4u : x.img_ncol) : 1u);
+                if (k == 0 && !(cap < (1ull << 31) && cap < free_b / 8)) { x.img_ncol = 1; cap = one; if (x.merge) cap = 1ull << 40; /* (no merge images) */ }
                 x.img_ok[k] = (cap < (1ull << 31) && cap < free_b / 8) ? 1u : 0u;  // (a descriptor's source offset has 31 bits)
                 if (!x.img_ok[k]) continue;
                 const size_t ni = (size_t)(k == 0 ? x.img_ncol : 1u) * C;
@@ -1061,8 +1064,9 @@ int chd_world_create(chd_ctx *ctx, const chd_world_cfg *cfg) {
                 TRY(walloc(ctx, &x.img_own[k], ni));
                 TRY(walloc(ctx, &x.img_bad[k], ni));
                 TRY(walloc(ctx, &x.img_end[k], k == 0 ? (size_t)x.img_ncol * d.wcol_stride + 520 : N + 2));
+                if (k == 0 && x.merge) TRY(walloc(ctx, &x.img_need, ni));
             }
-            if (!x.img_ok[0] && !x.img_ok[1]) x.img_on = 0;
+            if ((!x.img_ok[0] && !x.img_ok[1]) || (x.merge && (!x.img_ok[0] || x.img_ncol == 1u))) x.img_on = 0;
             if (x.img_on) {
                 // (see WorldDev::seg_no_pos) — and with them the window columns of partially updating ticks stay available
                 d.seg_no_pos = 1;

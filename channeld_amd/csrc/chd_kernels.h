@@ -392,7 +392,8 @@ struct WireDev {
     // of the cell's messages — [own message][entity messages in column order] — built once per tick
     uint32_t img_on;                    // the path exists for this world (no merged updates)
     uint32_t img_ok[2];                 // ... and its arena of kind f
-    uint32_t img_ncol;                  // update images per cell: 1 (the full column) or 1 + CHD_WCOLS (+ the window columns)
+    uint32_t img_ncol;                  // update images per cell: 1 (the full column) or 1 + CHD_WCOLS (+ the window columns; merge mode: one per window mask)
+    uint32_t *img_need;                 // merge mode: [img_ncol * ncell] the tick's descriptors copy from this image
     uint8_t *img[2];
     uint64_t img_cap[2];
     // indexed by image = col * ncell + cell (family 0: col < img_ncol; family 1: col 0)

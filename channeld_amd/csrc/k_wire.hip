@@ -1025,7 +1025,20 @@ void launch_wire_set_payloads(hipStream_t st, WireDev x, int full, int cell, uin
 // WINDOW COLUMN col - 1 (partially updating ticks: the entities with an update inside that window shape, k_window_columns) —,
 // f = 1 the full states (col 0 only).  Its k-th message is the entity at table position start + k (col 0) or the k-th entry of
 // the window column (channel id in ce_chan's column, slot in wcol_slot's).
-struct ImgSel { uint32_t f, col, c, start, n, ii; size_t e0; };  // ii: index into img_len / img_own / img_bad / img_off; e0: into img_end
+// In MERGE mode (CHD_WORLD_WIRE | CHD_WORLD_UPDATE_MASKS: a message carries the buffered updates its window selected) the
+// update images of a cell are per WINDOW MASK instead: col 1..9 = every entity of the cell with the updates of
+// wcol_mask(col - 1) merged — what a simple descriptor's window with that mask sends (k_fanout_plan_seg: the mask is the same
+// for every entity of the cell) —, built only where a descriptor of the tick asks for it (img_need); no own message in front
+// (a window with the spatial channel's own update is never simple in a masks world).
+struct ImgSel { uint32_t f, col, c, start, n, ii, mask; bool by_column; size_t e0; };  // ii: index into img_len / img_own / img_bad / img_off; e0: into img_end
+
+__device__ __forceinline__ uint32_t wcol_shape(uint32_t mask) {  // k with wcol_mask(k) == mask, else CHD_WCOLS
+    uint32_t r = CHD_WCOLS;
+#pragma unroll
+    for (uint32_t k = 0; k < CHD_WCOLS; k++)
+        if (mask == wcol_mask(k)) r = k;
+    return r;
+}
 
 __device__ __forceinline__ ImgSel img_sel(const WorldDev &w, const WireDev &x, uint32_t c, uint32_t y, uint32_t ncol) {
     ImgSel s;
@@ -1034,22 +1047,45 @@ __device__ __forceinline__ ImgSel img_sel(const WorldDev &w, const WireDev &x, u
     s.c = c;
     s.start = w.cell_start[c];
     s.n = w.cell_end[c] - s.start;
-    if (s.col) {
+    s.mask = 0;
+    s.by_column = false;
+    s.ii = s.col * x.ncell + c;
+    if (x.merge && !s.f) {
+        s.mask = s.col ? wcol_mask(s.col - 1u) : 0u;
+        if (!s.col || !x.img_need[s.ii]) s.n = 0;  // (column 0 has no meaning here)
+    } else if (s.col) {
         // a column the cell's common history covers is never built (k_window_columns) nor referenced (k_fanout_plan_seg)
         s.n = (w.cell_hand[c] & wcol_mask(s.col - 1u)) ? 0u : w.cell_wcnt[(size_t)(s.col - 1u) * x.ncell + c];
+        s.by_column = true;
     }
-    s.ii = s.col * x.ncell + c;
     s.e0 = (size_t)s.col * w.wcol_stride + s.start;
     return s;
 }
 __device__ __forceinline__ void img_entry(const WorldDev &w, const ImgSel &s, uint32_t k, uint32_t &slot, uint32_t &chan) {
-    if (s.col) {
+    if (s.by_column) {
         const size_t at = (size_t)s.col * w.wcol_stride + s.start + k;
         chan = w.ce_chan[at];
         slot = w.wcol_slot[at];
     } else {
         chan = w.ce_chan_view[s.start + k];
         slot = w.ce_slot[s.start + k];
+    }
+}
+
+// MERGE mode: which (mask, cell) images the tick's descriptors copy from.  One wave per connection, lanes over its descriptors.
+__global__ void __launch_bounds__(256) k_wire_img_need(WorldDev w, WireDev x) {
+    const uint32_t s = blockIdx.x * 4u + (threadIdx.x >> 6);
+    if (s >= w.S || !w.sub_alive[s] || w.rec_ub[s + 1] > w.recs_cap) return;
+    const uint32_t lane = threadIdx.x & 63u, ns = w.n_simple[s];
+    const size_t pbase = (size_t)s * w.capq;
+    for (uint32_t k = lane; k < ns; k += 64) {
+        const uint32_t info = w.seg_desc[pbase + k].w, c = w.seg_desc2[pbase + k].x;
+        const uint4 wm = w.seg_wm[pbase + k];
+        const uint32_t m4[4] = {wm.x, wm.y, wm.z, wm.w};
+        for (uint32_t j = 0; j < (info & SDW_NWIN); j++) {
+            const uint32_t sh = wcol_shape(m4[j]);
+            if (sh < CHD_WCOLS && sh + 1u < x.img_ncol) x.img_need[(size_t)(sh + 1u) * x.ncell + c] = 1u;
+        }
     }
 }
 
@@ -1064,9 +1100,11 @@ __global__ void __launch_bounds__(256) k_wire_img_sizes(DevGrid g, WorldDev w, W
     chd_fanout_rec r;
     r.conn = f << 31;
     r.channel = c + g.id_start;
-    const WireMsg own = wire_msg(w, x, r, CHD_POS_CELL | c, 0u);
+    const bool no_own = x.merge && !f;  // (merge mode: the update images carry no own message)
+    WireMsg own = wire_msg(w, x, r, CHD_POS_CELL | c, 0u);
+    if (no_own) own.entry = 0;
     uint32_t carry = own.entry;
-    uint32_t bad = own.entry == 0 ? 1u : 0u;  // (dropped by Send: the record path counts it)
+    uint32_t bad = (own.entry == 0 && !no_own) ? 1u : 0u;  // (dropped by Send: the record path counts it)
     __syncthreads();
     for (uint32_t i0 = 0; i0 < n; i0 += 256) {
         const uint32_t i = i0 + tid;
@@ -1077,7 +1115,7 @@ __global__ void __launch_bounds__(256) k_wire_img_sizes(DevGrid g, WorldDev w, W
             if (slot >= w.N) bad = 1;
             else {
                 r.channel = chan;
-                entry = wire_msg(w, x, r, slot, 0u).entry;
+                entry = wire_msg(w, x, r, slot, sel.mask).entry;
                 if (!entry) bad = 1;
             }
         }
@@ -1132,7 +1170,7 @@ __global__ void __launch_bounds__(256) k_wire_img_fill(DevGrid g, WorldDev w, Wi
         WireMsg m;
         m.chan = 0; m.any_len = 0; m.body_len = 0; m.mp_len = 0; m.entry = 0; m.pay = nullptr; m.mask = 0; m.value_len = 0; m.kind = 0;
         if (ch < 0) {
-            if (lane == 0) {
+            if (lane == 0 && !(x.merge && !f)) {
                 r.channel = c + g.id_start;
                 m = wire_msg(w, x, r, CHD_POS_CELL | c, 0u);
                 begin = 0;
@@ -1143,14 +1181,14 @@ __global__ void __launch_bounds__(256) k_wire_img_fill(DevGrid g, WorldDev w, Wi
             if (i < n) {
                 uint32_t slot;
                 img_entry(w, sel, i, slot, r.channel);
-                m = wire_msg(w, x, r, slot, 0u);
+                m = wire_msg(w, x, r, slot, sel.mask);
                 begin = x.img_end[f][sel.e0 + i] - m.entry;
                 live = true;
             }
         }
         if (live) {
             hl = wire_hdr_len(x, m, 0u);
-            pl = m.any_len;
+            pl = m.kind ? m.value_len : m.any_len;
         }
         wire_put_messages(x, stream, img, live, begin, hl, pl, m, 0u, 0u);
     }
@@ -1196,7 +1234,10 @@ __device__ __forceinline__ bool desc_geom(const WorldDev &w, const WireDev &x, u
     const uint32_t csz = w.cell_end[c] - G.cst;
     bool usable = d.y == G.cst + G.col * w.wcol_stride && G.col < x.img_ncol &&
                   d.z == (G.col ? w.cell_wcnt[(size_t)(G.col - 1u) * x.ncell + c] : csz);
-    if (d.w & SDW_NWIN) {
+    if (x.merge) {
+        // merge mode: one image per window mask (checked per window: desc_windows_merge)
+        if (G.col) usable = false;
+    } else if (d.w & SDW_NWIN) {
         const uint32_t ii = G.col * x.ncell + c;
         if (!x.img_ok[0] || x.img_bad[0][ii]) usable = false;
         G.off0 = x.img_off[0][ii]; G.len0 = x.img_len[0][ii]; G.own0 = x.img_own[0][ii];
@@ -1209,6 +1250,29 @@ __device__ __forceinline__ bool desc_geom(const WorldDev &w, const WireDev &x, u
         if ((uint64_t)G.off1 + G.len1 > x.img_cap[1]) usable = false;
     }
     return usable;
+}
+
+// merge mode: window j of a descriptor copies the image of its mask (wm: the descriptor's seg_wm); false = not usable
+__device__ __forceinline__ bool desc_window_merge(const WorldDev &w, const WireDev &x, uint32_t c, uint32_t mask, uint32_t &col, uint32_t &off, uint32_t &len) {
+    const uint32_t sh = wcol_shape(mask);
+    col = sh + 1u;
+    off = len = 0;
+    if (sh >= CHD_WCOLS || col >= x.img_ncol || !x.img_ok[0]) return false;
+    const size_t ii = (size_t)col * x.ncell + c;
+    if (!x.img_need[ii] || x.img_bad[0][ii]) return false;
+    off = x.img_off[0][ii];
+    len = x.img_len[0][ii];
+    return (uint64_t)off + len <= x.img_cap[0];
+}
+__device__ __forceinline__ bool desc_windows_merge_ok(const WorldDev &w, const WireDev &x, uint32_t c, uint32_t info, uint4 wm) {
+    const uint32_t m4[4] = {wm.x, wm.y, wm.z, wm.w};
+    bool ok = !(info & SDW_NONE) || (info & SDW_NWIN) == 0u;
+    for (uint32_t j = 0; j < (info & SDW_NWIN); j++) {
+        uint32_t col, off, len;
+        if ((info >> (SDW_OWN_SHIFT + j)) & 1u) ok = false;  // (never simple in a masks world)
+        if (!desc_window_merge(w, x, c, m4[j], col, off, len)) ok = false;
+    }
+    return ok;
 }
 
 template <bool EMIT>
@@ -1224,14 +1288,24 @@ __global__ void __launch_bounds__(256) k_wire_layout_img(DevGrid g, WorldDev w, 
     uint8_t *stream = EMIT ? x.bytes + woff : nullptr;
     uint4 *dout = EMIT ? x.cdesc + x.rank_ndesc[x.conn_rank[s]] : nullptr;  // (rank_ndesc was scanned in place)
 
+    // A packet opened by a record of the record path: k_wire_copy writes contiguous byte ranges that span the messages of a
+    // chunk — the tag's five bytes in front of that record lie inside such a range, so the record itself must carry the tag
+    // (rec_wtag: packet length << 16, as k_wire_layout leaves it); the direct write below serves the packets opened by an
+    // image range.
+    uint64_t pkt_first = ~0ull;   // record that opened the current packet (~0: an image range did, or nothing yet)
+    uint32_t pkt_first_len = 0;   // ... and its Any length (the low half of rec_wtag)
+    bool pkt_started = false;     // the current packet holds an entry
     auto close_packet = [&]() {
         if (EMIT && lane == 0) {  // the 5-byte tag in front of the packet (connection.go:683-687)
             uint8_t *t = stream + pkt_base;
             t[0] = 67; t[1] = 72; t[2] = (uint8_t)(pkt_used >> 8); t[3] = (uint8_t)pkt_used; t[4] = 0;
+            if (pkt_first != ~0ull) x.rec_wtag[pkt_first] = (pkt_used << 16) | pkt_first_len;
         }
         pkt_base += 5u + pkt_used;
         npk += 1;
         pkt_used = 0;
+        pkt_first = ~0ull;
+        pkt_started = false;
     };
     // The descriptors of a connection are contiguous, in stream order (consecutive ranges are adjacent in the stream: the
     // copy kernel's neighbouring waves fill whole 128-byte lines between them); the CONNECTIONS are ordered by the cell of
@@ -1243,6 +1317,7 @@ __global__ void __launch_bounds__(256) k_wire_layout_img(DevGrid g, WorldDev w, 
         }
         ndesc += 1;
         pkt_used += len;
+        pkt_started = true;
     };
     // bytes [a, b) of cell c's image f (off / own = image offset / own-message bytes; E = the entity messages' ends)
     auto piece = [&](uint32_t f, uint32_t off, uint32_t own, const uint32_t *__restrict__ E, uint32_t n, uint32_t a, uint32_t b, uint32_t ilen) {
@@ -1292,6 +1367,11 @@ __global__ void __launch_bounds__(256) k_wire_layout_img(DevGrid g, WorldDev w, 
             if (simple) {
                 usable = desc_geom(w, x, w.seg_desc[pbase + dfirst], w.seg_desc2[pbase + dfirst].x, G);
                 if (w.seg_desc[pbase + dfirst].x != rel) usable = false;
+                if (x.merge) {
+                    if (!desc_windows_merge_ok(w, x, G.c, G.info, w.seg_wm[pbase + dfirst])) usable = false;
+                    // DataFieldMasks make the typed merge the subscription's own: record path
+                    if (x.schema && ((w.pair_flags[pbase + p] >> PF_FIELD_MASK_SHIFT) & 0xFFu)) usable = false;
+                }
             }
             for (uint64_t act = __ballot(nrec != 0); act; act &= act - 1) {
                 const int L = __ffsll((unsigned long long)act) - 1;
@@ -1303,6 +1383,7 @@ __global__ void __launch_bounds__(256) k_wire_layout_img(DevGrid g, WorldDev w, 
                 for (uint32_t t = 1; ok && t < ndL; t++) {
                     DescGeom Gt;
                     ok = desc_geom(w, x, w.seg_desc[pbase + dfL + t], w.seg_desc2[pbase + dfL + t].x, Gt);
+                    if (ok && x.merge) ok = desc_windows_merge_ok(w, x, Gt.c, Gt.info, w.seg_wm[pbase + dfL + t]);
                 }
                 if (ok) {
                     for (uint32_t t = 0; t < ndL; t++) {
@@ -1319,6 +1400,16 @@ __global__ void __launch_bounds__(256) k_wire_layout_img(DevGrid g, WorldDev w, 
                         }
                         if (H.info & SDW_FIRST) piece(1u, H.off1, H.own1, x.img_end[1] + H.cst, H.n, 0u, H.len1, H.len1);
                         const uint32_t nw = H.info & SDW_NWIN;
+                        if (x.merge) {
+                            const uint4 wm = w.seg_wm[pbase + dfL + t];
+                            const uint32_t m4[4] = {wm.x, wm.y, wm.z, wm.w};
+                            for (uint32_t j = 0; j < nw; j++) {
+                                uint32_t col, off, len;
+                                (void)desc_window_merge(w, x, H.c, m4[j], col, off, len);
+                                piece(0u, off, 0u, x.img_end[0] + (size_t)col * w.wcol_stride + H.cst, H.n, 0u, len, len);
+                            }
+                            continue;
+                        }
                         const uint32_t *E0 = x.img_end[0] + (size_t)H.col * w.wcol_stride + H.cst;
                         for (uint32_t j = 0; j < nw; j++) {
                             const uint32_t a = ((H.info >> (SDW_OWN_SHIFT + j)) & 1u) ? 0u : H.own0;
@@ -1404,6 +1495,15 @@ __global__ void __launch_bounds__(256) k_wire_layout_img(DevGrid g, WorldDev w, 
                         if (EMIT && mine && lane < fo && entry != 0) {
                             x.rec_woff[seg + i] = (uint32_t)(pkt_base + 5u + relb - entry);
                             x.rec_wtag[seg + i] = alen;
+                        }
+                        const uint64_t firsts = __ballot(mine && lane < fo && entry != 0);
+                        if (firsts) {
+                            if (!pkt_started) {
+                                const uint32_t fl = (uint32_t)__ffsll((unsigned long long)firsts) - 1u;
+                                pkt_first = seg + i0 + fl;
+                                pkt_first_len = (uint32_t)__shfl((int)alen, (int)fl);
+                            }
+                            pkt_started = true;
                         }
                         const uint32_t cum_f = fo < 64 ? __shfl(cum - entry, (int)fo) : __shfl(cum, 63);
                         pkt_used += cum_f - cum_before_start;
@@ -1604,7 +1704,12 @@ void launch_wire_conn_order(hipStream_t st, WorldDev w, WireDev x) {
 
 void launch_wire_images(hipStream_t st, DevGrid g, WorldDev w, WireDev x) {
     if (!g.ncell) return;
-    const uint32_t ncol = w.wcol_on ? x.img_ncol : 1u;  // update images per cell: the full column (+ the window columns of this tick)
+    // update images per cell: the full column (+ the window columns of a partially updating tick; merge mode: one per window mask)
+    const uint32_t ncol = (w.wcol_on || x.merge) ? x.img_ncol : 1u;
+    if (x.merge) {
+        (void)hipMemsetAsync(x.img_need, 0, sizeof(uint32_t) * (size_t)x.img_ncol * g.ncell, st);
+        hipLaunchKernelGGL(k_wire_img_need, dim3((w.S + 3) / 4), dim3(256), 0, st, w, x);
+    }
     hipLaunchKernelGGL(k_wire_img_sizes, dim3(g.ncell, ncol + 1u), dim3(256), 0, st, g, w, x, ncol);
     launch_scan_u32_inplace(st, x.img_off[0], ncol * g.ncell);
     launch_scan_u32_inplace(st, x.img_off[1], g.ncell);

@@ -8,6 +8,7 @@ oracle/wire.py, which tests/test_wire_oracle.py pins against packets serialized 
 reference's own protobuf descriptor.  WHICH messages go to whom is the records' parity
 (tests/test_gpu_world.py); here the records of each tick are the message list."""
 import json
+import os
 
 import numpy as np
 import pytest
@@ -161,7 +162,8 @@ def test_wire_benchmark_grid_position_updates(amd, mode):
     assert tb > 1_000_000 and td == 0
 
 
-def test_wire_merged_updates_for_slow_subscribers(amd):
+@pytest.mark.parametrize("mode,dense", [(CONN_MAJOR, False), (DESC, False), (DESC, True)])
+def test_wire_merged_updates_for_slow_subscribers(amd, mode, dense):
     """SURVEY 8f-3 on the device: a WIRE | UPDATE_MASKS world builds every message from the buffered updates the
     subscriber's window selected (data.go:225-269) — Any{type_url, value = those updates' bytes, oldest first}.  Sparse
     updates and 33 ms ticks so that 20 / 50 / 100 ms subscriptions merge different sets (one, two, three or four ticks'
@@ -173,10 +175,13 @@ def test_wire_merged_updates_for_slow_subscribers(amd):
     sw = synth.SynthWorld(synth.WorldSpec(cfg, N, S, 0xC0FFEE45, tick_ms=33))
     ctl = amd.StaticGrid2DSpatialController()
     assert ctl.LoadConfig(json.dumps(cfg).encode(), strict=False) is None
-    w = amd.SpatialWorld(ctl, N, S, flags=CONN_MAJOR | WIRE | MASKS, max_records=1 << 21, wire_max_update_len=64, wire_max_full_len=256)
+    # DESC: the fan-out's descriptor path; dense: every entity updates every tick, so that a window's mask is the same for every
+    # entity of a cell and its bytes come from the (mask, cell) image (k_wire_layout_img, merge mode)
+    w = amd.SpatialWorld(ctl, N, S, flags=mode | WIRE | MASKS, max_records=1 << 21, wire_max_update_len=64, wire_max_full_len=256)
     w.spawn(None, sw.chan_id, sw.x, sw.z, sw.flags, sw.sender)
     w.add_subscribers(None, sw.sub_conn)
     rng = np.random.default_rng(45)
+    image_ranges = 0
     ncell = ctl.GridCols * ctl.GridRows
     url_e, url_c = b"type.googleapis.com/tpspb.EntityChannelData", b"type.googleapis.com/unrealpb.SpatialChannelData"
     w.wire_set_type_url(False, url_e)
@@ -189,7 +194,7 @@ def test_wire_merged_updates_for_slow_subscribers(amd):
     merged2 = merged3 = 0
     for k in range(14):
         sw.step()
-        idx = np.sort(rng.choice(N, N // 2, replace=False)).astype(np.uint32) if k % 3 else np.arange(N, dtype=np.uint32)
+        idx = np.sort(rng.choice(N, N // 2, replace=False)).astype(np.uint32) if (k % 3 and not dense) else np.arange(N, dtype=np.uint32)
         pay = [any_bytes(rng, rng.integers(0, 60)) for _ in idx]
         for i, b in zip(idx, pay):
             upd_e[(int(i), k)] = b
@@ -203,6 +208,7 @@ def test_wire_merged_updates_for_slow_subscribers(amd):
                      cell_upd_sender=np.full(len(cu), 5, dtype=np.uint32), records_cap=1 << 21)
         assert res.overflow == 0 and res.history_overflow == 0
         nbytes, npackets, ndropped = w.wire_build()
+        image_ranges += w.wire_build_info()[0]
         off, npk, data = w.wire_fetch()
         assert int(off[S]) == nbytes == len(data) and ndropped == 0
         for s in range(S):
@@ -223,9 +229,32 @@ def test_wire_merged_updates_for_slow_subscribers(amd):
                 packs.append(wire.fanout_message_pack(ch, body))
             want, counts = wire.flush_stream(packs)
             got = data[int(off[s]):int(off[s + 1])].tobytes()
+            if got != want and os.environ.get("CHD_TEST_DEBUG"):
+                c0 = counts[0]
+                recs_s, masks_s = res.records[a:a + n], res.record_masks[a:a + n]
+                print("DEBUG tick", k, "slot", s, "len", len(got), len(want), "npk", int(npk[s]), len(counts), "first packet msgs", c0)
+                for q in range(max(0, c0 - 3), min(n, c0 + 3)):
+                    print("  rec", q, hex(int(recs_s[q]["conn"])), hex(int(recs_s[q]["channel"])), bin(int(masks_s[q])), "pack len", len(packs[q]))
+                d0 = next(i for i in range(min(len(got), len(want))) if got[i] != want[i])
+                print("  first diff", d0, "want", want[d0 - 24:d0 + 16].hex(), "got", got[d0 - 24:d0 + 16].hex())
+                tags = [i for i in range(len(got) - 4) if got[i] == 67 and got[i + 1] == 72 and got[i + 4] == 0]
+                print("  got CH.. candidates", tags[:12], "want", [i for i in range(len(want) - 4) if want[i] == 67 and want[i + 1] == 72 and want[i + 4] == 0][:12])
+                acc = 5
+                for q in range(n):
+                    e = 1 + (2 if len(packs[q]) >= 128 else 1) + len(packs[q])
+                    if c0 - 4 <= q <= c0 + 1:
+                        print("  msg", q, "starts at", acc, "entry", e)
+                    acc += e
+                segs = w.fetch_segments()
+                so = segs["conn_seg_off"]
+                tot = 0
+                for g in segs["segments"][int(so[s]):int(so[s + 1])]:
+                    print("  seg", hex(int(g["channel"])), int(g["off"]), hex(int(g["n_info"])), int(g["n_records"]), "records before", tot)
+                    tot += int(g["n_records"])
             assert got == want, f"tick {k} slot {s}: merged stream bytes ({len(got)} vs {len(want)})"
             assert int(npk[s]) == len(counts)
     assert merged2 > 1000 and merged3 > 10  # windows that merged two / three and more ticks' updates were exercised
+    assert (image_ranges > (800 if dense else 200)) == (mode == DESC), image_ranges  # (sparse: first fan-outs and the complete ticks)
 
 
 def test_handover_messages_on_the_device(amd):
@@ -288,7 +317,8 @@ def test_handover_messages_on_the_device(amd):
     assert n_total > 100 and n_group > 5 and n_ctx > 5
 
 
-def test_typed_merge_is_byte_identical_to_the_reference_marshal(amd):
+@pytest.mark.parametrize("mode,dense", [(CONN_MAJOR, False), (DESC, True)])
+def test_typed_merge_is_byte_identical_to_the_reference_marshal(amd, mode, dense):
     """VERDICT r2 #9 / SURVEY 8f-3: with CHD_MERGE_SCHEMA_TPS_ENTITY_MOVEMENT the accumulated update of a slow subscriber is
     merged FIELD BY FIELD on the device and marshalled as Go marshals it — proto.Merge of the first selected update, tpspb's
     EntityChannelData.Merge for the rest (data.go:249-253, tpspb/data.go:227-252), fmutils.Filter with the subscription's
@@ -304,10 +334,12 @@ def test_typed_merge_is_byte_identical_to_the_reference_marshal(amd):
     sw = synth.SynthWorld(synth.WorldSpec(cfg, N, S, 0xC0FFEE46, tick_ms=33))
     ctl = amd.StaticGrid2DSpatialController()
     assert ctl.LoadConfig(json.dumps(cfg).encode(), strict=False) is None
-    w = amd.SpatialWorld(ctl, N, S, flags=CONN_MAJOR | WIRE | MASKS, max_records=1 << 21, wire_max_update_len=96, wire_max_full_len=256)
+    # (DESC + dense: the typed merge inside the (mask, cell) images; subscriptions with DataFieldMasks keep the record path)
+    w = amd.SpatialWorld(ctl, N, S, flags=mode | WIRE | MASKS, max_records=1 << 21, wire_max_update_len=96, wire_max_full_len=256)
     w.spawn(None, sw.chan_id, sw.x, sw.z, sw.flags, sw.sender)
     w.add_subscribers(None, sw.sub_conn)
     w.wire_set_merge_schema(1)
+    image_ranges = 0
     rng = np.random.default_rng(46)
     ncell = ctl.GridCols * ctl.GridRows
     url_e, url_c = b"type.googleapis.com/tpspb.EntityChannelData", b"type.googleapis.com/unrealpb.SpatialChannelData"
@@ -323,7 +355,7 @@ def test_typed_merge_is_byte_identical_to_the_reference_marshal(amd):
     typed2 = typed_masked = generic = 0
     for k in range(14):
         sw.step()
-        idx = np.sort(rng.choice(N, N // 2, replace=False)).astype(np.uint32) if k % 3 else np.arange(N, dtype=np.uint32)
+        idx = np.sort(rng.choice(N, N // 2, replace=False)).astype(np.uint32) if (k % 3 and not dense) else np.arange(N, dtype=np.uint32)
         pay = [foreign + merge.make_update(rng) if rng.random() < 0.03 else merge.make_update(rng) for _ in idx]
         for i, b in zip(idx, pay):
             upd_e[(int(i), k)] = b
@@ -331,6 +363,7 @@ def test_typed_merge_is_byte_identical_to_the_reference_marshal(amd):
         res = w.tick(sw.now_ns(), upd_idx=idx, upd_x=sw.x[idx], upd_z=sw.z[idx], queries=sw.queries(), records_cap=1 << 21)
         assert res.overflow == 0 and res.history_overflow == 0
         nbytes, npackets, ndropped = w.wire_build()
+        image_ranges += w.wire_build_info()[0]
         off, npk, data = w.wire_fetch()
         member = w.entity_state()[1]  # the spatial channel whose entity map holds each entity
         for s in range(S):
@@ -373,3 +406,4 @@ def test_typed_merge_is_byte_identical_to_the_reference_marshal(amd):
                     fmask[(s, int(c))] = m
             w.set_sub_options(sw.now_ns(), opts)
     assert typed2 > 1000 and typed_masked > 300 and generic > 20, (typed2, typed_masked, generic)
+    assert (image_ranges > 200) == (mode == DESC), image_ranges
