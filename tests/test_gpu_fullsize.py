@@ -344,19 +344,25 @@ def test_config_b_segments_expand_to_the_device_digest(amd):
     assert cnt > 50_000_000 and nbytes < 8 * cnt / 50, compact
 
 
-def test_config_b_wire_streams_from_images_equal_the_record_path(amd, monkeypatch):
-    """SURVEY 8f-1 at full size: the packet streams of config B's ticks (5 - 8 GB each) built from the fan-out descriptors
+@pytest.mark.parametrize("variant", ["full", "partial", "merged"])
+def test_config_b_wire_streams_from_images_equal_the_record_path(amd, monkeypatch, variant):
+    """SURVEY 8f-1 at full size: the packet streams of config B's ticks (3 - 11 GB each) built from the fan-out descriptors
     (per-cell message images + copy ranges, k_wire_layout_img) equal, byte for byte, the streams the record path builds for
     the same ticks (k_wire_layout + copy kernels, CHD_WIRE_IMAGES=0) — and the record path is what tests/test_gpu_wire.py
     pins to the wire oracle.  Payload lengths vary per channel (20 - 120 bytes, full states 100 - 400) so that message
-    boundaries, packet cuts and the 16-byte alignment of every copied range differ from connection to connection."""
-    N, S, WIRE = 100_000, 10_000, 8
+    boundaries, packet cuts and the 16-byte alignment of every copied range differ from connection to connection.
+    full: every entity updates every tick.  partial: 90 % do (the image world keeps the window columns and builds their
+    images, the record-path world takes the one-launch filtering emit: same records, same order).  merged: a masks world,
+    every message the merge of the updates its window selected (one image per window mask and cell)."""
+    N, S, WIRE, MASKS = 100_000, 10_000, 8, 32
     cfg = synth.load_config("spatial_static_benchmark.json")
     rng = np.random.default_rng(0xB17E5)
     upd_len = rng.integers(20, 121, N)
     full_len = rng.integers(100, 401, N)
     blob = rng.integers(0, 256, 400, dtype=np.uint8).tobytes() * 2
     ncell = int(cfg["GridCols"]) * int(cfg["GridRows"])
+    merged = variant == "merged"
+    upd_payloads = [blob[i % 37: i % 37 + (int(upd_len[i]) if not merged else 12 + i % 30)] for i in range(N)]
 
     def make(images):
         if images:
@@ -366,22 +372,33 @@ def test_config_b_wire_streams_from_images_equal_the_record_path(amd, monkeypatc
         sw = synth.SynthWorld(synth.WorldSpec(cfg, N, S, 0xC0FFEE51))
         ctl = amd.StaticGrid2DSpatialController()
         assert ctl.LoadConfig(json.dumps(cfg).encode(), strict=False) is None
-        w = amd.SpatialWorld(ctl, N, S, flags=WIRE, max_records=400_000_000, wire_max_update_len=128, wire_max_full_len=400)
+        w = amd.SpatialWorld(ctl, N, S, flags=WIRE | (MASKS if merged else 0), max_records=400_000_000, wire_max_update_len=128, wire_max_full_len=400)
         w.spawn(None, sw.chan_id, sw.x, sw.z, sw.flags, sw.sender)
         w.add_subscribers(None, sw.sub_conn)
-        w.wire_set_payloads(0, np.arange(N), [blob[i % 37: i % 37 + int(upd_len[i])] for i in range(N)])
+        if merged:
+            w.wire_set_type_url(False, b"type.googleapis.com/tpspb.EntityChannelData")
+            w.wire_set_type_url(True, b"type.googleapis.com/unrealpb.SpatialChannelData")
+        else:
+            w.wire_set_payloads(0, np.arange(N), upd_payloads)
         w.wire_set_payloads(1, np.arange(N), [blob[i % 41: i % 41 + int(full_len[i])] for i in range(N)])
         w.wire_set_payloads(2, 0x10000 + np.arange(ncell), [blob[c % 29: c % 29 + 40 + c % 50] for c in range(ncell)])
         w.wire_set_payloads(3, 0x10000 + np.arange(ncell), [blob[c % 31: c % 31 + 200 + c % 90] for c in range(ncell)])
         return sw, ctl, w
 
     worlds = [make(True), make(False)]
+    pick = np.random.default_rng(0x9A87)
     checked = 0
     for k in range(6):
+        idx = None
+        if variant == "partial" and k >= 2:
+            idx = np.flatnonzero(pick.random(N) < 0.9).astype(np.uint32)
         outs = []
         for sw, _ctl, w in worlds:
             sw.step()
-            w.tick(sw.now_ns(), upd_x=sw.x, upd_z=sw.z, queries=sw.queries(), want_records=False)
+            if merged:
+                w.wire_set_payloads(0, np.arange(N), upd_payloads)  # (this tick's update messages: the tick's ring slot)
+            w.tick(sw.now_ns(), upd_idx=idx, upd_x=sw.x if idx is None else sw.x[idx], upd_z=sw.z if idx is None else sw.z[idx],
+                   queries=sw.queries(), want_records=False)
             if k < 3:
                 continue  # (the first fan-outs are full states of ~10^8 channels: tens of GB of packets)
             nbytes, npackets, ndropped = w.wire_build()
@@ -390,7 +407,7 @@ def test_config_b_wire_streams_from_images_equal_the_record_path(amd, monkeypatc
             continue
         (nb0, np0, nd0, info0, (off0, npk0, data0)), (nb1, np1, nd1, info1, (off1, npk1, data1)) = outs
         assert info0[0] > 100_000 and info1[0] == 0, "one world takes the image path, the other the record path"
-        assert (nb0, np0, nd0) == (nb1, np1, nd1) and nb0 > 3_000_000_000
+        assert (nb0, np0, nd0) == (nb1, np1, nd1) and nb0 > 2_000_000_000
         assert np.array_equal(off0, off1) and np.array_equal(npk0, npk1)
         step = 1 << 28
         for a in range(0, nb0, step):
