@@ -30,6 +30,9 @@ if [ -n "$DIAG" ]; then
   for f in 0.98 0.9 0.5; do timeout 120 python bench.py --only-timed --steps 60 --warmup 10 --update-frac $f > $O/diag_update_frac_$f.json 2>> $O/diag.err; done
   timeout 120 python bench.py --only-timed --steps 60 --warmup 10 --update-masks > $O/diag_update_masks.json 2>> $O/diag.err
   trace uf09 10 --steps 50 --warmup 10 --only-timed --update-frac 0.9
+  # the wire builder on a partially updating world and with merged updates (bench.py --wire N: "wire" in the line)
+  timeout 120 python bench.py --only-timed --steps 12 --warmup 6 --wire 6 --update-frac 0.9 > $O/diag_wire_update_frac_0.9.json 2>> $O/diag.err
+  timeout 120 python bench.py --only-timed --steps 12 --warmup 6 --wire 6 --update-masks > $O/diag_wire_merged_updates.json 2>> $O/diag.err
 fi
 CHD_BENCH_SHARE_GPU=1 CHD_DIST_BACKEND=gloo timeout 200 python bench.py --gpus 2 --steps 20 --warmup 5 --verify 3 --latency-steps 0 --no-cpu --entities 50000 --subs 5000 --max-records 400000000 > $O/bench_2ranks_shared_gpu_verified.json 2> $O/bench_2ranks.err
 timeout -s KILL ${PYTEST_LIMIT:-420} python -m pytest tests -m gpu -q -p no:cacheprovider --durations=8 "$@" > $O/pytest_gpu.log 2>&1; echo "pytest rc=$?" >> $O/pytest_gpu.log
