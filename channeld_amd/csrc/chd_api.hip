@@ -1064,9 +1064,9 @@ int chd_world_create(chd_ctx *ctx, const chd_world_cfg *cfg) {
                 TRY(walloc(ctx, &x.img_own[k], ni));
                 TRY(walloc(ctx, &x.img_bad[k], ni));
                 TRY(walloc(ctx, &x.img_end[k], k == 0 ? (size_t)x.img_ncol * d.wcol_stride + 520 : N + 2));
-                if (k == 0 && x.merge) TRY(walloc(ctx, &x.img_need, ni));
+                if (k == 0) TRY(walloc(ctx, &x.img_need, ni + C));
             }
-            if ((!x.img_ok[0] && !x.img_ok[1]) || (x.merge && (!x.img_ok[0] || x.img_ncol == 1u))) x.img_on = 0;
+            if (!x.img_ok[0] || (x.merge && x.img_ncol == 1u)) x.img_on = 0;  // (the update images are the point; full states alone are not worth the path)
             if (x.img_on) {
                 // (see WorldDev::seg_no_pos) — and with them the window columns of partially updating ticks stay available
                 d.seg_no_pos = 1;
@@ -2342,6 +2342,7 @@ int chd_wire_build(chd_ctx *ctx, uint64_t *total_bytes, uint64_t *total_packets,
             HIPCHK(hipMemsetAsync(W.x.cell_dcnt, 0, ((size_t)W.x.ncell * W.x.dpad + 1) * sizeof(uint32_t), st));
             launch_wire_images(st, ctx->g, d, W.x);
             launch_wire_layout_img(st, ctx->g, d, W.x, false);
+            launch_wire_images_fill(st, ctx->g, d, W.x);
             launch_wire_conn_order(st, d, W.x);
         } else {
             launch_wire_layout(st, d, W.x);

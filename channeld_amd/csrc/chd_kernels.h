@@ -393,7 +393,7 @@ struct WireDev {
     uint32_t img_on;                    // the path exists for this world (no merged updates)
     uint32_t img_ok[2];                 // ... and its arena of kind f
     uint32_t img_ncol;                  // update images per cell: 1 (the full column) or 1 + CHD_WCOLS (+ the window columns; merge mode: one per window mask)
-    uint32_t *img_need;                 // merge mode: [img_ncol * ncell] the tick's descriptors copy from this image
+    uint32_t *img_need;                 // [(img_ncol + 1) * ncell] the tick's descriptors copy from this image (the last ncell: the full-state images)
     uint8_t *img[2];
     uint64_t img_cap[2];
     // indexed by image = col * ncell + cell (family 0: col < img_ncol; family 1: col 0)
@@ -411,6 +411,7 @@ struct WireDev {
     uint32_t *cp_ticket;                // k_wire_copy_img's ticket counter
 };
 void launch_wire_images(hipStream_t st, DevGrid g, WorldDev w, WireDev x);
+void launch_wire_images_fill(hipStream_t st, DevGrid g, WorldDev w, WireDev x);
 void launch_wire_layout_img(hipStream_t st, DevGrid g, WorldDev w, WireDev x, bool emit);
 void launch_wire_conn_order(hipStream_t st, WorldDev w, WireDev x);
 void launch_wire_copy_img(hipStream_t st, WorldDev w, WireDev x, uint32_t waves);

@@ -1157,6 +1157,7 @@ __global__ void __launch_bounds__(256) k_wire_img_fill(DevGrid g, WorldDev w, Wi
     const uint32_t f = sel.f, n = sel.n;
     const uint32_t wv = (threadIdx.x >> 6) + 4u * part;
     if (x.img_bad[f][sel.ii] || !x.img_len[f][sel.ii]) return;
+    if (!x.img_need[f ? (size_t)x.img_ncol * x.ncell + c : sel.ii]) return;  // (no descriptor of the tick copies from it)
     const uint64_t off = x.img_off[f][sel.ii];
     if (off + x.img_len[f][sel.ii] > x.img_cap[f]) return;  // (never: the arena is sized for the worst case; the layout checks the same)
     uint8_t *stream = x.img[f] + off;
@@ -1398,6 +1399,11 @@ __global__ void __launch_bounds__(256) k_wire_layout_img(DevGrid g, WorldDev w, 
                         } else {
                             (void)desc_geom(w, x, w.seg_desc[pbase + dfL + t], w.seg_desc2[pbase + dfL + t].x, H);
                         }
+                        // (the sizing pass says which images the tick reads: k_wire_img_fill builds only those)
+                        if (!EMIT && lane == 0) {
+                            if (H.info & SDW_FIRST) x.img_need[(size_t)x.img_ncol * x.ncell + H.c] = 1u;
+                            if (!x.merge && (H.info & SDW_NWIN)) x.img_need[(size_t)H.col * x.ncell + H.c] = 1u;
+                        }
                         if (H.info & SDW_FIRST) piece(1u, H.off1, H.own1, x.img_end[1] + H.cst, H.n, 0u, H.len1, H.len1);
                         const uint32_t nw = H.info & SDW_NWIN;
                         if (x.merge) {
@@ -1560,18 +1566,24 @@ __device__ __forceinline__ CpRange cp_range(const WireDev &x, uint4 d) {
     return r;
 }
 
+// 32 threads per range: thread j < 16 the j-th byte in front of the body, thread 16 + j the j-th byte behind it (one
+// thread per range walking up to 30 bytes took 54 us: its byte loads and stores serialise)
 __global__ void __launch_bounds__(256) k_wire_copy_ends(WorldDev w, WireDev x) {
     if (!wire_img_fits(w, x)) return;
     const uint32_t ndesc = x.rank_ndesc[w.S];
-    for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < ndesc; i += gridDim.x * 256u) {
-    const uint4 d = x.cdesc[i];
-    uint8_t *dst = x.bytes + (((uint64_t)d.y << 32) | d.x);
-    const uint8_t *src = x.img[d.z >> 31] + (d.z & 0x7FFFFFFFu);
-    const uint32_t len = d.w;
-    const uint32_t head = min((16u - (uint32_t)((uintptr_t)dst & 15u)) & 15u, len);
-    const uint32_t done = head + (((len - head) >> 4) << 4);
-    for (uint32_t k = 0; k < head; k++) dst[k] = src[k];
-    for (uint32_t k = done; k < len; k++) dst[k] = src[k];
+    const uint32_t j = threadIdx.x & 31u;
+    for (uint32_t i = blockIdx.x * 8u + (threadIdx.x >> 5); i < ndesc; i += gridDim.x * 8u) {
+        const uint4 d = x.cdesc[i];
+        uint8_t *dst = x.bytes + (((uint64_t)d.y << 32) | d.x);
+        const uint8_t *src = x.img[d.z >> 31] + (d.z & 0x7FFFFFFFu);
+        const uint32_t len = d.w;
+        const uint32_t head = min((16u - (uint32_t)((uintptr_t)dst & 15u)) & 15u, len);
+        const uint32_t done = head + (((len - head) >> 4) << 4);
+        if (j < 16u) {
+            if (j < head) dst[j] = src[j];
+        } else if (done + (j - 16u) < len) {
+            dst[done + (j - 16u)] = src[done + (j - 16u)];
+        }
     }
 }
 
@@ -1702,17 +1714,26 @@ void launch_wire_conn_order(hipStream_t st, WorldDev w, WireDev x) {
     launch_scan_u32_inplace(st, x.rank_ndesc, w.S);
 }
 
+static uint32_t wire_image_columns(const WorldDev &w, const WireDev &x) {
+    // update images per cell: the full column (+ the window columns of a partially updating tick; merge mode: one per window mask)
+    return (w.wcol_on || x.merge) ? x.img_ncol : 1u;
+}
+
+// the message boundaries and lengths of every image (the layout needs them) ...
 void launch_wire_images(hipStream_t st, DevGrid g, WorldDev w, WireDev x) {
     if (!g.ncell) return;
-    // update images per cell: the full column (+ the window columns of a partially updating tick; merge mode: one per window mask)
-    const uint32_t ncol = (w.wcol_on || x.merge) ? x.img_ncol : 1u;
-    if (x.merge) {
-        (void)hipMemsetAsync(x.img_need, 0, sizeof(uint32_t) * (size_t)x.img_ncol * g.ncell, st);
-        hipLaunchKernelGGL(k_wire_img_need, dim3((w.S + 3) / 4), dim3(256), 0, st, w, x);
-    }
+    const uint32_t ncol = wire_image_columns(w, x);
+    (void)hipMemsetAsync(x.img_need, 0, sizeof(uint32_t) * ((size_t)x.img_ncol + 1u) * g.ncell, st);
+    if (x.merge) hipLaunchKernelGGL(k_wire_img_need, dim3((w.S + 3) / 4), dim3(256), 0, st, w, x);
     hipLaunchKernelGGL(k_wire_img_sizes, dim3(g.ncell, ncol + 1u), dim3(256), 0, st, g, w, x, ncol);
     launch_scan_u32_inplace(st, x.img_off[0], ncol * g.ncell);
     launch_scan_u32_inplace(st, x.img_off[1], g.ncell);
+}
+
+// ... and, after the sizing pass of the layout has marked them (img_need), the bytes of the images the tick copies from
+void launch_wire_images_fill(hipStream_t st, DevGrid g, WorldDev w, WireDev x) {
+    if (!g.ncell) return;
+    const uint32_t ncol = wire_image_columns(w, x);
     hipLaunchKernelGGL(k_wire_img_fill, dim3(g.ncell, (ncol + 1u) * WIRE_FILL_SPLIT), dim3(256), 0, st, g, w, x, ncol);
 }
 
@@ -1727,7 +1748,7 @@ void launch_wire_copy_img(hipStream_t st, WorldDev w, WireDev x, uint32_t waves)
     waves *= mult ? mult : 1u;
     static const bool nt = [] { const char *e = getenv("CHD_WIRE_COPY_NT"); return e && e[0] == '1'; }();
     // (everything sized on the device: the descriptor count and the list of record-path connections are not known to the host yet)
-    hipLaunchKernelGGL(k_wire_copy_ends, dim3(2048), dim3(256), 0, st, w, x);
+    hipLaunchKernelGGL(k_wire_copy_ends, dim3(16384), dim3(256), 0, st, w, x);
     const uint32_t wgs = waves / 4u ? waves / 4u : 1u;  // (four waves each)
     if (nt) hipLaunchKernelGGL(k_wire_copy_img<true>, dim3(wgs), dim3(256), 0, st, w, x);
     else hipLaunchKernelGGL(k_wire_copy_img<false>, dim3(wgs), dim3(256), 0, st, w, x);
