@@ -1850,6 +1850,8 @@ int chd_tick(chd_ctx *ctx, const chd_tick_in *in, chd_tick_out *out) {
     const size_t nu = in->n_updates, nq = in->n_queries, nc = in->n_cell_updates, ns = in->n_spots_total;
     if (nu && (!in->upd_x || !in->upd_z)) return fail(ctx, CHD_E_INVAL, "tick: NULL update positions");
     if (nq && !in->queries) return fail(ctx, CHD_E_INVAL, "tick: NULL queries");
+    if (nc && (!in->cell_upd_channel || !in->cell_upd_sender)) return fail(ctx, CHD_E_INVAL, "tick: NULL cell updates");
+    if (ns && (!in->spot_x || !in->spot_z)) return fail(ctx, CHD_E_INVAL, "tick: NULL spot coordinates");
     if (in->upd_idx)
         for (size_t i = 0; i < nu; i++)
             if (in->upd_idx[i] >= ctx->w.d.N) return fail(ctx, CHD_E_INVAL, "tick: entity slot %u out of range", in->upd_idx[i]);
@@ -2317,10 +2319,10 @@ int chd_handover_messages(chd_ctx *ctx, uint32_t n_handovers, uint32_t *offsets,
 int chd_wire_build(chd_ctx *ctx, uint64_t *total_bytes, uint64_t *total_packets, uint32_t *dropped) {
     NEED_WORLD();
     World &W = ctx->w;
+    std::lock_guard<std::mutex> lk(ctx->mu);
     if (!W.wire) return fail(ctx, CHD_E_STATE, "the world was created without CHD_WORLD_WIRE");
     if (!W.ticked) return fail(ctx, CHD_E_STATE, "no tick to build the wire buffers of");
     if (W.slot_mode == 2) return fail(ctx, CHD_E_STATE, "wire buffers are not available on region-sharded worlds yet");
-    std::lock_guard<std::mutex> lk(ctx->mu);
     TRY(bind(ctx));
     WorldDev &d = W.d;
     hipStream_t st = ctx->stream;
@@ -2415,8 +2417,8 @@ int chd_wire_build(chd_ctx *ctx, uint64_t *total_bytes, uint64_t *total_packets,
 int chd_wire_build_info(chd_ctx *ctx, uint64_t *n_image_ranges, uint32_t *n_record_path_connections) {
     NEED_WORLD();
     World &W = ctx->w;
-    if (!W.wire_built) return fail(ctx, CHD_E_STATE, "chd_wire_build has not run for the last tick");
     std::lock_guard<std::mutex> lk(ctx->mu);
+    if (!W.wire_built) return fail(ctx, CHD_E_STATE, "chd_wire_build has not run for the last tick");
     if (n_image_ranges) *n_image_ranges = W.wire_ranges;
     if (n_record_path_connections) *n_record_path_connections = W.wire_slow_conns;
     return CHD_OK;
@@ -2425,9 +2427,9 @@ int chd_wire_build_info(chd_ctx *ctx, uint64_t *n_image_ranges, uint32_t *n_reco
 int chd_wire_fetch(chd_ctx *ctx, uint64_t *conn_off, uint32_t *conn_packets, uint8_t *bytes, uint64_t cap) {
     NEED_WORLD();
     World &W = ctx->w;
-    if (!W.wire_built) return fail(ctx, CHD_E_STATE, "chd_wire_build has not run for the last tick");
     if (!conn_off) return fail(ctx, CHD_E_INVAL, "chd_wire_fetch: NULL conn_off");
     std::lock_guard<std::mutex> lk(ctx->mu);
+    if (!W.wire_built) return fail(ctx, CHD_E_STATE, "chd_wire_build has not run for the last tick");
     TRY(bind(ctx));
     TRY(down(ctx, conn_off, W.x.conn_woff, sizeof(uint64_t) * ((size_t)W.d.S + 1)));
     if (conn_packets) TRY(down(ctx, conn_packets, W.x.conn_npk, sizeof(uint32_t) * W.d.S));

@@ -37,6 +37,7 @@
 // HBM-bound: 8 B written per record (the stream) + the L2/MALL-resident cell
 // tables read; no MFMA — this is gather/compaction, not a contraction.
 #include <cstdlib>
+#include <cstring>
 
 #include "chd_kernels.h"
 
@@ -883,6 +884,10 @@ typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
 #ifndef FO_SEG_WAVES
 #define FO_SEG_WAVES 2   // waves per connection in k_fanout_emit_seg
 #endif
+#ifndef FO_SEG_TAIL_PCT
+#define FO_SEG_TAIL_PCT 10  // k_fanout_emit_seg: the last FO_SEG_TAIL_PCT % of the connections are cut into 2^FO_SEG_TAIL_SH pieces (CHD_SEG_TAIL)
+#define FO_SEG_TAIL_SH 2
+#endif
 #ifndef FO_SEG_OCC
 #define FO_SEG_OCC 4     // waves per SIMD the register allocator is asked for (what limits this kernel is bytes in flight per wave, not waves)
 #endif
@@ -1177,8 +1182,14 @@ extern "C" int chd_debug_trace(unsigned long long *out, unsigned n) {
 // MASKS (CHD_WORLD_UPDATE_MASKS): also the per-record merged-updates mask — on this path a constant per window, the window's
 // own mask (the plan took the subscription only if EVERY entity of the cell has an update at EVERY stamp of the window).
 template <int WAVES, bool MASKS = false>
-__global__ void __launch_bounds__(64, FO_SEG_OCC) k_fanout_emit_seg(DevGrid g, WorldDev w, uint32_t n_tickets) {
+__global__ void __launch_bounds__(64, FO_SEG_OCC) k_fanout_emit_seg(DevGrid g, WorldDev w, uint32_t n_tickets, uint32_t s_fine, uint32_t fine_sh) {
     constexpr int B = FO_SEG_BATCH;
+    static_assert((WAVES & (WAVES - 1)) == 0, "waves per connection: a power of two");
+    constexpr uint32_t WSH = WAVES == 1 ? 0u : WAVES == 2 ? 1u : WAVES == 4 ? 2u : 3u;
+    // The LAST connections (slots >= s_fine) are cut into 2^fine_sh pieces instead of WAVES: when the tickets run out every
+    // wave still finishes the piece it holds, and the chip drains for the length of one piece — shorter pieces, shorter tail
+    // (all of them short would pay the per-piece descriptor walk on every connection: profiles/r02_emit_variant_sweep.json).
+    const uint32_t t_fine = s_fine << WSH;
     const uint32_t lane = lane_id();
     const uint32_t bank = blockIdx.x & 7u;
     uint32_t *__restrict__ ctr = w.emit_ticket + 32u * bank;
@@ -1191,8 +1202,11 @@ __global__ void __launch_bounds__(64, FO_SEG_OCC) k_fanout_emit_seg(DevGrid g, W
     // the next ticket: requested now, read at the bottom of the loop
     uint32_t tk_next = 0;
     if (lane == 0) tk_next = atomicAdd(ctr, 1u);
-    const uint32_t s = T / WAVES;
-    const uint32_t wave = T % WAVES;
+    const bool fine = T >= t_fine;
+    const uint32_t wsh = fine ? fine_sh : WSH;
+    const uint32_t Tr = fine ? T - t_fine : T;
+    const uint32_t s = (fine ? s_fine : 0u) + (Tr >> wsh);
+    const uint32_t wave = Tr & ((1u << wsh) - 1u);
     PF_TRACE(0);
     const uint32_t ns = w.n_simple[s];
     const size_t pbase = (size_t)s * w.capq;
@@ -1207,9 +1221,9 @@ __global__ void __launch_bounds__(64, FO_SEG_OCC) k_fanout_emit_seg(DevGrid g, W
     // streaming loop reads them with v_readlane (scalar operands from there on).  No descriptor load ever sits between
     // record stores: the vm counter is in-order, so ANY load wait also waits for every record store issued before it,
     // and a store takes ~3.5 us to complete while the chip streams.
-    const uint32_t mine = (ns - wave + WAVES - 1) / WAVES;  // segments of this wave (a connection has at most 64 WAVES due ones per pass)
+    const uint32_t mine = (ns - wave + (1u << wsh) - 1u) >> wsh;  // segments of this wave (a connection has at most 64 WAVES due ones per pass)
     for (uint32_t j0 = 0; j0 < mine; j0 += 64) {
-        const uint32_t kl = wave + (j0 + lane) * WAVES;
+        const uint32_t kl = wave + ((j0 + lane) << wsh);
         u32x4 dv = {0, 0, 0, 0}, wmv = {0, 0, 0, 0};
         uint32_t cv = 0;
         if (kl < ns) {
@@ -1804,10 +1818,15 @@ void launch_fanout_emit_main(hipStream_t st, DevGrid g, WorldDev w, int64_t now_
     const bool one_wave = w.S >= 4096 || w.one_wave_emit;
     if (seg_path(w)) {
         // (k_fanout_plan_seg has decided everything; see launch_fanout_plan)
-        const uint32_t n_tickets = w.S * FO_SEG_WAVES;
+        // CHD_SEG_TAIL="<percent>,<log2 pieces>": the last <percent> % of the connection slots in 2^<log2 pieces> pieces each
+        static const uint32_t tail_pct = [] { const char *e = getenv("CHD_SEG_TAIL"); return e ? (uint32_t)atoi(e) : FO_SEG_TAIL_PCT; }();
+        static const uint32_t tail_sh = [] { const char *e = getenv("CHD_SEG_TAIL"); const char *c = e ? strchr(e, ',') : nullptr; return c ? (uint32_t)atoi(c + 1) : FO_SEG_TAIL_SH; }();
+        const uint32_t pct = tail_pct > 100u ? 100u : tail_pct, fsh = tail_sh < 1u ? 1u : tail_sh > 4u ? 4u : tail_sh;
+        const uint32_t s_fine = w.S - (uint32_t)((uint64_t)w.S * pct / 100u);
+        const uint32_t n_tickets = s_fine * FO_SEG_WAVES + ((w.S - s_fine) << fsh);
         const dim3 grid(n_tickets < w.seg_waves ? n_tickets : w.seg_waves);
-        if (w.rec_mask) hipLaunchKernelGGL((k_fanout_emit_seg<FO_SEG_WAVES, true>), grid, dim3(64), 0, st, g, w, n_tickets);
-        else hipLaunchKernelGGL((k_fanout_emit_seg<FO_SEG_WAVES, false>), grid, dim3(64), 0, st, g, w, n_tickets);
+        if (w.rec_mask) hipLaunchKernelGGL((k_fanout_emit_seg<FO_SEG_WAVES, true>), grid, dim3(64), 0, st, g, w, n_tickets, s_fine, fsh);
+        else hipLaunchKernelGGL((k_fanout_emit_seg<FO_SEG_WAVES, false>), grid, dim3(64), 0, st, g, w, n_tickets, s_fine, fsh);
     } else if (w.rec_mask) {
         if (one_wave) hipLaunchKernelGGL((k_fanout_emit<1, true>), dim3(w.S), dim3(64), 0, st, g, w, now_ns, ring);
         else hipLaunchKernelGGL((k_fanout_emit<4, true>), dim3(w.S), dim3(256), 0, st, g, w, now_ns, ring);
