@@ -33,6 +33,8 @@ if ROOT not in sys.path:
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8 TB/s spec
 BYTES_PER_MSG = 12     # 4 B entity id read + 8 B {conn, channel} record written
+# serial schedule: the filtering launch + epilogue beside the record kernel (CHD_WORLD_OVERLAP_DEFERRED; profiles/r03zz_overlap_deferred_ab.json)
+OVERLAP_DEFERRED_DEFAULT = 0
 DOMINANT = "k_fanout_emit_seg"  # the kernel the roofline object is about (rocprofv3 --kernel-trace name, template arguments dropped)
 
 
@@ -70,6 +72,8 @@ def parse():
                     help="also write, per record, which buffered updates the message merges (CHD_WORLD_UPDATE_MASKS, +4 B/record)")
     ap.add_argument("--overlap-interest", action="store_true",
                     help="run the interest updates on a second stream beside ingest + index (CHD_WORLD_OVERLAP_INTEREST)")
+    ap.add_argument("--overlap-deferred", type=int, default=OVERLAP_DEFERRED_DEFAULT, choices=(0, 1),
+                    help="serial schedule: the filtering launch + epilogue on a second stream beside the record kernel (CHD_WORLD_OVERLAP_DEFERRED)")
     ap.add_argument("--recipients", action="store_true",
                     help="also plan the handover-message recipients every tick (CHD_WORLD_HANDOVER_RECIPIENTS)")
     ap.add_argument("--flat-interval-ms", type=int, default=0,
@@ -304,7 +308,7 @@ def main():
     ctl = A.StaticGrid2DSpatialController(device=local_rank)
     err = ctl.LoadConfig(json.dumps(cfg).encode(), strict=False, **({"Damping": [(0xFFFFFFFF, args.flat_interval_ms)]} if args.flat_interval_ms else {}))
     assert err is None, err
-    world_flags = {"auto": 0, "conn-major": 1, "cell-major": 2}[args.emit] | (4 if args.recipients else 0) | (8 if args.wire else 0) | (16 if args.overlap_interest else 0) | (32 if args.update_masks else 0)
+    world_flags = {"auto": 0, "conn-major": 1, "cell-major": 2}[args.emit] | (4 if args.recipients else 0) | (8 if args.wire else 0) | (16 if args.overlap_interest else 0) | (32 if args.update_masks else 0) | (256 if args.overlap_deferred else 0)
     # successive ticks pipelined over two streams (include/chd_spatial.h: CHD_WORLD_PIPELINE_TICKS) where the descriptor emit runs
     pipe = not args.serial_ticks and args.emit != "cell-major" and not args.wire and not args.update_masks and S >= 4096
     if pipe:
@@ -519,7 +523,9 @@ def main():
                    "value_is": "chd_tick_device: inputs resident in HBM, records left in HBM (see e2e for what a host observes)",
                    "schedule": ("successive ticks pipelined over two HIP streams (CHD_WORLD_PIPELINE_TICKS): tick t's record kernel beside tick t+1's stages; "
                                 "every tick does all of its work inside the timed region, results equal the serial schedule's (tests/test_gpu_fullsize.py)")
-                               if head_pipe else "serial: every tick's kernels in sequence on one stream (see pipelined_schedule for CHD_WORLD_PIPELINE_TICKS)"},
+                               if head_pipe else ("serial: every tick's kernels in sequence on one stream (see pipelined_schedule for CHD_WORLD_PIPELINE_TICKS)"
+                                                  + ("; the tick's small filtering launch and its epilogue run beside the record kernel on a second stream and join "
+                                                     "before the tick ends (CHD_WORLD_OVERLAP_DEFERRED)" if args.overlap_deferred else ""))},
         "p50_tick_ms": float(np.percentile(lat, 50)), "p99_tick_ms": float(np.percentile(lat, 99)),
         "p99_tick_gpu_ms": float(np.percentile(gpu_lat, 99)), "latency_ticks": int(L),
         "digest_checked_ticks": digests_checked,

@@ -64,6 +64,7 @@ struct World {
     void *grp_buf[4] = {nullptr, nullptr, nullptr, nullptr};  // device arrays behind WorldDev::grp_*
     bool plan_recipients = false;      // CHD_WORLD_HANDOVER_RECIPIENTS
     bool overlap_interest = false;     // CHD_WORLD_OVERLAP_INTEREST
+    bool overlap_deferred = false;     // CHD_WORLD_OVERLAP_DEFERRED
     // CHD_WORLD_PIPELINE_TICKS: everything the record-writing kernel reads (and the record buffer) exists twice, by tick parity
     bool pipe_alloc = false, pipe_on = false;
     uint32_t *pb_n_simple[2] = {nullptr, nullptr}, *pb_ce_chan[2] = {nullptr, nullptr}, *pb_ticket[2] = {nullptr, nullptr};
@@ -863,7 +864,11 @@ int chd_world_create(chd_ctx *ctx, const chd_world_cfg *cfg) {
     if (d.wb) TRY(walloc(ctx, &d.sub_bits, S * d.wb));
     if (d.cm_emit) TRY(walloc(ctx, &d.items, n_items_max, false));
     W.plan_recipients = (cfg->flags & CHD_WORLD_HANDOVER_RECIPIENTS) != 0;
-    W.overlap_interest = (cfg->flags & CHD_WORLD_OVERLAP_INTEREST) != 0 && !cfg->history_depth;
+    // CHD_WORLD_FORCE_FLAGS (tests): schedule-only flags OR-ed into every world of the process, so that the parity suite can be run on them
+    uint32_t wflags = cfg->flags;
+    if (const char *e = getenv("CHD_WORLD_FORCE_FLAGS")) wflags |= (uint32_t)strtoul(e, nullptr, 0) & (CHD_WORLD_OVERLAP_INTEREST | CHD_WORLD_OVERLAP_DEFERRED);
+    W.overlap_interest = (wflags & CHD_WORLD_OVERLAP_INTEREST) != 0 && !cfg->history_depth;
+    W.overlap_deferred = (wflags & CHD_WORLD_OVERLAP_DEFERRED) != 0 && !cfg->history_depth;
     {
         hipDeviceProp_t prop;
         HIPCHK(hipGetDeviceProperties(&prop, ctx->device));
@@ -1550,6 +1555,20 @@ static int tick_locked(chd_ctx *ctx, const chd_tick_in *in) {
         // ... and whatever is enqueued on `stream` after this tick comes after ALL of it
         HIPCHK(hipEventRecord(W.ev_stages_all, bs));
         HIPCHK(hipStreamWaitEvent(st, W.ev_stages_all, 0));
+    } else if (W.overlap_deferred && fanout_seg_path(d) && !d.deep_depth) {
+        // CHD_WORLD_OVERLAP_DEFERRED: the filtering launch (the subscriptions the plan deferred + the state commit) and the epilogue
+        // on the second stream, beside the record kernel — the pair a pipelined tick already runs side by side: the record kernel
+        // reads descriptors, offsets and columns and writes records, nothing the other two touch
+        HIPCHK(hipEventRecord(ctx->ev_fork, st));
+        HIPCHK(hipStreamWaitEvent(ctx->aux_stream, ctx->ev_fork, 0));
+        if (prof) HIPCHK(hipEventRecord(ev[CHD_N_STAGES + 4], st));
+        launch_fanout_emit_main(st, ctx->g, d, in->now_ns, r);
+        if (prof) HIPCHK(hipEventRecord(ev[CHD_N_STAGES + 3], st));
+        launch_fanout_emit_deferred(ctx->aux_stream, ctx->g, d, in->now_ns, r);
+        launch_tick_epilogue(ctx->aux_stream, d, r.cur_tick % TICK_RING, ctx->g.ncell);
+        HIPCHK(hipEventRecord(ctx->ev_join, ctx->aux_stream));
+        HIPCHK(hipStreamWaitEvent(st, ctx->ev_join, 0));
+        if (prof_ends) HIPCHK(hipEventRecord(ev[5], st));
     } else {
         if (prof) HIPCHK(hipEventRecord(ev[CHD_N_STAGES + 4], st));
         launch_fanout_emit_main(st, ctx->g, d, in->now_ns, r);

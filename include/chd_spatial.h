@@ -221,6 +221,13 @@ typedef struct {
  * stream.  Everything else (chd_tick, fetch, digest, sync, any other entry point) orders itself after both streams. */
 #define CHD_WORLD_PIPELINE_TICKS 128u
 
+/* Serial schedule: run the filtering launch (the subscriptions the plan left to a per-entity decision, and the commit of every
+ * subscription's new fan-out state) and the tick's epilogue on a second HIP stream BESIDE the kernel that writes the records,
+ * joining before the tick ends — the same pair a pipelined tick runs side by side.  Results are the serial schedule's; the tick is
+ * shorter by what the two small launches took.  Takes effect where the descriptor-driven connection-major emit runs and the
+ * world keeps no exact update buffers (history_depth); ignored elsewhere, and by pipelined ticks (which already do this). */
+#define CHD_WORLD_OVERLAP_DEFERRED 256u
+
 #define CHD_ENTITY_LOCKED 1u /* member of a non-empty lock group (entity.go:197-224) */
 
 int chd_world_create(chd_ctx *ctx, const chd_world_cfg *cfg);
