@@ -1558,7 +1558,9 @@ static int tick_locked(chd_ctx *ctx, const chd_tick_in *in) {
     } else if (W.overlap_deferred && fanout_seg_path(d) && !d.deep_depth) {
         // CHD_WORLD_OVERLAP_DEFERRED: the filtering launch (the subscriptions the plan deferred + the state commit) and the epilogue
         // on the second stream, beside the record kernel — the pair a pipelined tick already runs side by side: the record kernel
-        // reads descriptors, offsets and columns and writes records, nothing the other two touch
+        // reads descriptors, offsets and columns and writes records, nothing the other two touch.  Measured on config B
+        // (profiles/r03zz_overlap_deferred_ab.json): NOT a gain there, the record kernel takes 149 instead of 141 us and the tick
+        // 0.273 instead of 0.264 ms; off unless the world asks for it.
         HIPCHK(hipEventRecord(ctx->ev_fork, st));
         HIPCHK(hipStreamWaitEvent(ctx->aux_stream, ctx->ev_fork, 0));
         if (prof) HIPCHK(hipEventRecord(ev[CHD_N_STAGES + 4], st));

@@ -223,9 +223,11 @@ typedef struct {
 
 /* Serial schedule: run the filtering launch (the subscriptions the plan left to a per-entity decision, and the commit of every
  * subscription's new fan-out state) and the tick's epilogue on a second HIP stream BESIDE the kernel that writes the records,
- * joining before the tick ends — the same pair a pipelined tick runs side by side.  Results are the serial schedule's; the tick is
- * shorter by what the two small launches took.  Takes effect where the descriptor-driven connection-major emit runs and the
- * world keeps no exact update buffers (history_depth); ignored elsewhere, and by pipelined ticks (which already do this). */
+ * joining before the tick ends — the same pair a pipelined tick runs side by side.  Results are the serial schedule's.  Off by
+ * default: at BASELINE config B it does not pay — the record kernel is HBM-write bound and slows down by what the launch beside
+ * it would have taken alone (0.273 against 0.264 ms per tick, record kernel 149 against 141 us); it is for worlds whose
+ * filtering launch is long and whose record kernel is not the bound.  Takes effect where the descriptor-driven connection-major
+ * emit runs and the world keeps no exact update buffers (history_depth); ignored elsewhere, and by pipelined ticks. */
 #define CHD_WORLD_OVERLAP_DEFERRED 256u
 
 #define CHD_ENTITY_LOCKED 1u /* member of a non-empty lock group (entity.go:197-224) */
