@@ -11,9 +11,9 @@ from .controller import (  # noqa: F401
     BoxAOI, ConeAOI, SpatialError, SpatialInfo, SpatialInterestQuery, SpatialRegion, SphereAOI, SpotsAOI,
     StaticGrid2DSpatialController,
 )
-from .engine import SpatialWorld, TickResult  # noqa: F401
+from .engine import SpatialWorld, TickResult, UpdateBatch  # noqa: F401
 
 __all__ = [
-    "StaticGrid2DSpatialController", "SpatialWorld", "TickResult", "SpatialInfo", "SpatialInterestQuery",
+    "StaticGrid2DSpatialController", "SpatialWorld", "TickResult", "UpdateBatch", "SpatialInfo", "SpatialInterestQuery",
     "SpotsAOI", "BoxAOI", "SphereAOI", "ConeAOI", "SpatialRegion", "SpatialError", "ChdError", "load",
 ]

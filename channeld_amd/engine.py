@@ -84,6 +84,86 @@ HANDOVER_DTYPE = np.dtype([("entity", np.uint32), ("channel", np.uint32), ("src"
 assert REC_DTYPE.itemsize == C.sizeof(FanoutRec) and HANDOVER_DTYPE.itemsize == C.sizeof(HandoverRec)
 
 
+class UpdateBatch:
+    """What the per-message callers of the path become on the host side of the boundary (a cgo call per message
+    is not affordable, the shim buffers and resolves at the next tick).  Between two ticks every entity-channel update
+    message — `Channel.tickMessages` -> `ChannelData.OnUpdate` + `Notify` (channel.go:296-310, data.go:149-173,
+    spatial.go:612) —, every update of a spatial channel's own data and every UPDATE_SPATIAL_INTEREST
+    (message_spatial.go:59) is recorded here in ARRIVAL order; `tick_args()` lays them out as `chd_tick_in` wants them:
+
+      exact worlds (`history_depth` > 0)  every update, with its own arrival stamp; a channel's r-th update of the tick goes to
+                                          round r (`upd_round_off`: one update per entity per round, rounds applied in order —
+                                          the reference's message order per channel)
+      ring worlds                         one update per entity and tick: the LAST one (position and sender), stamped by the tick
+      interest                            one update per connection and tick: the last one (the reference applies them in
+                                          turn; the subscriptions it ends with are the last query's)
+    """
+
+    def __init__(self, exact: bool):
+        self.exact = bool(exact)
+        self.clear()
+
+    def clear(self):
+        self._slot, self._x, self._z, self._sender, self._arr = [], [], [], [], []
+        self._cch, self._csnd, self._carr = [], [], []
+        self._q = {}  # subscriber slot -> (arrival index, query)
+        self._nq = 0
+
+    def on_update(self, slot: int, x: float, z: float, sender: int, arrival_ns: int):
+        self._slot.append(int(slot)); self._x.append(float(x)); self._z.append(float(z))
+        self._sender.append(int(sender)); self._arr.append(int(arrival_ns))
+
+    def on_cell_update(self, channel: int, sender: int, arrival_ns: int):
+        self._cch.append(int(channel)); self._csnd.append(int(sender)); self._carr.append(int(arrival_ns))
+
+    def on_interest(self, sub_slot: int, query):
+        self._q[int(sub_slot)] = (self._nq, query)
+        self._nq += 1
+
+    def layout(self):
+        """-> (upd_idx, upd_x, upd_z, upd_sender, upd_arrival_ns | None, upd_round_off | None) as numpy arrays"""
+        slot = np.asarray(self._slot, dtype=np.uint32)
+        x, z = np.asarray(self._x, dtype=np.float64), np.asarray(self._z, dtype=np.float64)
+        snd, arr = np.asarray(self._sender, dtype=np.uint32), np.asarray(self._arr, dtype=np.int64)
+        n = len(slot)
+        if not n:
+            return slot, x, z, snd, None, None
+        if not self.exact:
+            # the last update of every entity, entities in the order of their last update
+            last = {}
+            for i in range(n):
+                last[int(slot[i])] = i
+            keep = np.asarray(sorted(last.values()), dtype=np.int64)
+            return slot[keep], x[keep], z[keep], snd[keep], None, None
+        seen, rnd = {}, np.empty(n, dtype=np.int64)
+        for i in range(n):
+            k = int(slot[i])
+            rnd[i] = seen.get(k, 0)
+            seen[k] = rnd[i] + 1
+        order = np.argsort(rnd, kind="stable")  # round-major, arrival order inside a round
+        off = np.zeros(int(rnd.max()) + 2, dtype=np.uint32)
+        np.add.at(off, rnd + 1, 1)
+        return slot[order], x[order], z[order], snd[order], arr[order], np.cumsum(off, dtype=np.uint32)
+
+    def tick_args(self) -> dict:
+        """keyword arguments for SpatialWorld.tick (everything but now_ns and the output options)"""
+        ui, ux, uz, us, ua, ro = self.layout()
+        kw = dict(upd_idx=ui, upd_x=ux, upd_z=uz, upd_sender=us)
+        if ua is not None:
+            kw.update(upd_arrival_ns=ua, upd_round_off=ro)
+        if self._cch:
+            kw.update(cell_upd_channel=np.asarray(self._cch, dtype=np.uint32), cell_upd_sender=np.asarray(self._csnd, dtype=np.uint32))
+            if self.exact:
+                kw.update(cell_upd_arrival_ns=np.asarray(self._carr, dtype=np.int64))
+        if self._q:
+            subs = sorted(self._q, key=lambda k: self._q[k][0])  # in the order of each connection's last query
+            qs = [self._q[k][1] for k in subs]
+            if all(isinstance(q, np.void) for q in qs):  # packed chd_aoi_query records (synth.AOI_DTYPE): keep them packed
+                qs = np.array(qs, dtype=qs[0].dtype)
+            kw.update(query_sub=np.asarray(subs, dtype=np.uint32), queries=qs)
+        return kw
+
+
 @dataclass
 class TickResult:
     handovers: np.ndarray          # HANDOVER_DTYPE

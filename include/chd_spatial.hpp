@@ -401,6 +401,85 @@ class StaticGrid2DSpatialController {
     std::vector<ConnectionId> serverConnections_;  // 0 = free slot
 };
 
+// What the per-message callers of the path become on the host side of the boundary (a cgo / FFI call per message is not
+// affordable: the shim buffers and resolves at the next tick).  Between two ticks every entity-channel update message —
+// Channel.tickMessages -> ChannelData.OnUpdate + Notify (channel.go:296-310, data.go:149-173, spatial.go:612) —, every update
+// of a spatial channel's own data and every UPDATE_SPATIAL_INTEREST (message_spatial.go:59) is recorded here in ARRIVAL order;
+// Layout() arranges them as chd_tick_in wants them:
+//   exact worlds (history_depth > 0)  every update with its own arrival stamp; a channel's r-th update of the tick goes to round
+//                                     r (upd_round_off: one update per entity per round, rounds applied in order = the
+//                                     reference's message order per channel)
+//   ring worlds                       one update per entity and tick: the LAST one (position and sender), stamped by the tick
+//   interest                          one update per connection and tick: the last one
+// (channeld_amd/engine.py: UpdateBatch is the same, array for array — tests/test_cxx_host.py.)
+class UpdateBatch {
+  public:
+    explicit UpdateBatch(bool exact) : exact_(exact) {}
+    void OnUpdate(uint32_t slot, double x, double z, ConnectionId sender, int64_t arrivalNs) {
+        slot_.push_back(slot); x_.push_back(x); z_.push_back(z); sender_.push_back(sender); arrival_.push_back(arrivalNs);
+    }
+    void OnCellUpdate(ChannelId channel, ConnectionId sender, int64_t arrivalNs) {
+        cellChannel.push_back(channel); cellSender.push_back(sender); cellArrivalNs.push_back(arrivalNs);
+    }
+    void OnInterest(uint32_t subSlot, const SpatialInterestQuery *query) { interest_.push_back({subSlot, query}); }
+    void Clear() { *this = UpdateBatch(exact_); }
+    bool Exact() const { return exact_; }
+
+    // the arrays of chd_tick_in (valid until the next OnUpdate / Clear)
+    std::vector<uint32_t> updSlot, updSender, roundOff;  // roundOff: empty on ring worlds
+    std::vector<double> updX, updZ;
+    std::vector<int64_t> updArrivalNs;                   // empty on ring worlds
+    std::vector<ChannelId> cellChannel;
+    std::vector<ConnectionId> cellSender;
+    std::vector<int64_t> cellArrivalNs;
+    std::vector<uint32_t> querySub;
+    std::vector<const SpatialInterestQuery *> queries;
+
+    void Layout() {
+        const size_t n = slot_.size();
+        std::vector<size_t> order;
+        roundOff.clear();
+        if (!exact_) {
+            // the last update of every entity, entities in the order of their last update
+            std::map<uint32_t, size_t> last;
+            for (size_t i = 0; i < n; i++) last[slot_[i]] = i;
+            for (auto &kv : last) order.push_back(kv.second);
+            std::sort(order.begin(), order.end());
+        } else if (n) {
+            std::map<uint32_t, uint32_t> seen;
+            std::vector<uint32_t> rnd(n);
+            uint32_t rounds = 0;
+            for (size_t i = 0; i < n; i++) { rnd[i] = seen[slot_[i]]++; rounds = std::max(rounds, rnd[i] + 1); }
+            roundOff.assign((size_t)rounds + 1, 0);
+            for (size_t i = 0; i < n; i++) roundOff[rnd[i] + 1]++;
+            for (uint32_t r = 0; r < rounds; r++) roundOff[r + 1] += roundOff[r];
+            order.resize(n);
+            std::vector<uint32_t> at(roundOff.begin(), roundOff.end() - 1);
+            for (size_t i = 0; i < n; i++) order[at[rnd[i]]++] = i;  // round-major, arrival order inside a round
+        }
+        updSlot.clear(); updSender.clear(); updX.clear(); updZ.clear(); updArrivalNs.clear();
+        for (size_t i : order) {
+            updSlot.push_back(slot_[i]); updSender.push_back(sender_[i]); updX.push_back(x_[i]); updZ.push_back(z_[i]);
+            if (exact_) updArrivalNs.push_back(arrival_[i]);
+        }
+        // one interest update per connection: the last one, connections in the order of their last query
+        querySub.clear(); queries.clear();
+        std::map<uint32_t, size_t> lastq;
+        for (size_t i = 0; i < interest_.size(); i++) lastq[interest_[i].first] = i;
+        std::vector<size_t> qi;
+        for (auto &kv : lastq) qi.push_back(kv.second);
+        std::sort(qi.begin(), qi.end());
+        for (size_t i : qi) { querySub.push_back(interest_[i].first); queries.push_back(interest_[i].second); }
+    }
+
+  private:
+    bool exact_;
+    std::vector<uint32_t> slot_, sender_;
+    std::vector<double> x_, z_;
+    std::vector<int64_t> arrival_;
+    std::vector<std::pair<uint32_t, const SpatialInterestQuery *>> interest_;
+};
+
 // The batched engine: one Tick replaces N Notify calls, S handleUpdateSpatialInterest calls and tickData on every
 // spatial and entity channel (chd_tick).  Buffers are owned here and reused from tick to tick.
 class SpatialWorld {
@@ -522,9 +601,14 @@ class SpatialWorld {
         in.spot_z = p.spot_z.empty() ? nullptr : p.spot_z.data();
         in.spot_dist = p.spot_dist.empty() ? nullptr : p.spot_dist.data();
         in.n_spots_total = (uint32_t)p.spot_x.size();
+        return RunTick(in, p.q.size(), recordsCap, out);
+    }
+
+  private:
+    Error RunTick(const chd_tick_in &in, size_t nQueries, uint64_t recordsCap, TickResult &out) {
         const uint32_t listCap = std::max<uint32_t>(1u, S_ * capq_);  // (every connection can drop / gain a whole interest set)
         out.handovers.resize(std::max<uint32_t>(N_, 1u));
-        out.queryStatus.assign(std::max<size_t>(p.q.size(), 1), 0);
+        out.queryStatus.assign(std::max<size_t>(nQueries, 1), 0);
         for (auto *v : {&out.unsubSlot, &out.unsubChannel, &out.newSubSlot, &out.newSubChannel, &out.newSubIntervalMs}) v->resize(listCap);
         chd_tick_out o;
         std::memset(&o, 0, sizeof o);
@@ -548,6 +632,43 @@ class SpatialWorld {
         if (o.n_records > recordsCap) return {CHD_E_CAPACITY, "more fan-out records than recordsCap"};
         if (Error e = FetchSegments(out)) return e;
         return {};
+    }
+
+  public:
+
+    // the same tick from the messages recorded since the last one (UpdateBatch: any subset of the entities, several updates
+    // per entity and their arrival stamps on exact worlds, spatial-channel updates, interest updates of some connections)
+    Error Tick(int64_t nowNs, UpdateBatch &batch, uint64_t recordsCap, TickResult &out) {
+        batch.Layout();
+        PackedQueries p;
+        if (Error e = pack_queries(batch.queries, p)) return e;
+        chd_tick_in in;
+        std::memset(&in, 0, sizeof in);
+        in.now_ns = nowNs;
+        in.n_updates = (uint32_t)batch.updSlot.size();
+        in.upd_idx = batch.updSlot.data();
+        in.upd_x = batch.updX.data();
+        in.upd_z = batch.updZ.data();
+        in.upd_sender = batch.updSender.data();
+        if (batch.Exact() && in.n_updates) {
+            in.upd_arrival_ns = batch.updArrivalNs.data();
+            in.n_update_rounds = (uint32_t)batch.roundOff.size() - 1u;
+            in.upd_round_off = batch.roundOff.data();
+        }
+        in.n_cell_updates = (uint32_t)batch.cellChannel.size();
+        in.cell_upd_channel = batch.cellChannel.empty() ? nullptr : batch.cellChannel.data();
+        in.cell_upd_sender = batch.cellSender.empty() ? nullptr : batch.cellSender.data();
+        if (batch.Exact() && in.n_cell_updates) in.cell_upd_arrival_ns = batch.cellArrivalNs.data();
+        in.n_queries = (uint32_t)p.q.size();
+        in.query_sub = batch.querySub.empty() ? nullptr : batch.querySub.data();
+        in.queries = p.q.empty() ? nullptr : p.q.data();
+        in.spot_x = p.spot_x.empty() ? nullptr : p.spot_x.data();
+        in.spot_z = p.spot_z.empty() ? nullptr : p.spot_z.data();
+        in.spot_dist = p.spot_dist.empty() ? nullptr : p.spot_dist.data();
+        in.n_spots_total = (uint32_t)p.spot_x.size();
+        const Error e = RunTick(in, p.q.size(), recordsCap, out);
+        if (!e) batch.Clear();
+        return e;
     }
 
     // ---- the rest of the world API, one thin method per entry point (chd_spatial.h has the reference citations) ----

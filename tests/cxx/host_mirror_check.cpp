@@ -2,6 +2,7 @@
 // tests/test_cxx_host.py, which compares every line with what the Python mirror gets through the same C-ABI.
 //   host_mirror_check cos <x>...            go_cos bit patterns
 //   host_mirror_check pack                  the packed chd_aoi_query records of a fixed query set
+//   host_mirror_check batch <exact> <events>  UpdateBatch::Layout of a script: u,slot,x,z,sender,arrival | c,channel,sender,arrival | q,sub,index
 //   host_mirror_check groups < script     EntityGroupTable driven by a script on stdin
 //   host_mirror_check load <config.json>    LoadConfig only: prints the error code (CHD_E_NO_DEVICE without a GPU)
 //   host_mirror_check gpu <config.json>     the interface methods on golden inputs + one world of three ticks
@@ -49,6 +50,33 @@ int main(int argc, char **argv) {
             std::memcpy(&bits, &v, 8);
             std::printf("%016" PRIx64 "\n", bits);
         }
+        return 0;
+    }
+    if (mode == "batch") {
+        // the same script goes through channeld_amd.engine.UpdateBatch in tests/test_cxx_host.py
+        UpdateBatch b(std::atoi(argv[2]) != 0);
+        auto qs = fixed_queries();
+        for (int i = 3; i < argc; i++) {
+            std::vector<std::string> f;
+            std::stringstream ss(argv[i]);
+            for (std::string t; std::getline(ss, t, ',');) f.push_back(t);
+            if (f[0] == "u") b.OnUpdate((uint32_t)std::stoul(f[1]), std::stod(f[2]), std::stod(f[3]), (uint32_t)std::stoul(f[4]), std::stoll(f[5]));
+            else if (f[0] == "c") b.OnCellUpdate((uint32_t)std::stoul(f[1]), (uint32_t)std::stoul(f[2]), std::stoll(f[3]));
+            else if (f[0] == "q") b.OnInterest((uint32_t)std::stoul(f[1]), &qs[std::stoul(f[2]) % qs.size()]);
+        }
+        b.Layout();
+        auto line = [](const char *name, auto &v) {
+            std::printf("%s", name);
+            for (auto e : v) std::printf(" %lld", (long long)e);
+            std::printf("\n");
+        };
+        line("slot", b.updSlot); line("sender", b.updSender); line("round_off", b.roundOff); line("arrival", b.updArrivalNs);
+        hex(b.updX.data(), b.updX.size() * 8); hex(b.updZ.data(), b.updZ.size() * 8);
+        line("cell", b.cellChannel); line("cell_sender", b.cellSender); line("cell_arrival", b.cellArrivalNs);
+        line("query_sub", b.querySub);
+        std::printf("queries");
+        for (auto *q : b.queries) std::printf(" %lld", (long long)(q - qs.data()));
+        std::printf("\n");
         return 0;
     }
     if (mode == "pack") {

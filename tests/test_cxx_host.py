@@ -85,6 +85,52 @@ def test_query_packing_matches_the_python_mirror_byte_for_byte(exe):
     assert lines[4] == f"nil-extent {e.value.code}" and lines[5] == f"nil-query {_lib.E_INVAL}"
 
 
+def _batch_script(rng, n_events, n_slots, n_subs):
+    ev, t = [], 1000
+    for _ in range(n_events):
+        t += int(rng.integers(0, 50))
+        k = rng.random()
+        if k < 0.7:
+            ev.append(("u", int(rng.integers(0, n_slots)), float(np.float32(rng.uniform(-1e4, 1e4))), float(np.float32(rng.uniform(-1e4, 1e4))),
+                       int(rng.integers(1, 9)), t))
+        elif k < 0.8:
+            ev.append(("c", 0x10000 + int(rng.integers(0, 16)), int(rng.integers(1, 9)), t))
+        else:
+            ev.append(("q", int(rng.integers(0, n_subs)), int(rng.integers(0, 5))))
+    return ev
+
+
+@pytest.mark.parametrize("exact", [True, False])
+def test_update_batch_layout_is_the_same_in_both_mirrors(exe, exact):
+    """chd::UpdateBatch (include/chd_spatial.hpp) and channeld_amd.engine.UpdateBatch lay the messages of a tick out identically."""
+    from channeld_amd.engine import UpdateBatch
+
+    rng = np.random.default_rng(5 + exact)
+    qs = fixed_queries()
+    for n_events, n_slots in ((0, 4), (1, 1), (40, 6), (300, 25), (300, 1000)):
+        ev = _batch_script(rng, n_events, n_slots, 7)
+        b = UpdateBatch(exact)
+        for e in ev:
+            if e[0] == "u":
+                b.on_update(*e[1:])
+            elif e[0] == "c":
+                b.on_cell_update(*e[1:])
+            else:
+                b.on_interest(e[1], qs[e[2]])
+        ui, ux, uz, us, ua, ro = b.layout()
+        kw = b.tick_args()
+        got = run(exe, "batch", str(int(exact)), *[",".join(repr(v) if isinstance(v, float) else str(v) for v in e) for e in ev])
+        ints = lambda line: [int(v) for v in line.split()[1:]]
+        assert ints(got[0]) == list(ui) and ints(got[1]) == list(us)
+        assert ints(got[2]) == ([] if ro is None else list(ro)) and ints(got[3]) == ([] if ua is None else list(ua))
+        assert got[4] == ux.tobytes().hex() and got[5] == uz.tobytes().hex()
+        assert ints(got[6]) == list(kw.get("cell_upd_channel", [])) and ints(got[7]) == list(kw.get("cell_upd_sender", []))
+        if exact:
+            assert ints(got[8]) == list(kw.get("cell_upd_arrival_ns", []))
+        assert ints(got[9]) == list(kw.get("query_sub", []))
+        assert ints(got[10]) == [next(i for i, q in enumerate(qs) if q is qq) for qq in kw.get("queries", [])]
+
+
 def test_load_config_fails_loudly_without_a_device(exe):
     import torch
 

@@ -230,3 +230,66 @@ def test_arrival_stamps_need_history_depth(amd):
     assert ctl2.LoadConfig(json.dumps(cfg).encode(), strict=False) is None
     with pytest.raises(amd.ChdError):  # below the ring's own depth
         amd.SpatialWorld(ctl2, 8, 2, history_depth=8)
+
+
+def test_messages_delivered_one_by_one_through_the_update_batch(amd):
+    """The reference's calling pattern: entity-channel updates arrive as single messages in any interleaving — an entity may send
+    none, one or several between two ticks — and each is its own OnUpdate + Notify in its channel's order (channel.go:296-310,
+    spatial.go:612); interest updates arrive per connection, a later one replacing an earlier one.  The host records them in
+    an UpdateBatch (channeld_amd/engine.py) and the tick takes its layout (rounds, arrival stamps); the oracle is fed the raw
+    message stream in arrival order."""
+    N, S = 220, 18
+    cfg, sw, ctl, gw, ow = make_pair(amd, "spatial_static_4x4.json", N, S, 64, 1, seed=0xD17)
+    rng = np.random.default_rng(17)
+    x, z = sw.x.copy(), sw.z.copy()
+    lo_x, hi_x = sw.offx, sw.offx + sw.W
+    lo_z, hi_z = sw.offz, sw.offz + sw.H
+    batch = amd.UpdateBatch(True)
+    now = total = multi = 0
+    for k in range(30):
+        prev, now = now, now + int(rng.choice([20, 50, 50, 80])) * MS
+        M = int(rng.integers(N // 2, 2 * N))
+        who = rng.integers(0, N, M).astype(np.uint32)        # some entities several times, some not at all
+        arr = np.sort(rng.integers(prev + 1, now + 1, M)).astype(np.int64)
+        ux, uz = np.empty(M), np.empty(M)
+        snd = np.empty(M, dtype=np.uint32)
+        for m in range(M):
+            i = int(who[m])
+            if not sw.outside[i]:  # a step of up to a third of a cell: several handovers of one entity inside a tick happen
+                x[i] = float(np.float32(min(max(x[i] + rng.uniform(-0.35, 0.35) * sw.gw, lo_x), np.nextafter(np.float32(hi_x), np.float32(-np.inf)))))
+                z[i] = float(np.float32(min(max(z[i] + rng.uniform(-0.35, 0.35) * sw.gh, lo_z), np.nextafter(np.float32(hi_z), np.float32(-np.inf)))))
+            ux[m], uz[m] = x[i], z[i]
+            snd[m] = int(rng.choice([int(sw.sender[i]), 901, 902, int(sw.sub_conn[0])], p=[0.7, 0.1, 0.1, 0.1]))
+            batch.on_update(i, ux[m], uz[m], int(snd[m]), int(arr[m]))
+        multi += int(np.sum(np.bincount(who, minlength=N) > 1))
+        ncu = int(rng.integers(0, 4))
+        cu = (0x10000 + rng.integers(0, 16, ncu)).astype(np.uint32)
+        cus = rng.choice([1, 2, 903], ncu).astype(np.uint32)
+        cua = np.sort(rng.integers(prev + 1, now + 1, ncu)).astype(np.int64)
+        for c, s_, a in zip(cu, cus, cua):
+            batch.on_cell_update(int(c), int(s_), int(a))
+        # interest: most connections once, a few twice (an older query from positions of the previous tick first), a few not at all
+        sw.x, sw.z = x.copy(), z.copy()
+        sw.heading = 2.0 * np.pi * rng.random(N)
+        q_new = sw.queries()
+        subs = [int(v) for v in rng.permutation(S) if rng.random() < 0.85]
+        for s_ in subs[:4]:
+            stale = q_new[s_].copy()
+            for f in ("sph_cx", "cone_cx", "box_cx"):
+                stale[f] = stale[f] + 0.5 * sw.gw if stale[f] != 0 else stale[f]
+            batch.on_interest(s_, stale)
+        for s_ in subs:
+            batch.on_interest(s_, q_new[s_])
+        kw = batch.tick_args()
+        assert len(kw["upd_round_off"]) - 1 == int(np.bincount(who, minlength=N).max())
+        ow.tick(now, who, ux, uz, snd, cu - 0x10000, cus, np.asarray(subs, dtype=np.uint32) if subs else None,
+                q_new[subs] if subs else None, upd_arrival=arr, cu_arrival=cua)
+        res = gw.tick(now, **kw)
+        batch.clear()
+        compare_tick(k, res, ow, S, check_pairs=range(0, S, 4), gw=gw)
+        total += res.n_records
+    cell, member = gw.entity_state()
+    ocell, omember = ow.entity_state()
+    to_id = lambda a: np.where(a == 0xFFFFFFFF, 0, a + 0x10000).astype(np.uint32)
+    assert np.array_equal(cell, to_id(ocell)) and np.array_equal(member, to_id(omember))
+    assert total > 5_000 and multi > 500
