@@ -213,5 +213,34 @@ int main(int argc, char **argv) {
         for (uint32_t s = 0; s < S; s++) std::printf(" %u", r.connRecordCount[s]);
         std::printf("\n");
     }
+    {
+        // a fourth tick from single messages (UpdateBatch, ring world): every third entity sends two updates — the last one counts —,
+        // connection 1 re-queries twice (the later query counts), connection 3 once, the others not at all
+        UpdateBatch b(false);
+        for (uint32_t i = 0; i < N; i += 3) b.OnUpdate(i, x[i] + 0.1 * ctl.GridWidth, z[i], 1, 180000000);
+        for (uint32_t i = 0; i < N; i += 3) {
+            x[i] += 0.6 * ctl.GridWidth;
+            if (x[i] >= ctl.WorldOffsetX + W) x[i] -= W;
+            b.OnUpdate(i, x[i], z[i], 1, 190000000);
+        }
+        std::vector<SpatialInterestQuery> q(3);
+        q[0].SphereAOI = SphereAOI{SpatialInfo{x[16], 0, z[16]}, 1.2 * ctl.GridWidth};
+        q[1].SphereAOI = SphereAOI{SpatialInfo{x[48], 0, z[48]}, 2.0 * ctl.GridWidth};
+        q[2].SphereAOI = SphereAOI{SpatialInfo{x[16], 0, z[16]}, 0.8 * ctl.GridWidth};
+        b.OnInterest(1, &q[0]);
+        b.OnInterest(3, &q[1]);
+        b.OnInterest(1, &q[2]);
+        SpatialWorld::TickResult r;
+        Error e = world.Tick((int64_t)200000000, b, 1u << 16, r);
+        std::printf("tick 4 rc %d handovers %zu aborts %u unsubs %zu newsubs %zu records %zu overflow %u\n", e.code, r.handovers.size(),
+                    r.lockedAborts, r.unsubSlot.size(), r.newSubSlot.size(), r.records.size(), r.overflow);
+        uint64_t hsum = 0;
+        for (auto &h : r.handovers) hsum += (uint64_t)h.entity * 1315423911u + h.src * 31u + h.dst;
+        uint64_t rsum = 0;
+        for (auto &rec : r.records) rsum += ((uint64_t)rec.conn << 32 | rec.channel) * 0x9E3779B97F4A7C15ull;
+        std::printf("digest %" PRIu64 " %" PRIu64, hsum, rsum);
+        for (uint32_t s = 0; s < S; s++) std::printf(" %u", r.connRecordCount[s]);
+        std::printf("\n");
+    }
     return 0;
 }

@@ -213,6 +213,33 @@ def test_gpu_cxx_mirror_equals_the_python_mirror(exe):
         for rec in r.records:
             rsum = (rsum + ((int(rec["conn"]) << 32 | int(rec["channel"])) * 0x9E3779B97F4A7C15)) & M64
         want.append(f"digest {hsum} {rsum}" + "".join(f" {int(c)}" for c in r.conn_rec_cnt[:S]))
+    # a fourth tick from single messages (UpdateBatch, ring world): see host_mirror_check.cpp
+    b = A.UpdateBatch(False)
+    x = x.copy()
+    for i in range(0, N, 3):
+        b.on_update(i, float(x[i]) + 0.1 * ctl.GridWidth, float(z[i]), 1, 180_000_000)
+    for i in range(0, N, 3):
+        x[i] += 0.6 * ctl.GridWidth
+        if x[i] >= ctl.WorldOffsetX + W:
+            x[i] -= W
+        b.on_update(i, float(x[i]), float(z[i]), 1, 190_000_000)
+    q = [SpatialInterestQuery() for _ in range(3)]
+    q[0].SphereAOI = SphereAOI(SpatialInfo(float(x[16]), 0, float(z[16])), 1.2 * ctl.GridWidth)
+    q[1].SphereAOI = SphereAOI(SpatialInfo(float(x[48]), 0, float(z[48])), 2.0 * ctl.GridWidth)
+    q[2].SphereAOI = SphereAOI(SpatialInfo(float(x[16]), 0, float(z[16])), 0.8 * ctl.GridWidth)
+    b.on_interest(1, q[0])
+    b.on_interest(3, q[1])
+    b.on_interest(1, q[2])
+    r = world.tick(200_000_000, records_cap=1 << 16, **b.tick_args())
+    want.append("tick 4 rc 0 handovers %d aborts %d unsubs %d newsubs %d records %d overflow %d" % (
+        len(r.handovers), r.n_locked_aborts, len(r.unsub_sub), len(r.newsub_sub), r.n_records, r.overflow))
+    hsum = 0
+    for h in r.handovers:
+        hsum = (hsum + int(h["entity"]) * 1315423911 + int(h["src"]) * 31 + int(h["dst"])) & M64
+    rsum = 0
+    for rec in r.records:
+        rsum = (rsum + ((int(rec["conn"]) << 32 | int(rec["channel"])) * 0x9E3779B97F4A7C15)) & M64
+    want.append(f"digest {hsum} {rsum}" + "".join(f" {int(c)}" for c in r.conn_rec_cnt[:S]))
     assert got == want, "\n".join(f"{a!r} | {b!r}" for a, b in zip(got, want) if a != b)
 
 
