@@ -130,16 +130,16 @@ class UpdateBatch:
             return slot, x, z, snd, None, None
         if not self.exact:
             # the last update of every entity, entities in the order of their last update
-            last = {}
-            for i in range(n):
-                last[int(slot[i])] = i
-            keep = np.asarray(sorted(last.values()), dtype=np.int64)
+            _, first_rev = np.unique(slot[::-1], return_index=True)
+            keep = np.sort(n - 1 - first_rev)
             return slot[keep], x[keep], z[keep], snd[keep], None, None
-        seen, rnd = {}, np.empty(n, dtype=np.int64)
-        for i in range(n):
-            k = int(slot[i])
-            rnd[i] = seen.get(k, 0)
-            seen[k] = rnd[i] + 1
+        # rnd[i] = how many earlier updates of the same entity the tick holds (stable sort by slot, position inside the run)
+        by_slot = np.argsort(slot, kind="stable")
+        ss = slot[by_slot]
+        run_start = np.flatnonzero(np.concatenate([[True], ss[1:] != ss[:-1]]))
+        run_len = np.diff(np.concatenate([run_start, [n]]))
+        rnd = np.empty(n, dtype=np.int64)
+        rnd[by_slot] = np.arange(n) - np.repeat(run_start, run_len)
         order = np.argsort(rnd, kind="stable")  # round-major, arrival order inside a round
         off = np.zeros(int(rnd.max()) + 2, dtype=np.uint32)
         np.add.at(off, rnd + 1, 1)
