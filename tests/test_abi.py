@@ -120,3 +120,39 @@ def test_product_never_touches_the_oracle():
                 if re.search(r"liboracle|pyoracle|from oracle|import oracle|chd_oracle\.h|orc_", txt):
                     bad.append(os.path.join(dp, fn))
     assert not bad, bad
+
+
+def test_binding_constants_match_the_header(tmp_path):
+    """Every CHD_* constant the ctypes binding mirrors has the value the C compiler gives the header's #define."""
+    from channeld_amd import _lib
+
+    pairs = {
+        "CHD_OK": _lib.OK, "CHD_E_CONFIG": _lib.E_CONFIG, "CHD_E_INVAL": _lib.E_INVAL, "CHD_E_EXTENT": _lib.E_EXTENT,
+        "CHD_E_CENTER": _lib.E_CENTER, "CHD_E_CAPACITY": _lib.E_CAPACITY, "CHD_E_HANG": _lib.E_HANG, "CHD_E_TOO_LARGE": _lib.E_TOO_LARGE,
+        "CHD_E_NO_DEVICE": _lib.E_NO_DEVICE, "CHD_E_HIP": _lib.E_HIP, "CHD_E_STATE": _lib.E_STATE,
+        "CHD_SHAPE_SPOTS": _lib.SHAPE_SPOTS, "CHD_SHAPE_BOX": _lib.SHAPE_BOX, "CHD_SHAPE_SPHERE": _lib.SHAPE_SPHERE, "CHD_SHAPE_CONE": _lib.SHAPE_CONE,
+        "CHD_REC_FULL": _lib.REC_FULL, "CHD_ENTITY_LOCKED": _lib.ENTITY_LOCKED,
+        "CHD_WORLD_CONN_MAJOR_EMIT": _lib.WORLD_CONN_MAJOR_EMIT, "CHD_WORLD_CELL_MAJOR_EMIT": _lib.WORLD_CELL_MAJOR_EMIT,
+        "CHD_WORLD_HANDOVER_RECIPIENTS": _lib.WORLD_HANDOVER_RECIPIENTS, "CHD_WORLD_WIRE": _lib.WORLD_WIRE,
+        "CHD_WORLD_OVERLAP_INTEREST": _lib.WORLD_OVERLAP_INTEREST, "CHD_WORLD_UPDATE_MASKS": _lib.WORLD_UPDATE_MASKS,
+        "CHD_WORLD_ONE_WAVE_EMIT": _lib.WORLD_ONE_WAVE_EMIT, "CHD_WORLD_PIPELINE_TICKS": _lib.WORLD_PIPELINE_TICKS,
+        "CHD_WORLD_OVERLAP_DEFERRED": _lib.WORLD_OVERLAP_DEFERRED,
+        "CHD_WIRE_ENTITY_UPDATE": _lib.WIRE_ENTITY_UPDATE, "CHD_WIRE_ENTITY_FULL": _lib.WIRE_ENTITY_FULL, "CHD_WIRE_CELL_UPDATE": _lib.WIRE_CELL_UPDATE,
+        "CHD_WIRE_CELL_FULL": _lib.WIRE_CELL_FULL, "CHD_WIRE_ENTITY_OBJREF": _lib.WIRE_ENTITY_OBJREF,
+        "CHD_HO_SRC_ONLY": _lib.HO_SRC_ONLY, "CHD_HO_DST_NEW": _lib.HO_DST_NEW, "CHD_HO_DST_KNOWN": _lib.HO_DST_KNOWN,
+        "CHD_BROADCAST_ALL_BUT_SENDER": _lib.BROADCAST_ALL_BUT_SENDER, "CHD_BROADCAST_ALL_BUT_OWNER": _lib.BROADCAST_ALL_BUT_OWNER,
+        "CHD_BROADCAST_ALL_BUT_CLIENT": _lib.BROADCAST_ALL_BUT_CLIENT, "CHD_BROADCAST_ALL_BUT_SERVER": _lib.BROADCAST_ALL_BUT_SERVER,
+        "CHD_BROADCAST_ADJACENT_CHANNELS": _lib.BROADCAST_ADJACENT_CHANNELS, "CHD_MAX_DAMPING": _lib.MAX_DAMPING,
+        "CHD_N_STAGES": _lib.N_STAGES, "CHD_PROF_STAGES": _lib.PROF_STAGES, "CHD_PROF_RECORD_KERNEL": _lib.PROF_RECORD_KERNEL,
+    }
+    prog = '#include <stdio.h>\n#include "chd_spatial.h"\nint main(void){\n'
+    for n in pairs:
+        prog += f'  printf("{n} %lld\\n", (long long)({n}));\n'
+    prog += "  return 0; }\n"
+    c = tmp_path / "k.c"
+    c.write_text(prog)
+    exe = tmp_path / "k"
+    subprocess.run(["gcc", "-std=c11", "-I", os.path.join(ROOT, "include"), str(c), "-o", str(exe)], check=True)
+    out = subprocess.run([str(exe)], capture_output=True, text=True, check=True).stdout
+    got = {k: int(v) for k, v in (l.split() for l in out.splitlines())}
+    assert got == {k: int(v) for k, v in pairs.items()}
