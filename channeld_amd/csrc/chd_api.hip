@@ -1410,6 +1410,8 @@ static int tick_locked(chd_ctx *ctx, const chd_tick_in *in) {
         return fail(ctx, CHD_E_STATE, "tick: arrival stamps / update rounds need a world with history_depth > 0 (the 32-tick bit ring stamps a batch with its tick)");
     if (in->n_update_rounds) {
         if (!in->upd_round_off) return fail(ctx, CHD_E_INVAL, "tick: NULL upd_round_off");
+        // (the duplicate-slot mark of a round is (tick, round & 0xFF): rounds r and r + 256 would look like a repeated slot)
+        if (in->n_update_rounds > 256) return fail(ctx, CHD_E_INVAL, "tick: more than 256 update rounds (updates of ONE channel between two ticks)");
         if (in->upd_round_off[0] != 0 || in->upd_round_off[in->n_update_rounds] != in->n_updates)
             return fail(ctx, CHD_E_INVAL, "tick: upd_round_off must run from 0 to n_updates");
         for (uint32_t r = 0; r < in->n_update_rounds; r++)
@@ -2292,10 +2294,10 @@ int chd_wire_set_type_url(chd_ctx *ctx, int which, const uint8_t *url, uint32_t 
 
 int chd_wire_set_merge_schema(chd_ctx *ctx, int schema) {
     NEED_WORLD();
-    World &W = ctx->w;
-    if (!W.wire || !W.x.merge) return fail(ctx, CHD_E_STATE, "merge schemas belong to worlds with CHD_WORLD_WIRE | CHD_WORLD_UPDATE_MASKS");
     if (schema != CHD_MERGE_SCHEMA_NONE && schema != CHD_MERGE_SCHEMA_TPS_ENTITY_MOVEMENT) return fail(ctx, CHD_E_INVAL, "chd_wire_set_merge_schema: unknown schema %d", schema);
     std::lock_guard<std::mutex> lk(ctx->mu);
+    World &W = ctx->w;
+    if (!W.wire || !W.x.merge) return fail(ctx, CHD_E_STATE, "merge schemas belong to worlds with CHD_WORLD_WIRE | CHD_WORLD_UPDATE_MASKS");
     TRY(bind(ctx));
     HIPCHK(hipStreamSynchronize(ctx->stream));
     W.x.schema = (uint32_t)schema;

@@ -128,10 +128,12 @@ __device__ __forceinline__ bool sub_is_deep(const WorldDev &w, const TickRing &r
                                             uint32_t c) {
     return w.deep_depth != 0 && (fl & PF_HAD_FIRST) && (w.cell_irr[c] != 0 || history_lost(ring, oldest, L, I));
 }
-// worst case of its segment: per channel of the cell one record per due window, and no more than the buffer holds elements
+// worst case of its segment: per channel of the cell one record per due window, and no more than TWICE what the buffer holds
+// elements — an arrival stamp that sits exactly on a window edge lies in two windows (both ends are inclusive, data.go:236-241),
+// so deep_walk can write two records per element
 __device__ __forceinline__ uint64_t deep_upper_bound(const WorldDev &w, int64_t now, int64_t L, int64_t I, uint64_t size) {
     int64_t nwin = (now - L) / I;
-    if (nwin > (int64_t)w.deep_depth) nwin = (int64_t)w.deep_depth;
+    if (nwin > 2 * (int64_t)w.deep_depth) nwin = 2 * (int64_t)w.deep_depth;
     return (uint64_t)nwin * (size + 1);
 }
 

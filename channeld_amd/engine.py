@@ -30,16 +30,27 @@ def movement_field_mask(paths) -> int:
     if not paths:
         return 0
     m = 0
+    whole = specific = False
     for p in paths:
         parts = p.split(".")
         if parts[0] != "actorState":
             continue
         if len(parts) == 1 or (len(parts) == 2 and parts[1] == "replicatedMovement"):
             m |= 63  # the whole sub-message is listed
-        elif len(parts) >= 3 and parts[1] == "replicatedMovement" and parts[2] in MOVEMENT_FIELDS:
-            if len(parts) > 3:
-                raise ValueError("leaf-level DataFieldMasks (FVector components) are outside the engine's bit form: " + p)
+            whole = True
+        elif len(parts) == 3 and parts[1] == "replicatedMovement" and parts[2] in MOVEMENT_FIELDS:
             m |= 1 << MOVEMENT_FIELDS.index(parts[2])
+            specific = True
+        else:
+            # fmutils.Filter keeps a sub-message that a path walks INTO present and clears what the path does not name:
+            # "actorState.owner" leaves an empty actorState (12 00), "actorState.replicatedMovement.<unknown>" an empty
+            # replicatedMovement inside it (12 02 5A 00) — neither is one of the engine's bit forms, and FVector components
+            # are below its leaves.  The host keeps such a subscription's messages to itself (no data_field_mask -> no typed merge).
+            raise ValueError("DataFieldMasks path outside the engine's bit form (include/chd_spatial.h: chd_sub_options.data_field_mask): " + p)
+    if whole and specific:
+        # fmutils builds a NESTED mask: a more specific path under a listed message narrows it — which of the two wins depends
+        # on the order the library merges them; not a bit form either
+        raise ValueError("DataFieldMasks lists a message and a field inside it: outside the engine's bit form")
     return m if m else 64
 
 

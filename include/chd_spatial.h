@@ -177,7 +177,10 @@ typedef struct {
      * (upd_round_off), any number of senders and windows as old as the buffer reaches — subscriptions the bit ring cannot
      * answer are served from these buffers by a separate (slower) launch; history_overflow then only counts what the
      * reference's buffer would still hold and this one had to drop.  12 B x history_depth per entity and cell.  Not on
-     * region-sharded worlds (the buffers do not migrate). */
+     * region-sharded worlds (the buffers do not migrate).
+     * Deviation (beyond 512 buffered elements only): the eviction test uses ONE maxFanOutIntervalMs for the world — the largest
+     * FanOutIntervalMs any subscription ever had — where the reference keeps one per channel (subscription.go:84-85): a channel
+     * whose own subscribers all use short intervals keeps its oldest elements a little longer here than there. */
     uint32_t history_depth;
 } chd_world_cfg;
 
@@ -371,8 +374,9 @@ typedef struct {
      * Notify and its own buffer element).  The host hands them over in ROUNDS — round r holds every entity at most once, a
      * channel's r-th update of the tick — as consecutive ranges of the update arrays: round r = [upd_round_off[r],
      * upd_round_off[r+1]), upd_round_off[n_update_rounds] == n_updates; the rounds are applied in order (one ingest launch
-     * each).  n_update_rounds == 0 => one round (the precondition of chd_tick_device then covers all of upd_idx).
-     * upd_round_off is a HOST array in chd_tick AND chd_tick_device (the library reads it to launch). */
+     * each).  n_update_rounds == 0 => one round (the precondition of chd_tick_device then covers all of upd_idx).  At most 256
+     * rounds per tick (CHD_E_INVAL beyond: a channel with more than 256 updates between two ticks is split over two ticks by
+     * the host).  upd_round_off is a HOST array in chd_tick AND chd_tick_device (the library reads it to launch). */
     uint32_t n_update_rounds;
     const uint32_t *upd_round_off;
 } chd_tick_in;
@@ -478,7 +482,8 @@ typedef struct {
     uint64_t n_records;       /* what all segments expand to (== chd_tick_out.n_records of the same tick) */
 } chd_segments_out;
 
-/* The last tick's fan-out in that form.  All buffers caller-allocated (chd_host_alloc memory makes the copies DMA);
+/* The last tick's fan-out in that form (`columns`: max_entities entries — ten times that on ticks where some live entity skipped
+ * an update, when the per-window columns travel too).  All buffers caller-allocated (chd_host_alloc memory makes the copies DMA);
  * CHD_E_CAPACITY (n_* say what is needed) when one is too small.  replaces: the per-message loop of fanOutDataUpdate
  * (data.go:293-318) on the host side of the boundary — the host walks segments instead of 8-byte records. */
 int chd_tick_fetch_segments(chd_ctx *ctx, chd_segments_out *out);

@@ -99,6 +99,9 @@ typedef struct orc_world {
     /* spatialDampingSettings (message_spatial.go:16-29) replaced by the host (the table is a package variable there) */
     uint32_t n_damp, damp_dist[8], damp_iv[8];
     int digest_only;
+    /* sorted_walk: walk a buffer newest-first and stop at the first element older than the window (see window_has_update_sorted);
+     * unsorted = some channel's arrival stamps went backwards: the sorted walk is then not taken */
+    int sorted_walk, unsorted;
     uint64_t d_cnt, d_sum, d_xor, d_sum_masked;
     uint64_t *d_conn; /* [S] per subscriber slot: sum of the record hashes */
 } orc_world;
@@ -314,6 +317,29 @@ static int window_has_update(const orc_world *w, const wbuf *b, orc_time last, o
     return merged;
 }
 
+/* The same selection for buffers whose arrival stamps do not decrease (queue order: Channel.PutMessage stamps in enqueue order,
+ * channel.go:296-310): `arrival >= lastUpdateTime` then holds for every element behind the first one that passes, so the elements
+ * merged are exactly those with max(last, 0) <= arrival <= next from a sender that is not skipped — whichever way the buffer is
+ * walked.  Walked newest first the loop can stop at the first element older than the window: O(updates inside the reach) instead
+ * of O(buffer), which is what lets tests/golden/make_bench_digests.py run hundreds of full-size ticks with 512-deep buffers.
+ * Opt-in (orc_world_set_sorted_walk); tests/test_world_oracle.py holds it against the forward walk. */
+static int window_has_update_sorted(const orc_world *w, const wbuf *b, orc_time last, orc_time next,
+                                    uint32_t conn, int skip_self, uint32_t *mask) {
+    *mask = 0;
+    const orc_time lo = last >= 0 ? last : 0;
+    int merged = 0;
+    for (uint32_t i = b->len; i-- > 0;) {
+        const wupd *be = &b->v[b->head + i];
+        if (be->arrival < lo) break;
+        if (be->arrival > next) continue;
+        if (be->sender == conn && skip_self) continue;
+        merged = 1;
+        for (uint32_t j = 0; j < w->nstamps; j++)
+            if (w->stamps[j] == be->arrival) *mask |= 1u << j;
+    }
+    return merged;
+}
+
 typedef struct {
     uint8_t full;
     orc_time last, next;
@@ -415,7 +441,8 @@ static void *fan_cells(void *arg) {
                 for (uint32_t wi = 0; wi < nw; wi++) {
                     uint32_t mask = 0;
                     if (wins[wi].full) job_push(j, subs[si].s, conn | REC_FULL, chan, 0);
-                    else if (window_has_update(w, b, wins[wi].last, wins[wi].next, conn, tmp.skip_self, &mask))
+                    else if ((w->sorted_walk && !w->unsorted) ? window_has_update_sorted(w, b, wins[wi].last, wins[wi].next, conn, tmp.skip_self, &mask)
+                                                              : window_has_update(w, b, wins[wi].last, wins[wi].next, conn, tmp.skip_self, &mask))
                         job_push(j, subs[si].s, conn, chan, mask);
                 }
             }
@@ -521,7 +548,12 @@ int orc_world_tick_arrivals(orc_world *w, orc_time t, uint32_t n_upd, const uint
         uint32_t dst = cell_index(w, x[u], z[u]);
         w->cell[i] = dst; /* merged position is now the new one */
         if (sender) w->sender[i] = sender[u];
-        wbuf_push(&w->ebuf[i], upd_arrival ? upd_arrival[u] : t, w->sender[i], w->max_interval_ms);
+        {
+            const wbuf *eb = &w->ebuf[i];
+            const orc_time a = upd_arrival ? upd_arrival[u] : t;
+            if (eb->len && eb->v[eb->head + eb->len - 1].arrival > a) w->unsorted = 1;
+            wbuf_push(&w->ebuf[i], a, w->sender[i], w->max_interval_ms);
+        }
         if (src == W_INVALID || dst == W_INVALID || src == dst) continue; /* spatial.go:613-626 */
         /* GetHandoverEntities (entity.go:197-224): the notifier's handover group; a locked member empties it (:675-679) */
         int any_locked = (w->eflags[i] & 1u) != 0;
@@ -557,8 +589,12 @@ int orc_world_tick_arrivals(orc_world *w, orc_time t, uint32_t n_upd, const uint
             for (uint32_t m = 0; m < w->N; m++)
                 if (m != i && w->alive[m] && w->group[m] == w->group[i] && w->member[m] == src) w->member[m] = dst;
     }
-    for (uint32_t u = 0; u < n_cu; u++)
-        wbuf_push(&w->cbuf[cu_cell[u]], cu_arrival ? cu_arrival[u] : t, cu_sender[u], w->max_interval_ms);
+    for (uint32_t u = 0; u < n_cu; u++) {
+        const wbuf *cb = &w->cbuf[cu_cell[u]];
+        const orc_time a = cu_arrival ? cu_arrival[u] : t;
+        if (cb->len && cb->v[cb->head + cb->len - 1].arrival > a) w->unsorted = 1;
+        wbuf_push(&w->cbuf[cu_cell[u]], a, cu_sender[u], w->max_interval_ms);
+    }
 
     /* ---- 1b. who receives each handover's ChannelDataHandoverMessage (spatial.go:776-857) ----
      * srcChannelSubConns / dstChannelSubConns as they are now (Notify runs before this tick's
@@ -766,6 +802,8 @@ uint64_t orc_world_nrec(const orc_world *w) { return w->nrec; }
 /* digest mode: the window formulation folds every record into {count, sum, xor of mix64(conn << 32 | channel), sum of
  * mix64(that hash + merged-updates mask)} and per subscriber slot the sum of the hashes, instead of storing it */
 void orc_world_set_digest_only(orc_world *w, int on) { w->digest_only = on && !w->literal; }
+void orc_world_set_sorted_walk(orc_world *w, int on) { w->sorted_walk = on; }
+int orc_world_unsorted(const orc_world *w) { return w->unsorted; }
 void orc_world_digest(const orc_world *w, uint64_t out[4], uint64_t *conn_sum) {
     out[0] = w->d_cnt; out[1] = w->d_sum; out[2] = w->d_xor; out[3] = w->d_sum_masked;
     if (conn_sum && w->d_conn) memcpy(conn_sum, w->d_conn, 8 * (size_t)w->S);

@@ -134,6 +134,9 @@ def lib():
     L.orc_world_pair_options.argtypes = [C.c_void_p, C.c_uint32, u8p, u8p]
     L.orc_world_set_damping.argtypes = [C.c_void_p, C.c_uint32, up, up]
     L.orc_world_set_digest_only.argtypes = [C.c_void_p, C.c_int]
+    L.orc_world_set_sorted_walk.argtypes = [C.c_void_p, C.c_int]
+    L.orc_world_unsorted.argtypes = [C.c_void_p]
+    L.orc_world_unsorted.restype = C.c_int
     L.orc_world_digest.argtypes = [C.c_void_p, P(C.c_uint64), P(C.c_uint64)]
     L.orc_world_nhandover.restype = C.c_uint32
     L.orc_world_nhandover.argtypes = [C.c_void_p]
@@ -464,6 +467,14 @@ class World:
     def set_digest_only(self, on=True):
         """window mode: fold the records into an order-independent digest instead of storing them"""
         lib().orc_world_set_digest_only(self.h, 1 if on else 0)
+
+    def set_sorted_walk(self, on=True):
+        """window mode: walk the update buffers newest-first with an early exit (valid while no channel's arrival stamps
+        decrease — `unsorted()` says if one did, and the forward walk is then taken anyway)"""
+        lib().orc_world_set_sorted_walk(self.h, 1 if on else 0)
+
+    def unsorted(self):
+        return bool(lib().orc_world_unsorted(self.h))
 
     def digest(self):
         """(count, sum, xor, sum_masked), per-slot sums — of the last tick, digest mode"""

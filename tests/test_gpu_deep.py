@@ -293,3 +293,49 @@ def test_messages_delivered_one_by_one_through_the_update_batch(amd):
     to_id = lambda a: np.where(a == 0xFFFFFFFF, 0, a + 0x10000).astype(np.uint32)
     assert np.array_equal(cell, to_id(ocell)) and np.array_equal(member, to_id(omember))
     assert total > 5_000 and multi > 500
+
+
+def test_stamps_on_window_edges_count_twice_and_fit_their_segment(amd):
+    """an arrival stamp exactly on a window edge lies in TWO windows (both ends inclusive, data.go:236-241), so a
+    subscription that catches up over more windows than the buffer holds elements writes up to two records per element — the
+    segment the plan reserves must hold them (it used to reserve one per element: an out-of-bounds write into the next
+    subscription's records).  20 ms ticks with tick-aligned stamps, a 10 ms subscriber blocked for 90 ticks, history_depth 32:
+    on its return every buffered stamp is the upper edge of one of its windows and the lower edge of the next."""
+    N, S = 40, 4
+    cfg, sw, ctl, gw, ow = make_pair(amd, "spatial_static_2x2.json", N, S, 32, 1, seed=0xD18, tick_ms=20)
+    now = 0
+    for k in range(110):
+        sw.step()
+        now += 20 * MS
+        q = sw.queries() if k < 3 else None  # (the interest sets stay: a re-query would overwrite the 10 ms interval with the damped one)
+        # (explicit stamps equal to the tick's own: the exact buffers are filled, the masks stay regular where they can)
+        arr = np.full(N, now, dtype=np.int64)
+        ow.tick(now, None, sw.x, sw.z, None, None, None, None, q, upd_arrival=arr)
+        res = gw.tick(now, upd_x=sw.x, upd_z=sw.z, queries=q, upd_arrival_ns=arr, records_cap=1 << 22)
+        if k == 4:
+            for s in range(S):
+                ch = gw.subscriptions(s)[0]
+                gw.set_sub_options(now, [dict(slot=s, channel=int(c), fanout_interval_ms=10) for c in ch])
+                for c in ch:
+                    ow.set_sub_options(now, s, int(c), fanout_interval_ms=10)
+        if k == 8 or k == 100:
+            access = 0 if k == 8 else 1
+            for s in (1, 2):
+                ch = gw.subscriptions(s)[0]
+                gw.set_sub_options(now, [dict(slot=s, channel=int(c), data_access=access) for c in ch])
+                for c in ch:
+                    ow.set_sub_options(now, s, int(c), data_access=access)
+        if k < 12 or k >= 99:
+            # (the short buffer has dropped what the reference still holds: history_overflow says so on the catch-up tick; the
+            # records the device DOES write must be the oracle's for every connection that was never blocked)
+            oc, och = ow.records()
+            assert res.overflow == 0
+            for s in (0, 3):
+                conn = int(sw.sub_conn[s])
+                mine = (res.records["conn"] & 0x7FFFFFFF) == conn
+                theirs = (oc & 0x7FFFFFFF) == conn
+                assert np.array_equal(canon(res.records["conn"][mine], res.records["channel"][mine]), canon(oc[theirs], och[theirs])), (k, s)
+        if k == 101:
+            # the blocked connections caught up over 180 windows with 32 buffered elements per channel: two records per element
+            per_conn = {s: int(np.sum((res.records["conn"] & 0x7FFFFFFF) == int(sw.sub_conn[s]))) for s in range(S)}
+            assert per_conn[1] > 40 * N // 4 and per_conn[2] > 40 * N // 4, per_conn

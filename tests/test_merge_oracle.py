@@ -34,3 +34,21 @@ def test_generated_updates_are_canonical_and_a_foreign_field_is_refused():
 
     with pytest.raises(merge.NotInSubset):
         merge.merged_update([bytes([0x0A, 0x02, 0x08, 0x05])])  # objRef { netGUID: 5 }
+
+
+def test_field_mask_paths_outside_the_bit_form_are_refused():
+    """fmutils.Filter keeps a sub-message that a path walks INTO present but emptied, and a specific path under a
+    listed message narrows it — neither is one of the engine's bit forms, so the path mapper must refuse them (the host then keeps
+    that subscription's merge to itself) instead of returning a mask with other semantics."""
+    import pytest
+
+    from channeld_amd.engine import movement_field_mask
+
+    assert movement_field_mask([]) == 0
+    assert movement_field_mask(["actorState.replicatedMovement.location"]) == 1 << 2
+    assert movement_field_mask(["actorState"]) == 63 and movement_field_mask(["actorState.replicatedMovement"]) == 63
+    assert movement_field_mask(["characterState"]) == 64
+    for bad in (["actorState.owner"], ["actorState.replicatedMovement.nosuchfield"], ["actorState.replicatedMovement.location.x"],
+                ["actorState", "actorState.replicatedMovement.location"], ["actorState.replicatedMovement", "actorState.replicatedMovement.rotation"]):
+        with pytest.raises(ValueError):
+            movement_field_mask(bad)
