@@ -90,6 +90,15 @@ def parse():
     ap.add_argument("--serial-ticks", action="store_true",
                     help="never pipeline successive ticks: the world is created without CHD_WORLD_PIPELINE_TICKS and only the serial "
                          "schedule is timed")
+    ap.add_argument("--arrival-jitter", action="store_true",
+                    help="the reference's real arrival stamps (channel.go:296-310: an update is stamped when it is ENQUEUED, not when the tick "
+                         "handles it): every update of every tick carries a uniform random enqueue time inside its tick interval, the world keeps "
+                         "the exact update buffers (history_depth 1024) beside the per-slot offsets; the default run reports this as a sub-line "
+                         "(`arrival_jitter`), this flag makes it the timed workload (for profiles)")
+    ap.add_argument("--tick-jitter-us", type=int, default=0,
+                    help="diagnostic: every tick's channel time is off the tick grid by a uniform random amount of up to this many microseconds "
+                         "either way (a real gateway's ticks are never exactly periodic): subscriptions made at such a tick keep that phase, so "
+                         "with --arrival-jitter EVERY later fan-out window cuts through a tick's arrivals and needs a per-entity decision")
     ap.add_argument("--write-digests", action="store_true",
                     help="record the latency-phase ticks' record digests into tests/golden/bench_digests_B.json instead of checking them")
     ap.add_argument("--only-timed", action="store_true",
@@ -310,10 +319,14 @@ def main():
     assert err is None, err
     world_flags = {"auto": 0, "conn-major": 1, "cell-major": 2}[args.emit] | (4 if args.recipients else 0) | (8 if args.wire else 0) | (16 if args.overlap_interest else 0) | (32 if args.update_masks else 0) | (256 if args.overlap_deferred else 0)
     # successive ticks pipelined over two streams (include/chd_spatial.h: CHD_WORLD_PIPELINE_TICKS) where the descriptor emit runs
-    pipe = not args.serial_ticks and args.emit != "cell-major" and not args.wire and not args.update_masks and S >= 4096
+    pipe = not args.serial_ticks and args.emit != "cell-major" and not args.wire and not args.update_masks and S >= 4096 and not args.arrival_jitter
     if pipe:
         world_flags |= 128
-    world = A.SpatialWorld(ctl, N, S, flags=world_flags)
+    jitter = bool(args.arrival_jitter)
+    if jitter:
+        pipe = False  # (exact update buffers: serial schedule only)
+        world_flags &= ~128
+    world = A.SpatialWorld(ctl, N, S, flags=world_flags, history_depth=1024 if jitter else 0)
     if pipe:
         # the flag only takes effect where the descriptor-driven connection-major emit runs (include/chd_spatial.h): e.g. not in
         # a world whose populous cells select the cell-major emit (config C)
@@ -333,9 +346,12 @@ def main():
     zs = np.empty((T + E, N), dtype=np.float64)
     qs = np.empty((T + E, S), dtype=synth.AOI_DTYPE)
     now = np.empty(T + E, dtype=np.int64)
+    jrng = np.random.default_rng(seed ^ 0x71773)
     for t in range(T + E):
         sw.step()
         xs[t], zs[t], qs[t], now[t] = sw.x, sw.z, sw.queries(), sw.now_ns()
+        if args.tick_jitter_us:
+            now[t] += int(jrng.integers(-args.tick_jitter_us, args.tick_jitter_us + 1)) * 1000 + int(jrng.integers(0, 1000))
     e2e_frames = [(int(now[t]), xs[t].copy(), zs[t].copy(), qs[t].copy()) for t in range(T, T + E)]
     xs, zs, qs_dev = xs[:T], zs[:T], qs[:T]
     M, d_idx = N, None  # updates per tick
@@ -348,18 +364,27 @@ def main():
         d_idx = world.device_array(idx)
     d_x, d_z, d_q = world.device_array(xs), world.device_array(zs), world.device_array(qs_dev)
     del xs, zs
+    d_arr = None
+    if jitter:
+        # enqueue stamps: uniform in (previous tick, this tick] (channel.go:296-310 stamps at PutMessage; the tick handles the queue later)
+        prev = np.concatenate([[0], now[:T - 1]]) if T else now[:0]
+        arr = np.empty((T, M), dtype=np.int64)
+        for t in range(T):
+            arr[t] = now[t] - jrng.integers(0, max(int(now[t] - prev[t]), 1), M)
+        d_arr = world.device_array(arr)
+        del arr
 
     def tick(t):
         world.tick_device(int(now[t]), n_updates=M, d_upd_x=d_x.at(t * M * 8), d_upd_z=d_z.at(t * M * 8),
                           d_upd_idx=d_idx.at(t * M * 4) if d_idx is not None else None,
-                          n_queries=S, d_queries=d_q.at(t * S * 128))
+                          n_queries=S, d_queries=d_q.at(t * S * 128), d_upd_arrival=d_arr.at(t * M * 8) if d_arr is not None else None)
 
     world.set_profiling(min(1024, max(K, L, 1)))
     # throughput regions: only the event pair around the dominant kernel (a timed event at every stage boundary idles the
     # stream for a few microseconds each); the stage breakdown comes from the latency phase below
     # (diagnostic configurations whose records mostly come from another kernel - per-record masks, partial updates, populous
     # cells - keep the stage events: their roofline line is about the whole emit stage)
-    headline_like = args.update_frac >= 1.0 and not args.update_masks and args.emit != "cell-major" and N // max(ctl.GridCols * ctl.GridRows, 1) < 512
+    headline_like = args.update_frac >= 1.0 and not args.update_masks and args.emit != "cell-major" and N // max(ctl.GridCols * ctl.GridRows, 1) < 512 and not jitter
     world.set_profiling_scope(headline_like)
     if pipe and not head_pipe:
         world.set_pipelining(False)
@@ -461,7 +486,7 @@ def main():
 
     # ---- end to end, as a Go host would observe it ("kernel-only AND end-to-end through the C-ABI") ----
     e2e = None
-    if E and args.update_frac >= 1.0 and not args.wire:
+    if E and args.update_frac >= 1.0 and not args.wire and not jitter:
         e2e = {}
         trace("e2e host ticks")
         r = e2e_host_ticks(world, e2e_frames, E) if not os.environ.get("CHD_BENCH_SKIP_E2E_HOST") else [(1.0, 1)]
@@ -495,7 +520,8 @@ def main():
     # summary of the same command, and only for the workload it was measured on
     traffic, traffic_note = None, None
     tpath = os.path.join(ROOT, "profiles", "hbm_traffic.json")
-    if os.path.exists(tpath) and (N, S) == (100_000, 10_000) and args.aoi_scale == 1.0 and args.tick_ms == 50 and args.update_frac >= 1.0:
+    if os.path.exists(tpath) and (N, S) == (100_000, 10_000) and args.aoi_scale == 1.0 and args.tick_ms == 50 and args.update_frac >= 1.0 and not jitter \
+            and not args.tick_jitter_us:
         from channeld_amd.build import source_hash
 
         with open(tpath) as f:
@@ -516,7 +542,10 @@ def main():
         "ms_per_step": 1e3 * elapsed / K, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "f64", "data": "synthetic",
         "config": {"workload": f"spatial_static_benchmark.json, {N} entities / {S} subs, 1xMI355X"
-                               + ("" if args.update_frac >= 1.0 else f", DIAGNOSTIC: {args.update_frac:g} of the entities update per tick"),
+                               + ("" if args.update_frac >= 1.0 else f", DIAGNOSTIC: {args.update_frac:g} of the entities update per tick")
+                               + ("" if not jitter else ", ARRIVAL STAMPS AT ENQUEUE TIME: every update stamped uniformly inside its tick interval "
+                                                        "(channel.go:296-310), exact update buffers (history_depth 1024)")
+                               + ("" if not args.tick_jitter_us else f", tick times off the grid by up to +-{args.tick_jitter_us} us"),
                    "grid": "15x15 cells of 2000",
                    "tick_ms": args.tick_ms, "aoi": "70% sphere R=3 cells, 20% cone R=5 cells, 10% box extent 2 cells",
                    "msgs_per_tick": msgs / K, "message": "one fanOutDataUpdate decision (conn, channel); payload bytes excluded",
@@ -643,7 +672,8 @@ DIGEST_FILE = os.path.join(ROOT, "tests", "golden", "bench_digests_B.json")
 
 def load_bench_digests(args, N, S, M):
     """The committed per-tick record digests of the default world (config B, seed 0xC0FFEE01), or None when this run is another world."""
-    if (N, S, M) != (100_000, 10_000, 100_000) or args.aoi_scale != 1.0 or args.tick_ms != 50 or args.flat_interval_ms or not os.path.exists(DIGEST_FILE):
+    if (N, S, M) != (100_000, 10_000, 100_000) or args.aoi_scale != 1.0 or args.tick_ms != 50 or args.flat_interval_ms or args.arrival_jitter \
+            or args.tick_jitter_us or not os.path.exists(DIGEST_FILE):
         return None
     with open(DIGEST_FILE) as f:
         return json.load(f)["ticks"]

@@ -150,6 +150,7 @@ class TickStats(C.Structure):
         ("n_records", C.c_uint64), ("n_record_upper_bound", C.c_uint64),
         ("n_handovers", C.c_uint32), ("n_unsubs", C.c_uint32), ("n_pairs", C.c_uint32), ("n_deferred_records", C.c_uint32),
         ("algorithmic_bytes", C.c_uint64),
+        ("n_filtered_records", C.c_uint32), ("n_deep_records", C.c_uint32),
     ]
 
 

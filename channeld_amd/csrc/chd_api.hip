@@ -821,7 +821,7 @@ int chd_world_create(chd_ctx *ctx, const chd_world_cfg *cfg) {
     TRY(walloc(ctx, &d.blk_cnt, std::max(C * d.nblk + 1, 2 * C + 2)));
     TRY(walloc(ctx, &d.ce, N + 1));  // + 1: the emit kernel loads entries in adjacent pairs
     TRY(walloc(ctx, &d.ce_sprev, N));
-    TRY(walloc(ctx, &d.ce8, N + 2));
+    TRY(walloc(ctx, &d.ce8, N + 520));  // (+ 520: the filtered record kernel loads a whole 512-entry image at any cell start)
     TRY(walloc(ctx, &d.cell_usender, C));
     TRY(walloc(ctx, &d.cell_smin, C));
     TRY(walloc(ctx, &d.cell_smax, C));
@@ -1005,6 +1005,24 @@ int chd_world_create(chd_ctx *ctx, const chd_world_cfg *cfg) {
         // drop = INT64_MIN ("nothing was ever dropped"): the byte pattern 0x80 repeated is a very negative int64 as well
         HIPCHK(hipMemsetAsync(d.deep_drop, 0x80, sizeof(int64_t) * std::max<size_t>(N, 32), ctx->stream));
         HIPCHK(hipMemsetAsync(d.cdeep_drop, 0x80, sizeof(int64_t) * std::max<size_t>(C, 32), ctx->stream));
+        // Sub-tick arrival offsets (WorldDev::off_on): where the descriptor path runs every tick — connection-major, one wave per
+        // connection, no per-record masks, no wire positions — the stamps of regular updates are kept per ring slot and the
+        // fan-out decides on them; the other forms keep "regular = stamped with the tick's own time".  CHD_ARRIVAL_OFFSETS=0: off (A/B).
+        d.off_on = (!d.cm_emit && !masks && !W.wire && (S >= 4096 || d.one_wave_emit) && C <= 4096) ? 1u : 0u;
+        if (const char *e = getenv("CHD_ARRIVAL_OFFSETS")) if (e[0] == '0') d.off_on = 0;
+        if (d.off_on) {
+            d.off_stride = (uint32_t)((N + 520 + 63) & ~(size_t)63);
+            TRY(walloc(ctx, &d.eoff, 2 * N));
+            TRY(walloc(ctx, &d.ce_off, (size_t)CHD_OFF_SLOTS * d.off_stride + 520));
+            TRY(walloc(ctx, &d.cell_orng, C * CHD_OFF_SLOTS));
+            TRY(walloc(ctx, &d.cell_ooff, 2 * C));
+            TRY(walloc(ctx, &d.n_filt, S));
+            TRY(walloc(ctx, &d.filt_desc, P, false));
+            TRY(walloc(ctx, &d.filt_desc2, P, false));
+            TRY(walloc(ctx, &d.filt_ln, P, false));
+            TRY(walloc(ctx, &d.filt_win, P * 4, false));
+        }
+        d.prev_ns = -1;
     }
     if (W.wire) {
         WireDev &x = W.x;
@@ -1420,6 +1438,7 @@ static int tick_locked(chd_ctx *ctx, const chd_tick_in *in) {
     const bool chained = ctx->chain_prev;
     TRY(tick_begin(ctx, in->now_ns));
     TickRing &r = ctx->ring;
+    d.prev_ns = r.n > 1 ? r.t[1] : -1;  // (sub-tick arrival offsets: a regular update arrived after the previous tick)
     // CHD_WORLD_PIPELINE_TICKS: the record-writing kernel of this tick runs on `stream` while the NEXT tick's stages
     // (ingest ... plan, commit, the deferred subscriptions, epilogue) run on the second stream: they write the other parity's
     // copies of what that kernel reads.  Stream order: stages(t) -> records(t) on `stream`; stages(t+1) after stages(t)
@@ -1441,6 +1460,11 @@ static int tick_locked(chd_ctx *ctx, const chd_tick_in *in) {
     if (const char *e = getenv("CHD_WINDOW_COLUMNS")) if (e[0] == '0') {  // (A/B runs: the per-tick choice of round 2)
         d.wcol_on = 0;
         d.seg_off = (!d.one_wave_emit && W.full_streak < 2u) ? 1u : 0u;
+    }
+    if (d.off_on) {  // sub-tick arrival offsets: always the descriptor path, whose filtered descriptors take every partial window
+        d.wcol_on = 0;
+        d.seg_off = 0;
+        if (!fanout_seg_path(d)) return fail(ctx, CHD_E_STATE, "tick: CHD_EMIT_PIPELINED=0 on a world that keeps arrival offsets (set CHD_ARRIVAL_OFFSETS=0 as well)");
     }
     const bool pipe = W.pipe_on && fanout_seg_path(d);
     W.last_desc = fanout_seg_path(d);
@@ -1533,6 +1557,7 @@ static int tick_locked(chd_ctx *ctx, const chd_tick_in *in) {
         if (prof_stages) HIPCHK(hipEventRecord(ev[1], bs));
         launch_index_build(bs, ctx->g, d, r.cur_tick);
         if (d.wcol_on && fanout_seg_path(d)) launch_window_columns(bs, ctx->g, d);
+        launch_cell_offsets(bs, ctx->g, d);
         if (prof_stages) HIPCHK(hipEventRecord(ev[2], bs));
         if (overlap) HIPCHK(hipStreamWaitEvent(bs, ctx->ev_join, 0));
         else
@@ -1577,6 +1602,7 @@ static int tick_locked(chd_ctx *ctx, const chd_tick_in *in) {
         if (prof) HIPCHK(hipEventRecord(ev[CHD_N_STAGES + 4], st));
         launch_fanout_emit_main(st, ctx->g, d, in->now_ns, r);
         if (prof) HIPCHK(hipEventRecord(ev[CHD_N_STAGES + 3], st));
+        launch_fanout_emit_filt(st, ctx->g, d);
         launch_fanout_emit_deferred(st, ctx->g, d, in->now_ns, r);
         launch_fanout_emit_deep(st, ctx->g, d, in->now_ns, r);
         if (prof_ends) HIPCHK(hipEventRecord(ev[5], st));
@@ -2688,6 +2714,8 @@ int chd_get_tick_history(chd_ctx *ctx, uint32_t n, chd_tick_stats *out) {
         s.n_unsubs = (uint32_t)r[4];
         s.n_pairs = (uint32_t)r[6];
         s.n_deferred_records = (uint32_t)(r[6] >> 32);
+        s.n_deep_records = (uint32_t)(r[2] >> 32);
+        s.n_filtered_records = (uint32_t)(r[3] >> 32);
         s.algorithmic_bytes = 12ull * s.n_records + 32ull * s.n_handovers;
         if (ctx->prof_depth > 0 && k < (uint32_t)ctx->prof_depth) stage_times(ctx, tick, s);
     }

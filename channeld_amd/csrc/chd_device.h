@@ -17,6 +17,7 @@
 #define CHD_WAVE 64
 #define CHD_HIST_BITS 32
 #define CHD_MAX_UPDATE_BUFFER 512u  // MaxUpdateMsgBufferSize, data.go:53-55
+#define CHD_OFF_SLOTS 8u  // ticks back for which a channel's update keeps its sub-tick arrival offset (WorldDev::off_on)
 
 // pair flags (per subscriber x spatial channel subscription state,
 // subscription.go:13-31 + data.go:39-44)

@@ -26,6 +26,17 @@ struct WsItemG {
 #define WSF_NWIN_SHIFT 8    // bits 8..10: number of stored windows
 #define WSF_OWN_SHIFT 16    // bit 16+j: the spatial channel's own update passes window j
 
+// One fan-out window of a filtered descriptor: an entity's message passes when one of its buffered updates lies inside the
+// window — an update of a ring slot the window covers whole (full), or of one of the (at most two) slots a window edge cuts
+// through, with its offset inside that slot's bounds (slot index 0xFF = unused; offsets are t[slot] - arrival).
+struct FiltWin {
+    uint32_t full;       // mask over the tick ring: every update of these slots lies inside the window
+    uint32_t slots;      // slot_a | slot_b << 8
+    uint32_t a_lo, a_hi; // slot_a: a_lo <= offset <= a_hi
+    uint32_t b_lo, b_hi; // slot_b
+    uint32_t _pad[2];
+};
+
 // ---- world state (all device pointers, SoA) ----
 struct WorldDev {
     uint32_t N, S, capq;
@@ -64,6 +75,32 @@ struct WorldDev {
     uint32_t *cell_irr;
     uint32_t *max_iv;
     uint32_t *conn_deep;  // [S] this tick: the connection has PF_DEEP subscriptions
+    // SUB-TICK ARRIVAL OFFSETS (off_on: worlds with exact update buffers on the descriptor path).  The reference stamps an
+    // update when it is ENQUEUED (Channel.PutMessage: arrivalTime = ch.GetTime(), channel.go:296-310), so a tick's updates
+    // carry stamps anywhere inside (previous tick, this tick].  For such REGULAR updates — one per channel and tick, stamp
+    // inside the tick's own interval, fewer than 2^32 ns before the tick — the tick-ring mask bit of the update keeps its
+    // meaning "an update arrived WITH tick (cur - j)" and the exact stamp is t[j] - offset, offset kept per ring slot for the
+    // newest CHD_OFF_SLOTS ticks: eoff (entity slots, aligned to hist_tick like the masks), ce_off (the cell-sorted columns the
+    // filtering record kernel streams, aligned to this tick: slot j at j * off_stride), cell_orng (per cell and slot the
+    // {min, max} offset over its entities' updates — the plan decides "every update of the slot inside / outside this window"
+    // from it and sends only cells that a window edge cuts through to the per-entity compare), cell_ooff (the spatial
+    // channels' own updates).  Anything else (a second update of a channel in one tick, a stamp at or before the previous
+    // tick's, a third sender) marks the channel irregular as before and its cell's subscriptions walk the element buffers.
+    uint32_t off_on;
+    uint32_t off_stride;
+    int64_t prev_ns;      // stamp of the previous tick (-1 before the first): set per tick by the host
+    uint4 *eoff;          // [2 * N]
+    uint32_t *ce_off;     // [CHD_OFF_SLOTS * off_stride]
+    uint2 *cell_orng;     // [ncell * CHD_OFF_SLOTS]
+    uint4 *cell_ooff;     // [2 * ncell]
+    // FILTERED descriptors (k_fanout_plan_seg -> k_fanout_emit_filt): due subscriptions with a window that a per-entity compare
+    // must decide (an edge cuts through a tick's arrivals, or some entity has no update in it).  Row s holds n_filt[s] entries:
+    // filt_desc {segment offset, column start, entries, windows | own-update bits << 8}, filt_desc2 / filt_ln as seg_desc2 /
+    // seg_ln, filt_win[(row index) * 4 + window] = the window's test (FiltWin)
+    uint32_t *n_filt;     // [S]
+    uint4 *filt_desc, *filt_desc2;  // [S * capq]
+    int64_t *filt_ln;     // [S * capq]
+    struct FiltWin *filt_win;  // [S * capq * 4]
     // cell index (rebuilt every tick)
     uint32_t nblk;        // histogram blocks
     uint32_t *blk_cnt;    // [ncell*nblk + 1] counts -> exclusive scan (cell-major)
@@ -192,6 +229,21 @@ __device__ __forceinline__ void deep_push(int64_t *__restrict__ A, uint32_t *__r
     if (len > CHD_MAX_UPDATE_BUFFER && A[(n - len) % D] + (int64_t)max_iv_ms * 1000000 < arrival) len--;
 }
 
+// a channel's offsets of the newest CHD_OFF_SLOTS ticks, moved on by `age` ticks: slot j takes what slot j - age held
+__device__ __forceinline__ void off_shift(uint32_t (&o)[CHD_OFF_SLOTS], uint32_t age) {
+    if (age == 0) return;
+    uint32_t r[CHD_OFF_SLOTS];
+#pragma unroll
+    for (int j = 0; j < (int)CHD_OFF_SLOTS; j++) {
+        uint32_t v = 0;
+#pragma unroll
+        for (int k = 0; k < j; k++) v = (age == (uint32_t)(j - k)) ? o[k] : v;
+        r[j] = v;
+    }
+#pragma unroll
+    for (int j = 0; j < (int)CHD_OFF_SLOTS; j++) o[j] = r[j];
+}
+
 __device__ __forceinline__ void push_update(const WorldDev &w, uint32_t i, uint32_t snd, uint32_t cur_tick,
                                             int64_t arrival = 0, int64_t now = 0) {
     const uint32_t age = cur_tick - w.hist_tick[i];
@@ -199,6 +251,18 @@ __device__ __forceinline__ void push_update(const WorldDev &w, uint32_t i, uint3
     uint32_t hp = (age >= CHD_HIST_BITS) ? 0u : (w.hist_prev[i] << age);
     const uint32_t cur = w.sender[i];
     bool irregular = arrival != now;  // (the masks stand for "arrived with the tick's own stamp")
+    if (w.off_on) {
+        // ... or, with the per-slot offsets, "arrived inside the tick's own interval": (previous tick, this tick], one per tick
+        const uint64_t off = (uint64_t)(now - arrival);
+        uint4 a = w.eoff[2 * (size_t)i], b = w.eoff[2 * (size_t)i + 1];
+        uint32_t o[CHD_OFF_SLOTS] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+        off_shift(o, age);
+        irregular = !(arrival > w.prev_ns && arrival <= now && off <= 0xFFFFFFFFull);
+        if (age == 0 && ((h | hp) & 1u) && o[0] != (uint32_t)off) irregular = true;  // a second update in this tick, another stamp
+        o[0] = (uint32_t)off;
+        w.eoff[2 * (size_t)i] = make_uint4(o[0], o[1], o[2], o[3]);
+        w.eoff[2 * (size_t)i + 1] = make_uint4(o[4], o[5], o[6], o[7]);
+    }
     if (snd != cur) {
         const uint32_t prev = w.sender_prev[i];
         if (snd == prev) {  // the previous sender is back: the two histories swap roles
@@ -434,6 +498,10 @@ void launch_fanout_plan(hipStream_t st, DevGrid g, WorldDev w, int64_t now_ns, T
 bool fanout_seg_path(const WorldDev &w);
 void launch_fanout_emit_main(hipStream_t st, DevGrid g, WorldDev w, int64_t now_ns, TickRing ring);
 void launch_fanout_emit_deferred(hipStream_t st, DevGrid g, WorldDev w, int64_t now_ns, TickRing ring);
+// the filtered descriptors (WorldDev::filt_*); no-op unless off_on
+void launch_fanout_emit_filt(hipStream_t st, DevGrid g, WorldDev w);
+// per cell and ring slot the range of the sub-tick offsets (WorldDev::cell_orng); after the index build, off_on worlds only
+void launch_cell_offsets(hipStream_t st, DevGrid g, WorldDev w);
 // subscriptions the tick-ring masks cannot answer (PF_DEEP), from the exact update buffers; no-op without history_depth
 void launch_fanout_emit_deep(hipStream_t st, DevGrid g, WorldDev w, int64_t now_ns, TickRing ring);
 #define TICK_RING 1024

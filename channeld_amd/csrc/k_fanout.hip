@@ -238,13 +238,15 @@ static bool seg_path_enabled() {
 // (CHD_WORLD_UPDATE_MASKS) a window is a plain copy only where its mask is the same for every entity (k_fanout_plan_seg)
 static bool seg_path(const WorldDev &w) { return !w.cm_emit && !w.seg_off && (w.S >= 4096 || w.one_wave_emit) && seg_path_enabled(); }
 
+template <bool OFF>
 __global__ void __launch_bounds__(64 * FO_WAVES) k_fanout_plan_seg(DevGrid g, WorldDev w, int64_t now, TickRing ring);
 
 void launch_fanout_plan(hipStream_t st, DevGrid g, WorldDev w, int64_t now_ns, TickRing ring) {
     if (!w.S) return;
-    if (seg_path(w))
-        hipLaunchKernelGGL(k_fanout_plan_seg, dim3((w.S + FO_WAVES - 1) / FO_WAVES), dim3(64 * FO_WAVES), 0, st, g, w, now_ns, ring);
-    else
+    if (seg_path(w)) {
+        if (w.off_on) hipLaunchKernelGGL(k_fanout_plan_seg<true>, dim3((w.S + FO_WAVES - 1) / FO_WAVES), dim3(64 * FO_WAVES), 0, st, g, w, now_ns, ring);
+        else hipLaunchKernelGGL(k_fanout_plan_seg<false>, dim3((w.S + FO_WAVES - 1) / FO_WAVES), dim3(64 * FO_WAVES), 0, st, g, w, now_ns, ring);
+    } else
         hipLaunchKernelGGL(k_fanout_plan, dim3((w.S + FO_WAVES - 1) / FO_WAVES), dim3(64 * FO_WAVES), 0, st, g, w,
                            now_ns, ring);
     launch_scan_u64_inplace(st, w.rec_ub, w.S);
@@ -672,6 +674,14 @@ __global__ void __launch_bounds__(64 * WAVES) k_fanout_emit(DevGrid g, WorldDev 
             w.pair_last[pbase + d2.y] = w.seg_ln[pbase + k];
             w.pair_flags[pbase + d2.y] = d2.z;
         }
+        if (w.off_on) {  // ... and for the filtered descriptors (k_fanout_emit_filt wrote their records)
+            const uint32_t nf = w.n_filt[s];
+            for (uint32_t k = lane; k < nf; k += 64) {
+                const uint4 d2 = w.filt_desc2[pbase + k];
+                w.pair_last[pbase + d2.y] = w.filt_ln[pbase + k];
+                w.pair_flags[pbase + d2.y] = d2.z;
+            }
+        }
         if (!w.conn_defer[s]) return;
     }
 #ifdef CHD_PROFILE_CONN_EMIT
@@ -894,13 +904,98 @@ typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
 #define FO_SEG_OCC 4     // waves per SIMD the register allocator is asked for (what limits this kernel is bytes in flight per wave, not waves)
 #endif
 
+// ---- sub-tick arrival offsets (WorldDev::off_on): the window walk of tickData against the REAL arrival stamps ----
+// A due subscription's windows [max(L,0) + kI, L + (k+1)I] against the ring slots: slot j holds the updates that arrived inside
+// (t[j+1], t[j]] at stamp t[j] - offset.  Per window and slot the offsets that lie inside the window are [A, B] = [t[j] - hi,
+// t[j] - lo]; with the cell's offset range of the slot (cell_orng) the slot is covered WHOLE (every update of it passes: the
+// slot's bit joins the window's mask, as a stamp inside the window does on the tick grid), not at all, or CUT by a window edge —
+// then the entities need a per-entity compare (FiltWin) and the subscription becomes a filtered descriptor.  Slots older than
+// CHD_OFF_SLOTS keep no offsets: whole / not at all by the slot's own interval, else the exact buffers decide (deep).
+struct OffPlan {
+    uint32_t full[4], slots[4], alo[4], ahi[4], blo[4], bhi[4];  // per non-empty window (FiltWin)
+    uint32_t ownm[4];   // ... the slots whose OWN update of the spatial channel lies inside it
+    uint32_t nw;        // non-empty windows (<= 4)
+    bool cut;           // some window has a slot a window edge cuts through
+    bool deep;          // undecidable here: more than four non-empty windows, a cut through a slot without offsets, ...
+    int64_t Lw;         // lastFanOutTime after the walk
+};
+
+__device__ __forceinline__ void plan_windows_off(const WorldDev &w, const TickRing &ring, int64_t now, int64_t L, int64_t I, uint32_t c,
+                                                 uint32_t ch_any /* the spatial channel's own update bits, any sender */, OffPlan &o) {
+    o.nw = 0; o.cut = false; o.deep = false; o.Lw = L;
+#pragma unroll
+    for (int k = 0; k < 4; k++) { o.full[k] = 0; o.slots[k] = 0; o.alo[k] = 1; o.ahi[k] = 0; o.blo[k] = 1; o.bhi[k] = 0; o.ownm[k] = 0; }
+    // the cell's offset ranges and its own channel's offsets: one round trip
+    const uint4 *rp = (const uint4 *)(const void *)(w.cell_orng + (size_t)c * CHD_OFF_SLOTS);
+    const uint4 r0 = rp[0], r1 = rp[1], r2 = rp[2], r3 = rp[3];
+    const uint4 q0 = w.cell_ooff[2 * (size_t)c], q1 = w.cell_ooff[2 * (size_t)c + 1];
+    const uint32_t rmin[CHD_OFF_SLOTS] = {r0.x, r0.z, r1.x, r1.z, r2.x, r2.z, r3.x, r3.z};
+    const uint32_t rmax[CHD_OFF_SLOTS] = {r0.y, r0.w, r1.y, r1.w, r2.y, r2.w, r3.y, r3.w};
+    const uint32_t coff[CHD_OFF_SLOTS] = {q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w};
+    int64_t nwin = (now - L) / I;
+    if (nwin > 64) { o.deep = true; return; }  // (a long catch-up: the element walk handles any number of windows)
+    int64_t Lw = L;
+    for (int64_t k = 0; k < nwin; k++) {
+        const int64_t hi = Lw + I, lo = Lw > 0 ? Lw : 0;
+        uint32_t fm = 0, om = 0, sa = 0, sb = 0, alo = 1, ahi = 0, blo = 1, bhi = 0, ncut = 0;
+        bool undecided = false;
+#pragma unroll
+        for (int j = 0; j < (int)CHD_OFF_SLOTS; j++) {
+            if ((uint32_t)j >= ring.n) continue;
+            const int64_t tj = ring.t[j];
+            if (tj < lo) continue;  // the whole slot is older than the window
+            const bool last = (uint32_t)(j + 1) >= ring.n;
+            const int64_t tp = last ? -1 : ring.t[j + 1];  // arrivals of the slot are > tp (the world's first tick: >= 0)
+            if (tp >= hi) continue;  // the whole slot is newer than the window
+            if (last && ring.n == CHD_HIST_BITS) { undecided = true; continue; }  // (the evicted stamp below it is unknown)
+            const int64_t A64 = tj - hi > 0 ? tj - hi : 0, B64 = tj - lo;
+            if (A64 > 0xFFFFFFFFll) continue;
+            const uint32_t A = (uint32_t)A64, B = B64 > 0xFFFFFFFFll ? 0xFFFFFFFFu : (uint32_t)B64;
+            if (rmin[j] <= rmax[j]) {  // (the cell holds updates of this slot)
+                if (A <= rmin[j] && rmax[j] <= B) fm |= 1u << j;
+                else if (!(rmax[j] < A || rmin[j] > B)) {
+                    if (ncut == 0) { sa = (uint32_t)j; alo = A; ahi = B; }
+                    else if (ncut == 1) { sb = (uint32_t)j; blo = A; bhi = B; }
+                    else undecided = true;
+                    ncut++;
+                }
+            }
+            if (A <= coff[j] && coff[j] <= B) om |= 1u << j;
+        }
+        for (uint32_t j = CHD_OFF_SLOTS; j < ring.n; j++) {  // slots without offsets: by their own interval
+            const int64_t tj = ring.t[j];
+            if (tj < lo) break;
+            const bool last = j + 1 >= ring.n;
+            const int64_t tp = last ? -1 : ring.t[j + 1];
+            if (tp >= hi) continue;
+            if (last && ring.n == CHD_HIST_BITS) { undecided = true; continue; }
+            // every arrival of the slot inside the window?  (tp, tj] within [lo, hi]
+            if (tp + 1 >= lo && tj <= hi) { fm |= 1u << j; om |= 1u << j; }
+            else undecided = true;
+        }
+        if (undecided) { o.deep = true; return; }
+        Lw = hi;
+        if (!fm && !ncut && !(om & ch_any)) continue;  // nothing can pass this window
+        if (o.nw == 4) { o.deep = true; return; }
+#pragma unroll
+        for (int q = 0; q < 4; q++)
+            if ((uint32_t)q == o.nw) {
+                o.full[q] = fm; o.slots[q] = sa | (sb << 8); o.alo[q] = alo; o.ahi[q] = ahi; o.blo[q] = blo; o.bhi[q] = bhi; o.ownm[q] = om;
+            }
+        o.nw++;
+        if (ncut) o.cut = true;
+    }
+    o.Lw = Lw;
+}
+
+template <bool OFF>
 __global__ void __launch_bounds__(64 * FO_WAVES) k_fanout_plan_seg(DevGrid g, WorldDev w, int64_t now, TickRing ring) {
-    if (blockIdx.x == 0 && threadIdx.x < 8) w.emit_ticket[32u * threadIdx.x] = 0;  // (this tick's k_fanout_emit_seg starts after this kernel)
+    if (blockIdx.x == 0 && threadIdx.x < 16) w.emit_ticket[32u * (threadIdx.x & 7u) + (threadIdx.x >> 3)] = 0;  // (this tick's k_fanout_emit_seg / _filt start after this kernel)
     const uint32_t s = blockIdx.x * FO_WAVES + (threadIdx.x >> 6);
     if (s >= w.S) return;
     const uint32_t lane = lane_id();
     uint64_t carry = 0;
-    uint32_t n_simple = 0, any_deferred = 0, hist_ovf = 0, any_deep = 0;
+    uint32_t n_simple = 0, n_filt = 0, any_deferred = 0, hist_ovf = 0, any_deep = 0;
     unsigned long long rec_simple = 0;
     const uint32_t cnt = w.sub_alive[s] ? w.pair_cnt[s] : 0u;
     const size_t pbase = (size_t)s * w.capq;
@@ -910,11 +1005,13 @@ __global__ void __launch_bounds__(64 * FO_WAVES) k_fanout_plan_seg(DevGrid g, Wo
     for (uint32_t p0 = 0; p0 < cnt; p0 += 64) {
         const uint32_t p = p0 + lane;
         uint64_t ub = 0;
-        bool due = false, simple = false, deep = false;
+        bool due = false, simple = false, deep = false, filt = false;
         uint32_t fl = 0, c = 0, size = 0, start = 0, info = 0, count = 0;
         uint32_t nd = 0, wcolp = 0, own = 0, ncol0 = 0;  // descriptors of this subscription; per window its column (4 bits each)
         uint4 wm4 = make_uint4(0u, 0u, 0u, 0u);          // (per-record masks) the windows' masks
         int64_t Lw = 0;
+        OffPlan op;
+        op.nw = 0; op.deep = false; op.cut = false; op.Lw = 0;
         if (p < cnt) {
             fl = w.pair_flags[pbase + p] & ~(PF_DEFER | PF_DEEP);
             const int64_t L = w.pair_last[pbase + p];
@@ -948,6 +1045,18 @@ __global__ void __launch_bounds__(64 * FO_WAVES) k_fanout_plan_seg(DevGrid g, Wo
                     ub = (uint64_t)nwin * ((uint64_t)size + 1);
                 }
                 bool hlost = false;
+                if (OFF) {
+                  if (now >= Lw + I) {
+                    // the walk against the real arrival stamps (plan_windows_off); wms = the slots each window covers whole
+                    const uint32_t age = ring.cur_tick - w.cell_hist_tick[c];
+                    const uint32_t ch_any = age < CHD_HIST_BITS ? ((w.cell_hist[c] | w.cell_hist_prev[c]) << age) : 0u;
+                    plan_windows_off(w, ring, now, Lw, I, c, ch_any, op);
+                    Lw = op.Lw;
+                    nw = op.nw;
+#pragma unroll
+                    for (int q = 0; q < 4; q++) wms[q] = op.full[q];
+                  }
+                } else
                 if (now >= Lw + I) {
                     hlost = history_lost(ring, oldest, Lw, I);
                     while (now >= Lw + I) {  // data.go:224-271 + the revisit through :273-286
@@ -991,9 +1100,19 @@ __global__ void __launch_bounds__(64 * FO_WAVES) k_fanout_plan_seg(DevGrid g, Wo
                 // subscription served every interval sees).  A descriptor carries one column: windows that agree share one
                 // descriptor, a subscription whose windows differ gets one descriptor per window (contiguous parts).
                 bool same = true;
+                if (OFF && !none) {
+                    // A window is a plain copy of the cell's column when some slot it covers WHOLE holds an update of every entity
+                    // (hand); any other non-empty window — an edge cuts through the arrivals of a tick, some entity skipped an
+                    // update, only the spatial channel's own update passes — takes the per-entity compare (FiltWin)
+                    bool need = false;
+#pragma unroll
+                    for (uint32_t j = 0; j < 4; j++)
+                        if (j < nw && !(hand & wms[j])) need = true;
+                    if (need) { filt = simple && us != CHD_NONUNIFORM; simple = false; }
+                }
 #pragma unroll
                 for (uint32_t j = 0; j < 4; j++) {
-                    if (j >= nw || none) continue;
+                    if (j >= nw || none || (OFF && !simple)) continue;
                     uint32_t cj = 0xFFFFFFFEu;
                     if (us != CHD_NONUNIFORM) {
                         // (per-record masks: the record's mask is its entity's history inside the window — a constant, the
@@ -1009,14 +1128,30 @@ __global__ void __launch_bounds__(64 * FO_WAVES) k_fanout_plan_seg(DevGrid g, Wo
                     wcolp |= (cj & 15u) << (4u * j);
                     if (j && cj != (wcolp & 15u)) same = false;
                 }
-                if (simple) {  // (may still turn false below)
+                if (OFF && !(info & SD_FIRST) && (op.deep || (!simple && !filt))) {  // (a first fan-out evaluates no window: the filtering launch takes what is not simple)
+                    // not decidable from the masks and offsets (plan_windows_off), or a shape the filtered kernel does not take
+                    // (several senders of whom this connection may be one, a cell of more than 512 entities): the element buffers
+                    deep = true;
+                    due = false;
+                    simple = filt = false;
+                    ub = deep_upper_bound(w, now, L, I, size);
+                    w.pair_flags[pbase + p] = fl | PF_DEEP;
+                }
+                if (simple || filt) {  // (may still turn false below)
                     // exact record counts: the segment is as long as what will be written
                     const uint32_t age = ring.cur_tick - c_htick;
                     const uint32_t chh = age < CHD_HIST_BITS ? (c_hist << age) : 0u;
                     const uint32_t chhp = age < CHD_HIST_BITS ? (c_hprev << age) : 0u;
 #pragma unroll
                     for (uint32_t j = 0; j < 4; j++)
-                        if (j < nw && cell_update_passes(chh, chs, chhp, chsp, wms[j], skip_self, conn)) own |= 1u << j;
+                        if (j < nw && cell_update_passes(chh, chs, chhp, chsp, OFF ? op.ownm[j] : wms[j], skip_self, conn)) own |= 1u << j;
+                }
+                if (filt) {
+                    // worst case per window: every entity of the cell (+ the own update); the kernel writes the count
+                    ub = (uint64_t)__popc(own) + (uint64_t)nw * size;
+                    if (hlost) hist_ovf = 1;
+                }
+                if (simple) {
                     if (own && w.rec_mask) simple = false;  // (the spatial channel's own record carries its own mask: the filtering launch)
                     wm4 = make_uint4(wms[0], wms[1], wms[2], wms[3]);
                     info |= nw | (none ? SD_NONE : 0u);
@@ -1057,8 +1192,9 @@ __global__ void __launch_bounds__(64 * FO_WAVES) k_fanout_plan_seg(DevGrid g, Wo
             dbase = n_simple + mask_rank(__ballot(simple));
         }
         if (simple && dbase + nd > w.capq) simple = false;
-        if (due && !simple) w.pair_flags[pbase + p] = fl | PF_DEFER;
+        if (due && !simple && !filt) w.pair_flags[pbase + p] = fl | PF_DEFER;
         if (due && simple) ub = count;
+        const uint32_t fbase = OFF ? n_filt + mask_rank(__ballot(due && filt)) : 0u;
         // every segment starts on a 128-byte line and is padded to whole lines (k_fanout_plan)
         ub = (ub + (CHD_SEG_ALIGN - 1)) & ~(uint64_t)(CHD_SEG_ALIGN - 1);
         uint64_t inc = ub;
@@ -1075,8 +1211,25 @@ __global__ void __launch_bounds__(64 * FO_WAVES) k_fanout_plan_seg(DevGrid g, Wo
             if (w.pair_desc) w.pair_desc[pbase + p] = (due && simple) ? (dbase | (nd << 28)) : 0xFFFFFFFFu;
         }
         carry += __shfl((unsigned long long)inc, 63);
-        if (__ballot(due && !simple)) any_deferred = 1;
+        if (__ballot(due && !simple && !filt)) any_deferred = 1;
         if (__ballot(deep)) any_deep = 1;
+        if (OFF) {
+            if (due && filt) {
+                const size_t k = pbase + fbase;
+                w.filt_desc[k] = make_uint4(rel32, start, size, op.nw | (own << 8));
+                w.filt_desc2[k] = make_uint4(c, p, fl | PF_HAD_FIRST, 0u);
+                w.filt_ln[k] = Lw;
+#pragma unroll
+                for (uint32_t j = 0; j < 4; j++)
+                    if (j < op.nw) {
+                        FiltWin fw;
+                        fw.full = op.full[j]; fw.slots = op.slots[j]; fw.a_lo = op.alo[j]; fw.a_hi = op.ahi[j]; fw.b_lo = op.blo[j]; fw.b_hi = op.bhi[j];
+                        fw._pad[0] = 0; fw._pad[1] = 0;
+                        w.filt_win[k * 4 + j] = fw;
+                    }
+            }
+            n_filt += (uint32_t)__popcll(__ballot(due && filt));
+        }
         if (due && simple) {
             if (nd == 1) {
                 const uint32_t col = wcolp & 15u;
@@ -1113,6 +1266,7 @@ __global__ void __launch_bounds__(64 * FO_WAVES) k_fanout_plan_seg(DevGrid g, Wo
     if (lane == 0) {
         w.rec_ub[s] = carry > 0xFFFFFFFFull ? (1ull << 40) : carry;
         w.n_simple[s] = n_simple;
+        if (OFF) w.n_filt[s] = n_filt;
         w.conn_defer[s] = any_deferred;
         if (w.deep_depth) w.conn_deep[s] = any_deep;
         w.rec_cnt[s] = (uint32_t)rec_simple;
@@ -1320,6 +1474,181 @@ __global__ void __launch_bounds__(64, FO_SEG_OCC) k_fanout_emit_seg(DevGrid g, W
     if (threadIdx.x == 0 && s < 16384) fo_trace[4 * s + 3] = w.rec_cnt[s];
 #endif
     }
+}
+
+// ---------------------------------------------------------------------------
+// The FILTERED descriptors (WorldDev::off_on; k_fanout_plan_seg<true>): subscriptions with a window that needs a per-entity
+// decision — a window edge cuts through the arrival stamps of a tick (the reference stamps updates when they are enqueued,
+// channel.go:296-310, so every window of a subscription whose phase is off the tick grid does), or some entity of the cell has
+// no update inside it.  Per descriptor the wave loads the cell's {channel, history} entries once (adjacent pairs: one 16-byte
+// load per lane and 128 entries) and, per window, the offset columns of the one or two ring slots the edges cut (8 bytes per
+// lane and 128 entries each); an entity passes when an update of a slot the window covers whole is buffered, or one of a cut
+// slot with its offset inside the bounds (FiltWin) — the comparison of data.go:236-241 on exact nanosecond stamps.  Passing
+// entries are compacted by ballot / mbcnt in entry order and stored as {conn, channel} records; rows where everything passes
+// take one 16-byte store per lane.  Persistent single-wave workgroups, tickets as k_fanout_emit_seg (their own counters).
+// ---------------------------------------------------------------------------
+#ifndef FO_FILT_WAVES
+#define FO_FILT_WAVES 2
+#endif
+template <int WAVES>
+__global__ void __launch_bounds__(64, 4) k_fanout_emit_filt(DevGrid g, WorldDev w, uint32_t n_tickets) {
+    static_assert((WAVES & (WAVES - 1)) == 0, "waves per connection: a power of two");
+    constexpr uint32_t WSH = WAVES == 1 ? 0u : WAVES == 2 ? 1u : WAVES == 4 ? 2u : 3u;
+    const uint32_t lane = lane_id();
+    const uint32_t bank = blockIdx.x & 7u;
+    uint32_t *__restrict__ ctr = w.emit_ticket + 32u * bank + 1u;
+    const uint2 *__restrict__ ce8 = w.ce8_view;
+    const uint32_t *__restrict__ offs = w.ce_off;
+    uint32_t tk = 0;
+    if (lane == 0) tk = atomicAdd(ctr, 1u);
+    tk = (uint32_t)__builtin_amdgcn_readfirstlane((int)tk);
+    for (;;) {
+        const uint32_t T = 8u * tk + bank;
+        if (T >= n_tickets) break;
+        uint32_t tk_next = 0;
+        if (lane == 0) tk_next = atomicAdd(ctr, 1u);
+        const uint32_t s = T >> WSH, role = T & (WAVES - 1u);
+        const uint32_t nf = w.n_filt[s];
+        const size_t pbase = (size_t)s * w.capq;
+        const uint64_t base = w.rec_ub[s], end = w.rec_ub[s + 1];
+        tk = (uint32_t)__builtin_amdgcn_readfirstlane((int)tk_next);
+        // (end > recs_cap: no room for this connection's worst case — the deferred launch leaves its state as it was and flags the tick)
+        if (role >= nf || end > w.recs_cap) continue;
+        const uint32_t conn = w.conn_id[s];
+        uint32_t total = 0;
+        for (uint32_t k = role; k < nf; k += WAVES) {
+            const uint4 d = w.filt_desc[pbase + k];
+            const uint4 d2 = w.filt_desc2[pbase + k];
+            const uint32_t rel = (uint32_t)__builtin_amdgcn_readfirstlane((int)d.x), start = (uint32_t)__builtin_amdgcn_readfirstlane((int)d.y);
+            const uint32_t n = (uint32_t)__builtin_amdgcn_readfirstlane((int)d.z), info = (uint32_t)__builtin_amdgcn_readfirstlane((int)d.w);
+            const uint32_t cch = (uint32_t)__builtin_amdgcn_readfirstlane((int)d2.x) + g.id_start;
+            const uint32_t p = (uint32_t)__builtin_amdgcn_readfirstlane((int)d2.y);
+            const uint32_t nw = info & 7u, own = (info >> 8) & 15u;
+            chd_fanout_rec *__restrict__ out = w.recs + base + rel;
+            // the cell's entries: row h = entries 128 h + 2 lane, + 1 (lanes beyond the cell read spare entries: never used)
+            u32x4 e[4];
+            {
+                const uint2 *pa = ce8 + start + 2 * lane;
+                asm volatile(
+                    "global_load_dwordx4 %0, %4, off\n\t"
+                    "global_load_dwordx4 %1, %4, off offset:1024\n\t"
+                    "global_load_dwordx4 %2, %4, off offset:2048\n\t"
+                    "global_load_dwordx4 %3, %4, off offset:3072\n\t"
+                    "s_waitcnt vmcnt(0)"
+                    : "=&v"(e[0]), "=&v"(e[1]), "=&v"(e[2]), "=&v"(e[3])
+                    : "v"(pa)
+                    : "memory");
+            }
+            uint32_t n_out = 0;
+            for (uint32_t j = 0; j < nw; j++) {
+                const FiltWin *fwp = w.filt_win + (pbase + k) * 4 + j;
+                const uint4 f0 = *(const uint4 *)(const void *)fwp;
+                const uint2 f1 = *(const uint2 *)(const void *)&fwp->b_lo;
+                const uint32_t full = (uint32_t)__builtin_amdgcn_readfirstlane((int)f0.x), slots = (uint32_t)__builtin_amdgcn_readfirstlane((int)f0.y);
+                const uint32_t a_lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)f0.z), a_hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)f0.w);
+                const uint32_t b_lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)f1.x), b_hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)f1.y);
+                const uint32_t sa = slots & 0xFFu, sb = (slots >> 8) & 0xFFu;
+                const bool use_a = a_lo <= a_hi, use_b = b_lo <= b_hi;
+                if ((own >> j) & 1u) {  // the spatial channel's own buffered update lies inside this window
+                    if (lane == 0) {
+                        chd_fanout_rec r;
+                        r.conn = conn;
+                        r.channel = cch;
+                        out[n_out] = r;
+                    }
+                    n_out += 1;
+                }
+                u32x2 oa[4], ob[4];
+#pragma unroll
+                for (int h = 0; h < 4; h++) { oa[h].x = 0; oa[h].y = 0; ob[h].x = 0; ob[h].y = 0; }
+                // (the wait sits inside the block that issues the loads: the allocator may copy an asm output before a later wait,
+                // and the hardware does not interlock a v_mov on an outstanding load)
+                if (use_b) {
+                    const uint32_t *pa = offs + (size_t)sa * w.off_stride + start + 2 * lane;
+                    const uint32_t *pb = offs + (size_t)sb * w.off_stride + start + 2 * lane;
+                    asm volatile(
+                        "global_load_dwordx2 %0, %8, off\n\t"
+                        "global_load_dwordx2 %1, %8, off offset:512\n\t"
+                        "global_load_dwordx2 %2, %8, off offset:1024\n\t"
+                        "global_load_dwordx2 %3, %8, off offset:1536\n\t"
+                        "global_load_dwordx2 %4, %9, off\n\t"
+                        "global_load_dwordx2 %5, %9, off offset:512\n\t"
+                        "global_load_dwordx2 %6, %9, off offset:1024\n\t"
+                        "global_load_dwordx2 %7, %9, off offset:1536\n\t"
+                        "s_waitcnt vmcnt(0)"
+                        : "=&v"(oa[0]), "=&v"(oa[1]), "=&v"(oa[2]), "=&v"(oa[3]), "=&v"(ob[0]), "=&v"(ob[1]), "=&v"(ob[2]), "=&v"(ob[3])
+                        : "v"(pa), "v"(pb)
+                        : "memory");
+                } else if (use_a) {
+                    const uint32_t *pa = offs + (size_t)sa * w.off_stride + start + 2 * lane;
+                    asm volatile(
+                        "global_load_dwordx2 %0, %4, off\n\t"
+                        "global_load_dwordx2 %1, %4, off offset:512\n\t"
+                        "global_load_dwordx2 %2, %4, off offset:1024\n\t"
+                        "global_load_dwordx2 %3, %4, off offset:1536\n\t"
+                        "s_waitcnt vmcnt(0)"
+                        : "=&v"(oa[0]), "=&v"(oa[1]), "=&v"(oa[2]), "=&v"(oa[3])
+                        : "v"(pa)
+                        : "memory");
+                }
+                const uint32_t bit_a = use_a ? 1u << sa : 0u, bit_b = use_b ? 1u << sb : 0u;
+#pragma unroll
+                for (int h = 0; h < 4; h++) {
+                    if (n <= (uint32_t)(128 * h)) break;  // uniform
+                    const uint32_t q = 128u * h + 2 * lane;
+                    const bool in0 = q < n, in1 = q + 1 < n;
+                    const uint32_t h0 = e[h].y, h1 = e[h].w;
+                    const bool pass0 = in0 && ((h0 & full) != 0 || ((h0 & bit_a) != 0 && oa[h].x >= a_lo && oa[h].x <= a_hi) ||
+                                               ((h0 & bit_b) != 0 && ob[h].x >= b_lo && ob[h].x <= b_hi));
+                    const bool pass1 = in1 && ((h1 & full) != 0 || ((h1 & bit_a) != 0 && oa[h].y >= a_lo && oa[h].y <= a_hi) ||
+                                               ((h1 & bit_b) != 0 && ob[h].y >= b_lo && ob[h].y <= b_hi));
+                    const uint64_t m0 = __ballot(pass0), m1 = __ballot(pass1);
+                    if ((m0 & m1) == ~0ull) {
+                        u32x4 r;
+                        r.x = conn; r.y = e[h].x; r.z = conn; r.w = e[h].z;
+                        // (8-byte aligned: n_out is any record index)
+                        typedef u32x4 __attribute__((aligned(8))) u32x4_a8;
+                        *(u32x4_a8 *)(void *)(out + n_out + 2 * lane) = r;
+                        n_out += 128;
+                    } else {
+                        // entry order: records before this lane's pair = passing entries of lower lanes
+                        const uint32_t at = __builtin_amdgcn_mbcnt_hi((uint32_t)(m1 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m1,
+                                            __builtin_amdgcn_mbcnt_hi((uint32_t)(m0 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m0, n_out))));
+                        if (pass0) {
+                            chd_fanout_rec r;
+                            r.conn = conn;
+                            r.channel = e[h].x;
+                            out[at] = r;
+                        }
+                        if (pass1) {
+                            chd_fanout_rec r;
+                            r.conn = conn;
+                            r.channel = e[h].z;
+                            out[at + (pass0 ? 1u : 0u)] = r;
+                        }
+                        n_out += (uint32_t)__popcll(m0) + (uint32_t)__popcll(m1);
+                    }
+                }
+            }
+            pad_segment(out, n_out);
+            if (lane == 0) w.pair_nrec[pbase + p] = n_out;
+            total += n_out;
+        }
+        if (lane == 0 && total) {
+            atomicAdd(&w.rec_cnt[s], total);
+            unsigned long long *slot = (unsigned long long *)&w.tot64[(size_t)(s & 63u) * 16];
+            atomicAdd(slot, (unsigned long long)total);
+            atomicAdd(slot + 2, (unsigned long long)total);  // (not written by the dominant emit kernel)
+            atomicAdd(slot + 4, (unsigned long long)total);  // (chd_tick_stats.n_filtered_records)
+        }
+    }
+}
+
+void launch_fanout_emit_filt(hipStream_t st, DevGrid g, WorldDev w) {
+    if (!w.S || !w.off_on || !seg_path(w)) return;
+    const uint32_t n_tickets = w.S * FO_FILT_WAVES;
+    const dim3 grid(n_tickets < w.seg_waves ? n_tickets : w.seg_waves);
+    hipLaunchKernelGGL((k_fanout_emit_filt<FO_FILT_WAVES>), grid, dim3(64), 0, st, g, w, n_tickets);
 }
 
 // ---------------------------------------------------------------------------
@@ -1976,6 +2305,7 @@ __global__ void __launch_bounds__(64) k_fanout_emit_deep(DevGrid g, WorldDev w, 
         unsigned long long *slot = (unsigned long long *)&w.tot64[(size_t)(s & 63u) * 16];
         atomicAdd(slot, (unsigned long long)total);
         atomicAdd(slot + 2, (unsigned long long)total);  // (not written by the dominant emit kernel)
+        atomicAdd(slot + 3, (unsigned long long)total);  // (chd_tick_stats.n_deep_records)
     }
 }
 
@@ -1992,10 +2322,13 @@ __global__ void __launch_bounds__(64) k_tick_epilogue(WorldDev w, uint32_t slot,
     if (w.deep_depth)  // (set again by the next tick's index build)
         for (uint32_t c = lane; c < ncell; c += 64) w.cell_irr[c] = 0;
     unsigned long long sum = w.tot64[(size_t)lane * 16], pairs = w.tot64[(size_t)lane * 16 + 1], deferred = w.tot64[(size_t)lane * 16 + 2];
+    unsigned long long deepr = w.tot64[(size_t)lane * 16 + 3], filtr = w.tot64[(size_t)lane * 16 + 4];
     for (int d = 32; d >= 1; d >>= 1) {
         sum += __shfl_xor(sum, d);
         pairs += __shfl_xor(pairs, d);
         deferred += __shfl_xor(deferred, d);
+        deepr += __shfl_xor(deepr, d);
+        filtr += __shfl_xor(filtr, d);
     }
     // unsub / new-sub bank tails: totals for the ring, per-bank counts kept for chd_tick_fetch
     uint32_t un = w.list_ctr[lane * 32u], nn = w.list_ctr[(CHD_LIST_BANKS + lane) * 32u];
@@ -2013,8 +2346,9 @@ __global__ void __launch_bounds__(64) k_tick_epilogue(WorldDev w, uint32_t slot,
         uint64_t *r = w.tick_ring + (size_t)slot * 8;
         r[0] = sum;
         r[1] = w.rec_ub[w.S];
-        r[2] = w.counters[CTR_HANDOVERS];
-        r[3] = w.counters[CTR_LOCKED];
+        // (high halves, saturating: the records written by the element-buffer walk / by the filtered descriptors)
+        r[2] = (uint64_t)w.counters[CTR_HANDOVERS] | ((deepr > 0xFFFFFFFFull ? 0xFFFFFFFFull : deepr) << 32);
+        r[3] = (uint64_t)w.counters[CTR_LOCKED] | ((filtr > 0xFFFFFFFFull ? 0xFFFFFFFFull : filtr) << 32);
         r[4] = un;
         r[5] = nn;
         r[6] = (pairs & 0xFFFFFFFFull) | ((deferred > 0xFFFFFFFFull ? 0xFFFFFFFFull : deferred) << 32);
@@ -2026,6 +2360,8 @@ __global__ void __launch_bounds__(64) k_tick_epilogue(WorldDev w, uint32_t slot,
     w.tot64[(size_t)lane * 16] = 0;
     w.tot64[(size_t)lane * 16 + 1] = 0;
     w.tot64[(size_t)lane * 16 + 2] = 0;
+    w.tot64[(size_t)lane * 16 + 3] = 0;
+    w.tot64[(size_t)lane * 16 + 4] = 0;
 }
 
 void launch_tick_epilogue(hipStream_t st, WorldDev w, uint32_t slot, uint32_t ncell) {

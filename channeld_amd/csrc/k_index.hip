@@ -164,6 +164,15 @@ __global__ void __launch_bounds__(256) k_index_scan(WorldDev w, uint32_t ncell, 
     }
 }
 
+// the entity's sub-tick arrival offsets (WorldDev::off_on), aligned to this tick, into the cell-sorted columns
+__device__ __forceinline__ void scatter_offsets(const WorldDev &w, uint32_t i, uint32_t pos, uint32_t age) {
+    const uint4 a = w.eoff[2 * (size_t)i], b = w.eoff[2 * (size_t)i + 1];
+    uint32_t o[CHD_OFF_SLOTS] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+    off_shift(o, age);
+#pragma unroll
+    for (uint32_t j = 0; j < CHD_OFF_SLOTS; j++) w.ce_off[(size_t)j * w.off_stride + pos] = o[j];
+}
+
 __device__ __forceinline__ void index_scatter_block(const WorldDev &w, uint32_t ncell, uint32_t key_bits, uint32_t cur_tick, int local_base,
                                                     uint32_t bid, unsigned char *smem) {
     uint32_t *wcnt = (uint32_t *)smem;  // [4][ncell] running per-wave counters
@@ -255,6 +264,7 @@ __device__ __forceinline__ void index_scatter_block(const WorldDev &w, uint32_t 
         w.ce_chan[pos] = w.chan_id[i];
         w.ce_sprev[pos] = w.sender_prev[i];
         if (w.ce_slot) w.ce_slot[pos] = i;
+        if (w.off_on) scatter_offsets(w, i, pos, age);
     }
 }
 
@@ -299,6 +309,7 @@ __global__ void __launch_bounds__(256) k_index_scatter_global(WorldDev w, uint32
     w.ce_sprev[pos] = w.sender_prev[i];
     w.ce_chan[pos] = w.chan_id[i];
     if (w.ce_slot) w.ce_slot[pos] = i;
+    if (w.off_on) scatter_offsets(w, i, pos, age);
 }
 
 // ------------------------------------------------------------------------
@@ -414,6 +425,48 @@ __global__ void __launch_bounds__(256) k_window_columns(WorldDev w, uint32_t nce
 #pragma unroll
     for (int j = 0; j < CHD_WCOLS; j++)  // (constant indices: the counters stay in registers)
         if (threadIdx.x == (uint32_t)j) w.cell_wcnt[(size_t)j * ncell + c] = build[j] ? run[j] : n;
+}
+
+// Per cell and ring slot j < CHD_OFF_SLOTS the {min, max} sub-tick offset over the cell's entities that hold an update of that
+// slot (WorldDev::cell_orng; min > max: none does).  One workgroup per cell over its cell-sorted entries.
+__global__ void __launch_bounds__(256) k_cell_offsets(WorldDev w, uint32_t ncell) {
+    __shared__ uint32_t smn[4][CHD_OFF_SLOTS], smx[4][CHD_OFF_SLOTS];
+    const uint32_t c = blockIdx.x;
+    const uint32_t start = w.cell_off[c], n = w.cell_off[c + 1] - start;
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    uint32_t mn[CHD_OFF_SLOTS], mx[CHD_OFF_SLOTS];
+#pragma unroll
+    for (uint32_t j = 0; j < CHD_OFF_SLOTS; j++) { mn[j] = 0xFFFFFFFFu; mx[j] = 0u; }
+    for (uint32_t k = threadIdx.x; k < n; k += 256) {
+        const uint32_t h = w.ce8[start + k].y;  // history of any sender, aligned to this tick
+#pragma unroll
+        for (uint32_t j = 0; j < CHD_OFF_SLOTS; j++) {
+            if (!((h >> j) & 1u)) continue;
+            const uint32_t o = w.ce_off[(size_t)j * w.off_stride + start + k];
+            mn[j] = min(mn[j], o);
+            mx[j] = max(mx[j], o);
+        }
+    }
+#pragma unroll
+    for (uint32_t j = 0; j < CHD_OFF_SLOTS; j++) {
+        for (int d = 32; d >= 1; d >>= 1) {
+            mn[j] = min(mn[j], (uint32_t)__shfl_xor((int)mn[j], d));
+            mx[j] = max(mx[j], (uint32_t)__shfl_xor((int)mx[j], d));
+        }
+        if (lane == 0) { smn[wave][j] = mn[j]; smx[wave][j] = mx[j]; }
+    }
+    __syncthreads();
+    if (threadIdx.x < CHD_OFF_SLOTS) {
+        const uint32_t j = threadIdx.x;
+        const uint32_t a = min(min(smn[0][j], smn[1][j]), min(smn[2][j], smn[3][j]));
+        const uint32_t b = max(max(smx[0][j], smx[1][j]), max(smx[2][j], smx[3][j]));
+        w.cell_orng[(size_t)c * CHD_OFF_SLOTS + j] = make_uint2(a, b);
+    }
+}
+
+void launch_cell_offsets(hipStream_t st, DevGrid g, WorldDev w) {
+    if (!w.N || !w.off_on) return;
+    hipLaunchKernelGGL(k_cell_offsets, dim3(g.ncell), dim3(256), 0, st, w, g.ncell);
 }
 
 void launch_window_columns(hipStream_t st, DevGrid g, WorldDev w) {

@@ -536,8 +536,10 @@ __global__ void __launch_bounds__(256) k_cell_updates(DevGrid g, WorldDev w, uin
     uint32_t dn = 0, dlen = 0;
     int64_t ddrop = INT64_MIN;
     const uint32_t max_iv = w.deep_depth ? *w.max_iv : 0u;
+    uint32_t oo[CHD_OFF_SLOTS] = {0, 0, 0, 0, 0, 0, 0, 0};  // (off_on) the channel's sub-tick offsets, aligned to this tick
     for (uint32_t u = 0; u < n; u++) {
         if (chan[u] - g.id_start != c) continue;
+        bool first_now = false;
         if (!touched) {
             const uint32_t age = cur_tick - w.cell_hist_tick[c];
             h = (age >= CHD_HIST_BITS) ? 0u : (w.cell_hist[c] << age);
@@ -545,12 +547,24 @@ __global__ void __launch_bounds__(256) k_cell_updates(DevGrid g, WorldDev w, uin
             cur = w.cell_sender[c];
             prev = w.cell_sender_prev[c];
             touched = true;
+            first_now = !((h | hp) & 1u);
             if (w.deep_depth) { dn = w.cdeep_n[c]; dlen = w.cdeep_len[c]; ddrop = w.cdeep_drop[c]; }
+            if (w.off_on) {
+                const uint4 a = w.cell_ooff[2 * (size_t)c], b = w.cell_ooff[2 * (size_t)c + 1];
+                oo[0] = a.x; oo[1] = a.y; oo[2] = a.z; oo[3] = a.w; oo[4] = b.x; oo[5] = b.y; oo[6] = b.z; oo[7] = b.w;
+                off_shift(oo, age);
+            }
         }
         const uint32_t snd = sender[u];
         if (w.deep_depth) {
             const int64_t a = arrival ? arrival[u] : now;
-            if (a != now) irregular = true;
+            if (w.off_on) {
+                // regular: inside the tick's own interval, and the channel's only stamp of this tick (WorldDev::off_on)
+                const uint64_t off = (uint64_t)(now - a);
+                if (!(a > w.prev_ns && a <= now && off <= 0xFFFFFFFFull)) irregular = true;
+                if (!first_now && oo[0] != (uint32_t)off) irregular = true;
+                oo[0] = (uint32_t)off;
+            } else if (a != now) irregular = true;
             const size_t at = (size_t)c * w.deep_depth;
             deep_push(w.cdeep_a + at, w.cdeep_s + at, w.deep_depth, dn, dlen, ddrop, a, snd, max_iv);
         }
@@ -578,6 +592,10 @@ __global__ void __launch_bounds__(256) k_cell_updates(DevGrid g, WorldDev w, uin
     if (touched && w.deep_depth) {
         w.cdeep_n[c] = dn; w.cdeep_len[c] = dlen; w.cdeep_drop[c] = ddrop;
         if (irregular) w.cell_irr_tick[c] = cur_tick + 1u;
+        if (w.off_on) {
+            w.cell_ooff[2 * (size_t)c] = make_uint4(oo[0], oo[1], oo[2], oo[3]);
+            w.cell_ooff[2 * (size_t)c + 1] = make_uint4(oo[4], oo[5], oo[6], oo[7]);
+        }
     }
     if (touched) {
         w.cell_hist[c] = h;

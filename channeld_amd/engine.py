@@ -441,11 +441,13 @@ class SpatialWorld:
         return d
 
     def tick_device(self, now_ns: int, n_updates: int = 0, d_upd_x=None, d_upd_z=None, d_upd_idx=None,
-                    d_upd_sender=None, n_queries: int = 0, d_queries=None, d_query_sub=None):
+                    d_upd_sender=None, n_queries: int = 0, d_queries=None, d_query_sub=None, d_upd_arrival=None):
         ti = TickIn()
         ti.now_ns = int(now_ns)
         ti.n_updates, ti.upd_idx, ti.upd_x, ti.upd_z, ti.upd_sender = n_updates, d_upd_idx, d_upd_x, d_upd_z, d_upd_sender
         ti.n_queries, ti.query_sub, ti.queries = n_queries, d_query_sub, d_queries
+        if d_upd_arrival is not None:  # exact worlds (history_depth): the updates' own enqueue stamps (chd_tick_in.upd_arrival_ns)
+            ti.upd_arrival_ns = d_upd_arrival
         _lib.check(self.ctx, self.lib.chd_tick_device(self.ctx, C.byref(ti)))
         self._last_nq = n_queries
 
@@ -523,7 +525,8 @@ class SpatialWorld:
         for s in reversed(arr):
             out.append(dict(stage_us=[float(s.stage_us[i]) for i in range(_lib.N_STAGES)], total_us=float(s.total_us), emit_main_us=float(s.emit_main_us),
                             n_records=int(s.n_records), n_record_upper_bound=int(s.n_record_upper_bound),
-                            n_handovers=int(s.n_handovers), n_unsubs=int(s.n_unsubs), n_pairs=int(s.n_pairs), n_deferred_records=int(s.n_deferred_records)))
+                            n_handovers=int(s.n_handovers), n_unsubs=int(s.n_unsubs), n_pairs=int(s.n_pairs), n_deferred_records=int(s.n_deferred_records),
+                            n_filtered_records=int(s.n_filtered_records), n_deep_records=int(s.n_deep_records)))
         return out
 
     def stats(self) -> dict:

@@ -36,7 +36,7 @@
 extern "C" {
 #endif
 
-#define CHD_ABI_VERSION 7
+#define CHD_ABI_VERSION 8
 
 typedef struct chd_ctx chd_ctx;
 
@@ -764,6 +764,10 @@ typedef struct {
     uint32_t n_handovers, n_unsubs, n_pairs;
     uint32_t n_deferred_records; /* of n_records: written by the deferred-connection launch, not by the dominant emit kernel */
     uint64_t algorithmic_bytes; /* DESIGN.md §4 byte model for the last tick */
+    /* chd_get_tick_history only (saturating at 2^32 - 1), both part of n_deferred_records: written by the filtered descriptors
+     * (windows that needed a per-entity decision on arrival stamps / update histories) and by the walk of the exact update
+     * buffers (history_depth: irregular channels, long catch-ups) */
+    uint32_t n_filtered_records, n_deep_records;
 } chd_tick_stats;
 /* depth > 0: record HIP events around the stages of the next ticks, keeping the
  * last `depth` ticks (<= 1024); 0 turns it off. */

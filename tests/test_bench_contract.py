@@ -37,7 +37,7 @@ class FakeCtl:
 class FakeWorld:
     fail_wire = False
 
-    def __init__(self, ctl, N, S, flags=0, max_records=0):
+    def __init__(self, ctl, N, S, flags=0, max_records=0, history_depth=0):
         self.N, self.S, self.flags, self.capq = N, S, flags, 225
         self.ticks = 0
 

@@ -418,3 +418,43 @@ def test_config_b_wire_streams_from_images_equal_the_record_path(amd, monkeypatc
         checked += 1
         del data0, data1, outs
     assert checked == 3
+
+
+@pytest.mark.parametrize("tick_jitter_us", [0, 3000], ids=["ticks-on-grid", "ticks-off-grid"])
+def test_config_b_arrival_stamps_at_enqueue_time_record_digests(amd, tick_jitter_us):
+    """the reference stamps every update when it is ENQUEUED (Channel.PutMessage, channel.go:296-310), tickData compares
+    those stamps with the window edges (data.go:236-241).  Config B with every update stamped uniformly inside its tick interval,
+    on a world with exact update buffers (history_depth 1024): every connection's record digest equals the oracle's buffer walk
+    (orc_world_tick_arrivals; the sorted newest-first walk, tests/test_world_oracle.py), tick after tick, history_overflow == 0 —
+    and nearly every record comes from the streaming kernels (copy + filtered descriptors), not from the element-buffer walk.
+    ticks-off-grid: the tick times themselves are irregular, so the subscriptions' phases are off the tick grid and EVERY window
+    cuts through a tick's arrivals (all records through the per-entity compare)."""
+    N, S, seed, ticks = 100_000, 10_000, 0xC0FFEE05, 14 if tick_jitter_us else 26
+    cfg = synth.load_config("spatial_static_benchmark.json")
+    sw = synth.SynthWorld(synth.WorldSpec(cfg, N, S, seed))
+    ctl = amd.StaticGrid2DSpatialController()
+    assert ctl.LoadConfig(json.dumps(cfg).encode(), strict=False) is None
+    w = amd.SpatialWorld(ctl, N, S, max_records=200_000_000, history_depth=1024)
+    w.spawn(None, sw.chan_id, sw.x, sw.z, sw.flags, sw.sender)
+    w.add_subscribers(None, sw.sub_conn)
+    ow = oracle_world(cfg, sw, N, S, w.capq)
+    ow.set_sorted_walk(True)
+    rng = np.random.default_rng(seed)
+    prev = total = deep = filt = 0
+    for k in range(ticks):
+        sw.step()
+        now = sw.now_ns() + (int(rng.integers(-tick_jitter_us, tick_jitter_us + 1)) * 1000 + int(rng.integers(0, 1000)) if tick_jitter_us else 0)
+        arr = now - rng.integers(0, now - prev, N)  # in (prev, now]
+        q = sw.queries()
+        ow.tick(now, None, sw.x, sw.z, None, None, None, None, q, upd_arrival=arr)
+        res = w.tick(now, upd_x=sw.x, upd_z=sw.z, queries=q, upd_arrival_ns=arr, want_records=False, records_cap=1)
+        total += compare_tick(k, w, ow, res, sw)
+        h = w.history(1)[0]
+        deep += h["n_deep_records"]
+        filt += h["n_filtered_records"]
+        prev = now
+    assert not ow.unsorted() and total > (600_000_000 if tick_jitter_us else 1_400_000_000)
+    # the element-buffer walk is the exception, not the path: nothing in this world is irregular
+    assert deep == 0, (deep, filt, total)
+    # on the tick grid only the 20 ms subscriptions' windows cut through a tick's arrivals; off the grid every window does
+    assert filt > (0.8 * (total - 40_000_000) if tick_jitter_us else 0.01 * total), (filt, total)
