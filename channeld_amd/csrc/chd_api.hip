@@ -1020,7 +1020,7 @@ int chd_world_create(chd_ctx *ctx, const chd_world_cfg *cfg) {
             TRY(walloc(ctx, &d.filt_desc, P, false));
             TRY(walloc(ctx, &d.filt_desc2, P, false));
             TRY(walloc(ctx, &d.filt_ln, P, false));
-            TRY(walloc(ctx, &d.filt_win, P * 4, false));
+            TRY(walloc(ctx, &d.filt_win, P * CHD_FILT_WINS, false));
         }
         d.prev_ns = -1;
     }

@@ -32,10 +32,10 @@ struct WsItemG {
 struct FiltWin {
     uint32_t full;       // mask over the tick ring: every update of these slots lies inside the window
     uint32_t slots;      // slot_a | slot_b << 8
-    uint32_t a_lo, a_hi; // slot_a: a_lo <= offset <= a_hi
-    uint32_t b_lo, b_hi; // slot_b
-    uint32_t _pad[2];
+    uint32_t a_lo, a_hi; // slot_a: a_lo <= offset <= a_hi (lo > hi: unused)
+    uint32_t b_lo, b_hi; // slot_b (only with slot_a)
 };
+#define CHD_FILT_WINS 8u  // fan-out windows of one filtered descriptor (more non-empty ones: the exact update buffers decide)
 
 // ---- world state (all device pointers, SoA) ----
 struct WorldDev {
@@ -96,11 +96,12 @@ struct WorldDev {
     // FILTERED descriptors (k_fanout_plan_seg -> k_fanout_emit_filt): due subscriptions with a window that a per-entity compare
     // must decide (an edge cuts through a tick's arrivals, or some entity has no update in it).  Row s holds n_filt[s] entries:
     // filt_desc {segment offset, column start, entries, windows | own-update bits << 8}, filt_desc2 / filt_ln as seg_desc2 /
-    // seg_ln, filt_win[(row index) * 4 + window] = the window's test (FiltWin)
+    // seg_ln; the windows' tests are indexed by the SUBSCRIPTION, filt_win[(s * capq + p) * CHD_FILT_WINS + window] (FiltWin): the plan
+    // writes them as it walks the windows, whatever the subscription turns out to be
     uint32_t *n_filt;     // [S]
     uint4 *filt_desc, *filt_desc2;  // [S * capq]
     int64_t *filt_ln;     // [S * capq]
-    struct FiltWin *filt_win;  // [S * capq * 4]
+    struct FiltWin *filt_win;  // [S * capq * CHD_FILT_WINS]
     // cell index (rebuilt every tick)
     uint32_t nblk;        // histogram blocks
     uint32_t *blk_cnt;    // [ncell*nblk + 1] counts -> exclusive scan (cell-major)

@@ -36,6 +36,7 @@
 //                   [rec_ub[s] + pair_rel[s][p], + pair_nrec[s][p]).
 // HBM-bound: 8 B written per record (the stream) + the L2/MALL-resident cell
 // tables read; no MFMA — this is gather/compaction, not a contraction.
+#include <algorithm>
 #include <cstdlib>
 #include <cstring>
 
@@ -912,19 +913,20 @@ typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
 // then the entities need a per-entity compare (FiltWin) and the subscription becomes a filtered descriptor.  Slots older than
 // CHD_OFF_SLOTS keep no offsets: whole / not at all by the slot's own interval, else the exact buffers decide (deep).
 struct OffPlan {
-    uint32_t full[4], slots[4], alo[4], ahi[4], blo[4], bhi[4];  // per non-empty window (FiltWin)
-    uint32_t ownm[4];   // ... the slots whose OWN update of the spatial channel lies inside it
-    uint32_t nw;        // non-empty windows (<= 4)
-    bool cut;           // some window has a slot a window edge cuts through
-    bool deep;          // undecidable here: more than four non-empty windows, a cut through a slot without offsets, ...
+    uint32_t full[4];   // the first four non-empty windows' whole-slot masks (what the copy path needs)
+    uint32_t nw;        // non-empty windows (<= CHD_FILT_WINS); their tests are in filt_win[(pbase + p) * CHD_FILT_WINS + k]
+    uint32_t own;       // bit k: the spatial channel's own buffered update passes window k
+    bool need;          // some window is not a plain copy of the cell's column: the per-entity compare
+    bool deep;          // undecidable here: too many non-empty windows, a cut through a slot without offsets, ...
     int64_t Lw;         // lastFanOutTime after the walk
 };
 
 __device__ __forceinline__ void plan_windows_off(const WorldDev &w, const TickRing &ring, int64_t now, int64_t L, int64_t I, uint32_t c,
-                                                 uint32_t ch_any /* the spatial channel's own update bits, any sender */, OffPlan &o) {
-    o.nw = 0; o.cut = false; o.deep = false; o.Lw = L;
+                                                 uint32_t hand, uint32_t chh, uint32_t chs, uint32_t chhp, uint32_t chsp, bool skip_self,
+                                                 uint32_t conn, FiltWin *__restrict__ fwout, OffPlan &o) {
+    o.nw = 0; o.own = 0; o.need = false; o.deep = false; o.Lw = L;
 #pragma unroll
-    for (int k = 0; k < 4; k++) { o.full[k] = 0; o.slots[k] = 0; o.alo[k] = 1; o.ahi[k] = 0; o.blo[k] = 1; o.bhi[k] = 0; o.ownm[k] = 0; }
+    for (int k = 0; k < 4; k++) o.full[k] = 0;
     // the cell's offset ranges and its own channel's offsets: one round trip
     const uint4 *rp = (const uint4 *)(const void *)(w.cell_orng + (size_t)c * CHD_OFF_SLOTS);
     const uint4 r0 = rp[0], r1 = rp[1], r2 = rp[2], r3 = rp[3];
@@ -932,7 +934,7 @@ __device__ __forceinline__ void plan_windows_off(const WorldDev &w, const TickRi
     const uint32_t rmin[CHD_OFF_SLOTS] = {r0.x, r0.z, r1.x, r1.z, r2.x, r2.z, r3.x, r3.z};
     const uint32_t rmax[CHD_OFF_SLOTS] = {r0.y, r0.w, r1.y, r1.w, r2.y, r2.w, r3.y, r3.w};
     const uint32_t coff[CHD_OFF_SLOTS] = {q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w};
-    int64_t nwin = (now - L) / I;
+    const int64_t nwin = (now - L) / I;
     if (nwin > 64) { o.deep = true; return; }  // (a long catch-up: the element walk handles any number of windows)
     int64_t Lw = L;
     for (int64_t k = 0; k < nwin; k++) {
@@ -975,15 +977,19 @@ __device__ __forceinline__ void plan_windows_off(const WorldDev &w, const TickRi
         }
         if (undecided) { o.deep = true; return; }
         Lw = hi;
-        if (!fm && !ncut && !(om & ch_any)) continue;  // nothing can pass this window
-        if (o.nw == 4) { o.deep = true; return; }
+        const bool ownp = cell_update_passes(chh, chs, chhp, chsp, om, skip_self, conn);
+        if (!fm && !ncut && !ownp) continue;  // nothing can pass this window
+        if (o.nw == CHD_FILT_WINS) { o.deep = true; return; }
+        FiltWin fw;
+        fw.full = fm; fw.slots = sa | (sb << 8); fw.a_lo = alo; fw.a_hi = ahi; fw.b_lo = blo; fw.b_hi = bhi;
+        fwout[o.nw] = fw;
 #pragma unroll
         for (int q = 0; q < 4; q++)
-            if ((uint32_t)q == o.nw) {
-                o.full[q] = fm; o.slots[q] = sa | (sb << 8); o.alo[q] = alo; o.ahi[q] = ahi; o.blo[q] = blo; o.bhi[q] = bhi; o.ownm[q] = om;
-            }
+            if ((uint32_t)q == o.nw) o.full[q] = fm;
+        if (ownp) o.own |= 1u << o.nw;
+        // a plain copy of the cell's column only when some slot the window covers WHOLE holds an update of every entity
+        if (!(hand & fm)) o.need = true;
         o.nw++;
-        if (ncut) o.cut = true;
     }
     o.Lw = Lw;
 }
@@ -1011,7 +1017,7 @@ __global__ void __launch_bounds__(64 * FO_WAVES) k_fanout_plan_seg(DevGrid g, Wo
         uint4 wm4 = make_uint4(0u, 0u, 0u, 0u);          // (per-record masks) the windows' masks
         int64_t Lw = 0;
         OffPlan op;
-        op.nw = 0; op.deep = false; op.cut = false; op.Lw = 0;
+        op.nw = 0; op.own = 0; op.need = false; op.deep = false; op.Lw = 0;
         if (p < cnt) {
             fl = w.pair_flags[pbase + p] & ~(PF_DEFER | PF_DEEP);
             const int64_t L = w.pair_last[pbase + p];
@@ -1025,6 +1031,10 @@ __global__ void __launch_bounds__(64 * FO_WAVES) k_fanout_plan_seg(DevGrid g, Wo
                 start = w.cell_start[c];
                 size = w.cell_end[c] - start;
                 if (sub_is_deep(w, ring, oldest, fl, L, I, c)) {  // exact update buffers: k_fanout_emit_deep's
+#ifdef CHD_OFF_DEBUG
+                    if (ring.cur_tick == 12 && atomicAdd(&w.counters[15], 1u) < 40u)
+                        printf("sub_is_deep: s %u p %u c %u irr %u iv %u L %lld now %lld\n", s, p, c, w.cell_irr[c], iv, (long long)L, (long long)now);
+#endif
                     deep = true;
                     due = false;
                     ub = deep_upper_bound(w, now, L, I, size);
@@ -1046,16 +1056,7 @@ __global__ void __launch_bounds__(64 * FO_WAVES) k_fanout_plan_seg(DevGrid g, Wo
                 }
                 bool hlost = false;
                 if (OFF) {
-                  if (now >= Lw + I) {
-                    // the walk against the real arrival stamps (plan_windows_off); wms = the slots each window covers whole
-                    const uint32_t age = ring.cur_tick - w.cell_hist_tick[c];
-                    const uint32_t ch_any = age < CHD_HIST_BITS ? ((w.cell_hist[c] | w.cell_hist_prev[c]) << age) : 0u;
-                    plan_windows_off(w, ring, now, Lw, I, c, ch_any, op);
-                    Lw = op.Lw;
-                    nw = op.nw;
-#pragma unroll
-                    for (int q = 0; q < 4; q++) wms[q] = op.full[q];
-                  }
+                    // (the walk against the real arrival stamps comes below, once the cell's words are loaded: plan_windows_off)
                 } else
                 if (now >= Lw + I) {
                     hlost = history_lost(ring, oldest, Lw, I);
@@ -1091,6 +1092,16 @@ __global__ void __launch_bounds__(64 * FO_WAVES) k_fanout_plan_seg(DevGrid g, Wo
                     us = CHD_NOT_A_SENDER;
                 const uint32_t hand = chans ? c_hand : 0u;
                 const bool none = skip_self && us == conn;  // every buffered entity update is this connection's own
+                if (OFF && now >= Lw + I) {
+                    // the walk against the real arrival stamps; wms = the slots each window covers whole
+                    const uint32_t age = ring.cur_tick - c_htick;
+                    const uint32_t chh = age < CHD_HIST_BITS ? (c_hist << age) : 0u, chhp = age < CHD_HIST_BITS ? (c_hprev << age) : 0u;
+                    plan_windows_off(w, ring, now, Lw, I, c, hand, chh, chs, chhp, chsp, skip_self, conn, w.filt_win + (pbase + p) * CHD_FILT_WINS, op);
+                    Lw = op.Lw;
+                    nw = op.nw;
+#pragma unroll
+                    for (int q = 0; q < 4; q++) wms[q] = op.full[q];
+                }
                 // (a column of up to 512 entries is four 8-byte loads per lane; larger cells take the deferred launch — and at
                 // >= 1024 entities per cell the cell-major form is the default anyway)
                 simple = chans != nullptr && nw <= 4 && size <= 512;
@@ -1101,14 +1112,11 @@ __global__ void __launch_bounds__(64 * FO_WAVES) k_fanout_plan_seg(DevGrid g, Wo
                 // descriptor, a subscription whose windows differ gets one descriptor per window (contiguous parts).
                 bool same = true;
                 if (OFF && !none) {
-                    // A window is a plain copy of the cell's column when some slot it covers WHOLE holds an update of every entity
-                    // (hand); any other non-empty window — an edge cuts through the arrivals of a tick, some entity skipped an
-                    // update, only the spatial channel's own update passes — takes the per-entity compare (FiltWin)
-                    bool need = false;
-#pragma unroll
-                    for (uint32_t j = 0; j < 4; j++)
-                        if (j < nw && !(hand & wms[j])) need = true;
-                    if (need) { filt = simple && us != CHD_NONUNIFORM; simple = false; }
+                    // any window that is not a plain copy (an edge cuts through the arrivals of a tick, some entity skipped an update,
+                    // only the spatial channel's own update passes), more than four windows, or a cell beyond the copy kernel's
+                    // 512-entry column image: the filtered kernel
+                    const bool need = op.need || nw > 4 || (size > 512 && !(info & SD_FIRST));
+                    if (need) { filt = chans != nullptr && us != CHD_NONUNIFORM; simple = false; }
                 }
 #pragma unroll
                 for (uint32_t j = 0; j < 4; j++) {
@@ -1131,6 +1139,11 @@ __global__ void __launch_bounds__(64 * FO_WAVES) k_fanout_plan_seg(DevGrid g, Wo
                 if (OFF && !(info & SD_FIRST) && (op.deep || (!simple && !filt))) {  // (a first fan-out evaluates no window: the filtering launch takes what is not simple)
                     // not decidable from the masks and offsets (plan_windows_off), or a shape the filtered kernel does not take
                     // (several senders of whom this connection may be one, a cell of more than 512 entities): the element buffers
+#ifdef CHD_OFF_DEBUG
+                    if (ring.cur_tick == 12 && atomicAdd(&w.counters[15], 1u) < 40u)
+                        printf("deep: s %u p %u c %u size %u iv %u L %lld now %lld nwin %lld op.deep %d nw %u us %x skip %d simple %d filt %d\n", s, p, c, size, iv,
+                               (long long)L, (long long)now, (long long)((now - L) / I), (int)op.deep, op.nw, us, (int)skip_self, (int)simple, (int)filt);
+#endif
                     deep = true;
                     due = false;
                     simple = filt = false;
@@ -1144,7 +1157,8 @@ __global__ void __launch_bounds__(64 * FO_WAVES) k_fanout_plan_seg(DevGrid g, Wo
                     const uint32_t chhp = age < CHD_HIST_BITS ? (c_hprev << age) : 0u;
 #pragma unroll
                     for (uint32_t j = 0; j < 4; j++)
-                        if (j < nw && cell_update_passes(chh, chs, chhp, chsp, OFF ? op.ownm[j] : wms[j], skip_self, conn)) own |= 1u << j;
+                        if (!OFF && j < nw && cell_update_passes(chh, chs, chhp, chsp, wms[j], skip_self, conn)) own |= 1u << j;
+                    if (OFF) own = op.own;
                 }
                 if (filt) {
                     // worst case per window: every entity of the cell (+ the own update); the kernel writes the count
@@ -1219,14 +1233,6 @@ __global__ void __launch_bounds__(64 * FO_WAVES) k_fanout_plan_seg(DevGrid g, Wo
                 w.filt_desc[k] = make_uint4(rel32, start, size, op.nw | (own << 8));
                 w.filt_desc2[k] = make_uint4(c, p, fl | PF_HAD_FIRST, 0u);
                 w.filt_ln[k] = Lw;
-#pragma unroll
-                for (uint32_t j = 0; j < 4; j++)
-                    if (j < op.nw) {
-                        FiltWin fw;
-                        fw.full = op.full[j]; fw.slots = op.slots[j]; fw.a_lo = op.alo[j]; fw.a_hi = op.ahi[j]; fw.b_lo = op.blo[j]; fw.b_hi = op.bhi[j];
-                        fw._pad[0] = 0; fw._pad[1] = 0;
-                        w.filt_win[k * 4 + j] = fw;
-                    }
             }
             n_filt += (uint32_t)__popcll(__ballot(due && filt));
         }
@@ -1490,10 +1496,98 @@ __global__ void __launch_bounds__(64, FO_SEG_OCC) k_fanout_emit_seg(DevGrid g, W
 #ifndef FO_FILT_WAVES
 #define FO_FILT_WAVES 2
 #endif
+#ifndef FO_FILT_OCC
+#define FO_FILT_OCC 4      // waves per SIMD the register allocator is asked for
+#endif
+#ifndef FO_FILT_PER_CU
+#define FO_FILT_PER_CU 16  // persistent waves per CU: the kernel is latency-bound per descriptor (dependent loads), not store-bound
+#endif
+
+// the offset columns of one or two ring slots for one 512-entry chunk (row h = entries 128 h + 2 lane, + 1), optionally together
+// with the chunk's {channel, history} entries — ONE block with its wait inside: the allocator may copy an asm output before a
+// later wait, and the hardware does not interlock a v_mov on an outstanding load
+__device__ __forceinline__ void filt_load(const uint2 *pe, const uint32_t *pa, const uint32_t *pb, bool with_e, bool use_a, bool use_b,
+                                          u32x4 (&e)[4], u32x2 (&oa)[4], u32x2 (&ob)[4]) {
+    if (with_e) {
+        if (use_b) {
+            asm volatile(
+                "global_load_dwordx4 %0, %12, off\n\t"
+                "global_load_dwordx4 %1, %12, off offset:1024\n\t"
+                "global_load_dwordx4 %2, %12, off offset:2048\n\t"
+                "global_load_dwordx4 %3, %12, off offset:3072\n\t"
+                "global_load_dwordx2 %4, %13, off\n\t"
+                "global_load_dwordx2 %5, %13, off offset:512\n\t"
+                "global_load_dwordx2 %6, %13, off offset:1024\n\t"
+                "global_load_dwordx2 %7, %13, off offset:1536\n\t"
+                "global_load_dwordx2 %8, %14, off\n\t"
+                "global_load_dwordx2 %9, %14, off offset:512\n\t"
+                "global_load_dwordx2 %10, %14, off offset:1024\n\t"
+                "global_load_dwordx2 %11, %14, off offset:1536\n\t"
+                "s_waitcnt vmcnt(0)"
+                : "=&v"(e[0]), "=&v"(e[1]), "=&v"(e[2]), "=&v"(e[3]), "=&v"(oa[0]), "=&v"(oa[1]), "=&v"(oa[2]), "=&v"(oa[3]),
+                  "=&v"(ob[0]), "=&v"(ob[1]), "=&v"(ob[2]), "=&v"(ob[3])
+                : "v"(pe), "v"(pa), "v"(pb)
+                : "memory");
+        } else if (use_a) {
+            asm volatile(
+                "global_load_dwordx4 %0, %8, off\n\t"
+                "global_load_dwordx4 %1, %8, off offset:1024\n\t"
+                "global_load_dwordx4 %2, %8, off offset:2048\n\t"
+                "global_load_dwordx4 %3, %8, off offset:3072\n\t"
+                "global_load_dwordx2 %4, %9, off\n\t"
+                "global_load_dwordx2 %5, %9, off offset:512\n\t"
+                "global_load_dwordx2 %6, %9, off offset:1024\n\t"
+                "global_load_dwordx2 %7, %9, off offset:1536\n\t"
+                "s_waitcnt vmcnt(0)"
+                : "=&v"(e[0]), "=&v"(e[1]), "=&v"(e[2]), "=&v"(e[3]), "=&v"(oa[0]), "=&v"(oa[1]), "=&v"(oa[2]), "=&v"(oa[3])
+                : "v"(pe), "v"(pa)
+                : "memory");
+        } else {
+            asm volatile(
+                "global_load_dwordx4 %0, %4, off\n\t"
+                "global_load_dwordx4 %1, %4, off offset:1024\n\t"
+                "global_load_dwordx4 %2, %4, off offset:2048\n\t"
+                "global_load_dwordx4 %3, %4, off offset:3072\n\t"
+                "s_waitcnt vmcnt(0)"
+                : "=&v"(e[0]), "=&v"(e[1]), "=&v"(e[2]), "=&v"(e[3])
+                : "v"(pe)
+                : "memory");
+        }
+    } else if (use_b) {
+        asm volatile(
+            "global_load_dwordx2 %0, %8, off\n\t"
+            "global_load_dwordx2 %1, %8, off offset:512\n\t"
+            "global_load_dwordx2 %2, %8, off offset:1024\n\t"
+            "global_load_dwordx2 %3, %8, off offset:1536\n\t"
+            "global_load_dwordx2 %4, %9, off\n\t"
+            "global_load_dwordx2 %5, %9, off offset:512\n\t"
+            "global_load_dwordx2 %6, %9, off offset:1024\n\t"
+            "global_load_dwordx2 %7, %9, off offset:1536\n\t"
+            "s_waitcnt vmcnt(0)"
+            : "=&v"(oa[0]), "=&v"(oa[1]), "=&v"(oa[2]), "=&v"(oa[3]), "=&v"(ob[0]), "=&v"(ob[1]), "=&v"(ob[2]), "=&v"(ob[3])
+            : "v"(pa), "v"(pb)
+            : "memory");
+    } else if (use_a) {
+        asm volatile(
+            "global_load_dwordx2 %0, %4, off\n\t"
+            "global_load_dwordx2 %1, %4, off offset:512\n\t"
+            "global_load_dwordx2 %2, %4, off offset:1024\n\t"
+            "global_load_dwordx2 %3, %4, off offset:1536\n\t"
+            "s_waitcnt vmcnt(0)"
+            : "=&v"(oa[0]), "=&v"(oa[1]), "=&v"(oa[2]), "=&v"(oa[3])
+            : "v"(pa)
+            : "memory");
+    }
+}
+
+#define FO_FILT_BATCH 32  // descriptors whose windows a wave stages in LDS at a time
 template <int WAVES>
-__global__ void __launch_bounds__(64, 4) k_fanout_emit_filt(DevGrid g, WorldDev w, uint32_t n_tickets) {
+__global__ void __launch_bounds__(64, FO_FILT_OCC) k_fanout_emit_filt(DevGrid g, WorldDev w, uint32_t n_tickets) {
     static_assert((WAVES & (WAVES - 1)) == 0, "waves per connection: a power of two");
     constexpr uint32_t WSH = WAVES == 1 ? 0u : WAVES == 2 ? 1u : WAVES == 4 ? 2u : 3u;
+    // the windows' tests of the descriptors in flight: read back wave-uniformly (LDS counts on lgkmcnt — a wait for it does not
+    // drain the record stores, as a wait for a global load would: the vm counter is in-order)
+    __shared__ uint32_t fw_lds[FO_FILT_BATCH][CHD_FILT_WINS][6];
     const uint32_t lane = lane_id();
     const uint32_t bank = blockIdx.x & 7u;
     uint32_t *__restrict__ ctr = w.emit_ticket + 32u * bank + 1u;
@@ -1508,131 +1602,132 @@ __global__ void __launch_bounds__(64, 4) k_fanout_emit_filt(DevGrid g, WorldDev 
         uint32_t tk_next = 0;
         if (lane == 0) tk_next = atomicAdd(ctr, 1u);
         const uint32_t s = T >> WSH, role = T & (WAVES - 1u);
-        const uint32_t nf = w.n_filt[s];
         const size_t pbase = (size_t)s * w.capq;
+        // the connection's header words and (speculatively: the row exists whatever n_filt says) the first batch of descriptors
+        // in ONE round trip
+        const uint32_t kl0 = role + (lane << WSH);
+        u32x4 dv0 = {0, 0, 0, 0};
+        u32x2 cv0 = {0, 0};
+        if (lane < FO_FILT_BATCH && kl0 < w.capq) {
+            dv0 = *(const u32x4 *)(const void *)(w.filt_desc + pbase + kl0);
+            cv0 = *(const u32x2 *)(const void *)(w.filt_desc2 + pbase + kl0);
+        }
+        const uint32_t nf = w.n_filt[s];
         const uint64_t base = w.rec_ub[s], end = w.rec_ub[s + 1];
+        const uint32_t conn = w.conn_id[s];
         tk = (uint32_t)__builtin_amdgcn_readfirstlane((int)tk_next);
         // (end > recs_cap: no room for this connection's worst case — the deferred launch leaves its state as it was and flags the tick)
-        if (role >= nf || end > w.recs_cap) continue;
-        const uint32_t conn = w.conn_id[s];
+        if ((role >= nf) | (end > w.recs_cap)) continue;
         uint32_t total = 0;
-        for (uint32_t k = role; k < nf; k += WAVES) {
-            const uint4 d = w.filt_desc[pbase + k];
-            const uint4 d2 = w.filt_desc2[pbase + k];
-            const uint32_t rel = (uint32_t)__builtin_amdgcn_readfirstlane((int)d.x), start = (uint32_t)__builtin_amdgcn_readfirstlane((int)d.y);
-            const uint32_t n = (uint32_t)__builtin_amdgcn_readfirstlane((int)d.z), info = (uint32_t)__builtin_amdgcn_readfirstlane((int)d.w);
-            const uint32_t cch = (uint32_t)__builtin_amdgcn_readfirstlane((int)d2.x) + g.id_start;
-            const uint32_t p = (uint32_t)__builtin_amdgcn_readfirstlane((int)d2.y);
-            const uint32_t nw = info & 7u, own = (info >> 8) & 15u;
-            chd_fanout_rec *__restrict__ out = w.recs + base + rel;
-            // the cell's entries: row h = entries 128 h + 2 lane, + 1 (lanes beyond the cell read spare entries: never used)
-            u32x4 e[4];
-            {
-                const uint2 *pa = ce8 + start + 2 * lane;
-                asm volatile(
-                    "global_load_dwordx4 %0, %4, off\n\t"
-                    "global_load_dwordx4 %1, %4, off offset:1024\n\t"
-                    "global_load_dwordx4 %2, %4, off offset:2048\n\t"
-                    "global_load_dwordx4 %3, %4, off offset:3072\n\t"
-                    "s_waitcnt vmcnt(0)"
-                    : "=&v"(e[0]), "=&v"(e[1]), "=&v"(e[2]), "=&v"(e[3])
-                    : "v"(pa)
-                    : "memory");
-            }
-            uint32_t n_out = 0;
-            for (uint32_t j = 0; j < nw; j++) {
-                const FiltWin *fwp = w.filt_win + (pbase + k) * 4 + j;
-                const uint4 f0 = *(const uint4 *)(const void *)fwp;
-                const uint2 f1 = *(const uint2 *)(const void *)&fwp->b_lo;
-                const uint32_t full = (uint32_t)__builtin_amdgcn_readfirstlane((int)f0.x), slots = (uint32_t)__builtin_amdgcn_readfirstlane((int)f0.y);
-                const uint32_t a_lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)f0.z), a_hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)f0.w);
-                const uint32_t b_lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)f1.x), b_hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)f1.y);
-                const uint32_t sa = slots & 0xFFu, sb = (slots >> 8) & 0xFFu;
-                const bool use_a = a_lo <= a_hi, use_b = b_lo <= b_hi;
-                if ((own >> j) & 1u) {  // the spatial channel's own buffered update lies inside this window
-                    if (lane == 0) {
-                        chd_fanout_rec r;
-                        r.conn = conn;
-                        r.channel = cch;
-                        out[n_out] = r;
-                    }
-                    n_out += 1;
+        // the descriptors of this wave in ONE round of vector loads — lane q holds the wave's q-th descriptor, read with v_readlane
+        // below — and their windows' tests into LDS in a second one
+        const uint32_t mine = (nf - role + WAVES - 1u) >> WSH;
+        for (uint32_t j0 = 0; j0 < mine; j0 += FO_FILT_BATCH) {
+            const uint32_t kl = role + ((j0 + lane) << WSH);
+            u32x4 dv = dv0;
+            u32x2 cv = cv0;
+            if (lane < FO_FILT_BATCH && kl < nf) {
+                if (j0) {
+                    dv = *(const u32x4 *)(const void *)(w.filt_desc + pbase + kl);
+                    cv = *(const u32x2 *)(const void *)(w.filt_desc2 + pbase + kl);
                 }
+                const uint32_t lnw = dv.w & 15u;
+                const u32x4 *fwp = (const u32x4 *)(const void *)(w.filt_win + (pbase + cv.y) * CHD_FILT_WINS);  // (192-byte rows: 16-byte aligned)
+                // all of the descriptor's windows in one round of loads (two windows = three 16-byte words), then into LDS
+                u32x4 t[12];
+#pragma unroll
+                for (int q = 0; q < 12; q++) t[q] = u32x4{0, 0, 0, 0};
+#pragma unroll
+                for (int q = 0; q < 12; q++)
+                    if ((uint32_t)(2 * (q / 3)) < lnw) t[q] = fwp[q];
+                u32x4 *dst = (u32x4 *)(void *)&fw_lds[lane][0][0];
+#pragma unroll
+                for (int q = 0; q < 12; q++)
+                    if ((uint32_t)(2 * (q / 3)) < lnw) dst[q] = t[q];
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+            const uint32_t here = min(mine - j0, (uint32_t)FO_FILT_BATCH);
+            for (uint32_t jj = 0; jj < here; jj++) {
+                const int jl = (int)jj;
+                const uint32_t rel = (uint32_t)__builtin_amdgcn_readlane((int)dv.x, jl), start = (uint32_t)__builtin_amdgcn_readlane((int)dv.y, jl);
+                const uint32_t n = (uint32_t)__builtin_amdgcn_readlane((int)dv.z, jl), info = (uint32_t)__builtin_amdgcn_readlane((int)dv.w, jl);
+                const uint32_t cch = (uint32_t)__builtin_amdgcn_readlane((int)cv.x, jl) + g.id_start;
+                const uint32_t p = (uint32_t)__builtin_amdgcn_readlane((int)cv.y, jl);
+                const uint32_t nw = info & 15u, own = (info >> 8) & 0xFFu;
+                chd_fanout_rec *__restrict__ out = w.recs + base + rel;
+                u32x4 e[4];
                 u32x2 oa[4], ob[4];
 #pragma unroll
-                for (int h = 0; h < 4; h++) { oa[h].x = 0; oa[h].y = 0; ob[h].x = 0; ob[h].y = 0; }
-                // (the wait sits inside the block that issues the loads: the allocator may copy an asm output before a later wait,
-                // and the hardware does not interlock a v_mov on an outstanding load)
-                if (use_b) {
-                    const uint32_t *pa = offs + (size_t)sa * w.off_stride + start + 2 * lane;
-                    const uint32_t *pb = offs + (size_t)sb * w.off_stride + start + 2 * lane;
-                    asm volatile(
-                        "global_load_dwordx2 %0, %8, off\n\t"
-                        "global_load_dwordx2 %1, %8, off offset:512\n\t"
-                        "global_load_dwordx2 %2, %8, off offset:1024\n\t"
-                        "global_load_dwordx2 %3, %8, off offset:1536\n\t"
-                        "global_load_dwordx2 %4, %9, off\n\t"
-                        "global_load_dwordx2 %5, %9, off offset:512\n\t"
-                        "global_load_dwordx2 %6, %9, off offset:1024\n\t"
-                        "global_load_dwordx2 %7, %9, off offset:1536\n\t"
-                        "s_waitcnt vmcnt(0)"
-                        : "=&v"(oa[0]), "=&v"(oa[1]), "=&v"(oa[2]), "=&v"(oa[3]), "=&v"(ob[0]), "=&v"(ob[1]), "=&v"(ob[2]), "=&v"(ob[3])
-                        : "v"(pa), "v"(pb)
-                        : "memory");
-                } else if (use_a) {
-                    const uint32_t *pa = offs + (size_t)sa * w.off_stride + start + 2 * lane;
-                    asm volatile(
-                        "global_load_dwordx2 %0, %4, off\n\t"
-                        "global_load_dwordx2 %1, %4, off offset:512\n\t"
-                        "global_load_dwordx2 %2, %4, off offset:1024\n\t"
-                        "global_load_dwordx2 %3, %4, off offset:1536\n\t"
-                        "s_waitcnt vmcnt(0)"
-                        : "=&v"(oa[0]), "=&v"(oa[1]), "=&v"(oa[2]), "=&v"(oa[3])
-                        : "v"(pa)
-                        : "memory");
-                }
-                const uint32_t bit_a = use_a ? 1u << sa : 0u, bit_b = use_b ? 1u << sb : 0u;
+                for (int h = 0; h < 4; h++) { e[h] = u32x4{0, 0, 0, 0}; oa[h] = u32x2{0, 0}; ob[h] = u32x2{0, 0}; }
+                uint32_t n_out = 0;
+                for (uint32_t j = 0; j < nw; j++) {
+                    const uint32_t *fw = fw_lds[jj][j];
+                    const uint32_t full = (uint32_t)__builtin_amdgcn_readfirstlane((int)fw[0]), slots = (uint32_t)__builtin_amdgcn_readfirstlane((int)fw[1]);
+                    const uint32_t a_lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)fw[2]), a_hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)fw[3]);
+                    const uint32_t b_lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)fw[4]), b_hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)fw[5]);
+                    const uint32_t sa = slots & 0xFFu, sb = (slots >> 8) & 0xFFu;
+                    const bool use_a = a_lo <= a_hi, use_b = b_lo <= b_hi;  // (use_b only with use_a)
+                    const uint32_t bit_a = use_a ? 1u << sa : 0u, bit_b = use_b ? 1u << sb : 0u;
+                    if ((own >> j) & 1u) {  // the spatial channel's own buffered update lies inside this window
+                        if (lane == 0) {
+                            chd_fanout_rec r;
+                            r.conn = conn;
+                            r.channel = cch;
+                            out[n_out] = r;
+                        }
+                        n_out += 1;
+                    }
+                    // 512 entries per step; a cell of up to 512 keeps its entries in registers from the first window on
+                    for (uint32_t c0 = 0; c0 < n; c0 += 512) {
+                        const bool with_e = j == 0 || n > 512;
+                        const uint32_t at0 = start + c0 + 2 * lane;
+                        filt_load(ce8 + at0, offs + (size_t)sa * w.off_stride + at0, offs + (size_t)sb * w.off_stride + at0, with_e, use_a, use_b, e, oa, ob);
+                        const uint32_t nc = n - c0;  // entries of this step (row h: 128 h ...)
 #pragma unroll
-                for (int h = 0; h < 4; h++) {
-                    if (n <= (uint32_t)(128 * h)) break;  // uniform
-                    const uint32_t q = 128u * h + 2 * lane;
-                    const bool in0 = q < n, in1 = q + 1 < n;
-                    const uint32_t h0 = e[h].y, h1 = e[h].w;
-                    const bool pass0 = in0 && ((h0 & full) != 0 || ((h0 & bit_a) != 0 && oa[h].x >= a_lo && oa[h].x <= a_hi) ||
-                                               ((h0 & bit_b) != 0 && ob[h].x >= b_lo && ob[h].x <= b_hi));
-                    const bool pass1 = in1 && ((h1 & full) != 0 || ((h1 & bit_a) != 0 && oa[h].y >= a_lo && oa[h].y <= a_hi) ||
-                                               ((h1 & bit_b) != 0 && ob[h].y >= b_lo && ob[h].y <= b_hi));
-                    const uint64_t m0 = __ballot(pass0), m1 = __ballot(pass1);
-                    if ((m0 & m1) == ~0ull) {
-                        u32x4 r;
-                        r.x = conn; r.y = e[h].x; r.z = conn; r.w = e[h].z;
-                        // (8-byte aligned: n_out is any record index)
-                        typedef u32x4 __attribute__((aligned(8))) u32x4_a8;
-                        *(u32x4_a8 *)(void *)(out + n_out + 2 * lane) = r;
-                        n_out += 128;
-                    } else {
-                        // entry order: records before this lane's pair = passing entries of lower lanes
-                        const uint32_t at = __builtin_amdgcn_mbcnt_hi((uint32_t)(m1 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m1,
-                                            __builtin_amdgcn_mbcnt_hi((uint32_t)(m0 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m0, n_out))));
-                        if (pass0) {
-                            chd_fanout_rec r;
-                            r.conn = conn;
-                            r.channel = e[h].x;
-                            out[at] = r;
+                        for (int h = 0; h < 4; h++) {
+                            if (nc <= (uint32_t)(128 * h)) break;  // uniform
+                            const uint32_t q = 128u * h + 2 * lane;
+                            const bool in0 = q < nc, in1 = q + 1 < nc;
+                            const uint32_t h0 = e[h].y, h1 = e[h].w;
+                            // (no short-circuit evaluation: the compiler turns && / || chains into exec-masked branches)
+                            const bool pass0 = in0 & (((h0 & full) != 0) | (((h0 & bit_a) != 0) & (oa[h].x >= a_lo) & (oa[h].x <= a_hi)) |
+                                                      (((h0 & bit_b) != 0) & (ob[h].x >= b_lo) & (ob[h].x <= b_hi)));
+                            const bool pass1 = in1 & (((h1 & full) != 0) | (((h1 & bit_a) != 0) & (oa[h].y >= a_lo) & (oa[h].y <= a_hi)) |
+                                                      (((h1 & bit_b) != 0) & (ob[h].y >= b_lo) & (ob[h].y <= b_hi)));
+                            const uint64_t m0 = __ballot(pass0), m1 = __ballot(pass1);
+                            if ((m0 & m1) == ~0ull) {
+                                u32x4 r;
+                                r.x = conn; r.y = e[h].x; r.z = conn; r.w = e[h].z;
+                                typedef u32x4 __attribute__((aligned(8))) u32x4_a8;  // (n_out is any record index)
+                                *(u32x4_a8 *)(void *)(out + n_out + 2 * lane) = r;
+                                n_out += 128;
+                            } else {
+                                // entry order: records before this lane's pair = passing entries of lower lanes
+                                const uint32_t at = __builtin_amdgcn_mbcnt_hi((uint32_t)(m1 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m1,
+                                                    __builtin_amdgcn_mbcnt_hi((uint32_t)(m0 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m0, n_out))));
+                                if (pass0) {
+                                    chd_fanout_rec r;
+                                    r.conn = conn;
+                                    r.channel = e[h].x;
+                                    out[at] = r;
+                                }
+                                if (pass1) {
+                                    chd_fanout_rec r;
+                                    r.conn = conn;
+                                    r.channel = e[h].z;
+                                    out[at + (pass0 ? 1u : 0u)] = r;
+                                }
+                                n_out += (uint32_t)__popcll(m0) + (uint32_t)__popcll(m1);
+                            }
                         }
-                        if (pass1) {
-                            chd_fanout_rec r;
-                            r.conn = conn;
-                            r.channel = e[h].z;
-                            out[at + (pass0 ? 1u : 0u)] = r;
-                        }
-                        n_out += (uint32_t)__popcll(m0) + (uint32_t)__popcll(m1);
                     }
                 }
+                pad_segment(out, n_out);
+                if (lane == 0) w.pair_nrec[pbase + p] = n_out;
+                total += n_out;
             }
-            pad_segment(out, n_out);
-            if (lane == 0) w.pair_nrec[pbase + p] = n_out;
-            total += n_out;
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");  // (the next batch overwrites the LDS windows)
         }
         if (lane == 0 && total) {
             atomicAdd(&w.rec_cnt[s], total);
@@ -1647,7 +1742,9 @@ __global__ void __launch_bounds__(64, 4) k_fanout_emit_filt(DevGrid g, WorldDev 
 void launch_fanout_emit_filt(hipStream_t st, DevGrid g, WorldDev w) {
     if (!w.S || !w.off_on || !seg_path(w)) return;
     const uint32_t n_tickets = w.S * FO_FILT_WAVES;
-    const dim3 grid(n_tickets < w.seg_waves ? n_tickets : w.seg_waves);
+    static const uint32_t per_cu = [] { const char *e = getenv("CHD_FILT_WAVES_PER_CU"); return e ? (uint32_t)std::min(std::max(atoi(e), 1), 32) : (uint32_t)FO_FILT_PER_CU; }();
+    const uint32_t waves = w.seg_waves / 8u * per_cu;  // (seg_waves = 8 per CU unless CHD_EMIT_WAVES_PER_CU says otherwise)
+    const dim3 grid(n_tickets < waves ? n_tickets : waves);
     hipLaunchKernelGGL((k_fanout_emit_filt<FO_FILT_WAVES>), grid, dim3(64), 0, st, g, w, n_tickets);
 }
 
