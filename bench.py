@@ -100,7 +100,8 @@ def parse():
                          "either way (a real gateway's ticks are never exactly periodic): subscriptions made at such a tick keep that phase, so "
                          "with --arrival-jitter EVERY later fan-out window cuts through a tick's arrivals and needs a per-entity decision")
     ap.add_argument("--write-digests", action="store_true",
-                    help="record the latency-phase ticks' record digests into tests/golden/bench_digests_B.json instead of checking them")
+                    help="also write the latency-phase ticks' DEVICE digests to gpurun_out/bench_digests_device.json (the committed list is the "
+                         "oracle's: tests/golden/make_bench_digests.py)")
     ap.add_argument("--only-timed", action="store_true",
                     help="profiling runs (rocprofv3 --kernel-trace / --pmc): warm-up + the timed region and nothing else (= --no-cpu "
                          "--latency-steps 0 --e2e-ticks 0), so that per-kernel averages after skipping --warmup launches are the timed launches")
@@ -469,7 +470,7 @@ def main():
             (cnt, dsum, dxor, _), _ = world.digest(per_connection=False)
             if args.write_digests:
                 digests_out[str(t + 1)] = [cnt, dsum, dxor]
-            elif str(t + 1) in golden:
+            if golden is not None and str(t + 1) in golden:
                 if golden[str(t + 1)] != [cnt, dsum, dxor]:
                     raise SystemExit(f"bench.py: tick {t + 1}: records digest {[cnt, dsum, dxor]} != committed {golden[str(t + 1)]} "
                                      f"(tests/golden/bench_digests_B.json): the fan-out of this run is not the fan-out this world has")
@@ -558,8 +559,9 @@ def main():
         "p50_tick_ms": float(np.percentile(lat, 50)), "p99_tick_ms": float(np.percentile(lat, 99)),
         "p99_tick_gpu_ms": float(np.percentile(gpu_lat, 99)), "latency_ticks": int(L),
         "digest_checked_ticks": digests_checked,
-        "digest_check": "the latency-phase ticks' fan-out records (count, sum, xor of mix64(conn, channel), chd_tick_digest) against the committed per-tick "
-                        "list tests/golden/bench_digests_B.json; the same world's first 26 ticks are compared with the oracle in tests/test_gpu_fullsize.py",
+        "digest_check": "the latency-phase ticks' fan-out records (count, sum, xor of mix64(conn, channel), chd_tick_digest on the device) against the "
+                        "committed per-tick list tests/golden/bench_digests_B.json = what the CPU ORACLE computes for this seeded world "
+                        "(tests/golden/make_bench_digests.py, 701 ticks; the first 40 also through the literal forward buffer walk)",
         "stage_us_avg": {n: float(v) for n, v in zip(("ingest", "index", "interest", "plan", "emit"), stage_avg)},
         "stage_us_avg_is": "HIP events at every stage boundary of the latency-phase ticks (serial schedule, one synchronous tick at a time); the timed "
                            "region records only the pair around the dominant kernel (chd_set_profiling_scope)",
@@ -680,21 +682,14 @@ def load_bench_digests(args, N, S, M):
 
 
 def write_bench_digests(new):
-    """bench.py --write-digests (default world): merge this run's latency-phase ticks into the committed list."""
-    old = {}
-    if os.path.exists(DIGEST_FILE):
-        with open(DIGEST_FILE) as f:
-            old = json.load(f)["ticks"]
-    for k, v in new.items():
-        if k in old and old[k] != v:
-            raise SystemExit(f"--write-digests: tick {k} digests differently from the committed list: {v} vs {old[k]}")
-        old[k] = v
-    with open(DIGEST_FILE, "w") as f:
-        json.dump({"what": "per-tick digests {count, sum, xor of mix64(conn << 32 | channel)} of the fan-out records of bench.py's default world "
-                           "(spatial_static_benchmark.json, 100000 entities / 10000 subs, seed 0xC0FFEE01, 50 ms ticks), tick k = the k-th tick since the "
-                           "world began; computed on the device by chd_tick_digest (python bench.py --write-digests ...); the first 26 ticks of this "
-                           "world are compared with the CPU oracle in tests/test_gpu_fullsize.py, these pin the rest against drift and races",
-                   "ticks": dict(sorted(old.items(), key=lambda kv: int(kv[0])))}, f)
+    """bench.py --write-digests: this run's latency-phase DEVICE digests into gpurun_out/bench_digests_device.json — a snapshot for
+    comparisons between builds.  The committed list (tests/golden/bench_digests_B.json) is the ORACLE's and is written by
+    tests/golden/make_bench_digests.py only."""
+    out = os.path.join(ROOT, "gpurun_out", "bench_digests_device.json")
+    os.makedirs(os.path.dirname(out), exist_ok=True)
+    with open(out, "w") as f:
+        json.dump({"what": "per-tick device digests (chd_tick_digest) of bench.py's default world, latency-phase ticks of one run", "source": "device",
+                   "ticks": dict(sorted(new.items(), key=lambda kv: int(kv[0])))}, f)
 
 
 def trace(msg):

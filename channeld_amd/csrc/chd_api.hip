@@ -1021,6 +1021,16 @@ int chd_world_create(chd_ctx *ctx, const chd_world_cfg *cfg) {
             TRY(walloc(ctx, &d.filt_desc2, P, false));
             TRY(walloc(ctx, &d.filt_ln, P, false));
             TRY(walloc(ctx, &d.filt_win, P * CHD_FILT_WINS, false));
+            // the per-cell lists of the cell-major filtered kernel: 4 B per (cell, connection) — where that is too much the
+            // connection-major kernel takes the filtered descriptors (CHD_FILT_CELL_MAJOR=0: A/B)
+            d.fcm_on = C * S <= (1ull << 25) ? 1u : 0u;  // (32 B per entry: at most 1 GiB)
+            if (const char *e = getenv("CHD_FILT_CELL_MAJOR")) if (e[0] == '0') d.fcm_on = 0;
+            if (d.fcm_on) {
+                TRY(walloc(ctx, &d.cell_fcnt, C * 32));
+                TRY(walloc(ctx, &d.cell_flist, 2 * C * S, false));
+                TRY(walloc(ctx, &d.filt_items, P / 64 + C + 1, false));
+                TRY(walloc(ctx, &d.filt_nitems, 32));
+            }
         }
         d.prev_ns = -1;
     }

@@ -102,6 +102,16 @@ struct WorldDev {
     uint4 *filt_desc, *filt_desc2;  // [S * capq]
     int64_t *filt_ln;     // [S * capq]
     struct FiltWin *filt_win;  // [S * capq * CHD_FILT_WINS]
+    // ... and, for the cell-major filtered kernel (k_fanout_emit_filt_cm: a cell's columns staged once in LDS for all of its
+    // filtered descriptors), the descriptors listed per CELL, as self-contained 32-byte entries {segment offset, entries, windows
+    // | own bits << 8, subscription index p; connection slot s, -, -, -}: cell_flist[(c * S + i) * 2 ..], i < cell_fcnt[c * 32]
+    // (one counter per 128-byte line; the plan appends, the tick epilogue clears); filt_items = the kernel's work list {cell,
+    // first list entry, descriptors | tile entries << 8, column start} in chunks of 64 descriptors, n in filt_nitems (k_filt_items)
+    uint32_t fcm_on;
+    uint32_t *cell_fcnt;
+    uint4 *cell_flist;
+    uint4 *filt_items;
+    uint32_t *filt_nitems;
     // cell index (rebuilt every tick)
     uint32_t nblk;        // histogram blocks
     uint32_t *blk_cnt;    // [ncell*nblk + 1] counts -> exclusive scan (cell-major)
@@ -258,7 +268,7 @@ __device__ __forceinline__ void push_update(const WorldDev &w, uint32_t i, uint3
         uint4 a = w.eoff[2 * (size_t)i], b = w.eoff[2 * (size_t)i + 1];
         uint32_t o[CHD_OFF_SLOTS] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
         off_shift(o, age);
-        irregular = !(arrival > w.prev_ns && arrival <= now && off <= 0xFFFFFFFFull);
+        irregular = !(arrival > w.prev_ns && arrival <= now && off <= 0xFFFFFFFEull);  // (0xFFFFFFFF stands for "no update" in the staged columns)
         if (age == 0 && ((h | hp) & 1u) && o[0] != (uint32_t)off) irregular = true;  // a second update in this tick, another stamp
         o[0] = (uint32_t)off;
         w.eoff[2 * (size_t)i] = make_uint4(o[0], o[1], o[2], o[3]);

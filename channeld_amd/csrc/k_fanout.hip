@@ -951,8 +951,8 @@ __device__ __forceinline__ void plan_windows_off(const WorldDev &w, const TickRi
             if (tp >= hi) continue;  // the whole slot is newer than the window
             if (last && ring.n == CHD_HIST_BITS) { undecided = true; continue; }  // (the evicted stamp below it is unknown)
             const int64_t A64 = tj - hi > 0 ? tj - hi : 0, B64 = tj - lo;
-            if (A64 > 0xFFFFFFFFll) continue;
-            const uint32_t A = (uint32_t)A64, B = B64 > 0xFFFFFFFFll ? 0xFFFFFFFFu : (uint32_t)B64;
+            if (A64 > 0xFFFFFFFEll) continue;
+            const uint32_t A = (uint32_t)A64, B = B64 > 0xFFFFFFFEll ? 0xFFFFFFFEu : (uint32_t)B64;  // (offsets are at most 0xFFFFFFFE: WorldDev::off_on)
             if (rmin[j] <= rmax[j]) {  // (the cell holds updates of this slot)
                 if (A <= rmin[j] && rmax[j] <= B) fm |= 1u << j;
                 else if (!(rmax[j] < A || rmin[j] > B)) {
@@ -1231,8 +1231,16 @@ __global__ void __launch_bounds__(64 * FO_WAVES) k_fanout_plan_seg(DevGrid g, Wo
             if (due && filt) {
                 const size_t k = pbase + fbase;
                 w.filt_desc[k] = make_uint4(rel32, start, size, op.nw | (own << 8));
-                w.filt_desc2[k] = make_uint4(c, p, fl | PF_HAD_FIRST, 0u);
+                w.filt_desc2[k] = make_uint4(c, p, fl | PF_HAD_FIRST, s);
                 w.filt_ln[k] = Lw;
+                if (w.fcm_on) {  // ... listed under its cell (k_fanout_emit_filt_cm); the order inside a cell's list does not matter
+                    const uint32_t at = atomicAdd(&w.cell_fcnt[32u * c], 1u);
+                    if (at < w.S) {
+                        uint4 *e = w.cell_flist + ((size_t)c * w.S + at) * 2;
+                        e[0] = make_uint4(rel32, size, op.nw | (own << 8), p);
+                        e[1] = make_uint4(s, 0u, 0u, 0u);
+                    }
+                }
             }
             n_filt += (uint32_t)__popcll(__ballot(due && filt));
         }
@@ -1739,8 +1747,375 @@ __global__ void __launch_bounds__(64, FO_FILT_OCC) k_fanout_emit_filt(DevGrid g,
     }
 }
 
+// ---------------------------------------------------------------------------
+// The filtered descriptors, CELL-MAJOR and wave-specialised (WorldDev::fcm_on; the form that runs by default).
+//
+// What bounded the connection-major kernel above: every (descriptor, window) is a dependent round trip to the cell's columns
+// before its stores, and on gfx950's in-order vm counter each such wait also drains the wave's own record stores — ~5 us of
+// wave time per window for ~1.5 KB of records.  But the columns a window reads are its CELL's, and a cell has hundreds of filtered
+// descriptors per tick (every subscriber of the cell whose phase is off the tick grid).  So, as the cell-major record kernel
+// does for the window masks: work item = (cell, 64 of its filtered descriptors); in a workgroup of 8 waves wave 0 is the LOADER
+// — it gathers the item's descriptor headers (segment base, connection, the windows' tests) and stages the cell's columns
+// {channel, history, the offsets of all CHD_OFF_SLOTS ring slots} in LDS, double-buffered — and waves 1-7 are STREAMERS: they take
+// descriptors by an LDS ticket and do the per-entity compare of every window on LDS data only, ballot / mbcnt compaction, record
+// stores.  A streamer never issues a global load (rare exceptions: a descriptor with more than FC_LWIN windows, a cell beyond
+// the 512-entry tile), so it never waits on the vm counter and its stores stay in flight back to back.
+// Same records, same segment layout as k_fanout_emit_filt (the tests run both: CHD_FILT_CELL_MAJOR=0).
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ void lds_barrier();
+// one window of one descriptor over a cell's columns in GLOBAL memory (raw offsets: tested together with the history bits), in
+// steps of 512 entries: what k_fanout_emit_filt does per window; the cell-major kernel's path for cells beyond its LDS tile
+__device__ __forceinline__ uint32_t filt_window_global(const WorldDev &w, uint32_t start, uint32_t n, uint32_t full, uint32_t sa, uint32_t sb,
+                                                       uint32_t a_lo, uint32_t a_hi, uint32_t b_lo, uint32_t b_hi, uint32_t conn,
+                                                       chd_fanout_rec *__restrict__ out, uint32_t n_out) {
+    const uint32_t lane = lane_id();
+    const bool use_a = a_lo <= a_hi, use_b = b_lo <= b_hi;
+    const uint32_t bit_a = use_a ? 1u << sa : 0u, bit_b = use_b ? 1u << sb : 0u;
+    for (uint32_t c0 = 0; c0 < n; c0 += 512) {
+        const uint32_t nc = n - c0;
+        u32x4 e[4];
+        u32x2 oa[4], ob[4];
+#pragma unroll
+        for (int h = 0; h < 4; h++) { e[h] = u32x4{0, 0, 0, 0}; oa[h] = u32x2{0, 0}; ob[h] = u32x2{0, 0}; }
+        const uint32_t at0 = start + c0 + 2 * lane;
+        filt_load(w.ce8_view + at0, w.ce_off + (size_t)sa * w.off_stride + at0, w.ce_off + (size_t)sb * w.off_stride + at0, true, use_a, use_b, e, oa, ob);
+#pragma unroll
+        for (int h = 0; h < 4; h++) {
+            if (nc <= (uint32_t)(128 * h)) break;  // uniform
+            const uint32_t q = 128u * h + 2 * lane;
+            const bool in0 = q < nc, in1 = q + 1 < nc;
+            const uint32_t h0 = e[h].y, h1 = e[h].w;
+            const bool pass0 = in0 & (((h0 & full) != 0) | (((h0 & bit_a) != 0) & (oa[h].x >= a_lo) & (oa[h].x <= a_hi)) |
+                                      (((h0 & bit_b) != 0) & (ob[h].x >= b_lo) & (ob[h].x <= b_hi)));
+            const bool pass1 = in1 & (((h1 & full) != 0) | (((h1 & bit_a) != 0) & (oa[h].y >= a_lo) & (oa[h].y <= a_hi)) |
+                                      (((h1 & bit_b) != 0) & (ob[h].y >= b_lo) & (ob[h].y <= b_hi)));
+            const uint64_t m0 = __ballot(pass0), m1 = __ballot(pass1);
+            const uint32_t at = __builtin_amdgcn_mbcnt_hi((uint32_t)(m1 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m1,
+                                __builtin_amdgcn_mbcnt_hi((uint32_t)(m0 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m0, n_out))));
+            if (pass0) {
+                chd_fanout_rec r;
+                r.conn = conn;
+                r.channel = e[h].x;
+                out[at] = r;
+            }
+            if (pass1) {
+                chd_fanout_rec r;
+                r.conn = conn;
+                r.channel = e[h].z;
+                out[at + (pass0 ? 1u : 0u)] = r;
+            }
+            n_out += (uint32_t)__popcll(m0) + (uint32_t)__popcll(m1);
+        }
+    }
+    return n_out;
+}
+
+#define FC_DESCS 64
+#define FC_WAVES 8
+#define FC_LWIN 4  // windows per descriptor whose tests are held in LDS (the rest, rare, are read from global memory)
+struct FcHead {
+    uint32_t out16[FC_DESCS];  // segment start in the record buffer, in units of 16 records (128-byte lines)
+    uint32_t n[FC_DESCS], info[FC_DESCS];  // entries of the cell; windows | own-update bits << 8 (0xFFFFFFFF: skip — no room for the connection's worst case)
+    uint32_t conn[FC_DESCS], pidx[FC_DESCS], sidx[FC_DESCS];
+    uint32_t win[FC_DESCS][FC_LWIN][6];
+    uint32_t nd, cch, start, valid, ticket, _pad[3];
+};
+struct FcTile {
+    uint32_t chan[512], hist[512], off[CHD_OFF_SLOTS][512];
+};
+
+// work items: per cell with filtered descriptors, chunks of FC_DESCS of its list (one workgroup; ncell <= 4096)
+__global__ void __launch_bounds__(1024) k_filt_items(WorldDev w, uint32_t ncell) {
+    __shared__ uint32_t wtot[16];
+    __shared__ uint32_t carry_s;
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    if (threadIdx.x == 0) carry_s = 0;
+    __syncthreads();
+    for (uint32_t base = 0; base < ncell; base += 1024) {
+        const uint32_t c = base + threadIdx.x;
+        uint32_t cnt = c < ncell ? w.cell_fcnt[32u * c] : 0u;
+        if (cnt > w.S) cnt = w.S;
+        const uint32_t chunks = (cnt + FC_DESCS - 1u) / FC_DESCS;
+        uint32_t inc = chunks;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const uint32_t o = (uint32_t)__shfl_up((int)inc, d);
+            if ((int)lane >= d) inc += o;
+        }
+        if (lane == 63) wtot[wave] = inc;
+        __syncthreads();
+        uint32_t off = carry_s;
+        for (uint32_t k = 0; k < wave; k++) off += wtot[k];
+        if (chunks) {
+            const uint32_t start = w.cell_start[c], tn = min(w.cell_end[c] - start, 512u);
+            for (uint32_t q = 0; q < chunks; q++)
+                w.filt_items[off + inc - chunks + q] = make_uint4(c, q * FC_DESCS, min(cnt - q * FC_DESCS, (uint32_t)FC_DESCS) | (tn << 8), start);
+        }
+        __syncthreads();
+        if (threadIdx.x == 1023) carry_s = off + inc;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) *w.filt_nitems = carry_s;
+}
+
+__global__ void __launch_bounds__(64 * FC_WAVES, 4) k_fanout_emit_filt_cm(DevGrid g, WorldDev w) {
+    __shared__ FcHead heads[2];
+    __shared__ FcTile tiles[2];
+    const uint32_t lane = lane_id();
+    const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const uint32_t n_items = *w.filt_nitems;
+    unsigned long long wave_sum = 0;
+
+    if (wave == 0) {
+        // ---- loader ----
+        uint32_t item = blockIdx.x;
+        auto prepare = [&](uint32_t b) {
+            FcHead &H = heads[b];
+            FcTile &T = tiles[b];
+            if (item >= n_items) {
+                if (lane == 0) H.valid = 0;
+                return;
+            }
+            const uint4 it = w.filt_items[item];
+            item += gridDim.x;
+            const uint32_t c = (uint32_t)__builtin_amdgcn_readfirstlane((int)it.x), first = (uint32_t)__builtin_amdgcn_readfirstlane((int)it.y);
+            const uint32_t ndt = (uint32_t)__builtin_amdgcn_readfirstlane((int)it.z), start = (uint32_t)__builtin_amdgcn_readfirstlane((int)it.w);
+            const uint32_t nd = ndt & 0xFFu, tn = ndt >> 8;
+            // second round trip: the descriptors' list entries (one per lane) AND the cell's columns — lane l holds the adjacent
+            // entries 128 r + 2 l, + 1 of row r (entries beyond the cell: spare, never used)
+            uint4 e0 = make_uint4(0u, 0u, 0xFFFFFFFFu, 0u), e1 = make_uint4(0u, 0u, 0u, 0u);
+            if (lane < nd) {
+                const uint4 *ep = w.cell_flist + ((size_t)c * w.S + first + lane) * 2;
+                e0 = ep[0];
+                e1 = ep[1];
+            }
+            // (row by row: the whole tile at once would take 80 registers of every wave of the kernel)
+#pragma unroll 1
+            for (uint32_t r = 0; r < 4; r++) {
+                if (tn <= 128u * r) break;  // uniform
+                const uint32_t i = 128u * r + 2u * lane;
+                const u32x4 ce = *(const u32x4 *)(const void *)(w.ce8_view + start + i);
+                u32x2 co[CHD_OFF_SLOTS];
+#pragma unroll
+                for (uint32_t j = 0; j < CHD_OFF_SLOTS; j++) co[j] = *(const u32x2 *)(const void *)(w.ce_off + (size_t)j * w.off_stride + start + i);
+                *(u32x2 *)(void *)&T.chan[i] = u32x2{ce.x, ce.z};
+                *(u32x2 *)(void *)&T.hist[i] = u32x2{ce.y, ce.w};
+                // (an entity WITHOUT an update in slot j gets the offset 0xFFFFFFFF: outside every window's bounds)
+#pragma unroll
+                for (uint32_t j = 0; j < CHD_OFF_SLOTS; j++)
+                    *(u32x2 *)(void *)&T.off[j][i] = u32x2{((ce.y >> j) & 1u) ? co[j].x : 0xFFFFFFFFu, ((ce.w >> j) & 1u) ? co[j].y : 0xFFFFFFFFu};
+            }
+            // third: the connection's words and the windows' tests
+            uint32_t info = 0xFFFFFFFFu, out16 = 0, conn = 0;
+            const uint32_t sidx = e1.x, pidx = sidx * w.capq + e0.w, nn = e0.y;
+            if (lane < nd) {
+                const uint64_t base = w.rec_ub[sidx], end = w.rec_ub[sidx + 1];
+                conn = w.conn_id[sidx];
+                const uint32_t lnw = min(e0.z & 15u, (uint32_t)FC_LWIN);
+                const u32x4 *fwp = (const u32x4 *)(const void *)(w.filt_win + (size_t)pidx * CHD_FILT_WINS);  // (192-byte rows: 16-byte aligned)
+                u32x4 t[6];
+#pragma unroll
+                for (int q = 0; q < 6; q++) t[q] = u32x4{0, 0, 0, 0};
+#pragma unroll
+                for (int q = 0; q < 6; q++)
+                    if ((uint32_t)(2 * (q / 3)) < lnw) t[q] = fwp[q];
+                if (end <= w.recs_cap) {
+                    info = e0.z;
+                    out16 = (uint32_t)((base + e0.x) / CHD_SEG_ALIGN);
+                }
+                u32x4 *dst = (u32x4 *)(void *)&H.win[lane][0][0];
+#pragma unroll
+                for (int q = 0; q < 6; q++)
+                    if ((uint32_t)(2 * (q / 3)) < lnw) dst[q] = t[q];
+            }
+            if (lane < FC_DESCS) {
+                H.out16[lane] = out16; H.n[lane] = nn; H.info[lane] = info; H.conn[lane] = conn; H.pidx[lane] = pidx; H.sidx[lane] = sidx;
+            }
+            if (lane == 0) { H.nd = nd; H.cch = c + g.id_start; H.start = start; H.valid = 1; H.ticket = 0; }
+        };
+#ifdef CHD_FCM_PROFILE
+        long long t_work = 0, t_wait = 0, t_mark = clock64();
+        uint32_t n_units = 0;
+#define FCM_MARK(acc) do { long long _t = clock64(); acc += _t - t_mark; t_mark = _t; } while (0)
+#else
+#define FCM_MARK(acc) do { } while (0)
+#endif
+        prepare(0);
+        FCM_MARK(t_work);
+        lds_barrier();
+        FCM_MARK(t_wait);
+        for (uint32_t u = 0;; u++) {
+            if (!heads[u & 1u].valid) break;
+            prepare((u + 1u) & 1u);
+            FCM_MARK(t_work);
+            lds_barrier();
+            FCM_MARK(t_wait);
+#ifdef CHD_FCM_PROFILE
+            n_units++;
+#endif
+        }
+#ifdef CHD_FCM_PROFILE
+        if (lane == 0 && (blockIdx.x == 0 || blockIdx.x == 300) && *w.filt_nitems > 600 && atomicAdd(&w.counters[15], 1u) < 6u)
+            printf("fcm loader block %u: items %u of %u work %lld wait %lld\n", blockIdx.x, n_units, *w.filt_nitems, t_work, t_wait);
+#endif
+    } else {
+        // ---- streamers ----
+#ifdef CHD_FCM_PROFILE
+        long long t_work = 0, t_wait = 0, t_mark = clock64();
+        uint32_t n_desc = 0;
+#endif
+        lds_barrier();
+        FCM_MARK(t_wait);
+        for (uint32_t u = 0;; u++) {
+            FcHead &H = heads[u & 1u];
+            const FcTile &T = tiles[u & 1u];
+            if (!H.valid) break;
+            const uint32_t nd = H.nd, cch = H.cch, start = H.start;
+            for (;;) {
+                uint32_t k = 0;
+                if (lane == 0) k = atomicAdd(&H.ticket, 1u);
+                k = (uint32_t)__builtin_amdgcn_readfirstlane((int)k);
+                if (k >= nd) break;
+                const uint32_t info = H.info[k];
+                if (info == 0xFFFFFFFFu) continue;  // (the deferred launch leaves the connection's state as it was and flags the tick)
+                const uint32_t n = H.n[k], conn = H.conn[k], pidx = H.pidx[k];
+                const uint32_t nw = info & 15u, own = (info >> 8) & 0xFFu;
+                chd_fanout_rec *__restrict__ out = w.recs + (size_t)H.out16[k] * CHD_SEG_ALIGN;
+                uint32_t n_out = 0;
+                // the cell's entries (adjacent pairs per lane and row), once per descriptor
+                u32x2 ch[4], hh[4];
+#pragma unroll
+                for (int h = 0; h < 4; h++) {
+                    ch[h] = u32x2{0, 0};
+                    hh[h] = u32x2{0, 0};
+                    if (n <= 512 && n > (uint32_t)(128 * h)) {
+                        ch[h] = *(const u32x2 *)(const void *)&T.chan[128 * h + 2 * lane];
+                        hh[h] = *(const u32x2 *)(const void *)&T.hist[128 * h + 2 * lane];
+                    }
+                }
+                for (uint32_t j = 0; j < nw; j++) {
+                    // (the values become scalars INSIDE each branch: a vector register that merges a global load with an LDS read
+                    // would make the compiler wait on the vm counter — i.e. drain the record stores — on the common path too)
+                    uint32_t full, slots, a_lo, a_hi, b_lo, b_hi;
+                    if (j < FC_LWIN) {
+                        const uint32_t *f = H.win[k][j];
+                        full = (uint32_t)__builtin_amdgcn_readfirstlane((int)f[0]); slots = (uint32_t)__builtin_amdgcn_readfirstlane((int)f[1]);
+                        a_lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)f[2]); a_hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)f[3]);
+                        b_lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)f[4]); b_hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)f[5]);
+                    } else {  // (rare: more than FC_LWIN windows)
+                        const uint32_t *f = (const uint32_t *)(const void *)(w.filt_win + (size_t)pidx * CHD_FILT_WINS + j);
+                        full = (uint32_t)__builtin_amdgcn_readfirstlane((int)f[0]); slots = (uint32_t)__builtin_amdgcn_readfirstlane((int)f[1]);
+                        a_lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)f[2]); a_hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)f[3]);
+                        b_lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)f[4]); b_hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)f[5]);
+                    }
+                    const uint32_t sa = slots & 0xFFu, sb = (slots >> 8) & 0xFFu;
+                    const bool use_a = a_lo <= a_hi, use_b = b_lo <= b_hi;  // (use_b only with use_a)
+                    if ((own >> j) & 1u) {  // the spatial channel's own buffered update lies inside this window
+                        if (lane == 0) {
+                            chd_fanout_rec r;
+                            r.conn = conn;
+                            r.channel = cch;
+                            out[n_out] = r;
+                        }
+                        n_out += 1;
+                    }
+                    if (n <= 512) {
+                        // THE COMMON PATH, LDS only.  Per row of 128 entries the lanes do two and + compare for the whole-slot mask
+                        // and two subtract + compare per cut slot — the staged offsets of entities WITHOUT an update in a slot are
+                        // 0xFFFFFFFF, so the range test alone decides (bounds never exceed 0xFFFFFFFE) — and everything else (bounds,
+                        // combining the tests, the ranks' base) runs on the scalar unit over the ballots.  The offsets of all four
+                        // rows are read from LDS in one go (the entries were, once per descriptor): one LDS round trip per window
+                        const uint32_t a_rng = a_hi - a_lo, b_rng = b_hi - b_lo;
+                        const uint32_t *oa_col = T.off[use_a ? sa : 0u] + 2 * lane, *ob_col = T.off[use_b ? sb : 0u] + 2 * lane;
+                        u32x2 oa[4], ob[4];
+#pragma unroll
+                        for (int h = 0; h < 4; h++) {
+                            oa[h] = u32x2{0xFFFFFFFFu, 0xFFFFFFFFu};
+                            ob[h] = u32x2{0xFFFFFFFFu, 0xFFFFFFFFu};
+                            if (use_a && n > (uint32_t)(128 * h)) oa[h] = *(const u32x2 *)(const void *)&oa_col[128 * h];
+                            if (use_b && n > (uint32_t)(128 * h)) ob[h] = *(const u32x2 *)(const void *)&ob_col[128 * h];
+                        }
+                        // (the four rows' tests first, independent of each other, then the stores: the write positions are a scalar
+                        // prefix over the rows' counts — no branch between the rows, so their instruction streams interleave)
+                        uint64_t m0[4], m1[4];
+#pragma unroll
+                        for (int h = 0; h < 4; h++) {
+                            const uint32_t left = n > (uint32_t)(128 * h) ? n - 128u * h : 0u;  // entries of this row and beyond
+                            const uint64_t in0 = left >= 127u ? ~0ull : ((1ull << ((left + 1u) >> 1)) - 1ull);
+                            const uint64_t in1 = left >= 128u ? ~0ull : ((1ull << (left >> 1)) - 1ull);
+                            uint64_t a0 = __ballot((hh[h].x & full) != 0), a1 = __ballot((hh[h].y & full) != 0);
+                            if (use_a) {
+                                a0 |= __ballot(oa[h].x - a_lo <= a_rng);
+                                a1 |= __ballot(oa[h].y - a_lo <= a_rng);
+                            }
+                            if (use_b) {
+                                a0 |= __ballot(ob[h].x - b_lo <= b_rng);
+                                a1 |= __ballot(ob[h].y - b_lo <= b_rng);
+                            }
+                            m0[h] = a0 & in0;
+                            m1[h] = a1 & in1;
+                        }
+                        typedef u32x4 __attribute__((aligned(8))) u32x4_a8;  // (n_out is any record index)
+#pragma unroll
+                        for (int h = 0; h < 4; h++) {
+                            // entry order: records before this lane's pair = passing entries of lower lanes; a lane's two records are
+                            // adjacent: one 16-byte store when both pass
+                            const uint32_t at = __builtin_amdgcn_mbcnt_hi((uint32_t)(m1[h] >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m1[h],
+                                                __builtin_amdgcn_mbcnt_hi((uint32_t)(m0[h] >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m0[h], n_out))));
+                            const bool pass0 = (m0[h] >> lane) & 1ull, pass1 = (m1[h] >> lane) & 1ull;
+                            if (pass0 & pass1) {
+                                u32x4 r;
+                                r.x = conn; r.y = ch[h].x; r.z = conn; r.w = ch[h].y;
+                                *(u32x4_a8 *)(void *)(out + at) = r;
+                            } else if (pass0 | pass1) {
+                                chd_fanout_rec r;
+                                r.conn = conn;
+                                r.channel = pass0 ? ch[h].x : ch[h].y;
+                                out[at] = r;
+                            }
+                            n_out += (uint32_t)__popcll(m0[h]) + (uint32_t)__popcll(m1[h]);
+                        }
+                    } else {
+                        // (rare: a cell beyond the tile — its columns from global memory, step by step, tested with the history bits)
+                        n_out = filt_window_global(w, start, n, full, sa, sb, a_lo, a_hi, b_lo, b_hi, conn, out, n_out);
+                    }
+                }
+                pad_segment(out, n_out);
+                if (lane == 0) {
+                    w.pair_nrec[pidx] = n_out;
+                    if (n_out) atomicAdd(&w.rec_cnt[H.sidx[k]], n_out);
+                }
+                wave_sum += n_out;
+#ifdef CHD_FCM_PROFILE
+                n_desc++;
+#endif
+            }
+            FCM_MARK(t_work);
+            lds_barrier();
+            FCM_MARK(t_wait);
+        }
+#ifdef CHD_FCM_PROFILE
+        if (lane == 0 && (blockIdx.x == 0 || blockIdx.x == 300) && wave < 3 && *w.filt_nitems > 600 && atomicAdd(&w.counters[14], 1u) < 12u)
+            printf("fcm streamer block %u wave %u: descs %u records %llu work %lld wait %lld\n", blockIdx.x, wave, n_desc, wave_sum, t_work, t_wait);
+#endif
+    }
+    if (lane == 0 && wave_sum) {
+        unsigned long long *slot = (unsigned long long *)&w.tot64[(size_t)((blockIdx.x * FC_WAVES + wave) & 63u) * 16];
+        atomicAdd(slot, wave_sum);
+        atomicAdd(slot + 2, wave_sum);  // (not written by the dominant emit kernel)
+        atomicAdd(slot + 4, wave_sum);  // (chd_tick_stats.n_filtered_records)
+    }
+}
+
 void launch_fanout_emit_filt(hipStream_t st, DevGrid g, WorldDev w) {
     if (!w.S || !w.off_on || !seg_path(w)) return;
+    if (w.fcm_on) {
+        hipLaunchKernelGGL(k_filt_items, dim3(1), dim3(1024), 0, st, w, g.ncell);
+        const uint64_t max_items = (uint64_t)w.S * w.capq / FC_DESCS + g.ncell;
+        const uint32_t grid = (uint32_t)std::min<uint64_t>(max_items, (uint64_t)(w.seg_waves / 8u) * 2u);  // two 8-wave workgroups per CU (LDS)
+        hipLaunchKernelGGL(k_fanout_emit_filt_cm, dim3(grid), dim3(64 * FC_WAVES), 0, st, g, w);
+        return;
+    }
     const uint32_t n_tickets = w.S * FO_FILT_WAVES;
     static const uint32_t per_cu = [] { const char *e = getenv("CHD_FILT_WAVES_PER_CU"); return e ? (uint32_t)std::min(std::max(atoi(e), 1), 32) : (uint32_t)FO_FILT_PER_CU; }();
     const uint32_t waves = w.seg_waves / 8u * per_cu;  // (seg_waves = 8 per CU unless CHD_EMIT_WAVES_PER_CU says otherwise)
@@ -2418,6 +2793,8 @@ __global__ void __launch_bounds__(64) k_tick_epilogue(WorldDev w, uint32_t slot,
     const uint32_t lane = threadIdx.x;
     if (w.deep_depth)  // (set again by the next tick's index build)
         for (uint32_t c = lane; c < ncell; c += 64) w.cell_irr[c] = 0;
+    if (w.off_on && w.fcm_on)  // (the next tick's plan appends to the cells' lists of filtered descriptors)
+        for (uint32_t c = lane; c < ncell; c += 64) w.cell_fcnt[32u * c] = 0;
     unsigned long long sum = w.tot64[(size_t)lane * 16], pairs = w.tot64[(size_t)lane * 16 + 1], deferred = w.tot64[(size_t)lane * 16 + 2];
     unsigned long long deepr = w.tot64[(size_t)lane * 16 + 3], filtr = w.tot64[(size_t)lane * 16 + 4];
     for (int d = 32; d >= 1; d >>= 1) {

@@ -561,7 +561,7 @@ __global__ void __launch_bounds__(256) k_cell_updates(DevGrid g, WorldDev w, uin
             if (w.off_on) {
                 // regular: inside the tick's own interval, and the channel's only stamp of this tick (WorldDev::off_on)
                 const uint64_t off = (uint64_t)(now - a);
-                if (!(a > w.prev_ns && a <= now && off <= 0xFFFFFFFFull)) irregular = true;
+                if (!(a > w.prev_ns && a <= now && off <= 0xFFFFFFFEull)) irregular = true;
                 if (!first_now && oo[0] != (uint32_t)off) irregular = true;
                 oo[0] = (uint32_t)off;
             } else if (a != now) irregular = true;
