@@ -347,12 +347,15 @@ def main():
     zs = np.empty((T + E, N), dtype=np.float64)
     qs = np.empty((T + E, S), dtype=synth.AOI_DTYPE)
     now = np.empty(T + E, dtype=np.int64)
-    jrng = np.random.default_rng(seed ^ 0x71773)
+    aj = synth.ArrivalJitter(seed, N, args.tick_jitter_us) if (jitter or args.tick_jitter_us) else None
+    arr = np.empty((T, N), dtype=np.int64) if jitter else None
     for t in range(T + E):
         sw.step()
         xs[t], zs[t], qs[t], now[t] = sw.x, sw.z, sw.queries(), sw.now_ns()
-        if args.tick_jitter_us:
-            now[t] += int(jrng.integers(-args.tick_jitter_us, args.tick_jitter_us + 1)) * 1000 + int(jrng.integers(0, 1000))
+        if aj is not None:
+            now[t], a = aj.next(now[t])
+            if jitter and t < T:
+                arr[t] = a
     e2e_frames = [(int(now[t]), xs[t].copy(), zs[t].copy(), qs[t].copy()) for t in range(T, T + E)]
     xs, zs, qs_dev = xs[:T], zs[:T], qs[:T]
     M, d_idx = N, None  # updates per tick
@@ -367,11 +370,9 @@ def main():
     del xs, zs
     d_arr = None
     if jitter:
-        # enqueue stamps: uniform in (previous tick, this tick] (channel.go:296-310 stamps at PutMessage; the tick handles the queue later)
-        prev = np.concatenate([[0], now[:T - 1]]) if T else now[:0]
-        arr = np.empty((T, M), dtype=np.int64)
-        for t in range(T):
-            arr[t] = now[t] - jrng.integers(0, max(int(now[t] - prev[t]), 1), M)
+        # enqueue stamps: uniform in (previous tick, this tick] (synth.ArrivalJitter; channel.go:296-310 stamps at PutMessage)
+        if d_idx is not None:
+            arr = np.ascontiguousarray(np.take_along_axis(arr, idx.astype(np.int64), axis=1))
         d_arr = world.device_array(arr)
         del arr
 
@@ -615,6 +616,12 @@ def main():
             out["strict_reference_flat_50ms"] = flat_interval_line(A, synth, cfg, N, S, seed, args, local_rank, 50)
         except Exception as ex:  # noqa: BLE001
             errors["strict_reference_flat_50ms"] = f"{type(ex).__name__}: {ex}"
+    if e2e is not None and not args.flat_interval_ms and not os.environ.get("CHD_BENCH_SKIP_JITTER"):
+        for key, tj in (("arrival_jitter", 0), ("arrival_jitter_ticks_off_grid", 3000)):
+            try:
+                out[key] = arrival_jitter_line(A, synth, cfg, N, S, seed, args, local_rank, tj)
+            except Exception as ex:  # noqa: BLE001
+                errors[key] = f"{type(ex).__name__}: {ex}"
     if not args.no_cpu and args.cpu_seconds > 0:
         try:
             out["cpu_baseline"], one = cpu_baseline(cfg, N, S, seed, args.tick_ms, args.aoi_scale, args.cpu_seconds)
@@ -667,6 +674,78 @@ def flat_interval_line(A, synth, cfg, N, S, seed, args, local_rank, interval_ms,
                     + (" (ticks pipelined, as the headline)" if pipe else " (serial schedule, as the headline)"),
             "value": msgs / el, "unit": "msgs/s", "steps": steps, "ms_per_step": 1e3 * el / steps, "msgs_per_tick": msgs / steps,
             "emit_us": emit_us, "emit_frac_of_hbm_peak": BYTES_PER_MSG * (msgs / steps) / (emit_us * 1e-6) / 1e9 / HBM_PEAK_GBS}
+
+
+def arrival_jitter_line(A, synth, cfg, N, S, seed, args, local_rank, tick_jitter_us, warm=10, steps=40, check=16):
+    """The headline workload with the reference's REAL arrival stamps: every update stamped at its enqueue time
+    (channel.go:296-310; synth.ArrivalJitter), a world with exact update buffers (history_depth 1024).  warm + steps ticks
+    device-resident and timed like the headline, then `check` synchronous ticks whose record digests are compared with the
+    ORACLE's list of this world (tests/golden/bench_digests_B_jitter*.json, make_bench_digests.py --arrival-jitter)."""
+    import torch
+
+    ctl = A.StaticGrid2DSpatialController(device=local_rank)
+    assert ctl.LoadConfig(json.dumps(cfg).encode(), strict=False) is None
+    sw = synth.SynthWorld(synth.WorldSpec(cfg, N, S, seed, tick_ms=args.tick_ms, aoi_scale=args.aoi_scale))
+    w = A.SpatialWorld(ctl, N, S, max_records=400_000_000, history_depth=1024)
+    w.spawn(None, sw.chan_id, sw.x, sw.z, sw.flags, sw.sender)
+    w.add_subscribers(None, sw.sub_conn)
+    T = warm + steps + check
+    xs = np.empty((T, N)); zs = np.empty((T, N)); qs = np.empty((T, S), dtype=synth.AOI_DTYPE); now = np.empty(T, dtype=np.int64)
+    arr = np.empty((T, N), dtype=np.int64)
+    aj = synth.ArrivalJitter(seed, N, tick_jitter_us)
+    for t in range(T):
+        sw.step()
+        xs[t], zs[t], qs[t] = sw.x, sw.z, sw.queries()
+        now[t], arr[t] = aj.next(sw.now_ns())
+    dx, dz, dq, da = w.device_array(xs), w.device_array(zs), w.device_array(qs), w.device_array(arr)
+    w.set_profiling(steps)
+    w.set_profiling_scope(True)
+
+    def tick(t):
+        w.tick_device(int(now[t]), n_updates=N, d_upd_x=dx.at(t * N * 8), d_upd_z=dz.at(t * N * 8), n_queries=S, d_queries=dq.at(t * S * 128),
+                      d_upd_arrival=da.at(t * N * 8))
+
+    for t in range(warm):
+        tick(t)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for t in range(warm, warm + steps):
+        tick(t)
+    torch.cuda.synchronize()
+    el = time.perf_counter() - t0
+    hist = w.history(steps)
+    msgs = sum(h["n_records"] for h in hist)
+    emit_us = float(np.mean([h["emit_main_us"] for h in hist]))
+    stream_msgs = float(np.mean([h["n_records"] - h["n_deep_records"] for h in hist]))
+    res = w.fetch()
+    assert res.overflow == 0 and res.history_overflow == 0, (res.overflow, res.history_overflow)
+    golden, checked = None, 0
+    gpath = DIGEST_FILE.replace(".json", "_jitter_offgrid.json" if tick_jitter_us else "_jitter.json")
+    if (N, S) == (100_000, 10_000) and args.aoi_scale == 1.0 and args.tick_ms == 50 and tick_jitter_us in (0, 3000) and os.path.exists(gpath):
+        with open(gpath) as f:
+            golden = json.load(f)["ticks"]
+    for t in range(warm + steps, T):
+        tick(t)
+        w.sync()
+        if golden is not None and str(t + 1) in golden:
+            (cnt, dsum, dxor, _), _ = w.digest(per_connection=False)
+            if golden[str(t + 1)] != [cnt, dsum, dxor]:
+                raise SystemExit(f"bench.py (arrival stamps at enqueue time, tick jitter {tick_jitter_us} us): tick {t + 1}: records digest "
+                                 f"{[cnt, dsum, dxor]} != the oracle's {golden[str(t + 1)]} ({os.path.basename(gpath)})")
+            checked += 1
+    ctl.close()
+    return {"what": "the headline workload with every update stamped at its ENQUEUE time — uniform inside its tick interval, as Channel.PutMessage "
+                    "stamps them (channel.go:296-310) — on a world with exact update buffers (history_depth 1024); serial schedule"
+                    + (f"; tick times off the 50 ms grid by up to +-{tick_jitter_us} us, so every subscription's fan-out phase is off the grid too and "
+                       "every window cuts through a tick's arrivals" if tick_jitter_us else "; tick times on the 50 ms grid"),
+            "value": msgs / el, "unit": "msgs/s", "steps": steps, "ms_per_step": 1e3 * el / steps, "msgs_per_tick": msgs / steps,
+            "record_kernels_us": emit_us, "record_kernels": "k_fanout_emit_seg + k_fanout_emit_filt_cm (HIP event pair around both)",
+            "record_kernels_frac_of_hbm_peak": BYTES_PER_MSG * stream_msgs / (emit_us * 1e-6) / 1e9 / HBM_PEAK_GBS,
+            "filtered_msgs_per_tick": float(np.mean([h["n_filtered_records"] for h in hist])),
+            "element_walk_msgs_per_tick": float(np.mean([h["n_deep_records"] for h in hist])), "history_overflow": int(res.history_overflow),
+            "digest_checked_ticks": checked,
+            "digest_check": "chd_tick_digest of the ticks after the timed region against the CPU oracle's list of this world "
+                            f"({os.path.basename(gpath)}: orc_world_tick_arrivals over the same stamps)"}
 
 
 DIGEST_FILE = os.path.join(ROOT, "tests", "golden", "bench_digests_B.json")

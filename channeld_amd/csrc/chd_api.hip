@@ -1611,8 +1611,9 @@ static int tick_locked(chd_ctx *ctx, const chd_tick_in *in) {
     } else {
         if (prof) HIPCHK(hipEventRecord(ev[CHD_N_STAGES + 4], st));
         launch_fanout_emit_main(st, ctx->g, d, in->now_ns, r);
-        if (prof) HIPCHK(hipEventRecord(ev[CHD_N_STAGES + 3], st));
+        if (prof && !d.off_on) HIPCHK(hipEventRecord(ev[CHD_N_STAGES + 3], st));
         launch_fanout_emit_filt(st, ctx->g, d);
+        if (prof && d.off_on) HIPCHK(hipEventRecord(ev[CHD_N_STAGES + 3], st));  // (emit_main_us: both record-writing kernels)
         launch_fanout_emit_deferred(st, ctx->g, d, in->now_ns, r);
         launch_fanout_emit_deep(st, ctx->g, d, in->now_ns, r);
         if (prof_ends) HIPCHK(hipEventRecord(ev[5], st));

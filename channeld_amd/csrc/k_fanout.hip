@@ -1754,9 +1754,9 @@ __global__ void __launch_bounds__(64, FO_FILT_OCC) k_fanout_emit_filt(DevGrid g,
 // before its stores, and on gfx950's in-order vm counter each such wait also drains the wave's own record stores — ~5 us of
 // wave time per window for ~1.5 KB of records.  But the columns a window reads are its CELL's, and a cell has hundreds of filtered
 // descriptors per tick (every subscriber of the cell whose phase is off the tick grid).  So, as the cell-major record kernel
-// does for the window masks: work item = (cell, 64 of its filtered descriptors); in a workgroup of 8 waves wave 0 is the LOADER
+// does for the window masks: work item = (cell, 64 of its filtered descriptors); in a workgroup of FC_WAVES waves wave 0 is the LOADER
 // — it gathers the item's descriptor headers (segment base, connection, the windows' tests) and stages the cell's columns
-// {channel, history, the offsets of all CHD_OFF_SLOTS ring slots} in LDS, double-buffered — and waves 1-7 are STREAMERS: they take
+// {channel, history, the offsets of all CHD_OFF_SLOTS ring slots} in LDS, double-buffered — and the others are STREAMERS: they take
 // descriptors by an LDS ticket and do the per-entity compare of every window on LDS data only, ballot / mbcnt compaction, record
 // stores.  A streamer never issues a global load (rare exceptions: a descriptor with more than FC_LWIN windows, a cell beyond
 // the 512-entry tile), so it never waits on the vm counter and its stores stay in flight back to back.
@@ -1811,7 +1811,14 @@ __device__ __forceinline__ uint32_t filt_window_global(const WorldDev &w, uint32
 }
 
 #define FC_DESCS 64
-#define FC_WAVES 8
+// 12 waves (1 loader + 11 streamers), two workgroups per CU: measured on config B with jittered stamps against 8 waves (14
+// streamers per CU: emit stage 228 us) and 16 (30 per CU, registers spilled: 318 us) — 216 us
+#ifndef FC_WAVES
+#define FC_WAVES 12
+#endif
+#ifndef FC_OCC
+#define FC_OCC 6
+#endif
 #define FC_LWIN 4  // windows per descriptor whose tests are held in LDS (the rest, rare, are read from global memory)
 struct FcHead {
     uint32_t out16[FC_DESCS];  // segment start in the record buffer, in units of 16 records (128-byte lines)
@@ -1858,7 +1865,7 @@ __global__ void __launch_bounds__(1024) k_filt_items(WorldDev w, uint32_t ncell)
     if (threadIdx.x == 0) *w.filt_nitems = carry_s;
 }
 
-__global__ void __launch_bounds__(64 * FC_WAVES, 4) k_fanout_emit_filt_cm(DevGrid g, WorldDev w) {
+__global__ void __launch_bounds__(64 * FC_WAVES, FC_OCC) k_fanout_emit_filt_cm(DevGrid g, WorldDev w) {
     __shared__ FcHead heads[2];
     __shared__ FcTile tiles[2];
     const uint32_t lane = lane_id();
@@ -2112,7 +2119,7 @@ void launch_fanout_emit_filt(hipStream_t st, DevGrid g, WorldDev w) {
     if (w.fcm_on) {
         hipLaunchKernelGGL(k_filt_items, dim3(1), dim3(1024), 0, st, w, g.ncell);
         const uint64_t max_items = (uint64_t)w.S * w.capq / FC_DESCS + g.ncell;
-        const uint32_t grid = (uint32_t)std::min<uint64_t>(max_items, (uint64_t)(w.seg_waves / 8u) * 2u);  // two 8-wave workgroups per CU (LDS)
+        const uint32_t grid = (uint32_t)std::min<uint64_t>(max_items, (uint64_t)(w.seg_waves / 8u) * 2u);  // two workgroups per CU (LDS: 56 KB each)
         hipLaunchKernelGGL(k_fanout_emit_filt_cm, dim3(grid), dim3(64 * FC_WAVES), 0, st, g, w);
         return;
     }

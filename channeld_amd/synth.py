@@ -159,3 +159,26 @@ class SynthWorld:
 
     def now_ns(self) -> int:
         return int(self.tick_index) * self.spec.tick_ms * 1_000_000
+
+
+class ArrivalJitter:
+    """The reference's arrival stamps for a synthetic world: Channel.PutMessage stamps an update when it is ENQUEUED
+    (arrivalTime = ch.GetTime(), channel.go:296-310), the tick that handles the queue comes later — so a tick's updates carry
+    stamps anywhere inside (previous tick, this tick].  next(t) takes the tick's nominal channel time and returns (now,
+    arrivals[n]): now = t, or t off the tick grid by up to +-tick_jitter_us (a real gateway's ticks are never exactly periodic;
+    subscriptions made at such a tick keep that phase, so every later fan-out window cuts through a tick's arrivals), arrivals
+    uniform in (previous now, now].  Deterministic in (seed, call sequence): bench.py, tests/golden/make_bench_digests.py and the
+    tests draw the same stamps."""
+
+    def __init__(self, seed: int, n: int, tick_jitter_us: int = 0):
+        self.rng = np.random.default_rng((int(seed) ^ 0x71773) & 0xFFFFFFFF)
+        self.n, self.tick_jitter_us, self.prev = int(n), int(tick_jitter_us), 0
+
+    def next(self, nominal_now_ns: int):
+        now = int(nominal_now_ns)
+        if self.tick_jitter_us:
+            now += int(self.rng.integers(-self.tick_jitter_us, self.tick_jitter_us + 1)) * 1000 + int(self.rng.integers(0, 1000))
+        assert now > self.prev
+        arr = now - self.rng.integers(0, now - self.prev, self.n)
+        self.prev = now
+        return now, arr.astype(np.int64)

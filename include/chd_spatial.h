@@ -759,7 +759,8 @@ int chd_host_free(chd_ctx *ctx, void *ptr);
 typedef struct {
     float stage_us[CHD_N_STAGES];
     float total_us;
-    float emit_main_us; /* the emit stage's dominant kernel alone (k_fanout_emit_seg when the descriptor path runs; else = stage_us[4]) */
+    float emit_main_us; /* the emit stage's dominant kernel alone (k_fanout_emit_seg when the descriptor path runs — together with the
+                           filtered descriptors' kernel on worlds that keep arrival offsets, history_depth —; else = stage_us[4]) */
     uint64_t n_records, n_record_upper_bound;
     uint32_t n_handovers, n_unsubs, n_pairs;
     uint32_t n_deferred_records; /* of n_records: written by the deferred-connection launch, not by the dominant emit kernel */

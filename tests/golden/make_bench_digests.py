@@ -51,8 +51,14 @@ def main():
     ap.add_argument("--ticks", type=int, default=700)
     ap.add_argument("--cross", type=int, default=40)
     ap.add_argument("--threads", type=int, default=os.cpu_count() or 1)
-    ap.add_argument("--out", default=OUT)
+    ap.add_argument("--out", default=None)
+    ap.add_argument("--arrival-jitter", action="store_true",
+                    help="bench.py --arrival-jitter's world: every update stamped at its enqueue time (synth.ArrivalJitter), the oracle's "
+                         "buffers hold those stamps (orc_world_tick_arrivals); default output tests/golden/bench_digests_B_jitter.json")
+    ap.add_argument("--tick-jitter-us", type=int, default=0, help="with --arrival-jitter: tick times off the grid (…_jitter_offgrid.json)")
     args = ap.parse_args()
+    if args.out is None:
+        args.out = OUT if not args.arrival_jitter else OUT.replace(".json", "_jitter_offgrid.json" if args.tick_jitter_us else "_jitter.json")
     orc.build()
     cfg = synth.load_config("spatial_static_benchmark.json")
     sw = synth.SynthWorld(synth.WorldSpec(cfg, N, S, SEED, tick_ms=TICK_MS, aoi_scale=1.0))
@@ -60,13 +66,15 @@ def main():
     slow = new_world(cfg, sw, args.threads, False) if args.cross > 0 else None
     ticks = {}
     t0 = time.perf_counter()
+    aj = synth.ArrivalJitter(SEED, N, args.tick_jitter_us) if args.arrival_jitter else None
     for k in range(1, args.ticks + 1):
         sw.step()
         q = sw.queries()
-        fast.tick(sw.now_ns(), None, sw.x, sw.z, None, None, None, None, q)
+        now, arr = aj.next(sw.now_ns()) if aj is not None else (sw.now_ns(), None)
+        fast.tick(now, None, sw.x, sw.z, None, None, None, None, q, upd_arrival=arr)
         (cnt, sm, xr, _), _ = fast.digest()
         if slow is not None and k <= args.cross:
-            slow.tick(sw.now_ns(), None, sw.x, sw.z, None, None, None, None, q)
+            slow.tick(now, None, sw.x, sw.z, None, None, None, None, q, upd_arrival=arr)
             (c2, s2, x2, _), _ = slow.digest()
             if (cnt, sm, xr) != (c2, s2, x2):
                 raise SystemExit(f"tick {k}: sorted walk {(cnt, sm, xr)} != forward walk {(c2, s2, x2)}")
@@ -79,7 +87,8 @@ def main():
     with open(args.out, "w") as f:
         json.dump({"what": "per-tick digests {count, sum, xor of mix64(conn << 32 | channel)} of the fan-out records of bench.py's default world "
                            f"(spatial_static_benchmark.json, {N} entities / {S} subs, seed {SEED:#x}, {TICK_MS} ms ticks), tick k = the k-th tick "
-                           "since the world began, as the CPU ORACLE computes them (oracle/chd_world_oracle.c, window formulation, digest mode; "
+                           + ("" if not args.arrival_jitter else f"ARRIVAL STAMPS AT ENQUEUE TIME (bench.py --arrival-jitter; synth.ArrivalJitter, tick jitter {args.tick_jitter_us} us), ")
+                           + "since the world began, as the CPU ORACLE computes them (oracle/chd_world_oracle.c, window formulation, digest mode; "
                            "tests/golden/make_bench_digests.py — the device never ran for this file).  bench.py compares chd_tick_digest of its "
                            "latency-phase ticks with this list; tests/test_bench_digests.py recomputes a few entries",
                    "generator": "tests/golden/make_bench_digests.py", "source": "oracle",

@@ -70,7 +70,7 @@ class FakeWorld:
 
     def history(self, n):
         return [dict(stage_us=[1.0, 2.0, 3.0, 4.0, 50.0], total_us=60.0, emit_main_us=40.0, n_records=100_000, n_deferred_records=500,
-                     n_handovers=3, n_unsubs=1, n_pairs=10, n_record_upper_bound=120_000) for _ in range(n)]
+                     n_handovers=3, n_unsubs=1, n_pairs=10, n_record_upper_bound=120_000, n_filtered_records=300, n_deep_records=0) for _ in range(n)]
 
     def fetch(self, **kw):
         return types.SimpleNamespace(overflow=0, history_overflow=0, n_records=100_000)
@@ -131,7 +131,9 @@ def test_default_run_prints_one_line_with_the_contract_keys(monkeypatch):
         assert k in c, k
     assert c["kind"] == "port" and d["cpu_baseline_1t"]["cores"] == 1
     assert "errors" not in d
-    assert {"p50_tick_ms", "p99_tick_ms", "latency_ticks", "stage_us_avg", "e2e", "strict_reference_flat_50ms"} <= set(d)
+    assert {"p50_tick_ms", "p99_tick_ms", "latency_ticks", "stage_us_avg", "e2e", "strict_reference_flat_50ms", "arrival_jitter",
+            "arrival_jitter_ticks_off_grid"} <= set(d)
+    assert d["arrival_jitter"]["unit"] == "msgs/s" and d["arrival_jitter"]["history_overflow"] == 0
     assert d["latency_ticks"] == 3 and d["stage_us_avg"]["emit"] == 50.0
     assert "pipelined_schedule" not in d  # 300 connections: the pipeline flag is not requested below 4096
 
