@@ -9,6 +9,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <condition_variable>
 #include <mutex>
 #include <string>
 #include <vector>
@@ -18,6 +19,30 @@
 extern uint32_t index_num_blocks(uint32_t N);
 
 namespace {
+
+// The ctx lock, FIFO: a std::mutex makes no fairness promise, and under the reference's calling pattern — thousands of goroutines
+// in GetChannelId / QueryChannelIds (message_spatial.go:59,236,354; spatial.go:611) beside ONE ticking goroutine — sixteen threads
+// re-taking the lock back to back starved the tick for seconds (tests/c/concurrent_callers.c measured 2 ticks in 60 s).  Tickets:
+// whoever asked first is served first, so a tick waits for at most one call of every other thread.
+class FairMutex {
+    std::mutex m;
+    std::condition_variable cv;
+    uint64_t next = 0, serving = 0;
+
+public:
+    void lock() {
+        std::unique_lock<std::mutex> l(m);
+        const uint64_t t = next++;
+        cv.wait(l, [&] { return t == serving; });
+    }
+    void unlock() {
+        {
+            std::lock_guard<std::mutex> l(m);
+            serving++;
+        }
+        cv.notify_all();
+    }
+};
 
 struct DevBuf {
     void *p = nullptr;
@@ -98,7 +123,7 @@ struct chd_ctx {
     chd_grid_cfg cfg{};
     DevGrid g{};
     AoiLimits lim{};
-    std::mutex mu;
+    FairMutex mu;  // (every entry point that touches device state holds it for the call)
     std::string err;
     World w;
     TickRing ring{};
@@ -531,7 +556,7 @@ void chd_destroy(chd_ctx *ctx) {
 
 int chd_sync(chd_ctx *ctx) {
     if (!ctx) return fail(nullptr, CHD_E_INVAL, "NULL ctx");
-    std::lock_guard<std::mutex> lk(ctx->mu);
+    std::lock_guard<FairMutex> lk(ctx->mu);
     TRY(bind(ctx));
     HIPCHK(hipStreamSynchronize(ctx->stream));
     return CHD_OK;
@@ -569,7 +594,7 @@ int chd_get_channel_ids(chd_ctx *ctx, const double *x, const double *z, uint32_t
         for (uint32_t i = 0; i < n; i++) out_ids[i] = host_channel_id(ctx->g, x[i], z[i]);
         return CHD_OK;
     }
-    std::lock_guard<std::mutex> lk(ctx->mu);
+    std::lock_guard<FairMutex> lk(ctx->mu);
     TRY(bind(ctx));
     TRY(ensure(ctx, 0, sizeof(double) * n));
     TRY(ensure(ctx, 1, sizeof(double) * n));
@@ -597,7 +622,7 @@ int chd_notify_decide(chd_ctx *ctx, const double *old_x, const double *old_z, co
         }
         return CHD_OK;
     }
-    std::lock_guard<std::mutex> lk(ctx->mu);
+    std::lock_guard<FairMutex> lk(ctx->mu);
     TRY(bind(ctx));
     for (int k = 0; k < 4; k++) TRY(ensure(ctx, k, sizeof(double) * n));
     TRY(ensure(ctx, 4, sizeof(uint32_t) * n));
@@ -630,7 +655,7 @@ int chd_query_channel_ids(chd_ctx *ctx, const chd_aoi_query *queries, uint32_t n
     }
     offsets[0] = 0;
     if (!nq) return CHD_OK;
-    std::lock_guard<std::mutex> lk(ctx->mu);
+    std::lock_guard<FairMutex> lk(ctx->mu);
     TRY(bind(ctx));
     const uint32_t stride = std::min<uint32_t>(ctx->g.ncell, ctx->lim.winmax);
     TRY(ensure(ctx, 0, sizeof(chd_aoi_query) * nq));
@@ -706,7 +731,7 @@ int chd_get_regions(chd_ctx *ctx, double *min_x, double *min_z, double *max_x, d
     if (!ctx) return fail(nullptr, CHD_E_INVAL, "NULL ctx");
     if (!min_x || !min_z || !max_x || !max_z || !channel_id || !server_index)
         return fail(ctx, CHD_E_INVAL, "chd_get_regions: NULL buffer");
-    std::lock_guard<std::mutex> lk(ctx->mu);
+    std::lock_guard<FairMutex> lk(ctx->mu);
     TRY(bind(ctx));
     const uint32_t n = ctx->g.ncell;
     for (int k = 0; k < 4; k++) TRY(ensure(ctx, k, sizeof(double) * n));
@@ -730,7 +755,7 @@ int chd_get_adjacent_channels(chd_ctx *ctx, const uint32_t *channel_ids, uint32_
         if (channel_ids[i] < ctx->g.id_start || channel_ids[i] - ctx->g.id_start >= ctx->g.ncell)
             return fail(ctx, CHD_E_INVAL, "channel id %u is not a spatial channel of this grid", channel_ids[i]);
     if (!n) return CHD_OK;
-    std::lock_guard<std::mutex> lk(ctx->mu);
+    std::lock_guard<FairMutex> lk(ctx->mu);
     TRY(bind(ctx));
     TRY(ensure(ctx, 0, sizeof(uint32_t) * n));
     TRY(ensure(ctx, 1, sizeof(uint32_t) * 8 * (size_t)n));
@@ -751,7 +776,7 @@ static int server_cells_common(chd_ctx *ctx, uint32_t server_index, int mode, ui
     if (server_index >= ctx->g.server_cols * ctx->g.server_rows)
         return fail(ctx, CHD_E_INVAL, "all %u grids are allocated to %u servers", ctx->g.ncell,
                     ctx->g.server_cols * ctx->g.server_rows);  // spatial.go:390-392
-    std::lock_guard<std::mutex> lk(ctx->mu);
+    std::lock_guard<FairMutex> lk(ctx->mu);
     TRY(bind(ctx));
     TRY(ensure(ctx, 0, sizeof(uint32_t) * std::max(cap, 1u)));
     TRY(ensure(ctx, 1, 2 * sizeof(uint32_t)));
@@ -783,7 +808,7 @@ int chd_border_channels(chd_ctx *ctx, uint32_t server_index, uint32_t *out, uint
 
 int chd_world_create(chd_ctx *ctx, const chd_world_cfg *cfg) {
     if (!ctx || !cfg) return fail(ctx, CHD_E_INVAL, "chd_world_create: NULL argument");
-    std::lock_guard<std::mutex> lk(ctx->mu);
+    std::lock_guard<FairMutex> lk(ctx->mu);
     TRY(bind(ctx));
     World &W = ctx->w;
     if (W.created) return fail(ctx, CHD_E_STATE, "world already created");
@@ -1143,7 +1168,7 @@ int chd_world_spawn(chd_ctx *ctx, uint32_t n, const uint32_t *idx, const uint32_
     if (idx)
         for (uint32_t i = 0; i < n; i++)
             if (idx[i] >= ctx->w.d.N) return fail(ctx, CHD_E_INVAL, "entity slot %u out of range", idx[i]);
-    std::lock_guard<std::mutex> lk(ctx->mu);
+    std::lock_guard<FairMutex> lk(ctx->mu);
     if (ctx->w.slot_mode == 2) return fail(ctx, CHD_E_STATE, "chd_world_spawn on a world whose slots are library-managed (chd_shard_spawn)");
     ctx->w.slot_mode = 1;
     TRY(bind(ctx));
@@ -1178,7 +1203,7 @@ int chd_world_despawn(chd_ctx *ctx, uint32_t n, const uint32_t *idx) {
     NEED_WORLD();
     if (!n) return CHD_OK;
     if (!idx) return fail(ctx, CHD_E_INVAL, "chd_world_despawn: NULL idx");
-    std::lock_guard<std::mutex> lk(ctx->mu);
+    std::lock_guard<FairMutex> lk(ctx->mu);
     TRY(bind(ctx));
     TRY(ensure(ctx, 0, 4 * (size_t)n));
     TRY(up(ctx, sbuf<void>(ctx, 0), idx, 4 * (size_t)n));
@@ -1198,7 +1223,7 @@ int chd_world_set_entity_flags(chd_ctx *ctx, uint32_t n, const uint32_t *idx, co
     NEED_WORLD();
     if (!n) return CHD_OK;
     if (!idx || !flags) return fail(ctx, CHD_E_INVAL, "chd_world_set_entity_flags: NULL buffer");
-    std::lock_guard<std::mutex> lk(ctx->mu);
+    std::lock_guard<FairMutex> lk(ctx->mu);
     TRY(bind(ctx));
     TRY(ensure(ctx, 0, 4 * (size_t)n)); TRY(ensure(ctx, 1, 4 * (size_t)n));
     TRY(up(ctx, sbuf<void>(ctx, 0), idx, 4 * (size_t)n));
@@ -1218,7 +1243,7 @@ int chd_world_set_entity_groups(chd_ctx *ctx, uint32_t n, const uint32_t *idx, c
     WorldDev &d = W.d;
     for (uint32_t i = 0; i < n; i++)
         if (idx[i] >= d.N) return fail(ctx, CHD_E_INVAL, "entity slot %u out of range", idx[i]);
-    std::lock_guard<std::mutex> lk(ctx->mu);
+    std::lock_guard<FairMutex> lk(ctx->mu);
     if (W.slot_mode == 2) return fail(ctx, CHD_E_STATE, "handover groups are not available on region-sharded worlds (a group may span ranks)");
     TRY(bind(ctx));
     if (W.group_id.empty() || d.grp_exact) W.group_id.assign(d.N, 0u);  // (after chd_world_set_handover_lists: start over)
@@ -1277,7 +1302,7 @@ int chd_world_set_handover_lists(chd_ctx *ctx, uint32_t n_lists, const uint32_t 
         if (idx[i] >= d.N) return fail(ctx, CHD_E_INVAL, "entity slot %u out of range", idx[i]);
         if (list_of[i] != CHD_NO_HANDOVER_LIST && list_of[i] >= n_lists) return fail(ctx, CHD_E_INVAL, "entity slot %u: list %u of %u", idx[i], list_of[i], n_lists);
     }
-    std::lock_guard<std::mutex> lk(ctx->mu);
+    std::lock_guard<FairMutex> lk(ctx->mu);
     if (W.slot_mode == 2) return fail(ctx, CHD_E_STATE, "handover groups are not available on region-sharded worlds (a group may span ranks)");
     TRY(bind(ctx));
     std::vector<uint32_t> of(d.N, CHD_INVALID);
@@ -1317,7 +1342,7 @@ static int subs_common(chd_ctx *ctx, uint32_t n, const uint32_t *slot, const uin
     if (add)
         for (uint32_t i = 0; i < n; i++)
             if (conn[i] & CHD_REC_FULL) return fail(ctx, CHD_E_INVAL, "connection id %u exceeds 31 bits (settings.go:90)", conn[i]);
-    std::lock_guard<std::mutex> lk(ctx->mu);
+    std::lock_guard<FairMutex> lk(ctx->mu);
     TRY(bind(ctx));
     TRY(ensure(ctx, 0, 4 * (size_t)n)); TRY(ensure(ctx, 1, 4 * (size_t)n));
     if (slot) TRY(up(ctx, sbuf<void>(ctx, 0), slot, 4 * (size_t)n));
@@ -1356,7 +1381,7 @@ int chd_subs_set_options(chd_ctx *ctx, int64_t now_ns, uint32_t n, const chd_sub
         if (r == 0 || opts[order[r]].slot != opts[order[r - 1]].slot) grp.push_back(r);
     const uint32_t ngrp = (uint32_t)grp.size();
     grp.push_back(n);
-    std::lock_guard<std::mutex> lk(ctx->mu);
+    std::lock_guard<FairMutex> lk(ctx->mu);
     TRY(bind(ctx));
     TRY(ensure(ctx, 0, sizeof(chd_sub_options) * (size_t)n));
     TRY(ensure(ctx, 1, 4 * (size_t)n));
@@ -1389,7 +1414,7 @@ int chd_subs_get_options(chd_ctx *ctx, uint32_t slot, uint8_t *data_access, uint
     if (!data_access || !skip_self || !n_out) return fail(ctx, CHD_E_INVAL, "chd_subs_get_options: NULL buffer");
     WorldDev &d = ctx->w.d;
     if (slot >= d.S) return fail(ctx, CHD_E_INVAL, "subscriber slot %u out of range", slot);
-    std::lock_guard<std::mutex> lk(ctx->mu);
+    std::lock_guard<FairMutex> lk(ctx->mu);
     TRY(bind(ctx));
     TRY(ensure(ctx, 0, d.capq));
     TRY(ensure(ctx, 1, d.capq));
@@ -1630,7 +1655,7 @@ static int tick_locked(chd_ctx *ctx, const chd_tick_in *in) {
 int chd_tick_device(chd_ctx *ctx, const chd_tick_in *d_in) {
     NEED_WORLD();
     if (!d_in) return fail(ctx, CHD_E_INVAL, "chd_tick_device: NULL input");
-    std::lock_guard<std::mutex> lk(ctx->mu);
+    std::lock_guard<FairMutex> lk(ctx->mu);
     TRY(bind(ctx));
     return tick_locked(ctx, d_in);
 }
@@ -1805,7 +1830,7 @@ static int fetch_locked(chd_ctx *ctx, chd_tick_out *out) {
 int chd_tick_fetch(chd_ctx *ctx, chd_tick_out *out) {
     NEED_WORLD();
     if (!out) return fail(ctx, CHD_E_INVAL, "chd_tick_fetch: NULL output");
-    std::lock_guard<std::mutex> lk(ctx->mu);
+    std::lock_guard<FairMutex> lk(ctx->mu);
     TRY(bind(ctx));
     return fetch_locked(ctx, out);
 }
@@ -1813,7 +1838,7 @@ int chd_tick_fetch(chd_ctx *ctx, chd_tick_out *out) {
 int chd_tick_fetch_segments(chd_ctx *ctx, chd_segments_out *out) {
     NEED_WORLD();
     if (!out || !out->conn_seg_off || !out->conn_rec_off) return fail(ctx, CHD_E_INVAL, "chd_tick_fetch_segments: NULL output");
-    std::lock_guard<std::mutex> lk(ctx->mu);
+    std::lock_guard<FairMutex> lk(ctx->mu);
     TRY(bind(ctx));
     World &W = ctx->w;
     WorldDev &d = W.d;
@@ -1874,7 +1899,7 @@ int chd_tick_fetch_segments(chd_ctx *ctx, chd_segments_out *out) {
 int chd_tick_digest(chd_ctx *ctx, chd_records_digest *total, uint64_t *conn_sum) {
     NEED_WORLD();
     if (!total) return fail(ctx, CHD_E_INVAL, "chd_tick_digest: NULL output");
-    std::lock_guard<std::mutex> lk(ctx->mu);
+    std::lock_guard<FairMutex> lk(ctx->mu);
     TRY(bind(ctx));
     World &W = ctx->w;
     WorldDev &d = W.d;
@@ -1904,7 +1929,7 @@ int chd_tick_digest(chd_ctx *ctx, chd_records_digest *total, uint64_t *conn_sum)
 int chd_tick(chd_ctx *ctx, const chd_tick_in *in, chd_tick_out *out) {
     NEED_WORLD();
     if (!in || !out) return fail(ctx, CHD_E_INVAL, "chd_tick: NULL argument");
-    std::lock_guard<std::mutex> lk(ctx->mu);
+    std::lock_guard<FairMutex> lk(ctx->mu);
     TRY(bind(ctx));
     chd_tick_in din = *in;
     const size_t nu = in->n_updates, nq = in->n_queries, nc = in->n_cell_updates, ns = in->n_spots_total;
@@ -2001,7 +2026,7 @@ int chd_tick(chd_ctx *ctx, const chd_tick_in *in, chd_tick_out *out) {
 
 int chd_set_stream(chd_ctx *ctx, void *hip_stream, int external) {
     if (!ctx) return fail(nullptr, CHD_E_INVAL, "NULL ctx");
-    std::lock_guard<std::mutex> lk(ctx->mu);
+    std::lock_guard<FairMutex> lk(ctx->mu);
     TRY(bind(ctx));
     HIPCHK(hipStreamSynchronize(ctx->stream));
     ctx->stream = external ? (hipStream_t)hip_stream : ctx->own_stream;
@@ -2013,7 +2038,7 @@ int chd_shard_spawn(chd_ctx *ctx, uint32_t n, const uint32_t *chan_id, const dou
     NEED_WORLD();
     if (!n) return CHD_OK;
     if (!chan_id || !x || !z) return fail(ctx, CHD_E_INVAL, "chd_shard_spawn: NULL buffer");
-    std::lock_guard<std::mutex> lk(ctx->mu);
+    std::lock_guard<FairMutex> lk(ctx->mu);
     if (ctx->w.slot_mode == 1) return fail(ctx, CHD_E_STATE, "chd_shard_spawn on a world with caller-chosen slots (chd_world_spawn)");
     if (ctx->w.d.deep_depth) return fail(ctx, CHD_E_STATE, "history_depth is not available on region-sharded worlds (the update buffers do not migrate)");
     ctx->w.slot_mode = 2;
@@ -2062,7 +2087,7 @@ int chd_shard_halo_layout(chd_ctx *ctx, uint32_t rank, uint32_t world, chd_halo_
     if (!world || rank >= world) return fail(ctx, CHD_E_INVAL, "chd_shard_halo_layout: rank %u of %u", rank, world);
     if (world != g.server_cols * g.server_rows)
         return fail(ctx, CHD_E_INVAL, "chd_shard_halo_layout: %u ranks but the grid has %u server regions", world, g.server_cols * g.server_rows);
-    std::lock_guard<std::mutex> lk(ctx->mu);
+    std::lock_guard<FairMutex> lk(ctx->mu);
     TRY(bind(ctx));
     World &W = ctx->w;
     const uint32_t halo = g.border, region = g.sgc * g.sgr, N = W.d.N;
@@ -2132,7 +2157,7 @@ int chd_shard_ingest(chd_ctx *ctx, int64_t now_ns, const double *d_x_by_chan, co
         return fail(ctx, CHD_E_INVAL, "chd_shard_ingest: %u ranks but the grid has %u server regions", world,
                     ctx->g.server_cols * ctx->g.server_rows);
     if (world > 1 && (!d_send || !cap)) return fail(ctx, CHD_E_INVAL, "chd_shard_ingest: NULL send buffer");
-    std::lock_guard<std::mutex> lk(ctx->mu);
+    std::lock_guard<FairMutex> lk(ctx->mu);
     if (ctx->w.slot_mode == 1) return fail(ctx, CHD_E_STATE, "chd_shard_ingest on a world with caller-chosen slots");
     ctx->w.slot_mode = 2;
     TRY(bind(ctx));
@@ -2152,7 +2177,7 @@ int chd_shard_ingest(chd_ctx *ctx, int64_t now_ns, const double *d_x_by_chan, co
 int chd_shard_import(chd_ctx *ctx, const chd_entity_state *d_recv, uint32_t world, uint32_t cap, void *d_halo_send) {
     NEED_WORLD();
     if (world > 1 && !d_recv) return fail(ctx, CHD_E_INVAL, "chd_shard_import: NULL receive buffer");
-    std::lock_guard<std::mutex> lk(ctx->mu);
+    std::lock_guard<FairMutex> lk(ctx->mu);
     if (ctx->w.slot_mode != 2) return fail(ctx, CHD_E_STATE, "chd_shard_import before chd_shard_ingest");
     World &W = ctx->w;
     if (world > 1 && (W.halo_world != world || !d_halo_send)) return fail(ctx, CHD_E_STATE, "chd_shard_import: call chd_shard_halo_layout(rank, world) first and pass the halo send buffer");
@@ -2181,7 +2206,7 @@ int chd_shard_import(chd_ctx *ctx, const chd_entity_state *d_recv, uint32_t worl
 int chd_shard_interest(chd_ctx *ctx, const chd_tick_in *d_in) {
     NEED_WORLD();
     if (!d_in) return fail(ctx, CHD_E_INVAL, "chd_shard_interest: NULL input");
-    std::lock_guard<std::mutex> lk(ctx->mu);
+    std::lock_guard<FairMutex> lk(ctx->mu);
     if (ctx->w.slot_mode != 2) return fail(ctx, CHD_E_STATE, "chd_shard_interest before chd_shard_ingest");
     TRY(bind(ctx));
     TRY(check_queries(ctx, d_in));
@@ -2197,7 +2222,7 @@ int chd_shard_fanout(chd_ctx *ctx, const void *d_halo_recv, uint32_t world, cons
     if (!d_in) return fail(ctx, CHD_E_INVAL, "chd_shard_fanout: NULL input");
     if (!world) return fail(ctx, CHD_E_INVAL, "chd_shard_fanout: world = 0");
     if (world > 1 && !d_halo_recv) return fail(ctx, CHD_E_INVAL, "chd_shard_fanout: NULL halo receive buffer");
-    std::lock_guard<std::mutex> lk(ctx->mu);
+    std::lock_guard<FairMutex> lk(ctx->mu);
     if (ctx->w.slot_mode != 2) return fail(ctx, CHD_E_STATE, "chd_shard_fanout before chd_shard_ingest");
     TRY(bind(ctx));
     TRY(check_queries(ctx, d_in));
@@ -2246,7 +2271,7 @@ int chd_shard_get_entities(chd_ctx *ctx, uint32_t *chan_id, uint32_t *cell_chann
     NEED_WORLD();
     if (!chan_id || !n_out) return fail(ctx, CHD_E_INVAL, "chd_shard_get_entities: NULL buffer");
     WorldDev &d = ctx->w.d;
-    std::lock_guard<std::mutex> lk(ctx->mu);
+    std::lock_guard<FairMutex> lk(ctx->mu);
     TRY(bind(ctx));
     std::vector<uint32_t> ch(d.N), cell(d.N), mem(d.N), fl(d.N);
     TRY(down(ctx, ch.data(), d.chan_id, 4 * (size_t)d.N));
@@ -2297,7 +2322,7 @@ int chd_wire_set_payloads(chd_ctx *ctx, int kind, uint32_t n, const uint32_t *id
         total += lens[i];
     }
     if (total && !bytes) return fail(ctx, CHD_E_INVAL, "chd_wire_set_payloads: NULL bytes");
-    std::lock_guard<std::mutex> lk(ctx->mu);
+    std::lock_guard<FairMutex> lk(ctx->mu);
     TRY(bind(ctx));
     TRY(ensure(ctx, 0, 4 * (size_t)n)); TRY(ensure(ctx, 1, 4 * (size_t)n)); TRY(ensure(ctx, 2, 8 * (size_t)n));
     TRY(ensure(ctx, 3, std::max<uint64_t>(total, 16)));
@@ -2321,7 +2346,7 @@ int chd_wire_set_type_url(chd_ctx *ctx, int which, const uint8_t *url, uint32_t 
     if (which < 0 || which > 2) return fail(ctx, CHD_E_INVAL, "chd_wire_set_type_url: which = %d", which);
     if (which < 2 && !W.x.merge) return fail(ctx, CHD_E_STATE, "update type urls belong to worlds with CHD_WORLD_WIRE | CHD_WORLD_UPDATE_MASKS");
     if (len > 255 || (len && !url)) return fail(ctx, CHD_E_INVAL, "chd_wire_set_type_url: at most 255 bytes");
-    std::lock_guard<std::mutex> lk(ctx->mu);
+    std::lock_guard<FairMutex> lk(ctx->mu);
     TRY(bind(ctx));
     HIPCHK(hipStreamSynchronize(ctx->stream));
     if (len) HIPCHK(hipMemcpy(W.x.url[which], url, len, hipMemcpyHostToDevice));
@@ -2332,7 +2357,7 @@ int chd_wire_set_type_url(chd_ctx *ctx, int which, const uint8_t *url, uint32_t 
 int chd_wire_set_merge_schema(chd_ctx *ctx, int schema) {
     NEED_WORLD();
     if (schema != CHD_MERGE_SCHEMA_NONE && schema != CHD_MERGE_SCHEMA_TPS_ENTITY_MOVEMENT) return fail(ctx, CHD_E_INVAL, "chd_wire_set_merge_schema: unknown schema %d", schema);
-    std::lock_guard<std::mutex> lk(ctx->mu);
+    std::lock_guard<FairMutex> lk(ctx->mu);
     World &W = ctx->w;
     if (!W.wire || !W.x.merge) return fail(ctx, CHD_E_STATE, "merge schemas belong to worlds with CHD_WORLD_WIRE | CHD_WORLD_UPDATE_MASKS");
     TRY(bind(ctx));
@@ -2346,7 +2371,7 @@ int chd_handover_messages(chd_ctx *ctx, uint32_t n_handovers, uint32_t *offsets,
     NEED_WORLD();
     if (!offsets || !n_out || (cap && !bytes)) return fail(ctx, CHD_E_INVAL, "chd_handover_messages: NULL buffer");
     World &W = ctx->w;
-    std::lock_guard<std::mutex> lk(ctx->mu);
+    std::lock_guard<FairMutex> lk(ctx->mu);
     if (!W.wire) return fail(ctx, CHD_E_STATE, "the world was created without CHD_WORLD_WIRE");
     if (!W.ticked) return fail(ctx, CHD_E_STATE, "no tick yet");
     TRY(bind(ctx));
@@ -2379,7 +2404,7 @@ int chd_handover_messages(chd_ctx *ctx, uint32_t n_handovers, uint32_t *offsets,
 int chd_wire_build(chd_ctx *ctx, uint64_t *total_bytes, uint64_t *total_packets, uint32_t *dropped) {
     NEED_WORLD();
     World &W = ctx->w;
-    std::lock_guard<std::mutex> lk(ctx->mu);
+    std::lock_guard<FairMutex> lk(ctx->mu);
     if (!W.wire) return fail(ctx, CHD_E_STATE, "the world was created without CHD_WORLD_WIRE");
     if (!W.ticked) return fail(ctx, CHD_E_STATE, "no tick to build the wire buffers of");
     if (W.slot_mode == 2) return fail(ctx, CHD_E_STATE, "wire buffers are not available on region-sharded worlds yet");
@@ -2477,7 +2502,7 @@ int chd_wire_build(chd_ctx *ctx, uint64_t *total_bytes, uint64_t *total_packets,
 int chd_wire_build_info(chd_ctx *ctx, uint64_t *n_image_ranges, uint32_t *n_record_path_connections) {
     NEED_WORLD();
     World &W = ctx->w;
-    std::lock_guard<std::mutex> lk(ctx->mu);
+    std::lock_guard<FairMutex> lk(ctx->mu);
     if (!W.wire_built) return fail(ctx, CHD_E_STATE, "chd_wire_build has not run for the last tick");
     if (n_image_ranges) *n_image_ranges = W.wire_ranges;
     if (n_record_path_connections) *n_record_path_connections = W.wire_slow_conns;
@@ -2488,7 +2513,7 @@ int chd_wire_fetch(chd_ctx *ctx, uint64_t *conn_off, uint32_t *conn_packets, uin
     NEED_WORLD();
     World &W = ctx->w;
     if (!conn_off) return fail(ctx, CHD_E_INVAL, "chd_wire_fetch: NULL conn_off");
-    std::lock_guard<std::mutex> lk(ctx->mu);
+    std::lock_guard<FairMutex> lk(ctx->mu);
     if (!W.wire_built) return fail(ctx, CHD_E_STATE, "chd_wire_build has not run for the last tick");
     TRY(bind(ctx));
     TRY(down(ctx, conn_off, W.x.conn_woff, sizeof(uint64_t) * ((size_t)W.d.S + 1)));
@@ -2509,7 +2534,7 @@ int chd_handover_recipients(chd_ctx *ctx, uint32_t *offsets, uint32_t *conn, uin
     World &W = ctx->w;
     if (!W.plan_recipients) return fail(ctx, CHD_E_STATE, "the world was created without CHD_WORLD_HANDOVER_RECIPIENTS");
     if (!W.ticked) return fail(ctx, CHD_E_STATE, "no tick yet");
-    std::lock_guard<std::mutex> lk(ctx->mu);
+    std::lock_guard<FairMutex> lk(ctx->mu);
     TRY(bind(ctx));
     uint64_t ringrow[8];
     TRY(down(ctx, ringrow, W.d.tick_ring + (size_t)(ctx->ring.cur_tick % TICK_RING) * 8, sizeof ringrow));
@@ -2540,7 +2565,7 @@ int chd_adjacent_recipients(chd_ctx *ctx, uint32_t n_req, const uint32_t *channe
         if (channel[i] < ctx->g.id_start || channel[i] - ctx->g.id_start >= ctx->g.ncell)
             return fail(ctx, CHD_E_INVAL, "request %u: BroadcastType_ADJACENT_CHANNELS only works for a spatial channel (message.go:190-193)", i);
     }
-    std::lock_guard<std::mutex> lk(ctx->mu);
+    std::lock_guard<FairMutex> lk(ctx->mu);
     TRY(bind(ctx));
     const size_t nb = sizeof(uint32_t) * (size_t)n_req;
     for (int k = 0; k < 4; k++) TRY(ensure(ctx, k, nb));
@@ -2572,7 +2597,7 @@ int chd_subs_get(chd_ctx *ctx, uint32_t slot, uint32_t *channel, uint32_t *inter
     if (!n_out) return fail(ctx, CHD_E_INVAL, "chd_subs_get: NULL n_out");
     WorldDev &d = ctx->w.d;
     if (slot >= d.S) return fail(ctx, CHD_E_INVAL, "subscriber slot %u out of range", slot);
-    std::lock_guard<std::mutex> lk(ctx->mu);
+    std::lock_guard<FairMutex> lk(ctx->mu);
     TRY(bind(ctx));
     uint32_t cnt = 0, stick = 0;
     TRY(down(ctx, &cnt, d.pair_cnt + slot, 4));
@@ -2599,7 +2624,7 @@ int chd_world_get_entities(chd_ctx *ctx, uint32_t n, const uint32_t *idx, uint32
     NEED_WORLD();
     WorldDev &d = ctx->w.d;
     if (!idx && n > d.N) return fail(ctx, CHD_E_INVAL, "n > max_entities");
-    std::lock_guard<std::mutex> lk(ctx->mu);
+    std::lock_guard<FairMutex> lk(ctx->mu);
     TRY(bind(ctx));
     std::vector<uint32_t> cell(d.N), mem(d.N);
     TRY(down(ctx, cell.data(), d.cell, 4 * (size_t)d.N));
@@ -2616,14 +2641,14 @@ int chd_world_get_entities(chd_ctx *ctx, uint32_t n, const uint32_t *idx, uint32
 
 int chd_dev_alloc(chd_ctx *ctx, uint64_t bytes, void **d_out) {
     if (!ctx || !d_out) return fail(ctx, CHD_E_INVAL, "chd_dev_alloc: NULL argument");
-    std::lock_guard<std::mutex> lk(ctx->mu);
+    std::lock_guard<FairMutex> lk(ctx->mu);
     TRY(bind(ctx));
     HIPCHK(hipMalloc(d_out, bytes ? bytes : 256));
     return CHD_OK;
 }
 int chd_dev_free(chd_ctx *ctx, void *d_ptr) {
     if (!ctx) return fail(nullptr, CHD_E_INVAL, "NULL ctx");
-    std::lock_guard<std::mutex> lk(ctx->mu);
+    std::lock_guard<FairMutex> lk(ctx->mu);
     TRY(bind(ctx));
     HIPCHK(hipStreamSynchronize(ctx->stream));
     HIPCHK(hipFree(d_ptr));
@@ -2631,7 +2656,7 @@ int chd_dev_free(chd_ctx *ctx, void *d_ptr) {
 }
 int chd_dev_upload(chd_ctx *ctx, void *d_dst, const void *src, uint64_t bytes) {
     if (!ctx) return fail(nullptr, CHD_E_INVAL, "NULL ctx");
-    std::lock_guard<std::mutex> lk(ctx->mu);
+    std::lock_guard<FairMutex> lk(ctx->mu);
     TRY(bind(ctx));
     TRY(up(ctx, d_dst, src, bytes));
     HIPCHK(hipStreamSynchronize(ctx->stream));
@@ -2639,7 +2664,7 @@ int chd_dev_upload(chd_ctx *ctx, void *d_dst, const void *src, uint64_t bytes) {
 }
 int chd_dev_download(chd_ctx *ctx, void *dst, const void *d_src, uint64_t bytes) {
     if (!ctx) return fail(nullptr, CHD_E_INVAL, "NULL ctx");
-    std::lock_guard<std::mutex> lk(ctx->mu);
+    std::lock_guard<FairMutex> lk(ctx->mu);
     TRY(bind(ctx));
     TRY(down(ctx, dst, d_src, bytes));
     HIPCHK(hipStreamSynchronize(ctx->stream));
@@ -2648,14 +2673,14 @@ int chd_dev_download(chd_ctx *ctx, void *dst, const void *d_src, uint64_t bytes)
 
 int chd_host_alloc(chd_ctx *ctx, uint64_t bytes, void **out) {
     if (!ctx || !out) return fail(ctx, CHD_E_INVAL, "chd_host_alloc: NULL argument");
-    std::lock_guard<std::mutex> lk(ctx->mu);
+    std::lock_guard<FairMutex> lk(ctx->mu);
     TRY(bind(ctx));
     HIPCHK(hipHostMalloc(out, bytes ? bytes : 256, hipHostMallocDefault));
     return CHD_OK;
 }
 int chd_host_free(chd_ctx *ctx, void *ptr) {
     if (!ctx) return fail(nullptr, CHD_E_INVAL, "NULL ctx");
-    std::lock_guard<std::mutex> lk(ctx->mu);
+    std::lock_guard<FairMutex> lk(ctx->mu);
     TRY(bind(ctx));
     HIPCHK(hipStreamSynchronize(ctx->stream));
     HIPCHK(hipHostFree(ptr));
@@ -2665,7 +2690,7 @@ int chd_host_free(chd_ctx *ctx, void *ptr) {
 int chd_set_profiling(chd_ctx *ctx, int depth) {
     if (!ctx) return fail(nullptr, CHD_E_INVAL, "NULL ctx");
     if (depth < 0 || depth > TICK_RING) return fail(ctx, CHD_E_INVAL, "profiling depth must be in [0, %d]", TICK_RING);
-    std::lock_guard<std::mutex> lk(ctx->mu);
+    std::lock_guard<FairMutex> lk(ctx->mu);
     TRY(bind(ctx));
     HIPCHK(hipStreamSynchronize(ctx->stream));
     for (auto &e : ctx->ev) (void)hipEventDestroy(e);
@@ -2686,7 +2711,7 @@ int chd_set_profiling(chd_ctx *ctx, int depth) {
 int chd_set_profiling_scope(chd_ctx *ctx, int scope) {
     if (!ctx) return fail(nullptr, CHD_E_INVAL, "NULL ctx");
     if (scope != CHD_PROF_STAGES && scope != CHD_PROF_RECORD_KERNEL) return fail(ctx, CHD_E_INVAL, "chd_set_profiling_scope: unknown scope %d", scope);
-    std::lock_guard<std::mutex> lk(ctx->mu);
+    std::lock_guard<FairMutex> lk(ctx->mu);
     TRY(bind(ctx));
     HIPCHK(hipStreamSynchronize(ctx->stream));
     ctx->prof_kernel_only = scope == CHD_PROF_RECORD_KERNEL;
@@ -2695,7 +2720,7 @@ int chd_set_profiling_scope(chd_ctx *ctx, int scope) {
 
 int chd_world_set_pipelining(chd_ctx *ctx, int on) {
     NEED_WORLD();
-    std::lock_guard<std::mutex> lk(ctx->mu);
+    std::lock_guard<FairMutex> lk(ctx->mu);
     TRY(bind(ctx));
     if (!ctx->w.pipe_alloc) return fail(ctx, CHD_E_STATE, "chd_world_set_pipelining: the world was not created with CHD_WORLD_PIPELINE_TICKS (or the flag did not take effect)");
     HIPCHK(hipStreamSynchronize(ctx->stream));
@@ -2707,7 +2732,7 @@ int chd_world_set_pipelining(chd_ctx *ctx, int on) {
 int chd_get_tick_history(chd_ctx *ctx, uint32_t n, chd_tick_stats *out) {
     NEED_WORLD();
     if (!out || n == 0 || n > TICK_RING) return fail(ctx, CHD_E_INVAL, "chd_get_tick_history: bad arguments");
-    std::lock_guard<std::mutex> lk(ctx->mu);
+    std::lock_guard<FairMutex> lk(ctx->mu);
     TRY(bind(ctx));
     HIPCHK(hipStreamSynchronize(ctx->stream));
     std::vector<uint64_t> ring((size_t)TICK_RING * 8);
@@ -2735,7 +2760,7 @@ int chd_get_tick_history(chd_ctx *ctx, uint32_t n, chd_tick_stats *out) {
 
 int chd_get_tick_stats(chd_ctx *ctx, chd_tick_stats *out) {
     if (!ctx || !out) return fail(ctx, CHD_E_INVAL, "chd_get_tick_stats: NULL argument");
-    std::lock_guard<std::mutex> lk(ctx->mu);
+    std::lock_guard<FairMutex> lk(ctx->mu);
     // byte model of DESIGN.md §4: 12 B per emitted message dominate
     chd_tick_stats s = ctx->stats;
     s.algorithmic_bytes = 12ull * s.n_records + 32ull * s.n_handovers;

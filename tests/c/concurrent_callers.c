@@ -159,6 +159,7 @@ static void *ticker(void *arg) {
     for (int t = 1; t <= TICKS && !atomic_load(&failures); t++) {
         chd_records_digest d;
         if (one_tick(ctx, t, &d, &seg)) { FAIL("tick %d: %s", t, chd_last_error(ctx)); break; }
+        if (getenv("CHD_TEST_TRACE")) fprintf(stderr, "tick %d done, %llu stateless calls so far\n", t, (unsigned long long)atomic_load(&n_calls));
         if (d.count != want_digest[t].count || d.sum != want_digest[t].sum || d.xor_ != want_digest[t].xor_ || seg.n_records != d.count)
             FAIL("tick %d beside %d caller threads: %" PRIu64 " records, digest differs from the single-threaded run (%" PRIu64 ")", t, N_THREADS,
                  (uint64_t)d.count, (uint64_t)want_digest[t].count);
@@ -200,7 +201,7 @@ int main(void) {
         total += want_digest[t].count;
     }
     chd_destroy(ref);
-    if (total < 1000000) { fprintf(stderr, "only %" PRIu64 " records in the reference run\n", total); return 1; }
+    if (total < 100000) { fprintf(stderr, "only %" PRIu64 " records in the reference run\n", total); return 1; }
 
     pthread_t th[N_THREADS], tk;
     for (long i = 0; i < N_THREADS; i++) pthread_create(&th[i], NULL, caller, (void *)i);

@@ -57,11 +57,11 @@ def test_the_c_programs_build_warning_free_and_fail_loudly_without_a_device(exes
 
 @pytest.mark.gpu
 def test_the_cgo_call_sequence_in_plain_c(exes):
-    r = subprocess.run([exes["cgo_sequence"]], capture_output=True, text=True, timeout=300)
+    r = subprocess.run([exes["cgo_sequence"]], capture_output=True, text=True, timeout=90)
     assert r.returncode == 0 and "cgo sequence ok" in r.stdout, (r.returncode, r.stdout, r.stderr)
 
 
 @pytest.mark.gpu
 def test_sixteen_threads_call_the_stateless_api_while_another_ticks(exes):
-    r = subprocess.run([exes["concurrent_callers"]], capture_output=True, text=True, timeout=600)
+    r = subprocess.run([exes["concurrent_callers"]], capture_output=True, text=True, timeout=120)
     assert r.returncode == 0 and "concurrent callers ok" in r.stdout, (r.returncode, r.stdout, r.stderr)
