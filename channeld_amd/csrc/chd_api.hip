@@ -10,9 +10,12 @@
 #include <cstdlib>
 #include <cstring>
 #include <condition_variable>
+#include <dlfcn.h>
 #include <mutex>
 #include <string>
 #include <vector>
+
+#include <rccl/rccl.h>  // types and constants only: librccl.so is dlopen'ed by chd_shard_comm_init (a single-GPU gateway never loads it)
 
 #include "chd_kernels.h"
 
@@ -103,6 +106,14 @@ struct World {
     uint64_t *seg_exp = nullptr;       // [S + 1] explicit records per connection -> offsets
     chd_fanout_segment *seg_stage = nullptr; size_t seg_stage_cap = 0;
     chd_fanout_rec *seg_rec_stage = nullptr; size_t seg_rec_stage_cap = 0;
+    // native collectives (chd_shard_comm_init): the two exchanges of a sharded tick on RCCL inside the library
+    ncclComm_t comm = nullptr;
+    uint32_t comm_rank = 0, comm_world = 0, comm_cap = 0;
+    chd_entity_state *mig_send = nullptr, *mig_recv = nullptr;   // [world][cap + 1]
+    unsigned char *halo_send_buf = nullptr, *halo_recv_buf = nullptr;
+    std::vector<chd_halo_seg> halo_segs;
+    hipStream_t comm_stream = nullptr;
+    hipEvent_t ev_halo_ready = nullptr, ev_halo_done = nullptr;
     uint32_t *ho_rcp_off = nullptr;    // [handovers_cap + 1] recipients of handover h: [off[h], off[h+1])
     uint32_t *ho_rcp_conn = nullptr;   // connection ids
     uint8_t *ho_rcp_kind = nullptr;    // CHD_HO_*
@@ -527,6 +538,7 @@ void chd_destroy(chd_ctx *ctx) {
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
     (void)hipStreamSynchronize(ctx->aux_stream);
+    (void)chd_shard_comm_destroy(ctx);  // (no-op without a communicator)
     if (ctx->w.ev_stages_done) {
         (void)hipEventDestroy(ctx->w.ev_stages_done);
         (void)hipEventDestroy(ctx->w.ev_rec_sync);
@@ -2080,14 +2092,8 @@ static int shard_reserve_ghosts(chd_ctx *ctx, uint32_t ghosts) {
     return CHD_OK;
 }
 
-int chd_shard_halo_layout(chd_ctx *ctx, uint32_t rank, uint32_t world, chd_halo_seg *segs, uint64_t *send_total, uint64_t *recv_total) {
-    NEED_WORLD();
-    if (!segs || !send_total || !recv_total) return fail(ctx, CHD_E_INVAL, "chd_shard_halo_layout: NULL output");
+static int shard_halo_layout_locked(chd_ctx *ctx, uint32_t rank, uint32_t world, chd_halo_seg *segs, uint64_t *send_total, uint64_t *recv_total) {
     const DevGrid &g = ctx->g;
-    if (!world || rank >= world) return fail(ctx, CHD_E_INVAL, "chd_shard_halo_layout: rank %u of %u", rank, world);
-    if (world != g.server_cols * g.server_rows)
-        return fail(ctx, CHD_E_INVAL, "chd_shard_halo_layout: %u ranks but the grid has %u server regions", world, g.server_cols * g.server_rows);
-    std::lock_guard<FairMutex> lk(ctx->mu);
     TRY(bind(ctx));
     World &W = ctx->w;
     const uint32_t halo = g.border, region = g.sgc * g.sgr, N = W.d.N;
@@ -2132,6 +2138,17 @@ int chd_shard_halo_layout(chd_ctx *ctx, uint32_t rank, uint32_t world, chd_halo_
     return CHD_OK;
 }
 
+int chd_shard_halo_layout(chd_ctx *ctx, uint32_t rank, uint32_t world, chd_halo_seg *segs, uint64_t *send_total, uint64_t *recv_total) {
+    NEED_WORLD();
+    if (!segs || !send_total || !recv_total) return fail(ctx, CHD_E_INVAL, "chd_shard_halo_layout: NULL output");
+    const DevGrid &g = ctx->g;
+    if (!world || rank >= world) return fail(ctx, CHD_E_INVAL, "chd_shard_halo_layout: rank %u of %u", rank, world);
+    if (world != g.server_cols * g.server_rows)
+        return fail(ctx, CHD_E_INVAL, "chd_shard_halo_layout: %u ranks but the grid has %u server regions", world, g.server_cols * g.server_rows);
+    std::lock_guard<FairMutex> lk(ctx->mu);
+    return shard_halo_layout_locked(ctx, rank, world, segs, send_total, recv_total);
+}
+
 // Segment capacity of this tick's emigrant exchange.  Every rank must use the same value (the all-to-all's sizes), so it is a
 // pure function of a quantity every rank holds identically: the global maximum segment count of tick t - 2 (carried in the
 // segment headers, k_export_finish / k_import).  Four times that maximum plus a floor, as a power of two; the caller's `cap`
@@ -2147,17 +2164,8 @@ static uint32_t migrate_cap_for(World &W, uint32_t cur_tick, uint32_t cap_max) {
     return (uint32_t)std::min<uint64_t>(c, cap_max);
 }
 
-int chd_shard_ingest(chd_ctx *ctx, int64_t now_ns, const double *d_x_by_chan, const double *d_z_by_chan,
-                     const uint8_t *d_has_update, uint32_t n_chan, uint32_t rank, uint32_t world,
-                     chd_entity_state *d_send, uint32_t cap, uint32_t *cap_used) {
-    NEED_WORLD();
-    if (n_chan && (!d_x_by_chan || !d_z_by_chan)) return fail(ctx, CHD_E_INVAL, "chd_shard_ingest: NULL positions");
-    if (!world || rank >= world) return fail(ctx, CHD_E_INVAL, "chd_shard_ingest: rank %u of %u", rank, world);
-    if (world != ctx->g.server_cols * ctx->g.server_rows)
-        return fail(ctx, CHD_E_INVAL, "chd_shard_ingest: %u ranks but the grid has %u server regions", world,
-                    ctx->g.server_cols * ctx->g.server_rows);
-    if (world > 1 && (!d_send || !cap)) return fail(ctx, CHD_E_INVAL, "chd_shard_ingest: NULL send buffer");
-    std::lock_guard<FairMutex> lk(ctx->mu);
+static int shard_ingest_locked(chd_ctx *ctx, int64_t now_ns, const double *d_x_by_chan, const double *d_z_by_chan, const uint8_t *d_has_update, uint32_t n_chan,
+                               uint32_t rank, uint32_t world, chd_entity_state *d_send, uint32_t cap, uint32_t *cap_used) {
     if (ctx->w.slot_mode == 1) return fail(ctx, CHD_E_STATE, "chd_shard_ingest on a world with caller-chosen slots");
     ctx->w.slot_mode = 2;
     TRY(bind(ctx));
@@ -2174,10 +2182,21 @@ int chd_shard_ingest(chd_ctx *ctx, int64_t now_ns, const double *d_x_by_chan, co
     return CHD_OK;
 }
 
-int chd_shard_import(chd_ctx *ctx, const chd_entity_state *d_recv, uint32_t world, uint32_t cap, void *d_halo_send) {
+int chd_shard_ingest(chd_ctx *ctx, int64_t now_ns, const double *d_x_by_chan, const double *d_z_by_chan,
+                     const uint8_t *d_has_update, uint32_t n_chan, uint32_t rank, uint32_t world,
+                     chd_entity_state *d_send, uint32_t cap, uint32_t *cap_used) {
     NEED_WORLD();
-    if (world > 1 && !d_recv) return fail(ctx, CHD_E_INVAL, "chd_shard_import: NULL receive buffer");
+    if (n_chan && (!d_x_by_chan || !d_z_by_chan)) return fail(ctx, CHD_E_INVAL, "chd_shard_ingest: NULL positions");
+    if (!world || rank >= world) return fail(ctx, CHD_E_INVAL, "chd_shard_ingest: rank %u of %u", rank, world);
+    if (world != ctx->g.server_cols * ctx->g.server_rows)
+        return fail(ctx, CHD_E_INVAL, "chd_shard_ingest: %u ranks but the grid has %u server regions", world,
+                    ctx->g.server_cols * ctx->g.server_rows);
+    if (world > 1 && (!d_send || !cap)) return fail(ctx, CHD_E_INVAL, "chd_shard_ingest: NULL send buffer");
     std::lock_guard<FairMutex> lk(ctx->mu);
+    return shard_ingest_locked(ctx, now_ns, d_x_by_chan, d_z_by_chan, d_has_update, n_chan, rank, world, d_send, cap, cap_used);
+}
+
+static int shard_import_locked(chd_ctx *ctx, const chd_entity_state *d_recv, uint32_t world, uint32_t cap, void *d_halo_send) {
     if (ctx->w.slot_mode != 2) return fail(ctx, CHD_E_STATE, "chd_shard_import before chd_shard_ingest");
     World &W = ctx->w;
     if (world > 1 && (W.halo_world != world || !d_halo_send)) return fail(ctx, CHD_E_STATE, "chd_shard_import: call chd_shard_halo_layout(rank, world) first and pass the halo send buffer");
@@ -2203,10 +2222,14 @@ int chd_shard_import(chd_ctx *ctx, const chd_entity_state *d_recv, uint32_t worl
     return CHD_OK;
 }
 
-int chd_shard_interest(chd_ctx *ctx, const chd_tick_in *d_in) {
+int chd_shard_import(chd_ctx *ctx, const chd_entity_state *d_recv, uint32_t world, uint32_t cap, void *d_halo_send) {
     NEED_WORLD();
-    if (!d_in) return fail(ctx, CHD_E_INVAL, "chd_shard_interest: NULL input");
+    if (world > 1 && !d_recv) return fail(ctx, CHD_E_INVAL, "chd_shard_import: NULL receive buffer");
     std::lock_guard<FairMutex> lk(ctx->mu);
+    return shard_import_locked(ctx, d_recv, world, cap, d_halo_send);
+}
+
+static int shard_interest_locked(chd_ctx *ctx, const chd_tick_in *d_in) {
     if (ctx->w.slot_mode != 2) return fail(ctx, CHD_E_STATE, "chd_shard_interest before chd_shard_ingest");
     TRY(bind(ctx));
     TRY(check_queries(ctx, d_in));
@@ -2217,12 +2240,14 @@ int chd_shard_interest(chd_ctx *ctx, const chd_tick_in *d_in) {
     return CHD_OK;
 }
 
-int chd_shard_fanout(chd_ctx *ctx, const void *d_halo_recv, uint32_t world, const chd_tick_in *d_in) {
+int chd_shard_interest(chd_ctx *ctx, const chd_tick_in *d_in) {
     NEED_WORLD();
-    if (!d_in) return fail(ctx, CHD_E_INVAL, "chd_shard_fanout: NULL input");
-    if (!world) return fail(ctx, CHD_E_INVAL, "chd_shard_fanout: world = 0");
-    if (world > 1 && !d_halo_recv) return fail(ctx, CHD_E_INVAL, "chd_shard_fanout: NULL halo receive buffer");
+    if (!d_in) return fail(ctx, CHD_E_INVAL, "chd_shard_interest: NULL input");
     std::lock_guard<FairMutex> lk(ctx->mu);
+    return shard_interest_locked(ctx, d_in);
+}
+
+static int shard_fanout_locked(chd_ctx *ctx, const void *d_halo_recv, uint32_t world, const chd_tick_in *d_in) {
     if (ctx->w.slot_mode != 2) return fail(ctx, CHD_E_STATE, "chd_shard_fanout before chd_shard_ingest");
     TRY(bind(ctx));
     TRY(check_queries(ctx, d_in));
@@ -2264,6 +2289,173 @@ int chd_shard_fanout(chd_ctx *ctx, const void *d_halo_recv, uint32_t world, cons
     TRY(after_launch(ctx));
     if (d_in->n_queries) W.last_nq = d_in->n_queries;
     W.ticked = true;
+    return CHD_OK;
+}
+
+int chd_shard_fanout(chd_ctx *ctx, const void *d_halo_recv, uint32_t world, const chd_tick_in *d_in) {
+    NEED_WORLD();
+    if (!d_in) return fail(ctx, CHD_E_INVAL, "chd_shard_fanout: NULL input");
+    if (!world) return fail(ctx, CHD_E_INVAL, "chd_shard_fanout: world = 0");
+    if (world > 1 && !d_halo_recv) return fail(ctx, CHD_E_INVAL, "chd_shard_fanout: NULL halo receive buffer");
+    std::lock_guard<FairMutex> lk(ctx->mu);
+    return shard_fanout_locked(ctx, d_halo_recv, world, d_in);
+}
+
+// ---- native collectives: RCCL inside the library (include/chd_spatial.h: chd_shard_comm_*) ----
+namespace {
+struct Rccl {
+    void *so = nullptr;
+    ncclResult_t (*GetUniqueId)(ncclUniqueId *) = nullptr;
+    ncclResult_t (*CommInitRank)(ncclComm_t *, int, ncclUniqueId, int) = nullptr;
+    ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    ncclResult_t (*GroupStart)() = nullptr;
+    ncclResult_t (*GroupEnd)() = nullptr;
+    ncclResult_t (*Send)(const void *, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*Recv)(void *, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+    const char *(*GetErrorString)(ncclResult_t) = nullptr;
+};
+Rccl g_rccl;
+std::mutex g_rccl_mu;
+
+// librccl.so, loaded on first use: CHD_RCCL_LIB, else the soname as the process already has it (a host that also runs
+// torch.distributed has loaded its copy) or as the loader finds it, else ROCm's own
+int rccl_load(chd_ctx *ctx) {
+    std::lock_guard<std::mutex> lk(g_rccl_mu);
+    if (g_rccl.so) return CHD_OK;
+    const char *names[] = {getenv("CHD_RCCL_LIB"), "librccl.so", "librccl.so.1", "/opt/rocm/lib/librccl.so"};
+    void *so = nullptr;
+    for (const char *n : names)
+        if (n && n[0] && (so = dlopen(n, RTLD_NOW | RTLD_GLOBAL))) break;
+    if (!so) return fail(ctx, CHD_E_STATE, "chd_shard_comm: librccl.so not found (%s)", dlerror());
+    Rccl r;
+    r.so = so;
+#define SYM(field, name) if (!(*(void **)(&r.field) = dlsym(so, name))) return fail(ctx, CHD_E_STATE, "chd_shard_comm: librccl.so lacks %s", name)
+    SYM(GetUniqueId, "ncclGetUniqueId"); SYM(CommInitRank, "ncclCommInitRank"); SYM(CommDestroy, "ncclCommDestroy");
+    SYM(GroupStart, "ncclGroupStart"); SYM(GroupEnd, "ncclGroupEnd"); SYM(Send, "ncclSend"); SYM(Recv, "ncclRecv");
+    SYM(GetErrorString, "ncclGetErrorString");
+#undef SYM
+    g_rccl = r;
+    return CHD_OK;
+}
+#define NCCLCHK(call)                                                                                                   \
+    do {                                                                                                                \
+        ncclResult_t _r = (call);                                                                                       \
+        if (_r != ncclSuccess) return fail(ctx, CHD_E_HIP, "%s failed: %s (%s:%d)", #call, g_rccl.GetErrorString(_r), __FILE__, __LINE__); \
+    } while (0)
+}  // namespace
+
+int chd_shard_comm_unique_id(void *id_out) {
+    if (!id_out) return fail(nullptr, CHD_E_INVAL, "chd_shard_comm_unique_id: NULL output");
+    chd_ctx *ctx = nullptr;
+    TRY(rccl_load(ctx));
+    static_assert(sizeof(ncclUniqueId) == CHD_COMM_ID_BYTES, "CHD_COMM_ID_BYTES is RCCL's NCCL_UNIQUE_ID_BYTES");
+    ncclUniqueId id;
+    NCCLCHK(g_rccl.GetUniqueId(&id));
+    memcpy(id_out, &id, sizeof id);
+    return CHD_OK;
+}
+
+int chd_shard_comm_init(chd_ctx *ctx, const void *unique_id, uint32_t rank, uint32_t world, uint32_t migrate_cap) {
+    NEED_WORLD();
+    if (!unique_id) return fail(ctx, CHD_E_INVAL, "chd_shard_comm_init: NULL unique id");
+    if (!world || rank >= world || !migrate_cap) return fail(ctx, CHD_E_INVAL, "chd_shard_comm_init: rank %u of %u, capacity %u", rank, world, migrate_cap);
+    if (world != ctx->g.server_cols * ctx->g.server_rows)
+        return fail(ctx, CHD_E_INVAL, "chd_shard_comm_init: %u ranks but the grid has %u server regions", world, ctx->g.server_cols * ctx->g.server_rows);
+    TRY(rccl_load(ctx));
+    std::lock_guard<FairMutex> lk(ctx->mu);
+    TRY(bind(ctx));
+    World &W = ctx->w;
+    if (W.comm) return fail(ctx, CHD_E_STATE, "chd_shard_comm_init: the ctx already has a communicator");
+    if (W.slot_mode == 1) return fail(ctx, CHD_E_STATE, "chd_shard_comm_init on a world with caller-chosen slots (chd_world_spawn)");
+    // this rank's halo layout (installs it) and the exchange buffers: the library owns them
+    W.halo_segs.assign(world, chd_halo_seg{0, 0, 0, 0});
+    uint64_t st = 0, rt = 0;
+    TRY(shard_halo_layout_locked(ctx, rank, world, W.halo_segs.data(), &st, &rt));
+    const size_t seg = (size_t)migrate_cap + 1;
+    TRY(walloc(ctx, &W.mig_send, (size_t)world * seg));
+    TRY(walloc(ctx, &W.mig_recv, (size_t)world * seg));
+    TRY(walloc(ctx, &W.halo_send_buf, std::max<uint64_t>(st, 16)));
+    TRY(walloc(ctx, &W.halo_recv_buf, std::max<uint64_t>(rt, 16)));
+    HIPCHK(hipStreamCreateWithFlags(&W.comm_stream, hipStreamNonBlocking));
+    HIPCHK(hipEventCreateWithFlags(&W.ev_halo_ready, hipEventDisableTiming));
+    HIPCHK(hipEventCreateWithFlags(&W.ev_halo_done, hipEventDisableTiming));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    ncclUniqueId id;
+    memcpy(&id, unique_id, sizeof id);
+    NCCLCHK(g_rccl.CommInitRank(&W.comm, (int)world, id, (int)rank));
+    W.comm_rank = rank;
+    W.comm_world = world;
+    W.comm_cap = migrate_cap;
+    return CHD_OK;
+}
+
+int chd_shard_comm_destroy(chd_ctx *ctx) {
+    if (!ctx) return fail(nullptr, CHD_E_INVAL, "NULL ctx");
+    std::lock_guard<FairMutex> lk(ctx->mu);
+    World &W = ctx->w;
+    if (!W.comm) return CHD_OK;
+    TRY(bind(ctx));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    HIPCHK(hipStreamSynchronize(W.comm_stream));
+    NCCLCHK(g_rccl.CommDestroy(W.comm));
+    W.comm = nullptr;
+    (void)hipStreamDestroy(W.comm_stream);
+    W.comm_stream = nullptr;
+    (void)hipEventDestroy(W.ev_halo_ready);
+    (void)hipEventDestroy(W.ev_halo_done);
+    return CHD_OK;
+}
+
+// One tick of a region-sharded world with both exchanges inside: no host code between the stages, everything ordered by
+// streams and events.  ctx stream: ingest + export -> all-to-all of the emigrants (ncclSend / ncclRecv group, equal segments of
+// this tick's capacity) -> import + cell index + halo pack -> [event] -> interest updates -> [wait] -> fan-out; the halo
+// all-to-all(v) runs on the library's second stream between the two events, beside the interest updates (which do not read the
+// neighbours' tables).
+int chd_shard_tick(chd_ctx *ctx, int64_t now_ns, const double *d_x_by_chan, const double *d_z_by_chan, const uint8_t *d_has_update,
+                   uint32_t n_chan, const chd_tick_in *d_in) {
+    NEED_WORLD();
+    if (!d_in) return fail(ctx, CHD_E_INVAL, "chd_shard_tick: NULL input");
+    if (n_chan && (!d_x_by_chan || !d_z_by_chan)) return fail(ctx, CHD_E_INVAL, "chd_shard_tick: NULL positions");
+    std::lock_guard<FairMutex> lk(ctx->mu);
+    World &W = ctx->w;
+    if (!W.comm) return fail(ctx, CHD_E_STATE, "chd_shard_tick before chd_shard_comm_init");
+    const uint32_t world = W.comm_world, rank = W.comm_rank;
+    hipStream_t st = ctx->stream;
+    uint32_t use = W.comm_cap;
+    TRY(shard_ingest_locked(ctx, now_ns, d_x_by_chan, d_z_by_chan, d_has_update, n_chan, rank, world, W.mig_send, W.comm_cap, &use));
+    const size_t seg = (size_t)use + 1;
+    {   // the cross-server handovers (spatial.go:683-700): every rank's segment for every other rank, 32 B per emigrant.
+        // (One rank: its own segment to itself — nothing to move, but the tick keeps its shape and the transport is exercised.)
+        NCCLCHK(g_rccl.GroupStart());
+        for (uint32_t p = 0; p < world; p++) {
+            NCCLCHK(g_rccl.Send(W.mig_send + p * seg, seg * sizeof(chd_entity_state), ncclUint8, (int)p, W.comm, st));
+            NCCLCHK(g_rccl.Recv(W.mig_recv + p * seg, seg * sizeof(chd_entity_state), ncclUint8, (int)p, W.comm, st));
+        }
+        NCCLCHK(g_rccl.GroupEnd());
+    }
+    TRY(shard_import_locked(ctx, W.mig_recv, world, use, W.halo_send_buf));
+    bool halo = false;
+    for (uint32_t p = 0; p < world; p++) halo = halo || W.halo_segs[p].send_bytes || W.halo_segs[p].recv_bytes;
+    if (halo) {
+        HIPCHK(hipEventRecord(W.ev_halo_ready, st));
+        HIPCHK(hipStreamWaitEvent(W.comm_stream, W.ev_halo_ready, 0));
+        NCCLCHK(g_rccl.GroupStart());
+        for (uint32_t p = 0; p < world; p++) {
+            const chd_halo_seg &h = W.halo_segs[p];
+            if (h.send_bytes) NCCLCHK(g_rccl.Send(W.halo_send_buf + h.send_off, h.send_bytes, ncclUint8, (int)p, W.comm, W.comm_stream));
+            if (h.recv_bytes) NCCLCHK(g_rccl.Recv(W.halo_recv_buf + h.recv_off, h.recv_bytes, ncclUint8, (int)p, W.comm, W.comm_stream));
+        }
+        NCCLCHK(g_rccl.GroupEnd());
+        HIPCHK(hipEventRecord(W.ev_halo_done, W.comm_stream));
+    }
+    TRY(shard_interest_locked(ctx, d_in));
+    if (halo) HIPCHK(hipStreamWaitEvent(st, W.ev_halo_done, 0));
+    chd_tick_in rest = *d_in;
+    rest.n_queries = 0;  // (the interest updates ran above)
+    rest.queries = nullptr;
+    const uint32_t nq = d_in->n_queries;
+    TRY(shard_fanout_locked(ctx, W.halo_recv_buf, world, &rest));
+    W.last_nq = nq;
     return CHD_OK;
 }
 

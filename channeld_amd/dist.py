@@ -274,6 +274,37 @@ class HipShardEngine:
         self._r_interest, self._r_fanout = C.byref(self._ti_interest), C.byref(self._ti_fanout)
         self.cap_now = self.cap  # capacity this tick's exchange uses
         self.cap_seen = []       # (adaptive) every capacity used so far
+        self.native = False      # chd_shard_comm_init has run: the exchanges happen inside the library (tick_native)
+        self._ti_native = _lib.TickIn()
+        self._r_native = C.byref(self._ti_native)
+
+    def comm_init_native(self, comm: "Comm"):
+        """The library's own communicator (include/chd_spatial.h: chd_shard_comm_*): rank 0 draws the RCCL unique id, the
+        ranks' existing control channel — here torch.distributed, in a gateway its own connection between the gateways — carries
+        the 128 bytes, every rank joins.  From then on a tick is ONE C call (tick_native): no Python, no torch between the stages."""
+        ident = (C.c_uint8 * 128)()
+        if self.rank == 0:
+            self._lib.check(self.ctx, self.lib.chd_shard_comm_unique_id(ident))
+        if comm.active:
+            box = [bytes(ident)]
+            comm.dist.broadcast_object_list(box, src=0)
+            ident = (C.c_uint8 * 128).from_buffer_copy(box[0])
+        self._lib.check(self.ctx, self.lib.chd_shard_comm_init(self.ctx, ident, self.rank, self.world, self.cap))
+        self.native = True
+
+    def tick_native(self, now_ns: int, x_by_chan, z_by_chan, queries=None, n_queries: int = 0, has_update=None):
+        ti = self._ti_native
+        if queries is not None and n_queries:
+            ti.n_queries, ti.queries = int(n_queries), queries.data_ptr()
+        else:
+            ti.n_queries, ti.queries = 0, None
+        self._queries = queries
+        hp = C.c_void_p(has_update.data_ptr()) if has_update is not None else None
+        rc = self.lib.chd_shard_tick(self.ctx, int(now_ns), C.c_void_p(x_by_chan.data_ptr()), C.c_void_p(z_by_chan.data_ptr()), hp,
+                                     int(x_by_chan.numel()), self._r_native)
+        if rc:
+            self._lib.check(self.ctx, rc)
+        self.sw._last_nq = int(n_queries)
 
     def _layout(self, rank):
         segs = (self._lib.HaloSeg * self.world)()
@@ -359,6 +390,9 @@ class ShardedWorld:
 
     def tick(self, now_ns: int, x_by_chan, z_by_chan, queries=None, n_queries: int = 0, has_update=None):
         eng, comm = self.engine, self.comm
+        if getattr(eng, "native", False):  # the library's own RCCL communicator: the whole tick is one C call
+            eng.tick_native(now_ns, x_by_chan, z_by_chan, queries, n_queries, has_update)
+            return
         send = eng.ingest(now_ns, x_by_chan, z_by_chan, has_update)
         recv = comm.all_to_all(send) if comm.active else None
         halo_send = eng.import_(recv)
@@ -496,6 +530,10 @@ def run_bench(args, rank: int, world: int, local_rank: int, verifier=None) -> di
                          max_records=int(getattr(args, "max_records", 0) or 0), adaptive_migrate=True)
     eng.spawn(sw.chan_id[mine], sw.x[mine], sw.z[mine], sw.flags[mine], sw.sender[mine])
     eng.add_subscribers(sw.sub_conn[my_subs])
+    # RCCL runs inside the library (chd_shard_comm_init / chd_shard_tick) whenever the ranks have a GPU each; host-staged
+    # transports (gloo: ranks sharing one GPU in the tests) keep the four-stage path around torch.distributed.  CHD_DIST_NATIVE=0: A/B
+    if comm.backend == "nccl" and os.environ.get("CHD_DIST_NATIVE", "1") != "0":
+        eng.comm_init_native(comm)
     world_obj = ShardedWorld(eng, comm)
 
     # the single world the first V ticks are checked against lives on rank 0's host cores (the checker, never the thing
@@ -593,6 +631,9 @@ def run_bench(args, rank: int, world: int, local_rank: int, verifier=None) -> di
         "config": {"workload": label, "config": getattr(args, "config", None) or "B-weak", "aoi_scale": aoi_scale,
                    "grid": f"{cfg['GridCols']}x{cfg['GridRows']} cells of {int(cfg['GridWidth'])}, {sc}x{sr} server regions",
                    "tick_ms": args.tick_ms, "msgs_per_tick": msgs / K, "cross_rank_and_local_handovers_per_tick": handovers / K,
+                   "collectives_driver": ("native: RCCL inside libchd_spatial.so (chd_shard_comm_init + chd_shard_tick: ncclSend / ncclRecv groups on the ctx "
+                                          "stream and a second stream, no host code between the stages)" if eng.native else
+                                          "python: torch.distributed around the four chd_shard_* stages (host-staged transport)"),
                    "exchange": "all-to-all of emigrant states (32 B each; segment capacity adapted to 4x the largest count of two ticks ago: "
                                f"{eng.cap_now} records per peer now, {eng.cap} at start) + all-to-all(v) of the border bands of the cell tables "
                                f"({cfg['ServerInterestBorderSize']} cells wide: {sum(eng.send_splits)} bytes sent per rank and tick) per tick",

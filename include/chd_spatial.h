@@ -597,6 +597,27 @@ int chd_shard_interest(chd_ctx *ctx, const chd_tick_in *d_in);
  * are ignored) and the fan-out of this rank's connections over region + halo.  Outputs as chd_tick_device. */
 int chd_shard_fanout(chd_ctx *ctx, const void *d_halo_recv, uint32_t world, const chd_tick_in *d_in);
 
+/* ---- Native collectives: the two exchanges inside the library, on RCCL over xGMI (librccl.so, dlopen'ed here: a single-GPU
+ * gateway never loads it).  replaces: the transport of the cross-server handover (spatial.go:683-700: the reference sends the
+ * handover data to the destination spatial server's connection) and of the border subscriptions (spatial.go:481-590), which in
+ * the reference are TCP/KCP messages between the gateway and the spatial servers.  A Go host calls
+ *     rank 0:  chd_shard_comm_unique_id(id)            -> ships the 128 bytes to the other gateways over its own control channel
+ *     all:     chd_shard_comm_init(ctx, id, rank, world, migrate_cap)   (collective: every rank must call it)
+ *     tick:    chd_shard_tick(ctx, now_ns, positions ..., d_in)         (collective)
+ * and nothing else: the exchange buffers are the library's.  migrate_cap = capacity of one emigrant segment (entities crossing
+ * to ONE other rank in one tick; the library shrinks it to the traffic as chd_shard_ingest's cap_used does).  Same results as
+ * the four chd_shard_* stages around caller-run collectives (channeld_amd/dist.py keeps that path for host-staged test
+ * transports); outputs as chd_tick_device (chd_tick_fetch, chd_tick_digest, ...). */
+#define CHD_COMM_ID_BYTES 128
+int chd_shard_comm_unique_id(void *id_out /* CHD_COMM_ID_BYTES */);
+int chd_shard_comm_init(chd_ctx *ctx, const void *unique_id, uint32_t rank, uint32_t world, uint32_t migrate_cap);
+int chd_shard_comm_destroy(chd_ctx *ctx);
+/* One tick: chd_shard_ingest -> all-to-all(emigrants) -> chd_shard_import -> all-to-all(v)(halo) beside chd_shard_interest ->
+ * chd_shard_fanout, enqueued on the ctx stream (the halo exchange on a second stream of the library, joined by events) with no
+ * host synchronisation.  Arguments as chd_shard_ingest (positions by channel id) and chd_shard_fanout (d_in: the queries). */
+int chd_shard_tick(chd_ctx *ctx, int64_t now_ns, const double *d_x_by_chan, const double *d_z_by_chan, const uint8_t *d_has_update,
+                   uint32_t n_chan, const chd_tick_in *d_in);
+
 /* Live entities of this rank: channel ids and cell / member channel ids (0 = none).
  * Arrays have max_entities room; *n_out = count. */
 int chd_shard_get_entities(chd_ctx *ctx, uint32_t *chan_id, uint32_t *cell_channel,

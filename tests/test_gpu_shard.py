@@ -211,6 +211,14 @@ def test_rccl_single_rank_bench_path():
     # (tick 0 creates the subscriptions and fans nothing out yet; tick 1 carries the first, full-state fan-out)
     assert sharded["verified_ticks"] == 2 and sharded["verified"]["msgs_per_verified_tick"][1] > 0
     assert sharded["latency_ticks"] == 2 and sharded["collectives"]["ranks"] == 1
+    # the collectives run INSIDE the library (chd_shard_comm_init + chd_shard_tick: ncclSend / ncclRecv groups of
+    # librccl.so on the ctx stream), one C call per tick — and the four-stage path around torch.distributed gives the same ticks
+    assert sharded["config"]["collectives_driver"].startswith("native: RCCL inside libchd_spatial.so")
+    r = subprocess.run(cmd, env=dict(env, CHD_DIST_NATIVE="0"), capture_output=True, text=True, timeout=280, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-2000:]
+    staged = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert staged["config"]["collectives_driver"].startswith("python:") and staged["verified_ticks"] == 2
+    assert staged["config"]["msgs_per_tick"] == sharded["config"]["msgs_per_tick"]
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + common, capture_output=True, text=True, timeout=280, cwd=ROOT)
     assert r.returncode == 0, r.stderr[-2000:]
     single = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
