@@ -117,6 +117,7 @@ struct World {
     uint32_t *ho_rcp_off = nullptr;    // [handovers_cap + 1] recipients of handover h: [off[h], off[h+1])
     uint32_t *ho_rcp_conn = nullptr;   // connection ids
     uint8_t *ho_rcp_kind = nullptr;    // CHD_HO_*
+    uint32_t *ho_rcp_mask = nullptr;   // per recipient: which entities of its handover carry their entityData (chd_handover_recipients_ex)
     uint64_t ho_rcp_cap = 0;
 };
 
@@ -958,6 +959,8 @@ int chd_world_create(chd_ctx *ctx, const chd_world_cfg *cfg) {
         TRY(walloc(ctx, &W.ho_rcp_off, (size_t)d.handovers_cap + 1));
         TRY(walloc(ctx, &W.ho_rcp_conn, W.ho_rcp_cap, false));
         TRY(walloc(ctx, &W.ho_rcp_kind, W.ho_rcp_cap, false));
+        TRY(walloc(ctx, &W.ho_rcp_mask, W.ho_rcp_cap, false));
+        TRY(walloc(ctx, &d.ho_moved, d.handovers_cap));
     }
     // banked lists: a bank holds the worst case of the subscriber slots that map to it
     d.list_bank_cap = (uint32_t)std::min<size_t>((size_t)((S + CHD_LIST_BANKS - 1) / CHD_LIST_BANKS) * d.capq, 0x7FFFFFFFu / CHD_LIST_BANKS);
@@ -1599,7 +1602,7 @@ static int tick_locked(chd_ctx *ctx, const chd_tick_in *in) {
             // interest updates (the reference sends from Notify, spatial.go:776-857)
             launch_handover_recipients_count(bs, ctx->g, d, W.ho_rcp_off);
             launch_scan_u32_inplace_dev(bs, W.ho_rcp_off, d.handovers_cap, d.counters + CTR_HANDOVERS);
-            launch_handover_recipients_fill(bs, ctx->g, d, W.ho_rcp_off, W.ho_rcp_conn, W.ho_rcp_kind, W.ho_rcp_cap);
+            launch_handover_recipients_fill(bs, ctx->g, d, W.ho_rcp_off, W.ho_rcp_conn, W.ho_rcp_kind, W.ho_rcp_mask, W.ho_rcp_cap);
         }
         if (prof_stages) HIPCHK(hipEventRecord(ev[1], bs));
         launch_index_build(bs, ctx->g, d, r.cur_tick);
@@ -2577,7 +2580,7 @@ int chd_handover_messages(chd_ctx *ctx, uint32_t n_handovers, uint32_t *offsets,
         return fail(ctx, CHD_E_CAPACITY, "chd_handover_messages: the last tick had %u handovers, offsets has room for %u", nh, n_handovers);
     if (!nh) return CHD_OK;
     TRY(ensure(ctx, 0, sizeof(uint32_t) * (2 * (size_t)nh + 1)));
-    launch_handover_msg_sizes(ctx->stream, ctx->g, W.d, W.x, nh, sbuf<uint32_t>(ctx, 0));
+    launch_handover_msg_sizes(ctx->stream, ctx->g, W.d, W.x, 2 * nh, nullptr, nullptr, sbuf<uint32_t>(ctx, 0));
     launch_scan_u32_inplace(ctx->stream, sbuf<uint32_t>(ctx, 0), 2 * nh);
     TRY(after_launch(ctx));
     TRY(down(ctx, offsets, sbuf<void>(ctx, 0), sizeof(uint32_t) * (2 * (size_t)nh + 1)));
@@ -2586,7 +2589,46 @@ int chd_handover_messages(chd_ctx *ctx, uint32_t n_handovers, uint32_t *offsets,
     *n_out = total;
     if (total > cap) return fail(ctx, CHD_E_CAPACITY, "chd_handover_messages: %llu bytes, capacity %llu", (unsigned long long)total, (unsigned long long)cap);
     TRY(ensure(ctx, 1, std::max<uint64_t>(total, 16)));
-    launch_handover_msg_write(ctx->stream, ctx->g, W.d, W.x, nh, sbuf<uint32_t>(ctx, 0), sbuf<uint8_t>(ctx, 1), total);
+    launch_handover_msg_write(ctx->stream, ctx->g, W.d, W.x, 2 * nh, nullptr, nullptr, sbuf<uint32_t>(ctx, 0), sbuf<uint8_t>(ctx, 1), total);
+    TRY(after_launch(ctx));
+    TRY(down(ctx, bytes, sbuf<void>(ctx, 1), total));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    return CHD_OK;
+}
+
+int chd_handover_variants(chd_ctx *ctx, uint32_t n_var, const uint32_t *var_handover, const uint32_t *var_full_mask, uint32_t *offsets,
+                          uint8_t *bytes, uint64_t cap, uint64_t *n_out) {
+    NEED_WORLD();
+    if (!offsets || !n_out || (n_var && (!var_handover || !var_full_mask)) || (cap && !bytes)) return fail(ctx, CHD_E_INVAL, "chd_handover_variants: NULL buffer");
+    World &W = ctx->w;
+    std::lock_guard<FairMutex> lk(ctx->mu);
+    if (!W.wire) return fail(ctx, CHD_E_STATE, "the world was created without CHD_WORLD_WIRE");
+    if (!W.ticked) return fail(ctx, CHD_E_STATE, "no tick yet");
+    TRY(bind(ctx));
+    uint64_t ringrow[8];
+    TRY(down(ctx, ringrow, W.d.tick_ring + (size_t)(ctx->ring.cur_tick % TICK_RING) * 8, sizeof ringrow));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    const uint32_t nh = std::min<uint32_t>((uint32_t)ringrow[2], W.d.handovers_cap);
+    offsets[0] = 0;
+    *n_out = 0;
+    for (uint32_t v = 0; v < n_var; v++)
+        if (var_handover[v] >= nh) return fail(ctx, CHD_E_INVAL, "chd_handover_variants: variant %u names handover %u of %u", v, var_handover[v], nh);
+    if (!n_var) return CHD_OK;
+    TRY(ensure(ctx, 0, sizeof(uint32_t) * ((size_t)n_var + 1)));
+    TRY(ensure(ctx, 2, sizeof(uint32_t) * (size_t)n_var));
+    TRY(ensure(ctx, 3, sizeof(uint32_t) * (size_t)n_var));
+    TRY(up(ctx, sbuf<void>(ctx, 2), var_handover, sizeof(uint32_t) * (size_t)n_var));
+    TRY(up(ctx, sbuf<void>(ctx, 3), var_full_mask, sizeof(uint32_t) * (size_t)n_var));
+    launch_handover_msg_sizes(ctx->stream, ctx->g, W.d, W.x, n_var, sbuf<uint32_t>(ctx, 2), sbuf<uint32_t>(ctx, 3), sbuf<uint32_t>(ctx, 0));
+    launch_scan_u32_inplace(ctx->stream, sbuf<uint32_t>(ctx, 0), n_var);
+    TRY(after_launch(ctx));
+    TRY(down(ctx, offsets, sbuf<void>(ctx, 0), sizeof(uint32_t) * ((size_t)n_var + 1)));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    const uint64_t total = offsets[n_var];
+    *n_out = total;
+    if (total > cap) return fail(ctx, CHD_E_CAPACITY, "chd_handover_variants: %llu bytes, capacity %llu", (unsigned long long)total, (unsigned long long)cap);
+    TRY(ensure(ctx, 1, std::max<uint64_t>(total, 16)));
+    launch_handover_msg_write(ctx->stream, ctx->g, W.d, W.x, n_var, sbuf<uint32_t>(ctx, 2), sbuf<uint32_t>(ctx, 3), sbuf<uint32_t>(ctx, 0), sbuf<uint8_t>(ctx, 1), total);
     TRY(after_launch(ctx));
     TRY(down(ctx, bytes, sbuf<void>(ctx, 1), total));
     HIPCHK(hipStreamSynchronize(ctx->stream));
@@ -2721,6 +2763,10 @@ int chd_wire_fetch(chd_ctx *ctx, uint64_t *conn_off, uint32_t *conn_packets, uin
 }
 
 int chd_handover_recipients(chd_ctx *ctx, uint32_t *offsets, uint32_t *conn, uint8_t *kind, uint64_t cap, uint64_t *n_out) {
+    return chd_handover_recipients_ex(ctx, offsets, conn, kind, nullptr, cap, n_out);
+}
+
+int chd_handover_recipients_ex(chd_ctx *ctx, uint32_t *offsets, uint32_t *conn, uint8_t *kind, uint32_t *full_mask, uint64_t cap, uint64_t *n_out) {
     NEED_WORLD();
     if (!offsets || !n_out || (cap && (!conn || !kind))) return fail(ctx, CHD_E_INVAL, "chd_handover_recipients: NULL buffer");
     World &W = ctx->w;
@@ -2740,6 +2786,7 @@ int chd_handover_recipients(chd_ctx *ctx, uint32_t *offsets, uint32_t *conn, uin
     if (total > cap) return fail(ctx, CHD_E_CAPACITY, "handover recipients: %llu, capacity %llu", (unsigned long long)total, (unsigned long long)cap);
     TRY(down(ctx, conn, W.ho_rcp_conn, sizeof(uint32_t) * total));
     TRY(down(ctx, kind, W.ho_rcp_kind, total));
+    if (full_mask) TRY(down(ctx, full_mask, W.ho_rcp_mask, sizeof(uint32_t) * total));
     HIPCHK(hipStreamSynchronize(ctx->stream));
     return CHD_OK;
 }

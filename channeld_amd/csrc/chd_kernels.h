@@ -203,6 +203,11 @@ struct WorldDev {
     uint32_t *rec_pos;    // wire mode only (else nullptr): cell-table position of each record's entity, or CHD_POS_CELL | cell
     uint32_t *ce_slot;    // [N] entity slot of each cell-table entry (wire mode: payload lookup)
     chd_handover_rec *handovers; uint32_t handovers_cap;
+    // per handover record (worlds that plan recipients, else nullptr): bit q = entity q of the handover's entity list — the
+    // notifier alone, or the live members of its list / group in list order — was in src's entity map and moved with it
+    // (spatial.go:703-736); the others stayed where they were.  What chd_handover_recipients_ex needs to say, per member, whose
+    // entity channel a destination connection was already subscribed to (the subscribers of the cell that HELD the member).
+    uint32_t *ho_moved;
     // Unsub / new-sub lists are kept in CHD_LIST_BANKS banks (bank = subscriber slot & 63, list_bank_cap entries
     // each, one tail counter per bank on its own 128-B line): a single list tail is a same-address atomic for
     // every interest update in the tick, and those serialise at L2 (~5 ns each, 22 us per tick at 10K queries).
@@ -492,15 +497,18 @@ void launch_wire_conn_order(hipStream_t st, WorldDev w, WireDev x);
 void launch_wire_copy_img(hipStream_t st, WorldDev w, WireDev x, uint32_t waves);
 void launch_wire_layout(hipStream_t st, WorldDev w, WireDev x);
 // handover message assembly: sizes[2*nh] then, with off = exclusive scan of the sizes, the bytes
-void launch_handover_msg_sizes(hipStream_t st, DevGrid g, WorldDev w, WireDev x, uint32_t nh, uint32_t *sizes);
-void launch_handover_msg_write(hipStream_t st, DevGrid g, WorldDev w, WireDev x, uint32_t nh, const uint32_t *off, uint8_t *out, uint64_t cap);
+// blob b = handover var_h[b] with the entities of var_mask[b] carrying their entityData (var_h == nullptr: the two classic blobs
+// per handover, b >> 1 with none / all)
+void launch_handover_msg_sizes(hipStream_t st, DevGrid g, WorldDev w, WireDev x, uint32_t n_blobs, const uint32_t *var_h, const uint32_t *var_mask, uint32_t *sizes);
+void launch_handover_msg_write(hipStream_t st, DevGrid g, WorldDev w, WireDev x, uint32_t n_blobs, const uint32_t *var_h, const uint32_t *var_mask,
+                               const uint32_t *off, uint8_t *out, uint64_t cap);
 void launch_wire_copy(hipStream_t st, WorldDev w, WireDev x, uint32_t n_slow_conns);
 void launch_wire_set_payloads(hipStream_t st, WireDev x, int full, int cell, uint32_t n, uint32_t limit, const uint32_t *idx,
                               const uint32_t *lens, const uint64_t *off, const uint8_t *bytes, uint32_t ring_slot);
 // recipient planning (decision parts)
 void launch_handover_recipients_count(hipStream_t st, DevGrid g, WorldDev w, uint32_t *off);
 void launch_handover_recipients_fill(hipStream_t st, DevGrid g, WorldDev w, const uint32_t *off, uint32_t *conn,
-                                     uint8_t *kind, uint64_t cap);
+                                     uint8_t *kind, uint32_t *full_mask, uint64_t cap);
 void launch_adjacent_recipients(hipStream_t st, DevGrid g, WorldDev w, uint32_t n_req, const uint32_t *channel,
                                 const uint32_t *broadcast, const uint32_t *sender_conn, const uint32_t *client_conn,
                                 uint32_t *off, uint32_t *conns, uint64_t cap, int fill);

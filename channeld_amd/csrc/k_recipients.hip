@@ -47,9 +47,35 @@ __device__ __forceinline__ uint8_t handover_kind(const WorldDev &w, uint32_t s, 
     return in_src ? CHD_HO_SRC_ONLY : RCP_NONE;
 }
 
+// Which entities of handover h go out WITH their entityData to destination connection s: the reference decides it per
+// (connection, ENTITY) — `shouldSend` of SubscribeToChannel(entityCh) in the loop of spatial.go:797-857, i.e. the connection was
+// not yet subscribed to that entity's channel.  In the engine's model an entity channel's subscribers are the subscribers of the
+// cell whose entity map HELD the entity when Notify ran: src for the members that moved with the handover (ho_moved), the cell
+// that still holds them for the others.  Bit q = entity q of the handover's list (the order of chd_handover_messages).
+__device__ __forceinline__ uint32_t handover_full_mask(const WorldDev &w, uint32_t s, uint32_t h, uint32_t notifier, uint32_t src, bool in_src) {
+    const uint32_t moved = w.ho_moved ? w.ho_moved[h] : 1u;
+    const uint32_t gi = w.n_groups ? w.grp_of[notifier] : CHD_INVALID;
+    if (gi == CHD_INVALID) return in_src ? 0u : 1u;
+    uint32_t mask = 0, q = 0;
+    for (uint32_t k = w.grp_off[gi]; k < w.grp_off[gi + 1] && q < 32u; k++) {
+        const uint32_t m = w.grp_mem[k];
+        if (!(w.eflags[m] & EF_ALIVE)) continue;
+        bool known;
+        if ((moved >> q) & 1u) known = in_src;
+        else {
+            const uint32_t c = w.member[m];
+            known = c != CHD_INVALID && is_subscribed(w, s, c);
+        }
+        (void)src;
+        if (!known) mask |= 1u << q;
+        q++;
+    }
+    return mask;
+}
+
 // fill == 0: off[h] = number of recipients of handover h;  fill != 0: write them at off[h]
 __global__ void __launch_bounds__(256) k_handover_recipients(DevGrid g, WorldDev w, uint32_t *off, uint32_t *conn,
-                                                             uint8_t *kind, uint64_t cap, int fill) {
+                                                             uint8_t *kind, uint32_t *full_mask, uint64_t cap, int fill) {
     __shared__ uint32_t wcnt[4];
     const uint32_t n = min(w.counters[CTR_HANDOVERS], w.handovers_cap);
     for (uint32_t h = blockIdx.x; h < n; h += gridDim.x) {
@@ -64,6 +90,7 @@ __global__ void __launch_bounds__(256) k_handover_recipients(DevGrid g, WorldDev
             if (fill && k != RCP_NONE && pos < cap) {
                 conn[pos] = w.conn_id[s];
                 kind[pos] = k;
+                if (full_mask) full_mask[pos] = k == CHD_HO_SRC_ONLY ? 0u : handover_full_mask(w, s, h, r.entity, src, k == CHD_HO_DST_KNOWN);
             }
             run += total;
         }
@@ -73,13 +100,13 @@ __global__ void __launch_bounds__(256) k_handover_recipients(DevGrid g, WorldDev
 
 void launch_handover_recipients_count(hipStream_t st, DevGrid g, WorldDev w, uint32_t *off) {
     const unsigned grid = (unsigned)std::min<uint32_t>(w.handovers_cap ? w.handovers_cap : 1u, 2048u);
-    hipLaunchKernelGGL(k_handover_recipients, dim3(grid), dim3(256), 0, st, g, w, off, nullptr, nullptr, 0, 0);
+    hipLaunchKernelGGL(k_handover_recipients, dim3(grid), dim3(256), 0, st, g, w, off, nullptr, nullptr, nullptr, 0, 0);
 }
 
 void launch_handover_recipients_fill(hipStream_t st, DevGrid g, WorldDev w, const uint32_t *off, uint32_t *conn,
-                                     uint8_t *kind, uint64_t cap) {
+                                     uint8_t *kind, uint32_t *full_mask, uint64_t cap) {
     const unsigned grid = (unsigned)std::min<uint32_t>(w.handovers_cap ? w.handovers_cap : 1u, 2048u);
-    hipLaunchKernelGGL(k_handover_recipients, dim3(grid), dim3(256), 0, st, g, w, (uint32_t *)off, conn, kind, cap, 1);
+    hipLaunchKernelGGL(k_handover_recipients, dim3(grid), dim3(256), 0, st, g, w, (uint32_t *)off, conn, kind, full_mask, cap, 1);
 }
 
 __global__ void __launch_bounds__(256) k_adjacent_recipients(DevGrid g, WorldDev w, uint32_t n_req,

@@ -470,6 +470,7 @@ __device__ __forceinline__ void ingest_block(const DevGrid &g, const WorldDev &w
         if (!ho[j]) continue;
         const uint32_t i = ent[j];
         bool self_moves = true;
+        uint32_t moved = 1u, qa = 0;  // (WorldDev::ho_moved; no list: the notifier alone, entity 0 of its handover)
         if (w.n_groups) {
             // the whole handover group leaves src's entity map for dst's (spatial.go:703-736 run over handoverEntities):
             // members that are in src's map move; one that is elsewhere stays where it is (RemoveEntity(src) fails for
@@ -479,15 +480,22 @@ __device__ __forceinline__ void ingest_block(const DevGrid &g, const WorldDev &w
             const uint32_t gi = w.grp_of[i];
             if (gi != CHD_INVALID) {
                 if (w.grp_exact) self_moves = false;
+                moved = 0;
                 for (uint32_t q = w.grp_off[gi]; q < w.grp_off[gi + 1]; q++) {
                     const uint32_t m = w.grp_mem[q];
-                    if (m == i) self_moves = true;
-                    else if (w.eflags[m] & EF_ALIVE) atomicCAS(&w.member[m], src[j], dst[j]);
+                    bool mv = false;
+                    if (m == i) { self_moves = true; mv = true; }
+                    else if (w.eflags[m] & EF_ALIVE) mv = atomicCAS(&w.member[m], src[j], dst[j]) == src[j];
+                    if (m == i || (w.eflags[m] & EF_ALIVE)) {  // (position among the live members: the order the message lists them in)
+                        if (mv && qa < 32u) moved |= 1u << qa;
+                        qa++;
+                    }
                 }
             }
         }
         if (self_moves) w.member[i] = dst[j];
         uint32_t pos = s_cnt[wave * ING_ITEMS + j] + mask_rank(hm[j]);
+        if (pos < w.handovers_cap && w.ho_moved) w.ho_moved[pos] = moved;
         if (pos < w.handovers_cap) {
             chd_handover_rec r;
             r.entity = i;

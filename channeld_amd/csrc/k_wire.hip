@@ -875,11 +875,15 @@ __device__ __forceinline__ void ho_for_each_entity(const WorldDev &w, uint32_t n
 
 struct HoLayout { uint32_t sd_len, any_len, hom_len, mp_len, ctx; };
 
-__device__ __forceinline__ HoLayout ho_layout(const DevGrid &g, const WorldDev &w, const WireDev &x, const chd_handover_rec &r, bool full) {
+// fullmask: bit q = entity q of the list carries its entityData (entities beyond 31 follow bit 31)
+__device__ __forceinline__ bool ho_full(uint32_t fullmask, uint32_t q) { return (fullmask >> (q < 31u ? q : 31u)) & 1u; }
+
+__device__ __forceinline__ HoLayout ho_layout(const DevGrid &g, const WorldDev &w, const WireDev &x, const chd_handover_rec &r, uint32_t fullmask) {
     HoLayout L;
     L.sd_len = 0;
+    uint32_t q = 0;
     ho_for_each_entity(w, r.entity, [&](uint32_t m) {
-        const HoEnt e = ho_entity(w, x, m, full);
+        const HoEnt e = ho_entity(w, x, m, ho_full(fullmask, q++));
         L.sd_len += 1u + vlen(e.entry_len) + e.entry_len;  // SpatialChannelData.entities = 1
     });
     const uint32_t ul = x.url_len[2];
@@ -890,20 +894,23 @@ __device__ __forceinline__ HoLayout ho_layout(const DevGrid &g, const WorldDev &
     return L;
 }
 
-__global__ void __launch_bounds__(256) k_handover_msg_sizes(DevGrid g, WorldDev w, WireDev x, uint32_t nh, uint32_t *sizes) {
+__global__ void __launch_bounds__(256) k_handover_msg_sizes(DevGrid g, WorldDev w, WireDev x, uint32_t n_blobs, const uint32_t *__restrict__ var_h,
+                                                            const uint32_t *__restrict__ var_mask, uint32_t *sizes) {
     const uint32_t b = blockIdx.x * 256u + threadIdx.x;
-    if (b >= 2u * nh) return;
-    sizes[b] = ho_layout(g, w, x, w.handovers[b >> 1], (b & 1u) != 0).mp_len;
+    if (b >= n_blobs) return;
+    const uint32_t h = var_h ? var_h[b] : b >> 1, fullmask = var_h ? var_mask[b] : ((b & 1u) ? 0xFFFFFFFFu : 0u);
+    sizes[b] = ho_layout(g, w, x, w.handovers[h], fullmask).mp_len;
 }
 
-__global__ void __launch_bounds__(64) k_handover_msg_write(DevGrid g, WorldDev w, WireDev x, uint32_t nh, const uint32_t *__restrict__ off,
+__global__ void __launch_bounds__(64) k_handover_msg_write(DevGrid g, WorldDev w, WireDev x, uint32_t n_blobs, const uint32_t *__restrict__ var_h,
+                                                           const uint32_t *__restrict__ var_mask, const uint32_t *__restrict__ off,
                                                            uint8_t *__restrict__ out, uint64_t cap) {
     const uint32_t b = blockIdx.x;
-    if (b >= 2u * nh || off[b + 1] > cap) return;
+    if (b >= n_blobs || off[b + 1] > cap) return;
     const uint32_t lane = threadIdx.x;
-    const bool full = (b & 1u) != 0;
-    const chd_handover_rec r = w.handovers[b >> 1];
-    const HoLayout L = ho_layout(g, w, x, r, full);
+    const uint32_t fullmask = var_h ? var_mask[b] : ((b & 1u) ? 0xFFFFFFFFu : 0u);
+    const chd_handover_rec r = w.handovers[var_h ? var_h[b] : b >> 1];
+    const HoLayout L = ho_layout(g, w, x, r, fullmask);
     uint8_t *o = out + off[b];
     uint32_t n = 0;
     if (lane == 0) {
@@ -922,7 +929,9 @@ __global__ void __launch_bounds__(64) k_handover_msg_write(DevGrid g, WorldDev w
         if (L.sd_len) { o[n++] = 0x12; n = put_varint(o, n, L.sd_len); }  // Any.value = SpatialChannelData
     }
     n = (uint32_t)__shfl((int)n, 0);
+    uint32_t q = 0;
     ho_for_each_entity(w, r.entity, [&](uint32_t m) {
+        const bool full = ho_full(fullmask, q++);
         const HoEnt e = ho_entity(w, x, m, full);
         uint32_t k = n;
         if (lane == 0) {
@@ -945,13 +954,14 @@ __global__ void __launch_bounds__(64) k_handover_msg_write(DevGrid g, WorldDev w
     });
 }
 
-void launch_handover_msg_sizes(hipStream_t st, DevGrid g, WorldDev w, WireDev x, uint32_t nh, uint32_t *sizes) {
-    if (!nh) return;
-    hipLaunchKernelGGL(k_handover_msg_sizes, dim3((2 * nh + 255) / 256), dim3(256), 0, st, g, w, x, nh, sizes);
+void launch_handover_msg_sizes(hipStream_t st, DevGrid g, WorldDev w, WireDev x, uint32_t n_blobs, const uint32_t *var_h, const uint32_t *var_mask, uint32_t *sizes) {
+    if (!n_blobs) return;
+    hipLaunchKernelGGL(k_handover_msg_sizes, dim3((n_blobs + 255) / 256), dim3(256), 0, st, g, w, x, n_blobs, var_h, var_mask, sizes);
 }
-void launch_handover_msg_write(hipStream_t st, DevGrid g, WorldDev w, WireDev x, uint32_t nh, const uint32_t *off, uint8_t *out, uint64_t cap) {
-    if (!nh) return;
-    hipLaunchKernelGGL(k_handover_msg_write, dim3(2 * nh), dim3(64), 0, st, g, w, x, nh, off, out, cap);
+void launch_handover_msg_write(hipStream_t st, DevGrid g, WorldDev w, WireDev x, uint32_t n_blobs, const uint32_t *var_h, const uint32_t *var_mask,
+                               const uint32_t *off, uint8_t *out, uint64_t cap) {
+    if (!n_blobs) return;
+    hipLaunchKernelGGL(k_handover_msg_write, dim3(n_blobs), dim3(64), 0, st, g, w, x, n_blobs, var_h, var_mask, off, out, cap);
 }
 
 // payload upload: kind k, entry idx[i] <- lens[i] bytes at bytes + off[i]

@@ -598,6 +598,26 @@ class SpatialWorld:
         _lib.check(self.ctx, self.lib.chd_handover_recipients(self.ctx, _ptr(off), _ptr(conn), _ptr(kind), cap, C.byref(n)))
         return off, conn[: n.value], kind[: n.value]
 
+    def handover_recipients_ex(self, n_handovers: int):
+        """... with, per recipient, the mask of the handover's entities that go out WITH their entityData
+        (chd_handover_recipients_ex: `shouldSend` per (connection, entity), spatial.go:797-857): (offsets, conn ids, kinds, masks)."""
+        off = np.zeros(n_handovers + 1, dtype=np.uint32)
+        cap = max(n_handovers * self.S, 1)
+        conn, kind, mask = np.zeros(cap, dtype=np.uint32), np.zeros(cap, dtype=np.uint8), np.zeros(cap, dtype=np.uint32)
+        n = C.c_uint64(0)
+        _lib.check(self.ctx, self.lib.chd_handover_recipients_ex(self.ctx, _ptr(off), _ptr(conn), _ptr(kind), _ptr(mask), cap, C.byref(n)))
+        return off, conn[: n.value], kind[: n.value], mask[: n.value]
+
+    def handover_variants(self, handovers, full_masks, cap: int = 1 << 24):
+        """The MessagePack of every requested (handover, full mask) pair (chd_handover_variants): list of bytes."""
+        vh, vm = _u32(handovers), _u32(full_masks)
+        off = np.zeros(len(vh) + 1, dtype=np.uint32)
+        data = np.zeros(max(cap, 1), dtype=np.uint8)
+        n = C.c_uint64(0)
+        _lib.check(self.ctx, self.lib.chd_handover_variants(self.ctx, len(vh), _ptr(vh), _ptr(vm), _ptr(off), _ptr(data), cap, C.byref(n)))
+        b = data[: n.value].tobytes()
+        return [b[int(off[v]):int(off[v + 1])] for v in range(len(vh))]
+
     def adjacent_recipients(self, channel, broadcast, sender_conn, client_conn):
         """BroadcastType_ADJACENT_CHANNELS (message.go:188-239): CSR of de-duplicated connection ids per request."""
         ch, bc, sn, cl = _u32(channel), _u32(broadcast), _u32(sender_conn), _u32(client_conn)

@@ -642,6 +642,18 @@ int chd_shard_get_entities(chd_ctx *ctx, uint32_t *chan_id, uint32_t *cell_chann
 #define CHD_HO_DST_KNOWN 2 /* in dst and in src: already subscribed to the entity channel */
 int chd_handover_recipients(chd_ctx *ctx, uint32_t *offsets /* n_handovers+1 */, uint32_t *conn,
                             uint8_t *kind, uint64_t cap, uint64_t *n_out);
+/* The same, EXACT for handover groups.  The reference decides per (destination connection, ENTITY) whether the entity goes
+ * out with its entityData: `shouldSend` of conn.SubscribeToChannel(entityCh) inside the loop over handoverEntities
+ * (spatial.go:797-857) — the connection was not yet subscribed to THAT entity's channel.  A group's members may sit in different
+ * cells (only those in src's entity map move, :703-736), so a connection of dst can know some of them and not others.
+ * full_mask[i] (cap entries, parallel to conn / kind): bit q = entity q of the handover's entity list — the order
+ * chd_handover_messages / chd_handover_variants write them: the notifier alone, or the live members of its handover list / group
+ * in list order (first 32) — carries entityData for recipient i; 0 for CHD_HO_SRC_ONLY.  "Subscribed to the entity's channel"
+ * = subscribed to the cell whose entity map held the entity when Notify ran: src for the members that
+ * moved with this handover, the cell that still holds them for the others.  kind stays the single-entity classification of the
+ * NOTIFIER'S cell pair (DST_NEW <=> not in src). */
+int chd_handover_recipients_ex(chd_ctx *ctx, uint32_t *offsets /* n_handovers+1 */, uint32_t *conn, uint8_t *kind,
+                               uint32_t *full_mask, uint64_t cap, uint64_t *n_out);
 
 /* replaces: the connection merge of BroadcastType_ADJACENT_CHANNELS (message.go:188-239):
  * for request r the de-duplicated connections subscribed to spatial channel channel[r] or
@@ -731,12 +743,19 @@ int chd_wire_set_merge_schema(chd_ctx *ctx, int schema);
  * Exactness: the reference decides `fullData` per (dst connection, ENTITY) (spatial.go:797-857: shouldSend of that entity
  * channel's SubscribeToChannel); the two blobs are exact for single-entity handovers — every handover without groups —
  * and for group handovers whose dst connections know all members or none.  A dst connection already subscribed to SOME
- * members of a group gets a mixed message in the reference, which these two blobs cannot express: such a host assembles
- * that message itself from the per-entity payloads it handed to chd_wire_set_payloads.
+ * members of a group gets a mixed message in the reference: chd_handover_recipients_ex + chd_handover_variants below
+ * build exactly that one.
  * Needs CHD_WORLD_WIRE, the CHD_WIRE_ENTITY_OBJREF / CHD_WIRE_ENTITY_FULL payloads and the type url (and
  * CHD_WORLD_HANDOVER_RECIPIENTS for chd_handover_recipients, which says who gets which blob).  n_handovers = what the
  * caller sized `offsets` for: 2 * n_handovers + 1 entries; CHD_E_CAPACITY when the last tick had more handovers. */
 int chd_handover_messages(chd_ctx *ctx, uint32_t n_handovers, uint32_t *offsets, uint8_t *bytes, uint64_t cap, uint64_t *n_out);
+/* ... and the exact form: one MessagePack per requested VARIANT (handover index of the last tick, full mask as
+ * chd_handover_recipients_ex reports it) — the host asks for the distinct (handover, full_mask) pairs among a tick's
+ * recipients (one or two per handover; a group whose members sit in several cells a few more) and queues blob v for every
+ * recipient with that pair.  Variant v = bytes[offsets[v], offsets[v+1]).  replaces, byte for byte, what the loop of
+ * spatial.go:797-857 marshals per destination connection (handoverMerger.MergeTo(handoverDataMsg, shouldSend) per entity). */
+int chd_handover_variants(chd_ctx *ctx, uint32_t n_var, const uint32_t *var_handover, const uint32_t *var_full_mask,
+                          uint32_t *offsets /* n_var + 1 */, uint8_t *bytes, uint64_t cap, uint64_t *n_out);
 
 /* replaces, for every connection at once: queuedMessagePackSender.Send (connection.go:57-83:
  * MessagePack{ChannelId, MsgType: CHANNEL_DATA_UPDATE, MsgBody: ChannelDataUpdateMessage{Data}},

@@ -87,6 +87,11 @@ typedef struct orc_world {
     uint32_t *unsub_sub, *unsub_cell; uint32_t nunsub, capunsub;
     /* handover message recipients of the last tick (spatial.go:776-857) */
     uint32_t *rcp_ho, *rcp_conn; uint8_t *rcp_kind; uint64_t nrcp, caprcp;
+    /* per recipient: which entities of its handover go out WITH their entityData — `shouldSend` of SubscribeToChannel(entityCh)
+     * per (dst connection, entity), spatial.go:797-857; per handover (<= 32 entities each): the cell whose entity map held every
+     * handover entity when Notify ran (ho_ent_before[32 h + q], W_INVALID = none) and how many entities the handover has */
+    uint32_t *rcp_mask;
+    uint32_t *ho_ent_before, *ho_ent_n; uint32_t cap_ho_ent;
     int32_t *q_status; uint32_t nq_status;
     uint32_t n_locked_abort;
     uint64_t literal_mismatch;
@@ -178,7 +183,7 @@ orc_world *orc_world_new(const orc_grid *g, uint32_t n_entities, uint32_t n_subs
 static void orc__free_jobs(orc_world *w);
 
 void orc_world_free(orc_world *w) {
-    if (w) { free(w->rcp_ho); free(w->rcp_conn); free(w->rcp_kind); }
+    if (w) { free(w->rcp_ho); free(w->rcp_conn); free(w->rcp_kind); free(w->rcp_mask); free(w->ho_ent_before); free(w->ho_ent_n); }
     if (!w) return;
     for (uint32_t i = 0; i < w->N; i++) free(w->ebuf[i].v);
     for (uint32_t i = 0; i < w->C; i++) free(w->cbuf[i].v);
@@ -575,6 +580,29 @@ int orc_world_tick_arrivals(orc_world *w, orc_time t, uint32_t n_upd, const uint
         w->ho_dst[w->nho] = dst + w->g.id_start;
         w->ho_srv_src[w->nho] = w->server_of_cell[src];
         w->ho_srv_dst[w->nho] = w->server_of_cell[dst];
+        {   /* the handover's entity list, in the order the message carries it (GetHandoverEntities, entity.go:197-224: the
+             * notifier alone, or the live members of its list / group), and where each of them was held when Notify ran — the
+             * notifier itself is taken as held by src */
+            if (w->nho >= w->cap_ho_ent) {
+                w->cap_ho_ent = w->cap_ho_ent ? w->cap_ho_ent * 2 : 256;
+                w->ho_ent_before = (uint32_t *)realloc(w->ho_ent_before, 4 * 32 * (size_t)w->cap_ho_ent);
+                w->ho_ent_n = (uint32_t *)realloc(w->ho_ent_n, 4 * (size_t)w->cap_ho_ent);
+            }
+            uint32_t *bf = w->ho_ent_before + 32 * (size_t)w->nho, q = 0;
+            if (w->hl_has[i]) {
+                for (uint32_t k = 0; k < w->hl_n[i] && q < 32; k++) {
+                    uint32_t m = w->hl_mem[i][k];
+                    if (m == i) bf[q++] = src;
+                    else if (m < w->N && w->alive[m]) bf[q++] = w->member[m];
+                }
+            } else if (w->group[i]) {
+                for (uint32_t m = 0; m < w->N && q < 32; m++)
+                    if (w->alive[m] && w->group[m] == w->group[i]) bf[q++] = m == i ? src : w->member[m];
+            } else {
+                bf[q++] = src;
+            }
+            w->ho_ent_n[w->nho] = q;
+        }
         w->nho++;
         if (w->hl_has[i]) { /* RemoveEntity(src) + AddEntity(dst) over handoverEntities — the notifier only if it is one of them */
             for (uint32_t q = 0; q < w->hl_n[i]; q++) {
@@ -621,10 +649,24 @@ int orc_world_tick_arrivals(orc_world *w, orc_time t, uint32_t n_upd, const uint
                 w->rcp_ho = (uint32_t *)realloc(w->rcp_ho, 4 * w->caprcp);
                 w->rcp_conn = (uint32_t *)realloc(w->rcp_conn, 4 * w->caprcp);
                 w->rcp_kind = (uint8_t *)realloc(w->rcp_kind, w->caprcp);
+                w->rcp_mask = (uint32_t *)realloc(w->rcp_mask, 4 * w->caprcp);
             }
             w->rcp_ho[w->nrcp] = h;
             w->rcp_conn[w->nrcp] = w->conn_id[s];
             w->rcp_kind[w->nrcp] = (uint8_t)kind;
+            {   /* step 4-2 per entity: full data iff the connection was not yet subscribed to that entity's channel */
+                uint32_t mask = 0;
+                if (kind != 0)
+                    for (uint32_t q = 0; q < w->ho_ent_n[h]; q++) {
+                        uint32_t bc = w->ho_ent_before[32 * (size_t)h + q];
+                        int known = 0;
+                        if (bc != W_INVALID)
+                            for (uint32_t p = 0; p < w->pair_cnt[s]; p++)
+                                if (pp[p].cell == bc) { known = 1; break; }
+                        if (!known) mask |= 1u << q;
+                    }
+                w->rcp_mask[w->nrcp] = mask;
+            }
             w->nrcp++;
         }
     }
@@ -835,6 +877,7 @@ void orc_world_handovers(const orc_world *w, uint32_t *ent, uint32_t *src, uint3
     memcpy(srv_dst, w->ho_srv_dst, 4 * w->nho);
 }
 uint64_t orc_world_nrcp(const orc_world *w) { return w->nrcp; }
+void orc_world_recipient_masks(const orc_world *w, uint32_t *mask) { memcpy(mask, w->rcp_mask, 4 * w->nrcp); }
 void orc_world_recipients(const orc_world *w, uint32_t *ho, uint32_t *conn, uint8_t *kind) {
     memcpy(ho, w->rcp_ho, 4 * w->nrcp); memcpy(conn, w->rcp_conn, 4 * w->nrcp); memcpy(kind, w->rcp_kind, w->nrcp);
 }

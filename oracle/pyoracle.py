@@ -502,6 +502,16 @@ class World:
         lib().orc_world_unsubs(self.h, *[_p(v, C.c_uint32) for v in a])
         return a[0][:n], a[1][:n]
 
+    def recipient_masks(self):
+        """per recipient of recipients(): bit q = entity q of its handover's entity list goes out WITH its entityData
+        (`shouldSend` per (dst connection, entity), spatial.go:797-857)"""
+        n = int(lib().orc_world_nrcp(self.h))
+        m = np.zeros(max(n, 1), dtype=np.uint32)
+        f = lib().orc_world_recipient_masks
+        f.argtypes = [C.c_void_p, C.POINTER(C.c_uint32)]
+        f(self.h, _p(m, C.c_uint32))
+        return m[:n]
+
     def recipients(self):
         """(handover index, connection id, kind) of the last tick's handover messages."""
         n = int(lib().orc_world_nrcp(self.h))

@@ -81,6 +81,28 @@ def main():
     hom = Handover(srcChannelId=0x10001, dstChannelId=0x10002, data=data)
     out["group_pack"] = np.frombuffer(MessagePack(channelId=0x10002, msgType=12, msgBody=hom.SerializeToString(deterministic=True)).SerializeToString(), dtype=np.uint8)
     out["group_objrefs"] = np.array([ObjRef(netGUID=nid).SerializeToString() for nid in (0x80010, 0x80020)], dtype=object)
+    # ... and one handover list of five of whom the destination connection already knows two (members in a cell it is subscribed
+    # to): entityData for the other three only — what the per-(connection, entity) `shouldSend` of spatial.go:797-857 produces
+    sd = SpatialChannelData()
+    mixed_ids = [0x80100, 0x80101, 0x80102, 0x80103, 0x80104]
+    mixed_mask = 0b10110
+    mixed_any = []
+    for j, nid in enumerate(mixed_ids):
+        st = sd.entities[nid]
+        st.objRef.netGUID = nid
+        ea = AnyCls(type_url="type.googleapis.com/tpspb.EntityChannelData", value=bytes(rng.integers(0, 256, 20 + 7 * j, dtype=np.uint8)))
+        mixed_any.append(ea.SerializeToString())
+        if (mixed_mask >> j) & 1:
+            st.entityData.CopyFrom(ea)
+    data = AnyCls()
+    data.Pack(sd, type_url_prefix="type.googleapis.com/", deterministic=True)
+    hom = Handover(srcChannelId=0x10005, dstChannelId=0x10006, contextConnId=9, data=data)
+    out["mixed_pack"] = np.frombuffer(MessagePack(channelId=0x10006, msgType=12, msgBody=hom.SerializeToString(deterministic=True)).SerializeToString(), dtype=np.uint8)
+    out["mixed_mask"] = np.array([mixed_mask], dtype=np.uint32)
+    out["mixed_any_len"] = np.array([len(b) for b in mixed_any], dtype=np.uint32)
+    out["mixed_any_bytes"] = np.frombuffer(b"".join(mixed_any), dtype=np.uint8)
+    out["mixed_objref_len"] = np.array([len(ObjRef(netGUID=nid).SerializeToString()) for nid in mixed_ids], dtype=np.uint32)
+    out["mixed_objref_bytes"] = np.frombuffer(b"".join(ObjRef(netGUID=nid).SerializeToString() for nid in mixed_ids), dtype=np.uint8)
     for k, v in (("src", src), ("dst", dst), ("ctx", ctx), ("net", net), ("full", full)):
         out[k] = np.array(v, dtype=np.uint32)
     for k, v in (("objref", objrefs), ("any", anys), ("pack", packs)):

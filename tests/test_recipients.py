@@ -97,14 +97,17 @@ def run_recipients(amd, cfg, N, S, ticks, seed, flags=4, aoi_scale=1.0, capq=0):
         # ---- handover message recipients ----
         ent, src, dst, _, _ = ow.handovers()
         oh, oconn, okind = ow.recipients()
+        omask = ow.recipient_masks()
         off, conn, kind = gw.handover_recipients(len(res.handovers))
+        off2, conn2, kind2, mask = gw.handover_recipients_ex(len(res.handovers))
+        assert np.array_equal(off, off2) and np.array_equal(conn, conn2) and np.array_equal(kind, kind2)
         assert len(conn) == len(oconn), f"tick {k}: {len(conn)} recipients vs oracle {len(oconn)}"
         want = {}
-        for h, c, kd in zip(oh.tolist(), oconn.tolist(), okind.tolist()):
-            want.setdefault(int(ent[h]), []).append((c, kd))
+        for h, c, kd, mk in zip(oh.tolist(), oconn.tolist(), okind.tolist(), omask.tolist()):
+            want.setdefault(int(ent[h]), []).append((c, kd, mk))
         for h in range(len(res.handovers)):
             e = int(res.handovers["entity"][h])
-            got = list(zip(conn[off[h]:off[h + 1]].tolist(), kind[off[h]:off[h + 1]].tolist()))
+            got = list(zip(conn[off[h]:off[h + 1]].tolist(), kind[off[h]:off[h + 1]].tolist(), mask[off[h]:off[h + 1]].tolist()))
             assert got == want.get(e, []), f"tick {k}: recipients of the handover of entity {e}"
         n_rcp += len(conn)
         kinds.update(kind.tolist())
@@ -143,3 +146,87 @@ def test_gpu_recipients_large_grid_list_search(amd):
            "GridRows": 80, "ServerCols": 2, "ServerRows": 2, "ServerInterestBorderSize": 1}
     n_rcp, n_adj, kinds = run_recipients(amd, cfg, 3000, 200, 5, 0xC0FFEE33, aoi_scale=1.0, capq=256)
     assert n_rcp > 300 and kinds == {0, 1, 2}
+
+
+@pytest.mark.gpu
+def test_gpu_group_members_in_different_cells_get_mixed_handover_messages(amd):
+    """VERDICT r3 #5 (f2 exact for groups).  The reference decides `fullData` per (destination connection, ENTITY): the loop of
+    spatial.go:797-857 subscribes the connection to every handover entity's channel and merges that entity with full data iff
+    the subscription is new.  A handover list's members may sit in different cells (only those in src's entity map move,
+    spatial.go:703-736), so one destination connection can already know some of them.  Five-member lists scattered over the
+    grid: chd_handover_recipients_ex's per-recipient masks equal the oracle's, mixed masks occur, and chd_handover_variants
+    builds, for every distinct (handover, mask), the bytes oracle/wire.py composes from the per-entity decisions."""
+    import os
+
+    from oracle import wire
+
+    cfg = synth.load_config("spatial_static_4x4.json")
+    N, S = 400, 40
+    sw = synth.SynthWorld(synth.WorldSpec(cfg, N, S, 0xC0FFEE61, tick_ms=50, aoi_scale=0.35, outside_frac=0.0, locked_frac=0.0))
+    g = orc.grid_from_config(cfg)
+    ctl = amd.StaticGrid2DSpatialController()
+    assert ctl.LoadConfig(json.dumps(cfg).encode(), strict=False) is None
+    gw = amd.SpatialWorld(ctl, N, S, flags=1 | 4 | 8, max_records=1 << 21, wire_max_update_len=96, wire_max_full_len=256)
+    ow = orc.World(g, N, S, gw.capq, 20, 0)
+    ow.spawn(np.arange(N), sw.chan_id, sw.x, sw.z, sw.flags, sw.sender)
+    gw.spawn(None, sw.chan_id, sw.x, sw.z, sw.flags, sw.sender)
+    for s in range(S):
+        ow.add_sub(s, int(sw.sub_conn[s]))
+    gw.add_subscribers(None, sw.sub_conn)
+    # handover lists of five: entity 5k is the leader, its list = slots 5k .. 5k+4 wherever they are (every member of a list
+    # gets the same list, as GetHandoverEntities gives it)
+    n_lists = 40
+    list_off = np.arange(0, 5 * n_lists + 1, 5, dtype=np.uint32)
+    members = np.arange(5 * n_lists, dtype=np.uint32)
+    idx = np.arange(5 * n_lists, dtype=np.uint32)
+    gw.set_handover_lists(list_off, members, idx, idx // 5)
+    for i in range(5 * n_lists):
+        ow.set_handover_list(i, list(range(5 * (i // 5), 5 * (i // 5) + 5)))
+    rng = np.random.default_rng(61)
+    url = b"type.googleapis.com/unrealpb.SpatialChannelData"
+    gw.wire_set_type_url(2, url)
+    objref = {i: bytes(rng.integers(0, 256, int(rng.integers(1, 60)), dtype=np.uint8)) for i in range(N)}
+    full = {i: bytes(rng.integers(0, 256, int(rng.integers(10, 200)), dtype=np.uint8)) for i in range(N)}
+    gw.wire_set_payloads(4, list(objref), list(objref.values()))
+    gw.wire_set_payloads(1, list(full), list(full.values()))
+    mixed = variants = 0
+    for k in range(12):
+        sw.step()
+        jump = rng.random(N) < 0.08
+        sw.x = np.where(jump, np.float64(np.float32(sw.offx + rng.random(N) * sw.W * 0.999)), sw.x)
+        q = sw.queries()
+        ow.tick(sw.now_ns(), None, sw.x, sw.z, None, None, None, None, q)
+        res = gw.tick(sw.now_ns(), upd_x=sw.x, upd_z=sw.z, queries=q, records_cap=1 << 21)
+        nh = len(res.handovers)
+        ent, src, dst, _, _ = ow.handovers()
+        oh, oconn, okind = ow.recipients()
+        omask = ow.recipient_masks()
+        off, conn, kind, mask = gw.handover_recipients_ex(nh)
+        want = {}
+        for h, c, kd, mk in zip(oh.tolist(), oconn.tolist(), okind.tolist(), omask.tolist()):
+            want.setdefault(int(ent[h]), []).append((c, kd, mk))
+        pairs = set()
+        # (two members of ONE list handing over in the same tick move each other: which of the two Notify calls runs first is not
+        # defined in the reference either — one goroutine per entity channel — so those handovers are compared by recipients and
+        # kinds only)
+        per_list = np.bincount([int(e) // 5 for e in res.handovers["entity"] if int(e) < 5 * n_lists], minlength=n_lists)
+        for h in range(nh):
+            e = int(res.handovers["entity"][h])
+            got = list(zip(conn[off[h]:off[h + 1]].tolist(), kind[off[h]:off[h + 1]].tolist(), mask[off[h]:off[h + 1]].tolist()))
+            if e < 5 * n_lists and per_list[e // 5] > 1:
+                assert [t[:2] for t in got] == [t[:2] for t in want.get(e, [])], f"tick {k}: recipients of the handover of entity {e}"
+            else:
+                assert got == want.get(e, []), f"tick {k}: recipients of the handover of entity {e}"
+            pairs.update((h, m) for m in mask[off[h]:off[h + 1]].tolist())
+            nm = 5 if e < 5 * n_lists else 1
+            mixed += sum(1 for m in mask[off[h]:off[h + 1]].tolist() if 0 < m < (1 << nm) - 1)
+        pairs = sorted(pairs)
+        blobs = gw.handover_variants([p[0] for p in pairs], [p[1] for p in pairs])
+        for (h, m), blob in zip(pairs, blobs):
+            rec = res.handovers[h]
+            e = int(rec["entity"])
+            mem = list(range(5 * (e // 5), 5 * (e // 5) + 5)) if e < 5 * n_lists else [e]
+            entries = [(int(sw.chan_id[x]), wire.spatial_entity_state(objref[x], full[x] if (m >> j) & 1 else None)) for j, x in enumerate(mem)]
+            assert blob == wire.handover_message_pack(int(rec["src"]), int(rec["dst"]), 0, url, entries), (k, h, m)
+            variants += 1
+    assert mixed > 20 and variants > 100, (mixed, variants)

@@ -209,3 +209,12 @@ def test_handover_message_oracle_matches_the_reference_schema():
     # (the order of map entries on the wire is unspecified — Go's is random, python's is its hash order: either is the message)
     ents = [(0x80010, wire.spatial_entity_state(grefs[0])), (0x80020, wire.spatial_entity_state(grefs[1]))]
     assert g["group_pack"].tobytes() in (wire.handover_message_pack(0x10001, 0x10002, 0, url, ents), wire.handover_message_pack(0x10001, 0x10002, 0, url, ents[::-1]))
+    # a list of five of whom the destination connection already knows two: entityData for the other three only (the
+    # per-(connection, entity) decision of spatial.go:797-857; chd_handover_variants builds these)
+    mrefs, manys, mask = split("mixed_objref"), split("mixed_any"), int(g["mixed_mask"][0])
+    ents = [(0x80100 + j, wire.spatial_entity_state(mrefs[j], manys[j] if (mask >> j) & 1 else None)) for j in range(5)]
+    import itertools
+
+    # (map entries: any order is the message — python-protobuf wrote this one back to front)
+    assert any(g["mixed_pack"].tobytes() == wire.handover_message_pack(0x10005, 0x10006, 9, url, [ents[p] for p in perm])
+               for perm in itertools.permutations(range(5)))
