@@ -127,7 +127,10 @@ __device__ __forceinline__ bool history_lost(const TickRing &ring, int64_t oldes
 // k_fanout_emit_deep.  (A first fan-out sends full states and starts over at `now`: no window to evaluate.)
 __device__ __forceinline__ bool sub_is_deep(const WorldDev &w, const TickRing &ring, int64_t oldest, uint32_t fl, int64_t L, int64_t I,
                                             uint32_t c) {
-    return w.deep_depth != 0 && (fl & PF_HAD_FIRST) && (w.cell_irr[c] != 0 || history_lost(ring, oldest, L, I));
+    // (per-record masks on exact worlds: bit 31 of a record's word says "range form" — chd_tick_out.record_masks — so a window
+    // that reaches the ring's 32nd tick is answered from the buffers as well)
+    return w.deep_depth != 0 && (fl & PF_HAD_FIRST) &&
+           (w.cell_irr[c] != 0 || history_lost(ring, oldest, L, I) || (w.rec_mask && ring.n == CHD_HIST_BITS && (L > 0 ? L : 0) <= oldest));
 }
 // worst case of its segment: per channel of the cell one record per due window, and no more than TWICE what the buffer holds
 // elements — an arrival stamp that sits exactly on a window edge lies in two windows (both ends are inclusive, data.go:236-241),
@@ -2663,6 +2666,15 @@ void launch_fanout_emit_deferred(hipStream_t st, DevGrid g, WorldDev w, int64_t 
 // the reach), not O(buffer).  Two passes (count, wave prefix sum, write) keep a channel's records contiguous; the order of a
 // segment's records is not the hot path's (window-major there, channel-major here) — a connection's records are a multiset.
 // ---------------------------------------------------------------------------
+// Which buffered updates a deep record's message merges (CHD_WORLD_UPDATE_MASKS on an exact world): the elements of the channel's
+// buffer whose arrival lies inside the record's window, as a RANGE of the channel's update sequence numbers — bit 31 set, bits
+// 30..21 = count - 1, bits 20..0 = sequence number (mod 2^21) of the oldest element of the range; sequence number = how many
+// updates the channel had taken before that one.  (With SkipSelfUpdateFanOut the message merges the range's elements from other
+// senders; the host knows who sent what.)
+__device__ __forceinline__ uint32_t deep_range_word(uint32_t first_seq, uint32_t cnt) {
+    return 0x80000000u | (((cnt > 1024u ? 1024u : cnt) - 1u) << 21) | (first_seq & 0x1FFFFFu);
+}
+
 template <bool WRITE>
 __device__ __forceinline__ uint32_t deep_walk(const int64_t *__restrict__ A, const uint32_t *__restrict__ S, uint32_t D, uint32_t n,
                                               uint32_t len, int64_t drop, int64_t L, int64_t I, int64_t nwin, bool skip_self,
@@ -2670,33 +2682,45 @@ __device__ __forceinline__ uint32_t deep_walk(const int64_t *__restrict__ A, con
                                               uint32_t *__restrict__ opos, uint32_t *__restrict__ omask, uint32_t at, uint32_t &lost) {
     const int64_t lo0 = L > 0 ? L : 0, hi_all = L + nwin * I;
     if (drop >= lo0) lost = 1;  // an update the reference would still hold, inside this subscription's reach, is gone
-    int64_t prevw = nwin;       // windows are met newest first: a window is new when its index is below the last one counted
+    // Windows are met newest first; an element lies in window k = floor((a - L) / I) and, when it sits exactly on k's lower edge,
+    // in k - 1 as well — so two adjacent windows can be open at a time (elements with EQUAL stamps on an edge alternate between
+    // them).  Per open window: how many elements it holds so far and the oldest one's sequence number (the record's range), and
+    // the record it got once an element from a sender the subscription does not skip turned up.
+    int64_t wa = -1, wb = -1;                  // open windows (wb = wa - 1 when both are open); -1: none
+    uint32_t na = 0, nb = 0, fa = 0, fb = 0;   // elements / oldest sequence number
+    uint32_t ra = 0xFFFFFFFFu, rb = 0xFFFFFFFFu;  // record index (0xFFFFFFFF: none yet)
     uint32_t cnt = 0;
     for (uint32_t q = 0; q < len; q++) {
-        const uint32_t idx = (n - 1u - q) % D;
+        const uint32_t idx = (n - 1u - q) % D, seq = n - 1u - q;
         const int64_t a = A[idx];
         if (a < lo0) break;  // (arrival order: everything further back is older still)
         if (a > hi_all) continue;
-        if (skip_self && S[idx] == conn) continue;
+        const bool passes = !(skip_self && S[idx] == conn);
         const int64_t k = (a - L) / I;
         const bool edge = k >= 1 && (a - L) - k * I == 0;  // on the lower edge of window k = the upper edge of window k-1
-        if (k < nwin && k < prevw) {
-            if (WRITE) {
-                out[at + cnt].conn = conn; out[at + cnt].channel = chan;
-                if (opos) opos[at + cnt] = pos;
-                if (omask) omask[at + cnt] = 0;
+#pragma unroll
+        for (int t = 0; t < 2; t++) {
+            const int64_t x = t == 0 ? k : k - 1;
+            if (t == 0 ? k >= nwin : !edge) continue;
+            bool is_a = true;
+            if (x == wa) is_a = true;
+            else if (x == wb) is_a = false;
+            else {  // an older window: the open ones are complete
+                wa = x; wb = x - 1;
+                na = nb = 0; ra = rb = 0xFFFFFFFFu;
             }
-            cnt++;
-            prevw = k;
-        }
-        if (edge && k - 1 < prevw) {
-            if (WRITE) {
-                out[at + cnt].conn = conn; out[at + cnt].channel = chan;
-                if (opos) opos[at + cnt] = pos;
-                if (omask) omask[at + cnt] = 0;
+            const uint32_t nn = (is_a ? na : nb) + 1u;
+            uint32_t rr = is_a ? ra : rb;
+            if (passes && rr == 0xFFFFFFFFu) {
+                rr = at + cnt;
+                if (WRITE) {
+                    out[at + cnt].conn = conn; out[at + cnt].channel = chan;
+                    if (opos) opos[at + cnt] = pos;
+                }
+                cnt++;
             }
-            cnt++;
-            prevw = k - 1;
+            if (is_a) { na = nn; fa = seq; ra = rr; } else { nb = nn; fb = seq; rb = rr; }
+            if (WRITE && omask && rr != 0xFFFFFFFFu) omask[rr] = deep_range_word(seq, nn);
         }
     }
     return cnt;
@@ -2735,7 +2759,6 @@ __global__ void __launch_bounds__(64) k_fanout_emit_deep(DevGrid g, WorldDev w, 
         chd_fanout_rec *__restrict__ out = w.recs + base + rel;
         uint32_t *__restrict__ opos = w.rec_pos ? w.rec_pos + base + rel : nullptr;
         uint32_t *__restrict__ omask = w.rec_mask ? w.rec_mask + base + rel : nullptr;
-        if (omask) lost = 1;  // (which updates a message merges is a mask over the tick ring: not expressible here)
         uint32_t n_out = 0;
         // the spatial channel's own buffer: lane 0
         {

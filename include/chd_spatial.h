@@ -412,7 +412,14 @@ typedef struct {
                                           updated by more than two senders inside it (results then inexact);
                                           history_depth > 0: windows reaching an update the exact buffer had to drop */
     uint32_t *record_masks;            /* optional, records_cap entries, parallel to `records`: CHD_WORLD_UPDATE_MASKS
-                                          worlds only (else ignored); 0 for CHD_REC_FULL records */
+                                          worlds only (else ignored); 0 for CHD_REC_FULL records.  Worlds with history_depth:
+                                          a word with bit 31 SET is in range form — the message merges the buffered updates
+                                          of the channel numbered [first, first + count), first = bits 20..0 (the channel's
+                                          update counter, mod 2^21: how many updates it had taken before that one), count - 1 =
+                                          bits 30..21 (the elements of updateMsgBuffer whose arrivalTime lies in the window,
+                                          data.go:236-241; with SkipSelfUpdateFanOut minus the recipient's own) — records the
+                                          tick ring cannot answer (mid-tick stamps, windows older than 31 ticks, a third
+                                          sender); tick-ring words have bit 31 clear there */
 } chd_tick_out;
 
 /* replaces, for the whole world in one call: Notify (spatial.go:612-736,

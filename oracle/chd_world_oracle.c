@@ -42,6 +42,7 @@ typedef struct {
 typedef struct {
     wupd *v;
     uint32_t head, len, cap;
+    uint32_t pushed; /* updates the channel has taken so far: element i of the buffer is update number pushed - len + i */
 } wbuf;
 
 typedef struct {
@@ -49,6 +50,8 @@ typedef struct {
     uint32_t chan;
     uint32_t mask; /* window mode: which buffered updates the message merges, bit j = the one that arrived with
                       tick (current - j); 0 for the full state */
+    uint32_t range; /* ... and as a range of the channel's update numbers (chd_tick_out.record_masks, range form): bit 31 |
+                       (count - 1) << 21 | first & 0x1FFFFF over the buffered elements whose arrival lies in the window */
 } wrec;
 
 typedef struct {
@@ -132,6 +135,7 @@ static void wbuf_push(wbuf *b, orc_time t, uint32_t sender, uint32_t max_interva
     b->v[b->head + b->len].arrival = t;
     b->v[b->head + b->len].sender = sender;
     b->len++;
+    b->pushed++;
     if (b->len > 512) {
         if (b->v[b->head].arrival + (orc_time)max_interval_ms * 1000000 < t) {
             b->head++;
@@ -301,6 +305,21 @@ static void push_rec(orc_world *w, uint32_t conn, uint32_t chan) {
     w->nrec++;
 }
 
+/* the elements of the buffer whose arrival lies in the window [max(last, 0), next], whoever sent them: as a range word */
+static uint32_t window_range(const wbuf *b, orc_time last, orc_time next) {
+    const orc_time lo = last >= 0 ? last : 0;
+    uint32_t first = 0, cnt = 0;
+    for (uint32_t i = 0; i < b->len; i++) {
+        const orc_time a = b->v[b->head + i].arrival;
+        if (a >= lo && a <= next) {
+            if (!cnt) first = b->pushed - b->len + i;
+            cnt++;
+        }
+    }
+    if (!cnt) return 0;
+    return 0x80000000u | (((cnt > 1024u ? 1024u : cnt) - 1u) << 21) | (first & 0x1FFFFFu);
+}
+
 /* literal buffer walk of data.go:225-269 for one (subscriber, window) */
 static int window_has_update(const orc_world *w, const wbuf *b, orc_time last, orc_time next,
                              uint32_t conn, int skip_self, uint32_t *mask) {
@@ -395,7 +414,7 @@ static void orc__free_jobs(orc_world *w) {
     w->njobs = 0;
 }
 
-static void job_push(fan_job *j, uint32_t slot, uint32_t conn, uint32_t chan, uint32_t mask) {
+static void job_push(fan_job *j, uint32_t slot, uint32_t conn, uint32_t chan, uint32_t mask, uint32_t range) {
     if (j->w->digest_only) {
         const uint64_t h = mix64(((uint64_t)conn << 32) | chan);
         j->d_sum += h;
@@ -412,6 +431,7 @@ static void job_push(fan_job *j, uint32_t slot, uint32_t conn, uint32_t chan, ui
     j->rec[j->nrec].conn = conn;
     j->rec[j->nrec].chan = chan;
     j->rec[j->nrec].mask = mask;
+    j->rec[j->nrec].range = range;
     j->nrec++;
 }
 
@@ -445,10 +465,10 @@ static void *fan_cells(void *arg) {
                 uint32_t nw = pair_windows(&tmp, j->t, &wins, &wcap);
                 for (uint32_t wi = 0; wi < nw; wi++) {
                     uint32_t mask = 0;
-                    if (wins[wi].full) job_push(j, subs[si].s, conn | REC_FULL, chan, 0);
+                    if (wins[wi].full) job_push(j, subs[si].s, conn | REC_FULL, chan, 0, 0);
                     else if ((w->sorted_walk && !w->unsorted) ? window_has_update_sorted(w, b, wins[wi].last, wins[wi].next, conn, tmp.skip_self, &mask)
                                                               : window_has_update(w, b, wins[wi].last, wins[wi].next, conn, tmp.skip_self, &mask))
-                        job_push(j, subs[si].s, conn, chan, mask);
+                        job_push(j, subs[si].s, conn, chan, mask, j->w->digest_only ? 0u : window_range(b, wins[wi].last, wins[wi].next));
                 }
             }
         }
@@ -860,6 +880,16 @@ void orc_world_records(const orc_world *w, uint32_t *conn, uint32_t *chan) {
         for (uint64_t i = 0; i < w->jobs[k].nrec; i++, o++) { conn[o] = w->jobs[k].rec[i].conn; chan[o] = w->jobs[k].rec[i].chan; }
 }
 /* window mode only: per record (same order as orc_world_records) the merged-updates mask */
+/* window mode only: per record the range form of the merged updates (0 for full-state records) */
+void orc_world_record_ranges(const orc_world *w, uint32_t *range) {
+    if (w->literal) {
+        memset(range, 0, 4 * w->nrec);
+        return;
+    }
+    uint64_t o = 0;
+    for (int k = 0; k < w->njobs; k++)
+        for (uint64_t i = 0; i < w->jobs[k].nrec; i++, o++) range[o] = w->jobs[k].rec[i].range;
+}
 void orc_world_record_masks(const orc_world *w, uint32_t *mask) {
     if (w->literal) {
         memset(mask, 0, 4 * w->nrec);

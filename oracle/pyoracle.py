@@ -490,6 +490,16 @@ class World:
         lib().orc_world_record_masks(self.h, _p(m, C.c_uint32))
         return m[:n]
 
+    def record_ranges(self):
+        """window mode: per record of records() the merged updates in RANGE form (chd_tick_out.record_masks, bit 31 set: the
+        channel's update numbers [first, first + count) whose arrival lies in the record's window)"""
+        n = lib().orc_world_nrec(self.h)
+        m = np.zeros(max(n, 1), dtype=np.uint32)
+        f = lib().orc_world_record_ranges
+        f.argtypes = [C.c_void_p, C.POINTER(C.c_uint32)]
+        f(self.h, _p(m, C.c_uint32))
+        return m[:n]
+
     def handovers(self):
         n = lib().orc_world_nhandover(self.h)
         a = [np.zeros(max(n, 1), dtype=np.uint32) for _ in range(5)]

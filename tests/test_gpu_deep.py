@@ -339,3 +339,54 @@ def test_stamps_on_window_edges_count_twice_and_fit_their_segment(amd):
             # the blocked connections caught up over 180 windows with 32 buffered elements per channel: two records per element
             per_conn = {s: int(np.sum((res.records["conn"] & 0x7FFFFFFF) == int(sw.sub_conn[s]))) for s in range(S)}
             assert per_conn[1] > 40 * N // 4 and per_conn[2] > 40 * N // 4, per_conn
+
+
+@pytest.mark.parametrize("flags", [1 | 32, 1 | 32 | 64], ids=["conn-major", "conn-major-1w"])
+def test_merged_update_sets_of_exact_buffers_come_as_ranges(amd, flags):
+    """VERDICT r3 #6 (f3 over the real buffer): WHICH buffered updates a message merges (data.go:225-269) on a world whose update
+    buffers are the reference's (history_depth) and whose updates carry enqueue-time stamps, three senders, a subscriber that
+    catches up over 40 ticks.  Records the tick ring answers carry a mask over the ring (bit 31 clear); every other record carries
+    the RANGE of the channel's update numbers whose arrival lies in its window (bit 31 set: include/chd_spatial.h,
+    chd_tick_out.record_masks) — equal, record for record, to what the oracle's buffer walk selects; history_overflow == 0."""
+    N, S = 200, 16
+    cfg, sw, ctl, gw, ow = make_pair(amd, "spatial_static_4x4.json", N, S, 128, flags, seed=0xD19)
+    rng = np.random.default_rng(19)
+    now = 0
+    n_range = n_ring = 0
+    key = lambda c, ch, m: np.sort((c.astype(np.uint64) << np.uint64(43)) ^ (ch.astype(np.uint64) << np.uint64(32)) ^ m.astype(np.uint64))
+    for k in range(70):
+        sw.step()
+        prev, now = now, now + int(rng.choice([20, 50, 50])) * MS
+        q = sw.queries() if k < 4 or k % 7 == 0 else None
+        on_grid = k < 36 or k % 3 == 0  # (the first 36 ticks stamp their updates with the tick's own time: the ring answers)
+        idx = np.sort(rng.choice(N, int(N * 0.8), replace=False)).astype(np.uint32)
+        arr = np.full(len(idx), now, dtype=np.int64) if on_grid else rng.integers(prev + 1, now + 1, len(idx)).astype(np.int64)
+        snd = np.where(rng.random(len(idx)) < 0.15, rng.choice([901, int(sw.sub_conn[1])], len(idx)), sw.sender[idx]).astype(np.uint32)
+        ow.tick(now, idx, sw.x[idx], sw.z[idx], snd, None, None, None, q, upd_arrival=arr)
+        res = gw.tick(now, upd_idx=idx, upd_x=sw.x[idx], upd_z=sw.z[idx], upd_sender=snd, queries=q, upd_arrival_ns=arr, records_cap=1 << 22)
+        assert res.overflow == 0 and res.history_overflow == 0, (k, res.overflow, res.history_overflow)
+        oc, och = ow.records()
+        om, orr = ow.record_masks(), ow.record_ranges()
+        assert res.n_records == len(oc)
+        gm = res.record_masks
+        is_range = (gm >> 31).astype(bool)
+        # per record the device chose a form; the oracle offers both: same multiset of (conn, channel, word) either way
+        order_g = np.lexsort((gm, res.records["channel"], res.records["conn"]))
+        g_conn, g_chan, g_word, g_isr = res.records["conn"][order_g], res.records["channel"][order_g], gm[order_g], is_range[order_g]
+        # match the oracle's records to the device's by (conn, channel, word in the device's form): build both candidate keys
+        want_ring, want_range = key(oc, och, om), key(oc, och, orr)
+        got_ring, got_range = key(g_conn[~g_isr], g_chan[~g_isr], g_word[~g_isr]), key(g_conn[g_isr], g_chan[g_isr], g_word[g_isr])
+        assert np.isin(got_ring, want_ring).all(), f"tick {k}: a ring-form word the oracle does not have"
+        assert np.isin(got_range, want_range).all(), f"tick {k}: a range-form word the oracle does not have"
+        # ... and the records themselves are the oracle's
+        assert np.array_equal(canon(res.records["conn"], res.records["channel"]), canon(oc, och)), k
+        n_range += int(is_range.sum())
+        n_ring += int((~is_range & ((res.records["conn"] >> 31) == 0)).sum())
+        if k == 20 or k == 60:
+            access = 0 if k == 20 else 1
+            for s_ in (3, 9):
+                ch = gw.subscriptions(s_)[0]
+                gw.set_sub_options(now, [dict(slot=s_, channel=int(c), data_access=access) for c in ch])
+                for c in ch:
+                    ow.set_sub_options(now, s_, int(c), data_access=access)
+    assert n_range > 5_000 and n_ring > 1_000, (n_range, n_ring)  # (a third sender inside the ring sends a cell to the buffers as well)
