@@ -502,16 +502,21 @@ def main():
         try:
             trace("e2e segment ticks")
             frames = []  # the synthetic world continues after the frames already consumed (channel time never goes back)
-            for _ in range(max(7, E)):
+            n_seg_ticks = 104 if E >= 5 else max(7, E)  # (the default run: 100 ticks behind 4 that fault the pinned buffers in)
+            for _ in range(n_seg_ticks):
                 sw.step()
                 frames.append((sw.now_ns(), sw.x.copy(), sw.z.copy(), sw.queries().copy()))
             rs = e2e_segment_ticks(world, frames)
+            if len(rs) > 20:
+                rs = rs[4:]
             med = sorted(rs, key=lambda v: v[0])[len(rs) // 2]
             e2e["segments"] = {
                 "what": "chd_tick(host pointers, no dense records) + chd_tick_fetch_segments into page-locked buffers: per connection the segment "
                         "descriptors + the cells' entity-channel columns + explicit records of the subscriptions that needed a per-entity decision; "
                         "the host expands while it writes its sockets (tests/test_gpu_fullsize.py expands them and compares digests)",
-                "ticks": len(rs), "ms_per_tick": 1e3 * med[0], "ms_per_tick_is": "median", "ms_all": [round(1e3 * v[0], 3) for v in rs],
+                "ticks": len(rs), "ms_per_tick": 1e3 * med[0], "ms_per_tick_is": "median",
+                "p50_ms": float(np.percentile([1e3 * v[0] for v in rs], 50)), "p99_ms": float(np.percentile([1e3 * v[0] for v in rs], 99)),
+                "max_ms": float(max(1e3 * v[0] for v in rs)), "ms_all": [round(1e3 * v[0], 3) for v in rs][:16],
                 "msgs_per_tick": med[1], "value": med[1] / med[0], "unit": "msgs/s", "bytes_per_tick": med[2], "segments_per_tick": med[3],
                 "explicit_records_per_tick": med[4], "vs_dense_bytes": med[2] / (8.0 * med[1]) if med[1] else None}
         except Exception as ex:  # noqa: BLE001

@@ -110,6 +110,7 @@ struct World {
     ncclComm_t comm = nullptr;
     uint32_t comm_rank = 0, comm_world = 0, comm_cap = 0;
     chd_entity_state *mig_send = nullptr, *mig_recv = nullptr;   // [world][cap + 1]
+    chd_handover_request *req_send = nullptr, *req_recv = nullptr;  // [world][CHD_SHARD_REQ_CAP + 1] (handover lists only)
     unsigned char *halo_send_buf = nullptr, *halo_recv_buf = nullptr;
     std::vector<chd_halo_seg> halo_segs;
     hipStream_t comm_stream = nullptr;
@@ -2167,22 +2168,67 @@ static uint32_t migrate_cap_for(World &W, uint32_t cur_tick, uint32_t cap_max) {
     return (uint32_t)std::min<uint64_t>(c, cap_max);
 }
 
-static int shard_ingest_locked(chd_ctx *ctx, int64_t now_ns, const double *d_x_by_chan, const double *d_z_by_chan, const uint8_t *d_has_update, uint32_t n_chan,
-                               uint32_t rank, uint32_t world, chd_entity_state *d_send, uint32_t cap, uint32_t *cap_used) {
+// The ingest in two halves.  pre: positions -> cells, handovers, list members on THIS rank moved, handovers whose src map is another
+// rank's written to d_req_send (handover lists only).  post: the requests received applied, then the emigrants exported.
+static int shard_ingest_pre_locked(chd_ctx *ctx, int64_t now_ns, const double *d_x_by_chan, const double *d_z_by_chan, const uint8_t *d_has_update,
+                                   uint32_t n_chan, uint32_t rank, uint32_t world, chd_handover_request *d_req_send, uint32_t req_cap) {
     if (ctx->w.slot_mode == 1) return fail(ctx, CHD_E_STATE, "chd_shard_ingest on a world with caller-chosen slots");
     ctx->w.slot_mode = 2;
     TRY(bind(ctx));
     TRY(tick_begin(ctx, now_ns));
+    const uint32_t eid0 = ctx->cfg.entity_channel_id_start ? ctx->cfg.entity_channel_id_start : 0x80000u;
+    launch_ingest_by_channel(ctx->stream, ctx->g, ctx->w.d, d_x_by_chan, d_z_by_chan, d_has_update, n_chan, eid0,
+                             ctx->ring.cur_tick, rank, world, (uint4 *)d_req_send, req_cap);
+    return CHD_OK;
+}
+
+static int shard_ingest_post_locked(chd_ctx *ctx, const chd_handover_request *d_req_recv, uint32_t req_cap, uint32_t rank, uint32_t world,
+                                    chd_entity_state *d_send, uint32_t cap, uint32_t *cap_used) {
     World &W = ctx->w;
     const uint32_t use = (cap_used && world > 1) ? migrate_cap_for(W, ctx->ring.cur_tick, cap) : cap;
     if (cap_used) *cap_used = use;
     W.mig_cap = use;
-    const uint32_t eid0 = ctx->cfg.entity_channel_id_start ? ctx->cfg.entity_channel_id_start : 0x80000u;
-    launch_ingest_by_channel(ctx->stream, ctx->g, ctx->w.d, d_x_by_chan, d_z_by_chan, d_has_update, n_chan, eid0,
-                             ctx->ring.cur_tick);
+    if (world > 1 && d_req_recv) launch_apply_requests(ctx->stream, W.d, (const uint4 *)d_req_recv, world, req_cap);
     if (world > 1) launch_export(ctx->stream, ctx->g, ctx->w.d, rank, world, d_send, use, ctx->ring.cur_tick);
     TRY(after_launch(ctx));
     return CHD_OK;
+}
+
+static int shard_ingest_locked(chd_ctx *ctx, int64_t now_ns, const double *d_x_by_chan, const double *d_z_by_chan, const uint8_t *d_has_update, uint32_t n_chan,
+                               uint32_t rank, uint32_t world, chd_entity_state *d_send, uint32_t cap, uint32_t *cap_used) {
+    if (world > 1 && ctx->w.d.sh_list_of)
+        return fail(ctx, CHD_E_STATE, "chd_shard_ingest on a world with handover lists: a handover may concern another rank's entity map — "
+                                      "chd_shard_ingest_pre, exchange the requests, chd_shard_ingest_post (or chd_shard_tick)");
+    TRY(shard_ingest_pre_locked(ctx, now_ns, d_x_by_chan, d_z_by_chan, d_has_update, n_chan, rank, world, nullptr, 0));
+    return shard_ingest_post_locked(ctx, nullptr, 0, rank, world, d_send, cap, cap_used);
+}
+
+static int shard_args(chd_ctx *ctx, const char *fn, uint32_t rank, uint32_t world) {
+    if (!world || rank >= world) return fail(ctx, CHD_E_INVAL, "%s: rank %u of %u", fn, rank, world);
+    if (world != ctx->g.server_cols * ctx->g.server_rows)
+        return fail(ctx, CHD_E_INVAL, "%s: %u ranks but the grid has %u server regions", fn, world, ctx->g.server_cols * ctx->g.server_rows);
+    return CHD_OK;
+}
+
+int chd_shard_ingest_pre(chd_ctx *ctx, int64_t now_ns, const double *d_x_by_chan, const double *d_z_by_chan, const uint8_t *d_has_update,
+                         uint32_t n_chan, uint32_t rank, uint32_t world, chd_handover_request *d_req_send, uint32_t req_cap) {
+    NEED_WORLD();
+    if (n_chan && (!d_x_by_chan || !d_z_by_chan)) return fail(ctx, CHD_E_INVAL, "chd_shard_ingest_pre: NULL positions");
+    TRY(shard_args(ctx, "chd_shard_ingest_pre", rank, world));
+    if (world > 1 && (!d_req_send || !req_cap)) return fail(ctx, CHD_E_INVAL, "chd_shard_ingest_pre: NULL request buffer");
+    std::lock_guard<FairMutex> lk(ctx->mu);
+    TRY(shard_ingest_pre_locked(ctx, now_ns, d_x_by_chan, d_z_by_chan, d_has_update, n_chan, rank, world, world > 1 ? d_req_send : nullptr, req_cap));
+    return after_launch(ctx);
+}
+
+int chd_shard_ingest_post(chd_ctx *ctx, const chd_handover_request *d_req_recv, uint32_t req_cap, uint32_t rank, uint32_t world,
+                          chd_entity_state *d_send, uint32_t cap, uint32_t *cap_used) {
+    NEED_WORLD();
+    TRY(shard_args(ctx, "chd_shard_ingest_post", rank, world));
+    if (world > 1 && (!d_send || !cap || !d_req_recv || !req_cap)) return fail(ctx, CHD_E_INVAL, "chd_shard_ingest_post: NULL buffer");
+    std::lock_guard<FairMutex> lk(ctx->mu);
+    if (ctx->w.slot_mode != 2) return fail(ctx, CHD_E_STATE, "chd_shard_ingest_post before chd_shard_ingest_pre");
+    return shard_ingest_post_locked(ctx, d_req_recv, req_cap, rank, world, d_send, cap, cap_used);
 }
 
 int chd_shard_ingest(chd_ctx *ctx, int64_t now_ns, const double *d_x_by_chan, const double *d_z_by_chan,
@@ -2302,6 +2348,50 @@ int chd_shard_fanout(chd_ctx *ctx, const void *d_halo_recv, uint32_t world, cons
     if (world > 1 && !d_halo_recv) return fail(ctx, CHD_E_INVAL, "chd_shard_fanout: NULL halo receive buffer");
     std::lock_guard<FairMutex> lk(ctx->mu);
     return shard_fanout_locked(ctx, d_halo_recv, world, d_in);
+}
+
+int chd_shard_set_handover_lists(chd_ctx *ctx, uint32_t n_lists, const uint32_t *list_off, const uint32_t *list_member_chan, uint32_t n,
+                                 const uint32_t *chan_id, const uint32_t *list_of, uint32_t n_chan) {
+    NEED_WORLD();
+    if ((n_lists && (!list_off || (list_off[n_lists] && !list_member_chan))) || (n && (!chan_id || !list_of)))
+        return fail(ctx, CHD_E_INVAL, "chd_shard_set_handover_lists: NULL buffer");
+    if (!n_chan) return fail(ctx, CHD_E_INVAL, "chd_shard_set_handover_lists: n_chan = 0");
+    const uint32_t eid0 = ctx->cfg.entity_channel_id_start ? ctx->cfg.entity_channel_id_start : 0x80000u;
+    for (uint32_t k = 0; k < n_lists; k++)
+        if (list_off[k + 1] < list_off[k]) return fail(ctx, CHD_E_INVAL, "chd_shard_set_handover_lists: list_off decreases at %u", k);
+    for (uint32_t i = 0; i < n; i++) {
+        if (chan_id[i] - eid0 >= n_chan) return fail(ctx, CHD_E_INVAL, "chd_shard_set_handover_lists: channel %u outside [%u, %u)", chan_id[i], eid0, eid0 + n_chan);
+        if (list_of[i] != CHD_NO_HANDOVER_LIST && list_of[i] >= n_lists) return fail(ctx, CHD_E_INVAL, "chd_shard_set_handover_lists: list %u of %u", list_of[i], n_lists);
+    }
+    std::lock_guard<FairMutex> lk(ctx->mu);
+    World &W = ctx->w;
+    WorldDev &d = W.d;
+    if (W.slot_mode == 1) return fail(ctx, CHD_E_STATE, "chd_shard_set_handover_lists on a world with caller-chosen slots (use chd_world_set_handover_lists)");
+    W.slot_mode = 2;
+    TRY(bind(ctx));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    if (d.sh_nchan != n_chan) {  // (first call, or another id range: the tables are rebuilt)
+        d.sh_nchan = n_chan;
+        d.sh_eid0 = eid0;
+        TRY(walloc(ctx, &d.sh_slot_of, n_chan, false));
+        TRY(walloc(ctx, &d.sh_list_of, n_chan, false));
+        launch_slot_of_rebuild(ctx->stream, d);
+    }
+    std::vector<uint32_t> of(n_chan, CHD_NO_HANDOVER_LIST);
+    for (uint32_t i = 0; i < n; i++) of[chan_id[i] - eid0] = list_of[i];
+    const uint32_t nm = n_lists ? list_off[n_lists] : 0u;
+    uint32_t *doff = nullptr, *dmem = nullptr;
+    TRY(walloc(ctx, &doff, (size_t)n_lists + 1));
+    TRY(walloc(ctx, &dmem, std::max<size_t>(nm, 1)));
+    HIPCHK(hipMemcpy(d.sh_list_of, of.data(), 4 * (size_t)n_chan, hipMemcpyHostToDevice));
+    if (n_lists) HIPCHK(hipMemcpy(doff, list_off, 4 * ((size_t)n_lists + 1), hipMemcpyHostToDevice));
+    if (nm) HIPCHK(hipMemcpy(dmem, list_member_chan, 4 * (size_t)nm, hipMemcpyHostToDevice));
+    d.sh_list_off = doff;
+    d.sh_list_mem = dmem;
+    d.sh_nlists = n_lists;
+    TRY(after_launch(ctx));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    return CHD_OK;
 }
 
 // ---- native collectives: RCCL inside the library (include/chd_spatial.h: chd_shard_comm_*) ----
@@ -2425,7 +2515,26 @@ int chd_shard_tick(chd_ctx *ctx, int64_t now_ns, const double *d_x_by_chan, cons
     const uint32_t world = W.comm_world, rank = W.comm_rank;
     hipStream_t st = ctx->stream;
     uint32_t use = W.comm_cap;
-    TRY(shard_ingest_locked(ctx, now_ns, d_x_by_chan, d_z_by_chan, d_has_update, n_chan, rank, world, W.mig_send, W.comm_cap, &use));
+    if (world > 1 && W.d.sh_list_of) {
+        // handover lists: a handover whose src map is another rank's goes there as a request before anything is exported
+        // (k_shard.hip: k_apply_requests) — one more small exchange, only on worlds with lists, every rank alike
+        const uint32_t rc = CHD_SHARD_REQ_CAP;
+        if (!W.req_send) {
+            TRY(walloc(ctx, &W.req_send, (size_t)world * (rc + 1)));
+            TRY(walloc(ctx, &W.req_recv, (size_t)world * (rc + 1)));
+        }
+        TRY(shard_ingest_pre_locked(ctx, now_ns, d_x_by_chan, d_z_by_chan, d_has_update, n_chan, rank, world, W.req_send, rc));
+        NCCLCHK(g_rccl.GroupStart());
+        for (uint32_t p = 0; p < world; p++) {
+            NCCLCHK(g_rccl.Send(W.req_send + p * (rc + 1), (rc + 1) * sizeof(chd_handover_request), ncclUint8, (int)p, W.comm, st));
+            NCCLCHK(g_rccl.Recv(W.req_recv + p * (rc + 1), (rc + 1) * sizeof(chd_handover_request), ncclUint8, (int)p, W.comm, st));
+        }
+        NCCLCHK(g_rccl.GroupEnd());
+        TRY(shard_ingest_post_locked(ctx, W.req_recv, rc, rank, world, W.mig_send, W.comm_cap, &use));
+    } else {
+        TRY(shard_ingest_pre_locked(ctx, now_ns, d_x_by_chan, d_z_by_chan, d_has_update, n_chan, rank, world, nullptr, 0));
+        TRY(shard_ingest_post_locked(ctx, nullptr, 0, rank, world, W.mig_send, W.comm_cap, &use));
+    }
     const size_t seg = (size_t)use + 1;
     {   // the cross-server handovers (spatial.go:683-700): every rank's segment for every other rank, 32 B per emigrant.
         // (One rank: its own segment to itself — nothing to move, but the tick keeps its shape and the transport is exercised.)

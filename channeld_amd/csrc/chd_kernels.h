@@ -60,6 +60,13 @@ struct WorldDev {
     uint32_t *grp_of, *grp_off, *grp_mem, *grp_locked;
     uint32_t n_groups;
     uint32_t grp_exact;
+    // region-sharded worlds (chd_shard_set_handover_lists): the same lists keyed by ENTITY CHANNEL ID — slots are the library's
+    // there and change when an entity changes ranks.  sh_list_of[k] = list of channel (sh_eid0 + k) (CHD_NO_HANDOVER_LIST: the
+    // entity itself), list l = channel ids sh_list_mem[sh_list_off[l] .. sh_list_off[l+1]); sh_slot_of[k] = the slot that holds
+    // the channel on THIS rank (CHD_INVALID: it lives elsewhere), kept by spawn / import / export.  The members that move with a
+    // handover are those in src's entity map — by construction on the rank that owns src, i.e. the notifier's.
+    uint32_t sh_nchan, sh_eid0, sh_nlists;
+    uint32_t *sh_slot_of, *sh_list_of, *sh_list_off, *sh_list_mem;
     // spatial (cell) channels' own update history
     uint32_t *cell_hist, *cell_hist_tick, *cell_sender, *cell_hist_prev, *cell_sender_prev;
     // Exact update buffers (chd_world_cfg.history_depth = deep_depth > 0): ChannelData.updateMsgBuffer element for element,
@@ -374,9 +381,10 @@ void launch_cell_updates(hipStream_t st, DevGrid g, WorldDev w, uint32_t n,
                          const uint32_t *chan, const uint32_t *sender, uint32_t cur_tick,
                          const int64_t *arrival = nullptr, int64_t now_ns = 0);
 // pull-mode ingest of region-sharded worlds: every live slot reads its position by entity channel id
-void launch_ingest_by_channel(hipStream_t st, DevGrid g, WorldDev w, const double *x_by_chan,
-                              const double *z_by_chan, const uint8_t *has_update, uint32_t n_chan,
-                              uint32_t entity_id_start, uint32_t cur_tick);
+void launch_ingest_by_channel(hipStream_t st, DevGrid g, WorldDev w, const double *x_by_chan, const double *z_by_chan,
+                              const uint8_t *has_update, uint32_t n_chan, uint32_t entity_id_start, uint32_t cur_tick,
+                              uint32_t rank, uint32_t world, uint4 *req_send, uint32_t req_cap);
+void launch_apply_requests(hipStream_t st, WorldDev w, const uint4 *req_recv, uint32_t world, uint32_t req_cap);
 // entities whose member cell belongs to another rank leave (state packed per destination, slot freed)
 void launch_export(hipStream_t st, DevGrid g, WorldDev w, uint32_t rank, uint32_t world,
                    chd_entity_state *send, uint32_t cap, uint32_t cur_tick);
@@ -386,6 +394,7 @@ void launch_spawn_auto(hipStream_t st, DevGrid g, WorldDev w, uint32_t n, const 
                        const double *x, const double *z, const uint32_t *flags, const uint32_t *sender,
                        uint32_t cur_tick);
 void launch_free_stack_init(hipStream_t st, WorldDev w);
+void launch_slot_of_rebuild(hipStream_t st, WorldDev w);  // sh_slot_of from the live slots' channel ids
 // halo exchange: pack this rank's border bands per destination (segments at seg_off[d]), and append the received ones behind
 // the own cell tables (ghost entries from index N on) + the cell views
 void launch_halo_pack(hipStream_t st, DevGrid g, WorldDev w, uint32_t rank, uint32_t world, uint32_t halo, unsigned char *send,

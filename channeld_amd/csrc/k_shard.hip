@@ -26,6 +26,25 @@ void launch_free_stack_init(hipStream_t st, WorldDev w) {
     hipLaunchKernelGGL(k_free_stack_init, dim3(nblocks(w.N, 256)), dim3(256), 0, st, w);
 }
 
+// where channel `chan` lives on this rank (region-sharded handover lists)
+__device__ __forceinline__ void note_slot(const WorldDev &w, uint32_t chan, uint32_t slot) {
+    if (w.sh_slot_of) {
+        const uint32_t k = chan - w.sh_eid0;
+        if (k < w.sh_nchan) w.sh_slot_of[k] = slot;
+    }
+}
+
+__global__ void __launch_bounds__(256) k_slot_of_rebuild(WorldDev w) {
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    if (i < w.N && (w.eflags[i] & EF_ALIVE)) note_slot(w, w.chan_id[i], i);
+}
+
+void launch_slot_of_rebuild(hipStream_t st, WorldDev w) {
+    if (!w.N || !w.sh_slot_of) return;
+    (void)hipMemsetAsync(w.sh_slot_of, 0xFF, sizeof(uint32_t) * (size_t)w.sh_nchan, st);
+    hipLaunchKernelGGL(k_slot_of_rebuild, dim3(nblocks(w.N, 256)), dim3(256), 0, st, w);
+}
+
 __device__ __forceinline__ uint32_t pop_slot(const WorldDev &w) {
     int32_t k = atomicSub(w.free_top, 1) - 1;
     if (k < 0) {
@@ -55,6 +74,7 @@ __global__ void __launch_bounds__(256) k_spawn_auto(DevGrid g, WorldDev w, uint3
     w.hist_tick[i] = cur_tick;
     w.sender_prev[i] = 0;
     w.hist_prev[i] = 0;
+    note_slot(w, chan_id[u], i);
 }
 
 void launch_spawn_auto(hipStream_t st, DevGrid g, WorldDev w, uint32_t n, const uint32_t *chan_id,
@@ -71,7 +91,8 @@ __global__ void __launch_bounds__(256) k_ingest_by_channel(DevGrid g, WorldDev w
                                                            const double *__restrict__ zs,
                                                            const uint8_t *__restrict__ has_update,
                                                            uint32_t n_chan, uint32_t entity_id_start,
-                                                           uint32_t cur_tick) {
+                                                           uint32_t cur_tick, uint32_t rank, uint32_t world,
+                                                           uint4 *__restrict__ req_send, uint32_t req_cap) {
     __shared__ uint32_t s_cnt[4], s_lock[4];
     const uint32_t i = blockIdx.x * 256u + threadIdx.x;
     const uint32_t wave = threadIdx.x >> 6, lane = lane_id();
@@ -86,7 +107,14 @@ __global__ void __launch_bounds__(256) k_ingest_by_channel(DevGrid g, WorldDev w
             w.cell[i] = dst;
             push_update(w, i, w.sender[i], cur_tick);
             if (src != CHD_INVALID && dst != CHD_INVALID && src != dst) {
-                if (ef & EF_LOCKED) locked = true;
+                // GetHandoverEntities (entity.go:197-224) as the host's group controllers evaluated it: an EMPTY list = a locked
+                // member or an emptied group -> no handover (spatial.go:675-679)
+                bool lk = (ef & EF_LOCKED) != 0;
+                if (w.sh_list_of && k < w.sh_nchan) {
+                    const uint32_t li = w.sh_list_of[k];
+                    if (li != CHD_NO_HANDOVER_LIST && w.sh_list_off[li + 1] == w.sh_list_off[li]) lk = true;
+                }
+                if (lk) locked = true;
                 else ho = true;
             }
         }
@@ -103,7 +131,37 @@ __global__ void __launch_bounds__(256) k_ingest_by_channel(DevGrid g, WorldDev w
     }
     __syncthreads();
     if (ho) {
-        w.member[i] = dst;
+        bool self_moves = true;
+        if (w.sh_list_of) {
+            // every list member that is in src's entity map moves to dst's (spatial.go:703-736 over handoverEntities); the map of
+            // src is this rank's, so its members have slots here (a member that lives on another rank is in another cell's map)
+            const uint32_t kk = w.chan_id[i] - w.sh_eid0;
+            const uint32_t li = kk < w.sh_nchan ? w.sh_list_of[kk] : CHD_NO_HANDOVER_LIST;
+            if (li != CHD_NO_HANDOVER_LIST) {
+                self_moves = false;  // (the notifier itself only if its list names it)
+                // src is the cell of the notifier's last POSITION; the notifier lives on the rank of the cell whose MAP holds it.
+                // After another member's handover pulled it across a region border the two differ: src's map — the members to
+                // move — is then another rank's, and the handover travels there as a 16-byte request (k_apply_requests) before
+                // anything is exported.
+                const uint32_t own = server_of(g, src);
+                const bool remote = world > 1 && own != rank && own < world;
+                for (uint32_t q = w.sh_list_off[li]; q < w.sh_list_off[li + 1]; q++) {
+                    const uint32_t mc = w.sh_list_mem[q];
+                    if (mc == w.chan_id[i]) { self_moves = true; continue; }
+                    if (remote) continue;
+                    const uint32_t mk = mc - w.sh_eid0;
+                    const uint32_t j = mk < w.sh_nchan ? w.sh_slot_of[mk] : CHD_INVALID;
+                    if (j < w.N && (w.eflags[j] & EF_ALIVE) && w.chan_id[j] == mc) atomicCAS(&w.member[j], src, dst);
+                }
+                if (remote) {
+                    uint4 *seg = req_send + (size_t)own * (req_cap + 1);  // record 0 = {count, 0, 0, 0}
+                    const uint32_t r = req_send ? atomicAdd(&seg[0].x, 1u) : req_cap;
+                    if (r < req_cap) seg[1 + r] = make_uint4(li, src, dst, w.chan_id[i]);
+                    else atomicOr(&w.counters[CTR_OVERFLOW], OVF_MIGRATE);
+                }
+            }
+        }
+        if (self_moves) w.member[i] = dst;
         uint32_t pos = s_cnt[wave] + mask_rank(hm);
         if (pos < w.handovers_cap) {
             chd_handover_rec r;
@@ -122,10 +180,36 @@ __global__ void __launch_bounds__(256) k_ingest_by_channel(DevGrid g, WorldDev w
 
 void launch_ingest_by_channel(hipStream_t st, DevGrid g, WorldDev w, const double *x_by_chan,
                               const double *z_by_chan, const uint8_t *has_update, uint32_t n_chan,
-                              uint32_t entity_id_start, uint32_t cur_tick) {
+                              uint32_t entity_id_start, uint32_t cur_tick, uint32_t rank, uint32_t world, uint4 *req_send,
+                              uint32_t req_cap) {
+    if (req_send) (void)hipMemsetAsync(req_send, 0, sizeof(uint4) * (size_t)world * (req_cap + 1), st);
     if (!w.N || !n_chan) return;
     hipLaunchKernelGGL(k_ingest_by_channel, dim3(nblocks(w.N, 256)), dim3(256), 0, st, g, w, x_by_chan, z_by_chan,
-                       has_update, n_chan, entity_id_start, cur_tick);
+                       has_update, n_chan, entity_id_start, cur_tick, rank, world, req_send, req_cap);
+}
+
+// The other ranks' handovers whose src cell is one of OURS: the list members in src's map follow to dst (they leave with this
+// tick's export if dst is not ours either).  One thread per request; a tick carries a handful.
+__global__ void __launch_bounds__(256) k_apply_requests(WorldDev w, const uint4 *__restrict__ req_recv, uint32_t world, uint32_t req_cap) {
+    const uint32_t t = blockIdx.x * 256u + threadIdx.x;
+    const uint32_t from = t / req_cap, r = t % req_cap;
+    if (from >= world) return;
+    const uint4 *seg = req_recv + (size_t)from * (req_cap + 1);
+    if (r >= min(seg[0].x, req_cap)) return;
+    const uint4 rq = seg[1 + r];  // {list, src, dst, notifier channel}
+    if (!w.sh_list_of || rq.x >= w.sh_nlists) return;
+    for (uint32_t q = w.sh_list_off[rq.x]; q < w.sh_list_off[rq.x + 1]; q++) {
+        const uint32_t mc = w.sh_list_mem[q];
+        if (mc == rq.w) continue;
+        const uint32_t mk = mc - w.sh_eid0;
+        const uint32_t j = mk < w.sh_nchan ? w.sh_slot_of[mk] : CHD_INVALID;
+        if (j < w.N && (w.eflags[j] & EF_ALIVE) && w.chan_id[j] == mc) atomicCAS(&w.member[j], rq.y, rq.z);
+    }
+}
+
+void launch_apply_requests(hipStream_t st, WorldDev w, const uint4 *req_recv, uint32_t world, uint32_t req_cap) {
+    if (!req_recv || !world || !req_cap) return;
+    hipLaunchKernelGGL(k_apply_requests, dim3(nblocks((uint64_t)world * req_cap, 256)), dim3(256), 0, st, w, req_recv, world, req_cap);
 }
 
 __global__ void __launch_bounds__(256) k_export(DevGrid g, WorldDev w, uint32_t rank, uint32_t world,
@@ -160,6 +244,7 @@ __global__ void __launch_bounds__(256) k_export(DevGrid g, WorldDev w, uint32_t 
     e.hist_prev = age >= CHD_HIST_BITS ? 0u : (w.hist_prev[i] << age);
     e.sender_prev = w.sender_prev[i];
     seg[1 + k] = e;
+    note_slot(w, e.chan_id, CHD_INVALID);
     w.eflags[i] = 0;
     w.member[i] = CHD_INVALID;
     w.cell[i] = CHD_INVALID;
@@ -196,6 +281,7 @@ __device__ __forceinline__ void install_entity(const WorldDev &w, uint32_t i, co
     w.hist_tick[i] = cur_tick;
     w.hist_prev[i] = e.hist_prev;
     w.sender_prev[i] = e.sender_prev;
+    note_slot(w, e.chan_id, i);
 }
 
 // An immigrant that finds no free slot is not lost: it waits in LIMBO (a side list of states, two buffers by tick parity)

@@ -274,6 +274,7 @@ class HipShardEngine:
         self._r_interest, self._r_fanout = C.byref(self._ti_interest), C.byref(self._ti_fanout)
         self.cap_now = self.cap  # capacity this tick's exchange uses
         self.cap_seen = []       # (adaptive) every capacity used so far
+        self.lists_on, self.req_send = False, None  # set_handover_lists
         self.native = False      # chd_shard_comm_init has run: the exchanges happen inside the library (tick_native)
         self._ti_native = _lib.TickIn()
         self._r_native = C.byref(self._ti_native)
@@ -323,6 +324,42 @@ class HipShardEngine:
 
     def add_subscribers(self, conn_ids):
         self.sw.add_subscribers(None, conn_ids)
+
+    def set_handover_lists(self, list_off, list_member_chan, chan_id, list_of, n_chan: int):
+        """chd_shard_set_handover_lists: the handover lists of the WHOLE world, keyed by entity channel id (every rank gets the
+        same arrays; channeld_amd.groups.EntityGroupTable produces them from the group controllers)."""
+        from .controller import _ptr, _u32
+
+        off, mem, ch, lo = _u32(list_off), _u32(list_member_chan), _u32(chan_id), _u32(list_of)
+        n_lists = max(len(off) - 1, 0)
+        self._lib.check(self.ctx, self.lib.chd_shard_set_handover_lists(self.ctx, n_lists, _ptr(off) if n_lists else None,
+                                                                        _ptr(mem) if len(mem) else None, len(ch), _ptr(ch), _ptr(lo), int(n_chan)))
+        self.lists_on = True
+        if self.world > 1 and self.req_send is None:
+            self.req_send = self.torch.zeros(self.world * (self.REQ_CAP + 1) * 4, dtype=self.torch.int32, device=self.dev)
+
+    REQ_CAP = 256  # handover requests per peer and tick (16 B each)
+
+    def ingest_pre(self, now_ns: int, x_by_chan, z_by_chan, has_update=None):
+        """chd_shard_ingest_pre: returns the request segments [world, (REQ_CAP + 1) * 4] int32 for the all-to-all."""
+        hp = C.c_void_p(has_update.data_ptr()) if has_update is not None else None
+        rc = self.lib.chd_shard_ingest_pre(self.ctx, int(now_ns), C.c_void_p(x_by_chan.data_ptr()), C.c_void_p(z_by_chan.data_ptr()), hp,
+                                           int(x_by_chan.numel()), self.rank, self.world, C.c_void_p(self.req_send.data_ptr()), self.REQ_CAP)
+        if rc:
+            self._lib.check(self.ctx, rc)
+        return self.req_send.view(self.world, -1)
+
+    def ingest_post(self, req_recv):
+        self._keep_req = req_recv
+        rc = self.lib.chd_shard_ingest_post(self.ctx, C.c_void_p(req_recv.data_ptr()), self.REQ_CAP, self.rank, self.world,
+                                            self._p_send, self.cap, self._p_cap_used)
+        if rc:
+            self._lib.check(self.ctx, rc)
+        cu = self._cap_used.value
+        if cu != self.cap_now:
+            self.cap_now = cu
+            self.cap_seen.append(cu)
+        return self.send[: self.world * (cu + 1) * ENTITY_STATE_WORDS].view(self.world, -1)
 
     def ingest(self, now_ns: int, x_by_chan, z_by_chan, has_update=None):
         """x_by_chan / z_by_chan: float64 device tensors indexed by channel id - EntityChannelIdStart.  Returns the send
@@ -393,7 +430,12 @@ class ShardedWorld:
         if getattr(eng, "native", False):  # the library's own RCCL communicator: the whole tick is one C call
             eng.tick_native(now_ns, x_by_chan, z_by_chan, queries, n_queries, has_update)
             return
-        send = eng.ingest(now_ns, x_by_chan, z_by_chan, has_update)
+        if getattr(eng, "lists_on", False) and comm.active and eng.world > 1:
+            # handover lists: handovers that concern another rank's entity map travel there first (chd_shard_ingest_pre / _post)
+            req = eng.ingest_pre(now_ns, x_by_chan, z_by_chan, has_update)
+            send = eng.ingest_post(comm.all_to_all(req).contiguous())
+        else:
+            send = eng.ingest(now_ns, x_by_chan, z_by_chan, has_update)
         recv = comm.all_to_all(send) if comm.active else None
         halo_send = eng.import_(recv)
         send_splits, recv_splits, peer_off = eng.halo_splits()

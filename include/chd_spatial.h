@@ -270,7 +270,7 @@ int chd_world_set_entity_groups(chd_ctx *ctx, uint32_t n, const uint32_t *idx, c
  * list member that is in the src cell's entity map moves to dst's (:703-736) — the notifier itself only if the list names
  * it.  CHD_ENTITY_LOCKED is still honoured (it empties the notifier's own result).  Replaces the WHOLE group state of the
  * world (n_lists == 0 clears it); the later of this call and chd_world_set_entity_groups wins.  Same deviation as above for
- * members in a third cell's map.  Not available on region-sharded worlds. */
+ * members in a third cell's map.  Region-sharded worlds: chd_shard_set_handover_lists. */
 #define CHD_NO_HANDOVER_LIST 0xFFFFFFFFu
 int chd_world_set_handover_lists(chd_ctx *ctx, uint32_t n_lists, const uint32_t *list_off /* n_lists + 1 */,
                                  const uint32_t *list_members, uint32_t n, const uint32_t *idx, const uint32_t *list_of);
@@ -603,6 +603,39 @@ int chd_shard_interest(chd_ctx *ctx, const chd_tick_in *d_in);
  * as ghost entries; then the interest updates of d_in (queries of this rank's connections; the update fields of d_in
  * are ignored) and the fan-out of this rank's connections over region + halo.  Outputs as chd_tick_device. */
 int chd_shard_fanout(chd_ctx *ctx, const void *d_halo_recv, uint32_t world, const chd_tick_in *d_in);
+
+/* Handover lists on a region-sharded world: the meaning of chd_world_set_handover_lists, keyed by ENTITY CHANNEL ID — slots are
+ * the library's here and an entity changes ranks.  List k = the channel ids list_member_chan[list_off[k] .. list_off[k+1]); the
+ * entity with channel id chan_id[i] takes list list_of[i] (CHD_NO_HANDOVER_LIST: the entity itself; an EMPTY list: no handover,
+ * counted in n_locked_aborts).  Channel ids lie in [entity_channel_id_start, + n_chan).  EVERY rank is given the same, complete
+ * arrays (the group controllers are the host's, entity.go:58-244): a list's members may live on any rank — those that move
+ * with a handover are the ones in src's entity map (spatial.go:703-736), which is the notifier's rank's by construction; a
+ * member that thereby lands in another rank's region emigrates with the tick's exchange like any other entity.  Replaces the
+ * whole group state of this rank (n_lists == 0 clears it). */
+int chd_shard_set_handover_lists(chd_ctx *ctx, uint32_t n_lists, const uint32_t *list_off /* n_lists + 1 */,
+                                 const uint32_t *list_member_chan, uint32_t n, const uint32_t *chan_id, const uint32_t *list_of,
+                                 uint32_t n_chan);
+
+/* With lists, a handover can concern ANOTHER rank's entity map: the notifier lives on the rank of the cell whose map holds it, and
+ * after a list-mate's handover pulled it across a region border that is not the rank of the cell it stands in (src).  The members
+ * to move are in src's map, so the handover travels to src's rank as a 16-byte request and is applied there before anything is
+ * exported.  chd_shard_tick does this by itself; a host that drives the exchanges calls, instead of chd_shard_ingest (which
+ * refuses on a world with lists and world > 1):
+ *   chd_shard_ingest_pre   positions -> cells, handovers, local list members moved; d_req_send = world segments of
+ *                          (req_cap + 1) records, record 0 = {count} (more than req_cap: overflow bit 32)
+ *   all-to-all of the segments (equal sizes)
+ *   chd_shard_ingest_post  the received requests applied, the emigrants exported into d_send as chd_shard_ingest does */
+typedef struct chd_handover_request {
+    uint32_t list;     /* index into the lists every rank was given (record 0: the count) */
+    uint32_t src, dst; /* cell indices */
+    uint32_t notifier; /* its entity channel id: it moved, or not, on its own rank */
+} chd_handover_request;
+#define CHD_SHARD_REQ_CAP 1024u /* what chd_shard_tick uses per peer */
+int chd_shard_ingest_pre(chd_ctx *ctx, int64_t now_ns, const double *d_x_by_chan, const double *d_z_by_chan,
+                         const uint8_t *d_has_update, uint32_t n_chan, uint32_t rank, uint32_t world,
+                         chd_handover_request *d_req_send, uint32_t req_cap);
+int chd_shard_ingest_post(chd_ctx *ctx, const chd_handover_request *d_req_recv, uint32_t req_cap, uint32_t rank, uint32_t world,
+                          chd_entity_state *d_send, uint32_t cap, uint32_t *cap_used);
 
 /* ---- Native collectives: the two exchanges inside the library, on RCCL over xGMI (librccl.so, dlopen'ed here: a single-GPU
  * gateway never loads it).  replaces: the transport of the cross-server handover (spatial.go:683-700: the reference sends the

@@ -30,7 +30,43 @@ def canon(conn, chan):
     return np.sort((conn.astype(np.uint64) << np.uint64(32)) | chan.astype(np.uint64))
 
 
-def run_rank(rank, world, port, N, S, ticks, seed, out, cfg_name=None, halo=64, jump_frac=0.15, aoi_scale=1.0):
+def make_lists(sw, ids0, N, seed):
+    """Handover lists for a quarter of the world, by entity (index = channel id - 0x80000): pairs that start in one cell and name
+    each other; notifiers whose list names only a mate (they stay in src's map themselves); triples with a member in another
+    cell; empty lists (a locked member: no handover).  Returns ({entity: [members]}, and the flat arrays of the C call)."""
+    rng = np.random.default_rng(seed ^ 0x11575)
+    free = np.nonzero((sw.flags == 0) & (ids0 != 0))[0]
+    order = free[np.argsort(ids0[free], kind="stable")]
+    lists = {}
+    k = 0
+    while k + 3 < len(order):
+        a, b, c = (int(v) for v in order[k: k + 3])
+        r = rng.random()
+        if r < 0.10 and ids0[a] == ids0[b]:
+            lists[a] = lists[b] = [a, b]
+            k += 2
+        elif r < 0.14 and ids0[a] == ids0[b]:
+            lists[a] = [b]
+            k += 2
+        elif r < 0.18:
+            far = int(order[(k + len(order) // 2) % len(order)])
+            if far not in lists and far not in (a, b):
+                lists[a] = lists[b] = lists[far] = [a, b, far]
+            k += 2
+        elif r < 0.20:
+            lists[a] = []
+            k += 1
+        else:
+            k += 1
+    ents = np.array(sorted(lists), dtype=np.uint32)
+    off, mem = [0], []
+    for e in ents:
+        mem += [m + 0x80000 for m in lists[int(e)]]
+        off.append(len(mem))
+    return lists, (np.array(off, np.uint32), np.array(mem, np.uint32), ents + np.uint32(0x80000), np.arange(len(ents), dtype=np.uint32))
+
+
+def run_rank(rank, world, port, N, S, ticks, seed, out, cfg_name=None, halo=64, jump_frac=0.15, aoi_scale=1.0, lists=False):
     import torch
     import torch.distributed as dist
 
@@ -57,10 +93,17 @@ def run_rank(rank, world, port, N, S, ticks, seed, out, cfg_name=None, halo=64, 
         eng.spawn(sw.chan_id[mine], x0[mine], z0[mine], sw.flags[mine], sw.sender[mine])
         eng.add_subscribers(sw.sub_conn[my_subs])
         sworld = ShardedWorld(eng, Comm(rank, world))
+        if lists:
+            hl, (l_off, l_mem, l_chan, l_of) = make_lists(sw, ids0, N, seed)
+            assert len(hl) > N // 20
+            eng.set_handover_lists(l_off, l_mem, l_chan, l_of, N)  # (every rank: the same, whole-world arrays)
         ow = None
         if rank == 0:
             ow = orc.World(g, N, S, eng.sw.capq, 20, 0, literal=False)
             ow.spawn(np.arange(N), sw.chan_id, x0, z0, sw.flags, sw.sender)
+            if lists:
+                for e, m in hl.items():
+                    ow.set_handover_list(e, m)
             for s in range(S):
                 ow.add_sub(s, int(sw.sub_conn[s]))
         total = cross = 0
@@ -134,13 +177,13 @@ def run_rank(rank, world, port, N, S, ticks, seed, out, cfg_name=None, halo=64, 
             dist.destroy_process_group()
 
 
-def launch(world, N, S, ticks, seed, cfg_name=None, halo=64, jump_frac=0.15, aoi_scale=1.0):
+def launch(world, N, S, ticks, seed, cfg_name=None, halo=64, jump_frac=0.15, aoi_scale=1.0, lists=False):
     import torch.multiprocessing as mp
 
     ctx = mp.get_context("spawn")
     out = ctx.Queue()
     port = free_port()
-    procs = [ctx.Process(target=run_rank, args=(r, world, port, N, S, ticks, seed, out, cfg_name, halo, jump_frac, aoi_scale)) for r in range(world)]
+    procs = [ctx.Process(target=run_rank, args=(r, world, port, N, S, ticks, seed, out, cfg_name, halo, jump_frac, aoi_scale, lists)) for r in range(world)]
     for p in procs:
         p.start()
     for p in procs:
@@ -178,6 +221,18 @@ def test_8x8_world_on_its_eight_servers_matches_single_world():
     oracle, record for record."""
     total, cross = launch(8, 6000, 160, 6, 0xC0FFEE15, cfg_name="spatial_static_8x8.json")
     assert total > 0 and cross > 0
+
+
+@pytest.mark.parametrize("world", [1, 2, 4])
+def test_handover_lists_that_straddle_region_borders(world):
+    """chd_shard_set_handover_lists (entity.go:197-224 / spatial.go:675-736 on region-sharded worlds): a quarter of the world in
+    handover lists keyed by entity channel id — pairs, notifiers that are not in their own list, triples with a member in
+    another cell (often another rank), empty lists — while 15 % of the entities teleport across the regions every tick.  List
+    members follow their notifier out of src's entity map, emigrate with it when dst is another rank's, and a handover whose src
+    map sits on another rank than the notifier travels there as a request (chd_shard_ingest_pre / _post).  Every rank's records,
+    handovers, aborted handovers and every entity's (cell, member, rank) equal the single-world oracle's, tick for tick."""
+    total, cross = launch(world, 4000, 96, 10, 0xC0FFEE20 + world, lists=True)
+    assert total > 0 and (cross > 0 or world == 1)
 
 
 def test_narrow_halo_band_geometry_on_the_40x40_grid():
