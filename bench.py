@@ -35,6 +35,8 @@ HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8 TB/s spec
 BYTES_PER_MSG = 12     # 4 B entity id read + 8 B {conn, channel} record written
 # serial schedule: the filtering launch + epilogue beside the record kernel (CHD_WORLD_OVERLAP_DEFERRED; profiles/r03zz_overlap_deferred_ab.json)
 OVERLAP_DEFERRED_DEFAULT = 0
+# the interest updates (AOI queries -> subscription deltas) do not read this tick's cell index: second stream, beside ingest + index
+OVERLAP_INTEREST_DEFAULT = 1
 DOMINANT = "k_fanout_emit_seg"  # the kernel the roofline object is about (rocprofv3 --kernel-trace name, template arguments dropped)
 
 
@@ -70,8 +72,9 @@ def parse():
                          "config B is 1.0 (every entity moves every tick) - lower values exercise the filtering emit paths")
     ap.add_argument("--update-masks", action="store_true",
                     help="also write, per record, which buffered updates the message merges (CHD_WORLD_UPDATE_MASKS, +4 B/record)")
-    ap.add_argument("--overlap-interest", action="store_true",
-                    help="run the interest updates on a second stream beside ingest + index (CHD_WORLD_OVERLAP_INTEREST)")
+    ap.add_argument("--overlap-interest", type=int, nargs="?", const=1, default=OVERLAP_INTEREST_DEFAULT, choices=(0, 1),
+                    help="run the interest updates on a second stream beside ingest + index (CHD_WORLD_OVERLAP_INTEREST; default on: "
+                         "-3.4 %% per tick on the serial schedule, profiles/r04p_overlap_interest_ab.json)")
     ap.add_argument("--overlap-deferred", type=int, default=OVERLAP_DEFERRED_DEFAULT, choices=(0, 1),
                     help="serial schedule: the filtering launch + epilogue on a second stream beside the record kernel (CHD_WORLD_OVERLAP_DEFERRED)")
     ap.add_argument("--recipients", action="store_true",
@@ -560,6 +563,8 @@ def main():
                    "schedule": ("successive ticks pipelined over two HIP streams (CHD_WORLD_PIPELINE_TICKS): tick t's record kernel beside tick t+1's stages; "
                                 "every tick does all of its work inside the timed region, results equal the serial schedule's (tests/test_gpu_fullsize.py)")
                                if head_pipe else ("serial: every tick's kernels in sequence on one stream (see pipelined_schedule for CHD_WORLD_PIPELINE_TICKS)"
+                                                  + ("; the tick's interest updates run on a second stream beside its ingest + cell index and join before the plan "
+                                                     "(CHD_WORLD_OVERLAP_INTEREST)" if args.overlap_interest else "")
                                                   + ("; the tick's small filtering launch and its epilogue run beside the record kernel on a second stream and join "
                                                      "before the tick ends (CHD_WORLD_OVERLAP_DEFERRED)" if args.overlap_deferred else ""))},
         "p50_tick_ms": float(np.percentile(lat, 50)), "p99_tick_ms": float(np.percentile(lat, 99)),
