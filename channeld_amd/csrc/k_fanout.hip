@@ -1034,10 +1034,6 @@ __global__ void __launch_bounds__(64 * FO_WAVES) k_fanout_plan_seg(DevGrid g, Wo
                 start = w.cell_start[c];
                 size = w.cell_end[c] - start;
                 if (sub_is_deep(w, ring, oldest, fl, L, I, c)) {  // exact update buffers: k_fanout_emit_deep's
-#ifdef CHD_OFF_DEBUG
-                    if (ring.cur_tick == 12 && atomicAdd(&w.counters[15], 1u) < 40u)
-                        printf("sub_is_deep: s %u p %u c %u irr %u iv %u L %lld now %lld\n", s, p, c, w.cell_irr[c], iv, (long long)L, (long long)now);
-#endif
                     deep = true;
                     due = false;
                     ub = deep_upper_bound(w, now, L, I, size);
@@ -1142,11 +1138,6 @@ __global__ void __launch_bounds__(64 * FO_WAVES) k_fanout_plan_seg(DevGrid g, Wo
                 if (OFF && !(info & SD_FIRST) && (op.deep || (!simple && !filt))) {  // (a first fan-out evaluates no window: the filtering launch takes what is not simple)
                     // not decidable from the masks and offsets (plan_windows_off), or a shape the filtered kernel does not take
                     // (several senders of whom this connection may be one, a cell of more than 512 entities): the element buffers
-#ifdef CHD_OFF_DEBUG
-                    if (ring.cur_tick == 12 && atomicAdd(&w.counters[15], 1u) < 40u)
-                        printf("deep: s %u p %u c %u size %u iv %u L %lld now %lld nwin %lld op.deep %d nw %u us %x skip %d simple %d filt %d\n", s, p, c, size, iv,
-                               (long long)L, (long long)now, (long long)((now - L) / I), (int)op.deep, op.nw, us, (int)skip_self, (int)simple, (int)filt);
-#endif
                     deep = true;
                     due = false;
                     simple = filt = false;
@@ -1943,39 +1934,16 @@ __global__ void __launch_bounds__(64 * FC_WAVES, FC_OCC) k_fanout_emit_filt_cm(D
             }
             if (lane == 0) { H.nd = nd; H.cch = c + g.id_start; H.start = start; H.valid = 1; H.ticket = 0; }
         };
-#ifdef CHD_FCM_PROFILE
-        long long t_work = 0, t_wait = 0, t_mark = clock64();
-        uint32_t n_units = 0;
-#define FCM_MARK(acc) do { long long _t = clock64(); acc += _t - t_mark; t_mark = _t; } while (0)
-#else
-#define FCM_MARK(acc) do { } while (0)
-#endif
         prepare(0);
-        FCM_MARK(t_work);
         lds_barrier();
-        FCM_MARK(t_wait);
         for (uint32_t u = 0;; u++) {
             if (!heads[u & 1u].valid) break;
             prepare((u + 1u) & 1u);
-            FCM_MARK(t_work);
             lds_barrier();
-            FCM_MARK(t_wait);
-#ifdef CHD_FCM_PROFILE
-            n_units++;
-#endif
         }
-#ifdef CHD_FCM_PROFILE
-        if (lane == 0 && (blockIdx.x == 0 || blockIdx.x == 300) && *w.filt_nitems > 600 && atomicAdd(&w.counters[15], 1u) < 6u)
-            printf("fcm loader block %u: items %u of %u work %lld wait %lld\n", blockIdx.x, n_units, *w.filt_nitems, t_work, t_wait);
-#endif
     } else {
         // ---- streamers ----
-#ifdef CHD_FCM_PROFILE
-        long long t_work = 0, t_wait = 0, t_mark = clock64();
-        uint32_t n_desc = 0;
-#endif
         lds_barrier();
-        FCM_MARK(t_wait);
         for (uint32_t u = 0;; u++) {
             FcHead &H = heads[u & 1u];
             const FcTile &T = tiles[u & 1u];
@@ -2096,18 +2064,9 @@ __global__ void __launch_bounds__(64 * FC_WAVES, FC_OCC) k_fanout_emit_filt_cm(D
                     if (n_out) atomicAdd(&w.rec_cnt[H.sidx[k]], n_out);
                 }
                 wave_sum += n_out;
-#ifdef CHD_FCM_PROFILE
-                n_desc++;
-#endif
             }
-            FCM_MARK(t_work);
             lds_barrier();
-            FCM_MARK(t_wait);
         }
-#ifdef CHD_FCM_PROFILE
-        if (lane == 0 && (blockIdx.x == 0 || blockIdx.x == 300) && wave < 3 && *w.filt_nitems > 600 && atomicAdd(&w.counters[14], 1u) < 12u)
-            printf("fcm streamer block %u wave %u: descs %u records %llu work %lld wait %lld\n", blockIdx.x, wave, n_desc, wave_sum, t_work, t_wait);
-#endif
     }
     if (lane == 0 && wave_sum) {
         unsigned long long *slot = (unsigned long long *)&w.tot64[(size_t)((blockIdx.x * FC_WAVES + wave) & 63u) * 16];
@@ -2687,7 +2646,7 @@ __device__ __forceinline__ uint32_t deep_walk(const int64_t *__restrict__ A, con
     // them).  Per open window: how many elements it holds so far and the oldest one's sequence number (the record's range), and
     // the record it got once an element from a sender the subscription does not skip turned up.
     int64_t wa = -1, wb = -1;                  // open windows (wb = wa - 1 when both are open); -1: none
-    uint32_t na = 0, nb = 0, fa = 0, fb = 0;   // elements / oldest sequence number
+    uint32_t na = 0, nb = 0;                   // elements held so far (the newest one examined is the oldest: the record's range)
     uint32_t ra = 0xFFFFFFFFu, rb = 0xFFFFFFFFu;  // record index (0xFFFFFFFF: none yet)
     uint32_t cnt = 0;
     for (uint32_t q = 0; q < len; q++) {
@@ -2719,7 +2678,7 @@ __device__ __forceinline__ uint32_t deep_walk(const int64_t *__restrict__ A, con
                 }
                 cnt++;
             }
-            if (is_a) { na = nn; fa = seq; ra = rr; } else { nb = nn; fb = seq; rb = rr; }
+            if (is_a) { na = nn; ra = rr; } else { nb = nn; rb = rr; }
             if (WRITE && omask && rr != 0xFFFFFFFFu) omask[rr] = deep_range_word(seq, nn);
         }
     }

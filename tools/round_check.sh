@@ -4,7 +4,7 @@
 # (PMC=1), the diagnostic configurations (DIAG=1: partial updates, masks), the self-verifying sharded bench (ranks share the
 # GPU, gloo), then the GPU parity suite.  Every summary is stamped with the kernel-source hash (channeld_amd.build.source_hash:
 # the GPU box has no .git).
-# usage (repo root on the GPU box): [PMC=1] [WIRE_TRACE=1] [PIPE_TRACE=1] [DIAG=1|light] bash tools/round_check.sh <tag> [pytest args]
+# usage (repo root on the GPU box): [PMC=1] [WIRE_TRACE=1] [PIPE_TRACE=1] [JITTER_TRACE=1] [AB_INTEREST=1] [DIAG=1|light] bash tools/round_check.sh <tag> [pytest args]
 TAG=${1:-round}; shift
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 O=$R/gpurun_out/$TAG
@@ -28,6 +28,18 @@ trace() {  # trace <name> <skip> <bench args...>
 trace serial 10 --steps 50 --warmup 10 --only-timed
 [ -n "$PIPE_TRACE" ] && trace pipelined 10 --steps 50 --warmup 10 --only-timed --headline pipelined
 [ -n "$WIRE_TRACE" ] && trace wire 0 --steps 8 --warmup 6 --only-timed --wire 3
+if [ -n "$JITTER_TRACE" ]; then  # arrival stamps at enqueue time (exact update buffers): ticks on and off the 50 ms grid
+  trace arrival_jitter 10 --steps 40 --warmup 10 --only-timed --arrival-jitter
+  trace arrival_jitter_offgrid 10 --steps 40 --warmup 10 --only-timed --arrival-jitter --tick-jitter-us 3000
+fi
+if [ -n "$AB_INTEREST" ]; then  # the bench's default schedule against the one-stream schedule, alternating
+  (echo '{"what": "bench.py --only-timed --steps 200 --warmup 20, --overlap-interest 0 / 1 alternating (ms_per_step)", "source_hash": "'$HASH'", "runs": ['
+   for i in 1 2 3; do for v in 0 1; do
+     ms=$(timeout 120 python bench.py --only-timed --steps 200 --warmup 20 --overlap-interest $v 2>> $O/ab.err | python -c "import json,sys; print(json.loads(sys.stdin.readlines()[-1])['ms_per_step'])")
+     echo "  {\"overlap_interest\": $v, \"ms_per_step\": $ms},"
+   done; done
+   echo '  {}]}') > $O/overlap_interest_ab.json
+fi
 if [ -n "$DIAG" ]; then
   for f in 0.98 0.9 0.5; do timeout 120 python bench.py --only-timed --steps 60 --warmup 10 --update-frac $f > $O/diag_update_frac_$f.json 2>> $O/diag.err; done
   timeout 120 python bench.py --only-timed --steps 60 --warmup 10 --update-masks > $O/diag_update_masks.json 2>> $O/diag.err
