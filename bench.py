@@ -74,7 +74,7 @@ def parse():
                     help="also write, per record, which buffered updates the message merges (CHD_WORLD_UPDATE_MASKS, +4 B/record)")
     ap.add_argument("--overlap-interest", type=int, nargs="?", const=1, default=OVERLAP_INTEREST_DEFAULT, choices=(0, 1),
                     help="run the interest updates on a second stream beside ingest + index (CHD_WORLD_OVERLAP_INTEREST; default on: "
-                         "-3.4 %% per tick on the serial schedule, profiles/r04p_overlap_interest_ab.json)")
+                         "-3.4 %% per tick on the serial schedule, profiles/r04q_overlap_interest_ab.json)")
     ap.add_argument("--overlap-deferred", type=int, default=OVERLAP_DEFERRED_DEFAULT, choices=(0, 1),
                     help="serial schedule: the filtering launch + epilogue on a second stream beside the record kernel (CHD_WORLD_OVERLAP_DEFERRED)")
     ap.add_argument("--recipients", action="store_true",
