@@ -37,6 +37,9 @@ BYTES_PER_MSG = 12     # 4 B entity id read + 8 B {conn, channel} r
 OVERLAP_DEFERRED_DEFAULT = 0
 # the interest updates (AOI queries -> subscription deltas) do not read this tick's cell index: second stream, beside ingest + index
 OVERLAP_INTEREST_DEFAULT = 1
+# throughput regions take the HIP event pair around the dominant kernel on every n-th tick (CHD_PROF_RECORD_KERNEL_EVERY): each event idles
+# the stream for ~7 us beside the kernel (profiles/r04t_tick_timeline_*.csv), 14 us of a 255 us tick if every launch were timed
+PROF_EVERY_DEFAULT = 7  # (odd: the workload alternates between ticks of ~100 M and ~60 M messages — 100 ms subscriptions fire every other 50 ms tick)
 DOMINANT = "k_fanout_emit_seg"  # the kernel the roofline object is about (rocprofv3 --kernel-trace name, template arguments dropped)
 
 
@@ -75,6 +78,8 @@ def parse():
     ap.add_argument("--overlap-interest", type=int, nargs="?", const=1, default=OVERLAP_INTEREST_DEFAULT, choices=(0, 1),
                     help="run the interest updates on a second stream beside ingest + index (CHD_WORLD_OVERLAP_INTEREST; default on: "
                          "-3.4 %% per tick on the serial schedule, profiles/r04q_overlap_interest_ab.json)")
+    ap.add_argument("--prof-every", type=int, default=PROF_EVERY_DEFAULT,
+                    help="timed region: HIP event pair around the dominant kernel on every N-th tick (1 = every launch, as rounds 1-3 did)")
     ap.add_argument("--overlap-deferred", type=int, default=OVERLAP_DEFERRED_DEFAULT, choices=(0, 1),
                     help="serial schedule: the filtering launch + epilogue on a second stream beside the record kernel (CHD_WORLD_OVERLAP_DEFERRED)")
     ap.add_argument("--recipients", action="store_true",
@@ -390,7 +395,7 @@ def main():
     # (diagnostic configurations whose records mostly come from another kernel - per-record masks, partial updates, populous
     # cells - keep the stage events: their roofline line is about the whole emit stage)
     headline_like = args.update_frac >= 1.0 and not args.update_masks and args.emit != "cell-major" and N // max(ctl.GridCols * ctl.GridRows, 1) < 512 and not jitter
-    world.set_profiling_scope(headline_like)
+    world.set_profiling_scope(headline_like, every=args.prof_every)
     if pipe and not head_pipe:
         world.set_pipelining(False)
     for t in range(W):
@@ -406,8 +411,9 @@ def main():
     msgs = sum(h["n_records"] for h in hist)
     # the dominant kernel alone (k_fanout_emit_seg; its own HIP event pair on the tick's stream) and the records IT wrote
     # (the few connections it defers are written by a second, small launch inside the same emit stage)
-    emit_us = np.array([h["emit_main_us"] for h in hist])
-    emit_msgs = np.array([h["n_records"] - h["n_deferred_records"] for h in hist], dtype=np.float64)
+    timed = [h for h in hist if h["emit_main_us"] > 0] if headline_like else hist  # (the sampled launches: --prof-every)
+    emit_us = np.array([h["emit_main_us"] for h in timed])
+    emit_msgs = np.array([h["n_records"] - h["n_deferred_records"] for h in timed], dtype=np.float64)
     dominant = DOMINANT
     if not headline_like:
         emit_us = np.array([h["stage_us"][4] for h in hist])
@@ -430,14 +436,15 @@ def main():
         el2 = time.perf_counter() - t1
         hist2 = world.history(min(K2, 1024))
         m2 = sum(h["n_records"] for h in hist2) * (K2 / len(hist2))
-        k_us = float(np.mean([h["emit_main_us"] for h in hist2]))
+        t2 = [h for h in hist2 if h["emit_main_us"] > 0]
+        k_us = float(np.mean([h["emit_main_us"] for h in t2]))
         other = {"what": ("the same world, next %d ticks, CHD_WORLD_PIPELINE_TICKS switched %s: " % (K2, "off" if head_pipe else "on"))
                          + ("every tick's kernels in sequence on one stream" if head_pipe else
                             "tick t's record kernel on the ctx stream beside tick t+1's stages on a second (interest updates: third) stream; "
                             "every tick still does all of its work, results equal the serial schedule's (tests/test_gpu_fullsize.py)"),
                  "value": m2 / el2, "unit": "msgs/s", "ms_per_step": 1e3 * el2 / K2, "msgs_per_tick": m2 / K2,
                  "emit_kernel_us": k_us,
-                 "emit_kernel_frac_of_hbm_peak": float(BYTES_PER_MSG * np.mean([h["n_records"] - h["n_deferred_records"] for h in hist2])
+                 "emit_kernel_frac_of_hbm_peak": float(BYTES_PER_MSG * np.mean([h["n_records"] - h["n_deferred_records"] for h in t2])
                                                        / (k_us * 1e-6) / 1e9 / HBM_PEAK_GBS),
                  "whole_tick_frac_of_hbm_peak": float(BYTES_PER_MSG * (m2 / K2) / (el2 / K2) / 1e9 / HBM_PEAK_GBS)}
         if not head_pipe:
@@ -582,6 +589,10 @@ def main():
                                                        "kernel sources (profiles/hbm_traffic.json, source_hash checked)",
                      "algorithmic_bytes_per_launch": float(bytes_per_msg * emit_msgs.mean()),
                      "bytes_per_msg": bytes_per_msg, "msgs_per_launch": float(emit_msgs.mean()), "avg_launch_us": float(emit_us.mean()),
+                     "timed_launches": int(len(emit_us)),
+                     "timed_launches_are": (f"every {args.prof_every}-th launch of the timed region, its own HIP event pair on the stream it is launched on "
+                                            "(each event idles the stream for ~7 us: timing every launch would lengthen every tick by 14 us)"
+                                            if headline_like and args.prof_every > 1 else "every launch of the timed region"),
                      "emit_stage_us": float(stage_avg[4]), "deferred_msgs_per_tick": float(np.mean([h["n_deferred_records"] for h in hist]))},
     }
     out["roofline"]["whole_tick_frac"] = float(BYTES_PER_MSG * (msgs / K) / (elapsed / K) / 1e9 / HBM_PEAK_GBS)
@@ -661,7 +672,7 @@ def flat_interval_line(A, synth, cfg, N, S, seed, args, local_rank, interval_ms,
         xs[t], zs[t], qs[t], now[t] = sw.x, sw.z, sw.queries(), sw.now_ns()
     dx, dz, dq = w.device_array(xs), w.device_array(zs), w.device_array(qs)
     w.set_profiling(steps)
-    w.set_profiling_scope(True)
+    w.set_profiling_scope(True, every=4 if args.prof_every > 1 else 1)
 
     def tick(t):
         w.tick_device(int(now[t]), n_updates=N, d_upd_x=dx.at(t * N * 8), d_upd_z=dz.at(t * N * 8), n_queries=S, d_queries=dq.at(t * S * 128))
@@ -676,14 +687,15 @@ def flat_interval_line(A, synth, cfg, N, S, seed, args, local_rank, interval_ms,
     el = time.perf_counter() - t0
     hist = w.history(steps)
     msgs = sum(h["n_records"] for h in hist)
-    emit_us = float(np.mean([h["emit_main_us"] for h in hist]))
+    timed = [h for h in hist if h["emit_main_us"] > 0]
+    emit_us = float(np.mean([h["emit_main_us"] for h in timed]))
     res = w.fetch()
     assert res.overflow == 0 and res.history_overflow == 0
     ctl.close()
     return {"what": f"every subscription fans out every {interval_ms} ms (one-entry damping table), otherwise the headline workload"
                     + (" (ticks pipelined, as the headline)" if pipe else " (serial schedule, as the headline)"),
             "value": msgs / el, "unit": "msgs/s", "steps": steps, "ms_per_step": 1e3 * el / steps, "msgs_per_tick": msgs / steps,
-            "emit_us": emit_us, "emit_frac_of_hbm_peak": BYTES_PER_MSG * (msgs / steps) / (emit_us * 1e-6) / 1e9 / HBM_PEAK_GBS}
+            "emit_us": emit_us, "emit_frac_of_hbm_peak": BYTES_PER_MSG * float(np.mean([h["n_records"] for h in timed])) / (emit_us * 1e-6) / 1e9 / HBM_PEAK_GBS}
 
 
 def arrival_jitter_line(A, synth, cfg, N, S, seed, args, local_rank, tick_jitter_us, warm=10, steps=40, check=16):
@@ -709,7 +721,7 @@ def arrival_jitter_line(A, synth, cfg, N, S, seed, args, local_rank, tick_jitter
         now[t], arr[t] = aj.next(sw.now_ns())
     dx, dz, dq, da = w.device_array(xs), w.device_array(zs), w.device_array(qs), w.device_array(arr)
     w.set_profiling(steps)
-    w.set_profiling_scope(True)
+    w.set_profiling_scope(True, every=4 if args.prof_every > 1 else 1)
 
     def tick(t):
         w.tick_device(int(now[t]), n_updates=N, d_upd_x=dx.at(t * N * 8), d_upd_z=dz.at(t * N * 8), n_queries=S, d_queries=dq.at(t * S * 128),
@@ -725,8 +737,9 @@ def arrival_jitter_line(A, synth, cfg, N, S, seed, args, local_rank, tick_jitter
     el = time.perf_counter() - t0
     hist = w.history(steps)
     msgs = sum(h["n_records"] for h in hist)
-    emit_us = float(np.mean([h["emit_main_us"] for h in hist]))
-    stream_msgs = float(np.mean([h["n_records"] - h["n_deep_records"] for h in hist]))
+    timed = [h for h in hist if h["emit_main_us"] > 0]
+    emit_us = float(np.mean([h["emit_main_us"] for h in timed]))
+    stream_msgs = float(np.mean([h["n_records"] - h["n_deep_records"] for h in timed]))
     res = w.fetch()
     assert res.overflow == 0 and res.history_overflow == 0, (res.overflow, res.history_overflow)
     golden, checked = None, 0

@@ -145,6 +145,7 @@ struct chd_ctx {
     bool force_device = false;          // CHD_NO_HOST_FAST_PATH=1: small stateless calls go to the device too (tests, measurements)
     bool chain = false, chain_prev = false;  // the previous call on this ctx was a pipelined tick (bind() shifts them)
     int prof_depth = 0;                 // 0 = off
+    uint32_t prof_every = 1;            // CHD_PROF_RECORD_KERNEL_EVERY(n): that pair on every n-th tick only (the others record nothing)
     bool prof_kernel_only = false;      // chd_set_profiling_scope(CHD_PROF_RECORD_KERNEL): only the event pair around the dominant emit kernel
     std::vector<hipEvent_t> ev;         // [prof_depth][EV_PER_TICK]: stage boundaries on `stream`, then interest begin/end
     std::vector<uint8_t> ev_overlap;    // [prof_depth] the slot's tick ran the interest stage on aux_stream
@@ -1538,7 +1539,10 @@ static int tick_locked(chd_ctx *ctx, const chd_tick_in *in) {
     d.ce_sprev_stride = 0;
     d.cell_start = d.cell_off;
     d.cell_end = d.cell_off + 1;
-    const bool prof = ctx->prof_depth > 0;
+    // (sampled record-kernel pairs: the ticks in between record nothing and say so — ev_overlap bit 8)
+    const bool prof_skip = ctx->prof_depth > 0 && ctx->prof_kernel_only && ctx->prof_every > 1 && r.cur_tick % ctx->prof_every != 0;
+    if (prof_skip) ctx->ev_overlap[r.cur_tick % (uint32_t)ctx->prof_depth] = 8;
+    const bool prof = ctx->prof_depth > 0 && !prof_skip;
     hipEvent_t *ev = prof ? &ctx->ev[(size_t)(r.cur_tick % (uint32_t)ctx->prof_depth) * EV_PER_TICK] : nullptr;
     // CHD_WORLD_OVERLAP_INTEREST: the interest updates touch subscriptions only, ingest + index build entities
     // only, so the two can run side by side on two streams and join before the fan-out plan.  (Not with handover
@@ -1698,6 +1702,11 @@ static void stage_times(chd_ctx *ctx, uint32_t tick, chd_tick_stats &s) {
     const uint32_t slot = tick % (uint32_t)ctx->prof_depth;
     hipEvent_t *ev = &ctx->ev[(size_t)slot * EV_PER_TICK];
     float ms = 0;
+    if (ctx->ev_overlap[slot] & 8) {  // a tick between two sampled ones: nothing was recorded
+        for (int k = 0; k < CHD_N_STAGES; k++) s.stage_us[k] = 0.f;
+        s.total_us = s.emit_main_us = 0.f;
+        return;
+    }
     if (ctx->ev_overlap[slot] & 4) {
         // CHD_PROF_RECORD_KERNEL: only the record kernel's own pair was taken
         for (int k = 0; k < CHD_N_STAGES; k++) s.stage_us[k] = 0.f;
@@ -3058,11 +3067,14 @@ int chd_set_profiling(chd_ctx *ctx, int depth) {
 
 int chd_set_profiling_scope(chd_ctx *ctx, int scope) {
     if (!ctx) return fail(nullptr, CHD_E_INVAL, "NULL ctx");
-    if (scope != CHD_PROF_STAGES && scope != CHD_PROF_RECORD_KERNEL) return fail(ctx, CHD_E_INVAL, "chd_set_profiling_scope: unknown scope %d", scope);
+    const int what = scope & 0xFF, every = scope >> 8;
+    if ((what != CHD_PROF_STAGES && what != CHD_PROF_RECORD_KERNEL) || every < 0 || every > 1024 || (every && what != CHD_PROF_RECORD_KERNEL))
+        return fail(ctx, CHD_E_INVAL, "chd_set_profiling_scope: unknown scope %d", scope);
     std::lock_guard<FairMutex> lk(ctx->mu);
     TRY(bind(ctx));
     HIPCHK(hipStreamSynchronize(ctx->stream));
-    ctx->prof_kernel_only = scope == CHD_PROF_RECORD_KERNEL;
+    ctx->prof_kernel_only = what == CHD_PROF_RECORD_KERNEL;
+    ctx->prof_every = every > 1 ? (uint32_t)every : 1u;
     return CHD_OK;
 }
 

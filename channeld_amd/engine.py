@@ -509,9 +509,11 @@ class SpatialWorld:
         """depth > 0: HIP events around the stages of each tick, last `depth` ticks kept."""
         _lib.check(self.ctx, self.lib.chd_set_profiling(self.ctx, int(depth)))
 
-    def set_profiling_scope(self, record_kernel_only: bool):
-        """True: a profiled tick records only the event pair around the dominant record kernel (throughput runs); False (default): every stage boundary."""
-        _lib.check(self.ctx, self.lib.chd_set_profiling_scope(self.ctx, _lib.PROF_RECORD_KERNEL if record_kernel_only else _lib.PROF_STAGES))
+    def set_profiling_scope(self, record_kernel_only: bool, every: int = 1):
+        """True: a profiled tick records only the event pair around the dominant record kernel (throughput runs) — on every
+        `every`-th tick (CHD_PROF_RECORD_KERNEL_EVERY; the others report emit_main_us 0); False (default): every stage boundary."""
+        scope = (_lib.PROF_RECORD_KERNEL | ((int(every) << 8) if every > 1 else 0)) if record_kernel_only else _lib.PROF_STAGES
+        _lib.check(self.ctx, self.lib.chd_set_profiling_scope(self.ctx, scope))
 
     def set_pipelining(self, on: bool):
         """CHD_WORLD_PIPELINE_TICKS (flags & 128) worlds: serial schedule (False) or pipelined ticks (True)."""

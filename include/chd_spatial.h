@@ -860,6 +860,10 @@ int chd_set_profiling(chd_ctx *ctx, int depth);
  * of not scraping the reference's per-channel `channel_tick_duration` gauge (channel.go:382-383) while load-testing. */
 #define CHD_PROF_STAGES 0
 #define CHD_PROF_RECORD_KERNEL 1
+/* ... and that pair on every n-th tick only (2 <= n <= 1024; the ticks in between record nothing, their emit_main_us reads 0):
+ * each of the two events idles the stream for ~7 us beside a kernel of ~140 (profiles/r04t_tick_timeline_*.csv), so a throughput
+ * run that wants the kernel's duration AND an undisturbed tick time samples. */
+#define CHD_PROF_RECORD_KERNEL_EVERY(n) (CHD_PROF_RECORD_KERNEL | ((n) << 8))
 int chd_set_profiling_scope(chd_ctx *ctx, int scope);
 /* Turn the tick pipelining of a CHD_WORLD_PIPELINE_TICKS world off (on = 0: serial schedule on the ctx stream, as without
  * the flag) and on again; CHD_E_STATE for a world created without the flag (or where it did not take effect). */

@@ -53,7 +53,7 @@ class FakeWorld:
     def set_profiling(self, depth):
         pass
 
-    def set_profiling_scope(self, only):
+    def set_profiling_scope(self, only, every=1):
         self.light = only
 
     def set_pipelining(self, on):
