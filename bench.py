@@ -78,6 +78,8 @@ def parse():
     ap.add_argument("--overlap-interest", type=int, nargs="?", const=1, default=OVERLAP_INTEREST_DEFAULT, choices=(0, 1),
                     help="run the interest updates on a second stream beside ingest + index (CHD_WORLD_OVERLAP_INTEREST; default on: "
                          "-3.4 %% per tick on the serial schedule, profiles/r04q_overlap_interest_ab.json)")
+    ap.add_argument("--gated-overlap", type=int, default=1, choices=(0, 1),
+                    help="with --overlap-interest: fork / join of the second stream as device-side flags instead of HIP events (CHD_WORLD_GATED_OVERLAP)")
     ap.add_argument("--prof-every", type=int, default=PROF_EVERY_DEFAULT,
                     help="timed region: HIP event pair around the dominant kernel on every N-th tick (1 = every launch, as rounds 1-3 did)")
     ap.add_argument("--overlap-deferred", type=int, default=OVERLAP_DEFERRED_DEFAULT, choices=(0, 1),
@@ -326,7 +328,7 @@ def main():
     ctl = A.StaticGrid2DSpatialController(device=local_rank)
     err = ctl.LoadConfig(json.dumps(cfg).encode(), strict=False, **({"Damping": [(0xFFFFFFFF, args.flat_interval_ms)]} if args.flat_interval_ms else {}))
     assert err is None, err
-    world_flags = {"auto": 0, "conn-major": 1, "cell-major": 2}[args.emit] | (4 if args.recipients else 0) | (8 if args.wire else 0) | (16 if args.overlap_interest else 0) | (32 if args.update_masks else 0) | (256 if args.overlap_deferred else 0)
+    world_flags = {"auto": 0, "conn-major": 1, "cell-major": 2}[args.emit] | (4 if args.recipients else 0) | (8 if args.wire else 0) | (16 if args.overlap_interest else 0) | (32 if args.update_masks else 0) | (256 if args.overlap_deferred else 0) | (512 if args.overlap_interest and args.gated_overlap else 0)
     # successive ticks pipelined over two streams (include/chd_spatial.h: CHD_WORLD_PIPELINE_TICKS) where the descriptor emit runs
     pipe = not args.serial_ticks and args.emit != "cell-major" and not args.wire and not args.update_masks and S >= 4096 and not args.arrival_jitter
     if pipe:
@@ -571,7 +573,8 @@ def main():
                                 "every tick does all of its work inside the timed region, results equal the serial schedule's (tests/test_gpu_fullsize.py)")
                                if head_pipe else ("serial: every tick's kernels in sequence on one stream (see pipelined_schedule for CHD_WORLD_PIPELINE_TICKS)"
                                                   + ("; the tick's interest updates run on a second stream beside its ingest + cell index and join before the plan "
-                                                     "(CHD_WORLD_OVERLAP_INTEREST)" if args.overlap_interest else "")
+                                                     "(CHD_WORLD_OVERLAP_INTEREST" + (", forked and joined by device-side flags: CHD_WORLD_GATED_OVERLAP" if args.gated_overlap else "")
+                                                     + ")" if args.overlap_interest else "")
                                                   + ("; the tick's small filtering launch and its epilogue run beside the record kernel on a second stream and join "
                                                      "before the tick ends (CHD_WORLD_OVERLAP_DEFERRED)" if args.overlap_deferred else ""))},
         "p50_tick_ms": float(np.percentile(lat, 50)), "p99_tick_ms": float(np.percentile(lat, 99)),
@@ -672,7 +675,7 @@ def flat_interval_line(A, synth, cfg, N, S, seed, args, local_rank, interval_ms,
         xs[t], zs[t], qs[t], now[t] = sw.x, sw.z, sw.queries(), sw.now_ns()
     dx, dz, dq = w.device_array(xs), w.device_array(zs), w.device_array(qs)
     w.set_profiling(steps)
-    w.set_profiling_scope(True, every=4 if args.prof_every > 1 else 1)
+    w.set_profiling_scope(True, every=3 if args.prof_every > 1 else 1)
 
     def tick(t):
         w.tick_device(int(now[t]), n_updates=N, d_upd_x=dx.at(t * N * 8), d_upd_z=dz.at(t * N * 8), n_queries=S, d_queries=dq.at(t * S * 128))
@@ -721,7 +724,7 @@ def arrival_jitter_line(A, synth, cfg, N, S, seed, args, local_rank, tick_jitter
         now[t], arr[t] = aj.next(sw.now_ns())
     dx, dz, dq, da = w.device_array(xs), w.device_array(zs), w.device_array(qs), w.device_array(arr)
     w.set_profiling(steps)
-    w.set_profiling_scope(True, every=4 if args.prof_every > 1 else 1)
+    w.set_profiling_scope(True, every=3 if args.prof_every > 1 else 1)
 
     def tick(t):
         w.tick_device(int(now[t]), n_updates=N, d_upd_x=dx.at(t * N * 8), d_upd_z=dz.at(t * N * 8), n_queries=S, d_queries=dq.at(t * S * 128),

@@ -92,6 +92,9 @@ struct World {
     void *grp_buf[4] = {nullptr, nullptr, nullptr, nullptr};  // device arrays behind WorldDev::grp_*
     bool plan_recipients = false;      // CHD_WORLD_HANDOVER_RECIPIENTS
     bool overlap_interest = false;     // CHD_WORLD_OVERLAP_INTEREST
+    bool gated = false;                // CHD_WORLD_GATED_OVERLAP: its fork / join as device-side flags (GateArgs)
+    unsigned long long *gate = nullptr;
+    unsigned long long gate_cnt[8] = {0, 0, 0, 0, 0, 0, 0, 0}, gate_top = 0, gate_epi = 0;
     bool overlap_deferred = false;     // CHD_WORLD_OVERLAP_DEFERRED
     // CHD_WORLD_PIPELINE_TICKS: everything the record-writing kernel reads (and the record buffer) exists twice, by tick parity
     bool pipe_alloc = false, pipe_on = false;
@@ -143,6 +146,7 @@ struct chd_ctx {
     // scratch for the stateless entry points and for chd_tick's staging
     DevBuf scratch[16];
     bool force_device = false;          // CHD_NO_HOST_FAST_PATH=1: small stateless calls go to the device too (tests, measurements)
+    bool gchain = false, gchain_prev = false;  // ... was a serial tick with gated overlap (CHD_WORLD_GATED_OVERLAP)
     bool chain = false, chain_prev = false;  // the previous call on this ctx was a pipelined tick (bind() shifts them)
     int prof_depth = 0;                 // 0 = off
     uint32_t prof_every = 1;            // CHD_PROF_RECORD_KERNEL_EVERY(n): that pair on every n-th tick only (the others record nothing)
@@ -199,6 +203,8 @@ int bind(chd_ctx *ctx) {
     // of this ctx in between) may start its stages while the previous tick's records are still being written
     ctx->chain_prev = ctx->chain;
     ctx->chain = false;
+    ctx->gchain_prev = ctx->gchain;
+    ctx->gchain = false;
     return CHD_OK;
 }
 
@@ -906,9 +912,17 @@ int chd_world_create(chd_ctx *ctx, const chd_world_cfg *cfg) {
     W.plan_recipients = (cfg->flags & CHD_WORLD_HANDOVER_RECIPIENTS) != 0;
     // CHD_WORLD_FORCE_FLAGS (tests): schedule-only flags OR-ed into every world of the process, so that the parity suite can be run on them
     uint32_t wflags = cfg->flags;
-    if (const char *e = getenv("CHD_WORLD_FORCE_FLAGS")) wflags |= (uint32_t)strtoul(e, nullptr, 0) & (CHD_WORLD_OVERLAP_INTEREST | CHD_WORLD_OVERLAP_DEFERRED);
+    if (const char *e = getenv("CHD_WORLD_FORCE_FLAGS")) wflags |= (uint32_t)strtoul(e, nullptr, 0) & (CHD_WORLD_OVERLAP_INTEREST | CHD_WORLD_OVERLAP_DEFERRED | CHD_WORLD_GATED_OVERLAP);
     W.overlap_interest = (wflags & CHD_WORLD_OVERLAP_INTEREST) != 0 && !cfg->history_depth;
     W.overlap_deferred = (wflags & CHD_WORLD_OVERLAP_DEFERRED) != 0 && !cfg->history_depth;
+    W.gated = W.overlap_interest && (wflags & CHD_WORLD_GATED_OVERLAP) != 0;
+    if (W.gated) {
+        TRY(walloc(ctx, &W.gate, 10 * 16));
+        bool holds = false;  // (the release protocol of the gates: workgroup b on XCD b % 8; else the event form stays)
+        if (xcc_mapping_holds(ctx->stream, (unsigned *)W.gate, &holds) != 0) return fail(ctx, CHD_E_HIP, "XCD mapping probe failed");
+        HIPCHK(hipMemsetAsync(W.gate, 0, sizeof(unsigned long long) * 10 * 16, ctx->stream));
+        W.gated = holds;
+    }
     {
         hipDeviceProp_t prop;
         HIPCHK(hipGetDeviceProperties(&prop, ctx->device));
@@ -1560,6 +1574,7 @@ static int tick_locked(chd_ctx *ctx, const chd_tick_in *in) {
     const bool fuse = front_on && front_fusable(ctx->g, d) && !W.plan_recipients && !in->n_cell_updates && in->n_update_rounds <= 1 &&
                       !d.deep_depth && in->n_queries > 0 && in->n_updates > 0;
     const bool overlap = !fuse && (W.overlap_interest || pipe) && !W.plan_recipients && in->n_queries > 0;
+    const bool gated = overlap && W.gated && !pipe && !(W.overlap_deferred && fanout_seg_path(d));
     // stage events: the serial schedule marks every stage boundary; the pipelined one only the begin and end of the stage
     // stream's work (a timed event between two small kernels costs ~5 us of idle stream) — stage_times() reports that
     // span as stage 0
@@ -1580,13 +1595,28 @@ static int tick_locked(chd_ctx *ctx, const chd_tick_in *in) {
     } else {
         if (overlap) {
             hipStream_t ax = pipe ? ctx->aux2_stream : ctx->aux_stream;
-            HIPCHK(hipEventRecord(ctx->ev_fork, bs));
-            HIPCHK(hipStreamWaitEvent(ax, ctx->ev_fork, 0));
+            // fork: the second stream starts after everything enqueued on this one so far — or, gated and directly behind a gated
+            // tick, after that tick's epilogue said so (no event on the tick's stream)
+            if (gated && ctx->gchain_prev) launch_gate_wait(ax, d, W.gate + GATE_EPI, W.gate_epi);
+            else {
+                HIPCHK(hipEventRecord(ctx->ev_fork, bs));
+                HIPCHK(hipStreamWaitEvent(ax, ctx->ev_fork, 0));
+            }
             if (prof_stages) HIPCHK(hipEventRecord(ev[CHD_N_STAGES + 1], ax));
+            GateArgs ga{};
+            if (gated) {
+                const uint32_t nb = aoi_interest_blocks(ctx->lim, d, in->n_queries);
+                ga.base = W.gate;
+                for (uint32_t k = 0; k < 8; k++) {
+                    if (k < nb) W.gate_cnt[k] += (nb - k + 7u) / 8u;
+                    ga.cnt_target[k] = W.gate_cnt[k];
+                }
+                W.gate_top += std::min(nb, 8u);
+            }
             launch_aoi_interest(ax, ctx->g, ctx->lim, d, in->queries, in->n_queries, in->query_sub, in->spot_x, in->spot_z,
-                                in->spot_dist, in->now_ns, r.cur_tick);
+                                in->spot_dist, in->now_ns, r.cur_tick, gated ? &ga : nullptr);
             if (prof_stages) HIPCHK(hipEventRecord(ev[CHD_N_STAGES + 2], ax));
-            HIPCHK(hipEventRecord(ctx->ev_join, ax));
+            if (!gated) HIPCHK(hipEventRecord(ctx->ev_join, ax));
         }
         {
             // one ingest launch per round of updates (a channel's r-th update of this tick: chd_tick_in.upd_round_off)
@@ -1614,7 +1644,8 @@ static int tick_locked(chd_ctx *ctx, const chd_tick_in *in) {
         if (d.wcol_on && fanout_seg_path(d)) launch_window_columns(bs, ctx->g, d);
         launch_cell_offsets(bs, ctx->g, d);
         if (prof_stages) HIPCHK(hipEventRecord(ev[2], bs));
-        if (overlap) HIPCHK(hipStreamWaitEvent(bs, ctx->ev_join, 0));
+        if (overlap && gated) launch_gate_wait(bs, d, W.gate + GATE_TOP, W.gate_top);  // join: every group of the interest launch complete
+        else if (overlap) HIPCHK(hipStreamWaitEvent(bs, ctx->ev_join, 0));
         else
             launch_aoi_interest(bs, ctx->g, ctx->lim, d, in->queries, in->n_queries, in->query_sub, in->spot_x, in->spot_z,
                                 in->spot_dist, in->now_ns, r.cur_tick);
@@ -1662,10 +1693,12 @@ static int tick_locked(chd_ctx *ctx, const chd_tick_in *in) {
         launch_fanout_emit_deferred(st, ctx->g, d, in->now_ns, r);
         launch_fanout_emit_deep(st, ctx->g, d, in->now_ns, r);
         if (prof_ends) HIPCHK(hipEventRecord(ev[5], st));
-        launch_tick_epilogue(st, d, r.cur_tick % TICK_RING, ctx->g.ncell);
+        if (W.gated) launch_tick_epilogue(st, d, r.cur_tick % TICK_RING, ctx->g.ncell, W.gate + GATE_EPI, ++W.gate_epi);
+        else launch_tick_epilogue(st, d, r.cur_tick % TICK_RING, ctx->g.ncell);
     }
     TRY(after_launch(ctx));
     ctx->chain = pipe;
+    ctx->gchain = W.gated && !pipe && !(W.overlap_deferred && fanout_seg_path(d));  // (this tick's epilogue raised the flag)
     W.last_nq = in->n_queries;
     W.ticked = true;
     W.wire_built = false;
@@ -2041,6 +2074,7 @@ int chd_tick(chd_ctx *ctx, const chd_tick_in *in, chd_tick_out *out) {
     // asynchronous).  Host-pointer ticks therefore always take the un-chained path: the stage stream waits for everything
     // enqueued on `stream` so far.  (chd_tick_device keeps the chained fast path: its inputs must be complete at call time.)
     ctx->chain_prev = false;
+    ctx->gchain_prev = false;
     TRY(tick_locked(ctx, &din));
     return fetch_locked(ctx, out);
 }

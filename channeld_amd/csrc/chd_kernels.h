@@ -428,10 +428,27 @@ void launch_aoi_stateless(hipStream_t st, DevGrid g, AoiLimits lim, const chd_ao
                           const uint32_t *spot_dist, uint32_t stride, uint32_t *cells,
                           uint32_t *dists, uint32_t *ivs, uint32_t *counts, int32_t *status, unsigned char *scratch);
 size_t aoi_scratch_bytes(AoiLimits lim);  // global scratch per query (long-lattice path)
+// CHD_WORLD_GATED_OVERLAP: the two cross-stream dependencies of a serial tick whose interest updates run on a second stream,
+// as device-side flags instead of HIP events (an event record idles the recording stream ~7 us, a cross-queue wait takes ~11 us
+// to resolve: profiles/r04t_tick_timeline_*.csv).  `base` = 10 counters on their own 128-byte lines: [0..7] arrivals of the
+// interest launch's workgroups by group (blockIdx & 7 = the XCD they are observed to run on), [8] groups complete, [9] ticks
+// whose epilogue has finished.  Counters only grow; `cnt_target[g]` = cumulative members of group g including this launch.
+struct GateArgs {
+    unsigned long long *base;
+    unsigned long long cnt_target[8];
+};
+#define GATE_TOP (8 * 16)
+#define GATE_EPI (9 * 16)
 void launch_aoi_interest(hipStream_t st, DevGrid g, AoiLimits lim, WorldDev w,
                          const chd_aoi_query *q, uint32_t nq, const uint32_t *q_sub,
                          const double *spot_x, const double *spot_z, const uint32_t *spot_dist,
-                         int64_t now_ns, uint32_t cur_tick);
+                         int64_t now_ns, uint32_t cur_tick, const GateArgs *gate = nullptr, uint32_t *n_blocks_out = nullptr);
+uint32_t aoi_interest_blocks(AoiLimits lim, const WorldDev &w, uint32_t nq);  // workgroups of that launch
+// do the workgroups of a launch with equal (id % 8) share an XCD here?  (what the gates' release protocol rests on; checked once per
+// world.  NOT checked per workgroup: s_getreg HW_REG_XCC_ID costs ~20 us per wave under load — a 40 us kernel took 217)
+int xcc_mapping_holds(hipStream_t st, unsigned *d_scratch /* >= 4 bytes */, bool *holds);
+// one wave that returns when *p >= target (bounded: a dependency that never resolves flags overflow bit 0x8000 instead of hanging)
+void launch_gate_wait(hipStream_t st, WorldDev w, const unsigned long long *p, unsigned long long target);
 size_t aoi_lds_bytes(AoiLimits lim, uint32_t capq);
 size_t aoi_lds_limit();  // the most dynamic LDS an AOI launch may ask for (gfx950: 160 KiB per CU)
 // compaction of the fixed-stride stateless output into CSR
@@ -533,4 +550,4 @@ void launch_cell_offsets(hipStream_t st, DevGrid g, WorldDev w);
 // subscriptions the tick-ring masks cannot answer (PF_DEEP), from the exact update buffers; no-op without history_depth
 void launch_fanout_emit_deep(hipStream_t st, DevGrid g, WorldDev w, int64_t now_ns, TickRing ring);
 #define TICK_RING 1024
-void launch_tick_epilogue(hipStream_t st, WorldDev w, uint32_t slot, uint32_t ncell);
+void launch_tick_epilogue(hipStream_t st, WorldDev w, uint32_t slot, uint32_t ncell, unsigned long long *epi = nullptr, unsigned long long epi_seq = 0);

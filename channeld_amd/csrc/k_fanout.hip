@@ -2778,7 +2778,7 @@ void launch_fanout_emit_deep(hipStream_t st, DevGrid g, WorldDev w, int64_t now_
 // Per-tick totals into the device-side history ring (read back by chd_tick_fetch /
 // chd_get_tick_history), then the per-tick counters are cleared for the next tick.
 static_assert(CHD_LIST_BANKS == 64, "one epilogue lane per list bank");
-__global__ void __launch_bounds__(64) k_tick_epilogue(WorldDev w, uint32_t slot, uint32_t ncell) {
+__global__ void __launch_bounds__(64) k_tick_epilogue(WorldDev w, uint32_t slot, uint32_t ncell, unsigned long long *epi, unsigned long long epi_seq) {
     const uint32_t lane = threadIdx.x;
     if (w.deep_depth)  // (set again by the next tick's index build)
         for (uint32_t c = lane; c < ncell; c += 64) w.cell_irr[c] = 0;
@@ -2825,8 +2825,17 @@ __global__ void __launch_bounds__(64) k_tick_epilogue(WorldDev w, uint32_t slot,
     w.tot64[(size_t)lane * 16 + 2] = 0;
     w.tot64[(size_t)lane * 16 + 3] = 0;
     w.tot64[(size_t)lane * 16 + 4] = 0;
+    if (epi) {
+        // CHD_WORLD_GATED_OVERLAP: the tick is over, and says so to the second stream's gate (the next tick's interest updates)
+        __syncthreads();
+        if (lane == 0) {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __hip_atomic_store(epi, epi_seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
 }
 
-void launch_tick_epilogue(hipStream_t st, WorldDev w, uint32_t slot, uint32_t ncell) {
-    hipLaunchKernelGGL(k_tick_epilogue, dim3(1), dim3(64), 0, st, w, slot, ncell);
+void launch_tick_epilogue(hipStream_t st, WorldDev w, uint32_t slot, uint32_t ncell, unsigned long long *epi, unsigned long long epi_seq) {
+    hipLaunchKernelGGL(k_tick_epilogue, dim3(1), dim3(64), 0, st, w, slot, ncell, epi, epi_seq);
 }

@@ -232,6 +232,15 @@ typedef struct {
  * filtering launch is long and whose record kernel is not the bound.  Takes effect where the descriptor-driven connection-major
  * emit runs and the world keeps no exact update buffers (history_depth); ignored elsewhere, and by pipelined ticks. */
 #define CHD_WORLD_OVERLAP_DEFERRED 256u
+/* With CHD_WORLD_OVERLAP_INTEREST on the serial schedule: the two dependencies between the tick's stream and the second one —
+ * "the interest updates start after the previous tick", "the plan starts after the interest updates" — as device-side flags
+ * (one spinning wave each) instead of HIP events: recording an event idles the tick's stream for ~7 us and a cross-queue wait
+ * takes ~11 us to resolve, which together cost half of what the overlap saves.  Results unchanged.  As with
+ * CHD_WORLD_PIPELINE_TICKS the inputs of chd_tick_device must be COMPLETE when the call is made (the second stream no longer
+ * waits for work the caller enqueued on the tick's stream before the call); chd_tick (host pointers) and the first tick after
+ * any other call on the context take the event form by themselves.  A flag that never resolves (a bug, never a capacity)
+ * raises overflow bit 0x8000 after a bounded spin instead of hanging the queue. */
+#define CHD_WORLD_GATED_OVERLAP 512u
 
 #define CHD_ENTITY_LOCKED 1u /* member of a non-empty lock group (entity.go:197-224) */
 

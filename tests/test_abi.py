@@ -136,7 +136,7 @@ def test_binding_constants_match_the_header(tmp_path):
         "CHD_WORLD_HANDOVER_RECIPIENTS": _lib.WORLD_HANDOVER_RECIPIENTS, "CHD_WORLD_WIRE": _lib.WORLD_WIRE,
         "CHD_WORLD_OVERLAP_INTEREST": _lib.WORLD_OVERLAP_INTEREST, "CHD_WORLD_UPDATE_MASKS": _lib.WORLD_UPDATE_MASKS,
         "CHD_WORLD_ONE_WAVE_EMIT": _lib.WORLD_ONE_WAVE_EMIT, "CHD_WORLD_PIPELINE_TICKS": _lib.WORLD_PIPELINE_TICKS,
-        "CHD_WORLD_OVERLAP_DEFERRED": _lib.WORLD_OVERLAP_DEFERRED,
+        "CHD_WORLD_OVERLAP_DEFERRED": _lib.WORLD_OVERLAP_DEFERRED, "CHD_WORLD_GATED_OVERLAP": _lib.WORLD_GATED_OVERLAP,
         "CHD_WIRE_ENTITY_UPDATE": _lib.WIRE_ENTITY_UPDATE, "CHD_WIRE_ENTITY_FULL": _lib.WIRE_ENTITY_FULL, "CHD_WIRE_CELL_UPDATE": _lib.WIRE_CELL_UPDATE,
         "CHD_WIRE_CELL_FULL": _lib.WIRE_CELL_FULL, "CHD_WIRE_ENTITY_OBJREF": _lib.WIRE_ENTITY_OBJREF,
         "CHD_HO_SRC_ONLY": _lib.HO_SRC_ONLY, "CHD_HO_DST_NEW": _lib.HO_DST_NEW, "CHD_HO_DST_KNOWN": _lib.HO_DST_KNOWN,

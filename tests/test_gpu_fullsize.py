@@ -458,3 +458,36 @@ def test_config_b_arrival_stamps_at_enqueue_time_record_digests(amd, tick_jitter
     assert deep == 0, (deep, filt, total)
     # on the tick grid only the 20 ms subscriptions' windows cut through a tick's arrivals; off the grid every window does
     assert filt > (0.4 * total if tick_jitter_us else 0.01 * total), (filt, total)
+
+
+def test_config_b_gated_overlap_back_to_back_device_ticks_equal_the_oracle_list(amd):
+    """CHD_WORLD_OVERLAP_INTEREST | CHD_WORLD_GATED_OVERLAP — the bench's serial schedule: the interest updates on a second stream,
+    forked and joined by device-side flags instead of HIP events.  Config B (the bench's seed) as the bench drives it: groups of
+    back-to-back chd_tick_device calls on inputs resident in HBM (nothing else asked of the context in between: the gated fork),
+    every group's LAST tick digested — a wrong join or fork of any tick of the group changes the subscription state that tick
+    sees — against the CPU oracle's committed list (tests/golden/bench_digests_B.json).  A group that follows the digest call
+    starts with the event form, the others with the flag form."""
+    from channeld_amd import _lib
+
+    N, S, seed, groups, per = 100_000, 10_000, 0xC0FFEE01, 6, 5
+    with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "bench_digests_B.json")) as f:
+        golden = json.load(f)["ticks"]
+    cfg, sw, ctl, w = build(amd, N, S, seed, max_records=200_000_000, flags=_lib.WORLD_OVERLAP_INTEREST | _lib.WORLD_GATED_OVERLAP)
+    T = groups * per
+    xs = np.empty((T, N)); zs = np.empty((T, N)); qs = np.empty((T, S), dtype=synth.AOI_DTYPE); now = np.empty(T, dtype=np.int64)
+    for t in range(T):
+        sw.step()
+        xs[t], zs[t], qs[t], now[t] = sw.x, sw.z, sw.queries(), sw.now_ns()
+    dx, dz, dq = w.device_array(xs), w.device_array(zs), w.device_array(qs)
+    w.sync()
+    total = 0
+    for gi in range(groups):
+        for t in range(gi * per, (gi + 1) * per):
+            w.tick_device(int(now[t]), n_updates=N, d_upd_x=dx.at(t * N * 8), d_upd_z=dz.at(t * N * 8), n_queries=S, d_queries=dq.at(t * S * 128))
+        (cnt, dsum, dxor, _), _ = w.digest(per_connection=False)
+        assert [cnt, dsum, dxor] == golden[str((gi + 1) * per)], f"tick {(gi + 1) * per}: digest {[cnt, dsum, dxor]} != the oracle's {golden[str((gi + 1) * per)]}"
+        res = w.fetch()
+        assert res.overflow == 0 and res.history_overflow == 0
+        total += cnt
+    assert total > 300_000_000
+    ctl.close()
