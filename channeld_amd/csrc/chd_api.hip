@@ -1640,11 +1640,13 @@ static int tick_locked(chd_ctx *ctx, const chd_tick_in *in) {
             launch_handover_recipients_fill(bs, ctx->g, d, W.ho_rcp_off, W.ho_rcp_conn, W.ho_rcp_kind, W.ho_rcp_mask, W.ho_rcp_cap);
         }
         if (prof_stages) HIPCHK(hipEventRecord(ev[1], bs));
-        launch_index_build(bs, ctx->g, d, r.cur_tick);
+        const bool gate_in_index = launch_index_build(bs, ctx->g, d, r.cur_tick, (overlap && gated) ? W.gate + GATE_TOP : nullptr, W.gate_top);
         if (d.wcol_on && fanout_seg_path(d)) launch_window_columns(bs, ctx->g, d);
         launch_cell_offsets(bs, ctx->g, d);
         if (prof_stages) HIPCHK(hipEventRecord(ev[2], bs));
-        if (overlap && gated) launch_gate_wait(bs, d, W.gate + GATE_TOP, W.gate_top);  // join: every group of the interest launch complete
+        if (overlap && gated) {  // join: every group of the interest launch complete (the index build's last launch waited for it where it could)
+            if (!gate_in_index) launch_gate_wait(bs, d, W.gate + GATE_TOP, W.gate_top);
+        }
         else if (overlap) HIPCHK(hipStreamWaitEvent(bs, ctx->ev_join, 0));
         else
             launch_aoi_interest(bs, ctx->g, ctx->lim, d, in->queries, in->n_queries, in->query_sub, in->spot_x, in->spot_z,

@@ -402,7 +402,8 @@ void launch_halo_pack(hipStream_t st, DevGrid g, WorldDev w, uint32_t rank, uint
 void launch_halo_unpack(hipStream_t st, DevGrid g, WorldDev w, uint32_t rank, uint32_t world, uint32_t halo, const unsigned char *recv,
                         const uint64_t *seg_off, const uint32_t *ghost_off);
 // K2: cell index build
-void launch_index_build(hipStream_t st, DevGrid g, WorldDev w, uint32_t cur_tick);
+bool launch_index_build(hipStream_t st, DevGrid g, WorldDev w, uint32_t cur_tick, const unsigned long long *gate_p = nullptr,
+                        unsigned long long gate_target = 0);
 // K1 + K2 + K3/K4 in ONE launch (k_front.hip): the ingest -> index chain beside the interest updates.  launch_seq = 1, 2, ...
 // (how many times this world has taken the fused launch: the grid-barrier counters only grow).
 struct AoiLimits;

@@ -268,10 +268,21 @@ __device__ __forceinline__ void index_scatter_block(const WorldDev &w, uint32_t 
     }
 }
 
+// gate_p != nullptr (CHD_WORLD_GATED_OVERLAP): the launch also holds the tick's stream until *gate_p >= gate_target — the
+// interest updates on the second stream are complete (GateArgs) — by keeping workgroup 0 alive: what follows on the stream (the
+// fan-out plan) needs both the index and the subscriptions, and a separate one-wave wait kernel costs ~5 us of launch.
 __global__ void __launch_bounds__(IDX_BLOCK) k_index_scatter(WorldDev w, uint32_t ncell, uint32_t key_bits,
-                                                             uint32_t cur_tick, int local_base) {
+                                                             uint32_t cur_tick, int local_base, const unsigned long long *gate_p,
+                                                             unsigned long long gate_target) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     index_scatter_block(w, ncell, key_bits, cur_tick, local_base, blockIdx.x, smem);
+    if (gate_p && blockIdx.x == 0 && threadIdx.x == 0) {
+        uint32_t spins = 0;
+        while (__hip_atomic_load(gate_p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < gate_target) {
+            __builtin_amdgcn_s_sleep(2);
+            if (++spins > (1u << 23)) { atomicOr(&w.counters[CTR_OVERFLOW], OVF_INTERNAL); break; }  // (a bug, never a capacity)
+        }
+    }
 }
 
 // fallback for grids too large for the LDS counters: global atomics, the order
@@ -480,14 +491,16 @@ static uint32_t bits_for(uint32_t ncell) {
     return b ? b : 1;
 }
 
-void launch_index_build(hipStream_t st, DevGrid g, WorldDev w, uint32_t cur_tick) {
-    if (!w.N) return;
+// returns true when the launch took the gate wait with it (k_index_scatter)
+bool launch_index_build(hipStream_t st, DevGrid g, WorldDev w, uint32_t cur_tick, const unsigned long long *gate_p, unsigned long long gate_target) {
+    if (!w.N) return false;
     if (g.ncell <= IDX_MAX_LDS_CELLS) {
         hipLaunchKernelGGL(k_index_hist, dim3(w.nblk), dim3(IDX_BLOCK), 4 * g.ncell * 4, st, w, g.ncell, cur_tick);
         const int local_base = g.ncell <= 1024;
         hipLaunchKernelGGL(k_index_scan, dim3((g.ncell + 3) / 4), dim3(256), 0, st, w, g.ncell, !local_base);
         hipLaunchKernelGGL(k_index_scatter, dim3(w.nblk), dim3(IDX_BLOCK), (local_base ? 5 : 4) * g.ncell * 4, st, w,
-                           g.ncell, bits_for(g.ncell), cur_tick, local_base);
+                           g.ncell, bits_for(g.ncell), cur_tick, local_base, gate_p, gate_target);
+        return gate_p != nullptr;
     } else {
         // nblk == 1 layout: blk_cnt[c] then scan -> cell_off; cursor lives behind it
         uint32_t *cursor = w.blk_cnt + (size_t)g.ncell + 1;
@@ -502,4 +515,5 @@ void launch_index_build(hipStream_t st, DevGrid g, WorldDev w, uint32_t cur_tick
         hipLaunchKernelGGL(k_index_scatter_global, dim3((w.N + 255) / 256), dim3(256), 0, st, w, g.ncell, cursor,
                            cur_tick);
     }
+    return false;
 }
