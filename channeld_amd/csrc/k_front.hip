@@ -19,12 +19,14 @@
 #define FRONT_QUERIES_PER_BLOCK 4u
 
 // Barrier among the first `nb` workgroups of the grid, XCD-hierarchical (MI355X_MICROARCH.md, price list: barrier-xcd ~4-5 us
-// against 9-17 us for one flat counter with two __threadfence()): workgroup b belongs to group b % 8 — where it is observed
-// to run, XCD b % 8 — ; the LAST arriver of a group does ONE agent-scope release for it (buffer_wbl2 writes back the whole
-// XCD's L2), arrives on the top counter, waits for the other groups, acquires, and opens the group's generation; everybody
-// else polls that generation (relaxed sc1 loads) and then does its own agent-scope acquire.  The placement is only a speed
-// assumption: a workgroup that finds itself on another XCD than its group's (HW_REG_XCC_ID) releases its own L2 before it
-// arrives.  Counters only grow (`seq` = 1, 2, 3, ... over all barriers of all launches): no reset pass.  Spins are bounded:
+// against 9-17 us for one flat counter with two __threadfence()): workgroup b belongs to group b % 8 — the workgroups of a
+// dispatch are dealt round-robin over the 8 XCDs, so a group shares ONE XCD (which one depends on where the queue's previous
+// dispatch stopped; tools/ubench/xcc_map.hip) — ; the LAST arriver of a group does ONE agent-scope release for it (buffer_wbl2
+// writes back the whole XCD's L2), arrives on the top counter, waits for the other groups, acquires, and opens the group's
+// generation; everybody else polls that generation (relaxed sc1 loads) and then does its own agent-scope acquire.  (Round 3
+// read HW_REG_XCC_ID here to check the placement: that s_getreg costs ~20 us per wave under load and compared against the
+// wrong thing — the offset of the round-robin is not 0 — so every workgroup flushed its L2 at every barrier; removed in round
+// 4.)  Counters only grow (`seq` = 1, 2, 3, ... over all barriers of all launches): no reset pass.  Spins are bounded:
 // if the other workgroups never arrive (they cannot all be resident: a bug in the launch condition) the tick is flagged
 // (overflow bit 0x8000) and goes on with whatever is there rather than hanging the GPU.
 struct FrontBar {  // all fields on their own 128-byte lines
@@ -45,11 +47,6 @@ __device__ __forceinline__ void front_barrier(const WorldDev &w, FrontBar *fb, u
     if (threadIdx.x == 0) {
         const uint32_t grp = blockIdx.x & 7u;
         const uint32_t members = (nb - grp + 7u) / 8u, ngroups = nb < 8u ? nb : 8u;
-        const uint32_t xcc = __builtin_amdgcn_s_getreg((20 /* HW_REG_XCC_ID */) | (0 << 6) | ((4 - 1) << 11)) & 7u;
-        if (xcc != grp) {  // not where the group's leader will flush: write our XCD's L2 back ourselves
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        }
         const unsigned long long arrived = __hip_atomic_fetch_add(&fb->cnt[grp][0], 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1ull;
         if (arrived == (unsigned long long)members * seq) {
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
