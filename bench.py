@@ -40,6 +40,57 @@ OVERLAP_INTEREST_DEFAULT = 1
 # throughput regions take the HIP event pair around the dominant kernel on every n-th tick (CHD_PROF_RECORD_KERNEL_EVERY): each event idles
 # the stream for ~7 us beside the kernel (profiles/r04t_tick_timeline_*.csv), 14 us of a 255 us tick if every launch were timed
 PROF_EVERY_DEFAULT = 7  # (odd: the workload alternates between ticks of ~100 M and ~60 M messages — 100 ms subscriptions fire every other 50 ms tick)
+class GpuStateSampler:
+    """Clocks / power / temperature of the GPU beside a timed region: a thread reads the amdgpu hwmon files every
+    10 ms — freq1_input = sclk, power1_input = socket power, temp*_input — of the first card that exposes them.  Box-to-box spread
+    of a line (the pool's boxes differ by a few percent) can then be told from a change in the code."""
+
+    def __init__(self):
+        import glob
+        import threading
+
+        self.dir = None
+        for d in sorted(glob.glob("/sys/class/drm/card*/device/hwmon/hwmon*")):
+            if os.path.exists(os.path.join(d, "power1_input")) and os.path.exists(os.path.join(d, "freq1_input")):
+                self.dir = d
+                break
+        self.samples, self._stop, self._th = [], threading.Event(), None
+
+    def _read(self, name):
+        try:
+            with open(os.path.join(self.dir, name)) as f:
+                return float(f.read().strip())
+        except (OSError, ValueError):
+            return float("nan")
+
+    def _run(self):
+        while not self._stop.is_set():
+            self.samples.append((self._read("freq1_input") / 1e6, self._read("freq2_input") / 1e6, self._read("power1_input") / 1e6,
+                                 self._read("temp2_input") / 1e3))
+            self._stop.wait(0.01)
+
+    def __enter__(self):
+        import threading
+
+        if self.dir:
+            self._th = threading.Thread(target=self._run, daemon=True)
+            self._th.start()
+        return self
+
+    def __exit__(self, *a):
+        self._stop.set()
+        if self._th:
+            self._th.join()
+
+    def summary(self):
+        if not self.samples:
+            return None
+        a = np.array(self.samples)
+        f = lambda c: {"min": float(np.nanmin(a[:, c])), "mean": float(np.nanmean(a[:, c])), "max": float(np.nanmax(a[:, c]))}
+        return {"what": "amdgpu hwmon sampled every 10 ms beside the timed region", "samples": int(len(a)), "sclk_mhz": f(0), "mclk_mhz": f(1),
+                "socket_power_w": f(2), "temp_c": f(3)}
+
+
 DOMINANT = "k_fanout_emit_seg"  # the kernel the roofline object is about (rocprofv3 --kernel-trace name, template arguments dropped)
 
 
@@ -403,11 +454,12 @@ def main():
     for t in range(W):
         tick(t)
     torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for t in range(W, W + K):
-        tick(t)
-    torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
+    with GpuStateSampler() as gpu_state:
+        t0 = time.perf_counter()
+        for t in range(W, W + K):
+            tick(t)
+        torch.cuda.synchronize()
+        elapsed = time.perf_counter() - t0
 
     hist = world.history(min(K, 1024))
     msgs = sum(h["n_records"] for h in hist)
@@ -584,6 +636,7 @@ def main():
                         "committed per-tick list tests/golden/bench_digests_B.json = what the CPU ORACLE computes for this seeded world "
                         "(tests/golden/make_bench_digests.py, 701 ticks; the first 40 also through the literal forward buffer walk)",
         "stage_us_avg": {n: float(v) for n, v in zip(("ingest", "index", "interest", "plan", "emit"), stage_avg)},
+        "gpu_state": gpu_state.summary(),
         "stage_us_avg_is": "HIP events at every stage boundary of the latency-phase ticks (serial schedule, one synchronous tick at a time); the timed "
                            "region records only the pair around the dominant kernel (chd_set_profiling_scope)",
         "roofline": {"bound": "hbm", "kernel": dominant, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
