@@ -87,7 +87,7 @@ class GpuStateSampler:
             return None
         a = np.array(self.samples)
         f = lambda c: {"min": float(np.nanmin(a[:, c])), "mean": float(np.nanmean(a[:, c])), "max": float(np.nanmax(a[:, c]))}
-        return {"what": "amdgpu hwmon sampled every 10 ms beside the timed region", "samples": int(len(a)), "sclk_mhz": f(0), "mclk_mhz": f(1),
+        return {"what": "amdgpu hwmon (freq1 = sclk, freq2 = mclk, power1 = socket power, temp2) sampled every 10 ms from the start of the timed region to the end of the latency phase; the SMU reports averaged figures that lag a burst of a few hundred ms (an idle-state sclk beside 240 W means exactly that)", "samples": int(len(a)), "sclk_mhz": f(0), "mclk_mhz": f(1),
                 "socket_power_w": f(2), "temp_c": f(3)}
 
 
@@ -454,12 +454,13 @@ def main():
     for t in range(W):
         tick(t)
     torch.cuda.synchronize()
-    with GpuStateSampler() as gpu_state:
-        t0 = time.perf_counter()
-        for t in range(W, W + K):
-            tick(t)
-        torch.cuda.synchronize()
-        elapsed = time.perf_counter() - t0
+    gpu_state = GpuStateSampler()
+    gpu_state.__enter__()  # (until the latency phase ends: the timed region alone lasts ~50 ms, the SMU's figures move slower than that)
+    t0 = time.perf_counter()
+    for t in range(W, W + K):
+        tick(t)
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
 
     hist = world.history(min(K, 1024))
     msgs = sum(h["n_records"] for h in hist)
@@ -542,6 +543,7 @@ def main():
                 digests_checked += 1
     if args.write_digests:
         write_bench_digests(digests_out)
+    gpu_state.__exit__()
     lat = np.array(lat) if lat else np.array([0.0])
     lat_hist = world.history(min(L, 1024)) if L else []
     gpu_lat = np.array([h["total_us"] for h in lat_hist]) / 1e3 if L else np.array([0.0])
