@@ -448,7 +448,8 @@ def main():
     # (diagnostic configurations whose records mostly come from another kernel - per-record masks, partial updates, populous
     # cells - keep the stage events: their roofline line is about the whole emit stage)
     headline_like = args.update_frac >= 1.0 and not args.update_masks and args.emit != "cell-major" and N // max(ctl.GridCols * ctl.GridRows, 1) < 512 and not jitter
-    world.set_profiling_scope(headline_like, every=args.prof_every)
+    kernel_scope = headline_like or jitter  # (arrival stamps: the pair spans both record kernels, k_fanout_emit_seg + k_fanout_emit_filt_cm)
+    world.set_profiling_scope(kernel_scope, every=args.prof_every)
     if pipe and not head_pipe:
         world.set_pipelining(False)
     for t in range(W):
@@ -466,11 +467,14 @@ def main():
     msgs = sum(h["n_records"] for h in hist)
     # the dominant kernel alone (k_fanout_emit_seg; its own HIP event pair on the tick's stream) and the records IT wrote
     # (the few connections it defers are written by a second, small launch inside the same emit stage)
-    timed = [h for h in hist if h["emit_main_us"] > 0] if headline_like else hist  # (the sampled launches: --prof-every)
+    timed = [h for h in hist if h["emit_main_us"] > 0] if kernel_scope else hist  # (the sampled launches: --prof-every)
     emit_us = np.array([h["emit_main_us"] for h in timed])
     emit_msgs = np.array([h["n_records"] - h["n_deferred_records"] for h in timed], dtype=np.float64)
     dominant = DOMINANT
-    if not headline_like:
+    if jitter:
+        emit_msgs = np.array([h["n_records"] - h["n_deep_records"] for h in timed], dtype=np.float64)  # (as arrival_jitter_line counts them)
+        dominant = "k_fanout_emit_seg + k_fanout_emit_filt_cm (copy descriptors + filtered descriptors; one HIP event pair around both)"
+    elif not headline_like:
         emit_us = np.array([h["stage_us"][4] for h in hist])
         emit_msgs = np.array([h["n_records"] for h in hist], dtype=np.float64)
         dominant = "emit stage (all record-writing kernels of the tick; DIAGNOSTIC configuration)"
@@ -650,7 +654,7 @@ def main():
                      "timed_launches": int(len(emit_us)),
                      "timed_launches_are": (f"every {args.prof_every}-th launch of the timed region, its own HIP event pair on the stream it is launched on "
                                             "(each event idles the stream for ~7 us: timing every launch would lengthen every tick by 14 us)"
-                                            if headline_like and args.prof_every > 1 else "every launch of the timed region"),
+                                            if kernel_scope and args.prof_every > 1 else "every launch of the timed region"),
                      "emit_stage_us": float(stage_avg[4]), "deferred_msgs_per_tick": float(np.mean([h["n_deferred_records"] for h in hist]))},
     }
     out["roofline"]["whole_tick_frac"] = float(BYTES_PER_MSG * (msgs / K) / (elapsed / K) / 1e9 / HBM_PEAK_GBS)
@@ -766,7 +770,7 @@ def arrival_jitter_line(A, synth, cfg, N, S, seed, args, local_rank, tick_jitter
     ctl = A.StaticGrid2DSpatialController(device=local_rank)
     assert ctl.LoadConfig(json.dumps(cfg).encode(), strict=False) is None
     sw = synth.SynthWorld(synth.WorldSpec(cfg, N, S, seed, tick_ms=args.tick_ms, aoi_scale=args.aoi_scale))
-    w = A.SpatialWorld(ctl, N, S, max_records=400_000_000, history_depth=1024)
+    w = A.SpatialWorld(ctl, N, S, max_records=400_000_000, history_depth=1024, flags=(16 if args.overlap_interest else 0) | (512 if args.overlap_interest and args.gated_overlap else 0))
     w.spawn(None, sw.chan_id, sw.x, sw.z, sw.flags, sw.sender)
     w.add_subscribers(None, sw.sub_conn)
     T = warm + steps + check

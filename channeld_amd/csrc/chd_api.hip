@@ -913,7 +913,7 @@ int chd_world_create(chd_ctx *ctx, const chd_world_cfg *cfg) {
     // CHD_WORLD_FORCE_FLAGS (tests): schedule-only flags OR-ed into every world of the process, so that the parity suite can be run on them
     uint32_t wflags = cfg->flags;
     if (const char *e = getenv("CHD_WORLD_FORCE_FLAGS")) wflags |= (uint32_t)strtoul(e, nullptr, 0) & (CHD_WORLD_OVERLAP_INTEREST | CHD_WORLD_OVERLAP_DEFERRED | CHD_WORLD_GATED_OVERLAP);
-    W.overlap_interest = (wflags & CHD_WORLD_OVERLAP_INTEREST) != 0 && !cfg->history_depth;
+    W.overlap_interest = (wflags & CHD_WORLD_OVERLAP_INTEREST) != 0;  // (exact update buffers: WorldDev::max_iv is double-buffered for this)
     W.overlap_deferred = (wflags & CHD_WORLD_OVERLAP_DEFERRED) != 0 && !cfg->history_depth;
     W.gated = W.overlap_interest && (wflags & CHD_WORLD_GATED_OVERLAP) != 0;
     if (W.gated) {
@@ -1055,7 +1055,7 @@ int chd_world_create(chd_ctx *ctx, const chd_world_cfg *cfg) {
         TRY(walloc(ctx, &d.cdeep_drop, C, false));
         TRY(walloc(ctx, &d.cell_irr_tick, C));
         TRY(walloc(ctx, &d.cell_irr, C));
-        TRY(walloc(ctx, &d.max_iv, 1));
+        TRY(walloc(ctx, &d.max_iv, 2));
         TRY(walloc(ctx, &d.conn_deep, S));
         TRY(walloc(ctx, &d.ce_slot, N + 2));
         // drop = INT64_MIN ("nothing was ever dropped"): the byte pattern 0x80 repeated is a very negative int64 as well

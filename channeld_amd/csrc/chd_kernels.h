@@ -80,7 +80,7 @@ struct WorldDev {
     int64_t *deep_a, *cdeep_a, *deep_drop, *cdeep_drop;
     uint32_t *deep_s, *cdeep_s, *deep_n, *cdeep_n, *deep_len, *cdeep_len, *irr_tick, *cell_irr_tick;
     uint32_t *cell_irr;
-    uint32_t *max_iv;
+    uint32_t *max_iv;  // [2]: [0] what this tick's updates are buffered under, [1] raised by this tick's interest updates (folded into [0] by the epilogue: the interest updates may then run beside the ingest)
     uint32_t *conn_deep;  // [S] this tick: the connection has PF_DEEP subscriptions
     // SUB-TICK ARRIVAL OFFSETS (off_on: worlds with exact update buffers on the descriptor path).  The reference stamps an
     // update when it is ENQUEUED (Channel.PutMessage: arrivalTime = ch.GetTime(), channel.go:296-310), so a tick's updates

@@ -304,7 +304,7 @@ __global__ void __launch_bounds__(64) k_subs_set_options(DevGrid g, WorldDev w, 
                 if (o.set & CHD_SUBOPT_FIELD_MASK) fl = (fl & ~(0xFFu << PF_FIELD_MASK_SHIFT)) | ((o.data_field_mask & 0xFFu) << PF_FIELD_MASK_SHIFT);
                 w.pair_flags[pbase + pos] = fl;
                 if (o.set & CHD_SUBOPT_INTERVAL) w.pair_iv[pbase + pos] = o.fanout_interval_ms;
-                if (w.deep_depth && w.pair_iv[pbase + pos] > *w.max_iv) atomicMax(w.max_iv, w.pair_iv[pbase + pos]);
+                if (w.deep_depth && w.pair_iv[pbase + pos] > w.max_iv[1]) { atomicMax(w.max_iv, w.pair_iv[pbase + pos]); atomicMax(w.max_iv + 1, w.pair_iv[pbase + pos]); }
                 should_send[i] = acc != acc_old ? 1 : 0;  // dataAccessChanged
                 status[i] = CHD_OK;
             }
@@ -335,7 +335,7 @@ __global__ void __launch_bounds__(64) k_subs_set_options(DevGrid g, WorldDev w, 
             const int32_t delay = (o.set & CHD_SUBOPT_DELAY) ? o.fanout_delay_ms : g.default_delay_ms;
             w.pair_cell[pbase + pos] = c;
             w.pair_iv[pbase + pos] = (o.set & CHD_SUBOPT_INTERVAL) ? o.fanout_interval_ms : g.default_interval_ms;
-            if (w.deep_depth && w.pair_iv[pbase + pos] > *w.max_iv) atomicMax(w.max_iv, w.pair_iv[pbase + pos]);
+            if (w.deep_depth && w.pair_iv[pbase + pos] > w.max_iv[1]) { atomicMax(w.max_iv, w.pair_iv[pbase + pos]); atomicMax(w.max_iv + 1, w.pair_iv[pbase + pos]); }
             w.pair_last[pbase + pos] = now_ns + (int64_t)delay * 1000000;
             w.pair_flags[pbase + pos] = (acc == 0 ? PF_NO_ACCESS : acc == 2 ? PF_WRITE : 0u) | (skip_self ? PF_SKIP_SELF : 0u) |
                                         (skip_first ? PF_HAD_FIRST : 0u) |

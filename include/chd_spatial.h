@@ -197,9 +197,10 @@ typedef struct {
 /* keep what chd_wire_build needs: which channel table entry every fan-out record came from (+4 B per record) */
 #define CHD_WORLD_WIRE 8u
 /* run the interest updates on a second HIP stream, concurrently with the entity ingest and the cell index build
- * (they touch disjoint state: subscriptions vs entities), joining before the fan-out plan.  Off by default: at
- * BASELINE config B the two cross-stream dependencies cost what the overlap saves (0.3145 vs 0.3123 ms per tick);
- * it pays when the interest stage is long (many / large AOI queries).  Ignored with CHD_WORLD_HANDOVER_RECIPIENTS. */
+ * (they touch disjoint state: subscriptions vs entities; on worlds with exact update buffers maxFanOutIntervalMs is kept
+ * twice so that the tick's updates are buffered under the value from before the tick's interest updates, as in the serial
+ * order), joining before the fan-out plan.  At BASELINE config B: -3 % per tick with the dependencies as HIP events, -9 % with
+ * CHD_WORLD_GATED_OVERLAP.  Ignored with CHD_WORLD_HANDOVER_RECIPIENTS. */
 #define CHD_WORLD_OVERLAP_INTEREST 16u
 /* also say, per fan-out record, WHICH buffered updates the message merges (chd_tick_out.record_masks): the selection
  * of data.go:225-269 — arrival inside the subscription's window and, with SkipSelfUpdateFanOut, sender != connection —
