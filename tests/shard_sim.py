@@ -35,6 +35,7 @@ class SimShardEngine:
         self.table_words = 4 * max_entities + self.ncell + 1
         self.table_words += (-self.table_words) % 4
         self.table_bytes = 4 * self.table_words
+        self.lists, self.lists_on, self.locked_aborts, self.n_requests = {}, False, 0, 0
 
     def halo_splits(self):
         """This stand-in ships its whole cell table to every rank (the schedule and the split-size plumbing of dist.py are
@@ -57,6 +58,63 @@ class SimShardEngine:
     def add_subscribers(self, conn_ids):
         self.subs = [int(c) for c in conn_ids]
 
+    # ---- handover lists keyed by entity channel id (chd_shard_set_handover_lists): the protocol of k_shard.hip in numpy ----
+    REQ_CAP = 64
+
+    def set_handover_lists(self, lists):
+        """lists: {entity channel id: [member channel ids]} — the whole world's, the same on every rank"""
+        self.lists = {int(k): [int(m) for m in v] for k, v in lists.items()}
+        self.lists_on = True
+        self.locked_aborts = 0
+
+    def ingest_pre(self, now_ns, x_by_chan, z_by_chan, has_update=None):
+        x, z = np.asarray(x_by_chan), np.asarray(z_by_chan)
+        k = (self.chan - EID0).astype(np.int64)
+        dst = self._cells(x[k], z[k])
+        src = self.cell.copy()
+        self.cell = dst
+        cross = (src != INVALID) & (dst != INVALID) & (src != dst)
+        self.handovers, self.locked_aborts = [], 0
+        slot_of = {int(c): i for i, c in enumerate(self.chan)}
+        req = np.zeros((self.world, (self.REQ_CAP + 1) * 4), dtype=np.uint32)
+        for i in np.nonzero(cross)[0]:
+            ch = int(self.chan[i])
+            lst = self.lists.get(ch)
+            if (self.flags[i] & 1) or (lst is not None and len(lst) == 0):
+                self.locked_aborts += 1
+                continue
+            self.handovers.append((ch, int(src[i]), int(dst[i])))
+            if lst is None:
+                self.member[i] = dst[i]
+                continue
+            own = int(server_of_cell(self.cfg, np.array([src[i]]))[0])
+            if ch in lst:
+                self.member[i] = dst[i]
+            if own == self.rank or self.world == 1:
+                for m in lst:
+                    j = slot_of.get(m)
+                    if m != ch and j is not None and self.member[j] == src[i]:
+                        self.member[j] = dst[i]
+            else:  # src's entity map is another rank's: the handover travels there
+                n = int(req[own][0])
+                assert n < self.REQ_CAP
+                req[own][4 * (1 + n): 4 * (2 + n)] = (ch, src[i], dst[i], ch)
+                req[own][0] = n + 1
+                self.n_requests += 1
+        return torch.from_numpy(req.view(np.int32))
+
+    def ingest_post(self, req_recv):
+        r = req_recv.numpy().view(np.uint32)
+        slot_of = {int(c): i for i, c in enumerate(self.chan)}
+        for p in range(self.world):
+            for q in range(int(r[p][0])):
+                ch, s, d, _ = (int(v) for v in r[p][4 * (1 + q): 4 * (2 + q)])
+                for m in self.lists[ch]:
+                    j = slot_of.get(m)
+                    if m != ch and j is not None and self.member[j] == s:
+                        self.member[j] = d
+        return self._export()
+
     def ingest(self, now_ns, x_by_chan, z_by_chan, has_update=None):
         x = np.asarray(x_by_chan)
         z = np.asarray(z_by_chan)
@@ -68,7 +126,9 @@ class SimShardEngine:
         move = cross & ((self.flags & 1) == 0)
         self.handovers = [(int(c), int(s), int(d)) for c, s, d in zip(self.chan[move], src[move], dst[move])]
         self.member = np.where(move, dst, self.member)
-        # export
+        return self._export()
+
+    def _export(self):
         send = np.zeros((self.world, (self.cap + 1) * ENTITY_STATE_WORDS), dtype=np.int32)
         if self.world > 1:
             valid = self.member != INVALID

@@ -61,7 +61,7 @@ def world_inputs(cfg, N, S, ticks, seed, jump_frac=0.15, aoi_scale=1.0):
     return sw, x0, z0, frames
 
 
-def worker(rank, world, port, N, S, ticks, seed, out, cfg_name=None, halo=64, jump_frac=0.15, aoi_scale=1.0):
+def worker(rank, world, port, N, S, ticks, seed, out, cfg_name=None, halo=64, jump_frac=0.15, aoi_scale=1.0, lists=False):
     from oracle import pyoracle as orc
     from shard_sim import SimShardEngine
 
@@ -80,11 +80,21 @@ def worker(rank, world, port, N, S, ticks, seed, out, cfg_name=None, halo=64, ju
         eng.spawn(sw.chan_id[mine], x0[mine], z0[mine], sw.flags[mine])
         eng.add_subscribers(sw.sub_conn[my_subs])
         sworld = ShardedWorld(eng, Comm(rank, world))
+        hl = None
+        if lists:
+            from shard_lists import make_lists, one_handover_per_group_and_tick
+
+            hl, groups, _ = make_lists(sw, ids0, N, seed)
+            assert len(hl) > N // 20
+            frames = one_handover_per_group_and_tick(orc, g, groups, x0, z0, frames)
+            eng.set_handover_lists({e + 0x80000: [m + 0x80000 for m in v] for e, v in hl.items()})  # (every rank: the whole world's)
         # the single world, on rank 0 only
         ow = None
         if rank == 0:
             ow = orc.World(g, N, S, min(g.cols * g.rows, 256), 20, 0, literal=False)
             ow.spawn(np.arange(N), sw.chan_id, x0, z0, sw.flags, sw.sender)
+            for e, v in (hl or {}).items():
+                ow.set_handover_list(e, v)
             for s in range(S):
                 ow.add_sub(s, int(sw.sub_conn[s]))
         n_cross = 0
@@ -97,7 +107,7 @@ def worker(rank, world, port, N, S, ticks, seed, out, cfg_name=None, halo=64, ju
                 qb.append(b)
             sworld.tick(now, torch.from_numpy(x), torch.from_numpy(z), qb, len(qb))
             state = dict(chan=eng.chan.copy(), cell=eng.cell.copy(), member=eng.member.copy(), visible=eng.visible,
-                         handovers=eng.handovers)
+                         handovers=eng.handovers, locked=eng.locked_aborts, requests=getattr(eng, "n_requests", 0))
             gathered = [None] * world
             dist.all_gather_object(gathered, state)
             if rank != 0:
@@ -115,6 +125,10 @@ def worker(rank, world, port, N, S, ticks, seed, out, cfg_name=None, halo=64, ju
             got = sorted(h for s in gathered for h in s["handovers"])
             want = sorted((int(sw.chan_id[e]), int(a) - 0x10000, int(b) - 0x10000) for e, a, b in zip(ent, src, dst))
             assert got == want, f"tick {k}: handovers"
+            if lists:
+                assert sum(s["locked"] for s in gathered) == ow.locked_aborts(), f"tick {k}: aborted handovers"
+                if k == len(frames) - 1:  # (the case the protocol exists for did occur: a handover whose src map is another rank's)
+                    assert sum(s["requests"] for s in gathered) > 0, "no handover ever concerned another rank's entity map"
             n_cross += int((ssrc != sdst).sum())
             # visible sets
             member_of = omember
@@ -141,6 +155,26 @@ def test_sharded_schedule_matches_single_world(world):
     out = ctx.Queue()
     port = free_port()
     procs = [ctx.Process(target=worker, args=(r, world, port, 600, 48, 6, 0xC0FFEE07, out)) for r in range(world)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(timeout=240)
+    status, info = out.get(timeout=5)
+    assert status == "ok", info
+    assert all(p.exitcode == 0 for p in procs)
+    assert info > 0, "the test world never crossed a region border"
+
+
+@pytest.mark.parametrize("world", [2, 4])
+def test_handover_lists_across_ranks_follow_the_request_protocol(world):
+    """chd_shard_set_handover_lists' protocol (k_shard.hip; include/chd_spatial.h: chd_shard_ingest_pre / _post) restated in
+    numpy on the stand-in engine: lists keyed by entity channel id on every rank, members in src's entity map follow, a handover
+    whose src map is another rank's travels there as a request before the export — against the single-world oracle with the same
+    lists (entity.go:197-224, spatial.go:675-736): every entity's (cell, member, rank), handovers, aborted handovers, visible sets."""
+    ctx = mp.get_context("spawn")
+    out = ctx.Queue()
+    port = free_port()
+    procs = [ctx.Process(target=worker, args=(r, world, port, 900, 32, 8, 0xC0FFEE31, out, None, 64, 0.15, 1.0, True)) for r in range(world)]
     for p in procs:
         p.start()
     for p in procs:
