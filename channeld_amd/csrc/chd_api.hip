@@ -1574,7 +1574,7 @@ static int tick_locked(chd_ctx *ctx, const chd_tick_in *in) {
     const bool fuse = front_on && front_fusable(ctx->g, d) && !W.plan_recipients && !in->n_cell_updates && in->n_update_rounds <= 1 &&
                       !d.deep_depth && in->n_queries > 0 && in->n_updates > 0;
     const bool overlap = !fuse && (W.overlap_interest || pipe) && !W.plan_recipients && in->n_queries > 0;
-    const bool gated = overlap && W.gated && !pipe && !(W.overlap_deferred && fanout_seg_path(d));
+    const bool gated = overlap && W.gated && (pipe || !(W.overlap_deferred && fanout_seg_path(d)));
     // stage events: the serial schedule marks every stage boundary; the pipelined one only the begin and end of the stage
     // stream's work (a timed event between two small kernels costs ~5 us of idle stream) — stage_times() reports that
     // span as stage 0
@@ -1665,7 +1665,8 @@ static int tick_locked(chd_ctx *ctx, const chd_tick_in *in) {
         if (prof_ends) HIPCHK(hipEventRecord(ev[5], st));
         HIPCHK(hipEventRecord(W.ev_emit_done[par], st));
         launch_fanout_emit_deferred(bs, ctx->g, d, in->now_ns, r);
-        launch_tick_epilogue(bs, d, r.cur_tick % TICK_RING, ctx->g.ncell);
+        if (W.gated) launch_tick_epilogue(bs, d, r.cur_tick % TICK_RING, ctx->g.ncell, W.gate + GATE_EPI, ++W.gate_epi);
+        else launch_tick_epilogue(bs, d, r.cur_tick % TICK_RING, ctx->g.ncell);
         if (prof_ends) HIPCHK(hipEventRecord(ev[4], bs));
         // ... and whatever is enqueued on `stream` after this tick comes after ALL of it
         HIPCHK(hipEventRecord(W.ev_stages_all, bs));
@@ -1700,7 +1701,7 @@ static int tick_locked(chd_ctx *ctx, const chd_tick_in *in) {
     }
     TRY(after_launch(ctx));
     ctx->chain = pipe;
-    ctx->gchain = W.gated && !pipe && !(W.overlap_deferred && fanout_seg_path(d));  // (this tick's epilogue raised the flag)
+    ctx->gchain = W.gated && (pipe || !(W.overlap_deferred && fanout_seg_path(d)));  // (this tick's epilogue raised the flag)
     W.last_nq = in->n_queries;
     W.ticked = true;
     W.wire_built = false;
