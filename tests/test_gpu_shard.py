@@ -284,12 +284,13 @@ def test_bench_verify_fails_loudly_on_a_wrong_world():
 
 
 def test_bench_config_d_on_its_four_servers_verified():
-    """BASELINE config 4 through bench.py --config D: spatial_static_4x4.json, 2x2 server regions = 4 ranks (populous cells:
-    the cell-major emit over region + halo), first ticks verified against the single world."""
-    r, d = shared_gpu_bench(4, ["--config", "D", "--steps", "3", "--warmup", "2", "--verify", "2", "--entities", "40000", "--subs", "600",
-                                "--max-records", "30000000"])
+    """BASELINE config 4 AT ITS STATED SIZE through bench.py --config D: spatial_static_4x4.json, 100 000 entities / 10 000
+    subscribers, 2x2 server regions = 4 ranks (sharing the test box's one GPU; populous cells: the cell-major emit over region +
+    halo), the first ticks verified against the single world — ~0.45 G fan-out records per tick summed over the ranks."""
+    r, d = shared_gpu_bench(4, ["--config", "D", "--steps", "3", "--warmup", "2", "--verify", "2", "--max-records", "400000000"])
     assert r.returncode == 0, r.stderr[-3000:]
     assert d["verified_ticks"] == 2 and d["n_gpus"] == 4 and "spatial_static_4x4.json" in d["config"]["workload"]
+    assert "100000 entities / 10000 subs" in d["config"]["workload"] and max(d["verified"]["msgs_per_verified_tick"]) > 250_000_000
 
 
 def test_bench_config_e_on_its_eight_servers_verified():
