@@ -1275,7 +1275,7 @@ int chd_world_set_entity_groups(chd_ctx *ctx, uint32_t n, const uint32_t *idx, c
     for (uint32_t i = 0; i < n; i++)
         if (idx[i] >= d.N) return fail(ctx, CHD_E_INVAL, "entity slot %u out of range", idx[i]);
     std::lock_guard<FairMutex> lk(ctx->mu);
-    if (W.slot_mode == 2) return fail(ctx, CHD_E_STATE, "handover groups are not available on region-sharded worlds (a group may span ranks)");
+    if (W.slot_mode == 2) return fail(ctx, CHD_E_STATE, "chd_world_set_entity_groups on a region-sharded world: groups are given as lists keyed by channel id there (chd_shard_set_handover_lists)");
     TRY(bind(ctx));
     if (W.group_id.empty() || d.grp_exact) W.group_id.assign(d.N, 0u);  // (after chd_world_set_handover_lists: start over)
     d.grp_exact = 0;
@@ -1334,7 +1334,7 @@ int chd_world_set_handover_lists(chd_ctx *ctx, uint32_t n_lists, const uint32_t 
         if (list_of[i] != CHD_NO_HANDOVER_LIST && list_of[i] >= n_lists) return fail(ctx, CHD_E_INVAL, "entity slot %u: list %u of %u", idx[i], list_of[i], n_lists);
     }
     std::lock_guard<FairMutex> lk(ctx->mu);
-    if (W.slot_mode == 2) return fail(ctx, CHD_E_STATE, "handover groups are not available on region-sharded worlds (a group may span ranks)");
+    if (W.slot_mode == 2) return fail(ctx, CHD_E_STATE, "chd_world_set_handover_lists on a region-sharded world: the lists are keyed by channel id there (chd_shard_set_handover_lists)");
     TRY(bind(ctx));
     std::vector<uint32_t> of(d.N, CHD_INVALID);
     for (uint32_t i = 0; i < n; i++) of[idx[i]] = list_of[i] == CHD_NO_HANDOVER_LIST ? CHD_INVALID : list_of[i];
@@ -2427,8 +2427,13 @@ int chd_shard_set_handover_lists(chd_ctx *ctx, uint32_t n_lists, const uint32_t 
     for (uint32_t i = 0; i < n; i++) of[chan_id[i] - eid0] = list_of[i];
     const uint32_t nm = n_lists ? list_off[n_lists] : 0u;
     uint32_t *doff = nullptr, *dmem = nullptr;
-    TRY(walloc(ctx, &doff, (size_t)n_lists + 1));
-    TRY(walloc(ctx, &dmem, std::max<size_t>(nm, 1)));
+    HIPCHK(hipStreamSynchronize(ctx->aux_stream));
+    for (int k = 1; k <= 2; k++) { if (W.grp_buf[k]) HIPCHK(hipFree(W.grp_buf[k])); W.grp_buf[k] = nullptr; }  // (the previous call's lists)
+    HIPCHK(hipMalloc(&W.grp_buf[1], 4 * ((size_t)n_lists + 1)));
+    HIPCHK(hipMalloc(&W.grp_buf[2], 4 * std::max<size_t>(nm, 1)));
+    doff = (uint32_t *)W.grp_buf[1];
+    dmem = (uint32_t *)W.grp_buf[2];
+    HIPCHK(hipMemset(doff, 0, 4 * ((size_t)n_lists + 1)));
     HIPCHK(hipMemcpy(d.sh_list_of, of.data(), 4 * (size_t)n_chan, hipMemcpyHostToDevice));
     if (n_lists) HIPCHK(hipMemcpy(doff, list_off, 4 * ((size_t)n_lists + 1), hipMemcpyHostToDevice));
     if (nm) HIPCHK(hipMemcpy(dmem, list_member_chan, 4 * (size_t)nm, hipMemcpyHostToDevice));
