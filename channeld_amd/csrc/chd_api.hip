@@ -2354,7 +2354,9 @@ static int shard_fanout_locked(chd_ctx *ctx, const void *d_halo_recv, uint32_t w
     const TickRing &r = ctx->ring;
     const int64_t now = W.last_now;
     // stage events: ingest/index ran in the earlier phases (their slots read 0 here)
-    const bool prof = ctx->prof_depth > 0;
+    const bool prof_skip = ctx->prof_depth > 0 && ctx->prof_kernel_only && ctx->prof_every > 1 && r.cur_tick % ctx->prof_every != 0;
+    if (prof_skip) ctx->ev_overlap[r.cur_tick % (uint32_t)ctx->prof_depth] = 8;  // (CHD_PROF_RECORD_KERNEL_EVERY: nothing recorded)
+    const bool prof = ctx->prof_depth > 0 && !prof_skip;
     hipEvent_t *ev = prof ? &ctx->ev[(size_t)(r.cur_tick % (uint32_t)ctx->prof_depth) * EV_PER_TICK] : nullptr;
     const bool prof_ends = prof && !ctx->prof_kernel_only;  // (chd_set_profiling_scope)
     if (prof) {
@@ -2380,7 +2382,8 @@ static int shard_fanout_locked(chd_ctx *ctx, const void *d_halo_recv, uint32_t w
     if (prof) HIPCHK(hipEventRecord(ev[CHD_N_STAGES + 3], st));
     launch_fanout_emit_deferred(st, ctx->g, d, now, r);
     if (prof_ends) HIPCHK(hipEventRecord(ev[5], st));
-    launch_tick_epilogue(st, d, r.cur_tick % TICK_RING, ctx->g.ncell);
+    if (W.gated) launch_tick_epilogue(st, d, r.cur_tick % TICK_RING, ctx->g.ncell, W.gate + GATE_EPI, ++W.gate_epi);
+    else launch_tick_epilogue(st, d, r.cur_tick % TICK_RING, ctx->g.ncell);
     TRY(after_launch(ctx));
     if (d_in->n_queries) W.last_nq = d_in->n_queries;
     W.ticked = true;
@@ -2566,6 +2569,12 @@ int chd_shard_tick(chd_ctx *ctx, int64_t now_ns, const double *d_x_by_chan, cons
     const uint32_t world = W.comm_world, rank = W.comm_rank;
     hipStream_t st = ctx->stream;
     uint32_t use = W.comm_cap;
+    // CHD_WORLD_OVERLAP_INTEREST | CHD_WORLD_GATED_OVERLAP: the interest updates — they read nothing this tick's front writes —
+    // run on the second stream from the tick's START, beside ingest, both exchanges and the index build, and are joined by a
+    // device-side flag before the plan; the halo exchange then needs no stream of its own (and no events).  `chained`: the call
+    // before this one on the context was such a tick too (read before the stages below pass through bind()).
+    const bool g_on = W.gated && !W.plan_recipients;
+    const bool chained = g_on && ctx->gchain;
     if (world > 1 && W.d.sh_list_of) {
         // handover lists: a handover whose src map is another rank's goes there as a request before anything is exported
         // (k_shard.hip: k_apply_requests) — one more small exchange, only on worlds with lists, every rank alike
@@ -2586,6 +2595,25 @@ int chd_shard_tick(chd_ctx *ctx, int64_t now_ns, const double *d_x_by_chan, cons
         TRY(shard_ingest_pre_locked(ctx, now_ns, d_x_by_chan, d_z_by_chan, d_has_update, n_chan, rank, world, nullptr, 0));
         TRY(shard_ingest_post_locked(ctx, nullptr, 0, rank, world, W.mig_send, W.comm_cap, &use));
     }
+    if (g_on && d_in->n_queries) {
+        TRY(check_queries(ctx, d_in));
+        hipStream_t ax = ctx->aux_stream;
+        if (chained) launch_gate_wait(ax, W.d, W.gate + GATE_EPI, W.gate_epi);  // after the previous tick's epilogue
+        else {
+            HIPCHK(hipEventRecord(ctx->ev_fork, st));  // (recorded behind this tick's ingest: harmless, the two are independent)
+            HIPCHK(hipStreamWaitEvent(ax, ctx->ev_fork, 0));
+        }
+        GateArgs ga{};
+        const uint32_t nb = aoi_interest_blocks(ctx->lim, W.d, d_in->n_queries);
+        ga.base = W.gate;
+        for (uint32_t k = 0; k < 8; k++) {
+            if (k < nb) W.gate_cnt[k] += (nb - k + 7u) / 8u;
+            ga.cnt_target[k] = W.gate_cnt[k];
+        }
+        W.gate_top += std::min(nb, 8u);
+        launch_aoi_interest(ax, ctx->g, ctx->lim, W.d, d_in->queries, d_in->n_queries, d_in->query_sub, d_in->spot_x, d_in->spot_z,
+                            d_in->spot_dist, W.last_now, ctx->ring.cur_tick, &ga);
+    }
     const size_t seg = (size_t)use + 1;
     {   // the cross-server handovers (spatial.go:683-700): every rank's segment for every other rank, 32 B per emigrant.
         // (One rank: its own segment to itself — nothing to move, but the tick keeps its shape and the transport is exercised.)
@@ -2599,7 +2627,15 @@ int chd_shard_tick(chd_ctx *ctx, int64_t now_ns, const double *d_x_by_chan, cons
     TRY(shard_import_locked(ctx, W.mig_recv, world, use, W.halo_send_buf));
     bool halo = false;
     for (uint32_t p = 0; p < world; p++) halo = halo || W.halo_segs[p].send_bytes || W.halo_segs[p].recv_bytes;
-    if (halo) {
+    if (halo && g_on) {  // (nothing to overlap it with on this stream any more: in stream order, no events)
+        NCCLCHK(g_rccl.GroupStart());
+        for (uint32_t p = 0; p < world; p++) {
+            const chd_halo_seg &h = W.halo_segs[p];
+            if (h.send_bytes) NCCLCHK(g_rccl.Send(W.halo_send_buf + h.send_off, h.send_bytes, ncclUint8, (int)p, W.comm, st));
+            if (h.recv_bytes) NCCLCHK(g_rccl.Recv(W.halo_recv_buf + h.recv_off, h.recv_bytes, ncclUint8, (int)p, W.comm, st));
+        }
+        NCCLCHK(g_rccl.GroupEnd());
+    } else if (halo) {
         HIPCHK(hipEventRecord(W.ev_halo_ready, st));
         HIPCHK(hipStreamWaitEvent(W.comm_stream, W.ev_halo_ready, 0));
         NCCLCHK(g_rccl.GroupStart());
@@ -2611,14 +2647,19 @@ int chd_shard_tick(chd_ctx *ctx, int64_t now_ns, const double *d_x_by_chan, cons
         NCCLCHK(g_rccl.GroupEnd());
         HIPCHK(hipEventRecord(W.ev_halo_done, W.comm_stream));
     }
-    TRY(shard_interest_locked(ctx, d_in));
-    if (halo) HIPCHK(hipStreamWaitEvent(st, W.ev_halo_done, 0));
+    if (g_on) {
+        if (d_in->n_queries) launch_gate_wait(st, W.d, W.gate + GATE_TOP, W.gate_top);  // join: the interest updates are complete
+    } else {
+        TRY(shard_interest_locked(ctx, d_in));
+        if (halo) HIPCHK(hipStreamWaitEvent(st, W.ev_halo_done, 0));
+    }
     chd_tick_in rest = *d_in;
     rest.n_queries = 0;  // (the interest updates ran above)
     rest.queries = nullptr;
     const uint32_t nq = d_in->n_queries;
     TRY(shard_fanout_locked(ctx, W.halo_recv_buf, world, &rest));
     W.last_nq = nq;
+    ctx->gchain = g_on;  // (shard_fanout_locked's epilogue raised the flag the next tick's second stream waits for)
     return CHD_OK;
 }
 

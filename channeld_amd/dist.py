@@ -568,13 +568,17 @@ def run_bench(args, rank: int, world: int, local_rank: int, verifier=None) -> di
     my_subs = np.nonzero(owner[:S] == rank)[0]                    # connection j follows entity j
     if len(mine) > n_max or len(my_subs) > s_max:
         raise SystemExit(f"rank {rank}: {len(mine)} entities / {len(my_subs)} connections exceed the per-rank slots {n_max} / {s_max}")
+    # the library's own communicator (below) runs the interest updates beside the tick's front, joined by device-side flags
+    # (CHD_WORLD_OVERLAP_INTEREST | CHD_WORLD_GATED_OVERLAP); the four-stage path over torch.distributed ignores the flags
+    native_on = comm.backend == "nccl" and os.environ.get("CHD_DIST_NATIVE", "1") != "0"
+    gate_flags = (16 | 512) if (native_on and getattr(args, "overlap_interest", 1) and getattr(args, "gated_overlap", 1)) else 0
     eng = HipShardEngine(cfg, rank, world, n_max, s_max, migrate_cap=max(4096, n_max // 8), device=local_rank,
-                         max_records=int(getattr(args, "max_records", 0) or 0), adaptive_migrate=True)
+                         max_records=int(getattr(args, "max_records", 0) or 0), adaptive_migrate=True, flags=gate_flags)
     eng.spawn(sw.chan_id[mine], sw.x[mine], sw.z[mine], sw.flags[mine], sw.sender[mine])
     eng.add_subscribers(sw.sub_conn[my_subs])
     # RCCL runs inside the library (chd_shard_comm_init / chd_shard_tick) whenever the ranks have a GPU each; host-staged
     # transports (gloo: ranks sharing one GPU in the tests) keep the four-stage path around torch.distributed.  CHD_DIST_NATIVE=0: A/B
-    if comm.backend == "nccl" and os.environ.get("CHD_DIST_NATIVE", "1") != "0":
+    if native_on:
         eng.comm_init_native(comm)
     world_obj = ShardedWorld(eng, comm)
 
@@ -619,7 +623,8 @@ def run_bench(args, rank: int, world: int, local_rank: int, verifier=None) -> di
     del xs, zs, q_full
 
     eng.sw.set_profiling(min(1024, max(K, L, 1)))
-    eng.sw.set_profiling_scope(True)  # timed region: only the pair around the dominant kernel; stage breakdown from the latency phase
+    # timed region: only the pair around the dominant kernel, on every 7th tick (bench.py: PROF_EVERY_DEFAULT); stage breakdown from the latency phase
+    eng.sw.set_profiling_scope(True, every=int(getattr(args, "prof_every", 7) or 1))
     for t in range(V, W):
         tick(t)
     comm.barrier()
@@ -640,8 +645,9 @@ def run_bench(args, rank: int, world: int, local_rank: int, verifier=None) -> di
         raise SystemExit(f"rank {rank}: overflow 0x{res.overflow:x}, history overflow {res.history_overflow} in the timed region")
     msgs = comm.sum_int(msgs_local)
     handovers = comm.sum_int(sum(h["n_handovers"] for h in hist))
-    emit_us = np.array([h["emit_main_us"] for h in hist])
-    emit_msgs = np.array([h["n_records"] - h["n_deferred_records"] for h in hist], dtype=np.float64)
+    timed = [h for h in hist if h["emit_main_us"] > 0] or hist  # (the sampled launches)
+    emit_us = np.array([h["emit_main_us"] for h in timed])
+    emit_msgs = np.array([h["n_records"] - h["n_deferred_records"] for h in timed], dtype=np.float64)
     achieved = float(12.0 * emit_msgs.mean() / (emit_us.mean() * 1e-6) / 1e9) if emit_us.mean() > 0 else 0.0
     stage_avg = np.zeros(5)
     eng.sw.set_profiling_scope(False)
