@@ -611,3 +611,28 @@ def test_tick_device_reports_a_repeated_slot(amd):
     sw.step()
     gw.tick_device(sw.now_ns(), n_updates=N, d_upd_x=dx.at(0), d_upd_z=dz.at(0), n_queries=S, d_queries=dq.at(0))
     assert gw.fetch().overflow == 0
+
+
+def test_record_kernel_event_pairs_can_be_sampled(amd):
+    """chd_set_profiling_scope(CHD_PROF_RECORD_KERNEL_EVERY(n)): the HIP event pair around the record kernel on every n-th tick
+    only (each event idles the tick's stream for a few microseconds); the ticks in between report emit_main_us == 0, the counts of
+    every tick stay what they are."""
+    cfg = synth.load_config("spatial_static_benchmark.json")
+    sw = synth.SynthWorld(synth.WorldSpec(cfg, 6000, 4200, 0xC0FFEE21))
+    ctl, gw = make(amd, cfg, 6000, 4200, 0)
+    gw.spawn(None, sw.chan_id, sw.x, sw.z, sw.flags, sw.sender)
+    gw.add_subscribers(None, sw.sub_conn)
+    gw.set_profiling(16)
+    gw.set_profiling_scope(True, every=4)
+    for k in range(12):
+        sw.step()
+        gw.tick(sw.now_ns(), upd_x=sw.x, upd_z=sw.z, queries=sw.queries(), want_records=False, records_cap=1)
+    hist = gw.history(12)  # [0] = the most recent tick = tick 12
+    timed = [h["emit_main_us"] > 0 for h in hist]
+    assert timed == [(12 - j) % 4 == 0 for j in range(12)], timed
+    assert all(h["n_records"] > 0 for h in hist[:10])
+    gw.set_profiling_scope(True)  # every launch again
+    sw.step()
+    gw.tick(sw.now_ns(), upd_x=sw.x, upd_z=sw.z, queries=sw.queries(), want_records=False, records_cap=1)
+    assert gw.history(1)[0]["emit_main_us"] > 0
+    ctl.close()
