@@ -4,7 +4,7 @@
 # (PMC=1), the diagnostic configurations (DIAG=1: partial updates, masks), the self-verifying sharded bench (ranks share the
 # GPU, gloo), then the GPU parity suite.  Every summary is stamped with the kernel-source hash (channeld_amd.build.source_hash:
 # the GPU box has no .git).
-# usage (repo root on the GPU box): [PMC=1] [WIRE_TRACE=1] [PIPE_TRACE=1] [JITTER_TRACE=1] [AB_INTEREST=1] [DIAG=1|light] bash tools/round_check.sh <tag> [pytest args]
+# usage (repo root on the GPU box): [PMC=1] [WIRE_TRACE=1] [PIPE_TRACE=1] [JITTER_TRACE=1] [AB_GATE=1] [TIMELINE=1] [SHARD1=1] [DIAG=1|light] bash tools/round_check.sh <tag> [pytest args]
 TAG=${1:-round}; shift
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 O=$R/gpurun_out/$TAG
@@ -32,14 +32,14 @@ if [ -n "$JITTER_TRACE" ]; then  # arrival stamps at enqueue time (exact update 
   trace arrival_jitter 10 --steps 40 --warmup 10 --only-timed --arrival-jitter
   trace arrival_jitter_offgrid 10 --steps 40 --warmup 10 --only-timed --arrival-jitter --tick-jitter-us 3000
 fi
-if [ -n "$AB_INTEREST" ]; then  # the bench's default schedule against the one-stream schedule, alternating
-  (echo '{"what": "bench.py --only-timed --steps 200 --warmup 20, --overlap-interest 0 / 1 alternating (ms_per_step)", "source_hash": "'$HASH'", "runs": ['
-   for i in 1 2 3; do for v in 0 1; do
-     ms=$(timeout 120 python bench.py --only-timed --steps 200 --warmup 20 --overlap-interest $v 2>> $O/ab.err | python -c "import json,sys; print(json.loads(sys.stdin.readlines()[-1])['ms_per_step'])")
-     echo "  {\"overlap_interest\": $v, \"ms_per_step\": $ms},"
-   done; done
-   echo '  {}]}') > $O/overlap_interest_ab.json
+if [ -n "$AB_GATE" ]; then  # the bench's schedule (interest stream forked / joined by device-side flags) against the HIP-event form, and against one stream
+  bash tools/ab_gate.sh $TAG > /dev/null 2>> $O/ab.err
+  (echo '{"what": "bench.py --only-timed --steps 200 --warmup 20 --overlap-interest 0 (everything on one stream)", "source_hash": "'$HASH'", "ms_per_step": ['
+   for i in 1 2; do timeout 120 python bench.py --only-timed --steps 200 --warmup 20 --overlap-interest 0 2>> $O/ab.err | python -c "import json,sys; print(json.loads(sys.stdin.readlines()[-1])['ms_per_step'], ',')"; done
+   echo '0]}') > $O/one_stream.json
 fi
+[ -n "$TIMELINE" ] && bash tools/timeline.sh ${TAG}_tl > /dev/null 2>&1 && cp $R/gpurun_out/${TAG}_tl/tick_timeline.csv $O/tick_timeline.csv
+[ -n "$SHARD1" ] && bash tools/shard1.sh ${TAG}_shard1 > $O/shard1.log 2>&1 && cp $R/gpurun_out/${TAG}_shard1/tick_timeline.csv $O/shard_tick_timeline_one_rank.csv && cp $R/gpurun_out/${TAG}_shard1/bench.json $O/bench_shard_one_rank_rccl.json
 if [ -n "$DIAG" ]; then
   for f in 0.98 0.9 0.5; do timeout 120 python bench.py --only-timed --steps 60 --warmup 10 --update-frac $f > $O/diag_update_frac_$f.json 2>> $O/diag.err; done
   timeout 120 python bench.py --only-timed --steps 60 --warmup 10 --update-masks > $O/diag_update_masks.json 2>> $O/diag.err
