@@ -2399,6 +2399,16 @@ int chd_shard_fanout(chd_ctx *ctx, const void *d_halo_recv, uint32_t world, cons
     return shard_fanout_locked(ctx, d_halo_recv, world, d_in);
 }
 
+int chd_shard_set_update_senders(chd_ctx *ctx, const uint32_t *d_sender_by_chan, uint32_t n_chan) {
+    NEED_WORLD();
+    std::lock_guard<FairMutex> lk(ctx->mu);
+    TRY(bind(ctx));
+    if (ctx->w.slot_mode == 1) return fail(ctx, CHD_E_STATE, "chd_shard_set_update_senders on a world with caller-chosen slots (chd_tick_in.upd_sender)");
+    ctx->w.d.sh_sender_by_chan = n_chan ? d_sender_by_chan : nullptr;
+    ctx->w.d.sh_sender_n = d_sender_by_chan ? n_chan : 0u;
+    return CHD_OK;
+}
+
 int chd_shard_set_handover_lists(chd_ctx *ctx, uint32_t n_lists, const uint32_t *list_off, const uint32_t *list_member_chan, uint32_t n,
                                  const uint32_t *chan_id, const uint32_t *list_of, uint32_t n_chan) {
     NEED_WORLD();

@@ -65,6 +65,8 @@ struct WorldDev {
     // entity itself), list l = channel ids sh_list_mem[sh_list_off[l] .. sh_list_off[l+1]); sh_slot_of[k] = the slot that holds
     // the channel on THIS rank (CHD_INVALID: it lives elsewhere), kept by spawn / import / export.  The members that move with a
     // handover are those in src's entity map — by construction on the rank that owns src, i.e. the notifier's.
+    const uint32_t *sh_sender_by_chan;  // chd_shard_set_update_senders: senderConnId of this tick's update of channel (eid0 + k); nullptr: the entity's own
+    uint32_t sh_sender_n;
     uint32_t sh_nchan, sh_eid0, sh_nlists;
     uint32_t *sh_slot_of, *sh_list_of, *sh_list_off, *sh_list_mem;
     // spatial (cell) channels' own update history

@@ -105,7 +105,8 @@ __global__ void __launch_bounds__(256) k_ingest_by_channel(DevGrid g, WorldDev w
             dst = cell_of(g, xs[k], zs[k]);
             src = w.cell[i];
             w.cell[i] = dst;
-            push_update(w, i, w.sender[i], cur_tick);
+            // (who sent the update: the owner changes with a cross-server handover — chd_shard_set_update_senders — else the entity's own)
+            push_update(w, i, (w.sh_sender_by_chan && k < w.sh_sender_n) ? w.sh_sender_by_chan[k] : w.sender[i], cur_tick);
             if (src != CHD_INVALID && dst != CHD_INVALID && src != dst) {
                 // GetHandoverEntities (entity.go:197-224) as the host's group controllers evaluated it: an EMPTY list = a locked
                 // member or an emptied group -> no handover (spatial.go:675-679)

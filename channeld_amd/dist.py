@@ -325,6 +325,13 @@ class HipShardEngine:
     def add_subscribers(self, conn_ids):
         self.sw.add_subscribers(None, conn_ids)
 
+    def set_update_senders(self, sender_by_chan):
+        """chd_shard_set_update_senders: a uint32/int32 DEVICE tensor indexed by channel id - EntityChannelIdStart (kept alive here;
+        the host rewrites it in place between ticks), or None."""
+        self._senders = sender_by_chan
+        self._lib.check(self.ctx, self.lib.chd_shard_set_update_senders(
+            self.ctx, C.c_void_p(sender_by_chan.data_ptr()) if sender_by_chan is not None else None, int(sender_by_chan.numel()) if sender_by_chan is not None else 0))
+
     def set_handover_lists(self, list_off, list_member_chan, chan_id, list_of, n_chan: int):
         """chd_shard_set_handover_lists: the handover lists of the WHOLE world, keyed by entity channel id (every rank gets the
         same arrays; channeld_amd.groups.EntityGroupTable produces them from the group controllers)."""

@@ -614,6 +614,13 @@ int chd_shard_interest(chd_ctx *ctx, const chd_tick_in *d_in);
  * are ignored) and the fan-out of this rank's connections over region + halo.  Outputs as chd_tick_device. */
 int chd_shard_fanout(chd_ctx *ctx, const void *d_halo_recv, uint32_t world, const chd_tick_in *d_in);
 
+/* Who SENT the updates (senderConnId of data.go:159-164; SkipSelfUpdateFanOut compares it, data.go:242-245): a DEVICE array indexed
+ * like the positions of chd_shard_ingest (channel id - EntityChannelIdStart) that the following ticks read at ingest — the host
+ * keeps it resident and changes entries as owners change (after a cross-server handover the updates come from the new server's
+ * connection, spatial.go:683-700).  NULL / n_chan 0: back to every entity's own sender as given at spawn (it migrates with the
+ * entity).  chd_tick_in.upd_sender on unsharded worlds. */
+int chd_shard_set_update_senders(chd_ctx *ctx, const uint32_t *d_sender_by_chan, uint32_t n_chan);
+
 /* Handover lists on a region-sharded world: the meaning of chd_world_set_handover_lists, keyed by ENTITY CHANNEL ID — slots are
  * the library's here and an entity changes ranks.  List k = the channel ids list_member_chan[list_off[k] .. list_off[k+1]); the
  * entity with channel id chan_id[i] takes list list_of[i] (CHD_NO_HANDOVER_LIST: the entity itself; an EMPTY list: no handover,

@@ -33,7 +33,7 @@ def canon(conn, chan):
 from shard_lists import make_lists, one_handover_per_group_and_tick  # noqa: E402  (shared with the CPU gloo test)
 
 
-def run_rank(rank, world, port, N, S, ticks, seed, out, cfg_name=None, halo=64, jump_frac=0.15, aoi_scale=1.0, lists=False):
+def run_rank(rank, world, port, N, S, ticks, seed, out, cfg_name=None, halo=64, jump_frac=0.15, aoi_scale=1.0, lists=False, senders=False):
     import torch
     import torch.distributed as dist
 
@@ -75,7 +75,15 @@ def run_rank(rank, world, port, N, S, ticks, seed, out, cfg_name=None, halo=64, 
             for s in range(S):
                 ow.add_sub(s, int(sw.sub_conn[s]))
         total = cross = 0
+        d_snd = None
+        if senders:  # who sends an entity's updates changes over time: its spawn-time owner, then a CLIENT connection (which then skips its own)
+            d_snd = torch.zeros(N, dtype=torch.int32, device=dev)
+            eng.set_update_senders(d_snd)
         for k, (x, z, q, now) in enumerate(frames):
+            snd = None
+            if senders:
+                snd = np.where((np.arange(N) + k // 3) % 2 == 0, sw.sender, sw.sub_conn[np.arange(N) % S]).astype(np.uint32)
+                d_snd.copy_(torch.from_numpy(snd.view(np.int32)))
             dq = torch.from_numpy(np.ascontiguousarray(q[my_subs]).view(np.uint8)).to(dev)
             sworld.tick(now, torch.from_numpy(x).to(dev), torch.from_numpy(z).to(dev), dq, len(my_subs))
             res = eng.fetch(want_records=True, records_cap=1 << 22)
@@ -91,7 +99,7 @@ def run_rank(rank, world, port, N, S, ticks, seed, out, cfg_name=None, halo=64, 
                 gathered = [state]
             if rank != 0:
                 continue
-            ow.tick(now, None, x, z, None, None, None, None, q)
+            ow.tick(now, None, x, z, snd, None, None, None, q)
             assert all(s["ovf"] == (0, 0) for s in gathered)
             oc, och = ow.records()
             if os.environ.get("CHD_SHARD_DEBUG"):
@@ -145,13 +153,13 @@ def run_rank(rank, world, port, N, S, ticks, seed, out, cfg_name=None, halo=64, 
             dist.destroy_process_group()
 
 
-def launch(world, N, S, ticks, seed, cfg_name=None, halo=64, jump_frac=0.15, aoi_scale=1.0, lists=False):
+def launch(world, N, S, ticks, seed, cfg_name=None, halo=64, jump_frac=0.15, aoi_scale=1.0, lists=False, senders=False):
     import torch.multiprocessing as mp
 
     ctx = mp.get_context("spawn")
     out = ctx.Queue()
     port = free_port()
-    procs = [ctx.Process(target=run_rank, args=(r, world, port, N, S, ticks, seed, out, cfg_name, halo, jump_frac, aoi_scale, lists)) for r in range(world)]
+    procs = [ctx.Process(target=run_rank, args=(r, world, port, N, S, ticks, seed, out, cfg_name, halo, jump_frac, aoi_scale, lists, senders)) for r in range(world)]
     for p in procs:
         p.start()
     for p in procs:
@@ -200,6 +208,15 @@ def test_handover_lists_that_straddle_region_borders(world):
     map sits on another rank than the notifier travels there as a request (chd_shard_ingest_pre / _post).  Every rank's records,
     handovers, aborted handovers and every entity's (cell, member, rank) equal the single-world oracle's, tick for tick."""
     total, cross = launch(world, 4000, 96, 10, 0xC0FFEE20 + world, lists=True)
+    assert total > 0 and (cross > 0 or world == 1)
+
+
+@pytest.mark.parametrize("world", [1, 2])
+def test_update_senders_change_while_entities_migrate(world):
+    """chd_shard_set_update_senders: the sender of an entity's updates alternates between its spawn-time owner and a client
+    connection (whose own fan-out then skips them: SkipSelfUpdateFanOut, data.go:242-245) while entities cross the region border
+    — the two-sender history travels in the 32-byte emigrant state — against the single-world oracle fed the same senders."""
+    total, cross = launch(world, 4000, 96, 12, 0xC0FFEE40 + world, senders=True)
     assert total > 0 and (cross > 0 or world == 1)
 
 
