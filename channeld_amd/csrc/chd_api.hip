@@ -92,6 +92,7 @@ struct World {
     void *grp_buf[4] = {nullptr, nullptr, nullptr, nullptr};  // device arrays behind WorldDev::grp_*
     bool plan_recipients = false;      // CHD_WORLD_HANDOVER_RECIPIENTS
     bool overlap_interest = false;     // CHD_WORLD_OVERLAP_INTEREST
+    bool join_in_unpack = false;       // chd_shard_tick -> shard_fanout_locked: k_halo_unpack carries the join
     bool gated = false;                // CHD_WORLD_GATED_OVERLAP: its fork / join as device-side flags (GateArgs)
     unsigned long long *gate = nullptr;
     unsigned long long gate_cnt[8] = {0, 0, 0, 0, 0, 0, 0, 0}, gate_top = 0, gate_epi = 0;
@@ -2368,7 +2369,8 @@ static int shard_fanout_locked(chd_ctx *ctx, const void *d_halo_recv, uint32_t w
     d.seg_off = 0;
     W.last_desc = fanout_seg_path(d);
     launch_halo_unpack(st, ctx->g, d, world > 1 ? W.halo_rank : 0u, world, ctx->g.border, (const unsigned char *)d_halo_recv,
-                       W.d_halo_recv_off, W.d_ghost_off);
+                       W.d_halo_recv_off, W.d_ghost_off, W.join_in_unpack ? W.gate + GATE_TOP : nullptr, W.gate_top);
+    W.join_in_unpack = false;
     d.ce_view = d.ce; d.ce8_view = d.ce8; d.ce_chan_view = d.ce_chan; d.ce_sprev_view = d.ce_sprev; d.ce_sprev_stride = 0;
     d.cell_start = d.cell_tab;
     d.cell_end = d.cell_tab + ctx->g.ncell;
@@ -2658,7 +2660,7 @@ int chd_shard_tick(chd_ctx *ctx, int64_t now_ns, const double *d_x_by_chan, cons
         HIPCHK(hipEventRecord(W.ev_halo_done, W.comm_stream));
     }
     if (g_on) {
-        if (d_in->n_queries) launch_gate_wait(st, W.d, W.gate + GATE_TOP, W.gate_top);  // join: the interest updates are complete
+        W.join_in_unpack = d_in->n_queries != 0;  // join: the ghost unpack (first launch of shard_fanout_locked) waits for the interest updates
     } else {
         TRY(shard_interest_locked(ctx, d_in));
         if (halo) HIPCHK(hipStreamWaitEvent(st, W.ev_halo_done, 0));

@@ -402,7 +402,7 @@ void launch_slot_of_rebuild(hipStream_t st, WorldDev w);  // sh_slot_of from the
 void launch_halo_pack(hipStream_t st, DevGrid g, WorldDev w, uint32_t rank, uint32_t world, uint32_t halo, unsigned char *send,
                       const uint64_t *seg_off);
 void launch_halo_unpack(hipStream_t st, DevGrid g, WorldDev w, uint32_t rank, uint32_t world, uint32_t halo, const unsigned char *recv,
-                        const uint64_t *seg_off, const uint32_t *ghost_off);
+                        const uint64_t *seg_off, const uint32_t *ghost_off, const unsigned long long *gate_p = nullptr, unsigned long long gate_target = 0);
 // K2: cell index build
 bool launch_index_build(hipStream_t st, DevGrid g, WorldDev w, uint32_t cur_tick, const unsigned long long *gate_p = nullptr,
                         unsigned long long gate_target = 0);

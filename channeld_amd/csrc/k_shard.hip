@@ -399,7 +399,8 @@ void launch_halo_pack(hipStream_t st, DevGrid g, WorldDev w, uint32_t rank, uint
 // block s < world: the segment rank s sent; block `world`: this rank's own cells and the cells nobody covers
 __global__ void __launch_bounds__(256) k_halo_unpack(DevGrid g, WorldDev w, uint32_t rank, uint32_t world, uint32_t halo,
                                                      const unsigned char *__restrict__ recv, const uint64_t *__restrict__ seg_off,
-                                                     const uint32_t *__restrict__ ghost_off) {
+                                                     const uint32_t *__restrict__ ghost_off, const unsigned long long *gate_p,
+                                                     unsigned long long gate_target) {
     const uint32_t s = blockIdx.x;
     if (s == world) {
         // own region: the local index; cells of no received band: empty and NOT covered (a subscription to one of them is
@@ -415,6 +416,15 @@ __global__ void __launch_bounds__(256) k_halo_unpack(DevGrid g, WorldDev w, uint
                 const uint32_t x = c % g.cols, y = c / g.cols;
                 const bool in = o < world && r.w && x >= r.x0 && x < r.x0 + r.w && y >= r.y0 && y < r.y0 + r.h;
                 if (!in) { w.cell_tab[c] = 0; w.cell_tab[g.ncell + c] = 0; w.cell_cov[c] = 0; }
+            }
+        }
+        // chd_shard_tick with the interest updates on the second stream: this launch also holds the tick's stream until they
+        // are complete (GateArgs; as k_index_scatter does on unsharded worlds) — the plan that follows needs them
+        if (gate_p && threadIdx.x == 0) {
+            uint32_t spins = 0;
+            while (__hip_atomic_load(gate_p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < gate_target) {
+                __builtin_amdgcn_s_sleep(2);
+                if (++spins > (1u << 23)) { atomicOr(&w.counters[CTR_OVERFLOW], OVF_INTERNAL); break; }
             }
         }
         return;
@@ -475,6 +485,6 @@ __global__ void __launch_bounds__(256) k_halo_unpack(DevGrid g, WorldDev w, uint
 }
 
 void launch_halo_unpack(hipStream_t st, DevGrid g, WorldDev w, uint32_t rank, uint32_t world, uint32_t halo, const unsigned char *recv,
-                        const uint64_t *seg_off, const uint32_t *ghost_off) {
-    hipLaunchKernelGGL(k_halo_unpack, dim3(world + 1), dim3(256), 0, st, g, w, rank, world, halo, recv, seg_off, ghost_off);
+                        const uint64_t *seg_off, const uint32_t *ghost_off, const unsigned long long *gate_p, unsigned long long gate_target) {
+    hipLaunchKernelGGL(k_halo_unpack, dim3(world + 1), dim3(256), 0, st, g, w, rank, world, halo, recv, seg_off, ghost_off, gate_p, gate_target);
 }
