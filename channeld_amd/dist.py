@@ -32,6 +32,7 @@ from __future__ import annotations
 import ctypes as C
 import json
 import os
+import sys
 import time
 from typing import List, Optional, Tuple
 
@@ -585,8 +586,20 @@ def run_bench(args, rank: int, world: int, local_rank: int, verifier=None) -> di
     eng.add_subscribers(sw.sub_conn[my_subs])
     # RCCL runs inside the library (chd_shard_comm_init / chd_shard_tick) whenever the ranks have a GPU each; host-staged
     # transports (gloo: ranks sharing one GPU in the tests) keep the four-stage path around torch.distributed.  CHD_DIST_NATIVE=0: A/B
+    native_note = None
     if native_on:
-        eng.comm_init_native(comm)
+        # (a rank that cannot load RCCL fails BEFORE the collective ncclCommInitRank — the same on every rank of a node; the line then says
+        # which driver ran instead of ending the run)
+        try:
+            eng.comm_init_native(comm)
+            ok = 1
+        except Exception as e:  # noqa: BLE001
+            ok, native_note = 0, f"chd_shard_comm_init failed ({e}): the exchanges run through torch.distributed"
+        if comm.sum_int(ok) != world:
+            eng.native = False
+            native_note = native_note or "chd_shard_comm_init failed on another rank: the exchanges run through torch.distributed"
+            if rank == 0:
+                print("bench.py: " + native_note, file=sys.stderr, flush=True)
     world_obj = ShardedWorld(eng, comm)
 
     # the single world the first V ticks are checked against lives on rank 0's host cores (the checker, never the thing
@@ -688,7 +701,7 @@ def run_bench(args, rank: int, world: int, local_rank: int, verifier=None) -> di
                    "tick_ms": args.tick_ms, "msgs_per_tick": msgs / K, "cross_rank_and_local_handovers_per_tick": handovers / K,
                    "collectives_driver": ("native: RCCL inside libchd_spatial.so (chd_shard_comm_init + chd_shard_tick: ncclSend / ncclRecv groups on the ctx "
                                           "stream and a second stream, no host code between the stages)" if eng.native else
-                                          "python: torch.distributed around the four chd_shard_* stages (host-staged transport)"),
+                                          ("python: torch.distributed around the four chd_shard_* stages" + (f" — {native_note}" if native_note else " (host-staged transport)"))),
                    "exchange": "all-to-all of emigrant states (32 B each; segment capacity adapted to 4x the largest count of two ticks ago: "
                                f"{eng.cap_now} records per peer now, {eng.cap} at start) + all-to-all(v) of the border bands of the cell tables "
                                f"({cfg['ServerInterestBorderSize']} cells wide: {sum(eng.send_splits)} bytes sent per rank and tick) per tick",
