@@ -119,6 +119,27 @@ class EntityGroupTable:
         mem = np.array([m for key in order for m in key], dtype=np.uint32)
         return off, mem, np.array(idx, dtype=np.uint32), np.array(list_of, dtype=np.uint32)
 
+    def shard_lists(self) -> Tuple[np.ndarray, np.ndarray, np.ndarray, np.ndarray]:
+        """(list_off, list_member_chan, chan_id, list_of) for HipShardEngine.set_handover_lists / chd_shard_set_handover_lists: the
+        same evaluated lists keyed by ENTITY CHANNEL ID (an entity's id is its channel id, entity.go:58-73) — on a region-sharded
+        world slots are the library's and change when an entity changes ranks; every rank is given the same, whole-world arrays.
+        Members without an entity channel are left out, identical lists shared."""
+        lists: Dict[Tuple[int, ...], int] = {}
+        chan, list_of = [], []
+        for e in sorted(self._slot):
+            chan.append(e)
+            if self._handover[e] < 0:
+                list_of.append(NO_LIST)
+                continue
+            key = tuple(sorted(m for m in self.GetHandoverEntities(e) if m in self._slot))
+            list_of.append(lists.setdefault(key, len(lists)))
+        order = sorted(lists, key=lists.get)
+        off = np.zeros(len(order) + 1, dtype=np.uint32)
+        for k, key in enumerate(order):
+            off[k + 1] = off[k] + len(key)
+        mem = np.array([m for key in order for m in key], dtype=np.uint32)
+        return off, mem, np.array(chan, dtype=np.uint32), np.array(list_of, dtype=np.uint32)
+
     # -- internals ---------------------------------------------------------------------------------------------------
     def _pointer(self, t: int) -> Dict[int, int]:
         if t == EntityGroupType_HANDOVER:

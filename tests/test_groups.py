@@ -89,6 +89,31 @@ def test_mirror_equals_the_restatement_on_random_scripts():
         assert off[0] == 0 and (np.diff(off.astype(np.int64)) >= 0).all() and len(idx) == len(list_of) == n_ch
 
 
+def test_shard_lists_are_the_engine_lists_keyed_by_channel_id():
+    """EntityGroupTable.shard_lists (what chd_shard_set_handover_lists takes on region-sharded worlds): the same evaluated lists as
+    engine_lists, members and entities named by entity channel id instead of slot."""
+    rng = np.random.default_rng(9)
+    for trial in range(40):
+        n_ch = int(rng.integers(2, 9))
+        ids = [0x80000 + 7 * k for k in range(n_ch)]  # (entity id = its channel id)
+        extra = [50, 51]
+        t, ctl = both(ids)
+        for step in range(int(rng.integers(5, 30))):
+            e = int(rng.choice(ids))
+            members = [int(v) for v in rng.choice(ids + extra, size=int(rng.integers(1, 4)), replace=False)]
+            (t.AddToGroup if rng.random() < 0.7 else t.RemoveFromGroup)(e, int(rng.integers(0, 2)), members)
+        off, mem, idx, list_of = t.engine_lists()
+        soff, smem, chan, slist_of = t.shard_lists()
+        slot_to_chan = {int(t._slot[e]): e for e in t._slot}
+        assert [slot_to_chan[int(i)] for i in idx] == list(chan)
+        for k in range(len(idx)):
+            a, b = int(list_of[k]), int(slist_of[k])
+            assert (a == 0xFFFFFFFF) == (b == 0xFFFFFFFF)
+            if a != 0xFFFFFFFF:
+                assert sorted(slot_to_chan[int(m)] for m in mem[off[a]:off[a + 1]]) == sorted(int(m) for m in smem[soff[b]:soff[b + 1]])
+                assert sorted(int(m) for m in smem[soff[b]:soff[b + 1]]) == [m for m in t.GetHandoverEntities(int(chan[k])) if m in t._slot]
+
+
 def test_remove_channel_leaves_shared_groups():
     t, ctl = both([1, 2, 3])
     t.AddToGroup(1, G.EntityGroupType_HANDOVER, [1, 2, 3])
