@@ -696,6 +696,40 @@ class SpatialWorld {
         kind.resize(n);
         return err(rc);
     }
+    // ... and, per (recipient, entity of the handover), whether the message carries that entity's FULL state: the `shouldSend` of
+    // spatial.go:797-857 (bit q of fullMask[r] = entity q of the handover's list, in message order)
+    Error HandoverRecipientsEx(uint32_t nHandovers, std::vector<uint32_t> &offsets, std::vector<uint32_t> &conn, std::vector<uint8_t> &kind,
+                               std::vector<uint32_t> &fullMask) {
+        offsets.assign((size_t)nHandovers + 1, 0);
+        uint64_t n = 0;
+        int rc = chd_handover_recipients_ex(ctl_.ctx(), offsets.data(), nullptr, nullptr, nullptr, 0, &n);  // count
+        if (rc != CHD_OK && rc != CHD_E_CAPACITY) return err(rc);
+        conn.assign(std::max<uint64_t>(n, 1), 0);
+        kind.assign(std::max<uint64_t>(n, 1), 0);
+        fullMask.assign(std::max<uint64_t>(n, 1), 0);
+        rc = chd_handover_recipients_ex(ctl_.ctx(), offsets.data(), conn.data(), kind.data(), fullMask.data(), conn.size(), &n);
+        conn.resize(n);
+        kind.resize(n);
+        fullMask.resize(n);
+        return err(rc);
+    }
+    // one ChannelDataHandoverMessage per distinct (handover, full-state mask): varHandover[v] / varFullMask[v] name the variants
+    Error HandoverVariants(const std::vector<uint32_t> &varHandover, const std::vector<uint32_t> &varFullMask, std::vector<uint32_t> &offsets,
+                           std::vector<uint8_t> &bytes, uint64_t cap) {
+        offsets.assign(varHandover.size() + 1, 0);
+        bytes.assign(std::max<uint64_t>(cap, 1), 0);
+        uint64_t n = 0;
+        const int rc = chd_handover_variants(ctl_.ctx(), (uint32_t)varHandover.size(), varHandover.data(), varFullMask.data(), offsets.data(),
+                                             bytes.data(), cap, &n);
+        bytes.resize(std::min<uint64_t>(n, cap));
+        return err(rc);
+    }
+    // stage events of the next ticks: every boundary (recordKernelOnly = false), or only the pair around the record kernel, on every
+    // `every`-th tick (each event idles the tick's stream for a few microseconds)
+    void SetProfiling(int depth, bool recordKernelOnly = false, int every = 1) {
+        check(chd_set_profiling(ctl_.ctx(), depth));
+        check(chd_set_profiling_scope(ctl_.ctx(), recordKernelOnly ? (every > 1 ? CHD_PROF_RECORD_KERNEL_EVERY(every) : CHD_PROF_RECORD_KERNEL) : CHD_PROF_STAGES));
+    }
     // wire-format fan-out buffers (connection.go:57-83,626-714): payloads in, per-connection packet streams out
     void WireSetPayloads(int kind, const std::vector<uint32_t> &idx, const std::vector<uint32_t> &lens, const std::vector<uint8_t> &bytes) {
         check(chd_wire_set_payloads(ctl_.ctx(), kind, (uint32_t)idx.size(), idx.data(), lens.data(), bytes.data()));
@@ -744,6 +778,66 @@ class SpatialWorld {
     StaticGrid2DSpatialController &ctl_;
     uint32_t N_, S_, capq_ = 0;
     std::vector<ConnectionId> connIds_;  // ConnectionId per subscriber slot (the host registered them: AddSubscribers)
+};
+
+// ---------------------------------------------------------------------------------------------------------------------
+// One rank of a region-sharded world: rank r owns the cells whose ServerIndex == r (spatial.go:336-351,
+// 399-424) — the partition CreateChannels gives to spatial server r; entities live on the rank of the cell that holds them and
+// migrate with their 32-byte state (the cross-server handover of spatial.go:683-700); the tick's two exchanges run inside the
+// library on RCCL (chd_shard_comm_*).  The host keeps the positions (and, if owners change, the senders) of ALL entity channels in
+// device arrays indexed by channel id - EntityChannelIdStart and passes the pointers; what comes out is fetched as on one GPU.
+// ---------------------------------------------------------------------------------------------------------------------
+class EntityGroupTable;
+class ShardWorld {
+  public:
+    // flags: CHD_WORLD_OVERLAP_INTEREST | CHD_WORLD_GATED_OVERLAP lets the tick run its interest updates beside its front
+    ShardWorld(StaticGrid2DSpatialController &ctl, uint32_t rank, uint32_t world, uint32_t maxEntities, uint32_t maxSubscribers,
+               uint64_t maxRecords = 0, uint32_t flags = 0)
+        : ctl_(ctl), rank_(rank), world_(world) {
+        chd_world_cfg c;
+        std::memset(&c, 0, sizeof c);
+        c.max_entities = maxEntities;
+        c.max_subscribers = maxSubscribers;
+        c.max_records = maxRecords;
+        c.flags = flags;
+        check(chd_world_create(ctl.ctx(), &c));
+    }
+    // rank 0 draws the id, the gateways' own control connection carries its CHD_COMM_ID_BYTES bytes, every rank joins (collective)
+    static std::vector<uint8_t> CommUniqueId() {
+        std::vector<uint8_t> id(CHD_COMM_ID_BYTES);
+        if (chd_shard_comm_unique_id(id.data()) != CHD_OK) throw std::runtime_error("chd_shard_comm_unique_id failed");
+        return id;
+    }
+    void CommInit(const std::vector<uint8_t> &id, uint32_t migrateCap) { check(chd_shard_comm_init(ctl_.ctx(), id.data(), rank_, world_, migrateCap)); }
+    // the entities of this rank's region (entity channel ids; slots are the library's), the connections pinned to this rank
+    void Spawn(const std::vector<ChannelId> &entityChannelIds, const std::vector<double> &x, const std::vector<double> &z,
+               const std::vector<uint32_t> &flags, const std::vector<ConnectionId> &owner) {
+        check(chd_shard_spawn(ctl_.ctx(), (uint32_t)entityChannelIds.size(), entityChannelIds.data(), x.data(), z.data(),
+                              flags.empty() ? nullptr : flags.data(), owner.empty() ? nullptr : owner.data()));
+    }
+    void AddSubscribers(const std::vector<ConnectionId> &conn) { check(chd_subs_add(ctl_.ctx(), (uint32_t)conn.size(), nullptr, conn.data())); }
+    // who sends each channel's updates (device array by channel id; nullptr: the spawn-time owner, which migrates with the entity)
+    void SetUpdateSenders(const uint32_t *dSenderByChan, uint32_t nChan) { check(chd_shard_set_update_senders(ctl_.ctx(), dSenderByChan, nChan)); }
+    Error SetHandoverLists(const EntityGroupTable &groups, uint32_t nChan);
+    // one tick (collective): positions by channel id on the device, this rank's queries in dIn (device pointers)
+    Error Tick(int64_t nowNs, const double *dXByChan, const double *dZByChan, const uint8_t *dHasUpdate, uint32_t nChan, const chd_tick_in &dIn) {
+        const int rc = chd_shard_tick(ctl_.ctx(), nowNs, dXByChan, dZByChan, dHasUpdate, nChan, &dIn);
+        if (rc == CHD_OK) return {};
+        const char *m = chd_last_error(ctl_.ctx());
+        return {rc, m ? m : ""};
+    }
+    uint32_t Rank() const { return rank_; }
+    uint32_t WorldSize() const { return world_; }
+
+  private:
+    void check(int rc) {
+        if (rc != CHD_OK) {
+            const char *m = chd_last_error(ctl_.ctx());
+            throw std::runtime_error(std::string("chd error ") + std::to_string(rc) + ": " + (m ? m : ""));
+        }
+    }
+    StaticGrid2DSpatialController &ctl_;
+    uint32_t rank_, world_;
 };
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -830,6 +924,39 @@ class EntityGroupTable {
         }
         return L;
     }
+    // the same lists keyed by ENTITY CHANNEL ID (an entity's id is its channel id): what a region-sharded world takes
+    // (chd_shard_set_handover_lists — slots are the library's there); Lists::idx then holds channel ids
+    Lists ShardLists() const {
+        Lists L;
+        std::map<std::vector<uint32_t>, uint32_t> seen;
+        std::vector<std::vector<uint32_t>> order;
+        for (const auto &kv : ctl_) {
+            L.idx.push_back(kv.first);
+            if (kv.second.handover < 0) { L.list_of.push_back(CHD_NO_HANDOVER_LIST); continue; }
+            std::vector<uint32_t> key;
+            for (EntityId m : GetHandoverEntities(kv.first))
+                if (ctl_.count(m)) key.push_back(m);
+            std::sort(key.begin(), key.end());
+            auto ins = seen.insert({key, (uint32_t)order.size()});
+            if (ins.second) order.push_back(key);
+            L.list_of.push_back(ins.first->second);
+        }
+        for (const auto &key : order) {
+            L.list_members.insert(L.list_members.end(), key.begin(), key.end());
+            L.list_off.push_back((uint32_t)L.list_members.size());
+        }
+        return L;
+    }
+    Error UploadShard(chd_ctx *ctx, uint32_t nChan) const {  // (every rank: the same, whole-world lists)
+        const Lists L = ShardLists();
+        const uint32_t n_lists = (uint32_t)L.list_off.size() - 1;
+        const int rc = chd_shard_set_handover_lists(ctx, n_lists, n_lists ? L.list_off.data() : nullptr,
+                                                    L.list_members.empty() ? nullptr : L.list_members.data(), (uint32_t)L.idx.size(),
+                                                    L.idx.empty() ? nullptr : L.idx.data(), L.list_of.empty() ? nullptr : L.list_of.data(), nChan);
+        if (rc == CHD_OK) return {};
+        const char *m = chd_last_error(ctx);
+        return {rc, m ? m : ""};
+    }
     Error Upload(chd_ctx *ctx) const {
         const Lists L = EngineLists();
         const uint32_t n_lists = (uint32_t)L.list_off.size() - 1;
@@ -865,5 +992,7 @@ class EntityGroupTable {
     std::map<EntityId, Ctl> ctl_;
     std::vector<std::map<EntityId, bool>> sets_;  // arena of group instances: "two channels share one group" = same index
 };
+
+inline Error ShardWorld::SetHandoverLists(const EntityGroupTable &groups, uint32_t nChan) { return groups.UploadShard(ctl_.ctx(), nChan); }
 
 }  // namespace chd
