@@ -2566,10 +2566,12 @@ int chd_shard_comm_destroy(chd_ctx *ctx) {
 }
 
 // One tick of a region-sharded world with both exchanges inside: no host code between the stages, everything ordered by
-// streams and events.  ctx stream: ingest + export -> all-to-all of the emigrants (ncclSend / ncclRecv group, equal segments of
-// this tick's capacity) -> import + cell index + halo pack -> [event] -> interest updates -> [wait] -> fan-out; the halo
-// all-to-all(v) runs on the library's second stream between the two events, beside the interest updates (which do not read the
-// neighbours' tables).
+// streams, events and device-side flags.  Default form — ctx stream: ingest + export -> all-to-all of the emigrants (ncclSend /
+// ncclRecv group, equal segments of this tick's capacity) -> import + cell index + halo pack -> [event] -> interest updates ->
+// [wait] -> fan-out; the halo all-to-all(v) runs on the library's second stream between the two events, beside the interest
+// updates (which do not read the neighbours' tables).  Gated form (CHD_WORLD_OVERLAP_INTEREST | CHD_WORLD_GATED_OVERLAP): the
+// interest updates on the second stream from the tick's start, everything else — the halo exchange included — in order on the ctx
+// stream, the join as a flag that k_halo_unpack waits for (GateArgs).
 int chd_shard_tick(chd_ctx *ctx, int64_t now_ns, const double *d_x_by_chan, const double *d_z_by_chan, const uint8_t *d_has_update,
                    uint32_t n_chan, const chd_tick_in *d_in) {
     NEED_WORLD();

@@ -266,7 +266,7 @@ int chd_world_set_entity_flags(chd_ctx *ctx, uint32_t n, const uint32_t *idx,
  * handover record per notifying entity, as the reference sends one ChannelDataHandoverMessage per Notify.  group 0 =
  * no group (a group of one).  Deviations: a member that is in a THIRD cell's map stays there (the reference would
  * also add it to dst's map, leaving it in two maps); "locked" is the entity's flag, not the notifier's lock-group
- * membership test.  Not available on region-sharded worlds. */
+ * membership test.  Not available on region-sharded worlds (there: chd_shard_set_handover_lists). */
 int chd_world_set_entity_groups(chd_ctx *ctx, uint32_t n, const uint32_t *idx, const uint32_t *group);
 
 /* The exact form: the engine is given what FlatEntityGroupController.GetHandoverEntities (entity.go:197-224) returns for
@@ -670,8 +670,12 @@ int chd_shard_comm_unique_id(void *id_out /* CHD_COMM_ID_BYTES */);
 int chd_shard_comm_init(chd_ctx *ctx, const void *unique_id, uint32_t rank, uint32_t world, uint32_t migrate_cap);
 int chd_shard_comm_destroy(chd_ctx *ctx);
 /* One tick: chd_shard_ingest -> all-to-all(emigrants) -> chd_shard_import -> all-to-all(v)(halo) beside chd_shard_interest ->
- * chd_shard_fanout, enqueued on the ctx stream (the halo exchange on a second stream of the library, joined by events) with no
- * host synchronisation.  Arguments as chd_shard_ingest (positions by channel id) and chd_shard_fanout (d_in: the queries). */
+ * chd_shard_fanout, enqueued on the ctx stream (and the library's second stream) with events between them: no host code, no
+ * host synchronisation.  Arguments as chd_shard_ingest (positions by channel id) and chd_shard_fanout (d_in: the queries).
+ * On a world created with CHD_WORLD_OVERLAP_INTEREST | CHD_WORLD_GATED_OVERLAP the interest updates run on the second stream from
+ * the tick's START — beside ingest, both exchanges and the index build; they read nothing the front writes — and are joined by a
+ * device-side flag inside the ghost-table unpack; the halo exchange then runs in stream order on the ctx stream (no events).
+ * Worlds with handover lists (chd_shard_set_handover_lists) take one more small exchange before the export. */
 int chd_shard_tick(chd_ctx *ctx, int64_t now_ns, const double *d_x_by_chan, const double *d_z_by_chan, const uint8_t *d_has_update,
                    uint32_t n_chan, const chd_tick_in *d_in);
 
