@@ -160,3 +160,28 @@ def test_a_failing_secondary_leg_is_reported_and_the_line_survives(monkeypatch):
 def test_only_timed_runs_nothing_but_the_timed_region(monkeypatch):
     d = run_bench(monkeypatch, ["--entities", "3000", "--subs", "300", "--steps", "3", "--warmup", "1", "--only-timed"])
     assert "cpu_baseline" not in d and "e2e" not in d and d["latency_ticks"] == 0
+
+
+def test_gpu_state_sampler_reads_the_hwmon_files(tmp_path, monkeypatch):
+    """bench.py's gpu_state: sclk / mclk / socket power / temperature from the amdgpu hwmon files of the first card that has them;
+    no such card (this container) -> None, never an error."""
+    import glob
+    import time
+
+    import bench
+
+    assert bench.GpuStateSampler().dir is None or os.path.isdir(bench.GpuStateSampler().dir)
+    d = tmp_path / "card7" / "device" / "hwmon" / "hwmon3"
+    d.mkdir(parents=True)
+    for name, val in (("freq1_input", "2400000000"), ("freq2_input", "2000000000"), ("power1_input", "555000000"), ("temp2_input", "46000")):
+        (d / name).write_text(val + "\n")
+    monkeypatch.setattr(glob, "glob", lambda pat: [str(d)])
+    with bench.GpuStateSampler() as s:
+        time.sleep(0.05)
+    g = s.summary()
+    assert g["samples"] >= 2 and g["sclk_mhz"]["mean"] == 2400.0 and g["mclk_mhz"]["max"] == 2000.0
+    assert g["socket_power_w"]["min"] == 555.0 and g["temp_c"]["mean"] == 46.0
+    monkeypatch.setattr(glob, "glob", lambda pat: [])
+    with bench.GpuStateSampler() as s2:
+        pass
+    assert s2.summary() is None
