@@ -645,16 +645,35 @@ def run_bench(args, rank: int, world: int, local_rank: int, verifier=None) -> di
     eng.sw.set_profiling(min(1024, max(K, L, 1)))
     # timed region: only the pair around the dominant kernel, on every 7th tick (bench.py: PROF_EVERY_DEFAULT); stage breakdown from the latency phase
     eng.sw.set_profiling_scope(True, every=int(getattr(args, "prof_every", 7) or 1))
+    # a collective that never completes (a rank that died, a fabric problem) would hang this process until its launcher's clock
+    # runs out, with nothing in the log: say which phase hung and end the run instead.  CHD_BENCH_WATCHDOG_S=0 turns it off.
+    import threading
+
+    wd_s = float(os.environ.get("CHD_BENCH_WATCHDOG_S", "600"))
+    phase = ["warm-up"]
+
+    def _hung():
+        print(f"bench.py rank {rank}: the {phase[0]} ticks of the sharded run did not finish within {wd_s:.0f} s "
+              f"(collectives driver: {'native RCCL' if eng.native else 'torch.distributed'}): giving up", file=sys.stderr, flush=True)
+        os._exit(3)
+
+    wd = threading.Timer(wd_s, _hung) if wd_s > 0 else None
+    if wd:
+        wd.daemon = True
+        wd.start()
     for t in range(V, W):
         tick(t)
     comm.barrier()
     torch.cuda.synchronize()
+    phase[0] = "timed"
     t0 = time.perf_counter()
     for t in range(W, W + K):
         tick(t)
     torch.cuda.synchronize()
     comm.barrier()
     elapsed = comm.max_float(time.perf_counter() - t0)
+    if wd:
+        wd.cancel()
 
     hist = eng.sw.history(min(K, 1024))
     msgs_local = sum(h["n_records"] for h in hist)
