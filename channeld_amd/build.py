@@ -14,9 +14,8 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libchd_spatial.so")
-# k_front.hip is a unity build of k_spatial.hip + k_index.hip + k_aoi.hip (it fuses their kernel bodies into one launch)
-SOURCES = ["chd_api.hip", "k_front.hip", "k_fanout.hip", "k_shard.hip", "k_recipients.hip", "k_wire.hip"]
-UNITY_PARTS = ["k_spatial.hip", "k_index.hip", "k_aoi.hip"]
+SOURCES = ["chd_api.hip", "k_spatial.hip", "k_index.hip", "k_aoi.hip", "k_fanout.hip", "k_shard.hip", "k_recipients.hip", "k_wire.hip"]
+UNITY_PARTS = []
 HEADERS = ["chd_device.h", "chd_kernels.h", os.path.join("..", "..", "include", "chd_spatial.h")]
 FLAGS = [
     "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off",

@@ -93,9 +93,14 @@ struct World {
     bool plan_recipients = false;      // CHD_WORLD_HANDOVER_RECIPIENTS
     bool overlap_interest = false;     // CHD_WORLD_OVERLAP_INTEREST
     bool join_in_unpack = false;       // chd_shard_tick -> shard_fanout_locked: k_halo_unpack carries the join
-    bool gated = false;                // CHD_WORLD_GATED_OVERLAP: its fork / join as device-side flags (GateArgs)
-    unsigned long long *gate = nullptr;
-    unsigned long long gate_cnt[8] = {0, 0, 0, 0, 0, 0, 0, 0}, gate_top = 0, gate_epi = 0;
+    // CHD_WORLD_GATED_OVERLAP: the fork / join of the interest stream as device-side flags (chd_kernels.h: GATE_*).  gate_asked =
+    // the world's flag; gated = ... and the context's two streams were SEEN to run side by side (gate_probe; again whenever
+    // chd_set_stream changes the pair), and no gate has timed out since (OVF_GATE: note_overflow turns it off for good)
+    bool gate_asked = false, gated = false;
+    unsigned long long *gate = nullptr;  // [GATE_WORDS] the two counters, then the probe's scratch
+    unsigned long long gate_top = 0, gate_epi = 0;
+    uint32_t gate_timeouts = 0;
+    unsigned long long test_drop_raise = 0;  // CHD_TEST_DROP_GATE_RAISE (tests of the time-out path)
     bool overlap_deferred = false;     // CHD_WORLD_OVERLAP_DEFERRED
     // CHD_WORLD_PIPELINE_TICKS: everything the record-writing kernel reads (and the record buffer) exists twice, by tick parity
     bool pipe_alloc = false, pipe_on = false;
@@ -104,7 +109,6 @@ struct World {
     uint4 *pb_seg_desc[2] = {nullptr, nullptr}, *pb_seg_desc2[2] = {nullptr, nullptr};
     chd_fanout_rec *pb_recs[2] = {nullptr, nullptr};
     hipEvent_t ev_stages_done = nullptr, ev_stages_all = nullptr, ev_rec_sync = nullptr, ev_emit_done[2] = {nullptr, nullptr};
-    unsigned long long front_seq = 0;  // fused front launches so far (k_front.hip: its grid-barrier counters only grow)
     bool last_desc = false;            // the last tick took the descriptor path (k_fanout_plan_seg's descriptors are this tick's)
     uint32_t *seg_cnt = nullptr;       // [S + 1] chd_tick_fetch_segments: segments per connection -> offsets
     uint64_t *seg_exp = nullptr;       // [S + 1] explicit records per connection -> offsets
@@ -113,6 +117,7 @@ struct World {
     // native collectives (chd_shard_comm_init): the two exchanges of a sharded tick on RCCL inside the library
     ncclComm_t comm = nullptr;
     uint32_t comm_rank = 0, comm_world = 0, comm_cap = 0;
+    uint32_t comm_alloc_cap = 0, comm_alloc_world = 0;  // what mig_send / mig_recv / the halo buffers were sized for
     chd_entity_state *mig_send = nullptr, *mig_recv = nullptr;   // [world][cap + 1]
     chd_handover_request *req_send = nullptr, *req_recv = nullptr;  // [world][CHD_SHARD_REQ_CAP + 1] (handover lists only)
     unsigned char *halo_send_buf = nullptr, *halo_recv_buf = nullptr;
@@ -420,6 +425,64 @@ __global__ void __launch_bounds__(256) k_widen(const uint32_t *in, uint64_t *out
     if (i < n) out[i] = in[i];
 }
 
+namespace {
+// CHD_WORLD_GATED_OVERLAP holds only where a kernel on the tick's stream can WAIT for a kernel on the second stream: probed with the
+// real thing (streams_run_side_by_side), at world creation and whenever the stream pair changes.  Resets the counters: the
+// probe leaves the flags' lines dirty, and a changed pair starts a new chain anyway.
+static int gate_probe(chd_ctx *ctx) {
+    World &W = ctx->w;
+    W.gated = false;
+    if (!W.gate_asked || !W.gate || W.gate_timeouts) return CHD_OK;
+    bool ok = false;
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->aux_stream));
+    // (the serial schedule's pair, and the pipelined schedule's: its stages run on aux_stream, its interest updates on aux2_stream)
+    bool ok2 = true;
+    if (streams_run_side_by_side(ctx->stream, ctx->aux_stream, W.gate + GATE_WORDS, (unsigned *)(W.gate + GATE_WORDS + 16), &ok) != 0 ||
+        (ok && W.pipe_alloc && streams_run_side_by_side(ctx->aux_stream, ctx->aux2_stream, W.gate + GATE_WORDS, (unsigned *)(W.gate + GATE_WORDS + 16), &ok2) != 0))
+        return fail(ctx, CHD_E_HIP, "CHD_WORLD_GATED_OVERLAP: the stream probe failed");
+    ok = ok && ok2;
+    HIPCHK(hipMemsetAsync(W.gate, 0, sizeof(unsigned long long) * (GATE_WORDS + 32), ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    W.gate_top = W.gate_epi = 0;
+    ctx->gchain = ctx->gchain_prev = false;
+    W.gated = ok;
+    return CHD_OK;
+}
+
+static uint32_t schedule_bits(const chd_ctx *ctx) {
+    const World &W = ctx->w;
+    return (W.overlap_interest ? CHD_SCHED_OVERLAP_INTEREST : 0u) | (W.gated ? CHD_SCHED_GATED : 0u) | (W.pipe_on ? CHD_SCHED_PIPELINED : 0u);
+}
+
+// Every call that synchronises with the device and looks at a tick's results passes here: a gate that timed out (the sticky
+// count behind WorldDev::gate_fail; the tick it happened in carries overflow bit 0x4000 in its own row of the tick history) means
+// the two streams did not run side by side after all — the world takes HIP events from now on.
+static int gate_poll_begin(chd_ctx *ctx, unsigned long long *fails) {  // (enqueue; the caller's own synchronisation completes it)
+    World &W = ctx->w;
+    *fails = 0;
+    if (W.gate && W.gated) HIPCHK(hipMemcpyAsync(fails, W.gate + GATE_FAIL, sizeof *fails, hipMemcpyDeviceToHost, ctx->stream));
+    return CHD_OK;
+}
+static void gate_poll_end(chd_ctx *ctx, unsigned long long fails) {
+    World &W = ctx->w;
+    if (W.gated && fails > W.gate_timeouts) {
+        W.gate_timeouts = (uint32_t)fails;
+        W.gated = false;
+        ctx->gchain = ctx->gchain_prev = false;
+        fprintf(stderr, "chd: CHD_WORLD_GATED_OVERLAP: a device-side gate timed out (overflow bit 0x4000 in that tick): this world orders its streams with HIP events from now on\n");
+    }
+}
+static int gate_check(chd_ctx *ctx) {
+    unsigned long long fails = 0;
+    TRY(gate_poll_begin(ctx, &fails));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    gate_poll_end(ctx, fails);
+    return CHD_OK;
+}
+
+}  // namespace
+
 extern "C" {
 
 int chd_abi_version(void) { return CHD_ABI_VERSION; }
@@ -580,6 +643,7 @@ int chd_sync(chd_ctx *ctx) {
     if (!ctx) return fail(nullptr, CHD_E_INVAL, "NULL ctx");
     std::lock_guard<FairMutex> lk(ctx->mu);
     TRY(bind(ctx));
+    if (ctx->w.created) return gate_check(ctx);
     HIPCHK(hipStreamSynchronize(ctx->stream));
     return CHD_OK;
 }
@@ -916,13 +980,11 @@ int chd_world_create(chd_ctx *ctx, const chd_world_cfg *cfg) {
     if (const char *e = getenv("CHD_WORLD_FORCE_FLAGS")) wflags |= (uint32_t)strtoul(e, nullptr, 0) & (CHD_WORLD_OVERLAP_INTEREST | CHD_WORLD_OVERLAP_DEFERRED | CHD_WORLD_GATED_OVERLAP);
     W.overlap_interest = (wflags & CHD_WORLD_OVERLAP_INTEREST) != 0;  // (exact update buffers: WorldDev::max_iv is double-buffered for this)
     W.overlap_deferred = (wflags & CHD_WORLD_OVERLAP_DEFERRED) != 0 && !cfg->history_depth;
-    W.gated = W.overlap_interest && (wflags & CHD_WORLD_GATED_OVERLAP) != 0;
-    if (W.gated) {
-        TRY(walloc(ctx, &W.gate, 10 * 16));
-        bool holds = false;  // (the release protocol of the gates: workgroup b on XCD b % 8; else the event form stays)
-        if (xcc_mapping_holds(ctx->stream, (unsigned *)W.gate, &holds) != 0) return fail(ctx, CHD_E_HIP, "XCD mapping probe failed");
-        HIPCHK(hipMemsetAsync(W.gate, 0, sizeof(unsigned long long) * 10 * 16, ctx->stream));
-        W.gated = holds;
+    W.gate_asked = W.overlap_interest && (wflags & CHD_WORLD_GATED_OVERLAP) != 0;
+    W.gated = false;
+    if (W.gate_asked) {  // (probed at the end of this function)
+        TRY(walloc(ctx, &W.gate, GATE_WORDS + 32));
+        d.gate_fail = W.gate + GATE_FAIL;
     }
     {
         hipDeviceProp_t prop;
@@ -938,7 +1000,6 @@ int chd_world_create(chd_ctx *ctx, const chd_world_cfg *cfg) {
     d.ghost_cap = 0;
     TRY(walloc(ctx, &d.free_stack, N));
     TRY(walloc(ctx, &d.free_top, 1));
-    TRY(walloc(ctx, &d.front_bar, (8 + 8 + 1) * 16));  // (k_front.hip: struct FrontBar)
     d.limbo = nullptr;  // (chd_shard_halo_layout)
     TRY(walloc(ctx, &d.limbo_n, 2));
     TRY(walloc(ctx, &d.mig_gmax, 4));
@@ -1183,6 +1244,8 @@ int chd_world_create(chd_ctx *ctx, const chd_world_cfg *cfg) {
     launch_free_stack_init(ctx->stream, d);
     TRY(after_launch(ctx));
     HIPCHK(hipStreamSynchronize(ctx->stream));
+    if (W.gate_asked) TRY(gate_probe(ctx));
+    if (const char *e = getenv("CHD_TEST_DROP_GATE_RAISE")) W.test_drop_raise = strtoull(e, nullptr, 0);
     W.created = true;
     return CHD_OK;
 }
@@ -1563,18 +1626,7 @@ static int tick_locked(chd_ctx *ctx, const chd_tick_in *in) {
     // only, so the two can run side by side on two streams and join before the fan-out plan.  (Not with handover
     // recipients: those are planned on the subscriptions as they were BEFORE this tick's interest updates.)
     // Pipelined ticks always do, on a third stream (their stages are latency-bound and run beside an HBM-saturating kernel).
-    // The front of the tick — ingest -> cell index, and the interest updates — in ONE launch where it can be (k_front.hip):
-    // grids of up to 1024 cells, up to 512 index tiles (256 K entity slots), one round of updates, nothing between the ingest
-    // and the index (spatial-channel updates, handover recipients), no exact update buffers (their maxFanOutIntervalMs is
-    // written by the interest updates and read by the ingest).  OFF unless CHD_FRONT_FUSED=1: measured on config B it does not
-    // pay — the index chain with its three XCD-hierarchical grid barriers takes 44.6 us inside the launch (37 us as four
-    // kernels: a dependent kernel boundary costs ~1.5 us, a grid barrier 4-5), the interest half 44.3 us in 256-thread
-    // workgroups (40 in 64-thread ones), and together they take 68 us, not max(): both halves are issue-bound on the same CUs.
-    // Tick 0.2670 (fused) against 0.2695 ms.  Kept as an experiment (profiles/r03j_front_fusion.json).
-    const bool front_on = [] { const char *e = getenv("CHD_FRONT_FUSED"); return e && e[0] == '1'; }();
-    const bool fuse = front_on && front_fusable(ctx->g, d) && !W.plan_recipients && !in->n_cell_updates && in->n_update_rounds <= 1 &&
-                      !d.deep_depth && in->n_queries > 0 && in->n_updates > 0;
-    const bool overlap = !fuse && (W.overlap_interest || pipe) && !W.plan_recipients && in->n_queries > 0;
+    const bool overlap = (W.overlap_interest || pipe) && !W.plan_recipients && in->n_queries > 0;
     const bool gated = overlap && W.gated && (pipe || !(W.overlap_deferred && fanout_seg_path(d)));
     // stage events: the serial schedule marks every stage boundary; the pipelined one only the begin and end of the stage
     // stream's work (a timed event between two small kernels costs ~5 us of idle stream) — stage_times() reports that
@@ -1586,14 +1638,7 @@ static int tick_locked(chd_ctx *ctx, const chd_tick_in *in) {
         ctx->ev_overlap[r.cur_tick % (uint32_t)ctx->prof_depth] = (overlap ? 1 : 0) | (pipe ? 2 : 0) | (prof_ends ? 0 : 4);
         if (prof_ends) HIPCHK(hipEventRecord(ev[0], bs));
     }
-    if (fuse) {
-        launch_front(bs, ctx->g, ctx->lim, d, ++W.front_seq, in->n_updates, in->upd_idx, in->upd_x, in->upd_z, in->upd_sender,
-                     in->upd_arrival_ns, in->queries, in->n_queries, in->query_sub, in->spot_x, in->spot_z, in->spot_dist, in->now_ns,
-                     r.cur_tick);
-        if (d.wcol_on && fanout_seg_path(d)) launch_window_columns(bs, ctx->g, d);
-        // (one launch: the ingest / index / interest stage times read as one, under CHD_STAGE_INGEST)
-        if (prof_stages) { HIPCHK(hipEventRecord(ev[1], bs)); HIPCHK(hipEventRecord(ev[2], bs)); }
-    } else {
+    {
         if (overlap) {
             hipStream_t ax = pipe ? ctx->aux2_stream : ctx->aux_stream;
             // fork: the second stream starts after everything enqueued on this one so far — or, gated and directly behind a gated
@@ -1604,18 +1649,11 @@ static int tick_locked(chd_ctx *ctx, const chd_tick_in *in) {
                 HIPCHK(hipStreamWaitEvent(ax, ctx->ev_fork, 0));
             }
             if (prof_stages) HIPCHK(hipEventRecord(ev[CHD_N_STAGES + 1], ax));
-            GateArgs ga{};
-            if (gated) {
-                const uint32_t nb = aoi_interest_blocks(ctx->lim, d, in->n_queries);
-                ga.base = W.gate;
-                for (uint32_t k = 0; k < 8; k++) {
-                    if (k < nb) W.gate_cnt[k] += (nb - k + 7u) / 8u;
-                    ga.cnt_target[k] = W.gate_cnt[k];
-                }
-                W.gate_top += std::min(nb, 8u);
-            }
+            if (gated) W.gate_top++;  // (the join: a one-wave kernel behind the interest launch raises the flag, k_gate_raise)
+            // (CHD_TEST_DROP_GATE_RAISE=k, tests only: the k-th gated tick of the world never raises its flag — the time-out path)
+            const bool drop_raise = gated && W.test_drop_raise && W.gate_top == W.test_drop_raise;
             launch_aoi_interest(ax, ctx->g, ctx->lim, d, in->queries, in->n_queries, in->query_sub, in->spot_x, in->spot_z,
-                                in->spot_dist, in->now_ns, r.cur_tick, gated ? &ga : nullptr);
+                                in->spot_dist, in->now_ns, r.cur_tick, (gated && !drop_raise) ? W.gate + GATE_TOP : nullptr, W.gate_top);
             if (prof_stages) HIPCHK(hipEventRecord(ev[CHD_N_STAGES + 2], ax));
             if (!gated) HIPCHK(hipEventRecord(ctx->ev_join, ax));
         }
@@ -1796,7 +1834,10 @@ static int fetch_locked(chd_ctx *ctx, chd_tick_out *out) {
     TRY(down(ctx, ringrow, d.tick_ring + (size_t)(ctx->ring.cur_tick % TICK_RING) * 8, sizeof ringrow));
     uint64_t total = 0;
     TRY(down(ctx, &total, W.rec_off_exact + d.S, sizeof total));
+    unsigned long long gate_fails = 0;
+    TRY(gate_poll_begin(ctx, &gate_fails));
     HIPCHK(hipStreamSynchronize(st));
+    gate_poll_end(ctx, gate_fails);
     ctr[CTR_HANDOVERS] = (uint32_t)ringrow[2];
     ctr[CTR_LOCKED] = (uint32_t)ringrow[3];
     ctr[CTR_UNSUBS] = (uint32_t)ringrow[4];
@@ -1953,7 +1994,10 @@ int chd_tick_fetch_segments(chd_ctx *ctx, chd_segments_out *out) {
     TRY(down(ctx, out->segments, W.seg_stage, sizeof(chd_fanout_segment) * (size_t)nseg));
     TRY(down(ctx, out->records, W.seg_rec_stage, sizeof(chd_fanout_rec) * nexp));
     if (ncol) TRY(down(ctx, out->columns, d.ce_chan_view, sizeof(uint32_t) * ncol));
+    unsigned long long gate_fails = 0;
+    TRY(gate_poll_begin(ctx, &gate_fails));
     HIPCHK(hipStreamSynchronize(st));
+    gate_poll_end(ctx, gate_fails);
     if (ringrow[7] & 0xFFFFFFFFull) return fail(ctx, CHD_E_CAPACITY, "tick output truncated (overflow mask 0x%x)", (uint32_t)ringrow[7]);
     return CHD_OK;
 }
@@ -1977,7 +2021,10 @@ int chd_tick_digest(chd_ctx *ctx, chd_records_digest *total, uint64_t *conn_sum)
     uint64_t b[64 * 16];
     TRY(down(ctx, b, sbuf<void>(ctx, 14), sizeof b));
     if (conn_sum) TRY(down(ctx, conn_sum, sbuf<void>(ctx, 15), sizeof(uint64_t) * d.S));
+    unsigned long long gate_fails = 0;
+    TRY(gate_poll_begin(ctx, &gate_fails));
     HIPCHK(hipStreamSynchronize(st));
+    gate_poll_end(ctx, gate_fails);
     memset(total, 0, sizeof *total);
     for (int k = 0; k < 64; k++) {
         total->count += b[k * 16];
@@ -2093,6 +2140,7 @@ int chd_set_stream(chd_ctx *ctx, void *hip_stream, int external) {
     TRY(bind(ctx));
     HIPCHK(hipStreamSynchronize(ctx->stream));
     ctx->stream = external ? (hipStream_t)hip_stream : ctx->own_stream;
+    if (ctx->w.created) TRY(gate_probe(ctx));  // (CHD_WORLD_GATED_OVERLAP: does THIS pair of streams run side by side?)
     return CHD_OK;
 }
 
@@ -2503,6 +2551,28 @@ int rccl_load(chd_ctx *ctx) {
     } while (0)
 }  // namespace
 
+// the communicator, its stream and events go (the exchange buffers are the world's and stay); every handle is nulled
+static int comm_teardown(chd_ctx *ctx) {
+    World &W = ctx->w;
+    int rc = CHD_OK;
+    if (W.comm) {
+        const ncclResult_t r = g_rccl.CommDestroy(W.comm);
+        if (r != ncclSuccess) rc = fail(ctx, CHD_E_HIP, "ncclCommDestroy failed: %s", g_rccl.GetErrorString(r));
+        W.comm = nullptr;
+    }
+    if (W.comm_stream) { (void)hipStreamDestroy(W.comm_stream); W.comm_stream = nullptr; }
+    if (W.ev_halo_ready) { (void)hipEventDestroy(W.ev_halo_ready); W.ev_halo_ready = nullptr; }
+    if (W.ev_halo_done) { (void)hipEventDestroy(W.ev_halo_done); W.ev_halo_done = nullptr; }
+    W.comm_world = W.comm_rank = W.comm_cap = 0;
+    ctx->gchain = ctx->gchain_prev = false;
+    return rc;
+}
+
+int chd_shard_comm_available(void) {
+    chd_ctx *ctx = nullptr;
+    return rccl_load(ctx);
+}
+
 int chd_shard_comm_unique_id(void *id_out) {
     if (!id_out) return fail(nullptr, CHD_E_INVAL, "chd_shard_comm_unique_id: NULL output");
     chd_ctx *ctx = nullptr;
@@ -2530,21 +2600,38 @@ int chd_shard_comm_init(chd_ctx *ctx, const void *unique_id, uint32_t rank, uint
     W.halo_segs.assign(world, chd_halo_seg{0, 0, 0, 0});
     uint64_t st = 0, rt = 0;
     TRY(shard_halo_layout_locked(ctx, rank, world, W.halo_segs.data(), &st, &rt));
-    const size_t seg = (size_t)migrate_cap + 1;
-    TRY(walloc(ctx, &W.mig_send, (size_t)world * seg));
-    TRY(walloc(ctx, &W.mig_recv, (size_t)world * seg));
-    TRY(walloc(ctx, &W.halo_send_buf, std::max<uint64_t>(st, 16)));
-    TRY(walloc(ctx, &W.halo_recv_buf, std::max<uint64_t>(rt, 16)));
-    HIPCHK(hipStreamCreateWithFlags(&W.comm_stream, hipStreamNonBlocking));
-    HIPCHK(hipEventCreateWithFlags(&W.ev_halo_ready, hipEventDisableTiming));
-    HIPCHK(hipEventCreateWithFlags(&W.ev_halo_done, hipEventDisableTiming));
+    // the communicator FIRST (a collective: every rank is inside it, or none gets out); only a rank that has one allocates the
+    // exchange buffers, the second stream and the events — a failed init leaves nothing behind and may be retried
     HIPCHK(hipStreamSynchronize(ctx->stream));
     ncclUniqueId id;
     memcpy(&id, unique_id, sizeof id);
-    NCCLCHK(g_rccl.CommInitRank(&W.comm, (int)world, id, (int)rank));
+    ncclComm_t comm = nullptr;
+    NCCLCHK(g_rccl.CommInitRank(&comm, (int)world, id, (int)rank));
+    W.comm = comm;
     W.comm_rank = rank;
     W.comm_world = world;
     W.comm_cap = migrate_cap;
+    const size_t seg = (size_t)migrate_cap + 1;
+    int rc = CHD_OK;
+    if (!W.mig_send) {  // (world allocations: kept across chd_shard_comm_destroy / a second init of the same size)
+        if (rc == CHD_OK) rc = walloc(ctx, &W.mig_send, (size_t)world * seg);
+        if (rc == CHD_OK) rc = walloc(ctx, &W.mig_recv, (size_t)world * seg);
+        if (rc == CHD_OK) rc = walloc(ctx, &W.halo_send_buf, std::max<uint64_t>(st, 16));
+        if (rc == CHD_OK) rc = walloc(ctx, &W.halo_recv_buf, std::max<uint64_t>(rt, 16));
+        W.comm_alloc_cap = migrate_cap;
+        W.comm_alloc_world = world;
+    } else if (W.comm_alloc_cap != migrate_cap || W.comm_alloc_world != world) {
+        rc = fail(ctx, CHD_E_STATE, "chd_shard_comm_init: the context's exchange buffers were sized for %u ranks x %u emigrants", W.comm_alloc_world, W.comm_alloc_cap);
+    }
+    if (rc == CHD_OK && hipStreamCreateWithFlags(&W.comm_stream, hipStreamNonBlocking) != hipSuccess) rc = fail(ctx, CHD_E_HIP, "chd_shard_comm_init: no second stream");
+    if (rc == CHD_OK && (hipEventCreateWithFlags(&W.ev_halo_ready, hipEventDisableTiming) != hipSuccess ||
+                         hipEventCreateWithFlags(&W.ev_halo_done, hipEventDisableTiming) != hipSuccess))
+        rc = fail(ctx, CHD_E_HIP, "chd_shard_comm_init: no events");
+    if (rc != CHD_OK) {
+        const std::string why = ctx->err;
+        comm_teardown(ctx);
+        return fail(ctx, rc, "%s", why.c_str());
+    }
     return CHD_OK;
 }
 
@@ -2555,14 +2642,8 @@ int chd_shard_comm_destroy(chd_ctx *ctx) {
     if (!W.comm) return CHD_OK;
     TRY(bind(ctx));
     HIPCHK(hipStreamSynchronize(ctx->stream));
-    HIPCHK(hipStreamSynchronize(W.comm_stream));
-    NCCLCHK(g_rccl.CommDestroy(W.comm));
-    W.comm = nullptr;
-    (void)hipStreamDestroy(W.comm_stream);
-    W.comm_stream = nullptr;
-    (void)hipEventDestroy(W.ev_halo_ready);
-    (void)hipEventDestroy(W.ev_halo_done);
-    return CHD_OK;
+    if (W.comm_stream) HIPCHK(hipStreamSynchronize(W.comm_stream));
+    return comm_teardown(ctx);
 }
 
 // One tick of a region-sharded world with both exchanges inside: no host code between the stages, everything ordered by
@@ -2580,6 +2661,7 @@ int chd_shard_tick(chd_ctx *ctx, int64_t now_ns, const double *d_x_by_chan, cons
     std::lock_guard<FairMutex> lk(ctx->mu);
     World &W = ctx->w;
     if (!W.comm) return fail(ctx, CHD_E_STATE, "chd_shard_tick before chd_shard_comm_init");
+    TRY(check_queries(ctx, d_in));  // (before anything is enqueued: a refused tick leaves the world — and the gate counters — untouched)
     const uint32_t world = W.comm_world, rank = W.comm_rank;
     hipStream_t st = ctx->stream;
     uint32_t use = W.comm_cap;
@@ -2610,23 +2692,15 @@ int chd_shard_tick(chd_ctx *ctx, int64_t now_ns, const double *d_x_by_chan, cons
         TRY(shard_ingest_post_locked(ctx, nullptr, 0, rank, world, W.mig_send, W.comm_cap, &use));
     }
     if (g_on && d_in->n_queries) {
-        TRY(check_queries(ctx, d_in));
         hipStream_t ax = ctx->aux_stream;
         if (chained) launch_gate_wait(ax, W.d, W.gate + GATE_EPI, W.gate_epi);  // after the previous tick's epilogue
         else {
             HIPCHK(hipEventRecord(ctx->ev_fork, st));  // (recorded behind this tick's ingest: harmless, the two are independent)
             HIPCHK(hipStreamWaitEvent(ax, ctx->ev_fork, 0));
         }
-        GateArgs ga{};
-        const uint32_t nb = aoi_interest_blocks(ctx->lim, W.d, d_in->n_queries);
-        ga.base = W.gate;
-        for (uint32_t k = 0; k < 8; k++) {
-            if (k < nb) W.gate_cnt[k] += (nb - k + 7u) / 8u;
-            ga.cnt_target[k] = W.gate_cnt[k];
-        }
-        W.gate_top += std::min(nb, 8u);
+        W.gate_top++;
         launch_aoi_interest(ax, ctx->g, ctx->lim, W.d, d_in->queries, d_in->n_queries, d_in->query_sub, d_in->spot_x, d_in->spot_z,
-                            d_in->spot_dist, W.last_now, ctx->ring.cur_tick, &ga);
+                            d_in->spot_dist, W.last_now, ctx->ring.cur_tick, W.gate + GATE_TOP, W.gate_top);
     }
     const size_t seg = (size_t)use + 1;
     {   // the cross-server handovers (spatial.go:683-700): every rank's segment for every other rank, 32 B per emigrant.
@@ -3211,7 +3285,11 @@ int chd_get_tick_history(chd_ctx *ctx, uint32_t n, chd_tick_stats *out) {
         s.n_filtered_records = (uint32_t)(r[3] >> 32);
         s.algorithmic_bytes = 12ull * s.n_records + 32ull * s.n_handovers;
         if (ctx->prof_depth > 0 && k < (uint32_t)ctx->prof_depth) stage_times(ctx, tick, s);
+        s.overflow = (uint32_t)r[7];
+        s.history_overflow = (uint32_t)(r[7] >> 32);
     }
+    TRY(gate_check(ctx));
+    for (uint32_t k = 0; k < n; k++) { out[k].schedule = schedule_bits(ctx); out[k].gate_timeouts = ctx->w.gate_timeouts; }
     return CHD_OK;
 }
 
@@ -3221,6 +3299,8 @@ int chd_get_tick_stats(chd_ctx *ctx, chd_tick_stats *out) {
     // byte model of DESIGN.md §4: 12 B per emitted message dominate
     chd_tick_stats s = ctx->stats;
     s.algorithmic_bytes = 12ull * s.n_records + 32ull * s.n_handovers;
+    s.schedule = schedule_bits(ctx);
+    s.gate_timeouts = ctx->w.gate_timeouts;
     *out = s;
     return CHD_OK;
 }

@@ -57,6 +57,7 @@ enum {
 #define OVF_RECORDS 4u
 #define OVF_NEWSUB 8u
 #define OVF_INTERNAL 0x8000u  // a kernel's defensive loop bound tripped (a bug, never a capacity)
+#define OVF_GATE 0x4000u      // CHD_WORLD_GATED_OVERLAP: a device-side gate was not raised within its spin bound (the two streams did not run side by side): this tick's results are not valid; the world takes the event form from the next tick on
 #define OVF_SLOTS 16u    // sharded world: no free entity slot for a spawn / an immigrant (the immigrant waits in limbo, k_shard.hip)
 #define OVF_MIGRATE 32u  // sharded world: an emigrant did not fit its destination's send segment
 #define OVF_HALO 64u     // sharded world: a border band did not fit its halo segment, or a subscription reaches a cell beyond the halo

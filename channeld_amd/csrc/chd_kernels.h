@@ -171,7 +171,6 @@ struct WorldDev {
     uint32_t *limbo_n;        // [2]
     uint32_t *mig_gmax;       // [4] by tick & 3: the largest emigrant segment count of that tick's exchange, over ALL ranks
     // subscribers
-    unsigned long long *front_bar;  // [3 x 16] grid-barrier counters of the fused front kernel (k_front.hip), one 128-byte line each
     unsigned char *aoi_scratch;  // [S * aoi_scratch_bytes] the interest kernel's long-lattice work areas, per subscriber slot
     uint32_t *conn_id;    // [S]
     uint32_t *sub_alive;  // [S]
@@ -228,9 +227,16 @@ struct WorldDev {
     uint32_t list_bank_cap;
     int32_t *q_status;    // [S]
     uint32_t *counters;   // CTR_COUNT
+    unsigned long long *gate_fail;  // CHD_WORLD_GATED_OVERLAP (else nullptr): gates that timed out, ever (sticky: the per-tick counters are cleared by every epilogue)
     uint64_t *tot64;      // [64][16] hashed per-tick totals, one 128-B line per bucket: {records, subscriptions}
     uint64_t *tick_ring;  // [TICK_RING][8] per-tick totals written by the epilogue
 };
+
+// a gate's spin bound tripped (OVF_GATE): this tick's mask, and the world's sticky count (the host turns the gates off when it sees it)
+__device__ __forceinline__ void gate_timed_out(const WorldDev &w) {
+    atomicOr(&w.counters[CTR_OVERFLOW], OVF_GATE);
+    if (w.gate_fail) atomicAdd(w.gate_fail, 1ull);
+}
 
 // ChannelData.OnUpdate (data.go:159-164) on the entity channel's bit-mask update
 // buffer.  Every buffered update keeps its senderConnId (tickData compares it with
@@ -406,10 +412,6 @@ void launch_halo_unpack(hipStream_t st, DevGrid g, WorldDev w, uint32_t rank, ui
 // K2: cell index build
 bool launch_index_build(hipStream_t st, DevGrid g, WorldDev w, uint32_t cur_tick, const unsigned long long *gate_p = nullptr,
                         unsigned long long gate_target = 0);
-// K1 + K2 + K3/K4 in ONE launch (k_front.hip): the ingest -> index chain beside the interest updates.  launch_seq = 1, 2, ...
-// (how many times this world has taken the fused launch: the grid-barrier counters only grow).
-struct AoiLimits;
-bool front_fusable(const DevGrid &g, const WorldDev &w);
 // the window columns of the cells that are not fully updated (WorldDev::wcol_*); after the index build
 void launch_window_columns(hipStream_t st, DevGrid g, WorldDev w);
 #define CHD_WCOLS 9
@@ -422,10 +424,6 @@ struct AoiLimits {
     uint32_t winmax;  // cells in the per-query table
     uint32_t maxdim;  // max(window width, window height) <= max(cols, rows)
 };
-void launch_front(hipStream_t st, DevGrid g, AoiLimits lim, WorldDev w, unsigned long long launch_seq, uint32_t n_upd,
-                  const uint32_t *upd_idx, const double *upd_x, const double *upd_z, const uint32_t *upd_sender,
-                  const int64_t *upd_arrival, const chd_aoi_query *queries, uint32_t nq, const uint32_t *q_sub,
-                  const double *spot_x, const double *spot_z, const uint32_t *spot_dist, int64_t now_ns, uint32_t cur_tick);
 void launch_aoi_stateless(hipStream_t st, DevGrid g, AoiLimits lim, const chd_aoi_query *q,
                           uint32_t nq, const double *spot_x, const double *spot_z,
                           const uint32_t *spot_dist, uint32_t stride, uint32_t *cells,
@@ -433,24 +431,22 @@ void launch_aoi_stateless(hipStream_t st, DevGrid g, AoiLimits lim, const chd_ao
 size_t aoi_scratch_bytes(AoiLimits lim);  // global scratch per query (long-lattice path)
 // CHD_WORLD_GATED_OVERLAP: the two cross-stream dependencies of a serial tick whose interest updates run on a second stream,
 // as device-side flags instead of HIP events (an event record idles the recording stream ~7 us, a cross-queue wait takes ~11 us
-// to resolve: profiles/r04t_tick_timeline_*.csv).  `base` = 10 counters on their own 128-byte lines: [0..7] arrivals of the
-// interest launch's workgroups by group (blockIdx & 7 = the XCD they are observed to run on), [8] groups complete, [9] ticks
-// whose epilogue has finished.  Counters only grow; `cnt_target[g]` = cumulative members of group g including this launch.
-struct GateArgs {
-    unsigned long long *base;
-    unsigned long long cnt_target[8];
-};
-#define GATE_TOP (8 * 16)
-#define GATE_EPI (9 * 16)
+// to resolve: profiles/r04t_tick_timeline_*.csv).  Two monotonic counters on their own 128-byte lines: [GATE_TOP] interest
+// launches complete — raised by a one-wave kernel BEHIND the interest launch on its stream, so the release is the kernel
+// boundary itself and holds wherever the dispatcher placed the workgroups — and [GATE_EPI] ticks whose epilogue has finished.
+#define GATE_TOP 0
+#define GATE_EPI 16
+#define GATE_FAIL 32
+#define GATE_WORDS 48
 void launch_aoi_interest(hipStream_t st, DevGrid g, AoiLimits lim, WorldDev w,
                          const chd_aoi_query *q, uint32_t nq, const uint32_t *q_sub,
                          const double *spot_x, const double *spot_z, const uint32_t *spot_dist,
-                         int64_t now_ns, uint32_t cur_tick, const GateArgs *gate = nullptr, uint32_t *n_blocks_out = nullptr);
-uint32_t aoi_interest_blocks(AoiLimits lim, const WorldDev &w, uint32_t nq);  // workgroups of that launch
-// do the workgroups of a launch with equal (id % 8) share an XCD here?  (what the gates' release protocol rests on; checked once per
-// world.  NOT checked per workgroup: s_getreg HW_REG_XCC_ID costs ~20 us per wave under load — a 40 us kernel took 217)
-int xcc_mapping_holds(hipStream_t st, unsigned *d_scratch /* >= 4 bytes */, bool *holds);
-// one wave that returns when *p >= target (bounded: a dependency that never resolves flags overflow bit 0x8000 instead of hanging)
+                         int64_t now_ns, uint32_t cur_tick, unsigned long long *gate_p = nullptr, unsigned long long gate_value = 0);
+void launch_gate_raise(hipStream_t st, unsigned long long *p, unsigned long long value);
+// do kernels of the two streams run side by side (a waiter on one sees a flag raised on the other)?  What the gates need; probed
+// once per world with a bounded wait (tens of ms when they do not)
+int streams_run_side_by_side(hipStream_t waiter_st, hipStream_t raiser_st, unsigned long long *d_flag, unsigned *d_seen, bool *ok);
+// one wave that returns when *p >= target (bounded: a dependency that never resolves raises OVF_GATE instead of hanging)
 void launch_gate_wait(hipStream_t st, WorldDev w, const unsigned long long *p, unsigned long long target);
 size_t aoi_lds_bytes(AoiLimits lim, uint32_t capq);
 size_t aoi_lds_limit();  // the most dynamic LDS an AOI launch may ask for (gfx950: 160 KiB per CU)

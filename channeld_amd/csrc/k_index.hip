@@ -280,7 +280,7 @@ __global__ void __launch_bounds__(IDX_BLOCK) k_index_scatter(WorldDev w, uint32_
         uint32_t spins = 0;
         while (__hip_atomic_load(gate_p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < gate_target) {
             __builtin_amdgcn_s_sleep(2);
-            if (++spins > (1u << 23)) { atomicOr(&w.counters[CTR_OVERFLOW], OVF_INTERNAL); break; }  // (a bug, never a capacity)
+            if (++spins > (1u << 23)) { gate_timed_out(w); break; }  // (a bug, never a capacity)
         }
     }
 }

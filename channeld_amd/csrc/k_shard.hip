@@ -424,7 +424,7 @@ __global__ void __launch_bounds__(256) k_halo_unpack(DevGrid g, WorldDev w, uint
             uint32_t spins = 0;
             while (__hip_atomic_load(gate_p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < gate_target) {
                 __builtin_amdgcn_s_sleep(2);
-                if (++spins > (1u << 23)) { atomicOr(&w.counters[CTR_OVERFLOW], OVF_INTERNAL); break; }
+                if (++spins > (1u << 23)) { gate_timed_out(w); break; }
             }
         }
         return;

@@ -280,19 +280,41 @@ class HipShardEngine:
         self._ti_native = _lib.TickIn()
         self._r_native = C.byref(self._ti_native)
 
-    def comm_init_native(self, comm: "Comm"):
+    def comm_init_native(self, comm: "Comm") -> str | None:
         """The library's own communicator (include/chd_spatial.h: chd_shard_comm_*): rank 0 draws the RCCL unique id, the
         ranks' existing control channel — here torch.distributed, in a gateway its own connection between the gateways — carries
-        the 128 bytes, every rank joins.  From then on a tick is ONE C call (tick_native): no Python, no torch between the stages."""
+        the 128 bytes, every rank joins.  From then on a tick is ONE C call (tick_native): no Python, no torch between the stages.
+
+        COLLECTIVE, and every rank takes the same path through it whatever fails where: (1) a local step — can this process load
+        RCCL, and on rank 0 draw the id — whose outcome the ranks agree on (all-reduce) BEFORE anyone enters a collective that
+        needs all of them; (2) the id's broadcast and ncclCommInitRank; (3) a second agreement, and if any rank failed, every rank
+        destroys what it got.  Returns None when every rank holds a communicator (self.native = True), else why not (the exchanges
+        then run through torch.distributed on every rank)."""
         ident = (C.c_uint8 * 128)()
-        if self.rank == 0:
-            self._lib.check(self.ctx, self.lib.chd_shard_comm_unique_id(ident))
+        why = None
+        try:
+            rc = self.lib.chd_shard_comm_available()
+            if rc:
+                self._lib.check(None, rc)
+            if self.rank == 0:
+                self._lib.check(self.ctx, self.lib.chd_shard_comm_unique_id(ident))
+        except Exception as e:  # noqa: BLE001
+            why = f"RCCL is not available on rank {self.rank} ({e})"
+        if comm.sum_int(0 if why else 1) != self.world:
+            return why or "RCCL is not available on another rank"
         if comm.active:
             box = [bytes(ident)]
             comm.dist.broadcast_object_list(box, src=0)
             ident = (C.c_uint8 * 128).from_buffer_copy(box[0])
-        self._lib.check(self.ctx, self.lib.chd_shard_comm_init(self.ctx, ident, self.rank, self.world, self.cap))
+        try:
+            self._lib.check(self.ctx, self.lib.chd_shard_comm_init(self.ctx, ident, self.rank, self.world, self.cap))
+        except Exception as e:  # noqa: BLE001
+            why = f"chd_shard_comm_init failed on rank {self.rank} ({e})"
+        if comm.sum_int(0 if why else 1) != self.world:
+            self.lib.chd_shard_comm_destroy(self.ctx)  # (a no-op on the ranks that have none)
+            return why or "chd_shard_comm_init failed on another rank"
         self.native = True
+        return None
 
     def tick_native(self, now_ns: int, x_by_chan, z_by_chan, queries=None, n_queries: int = 0, has_update=None):
         ti = self._ti_native
@@ -586,18 +608,28 @@ def run_bench(args, rank: int, world: int, local_rank: int, verifier=None) -> di
     eng.add_subscribers(sw.sub_conn[my_subs])
     # RCCL runs inside the library (chd_shard_comm_init / chd_shard_tick) whenever the ranks have a GPU each; host-staged
     # transports (gloo: ranks sharing one GPU in the tests) keep the four-stage path around torch.distributed.  CHD_DIST_NATIVE=0: A/B
+    # a collective that never completes (a rank that died, a fabric problem) would hang this process until its launcher's clock
+    # runs out, with nothing in the log: say which phase hung and end the run instead.  CHD_BENCH_WATCHDOG_S=0 turns it off.
+    import threading
+
+    wd_s = float(os.environ.get("CHD_BENCH_WATCHDOG_S", "600"))
+    phase = ["communicator init"]
+
+    def _hung():
+        print(f"bench.py rank {rank}: the {phase[0]} phase of the sharded run did not finish within {wd_s:.0f} s "
+              f"(collectives driver: {'native RCCL' if eng.native else 'torch.distributed'}): giving up", file=sys.stderr, flush=True)
+        os._exit(3)
+
+    wd = threading.Timer(wd_s, _hung) if wd_s > 0 else None
+    if wd:
+        wd.daemon = True
+        wd.start()
     native_note = None
     if native_on:
-        # (a rank that cannot load RCCL fails BEFORE the collective ncclCommInitRank — the same on every rank of a node; the line then says
-        # which driver ran instead of ending the run)
-        try:
-            eng.comm_init_native(comm)
-            ok = 1
-        except Exception as e:  # noqa: BLE001
-            ok, native_note = 0, f"chd_shard_comm_init failed ({e}): the exchanges run through torch.distributed"
-        if comm.sum_int(ok) != world:
-            eng.native = False
-            native_note = native_note or "chd_shard_comm_init failed on another rank: the exchanges run through torch.distributed"
+        # (collective; every rank comes out of it with the same answer: HipShardEngine.comm_init_native)
+        why = eng.comm_init_native(comm)
+        if why:
+            native_note = why + ": the exchanges run through torch.distributed"
             if rank == 0:
                 print("bench.py: " + native_note, file=sys.stderr, flush=True)
     world_obj = ShardedWorld(eng, comm)
@@ -634,6 +666,7 @@ def run_bench(args, rank: int, world: int, local_rank: int, verifier=None) -> di
 
     # ---- the first V ticks, each checked against the single-world oracle ----
     verified_msgs = []
+    phase[0] = "verified ticks"
     t_verify = time.perf_counter()
     for t in range(V):
         tick(t)
@@ -645,22 +678,7 @@ def run_bench(args, rank: int, world: int, local_rank: int, verifier=None) -> di
     eng.sw.set_profiling(min(1024, max(K, L, 1)))
     # timed region: only the pair around the dominant kernel, on every 7th tick (bench.py: PROF_EVERY_DEFAULT); stage breakdown from the latency phase
     eng.sw.set_profiling_scope(True, every=int(getattr(args, "prof_every", 7) or 1))
-    # a collective that never completes (a rank that died, a fabric problem) would hang this process until its launcher's clock
-    # runs out, with nothing in the log: say which phase hung and end the run instead.  CHD_BENCH_WATCHDOG_S=0 turns it off.
-    import threading
-
-    wd_s = float(os.environ.get("CHD_BENCH_WATCHDOG_S", "600"))
-    phase = ["warm-up"]
-
-    def _hung():
-        print(f"bench.py rank {rank}: the {phase[0]} ticks of the sharded run did not finish within {wd_s:.0f} s "
-              f"(collectives driver: {'native RCCL' if eng.native else 'torch.distributed'}): giving up", file=sys.stderr, flush=True)
-        os._exit(3)
-
-    wd = threading.Timer(wd_s, _hung) if wd_s > 0 else None
-    if wd:
-        wd.daemon = True
-        wd.start()
+    phase[0] = "warm-up"
     for t in range(V, W):
         tick(t)
     comm.barrier()

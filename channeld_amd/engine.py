@@ -528,7 +528,8 @@ class SpatialWorld:
             out.append(dict(stage_us=[float(s.stage_us[i]) for i in range(_lib.N_STAGES)], total_us=float(s.total_us), emit_main_us=float(s.emit_main_us),
                             n_records=int(s.n_records), n_record_upper_bound=int(s.n_record_upper_bound),
                             n_handovers=int(s.n_handovers), n_unsubs=int(s.n_unsubs), n_pairs=int(s.n_pairs), n_deferred_records=int(s.n_deferred_records),
-                            n_filtered_records=int(s.n_filtered_records), n_deep_records=int(s.n_deep_records)))
+                            n_filtered_records=int(s.n_filtered_records), n_deep_records=int(s.n_deep_records),
+                            overflow=int(s.overflow), history_overflow=int(s.history_overflow)))
         return out
 
     def stats(self) -> dict:
@@ -537,7 +538,7 @@ class SpatialWorld:
         return dict(stage_us={n: float(s.stage_us[i]) for i, n in enumerate(_lib.STAGE_NAMES)}, total_us=float(s.total_us), emit_main_us=float(s.emit_main_us),
                     n_records=int(s.n_records), n_record_upper_bound=int(s.n_record_upper_bound),
                     n_handovers=int(s.n_handovers), n_unsubs=int(s.n_unsubs), n_pairs=int(s.n_pairs),
-                    algorithmic_bytes=int(s.algorithmic_bytes))
+                    algorithmic_bytes=int(s.algorithmic_bytes), schedule=int(s.schedule), gate_timeouts=int(s.gate_timeouts))
 
     # ---- wire-format fan-out buffers ----
     def wire_set_payloads(self, kind: int, idx, payloads):

@@ -36,7 +36,7 @@
 extern "C" {
 #endif
 
-#define CHD_ABI_VERSION 8
+#define CHD_ABI_VERSION 9
 
 typedef struct chd_ctx chd_ctx;
 
@@ -239,8 +239,14 @@ typedef struct {
  * takes ~11 us to resolve, which together cost half of what the overlap saves.  Results unchanged.  As with
  * CHD_WORLD_PIPELINE_TICKS the inputs of chd_tick_device must be COMPLETE when the call is made (the second stream no longer
  * waits for work the caller enqueued on the tick's stream before the call); chd_tick (host pointers) and the first tick after
- * any other call on the context take the event form by themselves.  A flag that never resolves (a bug, never a capacity)
- * raises overflow bit 0x8000 after a bounded spin instead of hanging the queue. */
+ * any other call on the context take the event form by themselves.
+ * Safe by construction: the join's release is a kernel boundary (a one-wave kernel behind the interest launch raises the flag),
+ * so nothing rests on where the dispatcher places workgroups; and the flag is only used where the context's two streams were
+ * SEEN to run side by side (probed with a waiter and a raiser at world creation and at every chd_set_stream: with both streams
+ * on one hardware queue — GPU_MAX_HW_QUEUES=1 — the raiser would sit behind the waiter; such a world takes HIP events and says
+ * so in chd_tick_stats.schedule).  A gate that still is not raised within its spin bound (2^23 polls, ~1 s) ends the wait, reports
+ * overflow bit 0x4000 for that tick (its results are not valid) and switches the world to events for good
+ * (chd_tick_stats.gate_timeouts). */
 #define CHD_WORLD_GATED_OVERLAP 512u
 
 #define CHD_ENTITY_LOCKED 1u /* member of a non-empty lock group (entity.go:197-224) */
@@ -417,6 +423,9 @@ typedef struct {
                                           band outgrew its halo segment or a subscription reaches beyond the halo;
                                           256 chd_tick_device: an entity slot twice in one round of updates, or a subscriber
                                           slot twice (the caller's precondition);
+                                          0x4000 CHD_WORLD_GATED_OVERLAP: a device-side gate was not raised within its spin bound —
+                                          this tick's results are NOT valid; the world orders its streams with HIP events from
+                                          the next tick on (chd_tick_stats.gate_timeouts);
                                           0x8000 an internal loop bound tripped (a bug, never a capacity) */
     uint32_t history_overflow;         /* windows reaching beyond the 32-tick update history, or channels
                                           updated by more than two senders inside it (results then inexact);
@@ -666,7 +675,12 @@ int chd_shard_ingest_post(chd_ctx *ctx, const chd_handover_request *d_req_recv, 
  * the four chd_shard_* stages around caller-run collectives (channeld_amd/dist.py keeps that path for host-staged test
  * transports); outputs as chd_tick_device (chd_tick_fetch, chd_tick_digest, ...). */
 #define CHD_COMM_ID_BYTES 128
+/* Can this process load RCCL at all?  LOCAL, no collective: every gateway asks this (and tells the others) BEFORE any of them enters
+ * chd_shard_comm_init, which is a collective and would wait for a rank that never comes.  CHD_OK, or CHD_E_STATE with the
+ * loader's message in chd_last_error(NULL). */
+int chd_shard_comm_available(void);
 int chd_shard_comm_unique_id(void *id_out /* CHD_COMM_ID_BYTES */);
+/* On failure nothing is left behind (no communicator, stream or events) and the call may be repeated with a fresh id. */
 int chd_shard_comm_init(chd_ctx *ctx, const void *unique_id, uint32_t rank, uint32_t world, uint32_t migrate_cap);
 int chd_shard_comm_destroy(chd_ctx *ctx);
 /* One tick: chd_shard_ingest -> all-to-all(emigrants) -> chd_shard_import -> all-to-all(v)(halo) beside chd_shard_interest ->
@@ -870,7 +884,16 @@ typedef struct {
      * (windows that needed a per-entity decision on arrival stamps / update histories) and by the walk of the exact update
      * buffers (history_depth: irregular channels, long catch-ups) */
     uint32_t n_filtered_records, n_deep_records;
+    /* how the world's ticks are scheduled NOW (CHD_SCHED_*), and how many device-side gates have timed out on this world (each one
+     * invalidated its tick — overflow bit 0x4000 — and turned CHD_SCHED_GATED off for good) */
+    uint32_t schedule, gate_timeouts;
+    /* chd_get_tick_history only: the tick's overflow mask and history_overflow count as chd_tick_out reports them for the LAST tick
+     * — a host that enqueues several chd_tick_device calls back to back reads the earlier ticks' here */
+    uint32_t overflow, history_overflow;
 } chd_tick_stats;
+#define CHD_SCHED_OVERLAP_INTEREST 1u /* the interest updates run on the second stream */
+#define CHD_SCHED_GATED 2u            /* ... forked / joined by device-side flags (CHD_WORLD_GATED_OVERLAP asked for AND the streams were seen to run side by side) */
+#define CHD_SCHED_PIPELINED 4u        /* CHD_WORLD_PIPELINE_TICKS in force */
 /* depth > 0: record HIP events around the stages of the next ticks, keeping the
  * last `depth` ticks (<= 1024); 0 turns it off. */
 int chd_set_profiling(chd_ctx *ctx, int depth);
