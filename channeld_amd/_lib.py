@@ -53,7 +53,7 @@ SYMBOLS = (
     "chd_shard_get_entities", "chd_shard_halo_layout", "chd_shard_interest",
     "chd_handover_recipients", "chd_adjacent_recipients", "chd_wire_set_payloads", "chd_wire_build", "chd_wire_build_info", "chd_wire_fetch",
     "chd_tick_digest", "chd_tick_fetch_segments", "chd_host_alloc", "chd_host_free", "chd_subs_set_options", "chd_subs_get_options", "chd_world_set_entity_groups", "chd_world_set_handover_lists", "chd_wire_set_type_url", "chd_wire_set_merge_schema", "chd_handover_messages",
-    "chd_handover_recipients_ex", "chd_handover_variants",
+    "chd_handover_recipients_ex", "chd_handover_variants", "chd_world_set_server_connections",
 )
 
 
@@ -252,6 +252,7 @@ def load():
     L.chd_shard_ingest_pre.argtypes = [C.c_void_p, C.c_int64, _vp, _vp, _vp, C.c_uint32, C.c_uint32, C.c_uint32, _vp, C.c_uint32]
     L.chd_shard_ingest_post.argtypes = [C.c_void_p, _vp, C.c_uint32, C.c_uint32, C.c_uint32, _vp, C.c_uint32, C.POINTER(C.c_uint32)]
     L.chd_shard_comm_available.argtypes = []
+    L.chd_world_set_server_connections.argtypes = [C.c_void_p, C.c_uint32, _u32p]
     L.chd_shard_comm_unique_id.argtypes = [_vp]
     L.chd_shard_comm_init.argtypes = [C.c_void_p, _vp, C.c_uint32, C.c_uint32, C.c_uint32]
     L.chd_shard_comm_destroy.argtypes = [C.c_void_p]

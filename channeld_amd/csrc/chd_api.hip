@@ -129,6 +129,7 @@ struct World {
     uint8_t *ho_rcp_kind = nullptr;    // CHD_HO_*
     uint32_t *ho_rcp_mask = nullptr;   // per recipient: which entities of its handover carry their entityData (chd_handover_recipients_ex)
     uint64_t ho_rcp_cap = 0;
+    uint32_t *server_conn = nullptr;   // chd_world_set_server_connections (device; WorldDev::server_conn points here while a table is set)
 };
 
 }  // namespace
@@ -3048,6 +3049,24 @@ int chd_wire_fetch(chd_ctx *ctx, uint64_t *conn_off, uint32_t *conn_packets, uin
         TRY(down(ctx, bytes, W.x.bytes, total));
         HIPCHK(hipStreamSynchronize(ctx->stream));
     }
+    return CHD_OK;
+}
+
+int chd_world_set_server_connections(chd_ctx *ctx, uint32_t n_servers, const uint32_t *conn_ids) {
+    NEED_WORLD();
+    if (n_servers && !conn_ids) return fail(ctx, CHD_E_INVAL, "chd_world_set_server_connections: NULL ids");
+    if (n_servers && n_servers != ctx->g.server_cols * ctx->g.server_rows)
+        return fail(ctx, CHD_E_INVAL, "chd_world_set_server_connections: %u ids but the grid has %u server regions", n_servers, ctx->g.server_cols * ctx->g.server_rows);
+    std::lock_guard<FairMutex> lk(ctx->mu);
+    TRY(bind(ctx));
+    World &W = ctx->w;
+    HIPCHK(hipStreamSynchronize(ctx->stream));  // (a planned tick may still read the old table)
+    if (!n_servers) { W.d.server_conn = nullptr; W.d.n_server_conn = 0; return CHD_OK; }
+    if (!W.server_conn) TRY(walloc(ctx, &W.server_conn, ctx->g.server_cols * ctx->g.server_rows));
+    TRY(up(ctx, W.server_conn, conn_ids, sizeof(uint32_t) * n_servers));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    W.d.server_conn = W.server_conn;
+    W.d.n_server_conn = n_servers;
     return CHD_OK;
 }
 

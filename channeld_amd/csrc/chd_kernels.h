@@ -216,6 +216,11 @@ struct WorldDev {
     // (spatial.go:703-736); the others stayed where they were.  What chd_handover_recipients_ex needs to say, per member, whose
     // entity channel a destination connection was already subscribed to (the subscribers of the cell that HELD the member).
     uint32_t *ho_moved;
+    // chd_world_set_server_connections (else nullptr): ConnectionId of spatial server k — the owner of its cells' spatial channels
+    // and, in the tick model, of the entity channels those cells hold (what SubscribeToChannel's DataAccess in the handover loop
+    // is derived from, spatial.go:812-817)
+    const uint32_t *server_conn;
+    uint32_t n_server_conn;
     // Unsub / new-sub lists are kept in CHD_LIST_BANKS banks (bank = subscriber slot & 63, list_bank_cap entries
     // each, one tail counter per bank on its own 128-B line): a single list tail is a same-address atomic for
     // every interest update in the tick, and those serialise at L2 (~5 ns each, 22 us per tick at 10K queries).

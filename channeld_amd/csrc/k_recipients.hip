@@ -48,26 +48,44 @@ __device__ __forceinline__ uint8_t handover_kind(const WorldDev &w, uint32_t s, 
 }
 
 // Which entities of handover h go out WITH their entityData to destination connection s: the reference decides it per
-// (connection, ENTITY) — `shouldSend` of SubscribeToChannel(entityCh) in the loop of spatial.go:797-857, i.e. the connection was
-// not yet subscribed to that entity's channel.  In the engine's model an entity channel's subscribers are the subscribers of the
-// cell whose entity map HELD the entity when Notify ran: src for the members that moved with the handover (ho_moved), the cell
-// that still holds them for the others.  Bit q = entity q of the handover's list (the order of chd_handover_messages).
-__device__ __forceinline__ uint32_t handover_full_mask(const WorldDev &w, uint32_t s, uint32_t h, uint32_t notifier, uint32_t src, bool in_src) {
+// (connection, ENTITY) — `shouldSend` of SubscribeToChannel(entityCh, {DataAccess: WRITE for the entity channel's owner, else READ})
+// in the loop of spatial.go:797-857, which is true when the connection was not yet subscribed to that entity's channel OR the merge
+// changed its DataAccess (subscription.go:44-57).  In the engine's model an entity channel's subscribers are the subscribers of
+// the cell whose entity map HELD the entity when Notify ran: src for the members that moved with the handover (ho_moved), the
+// cell that still holds them for the others; and its owner is the spatial server of that cell — after step 1 of a CROSS-SERVER
+// handover (spatial.go:683-700: entityCh.SetOwner(dstChannel.GetOwner()) for every handover entity) the dst cell's.  So the
+// DataAccess of a subscribed connection changes exactly when it is the old or the new owner's connection and the two differ:
+// the dst server (READ through its border interest -> WRITE) and the src server if it keeps interest in dst (WRITE -> READ).
+// Server connections are known through chd_world_set_server_connections (none set: no connection is an owner, nothing changes).
+// Bit q = entity q of the handover's list (the order of chd_handover_messages).
+__device__ __forceinline__ bool handover_access_changed(const DevGrid &g, const WorldDev &w, uint32_t conn, uint32_t before, uint32_t src, uint32_t dst) {
+    if (!w.server_conn || before == CHD_INVALID) return false;
+    const uint32_t old_srv = server_of(g, before);
+    const uint32_t new_srv = server_of(g, src) != server_of(g, dst) ? server_of(g, dst) : old_srv;
+    if (old_srv == new_srv) return false;
+    const bool was = old_srv < w.n_server_conn && w.server_conn[old_srv] == conn;
+    const bool is = new_srv < w.n_server_conn && w.server_conn[new_srv] == conn;
+    return was != is;
+}
+
+__device__ __forceinline__ uint32_t handover_full_mask(const DevGrid &g, const WorldDev &w, uint32_t s, uint32_t h, uint32_t notifier, uint32_t src,
+                                                       uint32_t dst, bool in_src) {
     const uint32_t moved = w.ho_moved ? w.ho_moved[h] : 1u;
     const uint32_t gi = w.n_groups ? w.grp_of[notifier] : CHD_INVALID;
-    if (gi == CHD_INVALID) return in_src ? 0u : 1u;
+    const uint32_t conn = w.conn_id[s];
+    if (gi == CHD_INVALID) return (!in_src || handover_access_changed(g, w, conn, src, src, dst)) ? 1u : 0u;
     uint32_t mask = 0, q = 0;
     for (uint32_t k = w.grp_off[gi]; k < w.grp_off[gi + 1] && q < 32u; k++) {
         const uint32_t m = w.grp_mem[k];
         if (!(w.eflags[m] & EF_ALIVE)) continue;
         bool known;
-        if ((moved >> q) & 1u) known = in_src;
+        uint32_t before;
+        if ((moved >> q) & 1u) { known = in_src; before = src; }
         else {
-            const uint32_t c = w.member[m];
-            known = c != CHD_INVALID && is_subscribed(w, s, c);
+            before = w.member[m];
+            known = before != CHD_INVALID && is_subscribed(w, s, before);
         }
-        (void)src;
-        if (!known) mask |= 1u << q;
+        if (!known || handover_access_changed(g, w, conn, before, src, dst)) mask |= 1u << q;
         q++;
     }
     return mask;
@@ -90,7 +108,7 @@ __global__ void __launch_bounds__(256) k_handover_recipients(DevGrid g, WorldDev
             if (fill && k != RCP_NONE && pos < cap) {
                 conn[pos] = w.conn_id[s];
                 kind[pos] = k;
-                if (full_mask) full_mask[pos] = k == CHD_HO_SRC_ONLY ? 0u : handover_full_mask(w, s, h, r.entity, src, k == CHD_HO_DST_KNOWN);
+                if (full_mask) full_mask[pos] = k == CHD_HO_SRC_ONLY ? 0u : handover_full_mask(g, w, s, h, r.entity, src, dst, k == CHD_HO_DST_KNOWN);
             }
             run += total;
         }

@@ -590,6 +590,11 @@ class SpatialWorld:
             _lib.check(self.ctx, self.lib.chd_wire_fetch(self.ctx, _ptr(off), _ptr(npk), data.ctypes.data_as(C.c_void_p), total))
         return off, npk, data[:total]
 
+    def set_server_connections(self, conn_ids):
+        """ConnectionId of spatial server k (chd_world_set_server_connections): which connection owns which region's channels."""
+        c = _u32(conn_ids)
+        _lib.check(self.ctx, self.lib.chd_world_set_server_connections(self.ctx, len(c), _ptr(c) if len(c) else None))
+
     # ---- recipient planning (SURVEY 8f-2 / 8f-4, decision parts) ----
     def handover_recipients(self, n_handovers: int):
         """Recipients of the last tick's handover messages: (offsets[n+1], conn ids, kinds)."""

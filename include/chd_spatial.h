@@ -717,6 +717,18 @@ int chd_shard_get_entities(chd_ctx *ctx, uint32_t *chan_id, uint32_t *cell_chann
 #define CHD_HO_DST_KNOWN 2 /* in dst and in src: already subscribed to the entity channel */
 int chd_handover_recipients(chd_ctx *ctx, uint32_t *offsets /* n_handovers+1 */, uint32_t *conn,
                             uint8_t *kind, uint64_t cap, uint64_t *n_out);
+/* Who OWNS the spatial channels: ConnectionId of spatial server k, k < n_servers = ServerCols x ServerRows (CreateChannels gives
+ * server k's connection the cells of region k, spatial.go:399-424; ctl.serverConnections).  The handover loop subscribes every dst
+ * connection to every handover entity's channel with DataAccess = WRITE for the entity channel's owner, else READ
+ * (spatial.go:812-817), and `shouldSend` — the entity goes out WITH its full data — is also true when that merge CHANGES the
+ * connection's DataAccess (subscription.go:44-57): on a cross-server handover the dst server's connection (subscribed through its
+ * border interest with READ, now the owner: WRITE) and the src server's, if it keeps interest in dst (WRITE -> READ).  In the tick
+ * model an entity channel's owner is the server of the cell that holds it.  Server connections take part as subscribers like any
+ * other (chd_subs_add + chd_subs_set_options for their region and border cells); this table only says which ConnectionId is
+ * which server.  n_servers == 0 clears it (no connection is an owner: chd_handover_recipients_ex then reports "newly subscribed"
+ * alone, as before ABI v9). */
+int chd_world_set_server_connections(chd_ctx *ctx, uint32_t n_servers, const uint32_t *conn_ids);
+
 /* The same, EXACT for handover groups.  The reference decides per (destination connection, ENTITY) whether the entity goes
  * out with its entityData: `shouldSend` of conn.SubscribeToChannel(entityCh) inside the loop over handoverEntities
  * (spatial.go:797-857) — the connection was not yet subscribed to THAT entity's channel.  A group's members may sit in different

@@ -99,6 +99,9 @@ typedef struct orc_world {
     uint32_t n_locked_abort;
     uint64_t literal_mismatch;
     uint32_t *server_of_cell;
+    /* orc_world_set_server_conns: ConnectionId of spatial server k (owner of its cells' channels, and — tick model — of the entity
+     * channels those cells hold); NULL: no connection is an owner */
+    uint32_t *server_conn; uint32_t n_server_conn;
     int threads;
     struct fan_job_s *jobs; int njobs; /* per-thread record buffers, kept across ticks */
     orc_time stamps[32]; uint32_t nstamps; /* channel times of the last 32 ticks, newest first */
@@ -198,7 +201,7 @@ void orc_world_free(orc_world *w) {
     free(w->sub_alive); free(w->conn_id); free(w->pairs); free(w->pair_cnt);
     free(w->rec); free(w->ho_ent); free(w->ho_src); free(w->ho_dst);
     free(w->ho_srv_src); free(w->ho_srv_dst); free(w->unsub_sub);
-    free(w->unsub_cell); free(w->q_status); free(w->server_of_cell); free(w->d_conn);
+    free(w->unsub_cell); free(w->q_status); free(w->server_of_cell); free(w->server_conn); free(w->d_conn);
     orc__free_jobs(w);
     free(w);
 }
@@ -206,6 +209,15 @@ void orc_world_free(orc_world *w) {
 void orc_world_set_damping(orc_world *w, uint32_t n, const uint32_t *max_dist, const uint32_t *interval_ms) {
     w->n_damp = n > 8 ? 8 : n;
     for (uint32_t i = 0; i < w->n_damp; i++) { w->damp_dist[i] = max_dist[i]; w->damp_iv[i] = interval_ms[i]; }
+}
+void orc_world_set_server_conns(orc_world *w, uint32_t n, const uint32_t *conn) {
+    free(w->server_conn);
+    w->server_conn = NULL;
+    w->n_server_conn = n;
+    if (n) {
+        w->server_conn = (uint32_t *)malloc(4 * (size_t)n);
+        memcpy(w->server_conn, conn, 4 * (size_t)n);
+    }
 }
 void orc_world_set_threads(orc_world *w, int threads) { w->threads = threads < 1 ? 1 : threads; }
 
@@ -648,8 +660,11 @@ int orc_world_tick_arrivals(orc_world *w, orc_time t, uint32_t n_upd, const uint
      * srcChannelSubConns / dstChannelSubConns as they are now (Notify runs before this tick's
      * interest updates).  Step 4-1: connections of src that are not in dst get the message without
      * per-recipient entity data (kind 0).  Step 4-2: connections of dst are subscribed to the entity
-     * channel; `shouldSend` (newly subscribed) -> full entity data (kind 1), else kind 2.  In the tick
-     * model the entity channel's subscribers are the subscribers of the cell that held it (src). */
+     * channel with DataAccess = WRITE for the entity channel's owner else READ (:812-817); `shouldSend`
+     * = newly subscribed OR the merge changed DataAccess (subscription.go:44-57) -> that entity's full
+     * data.  In the tick model the entity channel's subscribers are the subscribers of the cell that
+     * held it, and its owner is that cell's spatial server — after step 1 of a cross-server handover
+     * (:683-700, SetOwner(dstChannel.GetOwner()) for EVERY handover entity) the dst cell's. */
     for (uint32_t h = 0; h < w->nho; h++) {
         uint32_t src = w->ho_src[h] - w->g.id_start, dst = w->ho_dst[h] - w->g.id_start;
         for (uint32_t s = 0; s < w->S; s++) {
@@ -683,7 +698,15 @@ int orc_world_tick_arrivals(orc_world *w, orc_time t, uint32_t n_upd, const uint
                         if (bc != W_INVALID)
                             for (uint32_t p = 0; p < w->pair_cnt[s]; p++)
                                 if (pp[p].cell == bc) { known = 1; break; }
-                        if (!known) mask |= 1u << q;
+                        int changed = 0; /* dataAccessChanged: the connection is the old or the new owner's, and they differ */
+                        if (known && w->server_conn) {
+                            const uint32_t old_srv = w->server_of_cell[bc];
+                            const uint32_t new_srv = w->server_of_cell[src] != w->server_of_cell[dst] ? w->server_of_cell[dst] : old_srv;
+                            const int was = old_srv < w->n_server_conn && w->server_conn[old_srv] == w->conn_id[s];
+                            const int is = new_srv < w->n_server_conn && w->server_conn[new_srv] == w->conn_id[s];
+                            changed = was != is;
+                        }
+                        if (!known || changed) mask |= 1u << q;
                     }
                 w->rcp_mask[w->nrcp] = mask;
             }

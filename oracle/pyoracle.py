@@ -133,6 +133,7 @@ def lib():
     L.orc_world_pair_options.restype = C.c_uint32
     L.orc_world_pair_options.argtypes = [C.c_void_p, C.c_uint32, u8p, u8p]
     L.orc_world_set_damping.argtypes = [C.c_void_p, C.c_uint32, up, up]
+    L.orc_world_set_server_conns.argtypes = [C.c_void_p, C.c_uint32, up]
     L.orc_world_set_digest_only.argtypes = [C.c_void_p, C.c_int]
     L.orc_world_set_sorted_walk.argtypes = [C.c_void_p, C.c_int]
     L.orc_world_unsorted.argtypes = [C.c_void_p]
@@ -457,6 +458,11 @@ class World:
         acc, sk = np.zeros(self.capq, dtype=np.uint8), np.zeros(self.capq, dtype=np.uint8)
         n = lib().orc_world_pair_options(self.h, int(s), _p(acc, C.c_uint8), _p(sk, C.c_uint8))
         return acc[:n], sk[:n]
+
+    def set_server_connections(self, conn_ids):
+        """ConnectionId of spatial server k (spatial.go:399-424: the owner of its cells' channels)."""
+        c = np.ascontiguousarray(conn_ids, dtype=np.uint32)
+        lib().orc_world_set_server_conns(self.h, len(c), _p(c, C.c_uint32))
 
     def set_damping(self, table):
         """table: [(max_dist, interval_ms), ...] replacing spatialDampingSettings (message_spatial.go:16-29)"""

@@ -64,6 +64,52 @@ def test_oracle_adjacent_broadcast_flags():
     assert ow.adjacent_recipients(ch, ADJ | BUT_CLIENT, 0, 0).tolist() == []
 
 
+
+def server_scene():
+    """benchmark grid: 3x3 servers of 5x5 cells.  (4,7) -> (5,7) crosses from server 3 to server 4; (5,7) -> (6,7) stays in 4."""
+    cell = lambda gx, gz: (-15000 + 2000 * gx + 1000.0, -15000 + 2000 * gz + 1000.0)
+    ch = lambda gx, gz: 0x10000 + gx + gz * 15
+    # slot 0: server 3's connection 903 — WRITE on its own cell (4,7), READ on the border cell (5,7) (spatial.go:481-590)
+    # slot 1: server 4's connection 904 — WRITE on (5,7) and (6,7), READ on the border cell (4,7)
+    # slot 2: a client, 77, READ on all three
+    subs = [dict(slot=0, channel=ch(4, 7), data_access=2), dict(slot=0, channel=ch(5, 7), data_access=1),
+            dict(slot=1, channel=ch(5, 7), data_access=2), dict(slot=1, channel=ch(6, 7), data_access=2), dict(slot=1, channel=ch(4, 7), data_access=1),
+            dict(slot=2, channel=ch(4, 7)), dict(slot=2, channel=ch(5, 7)), dict(slot=2, channel=ch(6, 7))]
+    return cell, subs, [900 + k for k in range(9)]
+
+
+def test_oracle_handover_full_data_when_the_merge_changes_data_access():
+    """spatial.go:812-835 + subscription.go:44-57: `shouldSend` is also true when SubscribeToChannel(entityCh, {WRITE for the
+    owner else READ}) CHANGES an existing subscription's DataAccess — the dst spatial server (READ through its border interest,
+    now the owner) and the src server that keeps interest in dst (WRITE -> READ) get the entity's full data on a CROSS-SERVER
+    handover; nobody does on a handover inside one server's region."""
+    cell, subs, server_conns = server_scene()
+    cfg = synth.load_config("spatial_static_benchmark.json")
+    ow = orc.World(orc.grid_from_config(cfg), 4, 3, 225, 20, 0)
+    for s, c in enumerate((903, 904, 77)):
+        ow.add_sub(s, c)
+    for o in subs:
+        assert ow.set_sub_options(0, o["slot"], o["channel"], o.get("data_access")) == 1
+    x0, z0 = cell(4, 7)
+    ow.spawn([0], [0x80000], [x0], [z0], [0], [903])
+    ow.tick(20_000_000, [0], [x0], [z0], None, None, None, None, None)
+
+    def handover_to(gx, t):
+        x1, z1 = cell(gx, 7)
+        ow.tick(t, [0], [x1], [z1], None, None, None, None, None)
+        ent, src, dst, ssrv, dsrv = ow.handovers()
+        assert len(ent) == 1
+        _, conn, kind = ow.recipients()
+        return int(ssrv[0]), int(dsrv[0]), sorted(zip(conn.tolist(), kind.tolist(), ow.recipient_masks().tolist()))
+
+    # without the server table no connection is an owner: everybody already knew the entity's channel
+    assert handover_to(5, 40_000_000) == (3, 4, [(77, 2, 0), (903, 2, 0), (904, 2, 0)])
+    handover_to(4, 60_000_000)  # back
+    ow.set_server_connections(server_conns)
+    assert handover_to(5, 80_000_000) == (3, 4, [(77, 2, 0), (903, 2, 1), (904, 2, 1)])   # cross-server: both servers' access changes
+    assert handover_to(6, 100_000_000) == (4, 4, [(77, 2, 0), (903, 0, 0), (904, 2, 0)])   # same server: nothing changes (903 only sees src)
+
+
 @pytest.fixture(scope="module")
 def amd():
     import channeld_amd
@@ -72,18 +118,37 @@ def amd():
     return channeld_amd
 
 
-def run_recipients(amd, cfg, N, S, ticks, seed, flags=4, aoi_scale=1.0, capq=0):
+def run_recipients(amd, cfg, N, S, ticks, seed, flags=4, aoi_scale=1.0, capq=0, servers=False):
+    """servers: the spatial servers' connections take part as subscribers — slots S .. S + n_servers - 1, WRITE on the cells of
+    their region (CreateChannels, spatial.go:399-424), READ on their border cells (:481-590) — and the engine is told which
+    ConnectionId is which server (chd_world_set_server_connections): `shouldSend` by a changed DataAccess."""
     g = orc.grid_from_config(cfg)
     sw = synth.SynthWorld(synth.WorldSpec(cfg, N, S, seed, tick_ms=50, aoi_scale=aoi_scale, outside_frac=0.01, locked_frac=0.02))
     ctl = amd.StaticGrid2DSpatialController()
     assert ctl.LoadConfig(json.dumps(cfg).encode(), strict=False) is None
-    gw = amd.SpatialWorld(ctl, N, S, max_interest_cells=capq, flags=flags)
-    ow = orc.World(g, N, S, gw.capq, 20, 0)
+    n_srv = int(cfg["ServerCols"]) * int(cfg["ServerRows"]) if servers else 0
+    gw = amd.SpatialWorld(ctl, N, S + n_srv, max_interest_cells=capq, flags=flags)
+    ow = orc.World(g, N, S + n_srv, gw.capq, 20, 0)
     ow.spawn(np.arange(N), sw.chan_id, sw.x, sw.z, sw.flags, sw.sender)
     gw.spawn(None, sw.chan_id, sw.x, sw.z, sw.flags, sw.sender)
     for s in range(S):
         ow.add_sub(s, int(sw.sub_conn[s]))
     gw.add_subscribers(None, sw.sub_conn)
+    if servers:
+        srv_conn = (1_000_000 + np.arange(n_srv)).astype(np.uint32)
+        gw.add_subscribers(np.arange(S, S + n_srv, dtype=np.uint32), srv_conn)
+        opts = []
+        for k in range(n_srv):
+            ow.add_sub(S + k, int(srv_conn[k]))
+            own = orc.server_channels(g, k)
+            border = orc.border_channels(g, k) or []
+            opts += [dict(slot=S + k, channel=int(c), data_access=2) for c in own] + [dict(slot=S + k, channel=int(c), data_access=1) for c in border]
+        ss, st = gw.set_sub_options(0, opts)
+        assert (st == 0).all() and (ss == 1).all()
+        for o in opts:
+            assert ow.set_sub_options(0, o["slot"], o["channel"], o["data_access"]) == 1
+        gw.set_server_connections(srv_conn)
+        ow.set_server_connections(srv_conn)
     rng = np.random.default_rng(seed & 0xFFFF)
     n_rcp = n_adj = 0
     kinds = set()
@@ -111,6 +176,8 @@ def run_recipients(amd, cfg, N, S, ticks, seed, flags=4, aoi_scale=1.0, capq=0):
             assert got == want.get(e, []), f"tick {k}: recipients of the handover of entity {e}"
         n_rcp += len(conn)
         kinds.update(kind.tolist())
+        if servers:  # a connection that KNEW src and still gets full data: only a changed DataAccess does that
+            run_recipients.access_only = getattr(run_recipients, "access_only", 0) + int(((kind == 2) & (mask != 0)).sum())
         # ---- adjacent broadcast ----
         ncell = g.cols * g.rows
         chans = (0x10000 + rng.integers(0, ncell, 12)).astype(np.uint32)
@@ -123,6 +190,47 @@ def run_recipients(amd, cfg, N, S, ticks, seed, flags=4, aoi_scale=1.0, capq=0):
             assert np.array_equal(aconn[aoff[r]:aoff[r + 1]], want_r), f"tick {k}: adjacent request {r}"
             n_adj += len(want_r)
     return n_rcp, n_adj, kinds
+
+
+@pytest.mark.gpu
+def test_gpu_handover_full_data_when_the_merge_changes_data_access(amd):
+    """The hand-built scene of test_oracle_handover_full_data_when_the_merge_changes_data_access through the C-ABI, then seeded
+    worlds whose nine spatial servers are subscribers of their regions and borders: recipients, kinds and full-data masks of every
+    handover equal the oracle's, and some mask bit is owed to a changed DataAccess alone (a recipient that knew src)."""
+    cell, subs, server_conns = server_scene()
+    cfg = synth.load_config("spatial_static_benchmark.json")
+    ctl = amd.StaticGrid2DSpatialController()
+    assert ctl.LoadConfig(json.dumps(cfg).encode(), strict=False) is None
+    gw = amd.SpatialWorld(ctl, 4, 3, flags=4)
+    gw.add_subscribers(None, np.array([903, 904, 77], dtype=np.uint32))
+    ss, st = gw.set_sub_options(0, subs)
+    assert (st == 0).all() and (ss == 1).all()
+    x0, z0 = cell(4, 7)
+    gw.spawn(np.array([0], dtype=np.uint32), [0x80000], [x0], [z0], [0], [903])
+    gw.tick(20_000_000, upd_idx=np.array([0], dtype=np.uint32), upd_x=np.array([x0]), upd_z=np.array([z0]), want_records=False)
+
+    def handover_to(gx, t):
+        x1, z1 = cell(gx, 7)
+        res = gw.tick(t, upd_idx=np.array([0], dtype=np.uint32), upd_x=np.array([x1]), upd_z=np.array([z1]), want_records=False)
+        assert len(res.handovers) == 1
+        off, conn, kind, mask = gw.handover_recipients_ex(1)
+        return sorted(zip(conn.tolist(), kind.tolist(), mask.tolist()))
+
+    assert handover_to(5, 40_000_000) == [(77, 2, 0), (903, 2, 0), (904, 2, 0)]
+    handover_to(4, 60_000_000)
+    gw.set_server_connections(server_conns)
+    assert handover_to(5, 80_000_000) == [(77, 2, 0), (903, 2, 1), (904, 2, 1)]
+    assert handover_to(6, 100_000_000) == [(77, 2, 0), (903, 0, 0), (904, 2, 0)]
+    gw.set_server_connections([])
+    handover_to(4, 120_000_000)
+    assert handover_to(5, 140_000_000) == [(77, 2, 0), (903, 2, 0), (904, 2, 0)]
+    ctl.close()
+    # (ServerInterestBorderSize 1: every server also reads the rows of its neighbours' regions along its borders)
+    n_rcp, _, kinds = run_recipients(amd, dict(cfg, ServerInterestBorderSize=1), 3000, 300, 8, 0xC0FFEE35, servers=True)
+    assert n_rcp > 1000 and kinds == {0, 1, 2} and run_recipients.access_only > 20, run_recipients.access_only
+    cfg8 = dict(synth.load_config("spatial_static_8x8.json"), ServerInterestBorderSize=1)
+    n_rcp, _, kinds = run_recipients(amd, cfg8, 2000, 200, 6, 0xC0FFEE36, flags=4 | 2, aoi_scale=0.5, servers=True)
+    assert n_rcp > 500
 
 
 @pytest.mark.gpu
