@@ -88,6 +88,10 @@ struct World {
     hipEvent_t ev_mig[4] = {nullptr, nullptr, nullptr, nullptr};
     uint32_t mig_tick[4] = {0, 0, 0, 0};  // tick whose maximum the slot holds (0 = none)
     uint32_t mig_cap = 0;                 // capacity the last chd_shard_ingest used
+    // the update log by channel (WorldDev::log_on): this tick's update stream as chd_shard_ingest was given it, logged by shard_import_locked
+    const double *log_x = nullptr, *log_z = nullptr;
+    const uint8_t *log_has = nullptr;
+    uint32_t log_nchan = 0;
     std::vector<uint32_t> group_id;    // host copy: handover group id per entity slot (0 = none), chd_world_set_entity_groups
     void *grp_buf[4] = {nullptr, nullptr, nullptr, nullptr};  // device arrays behind WorldDev::grp_*
     bool plan_recipients = false;      // CHD_WORLD_HANDOVER_RECIPIENTS
@@ -913,16 +917,31 @@ int chd_world_create(chd_ctx *ctx, const chd_world_cfg *cfg) {
         return fail(ctx, CHD_E_CONFIG, "max_interest_cells %u on this grid needs %zu bytes of LDS per query (limit %zu)", d.capq,
                     aoi_lds_bytes(ctx->lim, d.capq), aoi_lds_limit());
     const size_t N = d.N, S = d.S, P = (size_t)d.S * d.capq, C = g.ncell;
+    // chd_world_cfg.shard_channels: the UPDATE LOG — everything push_update writes — is kept per entity channel id of the whole
+    // world, on every rank, instead of per entity slot (WorldDev::log_on); LN = how many logs there are
+    if (cfg->shard_channels && !cfg->history_depth)
+        return fail(ctx, CHD_E_INVAL, "shard_channels is for worlds with exact update buffers (history_depth > 0)");
+    if (cfg->shard_channels && (cfg->flags & (CHD_WORLD_WIRE | CHD_WORLD_PIPELINE_TICKS | CHD_WORLD_HANDOVER_RECIPIENTS)))
+        return fail(ctx, CHD_E_INVAL, "shard_channels: a region-sharded world (no wire buffers, pipelined ticks or recipient planning)");
+    d.log_on = cfg->shard_channels ? 1u : 0u;
+    d.log_n = cfg->shard_channels ? cfg->shard_channels : d.N;
+    d.log_eid0 = ctx->cfg.entity_channel_id_start ? ctx->cfg.entity_channel_id_start : 0x80000u;
+    const size_t LN = d.log_n;
     TRY(walloc(ctx, &d.chan_id, N));
     TRY(walloc(ctx, &d.cell, N));
     TRY(walloc(ctx, &d.member, N));
     TRY(walloc(ctx, &d.eflags, N));
-    TRY(walloc(ctx, &d.sender, N));
-    TRY(walloc(ctx, &d.hist, N));
-    TRY(walloc(ctx, &d.hist_tick, N));
-    TRY(walloc(ctx, &d.sender_prev, N));
-    TRY(walloc(ctx, &d.hist_prev, N));
+    TRY(walloc(ctx, &d.sender, LN));
+    TRY(walloc(ctx, &d.hist, LN));
+    TRY(walloc(ctx, &d.hist_tick, LN));
+    TRY(walloc(ctx, &d.sender_prev, LN));
+    TRY(walloc(ctx, &d.hist_prev, LN));
     TRY(walloc(ctx, &d.upd_mark, N));
+    if (d.log_on) {
+        TRY(walloc(ctx, &d.log_cell, LN, false));
+        TRY(walloc(ctx, &d.log_alive, LN));
+        HIPCHK(hipMemsetAsync(d.log_cell, 0xFF, sizeof(uint32_t) * LN, ctx->stream));
+    }
     TRY(walloc(ctx, &d.q_mark, S));
     TRY(walloc(ctx, &d.cell_hist, C));
     TRY(walloc(ctx, &d.cell_hist_tick, C));
@@ -979,7 +998,7 @@ int chd_world_create(chd_ctx *ctx, const chd_world_cfg *cfg) {
     // CHD_WORLD_FORCE_FLAGS (tests): schedule-only flags OR-ed into every world of the process, so that the parity suite can be run on them
     uint32_t wflags = cfg->flags;
     if (const char *e = getenv("CHD_WORLD_FORCE_FLAGS")) wflags |= (uint32_t)strtoul(e, nullptr, 0) & (CHD_WORLD_OVERLAP_INTEREST | CHD_WORLD_OVERLAP_DEFERRED | CHD_WORLD_GATED_OVERLAP);
-    W.overlap_interest = (wflags & CHD_WORLD_OVERLAP_INTEREST) != 0;  // (exact update buffers: WorldDev::max_iv is double-buffered for this)
+    W.overlap_interest = (wflags & CHD_WORLD_OVERLAP_INTEREST) != 0;  // (exact update buffers: WorldDev::cell_max_iv is double-buffered for this)
     W.overlap_deferred = (wflags & CHD_WORLD_OVERLAP_DEFERRED) != 0 && !cfg->history_depth;
     W.gate_asked = W.overlap_interest && (wflags & CHD_WORLD_GATED_OVERLAP) != 0;
     W.gated = false;
@@ -1105,12 +1124,12 @@ int chd_world_create(chd_ctx *ctx, const chd_world_cfg *cfg) {
     if (d.deep_depth) {
         if (d.deep_depth < CHD_HIST_BITS) return fail(ctx, CHD_E_INVAL, "history_depth must be 0 or at least %d (1024 covers the reference's 512-element buffers)", CHD_HIST_BITS);
         const size_t D = d.deep_depth;
-        TRY(walloc(ctx, &d.deep_a, N * D, false));
-        TRY(walloc(ctx, &d.deep_s, N * D, false));
-        TRY(walloc(ctx, &d.deep_n, N));
-        TRY(walloc(ctx, &d.deep_len, N));
-        TRY(walloc(ctx, &d.deep_drop, N, false));
-        TRY(walloc(ctx, &d.irr_tick, N));
+        TRY(walloc(ctx, &d.deep_a, LN * D, false));
+        TRY(walloc(ctx, &d.deep_s, LN * D, false));
+        TRY(walloc(ctx, &d.deep_n, LN));
+        TRY(walloc(ctx, &d.deep_len, LN));
+        TRY(walloc(ctx, &d.deep_drop, LN, false));
+        TRY(walloc(ctx, &d.irr_tick, LN));
         TRY(walloc(ctx, &d.cdeep_a, C * D, false));
         TRY(walloc(ctx, &d.cdeep_s, C * D, false));
         TRY(walloc(ctx, &d.cdeep_n, C));
@@ -1118,11 +1137,12 @@ int chd_world_create(chd_ctx *ctx, const chd_world_cfg *cfg) {
         TRY(walloc(ctx, &d.cdeep_drop, C, false));
         TRY(walloc(ctx, &d.cell_irr_tick, C));
         TRY(walloc(ctx, &d.cell_irr, C));
-        TRY(walloc(ctx, &d.max_iv, 2));
+        TRY(walloc(ctx, &d.cell_max_iv, 2 * C));
+        TRY(walloc(ctx, &d.ent_max_iv, LN));
         TRY(walloc(ctx, &d.conn_deep, S));
         TRY(walloc(ctx, &d.ce_slot, N + 2));
         // drop = INT64_MIN ("nothing was ever dropped"): the byte pattern 0x80 repeated is a very negative int64 as well
-        HIPCHK(hipMemsetAsync(d.deep_drop, 0x80, sizeof(int64_t) * std::max<size_t>(N, 32), ctx->stream));
+        HIPCHK(hipMemsetAsync(d.deep_drop, 0x80, sizeof(int64_t) * LN, ctx->stream));
         HIPCHK(hipMemsetAsync(d.cdeep_drop, 0x80, sizeof(int64_t) * std::max<size_t>(C, 32), ctx->stream));
         // Sub-tick arrival offsets (WorldDev::off_on): where the descriptor path runs every tick — connection-major, one wave per
         // connection, no per-record masks, no wire positions — the stamps of regular updates are kept per ring slot and the
@@ -1131,7 +1151,7 @@ int chd_world_create(chd_ctx *ctx, const chd_world_cfg *cfg) {
         if (const char *e = getenv("CHD_ARRIVAL_OFFSETS")) if (e[0] == '0') d.off_on = 0;
         if (d.off_on) {
             d.off_stride = (uint32_t)((N + 520 + 63) & ~(size_t)63);
-            TRY(walloc(ctx, &d.eoff, 2 * N));
+            TRY(walloc(ctx, &d.eoff, 2 * LN));
             TRY(walloc(ctx, &d.ce_off, (size_t)CHD_OFF_SLOTS * d.off_stride + 520));
             TRY(walloc(ctx, &d.cell_orng, C * CHD_OFF_SLOTS));
             TRY(walloc(ctx, &d.cell_ooff, 2 * C));
@@ -1644,7 +1664,7 @@ static int tick_locked(chd_ctx *ctx, const chd_tick_in *in) {
             hipStream_t ax = pipe ? ctx->aux2_stream : ctx->aux_stream;
             // fork: the second stream starts after everything enqueued on this one so far — or, gated and directly behind a gated
             // tick, after that tick's epilogue said so (no event on the tick's stream)
-            if (gated && ctx->gchain_prev) launch_gate_wait(ax, d, W.gate + GATE_EPI, W.gate_epi);
+            if (gated && ctx->gchain_prev) launch_gate_wait(ax, d, W.gate + GATE_EPI, W.gate_epi, true);
             else {
                 HIPCHK(hipEventRecord(ctx->ev_fork, bs));
                 HIPCHK(hipStreamWaitEvent(ax, ctx->ev_fork, 0));
@@ -1685,7 +1705,7 @@ static int tick_locked(chd_ctx *ctx, const chd_tick_in *in) {
         launch_cell_offsets(bs, ctx->g, d);
         if (prof_stages) HIPCHK(hipEventRecord(ev[2], bs));
         if (overlap && gated) {  // join: every group of the interest launch complete (the index build's last launch waited for it where it could)
-            if (!gate_in_index) launch_gate_wait(bs, d, W.gate + GATE_TOP, W.gate_top);
+            if (!gate_in_index) launch_gate_wait(bs, d, W.gate + GATE_TOP, W.gate_top, false);
         }
         else if (overlap) HIPCHK(hipStreamWaitEvent(bs, ctx->ev_join, 0));
         else
@@ -2152,7 +2172,8 @@ int chd_shard_spawn(chd_ctx *ctx, uint32_t n, const uint32_t *chan_id, const dou
     if (!chan_id || !x || !z) return fail(ctx, CHD_E_INVAL, "chd_shard_spawn: NULL buffer");
     std::lock_guard<FairMutex> lk(ctx->mu);
     if (ctx->w.slot_mode == 1) return fail(ctx, CHD_E_STATE, "chd_shard_spawn on a world with caller-chosen slots (chd_world_spawn)");
-    if (ctx->w.d.deep_depth) return fail(ctx, CHD_E_STATE, "history_depth is not available on region-sharded worlds (the update buffers do not migrate)");
+    if (ctx->w.d.deep_depth && !ctx->w.d.log_on)
+        return fail(ctx, CHD_E_STATE, "history_depth on a region-sharded world needs chd_world_cfg.shard_channels (the update log by channel id)");
     ctx->w.slot_mode = 2;
     TRY(bind(ctx));
     TRY(ensure(ctx, 1, 4 * (size_t)n));
@@ -2174,6 +2195,9 @@ int chd_shard_spawn(chd_ctx *ctx, uint32_t n, const uint32_t *chan_id, const dou
     return CHD_OK;
 }
 
+// records behind each emigrant segment's (cap + 1): the sender's maxFanOutIntervalMs per cell, 8 cells per 32-byte record (log_on)
+static uint32_t migrate_extra(const chd_ctx *ctx) { return ctx->w.d.log_on ? (ctx->g.ncell + 7u) / 8u : 0u; }
+
 // ghost room behind the own entries: reallocates the cell-sorted tables (rebuilt every tick, nothing to preserve)
 static int shard_reserve_ghosts(chd_ctx *ctx, uint32_t ghosts) {
     World &W = ctx->w;
@@ -2185,6 +2209,11 @@ static int shard_reserve_ghosts(chd_ctx *ctx, uint32_t ghosts) {
     TRY(walloc(ctx, &d.ce_sprev, n));
     TRY(walloc(ctx, &d.ce8, n + 2));
     TRY(walloc(ctx, &d.ce_chan, n + 520));
+    if (d.ce_slot) TRY(walloc(ctx, &d.ce_slot, n + 2));
+    if (d.off_on) {  // (the offset columns run beside the entries, ghosts included)
+        d.off_stride = (uint32_t)((n + 520 + 63) & ~(size_t)63);
+        TRY(walloc(ctx, &d.ce_off, (size_t)CHD_OFF_SLOTS * d.off_stride + 520));
+    }
     d.wcol_stride = 0;  // (no window columns on region-sharded worlds: the tables are rebuilt with ghost room, one column array)
     if (!d.cell_cov) TRY(walloc(ctx, &d.cell_cov, ctx->g.ncell));
     d.ghost_cap = ghosts;
@@ -2271,10 +2300,17 @@ static int shard_ingest_pre_locked(chd_ctx *ctx, int64_t now_ns, const double *d
     if (ctx->w.slot_mode == 1) return fail(ctx, CHD_E_STATE, "chd_shard_ingest on a world with caller-chosen slots");
     ctx->w.slot_mode = 2;
     TRY(bind(ctx));
+    World &W = ctx->w;
+    if (W.d.log_on && n_chan && !W.d.sh_sender_by_chan)
+        return fail(ctx, CHD_E_STATE, "a world with an update log by channel id takes its updates' senders by channel id too (chd_shard_set_update_senders)");
+    if (W.d.log_on && n_chan > W.d.log_n) return fail(ctx, CHD_E_INVAL, "chd_shard_ingest: %u channels, the world was created for %u (shard_channels)", n_chan, W.d.log_n);
     TRY(tick_begin(ctx, now_ns));
+    W.d.prev_ns = ctx->ring.n > 1 ? ctx->ring.t[1] : -1;  // (sub-tick arrival offsets: a regular update arrived after the previous tick)
     const uint32_t eid0 = ctx->cfg.entity_channel_id_start ? ctx->cfg.entity_channel_id_start : 0x80000u;
     launch_ingest_by_channel(ctx->stream, ctx->g, ctx->w.d, d_x_by_chan, d_z_by_chan, d_has_update, n_chan, eid0,
                              ctx->ring.cur_tick, rank, world, (uint4 *)d_req_send, req_cap);
+    // (log_on: the tick's updates are logged after the emigrant exchange — shard_import_locked — which also carries the cells' maxFanOutIntervalMs)
+    W.log_x = d_x_by_chan; W.log_z = d_z_by_chan; W.log_has = d_has_update; W.log_nchan = n_chan;
     return CHD_OK;
 }
 
@@ -2285,7 +2321,7 @@ static int shard_ingest_post_locked(chd_ctx *ctx, const chd_handover_request *d_
     if (cap_used) *cap_used = use;
     W.mig_cap = use;
     if (world > 1 && d_req_recv) launch_apply_requests(ctx->stream, W.d, (const uint4 *)d_req_recv, world, req_cap);
-    if (world > 1) launch_export(ctx->stream, ctx->g, ctx->w.d, rank, world, d_send, use, ctx->ring.cur_tick);
+    if (world > 1) launch_export(ctx->stream, ctx->g, ctx->w.d, rank, world, d_send, use, ctx->ring.cur_tick, migrate_extra(ctx));
     TRY(after_launch(ctx));
     return CHD_OK;
 }
@@ -2355,12 +2391,14 @@ static int shard_import_locked(chd_ctx *ctx, const chd_entity_state *d_recv, uin
     if (world > 1) {
         if (cap != W.mig_cap) return fail(ctx, CHD_E_INVAL, "chd_shard_import: cap %u, but this tick's chd_shard_ingest used %u", cap, W.mig_cap);
         if (!d.limbo) return fail(ctx, CHD_E_STATE, "chd_shard_import: chd_shard_halo_layout has not installed this rank's layout");
-        launch_import(st, d, d_recv, world, cap, ctx->ring.cur_tick);
+        launch_import(st, d, d_recv, world, cap, ctx->ring.cur_tick, migrate_extra(ctx), ctx->g.ncell);
         const uint32_t slot = ctx->ring.cur_tick & 3u;
         HIPCHK(hipMemcpyAsync(W.h_mig_gmax + slot, d.mig_gmax + slot, sizeof(uint32_t), hipMemcpyDeviceToHost, st));
         HIPCHK(hipEventRecord(W.ev_mig[slot], st));
         W.mig_tick[slot] = ctx->ring.cur_tick;
     }
+    // log_on: ChannelData.OnUpdate for every channel of the world, under the cells' world-wide maxFanOutIntervalMs (just folded)
+    launch_log_push(st, ctx->g, d, W.log_x, W.log_z, W.log_has, W.log_nchan, ctx->ring.cur_tick, W.last_now);
     launch_index_build(st, ctx->g, d, ctx->ring.cur_tick);
     if (world > 1) launch_halo_pack(st, ctx->g, d, W.halo_rank, world, ctx->g.border, (unsigned char *)d_halo_send, W.d_halo_send_off);
     TRY(after_launch(ctx));
@@ -2418,11 +2456,12 @@ static int shard_fanout_locked(chd_ctx *ctx, const void *d_halo_recv, uint32_t w
     d.seg_off = 0;
     W.last_desc = fanout_seg_path(d);
     launch_halo_unpack(st, ctx->g, d, world > 1 ? W.halo_rank : 0u, world, ctx->g.border, (const unsigned char *)d_halo_recv,
-                       W.d_halo_recv_off, W.d_ghost_off, W.join_in_unpack ? W.gate + GATE_TOP : nullptr, W.gate_top);
+                       W.d_halo_recv_off, W.d_ghost_off, r.cur_tick, W.join_in_unpack ? W.gate + GATE_TOP : nullptr, W.gate_top);
     W.join_in_unpack = false;
     d.ce_view = d.ce; d.ce8_view = d.ce8; d.ce_chan_view = d.ce_chan; d.ce_sprev_view = d.ce_sprev; d.ce_sprev_stride = 0;
     d.cell_start = d.cell_tab;
     d.cell_end = d.cell_tab + ctx->g.ncell;
+    launch_cell_offsets(st, ctx->g, d);  // (off_on: per cell and ring slot the range of the sub-tick offsets, ghost cells included)
     launch_aoi_interest(st, ctx->g, ctx->lim, d, d_in->queries, d_in->n_queries, d_in->query_sub, d_in->spot_x,
                         d_in->spot_z, d_in->spot_dist, now, r.cur_tick);
     if (prof_ends) HIPCHK(hipEventRecord(ev[3], st));
@@ -2430,8 +2469,11 @@ static int shard_fanout_locked(chd_ctx *ctx, const void *d_halo_recv, uint32_t w
     if (prof_ends) HIPCHK(hipEventRecord(ev[4], st));
     if (prof) HIPCHK(hipEventRecord(ev[CHD_N_STAGES + 4], st));
     launch_fanout_emit_main(st, ctx->g, d, now, r);
-    if (prof) HIPCHK(hipEventRecord(ev[CHD_N_STAGES + 3], st));
+    if (prof && !d.off_on) HIPCHK(hipEventRecord(ev[CHD_N_STAGES + 3], st));
+    launch_fanout_emit_filt(st, ctx->g, d);
+    if (prof && d.off_on) HIPCHK(hipEventRecord(ev[CHD_N_STAGES + 3], st));  // (emit_main_us: both record-writing kernels)
     launch_fanout_emit_deferred(st, ctx->g, d, now, r);
+    launch_fanout_emit_deep(st, ctx->g, d, now, r);
     if (prof_ends) HIPCHK(hipEventRecord(ev[5], st));
     if (W.gated) launch_tick_epilogue(st, d, r.cur_tick % TICK_RING, ctx->g.ncell, W.gate + GATE_EPI, ++W.gate_epi);
     else launch_tick_epilogue(st, d, r.cur_tick % TICK_RING, ctx->g.ncell);
@@ -2457,6 +2499,44 @@ int chd_shard_set_update_senders(chd_ctx *ctx, const uint32_t *d_sender_by_chan,
     if (ctx->w.slot_mode == 1) return fail(ctx, CHD_E_STATE, "chd_shard_set_update_senders on a world with caller-chosen slots (chd_tick_in.upd_sender)");
     ctx->w.d.sh_sender_by_chan = n_chan ? d_sender_by_chan : nullptr;
     ctx->w.d.sh_sender_n = d_sender_by_chan ? n_chan : 0u;
+    return CHD_OK;
+}
+
+int chd_shard_set_update_arrivals(chd_ctx *ctx, const int64_t *d_arrival_ns_by_chan, uint32_t n_chan) {
+    NEED_WORLD();
+    std::lock_guard<FairMutex> lk(ctx->mu);
+    TRY(bind(ctx));
+    if (!ctx->w.d.log_on) return fail(ctx, CHD_E_STATE, "chd_shard_set_update_arrivals: the world keeps no update log by channel id (chd_world_cfg.shard_channels)");
+    ctx->w.d.sh_arrival_by_chan = n_chan ? d_arrival_ns_by_chan : nullptr;
+    ctx->w.d.sh_arrival_n = d_arrival_ns_by_chan ? n_chan : 0u;
+    return CHD_OK;
+}
+
+int chd_shard_log_spawn(chd_ctx *ctx, uint32_t n, const uint32_t *chan_id, const double *x, const double *z) {
+    NEED_WORLD();
+    if (!n) return CHD_OK;
+    if (!chan_id || !x || !z) return fail(ctx, CHD_E_INVAL, "chd_shard_log_spawn: NULL buffer");
+    std::lock_guard<FairMutex> lk(ctx->mu);
+    if (!ctx->w.d.log_on) return fail(ctx, CHD_E_STATE, "chd_shard_log_spawn: the world keeps no update log by channel id (chd_world_cfg.shard_channels)");
+    TRY(bind(ctx));
+    TRY(ensure(ctx, 1, 4 * (size_t)n));
+    TRY(ensure(ctx, 2, 8 * (size_t)n)); TRY(ensure(ctx, 3, 8 * (size_t)n));
+    TRY(up(ctx, sbuf<void>(ctx, 1), chan_id, 4 * (size_t)n));
+    TRY(up(ctx, sbuf<void>(ctx, 2), x, 8 * (size_t)n));
+    TRY(up(ctx, sbuf<void>(ctx, 3), z, 8 * (size_t)n));
+    launch_log_spawn(ctx->stream, ctx->g, ctx->w.d, n, sbuf<uint32_t>(ctx, 1), sbuf<double>(ctx, 2), sbuf<double>(ctx, 3));
+    TRY(after_launch(ctx));
+    uint32_t ovf = 0;
+    TRY(down(ctx, &ovf, ctx->w.d.counters + CTR_OVERFLOW, 4));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    if (ovf & OVF_SLOTS) return fail(ctx, CHD_E_CAPACITY, "chd_shard_log_spawn: a channel id outside entity_channel_id_start .. + shard_channels");
+    return CHD_OK;
+}
+
+int chd_shard_migrate_extra_records(chd_ctx *ctx, uint32_t *extra) {
+    NEED_WORLD();
+    if (!extra) return fail(ctx, CHD_E_INVAL, "chd_shard_migrate_extra_records: NULL output");
+    *extra = migrate_extra(ctx);
     return CHD_OK;
 }
 
@@ -2612,7 +2692,7 @@ int chd_shard_comm_init(chd_ctx *ctx, const void *unique_id, uint32_t rank, uint
     W.comm_rank = rank;
     W.comm_world = world;
     W.comm_cap = migrate_cap;
-    const size_t seg = (size_t)migrate_cap + 1;
+    const size_t seg = (size_t)migrate_cap + 1 + migrate_extra(ctx);
     int rc = CHD_OK;
     if (!W.mig_send) {  // (world allocations: kept across chd_shard_comm_destroy / a second init of the same size)
         if (rc == CHD_OK) rc = walloc(ctx, &W.mig_send, (size_t)world * seg);
@@ -2694,7 +2774,7 @@ int chd_shard_tick(chd_ctx *ctx, int64_t now_ns, const double *d_x_by_chan, cons
     }
     if (g_on && d_in->n_queries) {
         hipStream_t ax = ctx->aux_stream;
-        if (chained) launch_gate_wait(ax, W.d, W.gate + GATE_EPI, W.gate_epi);  // after the previous tick's epilogue
+        if (chained) launch_gate_wait(ax, W.d, W.gate + GATE_EPI, W.gate_epi, true);  // after the previous tick's epilogue
         else {
             HIPCHK(hipEventRecord(ctx->ev_fork, st));  // (recorded behind this tick's ingest: harmless, the two are independent)
             HIPCHK(hipStreamWaitEvent(ax, ctx->ev_fork, 0));
@@ -2703,7 +2783,7 @@ int chd_shard_tick(chd_ctx *ctx, int64_t now_ns, const double *d_x_by_chan, cons
         launch_aoi_interest(ax, ctx->g, ctx->lim, W.d, d_in->queries, d_in->n_queries, d_in->query_sub, d_in->spot_x, d_in->spot_z,
                             d_in->spot_dist, W.last_now, ctx->ring.cur_tick, W.gate + GATE_TOP, W.gate_top);
     }
-    const size_t seg = (size_t)use + 1;
+    const size_t seg = (size_t)use + 1 + migrate_extra(ctx);
     {   // the cross-server handovers (spatial.go:683-700): every rank's segment for every other rank, 32 B per emigrant.
         // (One rank: its own segment to itself — nothing to move, but the tick keeps its shape and the transport is exercised.)
         NCCLCHK(g_rccl.GroupStart());

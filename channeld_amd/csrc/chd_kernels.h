@@ -49,6 +49,17 @@ struct WorldDev {
     uint32_t *hist;       // bit j: an update of `sender` arrived at tick (hist_tick - j)
     uint32_t *hist_tick;
     uint32_t *sender_prev, *hist_prev;  // the previous sender's updates still inside the history
+    // THE UPDATE LOG BY CHANNEL (region-sharded worlds with exact update buffers, chd_world_cfg.shard_channels; log_on): everything
+    // push_update writes — sender / hist / hist_tick / sender_prev / hist_prev above, eoff, deep_*, irr_tick, ent_max_iv below —
+    // is then indexed by the entity CHANNEL, u = chan_id - log_eid0 < log_n, not by the entity slot, and every rank keeps it for
+    // every channel of the whole world (k_log_push: the ranks are fed the same update stream by channel id).  An entity that
+    // changes ranks, a neighbour's ghost entry, a window older than the entity's stay on this rank: the log is already here.
+    // log_ix() maps a slot to its log.  log_cell[u] = cell of the channel's last merged position (CHD_INVALID: none / out of the
+    // world), log_alive[u] = the channel exists (chd_shard_log_spawn).  sh_arrival_by_chan: chd_shard_set_update_arrivals.
+    uint32_t log_on, log_n, log_eid0;
+    uint32_t *log_cell, *log_alive;
+    const int64_t *sh_arrival_by_chan;
+    uint32_t sh_arrival_n;
     uint32_t *upd_mark;   // [N] (tick, round) of the slot's last update: a second one in the same round is a caller error (OVF_DUPLICATE)
     uint32_t *q_mark;     // [S] tick of the slot's last interest update, likewise
     // handover groups (entity.go:58-244, FlatEntityGroupController): entities that cross cells together.  grp_of[i] =
@@ -77,12 +88,17 @@ struct WorldDev {
     // overwrite although the reference would still hold it (INT64_MIN: none).  irr_tick = 1 + the last tick at which the
     // channel took an update the tick-ring masks cannot represent (an arrival stamp off the tick's own, a third sender);
     // cell_irr[c] = this tick some channel of cell c is like that inside the 32-tick mask horizon: its subscriptions go to
-    // k_fanout_emit_deep.  max_iv = maxFanOutIntervalMs (only grows; the eviction test of data.go:165-171).
+    // k_fanout_emit_deep.  cell_max_iv / ent_max_iv = ChannelData.maxFanOutIntervalMs per CHANNEL (only grows; the eviction
+    // test of data.go:165-171): raised for spatial channel c when a subscription to it is CREATED (subscription.go:83-86 — the
+    // branch that merges options into an existing subscription does not touch it); for an entity channel — whose subscribers
+    // are, in the tick model, those of the cells that hold it — at every update, before the eviction test, to the maxima of the
+    // cell of its last merged position and of the new one (push_update).
     uint32_t deep_depth;
     int64_t *deep_a, *cdeep_a, *deep_drop, *cdeep_drop;
     uint32_t *deep_s, *cdeep_s, *deep_n, *cdeep_n, *deep_len, *cdeep_len, *irr_tick, *cell_irr_tick;
     uint32_t *cell_irr;
-    uint32_t *max_iv;  // [2]: [0] what this tick's updates are buffered under, [1] raised by this tick's interest updates (folded into [0] by the epilogue: the interest updates may then run beside the ingest)
+    uint32_t *cell_max_iv;  // [2 * ncell]: [c] what this tick's updates are buffered under, [ncell + c] raised by this tick's interest updates (folded into [c] by the epilogue: the interest updates may then run beside the ingest)
+    uint32_t *ent_max_iv;   // [N]
     uint32_t *conn_deep;  // [S] this tick: the connection has PF_DEEP subscriptions
     // SUB-TICK ARRIVAL OFFSETS (off_on: worlds with exact update buffers on the descriptor path).  The reference stamps an
     // update when it is ENQUEUED (Channel.PutMessage: arrivalTime = ch.GetTime(), channel.go:296-310), so a tick's updates
@@ -237,6 +253,9 @@ struct WorldDev {
     uint64_t *tick_ring;  // [TICK_RING][8] per-tick totals written by the epilogue
 };
 
+// where entity slot i's update log lives (WorldDev::log_on)
+__device__ __forceinline__ uint32_t log_ix(const WorldDev &w, uint32_t i) { return w.log_on ? w.chan_id[i] - w.log_eid0 : i; }
+
 // a gate's spin bound tripped (OVF_GATE): this tick's mask, and the world's sticky count (the host turns the gates off when it sees it)
 __device__ __forceinline__ void gate_timed_out(const WorldDev &w) {
     atomicOr(&w.counters[CTR_OVERFLOW], OVF_GATE);
@@ -280,7 +299,8 @@ __device__ __forceinline__ void off_shift(uint32_t (&o)[CHD_OFF_SLOTS], uint32_t
     for (int j = 0; j < (int)CHD_OFF_SLOTS; j++) o[j] = r[j];
 }
 
-__device__ __forceinline__ void push_update(const WorldDev &w, uint32_t i, uint32_t snd, uint32_t cur_tick,
+// c_old / c_new: the cells of the entity's last merged position and of this update's (CHD_INVALID: out of the world)
+__device__ __forceinline__ void push_update(const WorldDev &w, uint32_t i, uint32_t snd, uint32_t cur_tick, uint32_t c_old, uint32_t c_new,
                                             int64_t arrival = 0, int64_t now = 0) {
     const uint32_t age = cur_tick - w.hist_tick[i];
     uint32_t h = (age >= CHD_HIST_BITS) ? 0u : (w.hist[i] << age);
@@ -326,12 +346,25 @@ __device__ __forceinline__ void push_update(const WorldDev &w, uint32_t i, uint3
         uint32_t n = w.deep_n[i], len = w.deep_len[i];
         int64_t drop = w.deep_drop[i];
         const size_t at = (size_t)i * w.deep_depth;
-        deep_push(w.deep_a + at, w.deep_s + at, w.deep_depth, n, len, drop, arrival, snd, *w.max_iv);
+        // the entity channel's maxFanOutIntervalMs (WorldDev::ent_max_iv): the subscribers of the cells that hold it are its own
+        uint32_t miv = w.ent_max_iv[i];
+        const uint32_t m_old = c_old != CHD_INVALID ? w.cell_max_iv[c_old] : 0u, m_new = c_new != CHD_INVALID ? w.cell_max_iv[c_new] : 0u;
+        if (m_old > miv || m_new > miv) { miv = max(miv, max(m_old, m_new)); w.ent_max_iv[i] = miv; }
+        deep_push(w.deep_a + at, w.deep_s + at, w.deep_depth, n, len, drop, arrival, snd, miv);
         w.deep_n[i] = n;
         w.deep_len[i] = len;
         w.deep_drop[i] = drop;
         if (irregular) w.irr_tick[i] = cur_tick + 1u;
     }
+}
+
+// a channel's sub-tick arrival offsets (WorldDev::off_on; u = its log index), aligned to this tick, into the cell-sorted columns
+__device__ __forceinline__ void scatter_offsets(const WorldDev &w, uint32_t u, uint32_t pos, uint32_t age) {
+    const uint4 a = w.eoff[2 * (size_t)u], b = w.eoff[2 * (size_t)u + 1];
+    uint32_t o[CHD_OFF_SLOTS] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+    off_shift(o, age);
+#pragma unroll
+    for (uint32_t j = 0; j < CHD_OFF_SLOTS; j++) w.ce_off[(size_t)j * w.off_stride + pos] = o[j];
 }
 
 // Is connection slot s subscribed to cell c?  Interest bitmap where it exists, else a binary search of
@@ -400,20 +433,26 @@ void launch_ingest_by_channel(hipStream_t st, DevGrid g, WorldDev w, const doubl
 void launch_apply_requests(hipStream_t st, WorldDev w, const uint4 *req_recv, uint32_t world, uint32_t req_cap);
 // entities whose member cell belongs to another rank leave (state packed per destination, slot freed)
 void launch_export(hipStream_t st, DevGrid g, WorldDev w, uint32_t rank, uint32_t world,
-                   chd_entity_state *send, uint32_t cap, uint32_t cur_tick);
+                   chd_entity_state *send, uint32_t cap, uint32_t cur_tick, uint32_t extra = 0);
+// extra > 0 (log_on): behind a segment's (cap + 1) records, `extra` records of the sender's maxFanOutIntervalMs per cell
 void launch_import(hipStream_t st, WorldDev w, const chd_entity_state *recv, uint32_t world, uint32_t cap,
-                   uint32_t cur_tick);
+                   uint32_t cur_tick, uint32_t extra = 0, uint32_t ncell = 0);
 void launch_spawn_auto(hipStream_t st, DevGrid g, WorldDev w, uint32_t n, const uint32_t *chan_id,
                        const double *x, const double *z, const uint32_t *flags, const uint32_t *sender,
                        uint32_t cur_tick);
 void launch_free_stack_init(hipStream_t st, WorldDev w);
 void launch_slot_of_rebuild(hipStream_t st, WorldDev w);  // sh_slot_of from the live slots' channel ids
+// the update log by channel (WorldDev::log_on): note the channels that come to life; push this tick's updates of EVERY channel
+void launch_log_spawn(hipStream_t st, DevGrid g, WorldDev w, uint32_t n, const uint32_t *chan_id, const double *x, const double *z);
+void launch_log_push(hipStream_t st, DevGrid g, WorldDev w, const double *x_by_chan, const double *z_by_chan, const uint8_t *has_update,
+                     uint32_t n_chan, uint32_t cur_tick, int64_t now_ns);
 // halo exchange: pack this rank's border bands per destination (segments at seg_off[d]), and append the received ones behind
 // the own cell tables (ghost entries from index N on) + the cell views
 void launch_halo_pack(hipStream_t st, DevGrid g, WorldDev w, uint32_t rank, uint32_t world, uint32_t halo, unsigned char *send,
                       const uint64_t *seg_off);
 void launch_halo_unpack(hipStream_t st, DevGrid g, WorldDev w, uint32_t rank, uint32_t world, uint32_t halo, const unsigned char *recv,
-                        const uint64_t *seg_off, const uint32_t *ghost_off, const unsigned long long *gate_p = nullptr, unsigned long long gate_target = 0);
+                        const uint64_t *seg_off, const uint32_t *ghost_off, uint32_t cur_tick, const unsigned long long *gate_p = nullptr,
+                        unsigned long long gate_target = 0);
 // K2: cell index build
 bool launch_index_build(hipStream_t st, DevGrid g, WorldDev w, uint32_t cur_tick, const unsigned long long *gate_p = nullptr,
                         unsigned long long gate_target = 0);
@@ -452,7 +491,7 @@ void launch_gate_raise(hipStream_t st, unsigned long long *p, unsigned long long
 // once per world with a bounded wait (tens of ms when they do not)
 int streams_run_side_by_side(hipStream_t waiter_st, hipStream_t raiser_st, unsigned long long *d_flag, unsigned *d_seen, bool *ok);
 // one wave that returns when *p >= target (bounded: a dependency that never resolves raises OVF_GATE instead of hanging)
-void launch_gate_wait(hipStream_t st, WorldDev w, const unsigned long long *p, unsigned long long target);
+void launch_gate_wait(hipStream_t st, WorldDev w, const unsigned long long *p, unsigned long long target, bool fork);
 size_t aoi_lds_bytes(AoiLimits lim, uint32_t capq);
 size_t aoi_lds_limit();  // the most dynamic LDS an AOI launch may ask for (gfx950: 160 KiB per CU)
 // compaction of the fixed-stride stateless output into CSR

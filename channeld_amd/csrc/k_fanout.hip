@@ -2781,9 +2781,13 @@ static_assert(CHD_LIST_BANKS == 64, "one epilogue lane per list bank");
 __global__ void __launch_bounds__(64) k_tick_epilogue(WorldDev w, uint32_t slot, uint32_t ncell, unsigned long long *epi, unsigned long long epi_seq) {
     const uint32_t lane = threadIdx.x;
     if (w.deep_depth) {  // (set again by the next tick's index build)
-        for (uint32_t c = lane; c < ncell; c += 64) w.cell_irr[c] = 0;
-        // maxFanOutIntervalMs as this tick's interest updates left it: what the NEXT tick's updates are buffered under
-        if (lane == 0 && w.max_iv[1] > w.max_iv[0]) w.max_iv[0] = w.max_iv[1];
+        // ... and the spatial channels' maxFanOutIntervalMs as this tick's interest updates left it: what the NEXT tick's updates
+        // are buffered under
+        for (uint32_t c = lane; c < ncell; c += 64) {
+            w.cell_irr[c] = 0;
+            const uint32_t m = w.cell_max_iv[ncell + c];
+            if (m > w.cell_max_iv[c]) w.cell_max_iv[c] = m;
+        }
     }
     if (w.off_on && w.fcm_on)  // (the next tick's plan appends to the cells' lists of filtered descriptors)
         for (uint32_t c = lane; c < ncell; c += 64) w.cell_fcnt[32u * c] = 0;

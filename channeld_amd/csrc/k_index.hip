@@ -49,21 +49,22 @@ __device__ __forceinline__ void index_hist_block(const WorldDev &w, uint32_t nce
             uint32_t m = (w.eflags[i] & EF_ALIVE) ? w.member[i] : CHD_INVALID;
             if (m < ncell) {
                 atomicAdd(&h[m], 1u);
-                const uint32_t snd = w.sender[i];
+                const uint32_t u = log_ix(w, i);  // (where the entity's update log lives: its slot, or its channel — WorldDev::log_on)
+                const uint32_t snd = w.sender[u];
                 atomicMin(&smin[m], snd);
                 atomicMax(&smax[m], snd);
-                const uint32_t age = cur_tick - w.hist_tick[i];
-                const uint32_t hp = age < CHD_HIST_BITS ? (w.hist_prev[i] << age) : 0u;
-                const uint32_t hc = age < CHD_HIST_BITS ? (w.hist[i] << age) : 0u;
+                const uint32_t age = cur_tick - w.hist_tick[u];
+                const uint32_t hp = age < CHD_HIST_BITS ? (w.hist_prev[u] << age) : 0u;
+                const uint32_t hc = age < CHD_HIST_BITS ? (w.hist[u] << age) : 0u;
                 atomicAnd(&hand[m], hc | hp);
                 // exact update buffers: an update the masks cannot represent, still inside their horizon (rare: a plain
                 // global atomic; cell_irr is cleared by the tick epilogue)
                 if (w.deep_depth) {
-                    const uint32_t it = w.irr_tick[i];
+                    const uint32_t it = w.irr_tick[u];
                     if (it && cur_tick + 1u - it < CHD_HIST_BITS) atomicOr(&w.cell_irr[m], 1u);
                 }
                 if (hp != 0) {
-                    const uint32_t sp = w.sender_prev[i];
+                    const uint32_t sp = w.sender_prev[u];
                     atomicMin(&smin[m], sp);
                     atomicMax(&smax[m], sp);
                 }
@@ -164,14 +165,6 @@ __global__ void __launch_bounds__(256) k_index_scan(WorldDev w, uint32_t ncell, 
     }
 }
 
-// the entity's sub-tick arrival offsets (WorldDev::off_on), aligned to this tick, into the cell-sorted columns
-__device__ __forceinline__ void scatter_offsets(const WorldDev &w, uint32_t i, uint32_t pos, uint32_t age) {
-    const uint4 a = w.eoff[2 * (size_t)i], b = w.eoff[2 * (size_t)i + 1];
-    uint32_t o[CHD_OFF_SLOTS] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
-    off_shift(o, age);
-#pragma unroll
-    for (uint32_t j = 0; j < CHD_OFF_SLOTS; j++) w.ce_off[(size_t)j * w.off_stride + pos] = o[j];
-}
 
 __device__ __forceinline__ void index_scatter_block(const WorldDev &w, uint32_t ncell, uint32_t key_bits, uint32_t cur_tick, int local_base,
                                                     uint32_t bid, unsigned char *smem) {
@@ -256,15 +249,16 @@ __device__ __forceinline__ void index_scatter_block(const WorldDev &w, uint32_t 
         if (key[r] == CHD_INVALID) continue;
         uint32_t i = base + r * 64 + lane;
         uint32_t pos = mycnt[key[r]] + lrank[r];
-        uint32_t age = cur_tick - w.hist_tick[i];
-        uint32_t h = (age >= CHD_HIST_BITS) ? 0u : (w.hist[i] << age);
-        uint32_t hp = (age >= CHD_HIST_BITS) ? 0u : (w.hist_prev[i] << age);
-        w.ce[pos] = make_uint4(w.chan_id[i], h, w.sender[i], hp);
+        const uint32_t u = log_ix(w, i);
+        uint32_t age = cur_tick - w.hist_tick[u];
+        uint32_t h = (age >= CHD_HIST_BITS) ? 0u : (w.hist[u] << age);
+        uint32_t hp = (age >= CHD_HIST_BITS) ? 0u : (w.hist_prev[u] << age);
+        w.ce[pos] = make_uint4(w.chan_id[i], h, w.sender[u], hp);
         w.ce8[pos] = make_uint2(w.chan_id[i], h | hp);
         w.ce_chan[pos] = w.chan_id[i];
-        w.ce_sprev[pos] = w.sender_prev[i];
-        if (w.ce_slot) w.ce_slot[pos] = i;
-        if (w.off_on) scatter_offsets(w, i, pos, age);
+        w.ce_sprev[pos] = w.sender_prev[u];
+        if (w.ce_slot) w.ce_slot[pos] = u;  // (what the exact buffers are indexed by: the slot — or, log_on, the channel)
+        if (w.off_on) scatter_offsets(w, u, pos, age);
     }
 }
 
@@ -299,7 +293,7 @@ __global__ void __launch_bounds__(256) k_index_hist_global(WorldDev w, uint32_t 
     if (m < ncell) {
         atomicAdd(&w.blk_cnt[m], 1u);
         if (w.deep_depth) {
-            const uint32_t it = w.irr_tick[i];
+            const uint32_t it = w.irr_tick[log_ix(w, i)];
             if (it && cur_tick + 1u - it < CHD_HIST_BITS) atomicOr(&w.cell_irr[m], 1u);
         }
     }
@@ -313,14 +307,15 @@ __global__ void __launch_bounds__(256) k_index_scatter_global(WorldDev w, uint32
     uint32_t m = w.member[i];
     if (m >= ncell) return;
     uint32_t pos = w.blk_cnt[m] + atomicAdd(&cursor[m], 1u);
-    uint32_t age = cur_tick - w.hist_tick[i];
-    uint32_t h = (age >= CHD_HIST_BITS) ? 0u : (w.hist[i] << age);
-    uint32_t hp = (age >= CHD_HIST_BITS) ? 0u : (w.hist_prev[i] << age);
-    w.ce[pos] = make_uint4(w.chan_id[i], h, w.sender[i], hp);
-    w.ce_sprev[pos] = w.sender_prev[i];
+    const uint32_t u = log_ix(w, i);
+    uint32_t age = cur_tick - w.hist_tick[u];
+    uint32_t h = (age >= CHD_HIST_BITS) ? 0u : (w.hist[u] << age);
+    uint32_t hp = (age >= CHD_HIST_BITS) ? 0u : (w.hist_prev[u] << age);
+    w.ce[pos] = make_uint4(w.chan_id[i], h, w.sender[u], hp);
+    w.ce_sprev[pos] = w.sender_prev[u];
     w.ce_chan[pos] = w.chan_id[i];
-    if (w.ce_slot) w.ce_slot[pos] = i;
-    if (w.off_on) scatter_offsets(w, i, pos, age);
+    if (w.ce_slot) w.ce_slot[pos] = u;
+    if (w.off_on) scatter_offsets(w, u, pos, age);
 }
 
 // ------------------------------------------------------------------------
@@ -443,13 +438,13 @@ __global__ void __launch_bounds__(256) k_window_columns(WorldDev w, uint32_t nce
 __global__ void __launch_bounds__(256) k_cell_offsets(WorldDev w, uint32_t ncell) {
     __shared__ uint32_t smn[4][CHD_OFF_SLOTS], smx[4][CHD_OFF_SLOTS];
     const uint32_t c = blockIdx.x;
-    const uint32_t start = w.cell_off[c], n = w.cell_off[c + 1] - start;
+    const uint32_t start = w.cell_start[c], n = w.cell_end[c] - start;  // (region-sharded: the neighbours' ghost entries as well)
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
     uint32_t mn[CHD_OFF_SLOTS], mx[CHD_OFF_SLOTS];
 #pragma unroll
     for (uint32_t j = 0; j < CHD_OFF_SLOTS; j++) { mn[j] = 0xFFFFFFFFu; mx[j] = 0u; }
     for (uint32_t k = threadIdx.x; k < n; k += 256) {
-        const uint32_t h = w.ce8[start + k].y;  // history of any sender, aligned to this tick
+        const uint32_t h = w.ce8_view[start + k].y;  // history of any sender, aligned to this tick
 #pragma unroll
         for (uint32_t j = 0; j < CHD_OFF_SLOTS; j++) {
             if (!((h >> j) & 1u)) continue;

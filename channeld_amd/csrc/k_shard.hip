@@ -69,11 +69,13 @@ __global__ void __launch_bounds__(256) k_spawn_auto(DevGrid g, WorldDev w, uint3
     w.cell[i] = c;
     w.member[i] = c;
     w.eflags[i] = (flags ? (flags[u] & ~EF_ALIVE) : 0u) | EF_ALIVE;
-    w.sender[i] = sender ? sender[u] : 0u;
-    w.hist[i] = 0;
-    w.hist_tick[i] = cur_tick;
-    w.sender_prev[i] = 0;
-    w.hist_prev[i] = 0;
+    if (!w.log_on) {  // (log_on: the update log is the channel's, not the slot's — k_log_spawn)
+        w.sender[i] = sender ? sender[u] : 0u;
+        w.hist[i] = 0;
+        w.hist_tick[i] = cur_tick;
+        w.sender_prev[i] = 0;
+        w.hist_prev[i] = 0;
+    }
     note_slot(w, chan_id[u], i);
 }
 
@@ -106,7 +108,8 @@ __global__ void __launch_bounds__(256) k_ingest_by_channel(DevGrid g, WorldDev w
             src = w.cell[i];
             w.cell[i] = dst;
             // (who sent the update: the owner changes with a cross-server handover — chd_shard_set_update_senders — else the entity's own)
-            push_update(w, i, (w.sh_sender_by_chan && k < w.sh_sender_n) ? w.sh_sender_by_chan[k] : w.sender[i], cur_tick);
+            // log_on: every rank logs every channel's update, this one's included (k_log_push, after the emigrant exchange)
+            if (!w.log_on) push_update(w, i, (w.sh_sender_by_chan && k < w.sh_sender_n) ? w.sh_sender_by_chan[k] : w.sender[i], cur_tick, src, dst);
             if (src != CHD_INVALID && dst != CHD_INVALID && src != dst) {
                 // GetHandoverEntities (entity.go:197-224) as the host's group controllers evaluated it: an EMPTY list = a locked
                 // member or an emptied group -> no handover (spatial.go:675-679)
@@ -215,7 +218,7 @@ void launch_apply_requests(hipStream_t st, WorldDev w, const uint4 *req_recv, ui
 
 __global__ void __launch_bounds__(256) k_export(DevGrid g, WorldDev w, uint32_t rank, uint32_t world,
                                                 chd_entity_state *__restrict__ send, uint32_t cap,
-                                                uint32_t cur_tick) {
+                                                uint32_t cur_tick, uint32_t extra) {
     const uint32_t i = blockIdx.x * 256u + threadIdx.x;
     // (the limbo list this tick's import appends to starts empty: see k_import)
     if (i == 0) w.limbo_n[(cur_tick + 1u) & 1u] = 0;
@@ -226,7 +229,7 @@ __global__ void __launch_bounds__(256) k_export(DevGrid g, WorldDev w, uint32_t 
     if (m == CHD_INVALID) return;  // in no cell: visible to nobody, stays where it is
     const uint32_t dst = server_of(g, m);
     if (dst == rank || dst >= world) return;
-    chd_entity_state *seg = send + (size_t)dst * (cap + 1);  // record 0 = header, chan_id = count
+    chd_entity_state *seg = send + (size_t)dst * ((size_t)cap + 1 + extra);  // record 0 = header, chan_id = count
     const uint32_t k = atomicAdd(&seg[0].chan_id, 1u);
     if (k >= cap) {
         // no room in this tick's segment: stay (still owned here, still wrong owner) and retry next tick
@@ -239,11 +242,14 @@ __global__ void __launch_bounds__(256) k_export(DevGrid g, WorldDev w, uint32_t 
     e.cell = w.cell[i];
     e.member = m;
     e.eflags = ef;
-    e.sender = w.sender[i];
-    const uint32_t age = cur_tick - w.hist_tick[i];
-    e.hist = age >= CHD_HIST_BITS ? 0u : (w.hist[i] << age);
-    e.hist_prev = age >= CHD_HIST_BITS ? 0u : (w.hist_prev[i] << age);
-    e.sender_prev = w.sender_prev[i];
+    if (w.log_on) { e.sender = e.hist = e.hist_prev = e.sender_prev = 0; }  // (the destination has the channel's log already)
+    else {
+        e.sender = w.sender[i];
+        const uint32_t age = cur_tick - w.hist_tick[i];
+        e.hist = age >= CHD_HIST_BITS ? 0u : (w.hist[i] << age);
+        e.hist_prev = age >= CHD_HIST_BITS ? 0u : (w.hist_prev[i] << age);
+        e.sender_prev = w.sender_prev[i];
+    }
     seg[1 + k] = e;
     note_slot(w, e.chan_id, CHD_INVALID);
     w.eflags[i] = 0;
@@ -256,20 +262,30 @@ __global__ void __launch_bounds__(256) k_export(DevGrid g, WorldDev w, uint32_t 
 // Every header also carries the LARGEST count this rank put into any of its segments (field `cell` of record 0): after the
 // all-to-all every rank holds every source's maximum, i.e. the same global maximum — what the adaptive segment capacity of
 // the following ticks is derived from (chd_shard_ingest, cap_used), identically on every rank and without a collective.
-__global__ void __launch_bounds__(64) k_export_finish(chd_entity_state *__restrict__ send, uint32_t world, uint32_t cap) {
+// extra > 0 (WorldDev::log_on): every segment is followed by `extra` more records that carry THIS rank's maxFanOutIntervalMs per
+// spatial channel (cell_max_iv's in-force half: stable during the tick — the interest updates raise the other half), so that after
+// the exchange every rank folds the same world-wide maxima before it logs the tick's updates (k_import, k_log_push).
+__global__ void __launch_bounds__(64) k_export_finish(WorldDev w, chd_entity_state *__restrict__ send, uint32_t world, uint32_t cap, uint32_t extra,
+                                                      uint32_t ncell) {
+    const size_t pitch = (size_t)cap + 1 + extra;
     uint32_t m = 0;
-    for (uint32_t d = threadIdx.x; d < world; d += 64) m = max(m, min(send[(size_t)d * (cap + 1)].chan_id, cap));
+    for (uint32_t d = threadIdx.x; d < world; d += 64) m = max(m, min(send[d * pitch].chan_id, cap));
     for (int d = 32; d >= 1; d >>= 1) m = max(m, (uint32_t)__shfl_xor((int)m, d));
-    for (uint32_t d = threadIdx.x; d < world; d += 64) send[(size_t)d * (cap + 1)].cell = m;
+    for (uint32_t d = threadIdx.x; d < world; d += 64) send[d * pitch].cell = m;
+    if (extra)
+        for (uint32_t d = 0; d < world; d++) {
+            uint32_t *x = (uint32_t *)(send + d * pitch + cap + 1);
+            for (uint32_t c = threadIdx.x; c < extra * 8u; c += 64) x[c] = c < ncell ? w.cell_max_iv[c] : 0u;
+        }
 }
 
 void launch_export(hipStream_t st, DevGrid g, WorldDev w, uint32_t rank, uint32_t world,
-                   chd_entity_state *send, uint32_t cap, uint32_t cur_tick) {
-    // zero the segment headers (32 bytes at a pitch of (cap+1) records)
-    (void)hipMemset2DAsync(send, sizeof(chd_entity_state) * ((size_t)cap + 1), 0, sizeof(chd_entity_state), world, st);
+                   chd_entity_state *send, uint32_t cap, uint32_t cur_tick, uint32_t extra) {
+    // zero the segment headers (32 bytes at a pitch of (cap + 1 + extra) records)
+    (void)hipMemset2DAsync(send, sizeof(chd_entity_state) * ((size_t)cap + 1 + extra), 0, sizeof(chd_entity_state), world, st);
     if (!w.N) return;
-    hipLaunchKernelGGL(k_export, dim3(nblocks(w.N, 256)), dim3(256), 0, st, g, w, rank, world, send, cap, cur_tick);
-    hipLaunchKernelGGL(k_export_finish, dim3(1), dim3(64), 0, st, send, world, cap);
+    hipLaunchKernelGGL(k_export, dim3(nblocks(w.N, 256)), dim3(256), 0, st, g, w, rank, world, send, cap, cur_tick, extra);
+    hipLaunchKernelGGL(k_export_finish, dim3(1), dim3(64), 0, st, w, send, world, cap, extra, g.ncell);
 }
 
 __device__ __forceinline__ void install_entity(const WorldDev &w, uint32_t i, const chd_entity_state &e, uint32_t cur_tick) {
@@ -277,11 +293,13 @@ __device__ __forceinline__ void install_entity(const WorldDev &w, uint32_t i, co
     w.cell[i] = e.cell;
     w.member[i] = e.member;
     w.eflags[i] = e.eflags | EF_ALIVE;
-    w.sender[i] = e.sender;
-    w.hist[i] = e.hist;
-    w.hist_tick[i] = cur_tick;
-    w.hist_prev[i] = e.hist_prev;
-    w.sender_prev[i] = e.sender_prev;
+    if (!w.log_on) {
+        w.sender[i] = e.sender;
+        w.hist[i] = e.hist;
+        w.hist_tick[i] = cur_tick;
+        w.hist_prev[i] = e.hist_prev;
+        w.sender_prev[i] = e.sender_prev;
+    }
     note_slot(w, e.chan_id, i);
 }
 
@@ -299,10 +317,18 @@ __device__ __forceinline__ void to_limbo(const WorldDev &w, const chd_entity_sta
 // blockIdx.y < world: the segment rank y sent; blockIdx.y == world: the entities waiting in limbo since earlier ticks.
 // Also folds the global maximum segment count of this tick's exchange (k_export_finish) into mig_gmax[cur_tick & 3].
 __global__ void __launch_bounds__(256) k_import(WorldDev w, const chd_entity_state *__restrict__ recv,
-                                                uint32_t world, uint32_t cap, uint32_t cur_tick) {
+                                                uint32_t world, uint32_t cap, uint32_t cur_tick, uint32_t extra, uint32_t ncell) {
     const uint32_t src = blockIdx.y;
     const uint32_t k = blockIdx.x * 256u + threadIdx.x;
+    const size_t pitch = (size_t)cap + 1 + extra;
     if (src == world) {
+        // log_on: the world-wide maxFanOutIntervalMs of every spatial channel = the maximum over the ranks' own (k_export_finish)
+        if (extra)
+            for (uint32_t c = k; c < ncell; c += gridDim.x * 256u) {
+                uint32_t m = w.cell_max_iv[c];
+                for (uint32_t s = 0; s < world; s++) m = max(m, ((const uint32_t *)(recv + s * pitch + cap + 1))[c]);
+                w.cell_max_iv[c] = m;
+            }
         const uint32_t cb = cur_tick & 1u;
         const uint32_t n = min(w.limbo_n[cb], w.N);
         for (uint32_t q = k; q < n; q += gridDim.x * 256u) {
@@ -315,12 +341,12 @@ __global__ void __launch_bounds__(256) k_import(WorldDev w, const chd_entity_sta
         }
         if (k == 0) {
             uint32_t m = 0;
-            for (uint32_t s = 0; s < world; s++) m = max(m, recv[(size_t)s * (cap + 1)].cell);
+            for (uint32_t s = 0; s < world; s++) m = max(m, recv[s * pitch].cell);
             w.mig_gmax[cur_tick & 3u] = m;
         }
         return;
     }
-    const chd_entity_state *seg = recv + (size_t)src * (cap + 1);
+    const chd_entity_state *seg = recv + src * pitch;
     const uint32_t n = min(seg[0].chan_id, cap);
     if (k >= n) return;
     const chd_entity_state e = seg[1 + k];
@@ -330,9 +356,53 @@ __global__ void __launch_bounds__(256) k_import(WorldDev w, const chd_entity_sta
 }
 
 void launch_import(hipStream_t st, WorldDev w, const chd_entity_state *recv, uint32_t world, uint32_t cap,
-                   uint32_t cur_tick) {
+                   uint32_t cur_tick, uint32_t extra, uint32_t ncell) {
     if (!world || !cap) return;
-    hipLaunchKernelGGL(k_import, dim3(nblocks(cap, 256), world + 1), dim3(256), 0, st, w, recv, world, cap, cur_tick);
+    hipLaunchKernelGGL(k_import, dim3(nblocks(cap, 256), world + 1), dim3(256), 0, st, w, recv, world, cap, cur_tick, extra, ncell);
+}
+
+// ---------------------------------------------------------------------------
+// The update log by channel (WorldDev::log_on).  In the reference a channel's update buffer, its senders and its
+// maxFanOutIntervalMs live with the CHANNEL in the one gateway process (data.go:53-55); which spatial server owns the entity is
+// another matter (spatial.go:683-700).  Every rank of a region-sharded world is fed the same update stream by channel id, so
+// every rank keeps every channel's log: nothing of it has to travel with an emigrant or a border band.
+// ---------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_log_spawn(DevGrid g, WorldDev w, uint32_t n, const uint32_t *__restrict__ chan_id,
+                                                   const double *__restrict__ x, const double *__restrict__ z) {
+    const uint32_t t = blockIdx.x * 256u + threadIdx.x;
+    if (t >= n) return;
+    const uint32_t u = chan_id[t] - w.log_eid0;
+    if (u >= w.log_n) { atomicOr(&w.counters[CTR_OVERFLOW], OVF_SLOTS); return; }
+    w.log_cell[u] = cell_of(g, x[t], z[t]);
+    w.log_alive[u] = 1u;
+    // a new channel: an empty buffer, no history (a re-used channel id starts over)
+    w.hist[u] = 0; w.hist_prev[u] = 0; w.sender[u] = 0; w.sender_prev[u] = 0;
+    w.deep_n[u] = 0; w.deep_len[u] = 0; w.deep_drop[u] = INT64_MIN; w.irr_tick[u] = 0; w.ent_max_iv[u] = 0;
+    if (w.off_on) { w.eoff[2 * (size_t)u] = make_uint4(0, 0, 0, 0); w.eoff[2 * (size_t)u + 1] = make_uint4(0, 0, 0, 0); }
+}
+
+void launch_log_spawn(hipStream_t st, DevGrid g, WorldDev w, uint32_t n, const uint32_t *chan_id, const double *x, const double *z) {
+    if (!n) return;
+    hipLaunchKernelGGL(k_log_spawn, dim3(nblocks(n, 256)), dim3(256), 0, st, g, w, n, chan_id, x, z);
+}
+
+// ChannelData.OnUpdate (data.go:149-173) for this tick's update of EVERY channel of the world, on every rank alike: the Notify
+// decision's two cells (for the channel's maxFanOutIntervalMs, push_update), the sender and the arrival stamp by channel id.
+__global__ void __launch_bounds__(256) k_log_push(DevGrid g, WorldDev w, const double *__restrict__ xs, const double *__restrict__ zs,
+                                                  const uint8_t *__restrict__ has_update, uint32_t n_chan, uint32_t cur_tick, int64_t now) {
+    const uint32_t u = blockIdx.x * 256u + threadIdx.x;
+    if (u >= n_chan || u >= w.log_n || !w.log_alive[u] || (has_update && !has_update[u])) return;
+    const uint32_t c_new = cell_of(g, xs[u], zs[u]), c_old = w.log_cell[u];
+    w.log_cell[u] = c_new;
+    const uint32_t snd = (w.sh_sender_by_chan && u < w.sh_sender_n) ? w.sh_sender_by_chan[u] : 0u;
+    const int64_t a = (w.sh_arrival_by_chan && u < w.sh_arrival_n) ? w.sh_arrival_by_chan[u] : now;
+    push_update(w, u, snd, cur_tick, c_old, c_new, a, now);
+}
+
+void launch_log_push(hipStream_t st, DevGrid g, WorldDev w, const double *x_by_chan, const double *z_by_chan, const uint8_t *has_update,
+                     uint32_t n_chan, uint32_t cur_tick, int64_t now_ns) {
+    if (!w.log_on || !n_chan) return;
+    hipLaunchKernelGGL(k_log_push, dim3(nblocks(n_chan, 256)), dim3(256), 0, st, g, w, x_by_chan, z_by_chan, has_update, n_chan, cur_tick, now_ns);
 }
 
 // ---------------------------------------------------------------------------
@@ -399,7 +469,7 @@ void launch_halo_pack(hipStream_t st, DevGrid g, WorldDev w, uint32_t rank, uint
 // block s < world: the segment rank s sent; block `world`: this rank's own cells and the cells nobody covers
 __global__ void __launch_bounds__(256) k_halo_unpack(DevGrid g, WorldDev w, uint32_t rank, uint32_t world, uint32_t halo,
                                                      const unsigned char *__restrict__ recv, const uint64_t *__restrict__ seg_off,
-                                                     const uint32_t *__restrict__ ghost_off, const unsigned long long *gate_p,
+                                                     const uint32_t *__restrict__ ghost_off, uint32_t cur_tick, const unsigned long long *gate_p,
                                                      unsigned long long gate_target) {
     const uint32_t s = blockIdx.x;
     if (s == world) {
@@ -481,10 +551,31 @@ __global__ void __launch_bounds__(256) k_halo_unpack(DevGrid g, WorldDev w, uint
         w.ce_sprev[base + k] = sprev[k];
         w.ce8[base + k] = make_uint2(e.x, e.y | e.w);  // compact entry {channel, history of any sender}
         w.ce_chan[base + k] = e.x;
+        if (w.log_on) {
+            // the ghost's update log is HERE (by channel): where the exact buffers are, and its sub-tick offsets into the columns
+            const uint32_t u = e.x - w.log_eid0;
+            if (u < w.log_n) {
+                w.ce_slot[base + k] = u;
+                if (w.off_on) scatter_offsets(w, u, base + k, cur_tick - w.hist_tick[u]);
+            }
+        }
+    }
+    if (w.log_on) {  // ... and whether a ghost cell holds a channel the tick-ring masks cannot answer for (cell_irr, as the index build sets it)
+        __syncthreads();
+        for (uint32_t k = threadIdx.x; k < nc; k += 256) {
+            const uint32_t c = (r.x0 + k % r.w) + (r.y0 + k / r.w) * g.cols;
+            bool irr = false;
+            for (uint32_t p = w.cell_tab[c]; p < w.cell_tab[g.ncell + c]; p++) {
+                const uint32_t u = w.ce[p].x - w.log_eid0;
+                const uint32_t it = u < w.log_n ? w.irr_tick[u] : 0u;
+                irr = irr || (it && cur_tick + 1u - it < CHD_HIST_BITS);
+            }
+            if (irr) w.cell_irr[c] = 1u;
+        }
     }
 }
 
 void launch_halo_unpack(hipStream_t st, DevGrid g, WorldDev w, uint32_t rank, uint32_t world, uint32_t halo, const unsigned char *recv,
-                        const uint64_t *seg_off, const uint32_t *ghost_off, const unsigned long long *gate_p, unsigned long long gate_target) {
-    hipLaunchKernelGGL(k_halo_unpack, dim3(world + 1), dim3(256), 0, st, g, w, rank, world, halo, recv, seg_off, ghost_off, gate_p, gate_target);
+                        const uint64_t *seg_off, const uint32_t *ghost_off, uint32_t cur_tick, const unsigned long long *gate_p, unsigned long long gate_target) {
+    hipLaunchKernelGGL(k_halo_unpack, dim3(world + 1), dim3(256), 0, st, g, w, rank, world, halo, recv, seg_off, ghost_off, cur_tick, gate_p, gate_target);
 }

@@ -187,6 +187,7 @@ __global__ void __launch_bounds__(256) k_spawn(DevGrid g, WorldDev w, uint32_t n
         w.deep_len[i] = 0;
         w.deep_drop[i] = INT64_MIN;
         w.irr_tick[i] = 0;
+        w.ent_max_iv[i] = 0;
     }
 }
 
@@ -304,7 +305,7 @@ __global__ void __launch_bounds__(64) k_subs_set_options(DevGrid g, WorldDev w, 
                 if (o.set & CHD_SUBOPT_FIELD_MASK) fl = (fl & ~(0xFFu << PF_FIELD_MASK_SHIFT)) | ((o.data_field_mask & 0xFFu) << PF_FIELD_MASK_SHIFT);
                 w.pair_flags[pbase + pos] = fl;
                 if (o.set & CHD_SUBOPT_INTERVAL) w.pair_iv[pbase + pos] = o.fanout_interval_ms;
-                if (w.deep_depth && w.pair_iv[pbase + pos] > w.max_iv[1]) { atomicMax(w.max_iv, w.pair_iv[pbase + pos]); atomicMax(w.max_iv + 1, w.pair_iv[pbase + pos]); }
+                // (maxFanOutIntervalMs is not raised by a merge: subscription.go:83-86 sits on the new-subscription branch)
                 should_send[i] = acc != acc_old ? 1 : 0;  // dataAccessChanged
                 status[i] = CHD_OK;
             }
@@ -335,7 +336,10 @@ __global__ void __launch_bounds__(64) k_subs_set_options(DevGrid g, WorldDev w, 
             const int32_t delay = (o.set & CHD_SUBOPT_DELAY) ? o.fanout_delay_ms : g.default_delay_ms;
             w.pair_cell[pbase + pos] = c;
             w.pair_iv[pbase + pos] = (o.set & CHD_SUBOPT_INTERVAL) ? o.fanout_interval_ms : g.default_interval_ms;
-            if (w.deep_depth && w.pair_iv[pbase + pos] > w.max_iv[1]) { atomicMax(w.max_iv, w.pair_iv[pbase + pos]); atomicMax(w.max_iv + 1, w.pair_iv[pbase + pos]); }
+            if (w.deep_depth) {  // subscription.go:83-86 (a host call between ticks: in force at once, and kept by the next fold)
+                atomicMax(&w.cell_max_iv[c], w.pair_iv[pbase + pos]);
+                atomicMax(&w.cell_max_iv[g.ncell + c], w.pair_iv[pbase + pos]);
+            }
             w.pair_last[pbase + pos] = now_ns + (int64_t)delay * 1000000;
             w.pair_flags[pbase + pos] = (acc == 0 ? PF_NO_ACCESS : acc == 2 ? PF_WRITE : 0u) | (skip_self ? PF_SKIP_SELF : 0u) |
                                         (skip_first ? PF_HAD_FIRST : 0u) |
@@ -432,7 +436,7 @@ __device__ __forceinline__ void ingest_block(const DevGrid &g, const WorldDev &w
                 dst[j] = cell_of(g, x[u], z[u]);
                 src[j] = w.cell[i];
                 w.cell[i] = dst[j];
-                push_update(w, i, sender ? sender[u] : w.sender[i], cur_tick, arrival ? arrival[u] : now, now);
+                push_update(w, i, sender ? sender[u] : w.sender[i], cur_tick, src[j], dst[j], arrival ? arrival[u] : now, now);
                 if (src[j] != CHD_INVALID && dst[j] != CHD_INVALID && src[j] != dst[j]) {
                     // GetHandoverEntities (entity.go:197-224): a locked member of the notifier's handover group
                     // empties the list and the handover does not happen (spatial.go:675-679)
@@ -543,7 +547,7 @@ __global__ void __launch_bounds__(256) k_cell_updates(DevGrid g, WorldDev w, uin
     uint32_t h = 0, hp = 0, cur = 0, prev = 0;
     uint32_t dn = 0, dlen = 0;
     int64_t ddrop = INT64_MIN;
-    const uint32_t max_iv = w.deep_depth ? *w.max_iv : 0u;
+    const uint32_t max_iv = w.deep_depth ? w.cell_max_iv[c] : 0u;  // (the spatial channel's own maxFanOutIntervalMs)
     uint32_t oo[CHD_OFF_SLOTS] = {0, 0, 0, 0, 0, 0, 0, 0};  // (off_on) the channel's sub-tick offsets, aligned to this tick
     for (uint32_t u = 0; u < n; u++) {
         if (chan[u] - g.id_start != c) continue;

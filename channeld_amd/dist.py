@@ -236,7 +236,10 @@ class Comm:
 class HipShardEngine:
     def __init__(self, cfg: dict, rank: int, world: int, max_entities: int, max_subscribers: int,
                  migrate_cap: int = 4096, device: int = 0, max_records: int = 0, use_torch_stream: bool = True,
-                 adaptive_migrate: bool = False, flags: int = 0):
+                 adaptive_migrate: bool = False, flags: int = 0, history_depth: int = 0, shard_channels: int = 0):
+        """history_depth + shard_channels: exact update buffers on the sharded world — every rank keeps every channel's update log
+        by channel id (chd_world_cfg.shard_channels); then log_spawn (every rank: the whole world's entities) beside spawn (this
+        rank's), set_update_senders and set_update_arrivals."""
         import torch
 
         from . import _lib
@@ -251,11 +254,15 @@ class HipShardEngine:
         err = self.ctl.LoadConfig(json.dumps(cfg).encode(), strict=False)
         if err is not None:
             raise err
-        self.sw = SpatialWorld(self.ctl, max_entities, max_subscribers, max_records=max_records, flags=flags)
+        self.sw = SpatialWorld(self.ctl, max_entities, max_subscribers, max_records=max_records, flags=flags,
+                               history_depth=history_depth, shard_channels=shard_channels)
         self.lib, self.ctx = self.sw.lib, self.sw.ctx
         if use_torch_stream:
             _lib.check(self.ctx, self.lib.chd_set_stream(self.ctx, C.c_void_p(torch.cuda.current_stream(self.dev).cuda_stream), 1))
-        self.seg_words = (self.cap + 1) * ENTITY_STATE_WORDS
+        ex = C.c_uint32(0)
+        _lib.check(self.ctx, self.lib.chd_shard_migrate_extra_records(self.ctx, C.byref(ex)))
+        self.extra = int(ex.value)  # records behind every emigrant segment (the cells' maxFanOutIntervalMs: update log by channel)
+        self.seg_words = (self.cap + 1 + self.extra) * ENTITY_STATE_WORDS
         self.send = torch.zeros(world * self.seg_words, dtype=torch.int32, device=self.dev)
         # the halo layout of this rank (installs it in the library) and, for host-staged exchanges, where every other
         # rank keeps its segment for this one
@@ -348,6 +355,21 @@ class HipShardEngine:
     def add_subscribers(self, conn_ids):
         self.sw.add_subscribers(None, conn_ids)
 
+    def log_spawn(self, chan_id, x, z):
+        """chd_shard_log_spawn: EVERY rank, the whole world's new entity channels and where they appear (update log by channel)."""
+        from .controller import _f64, _ptr, _u32
+
+        ch, xa, za = _u32(chan_id), _f64(x), _f64(z)
+        self._lib.check(self.ctx, self.lib.chd_shard_log_spawn(self.ctx, len(ch), _ptr(ch), _ptr(xa), _ptr(za)))
+
+    def set_update_arrivals(self, arrival_by_chan):
+        """chd_shard_set_update_arrivals: an int64 DEVICE tensor (ns) indexed by channel id - EntityChannelIdStart, kept alive here and
+        rewritten in place by the host between ticks; None: every update is stamped with its tick's now_ns."""
+        self._arrivals = arrival_by_chan
+        self._lib.check(self.ctx, self.lib.chd_shard_set_update_arrivals(
+            self.ctx, C.c_void_p(arrival_by_chan.data_ptr()) if arrival_by_chan is not None else None,
+            int(arrival_by_chan.numel()) if arrival_by_chan is not None else 0))
+
     def set_update_senders(self, sender_by_chan):
         """chd_shard_set_update_senders: a uint32/int32 DEVICE tensor indexed by channel id - EntityChannelIdStart (kept alive here;
         the host rewrites it in place between ticks), or None."""
@@ -389,7 +411,7 @@ class HipShardEngine:
         if cu != self.cap_now:
             self.cap_now = cu
             self.cap_seen.append(cu)
-        return self.send[: self.world * (cu + 1) * ENTITY_STATE_WORDS].view(self.world, -1)
+        return self.send[: self.world * (cu + 1 + self.extra) * ENTITY_STATE_WORDS].view(self.world, -1)
 
     def ingest(self, now_ns: int, x_by_chan, z_by_chan, has_update=None):
         """x_by_chan / z_by_chan: float64 device tensors indexed by channel id - EntityChannelIdStart.  Returns the send
@@ -403,7 +425,7 @@ class HipShardEngine:
         if cu != self.cap_now:
             self.cap_now = cu
             self.cap_seen.append(cu)
-        return self.send[: self.world * (cu + 1) * ENTITY_STATE_WORDS].view(self.world, -1)
+        return self.send[: self.world * (cu + 1 + self.extra) * ENTITY_STATE_WORDS].view(self.world, -1)
 
     def import_(self, recv):
         rp = C.c_void_p(recv.data_ptr()) if recv is not None else None

@@ -226,7 +226,7 @@ class DeviceArray:
 class SpatialWorld:
     def __init__(self, ctl: StaticGrid2DSpatialController, max_entities: int, max_subscribers: int,
                  max_interest_cells: int = 0, max_records: int = 0, max_handovers: int = 0, flags: int = 0,
-                 wire_max_update_len: int = 0, wire_max_full_len: int = 0, history_depth: int = 0):
+                 wire_max_update_len: int = 0, wire_max_full_len: int = 0, history_depth: int = 0, shard_channels: int = 0):
         self.ctl = ctl
         self.lib = _lib.load()
         self.ctx = ctl.ctx
@@ -235,7 +235,7 @@ class SpatialWorld:
         ncell = ctl.GridCols * ctl.GridRows
         self.capq = int(max_interest_cells) if max_interest_cells else min(ncell, 256)
         cfg = WorldCfg(self.N, self.S, self.capq, int(max_records), int(max_handovers), int(flags),
-                       int(wire_max_update_len), int(wire_max_full_len), int(history_depth))
+                       int(wire_max_update_len), int(wire_max_full_len), int(history_depth), int(shard_channels))
         _lib.check(self.ctx, self.lib.chd_world_create(self.ctx, C.byref(cfg)))
 
     # ---- population ----

@@ -176,12 +176,24 @@ typedef struct {
      * exact for any arrival stamps (chd_tick_in.upd_arrival_ns), any number of updates of a channel per tick
      * (upd_round_off), any number of senders and windows as old as the buffer reaches — subscriptions the bit ring cannot
      * answer are served from these buffers by a separate (slower) launch; history_overflow then only counts what the
-     * reference's buffer would still hold and this one had to drop.  12 B x history_depth per entity and cell.  Not on
-     * region-sharded worlds (the buffers do not migrate).
-     * Deviation (beyond 512 buffered elements only): the eviction test uses ONE maxFanOutIntervalMs for the world — the largest
-     * FanOutIntervalMs any subscription ever had — where the reference keeps one per channel (subscription.go:84-85): a channel
-     * whose own subscribers all use short intervals keeps its oldest elements a little longer here than there. */
+     * reference's buffer would still hold and this one had to drop.  12 B x history_depth per entity and cell.
+     * Region-sharded worlds: with shard_channels (below).
+     * maxFanOutIntervalMs of the eviction test is kept per CHANNEL as in the reference (subscription.go:83-86: raised when a
+     * subscription is created, not when options are merged into an existing one): per spatial channel; and per entity channel,
+     * whose subscribers are — in the tick model — those of the cells that hold it: raised at every update of the entity to the
+     * maxima of the cells of its last merged and its new position, before the eviction test (OnUpdate merges first, and the
+     * merge's Notify subscribes the dst cell's connections to the entity channel, spatial.go:797-830). */
     uint32_t history_depth;
+    /* Region-sharded worlds that keep exact update buffers (history_depth > 0; else 0): the number of entity channels of the WHOLE
+     * world, ids entity_channel_id_start .. + shard_channels - 1.  In the reference a channel's update buffer lives in the one
+     * gateway process and never moves; a cross-server handover changes who owns the entity, not where its buffer is
+     * (spatial.go:683-700).  Here every rank is fed the same whole-world update stream by channel id (chd_shard_ingest:
+     * positions, chd_shard_set_update_arrivals / _senders), so every rank keeps every channel's UPDATE LOG — buffer, tick-ring
+     * masks, sub-tick offsets, maxFanOutIntervalMs — itself, indexed by channel id: a pure function of that stream and of the
+     * cells' maxFanOutIntervalMs, which travel with the emigrant exchange.  An entity that changes ranks, a ghost entry of a
+     * neighbour's border cell, a subscriber that regains access a hundred ticks after its entity left: all find the log where
+     * they are.  12 B x history_depth x shard_channels per rank (12 GiB at 1 M channels x 1024: HBM is 288 GB). */
+    uint32_t shard_channels;
 } chd_world_cfg;
 
 /* The fan-out emit kernel has two forms.  Connection-major: one workgroup per connection
@@ -629,6 +641,23 @@ int chd_shard_fanout(chd_ctx *ctx, const void *d_halo_recv, uint32_t world, cons
  * connection, spatial.go:683-700).  NULL / n_chan 0: back to every entity's own sender as given at spawn (it migrates with the
  * entity).  chd_tick_in.upd_sender on unsharded worlds. */
 int chd_shard_set_update_senders(chd_ctx *ctx, const uint32_t *d_sender_by_chan, uint32_t n_chan);
+
+/* Worlds with an update log by channel id (chd_world_cfg.shard_channels) only.
+ * chd_shard_log_spawn: EVERY rank is told about EVERY entity channel that comes to life and where (the whole-world list, the same on
+ * every rank, beside chd_shard_spawn's own-region list): the log notes the cell of the channel's first position (what the first
+ * update's Notify compares with, and what the channel's maxFanOutIntervalMs starts from) and takes updates for it from then on.
+ * chd_shard_set_update_arrivals: WHEN each update was enqueued (arrivalTime = ch.GetTime() in Channel.PutMessage,
+ * channel.go:296-310): a DEVICE array of int64 ns indexed like the positions (channel id - EntityChannelIdStart), read by the
+ * following ticks' ingest; resident, the host rewrites it between ticks.  NULL: every update is stamped with its tick's now_ns.
+ * chd_tick_in.upd_arrival_ns on unsharded worlds.  The senders must come by channel id as well (chd_shard_set_update_senders)
+ * — a rank does not hold the entity whose "own sender" it would otherwise fall back to.
+ * d_has_update of chd_shard_ingest / chd_shard_tick must only mark channels that exist somewhere (every rank logs them). */
+int chd_shard_log_spawn(chd_ctx *ctx, uint32_t n, const uint32_t *chan_id, const double *x, const double *z);
+int chd_shard_set_update_arrivals(chd_ctx *ctx, const int64_t *d_arrival_ns_by_chan, uint32_t n_chan);
+/* The emigrant segments of such a world carry, behind their (cap + 1) records, the sending rank's maxFanOutIntervalMs per
+ * spatial channel (4 B per cell): *extra = that many more 32-byte records per segment (0 on other worlds).  A caller that runs
+ * the exchange itself lays the segments out at a pitch of (cap_used + 1 + extra) records; chd_shard_tick does so by itself. */
+int chd_shard_migrate_extra_records(chd_ctx *ctx, uint32_t *extra);
 
 /* Handover lists on a region-sharded world: the meaning of chd_world_set_handover_lists, keyed by ENTITY CHANNEL ID — slots are
  * the library's here and an entity changes ranks.  List k = the channel ids list_member_chan[list_off[k] .. list_off[k+1]); the

@@ -78,7 +78,12 @@ typedef struct orc_world {
     uint32_t **hl_mem;
     wbuf *ebuf;     /* entity channel update buffers */
     wbuf *cbuf;     /* cell channel update buffers */
-    uint32_t max_interval_ms; /* maxFanOutIntervalMs (only grows) */
+    /* ChannelData.maxFanOutIntervalMs, one per CHANNEL, only grows (subscription.go:83-86: raised when a subscription is
+     * CREATED — the branch that merges options into an existing one does not touch it): cmax[c] for spatial channel c; emax[i]
+     * for entity channel i, whose subscribers are (tick model) those of the cells that hold it — raised at every update of the
+     * entity, before the eviction test (OnUpdate merges first: Notify -> the dst cell's connections are subscribed to the entity
+     * channel, spatial.go:797-830; then data.go:165-171), to the maxima of the cell of its last merged position and of the new one */
+    uint32_t *cmax, *emax;
     /* subscribers */
     uint8_t *sub_alive;
     uint32_t *conn_id;
@@ -172,6 +177,8 @@ orc_world *orc_world_new(const orc_grid *g, uint32_t n_entities, uint32_t n_subs
     w->hl_mem = (uint32_t **)calloc(n_entities + 1, sizeof(uint32_t *));
     w->ebuf = (wbuf *)calloc(n_entities + 1, sizeof(wbuf));
     w->cbuf = (wbuf *)calloc(w->C + 1, sizeof(wbuf));
+    w->cmax = (uint32_t *)calloc(w->C + 1, 4);
+    w->emax = (uint32_t *)calloc(n_entities + 1, 4);
     w->sub_alive = (uint8_t *)calloc(n_subs + 1, 1);
     w->conn_id = (uint32_t *)calloc(n_subs + 1, 4);
     w->pairs = (wpair *)calloc((size_t)n_subs * capq + 1, sizeof(wpair));
@@ -197,7 +204,7 @@ void orc_world_free(orc_world *w) {
     free(w->alive); free(w->chan_id); free(w->cell); free(w->member);
     for (uint32_t i = 0; i < w->N; i++) free(w->hl_mem[i]);
     free(w->hl_has); free(w->hl_n); free(w->hl_mem);
-    free(w->eflags); free(w->sender); free(w->group); free(w->ebuf); free(w->cbuf);
+    free(w->eflags); free(w->sender); free(w->group); free(w->ebuf); free(w->cbuf); free(w->cmax); free(w->emax);
     free(w->sub_alive); free(w->conn_id); free(w->pairs); free(w->pair_cnt);
     free(w->rec); free(w->ho_ent); free(w->ho_src); free(w->ho_dst);
     free(w->ho_srv_src); free(w->ho_srv_dst); free(w->unsub_sub);
@@ -237,6 +244,7 @@ void orc_world_spawn(orc_world *w, uint32_t i, uint32_t chan_id, double x,
     w->eflags[i] = flags;
     w->sender[i] = sender;
     w->ebuf[i].head = w->ebuf[i].len = 0;
+    w->emax[i] = 0; /* a new channel */
 }
 
 void orc_world_despawn(orc_world *w, uint32_t i) { w->alive[i] = 0; w->member[i] = W_INVALID; }
@@ -279,7 +287,7 @@ int orc_world_set_sub_options(orc_world *w, uint32_t s, uint32_t channel, uint32
         if (set & 2u) p->interval_ms = interval_ms;
         if (set & 8u) p->skip_self = (uint8_t)(skip_self != 0);
         /* FanOutDelayMs / SkipFirstFanOut only live in the stored options: the queue element is untouched */
-        if (w->max_interval_ms < p->interval_ms) w->max_interval_ms = p->interval_ms; /* (only grows; :83-86 is on the new branch) */
+        /* (maxFanOutIntervalMs is NOT raised here: subscription.go:83-86 sits on the new-subscription branch only) */
         return old_access != p->access;
     }
     if (n >= w->capq) return -5;
@@ -292,7 +300,7 @@ int orc_world_set_sub_options(orc_world *w, uint32_t s, uint32_t channel, uint32
     p->had_first = (set & 16u) ? (uint8_t)(skip_first != 0) : 0;          /* hadFirstFanOut: *cs.options.SkipFirstFanOut (:68) */
     p->last = now + (orc_time)((set & 4u) ? delay_ms : w->default_delay_ms) * 1000000; /* :70 */
     p->is_new = 0;
-    if (w->max_interval_ms < p->interval_ms) w->max_interval_ms = p->interval_ms; /* :83-86 */
+    if (w->cmax[c] < p->interval_ms) w->cmax[c] = p->interval_ms; /* :83-86 */
     w->pair_cnt[s] = n + 1;
     return 1;
 }
@@ -589,7 +597,9 @@ int orc_world_tick_arrivals(orc_world *w, orc_time t, uint32_t n_upd, const uint
             const wbuf *eb = &w->ebuf[i];
             const orc_time a = upd_arrival ? upd_arrival[u] : t;
             if (eb->len && eb->v[eb->head + eb->len - 1].arrival > a) w->unsorted = 1;
-            wbuf_push(&w->ebuf[i], a, w->sender[i], w->max_interval_ms);
+            if (src != W_INVALID && w->emax[i] < w->cmax[src]) w->emax[i] = w->cmax[src];
+            if (dst != W_INVALID && w->emax[i] < w->cmax[dst]) w->emax[i] = w->cmax[dst];
+            wbuf_push(&w->ebuf[i], a, w->sender[i], w->emax[i]);
         }
         if (src == W_INVALID || dst == W_INVALID || src == dst) continue; /* spatial.go:613-626 */
         /* GetHandoverEntities (entity.go:197-224): the notifier's handover group; a locked member empties it (:675-679) */
@@ -653,7 +663,7 @@ int orc_world_tick_arrivals(orc_world *w, orc_time t, uint32_t n_upd, const uint
         const wbuf *cb = &w->cbuf[cu_cell[u]];
         const orc_time a = cu_arrival ? cu_arrival[u] : t;
         if (cb->len && cb->v[cb->head + cb->len - 1].arrival > a) w->unsorted = 1;
-        wbuf_push(&w->cbuf[cu_cell[u]], a, cu_sender[u], w->max_interval_ms);
+        wbuf_push(&w->cbuf[cu_cell[u]], a, cu_sender[u], w->cmax[cu_cell[u]]);
     }
 
     /* ---- 1b. who receives each handover's ChannelDataHandoverMessage (spatial.go:776-857) ----
@@ -774,8 +784,8 @@ int orc_world_tick_arrivals(orc_world *w, orc_time t, uint32_t n_upd, const uint
                     np[k].skip_self = 1;   /* SkipSelfUpdateFanOut default true */
                     np[k].access = ORC_ACCESS_READ;
                     np[k].is_new = 1;
+                    if (w->cmax[c] < iv) w->cmax[c] = iv; /* :83-86 (a new subscription only) */
                 }
-                if (w->max_interval_ms < iv) w->max_interval_ms = iv;
             }
             memcpy(old, np, sizeof(wpair) * n);
             w->pair_cnt[s] = n;
@@ -968,6 +978,10 @@ void orc_world_unsubs(const orc_world *w, uint32_t *sub, uint32_t *cell) {
 }
 void orc_world_query_status(const orc_world *w, int32_t *out, uint32_t n) { memcpy(out, w->q_status, 4 * n); }
 uint32_t orc_world_locked_aborts(const orc_world *w) { return w->n_locked_abort; }
+/* update buffer of entity channel i: elements held; the channel's maxFanOutIntervalMs (entity i / spatial channel c) */
+uint32_t orc_world_entity_buffer_len(const orc_world *w, uint32_t i) { return i < w->N ? w->ebuf[i].len : 0; }
+uint32_t orc_world_entity_max_interval(const orc_world *w, uint32_t i) { return i < w->N ? w->emax[i] : 0; }
+uint32_t orc_world_cell_max_interval(const orc_world *w, uint32_t c) { return c < w->C ? w->cmax[c] : 0; }
 uint64_t orc_world_literal_mismatch(const orc_world *w) { return w->literal_mismatch; }
 void orc_world_entity_state(const orc_world *w, uint32_t *cell, uint32_t *member) {
     memcpy(cell, w->cell, 4 * w->N); memcpy(member, w->member, 4 * w->N);

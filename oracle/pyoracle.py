@@ -134,6 +134,9 @@ def lib():
     L.orc_world_pair_options.argtypes = [C.c_void_p, C.c_uint32, u8p, u8p]
     L.orc_world_set_damping.argtypes = [C.c_void_p, C.c_uint32, up, up]
     L.orc_world_set_server_conns.argtypes = [C.c_void_p, C.c_uint32, up]
+    for f in (L.orc_world_entity_buffer_len, L.orc_world_entity_max_interval, L.orc_world_cell_max_interval):
+        f.argtypes = [C.c_void_p, C.c_uint32]
+        f.restype = C.c_uint32
     L.orc_world_set_digest_only.argtypes = [C.c_void_p, C.c_int]
     L.orc_world_set_sorted_walk.argtypes = [C.c_void_p, C.c_int]
     L.orc_world_unsorted.argtypes = [C.c_void_p]
@@ -458,6 +461,16 @@ class World:
         acc, sk = np.zeros(self.capq, dtype=np.uint8), np.zeros(self.capq, dtype=np.uint8)
         n = lib().orc_world_pair_options(self.h, int(s), _p(acc, C.c_uint8), _p(sk, C.c_uint8))
         return acc[:n], sk[:n]
+
+    def entity_buffer_len(self, i):
+        return int(lib().orc_world_entity_buffer_len(self.h, int(i)))
+
+    def entity_max_interval(self, i):
+        """ChannelData.maxFanOutIntervalMs of entity channel i (subscription.go:83-86, tick model: chd_world_oracle.c)"""
+        return int(lib().orc_world_entity_max_interval(self.h, int(i)))
+
+    def cell_max_interval(self, c):
+        return int(lib().orc_world_cell_max_interval(self.h, int(c)))
 
     def set_server_connections(self, conn_ids):
         """ConnectionId of spatial server k (spatial.go:399-424: the owner of its cells' channels)."""

@@ -202,6 +202,47 @@ def test_the_reference_eviction_beyond_512_buffered_updates(amd):
                 ow.set_sub_options(now, 2, int(c), data_access=access)
 
 
+def test_max_fanout_interval_is_per_channel_beyond_512_elements(amd):
+    """subscription.go:83-86 / data.go:165-171: the eviction beyond 512 elements tests the CHANNEL's own maxFanOutIntervalMs.
+    tests/max_iv_scene.py: the channels of cell 0 (subscribers at 20 ms) take 120 updates per 10 ms tick while cell 3 has a
+    100 ms subscriber; a connection of cell 0 that regains access must find the catch-up windows beyond the 512 newest elements
+    EMPTY, as in the reference — under one world-wide maximum (round 4) it got a message for them.  Records every tick against
+    the oracle, history_overflow 0 (history_depth 1024 holds what the reference holds)."""
+    import max_iv_scene as sc
+
+    cfg = synth.load_config("spatial_static_2x2.json")
+    ctl = amd.StaticGrid2DSpatialController()
+    assert ctl.LoadConfig(json.dumps(cfg).encode(), strict=False) is None
+    gw = amd.SpatialWorld(ctl, sc.N, sc.S, flags=1, history_depth=1024)
+    ow = orc.World(orc.grid_from_config(cfg), sc.N, sc.S, gw.capq, 20, 0)
+    x, z = sc.positions(cfg)
+    chan = (0x80000 + np.arange(sc.N)).astype(np.uint32)
+    ow.spawn(np.arange(sc.N), chan, x, z, np.zeros(sc.N, dtype=np.uint32), np.full(sc.N, 900, dtype=np.uint32))
+    gw.spawn(None, chan, x, z, np.zeros(sc.N, dtype=np.uint32), np.full(sc.N, 900, dtype=np.uint32))
+    conns = np.array([50, 51, 52], dtype=np.uint32)
+    gw.add_subscribers(None, conns)
+    for s in range(sc.S):
+        ow.add_sub(s, int(conns[s]))
+    ss, st = gw.set_sub_options(0, sc.subscriptions())
+    assert (st == 0).all() and (ss == 1).all()
+    for o in sc.subscriptions():
+        assert ow.set_sub_options(0, o["slot"], o["channel"], fanout_interval_ms=o["fanout_interval_ms"]) == 1
+    regained = None
+    for k in range(sc.TICKS):
+        now, idx, ux, uz, arr, off = sc.tick_inputs(k, x, z)
+        ow.tick(now, idx, ux, uz, None, None, None, None, None, upd_arrival=arr)
+        res = gw.tick(now, upd_idx=idx, upd_x=ux, upd_z=uz, upd_arrival_ns=arr, upd_round_off=off, records_cap=1 << 20)
+        compare_tick(k, res, ow, sc.S, check_pairs=range(sc.S), gw=gw)
+        if k == sc.BLOCK_AT or k == sc.REGAIN_AT:
+            access = 0 if k == sc.BLOCK_AT else 1
+            gw.set_sub_options(now, [dict(slot=2, channel=0x10000, data_access=access)])
+            ow.set_sub_options(now, 2, 0x10000, data_access=access)
+        if k == sc.REGAIN_AT + 1:
+            regained = int(((res.records["conn"] & 0x7FFFFFFF) == 52).sum())
+    assert regained == 12 and ow.entity_buffer_len(0) == 512
+    ctl.close()
+
+
 def test_a_short_buffer_says_what_it_dropped(amd):
     """history_depth smaller than what a window reaches back to: never silently short — history_overflow counts it."""
     N, S = 12, 2

@@ -33,7 +33,11 @@ def canon(conn, chan):
 from shard_lists import make_lists, one_handover_per_group_and_tick  # noqa: E402  (shared with the CPU gloo test)
 
 
-def run_rank(rank, world, port, N, S, ticks, seed, out, cfg_name=None, halo=64, jump_frac=0.15, aoi_scale=1.0, lists=False, senders=False):
+def run_rank(rank, world, port, N, S, ticks, seed, out, cfg_name=None, halo=64, jump_frac=0.15, aoi_scale=1.0, lists=False, senders=False, exact=0):
+    """exact != 0 (= the world's emit flags): exact update buffers on the sharded world — history_depth 1024, the update log by
+    channel id on every rank (chd_world_cfg.shard_channels), per-update arrival stamps anywhere inside the tick's interval
+    (chd_shard_set_update_arrivals), and three connections that lose access at tick 8 and get it back twelve ticks before the end:
+    their catch-up walks the buffers of entities that have changed ranks many times since."""
     import torch
     import torch.distributed as dist
 
@@ -56,7 +60,10 @@ def run_rank(rank, world, port, N, S, ticks, seed, out, cfg_name=None, halo=64, 
         owner = np.where(ids0 == 0, 0, server_of_cell(cfg, np.where(ids0 == 0, 0, ids0 - 0x10000)))
         mine = np.nonzero(owner == rank)[0]
         my_subs = np.nonzero(owner[:S] == rank)[0]
-        eng = HipShardEngine(cfg, rank, world, N, max(len(my_subs), 1), migrate_cap=N, device=0, max_records=1 << 22)
+        eng = HipShardEngine(cfg, rank, world, N, max(len(my_subs), 1), migrate_cap=N, device=0, max_records=1 << 22,
+                             **(dict(flags=exact, history_depth=1024, shard_channels=N) if exact else {}))
+        if exact:
+            eng.log_spawn(sw.chan_id, x0, z0)  # (every rank: every channel of the world)
         eng.spawn(sw.chan_id[mine], x0[mine], z0[mine], sw.flags[mine], sw.sender[mine])
         eng.add_subscribers(sw.sub_conn[my_subs])
         sworld = ShardedWorld(eng, Comm(rank, world))
@@ -75,7 +82,15 @@ def run_rank(rank, world, port, N, S, ticks, seed, out, cfg_name=None, halo=64, 
             for s in range(S):
                 ow.add_sub(s, int(sw.sub_conn[s]))
         total = cross = 0
-        d_snd = None
+        d_snd = d_arr = None
+        blocked = [b for b in (1, 4, 7) if b < S] if exact else []
+        prev_now = 0
+        if exact:
+            d_arr = torch.zeros(N, dtype=torch.int64, device=dev)
+            eng.set_update_arrivals(d_arr)
+            if not senders:  # (an update log by channel takes its senders by channel id)
+                d_snd = torch.from_numpy(sw.sender.astype(np.uint32).view(np.int32)).to(dev)
+                eng.set_update_senders(d_snd)
         if senders:  # who sends an entity's updates changes over time: its spawn-time owner, then a CLIENT connection (which then skips its own)
             d_snd = torch.zeros(N, dtype=torch.int32, device=dev)
             eng.set_update_senders(d_snd)
@@ -84,6 +99,19 @@ def run_rank(rank, world, port, N, S, ticks, seed, out, cfg_name=None, halo=64, 
             if senders:
                 snd = np.where((np.arange(N) + k // 3) % 2 == 0, sw.sender, sw.sub_conn[np.arange(N) % S]).astype(np.uint32)
                 d_snd.copy_(torch.from_numpy(snd.view(np.int32)))
+            arr = None
+            if exact and blocked:  # the blocked connections stop moving their AOI (they keep the subscriptions they lost access to)
+                if k == 8:
+                    frozen = q[blocked].copy()
+                if k >= 8:
+                    q = q.copy()
+                    q[blocked] = frozen
+            if exact:  # stamps at ENQUEUE time (channel.go:296-310): anywhere in (previous tick, this tick]; every 4th tick on the grid
+                ra = np.random.default_rng((seed << 8) ^ k)
+                arr = np.where((ra.random(N) < 0.4) | (k % 4 == 3), now, ra.integers(prev_now + 1, now + 1, N)).astype(np.int64)
+                d_arr.copy_(torch.from_numpy(arr))
+                if snd is None:
+                    snd = sw.sender.astype(np.uint32)
             dq = torch.from_numpy(np.ascontiguousarray(q[my_subs]).view(np.uint8)).to(dev)
             sworld.tick(now, torch.from_numpy(x).to(dev), torch.from_numpy(z).to(dev), dq, len(my_subs))
             res = eng.fetch(want_records=True, records_cap=1 << 22)
@@ -97,9 +125,21 @@ def run_rank(rank, world, port, N, S, ticks, seed, out, cfg_name=None, halo=64, 
                 dist.all_gather_object(gathered, state)
             else:
                 gathered = [state]
+            if exact and (k == 8 or k == ticks - 12):  # the blocked connections: on the rank that holds them, and in the single world
+                access = 0 if k == 8 else 1
+                for b in blocked:
+                    loc = np.nonzero(my_subs == b)[0]
+                    if len(loc):
+                        chs = eng.sw.subscriptions(int(loc[0]))[0]
+                        eng.sw.set_sub_options(now, [dict(slot=int(loc[0]), channel=int(c), data_access=access) for c in chs])
+            prev_now = now
             if rank != 0:
                 continue
-            ow.tick(now, None, x, z, snd, None, None, None, q)
+            ow.tick(now, None, x, z, snd, None, None, None, q, **(dict(upd_arrival=arr) if exact else {}))
+            if exact and (k == 8 or k == ticks - 12):
+                for b in blocked:
+                    for c in ow.pairs(b)[0]:
+                        ow.set_sub_options(now, b, int(c), data_access=0 if k == 8 else 1)
             assert all(s["ovf"] == (0, 0) for s in gathered)
             oc, och = ow.records()
             if os.environ.get("CHD_SHARD_DEBUG"):
@@ -153,17 +193,17 @@ def run_rank(rank, world, port, N, S, ticks, seed, out, cfg_name=None, halo=64, 
             dist.destroy_process_group()
 
 
-def launch(world, N, S, ticks, seed, cfg_name=None, halo=64, jump_frac=0.15, aoi_scale=1.0, lists=False, senders=False):
+def launch(world, N, S, ticks, seed, cfg_name=None, halo=64, jump_frac=0.15, aoi_scale=1.0, lists=False, senders=False, exact=0, timeout=300):
     import torch.multiprocessing as mp
 
     ctx = mp.get_context("spawn")
     out = ctx.Queue()
     port = free_port()
-    procs = [ctx.Process(target=run_rank, args=(r, world, port, N, S, ticks, seed, out, cfg_name, halo, jump_frac, aoi_scale, lists, senders)) for r in range(world)]
+    procs = [ctx.Process(target=run_rank, args=(r, world, port, N, S, ticks, seed, out, cfg_name, halo, jump_frac, aoi_scale, lists, senders, exact)) for r in range(world)]
     for p in procs:
         p.start()
     for p in procs:
-        p.join(timeout=300)
+        p.join(timeout=timeout)
     status, total, cross = out.get(timeout=5)
     assert status == "ok", total
     assert all(p.exitcode == 0 for p in procs)
@@ -218,6 +258,20 @@ def test_update_senders_change_while_entities_migrate(world):
     — the two-sender history travels in the 32-byte emigrant state — against the single-world oracle fed the same senders."""
     total, cross = launch(world, 4000, 96, 12, 0xC0FFEE40 + world, senders=True)
     assert total > 0 and (cross > 0 or world == 1)
+
+
+@pytest.mark.parametrize("world,flags", [(1, 1 | 64), (2, 1 | 64), (2, 1), (4, 1 | 64)], ids=["1-rank-offsets", "2-ranks-offsets", "2-ranks-element-walk", "4-ranks-offsets"])
+def test_exact_update_buffers_and_enqueue_time_stamps_on_sharded_worlds(world, flags):
+    """the reference stamps every update when it is ENQUEUED (channel.go:296-310) and tickData compares those stamps
+    (data.go:225-269).  On a region-sharded world: history_depth 1024, the update log kept by channel id on every rank
+    (chd_world_cfg.shard_channels — nothing of it travels with an emigrant or a border band), per-update stamps anywhere inside the
+    tick's interval, 15 % of the entities teleporting across the regions every tick, and three connections that lose access at
+    tick 8 and regain it 110 ticks later: their catch-up walks ~110 ticks of buffered updates of entities that changed ranks many
+    times since.  Record for record the single-world oracle's (orc World.tick(upd_arrival=...)), history_overflow 0 on every rank.
+    flags 1 | 64: the descriptor path with sub-tick offsets (ghost columns filled from the log); flags 1: every off-grid stamp
+    makes its channel irregular and the element walk answers (ghost rings read through the log)."""
+    total, cross = launch(world, 700, 30, 130, 0xC0FFEE50 + world + flags, exact=flags, timeout=900)
+    assert total > 100_000 and (cross > 0 or world == 1)
 
 
 def test_narrow_halo_band_geometry_on_the_40x40_grid():

@@ -164,3 +164,37 @@ def test_sorted_newest_first_walk_equals_the_forward_walk_and_the_literal_list()
         w.tick(now, None, sw.x, sw.z, None, None, None, None, None, upd_arrival=arr)
     assert worlds[0].unsorted()
     assert np.array_equal(canon(*worlds[0].records()), canon(*worlds[1].records()))
+
+
+def test_max_fanout_interval_is_kept_per_channel():
+    """subscription.go:83-86 + data.go:165-171 in the tick model (chd_world_oracle.c: cmax / emax): the scene of
+    tests/max_iv_scene.py.  A channel whose own subscribers all use 20 ms evicts beyond 512 elements by 20 ms although another
+    cell has a 100 ms subscriber — its buffer stays at 512 elements — and a subscriber that regains access finds the older
+    catch-up windows empty."""
+    import max_iv_scene as sc
+    from channeld_amd import synth
+
+    cfg = synth.load_config("spatial_static_2x2.json")
+    ow = orc.World(orc.grid_from_config(cfg), sc.N, sc.S, 4, 20, 0)
+    x, z = sc.positions(cfg)
+    ow.spawn(np.arange(sc.N), 0x80000 + np.arange(sc.N), x, z, np.zeros(sc.N, dtype=np.uint32), np.full(sc.N, 900, dtype=np.uint32))
+    for s in range(sc.S):
+        ow.add_sub(s, 50 + s)
+    for o in sc.subscriptions():
+        assert ow.set_sub_options(0, o["slot"], o["channel"], fanout_interval_ms=o["fanout_interval_ms"]) == 1
+    assert ow.cell_max_interval(0) == 20 and ow.cell_max_interval(3) == 100
+    regained = None
+    for k in range(sc.TICKS):
+        now, idx, ux, uz, arr, off = sc.tick_inputs(k, x, z)
+        ow.tick(now, idx, ux, uz, None, None, None, None, None, upd_arrival=arr)
+        if k == sc.BLOCK_AT or k == sc.REGAIN_AT:
+            ow.set_sub_options(now, 2, 0x10000, data_access=0 if k == sc.BLOCK_AT else 1)
+        if k == sc.REGAIN_AT + 1:
+            conn, chan = ow.records()
+            regained = int(((conn & 0x7FFFFFFF) == 52).sum())
+    assert ow.entity_max_interval(0) == 20 and ow.entity_max_interval(5) == 100
+    assert ow.entity_buffer_len(0) == 512          # 20 ms rule: one out per push once beyond 512
+    assert ow.entity_buffer_len(5) == sc.TICKS      # one update per tick, never beyond 512
+    # connection 2 catches up 14 windows of 20 ms over four channels (+ the cell's own); only the windows the 512 newest elements
+    # (~43 ms) reach into carry a message: 3 per channel.  Under a world-wide maximum of 100 ms it would have been 5 or 6.
+    assert regained == 4 * 3, regained
