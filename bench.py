@@ -40,6 +40,16 @@ OVERLAP_INTEREST_DEFAULT = 1
 # throughput regions take the HIP event pair around the dominant kernel on every n-th tick (CHD_PROF_RECORD_KERNEL_EVERY): each event idles
 # the stream for ~7 us beside the kernel (profiles/r04t_tick_timeline_*.csv), 14 us of a 255 us tick if every launch were timed
 PROF_EVERY_DEFAULT = 7  # (odd: the workload alternates between ticks of ~100 M and ~60 M messages — 100 ms subscriptions fire every other 50 ms tick)
+
+
+def prof_every_for(steps: int, asked: int = 0) -> int:
+    """Which launches of the timed region carry a HIP event pair: every 7th at the default --steps 200, and at ANY step count
+    at least six of them (the driver runs --steps 20: every 3rd -> 6 or 7 launches, heavy and light ticks alike) — an odd stride,
+    so that the sample does not lock onto one parity of the alternating workload."""
+    if asked:
+        return max(1, int(asked))
+    e = max(1, min(PROF_EVERY_DEFAULT, int(steps) // 6))
+    return e if e % 2 else e - 1
 class GpuStateSampler:
     """Clocks / power / temperature of the GPU beside a timed region: a thread reads the amdgpu hwmon files every
     10 ms — freq1_input = sclk, power1_input = socket power, temp*_input — of the first card that exposes them.  Box-to-box spread
@@ -131,8 +141,9 @@ def parse():
                          "-3.4 %% per tick on the serial schedule, profiles/r04q_overlap_interest_ab.json)")
     ap.add_argument("--gated-overlap", type=int, default=1, choices=(0, 1),
                     help="with --overlap-interest: fork / join of the second stream as device-side flags instead of HIP events (CHD_WORLD_GATED_OVERLAP)")
-    ap.add_argument("--prof-every", type=int, default=PROF_EVERY_DEFAULT,
-                    help="timed region: HIP event pair around the dominant kernel on every N-th tick (1 = every launch, as rounds 1-3 did)")
+    ap.add_argument("--prof-every", type=int, default=0,
+                    help="timed region: HIP event pair around the dominant kernel on every N-th tick (1 = every launch, as rounds 1-3 did; "
+                         "default: prof_every_for(--steps) = 7 at 200 steps, never fewer than six timed launches)")
     ap.add_argument("--overlap-deferred", type=int, default=OVERLAP_DEFERRED_DEFAULT, choices=(0, 1),
                     help="serial schedule: the filtering launch + epilogue on a second stream beside the record kernel (CHD_WORLD_OVERLAP_DEFERRED)")
     ap.add_argument("--recipients", action="store_true",
@@ -167,6 +178,7 @@ def parse():
                     help="profiling runs (rocprofv3 --kernel-trace / --pmc): warm-up + the timed region and nothing else (= --no-cpu "
                          "--latency-steps 0 --e2e-ticks 0), so that per-kernel averages after skipping --warmup launches are the timed launches")
     args = ap.parse_args()
+    args.prof_every = prof_every_for(args.steps, args.prof_every)
     if args.only_timed:
         args.no_cpu, args.latency_steps, args.e2e_ticks = True, 0, 0
     if args.gpus <= 1 and not os.environ.get("CHD_BENCH_FORCE_DIST"):
@@ -252,12 +264,12 @@ class SingleWorldChecker:
         for s in range(n_subs):
             self.ow.add_sub(s, int(sw.sub_conn[s]))
 
-    def step(self, now_ns, x, z, queries):
+    def step(self, now_ns, x, z, queries, arrivals=None):
         ow = self.ow
         if os.environ.get("CHD_BENCH_VERIFY_SABOTAGE"):  # (tests: prove that a difference ends the run) one entity at a wrong position
             x = x.copy()
             x[0] = x[0] + 9000.0 if x[0] < 0 else x[0] - 9000.0
-        ow.tick(now_ns, None, x, z, None, None, None, None, queries)
+        ow.tick(now_ns, None, x, z, None, None, None, None, queries, **({} if arrivals is None else {"upd_arrival": arrivals}))
         (cnt, sm, xr, _), conn = ow.digest()
         return {"digest": (cnt, sm, xr), "conn": conn, "handovers": len(ow.handovers()[0]), "locked": int(ow.locked_aborts()),
                 "unsubs": len(ow.unsubs()[0])}

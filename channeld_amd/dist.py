@@ -624,8 +624,18 @@ def run_bench(args, rank: int, world: int, local_rank: int, verifier=None) -> di
     # (CHD_WORLD_OVERLAP_INTEREST | CHD_WORLD_GATED_OVERLAP); the four-stage path over torch.distributed ignores the flags
     native_on = comm.backend == "nccl" and os.environ.get("CHD_DIST_NATIVE", "1") != "0"
     gate_flags = (16 | 512) if (native_on and getattr(args, "overlap_interest", 1) and getattr(args, "gated_overlap", 1)) else 0
+    # --arrival-jitter: every update stamped when it was ENQUEUED (channel.go:296-310), the reference's tickData semantics on the
+    # sharded world: exact update buffers, kept by channel id on every rank (chd_world_cfg.shard_channels); CHD_WORLD_ONE_WAVE_EMIT
+    # keeps the descriptor path with sub-tick offsets below 4096 connections per rank
+    jitter = bool(getattr(args, "arrival_jitter", False))
+    tick_jitter_us = int(getattr(args, "tick_jitter_us", 0) or 0)
     eng = HipShardEngine(cfg, rank, world, n_max, s_max, migrate_cap=max(4096, n_max // 8), device=local_rank,
-                         max_records=int(getattr(args, "max_records", 0) or 0), adaptive_migrate=True, flags=gate_flags)
+                         max_records=int(getattr(args, "max_records", 0) or 0), adaptive_migrate=True,
+                         flags=gate_flags | (64 if jitter else 0), history_depth=1024 if jitter else 0, shard_channels=N if jitter else 0)
+    if jitter:
+        eng.log_spawn(sw.chan_id, sw.x, sw.z)  # (every rank: every channel of the world)
+        d_senders = torch.from_numpy(sw.sender.astype(np.uint32).view(np.int32)).to(dev)
+        eng.set_update_senders(d_senders)
     eng.spawn(sw.chan_id[mine], sw.x[mine], sw.z[mine], sw.flags[mine], sw.sender[mine])
     eng.add_subscribers(sw.sub_conn[my_subs])
     # RCCL runs inside the library (chd_shard_comm_init / chd_shard_tick) whenever the ranks have a GPU each; host-staged
@@ -669,9 +679,15 @@ def run_bench(args, rank: int, world: int, local_rank: int, verifier=None) -> di
     qs = np.empty((T, len(my_subs)), dtype=synth.AOI_DTYPE)
     now = np.empty(T, dtype=np.int64)
     q_full = []
+    aj = synth.ArrivalJitter(seed, N, tick_jitter_us) if (jitter or tick_jitter_us) else None
+    arr = np.empty((T, N), dtype=np.int64) if jitter else None
     for t in range(T):
         sw.step()
         xs[t], zs[t], now[t] = sw.x, sw.z, sw.now_ns()
+        if aj is not None:
+            now[t], a = aj.next(now[t])
+            if jitter:
+                arr[t] = a
         q = sw.queries()
         qs[t] = q[my_subs]
         if checking and t < V:
@@ -682,8 +698,11 @@ def run_bench(args, rank: int, world: int, local_rank: int, verifier=None) -> di
     xv, zv, qv = list(d_x.unbind(0)), list(d_z.unbind(0)), list(d_q.unbind(0))  # (per-tick views made once, not per tick)
     nq = len(my_subs)
     now_l = [int(v) for v in now]
+    av = list(torch.from_numpy(arr).to(dev).unbind(0)) if jitter else None
 
     def tick(t):
+        if av is not None:
+            eng.set_update_arrivals(av[t])  # (a pointer: the stamps of all T ticks are resident)
         world_obj.tick(now_l[t], xv[t], zv[t], qv[t], nq)
 
     # ---- the first V ticks, each checked against the single-world oracle ----
@@ -693,7 +712,7 @@ def run_bench(args, rank: int, world: int, local_rank: int, verifier=None) -> di
     for t in range(V):
         tick(t)
         verified_msgs.append(verify_tick(comm, eng, my_subs, s_max,
-                                         (lambda t=t: verifier.step(now_l[t], xs[t], zs[t], q_full[t])) if checking else None, t))
+                                         (lambda t=t: verifier.step(now_l[t], xs[t], zs[t], q_full[t], *((arr[t],) if jitter else ()))) if checking else None, t))
     t_verify = time.perf_counter() - t_verify
     del xs, zs, q_full
 
@@ -724,6 +743,10 @@ def run_bench(args, rank: int, world: int, local_rank: int, verifier=None) -> di
         raise SystemExit(f"rank {rank}: overflow 0x{res.overflow:x}, history overflow {res.history_overflow} in the timed region")
     msgs = comm.sum_int(msgs_local)
     handovers = comm.sum_int(sum(h["n_handovers"] for h in hist))
+    hist_ovf = comm.sum_int(sum(h["history_overflow"] for h in hist))
+    ovf_ticks = comm.sum_int(sum(1 for h in hist if h["overflow"]))
+    deep_msgs = comm.sum_int(sum(h["n_deep_records"] for h in hist))
+    filt_msgs = comm.sum_int(sum(h["n_filtered_records"] for h in hist))
     timed = [h for h in hist if h["emit_main_us"] > 0] or hist  # (the sampled launches)
     emit_us = np.array([h["emit_main_us"] for h in timed])
     emit_msgs = np.array([h["n_records"] - h["n_deferred_records"] for h in timed], dtype=np.float64)
@@ -764,7 +787,13 @@ def run_bench(args, rank: int, world: int, local_rank: int, verifier=None) -> di
                    "exchange": "all-to-all of emigrant states (32 B each; segment capacity adapted to 4x the largest count of two ticks ago: "
                                f"{eng.cap_now} records per peer now, {eng.cap} at start) + all-to-all(v) of the border bands of the cell tables "
                                f"({cfg['ServerInterestBorderSize']} cells wide: {sum(eng.send_splits)} bytes sent per rank and tick) per tick",
-                   "message": "one fanOutDataUpdate decision (conn, channel); payload bytes excluded"},
+                   "message": "one fanOutDataUpdate decision (conn, channel); payload bytes excluded",
+                   **({"arrival_stamps": "every update stamped when it was enqueued, uniform in (previous tick, this tick] (channel.go:296-310)"
+                                         + (f"; tick times off the grid by up to +-{tick_jitter_us} us" if tick_jitter_us else ""),
+                       "update_buffers": f"exact (history_depth 1024), kept by channel id on every rank (chd_world_cfg.shard_channels = {N}): "
+                                         "nothing of a channel's log travels with an emigrant or a border band",
+                       "filtered_msgs_per_tick": filt_msgs / K, "element_walk_msgs_per_tick": deep_msgs / K} if jitter else {})},
+        "history_overflow": hist_ovf, "ticks_with_overflow_flags": ovf_ticks,
         "p50_tick_ms": max(r[3] for r in per_rank), "p99_tick_ms": max(r[4] for r in per_rank), "latency_ticks": int(L),
         "stage_us_avg": {n: float(v) for n, v in zip(("ingest", "index", "interest", "plan", "emit"), stage_avg)},
         "per_rank": [{"rank": i, "roofline_frac": r[0], "emit_kernel_us": r[1], "msgs_per_launch": r[2], "p50_tick_ms": r[3],
