@@ -790,9 +790,12 @@ class SpatialWorld {
 class EntityGroupTable;
 class ShardWorld {
   public:
-    // flags: CHD_WORLD_OVERLAP_INTEREST | CHD_WORLD_GATED_OVERLAP lets the tick run its interest updates beside its front
+    // flags: CHD_WORLD_OVERLAP_INTEREST | CHD_WORLD_GATED_OVERLAP lets the tick run its interest updates beside its front.
+    // historyDepth + shardChannels (both or neither): ChannelData.updateMsgBuffer element for element (data.go:53-55,149-173) with the
+    // update log kept by channel id on EVERY rank — then LogSpawn (every rank, every channel of the world) beside Spawn (this rank's
+    // entities), SetUpdateSenders and SetUpdateArrivals (the stamps Channel.PutMessage took, channel.go:296-310).
     ShardWorld(StaticGrid2DSpatialController &ctl, uint32_t rank, uint32_t world, uint32_t maxEntities, uint32_t maxSubscribers,
-               uint64_t maxRecords = 0, uint32_t flags = 0)
+               uint64_t maxRecords = 0, uint32_t flags = 0, uint32_t historyDepth = 0, uint32_t shardChannels = 0)
         : ctl_(ctl), rank_(rank), world_(world) {
         chd_world_cfg c;
         std::memset(&c, 0, sizeof c);
@@ -800,6 +803,8 @@ class ShardWorld {
         c.max_subscribers = maxSubscribers;
         c.max_records = maxRecords;
         c.flags = flags;
+        c.history_depth = historyDepth;
+        c.shard_channels = shardChannels;
         check(chd_world_create(ctl.ctx(), &c));
     }
     // rank 0 draws the id, the gateways' own control connection carries its CHD_COMM_ID_BYTES bytes, every rank joins (collective)
@@ -818,6 +823,12 @@ class ShardWorld {
     void AddSubscribers(const std::vector<ConnectionId> &conn) { check(chd_subs_add(ctl_.ctx(), (uint32_t)conn.size(), nullptr, conn.data())); }
     // who sends each channel's updates (device array by channel id; nullptr: the spawn-time owner, which migrates with the entity)
     void SetUpdateSenders(const uint32_t *dSenderByChan, uint32_t nChan) { check(chd_shard_set_update_senders(ctl_.ctx(), dSenderByChan, nChan)); }
+    // worlds with an update log by channel id (shardChannels): every rank is told about every channel that comes to life, and when
+    // each update was enqueued (device array of int64 ns by channel id; nullptr: the tick's own time)
+    void LogSpawn(const std::vector<ChannelId> &entityChannelIds, const std::vector<double> &x, const std::vector<double> &z) {
+        check(chd_shard_log_spawn(ctl_.ctx(), (uint32_t)entityChannelIds.size(), entityChannelIds.data(), x.data(), z.data()));
+    }
+    void SetUpdateArrivals(const int64_t *dArrivalNsByChan, uint32_t nChan) { check(chd_shard_set_update_arrivals(ctl_.ctx(), dArrivalNsByChan, nChan)); }
     Error SetHandoverLists(const EntityGroupTable &groups, uint32_t nChan);
     // one tick (collective): positions by channel id on the device, this rank's queries in dIn (device pointers)
     Error Tick(int64_t nowNs, const double *dXByChan, const double *dZByChan, const uint8_t *dHasUpdate, uint32_t nChan, const chd_tick_in &dIn) {

@@ -319,6 +319,13 @@ def test_rccl_single_rank_bench_path():
     assert r.returncode == 0, r.stderr[-2000:]
     single = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
     assert sharded["config"]["msgs_per_tick"] == pytest.approx(single["config"]["msgs_per_tick"], rel=0, abs=0.5)
+    # chd_shard_tick with the reference's stamp semantics — arrival stamps at enqueue time, exact update buffers kept by
+    # channel id — through the library's own RCCL group (one rank), its first ticks verified against the single-world oracle
+    r = subprocess.run(cmd + ["--arrival-jitter", "--verify", "4", "--warmup", "4"], env=env, capture_output=True, text=True, timeout=280, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-2000:]
+    exact = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert exact["verified_ticks"] == 4 and exact["history_overflow"] == 0 and exact["ticks_with_overflow_flags"] == 0
+    assert exact["config"]["collectives_driver"].startswith("native: RCCL inside libchd_spatial.so") and "shard_channels" in exact["config"]["update_buffers"]
 
 
 def shared_gpu_bench(n, extra, timeout=420):
@@ -342,6 +349,17 @@ def test_bench_verify_two_ranks():
     assert d["verified_ticks"] == 3 and d["n_gpus"] == 2 and d["warmup"] == 3
     assert all(m > 0 for m in d["verified"]["msgs_per_verified_tick"][1:])
     assert d["config"]["config"] == "B-weak" and d["scaling"] == "weak"
+
+
+def test_bench_arrival_jitter_two_ranks_verified():
+    """bench.py --gpus N --arrival-jitter --verify K — the sharded bench with the reference's stamp semantics (every
+    update stamped when it was enqueued, exact update buffers kept by channel id on every rank), its first ticks compared with the
+    single-world oracle fed the same stamps; no history_overflow, no overflow flag in the timed ticks."""
+    r, d = shared_gpu_bench(2, ["--arrival-jitter", "--steps", "4", "--warmup", "5", "--verify", "5", "--entities", "6000", "--subs", "400"])
+    assert r.returncode == 0, r.stderr[-3000:]
+    assert d["verified_ticks"] == 5 and d["n_gpus"] == 2 and all(m > 0 for m in d["verified"]["msgs_per_verified_tick"][1:])
+    assert d["history_overflow"] == 0 and d["ticks_with_overflow_flags"] == 0
+    assert "enqueued" in d["config"]["arrival_stamps"] and d["config"]["filtered_msgs_per_tick"] > 0
 
 
 def test_bench_verify_fails_loudly_on_a_wrong_world():
