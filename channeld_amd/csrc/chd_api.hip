@@ -3,8 +3,16 @@
 // error reporting.  Every computation is a HIP kernel; there is no CPU path.
 #include <hip/hip_runtime.h>
 
+#include <fcntl.h>
+#include <sys/mman.h>
+#include <unistd.h>
+
 #include <algorithm>
+#include <atomic>
+#include <chrono>
 #include <cmath>
+#include <random>
+#include <thread>
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
@@ -120,6 +128,7 @@ struct World {
     chd_fanout_rec *seg_rec_stage = nullptr; size_t seg_rec_stage_cap = 0;
     // native collectives (chd_shard_comm_init): the two exchanges of a sharded tick on RCCL inside the library
     ncclComm_t comm = nullptr;
+    struct HostPipe *pipe = nullptr;   // CHD_SHARD_TRANSPORT=hostpipe (a TEST transport, see HostPipe): then comm == nullptr
     uint32_t comm_rank = 0, comm_world = 0, comm_cap = 0;
     uint32_t comm_alloc_cap = 0, comm_alloc_world = 0;  // what mig_send / mig_recv / the halo buffers were sized for
     chd_entity_state *mig_send = nullptr, *mig_recv = nullptr;   // [world][cap + 1]
@@ -2632,6 +2641,126 @@ int rccl_load(chd_ctx *ctx) {
     } while (0)
 }  // namespace
 
+// ---- CHD_SHARD_TRANSPORT=hostpipe: a TEST transport for chd_shard_tick ----
+// RCCL refuses two ranks on one device, so on a one-GPU box the library's own collectives — the segment sizes every rank must
+// derive alike, the request exchange in front of the export, the order of the stages, the gated join — would only ever run with ONE
+// rank.  This transport carries the same ncclSend / ncclRecv groups between PROCESSES through a POSIX shared-memory segment: one
+// mailbox per ordered pair of ranks, a message staged device -> mailbox -> device by blocking copies at group end.  Same entry points,
+// same call sequence, same buffers as the RCCL path; none of its asynchrony (the host blocks in every group) and none of its
+// speed: for tests (tests/test_gpu_shard.py) and for nothing else.  Chosen by rank 0's environment when it draws the unique id
+// (the id names the segment), so every rank of a world takes the same transport.
+namespace {
+struct HostPipe {
+    struct Box { std::atomic<uint64_t> written, read; unsigned char _pad[112]; };  // one 128-byte header per ordered pair
+    struct Op { bool send; void *dev; size_t bytes; uint32_t peer; hipStream_t st; };
+    int fd = -1;
+    unsigned char *base = nullptr;
+    size_t total = 0, box_bytes = 0;
+    uint32_t rank = 0, world = 0;
+    std::string name;
+    std::vector<Op> ops;
+    std::vector<uint64_t> sent, rcvd;  // messages so far, per peer
+    Box *hdr(uint32_t from, uint32_t to) { return (Box *)(base + 128 * ((size_t)from * world + to)); }
+    unsigned char *payload(uint32_t from, uint32_t to) { return base + 128 * (size_t)world * world + box_bytes * ((size_t)from * world + to); }
+};
+constexpr char PIPE_MAGIC[8] = {'C', 'H', 'D', 'P', 'I', 'P', 'E', '1'};
+
+int pipe_open(chd_ctx *ctx, const unsigned char *id, uint32_t rank, uint32_t world, size_t box_bytes) {
+    World &W = ctx->w;
+    auto *p = new HostPipe();
+    p->rank = rank; p->world = world;
+    p->box_bytes = (box_bytes + 127) & ~(size_t)127;
+    p->total = 128 * (size_t)world * world + p->box_bytes * (size_t)world * world + 128;
+    char nm[64];
+    snprintf(nm, sizeof nm, "/chd_pipe_%02x%02x%02x%02x%02x%02x%02x%02x", id[8], id[9], id[10], id[11], id[12], id[13], id[14], id[15]);
+    p->name = nm;
+    p->fd = shm_open(nm, O_CREAT | O_RDWR, 0600);
+    if (p->fd < 0 || ftruncate(p->fd, (off_t)p->total) != 0) { delete p; return fail(ctx, CHD_E_STATE, "hostpipe: shm_open(%s) failed", nm); }
+    p->base = (unsigned char *)mmap(nullptr, p->total, PROT_READ | PROT_WRITE, MAP_SHARED, p->fd, 0);
+    if (p->base == MAP_FAILED) { close(p->fd); delete p; return fail(ctx, CHD_E_STATE, "hostpipe: mmap failed"); }
+    p->sent.assign(world, 0); p->rcvd.assign(world, 0);
+    // the last rank to attach unlinks the name: nothing is left behind whatever happens later
+    auto *attached = (std::atomic<uint32_t> *)(p->base + p->total - 128);
+    if (attached->fetch_add(1) + 1 == world) shm_unlink(nm);
+    W.pipe = p;
+    return CHD_OK;
+}
+
+void pipe_close(World &W) {
+    if (!W.pipe) return;
+    if (W.pipe->base) munmap(W.pipe->base, W.pipe->total);
+    if (W.pipe->fd >= 0) close(W.pipe->fd);
+    delete W.pipe;
+    W.pipe = nullptr;
+}
+
+// blocks until `cond` holds; a peer that never comes is an error after CHD_HOSTPIPE_TIMEOUT_S (default 60) seconds, not a hang
+bool pipe_wait(const std::atomic<uint64_t> &a, uint64_t want) {
+    auto cond = [&] { return a.load(std::memory_order_acquire) == want; };
+    static const double limit = [] { const char *e = getenv("CHD_HOSTPIPE_TIMEOUT_S"); return e ? atof(e) : 60.0; }();
+    const auto t0 = std::chrono::steady_clock::now();
+    for (uint32_t k = 0; !cond(); k++) {
+        if ((k & 1023u) == 1023u) {
+            if (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > limit) return false;
+            std::this_thread::yield();
+        }
+    }
+    return true;
+}
+
+int pipe_group_end(chd_ctx *ctx) {
+    HostPipe &p = *ctx->w.pipe;
+    std::vector<HostPipe::Op> ops;
+    ops.swap(p.ops);
+    for (auto &o : ops) HIPCHK(hipStreamSynchronize(o.st));  // (what is sent has been written; what is received into is no longer read)
+    for (auto &o : ops) {
+        if (!o.send) continue;
+        if (o.bytes > p.box_bytes) return fail(ctx, CHD_E_CAPACITY, "hostpipe: a message of %zu bytes, mailboxes hold %zu", o.bytes, p.box_bytes);
+        auto *h = p.hdr(p.rank, o.peer);
+        const uint64_t n = p.sent[o.peer];
+        if (!pipe_wait(h->read, n)) return fail(ctx, CHD_E_STATE, "hostpipe: rank %u never took message %llu of rank %u", o.peer, (unsigned long long)n, p.rank);
+        HIPCHK(hipMemcpy(p.payload(p.rank, o.peer), o.dev, o.bytes, hipMemcpyDeviceToHost));
+        ((uint64_t *)(p.payload(p.rank, o.peer) + p.box_bytes))[-1] = o.bytes;  // (the last 8 bytes of the box: the size, checked by the receiver)
+        h->written.store(n + 1, std::memory_order_release);
+        p.sent[o.peer] = n + 1;
+    }
+    for (auto &o : ops) {
+        if (o.send) continue;
+        auto *h = p.hdr(o.peer, p.rank);
+        const uint64_t n = p.rcvd[o.peer];
+        if (!pipe_wait(h->written, n + 1)) return fail(ctx, CHD_E_STATE, "hostpipe: message %llu of rank %u never came (rank %u waits)", (unsigned long long)n, o.peer, p.rank);
+        const uint64_t got = ((const uint64_t *)(p.payload(o.peer, p.rank) + p.box_bytes))[-1];
+        if (got != o.bytes) return fail(ctx, CHD_E_STATE, "hostpipe: rank %u sent %llu bytes, rank %u expects %zu: the ranks disagree about a segment size", o.peer, (unsigned long long)got, p.rank, o.bytes);
+        HIPCHK(hipMemcpy(o.dev, p.payload(o.peer, p.rank), o.bytes, hipMemcpyHostToDevice));
+        h->read.store(n + 1, std::memory_order_release);
+        p.rcvd[o.peer] = n + 1;
+    }
+    return CHD_OK;
+}
+
+// the transport of chd_shard_tick: RCCL, or the test transport
+int xp_group_start(chd_ctx *ctx) {
+    if (ctx->w.pipe) { ctx->w.pipe->ops.clear(); return CHD_OK; }
+    NCCLCHK(g_rccl.GroupStart());
+    return CHD_OK;
+}
+int xp_send(chd_ctx *ctx, const void *buf, size_t bytes, uint32_t peer, hipStream_t st) {
+    if (ctx->w.pipe) { ctx->w.pipe->ops.push_back({true, const_cast<void *>(buf), bytes, peer, st}); return CHD_OK; }
+    NCCLCHK(g_rccl.Send(buf, bytes, ncclUint8, (int)peer, ctx->w.comm, st));
+    return CHD_OK;
+}
+int xp_recv(chd_ctx *ctx, void *buf, size_t bytes, uint32_t peer, hipStream_t st) {
+    if (ctx->w.pipe) { ctx->w.pipe->ops.push_back({false, buf, bytes, peer, st}); return CHD_OK; }
+    NCCLCHK(g_rccl.Recv(buf, bytes, ncclUint8, (int)peer, ctx->w.comm, st));
+    return CHD_OK;
+}
+int xp_group_end(chd_ctx *ctx) {
+    if (ctx->w.pipe) return pipe_group_end(ctx);
+    NCCLCHK(g_rccl.GroupEnd());
+    return CHD_OK;
+}
+}  // namespace
+
 // the communicator, its stream and events go (the exchange buffers are the world's and stay); every handle is nulled
 static int comm_teardown(chd_ctx *ctx) {
     World &W = ctx->w;
@@ -2641,6 +2770,7 @@ static int comm_teardown(chd_ctx *ctx) {
         if (r != ncclSuccess) rc = fail(ctx, CHD_E_HIP, "ncclCommDestroy failed: %s", g_rccl.GetErrorString(r));
         W.comm = nullptr;
     }
+    pipe_close(W);
     if (W.comm_stream) { (void)hipStreamDestroy(W.comm_stream); W.comm_stream = nullptr; }
     if (W.ev_halo_ready) { (void)hipEventDestroy(W.ev_halo_ready); W.ev_halo_ready = nullptr; }
     if (W.ev_halo_done) { (void)hipEventDestroy(W.ev_halo_done); W.ev_halo_done = nullptr; }
@@ -2651,12 +2781,21 @@ static int comm_teardown(chd_ctx *ctx) {
 
 int chd_shard_comm_available(void) {
     chd_ctx *ctx = nullptr;
+    if (const char *e = getenv("CHD_SHARD_TRANSPORT")) if (!strcmp(e, "hostpipe")) return CHD_OK;  // (the test transport needs no RCCL)
     return rccl_load(ctx);
 }
 
 int chd_shard_comm_unique_id(void *id_out) {
     if (!id_out) return fail(nullptr, CHD_E_INVAL, "chd_shard_comm_unique_id: NULL output");
     chd_ctx *ctx = nullptr;
+    if (const char *e = getenv("CHD_SHARD_TRANSPORT")) if (!strcmp(e, "hostpipe")) {  // (the TEST transport: the id names its shared-memory segment)
+        memset(id_out, 0, CHD_COMM_ID_BYTES);
+        memcpy(id_out, PIPE_MAGIC, 8);
+        std::random_device rd;
+        const uint64_t r = ((uint64_t)rd() << 32) ^ rd() ^ ((uint64_t)getpid() << 17);
+        memcpy((char *)id_out + 8, &r, 8);
+        return CHD_OK;
+    }
     TRY(rccl_load(ctx));
     static_assert(sizeof(ncclUniqueId) == CHD_COMM_ID_BYTES, "CHD_COMM_ID_BYTES is RCCL's NCCL_UNIQUE_ID_BYTES");
     ncclUniqueId id;
@@ -2671,11 +2810,12 @@ int chd_shard_comm_init(chd_ctx *ctx, const void *unique_id, uint32_t rank, uint
     if (!world || rank >= world || !migrate_cap) return fail(ctx, CHD_E_INVAL, "chd_shard_comm_init: rank %u of %u, capacity %u", rank, world, migrate_cap);
     if (world != ctx->g.server_cols * ctx->g.server_rows)
         return fail(ctx, CHD_E_INVAL, "chd_shard_comm_init: %u ranks but the grid has %u server regions", world, ctx->g.server_cols * ctx->g.server_rows);
-    TRY(rccl_load(ctx));
+    const bool hostpipe = !memcmp(unique_id, PIPE_MAGIC, 8);  // (CHD_SHARD_TRANSPORT=hostpipe where the id was drawn: the TEST transport)
+    if (!hostpipe) TRY(rccl_load(ctx));
     std::lock_guard<FairMutex> lk(ctx->mu);
     TRY(bind(ctx));
     World &W = ctx->w;
-    if (W.comm) return fail(ctx, CHD_E_STATE, "chd_shard_comm_init: the ctx already has a communicator");
+    if (W.comm || W.pipe) return fail(ctx, CHD_E_STATE, "chd_shard_comm_init: the ctx already has a communicator");
     if (W.slot_mode == 1) return fail(ctx, CHD_E_STATE, "chd_shard_comm_init on a world with caller-chosen slots (chd_world_spawn)");
     // this rank's halo layout (installs it) and the exchange buffers: the library owns them
     W.halo_segs.assign(world, chd_halo_seg{0, 0, 0, 0});
@@ -2684,11 +2824,24 @@ int chd_shard_comm_init(chd_ctx *ctx, const void *unique_id, uint32_t rank, uint
     // the communicator FIRST (a collective: every rank is inside it, or none gets out); only a rank that has one allocates the
     // exchange buffers, the second stream and the events — a failed init leaves nothing behind and may be retried
     HIPCHK(hipStreamSynchronize(ctx->stream));
-    ncclUniqueId id;
-    memcpy(&id, unique_id, sizeof id);
-    ncclComm_t comm = nullptr;
-    NCCLCHK(g_rccl.CommInitRank(&comm, (int)world, id, (int)rank));
-    W.comm = comm;
+    if (hostpipe) {
+        // one mailbox per ordered pair of ranks, as large as the largest message of the protocol: an emigrant segment, a request
+        // segment, any pair's halo segment (a pure function of the grid and max_entities: every rank computes the same)
+        const DevGrid &g = ctx->g;
+        size_t box = std::max(((size_t)migrate_cap + 1 + migrate_extra(ctx)) * sizeof(chd_entity_state), ((size_t)CHD_SHARD_REQ_CAP + 1) * sizeof(chd_handover_request));
+        for (uint32_t a = 0; a < world; a++)
+            for (uint32_t b = 0; b < world; b++) {
+                const HaloRect r = halo_rect(g.cols, g.rows, g.server_cols, g.sgc, g.sgr, g.border, a, b);
+                box = std::max<size_t>(box, halo_seg_bytes(halo_cap_entries(W.d.N, r.w * r.h, g.sgc * g.sgr), r.w * r.h));
+            }
+        TRY(pipe_open(ctx, (const unsigned char *)unique_id, rank, world, box + 8));
+    } else {
+        ncclUniqueId id;
+        memcpy(&id, unique_id, sizeof id);
+        ncclComm_t comm = nullptr;
+        NCCLCHK(g_rccl.CommInitRank(&comm, (int)world, id, (int)rank));
+        W.comm = comm;
+    }
     W.comm_rank = rank;
     W.comm_world = world;
     W.comm_cap = migrate_cap;
@@ -2720,7 +2873,7 @@ int chd_shard_comm_destroy(chd_ctx *ctx) {
     if (!ctx) return fail(nullptr, CHD_E_INVAL, "NULL ctx");
     std::lock_guard<FairMutex> lk(ctx->mu);
     World &W = ctx->w;
-    if (!W.comm) return CHD_OK;
+    if (!W.comm && !W.pipe) return CHD_OK;
     TRY(bind(ctx));
     HIPCHK(hipStreamSynchronize(ctx->stream));
     if (W.comm_stream) HIPCHK(hipStreamSynchronize(W.comm_stream));
@@ -2741,7 +2894,7 @@ int chd_shard_tick(chd_ctx *ctx, int64_t now_ns, const double *d_x_by_chan, cons
     if (n_chan && (!d_x_by_chan || !d_z_by_chan)) return fail(ctx, CHD_E_INVAL, "chd_shard_tick: NULL positions");
     std::lock_guard<FairMutex> lk(ctx->mu);
     World &W = ctx->w;
-    if (!W.comm) return fail(ctx, CHD_E_STATE, "chd_shard_tick before chd_shard_comm_init");
+    if (!W.comm && !W.pipe) return fail(ctx, CHD_E_STATE, "chd_shard_tick before chd_shard_comm_init");
     TRY(check_queries(ctx, d_in));  // (before anything is enqueued: a refused tick leaves the world — and the gate counters — untouched)
     const uint32_t world = W.comm_world, rank = W.comm_rank;
     hipStream_t st = ctx->stream;
@@ -2761,12 +2914,12 @@ int chd_shard_tick(chd_ctx *ctx, int64_t now_ns, const double *d_x_by_chan, cons
             TRY(walloc(ctx, &W.req_recv, (size_t)world * (rc + 1)));
         }
         TRY(shard_ingest_pre_locked(ctx, now_ns, d_x_by_chan, d_z_by_chan, d_has_update, n_chan, rank, world, W.req_send, rc));
-        NCCLCHK(g_rccl.GroupStart());
+        TRY(xp_group_start(ctx));
         for (uint32_t p = 0; p < world; p++) {
-            NCCLCHK(g_rccl.Send(W.req_send + p * (rc + 1), (rc + 1) * sizeof(chd_handover_request), ncclUint8, (int)p, W.comm, st));
-            NCCLCHK(g_rccl.Recv(W.req_recv + p * (rc + 1), (rc + 1) * sizeof(chd_handover_request), ncclUint8, (int)p, W.comm, st));
+            TRY(xp_send(ctx, W.req_send + p * (rc + 1), (rc + 1) * sizeof(chd_handover_request), p, st));
+            TRY(xp_recv(ctx, W.req_recv + p * (rc + 1), (rc + 1) * sizeof(chd_handover_request), p, st));
         }
-        NCCLCHK(g_rccl.GroupEnd());
+        TRY(xp_group_end(ctx));
         TRY(shard_ingest_post_locked(ctx, W.req_recv, rc, rank, world, W.mig_send, W.comm_cap, &use));
     } else {
         TRY(shard_ingest_pre_locked(ctx, now_ns, d_x_by_chan, d_z_by_chan, d_has_update, n_chan, rank, world, nullptr, 0));
@@ -2786,34 +2939,34 @@ int chd_shard_tick(chd_ctx *ctx, int64_t now_ns, const double *d_x_by_chan, cons
     const size_t seg = (size_t)use + 1 + migrate_extra(ctx);
     {   // the cross-server handovers (spatial.go:683-700): every rank's segment for every other rank, 32 B per emigrant.
         // (One rank: its own segment to itself — nothing to move, but the tick keeps its shape and the transport is exercised.)
-        NCCLCHK(g_rccl.GroupStart());
+        TRY(xp_group_start(ctx));
         for (uint32_t p = 0; p < world; p++) {
-            NCCLCHK(g_rccl.Send(W.mig_send + p * seg, seg * sizeof(chd_entity_state), ncclUint8, (int)p, W.comm, st));
-            NCCLCHK(g_rccl.Recv(W.mig_recv + p * seg, seg * sizeof(chd_entity_state), ncclUint8, (int)p, W.comm, st));
+            TRY(xp_send(ctx, W.mig_send + p * seg, seg * sizeof(chd_entity_state), p, st));
+            TRY(xp_recv(ctx, W.mig_recv + p * seg, seg * sizeof(chd_entity_state), p, st));
         }
-        NCCLCHK(g_rccl.GroupEnd());
+        TRY(xp_group_end(ctx));
     }
     TRY(shard_import_locked(ctx, W.mig_recv, world, use, W.halo_send_buf));
     bool halo = false;
     for (uint32_t p = 0; p < world; p++) halo = halo || W.halo_segs[p].send_bytes || W.halo_segs[p].recv_bytes;
     if (halo && g_on) {  // (nothing to overlap it with on this stream any more: in stream order, no events)
-        NCCLCHK(g_rccl.GroupStart());
+        TRY(xp_group_start(ctx));
         for (uint32_t p = 0; p < world; p++) {
             const chd_halo_seg &h = W.halo_segs[p];
-            if (h.send_bytes) NCCLCHK(g_rccl.Send(W.halo_send_buf + h.send_off, h.send_bytes, ncclUint8, (int)p, W.comm, st));
-            if (h.recv_bytes) NCCLCHK(g_rccl.Recv(W.halo_recv_buf + h.recv_off, h.recv_bytes, ncclUint8, (int)p, W.comm, st));
+            if (h.send_bytes) TRY(xp_send(ctx, W.halo_send_buf + h.send_off, h.send_bytes, p, st));
+            if (h.recv_bytes) TRY(xp_recv(ctx, W.halo_recv_buf + h.recv_off, h.recv_bytes, p, st));
         }
-        NCCLCHK(g_rccl.GroupEnd());
+        TRY(xp_group_end(ctx));
     } else if (halo) {
         HIPCHK(hipEventRecord(W.ev_halo_ready, st));
         HIPCHK(hipStreamWaitEvent(W.comm_stream, W.ev_halo_ready, 0));
-        NCCLCHK(g_rccl.GroupStart());
+        TRY(xp_group_start(ctx));
         for (uint32_t p = 0; p < world; p++) {
             const chd_halo_seg &h = W.halo_segs[p];
-            if (h.send_bytes) NCCLCHK(g_rccl.Send(W.halo_send_buf + h.send_off, h.send_bytes, ncclUint8, (int)p, W.comm, W.comm_stream));
-            if (h.recv_bytes) NCCLCHK(g_rccl.Recv(W.halo_recv_buf + h.recv_off, h.recv_bytes, ncclUint8, (int)p, W.comm, W.comm_stream));
+            if (h.send_bytes) TRY(xp_send(ctx, W.halo_send_buf + h.send_off, h.send_bytes, p, W.comm_stream));
+            if (h.recv_bytes) TRY(xp_recv(ctx, W.halo_recv_buf + h.recv_off, h.recv_bytes, p, W.comm_stream));
         }
-        NCCLCHK(g_rccl.GroupEnd());
+        TRY(xp_group_end(ctx));
         HIPCHK(hipEventRecord(W.ev_halo_done, W.comm_stream));
     }
     if (g_on) {

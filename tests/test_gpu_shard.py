@@ -33,11 +33,15 @@ def canon(conn, chan):
 from shard_lists import make_lists, one_handover_per_group_and_tick  # noqa: E402  (shared with the CPU gloo test)
 
 
-def run_rank(rank, world, port, N, S, ticks, seed, out, cfg_name=None, halo=64, jump_frac=0.15, aoi_scale=1.0, lists=False, senders=False, exact=0):
+def run_rank(rank, world, port, N, S, ticks, seed, out, cfg_name=None, halo=64, jump_frac=0.15, aoi_scale=1.0, lists=False, senders=False, exact=0,
+             pipe=False, wflags=0):
     """exact != 0 (= the world's emit flags): exact update buffers on the sharded world — history_depth 1024, the update log by
     channel id on every rank (chd_world_cfg.shard_channels), per-update arrival stamps anywhere inside the tick's interval
     (chd_shard_set_update_arrivals), and three connections that lose access at tick 8 and get it back twelve ticks before the end:
-    their catch-up walks the buffers of entities that have changed ranks many times since."""
+    their catch-up walks the buffers of entities that have changed ranks many times since.
+    pipe: the tick is ONE C call, chd_shard_tick, with the exchanges inside the library — over its TEST transport
+    (CHD_SHARD_TRANSPORT=hostpipe: shared-memory mailboxes between the rank processes; RCCL refuses two ranks on one device), the
+    unique id carried by gloo as a gateway's control connection would; wflags: world flags (16 | 512 = the gated overlap)."""
     import torch
     import torch.distributed as dist
 
@@ -61,12 +65,17 @@ def run_rank(rank, world, port, N, S, ticks, seed, out, cfg_name=None, halo=64, 
         mine = np.nonzero(owner == rank)[0]
         my_subs = np.nonzero(owner[:S] == rank)[0]
         eng = HipShardEngine(cfg, rank, world, N, max(len(my_subs), 1), migrate_cap=N, device=0, max_records=1 << 22,
-                             **(dict(flags=exact, history_depth=1024, shard_channels=N) if exact else {}))
+                             **(dict(flags=exact | wflags, history_depth=1024, shard_channels=N) if exact else dict(flags=wflags)))
         if exact:
             eng.log_spawn(sw.chan_id, x0, z0)  # (every rank: every channel of the world)
         eng.spawn(sw.chan_id[mine], x0[mine], z0[mine], sw.flags[mine], sw.sender[mine])
         eng.add_subscribers(sw.sub_conn[my_subs])
-        sworld = ShardedWorld(eng, Comm(rank, world))
+        comm = Comm(rank, world)
+        sworld = ShardedWorld(eng, comm)
+        if pipe:
+            os.environ["CHD_SHARD_TRANSPORT"] = "hostpipe"
+            why = eng.comm_init_native(comm)
+            assert why is None and eng.native, why
         if lists:
             hl, groups, (l_off, l_mem, l_chan, l_of) = make_lists(sw, ids0, N, seed)
             assert len(hl) > N // 20
@@ -193,13 +202,13 @@ def run_rank(rank, world, port, N, S, ticks, seed, out, cfg_name=None, halo=64, 
             dist.destroy_process_group()
 
 
-def launch(world, N, S, ticks, seed, cfg_name=None, halo=64, jump_frac=0.15, aoi_scale=1.0, lists=False, senders=False, exact=0, timeout=300):
+def launch(world, N, S, ticks, seed, cfg_name=None, halo=64, jump_frac=0.15, aoi_scale=1.0, lists=False, senders=False, exact=0, timeout=300, pipe=False, wflags=0):
     import torch.multiprocessing as mp
 
     ctx = mp.get_context("spawn")
     out = ctx.Queue()
     port = free_port()
-    procs = [ctx.Process(target=run_rank, args=(r, world, port, N, S, ticks, seed, out, cfg_name, halo, jump_frac, aoi_scale, lists, senders, exact)) for r in range(world)]
+    procs = [ctx.Process(target=run_rank, args=(r, world, port, N, S, ticks, seed, out, cfg_name, halo, jump_frac, aoi_scale, lists, senders, exact, pipe, wflags)) for r in range(world)]
     for p in procs:
         p.start()
     for p in procs:
@@ -260,7 +269,7 @@ def test_update_senders_change_while_entities_migrate(world):
     assert total > 0 and (cross > 0 or world == 1)
 
 
-@pytest.mark.parametrize("world,flags,ticks", [(1, 1 | 64, 130), (2, 1 | 64, 130), (2, 1, 130), (4, 1 | 64, 36)],
+@pytest.mark.parametrize("world,flags,ticks", [(1, 1 | 64, 130), (2, 1 | 64, 130), (2, 1, 60), (4, 1 | 64, 26)],
                          ids=["1-rank-offsets", "2-ranks-offsets", "2-ranks-element-walk", "4-ranks-offsets"])
 def test_exact_update_buffers_and_enqueue_time_stamps_on_sharded_worlds(world, flags, ticks):
     """the reference stamps every update when it is ENQUEUED (channel.go:296-310) and tickData compares those stamps
@@ -271,9 +280,24 @@ def test_exact_update_buffers_and_enqueue_time_stamps_on_sharded_worlds(world, f
     times since.  Record for record the single-world oracle's (orc World.tick(upd_arrival=...)), history_overflow 0 on every rank.
     flags 1 | 64: the descriptor path with sub-tick offsets (ghost columns filled from the log); flags 1: every off-grid stamp
     makes its channel irregular and the element walk answers (ghost rings read through the log).  (Four processes sharing the one
-    GPU of the test box take ~2 s per tick — context switches — so that case regains access after 16 ticks, not 110.)"""
+    GPU of the test box take ~2 s per tick — context switches — so that case regains access after 6 ticks, the element-walk case after 40, the two others after 110.)"""
     total, cross = launch(world, 700, 30, ticks, 0xC0FFEE50 + world + flags, exact=flags, timeout=900)
-    assert total > 100_000 and (cross > 0 or world == 1)
+    assert total > 50_000 and (cross > 0 or world == 1)
+
+
+@pytest.mark.parametrize("world,kw", [(2, dict()), (2, dict(wflags=16 | 512)), (2, dict(lists=True)), (2, dict(exact=1 | 64, wflags=16 | 512)), (4, dict(wflags=16 | 512))],
+                         ids=["2-ranks", "2-ranks-gated", "2-ranks-lists", "2-ranks-exact-gated", "4-ranks-gated"])
+def test_chd_shard_tick_with_more_than_one_rank_over_the_hostpipe_transport(world, kw):
+    """chd_shard_tick — the whole sharded tick as ONE C call with both exchanges inside the library — had
+    only ever run with one rank (RCCL refuses two ranks on one device).  CHD_SHARD_TRANSPORT=hostpipe carries the same send / recv
+    groups between the rank PROCESSES through shared-memory mailboxes (a test transport inside the library: same entry points, same
+    call sequence, same buffers; a receiver that is sent another size than it expects fails loudly), so the things only a second
+    rank exercises run here through the C entry point: the adaptive segment capacity every rank must derive alike from the maximum
+    of two ticks ago, the request exchange in front of the export (handover lists), the interest updates on the second stream joined
+    by the device-side gate while the peers' segments are still on their way, the update log by channel with the cells'
+    maxFanOutIntervalMs behind every segment.  Records, handovers, unsubs and entity placement equal the single-world oracle's."""
+    total, cross = launch(world, 4000 if "exact" not in kw else 900, 96 if "exact" not in kw else 30, 12 if world == 2 else 8, 0xC0FFEE60 + world + len(kw), pipe=True, timeout=600, **kw)
+    assert total > 0 and cross > 0
 
 
 def test_narrow_halo_band_geometry_on_the_40x40_grid():
