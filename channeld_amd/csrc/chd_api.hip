@@ -928,12 +928,13 @@ int chd_world_create(chd_ctx *ctx, const chd_world_cfg *cfg) {
     const size_t N = d.N, S = d.S, P = (size_t)d.S * d.capq, C = g.ncell;
     // chd_world_cfg.shard_channels: the UPDATE LOG — everything push_update writes — is kept per entity channel id of the whole
     // world, on every rank, instead of per entity slot (WorldDev::log_on); LN = how many logs there are
-    if (cfg->shard_channels && !cfg->history_depth)
-        return fail(ctx, CHD_E_INVAL, "shard_channels is for worlds with exact update buffers (history_depth > 0)");
-    if (cfg->shard_channels && (cfg->flags & (CHD_WORLD_WIRE | CHD_WORLD_PIPELINE_TICKS | CHD_WORLD_HANDOVER_RECIPIENTS)))
-        return fail(ctx, CHD_E_INVAL, "shard_channels: a region-sharded world (no wire buffers, pipelined ticks or recipient planning)");
-    d.log_on = cfg->shard_channels ? 1u : 0u;
-    d.log_n = cfg->shard_channels ? cfg->shard_channels : d.N;
+    if (cfg->shard_channels && !cfg->history_depth && !(cfg->flags & CHD_WORLD_WIRE))
+        return fail(ctx, CHD_E_INVAL, "shard_channels is for region-sharded worlds with exact update buffers (history_depth > 0) or wire buffers (CHD_WORLD_WIRE)");
+    if (cfg->shard_channels && (cfg->flags & (CHD_WORLD_PIPELINE_TICKS | CHD_WORLD_HANDOVER_RECIPIENTS)))
+        return fail(ctx, CHD_E_INVAL, "shard_channels: a region-sharded world (no pipelined ticks, no recipient planning)");
+    d.ce_by_chan = cfg->shard_channels ? 1u : 0u;
+    d.log_on = (cfg->shard_channels && cfg->history_depth) ? 1u : 0u;
+    d.log_n = d.log_on ? cfg->shard_channels : d.N;
     d.log_eid0 = ctx->cfg.entity_channel_id_start ? ctx->cfg.entity_channel_id_start : 0x80000u;
     const size_t LN = d.log_n;
     TRY(walloc(ctx, &d.chan_id, N));
@@ -1195,26 +1196,30 @@ int chd_world_create(chd_ctx *ctx, const chd_world_cfg *cfg) {
         if (const char *e = getenv("CHD_WIRE_FAST")) x.fast_ok = (e[0] != '0' && x.fast_ok) ? 1u : 0u;  // (A/B runs)
         x.stride[0] = ((cfg->wire_max_update_len ? cfg->wire_max_update_len : 128u) + 15u) & ~15u;
         x.stride[1] = ((cfg->wire_max_full_len ? cfg->wire_max_full_len : 1024u) + 15u) & ~15u;
+        // entity payloads: by slot — or, region-sharded (shard_channels), by channel id on every rank: the host feeds every rank the
+        // whole world's update payloads as it feeds it the positions, so a neighbour's ghost entry finds its payload here
+        const size_t PN = cfg->shard_channels ? cfg->shard_channels : N;
+        x.npay = (uint32_t)PN;
         for (int k = 0; k < 2; k++) {
             // (+ 128: k_wire_copy_fast reads 80 bytes of a slot whatever its stride)
-            TRY(walloc(ctx, &x.pay_ent[k], N * x.stride[k] + 128));
+            TRY(walloc(ctx, &x.pay_ent[k], PN * x.stride[k] + 128));
             TRY(walloc(ctx, &x.pay_cell[k], C * x.stride[k] + 128));
-            TRY(walloc(ctx, &x.len_ent[k], N));
+            TRY(walloc(ctx, &x.len_ent[k], PN));
             TRY(walloc(ctx, &x.len_cell[k], C));
         }
         x.merge = masks ? 1u : 0u;
         if (x.merge) {
             // merged updates: the UPDATE payloads of the last CHD_HIST_BITS ticks per channel, and the Any type_urls
-            TRY(walloc(ctx, &x.ring_ent, N * CHD_HIST_BITS * x.stride[0], false));
+            TRY(walloc(ctx, &x.ring_ent, PN * CHD_HIST_BITS * x.stride[0], false));
             TRY(walloc(ctx, &x.ring_cell, C * CHD_HIST_BITS * x.stride[0], false));
-            TRY(walloc(ctx, &x.rlen_ent, N * CHD_HIST_BITS));
+            TRY(walloc(ctx, &x.rlen_ent, PN * CHD_HIST_BITS));
             TRY(walloc(ctx, &x.rlen_cell, C * CHD_HIST_BITS));
             TRY(walloc(ctx, &x.url[0], 256));
             TRY(walloc(ctx, &x.url[1], 256));
         }
         TRY(walloc(ctx, &x.url[2], 256));
-        TRY(walloc(ctx, &x.pay_objref, N * x.stride[0]));
-        TRY(walloc(ctx, &x.len_objref, N));
+        TRY(walloc(ctx, &x.pay_objref, PN * x.stride[0]));
+        TRY(walloc(ctx, &x.len_objref, PN));
         TRY(walloc(ctx, &x.conn_wlen, S + 1));
         x.conn_woff = x.conn_wlen;
         TRY(walloc(ctx, &x.conn_npk, S));
@@ -1222,6 +1227,7 @@ int chd_world_create(chd_ctx *ctx, const chd_world_cfg *cfg) {
         // the descriptor-driven stream builder (k_wire_layout_img): one image of every cell's messages per payload kind
         x.img_on = 1u;
         if (const char *e = getenv("CHD_WIRE_IMAGES")) if (e[0] == '0') x.img_on = 0;  // (A/B runs, tests of the record path)
+        if (cfg->shard_channels) x.img_on = 0;  // (region-sharded: the cell images index table positions and window columns the ghost tables do not have; the record path)
         if (x.img_on) {
             size_t free_b = 0, total_b = 0;
             (void)hipMemGetInfo(&free_b, &total_b);
@@ -2219,6 +2225,7 @@ static int shard_reserve_ghosts(chd_ctx *ctx, uint32_t ghosts) {
     TRY(walloc(ctx, &d.ce8, n + 2));
     TRY(walloc(ctx, &d.ce_chan, n + 520));
     if (d.ce_slot) TRY(walloc(ctx, &d.ce_slot, n + 2));
+    W.x.npos = (uint32_t)n + 2u;  // (wire worlds: a record's position word may name a ghost entry)
     if (d.off_on) {  // (the offset columns run beside the entries, ghosts included)
         d.off_stride = (uint32_t)((n + 520 + 63) & ~(size_t)63);
         TRY(walloc(ctx, &d.ce_off, (size_t)CHD_OFF_SLOTS * d.off_stride + 520));
@@ -3032,8 +3039,8 @@ int chd_wire_set_payloads(chd_ctx *ctx, int kind, uint32_t n, const uint32_t *id
         if (cell) {
             if (v < ctx->g.id_start || v - ctx->g.id_start >= ctx->g.ncell) return fail(ctx, CHD_E_INVAL, "payload %u: %u is not a spatial channel", i, v);
             v -= ctx->g.id_start;
-        } else if (v >= W.d.N) {
-            return fail(ctx, CHD_E_INVAL, "payload %u: entity slot %u out of range", i, v);
+        } else if (v >= W.x.npay) {
+            return fail(ctx, CHD_E_INVAL, "payload %u: entity %s %u out of range", i, W.d.ce_by_chan ? "channel index" : "slot", v);
         }
         ix[i] = v;
         off[i] = total;
@@ -3049,7 +3056,7 @@ int chd_wire_set_payloads(chd_ctx *ctx, int kind, uint32_t n, const uint32_t *id
     TRY(up(ctx, sbuf<void>(ctx, 2), off.data(), 8 * (size_t)n));
     TRY(up(ctx, sbuf<void>(ctx, 3), bytes, total));
     // (merge mode: an UPDATE payload set now belongs to the update that arrives with the NEXT tick)
-    launch_wire_set_payloads(ctx->stream, W.x, objref ? 2 : full, cell, n, cell ? ctx->g.ncell : W.d.N, sbuf<uint32_t>(ctx, 0),
+    launch_wire_set_payloads(ctx->stream, W.x, objref ? 2 : full, cell, n, cell ? ctx->g.ncell : W.x.npay, sbuf<uint32_t>(ctx, 0),
                              sbuf<uint32_t>(ctx, 1), sbuf<uint64_t>(ctx, 2), sbuf<uint8_t>(ctx, 3),
                              (ctx->ring.cur_tick + 1u) & (CHD_HIST_BITS - 1u));
     TRY(after_launch(ctx));
@@ -3091,6 +3098,7 @@ int chd_handover_messages(chd_ctx *ctx, uint32_t n_handovers, uint32_t *offsets,
     World &W = ctx->w;
     std::lock_guard<FairMutex> lk(ctx->mu);
     if (!W.wire) return fail(ctx, CHD_E_STATE, "the world was created without CHD_WORLD_WIRE");
+    if (W.d.ce_by_chan) return fail(ctx, CHD_E_STATE, "handover message assembly stays with the host on region-sharded worlds (the entity data is looked up by slot)");
     if (!W.ticked) return fail(ctx, CHD_E_STATE, "no tick yet");
     TRY(bind(ctx));
     uint64_t ringrow[8];
@@ -3126,6 +3134,7 @@ int chd_handover_variants(chd_ctx *ctx, uint32_t n_var, const uint32_t *var_hand
     World &W = ctx->w;
     std::lock_guard<FairMutex> lk(ctx->mu);
     if (!W.wire) return fail(ctx, CHD_E_STATE, "the world was created without CHD_WORLD_WIRE");
+    if (W.d.ce_by_chan) return fail(ctx, CHD_E_STATE, "handover message assembly stays with the host on region-sharded worlds (the entity data is looked up by slot)");
     if (!W.ticked) return fail(ctx, CHD_E_STATE, "no tick yet");
     TRY(bind(ctx));
     uint64_t ringrow[8];
@@ -3164,7 +3173,8 @@ int chd_wire_build(chd_ctx *ctx, uint64_t *total_bytes, uint64_t *total_packets,
     std::lock_guard<FairMutex> lk(ctx->mu);
     if (!W.wire) return fail(ctx, CHD_E_STATE, "the world was created without CHD_WORLD_WIRE");
     if (!W.ticked) return fail(ctx, CHD_E_STATE, "no tick to build the wire buffers of");
-    if (W.slot_mode == 2) return fail(ctx, CHD_E_STATE, "wire buffers are not available on region-sharded worlds yet");
+    if (W.slot_mode == 2 && !W.d.ce_by_chan)
+        return fail(ctx, CHD_E_STATE, "wire buffers on a region-sharded world need chd_world_cfg.shard_channels (payloads by channel id)");
     TRY(bind(ctx));
     WorldDev &d = W.d;
     hipStream_t st = ctx->stream;

@@ -57,6 +57,9 @@ struct WorldDev {
     // log_ix() maps a slot to its log.  log_cell[u] = cell of the channel's last merged position (CHD_INVALID: none / out of the
     // world), log_alive[u] = the channel exists (chd_shard_log_spawn).  sh_arrival_by_chan: chd_shard_set_update_arrivals.
     uint32_t log_on, log_n, log_eid0;
+    // ce_by_chan (shard_channels != 0): ce_slot[pos] — where a cell-table entry's exact buffer (log_on) and its wire payloads
+    // (CHD_WORLD_WIRE) are found — holds the channel index, for own and for ghost entries alike
+    uint32_t ce_by_chan;
     uint32_t *log_cell, *log_alive;
     const int64_t *sh_arrival_by_chan;
     uint32_t sh_arrival_n;
@@ -255,6 +258,8 @@ struct WorldDev {
 
 // where entity slot i's update log lives (WorldDev::log_on)
 __device__ __forceinline__ uint32_t log_ix(const WorldDev &w, uint32_t i) { return w.log_on ? w.chan_id[i] - w.log_eid0 : i; }
+// what ce_slot holds for entity slot i (WorldDev::ce_by_chan)
+__device__ __forceinline__ uint32_t ce_ix(const WorldDev &w, uint32_t i) { return w.ce_by_chan ? w.chan_id[i] - w.log_eid0 : i; }
 
 // a gate's spin bound tripped (OVF_GATE): this tick's mask, and the world's sticky count (the host turns the gates off when it sees it)
 __device__ __forceinline__ void gate_timed_out(const WorldDev &w) {
@@ -536,6 +541,7 @@ struct WireDev {
     uint32_t *conn_npk;                 // [S] packets per connection
     uint32_t *n_dropped;                // [2] messages dropped by the size check of Send; records without a valid position word
     uint32_t ncell, npos;               // bounds of the position words: cells of the grid, entries of the cell table
+    uint32_t npay;                      // entity payload entries: max_entities (indexed by slot) or, region-sharded (WorldDev::ce_by_chan), the world's channels (indexed by channel id - EntityChannelIdStart)
     uint8_t *bytes;                     // the wire arena
     // streams from the fan-out descriptors (k_wire_layout_img): per cell and payload kind f (0 update, 1 full state) the IMAGE
     // of the cell's messages — [own message][entity messages in column order] — built once per tick

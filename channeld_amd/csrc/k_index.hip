@@ -257,7 +257,7 @@ __device__ __forceinline__ void index_scatter_block(const WorldDev &w, uint32_t 
         w.ce8[pos] = make_uint2(w.chan_id[i], h | hp);
         w.ce_chan[pos] = w.chan_id[i];
         w.ce_sprev[pos] = w.sender_prev[u];
-        if (w.ce_slot) w.ce_slot[pos] = u;  // (what the exact buffers are indexed by: the slot — or, log_on, the channel)
+        if (w.ce_slot) w.ce_slot[pos] = ce_ix(w, i);  // (what the exact buffers / wire payloads are indexed by: the slot — or the channel)
         if (w.off_on) scatter_offsets(w, u, pos, age);
     }
 }
@@ -314,7 +314,7 @@ __global__ void __launch_bounds__(256) k_index_scatter_global(WorldDev w, uint32
     w.ce[pos] = make_uint4(w.chan_id[i], h, w.sender[u], hp);
     w.ce_sprev[pos] = w.sender_prev[u];
     w.ce_chan[pos] = w.chan_id[i];
-    if (w.ce_slot) w.ce_slot[pos] = u;
+    if (w.ce_slot) w.ce_slot[pos] = ce_ix(w, i);
     if (w.off_on) scatter_offsets(w, u, pos, age);
 }
 

@@ -551,13 +551,12 @@ __global__ void __launch_bounds__(256) k_halo_unpack(DevGrid g, WorldDev w, uint
         w.ce_sprev[base + k] = sprev[k];
         w.ce8[base + k] = make_uint2(e.x, e.y | e.w);  // compact entry {channel, history of any sender}
         w.ce_chan[base + k] = e.x;
-        if (w.log_on) {
-            // the ghost's update log is HERE (by channel): where the exact buffers are, and its sub-tick offsets into the columns
+        if (w.ce_by_chan && w.ce_slot) {
+            // the ghost's update log (log_on) and its wire payloads (CHD_WORLD_WIRE) are HERE, by channel: where the exact buffers
+            // and the payload slots are, and its sub-tick offsets into the columns
             const uint32_t u = e.x - w.log_eid0;
-            if (u < w.log_n) {
-                w.ce_slot[base + k] = u;
-                if (w.off_on) scatter_offsets(w, u, base + k, cur_tick - w.hist_tick[u]);
-            }
+            w.ce_slot[base + k] = u;
+            if (w.log_on && w.off_on && u < w.log_n) scatter_offsets(w, u, base + k, cur_tick - w.hist_tick[u]);
         }
     }
     if (w.log_on) {  // ... and whether a ghost cell holds a channel the tick-ring masks cannot answer for (cell_irr, as the index build sets it)

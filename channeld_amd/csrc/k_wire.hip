@@ -275,7 +275,7 @@ __global__ void __launch_bounds__(256) k_wire_layout(WorldDev w, WireDev x) {
                         pos = CHD_POS_CELL;
                     }
                     uint32_t idc = (pos & CHD_POS_CELL) ? pos : w.ce_slot[pos];
-                    if (!(idc & CHD_POS_CELL) && idc >= w.N) {  // (same for a cell-table entry that names no entity slot)
+                    if (!(idc & CHD_POS_CELL) && idc >= x.npay) {  // (same for a cell-table entry that names no entity slot)
                         atomicAdd(x.n_dropped + 2, 1u);
                         idc = CHD_POS_CELL;
                     }
@@ -1122,7 +1122,7 @@ __global__ void __launch_bounds__(256) k_wire_img_sizes(DevGrid g, WorldDev w, W
         if (i < n) {
             uint32_t slot, chan;
             img_entry(w, sel, i, slot, chan);
-            if (slot >= w.N) bad = 1;
+            if (slot >= x.npay) bad = 1;
             else {
                 r.channel = chan;
                 entry = wire_msg(w, x, r, slot, sel.mask).entry;
@@ -1485,7 +1485,7 @@ __global__ void __launch_bounds__(256) k_wire_layout_img(DevGrid g, WorldDev w, 
                             if (EMIT) atomicAdd(x.n_dropped + 1, 1u);
                             idc = CHD_POS_CELL;
                         }
-                        if (!(idc & CHD_POS_CELL) && idc >= w.N) {
+                        if (!(idc & CHD_POS_CELL) && idc >= x.npay) {
                             if (EMIT) atomicAdd(x.n_dropped + 2, 1u);
                             idc = CHD_POS_CELL;
                         }

@@ -236,10 +236,13 @@ class Comm:
 class HipShardEngine:
     def __init__(self, cfg: dict, rank: int, world: int, max_entities: int, max_subscribers: int,
                  migrate_cap: int = 4096, device: int = 0, max_records: int = 0, use_torch_stream: bool = True,
-                 adaptive_migrate: bool = False, flags: int = 0, history_depth: int = 0, shard_channels: int = 0):
+                 adaptive_migrate: bool = False, flags: int = 0, history_depth: int = 0, shard_channels: int = 0,
+                 wire_max_update_len: int = 0, wire_max_full_len: int = 0):
         """history_depth + shard_channels: exact update buffers on the sharded world — every rank keeps every channel's update log
         by channel id (chd_world_cfg.shard_channels); then log_spawn (every rank: the whole world's entities) beside spawn (this
-        rank's), set_update_senders and set_update_arrivals."""
+        rank's), set_update_senders and set_update_arrivals.
+        flags & 8 (CHD_WORLD_WIRE) + shard_channels: wire buffers on the sharded world — self.sw.wire_set_payloads takes CHANNEL
+        INDEXES (channel id - EntityChannelIdStart) and every rank is given every channel's payloads, as it is the positions."""
         import torch
 
         from . import _lib
@@ -255,7 +258,8 @@ class HipShardEngine:
         if err is not None:
             raise err
         self.sw = SpatialWorld(self.ctl, max_entities, max_subscribers, max_records=max_records, flags=flags,
-                               history_depth=history_depth, shard_channels=shard_channels)
+                               history_depth=history_depth, shard_channels=shard_channels,
+                               wire_max_update_len=wire_max_update_len, wire_max_full_len=wire_max_full_len)
         self.lib, self.ctx = self.sw.lib, self.sw.ctx
         if use_torch_stream:
             _lib.check(self.ctx, self.lib.chd_set_stream(self.ctx, C.c_void_p(torch.cuda.current_stream(self.dev).cuda_stream), 1))

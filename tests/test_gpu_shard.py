@@ -34,14 +34,16 @@ from shard_lists import make_lists, one_handover_per_group_and_tick  # noqa: E40
 
 
 def run_rank(rank, world, port, N, S, ticks, seed, out, cfg_name=None, halo=64, jump_frac=0.15, aoi_scale=1.0, lists=False, senders=False, exact=0,
-             pipe=False, wflags=0):
+             pipe=False, wflags=0, wire=False):
     """exact != 0 (= the world's emit flags): exact update buffers on the sharded world — history_depth 1024, the update log by
     channel id on every rank (chd_world_cfg.shard_channels), per-update arrival stamps anywhere inside the tick's interval
     (chd_shard_set_update_arrivals), and three connections that lose access at tick 8 and get it back twelve ticks before the end:
     their catch-up walks the buffers of entities that have changed ranks many times since.
     pipe: the tick is ONE C call, chd_shard_tick, with the exchanges inside the library — over its TEST transport
     (CHD_SHARD_TRANSPORT=hostpipe: shared-memory mailboxes between the rank processes; RCCL refuses two ranks on one device), the
-    unique id carried by gloo as a gateway's control connection would; wflags: world flags (16 | 512 = the gated overlap)."""
+    unique id carried by gloo as a gateway's control connection would; wflags: world flags (16 | 512 = the gated overlap).
+    wire: CHD_WORLD_WIRE on the sharded world — payloads keyed by channel id on every rank; every connection's byte stream must
+    equal what oracle/wire.py makes of that connection's records (the rank's own, in its order) and the payloads."""
     import torch
     import torch.distributed as dist
 
@@ -65,7 +67,8 @@ def run_rank(rank, world, port, N, S, ticks, seed, out, cfg_name=None, halo=64, 
         mine = np.nonzero(owner == rank)[0]
         my_subs = np.nonzero(owner[:S] == rank)[0]
         eng = HipShardEngine(cfg, rank, world, N, max(len(my_subs), 1), migrate_cap=N, device=0, max_records=1 << 22,
-                             **(dict(flags=exact | wflags, history_depth=1024, shard_channels=N) if exact else dict(flags=wflags)))
+                             **(dict(flags=exact | wflags, history_depth=1024, shard_channels=N) if exact else
+                                dict(flags=wflags | 8 | 1, shard_channels=N) if wire else dict(flags=wflags)))
         if exact:
             eng.log_spawn(sw.chan_id, x0, z0)  # (every rank: every channel of the world)
         eng.spawn(sw.chan_id[mine], x0[mine], z0[mine], sw.flags[mine], sw.sender[mine])
@@ -91,6 +94,18 @@ def run_rank(rank, world, port, N, S, ticks, seed, out, cfg_name=None, halo=64, 
             for s in range(S):
                 ow.add_sub(s, int(sw.sub_conn[s]))
         total = cross = 0
+        pay = None
+        if wire:  # the same payloads on every rank, keyed by channel index / spatial channel id (the host has them anyway)
+            from oracle import wire as owire
+
+            prng = np.random.default_rng(seed ^ 0x77)
+            ncell = g.cols * g.rows
+            blob = lambda lo, hi: bytes(prng.integers(0, 256, int(prng.integers(lo, hi)), dtype=np.uint8))
+            pay = {"ent": {0: {}, 1: {u: blob(40, 300) for u in range(N)}},
+                   "cell": {0: {0x10000 + c: blob(0, 100) for c in range(ncell)}, 1: {0x10000 + c: blob(40, 300) for c in range(ncell)}}}
+            eng.sw.wire_set_payloads(1, list(pay["ent"][1]), list(pay["ent"][1].values()))
+            eng.sw.wire_set_payloads(2, list(pay["cell"][0]), list(pay["cell"][0].values()))
+            eng.sw.wire_set_payloads(3, list(pay["cell"][1]), list(pay["cell"][1].values()))
         d_snd = d_arr = None
         blocked = [b for b in (1, 4, 7) if b < S] if exact else []
         prev_now = 0
@@ -121,9 +136,28 @@ def run_rank(rank, world, port, N, S, ticks, seed, out, cfg_name=None, halo=64, 
                 d_arr.copy_(torch.from_numpy(arr))
                 if snd is None:
                     snd = sw.sender.astype(np.uint32)
+            if wire:  # this tick's update payload of every channel of the world, on every rank
+                urng = np.random.default_rng((seed << 8) ^ (k + 1000))
+                upd = {u: bytes(urng.integers(0, 256, int(urng.integers(0, 100)), dtype=np.uint8)) for u in range(N)}
+                pay["ent"][0].update(upd)
+                eng.sw.wire_set_payloads(0, list(upd), list(upd.values()))
             dq = torch.from_numpy(np.ascontiguousarray(q[my_subs]).view(np.uint8)).to(dev)
             sworld.tick(now, torch.from_numpy(x).to(dev), torch.from_numpy(z).to(dev), dq, len(my_subs))
             res = eng.fetch(want_records=True, records_cap=1 << 22)
+            if wire:
+                nbytes, npackets, ndropped = eng.sw.wire_build()
+                off, npk, data = eng.sw.wire_fetch()
+                assert int(off[len(my_subs)]) == nbytes == len(data) and ndropped == 0
+                for ls in range(len(my_subs)):
+                    packs = []
+                    for r in res.records_of(ls):
+                        full, ch = int(r["conn"]) >> 31, int(r["channel"])
+                        packs.append(owire.fanout_message_pack(ch, pay["cell"][full][ch] if ch < 0x80000 else pay["ent"][full][ch - 0x80000]))
+                    want, counts = owire.flush_stream(packs)
+                    got = data[int(off[ls]):int(off[ls + 1])].tobytes()
+                    assert got == want, f"rank {rank} tick {k} local slot {ls}: wire stream ({len(got)} bytes vs {len(want)})"
+                    assert int(npk[ls]) == len(counts)
+                wire_bytes = locals().get("wire_bytes", 0) + nbytes
             ch, cell, mem = eng.entities()
             state = dict(conn=res.records["conn"].copy(), chan=res.records["channel"].copy(), ho=res.handovers.copy(),
                          locked=res.n_locked_aborts, status=res.query_status.copy(), subs=my_subs,
@@ -202,13 +236,14 @@ def run_rank(rank, world, port, N, S, ticks, seed, out, cfg_name=None, halo=64, 
             dist.destroy_process_group()
 
 
-def launch(world, N, S, ticks, seed, cfg_name=None, halo=64, jump_frac=0.15, aoi_scale=1.0, lists=False, senders=False, exact=0, timeout=300, pipe=False, wflags=0):
+def launch(world, N, S, ticks, seed, cfg_name=None, halo=64, jump_frac=0.15, aoi_scale=1.0, lists=False, senders=False, exact=0, timeout=300, pipe=False, wflags=0,
+           wire=False):
     import torch.multiprocessing as mp
 
     ctx = mp.get_context("spawn")
     out = ctx.Queue()
     port = free_port()
-    procs = [ctx.Process(target=run_rank, args=(r, world, port, N, S, ticks, seed, out, cfg_name, halo, jump_frac, aoi_scale, lists, senders, exact, pipe, wflags)) for r in range(world)]
+    procs = [ctx.Process(target=run_rank, args=(r, world, port, N, S, ticks, seed, out, cfg_name, halo, jump_frac, aoi_scale, lists, senders, exact, pipe, wflags, wire)) for r in range(world)]
     for p in procs:
         p.start()
     for p in procs:
@@ -300,6 +335,19 @@ def test_chd_shard_tick_with_more_than_one_rank_over_the_hostpipe_transport(worl
     maxFanOutIntervalMs behind every segment.  Records, handovers, unsubs and entity placement equal the single-world oracle's."""
     total, cross = launch(world, 4000 if "exact" not in kw else 900, 96 if "exact" not in kw else 30, 12 if world == 2 else 8, 0xC0FFEE60 + world + len(kw), pipe=True, timeout=600, **kw)
     assert total > 0 and cross > 0
+
+
+@pytest.mark.parametrize("world,pipe", [(1, False), (2, False), (4, True)], ids=["1-rank", "2-ranks", "4-ranks-native-tick"])
+def test_wire_buffers_on_region_sharded_worlds(world, pipe):
+    """VERDICT r4 missing #2 (f1 x e): CHD_WORLD_WIRE on a region-sharded world.  connection.go:626-714 / data.go:293-308 build a
+    connection's packets from the messages of whatever channels it is subscribed to — own region or a neighbour's border cell
+    alike.  The entity payloads are keyed by CHANNEL ID (chd_world_cfg.shard_channels) and given to every rank, as the positions
+    are, so a ghost entry of a neighbour's cell finds its payload where the stream is built; nothing new crosses the wire.
+    Every connection's byte stream equals oracle/wire.py's flush of that connection's records (tag, greedy 65535-byte packets,
+    MessagePack{channelId, msgType 8, ChannelDataUpdateMessage{Any}}) — and the records equal the single world's, as in every
+    test of this file — while 15 % of the entities change regions every tick."""
+    total, cross = launch(world, 1500, 48, 8, 0xC0FFEE70 + world, wire=True, pipe=pipe, timeout=600)
+    assert total > 0 and (cross > 0 or world == 1)
 
 
 def test_narrow_halo_band_geometry_on_the_40x40_grid():
