@@ -141,6 +141,7 @@ def parse():
                          "-3.4 %% per tick on the serial schedule, profiles/r04q_overlap_interest_ab.json)")
     ap.add_argument("--gated-overlap", type=int, default=1, choices=(0, 1),
                     help="with --overlap-interest: fork / join of the second stream as device-side flags instead of HIP events (CHD_WORLD_GATED_OVERLAP)")
+    ap.add_argument("--history-out", default=None, metavar="PATH", help="write the timed ticks' record counts (per tick, oldest first) as JSON")
     ap.add_argument("--prof-every", type=int, default=0,
                     help="timed region: HIP event pair around the dominant kernel on every N-th tick (1 = every launch, as rounds 1-3 did; "
                          "default: prof_every_for(--steps) = 7 at 200 steps, never fewer than six timed launches)")
@@ -477,6 +478,9 @@ def main():
 
     hist = world.history(min(K, 1024))
     msgs = sum(h["n_records"] for h in hist)
+    if args.history_out:  # per timed tick, oldest first: what tools/filt_tail.sh joins with a kernel trace's per-dispatch durations
+        with open(args.history_out, "w") as f:
+            json.dump([{k: h[k] for k in ("n_records", "n_deferred_records", "n_filtered_records", "n_deep_records", "emit_main_us")} for h in hist], f)
     # the dominant kernel alone (k_fanout_emit_seg; its own HIP event pair on the tick's stream) and the records IT wrote
     # (the few connections it defers are written by a second, small launch inside the same emit stage)
     timed = [h for h in hist if h["emit_main_us"] > 0] if kernel_scope else hist  # (the sampled launches: --prof-every)

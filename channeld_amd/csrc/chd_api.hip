@@ -2496,6 +2496,7 @@ static int shard_fanout_locked(chd_ctx *ctx, const void *d_halo_recv, uint32_t w
     TRY(after_launch(ctx));
     if (d_in->n_queries) W.last_nq = d_in->n_queries;
     W.ticked = true;
+    W.wire_built = false;
     return CHD_OK;
 }
 

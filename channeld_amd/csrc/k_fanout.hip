@@ -1856,7 +1856,10 @@ __global__ void __launch_bounds__(1024) k_filt_items(WorldDev w, uint32_t ncell)
         if (threadIdx.x == 1023) carry_s = off + inc;
         __syncthreads();
     }
-    if (threadIdx.x == 0) *w.filt_nitems = carry_s;
+    if (threadIdx.x == 0) {
+        *w.filt_nitems = carry_s;
+        w.filt_nitems[16] = 0;  // k_fanout_emit_filt_cm's item ticket
+    }
 }
 
 __global__ void __launch_bounds__(64 * FC_WAVES, FC_OCC) k_fanout_emit_filt_cm(DevGrid g, WorldDev w) {
@@ -1869,16 +1872,19 @@ __global__ void __launch_bounds__(64 * FC_WAVES, FC_OCC) k_fanout_emit_filt_cm(D
 
     if (wave == 0) {
         // ---- loader ----
-        uint32_t item = blockIdx.x;
+        // items by TICKET, not by a static stride: an item is 1..64 descriptors of 1..8 windows over 1..4 rows, and with ~3 items per
+        // workgroup a static deal left the launch waiting for its unluckiest workgroup (off-grid ticks: 287 us max against 114 avg)
         auto prepare = [&](uint32_t b) {
             FcHead &H = heads[b];
             FcTile &T = tiles[b];
+            uint32_t item = 0;
+            if (lane == 0) item = atomicAdd(&w.filt_nitems[16], 1u);
+            item = (uint32_t)__builtin_amdgcn_readfirstlane((int)item);
             if (item >= n_items) {
                 if (lane == 0) H.valid = 0;
                 return;
             }
             const uint4 it = w.filt_items[item];
-            item += gridDim.x;
             const uint32_t c = (uint32_t)__builtin_amdgcn_readfirstlane((int)it.x), first = (uint32_t)__builtin_amdgcn_readfirstlane((int)it.y);
             const uint32_t ndt = (uint32_t)__builtin_amdgcn_readfirstlane((int)it.z), start = (uint32_t)__builtin_amdgcn_readfirstlane((int)it.w);
             const uint32_t nd = ndt & 0xFFu, tn = ndt >> 8;
@@ -2021,7 +2027,10 @@ __global__ void __launch_bounds__(64 * FC_WAVES, FC_OCC) k_fanout_emit_filt_cm(D
                             const uint32_t left = n > (uint32_t)(128 * h) ? n - 128u * h : 0u;  // entries of this row and beyond
                             const uint64_t in0 = left >= 127u ? ~0ull : ((1ull << ((left + 1u) >> 1)) - 1ull);
                             const uint64_t in1 = left >= 128u ? ~0ull : ((1ull << (left >> 1)) - 1ull);
-                            uint64_t a0 = __ballot((hh[h].x & full) != 0), a1 = __ballot((hh[h].y & full) != 0);
+                            // (a window that lies inside ONE tick's arrivals — the 20 ms subscriptions of a 50 ms world — covers no slot
+                            // whole: full == 0, a scalar, and the two and + compare + ballot of the whole-slot test are skipped)
+                            uint64_t a0 = 0, a1 = 0;
+                            if (full) { a0 = __ballot((hh[h].x & full) != 0); a1 = __ballot((hh[h].y & full) != 0); }
                             if (use_a) {
                                 a0 |= __ballot(oa[h].x - a_lo <= a_rng);
                                 a1 |= __ballot(oa[h].y - a_lo <= a_rng);
