@@ -23,7 +23,18 @@
 #include <string>
 #include <vector>
 
-#include <rccl/rccl.h>  // types and constants only: librccl.so is dlopen'ed by chd_shard_comm_init (a single-GPU gateway never loads it)
+// RCCL's few types and constants, declared here: librccl.so is dlopen'ed by chd_shard_comm_init (a single-GPU gateway never loads
+// it), and a single-GPU BUILD does not need its headers either.  CHD_WITH_RCCL_HEADER=1 takes them from <rccl/rccl.h> instead (the
+// static_asserts below then check these declarations against the real ones).
+#ifdef CHD_WITH_RCCL_HEADER
+#include <rccl/rccl.h>
+static_assert(ncclSuccess == 0 && ncclUint8 == 1 && sizeof(ncclUniqueId) == 128, "the declarations of the #else branch are RCCL's");
+#else
+typedef struct ncclComm *ncclComm_t;
+typedef struct { char internal[128]; } ncclUniqueId;
+typedef enum { ncclSuccess = 0 } ncclResult_t;
+typedef enum { ncclInt8 = 0, ncclChar = 0, ncclUint8 = 1 } ncclDataType_t;
+#endif
 
 #include "chd_kernels.h"
 
@@ -35,23 +46,28 @@ namespace {
 // in GetChannelId / QueryChannelIds (message_spatial.go:59,236,354; spatial.go:611) beside ONE ticking goroutine — sixteen threads
 // re-taking the lock back to back starved the tick for seconds (tests/c/concurrent_callers.c measured 2 ticks in 60 s).  Tickets:
 // whoever asked first is served first, so a tick waits for at most one call of every other thread.
+// A waiter sleeps on the condition variable of ITS ticket (ticket % 64): an unlock wakes the next ticket's holder and nobody else
+// (waiters 64 tickets apart share a variable and re-check) — one variable for all made every unlock wake every waiter, O(n^2)
+// wake-ups with thousands of goroutine threads queued.
 class FairMutex {
+    static constexpr unsigned K = 64;
     std::mutex m;
-    std::condition_variable cv;
+    std::condition_variable cv[K];
     uint64_t next = 0, serving = 0;
 
 public:
     void lock() {
         std::unique_lock<std::mutex> l(m);
         const uint64_t t = next++;
-        cv.wait(l, [&] { return t == serving; });
+        cv[t % K].wait(l, [&] { return t == serving; });
     }
     void unlock() {
+        uint64_t s;
         {
             std::lock_guard<std::mutex> l(m);
-            serving++;
+            s = ++serving;
         }
-        cv.notify_all();
+        cv[s % K].notify_all();
     }
 };
 
