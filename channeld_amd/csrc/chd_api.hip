@@ -1191,6 +1191,9 @@ int chd_world_create(chd_ctx *ctx, const chd_world_cfg *cfg) {
             d.fcm_on = C * S <= (1ull << 25) ? 1u : 0u;  // (32 B per entry: at most 1 GiB)
             if (const char *e = getenv("CHD_FILT_CELL_MAJOR")) if (e[0] == '0') d.fcm_on = 0;
             if (d.fcm_on) {
+                d.cell_sorted = nullptr;
+                const char *so = getenv("CHD_SORT_ARRIVALS");  // (A/B runs: 0 = every filtered window tested per entity, as in round 4)
+                if (!so || so[0] != '0') TRY(walloc(ctx, &d.cell_sorted, C));
                 TRY(walloc(ctx, &d.cell_fcnt, C * 32));
                 TRY(walloc(ctx, &d.cell_flist, 2 * C * S, false));
                 TRY(walloc(ctx, &d.filt_items, P / 64 + C + 1, false));

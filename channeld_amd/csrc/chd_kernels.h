@@ -136,6 +136,7 @@ struct WorldDev {
     // (one counter per 128-byte line; the plan appends, the tick epilogue clears); filt_items = the kernel's work list {cell,
     // first list entry, descriptors | tile entries << 8, column start} in chunks of 64 descriptors, n in filt_nitems (k_filt_items)
     uint32_t fcm_on;
+    uint32_t *cell_sorted;  // [ncell] (fcm_on, else nullptr) the cell's entries are in the order of this tick's arrival offsets (k_cell_sort0): a window inside the tick's own arrivals is a run of the column
     uint32_t *cell_fcnt;
     uint4 *cell_flist;
     uint4 *filt_items;

@@ -1819,7 +1819,7 @@ struct FcHead {
     uint32_t n[FC_DESCS], info[FC_DESCS];  // entries of the cell; windows | own-update bits << 8 (0xFFFFFFFF: skip — no room for the connection's worst case)
     uint32_t conn[FC_DESCS], pidx[FC_DESCS], sidx[FC_DESCS];
     uint32_t win[FC_DESCS][FC_LWIN][6];
-    uint32_t nd, cch, start, valid, ticket, _pad[3];
+    uint32_t nd, cch, start, valid, ticket, sorted, _pad[2];  // sorted: the cell's entries are in the order of this tick's arrival offsets (k_cell_sort0)
 };
 struct FcTile {
     uint32_t chan[512], hist[512], off[CHD_OFF_SLOTS][512];
@@ -1938,7 +1938,7 @@ __global__ void __launch_bounds__(64 * FC_WAVES, FC_OCC) k_fanout_emit_filt_cm(D
             if (lane < FC_DESCS) {
                 H.out16[lane] = out16; H.n[lane] = nn; H.info[lane] = info; H.conn[lane] = conn; H.pidx[lane] = pidx; H.sidx[lane] = sidx;
             }
-            if (lane == 0) { H.nd = nd; H.cch = c + g.id_start; H.start = start; H.valid = 1; H.ticket = 0; }
+            if (lane == 0) { H.nd = nd; H.cch = c + g.id_start; H.start = start; H.valid = 1; H.ticket = 0; H.sorted = w.cell_sorted ? w.cell_sorted[c] : 0u; }
         };
         prepare(0);
         lds_barrier();
@@ -1955,6 +1955,7 @@ __global__ void __launch_bounds__(64 * FC_WAVES, FC_OCC) k_fanout_emit_filt_cm(D
             const FcTile &T = tiles[u & 1u];
             if (!H.valid) break;
             const uint32_t nd = H.nd, cch = H.cch, start = H.start;
+            const bool sorted = __builtin_amdgcn_readfirstlane((int)H.sorted) != 0;
             for (;;) {
                 uint32_t k = 0;
                 if (lane == 0) k = atomicAdd(&H.ticket, 1u);
@@ -2003,7 +2004,34 @@ __global__ void __launch_bounds__(64 * FC_WAVES, FC_OCC) k_fanout_emit_filt_cm(D
                         }
                         n_out += 1;
                     }
-                    if (n <= 512) {
+                    if (n <= 512 && sorted && full == 0 && use_a && !use_b && sa == 0) {
+                        // A WINDOW INSIDE THIS TICK'S OWN ARRIVALS, on a cell whose entries are in arrival order (k_cell_sort0): the
+                        // entities that pass are the run [i0, i1) of the cell's column — i0 = entries with an offset below a_lo, i1 =
+                        // entries with an offset up to a_hi (entities without an update in this tick carry 0xFFFFFFFF and sit behind
+                        // every bound).  Each end by a two-level search over the staged offsets: every 8th entry across the lanes, then
+                        // the eight entries of the group the bound falls into — two LDS reads and two ballots instead of a compare
+                        // per entity — and then a plain copy of the run.
+                        const uint32_t *o0 = T.off[0];
+                        uint32_t ends[2];
+#pragma unroll
+                        for (int q = 0; q < 2; q++) {
+                            const uint32_t x = q == 0 ? a_lo : a_hi + 1u;  // (a_hi <= 0xFFFFFFFE)
+                            const uint32_t p1 = 8u * lane + 7u;
+                            const uint32_t v1 = p1 < n ? o0[p1] : 0xFFFFFFFFu;
+                            const uint32_t grp = (uint32_t)__popcll(__ballot(v1 < x));
+                            const uint32_t p2 = 8u * grp + lane;
+                            const uint32_t v2 = (lane < 8u && p2 < n) ? o0[p2] : 0xFFFFFFFFu;
+                            ends[q] = 8u * grp + (uint32_t)__popcll(__ballot(v2 < x));
+                        }
+                        const uint32_t i0 = ends[0], i1 = ends[1] > ends[0] ? ends[1] : ends[0];
+                        for (uint32_t e = i0 + lane; e < i1; e += 64) {
+                            chd_fanout_rec r;
+                            r.conn = conn;
+                            r.channel = T.chan[e];
+                            out[n_out + (e - i0)] = r;
+                        }
+                        n_out += i1 - i0;
+                    } else if (n <= 512) {
                         // THE COMMON PATH, LDS only.  Per row of 128 entries the lanes do two and + compare for the whole-slot mask
                         // and two subtract + compare per cut slot — the staged offsets of entities WITHOUT an update in a slot are
                         // 0xFFFFFFFF, so the range test alone decides (bounds never exceed 0xFFFFFFFE) — and everything else (bounds,

@@ -470,6 +470,73 @@ __global__ void __launch_bounds__(256) k_cell_offsets(WorldDev w, uint32_t ncell
     }
 }
 
+// Worlds that keep sub-tick arrival offsets (off_on, cell-major filtered kernel): every cell's entries IN THE ORDER OF THIS TICK'S
+// ARRIVALS — ascending offset of ring slot 0, entities without an update in this tick last (their slot-0 column entry becomes the
+// "no update" value 0xFFFFFFFF the record kernel stages anyway).  The order inside a cell is free (a connection's records are a
+// multiset), and in this one a fan-out window that lies inside the tick's own arrivals — every window of a subscription whose
+// interval is shorter than the tick: 20 ms on a 50 ms world — selects a CONTIGUOUS run of the cell's column: k_fanout_emit_filt_cm
+// finds its two ends by a two-level search and copies, instead of testing every entity of the cell against the window.
+// One workgroup per cell, bitonic sort of (offset, position) in LDS, then every per-entry array of the cell permuted in place
+// (all reads before the barrier, all writes behind it).  Cells beyond the record kernel's 512-entry tile stay as they are
+// (cell_sorted[c] = 0: their windows are tested per entity, as before).
+#define SORT0_MAX 512u
+__global__ void __launch_bounds__(256) k_cell_sort0(WorldDev w, uint32_t ncell) {
+    __shared__ uint32_t key[SORT0_MAX], idx[SORT0_MAX];
+    const uint32_t c = blockIdx.x, tid = threadIdx.x;
+    const uint32_t start = w.cell_off[c], n = w.cell_off[c + 1] - start;
+    if (n > SORT0_MAX) { if (tid == 0) w.cell_sorted[c] = 0; return; }
+    if (tid == 0) w.cell_sorted[c] = 1;
+    if (n < 2) {
+        if (n == 1 && tid == 0 && !(w.ce8[start].y & 1u)) w.ce_off[start] = 0xFFFFFFFFu;
+        return;
+    }
+    uint32_t P = 2;
+    while (P < n) P <<= 1;
+    for (uint32_t i = tid; i < P; i += 256) {
+        key[i] = (i < n && (w.ce8[start + i].y & 1u)) ? w.ce_off[start + i] : 0xFFFFFFFFu;
+        idx[i] = i;
+    }
+    __syncthreads();
+    for (uint32_t k = 2; k <= P; k <<= 1)
+        for (uint32_t j = k >> 1; j > 0; j >>= 1) {
+            for (uint32_t t = tid; t < (P >> 1); t += 256) {
+                const uint32_t i = 2u * t - (t & (j - 1u)), l = i + j;
+                const bool up = (i & k) == 0;
+                const uint32_t ka = key[i], kb = key[l], ia = idx[i], ib = idx[l];
+                // (ties by position: the order is then a function of the cell's content alone)
+                const bool gt = ka > kb || (ka == kb && ia > ib);
+                if (gt == up) { key[i] = kb; key[l] = ka; idx[i] = ib; idx[l] = ia; }
+            }
+            __syncthreads();
+        }
+    // permute: entry p of the cell takes what entry idx[p] held (entries n..P-1 are the padding: 0xFFFFFFFF keys with positions >= n sort behind every real entry)
+    uint4 e[2]; uint2 e8[2]; uint32_t ch[2], sp[2], sl[2], of[2][CHD_OFF_SLOTS];
+#pragma unroll
+    for (int r = 0; r < 2; r++) {
+        const uint32_t p = tid + 256u * r;
+        if (p < n) {
+            const uint32_t s = start + idx[p];
+            e[r] = w.ce[s]; e8[r] = w.ce8[s]; ch[r] = w.ce_chan[s]; sp[r] = w.ce_sprev[s];
+            sl[r] = w.ce_slot ? w.ce_slot[s] : 0u;
+#pragma unroll
+            for (uint32_t q = 1; q < CHD_OFF_SLOTS; q++) of[r][q] = w.ce_off[(size_t)q * w.off_stride + s];
+            of[r][0] = key[p];
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < 2; r++) {
+        const uint32_t p = tid + 256u * r;
+        if (p < n) {
+            const uint32_t d = start + p;
+            w.ce[d] = e[r]; w.ce8[d] = e8[r]; w.ce_chan[d] = ch[r]; w.ce_sprev[d] = sp[r];
+            if (w.ce_slot) w.ce_slot[d] = sl[r];
+#pragma unroll
+            for (uint32_t q = 0; q < CHD_OFF_SLOTS; q++) w.ce_off[(size_t)q * w.off_stride + d] = of[r][q];
+        }
+    }
+}
+
 void launch_cell_offsets(hipStream_t st, DevGrid g, WorldDev w) {
     if (!w.N || !w.off_on) return;
     hipLaunchKernelGGL(k_cell_offsets, dim3(g.ncell), dim3(256), 0, st, w, g.ncell);
@@ -495,6 +562,7 @@ bool launch_index_build(hipStream_t st, DevGrid g, WorldDev w, uint32_t cur_tick
         hipLaunchKernelGGL(k_index_scan, dim3((g.ncell + 3) / 4), dim3(256), 0, st, w, g.ncell, !local_base);
         hipLaunchKernelGGL(k_index_scatter, dim3(w.nblk), dim3(IDX_BLOCK), (local_base ? 5 : 4) * g.ncell * 4, st, w,
                            g.ncell, bits_for(g.ncell), cur_tick, local_base, gate_p, gate_target);
+        if (w.cell_sorted) hipLaunchKernelGGL(k_cell_sort0, dim3(g.ncell), dim3(256), 0, st, w, g.ncell);
         return gate_p != nullptr;
     } else {
         // nblk == 1 layout: blk_cnt[c] then scan -> cell_off; cursor lives behind it
@@ -509,6 +577,7 @@ bool launch_index_build(hipStream_t st, DevGrid g, WorldDev w, uint32_t cur_tick
         (void)hipMemcpyAsync(w.cell_off, w.blk_cnt, sizeof(uint32_t) * ((size_t)g.ncell + 1), hipMemcpyDeviceToDevice, st);
         hipLaunchKernelGGL(k_index_scatter_global, dim3((w.N + 255) / 256), dim3(256), 0, st, w, g.ncell, cursor,
                            cur_tick);
+        if (w.cell_sorted) hipLaunchKernelGGL(k_cell_sort0, dim3(g.ncell), dim3(256), 0, st, w, g.ncell);
     }
     return false;
 }

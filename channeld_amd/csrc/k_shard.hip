@@ -534,6 +534,7 @@ __global__ void __launch_bounds__(256) k_halo_unpack(DevGrid g, WorldDev w, uint
             w.cell_tab[c] = base + acc;
             w.cell_tab[g.ncell + c] = base + acc + n;
             w.cell_cov[c] = bad ? 0u : 1u;
+            if (w.cell_sorted) w.cell_sorted[c] = 0;  // (a neighbour's band: its windows are tested per entity)
             acc += n;
         }
         total_s = acc;
