@@ -248,6 +248,85 @@ def cpu_baseline(cfg, n_entities, n_subs, seed, tick_ms, aoi_scale, budget_s, si
     return out, one
 
 
+def measure_traffic_in_run(args, timeout_s=100):
+    """HBM bytes per launch of the dominant kernel, measured NOW: FETCH_SIZE and WRITE_SIZE in two separate `rocprofv3 --pmc` passes
+    (counters only: no tracing beside them) over a child run of this workload's timed region, summed per the guide's gfx950
+    corrections (FETCH_SIZE counts 128-byte read requests at 64 B: doubled; both are in KiB) and averaged over the kernel's launches
+    behind the first five.  None when the box has no rocprofv3, the run is itself a child (--only-timed) or a pass fails; the line
+    then quotes the committed measurement (profiles/hbm_traffic.json) if it is of these kernel sources."""
+    import csv
+    import shutil
+    import subprocess
+    import tempfile
+
+    if args.only_timed or os.environ.get("CHD_BENCH_NO_PMC") or not shutil.which("rocprofv3"):
+        return None
+    t0 = time.perf_counter()
+    per = {}
+    try:
+        for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+            with tempfile.TemporaryDirectory(dir="/tmp") as d:
+                cmd = ["rocprofv3", "--pmc", counter, "--output-format", "csv", "-d", d, "-o", "p", "--", sys.executable, os.path.abspath(__file__),
+                       "--steps", "20", "--warmup", "5", "--only-timed", "--overlap-interest", str(args.overlap_interest), "--gated-overlap", str(args.gated_overlap)]
+                r = subprocess.run(cmd, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp", CHD_BENCH_NO_PMC="1"), capture_output=True, text=True, timeout=timeout_s)
+                files = [os.path.join(dp, f) for dp, _, fs in os.walk(d) for f in fs if f.endswith("counter_collection.csv")]
+                if r.returncode != 0 or not files:
+                    return {"error": f"rocprofv3 --pmc {counter}: rc {r.returncode}, {len(files)} counter files", "seconds": round(time.perf_counter() - t0, 1)}
+                vals = []
+                with open(files[0]) as f:
+                    for row in csv.DictReader(f):
+                        if row["Counter_Name"] == counter and row["Kernel_Name"].split("(")[0].replace("void ", "").startswith(DOMINANT):
+                            vals.append(float(row["Counter_Value"]))
+                vals = vals[5:]
+                if not vals:
+                    return {"error": f"no launch of {DOMINANT} under --pmc {counter}", "seconds": round(time.perf_counter() - t0, 1)}
+                per[counter] = (sum(vals) / len(vals) * 1024.0, len(vals))
+    except Exception as ex:  # noqa: BLE001
+        return {"error": f"{type(ex).__name__}: {ex}", "seconds": round(time.perf_counter() - t0, 1)}
+    fetch, write = 2.0 * per["FETCH_SIZE"][0], per["WRITE_SIZE"][0]
+    return {"bytes_per_launch": fetch + write, "fetch_bytes_per_launch": fetch, "write_bytes_per_launch": write, "launches": per["WRITE_SIZE"][1],
+            "how": "two child runs `rocprofv3 --pmc FETCH_SIZE|WRITE_SIZE -- python bench.py --only-timed --steps 20 --warmup 5` of this workload; FETCH_SIZE doubled "
+                   "(gfx950 tallies 128-B read requests at 64 B), KiB -> bytes, averaged over the launches behind the first five",
+            "seconds": round(time.perf_counter() - t0, 1)}
+
+
+def cpu_baseline_literal(cfg, seed, tick_ms, aoi_scale, n_entities=10_000, n_subs=1_000, warm=8, ticks=2):
+    """SURVEY 8d asked for the reference's own loop nest as the CPU baseline: tickData's LITERAL walk — every subscriber of a
+    channel walks the channel's whole update buffer, list re-queueing and all (data.go:175-291; oracle literal = 1).  At config B
+    that takes minutes per tick, so it is timed here on a REDUCED world of the same grid — 10 000 entities / 1 000
+    connections, one thread — beside the window formulation ("port", what cpu_baseline times) on the same world and thread: the
+    ratio says what the port's shortcut is worth.  Both produce the same records (tests/test_world_oracle.py)."""
+    from channeld_amd import synth
+    from oracle import pyoracle as orc
+
+    g = orc.grid_from_config(cfg)
+    capq = min(g.cols * g.rows, 256)
+    res = {}
+    for name, literal in (("literal", True), ("port", False)):
+        sw = synth.SynthWorld(synth.WorldSpec(cfg, n_entities, n_subs, seed, tick_ms=tick_ms, aoi_scale=aoi_scale))
+        ow = orc.World(g, n_entities, n_subs, capq, 20, 0, literal=literal)
+        ow.set_threads(1)
+        ow.spawn(np.arange(n_entities), sw.chan_id, sw.x, sw.z, sw.flags, sw.sender)
+        for s in range(n_subs):
+            ow.add_sub(s, int(sw.sub_conn[s]))
+        secs, msgs = 0.0, 0
+        for k in range(warm + ticks):
+            sw.step()
+            q = sw.queries()
+            t0 = time.perf_counter()
+            ow.tick(sw.now_ns(), None, sw.x, sw.z, None, None, None, None, q)
+            if k >= warm:
+                secs += time.perf_counter() - t0
+                msgs += int(orc.lib().orc_world_nrec(ow.h))
+        res[name] = (secs, msgs)
+    (ls, lm), (ps, pm) = res["literal"], res["port"]
+    return {"world": f"the headline's grid, {n_entities} entities / {n_subs} connections, one thread, update buffers {warm + ticks} deep",
+            "literal": {"value": lm / ls if ls > 0 else 0.0, "unit": "msgs/s", "ms_per_tick": 1e3 * ls / ticks, "kind": "port",
+                        "what": "tickData's literal list walk (data.go:175-291 restated, oracle literal = 1)"},
+            "window_formulation": {"value": pm / ps if ps > 0 else 0.0, "unit": "msgs/s", "ms_per_tick": 1e3 * ps / ticks, "kind": "port"},
+            "same_msgs": lm == pm, "literal_over_window_time": (ls / ps) if ps > 0 else None}
+
+
 class SingleWorldChecker:
     """bench.py --gpus N --verify K: the SINGLE world the ranks' union is compared with — the oracle (restated reference
     algorithm, window formulation, digest mode) on rank 0's host cores.  The checker, never the thing measured."""
@@ -628,6 +707,13 @@ def main():
         traffic_note = "no PMC measurement of this configuration (profiles/hbm_traffic.json covers the headline workload only)"
     if args.update_masks and traffic is not None:
         traffic, traffic_note = None, "no PMC measurement of the masks configuration"
+    traffic_measured = None
+    if traffic_note is None or "other kernel sources" in (traffic_note or ""):
+        # ... and MEASURED in this run where rocprofv3 is on the box: the two PMC passes of MI355X_MICROARCH.md's HBM recipe, each a
+        # child `rocprofv3 --pmc <counter> -- python bench.py --only-timed --steps 20 --warmup 5` of this very workload
+        traffic_measured = measure_traffic_in_run(args)
+        if traffic_measured and traffic_measured.get("bytes_per_launch"):
+            traffic, traffic_note = traffic_measured["bytes_per_launch"], None
 
     out = {
         "metric": "AOI-filtered fanout msgs/sec + p99 tick latency, 100K entities / 10K subs",
@@ -662,7 +748,8 @@ def main():
         "stage_us_avg_is": "HIP events at every stage boundary of the latency-phase ticks (serial schedule, one synchronous tick at a time); the timed "
                            "region records only the pair around the dominant kernel (chd_set_profiling_scope)",
         "roofline": {"bound": "hbm", "kernel": dominant, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_quoted": traffic is not None,
+                     "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_quoted": traffic is not None and not (traffic_measured and traffic_measured.get("bytes_per_launch")),
+                     "traffic_measured_in_run": traffic_measured,
                      "traffic_source": traffic_note or "QUOTED, not measured in this run: bytes per launch from the rocprofv3 --pmc passes of this command on the same "
                                                        "kernel sources (profiles/hbm_traffic.json, source_hash checked)",
                      "algorithmic_bytes_per_launch": float(bytes_per_msg * emit_msgs.mean()),
@@ -715,6 +802,11 @@ def main():
             out["strict_reference_flat_50ms"] = flat_interval_line(A, synth, cfg, N, S, seed, args, local_rank, 50)
         except Exception as ex:  # noqa: BLE001
             errors["strict_reference_flat_50ms"] = f"{type(ex).__name__}: {ex}"
+    if e2e is not None and not args.flat_interval_ms and args.aoi_scale == 1.0:
+        try:  # SURVEY 8d's secondary run (R = 1.5 x GridWidth): smaller interest sets, ~a quarter of the messages per tick
+            out["aoi_scale_0.5"] = flat_interval_line(A, synth, cfg, N, S, seed, args, local_rank, 0, aoi_scale=0.5)
+        except Exception as ex:  # noqa: BLE001
+            errors["aoi_scale_0.5"] = f"{type(ex).__name__}: {ex}"
     if e2e is not None and not args.flat_interval_ms and not os.environ.get("CHD_BENCH_SKIP_JITTER"):
         for key, tj in (("arrival_jitter", 0), ("arrival_jitter_ticks_off_grid", 3000)):
             try:
@@ -726,6 +818,7 @@ def main():
             out["cpu_baseline"], one = cpu_baseline(cfg, N, S, seed, args.tick_ms, args.aoi_scale, args.cpu_seconds)
             if one:
                 out["cpu_baseline_1t"] = one
+            out["cpu_baseline_literal"] = cpu_baseline_literal(cfg, seed, args.tick_ms, args.aoi_scale)
         except Exception as ex:  # noqa: BLE001
             errors["cpu_baseline"] = f"{type(ex).__name__}: {ex}"
     if errors:
@@ -733,14 +826,18 @@ def main():
     print(json.dumps(out))
 
 
-def flat_interval_line(A, synth, cfg, N, S, seed, args, local_rank, interval_ms, warm=10, steps=40):
+def flat_interval_line(A, synth, cfg, N, S, seed, args, local_rank, interval_ms, warm=10, steps=40, aoi_scale=None):
+    """A variant of the headline workload, device-resident ticks timed like the headline: interval_ms = every subscription fans out
+    at that interval (strict-reference mode); aoi_scale = the AOI radii scaled (SURVEY 8d's secondary run: R = 1.5 x
+    GridWidth is aoi_scale 0.5), damped intervals as in the headline."""
     import torch
 
     ctl = A.StaticGrid2DSpatialController(device=local_rank)
-    assert ctl.LoadConfig(json.dumps(cfg).encode(), strict=False, Damping=[(0xFFFFFFFF, interval_ms)]) is None
-    sw = synth.SynthWorld(synth.WorldSpec(cfg, N, S, seed, tick_ms=args.tick_ms, aoi_scale=args.aoi_scale))
+    assert ctl.LoadConfig(json.dumps(cfg).encode(), strict=False, **({"Damping": [(0xFFFFFFFF, interval_ms)]} if interval_ms else {})) is None
+    sw = synth.SynthWorld(synth.WorldSpec(cfg, N, S, seed, tick_ms=args.tick_ms, aoi_scale=aoi_scale if aoi_scale is not None else args.aoi_scale))
     pipe = not args.serial_ticks and args.headline == "pipelined" and S >= 4096
-    w = A.SpatialWorld(ctl, N, S, max_records=400_000_000, flags=128 if pipe else 0)
+    sched = (16 if args.overlap_interest else 0) | (512 if args.overlap_interest and args.gated_overlap else 0)  # (the headline's serial schedule)
+    w = A.SpatialWorld(ctl, N, S, max_records=400_000_000, flags=128 if pipe else sched)
     w.spawn(None, sw.chan_id, sw.x, sw.z, sw.flags, sw.sender)
     w.add_subscribers(None, sw.sub_conn)
     T = warm + steps
@@ -770,7 +867,8 @@ def flat_interval_line(A, synth, cfg, N, S, seed, args, local_rank, interval_ms,
     res = w.fetch()
     assert res.overflow == 0 and res.history_overflow == 0
     ctl.close()
-    return {"what": f"every subscription fans out every {interval_ms} ms (one-entry damping table), otherwise the headline workload"
+    return {"what": (f"every subscription fans out every {interval_ms} ms (one-entry damping table), otherwise the headline workload" if interval_ms else
+                     f"the headline workload with every AOI radius x {aoi_scale} (SURVEY 8d's secondary run: sphere R = {3 * aoi_scale:g} x GridWidth, cone {5 * aoi_scale:g}, box {2 * aoi_scale:g})")
                     + (" (ticks pipelined, as the headline)" if pipe else " (serial schedule, as the headline)"),
             "value": msgs / el, "unit": "msgs/s", "steps": steps, "ms_per_step": 1e3 * el / steps, "msgs_per_tick": msgs / steps,
             "emit_us": emit_us, "emit_frac_of_hbm_peak": BYTES_PER_MSG * float(np.mean([h["n_records"] for h in timed])) / (emit_us * 1e-6) / 1e9 / HBM_PEAK_GBS}

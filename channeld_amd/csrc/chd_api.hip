@@ -1192,11 +1192,15 @@ int chd_world_create(chd_ctx *ctx, const chd_world_cfg *cfg) {
             if (const char *e = getenv("CHD_FILT_CELL_MAJOR")) if (e[0] == '0') d.fcm_on = 0;
             if (d.fcm_on) {
                 d.cell_sorted = nullptr;
-                const char *so = getenv("CHD_SORT_ARRIVALS");  // (A/B runs: 0 = every filtered window tested per entity, as in round 4)
-                if (!so || so[0] != '0') TRY(walloc(ctx, &d.cell_sorted, C));
+                // CHD_SORT_ARRIVALS=1: the cells' entries in arrival order (k_cell_sort0) and the windows inside a tick's own arrivals as
+                // runs of the column (k_fanout_emit_filt_cm).  OFF by default: measured on config B (profiles/r06c_ab_filt.csv) the
+                // record kernels gain 14-15 us per tick and the sort costs 24.6 — it has to come off the tick's critical path, or out
+                // of the index scatter itself, before it pays
+                const char *so = getenv("CHD_SORT_ARRIVALS");
+                if (so && so[0] == '1') TRY(walloc(ctx, &d.cell_sorted, C));
                 TRY(walloc(ctx, &d.cell_fcnt, C * 32));
                 TRY(walloc(ctx, &d.cell_flist, 2 * C * S, false));
-                TRY(walloc(ctx, &d.filt_items, P / 64 + C + 1, false));
+                TRY(walloc(ctx, &d.filt_items, P / 16 + C + 1, false));  // (work items of >= 16 descriptors: FC_DESCS)
                 TRY(walloc(ctx, &d.filt_nitems, 32));
             }
         }
@@ -1734,7 +1738,7 @@ static int tick_locked(chd_ctx *ctx, const chd_tick_in *in) {
             launch_handover_recipients_fill(bs, ctx->g, d, W.ho_rcp_off, W.ho_rcp_conn, W.ho_rcp_kind, W.ho_rcp_mask, W.ho_rcp_cap);
         }
         if (prof_stages) HIPCHK(hipEventRecord(ev[1], bs));
-        const bool gate_in_index = launch_index_build(bs, ctx->g, d, r.cur_tick, (overlap && gated) ? W.gate + GATE_TOP : nullptr, W.gate_top);
+        const bool gate_in_index = launch_index_build(bs, ctx->g, d, r.cur_tick, (overlap && gated) ? W.gate + GATE_TOP : nullptr, W.gate_top, in->now_ns);
         if (d.wcol_on && fanout_seg_path(d)) launch_window_columns(bs, ctx->g, d);
         launch_cell_offsets(bs, ctx->g, d);
         if (prof_stages) HIPCHK(hipEventRecord(ev[2], bs));
@@ -2434,7 +2438,7 @@ static int shard_import_locked(chd_ctx *ctx, const chd_entity_state *d_recv, uin
     }
     // log_on: ChannelData.OnUpdate for every channel of the world, under the cells' world-wide maxFanOutIntervalMs (just folded)
     launch_log_push(st, ctx->g, d, W.log_x, W.log_z, W.log_has, W.log_nchan, ctx->ring.cur_tick, W.last_now);
-    launch_index_build(st, ctx->g, d, ctx->ring.cur_tick);
+    launch_index_build(st, ctx->g, d, ctx->ring.cur_tick, nullptr, 0, W.last_now);
     if (world > 1) launch_halo_pack(st, ctx->g, d, W.halo_rank, world, ctx->g.border, (unsigned char *)d_halo_send, W.d_halo_send_off);
     TRY(after_launch(ctx));
     return CHD_OK;

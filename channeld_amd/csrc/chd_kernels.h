@@ -461,7 +461,7 @@ void launch_halo_unpack(hipStream_t st, DevGrid g, WorldDev w, uint32_t rank, ui
                         unsigned long long gate_target = 0);
 // K2: cell index build
 bool launch_index_build(hipStream_t st, DevGrid g, WorldDev w, uint32_t cur_tick, const unsigned long long *gate_p = nullptr,
-                        unsigned long long gate_target = 0);
+                        unsigned long long gate_target = 0, int64_t now_ns = 0);
 // the window columns of the cells that are not fully updated (WorldDev::wcol_*); after the index build
 void launch_window_columns(hipStream_t st, DevGrid g, WorldDev w);
 #define CHD_WCOLS 9

@@ -1804,7 +1804,9 @@ __device__ __forceinline__ uint32_t filt_window_global(const WorldDev &w, uint32
     return n_out;
 }
 
-#define FC_DESCS 64
+#ifndef FC_DESCS
+#define FC_DESCS 64  // (>= 16: filt_items' room)
+#endif
 // 12 waves (1 loader + 11 streamers), two workgroups per CU: measured on config B with jittered stamps against 8 waves (14
 // streamers per CU: emit stage 228 us) and 16 (30 per CU, registers spilled: 318 us) — 216 us
 #ifndef FC_WAVES

@@ -480,61 +480,87 @@ __global__ void __launch_bounds__(256) k_cell_offsets(WorldDev w, uint32_t ncell
 // (all reads before the barrier, all writes behind it).  Cells beyond the record kernel's 512-entry tile stay as they are
 // (cell_sorted[c] = 0: their windows are tested per entity, as before).
 #define SORT0_MAX 512u
-__global__ void __launch_bounds__(256) k_cell_sort0(WorldDev w, uint32_t ncell) {
-    __shared__ uint32_t key[SORT0_MAX], idx[SORT0_MAX];
+#define SORT0_BKT 64u
+// Two-level counting sort (a bitonic network took 40 us per tick: 45 barrier-separated steps for 225 workgroups of four waves):
+// 64 buckets over the tick's interval by the offset's leading bits (+ one for "no update"), a prefix over the bucket counts, then
+// every entry's rank = its bucket's start + the entries of the SAME bucket that sort before it (offset, then position: ~7 compares
+// with uniformly spread arrivals; a tick whose arrivals all share one bucket degrades to n compares per entry, still correct).
+__global__ void __launch_bounds__(256) k_cell_sort0(WorldDev w, uint32_t ncell, uint32_t shift) {
+    __shared__ uint32_t bcnt[SORT0_BKT + 1], boff[SORT0_BKT + 2], skey[SORT0_MAX], sidx[SORT0_MAX];
     const uint32_t c = blockIdx.x, tid = threadIdx.x;
     const uint32_t start = w.cell_off[c], n = w.cell_off[c + 1] - start;
     if (n > SORT0_MAX) { if (tid == 0) w.cell_sorted[c] = 0; return; }
     if (tid == 0) w.cell_sorted[c] = 1;
-    if (n < 2) {
-        if (n == 1 && tid == 0 && !(w.ce8[start].y & 1u)) w.ce_off[start] = 0xFFFFFFFFu;
-        return;
-    }
-    uint32_t P = 2;
-    while (P < n) P <<= 1;
-    for (uint32_t i = tid; i < P; i += 256) {
-        key[i] = (i < n && (w.ce8[start + i].y & 1u)) ? w.ce_off[start + i] : 0xFFFFFFFFu;
-        idx[i] = i;
-    }
+    if (n == 0) return;
+    if (tid <= SORT0_BKT) bcnt[tid] = 0;
     __syncthreads();
-    for (uint32_t k = 2; k <= P; k <<= 1)
-        for (uint32_t j = k >> 1; j > 0; j >>= 1) {
-            for (uint32_t t = tid; t < (P >> 1); t += 256) {
-                const uint32_t i = 2u * t - (t & (j - 1u)), l = i + j;
-                const bool up = (i & k) == 0;
-                const uint32_t ka = key[i], kb = key[l], ia = idx[i], ib = idx[l];
-                // (ties by position: the order is then a function of the cell's content alone)
-                const bool gt = ka > kb || (ka == kb && ia > ib);
-                if (gt == up) { key[i] = kb; key[l] = ka; idx[i] = ib; idx[l] = ia; }
-            }
-            __syncthreads();
-        }
-    // permute: entry p of the cell takes what entry idx[p] held (entries n..P-1 are the padding: 0xFFFFFFFF keys with positions >= n sort behind every real entry)
-    uint4 e[2]; uint2 e8[2]; uint32_t ch[2], sp[2], sl[2], of[2][CHD_OFF_SLOTS];
+    uint32_t key[2], bk[2], lp[2];
 #pragma unroll
     for (int r = 0; r < 2; r++) {
-        const uint32_t p = tid + 256u * r;
-        if (p < n) {
-            const uint32_t s = start + idx[p];
+        const uint32_t i = tid + 256u * r;
+        key[r] = 0xFFFFFFFFu; bk[r] = SORT0_BKT; lp[r] = 0;
+        if (i < n) {
+            if (w.ce8[start + i].y & 1u) {
+                key[r] = w.ce_off[start + i];
+                bk[r] = min(key[r] >> shift, SORT0_BKT - 1u);
+            }
+            lp[r] = atomicAdd(&bcnt[bk[r]], 1u);
+        }
+    }
+    __syncthreads();
+    if (tid == 0) {
+        uint32_t acc = 0;
+        for (uint32_t b = 0; b <= SORT0_BKT; b++) { boff[b] = acc; acc += bcnt[b]; }
+        boff[SORT0_BKT + 1] = acc;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < 2; r++) {
+        const uint32_t i = tid + 256u * r;
+        if (i < n) { skey[boff[bk[r]] + lp[r]] = key[r]; sidx[boff[bk[r]] + lp[r]] = i; }
+    }
+    __syncthreads();
+    // every entry's data (coalesced reads by position) and its rank; then, behind the barrier, the writes
+    uint4 e[2]; uint2 e8[2]; uint32_t ch[2], sp[2], sl[2], of[2][CHD_OFF_SLOTS], rank[2];
+#pragma unroll
+    for (int r = 0; r < 2; r++) {
+        const uint32_t i = tid + 256u * r;
+        rank[r] = 0;
+        if (i < n) {
+            const uint32_t s = start + i;
             e[r] = w.ce[s]; e8[r] = w.ce8[s]; ch[r] = w.ce_chan[s]; sp[r] = w.ce_sprev[s];
             sl[r] = w.ce_slot ? w.ce_slot[s] : 0u;
 #pragma unroll
             for (uint32_t q = 1; q < CHD_OFF_SLOTS; q++) of[r][q] = w.ce_off[(size_t)q * w.off_stride + s];
-            of[r][0] = key[p];
+            of[r][0] = key[r];  // (an entity without an update in this tick: 0xFFFFFFFF, what the record kernel stages for it anyway)
+            uint32_t before = 0;
+            for (uint32_t k = boff[bk[r]]; k < boff[bk[r] + 1u]; k++) {
+                const uint32_t kk = skey[k], ki = sidx[k];
+                before += (kk < key[r] || (kk == key[r] && ki < i)) ? 1u : 0u;
+            }
+            rank[r] = boff[bk[r]] + before;
         }
     }
     __syncthreads();
 #pragma unroll
     for (int r = 0; r < 2; r++) {
-        const uint32_t p = tid + 256u * r;
-        if (p < n) {
-            const uint32_t d = start + p;
+        const uint32_t i = tid + 256u * r;
+        if (i < n) {
+            const uint32_t d = start + rank[r];
             w.ce[d] = e[r]; w.ce8[d] = e8[r]; w.ce_chan[d] = ch[r]; w.ce_sprev[d] = sp[r];
             if (w.ce_slot) w.ce_slot[d] = sl[r];
 #pragma unroll
             for (uint32_t q = 0; q < CHD_OFF_SLOTS; q++) w.ce_off[(size_t)q * w.off_stride + d] = of[r][q];
         }
     }
+}
+
+// bucket = offset >> shift with the tick's interval spread over the 64 buckets
+static uint32_t sort0_shift(const WorldDev &w, int64_t now_ns) {
+    const uint64_t len = (w.prev_ns >= 0 && now_ns > w.prev_ns) ? (uint64_t)(now_ns - w.prev_ns) : 1ull << 26;
+    uint32_t sh = 0;
+    while (sh < 31u && (len >> sh) > SORT0_BKT) sh++;
+    return sh;
 }
 
 void launch_cell_offsets(hipStream_t st, DevGrid g, WorldDev w) {
@@ -554,7 +580,7 @@ static uint32_t bits_for(uint32_t ncell) {
 }
 
 // returns true when the launch took the gate wait with it (k_index_scatter)
-bool launch_index_build(hipStream_t st, DevGrid g, WorldDev w, uint32_t cur_tick, const unsigned long long *gate_p, unsigned long long gate_target) {
+bool launch_index_build(hipStream_t st, DevGrid g, WorldDev w, uint32_t cur_tick, const unsigned long long *gate_p, unsigned long long gate_target, int64_t now_ns) {
     if (!w.N) return false;
     if (g.ncell <= IDX_MAX_LDS_CELLS) {
         hipLaunchKernelGGL(k_index_hist, dim3(w.nblk), dim3(IDX_BLOCK), 4 * g.ncell * 4, st, w, g.ncell, cur_tick);
@@ -562,7 +588,7 @@ bool launch_index_build(hipStream_t st, DevGrid g, WorldDev w, uint32_t cur_tick
         hipLaunchKernelGGL(k_index_scan, dim3((g.ncell + 3) / 4), dim3(256), 0, st, w, g.ncell, !local_base);
         hipLaunchKernelGGL(k_index_scatter, dim3(w.nblk), dim3(IDX_BLOCK), (local_base ? 5 : 4) * g.ncell * 4, st, w,
                            g.ncell, bits_for(g.ncell), cur_tick, local_base, gate_p, gate_target);
-        if (w.cell_sorted) hipLaunchKernelGGL(k_cell_sort0, dim3(g.ncell), dim3(256), 0, st, w, g.ncell);
+        if (w.cell_sorted) hipLaunchKernelGGL(k_cell_sort0, dim3(g.ncell), dim3(256), 0, st, w, g.ncell, sort0_shift(w, now_ns));
         return gate_p != nullptr;
     } else {
         // nblk == 1 layout: blk_cnt[c] then scan -> cell_off; cursor lives behind it
@@ -577,7 +603,7 @@ bool launch_index_build(hipStream_t st, DevGrid g, WorldDev w, uint32_t cur_tick
         (void)hipMemcpyAsync(w.cell_off, w.blk_cnt, sizeof(uint32_t) * ((size_t)g.ncell + 1), hipMemcpyDeviceToDevice, st);
         hipLaunchKernelGGL(k_index_scatter_global, dim3((w.N + 255) / 256), dim3(256), 0, st, w, g.ncell, cursor,
                            cur_tick);
-        if (w.cell_sorted) hipLaunchKernelGGL(k_cell_sort0, dim3(g.ncell), dim3(256), 0, st, w, g.ncell);
+        if (w.cell_sorted) hipLaunchKernelGGL(k_cell_sort0, dim3(g.ncell), dim3(256), 0, st, w, g.ncell, sort0_shift(w, now_ns));
     }
     return false;
 }

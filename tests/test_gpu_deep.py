@@ -243,6 +243,34 @@ def test_max_fanout_interval_is_per_channel_beyond_512_elements(amd):
     ctl.close()
 
 
+def test_cells_in_arrival_order_give_the_same_records(amd, monkeypatch):
+    """CHD_SORT_ARRIVALS=1 (opt-in): every cell's entries in the order of the tick's arrival offsets, and a fan-out
+    window that lies inside the tick's own arrivals copied as a RUN of the cell's column instead of tested per entity.  The order
+    inside a cell is free (a connection's records are a multiset): records, handovers, subscription state equal the oracle's every
+    tick — 20 ms subscriptions on a 50 ms world (the windows the run form is for), stamps on and off the tick grid, ties in the
+    stamps, entities that skip ticks, cells beyond the 512-entry tile (2x2 grid: ~900 per cell) beside small ones (4x4)."""
+    monkeypatch.setenv("CHD_SORT_ARRIVALS", "1")
+    for cfg_name, N, S in (("spatial_static_4x4.json", 3000, 80), ("spatial_static_2x2.json", 3600, 40)):
+        cfg, sw, ctl, gw, ow = make_pair(amd, cfg_name, N, S, 64, 1 | 64, seed=0xD21)
+        rng = np.random.default_rng(21)
+        now = 0
+        total = 0
+        for k in range(24):
+            sw.step()
+            prev, now = now, now + (50 * MS if k % 3 else 47 * MS + int(rng.integers(0, 6 * MS)))
+            q = sw.queries()
+            upd = np.sort(rng.choice(N, N - N // 10, replace=False)).astype(np.uint32) if k % 5 == 4 else np.arange(N, dtype=np.uint32)
+            arr = rng.integers(prev + 1, now + 1, len(upd)).astype(np.int64)
+            arr[rng.random(len(upd)) < 0.02] = now                                  # on the tick's own stamp
+            arr[: len(upd) // 50] = prev + 1 + (now - prev) // 2                    # ties
+            ow.tick(now, upd, sw.x[upd], sw.z[upd], None, None, None, None, q, upd_arrival=arr)
+            res = gw.tick(now, upd_idx=upd, upd_x=sw.x[upd], upd_z=sw.z[upd], queries=q, upd_arrival_ns=arr, records_cap=1 << 23)
+            compare_tick(k, res, ow, S, check_pairs=range(0, S, 7), gw=gw)
+            total += res.n_records
+        assert total > 100_000
+        ctl.close()
+
+
 def test_a_short_buffer_says_what_it_dropped(amd):
     """history_depth smaller than what a window reaches back to: never silently short — history_overflow counts it."""
     N, S = 12, 2
