@@ -696,6 +696,12 @@ class SpatialWorld {
         kind.resize(n);
         return err(rc);
     }
+    // ctl.serverConnections (spatial.go:399-424): which ConnectionId is which spatial server — what SubscribeToChannel's DataAccess in
+    // the handover loop is derived from (WRITE for the entity channel's owner, spatial.go:812-817), and with it the `shouldSend` of a
+    // connection whose access the handover CHANGES (subscription.go:44-57).  Empty: no connection is an owner.
+    Error SetServerConnections(const std::vector<ConnectionId> &serverConnIds) {
+        return err(chd_world_set_server_connections(ctl_.ctx(), (uint32_t)serverConnIds.size(), serverConnIds.empty() ? nullptr : serverConnIds.data()));
+    }
     // ... and, per (recipient, entity of the handover), whether the message carries that entity's FULL state: the `shouldSend` of
     // spatial.go:797-857 (bit q of fullMask[r] = entity q of the handover's list, in message order)
     Error HandoverRecipientsEx(uint32_t nHandovers, std::vector<uint32_t> &offsets, std::vector<uint32_t> &conn, std::vector<uint8_t> &kind,

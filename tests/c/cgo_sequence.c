@@ -296,6 +296,23 @@ int main(void) {
     CHECK(total > 100000 && full_first == N_CONN && n_handovers > 0, "totals: %" PRIu64 " records, %" PRIu64 " first fan-outs, %" PRIu64 " handovers", total,
           full_first, n_handovers);
 
+    /* ---- ABI v9: which schedule the ticks took, the tick history's own overflow words, the server-connection table, the local
+     * "can this process take part in the library's collectives" question ---- */
+    {
+        chd_tick_stats st, hist[4];
+        OK(chd_get_tick_stats(ctx, &st));
+        CHECK(st.gate_timeouts == 0 && (st.schedule & ~(CHD_SCHED_OVERLAP_INTEREST | CHD_SCHED_GATED | CHD_SCHED_PIPELINED)) == 0, "schedule %#x, gate time-outs %u",
+              st.schedule, st.gate_timeouts);
+        OK(chd_get_tick_history(ctx, 4, hist));
+        for (int k = 0; k < 4; k++) CHECK(hist[k].overflow == 0 && hist[k].history_overflow == 0 && hist[k].n_records > 0, "tick history %d: overflow %#x", k, hist[k].overflow);
+        const uint32_t servers[4] = {901, 902, 903, 904}; /* the 4x4 grid of this program has 2x2 server regions */
+        OK(chd_world_set_server_connections(ctx, 4, servers));
+        CHECK(chd_world_set_server_connections(ctx, 3, servers) == CHD_E_INVAL, "a server table of the wrong size was accepted");
+        OK(chd_world_set_server_connections(ctx, 0, NULL));
+        const int avail = chd_shard_comm_available(); /* CHD_OK where librccl.so loads, CHD_E_STATE (with the loader's message) where not: never a hang */
+        CHECK(avail == CHD_OK || avail == CHD_E_STATE, "chd_shard_comm_available -> %d", avail);
+    }
+
     drop(px, 8 * N_ENT); drop(pz, 8 * N_ENT);
     OK(chd_host_free(ctx, ho));
     OK(chd_host_free(ctx, seg.segments));
