@@ -2212,6 +2212,12 @@ int chd_shard_spawn(chd_ctx *ctx, uint32_t n, const uint32_t *chan_id, const dou
     if (ctx->w.slot_mode == 1) return fail(ctx, CHD_E_STATE, "chd_shard_spawn on a world with caller-chosen slots (chd_world_spawn)");
     if (ctx->w.d.deep_depth && !ctx->w.d.log_on)
         return fail(ctx, CHD_E_STATE, "history_depth on a region-sharded world needs chd_world_cfg.shard_channels (the update log by channel id)");
+    if (ctx->w.d.ce_by_chan) {  // (tables by channel id: the log, the wire payloads — an id outside them would index past their ends)
+        const uint32_t eid0 = ctx->w.d.log_eid0, nch = ctx->w.cfg.shard_channels;
+        for (uint32_t i = 0; i < n; i++)
+            if (chan_id[i] < eid0 || chan_id[i] - eid0 >= nch)
+                return fail(ctx, CHD_E_INVAL, "chd_shard_spawn: channel id %#x outside entity_channel_id_start .. + shard_channels (%u)", chan_id[i], nch);
+    }
     ctx->w.slot_mode = 2;
     TRY(bind(ctx));
     TRY(ensure(ctx, 1, 4 * (size_t)n));
@@ -2746,7 +2752,7 @@ int pipe_group_end(chd_ctx *ctx) {
     for (auto &o : ops) HIPCHK(hipStreamSynchronize(o.st));  // (what is sent has been written; what is received into is no longer read)
     for (auto &o : ops) {
         if (!o.send) continue;
-        if (o.bytes > p.box_bytes) return fail(ctx, CHD_E_CAPACITY, "hostpipe: a message of %zu bytes, mailboxes hold %zu", o.bytes, p.box_bytes);
+        if (o.bytes + 8 > p.box_bytes) return fail(ctx, CHD_E_CAPACITY, "hostpipe: a message of %zu bytes, mailboxes hold %zu", o.bytes, p.box_bytes - 8);
         auto *h = p.hdr(p.rank, o.peer);
         const uint64_t n = p.sent[o.peer];
         if (!pipe_wait(h->read, n)) return fail(ctx, CHD_E_STATE, "hostpipe: rank %u never took message %llu of rank %u", o.peer, (unsigned long long)n, p.rank);
