@@ -382,9 +382,16 @@ def e2e_segment_ticks(world, sw_frames):
     buffers: per connection the segment descriptors + the cells' entity-channel columns + the explicit records of the few
     subscriptions that needed a per-entity decision — what a gateway walks while it writes its sockets."""
     out = []
+    # the INPUTS in page-locked memory too, written before the timed call: the shim's UpdateBatch collects a tick's updates there while
+    # the messages arrive (INTEGRATION 2), so chd_tick's uploads are real asynchronous DMA, not staged copies of pageable memory
+    px = pz = pq = None
     for (now, x, z, q) in sw_frames:
+        if px is None:
+            px, pz = world.host_array(len(x), np.float64), world.host_array(len(z), np.float64)
+            pq = world.host_array(len(q), q.dtype)
+        px[:], pz[:], pq[:] = x, z, q
         a = time.perf_counter()
-        res = world.tick(now, upd_x=x, upd_z=z, queries=q, want_records=False, pinned=True)
+        res = world.tick(now, upd_x=px, upd_z=pz, queries=pq, want_records=False, pinned=True)
         seg = world.fetch_segments(pinned=True)
         dt = time.perf_counter() - a
         assert res.overflow == 0 and seg["n_records"] == res.n_records
@@ -676,7 +683,8 @@ def main():
                 rs = rs[4:]
             med = sorted(rs, key=lambda v: v[0])[len(rs) // 2]
             e2e["segments"] = {
-                "what": "chd_tick(host pointers, no dense records) + chd_tick_fetch_segments into page-locked buffers: per connection the segment "
+                "host_to_device_bytes_per_tick": int(frames[0][1].nbytes + frames[0][2].nbytes + frames[0][3].nbytes),
+                "what": "chd_tick(host pointers in page-locked memory, no dense records) + chd_tick_fetch_segments into page-locked buffers: per connection the segment "
                         "descriptors + the cells' entity-channel columns + explicit records of the subscriptions that needed a per-entity decision; "
                         "the host expands while it writes its sockets (tests/test_gpu_fullsize.py expands them and compares digests)",
                 "ticks": len(rs), "ms_per_tick": 1e3 * med[0], "ms_per_tick_is": "median",
