@@ -49,7 +49,7 @@ SYMBOLS = (
     "chd_world_get_entities", "chd_dev_alloc", "chd_dev_free", "chd_dev_upload",
     "chd_dev_download", "chd_set_profiling", "chd_set_profiling_scope", "chd_world_set_pipelining", "chd_get_tick_stats", "chd_get_tick_history",
     "chd_set_stream", "chd_shard_spawn", "chd_shard_ingest", "chd_shard_import", "chd_shard_fanout",
-    "chd_shard_comm_available", "chd_shard_comm_unique_id", "chd_shard_comm_init", "chd_shard_comm_destroy", "chd_shard_tick", "chd_shard_set_handover_lists", "chd_shard_set_update_senders", "chd_shard_set_update_arrivals", "chd_shard_log_spawn", "chd_shard_migrate_extra_records", "chd_shard_ingest_pre", "chd_shard_ingest_post",
+    "chd_shard_comm_available", "chd_shard_comm_unique_id", "chd_shard_comm_init", "chd_shard_comm_destroy", "chd_shard_tick", "chd_shard_set_handover_lists", "chd_shard_set_update_senders", "chd_shard_set_update_arrivals", "chd_shard_log_spawn", "chd_shard_despawn", "chd_shard_migrate_extra_records", "chd_shard_ingest_pre", "chd_shard_ingest_post",
     "chd_shard_get_entities", "chd_shard_halo_layout", "chd_shard_interest",
     "chd_handover_recipients", "chd_adjacent_recipients", "chd_wire_set_payloads", "chd_wire_build", "chd_wire_build_info", "chd_wire_fetch",
     "chd_tick_digest", "chd_tick_fetch_segments", "chd_host_alloc", "chd_host_free", "chd_subs_set_options", "chd_subs_get_options", "chd_world_set_entity_groups", "chd_world_set_handover_lists", "chd_wire_set_type_url", "chd_wire_set_merge_schema", "chd_handover_messages",
@@ -252,6 +252,7 @@ def load():
     L.chd_shard_set_update_senders.argtypes = [C.c_void_p, _vp, C.c_uint32]
     L.chd_shard_set_update_arrivals.argtypes = [C.c_void_p, _vp, C.c_uint32]
     L.chd_shard_log_spawn.argtypes = [C.c_void_p, C.c_uint32, _u32p, _f64p, _f64p]
+    L.chd_shard_despawn.argtypes = [C.c_void_p, C.c_uint32, _u32p]
     L.chd_shard_migrate_extra_records.argtypes = [C.c_void_p, P(C.c_uint32)]
     L.chd_shard_ingest_pre.argtypes = [C.c_void_p, C.c_int64, _vp, _vp, _vp, C.c_uint32, C.c_uint32, C.c_uint32, _vp, C.c_uint32]
     L.chd_shard_ingest_post.argtypes = [C.c_void_p, _vp, C.c_uint32, C.c_uint32, C.c_uint32, _vp, C.c_uint32, C.POINTER(C.c_uint32)]

@@ -2239,6 +2239,23 @@ int chd_shard_spawn(chd_ctx *ctx, uint32_t n, const uint32_t *chan_id, const dou
     return CHD_OK;
 }
 
+int chd_shard_despawn(chd_ctx *ctx, uint32_t n, const uint32_t *chan_id) {
+    NEED_WORLD();
+    if (!n) return CHD_OK;
+    if (!chan_id) return fail(ctx, CHD_E_INVAL, "chd_shard_despawn: NULL ids");
+    std::lock_guard<FairMutex> lk(ctx->mu);
+    if (ctx->w.slot_mode == 1) return fail(ctx, CHD_E_STATE, "chd_shard_despawn on a world with caller-chosen slots (chd_world_despawn)");
+    TRY(bind(ctx));
+    std::vector<uint32_t> gone(chan_id, chan_id + n);
+    std::sort(gone.begin(), gone.end());
+    TRY(ensure(ctx, 1, 4 * (size_t)n));
+    TRY(up(ctx, sbuf<void>(ctx, 1), gone.data(), 4 * (size_t)n));
+    launch_shard_despawn(ctx->stream, ctx->w.d, sbuf<uint32_t>(ctx, 1), n);
+    TRY(after_launch(ctx));
+    HIPCHK(hipStreamSynchronize(ctx->stream));  // (the staging vector goes out of scope)
+    return CHD_OK;
+}
+
 // records behind each emigrant segment's (cap + 1): the sender's maxFanOutIntervalMs per cell, 8 cells per 32-byte record (log_on)
 static uint32_t migrate_extra(const chd_ctx *ctx) { return ctx->w.d.log_on ? (ctx->g.ncell + 7u) / 8u : 0u; }
 
@@ -2498,6 +2515,14 @@ static int shard_fanout_locked(chd_ctx *ctx, const void *d_halo_recv, uint32_t w
     }
     // the neighbours' border bands join the own tables as ghost entries: ONE local table over region + halo, so the
     // fan-out takes the same kernels (and fast paths) as on a single GPU
+    // the spatial channels' OWN updates (a cell's entity map changed: spawn, destroy, handover — ChannelData.OnUpdate on the spatial
+    // channel, data.go:149-173): per-cell state, so every rank applies the same list (the cells a rank fans out are its region's and
+    // its neighbours' border cells alike); given in d_in like chd_tick_device's
+    if (d_in->n_cell_updates) {
+        if (!d_in->cell_upd_channel || !d_in->cell_upd_sender) return fail(ctx, CHD_E_INVAL, "chd_shard_fanout: NULL cell updates");
+        if (!d.deep_depth && d_in->cell_upd_arrival_ns) return fail(ctx, CHD_E_STATE, "chd_shard_fanout: arrival stamps need a world with history_depth > 0");
+        launch_cell_updates(st, ctx->g, d, d_in->n_cell_updates, d_in->cell_upd_channel, d_in->cell_upd_sender, r.cur_tick, d_in->cell_upd_arrival_ns, now);
+    }
     d.seg_off = 0;
     W.last_desc = fanout_seg_path(d);
     launch_halo_unpack(st, ctx->g, d, world > 1 ? W.halo_rank : 0u, world, ctx->g.border, (const unsigned char *)d_halo_recv,

@@ -447,6 +447,7 @@ void launch_spawn_auto(hipStream_t st, DevGrid g, WorldDev w, uint32_t n, const 
                        const double *x, const double *z, const uint32_t *flags, const uint32_t *sender,
                        uint32_t cur_tick);
 void launch_free_stack_init(hipStream_t st, WorldDev w);
+void launch_shard_despawn(hipStream_t st, WorldDev w, const uint32_t *gone_sorted, uint32_t n);
 void launch_slot_of_rebuild(hipStream_t st, WorldDev w);  // sh_slot_of from the live slots' channel ids
 // the update log by channel (WorldDev::log_on): note the channels that come to life; push this tick's updates of EVERY channel
 void launch_log_spawn(hipStream_t st, DevGrid g, WorldDev w, uint32_t n, const uint32_t *chan_id, const double *x, const double *z);

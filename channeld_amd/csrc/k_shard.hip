@@ -87,6 +87,43 @@ void launch_spawn_auto(hipStream_t st, DevGrid g, WorldDev w, uint32_t n, const 
                        sender, cur_tick);
 }
 
+// chd_shard_despawn: the entity channels of the (ascending) list `gone` leave the world — the slot that holds one on this rank is freed,
+// its update log (log_on) is closed, an immigrant still waiting in limbo is dropped from the list (its state record is blanked).
+__device__ __forceinline__ bool in_sorted(const uint32_t *__restrict__ a, uint32_t n, uint32_t v) {
+    uint32_t lo = 0, hi = n;
+    while (lo < hi) {
+        const uint32_t mid = (lo + hi) >> 1;
+        if (a[mid] == v) return true;
+        if (a[mid] < v) lo = mid + 1; else hi = mid;
+    }
+    return false;
+}
+
+__global__ void __launch_bounds__(256) k_shard_despawn(WorldDev w, const uint32_t *__restrict__ gone, uint32_t n) {
+    const uint32_t t = blockIdx.x * 256u + threadIdx.x;
+    if (t < w.N && (w.eflags[t] & EF_ALIVE) && in_sorted(gone, n, w.chan_id[t])) {
+        note_slot(w, w.chan_id[t], CHD_INVALID);
+        w.eflags[t] = 0;
+        w.member[t] = CHD_INVALID;
+        w.cell[t] = CHD_INVALID;
+        const int32_t f = atomicAdd(w.free_top, 1);
+        w.free_stack[f] = t;
+    }
+    if (t < n && w.log_on) {
+        const uint32_t u = gone[t] - w.log_eid0;
+        if (u < w.log_n) { w.log_alive[u] = 0; w.log_cell[u] = CHD_INVALID; }
+    }
+    if (w.limbo)
+        for (uint32_t b = 0; b < 2; b++)
+            for (uint32_t q = t; q < min(w.limbo_n[b], w.N); q += gridDim.x * 256u)
+                if (in_sorted(gone, n, w.limbo[(size_t)b * w.N + q].chan_id)) w.limbo[(size_t)b * w.N + q].chan_id = CHD_INVALID;
+}
+
+void launch_shard_despawn(hipStream_t st, WorldDev w, const uint32_t *gone, uint32_t n) {
+    if (!n) return;
+    hipLaunchKernelGGL(k_shard_despawn, dim3(nblocks(std::max(w.N, n), 256)), dim3(256), 0, st, w, gone, n);
+}
+
 // Same decision as k_ingest (spatial.go:612-626,675-679,703-736), one thread per slot.
 __global__ void __launch_bounds__(256) k_ingest_by_channel(DevGrid g, WorldDev w,
                                                            const double *__restrict__ xs,
@@ -333,6 +370,7 @@ __global__ void __launch_bounds__(256) k_import(WorldDev w, const chd_entity_sta
         const uint32_t n = min(w.limbo_n[cb], w.N);
         for (uint32_t q = k; q < n; q += gridDim.x * 256u) {
             chd_entity_state e = w.limbo[(size_t)cb * w.N + q];
+            if (e.chan_id == CHD_INVALID) continue;  // (despawned while it waited: chd_shard_despawn)
             // (the histories were aligned to the tick of the export and have aged one tick per tick in limbo)
             e.hist <<= 1; e.hist_prev <<= 1;
             const uint32_t i = pop_slot(w);

@@ -327,8 +327,21 @@ class HipShardEngine:
         self.native = True
         return None
 
-    def tick_native(self, now_ns: int, x_by_chan, z_by_chan, queries=None, n_queries: int = 0, has_update=None):
+    @staticmethod
+    def _set_cell_updates(ti, cell_updates):
+        """cell_updates: None or (channel ids, senders[, arrival ns]) as int32 / int32 / int64 DEVICE tensors — the spatial channels' own
+        updates of this tick, the same whole-world list on every rank"""
+        if cell_updates is None or not int(cell_updates[0].numel()):
+            ti.n_cell_updates, ti.cell_upd_channel, ti.cell_upd_sender, ti.cell_upd_arrival_ns = 0, None, None, None
+            return
+        ti.n_cell_updates = int(cell_updates[0].numel())
+        ti.cell_upd_channel, ti.cell_upd_sender = cell_updates[0].data_ptr(), cell_updates[1].data_ptr()
+        ti.cell_upd_arrival_ns = cell_updates[2].data_ptr() if len(cell_updates) > 2 and cell_updates[2] is not None else None
+
+    def tick_native(self, now_ns: int, x_by_chan, z_by_chan, queries=None, n_queries: int = 0, has_update=None, cell_updates=None):
         ti = self._ti_native
+        self._set_cell_updates(ti, cell_updates)
+        self._cell_updates = cell_updates
         if queries is not None and n_queries:
             ti.n_queries, ti.queries = int(n_queries), queries.data_ptr()
         else:
@@ -358,6 +371,13 @@ class HipShardEngine:
 
     def add_subscribers(self, conn_ids):
         self.sw.add_subscribers(None, conn_ids)
+
+    def despawn(self, chan_id):
+        """chd_shard_despawn: EVERY rank, the entity channels that leave the world."""
+        from .controller import _ptr, _u32
+
+        ch = _u32(chan_id)
+        self._lib.check(self.ctx, self.lib.chd_shard_despawn(self.ctx, len(ch), _ptr(ch)))
 
     def log_spawn(self, chan_id, x, z):
         """chd_shard_log_spawn: EVERY rank, the whole world's new entity channels and where they appear (update log by channel)."""
@@ -452,8 +472,10 @@ class HipShardEngine:
             self._lib.check(self.ctx, rc)
         self.sw._last_nq = int(n_queries)
 
-    def fanout(self, halo_recv):
+    def fanout(self, halo_recv, cell_updates=None):
         self._halo_recv = halo_recv
+        self._set_cell_updates(self._ti_fanout, cell_updates)
+        self._cell_updates = cell_updates
         rc = self.lib.chd_shard_fanout(self.ctx, C.c_void_p(halo_recv.data_ptr()), self.world, self._r_fanout)
         if rc:
             self._lib.check(self.ctx, rc)
@@ -481,10 +503,10 @@ class ShardedWorld:
     def __init__(self, engine, comm: Comm):
         self.engine, self.comm = engine, comm
 
-    def tick(self, now_ns: int, x_by_chan, z_by_chan, queries=None, n_queries: int = 0, has_update=None):
+    def tick(self, now_ns: int, x_by_chan, z_by_chan, queries=None, n_queries: int = 0, has_update=None, cell_updates=None):
         eng, comm = self.engine, self.comm
         if getattr(eng, "native", False):  # the library's own RCCL communicator: the whole tick is one C call
-            eng.tick_native(now_ns, x_by_chan, z_by_chan, queries, n_queries, has_update)
+            eng.tick_native(now_ns, x_by_chan, z_by_chan, queries, n_queries, has_update, cell_updates)
             return
         if getattr(eng, "lists_on", False) and comm.active and eng.world > 1:
             # handover lists: handovers that concern another rank's entity map travel there first (chd_shard_ingest_pre / _post)
@@ -498,7 +520,10 @@ class ShardedWorld:
         # the interest updates do not read the neighbours' tables: they run under the halo exchange
         halo_recv = comm.halo_exchange(halo_send, send_splits, recv_splits, peer_off,
                                        overlap=lambda: eng.interest(queries, n_queries))
-        eng.fanout(halo_recv)
+        if cell_updates is not None:
+            eng.fanout(halo_recv, cell_updates)
+        else:
+            eng.fanout(halo_recv)
 
 
 # ---------------------------------------------------------------------------

@@ -580,6 +580,11 @@ typedef struct {
 int chd_shard_spawn(chd_ctx *ctx, uint32_t n, const uint32_t *chan_id, const double *x,
                     const double *z, const uint32_t *flags, const uint32_t *sender);
 
+/* The entity channels `chan_id` leave the world (RemoveChannel of an entity channel: the entity is destroyed): whichever rank holds one
+ * frees its slot; on worlds with an update log by channel id the channel's log is closed (a later chd_shard_log_spawn of the same id
+ * starts an empty one).  EVERY rank is given the same list, between two ticks.  chd_world_despawn on unsharded worlds. */
+int chd_shard_despawn(chd_ctx *ctx, uint32_t n, const uint32_t *chan_id);
+
 /* Phase 1.  Starts tick `now_ns`.  Every live entity e of this rank reads its new
  * position from d_x_by_chan/d_z_by_chan[e.chan_id - entity_channel_id_start]
  * (d_has_update, if not NULL, marks which channels carry an update this tick) and goes
@@ -631,8 +636,11 @@ int chd_shard_import(chd_ctx *ctx, const chd_entity_state *d_recv, uint32_t worl
 int chd_shard_interest(chd_ctx *ctx, const chd_tick_in *d_in);
 
 /* Phase 3, after the halo all-to-all: the received bands (d_halo_recv, chd_shard_halo_layout) join the own cell tables
- * as ghost entries; then the interest updates of d_in (queries of this rank's connections; the update fields of d_in
- * are ignored) and the fan-out of this rank's connections over region + halo.  Outputs as chd_tick_device. */
+ * as ghost entries; then the interest updates of d_in (queries of this rank's connections) and the fan-out of this rank's
+ * connections over region + halo.  Of d_in's update fields the ENTITY updates are ignored (they came by channel id with
+ * chd_shard_ingest); the SPATIAL CHANNELS' own updates (n_cell_updates, cell_upd_channel / _sender / _arrival_ns: device arrays) are
+ * applied — per-cell state that every rank keeps for every cell, so EVERY rank is given the same, whole-world list (a cell's
+ * subscribers live on its owner's rank and on the neighbours whose border it is).  Outputs as chd_tick_device. */
 int chd_shard_fanout(chd_ctx *ctx, const void *d_halo_recv, uint32_t world, const chd_tick_in *d_in);
 
 /* Who SENT the updates (senderConnId of data.go:159-164; SkipSelfUpdateFanOut compares it, data.go:242-245): a DEVICE array indexed

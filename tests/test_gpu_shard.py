@@ -34,7 +34,7 @@ from shard_lists import make_lists, one_handover_per_group_and_tick  # noqa: E40
 
 
 def run_rank(rank, world, port, N, S, ticks, seed, out, cfg_name=None, halo=64, jump_frac=0.15, aoi_scale=1.0, lists=False, senders=False, exact=0,
-             pipe=False, wflags=0, wire=False):
+             pipe=False, wflags=0, wire=False, cellupd=False, despawn=False):
     """exact != 0 (= the world's emit flags): exact update buffers on the sharded world — history_depth 1024, the update log by
     channel id on every rank (chd_world_cfg.shard_channels), per-update arrival stamps anywhere inside the tick's interval
     (chd_shard_set_update_arrivals), and three connections that lose access at tick 8 and get it back twelve ticks before the end:
@@ -43,7 +43,11 @@ def run_rank(rank, world, port, N, S, ticks, seed, out, cfg_name=None, halo=64, 
     (CHD_SHARD_TRANSPORT=hostpipe: shared-memory mailboxes between the rank processes; RCCL refuses two ranks on one device), the
     unique id carried by gloo as a gateway's control connection would; wflags: world flags (16 | 512 = the gated overlap).
     wire: CHD_WORLD_WIRE on the sharded world — payloads keyed by channel id on every rank; every connection's byte stream must
-    equal what oracle/wire.py makes of that connection's records (the rank's own, in its order) and the payloads."""
+    equal what oracle/wire.py makes of that connection's records (the rank's own, in its order) and the payloads.
+    cellupd: the spatial channels' own updates (three random cells per tick, alternating senders, one of them a client connection
+    that then skips its own), the same list on every rank.
+    despawn: after tick 3 every seventh entity channel leaves the world (chd_shard_despawn, every rank the same list); after tick 6
+    half of them come back where their channel's position now is (chd_shard_spawn on that rank, chd_shard_log_spawn everywhere)."""
     import torch
     import torch.distributed as dist
 
@@ -118,7 +122,9 @@ def run_rank(rank, world, port, N, S, ticks, seed, out, cfg_name=None, halo=64, 
         if senders:  # who sends an entity's updates changes over time: its spawn-time owner, then a CLIENT connection (which then skips its own)
             d_snd = torch.zeros(N, dtype=torch.int32, device=dev)
             eng.set_update_senders(d_snd)
+        dead = set()
         for k, (x, z, q, now) in enumerate(frames):
+            dead_before = len(dead)
             snd = None
             if senders:
                 snd = np.where((np.arange(N) + k // 3) % 2 == 0, sw.sender, sw.sub_conn[np.arange(N) % S]).astype(np.uint32)
@@ -141,8 +147,17 @@ def run_rank(rank, world, port, N, S, ticks, seed, out, cfg_name=None, halo=64, 
                 upd = {u: bytes(urng.integers(0, 256, int(urng.integers(0, 100)), dtype=np.uint8)) for u in range(N)}
                 pay["ent"][0].update(upd)
                 eng.sw.wire_set_payloads(0, list(upd), list(upd.values()))
+            cu = cus = cua = d_cu = None
+            if cellupd:
+                crng = np.random.default_rng((seed << 8) ^ (k + 7000))
+                ncell_all = g.cols * g.rows
+                cu = (0x10000 + crng.choice(ncell_all, min(3, ncell_all), replace=False)).astype(np.uint32)
+                cus = crng.choice([5, 6, int(sw.sub_conn[k % S])], len(cu)).astype(np.uint32)
+                if exact:
+                    cua = np.sort(crng.integers(prev_now + 1, now + 1, len(cu))).astype(np.int64)
+                d_cu = (torch.from_numpy(cu.view(np.int32)).to(dev), torch.from_numpy(cus.view(np.int32)).to(dev)) + ((torch.from_numpy(cua).to(dev),) if exact else ())
             dq = torch.from_numpy(np.ascontiguousarray(q[my_subs]).view(np.uint8)).to(dev)
-            sworld.tick(now, torch.from_numpy(x).to(dev), torch.from_numpy(z).to(dev), dq, len(my_subs))
+            sworld.tick(now, torch.from_numpy(x).to(dev), torch.from_numpy(z).to(dev), dq, len(my_subs), cell_updates=d_cu)
             res = eng.fetch(want_records=True, records_cap=1 << 22)
             if wire:
                 nbytes, npackets, ndropped = eng.sw.wire_build()
@@ -176,9 +191,24 @@ def run_rank(rank, world, port, N, S, ticks, seed, out, cfg_name=None, halo=64, 
                         chs = eng.sw.subscriptions(int(loc[0]))[0]
                         eng.sw.set_sub_options(now, [dict(slot=int(loc[0]), channel=int(c), data_access=access) for c in chs])
             prev_now = now
+            if despawn and k in (3, 6):  # (between two ticks, every rank alike)
+                gone = np.arange(3, N, 7)
+                if k == 3:
+                    eng.despawn(sw.chan_id[gone])
+                    dead = set(int(i) for i in gone)
+                else:
+                    back = gone[::2]
+                    bid = orc.channel_ids(g, x[back], z[back])
+                    bown = np.where(bid == 0, 0, server_of_cell(cfg, np.where(bid == 0, 0, bid - 0x10000)))
+                    if exact:
+                        eng.log_spawn(sw.chan_id[back], x[back], z[back])
+                    m = back[bown == rank]
+                    eng.spawn(sw.chan_id[m], x[m], z[m], sw.flags[m], sw.sender[m])
+                    dead -= set(int(i) for i in back)
             if rank != 0:
                 continue
-            ow.tick(now, None, x, z, snd, None, None, None, q, **(dict(upd_arrival=arr) if exact else {}))
+            ow.tick(now, None, x, z, snd, None if cu is None else cu - 0x10000, cus, None, q,
+                    **(dict(upd_arrival=arr, **({} if cua is None else dict(cu_arrival=cua))) if exact else {}))
             if exact and (k == 8 or k == ticks - 12):
                 for b in blocked:
                     for c in ow.pairs(b)[0]:
@@ -216,7 +246,8 @@ def run_rank(rank, world, port, N, S, ticks, seed, out, cfg_name=None, halo=64, 
             ocell, omember = ow.entity_state()
             to_id = lambda a: np.where(a == 0xFFFFFFFF, 0, a + 0x10000).astype(np.uint32)
             chans = np.concatenate([s["ent"][0] for s in gathered])
-            assert len(chans) == N and len(np.unique(chans)) == N, f"tick {k}: entity lost or duplicated"
+            n_alive = N - dead_before
+            assert len(chans) == n_alive and len(np.unique(chans)) == n_alive, f"tick {k}: entity lost or duplicated"
             for r, s in enumerate(gathered):
                 i = (s["ent"][0] - 0x80000).astype(np.int64)
                 assert np.array_equal(s["ent"][1], to_id(ocell)[i]) and np.array_equal(s["ent"][2], to_id(omember)[i])
@@ -224,6 +255,12 @@ def run_rank(rank, world, port, N, S, ticks, seed, out, cfg_name=None, halo=64, 
                 assert (server_of_cell(cfg, s["ent"][2][inw] - 0x10000) == r).all(), f"tick {k}: entity on the wrong rank"
             total += len(oc)
             cross += int((ssrc != sdst).sum())
+            if despawn and k in (3, 6):  # (the single world follows, between the same two ticks)
+                if k == 3:
+                    for i in gone:
+                        ow.despawn(int(i))
+                else:
+                    ow.spawn(back, sw.chan_id[back], x[back], z[back], sw.flags[back], sw.sender[back])
         if rank == 0:
             out.put(("ok", total, cross))
     except Exception as e:
@@ -237,13 +274,13 @@ def run_rank(rank, world, port, N, S, ticks, seed, out, cfg_name=None, halo=64, 
 
 
 def launch(world, N, S, ticks, seed, cfg_name=None, halo=64, jump_frac=0.15, aoi_scale=1.0, lists=False, senders=False, exact=0, timeout=300, pipe=False, wflags=0,
-           wire=False):
+           wire=False, cellupd=False, despawn=False):
     import torch.multiprocessing as mp
 
     ctx = mp.get_context("spawn")
     out = ctx.Queue()
     port = free_port()
-    procs = [ctx.Process(target=run_rank, args=(r, world, port, N, S, ticks, seed, out, cfg_name, halo, jump_frac, aoi_scale, lists, senders, exact, pipe, wflags, wire)) for r in range(world)]
+    procs = [ctx.Process(target=run_rank, args=(r, world, port, N, S, ticks, seed, out, cfg_name, halo, jump_frac, aoi_scale, lists, senders, exact, pipe, wflags, wire, cellupd, despawn)) for r in range(world)]
     for p in procs:
         p.start()
     for p in procs:
@@ -347,6 +384,27 @@ def test_wire_buffers_on_region_sharded_worlds(world, pipe):
     MessagePack{channelId, msgType 8, ChannelDataUpdateMessage{Any}}) — and the records equal the single world's, as in every
     test of this file — while 15 % of the entities change regions every tick."""
     total, cross = launch(world, 1500, 48, 8, 0xC0FFEE70 + world, wire=True, pipe=pipe, timeout=600)
+    assert total > 0 and (cross > 0 or world == 1)
+
+
+@pytest.mark.parametrize("world,kw", [(2, dict()), (2, dict(exact=1 | 64)), (4, dict(pipe=True, wflags=16 | 512))], ids=["2-ranks", "2-ranks-exact", "4-ranks-native-tick-gated"])
+def test_spatial_channels_own_updates_on_sharded_worlds(world, kw):
+    """A spatial channel's own data changes too (its entity map: spawn, destroy, handover — ChannelData.OnUpdate on the spatial channel)
+    and fans out to the cell's subscribers, who live on its owner's rank AND on the neighbours whose border cell it is.  The cells'
+    update state is kept for every cell on every rank; every rank is given the tick's whole-world list (chd_shard_fanout /
+    chd_shard_tick: d_in's cell-update fields).  Three random cells per tick, one of the senders a client connection (which skips its
+    own update), on exact worlds with arrival stamps: records equal the single-world oracle's fed the same list."""
+    total, cross = launch(world, 3000, 80, 10, 0xC0FFEE90 + world, cellupd=True, timeout=600, **kw)
+    assert total > 0 and cross > 0
+
+
+@pytest.mark.parametrize("world,kw", [(1, dict()), (2, dict()), (2, dict(exact=1 | 64))], ids=["1-rank", "2-ranks", "2-ranks-exact"])
+def test_entity_channels_leave_and_come_back_on_sharded_worlds(world, kw):
+    """chd_shard_despawn: every seventh entity channel is destroyed after tick 3 (whichever rank holds it frees its slot; with the
+    update log by channel id the channel's log is closed), half of them are created again after tick 6 where their positions then are
+    (possibly on another rank, with an EMPTY update buffer) — records, handovers, entity placement and the entity count over all
+    ranks equal the single-world oracle's despawn / spawn every tick."""
+    total, cross = launch(world, 3000, 80, 10, 0xC0FFEEA0 + world, despawn=True, timeout=600, **kw)
     assert total > 0 and (cross > 0 or world == 1)
 
 
