@@ -826,6 +826,8 @@ class ShardWorld {
         check(chd_shard_spawn(ctl_.ctx(), (uint32_t)entityChannelIds.size(), entityChannelIds.data(), x.data(), z.data(),
                               flags.empty() ? nullptr : flags.data(), owner.empty() ? nullptr : owner.data()));
     }
+    // entity channels that leave the world (every rank: the same list; whichever rank holds one frees its slot)
+    void Despawn(const std::vector<ChannelId> &entityChannelIds) { check(chd_shard_despawn(ctl_.ctx(), (uint32_t)entityChannelIds.size(), entityChannelIds.data())); }
     void AddSubscribers(const std::vector<ConnectionId> &conn) { check(chd_subs_add(ctl_.ctx(), (uint32_t)conn.size(), nullptr, conn.data())); }
     // who sends each channel's updates (device array by channel id; nullptr: the spawn-time owner, which migrates with the entity)
     void SetUpdateSenders(const uint32_t *dSenderByChan, uint32_t nChan) { check(chd_shard_set_update_senders(ctl_.ctx(), dSenderByChan, nChan)); }

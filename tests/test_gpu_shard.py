@@ -152,7 +152,8 @@ def run_rank(rank, world, port, N, S, ticks, seed, out, cfg_name=None, halo=64, 
                 crng = np.random.default_rng((seed << 8) ^ (k + 7000))
                 ncell_all = g.cols * g.rows
                 cu = (0x10000 + crng.choice(ncell_all, min(3, ncell_all), replace=False)).astype(np.uint32)
-                cus = crng.choice([5, 6, int(sw.sub_conn[k % S])], len(cu)).astype(np.uint32)
+                # (ring worlds keep two senders per channel inside the 32-tick horizon — a third is history_overflow, there as on one GPU —; exact worlds any number)
+                cus = crng.choice([5, 6, int(sw.sub_conn[k % S])] if exact else [5, int(sw.sub_conn[0])], len(cu)).astype(np.uint32)
                 if exact:
                     cua = np.sort(crng.integers(prev_now + 1, now + 1, len(cu))).astype(np.int64)
                 d_cu = (torch.from_numpy(cu.view(np.int32)).to(dev), torch.from_numpy(cus.view(np.int32)).to(dev)) + ((torch.from_numpy(cua).to(dev),) if exact else ())
