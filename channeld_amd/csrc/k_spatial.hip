@@ -603,7 +603,9 @@ __global__ void __launch_bounds__(256) k_cell_updates(DevGrid g, WorldDev w, uin
     }
     if (touched && w.deep_depth) {
         w.cdeep_n[c] = dn; w.cdeep_len[c] = dlen; w.cdeep_drop[c] = ddrop;
-        if (irregular) w.cell_irr_tick[c] = cur_tick + 1u;
+        // (cell_irr as well: on region-sharded worlds the spatial channels' updates arrive behind the index build, which is where the
+        // flag is otherwise raised from cell_irr_tick)
+        if (irregular) { w.cell_irr_tick[c] = cur_tick + 1u; w.cell_irr[c] = 1u; }
         if (w.off_on) {
             w.cell_ooff[2 * (size_t)c] = make_uint4(oo[0], oo[1], oo[2], oo[3]);
             w.cell_ooff[2 * (size_t)c + 1] = make_uint4(oo[4], oo[5], oo[6], oo[7]);
