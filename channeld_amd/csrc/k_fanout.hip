@@ -926,7 +926,7 @@ struct OffPlan {
 
 __device__ __forceinline__ void plan_windows_off(const WorldDev &w, const TickRing &ring, int64_t now, int64_t L, int64_t I, uint32_t c,
                                                  uint32_t hand, uint32_t chh, uint32_t chs, uint32_t chhp, uint32_t chsp, bool skip_self,
-                                                 uint32_t conn, FiltWin *__restrict__ fwout, OffPlan &o) {
+                                                 uint32_t conn, FiltWin *__restrict__ fwout, OffPlan &o, uint32_t cell_age) {
     o.nw = 0; o.own = 0; o.need = false; o.deep = false; o.Lw = L;
 #pragma unroll
     for (int k = 0; k < 4; k++) o.full[k] = 0;
@@ -936,7 +936,11 @@ __device__ __forceinline__ void plan_windows_off(const WorldDev &w, const TickRi
     const uint4 q0 = w.cell_ooff[2 * (size_t)c], q1 = w.cell_ooff[2 * (size_t)c + 1];
     const uint32_t rmin[CHD_OFF_SLOTS] = {r0.x, r0.z, r1.x, r1.z, r2.x, r2.z, r3.x, r3.z};
     const uint32_t rmax[CHD_OFF_SLOTS] = {r0.y, r0.w, r1.y, r1.w, r2.y, r2.w, r3.y, r3.w};
-    const uint32_t coff[CHD_OFF_SLOTS] = {q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w};
+    // (the spatial channel's offsets are stored aligned to the tick of ITS last update, like its history bits: moved on to this tick —
+    // round 4 compared them unaligned, which delivered a cell's update of tick t - 1 once more at tick t to every window that starts
+    // exactly at t - 1 whenever the cell had no update at t; found by the sharded worlds' cell-update test, wrong on one GPU as well)
+    uint32_t coff[CHD_OFF_SLOTS] = {q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w};
+    off_shift(coff, cell_age < CHD_OFF_SLOTS ? cell_age : CHD_OFF_SLOTS);
     const int64_t nwin = (now - L) / I;
     if (nwin > 64) { o.deep = true; return; }  // (a long catch-up: the element walk handles any number of windows)
     int64_t Lw = L;
@@ -1095,7 +1099,7 @@ __global__ void __launch_bounds__(64 * FO_WAVES) k_fanout_plan_seg(DevGrid g, Wo
                     // the walk against the real arrival stamps; wms = the slots each window covers whole
                     const uint32_t age = ring.cur_tick - c_htick;
                     const uint32_t chh = age < CHD_HIST_BITS ? (c_hist << age) : 0u, chhp = age < CHD_HIST_BITS ? (c_hprev << age) : 0u;
-                    plan_windows_off(w, ring, now, Lw, I, c, hand, chh, chs, chhp, chsp, skip_self, conn, w.filt_win + (pbase + p) * CHD_FILT_WINS, op);
+                    plan_windows_off(w, ring, now, Lw, I, c, hand, chh, chs, chhp, chsp, skip_self, conn, w.filt_win + (pbase + p) * CHD_FILT_WINS, op, age);
                     Lw = op.Lw;
                     nw = op.nw;
 #pragma unroll

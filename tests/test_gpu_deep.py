@@ -243,6 +243,35 @@ def test_max_fanout_interval_is_per_channel_beyond_512_elements(amd):
     ctl.close()
 
 
+def test_a_spatial_channels_own_update_is_delivered_once(amd):
+    """A spatial channel's own update (its entity map changed) with an enqueue-time stamp, on the descriptor path with sub-tick
+    offsets (flags 1 | 64): ONE sender, so the channel stays regular and the plan — not the element walk — decides from the
+    channel's offsets, which are stored aligned to the tick of its last update.  Round 4 compared them unaligned: a cell updated at
+    tick t - 1 and not at t was delivered once more at t to every window starting exactly at t - 1 (every 50 ms subscription on a
+    50 ms world).  Two random cells per tick, some ticks none, 50 ms ticks: records equal the oracle's every tick."""
+    N, S = 600, 32
+    cfg, sw, ctl, gw, ow = make_pair(amd, "spatial_static_4x4.json", N, S, 64, 1 | 64, seed=0xD31)
+    rng = np.random.default_rng(31)
+    now = 0
+    own = 0
+    for k in range(24):
+        sw.step()
+        prev, now = now, now + 50 * MS
+        q = sw.queries()
+        arr = rng.integers(prev + 1, now + 1, N).astype(np.int64)
+        ncu = 0 if k % 5 == 4 else 2
+        cu = (0x10000 + rng.choice(16, ncu, replace=False)).astype(np.uint32)
+        cus = np.full(ncu, 5, dtype=np.uint32)
+        cua = np.sort(rng.integers(prev + 1, now + 1, ncu)).astype(np.int64)
+        ow.tick(now, None, sw.x, sw.z, None, cu - 0x10000, cus, None, q, upd_arrival=arr, cu_arrival=cua)
+        res = gw.tick(now, upd_x=sw.x, upd_z=sw.z, cell_upd_channel=cu, cell_upd_sender=cus, queries=q, upd_arrival_ns=arr,
+                      cell_upd_arrival_ns=cua, records_cap=1 << 22)
+        compare_tick(k, res, ow, S, check_pairs=range(0, S, 6), gw=gw)
+        own += int((res.records["channel"] < 0x80000).sum())
+    assert own > 500  # (the spatial channels' own messages were there to be counted)
+    ctl.close()
+
+
 def test_cells_in_arrival_order_give_the_same_records(amd, monkeypatch):
     """CHD_SORT_ARRIVALS=1 (opt-in): every cell's entries in the order of the tick's arrival offsets, and a fan-out
     window that lies inside the tick's own arrivals copied as a RUN of the cell's column instead of tested per entity.  The order
