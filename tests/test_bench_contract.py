@@ -185,3 +185,20 @@ def test_gpu_state_sampler_reads_the_hwmon_files(tmp_path, monkeypatch):
     with bench.GpuStateSampler() as s2:
         pass
     assert s2.summary() is None
+
+
+def test_at_least_six_launches_are_timed_at_any_step_count():
+    """the driver runs --steps 20; the roofline's duration must not rest on three launches.  prof_every_for picks
+    the stride of the HIP event pairs: odd (the workload alternates heavy and light ticks), 7 at the default 200 steps, and never
+    fewer than six timed launches once there are six steps."""
+    import importlib.util
+    import os
+
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "bench.py"))
+    b = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(b)
+    for steps in list(range(1, 60)) + [100, 200, 1000]:
+        e = b.prof_every_for(steps)
+        timed = len([t for t in range(steps) if t % e == 0])
+        assert e % 2 == 1 and 1 <= e <= 7 and timed >= min(steps, 6), (steps, e, timed)
+    assert b.prof_every_for(200) == 7 and b.prof_every_for(20) == 3 and b.prof_every_for(200, 5) == 5
