@@ -595,20 +595,22 @@ __global__ void __launch_bounds__(256) k_halo_unpack(DevGrid g, WorldDev w, uint
             // and the payload slots are, and its sub-tick offsets into the columns
             const uint32_t u = e.x - w.log_eid0;
             w.ce_slot[base + k] = u;
-            if (w.log_on && w.off_on && u < w.log_n) scatter_offsets(w, u, base + k, cur_tick - w.hist_tick[u]);
-        }
-    }
-    if (w.log_on) {  // ... and whether a ghost cell holds a channel the tick-ring masks cannot answer for (cell_irr, as the index build sets it)
-        __syncthreads();
-        for (uint32_t k = threadIdx.x; k < nc; k += 256) {
-            const uint32_t c = (r.x0 + k % r.w) + (r.y0 + k / r.w) * g.cols;
-            bool irr = false;
-            for (uint32_t p = w.cell_tab[c]; p < w.cell_tab[g.ncell + c]; p++) {
-                const uint32_t u = w.ce[p].x - w.log_eid0;
-                const uint32_t it = u < w.log_n ? w.irr_tick[u] : 0u;
-                irr = irr || (it && cur_tick + 1u - it < CHD_HIST_BITS);
+            if (w.log_on && u < w.log_n) {
+                if (w.off_on) scatter_offsets(w, u, base + k, cur_tick - w.hist_tick[u]);
+                // ... and a ghost cell that holds a channel the tick-ring masks cannot answer for is flagged as the index build flags
+                // its own cells (cell_irr).  Rare: the entry's cell by a binary search over the band's cell starts (ascending in
+                // rectangle order; written by thread 0 before the barrier above)
+                const uint32_t it = w.irr_tick[u];
+                if (it && cur_tick + 1u - it < CHD_HIST_BITS) {
+                    uint32_t lo = 0, hi = nc;  // last cell whose first entry is <= k
+                    while (hi - lo > 1) {
+                        const uint32_t mid = (lo + hi) >> 1;
+                        const uint32_t cm = (r.x0 + mid % r.w) + (r.y0 + mid / r.w) * g.cols;
+                        if (w.cell_tab[cm] - base <= k) lo = mid; else hi = mid;
+                    }
+                    w.cell_irr[(r.x0 + lo % r.w) + (r.y0 + lo / r.w) * g.cols] = 1u;
+                }
             }
-            if (irr) w.cell_irr[c] = 1u;
         }
     }
 }
