@@ -360,8 +360,9 @@ def test_exact_update_buffers_and_enqueue_time_stamps_on_sharded_worlds(world, f
     assert total > 50_000 and (cross > 0 or world == 1)
 
 
-@pytest.mark.parametrize("world,kw", [(2, dict()), (2, dict(wflags=16 | 512)), (2, dict(lists=True)), (2, dict(exact=1 | 64, wflags=16 | 512)), (4, dict(wflags=16 | 512))],
-                         ids=["2-ranks", "2-ranks-gated", "2-ranks-lists", "2-ranks-exact-gated", "4-ranks-gated"])
+@pytest.mark.parametrize("world,kw", [(2, dict()), (2, dict(wflags=16 | 512)), (2, dict(lists=True)), (2, dict(exact=1 | 64, wflags=16 | 512)), (4, dict(wflags=16 | 512)),
+                                      (2, dict(lists=True, exact=1 | 64, cellupd=True))],
+                         ids=["2-ranks", "2-ranks-gated", "2-ranks-lists", "2-ranks-exact-gated", "4-ranks-gated", "2-ranks-lists-exact-cell-updates"])
 def test_chd_shard_tick_with_more_than_one_rank_over_the_hostpipe_transport(world, kw):
     """chd_shard_tick — the whole sharded tick as ONE C call with both exchanges inside the library — had
     only ever run with one rank (RCCL refuses two ranks on one device).  CHD_SHARD_TRANSPORT=hostpipe carries the same send / recv
