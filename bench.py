@@ -391,8 +391,7 @@ def e2e_segment_ticks(world, sw_frames):
             pq = world.host_array(len(q), q.dtype)
         px[:], pz[:], pq[:] = x, z, q
         a = time.perf_counter()
-        res = world.tick(now, upd_x=px, upd_z=pz, queries=pq, want_records=False, pinned=True)
-        seg = world.fetch_segments(pinned=True)
+        res, seg = world.tick_segments(now, upd_x=px, upd_z=pz, queries=pq, pinned=True)  # (chd_tick_segments: the tick + its segments in one call)
         dt = time.perf_counter() - a
         assert res.overflow == 0 and seg["n_records"] == res.n_records
         nbytes = seg["segments"].nbytes + seg["columns"].nbytes + seg["records"].nbytes + seg["conn_seg_off"].nbytes + seg["conn_rec_off"].nbytes
@@ -684,7 +683,7 @@ def main():
             med = sorted(rs, key=lambda v: v[0])[len(rs) // 2]
             e2e["segments"] = {
                 "host_to_device_bytes_per_tick": int(frames[0][1].nbytes + frames[0][2].nbytes + frames[0][3].nbytes),
-                "what": "chd_tick(host pointers in page-locked memory, no dense records) + chd_tick_fetch_segments into page-locked buffers: per connection the segment "
+                "what": "chd_tick_segments (= chd_tick with host pointers in page-locked memory, no dense records, + chd_tick_fetch_segments, as one call with two synchronisations) into page-locked buffers: per connection the segment "
                         "descriptors + the cells' entity-channel columns + explicit records of the subscriptions that needed a per-entity decision; "
                         "the host expands while it writes its sockets (tests/test_gpu_fullsize.py expands them and compares digests)",
                 "ticks": len(rs), "ms_per_tick": 1e3 * med[0], "ms_per_tick_is": "median",

@@ -52,7 +52,7 @@ SYMBOLS = (
     "chd_shard_comm_available", "chd_shard_comm_unique_id", "chd_shard_comm_init", "chd_shard_comm_destroy", "chd_shard_tick", "chd_shard_set_handover_lists", "chd_shard_set_update_senders", "chd_shard_set_update_arrivals", "chd_shard_log_spawn", "chd_shard_despawn", "chd_shard_migrate_extra_records", "chd_shard_ingest_pre", "chd_shard_ingest_post",
     "chd_shard_get_entities", "chd_shard_halo_layout", "chd_shard_interest",
     "chd_handover_recipients", "chd_adjacent_recipients", "chd_wire_set_payloads", "chd_wire_build", "chd_wire_build_info", "chd_wire_fetch",
-    "chd_tick_digest", "chd_tick_fetch_segments", "chd_host_alloc", "chd_host_free", "chd_subs_set_options", "chd_subs_get_options", "chd_world_set_entity_groups", "chd_world_set_handover_lists", "chd_wire_set_type_url", "chd_wire_set_merge_schema", "chd_handover_messages",
+    "chd_tick_digest", "chd_tick_fetch_segments", "chd_tick_segments", "chd_host_alloc", "chd_host_free", "chd_subs_set_options", "chd_subs_get_options", "chd_world_set_entity_groups", "chd_world_set_handover_lists", "chd_wire_set_type_url", "chd_wire_set_merge_schema", "chd_handover_messages",
     "chd_handover_recipients_ex", "chd_handover_variants", "chd_world_set_server_connections",
 )
 
@@ -277,6 +277,7 @@ def load():
     L.chd_adjacent_recipients.argtypes = [C.c_void_p, C.c_uint32, _u32p, _u32p, _u32p, _u32p, _u32p, _u32p, C.c_uint64]
     L.chd_tick_digest.argtypes = [C.c_void_p, P(RecordsDigest), _u64p]
     L.chd_tick_fetch_segments.argtypes = [C.c_void_p, P(SegmentsOut)]
+    L.chd_tick_segments.argtypes = [C.c_void_p, P(TickIn), P(TickOut), P(SegmentsOut)]
     L.chd_subs_set_options.argtypes = [C.c_void_p, C.c_int64, C.c_uint32, P(SubOptions), _u8p, _i32p]
     L.chd_subs_get_options.argtypes = [C.c_void_p, C.c_uint32, _u8p, _u8p, P(C.c_uint32)]
     L.chd_host_alloc.argtypes = [C.c_void_p, C.c_uint64, P(C.c_void_p)]

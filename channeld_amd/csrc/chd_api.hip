@@ -1878,46 +1878,18 @@ static void stage_times(chd_ctx *ctx, uint32_t tick, chd_tick_stats &s) {
     s.emit_main_us = ms * 1000.f;
 }
 
-static int fetch_locked(chd_ctx *ctx, chd_tick_out *out) {
+// the small lists of a tick — handover records, per-query status, the packed unsub / new-sub lists — enqueued for download once the
+// counts are known (out->n_* filled from the tick's row of the history ring); rc becomes CHD_E_CAPACITY where a list was cut
+static int fetch_lists_enqueue(chd_ctx *ctx, chd_tick_out *out, int &rc) {
     World &W = ctx->w;
     WorldDev &d = W.d;
-    if (!W.ticked) return fail(ctx, CHD_E_STATE, "no tick to fetch");
     hipStream_t st = ctx->stream;
-    uint32_t ctr[CTR_COUNT] = {0};
-    uint64_t ringrow[8];
-    // per-connection record counts (sum of its subscriptions' segments), then exact offsets
-    hipLaunchKernelGGL(k_rec_cnt, dim3((d.S + 3) / 4), dim3(256), 0, st, d);
-    hipLaunchKernelGGL(k_widen, dim3((d.S + 255) / 256), dim3(256), 0, st, d.rec_cnt, W.rec_off_exact, d.S);
-    launch_scan_u64_inplace(st, W.rec_off_exact, d.S);
-    // the per-tick counters were folded into the history ring by the tick's epilogue
-    TRY(down(ctx, ringrow, d.tick_ring + (size_t)(ctx->ring.cur_tick % TICK_RING) * 8, sizeof ringrow));
-    uint64_t total = 0;
-    TRY(down(ctx, &total, W.rec_off_exact + d.S, sizeof total));
-    unsigned long long gate_fails = 0;
-    TRY(gate_poll_begin(ctx, &gate_fails));
-    HIPCHK(hipStreamSynchronize(st));
-    gate_poll_end(ctx, gate_fails);
-    ctr[CTR_HANDOVERS] = (uint32_t)ringrow[2];
-    ctr[CTR_LOCKED] = (uint32_t)ringrow[3];
-    ctr[CTR_UNSUBS] = (uint32_t)ringrow[4];
-    ctr[CTR_NEWSUBS] = (uint32_t)ringrow[5];
-    ctr[CTR_PAIRS] = (uint32_t)ringrow[6];
-    ctr[CTR_OVERFLOW] = (uint32_t)(ringrow[7] & 0xFFFFFFFFu);
-    ctr[CTR_HIST_OVERFLOW] = (uint32_t)(ringrow[7] >> 32);
-    out->n_handovers = std::min(ctr[CTR_HANDOVERS], d.handovers_cap);
-    out->n_locked_aborts = ctr[CTR_LOCKED];
-    out->n_unsubs = std::min(ctr[CTR_UNSUBS], d.unsub_cap);
-    out->overflow = ctr[CTR_OVERFLOW];
-    out->history_overflow = ctr[CTR_HIST_OVERFLOW];
-    out->n_records = total;
-    int rc = CHD_OK;
     if (out->handovers) {
         uint32_t n = std::min(out->n_handovers, out->handovers_cap);
         if (n < out->n_handovers) { out->overflow |= OVF_HANDOVER; rc = CHD_E_CAPACITY; }
         TRY(down(ctx, out->handovers, d.handovers, sizeof(chd_handover_rec) * n));
     }
     if (out->query_status) TRY(down(ctx, out->query_status, d.q_status, sizeof(int32_t) * W.last_nq));
-    out->n_newsubs = std::min(ctr[CTR_NEWSUBS], d.newsub_cap);
     const bool want_un = out->unsub_sub && out->unsub_channel && out->n_unsubs;
     const bool want_new = out->newsub_sub && out->newsub_channel && out->n_newsubs;
     if (want_un || want_new) {
@@ -1952,6 +1924,56 @@ static int fetch_locked(chd_ctx *ctx, chd_tick_out *out) {
             if (out->newsub_interval_ms) TRY(down(ctx, out->newsub_interval_ms, dn + 2 * nn, 4 * (size_t)n));
         }
     }
+    return CHD_OK;
+}
+
+// the tick's counts from its row of the history ring (written by the epilogue)
+static void fetch_counts_from_row(chd_ctx *ctx, const uint64_t *ringrow, chd_tick_out *out, uint32_t *pairs) {
+    const WorldDev &d = ctx->w.d;
+    out->n_handovers = std::min((uint32_t)ringrow[2], d.handovers_cap);
+    out->n_locked_aborts = (uint32_t)ringrow[3];
+    out->n_unsubs = std::min((uint32_t)ringrow[4], d.unsub_cap);
+    out->n_newsubs = std::min((uint32_t)ringrow[5], d.newsub_cap);
+    out->overflow = (uint32_t)(ringrow[7] & 0xFFFFFFFFu);
+    out->history_overflow = (uint32_t)(ringrow[7] >> 32);
+    *pairs = (uint32_t)ringrow[6];
+}
+
+static int fetch_locked(chd_ctx *ctx, chd_tick_out *out) {
+    World &W = ctx->w;
+    WorldDev &d = W.d;
+    if (!W.ticked) return fail(ctx, CHD_E_STATE, "no tick to fetch");
+    hipStream_t st = ctx->stream;
+    uint32_t ctr[CTR_COUNT] = {0};
+    uint64_t ringrow[8];
+    // per-connection record counts (sum of its subscriptions' segments), then exact offsets
+    hipLaunchKernelGGL(k_rec_cnt, dim3((d.S + 3) / 4), dim3(256), 0, st, d);
+    hipLaunchKernelGGL(k_widen, dim3((d.S + 255) / 256), dim3(256), 0, st, d.rec_cnt, W.rec_off_exact, d.S);
+    launch_scan_u64_inplace(st, W.rec_off_exact, d.S);
+    // the per-tick counters were folded into the history ring by the tick's epilogue
+    TRY(down(ctx, ringrow, d.tick_ring + (size_t)(ctx->ring.cur_tick % TICK_RING) * 8, sizeof ringrow));
+    uint64_t total = 0;
+    TRY(down(ctx, &total, W.rec_off_exact + d.S, sizeof total));
+    unsigned long long gate_fails = 0;
+    TRY(gate_poll_begin(ctx, &gate_fails));
+    HIPCHK(hipStreamSynchronize(st));
+    gate_poll_end(ctx, gate_fails);
+    ctr[CTR_HANDOVERS] = (uint32_t)ringrow[2];
+    ctr[CTR_LOCKED] = (uint32_t)ringrow[3];
+    ctr[CTR_UNSUBS] = (uint32_t)ringrow[4];
+    ctr[CTR_NEWSUBS] = (uint32_t)ringrow[5];
+    ctr[CTR_PAIRS] = (uint32_t)ringrow[6];
+    ctr[CTR_OVERFLOW] = (uint32_t)(ringrow[7] & 0xFFFFFFFFu);
+    ctr[CTR_HIST_OVERFLOW] = (uint32_t)(ringrow[7] >> 32);
+    out->n_handovers = std::min(ctr[CTR_HANDOVERS], d.handovers_cap);
+    out->n_locked_aborts = ctr[CTR_LOCKED];
+    out->n_unsubs = std::min(ctr[CTR_UNSUBS], d.unsub_cap);
+    out->overflow = ctr[CTR_OVERFLOW];
+    out->history_overflow = ctr[CTR_HIST_OVERFLOW];
+    out->n_records = total;
+    int rc = CHD_OK;
+    out->n_newsubs = std::min(ctr[CTR_NEWSUBS], d.newsub_cap);
+    TRY(fetch_lists_enqueue(ctx, out, rc));
     if (out->conn_rec_off) TRY(down(ctx, out->conn_rec_off, W.rec_off_exact, sizeof(uint64_t) * (d.S + 1)));
     if (out->conn_rec_cnt) TRY(down(ctx, out->conn_rec_cnt, d.rec_cnt, sizeof(uint32_t) * d.S));
     if (out->records && total) {
@@ -2094,12 +2116,11 @@ int chd_tick_digest(chd_ctx *ctx, chd_records_digest *total, uint64_t *conn_sum)
     return CHD_OK;
 }
 
-int chd_tick(chd_ctx *ctx, const chd_tick_in *in, chd_tick_out *out) {
-    NEED_WORLD();
-    if (!in || !out) return fail(ctx, CHD_E_INVAL, "chd_tick: NULL argument");
-    std::lock_guard<FairMutex> lk(ctx->mu);
-    TRY(bind(ctx));
-    chd_tick_in din = *in;
+// chd_tick's host half: the arguments checked as the reference's callers would have (one update per entity and round, one interest
+// update per connection, ids in range, stamps inside [0, now]), then every input array staged into device scratch on the ctx stream
+// (asynchronous where the caller's memory is page-locked); din = the same tick with DEVICE pointers
+static int host_tick_stage(chd_ctx *ctx, const chd_tick_in *in, chd_tick_in &din) {
+    din = *in;
     const size_t nu = in->n_updates, nq = in->n_queries, nc = in->n_cell_updates, ns = in->n_spots_total;
     if (nu && (!in->upd_x || !in->upd_z)) return fail(ctx, CHD_E_INVAL, "tick: NULL update positions");
     if (nq && !in->queries) return fail(ctx, CHD_E_INVAL, "tick: NULL queries");
@@ -2185,8 +2206,106 @@ int chd_tick(chd_ctx *ctx, const chd_tick_in *in, chd_tick_out *out) {
     // enqueued on `stream` so far.  (chd_tick_device keeps the chained fast path: its inputs must be complete at call time.)
     ctx->chain_prev = false;
     ctx->gchain_prev = false;
+    return CHD_OK;
+}
+
+int chd_tick(chd_ctx *ctx, const chd_tick_in *in, chd_tick_out *out) {
+    NEED_WORLD();
+    if (!in || !out) return fail(ctx, CHD_E_INVAL, "chd_tick: NULL argument");
+    std::lock_guard<FairMutex> lk(ctx->mu);
+    TRY(bind(ctx));
+    chd_tick_in din;
+    TRY(host_tick_stage(ctx, in, din));
     TRY(tick_locked(ctx, &din));
     return fetch_locked(ctx, out);
+}
+
+// chd_tick + chd_tick_fetch_segments as ONE call with two synchronisations instead of five: [uploads, the tick, the segment sizing
+// pass, the counts' download] sync [the small lists, the segment filling pass, every download] sync.  What a gateway that writes its
+// sockets from segments calls per tick.  `out` takes no dense records (records / conn_rec_off / conn_rec_cnt must be NULL).
+int chd_tick_segments(chd_ctx *ctx, const chd_tick_in *in, chd_tick_out *out, chd_segments_out *seg) {
+    NEED_WORLD();
+    if (!in || !out || !seg || !seg->conn_seg_off || !seg->conn_rec_off) return fail(ctx, CHD_E_INVAL, "chd_tick_segments: NULL argument");
+    if (out->records || out->conn_rec_off || out->conn_rec_cnt) return fail(ctx, CHD_E_INVAL, "chd_tick_segments: the dense record outputs belong to chd_tick");
+    std::lock_guard<FairMutex> lk(ctx->mu);
+    TRY(bind(ctx));
+    World &W = ctx->w;
+    WorldDev &d = W.d;
+    if (d.capq > 32u * SEG_BITMAP_WORDS) return fail(ctx, CHD_E_TOO_LARGE, "chd_tick_segments: max_interest_cells %u > %u", d.capq, 32u * SEG_BITMAP_WORDS);
+    if ((uint64_t)d.S * d.capq > 0xFFFFFFFFull) return fail(ctx, CHD_E_TOO_LARGE, "chd_tick_segments: more than 2^32 subscriptions");
+    chd_tick_in din;
+    TRY(host_tick_stage(ctx, in, din));
+    TRY(tick_locked(ctx, &din));
+    hipStream_t st = ctx->stream;
+    if (!W.seg_cnt) {
+        TRY(walloc(ctx, &W.seg_cnt, (size_t)d.S + 1));
+        TRY(walloc(ctx, &W.seg_exp, (size_t)d.S + 1));
+    }
+    // ---- sizing, and everything whose size the host must know first ----
+    hipLaunchKernelGGL(k_segments, dim3(d.S), dim3(64), 0, st, ctx->g, d, W.last_desc ? 1 : 0, 0, W.seg_cnt, (unsigned long long *)W.seg_exp,
+                       (chd_fanout_segment *)nullptr, (chd_fanout_rec *)nullptr);
+    launch_scan_u32_inplace(st, W.seg_cnt, d.S);
+    launch_scan_u64_inplace(st, W.seg_exp, d.S);
+    TRY(after_launch(ctx));
+    uint32_t nseg = 0, pairs = 0;
+    uint64_t nexp = 0, ub = 0, ringrow[8];
+    TRY(down(ctx, &nseg, W.seg_cnt + d.S, sizeof nseg));
+    TRY(down(ctx, &nexp, W.seg_exp + d.S, sizeof nexp));
+    TRY(down(ctx, &ub, d.rec_ub + d.S, sizeof ub));
+    TRY(down(ctx, ringrow, d.tick_ring + (size_t)(ctx->ring.cur_tick % TICK_RING) * 8, sizeof ringrow));
+    HIPCHK(hipStreamSynchronize(st));
+    fetch_counts_from_row(ctx, ringrow, out, &pairs);
+    out->n_records = ringrow[0];
+    const uint64_t ncol = !W.last_desc ? 0ull : d.wcol_on ? (uint64_t)(CHD_WCOLS + 1) * d.wcol_stride : (uint64_t)d.N + d.ghost_cap;
+    seg->n_segments = nseg;
+    seg->n_explicit = nexp;
+    seg->n_columns = ncol;
+    seg->n_records = ringrow[0];
+    const bool seg_fits = !(nseg > seg->segments_cap || nexp > seg->records_cap || ncol > seg->columns_cap || (nseg && !seg->segments) || (nexp && !seg->records) ||
+                            (ncol && !seg->columns));
+    // ---- the lists and the segments ----
+    int rc = CHD_OK;
+    TRY(fetch_lists_enqueue(ctx, out, rc));
+    if (seg_fits) {
+        if (W.seg_stage_cap < nseg) {
+            if (W.seg_stage) HIPCHK(hipFree(W.seg_stage));
+            W.seg_stage = nullptr;
+            W.seg_stage_cap = nseg + nseg / 4 + 1024;
+            HIPCHK(hipMalloc((void **)&W.seg_stage, W.seg_stage_cap * sizeof(chd_fanout_segment)));
+        }
+        if (W.seg_rec_stage_cap < nexp) {
+            if (W.seg_rec_stage) HIPCHK(hipFree(W.seg_rec_stage));
+            W.seg_rec_stage = nullptr;
+            W.seg_rec_stage_cap = nexp + nexp / 4 + 1024;
+            HIPCHK(hipMalloc((void **)&W.seg_rec_stage, W.seg_rec_stage_cap * sizeof(chd_fanout_rec)));
+        }
+        hipLaunchKernelGGL(k_segments, dim3(d.S), dim3(64), 0, st, ctx->g, d, W.last_desc ? 1 : 0, 1, W.seg_cnt, (unsigned long long *)W.seg_exp,
+                           W.seg_stage, W.seg_rec_stage);
+        TRY(after_launch(ctx));
+        TRY(down(ctx, seg->conn_seg_off, W.seg_cnt, sizeof(uint32_t) * ((size_t)d.S + 1)));
+        TRY(down(ctx, seg->conn_rec_off, W.seg_exp, sizeof(uint64_t) * ((size_t)d.S + 1)));
+        TRY(down(ctx, seg->segments, W.seg_stage, sizeof(chd_fanout_segment) * (size_t)nseg));
+        TRY(down(ctx, seg->records, W.seg_rec_stage, sizeof(chd_fanout_rec) * nexp));
+        if (ncol) TRY(down(ctx, seg->columns, d.ce_chan_view, sizeof(uint32_t) * ncol));
+    }
+    unsigned long long gate_fails = 0;
+    TRY(gate_poll_begin(ctx, &gate_fails));
+    HIPCHK(hipStreamSynchronize(st));
+    gate_poll_end(ctx, gate_fails);
+    chd_tick_stats &stt = ctx->stats;
+    stt.n_records = ringrow[0];
+    stt.n_record_upper_bound = ub;
+    stt.n_handovers = out->n_handovers;
+    stt.n_unsubs = out->n_unsubs;
+    stt.n_pairs = pairs;
+    if (ctx->prof_depth > 0) stage_times(ctx, ctx->ring.cur_tick, stt);
+    if (out->overflow && rc == CHD_OK) rc = CHD_E_CAPACITY;
+    if (rc == CHD_E_CAPACITY) return fail(ctx, rc, "tick output truncated (overflow mask 0x%x)", out->overflow);
+    // (the tick itself is done: a caller whose segment buffers were too small grows them and calls chd_tick_fetch_segments)
+    if (!seg_fits)
+        return fail(ctx, CHD_E_CAPACITY, "chd_tick_segments: %u segments, %llu explicit records, %llu column entries needed", nseg,
+                    (unsigned long long)nexp, (unsigned long long)ncol);
+    return rc;
 }
 
 // ---------------------------------------------------------------------------

@@ -385,7 +385,7 @@ class SpatialWorld:
              cell_upd_channel=None, cell_upd_sender=None, query_sub=None,
              queries: Optional[Sequence[SpatialInterestQuery]] = None, records_cap: int = 1 << 22,
              want_records: bool = True, pinned: bool = False, upd_arrival_ns=None, cell_upd_arrival_ns=None,
-             upd_round_off=None) -> TickResult:
+             upd_round_off=None, _segments: bool = False) -> TickResult:
         """upd_arrival_ns / cell_upd_arrival_ns: the arrivalTime of every update (history_depth worlds; None = now_ns);
         upd_round_off: [0, ..., n_updates], the rounds of updates (a channel's r-th update of this tick lies in round r)."""
         ti = TickIn()
@@ -427,11 +427,21 @@ class SpatialWorld:
                 keep += [arr, sx, sz, sd, qs]
                 ti.n_queries, ti.query_sub, ti.queries = nq, _ptr(qs), C.cast(arr, C.c_void_p)
                 ti.spot_x, ti.spot_z, ti.spot_dist, ti.n_spots_total = _ptr(sx), _ptr(sz), _ptr(sd), len(sx)
+        if _segments:  # tick_segments: one C call for the tick and its segment output (chd_tick_segments)
+            o = self._alloc_out(nq, False, 0, pinned)
+            o.conn_rec_off, o.conn_rec_cnt = None, None
+            seg = self._segments_call(lambda so: self.lib.chd_tick_segments(self.ctx, C.byref(ti), C.byref(o), C.byref(so)), pinned)
+            return self._result(o, nq), seg
         o = self._alloc_out(nq, want_records, records_cap, pinned)
         rc = self.lib.chd_tick(self.ctx, C.byref(ti), C.byref(o))
         if rc not in (_lib.OK,):
             _lib.check(self.ctx, rc)
         return self._result(o, nq)
+
+    def tick_segments(self, now_ns: int, pinned: bool = True, **kw):
+        """chd_tick_segments: the tick (host buffers, arguments as tick()) and its fan-out in the compact segment form in ONE C call —
+        (TickResult without dense records, the dict fetch_segments returns)."""
+        return self.tick(now_ns, want_records=False, pinned=pinned, _segments=True, **kw)
 
     # ---- device-resident path (bench): inputs already in HBM ----
     def device_array(self, host: np.ndarray) -> DeviceArray:
@@ -468,19 +478,24 @@ class SpatialWorld:
         u32[S+1], columns u32[], records REC_DTYPE[] (the explicit segments'), conn_rec_off u64[S+1], n_records).  Buffers
         (page-locked with pinned=True) are allocated once, grown on CHD_E_CAPACITY, and reused: the arrays returned are
         views into them, valid until the next call."""
+        return self._segments_call(lambda so: self.lib.chd_tick_fetch_segments(self.ctx, C.byref(so)), pinned)
+
+    def _segments_call(self, call, pinned: bool):
+        """call(SegmentsOut) -> rc: chd_tick_fetch_segments, or chd_tick_segments (the tick + the fetch).  Buffers grown on
+        CHD_E_CAPACITY; a second round is always the plain fetch (the tick has run by then)."""
         alloc = self.host_array if pinned else (lambda n, dt: np.zeros(n, dtype=dt))
         b = getattr(self, "_seg_bufs", None)
         if b is None:
             b = self._seg_bufs = dict(seg=alloc(max(self.S * 8, 1024), self.SEG_DTYPE), off=alloc(self.S + 1, np.uint32),
                                       col=alloc(self.N + 1024, np.uint32), rec=alloc(1 << 16, REC_DTYPE), roff=alloc(self.S + 1, np.uint64))
-        for _ in range(2):
+        for attempt in range(2):
             so = _lib.SegmentsOut()
             so.segments, so.segments_cap = b["seg"].ctypes.data_as(C.c_void_p), len(b["seg"])
             so.conn_seg_off = _ptr(b["off"])
             so.columns, so.columns_cap = _ptr(b["col"]), len(b["col"])
             so.records, so.records_cap = b["rec"].ctypes.data_as(C.c_void_p), len(b["rec"])
             so.conn_rec_off = _ptr(b["roff"])
-            rc = self.lib.chd_tick_fetch_segments(self.ctx, C.byref(so))
+            rc = call(so) if attempt == 0 else self.lib.chd_tick_fetch_segments(self.ctx, C.byref(so))
             grow = rc == _lib.E_CAPACITY and (so.n_segments > so.segments_cap or so.n_columns > so.columns_cap or so.n_explicit > so.records_cap)
             if not grow:
                 break

@@ -526,6 +526,13 @@ typedef struct {
  * (data.go:293-318) on the host side of the boundary — the host walks segments instead of 8-byte records. */
 int chd_tick_fetch_segments(chd_ctx *ctx, chd_segments_out *out);
 
+/* chd_tick followed by chd_tick_fetch_segments, as ONE call: what a gateway that writes its sockets from segments does every tick.
+ * Same results as the two calls; two host synchronisations instead of five (uploads + tick + sizing pass | lists + filling pass +
+ * downloads).  `out` as for chd_tick but WITHOUT the dense record outputs (records, conn_rec_off, conn_rec_cnt must be NULL:
+ * CHD_E_INVAL).  If `seg`'s buffers are too small the tick is still done and its lists fetched: CHD_E_CAPACITY with the needed
+ * sizes in seg->n_*, grow and call chd_tick_fetch_segments. */
+int chd_tick_segments(chd_ctx *ctx, const chd_tick_in *in, chd_tick_out *out, chd_segments_out *seg);
+
 /* Read back the interest set of a subscriber slot (the keys of
  * Connection.spatialSubscriptions, with the per-subscription fan-out state of
  * subscription.go:13-31 / data.go:39-44).  Arrays have max_interest_cells
