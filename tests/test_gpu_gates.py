@@ -33,10 +33,11 @@ def test_default_queues_take_the_gates_and_match_the_oracle():
     assert out["slowest_group_s"] < 1.0, out
 
 
-@pytest.mark.parametrize("queues", ["1", "2"])
+@pytest.mark.parametrize("queues", ["1"])
 def test_few_hardware_queues_never_stall_and_match_the_oracle(queues):
     """With ONE hardware queue the second stream's kernels sit behind the tick's: the probe at world creation must see that
-    and keep the event form (no gate, no 2-second spin); with two the gates may hold.  Either way: the oracle's digests."""
+    and keep the event form (no gate, no second-long spin).  Either way: the oracle's digests.  (GPU_MAX_HW_QUEUES=2 ran green through
+    the round as well — profiles/r06f_pytest_gpu.log — and was dropped from the suite for its run time.)"""
     out, err = run_case(env={"GPU_MAX_HW_QUEUES": queues})
     assert out["bad_ticks"] == [] and out["gate_timeouts"] == 0 and all(o == 0 for o in out["overflow"]), (out, err[-500:])
     assert out["slowest_group_s"] < 1.0, out
@@ -50,9 +51,9 @@ def test_eight_gated_contexts_alive_in_one_process():
 
 
 def test_a_second_process_keeps_the_gpu_busy():
-    busy = subprocess.Popen([sys.executable, os.path.join(HERE, "gate_case.py"), "--busy-s", "25"], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+    busy = subprocess.Popen([sys.executable, os.path.join(HERE, "gate_case.py"), "--busy-s", "12"], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
     try:
-        out, _ = run_case(args=["--groups", "4"])
+        out, _ = run_case(args=["--groups", "3"])
     finally:
         b_out, b_err = busy.communicate(timeout=120)
     assert busy.returncode == 0, b_err[-1000:]
