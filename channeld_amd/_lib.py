@@ -159,7 +159,7 @@ class TickStats(C.Structure):
     ]
 
 
-SCHED_OVERLAP_INTEREST, SCHED_GATED, SCHED_PIPELINED = 1, 2, 4
+SCHED_OVERLAP_INTEREST, SCHED_GATED, SCHED_PIPELINED, SCHED_CELL_MAJOR, SCHED_ARRIVAL_OFFSETS = 1, 2, 4, 8, 16
 
 
 SUBOPT_ACCESS, SUBOPT_INTERVAL, SUBOPT_DELAY, SUBOPT_SKIP_SELF, SUBOPT_SKIP_FIRST, SUBOPT_FIELD_MASK = 1, 2, 4, 8, 16, 32

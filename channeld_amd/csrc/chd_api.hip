@@ -482,7 +482,8 @@ static int gate_probe(chd_ctx *ctx) {
 
 static uint32_t schedule_bits(const chd_ctx *ctx) {
     const World &W = ctx->w;
-    return (W.overlap_interest ? CHD_SCHED_OVERLAP_INTEREST : 0u) | (W.gated ? CHD_SCHED_GATED : 0u) | (W.pipe_on ? CHD_SCHED_PIPELINED : 0u);
+    return (W.overlap_interest ? CHD_SCHED_OVERLAP_INTEREST : 0u) | (W.gated ? CHD_SCHED_GATED : 0u) | (W.pipe_on ? CHD_SCHED_PIPELINED : 0u) |
+           (W.d.cm_emit ? CHD_SCHED_CELL_MAJOR : 0u) | (W.d.off_on ? CHD_SCHED_ARRIVAL_OFFSETS : 0u);
 }
 
 // Every call that synchronises with the device and looks at a tick's results passes here: a gate that timed out (the sticky
@@ -1002,8 +1003,15 @@ int chd_world_create(chd_ctx *ctx, const chd_world_cfg *cfg) {
     // (also bounded by the memory of the per-item due lists: ~40 B per cell x connection slot)
     const size_t n_items_max = C * ((S + 255) / 256);
     const bool cm_possible = C <= 4096 && n_items_max * sizeof(WsItemG) <= (2ull << 30);
+    // Exact update buffers (history_depth): the connection-major descriptor path keeps sub-tick arrival offsets (WorldDev::off_on) and
+    // decides a window that cuts through a tick's arrivals in the plan / the filtered kernel; the cell-major form has no such columns
+    // and sends every such subscription to the element walk (k_fanout_emit_deep) — measured at config C (1 M entities, 4.4 K per
+    // cell, every update stamped at its enqueue time): 155 ms per tick cell-major, 2.2 ms connection-major
+    // (profiles/r06j_kernel_stats_c1m_aj{,_cm}.csv).  So populous cells alone do not select the cell-major form on such a world.
+    const bool off_possible = cfg->history_depth && !(cfg->flags & (CHD_WORLD_UPDATE_MASKS | CHD_WORLD_WIRE)) &&
+                              (S >= 4096 || (cfg->flags & CHD_WORLD_ONE_WAVE_EMIT)) && C <= 4096;
     const bool cm_wanted = (cfg->flags & CHD_WORLD_CELL_MAJOR_EMIT) ||
-                           (!(cfg->flags & CHD_WORLD_CONN_MAJOR_EMIT) && N / C >= 1024);
+                           (!(cfg->flags & CHD_WORLD_CONN_MAJOR_EMIT) && N / C >= 1024 && !off_possible);
     if ((cfg->flags & CHD_WORLD_CELL_MAJOR_EMIT) && !cm_possible)
         return fail(ctx, CHD_E_INVAL, "cell-major emit needs a grid of at most 4096 cells (and cells x subscribers x 40 B <= 2 GiB)");
     // update masks: written by the connection-major form only (the cell-major streamers replay precomputed window

@@ -201,7 +201,12 @@ typedef struct {
  * tables are small.  Cell-major (grids up to 4096 cells): each cell's entity table is
  * staged once in LDS by a loader wave and streamed to all its due subscribers by
  * load-free streamer waves — best for populous cells (1.6x at 1M entities on 225 cells).
- * Default: cell-major when max_entities / cells >= 1024.  The flags force one form. */
+ * Default: cell-major when max_entities / cells >= 1024 — except on a world that keeps exact
+ * update buffers where the descriptor path can run (history_depth > 0, >= 4096 subscriber slots
+ * or CHD_WORLD_ONE_WAVE_EMIT, no UPDATE_MASKS / WIRE): only the connection-major form keeps the
+ * sub-tick arrival offsets, the cell-major form would send every window that cuts through a
+ * tick's arrivals to the element walk (70 x slower at 1 M entities).  The flags force one form;
+ * chd_tick_stats.schedule says which is in force (CHD_SCHED_CELL_MAJOR, CHD_SCHED_ARRIVAL_OFFSETS). */
 #define CHD_WORLD_CONN_MAJOR_EMIT 1u
 #define CHD_WORLD_CELL_MAJOR_EMIT 2u
 /* also plan, every tick, who receives each handover's ChannelDataHandoverMessage (chd_handover_recipients) */
@@ -950,6 +955,8 @@ typedef struct {
 #define CHD_SCHED_OVERLAP_INTEREST 1u /* the interest updates run on the second stream */
 #define CHD_SCHED_GATED 2u            /* ... forked / joined by device-side flags (CHD_WORLD_GATED_OVERLAP asked for AND the streams were seen to run side by side) */
 #define CHD_SCHED_PIPELINED 4u        /* CHD_WORLD_PIPELINE_TICKS in force */
+#define CHD_SCHED_CELL_MAJOR 8u       /* the cell-major emit form (asked for, or chosen for cells of >= 1024 entities on a world without exact update buffers) */
+#define CHD_SCHED_ARRIVAL_OFFSETS 16u /* history_depth > 0 on the descriptor path: sub-tick arrival offsets decide the windows that cut through a tick's arrivals */
 /* depth > 0: record HIP events around the stages of the next ticks, keeping the
  * last `depth` ticks (<= 1024); 0 turns it off. */
 int chd_set_profiling(chd_ctx *ctx, int depth);

@@ -300,6 +300,36 @@ def test_cells_in_arrival_order_give_the_same_records(amd, monkeypatch):
         ctl.close()
 
 
+def test_populous_cells_with_exact_buffers_stay_on_the_descriptor_path(amd):
+    """max_entities / cells >= 1024 selects the cell-major emit form by default — but not on a world with exact update buffers where
+    the descriptor path can run: only that path keeps the sub-tick arrival offsets; the cell-major form sends every window that cuts
+    through a tick's arrivals to the element walk (config C with enqueue-time stamps: 155 ms per tick against 2.2,
+    profiles/r06j_kernel_stats_c1m_aj*.csv).  A 2x2 world of 1100 entities per cell, no form asked for (flags = ONE_WAVE_EMIT only):
+    the schedule says connection-major with arrival offsets, and the records equal the oracle's every tick — 20 and 50 ms windows
+    through cells beyond the 512-entry tile, stamps anywhere inside the tick, entities that skip ticks.  Asking for the cell-major
+    form still gives it (same records)."""
+    N, S = 4400, 40
+    for flags, want_cm in ((64, False), (64 | 2, True)):
+        cfg, sw, ctl, gw, ow = make_pair(amd, "spatial_static_2x2.json", N, S, 64, flags, seed=0xD41)
+        sched = gw.stats()["schedule"]
+        assert bool(sched & 8) == want_cm and bool(sched & 16) == (not want_cm), sched
+        rng = np.random.default_rng(41)
+        now = 0
+        total = 0
+        for k in range(14 if not want_cm else 6):
+            sw.step()
+            prev, now = now, now + (50 * MS if k % 3 else 47 * MS + int(rng.integers(0, 6 * MS)))
+            q = sw.queries()
+            upd = np.sort(rng.choice(N, N - N // 10, replace=False)).astype(np.uint32) if k % 5 == 4 else np.arange(N, dtype=np.uint32)
+            arr = rng.integers(prev + 1, now + 1, len(upd)).astype(np.int64)
+            ow.tick(now, upd, sw.x[upd], sw.z[upd], None, None, None, None, q, upd_arrival=arr)
+            res = gw.tick(now, upd_idx=upd, upd_x=sw.x[upd], upd_z=sw.z[upd], queries=q, upd_arrival_ns=arr, records_cap=1 << 23)
+            compare_tick(k, res, ow, S, check_pairs=range(0, S, 7), gw=gw)
+            total += res.n_records
+        assert total > 100_000
+        ctl.close()
+
+
 def test_a_short_buffer_says_what_it_dropped(amd):
     """history_depth smaller than what a window reaches back to: never silently short — history_overflow counts it."""
     N, S = 12, 2
