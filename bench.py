@@ -727,6 +727,8 @@ def main():
         "value": msgs / elapsed, "unit": "msgs/s", "n_gpus": 1, "steps": K, "warmup": W,
         "ms_per_step": 1e3 * elapsed / K, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "f64", "data": "synthetic",
+        # (the latency half of the metric in front of the long sub-objects: a reader that keeps only the head of the line still has it)
+        "p50_tick_ms": float(np.percentile(lat, 50)), "p99_tick_ms": float(np.percentile(lat, 99)),
         "config": {"workload": f"spatial_static_benchmark.json, {N} entities / {S} subs, 1xMI355X"
                                + ("" if args.update_frac >= 1.0 else f", DIAGNOSTIC: {args.update_frac:g} of the entities update per tick")
                                + ("" if not jitter else ", ARRIVAL STAMPS AT ENQUEUE TIME: every update stamped uniformly inside its tick interval "
@@ -744,7 +746,6 @@ def main():
                                                      + ")" if args.overlap_interest else "")
                                                   + ("; the tick's small filtering launch and its epilogue run beside the record kernel on a second stream and join "
                                                      "before the tick ends (CHD_WORLD_OVERLAP_DEFERRED)" if args.overlap_deferred else ""))},
-        "p50_tick_ms": float(np.percentile(lat, 50)), "p99_tick_ms": float(np.percentile(lat, 99)),
         "p99_tick_gpu_ms": float(np.percentile(gpu_lat, 99)), "latency_ticks": int(L),
         "digest_checked_ticks": digests_checked,
         "digest_check": "the latency-phase ticks' fan-out records (count, sum, xor of mix64(conn, channel), chd_tick_digest on the device) against the "
@@ -757,8 +758,14 @@ def main():
         "roofline": {"bound": "hbm", "kernel": dominant, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_quoted": traffic is not None and not (traffic_measured and traffic_measured.get("bytes_per_launch")),
                      "traffic_measured_in_run": traffic_measured,
-                     "traffic_source": traffic_note or "QUOTED, not measured in this run: bytes per launch from the rocprofv3 --pmc passes of this command on the same "
-                                                       "kernel sources (profiles/hbm_traffic.json, source_hash checked)",
+                     "traffic_source": (traffic_note if traffic_note else
+                                        ("MEASURED in this run: two child runs `rocprofv3 --pmc FETCH_SIZE|WRITE_SIZE` of this workload (traffic_measured_in_run)"
+                                         if (traffic_measured and traffic_measured.get("bytes_per_launch")) else
+                                         "QUOTED, not measured in this run: bytes per launch from the rocprofv3 --pmc passes of this command on the same "
+                                         "kernel sources (profiles/hbm_traffic.json, source_hash checked)")),
+                     # the same launch as a PHYSICAL rate: HBM bytes the counters saw per launch / its duration (the algorithmic 12 B per
+                     # message count a 4-byte id read that is an L2 hit; spec peak 8 TB/s, ~6.3 TB/s achievable per MI355X_MICROARCH.md)
+                     "physical_frac": (traffic / (float(emit_us.mean()) * 1e-6) / 1e9 / HBM_PEAK_GBS) if traffic else None,
                      "algorithmic_bytes_per_launch": float(bytes_per_msg * emit_msgs.mean()),
                      "bytes_per_msg": bytes_per_msg, "msgs_per_launch": float(emit_msgs.mean()), "avg_launch_us": float(emit_us.mean()),
                      "timed_launches": int(len(emit_us)),

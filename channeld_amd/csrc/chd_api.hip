@@ -49,6 +49,18 @@ namespace {
 // A waiter sleeps on the condition variable of ITS ticket (ticket % 64): an unlock wakes the next ticket's holder and nobody else
 // (waiters 64 tickets apart share a variable and re-check) — one variable for all made every unlock wake every waiter, O(n^2)
 // wake-ups with thousands of goroutine threads queued.
+// The library's two TEST hooks are environment variables: CHD_SHARD_TRANSPORT=hostpipe (a blocking POSIX-shm stand-in for RCCL so that
+// chd_shard_tick can run with several ranks on one GPU) and CHD_TEST_DROP_GATE_RAISE (drops one gate raise: the time-out path).  A
+// production build compiles them out: -DCHD_NO_TEST_HOOKS (CHD_EXTRA_FLAGS of channeld_amd/build.py).
+static inline const char *test_hook_env(const char *name) {
+#ifdef CHD_NO_TEST_HOOKS
+    (void)name;
+    return nullptr;
+#else
+    return getenv(name);
+#endif
+}
+
 class FairMutex {
     static constexpr unsigned K = 64;
     std::mutex m;
@@ -81,6 +93,8 @@ struct World {
     chd_world_cfg cfg{};
     WorldDev d{};
     std::vector<void *> allocs;
+    unsigned char *slab_cur = nullptr;  // (walloc: the slab being filled)
+    size_t slab_used = 0;
     chd_fanout_rec *recs_dense = nullptr;
     uint64_t recs_dense_cap = 0;
     uint32_t *list_dense = nullptr;  // fetch-time staging of the packed unsub / new-sub lists
@@ -116,6 +130,7 @@ struct World {
     const double *log_x = nullptr, *log_z = nullptr;
     const uint8_t *log_has = nullptr;
     uint32_t log_nchan = 0;
+    bool ingest_pending = false;  // chd_shard_ingest[_pre] ran and chd_shard_import has not yet
     std::vector<uint32_t> group_id;    // host copy: handover group id per entity slot (0 = none), chd_world_set_entity_groups
     void *grp_buf[4] = {nullptr, nullptr, nullptr, nullptr};  // device arrays behind WorldDev::grp_*
     bool plan_recipients = false;      // CHD_WORLD_HANDOVER_RECIPIENTS
@@ -147,6 +162,7 @@ struct World {
     struct HostPipe *pipe = nullptr;   // CHD_SHARD_TRANSPORT=hostpipe (a TEST transport, see HostPipe): then comm == nullptr
     uint32_t comm_rank = 0, comm_world = 0, comm_cap = 0;
     uint32_t comm_alloc_cap = 0, comm_alloc_world = 0;  // what mig_send / mig_recv / the halo buffers were sized for
+    uint32_t comm_try_cap = 0, comm_try_world = 0;      // ... what a call that may have failed half-way began to size them for
     chd_entity_state *mig_send = nullptr, *mig_recv = nullptr;   // [world][cap + 1]
     chd_handover_request *req_send = nullptr, *req_recv = nullptr;  // [world][CHD_SHARD_REQ_CAP + 1] (handover lists only)
     unsigned char *halo_send_buf = nullptr, *halo_recv_buf = nullptr;
@@ -266,12 +282,31 @@ int after_launch(chd_ctx *ctx) {
         if (_rc) return _rc;  \
     } while (0)
 
+// The world's arrays come out of a few large slabs, not one hipMalloc each: the tick's small kernels touch ten to twenty arrays per
+// workgroup, and separately mapped allocations of a few hundred KB each cost them an address translation per array (measured:
+// k_cell_arrange over 13 arrays of one cell took 18-28 us for a 3 us body).  Arrays of 32 MiB and more keep their own allocation.
+// CHD_WORLD_SLABS=0: one allocation per array, as before (A/B runs).
 template <typename T>
 int walloc(chd_ctx *ctx, T **out, size_t count, bool zero = true) {
+    World &W = ctx->w;
     void *p = nullptr;
-    size_t bytes = std::max<size_t>(count * sizeof(T), 256);
-    HIPCHK(hipMalloc(&p, bytes));
-    ctx->w.allocs.push_back(p);
+    size_t bytes = (std::max<size_t>(count * sizeof(T), 256) + 255) & ~(size_t)255;
+    static const bool slabs = [] { const char *e = getenv("CHD_WORLD_SLABS"); return !(e && e[0] == '0'); }();
+    constexpr size_t SLAB = 64ull << 20;
+    if (slabs && bytes < (32ull << 20)) {
+        if (!W.slab_cur || W.slab_used + bytes > SLAB) {
+            void *sl = nullptr;
+            HIPCHK(hipMalloc(&sl, SLAB));
+            W.allocs.push_back(sl);
+            W.slab_cur = (unsigned char *)sl;
+            W.slab_used = 0;
+        }
+        p = W.slab_cur + W.slab_used;
+        W.slab_used += bytes;
+    } else {
+        HIPCHK(hipMalloc(&p, bytes));
+        W.allocs.push_back(p);
+    }
     if (zero) HIPCHK(hipMemsetAsync(p, 0, bytes, ctx->stream));
     *out = (T *)p;
     return CHD_OK;
@@ -950,6 +985,9 @@ int chd_world_create(chd_ctx *ctx, const chd_world_cfg *cfg) {
     if (cfg->shard_channels && (cfg->flags & (CHD_WORLD_PIPELINE_TICKS | CHD_WORLD_HANDOVER_RECIPIENTS)))
         return fail(ctx, CHD_E_INVAL, "shard_channels: a region-sharded world (no pipelined ticks, no recipient planning)");
     d.ce_by_chan = cfg->shard_channels ? 1u : 0u;
+    // (a world with by-channel arrays is region-sharded from its creation on: chd_world_spawn / chd_tick / chd_tick_device index those
+    // arrays by entity SLOT and would write past them whenever shard_channels < max_entities — they answer CHD_E_STATE)
+    W.slot_mode = cfg->shard_channels ? 2 : 0;
     d.log_on = (cfg->shard_channels && cfg->history_depth) ? 1u : 0u;
     d.log_n = d.log_on ? cfg->shard_channels : d.N;
     d.log_eid0 = ctx->cfg.entity_channel_id_start ? ctx->cfg.entity_channel_id_start : 0x80000u;
@@ -1073,7 +1111,10 @@ int chd_world_create(chd_ctx *ctx, const chd_world_cfg *cfg) {
     TRY(walloc(ctx, &d.pair_iv, P));
     TRY(walloc(ctx, &d.pair_last, P));
     TRY(walloc(ctx, &d.pair_flags, P));
-    TRY(walloc(ctx, &d.conn_defer, S));
+    TRY(walloc(ctx, &d.conn_defer, S + 4));  // (+ 4: k_fanout_scan reads four connections' words with one load)
+    TRY(walloc(ctx, &d.defer_list, S));
+    TRY(walloc(ctx, &d.deep_list, S));
+    TRY(walloc(ctx, &d.tail_ctl, 16));
     TRY(walloc(ctx, &d.n_simple, S));
     TRY(walloc(ctx, &d.emit_ticket, 8 * 32));
     TRY(walloc(ctx, &d.seg_desc, P, false));
@@ -1081,7 +1122,7 @@ int chd_world_create(chd_ctx *ctx, const chd_world_cfg *cfg) {
     TRY(walloc(ctx, &d.seg_ln, P, false));
     TRY(walloc(ctx, &d.pair_rel, P));
     TRY(walloc(ctx, &d.pair_nrec, P));
-    TRY(walloc(ctx, &d.rec_ub, S + 1));
+    TRY(walloc(ctx, &d.rec_ub, S + 1 + 4));
     TRY(walloc(ctx, &d.rec_cnt, S));
     TRY(walloc(ctx, &W.rec_off_exact, S + 1));
     d.handovers_cap = cfg->max_handovers ? cfg->max_handovers : d.N;
@@ -1132,7 +1173,7 @@ int chd_world_create(chd_ctx *ctx, const chd_world_cfg *cfg) {
         W.pb_ce_chan[0] = d.ce_chan; W.pb_recs[0] = d.recs; W.pb_ticket[0] = d.emit_ticket;
         TRY(walloc(ctx, &W.pb_ticket[1], 8 * 32));
         TRY(walloc(ctx, &W.pb_n_simple[1], S));
-        TRY(walloc(ctx, &W.pb_rec_ub[1], S + 1));
+        TRY(walloc(ctx, &W.pb_rec_ub[1], S + 1 + 4));
         TRY(walloc(ctx, &W.pb_seg_desc[1], P, false));
         TRY(walloc(ctx, &W.pb_seg_desc2[1], P, false));
         TRY(walloc(ctx, &W.pb_ce_chan[1], (size_t)(CHD_WCOLS + 1) * d.wcol_stride + 520));
@@ -1173,7 +1214,7 @@ int chd_world_create(chd_ctx *ctx, const chd_world_cfg *cfg) {
         TRY(walloc(ctx, &d.cell_irr, C));
         TRY(walloc(ctx, &d.cell_max_iv, 2 * C));
         TRY(walloc(ctx, &d.ent_max_iv, LN));
-        TRY(walloc(ctx, &d.conn_deep, S));
+        TRY(walloc(ctx, &d.conn_deep, S + 4));
         TRY(walloc(ctx, &d.ce_slot, N + 2));
         // drop = INT64_MIN ("nothing was ever dropped"): the byte pattern 0x80 repeated is a very negative int64 as well
         HIPCHK(hipMemsetAsync(d.deep_drop, 0x80, sizeof(int64_t) * LN, ctx->stream));
@@ -1199,13 +1240,10 @@ int chd_world_create(chd_ctx *ctx, const chd_world_cfg *cfg) {
             d.fcm_on = C * S <= (1ull << 25) ? 1u : 0u;  // (32 B per entry: at most 1 GiB)
             if (const char *e = getenv("CHD_FILT_CELL_MAJOR")) if (e[0] == '0') d.fcm_on = 0;
             if (d.fcm_on) {
-                d.cell_sorted = nullptr;
-                // CHD_SORT_ARRIVALS=1: the cells' entries in arrival order (k_cell_sort0) and the windows inside a tick's own arrivals as
-                // runs of the column (k_fanout_emit_filt_cm).  OFF by default: measured on config B (profiles/r06c_ab_filt.csv) the
-                // record kernels gain 14-15 us per tick and the sort costs 24.6 — it has to come off the tick's critical path, or out
-                // of the index scatter itself, before it pays
-                const char *so = getenv("CHD_SORT_ARRIVALS");
-                if (so && so[0] == '1') TRY(walloc(ctx, &d.cell_sorted, C));
+                // the cells' entries in the order of the tick's arrivals (k_cell_arrange, the launch that also takes the cells' offset
+                // ranges) and the part of a window inside the tick's own arrivals as a run of the column (k_fanout_emit_filt_cm);
+                // CHD_SORT_ARRIVALS=0 keeps the entries in slot order (A/B runs)
+                TRY(walloc(ctx, &d.cell_sorted, C));
                 TRY(walloc(ctx, &d.cell_fcnt, C * 32));
                 TRY(walloc(ctx, &d.cell_flist, 2 * C * S, false));
                 TRY(walloc(ctx, &d.filt_items, P / 16 + C + 1, false));  // (work items of >= 16 descriptors: FC_DESCS)
@@ -1312,7 +1350,7 @@ int chd_world_create(chd_ctx *ctx, const chd_world_cfg *cfg) {
     TRY(after_launch(ctx));
     HIPCHK(hipStreamSynchronize(ctx->stream));
     if (W.gate_asked) TRY(gate_probe(ctx));
-    if (const char *e = getenv("CHD_TEST_DROP_GATE_RAISE")) W.test_drop_raise = strtoull(e, nullptr, 0);
+    if (const char *e = test_hook_env("CHD_TEST_DROP_GATE_RAISE")) W.test_drop_raise = strtoull(e, nullptr, 0);
     W.created = true;
     return CHD_OK;
 }
@@ -1770,9 +1808,8 @@ static int tick_locked(chd_ctx *ctx, const chd_tick_in *in) {
         if (prof) HIPCHK(hipEventRecord(ev[CHD_N_STAGES + 3], st));
         if (prof_ends) HIPCHK(hipEventRecord(ev[5], st));
         HIPCHK(hipEventRecord(W.ev_emit_done[par], st));
-        launch_fanout_emit_deferred(bs, ctx->g, d, in->now_ns, r);
-        if (W.gated) launch_tick_epilogue(bs, d, r.cur_tick % TICK_RING, ctx->g.ncell, W.gate + GATE_EPI, ++W.gate_epi);
-        else launch_tick_epilogue(bs, d, r.cur_tick % TICK_RING, ctx->g.ncell);
+        if (W.gated) launch_fanout_tail(bs, ctx->g, d, in->now_ns, r, r.cur_tick % TICK_RING, W.gate + GATE_EPI, ++W.gate_epi);
+        else launch_fanout_tail(bs, ctx->g, d, in->now_ns, r, r.cur_tick % TICK_RING);
         if (prof_ends) HIPCHK(hipEventRecord(ev[4], bs));
         // ... and whatever is enqueued on `stream` after this tick comes after ALL of it
         HIPCHK(hipEventRecord(W.ev_stages_all, bs));
@@ -1788,8 +1825,7 @@ static int tick_locked(chd_ctx *ctx, const chd_tick_in *in) {
         if (prof) HIPCHK(hipEventRecord(ev[CHD_N_STAGES + 4], st));
         launch_fanout_emit_main(st, ctx->g, d, in->now_ns, r);
         if (prof) HIPCHK(hipEventRecord(ev[CHD_N_STAGES + 3], st));
-        launch_fanout_emit_deferred(ctx->aux_stream, ctx->g, d, in->now_ns, r);
-        launch_tick_epilogue(ctx->aux_stream, d, r.cur_tick % TICK_RING, ctx->g.ncell);
+        launch_fanout_tail(ctx->aux_stream, ctx->g, d, in->now_ns, r, r.cur_tick % TICK_RING);
         HIPCHK(hipEventRecord(ctx->ev_join, ctx->aux_stream));
         HIPCHK(hipStreamWaitEvent(st, ctx->ev_join, 0));
         if (prof_ends) HIPCHK(hipEventRecord(ev[5], st));
@@ -1799,11 +1835,10 @@ static int tick_locked(chd_ctx *ctx, const chd_tick_in *in) {
         if (prof && !d.off_on) HIPCHK(hipEventRecord(ev[CHD_N_STAGES + 3], st));
         launch_fanout_emit_filt(st, ctx->g, d);
         if (prof && d.off_on) HIPCHK(hipEventRecord(ev[CHD_N_STAGES + 3], st));  // (emit_main_us: both record-writing kernels)
-        launch_fanout_emit_deferred(st, ctx->g, d, in->now_ns, r);
-        launch_fanout_emit_deep(st, ctx->g, d, in->now_ns, r);
+        // (the deferred subscriptions, the element walk and the epilogue: one launch)
+        if (W.gated) launch_fanout_tail(st, ctx->g, d, in->now_ns, r, r.cur_tick % TICK_RING, W.gate + GATE_EPI, ++W.gate_epi);
+        else launch_fanout_tail(st, ctx->g, d, in->now_ns, r, r.cur_tick % TICK_RING);
         if (prof_ends) HIPCHK(hipEventRecord(ev[5], st));
-        if (W.gated) launch_tick_epilogue(st, d, r.cur_tick % TICK_RING, ctx->g.ncell, W.gate + GATE_EPI, ++W.gate_epi);
-        else launch_tick_epilogue(st, d, r.cur_tick % TICK_RING, ctx->g.ncell);
     }
     TRY(after_launch(ctx));
     ctx->chain = pipe;
@@ -2500,6 +2535,7 @@ static int shard_ingest_pre_locked(chd_ctx *ctx, int64_t now_ns, const double *d
                              ctx->ring.cur_tick, rank, world, (uint4 *)d_req_send, req_cap);
     // (log_on: the tick's updates are logged after the emigrant exchange — shard_import_locked — which also carries the cells' maxFanOutIntervalMs)
     W.log_x = d_x_by_chan; W.log_z = d_z_by_chan; W.log_has = d_has_update; W.log_nchan = n_chan;
+    W.ingest_pending = true;  // (chd_shard_import consumes it: one import per ingest — a second one would log the tick's updates twice)
     return CHD_OK;
 }
 
@@ -2567,7 +2603,7 @@ int chd_shard_ingest(chd_ctx *ctx, int64_t now_ns, const double *d_x_by_chan, co
 }
 
 static int shard_import_locked(chd_ctx *ctx, const chd_entity_state *d_recv, uint32_t world, uint32_t cap, void *d_halo_send) {
-    if (ctx->w.slot_mode != 2) return fail(ctx, CHD_E_STATE, "chd_shard_import before chd_shard_ingest");
+    if (ctx->w.slot_mode != 2 || !ctx->w.ingest_pending) return fail(ctx, CHD_E_STATE, "chd_shard_import before chd_shard_ingest (one import per ingest)");
     World &W = ctx->w;
     if (world > 1 && (W.halo_world != world || !d_halo_send)) return fail(ctx, CHD_E_STATE, "chd_shard_import: call chd_shard_halo_layout(rank, world) first and pass the halo send buffer");
     TRY(bind(ctx));
@@ -2588,6 +2624,8 @@ static int shard_import_locked(chd_ctx *ctx, const chd_entity_state *d_recv, uin
     }
     // log_on: ChannelData.OnUpdate for every channel of the world, under the cells' world-wide maxFanOutIntervalMs (just folded)
     launch_log_push(st, ctx->g, d, W.log_x, W.log_z, W.log_has, W.log_nchan, ctx->ring.cur_tick, W.last_now);
+    W.log_x = W.log_z = nullptr; W.log_has = nullptr; W.log_nchan = 0;  // (the caller's arrays are its own again)
+    W.ingest_pending = false;
     launch_index_build(st, ctx->g, d, ctx->ring.cur_tick, nullptr, 0, W.last_now);
     if (world > 1) launch_halo_pack(st, ctx->g, d, W.halo_rank, world, ctx->g.border, (unsigned char *)d_halo_send, W.d_halo_send_off);
     TRY(after_launch(ctx));
@@ -2669,11 +2707,9 @@ static int shard_fanout_locked(chd_ctx *ctx, const void *d_halo_recv, uint32_t w
     if (prof && !d.off_on) HIPCHK(hipEventRecord(ev[CHD_N_STAGES + 3], st));
     launch_fanout_emit_filt(st, ctx->g, d);
     if (prof && d.off_on) HIPCHK(hipEventRecord(ev[CHD_N_STAGES + 3], st));  // (emit_main_us: both record-writing kernels)
-    launch_fanout_emit_deferred(st, ctx->g, d, now, r);
-    launch_fanout_emit_deep(st, ctx->g, d, now, r);
+    if (W.gated) launch_fanout_tail(st, ctx->g, d, now, r, r.cur_tick % TICK_RING, W.gate + GATE_EPI, ++W.gate_epi);
+    else launch_fanout_tail(st, ctx->g, d, now, r, r.cur_tick % TICK_RING);
     if (prof_ends) HIPCHK(hipEventRecord(ev[5], st));
-    if (W.gated) launch_tick_epilogue(st, d, r.cur_tick % TICK_RING, ctx->g.ncell, W.gate + GATE_EPI, ++W.gate_epi);
-    else launch_tick_epilogue(st, d, r.cur_tick % TICK_RING, ctx->g.ncell);
     TRY(after_launch(ctx));
     if (d_in->n_queries) W.last_nq = d_in->n_queries;
     W.ticked = true;
@@ -2716,6 +2752,12 @@ int chd_shard_log_spawn(chd_ctx *ctx, uint32_t n, const uint32_t *chan_id, const
     if (!chan_id || !x || !z) return fail(ctx, CHD_E_INVAL, "chd_shard_log_spawn: NULL buffer");
     std::lock_guard<FairMutex> lk(ctx->mu);
     if (!ctx->w.d.log_on) return fail(ctx, CHD_E_STATE, "chd_shard_log_spawn: the world keeps no update log by channel id (chd_world_cfg.shard_channels)");
+    // (the ids are checked HERE, on the host, as chd_shard_spawn does: the tick's sticky overflow mask is no place to look — an earlier
+    // slot overflow would fail a valid call, and a bit set here would show up in the next tick as a bogus "no free slot")
+    for (uint32_t k = 0; k < n; k++)
+        if (chan_id[k] < ctx->w.d.log_eid0 || chan_id[k] - ctx->w.d.log_eid0 >= ctx->w.d.log_n)
+            return fail(ctx, CHD_E_CAPACITY, "chd_shard_log_spawn: channel id %u outside entity_channel_id_start .. + shard_channels (%u .. %u)", chan_id[k],
+                        ctx->w.d.log_eid0, ctx->w.d.log_eid0 + ctx->w.d.log_n - 1u);
     TRY(bind(ctx));
     TRY(ensure(ctx, 1, 4 * (size_t)n));
     TRY(ensure(ctx, 2, 8 * (size_t)n)); TRY(ensure(ctx, 3, 8 * (size_t)n));
@@ -2724,10 +2766,7 @@ int chd_shard_log_spawn(chd_ctx *ctx, uint32_t n, const uint32_t *chan_id, const
     TRY(up(ctx, sbuf<void>(ctx, 3), z, 8 * (size_t)n));
     launch_log_spawn(ctx->stream, ctx->g, ctx->w.d, n, sbuf<uint32_t>(ctx, 1), sbuf<double>(ctx, 2), sbuf<double>(ctx, 3));
     TRY(after_launch(ctx));
-    uint32_t ovf = 0;
-    TRY(down(ctx, &ovf, ctx->w.d.counters + CTR_OVERFLOW, 4));
-    HIPCHK(hipStreamSynchronize(ctx->stream));
-    if (ovf & OVF_SLOTS) return fail(ctx, CHD_E_CAPACITY, "chd_shard_log_spawn: a channel id outside entity_channel_id_start .. + shard_channels");
+    HIPCHK(hipStreamSynchronize(ctx->stream));  // (the staging buffers are the context's)
     return CHD_OK;
 }
 
@@ -2864,9 +2903,11 @@ int pipe_open(chd_ctx *ctx, const unsigned char *id, uint32_t rank, uint32_t wor
     snprintf(nm, sizeof nm, "/chd_pipe_%02x%02x%02x%02x%02x%02x%02x%02x", id[8], id[9], id[10], id[11], id[12], id[13], id[14], id[15]);
     p->name = nm;
     p->fd = shm_open(nm, O_CREAT | O_RDWR, 0600);
-    if (p->fd < 0 || ftruncate(p->fd, (off_t)p->total) != 0) { delete p; return fail(ctx, CHD_E_STATE, "hostpipe: shm_open(%s) failed", nm); }
+    if (p->fd < 0) { delete p; return fail(ctx, CHD_E_STATE, "hostpipe: shm_open(%s) failed", nm); }
+    // (a rank that fails here takes the name with it: its peers' attach then times out instead of finding a half-made segment)
+    if (ftruncate(p->fd, (off_t)p->total) != 0) { close(p->fd); shm_unlink(nm); delete p; return fail(ctx, CHD_E_STATE, "hostpipe: ftruncate(%s) failed", nm); }
     p->base = (unsigned char *)mmap(nullptr, p->total, PROT_READ | PROT_WRITE, MAP_SHARED, p->fd, 0);
-    if (p->base == MAP_FAILED) { close(p->fd); delete p; return fail(ctx, CHD_E_STATE, "hostpipe: mmap failed"); }
+    if (p->base == MAP_FAILED) { close(p->fd); shm_unlink(nm); delete p; return fail(ctx, CHD_E_STATE, "hostpipe: mmap failed"); }
     p->sent.assign(world, 0); p->rcvd.assign(world, 0);
     // the last rank to attach unlinks the name: nothing is left behind whatever happens later
     auto *attached = (std::atomic<uint32_t> *)(p->base + p->total - 128);
@@ -2970,14 +3011,14 @@ static int comm_teardown(chd_ctx *ctx) {
 
 int chd_shard_comm_available(void) {
     chd_ctx *ctx = nullptr;
-    if (const char *e = getenv("CHD_SHARD_TRANSPORT")) if (!strcmp(e, "hostpipe")) return CHD_OK;  // (the test transport needs no RCCL)
+    if (const char *e = test_hook_env("CHD_SHARD_TRANSPORT")) if (!strcmp(e, "hostpipe")) return CHD_OK;  // (the test transport needs no RCCL)
     return rccl_load(ctx);
 }
 
 int chd_shard_comm_unique_id(void *id_out) {
     if (!id_out) return fail(nullptr, CHD_E_INVAL, "chd_shard_comm_unique_id: NULL output");
     chd_ctx *ctx = nullptr;
-    if (const char *e = getenv("CHD_SHARD_TRANSPORT")) if (!strcmp(e, "hostpipe")) {  // (the TEST transport: the id names its shared-memory segment)
+    if (const char *e = test_hook_env("CHD_SHARD_TRANSPORT")) if (!strcmp(e, "hostpipe")) {  // (the TEST transport: the id names its shared-memory segment)
         memset(id_out, 0, CHD_COMM_ID_BYTES);
         memcpy(id_out, PIPE_MAGIC, 8);
         std::random_device rd;
@@ -3000,6 +3041,9 @@ int chd_shard_comm_init(chd_ctx *ctx, const void *unique_id, uint32_t rank, uint
     if (world != ctx->g.server_cols * ctx->g.server_rows)
         return fail(ctx, CHD_E_INVAL, "chd_shard_comm_init: %u ranks but the grid has %u server regions", world, ctx->g.server_cols * ctx->g.server_rows);
     const bool hostpipe = !memcmp(unique_id, PIPE_MAGIC, 8);  // (CHD_SHARD_TRANSPORT=hostpipe where the id was drawn: the TEST transport)
+#ifdef CHD_NO_TEST_HOOKS
+    if (hostpipe) return fail(ctx, CHD_E_STATE, "chd_shard_comm_init: the id names the hostpipe TEST transport, which this build leaves out (CHD_NO_TEST_HOOKS)");
+#endif
     if (!hostpipe) TRY(rccl_load(ctx));
     std::lock_guard<FairMutex> lk(ctx->mu);
     TRY(bind(ctx));
@@ -3036,13 +3080,17 @@ int chd_shard_comm_init(chd_ctx *ctx, const void *unique_id, uint32_t rank, uint
     W.comm_cap = migrate_cap;
     const size_t seg = (size_t)migrate_cap + 1 + migrate_extra(ctx);
     int rc = CHD_OK;
-    if (!W.mig_send) {  // (world allocations: kept across chd_shard_comm_destroy / a second init of the same size)
-        if (rc == CHD_OK) rc = walloc(ctx, &W.mig_send, (size_t)world * seg);
-        if (rc == CHD_OK) rc = walloc(ctx, &W.mig_recv, (size_t)world * seg);
-        if (rc == CHD_OK) rc = walloc(ctx, &W.halo_send_buf, std::max<uint64_t>(st, 16));
-        if (rc == CHD_OK) rc = walloc(ctx, &W.halo_recv_buf, std::max<uint64_t>(rt, 16));
-        W.comm_alloc_cap = migrate_cap;
-        W.comm_alloc_world = world;
+    if (!W.comm_alloc_cap) {  // (world allocations: kept across chd_shard_comm_destroy / a second init of the same size)
+        // each buffer on its own pointer: a call that failed half-way is repeated from where it stopped, and the sizes are noted
+        // only once all four exist
+        if (W.mig_send && (W.comm_try_cap != migrate_cap || W.comm_try_world != world))
+            rc = fail(ctx, CHD_E_STATE, "chd_shard_comm_init: an earlier, failed call began to size the exchange buffers for %u ranks x %u emigrants", W.comm_try_world, W.comm_try_cap);
+        W.comm_try_cap = migrate_cap; W.comm_try_world = world;
+        if (rc == CHD_OK && !W.mig_send) rc = walloc(ctx, &W.mig_send, (size_t)world * seg);
+        if (rc == CHD_OK && !W.mig_recv) rc = walloc(ctx, &W.mig_recv, (size_t)world * seg);
+        if (rc == CHD_OK && !W.halo_send_buf) rc = walloc(ctx, &W.halo_send_buf, std::max<uint64_t>(st, 16));
+        if (rc == CHD_OK && !W.halo_recv_buf) rc = walloc(ctx, &W.halo_recv_buf, std::max<uint64_t>(rt, 16));
+        if (rc == CHD_OK) { W.comm_alloc_cap = migrate_cap; W.comm_alloc_world = world; }
     } else if (W.comm_alloc_cap != migrate_cap || W.comm_alloc_world != world) {
         rc = fail(ctx, CHD_E_STATE, "chd_shard_comm_init: the context's exchange buffers were sized for %u ranks x %u emigrants", W.comm_alloc_world, W.comm_alloc_cap);
     }

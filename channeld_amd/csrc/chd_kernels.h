@@ -214,6 +214,14 @@ struct WorldDev {
     uint32_t *emit_ticket;          // [8 x 32] k_fanout_emit_seg's ticket counters, one 128-byte line each (zeroed by k_fanout_plan_seg)
     WsItemG *items;                 // [ncell * ceil(S/256)]
     uint32_t *conn_defer; // [S] this tick: the connection has subscriptions left to the deferred emit launch
+    // The tick's TAIL LISTS (k_fanout_scan, the single-workgroup pass behind the plan): the connections with deferred subscriptions
+    // (defer_list) and with PF_DEEP ones (deep_list), compacted in slot order, and the first connection without room for its records
+    // (rec_ub[s + 1] > recs_cap; the exclusive prefix is monotonic, so every later one has none either).  The plan COMMITS a
+    // subscription's new fan-out state itself and keeps the old one in seg_ln / seg_desc2.z (filt_ln / filt_desc2.z); the deferred
+    // launch walks defer_list and puts the old state back for the connections from tail_ctl[TC_SCAP] on — a launch over a few
+    // workgroups instead of one per connection slot (9.7 us for ~0 deferred records at config B).
+    uint32_t *defer_list, *deep_list;  // [S]
+    uint32_t *tail_ctl;   // [16] TC_*
     // descriptor-driven emit (k_fanout_plan_seg -> k_fanout_emit_seg): per connection the first n_simple[s] entries of its
     // row [s*capq, ...) describe the due subscriptions whose every window is a plain copy of the cell's channel column
     uint32_t *n_simple;   // [S]
@@ -305,19 +313,41 @@ __device__ __forceinline__ void off_shift(uint32_t (&o)[CHD_OFF_SLOTS], uint32_t
     for (int j = 0; j < (int)CHD_OFF_SLOTS; j++) o[j] = r[j];
 }
 
+// Every word of channel i's update log that push_update reads, requested TOGETHER and unconditionally (the caller issues this with its
+// other loads, before any test: the ingest launches are one short workgroup per CU and as long as their chain of dependent round
+// trips — with each of these words behind "alive?", "another sender?", "exact buffers?" that chain was six trips long).
+struct UpdPre {
+    uint32_t hist_tick, hist, hist_prev, sender, sender_prev;
+    uint4 oa, ob;                    // eoff (off_on)
+    uint32_t deep_n, deep_len, miv;  // exact buffers (deep_depth)
+    int64_t deep_drop;
+};
+__device__ __forceinline__ UpdPre upd_prefetch(const WorldDev &w, uint32_t i) {
+    UpdPre p;
+    p.hist_tick = w.hist_tick[i]; p.hist = w.hist[i]; p.hist_prev = w.hist_prev[i]; p.sender = w.sender[i]; p.sender_prev = w.sender_prev[i];
+    // (not kept by this world: any readable words, unused — a load behind a uniform test would still be awaited at the join)
+    const uint4 *ep = w.off_on ? w.eoff : (const uint4 *)(const void *)w.hist;
+    const size_t ei = w.off_on ? 2 * (size_t)i : 0;
+    p.oa = ep[ei]; p.ob = ep[ei + 1];
+    const uint32_t *dn = w.deep_depth ? w.deep_n : w.hist, *dl = w.deep_depth ? w.deep_len : w.hist, *dm = w.deep_depth ? w.ent_max_iv : w.hist;
+    const int64_t *dd = w.deep_depth ? w.deep_drop : (const int64_t *)(const void *)w.hist;
+    const uint32_t di = w.deep_depth ? i : 0u;
+    p.deep_n = dn[di]; p.deep_len = dl[di]; p.miv = dm[di]; p.deep_drop = dd[di];
+    return p;
+}
+
 // c_old / c_new: the cells of the entity's last merged position and of this update's (CHD_INVALID: out of the world)
-__device__ __forceinline__ void push_update(const WorldDev &w, uint32_t i, uint32_t snd, uint32_t cur_tick, uint32_t c_old, uint32_t c_new,
-                                            int64_t arrival = 0, int64_t now = 0) {
-    const uint32_t age = cur_tick - w.hist_tick[i];
-    uint32_t h = (age >= CHD_HIST_BITS) ? 0u : (w.hist[i] << age);
-    uint32_t hp = (age >= CHD_HIST_BITS) ? 0u : (w.hist_prev[i] << age);
-    const uint32_t cur = w.sender[i];
+__device__ __forceinline__ void push_update_pre(const WorldDev &w, uint32_t i, const UpdPre &P, uint32_t snd, uint32_t cur_tick, uint32_t c_old, uint32_t c_new,
+                                                int64_t arrival = 0, int64_t now = 0) {
+    const uint32_t age = cur_tick - P.hist_tick;
+    uint32_t h = (age >= CHD_HIST_BITS) ? 0u : (P.hist << age);
+    uint32_t hp = (age >= CHD_HIST_BITS) ? 0u : (P.hist_prev << age);
+    const uint32_t cur = P.sender;
     bool irregular = arrival != now;  // (the masks stand for "arrived with the tick's own stamp")
     if (w.off_on) {
         // ... or, with the per-slot offsets, "arrived inside the tick's own interval": (previous tick, this tick], one per tick
         const uint64_t off = (uint64_t)(now - arrival);
-        uint4 a = w.eoff[2 * (size_t)i], b = w.eoff[2 * (size_t)i + 1];
-        uint32_t o[CHD_OFF_SLOTS] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+        uint32_t o[CHD_OFF_SLOTS] = {P.oa.x, P.oa.y, P.oa.z, P.oa.w, P.ob.x, P.ob.y, P.ob.z, P.ob.w};
         off_shift(o, age);
         irregular = !(arrival > w.prev_ns && arrival <= now && off <= 0xFFFFFFFEull);  // (0xFFFFFFFF stands for "no update" in the staged columns)
         if (age == 0 && ((h | hp) & 1u) && o[0] != (uint32_t)off) irregular = true;  // a second update in this tick, another stamp
@@ -326,7 +356,7 @@ __device__ __forceinline__ void push_update(const WorldDev &w, uint32_t i, uint3
         w.eoff[2 * (size_t)i + 1] = make_uint4(o[4], o[5], o[6], o[7]);
     }
     if (snd != cur) {
-        const uint32_t prev = w.sender_prev[i];
+        const uint32_t prev = P.sender_prev;
         if (snd == prev) {  // the previous sender is back: the two histories swap roles
             const uint32_t t = h;
             h = hp;
@@ -349,11 +379,11 @@ __device__ __forceinline__ void push_update(const WorldDev &w, uint32_t i, uint3
     w.hist_prev[i] = hp;
     w.hist_tick[i] = cur_tick;
     if (w.deep_depth) {
-        uint32_t n = w.deep_n[i], len = w.deep_len[i];
-        int64_t drop = w.deep_drop[i];
+        uint32_t n = P.deep_n, len = P.deep_len;
+        int64_t drop = P.deep_drop;
         const size_t at = (size_t)i * w.deep_depth;
         // the entity channel's maxFanOutIntervalMs (WorldDev::ent_max_iv): the subscribers of the cells that hold it are its own
-        uint32_t miv = w.ent_max_iv[i];
+        uint32_t miv = P.miv;
         const uint32_t m_old = c_old != CHD_INVALID ? w.cell_max_iv[c_old] : 0u, m_new = c_new != CHD_INVALID ? w.cell_max_iv[c_new] : 0u;
         if (m_old > miv || m_new > miv) { miv = max(miv, max(m_old, m_new)); w.ent_max_iv[i] = miv; }
         deep_push(w.deep_a + at, w.deep_s + at, w.deep_depth, n, len, drop, arrival, snd, miv);
@@ -362,6 +392,12 @@ __device__ __forceinline__ void push_update(const WorldDev &w, uint32_t i, uint3
         w.deep_drop[i] = drop;
         if (irregular) w.irr_tick[i] = cur_tick + 1u;
     }
+}
+// (one update on its own: the spawn / by-channel paths)
+__device__ __forceinline__ void push_update(const WorldDev &w, uint32_t i, uint32_t snd, uint32_t cur_tick, uint32_t c_old, uint32_t c_new,
+                                            int64_t arrival = 0, int64_t now = 0) {
+    const UpdPre P = upd_prefetch(w, i);
+    push_update_pre(w, i, P, snd, cur_tick, c_old, c_new, arrival, now);
 }
 
 // a channel's sub-tick arrival offsets (WorldDev::off_on; u = its log index), aligned to this tick, into the cell-sorted columns
@@ -590,15 +626,18 @@ void launch_adjacent_recipients(hipStream_t st, DevGrid g, WorldDev w, uint32_t 
                                 const uint32_t *broadcast, const uint32_t *sender_conn, const uint32_t *client_conn,
                                 uint32_t *off, uint32_t *conns, uint64_t cap, int fill);
 // K5: fan-out
+#define TC_NDEFER 0
+#define TC_NDEEP 1
+#define TC_SCAP 2
 void launch_fanout_plan(hipStream_t st, DevGrid g, WorldDev w, int64_t now_ns, TickRing ring);
 bool fanout_seg_path(const WorldDev &w);
 void launch_fanout_emit_main(hipStream_t st, DevGrid g, WorldDev w, int64_t now_ns, TickRing ring);
-void launch_fanout_emit_deferred(hipStream_t st, DevGrid g, WorldDev w, int64_t now_ns, TickRing ring);
+// the tick's tail in one launch: deferred subscriptions, connections without room, the element walk (PF_DEEP), the epilogue
+void launch_fanout_tail(hipStream_t st, DevGrid g, WorldDev w, int64_t now_ns, TickRing ring, uint32_t slot, unsigned long long *epi = nullptr,
+                        unsigned long long epi_seq = 0);
 // the filtered descriptors (WorldDev::filt_*); no-op unless off_on
 void launch_fanout_emit_filt(hipStream_t st, DevGrid g, WorldDev w);
 // per cell and ring slot the range of the sub-tick offsets (WorldDev::cell_orng); after the index build, off_on worlds only
 void launch_cell_offsets(hipStream_t st, DevGrid g, WorldDev w);
-// subscriptions the tick-ring masks cannot answer (PF_DEEP), from the exact update buffers; no-op without history_depth
-void launch_fanout_emit_deep(hipStream_t st, DevGrid g, WorldDev w, int64_t now_ns, TickRing ring);
 #define TICK_RING 1024
 void launch_tick_epilogue(hipStream_t st, WorldDev w, uint32_t slot, uint32_t ncell, unsigned long long *epi = nullptr, unsigned long long epi_seq = 0);

@@ -244,6 +244,7 @@ static bool seg_path(const WorldDev &w) { return !w.cm_emit && !w.seg_off && (w.
 
 template <bool OFF>
 __global__ void __launch_bounds__(64 * FO_WAVES) k_fanout_plan_seg(DevGrid g, WorldDev w, int64_t now, TickRing ring);
+__global__ void __launch_bounds__(1024) k_fanout_scan(WorldDev w, uint32_t ncell, int seg);
 
 void launch_fanout_plan(hipStream_t st, DevGrid g, WorldDev w, int64_t now_ns, TickRing ring) {
     if (!w.S) return;
@@ -253,7 +254,7 @@ void launch_fanout_plan(hipStream_t st, DevGrid g, WorldDev w, int64_t now_ns, T
     } else
         hipLaunchKernelGGL(k_fanout_plan, dim3((w.S + FO_WAVES - 1) / FO_WAVES), dim3(64 * FO_WAVES), 0, st, g, w,
                            now_ns, ring);
-    launch_scan_u64_inplace(st, w.rec_ub, w.S);
+    hipLaunchKernelGGL(k_fanout_scan, dim3(1), dim3(1024), 0, st, w, g.ncell, seg_path(w) ? 1 : 0);
     if (w.cm_emit) hipLaunchKernelGGL(k_active_cells, dim3(1), dim3(1024), 0, st, w, g.ncell);
 }
 
@@ -631,7 +632,7 @@ __device__ __forceinline__ uint32_t emit_cell_all(const uint32_t *__restrict__ c
 // DEFERRED: second launch behind k_fanout_emit_seg — only the subscriptions k_fanout_plan_seg marked PF_DEFER (their
 // connections are flagged in conn_defer; every other workgroup exits at once), record counts ADDED to the first launch's.
 template <int WAVES, bool MASKS, bool DEFERRED = false>
-__global__ void __launch_bounds__(64 * WAVES) k_fanout_emit(DevGrid g, WorldDev w, int64_t now, TickRing ring) {
+__device__ __forceinline__ void fanout_emit_conn(const DevGrid &g, const WorldDev &w, int64_t now, const TickRing &ring, const uint32_t s) {
     constexpr uint32_t FO_TILE = 64 * WAVES;
     // due subscriptions of this connection, staged once per workgroup so that the
     // streaming waves never wait on per-subscription pointer chasing
@@ -640,7 +641,6 @@ __global__ void __launch_bounds__(64 * WAVES) k_fanout_emit(DevGrid g, WorldDev 
     __shared__ int64_t d_L[FO_TILE];
     __shared__ uint32_t n_due, ticket;
     __shared__ uint32_t wave_total[WAVES];
-    const uint32_t s = blockIdx.x;
     const uint32_t lane = lane_id();
     const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     if (!DEFERRED && !w.sub_alive[s]) {
@@ -650,43 +650,16 @@ __global__ void __launch_bounds__(64 * WAVES) k_fanout_emit(DevGrid g, WorldDev 
     const uint32_t cnt = w.pair_cnt[s];
     const size_t pbase = (size_t)s * w.capq;
     const uint64_t base = w.rec_ub[s];
-    if (w.rec_ub[s + 1] > w.recs_cap) {
+    // (DEFERRED: k_fanout_emit_tail calls this only for connections that have room — fanout_no_room takes the others)
+    if (!DEFERRED && w.rec_ub[s + 1] > w.recs_cap) {
         // no room for this connection's worst case: leave its state untouched, it
-        // catches up next tick (the reference's catch-up loop), and say so.  (DEFERRED: also for the part
-        // k_fanout_emit_seg would have written — it skips such a connection without a word.)
-        if (!DEFERRED || w.rec_ub[s + 1] > base) {
-            for (uint32_t p = threadIdx.x; p < cnt; p += 64 * WAVES) w.pair_nrec[pbase + p] = 0;
-            if (threadIdx.x == 0) {
-                // (k_fanout_plan_seg has already counted the records it planned for this connection into the tick's total)
-                if (DEFERRED && w.rec_cnt[s])
-                    atomicAdd((unsigned long long *)&w.tot64[(size_t)(s & 63u) * 16], 0ull - (unsigned long long)w.rec_cnt[s]);
-                w.rec_cnt[s] = 0;
-                if (w.rec_ub[s + 1] > base) atomicOr(&w.counters[CTR_OVERFLOW], OVF_RECORDS);
-            }
+        // catches up next tick (the reference's catch-up loop), and say so.
+        for (uint32_t p = threadIdx.x; p < cnt; p += 64 * WAVES) w.pair_nrec[pbase + p] = 0;
+        if (threadIdx.x == 0) {
+            w.rec_cnt[s] = 0;
+            if (w.rec_ub[s + 1] > base) atomicOr(&w.counters[CTR_OVERFLOW], OVF_RECORDS);
         }
         return;
-    }
-    if (DEFERRED) {
-        // The subscriptions' new fan-out state (lastFanOutTime, hadFirstFanOut: data.go:217-223,271) for everything
-        // k_fanout_plan_seg decided: one coalesced pass over the connection's descriptors.  Here and not in
-        // k_fanout_emit_seg, which therefore reads nothing that a later tick's stages write and writes nothing but
-        // records: with CHD_WORLD_PIPELINE_TICKS it runs on the record stream while this launch, the epilogue and the
-        // next tick's stages run beside it.
-        const uint32_t ns = w.n_simple[s];
-        for (uint32_t k = lane; k < ns; k += 64) {
-            const uint4 d2 = w.seg_desc2[pbase + k];
-            w.pair_last[pbase + d2.y] = w.seg_ln[pbase + k];
-            w.pair_flags[pbase + d2.y] = d2.z;
-        }
-        if (w.off_on) {  // ... and for the filtered descriptors (k_fanout_emit_filt wrote their records)
-            const uint32_t nf = w.n_filt[s];
-            for (uint32_t k = lane; k < nf; k += 64) {
-                const uint4 d2 = w.filt_desc2[pbase + k];
-                w.pair_last[pbase + d2.y] = w.filt_ln[pbase + k];
-                w.pair_flags[pbase + d2.y] = d2.z;
-            }
-        }
-        if (!w.conn_defer[s]) return;
     }
 #ifdef CHD_PROFILE_CONN_EMIT
     long long ce_mark = clock64(), ce_pro = 0, ce_stage = 0, ce_ticket = 0, ce_decide = 0, ce_stream = 0, ce_tail = 0, ce_ls[3] = {0, 0, 0};
@@ -849,13 +822,52 @@ __global__ void __launch_bounds__(64 * WAVES) k_fanout_emit(DevGrid g, WorldDev 
     if (threadIdx.x == 0) {
         uint32_t t = 0;
         for (int k = 0; k < WAVES; k++) t += wave_total[k];
-        w.rec_cnt[s] = DEFERRED ? w.rec_cnt[s] + t : t;
+        if (DEFERRED) { if (t) atomicAdd(&w.rec_cnt[s], t); }  // (beside the element walk of the same connection: k_fanout_tail)
+        else w.rec_cnt[s] = t;
         // per-tick totals go through 64 hashed counters, one 128-byte line each: a
         // single word (or words sharing a line) would serialise S atomics at ~12 ns
         unsigned long long *slot = (unsigned long long *)&w.tot64[(size_t)(s & 63u) * 16];
         if (t) atomicAdd(slot, (unsigned long long)t);
         if (t && DEFERRED) atomicAdd(slot + 2, (unsigned long long)t);  // (bench.py: what the descriptor kernel did NOT write)
         if (cnt && !DEFERRED) atomicAdd(slot + 1, (unsigned long long)cnt);
+    }
+}
+
+template <int WAVES, bool MASKS>
+__global__ void __launch_bounds__(64 * WAVES) k_fanout_emit(DevGrid g, WorldDev w, int64_t now, TickRing ring) {
+    fanout_emit_conn<WAVES, MASKS, false>(g, w, now, ring, blockIdx.x);
+}
+
+// Descriptor path: a connection without room for its worst case this tick (rec_ub[s + 1] > recs_cap; the record kernels skip it without
+// a word): nothing of it was served, so the fan-out state the plan has already committed for its simple and filtered subscriptions
+// goes back to what the descriptors kept (seg_ln / seg_desc2.z), its record counts to zero, and the tick says so.  It catches up
+// next tick (the reference's catch-up loop).  One wave.
+__device__ __forceinline__ void fanout_no_room(const WorldDev &w, uint32_t s) {
+    const uint32_t lane = lane_id();
+    const size_t pbase = (size_t)s * w.capq;
+    const uint32_t cnt = w.sub_alive[s] ? w.pair_cnt[s] : 0u;
+    const uint32_t ns = w.n_simple[s];
+    for (uint32_t k = lane; k < ns; k += 64) {
+        const uint4 d2 = w.seg_desc2[pbase + k];
+        w.pair_last[pbase + d2.y] = w.seg_ln[pbase + k];
+        w.pair_flags[pbase + d2.y] = d2.z;
+    }
+    if (w.off_on) {
+        const uint32_t nf = w.n_filt[s];
+        for (uint32_t k = lane; k < nf; k += 64) {
+            const uint4 d2 = w.filt_desc2[pbase + k];
+            w.pair_last[pbase + d2.y] = w.filt_ln[pbase + k];
+            w.pair_flags[pbase + d2.y] = d2.z;
+        }
+    }
+    if (w.rec_ub[s + 1] > w.rec_ub[s]) {
+        for (uint32_t p = lane; p < cnt; p += 64) w.pair_nrec[pbase + p] = 0;
+        if (lane == 0) {
+            // (k_fanout_plan_seg has already counted the records it planned for this connection into the tick's total)
+            if (w.rec_cnt[s]) atomicAdd((unsigned long long *)&w.tot64[(size_t)(s & 63u) * 16], 0ull - (unsigned long long)w.rec_cnt[s]);
+            w.rec_cnt[s] = 0;
+            atomicOr(&w.counters[CTR_OVERFLOW], OVF_RECORDS);
+        }
     }
 }
 
@@ -943,6 +955,16 @@ __device__ __forceinline__ void plan_windows_off(const WorldDev &w, const TickRi
     off_shift(coff, cell_age < CHD_OFF_SLOTS ? cell_age : CHD_OFF_SLOTS);
     const int64_t nwin = (now - L) / I;
     if (nwin > 64) { o.deep = true; return; }  // (a long catch-up: the element walk handles any number of windows)
+    // The ring slots ANY lane of the wave can reach: the stamps do not increase with the slot index and no window starts before the
+    // lane's max(L, 0), so slots older than the wave's oldest start are skipped by a uniform branch — subscriptions served every
+    // tick reach two or three of the eight, and the unrolled slot loop below was what made this kernel instruction-bound (40 us).
+    uint32_t jn = 0;
+    {
+        const int64_t lo0 = L > 0 ? L : 0;
+#pragma unroll
+        for (int j = 0; j < (int)CHD_OFF_SLOTS; j++)
+            if ((uint32_t)j < ring.n && __ballot(ring.t[j] >= lo0) != 0) jn = (uint32_t)j + 1u;
+    }
     int64_t Lw = L;
     for (int64_t k = 0; k < nwin; k++) {
         const int64_t hi = Lw + I, lo = Lw > 0 ? Lw : 0;
@@ -950,7 +972,7 @@ __device__ __forceinline__ void plan_windows_off(const WorldDev &w, const TickRi
         bool undecided = false;
 #pragma unroll
         for (int j = 0; j < (int)CHD_OFF_SLOTS; j++) {
-            if ((uint32_t)j >= ring.n) continue;
+            if ((uint32_t)j >= jn) break;  // (uniform)
             const int64_t tj = ring.t[j];
             if (tj < lo) continue;  // the whole slot is older than the window
             const bool last = (uint32_t)(j + 1) >= ring.n;
@@ -1021,13 +1043,15 @@ __global__ void __launch_bounds__(64 * FO_WAVES) k_fanout_plan_seg(DevGrid g, Wo
         bool due = false, simple = false, deep = false, filt = false;
         uint32_t fl = 0, c = 0, size = 0, start = 0, info = 0, count = 0;
         uint32_t nd = 0, wcolp = 0, own = 0, ncol0 = 0;  // descriptors of this subscription; per window its column (4 bits each)
+        uint32_t nwin_s = 0;                               // its non-empty windows, when it is cut into chunks (cells beyond 512 entries)
         uint4 wm4 = make_uint4(0u, 0u, 0u, 0u);          // (per-record masks) the windows' masks
-        int64_t Lw = 0;
+        int64_t Lw = 0, Lold = 0;
         OffPlan op;
         op.nw = 0; op.own = 0; op.need = false; op.deep = false; op.Lw = 0;
         if (p < cnt) {
             fl = w.pair_flags[pbase + p] & ~(PF_DEFER | PF_DEEP);
             const int64_t L = w.pair_last[pbase + p];
+            Lold = L;
             const uint32_t iv = w.pair_iv[pbase + p];
             const int64_t I = (int64_t)iv * 1000000;
             // data.go:194-197: NO_ACCESS is skipped but stays queued
@@ -1105,9 +1129,12 @@ __global__ void __launch_bounds__(64 * FO_WAVES) k_fanout_plan_seg(DevGrid g, Wo
 #pragma unroll
                     for (int q = 0; q < 4; q++) wms[q] = op.full[q];
                 }
-                // (a column of up to 512 entries is four 8-byte loads per lane; larger cells take the deferred launch — and at
-                // >= 1024 entities per cell the cell-major form is the default anyway)
-                simple = chans != nullptr && nw <= 4 && size <= 512;
+                // (a column of up to 512 entries is four 8-byte loads per lane: a descriptor copies at most that.  A larger cell's windows
+                // are cut into CHUNKS of 512 entries, one descriptor per (window, chunk) — `big`; not for a first fan-out (its cell
+                // record + FULL-tagged entity records would need a second descriptor kind: the deferred launch keeps those) and not on
+                // wire worlds, whose layout reads a descriptor as a whole cell column)
+                const bool big = size > 512u;
+                simple = chans != nullptr && nw <= 4 && (!big || (!(info & SD_FIRST) && !w.rec_pos && size <= 1024u));  // (two chunks: a row of capq descriptors holds them)
                 // Which column every non-empty window copies: the cell's full column when every entity has an update inside
                 // the window (the AND of their histories intersects it), else — partially updating worlds — the WINDOW COLUMN
                 // of exactly that mask (wcol_mask: runs of 1..3 ticks that start at the newest or the one before — what a
@@ -1118,7 +1145,7 @@ __global__ void __launch_bounds__(64 * FO_WAVES) k_fanout_plan_seg(DevGrid g, Wo
                     // any window that is not a plain copy (an edge cuts through the arrivals of a tick, some entity skipped an update,
                     // only the spatial channel's own update passes), more than four windows, or a cell beyond the copy kernel's
                     // 512-entry column image: the filtered kernel
-                    const bool need = op.need || nw > 4 || (size > 512 && !(info & SD_FIRST));
+                    const bool need = op.need || nw > 4 || (big && !simple && !(info & SD_FIRST));
                     if (need) { filt = chans != nullptr && us != CHD_NONUNIFORM; simple = false; }
                 }
 #pragma unroll
@@ -1135,7 +1162,7 @@ __global__ void __launch_bounds__(64 * FO_WAVES) k_fanout_plan_seg(DevGrid g, Wo
                                 if (wms[j] == wcol_mask(k)) cj = k + 1u;
                         }
                     }
-                    if (cj == 0xFFFFFFFEu) simple = false;
+                    if (cj == 0xFFFFFFFEu || (big && cj != 0u)) simple = false;  // (chunks are cut from the full column only)
                     wcolp |= (cj & 15u) << (4u * j);
                     if (j && cj != (wcolp & 15u)) same = false;
                 }
@@ -1167,7 +1194,12 @@ __global__ void __launch_bounds__(64 * FO_WAVES) k_fanout_plan_seg(DevGrid g, Wo
                     if (own && w.rec_mask) simple = false;  // (the spatial channel's own record carries its own mask: the filtering launch)
                     wm4 = make_uint4(wms[0], wms[1], wms[2], wms[3]);
                     info |= nw | (none ? SD_NONE : 0u);
-                    if ((info & SD_FIRST) || nw == 0 || none || same) {
+                    if (big && nw != 0 && !none) {
+                        // one descriptor per (window, chunk of 512 entries)
+                        nwin_s = nw;
+                        nd = nw * ((size + 511u) >> 9);
+                        count = (uint32_t)__popc(own) + nw * size;
+                    } else if ((info & SD_FIRST) || nw == 0 || none || same) {
                         // one descriptor: first fan-out (full column, no window), nothing to send, or windows that agree
                         if ((info & SD_FIRST) || nw == 0 || none) wcolp = 0u;
                         const uint32_t col = wcolp & 15u;
@@ -1192,7 +1224,8 @@ __global__ void __launch_bounds__(64 * FO_WAVES) k_fanout_plan_seg(DevGrid g, Wo
         // descriptor slots of this round: exclusive prefix over the lanes; a connection's row holds capq descriptors — a
         // subscription that would not fit goes to the deferred launch instead (never seen: ~20 subscriptions per connection)
         uint32_t dbase;
-        if (w.wcol_on) {  // (uniform) a subscription may take several descriptors
+        const bool multi = w.wcol_on || __ballot(simple && nd > 1u) != 0;  // (uniform) a subscription may take several descriptors
+        if (multi) {
             uint32_t dinc = simple ? nd : 0u;
 #pragma unroll
             for (int d = 1; d < 64; d <<= 1) {
@@ -1229,8 +1262,12 @@ __global__ void __launch_bounds__(64 * FO_WAVES) k_fanout_plan_seg(DevGrid g, Wo
             if (due && filt) {
                 const size_t k = pbase + fbase;
                 w.filt_desc[k] = make_uint4(rel32, start, size, op.nw | (own << 8));
-                w.filt_desc2[k] = make_uint4(c, p, fl | PF_HAD_FIRST, s);
-                w.filt_ln[k] = Lw;
+                // (the subscription's new fan-out state is committed right here — data.go:217-223,271 — and the OLD one kept in the
+                // descriptor: the deferred launch puts it back for a connection that turns out to have no room, WorldDev::tail_ctl)
+                w.filt_desc2[k] = make_uint4(c, p, fl, s);
+                w.filt_ln[k] = Lold;
+                w.pair_last[pbase + p] = Lw;
+                w.pair_flags[pbase + p] = fl | PF_HAD_FIRST;
                 if (w.fcm_on) {  // ... listed under its cell (k_fanout_emit_filt_cm); the order inside a cell's list does not matter
                     const uint32_t at = atomicAdd(&w.cell_fcnt[32u * c], 1u);
                     if (at < w.S) {
@@ -1243,12 +1280,27 @@ __global__ void __launch_bounds__(64 * FO_WAVES) k_fanout_plan_seg(DevGrid g, Wo
             n_filt += (uint32_t)__popcll(__ballot(due && filt));
         }
         if (due && simple) {
-            if (nd == 1) {
+            if (nwin_s) {
+                uint32_t at = rel32, kk = 0;
+                const uint32_t nch = (size + 511u) >> 9;
+                for (uint32_t j = 0; j < nwin_s; j++) {
+                    const uint32_t o = (own >> j) & 1u;
+                    for (uint32_t ch = 0; ch < nch; ch++, kk++) {
+                        const uint32_t nc = min(512u, size - 512u * ch), oo = ch == 0u ? o : 0u;
+                        const size_t k = pbase + dbase + kk;
+                        w.seg_desc[k] = make_uint4(at, start + 512u * ch, nc, 1u | (oo << SD_OWN_SHIFT) | (kk + 1u < nd ? SD_NOPAD : 0u));
+                        w.seg_desc2[k] = make_uint4(c, p, fl, 0u);
+                        w.seg_ln[k] = Lold;
+                        if (w.rec_mask) w.seg_wm[k] = make_uint4(j == 0 ? wm4.x : j == 1 ? wm4.y : j == 2 ? wm4.z : wm4.w, 0u, 0u, 0u);
+                        at += oo + nc;
+                    }
+                }
+            } else if (nd == 1) {
                 const uint32_t col = wcolp & 15u;
                 const size_t k = pbase + dbase;
                 w.seg_desc[k] = make_uint4(rel32, start + col * w.wcol_stride, ncol0, info | (own << SD_OWN_SHIFT));
-                w.seg_desc2[k] = make_uint4(c, p, fl | PF_HAD_FIRST, 0u);
-                w.seg_ln[k] = Lw;
+                w.seg_desc2[k] = make_uint4(c, p, fl, 0u);  // (.z and seg_ln: the state BEFORE this tick, see the filtered descriptors below)
+                w.seg_ln[k] = Lold;
                 if (w.rec_mask) w.seg_wm[k] = wm4;
             } else {
                 uint32_t at = rel32;
@@ -1258,14 +1310,16 @@ __global__ void __launch_bounds__(64 * FO_WAVES) k_fanout_plan_seg(DevGrid g, Wo
                     const uint32_t o = (own >> j) & 1u;
                     const size_t k = pbase + dbase + j;
                     w.seg_desc[k] = make_uint4(at, start + col * w.wcol_stride, ncol, 1u | (o << SD_OWN_SHIFT) | (j + 1u < nd ? SD_NOPAD : 0u));
-                    w.seg_desc2[k] = make_uint4(c, p, fl | PF_HAD_FIRST, 0u);
-                    w.seg_ln[k] = Lw;
+                    w.seg_desc2[k] = make_uint4(c, p, fl, 0u);
+                    w.seg_ln[k] = Lold;
                     at += o + ncol;
                 }
             }
+            w.pair_last[pbase + p] = Lw;
+            w.pair_flags[pbase + p] = fl | PF_HAD_FIRST;
             rec_simple += count;
         }
-        if (w.wcol_on) {
+        if (multi) {
             uint32_t tot = (due && simple) ? nd : 0u;
             for (int d = 32; d >= 1; d >>= 1) tot += (uint32_t)__shfl_xor((int)tot, d);
             n_simple += tot;
@@ -1820,19 +1874,23 @@ __device__ __forceinline__ uint32_t filt_window_global(const WorldDev &w, uint32
 #define FC_OCC 6
 #endif
 #define FC_LWIN 4  // windows per descriptor whose tests are held in LDS (the rest, rare, are read from global memory)
+#define FC_NORUN 0xFFFFFFFFu
 struct FcHead {
     uint32_t out16[FC_DESCS];  // segment start in the record buffer, in units of 16 records (128-byte lines)
     uint32_t n[FC_DESCS], info[FC_DESCS];  // entries of the cell; windows | own-update bits << 8 (0xFFFFFFFF: skip — no room for the connection's worst case)
     uint32_t conn[FC_DESCS], pidx[FC_DESCS], sidx[FC_DESCS];
     uint32_t win[FC_DESCS][FC_LWIN][6];
-    uint32_t nd, cch, start, valid, ticket, sorted, _pad[2];  // sorted: the cell's entries are in the order of this tick's arrival offsets (k_cell_sort0)
+    // sorted cells (k_cell_arrange): the part of window j that lies inside THIS tick's arrivals (a cut through ring slot 0) as the run
+    // [i0, i1) of the cell's column, i0 | i1 << 16; FC_NORUN: none (the per-entity compare decides the whole window)
+    uint32_t run[FC_DESCS][FC_LWIN];
+    uint32_t nd, cch, start, valid, ticket, sorted, _pad[2];  // sorted: the cell's entries are in the order of this tick's arrival offsets
 };
 struct FcTile {
     uint32_t chan[512], hist[512], off[CHD_OFF_SLOTS][512];
 };
 
 // work items: per cell with filtered descriptors, chunks of FC_DESCS of its list (one workgroup; ncell <= 4096)
-__global__ void __launch_bounds__(1024) k_filt_items(WorldDev w, uint32_t ncell) {
+__device__ __forceinline__ void filt_items_block(const WorldDev &w, uint32_t ncell) {
     __shared__ uint32_t wtot[16];
     __shared__ uint32_t carry_s;
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
@@ -1866,6 +1924,138 @@ __global__ void __launch_bounds__(1024) k_filt_items(WorldDev w, uint32_t ncell)
         *w.filt_nitems = carry_s;
         w.filt_nitems[16] = 0;  // k_fanout_emit_filt_cm's item ticket
     }
+}
+
+// The single-workgroup pass between the plan and the record kernels: (1) the exclusive scan of the connections' record ranges
+// (rec_ub, in place; rec_ub[S] = total), (2) the tick's tail lists (WorldDev::defer_list / deep_list / tail_ctl: the connections
+// the deferred and the element-walk launches have work for, in slot order, and the first connection without room), (3) the
+// cell-major filtered kernel's work items (filt_items_block).  One launch where there were two (k_scan_excl, k_filt_items), and what
+// lets the two tail launches run over a few workgroups instead of one per connection slot.
+// inclusive scan over the wave by DPP row shifts + row broadcasts (gfx9: ~8 cycles a step; __shfl_up is an LDS-path bpermute,
+// ~100 cycles a step, and this kernel is one chain of such steps)
+template <int CTRL, int ROW_MASK, bool BOUND>
+__device__ __forceinline__ uint32_t dpp_add(uint32_t v) {
+    return v + (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, ROW_MASK, 0xF, BOUND);
+}
+// inclusive scan inside every row of 16 lanes
+__device__ __forceinline__ uint32_t row_incl_scan_dpp(uint32_t v) {
+    v = dpp_add<0x111, 0xF, true>(v);   // row_shr:1 (lanes shifted in from outside the row read 0)
+    v = dpp_add<0x112, 0xF, true>(v);   // row_shr:2
+    v = dpp_add<0x114, 0xF, true>(v);   // row_shr:4
+    v = dpp_add<0x118, 0xF, true>(v);   // row_shr:8
+    return v;
+}
+__device__ __forceinline__ uint32_t wave_incl_scan_dpp(uint32_t v) {
+    v = row_incl_scan_dpp(v);
+    v = dpp_add<0x142, 0xA, false>(v);  // row_bcast:15 into rows 1 and 3
+    v = dpp_add<0x143, 0xC, false>(v);  // row_bcast:31 into rows 2 and 3
+    return v;
+}
+// ... of 64-bit values below 2^44 per lane, as two 32-bit scans (low 20 bits / the rest)
+__device__ __forceinline__ uint64_t wave_incl_scan_dpp64(uint64_t v) {
+    const uint32_t lo = wave_incl_scan_dpp((uint32_t)v & 0xFFFFFu), hi = wave_incl_scan_dpp((uint32_t)(v >> 20));
+    return ((uint64_t)hi << 20) + lo;
+}
+
+__global__ void __launch_bounds__(1024) k_fanout_scan(WorldDev w, uint32_t ncell, int seg) {
+    __shared__ uint64_t wtot[2][16];
+    __shared__ uint32_t ctot[2][16];
+    __shared__ uint32_t scap_s;
+    const uint32_t lane = threadIdx.x & 63u;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const uint32_t n = w.S;
+    const uint64_t cap = w.recs_cap;
+    if (threadIdx.x == 0) scap_s = n;
+    uint64_t carry = 0;             // (kept by every thread: the totals of the tiles before this one)
+    uint32_t dcarry = 0, pcarry = 0;
+    // FOUR tiles of 4096 connections are loaded together, then scanned from registers one after the other: the kernel is a chain of
+    // dependent round trips to words another kernel has just written (nothing of it is in this CU's caches)
+    constexpr int T = 4;
+    uint32_t tile = 0;
+    for (uint32_t g0 = 0; g0 < n; g0 += T * 4096u) {
+        uint64_t v[T][4];
+        uint32_t fdp[T];  // bits 0..3: connection i0 + k has deferred subscriptions; bits 4..7: PF_DEEP ones
+        {
+            // Wide loads, all of them unconditional and issued before anything is used: a thread's four connections are 32 + 16 + 16
+            // contiguous bytes (the arrays carry four spare elements: no tail case).  This workgroup owns ONE CU's memory pipeline, and
+            // 48 narrow loads per thread (16 waves) kept it busy for 5 us.  A load behind a per-lane condition is awaited before the
+            // next one is issued, and so is a value merged behind a uniform branch: what is not wanted is read from a zero word
+            // (tail_ctl[8..11]) by every lane.
+            typedef unsigned long long u64x2 __attribute__((ext_vector_type(2)));
+            u64x2 va[T], vb[T];
+            u32x4 cd[T], cp[T];
+            const uint32_t *pd = seg ? w.conn_defer : w.tail_ctl + 8, *pp = w.deep_depth ? w.conn_deep : w.tail_ctl + 8;
+            const uint32_t md = seg ? 0xFFFFFFFFu : 0u, mp = w.deep_depth ? 0xFFFFFFFFu : 0u;
+#pragma unroll
+            for (int t = 0; t < T; t++) {
+                const uint32_t i0 = g0 + (uint32_t)t * 4096u + threadIdx.x * 4u;
+                const uint32_t ix = i0 < n ? i0 : 0u;
+                va[t] = *(const u64x2 *)(const void *)(w.rec_ub + ix);
+                vb[t] = *(const u64x2 *)(const void *)(w.rec_ub + ix + 2);
+                cd[t] = *(const u32x4 *)(const void *)(pd + (ix & md));
+                cp[t] = *(const u32x4 *)(const void *)(pp + (ix & mp));
+            }
+#pragma unroll
+            for (int t = 0; t < T; t++) {
+                const uint32_t i0 = g0 + (uint32_t)t * 4096u + threadIdx.x * 4u;
+                const uint64_t vv[4] = {va[t].x, va[t].y, vb[t].x, vb[t].y};
+                const uint32_t dd[4] = {cd[t].x, cd[t].y, cd[t].z, cd[t].w}, pq[4] = {cp[t].x, cp[t].y, cp[t].z, cp[t].w};
+                fdp[t] = 0;
+#pragma unroll
+                for (int k = 0; k < 4; k++) {
+                    const bool in = i0 + k < n;
+                    v[t][k] = in ? (vv[k] < (1ull << 40) ? vv[k] : (1ull << 40)) : 0ull;  // (the plan's "does not fit 32-bit offsets" mark, at most)
+                    fdp[t] |= (in && dd[k]) ? 1u << k : 0u;
+                    fdp[t] |= (in && pq[k]) ? 16u << k : 0u;
+                }
+            }
+        }
+#pragma unroll
+        for (int t = 0; t < T; t++, tile++) {
+            if (g0 + (uint32_t)t * 4096u >= n) break;  // uniform
+            const uint32_t i0 = g0 + (uint32_t)t * 4096u + threadIdx.x * 4u;
+            const uint32_t par = tile & 1u;
+            const uint64_t sum = v[t][0] + v[t][1] + v[t][2] + v[t][3];  // (a connection's range is at most 2^40: < 2^44 per lane)
+            const uint64_t inc = wave_incl_scan_dpp64(sum);
+            const uint32_t cown = (uint32_t)__popc(fdp[t] & 15u) | ((uint32_t)__popc(fdp[t] >> 4) << 16);  // (4096 per tile: both counts fit 16 bits)
+            const uint32_t cinc = wave_incl_scan_dpp(cown);
+            if (lane == 63) { wtot[par][wave] = inc; ctot[par][wave] = cinc; }
+            __syncthreads();  // (the only barrier of a tile: the totals' buffers alternate)
+            // the 16 waves' totals, scanned by lanes 0..15 of every wave
+            uint64_t wt = wtot[par][lane & 15u];
+            wt = wt < (1ull << 44) ? wt : (1ull << 44);  // (beyond every capacity: saturate, the scans below are 32-bit)
+            const uint32_t ct = ctot[par][lane & 15u];
+            const uint32_t wlo = row_incl_scan_dpp((uint32_t)wt & 0xFFFFFu), whi = row_incl_scan_dpp((uint32_t)(wt >> 20)), wc = row_incl_scan_dpp(ct);
+            const uint32_t blo = wave ? (uint32_t)__builtin_amdgcn_readlane((int)wlo, wave - 1) : 0u, bhi = wave ? (uint32_t)__builtin_amdgcn_readlane((int)whi, wave - 1) : 0u;
+            const uint32_t bc = wave ? (uint32_t)__builtin_amdgcn_readlane((int)wc, wave - 1) : 0u;
+            const uint64_t ttot = ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)whi, 15) << 20) + (uint32_t)__builtin_amdgcn_readlane((int)wlo, 15);
+            const uint32_t tc = (uint32_t)__builtin_amdgcn_readlane((int)wc, 15);
+            uint64_t run = carry + ((uint64_t)bhi << 20) + blo + inc - sum;
+            const uint32_t crun = bc + cinc - cown;
+            uint32_t dpos = dcarry + (crun & 0xFFFFu), ppos = pcarry + (crun >> 16);
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                if (i0 + k < n) {
+                    w.rec_ub[i0 + k] = run;
+                    run += v[t][k];
+                    if (run > cap) atomicMin(&scap_s, i0 + k);  // rec_ub[s + 1] > recs_cap: no room from here on
+                    if ((fdp[t] >> k) & 1u) w.defer_list[dpos++] = i0 + k;
+                    if ((fdp[t] >> (4 + k)) & 1u) w.deep_list[ppos++] = i0 + k;
+                }
+            }
+            carry += ttot;
+            dcarry += tc & 0xFFFFu;
+            pcarry += tc >> 16;
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        w.rec_ub[n] = carry;
+        w.tail_ctl[TC_NDEFER] = dcarry;
+        w.tail_ctl[TC_NDEEP] = pcarry;
+        w.tail_ctl[TC_SCAP] = scap_s;
+    }
+    if (seg && w.off_on && w.fcm_on) filt_items_block(w, ncell);
 }
 
 __global__ void __launch_bounds__(64 * FC_WAVES, FC_OCC) k_fanout_emit_filt_cm(DevGrid g, WorldDev w) {
@@ -1940,6 +2130,27 @@ __global__ void __launch_bounds__(64 * FC_WAVES, FC_OCC) k_fanout_emit_filt_cm(D
 #pragma unroll
                 for (int q = 0; q < 6; q++)
                     if ((uint32_t)(2 * (q / 3)) < lnw) dst[q] = t[q];
+                // the runs of this descriptor's windows: two binary searches each over the staged slot-0 offsets (ascending on a sorted
+                // cell, 0xFFFFFFFF = no update last; this wave wrote them just above: LDS operations of one wave execute in order)
+                const bool srt = w.cell_sorted && w.cell_sorted[c] != 0u && tn == nn;  // (tn == nn: the whole cell is in the tile)
+                const uint32_t tw[24] = {t[0].x, t[0].y, t[0].z, t[0].w, t[1].x, t[1].y, t[1].z, t[1].w, t[2].x, t[2].y, t[2].z, t[2].w,
+                                         t[3].x, t[3].y, t[3].z, t[3].w, t[4].x, t[4].y, t[4].z, t[4].w, t[5].x, t[5].y, t[5].z, t[5].w};
+#pragma unroll
+                for (int j = 0; j < FC_LWIN; j++) {
+                    uint32_t run = FC_NORUN;
+                    const uint32_t slots = tw[6 * j + 1], a_lo = tw[6 * j + 2], a_hi = tw[6 * j + 3];
+                    if (srt && (uint32_t)j < lnw && a_lo <= a_hi && (slots & 0xFFu) == 0u) {
+                        uint32_t i0 = 0, i1 = 0;
+#pragma unroll
+                        for (uint32_t step = 512u; step; step >>= 1) {
+                            const uint32_t p0 = i0 + step, p1 = i1 + step;
+                            if (p0 <= tn && T.off[0][p0 - 1u] < a_lo) i0 = p0;
+                            if (p1 <= tn && T.off[0][p1 - 1u] <= a_hi) i1 = p1;
+                        }
+                        run = i0 | (i1 << 16);
+                    }
+                    H.run[lane][j] = run;
+                }
             }
             if (lane < FC_DESCS) {
                 H.out16[lane] = out16; H.n[lane] = nn; H.info[lane] = info; H.conn[lane] = conn; H.pidx[lane] = pidx; H.sidx[lane] = sidx;
@@ -2010,33 +2221,55 @@ __global__ void __launch_bounds__(64 * FC_WAVES, FC_OCC) k_fanout_emit_filt_cm(D
                         }
                         n_out += 1;
                     }
-                    if (n <= 512 && sorted && full == 0 && use_a && !use_b && sa == 0) {
-                        // A WINDOW INSIDE THIS TICK'S OWN ARRIVALS, on a cell whose entries are in arrival order (k_cell_sort0): the
-                        // entities that pass are the run [i0, i1) of the cell's column — i0 = entries with an offset below a_lo, i1 =
-                        // entries with an offset up to a_hi (entities without an update in this tick carry 0xFFFFFFFF and sit behind
-                        // every bound).  Each end by a two-level search over the staged offsets: every 8th entry across the lanes, then
-                        // the eight entries of the group the bound falls into — two LDS reads and two ballots instead of a compare
-                        // per entity — and then a plain copy of the run.
-                        const uint32_t *o0 = T.off[0];
-                        uint32_t ends[2];
-#pragma unroll
-                        for (int q = 0; q < 2; q++) {
-                            const uint32_t x = q == 0 ? a_lo : a_hi + 1u;  // (a_hi <= 0xFFFFFFFE)
-                            const uint32_t p1 = 8u * lane + 7u;
-                            const uint32_t v1 = p1 < n ? o0[p1] : 0xFFFFFFFFu;
-                            const uint32_t grp = (uint32_t)__popcll(__ballot(v1 < x));
-                            const uint32_t p2 = 8u * grp + lane;
-                            const uint32_t v2 = (lane < 8u && p2 < n) ? o0[p2] : 0xFFFFFFFFu;
-                            ends[q] = 8u * grp + (uint32_t)__popcll(__ballot(v2 < x));
+                    const uint32_t run = (sorted && j < FC_LWIN) ? (uint32_t)__builtin_amdgcn_readfirstlane((int)H.run[k][j]) : FC_NORUN;
+                    if (n <= 512 && run != FC_NORUN) {
+                        // THE WINDOW'S PART INSIDE THIS TICK'S OWN ARRIVALS, on a cell whose entries are in arrival order (k_cell_arrange): the
+                        // entities it selects are the run [i0, i1) of the cell's column (the loader found the two ends) — a plain copy, two
+                        // records per lane and store
+                        const uint32_t i0 = run & 0xFFFFu, i1 = run >> 16, len = i1 - i0;
+                        typedef u32x4 __attribute__((aligned(8))) u32x4_a8;  // (n_out is any record index)
+                        for (uint32_t b0 = 0; b0 < len; b0 += 128) {
+                            const uint32_t q = b0 + 2 * lane, ea = min(i0 + q, 511u), eb = min(i0 + q + 1u, 511u);
+                            const uint32_t c0 = T.chan[ea], c1 = T.chan[eb];
+                            if (q + 1 < len) {
+                                u32x4 r;
+                                r.x = conn; r.y = c0; r.z = conn; r.w = c1;
+                                *(u32x4_a8 *)(void *)(out + n_out + q) = r;
+                            } else if (q < len) {
+                                chd_fanout_rec r;
+                                r.conn = conn;
+                                r.channel = c0;
+                                out[n_out + q] = r;
+                            }
                         }
-                        const uint32_t i0 = ends[0], i1 = ends[1] > ends[0] ? ends[1] : ends[0];
-                        for (uint32_t e = i0 + lane; e < i1; e += 64) {
-                            chd_fanout_rec r;
-                            r.conn = conn;
-                            r.channel = T.chan[e];
-                            out[n_out + (e - i0)] = r;
+                        n_out += len;
+                        // ... and whatever else the window selects — a ring slot it covers whole, the cut through an older slot's arrivals —
+                        // by the per-entity compare over the entries OUTSIDE the run (an entity inside it has its record)
+                        if (full | (use_b ? 1u : 0u)) {
+                            const uint32_t rest = n - len, b_rng = b_hi - b_lo;
+                            const uint32_t *ob_col = T.off[use_b ? sb : 0u];
+                            for (uint32_t b0 = 0; b0 < rest; b0 += 128) {
+                                const uint32_t q0 = b0 + 2 * lane, q1 = q0 + 1u;
+                                const uint32_t e0 = min(q0 < i0 ? q0 : q0 + len, 511u), e1 = min(q1 < i0 ? q1 : q1 + len, 511u);
+                                const uint32_t h0 = T.hist[e0], h1 = T.hist[e1], o0 = ob_col[e0], o1 = ob_col[e1];
+                                const bool p0 = (q0 < rest) & (((h0 & full) != 0) | (use_b & (o0 - b_lo <= b_rng)));
+                                const bool p1 = (q1 < rest) & (((h1 & full) != 0) | (use_b & (o1 - b_lo <= b_rng)));
+                                const uint64_t m0 = __ballot(p0), m1 = __ballot(p1);
+                                const uint32_t at = __builtin_amdgcn_mbcnt_hi((uint32_t)(m1 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m1,
+                                                    __builtin_amdgcn_mbcnt_hi((uint32_t)(m0 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m0, n_out))));
+                                if (p0 & p1) {
+                                    u32x4 r;
+                                    r.x = conn; r.y = T.chan[e0]; r.z = conn; r.w = T.chan[e1];
+                                    *(u32x4_a8 *)(void *)(out + at) = r;
+                                } else if (p0 | p1) {
+                                    chd_fanout_rec r;
+                                    r.conn = conn;
+                                    r.channel = p0 ? T.chan[e0] : T.chan[e1];
+                                    out[at] = r;
+                                }
+                                n_out += (uint32_t)__popcll(m0) + (uint32_t)__popcll(m1);
+                            }
                         }
-                        n_out += i1 - i0;
                     } else if (n <= 512) {
                         // THE COMMON PATH, LDS only.  Per row of 128 entries the lanes do two and + compare for the whole-slot mask
                         // and two subtract + compare per cut slot — the staged offsets of entities WITHOUT an update in a slot are
@@ -2122,7 +2355,6 @@ __global__ void __launch_bounds__(64 * FC_WAVES, FC_OCC) k_fanout_emit_filt_cm(D
 void launch_fanout_emit_filt(hipStream_t st, DevGrid g, WorldDev w) {
     if (!w.S || !w.off_on || !seg_path(w)) return;
     if (w.fcm_on) {
-        hipLaunchKernelGGL(k_filt_items, dim3(1), dim3(1024), 0, st, w, g.ncell);
         const uint64_t max_items = (uint64_t)w.S * w.capq / FC_DESCS + g.ncell;
         const uint32_t grid = (uint32_t)std::min<uint64_t>(max_items, (uint64_t)(w.seg_waves / 8u) * 2u);  // two workgroups per CU (LDS: 56 KB each)
         hipLaunchKernelGGL(k_fanout_emit_filt_cm, dim3(grid), dim3(64 * FC_WAVES), 0, st, g, w);
@@ -2649,13 +2881,6 @@ void launch_fanout_emit_main(hipStream_t st, DevGrid g, WorldDev w, int64_t now_
     else hipLaunchKernelGGL((k_fanout_emit<4, false>), dim3(w.S), dim3(256), 0, st, g, w, now_ns, ring);
 }
 
-// the subscriptions k_fanout_plan_seg left to the filtering kernel (descriptor path only)
-void launch_fanout_emit_deferred(hipStream_t st, DevGrid g, WorldDev w, int64_t now_ns, TickRing ring) {
-    if (!w.S || !seg_path(w)) return;
-    if (w.rec_mask) hipLaunchKernelGGL((k_fanout_emit<1, true, true>), dim3(w.S), dim3(64), 0, st, g, w, now_ns, ring);
-    else hipLaunchKernelGGL((k_fanout_emit<1, false, true>), dim3(w.S), dim3(64), 0, st, g, w, now_ns, ring);
-}
-
 
 // ---------------------------------------------------------------------------
 // Exact update buffers (chd_world_cfg.history_depth): tickData's buffer walk itself (data.go:225-269), for the subscriptions
@@ -2728,9 +2953,7 @@ __device__ __forceinline__ uint32_t deep_walk(const int64_t *__restrict__ A, con
     return cnt;
 }
 
-__global__ void __launch_bounds__(64) k_fanout_emit_deep(DevGrid g, WorldDev w, int64_t now, TickRing ring) {
-    const uint32_t s = blockIdx.x;
-    if (!w.conn_deep[s]) return;
+__device__ __forceinline__ void fanout_deep_conn(const DevGrid &g, const WorldDev &w, int64_t now, const TickRing &ring, const uint32_t s) {
     const uint32_t lane = lane_id();
     const uint32_t cnt = w.pair_cnt[s];
     const size_t pbase = (size_t)s * w.capq;
@@ -2805,7 +3028,7 @@ __global__ void __launch_bounds__(64) k_fanout_emit_deep(DevGrid g, WorldDev w, 
     }
     if (__ballot(lost != 0) && lane == 0) atomicAdd(&w.counters[CTR_HIST_OVERFLOW], 1u);
     if (lane == 0 && total) {
-        w.rec_cnt[s] += total;
+        atomicAdd(&w.rec_cnt[s], total);
         unsigned long long *slot = (unsigned long long *)&w.tot64[(size_t)(s & 63u) * 16];
         atomicAdd(slot, (unsigned long long)total);
         atomicAdd(slot + 2, (unsigned long long)total);  // (not written by the dominant emit kernel)
@@ -2813,15 +3036,10 @@ __global__ void __launch_bounds__(64) k_fanout_emit_deep(DevGrid g, WorldDev w, 
     }
 }
 
-void launch_fanout_emit_deep(hipStream_t st, DevGrid g, WorldDev w, int64_t now_ns, TickRing ring) {
-    if (!w.S || !w.deep_depth) return;
-    hipLaunchKernelGGL(k_fanout_emit_deep, dim3(w.S), dim3(64), 0, st, g, w, now_ns, ring);
-}
-
 // Per-tick totals into the device-side history ring (read back by chd_tick_fetch /
 // chd_get_tick_history), then the per-tick counters are cleared for the next tick.
 static_assert(CHD_LIST_BANKS == 64, "one epilogue lane per list bank");
-__global__ void __launch_bounds__(64) k_tick_epilogue(WorldDev w, uint32_t slot, uint32_t ncell, unsigned long long *epi, unsigned long long epi_seq) {
+__device__ __forceinline__ void tick_epilogue_wave(const WorldDev &w, uint32_t slot, uint32_t ncell, unsigned long long *epi, unsigned long long epi_seq) {
     const uint32_t lane = threadIdx.x;
     if (w.deep_depth) {  // (set again by the next tick's index build)
         // ... and the spatial channels' maxFanOutIntervalMs as this tick's interest updates left it: what the NEXT tick's updates
@@ -2886,6 +3104,67 @@ __global__ void __launch_bounds__(64) k_tick_epilogue(WorldDev w, uint32_t slot,
     }
 }
 
+__global__ void __launch_bounds__(64) k_tick_epilogue(WorldDev w, uint32_t slot, uint32_t ncell, unsigned long long *epi, unsigned long long epi_seq) {
+    tick_epilogue_wave(w, slot, ncell, epi, epi_seq);
+}
+
 void launch_tick_epilogue(hipStream_t st, WorldDev w, uint32_t slot, uint32_t ncell, unsigned long long *epi, unsigned long long epi_seq) {
     hipLaunchKernelGGL(k_tick_epilogue, dim3(1), dim3(64), 0, st, w, slot, ncell, epi, epi_seq);
+}
+
+// ---------------------------------------------------------------------------
+// The tick's TAIL, behind the record kernels, as ONE launch (a launch of this size costs ~5 us whatever it does; the three that
+// were here — the filtering launch with the state commit over one workgroup per connection slot, the element walk likewise, the
+// epilogue — took 16 us at config B for ~0 records, 23 us with exact update buffers):
+//   * the subscriptions k_fanout_plan_seg left to the filtering streams (PF_DEFER; their connections come compacted in
+//     WorldDev::defer_list from k_fanout_scan) — descriptor path only;
+//   * the connections without room for their records (slots tail_ctl[TC_SCAP] ..: fanout_no_room) — descriptor path only, the
+//     one-launch forms handle theirs in place;
+//   * the subscriptions the tick-ring masks cannot answer (PF_DEEP, WorldDev::deep_list), from the exact update buffers;
+//   * the tick epilogue, by the workgroup that finishes last (each working workgroup releases its writes at agent scope and takes
+//     a ticket; workgroups without an item leave at once and take none).
+// Single-wave workgroups stride over the items; the grid is what the host can afford without knowing the lists' lengths.
+// ---------------------------------------------------------------------------
+#define TC_TICKET 4
+template <bool MASKS>
+__global__ void __launch_bounds__(64) k_fanout_tail(DevGrid g, WorldDev w, int64_t now, TickRing ring, int seg, uint32_t slot, uint32_t ncell,
+                                                    unsigned long long *epi, unsigned long long epi_seq) {
+    const uint32_t nd = seg ? w.tail_ctl[TC_NDEFER] : 0u, scap = seg ? w.tail_ctl[TC_SCAP] : w.S;
+    const uint32_t np = w.deep_depth ? w.tail_ctl[TC_NDEEP] : 0u;
+    const uint32_t n1 = nd + (w.S - scap), total = n1 + np;
+    const uint32_t workers = total < gridDim.x ? total : gridDim.x;
+    if (blockIdx.x >= (workers ? workers : 1u)) return;
+    for (uint32_t i = blockIdx.x; i < total; i += gridDim.x) {
+        if (i < nd) {
+            const uint32_t s = w.defer_list[i];
+            if (s < scap) fanout_emit_conn<1, MASKS, true>(g, w, now, ring, s);
+        } else if (i < n1) {
+            fanout_no_room(w, scap + (i - nd));
+        } else {
+            fanout_deep_conn(g, w, now, ring, w.deep_list[i - n1]);
+        }
+        __syncthreads();  // (the connection's LDS staging is reused)
+    }
+    if (workers > 1u) {
+        __threadfence();
+        uint32_t t = 0;
+        if (threadIdx.x == 0) t = atomicAdd(&w.tail_ctl[TC_TICKET], 1u);
+        t = (uint32_t)__builtin_amdgcn_readfirstlane((int)t);
+        if (t != workers - 1u) return;
+        __threadfence();
+    }
+    if (threadIdx.x == 0) w.tail_ctl[TC_TICKET] = 0;
+    tick_epilogue_wave(w, slot, ncell, epi, epi_seq);
+}
+
+static uint32_t tail_grid() {  // (CHD_TAIL_GRID: A/B runs)
+    static const uint32_t n = [] { const char *e = getenv("CHD_TAIL_GRID"); return e ? (uint32_t)std::max(atoi(e), 1) : 512u; }();
+    return n;
+}
+void launch_fanout_tail(hipStream_t st, DevGrid g, WorldDev w, int64_t now_ns, TickRing ring, uint32_t slot, unsigned long long *epi, unsigned long long epi_seq) {
+    if (!w.S) { launch_tick_epilogue(st, w, slot, g.ncell, epi, epi_seq); return; }
+    const int seg = seg_path(w) ? 1 : 0;
+    const dim3 grid(std::min(std::max(w.S, 1u), tail_grid()));
+    if (w.rec_mask) hipLaunchKernelGGL((k_fanout_tail<true>), grid, dim3(64), 0, st, g, w, now_ns, ring, seg, slot, g.ncell, epi, epi_seq);
+    else hipLaunchKernelGGL((k_fanout_tail<false>), grid, dim3(64), 0, st, g, w, now_ns, ring, seg, slot, g.ncell, epi, epi_seq);
 }

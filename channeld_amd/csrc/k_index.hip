@@ -41,33 +41,58 @@ __device__ __forceinline__ void index_hist_block(const WorldDev &w, uint32_t nce
     for (uint32_t c = threadIdx.x; c < ncell; c += IDX_BLOCK) { h[c] = 0; smin[c] = 0xFFFFFFFFu; smax[c] = 0; hand[c] = 0xFFFFFFFFu; }
     __syncthreads();
     uint32_t base = bid * IDX_TILE;
+    // Every word of the workgroup's entities is requested up front, unconditionally (an entity beyond N or dead reads slot 0 and
+    // is masked afterwards): the launch is one workgroup per CU, as long as its chain of dependent round trips, and loads behind
+    // per-lane tests — alive? in a cell? a previous sender? — were five such trips.  Only the update log by CHANNEL (region-sharded
+    // exact worlds, log_ix) costs a second one.
+    uint32_t ef[IDX_ITEMS], mem[IDX_ITEMS], snd[IDX_ITEMS], htk[IDX_ITEMS], hpv[IDX_ITEMS], hcu[IDX_ITEMS], spv[IDX_ITEMS], irr[IDX_ITEMS];
+    const uint32_t *irr_p = w.deep_depth ? w.irr_tick : w.hist_tick;  // (no exact buffers: any readable word, unused)
+    // (two copies of the loads, chosen by a uniform branch around ALL of them: a value merged behind a branch is awaited at the join)
+    if (!w.log_on) {
+#pragma unroll
+        for (int r = 0; r < IDX_ITEMS; r++) {
+            // wave w handles the contiguous chunk [base + w*256 + r*64, +64)
+            const uint32_t i = base + (threadIdx.x >> 6) * (IDX_ITEMS * 64) + r * 64 + (threadIdx.x & 63);
+            const uint32_t u = i < w.N ? i : 0u;
+            ef[r] = w.eflags[u]; mem[r] = w.member[u];
+            snd[r] = w.sender[u]; htk[r] = w.hist_tick[u]; hpv[r] = w.hist_prev[u]; hcu[r] = w.hist[u]; spv[r] = w.sender_prev[u];
+            irr[r] = irr_p[u];
+            if (i >= w.N) ef[r] = 0u;
+        }
+    } else {
+        uint32_t lu[IDX_ITEMS];
+#pragma unroll
+        for (int r = 0; r < IDX_ITEMS; r++) {
+            const uint32_t i = base + (threadIdx.x >> 6) * (IDX_ITEMS * 64) + r * 64 + (threadIdx.x & 63);
+            const uint32_t u = i < w.N ? i : 0u;
+            ef[r] = w.eflags[u]; mem[r] = w.member[u];
+            lu[r] = w.chan_id[u] - w.log_eid0;
+            if (i >= w.N) ef[r] = 0u;
+        }
+#pragma unroll
+        for (int r = 0; r < IDX_ITEMS; r++) {
+            const uint32_t u = (ef[r] & EF_ALIVE) ? lu[r] : 0u;  // (a dead slot's channel id means nothing: log 0, masked)
+            snd[r] = w.sender[u]; htk[r] = w.hist_tick[u]; hpv[r] = w.hist_prev[u]; hcu[r] = w.hist[u]; spv[r] = w.sender_prev[u];
+            irr[r] = irr_p[u];
+        }
+    }
 #pragma unroll
     for (int r = 0; r < IDX_ITEMS; r++) {
-        // wave w handles the contiguous chunk [base + w*256 + r*64, +64)
-        uint32_t i = base + (threadIdx.x >> 6) * (IDX_ITEMS * 64) + r * 64 + (threadIdx.x & 63);
-        if (i < w.N) {
-            uint32_t m = (w.eflags[i] & EF_ALIVE) ? w.member[i] : CHD_INVALID;
-            if (m < ncell) {
-                atomicAdd(&h[m], 1u);
-                const uint32_t u = log_ix(w, i);  // (where the entity's update log lives: its slot, or its channel — WorldDev::log_on)
-                const uint32_t snd = w.sender[u];
-                atomicMin(&smin[m], snd);
-                atomicMax(&smax[m], snd);
-                const uint32_t age = cur_tick - w.hist_tick[u];
-                const uint32_t hp = age < CHD_HIST_BITS ? (w.hist_prev[u] << age) : 0u;
-                const uint32_t hc = age < CHD_HIST_BITS ? (w.hist[u] << age) : 0u;
-                atomicAnd(&hand[m], hc | hp);
-                // exact update buffers: an update the masks cannot represent, still inside their horizon (rare: a plain
-                // global atomic; cell_irr is cleared by the tick epilogue)
-                if (w.deep_depth) {
-                    const uint32_t it = w.irr_tick[u];
-                    if (it && cur_tick + 1u - it < CHD_HIST_BITS) atomicOr(&w.cell_irr[m], 1u);
-                }
-                if (hp != 0) {
-                    const uint32_t sp = w.sender_prev[u];
-                    atomicMin(&smin[m], sp);
-                    atomicMax(&smax[m], sp);
-                }
+        const uint32_t m = (ef[r] & EF_ALIVE) ? mem[r] : CHD_INVALID;
+        if (m < ncell) {
+            atomicAdd(&h[m], 1u);
+            atomicMin(&smin[m], snd[r]);
+            atomicMax(&smax[m], snd[r]);
+            const uint32_t age = cur_tick - htk[r];
+            const uint32_t hp = age < CHD_HIST_BITS ? (hpv[r] << age) : 0u;
+            const uint32_t hc = age < CHD_HIST_BITS ? (hcu[r] << age) : 0u;
+            atomicAnd(&hand[m], hc | hp);
+            // exact update buffers: an update the masks cannot represent, still inside their horizon (rare: a plain
+            // global atomic; cell_irr is cleared by the tick epilogue)
+            if (w.deep_depth && irr[r] && cur_tick + 1u - irr[r] < CHD_HIST_BITS) atomicOr(&w.cell_irr[m], 1u);
+            if (hp != 0) {
+                atomicMin(&smin[m], spv[r]);
+                atomicMax(&smax[m], spv[r]);
             }
         }
     }
@@ -171,15 +196,52 @@ __device__ __forceinline__ void index_scatter_block(const WorldDev &w, uint32_t 
     uint32_t *wcnt = (uint32_t *)smem;  // [4][ncell] running per-wave counters
     const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     for (uint32_t c = threadIdx.x; c < 4 * ncell; c += IDX_BLOCK) wcnt[c] = 0;
-    __syncthreads();
     uint32_t *mycnt = wcnt + wave * ncell;
     uint32_t base = bid * IDX_TILE + wave * (IDX_ITEMS * 64);
+    // EVERY global word the workgroup needs is requested here, unconditionally (an entity beyond N reads slot 0 and is masked; a dead
+    // one's words are read and dropped): its entities' flags, cells and entry words, and the first round of the per-cell bases.  The
+    // launch is one workgroup per CU and as long as its chain of dependent round trips; with the loads behind the "alive / in a
+    // cell" tests and the bases behind two barriers that chain was five trips long.  Only the update log by CHANNEL (region-sharded
+    // exact worlds) keeps a second trip.
+    uint32_t ef[IDX_ITEMS], mem[IDX_ITEMS], chn[IDX_ITEMS], htk[IDX_ITEMS], hcu[IDX_ITEMS], hpv[IDX_ITEMS], snd[IDX_ITEMS], spv[IDX_ITEMS], lix[IDX_ITEMS];
+    uint4 oa[IDX_ITEMS], ob[IDX_ITEMS];
+    const uint4 *eoff_p = w.off_on ? w.eoff : (const uint4 *)(const void *)w.ce;  // (no offsets: any readable 32 bytes, unused)
+    const uint32_t eoff_m = w.off_on ? 0xFFFFFFFFu : 0u;
+    if (!w.log_on) {
+#pragma unroll
+        for (int r = 0; r < IDX_ITEMS; r++) {
+            const uint32_t i = base + r * 64 + lane, u = i < w.N ? i : 0u;
+            ef[r] = w.eflags[u]; mem[r] = w.member[u]; chn[r] = w.chan_id[u];
+            htk[r] = w.hist_tick[u]; hcu[r] = w.hist[u]; hpv[r] = w.hist_prev[u]; snd[r] = w.sender[u]; spv[r] = w.sender_prev[u];
+            oa[r] = eoff_p[2 * (size_t)(u & eoff_m)]; ob[r] = eoff_p[2 * (size_t)(u & eoff_m) + 1];
+            lix[r] = u;
+            if (i >= w.N) ef[r] = 0u;
+        }
+    } else {
+#pragma unroll
+        for (int r = 0; r < IDX_ITEMS; r++) {
+            const uint32_t i = base + r * 64 + lane, u = i < w.N ? i : 0u;
+            ef[r] = w.eflags[u]; mem[r] = w.member[u]; chn[r] = w.chan_id[u];
+            if (i >= w.N) ef[r] = 0u;
+        }
+#pragma unroll
+        for (int r = 0; r < IDX_ITEMS; r++) {
+            const uint32_t u = (ef[r] & EF_ALIVE) ? chn[r] - w.log_eid0 : 0u;  // (a dead slot's channel id means nothing: log 0, masked)
+            htk[r] = w.hist_tick[u]; hcu[r] = w.hist[u]; hpv[r] = w.hist_prev[u]; snd[r] = w.sender[u]; spv[r] = w.sender_prev[u];
+            oa[r] = eoff_p[2 * (size_t)(u & eoff_m)]; ob[r] = eoff_p[2 * (size_t)(u & eoff_m) + 1];
+            lix[r] = u;
+        }
+    }
+    // ... the cell bases of this thread's first cell (grids of up to 256 cells: its only one)
+    const uint32_t c0 = threadIdx.x < ncell ? threadIdx.x : 0u;
+    const uint32_t pre_blk = w.blk_cnt[(size_t)c0 * w.nblk + bid];
+    const uint32_t pre_base = local_base ? w.cell_tot[c0] : w.cell_off[c0];
+    __syncthreads();
     uint32_t key[IDX_ITEMS], lrank[IDX_ITEMS];
 #pragma unroll
     for (int r = 0; r < IDX_ITEMS; r++) {
-        uint32_t i = base + r * 64 + lane;
         uint32_t m = CHD_INVALID;
-        if (i < w.N && (w.eflags[i] & EF_ALIVE)) m = w.member[i];
+        if (ef[r] & EF_ALIVE) m = mem[r];
         bool valid = m < ncell;
         key[r] = valid ? m : CHD_INVALID;
         // peers = lanes of this wave holding the same key
@@ -211,7 +273,8 @@ __device__ __forceinline__ void index_scatter_block(const WorldDev &w, uint32_t 
         const uint32_t per = (ncell + IDX_BLOCK - 1) / IDX_BLOCK;
         const uint32_t lo = threadIdx.x * per, hi = min(lo + per, ncell);
         uint32_t sum = 0;
-        for (uint32_t i = lo; i < hi; i++) sum += w.cell_tot[i];
+        if (per == 1u) sum = lo < hi ? pre_base : 0u;  // (lo == threadIdx.x == c0)
+        else for (uint32_t i = lo; i < hi; i++) sum += w.cell_tot[i];
         part[threadIdx.x] = sum;
         __syncthreads();
         if (threadIdx.x < 64) {  // scan of the 256 partials by one wave, 4 per lane
@@ -225,11 +288,11 @@ __device__ __forceinline__ void index_scatter_block(const WorldDev &w, uint32_t 
         uint32_t run = part[threadIdx.x];
         for (uint32_t i = lo; i < hi; i++) {
             cbase[i] = run;
-            run += w.cell_tot[i];
+            run += per == 1u ? pre_base : w.cell_tot[i];
         }
         if (bid == 0) {  // publish the CSR offsets for the fan-out kernels
             uint32_t r2 = part[threadIdx.x];
-            for (uint32_t i = lo; i < hi; i++) { w.cell_off[i] = r2; r2 += w.cell_tot[i]; }
+            for (uint32_t i = lo; i < hi; i++) { w.cell_off[i] = r2; r2 += per == 1u ? pre_base : w.cell_tot[i]; }
             if (hi == ncell && lo < hi) w.cell_off[ncell] = r2;
         }
         __syncthreads();
@@ -237,7 +300,8 @@ __device__ __forceinline__ void index_scatter_block(const WorldDev &w, uint32_t 
     // exclusive prefix over the 4 waves, in place: wcnt[w][c] -> entities of c in waves < w
     for (uint32_t c = threadIdx.x; c < ncell; c += IDX_BLOCK) {
         uint32_t a0 = wcnt[c], a1 = wcnt[ncell + c], a2 = wcnt[2 * ncell + c];
-        uint32_t g0 = (local_base ? cbase[c] : w.cell_off[c]) + w.blk_cnt[(size_t)c * w.nblk + bid];  // cell base + entities of c in earlier blocks
+        const bool first = c == threadIdx.x;  // (the prefetched round)
+        uint32_t g0 = (local_base ? cbase[c] : (first ? pre_base : w.cell_off[c])) + (first ? pre_blk : w.blk_cnt[(size_t)c * w.nblk + bid]);  // cell base + entities of c in earlier blocks
         wcnt[c] = g0;
         wcnt[ncell + c] = g0 + a0;
         wcnt[2 * ncell + c] = g0 + a0 + a1;
@@ -247,18 +311,21 @@ __device__ __forceinline__ void index_scatter_block(const WorldDev &w, uint32_t 
 #pragma unroll
     for (int r = 0; r < IDX_ITEMS; r++) {
         if (key[r] == CHD_INVALID) continue;
-        uint32_t i = base + r * 64 + lane;
         uint32_t pos = mycnt[key[r]] + lrank[r];
-        const uint32_t u = log_ix(w, i);
-        uint32_t age = cur_tick - w.hist_tick[u];
-        uint32_t h = (age >= CHD_HIST_BITS) ? 0u : (w.hist[u] << age);
-        uint32_t hp = (age >= CHD_HIST_BITS) ? 0u : (w.hist_prev[u] << age);
-        w.ce[pos] = make_uint4(w.chan_id[i], h, w.sender[u], hp);
-        w.ce8[pos] = make_uint2(w.chan_id[i], h | hp);
-        w.ce_chan[pos] = w.chan_id[i];
-        w.ce_sprev[pos] = w.sender_prev[u];
-        if (w.ce_slot) w.ce_slot[pos] = ce_ix(w, i);  // (what the exact buffers / wire payloads are indexed by: the slot — or the channel)
-        if (w.off_on) scatter_offsets(w, u, pos, age);
+        uint32_t age = cur_tick - htk[r];
+        uint32_t h = (age >= CHD_HIST_BITS) ? 0u : (hcu[r] << age);
+        uint32_t hp = (age >= CHD_HIST_BITS) ? 0u : (hpv[r] << age);
+        w.ce[pos] = make_uint4(chn[r], h, snd[r], hp);
+        w.ce8[pos] = make_uint2(chn[r], h | hp);
+        w.ce_chan[pos] = chn[r];
+        w.ce_sprev[pos] = spv[r];
+        if (w.ce_slot) w.ce_slot[pos] = w.ce_by_chan ? chn[r] - w.log_eid0 : base + r * 64 + lane;  // (what the exact buffers / wire payloads are indexed by: the slot — or the channel)
+        if (w.off_on) {
+            uint32_t o[CHD_OFF_SLOTS] = {oa[r].x, oa[r].y, oa[r].z, oa[r].w, ob[r].x, ob[r].y, ob[r].z, ob[r].w};
+            off_shift(o, age);
+#pragma unroll
+            for (uint32_t j = 0; j < CHD_OFF_SLOTS; j++) w.ce_off[(size_t)j * w.off_stride + pos] = o[j];
+        }
     }
 }
 
@@ -433,139 +500,184 @@ __global__ void __launch_bounds__(256) k_window_columns(WorldDev w, uint32_t nce
         if (threadIdx.x == (uint32_t)j) w.cell_wcnt[(size_t)j * ncell + c] = build[j] ? run[j] : n;
 }
 
-// Per cell and ring slot j < CHD_OFF_SLOTS the {min, max} sub-tick offset over the cell's entities that hold an update of that
-// slot (WorldDev::cell_orng; min > max: none does).  One workgroup per cell over its cell-sorted entries.
-__global__ void __launch_bounds__(256) k_cell_offsets(WorldDev w, uint32_t ncell) {
+// ---------------------------------------------------------------------------
+// k_cell_arrange: worlds that keep sub-tick arrival offsets (off_on), one workgroup per cell over its cell-sorted entries, behind
+// the index build (region-sharded: behind the halo unpack, so the neighbours' ghost entries as well).  Two products:
+//  (1) per ring slot j < CHD_OFF_SLOTS the {min, max} sub-tick offset over the cell's entities that hold an update of that slot
+//      (WorldDev::cell_orng; min > max: none does): what the plan decides "every update of the slot inside / outside this window" from;
+//  (2) cells of up to ARR_MAX entries (the filtered record kernel's LDS tile): the entries IN THE ORDER OF THIS TICK'S ARRIVALS —
+//      ascending offset of ring slot 0, entities without an update in this tick last (cell_sorted[c] = 1).  The order inside a cell is
+//      free (a connection's records are a multiset), and in this one the part of a fan-out window that lies inside the tick's own
+//      arrivals — every window of a subscription whose interval is shorter than the tick, one end of every window whose phase is off
+//      the tick grid — selects a CONTIGUOUS RUN of the cell's column: k_fanout_emit_filt_cm finds the run's two ends by a binary search
+//      over the staged offsets and copies it, instead of testing every entity of the cell against the window.
+// One load round trip (every per-entry array of the cell into registers), a counting sort in LDS — 64 buckets over the span of the
+// cell's own slot-0 offsets (their {min, max} is product (1)), the rank inside a bucket by comparing with the bucket's other entries
+// (offset, then position: deterministic) —, then every array written back permuted, in place (every thread's loads have returned
+// before the barrier in front of the first store).  A cell whose arrivals crowd into one bucket (more than ARR_BKT_MAX entries: the
+// rank loop would be quadratic) stays as it is, cell_sorted[c] = 0: its windows are tested per entity, which is always correct.
+// ---------------------------------------------------------------------------
+#define ARR_MAX 512u
+#define ARR_BKT 64u
+#define ARR_BKT_MAX 48u
+template <int CTRL>
+__device__ __forceinline__ uint32_t dpp_mov(uint32_t v) { return (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, CTRL, 0xF, 0xF, false); }
+// min / max over the wave: inside every row of 16 lanes by DPP (quad permutes, then the mirrors), across the four rows on the scalar unit
+__device__ __forceinline__ uint32_t wave_min_u32(uint32_t v) {
+    v = min(v, dpp_mov<0xB1>(v)); v = min(v, dpp_mov<0x4E>(v)); v = min(v, dpp_mov<0x141>(v)); v = min(v, dpp_mov<0x140>(v));
+    return min(min((uint32_t)__builtin_amdgcn_readlane((int)v, 0), (uint32_t)__builtin_amdgcn_readlane((int)v, 16)),
+               min((uint32_t)__builtin_amdgcn_readlane((int)v, 32), (uint32_t)__builtin_amdgcn_readlane((int)v, 48)));
+}
+__device__ __forceinline__ uint32_t wave_max_u32(uint32_t v) {
+    v = max(v, dpp_mov<0xB1>(v)); v = max(v, dpp_mov<0x4E>(v)); v = max(v, dpp_mov<0x141>(v)); v = max(v, dpp_mov<0x140>(v));
+    return max(max((uint32_t)__builtin_amdgcn_readlane((int)v, 0), (uint32_t)__builtin_amdgcn_readlane((int)v, 16)),
+               max((uint32_t)__builtin_amdgcn_readlane((int)v, 32), (uint32_t)__builtin_amdgcn_readlane((int)v, 48)));
+}
+
+// LDS staging of one cell: every per-entry word as a column (the counting sort's scratch shares nothing with it)
+struct ArrStage {
+    uint32_t ce[4][ARR_MAX];              // the 16-byte entry {channel, history, sender, previous sender's history}
+    uint32_t chan8[ARR_MAX], hist8[ARR_MAX];  // the compact entry {channel, history of any sender}
+    uint32_t chan[ARR_MAX], sprev[ARR_MAX], slot[ARR_MAX];
+    uint32_t off[CHD_OFF_SLOTS][ARR_MAX];
+};
+__global__ void __launch_bounds__(256) k_cell_arrange(WorldDev w, uint32_t ncell, int sort) {
+    __shared__ ArrStage L;
     __shared__ uint32_t smn[4][CHD_OFF_SLOTS], smx[4][CHD_OFF_SLOTS];
-    const uint32_t c = blockIdx.x;
+    __shared__ uint32_t bcnt[ARR_BKT + 1], boff[ARR_BKT + 2], skey[ARR_MAX], wcnt[4], crowded;
+    __shared__ unsigned short sidx[ARR_MAX], perm[ARR_MAX];
+    const uint32_t c = blockIdx.x, tid = threadIdx.x;
     const uint32_t start = w.cell_start[c], n = w.cell_end[c] - start;  // (region-sharded: the neighbours' ghost entries as well)
-    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    const uint32_t lane = tid & 63u, wave = tid >> 6;
+    const bool small = n <= ARR_MAX, arrange = small && sort && w.cell_sorted != nullptr;
+    // PHASE A: the cell's words into LDS (small cells; plain loops of unconditional loads: the whole launch is as long as its slowest
+    // workgroup, and loads behind per-lane tests — or a large unrolled body kept live in registers — made that 18-28 us), and per
+    // thread the {min, max} offset of every ring slot over its entries
     uint32_t mn[CHD_OFF_SLOTS], mx[CHD_OFF_SLOTS];
 #pragma unroll
     for (uint32_t j = 0; j < CHD_OFF_SLOTS; j++) { mn[j] = 0xFFFFFFFFu; mx[j] = 0u; }
-    for (uint32_t k = threadIdx.x; k < n; k += 256) {
-        const uint32_t h = w.ce8_view[start + k].y;  // history of any sender, aligned to this tick
+    for (uint32_t i = tid; i < n; i += 256) {
+        const uint32_t s = start + i;
+        const uint32_t h = w.ce8_view[s].y;  // history of any sender, aligned to this tick
+        uint32_t o[CHD_OFF_SLOTS];
 #pragma unroll
-        for (uint32_t j = 0; j < CHD_OFF_SLOTS; j++) {
-            if (!((h >> j) & 1u)) continue;
-            const uint32_t o = w.ce_off[(size_t)j * w.off_stride + start + k];
-            mn[j] = min(mn[j], o);
-            mx[j] = max(mx[j], o);
+        for (uint32_t q = 0; q < CHD_OFF_SLOTS; q++) o[q] = w.ce_off[(size_t)q * w.off_stride + s];
+#pragma unroll
+        for (uint32_t q = 0; q < CHD_OFF_SLOTS; q++) {
+            const bool has = (h >> q) & 1u;
+            mn[q] = min(mn[q], has ? o[q] : 0xFFFFFFFFu);
+            mx[q] = max(mx[q], has ? o[q] : 0u);
+            if (arrange) L.off[q][i] = o[q];
         }
+        if (arrange) L.hist8[i] = h;
+    }
+    if (arrange) {
+        for (uint32_t i = tid; i < n; i += 256) {
+            const uint32_t s = start + i;
+            const uint4 e = w.ce_view[s];
+            L.ce[0][i] = e.x; L.ce[1][i] = e.y; L.ce[2][i] = e.z; L.ce[3][i] = e.w;
+            L.chan8[i] = w.ce8_view[s].x; L.chan[i] = w.ce_chan_view[s]; L.sprev[i] = w.ce_sprev_view[s];
+        }
+        if (w.ce_slot) for (uint32_t i = tid; i < n; i += 256) L.slot[i] = w.ce_slot[start + i];
     }
 #pragma unroll
     for (uint32_t j = 0; j < CHD_OFF_SLOTS; j++) {
-        for (int d = 32; d >= 1; d >>= 1) {
-            mn[j] = min(mn[j], (uint32_t)__shfl_xor((int)mn[j], d));
-            mx[j] = max(mx[j], (uint32_t)__shfl_xor((int)mx[j], d));
-        }
-        if (lane == 0) { smn[wave][j] = mn[j]; smx[wave][j] = mx[j]; }
+        const uint32_t a = wave_min_u32(mn[j]), b = wave_max_u32(mx[j]);
+        if (lane == 0) { smn[wave][j] = a; smx[wave][j] = b; }
     }
+    if (tid <= ARR_BKT) bcnt[tid] = 0;
+    if (tid == 0) crowded = 0;
     __syncthreads();
-    if (threadIdx.x < CHD_OFF_SLOTS) {
-        const uint32_t j = threadIdx.x;
+    if (tid < CHD_OFF_SLOTS) {
+        const uint32_t j = tid;
         const uint32_t a = min(min(smn[0][j], smn[1][j]), min(smn[2][j], smn[3][j]));
         const uint32_t b = max(max(smx[0][j], smx[1][j]), max(smx[2][j], smx[3][j]));
         w.cell_orng[(size_t)c * CHD_OFF_SLOTS + j] = make_uint2(a, b);
     }
-}
-
-// Worlds that keep sub-tick arrival offsets (off_on, cell-major filtered kernel): every cell's entries IN THE ORDER OF THIS TICK'S
-// ARRIVALS — ascending offset of ring slot 0, entities without an update in this tick last (their slot-0 column entry becomes the
-// "no update" value 0xFFFFFFFF the record kernel stages anyway).  The order inside a cell is free (a connection's records are a
-// multiset), and in this one a fan-out window that lies inside the tick's own arrivals — every window of a subscription whose
-// interval is shorter than the tick: 20 ms on a 50 ms world — selects a CONTIGUOUS run of the cell's column: k_fanout_emit_filt_cm
-// finds its two ends by a two-level search and copies, instead of testing every entity of the cell against the window.
-// One workgroup per cell, bitonic sort of (offset, position) in LDS, then every per-entry array of the cell permuted in place
-// (all reads before the barrier, all writes behind it).  Cells beyond the record kernel's 512-entry tile stay as they are
-// (cell_sorted[c] = 0: their windows are tested per entity, as before).
-#define SORT0_MAX 512u
-#define SORT0_BKT 64u
-// Two-level counting sort (a bitonic network took 40 us per tick: 45 barrier-separated steps for 225 workgroups of four waves):
-// 64 buckets over the tick's interval by the offset's leading bits (+ one for "no update"), a prefix over the bucket counts, then
-// every entry's rank = its bucket's start + the entries of the SAME bucket that sort before it (offset, then position: ~7 compares
-// with uniformly spread arrivals; a tick whose arrivals all share one bucket degrades to n compares per entry, still correct).
-__global__ void __launch_bounds__(256) k_cell_sort0(WorldDev w, uint32_t ncell, uint32_t shift) {
-    __shared__ uint32_t bcnt[SORT0_BKT + 1], boff[SORT0_BKT + 2], skey[SORT0_MAX], sidx[SORT0_MAX];
-    const uint32_t c = blockIdx.x, tid = threadIdx.x;
-    const uint32_t start = w.cell_off[c], n = w.cell_off[c + 1] - start;
-    if (n > SORT0_MAX) { if (tid == 0) w.cell_sorted[c] = 0; return; }
-    if (tid == 0) w.cell_sorted[c] = 1;
-    if (n == 0) return;
-    if (tid <= SORT0_BKT) bcnt[tid] = 0;
-    __syncthreads();
-    uint32_t key[2], bk[2], lp[2];
-#pragma unroll
-    for (int r = 0; r < 2; r++) {
-        const uint32_t i = tid + 256u * r;
-        key[r] = 0xFFFFFFFFu; bk[r] = SORT0_BKT; lp[r] = 0;
-        if (i < n) {
-            if (w.ce8[start + i].y & 1u) {
-                key[r] = w.ce_off[start + i];
-                bk[r] = min(key[r] >> shift, SORT0_BKT - 1u);
-            }
-            lp[r] = atomicAdd(&bcnt[bk[r]], 1u);
-        }
-    }
-    __syncthreads();
-    if (tid == 0) {
-        uint32_t acc = 0;
-        for (uint32_t b = 0; b <= SORT0_BKT; b++) { boff[b] = acc; acc += bcnt[b]; }
-        boff[SORT0_BKT + 1] = acc;
-    }
-    __syncthreads();
-#pragma unroll
-    for (int r = 0; r < 2; r++) {
-        const uint32_t i = tid + 256u * r;
-        if (i < n) { skey[boff[bk[r]] + lp[r]] = key[r]; sidx[boff[bk[r]] + lp[r]] = i; }
-    }
-    __syncthreads();
-    // every entry's data (coalesced reads by position) and its rank; then, behind the barrier, the writes
-    uint4 e[2]; uint2 e8[2]; uint32_t ch[2], sp[2], sl[2], of[2][CHD_OFF_SLOTS], rank[2];
-#pragma unroll
-    for (int r = 0; r < 2; r++) {
-        const uint32_t i = tid + 256u * r;
-        rank[r] = 0;
-        if (i < n) {
-            const uint32_t s = start + i;
-            e[r] = w.ce[s]; e8[r] = w.ce8[s]; ch[r] = w.ce_chan[s]; sp[r] = w.ce_sprev[s];
-            sl[r] = w.ce_slot ? w.ce_slot[s] : 0u;
-#pragma unroll
-            for (uint32_t q = 1; q < CHD_OFF_SLOTS; q++) of[r][q] = w.ce_off[(size_t)q * w.off_stride + s];
-            of[r][0] = key[r];  // (an entity without an update in this tick: 0xFFFFFFFF, what the record kernel stages for it anyway)
-            uint32_t before = 0;
-            for (uint32_t k = boff[bk[r]]; k < boff[bk[r] + 1u]; k++) {
-                const uint32_t kk = skey[k], ki = sidx[k];
-                before += (kk < key[r] || (kk == key[r] && ki < i)) ? 1u : 0u;
-            }
-            rank[r] = boff[bk[r]] + before;
-        }
-    }
-    __syncthreads();
-#pragma unroll
-    for (int r = 0; r < 2; r++) {
-        const uint32_t i = tid + 256u * r;
-        if (i < n) {
-            const uint32_t d = start + rank[r];
-            w.ce[d] = e[r]; w.ce8[d] = e8[r]; w.ce_chan[d] = ch[r]; w.ce_sprev[d] = sp[r];
-            if (w.ce_slot) w.ce_slot[d] = sl[r];
-#pragma unroll
-            for (uint32_t q = 0; q < CHD_OFF_SLOTS; q++) w.ce_off[(size_t)q * w.off_stride + d] = of[r][q];
-        }
-    }
-}
-
-// bucket = offset >> shift with the tick's interval spread over the 64 buckets
-static uint32_t sort0_shift(const WorldDev &w, int64_t now_ns) {
-    const uint64_t len = (w.prev_ns >= 0 && now_ns > w.prev_ns) ? (uint64_t)(now_ns - w.prev_ns) : 1ull << 26;
+    if (!w.cell_sorted) return;
+    const uint32_t mn0 = min(min(smn[0][0], smn[1][0]), min(smn[2][0], smn[3][0])), mx0 = max(max(smx[0][0], smx[1][0]), max(smx[2][0], smx[3][0]));
+    if (!arrange) { if (tid == 0) w.cell_sorted[c] = 0; return; }  // (not asked for / a cell beyond the tile)
+    if (n == 0 || mn0 > mx0) { if (tid == 0) w.cell_sorted[c] = 1; return; }  // (nothing to order: no entry holds an update of this tick)
+    // PHASE B: counting sort on the slot-0 offset.  bucket = (offset - min) >> sh with the span of the cell's own offsets over the 64
+    // buckets; no update in this tick: bucket 64
     uint32_t sh = 0;
-    while (sh < 31u && (len >> sh) > SORT0_BKT) sh++;
-    return sh;
+    { const uint32_t span = mx0 - mn0; while (sh < 31u && (span >> sh) >= ARR_BKT) sh++; }
+    uint32_t key[2], bk[2], lp[2];
+    uint64_t inv_m[2];
+#pragma unroll
+    for (int r = 0; r < 2; r++) {
+        const uint32_t i = tid + 256u * r;
+        const bool in = i < n, has = in && (L.hist8[in ? i : 0u] & 1u);
+        key[r] = has ? L.off[0][i] : 0xFFFFFFFFu;
+        bk[r] = has ? min((key[r] - mn0) >> sh, ARR_BKT - 1u) : ARR_BKT;
+        lp[r] = 0;
+        if (has) lp[r] = atomicAdd(&bcnt[bk[r]], 1u);
+        // (the entities without an update keep their relative order: position among them by ballots, no atomics)
+        inv_m[r] = __ballot(in && !has);
+    }
+    if (lane == 0) wcnt[wave] = (uint32_t)__popcll(inv_m[0]) | ((uint32_t)__popcll(inv_m[1]) << 16);
+    __syncthreads();
+    if (tid < 64) {  // exclusive prefix over the 64 buckets (one wave), the "no update" bucket behind them
+        const uint32_t v = bcnt[tid];
+        if (v > ARR_BKT_MAX) crowded = 1;
+        uint32_t inc = v;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const uint32_t o = (uint32_t)__shfl_up((int)inc, d);
+            if ((int)lane >= d) inc += o;
+        }
+        boff[tid] = inc - v;
+        if (tid == 63) { boff[64] = inc; boff[65] = n; }
+    }
+    __syncthreads();
+    if (crowded) { if (tid == 0) w.cell_sorted[c] = 0; return; }  // (uniform: the arrays have not been touched)
+#pragma unroll
+    for (int r = 0; r < 2; r++) {
+        const uint32_t i = tid + 256u * r;
+        if (i < n && bk[r] < ARR_BKT) { skey[boff[bk[r]] + lp[r]] = key[r]; sidx[boff[bk[r]] + lp[r]] = (unsigned short)i; }
+    }
+    __syncthreads();
+    {
+        // invalid entries before this one: round 0's of lower waves and lanes; round 1's come behind all of round 0's
+        uint32_t w0 = 0, w1 = 0, a0 = 0;
+        for (uint32_t q = 0; q < 4; q++) { const uint32_t t = wcnt[q]; a0 += t & 0xFFFFu; if (q < wave) { w0 += t & 0xFFFFu; w1 += t >> 16; } }
+#pragma unroll
+        for (int r = 0; r < 2; r++) {
+            const uint32_t i = tid + 256u * r;
+            if (i >= n) continue;
+            uint32_t rank;
+            if (bk[r] == ARR_BKT) {
+                rank = boff[64] + (r == 0 ? w0 : a0 + w1) + mask_rank(inv_m[r]);
+            } else {
+                uint32_t before = 0;
+                for (uint32_t k = boff[bk[r]]; k < boff[bk[r] + 1u]; k++) {
+                    const uint32_t kk = skey[k], ki = sidx[k];
+                    before += (kk < key[r] || (kk == key[r] && ki < i)) ? 1u : 0u;
+                }
+                rank = boff[bk[r]] + before;
+            }
+            perm[rank] = (unsigned short)i;
+        }
+    }
+    __syncthreads();
+    // PHASE C: every array written back in the new order, destination by destination (whole lines per store instruction)
+    if (tid == 0) w.cell_sorted[c] = 1;
+    uint4 *ce = (uint4 *)w.ce_view; uint2 *ce8 = (uint2 *)w.ce8_view; uint32_t *cc = (uint32_t *)w.ce_chan_view, *cs = (uint32_t *)w.ce_sprev_view;
+    for (uint32_t d = tid; d < n; d += 256) {
+        const uint32_t i = perm[d], s = start + d;
+        ce[s] = make_uint4(L.ce[0][i], L.ce[1][i], L.ce[2][i], L.ce[3][i]);
+        ce8[s] = make_uint2(L.chan8[i], L.hist8[i]);
+        cc[s] = L.chan[i]; cs[s] = L.sprev[i];
+#pragma unroll
+        for (uint32_t q = 0; q < CHD_OFF_SLOTS; q++) w.ce_off[(size_t)q * w.off_stride + s] = L.off[q][i];
+    }
+    if (w.ce_slot) for (uint32_t d = tid; d < n; d += 256) w.ce_slot[start + d] = L.slot[perm[d]];
 }
 
 void launch_cell_offsets(hipStream_t st, DevGrid g, WorldDev w) {
     if (!w.N || !w.off_on) return;
-    hipLaunchKernelGGL(k_cell_offsets, dim3(g.ncell), dim3(256), 0, st, w, g.ncell);
+    static const int sort = [] { const char *e = getenv("CHD_SORT_ARRIVALS"); return (e && e[0] == '0') ? 0 : 1; }();  // (A/B runs)
+    hipLaunchKernelGGL(k_cell_arrange, dim3(g.ncell), dim3(256), 0, st, w, g.ncell, sort);
 }
 
 void launch_window_columns(hipStream_t st, DevGrid g, WorldDev w) {
@@ -588,7 +700,6 @@ bool launch_index_build(hipStream_t st, DevGrid g, WorldDev w, uint32_t cur_tick
         hipLaunchKernelGGL(k_index_scan, dim3((g.ncell + 3) / 4), dim3(256), 0, st, w, g.ncell, !local_base);
         hipLaunchKernelGGL(k_index_scatter, dim3(w.nblk), dim3(IDX_BLOCK), (local_base ? 5 : 4) * g.ncell * 4, st, w,
                            g.ncell, bits_for(g.ncell), cur_tick, local_base, gate_p, gate_target);
-        if (w.cell_sorted) hipLaunchKernelGGL(k_cell_sort0, dim3(g.ncell), dim3(256), 0, st, w, g.ncell, sort0_shift(w, now_ns));
         return gate_p != nullptr;
     } else {
         // nblk == 1 layout: blk_cnt[c] then scan -> cell_off; cursor lives behind it
@@ -603,7 +714,6 @@ bool launch_index_build(hipStream_t st, DevGrid g, WorldDev w, uint32_t cur_tick
         (void)hipMemcpyAsync(w.cell_off, w.blk_cnt, sizeof(uint32_t) * ((size_t)g.ncell + 1), hipMemcpyDeviceToDevice, st);
         hipLaunchKernelGGL(k_index_scatter_global, dim3((w.N + 255) / 256), dim3(256), 0, st, w, g.ncell, cursor,
                            cur_tick);
-        if (w.cell_sorted) hipLaunchKernelGGL(k_cell_sort0, dim3(g.ncell), dim3(256), 0, st, w, g.ncell, sort0_shift(w, now_ns));
     }
     return false;
 }

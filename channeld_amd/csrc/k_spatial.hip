@@ -428,15 +428,25 @@ __device__ __forceinline__ void ingest_block(const DevGrid &g, const WorldDev &w
         if (u < n) {
             const uint32_t i = idx ? idx[u] : u;
             ent[j] = i;
+            // every word of the update and of the entity's state, requested before the first test (an index beyond N reads slot 0's
+            // and is dropped): see upd_prefetch
+            const uint32_t ic = i < w.N ? i : 0u;
+            const double px = x[u], pz = z[u];
+            const uint32_t efl = w.eflags[ic], cell_old = w.cell[ic];
+            const UpdPre P = upd_prefetch(w, ic);
+            const uint32_t *sp = sender ? sender : w.sender;
+            const uint32_t snd_u = sp[sender ? u : ic];
+            const int64_t *ap = arrival ? arrival : (const int64_t *)(const void *)x;  // (no stamps: any readable 8 bytes, unused)
+            const int64_t arr_raw = ap[u];
             // chd_tick_device cannot see duplicates on the host: one returning atomic per EXPLICITLY indexed update (the identity
             // mapping cannot repeat a slot) turns a broken precondition into an error instead of a race
             if (idx && i < w.N && atomicExch(&w.upd_mark[i], mark) == mark) atomicOr(&w.counters[CTR_OVERFLOW], OVF_DUPLICATE);
-            uint32_t ef = (i < w.N) ? w.eflags[i] : 0u;
+            uint32_t ef = (i < w.N) ? efl : 0u;
             if (ef & EF_ALIVE) {
-                dst[j] = cell_of(g, x[u], z[u]);
-                src[j] = w.cell[i];
+                dst[j] = cell_of(g, px, pz);
+                src[j] = cell_old;
                 w.cell[i] = dst[j];
-                push_update(w, i, sender ? sender[u] : w.sender[i], cur_tick, src[j], dst[j], arrival ? arrival[u] : now, now);
+                push_update_pre(w, i, P, snd_u, cur_tick, src[j], dst[j], arrival ? arr_raw : now, now);
                 if (src[j] != CHD_INVALID && dst[j] != CHD_INVALID && src[j] != dst[j]) {
                     // GetHandoverEntities (entity.go:197-224): a locked member of the notifier's handover group
                     // empties the list and the handover does not happen (spatial.go:675-679)

@@ -612,7 +612,11 @@ int chd_shard_despawn(chd_ctx *ctx, uint32_t n, const uint32_t *chan_id);
  * count any rank saw two ticks ago (every header carries its sender's maximum, so every rank derives the SAME value and the
  * all-to-all sizes agree without a collective), a power of two in [256, cap] — lays the segments out at a pitch of
  * (*cap_used + 1) records and returns it: exchange world x (*cap_used + 1) records and pass *cap_used to chd_shard_import.
- * Record 0's other fields are reserved (the library uses `cell`). */
+ * Record 0's other fields are reserved (the library uses `cell`).
+ * LIFETIME of d_x_by_chan / d_z_by_chan / d_has_update on a world with the update log by channel id (shard_channels + history_depth):
+ * the tick's updates are logged by chd_shard_IMPORT, behind the emigrant exchange (which carries the cells' maxFanOutIntervalMs) — the
+ * three arrays must stay valid and unmodified until that call has been enqueued; it releases them.  One import per ingest: a
+ * chd_shard_import without a fresh chd_shard_ingest[_pre] answers CHD_E_STATE (it would log the tick's updates twice). */
 int chd_shard_ingest(chd_ctx *ctx, int64_t now_ns, const double *d_x_by_chan,
                      const double *d_z_by_chan, const uint8_t *d_has_update, uint32_t n_chan,
                      uint32_t rank, uint32_t world, chd_entity_state *d_send, uint32_t cap, uint32_t *cap_used);
@@ -728,6 +732,10 @@ int chd_shard_ingest_post(chd_ctx *ctx, const chd_handover_request *d_req_recv, 
  * chd_shard_comm_init, which is a collective and would wait for a rank that never comes.  CHD_OK, or CHD_E_STATE with the
  * loader's message in chd_last_error(NULL). */
 int chd_shard_comm_available(void);
+/* (CHD_SHARD_TRANSPORT=hostpipe in rank 0's environment makes the id name a POSIX shared-memory segment instead: a blocking, host-staged
+ * TEST transport for running chd_shard_tick with several ranks on one GPU — call sequence, sizes and the gated join, none of RCCL's
+ * asynchrony.  It and the library's other test hook, CHD_TEST_DROP_GATE_RAISE, are environment-driven; a production build may compile
+ * both out with -DCHD_NO_TEST_HOOKS, and chd_shard_comm_init then refuses such an id.) */
 int chd_shard_comm_unique_id(void *id_out /* CHD_COMM_ID_BYTES */);
 /* On failure nothing is left behind (no communicator, stream or events) and the call may be repeated with a fresh id. */
 int chd_shard_comm_init(chd_ctx *ctx, const void *unique_id, uint32_t rank, uint32_t world, uint32_t migrate_cap);

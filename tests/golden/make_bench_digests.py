@@ -56,9 +56,17 @@ def main():
                     help="bench.py --arrival-jitter's world: every update stamped at its enqueue time (synth.ArrivalJitter), the oracle's "
                          "buffers hold those stamps (orc_world_tick_arrivals); default output tests/golden/bench_digests_B_jitter.json")
     ap.add_argument("--tick-jitter-us", type=int, default=0, help="with --arrival-jitter: tick times off the grid (…_jitter_offgrid.json)")
+    ap.add_argument("--config", choices=["B", "C"], default="B",
+                    help="C: BASELINE config C (1 M entities / 10 K subscribers, seed 0xC0FFEE02) — tests/test_gpu_fullsize.py's committed list "
+                         "for the reference-stamp path at that size (bench_digests_C_jitter.json; ~70 s per tick on 8 cores)")
     args = ap.parse_args()
+    global SEED, N
+    if args.config == "C":
+        SEED, N = 0xC0FFEE02, 1_000_000
     if args.out is None:
         args.out = OUT if not args.arrival_jitter else OUT.replace(".json", "_jitter_offgrid.json" if args.tick_jitter_us else "_jitter.json")
+        if args.config == "C":
+            args.out = args.out.replace("bench_digests_B", "bench_digests_C")
     orc.build()
     cfg = synth.load_config("spatial_static_benchmark.json")
     sw = synth.SynthWorld(synth.WorldSpec(cfg, N, S, SEED, tick_ms=TICK_MS, aoi_scale=1.0))
@@ -82,7 +90,7 @@ def main():
                 slow = None
         assert not fast.unsorted()
         ticks[str(k)] = [cnt, sm, xr]
-        if k % 20 == 0:
+        if k % 20 == 0 or args.config == "C":
             print(f"tick {k}: {cnt} records, {time.perf_counter() - t0:.0f} s", file=sys.stderr, flush=True)
     with open(args.out, "w") as f:
         json.dump({"what": "per-tick digests {count, sum, xor of mix64(conn << 32 | channel)} of the fan-out records of bench.py's default world "
