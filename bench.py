@@ -120,6 +120,9 @@ def parse():
                     help="N > 1: check the first K ticks (part of the warm-up) against the single-world CPU oracle on rank 0's host cores - "
                          "sum over ranks of chd_tick_digest, per-connection digests, handover / unsub counts - and fail loudly on any "
                          "difference; `verified_ticks` in the line.  Default 2 when N > 1")
+    ap.add_argument("--verify-golden", default=None, metavar="FILE",
+                    help="with --verify K: compare with the single world's COMMITTED oracle results (tests/golden/bench_digests_E.json) instead of "
+                         "advancing the oracle on rank 0's host cores")
     ap.add_argument("--max-records", type=int, default=0, help="fan-out record capacity per rank (0 = half of the free HBM; ranks sharing a GPU need a number)")
     ap.add_argument("--latency-steps", type=int, default=200, help="extra synchronous ticks for p50/p99 (SURVEY 8d: >= 200), independent of --steps")
     ap.add_argument("--e2e-ticks", type=int, default=5,
@@ -355,6 +358,31 @@ class SingleWorldChecker:
                 "unsubs": len(ow.unsubs()[0])}
 
 
+class GoldenChecker:
+    """bench.py --gpus N --verify K --verify-golden FILE: the single world's per-tick results as the CPU oracle computed them ONCE
+    (tests/golden/make_bench_digests.py --config E: SingleWorldChecker over the same frames, 80-100 s per tick of config E on a few
+    cores) and committed — {count, sum, xor} of all records, the fold of every connection's own digest, handover / abort / unsub
+    counts.  For worlds whose oracle does not fit a test suite's time; the comparison is the one --verify makes."""
+
+    def __init__(self, path):
+        with open(path) as f:
+            self.doc = json.load(f)
+        self.k = 0
+
+    def setup(self, cfg, n_entities, n_subs, capq, synth_world):
+        want = self.doc["world"]
+        have = {"entities": int(n_entities), "subs": int(n_subs), "grid": [int(cfg["GridCols"]), int(cfg["GridRows"])]}
+        if any(want[k] != have[k] for k in have):
+            raise SystemExit(f"bench.py --verify-golden: the file is of {want}, this run is {have}")
+
+    def step(self, now_ns, x, z, queries, arrivals=None):
+        self.k += 1
+        t = self.doc["ticks"].get(str(self.k))
+        if t is None:
+            raise SystemExit(f"bench.py --verify-golden: the file holds no tick {self.k}")
+        return {"digest": tuple(t["digest"]), "conn": None, "conn_fold": t["conn_fold"], "handovers": t["handovers"], "locked": t["locked"], "unsubs": t["unsubs"]}
+
+
 def self_launch(args):
     """`python bench.py --gpus N` run plainly (no WORLD_SIZE): become N ranks under torch.distributed.run."""
     import socket
@@ -455,7 +483,9 @@ def main():
     if dist_on:
         from channeld_amd import dist as cdist
 
-        result = cdist.run_bench(args, rank, world_size, local_rank, verifier=SingleWorldChecker())
+        result = cdist.run_bench(args, rank, world_size, local_rank, verifier=GoldenChecker(args.verify_golden) if args.verify_golden else SingleWorldChecker())
+        if rank == 0 and args.verify_golden:
+            result["verified_against"] = "the committed single-world oracle results of " + os.path.basename(args.verify_golden)
         if rank == 0:
             result["collectives"] = {"backend": str(dist.get_backend()) + (" (RCCL over xGMI)" if str(dist.get_backend()) == "nccl" else ""),
                                      "ranks": int(dist.get_world_size()), "devices_visible": int(torch.cuda.device_count())}

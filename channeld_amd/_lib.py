@@ -48,7 +48,7 @@ SYMBOLS = (
     "chd_tick_device", "chd_tick_fetch", "chd_sync", "chd_subs_get",
     "chd_world_get_entities", "chd_dev_alloc", "chd_dev_free", "chd_dev_upload",
     "chd_dev_download", "chd_set_profiling", "chd_set_profiling_scope", "chd_world_set_pipelining", "chd_get_tick_stats", "chd_get_tick_history",
-    "chd_set_stream", "chd_shard_spawn", "chd_shard_ingest", "chd_shard_import", "chd_shard_fanout",
+    "chd_set_stream", "chd_world_emit_form", "chd_shard_spawn", "chd_shard_ingest", "chd_shard_import", "chd_shard_fanout",
     "chd_shard_comm_available", "chd_shard_comm_unique_id", "chd_shard_comm_init", "chd_shard_comm_destroy", "chd_shard_tick", "chd_shard_set_handover_lists", "chd_shard_set_update_senders", "chd_shard_set_update_arrivals", "chd_shard_log_spawn", "chd_shard_despawn", "chd_shard_migrate_extra_records", "chd_shard_ingest_pre", "chd_shard_ingest_post",
     "chd_shard_get_entities", "chd_shard_halo_layout", "chd_shard_interest",
     "chd_handover_recipients", "chd_adjacent_recipients", "chd_wire_set_payloads", "chd_wire_build", "chd_wire_build_info", "chd_wire_fetch",
@@ -232,6 +232,7 @@ def load():
     L.chd_world_set_entity_groups.argtypes = [C.c_void_p, C.c_uint32, _u32p, _u32p]
     L.chd_subs_add.argtypes = [C.c_void_p, C.c_uint32, _u32p, _u32p]
     L.chd_subs_remove.argtypes = [C.c_void_p, C.c_uint32, _u32p]
+    L.chd_world_emit_form.argtypes = [C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, P(C.c_uint32)]
     L.chd_tick.argtypes = [C.c_void_p, P(TickIn), P(TickOut)]
     L.chd_tick_device.argtypes = [C.c_void_p, P(TickIn)]
     L.chd_tick_fetch.argtypes = [C.c_void_p, P(TickOut)]

@@ -958,6 +958,49 @@ int chd_border_channels(chd_ctx *ctx, uint32_t server_index, uint32_t *out, uint
 // world
 // ---------------------------------------------------------------------------
 
+// WHICH FORM a world's fan-out takes — everything chd_world_create decides from the world's shape, in one place (round 5 found
+// BASELINE config C with the reference's stamps 70 x slow because a 40-line `if` inside the creation picked the cell-major form for
+// it; tests/test_emit_form.py walks this function over (entities / cell, history_depth, subscriber slots, flags)).
+//   cell-major emit: grids up to 4096 cells (64 bitmap words per connection; also bounded by the memory of the per-item due lists:
+//     ~40 B per cell x connection slot), asked for — or chosen for populous cells (>= 1024 entities per cell) unless the world keeps
+//     EXACT UPDATE BUFFERS and the descriptor path can run: that path keeps sub-tick arrival offsets and decides a window that cuts
+//     through a tick's arrivals in the plan / the filtered kernel, the cell-major form has no such columns and sends every such
+//     subscription to the element walk (config C, every update stamped at its enqueue time: 155 ms per tick cell-major, 2.2 ms
+//     connection-major, profiles/r06j_kernel_stats_c1m_aj{,_cm}.csv);
+//   arrival offsets: where the descriptor path runs every tick — connection-major, one wave per connection, no per-record masks, no
+//     wire positions, at most 4096 cells — on a world with history_depth;
+//   tick pipelining: the descriptor path without masks / wire / exact buffers.
+struct EmitForm {
+    bool cm_possible, cm_emit, one_wave, off_on, pipe;
+    const char *refusal;  // nullptr: fine
+};
+static EmitForm select_emit_form(uint64_t N, uint64_t S, uint64_t C, uint32_t flags, uint32_t history_depth) {
+    EmitForm f{};
+    const uint64_t n_items_max = C * ((S + 255) / 256);
+    f.cm_possible = C <= 4096 && n_items_max * sizeof(WsItemG) <= (2ull << 30);
+    const bool masks = (flags & CHD_WORLD_UPDATE_MASKS) != 0, wire = (flags & CHD_WORLD_WIRE) != 0;
+    f.one_wave = (flags & CHD_WORLD_ONE_WAVE_EMIT) != 0;
+    const bool desc_geometry = S >= 4096 || f.one_wave;  // one wave per connection: the descriptor path's shape
+    const bool off_possible = history_depth && !masks && !wire && desc_geometry && C <= 4096;
+    const bool cm_wanted = (flags & CHD_WORLD_CELL_MAJOR_EMIT) || (!(flags & CHD_WORLD_CONN_MAJOR_EMIT) && N / C >= 1024 && !off_possible);
+    if ((flags & CHD_WORLD_CELL_MAJOR_EMIT) && !f.cm_possible) f.refusal = "cell-major emit needs a grid of at most 4096 cells (and cells x subscribers x 40 B <= 2 GiB)";
+    // update masks: written by the connection-major form only (the cell-major streamers replay precomputed window masks from LDS and
+    // would need the cell's own histories per window)
+    else if (masks && (flags & CHD_WORLD_CELL_MAJOR_EMIT)) f.refusal = "CHD_WORLD_UPDATE_MASKS is implemented by the connection-major emit only";
+    f.cm_emit = f.cm_possible && cm_wanted && !masks;
+    f.off_on = history_depth && !f.cm_emit && !masks && !wire && desc_geometry && C <= 4096;
+    f.pipe = (flags & CHD_WORLD_PIPELINE_TICKS) && !f.cm_emit && !masks && !wire && !history_depth && desc_geometry;
+    return f;
+}
+
+int chd_world_emit_form(uint32_t max_entities, uint32_t max_subscribers, uint32_t n_cells, uint32_t world_flags, uint32_t history_depth, uint32_t *schedule) {
+    if (!max_entities || !max_subscribers || !n_cells || !schedule) return CHD_E_INVAL;
+    const EmitForm f = select_emit_form(max_entities, max_subscribers, n_cells, world_flags, history_depth);
+    if (f.refusal) return CHD_E_INVAL;
+    *schedule = (f.cm_emit ? CHD_SCHED_CELL_MAJOR : 0u) | (f.off_on ? CHD_SCHED_ARRIVAL_OFFSETS : 0u) | (f.pipe ? CHD_SCHED_PIPELINED : 0u);
+    return CHD_OK;
+}
+
 int chd_world_create(chd_ctx *ctx, const chd_world_cfg *cfg) {
     if (!ctx || !cfg) return fail(ctx, CHD_E_INVAL, "chd_world_create: NULL argument");
     std::lock_guard<FairMutex> lk(ctx->mu);
@@ -1037,31 +1080,14 @@ int chd_world_create(chd_ctx *ctx, const chd_world_cfg *cfg) {
     TRY(walloc(ctx, &d.cell_ref, C));
     TRY(walloc(ctx, &d.active_cells, C));
     TRY(walloc(ctx, &d.n_active, 1));
-    // cell-major emit: grids up to 4096 cells (64 bitmap words per connection), unless the caller opts out
-    // (also bounded by the memory of the per-item due lists: ~40 B per cell x connection slot)
     const size_t n_items_max = C * ((S + 255) / 256);
-    const bool cm_possible = C <= 4096 && n_items_max * sizeof(WsItemG) <= (2ull << 30);
-    // Exact update buffers (history_depth): the connection-major descriptor path keeps sub-tick arrival offsets (WorldDev::off_on) and
-    // decides a window that cuts through a tick's arrivals in the plan / the filtered kernel; the cell-major form has no such columns
-    // and sends every such subscription to the element walk (k_fanout_emit_deep) — measured at config C (1 M entities, 4.4 K per
-    // cell, every update stamped at its enqueue time): 155 ms per tick cell-major, 2.2 ms connection-major
-    // (profiles/r06j_kernel_stats_c1m_aj{,_cm}.csv).  So populous cells alone do not select the cell-major form on such a world.
-    const bool off_possible = cfg->history_depth && !(cfg->flags & (CHD_WORLD_UPDATE_MASKS | CHD_WORLD_WIRE)) &&
-                              (S >= 4096 || (cfg->flags & CHD_WORLD_ONE_WAVE_EMIT)) && C <= 4096;
-    const bool cm_wanted = (cfg->flags & CHD_WORLD_CELL_MAJOR_EMIT) ||
-                           (!(cfg->flags & CHD_WORLD_CONN_MAJOR_EMIT) && N / C >= 1024 && !off_possible);
-    if ((cfg->flags & CHD_WORLD_CELL_MAJOR_EMIT) && !cm_possible)
-        return fail(ctx, CHD_E_INVAL, "cell-major emit needs a grid of at most 4096 cells (and cells x subscribers x 40 B <= 2 GiB)");
-    // update masks: written by the connection-major form only (the cell-major streamers replay precomputed window
-    // masks from LDS and would need the cell's own histories per window)
-    const bool want_masks = (cfg->flags & CHD_WORLD_UPDATE_MASKS) != 0;
-    if (want_masks && (cfg->flags & CHD_WORLD_CELL_MAJOR_EMIT))
-        return fail(ctx, CHD_E_INVAL, "CHD_WORLD_UPDATE_MASKS is implemented by the connection-major emit only");
+    const EmitForm form = select_emit_form(N, S, C, cfg->flags, cfg->history_depth);
+    if (form.refusal) return fail(ctx, CHD_E_INVAL, "%s", form.refusal);
     // the interest bitmap (one bit per cell and connection) exists for every grid of up to 4096 cells:
     // the recipient planners use it too; larger grids fall back to searching the sorted subscription lists
     d.wb = C <= 4096 ? (uint32_t)((C + 63) / 64) : 0u;
-    d.cm_emit = (cm_possible && cm_wanted && !want_masks) ? 1u : 0u;
-    d.one_wave_emit = (cfg->flags & CHD_WORLD_ONE_WAVE_EMIT) ? 1u : 0u;
+    d.cm_emit = form.cm_emit ? 1u : 0u;
+    d.one_wave_emit = form.one_wave ? 1u : 0u;
     d.sub_bits = nullptr;
     d.items = nullptr;
     if (d.wb) TRY(walloc(ctx, &d.sub_bits, S * d.wb));
@@ -1163,7 +1189,7 @@ int chd_world_create(chd_ctx *ctx, const chd_world_cfg *cfg) {
     // tick pipelining: only with the descriptor-driven connection-major emit (its record kernel reads descriptors, offsets
     // and one column array: all of them, and the record buffer, then exist once per tick parity)
     // (not with exact update buffers: maxFanOutIntervalMs is written by the interest updates and read by the ingest)
-    W.pipe_alloc = (cfg->flags & CHD_WORLD_PIPELINE_TICKS) && !d.cm_emit && !masks && !W.wire && !cfg->history_depth && (S >= 4096 || d.one_wave_emit);
+    W.pipe_alloc = form.pipe;
     W.pipe_on = W.pipe_alloc;
     if (W.pipe_alloc && !cfg->max_records) nrec /= 2;
     d.recs_cap = nrec;
@@ -1222,7 +1248,7 @@ int chd_world_create(chd_ctx *ctx, const chd_world_cfg *cfg) {
         // Sub-tick arrival offsets (WorldDev::off_on): where the descriptor path runs every tick — connection-major, one wave per
         // connection, no per-record masks, no wire positions — the stamps of regular updates are kept per ring slot and the
         // fan-out decides on them; the other forms keep "regular = stamped with the tick's own time".  CHD_ARRIVAL_OFFSETS=0: off (A/B).
-        d.off_on = (!d.cm_emit && !masks && !W.wire && (S >= 4096 || d.one_wave_emit) && C <= 4096) ? 1u : 0u;
+        d.off_on = form.off_on ? 1u : 0u;
         if (const char *e = getenv("CHD_ARRIVAL_OFFSETS")) if (e[0] == '0') d.off_on = 0;
         if (d.off_on) {
             d.off_stride = (uint32_t)((N + 520 + 63) & ~(size_t)63);

@@ -132,6 +132,12 @@ __device__ __forceinline__ bool sub_is_deep(const WorldDev &w, const TickRing &r
     return w.deep_depth != 0 && (fl & PF_HAD_FIRST) &&
            (w.cell_irr[c] != 0 || history_lost(ring, oldest, L, I) || (w.rec_mask && ring.n == CHD_HIST_BITS && (L > 0 ? L : 0) <= oldest));
 }
+// (the same with cell_irr[c] already loaded)
+__device__ __forceinline__ bool sub_is_deep_pre(const WorldDev &w, const TickRing &ring, int64_t oldest, uint32_t fl, int64_t L, int64_t I,
+                                                uint32_t cell_irr_c) {
+    return w.deep_depth != 0 && (fl & PF_HAD_FIRST) &&
+           (cell_irr_c != 0 || history_lost(ring, oldest, L, I) || (w.rec_mask && ring.n == CHD_HIST_BITS && (L > 0 ? L : 0) <= oldest));
+}
 // worst case of its segment: per channel of the cell one record per due window, and no more than TWICE what the buffer holds
 // elements — an arrival stamp that sits exactly on a window edge lies in two windows (both ends are inclusive, data.go:236-241),
 // so deep_walk can write two records per element
@@ -938,14 +944,13 @@ struct OffPlan {
 
 __device__ __forceinline__ void plan_windows_off(const WorldDev &w, const TickRing &ring, int64_t now, int64_t L, int64_t I, uint32_t c,
                                                  uint32_t hand, uint32_t chh, uint32_t chs, uint32_t chhp, uint32_t chsp, bool skip_self,
-                                                 uint32_t conn, FiltWin *__restrict__ fwout, OffPlan &o, uint32_t cell_age) {
+                                                 uint32_t conn, FiltWin *__restrict__ fwout, OffPlan &o, uint32_t cell_age,
+                                                 const uint4 &r0, const uint4 &r1, const uint4 &r2, const uint4 &r3, const uint4 &q0, const uint4 &q1) {
     o.nw = 0; o.own = 0; o.need = false; o.deep = false; o.Lw = L;
 #pragma unroll
     for (int k = 0; k < 4; k++) o.full[k] = 0;
-    // the cell's offset ranges and its own channel's offsets: one round trip
-    const uint4 *rp = (const uint4 *)(const void *)(w.cell_orng + (size_t)c * CHD_OFF_SLOTS);
-    const uint4 r0 = rp[0], r1 = rp[1], r2 = rp[2], r3 = rp[3];
-    const uint4 q0 = w.cell_ooff[2 * (size_t)c], q1 = w.cell_ooff[2 * (size_t)c + 1];
+    // (r0..r3: the cell's offset ranges, cell_orng; q0, q1: its own channel's offsets, cell_ooff — requested by the caller with its other
+    // per-cell words)
     const uint32_t rmin[CHD_OFF_SLOTS] = {r0.x, r0.z, r1.x, r1.z, r2.x, r2.z, r3.x, r3.z};
     const uint32_t rmax[CHD_OFF_SLOTS] = {r0.y, r0.w, r1.y, r1.w, r2.y, r2.w, r3.y, r3.w};
     // (the spatial channel's offsets are stored aligned to the tick of ITS last update, like its history bits: moved on to this tick —
@@ -1048,20 +1053,40 @@ __global__ void __launch_bounds__(64 * FO_WAVES) k_fanout_plan_seg(DevGrid g, Wo
         int64_t Lw = 0, Lold = 0;
         OffPlan op;
         op.nw = 0; op.own = 0; op.need = false; op.deep = false; op.Lw = 0;
+        // Two round trips for everything a lane may read: the subscription's own words, then — by its cell — every per-cell word
+        // (bounds, senders, histories, with offsets: ranges and the cell's own).  All unconditional (a lane without a subscription reads
+        // the row's first one, a cell index is clamped): with each of them behind "due?", "deep?", "with offsets?" the kernel was a chain
+        // of five dependent trips per wave, and it is as long as that chain (one wave per connection, a round of them per CU).
+        const uint32_t pp = p < cnt ? p : 0u;
+        const uint32_t fl_raw = w.pair_flags[pbase + pp], iv_raw = w.pair_iv[pbase + pp];
+        const int64_t L_raw = w.pair_last[pbase + pp];
+        const uint32_t c_raw = min(w.pair_cell[pbase + pp], g.ncell - 1u);
+        const uint32_t pc_start = w.cell_start[c_raw], pc_end = w.cell_end[c_raw];
+        const uint32_t *irr_p = w.deep_depth ? w.cell_irr : w.cell_start, *cov_p = w.cell_cov ? w.cell_cov : w.cell_start;
+        const uint32_t pc_irr = irr_p[c_raw], pc_cov = cov_p[c_raw];
+        const uint32_t c_us = w.cell_usender[c_raw], c_smin = w.cell_smin[c_raw], c_smax = w.cell_smax[c_raw], c_hand = w.cell_hand[c_raw];
+        const uint32_t c_htick = w.cell_hist_tick[c_raw], c_hist = w.cell_hist[c_raw], c_hprev = w.cell_hist_prev[c_raw];
+        const uint32_t chs = w.cell_sender[c_raw], chsp = w.cell_sender_prev[c_raw];
+        uint4 o_r0 = make_uint4(0u, 0u, 0u, 0u), o_r1 = o_r0, o_r2 = o_r0, o_r3 = o_r0, o_q0 = o_r0, o_q1 = o_r0;
+        if (OFF) {
+            const uint4 *rp = (const uint4 *)(const void *)(w.cell_orng + (size_t)c_raw * CHD_OFF_SLOTS);
+            o_r0 = rp[0]; o_r1 = rp[1]; o_r2 = rp[2]; o_r3 = rp[3];
+            o_q0 = w.cell_ooff[2 * (size_t)c_raw]; o_q1 = w.cell_ooff[2 * (size_t)c_raw + 1];
+        }
         if (p < cnt) {
-            fl = w.pair_flags[pbase + p] & ~(PF_DEFER | PF_DEEP);
-            const int64_t L = w.pair_last[pbase + p];
+            fl = fl_raw & ~(PF_DEFER | PF_DEEP);
+            const int64_t L = L_raw;
             Lold = L;
-            const uint32_t iv = w.pair_iv[pbase + p];
+            const uint32_t iv = iv_raw;
             const int64_t I = (int64_t)iv * 1000000;
             // data.go:194-197: NO_ACCESS is skipped but stays queued
             due = !(fl & PF_NO_ACCESS) && I > 0 && now >= L + I;
             if (due) {
-                c = w.pair_cell[pbase + p];
-                if (w.cell_cov && !w.cell_cov[c]) atomicOr(&w.counters[CTR_OVERFLOW], OVF_HALO);  // (see k_fanout_plan)
-                start = w.cell_start[c];
-                size = w.cell_end[c] - start;
-                if (sub_is_deep(w, ring, oldest, fl, L, I, c)) {  // exact update buffers: k_fanout_emit_deep's
+                c = c_raw;
+                if (w.cell_cov && !pc_cov) atomicOr(&w.counters[CTR_OVERFLOW], OVF_HALO);  // (see k_fanout_plan)
+                start = pc_start;
+                size = pc_end - start;
+                if (sub_is_deep_pre(w, ring, oldest, fl, L, I, pc_irr)) {  // exact update buffers: k_fanout_emit_deep's
                     deep = true;
                     due = false;
                     ub = deep_upper_bound(w, now, L, I, size);
@@ -1109,10 +1134,6 @@ __global__ void __launch_bounds__(64 * FO_WAVES) k_fanout_plan_seg(DevGrid g, Wo
                         Lw = next;
                     }
                 }
-                // (every per-cell word this lane may need is requested here, in one round trip with the cell bounds above)
-                const uint32_t c_us = w.cell_usender[c], c_smin = w.cell_smin[c], c_smax = w.cell_smax[c], c_hand = w.cell_hand[c];
-                const uint32_t c_htick = w.cell_hist_tick[c], c_hist = w.cell_hist[c], c_hprev = w.cell_hist_prev[c];
-                const uint32_t chs = w.cell_sender[c], chsp = w.cell_sender_prev[c];
                 uint32_t us = w.ce8_view ? c_us : CHD_NONUNIFORM;
                 const bool skip_self = (fl & PF_SKIP_SELF) != 0;
                 if (w.ce8_view && us == CHD_NONUNIFORM && (!skip_self || conn < c_smin || conn > c_smax))
@@ -1123,7 +1144,8 @@ __global__ void __launch_bounds__(64 * FO_WAVES) k_fanout_plan_seg(DevGrid g, Wo
                     // the walk against the real arrival stamps; wms = the slots each window covers whole
                     const uint32_t age = ring.cur_tick - c_htick;
                     const uint32_t chh = age < CHD_HIST_BITS ? (c_hist << age) : 0u, chhp = age < CHD_HIST_BITS ? (c_hprev << age) : 0u;
-                    plan_windows_off(w, ring, now, Lw, I, c, hand, chh, chs, chhp, chsp, skip_self, conn, w.filt_win + (pbase + p) * CHD_FILT_WINS, op, age);
+                    plan_windows_off(w, ring, now, Lw, I, c, hand, chh, chs, chhp, chsp, skip_self, conn, w.filt_win + (pbase + p) * CHD_FILT_WINS, op, age,
+                                     o_r0, o_r1, o_r2, o_r3, o_q0, o_q1);
                     Lw = op.Lw;
                     nw = op.nw;
 #pragma unroll

@@ -577,6 +577,18 @@ def bench_world(args, world: int):
     return cfg, N, S, int(1.5 * N / world) + 4096, int(1.5 * S / world) + 256, aoi, label, "strong"
 
 
+def conn_fold(slots, sums) -> int:
+    """Every connection's record digest (global slot, sum) folded into one order-independent 64-bit word: what a committed reference
+    (tests/golden/bench_digests_E.json) keeps instead of 100 000 sums per tick."""
+    M = np.uint64(0xFFFFFFFFFFFFFFFF)
+    with np.errstate(over="ignore"):
+        v = (np.asarray(slots, dtype=np.uint64) + np.uint64(1)) * np.uint64(0x9E3779B97F4A7C15) ^ np.asarray(sums, dtype=np.uint64)
+        v ^= v >> np.uint64(29)
+        v = (v * np.uint64(0xBF58476D1CE4E5B9)) & M
+        v ^= v >> np.uint64(32)
+        return int(np.add.reduce(v, dtype=np.uint64) & M)
+
+
 def verify_tick(comm: Comm, eng: "HipShardEngine", my_subs, s_cap: int, step, tick_index: int):
     """One tick of bench.py --verify: the ranks' fan-out digests (chd_tick_digest is additive over disjoint record sets:
     count and sum add, xor xors), handover / locked-abort / unsub counts and every connection's own digest against a
@@ -603,6 +615,11 @@ def verify_tick(comm: Comm, eng: "HipShardEngine", my_subs, s_cap: int, step, ti
             msg = f"tick {tick_index}: overflow flags {[int(v) for v in g[:, 7]]}, history overflow {[int(v) for v in g[:, 8]]}"
         elif got != want:
             msg = f"tick {tick_index}: records digest (count, sum, xor) over all ranks {got} != the single world's {want}"
+        elif oconn is None:
+            # a COMMITTED reference (bench.py --verify-golden): every connection's digest folded into one word, order-independent
+            fold = conn_fold(np.concatenate([subs[r] for r in range(comm.world)]), np.concatenate([sums[r] for r in range(comm.world)]))
+            if fold != int(ref["conn_fold"]):
+                msg = f"tick {tick_index}: the fold of every connection's record digest {fold:#x} != the committed single world's {int(ref['conn_fold']):#x}"
         else:
             for r in range(comm.world):
                 bad = np.nonzero(sums[r] != oconn[subs[r].astype(np.int64)])[0]

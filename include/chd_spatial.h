@@ -270,6 +270,15 @@ typedef struct {
 
 int chd_world_create(chd_ctx *ctx, const chd_world_cfg *cfg);
 
+/* Which form a world of this shape WILL take, without creating it: *schedule = the CHD_SCHED_CELL_MAJOR / CHD_SCHED_ARRIVAL_OFFSETS /
+ * CHD_SCHED_PIPELINED bits chd_tick_stats.schedule of such a world reports (the stream-overlap bits depend on the device and are not
+ * predicted).  Pure host arithmetic — the one function chd_world_create itself decides with — so that a gateway (and the test-suite)
+ * can check that its configuration keeps the streaming path: populous cells (>= 1024 entities per cell) select the cell-major form
+ * unless the world keeps exact update buffers (history_depth) and can run the descriptor path, where sub-tick arrival offsets decide
+ * the windows that cut through a tick's arrivals.  CHD_E_INVAL for a combination chd_world_create refuses. */
+int chd_world_emit_form(uint32_t max_entities, uint32_t max_subscribers, uint32_t n_cells, uint32_t world_flags, uint32_t history_depth,
+                        uint32_t *schedule);
+
 /* Entity channel creation + spawn into the cell containing (x,z)
  * (message_spatial.go:231-237, pkg/unreal/message.go:55).  idx = entity slots,
  * chan_id = entity channel ids (NetGUIDs), sender = the connection that will

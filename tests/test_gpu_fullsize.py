@@ -268,6 +268,42 @@ def test_config_c_one_million_entities_12_ticks_record_digests(amd):
     assert r3.n_records == 0
 
 
+def test_config_c_arrival_stamps_record_digests(amd):
+    """BASELINE config C (1 M entities / 10 K subscribers) with the REFERENCE's stamp semantics — every update stamped when it is
+    enqueued (channel.go:296-310), exact update buffers (history_depth 1024) — against the ORACLE's committed per-tick digests
+    (tests/golden/bench_digests_C_jitter.json = make_bench_digests.py --config C --arrival-jitter: the 18-70 s per tick of the CPU
+    oracle do not run inside the suite).  And the SCHEDULE is asserted, not only the records: round 5 found this configuration 70 x
+    slow on its last day (every populous cell fell to the serial element walk) because nothing looked at which path
+    a world of this shape takes — the descriptor path with arrival offsets, and not one record from the element walk."""
+    import os
+
+    N, S, seed, ticks = 1_000_000, 10_000, 0xC0FFEE02, 8
+    with open(os.path.join(os.path.dirname(__file__), "golden", "bench_digests_C_jitter.json")) as f:
+        golden = json.load(f)["ticks"]
+    cfg = synth.load_config("spatial_static_benchmark.json")
+    sw = synth.SynthWorld(synth.WorldSpec(cfg, N, S, seed))
+    ctl = amd.StaticGrid2DSpatialController()
+    assert ctl.LoadConfig(json.dumps(cfg).encode(), strict=False) is None
+    w = amd.SpatialWorld(ctl, N, S, max_records=3_000_000_000, history_depth=1024)
+    w.spawn(None, sw.chan_id, sw.x, sw.z, sw.flags, sw.sender)
+    w.add_subscribers(None, sw.sub_conn)
+    aj = synth.ArrivalJitter(seed, N, 0)
+    total = 0
+    for k in range(1, ticks + 1):
+        sw.step()
+        now, arr = aj.next(sw.now_ns())
+        res = w.tick(now, upd_x=sw.x, upd_z=sw.z, queries=sw.queries(), upd_arrival_ns=arr, want_records=False, records_cap=1)
+        assert res.overflow == 0 and res.history_overflow == 0, (k, res.overflow, res.history_overflow)
+        (cnt, dsum, dxor, _), _ = w.digest(per_connection=False)
+        assert [cnt, dsum, dxor] == golden[str(k)], f"tick {k}: records digest {[cnt, dsum, dxor]} != the oracle's {golden[str(k)]}"
+        h = w.history(1)[0]
+        sched = w.stats()["schedule"]
+        assert sched & 16 and not (sched & 8), sched                          # CHD_SCHED_ARRIVAL_OFFSETS, not CHD_SCHED_CELL_MAJOR
+        assert h["n_deep_records"] == 0, (k, h["n_deep_records"])               # nothing from the element walk
+        total += cnt
+    assert total > 4_000_000_000
+
+
 def test_emit_form_follows_the_update_pattern(amd):
     """A world of >= 4096 connections created without emit flags takes the descriptor path every tick; what its windows copy
     changes with the update pattern (chd_api.hip, tick_locked): the cells' full columns while every live entity sends an update

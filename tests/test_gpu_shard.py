@@ -570,6 +570,32 @@ def test_bench_config_d_on_its_four_servers_verified():
     assert "100000 entities / 10000 subs" in d["config"]["workload"] and max(d["verified"]["msgs_per_verified_tick"]) > 250_000_000
 
 
+def test_bench_config_d_with_enqueue_time_stamps_on_its_four_servers_verified():
+    """BASELINE config 4 AT ITS STATED SIZE with the REFERENCE's stamp semantics (VERDICT r5 #1b): bench.py --config D --arrival-jitter —
+    every update stamped when it was enqueued, exact update buffers by channel id on every rank — 4 ranks sharing the test box's GPU,
+    the first ticks against the single-world oracle fed the same stamps.  Its cells hold ~6 K entities: before DESIGN 13.8c's fix such a
+    world ran the serial element walk; the line's own counters say it does not."""
+    r, d = shared_gpu_bench(4, ["--config", "D", "--arrival-jitter", "--steps", "2", "--warmup", "2", "--verify", "2", "--max-records", "1600000000"], timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    assert d["verified_ticks"] == 2 and d["n_gpus"] == 4 and "100000 entities / 10000 subs" in d["config"]["workload"]
+    assert d["history_overflow"] == 0 and d["ticks_with_overflow_flags"] == 0
+    assert d["config"]["filtered_msgs_per_tick"] > 0 and d["config"].get("element_walk_msgs_per_tick", 0) == 0, d["config"]
+
+
+def test_bench_config_e_at_its_stated_size_against_the_committed_oracle_results():
+    """BASELINE config 5 AT ITS STATED SIZE (VERDICT r5 #1c): 8 x 8 world, 1 M entities / 100 K subscribers on its 4 x 2 server regions = 8
+    ranks sharing the test box's GPU, tick-aligned stamps, AOI x 0.5 — the first fan-out alone is 9 G records.  The single world's
+    oracle takes 80-100 s per tick, so its results are COMMITTED (tests/golden/bench_digests_E.json, make_shard_golden.py) and the bench
+    compares with those: all records' {count, sum, xor}, the fold of every connection's digest, handover / abort / unsub counts.
+    (E with exact update buffers stays at half size — profiles/r06j_*: eight ranks' 12 GiB update logs + worst-case filtered segments
+    exceed ONE GPU's 288 GB; eight GPUs hold it.)"""
+    golden = os.path.join(ROOT, "tests", "golden", "bench_digests_E.json")
+    r, d = shared_gpu_bench(8, ["--config", "E", "--steps", "1", "--warmup", "2", "--verify", "2", "--verify-golden", golden, "--max-records", "1700000000"], timeout=1100)
+    assert r.returncode == 0, r.stderr[-3000:]
+    assert d["verified_ticks"] == 2 and d["n_gpus"] == 8 and "1000000 entities / 100000 subs" in d["config"]["workload"]
+    assert max(d["verified"]["msgs_per_verified_tick"]) > 9_000_000_000 and "bench_digests_E.json" in d["verified_against"]
+
+
 def test_bench_config_e_on_its_eight_servers_verified():
     """BASELINE config 5's world through bench.py --config E (scaled down to fit eight ranks on one test GPU): 8x8 cells,
     4x2 server regions, emigrant all-to-all + halo all-to-all(v) between eight ranks, verified against the single world."""
@@ -633,3 +659,41 @@ def test_immigrants_without_a_slot_wait_in_limbo_and_come_back():
     assert len(present) == N and len(np.unique(present)) == N
     ovf, present = tick(5, x3)
     assert ovf == [0, 0] and len(present) == N
+
+
+def test_a_world_with_by_channel_arrays_refuses_the_slot_indexed_entry_points():
+    """chd_world_cfg.shard_channels sizes the update log and the payload tables by CHANNEL; chd_world_spawn,
+    chd_tick and chd_tick_device index them by entity SLOT and would write past them whenever shard_channels < max_entities.  Such a
+    world is region-sharded from its creation on: the three answer CHD_E_STATE, and chd_shard_import wants a fresh chd_shard_ingest
+    (it would otherwise log the last tick's updates a second time)."""
+    import ctypes as C
+    import json
+
+    import channeld_amd as amd
+    from channeld_amd import _lib, synth
+
+    cfg = synth.load_config("spatial_static_4x4.json")
+    ctl = amd.StaticGrid2DSpatialController()
+    assert ctl.LoadConfig(json.dumps(cfg).encode(), strict=False) is None
+    w = amd.SpatialWorld(ctl, 512, 64, max_records=1_000_000, history_depth=64, shard_channels=128)
+    lib, ctx = ctl._lib, ctl.ctx
+    u32p, f64p = C.POINTER(C.c_uint32), C.POINTER(C.c_double)
+    chan = np.arange(0x80000, 0x80000 + 8, dtype=np.uint32)
+    x = np.zeros(8); z = np.zeros(8)
+    rc = lib.chd_world_spawn(ctx, 8, None, chan.ctypes.data_as(u32p), x.ctypes.data_as(f64p), z.ctypes.data_as(f64p), None, None)
+    assert rc == _lib.E_STATE, rc
+    tin = _lib.TickIn()
+    tin.now_ns = 1_000_000
+    assert lib.chd_tick_device(ctx, C.byref(tin)) == _lib.E_STATE
+    tout = _lib.TickOut()
+    assert lib.chd_tick(ctx, C.byref(tin), C.byref(tout)) == _lib.E_STATE
+    # no ingest yet: import refuses
+    assert lib.chd_shard_import(ctx, None, 1, 256, None) == _lib.E_STATE
+    # a channel id outside the log is reported by the call itself, whatever the tick's overflow mask holds
+    bad = np.array([0x80000 + 128], dtype=np.uint32)
+    rc = lib.chd_shard_log_spawn(ctx, 1, bad.ctypes.data_as(u32p), x.ctypes.data_as(f64p), z.ctypes.data_as(f64p))
+    assert rc == _lib.E_CAPACITY, rc
+    rc = lib.chd_shard_log_spawn(ctx, 8, chan.ctypes.data_as(u32p), x.ctypes.data_as(f64p), z.ctypes.data_as(f64p))
+    assert rc == 0, rc
+    del w
+    ctl.close()
