@@ -88,6 +88,17 @@ __device__ __forceinline__ int64_t div_interval(int64_t d, uint32_t iv) {
     return (int64_t)(m32 / iv);
 }
 
+// floor(d / (iv ms)) EXACTLY, for d >= 0 ns: floor(floor(d / 10^6) / iv) is the same number, the inner division is by a constant
+// (multiply-high) and the outer one 32-bit unless d is beyond 2^32 ms (49 days: a rare per-lane branch keeps the 64-bit form).  A 64-bit
+// signed division is ~100 vector instructions on this hardware, and the plan kernels did three of them per subscription.
+__device__ __forceinline__ int64_t div_windows(int64_t d, uint32_t iv) {
+    const uint64_t ms = (uint64_t)d / 1000000u;
+    if (ms <= 0xFFFFFFFFull) return (int64_t)((uint32_t)ms / iv);
+    return (int64_t)(ms / iv);
+}
+// ... given the interval in nanoseconds (I = iv x 10^6 > 0)
+__device__ __forceinline__ int64_t div_windows_ns(int64_t d, int64_t I) { return div_windows(d, (uint32_t)((uint64_t)I / 1000000u)); }
+
 // The window [max(L,0), L + I] holds no buffered stamp: how many windows to move `last` on in one go.  Empty
 // windows emit nothing, so this is the walk of tickData with its empty iterations folded: straight to the window
 // that holds the oldest stamp newer than L + I, or past every due window when there is none.  (A connection
@@ -142,7 +153,7 @@ __device__ __forceinline__ bool sub_is_deep_pre(const WorldDev &w, const TickRin
 // elements — an arrival stamp that sits exactly on a window edge lies in two windows (both ends are inclusive, data.go:236-241),
 // so deep_walk can write two records per element
 __device__ __forceinline__ uint64_t deep_upper_bound(const WorldDev &w, int64_t now, int64_t L, int64_t I, uint64_t size) {
-    int64_t nwin = (now - L) / I;
+    int64_t nwin = div_windows_ns(now - L, I);
     if (nwin > 2 * (int64_t)w.deep_depth) nwin = 2 * (int64_t)w.deep_depth;
     return (uint64_t)nwin * (size + 1);
 }
@@ -180,7 +191,7 @@ __global__ void __launch_bounds__(64 * FO_WAVES) k_fanout_plan(DevGrid g, WorldD
                     } else if (!(fl & PF_HAD_FIRST)) {
                         ub = size;  // one full-state window, then last = now
                     } else {
-                        int64_t nwin = (now - L) / I;
+                        int64_t nwin = div_windows_ns(now - L, I);
                         int64_t lim = 2 * (int64_t)ring.n;  // a stamp lies in at most two windows
                         if (nwin > lim) nwin = lim;
                         ub = (uint64_t)nwin * size;
@@ -958,7 +969,7 @@ __device__ __forceinline__ void plan_windows_off(const WorldDev &w, const TickRi
     // exactly at t - 1 whenever the cell had no update at t; found by the sharded worlds' cell-update test, wrong on one GPU as well)
     uint32_t coff[CHD_OFF_SLOTS] = {q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w};
     off_shift(coff, cell_age < CHD_OFF_SLOTS ? cell_age : CHD_OFF_SLOTS);
-    const int64_t nwin = (now - L) / I;
+    const int64_t nwin = div_windows_ns(now - L, I);
     if (nwin > 64) { o.deep = true; return; }  // (a long catch-up: the element walk handles any number of windows)
     // The ring slots ANY lane of the wave can reach: the stamps do not increase with the slot index and no window starts before the
     // lane's max(L, 0), so slots older than the wave's oldest start are skipped by a uniform branch — subscriptions served every
@@ -970,33 +981,67 @@ __device__ __forceinline__ void plan_windows_off(const WorldDev &w, const TickRi
         for (int j = 0; j < (int)CHD_OFF_SLOTS; j++)
             if ((uint32_t)j < ring.n && __ballot(ring.t[j] >= lo0) != 0) jn = (uint32_t)j + 1u;
     }
+    // THE COMMON CASE IN 32 BITS.  Everything above is wave-uniform or per lane in nanoseconds as int64; when no lane of the wave reaches
+    // further back than 2^31 ns (2.1 s — every subscription that is served regularly), the same comparisons are made on 32-bit
+    // distances from `now`: dj = now - t[j] and dp = now - t[j + 1] per slot (scalars, saturated), dlo = now - lo and dhi = now - hi
+    // per lane and window.  tj < lo <=> dj > dlo; tp >= hi <=> dp <= dhi; the offsets inside the window are [t[j] - hi, t[j] - lo] =
+    // [dhi - dj (or 0), dlo - dj].  Half the vector instructions of the 64-bit form, which was what this kernel's time consisted of
+    // (40 us with the classification, 15 without).
+    const bool fast = __ballot((uint64_t)(now - (L > 0 ? L : 0)) >= (1ull << 31)) == 0;
+    uint32_t dj[CHD_OFF_SLOTS], dp[CHD_OFF_SLOTS];
+#pragma unroll
+    for (int j = 0; j < (int)CHD_OFF_SLOTS; j++) {
+        const uint64_t a = (uint32_t)j < ring.n ? (uint64_t)(now - ring.t[j]) : ~0ull;
+        const uint64_t b = (uint32_t)(j + 1) < ring.n ? (uint64_t)(now - ring.t[(j + 1) & (CHD_HIST_BITS - 1)]) : ~0ull;  // (last slot: tp = -1, never >= hi)
+        dj[j] = a > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)a;
+        dp[j] = b > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)b;
+    }
     int64_t Lw = L;
     for (int64_t k = 0; k < nwin; k++) {
         const int64_t hi = Lw + I, lo = Lw > 0 ? Lw : 0;
         uint32_t fm = 0, om = 0, sa = 0, sb = 0, alo = 1, ahi = 0, blo = 1, bhi = 0, ncut = 0;
         bool undecided = false;
+        // one ring slot against the window, given the offsets [A, B] of the slot's updates that lie inside it (`act`: the slot and the
+        // window overlap at all).  BRANCH-FREE on purpose (0 / 1 values combined with & and |, selects): per-lane tests compile to
+        // exec-masked branches, a dozen per slot — what this kernel's time consisted of, not the arithmetic (40 us with the
+        // classification, 15 without it; halving the arithmetic's width changed nothing).
+        auto slot = [&](const int j, const bool act, const uint32_t A, const uint32_t B) {
+            const bool has = act & (rmin[j] <= rmax[j]);  // (the cell holds updates of this slot)
+            const bool whole = has & (A <= rmin[j]) & (rmax[j] <= B);
+            const bool cut = has & !whole & !((rmax[j] < A) | (rmin[j] > B));
+            fm |= whole ? 1u << j : 0u;
+            const bool c0 = cut & (ncut == 0u), c1 = cut & (ncut == 1u);
+            undecided |= cut & (ncut >= 2u);
+            sa = c0 ? (uint32_t)j : sa; alo = c0 ? A : alo; ahi = c0 ? B : ahi;
+            sb = c1 ? (uint32_t)j : sb; blo = c1 ? A : blo; bhi = c1 ? B : bhi;
+            ncut += cut ? 1u : 0u;
+            om |= (act & (A <= coff[j]) & (coff[j] <= B)) ? 1u << j : 0u;
+        };
+        if (fast) {
+            const uint32_t dlo = (uint32_t)(now - lo), dhi = (uint32_t)(now - hi);  // (hi <= now: the window is due)
 #pragma unroll
-        for (int j = 0; j < (int)CHD_OFF_SLOTS; j++) {
-            if ((uint32_t)j >= jn) break;  // (uniform)
-            const int64_t tj = ring.t[j];
-            if (tj < lo) continue;  // the whole slot is older than the window
-            const bool last = (uint32_t)(j + 1) >= ring.n;
-            const int64_t tp = last ? -1 : ring.t[j + 1];  // arrivals of the slot are > tp (the world's first tick: >= 0)
-            if (tp >= hi) continue;  // the whole slot is newer than the window
-            if (last && ring.n == CHD_HIST_BITS) { undecided = true; continue; }  // (the evicted stamp below it is unknown)
-            const int64_t A64 = tj - hi > 0 ? tj - hi : 0, B64 = tj - lo;
-            if (A64 > 0xFFFFFFFEll) continue;
-            const uint32_t A = (uint32_t)A64, B = B64 > 0xFFFFFFFEll ? 0xFFFFFFFEu : (uint32_t)B64;  // (offsets are at most 0xFFFFFFFE: WorldDev::off_on)
-            if (rmin[j] <= rmax[j]) {  // (the cell holds updates of this slot)
-                if (A <= rmin[j] && rmax[j] <= B) fm |= 1u << j;
-                else if (!(rmax[j] < A || rmin[j] > B)) {
-                    if (ncut == 0) { sa = (uint32_t)j; alo = A; ahi = B; }
-                    else if (ncut == 1) { sb = (uint32_t)j; blo = A; bhi = B; }
-                    else undecided = true;
-                    ncut++;
-                }
+            for (int j = 0; j < (int)CHD_OFF_SLOTS; j++) {
+                if ((uint32_t)j >= jn) break;  // (uniform)
+                // (older than the window: dj > dlo; newer: dp <= dhi; the ring's last slot of a full ring: the evicted stamp below it is unknown)
+                const bool overlap = (dj[j] <= dlo) & (dp[j] > dhi);
+                const bool blind = (uint32_t)(j + 1) >= ring.n && ring.n == CHD_HIST_BITS;  // (uniform)
+                undecided |= overlap & blind;
+                slot(j, overlap & !blind, dhi > dj[j] ? dhi - dj[j] : 0u, dlo - dj[j]);
             }
-            if (A <= coff[j] && coff[j] <= B) om |= 1u << j;
+        } else {
+#pragma unroll
+            for (int j = 0; j < (int)CHD_OFF_SLOTS; j++) {
+                if ((uint32_t)j >= jn) break;  // (uniform)
+                const int64_t tj = ring.t[j];
+                const bool last = (uint32_t)(j + 1) >= ring.n;
+                const int64_t tp = last ? -1 : ring.t[j + 1];  // arrivals of the slot are > tp (the world's first tick: >= 0)
+                const bool overlap = (tj >= lo) & (tp < hi);   // (else the whole slot is older / newer than the window)
+                const bool blind = last && ring.n == CHD_HIST_BITS;
+                undecided |= overlap & blind;
+                const int64_t A64 = tj - hi > 0 ? tj - hi : 0, B64 = tj - lo;
+                // (offsets are at most 0xFFFFFFFE: WorldDev::off_on)
+                slot(j, overlap & !blind & (A64 <= 0xFFFFFFFEll), (uint32_t)A64, B64 > 0xFFFFFFFEll ? 0xFFFFFFFEu : (uint32_t)B64);
+            }
         }
         for (uint32_t j = CHD_OFF_SLOTS; j < ring.n; j++) {  // slots without offsets: by their own interval
             const int64_t tj = ring.t[j];
@@ -1101,7 +1146,7 @@ __global__ void __launch_bounds__(64 * FO_WAVES) k_fanout_plan_seg(DevGrid g, Wo
                     Lw = now;
                     ub = (uint64_t)size + 1;  // (the worst case of a deferred first fan-out, as k_fanout_plan)
                 } else {
-                    int64_t nwin = (now - L) / I;
+                    int64_t nwin = div_windows(now - L, iv);
                     const int64_t lim = 2 * (int64_t)ring.n;  // a stamp lies in at most two windows
                     if (nwin > lim) nwin = lim;
                     ub = (uint64_t)nwin * ((uint64_t)size + 1);
@@ -2998,7 +3043,7 @@ __device__ __forceinline__ void fanout_deep_conn(const DevGrid &g, const WorldDe
         }
         const int64_t L = w.pair_last[pbase + p];
         const int64_t I = (int64_t)w.pair_iv[pbase + p] * 1000000;
-        const int64_t nwin = (now - L) / I;  // >= 1: the plan found it due
+        const int64_t nwin = div_windows_ns(now - L, I);  // >= 1: the plan found it due
         const uint32_t c = w.pair_cell[pbase + p];
         const uint32_t start = w.cell_start[c], end = w.cell_end[c];
         const bool skip_self = (fl & PF_SKIP_SELF) != 0;

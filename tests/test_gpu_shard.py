@@ -590,7 +590,7 @@ def test_bench_config_e_at_its_stated_size_against_the_committed_oracle_results(
     (E with exact update buffers stays at half size — profiles/r06j_*: eight ranks' 12 GiB update logs + worst-case filtered segments
     exceed ONE GPU's 288 GB; eight GPUs hold it.)"""
     golden = os.path.join(ROOT, "tests", "golden", "bench_digests_E.json")
-    r, d = shared_gpu_bench(8, ["--config", "E", "--steps", "1", "--warmup", "2", "--verify", "2", "--verify-golden", golden, "--max-records", "1700000000"], timeout=1100)
+    r, d = shared_gpu_bench(8, ["--config", "E", "--steps", "1", "--warmup", "2", "--verify", "2", "--verify-golden", golden, "--max-records", "2600000000"], timeout=1100)
     assert r.returncode == 0, r.stderr[-3000:]
     assert d["verified_ticks"] == 2 and d["n_gpus"] == 8 and "1000000 entities / 100000 subs" in d["config"]["workload"]
     assert max(d["verified"]["msgs_per_verified_tick"]) > 9_000_000_000 and "bench_digests_E.json" in d["verified_against"]
