@@ -123,6 +123,10 @@ def parse():
     ap.add_argument("--verify-golden", default=None, metavar="FILE",
                     help="with --verify K: compare with the single world's COMMITTED oracle results (tests/golden/bench_digests_E.json) instead of "
                          "advancing the oracle on rank 0's host cores")
+    ap.add_argument("--shard-shape", choices=["D", "E"], default=None,
+                    help="DIAGNOSTIC, one GPU: ONE rank's tick of BASELINE config D / E — every rank's context in this one process, the exchanges as "
+                         "device copies, rank 0's stages timed alone (HIP events) — and the upload of a tick's whole-world inputs: how much of a rank's "
+                         "tick does not divide by the number of ranks (channeld_amd.dist.run_shard_shape)")
     ap.add_argument("--max-records", type=int, default=0, help="fan-out record capacity per rank (0 = half of the free HBM; ranks sharing a GPU need a number)")
     ap.add_argument("--latency-steps", type=int, default=200, help="extra synchronous ticks for p50/p99 (SURVEY 8d: >= 200), independent of --steps")
     ap.add_argument("--e2e-ticks", type=int, default=5,
@@ -185,6 +189,8 @@ def parse():
     args.prof_every = prof_every_for(args.steps, args.prof_every)
     if args.only_timed:
         args.no_cpu, args.latency_steps, args.e2e_ticks = True, 0, 0
+    if args.shard_shape:
+        return args  # (the configuration's own sizes and AOI scale unless given: channeld_amd.dist.run_shard_shape)
     if args.gpus <= 1 and not os.environ.get("CHD_BENCH_FORCE_DIST"):
         if args.config not in (None, "B"):
             ap.error("--config D / E / B-weak are multi-GPU workloads (--gpus N)")
@@ -442,6 +448,11 @@ def e2e_host_ticks(world, sw_frames, n):
 
 def main():
     args = parse()
+    if args.shard_shape:
+        from channeld_amd import dist as cdist
+
+        print(json.dumps(cdist.run_shard_shape(args)))
+        return
     world_size = int(os.environ.get("WORLD_SIZE", "0") or 0)
     if args.gpus > 1 and world_size == 0:
         self_launch(args)  # does not return

@@ -849,3 +849,114 @@ def run_bench(args, rank: int, world: int, local_rank: int, verifier=None) -> di
                      "frac": achieved / 8000.0, "traffic": None, "traffic_quoted": False, "bytes_per_msg": 12, "rank": 0,
                      "msgs_per_launch": float(emit_msgs.mean()), "avg_launch_us": float(emit_us.mean())},
     }
+
+
+# ---------------------------------------------------------------------------
+# bench.py --shard-shape D|E: ONE rank's tick of a multi-GPU configuration, measured on one GPU
+# ---------------------------------------------------------------------------
+
+def run_shard_shape(args) -> dict:
+    """What does ONE rank of BASELINE config D / E do per tick, and how much of it is the part that does NOT divide by the number of
+    ranks (every rank is fed the whole world's update stream by channel id; with exact update buffers every rank logs every channel)?
+    No 8-GPU node exists here, and ranks SHARING a GPU as processes are time-sliced by the driver (a stage of rank 0 "alone" measured
+    10 ms that way).  So: ONE process holds every rank's context on the one GPU, runs the four stages rank by rank, moves the two
+    exchanges' segments with device copies — and times rank 0's stages with HIP events while nothing else runs.  Rank 0's stages are
+    then exactly what its own GPU would execute (same kernels, same tables incl. the neighbours' ghost entries); the exchanges
+    themselves (xGMI) are not measured.  h2d = one tick's whole-world inputs from page-locked host memory (a gateway uploads them
+    every tick; bench.py's timed regions keep them resident)."""
+    import torch
+
+    from . import synth
+
+    name = args.shard_shape
+    world = {"D": 4, "E": 8}[name]
+    a2 = type("A", (), {})()
+    a2.config, a2.entities, a2.subs, a2.aoi_scale, a2.tick_ms = name, args.entities, args.subs, args.aoi_scale, args.tick_ms
+    cfg, N, S, n_max, s_max, aoi_scale, label, _ = bench_world(a2, world)
+    dev = torch.device("cuda", 0)
+    jitter = bool(getattr(args, "arrival_jitter", False))
+    sw = synth.SynthWorld(synth.WorldSpec(cfg, N, S, BENCH_SEED, tick_ms=args.tick_ms, aoi_scale=aoi_scale))
+    cols = int(cfg["GridCols"])
+    gx = np.floor((sw.x - sw.offx) / sw.gw); gy = np.floor((sw.z - sw.offz) / sw.gh)
+    inside = (gx >= 0) & (gx < cols) & (gy >= 0) & (gy < int(cfg["GridRows"]))
+    owner = np.where(inside, server_of_cell(cfg, np.where(inside, gx + gy * cols, 0).astype(np.int64)), 0)
+    maxrec = int(getattr(args, "max_records", 0) or 0) or (2_600_000_000 if name == "E" else 800_000_000)
+    engs, subs_of = [], []
+    for r in range(world):
+        e = HipShardEngine(cfg, r, world, n_max, s_max, migrate_cap=max(4096, n_max // 8), device=0, max_records=maxrec, adaptive_migrate=False,
+                           flags=(64 if jitter else 0), history_depth=1024 if jitter else 0, shard_channels=N if jitter else 0)
+        if jitter:
+            e.log_spawn(sw.chan_id, sw.x, sw.z)
+            e.set_update_senders(torch.from_numpy(sw.sender.astype(np.uint32).view(np.int32)).to(dev))
+        mine = np.nonzero(owner == r)[0]
+        e.spawn(sw.chan_id[mine], sw.x[mine], sw.z[mine], sw.flags[mine], sw.sender[mine])
+        ms = np.nonzero(owner[:S] == r)[0]
+        e.add_subscribers(sw.sub_conn[ms])
+        engs.append(e); subs_of.append(ms)
+    W, K = max(int(args.warmup), 3), max(int(args.steps), 4)
+    aj = synth.ArrivalJitter(BENCH_SEED, N, 0) if jitter else None
+    ev = lambda: torch.cuda.Event(enable_timing=True)
+    acc = {k: [] for k in ("h2d", "ingest", "import", "interest", "fanout")}
+    px, pz = torch.empty(N, dtype=torch.float64).pin_memory(), torch.empty(N, dtype=torch.float64).pin_memory()
+    pa = torch.empty(N, dtype=torch.int64).pin_memory() if jitter else None
+    d_x, d_z = torch.empty(N, dtype=torch.float64, device=dev), torch.empty(N, dtype=torch.float64, device=dev)
+    d_a = torch.empty(N, dtype=torch.int64, device=dev) if jitter else None
+    msgs0 = []
+
+    def timed(key, fn, keep):
+        a, b = ev(), ev()
+        a.record(); out = fn(); b.record()
+        b.synchronize()
+        if keep:
+            acc[key].append(a.elapsed_time(b) * 1e3)
+        return out
+
+    for t in range(W + K):
+        keep = t >= W
+        sw.step()
+        now = sw.now_ns()
+        px.copy_(torch.from_numpy(sw.x)); pz.copy_(torch.from_numpy(sw.z))
+        if jitter:
+            now, arr = aj.next(now)
+            pa.copy_(torch.from_numpy(arr))
+        q = sw.queries()
+        timed("h2d", lambda: [d_x.copy_(px, non_blocking=True), d_z.copy_(pz, non_blocking=True)] + ([d_a.copy_(pa, non_blocking=True)] if jitter else []), keep)
+        dq = [torch.from_numpy(np.ascontiguousarray(q[subs_of[r]]).view(np.uint8).reshape(-1)).to(dev) for r in range(world)]
+        torch.cuda.synchronize()
+        send = []
+        for r, e in enumerate(engs):
+            if jitter:
+                e.set_update_arrivals(d_a)
+            send.append(timed("ingest", lambda: e.ingest(now, d_x, d_z, None), keep and r == 0) if r == 0 else e.ingest(now, d_x, d_z, None))
+        torch.cuda.synchronize()
+        halo_send = []
+        for r, e in enumerate(engs):
+            recv = torch.stack([send[src][r] for src in range(world)]).contiguous()
+            halo_send.append(timed("import", lambda: e.import_(recv), keep and r == 0) if r == 0 else e.import_(recv))
+        torch.cuda.synchronize()
+        for r, e in enumerate(engs):
+            _, recv_splits, peer_off = e.halo_splits()
+            parts = [halo_send[src].view(-1)[int(peer_off[src]): int(peer_off[src]) + int(recv_splits[src])] for src in range(world) if int(recv_splits[src])]
+            halo_recv = torch.cat(parts) if parts else halo_send[r].view(-1)[:0]
+            nq = len(subs_of[r])
+            if r == 0:
+                timed("interest", lambda: e.interest(dq[r], nq), keep)
+                timed("fanout", lambda: e.fanout(halo_recv), keep)
+            else:
+                e.interest(dq[r], nq); e.fanout(halo_recv)
+        torch.cuda.synchronize()
+        if keep:
+            msgs0.append(engs[0].sw.history(1)[0]["n_records"])
+    res = engs[0].fetch()
+    med = {k: float(np.median(v)) for k, v in acc.items()}
+    sharded = med["ingest"] + med["import"] + med["interest"] + med["fanout"]
+    own = int((owner == 0).sum())
+    return {"metric": f"one rank's tick of BASELINE config {name}, measured on one GPU (diagnostic: not the headline metric)",
+            "shard_shape": name, "n_gpus": 1, "ranks_emulated": world, "data": "synthetic", "steps": K, "warmup": W,
+            "config": {"workload": label, "arrival_stamps": "at enqueue time, exact update buffers by channel id on every rank" if jitter else "tick-aligned",
+                       "rank0": {"entities": own, "subs": int(len(subs_of[0])), "msgs_per_tick": float(np.mean(msgs0))}},
+            "how": "one process holds every rank's context on the one GPU and runs the four chd_shard_* stages rank by rank, the two exchanges as device "
+                   "copies; rank 0's stages timed with HIP events while nothing else runs (its tables hold its neighbours' ghost entries as on its own "
+                   "GPU); the exchanges themselves are not measured; h2d = one tick's whole-world by-channel inputs from page-locked memory",
+            "us": med, "h2d_bytes": int(N * (16 + (8 if jitter else 0))), "replicated_input_us": med["h2d"], "sharded_stages_us": sharded,
+            "rank0_tick_us_with_upload": sharded + med["h2d"], "overflow": int(res.overflow), "history_overflow": int(res.history_overflow)}
