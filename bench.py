@@ -433,6 +433,45 @@ def e2e_segment_ticks(world, sw_frames):
     return out
 
 
+def e2e_segment_ticks_pipelined(world, sw_frames, timed=False):
+    """(iv) of --e2e-ticks: the same ticks through chd_tick_segments_begin / chd_tick_segments_end, two ticks in flight: the host
+    writes tick t+1's inputs into page-locked memory and enqueues it, THEN waits for tick t's block (one event, one page-locked
+    block, no sizing round trip).  Per tick: (the loop's period, time inside end(), begin()'s enqueue time, begin(t) -> end(t) returned,
+    records, bytes, end()'s wait for the tick's last kernel, device_ms, end()'s copy of the block)."""
+    out = []
+    bufs = []
+    t_begin = {}
+    n = len(sw_frames)
+
+    # every tick's inputs in page-locked memory before the loop (as in e2e_segment_ticks, where they are written before the timed call:
+    # the shim's UpdateBatch collects a tick's updates there while the messages arrive)
+    for (_, x, z, q) in sw_frames:
+        px, pz, pq = world.host_array(len(x), np.float64), world.host_array(len(z), np.float64), world.host_array(len(q), q.dtype)
+        px[:], pz[:], pq[:] = x, z, q
+        bufs.append((px, pz, pq))
+
+    def begin(t):
+        now = sw_frames[t][0]
+        px, pz, pq = bufs[t]
+        a = time.perf_counter()
+        world.tick_segments_begin(now, upd_x=px, upd_z=pz, queries=pq)
+        b = time.perf_counter()
+        t_begin[t] = a
+        return b - a
+
+    begin(0)
+    last = time.perf_counter()
+    for t in range(n):
+        enq = begin(t + 1) if t + 1 < n else 0.0
+        a = time.perf_counter()
+        res, seg, info = world.tick_segments_end()
+        b = time.perf_counter()
+        assert res.overflow == 0 and seg["n_records"] == res.n_records
+        out.append((b - last, b - a, enq, b - t_begin[t], res.n_records, info["block_bytes"], info["wait_ms"], info["device_ms"], info["copy_ms"]))
+        last = b
+    return out
+
+
 def e2e_host_ticks(world, sw_frames, n):
     """(i) of --e2e-ticks: chd_tick with HOST buffers — upload of the positions and queries, the tick, the dense
     per-connection pack of the records and their download (8 B per message over PCIe)."""
@@ -734,6 +773,38 @@ def main():
                 "explicit_records_per_tick": med[4], "vs_dense_bytes": med[2] / (8.0 * med[1]) if med[1] else None}
         except Exception as ex:  # noqa: BLE001
             e2e["segments"] = {"error": f"{type(ex).__name__}: {ex}"}
+        try:
+            trace("e2e pipelined segment ticks")
+            frames = []
+            for _ in range(n_seg_ticks + 24):
+                sw.step()
+                frames.append((sw.now_ns(), sw.x.copy(), sw.z.copy(), sw.queries().copy()))
+            rp = e2e_segment_ticks_pipelined(world, frames[:n_seg_ticks])
+            if len(rp) > 20:
+                rp = rp[4:]
+            # the same loop once more with the HIP event pairs on (device time | copy time of each tick): a breakdown, not the latency line
+            world.set_profiling(8)
+            world.set_profiling_scope(True, every=1024)
+            rt = e2e_segment_ticks_pipelined(world, frames[n_seg_ticks:])[4:]
+            world.set_profiling(0)
+            pct = lambda col, q, rows=rp: float(np.percentile([1e3 * v[col] for v in rows], q))  # noqa: E731
+            medp = sorted(rp, key=lambda v: v[0])[len(rp) // 2]
+            e2e["segments_pipelined"] = {
+                "what": "chd_tick_segments_begin(t+1) enqueued (uploads on a side stream, no host wait), then chd_tick_segments_end(t): wait for tick t's last kernel, read the sizes from the "
+                        "page-locked header the device wrote, ONE copy of exactly the block's bytes (offsets, segments, columns, explicit records, handovers, lists, query status) while tick "
+                        "t+1 runs.  Inputs written into page-locked memory before begin.  period = wall time per loop iteration (what bounds the tick rate); latency = begin(t) called -> "
+                        "end(t) returned (two ticks deep, so about two periods)",
+                "ticks": len(rp), "period_p50_ms": pct(0, 50), "period_p99_ms": pct(0, 99), "period_max_ms": float(max(1e3 * v[0] for v in rp)),
+                "latency_p50_ms": pct(3, 50), "latency_p99_ms": pct(3, 99),
+                "sync_ms": float(np.median([v[6] for v in rp])), "sync_ms_is": "host blocked in _end until the tick's last kernel (0 = the device finished first: the loop is host-bound)",
+                "pcie_ms": float(np.median([v[8] for v in rp])), "pcie_ms_is": "host time of the one D2H copy of the block in _end (enqueue to completion); overlaps the next tick's kernels",
+                "enqueue_ms": pct(2, 50), "enqueue_p99_ms": pct(2, 99),
+                "kernels_ms": float(np.median([v[7] for v in rt])) if rt else None,
+                "kernels_ms_is": "HIP events on the ctx stream: the tick + the two segment passes + the scan + the staging kernel (a second, profiled pass of the same loop)",
+                "bytes_per_tick": int(medp[5]), "msgs_per_tick": int(medp[4]),
+                "value": medp[4] / medp[0], "unit": "msgs/s", "ms_all": [round(1e3 * v[0], 3) for v in rp][:16]}
+        except Exception as ex:  # noqa: BLE001
+            e2e["segments_pipelined"] = {"error": f"{type(ex).__name__}: {ex}"}
 
     # HBM bytes per launch of the dominant kernel from the PMC passes (FETCH_SIZE / WRITE_SIZE in separate
     # rocprofv3 runs, tools/pmc_summary.py): not measurable from inside this process, so QUOTED from the committed

@@ -52,7 +52,7 @@ SYMBOLS = (
     "chd_shard_comm_available", "chd_shard_comm_unique_id", "chd_shard_comm_init", "chd_shard_comm_destroy", "chd_shard_tick", "chd_shard_set_handover_lists", "chd_shard_set_update_senders", "chd_shard_set_update_arrivals", "chd_shard_log_spawn", "chd_shard_despawn", "chd_shard_migrate_extra_records", "chd_shard_ingest_pre", "chd_shard_ingest_post",
     "chd_shard_get_entities", "chd_shard_halo_layout", "chd_shard_interest",
     "chd_handover_recipients", "chd_adjacent_recipients", "chd_wire_set_payloads", "chd_wire_build", "chd_wire_build_info", "chd_wire_fetch",
-    "chd_tick_digest", "chd_tick_fetch_segments", "chd_tick_segments", "chd_host_alloc", "chd_host_free", "chd_subs_set_options", "chd_subs_get_options", "chd_world_set_entity_groups", "chd_world_set_handover_lists", "chd_wire_set_type_url", "chd_wire_set_merge_schema", "chd_handover_messages",
+    "chd_tick_digest", "chd_tick_fetch_segments", "chd_tick_segments", "chd_tick_segments_begin", "chd_tick_segments_end", "chd_host_alloc", "chd_host_free", "chd_subs_set_options", "chd_subs_get_options", "chd_world_set_entity_groups", "chd_world_set_handover_lists", "chd_wire_set_type_url", "chd_wire_set_merge_schema", "chd_handover_messages",
     "chd_handover_recipients_ex", "chd_handover_variants", "chd_world_set_server_connections",
 )
 
@@ -193,6 +193,22 @@ class SegmentsOut(C.Structure):
                 ("conn_rec_off", _u64p), ("n_records", C.c_uint64)]
 
 
+class SegmentsBlock(C.Structure):  # chd_segments_block: what chd_tick_segments_end hands out (pointers into a page-locked block)
+    _fields_ = [("conn_seg_off", _vp), ("conn_rec_off", _vp),
+                ("segments", _vp), ("n_segments", C.c_uint64),
+                ("columns", _vp), ("n_columns", C.c_uint64),
+                ("records", _vp), ("n_explicit", C.c_uint64),
+                ("n_records", C.c_uint64),
+                ("handovers", _vp), ("n_handovers", C.c_uint32), ("n_locked_aborts", C.c_uint32),
+                ("unsub_sub", _vp), ("unsub_channel", _vp), ("n_unsubs", C.c_uint32),
+                ("n_newsubs", C.c_uint32),
+                ("newsub_sub", _vp), ("newsub_channel", _vp), ("newsub_interval_ms", _vp),
+                ("query_status", _vp), ("n_queries", C.c_uint32),
+                ("overflow", C.c_uint32), ("history_overflow", C.c_uint32),
+                ("reserved", C.c_uint32), ("block", _vp), ("block_bytes", C.c_uint64),
+                ("wait_ms", C.c_float), ("copy_ms", C.c_float), ("device_ms", C.c_float), ("reserved2", C.c_uint32)]
+
+
 SEG_FIRST, SEG_NONE, SEG_EXPLICIT = 1 << 22, 1 << 23, 1 << 24
 
 _lib = None
@@ -279,6 +295,8 @@ def load():
     L.chd_tick_digest.argtypes = [C.c_void_p, P(RecordsDigest), _u64p]
     L.chd_tick_fetch_segments.argtypes = [C.c_void_p, P(SegmentsOut)]
     L.chd_tick_segments.argtypes = [C.c_void_p, P(TickIn), P(TickOut), P(SegmentsOut)]
+    L.chd_tick_segments_begin.argtypes = [C.c_void_p, P(TickIn)]
+    L.chd_tick_segments_end.argtypes = [C.c_void_p, P(SegmentsBlock)]
     L.chd_subs_set_options.argtypes = [C.c_void_p, C.c_int64, C.c_uint32, P(SubOptions), _u8p, _i32p]
     L.chd_subs_get_options.argtypes = [C.c_void_p, C.c_uint32, _u8p, _u8p, P(C.c_uint32)]
     L.chd_host_alloc.argtypes = [C.c_void_p, C.c_uint64, P(C.c_void_p)]

@@ -157,6 +157,22 @@ struct World {
     uint64_t *seg_exp = nullptr;       // [S + 1] explicit records per connection -> offsets
     chd_fanout_segment *seg_stage = nullptr; size_t seg_stage_cap = 0;
     chd_fanout_rec *seg_rec_stage = nullptr; size_t seg_rec_stage_cap = 0;
+    // chd_tick_segments_begin / _end: two ticks in flight; everything a tick hands out packed into one block per parity on the
+    // device (header | per-connection offsets | query status | columns | segments | explicit records | handovers | lists) and
+    // copied into its page-locked twin with ONE copy of exactly its bytes
+    struct SegPipeSlot {
+        unsigned char *d_blk = nullptr, *h = nullptr;
+        unsigned long long *h_dev = nullptr;  // the page-locked block's header as the device addresses it
+        hipEvent_t ev_up = nullptr, ev_begin = nullptr, ev_fill = nullptr;
+        uint64_t ncol = 0, tick_no = 0;
+        uint32_t nq = 0;
+        bool timed = false;
+    } segp[2];
+    DevBuf segp_scratch[2][13];  // the input uploads' device buffers, one bank per parity (swapped into chd_ctx::scratch for the call)
+    bool segp_ready = false;
+    uint32_t segp_head = 0, segp_tail = 0, segp_pending = 0;
+    hipStream_t segp_stream = nullptr;
+    size_t segp_o_cnt = 0, segp_o_exp = 0, segp_o_qst = 0, segp_o_var = 0, segp_cap = 0;
     // native collectives (chd_shard_comm_init): the two exchanges of a sharded tick on RCCL inside the library
     ncclComm_t comm = nullptr;
     struct HostPipe *pipe = nullptr;   // CHD_SHARD_TRANSPORT=hostpipe (a TEST transport, see HostPipe): then comm == nullptr
@@ -197,6 +213,7 @@ struct chd_ctx {
     TickRing ring{};
     // scratch for the stateless entry points and for chd_tick's staging
     DevBuf scratch[16];
+    hipStream_t up_stream = nullptr;    // chd_tick_segments_begin: host_tick_stage's uploads go to this stream
     bool force_device = false;          // CHD_NO_HOST_FAST_PATH=1: small stateless calls go to the device too (tests, measurements)
     bool gchain = false, gchain_prev = false;  // ... was a serial tick with gated overlap (CHD_WORLD_GATED_OVERLAP)
     bool chain = false, chain_prev = false;  // the previous call on this ctx was a pipelined tick (bind() shifts them)
@@ -262,7 +279,7 @@ int bind(chd_ctx *ctx) {
 
 int up(chd_ctx *ctx, void *dst, const void *src, size_t bytes) {
     if (!bytes) return CHD_OK;
-    HIPCHK(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, ctx->up_stream ? ctx->up_stream : ctx->stream));
     return CHD_OK;
 }
 int down(chd_ctx *ctx, void *dst, const void *src, size_t bytes) {
@@ -414,10 +431,22 @@ __global__ void __launch_bounds__(256) k_rec_cnt(WorldDev w) {
 // One wave per connection.  Simple subscriptions = the descriptors of k_fanout_plan_seg (have_desc); explicit = every other
 // subscription that emitted records this tick.  LDS: one bit per subscription index (capq <= 65534).
 #define SEG_BITMAP_WORDS 2048
+// The header of a chd_tick_segments_begin block (u64 words): counts, the tick's row of the history ring, and the byte offsets of
+// the block's sections — written by k_seg_scan into the device block and into the page-locked copy the host reads first
+enum { SEGH_NSEG = 0, SEGH_NEXP = 1, SEGH_ROW = 2 /* ..9 */, SEGH_GATE_FAIL = 10, SEGH_REC_UB = 11, SEGH_TOTAL = 12, SEGH_OFF_COL = 13,
+       SEGH_OFF_SEG = 14, SEGH_OFF_REC = 15, SEGH_OFF_HO = 16, SEGH_OFF_UN = 17 /* sub, channel */, SEGH_OFF_NEW = 19 /* sub, channel, interval */,
+       SEGH_NCOL = 22, SEGH_NQ = 23, SEGH_CAP = 24, SEGH_NHO = 25, SEGH_NUN = 26, SEGH_NNEW = 27, SEGH_FITS = 28, SEGH_TICK = 29, SEGH_WORDS = 32 };
+
 __global__ void __launch_bounds__(64) k_segments(DevGrid g, WorldDev w, int have_desc, int fill, uint32_t *nseg, unsigned long long *nexp,
-                                                 chd_fanout_segment *seg_out, chd_fanout_rec *rec_out) {
+                                                 chd_fanout_segment *seg_out, chd_fanout_rec *rec_out, unsigned char *blk = nullptr) {
     __shared__ uint32_t simple_bits[SEG_BITMAP_WORDS];
     const uint32_t s = blockIdx.x, lane = threadIdx.x;
+    if (blk) {  // chd_tick_segments_begin: the outputs' places in the tick's block are in its header (k_seg_scan)
+        const unsigned long long *hdr = (const unsigned long long *)blk;
+        if (!hdr[SEGH_FITS]) return;
+        seg_out = (chd_fanout_segment *)(blk + hdr[SEGH_OFF_SEG]);
+        rec_out = (chd_fanout_rec *)(blk + hdr[SEGH_OFF_REC]);
+    }
     const uint32_t cnt = w.sub_alive[s] ? w.pair_cnt[s] : 0u;
     const size_t pbase = (size_t)s * w.capq;
     const bool served = w.rec_ub[s + 1] <= w.recs_cap;  // (else the connection was skipped this tick and flagged)
@@ -691,6 +720,20 @@ void chd_destroy(chd_ctx *ctx) {
     if (ctx->w.recs_dense) (void)hipFree(ctx->w.recs_dense);
     if (ctx->w.seg_stage) (void)hipFree(ctx->w.seg_stage);
     if (ctx->w.seg_rec_stage) (void)hipFree(ctx->w.seg_rec_stage);
+    if (ctx->w.segp_stream) {
+        (void)hipStreamSynchronize(ctx->w.segp_stream);
+        (void)hipStreamDestroy(ctx->w.segp_stream);
+    }
+    for (auto &sl : ctx->w.segp) {
+        if (sl.h) (void)hipHostFree(sl.h);
+        if (sl.d_blk) (void)hipFree(sl.d_blk);
+        if (sl.ev_up) (void)hipEventDestroy(sl.ev_up);
+        if (sl.ev_begin) (void)hipEventDestroy(sl.ev_begin);
+        if (sl.ev_fill) (void)hipEventDestroy(sl.ev_fill);
+    }
+    for (auto &bank : ctx->w.segp_scratch)
+        for (auto &b : bank)
+            if (b.p) (void)hipFree(b.p);
     if (ctx->w.list_dense) (void)hipFree(ctx->w.list_dense);
     if (ctx->w.x.bytes) (void)hipFree(ctx->w.x.bytes);
     if (ctx->w.x.cdesc) (void)hipFree(ctx->w.x.cdesc);
@@ -1899,6 +1942,140 @@ __global__ void __launch_bounds__(256) k_list_pack(const uint32_t *bank_n, uint3
     }
 }
 
+#define SEG_SCAN_ITEMS 4
+__device__ __forceinline__ unsigned long long seg_wave_incl_scan(unsigned long long v) {
+    const int lane = threadIdx.x & 63;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const unsigned long long o = __shfl_up(v, d);
+        if (lane >= d) v += o;
+    }
+    return v;
+}
+
+// chd_tick_segments_begin, between k_segments' two passes: the per-connection segment and explicit-record counts (inside the block,
+// at o_cnt / o_exp) become offsets, and — every size of the tick being known on the device now — the block's header: counts, the
+// tick's row of the history ring, where each section starts.  One workgroup; the header goes to the device block (what the next
+// kernels read) and to the page-locked copy (what the host reads before it sizes the one copy of the block).
+__global__ void __launch_bounds__(1024) k_seg_scan(WorldDev w, uint32_t ring_slot, unsigned char *blk, unsigned long long *hdr_host, uint32_t o_cnt,
+                                                   uint32_t o_exp, unsigned long long o_var, unsigned long long ncol, uint32_t nq, unsigned long long cap,
+                                                   const unsigned long long *gate_fail, unsigned long long tick_no) {
+    __shared__ unsigned long long wtot[2][16];
+    __shared__ unsigned long long carry_s[2];
+    uint32_t *cnt = (uint32_t *)(blk + o_cnt);
+    unsigned long long *exp = (unsigned long long *)(blk + o_exp);
+    const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6, n = w.S;
+    if (threadIdx.x < 2) carry_s[threadIdx.x] = 0;
+    __syncthreads();
+    for (uint32_t base = 0; base < n; base += 1024 * SEG_SCAN_ITEMS) {
+        const uint32_t i0 = base + threadIdx.x * SEG_SCAN_ITEMS;
+        uint32_t a[SEG_SCAN_ITEMS];
+        unsigned long long b[SEG_SCAN_ITEMS], sa = 0, sb = 0;
+#pragma unroll
+        for (int k = 0; k < SEG_SCAN_ITEMS; k++) {
+            a[k] = (i0 + k < n) ? cnt[i0 + k] : 0u;
+            b[k] = (i0 + k < n) ? exp[i0 + k] : 0ull;
+            sa += a[k]; sb += b[k];
+        }
+        const unsigned long long ia = seg_wave_incl_scan(sa), ib = seg_wave_incl_scan(sb);
+        if (lane == 63) { wtot[0][wave] = ia; wtot[1][wave] = ib; }
+        __syncthreads();
+        unsigned long long ra = carry_s[0] + ia - sa, rb = carry_s[1] + ib - sb;
+        for (uint32_t k = 0; k < wave; k++) { ra += wtot[0][k]; rb += wtot[1][k]; }
+#pragma unroll
+        for (int k = 0; k < SEG_SCAN_ITEMS; k++) {
+            if (i0 + k < n) { cnt[i0 + k] = (uint32_t)ra; exp[i0 + k] = rb; }
+            ra += a[k]; rb += b[k];
+        }
+        __syncthreads();
+        if (threadIdx.x == 1023) { carry_s[0] = ra; carry_s[1] = rb; }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) { cnt[n] = (uint32_t)carry_s[0]; exp[n] = carry_s[1]; }
+    if (threadIdx.x < 64) {
+        const uint32_t t = threadIdx.x;
+        unsigned long long v = 0;
+        const uint64_t *row = w.tick_ring + (size_t)ring_slot * 8;
+        const unsigned long long nseg = carry_s[0], nexp = carry_s[1];
+        const unsigned long long nho = min((unsigned long long)(uint32_t)row[2], (unsigned long long)w.handovers_cap),
+                                 nun = min((unsigned long long)(uint32_t)row[4], (unsigned long long)w.unsub_cap),
+                                 nnew = min((unsigned long long)(uint32_t)row[5], (unsigned long long)w.newsub_cap);
+        auto al = [](unsigned long long x) { return (x + 255ull) & ~255ull; };
+        const unsigned long long off_col = o_var, off_seg = off_col + al(4 * ncol), off_rec = off_seg + al(sizeof(chd_fanout_segment) * nseg),
+                                 off_ho = off_rec + al(sizeof(chd_fanout_rec) * nexp), off_un = off_ho + al(sizeof(chd_handover_rec) * nho),
+                                 off_new = off_un + 2 * al(4 * nun), total = off_new + 3 * al(4 * nnew);
+        if (t == SEGH_NSEG) v = nseg;
+        else if (t == SEGH_NEXP) v = nexp;
+        else if (t >= SEGH_ROW && t < SEGH_ROW + 8) v = row[t - SEGH_ROW];
+        else if (t == SEGH_GATE_FAIL) v = gate_fail ? *gate_fail : 0ull;
+        else if (t == SEGH_REC_UB) v = w.rec_ub[w.S];
+        else if (t == SEGH_TOTAL) v = total;
+        else if (t == SEGH_OFF_COL) v = off_col;
+        else if (t == SEGH_OFF_SEG) v = off_seg;
+        else if (t == SEGH_OFF_REC) v = off_rec;
+        else if (t == SEGH_OFF_HO) v = off_ho;
+        else if (t == SEGH_OFF_UN) v = off_un;
+        else if (t == SEGH_OFF_UN + 1) v = off_un + al(4 * nun);
+        else if (t >= SEGH_OFF_NEW && t < SEGH_OFF_NEW + 3) v = off_new + (t - SEGH_OFF_NEW) * al(4 * nnew);
+        else if (t == SEGH_NCOL) v = ncol;
+        else if (t == SEGH_NQ) v = nq;
+        else if (t == SEGH_CAP) v = cap;
+        else if (t == SEGH_NHO) v = nho;
+        else if (t == SEGH_NUN) v = nun;
+        else if (t == SEGH_NNEW) v = nnew;
+        else if (t == SEGH_FITS) v = total <= cap ? 1ull : 0ull;
+        else if (t == SEGH_TICK) v = tick_no;
+        if (t < SEGH_WORDS) {
+            ((unsigned long long *)blk)[t] = v;
+            hdr_host[t] = v;
+        }
+    }
+}
+
+// chd_tick_segments_begin, last kernel: what the NEXT tick's kernels overwrite — the entity-channel columns, the query status, the
+// handover records, the two banked lists (packed as k_list_pack does) — copied into the tick's block at the header's offsets
+__global__ void __launch_bounds__(256) k_seg_stage(WorldDev w, unsigned char *blk, uint32_t o_qst) {
+    const unsigned long long *hdr = (const unsigned long long *)blk;
+    if (!hdr[SEGH_FITS]) return;
+    const size_t tid = (size_t)blockIdx.x * 256 + threadIdx.x, nth = (size_t)gridDim.x * 256;
+    {
+        const size_t n = hdr[SEGH_NCOL], n4 = n >> 2;  // (both sides 16-byte aligned)
+        const uint4 *src = (const uint4 *)w.ce_chan_view;
+        uint4 *dst = (uint4 *)(blk + hdr[SEGH_OFF_COL]);
+        for (size_t i = tid; i < n4; i += nth) dst[i] = src[i];
+        for (size_t i = (n4 << 2) + tid; i < n; i += nth) ((uint32_t *)dst)[i] = w.ce_chan_view[i];
+    }
+    {
+        const size_t n = hdr[SEGH_NQ];
+        int32_t *dst = (int32_t *)(blk + o_qst);
+        for (size_t i = tid; i < n; i += nth) dst[i] = w.q_status[i];
+    }
+    {
+        const size_t n = hdr[SEGH_NHO] * (sizeof(chd_handover_rec) / 8);
+        const uint2 *src = (const uint2 *)w.handovers;
+        uint2 *dst = (uint2 *)(blk + hdr[SEGH_OFF_HO]);
+        for (size_t i = tid; i < n; i += nth) dst[i] = src[i];
+    }
+    for (uint32_t job = blockIdx.x; job < 2u * CHD_LIST_BANKS; job += gridDim.x) {
+        const uint32_t row = job / CHD_LIST_BANKS, bank = job % CHD_LIST_BANKS;
+        const uint32_t *bank_n = w.list_bank_n + row * CHD_LIST_BANKS;
+        size_t off = 0;
+        for (uint32_t i = 0; i < bank; i++) off += bank_n[i];
+        const uint32_t n = bank_n[bank];
+        const size_t src = (size_t)bank * w.list_bank_cap;
+        const size_t lim = row ? hdr[SEGH_NNEW] : hdr[SEGH_NUN];  // (the counts the header was sized with: the banks hold no more)
+        const uint32_t *a = row ? w.newsub_sub : w.unsub_sub, *b = row ? w.newsub_cell : w.unsub_cell;
+        uint32_t *da = (uint32_t *)(blk + hdr[row ? SEGH_OFF_NEW : SEGH_OFF_UN]), *db = (uint32_t *)(blk + hdr[(row ? SEGH_OFF_NEW : SEGH_OFF_UN) + 1]);
+        uint32_t *dc = row ? (uint32_t *)(blk + hdr[SEGH_OFF_NEW + 2]) : nullptr;
+        for (uint32_t i = threadIdx.x; i < n; i += 256) {
+            if (off + i >= lim) break;
+            da[off + i] = a[src + i];
+            db[off + i] = b[src + i];
+            if (dc) dc[off + i] = w.newsub_iv[src + i];
+        }
+    }
+}
+
 // Stage times of one profiled tick.  With the interest stage on the second stream its time is its own
 // begin/end pair; the tick total is always first-to-last event on the main stream.
 static void stage_times(chd_ctx *ctx, uint32_t tick, chd_tick_stats &s) {
@@ -2266,7 +2443,7 @@ static int host_tick_stage(chd_ctx *ctx, const chd_tick_in *in, chd_tick_in &din
     TRY(stage(12, in->cell_upd_arrival_ns, 8 * nc, (const void **)&din.cell_upd_arrival_ns));
     if (ns && !in->spot_dist) {
         TRY(ensure(ctx, 10, 4 * ns));
-        HIPCHK(hipMemsetAsync(ctx->scratch[10].p, 0, 4 * ns, ctx->stream));
+        HIPCHK(hipMemsetAsync(ctx->scratch[10].p, 0, 4 * ns, ctx->up_stream ? ctx->up_stream : ctx->stream));
         din.spot_dist = (const uint32_t *)ctx->scratch[10].p;
     }
     // The staging uploads above were enqueued on `stream`; a CHAINED pipelined tick starts its stages on the second stream
@@ -2380,6 +2557,143 @@ int chd_tick_segments(chd_ctx *ctx, const chd_tick_in *in, chd_tick_out *out, ch
 // ---------------------------------------------------------------------------
 // region-sharded worlds
 // ---------------------------------------------------------------------------
+
+// ---- chd_tick_segments_begin / _end: the tick and its segment output as an asynchronous pair, two ticks in flight ----
+// Stream plan (measured, profiles/r07f_*: a barrier packet that WAITS in a second hardware queue while kernels run in the first one
+// delays those kernels by ~40 us every ~55 us, so the copies are not chained behind the tick with hipStreamWaitEvent):
+//   _begin(t):  side stream: the input uploads into the scratch bank of t's parity (tick t-1's kernels are still running)
+//               ctx stream:  [wait uploads] the tick | k_segments (sizes) | k_seg_scan (offsets + header, also into the page-locked
+//                            block) | k_segments (fill) | k_seg_stage (columns, query status, handovers, lists) | event
+//   _end(t):    host waits for that event (tick t+1's kernels are queued behind it and start at once), reads the sizes from the
+//               page-locked header, enqueues ONE copy of exactly the block's bytes on the side stream, waits for it.
+static int segp_setup(chd_ctx *ctx) {
+    World &W = ctx->w;
+    WorldDev &d = W.d;
+    if (W.segp_ready) return CHD_OK;
+    const size_t S = d.S;
+    auto al = [](size_t v) { return (v + 255) & ~(size_t)255; };
+    W.segp_o_cnt = al(SEGH_WORDS * 8);
+    W.segp_o_exp = W.segp_o_cnt + al(4 * (S + 1));
+    W.segp_o_qst = W.segp_o_exp + al(8 * (S + 1));
+    W.segp_o_var = W.segp_o_qst + al(4 * S);
+    const size_t colcap = d.wcol_stride ? (size_t)(CHD_WCOLS + 1) * d.wcol_stride : (size_t)d.N + d.ghost_cap;
+    // the variable part: the columns + 96 MiB (6M segments, or 12M explicit records)
+    W.segp_cap = W.segp_o_var + al(4 * colcap) + (96ull << 20);
+    if (hipStreamCreateWithFlags(&W.segp_stream, hipStreamNonBlocking) != hipSuccess) return fail(ctx, CHD_E_HIP, "chd_tick_segments_begin: no side stream");
+    for (auto &sl : W.segp) {
+        HIPCHK(hipMalloc((void **)&sl.d_blk, W.segp_cap));
+        HIPCHK(hipHostMalloc((void **)&sl.h, W.segp_cap, hipHostMallocDefault));
+        HIPCHK(hipHostGetDevicePointer((void **)&sl.h_dev, sl.h, 0));
+        memset(sl.h, 0, SEGH_WORDS * 8);
+        HIPCHK(hipEventCreateWithFlags(&sl.ev_up, hipEventDisableTiming));
+        HIPCHK(hipEventCreate(&sl.ev_begin));  // (with timestamps: chd_set_profiling worlds report the tick's device time)
+        HIPCHK(hipEventCreate(&sl.ev_fill));
+    }
+    W.segp_ready = true;
+    return CHD_OK;
+}
+
+int chd_tick_segments_begin(chd_ctx *ctx, const chd_tick_in *in) {
+    NEED_WORLD();
+    if (!in) return fail(ctx, CHD_E_INVAL, "chd_tick_segments_begin: NULL argument");
+    std::lock_guard<FairMutex> lk(ctx->mu);
+    TRY(bind(ctx));
+    World &W = ctx->w;
+    WorldDev &d = W.d;
+    if (d.capq > 32u * SEG_BITMAP_WORDS) return fail(ctx, CHD_E_TOO_LARGE, "chd_tick_segments_begin: max_interest_cells %u > %u", d.capq, 32u * SEG_BITMAP_WORDS);
+    if ((uint64_t)d.S * d.capq > 0xFFFFFFFFull) return fail(ctx, CHD_E_TOO_LARGE, "chd_tick_segments_begin: more than 2^32 subscriptions");
+    if (W.slot_mode == 2) return fail(ctx, CHD_E_STATE, "chd_tick_segments_begin on a region-sharded world");
+    TRY(segp_setup(ctx));
+    if (W.segp_pending >= 2) return fail(ctx, CHD_E_STATE, "chd_tick_segments_begin: two ticks are in flight already: chd_tick_segments_end first");
+    World::SegPipeSlot &sl = W.segp[W.segp_head];
+    hipStream_t st = ctx->stream;
+    // the uploads: on the side stream, into this parity's bank of scratch buffers (the other bank may still be read by the tick in
+    // flight; this one was last read by the tick two back, whose _end has returned)
+    for (int i = 0; i < 13; i++) std::swap(ctx->scratch[i], W.segp_scratch[W.segp_head][i]);
+    ctx->up_stream = W.segp_stream;
+    chd_tick_in din;
+    int rc = host_tick_stage(ctx, in, din);
+    ctx->up_stream = nullptr;
+    auto unbank = [&]() { for (int i = 0; i < 13; i++) std::swap(ctx->scratch[i], W.segp_scratch[W.segp_head][i]); };
+    if (rc != CHD_OK) { unbank(); return rc; }
+    if (hipEventRecord(sl.ev_up, W.segp_stream) != hipSuccess || hipStreamWaitEvent(st, sl.ev_up, 0) != hipSuccess) { unbank(); return fail(ctx, CHD_E_HIP, "chd_tick_segments_begin: event"); }
+    sl.timed = ctx->prof_depth > 0;
+    if (sl.timed) (void)hipEventRecord(sl.ev_begin, st);
+    rc = tick_locked(ctx, &din);
+    unbank();
+    if (rc != CHD_OK) return rc;
+    const int have_desc = W.last_desc ? 1 : 0;
+    uint32_t *cnt = (uint32_t *)(sl.d_blk + W.segp_o_cnt);
+    unsigned long long *exp = (unsigned long long *)(sl.d_blk + W.segp_o_exp);
+    sl.ncol = !W.last_desc ? 0ull : d.wcol_on ? (uint64_t)(CHD_WCOLS + 1) * d.wcol_stride : (uint64_t)d.N + d.ghost_cap;
+    sl.nq = in->n_queries;
+    hipLaunchKernelGGL(k_segments, dim3(d.S), dim3(64), 0, st, ctx->g, d, have_desc, 0, cnt, exp, (chd_fanout_segment *)nullptr, (chd_fanout_rec *)nullptr,
+                       (unsigned char *)nullptr);
+    hipLaunchKernelGGL(k_seg_scan, dim3(1), dim3(1024), 0, st, d, ctx->ring.cur_tick % TICK_RING, sl.d_blk, sl.h_dev, (uint32_t)W.segp_o_cnt, (uint32_t)W.segp_o_exp,
+                       (unsigned long long)W.segp_o_var, (unsigned long long)sl.ncol, sl.nq, (unsigned long long)W.segp_cap,
+                       (const unsigned long long *)((W.gate && W.gated) ? W.gate + GATE_FAIL : nullptr), (unsigned long long)ctx->ring.cur_tick);
+    hipLaunchKernelGGL(k_segments, dim3(d.S), dim3(64), 0, st, ctx->g, d, have_desc, 1, cnt, exp, (chd_fanout_segment *)nullptr, (chd_fanout_rec *)nullptr, sl.d_blk);
+    hipLaunchKernelGGL(k_seg_stage, dim3(128), dim3(256), 0, st, d, sl.d_blk, (uint32_t)W.segp_o_qst);
+    TRY(after_launch(ctx));
+    HIPCHK(hipEventRecord(sl.ev_fill, st));
+    sl.tick_no = ctx->ring.cur_tick;
+    W.segp_pending++;
+    W.segp_head ^= 1u;
+    return CHD_OK;
+}
+
+int chd_tick_segments_end(chd_ctx *ctx, chd_segments_block *out) {
+    NEED_WORLD();
+    if (!out) return fail(ctx, CHD_E_INVAL, "chd_tick_segments_end: NULL argument");
+    std::lock_guard<FairMutex> lk(ctx->mu);
+    TRY(bind(ctx));
+    World &W = ctx->w;
+    if (!W.segp_pending) return fail(ctx, CHD_E_STATE, "chd_tick_segments_end without a chd_tick_segments_begin");
+    World::SegPipeSlot &sl = W.segp[W.segp_tail];
+    memset(out, 0, sizeof *out);
+    const auto t0 = std::chrono::steady_clock::now();
+    HIPCHK(hipEventSynchronize(sl.ev_fill));
+    const auto t1 = std::chrono::steady_clock::now();
+    W.segp_pending--;
+    W.segp_tail ^= 1u;
+    const unsigned long long *hdr = (const unsigned long long *)sl.h;  // (k_seg_scan wrote it there)
+    if (hdr[SEGH_TICK] != sl.tick_no) return fail(ctx, CHD_E_HIP, "chd_tick_segments_end: the block's header is of tick %llu, not %llu", hdr[SEGH_TICK], (unsigned long long)sl.tick_no);
+    const uint64_t nseg = hdr[SEGH_NSEG], nexp = hdr[SEGH_NEXP], nho = hdr[SEGH_NHO], nun = hdr[SEGH_NUN], nnew = hdr[SEGH_NNEW], total = hdr[SEGH_TOTAL];
+    const unsigned long long *row = hdr + SEGH_ROW;
+    if (!hdr[SEGH_FITS])
+        return fail(ctx, CHD_E_CAPACITY, "chd_tick_segments_end: %llu segments, %llu explicit records, %llu handovers, %llu / %llu list entries: %llu bytes exceed the "
+                    "block's %llu: take this tick with chd_tick_fetch + chd_tick_fetch_segments", (unsigned long long)nseg, (unsigned long long)nexp,
+                    (unsigned long long)nho, (unsigned long long)nun, (unsigned long long)nnew, (unsigned long long)total, (unsigned long long)W.segp_cap);
+    // ONE copy of exactly the block's bytes (behind the header the host has already): the next tick's kernels run meanwhile
+    const size_t skip = SEGH_WORDS * 8;
+    HIPCHK(hipMemcpyAsync(sl.h + skip, sl.d_blk + skip, total - skip, hipMemcpyDeviceToHost, W.segp_stream));
+    HIPCHK(hipStreamSynchronize(W.segp_stream));
+    out->wait_ms = std::chrono::duration<float, std::milli>(t1 - t0).count();
+    out->copy_ms = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t1).count();
+    out->conn_seg_off = (const uint32_t *)(sl.h + W.segp_o_cnt);
+    out->conn_rec_off = (const uint64_t *)(sl.h + W.segp_o_exp);
+    out->columns = (const uint32_t *)(sl.h + hdr[SEGH_OFF_COL]); out->n_columns = hdr[SEGH_NCOL];
+    out->segments = (const chd_fanout_segment *)(sl.h + hdr[SEGH_OFF_SEG]); out->n_segments = nseg;
+    out->records = (const chd_fanout_rec *)(sl.h + hdr[SEGH_OFF_REC]); out->n_explicit = nexp;
+    out->n_records = row[0];
+    out->handovers = (const chd_handover_rec *)(sl.h + hdr[SEGH_OFF_HO]); out->n_handovers = (uint32_t)nho; out->n_locked_aborts = (uint32_t)row[3];
+    out->unsub_sub = (const uint32_t *)(sl.h + hdr[SEGH_OFF_UN]); out->unsub_channel = (const uint32_t *)(sl.h + hdr[SEGH_OFF_UN + 1]); out->n_unsubs = (uint32_t)nun;
+    out->newsub_sub = (const uint32_t *)(sl.h + hdr[SEGH_OFF_NEW]); out->newsub_channel = (const uint32_t *)(sl.h + hdr[SEGH_OFF_NEW + 1]);
+    out->newsub_interval_ms = (const uint32_t *)(sl.h + hdr[SEGH_OFF_NEW + 2]); out->n_newsubs = (uint32_t)nnew;
+    out->query_status = (const int32_t *)(sl.h + W.segp_o_qst); out->n_queries = (uint32_t)hdr[SEGH_NQ];
+    out->overflow = (uint32_t)(row[7] & 0xFFFFFFFFull); out->history_overflow = (uint32_t)(row[7] >> 32);
+    out->block = sl.h; out->block_bytes = total;
+    if (sl.timed) (void)hipEventElapsedTime(&out->device_ms, sl.ev_begin, sl.ev_fill);
+    gate_poll_end(ctx, hdr[SEGH_GATE_FAIL]);
+    chd_tick_stats &stt = ctx->stats;
+    stt.n_records = row[0];
+    stt.n_record_upper_bound = hdr[SEGH_REC_UB];
+    stt.n_handovers = (uint32_t)nho;
+    stt.n_unsubs = (uint32_t)nun;
+    stt.n_pairs = (uint32_t)row[6];
+    if (out->overflow) return fail(ctx, CHD_E_CAPACITY, "tick output truncated (overflow mask 0x%x)", out->overflow);
+    return CHD_OK;
+}
 
 int chd_set_stream(chd_ctx *ctx, void *hip_stream, int external) {
     if (!ctx) return fail(nullptr, CHD_E_INVAL, "NULL ctx");

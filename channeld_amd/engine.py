@@ -388,6 +388,22 @@ class SpatialWorld:
              upd_round_off=None, _segments: bool = False) -> TickResult:
         """upd_arrival_ns / cell_upd_arrival_ns: the arrivalTime of every update (history_depth worlds; None = now_ns);
         upd_round_off: [0, ..., n_updates], the rounds of updates (a channel's r-th update of this tick lies in round r)."""
+        ti, keep, nq = self._tick_in(now_ns, upd_idx, upd_x, upd_z, upd_sender, cell_upd_channel, cell_upd_sender, query_sub, queries,
+                                     upd_arrival_ns, cell_upd_arrival_ns, upd_round_off)
+        if _segments:  # tick_segments: one C call for the tick and its segment output (chd_tick_segments)
+            o = self._alloc_out(nq, False, 0, pinned)
+            o.conn_rec_off, o.conn_rec_cnt = None, None
+            seg = self._segments_call(lambda so: self.lib.chd_tick_segments(self.ctx, C.byref(ti), C.byref(o), C.byref(so)), pinned)
+            return self._result(o, nq), seg
+        o = self._alloc_out(nq, want_records, records_cap, pinned)
+        rc = self.lib.chd_tick(self.ctx, C.byref(ti), C.byref(o))
+        if rc not in (_lib.OK,):
+            _lib.check(self.ctx, rc)
+        return self._result(o, nq)
+
+    def _tick_in(self, now_ns, upd_idx, upd_x, upd_z, upd_sender, cell_upd_channel, cell_upd_sender, query_sub, queries,
+                 upd_arrival_ns, cell_upd_arrival_ns, upd_round_off):
+        """chd_tick_in over host arrays: (TickIn, the arrays it points into, n_queries)."""
         ti = TickIn()
         ti.now_ns = int(now_ns)
         keep = []
@@ -427,21 +443,57 @@ class SpatialWorld:
                 keep += [arr, sx, sz, sd, qs]
                 ti.n_queries, ti.query_sub, ti.queries = nq, _ptr(qs), C.cast(arr, C.c_void_p)
                 ti.spot_x, ti.spot_z, ti.spot_dist, ti.n_spots_total = _ptr(sx), _ptr(sz), _ptr(sd), len(sx)
-        if _segments:  # tick_segments: one C call for the tick and its segment output (chd_tick_segments)
-            o = self._alloc_out(nq, False, 0, pinned)
-            o.conn_rec_off, o.conn_rec_cnt = None, None
-            seg = self._segments_call(lambda so: self.lib.chd_tick_segments(self.ctx, C.byref(ti), C.byref(o), C.byref(so)), pinned)
-            return self._result(o, nq), seg
-        o = self._alloc_out(nq, want_records, records_cap, pinned)
-        rc = self.lib.chd_tick(self.ctx, C.byref(ti), C.byref(o))
-        if rc not in (_lib.OK,):
-            _lib.check(self.ctx, rc)
-        return self._result(o, nq)
+        return ti, keep, nq
 
     def tick_segments(self, now_ns: int, pinned: bool = True, **kw):
         """chd_tick_segments: the tick (host buffers, arguments as tick()) and its fan-out in the compact segment form in ONE C call —
         (TickResult without dense records, the dict fetch_segments returns)."""
         return self.tick(now_ns, want_records=False, pinned=pinned, _segments=True, **kw)
+
+    def tick_segments_begin(self, now_ns: int, upd_idx=None, upd_x=None, upd_z=None, upd_sender=None, cell_upd_channel=None,
+                            cell_upd_sender=None, query_sub=None, queries=None, upd_arrival_ns=None, cell_upd_arrival_ns=None,
+                            upd_round_off=None):
+        """chd_tick_segments_begin: enqueue the tick, its segment passes and the copies of everything it hands out; no host wait.
+        At most two ticks in flight.  The input arrays are kept alive until the matching tick_segments_end."""
+        ti, keep, _ = self._tick_in(now_ns, upd_idx, upd_x, upd_z, upd_sender, cell_upd_channel, cell_upd_sender, query_sub, queries,
+                                    upd_arrival_ns, cell_upd_arrival_ns, upd_round_off)
+        _lib.check(self.ctx, self.lib.chd_tick_segments_begin(self.ctx, C.byref(ti)))
+        self.__dict__.setdefault("_segp_keep", []).append(keep)
+
+    def tick_segments_end(self, copy: bool = False):
+        """chd_tick_segments_end: the oldest tick in flight, as (TickResult without dense records, the dict fetch_segments returns,
+        info).  The arrays are VIEWS into the library's page-locked block of that tick (copy=True: copies), valid until the
+        next-but-one tick_segments_begin.  info: dict(block_bytes, wait_ms, copy_ms, device_ms)."""
+        b = _lib.SegmentsBlock()
+        rc = self.lib.chd_tick_segments_end(self.ctx, C.byref(b))
+        if getattr(self, "_segp_keep", None):
+            self._segp_keep.pop(0)
+        _lib.check(self.ctx, rc)
+        base, nbytes = int(b.block), int(b.block_bytes)
+        blocks = self.__dict__.setdefault("_segp_blocks", {})
+        mem = blocks.get(base)
+        if mem is None or len(mem) < nbytes:  # one numpy view per page-locked block, grown to the largest tick seen
+            mem = blocks[base] = np.frombuffer((C.c_char * max(nbytes, 1 << 26)).from_address(base), dtype=np.uint8)
+
+        def view(ptr, n, dt):
+            n, dt = int(n), np.dtype(dt)
+            if not n:
+                return np.zeros(0, dtype=dt)
+            off = int(ptr) - base
+            a = mem[off: off + n * dt.itemsize].view(dt)
+            return a.copy() if copy else a
+        S = self.S
+        seg = dict(segments=view(b.segments, b.n_segments, self.SEG_DTYPE), conn_seg_off=view(b.conn_seg_off, S + 1, np.uint32),
+                   columns=view(b.columns, b.n_columns, np.uint32), records=view(b.records, b.n_explicit, REC_DTYPE),
+                   conn_rec_off=view(b.conn_rec_off, S + 1, np.uint64), n_records=int(b.n_records))
+        res = TickResult(
+            handovers=view(b.handovers, b.n_handovers, HANDOVER_DTYPE), n_locked_aborts=int(b.n_locked_aborts),
+            query_status=view(b.query_status, b.n_queries, np.int32),
+            unsub_sub=view(b.unsub_sub, b.n_unsubs, np.uint32), unsub_channel=view(b.unsub_channel, b.n_unsubs, np.uint32),
+            newsub_sub=view(b.newsub_sub, b.n_newsubs, np.uint32), newsub_channel=view(b.newsub_channel, b.n_newsubs, np.uint32),
+            newsub_interval_ms=view(b.newsub_interval_ms, b.n_newsubs, np.uint32), records=None, conn_rec_off=None, conn_rec_cnt=None,
+            n_records=int(b.n_records), overflow=int(b.overflow), history_overflow=int(b.history_overflow))
+        return res, seg, dict(block_bytes=nbytes, wait_ms=float(b.wait_ms), copy_ms=float(b.copy_ms), device_ms=float(b.device_ms))
 
     # ---- device-resident path (bench): inputs already in HBM ----
     def device_array(self, host: np.ndarray) -> DeviceArray:

@@ -547,6 +547,44 @@ int chd_tick_fetch_segments(chd_ctx *ctx, chd_segments_out *out);
  * sizes in seg->n_*, grow and call chd_tick_fetch_segments. */
 int chd_tick_segments(chd_ctx *ctx, const chd_tick_in *in, chd_tick_out *out, chd_segments_out *seg);
 
+/* The same tick and the same outputs as an ASYNCHRONOUS PAIR, for a host loop that prepares tick t+1 while tick t's results travel:
+ *     chd_tick_segments_begin(ctx, &in[t+1]);     enqueue only: uploads, the tick, the segment passes — no host wait
+ *     chd_tick_segments_end(ctx, &blk);            tick t: wait for its last kernel, ONE copy of its block, pointers into it
+ * _begin uploads the inputs on a side stream (while the tick in flight still runs), enqueues the tick on the ctx stream and packs
+ * everything the tick hands out — a header with every count and offset, the per-connection offsets, query status, columns,
+ * segments, explicit records, handover records, the unsub / new-sub lists — into ONE block in device memory.  _end waits for that
+ * tick's last kernel (the next tick's kernels are queued behind it and start at once), reads the sizes from the header (the device
+ * wrote it into page-locked memory itself: no sizing round trip), copies exactly the block's bytes with one DMA into its page-locked
+ * twin while the next tick runs, and returns pointers into it.  At most TWO ticks in flight (a third _begin: CHD_E_STATE).  _end
+ * returns ticks in the order they were begun; its pointers stay valid until the next-but-one _begin (the same parity's).  Results:
+ * those of chd_tick_segments on the same inputs — offsets, segments and columns byte for byte; explicit records and lists in the
+ * order of the device's atomics, as there.  The block is fixed-size (the columns + 96 MiB: 6M segments or 12M explicit records): a
+ * tick beyond it returns CHD_E_CAPACITY from _end with the counts — the world has advanced; chd_tick_fetch +
+ * chd_tick_fetch_segments still deliver that tick if called before the next _begin.  Do not interleave with chd_tick /
+ * chd_tick_device / chd_tick_segments while a tick is in flight (_end first); not on region-sharded worlds (CHD_E_STATE).
+ * replaces: the host side of Channel.tickData → fanOutDataUpdate (data.go:201-233, 235-318) as a loop that never idles the device. */
+typedef struct {
+    const uint32_t *conn_seg_off;          /* max_subscribers + 1 */
+    const uint64_t *conn_rec_off;          /* max_subscribers + 1 */
+    const chd_fanout_segment *segments; uint64_t n_segments;
+    const uint32_t *columns; uint64_t n_columns;
+    const chd_fanout_rec *records; uint64_t n_explicit;
+    uint64_t n_records;                    /* what the segments expand to */
+    const chd_handover_rec *handovers; uint32_t n_handovers; uint32_t n_locked_aborts;
+    const uint32_t *unsub_sub, *unsub_channel; uint32_t n_unsubs;
+    uint32_t n_newsubs;
+    const uint32_t *newsub_sub, *newsub_channel, *newsub_interval_ms;
+    const int32_t *query_status; uint32_t n_queries;
+    uint32_t overflow, history_overflow;   /* as chd_tick_out */
+    uint32_t reserved;
+    const void *block; uint64_t block_bytes; /* the page-locked block all pointers above point into; the bytes of it this tick filled */
+    float wait_ms, copy_ms;                /* host time inside _end: blocked until the tick's last kernel | the copy of the block */
+    float device_ms;                       /* chd_set_profiling(depth > 0): ctx-stream time of the tick + the segment passes (HIP events); else 0 */
+    uint32_t reserved2;
+} chd_segments_block;
+int chd_tick_segments_begin(chd_ctx *ctx, const chd_tick_in *in);
+int chd_tick_segments_end(chd_ctx *ctx, chd_segments_block *out);
+
 /* Read back the interest set of a subscriber slot (the keys of
  * Connection.spatialSubscriptions, with the per-subscription fan-out state of
  * subscription.go:13-31 / data.go:39-44).  Arrays have max_interest_cells

@@ -623,6 +623,87 @@ def test_tick_segments_in_one_call_equals_the_two_calls(amd):
         ctl.close()
 
 
+def test_tick_segments_begin_end_pair_equals_tick_segments(amd):
+    """chd_tick_segments_begin / chd_tick_segments_end — tick t+1 enqueued while tick t's results travel, one wait, one
+    copy and one page-locked block per tick.  Two identical worlds, one ticked by chd_tick_segments, one by the pair kept TWO ticks deep
+    (begin(t+1) before end(t)): the offsets, the segments, the columns, the explicit records' offsets and every count are
+    byte-identical tick for tick; the explicit records and the lists (whose order inside a connection / a list is the order of
+    device atomics in both forms) equal as multisets per connection / per list.  The world starts with no subscriptions and then
+    subscribes everybody at once (block sizes from a few KB to MBs from one tick to the next); a third begin without an end is
+    refused, and so is an end with nothing in flight."""
+    from channeld_amd.engine import expand_segments
+
+    cfg = synth.load_config("spatial_static_40x40.json")
+    N, S = 30_000, 1500
+    sw = synth.SynthWorld(synth.WorldSpec(cfg, N, S, 0x5E8, tick_ms=50, outside_frac=0.01, locked_frac=0.02))
+    worlds = []
+    for _ in range(2):
+        ctl, gw = make(amd, cfg, N, S)
+        gw.spawn(None, sw.chan_id, sw.x, sw.z, sw.flags, sw.sender)
+        gw.add_subscribers(None, sw.sub_conn)
+        worlds.append((ctl, gw))
+    (_, ga), (_, gb) = worlds
+    with pytest.raises(Exception):
+        gb.tick_segments_end()
+    rng = np.random.default_rng(8)
+    T = 14
+    ins, want = [], []
+    for k in range(T):
+        sw.step()
+        idx = np.arange(N, dtype=np.uint32) if k % 4 != 2 else np.sort(rng.choice(N, N // 2, replace=False)).astype(np.uint32)
+        kw = dict(upd_idx=idx, upd_x=sw.x[idx].copy(), upd_z=sw.z[idx].copy())
+        if k >= 2:
+            kw["queries"] = sw.queries()
+        ins.append((sw.now_ns(), kw))
+        ra, sa = ga.tick_segments(sw.now_ns(), pinned=False, **kw)
+        want.append((ra, {a: (np.array(v) if isinstance(v, np.ndarray) else v) for a, v in sa.items()}))
+    total = 0
+    sizes = []
+
+    def check(k):
+        nonlocal total
+        rb, sb, info = gb.tick_segments_end()
+        ra, sa = want[k]
+        sizes.append(info["block_bytes"])
+        assert ra.n_records == rb.n_records == sa["n_records"] == sb["n_records"] and ra.overflow == rb.overflow == 0, f"tick {k}"
+        for name in ("conn_seg_off", "conn_rec_off", "segments", "columns"):
+            assert len(sa[name]) == len(sb[name]) and sa[name].tobytes() == sb[name].tobytes(), f"tick {k}: {name}"
+        assert len(sa["records"]) == len(sb["records"])
+        for s_ in range(S):
+            a, b = int(sa["conn_rec_off"][s_]), int(sa["conn_rec_off"][s_ + 1])
+            if b > a:
+                assert np.array_equal(canon(sa["records"]["conn"][a:b], sa["records"]["channel"][a:b]), canon(sb["records"]["conn"][a:b], sb["records"]["channel"][a:b])), f"tick {k} slot {s_}"
+        assert np.array_equal(np.sort(ra.handovers, order=["entity", "src", "dst"]), np.sort(rb.handovers, order=["entity", "src", "dst"]))
+        assert ra.n_locked_aborts == rb.n_locked_aborts and np.array_equal(ra.query_status, rb.query_status)
+        assert np.array_equal(canon(ra.unsub_sub, ra.unsub_channel), canon(rb.unsub_sub, rb.unsub_channel))
+        assert np.array_equal(canon(ra.newsub_sub, ra.newsub_channel), canon(rb.newsub_sub, rb.newsub_channel))
+        ia, ib = np.lexsort((ra.newsub_channel, ra.newsub_sub)), np.lexsort((rb.newsub_channel, rb.newsub_sub))
+        assert np.array_equal(ra.newsub_interval_ms[ia], rb.newsub_interval_ms[ib])
+        eb = expand_segments(sb, sw.sub_conn)
+        assert len(eb) == ra.n_records
+        total += ra.n_records
+        assert info["block_bytes"] > 12 * (S + 1)
+
+    gb.tick_segments_begin(ins[0][0], **ins[0][1])
+    for k in range(1, T):
+        gb.tick_segments_begin(ins[k][0], **ins[k][1])
+        if k == 5:
+            with pytest.raises(Exception):  # a third tick in flight
+                gb.tick_segments_begin(ins[k][0] + 1, **ins[k][1])
+        check(k - 1)
+    check(T - 1)
+    assert total > 1_000_000 and max(sizes) > 4 * min(sizes)
+    # the synchronous calls work again once nothing is in flight, and see the same world
+    sw.step()
+    idx = np.arange(N, dtype=np.uint32)
+    kw = dict(upd_idx=idx, upd_x=sw.x, upd_z=sw.z, queries=sw.queries())
+    ra, sa = ga.tick_segments(sw.now_ns(), pinned=False, **kw)
+    rb, sb = gb.tick_segments(sw.now_ns(), pinned=False, **kw)
+    assert ra.n_records == rb.n_records and sa["segments"].tobytes() == sb["segments"].tobytes()
+    for ctl, _ in worlds:
+        ctl.close()
+
+
 def test_tick_device_reports_a_repeated_slot(amd):
     """VERDICT r2 #10 / ADVICE r1: chd_tick_device cannot check its precondition on the host (the inputs are device arrays) —
     the device does while it ingests: an entity slot twice in one round of updates, or a subscriber slot twice, sets overflow
