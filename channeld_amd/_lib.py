@@ -53,7 +53,7 @@ SYMBOLS = (
     "chd_shard_get_entities", "chd_shard_halo_layout", "chd_shard_interest",
     "chd_handover_recipients", "chd_adjacent_recipients", "chd_wire_set_payloads", "chd_wire_build", "chd_wire_build_info", "chd_wire_fetch",
     "chd_tick_digest", "chd_tick_fetch_segments", "chd_tick_segments", "chd_tick_segments_begin", "chd_tick_segments_end", "chd_host_alloc", "chd_host_free", "chd_subs_set_options", "chd_subs_get_options", "chd_world_set_entity_groups", "chd_world_set_handover_lists", "chd_wire_set_type_url", "chd_wire_set_merge_schema", "chd_handover_messages",
-    "chd_handover_recipients_ex", "chd_handover_variants", "chd_world_set_server_connections",
+    "chd_handover_recipients_ex", "chd_handover_src_owner_unsubscribed", "chd_shard_handover_recipients", "chd_handover_variants", "chd_world_set_server_connections",
 )
 
 
@@ -290,6 +290,8 @@ def load():
     L.chd_wire_fetch.argtypes = [C.c_void_p, _u64p, _u32p, _u8p, C.c_uint64]
     L.chd_handover_recipients.argtypes = [C.c_void_p, _u32p, _u32p, _u8p, C.c_uint64, P(C.c_uint64)]
     L.chd_handover_recipients_ex.argtypes = [C.c_void_p, _u32p, _u32p, _u8p, _u32p, C.c_uint64, P(C.c_uint64)]
+    L.chd_handover_src_owner_unsubscribed.argtypes = [C.c_void_p, _u8p, C.c_uint32, P(C.c_uint32)]
+    L.chd_shard_handover_recipients.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, _u32p, _u32p, _u8p, _u32p, _u8p, C.c_uint64, P(C.c_uint64)]
     L.chd_handover_variants.argtypes = [C.c_void_p, C.c_uint32, _u32p, _u32p, _u32p, _u8p, C.c_uint64, P(C.c_uint64)]
     L.chd_adjacent_recipients.argtypes = [C.c_void_p, C.c_uint32, _u32p, _u32p, _u32p, _u32p, _u32p, _u32p, C.c_uint64]
     L.chd_tick_digest.argtypes = [C.c_void_p, P(RecordsDigest), _u64p]

@@ -190,6 +190,12 @@ struct World {
     uint8_t *ho_rcp_kind = nullptr;    // CHD_HO_*
     uint32_t *ho_rcp_mask = nullptr;   // per recipient: which entities of its handover carry their entityData (chd_handover_recipients_ex)
     uint64_t ho_rcp_cap = 0;
+    uint32_t *ho_rcp_own = nullptr;    // [handovers_cap] step 1 unsubscribes the src spatial server's connection (spatial.go:688-694)
+    // region-sharded worlds: the subscriptions as they were at the tick's start (chd_shard_handover_recipients plans on them after the
+    // tick, when the host has gathered the whole world's handover records), the uploaded records, their count as k_handover_recipients reads it
+    unsigned long long *snap_bits = nullptr; uint32_t *snap_cell = nullptr, *snap_cnt = nullptr;
+    chd_handover_rec *rcp_recs = nullptr; uint32_t rcp_recs_cap = 0; uint32_t *rcp_ctr = nullptr;
+    uint32_t *rcp_off = nullptr, *rcp_own = nullptr;
     uint32_t *server_conn = nullptr;   // chd_world_set_server_connections (device; WorldDev::server_conn points here while a table is set)
 };
 
@@ -1068,8 +1074,8 @@ int chd_world_create(chd_ctx *ctx, const chd_world_cfg *cfg) {
     // world, on every rank, instead of per entity slot (WorldDev::log_on); LN = how many logs there are
     if (cfg->shard_channels && !cfg->history_depth && !(cfg->flags & CHD_WORLD_WIRE))
         return fail(ctx, CHD_E_INVAL, "shard_channels is for region-sharded worlds with exact update buffers (history_depth > 0) or wire buffers (CHD_WORLD_WIRE)");
-    if (cfg->shard_channels && (cfg->flags & (CHD_WORLD_PIPELINE_TICKS | CHD_WORLD_HANDOVER_RECIPIENTS)))
-        return fail(ctx, CHD_E_INVAL, "shard_channels: a region-sharded world (no pipelined ticks, no recipient planning)");
+    if (cfg->shard_channels && (cfg->flags & CHD_WORLD_PIPELINE_TICKS))
+        return fail(ctx, CHD_E_INVAL, "shard_channels: a region-sharded world (no pipelined ticks)");
     d.ce_by_chan = cfg->shard_channels ? 1u : 0u;
     // (a world with by-channel arrays is region-sharded from its creation on: chd_world_spawn / chd_tick / chd_tick_device index those
     // arrays by entity SLOT and would write past them whenever shard_channels < max_entities — they answer CHD_E_STATE)
@@ -1202,6 +1208,7 @@ int chd_world_create(chd_ctx *ctx, const chd_world_cfg *cfg) {
         TRY(walloc(ctx, &W.ho_rcp_conn, W.ho_rcp_cap, false));
         TRY(walloc(ctx, &W.ho_rcp_kind, W.ho_rcp_cap, false));
         TRY(walloc(ctx, &W.ho_rcp_mask, W.ho_rcp_cap, false));
+        TRY(walloc(ctx, &W.ho_rcp_own, (size_t)d.handovers_cap + 1));
         TRY(walloc(ctx, &d.ho_moved, d.handovers_cap));
     }
     // banked lists: a bank holds the worst case of the subscriber slots that map to it
@@ -1848,7 +1855,7 @@ static int tick_locked(chd_ctx *ctx, const chd_tick_in *in) {
         if (W.plan_recipients) {
             // who receives each handover's message: on the subscriptions as they are NOW, before this tick's
             // interest updates (the reference sends from Notify, spatial.go:776-857)
-            launch_handover_recipients_count(bs, ctx->g, d, W.ho_rcp_off);
+            launch_handover_recipients_count(bs, ctx->g, d, W.ho_rcp_off, W.ho_rcp_own);
             launch_scan_u32_inplace_dev(bs, W.ho_rcp_off, d.handovers_cap, d.counters + CTR_HANDOVERS);
             launch_handover_recipients_fill(bs, ctx->g, d, W.ho_rcp_off, W.ho_rcp_conn, W.ho_rcp_kind, W.ho_rcp_mask, W.ho_rcp_cap);
         }
@@ -2869,6 +2876,18 @@ static int shard_ingest_pre_locked(chd_ctx *ctx, int64_t now_ns, const double *d
         return fail(ctx, CHD_E_STATE, "a world with an update log by channel id takes its updates' senders by channel id too (chd_shard_set_update_senders)");
     if (W.d.log_on && n_chan > W.d.log_n) return fail(ctx, CHD_E_INVAL, "chd_shard_ingest: %u channels, the world was created for %u (shard_channels)", n_chan, W.d.log_n);
     TRY(tick_begin(ctx, now_ns));
+    if (W.plan_recipients) {
+        // Notify runs before the tick's interest updates (spatial.go:776-857 reads the subscriptions as they are then): keep them
+        WorldDev &d = W.d;
+        if (d.wb) {
+            if (!W.snap_bits) TRY(walloc(ctx, &W.snap_bits, (size_t)d.S * d.wb, false));
+            HIPCHK(hipMemcpyAsync(W.snap_bits, d.sub_bits, sizeof(uint64_t) * (size_t)d.S * d.wb, hipMemcpyDeviceToDevice, ctx->stream));
+        } else {
+            if (!W.snap_cell) { TRY(walloc(ctx, &W.snap_cell, (size_t)d.S * d.capq, false)); TRY(walloc(ctx, &W.snap_cnt, d.S, false)); }
+            HIPCHK(hipMemcpyAsync(W.snap_cell, d.pair_cell, sizeof(uint32_t) * (size_t)d.S * d.capq, hipMemcpyDeviceToDevice, ctx->stream));
+            HIPCHK(hipMemcpyAsync(W.snap_cnt, d.pair_cnt, sizeof(uint32_t) * d.S, hipMemcpyDeviceToDevice, ctx->stream));
+        }
+    }
     W.d.prev_ns = ctx->ring.n > 1 ? ctx->ring.t[1] : -1;  // (sub-tick arrival offsets: a regular update arrived after the previous tick)
     const uint32_t eid0 = ctx->cfg.entity_channel_id_start ? ctx->cfg.entity_channel_id_start : 0x80000u;
     launch_ingest_by_channel(ctx->stream, ctx->g, ctx->w.d, d_x_by_chan, d_z_by_chan, d_has_update, n_chan, eid0,
@@ -3909,6 +3928,91 @@ int chd_handover_recipients_ex(chd_ctx *ctx, uint32_t *offsets, uint32_t *conn, 
     TRY(down(ctx, kind, W.ho_rcp_kind, total));
     if (full_mask) TRY(down(ctx, full_mask, W.ho_rcp_mask, sizeof(uint32_t) * total));
     HIPCHK(hipStreamSynchronize(ctx->stream));
+    return CHD_OK;
+}
+
+int chd_handover_src_owner_unsubscribed(chd_ctx *ctx, uint8_t *flags, uint32_t cap, uint32_t *n_out) {
+    NEED_WORLD();
+    if (!n_out || (cap && !flags)) return fail(ctx, CHD_E_INVAL, "chd_handover_src_owner_unsubscribed: NULL buffer");
+    World &W = ctx->w;
+    if (!W.plan_recipients) return fail(ctx, CHD_E_STATE, "the world was created without CHD_WORLD_HANDOVER_RECIPIENTS");
+    if (W.slot_mode == 2) return fail(ctx, CHD_E_STATE, "chd_handover_src_owner_unsubscribed on a region-sharded world: chd_shard_handover_recipients");
+    if (!W.ticked) return fail(ctx, CHD_E_STATE, "no tick yet");
+    std::lock_guard<FairMutex> lk(ctx->mu);
+    TRY(bind(ctx));
+    uint64_t ringrow[8];
+    TRY(down(ctx, ringrow, W.d.tick_ring + (size_t)(ctx->ring.cur_tick % TICK_RING) * 8, sizeof ringrow));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    const uint32_t nh = std::min<uint32_t>((uint32_t)ringrow[2], W.d.handovers_cap);
+    *n_out = nh;
+    if (nh > cap) return fail(ctx, CHD_E_CAPACITY, "chd_handover_src_owner_unsubscribed: %u handovers, capacity %u", nh, cap);
+    std::vector<uint32_t> own(nh);
+    TRY(down(ctx, own.data(), W.ho_rcp_own, sizeof(uint32_t) * (size_t)nh));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    for (uint32_t h = 0; h < nh; h++) flags[h] = own[h] ? 1 : 0;
+    return CHD_OK;
+}
+
+int chd_shard_handover_recipients(chd_ctx *ctx, uint32_t n_handovers, const chd_handover_rec *handovers, uint32_t *offsets, uint32_t *conn, uint8_t *kind,
+                                  uint32_t *full_mask, uint8_t *src_owner_unsubscribed, uint64_t cap, uint64_t *n_out) {
+    NEED_WORLD();
+    if (!offsets || !n_out || (n_handovers && !handovers) || (cap && (!conn || !kind))) return fail(ctx, CHD_E_INVAL, "chd_shard_handover_recipients: NULL buffer");
+    World &W = ctx->w;
+    if (!W.plan_recipients) return fail(ctx, CHD_E_STATE, "the world was created without CHD_WORLD_HANDOVER_RECIPIENTS");
+    if (W.slot_mode != 2 || !W.ticked) return fail(ctx, CHD_E_STATE, "chd_shard_handover_recipients: no tick of a region-sharded world yet");
+    if (full_mask && W.d.sh_list_of) return fail(ctx, CHD_E_STATE, "chd_shard_handover_recipients: full_mask on a world with handover lists (the members' cells are other ranks' state)");
+    for (uint32_t h = 0; h < n_handovers; h++)
+        if (handovers[h].src < ctx->g.id_start || handovers[h].src - ctx->g.id_start >= ctx->g.ncell || handovers[h].dst < ctx->g.id_start ||
+            handovers[h].dst - ctx->g.id_start >= ctx->g.ncell)
+            return fail(ctx, CHD_E_INVAL, "chd_shard_handover_recipients: handover %u is not between two spatial channels", h);
+    std::lock_guard<FairMutex> lk(ctx->mu);
+    TRY(bind(ctx));
+    offsets[0] = 0;
+    *n_out = 0;
+    if (!n_handovers) return CHD_OK;
+    if (W.rcp_recs_cap < n_handovers) {
+        HIPCHK(hipStreamSynchronize(ctx->stream));
+        W.rcp_recs_cap = n_handovers + n_handovers / 4 + 256;
+        TRY(walloc(ctx, &W.rcp_recs, W.rcp_recs_cap, false));
+        TRY(walloc(ctx, &W.rcp_off, (size_t)W.rcp_recs_cap + 1));
+        TRY(walloc(ctx, &W.rcp_own, (size_t)W.rcp_recs_cap + 1));
+        if (!W.rcp_ctr) TRY(walloc(ctx, &W.rcp_ctr, CTR_COUNT));
+    }
+    const uint64_t rcap = std::min<uint64_t>((uint64_t)n_handovers * W.d.S, 1ull << 25);
+    if (W.ho_rcp_cap < rcap || !W.ho_rcp_conn) {
+        HIPCHK(hipStreamSynchronize(ctx->stream));
+        W.ho_rcp_cap = rcap;
+        TRY(walloc(ctx, &W.ho_rcp_conn, W.ho_rcp_cap, false));
+        TRY(walloc(ctx, &W.ho_rcp_kind, W.ho_rcp_cap, false));
+        TRY(walloc(ctx, &W.ho_rcp_mask, W.ho_rcp_cap, false));
+    }
+    hipStream_t st = ctx->stream;
+    TRY(up(ctx, W.rcp_recs, handovers, sizeof(chd_handover_rec) * (size_t)n_handovers));
+    HIPCHK(hipMemsetAsync(W.rcp_ctr, 0, sizeof(uint32_t) * CTR_COUNT, st));
+    HIPCHK(hipMemcpyAsync(W.rcp_ctr + CTR_HANDOVERS, &n_handovers, sizeof(uint32_t), hipMemcpyHostToDevice, st));
+    // the kernels of the single-GPU world over: the given records, this rank's subscriptions as they were at the tick's start
+    WorldDev v = W.d;
+    v.handovers = W.rcp_recs; v.handovers_cap = n_handovers; v.counters = W.rcp_ctr;
+    v.ho_moved = nullptr; v.n_groups = 0;  // (every handover as its notifier alone: bit 0 of full_mask)
+    if (v.wb) v.sub_bits = W.snap_bits ? W.snap_bits : v.sub_bits;
+    else if (W.snap_cell) { v.pair_cell = W.snap_cell; v.pair_cnt = W.snap_cnt; }
+    launch_handover_recipients_count(st, ctx->g, v, W.rcp_off, W.rcp_own);
+    launch_scan_u32_inplace(st, W.rcp_off, n_handovers);
+    launch_handover_recipients_fill(st, ctx->g, v, W.rcp_off, W.ho_rcp_conn, W.ho_rcp_kind, W.ho_rcp_mask, W.ho_rcp_cap);
+    TRY(after_launch(ctx));
+    TRY(down(ctx, offsets, W.rcp_off, sizeof(uint32_t) * ((size_t)n_handovers + 1)));
+    std::vector<uint32_t> own(src_owner_unsubscribed ? n_handovers : 0);
+    if (src_owner_unsubscribed) TRY(down(ctx, own.data(), W.rcp_own, sizeof(uint32_t) * (size_t)n_handovers));
+    HIPCHK(hipStreamSynchronize(st));
+    for (uint32_t h = 0; h < n_handovers && src_owner_unsubscribed; h++) src_owner_unsubscribed[h] = own[h] ? 1 : 0;
+    const uint64_t total = offsets[n_handovers];
+    *n_out = total;
+    if (total > W.ho_rcp_cap) return fail(ctx, CHD_E_CAPACITY, "handover recipients: %llu exceed the engine capacity %llu", (unsigned long long)total, (unsigned long long)W.ho_rcp_cap);
+    if (total > cap) return fail(ctx, CHD_E_CAPACITY, "handover recipients: %llu, capacity %llu", (unsigned long long)total, (unsigned long long)cap);
+    TRY(down(ctx, conn, W.ho_rcp_conn, sizeof(uint32_t) * total));
+    TRY(down(ctx, kind, W.ho_rcp_kind, total));
+    if (full_mask) TRY(down(ctx, full_mask, W.ho_rcp_mask, sizeof(uint32_t) * total));
+    HIPCHK(hipStreamSynchronize(st));
     return CHD_OK;
 }
 

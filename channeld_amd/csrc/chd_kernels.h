@@ -619,7 +619,7 @@ void launch_wire_copy(hipStream_t st, WorldDev w, WireDev x, uint32_t n_slow_con
 void launch_wire_set_payloads(hipStream_t st, WireDev x, int full, int cell, uint32_t n, uint32_t limit, const uint32_t *idx,
                               const uint32_t *lens, const uint64_t *off, const uint8_t *bytes, uint32_t ring_slot);
 // recipient planning (decision parts)
-void launch_handover_recipients_count(hipStream_t st, DevGrid g, WorldDev w, uint32_t *off);
+void launch_handover_recipients_count(hipStream_t st, DevGrid g, WorldDev w, uint32_t *off, uint32_t *own_unsub = nullptr);
 void launch_handover_recipients_fill(hipStream_t st, DevGrid g, WorldDev w, const uint32_t *off, uint32_t *conn,
                                      uint8_t *kind, uint32_t *full_mask, uint64_t cap);
 void launch_adjacent_recipients(hipStream_t st, DevGrid g, WorldDev w, uint32_t n_req, const uint32_t *channel,

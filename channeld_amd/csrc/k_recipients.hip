@@ -92,17 +92,30 @@ __device__ __forceinline__ uint32_t handover_full_mask(const DevGrid &g, const W
 }
 
 // fill == 0: off[h] = number of recipients of handover h;  fill != 0: write them at off[h]
+// own_unsub (count pass, may be NULL): own_unsub[h] = 1 when step 1 of a cross-server handover unsubscribes the src spatial server's
+// connection from the handover entities' channels (spatial.go:688-694: `ownerConn := srcChannel.GetOwner(); ... !ownerConn.
+// HasInterestIn(dstChannelId)`): a live slot holds the src server's ConnectionId (chd_world_set_server_connections) and dst is not
+// among its subscriptions.
 __global__ void __launch_bounds__(256) k_handover_recipients(DevGrid g, WorldDev w, uint32_t *off, uint32_t *conn,
-                                                             uint8_t *kind, uint32_t *full_mask, uint64_t cap, int fill) {
+                                                             uint8_t *kind, uint32_t *full_mask, uint64_t cap, int fill, uint32_t *own_unsub) {
     __shared__ uint32_t wcnt[4];
+    __shared__ uint32_t own_flag;
     const uint32_t n = min(w.counters[CTR_HANDOVERS], w.handovers_cap);
     for (uint32_t h = blockIdx.x; h < n; h += gridDim.x) {
         const chd_handover_rec r = w.handovers[h];
         const uint32_t src = r.src - g.id_start, dst = r.dst - g.id_start;
         uint32_t run = fill ? off[h] : 0u;
+        const uint32_t ssrv = server_of(g, src);
+        const bool own_on = !fill && own_unsub && w.server_conn && ssrv != server_of(g, dst) && ssrv < w.n_server_conn;
+        const uint32_t owner = own_on ? w.server_conn[ssrv] : 0u;
+        if (own_unsub && !fill) {
+            if (threadIdx.x == 0) own_flag = 0;
+            __syncthreads();
+        }
         for (uint32_t s0 = 0; s0 < w.S; s0 += 256) {
             const uint32_t s = s0 + threadIdx.x;
             const uint8_t k = handover_kind(w, s, src, dst);
+            if (own_on && s < w.S && w.sub_alive[s] && w.conn_id[s] == owner && k != CHD_HO_DST_NEW && k != CHD_HO_DST_KNOWN) own_flag = 1;
             uint32_t total;
             const uint32_t pos = run + block_rank(k != RCP_NONE, wcnt, total);
             if (fill && k != RCP_NONE && pos < cap) {
@@ -113,18 +126,23 @@ __global__ void __launch_bounds__(256) k_handover_recipients(DevGrid g, WorldDev
             run += total;
         }
         if (!fill && threadIdx.x == 0) off[h] = run;
+        if (!fill && own_unsub) {
+            __syncthreads();
+            if (threadIdx.x == 0) own_unsub[h] = own_flag;
+            __syncthreads();
+        }
     }
 }
 
-void launch_handover_recipients_count(hipStream_t st, DevGrid g, WorldDev w, uint32_t *off) {
+void launch_handover_recipients_count(hipStream_t st, DevGrid g, WorldDev w, uint32_t *off, uint32_t *own_unsub) {
     const unsigned grid = (unsigned)std::min<uint32_t>(w.handovers_cap ? w.handovers_cap : 1u, 2048u);
-    hipLaunchKernelGGL(k_handover_recipients, dim3(grid), dim3(256), 0, st, g, w, off, nullptr, nullptr, nullptr, 0, 0);
+    hipLaunchKernelGGL(k_handover_recipients, dim3(grid), dim3(256), 0, st, g, w, off, nullptr, nullptr, nullptr, 0, 0, own_unsub);
 }
 
 void launch_handover_recipients_fill(hipStream_t st, DevGrid g, WorldDev w, const uint32_t *off, uint32_t *conn,
                                      uint8_t *kind, uint32_t *full_mask, uint64_t cap) {
     const unsigned grid = (unsigned)std::min<uint32_t>(w.handovers_cap ? w.handovers_cap : 1u, 2048u);
-    hipLaunchKernelGGL(k_handover_recipients, dim3(grid), dim3(256), 0, st, g, w, (uint32_t *)off, conn, kind, full_mask, cap, 1);
+    hipLaunchKernelGGL(k_handover_recipients, dim3(grid), dim3(256), 0, st, g, w, (uint32_t *)off, conn, kind, full_mask, cap, 1, (uint32_t *)nullptr);
 }
 
 __global__ void __launch_bounds__(256) k_adjacent_recipients(DevGrid g, WorldDev w, uint32_t n_req,

@@ -683,6 +683,28 @@ class SpatialWorld:
         _lib.check(self.ctx, self.lib.chd_handover_recipients_ex(self.ctx, _ptr(off), _ptr(conn), _ptr(kind), _ptr(mask), cap, C.byref(n)))
         return off, conn[: n.value], kind[: n.value], mask[: n.value]
 
+    def handover_src_owner_unsubscribed(self, n_handovers: int):
+        """per handover of the last tick: 1 = step 1 of the cross-server handover unsubscribes the src spatial server's connection from
+        the handover entities' channels (chd_handover_src_owner_unsubscribed; spatial.go:688-694)."""
+        f = np.zeros(max(n_handovers, 1), dtype=np.uint8)
+        n = C.c_uint32(0)
+        _lib.check(self.ctx, self.lib.chd_handover_src_owner_unsubscribed(self.ctx, f.ctypes.data_as(C.POINTER(C.c_uint8)), len(f), C.byref(n)))
+        return f[: n.value]
+
+    def shard_handover_recipients(self, handovers: np.ndarray):
+        """Region-sharded worlds (chd_shard_handover_recipients): THIS rank's recipients of the given handover records (HANDOVER_DTYPE, the
+        whole world's of the last tick, gathered from every rank's fetch) — (offsets[n+1], conn ids, kinds, masks, src_owner_unsubscribed[n])."""
+        ho = np.ascontiguousarray(handovers, dtype=HANDOVER_DTYPE)
+        nh = len(ho)
+        off = np.zeros(nh + 1, dtype=np.uint32)
+        cap = max(nh * self.S, 1)
+        conn, kind, mask = np.zeros(cap, dtype=np.uint32), np.zeros(cap, dtype=np.uint8), np.zeros(cap, dtype=np.uint32)
+        own = np.zeros(max(nh, 1), dtype=np.uint8)
+        n = C.c_uint64(0)
+        _lib.check(self.ctx, self.lib.chd_shard_handover_recipients(self.ctx, nh, ho.ctypes.data_as(C.c_void_p), _ptr(off), _ptr(conn), _ptr(kind), _ptr(mask),
+                                                                    own.ctypes.data_as(C.POINTER(C.c_uint8)), cap, C.byref(n)))
+        return off, conn[: n.value], kind[: n.value], mask[: n.value], own[:nh]
+
     def handover_variants(self, handovers, full_masks, cap: int = 1 << 24):
         """The MessagePack of every requested (handover, full mask) pair (chd_handover_variants): list of bytes."""
         vh, vm = _u32(handovers), _u32(full_masks)

@@ -845,6 +845,39 @@ int chd_world_set_server_connections(chd_ctx *ctx, uint32_t n_servers, const uin
  * NOTIFIER'S cell pair (DST_NEW <=> not in src). */
 int chd_handover_recipients_ex(chd_ctx *ctx, uint32_t *offsets /* n_handovers+1 */, uint32_t *conn, uint8_t *kind,
                                uint32_t *full_mask, uint64_t cap, uint64_t *n_out);
+/* The ownership assumption behind full_mask's `dataAccessChanged` part: the DataAccess a connection holds on an entity channel is
+ * DERIVED — WRITE exactly for the connection chd_world_set_server_connections names as the spatial server of the cell that holds the
+ * entity, READ for every other connection — not the value stored in the subscription (subscription.go:44-57 compares the stored one).
+ * A client that subscribed to an entity channel with WRITE explicitly, or an entity channel owned by a connection that is not its cell's
+ * spatial server, diverges from the reference here; SURVEY 8c lists the Notify outputs as unpinned by anything the reference holds. */
+
+/* Step 1 of a CROSS-SERVER handover (spatial.go:683-700): `ownerConn := srcChannel.GetOwner(); ownerConn != nil && !ownerConn.IsClosing()
+ * && !ownerConn.HasInterestIn(dstChannelId)` -> ownerConn.UnsubscribeFromChannel(entityCh) + sendUnsubscribed, for every handover
+ * entity.  flags[h] (handover h of the LAST tick, as chd_handover_recipients) = 1 when a live subscriber slot holds the ConnectionId
+ * chd_world_set_server_connections names for src's server, src and dst belong to different servers, and dst is not among that
+ * connection's spatial subscriptions (subscription.go:181-187) as they were when the handover happened; else 0 (also when the
+ * owner's connection is not registered with chd_subs_add: the engine cannot know its interest).  Needs CHD_WORLD_HANDOVER_RECIPIENTS. */
+int chd_handover_src_owner_unsubscribed(chd_ctx *ctx, uint8_t *flags /* cap */, uint32_t cap, uint32_t *n_out);
+
+/* Region-sharded worlds (CHD_WORLD_HANDOVER_RECIPIENTS on every rank).  A handover's recipients are the connections subscribed to its
+ * src or dst cell: they live on the rank that owns the cell and on the neighbours whose halo it is in — the placement the fan-out
+ * already has.  Each rank detects the handovers of the entities it holds (chd_tick_fetch: handovers); the gateways gather the
+ * ranks' records into ONE whole-world list (rank order, the same on every rank: they exchange handover messages anyway) and every
+ * rank asks for ITS connections' share:
+ *   handovers[n_handovers]   the whole world's handover records of the LAST tick (host memory; records between cells beyond this
+ *                            rank's region + halo simply have no recipients here);
+ *   offsets / conn / kind / full_mask   as chd_handover_recipients_ex, for this rank's connections, evaluated on the subscriptions
+ *                            as they were at the START of the last tick (the library keeps that copy: Notify runs before the tick's
+ *                            interest updates).  full_mask: bit 0 only — every handover as its notifier alone; on a world with
+ *                            handover lists (chd_shard_set_handover_lists) pass NULL (CHD_E_STATE otherwise: the other members'
+ *                            cells are other ranks' state);
+ *   src_owner_unsubscribed[n_handovers]  (may be NULL) as chd_handover_src_owner_unsubscribed, for the src server's connection IF
+ *                            THIS RANK HOLDS IT (a spatial server's connection is registered on its own gateway): the gateway that
+ *                            reads 1 sends the unsubscribe; the union over the ranks is the single world's flag.
+ * The union of the ranks' lists is the single world's recipient list (tests/test_gpu_shard.py, 2 and 4 ranks against
+ * orc_world_recipients).  replaces: spatial.go:738-857 on a deployment of one channeld gateway per spatial server region. */
+int chd_shard_handover_recipients(chd_ctx *ctx, uint32_t n_handovers, const chd_handover_rec *handovers, uint32_t *offsets /* n_handovers+1 */,
+                                  uint32_t *conn, uint8_t *kind, uint32_t *full_mask, uint8_t *src_owner_unsubscribed, uint64_t cap, uint64_t *n_out);
 
 /* replaces: the connection merge of BroadcastType_ADJACENT_CHANNELS (message.go:188-239):
  * for request r the de-duplicated connections subscribed to spatial channel channel[r] or

@@ -100,6 +100,7 @@ typedef struct orc_world {
      * handover entity when Notify ran (ho_ent_before[32 h + q], W_INVALID = none) and how many entities the handover has */
     uint32_t *rcp_mask;
     uint32_t *ho_ent_before, *ho_ent_n; uint32_t cap_ho_ent;
+    uint8_t *ho_own_unsub; uint32_t cap_ho_own; /* per handover: step 1 unsubscribes the src spatial server (spatial.go:688-694) */
     int32_t *q_status; uint32_t nq_status;
     uint32_t n_locked_abort;
     uint64_t literal_mismatch;
@@ -197,7 +198,7 @@ orc_world *orc_world_new(const orc_grid *g, uint32_t n_entities, uint32_t n_subs
 static void orc__free_jobs(orc_world *w);
 
 void orc_world_free(orc_world *w) {
-    if (w) { free(w->rcp_ho); free(w->rcp_conn); free(w->rcp_kind); free(w->rcp_mask); free(w->ho_ent_before); free(w->ho_ent_n); }
+    if (w) { free(w->rcp_ho); free(w->rcp_conn); free(w->rcp_kind); free(w->rcp_mask); free(w->ho_ent_before); free(w->ho_ent_n); free(w->ho_own_unsub); }
     if (!w) return;
     for (uint32_t i = 0; i < w->N; i++) free(w->ebuf[i].v);
     for (uint32_t i = 0; i < w->C; i++) free(w->cbuf[i].v);
@@ -675,8 +676,27 @@ int orc_world_tick_arrivals(orc_world *w, orc_time t, uint32_t n_upd, const uint
      * data.  In the tick model the entity channel's subscribers are the subscribers of the cell that
      * held it, and its owner is that cell's spatial server — after step 1 of a cross-server handover
      * (:683-700, SetOwner(dstChannel.GetOwner()) for EVERY handover entity) the dst cell's. */
+    if (w->nho > w->cap_ho_own) {
+        w->cap_ho_own = w->nho + 256;
+        w->ho_own_unsub = (uint8_t *)realloc(w->ho_own_unsub, w->cap_ho_own);
+    }
     for (uint32_t h = 0; h < w->nho; h++) {
         uint32_t src = w->ho_src[h] - w->g.id_start, dst = w->ho_dst[h] - w->g.id_start;
+        /* step 1 of a CROSS-SERVER handover (spatial.go:683-700): `ownerConn := srcChannel.GetOwner(); ownerConn != nil &&
+         * !ownerConn.IsClosing() && !ownerConn.HasInterestIn(dstChannelId)` -> UnsubscribeFromChannel(entityCh) + sendUnsubscribed for
+         * every handover entity.  HasInterestIn = dst is among the connection's spatialSubscriptions (subscription.go:181-187).  The
+         * owner's connection is known where orc_world_set_server_conns named it AND it is registered as a subscriber. */
+        w->ho_own_unsub[h] = 0;
+        if (w->server_conn && w->server_of_cell[src] != w->server_of_cell[dst] && w->server_of_cell[src] < w->n_server_conn)
+            for (uint32_t s = 0; s < w->S; s++) {
+                if (!w->sub_alive[s] || w->conn_id[s] != w->server_conn[w->server_of_cell[src]]) continue;
+                int in_dst = 0;
+                const wpair *pp = &w->pairs[(size_t)s * w->capq];
+                for (uint32_t p = 0; p < w->pair_cnt[s]; p++)
+                    if (pp[p].cell == dst) in_dst = 1;
+                w->ho_own_unsub[h] = !in_dst;
+                break;
+            }
         for (uint32_t s = 0; s < w->S; s++) {
             if (!w->sub_alive[s]) continue;
             int in_src = 0, in_dst = 0;
@@ -939,6 +959,7 @@ void orc_world_handovers(const orc_world *w, uint32_t *ent, uint32_t *src, uint3
     memcpy(dst, w->ho_dst, 4 * w->nho); memcpy(srv_src, w->ho_srv_src, 4 * w->nho);
     memcpy(srv_dst, w->ho_srv_dst, 4 * w->nho);
 }
+void orc_world_handover_owner_unsubs(const orc_world *w, uint8_t *flags) { if (w->nho) memcpy(flags, w->ho_own_unsub, w->nho); }
 uint64_t orc_world_nrcp(const orc_world *w) { return w->nrcp; }
 void orc_world_recipient_masks(const orc_world *w, uint32_t *mask) { memcpy(mask, w->rcp_mask, 4 * w->nrcp); }
 void orc_world_recipients(const orc_world *w, uint32_t *ho, uint32_t *conn, uint8_t *kind) {

@@ -541,6 +541,16 @@ class World:
         f(self.h, _p(m, C.c_uint32))
         return m[:n]
 
+    def owner_unsubs(self):
+        """per handover of the last tick: 1 = step 1 of the cross-server handover unsubscribes the src spatial server's connection
+        from the handover entities' channels (it has no interest in dst; spatial.go:688-694)"""
+        n = int(lib().orc_world_nhandover(self.h))
+        f = lib().orc_world_handover_owner_unsubs
+        f.argtypes = [C.c_void_p, C.POINTER(C.c_uint8)]
+        a = np.zeros(max(n, 1), dtype=np.uint8)
+        f(self.h, _p(a, C.c_uint8))
+        return a[:n]
+
     def recipients(self):
         """(handover index, connection id, kind) of the last tick's handover messages."""
         n = int(lib().orc_world_nrcp(self.h))

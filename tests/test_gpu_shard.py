@@ -34,7 +34,7 @@ from shard_lists import make_lists, one_handover_per_group_and_tick  # noqa: E40
 
 
 def run_rank(rank, world, port, N, S, ticks, seed, out, cfg_name=None, halo=64, jump_frac=0.15, aoi_scale=1.0, lists=False, senders=False, exact=0,
-             pipe=False, wflags=0, wire=False, cellupd=False, despawn=False):
+             pipe=False, wflags=0, wire=False, cellupd=False, despawn=False, recipients=False):
     """exact != 0 (= the world's emit flags): exact update buffers on the sharded world — history_depth 1024, the update log by
     channel id on every rank (chd_world_cfg.shard_channels), per-update arrival stamps anywhere inside the tick's interval
     (chd_shard_set_update_arrivals), and three connections that lose access at tick 8 and get it back twelve ticks before the end:
@@ -47,7 +47,11 @@ def run_rank(rank, world, port, N, S, ticks, seed, out, cfg_name=None, halo=64, 
     cellupd: the spatial channels' own updates (three random cells per tick, alternating senders, one of them a client connection
     that then skips its own), the same list on every rank.
     despawn: after tick 3 every seventh entity channel leaves the world (chd_shard_despawn, every rank the same list); after tick 6
-    half of them come back where their channel's position now is (chd_shard_spawn on that rank, chd_shard_log_spawn everywhere)."""
+    half of them come back where their channel's position now is (chd_shard_spawn on that rank, chd_shard_log_spawn everywhere).
+    recipients: CHD_WORLD_HANDOVER_RECIPIENTS on every rank, one connection per region named as its spatial server's
+    (chd_world_set_server_connections); after every tick the ranks' handover records are gathered into the whole-world list, every
+    rank plans ITS connections' share (chd_shard_handover_recipients) and the union must be the single world's recipient list —
+    connections, kinds, full-data masks — and the src servers' step-1 unsubscriptions (spatial.go:688-694)."""
     import torch
     import torch.distributed as dist
 
@@ -70,6 +74,8 @@ def run_rank(rank, world, port, N, S, ticks, seed, out, cfg_name=None, halo=64, 
         owner = np.where(ids0 == 0, 0, server_of_cell(cfg, np.where(ids0 == 0, 0, ids0 - 0x10000)))
         mine = np.nonzero(owner == rank)[0]
         my_subs = np.nonzero(owner[:S] == rank)[0]
+        if recipients:
+            wflags |= 4
         eng = HipShardEngine(cfg, rank, world, N, max(len(my_subs), 1), migrate_cap=N, device=0, max_records=1 << 22,
                              **(dict(flags=exact | wflags, history_depth=1024, shard_channels=N) if exact else
                                 dict(flags=wflags | 8 | 1, shard_channels=N) if wire else dict(flags=wflags)))
@@ -98,6 +104,12 @@ def run_rank(rank, world, port, N, S, ticks, seed, out, cfg_name=None, halo=64, 
             for s in range(S):
                 ow.add_sub(s, int(sw.sub_conn[s]))
         total = cross = 0
+        n_rcp = n_own = n_changed = 0
+        if recipients:  # the first connection pinned to rank k stands for spatial server k's (0 where a region has none)
+            srv_conn = np.array([int(sw.sub_conn[np.nonzero(owner[:S] == k)[0][0]]) if (owner[:S] == k).any() else 0 for k in range(world)], dtype=np.uint32)
+            eng.sw.set_server_connections(srv_conn)
+            if ow is not None:
+                ow.set_server_connections(srv_conn)
         pay = None
         if wire:  # the same payloads on every rank, keyed by channel index / spatial channel id (the host has them anyway)
             from oracle import wire as owire
@@ -184,6 +196,15 @@ def run_rank(rank, world, port, N, S, ticks, seed, out, cfg_name=None, halo=64, 
                 dist.all_gather_object(gathered, state)
             else:
                 gathered = [state]
+            rcp_all = None
+            if recipients:
+                ho_all = np.concatenate([s["ho"] for s in gathered])
+                mine_rcp = eng.sw.shard_handover_recipients(ho_all)
+                if world > 1:
+                    rcp_all = [None] * world
+                    dist.all_gather_object(rcp_all, mine_rcp)
+                else:
+                    rcp_all = [mine_rcp]
             if exact and (k == 8 or k == ticks - 12):  # the blocked connections: on the rank that holds them, and in the single world
                 access = 0 if k == 8 else 1
                 for b in blocked:
@@ -238,6 +259,25 @@ def run_rank(rank, world, port, N, S, ticks, seed, out, cfg_name=None, halo=64, 
             for f, want in (("src", src), ("dst", dst), ("src_server", ssrc), ("dst_server", sdst)):
                 assert np.array_equal(ho[f][o1], want[o2]), f"tick {k}: handover {f}"
             assert sum(s["locked"] for s in gathered) == ow.locked_aborts()
+            if recipients:
+                oh, oconn, okind = ow.recipients()
+                omask, oown = ow.recipient_masks(), ow.owner_unsubs()
+                want = {}
+                for h, c, kd, mk in zip(oh.tolist(), oconn.tolist(), okind.tolist(), omask.tolist()):
+                    want.setdefault(int(sw.chan_id[ent[h]]), []).append((c, kd, mk))
+                want_own = {int(sw.chan_id[ent[h]]): int(oown[h]) for h in range(len(ent))}
+                for h in range(len(ho)):
+                    got, own = [], 0
+                    for (off, conn, kind, mask, ownf) in rcp_all:
+                        a, b = int(off[h]), int(off[h + 1])
+                        got += list(zip(conn[a:b].tolist(), kind[a:b].tolist(), mask[a:b].tolist()))
+                        own += int(ownf[h])
+                    chn = int(ho["channel"][h])
+                    assert sorted(got) == sorted(want.get(chn, [])), f"tick {k}: recipients of the handover of channel {chn:#x}: {sorted(got)} vs {sorted(want.get(chn, []))}"
+                    assert own == want_own[chn], f"tick {k}: src_owner_unsubscribed of the handover of channel {chn:#x}"
+                    n_rcp += len(got)
+                    n_own += own
+                    n_changed += sum(1 for g_ in got if g_[1] == 2 and g_[2])
             us, uc = ow.unsubs()
             gu = canon(np.concatenate([s["unsub"][0] for s in gathered]), np.concatenate([s["unsub"][1] for s in gathered]))
             assert np.array_equal(gu, canon(sw.sub_conn[us], uc)), f"tick {k}: unsubs"
@@ -263,7 +303,7 @@ def run_rank(rank, world, port, N, S, ticks, seed, out, cfg_name=None, halo=64, 
                 else:
                     ow.spawn(back, sw.chan_id[back], x[back], z[back], sw.flags[back], sw.sender[back])
         if rank == 0:
-            out.put(("ok", total, cross))
+            out.put(("ok", total, (cross, n_rcp, n_own, n_changed) if recipients else cross))
     except Exception as e:
         import traceback
 
@@ -275,13 +315,13 @@ def run_rank(rank, world, port, N, S, ticks, seed, out, cfg_name=None, halo=64, 
 
 
 def launch(world, N, S, ticks, seed, cfg_name=None, halo=64, jump_frac=0.15, aoi_scale=1.0, lists=False, senders=False, exact=0, timeout=300, pipe=False, wflags=0,
-           wire=False, cellupd=False, despawn=False):
+           wire=False, cellupd=False, despawn=False, recipients=False):
     import torch.multiprocessing as mp
 
     ctx = mp.get_context("spawn")
     out = ctx.Queue()
     port = free_port()
-    procs = [ctx.Process(target=run_rank, args=(r, world, port, N, S, ticks, seed, out, cfg_name, halo, jump_frac, aoi_scale, lists, senders, exact, pipe, wflags, wire, cellupd, despawn)) for r in range(world)]
+    procs = [ctx.Process(target=run_rank, args=(r, world, port, N, S, ticks, seed, out, cfg_name, halo, jump_frac, aoi_scale, lists, senders, exact, pipe, wflags, wire, cellupd, despawn, recipients)) for r in range(world)]
     for p in procs:
         p.start()
     for p in procs:
@@ -398,6 +438,18 @@ def test_spatial_channels_own_updates_on_sharded_worlds(world, kw):
     own update), on exact worlds with arrival stamps: records equal the single-world oracle's fed the same list."""
     total, cross = launch(world, 3000, 80, 10, 0xC0FFEE90 + world, cellupd=True, timeout=600, **kw)
     assert total > 0 and cross > 0
+
+
+@pytest.mark.parametrize("world,kw", [(2, dict()), (4, dict()), (2, dict(exact=1 | 64)), (4, dict(pipe=True))], ids=["2-ranks", "4-ranks", "2-ranks-exact", "4-ranks-native-tick"])
+def test_handover_recipients_on_region_sharded_worlds(world, kw):
+    """VERDICT r5 #6 (f2 on sharded worlds): chd_shard_handover_recipients.  A handover's recipients are the connections subscribed to
+    its src or dst cell — on the rank that owns the cell and on the neighbours whose halo it is in; every rank plans its own
+    connections' share of the whole-world handover list on the subscriptions as they were at the tick's start, and the union over
+    the ranks equals orc_world_recipients of the single world: connection, kind, full-data bit (new to the entity channel, or its
+    DataAccess changes: the spatial servers' connections on cross-server handovers), plus the src server's step-1 unsubscription
+    (spatial.go:688-694) on the rank that holds its connection."""
+    total, (cross, n_rcp, n_own, n_changed) = launch(world, 2400, 160, 10, 0xC0FFEE71 + world, recipients=True, **kw)
+    assert total > 0 and cross > 30 and n_rcp > 2000 and n_own > 5 and n_changed > 0, (total, cross, n_rcp, n_own, n_changed)
 
 
 @pytest.mark.parametrize("world,kw", [(1, dict()), (2, dict()), (2, dict(exact=1 | 64))], ids=["1-rank", "2-ranks", "2-ranks-exact"])

@@ -107,7 +107,16 @@ def test_oracle_handover_full_data_when_the_merge_changes_data_access():
     handover_to(4, 60_000_000)  # back
     ow.set_server_connections(server_conns)
     assert handover_to(5, 80_000_000) == (3, 4, [(77, 2, 0), (903, 2, 1), (904, 2, 1)])   # cross-server: both servers' access changes
+    assert ow.owner_unsubs().tolist() == [0]  # 903 reads (5,7): the src server keeps its subscription to the entity channel
     assert handover_to(6, 100_000_000) == (4, 4, [(77, 2, 0), (903, 0, 0), (904, 2, 0)])   # same server: nothing changes (903 only sees src)
+    assert ow.owner_unsubs().tolist() == [0]
+    # step 1 of the cross-server handover (spatial.go:688-694): the src server's connection is unsubscribed from the entity channel
+    # when it has no interest in dst — 904 reads (4,7), 903 does not see (6,7)
+    assert handover_to(4, 120_000_000)[:2] == (4, 3) and ow.owner_unsubs().tolist() == [0]
+    assert handover_to(6, 140_000_000)[:2] == (3, 4) and ow.owner_unsubs().tolist() == [1]
+    ow.set_server_connections([])
+    handover_to(4, 160_000_000)
+    assert handover_to(6, 180_000_000)[:2] == (3, 4) and ow.owner_unsubs().tolist() == [0]  # nobody is known as an owner
 
 
 @pytest.fixture(scope="module")
@@ -178,6 +187,12 @@ def run_recipients(amd, cfg, N, S, ticks, seed, flags=4, aoi_scale=1.0, capq=0, 
         kinds.update(kind.tolist())
         if servers:  # a connection that KNEW src and still gets full data: only a changed DataAccess does that
             run_recipients.access_only = getattr(run_recipients, "access_only", 0) + int(((kind == 2) & (mask != 0)).sum())
+            # step 1's unsubscription of the src server (spatial.go:688-694), handover by handover
+            own, oown = gw.handover_src_owner_unsubscribed(len(res.handovers)), ow.owner_unsubs()
+            want_own = {int(ent[h]): int(oown[h]) for h in range(len(ent))}
+            assert [int(v) for v in own] == [want_own[int(e)] for e in res.handovers["entity"]], f"tick {k}: src_owner_unsubscribed"
+            run_recipients.own_unsubs = getattr(run_recipients, "own_unsubs", 0) + int(own.sum())
+            run_recipients.own_kept = getattr(run_recipients, "own_kept", 0) + int(((res.handovers["src_server"] != res.handovers["dst_server"]) & (own == 0)).sum())
         # ---- adjacent broadcast ----
         ncell = g.cols * g.rows
         chans = (0x10000 + rng.integers(0, ncell, 12)).astype(np.uint32)
@@ -220,14 +235,22 @@ def test_gpu_handover_full_data_when_the_merge_changes_data_access(amd):
     handover_to(4, 60_000_000)
     gw.set_server_connections(server_conns)
     assert handover_to(5, 80_000_000) == [(77, 2, 0), (903, 2, 1), (904, 2, 1)]
+    assert gw.handover_src_owner_unsubscribed(1).tolist() == [0]
     assert handover_to(6, 100_000_000) == [(77, 2, 0), (903, 0, 0), (904, 2, 0)]
+    assert gw.handover_src_owner_unsubscribed(1).tolist() == [0]
+    handover_to(4, 120_000_000)  # server 4 -> 3: 904 reads (4,7)
+    assert gw.handover_src_owner_unsubscribed(1).tolist() == [0]
+    handover_to(6, 140_000_000)  # server 3 -> 4: 903 does not see (6,7) (spatial.go:688-694)
+    assert gw.handover_src_owner_unsubscribed(1).tolist() == [1]
     gw.set_server_connections([])
-    handover_to(4, 120_000_000)
-    assert handover_to(5, 140_000_000) == [(77, 2, 0), (903, 2, 0), (904, 2, 0)]
+    handover_to(4, 160_000_000)
+    assert handover_to(5, 180_000_000) == [(77, 2, 0), (903, 2, 0), (904, 2, 0)]
+    assert gw.handover_src_owner_unsubscribed(1).tolist() == [0]
     ctl.close()
     # (ServerInterestBorderSize 1: every server also reads the rows of its neighbours' regions along its borders)
     n_rcp, _, kinds = run_recipients(amd, dict(cfg, ServerInterestBorderSize=1), 3000, 300, 8, 0xC0FFEE35, servers=True)
     assert n_rcp > 1000 and kinds == {0, 1, 2} and run_recipients.access_only > 20, run_recipients.access_only
+    assert run_recipients.own_unsubs > 20 and run_recipients.own_kept > 20, (run_recipients.own_unsubs, run_recipients.own_kept)
     cfg8 = dict(synth.load_config("spatial_static_8x8.json"), ServerInterestBorderSize=1)
     n_rcp, _, kinds = run_recipients(amd, cfg8, 2000, 200, 6, 0xC0FFEE36, flags=4 | 2, aoi_scale=0.5, servers=True)
     assert n_rcp > 500
