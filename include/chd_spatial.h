@@ -874,8 +874,8 @@ int chd_handover_src_owner_unsubscribed(chd_ctx *ctx, uint8_t *flags /* cap */, 
  *   src_owner_unsubscribed[n_handovers]  (may be NULL) as chd_handover_src_owner_unsubscribed, for the src server's connection IF
  *                            THIS RANK HOLDS IT (a spatial server's connection is registered on its own gateway): the gateway that
  *                            reads 1 sends the unsubscribe; the union over the ranks is the single world's flag.
- * The union of the ranks' lists is the single world's recipient list (tests/test_gpu_shard.py, 2 and 4 ranks against
- * orc_world_recipients).  replaces: spatial.go:738-857 on a deployment of one channeld gateway per spatial server region. */
+ * The union of the ranks' lists is the single world's recipient list (tests/test_gpu_shard.py: 2 and 4 ranks against the
+ * single-world CPU restatement).  replaces: spatial.go:738-857 on a deployment of one channeld gateway per spatial server region. */
 int chd_shard_handover_recipients(chd_ctx *ctx, uint32_t n_handovers, const chd_handover_rec *handovers, uint32_t *offsets /* n_handovers+1 */,
                                   uint32_t *conn, uint8_t *kind, uint32_t *full_mask, uint8_t *src_owner_unsubscribed, uint64_t cap, uint64_t *n_out);
 
