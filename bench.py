@@ -559,12 +559,12 @@ def main():
     assert err is None, err
     world_flags = {"auto": 0, "conn-major": 1, "cell-major": 2}[args.emit] | (4 if args.recipients else 0) | (8 if args.wire else 0) | (16 if args.overlap_interest else 0) | (32 if args.update_masks else 0) | (256 if args.overlap_deferred else 0) | (512 if args.overlap_interest and args.gated_overlap else 0)
     # successive ticks pipelined over two streams (include/chd_spatial.h: CHD_WORLD_PIPELINE_TICKS) where the descriptor emit runs
-    pipe = not args.serial_ticks and args.emit != "cell-major" and not args.wire and not args.update_masks and S >= 4096 and not args.arrival_jitter
+    pipe = not args.serial_ticks and args.emit != "cell-major" and not args.wire and not args.update_masks and S >= 4096 and (not args.arrival_jitter or args.headline == "pipelined")
     if pipe:
         world_flags |= 128
     jitter = bool(args.arrival_jitter)
-    if jitter:
-        pipe = False  # (exact update buffers: serial schedule only)
+    if jitter and args.headline != "pipelined":
+        pipe = False  # (exact update buffers: the serial schedule unless the pipelined one is asked for as the timed workload — profiles)
         world_flags &= ~128
     world = A.SpatialWorld(ctl, N, S, flags=world_flags, history_depth=1024 if jitter else 0)
     if pipe:
@@ -1000,7 +1000,7 @@ def flat_interval_line(A, synth, cfg, N, S, seed, args, local_rank, interval_ms,
             "emit_us": emit_us, "emit_frac_of_hbm_peak": BYTES_PER_MSG * float(np.mean([h["n_records"] for h in timed])) / (emit_us * 1e-6) / 1e9 / HBM_PEAK_GBS}
 
 
-def arrival_jitter_line(A, synth, cfg, N, S, seed, args, local_rank, tick_jitter_us, warm=10, steps=40, check=16):
+def arrival_jitter_line(A, synth, cfg, N, S, seed, args, local_rank, tick_jitter_us, warm=10, steps=40, check=16, pipelined=None):
     """The headline workload with the reference's REAL arrival stamps: every update stamped at its enqueue time
     (channel.go:296-310; synth.ArrivalJitter), a world with exact update buffers (history_depth 1024).  warm + steps ticks
     device-resident and timed like the headline, then `check` synchronous ticks whose record digests are compared with the
@@ -1010,7 +1010,15 @@ def arrival_jitter_line(A, synth, cfg, N, S, seed, args, local_rank, tick_jitter
     ctl = A.StaticGrid2DSpatialController(device=local_rank)
     assert ctl.LoadConfig(json.dumps(cfg).encode(), strict=False) is None
     sw = synth.SynthWorld(synth.WorldSpec(cfg, N, S, seed, tick_ms=args.tick_ms, aoi_scale=args.aoi_scale))
-    w = A.SpatialWorld(ctl, N, S, max_records=400_000_000, history_depth=1024, flags=(16 if args.overlap_interest else 0) | (512 if args.overlap_interest and args.gated_overlap else 0))
+    if pipelined is None:  # the serial line, and the pipelined schedule of the same world as a sub-object
+        pipelined = False
+        want_pipe = not args.serial_ticks and S >= 4096
+    else:
+        want_pipe = False
+    w = A.SpatialWorld(ctl, N, S, max_records=400_000_000, history_depth=1024,
+                       flags=128 if pipelined else (16 if args.overlap_interest else 0) | (512 if args.overlap_interest and args.gated_overlap else 0))
+    if pipelined:
+        w.set_pipelining(True)  # (raises where the world's shape does not pipeline)
     w.spawn(None, sw.chan_id, sw.x, sw.z, sw.flags, sw.sender)
     w.add_subscribers(None, sw.sub_conn)
     T = warm + steps + check
@@ -1059,8 +1067,19 @@ def arrival_jitter_line(A, synth, cfg, N, S, seed, args, local_rank, tick_jitter
                                  f"{[cnt, dsum, dxor]} != the oracle's {golden[str(t + 1)]} ({os.path.basename(gpath)})")
             checked += 1
     ctl.close()
-    return {"what": "the headline workload with every update stamped at its ENQUEUE time — uniform inside its tick interval, as Channel.PutMessage "
-                    "stamps them (channel.go:296-310) — on a world with exact update buffers (history_depth 1024); serial schedule"
+    sub = None
+    if want_pipe:
+        try:
+            sub = arrival_jitter_line(A, synth, cfg, N, S, seed, args, local_rank, tick_jitter_us, warm, steps, check, pipelined=True)
+            sub = {k: sub[k] for k in ("value", "unit", "steps", "ms_per_step", "msgs_per_tick", "record_kernels_us", "record_kernels_frac_of_hbm_peak",
+                                       "filtered_msgs_per_tick", "element_walk_msgs_per_tick", "history_overflow", "digest_checked_ticks")}
+            sub["what"] = ("CHD_WORLD_PIPELINE_TICKS on the same world: tick t's record kernels beside tick t+1's stages (what the filtered kernel reads exists "
+                           "once per tick parity); the same digest check behind the timed region")
+        except Exception as ex:  # noqa: BLE001
+            sub = {"error": f"{type(ex).__name__}: {ex}"}
+    return {**({"pipelined_schedule": sub} if sub is not None else {}),
+            "what": "the headline workload with every update stamped at its ENQUEUE time — uniform inside its tick interval, as Channel.PutMessage "
+                    "stamps them (channel.go:296-310) — on a world with exact update buffers (history_depth 1024); " + ("ticks pipelined" if pipelined else "serial schedule")
                     + (f"; tick times off the 50 ms grid by up to +-{tick_jitter_us} us, so every subscription's fan-out phase is off the grid too and "
                        "every window cuts through a tick's arrivals" if tick_jitter_us else "; tick times on the 50 ms grid"),
             "value": msgs / el, "unit": "msgs/s", "steps": steps, "ms_per_step": 1e3 * el / steps, "msgs_per_tick": msgs / steps,

@@ -151,6 +151,15 @@ struct World {
     uint64_t *pb_rec_ub[2] = {nullptr, nullptr};
     uint4 *pb_seg_desc[2] = {nullptr, nullptr}, *pb_seg_desc2[2] = {nullptr, nullptr};
     chd_fanout_rec *pb_recs[2] = {nullptr, nullptr};
+    // ... and on worlds with exact update buffers (WorldDev::off_on): what k_fanout_emit_filt_cm(t) reads or writes while the stages
+    // of tick t+1 rebuild it — the cells' compact entries and offset columns, the filtered descriptors' lists, items and windows, the
+    // per-subscription and per-connection record counts
+    bool pipe_exact = false;
+    uint2 *pb_ce8[2] = {nullptr, nullptr};
+    uint32_t *pb_ce_off[2] = {nullptr, nullptr}, *pb_cell_sorted[2] = {nullptr, nullptr}, *pb_filt_nitems[2] = {nullptr, nullptr};
+    uint32_t *pb_pair_nrec[2] = {nullptr, nullptr}, *pb_rec_cnt[2] = {nullptr, nullptr};
+    uint4 *pb_cell_flist[2] = {nullptr, nullptr}, *pb_filt_items[2] = {nullptr, nullptr};
+    FiltWin *pb_filt_win[2] = {nullptr, nullptr};
     hipEvent_t ev_stages_done = nullptr, ev_stages_all = nullptr, ev_rec_sync = nullptr, ev_emit_done[2] = {nullptr, nullptr};
     bool last_desc = false;            // the last tick took the descriptor path (k_fanout_plan_seg's descriptors are this tick's)
     uint32_t *seg_cnt = nullptr;       // [S + 1] chd_tick_fetch_segments: segments per connection -> offsets
@@ -1038,7 +1047,9 @@ static EmitForm select_emit_form(uint64_t N, uint64_t S, uint64_t C, uint32_t fl
     else if (masks && (flags & CHD_WORLD_CELL_MAJOR_EMIT)) f.refusal = "CHD_WORLD_UPDATE_MASKS is implemented by the connection-major emit only";
     f.cm_emit = f.cm_possible && cm_wanted && !masks;
     f.off_on = history_depth && !f.cm_emit && !masks && !wire && desc_geometry && C <= 4096;
-    f.pipe = (flags & CHD_WORLD_PIPELINE_TICKS) && !f.cm_emit && !masks && !wire && !history_depth && desc_geometry;
+    // (exact update buffers: where the sub-tick offsets AND the cell-major filtered kernel exist — what that kernel reads beside the
+    // next tick's stages then exists once per tick parity too, chd_world_create)
+    f.pipe = (flags & CHD_WORLD_PIPELINE_TICKS) && !f.cm_emit && !masks && !wire && desc_geometry && (!history_depth || (f.off_on && C * S <= (1ull << 25)));
     return f;
 }
 
@@ -1327,6 +1338,22 @@ int chd_world_create(chd_ctx *ctx, const chd_world_cfg *cfg) {
             }
         }
         d.prev_ns = -1;
+        if (W.pipe_alloc && !(d.off_on && d.fcm_on)) W.pipe_alloc = W.pipe_on = false;  // (CHD_ARRIVAL_OFFSETS=0 / CHD_FILT_CELL_MAJOR=0: A/B runs)
+        if (W.pipe_alloc) {
+            W.pipe_exact = true;
+            W.pb_ce8[0] = d.ce8; W.pb_ce_off[0] = d.ce_off; W.pb_cell_sorted[0] = d.cell_sorted; W.pb_filt_nitems[0] = d.filt_nitems;
+            W.pb_pair_nrec[0] = d.pair_nrec; W.pb_rec_cnt[0] = d.rec_cnt; W.pb_cell_flist[0] = d.cell_flist; W.pb_filt_items[0] = d.filt_items;
+            W.pb_filt_win[0] = d.filt_win;
+            TRY(walloc(ctx, &W.pb_ce8[1], N + 520));
+            TRY(walloc(ctx, &W.pb_ce_off[1], (size_t)CHD_OFF_SLOTS * d.off_stride + 520));
+            TRY(walloc(ctx, &W.pb_cell_sorted[1], C));
+            TRY(walloc(ctx, &W.pb_filt_nitems[1], 32));
+            TRY(walloc(ctx, &W.pb_pair_nrec[1], P));
+            TRY(walloc(ctx, &W.pb_rec_cnt[1], S));
+            TRY(walloc(ctx, &W.pb_cell_flist[1], 2 * C * S, false));
+            TRY(walloc(ctx, &W.pb_filt_items[1], P / 16 + C + 1, false));
+            TRY(walloc(ctx, &W.pb_filt_win[1], P * CHD_FILT_WINS, false));
+        }
     }
     if (W.wire) {
         WireDev &x = W.x;
@@ -1778,6 +1805,7 @@ static int tick_locked(chd_ctx *ctx, const chd_tick_in *in) {
         if (!fanout_seg_path(d)) return fail(ctx, CHD_E_STATE, "tick: CHD_EMIT_PIPELINED=0 on a world that keeps arrival offsets (set CHD_ARRIVAL_OFFSETS=0 as well)");
     }
     const bool pipe = W.pipe_on && fanout_seg_path(d);
+    d.late_tot = (pipe && d.off_on) ? 1u : 0u;  // (the filtered kernel's count reaches the tick's row by k_filt_fold: the epilogue runs beside it)
     W.last_desc = fanout_seg_path(d);
     hipStream_t st = ctx->stream;
     hipStream_t bs = pipe ? ctx->aux_stream : st;
@@ -1785,6 +1813,11 @@ static int tick_locked(chd_ctx *ctx, const chd_tick_in *in) {
     if (pipe) {
         d.n_simple = W.pb_n_simple[par]; d.rec_ub = W.pb_rec_ub[par]; d.seg_desc = W.pb_seg_desc[par];
         d.seg_desc2 = W.pb_seg_desc2[par]; d.ce_chan = W.pb_ce_chan[par]; d.recs = W.pb_recs[par]; d.emit_ticket = W.pb_ticket[par];
+        if (W.pipe_exact) {
+            d.ce8 = W.pb_ce8[par]; d.ce_off = W.pb_ce_off[par]; d.cell_sorted = W.pb_cell_sorted[par]; d.filt_nitems = W.pb_filt_nitems[par];
+            d.pair_nrec = W.pb_pair_nrec[par]; d.rec_cnt = W.pb_rec_cnt[par]; d.cell_flist = W.pb_cell_flist[par]; d.filt_items = W.pb_filt_items[par];
+            d.filt_win = W.pb_filt_win[par];
+        }
         if (chained) HIPCHK(hipStreamWaitEvent(bs, W.ev_emit_done[par], 0));
         else {  // something else was enqueued on `stream` since the last tick (or this is the first one): after all of it
             HIPCHK(hipEventRecord(W.ev_rec_sync, st));
@@ -1881,7 +1914,9 @@ static int tick_locked(chd_ctx *ctx, const chd_tick_in *in) {
         HIPCHK(hipStreamWaitEvent(st, W.ev_stages_done, 0));
         if (prof) HIPCHK(hipEventRecord(ev[CHD_N_STAGES + 4], st));
         launch_fanout_emit_main(st, ctx->g, d, in->now_ns, r);
-        if (prof) HIPCHK(hipEventRecord(ev[CHD_N_STAGES + 3], st));
+        if (prof && !d.off_on) HIPCHK(hipEventRecord(ev[CHD_N_STAGES + 3], st));
+        launch_fanout_emit_filt(st, ctx->g, d);
+        if (prof && d.off_on) HIPCHK(hipEventRecord(ev[CHD_N_STAGES + 3], st));  // (emit_main_us: both record-writing kernels)
         if (prof_ends) HIPCHK(hipEventRecord(ev[5], st));
         HIPCHK(hipEventRecord(W.ev_emit_done[par], st));
         if (W.gated) launch_fanout_tail(bs, ctx->g, d, in->now_ns, r, r.cur_tick % TICK_RING, W.gate + GATE_EPI, ++W.gate_epi);
@@ -1890,6 +1925,7 @@ static int tick_locked(chd_ctx *ctx, const chd_tick_in *in) {
         // ... and whatever is enqueued on `stream` after this tick comes after ALL of it
         HIPCHK(hipEventRecord(W.ev_stages_all, bs));
         HIPCHK(hipStreamWaitEvent(st, W.ev_stages_all, 0));
+        if (d.late_tot) launch_filt_fold(st, d, r.cur_tick % TICK_RING);  // (behind the epilogue, which wrote the row, and the filtered kernel)
     } else if (W.overlap_deferred && fanout_seg_path(d) && !d.deep_depth) {
         // CHD_WORLD_OVERLAP_DEFERRED: the filtering launch (the subscriptions the plan deferred + the state commit) and the epilogue
         // on the second stream, beside the record kernel — the pair a pipelined tick already runs side by side: the record kernel

@@ -141,6 +141,7 @@ struct WorldDev {
     uint4 *cell_flist;
     uint4 *filt_items;
     uint32_t *filt_nitems;
+    uint32_t late_tot;      // pipelined ticks on off_on worlds: k_fanout_emit_filt_cm counts into tot64[..][8], k_filt_fold adds that to the tick's row
     // cell index (rebuilt every tick)
     uint32_t nblk;        // histogram blocks
     uint32_t *blk_cnt;    // [ncell*nblk + 1] counts -> exclusive scan (cell-major)
@@ -637,6 +638,7 @@ void launch_fanout_tail(hipStream_t st, DevGrid g, WorldDev w, int64_t now_ns, T
                         unsigned long long epi_seq = 0);
 // the filtered descriptors (WorldDev::filt_*); no-op unless off_on
 void launch_fanout_emit_filt(hipStream_t st, DevGrid g, WorldDev w);
+void launch_filt_fold(hipStream_t st, WorldDev w, uint32_t ring_slot);
 // per cell and ring slot the range of the sub-tick offsets (WorldDev::cell_orng); after the index build, off_on worlds only
 void launch_cell_offsets(hipStream_t st, DevGrid g, WorldDev w);
 #define TICK_RING 1024

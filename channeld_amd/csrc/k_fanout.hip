@@ -2413,11 +2413,35 @@ __global__ void __launch_bounds__(64 * FC_WAVES, FC_OCC) k_fanout_emit_filt_cm(D
     }
     if (lane == 0 && wave_sum) {
         unsigned long long *slot = (unsigned long long *)&w.tot64[(size_t)((blockIdx.x * FC_WAVES + wave) & 63u) * 16];
-        atomicAdd(slot, wave_sum);
-        atomicAdd(slot + 2, wave_sum);  // (not written by the dominant emit kernel)
-        atomicAdd(slot + 4, wave_sum);  // (chd_tick_stats.n_filtered_records)
+        if (w.late_tot) atomicAdd(slot + 8, wave_sum);  // (pipelined: the epilogue runs beside this kernel — k_filt_fold)
+        else {
+            atomicAdd(slot, wave_sum);
+            atomicAdd(slot + 2, wave_sum);  // (not written by the dominant emit kernel)
+            atomicAdd(slot + 4, wave_sum);  // (chd_tick_stats.n_filtered_records)
+        }
     }
 }
+
+// Pipelined ticks on worlds with sub-tick offsets: the filtered kernel's record count joins the tick's row of the history ring — total,
+// deferred share, filtered share, as the epilogue would have written them had it run behind that kernel (serial schedule)
+__global__ void __launch_bounds__(64) k_filt_fold(WorldDev w, uint32_t slot) {
+    const uint32_t lane = threadIdx.x;
+    unsigned long long v = w.tot64[(size_t)lane * 16 + 8];
+    w.tot64[(size_t)lane * 16 + 8] = 0;
+    for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d);
+    if (lane == 0 && v) {
+        uint64_t *r = w.tick_ring + (size_t)slot * 8;
+        auto hi_add = [](uint64_t x, unsigned long long a) {
+            const unsigned long long h = (x >> 32) + a;
+            return (x & 0xFFFFFFFFull) | ((h > 0xFFFFFFFFull ? 0xFFFFFFFFull : h) << 32);
+        };
+        r[0] += v;
+        r[3] = hi_add(r[3], v);
+        r[6] = hi_add(r[6], v);
+    }
+}
+
+void launch_filt_fold(hipStream_t st, WorldDev w, uint32_t ring_slot) { hipLaunchKernelGGL(k_filt_fold, dim3(1), dim3(64), 0, st, w, ring_slot); }
 
 void launch_fanout_emit_filt(hipStream_t st, DevGrid g, WorldDev w) {
     if (!w.S || !w.off_on || !seg_path(w)) return;

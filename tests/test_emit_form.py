@@ -27,7 +27,9 @@ TABLE = [
     ((100_000, 10_000, 225, 0, 0), 0),
     ((100_000, 10_000, 225, 0, 1024), S_OFFSETS),
     ((100_000, 10_000, 225, PIPE, 0), S_PIPE),
-    ((100_000, 10_000, 225, PIPE, 1024), S_OFFSETS),          # no pipelining with exact buffers
+    ((100_000, 10_000, 225, PIPE, 1024), S_OFFSETS | S_PIPE),  # exact buffers pipeline where the cell-major filtered kernel exists (round 6)
+    ((1_000_000, 100_000, 1024, PIPE, 1024), S_OFFSETS),       # ... cells x subscribers beyond 2^25: its per-cell lists do not exist, serial
+    ((100_000, 10_000, 225, PIPE | MASKS, 1024), 0),
     # BASELINE config C: 4.4 K entities per cell — cell-major, UNLESS the world keeps exact buffers (the 70 x cliff of round 5)
     ((1_000_000, 10_000, 225, 0, 0), S_CELL_MAJOR),
     ((1_000_000, 10_000, 225, 0, 1024), S_OFFSETS),

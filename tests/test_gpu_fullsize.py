@@ -496,6 +496,77 @@ def test_config_b_arrival_stamps_at_enqueue_time_record_digests(amd, tick_jitter
     assert filt > (0.4 * total if tick_jitter_us else 0.01 * total), (filt, total)
 
 
+@pytest.mark.parametrize("tick_jitter_us", [0, 3000], ids=["ticks-on-grid", "ticks-off-grid"])
+def test_config_b_pipelined_ticks_on_exact_update_buffers_match_the_oracle(amd, tick_jitter_us):
+    """CHD_WORLD_PIPELINE_TICKS on a world with exact update buffers and enqueue-time stamps.  Tick t's record kernels
+    (k_fanout_emit_seg + k_fanout_emit_filt_cm) run beside tick t+1's stages; what the filtered kernel reads or writes meanwhile —
+    the cells' compact entries and offset columns, the filtered descriptors' lists / items / windows, the per-subscription and
+    per-connection record counts — exists once per tick parity, and its record count joins the tick's row behind the epilogue
+    (k_filt_fold).  Groups of back-to-back chd_tick_device calls: the group's LAST tick against the oracle in full (every
+    connection's digest, handovers, unsubs, state), every tick of the group by its counts from the history ring (records — the
+    filtered ones included —, handovers, unsubs), history_overflow 0, no element walk; then the schedule switched off and on
+    again on the same world."""
+    N, S, seed, groups, per_group = 100_000, 10_000, 0xC0FFEE25, 5, 3
+    cfg = synth.load_config("spatial_static_benchmark.json")
+    sw = synth.SynthWorld(synth.WorldSpec(cfg, N, S, seed))
+    ctl = amd.StaticGrid2DSpatialController()
+    assert ctl.LoadConfig(json.dumps(cfg).encode(), strict=False) is None
+    w = amd.SpatialWorld(ctl, N, S, max_records=200_000_000, history_depth=1024, flags=128)
+    assert w.stats()["schedule"] & 16 and w.stats()["schedule"] & 4, w.stats()["schedule"]  # arrival offsets, pipelined
+    w.spawn(None, sw.chan_id, sw.x, sw.z, sw.flags, sw.sender)
+    w.add_subscribers(None, sw.sub_conn)
+    ow = oracle_world(cfg, sw, N, S, w.capq)
+    ow.set_sorted_walk(True)
+    rng = np.random.default_rng(seed)
+    prev = total = filt = k = 0
+
+    def frame():
+        nonlocal prev
+        sw.step()
+        now = sw.now_ns() + (int(rng.integers(-tick_jitter_us, tick_jitter_us + 1)) * 1000 + int(rng.integers(0, 1000)) if tick_jitter_us else 0)
+        arr = now - rng.integers(0, now - prev, N)  # in (prev, now]
+        prev = now
+        return now, arr, sw.queries()
+
+    for g in range(groups):
+        xs = np.empty((per_group, N)); zs = np.empty((per_group, N)); qs = np.empty((per_group, S), dtype=synth.AOI_DTYPE)
+        arrs = np.empty((per_group, N), dtype=np.int64)
+        nows, want = [], []
+        for t in range(per_group):
+            now, arrs[t], qs[t] = frame()
+            xs[t], zs[t] = sw.x, sw.z
+            nows.append(now)
+            ow.tick(now, None, sw.x, sw.z, None, None, None, None, qs[t], upd_arrival=arrs[t])
+            want.append((ow.digest()[0][0], len(ow.handovers()[0]), len(ow.unsubs()[0])))
+        dx, dz, dq, da = w.device_array(xs), w.device_array(zs), w.device_array(qs), w.device_array(arrs)
+        w.sync()
+        for t in range(per_group):  # back to back: every call after the first is chained to a pipelined tick
+            w.tick_device(nows[t], n_updates=N, d_upd_x=dx.at(t * N * 8), d_upd_z=dz.at(t * N * 8), n_queries=S, d_queries=dq.at(t * S * 128),
+                          d_upd_arrival=da.at(t * N * 8))
+        res = w.fetch(want_records=False)
+        assert res.history_overflow == 0
+        compare_tick(k + per_group - 1, w, ow, res, sw)
+        hist = w.history(per_group)
+        got = [(h["n_records"], h["n_handovers"], h["n_unsubs"]) for h in hist]
+        assert got == want, f"group {g}: per-tick counts {got} != oracle {want}"
+        assert all(h["n_deep_records"] == 0 for h in hist)
+        filt += sum(h["n_filtered_records"] for h in hist)
+        total += sum(c for c, _, _ in want)
+        k += per_group
+        for a in (dx, dz, dq, da):
+            a.free()
+    assert not ow.unsorted() and total > 500_000_000 and filt > (0.4 * total if tick_jitter_us else 0.01 * total), (total, filt)
+    for on in (False, True):  # the serial schedule continues from the same state, and back (single ticks, never chained)
+        w.set_pipelining(on)
+        for _ in range(2):
+            now, arr, q = frame()
+            ow.tick(now, None, sw.x, sw.z, None, None, None, None, q, upd_arrival=arr)
+            res = w.tick(now, upd_x=sw.x, upd_z=sw.z, queries=q, upd_arrival_ns=arr, want_records=False, records_cap=1)
+            compare_tick(k, w, ow, res, sw)
+            k += 1
+    ctl.close()
+
+
 def test_config_b_gated_overlap_back_to_back_device_ticks_equal_the_oracle_list(amd):
     """CHD_WORLD_OVERLAP_INTEREST | CHD_WORLD_GATED_OVERLAP — the bench's serial schedule: the interest updates on a second stream,
     forked and joined by device-side flags instead of HIP events.  Config B (the bench's seed) as the bench drives it: groups of
