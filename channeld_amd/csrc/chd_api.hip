@@ -1335,6 +1335,8 @@ int chd_world_create(chd_ctx *ctx, const chd_world_cfg *cfg) {
                 TRY(walloc(ctx, &d.cell_flist, 2 * C * S, false));
                 TRY(walloc(ctx, &d.filt_items, P / 16 + C + 1, false));  // (work items of >= 16 descriptors: FC_DESCS)
                 TRY(walloc(ctx, &d.filt_nitems, 32));
+                d.filt_target = 0;
+                if (const char *e = getenv("CHD_FILT_ITEMS_TARGET")) d.filt_target = (uint32_t)strtoul(e, nullptr, 0);  // (A/B runs)
             }
         }
         d.prev_ns = -1;

@@ -289,6 +289,21 @@ __device__ __forceinline__ void pad_segment(chd_fanout_rec *__restrict__ out, ui
     }
 }
 
+// ... with the pad record materialised where it is stored: under k_fanout_emit_filt_cm's register cap the compiler hoisted the
+// constant pair to the kernel's start and SPILLED it — a scratch reload per descriptor, i.e. a wait for all of the wave's own record
+// stores (gfx950's in-order vm counter)
+__device__ __forceinline__ void pad_segment_here(chd_fanout_rec *__restrict__ out, uint32_t n_out) {
+    const uint32_t pad = (0u - n_out) & (CHD_SEG_ALIGN - 1);
+    if (lane_id() < pad) {
+        uint32_t m1, z;
+        asm volatile("v_mov_b32 %0, -1\n\tv_mov_b32 %1, 0" : "=v"(m1), "=v"(z));
+        chd_fanout_rec r;
+        r.conn = m1;
+        r.channel = z;
+        out[n_out + lane_id()] = r;
+    }
+}
+
 // the spatial channel's own buffered updates against one window (two-sender history)
 __device__ __forceinline__ bool cell_update_passes(uint32_t h, uint32_t snd, uint32_t hp, uint32_t sndp, uint32_t wm,
                                                    bool skip_self, uint32_t conn) {
@@ -1957,39 +1972,68 @@ struct FcTile {
 };
 
 // work items: per cell with filtered descriptors, chunks of FC_DESCS of its list (one workgroup; ncell <= 4096)
+// k_fanout_emit_filt_cm's grid: two workgroups per CU (LDS: 56 KB each), no more than there can be items
+__host__ __device__ __forceinline__ uint32_t fc_grid(const WorldDev &w, uint32_t ncell) {
+    const uint64_t max_items = (uint64_t)w.S * w.capq / 16u + ncell, cap = (uint64_t)(w.seg_waves / 8u) * 2u;
+    return (uint32_t)(max_items < cap ? max_items : cap);
+}
+
 __device__ __forceinline__ void filt_items_block(const WorldDev &w, uint32_t ncell) {
-    __shared__ uint32_t wtot[16];
-    __shared__ uint32_t carry_s;
-    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
-    if (threadIdx.x == 0) carry_s = 0;
+    __shared__ uint32_t carry_s, total_s;
+    const uint32_t lane = threadIdx.x & 63u;
+    if (threadIdx.x == 0) { carry_s = 0; total_s = 0; }
     __syncthreads();
-    for (uint32_t base = 0; base < ncell; base += 1024) {
-        const uint32_t c = base + threadIdx.x;
-        uint32_t cnt = c < ncell ? w.cell_fcnt[32u * c] : 0u;
-        if (cnt > w.S) cnt = w.S;
-        const uint32_t chunks = (cnt + FC_DESCS - 1u) / FC_DESCS;
-        uint32_t inc = chunks;
-#pragma unroll
-        for (int d = 1; d < 64; d <<= 1) {
-            const uint32_t o = (uint32_t)__shfl_up((int)inc, d);
-            if ((int)lane >= d) inc += o;
-        }
-        if (lane == 63) wtot[wave] = inc;
-        __syncthreads();
-        uint32_t off = carry_s;
-        for (uint32_t k = 0; k < wave; k++) off += wtot[k];
-        if (chunks) {
-            const uint32_t start = w.cell_start[c], tn = min(w.cell_end[c] - start, 512u);
-            for (uint32_t q = 0; q < chunks; q++)
-                w.filt_items[off + inc - chunks + q] = make_uint4(c, q * FC_DESCS, min(cnt - q * FC_DESCS, (uint32_t)FC_DESCS) | (tn << 8), start);
-        }
-        __syncthreads();
-        if (threadIdx.x == 1023) carry_s = off + inc;
-        __syncthreads();
+    // How many descriptors a work item takes.  The kernel runs ~512 workgroups that draw items by ticket and handle 1-3 each: with items
+    // of up to FC_DESCS = 64 descriptors cut off the front of each cell's list (64, 64, 12 ...) the launch lasted as long as the
+    // workgroups that drew two full ones (profiles/r07l_filt_prof.json: the average workgroup was busy for half of it).  So: about
+    // filt_target items per launch (two per workgroup), a cell's list cut into EQUAL parts of at most that size, never below 16
+    // descriptors (every item stages its cell's tile: 20 KB).
+    {
+        uint32_t t = 0;
+        for (uint32_t c = threadIdx.x; c < ncell; c += 1024) t += min(w.cell_fcnt[32u * c], w.S);
+        for (int d = 32; d >= 1; d >>= 1) t += (uint32_t)__shfl_xor((int)t, d);
+        if (lane == 0 && t) atomicAdd(&total_s, t);
     }
+    __syncthreads();
+    const uint32_t target = (w.filt_target & 0x7FFFFFFFu) ? (w.filt_target & 0x7FFFFFFFu) : 512u;
+    const bool lpt = !(w.filt_target >> 31);  // (A/B runs: bit 31 of CHD_FILT_ITEMS_TARGET = the items in no particular order)
+    const uint32_t D = min(max((total_s + target - 1u) / target, 16u), (uint32_t)FC_DESCS);
+    // The items in order of DESCENDING size (a counting sort over the 64 possible sizes): the workgroups draw them in that order —
+    // the first gridDim.x statically —, so the ones that start with a large item draw fewer afterwards and the launch ends when the
+    // SMALL items run out (longest-processing-time-first; in cell order the launch lasted 73 us while its average workgroup was
+    // busy for 54).  A cell's list is cut into `chunks` parts of floor or ceil(cnt / chunks) descriptors.
+    __shared__ uint32_t bucket[FC_DESCS + 2];
+    for (uint32_t k = threadIdx.x; k < FC_DESCS + 2u; k += 1024) bucket[k] = 0;
+    __syncthreads();
+    for (uint32_t c = threadIdx.x; c < ncell; c += 1024) {
+        const uint32_t cnt = min(w.cell_fcnt[32u * c], w.S);
+        if (!cnt) continue;
+        const uint32_t chunks = (cnt + D - 1u) / D, lo = cnt / chunks, n_hi = cnt - lo * chunks;  // n_hi parts of lo + 1, the rest of lo
+        if (n_hi) atomicAdd(&bucket[lpt ? lo + 1u : 0u], n_hi);
+        atomicAdd(&bucket[lpt ? lo : 0u], chunks - n_hi);
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {  // exclusive prefix from the largest size down; bucket[k] becomes the first position of size k
+        uint32_t run = 0;
+        for (int k = (int)FC_DESCS + 1; k >= 0; k--) { const uint32_t n = bucket[k]; bucket[k] = run; run += n; }
+        carry_s = run;
+    }
+    __syncthreads();
+    for (uint32_t c = threadIdx.x; c < ncell; c += 1024) {
+        const uint32_t cnt = min(w.cell_fcnt[32u * c], w.S);
+        if (!cnt) continue;
+        const uint32_t chunks = (cnt + D - 1u) / D;
+        const uint32_t start = w.cell_start[c], tn = min(w.cell_end[c] - start, 512u);
+        for (uint32_t q = 0; q < chunks; q++) {
+            const uint32_t a = (uint32_t)(((uint64_t)cnt * q) / chunks), b = (uint32_t)(((uint64_t)cnt * (q + 1u)) / chunks);  // (b - a <= D <= FC_DESCS)
+            const uint32_t at = atomicAdd(&bucket[lpt ? b - a : 0u], 1u);
+            w.filt_items[at] = make_uint4(c, a, (b - a) | (tn << 8), start);
+        }
+    }
+    __syncthreads();
     if (threadIdx.x == 0) {
         *w.filt_nitems = carry_s;
-        w.filt_nitems[16] = 0;  // k_fanout_emit_filt_cm's item ticket
+        w.filt_nitems[16] = fc_grid(w, ncell);  // k_fanout_emit_filt_cm's item ticket: every workgroup's first item is its own index
     }
 }
 
@@ -2125,6 +2169,33 @@ __global__ void __launch_bounds__(1024) k_fanout_scan(WorldDev w, uint32_t ncell
     if (seg && w.off_on && w.fcm_on) filt_items_block(w, ncell);
 }
 
+// -DCHD_PROFILE_FILT (diagnosis builds): cycles the loader wave spends preparing items / waiting at the hand-over barrier, and the
+// streamer waves working / waiting, summed over the launch; chd_debug_filt_prof reads and clears them
+#ifdef CHD_PROFILE_FILT
+__device__ unsigned long long fc_wg[4 * 1024];
+__device__ unsigned long long fc_prof[8 * 64];  // [counter][hashed slot]: one atomic per wave and counter at the kernel's end
+extern "C" int chd_debug_filt_prof(unsigned long long *out) {
+    static unsigned long long h[8 * 64], z[8 * 64];
+    int rc = (int)hipMemcpyFromSymbol(h, HIP_SYMBOL(fc_prof), sizeof h);
+    (void)hipMemcpyToSymbol(HIP_SYMBOL(fc_prof), z, sizeof z);
+    for (int k = 0; k < 8; k++) { out[k] = 0; for (int i = 0; i < 64; i++) out[k] += h[k * 64 + i]; }
+    return rc;
+}
+// per workgroup: wall_clock64 (100 MHz) at its loader's start and end, items it drew — written without atomics
+extern "C" int chd_debug_filt_wgs(unsigned long long *out, unsigned n) {
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(fc_wg), sizeof(unsigned long long) * 4 * (n < 1024 ? n : 1024));
+}
+#define FCP_T0() long long fcp_t = clock64(); const unsigned long long fcp_w0 = wall_clock64(); unsigned long long fcp_acc[7] = {0, 0, 0, 0, 0, 0, 0}
+#define FCP_ADD(k) do { long long _n = clock64(); fcp_acc[k] += (unsigned long long)(_n - fcp_t); fcp_t = _n; } while (0)
+#define FCP_CNT(k, v) do { fcp_acc[k] += (unsigned long long)(v); } while (0)
+#define FCP_END() do { const unsigned long long _w1 = wall_clock64(); fcp_acc[6] = _w1 - fcp_w0; if (lane == 0 && wave == 0 && blockIdx.x < 1024) { fc_wg[4 * blockIdx.x] = fcp_w0; fc_wg[4 * blockIdx.x + 1] = _w1; fc_wg[4 * blockIdx.x + 2] = fcp_acc[4]; fc_wg[4 * blockIdx.x + 3] = fcp_acc[5]; } if (lane == 0) for (int _k = 0; _k < 7; _k++) if (fcp_acc[_k]) atomicAdd(&fc_prof[_k * 64 + ((blockIdx.x * FC_WAVES + wave) & 63u)], fcp_acc[_k]); } while (0)
+#else
+#define FCP_T0() do { } while (0)
+#define FCP_ADD(k) do { } while (0)
+#define FCP_CNT(k, v) do { } while (0)
+#define FCP_END() do { } while (0)
+#endif
+
 __global__ void __launch_bounds__(64 * FC_WAVES, FC_OCC) k_fanout_emit_filt_cm(DevGrid g, WorldDev w) {
     __shared__ FcHead heads[2];
     __shared__ FcTile tiles[2];
@@ -2133,16 +2204,21 @@ __global__ void __launch_bounds__(64 * FC_WAVES, FC_OCC) k_fanout_emit_filt_cm(D
     const uint32_t n_items = *w.filt_nitems;
     unsigned long long wave_sum = 0;
 
+    FCP_T0();
     if (wave == 0) {
         // ---- loader ----
         // items by TICKET, not by a static stride: an item is 1..64 descriptors of 1..8 windows over 1..4 rows, and with ~3 items per
         // workgroup a static deal left the launch waiting for its unluckiest workgroup (off-grid ticks: 287 us max against 114 avg)
-        auto prepare = [&](uint32_t b) {
+        auto prepare = [&](uint32_t b, bool own_item) {
             FcHead &H = heads[b];
             FcTile &T = tiles[b];
-            uint32_t item = 0;
-            if (lane == 0) item = atomicAdd(&w.filt_nitems[16], 1u);
-            item = (uint32_t)__builtin_amdgcn_readfirstlane((int)item);
+            // (a workgroup's FIRST item is its own index — the tickets start behind the grid, k_fanout_scan —: one round trip less
+            // before its eleven streamer waves have anything to do)
+            uint32_t item = blockIdx.x;
+            if (!own_item) {
+                if (lane == 0) item = atomicAdd(&w.filt_nitems[16], 1u);
+                item = (uint32_t)__builtin_amdgcn_readfirstlane((int)item);
+            }
             if (item >= n_items) {
                 if (lane == 0) H.valid = 0;
                 return;
@@ -2224,16 +2300,22 @@ __global__ void __launch_bounds__(64 * FC_WAVES, FC_OCC) k_fanout_emit_filt_cm(D
             }
             if (lane == 0) { H.nd = nd; H.cch = c + g.id_start; H.start = start; H.valid = 1; H.ticket = 0; H.sorted = w.cell_sorted ? w.cell_sorted[c] : 0u; }
         };
-        prepare(0);
+        prepare(0, true);
+        FCP_ADD(0);
         lds_barrier();
+        FCP_ADD(1);
         for (uint32_t u = 0;; u++) {
             if (!heads[u & 1u].valid) break;
-            prepare((u + 1u) & 1u);
+            FCP_CNT(4, 1); FCP_CNT(5, heads[u & 1u].nd);
+            prepare((u + 1u) & 1u, false);
+            FCP_ADD(0);
             lds_barrier();
+            FCP_ADD(1);
         }
     } else {
         // ---- streamers ----
         lds_barrier();
+        FCP_ADD(3);
         for (uint32_t u = 0;; u++) {
             FcHead &H = heads[u & 1u];
             const FcTile &T = tiles[u & 1u];
@@ -2249,8 +2331,12 @@ __global__ void __launch_bounds__(64 * FC_WAVES, FC_OCC) k_fanout_emit_filt_cm(D
                 if (info == 0xFFFFFFFFu) continue;  // (the deferred launch leaves the connection's state as it was and flags the tick)
                 const uint32_t n = H.n[k], conn = H.conn[k], pidx = H.pidx[k];
                 const uint32_t nw = info & 15u, own = (info >> 8) & 0xFFu;
-                chd_fanout_rec *__restrict__ out = w.recs + (size_t)H.out16[k] * CHD_SEG_ALIGN;
+                // (a scalar: the segment's start is the same for every lane — kept in SGPRs, not as a per-lane pointer that would be spilled
+                // and reloaded with a wait on the wave's own stores)
+                chd_fanout_rec *__restrict__ out = w.recs + (size_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)H.out16[k]) * CHD_SEG_ALIGN;
                 uint32_t n_out = 0;
+                uint32_t lane2 = 2u * lane;  // (opaque per descriptor: `recs + 16 * lane` hoisted to the kernel's start was spilled — see pad_segment_here)
+                asm volatile("" : "+v"(lane2));
                 // the cell's entries (adjacent pairs per lane and row), once per descriptor
                 u32x2 ch[4], hh[4];
 #pragma unroll
@@ -2296,7 +2382,7 @@ __global__ void __launch_bounds__(64 * FC_WAVES, FC_OCC) k_fanout_emit_filt_cm(D
                         const uint32_t i0 = run & 0xFFFFu, i1 = run >> 16, len = i1 - i0;
                         typedef u32x4 __attribute__((aligned(8))) u32x4_a8;  // (n_out is any record index)
                         for (uint32_t b0 = 0; b0 < len; b0 += 128) {
-                            const uint32_t q = b0 + 2 * lane, ea = min(i0 + q, 511u), eb = min(i0 + q + 1u, 511u);
+                            const uint32_t q = b0 + lane2, ea = min(i0 + q, 511u), eb = min(i0 + q + 1u, 511u);
                             const uint32_t c0 = T.chan[ea], c1 = T.chan[eb];
                             if (q + 1 < len) {
                                 u32x4 r;
@@ -2401,16 +2487,19 @@ __global__ void __launch_bounds__(64 * FC_WAVES, FC_OCC) k_fanout_emit_filt_cm(D
                         n_out = filt_window_global(w, start, n, full, sa, sb, a_lo, a_hi, b_lo, b_hi, conn, out, n_out);
                     }
                 }
-                pad_segment(out, n_out);
+                pad_segment_here(out, n_out);
                 if (lane == 0) {
                     w.pair_nrec[pidx] = n_out;
                     if (n_out) atomicAdd(&w.rec_cnt[H.sidx[k]], n_out);
                 }
                 wave_sum += n_out;
             }
+            FCP_ADD(2);
             lds_barrier();
+            FCP_ADD(3);
         }
     }
+    FCP_END();
     if (lane == 0 && wave_sum) {
         unsigned long long *slot = (unsigned long long *)&w.tot64[(size_t)((blockIdx.x * FC_WAVES + wave) & 63u) * 16];
         if (w.late_tot) atomicAdd(slot + 8, wave_sum);  // (pipelined: the epilogue runs beside this kernel — k_filt_fold)
@@ -2446,9 +2535,7 @@ void launch_filt_fold(hipStream_t st, WorldDev w, uint32_t ring_slot) { hipLaunc
 void launch_fanout_emit_filt(hipStream_t st, DevGrid g, WorldDev w) {
     if (!w.S || !w.off_on || !seg_path(w)) return;
     if (w.fcm_on) {
-        const uint64_t max_items = (uint64_t)w.S * w.capq / FC_DESCS + g.ncell;
-        const uint32_t grid = (uint32_t)std::min<uint64_t>(max_items, (uint64_t)(w.seg_waves / 8u) * 2u);  // two workgroups per CU (LDS: 56 KB each)
-        hipLaunchKernelGGL(k_fanout_emit_filt_cm, dim3(grid), dim3(64 * FC_WAVES), 0, st, g, w);
+        hipLaunchKernelGGL(k_fanout_emit_filt_cm, dim3(fc_grid(w, g.ncell)), dim3(64 * FC_WAVES), 0, st, g, w);
         return;
     }
     const uint32_t n_tickets = w.S * FO_FILT_WAVES;

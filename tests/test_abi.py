@@ -156,3 +156,30 @@ def test_binding_constants_match_the_header(tmp_path):
     out = subprocess.run([str(exe)], capture_output=True, text=True, check=True).stdout
     got = {k: int(v) for k, v in (l.split() for l in out.splitlines())}
     assert got == {k: int(v) for k, v in pairs.items()}
+
+
+def test_the_record_kernels_use_no_scratch_memory():
+    """A spilled VGPR in a record-writing kernel is not a small cost on gfx950: the reload is a vector-memory load, the vm counter is
+    in-order, so the wave waits for ALL of its outstanding record stores at every reload.  Round 6 found three such reloads per
+    descriptor in k_fanout_emit_filt_cm (a hoisted pointer, a hoisted pad constant) behind its 80-VGPR occupancy cap — 82.6 us.
+    hipcc -S of the fan-out kernels: no kernel of the file may have a private segment."""
+    import re
+    import shutil
+    import subprocess
+    import tempfile
+
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        pytest.skip("no hipcc")
+    src = os.path.join(ROOT, "channeld_amd", "csrc", "k_fanout.hip")
+    with tempfile.TemporaryDirectory() as td:
+        out = os.path.join(td, "k.s")
+        subprocess.run([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fno-fast-math", "-S", "--cuda-device-only", "-o", out, src],
+                       check=True, capture_output=True, timeout=600)
+        txt = open(out).read()
+    bad = []
+    for m in re.finditer(r"\.amdhsa_kernel (\S+)(.*?)\.end_amdhsa_kernel", txt, re.S):
+        seg = re.search(r"\.amdhsa_private_segment_fixed_size (\d+)", m.group(2))
+        if seg and int(seg.group(1)) > 0:
+            bad.append((m.group(1), int(seg.group(1))))
+    assert not bad, bad
