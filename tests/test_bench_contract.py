@@ -134,7 +134,7 @@ def test_default_run_prints_one_line_with_the_contract_keys(monkeypatch):
     assert {"p50_tick_ms", "p99_tick_ms", "latency_ticks", "stage_us_avg", "e2e", "strict_reference_flat_50ms", "arrival_jitter",
             "arrival_jitter_ticks_off_grid"} <= set(d)
     assert d["arrival_jitter"]["unit"] == "msgs/s" and d["arrival_jitter"]["history_overflow"] == 0
-    assert d["latency_ticks"] == 3 and d["stage_us_avg"]["emit"] == 50.0
+    assert d["latency_ticks"] == 2 and d["stage_us_avg"]["emit"] == 50.0  # (3 synchronous ticks: two without stage events, one with)
     assert "pipelined_schedule" not in d  # 300 connections: the pipeline flag is not requested below 4096
 
 
