@@ -719,6 +719,21 @@ class SpatialWorld {
         fullMask.resize(n);
         return err(rc);
     }
+    // step 1 of a cross-server handover (spatial.go:688-694): flags[h] = the src spatial server's connection is unsubscribed from the
+    // handover entities' channels (it has no interest in dst) — for the handovers of the last tick
+    Error HandoverSrcOwnerUnsubscribed(uint32_t nHandovers, std::vector<uint8_t> &flags) {
+        flags.assign(std::max<uint32_t>(nHandovers, 1u), 0);
+        uint32_t n = 0;
+        const int rc = chd_handover_src_owner_unsubscribed(ctl_.ctx(), flags.data(), (uint32_t)flags.size(), &n);
+        flags.resize(n);
+        return err(rc);
+    }
+    // The tick two deep (chd_tick_segments_begin / _end): TickSegmentsBegin enqueues tick t+1 (uploads, the tick, the segment passes;
+    // no host wait); TickSegmentsEnd waits for the OLDEST tick in flight and hands out pointers into the library's page-locked block
+    // of that tick (valid until the next-but-one Begin).  The arrays `in` points to (chd_host_alloc memory) must stay untouched until
+    // the matching End.  At most two ticks in flight.
+    Error TickSegmentsBegin(const chd_tick_in &in) { return err(chd_tick_segments_begin(ctl_.ctx(), &in)); }
+    Error TickSegmentsEnd(chd_segments_block &block) { return err(chd_tick_segments_end(ctl_.ctx(), &block)); }
     // one ChannelDataHandoverMessage per distinct (handover, full-state mask): varHandover[v] / varFullMask[v] name the variants
     Error HandoverVariants(const std::vector<uint32_t> &varHandover, const std::vector<uint32_t> &varFullMask, std::vector<uint32_t> &offsets,
                            std::vector<uint8_t> &bytes, uint64_t cap) {
@@ -841,6 +856,28 @@ class ShardWorld {
     // one tick (collective): positions by channel id on the device, this rank's queries in dIn (device pointers)
     Error Tick(int64_t nowNs, const double *dXByChan, const double *dZByChan, const uint8_t *dHasUpdate, uint32_t nChan, const chd_tick_in &dIn) {
         const int rc = chd_shard_tick(ctl_.ctx(), nowNs, dXByChan, dZByChan, dHasUpdate, nChan, &dIn);
+        if (rc == CHD_OK) return {};
+        const char *m = chd_last_error(ctl_.ctx());
+        return {rc, m ? m : ""};
+    }
+    // THIS rank's connections' share of the recipients of the whole world's handovers of the last tick (gathered from every rank in
+    // rank order; spatial.go:738-857 on one gateway per server region): CSR over `handovers`, kinds as CHD_HO_*, bit 0 of fullMask =
+    // the notifier goes out with its full state, srcOwnerUnsubscribed[h] = this rank holds the src server's connection and it loses
+    // its subscription to the entity channel (spatial.go:688-694)
+    Error HandoverRecipients(const std::vector<chd_handover_rec> &handovers, std::vector<uint32_t> &offsets, std::vector<uint32_t> &conn,
+                             std::vector<uint8_t> &kind, std::vector<uint32_t> &fullMask, std::vector<uint8_t> &srcOwnerUnsubscribed) {
+        const uint32_t nh = (uint32_t)handovers.size();
+        offsets.assign((size_t)nh + 1, 0);
+        srcOwnerUnsubscribed.assign(std::max<uint32_t>(nh, 1u), 0);
+        uint64_t n = 0;
+        int rc = chd_shard_handover_recipients(ctl_.ctx(), nh, handovers.data(), offsets.data(), nullptr, nullptr, nullptr, nullptr, 0, &n);  // count
+        if (rc != CHD_OK && rc != CHD_E_CAPACITY) { const char *m = chd_last_error(ctl_.ctx()); return {rc, m ? m : ""}; }
+        conn.assign(std::max<uint64_t>(n, 1), 0);
+        kind.assign(std::max<uint64_t>(n, 1), 0);
+        fullMask.assign(std::max<uint64_t>(n, 1), 0);
+        rc = chd_shard_handover_recipients(ctl_.ctx(), nh, handovers.data(), offsets.data(), conn.data(), kind.data(), fullMask.data(),
+                                           srcOwnerUnsubscribed.data(), conn.size(), &n);
+        conn.resize(n); kind.resize(n); fullMask.resize(n); srcOwnerUnsubscribed.resize(nh);
         if (rc == CHD_OK) return {};
         const char *m = chd_last_error(ctl_.ctx());
         return {rc, m ? m : ""};
