@@ -812,6 +812,34 @@ def main():
                 "value": medp[4] / medp[0], "unit": "msgs/s", "ms_all": [round(1e3 * v[0], 3) for v in rp][:16]}
         except Exception as ex:  # noqa: BLE001
             e2e["segments_pipelined"] = {"error": f"{type(ex).__name__}: {ex}"}
+        try:
+            # the same loop on a world created for it: CHD_WORLD_SEGMENTS_ONLY — a gateway that walks segments never reads the dense
+            # records from HBM, so the plain-copy records are not written (NOT the headline: `value` is a world that writes every record)
+            trace("e2e segments-only world")
+            sw3 = synth.SynthWorld(synth.WorldSpec(cfg, N, S, seed, tick_ms=args.tick_ms, aoi_scale=args.aoi_scale))
+            ctl3 = A.StaticGrid2DSpatialController(device=local_rank)
+            assert ctl3.LoadConfig(json.dumps(cfg).encode(), strict=False) is None
+            w3 = A.SpatialWorld(ctl3, N, S, flags=1024, max_records=200_000_000)
+            w3.spawn(None, sw3.chan_id, sw3.x, sw3.z, sw3.flags, sw3.sender)
+            w3.add_subscribers(None, sw3.sub_conn)
+            frames3 = []
+            for _ in range(16 + (100 if E >= 5 else 8)):
+                sw3.step()
+                frames3.append((sw3.now_ns(), sw3.x.copy(), sw3.z.copy(), sw3.queries().copy()))
+            r3 = e2e_segment_ticks_pipelined(w3, frames3)[16:]  # (behind the first fan-outs and the page faults of the block's first uses)
+            ctl3.close()
+            pct3 = lambda col, q: float(np.percentile([1e3 * v[col] for v in r3], q))  # noqa: E731
+            med3 = sorted(r3, key=lambda v: v[0])[len(r3) // 2]
+            e2e["segments_only_world"] = {
+                "what": "e2e.segments_pipelined's loop on a world created with CHD_WORLD_SEGMENTS_ONLY: the records a segment names as a plain copy of a column are "
+                        "not written to HBM (the host expands them from the columns it receives anyway); counts, segments, columns and explicit records "
+                        "are those of the other world (tests/test_gpu_fullsize.py expands them to the oracle's digests).  Not comparable with `value`: "
+                        "the headline world writes all 80 M records per tick",
+                "ticks": len(r3), "period_p50_ms": pct3(0, 50), "period_p99_ms": pct3(0, 99), "sync_ms": float(np.median([v[6] for v in r3])),
+                "pcie_ms": float(np.median([v[8] for v in r3])), "enqueue_ms": pct3(2, 50), "bytes_per_tick": int(med3[5]), "msgs_per_tick": int(med3[4]),
+                "value": med3[4] / med3[0], "unit": "msgs/s (expandable on the host)"}
+        except Exception as ex:  # noqa: BLE001
+            e2e["segments_only_world"] = {"error": f"{type(ex).__name__}: {ex}"}
 
     # HBM bytes per launch of the dominant kernel from the PMC passes (FETCH_SIZE / WRITE_SIZE in separate
     # rocprofv3 runs, tools/pmc_summary.py): not measurable from inside this process, so QUOTED from the committed

@@ -29,6 +29,7 @@ WORLD_ONE_WAVE_EMIT = 64
 WORLD_PIPELINE_TICKS = 128
 WORLD_OVERLAP_DEFERRED = 256
 WORLD_GATED_OVERLAP = 512
+WORLD_SEGMENTS_ONLY = 1024
 WIRE_ENTITY_UPDATE, WIRE_ENTITY_FULL, WIRE_CELL_UPDATE, WIRE_CELL_FULL, WIRE_ENTITY_OBJREF = 0, 1, 2, 3, 4
 HO_SRC_ONLY, HO_DST_NEW, HO_DST_KNOWN = 0, 1, 2
 BROADCAST_ALL_BUT_SENDER, BROADCAST_ALL_BUT_OWNER, BROADCAST_ALL_BUT_CLIENT, BROADCAST_ALL_BUT_SERVER = 4, 8, 16, 32

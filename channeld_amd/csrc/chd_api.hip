@@ -1153,6 +1153,11 @@ int chd_world_create(chd_ctx *ctx, const chd_world_cfg *cfg) {
     if (d.wb) TRY(walloc(ctx, &d.sub_bits, S * d.wb));
     if (d.cm_emit) TRY(walloc(ctx, &d.items, n_items_max, false));
     W.plan_recipients = (cfg->flags & CHD_WORLD_HANDOVER_RECIPIENTS) != 0;
+    if (cfg->flags & CHD_WORLD_SEGMENTS_ONLY) {
+        if ((cfg->flags & (CHD_WORLD_WIRE | CHD_WORLD_UPDATE_MASKS)) || form.cm_emit)
+            return fail(ctx, CHD_E_INVAL, "CHD_WORLD_SEGMENTS_ONLY: not with wire buffers, per-record masks or the cell-major emit (they are made of dense records)");
+        d.seg_only = 1u;
+    }
     // CHD_WORLD_FORCE_FLAGS (tests): schedule-only flags OR-ed into every world of the process, so that the parity suite can be run on them
     uint32_t wflags = cfg->flags;
     if (const char *e = getenv("CHD_WORLD_FORCE_FLAGS")) wflags |= (uint32_t)strtoul(e, nullptr, 0) & (CHD_WORLD_OVERLAP_INTEREST | CHD_WORLD_OVERLAP_DEFERRED | CHD_WORLD_GATED_OVERLAP);
@@ -2234,6 +2239,7 @@ static int fetch_locked(chd_ctx *ctx, chd_tick_out *out) {
     World &W = ctx->w;
     WorldDev &d = W.d;
     if (!W.ticked) return fail(ctx, CHD_E_STATE, "no tick to fetch");
+    if (d.seg_only && (out->records || out->record_masks)) return fail(ctx, CHD_E_STATE, "CHD_WORLD_SEGMENTS_ONLY: the world writes no dense records (chd_tick_fetch_segments)");
     hipStream_t st = ctx->stream;
     uint32_t ctr[CTR_COUNT] = {0};
     uint64_t ringrow[8];
@@ -2382,6 +2388,7 @@ int chd_tick_digest(chd_ctx *ctx, chd_records_digest *total, uint64_t *conn_sum)
     World &W = ctx->w;
     WorldDev &d = W.d;
     if (!W.ticked) return fail(ctx, CHD_E_STATE, "no tick to digest");
+    if (d.seg_only) return fail(ctx, CHD_E_STATE, "CHD_WORLD_SEGMENTS_ONLY: the world writes no dense records");
     hipStream_t st = ctx->stream;
     TRY(ensure(ctx, 14, sizeof(uint64_t) * 64 * 16));
     TRY(ensure(ctx, 15, sizeof(uint64_t) * std::max<size_t>(d.S, 1)));

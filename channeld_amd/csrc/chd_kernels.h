@@ -142,6 +142,7 @@ struct WorldDev {
     uint4 *filt_items;
     uint32_t *filt_nitems;
     uint32_t filt_target;   // work items per launch of k_fanout_emit_filt_cm that filt_items_block aims for (0: 1024; CHD_FILT_ITEMS_TARGET)
+    uint32_t seg_only;      // CHD_WORLD_SEGMENTS_ONLY: on descriptor-path ticks the record kernel of the simple descriptors does not run
     uint32_t late_tot;      // pipelined ticks on off_on worlds: k_fanout_emit_filt_cm counts into tot64[..][8], k_filt_fold adds that to the tick's row
     // cell index (rebuilt every tick)
     uint32_t nblk;        // histogram blocks

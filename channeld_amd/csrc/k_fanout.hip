@@ -3042,6 +3042,10 @@ void launch_fanout_emit_main(hipStream_t st, DevGrid g, WorldDev w, int64_t now_
     // four waves per connection otherwise
     const bool one_wave = w.S >= 4096 || w.one_wave_emit;
     if (seg_path(w)) {
+        // CHD_WORLD_SEGMENTS_ONLY: the simple descriptors' records are plain copies of columns the host expands itself from the segment
+        // form (chd_tick_fetch_segments): nobody reads them from HBM.  (The deferred and filtered subscriptions' records ARE the
+        // segment form's explicit records: their kernels run as ever.)
+        if (w.seg_only) return;
         // (k_fanout_plan_seg has decided everything; see launch_fanout_plan)
         // CHD_SEG_TAIL="<percent>,<log2 pieces>": the last <percent> % of the connection slots in 2^<log2 pieces> pieces each
         static const uint32_t tail_pct = [] { const char *e = getenv("CHD_SEG_TAIL"); return e ? (uint32_t)atoi(e) : FO_SEG_TAIL_PCT; }();

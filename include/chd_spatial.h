@@ -265,6 +265,13 @@ typedef struct {
  * overflow bit 0x4000 for that tick (its results are not valid) and switches the world to events for good
  * (chd_tick_stats.gate_timeouts). */
 #define CHD_WORLD_GATED_OVERLAP 512u
+/* A world whose fan-out is consumed in the SEGMENT form only (chd_tick_fetch_segments, chd_tick_segments, chd_tick_segments_begin /
+ * _end: what INTEGRATION.md's tick driver does).  On ticks of the descriptor path the plain-copy records — the ones a segment names
+ * as "column [off, off + n) once per window" — are then NOT written to HBM at all: the host expands them from the columns anyway.
+ * Counts, segments, columns, explicit records (the subscriptions that needed a per-entity decision) and every other output are
+ * unchanged; chd_tick's dense record outputs, chd_tick_digest and the wire builder answer CHD_E_STATE on such a world (there are
+ * no dense records to pack, digest or assemble).  Not with CHD_WORLD_WIRE / CHD_WORLD_UPDATE_MASKS / the cell-major emit. */
+#define CHD_WORLD_SEGMENTS_ONLY 1024u
 
 #define CHD_ENTITY_LOCKED 1u /* member of a non-empty lock group (entity.go:197-224) */
 

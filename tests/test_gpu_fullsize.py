@@ -380,6 +380,35 @@ def test_config_b_segments_expand_to_the_device_digest(amd):
     assert cnt > 50_000_000 and nbytes < 8 * cnt / 50, compact
 
 
+def test_config_b_segments_only_world_expands_to_the_oracle_digests(amd):
+    """CHD_WORLD_SEGMENTS_ONLY at full size: a world whose fan-out is consumed in the segment form writes no plain-copy records at
+    all (the host expands them from the columns) — the bench's world (its seed), ticked through chd_tick_segments, every tick's
+    segments expanded on the host and digested: equal to the CPU ORACLE's committed list (tests/golden/bench_digests_B.json), first
+    fan-out, the crossing to the descriptor path and steady state; the dense outputs answer CHD_E_STATE."""
+    from channeld_amd import _lib
+    from channeld_amd.engine import expand_segments
+
+    N, S, seed = 100_000, 10_000, 0xC0FFEE01
+    with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "bench_digests_B.json")) as f:
+        golden = json.load(f)["ticks"]
+    cfg, sw, ctl, w = build(amd, N, S, seed, max_records=200_000_000, flags=_lib.WORLD_SEGMENTS_ONLY)
+    total = 0
+    for k in range(8):
+        sw.step()
+        res, seg = w.tick_segments(sw.now_ns(), upd_x=sw.x, upd_z=sw.z, queries=sw.queries())
+        rec = expand_segments(seg, sw.sub_conn)
+        cnt, sm, xr = digest(rec["conn"], rec["channel"])
+        assert [cnt, sm, xr] == golden[str(k + 1)], f"tick {k + 1}: expanded segments digest {[cnt, sm, xr]} != the oracle's {golden[str(k + 1)]}"
+        assert res.n_records == cnt and res.overflow == 0
+        total += cnt
+    assert total > 500_000_000
+    with pytest.raises(amd.ChdError):
+        w.digest(per_connection=False)
+    with pytest.raises(amd.ChdError):
+        w.fetch(want_records=True, records_cap=1 << 20)
+    ctl.close()
+
+
 @pytest.mark.parametrize("variant", ["full", "partial", "merged"])
 def test_config_b_wire_streams_from_images_equal_the_record_path(amd, monkeypatch, variant):
     """SURVEY 8f-1 at full size: the packet streams of config B's ticks (3 - 11 GB each) built from the fan-out descriptors
