@@ -1471,6 +1471,9 @@ extern "C" int chd_debug_trace(unsigned long long *out, unsigned n) {
 #define PF_TRACE(slot) do { } while (0)
 #endif
 
+#ifndef FO_SEG_SPEC
+#define FO_SEG_SPEC 16u  // descriptors per wave loaded with the ticket's header, before n_simple is known
+#endif
 #ifndef FO_SEG_BATCH
 #define FO_SEG_BATCH 2   // segments whose columns a wave loads together, between two waits
 #endif
@@ -1503,22 +1506,43 @@ __global__ void __launch_bounds__(64, FO_SEG_OCC) k_fanout_emit_seg(DevGrid g, W
     for (;;) {
     const uint32_t T = 8u * tk + bank;
     if (T >= n_tickets) break;
-    // the next ticket: requested now, read at the bottom of the loop
+    // the next ticket: requested now, read with the ticket's header words.  (atomicInc, not atomicAdd: the compiler's atomic optimizer
+    // turns a uniform-address add into a wave reduction + readfirstlane and waits for the value RIGHT HERE — on the in-order vm counter
+    // that also drains the previous ticket's record stores; it leaves the wrapping increment alone)
     uint32_t tk_next = 0;
-    if (lane == 0) tk_next = atomicAdd(ctr, 1u);
+    if (lane == 0) tk_next = atomicInc(ctr, 0xFFFFFFFFu);
     const bool fine = T >= t_fine;
     const uint32_t wsh = fine ? fine_sh : WSH;
     const uint32_t Tr = fine ? T - t_fine : T;
     const uint32_t s = (fine ? s_fine : 0u) + (Tr >> wsh);
     const uint32_t wave = Tr & ((1u << wsh) - 1u);
     PF_TRACE(0);
-    const uint32_t ns = w.n_simple[s];
     const size_t pbase = (size_t)s * w.capq;
-    const uint64_t base = w.rec_ub[s], end = w.rec_ub[s + 1];
+    // ONE round trip for everything the ticket needs before its columns: the connection's words, the next ticket and — speculatively, the
+    // row exists whatever n_simple says — the wave's first FO_SEG_SPEC descriptors.  As a chain "ticket -> segments? -> room? -> base,
+    // connection -> descriptors" these were five dependent trips in front of every ticket's first column load, each behind the previous
+    // ticket's draining stores: nothing at config B, where a ticket is ~30 KB of records (profiles/r08b_ab_emit_seg_header.txt), but
+    // most of the kernel's time where tickets are short (cells of 44 entities: 8 KB per ticket, profiles/r08i_ab_emit_seg_header_small.txt).
+    // (More than 16 speculative descriptors cost bandwidth: 64 per wave = 40 MB of rows nobody reads, +8 us at config B.)
+    const uint32_t kl0 = wave + (lane << wsh);
+    const bool spec = lane < FO_SEG_SPEC && kl0 < w.capq;
+    uint32_t ns_v = w.n_simple[s];
+    uint64_t base_v = w.rec_ub[s], end_v = w.rec_ub[s + 1];
+    uint32_t conn_v = w.conn_id[s];
+    u32x4 dv0 = {0, 0, 0, 0}, wmv0 = {0, 0, 0, 0};
+    uint32_t cv0 = 0;
+    if (spec) {
+        dv0 = *(const u32x4 *)(const void *)(w.seg_desc + pbase + kl0);
+        cv0 = w.seg_desc2[pbase + kl0].x;
+        if (MASKS) wmv0 = *(const u32x4 *)(const void *)(w.seg_wm + pbase + kl0);
+    }
+    asm volatile("" : "+v"(ns_v), "+v"(base_v), "+v"(end_v), "+v"(conn_v), "+v"(dv0), "+v"(cv0), "+v"(wmv0), "+v"(tk_next));  // (all of them issued, then awaited together)
+    const uint32_t ns = (uint32_t)__builtin_amdgcn_readfirstlane((int)ns_v), conn = (uint32_t)__builtin_amdgcn_readfirstlane((int)conn_v);
+    const uint64_t base = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(base_v >> 32)) << 32) | (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)base_v);
+    const uint64_t end = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(end_v >> 32)) << 32) | (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)end_v);
     tk = (uint32_t)__builtin_amdgcn_readfirstlane((int)tk_next);
     // (end > recs_cap: no room for this connection's worst case — the deferred launch leaves its state as it was and flags the tick)
     if (wave >= ns || end > w.recs_cap) continue;
-    const uint32_t conn = w.conn_id[s];
     const uint32_t *__restrict__ chans = w.ce_chan_view;
     PF_TRACE(1);
     // Every descriptor of this wave in ONE vector load: lane j holds the wave's j-th segment (k = wave + j WAVES); the
@@ -1531,9 +1555,12 @@ __global__ void __launch_bounds__(64, FO_SEG_OCC) k_fanout_emit_seg(DevGrid g, W
         u32x4 dv = {0, 0, 0, 0}, wmv = {0, 0, 0, 0};
         uint32_t cv = 0;
         if (kl < ns) {
-            dv = *(const u32x4 *)(const void *)(w.seg_desc + pbase + kl);
-            cv = w.seg_desc2[pbase + kl].x;
-            if (MASKS) wmv = *(const u32x4 *)(const void *)(w.seg_wm + pbase + kl);
+            if (j0 == 0 && lane < FO_SEG_SPEC) { dv = dv0; cv = cv0; wmv = wmv0; }
+            else {
+                dv = *(const u32x4 *)(const void *)(w.seg_desc + pbase + kl);
+                cv = w.seg_desc2[pbase + kl].x;
+                if (MASKS) wmv = *(const u32x4 *)(const void *)(w.seg_wm + pbase + kl);
+            }
         }
         const uint32_t here = min(mine - j0, 64u);
         // ... and the columns of B segments are loaded TOGETHER, one wait, then B segments' records are stored back to
