@@ -214,6 +214,7 @@ struct WorldDev {
     uint32_t *n_active;             // [1]
     uint32_t emit_grid;             // persistent grid of the cell-major emit kernel (workgroups)
     uint32_t seg_waves;             // persistent waves of k_fanout_emit_seg (connection-major descriptor emit)
+    uint32_t emit_waves;            // ... of THIS world's launches (seg_waves, or twice that where the cells are small: chd_world_create); seg_waves also sizes the filtered kernel's and the wire copy's grids
     uint32_t *emit_ticket;          // [8 x 32] k_fanout_emit_seg's ticket counters, one 128-byte line each (zeroed by k_fanout_plan_seg)
     WsItemG *items;                 // [ncell * ceil(S/256)]
     uint32_t *conn_defer; // [S] this tick: the connection has subscriptions left to the deferred emit launch

@@ -3080,7 +3080,7 @@ void launch_fanout_emit_main(hipStream_t st, DevGrid g, WorldDev w, int64_t now_
         const uint32_t pct = tail_pct > 100u ? 100u : tail_pct, fsh = tail_sh < 1u ? 1u : tail_sh > 4u ? 4u : tail_sh;
         const uint32_t s_fine = w.S - (uint32_t)((uint64_t)w.S * pct / 100u);
         const uint32_t n_tickets = s_fine * FO_SEG_WAVES + ((w.S - s_fine) << fsh);
-        const dim3 grid(n_tickets < w.seg_waves ? n_tickets : w.seg_waves);
+        const dim3 grid(n_tickets < w.emit_waves ? n_tickets : w.emit_waves);
         if (w.rec_mask) hipLaunchKernelGGL((k_fanout_emit_seg<FO_SEG_WAVES, true>), grid, dim3(64), 0, st, g, w, n_tickets, s_fine, fsh);
         else hipLaunchKernelGGL((k_fanout_emit_seg<FO_SEG_WAVES, false>), grid, dim3(64), 0, st, g, w, n_tickets, s_fine, fsh);
     } else if (w.rec_mask) {
