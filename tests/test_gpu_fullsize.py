@@ -129,6 +129,16 @@ def test_config_b_full_size_26_ticks_record_digests(amd):
     assert max(senders_per_cell) >= 2
 
 
+def test_small_cells_at_full_connection_count_record_digests(amd):
+    """10 K entities under config B's 10 K subscribers (44 entities per cell): the descriptor path with short descriptors — where
+    k_fanout_emit_seg runs 16 persistent waves per CU and a ticket is a few KB of records (chd_world_create: fewer than 256 entity
+    slots per cell) — every connection's record digest against the oracle for 10 ticks, the first three also through the
+    host-facing records."""
+    total, per_tick, (cfg, sw, ctl, w, ow) = run_digest_ticks(amd, 10_000, 10_000, 0xC0FFEE05, 10, max_records=40_000_000, host_ticks=3, host_cap=30_000_000)
+    assert per_tick[0] == 0 and per_tick[1] > 3_000_000 and min(per_tick[2:]) > 3_000_000 and total > 50_000_000
+    ctl.close()
+
+
 def test_config_b_cell_major_emit_record_digests(amd):
     total, per_tick, _ = run_digest_ticks(amd, 100_000, 10_000, 0xC0FFEE03, 8, flags=2, max_records=200_000_000)
     assert total > 400_000_000
