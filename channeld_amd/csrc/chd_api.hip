@@ -1177,11 +1177,9 @@ int chd_world_create(chd_ctx *ctx, const chd_world_cfg *cfg) {
         uint32_t per_cu = 8;   // (measured on config B: 8 -> 141 us, 16 -> 154 us, 32 -> 159 us; 6 -> 160 us)
         if (const char *e = getenv("CHD_EMIT_WAVES_PER_CU")) per_cu = (uint32_t)std::min(std::max(atoi(e), 1), 64);
         d.seg_waves = (uint32_t)std::max(prop.multiProcessorCount, 1) * per_cu;
-        // ... 16 where the cells are small (fewer than 256 entity slots per cell): a descriptor then copies a few hundred bytes, the
-        // kernel's time follows its descriptors, not its bytes, and twice the waves hide twice the latency (profiles/r08g_ab_emit_waves.txt:
-        // 10 K / 30 K entities on the 15 x 15 grid 78.6 -> 68.8 / 86.7 -> 76.6 us; config B 148 -> 158)
-        d.emit_waves = d.seg_waves;
-        if (!getenv("CHD_EMIT_WAVES_PER_CU") && (uint64_t)N < 256ull * C) d.emit_waves = (uint32_t)std::max(prop.multiProcessorCount, 1) * 16u;
+        // ... the launch has twice that; how many of them take tickets is decided per tick on the device, from the records per connection
+        // (k_fanout_scan: 8, 12 or 16 per CU)
+        d.emit_waves = getenv("CHD_EMIT_WAVES_PER_CU") ? d.seg_waves : 2u * d.seg_waves;
     }
     TRY(walloc(ctx, &d.cell_tab, 2 * C));
     d.cell_cov = nullptr;  // (region-sharded worlds allocate it with the ghost room, chd_shard_halo_layout)

@@ -214,8 +214,8 @@ struct WorldDev {
     uint32_t *n_active;             // [1]
     uint32_t emit_grid;             // persistent grid of the cell-major emit kernel (workgroups)
     uint32_t seg_waves;             // persistent waves of k_fanout_emit_seg (connection-major descriptor emit)
-    uint32_t emit_waves;            // ... of THIS world's launches (seg_waves, or twice that where the cells are small: chd_world_create); seg_waves also sizes the filtered kernel's and the wire copy's grids
-    uint32_t *emit_ticket;          // [8 x 32] k_fanout_emit_seg's ticket counters, one 128-byte line each (zeroed by k_fanout_plan_seg)
+    uint32_t emit_waves;            // workgroups of a k_fanout_emit_seg launch (2 x seg_waves; CHD_EMIT_WAVES_PER_CU: seg_waves); how many of them are ACTIVE in a tick — seg_waves, 1.5 x or 2 x — k_fanout_scan writes into emit_ticket[32 b + 3]; seg_waves also sizes the filtered kernel's and the wire copy's grids
+    uint32_t *emit_ticket;          // [8 x 32] k_fanout_emit_seg's ticket counters, one 128-byte line each (zeroed by k_fanout_plan_seg; word 0 then set to the bank's first free ticket and word 3 to the tick's active waves by k_fanout_scan; word 1: k_fanout_emit_filt's)
     WsItemG *items;                 // [ncell * ceil(S/256)]
     uint32_t *conn_defer; // [S] this tick: the connection has subscriptions left to the deferred emit launch
     // The tick's TAIL LISTS (k_fanout_scan, the single-workgroup pass behind the plan): the connections with deferred subscriptions

@@ -1500,9 +1500,10 @@ __global__ void __launch_bounds__(64, FO_SEG_OCC) k_fanout_emit_seg(DevGrid g, W
     const uint32_t lane = lane_id();
     const uint32_t bank = blockIdx.x & 7u;
     uint32_t *__restrict__ ctr = w.emit_ticket + 32u * bank;
-    uint32_t tk = 0;
-    if (lane == 0) tk = atomicAdd(ctr, 1u);
-    tk = (uint32_t)__builtin_amdgcn_readfirstlane((int)tk);
+    // (this tick's active waves, k_fanout_scan: the launch has emit_waves workgroups, the ones beyond leave at once; an active
+    // workgroup's first ticket is its own index — the banks' counters start behind them)
+    if (blockIdx.x >= (uint32_t)__builtin_amdgcn_readfirstlane((int)ctr[3])) return;
+    uint32_t tk = blockIdx.x >> 3;
     for (;;) {
     const uint32_t T = 8u * tk + bank;
     if (T >= n_tickets) break;
@@ -2192,6 +2193,19 @@ __global__ void __launch_bounds__(1024) k_fanout_scan(WorldDev w, uint32_t ncell
         w.tail_ctl[TC_NDEFER] = dcarry;
         w.tail_ctl[TC_NDEEP] = pcarry;
         w.tail_ctl[TC_SCAP] = scap_s;
+    }
+    // k_fanout_emit_seg's waves of THIS tick (of the emit_waves its launch has): the kernel's time follows its bytes where a
+    // connection's range is long — 8 persistent waves per CU then, more cost the store stream (config B: 148 us, 12 -> 156) — and its
+    // DESCRIPTORS where ranges are short, where twice the waves hide twice the latency (profiles/r08g_ab_emit_waves.txt: R = 1.5 cells,
+    // 3.4 K records per connection: 12 waves 79 us, 8: 84; cells of 44 entities, 800 per connection: 16 waves 69 us, 8: 79).  Every
+    // bank's line gets the count and its first ticket: workgroup b of the active ones starts with ticket b, without an atomic.
+    if (seg && threadIdx.x < 8) {
+        const uint64_t per_conn = n ? carry / n : 0ull;
+        uint32_t act = per_conn >= 5000ull ? w.seg_waves : per_conn >= 1500ull ? w.seg_waves + w.seg_waves / 2u : 2u * w.seg_waves;
+        act = min(act, w.emit_waves) & ~7u;
+        if (act < 8u) act = 8u;
+        w.emit_ticket[32u * threadIdx.x] = act >> 3;
+        w.emit_ticket[32u * threadIdx.x + 3u] = act;
     }
     if (seg && w.off_on && w.fcm_on) filt_items_block(w, ncell);
 }
