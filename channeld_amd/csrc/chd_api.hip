@@ -1180,6 +1180,11 @@ int chd_world_create(chd_ctx *ctx, const chd_world_cfg *cfg) {
         // ... the launch has twice that; how many of them take tickets is decided per tick on the device, from the records per connection
         // (k_fanout_scan: 8, 12 or 16 per CU)
         d.emit_waves = getenv("CHD_EMIT_WAVES_PER_CU") ? d.seg_waves : 2u * d.seg_waves;
+        d.emit_act_t1 = 5000; d.emit_act_t2 = 1500;
+        if (const char *e = getenv("CHD_EMIT_ACTIVE_THRESHOLDS")) {  // (A/B runs)
+            d.emit_act_t1 = (uint32_t)strtoul(e, nullptr, 0);
+            if (const char *c = strchr(e, ',')) d.emit_act_t2 = (uint32_t)strtoul(c + 1, nullptr, 0);
+        }
     }
     TRY(walloc(ctx, &d.cell_tab, 2 * C));
     d.cell_cov = nullptr;  // (region-sharded worlds allocate it with the ghost room, chd_shard_halo_layout)

@@ -214,6 +214,7 @@ struct WorldDev {
     uint32_t *n_active;             // [1]
     uint32_t emit_grid;             // persistent grid of the cell-major emit kernel (workgroups)
     uint32_t seg_waves;             // persistent waves of k_fanout_emit_seg (connection-major descriptor emit)
+    uint32_t emit_act_t1, emit_act_t2;  // records per connection from which a tick runs seg_waves / 1.5 x seg_waves active waves (below: 2 x; CHD_EMIT_ACTIVE_THRESHOLDS="t1,t2")
     uint32_t emit_waves;            // workgroups of a k_fanout_emit_seg launch (2 x seg_waves; CHD_EMIT_WAVES_PER_CU: seg_waves); how many of them are ACTIVE in a tick — seg_waves, 1.5 x or 2 x — k_fanout_scan writes into emit_ticket[32 b + 3]; seg_waves also sizes the filtered kernel's and the wire copy's grids
     uint32_t *emit_ticket;          // [8 x 32] k_fanout_emit_seg's ticket counters, one 128-byte line each (zeroed by k_fanout_plan_seg; word 0 then set to the bank's first free ticket and word 3 to the tick's active waves by k_fanout_scan; word 1: k_fanout_emit_filt's)
     WsItemG *items;                 // [ncell * ceil(S/256)]

@@ -2201,7 +2201,7 @@ __global__ void __launch_bounds__(1024) k_fanout_scan(WorldDev w, uint32_t ncell
     // bank's line gets the count and its first ticket: workgroup b of the active ones starts with ticket b, without an atomic.
     if (seg && threadIdx.x < 8) {
         const uint64_t per_conn = n ? carry / n : 0ull;
-        uint32_t act = per_conn >= 5000ull ? w.seg_waves : per_conn >= 1500ull ? w.seg_waves + w.seg_waves / 2u : 2u * w.seg_waves;
+        uint32_t act = per_conn >= w.emit_act_t1 ? w.seg_waves : per_conn >= w.emit_act_t2 ? w.seg_waves + w.seg_waves / 2u : 2u * w.seg_waves;
         act = min(act, w.emit_waves) & ~7u;
         if (act < 8u) act = 8u;
         w.emit_ticket[32u * threadIdx.x] = act >> 3;
