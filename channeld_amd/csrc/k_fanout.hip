@@ -1090,7 +1090,7 @@ __device__ __forceinline__ void plan_windows_off(const WorldDev &w, const TickRi
 
 template <bool OFF>
 __global__ void __launch_bounds__(64 * FO_WAVES) k_fanout_plan_seg(DevGrid g, WorldDev w, int64_t now, TickRing ring) {
-    if (blockIdx.x == 0 && threadIdx.x < 24) w.emit_ticket[32u * (threadIdx.x & 7u) + (threadIdx.x >> 3)] = 0;  // (this tick's k_fanout_emit_seg / _filt / _filt_cm start after this kernel)
+    if (blockIdx.x == 0 && threadIdx.x < 16) w.emit_ticket[32u * (threadIdx.x & 7u) + (threadIdx.x >> 3)] = 0;  // (this tick's k_fanout_emit_seg / _filt start after this kernel)
     const uint32_t s = blockIdx.x * FO_WAVES + (threadIdx.x >> 6);
     if (s >= w.S) return;
     const uint32_t lane = lane_id();
@@ -2255,13 +2255,10 @@ __global__ void __launch_bounds__(64 * FC_WAVES, FC_OCC) k_fanout_emit_filt_cm(D
             FcTile &T = tiles[b];
             // (a workgroup's FIRST item is its own index — the tickets start behind the grid, k_fanout_scan —: one round trip less
             // before its eleven streamer waves have anything to do)
-            // (... and the later ones from ONE COUNTER PER XCD — ticket t of bank b = item gridDim + 8 t + b, as k_fanout_emit_seg's: the
-            // returning atomics of all eight XCDs on one address serialise at the memory side, ~35 ns each, and the workgroups finish
-            // their first items at about the same time)
             uint32_t item = blockIdx.x;
             if (!own_item) {
-                if (lane == 0) item = atomicAdd(&w.emit_ticket[32u * (blockIdx.x & 7u) + 2u], 1u);
-                item = gridDim.x + 8u * (uint32_t)__builtin_amdgcn_readfirstlane((int)item) + (blockIdx.x & 7u);
+                if (lane == 0) item = atomicAdd(&w.filt_nitems[16], 1u);
+                item = (uint32_t)__builtin_amdgcn_readfirstlane((int)item);
             }
             if (item >= n_items) {
                 if (lane == 0) H.valid = 0;
