@@ -1090,7 +1090,7 @@ __device__ __forceinline__ void plan_windows_off(const WorldDev &w, const TickRi
 
 template <bool OFF>
 __global__ void __launch_bounds__(64 * FO_WAVES) k_fanout_plan_seg(DevGrid g, WorldDev w, int64_t now, TickRing ring) {
-    if (blockIdx.x == 0 && threadIdx.x < 16) w.emit_ticket[32u * (threadIdx.x & 7u) + (threadIdx.x >> 3)] = 0;  // (this tick's k_fanout_emit_seg / _filt start after this kernel)
+    if (blockIdx.x == 0 && threadIdx.x < 24) w.emit_ticket[32u * (threadIdx.x & 7u) + (threadIdx.x >> 3)] = 0;  // (this tick's k_fanout_emit_seg / _filt / _filt_cm start after this kernel)
     const uint32_t s = blockIdx.x * FO_WAVES + (threadIdx.x >> 6);
     if (s >= w.S) return;
     const uint32_t lane = lane_id();
@@ -1488,6 +1488,7 @@ extern "C" int chd_debug_trace(unsigned long long *out, unsigned n) {
 // with the first column loads and never drains record stores.
 // MASKS (CHD_WORLD_UPDATE_MASKS): also the per-record merged-updates mask — on this path a constant per window, the window's
 // own mask (the plan took the subscription only if EVERY entity of the cell has an update at EVERY stamp of the window).
+__device__ __forceinline__ void filt_items_block(const WorldDev &w, uint32_t ncell);
 template <int WAVES, bool MASKS = false>
 __global__ void __launch_bounds__(64, FO_SEG_OCC) k_fanout_emit_seg(DevGrid g, WorldDev w, uint32_t n_tickets, uint32_t s_fine, uint32_t fine_sh) {
     constexpr int B = FO_SEG_BATCH;
@@ -1500,6 +1501,10 @@ __global__ void __launch_bounds__(64, FO_SEG_OCC) k_fanout_emit_seg(DevGrid g, W
     const uint32_t lane = lane_id();
     const uint32_t bank = blockIdx.x & 7u;
     uint32_t *__restrict__ ctr = w.emit_ticket + 32u * bank;
+    // The filtered kernel's work items (worlds with sub-tick offsets) are built HERE, by the launch's last workgroup — as a rule one of
+    // those that take no ticket —, beside the record stream: nobody needs them before this kernel has ended, and in k_fanout_scan
+    // their one-workgroup pass stood 6.5 us in front of every record (14.4 us against 7.9).
+    if (blockIdx.x == gridDim.x - 1u && w.off_on && w.fcm_on && !w.late_tot) filt_items_block(w, g.ncell);
     // (this tick's active waves, k_fanout_scan: the launch has emit_waves workgroups, the ones beyond leave at once; an active
     // workgroup's first ticket is its own index — the banks' counters start behind them)
     if (blockIdx.x >= (uint32_t)__builtin_amdgcn_readfirstlane((int)ctr[3])) return;
@@ -2018,7 +2023,7 @@ __device__ __forceinline__ void filt_items_block(const WorldDev &w, uint32_t nce
     // descriptors (every item stages its cell's tile: 20 KB).
     {
         uint32_t t = 0;
-        for (uint32_t c = threadIdx.x; c < ncell; c += 1024) t += min(w.cell_fcnt[32u * c], w.S);
+        for (uint32_t c = threadIdx.x; c < ncell; c += blockDim.x) t += min(w.cell_fcnt[32u * c], w.S);
         for (int d = 32; d >= 1; d >>= 1) t += (uint32_t)__shfl_xor((int)t, d);
         if (lane == 0 && t) atomicAdd(&total_s, t);
     }
@@ -2031,9 +2036,9 @@ __device__ __forceinline__ void filt_items_block(const WorldDev &w, uint32_t nce
     // SMALL items run out (longest-processing-time-first; in cell order the launch lasted 73 us while its average workgroup was
     // busy for 54).  A cell's list is cut into `chunks` parts of floor or ceil(cnt / chunks) descriptors.
     __shared__ uint32_t bucket[FC_DESCS + 2];
-    for (uint32_t k = threadIdx.x; k < FC_DESCS + 2u; k += 1024) bucket[k] = 0;
+    for (uint32_t k = threadIdx.x; k < FC_DESCS + 2u; k += blockDim.x) bucket[k] = 0;
     __syncthreads();
-    for (uint32_t c = threadIdx.x; c < ncell; c += 1024) {
+    for (uint32_t c = threadIdx.x; c < ncell; c += blockDim.x) {
         const uint32_t cnt = min(w.cell_fcnt[32u * c], w.S);
         if (!cnt) continue;
         const uint32_t chunks = (cnt + D - 1u) / D, lo = cnt / chunks, n_hi = cnt - lo * chunks;  // n_hi parts of lo + 1, the rest of lo
@@ -2047,7 +2052,7 @@ __device__ __forceinline__ void filt_items_block(const WorldDev &w, uint32_t nce
         carry_s = run;
     }
     __syncthreads();
-    for (uint32_t c = threadIdx.x; c < ncell; c += 1024) {
+    for (uint32_t c = threadIdx.x; c < ncell; c += blockDim.x) {
         const uint32_t cnt = min(w.cell_fcnt[32u * c], w.S);
         if (!cnt) continue;
         const uint32_t chunks = (cnt + D - 1u) / D;
@@ -2207,7 +2212,9 @@ __global__ void __launch_bounds__(1024) k_fanout_scan(WorldDev w, uint32_t ncell
         w.emit_ticket[32u * threadIdx.x] = act >> 3;
         w.emit_ticket[32u * threadIdx.x + 3u] = act;
     }
-    if (seg && w.off_on && w.fcm_on) filt_items_block(w, ncell);
+    // (the filtered kernel's work items: here only where k_fanout_emit_seg cannot build them beside its own work — it does not run, or
+    // the tick's epilogue, which clears the cells' counts, runs beside it: pipelined ticks)
+    if (seg && w.off_on && w.fcm_on && (w.seg_only || w.late_tot)) filt_items_block(w, ncell);
 }
 
 // -DCHD_PROFILE_FILT (diagnosis builds): cycles the loader wave spends preparing items / waiting at the hand-over barrier, and the
@@ -2255,10 +2262,13 @@ __global__ void __launch_bounds__(64 * FC_WAVES, FC_OCC) k_fanout_emit_filt_cm(D
             FcTile &T = tiles[b];
             // (a workgroup's FIRST item is its own index — the tickets start behind the grid, k_fanout_scan —: one round trip less
             // before its eleven streamer waves have anything to do)
+            // (... and the later ones from ONE COUNTER PER XCD — ticket t of bank b = item gridDim + 8 t + b, as k_fanout_emit_seg's: the
+            // returning atomics of all eight XCDs on one address serialise at the memory side, ~35 ns each, and the workgroups finish
+            // their first items at about the same time)
             uint32_t item = blockIdx.x;
             if (!own_item) {
-                if (lane == 0) item = atomicAdd(&w.filt_nitems[16], 1u);
-                item = (uint32_t)__builtin_amdgcn_readfirstlane((int)item);
+                if (lane == 0) item = atomicAdd(&w.emit_ticket[32u * (blockIdx.x & 7u) + 2u], 1u);
+                item = gridDim.x + 8u * (uint32_t)__builtin_amdgcn_readfirstlane((int)item) + (blockIdx.x & 7u);
             }
             if (item >= n_items) {
                 if (lane == 0) H.valid = 0;
