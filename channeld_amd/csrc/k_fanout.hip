@@ -1935,44 +1935,40 @@ __device__ __forceinline__ void lds_barrier();
 __device__ __forceinline__ uint32_t filt_window_global(const WorldDev &w, uint32_t start, uint32_t n, uint32_t full, uint32_t sa, uint32_t sb,
                                                        uint32_t a_lo, uint32_t a_hi, uint32_t b_lo, uint32_t b_hi, uint32_t conn,
                                                        chd_fanout_rec *__restrict__ out, uint32_t n_out) {
+    // (a RARE path of the cell-major kernel — cells beyond its tile, cuts through ring slots the tile does not hold —: one row of 128
+    // entries per trip, so that it holds a handful of registers where the unrolled form held 32 and set the whole kernel's count)
     const uint32_t lane = lane_id();
     const bool use_a = a_lo <= a_hi, use_b = b_lo <= b_hi;
     const uint32_t bit_a = use_a ? 1u << sa : 0u, bit_b = use_b ? 1u << sb : 0u;
-    for (uint32_t c0 = 0; c0 < n; c0 += 512) {
-        const uint32_t nc = n - c0;
-        u32x4 e[4];
-        u32x2 oa[4], ob[4];
-#pragma unroll
-        for (int h = 0; h < 4; h++) { e[h] = u32x4{0, 0, 0, 0}; oa[h] = u32x2{0, 0}; ob[h] = u32x2{0, 0}; }
-        const uint32_t at0 = start + c0 + 2 * lane;
-        filt_load(w.ce8_view + at0, w.ce_off + (size_t)sa * w.off_stride + at0, w.ce_off + (size_t)sb * w.off_stride + at0, true, use_a, use_b, e, oa, ob);
-#pragma unroll
-        for (int h = 0; h < 4; h++) {
-            if (nc <= (uint32_t)(128 * h)) break;  // uniform
-            const uint32_t q = 128u * h + 2 * lane;
-            const bool in0 = q < nc, in1 = q + 1 < nc;
-            const uint32_t h0 = e[h].y, h1 = e[h].w;
-            const bool pass0 = in0 & (((h0 & full) != 0) | (((h0 & bit_a) != 0) & (oa[h].x >= a_lo) & (oa[h].x <= a_hi)) |
-                                      (((h0 & bit_b) != 0) & (ob[h].x >= b_lo) & (ob[h].x <= b_hi)));
-            const bool pass1 = in1 & (((h1 & full) != 0) | (((h1 & bit_a) != 0) & (oa[h].y >= a_lo) & (oa[h].y <= a_hi)) |
-                                      (((h1 & bit_b) != 0) & (ob[h].y >= b_lo) & (ob[h].y <= b_hi)));
-            const uint64_t m0 = __ballot(pass0), m1 = __ballot(pass1);
-            const uint32_t at = __builtin_amdgcn_mbcnt_hi((uint32_t)(m1 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m1,
-                                __builtin_amdgcn_mbcnt_hi((uint32_t)(m0 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m0, n_out))));
-            if (pass0) {
-                chd_fanout_rec r;
-                r.conn = conn;
-                r.channel = e[h].x;
-                out[at] = r;
-            }
-            if (pass1) {
-                chd_fanout_rec r;
-                r.conn = conn;
-                r.channel = e[h].z;
-                out[at + (pass0 ? 1u : 0u)] = r;
-            }
-            n_out += (uint32_t)__popcll(m0) + (uint32_t)__popcll(m1);
+    const uint32_t *pa = w.ce_off + (size_t)(use_a ? sa : 0u) * w.off_stride + start, *pb = w.ce_off + (size_t)(use_b ? sb : 0u) * w.off_stride + start;
+#pragma unroll 1
+    for (uint32_t c0 = 0; c0 < n; c0 += 128) {
+        const uint32_t q = c0 + 2 * lane;
+        const bool in0 = q < n, in1 = q + 1 < n;
+        // (the pair may straddle the cell's end: its second entry then belongs to the next cell or the arrays' spare entries, and is dropped)
+        const u32x4 e = *(const u32x4 *)(const void *)(w.ce8_view + start + q);
+        const u32x2 oa = *(const u32x2 *)(const void *)(pa + q), ob = *(const u32x2 *)(const void *)(pb + q);
+        const uint32_t h0 = e.y, h1 = e.w;
+        const bool pass0 = in0 & (((h0 & full) != 0) | (((h0 & bit_a) != 0) & (oa.x >= a_lo) & (oa.x <= a_hi)) |
+                                  (((h0 & bit_b) != 0) & (ob.x >= b_lo) & (ob.x <= b_hi)));
+        const bool pass1 = in1 & (((h1 & full) != 0) | (((h1 & bit_a) != 0) & (oa.y >= a_lo) & (oa.y <= a_hi)) |
+                                  (((h1 & bit_b) != 0) & (ob.y >= b_lo) & (ob.y <= b_hi)));
+        const uint64_t m0 = __ballot(pass0), m1 = __ballot(pass1);
+        const uint32_t at = __builtin_amdgcn_mbcnt_hi((uint32_t)(m1 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m1,
+                            __builtin_amdgcn_mbcnt_hi((uint32_t)(m0 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m0, n_out))));
+        if (pass0) {
+            chd_fanout_rec r;
+            r.conn = conn;
+            r.channel = e.x;
+            out[at] = r;
         }
+        if (pass1) {
+            chd_fanout_rec r;
+            r.conn = conn;
+            r.channel = e.z;
+            out[at + (pass0 ? 1u : 0u)] = r;
+        }
+        n_out += (uint32_t)__popcll(m0) + (uint32_t)__popcll(m1);
     }
     return n_out;
 }
@@ -1981,12 +1977,26 @@ __device__ __forceinline__ uint32_t filt_window_global(const WorldDev &w, uint32
 #define FC_DESCS 64  // (>= 16: filt_items' room)
 #endif
 // 12 waves (1 loader + 11 streamers), two workgroups per CU: measured on config B with jittered stamps against 8 waves (14
-// streamers per CU: emit stage 228 us) and 16 (30 per CU, registers spilled: 318 us) — 216 us
+// streamers per CU: emit stage 228 us) and 16 (30 per CU, registers spilled: 318 us) — 216 us.  Round 6, with the two rare paths
+// rolled (60 registers, nothing spilled: every shape below fits): 16 waves x 2 workgroups (30 streamers per CU) and 8 waves x 4
+// workgroups on a tile of three offset slots (FC_TSLOTS = 3, 38 KB: 28 streamers, four loaders per CU) measure what 12 x 2 does,
+// 10 x 3 and 14 x 2 more (profiles/r09p_*, r09q_*): the kernel does not respond to the number of waves either.
 #ifndef FC_WAVES
 #define FC_WAVES 12
 #endif
 #ifndef FC_OCC
 #define FC_OCC 6
+#endif
+// ring slots whose sub-tick offsets the LDS tile holds (slot 0 = this tick's arrivals).  A window that cuts through a slot beyond them
+// takes the global-memory path (filt_window_global): windows of the shipped intervals reach three slots at most.
+#ifndef FC_TSLOTS
+#define FC_TSLOTS CHD_OFF_SLOTS
+#endif
+#ifndef FC_WG_PER_CU
+#define FC_WG_PER_CU 2u
+#endif
+#ifndef FC_ITEMS_DEFAULT
+#define FC_ITEMS_DEFAULT 512u
 #endif
 #define FC_LWIN 4  // windows per descriptor whose tests are held in LDS (the rest, rare, are read from global memory)
 #define FC_NORUN 0xFFFFFFFFu
@@ -2001,13 +2011,13 @@ struct FcHead {
     uint32_t nd, cch, start, valid, ticket, sorted, _pad[2];  // sorted: the cell's entries are in the order of this tick's arrival offsets
 };
 struct FcTile {
-    uint32_t chan[512], hist[512], off[CHD_OFF_SLOTS][512];
+    uint32_t chan[512], hist[512], off[FC_TSLOTS][512];
 };
 
 // work items: per cell with filtered descriptors, chunks of FC_DESCS of its list (one workgroup; ncell <= 4096)
 // k_fanout_emit_filt_cm's grid: two workgroups per CU (LDS: 56 KB each), no more than there can be items
 __host__ __device__ __forceinline__ uint32_t fc_grid(const WorldDev &w, uint32_t ncell) {
-    const uint64_t max_items = (uint64_t)w.S * w.capq / 16u + ncell, cap = (uint64_t)(w.seg_waves / 8u) * 2u;
+    const uint64_t max_items = (uint64_t)w.S * w.capq / 16u + ncell, cap = (uint64_t)(w.seg_waves / 8u) * FC_WG_PER_CU;
     return (uint32_t)(max_items < cap ? max_items : cap);
 }
 
@@ -2028,7 +2038,7 @@ __device__ __forceinline__ void filt_items_block(const WorldDev &w, uint32_t nce
         if (lane == 0 && t) atomicAdd(&total_s, t);
     }
     __syncthreads();
-    const uint32_t target = (w.filt_target & 0x7FFFFFFFu) ? (w.filt_target & 0x7FFFFFFFu) : 512u;
+    const uint32_t target = (w.filt_target & 0x7FFFFFFFu) ? (w.filt_target & 0x7FFFFFFFu) : FC_ITEMS_DEFAULT;
     const bool lpt = !(w.filt_target >> 31);  // (A/B runs: bit 31 of CHD_FILT_ITEMS_TARGET = the items in no particular order)
     const uint32_t D = min(max((total_s + target - 1u) / target, 16u), (uint32_t)FC_DESCS);
     // The items in order of DESCENDING size (a counting sort over the 64 possible sizes): the workgroups draw them in that order —
@@ -2292,14 +2302,14 @@ __global__ void __launch_bounds__(64 * FC_WAVES, FC_OCC) k_fanout_emit_filt_cm(D
                 if (tn <= 128u * r) break;  // uniform
                 const uint32_t i = 128u * r + 2u * lane;
                 const u32x4 ce = *(const u32x4 *)(const void *)(w.ce8_view + start + i);
-                u32x2 co[CHD_OFF_SLOTS];
+                u32x2 co[FC_TSLOTS];
 #pragma unroll
-                for (uint32_t j = 0; j < CHD_OFF_SLOTS; j++) co[j] = *(const u32x2 *)(const void *)(w.ce_off + (size_t)j * w.off_stride + start + i);
+                for (uint32_t j = 0; j < FC_TSLOTS; j++) co[j] = *(const u32x2 *)(const void *)(w.ce_off + (size_t)j * w.off_stride + start + i);
                 *(u32x2 *)(void *)&T.chan[i] = u32x2{ce.x, ce.z};
                 *(u32x2 *)(void *)&T.hist[i] = u32x2{ce.y, ce.w};
                 // (an entity WITHOUT an update in slot j gets the offset 0xFFFFFFFF: outside every window's bounds)
 #pragma unroll
-                for (uint32_t j = 0; j < CHD_OFF_SLOTS; j++)
+                for (uint32_t j = 0; j < FC_TSLOTS; j++)
                     *(u32x2 *)(void *)&T.off[j][i] = u32x2{((ce.y >> j) & 1u) ? co[j].x : 0xFFFFFFFFu, ((ce.w >> j) & 1u) ? co[j].y : 0xFFFFFFFFu};
             }
             // third: the connection's words and the windows' tests
@@ -2333,7 +2343,9 @@ __global__ void __launch_bounds__(64 * FC_WAVES, FC_OCC) k_fanout_emit_filt_cm(D
                 for (int j = 0; j < FC_LWIN; j++) {
                     uint32_t run = FC_NORUN;
                     const uint32_t slots = tw[6 * j + 1], a_lo = tw[6 * j + 2], a_hi = tw[6 * j + 3];
-                    if (srt && (uint32_t)j < lnw && a_lo <= a_hi && (slots & 0xFFu) == 0u) {
+                    // (a second cut through a slot the tile does not hold: no run, the window goes to the global-memory path whole)
+                    const bool b_in_tile = tw[6 * j + 4] > tw[6 * j + 5] || ((slots >> 8) & 0xFFu) < FC_TSLOTS;
+                    if (srt && (uint32_t)j < lnw && a_lo <= a_hi && (slots & 0xFFu) == 0u && b_in_tile) {
                         uint32_t i0 = 0, i1 = 0;
 #pragma unroll
                         for (uint32_t step = 512u; step; step >>= 1) {
@@ -2388,17 +2400,6 @@ __global__ void __launch_bounds__(64 * FC_WAVES, FC_OCC) k_fanout_emit_filt_cm(D
                 uint32_t n_out = 0;
                 uint32_t lane2 = 2u * lane;  // (opaque per descriptor: `recs + 16 * lane` hoisted to the kernel's start was spilled — see pad_segment_here)
                 asm volatile("" : "+v"(lane2));
-                // the cell's entries (adjacent pairs per lane and row), once per descriptor
-                u32x2 ch[4], hh[4];
-#pragma unroll
-                for (int h = 0; h < 4; h++) {
-                    ch[h] = u32x2{0, 0};
-                    hh[h] = u32x2{0, 0};
-                    if (n <= 512 && n > (uint32_t)(128 * h)) {
-                        ch[h] = *(const u32x2 *)(const void *)&T.chan[128 * h + 2 * lane];
-                        hh[h] = *(const u32x2 *)(const void *)&T.hist[128 * h + 2 * lane];
-                    }
-                }
                 for (uint32_t j = 0; j < nw; j++) {
                     // (the values become scalars INSIDE each branch: a vector register that merges a global load with an LDS read
                     // would make the compiler wait on the vm counter — i.e. drain the record stores — on the common path too)
@@ -2474,64 +2475,54 @@ __global__ void __launch_bounds__(64 * FC_WAVES, FC_OCC) k_fanout_emit_filt_cm(D
                                 n_out += (uint32_t)__popcll(m0) + (uint32_t)__popcll(m1);
                             }
                         }
-                    } else if (n <= 512) {
-                        // THE COMMON PATH, LDS only.  Per row of 128 entries the lanes do two and + compare for the whole-slot mask
-                        // and two subtract + compare per cut slot — the staged offsets of entities WITHOUT an update in a slot are
-                        // 0xFFFFFFFF, so the range test alone decides (bounds never exceed 0xFFFFFFFE) — and everything else (bounds,
-                        // combining the tests, the ranks' base) runs on the scalar unit over the ballots.  The offsets of all four
-                        // rows are read from LDS in one go (the entries were, once per descriptor): one LDS round trip per window
+                    } else if (n <= 512 && (!use_a || sa < FC_TSLOTS) && (!use_b || sb < FC_TSLOTS)) {
+                        // THE PER-ENTITY PATH, LDS only (since the cells come in arrival order a RARE one: windows without a run — a cell too
+                        // crowded to sort, a window that lies in older slots only; ~1 % of the windows, profiles/r09m_filt_paths.txt — so it
+                        // goes row by row and holds a handful of registers; unrolled over the four rows it held 32 and set the kernel's
+                        // count).  Per row of 128 entries the lanes do two and + compare for the whole-slot mask and two subtract + compare
+                        // per cut slot — the staged offsets of entities WITHOUT an update in a slot are 0xFFFFFFFF, so the range test alone
+                        // decides (bounds never exceed 0xFFFFFFFE) — and everything else runs on the scalar unit over the ballots.
+                        typedef u32x4 __attribute__((aligned(8))) u32x4_a8;  // (n_out is any record index)
                         const uint32_t a_rng = a_hi - a_lo, b_rng = b_hi - b_lo;
-                        const uint32_t *oa_col = T.off[use_a ? sa : 0u] + 2 * lane, *ob_col = T.off[use_b ? sb : 0u] + 2 * lane;
-                        u32x2 oa[4], ob[4];
-#pragma unroll
-                        for (int h = 0; h < 4; h++) {
-                            oa[h] = u32x2{0xFFFFFFFFu, 0xFFFFFFFFu};
-                            ob[h] = u32x2{0xFFFFFFFFu, 0xFFFFFFFFu};
-                            if (use_a && n > (uint32_t)(128 * h)) oa[h] = *(const u32x2 *)(const void *)&oa_col[128 * h];
-                            if (use_b && n > (uint32_t)(128 * h)) ob[h] = *(const u32x2 *)(const void *)&ob_col[128 * h];
-                        }
-                        // (the four rows' tests first, independent of each other, then the stores: the write positions are a scalar
-                        // prefix over the rows' counts — no branch between the rows, so their instruction streams interleave)
-                        uint64_t m0[4], m1[4];
-#pragma unroll
-                        for (int h = 0; h < 4; h++) {
-                            const uint32_t left = n > (uint32_t)(128 * h) ? n - 128u * h : 0u;  // entries of this row and beyond
+                        const uint32_t *oa_col = T.off[use_a ? sa : 0u] + lane2, *ob_col = T.off[use_b ? sb : 0u] + lane2;
+#pragma unroll 1
+                        for (uint32_t r0 = 0; r0 < n; r0 += 128) {
+                            const uint32_t left = n - r0;  // entries of this row and beyond
                             const uint64_t in0 = left >= 127u ? ~0ull : ((1ull << ((left + 1u) >> 1)) - 1ull);
                             const uint64_t in1 = left >= 128u ? ~0ull : ((1ull << (left >> 1)) - 1ull);
-                            // (a window that lies inside ONE tick's arrivals — the 20 ms subscriptions of a 50 ms world — covers no slot
-                            // whole: full == 0, a scalar, and the two and + compare + ballot of the whole-slot test are skipped)
+                            const u32x2 chv = *(const u32x2 *)(const void *)&T.chan[r0 + lane2];
                             uint64_t a0 = 0, a1 = 0;
-                            if (full) { a0 = __ballot((hh[h].x & full) != 0); a1 = __ballot((hh[h].y & full) != 0); }
+                            if (full) {
+                                const u32x2 hv = *(const u32x2 *)(const void *)&T.hist[r0 + lane2];
+                                a0 = __ballot((hv.x & full) != 0); a1 = __ballot((hv.y & full) != 0);
+                            }
                             if (use_a) {
-                                a0 |= __ballot(oa[h].x - a_lo <= a_rng);
-                                a1 |= __ballot(oa[h].y - a_lo <= a_rng);
+                                const u32x2 o = *(const u32x2 *)(const void *)&oa_col[r0];
+                                a0 |= __ballot(o.x - a_lo <= a_rng);
+                                a1 |= __ballot(o.y - a_lo <= a_rng);
                             }
                             if (use_b) {
-                                a0 |= __ballot(ob[h].x - b_lo <= b_rng);
-                                a1 |= __ballot(ob[h].y - b_lo <= b_rng);
+                                const u32x2 o = *(const u32x2 *)(const void *)&ob_col[r0];
+                                a0 |= __ballot(o.x - b_lo <= b_rng);
+                                a1 |= __ballot(o.y - b_lo <= b_rng);
                             }
-                            m0[h] = a0 & in0;
-                            m1[h] = a1 & in1;
-                        }
-                        typedef u32x4 __attribute__((aligned(8))) u32x4_a8;  // (n_out is any record index)
-#pragma unroll
-                        for (int h = 0; h < 4; h++) {
+                            const uint64_t m0 = a0 & in0, m1 = a1 & in1;
                             // entry order: records before this lane's pair = passing entries of lower lanes; a lane's two records are
                             // adjacent: one 16-byte store when both pass
-                            const uint32_t at = __builtin_amdgcn_mbcnt_hi((uint32_t)(m1[h] >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m1[h],
-                                                __builtin_amdgcn_mbcnt_hi((uint32_t)(m0[h] >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m0[h], n_out))));
-                            const bool pass0 = (m0[h] >> lane) & 1ull, pass1 = (m1[h] >> lane) & 1ull;
+                            const uint32_t at = __builtin_amdgcn_mbcnt_hi((uint32_t)(m1 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m1,
+                                                __builtin_amdgcn_mbcnt_hi((uint32_t)(m0 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m0, n_out))));
+                            const bool pass0 = (m0 >> lane) & 1ull, pass1 = (m1 >> lane) & 1ull;
                             if (pass0 & pass1) {
                                 u32x4 r;
-                                r.x = conn; r.y = ch[h].x; r.z = conn; r.w = ch[h].y;
+                                r.x = conn; r.y = chv.x; r.z = conn; r.w = chv.y;
                                 *(u32x4_a8 *)(void *)(out + at) = r;
                             } else if (pass0 | pass1) {
                                 chd_fanout_rec r;
                                 r.conn = conn;
-                                r.channel = pass0 ? ch[h].x : ch[h].y;
+                                r.channel = pass0 ? chv.x : chv.y;
                                 out[at] = r;
                             }
-                            n_out += (uint32_t)__popcll(m0[h]) + (uint32_t)__popcll(m1[h]);
+                            n_out += (uint32_t)__popcll(m0) + (uint32_t)__popcll(m1);
                         }
                     } else {
                         // (rare: a cell beyond the tile — its columns from global memory, step by step, tested with the history bits)
